@@ -1,0 +1,392 @@
+"""oracle/fqss_oracle.py -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+CPU restatement (torch fp32 ATen ops + autograd) of the FQSS ConvTasNet QAT step, written
+functionally over a flat ``{state_dict key: tensor}`` table instead of the reference's module
+tree.  Only tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may import it.
+
+Reference followed (ssi-research/FQSS @ 2024_10_08), one function per cited range:
+  act_quantize        quantization/qat/qat_quant.py:136-147   (asym uniform quantizer + STE :88-103)
+  weight_quantize     quantization/qat/qat_quant.py:126-135   (per-channel symmetric)
+  ActRange.__call__   quantization/qat/qat_quant.py:227-242   (50-call EMA observer, then quantize)
+  WeightRange.__call__quantization/qat/qat_quant.py:372-381   (one-shot amax/amin observer)
+  split / combine     process.py:10-52
+  student_forward     quantization/qat/models/convtasnetq.py:182-223, 101-115, 37-42 with the
+                      LayerQ forwards of quantization/qat/qat_layers.py:62-71 (AddQ), 86-101 (MulQ),
+                      124-153 (Conv1dQ), 188-219 (Conv1dNlQ), 438-452 (GroupNormQ), 511-518 (NlQ),
+                      993-1039 (Conv1dEncoderQ), 1105-1202 (ResidualErrorBlock), 1305-1354 (ConvTr1dDecoderQ)
+  teacher_forward     same graph with plain float ops (train_env/train_utils.py:25 deep-copies the
+                      float model before quantization; n_splitter = n_combiner = 1)
+  pairwise_sisdr      train_env/asteroid_librimix/wsdr.py:56-95 (PairwiseWSDR, 'sisdr')
+  pit_mean            asteroid 0.6.0 PITLossWrapper(pit_from='pw_mtx') -- third-party, NOT under
+                      /root/reference (requirements.txt:14): restated from its published algorithm
+                      (min over the n_src! permutations of the mean pairwise loss, then batch mean).
+                      PARITY UNPINNED for this one function: no reference test or vector pins it.
+  kd_step             train_env/asteroid_librimix/mysystem.py:124-151
+  Trainer             asteroid_librimix_trainer.py:94 (Adam lr 1e-3) + :132 (gradient_clip_val 5.0)
+
+Pinned by: tests/golden/*.npz, produced by tools/make_goldens.py from the imported reference
+(tests/test_oracle_goldens.py checks every fixture).
+"""
+import itertools
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-8
+
+
+# ------------------------------------------------------------------------------------------
+# quantizers
+# ------------------------------------------------------------------------------------------
+def _ste_round(t):
+    return (torch.round(t) - t).detach() + t
+
+
+def act_quantize(x, lo, hi, n_bits=8):
+    qmax = 2 ** n_bits - 1
+    delta = (hi - lo) / qmax
+    X = _ste_round((x - lo) / delta)
+    return delta * torch.clip(X, 0, qmax) + lo
+
+
+def act_indices(x, lo, hi, n_bits=8):
+    """integer bin index 0..255 -- the bit-exact quantity of the parity contract"""
+    qmax = 2 ** n_bits - 1
+    delta = (hi - lo) / qmax
+    return torch.clip(torch.round((x - lo) / delta), 0, qmax).to(torch.uint8)
+
+
+def weight_quantize(w, lo, hi, n_bits=8):
+    a = torch.maximum(torch.abs(lo), torch.abs(hi))
+    delta = 2 * a / (2 ** n_bits - 1)
+    X = _ste_round(w / delta)
+    return delta * torch.clip(X, -2 ** (n_bits - 1), 2 ** (n_bits - 1) - 1)
+
+
+def weight_indices(w, lo, hi, n_bits=8):
+    a = torch.maximum(torch.abs(lo), torch.abs(hi))
+    delta = 2 * a / (2 ** n_bits - 1)
+    return torch.clip(torch.round(w / delta), -2 ** (n_bits - 1), 2 ** (n_bits - 1) - 1).to(torch.int8)
+
+
+class ActRange:
+    """host-side state of one per-tensor activation quantizer (n_iter / observer flag are plain
+    attributes in the reference too, qat_quant.py:216-220)"""
+    max_observations = 50
+    alpha = 0.9
+
+    def __init__(self, table, prefix):
+        self.t, self.kmin, self.kmax = table, prefix + ".min_range", prefix + ".max_range"
+        self.n_iter = 0
+        self.observer = True
+        self.last_pre = None   # pre-quant tensor of the last call (for index checks)
+
+    def __call__(self, x):
+        self.last_pre = x.detach()
+        lo, hi = self.t[self.kmin], self.t[self.kmax]
+        if self.observer and self.n_iter < self.max_observations:
+            self.n_iter += 1
+            with torch.no_grad():
+                tmax, tmin = x.max(), x.min()
+                lo.copy_(self.alpha * lo + (1 - self.alpha) * tmin)
+                hi.copy_(self.alpha * hi + (1 - self.alpha) * tmax)
+            return x
+        return act_quantize(x, lo, hi)
+
+
+class WeightRange:
+    def __init__(self, table, prefix, axis):
+        self.t, self.kmin, self.kmax = table, prefix + ".min_range", prefix + ".max_range"
+        self.axis = axis
+        self.observer = True
+
+    def __call__(self, w):
+        lo, hi = self.t[self.kmin], self.t[self.kmax]
+        if self.observer:
+            dims = [d for d in range(w.dim()) if d != self.axis]
+            with torch.no_grad():
+                hi.copy_(torch.amax(w, dim=dims, keepdim=True))
+                lo.copy_(torch.amin(w, dim=dims, keepdim=True))
+            self.observer = False
+            return w
+        return weight_quantize(w, lo, hi)
+
+
+# ------------------------------------------------------------------------------------------
+# splitter / combiner
+# ------------------------------------------------------------------------------------------
+def floor_quantize(x, threshold=1.0, n_bits=8):
+    delta = threshold / (2 ** (n_bits - 1))
+    return torch.clip(torch.floor(x / delta), -2 ** (n_bits - 1), 2 ** (n_bits - 1) - 1) * delta
+
+
+def split(x, n_splitter=2, n_bits=8):
+    if x.dim() == 2:
+        x = x.unsqueeze(1)
+    if n_splitter <= 1:
+        return x
+    x = x / max(abs(x.min()), abs(x.max()))
+    thr = 1
+    delta = thr / (2 ** (n_bits - 1))
+    parts = []
+    for _ in range(n_splitter):
+        q = floor_quantize(x, thr, n_bits)
+        parts.append(q)
+        x = 2 * (x - q) * thr / delta - thr
+    return torch.cat(parts, dim=1)
+
+
+def combine(x, n_combiner=2, n_bits=8):
+    if n_combiner == 1:
+        y = x.squeeze(0)
+    else:
+        delta = 1 / (2 ** (n_bits - 1))
+        y = x[0]
+        for i in range(1, n_combiner):
+            y = y + x[i] * (0.5 * delta) ** i
+    if y.dim() <= 4 and y.shape[-2] == 1:
+        y = y.squeeze(-2)
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# model
+# ------------------------------------------------------------------------------------------
+class QTable:
+    """flat ``{state_dict key: tensor}`` parameter table + the host-side quantizer state that the
+    reference keeps as plain module attributes; provides the LayerQ forwards by key prefix."""
+
+    def __init__(self, state_dict):
+        self.p = {k: v.detach().clone().float().requires_grad_(True) for k, v in state_dict.items()}
+        self.aq, self.wq = {}, {}
+        for k in self.p:
+            if k.endswith(".min_range"):
+                pre = k[: -len(".min_range")]
+                if pre.endswith("weight_fake_quantize"):
+                    owner = pre[: -len("weight_fake_quantize")]
+                    axis = 1 if (owner + "convTr1d.weight") in self.p else 0   # ch_out_idx=1, qat_layers.py:1317
+                    self.wq[pre] = WeightRange(self.p, pre, axis)
+                else:
+                    self.aq[pre] = ActRange(self.p, pre)
+
+    def parameters(self):
+        return list(self.p.values())
+
+    def named_parameters(self):
+        return self.p.items()
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.p.items()}
+
+    def enable_observer(self, mode):
+        for q in self.aq.values():
+            q.observer = mode
+        for q in self.wq.values():
+            q.observer = mode
+
+    def leave_observer_phase(self):
+        for q in self.aq.values():
+            q.n_iter = q.max_observations
+        for q in self.wq.values():
+            q.observer = False
+
+    def _A(self, name, x):
+        return self.aq[name + ".activation_fake_quantize"](x)
+
+    def _W(self, name, w):
+        return self.wq[name + ".weight_fake_quantize"](w)
+
+    def _conv(self, name, x, nl=None, **kw):
+        w = self._W(name, self.p[name + ".conv1d.weight"])
+        y = F.conv1d(x, w, self.p.get(name + ".conv1d.bias"), **kw)
+        if nl == "prelu":
+            y = F.prelu(y, self.p[name + ".nl.weight"])
+        elif nl == "relu":
+            y = F.relu(y)
+        return self._A(name, y)
+
+    def _gn(self, name, x):
+        y = F.group_norm(x, 1, self.p[name + ".groupnorm.weight"], self.p[name + ".groupnorm.bias"], EPS)
+        return self._A(name, y)
+
+    def _nl(self, name, x):
+        return self._A(name, F.prelu(x, self.p[name + ".nl.weight"]))
+
+    def _decoder(self, name, x, stride, n_combiner=2):
+        w = self._W(name, self.p[name + ".convTr1d.weight"])
+        y0 = self._A(name, F.conv_transpose1d(x, w, None, stride=stride))
+        if n_combiner == 1:
+            return y0
+        rb = name + ".residual_error_block"
+        w_res = self._W(rb, self.p[rb + ".residual_encoder.weight"])
+        Yq = F.conv1d(y0, w_res, None, stride=stride)
+        Y1 = self._A(rb, x - Yq)
+        y1 = F.conv_transpose1d(Y1, w, None, stride=stride)
+        y1 = self.aq[name + ".activation_fake_quantize_residual"](y1)
+        return torch.stack([y0, y1])
+
+
+class StudentConvTasNetQ(QTable):
+    """W8A8 fake-quantized ConvTasNet over a flat parameter table with the reference's
+    state_dict key names (948 keys at full size)."""
+
+    def __init__(self, state_dict, n_src=2, kernel_size=16, stride=8, n_splitter=2, n_combiner=2,
+                 layers_per_stack=8):
+        super().__init__(state_dict)
+        self.n_src, self.K, self.stride = n_src, kernel_size, stride
+        self.n_splitter, self.n_combiner = n_splitter, n_combiner
+        self.layers_per_stack = layers_per_stack   # dilation = 2**layer restarts per stack (convtasnetq.py:72-76)
+        self.n_blocks = 1 + max(int(k.split(".")[2]) for k in self.p if k.startswith("masker.TCN."))
+
+    # -- forward -------------------------------------------------------------------------
+    def masker(self, feats):
+        B = feats.shape[0]
+        x = self._gn("masker.bottleneck.0", feats)
+        x = self._conv("masker.bottleneck.1", x)
+        out = None
+        for i in range(self.n_blocks):
+            b = f"masker.TCN.{i}"
+            dil = 2 ** (i % self.layers_per_stack)
+            h = self._conv(b + ".shared_block.0", x, nl="prelu")
+            h = self._gn(b + ".shared_block.2", h)
+            h = self._conv(b + ".shared_block.3", h, nl="prelu", padding=dil, dilation=dil, groups=h.shape[1])
+            h = self._gn(b + ".shared_block.5", h)
+            res = self._conv(b + ".res_conv", h)
+            skip = self._conv(b + ".skip_conv", h)
+            x = self._A(b + ".add", x + res)
+            out = skip if out is None else self._A(f"masker.adds.{i - 1}", out + skip)
+        y = self._nl("masker.mask_net.0", out)
+        y = self._conv("masker.mask_net.1", y, nl="relu")
+        return y.reshape(B, self.n_src, feats.shape[1], -1)
+
+    def forward(self, x):
+        x = split(x, self.n_splitter)
+        B = x.shape[0]
+        feats = self._conv("encoder", x, stride=self.stride)
+        masked = self._A("mul", self.masker(feats) * feats.unsqueeze(1))
+        dec = self._decoder("decoder", masked.reshape(B * self.n_src, feats.shape[1], -1), self.stride, self.n_combiner)
+        return combine(dec.reshape(self.n_combiner, B, self.n_src, 1, -1), self.n_combiner)
+
+    __call__ = forward
+
+
+class TeacherConvTasNet:
+    """float copy of the same network (no splitter, no quantizers)."""
+
+    def __init__(self, state_dict, n_src=2, stride=8, layers_per_stack=8):
+        self.p = {k: v.detach().clone().float() for k, v in state_dict.items()}
+        self.n_src, self.stride, self.layers_per_stack = n_src, stride, layers_per_stack
+        self.n_blocks = 1 + max(int(k.split(".")[2]) for k in self.p if k.startswith("masker.TCN."))
+
+    def forward(self, x):
+        p = self.p
+        if x.dim() == 2:
+            x = x.unsqueeze(1)
+        B = x.shape[0]
+        feats = F.conv1d(x, p["encoder.weight"], None, stride=self.stride)
+        h = F.group_norm(feats, 1, p["masker.bottleneck.0.weight"], p["masker.bottleneck.0.bias"], EPS)
+        h = F.conv1d(h, p["masker.bottleneck.1.weight"], p["masker.bottleneck.1.bias"])
+        out = None
+        for i in range(self.n_blocks):
+            b = f"masker.TCN.{i}"
+            dil = 2 ** (i % self.layers_per_stack)
+            s = b + ".shared_block"
+            y = F.prelu(F.conv1d(h, p[s + ".0.weight"], p[s + ".0.bias"]), p[s + ".1.weight"])
+            y = F.group_norm(y, 1, p[s + ".2.weight"], p[s + ".2.bias"], EPS)
+            y = F.prelu(F.conv1d(y, p[s + ".3.weight"], p[s + ".3.bias"], padding=dil, dilation=dil,
+                                 groups=y.shape[1]), p[s + ".4.weight"])
+            y = F.group_norm(y, 1, p[s + ".5.weight"], p[s + ".5.bias"], EPS)
+            res = F.conv1d(y, p[b + ".res_conv.weight"], p[b + ".res_conv.bias"])
+            skip = F.conv1d(y, p[b + ".skip_conv.weight"], p[b + ".skip_conv.bias"])
+            h = h + res
+            out = skip if out is None else out + skip
+        m = F.prelu(out, p["masker.mask_net.0.weight"])
+        m = F.relu(F.conv1d(m, p["masker.mask_net.1.weight"], p["masker.mask_net.1.bias"]))
+        masked = m.reshape(B, self.n_src, feats.shape[1], -1) * feats.unsqueeze(1)
+        dec = F.conv_transpose1d(masked.reshape(B * self.n_src, feats.shape[1], -1),
+                                 p["decoder.weight"], None, stride=self.stride)
+        return combine(dec.reshape(1, B, self.n_src, 1, -1), 1)
+
+    __call__ = forward
+
+
+# ------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------
+def pairwise_sisdr(est, tgt, weights=None, take_log=False):
+    """[B,S,T] x [B,S,T] -> [B, S_est, S_tgt]; zero-mean SI-SDR ratio (wsdr.py:56-95).
+    take_log=False returns the NEGATED linear ratio like the reference alias `pairwise_wsisdr`;
+    take_log=True returns +10 log10(ratio + eps)."""
+    tgt = tgt - torch.mean(tgt, dim=2, keepdim=True)
+    est = est - torch.mean(est, dim=2, keepdim=True)
+    s_t = tgt.unsqueeze(1)
+    s_e = est.unsqueeze(2)
+    dot = torch.sum(s_e * s_t, dim=3, keepdim=True)
+    energy = torch.sum(s_t ** 2, dim=3, keepdim=True) + EPS
+    proj = dot * s_t / energy
+    noise = s_e - proj
+    sdr = torch.sum(proj ** 2, dim=3) / (torch.sum(noise ** 2, dim=3) + EPS)
+    if weights is not None:
+        sdr = sdr * weights[:, None, None]
+    return 10 * torch.log10(sdr + EPS) if take_log else -sdr
+
+
+def pit_mean(pw):
+    n = pw.shape[-1]
+    cand = [sum(pw[:, p[i], i] for i in range(n)) / n for p in itertools.permutations(range(n))]
+    return torch.mean(torch.min(torch.stack(cand, dim=1), dim=1)[0])
+
+
+def neg_sisdr_pit(est, tgt):
+    """asteroid PITLossWrapper(pairwise_neg_sisdr) (asteroid_librimix_trainer.py:105)"""
+    return pit_mean(-pairwise_sisdr(est, tgt, take_log=True))
+
+
+def kd_loss(est, fest, tgt, kd_lambda=0.1):
+    with torch.no_grad():
+        sdrs = torch.stack([neg_sisdr_pit(fest[b:b + 1], tgt[b:b + 1]) for b in range(len(fest))])
+        sdrqs = torch.stack([neg_sisdr_pit(est[b:b + 1].detach(), tgt[b:b + 1]) for b in range(len(fest))])
+        w = 10 ** ((sdrs - sdrqs) / 10)
+    kd = -pit_mean(pairwise_sisdr(est, fest, weights=w))
+    task = -pit_mean(pairwise_sisdr(est, tgt))
+    loss = -10 * torch.log10((1 - kd_lambda) * task + kd_lambda * kd + EPS)
+    return loss, kd, task, w, sdrs, sdrqs
+
+
+def kd_step(student, teacher, x, tgt, kd_lambda=0.1):
+    est = student(x)
+    with torch.no_grad():
+        fest = teacher(x).detach()
+    loss, kd, task, w, sdrs, sdrqs = kd_loss(est, fest, tgt, kd_lambda)
+    return dict(est=est, fest=fest, loss=loss, kd=kd, task=task, w=w, sdrs=sdrs, sdrqs=sdrqs)
+
+
+def si_sdr_db(est, tgt):
+    """mean best-permutation SI-SDR in dB (the accuracy half of the metric)"""
+    return -neg_sisdr_pit(est, tgt)
+
+
+class Trainer:
+    """Adam(lr, betas 0.9/0.999, eps 1e-8, wd 0) + global-norm clip 5.0 on the student table."""
+
+    def __init__(self, student, teacher, lr=1e-3, clip=5.0, kd_lambda=0.1):
+        self.s, self.t, self.clip, self.kd_lambda = student, teacher, clip, kd_lambda
+        self.opt = torch.optim.Adam(student.parameters(), lr=lr)
+
+    def step(self, x, tgt):
+        self.opt.zero_grad()
+        r = kd_step(self.s, self.t, x, tgt, self.kd_lambda)
+        r["loss"].backward()
+        r["gnorm"] = torch.nn.utils.clip_grad_norm_(self.s.parameters(), self.clip)
+        self.opt.step()
+        return r
+
+
+def synth_batch(B, T, seed=0):
+    """synthetic 2-speaker mixtures of SURVEY.md §8(d): 0.05*randn band-limited by a 5-tap FIR"""
+    g = torch.Generator().manual_seed(seed)
+    s = 0.05 * torch.randn(B, 2, T + 4, generator=g)
+    fir = torch.tensor([0.1, 0.25, 0.3, 0.25, 0.1]).view(1, 1, 5)
+    s = F.conv1d(s.view(B * 2, 1, T + 4), fir).view(B, 2, T)
+    return s.sum(1, keepdim=True), s
