@@ -1,0 +1,83 @@
+"""ctypes binding of csrc/libfqss_hip.so (C ABI declared in include/fqss.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libfqss_hip.so")
+
+P, I64, I32, F32, F64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double
+
+# name -> argtypes (restype is always int unless listed in _RESTYPE)
+_PROTOS = {
+    "fqss_version": [],
+    "fqss_last_error": [],
+    "fqss_actq_fwd": [P, P, P, I64, I64, I64, I64, I32, P, I32, P, P, P, P],
+    "fqss_obs_reset": [P, I64, P],
+    "fqss_observer_ema": [P, P, P, F64, P],
+    "fqss_actq_bwd": [P, P, P, I64, I64, I64, I64, I64, I32, P, I32, P, P, P, P, I64, P],
+    "fqss_minmax": [P, I64, I64, I64, P, P],
+    "fqss_wq_observe": [P, I64, I64, I64, P, P, P],
+    "fqss_wq_fwd": [P, P, P, I64, I64, I64, P, P, P],
+    "fqss_wq_bwd": [P, P, P, P, P, I64, I64, I64, P, P, P],
+    "fqss_pwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_pwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_pwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_dwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
+    "fqss_dwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
+    "fqss_dwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
+    "fqss_gn_fwd": [P, P, P, P, P, I32, I32, I32, I64, I64, F32, P, P],
+    "fqss_gn_bwd": [P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P],
+    "fqss_axpby": [P, P, F32, P, I64, I64, I64, I64, I64, P],
+    "fqss_mul_bcast_fwd": [P, P, P, I32, I32, I32, I32, I64, I64, I64, P],
+    "fqss_mul_bcast_bwd": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, P],
+    "fqss_splitter2": [P, P, I32, I64, P, P],
+    "fqss_frames_conv_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I32, I64, P],
+    "fqss_ola_convtr_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I64, P],
+    "fqss_frames_wgrad": [P, P, P, I32, I32, I32, I32, I64, I64, I32, I32, P],
+    "fqss_kd_loss": [P, P, P, I32, I64, F32, P, P, P, P, P, P],
+    "fqss_sumsq": [P, I64, P, P],
+    "fqss_adam_clip": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, F32, P, P, P],
+}
+_RESTYPE = {"fqss_last_error": C.c_char_p}
+
+EXPORTS = tuple(_PROTOS)
+
+
+class FqssError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(strict=False):
+    """Load the HIP library; fail LOUDLY when it is missing (no CPU fallback exists).
+    strict=True additionally requires every symbol declared in include/fqss.h to be exported."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise FqssError(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C fqss_amd/csrc`). fqss_amd has no CPU fallback.")
+        _lib = C.CDLL(SO_PATH)
+        _lib.fqss_last_error.restype = C.c_char_p
+    if strict:
+        missing = [n for n in _PROTOS if not hasattr(_lib, n)]
+        if missing:
+            raise FqssError(f"{SO_PATH} does not export: {missing}")
+    return _lib
+
+
+_bound = {}
+
+
+def call(name, *args):
+    fn = _bound.get(name)
+    if fn is None:
+        fn = getattr(load(), name)       # AttributeError (loud) if the symbol is not exported
+        fn.argtypes = _PROTOS[name]
+        fn.restype = _RESTYPE.get(name, C.c_int)
+        _bound[name] = fn
+    rc = fn(*args)
+    if rc != 0:
+        raise FqssError(f"{name} failed ({rc}): {load().fqss_last_error().decode()}")

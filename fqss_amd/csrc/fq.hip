@@ -1,0 +1,436 @@
+// fq.hip -- K1/K1b/K2/K3: per-tensor activation fake-quant (+PReLU/ReLU), observer, STE backward,
+// per-channel symmetric weight fake-quant.  HBM-bound streaming kernels: 16 B/lane vector loads
+// when rows are 16-B aligned, wave shuffles + one atomic per block for the range reductions.
+//
+// Reference semantics restated (see include/fqss.h for the entry-point contract):
+//   quantization/qat/qat_quant.py:125-147  linear_quantize
+//   quantization/qat/qat_quant.py:227-242  GradientActivationFakeQuantize.forward
+//   quantization/qat/qat_quant.py:372-381  GradientWeightFakeQuantize.forward
+#include <cstdarg>
+#include <cstdio>
+
+#include "fqss_dev.h"
+
+namespace fqss {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return FQSS_ELAUNCH;
+    }
+    return FQSS_OK;
+}
+
+// =============================================================================================
+// activation epilogue forward
+// =============================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, float* __restrict__ out,
+                                                   uint8_t* __restrict__ idx, int64_t rows, int64_t cols,
+                                                   int64_t ld_z, int64_t ld_o, int act,
+                                                   const float* __restrict__ slope_p, int qmode,
+                                                   const float* __restrict__ qmin,
+                                                   const float* __restrict__ qmax, uint32_t* obs) {
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    QRange r{0.0f, 1.0f};
+    if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
+    float vmin = INFINITY, vmax = -INFINITY;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* zr = z + row * ld_z;
+        float* orow = out + row * ld_o;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
+            float v[VEC];
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(zr + c0);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                v[0] = zr[c0];
+            }
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float t = act_apply(v[j], act, slope);
+                if (qmode == FQSS_Q_QUANT) {
+                    float c, u;
+                    bool inr;
+                    o[j] = fq_asym(t, r, c, u, inr);
+                    if (idx != nullptr && c0 + j < cols) idx[row * cols + c0 + j] = (uint8_t)c;
+                } else {
+                    o[j] = t;
+                    if (qmode == FQSS_Q_OBSERVE && c0 + j < cols) {
+                        vmin = fminf(vmin, t);
+                        vmax = fmaxf(vmax, t);
+                    }
+                }
+            }
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                orow[c0] = o[0];
+            }
+        }
+    }
+    if (qmode == FQSS_Q_OBSERVE) {
+        vmin = wave_min(vmin);
+        vmax = wave_max(vmax);
+        if ((threadIdx.x & 63) == 0) {
+            const uint32_t kmin = f2ord(vmin), kmax = f2ord(vmax);
+            // most waves do not improve the running extremum: test with a relaxed load first
+            if (kmin < __hip_atomic_load(&obs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&obs[0], kmin);
+            if (kmax > __hip_atomic_load(&obs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&obs[1], kmax);
+        }
+    }
+}
+
+__global__ void k_obs_reset(uint32_t* obs, int64_t n_pairs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pairs) {
+        obs[2 * i] = 0xFFFFFFFFu;
+        obs[2 * i + 1] = 0u;
+    }
+}
+
+__global__ void k_observer_ema(float* qmin, float* qmax, uint32_t* obs, float alpha, float one_minus_alpha) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float tmin = ord2f(obs[0]), tmax = ord2f(obs[1]);
+        // self.alpha*self.min_range + (1-self.alpha)*tilde_range_min   (qat_quant.py:231-232)
+        *qmin = alpha * (*qmin) + one_minus_alpha * tmin;
+        *qmax = alpha * (*qmax) + one_minus_alpha * tmax;
+        obs[0] = 0xFFFFFFFFu;
+        obs[1] = 0u;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x, int64_t rows, int64_t cols,
+                                                 int64_t ld, uint32_t* obs) {
+    float vmin = INFINITY, vmax = -INFINITY;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* xr = x + row * ld;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + c0);
+                const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + j < cols) {
+                        vmin = fminf(vmin, v[j]);
+                        vmax = fmaxf(vmax, v[j]);
+                    }
+            } else {
+                vmin = fminf(vmin, xr[c0]);
+                vmax = fmaxf(vmax, xr[c0]);
+            }
+        }
+    }
+    vmin = wave_min(vmin);
+    vmax = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t kmin = f2ord(vmin), kmax = f2ord(vmax);
+        if (kmin < __hip_atomic_load(&obs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&obs[0], kmin);
+        if (kmax > __hip_atomic_load(&obs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&obs[1], kmax);
+    }
+}
+
+// =============================================================================================
+// activation epilogue backward (STE + range gradients + PReLU/ReLU + optional bias row-sums)
+//   autograd of qat_quant.py:139-146 restated op by op:
+//     g_C = g*delta ; g_u = g_C*m ; g_t = g_u/delta
+//     d/dmax = sum g*(c - m*u)/255 ; d/dmin = sum g*(1-m) - d/dmax
+// =============================================================================================
+template <int VEC, bool BIAS>
+__global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, const float* __restrict__ g,
+                                                   float* __restrict__ gz, int64_t rows, int64_t cols,
+                                                   int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act,
+                                                   const float* __restrict__ slope_p, int qmode,
+                                                   const float* __restrict__ qmin,
+                                                   const float* __restrict__ qmax, double* gacc,
+                                                   float* gbias, int64_t C) {
+    __shared__ double red[3 * 4];
+    __shared__ float redf[4];
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    QRange r{0.0f, 1.0f};
+    if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
+    float p_du = 0.0f;    // sum g*(c - m*u)
+    float p_out = 0.0f;   // sum g*(1-m)
+    float p_slope = 0.0f; // sum [z<=0] z*g_t
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* zr = z + row * ld_z;
+        const float* gr = g + row * ld_g;
+        float* or_ = gz + row * ld_gz;
+        float p_bias = 0.0f;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
+            float zv[VEC], gv[VEC], o[VEC];
+            if constexpr (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(zr + c0);
+                const float4 b = *reinterpret_cast<const float4*>(gr + c0);
+                zv[0] = a.x; zv[1] = a.y; zv[2] = a.z; zv[3] = a.w;
+                gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+            } else {
+                zv[0] = zr[c0];
+                gv[0] = gr[c0];
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const bool valid = (c0 + j < cols);
+                const float gj = valid ? gv[j] : 0.0f;
+                const float t = act_apply(zv[j], act, slope);
+                float gt = gj;
+                if (qmode == FQSS_Q_QUANT) {
+                    float c, u;
+                    bool inr;
+                    (void)fq_asym(t, r, c, u, inr);
+                    gt = inr ? (gj * r.delta) / r.delta : 0.0f;
+                    if (valid) {
+                        p_du += gj * (inr ? (c - u) : c);
+                        p_out += inr ? 0.0f : gj;
+                    }
+                }
+                float gzj = gt;
+                if (act == FQSS_ACT_PRELU) {
+                    const bool pos = zv[j] > 0.0f;
+                    gzj = pos ? gt : slope * gt;
+                    if (valid && !pos) p_slope += zv[j] * gt;
+                } else if (act == FQSS_ACT_RELU) {
+                    gzj = (t > 0.0f) ? gt : 0.0f;
+                }
+                o[j] = gzj;
+                if (BIAS && valid) p_bias += gzj;
+            }
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<float4*>(or_ + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                or_[c0] = o[0];
+            }
+        }
+        if constexpr (BIAS) {
+            float pb[1] = {p_bias};
+            block_sum<float, 1>(pb, redf);
+            if (threadIdx.x == 0) atomicAdd(&gbias[row % C], pb[0]);
+        }
+    }
+    if (qmode == FQSS_Q_QUANT || act == FQSS_ACT_PRELU) {
+        double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
+        block_sum<double, 3>(v, red);
+        if (threadIdx.x == 0) {
+            if (qmode == FQSS_Q_QUANT) {
+                const double dmax = v[0] / 255.0;
+                atomicAdd(&gacc[0], v[1] - dmax);
+                atomicAdd(&gacc[1], dmax);
+            }
+            if (act == FQSS_ACT_PRELU) atomicAdd(&gacc[2], v[2]);
+        }
+    }
+}
+
+// =============================================================================================
+// per-channel symmetric weight quantizer; tensor layout [outer][C][inner]
+// =============================================================================================
+__device__ __forceinline__ float wq_delta(float lo, float hi) {
+    const float a = fmaxf(fabsf(lo), fabsf(hi));
+    return (2.0f * a) / 255.0f;
+}
+
+__global__ __launch_bounds__(256) void k_wq_observe(const float* __restrict__ w, int64_t outer, int64_t C,
+                                                     int64_t inner, float* qmin, float* qmax) {
+    __shared__ float smin[4], smax[4];
+    const int64_t c = blockIdx.x;
+    float vmin = INFINITY, vmax = -INFINITY;
+    const int64_t n = outer * inner;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const int64_t o = e / inner, i = e - o * inner;
+        const float v = w[(o * C + c) * inner + i];
+        vmin = fminf(vmin, v);
+        vmax = fmaxf(vmax, v);
+    }
+    vmin = wave_min(vmin);
+    vmax = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = vmin;
+        smax[threadIdx.x >> 6] = vmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+            vmin = fminf(vmin, smin[k]);
+            vmax = fmaxf(vmax, smax[k]);
+        }
+        qmin[c] = vmin;
+        qmax[c] = vmax;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wq_fwd(const float* __restrict__ w, float* __restrict__ wq,
+                                                 int8_t* __restrict__ idx, int64_t n, int64_t C, int64_t inner,
+                                                 const float* __restrict__ qmin, const float* __restrict__ qmax) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = (e / inner) % C;
+        const float delta = wq_delta(qmin[c], qmax[c]);
+        const float X = rintf(w[e] / delta);
+        const float q = fminf(fmaxf(X, -128.0f), 127.0f);
+        wq[e] = delta * q;
+        if (idx != nullptr) idx[e] = (int8_t)q;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wq_bwd(const float* __restrict__ w, const float* __restrict__ g,
+                                                 float* __restrict__ gw, float* gmin, float* gmax, int64_t outer,
+                                                 int64_t C, int64_t inner, const float* __restrict__ qmin,
+                                                 const float* __restrict__ qmax) {
+    __shared__ double red[4];
+    const int64_t c = blockIdx.x;
+    const float lo = qmin[c], hi = qmax[c];
+    const float delta = wq_delta(lo, hi);
+    const int64_t n = outer * inner;
+    float p = 0.0f;
+    for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const int64_t o = e / inner, i = e - o * inner;
+        const int64_t k = (o * C + c) * inner + i;
+        const float u = w[k] / delta;
+        const float X = rintf(u);
+        const bool inr = (X >= -128.0f) && (X <= 127.0f);
+        const float q = fminf(fmaxf(X, -128.0f), 127.0f);
+        const float gk = g[k];
+        gw[k] = inr ? (gk * delta) / delta : 0.0f;
+        p += gk * (inr ? (q - u) : q);
+    }
+    double v[1] = {(double)p};
+    block_sum<double, 1>(v, red);
+    if (threadIdx.x == 0) {
+        const double D = v[0] * (2.0 / 255.0);
+        const float al = fabsf(lo), ah = fabsf(hi);
+        // torch.maximum routes the gradient to the larger operand, 1/2-1/2 on ties; |x|' = sign(x)
+        const double wl = al > ah ? 1.0 : (al == ah ? 0.5 : 0.0);
+        const double wh = ah > al ? 1.0 : (al == ah ? 0.5 : 0.0);
+        const double sl = lo > 0.0f ? 1.0 : (lo < 0.0f ? -1.0 : 0.0);
+        const double sh = hi > 0.0f ? 1.0 : (hi < 0.0f ? -1.0 : 0.0);
+        gmin[c] = (float)(D * wl * sl);
+        gmax[c] = (float)(D * wh * sh);
+    }
+}
+
+}  // namespace fqss
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace fqss;
+
+extern "C" int fqss_version(void) { return FQSS_VERSION; }
+extern "C" const char* fqss_last_error(void) { return fqss::g_err; }
+
+extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols, int64_t ld_z,
+                             int64_t ld_out, int act, const float* slope, int qmode, const float* qmin,
+                             const float* qmax, uint32_t* obs_ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(z && out, "null tensor");
+    FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_out >= cols, "bad shape");
+    FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
+    FQSS_REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    const bool vec = aligned16(z) && aligned16(out) && (ld_z % 4 == 0) && (ld_out % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (vec) {
+        hipLaunchKernelGGL(k_actq_fwd<4>, grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,
+                           ld_out, act, slope, qmode, qmin, qmax, obs_ws);
+    } else {
+        hipLaunchKernelGGL(k_actq_fwd<1>, grid_rows(rows, cols, 1), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,
+                           ld_out, act, slope, qmode, qmin, qmax, obs_ws);
+    }
+    return launch_status("fqss_actq_fwd");
+}
+
+extern "C" int fqss_obs_reset(uint32_t* obs_ws, int64_t n_pairs, fqss_stream_t stream) {
+    FQSS_REQUIRE(obs_ws && n_pairs >= 0, "bad args");
+    if (n_pairs == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_obs_reset, dim3((unsigned)cdiv(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream, obs_ws,
+                       n_pairs);
+    return launch_status("fqss_obs_reset");
+}
+
+extern "C" int fqss_observer_ema(float* qmin, float* qmax, uint32_t* obs_ws, double alpha, fqss_stream_t stream) {
+    FQSS_REQUIRE(qmin && qmax && obs_ws, "null pointer");
+    // python evaluates alpha and (1 - alpha) in double; ATen casts each scalar to fp32 and multiplies
+    // in fp32 (qat_quant.py:231): 1-0.9 = 0.09999999999999998 -> 0.1f, NOT 1-(float)0.9
+    const float a = (float)alpha, oma = (float)(1.0 - alpha);
+    hipLaunchKernelGGL(k_observer_ema, dim3(1), dim3(64), 0, (hipStream_t)stream, qmin, qmax, obs_ws, a, oma);
+    return launch_status("fqss_observer_ema");
+}
+
+extern "C" int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* obs_ws,
+                           fqss_stream_t stream) {
+    FQSS_REQUIRE(x && obs_ws && rows >= 0 && cols >= 0 && ld >= cols, "bad args");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    const bool vec = aligned16(x) && (ld % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_minmax<4>, grid_rows(rows, cols, 4, 1024), dim3(256), 0, (hipStream_t)stream, x, rows,
+                           cols, ld, obs_ws);
+    else
+        hipLaunchKernelGGL(k_minmax<1>, grid_rows(rows, cols, 1, 1024), dim3(256), 0, (hipStream_t)stream, x, rows,
+                           cols, ld, obs_ws);
+    return launch_status("fqss_minmax");
+}
+
+extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64_t cols, int64_t ld_z,
+                             int64_t ld_g, int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin,
+                             const float* qmax, double* gacc, float* gbias, int64_t C, fqss_stream_t stream) {
+    FQSS_REQUIRE(z && g && gz, "null tensor");
+    FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_g >= cols && ld_gz >= cols, "bad shape");
+    FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
+    FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");
+    FQSS_REQUIRE(!gbias || C > 0, "gbias needs C");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    const bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+#define FQSS_LAUNCH_BWD(V, Bi)                                                                                       \
+    hipLaunchKernelGGL((k_actq_bwd<V, Bi>), grid_rows(rows, cols, V, 4096), dim3(256), 0, s, z, g, gz, rows, cols,   \
+                       ld_z, ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, gbias, C)
+    if (vec) {
+        if (gbias) FQSS_LAUNCH_BWD(4, true); else FQSS_LAUNCH_BWD(4, false);
+    } else {
+        if (gbias) FQSS_LAUNCH_BWD(1, true); else FQSS_LAUNCH_BWD(1, false);
+    }
+#undef FQSS_LAUNCH_BWD
+    return launch_status("fqss_actq_bwd");
+}
+
+extern "C" int fqss_wq_observe(const float* w, int64_t outer, int64_t C, int64_t inner, float* qmin, float* qmax,
+                               fqss_stream_t stream) {
+    FQSS_REQUIRE(w && qmin && qmax && outer > 0 && C > 0 && inner > 0, "bad args");
+    hipLaunchKernelGGL(k_wq_observe, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, w, outer, C, inner, qmin, qmax);
+    return launch_status("fqss_wq_observe");
+}
+
+extern "C" int fqss_wq_fwd(const float* w, float* wq, int8_t* idx, int64_t outer, int64_t C, int64_t inner,
+                           const float* qmin, const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(w && wq && qmin && qmax && outer > 0 && C > 0 && inner > 0, "bad args");
+    const int64_t n = outer * C * inner;
+    int64_t nb = cdiv(n, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_wq_fwd, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, wq, idx, n, C, inner, qmin, qmax);
+    return launch_status("fqss_wq_fwd");
+}
+
+extern "C" int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* gmax, int64_t outer,
+                           int64_t C, int64_t inner, const float* qmin, const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(w && g && gw && gmin && gmax && qmin && qmax && outer > 0 && C > 0 && inner > 0, "bad args");
+    hipLaunchKernelGGL(k_wq_bwd, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, w, g, gw, gmin, gmax, outer, C,
+                       inner, qmin, qmax);
+    return launch_status("fqss_wq_bwd");
+}

@@ -1,0 +1,120 @@
+// fqss_dev.h -- shared device/host helpers for the gfx950 kernels of libfqss_hip.so.
+// Built with -ffp-contract=off: every fp32 operator below is ONE IEEE-754 operation (the parity
+// contract restates ATen op sequences whose intermediate roundings matter for the bin index).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fqss.h"
+
+namespace fqss {
+
+// ---------------------------------------------------------------- host side
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);
+
+#define FQSS_REQUIRE(cond, msg)                          \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            ::fqss::set_error("%s: %s", __func__, msg);  \
+            return FQSS_EINVAL;                          \
+        }                                                \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 2-D launch shape for row-matrix element-wise kernels: x covers column chunks, y strides rows.
+static inline dim3 grid_rows(int64_t rows, int64_t cols, int vec, int64_t max_blocks = 8192) {
+    int64_t gx = cdiv(cols, 256 * (int64_t)vec);
+    if (gx < 1) gx = 1;
+    if (gx > 1024) gx = 1024;
+    int64_t gy = max_blocks / gx;
+    if (gy < 1) gy = 1;
+    if (gy > rows) gy = rows;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy, 1);
+}
+
+// ---------------------------------------------------------------- device side
+#if defined(__HIPCC__)
+
+constexpr int kWave = 64;
+
+// order-preserving float <-> uint map, so float min/max run on integer atomics (exact, order-free)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum of N values per thread; result valid in thread 0.  smem: N * (blockDim/64) T's.
+template <typename T, int N>
+__device__ __forceinline__ void block_sum(T (&v)[N], T* smem) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) smem[i * nw + w] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T s = smem[i * nw];
+            for (int k = 1; k < nw; ++k) s += smem[i * nw + k];
+            v[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- the quantizer arithmetic, op for op (qat_quant.py:139-146) ----
+struct QRange {
+    float lo, delta;
+};
+__device__ __forceinline__ QRange load_qrange(const float* qmin, const float* qmax) {
+    const float lo = *qmin, hi = *qmax;
+    QRange r;
+    r.lo = lo;
+    r.delta = (hi - lo) / 255.0f;  // fp32 sub, IEEE fp32 div
+    return r;
+}
+__device__ __forceinline__ float act_apply(float z, int act, float slope) {
+    if (act == FQSS_ACT_PRELU) return z > 0.0f ? z : slope * z;  // ATen prelu kernel
+    if (act == FQSS_ACT_RELU) return z > 0.0f ? z : 0.0f;
+    return z;
+}
+// returns the de-quantised value, c = clamped integer index as float, u = pre-round coordinate
+__device__ __forceinline__ float fq_asym(float t, const QRange& r, float& c, float& u, bool& inr) {
+    u = (t - r.lo) / r.delta;   // true division (x*(1/delta) flips 2.7 ppm of indices)
+    const float X = rintf(u);   // v_rndne_f32: round-half-to-even == torch.round
+    inr = (X >= 0.0f) && (X <= 255.0f);
+    c = fminf(fmaxf(X, 0.0f), 255.0f);
+    return r.delta * c + r.lo;  // two roundings (mul, add): contraction is off
+}
+
+#endif  // __HIPCC__
+}  // namespace fqss

@@ -1,0 +1,331 @@
+// gemm.hip -- K4/K5 (+ the weight-gradient of K11-K13): pointwise Conv1d as an fp32 GEMM on the
+// matrix cores.  v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (no TF32 on gfx950), so the
+// result is a true fp32 convolution like the reference's MKL-DNN path, only the summation order
+// differs (parity gate G1).
+//
+// One kernel template, one LDS-tiled 128x128x16 block tile, 4 waves of 64x64 (2x2 MFMA tiles of
+// 32x32), operands addressed through (batch, row, col) strides so the same code serves
+//   fwd    z[b]  = W      * x[b]        A = W   (k contiguous)   B = x[b]   (j contiguous)
+//   dgrad  gx[b] = W^T    * gz[b]       A = W^T (i contiguous)   B = gz[b]  (j contiguous)
+//   wgrad  gW   += gz[b]  * x[b]^T      A = gz  (k contiguous)   B = x[b]^T (k contiguous), split-K + atomics
+//   frames gW   += a[n]   * F(x[n])     A = a   (k contiguous)   B = frames of x (j contiguous, k stride = hop)
+// LDS images are k-major (As[k][m], Bs[k][n]) so that every MFMA operand fetch is a conflict-free
+// ds_read_b32 of 32 consecutive floats per half-wave.
+//
+// Reference replaced: F.conv1d(k=1) in Conv1dQ/Conv1dNlQ (qat_layers.py:137-146, 202-212) and its
+// autograd (convolution_backward), F.conv1d/F.conv_transpose1d weight gradients of the
+// encoder/decoder (qat_layers.py:1028-1039, 1330-1341, 1189-1202).
+#include "fqss_dev.h"
+
+namespace fqss {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;  // [M] or null
+    int M, N, K;        // per-batch problem
+    int64_t sAb, sAi, sAk;
+    int64_t sBb, sBk, sBj;
+    int64_t sCb, sCi;
+    int ksplit, kchunk;  // split-K over blockIdx.z (ATOMIC only)
+};
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded LDS row (floats)
+
+template <bool A_KC, bool B_KC, bool VEC, bool ATOMIC>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bz = blockIdx.z;
+    const int b = ATOMIC ? bz / g.ksplit : bz;
+    const int ks = ATOMIC ? bz % g.ksplit : 0;
+    const int kbeg = ATOMIC ? ks * g.kchunk : 0;
+    const int kend = ATOMIC ? min(g.K, kbeg + g.kchunk) : g.K;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+
+    const float* Ab = g.A + (int64_t)b * g.sAb;
+    const float* Bb = g.B + (int64_t)b * g.sBb;
+
+    float ra[8], rb[8];
+
+    auto load_tiles = [&](int k0) {
+        // ---------------- A tile: 128 (i) x 16 (k)
+        if constexpr (VEC) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int f = tid + 256 * p;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (A_KC) {
+                    const int i = f >> 2, k = (f & 3) * 4;
+                    if (i0 + i < g.M && k0 + k < kend) {
+                        v = *reinterpret_cast<const float4*>(Ab + (int64_t)(i0 + i) * g.sAi + (k0 + k));
+                        if (k0 + k + 1 >= kend) v.y = 0.f;
+                        if (k0 + k + 2 >= kend) v.z = 0.f;
+                        if (k0 + k + 3 >= kend) v.w = 0.f;
+                    }
+                } else {
+                    const int k = f >> 5, i = (f & 31) * 4;
+                    if (k0 + k < kend && i0 + i < g.M) {
+                        v = *reinterpret_cast<const float4*>(Ab + (int64_t)(k0 + k) * g.sAk + (i0 + i));
+                        if (i0 + i + 1 >= g.M) v.y = 0.f;
+                        if (i0 + i + 2 >= g.M) v.z = 0.f;
+                        if (i0 + i + 3 >= g.M) v.w = 0.f;
+                    }
+                }
+                ra[4 * p + 0] = v.x; ra[4 * p + 1] = v.y; ra[4 * p + 2] = v.z; ra[4 * p + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int e = tid + 256 * p;
+                int i, k;
+                if constexpr (A_KC) { i = e >> 4; k = e & 15; } else { k = e >> 7; i = e & 127; }
+                float v = 0.f;
+                if (i0 + i < g.M && k0 + k < kend) v = Ab[(int64_t)(i0 + i) * g.sAi + (int64_t)(k0 + k) * g.sAk];
+                ra[p] = v;
+            }
+        }
+        // ---------------- B tile: 16 (k) x 128 (j)
+        if constexpr (VEC) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int f = tid + 256 * p;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (B_KC) {
+                    const int j = f >> 2, k = (f & 3) * 4;
+                    if (j0 + j < g.N && k0 + k < kend) {
+                        v = *reinterpret_cast<const float4*>(Bb + (int64_t)(j0 + j) * g.sBj + (k0 + k));
+                        if (k0 + k + 1 >= kend) v.y = 0.f;
+                        if (k0 + k + 2 >= kend) v.z = 0.f;
+                        if (k0 + k + 3 >= kend) v.w = 0.f;
+                    }
+                } else {
+                    const int k = f >> 5, j = (f & 31) * 4;
+                    if (k0 + k < kend && j0 + j < g.N) {
+                        v = *reinterpret_cast<const float4*>(Bb + (int64_t)(k0 + k) * g.sBk + (j0 + j));
+                        if (j0 + j + 1 >= g.N) v.y = 0.f;
+                        if (j0 + j + 2 >= g.N) v.z = 0.f;
+                        if (j0 + j + 3 >= g.N) v.w = 0.f;
+                    }
+                }
+                rb[4 * p + 0] = v.x; rb[4 * p + 1] = v.y; rb[4 * p + 2] = v.z; rb[4 * p + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int e = tid + 256 * p;
+                int j, k;
+                if constexpr (B_KC) { j = e >> 4; k = e & 15; } else { k = e >> 7; j = e & 127; }
+                float v = 0.f;
+                if (j0 + j < g.N && k0 + k < kend) v = Bb[(int64_t)(k0 + k) * g.sBk + (int64_t)(j0 + j) * g.sBj];
+                rb[p] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int f = tid + 256 * p;
+                if constexpr (A_KC) {
+                    const int i = f >> 2, k = (f & 3) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) As[k + e][i] = ra[4 * p + e];
+                } else {
+                    const int k = f >> 5, i = (f & 31) * 4;
+                    *reinterpret_cast<float4*>(&As[k][i]) = make_float4(ra[4 * p], ra[4 * p + 1], ra[4 * p + 2], ra[4 * p + 3]);
+                }
+                if constexpr (B_KC) {
+                    const int j = f >> 2, k = (f & 3) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Bs[k + e][j] = rb[4 * p + e];
+                } else {
+                    const int k = f >> 5, j = (f & 31) * 4;
+                    *reinterpret_cast<float4*>(&Bs[k][j]) = make_float4(rb[4 * p], rb[4 * p + 1], rb[4 * p + 2], rb[4 * p + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int e = tid + 256 * p;
+                int i, k, j, k2;
+                if constexpr (A_KC) { i = e >> 4; k = e & 15; } else { k = e >> 7; i = e & 127; }
+                if constexpr (B_KC) { j = e >> 4; k2 = e & 15; } else { k2 = e >> 7; j = e & 127; }
+                As[k][i] = ra[p];
+                Bs[k2][j] = rb[p];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tiles(kbeg);
+        store_tiles();
+    }
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);  // global loads fly under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[kk + lk][wm * 64 + lr];
+            const float a1 = As[kk + lk][wm * 64 + 32 + lr];
+            const float b0 = Bs[kk + lk][wn * 64 + lr];
+            const float b1 = Bs[kk + lk][wn * 64 + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cb = g.C + (int64_t)b * g.sCb;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = j0 + wn * 64 + ni * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < g.M && col < g.N) {
+                    float v = acc[mi][ni][r];
+                    if (g.bias != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias[row];
+                    float* dst = Cb + (int64_t)row * g.sCi + col;
+                    if constexpr (ATOMIC) atomicAdd(dst, v); else *dst = v;
+                }
+            }
+        }
+}
+
+static inline int64_t rup4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+// a_kc / b_kc: which dimension of the operand is contiguous in memory
+static int launch_gemm(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, int batch, hipStream_t s, const char* what) {
+    if (g.M <= 0 || g.N <= 0 || batch <= 0) return FQSS_OK;
+    // 16-B vector path: aligned bases, strides multiple of 4 floats, and the 4-wide over-read at the
+    // edge of the contiguous dimension stays inside the (padded) row
+    bool vec = aligned16(g.A) && aligned16(g.B) && (g.sAb % 4 == 0) && (g.sBb % 4 == 0);
+    if (a_kc) vec = vec && (g.sAk == 1) && (g.sAi % 4 == 0) && (g.sAi >= rup4(g.K));
+    else      vec = vec && (g.sAi == 1) && (g.sAk % 4 == 0) && (g.sAk >= rup4(g.M));
+    if (b_kc) vec = vec && (g.sBk == 1) && (g.sBj % 4 == 0) && (g.sBj >= rup4(g.K));
+    else      vec = vec && (g.sBj == 1) && (g.sBk % 4 == 0) && (g.N % 4 == 0 || g.sBk >= rup4(g.N));
+    if (atomic) vec = vec && (g.kchunk % 4 == 0);
+    dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)(batch * (atomic ? g.ksplit : 1)));
+    dim3 block(256);
+#define FQSS_GEMM(AK, BKc, V, AT) hipLaunchKernelGGL((k_gemm_f32<AK, BKc, V, AT>), grid, block, 0, s, g)
+    if (!atomic) {
+        if (a_kc && !b_kc) { if (vec) FQSS_GEMM(true, false, true, false); else FQSS_GEMM(true, false, false, false); }
+        else if (!a_kc && !b_kc) { if (vec) FQSS_GEMM(false, false, true, false); else FQSS_GEMM(false, false, false, false); }
+        else { set_error("%s: unsupported operand layout", what); return FQSS_EINVAL; }
+    } else {
+        if (a_kc && b_kc) { if (vec) FQSS_GEMM(true, true, true, true); else FQSS_GEMM(true, true, false, true); }
+        else if (a_kc && !b_kc) { if (vec) FQSS_GEMM(true, false, true, true); else FQSS_GEMM(true, false, false, true); }
+        else { set_error("%s: unsupported operand layout", what); return FQSS_EINVAL; }
+    }
+#undef FQSS_GEMM
+    return launch_status(what);
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_pwconv_fwd(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
+                               int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && w && z, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= M && ld_z >= M, "bad shape");
+    GemmArgs g{};
+    g.A = w; g.B = x; g.C = z; g.bias = bias;
+    g.M = Co; g.N = M; g.K = Ci;
+    g.sAb = 0; g.sAi = Ci; g.sAk = 1;
+    g.sBb = (int64_t)Ci * ld_x; g.sBk = ld_x; g.sBj = 1;
+    g.sCb = (int64_t)Co * ld_z; g.sCi = ld_z;
+    g.ksplit = 1; g.kchunk = Ci;
+    return launch_gemm(g, true, false, false, B, (hipStream_t)stream, "fqss_pwconv_fwd");
+}
+
+extern "C" int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci, int Co, int M,
+                                 int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && w && gx, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_gx >= M, "bad shape");
+    GemmArgs g{};
+    g.A = w; g.B = gz; g.C = gx; g.bias = nullptr;
+    g.M = Ci; g.N = M; g.K = Co;
+    g.sAb = 0; g.sAi = 1; g.sAk = Ci;  // A = W^T: A(i=ci, k=co) = W[co*Ci + ci]
+    g.sBb = (int64_t)Co * ld_gz; g.sBk = ld_gz; g.sBj = 1;
+    g.sCb = (int64_t)Ci * ld_gx; g.sCi = ld_gx;
+    g.ksplit = 1; g.kchunk = Co;
+    return launch_gemm(g, false, false, false, B, (hipStream_t)stream, "fqss_pwconv_bwd_x");
+}
+
+extern "C" int fqss_pwconv_bwd_w(const float* gz, const float* x, float* gw, int B, int Ci, int Co, int M,
+                                 int64_t ld_gz, int64_t ld_x, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && x && gw, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_x >= M, "bad shape");
+    if (M == 0) return FQSS_OK;
+    GemmArgs g{};
+    g.A = gz; g.B = x; g.C = gw; g.bias = nullptr;
+    g.M = Co; g.N = Ci; g.K = M;
+    g.sAb = (int64_t)Co * ld_gz; g.sAi = ld_gz; g.sAk = 1;
+    g.sBb = (int64_t)Ci * ld_x; g.sBk = 1; g.sBj = ld_x;  // B(k=m, j=ci) = x[ci*ld + m]
+    g.sCb = 0; g.sCi = Ci;
+    // split the long reduction (B*M) so that >= ~256 workgroups are in flight
+    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
+    int want = (int)cdiv(512, (int64_t)tiles * (B > 0 ? B : 1));
+    if (want < 1) want = 1;
+    int kchunk = (int)cdiv(cdiv(M, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    g.kchunk = kchunk;
+    g.ksplit = (int)cdiv(M, kchunk);
+    return launch_gemm(g, true, true, true, B, (hipStream_t)stream, "fqss_pwconv_bwd_w");
+}
+
+extern "C" int fqss_frames_wgrad(const float* a, const float* x, float* gw, int N, int C, int Ci, int M, int64_t ld_a,
+                                 int64_t T, int K, int stride, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && x && gw, "null tensor");
+    FQSS_REQUIRE(N >= 0 && C > 0 && Ci > 0 && M >= 0 && ld_a >= M && K > 0 && stride > 0, "bad shape");
+    FQSS_REQUIRE((int64_t)(M - 1) * stride + K <= T || M == 0, "frames exceed the signal");
+    if (M == 0) return FQSS_OK;
+    const int tiles = (int)cdiv(C, BM);
+    int want = (int)cdiv(256, (int64_t)tiles * (N > 0 ? N : 1));
+    if (want < 1) want = 1;
+    int kchunk = (int)cdiv(cdiv(M, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    for (int ci = 0; ci < Ci; ++ci) {
+        GemmArgs g{};
+        g.A = a; g.B = x + (int64_t)ci * T; g.C = gw + (int64_t)ci * K; g.bias = nullptr;
+        g.M = C; g.N = K; g.K = M;
+        g.sAb = (int64_t)C * ld_a; g.sAi = ld_a; g.sAk = 1;
+        g.sBb = (int64_t)Ci * T; g.sBk = stride; g.sBj = 1;  // B(k=m, j=k') = x[n][ci][m*stride + k']
+        g.sCb = 0; g.sCi = (int64_t)Ci * K;
+        g.kchunk = kchunk;
+        g.ksplit = (int)cdiv(M, kchunk);
+        int rc = launch_gemm(g, true, false, true, N, (hipStream_t)stream, "fqss_frames_wgrad");
+        if (rc != FQSS_OK) return rc;
+    }
+    return FQSS_OK;
+}

@@ -1,0 +1,499 @@
+// stream_ops.hip -- K6/K7/K8/K9/K14: the HBM-streaming producers of the TCN block:
+// depthwise dilated conv, GroupNorm(1 group), add/sub, mask*feats broadcast multiply.
+// All are pure memory-bound: 16 B/lane loads where rows are aligned, fp64 accumulation for the
+// statistics (the fp64 VALU is far from being the limiter of a 2-flop/byte kernel).
+//
+// Reference replaced: convtasnetq.py:28-30 (depthwise F.conv1d), nn.GroupNorm(1,C,eps=1e-8)
+// (qat_layers.py:445-448), torch.add/sub/mul (qat_layers.py:69-71, 93-96, 1193), and their autograd.
+#include "fqss_dev.h"
+
+namespace fqss {
+
+// =============================================================================================
+// z = a + sb*b          (sb = +1: AddQ, -1: ResidualErrorBlock's Y - Y_q; +-1 multiply is exact)
+// =============================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void k_axpby(const float* __restrict__ a, const float* __restrict__ b, float sb,
+                                                float* __restrict__ z, int64_t rows, int64_t cols, int64_t ld_a,
+                                                int64_t ld_b, int64_t ld_z) {
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* ar = a + row * ld_a;
+        const float* br = b + row * ld_b;
+        float* zr = z + row * ld_z;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
+            if constexpr (VEC == 4) {
+                const float4 x = *reinterpret_cast<const float4*>(ar + c0);
+                const float4 y = *reinterpret_cast<const float4*>(br + c0);
+                *reinterpret_cast<float4*>(zr + c0) =
+                    make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w);
+            } else {
+                zr[c0] = ar[c0] + sb * br[c0];
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// z[b][s][c][:] = mask[b][s][c][:] * feat[b][c][:]        (MulQ, convtasnetq.py:209)
+// =============================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void k_mul_bcast_fwd(const float* __restrict__ mask, const float* __restrict__ feat,
+                                                        float* __restrict__ z, int B, int S, int C, int M,
+                                                        int64_t ld_m, int64_t ld_f, int64_t ld_z) {
+    const int64_t rows = (int64_t)B * S * C;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int64_t b = row / ((int64_t)S * C), c = row % C;
+        const float* mr = mask + row * ld_m;
+        const float* fr = feat + (b * C + c) * ld_f;
+        float* zr = z + row * ld_z;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < M; c0 += cstep) {
+            if constexpr (VEC == 4) {
+                const float4 x = *reinterpret_cast<const float4*>(mr + c0);
+                const float4 y = *reinterpret_cast<const float4*>(fr + c0);
+                *reinterpret_cast<float4*>(zr + c0) = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+            } else {
+                zr[c0] = mr[c0] * fr[c0];
+            }
+        }
+    }
+}
+
+// gmask = gz*feat ; gfeat = sum_s gz*mask   (one pass: each thread owns (b,c,m) and walks s)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_mul_bcast_bwd(const float* __restrict__ gz, const float* __restrict__ mask,
+                                                        const float* __restrict__ feat, float* __restrict__ gmask,
+                                                        float* __restrict__ gfeat, int B, int S, int C, int M,
+                                                        int64_t ld_gz, int64_t ld_m, int64_t ld_f, int64_t ld_gm,
+                                                        int64_t ld_gf) {
+    const int64_t rows = (int64_t)B * C;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int64_t b = row / C, c = row % C;
+        const float* fr = feat + row * ld_f;
+        float* gfr = gfeat + row * ld_gf;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < M; c0 += cstep) {
+            float f[VEC], acc[VEC];
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(fr + c0);
+                f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+            } else {
+                f[0] = fr[c0];
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+            for (int s = 0; s < S; ++s) {
+                const int64_t r2 = (b * S + s) * C + c;
+                float gv[VEC], mv[VEC], o[VEC];
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(gz + r2 * ld_gz + c0);
+                    const float4 u = *reinterpret_cast<const float4*>(mask + r2 * ld_m + c0);
+                    gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+                    mv[0] = u.x; mv[1] = u.y; mv[2] = u.z; mv[3] = u.w;
+                } else {
+                    gv[0] = gz[r2 * ld_gz + c0];
+                    mv[0] = mask[r2 * ld_m + c0];
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    o[j] = gv[j] * f[j];
+                    acc[j] = acc[j] + gv[j] * mv[j];
+                }
+                if constexpr (VEC == 4)
+                    *reinterpret_cast<float4*>(gmask + r2 * ld_gm + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                else
+                    gmask[r2 * ld_gm + c0] = o[0];
+            }
+            if constexpr (VEC == 4)
+                *reinterpret_cast<float4*>(gfr + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            else
+                gfr[c0] = acc[0];
+        }
+    }
+}
+
+// =============================================================================================
+// depthwise dilated conv (cross-correlation, zero padding), K <= 8 taps
+// =============================================================================================
+constexpr int kMaxTaps = 8;
+
+// FLIP=false: z[m] = bias + sum_k w[k] * x[m + k*dil - pad]            (forward)
+// FLIP=true : gx[m] =        sum_k w[k] * gz[m - k*dil + pad]          (input gradient)
+template <bool FLIP>
+__global__ __launch_bounds__(256) void k_dwconv(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ z, int64_t rows,
+                                                 int C, int M, int K, int dil, int pad, int64_t ld_x, int64_t ld_z) {
+    const int64_t cstep = (int64_t)gridDim.x * 256;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int c = (int)(row % C);
+        const float* xr = x + row * ld_x;
+        float* zr = z + row * ld_z;
+        float wk[kMaxTaps];
+#pragma unroll
+        for (int k = 0; k < kMaxTaps; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+        const float bv = (!FLIP && bias != nullptr) ? bias[c] : 0.0f;
+        for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += cstep) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMaxTaps; ++k) {
+                if (k < K) {
+                    const int64_t src = FLIP ? (m - (int64_t)k * dil + pad) : (m + (int64_t)k * dil - pad);
+                    if (src >= 0 && src < M) acc = fmaf(wk[k], xr[src], acc);
+                }
+            }
+            zr[m] = acc + bv;
+        }
+    }
+}
+
+// gw[c][k] += sum_{b,m} gz[b][c][m] * x[b][c][m + k*dil - pad]   ; grid (C, B)
+__global__ __launch_bounds__(256) void k_dwconv_bwd_w(const float* __restrict__ gz, const float* __restrict__ x,
+                                                       float* gw, int C, int M, int K, int dil, int pad, int64_t ld_gz,
+                                                       int64_t ld_x) {
+    __shared__ double red[kMaxTaps * 4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int64_t row = (int64_t)b * C + c;
+    const float* gr = gz + row * ld_gz;
+    const float* xr = x + row * ld_x;
+    float p[kMaxTaps];
+#pragma unroll
+    for (int k = 0; k < kMaxTaps; ++k) p[k] = 0.0f;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const float g = gr[m];
+#pragma unroll
+        for (int k = 0; k < kMaxTaps; ++k) {
+            if (k < K) {
+                const int64_t src = m + (int64_t)k * dil - pad;
+                if (src >= 0 && src < M) p[k] = fmaf(g, xr[src], p[k]);
+            }
+        }
+    }
+    double v[kMaxTaps];
+#pragma unroll
+    for (int k = 0; k < kMaxTaps; ++k) v[k] = (double)p[k];
+    block_sum<double, kMaxTaps>(v, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[k]);
+}
+
+// =============================================================================================
+// GroupNorm(1, C): statistics over the C*M elements of one sample
+// =============================================================================================
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, int C, int M, int64_t ld, double* ws) {
+    __shared__ double red[2 * 4];
+    const int b = blockIdx.y;
+    double s = 0.0, ss = 0.0;
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        const float* xr = x + ((int64_t)b * C + c) * ld;
+        for (int m = threadIdx.x * VEC; m < M; m += 256 * VEC) {
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + m);
+                const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (m + j < M) {
+                        s += (double)v[j];
+                        ss += (double)v[j] * (double)v[j];
+                    }
+            } else {
+                const double v = (double)xr[m];
+                s += v;
+                ss += v * v;
+            }
+        }
+    }
+    double v[2] = {s, ss};
+    block_sum<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&ws[2 * b], v[0]);
+        atomicAdd(&ws[2 * b + 1], v[1]);
+    }
+}
+
+__device__ __forceinline__ void gn_mean_rstd(const double* ws, int b, int64_t n, float eps, float& mean, float& rstd) {
+    const double mu = ws[2 * b] / (double)n;
+    double var = ws[2 * b + 1] / (double)n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = x*scale + shift ; scale = rstd*gamma[c] ; shift = beta[c] - scale*mean   (ATen GroupNorm kernel form)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ z,
+                                                   float* mean_rstd, int B, int C, int M, int64_t ld_x, int64_t ld_z,
+                                                   float eps, const double* ws) {
+    const int64_t rows = (int64_t)B * C;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = (int)(row / C), c = (int)(row % C);
+        float mean, rstd;
+        gn_mean_rstd(ws, b, (int64_t)C * M, eps, mean, rstd);
+        if (c == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+            mean_rstd[2 * b] = mean;
+            mean_rstd[2 * b + 1] = rstd;
+        }
+        const float scale = rstd * gamma[c];
+        const float shift = fmaf(-scale, mean, beta[c]);
+        const float* xr = x + row * ld_x;
+        float* zr = z + row * ld_z;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < M; c0 += cstep) {
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + c0);
+                *reinterpret_cast<float4*>(zr + c0) = make_float4(fmaf(t.x, scale, shift), fmaf(t.y, scale, shift),
+                                                                  fmaf(t.z, scale, shift), fmaf(t.w, scale, shift));
+            } else {
+                zr[c0] = fmaf(xr[c0], scale, shift);
+            }
+        }
+    }
+}
+
+// backward pass 1: per (b,c) row sums  ds = sum gz*x, db = sum gz   -> ws[(b*C+c)*2 + {0,1}]
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gn_bwd_rows(const float* __restrict__ gz, const float* __restrict__ x, int C,
+                                                      int M, int64_t ld_gz, int64_t ld_x, double* ws) {
+    __shared__ double red[2 * 4];
+    const int64_t row = (int64_t)blockIdx.y * C + blockIdx.x;
+    const float* gr = gz + row * ld_gz;
+    const float* xr = x + row * ld_x;
+    double ds = 0.0, db = 0.0;
+    for (int m = threadIdx.x * VEC; m < M; m += 256 * VEC) {
+        if constexpr (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(gr + m);
+            const float4 t = *reinterpret_cast<const float4*>(xr + m);
+            const float gv[4] = {a.x, a.y, a.z, a.w}, xv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (m + j < M) {
+                    ds += (double)gv[j] * (double)xv[j];
+                    db += (double)gv[j];
+                }
+        } else {
+            ds += (double)gr[m] * (double)xr[m];
+            db += (double)gr[m];
+        }
+    }
+    double v[2] = {ds, db};
+    block_sum<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        ws[2 * row] = v[0];
+        ws[2 * row + 1] = v[1];
+    }
+}
+
+// backward pass 2 (tiny): per-sample coefficients c2,c3 (ATen GroupNormBackward form) and gamma/beta grads
+//   ds_sum = sum_c gamma_c ds[b][c], db_sum = sum_c gamma_c db[b][c]
+//   c2 = (db_sum*mean - ds_sum) * rstd^3 / N ; c3 = -c2*mean - db_sum*rstd/N
+//   ggamma[c] += sum_b (ds[b][c] - db[b][c]*mean_b)*rstd_b ; gbeta[c] += sum_b db[b][c]
+__global__ __launch_bounds__(256) void k_gn_bwd_coef(const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                      int B, int C, int M, double* ws, float* ggamma, float* gbeta) {
+    __shared__ double red[2 * 4];
+    const int b = blockIdx.x;
+    double* coef = ws + 2 * (int64_t)B * C;
+    if (b < B) {
+        double s_ds = 0.0, s_db = 0.0;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const double gmm = (double)gamma[c];
+            s_ds += gmm * ws[2 * ((int64_t)b * C + c)];
+            s_db += gmm * ws[2 * ((int64_t)b * C + c) + 1];
+        }
+        double v[2] = {s_ds, s_db};
+        block_sum<double, 2>(v, red);
+        if (threadIdx.x == 0) {
+            const double mean = (double)mean_rstd[2 * b], rstd = (double)mean_rstd[2 * b + 1];
+            const double inv_n = 1.0 / ((double)C * (double)M);
+            const double c2 = (v[1] * mean - v[0]) * rstd * rstd * rstd * inv_n;
+            const double c3 = -c2 * mean - v[1] * rstd * inv_n;
+            coef[2 * b] = c2;
+            coef[2 * b + 1] = c3;
+        }
+    } else {
+        // extra blocks (blockIdx.x >= B): parameter gradients, one thread per channel
+        const int c = (b - B) * 256 + threadIdx.x;
+        if (c < C) {
+            double gg = 0.0, gb = 0.0;
+            for (int bb = 0; bb < B; ++bb) {
+                const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
+                gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
+                gb += db;
+            }
+            ggamma[c] += (float)gg;
+            gbeta[c] += (float)gb;
+        }
+    }
+}
+
+// backward pass 3: gx = gz*(gamma_c*rstd) + x*c2 + c3
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ gz, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean_rstd, float* __restrict__ gx,
+                                                       int B, int C, int M, int64_t ld_gz, int64_t ld_x, int64_t ld_gx,
+                                                       const double* ws) {
+    const double* coef = ws + 2 * (int64_t)B * C;
+    const int64_t rows = (int64_t)B * C;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = (int)(row / C), c = (int)(row % C);
+        const float c1 = mean_rstd[2 * b + 1] * gamma[c];
+        const float c2 = (float)coef[2 * b], c3 = (float)coef[2 * b + 1];
+        const float* gr = gz + row * ld_gz;
+        const float* xr = x + row * ld_x;
+        float* orow = gx + row * ld_gx;
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < M; c0 += cstep) {
+            if constexpr (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(gr + c0);
+                const float4 t = *reinterpret_cast<const float4*>(xr + c0);
+                *reinterpret_cast<float4*>(orow + c0) =
+                    make_float4(fmaf(a.x, c1, fmaf(t.x, c2, c3)), fmaf(a.y, c1, fmaf(t.y, c2, c3)),
+                                fmaf(a.z, c1, fmaf(t.z, c2, c3)), fmaf(a.w, c1, fmaf(t.w, c2, c3)));
+            } else {
+                orow[c0] = fmaf(gr[c0], c1, fmaf(xr[c0], c2, c3));
+            }
+        }
+    }
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+#define FQSS_VEC_OK2(p0, l0, p1, l1) (aligned16(p0) && aligned16(p1) && ((l0) % 4 == 0) && ((l1) % 4 == 0))
+
+extern "C" int fqss_axpby(const float* a, const float* b, float sb, float* z, int64_t rows, int64_t cols,
+                          int64_t ld_a, int64_t ld_b, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && b && z, "null tensor");
+    FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_a >= cols && ld_b >= cols && ld_z >= cols, "bad shape");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    const bool vec = FQSS_VEC_OK2(a, ld_a, b, ld_b) && aligned16(z) && ld_z % 4 == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_axpby<4>, grid_rows(rows, cols, 4), dim3(256), 0, (hipStream_t)stream, a, b, sb, z, rows,
+                           cols, ld_a, ld_b, ld_z);
+    else
+        hipLaunchKernelGGL(k_axpby<1>, grid_rows(rows, cols, 1), dim3(256), 0, (hipStream_t)stream, a, b, sb, z, rows,
+                           cols, ld_a, ld_b, ld_z);
+    return launch_status("fqss_axpby");
+}
+
+extern "C" int fqss_mul_bcast_fwd(const float* mask, const float* feat, float* z, int B, int S, int C, int M,
+                                  int64_t ld_mask, int64_t ld_feat, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(mask && feat && z, "null tensor");
+    FQSS_REQUIRE(B >= 0 && S > 0 && C > 0 && M >= 0 && ld_mask >= M && ld_feat >= M && ld_z >= M, "bad shape");
+    if (B == 0 || M == 0) return FQSS_OK;
+    const int64_t rows = (int64_t)B * S * C;
+    const bool vec = FQSS_VEC_OK2(mask, ld_mask, feat, ld_feat) && aligned16(z) && ld_z % 4 == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_mul_bcast_fwd<4>, grid_rows(rows, M, 4), dim3(256), 0, (hipStream_t)stream, mask, feat, z,
+                           B, S, C, M, ld_mask, ld_feat, ld_z);
+    else
+        hipLaunchKernelGGL(k_mul_bcast_fwd<1>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, mask, feat, z,
+                           B, S, C, M, ld_mask, ld_feat, ld_z);
+    return launch_status("fqss_mul_bcast_fwd");
+}
+
+extern "C" int fqss_mul_bcast_bwd(const float* gz, const float* mask, const float* feat, float* gmask, float* gfeat,
+                                  int B, int S, int C, int M, int64_t ld_gz, int64_t ld_mask, int64_t ld_feat,
+                                  int64_t ld_gmask, int64_t ld_gfeat, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && mask && feat && gmask && gfeat, "null tensor");
+    FQSS_REQUIRE(B >= 0 && S > 0 && C > 0 && M >= 0 && ld_gz >= M && ld_mask >= M && ld_feat >= M && ld_gmask >= M &&
+                     ld_gfeat >= M, "bad shape");
+    if (B == 0 || M == 0) return FQSS_OK;
+    const int64_t rows = (int64_t)B * C;
+    const bool vec = FQSS_VEC_OK2(gz, ld_gz, mask, ld_mask) && FQSS_VEC_OK2(feat, ld_feat, gmask, ld_gmask) &&
+                     aligned16(gfeat) && ld_gfeat % 4 == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_mul_bcast_bwd<4>, grid_rows(rows, M, 4), dim3(256), 0, (hipStream_t)stream, gz, mask, feat,
+                           gmask, gfeat, B, S, C, M, ld_gz, ld_mask, ld_feat, ld_gmask, ld_gfeat);
+    else
+        hipLaunchKernelGGL(k_mul_bcast_bwd<1>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, gz, mask, feat,
+                           gmask, gfeat, B, S, C, M, ld_gz, ld_mask, ld_feat, ld_gmask, ld_gfeat);
+    return launch_status("fqss_mul_bcast_bwd");
+}
+
+extern "C" int fqss_dwconv_fwd(const float* x, const float* w, const float* bias, float* z, int B, int C, int M, int K,
+                               int dil, int pad, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && w && z, "null tensor");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kMaxTaps && dil > 0 && pad >= 0, "bad shape");
+    FQSS_REQUIRE(2 * pad == dil * (K - 1), "only 'same' depthwise convs (2*pad == dil*(K-1)) are supported");
+    FQSS_REQUIRE(ld_x >= M && ld_z >= M, "bad ld");
+    if (B == 0 || M == 0) return FQSS_OK;
+    const int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(k_dwconv<false>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, rows, C,
+                       M, K, dil, pad, ld_x, ld_z);
+    return launch_status("fqss_dwconv_fwd");
+}
+
+extern "C" int fqss_dwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int C, int M, int K, int dil,
+                                 int pad, int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && w && gx, "null tensor");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kMaxTaps && dil > 0 && pad >= 0, "bad shape");
+    FQSS_REQUIRE(2 * pad == dil * (K - 1), "only 'same' depthwise convs are supported");
+    FQSS_REQUIRE(ld_gz >= M && ld_gx >= M, "bad ld");
+    if (B == 0 || M == 0) return FQSS_OK;
+    const int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(k_dwconv<true>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, gz, w,
+                       (const float*)nullptr, gx, rows, C, M, K, dil, pad, ld_gz, ld_gx);
+    return launch_status("fqss_dwconv_bwd_x");
+}
+
+extern "C" int fqss_dwconv_bwd_w(const float* gz, const float* x, float* gw, int B, int C, int M, int K, int dil,
+                                 int pad, int64_t ld_gz, int64_t ld_x, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && x && gw, "null tensor");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kMaxTaps && dil > 0 && pad >= 0, "bad shape");
+    FQSS_REQUIRE(ld_gz >= M && ld_x >= M && B <= 65535, "bad ld / batch");
+    if (B == 0 || M == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_dwconv_bwd_w, dim3((unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, gz, x, gw, C, M,
+                       K, dil, pad, ld_gz, ld_x);
+    return launch_status("fqss_dwconv_bwd_w");
+}
+
+extern "C" int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd, int B,
+                           int C, int M, int64_t ld_x, int64_t ld_z, float eps, double* ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gamma && beta && z && mean_rstd && ws, "null tensor");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_x >= M && ld_z >= M, "bad shape");
+    if (B == 0) return FQSS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s) != hipSuccess) return launch_status("fqss_gn_fwd(memset)");
+    const bool vec_x = aligned16(x) && ld_x % 4 == 0;
+    int nb = C < 64 ? C : 64;
+    if (vec_x)
+        hipLaunchKernelGGL(k_gn_stats<4>, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, x, C, M, ld_x, ws);
+    else
+        hipLaunchKernelGGL(k_gn_stats<1>, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, x, C, M, ld_x, ws);
+    const int64_t rows = (int64_t)B * C;
+    if (vec_x && aligned16(z) && ld_z % 4 == 0)
+        hipLaunchKernelGGL(k_gn_apply<4>, grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
+                           ld_x, ld_z, eps, ws);
+    else
+        hipLaunchKernelGGL(k_gn_apply<1>, grid_rows(rows, M, 1), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
+                           ld_x, ld_z, eps, ws);
+    return launch_status("fqss_gn_fwd");
+}
+
+extern "C" int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd, float* gx,
+                           float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz, int64_t ld_x,
+                           int64_t ld_gx, double* ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && x && gamma && mean_rstd && gx && ggamma && gbeta && ws, "null tensor");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_gz >= M && ld_x >= M && ld_gx >= M, "bad shape");
+    if (B == 0) return FQSS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = FQSS_VEC_OK2(gz, ld_gz, x, ld_x);
+    if (vec)
+        hipLaunchKernelGGL(k_gn_bwd_rows<4>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
+    else
+        hipLaunchKernelGGL(k_gn_bwd_rows<1>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
+    hipLaunchKernelGGL(k_gn_bwd_coef, dim3((unsigned)(B + cdiv(C, 256))), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
+                       ggamma, gbeta);
+    const int64_t rows = (int64_t)B * C;
+    if (vec && aligned16(gx) && ld_gx % 4 == 0)
+        hipLaunchKernelGGL(k_gn_bwd_apply<4>, grid_rows(rows, M, 4), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
+                           M, ld_gz, ld_x, ld_gx, ws);
+    else
+        hipLaunchKernelGGL(k_gn_bwd_apply<1>, grid_rows(rows, M, 1), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
+                           M, ld_gz, ld_x, ld_gx, ws);
+    return launch_status("fqss_gn_bwd");
+}

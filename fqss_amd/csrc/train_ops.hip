@@ -1,0 +1,263 @@
+// train_ops.hip -- K15/K16: the scalar end of the step.
+//   kd_loss    SDR-weighted knowledge-distillation loss with 2-speaker PIT, forward AND backward:
+//              one streaming pass accumulates the 24 second-order moments of (est, teacher, target)
+//              per sample in fp64, a one-block kernel does PIT / weights / loss / gradient
+//              coefficients, one streaming pass writes dL/d est.
+//   sumsq + adam_clip   global-norm clip and Adam over ONE flat fp32 parameter buffer.
+//
+// Reference replaced: System.common_step (mysystem.py:124-151), PairwiseWSDR (wsdr.py:56-95),
+// asteroid PITLossWrapper("pw_mtx") for n_src=2 (third-party, restated in oracle/fqss_oracle.py),
+// pl gradient_clip_val=5.0 + torch.optim.Adam (asteroid_librimix_trainer.py:94,132).
+#include "fqss_dev.h"
+
+namespace fqss {
+
+constexpr double kEps = 1e-8;
+constexpr int kNMom = 24;
+constexpr int kStatStride = 32;
+// moment slots per sample. signals: e0 e1 (student) f0 f1 (teacher) t0 t1 (targets)
+//  0..5   sums            S[e0,e1,f0,f1,t0,t1]
+//  6..11  self products   ee0 ee1 ff0 ff1 tt0 tt1
+// 12..15  e_i.t_j  (i*2+j)      16..19  e_i.f_j      20..23  f_i.t_j
+
+__global__ __launch_bounds__(256) void k_kd_moments(const float* __restrict__ est, const float* __restrict__ fest,
+                                                     const float* __restrict__ tgt, int64_t T, double* stats) {
+    __shared__ double red[kNMom * 4];
+    const int b = blockIdx.y;
+    const float* e0 = est + (int64_t)b * 2 * T;
+    const float* f0 = fest + (int64_t)b * 2 * T;
+    const float* t0 = tgt + (int64_t)b * 2 * T;
+    double a[kNMom];
+#pragma unroll
+    for (int i = 0; i < kNMom; ++i) a[i] = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256) {
+        const double s[6] = {(double)e0[t], (double)e0[T + t], (double)f0[t], (double)f0[T + t], (double)t0[t], (double)t0[T + t]};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            a[i] += s[i];
+            a[6 + i] += s[i] * s[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                a[12 + i * 2 + j] += s[i] * s[4 + j];
+                a[16 + i * 2 + j] += s[i] * s[2 + j];
+                a[20 + i * 2 + j] += s[2 + i] * s[4 + j];
+            }
+    }
+    block_sum<double, kNMom>(a, red);
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kNMom; ++i) atomicAdd(&stats[(int64_t)b * kStatStride + i], a[i]);
+}
+
+struct PairSdr {
+    double sdr;      // ||proj||^2 / (||noise||^2 + eps)
+    double cx, cy;   // d sdr / d x~ = cx * x~ + cy * y~   (x~, y~ zero-mean)
+};
+
+// x: estimate, y: reference; raw moments over T samples (wsdr.py:63-89 with sdr_type='sisdr')
+__device__ PairSdr pair_sdr(double Sx, double Sy, double Sxx, double Syy, double Sxy, double T) {
+    const double X2 = Sxx - Sx * Sx / T, Y2 = Syy - Sy * Sy / T, D = Sxy - Sx * Sy / T;
+    const double E = Y2 + kEps;
+    const double alpha = D / E;
+    const double P = alpha * alpha * Y2;
+    double Nn = X2 - 2.0 * alpha * D + alpha * alpha * Y2;
+    if (Nn < 0.0) Nn = 0.0;
+    const double den = Nn + kEps;
+    PairSdr r;
+    r.sdr = P / den;
+    r.cx = -2.0 * P / (den * den);
+    r.cy = 2.0 * alpha * Y2 / (E * den) + P * (2.0 * alpha + 2.0 * D * kEps / (E * E)) / (den * den);
+    return r;
+}
+
+// one block; thread b < B handles sample b. coef[b][i][8] = {A, Bt, jt, Bf, jf, mean_e, -, -}, means[b][6]
+__global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_lambda, double* stats, float* out,
+                                                    float* w_out, float* sisdr_out) {
+    __shared__ double red[2 * 16];
+    const int b = threadIdx.x;
+    const double Td = (double)T;
+    double task_b = 0.0, kd_b = 0.0, wb = 0.0;
+    int pt = 0, pf = 0;  // selected permutation (0: identity, 1: swapped) for task / kd
+    PairSdr st[2][2], sf[2][2];
+    if (b < B) {
+        const double* m = stats + (int64_t)b * kStatStride;
+        double neg_log_ft[2][2], neg_log_et[2][2];
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                st[i][j] = pair_sdr(m[i], m[4 + j], m[6 + i], m[10 + j], m[12 + i * 2 + j], Td);        // e_i vs t_j
+                sf[i][j] = pair_sdr(m[i], m[2 + j], m[6 + i], m[8 + j], m[16 + i * 2 + j], Td);         // e_i vs f_j
+                const PairSdr ft = pair_sdr(m[2 + i], m[4 + j], m[8 + i], m[10 + j], m[20 + i * 2 + j], Td);  // f_i vs t_j
+                neg_log_ft[i][j] = -10.0 * log10(ft.sdr + kEps);
+                neg_log_et[i][j] = -10.0 * log10(st[i][j].sdr + kEps);
+            }
+        // PIT (pw_mtx): loss_p = mean_i pw[est=p[i]][tgt=i]; p0 = (0,1), p1 = (1,0); torch.min keeps the first on ties
+        const double lf0 = 0.5 * (neg_log_ft[0][0] + neg_log_ft[1][1]), lf1 = 0.5 * (neg_log_ft[1][0] + neg_log_ft[0][1]);
+        const double le0 = 0.5 * (neg_log_et[0][0] + neg_log_et[1][1]), le1 = 0.5 * (neg_log_et[1][0] + neg_log_et[0][1]);
+        const double sdrs = lf1 < lf0 ? lf1 : lf0, sdrqs = le1 < le0 ? le1 : le0;
+        wb = pow(10.0, (sdrs - sdrqs) / 10.0);  // w = SDR_student / SDR_teacher (mysystem.py:141)
+        // task / kd use the NEGATED linear ratio through the same PIT (min of negatives = max of ratios)
+        const double t0 = -0.5 * (st[0][0].sdr + st[1][1].sdr), t1 = -0.5 * (st[1][0].sdr + st[0][1].sdr);
+        pt = t1 < t0 ? 1 : 0;
+        task_b = -(pt ? t1 : t0);
+        const double k0 = -0.5 * wb * (sf[0][0].sdr + sf[1][1].sdr), k1 = -0.5 * wb * (sf[1][0].sdr + sf[0][1].sdr);
+        pf = k1 < k0 ? 1 : 0;
+        kd_b = -(pf ? k1 : k0);
+        w_out[b] = (float)wb;
+        sisdr_out[b] = (float)(-sdrqs);
+    }
+    double v[2] = {task_b, kd_b};
+    block_sum<double, 2>(v, red);
+    __shared__ double sh_task, sh_kd;
+    if (threadIdx.x == 0) {
+        sh_task = v[0] / (double)B;
+        sh_kd = v[1] / (double)B;
+    }
+    __syncthreads();
+    const double task = sh_task, kd = sh_kd;
+    const double lam = (double)kd_lambda;
+    const double arg = (1.0 - lam) * task + lam * kd + kEps;
+    if (threadIdx.x == 0) {
+        out[0] = (float)(-10.0 * log10(arg));
+        out[1] = (float)(-10.0 * log10(kd + kEps));
+        out[2] = (float)task;
+        out[3] = (float)kd;
+    }
+    if (b < B) {
+        // dL/d arg = -10/(ln10 * arg); d arg/d sdr_task(b, pair) = (1-lam)/(2B); d arg/d sdr_kd = lam*w_b/(2B)
+        const double dL = -10.0 / (log(10.0) * arg);
+        const double gt = dL * (1.0 - lam) / (2.0 * (double)B);
+        const double gk = dL * lam * wb / (2.0 * (double)B);
+        double* m = stats + (int64_t)b * kStatStride;
+        double cf[2][5];
+        for (int i = 0; i < 2; ++i) {
+            // target index paired with estimate i: perm p has est p[j] on tgt j -> est i sits on tgt j with p[j]==i
+            const int jt = pt ? 1 - i : i, jf = pf ? 1 - i : i;
+            cf[i][0] = gt * st[i][jt].cx + gk * sf[i][jf].cx;  // coefficient of e~_i
+            cf[i][1] = gt * st[i][jt].cy;                      // coefficient of t~_jt
+            cf[i][2] = (double)jt;
+            cf[i][3] = gk * sf[i][jf].cy;                      // coefficient of f~_jf
+            cf[i][4] = (double)jf;
+        }
+        // means for the zero-mean views, then the coefficient table (overwrites the moment slots)
+        double mean[6];
+        for (int i = 0; i < 6; ++i) mean[i] = m[i] / Td;
+        for (int i = 0; i < 6; ++i) m[i] = mean[i];
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 5; ++k) m[8 + i * 8 + k] = cf[i][k];
+    }
+}
+
+// gest[b][i][t] = A*(e_i - mean) + Bt*(t_jt - mean) + Bf*(f_jf - mean)
+__global__ __launch_bounds__(256) void k_kd_grad(const float* __restrict__ est, const float* __restrict__ fest,
+                                                  const float* __restrict__ tgt, int64_t T, const double* stats,
+                                                  float* __restrict__ gest) {
+    const int b = blockIdx.y >> 1, i = blockIdx.y & 1;
+    const double* m = stats + (int64_t)b * kStatStride;
+    const double* cf = m + 8 + i * 8;
+    const int jt = (int)cf[2], jf = (int)cf[4];
+    const float A = (float)cf[0], Bt = (float)cf[1], Bf = (float)cf[3];
+    const float me = (float)m[i], mt = (float)m[4 + jt], mf = (float)m[2 + jf];
+    const float* e = est + ((int64_t)b * 2 + i) * T;
+    const float* tt = tgt + ((int64_t)b * 2 + jt) * T;
+    const float* ff = fest + ((int64_t)b * 2 + jf) * T;
+    float* g = gest + ((int64_t)b * 2 + i) * T;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256)
+        g[t] = A * (e[t] - me) + Bt * (tt[t] - mt) + Bf * (ff[t] - mf);
+}
+
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, double* acc) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)g[i];
+        s += v * v;
+    }
+    double v[1] = {s};
+    block_sum<double, 1>(v, red);
+    if (threadIdx.x == 0) atomicAdd(acc, v[0]);
+}
+
+// torch.optim.Adam single-tensor math (amsgrad=False, weight_decay=0, maximize=False):
+//   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
+__global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    const double* sumsq, float max_norm, float grad_scale, float lr,
+                                                    float beta1, float beta2, float eps, const int32_t* step_t) {
+    const int t = *step_t + 1;
+    const double norm = sqrt(*sumsq) * (double)grad_scale;
+    double coef = (double)max_norm / (norm + 1e-6);   // torch.nn.utils.clip_grad_norm_
+    if (coef > 1.0) coef = 1.0;
+    if (max_norm <= 0.0f) coef = 1.0;
+    const float gs = (float)((double)grad_scale * coef);
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        const float mi = m[i] + omb1 * (gi - m[i]);
+        const float vi = v[i] * beta2 + (omb2 * gi) * gi;   // addcmul: self + value*t1*t2
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + ((-step_size) * mi) / denom;           // addcdiv: self + value*t1/t2
+    }
+}
+
+__global__ void k_step_end(int32_t* step_t, const double* sumsq, float grad_scale, float* gnorm_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *step_t = *step_t + 1;
+        if (gnorm_out) *gnorm_out = (float)(sqrt(*sumsq) * (double)grad_scale);
+    }
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, int64_t T, float kd_lambda,
+                            double* stats, float* out, float* w_out, float* sisdr_out, float* gest,
+                            fqss_stream_t stream) {
+    FQSS_REQUIRE(est && fest && tgt && stats && out && w_out && sisdr_out, "null tensor");
+    FQSS_REQUIRE(B > 0 && B <= 1024 && T > 0, "B must be in 1..1024");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * kStatStride * B, s) != hipSuccess) return launch_status("fqss_kd_loss(memset)");
+    int64_t nb = cdiv(T, 256 * 8);
+    if (nb > 64) nb = 64;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_kd_moments, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, est, fest, tgt, T, stats);
+    hipLaunchKernelGGL(k_kd_final, dim3(1), dim3(1024), 0, s, B, T, kd_lambda, stats, out, w_out, sisdr_out);
+    if (gest) {
+        int64_t ng = cdiv(T, 256 * 4);
+        if (ng > 256) ng = 256;
+        hipLaunchKernelGGL(k_kd_grad, dim3((unsigned)ng, (unsigned)(2 * B)), dim3(256), 0, s, est, fest, tgt, T, stats, gest);
+    }
+    return launch_status("fqss_kd_loss");
+}
+
+extern "C" int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && sumsq && n >= 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    int64_t nb = cdiv(n, 256 * 8);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_sumsq, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, n, sumsq);
+    return launch_status("fqss_sumsq");
+}
+
+extern "C" int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                              float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                              int32_t* step_t, float* gnorm_out, fqss_stream_t stream) {
+    FQSS_REQUIRE(p && g && m && v && sumsq && step_t && n >= 0, "bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0) {
+        int64_t nb = cdiv(n, 256 * 4);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_adam_clip, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, v, n, sumsq, max_norm, grad_scale,
+                           lr, beta1, beta2, eps, step_t);
+    }
+    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, s, step_t, sumsq, grad_scale, gnorm_out);
+    return launch_status("fqss_adam_clip");
+}

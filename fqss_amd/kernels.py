@@ -1,0 +1,339 @@
+"""Thin torch-tensor front end of the C ABI: shape/stride checks on the host, then one ctypes
+call per kernel on torch's current HIP stream.  No arithmetic happens in this file."""
+import torch
+
+from . import _lib
+
+Q_BYPASS, Q_OBSERVE, Q_QUANT = 0, 1, 2
+ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
+
+LD_ALIGN = 16  # row stride of activation buffers is padded to 16 floats (64 B) -> 16-B/lane path
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.FqssError("fqss_amd ops need ROCm device tensors (no CPU fallback; see oracle/ for the CPU checker)")
+        if t is not None and t.dtype not in (torch.float32,):
+            raise _lib.FqssError(f"fp32 tensor expected, got {t.dtype}")
+
+
+def empty_act(shape, device, ld_align=LD_ALIGN):
+    """[..., M] fp32 activation whose rows are padded to a multiple of `ld_align` floats."""
+    M = shape[-1]
+    ld = (M + ld_align - 1) // ld_align * ld_align
+    buf = torch.empty(*shape[:-1], ld, device=device, dtype=torch.float32)
+    return buf[..., :M] if ld != M else buf
+
+
+def rowmat(t):
+    """(rows, cols, ld) of a tensor that is a row matrix with unit column stride, else None.
+    Size-1 dims are ignored; the first non-unit dim above the last one defines the row stride."""
+    if t.dim() == 0:
+        return None
+    cols = t.shape[-1]
+    if cols > 1 and t.stride(-1) != 1:
+        return None
+    rows, ld = 1, None
+    for d in range(t.dim() - 2, -1, -1):
+        n = t.shape[d]
+        if n == 1:
+            continue
+        if ld is None:
+            ld = t.stride(d)
+            if ld < cols:
+                return None
+        elif t.stride(d) != ld * rows:
+            return None
+        rows *= n
+    if ld is None:
+        ld = max(cols, 1)
+    return rows, cols, ld
+
+
+def as_rowmat(t):
+    """return (tensor, rows, cols, ld); copies into a padded buffer only if the layout is foreign"""
+    rm = rowmat(t)
+    if rm is None:
+        c = empty_act(tuple(t.shape), t.device)
+        c.copy_(t)
+        t, rm = c, rowmat(c)
+    return (t,) + rm
+
+
+# ------------------------------------------------------------------ K1 / K3
+def actq_fwd(z, act, slope, qmode, qmin, qmax, obs_ws, want_idx=False):
+    _need_gpu(z, slope, qmin, qmax)
+    z, rows, cols, ld_z = as_rowmat(z)
+    out = empty_act(tuple(z.shape), z.device)
+    _, _, _, ld_o = (out,) + rowmat(out)
+    idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if want_idx else None
+    _lib.call("fqss_actq_fwd", _p(z), _p(out), _p(idx), rows, cols, ld_z, ld_o, act, _p(slope), qmode,
+              _p(qmin), _p(qmax), _p(obs_ws), _stream())
+    return (out, idx) if want_idx else out
+
+
+def obs_reset(obs_ws):
+    _lib.call("fqss_obs_reset", _p(obs_ws), obs_ws.numel() // 2, _stream())
+
+
+def observer_ema(qmin, qmax, obs_ws, alpha=0.9):
+    _lib.call("fqss_observer_ema", _p(qmin), _p(qmax), _p(obs_ws), float(alpha), _stream())
+
+
+def minmax(x, obs_ws):
+    _need_gpu(x)
+    x, rows, cols, ld = as_rowmat(x)
+    _lib.call("fqss_minmax", _p(x), rows, cols, ld, _p(obs_ws), _stream())
+
+
+def actq_bwd(z, g, act, slope, qmode, qmin, qmax, gacc, gbias=None, C=0):
+    _need_gpu(z, g)
+    z, rows, cols, ld_z = as_rowmat(z)
+    g, r2, c2, ld_g = as_rowmat(g)
+    assert (rows, cols) == (r2, c2), "actq_bwd: z/g shape mismatch"
+    gz = empty_act(tuple(z.shape), z.device)
+    ld_gz = rowmat(gz)[2]
+    _lib.call("fqss_actq_bwd", _p(z), _p(g), _p(gz), rows, cols, ld_z, ld_g, ld_gz, act, _p(slope), qmode,
+              _p(qmin), _p(qmax), _p(gacc), _p(gbias), C, _stream())
+    return gz
+
+
+# ------------------------------------------------------------------ K2
+def _w_layout(shape, axis):
+    outer = 1
+    for d in shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in shape[axis + 1:]:
+        inner *= d
+    return outer, shape[axis], inner
+
+
+def wq_observe(w, axis, qmin, qmax):
+    _need_gpu(w, qmin, qmax)
+    o, c, i = _w_layout(w.shape, axis)
+    _lib.call("fqss_wq_observe", _p(w.contiguous()), o, c, i, _p(qmin), _p(qmax), _stream())
+
+
+def wq_fwd(w, axis, qmin, qmax, want_idx=False):
+    _need_gpu(w, qmin, qmax)
+    w = w.contiguous()
+    o, c, i = _w_layout(w.shape, axis)
+    wq = torch.empty_like(w)
+    idx = torch.empty(w.shape, device=w.device, dtype=torch.int8) if want_idx else None
+    _lib.call("fqss_wq_fwd", _p(w), _p(wq), _p(idx), o, c, i, _p(qmin), _p(qmax), _stream())
+    return (wq, idx) if want_idx else wq
+
+
+def wq_bwd(w, g, axis, qmin, qmax):
+    _need_gpu(w, g, qmin, qmax)
+    w, g = w.contiguous(), g.contiguous()
+    o, c, i = _w_layout(w.shape, axis)
+    gw = torch.empty_like(w)
+    gmin = torch.empty_like(qmin)
+    gmax = torch.empty_like(qmax)
+    _lib.call("fqss_wq_bwd", _p(w), _p(g), _p(gw), _p(gmin), _p(gmax), o, c, i, _p(qmin), _p(qmax), _stream())
+    return gw, gmin, gmax
+
+
+# ------------------------------------------------------------------ K4 / K5  pointwise conv
+def _bcm(t):
+    """[B][C][M] tensor -> (tensor, B, C, M, ld) with batch stride C*ld"""
+    assert t.dim() == 3, "expected [B, C, M]"
+    t, rows, cols, ld = as_rowmat(t)
+    return t, t.shape[0], t.shape[1], t.shape[2], ld
+
+
+def pwconv_fwd(x, w, bias):
+    _need_gpu(x, w, bias)
+    x, B, Ci, M, ld_x = _bcm(x)
+    Co = w.shape[0]
+    assert w.is_contiguous() and w.numel() == Co * Ci
+    z = empty_act((B, Co, M), x.device)
+    _lib.call("fqss_pwconv_fwd", _p(x), _p(w), _p(bias), _p(z), B, Ci, Co, M, ld_x, rowmat(z)[2], _stream())
+    return z
+
+
+def pwconv_bwd_x(gz, w, Ci):
+    _need_gpu(gz, w)
+    gz, B, Co, M, ld_gz = _bcm(gz)
+    gx = empty_act((B, Ci, M), gz.device)
+    _lib.call("fqss_pwconv_bwd_x", _p(gz), _p(w), _p(gx), B, Ci, Co, M, ld_gz, rowmat(gx)[2], _stream())
+    return gx
+
+
+def pwconv_bwd_w(gz, x, gw):
+    """gw[Co][Ci] += sum_b gz[b] x[b]^T (gw: caller-zeroed accumulator)"""
+    _need_gpu(gz, x, gw)
+    gz, B, Co, M, ld_gz = _bcm(gz)
+    x, _, Ci, _, ld_x = _bcm(x)
+    assert gw.is_contiguous() and gw.numel() == Co * Ci
+    _lib.call("fqss_pwconv_bwd_w", _p(gz), _p(x), _p(gw), B, Ci, Co, M, ld_gz, ld_x, _stream())
+
+
+# ------------------------------------------------------------------ K6  depthwise conv
+def dwconv_fwd(x, w, bias, dil, pad):
+    _need_gpu(x, w, bias)
+    x, B, C, M, ld_x = _bcm(x)
+    K = w.shape[-1]
+    z = empty_act((B, C, M), x.device)
+    _lib.call("fqss_dwconv_fwd", _p(x), _p(w), _p(bias), _p(z), B, C, M, K, dil, pad, ld_x, rowmat(z)[2], _stream())
+    return z
+
+
+def dwconv_bwd_x(gz, w, dil, pad):
+    _need_gpu(gz, w)
+    gz, B, C, M, ld_gz = _bcm(gz)
+    K = w.shape[-1]
+    gx = empty_act((B, C, M), gz.device)
+    _lib.call("fqss_dwconv_bwd_x", _p(gz), _p(w), _p(gx), B, C, M, K, dil, pad, ld_gz, rowmat(gx)[2], _stream())
+    return gx
+
+
+def dwconv_bwd_w(gz, x, gw, dil, pad):
+    _need_gpu(gz, x, gw)
+    gz, B, C, M, ld_gz = _bcm(gz)
+    x, _, _, _, ld_x = _bcm(x)
+    K = gw.shape[-1]
+    _lib.call("fqss_dwconv_bwd_w", _p(gz), _p(x), _p(gw), B, C, M, K, dil, pad, ld_gz, ld_x, _stream())
+
+
+# ------------------------------------------------------------------ K7  GroupNorm(1, C)
+def gn_fwd(x, gamma, beta, eps):
+    _need_gpu(x, gamma, beta)
+    x, B, C, M, ld_x = _bcm(x)
+    z = empty_act((B, C, M), x.device)
+    mean_rstd = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gn_fwd", _p(x), _p(gamma), _p(beta), _p(z), _p(mean_rstd), B, C, M, ld_x, rowmat(z)[2],
+              float(eps), _p(ws), _stream())
+    return z, mean_rstd
+
+
+def gn_bwd(gz, x, gamma, mean_rstd, ggamma, gbeta):
+    _need_gpu(gz, x, gamma, mean_rstd, ggamma, gbeta)
+    gz, B, C, M, ld_gz = _bcm(gz)
+    x, _, _, _, ld_x = _bcm(x)
+    gx = empty_act((B, C, M), x.device)
+    ws = torch.empty(2 * B * C + 2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gn_bwd", _p(gz), _p(x), _p(gamma), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), B, C, M, ld_gz,
+              ld_x, rowmat(gx)[2], _p(ws), _stream())
+    return gx
+
+
+# ------------------------------------------------------------------ K8 / K9 / K14
+def axpby(a, b, sb):
+    _need_gpu(a, b)
+    assert a.shape == b.shape
+    a, rows, cols, ld_a = as_rowmat(a)
+    b, _, _, ld_b = as_rowmat(b)
+    z = empty_act(tuple(a.shape), a.device)
+    _lib.call("fqss_axpby", _p(a), _p(b), float(sb), _p(z), rows, cols, ld_a, ld_b, rowmat(z)[2], _stream())
+    return z
+
+
+def mul_bcast_fwd(mask, feat):
+    """mask [B,S,C,M] * feat [B,C,M] -> [B,S,C,M]"""
+    _need_gpu(mask, feat)
+    B, S, C, M = mask.shape
+    mask, _, _, ld_m = as_rowmat(mask)
+    feat, _, _, ld_f = as_rowmat(feat)
+    z = empty_act((B, S, C, M), mask.device)
+    _lib.call("fqss_mul_bcast_fwd", _p(mask), _p(feat), _p(z), B, S, C, M, ld_m, ld_f, rowmat(z)[2], _stream())
+    return z
+
+
+def mul_bcast_bwd(gz, mask, feat):
+    _need_gpu(gz, mask, feat)
+    B, S, C, M = mask.shape
+    gz, _, _, ld_gz = as_rowmat(gz)
+    mask, _, _, ld_m = as_rowmat(mask)
+    feat, _, _, ld_f = as_rowmat(feat)
+    gmask = empty_act((B, S, C, M), mask.device)
+    gfeat = empty_act((B, C, M), mask.device)
+    _lib.call("fqss_mul_bcast_bwd", _p(gz), _p(mask), _p(feat), _p(gmask), _p(gfeat), B, S, C, M, ld_gz, ld_m, ld_f,
+              rowmat(gmask)[2], rowmat(gfeat)[2], _stream())
+    return gmask, gfeat
+
+
+# ------------------------------------------------------------------ K10-K13  codec
+def splitter2(x):
+    """x [B,1,T] or [B,T] -> [B,2,T] (process.preprocess, n_splitter=2)"""
+    _need_gpu(x)
+    x2 = x.reshape(x.shape[0], -1).contiguous()
+    B, T = x2.shape
+    ws = torch.empty(2, device=x.device, dtype=torch.int32)
+    obs_reset(ws)
+    minmax(x2, ws)
+    out = torch.empty(B, 2, T, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_splitter2", _p(x2), _p(out), B, T, _p(ws), _stream())
+    return out
+
+
+def frames_conv_fwd(x, w, stride):
+    """x [N,Ci,T] dense, w [Co,Ci,K] -> z [N,Co,M]"""
+    _need_gpu(x, w)
+    x = x.contiguous()
+    N, Ci, T = x.shape
+    Co, _, K = w.shape
+    M = (T - K) // stride + 1
+    z = empty_act((N, Co, M), x.device)
+    _lib.call("fqss_frames_conv_fwd", _p(x), _p(w.contiguous()), _p(z), N, Ci, Co, T, K, stride, M, rowmat(z)[2], _stream())
+    return z
+
+
+def ola_convtr_fwd(x, w, stride):
+    """x [N,C,M], w [C,1,K] (or [C,K]) -> out [N,1,T], T=(M-1)*stride+K"""
+    _need_gpu(x, w)
+    x, N, C, M, ld_x = _bcm(x)
+    K = w.shape[-1]
+    T = (M - 1) * stride + K
+    out = torch.empty(N, 1, T, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_ola_convtr_fwd", _p(x), _p(w.contiguous()), _p(out), N, C, M, ld_x, K, stride, T, _stream())
+    return out
+
+
+def frames_wgrad(a, x, gw, stride):
+    """gw[C][Ci][K] += sum_{n,m} a[n][c][m] * x[n][ci][m*stride+k]"""
+    _need_gpu(a, x, gw)
+    a, N, C, M, ld_a = _bcm(a)
+    x = x.contiguous()
+    _, Ci, T = x.shape
+    K = gw.shape[-1]
+    assert gw.is_contiguous() and gw.numel() == C * Ci * K
+    _lib.call("fqss_frames_wgrad", _p(a), _p(x), _p(gw), N, C, Ci, M, ld_a, T, K, stride, _stream())
+
+
+# ------------------------------------------------------------------ K15 / K16
+def kd_loss(est, fest, tgt, kd_lambda, want_grad=True):
+    _need_gpu(est, fest, tgt)
+    est, fest, tgt = est.contiguous(), fest.contiguous(), tgt.contiguous()
+    B, S, T = est.shape
+    assert S == 2, "the PIT kernel is built for n_src = 2"
+    dev = est.device
+    stats = torch.empty(B, 32, device=dev, dtype=torch.float64)
+    out = torch.empty(4, device=dev, dtype=torch.float32)
+    w = torch.empty(B, device=dev, dtype=torch.float32)
+    sisdr = torch.empty(B, device=dev, dtype=torch.float32)
+    gest = torch.empty_like(est) if want_grad else None
+    _lib.call("fqss_kd_loss", _p(est), _p(fest), _p(tgt), B, T, float(kd_lambda), _p(stats), _p(out), _p(w),
+              _p(sisdr), _p(gest), _stream())
+    return out, w, sisdr, gest
+
+
+def sumsq(g, acc):
+    _lib.call("fqss_sumsq", _p(g), g.numel(), _p(acc), _stream())
+
+
+def adam_clip(p, g, m, v, sumsq_acc, step_t, gnorm_out, max_norm, grad_scale, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    _lib.call("fqss_adam_clip", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_acc), float(max_norm),
+              float(grad_scale), float(lr), float(beta1), float(beta2), float(eps), _p(step_t), _p(gnorm_out), _stream())

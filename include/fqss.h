@@ -1,0 +1,198 @@
+/*
+ * fqss.h -- C ABI of libfqss_hip.so: the MI355X (gfx950) kernels of the FQSS QAT hot path.
+ *
+ * The reference (ssi-research/FQSS @ 2024_10_08) is pure Python/PyTorch and has no FFI of its
+ * own; its drop-in surface is the `quantization.qat` module API.  This header
+ * is the boundary inserted BENEATH that surface: each entry point replaces the ATen op sequence
+ * of the cited reference lines.  The Python host (fqss_amd/) binds it with ctypes; the binding a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a caller-owned DEVICE pointer (PyTorch caching allocator); the library
+ *    allocates nothing and keeps no mutable global state;
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*) and return without syncing;
+ *    safe under hipGraph capture;
+ *  - return value: 0 = ok, negative = error (FQSS_E*); fqss_last_error() gives the text;
+ *    nothing throws across the boundary;
+ *  - activations are fp32 row matrices [rows][cols] with a row stride `ld` (elements, ld >= cols);
+ *    a [B][C][M] tensor is rows = B*C; rows whose `ld` is a multiple of 4 floats and whose base
+ *    is 16-byte aligned take the 16-B/lane vector path;
+ *  - "+=" outputs are accumulated (caller zeroes them once per step), "=" outputs are overwritten.
+ */
+#ifndef FQSS_H
+#define FQSS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQSS_VERSION 100 /* 0.1.0 */
+
+#define FQSS_OK 0
+#define FQSS_EINVAL (-22)
+#define FQSS_ELAUNCH (-5)
+
+/* activation-quantizer mode (GradientActivationFakeQuantize.forward, qat_quant.py:227-242) */
+#define FQSS_Q_BYPASS 0  /* float teacher / act_quant=False: identity                      */
+#define FQSS_Q_OBSERVE 1 /* first 50 calls: pass-through + running min/max (:228-233)      */
+#define FQSS_Q_QUANT 2   /* linear_quantize asym 8 bit (:136-147)                          */
+
+/* non-linearity fused in front of the quantizer (Conv1dNlQ / NlQ, qat_layers.py:188-219,511-518) */
+#define FQSS_ACT_NONE 0
+#define FQSS_ACT_PRELU 1 /* one shared slope, nn.PReLU() */
+#define FQSS_ACT_RELU 2
+
+typedef void* fqss_stream_t;
+
+int fqss_version(void);
+const char* fqss_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1/K1b/K3  per-tensor activation fake-quant (+ fused PReLU/ReLU), observer, STE backward
+ * replaces: qat_quant.py:136-147 (8 elementwise ATen passes), :228-233 (x.min()/x.max() + EMA),
+ *           autograd of both; nn.PReLU / F.relu in front (qat_layers.py:211, 517)
+ * ------------------------------------------------------------------------------------------- */
+
+/* out = fq(act(z)).  idx (optional, dense [rows][cols] u8) receives the integer bin index.
+ * OBSERVE: out = act(z) and obs_ws[0..1] (ordered-uint min / max) are updated atomically.      */
+int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols,
+                  int64_t ld_z, int64_t ld_out, int act, const float* slope, int qmode,
+                  const float* qmin, const float* qmax, uint32_t* obs_ws, fqss_stream_t stream);
+
+/* obs_ws = {0xFFFFFFFF, 0}: must hold before the first OBSERVE launch of a call */
+int fqss_obs_reset(uint32_t* obs_ws, int64_t n_pairs, fqss_stream_t stream);
+
+/* min = alpha*min + (1-alpha)*obs_min (same for max), fp32 op order of qat_quant.py:231-232;
+ * then resets obs_ws.                                                                           */
+int fqss_observer_ema(float* qmin, float* qmax, uint32_t* obs_ws, double alpha, fqss_stream_t stream);
+
+/* backward of out = fq(act(z)) given g = dL/dout:
+ *   gz = dL/dz ; gacc[0] += dL/dmin ; gacc[1] += dL/dmax ; gacc[2] += dL/dslope (fp64 atomics)
+ *   gbias[row % C] += sum_cols gz   (optional, fp32 atomics; bias of the producing conv)         */
+int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64_t cols,
+                  int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act, const float* slope, int qmode,
+                  const float* qmin, const float* qmax, double* gacc, float* gbias, int64_t C,
+                  fqss_stream_t stream);
+
+/* running min/max of a plain tensor into obs_ws (used by the splitter's global max, process.py:24) */
+int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* obs_ws,
+                fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  per-channel symmetric weight fake-quant.  Weight layout [outer][C][inner]:
+ *     ch_out_idx=0 -> outer=1 (Conv1d), ch_out_idx=1 -> outer=shape[0] (ConvTranspose1d).
+ * replaces: qat_quant.py:126-135, :372-381 and their autograd
+ * ------------------------------------------------------------------------------------------- */
+int fqss_wq_observe(const float* w, int64_t outer, int64_t C, int64_t inner, float* qmin,
+                    float* qmax, fqss_stream_t stream);
+int fqss_wq_fwd(const float* w, float* wq, int8_t* idx, int64_t outer, int64_t C, int64_t inner,
+                const float* qmin, const float* qmax, fqss_stream_t stream);
+/* gw = ; gmin[C] = ; gmax[C] = */
+int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* gmax,
+                int64_t outer, int64_t C, int64_t inner, const float* qmin, const float* qmax,
+                fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4/K5  pointwise (k=1) Conv1d as an fp32-MFMA GEMM:  z[b] = W[Co x Ci] * x[b][Ci x M] + bias
+ * replaces: F.conv1d(k=1) in Conv1dQ / Conv1dNlQ (qat_layers.py:137-146, 202-212) + autograd
+ * ------------------------------------------------------------------------------------------- */
+int fqss_pwconv_fwd(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
+                    int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
+/* gx[b] = W^T * gz[b] */
+int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci, int Co, int M,
+                      int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
+/* gw[Co][Ci] += sum_b gz[b] * x[b]^T */
+int fqss_pwconv_bwd_w(const float* gz, const float* x, float* gw, int B, int Ci, int Co, int M,
+                      int64_t ld_gz, int64_t ld_x, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  depthwise dilated Conv1d (groups = C): z[b][c][m] = bias[c] + sum_k w[c][k] x[b][c][m+k*dil-pad]
+ * replaces: F.conv1d(groups=C) of convtasnetq.py:28-30 + autograd
+ * ------------------------------------------------------------------------------------------- */
+int fqss_dwconv_fwd(const float* x, const float* w, const float* bias, float* z, int B, int C,
+                    int M, int K, int dil, int pad, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
+int fqss_dwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int C, int M, int K,
+                      int dil, int pad, int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
+/* gw[C][K] += */
+int fqss_dwconv_bwd_w(const float* gz, const float* x, float* gw, int B, int C, int M, int K,
+                      int dil, int pad, int64_t ld_gz, int64_t ld_x, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  GroupNorm(num_groups=1, C, eps) : per-sample statistics over C*M
+ * replaces: nn.GroupNorm in GroupNormQ (qat_layers.py:445-448) + autograd
+ * ws: fp64 scratch, fwd needs 2*B doubles, bwd needs 2*B*C + 2*B doubles (callee zeroes what it needs)
+ * ------------------------------------------------------------------------------------------- */
+int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd,
+                int B, int C, int M, int64_t ld_x, int64_t ld_z, float eps, double* ws,
+                fqss_stream_t stream);
+/* gx = ; ggamma[C] += ; gbeta[C] += */
+int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd,
+                float* gx, float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz,
+                int64_t ld_x, int64_t ld_gx, double* ws, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8/K9/K14  element-wise producers
+ * replaces: torch.add / torch.sub / torch.mul in AddQ, ResidualErrorBlock, MulQ
+ *           (qat_layers.py:69-71, 1193, 93-96), postprocess (process.py:44-47)
+ * ------------------------------------------------------------------------------------------- */
+/* z = a + sb*b */
+int fqss_axpby(const float* a, const float* b, float sb, float* z, int64_t rows, int64_t cols,
+               int64_t ld_a, int64_t ld_b, int64_t ld_z, fqss_stream_t stream);
+/* z[b][s][c][:] = mask[b][s][c][:] * feat[b][c][:] */
+int fqss_mul_bcast_fwd(const float* mask, const float* feat, float* z, int B, int S, int C, int M,
+                       int64_t ld_mask, int64_t ld_feat, int64_t ld_z, fqss_stream_t stream);
+/* gmask = gz*feat ; gfeat = sum_s gz*mask */
+int fqss_mul_bcast_bwd(const float* gz, const float* mask, const float* feat, float* gmask,
+                       float* gfeat, int B, int S, int C, int M, int64_t ld_gz, int64_t ld_mask,
+                       int64_t ld_feat, int64_t ld_gmask, int64_t ld_gfeat, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K10-K13  8-bit splitter, strided framing conv (encoder), transposed conv + overlap-add (decoder)
+ * replaces: process.preprocess (process.py:16-37); F.conv1d(k, stride) of Conv1dEncoderQ and of
+ *           ResidualErrorBlock (qat_layers.py:1028-1039, 1189-1192); F.conv_transpose1d of
+ *           ConvTr1dDecoderQ / ResidualErrorBlock (:1330-1341, 1194-1202) + autograd
+ * ------------------------------------------------------------------------------------------- */
+/* x [B][T] -> out [B][2][T]; obs_ws must hold the global min/max of x (fqss_minmax) */
+int fqss_splitter2(const float* x, float* out, int B, int64_t T, const uint32_t* obs_ws,
+                   fqss_stream_t stream);
+/* z[n][co][m] = sum_{ci,k} w[co][ci][k] * x[n][ci][m*stride+k]   (x: [N][Ci][T] dense)        */
+int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci, int Co,
+                         int64_t T, int K, int stride, int M, int64_t ld_z, fqss_stream_t stream);
+/* out[n][t] = sum_{c} sum_{m*stride+k=t} x[n][c][m] * w[c][k]   (w: [C][K], out: [N][T] dense) */
+int fqss_ola_convtr_fwd(const float* x, const float* w, float* out, int N, int C, int M,
+                        int64_t ld_x, int K, int stride, int64_t T, fqss_stream_t stream);
+/* gw[c][ci][k] += sum_{n,m} a[n][c][m] * x[n][ci][m*stride+k]    (a: [N][C][M] ld_a; x dense) */
+int fqss_frames_wgrad(const float* a, const float* x, float* gw, int N, int C, int Ci, int M,
+                      int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K15  SDR-weighted KD loss with 2-speaker PIT, forward + backward in one call
+ * replaces: System.common_step (mysystem.py:124-151), PairwiseWSDR (wsdr.py:56-95),
+ *           asteroid PITLossWrapper(pit_from="pw_mtx") for n_src = 2
+ * est/fest/tgt: [B][2][T] dense.  stats: fp64 scratch [B][32] (callee zeroes).
+ * out[0]=loss out[1]=kd(dB, logged as kd_loss) out[2]=task out[3]=kd (linear); w_out[B]; gest = dL/dest
+ * ------------------------------------------------------------------------------------------- */
+int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, int64_t T,
+                 float kd_lambda, double* stats, float* out, float* w_out, float* sisdr_out,
+                 float* gest, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K16  global-norm clip + Adam over one flat fp32 parameter buffer
+ * replaces: pl.Trainer(gradient_clip_val=5.0) + torch.optim.Adam (asteroid_librimix_trainer.py:94,132)
+ * ------------------------------------------------------------------------------------------- */
+/* sumsq[0] += sum g^2  (fp64) */
+int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_t stream);
+/* step_t: device int32 step counter (incremented by the kernel -> graph-replay safe).
+ * g is scaled by min(1, max_norm/(sqrt(sumsq)+1e-6)) (torch.nn.utils.clip_grad_norm_), grad_scale
+ * pre-multiplies g (1/world for DDP averaging).                                                  */
+int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                   float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                   int32_t* step_t, float* gnorm_out, fqss_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQSS_H */

@@ -1,0 +1,210 @@
+"""GPU parity of every linear/streaming kernel behind the C ABI against torch fp32 on the CPU
+(the same ATen ops the reference calls).  Tolerances are fp32 summation-order noise (gate G1)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle.fqss_oracle as O
+
+pytestmark = pytest.mark.gpu
+K = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    global K
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from fqss_amd import kernels
+    K = kernels
+    yield
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def padded(t):
+    d = K.empty_act(tuple(t.shape), "cuda")
+    d.copy_(t)
+    return d
+
+
+def close(a, b, rtol=1e-4, atol=1e-4, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+PW_SHAPES = [(2, 16, 24, 77), (1, 128, 512, 333), (2, 512, 128, 999), (3, 20, 36, 130), (1, 128, 1024, 64)]
+
+
+@pytest.mark.parametrize("B,Ci,Co,M", PW_SHAPES)
+@pytest.mark.parametrize("pad", [True, False])
+def test_pwconv(B, Ci, Co, M, pad):
+    x, w, b = rnd(B, Ci, M, seed=1), rnd(Co, Ci, 1, seed=2, scale=Ci ** -0.5), rnd(Co, seed=3)
+    gz = rnd(B, Co, M, seed=4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv1d(xr, wr, b)
+    y.backward(gz)
+    conv = padded if pad else (lambda t: t.cuda())
+    xd, gzd = conv(x), conv(gz)
+    z = K.pwconv_fwd(xd, w.cuda(), b.cuda())
+    close(z, y, msg="fwd")
+    z2 = K.pwconv_fwd(xd, w.cuda(), None)
+    close(z2, F.conv1d(x, w), msg="fwd nobias")
+    gx = K.pwconv_bwd_x(gzd, w.cuda(), Ci)
+    close(gx, xr.grad, msg="dgrad")
+    gw = torch.zeros(Co, Ci, 1, device="cuda")
+    K.pwconv_bwd_w(gzd, xd, gw)
+    close(gw, wr.grad, rtol=2e-4, atol=2e-3 * (B * M) ** 0.5 / 30, msg="wgrad")
+
+
+def test_pwconv_exact_integers():
+    """asymmetric integer operands: the MFMA fragment maps must be exact (no transposed tiles)"""
+    B, Ci, Co, M = 1, 128, 256, 256
+    x = torch.arange(Ci * M, dtype=torch.float32).reshape(1, Ci, M) % 7 - 3
+    w = (torch.arange(Co * Ci, dtype=torch.float32).reshape(Co, Ci, 1) % 5 - 2) + torch.eye(Co, Ci).unsqueeze(-1)
+    y = F.conv1d(x, w)
+    z = K.pwconv_fwd(x.cuda(), w.cuda(), None)
+    assert torch.equal(z.cpu(), y)
+    gx = K.pwconv_bwd_x(y.cuda(), w.cuda(), Ci)
+    assert torch.equal(gx.cpu(), torch.einsum("oc,bom->bcm", w[:, :, 0], y))
+
+
+@pytest.mark.parametrize("B,C,M,dil", [(2, 32, 77, 1), (2, 32, 77, 4), (1, 512, 999, 128), (3, 7, 130, 2)])
+def test_dwconv(B, C, M, dil):
+    x, w, b, gz = rnd(B, C, M, seed=1), rnd(C, 1, 3, seed=2), rnd(C, seed=3), rnd(B, C, M, seed=4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv1d(xr, wr, b, padding=dil, dilation=dil, groups=C)
+    y.backward(gz)
+    for conv in (padded, lambda t: t.cuda()):
+        xd, gzd = conv(x), conv(gz)
+        close(K.dwconv_fwd(xd, w.cuda(), b.cuda(), dil, dil), y, atol=1e-5)
+        close(K.dwconv_bwd_x(gzd, w.cuda(), dil, dil), xr.grad, atol=1e-5)
+        gw = torch.zeros(C, 1, 3, device="cuda")
+        K.dwconv_bwd_w(gzd, xd, gw, dil, dil)
+        close(gw, wr.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,C,M", [(2, 24, 77), (2, 512, 999), (3, 5, 130), (1, 1, 64)])
+def test_groupnorm(B, C, M):
+    x = rnd(B, C, M, seed=1) * 1.7 + 0.3
+    gm, bt, gz = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, M, seed=4)
+    xr, gr, br = x.clone().requires_grad_(True), gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    y = F.group_norm(xr, 1, gr, br, 1e-8)
+    y.backward(gz)
+    for conv in (padded, lambda t: t.cuda()):
+        xd, gzd = conv(x), conv(gz)
+        z, mr = K.gn_fwd(xd, gm.cuda(), bt.cuda(), 1e-8)
+        close(z, y, rtol=1e-5, atol=2e-6)
+        gg, gb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        gx = K.gn_bwd(gzd, xd, gm.cuda(), mr, gg, gb)
+        close(gx, xr.grad, rtol=1e-4, atol=1e-5)
+        close(gg, gr.grad, rtol=1e-4, atol=1e-3)
+        close(gb, br.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_elementwise():
+    a, b = rnd(3, 20, 131, seed=1), rnd(3, 20, 131, seed=2)
+    for conv in (padded, lambda t: t.cuda()):
+        assert torch.equal(K.axpby(conv(a), conv(b), 1.0).cpu(), a + b)
+        assert torch.equal(K.axpby(conv(a), conv(b), -1.0).cpu(), a - b)
+        mask, feat, gz = rnd(2, 2, 24, 77, seed=3), rnd(2, 24, 77, seed=4), rnd(2, 2, 24, 77, seed=5)
+        z = K.mul_bcast_fwd(conv(mask), conv(feat))
+        assert torch.equal(z.cpu(), mask * feat.unsqueeze(1))
+        gm, gf = K.mul_bcast_bwd(conv(gz), conv(mask), conv(feat))
+        assert torch.equal(gm.cpu(), gz * feat.unsqueeze(1))
+        close(gf, (gz * mask).sum(1), rtol=1e-6, atol=1e-6)
+
+
+def test_splitter_golden(golden):
+    g = golden("process")
+    out = K.splitter2(torch.from_numpy(g["x"]).cuda())
+    assert np.array_equal(out.cpu().numpy(), g["pre2"])
+    out = K.splitter2(torch.from_numpy(g["x2d"]).cuda())
+    assert np.array_equal(out.cpu().numpy(), g["pre2_2d"])
+    x = rnd(8, 1, 32000, seed=9, scale=0.1)
+    assert torch.equal(K.splitter2(x.cuda()).cpu(), O.split(x, 2))
+
+
+@pytest.mark.parametrize("N,Ci,Co,M,K_,S", [(2, 2, 24, 77, 16, 8), (3, 1, 40, 130, 16, 8), (2, 2, 512, 999, 16, 8), (2, 1, 16, 50, 32, 16)])
+def test_frames_conv_and_wgrad(N, Ci, Co, M, K_, S):
+    T = (M - 1) * S + K_
+    x, w, gz = rnd(N, Ci, T, seed=1), rnd(Co, Ci, K_, seed=2, scale=0.2), rnd(N, Co, M, seed=3)
+    wr = w.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv1d(xr, wr, None, stride=S)
+    y.backward(gz)
+    z = K.frames_conv_fwd(x.cuda(), w.cuda(), S)
+    close(z, y, rtol=1e-5, atol=1e-5)
+    gw = torch.zeros(Co, Ci, K_, device="cuda")
+    K.frames_wgrad(padded(gz), x.cuda(), gw, S)
+    close(gw, wr.grad, rtol=1e-4, atol=2e-3)
+    # the conv's input gradient is the transposed conv of gz (Ci == 1 path of the residual encoder)
+    if Ci == 1:
+        gx = K.ola_convtr_fwd(padded(gz), w.cuda().reshape(Co, K_), S)
+        close(gx, xr.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("N,C,M,K_,S", [(4, 24, 77, 16, 8), (2, 512, 999, 16, 8), (1, 8, 1, 16, 8), (2, 16, 63, 16, 8), (2, 16, 64, 32, 16)])
+def test_ola_convtr(N, C, M, K_, S):
+    x, w = rnd(N, C, M, seed=1), rnd(C, 1, K_, seed=2, scale=0.2)
+    g = rnd(N, 1, (M - 1) * S + K_, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv_transpose1d(xr, wr, None, stride=S)
+    y.backward(g)
+    for conv in (padded, lambda t: t.cuda()):
+        out = K.ola_convtr_fwd(conv(x), w.cuda(), S)
+        close(out, y, rtol=1e-4, atol=1e-4)
+    # decoder backward = framing conv of the output gradient with the same taps
+    gx = K.frames_conv_fwd(g.cuda(), w.cuda().reshape(C, 1, K_), S)
+    close(gx, xr.grad, rtol=1e-5, atol=1e-5)
+    gw = torch.zeros(C, 1, K_, device="cuda")
+    K.frames_wgrad(padded(x), g.cuda(), gw, S)
+    close(gw, wr.grad, rtol=1e-4, atol=2e-3)
+
+
+def test_kd_loss_golden_and_oracle(golden):
+    g = golden("loss")
+    est, fest, tgt = (torch.from_numpy(g[k]).cuda() for k in ("est", "fest", "tgt"))
+    out, w, sisdr, gest = K.kd_loss(est, fest, tgt, 0.1)
+    np.testing.assert_allclose(w.cpu().numpy(), g["w"], rtol=1e-5)
+    np.testing.assert_allclose(out[0].item(), g["loss"], rtol=1e-5)      # KD loss: 1e-5 relative (north-star tolerance)
+    np.testing.assert_allclose(out[3].item(), g["kd"], rtol=1e-5)
+    np.testing.assert_allclose(out[2].item(), g["task"], rtol=1e-5)
+    np.testing.assert_allclose(gest.cpu().numpy(), g["gest"], rtol=2e-4, atol=1e-8)
+    np.testing.assert_allclose(sisdr.cpu().numpy(), -g["sdrqs"], atol=1e-3)   # SI-SDR: 1e-3 dB
+    # cfg-2 sized batch vs the oracle
+    x, s = O.synth_batch(8, 32000, seed=3)
+    e = (s + 0.3 * rnd(8, 2, 32000, seed=5, scale=0.05)).requires_grad_(True)
+    f = s + 0.2 * rnd(8, 2, 32000, seed=6, scale=0.05)
+    loss, kd, task, w_r, sdrs, sdrqs = O.kd_loss(e, f, s)
+    loss.backward()
+    out, w, sisdr, gest = K.kd_loss(e.detach().cuda(), f.cuda(), s.cuda(), 0.1)
+    np.testing.assert_allclose(out[0].item(), loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), w_r.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(sisdr.cpu().numpy(), -sdrqs.numpy(), atol=1e-3)
+    np.testing.assert_allclose(gest.cpu().numpy(), e.grad.numpy(), rtol=5e-4, atol=1e-9)
+
+
+def test_adam_clip_vs_torch():
+    n = 100003
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.05)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    acc = torch.zeros(1, device="cuda", dtype=torch.float64)
+    step = torch.zeros(1, device="cuda", dtype=torch.int32)
+    gn = torch.zeros(1, device="cuda")
+    for it in range(5):
+        gi = g * (1 + it)
+        pr.grad = gi.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        acc.zero_()
+        K.sumsq(gi.cuda(), acc)
+        K.adam_clip(p, gi.cuda(), m, v, acc, step, gn, 5.0, 1.0, 1e-3)
+        np.testing.assert_allclose(gn.item(), ref_norm.item(), rtol=1e-6)
+        np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert step.item() == 5
