@@ -18,7 +18,8 @@ _PROTOS = {
     "fqss_minmax": [P, I64, I64, I64, P, P],
     "fqss_wq_observe": [P, I64, I64, I64, P, P, P],
     "fqss_wq_fwd": [P, P, P, I64, I64, I64, P, P, P],
-    "fqss_wq_bwd": [P, P, P, P, P, I64, I64, I64, P, P, P],
+    "fqss_wq_bwd": [P, P, P, P, P, I64, I64, I64, P, P, I32, P],
+    "fqss_gacc_flush": [P, P, P, P, P],
     "fqss_pwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I64, I64, P],
@@ -27,7 +28,7 @@ _PROTOS = {
     "fqss_dwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_gn_fwd": [P, P, P, P, P, I32, I32, I32, I64, I64, F32, P, P],
     "fqss_gn_bwd": [P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P],
-    "fqss_axpby": [P, P, F32, P, I64, I64, I64, I64, I64, P],
+    "fqss_axpby": [P, P, F32, F32, P, I64, I64, I64, I64, I64, P],
     "fqss_mul_bcast_fwd": [P, P, P, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_mul_bcast_bwd": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, P],
     "fqss_splitter2": [P, P, I32, I64, P, P],
@@ -36,7 +37,7 @@ _PROTOS = {
     "fqss_frames_wgrad": [P, P, P, I32, I32, I32, I32, I64, I64, I32, I32, P],
     "fqss_kd_loss": [P, P, P, I32, I64, F32, P, P, P, P, P, P],
     "fqss_sumsq": [P, I64, P, P],
-    "fqss_adam_clip": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, F32, P, P, P],
+    "fqss_adam_clip": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, F32, P, P, P, P],
 }
 _RESTYPE = {"fqss_last_error": C.c_char_p}
 

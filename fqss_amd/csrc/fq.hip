@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void k_wq_fwd(const float* __restrict__ w, flo
 __global__ __launch_bounds__(256) void k_wq_bwd(const float* __restrict__ w, const float* __restrict__ g,
                                                  float* __restrict__ gw, float* gmin, float* gmax, int64_t outer,
                                                  int64_t C, int64_t inner, const float* __restrict__ qmin,
-                                                 const float* __restrict__ qmax) {
+                                                 const float* __restrict__ qmax, int accumulate) {
     __shared__ double red[4];
     const int64_t c = blockIdx.x;
     const float lo = qmin[c], hi = qmax[c];
@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void k_wq_bwd(const float* __restrict__ w, con
         const bool inr = (X >= -128.0f) && (X <= 127.0f);
         const float q = fminf(fmaxf(X, -128.0f), 127.0f);
         const float gk = g[k];
-        gw[k] = inr ? (gk * delta) / delta : 0.0f;
+        const float gwk = inr ? (gk * delta) / delta : 0.0f;
+        gw[k] = accumulate ? gw[k] + gwk : gwk;
         p += gk * (inr ? (q - u) : q);
     }
     double v[1] = {(double)p};
@@ -317,8 +318,20 @@ __global__ __launch_bounds__(256) void k_wq_bwd(const float* __restrict__ w, con
         const double wh = ah > al ? 1.0 : (al == ah ? 0.5 : 0.0);
         const double sl = lo > 0.0f ? 1.0 : (lo < 0.0f ? -1.0 : 0.0);
         const double sh = hi > 0.0f ? 1.0 : (hi < 0.0f ? -1.0 : 0.0);
-        gmin[c] = (float)(D * wl * sl);
-        gmax[c] = (float)(D * wh * sh);
+        const float dmin = (float)(D * wl * sl), dmax = (float)(D * wh * sh);
+        gmin[c] = accumulate ? gmin[c] + dmin : dmin;
+        gmax[c] = accumulate ? gmax[c] + dmax : dmax;
+    }
+}
+
+__global__ void k_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (gmin) *gmin += (float)gacc[0];
+        if (gmax) *gmax += (float)gacc[1];
+        if (gslope) *gslope += (float)gacc[2];
+        gacc[0] = 0.0;
+        gacc[1] = 0.0;
+        gacc[2] = 0.0;
     }
 }
 
@@ -427,10 +440,17 @@ extern "C" int fqss_wq_fwd(const float* w, float* wq, int8_t* idx, int64_t outer
     return launch_status("fqss_wq_fwd");
 }
 
+extern "C" int fqss_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope, fqss_stream_t stream) {
+    FQSS_REQUIRE(gacc, "null accumulator");
+    hipLaunchKernelGGL(k_gacc_flush, dim3(1), dim3(64), 0, (hipStream_t)stream, gacc, gmin, gmax, gslope);
+    return launch_status("fqss_gacc_flush");
+}
+
 extern "C" int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* gmax, int64_t outer,
-                           int64_t C, int64_t inner, const float* qmin, const float* qmax, fqss_stream_t stream) {
+                           int64_t C, int64_t inner, const float* qmin, const float* qmax, int accumulate,
+                           fqss_stream_t stream) {
     FQSS_REQUIRE(w && g && gw && gmin && gmax && qmin && qmax && outer > 0 && C > 0 && inner > 0, "bad args");
     hipLaunchKernelGGL(k_wq_bwd, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, w, g, gw, gmin, gmax, outer, C,
-                       inner, qmin, qmax);
+                       inner, qmin, qmax, accumulate);
     return launch_status("fqss_wq_bwd");
 }

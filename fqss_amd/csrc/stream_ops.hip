@@ -10,10 +10,10 @@
 namespace fqss {
 
 // =============================================================================================
-// z = a + sb*b          (sb = +1: AddQ, -1: ResidualErrorBlock's Y - Y_q; +-1 multiply is exact)
+// z = sa*a + sb*b       (sa=1, sb=+1: AddQ; sb=-1: ResidualErrorBlock's Y - Y_q; multiplies by +-1 / 2^k are exact)
 // =============================================================================================
 template <int VEC>
-__global__ __launch_bounds__(256) void k_axpby(const float* __restrict__ a, const float* __restrict__ b, float sb,
+__global__ __launch_bounds__(256) void k_axpby(const float* __restrict__ a, const float* __restrict__ b, float sa, float sb,
                                                 float* __restrict__ z, int64_t rows, int64_t cols, int64_t ld_a,
                                                 int64_t ld_b, int64_t ld_z) {
     const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
@@ -26,9 +26,9 @@ __global__ __launch_bounds__(256) void k_axpby(const float* __restrict__ a, cons
                 const float4 x = *reinterpret_cast<const float4*>(ar + c0);
                 const float4 y = *reinterpret_cast<const float4*>(br + c0);
                 *reinterpret_cast<float4*>(zr + c0) =
-                    make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w);
+                    make_float4(sa * x.x + sb * y.x, sa * x.y + sb * y.y, sa * x.z + sb * y.z, sa * x.w + sb * y.w);
             } else {
-                zr[c0] = ar[c0] + sb * br[c0];
+                zr[c0] = sa * ar[c0] + sb * br[c0];
             }
         }
     }
@@ -364,17 +364,17 @@ using namespace fqss;
 
 #define FQSS_VEC_OK2(p0, l0, p1, l1) (aligned16(p0) && aligned16(p1) && ((l0) % 4 == 0) && ((l1) % 4 == 0))
 
-extern "C" int fqss_axpby(const float* a, const float* b, float sb, float* z, int64_t rows, int64_t cols,
+extern "C" int fqss_axpby(const float* a, const float* b, float sa, float sb, float* z, int64_t rows, int64_t cols,
                           int64_t ld_a, int64_t ld_b, int64_t ld_z, fqss_stream_t stream) {
     FQSS_REQUIRE(a && b && z, "null tensor");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_a >= cols && ld_b >= cols && ld_z >= cols, "bad shape");
     if (rows == 0 || cols == 0) return FQSS_OK;
     const bool vec = FQSS_VEC_OK2(a, ld_a, b, ld_b) && aligned16(z) && ld_z % 4 == 0;
     if (vec)
-        hipLaunchKernelGGL(k_axpby<4>, grid_rows(rows, cols, 4), dim3(256), 0, (hipStream_t)stream, a, b, sb, z, rows,
+        hipLaunchKernelGGL(k_axpby<4>, grid_rows(rows, cols, 4), dim3(256), 0, (hipStream_t)stream, a, b, sa, sb, z, rows,
                            cols, ld_a, ld_b, ld_z);
     else
-        hipLaunchKernelGGL(k_axpby<1>, grid_rows(rows, cols, 1), dim3(256), 0, (hipStream_t)stream, a, b, sb, z, rows,
+        hipLaunchKernelGGL(k_axpby<1>, grid_rows(rows, cols, 1), dim3(256), 0, (hipStream_t)stream, a, b, sa, sb, z, rows,
                            cols, ld_a, ld_b, ld_z);
     return launch_status("fqss_axpby");
 }

@@ -182,21 +182,32 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int6
 
 // torch.optim.Adam single-tensor math (amsgrad=False, weight_decay=0, maximize=False):
 //   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
+// torch keeps `t` PER PARAMETER and starts it when the parameter first receives a gradient (weights:
+// step 1, weight ranges: step 2, activation ranges: step 51, never-used parameters: never touched).
+// t0[i] = number of global steps that passed before element i became active (INT_MAX: inactive).
 __global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                     const double* sumsq, float max_norm, float grad_scale, float lr,
-                                                    float beta1, float beta2, float eps, const int32_t* step_t) {
-    const int t = *step_t + 1;
+                                                    float beta1, float beta2, float eps, const int32_t* step_t,
+                                                    const int32_t* __restrict__ t0) {
+    const int tg = *step_t + 1;
     const double norm = sqrt(*sumsq) * (double)grad_scale;
     double coef = (double)max_norm / (norm + 1e-6);   // torch.nn.utils.clip_grad_norm_
     if (coef > 1.0) coef = 1.0;
     if (max_norm <= 0.0f) coef = 1.0;
     const float gs = (float)((double)grad_scale * coef);
-    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
     const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+    int cached = -1;
+    float step_size = 0.0f, bc2_sqrt = 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int t = tg - (t0 ? t0[i] : 0);
+        if (t <= 0) continue;  // parameter has never had a gradient: torch.optim skips it
+        if (t != cached) {
+            const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+            step_size = (float)((double)lr / bc1);
+            bc2_sqrt = (float)sqrt(bc2);
+            cached = t;
+        }
         const float gi = g[i] * gs;
         const float mi = m[i] + omb1 * (gi - m[i]);
         const float vi = v[i] * beta2 + (omb2 * gi) * gi;   // addcmul: self + value*t1*t2
@@ -249,14 +260,14 @@ extern "C" int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_
 
 extern "C" int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
                               float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
-                              int32_t* step_t, float* gnorm_out, fqss_stream_t stream) {
+                              int32_t* step_t, const int32_t* t0, float* gnorm_out, fqss_stream_t stream) {
     FQSS_REQUIRE(p && g && m && v && sumsq && step_t && n >= 0, "bad args");
     hipStream_t s = (hipStream_t)stream;
     if (n > 0) {
         int64_t nb = cdiv(n, 256 * 4);
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(k_adam_clip, dim3((unsigned)nb), dim3(256), 0, s, p, g, m, v, n, sumsq, max_norm, grad_scale,
-                           lr, beta1, beta2, eps, step_t);
+                           lr, beta1, beta2, eps, step_t, t0);
     }
     hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, s, step_t, sumsq, grad_scale, gnorm_out);
     return launch_status("fqss_adam_clip");

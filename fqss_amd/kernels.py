@@ -134,15 +134,22 @@ def wq_fwd(w, axis, qmin, qmax, want_idx=False):
     return (wq, idx) if want_idx else wq
 
 
-def wq_bwd(w, g, axis, qmin, qmax):
+def wq_bwd(w, g, axis, qmin, qmax, out=None):
+    """out=None: fresh (gw, gmin, gmax); out=(gw, gmin, gmax): accumulate (+=) into the given buffers"""
     _need_gpu(w, g, qmin, qmax)
     w, g = w.contiguous(), g.contiguous()
     o, c, i = _w_layout(w.shape, axis)
-    gw = torch.empty_like(w)
-    gmin = torch.empty_like(qmin)
-    gmax = torch.empty_like(qmax)
-    _lib.call("fqss_wq_bwd", _p(w), _p(g), _p(gw), _p(gmin), _p(gmax), o, c, i, _p(qmin), _p(qmax), _stream())
+    if out is None:
+        gw, gmin, gmax, acc = torch.empty_like(w), torch.empty_like(qmin), torch.empty_like(qmax), 0
+    else:
+        (gw, gmin, gmax), acc = out, 1
+        assert gw.is_contiguous() and gmin.is_contiguous() and gmax.is_contiguous()
+    _lib.call("fqss_wq_bwd", _p(w), _p(g), _p(gw), _p(gmin), _p(gmax), o, c, i, _p(qmin), _p(qmax), acc, _stream())
     return gw, gmin, gmax
+
+
+def gacc_flush(gacc, gmin, gmax, gslope):
+    _lib.call("fqss_gacc_flush", _p(gacc), _p(gmin), _p(gmax), _p(gslope), _stream())
 
 
 # ------------------------------------------------------------------ K4 / K5  pointwise conv
@@ -231,13 +238,14 @@ def gn_bwd(gz, x, gamma, mean_rstd, ggamma, gbeta):
 
 
 # ------------------------------------------------------------------ K8 / K9 / K14
-def axpby(a, b, sb):
+def axpby(a, b, sb, sa=1.0):
+    """z = sa*a + sb*b"""
     _need_gpu(a, b)
     assert a.shape == b.shape
     a, rows, cols, ld_a = as_rowmat(a)
     b, _, _, ld_b = as_rowmat(b)
     z = empty_act(tuple(a.shape), a.device)
-    _lib.call("fqss_axpby", _p(a), _p(b), float(sb), _p(z), rows, cols, ld_a, ld_b, rowmat(z)[2], _stream())
+    _lib.call("fqss_axpby", _p(a), _p(b), float(sa), float(sb), _p(z), rows, cols, ld_a, ld_b, rowmat(z)[2], _stream())
     return z
 
 
@@ -334,6 +342,8 @@ def sumsq(g, acc):
     _lib.call("fqss_sumsq", _p(g), g.numel(), _p(acc), _stream())
 
 
-def adam_clip(p, g, m, v, sumsq_acc, step_t, gnorm_out, max_norm, grad_scale, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_clip(p, g, m, v, sumsq_acc, step_t, gnorm_out, max_norm, grad_scale, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+              t0=None):
     _lib.call("fqss_adam_clip", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_acc), float(max_norm),
-              float(grad_scale), float(lr), float(beta1), float(beta2), float(eps), _p(step_t), _p(gnorm_out), _stream())
+              float(grad_scale), float(lr), float(beta1), float(beta2), float(eps), _p(step_t), _p(t0), _p(gnorm_out),
+              _stream())

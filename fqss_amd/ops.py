@@ -1,0 +1,301 @@
+"""Autograd glue between the `quantization.qat` module API and the HIP kernels (fqss_amd/kernels.py).
+
+One ``torch.autograd.Function`` per LayerQ-granularity op: forward = linear kernel + act/fake-quant
+epilogue kernel, backward = STE/range-gradient kernel + input/weight gradient kernels.  No tensor
+arithmetic is done with ATen here; torch is used for memory, streams and the autograd graph only.
+
+Parameter gradients: when a parameter carries ``_fqss_direct = True`` and a pre-allocated ``.grad``
+(see fqss_amd.runtime.ParamArena) the kernels accumulate ("+=") straight into it and the Function
+returns ``None`` for that input; otherwise a fresh zero buffer is filled and returned to autograd.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+Q_BYPASS, Q_OBSERVE, Q_QUANT = K.Q_BYPASS, K.Q_OBSERVE, K.Q_QUANT
+ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
+
+
+class QCtx:
+    """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner")
+
+    def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
+        self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
+
+
+BYPASS = QCtx()
+
+
+def _grad_buf(param, like):
+    """(buffer, direct): direct -> accumulate in place into param.grad and return None to autograd"""
+    if param is not None:
+        param._fqss_touched = True      # the arena starts this parameter's Adam step count (torch: grad is not None)
+        if getattr(param, "_fqss_direct", False) and param.grad is not None:
+            return param.grad, True
+    return torch.zeros_like(like), False
+
+
+def _epilogue_fwd(z, act, slope, q):
+    return K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws)
+
+
+def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=None, C=0):
+    """returns gz and the autograd gradients (g_slope, g_qmin, g_qmax, g_bias)"""
+    need_acc = (q.qmode == Q_QUANT) or (act == ACT_PRELU)
+    gacc = None
+    if need_acc:
+        gacc = q.gacc if q.gacc is not None else torch.zeros(3, dtype=torch.float64, device=z.device)
+    gb, gb_direct = (None, True)
+    if bias_like is not None:
+        gb, gb_direct = _grad_buf(bias_param, bias_like)
+    gz = K.actq_bwd(z, g, act, slope, q.qmode, q.qmin, q.qmax, gacc, gbias=gb, C=C)
+    g_slope = g_min = g_max = None
+    if need_acc:
+        s_buf = mn_buf = mx_buf = None
+        s_direct = mn_direct = mx_direct = True
+        if act == ACT_PRELU:
+            s_buf, s_direct = _grad_buf(slope_param, slope)
+        if q.qmode == Q_QUANT:
+            mn_buf, mn_direct = _grad_buf(q.owner.min_range if q.owner is not None else None, q.qmin)
+            mx_buf, mx_direct = _grad_buf(q.owner.max_range if q.owner is not None else None, q.qmax)
+        K.gacc_flush(gacc, mn_buf, mx_buf, s_buf)
+        g_slope = None if s_direct else s_buf
+        g_min = None if mn_direct else mn_buf
+        g_max = None if mx_direct else mx_buf
+    return gz, g_slope, g_min, g_max, (None if gb_direct else gb)
+
+
+def _plain_or_bwd(z, g, q):
+    """float (BYPASS) producers have no epilogue: the gradient passes through untouched"""
+    if q.qmode == Q_BYPASS:
+        return g, None, None, None, None
+    return _epilogue_bwd(z, g, ACT_NONE, None, None, q)
+
+
+# ----------------------------------------------------------------------------------------------
+# linear kinds
+# ----------------------------------------------------------------------------------------------
+class _Lin:
+    """geometry of the linear op in front of the epilogue"""
+    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param")
+
+    def __init__(self, kind, stride=1, dil=1, pad=0, w_param=None, b_param=None, slope_param=None):
+        self.kind, self.stride, self.dil, self.pad = kind, stride, dil, pad
+        self.w_param, self.b_param, self.slope_param = w_param, b_param, slope_param
+
+
+def _lin_fwd(L, x, w, bias):
+    if L.kind == "pw":
+        return K.pwconv_fwd(x, w, bias)
+    if L.kind == "dw":
+        return K.dwconv_fwd(x, w, bias, L.dil, L.pad)
+    if L.kind == "frames":       # strided framing conv (encoder), no bias in the networks served
+        assert bias is None
+        return K.frames_conv_fwd(x, w, L.stride)
+    if L.kind == "convtr":       # transposed conv + overlap-add (decoder), Co = 1
+        assert bias is None and w.shape[1] == 1
+        return K.ola_convtr_fwd(x, w, L.stride)
+    raise NotImplementedError(L.kind)
+
+
+def _lin_bwd_x(L, gz, w, x_shape):
+    if L.kind == "pw":
+        return K.pwconv_bwd_x(gz, w, x_shape[1])
+    if L.kind == "dw":
+        return K.dwconv_bwd_x(gz, w, L.dil, L.pad)
+    if L.kind == "frames":
+        # transposed conv of gz, one input channel at a time (Ci = 1 on the training path: the residual
+        # encoder; the waveform-side encoder input never needs a gradient)
+        parts = [K.ola_convtr_fwd(gz, w[:, ci, :].contiguous(), L.stride) for ci in range(x_shape[1])]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    if L.kind == "convtr":
+        return K.frames_conv_fwd(gz, w.reshape(w.shape[0], 1, w.shape[2]), L.stride)
+    raise NotImplementedError(L.kind)
+
+
+def _lin_bwd_w(L, gz, x, gw):
+    if L.kind == "pw":
+        K.pwconv_bwd_w(gz, x, gw)
+    elif L.kind == "dw":
+        K.dwconv_bwd_w(gz, x, gw, L.dil, L.pad)
+    elif L.kind == "frames":
+        K.frames_wgrad(gz, x, gw, L.stride)
+    elif L.kind == "convtr":
+        K.frames_wgrad(x, gz, gw, L.stride)
+    else:
+        raise NotImplementedError(L.kind)
+
+
+class LinearActQ(Function):
+    """out = fq(act(linear(x, w) + bias))  -- Conv1dQ / Conv1dNlQ / Conv1dEncoderQ / decoder convT"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope, qmin, qmax, L, act, q):
+        z = _lin_fwd(L, x, w, bias)
+        ctx.plain = (q.qmode == Q_BYPASS and act == ACT_NONE)   # float linear op: no epilogue pass at all
+        out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
+        ctx.save_for_backward(x, w, None if ctx.plain else z, slope)
+        ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
+        ctx.bias_like = bias
+        ctx.C = z.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, z, slope = ctx.saved_tensors
+        L, act, q = ctx.L, ctx.act, ctx.q
+        if ctx.plain and not ctx.has_bias:
+            gz, g_slope, g_min, g_max, g_bias = g, None, None, None, None
+        else:
+            gz, g_slope, g_min, g_max, g_bias = _epilogue_bwd(
+                g if ctx.plain else z, g, act, slope, L.slope_param, q, bias_param=L.b_param,
+                bias_like=ctx.bias_like if ctx.has_bias else None, C=ctx.C)
+        gx = _lin_bwd_x(L, gz, w, x.shape) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            # w here is the fake-quantized weight (a non-leaf): its gradient always goes back through autograd
+            gw = torch.zeros_like(w)
+            _lin_bwd_w(L, gz, x, gw)
+            if L.w_param is not None and w is L.w_param:
+                L.w_param._fqss_touched = True
+        return gx, gw, g_bias, g_slope, g_min, g_max, None, None, None
+
+
+class GroupNormActQ(Function):
+    """out = fq(GroupNorm(1, C)(x))  -- GroupNormQ"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, qmin, qmax, eps, q, gamma_param, beta_param):
+        z, mean_rstd = K.gn_fwd(x, gamma, beta, eps)
+        plain = q.qmode == Q_BYPASS
+        out = z if plain else _epilogue_fwd(z, ACT_NONE, None, q)
+        ctx.save_for_backward(x, gamma, None if plain else z, mean_rstd)
+        ctx.q, ctx.gp, ctx.bp = q, gamma_param, beta_param
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, z, mean_rstd = ctx.saved_tensors
+        q = ctx.q
+        gz, _, g_min, g_max, _ = _plain_or_bwd(z, g, q)
+        gg, gg_direct = _grad_buf(ctx.gp, gamma)
+        gb, gb_direct = _grad_buf(ctx.bp, gamma)
+        gx = K.gn_bwd(gz, x, gamma, mean_rstd, gg, gb)
+        return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None
+
+
+class AddActQ(Function):
+    """out = fq(a + sign*b)  -- AddQ (sign=+1), ResidualErrorBlock's Y - Y_q (sign=-1)"""
+
+    @staticmethod
+    def forward(ctx, a, b, qmin, qmax, sign, q):
+        z = K.axpby(a, b, sign)
+        plain = q.qmode == Q_BYPASS
+        out = z if plain else _epilogue_fwd(z, ACT_NONE, None, q)
+        ctx.save_for_backward(None if plain else z)
+        ctx.q, ctx.sign = q, sign
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        gz, _, g_min, g_max, _ = _plain_or_bwd(z, g, ctx.q)
+        ga = gz if ctx.needs_input_grad[0] else None
+        gb = None
+        if ctx.needs_input_grad[1]:
+            gb = gz if ctx.sign == 1.0 else K.axpby(gz, gz, 0.0, sa=float(ctx.sign))
+        return ga, gb, g_min, g_max, None, None
+
+
+class MulActQ(Function):
+    """out = fq(mask[B,S,C,M] * feat[B,1,C,M])  -- MulQ of ConvTasNetQ.forward"""
+
+    @staticmethod
+    def forward(ctx, mask, feat, qmin, qmax, q):
+        z = K.mul_bcast_fwd(mask, feat)
+        plain = q.qmode == Q_BYPASS
+        out = z if plain else _epilogue_fwd(z, ACT_NONE, None, q)
+        ctx.save_for_backward(mask, feat, None if plain else z)
+        ctx.q = q
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, feat, z = ctx.saved_tensors
+        gz, _, g_min, g_max, _ = _plain_or_bwd(z, g, ctx.q)
+        gmask, gfeat = K.mul_bcast_bwd(gz, mask, feat)
+        return gmask, gfeat, g_min, g_max, None
+
+
+class NlActQ(Function):
+    """out = fq(act(x))  -- NlQ, and the bare GradientActivationFakeQuantize module (act = NONE)"""
+
+    @staticmethod
+    def forward(ctx, x, slope, qmin, qmax, act, q, slope_param):
+        out = _epilogue_fwd(x, act, slope, q)
+        ctx.save_for_backward(x, slope)
+        ctx.act, ctx.q, ctx.sp = act, q, slope_param
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, slope = ctx.saved_tensors
+        gz, g_slope, g_min, g_max, _ = _epilogue_bwd(x, g, ctx.act, slope, ctx.sp, ctx.q)
+        return gz, g_slope, g_min, g_max, None, None, None
+
+
+class WeightFq(Function):
+    """w_q = per-channel symmetric fake-quant of w  -- GradientWeightFakeQuantize (quantizing call)"""
+
+    @staticmethod
+    def forward(ctx, w, qmin, qmax, axis, owner, w_param):
+        wq = K.wq_fwd(w, axis, qmin, qmax)
+        ctx.save_for_backward(w, qmin, qmax)
+        ctx.axis, ctx.owner, ctx.w_param = axis, owner, w_param
+        return wq
+
+    @staticmethod
+    def backward(ctx, g):
+        w, qmin, qmax = ctx.saved_tensors
+        gw, d0 = _grad_buf(ctx.w_param, w)
+        gmn, d1 = _grad_buf(ctx.owner.min_range if ctx.owner is not None else None, qmin)
+        gmx, d2 = _grad_buf(ctx.owner.max_range if ctx.owner is not None else None, qmax)
+        K.wq_bwd(w, g, ctx.axis, qmin, qmax, out=(gw, gmn, gmx))
+        return (None if d0 else gw), (None if d1 else gmn), (None if d2 else gmx), None, None, None
+
+
+class Combine2(Function):
+    """y = x0 + x1 * 2^-8  -- process.postprocess with n_combiner = 2"""
+
+    @staticmethod
+    def forward(ctx, x0, x1):
+        return K.axpby(x0, x1, 0.00390625)
+
+    @staticmethod
+    def backward(ctx, g):
+        g1 = K.axpby(g, g, 0.0, sa=0.00390625) if ctx.needs_input_grad[1] else None
+        return g, g1
+
+
+def splitter2(x):
+    with torch.no_grad():
+        return K.splitter2(x)
+
+
+class KDLoss(Function):
+    """loss = -10 log10((1-l)*task + l*kd + eps) with SDR-weighted KD and 2-speaker PIT
+    (mysystem.py:124-151); forward and backward come out of ONE kernel sequence."""
+
+    @staticmethod
+    def forward(ctx, est, fest, tgt, kd_lambda):
+        out, w, sisdr, gest = K.kd_loss(est, fest, tgt, kd_lambda, want_grad=True)
+        ctx.save_for_backward(gest)
+        ctx.mark_non_differentiable(w, sisdr)
+        return out[0], out[1].detach(), w, sisdr
+
+    @staticmethod
+    def backward(ctx, g_loss, g_kd, g_w, g_s):
+        (gest,) = ctx.saved_tensors
+        return gest * g_loss, None, None, None

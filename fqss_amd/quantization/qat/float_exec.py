@@ -1,0 +1,41 @@
+"""Runs plain float nn modules (the un-quantized student before `quantize_model`, and the frozen
+teacher of the KD step) on the SAME HIP kernels as their LayerQ counterparts, in BYPASS mode.
+The reference relies on ATen for these (`nn.Conv1d.forward` ...); here no ATen compute op is on
+the hot path, so the module containers dispatch through this file instead."""
+import torch.nn as nn
+
+from . import qat_layers as QL
+
+
+def apply_module(m, x):
+    if isinstance(m, (QL.LayerQ, HipSequential)):
+        return m(x)
+    if isinstance(m, nn.Identity):
+        return x
+    if isinstance(m, nn.Conv1d):
+        return QL.run_conv1d(m, x, m.weight, None, None)
+    if isinstance(m, nn.ConvTranspose1d):
+        return QL.run_convtr1d(m, x, m.weight, None)
+    if isinstance(m, nn.GroupNorm):
+        return QL.run_groupnorm(m, x, None)
+    if isinstance(m, (nn.PReLU, nn.ReLU)):
+        return QL.run_nl(m, x, None)
+    raise NotImplementedError(f"{type(m).__name__} has no HIP kernel on the float path")
+
+
+class HipSequential(nn.Sequential):
+    """nn.Sequential (same state_dict keys) whose float members execute on the HIP kernels;
+    a Conv1d followed by PReLU/ReLU runs as one fused launch pair."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv1d) and i + 1 < len(mods) and isinstance(mods[i + 1], (nn.PReLU, nn.ReLU)):
+                x = QL.run_conv1d(m, x, m.weight, mods[i + 1], None)
+                i += 2
+                continue
+            x = apply_module(m, x)
+            i += 1
+        return x

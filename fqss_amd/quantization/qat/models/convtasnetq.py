@@ -1,0 +1,148 @@
+"""Conv-TasNet (non-causal) ready for W8A8 fake-quantization, MI355X edition.
+
+Same module tree / attribute names / constructor arguments / `quantize_model` path table as the
+reference's quantization/qat/models/convtasnetq.py (ConvBlock :11-42, MaskGenerator :45-115,
+ConvTasNetQ :118-288), so float and quantized `state_dict`s interchange key for key (948 keys at
+the shipped size).  Every op -- float or quantized -- executes as a HIP kernel (no ATen compute).
+"""
+import torch
+import torch.nn as nn
+
+from ....process import postprocess, preprocess
+from ..float_exec import HipSequential, apply_module
+from ..qat_layers import Add, Mul
+from ..qat_utils import quantize_modules, replace_decoderq, replace_encoderq
+
+EPS = 1e-8
+
+
+class ConvBlock(nn.Module):
+    """1x1 conv + PReLU + gLN + depthwise dilated conv + PReLU + gLN, then residual and skip 1x1 convs."""
+
+    def __init__(self, io_channels, hidden_channels, kernel_size, padding, dilation=1):
+        super().__init__()
+        self.shared_block = HipSequential(
+            nn.Conv1d(io_channels, hidden_channels, 1),
+            nn.PReLU(),
+            nn.GroupNorm(1, hidden_channels, eps=EPS),
+            nn.Conv1d(hidden_channels, hidden_channels, kernel_size, padding=padding, dilation=dilation,
+                      groups=hidden_channels),
+            nn.PReLU(),
+            nn.GroupNorm(1, hidden_channels, eps=EPS),
+        )
+        self.res_conv = nn.Conv1d(hidden_channels, io_channels, 1)
+        self.skip_conv = nn.Conv1d(hidden_channels, io_channels, 1)
+        self.add = Add()
+
+    def forward(self, x):
+        feature = self.shared_block(x)
+        residual = apply_module(self.res_conv, feature)
+        skip_out = apply_module(self.skip_conv, feature)
+        return self.add(x, residual), skip_out
+
+
+class MaskGenerator(nn.Module):
+    """TCN separation module: bottleneck, num_stacks x num_layers ConvBlocks with dilation 2**layer,
+    skip-sum, PReLU + 1x1 conv + mask activation."""
+
+    def __init__(self, input_dim, n_srcs, kernel_size, num_feats, num_hidden, num_layers, num_stacks, msk_activate):
+        super().__init__()
+        self.input_dim = input_dim
+        self.n_srcs = n_srcs
+        self.bottleneck = HipSequential(nn.GroupNorm(1, input_dim, eps=EPS), nn.Conv1d(input_dim, num_feats, 1))
+        self.receptive_field = 0
+        self.TCN = nn.ModuleList([])
+        for s in range(num_stacks):
+            for layer in range(num_layers):
+                d = 2 ** layer
+                self.TCN.append(ConvBlock(num_feats, num_hidden, kernel_size, dilation=d, padding=d))
+                self.receptive_field += kernel_size if s == 0 and layer == 0 else (kernel_size - 1) * d
+        self.adds = nn.ModuleList([Add() for _ in range(len(self.TCN) - 1)])
+        if msk_activate == "sigmoid":
+            act = nn.Sigmoid()
+        elif msk_activate == "relu":
+            act = nn.ReLU()
+        else:
+            raise ValueError(f"Unsupported activation {msk_activate}")
+        self.mask_net = HipSequential(nn.PReLU(), nn.Conv1d(num_feats, input_dim * n_srcs, 1), act)
+
+    def forward(self, x):
+        batch = x.shape[0]
+        feats = self.bottleneck(x)
+        feats, output = self.TCN[0](feats)
+        for i, layer in enumerate(self.TCN[1:]):
+            feats, skip = layer(feats)
+            output = self.adds[i](output, skip)
+        output = self.mask_net(output)
+        return output.reshape(batch, self.n_srcs, self.input_dim, -1)
+
+
+class ConvTasNetQ(nn.Module):
+    def __init__(self, n_spks=1, kernel_size=32, stride=16, n_filters=512, mask_kernel_size=3, bn_chan=128,
+                 hid_chan=512, n_blocks=8, n_repeats=3, mask_act="relu"):
+        super().__init__()
+        self.n_srcs = n_spks
+        self.enc_num_feats = n_filters
+        self.set_splitter_combiner(1, 1)
+        self.encoder = nn.Conv1d(1, n_filters, kernel_size, stride=stride, padding=0, bias=False)
+        self.masker = MaskGenerator(input_dim=n_filters, n_srcs=n_spks, kernel_size=mask_kernel_size, num_feats=bn_chan,
+                                    num_hidden=hid_chan, num_layers=n_blocks, num_stacks=n_repeats, msk_activate=mask_act)
+        self.decoder = nn.ConvTranspose1d(n_filters, 1, kernel_size, stride=stride, padding=0, bias=False)
+        self.mul = Mul()
+
+    def pre_process(self, x):
+        return preprocess(x, n_splitter=self.n_splitter)
+
+    def post_process(self, x):
+        return postprocess(x, n_combiner=self.n_combiner)
+
+    def forward(self, x):
+        """x [B, 1, L] (or [B, L]) -> separated sources [B, S, L']"""
+        x = self.pre_process(x)
+        batch = x.shape[0]
+        feats = apply_module(self.encoder, x)                                  # [B, F, M]
+        masked = self.mul(self.masker(feats), feats.unsqueeze(1))              # [B, S, F, M]
+        masked = torch.reshape(masked, (batch * self.n_srcs, self.enc_num_feats, -1))
+        out = apply_module(self.decoder, masked)                               # [D, B*S, 1, L] or [B*S, 1, L]
+        out = out.reshape((self.n_combiner, batch, self.n_srcs, 1, -1))
+        return self.post_process(out)
+
+    def load_pretrain(self, weights_path):
+        """order-based key mapping of a checkpoint with the same number of entries (reference :225-237)"""
+        own = self.state_dict()
+        loaded = torch.load(weights_path, map_location="cpu")
+        loaded = loaded.get("state_dict", loaded)
+        loaded = {k: v for k, v in loaded.items() if not k.startswith("fmodel.")}
+        assert len(own) == len(loaded), ("Error: mismatch models weights. Please check if the model configurations "
+                                         "match to model weights!")
+        self.load_state_dict({nk: v for nk, v in zip(own.keys(), loaded.values())}, strict=True)
+
+    def set_splitter_combiner(self, n_splitter, n_combiner):
+        self.n_splitter = n_splitter
+        self.n_combiner = n_combiner
+
+    def quantize_model(self, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True, act_n_bits=8,
+                       inout_nl_quant=False, in_quant=False, in_act_n_bits=8, out_quant=True, out_act_n_bits=8):
+        p = {"gradient_based": gradient_based, "act_quant": act_quant, "weight_quant": weight_quant,
+             "weight_n_bits": weight_n_bits, "act_n_bits": act_n_bits}
+        io = {"gradient_based": gradient_based, "act_quant": act_quant, "inout_nl_quant": inout_nl_quant,
+              "weight_quant": weight_quant, "weight_n_bits": weight_n_bits}
+        for _, m in list(self.named_modules()):
+            if type(m) is ConvTasNetQ:
+                replace_encoderq(m, ["encoder"], dict(io, n_splitter=self.n_splitter, act_n_bits=act_n_bits,
+                                                      in_quant=in_quant, in_act_n_bits=in_act_n_bits))
+                replace_decoderq(m, ["decoder"], dict(io, n_combiner=self.n_combiner, act_n_bits=out_act_n_bits,
+                                                      out_quant=out_quant, out_act_n_bits=out_act_n_bits))
+                quantize_modules(m, ["mul"], p)
+            elif type(m) is ConvBlock:
+                for group in (["0", "1"], ["2"], ["3", "4"], ["5"]):
+                    quantize_modules(m.shared_block, group, p)
+                for name in ("res_conv", "skip_conv", "add"):
+                    quantize_modules(m, [name], p)
+            elif type(m) is MaskGenerator:
+                for group in (["0"], ["1"]):
+                    quantize_modules(m.bottleneck, group, p)
+                quantize_modules(m.mask_net, ["0"], p)
+                quantize_modules(m.mask_net, ["1", "2"], p)
+                for i in range(len(m.adds)):
+                    quantize_modules(m.adds, [str(i)], p)

@@ -1,0 +1,139 @@
+"""Learned-range fake-quantizers of FQSS on MI355X.
+
+Same public names, constructor signatures, parameter names/shapes (=> same state_dict keys) and
+host-side state (`n_iter`, `observer_mode`, `max_observations`, `alpha`) as the reference's
+quantization/qat/qat_quant.py; the arithmetic runs in the HIP kernels of csrc/fq.hip:
+
+  linear_quantize                    qat_quant.py:125-147  -> fqss_actq_fwd/bwd, fqss_wq_fwd/bwd
+  GradientActivationFakeQuantize     qat_quant.py:206-242  -> observer: fqss_actq_fwd(OBSERVE)+fqss_observer_ema
+  GradientWeightFakeQuantize         qat_quant.py:350-381  -> fqss_wq_observe / fqss_wq_fwd / fqss_wq_bwd
+
+Deliberate differences (documented in DESIGN.md):
+  * no host syncs: the reference does `.item()` + `assert max >= min` on every training forward
+    (qat_quant.py:235-238); here nothing reads device memory from the host.
+  * 8-bit only (every shipped config); other widths raise NotImplementedError.
+"""
+import torch
+import torch.nn as nn
+
+from ... import kernels as K
+from ... import ops
+
+
+def _check_bits(n_bits):
+    if n_bits != 8:
+        raise NotImplementedError("fqss_amd kernels implement the 8-bit quantizers of the shipped FQSS configs")
+
+
+def linear_quantize(x, min_range, max_range, n_bits, sign=True, sym=False, scale_grad=False):
+    """Functional form (differentiable w.r.t. x, min_range, max_range) on device tensors."""
+    _check_bits(n_bits)
+    if scale_grad:
+        raise NotImplementedError("scale_grad=True is not used by any FQSS config")
+    if sym:
+        shape = tuple(min_range.shape)
+        axis = next((i for i, s in enumerate(shape) if s != 1), 0)
+        return ops.WeightFq.apply(x, min_range, max_range, axis, None, None)
+    q = ops.QCtx(ops.Q_QUANT, min_range, max_range, None, None, None)
+    return ops.NlActQ.apply(x, None, min_range, max_range, ops.ACT_NONE, q, None)
+
+
+class GradientActivationFakeQuantize(nn.Module):
+    """Per-tensor asymmetric activation quantizer with a 50-call EMA observer, then learned ranges."""
+
+    def __init__(self, gradient_based, n_bits=8, sym=False, scale_grad=False):
+        super().__init__()
+        _check_bits(n_bits)
+        if sym or scale_grad:
+            raise NotImplementedError("sym/scale_grad activation quantizers are not reachable from the FQSS configs")
+        self.n_bits = n_bits
+        self.sym = sym
+        self.min_range = nn.Parameter(torch.tensor([-0.5]), requires_grad=gradient_based)
+        self.max_range = nn.Parameter(torch.tensor([0.5]), requires_grad=gradient_based)
+        self.max_observations = 50
+        self.observer_mode = True
+        self.alpha = 0.9
+        self.n_iter = 0
+        self.sign = True
+        self.scale_grad = scale_grad
+        # device scratch: not part of the state_dict (persistent=False keeps the reference's key set)
+        self.register_buffer("_obs_ws", torch.tensor([-1, 0], dtype=torch.int32), persistent=False)
+        self.register_buffer("_gacc", torch.zeros(3, dtype=torch.float64), persistent=False)
+
+    def enable_observer(self, observer_mode):
+        self.observer_mode = observer_mode
+
+    # -- fused entry points used by the LayerQ modules ---------------------------------------
+    def next_mode(self):
+        """advance the host-side observer counter exactly like qat_quant.py:228-229"""
+        if self.observer_mode and self.n_iter < self.max_observations:
+            self.n_iter += 1
+            return ops.Q_OBSERVE
+        return ops.Q_QUANT
+
+    def qctx(self):
+        return ops.QCtx(self.next_mode(), self.min_range, self.max_range, self._obs_ws, self._gacc, self)
+
+    def after_forward(self, q):
+        if q.qmode == ops.Q_OBSERVE:
+            K.observer_ema(self.min_range.data, self.max_range.data, self._obs_ws, self.alpha)
+
+    def forward(self, x):
+        q = self.qctx()
+        y = ops.NlActQ.apply(x, None, self.min_range, self.max_range, ops.ACT_NONE, q, None)
+        self.after_forward(q)
+        return y
+
+
+class GradientWeightFakeQuantize(nn.Module):
+    """Per-output-channel symmetric weight quantizer; the first call only records amax/amin."""
+
+    def __init__(self, gradient_based, weight_shape, n_bits=8, sym=True, ch_out_idx=0, scale_grad=False):
+        super().__init__()
+        _check_bits(n_bits)
+        if not sym or scale_grad:
+            raise NotImplementedError("asymmetric/scale_grad weight quantizers are not reachable from the FQSS configs")
+        self.n_bits = n_bits
+        self.sym = sym
+        self.axis = ch_out_idx
+        init_shape = [1] * len(weight_shape)
+        init_shape[ch_out_idx] = weight_shape[ch_out_idx]
+        self.min_range = nn.Parameter(-0.5 * torch.ones(init_shape), requires_grad=gradient_based)
+        self.max_range = nn.Parameter(0.5 * torch.ones(init_shape), requires_grad=gradient_based)
+        self.observer_mode = True
+        self.sign = True
+        self.scale_grad = scale_grad
+
+    def enable_observer(self, observer_mode):
+        self.observer_mode = observer_mode
+
+    def forward(self, x, w_param=None):
+        if self.observer_mode:
+            K.wq_observe(x.detach(), self.axis, self.min_range.data, self.max_range.data)
+            self.observer_mode = False
+            return x
+        return ops.WeightFq.apply(x, self.min_range, self.max_range, self.axis, self, w_param if w_param is not None else x)
+
+
+class _BypassQuantizer(nn.Identity):
+    """act_quant / weight_quant = False (the reference installs nn.Identity, qat_layers.py:56-57)"""
+
+    def qctx(self):
+        return ops.BYPASS
+
+    def after_forward(self, q):
+        pass
+
+
+def get_activation_quantizer(gradient_based=True, nl=False, n_bits=8):
+    if nl:
+        raise NotImplementedError("mu-law (inout_nl_quant) quantizer: unreachable from the FQSS configs (load_model.py:61)")
+    return GradientActivationFakeQuantize(gradient_based, n_bits=n_bits)
+
+
+def get_weight_quantizer(gradient_based=True, weight_shape=(1, 1, 1), n_bits=8, ch_out_idx=0):
+    return GradientWeightFakeQuantize(gradient_based, weight_shape, n_bits=n_bits, ch_out_idx=ch_out_idx)
+
+
+def get_dym_activation_quantizer(n_bits=8, factor=0.99):
+    raise NotImplementedError("dynamic activation quantizer: no call site in the FQSS training path")

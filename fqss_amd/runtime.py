@@ -1,0 +1,96 @@
+"""Step runtime: flat parameter arena, fused clip+Adam, and the KD training step.
+
+MI355X-first choices:
+  * ONE flat fp32 buffer each for parameters, gradients and the two Adam moments: kernels accumulate
+    parameter gradients straight into the flat gradient buffer (no per-parameter AccumulateGrad
+    kernels), the optimizer is two launches over the whole model, and data-parallel training
+    all-reduces that one buffer over RCCL/xGMI.
+  * nothing on the step reads device memory from the host (the reference syncs ~400x per forward,
+    qat_quant.py:235-238), so the whole step can be captured in a hipGraph.
+"""
+import torch
+
+from . import kernels as K
+
+
+class ParamArena:
+    def __init__(self, params, align=64):
+        params = [p for p in params if p.requires_grad]
+        assert params, "no trainable parameters"
+        dev = params[0].device
+        assert dev.type == "cuda", "ParamArena needs ROCm device parameters"
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + align - 1) // align * align
+        self.params, self.offsets, self.numel = params, offs, n
+        self.flat_p = torch.zeros(n, device=dev)
+        self.flat_g = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self.step_t = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.gnorm = torch.zeros(1, device=dev)
+        # torch.optim.Adam counts steps per parameter, from the first step the parameter has a gradient
+        self.t0 = torch.full((n,), 2 ** 31 - 1, device=dev, dtype=torch.int32)
+        self._inactive = list(zip(params, offs))
+        self._host_step = 0
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                v = self.flat_p[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+                p._fqss_direct = True
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def _activate_touched(self):
+        if self._inactive:
+            still = []
+            for p, o in self._inactive:
+                if getattr(p, "_fqss_touched", False):
+                    self.t0[o:o + p.numel()] = self._host_step
+                else:
+                    still.append((p, o))
+            self._inactive = still
+        self._host_step += 1
+
+    def clip_adam_step(self, lr, max_norm=5.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+        self._activate_touched()
+        self.sumsq.zero_()
+        K.sumsq(self.flat_g, self.sumsq)
+        K.adam_clip(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.sumsq, self.step_t, self.gnorm,
+                    max_norm, grad_scale, lr, betas[0], betas[1], eps, t0=self.t0)
+
+
+class KDTrainStep:
+    """one QAT step = student fwd + teacher fwd + KD loss + bwd (+ grad all-reduce) + clip + Adam
+    (reference: System.training_step / common_step, mysystem.py:124-157; Adam + clip 5.0,
+    asteroid_librimix_trainer.py:94,132)."""
+
+    def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None):
+        self.model, self.fmodel = model, fmodel
+        self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
+        self.comm = comm
+        self.arena = ParamArena(list(model.parameters()))
+        for p in fmodel.parameters():
+            p.requires_grad_(False)
+        self.last = None
+
+    def __call__(self, x, tgt):
+        a = self.arena
+        a.zero_grad()
+        est = self.model(x)
+        with torch.no_grad():
+            fest = self.fmodel(x)
+        out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
+        est.backward(gest)
+        scale = 1.0
+        if self.comm is not None and self.comm.world > 1:
+            self.comm.all_reduce_sum(a.flat_g)
+            scale = 1.0 / self.comm.world
+        a.clip_adam_step(self.lr, self.clip, scale)
+        self.last = dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
+        return self.last

@@ -77,6 +77,10 @@ int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64
                   const float* qmin, const float* qmax, double* gacc, float* gbias, int64_t C,
                   fqss_stream_t stream);
 
+/* out_k += (float)gacc[k] for the non-null outputs (k = 0 min, 1 max, 2 slope), then gacc[0..2] = 0:
+ * hands the fp64 range/slope accumulators of fqss_actq_bwd over to fp32 parameter gradients     */
+int fqss_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope, fqss_stream_t stream);
+
 /* running min/max of a plain tensor into obs_ws (used by the splitter's global max, process.py:24) */
 int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* obs_ws,
                 fqss_stream_t stream);
@@ -90,10 +94,10 @@ int fqss_wq_observe(const float* w, int64_t outer, int64_t C, int64_t inner, flo
                     float* qmax, fqss_stream_t stream);
 int fqss_wq_fwd(const float* w, float* wq, int8_t* idx, int64_t outer, int64_t C, int64_t inner,
                 const float* qmin, const float* qmax, fqss_stream_t stream);
-/* gw = ; gmin[C] = ; gmax[C] = */
+/* accumulate=0: gw = ; gmin[C] = ; gmax[C] =      accumulate=1: all three are "+=" */
 int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* gmax,
                 int64_t outer, int64_t C, int64_t inner, const float* qmin, const float* qmax,
-                fqss_stream_t stream);
+                int accumulate, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4/K5  pointwise (k=1) Conv1d as an fp32-MFMA GEMM:  z[b] = W[Co x Ci] * x[b][Ci x M] + bias
@@ -138,9 +142,9 @@ int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float
  * replaces: torch.add / torch.sub / torch.mul in AddQ, ResidualErrorBlock, MulQ
  *           (qat_layers.py:69-71, 1193, 93-96), postprocess (process.py:44-47)
  * ------------------------------------------------------------------------------------------- */
-/* z = a + sb*b */
-int fqss_axpby(const float* a, const float* b, float sb, float* z, int64_t rows, int64_t cols,
-               int64_t ld_a, int64_t ld_b, int64_t ld_z, fqss_stream_t stream);
+/* z = sa*a + sb*b   (sa = 1, sb = +-1: add / sub, exact; sa = 2^-8, sb = 0: the combiner's scale) */
+int fqss_axpby(const float* a, const float* b, float sa, float sb, float* z, int64_t rows,
+               int64_t cols, int64_t ld_a, int64_t ld_b, int64_t ld_z, fqss_stream_t stream);
 /* z[b][s][c][:] = mask[b][s][c][:] * feat[b][c][:] */
 int fqss_mul_bcast_fwd(const float* mask, const float* feat, float* z, int B, int S, int C, int M,
                        int64_t ld_mask, int64_t ld_feat, int64_t ld_z, fqss_stream_t stream);
@@ -185,12 +189,15 @@ int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, i
  * ------------------------------------------------------------------------------------------- */
 /* sumsq[0] += sum g^2  (fp64) */
 int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_t stream);
-/* step_t: device int32 step counter (incremented by the kernel -> graph-replay safe).
+/* step_t: device int32 global step counter (incremented by the call -> graph-replay safe).
+ * t0 (nullable): per-element int32, number of global steps that passed before the element's
+ * parameter first received a gradient (torch.optim.Adam counts steps per parameter); INT32_MAX
+ * marks parameters that never had one (skipped, like torch skips grad=None).
  * g is scaled by min(1, max_norm/(sqrt(sumsq)+1e-6)) (torch.nn.utils.clip_grad_norm_), grad_scale
  * pre-multiplies g (1/world for DDP averaging).                                                  */
 int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
                    float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
-                   int32_t* step_t, float* gnorm_out, fqss_stream_t stream);
+                   int32_t* step_t, const int32_t* t0, float* gnorm_out, fqss_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,141 @@
+"""CPU tests of the host side: C-ABI surface, module/graph-rewrite mirror, layout helpers, and the
+world_size-2 data-parallel plumbing (gloo).  No kernel is launched here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """the library loads and exports exactly what include/fqss.h declares (and _lib binds all of it)"""
+    from fqss_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fqss.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(fqss_\w+)\s*\(", hdr, flags=re.M))
+    assert declared and declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    if not os.path.exists(_lib.SO_PATH):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
+    lib = _lib.load(strict=True)
+    assert lib.fqss_version() == 100
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback():
+    from fqss_amd import _lib
+    from fqss_amd.quantization.qat import qat_quant as QQ
+    q = QQ.GradientActivationFakeQuantize(True)
+    with pytest.raises(_lib.FqssError):
+        q(torch.randn(4, 4))
+    w = QQ.GradientWeightFakeQuantize(True, (4, 3, 1))
+    with pytest.raises(_lib.FqssError):
+        w(torch.randn(4, 3, 1))
+
+
+def test_product_never_imports_oracle():
+    """only smoke.py (the driver's checker entry) may reference oracle/ inside the package"""
+    pkg = os.path.join(ROOT, "fqss_amd")
+    offenders = []
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py") and f != "smoke.py":
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M):
+                    offenders.append(os.path.join(dp, f))
+    assert not offenders, offenders
+
+
+def test_quantizer_api_surface():
+    from fqss_amd.quantization.qat import qat_quant as QQ
+    q = QQ.get_activation_quantizer(True, n_bits=8)
+    assert isinstance(q, QQ.GradientActivationFakeQuantize)
+    assert list(q.state_dict().keys()) == ["min_range", "max_range"]          # scratch buffers are non-persistent
+    assert q.min_range.shape == (1,) and q.min_range.item() == -0.5 and q.max_range.item() == 0.5
+    assert (q.max_observations, q.alpha, q.n_iter, q.observer_mode) == (50, 0.9, 0, True)
+    modes = [q.next_mode() for _ in range(52)]
+    assert modes[:50] == [1] * 50 and modes[50:] == [2, 2] and q.n_iter == 50
+    q.enable_observer(False)
+    w = QQ.get_weight_quantizer(True, (7, 3, 16), ch_out_idx=1)
+    assert w.min_range.shape == (1, 3, 1) and w.axis == 1
+    with pytest.raises(NotImplementedError):
+        QQ.GradientActivationFakeQuantize(True, n_bits=4)
+
+
+def test_graph_rewrite_and_state_dict_layout(golden):
+    from fqss_amd.quantization.qat import qat_layers as QL
+    from fqss_amd.quantization.qat.models.convtasnetq import ConvBlock, ConvTasNetQ
+    from fqss_amd.quantization.qat.models.load_model import create_model, enable_observer, quantize_model
+    from fqss_amd.smoke import QCFG
+    g = golden("tiny_step")
+    torch.manual_seed(0)
+    m = ConvTasNetQ(n_spks=2, kernel_size=16, stride=8, n_filters=32, bn_chan=16, hid_chan=32, n_blocks=2, n_repeats=1)
+    assert list(m.state_dict().keys()) == [k[4:] for k in g.files if k.startswith("fsd.")]
+    m = quantize_model(m, dict(QCFG))
+    assert list(m.state_dict().keys()) == list(g["sd_keys"])
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == g["sd0." + k].shape, k
+    blk = m.masker.TCN[0]
+    assert isinstance(blk, ConvBlock)
+    assert isinstance(blk.shared_block[0], QL.Conv1dNlQ) and isinstance(blk.shared_block[1], nn.Identity)
+    assert isinstance(blk.shared_block[2], QL.GroupNormQ) and isinstance(blk.res_conv, QL.Conv1dQ)
+    assert isinstance(m.encoder, QL.Conv1dEncoderQ) and m.encoder.conv1d.in_channels == 2
+    assert isinstance(m.decoder, QL.ConvTr1dDecoderQ) and m.decoder.weight_fake_quantize.axis == 1
+    assert isinstance(m.mul, QL.MulQ) and isinstance(m.masker.adds[0], QL.AddQ)
+    enable_observer(m, False)
+    assert not m.encoder.activation_fake_quantize.observer_mode
+    full = quantize_model(create_model({"name": "ConvTasNet", "n_src": 2, "kernel_size": 16, "stride": 8}), dict(QCFG))
+    assert len(full.state_dict()) == 948
+    assert sum(p.numel() for p in full.parameters()) == 5133123
+    with pytest.raises(NotImplementedError):
+        create_model({"name": "DPTNet"})
+
+
+def test_rowmat_layouts():
+    from fqss_amd.kernels import empty_act, rowmat
+    assert rowmat(torch.empty(2, 3, 77)) == (6, 77, 77)
+    b = empty_act((2, 6, 77), "cpu")
+    assert b.shape == (2, 6, 77) and rowmat(b) == (12, 77, 80)
+    assert rowmat(b.reshape(2, 2, 3, 77)) == (12, 77, 80) and rowmat(b.reshape(4, 3, 77)) == (12, 77, 80)
+    assert rowmat(b.unsqueeze(1)) == (12, 77, 80)
+    assert rowmat(torch.empty(4, 800).t()) is None and rowmat(torch.empty(2, 3, 77)[:, :, ::2]) is None
+    assert rowmat(torch.empty(4, 1, 800)) == (4, 800, 800)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fqss_amd.parallel import Comm
+    comm = Comm.from_env(device_type="cpu")
+    assert comm.world == world and comm.backend == "gloo"
+    lo, hi = comm.shard(16)
+    g = torch.full((1000,), float(rank + 1))
+    comm.all_reduce_sum(g)                      # the flat-gradient exchange
+    t = torch.tensor([float(rank)])
+    comm.all_reduce_max(t)                      # the bench's max-over-ranks timing
+    b = torch.tensor([3.0 if rank == 0 else -1.0])
+    comm.broadcast(b, 0)
+    comm.barrier()
+    q.put((rank, lo, hi, float(g[0]), float(g.sum()), float(t), float(b)))
+    comm.close()
+
+
+def test_data_parallel_plumbing_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(o[1], o[2]) for o in out] == [(0, 8), (8, 16)]           # disjoint batch shards
+    assert all(o[3] == 3.0 and o[4] == 3000.0 for o in out)          # sum over ranks
+    assert all(o[5] == 1.0 and o[6] == 3.0 for o in out)

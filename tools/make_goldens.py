@@ -386,7 +386,7 @@ def gen_tiny_step(out, n_steps=53):
         opt.step()
         if step in record:
             for k, v in model.state_dict().items():
-                if k.endswith("min_range") or k.endswith("max_range") or step in (1, 53):
+                if k.endswith("min_range") or k.endswith("max_range") or step in (1, 50, 53):
                     d[f"s{step}.post_sd.{k}"] = npy(v)
     np.savez_compressed(os.path.join(out, "tiny_step.npz"), **d)
     print("tiny_step: final loss", float(loss), "keys", len(d))
