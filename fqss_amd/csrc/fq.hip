@@ -150,6 +150,14 @@ __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x, int
 //     g_C = g*delta ; g_u = g_C*m ; g_t = g_u/delta
 //     d/dmax = sum g*(c - m*u)/255 ; d/dmin = sum g*(1-m) - d/dmax
 // =============================================================================================
+// Reductions: NO same-address atomics (4096 blocks x 3 fp64 atomics on one address cost ~100-160 us,
+// 3-5x the streaming time of the kernel).  Every block stores its three fp64 partials to its own slot
+// of `gacc` ([kGaccSlots][3], all-zero on entry); fqss_gacc_flush sums the slots in a fixed order
+// (=> deterministic range/slope gradients) and re-zeroes them.
+// Rows are walked channel-major (c outer, batch inner) so that the bias row-sum of a channel is ONE
+// block reduction + one fp32 atomic per (column chunk, channel).
+constexpr int kGaccSlots = FQSS_GACC_SLOTS;
+
 template <int VEC, bool BIAS>
 __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, const float* __restrict__ g,
                                                    float* __restrict__ gz, int64_t rows, int64_t cols,
@@ -167,71 +175,74 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
     float p_out = 0.0f;   // sum g*(1-m)
     float p_slope = 0.0f; // sum [z<=0] z*g_t
     const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
-    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
-        const float* zr = z + row * ld_z;
-        const float* gr = g + row * ld_g;
-        float* or_ = gz + row * ld_gz;
+    const int64_t nb = rows / C;  // batch entries per channel
+    for (int64_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
         float p_bias = 0.0f;
-        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
-            float zv[VEC], gv[VEC], o[VEC];
-            if constexpr (VEC == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(zr + c0);
-                const float4 b = *reinterpret_cast<const float4*>(gr + c0);
-                zv[0] = a.x; zv[1] = a.y; zv[2] = a.z; zv[3] = a.w;
-                gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
-            } else {
-                zv[0] = zr[c0];
-                gv[0] = gr[c0];
-            }
+        for (int64_t bi = 0; bi < nb; ++bi) {
+            const int64_t row = bi * C + ch;
+            const float* zr = z + row * ld_z;
+            const float* gr = g + row * ld_g;
+            float* or_ = gz + row * ld_gz;
+            for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
+                float zv[VEC], gv[VEC], o[VEC];
+                if constexpr (VEC == 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(zr + c0);
+                    const float4 b = *reinterpret_cast<const float4*>(gr + c0);
+                    zv[0] = a.x; zv[1] = a.y; zv[2] = a.z; zv[3] = a.w;
+                    gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+                } else {
+                    zv[0] = zr[c0];
+                    gv[0] = gr[c0];
+                }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const bool valid = (c0 + j < cols);
-                const float gj = valid ? gv[j] : 0.0f;
-                const float t = act_apply(zv[j], act, slope);
-                float gt = gj;
-                if (qmode == FQSS_Q_QUANT) {
-                    float c, u;
-                    bool inr;
-                    (void)fq_asym(t, r, c, u, inr);
-                    gt = inr ? (gj * r.delta) / r.delta : 0.0f;
-                    if (valid) {
-                        p_du += gj * (inr ? (c - u) : c);
-                        p_out += inr ? 0.0f : gj;
+                for (int j = 0; j < VEC; ++j) {
+                    const bool valid = (c0 + j < cols);
+                    const float gj = valid ? gv[j] : 0.0f;
+                    const float t = act_apply(zv[j], act, slope);
+                    float gt = gj;
+                    if (qmode == FQSS_Q_QUANT) {
+                        float c, u;
+                        bool inr;
+                        (void)fq_asym(t, r, c, u, inr);
+                        gt = inr ? (gj * r.delta) / r.delta : 0.0f;
+                        if (valid) {
+                            p_du += gj * (inr ? (c - u) : c);
+                            p_out += inr ? 0.0f : gj;
+                        }
                     }
+                    float gzj = gt;
+                    if (act == FQSS_ACT_PRELU) {
+                        const bool pos = zv[j] > 0.0f;
+                        gzj = pos ? gt : slope * gt;
+                        if (valid && !pos) p_slope += zv[j] * gt;
+                    } else if (act == FQSS_ACT_RELU) {
+                        gzj = (t > 0.0f) ? gt : 0.0f;
+                    }
+                    o[j] = gzj;
+                    if (BIAS && valid) p_bias += gzj;
                 }
-                float gzj = gt;
-                if (act == FQSS_ACT_PRELU) {
-                    const bool pos = zv[j] > 0.0f;
-                    gzj = pos ? gt : slope * gt;
-                    if (valid && !pos) p_slope += zv[j] * gt;
-                } else if (act == FQSS_ACT_RELU) {
-                    gzj = (t > 0.0f) ? gt : 0.0f;
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4*>(or_ + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    or_[c0] = o[0];
                 }
-                o[j] = gzj;
-                if (BIAS && valid) p_bias += gzj;
-            }
-            if constexpr (VEC == 4) {
-                *reinterpret_cast<float4*>(or_ + c0) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-                or_[c0] = o[0];
             }
         }
         if constexpr (BIAS) {
             float pb[1] = {p_bias};
             block_sum<float, 1>(pb, redf);
-            if (threadIdx.x == 0) atomicAdd(&gbias[row % C], pb[0]);
+            if (threadIdx.x == 0) atomicAdd(&gbias[ch], pb[0]);
         }
     }
     if (qmode == FQSS_Q_QUANT || act == FQSS_ACT_PRELU) {
         double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
         block_sum<double, 3>(v, red);
         if (threadIdx.x == 0) {
-            if (qmode == FQSS_Q_QUANT) {
-                const double dmax = v[0] / 255.0;
-                atomicAdd(&gacc[0], v[1] - dmax);
-                atomicAdd(&gacc[1], dmax);
-            }
-            if (act == FQSS_ACT_PRELU) atomicAdd(&gacc[2], v[2]);
+            double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+            const double dmax = v[0] / 255.0;
+            slot[0] += (qmode == FQSS_Q_QUANT) ? v[1] - dmax : 0.0;
+            slot[1] += (qmode == FQSS_Q_QUANT) ? dmax : 0.0;
+            slot[2] += v[2];
         }
     }
 }
@@ -324,14 +335,21 @@ __global__ __launch_bounds__(256) void k_wq_bwd(const float* __restrict__ w, con
     }
 }
 
-__global__ void k_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (gmin) *gmin += (float)gacc[0];
-        if (gmax) *gmax += (float)gacc[1];
-        if (gslope) *gslope += (float)gacc[2];
-        gacc[0] = 0.0;
-        gacc[1] = 0.0;
-        gacc[2] = 0.0;
+__global__ __launch_bounds__(256) void k_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope) {
+    __shared__ double red[3 * 4];
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < kGaccSlots; i += 256) {   // fixed order => deterministic sums
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] += gacc[3 * i + k];
+            gacc[3 * i + k] = 0.0;
+        }
+    }
+    block_sum<double, 3>(v, red);
+    if (threadIdx.x == 0) {
+        if (gmin) *gmin += (float)v[0];
+        if (gmax) *gmax += (float)v[1];
+        if (gslope) *gslope += (float)v[2];
     }
 }
 
@@ -407,13 +425,21 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");
-    FQSS_REQUIRE(!gbias || C > 0, "gbias needs C");
+    FQSS_REQUIRE(!gbias || (C > 0 && rows % C == 0), "gbias needs C dividing rows");
     if (rows == 0 || cols == 0) return FQSS_OK;
+    if (!gbias || C <= 0) C = rows;   // no channel semantics: every row is its own "channel"
     const bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
+    const int v = vec ? 4 : 1;
+    int64_t gx = cdiv(cols, 256 * (int64_t)v);
+    if (gx > 64) gx = 64;
+    int64_t gy = kGaccSlots / gx;
+    if (gy > C) gy = C;
+    if (gy < 1) gy = 1;
+    dim3 grid((unsigned)gx, (unsigned)gy);
 #define FQSS_LAUNCH_BWD(V, Bi)                                                                                       \
-    hipLaunchKernelGGL((k_actq_bwd<V, Bi>), grid_rows(rows, cols, V, 4096), dim3(256), 0, s, z, g, gz, rows, cols,   \
-                       ld_z, ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, gbias, C)
+    hipLaunchKernelGGL((k_actq_bwd<V, Bi>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act,     \
+                       slope, qmode, qmin, qmax, gacc, gbias, C)
     if (vec) {
         if (gbias) FQSS_LAUNCH_BWD(4, true); else FQSS_LAUNCH_BWD(4, false);
     } else {
@@ -442,7 +468,7 @@ extern "C" int fqss_wq_fwd(const float* w, float* wq, int8_t* idx, int64_t outer
 
 extern "C" int fqss_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope, fqss_stream_t stream) {
     FQSS_REQUIRE(gacc, "null accumulator");
-    hipLaunchKernelGGL(k_gacc_flush, dim3(1), dim3(64), 0, (hipStream_t)stream, gacc, gmin, gmax, gslope);
+    hipLaunchKernelGGL(k_gacc_flush, dim3(1), dim3(256), 0, (hipStream_t)stream, gacc, gmin, gmax, gslope);
     return launch_status("fqss_gacc_flush");
 }
 

@@ -147,6 +147,54 @@ __global__ __launch_bounds__(256) void k_dwconv(const float* __restrict__ x, con
     }
 }
 
+// 16-B/lane variant: each thread produces 4 consecutive outputs; a tap whose offset is a multiple of
+// 4 floats (dil = 4..128 and the centre tap) is ONE aligned float4 load, the others are L1-resident
+// scalar loads.  Rows must be 16-B aligned (ld % 4 == 0).
+template <bool FLIP>
+__global__ __launch_bounds__(256) void k_dwconv_v4(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ z,
+                                                    int64_t rows, int C, int M, int K, int dil, int pad, int64_t ld_x,
+                                                    int64_t ld_z) {
+    const int64_t cstep = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int c = (int)(row % C);
+        const float* xr = x + row * ld_x;
+        float* zr = z + row * ld_z;
+        float wk[kMaxTaps];
+#pragma unroll
+        for (int k = 0; k < kMaxTaps; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+        const float bv = (!FLIP && bias != nullptr) ? bias[c] : 0.0f;
+        for (int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; m < M; m += cstep) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < kMaxTaps; ++k) {
+                if (k < K) {
+                    const int off = FLIP ? (pad - k * dil) : (k * dil - pad);
+                    const int64_t s0 = m + off;
+                    float v[4];
+                    if ((off & 3) == 0 && s0 >= 0 && s0 + 3 < ld_x) {
+                        const float4 t = *reinterpret_cast<const float4*>(xr + s0);
+                        v[0] = t.x;
+                        v[1] = (s0 + 1 < M) ? t.y : 0.0f;
+                        v[2] = (s0 + 2 < M) ? t.z : 0.0f;
+                        v[3] = (s0 + 3 < M) ? t.w : 0.0f;
+                        if (s0 >= M) v[0] = 0.0f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int64_t sj = s0 + j;
+                            v[j] = (sj >= 0 && sj < M) ? xr[sj] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+                }
+            }
+            *reinterpret_cast<float4*>(zr + m) = make_float4(acc[0] + bv, acc[1] + bv, acc[2] + bv, acc[3] + bv);
+        }
+    }
+}
+
 // gw[c][k] += sum_{b,m} gz[b][c][m] * x[b][c][m + k*dil - pad]   ; grid (C, B)
 __global__ __launch_bounds__(256) void k_dwconv_bwd_w(const float* __restrict__ gz, const float* __restrict__ x,
                                                        float* gw, int C, int M, int K, int dil, int pad, int64_t ld_gz,
@@ -422,8 +470,12 @@ extern "C" int fqss_dwconv_fwd(const float* x, const float* w, const float* bias
     FQSS_REQUIRE(ld_x >= M && ld_z >= M, "bad ld");
     if (B == 0 || M == 0) return FQSS_OK;
     const int64_t rows = (int64_t)B * C;
-    hipLaunchKernelGGL(k_dwconv<false>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, rows, C,
-                       M, K, dil, pad, ld_x, ld_z);
+    if (aligned16(x) && aligned16(z) && ld_x % 4 == 0 && ld_z % 4 == 0)
+        hipLaunchKernelGGL(k_dwconv_v4<false>, grid_rows(rows, M, 4), dim3(256), 0, (hipStream_t)stream, x, w, bias, z,
+                           rows, C, M, K, dil, pad, ld_x, ld_z);
+    else
+        hipLaunchKernelGGL(k_dwconv<false>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, rows,
+                           C, M, K, dil, pad, ld_x, ld_z);
     return launch_status("fqss_dwconv_fwd");
 }
 
@@ -435,8 +487,12 @@ extern "C" int fqss_dwconv_bwd_x(const float* gz, const float* w, float* gx, int
     FQSS_REQUIRE(ld_gz >= M && ld_gx >= M, "bad ld");
     if (B == 0 || M == 0) return FQSS_OK;
     const int64_t rows = (int64_t)B * C;
-    hipLaunchKernelGGL(k_dwconv<true>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, gz, w,
-                       (const float*)nullptr, gx, rows, C, M, K, dil, pad, ld_gz, ld_gx);
+    if (aligned16(gz) && aligned16(gx) && ld_gz % 4 == 0 && ld_gx % 4 == 0)
+        hipLaunchKernelGGL(k_dwconv_v4<true>, grid_rows(rows, M, 4), dim3(256), 0, (hipStream_t)stream, gz, w,
+                           (const float*)nullptr, gx, rows, C, M, K, dil, pad, ld_gz, ld_gx);
+    else
+        hipLaunchKernelGGL(k_dwconv<true>, grid_rows(rows, M, 1), dim3(256), 0, (hipStream_t)stream, gz, w,
+                           (const float*)nullptr, gx, rows, C, M, K, dil, pad, ld_gz, ld_gx);
     return launch_status("fqss_dwconv_bwd_x");
 }
 

@@ -7,6 +7,7 @@ from . import _lib
 Q_BYPASS, Q_OBSERVE, Q_QUANT = 0, 1, 2
 ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
 
+GACC_DOUBLES = 2048 * 3   # FQSS_GACC_SLOTS x (dmin, dmax, dslope)
 LD_ALIGN = 16  # row stride of activation buffers is padded to 16 floats (64 B) -> 16-B/lane path
 
 

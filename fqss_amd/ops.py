@@ -46,7 +46,7 @@ def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=N
     need_acc = (q.qmode == Q_QUANT) or (act == ACT_PRELU)
     gacc = None
     if need_acc:
-        gacc = q.gacc if q.gacc is not None else torch.zeros(3, dtype=torch.float64, device=z.device)
+        gacc = q.gacc if q.gacc is not None else torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=z.device)
     gb, gb_direct = (None, True)
     if bias_like is not None:
         gb, gb_direct = _grad_buf(bias_param, bias_like)
@@ -282,6 +282,29 @@ class Combine2(Function):
 def splitter2(x):
     with torch.no_grad():
         return K.splitter2(x)
+
+
+class Fork2(Function):
+    """identity with two consumers: the two incoming gradients are summed by the padded HIP axpby
+    (autograd's own accumulation would densify the row stride and push consumers onto the scalar path)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return K.axpby(g1, g2, 1.0)
+
+
+def fork2(x):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return Fork2.apply(x)
+    return x, x
 
 
 class KDLoss(Function):

@@ -8,6 +8,7 @@ the shipped size).  Every op -- float or quantized -- executes as a HIP kernel (
 import torch
 import torch.nn as nn
 
+from .... import ops
 from ....process import postprocess, preprocess
 from ..float_exec import HipSequential, apply_module
 from ..qat_layers import Add, Mul
@@ -35,10 +36,11 @@ class ConvBlock(nn.Module):
         self.add = Add()
 
     def forward(self, x):
-        feature = self.shared_block(x)
-        residual = apply_module(self.res_conv, feature)
-        skip_out = apply_module(self.skip_conv, feature)
-        return self.add(x, residual), skip_out
+        x_blk, x_res = ops.fork2(x)
+        f_res, f_skip = ops.fork2(self.shared_block(x_blk))
+        residual = apply_module(self.res_conv, f_res)
+        skip_out = apply_module(self.skip_conv, f_skip)
+        return self.add(x_res, residual), skip_out
 
 
 class MaskGenerator(nn.Module):
@@ -101,7 +103,8 @@ class ConvTasNetQ(nn.Module):
         x = self.pre_process(x)
         batch = x.shape[0]
         feats = apply_module(self.encoder, x)                                  # [B, F, M]
-        masked = self.mul(self.masker(feats), feats.unsqueeze(1))              # [B, S, F, M]
+        f_mask, f_mul = ops.fork2(feats)
+        masked = self.mul(self.masker(f_mask), f_mul.unsqueeze(1))             # [B, S, F, M]
         masked = torch.reshape(masked, (batch * self.n_srcs, self.enc_num_feats, -1))
         out = apply_module(self.decoder, masked)                               # [D, B*S, 1, L] or [B*S, 1, L]
         out = out.reshape((self.n_combiner, batch, self.n_srcs, 1, -1))

@@ -344,12 +344,13 @@ class ConvTr1dDecoderQ(LayerQ):
 
     def forward(self, x):
         w_decoder = self._wq(self.convTr1d.weight)
-        y = run_convtr1d(self.convTr1d, x, w_decoder, self.activation_fake_quantize)
         if self.n_combiner == 1:
-            return y
+            return run_convtr1d(self.convTr1d, x, w_decoder, self.activation_fake_quantize)
+        x_dec, x_res = ops.fork2(x)
+        y = run_convtr1d(self.convTr1d, x_dec, w_decoder, self.activation_fake_quantize)
         outs = [y]
         for _ in range(1, self.n_combiner):
-            y = self.residual_error_block(x, y, w_decoder, self.convTr1d, self.activation_fake_quantize_residual)
+            y = self.residual_error_block(x_res, y, w_decoder, self.convTr1d, self.activation_fake_quantize_residual)
             outs.append(y)
         return torch.stack(outs)
 

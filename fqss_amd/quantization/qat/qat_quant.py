@@ -58,7 +58,7 @@ class GradientActivationFakeQuantize(nn.Module):
         self.scale_grad = scale_grad
         # device scratch: not part of the state_dict (persistent=False keeps the reference's key set)
         self.register_buffer("_obs_ws", torch.tensor([-1, 0], dtype=torch.int32), persistent=False)
-        self.register_buffer("_gacc", torch.zeros(3, dtype=torch.float64), persistent=False)
+        self.register_buffer("_gacc", torch.zeros(K.GACC_DOUBLES, dtype=torch.float64), persistent=False)
 
     def enable_observer(self, observer_mode):
         self.observer_mode = observer_mode

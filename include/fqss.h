@@ -70,15 +70,19 @@ int fqss_obs_reset(uint32_t* obs_ws, int64_t n_pairs, fqss_stream_t stream);
 int fqss_observer_ema(float* qmin, float* qmax, uint32_t* obs_ws, double alpha, fqss_stream_t stream);
 
 /* backward of out = fq(act(z)) given g = dL/dout:
- *   gz = dL/dz ; gacc[0] += dL/dmin ; gacc[1] += dL/dmax ; gacc[2] += dL/dslope (fp64 atomics)
+ *   gz = dL/dz ;
+ *   gacc: fp64 scratch of FQSS_GACC_SLOTS x 3 doubles, all-zero on entry: each workgroup adds its
+ *         partial (dL/dmin, dL/dmax, dL/dslope) to its own slot (no same-address atomics);
+ *         fqss_gacc_flush reduces the slots in a fixed order and re-zeroes them;
  *   gbias[row % C] += sum_cols gz   (optional, fp32 atomics; bias of the producing conv)         */
+#define FQSS_GACC_SLOTS 2048
 int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64_t cols,
                   int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act, const float* slope, int qmode,
                   const float* qmin, const float* qmax, double* gacc, float* gbias, int64_t C,
                   fqss_stream_t stream);
 
-/* out_k += (float)gacc[k] for the non-null outputs (k = 0 min, 1 max, 2 slope), then gacc[0..2] = 0:
- * hands the fp64 range/slope accumulators of fqss_actq_bwd over to fp32 parameter gradients     */
+/* out_k += (float) sum_slots gacc[slot][k] for the non-null outputs (k = 0 min, 1 max, 2 slope), then
+ * gacc = 0: hands the fp64 range/slope partials of fqss_actq_bwd over to fp32 parameter gradients */
 int fqss_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope, fqss_stream_t stream);
 
 /* running min/max of a plain tensor into obs_ws (used by the splitter's global max, process.py:24) */

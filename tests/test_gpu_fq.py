@@ -39,10 +39,10 @@ def test_golden_fq_act_bit_exact(golden):
         y, idx = K.actq_fwd(x, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True)
         assert np.array_equal(idx.cpu().numpy(), g[f"idx{i}"])
         assert np.array_equal(y.cpu().numpy(), g[f"y{i}"])
-        gacc = torch.zeros(3, dtype=torch.float64, device="cuda")
+        gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
         gx = K.actq_bwd(x, dev(g[f"g{i}"]), K.ACT_NONE, None, K.Q_QUANT, lo, hi, gacc)
         assert np.array_equal(gx.cpu().numpy(), g[f"gx{i}"])
-        ga = gacc.cpu().numpy()
+        ga = gacc.view(-1, 3).sum(0).cpu().numpy()
         np.testing.assert_allclose(ga[0], g[f"gmin{i}"][0], rtol=2e-5, atol=1e-5)
         np.testing.assert_allclose(ga[1], g[f"gmax{i}"][0], rtol=2e-5, atol=1e-5)
 
@@ -72,15 +72,29 @@ def test_actq_vs_oracle(shape, act):
         out, idx = K.actq_fwd(zd, act, sd, K.Q_QUANT, lo.cuda(), hi.cuda(), None, want_idx=True)
         assert torch.equal(idx.cpu(), idx_ref)
         assert torch.equal(out.cpu(), y.detach())
-        gacc = torch.zeros(3, dtype=torch.float64, device="cuda")
+        gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
         gz = K.actq_bwd(zd, gd, act, sd, K.Q_QUANT, lo.cuda(), hi.cuda(), gacc)
         np.testing.assert_allclose(gz.cpu().numpy(), zr.grad.numpy(), rtol=1e-6, atol=1e-7)
-        ga = gacc.cpu().numpy()
+        ga = gacc.view(-1, 3).sum(0).cpu().numpy()
         scale = float(g.abs().sum()) * 1e-6 + 1e-5
         np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=2e-4, atol=scale)
         np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=2e-4, atol=scale)
         if act == 1:
             np.testing.assert_allclose(ga[2], sl_r.grad.item(), rtol=2e-4, atol=scale)
+
+
+def test_gacc_flush_is_deterministic_and_rezeroes():
+    z, g = torch.randn(8, 128, 3999, device="cuda"), torch.randn(8, 128, 3999, device="cuda")
+    lo, hi, sl = torch.tensor([-1.0], device="cuda"), torch.tensor([1.5], device="cuda"), torch.tensor([0.25], device="cuda")
+    outs = []
+    for _ in range(3):
+        gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
+        K.actq_bwd(z, g, K.ACT_PRELU, sl, K.Q_QUANT, lo, hi, gacc)
+        o = [torch.zeros(1, device="cuda") for _ in range(3)]
+        K.gacc_flush(gacc, *o)
+        assert float(gacc.abs().max()) == 0.0
+        outs.append(torch.cat(o).cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])   # bitwise run-to-run reproducible
 
 
 def test_actq_bias_rowsum():
