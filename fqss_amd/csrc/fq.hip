@@ -37,7 +37,7 @@ int launch_status(const char* what) {
 template <int VEC>
 __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, float* __restrict__ out,
                                                    uint8_t* __restrict__ idx, int64_t rows, int64_t cols,
-                                                   int64_t ld_z, int64_t ld_o, int act,
+                                                   int64_t ld_z, int64_t ld_o, int64_t ld_i, int act,
                                                    const float* __restrict__ slope_p, int qmode,
                                                    const float* __restrict__ qmin,
                                                    const float* __restrict__ qmax, uint32_t* obs) {
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
                 v[0] = zr[c0];
             }
             float o[VEC];
+            unsigned int packed = 0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float t = act_apply(v[j], act, slope);
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
                     float c, u;
                     bool inr;
                     o[j] = fq_asym(t, r, c, u, inr);
-                    if (idx != nullptr && c0 + j < cols) idx[row * cols + c0 + j] = (uint8_t)c;
+                    if (idx != nullptr) {
+                        if (VEC == 4 && (ld_i & 3) == 0) packed |= ((unsigned int)c & 0xFFu) << (8 * j);
+                        else if (c0 + j < cols) idx[row * ld_i + c0 + j] = (uint8_t)c;
+                    }
                 } else {
                     o[j] = t;
                     if (qmode == FQSS_Q_OBSERVE && c0 + j < cols) {
@@ -76,6 +80,8 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
             }
             if constexpr (VEC == 4) {
                 *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (qmode == FQSS_Q_QUANT && idx != nullptr && (ld_i & 3) == 0)
+                    *reinterpret_cast<unsigned int*>(idx + row * ld_i + c0) = packed;
             } else {
                 orow[c0] = o[0];
             }
@@ -364,9 +370,11 @@ extern "C" int fqss_version(void) { return FQSS_VERSION; }
 extern "C" const char* fqss_last_error(void) { return fqss::g_err; }
 
 extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols, int64_t ld_z,
-                             int64_t ld_out, int act, const float* slope, int qmode, const float* qmin,
+                             int64_t ld_out, int64_t ld_idx, int act, const float* slope, int qmode, const float* qmin,
                              const float* qmax, uint32_t* obs_ws, fqss_stream_t stream) {
     FQSS_REQUIRE(z && out, "null tensor");
+    FQSS_REQUIRE(!idx || ld_idx >= cols, "bad ld_idx");
+    FQSS_REQUIRE(!idx || (ld_idx & 3) != 0 || (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, "idx rows must be 4-B aligned");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_out >= cols, "bad shape");
     FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
@@ -377,10 +385,10 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     hipStream_t s = (hipStream_t)stream;
     if (vec) {
         hipLaunchKernelGGL(k_actq_fwd<4>, grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,
-                           ld_out, act, slope, qmode, qmin, qmax, obs_ws);
+                           ld_out, ld_idx, act, slope, qmode, qmin, qmax, obs_ws);
     } else {
         hipLaunchKernelGGL(k_actq_fwd<1>, grid_rows(rows, cols, 1), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,
-                           ld_out, act, slope, qmode, qmin, qmax, obs_ws);
+                           ld_out, ld_idx, act, slope, qmode, qmin, qmax, obs_ws);
     }
     return launch_status("fqss_actq_fwd");
 }

@@ -1,0 +1,393 @@
+// qgemm.hip -- the student's pointwise convolutions on the bf16 matrix cores, EXACTLY.
+//
+// In the quantizing phase both operands of a student 1x1 conv live on 8-bit grids:
+//     W_q[co][ci] = dw[co] * Wi[co][ci]          Wi in [-128,127]   (qat_quant.py:126-135)
+//     x  [ci][n]  = dx * c[ci][n] + min_x        c  in [0,255]      (qat_quant.py:136-147)
+// so   z = W_q x + b = dw[co] * ( dx * S[co][n] + min_x * R[co] ) + b[co]
+// with S = sum_ci Wi*c and R = sum_ci Wi integer sums.  |Wi*c| <= 32640 and Ci <= 512 keep |S| < 2^24,
+// so S accumulated in the fp32 accumulators of v_mfma_f32_32x32x16_bf16 (integers <= 255 are exact in
+// bf16) is the EXACT integer: the result carries 4 roundings instead of the reference's Ci, at 16x the
+// fp32-MFMA rate.  It differs from the reference's fp32 sum only by the reference's own rounding (G1).
+//
+// Backward operands are gradients (not on a grid).  They are split exactly into three bf16 pieces
+// (24-bit mantissa = 8+8+8, by truncation) so every product with an 8-bit-grid value is exact and only
+// the fp32 accumulation rounds -- the numerics of an fp32 fma chain at 3/16 of its MFMA cost:
+//     dgrad  gx[ci][n]   = sum_co Wi[co][ci] * (dw[co]*gz[co][n])
+//     wgrad  gW_q[co][ci]+= dx * sum_n gz[co][n]*c[ci][n] + min_x * sum_n gz[co][n]
+//
+// Tiles: 128x128x32 per 256-thread block, 4 waves of 64x64 (2x2 MFMA 32x32x16).  A/B fragments need 8
+// consecutive k per lane; operands that are n-contiguous in HBM (activations in fwd/dgrad) keep their
+// natural [k][n] image in LDS and are transposed on the fly by ds_read_b64_tr_b16.
+//
+// Reference replaced: F.conv1d(k=1) of Conv1dQ / Conv1dNlQ (qat_layers.py:137-146, 202-212) and its autograd.
+#include "fqss_dev.h"
+
+namespace fqss {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int QBM = 128, QBN = 128, QBK = 32;
+constexpr int LDK = 40;    // bf16 per row of a k-contiguous image (32 + 8 pad = 80 B: conflict-free ds_read_b128)
+constexpr int LDN = 160;   // bf16 per row of an n-contiguous image (128 + 32 pad = 320 B: conflict-free tr reads)
+
+__device__ __forceinline__ unsigned short f2bf_trunc(float f) { return (unsigned short)(__float_as_uint(f) >> 16); }
+__device__ __forceinline__ float bf_trunc(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
+
+// exact 3-way split g = b1 + b2 + b3 (each bf16-representable)
+__device__ __forceinline__ void split3(float g, unsigned short& b1, unsigned short& b2, unsigned short& b3) {
+    const float h1 = bf_trunc(g);
+    const float r1 = g - h1;
+    const float h2 = bf_trunc(r1);
+    const float r2 = r1 - h2;
+    b1 = f2bf_trunc(h1);
+    b2 = f2bf_trunc(h2);
+    b3 = f2bf_trunc(r2);
+}
+
+struct QGemmArgs {
+    // forward / dgrad: A = int8 weight codes [M][K] (k contiguous), B = per-batch [K][ldb] (n contiguous)
+    // wgrad          : A = fp32 gz [M][lda] per batch (k = n contiguous), B = u8 codes [N][ldb] per batch
+    const void* A;
+    const void* B;
+    float* C;
+    int M, N, K;
+    int64_t lda, ldb, ldc;        // row strides (elements)
+    int64_t sAb, sBb, sCb;        // batch strides (elements)
+    const float* dw;              // [M] fwd: delta_w[co] ; dgrad: [K] delta_w[co] scaling gz rows
+    const float* rw;              // [M] fwd: integer row sums of Wi (as float)
+    const float* bias;            // [M] fwd
+    const float* qmin_x;          // device scalars of the input activation quantizer (fwd, wgrad)
+    const float* qmax_x;
+    int ksplit, kchunk;           // wgrad split-K
+};
+
+template <int MODE>  // 0 fwd (u8 codes B), 1 dgrad (fp32 B, split3), 2 wgrad (fp32 A split3, u8 codes B k-contiguous)
+__global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
+    constexpr int NSPLIT = (MODE == 0) ? 1 : 3;
+    constexpr int NA = (MODE == 2) ? 3 : 1;   // A images
+    constexpr int NB = (MODE == 1) ? 3 : 1;   // B images
+    __shared__ __attribute__((aligned(16))) unsigned short As[NA][QBM][LDK];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NB][(MODE == 2) ? QBN : QBK][(MODE == 2) ? LDK : LDN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int bz = blockIdx.z;
+    const int b = (MODE == 2) ? bz / g.ksplit : bz;
+    const int ks_id = (MODE == 2) ? bz % g.ksplit : 0;
+    const int kbeg = (MODE == 2) ? ks_id * g.kchunk : 0;
+    const int kend = (MODE == 2) ? min(g.K, kbeg + g.kchunk) : g.K;
+    const int i0 = blockIdx.y * QBM, j0 = blockIdx.x * QBN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    float rowsum = 0.0f;  // wgrad: running sum of this thread's piece of gz rows (for the min_x term)
+
+    // ---------------------------------------------------------------- staging (global -> regs -> LDS)
+    uint4 ra_i8;            // MODE 0/1: 16 int8 weight codes
+    float4 ra_f[4];         // MODE 2: 16 fp32 gz
+    uint4 rb_u8;            // MODE 0/2: 16 u8 activation codes
+    float4 rb_f[4];         // MODE 1: 16 fp32 gz
+    float rb_scale = 0.0f;  // MODE 1: delta_w of this thread's k row
+
+    const int a_row = tid >> 1, a_k = (tid & 1) * 16;              // A tile: 128 rows x 32 k
+    const int bk_row = tid >> 3, bk_n = (tid & 7) * 16;            // B tile [k][n]: 32 k x 128 n
+    const int bn_row = tid >> 1, bn_k = (tid & 1) * 16;            // B tile [n][k] (wgrad): 128 n x 32 k
+
+    auto load_tiles = [&](int k0) {
+        if constexpr (MODE != 2) {
+            const signed char* A = (const signed char*)g.A;
+            ra_i8 = make_uint4(0, 0, 0, 0);
+            if (i0 + a_row < g.M && k0 + a_k < kend)
+                ra_i8 = *reinterpret_cast<const uint4*>(A + (int64_t)(i0 + a_row) * g.lda + k0 + a_k);
+        } else {
+            const float* A = (const float*)g.A + (int64_t)b * g.sAb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k = k0 + a_k + 4 * q;
+                if (i0 + a_row < g.M && k < kend) {
+                    v = *reinterpret_cast<const float4*>(A + (int64_t)(i0 + a_row) * g.lda + k);
+                    if (k + 1 >= kend) v.y = 0.f;
+                    if (k + 2 >= kend) v.z = 0.f;
+                    if (k + 3 >= kend) v.w = 0.f;
+                }
+                ra_f[q] = v;
+            }
+        }
+        if constexpr (MODE == 0) {
+            const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb;
+            rb_u8 = make_uint4(0, 0, 0, 0);
+            if (k0 + bk_row < kend && j0 + bk_n < g.N)
+                rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + j0 + bk_n);
+        } else if constexpr (MODE == 1) {
+            const float* Bp = (const float*)g.B + (int64_t)b * g.sBb;
+            const bool ok = (k0 + bk_row < kend);
+            rb_scale = ok ? g.dw[k0 + bk_row] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int n = j0 + bk_n + 4 * q;
+                if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + n);
+                rb_f[q] = v;
+            }
+        } else {
+            const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb;
+            rb_u8 = make_uint4(0, 0, 0, 0);
+            if (j0 + bn_row < g.N && k0 + bn_k < kend)
+                rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(j0 + bn_row) * g.ldb + k0 + bn_k);
+        }
+    };
+
+    auto store_u8x16 = [&](unsigned short* dst, uint4 v, bool is_signed) {
+        // 16 8-bit integers -> 16 bf16 (exact), two 16-B LDS stores
+        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+        unsigned short o[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int byte = (w[q] >> (8 * e)) & 0xFFu;
+                const float f = is_signed ? (float)(int)(signed char)byte : (float)byte;
+                o[4 * q + e] = f2bf_trunc(f);
+            }
+        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+        *reinterpret_cast<uint4*>(dst + 8) =
+            make_uint4(o[8] | (o[9] << 16), o[10] | (o[11] << 16), o[12] | (o[13] << 16), o[14] | (o[15] << 16));
+    };
+
+    auto store_split3 = [&](unsigned short* d1, unsigned short* d2, unsigned short* d3, const float4* v, float scale,
+                            bool do_scale) {
+        unsigned short o1[16], o2[16], o3[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = do_scale ? scale * x[e] : x[e];
+                split3(t, o1[4 * q + e], o2[4 * q + e], o3[4 * q + e]);
+            }
+        }
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel) {
+            const int o = 8 * hsel;
+            *reinterpret_cast<uint4*>(d1 + o) = make_uint4(o1[o] | (o1[o + 1] << 16), o1[o + 2] | (o1[o + 3] << 16),
+                                                           o1[o + 4] | (o1[o + 5] << 16), o1[o + 6] | (o1[o + 7] << 16));
+            *reinterpret_cast<uint4*>(d2 + o) = make_uint4(o2[o] | (o2[o + 1] << 16), o2[o + 2] | (o2[o + 3] << 16),
+                                                           o2[o + 4] | (o2[o + 5] << 16), o2[o + 6] | (o2[o + 7] << 16));
+            *reinterpret_cast<uint4*>(d3 + o) = make_uint4(o3[o] | (o3[o + 1] << 16), o3[o + 2] | (o3[o + 3] << 16),
+                                                           o3[o + 4] | (o3[o + 5] << 16), o3[o + 6] | (o3[o + 7] << 16));
+        }
+    };
+
+    auto store_tiles = [&]() {
+        if constexpr (MODE != 2) {
+            store_u8x16(&As[0][a_row][a_k], ra_i8, true);
+        } else {
+            store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], ra_f, 1.0f, false);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rowsum += (ra_f[q].x + ra_f[q].y) + (ra_f[q].z + ra_f[q].w);
+        }
+        if constexpr (MODE == 0) {
+            store_u8x16(&Bs[0][bk_row][bk_n], rb_u8, false);
+        } else if constexpr (MODE == 1) {
+            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, true);
+        } else {
+            store_u8x16(&Bs[0][bn_row][bn_k], rb_u8, false);
+        }
+    };
+
+    // ---------------------------------------------------------------- main loop
+    const int nkt = (kend - kbeg + QBK - 1) / QBK;
+    if (nkt > 0) {
+        load_tiles(kbeg);
+        store_tiles();
+    }
+    __syncthreads();
+    // lane geometry of the transposed read: 16-lane group gq reads a 4(k) x 16(n) block
+    const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * QBK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int sp = 0; sp < NSPLIT; ++sp) {
+                const int ia = (MODE == 2) ? sp : 0, ib = (MODE == 1) ? sp : 0;
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    af[mi] = *reinterpret_cast<const bf16x8*>(&As[ia][wm * 64 + mi * 32 + lr][ks * 16 + 8 * lh]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (MODE == 2) {
+                        bfr[ni] = *reinterpret_cast<const bf16x8*>(&Bs[ib][wn * 64 + ni * 32 + lr][ks * 16 + 8 * lh]);
+                    } else {
+                        // B[k = 8h + j][col r]: two transposed 4x16 block reads (rows 8h+0..3 and 8h+4..7)
+                        const int kr = ks * 16 + 8 * (gq >> 1) + tq;
+                        const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
+                        union { bf16x8 v; s16x4 h[2]; } u;
+                        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(&Bs[ib][kr][nc]));
+                        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(&Bs[ib][kr + 4][nc]));
+                        bfr[ni] = u.v;
+                    }
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    float dx = 0.f, mnx = 0.f;
+    if constexpr (MODE != 1) {
+        const float lo = *g.qmin_x, hi = *g.qmax_x;
+        dx = (hi - lo) / 255.0f;
+        mnx = lo;
+    }
+    __shared__ float rs[QBM];
+    if constexpr (MODE == 2) {
+        // row sums of this block's gz slice: the two threads of a row are adjacent lanes
+        const float tot = rowsum + __shfl_xor(rowsum, 1, 64);
+        if ((tid & 1) == 0) rs[a_row] = tot;
+        __syncthreads();
+    }
+    float* Cb = g.C + (int64_t)b * g.sCb;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = j0 + wn * 64 + ni * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = i0 + rl;
+                if (row < g.M && col < g.N) {
+                    const float S = acc[mi][ni][r];
+                    if constexpr (MODE == 0) {
+                        const float t = dx * S + mnx * g.rw[row];
+                        float v = g.dw[row] * t;
+                        if (g.bias != nullptr) v = v + g.bias[row];
+                        Cb[(int64_t)row * g.ldc + col] = v;
+                    } else if constexpr (MODE == 1) {
+                        Cb[(int64_t)row * g.ldc + col] = S;
+                    } else {
+                        atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * S + mnx * rs[rl]);
+                    }
+                }
+            }
+        }
+}
+
+// per-channel weight codes for the q-GEMMs: idx [Co][Ci], idxT [Ci][Co], dw[Co], rw[Co] (one block per channel)
+__global__ __launch_bounds__(256) void k_wq_codes(const float* __restrict__ w, signed char* __restrict__ idx,
+                                                   signed char* __restrict__ idxT, float* dw, float* rw, int Co, int Ci,
+                                                   const float* __restrict__ qmin, const float* __restrict__ qmax) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    const float a = fmaxf(fabsf(qmin[co]), fabsf(qmax[co]));
+    const float delta = (2.0f * a) / 255.0f;
+    float s = 0.0f;
+    for (int ci = threadIdx.x; ci < Ci; ci += 256) {
+        const float X = rintf(w[(int64_t)co * Ci + ci] / delta);
+        const float q = fminf(fmaxf(X, -128.0f), 127.0f);
+        idx[(int64_t)co * Ci + ci] = (signed char)q;
+        idxT[(int64_t)ci * Co + co] = (signed char)q;
+        s += q;   // |sum| <= 512*128 : exact in fp32
+    }
+    float v[1] = {s};
+    block_sum<float, 1>(v, red);
+    if (threadIdx.x == 0) {
+        dw[co] = delta;
+        rw[co] = v[0];
+    }
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_wq_codes(const float* w, int8_t* idx, int8_t* idxT, float* dw, float* rw, int Co, int Ci,
+                             const float* qmin, const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(w && idx && idxT && dw && rw && qmin && qmax && Co > 0 && Ci > 0, "bad args");
+    hipLaunchKernelGGL(k_wq_codes, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, w, (signed char*)idx,
+                       (signed char*)idxT, dw, rw, Co, Ci, qmin, qmax);
+    return launch_status("fqss_wq_codes");
+}
+
+extern "C" int fqss_qpw_fwd(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias,
+                            const float* qmin_x, const float* qmax_x, float* z, int B, int Ci, int Co, int M,
+                            int64_t ld_xc, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && wi && dw && rw && qmin_x && qmax_x && z, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_xc >= M && ld_z >= M, "bad shape");
+    FQSS_REQUIRE(Ci % 16 == 0 && Ci <= 512 && ld_xc % 16 == 0 && aligned16(xc) && aligned16(wi),
+                 "q-GEMM needs Ci % 16 == 0, Ci <= 512 (exact fp32 integer sum) and 16-B aligned code rows");
+    if (B == 0 || M == 0) return FQSS_OK;
+    QGemmArgs g{};
+    g.A = wi; g.B = xc; g.C = z; g.M = Co; g.N = M; g.K = Ci;
+    g.lda = Ci; g.ldb = ld_xc; g.ldc = ld_z;
+    g.sAb = 0; g.sBb = (int64_t)Ci * ld_xc; g.sCb = (int64_t)Co * ld_z;
+    g.dw = dw; g.rw = rw; g.bias = bias; g.qmin_x = qmin_x; g.qmax_x = qmax_x; g.ksplit = 1; g.kchunk = Ci;
+    dim3 grid((unsigned)cdiv(M, QBN), (unsigned)cdiv(Co, QBM), (unsigned)B);
+    hipLaunchKernelGGL((k_qgemm<0>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_qpw_fwd");
+}
+
+extern "C" int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* dw, float* gx, int B, int Ci, int Co,
+                              int M, int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && wiT && dw && gx, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_gx >= M, "bad shape");
+    FQSS_REQUIRE(Co % 16 == 0 && ld_gz % 4 == 0 && aligned16(gz) && aligned16(wiT) && (M % 4 == 0 || ld_gz >= ((M + 3) & ~3)),
+                 "q-GEMM dgrad needs Co % 16 == 0 and 16-B aligned gradient rows");
+    if (B == 0 || M == 0) return FQSS_OK;
+    QGemmArgs g{};
+    g.A = wiT; g.B = gz; g.C = gx; g.M = Ci; g.N = M; g.K = Co;
+    g.lda = Co; g.ldb = ld_gz; g.ldc = ld_gx;
+    g.sAb = 0; g.sBb = (int64_t)Co * ld_gz; g.sCb = (int64_t)Ci * ld_gx;
+    g.dw = dw; g.ksplit = 1; g.kchunk = Co;
+    dim3 grid((unsigned)cdiv(M, QBN), (unsigned)cdiv(Ci, QBM), (unsigned)B);
+    hipLaunchKernelGGL((k_qgemm<1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_qpw_bwd_x");
+}
+
+extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw,
+                              int B, int Ci, int Co, int M, int64_t ld_gz, int64_t ld_xc, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_xc >= M, "bad shape");
+    FQSS_REQUIRE(ld_gz % 4 == 0 && ld_xc % 16 == 0 && aligned16(gz) && aligned16(xc) && ld_gz >= ((M + 3) & ~3),
+                 "q-GEMM wgrad needs 16-B aligned gradient and code rows");
+    if (B == 0 || M == 0) return FQSS_OK;
+    QGemmArgs g{};
+    g.A = gz; g.B = xc; g.C = gw; g.M = Co; g.N = Ci; g.K = M;
+    g.lda = ld_gz; g.ldb = ld_xc; g.ldc = Ci;
+    g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_xc; g.sCb = 0;
+    g.qmin_x = qmin_x; g.qmax_x = qmax_x;
+    const int tiles = (int)(cdiv(Co, QBM) * cdiv(Ci, QBN));
+    int want = (int)cdiv(512, (int64_t)tiles * B);
+    if (want < 1) want = 1;
+    int kchunk = (int)cdiv(cdiv(M, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    g.kchunk = kchunk;
+    g.ksplit = (int)cdiv(M, kchunk);
+    dim3 grid((unsigned)cdiv(Ci, QBN), (unsigned)cdiv(Co, QBM), (unsigned)(B * g.ksplit));
+    hipLaunchKernelGGL((k_qgemm<2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_qpw_bwd_w");
+}

@@ -71,13 +71,24 @@ def as_rowmat(t):
 
 
 # ------------------------------------------------------------------ K1 / K3
-def actq_fwd(z, act, slope, qmode, qmin, qmax, obs_ws, want_idx=False):
+def empty_codes(shape, device):
+    """u8 activation codes [..., M] with rows padded to 16 B (the q-GEMM staging loads 16 codes/lane)"""
+    M = shape[-1]
+    ld = (M + 15) // 16 * 16
+    buf = torch.empty(*shape[:-1], ld, device=device, dtype=torch.uint8)
+    return buf[..., :M] if ld != M else buf
+
+
+def actq_fwd(z, act, slope, qmode, qmin, qmax, obs_ws, want_idx=False, dense_idx=False):
     _need_gpu(z, slope, qmin, qmax)
     z, rows, cols, ld_z = as_rowmat(z)
     out = empty_act(tuple(z.shape), z.device)
     _, _, _, ld_o = (out,) + rowmat(out)
-    idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if want_idx else None
-    _lib.call("fqss_actq_fwd", _p(z), _p(out), _p(idx), rows, cols, ld_z, ld_o, act, _p(slope), qmode,
+    idx, ld_i = None, cols
+    if want_idx:
+        idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if dense_idx else empty_codes(tuple(z.shape), z.device)
+        ld_i = rowmat(idx)[2]
+    _lib.call("fqss_actq_fwd", _p(z), _p(out), _p(idx), rows, cols, ld_z, ld_o, ld_i, act, _p(slope), qmode,
               _p(qmin), _p(qmax), _p(obs_ws), _stream())
     return (out, idx) if want_idx else out
 
@@ -186,6 +197,62 @@ def pwconv_bwd_w(gz, x, gw):
     x, _, Ci, _, ld_x = _bcm(x)
     assert gw.is_contiguous() and gw.numel() == Co * Ci
     _lib.call("fqss_pwconv_bwd_w", _p(gz), _p(x), _p(gw), B, Ci, Co, M, ld_gz, ld_x, _stream())
+
+
+# ------------------------------------------------------------------ K4q / K5q  grid-valued pointwise conv (bf16 MFMA)
+class WCodes:
+    """int8 codes of a fake-quantized pointwise weight: idx [Co][Ci], idxT [Ci][Co], dw[Co], rw[Co]"""
+    __slots__ = ("idx", "idxT", "dw", "rw", "Co", "Ci")
+
+
+def wq_codes(w, qmin, qmax):
+    _need_gpu(w, qmin, qmax)
+    Co, Ci = w.shape[0], w.shape[1]
+    assert w.numel() == Co * Ci and w.is_contiguous()
+    c = WCodes()
+    c.Co, c.Ci = Co, Ci
+    c.idx = torch.empty(Co, Ci, device=w.device, dtype=torch.int8)
+    c.idxT = torch.empty(Ci, Co, device=w.device, dtype=torch.int8)
+    c.dw = torch.empty(Co, device=w.device, dtype=torch.float32)
+    c.rw = torch.empty(Co, device=w.device, dtype=torch.float32)
+    _lib.call("fqss_wq_codes", _p(w), _p(c.idx), _p(c.idxT), _p(c.dw), _p(c.rw), Co, Ci, _p(qmin), _p(qmax), _stream())
+    return c
+
+
+def q_eligible(Ci, Co):
+    return Ci % 16 == 0 and Co % 16 == 0 and Ci <= 512
+
+
+def qpw_fwd(xc, wc, bias, qmin_x, qmax_x):
+    """xc: u8 codes [B,Ci,M] (padded rows) -> z fp32 [B,Co,M]"""
+    B, Ci, M = xc.shape
+    rm = rowmat(xc)
+    assert rm is not None and rm[2] % 16 == 0
+    z = empty_act((B, wc.Co, M), xc.device)
+    _lib.call("fqss_qpw_fwd", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias), _p(qmin_x), _p(qmax_x), _p(z),
+              B, Ci, wc.Co, M, rm[2], rowmat(z)[2], _stream())
+    return z
+
+
+def qpw_bwd_x(gz, wc):
+    gz, B, Co, M, ld_gz = _bcm(gz)
+    if ld_gz % 4 != 0 or gz.data_ptr() % 16 != 0:
+        c = empty_act(tuple(gz.shape), gz.device)
+        c.copy_(gz)
+        gz, ld_gz = c, rowmat(c)[2]
+    gx = empty_act((B, wc.Ci, M), gz.device)
+    _lib.call("fqss_qpw_bwd_x", _p(gz), _p(wc.idxT), _p(wc.dw), _p(gx), B, wc.Ci, Co, M, ld_gz, rowmat(gx)[2], _stream())
+    return gx
+
+
+def qpw_bwd_w(gz, xc, qmin_x, qmax_x, gw):
+    gz, B, Co, M, ld_gz = _bcm(gz)
+    if ld_gz % 4 != 0 or gz.data_ptr() % 16 != 0:
+        c = empty_act(tuple(gz.shape), gz.device)
+        c.copy_(gz)
+        gz, ld_gz = c, rowmat(c)[2]
+    Ci = xc.shape[1]
+    _lib.call("fqss_qpw_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), B, Ci, Co, M, ld_gz, rowmat(xc)[2], _stream())
 
 
 # ------------------------------------------------------------------ K6  depthwise conv

@@ -19,10 +19,32 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
+        self.idx = None     # u8 codes of the output produced by this call (QUANT mode)
+
+
+class ActCodes:
+    """u8 bin indices of a fake-quantized activation + the ranges of the quantizer that made them;
+    travels as the `_fqss_q` attribute of the fp32 tensor so that a consuming q-GEMM can use it"""
+    __slots__ = ("idx", "qmin", "qmax")
+
+    def __init__(self, idx, qmin, qmax):
+        self.idx, self.qmin, self.qmax = idx, qmin, qmax
+
+
+def tag_codes(y, q):
+    """attach the codes produced by the epilogue of this call to its output tensor"""
+    if q.idx is not None:
+        y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
+        q.idx = None
+    return y
+
+
+def codes_of(x):
+    return getattr(x, "_fqss_q", None)
 
 
 BYPASS = QCtx()
@@ -38,6 +60,9 @@ def _grad_buf(param, like):
 
 
 def _epilogue_fwd(z, act, slope, q):
+    if q.qmode == Q_QUANT:
+        out, q.idx = K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws, want_idx=True)
+        return out
     return K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws)
 
 
@@ -132,8 +157,14 @@ class LinearActQ(Function):
     """out = fq(act(linear(x, w) + bias))  -- Conv1dQ / Conv1dNlQ / Conv1dEncoderQ / decoder convT"""
 
     @staticmethod
-    def forward(ctx, x, w, bias, slope, qmin, qmax, L, act, q):
-        z = _lin_fwd(L, x, w, bias)
+    def forward(ctx, x, w, bias, slope, qmin, qmax, L, act, q, xq=None, wc=None):
+        # grid-valued operands (student, quantizing phase): exact bf16-MFMA GEMM on the codes
+        ctx.xq = xq if (L.kind == "pw" and xq is not None and K.q_eligible(w.shape[1], w.shape[0])) else None
+        ctx.wc = wc if (L.kind == "pw" and wc is not None and K.q_eligible(w.shape[1], w.shape[0])) else None
+        if ctx.xq is not None and ctx.wc is not None:
+            z = K.qpw_fwd(ctx.xq.idx, ctx.wc, bias, ctx.xq.qmin, ctx.xq.qmax)
+        else:
+            z = _lin_fwd(L, x, w, bias)
         ctx.plain = (q.qmode == Q_BYPASS and act == ACT_NONE)   # float linear op: no epilogue pass at all
         out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
         ctx.save_for_backward(x, w, None if ctx.plain else z, slope)
@@ -152,15 +183,20 @@ class LinearActQ(Function):
             gz, g_slope, g_min, g_max, g_bias = _epilogue_bwd(
                 g if ctx.plain else z, g, act, slope, L.slope_param, q, bias_param=L.b_param,
                 bias_like=ctx.bias_like if ctx.has_bias else None, C=ctx.C)
-        gx = _lin_bwd_x(L, gz, w, x.shape) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, x.shape)
         gw = None
         if ctx.needs_input_grad[1]:
             # w here is the fake-quantized weight (a non-leaf): its gradient always goes back through autograd
             gw = torch.zeros_like(w)
-            _lin_bwd_w(L, gz, x, gw)
+            if ctx.xq is not None:
+                K.qpw_bwd_w(gz, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
+            else:
+                _lin_bwd_w(L, gz, x, gw)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
-        return gx, gw, g_bias, g_slope, g_min, g_max, None, None, None
+        return gx, gw, g_bias, g_slope, g_min, g_max, None, None, None, None, None
 
 
 class GroupNormActQ(Function):
@@ -303,7 +339,11 @@ class Fork2(Function):
 
 def fork2(x):
     if torch.is_grad_enabled() and x.requires_grad:
-        return Fork2.apply(x)
+        a, b = Fork2.apply(x)
+        c = codes_of(x)
+        if c is not None:
+            a._fqss_q = b._fqss_q = c
+        return a, b
     return x, x
 
 

@@ -98,7 +98,7 @@ class AddQ(LayerQ):
         q = aq.qctx()
         y = ops.AddActQ.apply(x1, x2, q.qmin, q.qmax, 1.0, q)
         aq.after_forward(q)
-        return y
+        return ops.tag_codes(y, q)
 
 
 class SubQ(LayerQ):
@@ -172,10 +172,11 @@ def run_conv1d(conv, x, weight, nl, aq):
     act, slope = _act_of(nl)
     L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, slope
     q = aq.qctx() if aq is not None else ops.BYPASS
-    y = ops.LinearActQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q)
+    y = ops.LinearActQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q, ops.codes_of(x),
+                             getattr(weight, "_fqss_wcodes", None))
     if aq is not None:
         aq.after_forward(q)
-    return y
+    return ops.tag_codes(y, q)
 
 
 class Conv1dQ(LayerQ):
@@ -218,7 +219,7 @@ def run_groupnorm(gn, x, aq):
     y = ops.GroupNormActQ.apply(x, gn.weight, gn.bias, q.qmin, q.qmax, gn.eps, q, gn.weight, gn.bias)
     if aq is not None:
         aq.after_forward(q)
-    return y
+    return ops.tag_codes(y, q)
 
 
 def run_nl(nl, x, aq):
@@ -227,7 +228,7 @@ def run_nl(nl, x, aq):
     y = ops.NlActQ.apply(x, slope, q.qmin, q.qmax, act, q, slope)
     if aq is not None:
         aq.after_forward(q)
-    return y
+    return ops.tag_codes(y, q)
 
 
 class NlQ(LayerQ):

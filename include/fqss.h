@@ -56,10 +56,10 @@ const char* fqss_last_error(void);
  *           autograd of both; nn.PReLU / F.relu in front (qat_layers.py:211, 517)
  * ------------------------------------------------------------------------------------------- */
 
-/* out = fq(act(z)).  idx (optional, dense [rows][cols] u8) receives the integer bin index.
- * OBSERVE: out = act(z) and obs_ws[0..1] (ordered-uint min / max) are updated atomically.      */
+/* out = fq(act(z)).  idx (optional, u8 [rows][ld_idx]) receives the integer bin index (the codes
+ * the q-GEMMs consume).  OBSERVE: out = act(z) and obs_ws[0..1] (ordered-uint min / max) are updated. */
 int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols,
-                  int64_t ld_z, int64_t ld_out, int act, const float* slope, int qmode,
+                  int64_t ld_z, int64_t ld_out, int64_t ld_idx, int act, const float* slope, int qmode,
                   const float* qmin, const float* qmax, uint32_t* obs_ws, fqss_stream_t stream);
 
 /* obs_ws = {0xFFFFFFFF, 0}: must hold before the first OBSERVE launch of a call */
@@ -115,6 +115,26 @@ int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci,
 /* gw[Co][Ci] += sum_b gz[b] * x[b]^T */
 int fqss_pwconv_bwd_w(const float* gz, const float* x, float* gw, int B, int Ci, int Co, int M,
                       int64_t ld_gz, int64_t ld_x, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4q/K5q  the same pointwise conv for operands on 8-bit grids (student, quantizing phase), on the
+ * bf16 matrix cores (csrc/qgemm.hip):  z = dw[co]*(dx*sum_ci Wi*c + min_x*sum_ci Wi) + bias  -- the
+ * integer sum is exact in the fp32 accumulators.  Gradients are split exactly into 3 bf16 pieces.
+ *   xc : u8 activation codes [B][Ci][ld_xc] (fqss_actq_fwd idx), qmin_x/qmax_x its quantizer ranges
+ *   wi : int8 weight codes [Co][Ci], wiT [Ci][Co], dw[Co] = delta_w, rw[Co] = sum_ci Wi  (fqss_wq_codes)
+ * ------------------------------------------------------------------------------------------- */
+int fqss_wq_codes(const float* w, int8_t* idx, int8_t* idxT, float* dw, float* rw, int Co, int Ci,
+                  const float* qmin, const float* qmax, fqss_stream_t stream);
+int fqss_qpw_fwd(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw,
+                 const float* bias, const float* qmin_x, const float* qmax_x, float* z, int B, int Ci,
+                 int Co, int M, int64_t ld_xc, int64_t ld_z, fqss_stream_t stream);
+/* gx[b] = W_q^T gz[b] */
+int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* dw, float* gx, int B, int Ci,
+                   int Co, int M, int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
+/* gw[Co][Ci] += sum_b gz[b] x[b]^T   (gradient w.r.t. the fake-quantized weight) */
+int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
+                   float* gw, int B, int Ci, int Co, int M, int64_t ld_gz, int64_t ld_xc,
+                   fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  depthwise dilated Conv1d (groups = C): z[b][c][m] = bias[c] + sum_k w[c][k] x[b][c][m+k*dil-pad]

@@ -36,7 +36,7 @@ def test_golden_fq_act_bit_exact(golden):
     for i in range(int(g["n_cases"])):
         x = dev(g[f"x{i}"])
         lo, hi = dev(g[f"range{i}"][:1]), dev(g[f"range{i}"][1:])
-        y, idx = K.actq_fwd(x, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True)
+        y, idx = K.actq_fwd(x, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True, dense_idx=True)
         assert np.array_equal(idx.cpu().numpy(), g[f"idx{i}"])
         assert np.array_equal(y.cpu().numpy(), g[f"y{i}"])
         gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
@@ -69,7 +69,7 @@ def test_actq_vs_oracle(shape, act):
         gd = K.empty_act(shape, "cuda") if padded else torch.empty(shape, device="cuda")
         gd.copy_(g)
         sd = slope.cuda() if act == 1 else None
-        out, idx = K.actq_fwd(zd, act, sd, K.Q_QUANT, lo.cuda(), hi.cuda(), None, want_idx=True)
+        out, idx = K.actq_fwd(zd, act, sd, K.Q_QUANT, lo.cuda(), hi.cuda(), None, want_idx=True, dense_idx=True)
         assert torch.equal(idx.cpu(), idx_ref)
         assert torch.equal(out.cpu(), y.detach())
         gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
@@ -168,8 +168,8 @@ def test_full_size_properties():
     """cfg-2 sized tensor (8x512x3999): idempotence of the quantizer and index range."""
     x = torch.randn(8, 512, 3999, device="cuda")
     lo, hi = torch.tensor([-2.0], device="cuda"), torch.tensor([2.5], device="cuda")
-    y, idx = K.actq_fwd(x, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True)
-    y2, idx2 = K.actq_fwd(y, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True)
+    y, idx = K.actq_fwd(x, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True, dense_idx=True)
+    y2, idx2 = K.actq_fwd(y, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None, want_idx=True, dense_idx=True)
     assert torch.equal(idx, idx2)            # fq(fq(x)) has the same bins
     assert int((y2 - y).abs().max() * 1e7) <= 3   # and the same values up to 1 ulp of (delta*c+lo)
     delta = (hi - lo) / 255

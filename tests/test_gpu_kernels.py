@@ -208,3 +208,66 @@ def test_adam_clip_vs_torch():
         np.testing.assert_allclose(gn.item(), ref_norm.item(), rtol=1e-6)
         np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=1e-6, atol=1e-7)
     assert step.item() == 5
+
+
+# ---------------------------------------------------------------------------------------------
+# q-GEMMs: grid-valued pointwise conv on the bf16 matrix cores
+# ---------------------------------------------------------------------------------------------
+def _q_setup(B, Ci, Co, M, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    w = torch.randn(Co, Ci, 1, generator=gen) * Ci ** -0.5
+    wlo = -(torch.rand(Co, 1, 1, generator=gen) * 0.2 + 0.05)
+    whi = torch.rand(Co, 1, 1, generator=gen) * 0.2 + 0.05
+    xlo, xhi = torch.tensor([-0.731]), torch.tensor([1.913])
+    x = torch.randn(B, Ci, M, generator=gen) * 0.8 + 0.4
+    bias = torch.randn(Co, generator=gen)
+    wq = O.weight_quantize(w, wlo, whi)                 # reference fake-quant (fp32)
+    xq = O.act_quantize(x, xlo, xhi)
+    return w, wlo, whi, xlo, xhi, x, bias, wq, xq
+
+
+@pytest.mark.parametrize("B,Ci,Co,M", [(2, 16, 32, 77), (1, 128, 512, 333), (2, 512, 128, 999), (1, 128, 1024, 130), (3, 48, 80, 64)])
+def test_qgemm_fwd_bwd(B, Ci, Co, M):
+    w, wlo, whi, xlo, xhi, x, bias, wq, xq = _q_setup(B, Ci, Co, M, seed=Ci + Co)
+    wc = K.wq_codes(w.cuda().contiguous(), wlo.cuda(), whi.cuda())
+    assert torch.equal(wc.idx.cpu(), O.weight_indices(w, wlo, whi)[:, :, 0])
+    assert torch.equal(wc.idxT.cpu(), wc.idx.cpu().t())
+    _, xc = K.actq_fwd(padded(x), K.ACT_NONE, None, K.Q_QUANT, xlo.cuda(), xhi.cuda(), None, want_idx=True)
+    assert torch.equal(xc.cpu(), O.act_indices(x, xlo, xhi))
+    z = K.qpw_fwd(xc, wc, bias.cuda(), xlo.cuda(), xhi.cuda())
+    ref64 = F.conv1d(xq.double(), wq.double(), bias.double())
+    ref32 = F.conv1d(xq, wq, bias)
+    err_q = (z.cpu().double() - ref64).abs().max().item()
+    err_32 = (ref32.double() - ref64).abs().max().item()
+    assert err_q <= max(2e-6 * ref64.abs().max().item(), 0.75 * err_32 + 1e-7), (err_q, err_32)   # at least as exact as fp32 ATen
+    # backward
+    gz = rnd(B, Co, M, seed=11)
+    gx = K.qpw_bwd_x(padded(gz), wc)
+    gx_ref = torch.einsum("oc,bom->bcm", wq[:, :, 0].double(), gz.double())
+    close(gx.cpu().double(), gx_ref, rtol=1e-5, atol=2e-6 * float(gx_ref.abs().max()))
+    gw = torch.zeros(Co, Ci, device="cuda")
+    K.qpw_bwd_w(padded(gz), xc, xlo.cuda(), xhi.cuda(), gw)
+    gw_ref = torch.einsum("bom,bcm->oc", gz.double(), xq.double())
+    close(gw.cpu().double(), gw_ref, rtol=1e-5, atol=3e-6 * float(gw_ref.abs().max()))
+
+
+def test_qgemm_exact_integer_maps():
+    """A = I-like asymmetric integer codes: catches transposed fragments / wrong tr-read lane maps bit-exactly"""
+    B, Ci, Co, M = 1, 64, 96, 160
+    wi = ((torch.arange(Co * Ci).reshape(Co, Ci) * 7) % 23 - 11).float() + 20 * torch.eye(Co, Ci)
+    c = ((torch.arange(Ci * M).reshape(1, Ci, M) * 13) % 251).float()
+    # ranges chosen so that delta_w = 1 (2a/255 = 1) and delta_x = 1, min_x = 0  => z = sum Wi*c exactly
+    wlo, whi = torch.full((Co, 1, 1), -127.5), torch.full((Co, 1, 1), 127.5)
+    xlo, xhi = torch.tensor([0.0]), torch.tensor([255.0])
+    wc = K.wq_codes(wi.reshape(Co, Ci, 1).cuda().contiguous(), wlo.cuda(), whi.cuda())
+    assert torch.equal(wc.idx.cpu().float(), wi)
+    _, xc = K.actq_fwd(padded(c), K.ACT_NONE, None, K.Q_QUANT, xlo.cuda(), xhi.cuda(), None, want_idx=True)
+    assert torch.equal(xc.cpu().float(), c)
+    z = K.qpw_fwd(xc, wc, None, xlo.cuda(), xhi.cuda())
+    assert torch.equal(z.cpu(), torch.einsum("oc,bcm->bom", wi, c))
+    g = ((torch.arange(Co * M).reshape(1, Co, M) * 5) % 17 - 8).float()
+    gx = K.qpw_bwd_x(padded(g), wc)
+    assert torch.equal(gx.cpu(), torch.einsum("oc,bom->bcm", wi, g))
+    gw = torch.zeros(Co, Ci, device="cuda")
+    K.qpw_bwd_w(padded(g), xc, xlo.cuda(), xhi.cuda(), gw)
+    assert torch.equal(gw.cpu(), torch.einsum("bom,bcm->oc", g, c))
