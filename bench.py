@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -118,6 +119,9 @@ def main():
             model(x)
     assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
 
+    step(x, tgt)                       # first quantizing step, eager (starts the activation ranges' Adam clocks)
+    if not a.no_graph:
+        step.capture(x, tgt)           # whole step -> hipGraphs; every later call is a replay
     for _ in range(a.warmup):
         step(x, tgt)
     comm.barrier()
@@ -142,7 +146,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ConvTasNet 2spk 8 kHz W8A8 QAT step (cfg 2), batch 8 x 4 s per GPU, quantizing phase",
                        "global_batch": B_PER_GPU * comm.world, "segment_samples": T_SAMPLES, "parallelism": f"dp{comm.world}",
-                       "kd_lambda": 0.1, "optimizer": "adam lr 1e-3 + clip 5.0"},
+                       "kd_lambda": 0.1, "optimizer": "adam lr 1e-3 + clip 5.0",
+                       "launch": "eager" if a.no_graph else "hipGraph replay"},
             "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
             "step_algorithmic_GB": 74.8,
             "step_algorithmic_frac_of_hbm_peak": round(74.8 / (ms * 1e-3) / HBM_PEAK_GBS, 4),

@@ -57,8 +57,9 @@ class ParamArena:
             self._inactive = still
         self._host_step += 1
 
-    def clip_adam_step(self, lr, max_norm=5.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
-        self._activate_touched()
+    def clip_adam_step(self, lr, max_norm=5.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, activate=True):
+        if activate:
+            self._activate_touched()
         self.sumsq.zero_()
         K.sumsq(self.flat_g, self.sumsq)
         K.adam_clip(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.sumsq, self.step_t, self.gnorm,
@@ -68,7 +69,11 @@ class ParamArena:
 class KDTrainStep:
     """one QAT step = student fwd + teacher fwd + KD loss + bwd (+ grad all-reduce) + clip + Adam
     (reference: System.training_step / common_step, mysystem.py:124-157; Adam + clip 5.0,
-    asteroid_librimix_trainer.py:94,132)."""
+    asteroid_librimix_trainer.py:94,132).
+
+    `capture()` records the step into two hipGraphs (fwd+loss+bwd | clip+Adam) once the model has
+    left the observer phase; the step has no host sync, so replay needs no Python at all.  At N>1 the
+    RCCL all-reduce of the flat gradient buffer runs between the two graphs."""
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None):
         self.model, self.fmodel = model, fmodel
@@ -78,8 +83,11 @@ class KDTrainStep:
         for p in fmodel.parameters():
             p.requires_grad_(False)
         self.last = None
+        self._graphs = None
+        self._sx = self._st = None
 
-    def __call__(self, x, tgt):
+    # ---- the two halves of a step -----------------------------------------------------------
+    def _fwd_bwd(self, x, tgt):
         a = self.arena
         a.zero_grad()
         est = self.model(x)
@@ -87,10 +95,61 @@ class KDTrainStep:
             fest = self.fmodel(x)
         out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
         est.backward(gest)
-        scale = 1.0
-        if self.comm is not None and self.comm.world > 1:
-            self.comm.all_reduce_sum(a.flat_g)
-            scale = 1.0 / self.comm.world
-        a.clip_adam_step(self.lr, self.clip, scale)
-        self.last = dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
+        return dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
+
+    def _world(self):
+        return self.comm.world if self.comm is not None else 1
+
+    def _optimize(self, activate=True):
+        if activate:
+            self.arena._activate_touched()
+        self.arena.clip_adam_step(self.lr, self.clip, 1.0 / self._world(), activate=False)
+
+    def __call__(self, x, tgt):
+        if self._graphs is not None:
+            return self.replay(x, tgt)
+        self.last = self._fwd_bwd(x, tgt)
+        if self._world() > 1:
+            self.comm.all_reduce_sum(self.arena.flat_g)
+        self._optimize()
+        return self.last
+
+    # ---- hipGraph capture -------------------------------------------------------------------
+    def capture(self, x, tgt, warmup=2):
+        from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
+        for m in self.model.modules():
+            if isinstance(m, GradientActivationFakeQuantize):
+                assert not (m.observer_mode and m.n_iter < m.max_observations), "capture() needs the observer phase to be over"
+            if isinstance(m, GradientWeightFakeQuantize):
+                assert not m.observer_mode, "capture() needs the weight observers to have run"
+        self._sx, self._st = x.clone(), tgt.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):      # eager steps: activates every live parameter's Adam clock
+                self.last = self._fwd_bwd(self._sx, self._st)
+                if self._world() > 1:
+                    self.comm.all_reduce_sum(self.arena.flat_g)
+                self._optimize()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self.last = self._fwd_bwd(self._sx, self._st)
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self._optimize(activate=False)
+        self._graphs = (g1, g2)
+        return self
+
+    def replay(self, x=None, tgt=None):
+        if x is not None and x.data_ptr() != self._sx.data_ptr():
+            self._sx.copy_(x)
+            self._st.copy_(tgt)
+        g1, g2 = self._graphs
+        g1.replay()
+        if self._world() > 1:
+            self.comm.all_reduce_sum(self.arena.flat_g)
+        self.arena._host_step += 1
+        g2.replay()
         return self.last

@@ -307,3 +307,28 @@ def test_full_size_step_properties():
     assert len(grid_checked) == 6
     assert torch.isfinite(r["loss"]).item() and torch.isfinite(step.arena.flat_g).all().item()
     assert float(step.arena.flat_g.abs().max()) > 0
+
+
+def test_hipgraph_replay_matches_eager(golden):
+    """the captured step (two hipGraphs) must reproduce the eager step: same state in, same loss /
+    parameters out (the only run-to-run noise left is the fp32 atomics of the weight gradients)"""
+    from fqss_amd.runtime import KDTrainStep
+    g = golden("tiny_step")
+    x, tgt = T(g["x"]).cuda(), T(g["tgt"]).cuda()
+    runs = []
+    for use_graph in (False, True):
+        model, fmodel = _tiny_pair(g, prefix="s50.post_sd.")
+        _leave_observer(model)
+        step = KDTrainStep(model, fmodel)
+        losses = [step(x, tgt)["loss"].item()]          # eager step (all Adam clocks start)
+        if use_graph:
+            step.capture(x, tgt, warmup=1)
+        else:
+            step(x, tgt)
+        for _ in range(3):
+            losses.append(step(x, tgt)["loss"].item())
+        runs.append((losses, step.arena.flat_p.clone()))
+    (l0, p0), (l1, p1) = runs
+    np.testing.assert_allclose(l0[0], l1[0], rtol=1e-6)
+    np.testing.assert_allclose(l0[1:], l1[1:], atol=0.05)          # dB; chaotic after the first quantized update
+    assert float((p0 - p1).abs().max()) < 5e-3
