@@ -1,0 +1,72 @@
+"""`train(yml_path, device)` of the asteroid env (reference: asteroid_librimix_trainer.py:140-214),
+MI355X edition: same YAML keys (work_dir, model_cfg{,.quantization}, dataset_cfg, training_cfg), same
+outputs (conf.yml, latest_model.pth, best_model.pth = student state_dict), data-parallel over the
+GPUs of one node when launched with torch.distributed.run (one process per GPU, RCCL).
+
+Data: `dataset_cfg.name: synthetic` generates the seeded 2-speaker mixtures of the measurement
+contract.  The LibriMix CSV/soundfile reader is the reference's CPU data side."""
+import json
+import os
+
+import torch
+import yaml
+
+from ...data import synth_batch
+from ...parallel import Comm
+from ...utils import set_seed
+from ..train_utils import create_pretrained_model
+from .mysystem import System
+
+
+def _batches(dataset_cfg, training_cfg, comm, device, split):
+    if dataset_cfg.get("name") != "synthetic":
+        raise NotImplementedError("only dataset_cfg.name == 'synthetic' is built in; the LibriMix reader is a later §8(f) row")
+    sr = int(dataset_cfg.get("sample_rate", 16000) * dataset_cfg.get("resample", 0.5))
+    T = int(dataset_cfg.get("segment", 3) * sr)
+    n = int(dataset_cfg.get("steps_per_epoch" if split == "train" else "val_steps", 20 if split == "train" else 4))
+    B = training_cfg["batch_size"]
+    for i in range(n):
+        yield synth_batch(B, T, seed=(0 if split == "train" else 10_000) + i * comm.world + comm.rank, device=device)
+
+
+def train(yml_path, device):
+    if device == "cpu":
+        raise RuntimeError("fqss_amd is MI355X-only (no CPU fallback); the CPU checker lives in oracle/")
+    with open(yml_path) as f:
+        conf = yaml.safe_load(f)
+    work_dir, model_cfg, dataset_cfg = conf["work_dir"], conf["model_cfg"], conf["dataset_cfg"]
+    training_cfg = conf["training_cfg"]
+    set_seed(training_cfg.get("seed", 0))
+    comm = Comm.from_env("cuda")
+    dev = torch.device("cuda", comm.local_rank)
+    torch.cuda.set_device(dev)
+
+    model_cfg.update({"model_path": training_cfg.get("pretrained", None)})
+    model, fmodel = create_pretrained_model(model_cfg)
+    model.to(dev).train()
+    fmodel.to(dev).eval()
+    if comm.rank == 0:
+        os.makedirs(work_dir, exist_ok=True)
+        with open(os.path.join(work_dir, "conf.yml"), "w") as out:
+            for blk in (model_cfg, dataset_cfg, training_cfg):
+                yaml.safe_dump(blk, out)
+
+    opt = training_cfg.get("optim", {})
+    system = System(model, fmodel, training_cfg.get("kd_lambda", 0), lr=opt.get("lr", 1e-3), clip=5.0, comm=comm)
+    best, history = float("inf"), []
+    for epoch in range(training_cfg["epochs"]):
+        for i, batch in enumerate(_batches(dataset_cfg, training_cfg, comm, dev, "train")):
+            system.training_step(batch, i)
+        val = torch.stack([system.validation_step(b, i) for i, b in enumerate(_batches(dataset_cfg, training_cfg, comm, dev, "val"))]).mean()
+        comm.all_reduce_sum(val)
+        val = val.item() / comm.world
+        history.append({"epoch": epoch, "loss": system.logged["loss"].item(), "val_loss": val})
+        if comm.rank == 0:
+            print(json.dumps(history[-1]), flush=True)
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            torch.save(sd, os.path.join(work_dir, "latest_model.pth"))
+            if val < best:
+                best = val
+                torch.save(sd, os.path.join(work_dir, "best_model.pth"))
+    comm.barrier()
+    return history

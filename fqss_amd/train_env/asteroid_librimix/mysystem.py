@@ -1,0 +1,49 @@
+"""Training system of the asteroid env without the PyTorch-Lightning dependency.
+
+Keeps the step semantics of the reference's System (train_env/asteroid_librimix/mysystem.py):
+`common_step(batch, batch_nb, train)` -> (loss, kd_loss) with the SDR-weighted KD objective when
+`train and kd_lambda > 0`, the plain PIT SI-SDR loss otherwise; `training_step` / `validation_step`.
+The fast path used by the trainer is fqss_amd.runtime.KDTrainStep (flat-arena Adam, hipGraph)."""
+import torch
+
+from ...runtime import KDTrainStep
+from .wsdr import KDObjective, si_sdr
+
+
+class System:
+    default_monitor = "val_loss"
+
+    def __init__(self, model, fmodel, kd_lambda, lr=1e-3, clip=5.0, comm=None):
+        self.model = model
+        self.fmodel = fmodel if kd_lambda > 0 else None
+        self.kd_lambda = kd_lambda
+        self.objective = KDObjective(kd_lambda)
+        self.stepper = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip, comm=comm) if kd_lambda > 0 else None
+        self.logged = {}
+
+    def forward(self, *a, **k):
+        return self.model(*a, **k)
+
+    __call__ = forward
+
+    def common_step(self, batch, batch_nb, train=True):
+        inputs, targets = batch
+        est = self(inputs)
+        if train and self.kd_lambda > 0:
+            with torch.no_grad():
+                fest = self.fmodel(inputs)
+            loss, kd_db, _, _ = self.objective(est, fest, targets)
+            return loss, kd_db
+        return -si_sdr(est, targets).mean(), 0
+
+    def training_step(self, batch, batch_nb):
+        """one optimiser step through the fused runtime; logs `loss` / `kd_loss` like the reference"""
+        r = self.stepper(*batch)
+        self.logged.update(loss=r["loss"], kd_loss=r["kd_loss"])
+        return r["loss"]
+
+    def validation_step(self, batch, batch_nb):
+        with torch.no_grad():
+            loss, _ = self.common_step(batch, batch_nb, train=False)
+        self.logged.update(val_loss=loss)
+        return loss
