@@ -104,8 +104,9 @@ def main():
 
     comm = Comm.from_env("cuda")
     assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
-    torch.cuda.set_device(comm.local_rank)
-    dev = torch.device("cuda", comm.local_rank)
+    ldev = comm.local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(ldev)
+    dev = torch.device("cuda", ldev)
 
     model, fmodel = build_pair(dev, 0, n_spks=2, kernel_size=16, stride=8)   # same init on every rank
     x, tgt = synth_batch(B_PER_GPU, T_SAMPLES, seed=100 + comm.rank, device=dev)   # per-rank shard (weak scaling)
@@ -120,8 +121,26 @@ def main():
     assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
 
     step(x, tgt)                       # first quantizing step, eager (starts the activation ranges' Adam clocks)
+    launch = "eager"
     if not a.no_graph:
         step.capture(x, tgt)           # whole step -> hipGraphs; every later call is a replay
+        launch = "hipGraph replay"
+        if comm.world > 1:
+            # RCCL between two graph replays cannot be exercised on the 1-GPU dev box: self-calibrate (untimed)
+            # and keep whichever launch mode is faster on THIS node; all ranks take the same decision.
+            t = []
+            for mode in (True, False):
+                step.use_graph = mode
+                step(x, tgt)
+                comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(2):
+                    step(x, tgt)
+                torch.cuda.synchronize()
+                d = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                comm.all_reduce_max(d)
+                t.append(d.item())
+            step.use_graph = t[0] <= t[1]
+            launch = "hipGraph replay" if step.use_graph else "eager (graph replay slower on this node)"
     for _ in range(a.warmup):
         step(x, tgt)
     comm.barrier()
@@ -147,7 +166,7 @@ def main():
             "config": {"workload": "ConvTasNet 2spk 8 kHz W8A8 QAT step (cfg 2), batch 8 x 4 s per GPU, quantizing phase",
                        "global_batch": B_PER_GPU * comm.world, "segment_samples": T_SAMPLES, "parallelism": f"dp{comm.world}",
                        "kd_lambda": 0.1, "optimizer": "adam lr 1e-3 + clip 5.0",
-                       "launch": "eager" if a.no_graph else "hipGraph replay"},
+                       "launch": launch},
             "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
             "step_algorithmic_GB": 74.8,
             "step_algorithmic_frac_of_hbm_peak": round(74.8 / (ms * 1e-3) / HBM_PEAK_GBS, 4),

@@ -24,9 +24,10 @@ class Comm:
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = "nccl" if device_type == "cuda" else "gloo"
+            # RCCL ("nccl" on ROCm) on GPUs; FQSS_DIST_BACKEND=gloo lets several ranks share one GPU in tests
+            backend = os.environ.get("FQSS_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
             if device_type == "cuda":
-                torch.cuda.set_device(local)
+                torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
             return cls(rank, world, local, backend)
         return cls(rank, world, local, dist.get_backend() if dist.is_initialized() else None)

@@ -84,6 +84,7 @@ class KDTrainStep:
             p.requires_grad_(False)
         self.last = None
         self._graphs = None
+        self.use_graph = True
         self._sx = self._st = None
 
     # ---- the two halves of a step -----------------------------------------------------------
@@ -106,7 +107,7 @@ class KDTrainStep:
         self.arena.clip_adam_step(self.lr, self.clip, 1.0 / self._world(), activate=False)
 
     def __call__(self, x, tgt):
-        if self._graphs is not None:
+        if self._graphs is not None and self.use_graph:
             return self.replay(x, tgt)
         self.last = self._fwd_bwd(x, tgt)
         if self._world() > 1:
