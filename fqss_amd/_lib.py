@@ -11,6 +11,7 @@ P, I64, I32, F32, F64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double
 _PROTOS = {
     "fqss_version": [],
     "fqss_last_error": [],
+    "fqss_selftest_div": [P, I64, F32, P, P],
     "fqss_actq_fwd": [P, P, P, I64, I64, I64, I64, I64, I32, P, I32, P, P, P, P],
     "fqss_obs_reset": [P, I64, P],
     "fqss_observer_ema": [P, P, P, F64, P],
@@ -21,12 +22,19 @@ _PROTOS = {
     "fqss_wq_bwd": [P, P, P, P, P, I64, I64, I64, P, P, I32, P],
     "fqss_gacc_flush": [P, P, P, P, P],
     "fqss_pwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_pwconv_fwd_x3": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_wq_codes": [P, P, P, P, P, I32, I32, P, P, P],
     "fqss_qpw_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_x": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_decode": [P, P, I64, I64, I64, I64, P, P, P],
+    "fqss_gnq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P],
+    "fqss_gnq_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],
+    "fqss_dwq_fwd": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P],
+    "fqss_dwq_bwd_z": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],
+    "fqss_dwq_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_dwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_dwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_dwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],

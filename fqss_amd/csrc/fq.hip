@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
                                                    const float* __restrict__ qmin,
                                                    const float* __restrict__ qmax, uint32_t* obs) {
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
-    QRange r{0.0f, 1.0f};
+    QRange r{0.0f, 1.0f, 1.0f};
     if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
     float vmin = INFINITY, vmax = -INFINITY;
     const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
                 }
             }
             if constexpr (VEC == 4) {
-                *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (out != nullptr) *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
                 if (qmode == FQSS_Q_QUANT && idx != nullptr && (ld_i & 3) == 0)
                     *reinterpret_cast<unsigned int*>(idx + row * ld_i + c0) = packed;
             } else {
-                orow[c0] = o[0];
+                if (out != nullptr) orow[c0] = o[0];
             }
         }
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
     __shared__ double red[3 * 4];
     __shared__ float redf[4];
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
-    QRange r{0.0f, 1.0f};
+    QRange r{0.0f, 1.0f, 1.0f};
     if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
     float p_du = 0.0f;    // sum g*(c - m*u)
     float p_out = 0.0f;   // sum g*(1-m)
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
                         float c, u;
                         bool inr;
                         (void)fq_asym(t, r, c, u, inr);
-                        gt = inr ? (gj * r.delta) / r.delta : 0.0f;
+                        gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
                         if (valid) {
                             p_du += gj * (inr ? (c - u) : c);
                             p_out += inr ? 0.0f : gj;
@@ -359,6 +359,17 @@ __global__ __launch_bounds__(256) void k_gacc_flush(double* gacc, float* gmin, f
     }
 }
 
+// brute-force self test: count elements where div_by differs from the IEEE division (bitwise)
+__global__ void k_selftest_div(const float* __restrict__ a, int64_t n, float b, unsigned long long* mism) {
+    const float y = 1.0f / b;
+    unsigned long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float q0 = a[i] / b, q1 = div_by(a[i], b, y);
+        m += (__float_as_uint(q0) != __float_as_uint(q1)) ? 1ull : 0ull;
+    }
+    if (m) atomicAdd(mism, m);
+}
+
 }  // namespace fqss
 
 // =============================================================================================
@@ -367,13 +378,21 @@ __global__ __launch_bounds__(256) void k_gacc_flush(double* gacc, float* gmin, f
 using namespace fqss;
 
 extern "C" int fqss_version(void) { return FQSS_VERSION; }
+
+extern "C" int fqss_selftest_div(const float* a, int64_t n, float b, uint64_t* mismatches, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && mismatches && n >= 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_selftest_div, dim3(2048), dim3(256), 0, (hipStream_t)stream, a, n, b, (unsigned long long*)mismatches);
+    return launch_status("fqss_selftest_div");
+}
 extern "C" const char* fqss_last_error(void) { return fqss::g_err; }
 
 extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols, int64_t ld_z,
                              int64_t ld_out, int64_t ld_idx, int act, const float* slope, int qmode, const float* qmin,
                              const float* qmax, uint32_t* obs_ws, fqss_stream_t stream) {
-    FQSS_REQUIRE(z && out, "null tensor");
+    FQSS_REQUIRE(z && (out || (idx && qmode == FQSS_Q_QUANT)), "null tensor");
     FQSS_REQUIRE(!idx || ld_idx >= cols, "bad ld_idx");
+    if (!out) ld_out = ld_z;
     FQSS_REQUIRE(!idx || (ld_idx & 3) != 0 || (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, "idx rows must be 4-B aligned");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_out >= cols, "bad shape");
     FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
@@ -381,7 +400,7 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
     if (rows == 0 || cols == 0) return FQSS_OK;
-    const bool vec = aligned16(z) && aligned16(out) && (ld_z % 4 == 0) && (ld_out % 4 == 0);
+    const bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
     if (vec) {
         hipLaunchKernelGGL(k_actq_fwd<4>, grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,

@@ -93,14 +93,24 @@ __device__ __forceinline__ void block_sum(T (&v)[N], T* smem) {
 
 // ---- the quantizer arithmetic, op for op (qat_quant.py:139-146) ----
 struct QRange {
-    float lo, delta;
+    float lo, delta, inv;   // inv = RN(1/delta), one IEEE division per thread
 };
 __device__ __forceinline__ QRange load_qrange(const float* qmin, const float* qmax) {
     const float lo = *qmin, hi = *qmax;
     QRange r;
     r.lo = lo;
     r.delta = (hi - lo) / 255.0f;  // fp32 sub, IEEE fp32 div
+    r.inv = 1.0f / r.delta;        // correctly rounded reciprocal (IEEE division)
     return r;
+}
+// Correctly rounded a/b in 3 instructions given y = RN(1/b) (Markstein: q = RN(a*y), r = a - b*q exactly by
+// fma, RN(q + r*y) is the correctly rounded quotient; valid away from overflow/underflow).  The divisor
+// (delta) is uniform per tensor, so the ~12-instruction IEEE sequence is paid once per thread instead of
+// once per element.  Bit-equality with the IEEE division is brute-force checked on the GPU (tests/test_gpu_fq.py).
+__device__ __forceinline__ float div_by(float a, float b, float y) {
+    const float q = a * y;
+    const float r = fmaf(-b, q, a);
+    return fmaf(r, y, q);
 }
 __device__ __forceinline__ float act_apply(float z, int act, float slope) {
     if (act == FQSS_ACT_PRELU) return z > 0.0f ? z : slope * z;  // ATen prelu kernel
@@ -109,10 +119,10 @@ __device__ __forceinline__ float act_apply(float z, int act, float slope) {
 }
 // returns the de-quantised value, c = clamped integer index as float, u = pre-round coordinate
 __device__ __forceinline__ float fq_asym(float t, const QRange& r, float& c, float& u, bool& inr) {
-    u = (t - r.lo) / r.delta;   // true division (x*(1/delta) flips 2.7 ppm of indices)
+    u = div_by(t - r.lo, r.delta, r.inv);   // == (t-lo)/delta, correctly rounded (x*(1/delta) alone flips 2.7 ppm of indices)
     const float X = rintf(u);   // v_rndne_f32: round-half-to-even == torch.round
     inr = (X >= 0.0f) && (X <= 255.0f);
-    c = fminf(fmaxf(X, 0.0f), 255.0f);
+    c = __builtin_amdgcn_fmed3f(X, 0.0f, 255.0f);
     return r.delta * c + r.lo;  // two roundings (mul, add): contraction is off
 }
 

@@ -1,0 +1,547 @@
+// fused_q.hip -- "codes-only" streaming layers of the student in the quantizing phase.
+//
+// Every LayerQ output is a per-tensor 8-bit code c with (delta, min); its fp32 value delta*c + min is
+// recomputed on load (bit-identical to what the producer's epilogue would have stored).  So a layer
+//   reads  u8 codes (1 B/elem instead of 4),
+//   fuses  its own non-linearity + fake-quant epilogue and writes u8 codes (1 B/elem instead of 4+4+1),
+//   saves  nothing for the backward: the pre-quant value z is recomputed there from the input codes.
+// GroupNormQ drops from 53 to 17 HBM bytes per element (fwd+bwd), the depthwise Conv1dNlQ from 45 to 24.
+//
+//   fqss_gnq_fwd / fqss_gnq_bwd      GroupNorm(1,C) + fake-quant          (qat_layers.py:445-448, qat_quant.py:136-147)
+//   fqss_dwq_fwd / fqss_dwq_bwd_z    depthwise dilated conv + PReLU + fake-quant (convtasnetq.py:28-30)
+//   fqss_decode                      codes -> fp32 (fallback for consumers without a coded-input kernel)
+// Statistics of a coded tensor are exact integer sums (sum c, sum c^2 in int64).
+#include "fqss_dev.h"
+
+namespace fqss {
+
+constexpr int kGnSlots = 64;       // partial-sum slots per sample (one per stats workgroup)
+constexpr int kSlots = FQSS_GACC_SLOTS;
+
+__device__ __forceinline__ float dec(unsigned int c, const QRange& r) { return r.delta * (float)c + r.lo; }
+
+// ---------------------------------------------------------------------------------------------
+// codes -> fp32
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ c, float* __restrict__ out, int64_t rows,
+                                                 int64_t cols, int64_t ld_c, int64_t ld_o, const float* qmin,
+                                                 const float* qmax) {
+    const QRange r = load_qrange(qmin, qmax);
+    const int64_t cstep = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y)
+        for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; c0 < cols; c0 += cstep) {
+            const unsigned int w = *reinterpret_cast<const unsigned int*>(c + row * ld_c + c0);
+            *reinterpret_cast<float4*>(out + row * ld_o + c0) =
+                make_float4(dec(w & 255u, r), dec((w >> 8) & 255u, r), dec((w >> 16) & 255u, r), dec(w >> 24, r));
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(1, C) on coded input
+// ---------------------------------------------------------------------------------------------
+// stats: exact integer partial sums of one sample per workgroup slot: ws[(b*kGnSlots + blk)*2 + {0,1}] (int64 as double bits)
+__global__ __launch_bounds__(256) void k_gnq_stats(const uint8_t* __restrict__ xc, int C, int M, int64_t ld_c,
+                                                    long long* ws) {
+    __shared__ long long red[2 * 4];
+    const int b = blockIdx.y;
+    long long s = 0, ss = 0;
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        const uint8_t* xr = xc + ((int64_t)b * C + c) * ld_c;
+        for (int m = threadIdx.x * 16; m < M; m += 256 * 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(xr + m);
+            const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+            unsigned int ls = 0, lss = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int cv = (m + 4 * q + e < M) ? ((w[q] >> (8 * e)) & 255u) : 0u;
+                    ls += cv;
+                    lss += cv * cv;
+                }
+            s += ls;
+            ss += lss;
+        }
+    }
+    long long v[2] = {s, ss};
+    block_sum<long long, 2>(v, red);
+    if (threadIdx.x == 0) {
+        ws[((int64_t)b * kGnSlots + blockIdx.x) * 2] = v[0];
+        ws[((int64_t)b * kGnSlots + blockIdx.x) * 2 + 1] = v[1];
+    }
+}
+
+// mean / rstd of the DECODED tensor from the exact integer sums: one tiny workgroup per sample
+__global__ __launch_bounds__(64) void k_gnq_finalize(const long long* ws, int nslots, int64_t n, float eps, float* mean_rstd,
+                                                      const float* qmin_x, const float* qmax_x) {
+    const QRange rx = load_qrange(qmin_x, qmax_x);
+    const int b = blockIdx.x, lane = threadIdx.x;
+    long long s = 0, ss = 0;
+    if (lane < nslots) {
+        s = ws[((int64_t)b * kGnSlots + lane) * 2];
+        ss = ws[((int64_t)b * kGnSlots + lane) * 2 + 1];
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const double mc = (double)s / (double)n;
+        double vc = (double)ss / (double)n - mc * mc;
+        if (vc < 0.0) vc = 0.0;
+        const double d = (double)rx.delta;
+        mean_rstd[2 * b] = (float)(d * mc + (double)rx.lo);
+        mean_rstd[2 * b + 1] = (float)(1.0 / sqrt(d * d * vc + (double)eps));
+    }
+}
+
+// y = fq( decode(x)*scale + shift ) -> codes (and fp32 out when asked); 16 elements per thread
+__global__ __launch_bounds__(256) void k_gnq_apply(const uint8_t* __restrict__ xc, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, uint8_t* __restrict__ yc,
+                                                    float* __restrict__ yout, const float* __restrict__ mean_rstd, int B, int C,
+                                                    int M, int64_t ld_xc, int64_t ld_yc, int64_t ld_o, const float* qmin_x,
+                                                    const float* qmax_x, const float* qmin, const float* qmax) {
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const int rows = B * C;
+    const int cstep = gridDim.x * 256 * 16;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = row / C, c = row - b * C;
+        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+        const float scale = rstd * gamma[c];
+        const float shift = fmaf(-scale, mean, beta[c]);
+        const uint8_t* xr = xc + (int64_t)row * ld_xc;
+        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 16; c0 < M; c0 += cstep) {
+            const uint4 v = *reinterpret_cast<const uint4*>(xr + c0);
+            const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned int pk = 0;
+                float fo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = fmaf(dec((w[q] >> (8 * e)) & 255u, rx), scale, shift);
+                    float cq, u;
+                    bool inr;
+                    fo[e] = fq_asym(z, ry, cq, u, inr);
+                    pk |= ((unsigned int)cq & 255u) << (8 * e);
+                }
+                o[q] = pk;
+                if (yout != nullptr && c0 + 4 * q < M)
+                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + c0 + 4 * q) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+            }
+            *reinterpret_cast<uint4*>(yc + (int64_t)row * ld_yc + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// backward pass 1: per (b,c) row: recompute z and the STE, ds = sum gz*x, db = sum gz; range partials to gacc slots
+__global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict__ xc, const float* __restrict__ g,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean_rstd, int C, int M, int64_t ld_xc,
+                                                       int64_t ld_g, double* ws, const float* qmin_x, const float* qmax_x,
+                                                       const float* qmin, const float* qmax, double* gacc) {
+    __shared__ double red[4 * 4];
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int64_t row = (int64_t)b * C + c;
+    const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+    const float scale = rstd * gamma[c];
+    const float shift = fmaf(-scale, mean, beta[c]);
+    const uint8_t* xr = xc + row * ld_xc;
+    const float* gr = g + row * ld_g;
+    float ds = 0.f, db = 0.f, p_du = 0.f, p_out = 0.f;
+    for (int m = threadIdx.x * 4; m < M; m += 256 * 4) {
+        const unsigned int w = *reinterpret_cast<const unsigned int*>(xr + m);
+        const float4 gv4 = *reinterpret_cast<const float4*>(gr + m);
+        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (m + e < M) {
+                const float x = dec((w >> (8 * e)) & 255u, rx);
+                const float z = fmaf(x, scale, shift);
+                float cq, u;
+                bool inr;
+                (void)fq_asym(z, ry, cq, u, inr);
+                const float gz = inr ? div_by(gv[e] * ry.delta, ry.delta, ry.inv) : 0.0f;
+                p_du += gv[e] * (inr ? (cq - u) : cq);
+                p_out += inr ? 0.0f : gv[e];
+                ds = fmaf(gz, x, ds);
+                db += gz;
+            }
+        }
+    }
+    double v[4] = {(double)ds, (double)db, (double)p_du, (double)p_out};
+    block_sum<double, 4>(v, red);
+    if (threadIdx.x == 0) {
+        ws[2 * row] = v[0];
+        ws[2 * row + 1] = v[1];
+        double* slot = gacc + 3 * (row % kSlots);
+        const double dmax = v[2] / 255.0;
+        atomicAdd(&slot[0], v[3] - dmax);   // rows share slots modulo kSlots: few adders per address, order-insensitive in fp64
+        atomicAdd(&slot[1], dmax);
+    }
+}
+
+// backward pass 3: gx = gz*(gamma*rstd) + x*c2 + c3 with gz recomputed from (x codes, g)
+__global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict__ xc, const float* __restrict__ g,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean_rstd, float* __restrict__ gx, int B,
+                                                        int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx,
+                                                        const double* ws, const float* qmin_x, const float* qmax_x,
+                                                        const float* qmin, const float* qmax) {
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const double* coef = ws + 2 * (int64_t)B * C;
+    const int rows = B * C;
+    const int cstep = gridDim.x * 256 * 4;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = row / C, c = row - b * C;
+        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+        const float scale = rstd * gamma[c];
+        const float shift = fmaf(-scale, mean, beta[c]);
+        const float c2 = (float)coef[2 * b], c3 = (float)coef[2 * b + 1];
+        const uint8_t* xr = xc + (int64_t)row * ld_xc;
+        const float* gr = g + (int64_t)row * ld_g;
+        float* orow = gx + (int64_t)row * ld_gx;
+        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += cstep) {
+            const unsigned int w = *reinterpret_cast<const unsigned int*>(xr + c0);
+            const float4 gv4 = *reinterpret_cast<const float4*>(gr + c0);
+            const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = dec((w >> (8 * e)) & 255u, rx);
+                const float z = fmaf(x, scale, shift);
+                float cq, u;
+                bool inr;
+                (void)fq_asym(z, ry, cq, u, inr);
+                const float gz = inr ? div_by(gv[e] * ry.delta, ry.delta, ry.inv) : 0.0f;
+                o[e] = fmaf(gz, scale, fmaf(x, c2, c3));
+            }
+            *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise dilated conv + PReLU/none + fake-quant on coded input
+// ---------------------------------------------------------------------------------------------
+constexpr int kTaps = 8;
+
+// the 4 codes xr[s0..s0+3] of a row for any (negative / unaligned) s0: two aligned word loads + v_alignbyte
+// (bytes outside [0, ld) read as 0; the caller masks elements outside [0, M))
+__device__ __forceinline__ unsigned int load_codes4(const uint8_t* __restrict__ xr, int s0, int ld) {
+    const int a0 = s0 & ~3;
+    const unsigned int sh = (unsigned int)(s0 - a0);
+    const unsigned int lo = (a0 >= 0 && a0 < ld) ? *reinterpret_cast<const unsigned int*>(xr + a0) : 0u;
+    if (sh == 0) return lo;
+    const unsigned int hi = (a0 + 4 >= 0 && a0 + 4 < ld) ? *reinterpret_cast<const unsigned int*>(xr + a0 + 4) : 0u;
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
+// z[m..m+3] from the coded row (zero padding)
+__device__ __forceinline__ void dwq_z4(const uint8_t* __restrict__ xr, int m, int M, int ld_c, const float* wk, int K,
+                                        int dil, int pad, float bv, const QRange& rx, float (&z)[4]) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+        if (k < K) {
+            const int s0 = m + k * dil - pad;
+            float v[4];
+            const unsigned int w = load_codes4(xr, s0, ld_c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? dec((w >> (8 * j)) & 255u, rx) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = acc[j] + bv;
+}
+
+__global__ __launch_bounds__(256) void k_dwq_fwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, uint8_t* __restrict__ yc,
+                                                  float* __restrict__ yout, int rows, int C, int M, int K, int dil, int pad,
+                                                  int ld_xc, int ld_yc, int ld_o, int act, const float* slope_p,
+                                                  const float* qmin_x, const float* qmax_x, const float* qmin,
+                                                  const float* qmax) {
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int c = row % C;
+        float wk[kTaps];
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+        const float bv = bias ? bias[c] : 0.0f;
+        const uint8_t* xr = xc + (int64_t)row * ld_xc;
+        uint8_t* yr = yc + (int64_t)row * ld_yc;
+        for (int m0 = (blockIdx.x * 256 + threadIdx.x) * 16; m0 < M; m0 += gridDim.x * 256 * 16) {
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 4 * q;
+                float z[4], fo[4];
+                dwq_z4(xr, m, M, ld_xc, wk, K, dil, pad, bv, rx, z);
+                unsigned int pk = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float cq, u;
+                    bool inr;
+                    fo[j] = fq_asym(act_apply(z[j], act, slope), ry, cq, u, inr);
+                    pk |= ((unsigned int)cq & 255u) << (8 * j);
+                }
+                o[q] = pk;
+                if (yout != nullptr && m < M)
+                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + m) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+            }
+            *reinterpret_cast<uint4*>(yr + m0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// backward: recompute z, STE + PReLU -> gz (fp32), bias row-sums, range/slope partials (gacc slots)
+__global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ xc, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, const float* __restrict__ g,
+                                                    float* __restrict__ gz, int B, int C, int M, int K, int dil, int pad,
+                                                    int64_t ld_xc, int64_t ld_g, int64_t ld_gz, int act, const float* slope_p,
+                                                    const float* qmin_x, const float* qmax_x, const float* qmin,
+                                                    const float* qmax, double* gacc, float* gbias) {
+    __shared__ double red[3 * 4];
+    __shared__ float redf[4];
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    const int cstep = gridDim.x * 256 * 4;
+    float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        float wk[kTaps];
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+        const float bv = bias ? bias[c] : 0.0f;
+        float p_bias = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int64_t row = (int64_t)b * C + c;
+            const uint8_t* xr = xc + row * ld_xc;
+            for (int m = (blockIdx.x * 256 + threadIdx.x) * 4; m < M; m += cstep) {
+                float z[4], o[4];
+                dwq_z4(xr, m, M, (int)ld_xc, wk, K, dil, pad, bv, rx, z);
+                const float4 gv4 = *reinterpret_cast<const float4*>(g + row * ld_g + m);
+                const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool valid = (m + j < M);
+                    const float gj = valid ? gv[j] : 0.0f;
+                    const float t = act_apply(z[j], act, slope);
+                    float cq, u;
+                    bool inr;
+                    (void)fq_asym(t, ry, cq, u, inr);
+                    const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+                    if (valid) {
+                        p_du += gj * (inr ? (cq - u) : cq);
+                        p_out += inr ? 0.0f : gj;
+                    }
+                    float gzj = gt;
+                    if (act == FQSS_ACT_PRELU) {
+                        const bool pos = z[j] > 0.0f;
+                        gzj = pos ? gt : slope * gt;
+                        if (valid && !pos) p_slope += z[j] * gt;
+                    } else if (act == FQSS_ACT_RELU) {
+                        gzj = (t > 0.0f) ? gt : 0.0f;
+                    }
+                    o[j] = gzj;
+                    if (valid) p_bias += gzj;
+                }
+                *reinterpret_cast<float4*>(gz + row * ld_gz + m) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (gbias != nullptr) {
+            float pb[1] = {p_bias};
+            block_sum<float, 1>(pb, redf);
+            if (threadIdx.x == 0) atomicAdd(&gbias[c], pb[0]);
+        }
+    }
+    double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
+    block_sum<double, 3>(v, red);
+    if (threadIdx.x == 0) {
+        double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+        const double dmax = v[0] / 255.0;
+        slot[0] += v[1] - dmax;
+        slot[1] += dmax;
+        slot[2] += v[2];
+    }
+}
+
+// gw[c][k] += sum_{b,m} gz[b][c][m] * decode(x[b][c][m + k*dil - pad])   ; grid (C, B), 4 m per thread
+__global__ __launch_bounds__(256) void k_dwq_bwd_w(const float* __restrict__ gz, const uint8_t* __restrict__ xc, float* gw,
+                                                    int C, int M, int K, int dil, int pad, int64_t ld_gz, int64_t ld_xc,
+                                                    const float* qmin_x, const float* qmax_x) {
+    __shared__ double red[kTaps * 4];
+    const QRange rx = load_qrange(qmin_x, qmax_x);
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int64_t row = (int64_t)b * C + c;
+    const float* gr = gz + row * ld_gz;
+    const uint8_t* xr = xc + row * ld_xc;
+    float p[kTaps];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) p[k] = 0.0f;
+    for (int m = threadIdx.x * 4; m < M; m += 256 * 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gr + m);
+        const float gv[4] = {g4.x, (m + 1 < M) ? g4.y : 0.f, (m + 2 < M) ? g4.z : 0.f, (m + 3 < M) ? g4.w : 0.f};
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+            if (k < K) {
+                const int s0 = m + k * dil - pad;
+                const unsigned int w = load_codes4(xr, s0, (int)ld_xc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (s0 + j >= 0 && s0 + j < M) p[k] = fmaf(gv[j], dec((w >> (8 * j)) & 255u, rx), p[k]);
+            }
+        }
+    }
+    double v[kTaps];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) v[k] = (double)p[k];
+    block_sum<double, kTaps>(v, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[k]);
+}
+
+// shared with stream_ops.hip's GroupNorm backward
+__global__ void k_gnq_bwd_coef(const float* __restrict__ gamma, const float* __restrict__ mean_rstd, int B, int C, int M,
+                               double* ws, float* ggamma, float* gbeta) {
+    __shared__ double red[2 * 4];
+    const int b = blockIdx.x;
+    double* coef = ws + 2 * (int64_t)B * C;
+    if (b < B) {
+        double s_ds = 0.0, s_db = 0.0;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const double gmm = (double)gamma[c];
+            s_ds += gmm * ws[2 * ((int64_t)b * C + c)];
+            s_db += gmm * ws[2 * ((int64_t)b * C + c) + 1];
+        }
+        double v[2] = {s_ds, s_db};
+        block_sum<double, 2>(v, red);
+        if (threadIdx.x == 0) {
+            const double mean = (double)mean_rstd[2 * b], rstd = (double)mean_rstd[2 * b + 1];
+            const double inv_n = 1.0 / ((double)C * (double)M);
+            const double c2 = (v[1] * mean - v[0]) * rstd * rstd * rstd * inv_n;
+            coef[2 * b] = c2;
+            coef[2 * b + 1] = -c2 * mean - v[1] * rstd * inv_n;
+        }
+    } else {
+        const int c = (b - B) * 256 + threadIdx.x;
+        if (c < C) {
+            double gg = 0.0, gb = 0.0;
+            for (int bb = 0; bb < B; ++bb) {
+                const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
+                gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
+                gb += db;
+            }
+            ggamma[c] += (float)gg;
+            gbeta[c] += (float)gb;
+        }
+    }
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+static inline bool codes_ok(const void* p, int64_t ld) { return aligned16(p) && (ld % 16 == 0); }
+
+extern "C" int fqss_decode(const uint8_t* codes, float* out, int64_t rows, int64_t cols, int64_t ld_c, int64_t ld_out,
+                           const float* qmin, const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(codes && out && qmin && qmax, "null pointer");
+    FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_c >= cols && ld_out >= cols, "bad shape");
+    FQSS_REQUIRE(codes_ok(codes, ld_c) && aligned16(out) && ld_out % 4 == 0, "decode needs 16-B aligned code rows / fp32 rows");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_decode, grid_rows(rows, cols, 4), dim3(256), 0, (hipStream_t)stream, codes, out, rows, cols, ld_c,
+                       ld_out, qmin, qmax);
+    return launch_status("fqss_decode");
+}
+
+extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma,
+                            const float* beta, uint8_t* yc, float* yout, float* mean_rstd, int B, int C, int M,
+                            int64_t ld_xc, int64_t ld_yc, int64_t ld_out, float eps, const float* qmin, const float* qmax,
+                            void* ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && gamma && beta && yc && mean_rstd && qmin && qmax && ws, "null pointer");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_yc >= M, "bad shape");
+    FQSS_REQUIRE(codes_ok(xc, ld_xc) && codes_ok(yc, ld_yc), "code rows must be 16-B aligned");
+    FQSS_REQUIRE(!yout || (aligned16(yout) && ld_out % 4 == 0 && ld_out >= ((M + 3) & ~3)), "bad fp32 output rows");
+    if (B == 0) return FQSS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nslots = C < kGnSlots ? C : kGnSlots;
+    hipLaunchKernelGGL(k_gnq_stats, dim3((unsigned)nslots, (unsigned)B), dim3(256), 0, s, xc, C, M, ld_xc, (long long*)ws);
+    hipLaunchKernelGGL(k_gnq_finalize, dim3((unsigned)B), dim3(64), 0, s, (const long long*)ws, nslots, (int64_t)C * M, eps,
+                       mean_rstd, qmin_x, qmax_x);
+    const int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(k_gnq_apply, grid_rows(rows, M, 16), dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd, B, C, M,
+                       ld_xc, ld_yc, ld_out, qmin_x, qmax_x, qmin, qmax);
+    return launch_status("fqss_gnq_fwd");
+}
+
+extern "C" int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
+                            const float* gamma, const float* beta, const float* mean_rstd, float* gx, float* ggamma,
+                            float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin,
+                            const float* qmax, double* gacc, double* ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && g && gamma && beta && mean_rstd && gx && ggamma && gbeta && qmin && qmax && gacc && ws,
+                 "null pointer");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_g >= M && ld_gx >= M, "bad shape");
+    FQSS_REQUIRE(codes_ok(xc, ld_xc) && aligned16(g) && aligned16(gx) && ld_g % 4 == 0 && ld_gx % 4 == 0 &&
+                     ld_g >= ((M + 3) & ~3), "rows must be 16-B aligned");
+    if (B == 0) return FQSS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gnq_bwd_rows, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, C, M,
+                       ld_xc, ld_g, ws, qmin_x, qmax_x, qmin, qmax, gacc);
+    hipLaunchKernelGGL(k_gnq_bwd_coef, dim3((unsigned)(B + cdiv(C, 256))), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
+                       ggamma, gbeta);
+    const int64_t rows = (int64_t)B * C;
+    hipLaunchKernelGGL(k_gnq_bwd_apply, grid_rows(rows, M, 4), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C, M,
+                       ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax);
+    return launch_status("fqss_gnq_bwd");
+}
+
+extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
+                            uint8_t* yc, float* yout, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
+                            int64_t ld_yc, int64_t ld_out, int act, const float* slope, const float* qmin, const float* qmax,
+                            fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && w && yc && qmin && qmax, "null pointer");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
+    FQSS_REQUIRE(ld_xc >= M && ld_yc >= M && codes_ok(xc, ld_xc) && codes_ok(yc, ld_yc), "code rows must be 16-B aligned");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    FQSS_REQUIRE(!yout || (aligned16(yout) && ld_out % 4 == 0 && ld_out >= ((M + 3) & ~3)), "bad fp32 output rows");
+    if (B == 0 || M == 0) return FQSS_OK;
+    const int64_t rows = (int64_t)B * C;
+    FQSS_REQUIRE(rows < (1ll << 30) && ld_xc < (1ll << 30), "tensor too large for the 32-bit row kernels");
+    hipLaunchKernelGGL(k_dwq_fwd, grid_rows(rows, M, 16), dim3(256), 0, (hipStream_t)stream, xc, w, bias, yc, yout, (int)rows,
+                       C, M, K, dil, pad, (int)ld_xc, (int)ld_yc, (int)ld_out, act, slope, qmin_x, qmax_x, qmin, qmax);
+    return launch_status("fqss_dwq_fwd");
+}
+
+extern "C" int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
+                              const float* bias, const float* g, float* gz, int B, int C, int M, int K, int dil, int pad,
+                              int64_t ld_xc, int64_t ld_g, int64_t ld_gz, int act, const float* slope, const float* qmin,
+                              const float* qmax, double* gacc, float* gbias, fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && w && g && gz && qmin && qmax && gacc, "null pointer");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
+    FQSS_REQUIRE(ld_xc >= M && codes_ok(xc, ld_xc) && aligned16(g) && aligned16(gz) && ld_g % 4 == 0 && ld_gz % 4 == 0 &&
+                     ld_g >= ((M + 3) & ~3) && ld_gz >= ((M + 3) & ~3), "rows must be 16-B aligned");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    if (B == 0 || M == 0) return FQSS_OK;
+    int64_t gx_ = cdiv(M, 256 * 4);
+    if (gx_ > 64) gx_ = 64;
+    int64_t gy = kSlots / gx_;
+    if (gy > C) gy = C;
+    hipLaunchKernelGGL(k_dwq_bwd_z, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, xc, w, bias, g, gz,
+                       B, C, M, K, dil, pad, ld_xc, ld_g, ld_gz, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias);
+    return launch_status("fqss_dwq_bwd_z");
+}
+
+extern "C" int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int B,
+                              int C, int M, int K, int dil, int pad, int64_t ld_gz, int64_t ld_xc, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null pointer");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && pad >= 0, "bad shape");
+    FQSS_REQUIRE(ld_gz >= ((M + 3) & ~3) && ld_gz % 4 == 0 && aligned16(gz) && codes_ok(xc, ld_xc) && ld_xc >= M,
+                 "rows must be 16-B aligned");
+    if (B == 0 || M == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_dwq_bwd_w, dim3((unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, gz, xc, gw, C, M, K, dil,
+                       pad, ld_gz, ld_xc, qmin_x, qmax_x);
+    return launch_status("fqss_dwq_bwd_w");
+}

@@ -64,11 +64,12 @@ struct QGemmArgs {
     int ksplit, kchunk;           // wgrad split-K
 };
 
-template <int MODE>  // 0 fwd (u8 codes B), 1 dgrad (fp32 B, split3), 2 wgrad (fp32 A split3, u8 codes B k-contiguous)
+// MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
+//      2 wgrad (fp32 A split3, u8 B codes [n][k])  3 plain fp32 x fp32 (A split3 x B split3 = 9 exact products)
+template <int MODE>
 __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
-    constexpr int NSPLIT = (MODE == 0) ? 1 : 3;
-    constexpr int NA = (MODE == 2) ? 3 : 1;   // A images
-    constexpr int NB = (MODE == 1) ? 3 : 1;   // B images
+    constexpr int NA = (MODE >= 2) ? 3 : 1;                 // A images
+    constexpr int NB = (MODE == 1 || MODE == 3) ? 3 : 1;    // B images
     __shared__ __attribute__((aligned(16))) unsigned short As[NA][QBM][LDK];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[NB][(MODE == 2) ? QBN : QBK][(MODE == 2) ? LDK : LDN];
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
     const int bn_row = tid >> 1, bn_k = (tid & 1) * 16;            // B tile [n][k] (wgrad): 128 n x 32 k
 
     auto load_tiles = [&](int k0) {
-        if constexpr (MODE != 2) {
+        if constexpr (MODE < 2) {
             const signed char* A = (const signed char*)g.A;
             ra_i8 = make_uint4(0, 0, 0, 0);
             if (i0 + a_row < g.M && k0 + a_k < kend)
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
             rb_u8 = make_uint4(0, 0, 0, 0);
             if (k0 + bk_row < kend && j0 + bk_n < g.N)
                 rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + j0 + bk_n);
-        } else if constexpr (MODE == 1) {
+        } else if constexpr (MODE == 1 || MODE == 3) {
             const float* Bp = (const float*)g.B + (int64_t)b * g.sBb;
             const bool ok = (k0 + bk_row < kend);
-            rb_scale = ok ? g.dw[k0 + bk_row] : 0.0f;
+            rb_scale = (ok && MODE == 1) ? g.dw[k0 + bk_row] : 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -190,17 +191,19 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
     };
 
     auto store_tiles = [&]() {
-        if constexpr (MODE != 2) {
+        if constexpr (MODE < 2) {
             store_u8x16(&As[0][a_row][a_k], ra_i8, true);
         } else {
             store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], ra_f, 1.0f, false);
+            if constexpr (MODE == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rowsum += (ra_f[q].x + ra_f[q].y) + (ra_f[q].z + ra_f[q].w);
+                for (int q = 0; q < 4; ++q) rowsum += (ra_f[q].x + ra_f[q].y) + (ra_f[q].z + ra_f[q].w);
+            }
         }
         if constexpr (MODE == 0) {
             store_u8x16(&Bs[0][bk_row][bk_n], rb_u8, false);
-        } else if constexpr (MODE == 1) {
-            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, true);
+        } else if constexpr (MODE == 1 || MODE == 3) {
+            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, MODE == 1);
         } else {
             store_u8x16(&Bs[0][bn_row][bn_k], rb_u8, false);
         }
@@ -220,8 +223,9 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int sp = 0; sp < NSPLIT; ++sp) {
-                const int ia = (MODE == 2) ? sp : 0, ib = (MODE == 1) ? sp : 0;
+            for (int sp = 0; sp < NA * NB; ++sp) {
+                // smallest pieces first: (3,3) ... (1,1) so that the large products are added last
+                const int ia = (NA == 3) ? 2 - (sp / NB) : 0, ib = (NB == 3) ? 2 - (sp % NB) : 0;
                 bf16x8 af[2], bfr[2];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
 
     // ---------------------------------------------------------------- epilogue
     float dx = 0.f, mnx = 0.f;
-    if constexpr (MODE != 1) {
+    if constexpr (MODE == 0 || MODE == 2) {
         const float lo = *g.qmin_x, hi = *g.qmax_x;
         dx = (hi - lo) / 255.0f;
         mnx = lo;
@@ -289,6 +293,8 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
                         Cb[(int64_t)row * g.ldc + col] = v;
                     } else if constexpr (MODE == 1) {
                         Cb[(int64_t)row * g.ldc + col] = S;
+                    } else if constexpr (MODE == 3) {
+                        Cb[(int64_t)row * g.ldc + col] = (g.bias != nullptr) ? S + g.bias[row] : S;
                     } else {
                         atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * S + mnx * rs[rl]);
                     }
@@ -390,4 +396,22 @@ extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* q
     dim3 grid((unsigned)cdiv(Ci, QBN), (unsigned)cdiv(Co, QBM), (unsigned)(B * g.ksplit));
     hipLaunchKernelGGL((k_qgemm<2>), grid, dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qpw_bwd_w");
+}
+
+// plain fp32 pointwise conv z = W x + b on the bf16 matrix cores: both operands split exactly in three
+extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
+                                  int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && w && z, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= M && ld_z >= M, "bad shape");
+    FQSS_REQUIRE(Ci % 4 == 0 && ld_x % 4 == 0 && aligned16(x) && aligned16(w) && ld_x >= ((M + 3) & ~3),
+                 "x3 GEMM needs Ci % 4 == 0 and 16-B aligned activation rows");
+    if (B == 0 || M == 0) return FQSS_OK;
+    QGemmArgs g{};
+    g.A = w; g.B = x; g.C = z; g.M = Co; g.N = M; g.K = Ci;
+    g.lda = Ci; g.ldb = ld_x; g.ldc = ld_z;
+    g.sAb = 0; g.sBb = (int64_t)Ci * ld_x; g.sCb = (int64_t)Co * ld_z;
+    g.bias = bias; g.ksplit = 1; g.kchunk = Ci;
+    dim3 grid((unsigned)cdiv(M, QBN), (unsigned)cdiv(Co, QBM), (unsigned)B);
+    hipLaunchKernelGGL((k_qgemm<3>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_pwconv_fwd_x3");
 }

@@ -8,6 +8,7 @@ Q_BYPASS, Q_OBSERVE, Q_QUANT = 0, 1, 2
 ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
 
 GACC_DOUBLES = 2048 * 3   # FQSS_GACC_SLOTS x (dmin, dmax, dslope)
+USE_X3 = True            # route plain fp32 pointwise convs through the bf16 3x3-split GEMM
 LD_ALIGN = 16  # row stride of activation buffers is padded to 16 floats (64 B) -> 16-B/lane path
 
 
@@ -79,17 +80,19 @@ def empty_codes(shape, device):
     return buf[..., :M] if ld != M else buf
 
 
-def actq_fwd(z, act, slope, qmode, qmin, qmax, obs_ws, want_idx=False, dense_idx=False):
+def actq_fwd(z, act, slope, qmode, qmin, qmax, obs_ws, want_idx=False, dense_idx=False, write_out=True):
+    """write_out=False (QUANT + want_idx only): the fp32 result is an UNINITIALISED carrier, only codes are written"""
     _need_gpu(z, slope, qmin, qmax)
     z, rows, cols, ld_z = as_rowmat(z)
     out = empty_act(tuple(z.shape), z.device)
     _, _, _, ld_o = (out,) + rowmat(out)
+    skip_out = (not write_out) and want_idx and qmode == Q_QUANT
     idx, ld_i = None, cols
     if want_idx:
         idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if dense_idx else empty_codes(tuple(z.shape), z.device)
         ld_i = rowmat(idx)[2]
-    _lib.call("fqss_actq_fwd", _p(z), _p(out), _p(idx), rows, cols, ld_z, ld_o, ld_i, act, _p(slope), qmode,
-              _p(qmin), _p(qmax), _p(obs_ws), _stream())
+    _lib.call("fqss_actq_fwd", _p(z), None if skip_out else _p(out), _p(idx), rows, cols, ld_z, ld_o, ld_i, act,
+              _p(slope), qmode, _p(qmin), _p(qmax), _p(obs_ws), _stream())
     return (out, idx) if want_idx else out
 
 
@@ -178,7 +181,9 @@ def pwconv_fwd(x, w, bias):
     Co = w.shape[0]
     assert w.is_contiguous() and w.numel() == Co * Ci
     z = empty_act((B, Co, M), x.device)
-    _lib.call("fqss_pwconv_fwd", _p(x), _p(w), _p(bias), _p(z), B, Ci, Co, M, ld_x, rowmat(z)[2], _stream())
+    # bf16-MFMA 3x3 exact split when rows are 16-B aligned, fp32-MFMA kernel otherwise
+    fn = "fqss_pwconv_fwd_x3" if (USE_X3 and Ci % 4 == 0 and ld_x % 4 == 0 and x.data_ptr() % 16 == 0) else "fqss_pwconv_fwd"
+    _lib.call(fn, _p(x), _p(w), _p(bias), _p(z), B, Ci, Co, M, ld_x, rowmat(z)[2], _stream())
     return z
 
 
@@ -253,6 +258,75 @@ def qpw_bwd_w(gz, xc, qmin_x, qmax_x, gw):
         gz, ld_gz = c, rowmat(c)[2]
     Ci = xc.shape[1]
     _lib.call("fqss_qpw_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), B, Ci, Co, M, ld_gz, rowmat(xc)[2], _stream())
+
+
+# ------------------------------------------------------------------ K6q / K7q  codes-only layers (csrc/fused_q.hip)
+def _codes3(xc):
+    """u8 codes [B,C,M] with 16-B aligned rows -> (B, C, M, ld)"""
+    rm = rowmat(xc)
+    assert xc.dim() == 3 and rm is not None and rm[2] % 16 == 0 and xc.data_ptr() % 16 == 0, "bad code layout"
+    return xc.shape[0], xc.shape[1], xc.shape[2], rm[2]
+
+
+def decode(xc, qmin, qmax):
+    rm = rowmat(xc)
+    out = empty_act(tuple(xc.shape), xc.device)
+    _lib.call("fqss_decode", _p(xc), _p(out), rm[0], rm[1], rm[2], rowmat(out)[2], _p(qmin), _p(qmax), _stream())
+    return out
+
+
+def gnq_fwd(xc, qmin_x, qmax_x, gamma, beta, eps, qmin, qmax, write_out):
+    B, C, M, ld_xc = _codes3(xc)
+    yc = empty_codes((B, C, M), xc.device)
+    out = empty_act((B, C, M), xc.device)      # carrier; written only when write_out
+    mean_rstd = torch.empty(B, 2, device=xc.device, dtype=torch.float32)
+    ws = torch.empty(2 * 64 * B, device=xc.device, dtype=torch.int64)
+    _lib.call("fqss_gnq_fwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(gamma), _p(beta), _p(yc), _p(out) if write_out else None,
+              _p(mean_rstd), B, C, M, ld_xc, rowmat(yc)[2], rowmat(out)[2], float(eps), _p(qmin), _p(qmax), _p(ws), _stream())
+    return out, yc, mean_rstd
+
+
+def _aligned_grad(g):
+    g, _, _, ld = as_rowmat(g)
+    if ld % 4 != 0 or g.data_ptr() % 16 != 0:
+        c = empty_act(tuple(g.shape), g.device)
+        c.copy_(g)
+        g, ld = c, rowmat(c)[2]
+    return g, ld
+
+
+def gnq_bwd(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, gacc, ggamma, gbeta):
+    B, C, M, ld_xc = _codes3(xc)
+    g, ld_g = _aligned_grad(g)
+    gx = empty_act((B, C, M), xc.device)
+    ws = torch.empty(2 * B * C + 2 * B, device=xc.device, dtype=torch.float64)
+    _lib.call("fqss_gnq_bwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(g), _p(gamma), _p(beta), _p(mean_rstd), _p(gx),
+              _p(ggamma), _p(gbeta), B, C, M, ld_xc, ld_g, rowmat(gx)[2], _p(qmin), _p(qmax), _p(gacc), _p(ws), _stream())
+    return gx
+
+
+def dwq_fwd(xc, qmin_x, qmax_x, w, bias, dil, pad, act, slope, qmin, qmax, write_out):
+    B, C, M, ld_xc = _codes3(xc)
+    yc = empty_codes((B, C, M), xc.device)
+    out = empty_act((B, C, M), xc.device)
+    _lib.call("fqss_dwq_fwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(w), _p(bias), _p(yc), _p(out) if write_out else None,
+              B, C, M, w.shape[-1], dil, pad, ld_xc, rowmat(yc)[2], rowmat(out)[2], act, _p(slope), _p(qmin), _p(qmax), _stream())
+    return out, yc
+
+
+def dwq_bwd_z(xc, qmin_x, qmax_x, w, bias, g, dil, pad, act, slope, qmin, qmax, gacc, gbias):
+    B, C, M, ld_xc = _codes3(xc)
+    g, ld_g = _aligned_grad(g)
+    gz = empty_act((B, C, M), xc.device)
+    _lib.call("fqss_dwq_bwd_z", _p(xc), _p(qmin_x), _p(qmax_x), _p(w), _p(bias), _p(g), _p(gz), B, C, M, w.shape[-1], dil,
+              pad, ld_xc, ld_g, rowmat(gz)[2], act, _p(slope), _p(qmin), _p(qmax), _p(gacc), _p(gbias), _stream())
+    return gz
+
+
+def dwq_bwd_w(gz, xc, qmin_x, qmax_x, gw, dil, pad):
+    B, C, M, ld_xc = _codes3(xc)
+    _lib.call("fqss_dwq_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), B, C, M, gw.shape[-1], dil, pad,
+              rowmat(gz)[2], ld_xc, _stream())
 
 
 # ------------------------------------------------------------------ K6  depthwise conv

@@ -19,11 +19,13 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
-        self.idx = None     # u8 codes of the output produced by this call (QUANT mode)
+        self.idx = None         # u8 codes of the output produced by this call (QUANT mode)
+        self.carrier = False    # True: the fp32 output of this call is an uninitialised carrier (codes-only fast path)
+        self.keep_out = False   # force a real fp32 output even in the fast path (model outputs)
 
 
 class ActCodes:
@@ -39,12 +41,77 @@ def tag_codes(y, q):
     """attach the codes produced by the epilogue of this call to its output tensor"""
     if q.idx is not None:
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
+        y._fqss_carrier = q.carrier
         q.idx = None
     return y
 
 
 def codes_of(x):
     return getattr(x, "_fqss_q", None)
+
+
+def is_carrier(x):
+    return getattr(x, "_fqss_carrier", False)
+
+
+# ---- codes-only fast path -----------------------------------------------------------------------
+# With FAST on, a quantizing layer writes ONLY the u8 codes of its output; the fp32 tensor it returns is
+# an uninitialised "carrier" that keeps shapes/autograd intact.  Consumers with a coded-input kernel read
+# the codes; every other consumer calls real(x) first.  Off by default (module outputs are then real
+# fp32, like the reference's); fqss_amd.runtime.KDTrainStep turns it on around the student forward.
+FAST = False
+DEBUG_POISON = bool(int(__import__("os").environ.get("FQSS_DEBUG_CARRIER", "0")))   # NaN-fill carriers (tests)
+
+
+class fast_codes:
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global FAST
+        self.prev, FAST = FAST, self.on
+
+    def __exit__(self, *a):
+        global FAST
+        FAST = self.prev
+
+
+def _carrier(out):
+    if DEBUG_POISON:
+        out.fill_(float("nan"))
+    return out
+
+
+class Materialize(Function):
+    """carrier -> real fp32 tensor (decode kernel); gradient passes through"""
+
+    @staticmethod
+    def forward(ctx, x, xq):
+        return K.decode(xq.idx, xq.qmin, xq.qmax)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def real(x):
+    """the fp32 values of x (decodes a carrier; no-op for ordinary tensors)"""
+    if torch.is_tensor(x) and is_carrier(x):
+        xq = codes_of(x)
+        y = Materialize.apply(x, xq)
+        y._fqss_q, y._fqss_carrier = xq, False
+        return y
+    return x
+
+
+def reshape_tagged(x, *shape):
+    """x.reshape(shape) that keeps the codes (reshaped alike) and the carrier flag"""
+    y = x.reshape(*shape)
+    xq = codes_of(x)
+    if xq is not None:
+        y._fqss_q = ActCodes(xq.idx.reshape(*shape), xq.qmin, xq.qmax)
+        y._fqss_carrier = is_carrier(x)
+    return y
 
 
 BYPASS = QCtx()
@@ -61,9 +128,22 @@ def _grad_buf(param, like):
 
 def _epilogue_fwd(z, act, slope, q):
     if q.qmode == Q_QUANT:
-        out, q.idx = K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws, want_idx=True)
-        return out
+        q.carrier = FAST and not q.keep_out
+        out, q.idx = K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws, want_idx=True, write_out=not q.carrier)
+        return _carrier(out) if q.carrier else out
     return K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws)
+
+
+def _flush_ranges(q, slope, slope_param, act):
+    """fp64 partial slots -> fp32 parameter gradients (ranges always, slope for PReLU)"""
+    s_buf = None
+    s_direct = True
+    if act == ACT_PRELU:
+        s_buf, s_direct = _grad_buf(slope_param, slope)
+    mn_buf, mn_direct = _grad_buf(q.owner.min_range if q.owner is not None else None, q.qmin)
+    mx_buf, mx_direct = _grad_buf(q.owner.max_range if q.owner is not None else None, q.qmax)
+    K.gacc_flush(q.gacc, mn_buf, mx_buf, s_buf)
+    return (None if s_direct else s_buf), (None if mn_direct else mn_buf), (None if mx_direct else mx_buf)
 
 
 def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=None, C=0):
@@ -167,7 +247,8 @@ class LinearActQ(Function):
             z = _lin_fwd(L, x, w, bias)
         ctx.plain = (q.qmode == Q_BYPASS and act == ACT_NONE)   # float linear op: no epilogue pass at all
         out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
-        ctx.save_for_backward(x, w, None if ctx.plain else z, slope)
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(None if (ctx.xq is not None and ctx.wc is not None) else x, w, None if ctx.plain else z, slope)
         ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
         ctx.bias_like = bias
         ctx.C = z.shape[1]
@@ -185,7 +266,7 @@ class LinearActQ(Function):
                 bias_like=ctx.bias_like if ctx.has_bias else None, C=ctx.C)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, x.shape)
+            gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)
         gw = None
         if ctx.needs_input_grad[1]:
             # w here is the fake-quantized weight (a non-leaf): its gradient always goes back through autograd
@@ -200,26 +281,71 @@ class LinearActQ(Function):
 
 
 class GroupNormActQ(Function):
-    """out = fq(GroupNorm(1, C)(x))  -- GroupNormQ"""
+    """out = fq(GroupNorm(1, C)(x))  -- GroupNormQ.  With coded input in the quantizing phase the layer
+    runs codes -> codes (csrc/fused_q.hip) and saves nothing but the input codes and the statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, qmin, qmax, eps, q, gamma_param, beta_param):
+    def forward(ctx, x, gamma, beta, qmin, qmax, eps, q, gamma_param, beta_param, xq=None):
+        ctx.q, ctx.gp, ctx.bp = q, gamma_param, beta_param
+        ctx.coded = xq is not None and q.qmode == Q_QUANT
+        if ctx.coded:
+            q.carrier = FAST and not q.keep_out
+            out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier)
+            ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
+            return _carrier(out) if q.carrier else out
         z, mean_rstd = K.gn_fwd(x, gamma, beta, eps)
         plain = q.qmode == Q_BYPASS
         out = z if plain else _epilogue_fwd(z, ACT_NONE, None, q)
         ctx.save_for_backward(x, gamma, None if plain else z, mean_rstd)
-        ctx.q, ctx.gp, ctx.bp = q, gamma_param, beta_param
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, gamma, z, mean_rstd = ctx.saved_tensors
         q = ctx.q
+        if ctx.coded:
+            gamma, beta, mean_rstd, xc, xmin, xmax, qmin, qmax = ctx.saved_tensors
+            gg, gg_direct = _grad_buf(ctx.gp, gamma)
+            gb, gb_direct = _grad_buf(ctx.bp, gamma)
+            gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb)
+            _, g_min, g_max = _flush_ranges(q, None, None, ACT_NONE)
+            return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
+        x, gamma, z, mean_rstd = ctx.saved_tensors
         gz, _, g_min, g_max, _ = _plain_or_bwd(z, g, q)
         gg, gg_direct = _grad_buf(ctx.gp, gamma)
         gb, gb_direct = _grad_buf(ctx.bp, gamma)
         gx = K.gn_bwd(gz, x, gamma, mean_rstd, gg, gb)
-        return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None
+        return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
+
+
+class DwConvQ(Function):
+    """out = fq(act(depthwise_conv(x, w) + bias)) on coded input, codes -> codes; the backward
+    recomputes the pre-quant value from the input codes (csrc/fused_q.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope, qmin, qmax, L, act, q, xq):
+        q.carrier = FAST and not q.keep_out
+        out, q.idx = K.dwq_fwd(xq.idx, xq.qmin, xq.qmax, w, bias, L.dil, L.pad, act, slope, qmin, qmax, write_out=not q.carrier)
+        ctx.save_for_backward(w, bias, slope, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
+        ctx.L, ctx.act, ctx.q = L, act, q
+        return _carrier(out) if q.carrier else out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, bias, slope, xc, xmin, xmax, qmin, qmax = ctx.saved_tensors
+        L, act, q = ctx.L, ctx.act, ctx.q
+        gb, gb_direct = (None, True)
+        if bias is not None:
+            gb, gb_direct = _grad_buf(L.b_param, bias)
+        gz = K.dwq_bwd_z(xc, xmin, xmax, w, bias, g, L.dil, L.pad, act, slope, qmin, qmax, q.gacc, gb)
+        g_slope, g_min, g_max = _flush_ranges(q, slope, L.slope_param, act)
+        gx = K.dwconv_bwd_x(gz, w, L.dil, L.pad) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros_like(w)
+            K.dwq_bwd_w(gz, xc, xmin, xmax, gw, L.dil, L.pad)
+            if L.w_param is not None and w is L.w_param:
+                L.w_param._fqss_touched = True
+        return gx, gw, (None if gb_direct else gb), g_slope, g_min, g_max, None, None, None, None
 
 
 class AddActQ(Function):
@@ -343,6 +469,7 @@ def fork2(x):
         c = codes_of(x)
         if c is not None:
             a._fqss_q = b._fqss_q = c
+            a._fqss_carrier = b._fqss_carrier = is_carrier(x)
         return a, b
     return x, x
 

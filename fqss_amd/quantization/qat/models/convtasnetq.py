@@ -76,7 +76,7 @@ class MaskGenerator(nn.Module):
             feats, skip = layer(feats)
             output = self.adds[i](output, skip)
         output = self.mask_net(output)
-        return output.reshape(batch, self.n_srcs, self.input_dim, -1)
+        return ops.reshape_tagged(output, batch, self.n_srcs, self.input_dim, -1)
 
 
 class ConvTasNetQ(nn.Module):
@@ -104,8 +104,8 @@ class ConvTasNetQ(nn.Module):
         batch = x.shape[0]
         feats = apply_module(self.encoder, x)                                  # [B, F, M]
         f_mask, f_mul = ops.fork2(feats)
-        masked = self.mul(self.masker(f_mask), f_mul.unsqueeze(1))             # [B, S, F, M]
-        masked = torch.reshape(masked, (batch * self.n_srcs, self.enc_num_feats, -1))
+        masked = self.mul(self.masker(f_mask), ops.reshape_tagged(f_mul, batch, 1, self.enc_num_feats, -1))  # [B, S, F, M]
+        masked = ops.reshape_tagged(masked, batch * self.n_srcs, self.enc_num_feats, -1)
         out = apply_module(self.decoder, masked)                               # [D, B*S, 1, L] or [B*S, 1, L]
         out = out.reshape((self.n_combiner, batch, self.n_srcs, 1, -1))
         return self.post_process(out)

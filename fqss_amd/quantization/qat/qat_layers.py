@@ -96,7 +96,7 @@ class AddQ(LayerQ):
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        y = ops.AddActQ.apply(x1, x2, q.qmin, q.qmax, 1.0, q)
+        y = ops.AddActQ.apply(ops.real(x1), ops.real(x2), q.qmin, q.qmax, 1.0, q)
         aq.after_forward(q)
         return ops.tag_codes(y, q)
 
@@ -110,9 +110,9 @@ class SubQ(LayerQ):
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        y = ops.AddActQ.apply(x1, x2, q.qmin, q.qmax, -1.0, q)
+        y = ops.AddActQ.apply(ops.real(x1), ops.real(x2), q.qmin, q.qmax, -1.0, q)
         aq.after_forward(q)
-        return y
+        return ops.tag_codes(y, q)
 
 
 class MulQ(LayerQ):
@@ -124,9 +124,9 @@ class MulQ(LayerQ):
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        y = _mul_any(x1, x2, q.qmin, q.qmax, q)
+        y = _mul_any(ops.real(x1), ops.real(x2), q.qmin, q.qmax, q)
         aq.after_forward(q)
-        return y
+        return ops.tag_codes(y, q)
 
 
 class ConstQ(LayerQ):
@@ -135,7 +135,7 @@ class ConstQ(LayerQ):
         self.const = const
 
     def forward(self, x):
-        return self.activation_fake_quantize(x)
+        return self.activation_fake_quantize(ops.real(x))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -172,8 +172,13 @@ def run_conv1d(conv, x, weight, nl, aq):
     act, slope = _act_of(nl)
     L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, slope
     q = aq.qctx() if aq is not None else ops.BYPASS
-    y = ops.LinearActQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q, ops.codes_of(x),
-                             getattr(weight, "_fqss_wcodes", None))
+    xq, wc = ops.codes_of(x), getattr(weight, "_fqss_wcodes", None)
+    if L.kind == "dw" and xq is not None and q.qmode == ops.Q_QUANT and conv.kernel_size[0] <= 8:
+        y = ops.DwConvQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q, xq)
+    else:
+        if not (L.kind == "pw" and xq is not None and wc is not None):
+            x = ops.real(x)             # no coded-input kernel for this case: decode a carrier first
+        y = ops.LinearActQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q, xq, wc)
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)
@@ -216,7 +221,10 @@ def run_groupnorm(gn, x, aq):
     if gn.num_groups != 1 or not gn.affine:
         raise NotImplementedError("only GroupNorm(num_groups=1, affine=True) (gLN) has a HIP kernel")
     q = aq.qctx() if aq is not None else ops.BYPASS
-    y = ops.GroupNormActQ.apply(x, gn.weight, gn.bias, q.qmin, q.qmax, gn.eps, q, gn.weight, gn.bias)
+    xq = ops.codes_of(x)
+    if not (xq is not None and q.qmode == ops.Q_QUANT):
+        x, xq = ops.real(x), None
+    y = ops.GroupNormActQ.apply(x, gn.weight, gn.bias, q.qmin, q.qmax, gn.eps, q, gn.weight, gn.bias, xq)
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)
@@ -225,7 +233,7 @@ def run_groupnorm(gn, x, aq):
 def run_nl(nl, x, aq):
     act, slope = _act_of(nl)
     q = aq.qctx() if aq is not None else ops.BYPASS
-    y = ops.NlActQ.apply(x, slope, q.qmin, q.qmax, act, q, slope)
+    y = ops.NlActQ.apply(ops.real(x), slope, q.qmin, q.qmax, act, q, slope)
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)
@@ -306,8 +314,9 @@ class ResidualErrorBlock(LayerQ):
         Y_q = run_conv1d(enc, y_q, self._wq(enc.weight), None, None)
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        Y1 = ops.AddActQ.apply(Y, Y_q, q.qmin, q.qmax, -1.0, q)
+        Y1 = ops.tag_codes(ops.AddActQ.apply(ops.real(Y), ops.real(Y_q), q.qmin, q.qmax, -1.0, q), q)
         aq.after_forward(q)
+        Y1 = ops.real(Y1)
         if decoder_conv is None:
             L = ops._Lin("convtr", stride=self.decoder_stride[0])
             return ops.LinearActQ.apply(Y1, w_decoder, None, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
@@ -319,11 +328,12 @@ def run_convtr1d(convtr, x, weight, aq):
             or convtr.groups != 1 or convtr.bias is not None:
         raise NotImplementedError("ConvTranspose1d: only the mono, bias-free, unpadded decoder has a HIP kernel")
     L = ops._Lin("convtr", stride=convtr.stride[0], w_param=convtr.weight)
-    q = aq.qctx() if aq is not None else ops.BYPASS
-    y = ops.LinearActQ.apply(x, weight, None, None, q.qmin, q.qmax, L, ops.ACT_NONE, q)
+    q = aq.qctx() if aq is not None else ops.QCtx()
+    q.keep_out = True          # waveform-side outputs are the model's outputs: always real fp32
+    y = ops.LinearActQ.apply(ops.real(x), weight, None, None, q.qmin, q.qmax, L, ops.ACT_NONE, q)
     if aq is not None:
         aq.after_forward(q)
-    return y
+    return ops.tag_codes(y, q)
 
 
 class ConvTr1dDecoderQ(LayerQ):

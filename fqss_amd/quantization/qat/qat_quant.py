@@ -80,9 +80,9 @@ class GradientActivationFakeQuantize(nn.Module):
 
     def forward(self, x):
         q = self.qctx()
-        y = ops.NlActQ.apply(x, None, self.min_range, self.max_range, ops.ACT_NONE, q, None)
+        y = ops.NlActQ.apply(ops.real(x), None, self.min_range, self.max_range, ops.ACT_NONE, q, None)
         self.after_forward(q)
-        return y
+        return ops.tag_codes(y, q)
 
 
 class GradientWeightFakeQuantize(nn.Module):

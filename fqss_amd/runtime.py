@@ -11,6 +11,7 @@ MI355X-first choices:
 import torch
 
 from . import kernels as K
+from . import ops
 
 
 class ParamArena:
@@ -91,7 +92,8 @@ class KDTrainStep:
     def _fwd_bwd(self, x, tgt):
         a = self.arena
         a.zero_grad()
-        est = self.model(x)
+        with ops.fast_codes(True):         # student: codes-only dataflow between quantizing layers
+            est = self.model(x)
         with torch.no_grad():
             fest = self.fmodel(x)
         out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)

@@ -49,6 +49,8 @@ typedef void* fqss_stream_t;
 
 int fqss_version(void);
 const char* fqss_last_error(void);
+/* self test: *mismatches += #{i : a[i]/b computed by the kernels' 3-instruction division != IEEE a[i]/b} */
+int fqss_selftest_div(const float* a, int64_t n, float b, uint64_t* mismatches, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K1/K1b/K3  per-tensor activation fake-quant (+ fused PReLU/ReLU), observer, STE backward
@@ -57,7 +59,7 @@ const char* fqss_last_error(void);
  * ------------------------------------------------------------------------------------------- */
 
 /* out = fq(act(z)).  idx (optional, u8 [rows][ld_idx]) receives the integer bin index (the codes
- * the q-GEMMs consume).  OBSERVE: out = act(z) and obs_ws[0..1] (ordered-uint min / max) are updated. */
+ * the q-GEMMs / coded layers consume); with idx given, out may be NULL (codes-only fast path).  OBSERVE: out = act(z) and obs_ws[0..1] (ordered-uint min / max) are updated. */
 int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols,
                   int64_t ld_z, int64_t ld_out, int64_t ld_idx, int act, const float* slope, int qmode,
                   const float* qmin, const float* qmax, uint32_t* obs_ws, fqss_stream_t stream);
@@ -109,6 +111,11 @@ int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* g
  * ------------------------------------------------------------------------------------------- */
 int fqss_pwconv_fwd(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
                     int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
+/* same contract as fqss_pwconv_fwd, computed on the bf16 matrix cores with both fp32 operands split
+ * exactly into 3 bf16 pieces (9 exact partial products per k, fp32 accumulation): fp32-grade result
+ * at 9/16 of the fp32-MFMA cost.  Needs Ci % 4 == 0 and 16-B aligned rows (csrc/qgemm.hip).        */
+int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
+                       int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
 /* gx[b] = W^T * gz[b] */
 int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci, int Co, int M,
                       int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
@@ -160,6 +167,38 @@ int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z,
 int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd,
                 float* gx, float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz,
                 int64_t ld_x, int64_t ld_gx, double* ws, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6q/K7q  "codes-only" streaming layers (csrc/fused_q.hip): input = u8 codes + its quantizer ranges,
+ * the layer's own PReLU + fake-quant fused, output = u8 codes (yout: optional fp32 copy, NULL in the
+ * fast path), nothing saved -- the backward recomputes the pre-quant value from the input codes.
+ * Code rows are 16-B aligned (ld % 16 == 0).  ws: gnq_fwd 2*64*B int64, gnq_bwd 2*B*C + 2*B doubles.
+ * ------------------------------------------------------------------------------------------- */
+int fqss_decode(const uint8_t* codes, float* out, int64_t rows, int64_t cols, int64_t ld_c,
+                int64_t ld_out, const float* qmin, const float* qmax, fqss_stream_t stream);
+int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma,
+                 const float* beta, uint8_t* yc, float* yout, float* mean_rstd, int B, int C, int M,
+                 int64_t ld_xc, int64_t ld_yc, int64_t ld_out, float eps, const float* qmin,
+                 const float* qmax, void* ws, fqss_stream_t stream);
+int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
+                 const float* gamma, const float* beta, const float* mean_rstd, float* gx,
+                 float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g,
+                 int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, double* ws,
+                 fqss_stream_t stream);
+int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
+                 const float* bias, uint8_t* yc, float* yout, int B, int C, int M, int K, int dil,
+                 int pad, int64_t ld_xc, int64_t ld_yc, int64_t ld_out, int act, const float* slope,
+                 const float* qmin, const float* qmax, fqss_stream_t stream);
+/* gz = dL/d(conv output) recomputed from the input codes; gacc slots += range/slope partials; gbias[C] += */
+int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
+                   const float* bias, const float* g, float* gz, int B, int C, int M, int K, int dil,
+                   int pad, int64_t ld_xc, int64_t ld_g, int64_t ld_gz, int act, const float* slope,
+                   const float* qmin, const float* qmax, double* gacc, float* gbias,
+                   fqss_stream_t stream);
+/* gw[C][K] += */
+int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
+                   float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_gz,
+                   int64_t ld_xc, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8/K9/K14  element-wise producers

@@ -180,3 +180,24 @@ def test_full_size_properties():
     lo2, hi2 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
     K.observer_ema(lo2, hi2, ws, 0.0)
     assert lo2.item() == x.min().item() and hi2.item() == x.max().item()
+
+
+def test_fast_division_is_bitwise_ieee():
+    """the kernels' 3-instruction division (Markstein correction with y = RN(1/delta)) must equal the IEEE
+    division bit for bit: brute force over 2^28 numerators per divisor, incl. exact half-bin edges"""
+    from fqss_amd import _lib
+    n = 1 << 26
+    mism = torch.zeros(1, dtype=torch.int64, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for lo, hi in [(-1.3, 1.7), (0.0, 6.0), (-0.5, 0.5), (-0.0371, 0.2113), (-3.1e-4, 7.7e-3), (-117.0, 351.0)]:
+        delta = float((torch.tensor(hi) - torch.tensor(lo)) / 255.0)
+        for rep in range(4):
+            a = (torch.rand(n, device="cuda", generator=gen) * 1.2 - 0.1) * (hi - lo)       # covers [-0.1, 1.1] x range
+            if rep == 0:   # exact bin edges (k + 0.5) * delta and their neighbours
+                k = torch.arange(0, 256, device="cuda", dtype=torch.float32)
+                edges = (k + 0.5) * delta
+                a[:256] = edges
+                a[256:512] = torch.nextafter(edges, torch.full_like(edges, 1e9))
+                a[512:768] = torch.nextafter(edges, torch.full_like(edges, -1e9))
+            _lib.call("fqss_selftest_div", a.data_ptr(), n, delta, mism.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(mism.item()) == 0

@@ -271,3 +271,84 @@ def test_qgemm_exact_integer_maps():
     gw = torch.zeros(Co, Ci, device="cuda")
     K.qpw_bwd_w(padded(g), xc, xlo.cuda(), xhi.cuda(), gw)
     assert torch.equal(gw.cpu(), torch.einsum("bom,bcm->oc", g, c))
+
+
+# ---------------------------------------------------------------------------------------------
+# codes-only layers (csrc/fused_q.hip)
+# ---------------------------------------------------------------------------------------------
+def _coded_input(B, C, M, seed):
+    gen = torch.Generator().manual_seed(seed)
+    codes = torch.randint(0, 256, (B, C, M), generator=gen, dtype=torch.uint8)
+    xlo, xhi = torch.tensor([-0.913]), torch.tensor([1.377])
+    x = ((xhi - xlo) / 255) * codes.float() + xlo          # exactly what a producer's epilogue stores
+    xc = K.empty_codes((B, C, M), "cuda")
+    xc.copy_(codes)
+    return codes, x, xc, xlo, xhi
+
+
+def _idx_mismatch(a, b):
+    d = (a.int() - b.int()).abs()
+    return float((d > 0).float().mean()), int(d.max())
+
+
+@pytest.mark.parametrize("B,C,M", [(2, 24, 77), (2, 512, 999), (3, 5, 130)])
+def test_gnq_coded(B, C, M):
+    codes, x, xc, xlo, xhi = _coded_input(B, C, M, seed=C)
+    assert torch.equal(K.decode(xc, xlo.cuda(), xhi.cuda()).cpu(), x)
+    gm, bt, g = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, M, seed=4)
+    ylo, yhi = torch.tensor([-2.1]), torch.tensor([2.4])
+    xr, gr, br = x.clone().requires_grad_(True), gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    lo_r, hi_r = ylo.clone().requires_grad_(True), yhi.clone().requires_grad_(True)
+    z = F.group_norm(xr, 1, gr, br, 1e-8)
+    y = O.act_quantize(z, lo_r, hi_r)
+    y.backward(g)
+    out, yc, mr = K.gnq_fwd(xc, xlo.cuda(), xhi.cuda(), gm.cuda(), bt.cuda(), 1e-8, ylo.cuda(), yhi.cuda(), True)
+    frac, dmax = _idx_mismatch(yc.cpu(), O.act_indices(z.detach(), ylo, yhi))
+    assert dmax <= 1 and frac <= 2e-3, (frac, dmax)
+    delta = (yhi - ylo) / 255
+    assert torch.equal(out.cpu(), delta * yc.cpu().float() + ylo)         # fp32 copy == decode(codes)
+    gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
+    gg, gb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    gx = K.gnq_bwd(xc, xlo.cuda(), xhi.cuda(), padded(g), gm.cuda(), bt.cuda(), mr, ylo.cuda(), yhi.cuda(), gacc, gg, gb)
+    tol = 2e-3 + 20 * frac
+    bad = (gx.cpu() - xr.grad).abs() > 1e-4 + 1e-3 * xr.grad.abs()
+    assert bad.float().mean() <= tol, bad.float().mean()
+    close(gg, gr.grad, rtol=5e-3, atol=5e-3 * float(gr.grad.abs().max()) + 1e-3)
+    close(gb, br.grad, rtol=5e-3, atol=5e-3 * float(br.grad.abs().max()) + 1e-3)
+    ga = gacc.view(-1, 3).sum(0).cpu().numpy()
+    sc = float(g.abs().sum()) * 2e-5 + 1e-4
+    np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=5e-3, atol=sc)
+    np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=5e-3, atol=sc)
+
+
+@pytest.mark.parametrize("B,C,M,dil", [(2, 32, 77, 1), (2, 32, 77, 4), (1, 512, 999, 128), (3, 7, 130, 2)])
+def test_dwq_coded(B, C, M, dil):
+    codes, x, xc, xlo, xhi = _coded_input(B, C, M, seed=C + dil)
+    w, bias, g = rnd(C, 1, 3, seed=2, scale=0.5), rnd(C, seed=3, scale=0.1), rnd(B, C, M, seed=4)
+    slope = torch.tensor([0.25])
+    ylo, yhi = torch.tensor([-1.3]), torch.tensor([2.2])
+    xr, wr, br, sr = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True), slope.clone().requires_grad_(True)
+    lo_r, hi_r = ylo.clone().requires_grad_(True), yhi.clone().requires_grad_(True)
+    z = F.prelu(F.conv1d(xr, wr, br, padding=dil, dilation=dil, groups=C), sr)
+    y = O.act_quantize(z, lo_r, hi_r)
+    y.backward(g)
+    cu = lambda t: t.cuda()
+    out, yc = K.dwq_fwd(xc, cu(xlo), cu(xhi), cu(w), cu(bias), dil, dil, K.ACT_PRELU, cu(slope), cu(ylo), cu(yhi), True)
+    frac, dmax = _idx_mismatch(yc.cpu(), O.act_indices(z.detach(), ylo, yhi))
+    assert dmax <= 1 and frac <= 2e-3, (frac, dmax)
+    assert torch.equal(out.cpu(), ((yhi - ylo) / 255) * yc.cpu().float() + ylo)
+    gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
+    gb = torch.zeros(C, device="cuda")
+    gz = K.dwq_bwd_z(xc, cu(xlo), cu(xhi), cu(w), cu(bias), padded(g), dil, dil, K.ACT_PRELU, cu(slope), cu(ylo), cu(yhi), gacc, gb)
+    gx = K.dwconv_bwd_x(gz, cu(w), dil, dil)
+    gw = torch.zeros(C, 1, 3, device="cuda")
+    K.dwq_bwd_w(gz, xc, cu(xlo), cu(xhi), gw, dil, dil)
+    bad = (gx.cpu() - xr.grad).abs() > 1e-4 + 1e-3 * xr.grad.abs()
+    assert bad.float().mean() <= 2e-3 + 20 * frac
+    close(gw, wr.grad, rtol=5e-3, atol=5e-3 * float(wr.grad.abs().max()) + 1e-3)
+    close(gb, br.grad, rtol=5e-3, atol=5e-3 * float(br.grad.abs().max()) + 1e-3)
+    ga = gacc.view(-1, 3).sum(0).cpu().numpy()
+    sc = float(g.abs().sum()) * 2e-5 + 1e-4
+    np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=5e-3, atol=sc)
+    np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=5e-3, atol=sc)
+    np.testing.assert_allclose(ga[2], sr.grad.item(), rtol=5e-3, atol=sc)

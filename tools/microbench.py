@@ -61,6 +61,24 @@ for C in (CF, CB):
         gw3 = torch.zeros_like(w3)
         rep(f"dwconv_bwd_w C={C} dil={dil}", timeit(lambda: K.dwconv_bwd_w(g, z, gw3, dil, dil)), 8 * n)
 
+# codes-only layers
+for C in (CF,):
+    xc = K.empty_codes((B, C, M), dev); xc.random_(0, 256)
+    n = B * C * M
+    gm, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    g = act(C)
+    gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev)
+    rep(f"gnq_fwd C={C} (codes->codes)", timeit(lambda: K.gnq_fwd(xc, lo, hi, gm, bt, 1e-8, lo, hi, False)), 3 * n)
+    _, _, mr = K.gnq_fwd(xc, lo, hi, gm, bt, 1e-8, lo, hi, False)
+    gg, gbb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    rep(f"gnq_bwd C={C}", timeit(lambda: K.gnq_bwd(xc, lo, hi, g, gm, bt, mr, lo, hi, gacc, gg, gbb)), 14 * n)
+    w3 = torch.randn(C, 1, 3, device=dev)
+    for dil in (1, 2, 128):
+        rep(f"dwq_fwd C={C} dil={dil}", timeit(lambda: K.dwq_fwd(xc, lo, hi, w3, gm, dil, dil, 1, slope, lo, hi, False)), 2 * n)
+        rep(f"dwq_bwd_z C={C} dil={dil}", timeit(lambda: K.dwq_bwd_z(xc, lo, hi, w3, gm, g, dil, dil, 1, slope, lo, hi, gacc, gbb)), 9 * n)
+        gw3 = torch.zeros_like(w3)
+        rep(f"dwq_bwd_w C={C} dil={dil}", timeit(lambda: K.dwq_bwd_w(g, xc, lo, hi, gw3, dil, dil)), 5 * n)
+
 x128, x512 = act(CB), act(CF)
 for (ci, co, xin) in ((128, 512, x128), (512, 128, x512), (128, 1024, x128)):
     w = torch.randn(co, ci, 1, device=dev) * 0.05
