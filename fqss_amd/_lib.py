@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libfqss_hip.so")
+SO_PATH = os.environ.get("FQSS_LIB") or os.path.join(_HERE, "csrc", "libfqss_hip.so")   # FQSS_LIB: kernel A/B experiments
 
 P, I64, I32, F32, F64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double
 
@@ -21,6 +21,9 @@ _PROTOS = {
     "fqss_wq_fwd": [P, P, P, I64, I64, I64, P, P, P],
     "fqss_wq_bwd": [P, P, P, P, P, I64, I64, I64, P, P, I32, P],
     "fqss_gacc_flush": [P, P, P, P, P],
+    "fqss_gacc_flush_multi": [P, I32, P],
+    "fqss_wq_multi_fwd": [P, I32, I32, P],
+    "fqss_wq_multi_bwd": [P, I32, I32, P],
     "fqss_pwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_fwd_x3": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I64, I64, P],

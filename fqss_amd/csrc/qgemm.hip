@@ -20,6 +20,8 @@
 // natural [k][n] image in LDS and are transposed on the fly by ds_read_b64_tr_b16.
 //
 // Reference replaced: F.conv1d(k=1) of Conv1dQ / Conv1dNlQ (qat_layers.py:137-146, 202-212) and its autograd.
+#include <type_traits>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -29,9 +31,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int QBM = 128, QBN = 128, QBK = 32;
+// block tile 128(m) x 64(n) x 32(k): 4 waves as 2x2, each 64x32 (2 MFMA 32x32x16 tiles).  The narrow N tile keeps
+// LDS/VGPR use low enough for 3-4 workgroups per CU, whose load / MFMA / store phases then overlap each other
+// (ablation on MI355X: with 128x128 tiles and 1-2 workgroups per CU the three phases simply added up).
+constexpr int QBM = 128, QBN = 64, QBK = 32;
 constexpr int LDK = 40;    // bf16 per row of a k-contiguous image (32 + 8 pad = 80 B: conflict-free ds_read_b128)
-constexpr int LDN = 160;   // bf16 per row of an n-contiguous image (128 + 32 pad = 320 B: conflict-free tr reads)
+constexpr int LDN = 96;    // bf16 per row of an n-contiguous image (64 + 32 pad = 192 B: conflict-free tr reads)
+constexpr int LDT = 36;    // fp32 per row of the epilogue staging tile (32 + 4 pad, 16-B aligned rows)
+#ifndef FQSS_WGRAD_BLOCKS
+#define FQSS_WGRAD_BLOCKS 768
+#endif
 
 __device__ __forceinline__ unsigned short f2bf_trunc(float f) { return (unsigned short)(__float_as_uint(f) >> 16); }
 __device__ __forceinline__ float bf_trunc(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
@@ -67,11 +76,18 @@ struct QGemmArgs {
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
 //      2 wgrad (fp32 A split3, u8 B codes [n][k])  3 plain fp32 x fp32 (A split3 x B split3 = 9 exact products)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     constexpr int NA = (MODE >= 2) ? 3 : 1;                 // A images
     constexpr int NB = (MODE == 1 || MODE == 3) ? 3 : 1;    // B images
-    __shared__ __attribute__((aligned(16))) unsigned short As[NA][QBM][LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[NB][(MODE == 2) ? QBN : QBK][(MODE == 2) ? LDK : LDN];
+    constexpr int BROWS = (MODE == 2) ? QBN : QBK, BLD = (MODE == 2) ? LDK : LDN;
+    constexpr int A_BYTES = NA * QBM * LDK * 2, B_BYTES = NB * BROWS * BLD * 2;
+    constexpr int T_BYTES = 4 * 32 * LDT * 4;   // epilogue staging: one 32x32 fp32 tile per wave
+    constexpr int SMEM = (A_BYTES + B_BYTES > T_BYTES) ? A_BYTES + B_BYTES : T_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    typedef unsigned short (*AsT)[QBM][LDK];
+    typedef unsigned short (*BsT)[BROWS][BLD];
+    AsT As = reinterpret_cast<AsT>(smem);
+    BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -83,26 +99,39 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
     const int kend = (MODE == 2) ? min(g.K, kbeg + g.kchunk) : g.K;
     const int i0 = blockIdx.y * QBM, j0 = blockIdx.x * QBN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
     float rowsum = 0.0f;  // wgrad: running sum of this thread's piece of gz rows (for the min_x term)
 
+    // per-row epilogue coefficients of this block's 128 rows, staged once in LDS (fetching them per output
+    // element from global memory was ~60 % of the forward kernel's time)
+    __shared__ float rowc[3][QBM];
+    if constexpr (MODE == 0 || MODE == 3) {
+        if (tid < QBM) {
+            const int row = i0 + tid;
+            const bool ok = row < g.M;
+            rowc[0][tid] = (MODE == 0 && ok) ? g.dw[row] : 1.0f;
+            rowc[1][tid] = (MODE == 0 && ok) ? g.rw[row] : 0.0f;
+            rowc[2][tid] = (ok && g.bias != nullptr) ? g.bias[row] : 0.0f;
+        }
+    }
+
     // ---------------------------------------------------------------- staging (global -> regs -> LDS)
     uint4 ra_i8;            // MODE 0/1: 16 int8 weight codes
-    float4 ra_f[4];         // MODE 2: 16 fp32 gz
-    uint4 rb_u8;            // MODE 0/2: 16 u8 activation codes
-    float4 rb_f[4];         // MODE 1: 16 fp32 gz
+    float4 ra_f[4];         // MODE 2/3: 16 fp32 values
+    uint4 rb_u8;            // MODE 0/2: 16 u8 activation codes (threads < 128)
+    float4 rb_f[2];         // MODE 1/3: 8 fp32 values
     float rb_scale = 0.0f;  // MODE 1: delta_w of this thread's k row
 
-    const int a_row = tid >> 1, a_k = (tid & 1) * 16;              // A tile: 128 rows x 32 k
-    const int bk_row = tid >> 3, bk_n = (tid & 7) * 16;            // B tile [k][n]: 32 k x 128 n
-    const int bn_row = tid >> 1, bn_k = (tid & 1) * 16;            // B tile [n][k] (wgrad): 128 n x 32 k
+    const int a_row = tid >> 1, a_k = (tid & 1) * 16;              // A tile: 128 rows x 32 k, 16 per thread
+    const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;             // fp32 B tile [k][n]: 32 k x 64 n, 8 per thread
+    const int bu_row = (tid & 127) >> 2, bu_n = (tid & 3) * 16;    // u8 B tile [k][n]: 32 k x 64 n, 16 per thread (<128)
+    const int bn_row = (tid & 127) >> 1, bn_k = (tid & 1) * 16;    // u8 B tile [n][k] (wgrad): 64 n x 32 k (<128)
+    const bool b_u8_active = tid < 128;
 
     auto load_tiles = [&](int k0) {
         if constexpr (MODE < 2) {
@@ -128,14 +157,14 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
         if constexpr (MODE == 0) {
             const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb;
             rb_u8 = make_uint4(0, 0, 0, 0);
-            if (k0 + bk_row < kend && j0 + bk_n < g.N)
-                rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + j0 + bk_n);
+            if (b_u8_active && k0 + bu_row < kend && j0 + bu_n < g.N)
+                rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(k0 + bu_row) * g.ldb + j0 + bu_n);
         } else if constexpr (MODE == 1 || MODE == 3) {
             const float* Bp = (const float*)g.B + (int64_t)b * g.sBb;
             const bool ok = (k0 + bk_row < kend);
             rb_scale = (ok && MODE == 1) ? g.dw[k0 + bk_row] : 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2; ++q) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int n = j0 + bk_n + 4 * q;
                 if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + n);
@@ -144,7 +173,7 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
         } else {
             const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb;
             rb_u8 = make_uint4(0, 0, 0, 0);
-            if (j0 + bn_row < g.N && k0 + bn_k < kend)
+            if (b_u8_active && j0 + bn_row < g.N && k0 + bn_k < kend)
                 rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(j0 + bn_row) * g.ldb + k0 + bn_k);
         }
     };
@@ -167,10 +196,11 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
     };
 
     auto store_split3 = [&](unsigned short* d1, unsigned short* d2, unsigned short* d3, const float4* v, float scale,
-                            bool do_scale) {
+                            bool do_scale, auto nq_tag) {
+        constexpr int NQ = decltype(nq_tag)::value;   // float4 count: 4 (16 values) or 2 (8 values)
         unsigned short o1[16], o2[16], o3[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -179,7 +209,7 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
             }
         }
 #pragma unroll
-        for (int hsel = 0; hsel < 2; ++hsel) {
+        for (int hsel = 0; hsel < NQ / 2; ++hsel) {
             const int o = 8 * hsel;
             *reinterpret_cast<uint4*>(d1 + o) = make_uint4(o1[o] | (o1[o + 1] << 16), o1[o + 2] | (o1[o + 3] << 16),
                                                            o1[o + 4] | (o1[o + 5] << 16), o1[o + 6] | (o1[o + 7] << 16));
@@ -194,18 +224,20 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
         if constexpr (MODE < 2) {
             store_u8x16(&As[0][a_row][a_k], ra_i8, true);
         } else {
-            store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], ra_f, 1.0f, false);
+            store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], ra_f, 1.0f, false,
+                         std::integral_constant<int, 4>{});
             if constexpr (MODE == 2) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rowsum += (ra_f[q].x + ra_f[q].y) + (ra_f[q].z + ra_f[q].w);
             }
         }
         if constexpr (MODE == 0) {
-            store_u8x16(&Bs[0][bk_row][bk_n], rb_u8, false);
+            if (b_u8_active) store_u8x16(&Bs[0][bu_row][bu_n], rb_u8, false);
         } else if constexpr (MODE == 1 || MODE == 3) {
-            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, MODE == 1);
+            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, MODE == 1,
+                         std::integral_constant<int, 2>{});
         } else {
-            store_u8x16(&Bs[0][bn_row][bn_k], rb_u8, false);
+            if (b_u8_active) store_u8x16(&Bs[0][bn_row][bn_k], rb_u8, false);
         }
     };
 
@@ -226,31 +258,26 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
             for (int sp = 0; sp < NA * NB; ++sp) {
                 // smallest pieces first: (3,3) ... (1,1) so that the large products are added last
                 const int ia = (NA == 3) ? 2 - (sp / NB) : 0, ib = (NB == 3) ? 2 - (sp % NB) : 0;
-                bf16x8 af[2], bfr[2];
+                bf16x8 af[2], bfr;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
                     af[mi] = *reinterpret_cast<const bf16x8*>(&As[ia][wm * 64 + mi * 32 + lr][ks * 16 + 8 * lh]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (MODE == 2) {
-                        bfr[ni] = *reinterpret_cast<const bf16x8*>(&Bs[ib][wn * 64 + ni * 32 + lr][ks * 16 + 8 * lh]);
-                    } else {
-                        // B[k = 8h + j][col r]: two transposed 4x16 block reads (rows 8h+0..3 and 8h+4..7)
-                        const int kr = ks * 16 + 8 * (gq >> 1) + tq;
-                        const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
-                        union { bf16x8 v; s16x4 h[2]; } u;
-                        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)(&Bs[ib][kr][nc]));
-                        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3)))*)(&Bs[ib][kr + 4][nc]));
-                        bfr[ni] = u.v;
-                    }
+                if constexpr (MODE == 2) {
+                    bfr = *reinterpret_cast<const bf16x8*>(&Bs[ib][wn * 32 + lr][ks * 16 + 8 * lh]);
+                } else {
+                    // B[k = 8h + j][col r]: two transposed 4x16 block reads (rows 8h+0..3 and 8h+4..7)
+                    const int kr = ks * 16 + 8 * (gq >> 1) + tq;
+                    const int nc = wn * 32 + 16 * (gq & 1) + 4 * tp;
+                    union { bf16x8 v; s16x4 h[2]; } u;
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(&Bs[ib][kr][nc]));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(&Bs[ib][kr + 4][nc]));
+                    bfr = u.v;
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -275,32 +302,60 @@ __global__ __launch_bounds__(256) void k_qgemm(QGemmArgs g) {
         __syncthreads();
     }
     float* Cb = g.C + (int64_t)b * g.sCb;
+    if constexpr (MODE == 2) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = j0 + wn * 64 + ni * 32 + lr;
+        for (int mi = 0; mi < 2; ++mi) {
+            const int col = j0 + wn * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int row = i0 + rl;
+                if (row < g.M && col < g.N) atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * acc[mi][r] + mnx * rs[rl]);
+            }
+        }
+    } else {
+        // stage each 32x32 accumulator tile through LDS and store whole 128-B rows with 16 B per lane
+        // (the lane-per-column layout of the MFMA result would need 16 strided 4-B stores per tile: that
+        // store-issue-bound tail was 60 % of the forward kernel's time)
+        __syncthreads();   // every wave is done with As/Bs
+        float(*Tt)[LDT] = reinterpret_cast<float(*)[LDT]>(smem + wave * 32 * LDT * 4);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int rb = wm * 64 + mi * 32 + rl;   // row within the block
+                const float S = acc[mi][r];
+                float v = S;
+                if constexpr (MODE == 0) {
+                    v = rowc[0][rb] * (dx * S + mnx * rowc[1][rb]);
+                    if (g.bias != nullptr) v = v + rowc[2][rb];
+                } else if constexpr (MODE == 3) {
+                    if (g.bias != nullptr) v = S + rowc[2][rb];
+                }
+                Tt[rl][lr] = v;
+            }
+            // same-wave LDS round trip: program order + the compiler's lgkmcnt waits are sufficient
+            const int c4 = (lane & 7) * 4;
+            const int col = j0 + wn * 32 + c4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int rl = pass * 8 + (lane >> 3);
+                const int row = i0 + wm * 64 + mi * 32 + rl;
+                const float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
                 if (row < g.M && col < g.N) {
-                    const float S = acc[mi][ni][r];
-                    if constexpr (MODE == 0) {
-                        const float t = dx * S + mnx * g.rw[row];
-                        float v = g.dw[row] * t;
-                        if (g.bias != nullptr) v = v + g.bias[row];
-                        Cb[(int64_t)row * g.ldc + col] = v;
-                    } else if constexpr (MODE == 1) {
-                        Cb[(int64_t)row * g.ldc + col] = S;
-                    } else if constexpr (MODE == 3) {
-                        Cb[(int64_t)row * g.ldc + col] = (g.bias != nullptr) ? S + g.bias[row] : S;
+                    float* dst = Cb + (int64_t)row * g.ldc + col;
+                    if (col + 3 < g.N || col + 3 < g.ldc) {
+                        *reinterpret_cast<float4*>(dst) = t;    // columns >= N fall into the row padding
                     } else {
-                        atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * S + mnx * rs[rl]);
+                        dst[0] = t.x;
+                        if (col + 1 < g.N) dst[1] = t.y;
+                        if (col + 2 < g.N) dst[2] = t.z;
                     }
                 }
             }
         }
+    }
 }
 
 // per-channel weight codes for the q-GEMMs: idx [Co][Ci], idxT [Ci][Co], dw[Co], rw[Co] (one block per channel)
@@ -346,6 +401,7 @@ extern "C" int fqss_qpw_fwd(const uint8_t* xc, const int8_t* wi, const float* dw
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_xc >= M && ld_z >= M, "bad shape");
     FQSS_REQUIRE(Ci % 16 == 0 && Ci <= 512 && ld_xc % 16 == 0 && aligned16(xc) && aligned16(wi),
                  "q-GEMM needs Ci % 16 == 0, Ci <= 512 (exact fp32 integer sum) and 16-B aligned code rows");
+    FQSS_REQUIRE(aligned16(z) && ld_z % 4 == 0, "output rows must be 16-B aligned");
     if (B == 0 || M == 0) return FQSS_OK;
     QGemmArgs g{};
     g.A = wi; g.B = xc; g.C = z; g.M = Co; g.N = M; g.K = Ci;
@@ -363,6 +419,7 @@ extern "C" int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* d
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_gx >= M, "bad shape");
     FQSS_REQUIRE(Co % 16 == 0 && ld_gz % 4 == 0 && aligned16(gz) && aligned16(wiT) && (M % 4 == 0 || ld_gz >= ((M + 3) & ~3)),
                  "q-GEMM dgrad needs Co % 16 == 0 and 16-B aligned gradient rows");
+    FQSS_REQUIRE(aligned16(gx) && ld_gx % 4 == 0, "output rows must be 16-B aligned");
     if (B == 0 || M == 0) return FQSS_OK;
     QGemmArgs g{};
     g.A = wiT; g.B = gz; g.C = gx; g.M = Ci; g.N = M; g.K = Co;
@@ -387,7 +444,7 @@ extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* q
     g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_xc; g.sCb = 0;
     g.qmin_x = qmin_x; g.qmax_x = qmax_x;
     const int tiles = (int)(cdiv(Co, QBM) * cdiv(Ci, QBN));
-    int want = (int)cdiv(512, (int64_t)tiles * B);
+    int want = (int)cdiv(FQSS_WGRAD_BLOCKS, (int64_t)tiles * B);
     if (want < 1) want = 1;
     int kchunk = (int)cdiv(cdiv(M, want), 64) * 64;
     if (kchunk < 64) kchunk = 64;
@@ -405,6 +462,7 @@ extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* b
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= M && ld_z >= M, "bad shape");
     FQSS_REQUIRE(Ci % 4 == 0 && ld_x % 4 == 0 && aligned16(x) && aligned16(w) && ld_x >= ((M + 3) & ~3),
                  "x3 GEMM needs Ci % 4 == 0 and 16-B aligned activation rows");
+    FQSS_REQUIRE(aligned16(z) && ld_z % 4 == 0, "output rows must be 16-B aligned");
     if (B == 0 || M == 0) return FQSS_OK;
     QGemmArgs g{};
     g.A = w; g.B = x; g.C = z; g.M = Co; g.N = M; g.K = Ci;

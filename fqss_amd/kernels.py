@@ -163,6 +163,18 @@ def wq_bwd(w, g, axis, qmin, qmax, out=None):
     return gw, gmin, gmax
 
 
+def gacc_flush_multi(table):
+    _lib.call("fqss_gacc_flush_multi", _p(table), table.shape[0], _stream())
+
+
+def wq_multi_fwd(table, total_channels):
+    _lib.call("fqss_wq_multi_fwd", _p(table), table.shape[0], total_channels, _stream())
+
+
+def wq_multi_bwd(table, total_channels):
+    _lib.call("fqss_wq_multi_bwd", _p(table), table.shape[0], total_channels, _stream())
+
+
 def gacc_flush(gacc, gmin, gmax, gslope):
     _lib.call("fqss_gacc_flush", _p(gacc), _p(gmin), _p(gmax), _p(gslope), _stream())
 

@@ -63,6 +63,25 @@ FAST = False
 DEBUG_POISON = bool(int(__import__("os").environ.get("FQSS_DEBUG_CARRIER", "0")))   # NaN-fill carriers (tests)
 
 
+# ---- deferred per-quantizer work ------------------------------------------------------------------
+# When a runtime.QuantTables is active (DEFER), the per-call gacc flush and the per-weight fake-quant
+# backward are NOT launched by the Functions; the stepper runs them once per step as multi-tensor kernels.
+DEFER = None
+
+
+class deferred:
+    def __init__(self, tables):
+        self.t = tables
+
+    def __enter__(self):
+        global DEFER
+        self.prev, DEFER = DEFER, self.t
+
+    def __exit__(self, *a):
+        global DEFER
+        DEFER = self.prev
+
+
 class fast_codes:
     def __init__(self, on=True):
         self.on = on
@@ -134,8 +153,17 @@ def _epilogue_fwd(z, act, slope, q):
     return K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws)
 
 
+def _touch(*params):
+    for p in params:
+        if p is not None:
+            p._fqss_touched = True
+
+
 def _flush_ranges(q, slope, slope_param, act):
     """fp64 partial slots -> fp32 parameter gradients (ranges always, slope for PReLU)"""
+    if q.owner is not None and getattr(q.owner, "_fqss_deferred", False):
+        _touch(slope_param if act == ACT_PRELU else None, q.owner.min_range, q.owner.max_range)
+        return None, None, None        # flushed once per step by fqss_gacc_flush_multi
     s_buf = None
     s_direct = True
     if act == ACT_PRELU:
@@ -157,7 +185,10 @@ def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=N
         gb, gb_direct = _grad_buf(bias_param, bias_like)
     gz = K.actq_bwd(z, g, act, slope, q.qmode, q.qmin, q.qmax, gacc, gbias=gb, C=C)
     g_slope = g_min = g_max = None
-    if need_acc:
+    if need_acc and q.owner is not None and getattr(q.owner, "_fqss_deferred", False):
+        _touch(slope_param if act == ACT_PRELU else None, q.owner.min_range if q.qmode == Q_QUANT else None,
+               q.owner.max_range if q.qmode == Q_QUANT else None)
+    elif need_acc:
         s_buf = mn_buf = mx_buf = None
         s_direct = mn_direct = mx_direct = True
         if act == ACT_PRELU:
@@ -268,15 +299,19 @@ class LinearActQ(Function):
         if ctx.needs_input_grad[0]:
             gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)
         gw = None
-        if ctx.needs_input_grad[1]:
-            # w here is the fake-quantized weight (a non-leaf): its gradient always goes back through autograd
-            gw = torch.zeros_like(w)
+        gwq = getattr(w, "_fqss_gwq", None)    # deferred mode: dL/dW_q accumulates in the step's arena
+        if ctx.needs_input_grad[1] or gwq is not None:
+            # w here is the fake-quantized weight (a non-leaf): its gradient goes back through autograd, or
+            # (deferred) into the arena consumed by fqss_wq_multi_bwd
+            gw = gwq if gwq is not None else torch.zeros_like(w)
             if ctx.xq is not None:
                 K.qpw_bwd_w(gz, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
             else:
                 _lin_bwd_w(L, gz, x, gw)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
+            if gwq is not None:
+                gw = None
         return gx, gw, g_bias, g_slope, g_min, g_max, None, None, None, None, None
 
 
@@ -340,11 +375,14 @@ class DwConvQ(Function):
         g_slope, g_min, g_max = _flush_ranges(q, slope, L.slope_param, act)
         gx = K.dwconv_bwd_x(gz, w, L.dil, L.pad) if ctx.needs_input_grad[0] else None
         gw = None
-        if ctx.needs_input_grad[1]:
-            gw = torch.zeros_like(w)
+        gwq = getattr(w, "_fqss_gwq", None)
+        if ctx.needs_input_grad[1] or gwq is not None:
+            gw = gwq if gwq is not None else torch.zeros_like(w)
             K.dwq_bwd_w(gz, xc, xmin, xmax, gw, L.dil, L.pad)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
+            if gwq is not None:
+                gw = None
         return gx, gw, (None if gb_direct else gb), g_slope, g_min, g_max, None, None, None, None
 
 

@@ -112,6 +112,9 @@ class GradientWeightFakeQuantize(nn.Module):
             K.wq_observe(x.detach(), self.axis, self.min_range.data, self.max_range.data)
             self.observer_mode = False
             return x
+        pre = getattr(x, "_fqss_wq", None)
+        if pre is not None and ops.DEFER is not None:
+            return pre        # already fake-quantized this step by fqss_wq_multi_fwd (runtime.QuantTables)
         wq = ops.WeightFq.apply(x, self.min_range, self.max_range, self.axis, self, w_param if w_param is not None else x)
         if self.axis == 0 and x.dim() == 3 and x.shape[2] == 1 and K.q_eligible(x.shape[1], x.shape[0]):
             # pointwise-conv weight: also hand its int8 codes to the bf16-MFMA q-GEMMs (csrc/qgemm.hip)

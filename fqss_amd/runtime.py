@@ -67,6 +67,93 @@ class ParamArena:
                     max_norm, grad_scale, lr, betas[0], betas[1], eps, t0=self.t0)
 
 
+class QuantTables:
+    """Device-side descriptor tables that let ONE launch each do, for the whole model: the weight
+    fake-quant forward (+ int8 codes), its backward, and the range/slope gradient flush (csrc/multi.hip).
+    Built once the observer phase is over and the parameters live in a ParamArena (stable addresses)."""
+
+    def __init__(self, model, arena):
+        import torch.nn as nn
+        from .quantization.qat.qat_layers import LayerQ
+        from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
+        dev = arena.flat_p.device
+        # ---- activation quantizers: one gacc arena, flush table ---------------------------------
+        aqs = [m for m in model.modules() if isinstance(m, GradientActivationFakeQuantize)]
+        slope_of = {}
+        for layer in model.modules():
+            if isinstance(layer, LayerQ) and isinstance(getattr(layer, "nl", None), nn.PReLU):
+                slope_of[id(layer.activation_fake_quantize)] = layer.nl.weight
+        self.gacc = torch.zeros(len(aqs), K.GACC_DOUBLES, dtype=torch.float64, device=dev)
+        rows = []
+        for i, m in enumerate(aqs):
+            m._buffers["_gacc"] = self.gacc[i]
+            m._fqss_deferred = True
+            sl = slope_of.get(id(m))
+            rows.append([self.gacc[i].data_ptr(), m.min_range.grad.data_ptr(), m.max_range.grad.data_ptr(),
+                         sl.grad.data_ptr() if sl is not None else 0])
+        self.flush_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.aqs = aqs
+        # ---- weight quantizers --------------------------------------------------------------------
+        owners = []
+        for layer in model.modules():
+            wqm = getattr(layer, "weight_fake_quantize", None)
+            if isinstance(wqm, GradientWeightFakeQuantize):
+                for cand in ("conv1d", "convTr1d", "residual_encoder"):
+                    conv = getattr(layer, cand, None)
+                    if conv is not None and hasattr(conv, "weight") and tuple(wqm.min_range.shape) == tuple(
+                            1 if d != wqm.axis else conv.weight.shape[d] for d in range(conv.weight.dim())):
+                        owners.append((wqm, conv.weight))
+                        break
+        n_gwq = sum((w.numel() + 63) // 64 * 64 for _, w in owners)
+        self.gwq = torch.zeros(n_gwq, device=dev)                       # dL/dW_q arena (zeroed once per step)
+        self.wq_store = torch.empty(n_gwq, device=dev)
+        rows, off, blk = [], 0, 0
+        self.weights = []
+        for wqm, w in owners:
+            shape, axis = tuple(w.shape), wqm.axis
+            outer = 1
+            for d in shape[:axis]:
+                outer *= d
+            inner = 1
+            for d in shape[axis + 1:]:
+                inner *= d
+            C = shape[axis]
+            wq = self.wq_store[off:off + w.numel()].view(shape)
+            gwq = self.gwq[off:off + w.numel()].view(shape)
+            pw = axis == 0 and w.dim() == 3 and shape[2] == 1 and K.q_eligible(shape[1], shape[0])
+            wc = None
+            if pw:
+                wc = K.WCodes()
+                wc.Co, wc.Ci = shape[0], shape[1]
+                wc.idx = torch.empty(shape[0], shape[1], device=dev, dtype=torch.int8)
+                wc.idxT = torch.empty(shape[1], shape[0], device=dev, dtype=torch.int8)
+                wc.dw = torch.empty(shape[0], device=dev)
+                wc.rw = torch.empty(shape[0], device=dev)
+            rows.append([w.data_ptr(), wq.data_ptr(), wc.idx.data_ptr() if pw else 0, wc.idxT.data_ptr() if pw else 0,
+                         wc.dw.data_ptr() if pw else 0, wc.rw.data_ptr() if pw else 0, wqm.min_range.data_ptr(),
+                         wqm.max_range.data_ptr(), gwq.data_ptr(), w.grad.data_ptr(), wqm.min_range.grad.data_ptr(),
+                         wqm.max_range.grad.data_ptr(), outer, C, inner, blk])
+            wq._fqss_gwq = gwq
+            if pw:
+                wq._fqss_wcodes = wc
+            w._fqss_wq = wq
+            self.weights.append((wqm, w, wq, wc))
+            off += (w.numel() + 63) // 64 * 64
+            blk += C
+        self.wq_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.total_channels = blk
+
+    def weights_forward(self):
+        K.wq_multi_fwd(self.wq_table, self.total_channels)
+
+    def finish_backward(self):
+        """after autograd: weight STE/range gradients from the dL/dW_q arena, then every range/slope flush"""
+        K.wq_multi_bwd(self.wq_table, self.total_channels)
+        K.gacc_flush_multi(self.flush_table)
+        for wqm, w, _, _ in self.weights:
+            w._fqss_touched = wqm.min_range._fqss_touched = wqm.max_range._fqss_touched = True
+
+
 class KDTrainStep:
     """one QAT step = student fwd + teacher fwd + KD loss + bwd (+ grad all-reduce) + clip + Adam
     (reference: System.training_step / common_step, mysystem.py:124-157; Adam + clip 5.0,
@@ -84,6 +171,7 @@ class KDTrainStep:
         for p in fmodel.parameters():
             p.requires_grad_(False)
         self.last = None
+        self.tables = None          # QuantTables once the quantizing phase is reached
         self._graphs = None
         self.use_graph = True
         self._sx = self._st = None
@@ -92,13 +180,32 @@ class KDTrainStep:
     def _fwd_bwd(self, x, tgt):
         a = self.arena
         a.zero_grad()
-        with ops.fast_codes(True):         # student: codes-only dataflow between quantizing layers
+        t = self._quant_tables()
+        if t is not None:
+            t.gwq.zero_()
+            t.weights_forward()                # all 101 weight fake-quants (+ int8 codes): one launch
+        with ops.fast_codes(True), ops.deferred(t):     # student: codes-only dataflow between quantizing layers
             est = self.model(x)
         with torch.no_grad():
             fest = self.fmodel(x)
         out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
-        est.backward(gest)
+        with ops.deferred(t):
+            est.backward(gest)
+        if t is not None:
+            t.finish_backward()                # weight STE + every range/slope gradient: two launches
         return dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
+
+    def _quant_tables(self):
+        """batched per-quantizer work becomes available once every observer has finished"""
+        if self.tables is None:
+            from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
+            for m in self.model.modules():
+                if isinstance(m, GradientActivationFakeQuantize) and m.observer_mode and m.n_iter < m.max_observations:
+                    return None
+                if isinstance(m, GradientWeightFakeQuantize) and m.observer_mode:
+                    return None
+            self.tables = QuantTables(self.model, self.arena)
+        return self.tables
 
     def _world(self):
         return self.comm.world if self.comm is not None else 1

@@ -106,6 +106,19 @@ int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* g
                 int accumulate, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * multi-tensor forms of the per-quantizer small work (csrc/multi.hip): ONE launch each, driven by a
+ * device table of int64 words the host builds once.
+ *   flush table  : n x 4  = {gacc, gmin, gmax, gslope} addresses (0 = absent)
+ *   weight table : n x 16 = {w, wq, idx, idxT, dw, rw, qmin, qmax, gwq, gw, gmin, gmax, outer, C, inner,
+ *                  first_block}; entries sorted by first_block, one workgroup per output channel;
+ *                  idx/idxT/dw/rw only for pointwise-conv weights (0 otherwise);
+ *                  bwd: gw += STE(gwq), gmin/gmax += range gradients  (gwq = accumulated dL/dW_q)
+ * ------------------------------------------------------------------------------------------- */
+int fqss_gacc_flush_multi(const int64_t* table, int n, fqss_stream_t stream);
+int fqss_wq_multi_fwd(const int64_t* table, int n, int total_channels, fqss_stream_t stream);
+int fqss_wq_multi_bwd(const int64_t* table, int n, int total_channels, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K4/K5  pointwise (k=1) Conv1d as an fp32-MFMA GEMM:  z[b] = W[Co x Ci] * x[b][Ci x M] + bias
  * replaces: F.conv1d(k=1) in Conv1dQ / Conv1dNlQ (qat_layers.py:137-146, 202-212) + autograd
  * ------------------------------------------------------------------------------------------- */

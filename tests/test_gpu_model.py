@@ -335,3 +335,26 @@ def test_hipgraph_replay_matches_eager(golden):
     np.testing.assert_allclose(l0[0], l1[0], rtol=1e-6)
     np.testing.assert_allclose(l0[1:], l1[1:], atol=0.05)          # dB; chaotic after the first quantized update
     assert float((p0 - p1).abs().max()) < 5e-3
+
+
+def test_batched_quant_tables_match_per_module_path(golden):
+    """multi-tensor weight fake-quant / range-flush kernels (runtime.QuantTables) vs the per-module
+    autograd path: same state, same batch -> same loss and the same flat gradient"""
+    from fqss_amd.runtime import KDTrainStep
+    g = golden("tiny_step")
+    x, tgt = T(g["x"]).cuda(), T(g["tgt"]).cuda()
+    grads, losses = [], []
+    for batched in (False, True):
+        model, fmodel = _tiny_pair(g, prefix="s50.post_sd.")
+        _leave_observer(model)
+        step = KDTrainStep(model, fmodel)
+        if not batched:
+            step._quant_tables = lambda: None
+        r = step._fwd_bwd(x, tgt)
+        assert (step.tables is not None) == batched
+        losses.append(r["loss"].item())
+        grads.append(step.arena.flat_g.clone())
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-6)
+    ref = grads[0]
+    err = float((grads[0] - grads[1]).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-7, err
