@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
     __shared__ float redf[4];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
-    const int cstep = gridDim.x * 256 * 4;
+    const int cstep = gridDim.x * 256 * 16;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
     for (int c = blockIdx.y; c < C; c += gridDim.y) {
         float wk[kTaps];
@@ -319,7 +319,11 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
         for (int b = 0; b < B; ++b) {
             const int64_t row = (int64_t)b * C + c;
             const uint8_t* xr = xc + row * ld_xc;
-            for (int m = (blockIdx.x * 256 + threadIdx.x) * 4; m < M; m += cstep) {
+            for (int m0 = (blockIdx.x * 256 + threadIdx.x) * 16; m0 < M; m0 += cstep)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int m = m0 + 4 * qq;
+                if (m >= M) break;
                 float z[4], o[4];
                 dwq_z4(xr, m, M, (int)ld_xc, wk, K, dil, pad, bv, rx, z);
                 const float4 gv4 = *reinterpret_cast<const float4*>(g + row * ld_g + m);
@@ -525,7 +529,7 @@ extern "C" int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const floa
                      ld_g >= ((M + 3) & ~3) && ld_gz >= ((M + 3) & ~3), "rows must be 16-B aligned");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     if (B == 0 || M == 0) return FQSS_OK;
-    int64_t gx_ = cdiv(M, 256 * 4);
+    int64_t gx_ = cdiv(M, 256 * 16);
     if (gx_ > 64) gx_ = 64;
     int64_t gy = kSlots / gx_;
     if (gy > C) gy = C;
