@@ -37,6 +37,8 @@ _PROTOS = {
     "fqss_gnq_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],
     "fqss_dwq_fwd": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P],
     "fqss_dwq_bwd_z": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],
+    "fqss_ewq_fwd": [P, P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I64, I32, P, P, P, P],
+    "fqss_ewq_bwd": [P, P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
     "fqss_dwq_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_dwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_dwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],

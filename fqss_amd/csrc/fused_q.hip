@@ -407,6 +407,123 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_w(const float* __restrict__ gz,
         for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[k]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// element-wise layers on codes: out = fq( act( dec(a) + sb * (dec(b) | b_fp32) ) )  -- AddQ, the residual
+// Sub of ResidualErrorBlock (b in fp32), NlQ (no b).  16 elements per thread, codes in / codes out.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ewq_fwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
+                                                  const float* __restrict__ bf, float sb, uint8_t* __restrict__ yc,
+                                                  float* __restrict__ yout, int rows, int cols, int ld_a, int ld_b, int ld_bf,
+                                                  int ld_y, int ld_o, int act, const float* slope_p, const float* amin,
+                                                  const float* amax, const float* bmin, const float* bmax, const float* qmin,
+                                                  const float* qmax) {
+    const QRange ra = load_qrange(amin, amax), ry = load_qrange(qmin, qmax);
+    QRange rb{0.f, 1.f, 1.f};
+    if (bc != nullptr) rb = load_qrange(bmin, bmax);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 16; c0 < cols; c0 += gridDim.x * 256 * 16) {
+            const uint4 va = *reinterpret_cast<const uint4*>(ac + (int64_t)row * ld_a + c0);
+            const unsigned int wa[4] = {va.x, va.y, va.z, va.w};
+            unsigned int wb[4] = {0, 0, 0, 0};
+            if (bc != nullptr) {
+                const uint4 vb = *reinterpret_cast<const uint4*>(bc + (int64_t)row * ld_b + c0);
+                wb[0] = vb.x; wb[1] = vb.y; wb[2] = vb.z; wb[3] = vb.w;
+            }
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bf != nullptr && c0 + 4 * q < cols) {
+                    const float4 t = *reinterpret_cast<const float4*>(bf + (int64_t)row * ld_bf + c0 + 4 * q);
+                    bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+                }
+                unsigned int pk = 0;
+                float fo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float z = dec((wa[q] >> (8 * e)) & 255u, ra);
+                    if (bc != nullptr) z = z + sb * dec((wb[q] >> (8 * e)) & 255u, rb);
+                    else if (bf != nullptr) z = z + sb * bv[e];
+                    float cq, u;
+                    bool inr;
+                    fo[e] = fq_asym(act_apply(z, act, slope), ry, cq, u, inr);
+                    pk |= ((unsigned int)cq & 255u) << (8 * e);
+                }
+                o[q] = pk;
+                if (yout != nullptr && c0 + 4 * q < cols)
+                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + c0 + 4 * q) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+            }
+            *reinterpret_cast<uint4*>(yc + (int64_t)row * ld_y + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// backward: recompute z from the input codes; gz = STE(act') ; range/slope partials to the gacc slots
+__global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
+                                                  const float* __restrict__ bf, float sb, const float* __restrict__ g,
+                                                  float* __restrict__ gz, int rows, int cols, int ld_a, int ld_b, int ld_bf,
+                                                  int ld_g, int ld_gz, int act, const float* slope_p, const float* amin,
+                                                  const float* amax, const float* bmin, const float* bmax, const float* qmin,
+                                                  const float* qmax, double* gacc) {
+    __shared__ double red[3 * 4];
+    const QRange ra = load_qrange(amin, amax), ry = load_qrange(qmin, qmax);
+    QRange rb{0.f, 1.f, 1.f};
+    if (bc != nullptr) rb = load_qrange(bmin, bmax);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < cols; c0 += gridDim.x * 256 * 4) {
+            const unsigned int wa = *reinterpret_cast<const unsigned int*>(ac + (int64_t)row * ld_a + c0);
+            const unsigned int wb = bc ? *reinterpret_cast<const unsigned int*>(bc + (int64_t)row * ld_b + c0) : 0u;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bf != nullptr) {
+                const float4 t = *reinterpret_cast<const float4*>(bf + (int64_t)row * ld_bf + c0);
+                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+            }
+            const float4 g4 = *reinterpret_cast<const float4*>(g + (int64_t)row * ld_g + c0);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = c0 + e < cols;
+                const float gj = valid ? gv[e] : 0.0f;
+                float z = dec((wa >> (8 * e)) & 255u, ra);
+                if (bc != nullptr) z = z + sb * dec((wb >> (8 * e)) & 255u, rb);
+                else if (bf != nullptr) z = z + sb * bv[e];
+                const float t = act_apply(z, act, slope);
+                float cq, u;
+                bool inr;
+                (void)fq_asym(t, ry, cq, u, inr);
+                const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+                if (valid) {
+                    p_du += gj * (inr ? (cq - u) : cq);
+                    p_out += inr ? 0.0f : gj;
+                }
+                float gzj = gt;
+                if (act == FQSS_ACT_PRELU) {
+                    const bool pos = z > 0.0f;
+                    gzj = pos ? gt : slope * gt;
+                    if (valid && !pos) p_slope += z * gt;
+                } else if (act == FQSS_ACT_RELU) {
+                    gzj = (t > 0.0f) ? gt : 0.0f;
+                }
+                o[e] = gzj;
+            }
+            *reinterpret_cast<float4*>(gz + (int64_t)row * ld_gz + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
+    block_sum<double, 3>(v, red);
+    if (threadIdx.x == 0) {
+        double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+        const double dmax = v[0] / 255.0;
+        slot[0] += v[1] - dmax;
+        slot[1] += dmax;
+        slot[2] += v[2];
+    }
+}
+
 // shared with stream_ops.hip's GroupNorm backward
 __global__ void k_gnq_bwd_coef(const float* __restrict__ gamma, const float* __restrict__ mean_rstd, int B, int C, int M,
                                double* ws, float* ggamma, float* gbeta) {
@@ -548,4 +665,46 @@ extern "C" int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* q
     hipLaunchKernelGGL(k_dwq_bwd_w, dim3((unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, gz, xc, gw, C, M, K, dil,
                        pad, ld_gz, ld_xc, qmin_x, qmax_x);
     return launch_status("fqss_dwq_bwd_w");
+}
+
+extern "C" int fqss_ewq_fwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,
+                            const float* bmax, const float* bf, float sb, uint8_t* yc, float* yout, int64_t rows, int64_t cols,
+                            int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_y, int64_t ld_out, int act, const float* slope,
+                            const float* qmin, const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(ac && amin && amax && yc && qmin && qmax, "null pointer");
+    FQSS_REQUIRE(!(bc && bf), "second operand is either codes or fp32");
+    FQSS_REQUIRE(!bc || (bmin && bmax), "coded second operand needs its ranges");
+    FQSS_REQUIRE(rows >= 0 && cols >= 0 && rows < (1ll << 30) && ld_a < (1ll << 30), "bad shape");
+    FQSS_REQUIRE(codes_ok(ac, ld_a) && codes_ok(yc, ld_y) && (!bc || codes_ok(bc, ld_b)) && ld_a >= cols && ld_y >= cols,
+                 "code rows must be 16-B aligned");
+    FQSS_REQUIRE(!bf || (aligned16(bf) && ld_bf % 4 == 0 && ld_bf >= ((cols + 3) & ~3)), "bad fp32 operand rows");
+    FQSS_REQUIRE(!yout || (aligned16(yout) && ld_out % 4 == 0 && ld_out >= ((cols + 3) & ~3)), "bad fp32 output rows");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_ewq_fwd, grid_rows(rows, cols, 16), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, yc, yout,
+                       (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_y, (int)ld_out, act, slope, amin, amax,
+                       bmin, bmax, qmin, qmax);
+    return launch_status("fqss_ewq_fwd");
+}
+
+extern "C" int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,
+                            const float* bmax, const float* bf, float sb, const float* g, float* gz, int64_t rows, int64_t cols,
+                            int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_g, int64_t ld_gz, int act, const float* slope,
+                            const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+    FQSS_REQUIRE(ac && amin && amax && g && gz && qmin && qmax && gacc, "null pointer");
+    FQSS_REQUIRE(!(bc && bf) && (!bc || (bmin && bmax)), "bad second operand");
+    FQSS_REQUIRE(rows >= 0 && cols >= 0 && rows < (1ll << 30) && ld_a < (1ll << 30), "bad shape");
+    FQSS_REQUIRE(codes_ok(ac, ld_a) && (!bc || codes_ok(bc, ld_b)) && aligned16(g) && aligned16(gz) && ld_g % 4 == 0 &&
+                     ld_gz % 4 == 0 && ld_g >= ((cols + 3) & ~3) && ld_gz >= ((cols + 3) & ~3), "rows must be 16-B aligned");
+    FQSS_REQUIRE(!bf || (aligned16(bf) && ld_bf % 4 == 0 && ld_bf >= ((cols + 3) & ~3)), "bad fp32 operand rows");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    int64_t gx_ = cdiv(cols, 256 * 4);
+    if (gx_ > 64) gx_ = 64;
+    int64_t gy = kSlots / gx_;
+    if (gy > rows) gy = rows;
+    hipLaunchKernelGGL(k_ewq_bwd, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
+                       (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
+                       bmin, bmax, qmin, qmax, gacc);
+    return launch_status("fqss_ewq_bwd");
 }

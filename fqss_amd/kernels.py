@@ -335,6 +335,40 @@ def dwq_bwd_z(xc, qmin_x, qmax_x, w, bias, g, dil, pad, act, slope, qmin, qmax, 
     return gz
 
 
+def _codes2(xc):
+    rm = rowmat(xc)
+    assert rm is not None and rm[2] % 16 == 0 and xc.data_ptr() % 16 == 0, "bad code layout"
+    return rm
+
+
+def ewq_fwd(ac, amin, amax, bc, bmin, bmax, bf, sb, act, slope, qmin, qmax, write_out):
+    """y = fq(act(dec(a) + sb*B)); B = codes bc | fp32 bf | None.  returns (carrier/out, codes)"""
+    rows, cols, ld_a = _codes2(ac)
+    ld_b = _codes2(bc)[2] if bc is not None else 0
+    ld_bf = 0
+    if bf is not None:
+        bf, ld_bf = _aligned_grad(bf)
+    yc = empty_codes(tuple(ac.shape), ac.device)
+    out = empty_act(tuple(ac.shape), ac.device)
+    _lib.call("fqss_ewq_fwd", _p(ac), _p(amin), _p(amax), _p(bc), _p(bmin), _p(bmax), _p(bf), float(sb), _p(yc),
+              _p(out) if write_out else None, rows, cols, ld_a, ld_b, ld_bf, rowmat(yc)[2], rowmat(out)[2], act, _p(slope),
+              _p(qmin), _p(qmax), _stream())
+    return out, yc
+
+
+def ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, sb, g, act, slope, qmin, qmax, gacc):
+    rows, cols, ld_a = _codes2(ac)
+    ld_b = _codes2(bc)[2] if bc is not None else 0
+    ld_bf = 0
+    if bf is not None:
+        bf, ld_bf = _aligned_grad(bf)
+    g, ld_g = _aligned_grad(g)
+    gz = empty_act(tuple(ac.shape), ac.device)
+    _lib.call("fqss_ewq_bwd", _p(ac), _p(amin), _p(amax), _p(bc), _p(bmin), _p(bmax), _p(bf), float(sb), _p(g), _p(gz),
+              rows, cols, ld_a, ld_b, ld_bf, ld_g, rowmat(gz)[2], act, _p(slope), _p(qmin), _p(qmax), _p(gacc), _stream())
+    return gz
+
+
 def dwq_bwd_w(gz, xc, qmin_x, qmax_x, gw, dil, pad):
     B, C, M, ld_xc = _codes3(xc)
     _lib.call("fqss_dwq_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), B, C, M, gw.shape[-1], dil, pad,

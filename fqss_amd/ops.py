@@ -386,6 +386,47 @@ class DwConvQ(Function):
         return gx, gw, (None if gb_direct else gb), g_slope, g_min, g_max, None, None, None, None
 
 
+class EwQ(Function):
+    """out = fq(act(a + sb*b)) on coded a (b: coded | real fp32 | absent), codes -> codes; the backward
+    recomputes z from the codes.  AddQ / Sub of the residual block / NlQ in the quantizing phase."""
+
+    @staticmethod
+    def forward(ctx, a, b, slope, qmin, qmax, sb, act, q, aq_, bq_, slope_param):
+        q.carrier = FAST and not q.keep_out
+        bf = None if (b is None or bq_ is not None) else b
+        out, q.idx = K.ewq_fwd(aq_.idx, aq_.qmin, aq_.qmax, bq_.idx if bq_ else None, bq_.qmin if bq_ else None,
+                               bq_.qmax if bq_ else None, bf, sb, act, slope, qmin, qmax, write_out=not q.carrier)
+        ctx.save_for_backward(aq_.idx, aq_.qmin, aq_.qmax, bq_.idx if bq_ else None, bq_.qmin if bq_ else None,
+                              bq_.qmax if bq_ else None, bf, slope, qmin, qmax)
+        ctx.sb, ctx.act, ctx.q, ctx.sp, ctx.has_b = sb, act, q, slope_param, b is not None
+        return _carrier(out) if q.carrier else out
+
+    @staticmethod
+    def backward(ctx, g):
+        ac, amin, amax, bc, bmin, bmax, bf, slope, qmin, qmax = ctx.saved_tensors
+        q = ctx.q
+        gz = K.ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, ctx.sb, g, ctx.act, slope, qmin, qmax, q.gacc)
+        g_slope, g_min, g_max = _flush_ranges(q, slope, ctx.sp, ctx.act)
+        ga = gz if ctx.needs_input_grad[0] else None
+        gb = None
+        if ctx.has_b and ctx.needs_input_grad[1]:
+            gb = gz if ctx.sb == 1.0 else K.axpby(gz, gz, 0.0, sa=float(ctx.sb))
+        return ga, gb, g_slope, g_min, g_max, None, None, None, None, None, None
+
+
+def ew_layer(x1, x2, sb, act, slope, q):
+    """dispatch an element-wise quantized layer: coded kernel when the first operand carries codes and the
+    layer quantizes, the fp32 kernels otherwise (decoding carriers first)"""
+    aq_ = codes_of(x1)
+    if aq_ is not None and q.qmode == Q_QUANT and q.gacc is not None:
+        bq_ = codes_of(x2) if x2 is not None else None
+        b = x2 if (x2 is None or bq_ is not None) else real(x2)
+        return EwQ.apply(x1, b, slope, q.qmin, q.qmax, sb, act, q, aq_, bq_, slope)
+    if x2 is None:
+        return NlActQ.apply(real(x1), slope, q.qmin, q.qmax, act, q, slope)
+    return AddActQ.apply(real(x1), real(x2), q.qmin, q.qmax, sb, q)
+
+
 class AddActQ(Function):
     """out = fq(a + sign*b)  -- AddQ (sign=+1), ResidualErrorBlock's Y - Y_q (sign=-1)"""
 

@@ -96,7 +96,7 @@ class AddQ(LayerQ):
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        y = ops.AddActQ.apply(ops.real(x1), ops.real(x2), q.qmin, q.qmax, 1.0, q)
+        y = ops.ew_layer(x1, x2, 1.0, ops.ACT_NONE, None, q)
         aq.after_forward(q)
         return ops.tag_codes(y, q)
 
@@ -110,7 +110,7 @@ class SubQ(LayerQ):
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        y = ops.AddActQ.apply(ops.real(x1), ops.real(x2), q.qmin, q.qmax, -1.0, q)
+        y = ops.ew_layer(x1, x2, -1.0, ops.ACT_NONE, None, q)
         aq.after_forward(q)
         return ops.tag_codes(y, q)
 
@@ -233,7 +233,7 @@ def run_groupnorm(gn, x, aq):
 def run_nl(nl, x, aq):
     act, slope = _act_of(nl)
     q = aq.qctx() if aq is not None else ops.BYPASS
-    y = ops.NlActQ.apply(ops.real(x), slope, q.qmin, q.qmax, act, q, slope)
+    y = ops.ew_layer(x, None, 0.0, act, slope, q)
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)
@@ -314,7 +314,7 @@ class ResidualErrorBlock(LayerQ):
         Y_q = run_conv1d(enc, y_q, self._wq(enc.weight), None, None)
         aq = self.activation_fake_quantize
         q = aq.qctx()
-        Y1 = ops.tag_codes(ops.AddActQ.apply(ops.real(Y), ops.real(Y_q), q.qmin, q.qmax, -1.0, q), q)
+        Y1 = ops.tag_codes(ops.ew_layer(Y, Y_q, -1.0, ops.ACT_NONE, None, q), q)
         aq.after_forward(q)
         Y1 = ops.real(Y1)
         if decoder_conv is None:

@@ -208,6 +208,18 @@ int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const float* qmax_x, 
                    int pad, int64_t ld_xc, int64_t ld_g, int64_t ld_gz, int act, const float* slope,
                    const float* qmin, const float* qmax, double* gacc, float* gbias,
                    fqss_stream_t stream);
+/* element-wise layer on codes: y = fq(act(dec(a) + sb * B)), B = dec(bc) | bf (fp32) | absent  -- AddQ,
+ * ResidualErrorBlock's Sub, NlQ.  bwd: gz = dL/dz recomputed from the codes (ga = gz, gb = sb*gz). */
+int fqss_ewq_fwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc,
+                 const float* bmin, const float* bmax, const float* bf, float sb, uint8_t* yc, float* yout,
+                 int64_t rows, int64_t cols, int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_y,
+                 int64_t ld_out, int act, const float* slope, const float* qmin, const float* qmax,
+                 fqss_stream_t stream);
+int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc,
+                 const float* bmin, const float* bmax, const float* bf, float sb, const float* g, float* gz,
+                 int64_t rows, int64_t cols, int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_g,
+                 int64_t ld_gz, int act, const float* slope, const float* qmin, const float* qmax,
+                 double* gacc, fqss_stream_t stream);
 /* gw[C][K] += */
 int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
                    float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_gz,
