@@ -1,0 +1,416 @@
+// teacher.hip -- the frozen float teacher of the KD step as a fused inference chain.
+//
+// The teacher (train_env/train_utils.py:25: deepcopy of the float model; mysystem.py:132-133: forward under
+// no_grad) needs no autograd and its weights never change, so per TCN block (convtasnetq.py:11-42) it runs as
+// THREE kernels instead of the ~11 of the module-by-module path:
+//   T1  k_tgemm        1x1 conv (+bias) + PReLU, GroupNorm statistics (sum, sum^2 per sample) in the epilogue
+//   T2  k_tdw          GroupNorm-apply on the fly + depthwise dilated conv (+bias) + PReLU + statistics
+//   T3  k_tgemm        res and skip 1x1 convs as ONE GEMM (Co = 256): GroupNorm-apply in the B-operand
+//                      prologue; epilogue adds the residual (rows < 128 -> next block input) and the running
+//                      skip sum (rows >= 128)
+// Every N_F-sized tensor is written once and read once (4 passes per block instead of ~17).
+// GEMMs: both operands fp32; the frozen weights are split ONCE into three exact bf16 planes
+// (fqss_split3_planes), activations are split on the fly: 9 exact bf16 products per k, fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16) -- the result is fp32-grade (same error class as an fp32 fma chain).
+#include <type_traits>
+
+#include "fqss_dev.h"
+
+namespace fqss {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TBM = 128, TBN = 64, TBK = 32;
+constexpr int TLDK = 40, TLDN = 96, TLDT = 36;
+
+__device__ __forceinline__ unsigned short t_bf(float f) { return (unsigned short)(__float_as_uint(f) >> 16); }
+__device__ __forceinline__ float t_tr(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
+__device__ __forceinline__ void t_split3(float g, unsigned short& b1, unsigned short& b2, unsigned short& b3) {
+    const float h1 = t_tr(g), r1 = g - h1, h2 = t_tr(r1), r2 = r1 - h2;
+    b1 = t_bf(h1);
+    b2 = t_bf(h2);
+    b3 = t_bf(r2);
+}
+
+__global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                        int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        unsigned short a, b, c;
+        t_split3(w[i], a, b, c);
+        planes[i] = a;
+        planes[n + i] = b;
+        planes[2 * n + i] = c;
+    }
+}
+
+struct TGemmArgs {
+    const unsigned short* A;   // [3][M][K] bf16 planes of the weight
+    const float* B;            // [batch][K][ldb] fp32 activations
+    int M, N, K;
+    int64_t ldb, sBb;
+    // prologue on B rows (k = input channel): 0 none, 1 GroupNorm affine, 2 PReLU
+    int pro;
+    const double* pro_stats;   // [batch][2] sum, sum^2 of the producer's output
+    const float* pro_gamma;    // [K]
+    const float* pro_beta;     // [K]
+    double pro_count;          // elements per sample (K * N)
+    float pro_eps;
+    const float* pro_slope;    // PReLU on the input
+    // epilogue
+    const float* bias;         // [M] or null
+    int act;                   // FQSS_ACT_*
+    const float* slope;
+    double* stats_out;         // [batch][2] or null
+    int M1;                    // rows [0,M1) -> C1 (+R1), rows [M1,M) -> C2 (+R2)
+    float* C1; const float* R1; int64_t ldc1, sC1b;
+    float* C2; const float* R2; int64_t ldc2, sC2b;
+};
+
+__global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
+    constexpr int A_BYTES = 3 * TBM * TLDK * 2, B_BYTES = 3 * TBK * TLDN * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+    typedef unsigned short (*AsT)[TBM][TLDK];
+    typedef unsigned short (*BsT)[TBK][TLDN];
+    AsT As = reinterpret_cast<AsT>(smem);
+    BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
+    __shared__ float rowb[TBM];
+    __shared__ double red[2 * 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, i0 = blockIdx.y * TBM, j0 = blockIdx.x * TBN;
+    const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+
+    if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
+
+    __shared__ float pms[2];
+    if (g.pro == 1 && tid == 0) {
+        const double mu = g.pro_stats[2 * b] / g.pro_count;
+        double var = g.pro_stats[2 * b + 1] / g.pro_count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        pms[0] = (float)mu;
+        pms[1] = (float)(1.0 / sqrt(var + (double)g.pro_eps));
+    }
+    __syncthreads();
+    const float pmean = (g.pro == 1) ? pms[0] : 0.f, prstd = (g.pro == 1) ? pms[1] : 1.f;
+    const float pslope = (g.pro == 2) ? *g.pro_slope : 0.0f;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    const int a_row = tid >> 1, a_k = (tid & 1) * 16;
+    const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;
+    const float* Bb = g.B + (int64_t)b * g.sBb;
+    const int64_t plane = (int64_t)g.M * g.K;
+    uint4 ra[3][2];
+    float4 rb[2];
+    float p_a = 1.f, p_b = 0.f;
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i0 + a_row < g.M && k0 + a_k + 8 * h < g.K)
+                    v = *reinterpret_cast<const uint4*>(g.A + p * plane + (int64_t)(i0 + a_row) * g.K + k0 + a_k + 8 * h);
+                ra[p][h] = v;
+            }
+        const int k = k0 + bk_row;
+        const bool ok = k < g.K;
+        if (g.pro == 1 && ok) {
+            p_a = prstd * g.pro_gamma[k];
+            p_b = fmaf(-p_a, pmean, g.pro_beta[k]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = j0 + bk_n + 4 * q;
+            if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bb + (int64_t)k * g.ldb + n);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = v;
+        }
+    };
+    auto store_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<uint4*>(&As[p][a_row][a_k]) = ra[p][0];
+            *reinterpret_cast<uint4*>(&As[p][a_row][a_k + 8]) = ra[p][1];
+        }
+        const bool ok = (k0 + bk_row) < g.K;
+        unsigned short o1[8], o2[8], o3[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = x[e];
+                if (g.pro == 1) t = fmaf(t, p_a, p_b);
+                else if (g.pro == 2) t = t > 0.f ? t : pslope * t;
+                if (!ok) t = 0.f;
+                t_split3(t, o1[4 * q + e], o2[4 * q + e], o3[4 * q + e]);
+            }
+        }
+        *reinterpret_cast<uint4*>(&Bs[0][bk_row][bk_n]) = make_uint4(o1[0] | (o1[1] << 16), o1[2] | (o1[3] << 16), o1[4] | (o1[5] << 16), o1[6] | (o1[7] << 16));
+        *reinterpret_cast<uint4*>(&Bs[1][bk_row][bk_n]) = make_uint4(o2[0] | (o2[1] << 16), o2[2] | (o2[3] << 16), o2[4] | (o2[5] << 16), o2[6] | (o2[7] << 16));
+        *reinterpret_cast<uint4*>(&Bs[2][bk_row][bk_n]) = make_uint4(o3[0] | (o3[1] << 16), o3[2] | (o3[3] << 16), o3[4] | (o3[5] << 16), o3[6] | (o3[7] << 16));
+    };
+
+    const int nkt = (g.K + TBK - 1) / TBK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tiles((kt + 1) * TBK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3][2], bfr[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    af[p][mi] = *reinterpret_cast<const bf16x8*>(&As[p][wm * 64 + mi * 32 + lr][ks * 16 + 8 * lh]);
+                const int kr = ks * 16 + 8 * (gq >> 1) + tq;
+                const int nc = wn * 32 + 16 * (gq & 1) + 4 * tp;
+                union { bf16x8 v; s16x4 h[2]; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                bfr[p] = u.v;
+            }
+            // 9 exact partial products, smallest pieces first
+#pragma unroll
+            for (int sp = 0; sp < 9; ++sp) {
+                const int ia = 2 - sp / 3, ib = 2 - sp % 3;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia][mi], bfr[ib], acc[mi], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tiles((kt + 1) * TBK);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: bias + act (+ residual), 16-B/lane row stores via an LDS staging tile, statistics
+    const float eslope = (g.act == FQSS_ACT_PRELU) ? *g.slope : 0.0f;
+    float(*Tt)[TLDT] = reinterpret_cast<float(*)[TLDT]>(smem + wave * 32 * TLDT * 4);
+    float s1 = 0.0f, s2 = 0.0f;   // <= 32 values per thread: fp32 partials, widened to fp64 for the cross-thread sum
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            Tt[rl][lr] = act_apply(acc[mi][r] + rowb[wm * 64 + mi * 32 + rl], g.act, eslope);
+        }
+        const int c4 = (lane & 7) * 4;
+        const int col = j0 + wn * 32 + c4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int rl = pass * 8 + (lane >> 3);
+            const int row = i0 + wm * 64 + mi * 32 + rl;
+            float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
+            if (row < g.M && col < g.N) {
+                const bool first = row < g.M1;
+                const int rr = first ? row : row - g.M1;
+                float* C = first ? g.C1 : g.C2;
+                const float* R = first ? g.R1 : g.R2;
+                const int64_t off = (int64_t)b * (first ? g.sC1b : g.sC2b) + (int64_t)rr * (first ? g.ldc1 : g.ldc2) + col;
+                if (C != nullptr) {
+                    if (R != nullptr) {
+                        const float4 q = *reinterpret_cast<const float4*>(R + off);
+                        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                    }
+                    *reinterpret_cast<float4*>(C + off) = t;
+                }
+                if (g.stats_out != nullptr) {
+                    const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < g.N) {
+                            s1 += v[e];
+                            s2 = fmaf(v[e], v[e], s2);
+                        }
+                }
+            }
+        }
+    }
+    if (g.stats_out != nullptr) {
+        double v[2] = {(double)s1, (double)s2};
+        block_sum<double, 2>(v, red);
+        if (tid == 0) {
+            atomicAdd(&g.stats_out[2 * b], v[0]);
+            atomicAdd(&g.stats_out[2 * b + 1], v[1]);
+        }
+    }
+}
+
+// T2: y = PReLU( dwconv( GN(x) ) + bias ), statistics of y.  One workgroup per (sample, channel) row,
+// 16 outputs per thread; the GroupNorm coefficients are computed once per workgroup.
+__global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const double* __restrict__ stats_in,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta, double count,
+                                              float eps, const float* __restrict__ w, const float* __restrict__ bias,
+                                              const float* slope_p, float* __restrict__ y, double* stats_out, int rows, int C,
+                                              int M, int K, int dil, int pad, int ld_x, int ld_y) {
+    __shared__ double red[2 * 4];
+    __shared__ float coef[2];
+    const float slope = *slope_p;
+    const int row = blockIdx.x;
+    const int bsmp = row / C, c = row - bsmp * C;
+    if (threadIdx.x == 0) {
+        const double mu = stats_in[2 * bsmp] / count;
+        double var = stats_in[2 * bsmp + 1] / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float ga0 = rstd * gamma[c];
+        coef[0] = ga0;
+        coef[1] = fmaf(-ga0, (float)mu, beta[c]);
+    }
+    __syncthreads();
+    const float ga = coef[0], gb = coef[1];
+    float wk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+    const float bv = bias ? bias[c] : 0.0f;
+    const float* xr = x + (int64_t)row * ld_x;
+    float* yr = y + (int64_t)row * ld_y;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int m0 = threadIdx.x * 16; m0 < M; m0 += 256 * 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + 4 * q;
+            if (m >= M) break;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < K) {
+                    const int s0 = m + k * dil - pad;
+                    float v[4];
+                    if ((s0 & 3) == 0 && s0 >= 0 && s0 + 3 < ld_x) {
+                        const float4 t = *reinterpret_cast<const float4*>(xr + s0);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? xr[s0 + j] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = (s0 + j >= 0 && s0 + j < M) ? fmaf(v[j], ga, gb) : 0.0f;   // zero padding AFTER the norm
+                        acc[j] = fmaf(wk[k], t, acc[j]);
+                    }
+                }
+            }
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = acc[j] + bv;
+                o[j] = t > 0.f ? t : slope * t;
+                if (m + j < M) {
+                    s1 += o[j];
+                    s2 = fmaf(o[j], o[j], s2);
+                }
+            }
+            *reinterpret_cast<float4*>(yr + m) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    double v[2] = {(double)s1, (double)s2};
+    block_sum<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats_out[2 * bsmp], v[0]);
+        atomicAdd(&stats_out[2 * bsmp + 1], v[1]);
+    }
+}
+
+// statistics only (sum, sum^2 per sample), atomically added into ws[b][2]
+__global__ __launch_bounds__(256) void k_tstats(const float* __restrict__ x, int C, int M, int64_t ld, double* ws) {
+    __shared__ double red[2 * 4];
+    const int b = blockIdx.y;
+    double s = 0.0, ss = 0.0;
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        const float* xr = x + ((int64_t)b * C + c) * ld;
+        for (int m = threadIdx.x * 4; m < M; m += 256 * 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + m);
+            const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (m + j < M) {
+                    s += (double)v[j];
+                    ss += (double)v[j] * (double)v[j];
+                }
+        }
+    }
+    double v[2] = {s, ss};
+    block_sum<double, 2>(v, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&ws[2 * b], v[0]);
+        atomicAdd(&ws[2 * b + 1], v[1]);
+    }
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_split3_planes(const float* w, uint16_t* planes, int64_t n, fqss_stream_t stream) {
+    FQSS_REQUIRE(w && planes && n >= 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    int64_t nb = cdiv(n, 256);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_split3_planes, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, planes, n);
+    return launch_status("fqss_split3_planes");
+}
+
+extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci, int Co, int M, int64_t ld_x, int pro,
+                          const double* pro_stats, const float* pro_gamma, const float* pro_beta, float pro_eps,
+                          const float* pro_slope, const float* bias, int act, const float* slope, double* stats_out, int M1,
+                          float* c1, const float* r1, int64_t ld_c1, float* c2, const float* r2, int64_t ld_c2,
+                          fqss_stream_t stream) {
+    FQSS_REQUIRE(planes && x && c1, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= ((M + 3) & ~3) && ld_x % 4 == 0 && aligned16(x), "bad input rows");
+    FQSS_REQUIRE(Ci % 8 == 0 && aligned16(planes), "planes need Ci % 8 == 0 and 16-B alignment");
+    FQSS_REQUIRE(M1 > 0 && M1 <= Co && (M1 == Co || c2), "bad output split");
+    FQSS_REQUIRE(aligned16(c1) && ld_c1 % 4 == 0 && ld_c1 >= ((M + 3) & ~3) && (!c2 || (aligned16(c2) && ld_c2 % 4 == 0 && ld_c2 >= ((M + 3) & ~3))),
+                 "output rows must be 16-B aligned");
+    FQSS_REQUIRE((!r1 || aligned16(r1)) && (!r2 || aligned16(r2)), "residual rows must be 16-B aligned");
+    FQSS_REQUIRE(pro >= 0 && pro <= 2 && (pro != 1 || (pro_stats && pro_gamma && pro_beta)) && (pro != 2 || pro_slope), "bad prologue");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    if (B == 0 || M == 0) return FQSS_OK;
+    TGemmArgs g{};
+    g.A = planes; g.B = x; g.M = Co; g.N = M; g.K = Ci; g.ldb = ld_x; g.sBb = (int64_t)Ci * ld_x;
+    g.pro = pro; g.pro_stats = pro_stats; g.pro_gamma = pro_gamma; g.pro_beta = pro_beta; g.pro_count = (double)Ci * (double)M;
+    g.pro_eps = pro_eps; g.pro_slope = pro_slope;
+    g.bias = bias; g.act = act; g.slope = slope; g.stats_out = stats_out; g.M1 = M1;
+    g.C1 = c1; g.R1 = r1; g.ldc1 = ld_c1; g.sC1b = (int64_t)M1 * ld_c1;
+    g.C2 = c2; g.R2 = r2; g.ldc2 = ld_c2; g.sC2b = (int64_t)(Co - M1) * ld_c2;
+    dim3 grid((unsigned)cdiv(M, TBN), (unsigned)cdiv(Co, TBM), (unsigned)B);
+    hipLaunchKernelGGL(k_tgemm, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_tgemm");
+}
+
+extern "C" int fqss_tdw(const float* x, const double* stats_in, const float* gamma, const float* beta, float eps,
+                        const float* w, const float* bias, const float* slope, float* y, double* stats_out, int B, int C,
+                        int M, int K, int dil, int pad, int64_t ld_x, int64_t ld_y, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && stats_in && gamma && beta && w && slope && y && stats_out, "null pointer");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M > 0 && K > 0 && K <= 8 && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
+    FQSS_REQUIRE(aligned16(x) && aligned16(y) && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= ((M + 3) & ~3) && ld_y >= ((M + 3) & ~3) &&
+                     (int64_t)B * C <= 65535 * 16ll && ld_x < (1ll << 30), "rows must be 16-B aligned");
+    if (B == 0) return FQSS_OK;
+    const int rows = B * C;
+    hipLaunchKernelGGL(k_tdw, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stats_in, gamma, beta,
+                       (double)C * (double)M, eps, w, bias, slope, y, stats_out, rows, C, M, K, dil, pad, (int)ld_x, (int)ld_y);
+    return launch_status("fqss_tdw");
+}
+
+extern "C" int fqss_tstats(const float* x, int B, int C, int M, int64_t ld, double* ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && ws && B >= 0 && B <= 65535 && C > 0 && M > 0 && aligned16(x) && ld % 4 == 0 && ld >= ((M + 3) & ~3), "bad args");
+    if (B == 0) return FQSS_OK;
+    const int nb = C < 64 ? C : 64;
+    hipLaunchKernelGGL(k_tstats, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, C, M, ld, ws);
+    return launch_status("fqss_tstats");
+}

@@ -535,3 +535,39 @@ def adam_clip(p, g, m, v, sumsq_acc, step_t, gnorm_out, max_norm, grad_scale, lr
     _lib.call("fqss_adam_clip", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_acc), float(max_norm),
               float(grad_scale), float(lr), float(beta1), float(beta2), float(eps), _p(step_t), _p(t0), _p(gnorm_out),
               _stream())
+
+
+# ------------------------------------------------------------------ fused float-teacher chain (csrc/teacher.hip)
+def split3_planes(w2d):
+    """fp32 [Co, Ci] -> three exact bf16 planes [3, Co, Ci] (uint16 storage)"""
+    w2d = w2d.contiguous()
+    planes = torch.empty(3, *w2d.shape, device=w2d.device, dtype=torch.int16)
+    _lib.call("fqss_split3_planes", _p(w2d), _p(planes), w2d.numel(), _stream())
+    return planes
+
+
+def tgemm(planes, x, bias, act=ACT_NONE, slope=None, pro=0, pro_stats=None, pro_gamma=None, pro_beta=None, pro_eps=1e-8,
+          pro_slope=None, stats_out=None, M1=None, r1=None, r2=None):
+    """fused teacher GEMM; returns c1 (and c2 when M1 < Co)"""
+    x, B, Ci, M, ld_x = _bcm(x)
+    Co = planes.shape[1]
+    M1 = Co if M1 is None else M1
+    c1 = empty_act((B, M1, M), x.device)
+    c2 = empty_act((B, Co - M1, M), x.device) if M1 < Co else None
+    _lib.call("fqss_tgemm", _p(planes), _p(x), B, Ci, Co, M, ld_x, pro, _p(pro_stats), _p(pro_gamma), _p(pro_beta),
+              float(pro_eps), _p(pro_slope), _p(bias), act, _p(slope), _p(stats_out), M1, _p(c1), _p(r1), rowmat(c1)[2],
+              _p(c2), _p(r2), rowmat(c2)[2] if c2 is not None else 0, _stream())
+    return (c1, c2) if c2 is not None else c1
+
+
+def tdw(x, stats_in, gamma, beta, eps, w, bias, slope, stats_out, dil, pad):
+    x, B, C, M, ld_x = _bcm(x)
+    y = empty_act((B, C, M), x.device)
+    _lib.call("fqss_tdw", _p(x), _p(stats_in), _p(gamma), _p(beta), float(eps), _p(w), _p(bias), _p(slope), _p(y),
+              _p(stats_out), B, C, M, w.shape[-1], dil, pad, ld_x, rowmat(y)[2], _stream())
+    return y
+
+
+def tstats(x, ws):
+    x, B, C, M, ld = _bcm(x)
+    _lib.call("fqss_tstats", _p(x), B, C, M, ld, _p(ws), _stream())

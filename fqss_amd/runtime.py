@@ -67,6 +67,80 @@ class ParamArena:
                     max_norm, grad_scale, lr, betas[0], betas[1], eps, t0=self.t0)
 
 
+class TeacherRunner:
+    """Frozen float ConvTasNet teacher as a fused inference chain (csrc/teacher.hip): 3 kernels per TCN
+    block, weights pre-split once into exact bf16 planes.  Falls back to the module forward for any other
+    teacher structure."""
+
+    def __init__(self, fmodel):
+        import torch.nn as nn
+        from .quantization.qat.models.convtasnetq import ConvBlock, ConvTasNetQ
+        self.fmodel = fmodel
+        self.ok = False
+        m = fmodel
+        try:
+            ok = isinstance(m, ConvTasNetQ) and type(m.encoder) is nn.Conv1d and type(m.decoder) is nn.ConvTranspose1d
+            mk = m.masker
+            ok = ok and type(mk.bottleneck[0]) is nn.GroupNorm and type(mk.bottleneck[1]) is nn.Conv1d
+            ok = ok and type(mk.mask_net[0]) is nn.PReLU and type(mk.mask_net[1]) is nn.Conv1d and type(mk.mask_net[2]) is nn.ReLU
+            for blk in mk.TCN:
+                sb = blk.shared_block
+                ok = ok and isinstance(blk, ConvBlock) and [type(t) for t in sb] == [nn.Conv1d, nn.PReLU, nn.GroupNorm, nn.Conv1d,
+                                                                                   nn.PReLU, nn.GroupNorm]
+                ok = ok and type(blk.res_conv) is nn.Conv1d and type(blk.skip_conv) is nn.Conv1d and sb[3].kernel_size[0] <= 8
+                ok = ok and sb[0].in_channels % 8 == 0 and sb[0].out_channels % 8 == 0
+            ok = ok and m.n_splitter == 1 and m.n_combiner == 1 and m.encoder.bias is None and m.decoder.bias is None
+            ok = ok and m.decoder.out_channels == 1 and m.encoder.in_channels == 1 and m.encoder.kernel_size[0] in (16, 32)
+            self.ok = bool(ok)
+        except AttributeError:
+            self.ok = False
+        self._planes = None
+
+    def _prepare(self):
+        mk = self.fmodel.masker
+        P = lambda conv: K.split3_planes(conv.weight.detach().reshape(conv.out_channels, conv.in_channels))
+        blocks = []
+        for blk in mk.TCN:
+            sb = blk.shared_block
+            rs_w = torch.cat([blk.res_conv.weight.detach(), blk.skip_conv.weight.detach()], 0)
+            rs_b = torch.cat([blk.res_conv.bias.detach(), blk.skip_conv.bias.detach()], 0).contiguous()
+            blocks.append((P(sb[0]), K.split3_planes(rs_w.reshape(rs_w.shape[0], rs_w.shape[1])), rs_b))
+        self._planes = dict(bn=P(mk.bottleneck[1]), mask=P(mk.mask_net[1]), blocks=blocks)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if not self.ok:
+            return self.fmodel(x)
+        if self._planes is None:
+            self._prepare()
+        m, mk, pl = self.fmodel, self.fmodel.masker, self._planes
+        if x.dim() == 2:
+            x = x.unsqueeze(1)
+        B = x.shape[0]
+        stride = m.encoder.stride[0]
+        feats = K.frames_conv_fwd(x, m.encoder.weight, stride)                       # [B, F, M]
+        nb = len(mk.TCN)
+        st = torch.zeros(1 + 2 * nb, B, 2, device=x.device, dtype=torch.float64)     # GroupNorm (sum, sum^2) per sample
+        K.tstats(feats, st[0])
+        gn0, bn = mk.bottleneck[0], mk.bottleneck[1]
+        h = K.tgemm(pl["bn"], feats, bn.bias, pro=1, pro_stats=st[0], pro_gamma=gn0.weight, pro_beta=gn0.bias, pro_eps=gn0.eps)
+        acc = None
+        nfeat = h.shape[1]
+        for i, blk in enumerate(mk.TCN):
+            sb = blk.shared_block
+            p_c1, p_rs, b_rs = pl["blocks"][i]
+            y1 = K.tgemm(p_c1, h, sb[0].bias, act=K.ACT_PRELU, slope=sb[1].weight, stats_out=st[1 + 2 * i])
+            y3 = K.tdw(y1, st[1 + 2 * i], sb[2].weight, sb[2].bias, sb[2].eps, sb[3].weight, sb[3].bias, sb[4].weight,
+                       st[2 + 2 * i], sb[3].dilation[0], sb[3].padding[0])
+            h, acc = K.tgemm(p_rs, y3, b_rs, pro=1, pro_stats=st[2 + 2 * i], pro_gamma=sb[5].weight, pro_beta=sb[5].bias,
+                             pro_eps=sb[5].eps, M1=nfeat, r1=h, r2=acc)
+        mask = K.tgemm(pl["mask"], acc, mk.mask_net[1].bias, act=K.ACT_RELU, pro=2, pro_slope=mk.mask_net[0].weight)
+        F_ = feats.shape[1]
+        masked = K.mul_bcast_fwd(mask.reshape(B, m.n_srcs, F_, -1), feats)
+        dec = K.ola_convtr_fwd(masked.reshape(B * m.n_srcs, F_, -1), m.decoder.weight, stride)
+        return dec.reshape(B, m.n_srcs, -1)
+
+
 class QuantTables:
     """Device-side descriptor tables that let ONE launch each do, for the whole model: the weight
     fake-quant forward (+ int8 codes), its backward, and the range/slope gradient flush (csrc/multi.hip).
@@ -170,6 +244,7 @@ class KDTrainStep:
         self.arena = ParamArena(list(model.parameters()))
         for p in fmodel.parameters():
             p.requires_grad_(False)
+        self.teacher = TeacherRunner(fmodel)     # fused inference chain for the frozen float teacher
         self.last = None
         self.tables = None          # QuantTables once the quantizing phase is reached
         self._graphs = None
@@ -186,8 +261,7 @@ class KDTrainStep:
             t.weights_forward()                # all 101 weight fake-quants (+ int8 codes): one launch
         with ops.fast_codes(True), ops.deferred(t):     # student: codes-only dataflow between quantizing layers
             est = self.model(x)
-        with torch.no_grad():
-            fest = self.fmodel(x)
+        fest = self.teacher(x)
         out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
         with ops.deferred(t):
             est.backward(gest)

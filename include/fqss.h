@@ -226,6 +226,26 @@ int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, cons
                    int64_t ld_xc, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * fused float-teacher chain (csrc/teacher.hip): inference only, frozen weights pre-split into three
+ * exact bf16 planes; per TCN block T1 (fqss_tgemm: conv + PReLU + stats), T2 (fqss_tdw: GN-apply +
+ * depthwise conv + PReLU + stats), T3 (fqss_tgemm: res+skip as one GEMM, GN-apply prologue, residual /
+ * skip accumulation epilogue).  stats: fp64 [B][2] = (sum, sum^2) per sample, "+=" (caller zeroes).
+ * replaces: the plain nn.Module forward of the deep-copied float model (mysystem.py:132-133)
+ * ------------------------------------------------------------------------------------------- */
+int fqss_split3_planes(const float* w, uint16_t* planes, int64_t n, fqss_stream_t stream);
+/* pro: 0 none | 1 GroupNorm(1,Ci) affine from pro_stats/gamma/beta on the input | 2 PReLU(pro_slope) on it.
+ * rows [0,M1) -> c1 (+ r1), rows [M1,Co) -> c2 (+ r2); stats_out: statistics of everything written */
+int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci, int Co, int M, int64_t ld_x, int pro,
+               const double* pro_stats, const float* pro_gamma, const float* pro_beta, float pro_eps,
+               const float* pro_slope, const float* bias, int act, const float* slope, double* stats_out,
+               int M1, float* c1, const float* r1, int64_t ld_c1, float* c2, const float* r2,
+               int64_t ld_c2, fqss_stream_t stream);
+int fqss_tdw(const float* x, const double* stats_in, const float* gamma, const float* beta, float eps,
+             const float* w, const float* bias, const float* slope, float* y, double* stats_out, int B,
+             int C, int M, int K, int dil, int pad, int64_t ld_x, int64_t ld_y, fqss_stream_t stream);
+int fqss_tstats(const float* x, int B, int C, int M, int64_t ld, double* ws, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K8/K9/K14  element-wise producers
  * replaces: torch.add / torch.sub / torch.mul in AddQ, ResidualErrorBlock, MulQ
  *           (qat_layers.py:69-71, 1193, 93-96), postprocess (process.py:44-47)

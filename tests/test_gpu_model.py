@@ -358,3 +358,26 @@ def test_batched_quant_tables_match_per_module_path(golden):
     ref = grads[0]
     err = float((grads[0] - grads[1]).abs().max())
     assert err <= 2e-5 * float(ref.abs().max()) + 1e-7, err
+
+
+def test_fused_teacher_chain_matches_oracle_and_module_path():
+    """runtime.TeacherRunner (3 fused kernels per block, bf16 3x3-split GEMMs) vs the oracle's float
+    teacher and vs the module-by-module HIP path"""
+    from fqss_amd.runtime import TeacherRunner
+    from fqss_amd.smoke import build_pair
+    for kw, B, T_ in ((dict(n_spks=2, kernel_size=16, stride=8, n_filters=64, bn_chan=32, hid_chan=64, n_blocks=3, n_repeats=2), 3, 4000),
+                      (dict(n_spks=2, kernel_size=16, stride=8), 2, 8000)):
+        _, fmodel = build_pair("cuda", 1, **kw)
+        tr = TeacherRunner(fmodel)
+        assert tr.ok
+        x, _ = O.synth_batch(B, T_, seed=2)
+        y = tr(x.cuda()).cpu()
+        with torch.no_grad():
+            y_mod = fmodel(x.cuda()).cpu()
+        ref = O.TeacherConvTasNet({k: v.cpu() for k, v in fmodel.state_dict().items()},
+                                  layers_per_stack=kw.get("n_blocks", 8))(x)
+        scale = float(ref.abs().max())
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=2e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(y.numpy(), y_mod.numpy(), rtol=2e-4, atol=2e-5 * scale)
+        # SI-SDR of the two teacher outputs against each other must be essentially infinite (> 80 dB)
+        assert float(O.si_sdr_db(y, ref)) > 70.0
