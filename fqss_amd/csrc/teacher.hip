@@ -10,7 +10,7 @@
 //                      skip sum (rows >= 128)
 // Every N_F-sized tensor is written once and read once (4 passes per block instead of ~17).
 // GEMMs: both operands fp32; the frozen weights are split ONCE into three exact bf16 planes
-// (fqss_split3_planes), activations are split on the fly: 9 exact bf16 products per k, fp32 accumulation
+// (fqss_split3_planes), activations are split on the fly: the 6 leading exact bf16 products per k, fp32 accumulation
 // (v_mfma_f32_32x32x16_bf16) -- the result is fp32-grade (same error class as an fp32 fma chain).
 #include <type_traits>
 
@@ -22,8 +22,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TBM = 128, TBN = 64, TBK = 32;
-constexpr int TLDK = 40, TLDN = 96, TLDT = 36;
+constexpr int TBM = 128, TBN = 128, TBK = 32;
+constexpr int TLDK = 40, TLDN = 160, TLDT = 36;
+// GroupNorm statistics travel as kTSlots partial (sum, sum^2) pairs per sample, each pair on its own 128-B
+// line: same-address fp64 atomics serialise at ~12 ns apiece, spreading them over 32 lines removes that wall.
+constexpr int kTSlots = FQSS_TSTAT_SLOTS, kTSlotStride = FQSS_TSTAT_STRIDE;
 
 __device__ __forceinline__ unsigned short t_bf(float f) { return (unsigned short)(__float_as_uint(f) >> 16); }
 __device__ __forceinline__ float t_tr(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
@@ -32,6 +35,27 @@ __device__ __forceinline__ void t_split3(float g, unsigned short& b1, unsigned s
     b1 = t_bf(h1);
     b2 = t_bf(h2);
     b3 = t_bf(r2);
+}
+
+// mean / rstd of one sample from its slot partials -> out2[0..1] (LDS); every thread of the block calls this.
+__device__ __forceinline__ void t_stats_finalize(const double* __restrict__ st, double count, float eps, float* out2) {
+    if (threadIdx.x < 64) {
+        double a = 0.0, q = 0.0;
+        if (threadIdx.x < kTSlots) {
+            a = st[threadIdx.x * kTSlotStride];
+            q = st[threadIdx.x * kTSlotStride + 1];
+        }
+        a = wave_sum(a);
+        q = wave_sum(q);
+        if (threadIdx.x == 0) {
+            const double mu = a / count;
+            double var = q / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            out2[0] = (float)mu;
+            out2[1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__ w, unsigned short* __restrict__ planes,
@@ -77,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
     __shared__ float rowb[TBM];
     __shared__ double red[2 * 4];
+    __shared__ float pms[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -84,31 +109,25 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 
     if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
-
-    __shared__ float pms[2];
-    if (g.pro == 1 && tid == 0) {
-        const double mu = g.pro_stats[2 * b] / g.pro_count;
-        double var = g.pro_stats[2 * b + 1] / g.pro_count - mu * mu;
-        if (var < 0.0) var = 0.0;
-        pms[0] = (float)mu;
-        pms[1] = (float)(1.0 / sqrt(var + (double)g.pro_eps));
-    }
-    __syncthreads();
+    if (g.pro == 1) t_stats_finalize(g.pro_stats + (int64_t)b * kTSlots * kTSlotStride, g.pro_count, g.pro_eps, pms);
+    else __syncthreads();
     const float pmean = (g.pro == 1) ? pms[0] : 0.f, prstd = (g.pro == 1) ? pms[1] : 1.f;
     const float pslope = (g.pro == 2) ? *g.pro_slope : 0.0f;
 
-    f32x16 acc[2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int a_row = tid >> 1, a_k = (tid & 1) * 16;
-    const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;
+    const int bk_row = tid >> 3, bk_c = (tid & 7) * 4;   // 4 float4 per thread at columns 32*q + bk_c
     const float* Bb = g.B + (int64_t)b * g.sBb;
     const int64_t plane = (int64_t)g.M * g.K;
     uint4 ra[3][2];
-    float4 rb[2];
+    float4 rb[4];
     float p_a = 1.f, p_b = 0.f;
 
     auto load_tiles = [&](int k0) {
@@ -128,11 +147,10 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
             p_b = fmaf(-p_a, pmean, g.pro_beta[k]);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int n = j0 + bk_n + 4 * q;
+            const int n = j0 + 32 * q + bk_c;
             if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bb + (int64_t)k * g.ldb + n);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             rb[q] = v;
         }
     };
@@ -143,22 +161,32 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
             *reinterpret_cast<uint4*>(&As[p][a_row][a_k + 8]) = ra[p][1];
         }
         const bool ok = (k0 + bk_row) < g.K;
-        unsigned short o1[8], o2[8], o3[8];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const float x[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+            float h0[4], r1[4], r2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = x[e];
                 if (g.pro == 1) t = fmaf(t, p_a, p_b);
                 else if (g.pro == 2) t = t > 0.f ? t : pslope * t;
                 if (!ok) t = 0.f;
-                t_split3(t, o1[4 * q + e], o2[4 * q + e], o3[4 * q + e]);
+                h0[e] = t;
+                r1[e] = t - t_tr(t);
+                r2[e] = r1[e] - t_tr(r1[e]);
             }
+            // bf16 pairs: v_perm picks the high halves of two fp32 words
+            uint2 o1, o2, o3;
+            o1.x = __builtin_amdgcn_perm(__float_as_uint(h0[1]), __float_as_uint(h0[0]), 0x07060302u);
+            o1.y = __builtin_amdgcn_perm(__float_as_uint(h0[3]), __float_as_uint(h0[2]), 0x07060302u);
+            o2.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+            o2.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+            o3.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+            o3.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            *reinterpret_cast<uint2*>(&Bs[0][bk_row][32 * q + bk_c]) = o1;
+            *reinterpret_cast<uint2*>(&Bs[1][bk_row][32 * q + bk_c]) = o2;
+            *reinterpret_cast<uint2*>(&Bs[2][bk_row][32 * q + bk_c]) = o3;
         }
-        *reinterpret_cast<uint4*>(&Bs[0][bk_row][bk_n]) = make_uint4(o1[0] | (o1[1] << 16), o1[2] | (o1[3] << 16), o1[4] | (o1[5] << 16), o1[6] | (o1[7] << 16));
-        *reinterpret_cast<uint4*>(&Bs[1][bk_row][bk_n]) = make_uint4(o2[0] | (o2[1] << 16), o2[2] | (o2[3] << 16), o2[4] | (o2[5] << 16), o2[6] | (o2[7] << 16));
-        *reinterpret_cast<uint4*>(&Bs[2][bk_row][bk_n]) = make_uint4(o3[0] | (o3[1] << 16), o3[2] | (o3[3] << 16), o3[4] | (o3[5] << 16), o3[6] | (o3[7] << 16));
     };
 
     const int nkt = (g.K + TBK - 1) / TBK;
@@ -169,27 +197,32 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
         if (kt + 1 < nkt) load_tiles((kt + 1) * TBK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[3][2], bfr[3];
+            bf16x8 af[3][2], bfr[3][2];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
                     af[p][mi] = *reinterpret_cast<const bf16x8*>(&As[p][wm * 64 + mi * 32 + lr][ks * 16 + 8 * lh]);
-                const int kr = ks * 16 + 8 * (gq >> 1) + tq;
-                const int nc = wn * 32 + 16 * (gq & 1) + 4 * tp;
-                union { bf16x8 v; s16x4 h[2]; } u;
-                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
-                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
-                bfr[p] = u.v;
-            }
-            // 9 exact partial products, smallest pieces first
 #pragma unroll
-            for (int sp = 0; sp < 9; ++sp) {
-                const int ia = 2 - sp / 3, ib = 2 - sp % 3;
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int kr = ks * 16 + 8 * (gq >> 1) + tq;
+                    const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
+                    union { bf16x8 v; s16x4 h[2]; } u;
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                    bfr[p][ni] = u.v;
+                }
+            }
+            // the 6 partial products of weight >= 2^-16 (the dropped a2*b3, a3*b2, a3*b3 are below the fp32
+            // rounding of the sum), smallest pieces first
+            constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia][mi], bfr[ib], acc[mi], 0, 0, 0);
-            }
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -201,42 +234,43 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     // epilogue: bias + act (+ residual), 16-B/lane row stores via an LDS staging tile, statistics
     const float eslope = (g.act == FQSS_ACT_PRELU) ? *g.slope : 0.0f;
     float(*Tt)[TLDT] = reinterpret_cast<float(*)[TLDT]>(smem + wave * 32 * TLDT * 4);
-    float s1 = 0.0f, s2 = 0.0f;   // <= 32 values per thread: fp32 partials, widened to fp64 for the cross-thread sum
+    float s1 = 0.0f, s2 = 0.0f;   // <= 64 values per thread: fp32 partials, widened to fp64 for the cross-thread sum
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            Tt[rl][lr] = act_apply(acc[mi][r] + rowb[wm * 64 + mi * 32 + rl], g.act, eslope);
-        }
-        const int c4 = (lane & 7) * 4;
-        const int col = j0 + wn * 32 + c4;
+        for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int rl = pass * 8 + (lane >> 3);
-            const int row = i0 + wm * 64 + mi * 32 + rl;
-            float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
-            if (row < g.M && col < g.N) {
-                const bool first = row < g.M1;
-                const int rr = first ? row : row - g.M1;
-                float* C = first ? g.C1 : g.C2;
-                const float* R = first ? g.R1 : g.R2;
-                const int64_t off = (int64_t)b * (first ? g.sC1b : g.sC2b) + (int64_t)rr * (first ? g.ldc1 : g.ldc2) + col;
-                if (C != nullptr) {
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Tt[rl][lr] = act_apply(acc[mi][ni][r] + rowb[wm * 64 + mi * 32 + rl], g.act, eslope);
+            }
+            const int c4 = (lane & 7) * 4;
+            const int col = j0 + wn * 64 + ni * 32 + c4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int rl = pass * 8 + (lane >> 3);
+                const int row = i0 + wm * 64 + mi * 32 + rl;
+                float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
+                if (row < g.M && col < g.N) {
+                    const bool first = row < g.M1;
+                    const int rr = first ? row : row - g.M1;
+                    float* C = first ? g.C1 : g.C2;
+                    const float* R = first ? g.R1 : g.R2;
+                    const int64_t off = (int64_t)b * (first ? g.sC1b : g.sC2b) + (int64_t)rr * (first ? g.ldc1 : g.ldc2) + col;
                     if (R != nullptr) {
                         const float4 q = *reinterpret_cast<const float4*>(R + off);
                         t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
                     }
                     *reinterpret_cast<float4*>(C + off) = t;
-                }
-                if (g.stats_out != nullptr) {
-                    const float v[4] = {t.x, t.y, t.z, t.w};
+                    if (g.stats_out != nullptr) {
+                        const float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < g.N) {
-                            s1 += v[e];
-                            s2 = fmaf(v[e], v[e], s2);
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < g.N) {
+                                s1 += v[e];
+                                s2 = fmaf(v[e], v[e], s2);
+                            }
+                    }
                 }
             }
         }
@@ -245,8 +279,9 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
         double v[2] = {(double)s1, (double)s2};
         block_sum<double, 2>(v, red);
         if (tid == 0) {
-            atomicAdd(&g.stats_out[2 * b], v[0]);
-            atomicAdd(&g.stats_out[2 * b + 1], v[1]);
+            double* so = g.stats_out + ((int64_t)b * kTSlots + ((blockIdx.x + blockIdx.y * gridDim.x) & (kTSlots - 1))) * kTSlotStride;
+            atomicAdd(&so[0], v[0]);
+            atomicAdd(&so[1], v[1]);
         }
     }
 }
@@ -263,14 +298,12 @@ __global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const 
     const float slope = *slope_p;
     const int row = blockIdx.x;
     const int bsmp = row / C, c = row - bsmp * C;
+    __shared__ float ms[2];
+    t_stats_finalize(stats_in + (int64_t)bsmp * kTSlots * kTSlotStride, count, eps, ms);
     if (threadIdx.x == 0) {
-        const double mu = stats_in[2 * bsmp] / count;
-        double var = stats_in[2 * bsmp + 1] / count - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float ga0 = rstd * gamma[c];
+        const float ga0 = ms[1] * gamma[c];
         coef[0] = ga0;
-        coef[1] = fmaf(-ga0, (float)mu, beta[c]);
+        coef[1] = fmaf(-ga0, ms[0], beta[c]);
     }
     __syncthreads();
     const float ga = coef[0], gb = coef[1];
@@ -281,11 +314,9 @@ __global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const 
     const float* xr = x + (int64_t)row * ld_x;
     float* yr = y + (int64_t)row * ld_y;
     float s1 = 0.0f, s2 = 0.0f;
-    for (int m0 = threadIdx.x * 16; m0 < M; m0 += 256 * 16) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + 4 * q;
-            if (m >= M) break;
+    // consecutive lanes own consecutive float4 (coalesced 1-KiB wave loads/stores)
+    {
+        for (int m = threadIdx.x * 4; m < M; m += 256 * 4) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -322,12 +353,13 @@ __global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const 
     double v[2] = {(double)s1, (double)s2};
     block_sum<double, 2>(v, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&stats_out[2 * bsmp], v[0]);
-        atomicAdd(&stats_out[2 * bsmp + 1], v[1]);
+        double* so = stats_out + ((int64_t)bsmp * kTSlots + (c & (kTSlots - 1))) * kTSlotStride;
+        atomicAdd(&so[0], v[0]);
+        atomicAdd(&so[1], v[1]);
     }
 }
 
-// statistics only (sum, sum^2 per sample), atomically added into ws[b][2]
+// statistics only (sum, sum^2 per sample), atomically added into the slot partials ws[b][kTSlots][kTSlotStride]
 __global__ __launch_bounds__(256) void k_tstats(const float* __restrict__ x, int C, int M, int64_t ld, double* ws) {
     __shared__ double red[2 * 4];
     const int b = blockIdx.y;
@@ -348,8 +380,9 @@ __global__ __launch_bounds__(256) void k_tstats(const float* __restrict__ x, int
     double v[2] = {s, ss};
     block_sum<double, 2>(v, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&ws[2 * b], v[0]);
-        atomicAdd(&ws[2 * b + 1], v[1]);
+        double* so = ws + ((int64_t)b * kTSlots + (blockIdx.x & (kTSlots - 1))) * kTSlotStride;
+        atomicAdd(&so[0], v[0]);
+        atomicAdd(&so[1], v[1]);
     }
 }
 

@@ -546,6 +546,14 @@ def split3_planes(w2d):
     return planes
 
 
+TSTAT_SLOTS, TSTAT_STRIDE = 32, 16   # FQSS_TSTAT_SLOTS / FQSS_TSTAT_STRIDE (include/fqss.h)
+
+
+def tstat_buffer(n, B, device):
+    """n zeroed GroupNorm-statistics buffers for B samples (slot partials of (sum, sum^2), fp64)"""
+    return torch.zeros(n, B, TSTAT_SLOTS, TSTAT_STRIDE, device=device, dtype=torch.float64)
+
+
 def tgemm(planes, x, bias, act=ACT_NONE, slope=None, pro=0, pro_stats=None, pro_gamma=None, pro_beta=None, pro_eps=1e-8,
           pro_slope=None, stats_out=None, M1=None, r1=None, r2=None):
     """fused teacher GEMM; returns c1 (and c2 when M1 < Co)"""

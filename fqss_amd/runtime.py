@@ -120,7 +120,7 @@ class TeacherRunner:
         stride = m.encoder.stride[0]
         feats = K.frames_conv_fwd(x, m.encoder.weight, stride)                       # [B, F, M]
         nb = len(mk.TCN)
-        st = torch.zeros(1 + 2 * nb, B, 2, device=x.device, dtype=torch.float64)     # GroupNorm (sum, sum^2) per sample
+        st = K.tstat_buffer(1 + 2 * nb, B, x.device)                                 # GroupNorm (sum, sum^2) partials per sample
         K.tstats(feats, st[0])
         gn0, bn = mk.bottleneck[0], mk.bottleneck[1]
         h = K.tgemm(pl["bn"], feats, bn.bias, pro=1, pro_stats=st[0], pro_gamma=gn0.weight, pro_beta=gn0.bias, pro_eps=gn0.eps)

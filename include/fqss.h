@@ -229,9 +229,13 @@ int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, cons
  * fused float-teacher chain (csrc/teacher.hip): inference only, frozen weights pre-split into three
  * exact bf16 planes; per TCN block T1 (fqss_tgemm: conv + PReLU + stats), T2 (fqss_tdw: GN-apply +
  * depthwise conv + PReLU + stats), T3 (fqss_tgemm: res+skip as one GEMM, GN-apply prologue, residual /
- * skip accumulation epilogue).  stats: fp64 [B][2] = (sum, sum^2) per sample, "+=" (caller zeroes).
+ * skip accumulation epilogue).  stats: fp64 [B][FQSS_TSTAT_SLOTS][FQSS_TSTAT_STRIDE], the first two
+ * doubles of every slot hold a partial (sum, sum^2) of the sample, "+=" (caller zeroes); consumers add the
+ * slots up (one slot per 128-B line keeps the fp64 atomics off a single address).
  * replaces: the plain nn.Module forward of the deep-copied float model (mysystem.py:132-133)
  * ------------------------------------------------------------------------------------------- */
+#define FQSS_TSTAT_SLOTS 32
+#define FQSS_TSTAT_STRIDE 16
 int fqss_split3_planes(const float* w, uint16_t* planes, int64_t n, fqss_stream_t stream);
 /* pro: 0 none | 1 GroupNorm(1,Ci) affine from pro_stats/gamma/beta on the input | 2 PReLU(pro_slope) on it.
  * rows [0,M1) -> c1 (+ r1), rows [M1,Co) -> c2 (+ r2); stats_out: statistics of everything written */
