@@ -39,7 +39,7 @@ constexpr int LDK = 40;    // bf16 per row of a k-contiguous image (32 + 8 pad =
 constexpr int LDN = 96;    // bf16 per row of an n-contiguous image (64 + 32 pad = 192 B: conflict-free tr reads)
 constexpr int LDT = 36;    // fp32 per row of the epilogue staging tile (32 + 4 pad, 16-B aligned rows)
 #ifndef FQSS_WGRAD_BLOCKS
-#define FQSS_WGRAD_BLOCKS 768
+#define FQSS_WGRAD_BLOCKS 256   // one workgroup per CU: the fp32 atomics of the epilogue cost ~20 ns per workgroup-tile, more slices lose
 #endif
 
 __device__ __forceinline__ unsigned short f2bf_trunc(float f) { return (unsigned short)(__float_as_uint(f) >> 16); }
@@ -74,12 +74,13 @@ struct QGemmArgs {
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
-//      2 wgrad (fp32 A split3, u8 B codes [n][k])  3 plain fp32 x fp32 (A split3 x B split3 = 9 exact products)
+//      3 plain fp32 x fp32 (A split3 x B split3 = 9 exact products)       (wgrad: k_qwgrad below)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
-    constexpr int NA = (MODE >= 2) ? 3 : 1;                 // A images
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "unknown q-GEMM mode");
+    constexpr int NA = (MODE == 3) ? 3 : 1;                 // A images
     constexpr int NB = (MODE == 1 || MODE == 3) ? 3 : 1;    // B images
-    constexpr int BROWS = (MODE == 2) ? QBN : QBK, BLD = (MODE == 2) ? LDK : LDN;
+    constexpr int BROWS = QBK, BLD = LDN;
     constexpr int A_BYTES = NA * QBM * LDK * 2, B_BYTES = NB * BROWS * BLD * 2;
     constexpr int T_BYTES = 4 * 32 * LDT * 4;   // epilogue staging: one 32x32 fp32 tile per wave
     constexpr int SMEM = (A_BYTES + B_BYTES > T_BYTES) ? A_BYTES + B_BYTES : T_BYTES;
@@ -93,10 +94,8 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     const int bz = blockIdx.z;
-    const int b = (MODE == 2) ? bz / g.ksplit : bz;
-    const int ks_id = (MODE == 2) ? bz % g.ksplit : 0;
-    const int kbeg = (MODE == 2) ? ks_id * g.kchunk : 0;
-    const int kend = (MODE == 2) ? min(g.K, kbeg + g.kchunk) : g.K;
+    const int b = bz;
+    const int kbeg = 0, kend = g.K;
     const int i0 = blockIdx.y * QBM, j0 = blockIdx.x * QBN;
 
     f32x16 acc[2];
@@ -104,8 +103,6 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-
-    float rowsum = 0.0f;  // wgrad: running sum of this thread's piece of gz rows (for the min_x term)
 
     // per-row epilogue coefficients of this block's 128 rows, staged once in LDS (fetching them per output
     // element from global memory was ~60 % of the forward kernel's time)
@@ -122,15 +119,14 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
 
     // ---------------------------------------------------------------- staging (global -> regs -> LDS)
     uint4 ra_i8;            // MODE 0/1: 16 int8 weight codes
-    float4 ra_f[4];         // MODE 2/3: 16 fp32 values
-    uint4 rb_u8;            // MODE 0/2: 16 u8 activation codes (threads < 128)
+    float4 ra_f[4];         // MODE 3: 16 fp32 values
+    uint4 rb_u8;            // MODE 0: 16 u8 activation codes (threads < 128)
     float4 rb_f[2];         // MODE 1/3: 8 fp32 values
     float rb_scale = 0.0f;  // MODE 1: delta_w of this thread's k row
 
     const int a_row = tid >> 1, a_k = (tid & 1) * 16;              // A tile: 128 rows x 32 k, 16 per thread
     const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;             // fp32 B tile [k][n]: 32 k x 64 n, 8 per thread
     const int bu_row = (tid & 127) >> 2, bu_n = (tid & 3) * 16;    // u8 B tile [k][n]: 32 k x 64 n, 16 per thread (<128)
-    const int bn_row = (tid & 127) >> 1, bn_k = (tid & 1) * 16;    // u8 B tile [n][k] (wgrad): 64 n x 32 k (<128)
     const bool b_u8_active = tid < 128;
 
     auto load_tiles = [&](int k0) {
@@ -170,11 +166,6 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                 if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + n);
                 rb_f[q] = v;
             }
-        } else {
-            const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb;
-            rb_u8 = make_uint4(0, 0, 0, 0);
-            if (b_u8_active && j0 + bn_row < g.N && k0 + bn_k < kend)
-                rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(j0 + bn_row) * g.ldb + k0 + bn_k);
         }
     };
 
@@ -226,18 +217,12 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         } else {
             store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], ra_f, 1.0f, false,
                          std::integral_constant<int, 4>{});
-            if constexpr (MODE == 2) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rowsum += (ra_f[q].x + ra_f[q].y) + (ra_f[q].z + ra_f[q].w);
-            }
         }
         if constexpr (MODE == 0) {
             if (b_u8_active) store_u8x16(&Bs[0][bu_row][bu_n], rb_u8, false);
         } else if constexpr (MODE == 1 || MODE == 3) {
             store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, MODE == 1,
                          std::integral_constant<int, 2>{});
-        } else {
-            if (b_u8_active) store_u8x16(&Bs[0][bn_row][bn_k], rb_u8, false);
         }
     };
 
@@ -262,9 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
                     af[mi] = *reinterpret_cast<const bf16x8*>(&As[ia][wm * 64 + mi * 32 + lr][ks * 16 + 8 * lh]);
-                if constexpr (MODE == 2) {
-                    bfr = *reinterpret_cast<const bf16x8*>(&Bs[ib][wn * 32 + lr][ks * 16 + 8 * lh]);
-                } else {
+                {
                     // B[k = 8h + j][col r]: two transposed 4x16 block reads (rows 8h+0..3 and 8h+4..7)
                     const int kr = ks * 16 + 8 * (gq >> 1) + tq;
                     const int nc = wn * 32 + 16 * (gq & 1) + 4 * tp;
@@ -289,31 +272,13 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
 
     // ---------------------------------------------------------------- epilogue
     float dx = 0.f, mnx = 0.f;
-    if constexpr (MODE == 0 || MODE == 2) {
+    if constexpr (MODE == 0) {
         const float lo = *g.qmin_x, hi = *g.qmax_x;
         dx = (hi - lo) / 255.0f;
         mnx = lo;
     }
-    __shared__ float rs[QBM];
-    if constexpr (MODE == 2) {
-        // row sums of this block's gz slice: the two threads of a row are adjacent lanes
-        const float tot = rowsum + __shfl_xor(rowsum, 1, 64);
-        if ((tid & 1) == 0) rs[a_row] = tot;
-        __syncthreads();
-    }
     float* Cb = g.C + (int64_t)b * g.sCb;
-    if constexpr (MODE == 2) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int col = j0 + wn * 32 + lr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int row = i0 + rl;
-                if (row < g.M && col < g.N) atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * acc[mi][r] + mnx * rs[rl]);
-            }
-        }
-    } else {
+    {
         // stage each 32x32 accumulator tile through LDS and store whole 128-B rows with 16 B per lane
         // (the lane-per-column layout of the MFMA result would need 16 strided 4-B stores per tile: that
         // store-issue-bound tail was 60 % of the forward kernel's time)
@@ -354,6 +319,147 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                     }
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad, register-direct:  gW_q[co][ci] += dx * sum_n gz[co][n]*c[ci][n] + min_x * sum_n gz[co][n]
+// Both operands are n-contiguous in HBM and n is the reduction index, so every lane can load its MFMA
+// fragment straight from global memory: lane (row lr, half lh) of a 32-wide k chunk owns the 16
+// consecutive positions n0+16*lh .. +15 of "its" gz row (64 B) and of "its" code row (16 B); the two k-steps
+// of the chunk use the first / second 8 of them for A and B alike (the k labelling inside an MFMA is
+// arbitrary as long as A and B agree).  No LDS, no barriers: each wave free-runs over its n range with a
+// ring of WG_STAGES chunk loads in flight (an LDS-tiled version of this kernel was load-latency bound at
+// 2x the time: 12 exposed global-load round trips per workgroup, two barriers each).
+// Wave tile 32(co) x 64(ci); workgroup = 2x2 waves = 64 x 128; grid.z = batch x n-split.
+constexpr int WG_STAGES = 4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct WgStage {
+    f32x4 a[4];   // 16 gz values of this lane's row
+    u32x4 c[2];   // 16 codes for each of the two 32-column tiles
+};
+// The ring is hand-scheduled: the compiler sinks plain loads next to their first use (draining the ring to
+// vmcnt(0) every chunk), so the loads are issued through asm and retired with an explicit s_waitcnt that
+// carries the stage's registers as in/out operands (every use of the data is ordered after the wait).
+__device__ __forceinline__ void wg_load16(f32x4& d, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wg_load16(u32x4& d, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wg_wait(WgStage& st) {
+    asm volatile("s_waitcnt vmcnt(%6)"
+                 : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.a[2]), "+v"(st.a[3]), "+v"(st.c[0]), "+v"(st.c[1])
+                 : "n"(N)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void k_qwgrad(QGemmArgs g) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z / g.ksplit, ks_id = blockIdx.z % g.ksplit;
+    const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int row0 = blockIdx.y * 64 + wr * 32, col0 = blockIdx.x * 128 + wc * 64;
+    const int nchunks = (kend - kbeg + 31) >> 5;
+
+    const bool arow_ok = row0 + lr < g.M;
+    const float* Ap = (const float*)g.A + (int64_t)b * g.sAb + (int64_t)(arow_ok ? row0 + lr : 0) * g.lda;
+    const unsigned char* Bb = (const unsigned char*)g.B + (int64_t)b * g.sBb;
+    const unsigned char* Bp[2] = {Bb + (int64_t)min(col0 + lr, g.N - 1) * g.ldb, Bb + (int64_t)min(col0 + 32 + lr, g.N - 1) * g.ldb};
+
+    // Loads are unconditional: addresses are clamped into the row, values masked at use.
+    const int ka_last = (kend - 1) & ~3, kb_last = (kend - 1) & ~15;
+    auto load = [&](WgStage& st, int chunk) {
+        const int k = kbeg + chunk * 32 + 16 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wg_load16(st.a[q], Ap + min(k + 4 * q, ka_last));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wg_load16(st.c[t], Bp[t] + min(k, kb_last));
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float rowsum = 0.0f;
+
+    auto compute = [&](WgStage& st, int chunk) {
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = st.a[q][e];
+        // positions >= kend (row padding, clamped re-reads) and rows >= Co contribute exact zeros; codes need no
+        // mask (finite, and they only ever meet a zero)
+        const int nvalid = arow_ok ? kend - (kbeg + chunk * 32 + 16 * lh) : 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = (e < nvalid) ? x[e] : 0.0f;
+        // exact 3-way split, packed as bf16 pairs with v_perm (high halves of two fp32 words)
+        union { uint32_t u[8]; bf16x8 v[2]; } A1, A2, A3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a0 = x[2 * e], a1 = x[2 * e + 1];
+            rowsum += a0 + a1;
+            const float r0 = a0 - bf_trunc(a0), r1 = a1 - bf_trunc(a1);
+            const float s0 = r0 - bf_trunc(r0), s1 = r1 - bf_trunc(r1);
+            A1.u[e] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+            A2.u[e] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+            A3.u[e] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t w[4] = {st.c[t][0], st.c[t][1], st.c[t][2], st.c[t][3]};
+            union { uint32_t u[8]; bf16x8 v[2]; } Bc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float f0 = (float)(w[q] & 0xFFu), f1 = (float)((w[q] >> 8) & 0xFFu);
+                const float f2 = (float)((w[q] >> 16) & 0xFFu), f3 = (float)(w[q] >> 24);
+                Bc.u[2 * q] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                Bc.u[2 * q + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {   // smallest pieces first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3.v[s], Bc.v[s], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2.v[s], Bc.v[s], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1.v[s], Bc.v[s], acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    WgStage st[WG_STAGES];
+#pragma unroll
+    for (int s = 0; s < WG_STAGES - 1; ++s) load(st[s], s);
+    for (int c0 = 0; c0 < nchunks; c0 += WG_STAGES) {
+#pragma unroll
+        for (int s = 0; s < WG_STAGES; ++s) {
+            load(st[(s + WG_STAGES - 1) % WG_STAGES], c0 + s + WG_STAGES - 1);   // 4 stages x 6 loads in flight ...
+            wg_wait<6 * (WG_STAGES - 1)>(st[s]);                                 // ... the oldest stage has landed
+            compute(st[s], c0 + s);   // chunks past the end are fully masked: the body stays branch-free
+        }
+    }
+
+    // the ring's trailing (clamped, unused) loads still target the stage registers, which the compiler
+    // considers dead from here on: drain them before anything else may be allocated there
+#pragma unroll
+    for (int s = 0; s < WG_STAGES; ++s) wg_wait<0>(st[s]);   // in/out operands keep every stage register reserved up to here
+
+    // epilogue: the gz row sums (min_x term) live in lane == row; results are atomically added (n-split, batch)
+    const float lo = *g.qmin_x, hi = *g.qmax_x;
+    const float dx = (hi - lo) / 255.0f, mnx = lo;
+    const float rtot = rowsum + __shfl_xor(rowsum, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float rsum = __shfl(rtot, rl, 64);
+        const int row = row0 + rl;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = col0 + 32 * t + lr;
+            if (row < g.M && col < g.N) atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * acc[t][r] + mnx * rsum);
         }
     }
 }
@@ -443,15 +549,16 @@ extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* q
     g.lda = ld_gz; g.ldb = ld_xc; g.ldc = Ci;
     g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_xc; g.sCb = 0;
     g.qmin_x = qmin_x; g.qmax_x = qmax_x;
-    const int tiles = (int)(cdiv(Co, QBM) * cdiv(Ci, QBN));
-    int want = (int)cdiv(FQSS_WGRAD_BLOCKS, (int64_t)tiles * B);
+    // one workgroup = 64 (co) x 128 (ci); split n so that ~FQSS_WGRAD_BLOCKS workgroups stream the operands
+    const int64_t tiles = cdiv(Co, 64) * cdiv(Ci, 128) * B;
+    int want = (int)((FQSS_WGRAD_BLOCKS + tiles / 2) / tiles);
     if (want < 1) want = 1;
-    int kchunk = (int)cdiv(cdiv(M, want), 64) * 64;
-    if (kchunk < 64) kchunk = 64;
+    int kchunk = (int)cdiv(cdiv(M, want), 32 * WG_STAGES) * 32 * WG_STAGES;   // whole rounds of the load ring
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(M, kchunk);
-    dim3 grid((unsigned)cdiv(Ci, QBN), (unsigned)cdiv(Co, QBM), (unsigned)(B * g.ksplit));
-    hipLaunchKernelGGL((k_qgemm<2>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    FQSS_REQUIRE((int64_t)B * g.ksplit <= 65535, "too many batch x n-split slices");
+    dim3 grid((unsigned)cdiv(Ci, 128), (unsigned)cdiv(Co, 64), (unsigned)(B * g.ksplit));
+    hipLaunchKernelGGL(k_qwgrad, grid, dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qpw_bwd_w");
 }
 
