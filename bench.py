@@ -24,7 +24,6 @@ import torch  # noqa: E402
 
 B_PER_GPU, T_SAMPLES = 8, 32000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 
 
 def parse():
@@ -39,34 +38,24 @@ def parse():
 
 
 def dominant_kernel_roofline(dev):
-    """Times the dominant kernel of the step live with HIP events on the launch stream.
-
-    Dominant kernel (profiles/r01_step_stats.csv): the fp32-MFMA pointwise-conv GEMM k_gemm_f32 --
-    24 blocks x (1x 128->512 + 2x 512->128) fwd for student and teacher, the same again as dgrad, plus
-    wgrad.  Timed here on its most frequent launch: z[8][512][3999] = W[512x128] * x[8][128][3999].
-    Algorithmic work per launch: 2*Co*Ci*B*M flop; algorithmic bytes 4*(Ci+Co)*B*M (SURVEY §8(d)
-    convention: each LayerQ boundary tensor moves once)."""
-    from fqss_amd import kernels as K
-    B, Ci, Co, M = B_PER_GPU, 128, 512, (T_SAMPLES - 16) // 8 + 1
-    x = K.empty_act((B, Ci, M), dev).normal_()
-    w = torch.randn(Co, Ci, 1, device=dev) * 0.1
-    bias = torch.randn(Co, device=dev)
-    for _ in range(3):
-        K.pwconv_fwd(x, w, bias)
-    n = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        K.pwconv_fwd(x, w, bias)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * Co * Ci * B * M
-    abytes = 4.0 * (Ci + Co) * B * M
-    tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "k_gemm_f32 (pwconv_fwd 128->512, B=8, M=3999)", "bound": "mfma", "achieved": round(tf, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": None, "launch_ms": round(ms, 4), "algorithmic_GBps": round(abytes / (ms * 1e-3) / 1e9, 1)}
+    """Times the step's heaviest kernels live at their cfg-2 launch shapes (fqss_amd/roofline_cases.py)
+    with HIP events on the launch stream, and reports the one with the largest time per step as
+    `roofline` (launch-weighted over its shapes).  `traffic` = HBM bytes per launch from the rocprofv3
+    PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/roofline_probe.py);
+    null when no measurement of that kernel is committed."""
+    from fqss_amd import roofline_cases as RC
+    cases = RC.build(dev)
+    times = [RC.time_case(c) for c in cases]
+    groups = RC.summarize(cases, times)
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f).get("per_launch_bytes", {})
+    except (OSError, ValueError):
+        pmc = {}
+    dom = RC.roofline_object(groups[0], traffic=pmc.get(groups[0]["kernel"]))
+    others = [{k: v for k, v in RC.roofline_object(g, traffic=pmc.get(g["kernel"])).items() if k != "shapes"} for g in groups[1:]]
+    return dom, others
 
 
 def cpu_baseline(threads):
@@ -171,7 +160,7 @@ def main():
             "step_algorithmic_GB": 74.8,
             "step_algorithmic_frac_of_hbm_peak": round(74.8 / (ms * 1e-3) / HBM_PEAK_GBS, 4),
         }
-        out["roofline"] = dominant_kernel_roofline(dev)
+        out["roofline"], out["roofline_other_kernels"] = dominant_kernel_roofline(dev)
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_threads)
         print(json.dumps(out), flush=True)

@@ -37,8 +37,21 @@ static inline dim3 grid_rows(int64_t rows, int64_t cols, int vec, int64_t max_bl
     return dim3((unsigned)gx, (unsigned)gy, 1);
 }
 
+// XCD-aware tile order for GEMM-like grids.  Workgroups are dealt round-robin to the 8 XCDs by linear id, and
+// every XCD has its own L2: tiles that re-read the same operand panel ("group" = the tiles of one panel) are made
+// consecutive workgroups of ONE XCD, so the panel comes from HBM once and from that L2 afterwards.
+// Launch xcd_grid(groups, per_group) workgroups; tile_of() maps blockIdx.x -> (group, index in group) or false.
+constexpr int kXcds = 8;
+static inline unsigned xcd_grid(int64_t groups, int64_t per_group) { return (unsigned)(cdiv(groups, kXcds) * kXcds * per_group); }
+
 // ---------------------------------------------------------------- device side
 #if defined(__HIPCC__)
+__device__ __forceinline__ bool xcd_tile(int groups, int per_group, int& group, int& idx) {
+    const int L = blockIdx.x, xcd = L % kXcds, slot = L / kXcds;
+    idx = slot % per_group;
+    group = (slot / per_group) * kXcds + xcd;
+    return group < groups;
+}
 
 constexpr int kWave = 64;
 

@@ -71,6 +71,7 @@ struct QGemmArgs {
     const float* qmin_x;          // device scalars of the input activation quantizer (fwd, wgrad)
     const float* qmax_x;
     int ksplit, kchunk;           // wgrad split-K
+    int tiles_m, tiles_n, batches;   // logical grid (launched 1-D in XCD-aware order, fqss_dev.h)
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
@@ -93,10 +94,12 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int bz = blockIdx.z;
-    const int b = bz;
+    // group = one (batch, n-tile) activation panel, re-read by the tiles_m row tiles of the weight
+    int panel, mt;
+    if (!xcd_tile(g.tiles_n * g.batches, g.tiles_m, panel, mt)) return;
+    const int b = panel / g.tiles_n;
     const int kbeg = 0, kend = g.K;
-    const int i0 = blockIdx.y * QBM, j0 = blockIdx.x * QBN;
+    const int i0 = mt * QBM, j0 = (panel % g.tiles_n) * QBN;
 
     f32x16 acc[2];
 #pragma unroll
@@ -360,9 +363,12 @@ __device__ __forceinline__ void wg_wait(WgStage& st) {
 __global__ __launch_bounds__(256, 2) void k_qwgrad(QGemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z / g.ksplit, ks_id = blockIdx.z % g.ksplit;
+    // group = one (batch, n-slice): its tiles_m x tiles_n workgroups share the gz rows / code rows of that slice
+    int slice, t;
+    if (!xcd_tile(g.batches * g.ksplit, g.tiles_m * g.tiles_n, slice, t)) return;
+    const int b = slice / g.ksplit, ks_id = slice % g.ksplit;
     const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    const int row0 = blockIdx.y * 64 + wr * 32, col0 = blockIdx.x * 128 + wc * 64;
+    const int row0 = (t / g.tiles_n) * 64 + wr * 32, col0 = (t % g.tiles_n) * 128 + wc * 64;
     const int nchunks = (kend - kbeg + 31) >> 5;
 
     const bool arow_ok = row0 + lr < g.M;
@@ -514,8 +520,8 @@ extern "C" int fqss_qpw_fwd(const uint8_t* xc, const int8_t* wi, const float* dw
     g.lda = Ci; g.ldb = ld_xc; g.ldc = ld_z;
     g.sAb = 0; g.sBb = (int64_t)Ci * ld_xc; g.sCb = (int64_t)Co * ld_z;
     g.dw = dw; g.rw = rw; g.bias = bias; g.qmin_x = qmin_x; g.qmax_x = qmax_x; g.ksplit = 1; g.kchunk = Ci;
-    dim3 grid((unsigned)cdiv(M, QBN), (unsigned)cdiv(Co, QBM), (unsigned)B);
-    hipLaunchKernelGGL((k_qgemm<0>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
+    hipLaunchKernelGGL((k_qgemm<0>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qpw_fwd");
 }
 
@@ -532,8 +538,8 @@ extern "C" int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* d
     g.lda = Co; g.ldb = ld_gz; g.ldc = ld_gx;
     g.sAb = 0; g.sBb = (int64_t)Co * ld_gz; g.sCb = (int64_t)Ci * ld_gx;
     g.dw = dw; g.ksplit = 1; g.kchunk = Co;
-    dim3 grid((unsigned)cdiv(M, QBN), (unsigned)cdiv(Ci, QBM), (unsigned)B);
-    hipLaunchKernelGGL((k_qgemm<1>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Ci, QBM); g.batches = B;
+    hipLaunchKernelGGL((k_qgemm<1>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qpw_bwd_x");
 }
 
@@ -556,9 +562,8 @@ extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* q
     int kchunk = (int)cdiv(cdiv(M, want), 32 * WG_STAGES) * 32 * WG_STAGES;   // whole rounds of the load ring
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(M, kchunk);
-    FQSS_REQUIRE((int64_t)B * g.ksplit <= 65535, "too many batch x n-split slices");
-    dim3 grid((unsigned)cdiv(Ci, 128), (unsigned)cdiv(Co, 64), (unsigned)(B * g.ksplit));
-    hipLaunchKernelGGL(k_qwgrad, grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.tiles_n = (int)cdiv(Ci, 128); g.tiles_m = (int)cdiv(Co, 64); g.batches = B;
+    hipLaunchKernelGGL(k_qwgrad, dim3(xcd_grid((int64_t)B * g.ksplit, (int64_t)g.tiles_m * g.tiles_n)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qpw_bwd_w");
 }
 
@@ -576,7 +581,7 @@ extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* b
     g.lda = Ci; g.ldb = ld_x; g.ldc = ld_z;
     g.sAb = 0; g.sBb = (int64_t)Ci * ld_x; g.sCb = (int64_t)Co * ld_z;
     g.bias = bias; g.ksplit = 1; g.kchunk = Ci;
-    dim3 grid((unsigned)cdiv(M, QBN), (unsigned)cdiv(Co, QBM), (unsigned)B);
-    hipLaunchKernelGGL((k_qgemm<3>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
+    hipLaunchKernelGGL((k_qgemm<3>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_pwconv_fwd_x3");
 }

@@ -90,6 +90,7 @@ struct TGemmArgs {
     int M1;                    // rows [0,M1) -> C1 (+R1), rows [M1,M) -> C2 (+R2)
     float* C1; const float* R1; int64_t ldc1, sC1b;
     float* C2; const float* R2; int64_t ldc2, sC2b;
+    int tiles_m, tiles_n, batches;   // logical grid (launched 1-D in XCD-aware order, fqss_dev.h)
 };
 
 __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
@@ -105,7 +106,10 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z, i0 = blockIdx.y * TBM, j0 = blockIdx.x * TBN;
+    // group = one (sample, n-tile) activation panel, re-read by the tiles_m row tiles of the weight
+    int panel, mt;
+    if (!xcd_tile(g.tiles_n * g.batches, g.tiles_m, panel, mt)) return;
+    const int b = panel / g.tiles_n, i0 = mt * TBM, j0 = (panel % g.tiles_n) * TBN;
     const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 
     if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
         double v[2] = {(double)s1, (double)s2};
         block_sum<double, 2>(v, red);
         if (tid == 0) {
-            double* so = g.stats_out + ((int64_t)b * kTSlots + ((blockIdx.x + blockIdx.y * gridDim.x) & (kTSlots - 1))) * kTSlotStride;
+            double* so = g.stats_out + ((int64_t)b * kTSlots + ((panel * g.tiles_m + mt) & (kTSlots - 1))) * kTSlotStride;
             atomicAdd(&so[0], v[0]);
             atomicAdd(&so[1], v[1]);
         }
@@ -421,8 +425,8 @@ extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci,
     g.bias = bias; g.act = act; g.slope = slope; g.stats_out = stats_out; g.M1 = M1;
     g.C1 = c1; g.R1 = r1; g.ldc1 = ld_c1; g.sC1b = (int64_t)M1 * ld_c1;
     g.C2 = c2; g.R2 = r2; g.ldc2 = ld_c2; g.sC2b = (int64_t)(Co - M1) * ld_c2;
-    dim3 grid((unsigned)cdiv(M, TBN), (unsigned)cdiv(Co, TBM), (unsigned)B);
-    hipLaunchKernelGGL(k_tgemm, grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.tiles_n = (int)cdiv(M, TBN); g.tiles_m = (int)cdiv(Co, TBM); g.batches = B;
+    hipLaunchKernelGGL(k_tgemm, dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_tgemm");
 }
 
