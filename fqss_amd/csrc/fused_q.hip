@@ -375,6 +375,136 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
     }
 }
 
+// ---- the whole depthwise backward of one (sample, channel) row in ONE workgroup ------------------------------
+// gz (the gradient at the conv output, after the fake-quant STE and the PReLU) is needed at +-dil neighbours
+// for gx and against the shifted input for gw.  A row is at most kDwRowMax positions: the workgroup keeps
+// its gz in LDS instead of HBM, so the layer's backward moves  codes (1 B) + g (4 B) in, gx (4 B) out  per
+// position -- instead of 9 + 8 + 5 B over three kernels.
+//   phase 1 (per float4 group, consecutive lanes = consecutive groups): z from the 3 taps of the input codes,
+//           STE/PReLU -> gz to LDS; partials for the bias / weight / range / slope gradients
+//   phase 2: gx[m] = sum_k w[k] * gz[m + pad - k*dil] from LDS
+constexpr int kDwRowMax = 12 * 1024;   // 48 KiB of LDS
+
+__global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, const float* __restrict__ g,
+                                                  float* __restrict__ gx, float* gw, int C, int M, int K, int dil, int pad,
+                                                  int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope_p,
+                                                  const float* qmin_x, const float* qmax_x, const float* qmin,
+                                                  const float* qmax, double* gacc, float* gbias, int want_gx) {
+    extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
+    __shared__ double red[(4 + kTaps) * 4];
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    const int row = blockIdx.x, c = row % C;
+    float wk[kTaps], pw[kTaps];
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+        wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+        pw[k] = 0.0f;
+    }
+    const float bv = bias ? bias[c] : 0.0f;
+    const uint8_t* xr = xc + (int64_t)row * ld_xc;
+    const float* gr = g + (int64_t)row * ld_g;
+    float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
+
+    for (int m = 4 * threadIdx.x; m < M; m += 1024) {
+        float v[kTaps][4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k) {
+            if (k < K) {
+                const int s0 = m + k * dil - pad;
+                const unsigned int cw = load_codes4(xr, s0, (int)ld_xc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[k][j] = (s0 + j >= 0 && s0 + j < M) ? dec((cw >> (8 * j)) & 255u, rx) : 0.0f;
+                    acc[j] = fmaf(wk[k], v[k][j], acc[j]);
+                }
+            }
+        }
+        const float4 gv4 = *reinterpret_cast<const float4*>(gr + m);
+        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = (m + j < M);
+            const float gj = valid ? gv[j] : 0.0f;
+            const float z = acc[j] + bv;
+            const float t = act_apply(z, act, slope);
+            float cq, u;
+            bool inr;
+            (void)fq_asym(t, ry, cq, u, inr);
+            const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+            if (valid) {
+                p_du += gj * (inr ? (cq - u) : cq);
+                p_out += inr ? 0.0f : gj;
+            }
+            float gzj = gt;
+            if (act == FQSS_ACT_PRELU) {
+                const bool pos = z > 0.0f;
+                gzj = pos ? gt : slope * gt;
+                if (valid && !pos) p_slope += z * gt;
+            } else if (act == FQSS_ACT_RELU) {
+                gzj = (t > 0.0f) ? gt : 0.0f;
+            }
+            gzj = valid ? gzj : 0.0f;
+            o[j] = gzj;
+            p_bias += gzj;
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k)
+                if (k < K) pw[k] = fmaf(gzj, v[k][j], pw[k]);   // v is 0 outside the row (zero padding)
+        }
+        *reinterpret_cast<float4*>(&sgz[m]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+
+    if (want_gx) {
+        float* xo = gx + (int64_t)row * ld_gx;
+        const bool aligned = ((dil & 3) == 0) && ((pad & 3) == 0);
+        for (int m = 4 * threadIdx.x; m < M; m += 1024) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) {
+                if (k < K) {
+                    const int s0 = m + pad - k * dil;
+                    if (aligned) {
+                        if (s0 >= 0 && s0 < M) {   // whole float4 inside [0, ceil4(M)): sgz beyond M holds zeros
+                            const float4 t = *reinterpret_cast<const float4*>(&sgz[s0]);
+                            a[0] = fmaf(wk[k], t.x, a[0]);
+                            a[1] = fmaf(wk[k], t.y, a[1]);
+                            a[2] = fmaf(wk[k], t.z, a[2]);
+                            a[3] = fmaf(wk[k], t.w, a[3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int sj = s0 + j;
+                            const float t = (sj >= 0 && sj < M) ? sgz[sj] : 0.0f;
+                            a[j] = fmaf(wk[k], t, a[j]);
+                        }
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(xo + m) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    }
+
+    double v[4 + kTaps];
+    v[0] = (double)p_du; v[1] = (double)p_out; v[2] = (double)p_slope; v[3] = (double)p_bias;
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) v[4 + k] = (double)pw[k];
+    block_sum<double, 4 + kTaps>(v, red);
+    if (threadIdx.x == 0) {
+        double* slot = gacc + 3 * (row % kSlots);
+        const double dmax = v[0] / 255.0;
+        atomicAdd(&slot[0], v[1] - dmax);   // rows share slots modulo kSlots: few adders per address, order-insensitive in fp64
+        atomicAdd(&slot[1], dmax);
+        if (act == FQSS_ACT_PRELU) atomicAdd(&slot[2], v[2]);
+        if (gbias != nullptr) atomicAdd(&gbias[c], (float)v[3]);
+        if (gw != nullptr)
+            for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[4 + k]);
+    }
+}
+
 // gw[c][k] += sum_{b,m} gz[b][c][m] * decode(x[b][c][m + k*dil - pad])   ; grid (C, B), 4 m per thread
 __global__ __launch_bounds__(256) void k_dwq_bwd_w(const float* __restrict__ gz, const uint8_t* __restrict__ xc, float* gw,
                                                     int C, int M, int K, int dil, int pad, int64_t ld_gz, int64_t ld_xc,
@@ -675,6 +805,24 @@ extern "C" int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* q
     hipLaunchKernelGGL(k_dwq_bwd_w, dim3((unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, gz, xc, gw, C, M, K, dil,
                        pad, ld_gz, ld_xc, qmin_x, qmax_x);
     return launch_status("fqss_dwq_bwd_w");
+}
+
+extern "C" int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
+                            const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
+                            int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
+                            double* gacc, float* gbias, fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && w && g && qmin && qmax && gacc, "null pointer");
+    FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
+    FQSS_REQUIRE(M <= kDwRowMax, "row too long for the single-workgroup backward (use fqss_dwq_bwd_z / dwconv_bwd_x / dwq_bwd_w)");
+    FQSS_REQUIRE(ld_xc >= M && codes_ok(xc, ld_xc) && aligned16(g) && ld_g % 4 == 0 && ld_g >= ((M + 3) & ~3), "rows must be 16-B aligned");
+    FQSS_REQUIRE(!gx || (aligned16(gx) && ld_gx % 4 == 0 && ld_gx >= ((M + 3) & ~3)), "gx rows must be 16-B aligned");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    FQSS_REQUIRE((int64_t)B * C < (1ll << 31), "too many rows");
+    if (B == 0 || M == 0) return FQSS_OK;
+    const size_t lds = (size_t)((M + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL(k_dwq_bwd, dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, K, dil,
+                       pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0);
+    return launch_status("fqss_dwq_bwd");
 }
 
 extern "C" int fqss_ewq_fwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,

@@ -369,6 +369,20 @@ def ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, sb, g, act, slope, qmin, qmax, g
     return gz
 
 
+DWQ_ROW_MAX = 12 * 1024   # kDwRowMax (csrc/fused_q.hip)
+
+
+def dwq_bwd(xc, qmin_x, qmax_x, w, bias, g, dil, pad, act, slope, qmin, qmax, gacc, gbias, gw, want_gx=True):
+    """whole backward of the coded depthwise layer in one launch: returns gx (or None); gw / gbias / gacc are "+=" """
+    B, C, M, ld_xc = _codes3(xc)
+    assert M <= DWQ_ROW_MAX
+    g, ld_g = _aligned_grad(g)
+    gx = empty_act((B, C, M), xc.device) if want_gx else None
+    _lib.call("fqss_dwq_bwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(w), _p(bias), _p(g), _p(gx), _p(gw), B, C, M, w.shape[-1], dil, pad,
+              ld_xc, ld_g, rowmat(gx)[2] if gx is not None else 0, act, _p(slope), _p(qmin), _p(qmax), _p(gacc), _p(gbias), _stream())
+    return gx
+
+
 def dwq_bwd_w(gz, xc, qmin_x, qmax_x, gw, dil, pad):
     B, C, M, ld_xc = _codes3(xc)
     _lib.call("fqss_dwq_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), B, C, M, gw.shape[-1], dil, pad,

@@ -371,14 +371,22 @@ class DwConvQ(Function):
         gb, gb_direct = (None, True)
         if bias is not None:
             gb, gb_direct = _grad_buf(L.b_param, bias)
-        gz = K.dwq_bwd_z(xc, xmin, xmax, w, bias, g, L.dil, L.pad, act, slope, qmin, qmax, q.gacc, gb)
-        g_slope, g_min, g_max = _flush_ranges(q, slope, L.slope_param, act)
-        gx = K.dwconv_bwd_x(gz, w, L.dil, L.pad) if ctx.needs_input_grad[0] else None
         gw = None
         gwq = getattr(w, "_fqss_gwq", None)
-        if ctx.needs_input_grad[1] or gwq is not None:
+        want_gw = ctx.needs_input_grad[1] or gwq is not None
+        if want_gw:
             gw = gwq if gwq is not None else torch.zeros_like(w)
-            K.dwq_bwd_w(gz, xc, xmin, xmax, gw, L.dil, L.pad)
+        if xc.shape[-1] <= K.DWQ_ROW_MAX:
+            # one launch: gz stays in LDS (csrc/fused_q.hip k_dwq_bwd)
+            gx = K.dwq_bwd(xc, xmin, xmax, w, bias, g, L.dil, L.pad, act, slope, qmin, qmax, q.gacc, gb, gw,
+                           want_gx=ctx.needs_input_grad[0])
+        else:
+            gz = K.dwq_bwd_z(xc, xmin, xmax, w, bias, g, L.dil, L.pad, act, slope, qmin, qmax, q.gacc, gb)
+            gx = K.dwconv_bwd_x(gz, w, L.dil, L.pad) if ctx.needs_input_grad[0] else None
+            if want_gw:
+                K.dwq_bwd_w(gz, xc, xmin, xmax, gw, L.dil, L.pad)
+        g_slope, g_min, g_max = _flush_ranges(q, slope, L.slope_param, act)
+        if want_gw:
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
             if gwq is not None:

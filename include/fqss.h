@@ -224,6 +224,12 @@ int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* amax, const 
 int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
                    float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_gz,
                    int64_t ld_xc, fqss_stream_t stream);
+/* the three of them in one launch (one workgroup per row keeps gz in LDS): gx (nullable), gw += , gbias += , gacc slots += ;
+ * rows up to 12288 positions */
+int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
+                 const float* bias, const float* g, float* gx, float* gw, int B, int C, int M, int K,
+                 int dil, int pad, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope,
+                 const float* qmin, const float* qmax, double* gacc, float* gbias, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fused float-teacher chain (csrc/teacher.hip): inference only, frozen weights pre-split into three

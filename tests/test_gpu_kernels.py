@@ -352,3 +352,13 @@ def test_dwq_coded(B, C, M, dil):
     np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=5e-3, atol=sc)
     np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=5e-3, atol=sc)
     np.testing.assert_allclose(ga[2], sr.grad.item(), rtol=5e-3, atol=sc)
+    # the single-launch backward (gz kept in LDS) agrees with the three-kernel chain: gx bit for bit, sums to fp32 noise
+    gacc1 = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
+    gb1, gw1 = torch.zeros(C, device="cuda"), torch.zeros(C, 1, 3, device="cuda")
+    gx1 = K.dwq_bwd(xc, cu(xlo), cu(xhi), cu(w), cu(bias), padded(g), dil, dil, K.ACT_PRELU, cu(slope), cu(ylo), cu(yhi), gacc1, gb1, gw1)
+    assert torch.equal(gx1.cpu(), gx.cpu())
+    close(gw1, gw, rtol=1e-4, atol=1e-5 * float(gw.abs().max()) + 1e-6)
+    close(gb1, gb, rtol=1e-4, atol=1e-5 * float(gb.abs().max()) + 1e-6)
+    np.testing.assert_allclose(gacc1.view(-1, 3).sum(0).cpu().numpy(), ga, rtol=1e-4, atol=1e-3 * sc)   # fp32 per-thread partials, other order
+    assert K.dwq_bwd(xc, cu(xlo), cu(xhi), cu(w), cu(bias), padded(g), dil, dil, K.ACT_PRELU, cu(slope), cu(ylo), cu(yhi), gacc1, gb1, None,
+                     want_gx=False) is None
