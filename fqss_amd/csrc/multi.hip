@@ -14,7 +14,7 @@
 namespace fqss {
 
 constexpr int kSlotsM = FQSS_GACC_SLOTS;
-constexpr int kWqFields = 16;   // int64 words per weight descriptor
+constexpr int kWqFields = FQSS_WQ_DESC_WORDS;   // int64 words per weight descriptor
 
 // table[q] = {gacc, gmin, gmax, gslope} (addresses; 0 = absent)
 __global__ __launch_bounds__(256) void k_gacc_flush_multi(const long long* __restrict__ table) {
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void k_gacc_flush_multi(const long long* __res
 }
 
 // weight descriptor (int64 words): 0 w, 1 wq, 2 idx, 3 idxT, 4 dw, 5 rw, 6 qmin, 7 qmax, 8 gwq, 9 gw, 10 gmin, 11 gmax,
-//                                  12 outer, 13 C, 14 inner, 15 first block
+//                                  12 outer, 13 C, 14 inner, 15 first block, 16 row stride of idxT (>= C: the codes of
+//                                  paired layers are concatenated along the output channels)
 __device__ __forceinline__ const long long* find_desc(const long long* table, int n, int blk) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {   // last descriptor whose first block <= blk
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void k_wq_multi_fwd(const long long* __restric
     const float* qmax = reinterpret_cast<const float*>(d[7]);
     const int outer = (int)d[12], C = (int)d[13], inner = (int)d[14];
     const int c = blockIdx.x - (int)d[15];
+    const int64_t ldT = d[16];
     const float a = fmaxf(fabsf(qmin[c]), fabsf(qmax[c]));
     const float delta = (2.0f * a) / 255.0f;
     const float inv = 1.0f / delta;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void k_wq_multi_fwd(const long long* __restric
         wq[k] = delta * q;
         if (idx) {   // pointwise conv weight [C][outer*inner == Ci]: codes for the q-GEMMs
             idx[(int64_t)c * nel + e] = (signed char)q;
-            idxT[(int64_t)e * C + c] = (signed char)q;
+            idxT[(int64_t)e * ldT + c] = (signed char)q;
             s += q;
         }
     }

@@ -72,6 +72,14 @@ struct QGemmArgs {
     const float* qmax_x;
     int ksplit, kchunk;           // wgrad split-K
     int tiles_m, tiles_n, batches;   // logical grid (launched 1-D in XCD-aware order, fqss_dev.h)
+    // paired layers (two convs on the same input, e.g. res|skip of a TCN block) run as ONE GEMM over the
+    // concatenated output channels; the per-layer tensors stay separate in HBM:
+    int M1;                          // fwd: rows >= M1 go to C2 / bias2;  wgrad: gz rows >= M1 come from A2
+    float* C2; int64_t ldc2, sC2b;
+    const float* bias2;
+    const void* A2; int64_t lda2, sA2b;
+    int K1;                          // dgrad: reduction rows >= K1 (the second layer's gz) come from B2
+    const void* B2; int64_t ldb2, sB2b;
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             const bool ok = row < g.M;
             rowc[0][tid] = (MODE == 0 && ok) ? g.dw[row] : 1.0f;
             rowc[1][tid] = (MODE == 0 && ok) ? g.rw[row] : 0.0f;
-            rowc[2][tid] = (ok && g.bias != nullptr) ? g.bias[row] : 0.0f;
+            rowc[2][tid] = (ok && g.bias != nullptr) ? (row < g.M1 ? g.bias[row] : g.bias2[row - g.M1]) : 0.0f;
         }
     }
 
@@ -159,14 +167,16 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             if (b_u8_active && k0 + bu_row < kend && j0 + bu_n < g.N)
                 rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(k0 + bu_row) * g.ldb + j0 + bu_n);
         } else if constexpr (MODE == 1 || MODE == 3) {
-            const float* Bp = (const float*)g.B + (int64_t)b * g.sBb;
-            const bool ok = (k0 + bk_row < kend);
-            rb_scale = (ok && MODE == 1) ? g.dw[k0 + bk_row] : 0.0f;
+            const int kk = k0 + bk_row;
+            const bool ok = (kk < kend);
+            const float* Bp = (kk < g.K1) ? (const float*)g.B + (int64_t)b * g.sBb + (int64_t)kk * g.ldb
+                                          : (const float*)g.B2 + (int64_t)b * g.sB2b + (int64_t)(kk - g.K1) * g.ldb2;
+            rb_scale = (ok && MODE == 1) ? g.dw[kk] : 0.0f;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int n = j0 + bk_n + 4 * q;
-                if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bp + (int64_t)(k0 + bk_row) * g.ldb + n);
+                if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bp + n);
                 rb_f[q] = v;
             }
         }
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         mnx = lo;
     }
     float* Cb = g.C + (int64_t)b * g.sCb;
+    float* C2b = (g.C2 != nullptr) ? g.C2 + (int64_t)b * g.sC2b : nullptr;
     {
         // stage each 32x32 accumulator tile through LDS and store whole 128-B rows with 16 B per lane
         // (the lane-per-column layout of the MFMA result would need 16 strided 4-B stores per tile: that
@@ -312,8 +323,10 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                 const int row = i0 + wm * 64 + mi * 32 + rl;
                 const float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
                 if (row < g.M && col < g.N) {
-                    float* dst = Cb + (int64_t)row * g.ldc + col;
-                    if (col + 3 < g.N || col + 3 < g.ldc) {
+                    const bool first = row < g.M1;
+                    const int64_t ldc = first ? g.ldc : g.ldc2;
+                    float* dst = (first ? Cb + (int64_t)row * ldc : C2b + (int64_t)(row - g.M1) * ldc) + col;
+                    if (col + 3 < g.N || col + 3 < ldc) {
                         *reinterpret_cast<float4*>(dst) = t;    // columns >= N fall into the row padding
                     } else {
                         dst[0] = t.x;
@@ -372,7 +385,9 @@ __global__ __launch_bounds__(256, 2) void k_qwgrad(QGemmArgs g) {
     const int nchunks = (kend - kbeg + 31) >> 5;
 
     const bool arow_ok = row0 + lr < g.M;
-    const float* Ap = (const float*)g.A + (int64_t)b * g.sAb + (int64_t)(arow_ok ? row0 + lr : 0) * g.lda;
+    const int arow = arow_ok ? row0 + lr : 0;
+    const float* Ap = (arow < g.M1) ? (const float*)g.A + (int64_t)b * g.sAb + (int64_t)arow * g.lda
+                                    : (const float*)g.A2 + (int64_t)b * g.sA2b + (int64_t)(arow - g.M1) * g.lda2;
     const unsigned char* Bb = (const unsigned char*)g.B + (int64_t)b * g.sBb;
     const unsigned char* Bp[2] = {Bb + (int64_t)min(col0 + lr, g.N - 1) * g.ldb, Bb + (int64_t)min(col0 + 32 + lr, g.N - 1) * g.ldb};
 
@@ -506,54 +521,88 @@ extern "C" int fqss_wq_codes(const float* w, int8_t* idx, int8_t* idxT, float* d
     return launch_status("fqss_wq_codes");
 }
 
+static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                        const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int B, int Ci, int Co1,
+                        int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, fqss_stream_t stream) {
+    const int Co = Co1 + Co2;
+    FQSS_REQUIRE(xc && wi && dw && rw && qmin_x && qmax_x && z1 && (Co2 == 0 || z2), "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_xc >= M && ld_z1 >= M && (Co2 == 0 || ld_z2 >= M), "bad shape");
+    FQSS_REQUIRE(Ci % 16 == 0 && Ci <= 512 && ld_xc % 16 == 0 && aligned16(xc) && aligned16(wi),
+                 "q-GEMM needs Ci % 16 == 0, Ci <= 512 (exact fp32 integer sum) and 16-B aligned code rows");
+    FQSS_REQUIRE(aligned16(z1) && ld_z1 % 4 == 0 && (Co2 == 0 || (aligned16(z2) && ld_z2 % 4 == 0)), "output rows must be 16-B aligned");
+    FQSS_REQUIRE((bias1 == nullptr) == (bias2 == nullptr) || Co2 == 0, "paired layers: both or neither with bias");
+    if (B == 0 || M == 0) return FQSS_OK;
+    QGemmArgs g{};
+    g.A = wi; g.B = xc; g.C = z1; g.M = Co; g.N = M; g.K = Ci;
+    g.lda = Ci; g.ldb = ld_xc; g.ldc = ld_z1;
+    g.sAb = 0; g.sBb = (int64_t)Ci * ld_xc; g.sCb = (int64_t)Co1 * ld_z1;
+    g.M1 = Co1; g.C2 = z2; g.ldc2 = ld_z2; g.sC2b = (int64_t)Co2 * ld_z2; g.bias2 = bias2; g.K1 = Ci;
+    g.dw = dw; g.rw = rw; g.bias = bias1; g.qmin_x = qmin_x; g.qmax_x = qmax_x; g.ksplit = 1; g.kchunk = Ci;
+    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
+    hipLaunchKernelGGL((k_qgemm<0>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status(who);
+}
+
 extern "C" int fqss_qpw_fwd(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias,
                             const float* qmin_x, const float* qmax_x, float* z, int B, int Ci, int Co, int M,
                             int64_t ld_xc, int64_t ld_z, fqss_stream_t stream) {
-    FQSS_REQUIRE(xc && wi && dw && rw && qmin_x && qmax_x && z, "null tensor");
-    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_xc >= M && ld_z >= M, "bad shape");
-    FQSS_REQUIRE(Ci % 16 == 0 && Ci <= 512 && ld_xc % 16 == 0 && aligned16(xc) && aligned16(wi),
-                 "q-GEMM needs Ci % 16 == 0, Ci <= 512 (exact fp32 integer sum) and 16-B aligned code rows");
-    FQSS_REQUIRE(aligned16(z) && ld_z % 4 == 0, "output rows must be 16-B aligned");
+    return qpw_fwd_impl("fqss_qpw_fwd", xc, wi, dw, rw, bias, nullptr, qmin_x, qmax_x, z, nullptr, B, Ci, Co, 0, M, ld_xc, ld_z, 0, stream);
+}
+
+extern "C" int fqss_qpw_fwd2(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                             const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int B, int Ci,
+                             int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, fqss_stream_t stream) {
+    FQSS_REQUIRE(Co2 > 0, "second layer missing");
+    return qpw_fwd_impl("fqss_qpw_fwd2", xc, wi, dw, rw, bias1, bias2, qmin_x, qmax_x, z1, z2, B, Ci, Co1, Co2, M, ld_xc, ld_z1, ld_z2, stream);
+}
+
+static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B,
+                          int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_gx, fqss_stream_t stream) {
+    const int Co = Co1 + Co2;
+    FQSS_REQUIRE(gz1 && wiT && dw && gx && (Co2 == 0 || gz2), "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_gz1 >= M && ld_gx >= M, "bad shape");
+    FQSS_REQUIRE(Co1 % 16 == 0 && Co2 % 16 == 0 && ld_gz1 % 4 == 0 && aligned16(gz1) && aligned16(wiT) && ld_gz1 >= ((M + 3) & ~3),
+                 "q-GEMM dgrad needs Co % 16 == 0 and 16-B aligned gradient rows");
+    FQSS_REQUIRE(Co2 == 0 || (ld_gz2 % 4 == 0 && aligned16(gz2) && ld_gz2 >= ((M + 3) & ~3)), "second gradient: 16-B aligned rows");
+    FQSS_REQUIRE(aligned16(gx) && ld_gx % 4 == 0, "output rows must be 16-B aligned");
     if (B == 0 || M == 0) return FQSS_OK;
     QGemmArgs g{};
-    g.A = wi; g.B = xc; g.C = z; g.M = Co; g.N = M; g.K = Ci;
-    g.lda = Ci; g.ldb = ld_xc; g.ldc = ld_z;
-    g.sAb = 0; g.sBb = (int64_t)Ci * ld_xc; g.sCb = (int64_t)Co * ld_z;
-    g.dw = dw; g.rw = rw; g.bias = bias; g.qmin_x = qmin_x; g.qmax_x = qmax_x; g.ksplit = 1; g.kchunk = Ci;
-    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
-    hipLaunchKernelGGL((k_qgemm<0>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
-    return launch_status("fqss_qpw_fwd");
+    g.A = wiT; g.B = gz1; g.C = gx; g.M = Ci; g.N = M; g.K = Co;
+    g.lda = Co; g.ldb = ld_gz1; g.ldc = ld_gx;
+    g.sAb = 0; g.sBb = (int64_t)Co1 * ld_gz1; g.sCb = (int64_t)Ci * ld_gx;
+    g.M1 = Ci; g.K1 = Co1; g.B2 = gz2; g.ldb2 = ld_gz2; g.sB2b = (int64_t)Co2 * ld_gz2;
+    g.dw = dw; g.ksplit = 1; g.kchunk = Co;
+    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Ci, QBM); g.batches = B;
+    hipLaunchKernelGGL((k_qgemm<1>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status(who);
 }
 
 extern "C" int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* dw, float* gx, int B, int Ci, int Co,
                               int M, int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream) {
-    FQSS_REQUIRE(gz && wiT && dw && gx, "null tensor");
-    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_gx >= M, "bad shape");
-    FQSS_REQUIRE(Co % 16 == 0 && ld_gz % 4 == 0 && aligned16(gz) && aligned16(wiT) && (M % 4 == 0 || ld_gz >= ((M + 3) & ~3)),
-                 "q-GEMM dgrad needs Co % 16 == 0 and 16-B aligned gradient rows");
-    FQSS_REQUIRE(aligned16(gx) && ld_gx % 4 == 0, "output rows must be 16-B aligned");
-    if (B == 0 || M == 0) return FQSS_OK;
-    QGemmArgs g{};
-    g.A = wiT; g.B = gz; g.C = gx; g.M = Ci; g.N = M; g.K = Co;
-    g.lda = Co; g.ldb = ld_gz; g.ldc = ld_gx;
-    g.sAb = 0; g.sBb = (int64_t)Co * ld_gz; g.sCb = (int64_t)Ci * ld_gx;
-    g.dw = dw; g.ksplit = 1; g.kchunk = Co;
-    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Ci, QBM); g.batches = B;
-    hipLaunchKernelGGL((k_qgemm<1>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
-    return launch_status("fqss_qpw_bwd_x");
+    return qpw_bwd_x_impl("fqss_qpw_bwd_x", gz, nullptr, wiT, dw, gx, B, Ci, Co, 0, M, ld_gz, 0, ld_gx, stream);
 }
 
-extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw,
-                              int B, int Ci, int Co, int M, int64_t ld_gz, int64_t ld_xc, fqss_stream_t stream) {
-    FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null tensor");
-    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_gz >= M && ld_xc >= M, "bad shape");
-    FQSS_REQUIRE(ld_gz % 4 == 0 && ld_xc % 16 == 0 && aligned16(gz) && aligned16(xc) && ld_gz >= ((M + 3) & ~3),
+extern "C" int fqss_qpw_bwd_x2(const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B, int Ci,
+                               int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(Co2 > 0, "second layer missing");
+    return qpw_bwd_x_impl("fqss_qpw_bwd_x2", gz1, gz2, wiT, dw, gx, B, Ci, Co1, Co2, M, ld_gz1, ld_gz2, ld_gx, stream);
+}
+
+static int qpw_bwd_w_impl(const char* who, const float* gz1, const float* gz2, const uint8_t* xc, const float* qmin_x,
+                          const float* qmax_x, float* gw, int B, int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2,
+                          int64_t ld_xc, fqss_stream_t stream) {
+    const int Co = Co1 + Co2;
+    FQSS_REQUIRE(gz1 && xc && qmin_x && qmax_x && gw && (Co2 == 0 || gz2), "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_gz1 >= M && ld_xc >= M, "bad shape");
+    FQSS_REQUIRE(ld_gz1 % 4 == 0 && ld_xc % 16 == 0 && aligned16(gz1) && aligned16(xc) && ld_gz1 >= ((M + 3) & ~3),
                  "q-GEMM wgrad needs 16-B aligned gradient and code rows");
+    FQSS_REQUIRE(Co2 == 0 || (ld_gz2 % 4 == 0 && aligned16(gz2) && ld_gz2 >= ((M + 3) & ~3)), "second gradient: 16-B aligned rows");
     if (B == 0 || M == 0) return FQSS_OK;
     QGemmArgs g{};
-    g.A = gz; g.B = xc; g.C = gw; g.M = Co; g.N = Ci; g.K = M;
-    g.lda = ld_gz; g.ldb = ld_xc; g.ldc = Ci;
-    g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_xc; g.sCb = 0;
+    g.A = gz1; g.B = xc; g.C = gw; g.M = Co; g.N = Ci; g.K = M;
+    g.lda = ld_gz1; g.ldb = ld_xc; g.ldc = Ci;
+    g.sAb = (int64_t)Co1 * ld_gz1; g.sBb = (int64_t)Ci * ld_xc; g.sCb = 0;
+    g.M1 = Co1; g.A2 = gz2; g.lda2 = ld_gz2; g.sA2b = (int64_t)Co2 * ld_gz2; g.K1 = M;
     g.qmin_x = qmin_x; g.qmax_x = qmax_x;
     // one workgroup = 64 (co) x 128 (ci); split n so that ~FQSS_WGRAD_BLOCKS workgroups stream the operands
     const int64_t tiles = cdiv(Co, 64) * cdiv(Ci, 128) * B;
@@ -564,7 +613,19 @@ extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* q
     g.ksplit = (int)cdiv(M, kchunk);
     g.tiles_n = (int)cdiv(Ci, 128); g.tiles_m = (int)cdiv(Co, 64); g.batches = B;
     hipLaunchKernelGGL(k_qwgrad, dim3(xcd_grid((int64_t)B * g.ksplit, (int64_t)g.tiles_m * g.tiles_n)), dim3(256), 0, (hipStream_t)stream, g);
-    return launch_status("fqss_qpw_bwd_w");
+    return launch_status(who);
+}
+
+extern "C" int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw,
+                              int B, int Ci, int Co, int M, int64_t ld_gz, int64_t ld_xc, fqss_stream_t stream) {
+    return qpw_bwd_w_impl("fqss_qpw_bwd_w", gz, nullptr, xc, qmin_x, qmax_x, gw, B, Ci, Co, 0, M, ld_gz, 0, ld_xc, stream);
+}
+
+extern "C" int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
+                               float* gw, int B, int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_xc,
+                               fqss_stream_t stream) {
+    FQSS_REQUIRE(Co2 > 0, "second layer missing");
+    return qpw_bwd_w_impl("fqss_qpw_bwd_w2", gz1, gz2, xc, qmin_x, qmax_x, gw, B, Ci, Co1, Co2, M, ld_gz1, ld_gz2, ld_xc, stream);
 }
 
 // plain fp32 pointwise conv z = W x + b on the bf16 matrix cores: both operands split exactly in three
@@ -580,7 +641,7 @@ extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* b
     g.A = w; g.B = x; g.C = z; g.M = Co; g.N = M; g.K = Ci;
     g.lda = Ci; g.ldb = ld_x; g.ldc = ld_z;
     g.sAb = 0; g.sBb = (int64_t)Ci * ld_x; g.sCb = (int64_t)Co * ld_z;
-    g.bias = bias; g.ksplit = 1; g.kchunk = Ci;
+    g.bias = bias; g.ksplit = 1; g.kchunk = Ci; g.M1 = Co; g.K1 = Ci;
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
     hipLaunchKernelGGL((k_qgemm<3>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_pwconv_fwd_x3");

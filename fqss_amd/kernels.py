@@ -252,6 +252,7 @@ def qpw_fwd(xc, wc, bias, qmin_x, qmax_x):
 
 
 def qpw_bwd_x(gz, wc):
+    assert wc.idxT is not None, "this layer's codes live in a concatenated pair image: use qpw_bwd_x2"
     gz, B, Co, M, ld_gz = _bcm(gz)
     if ld_gz % 4 != 0 or gz.data_ptr() % 16 != 0:
         c = empty_act(tuple(gz.shape), gz.device)
@@ -273,6 +274,41 @@ def qpw_bwd_w(gz, xc, qmin_x, qmax_x, gw):
 
 
 # ------------------------------------------------------------------ K6q / K7q  codes-only layers (csrc/fused_q.hip)
+def qpw_fwd2(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1):
+    """two layers on the same coded input as one GEMM over concatenated channels -> (z1 [B,Co1,M], z2 [B,Co-Co1,M])"""
+    B, Ci, M = xc.shape
+    rm = rowmat(xc)
+    assert rm is not None and Ci == wc.Ci and 0 < Co1 < wc.Co
+    z1, z2 = empty_act((B, Co1, M), xc.device), empty_act((B, wc.Co - Co1, M), xc.device)
+    _lib.call("fqss_qpw_fwd2", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias1), _p(bias2), _p(qmin_x), _p(qmax_x), _p(z1), _p(z2),
+              B, Ci, Co1, wc.Co - Co1, M, rm[2], rowmat(z1)[2], rowmat(z2)[2], _stream())
+    return z1, z2
+
+
+def qpw_bwd_x2(gz1, gz2, wc):
+    """gx = W1q^T gz1 + W2q^T gz2 in one GEMM (K = Co1 + Co2)"""
+    gz1, ld1 = _aligned_grad(gz1)
+    gz2, ld2 = _aligned_grad(gz2)
+    B, Co1, M = gz1.shape
+    Co2 = gz2.shape[1]
+    assert Co1 + Co2 == wc.Co and gz2.shape[0] == B and gz2.shape[2] == M
+    gx = empty_act((B, wc.Ci, M), gz1.device)
+    _lib.call("fqss_qpw_bwd_x2", _p(gz1), _p(gz2), _p(wc.idxT), _p(wc.dw), _p(gx), B, wc.Ci, Co1, Co2, M, ld1, ld2, rowmat(gx)[2], _stream())
+    return gx
+
+
+def qpw_bwd_w2(gz1, gz2, xc, qmin_x, qmax_x, gw):
+    """gw [Co1+Co2, Ci] += [gz1; gz2] x^T"""
+    gz1, ld1 = _aligned_grad(gz1)
+    gz2, ld2 = _aligned_grad(gz2)
+    B, Co1, M = gz1.shape
+    Co2 = gz2.shape[1]
+    Ci = xc.shape[1]
+    assert gw.is_contiguous() and gw.numel() == (Co1 + Co2) * Ci
+    _lib.call("fqss_qpw_bwd_w2", _p(gz1), _p(gz2), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), B, Ci, Co1, Co2, M, ld1, ld2, rowmat(xc)[2],
+              _stream())
+
+
 def _codes3(xc):
     """u8 codes [B,C,M] with 16-B aligned rows -> (B, C, M, ld)"""
     rm = rowmat(xc)

@@ -315,6 +315,38 @@ class LinearActQ(Function):
         return gx, gw, g_bias, g_slope, g_min, g_max, None, None, None, None, None
 
 
+class LinearActQPair(Function):
+    """Two quantized pointwise convs on the SAME coded input (res | skip of a TCN block) as one node:
+    one forward GEMM over the concatenated output channels, one dgrad GEMM whose reduction runs over both
+    layers' gradients (= autograd's accumulation at the fork, without the extra pass), one wgrad launch.
+    Only in the quantizing phase with a runtime.QuantTables active (concatenated weight codes)."""
+
+    @staticmethod
+    def forward(ctx, x, b1, b2, qmin1, qmax1, qmin2, qmax2, L1, L2, q1, q2, xq, pair):
+        Co1 = pair.Co1
+        z1, z2 = K.qpw_fwd2(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1)
+        out1 = _epilogue_fwd(z1, ACT_NONE, None, q1)
+        out2 = _epilogue_fwd(z2, ACT_NONE, None, q2)
+        ctx.save_for_backward(z1, z2)
+        ctx.L, ctx.q, ctx.b, ctx.xq, ctx.pair = (L1, L2), (q1, q2), (b1, b2), xq, pair
+        return out1, out2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        z = ctx.saved_tensors
+        gs, gz, gbias, gmin, gmax = [g1, g2], [], [], [], []
+        for i in range(2):
+            if gs[i] is None:      # an unused output (the last block's residual): its gradient is zero
+                gs[i] = K.empty_act(tuple(z[i].shape), z[i].device).zero_()
+            L, q, b = ctx.L[i], ctx.q[i], ctx.b[i]
+            gzi, _, g_min, g_max, g_bias = _epilogue_bwd(z[i], gs[i], ACT_NONE, None, None, q, bias_param=L.b_param,
+                                                          bias_like=b, C=z[i].shape[1])
+            gz.append(gzi); gbias.append(g_bias); gmin.append(g_min); gmax.append(g_max)
+        gx = K.qpw_bwd_x2(gz[0], gz[1], ctx.pair.wc) if ctx.needs_input_grad[0] else None
+        K.qpw_bwd_w2(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
+        return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None
+
+
 class GroupNormActQ(Function):
     """out = fq(GroupNorm(1, C)(x))  -- GroupNormQ.  With coded input in the quantizing phase the layer
     runs codes -> codes (csrc/fused_q.hip) and saves nothing but the input codes and the statistics."""

@@ -11,7 +11,7 @@ import torch.nn as nn
 from .... import ops
 from ....process import postprocess, preprocess
 from ..float_exec import HipSequential, apply_module
-from ..qat_layers import Add, Mul
+from ..qat_layers import Add, Mul, run_conv1d_pair
 from ..qat_utils import quantize_modules, replace_decoderq, replace_encoderq
 
 EPS = 1e-8
@@ -35,11 +35,18 @@ class ConvBlock(nn.Module):
         self.skip_conv = nn.Conv1d(hidden_channels, io_channels, 1)
         self.add = Add()
 
+    fqss_linear_pairs = (("res_conv", "skip_conv"),)   # same-input 1x1 convs: runtime.QuantTables concatenates their codes
+
     def forward(self, x):
         x_blk, x_res = ops.fork2(x)
-        f_res, f_skip = ops.fork2(self.shared_block(x_blk))
-        residual = apply_module(self.res_conv, f_res)
-        skip_out = apply_module(self.skip_conv, f_skip)
+        f = self.shared_block(x_blk)
+        fused = run_conv1d_pair(self.res_conv, self.skip_conv, f)   # one GEMM for both (quantizing phase, graph mode)
+        if fused is not None:
+            residual, skip_out = fused
+        else:
+            f_res, f_skip = ops.fork2(f)
+            residual = apply_module(self.res_conv, f_res)
+            skip_out = apply_module(self.skip_conv, f_skip)
         return self.add(x_res, residual), skip_out
 
 

@@ -184,6 +184,34 @@ def run_conv1d(conv, x, weight, nl, aq):
     return ops.tag_codes(y, q)
 
 
+def run_conv1d_pair(l1, l2, x):
+    """(l1(x), l2(x)) for two Conv1dQ layers fed by the same tensor, as ONE fused node (ops.LinearActQPair);
+    None when the fused path does not apply (observer phase, eager mode, float layers): the caller then runs
+    the two layers one by one."""
+    if ops.DEFER is None or type(l1) is not Conv1dQ or type(l2) is not Conv1dQ:
+        return None
+    pre = getattr(l1.conv1d.weight, "_fqss_wq", None)
+    pair = getattr(pre, "_fqss_pair", None)
+    if pair is None or pair.partner is not getattr(l2.conv1d.weight, "_fqss_wq", None):
+        return None
+    aqs = (l1.activation_fake_quantize, l2.activation_fake_quantize)
+    if any(not hasattr(a, "next_mode") or (a.observer_mode and a.n_iter < a.max_observations) for a in aqs):
+        return None
+    if l1.weight_fake_quantize.observer_mode or l2.weight_fake_quantize.observer_mode:
+        return None
+    xq = ops.codes_of(x)
+    if xq is None:
+        return None
+    q1, q2 = aqs[0].qctx(), aqs[1].qctx()
+    L1, L2 = conv1d_geometry(l1.conv1d), conv1d_geometry(l2.conv1d)
+    for L, conv in ((L1, l1.conv1d), (L2, l2.conv1d)):
+        L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, None
+    y1, y2 = ops.LinearActQPair.apply(x, l1.conv1d.bias, l2.conv1d.bias, q1.qmin, q1.qmax, q2.qmin, q2.qmax, L1, L2, q1, q2, xq, pair)
+    aqs[0].after_forward(q1)
+    aqs[1].after_forward(q2)
+    return ops.tag_codes(y1, q1), ops.tag_codes(y2, q2)
+
+
 class Conv1dQ(LayerQ):
     def __init__(self, conv1d, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
         _expect(conv1d, nn.Conv1d, "Conv1d")

@@ -141,6 +141,11 @@ class TeacherRunner:
         return dec.reshape(B, m.n_srcs, -1)
 
 
+class _LinearPair:
+    """concatenated weight codes / dL/dW_q view of two same-input pointwise layers (ops.LinearActQPair)"""
+    __slots__ = ("wc", "gw", "Co1", "partner")
+
+
 class QuantTables:
     """Device-side descriptor tables that let ONE launch each do, for the whole model: the weight
     fake-quant forward (+ int8 codes), its backward, and the range/slope gradient flush (csrc/multi.hip).
@@ -178,11 +183,40 @@ class QuantTables:
                             1 if d != wqm.axis else conv.weight.shape[d] for d in range(conv.weight.dim())):
                         owners.append((wqm, conv.weight))
                         break
+        # layers declared as same-input pairs by their parent (`fqss_linear_pairs`) get adjacent storage: one
+        # concatenated code image [Co1+Co2][Ci] (+ transposed, scales, row sums) and one dL/dW_q block, so that the
+        # paired q-GEMMs (ops.LinearActQPair) see them as a single weight
+        partner = {}
+        for mod in model.modules():
+            for n1, n2 in getattr(mod, "fqss_linear_pairs", ()):
+                l1, l2 = getattr(mod, n1, None), getattr(mod, n2, None)
+                w1 = getattr(getattr(l1, "conv1d", None), "weight", None)
+                w2 = getattr(getattr(l2, "conv1d", None), "weight", None)
+                own = {id(w) for _, w in owners}
+                if w1 is None or w2 is None or id(w1) not in own or id(w2) not in own:
+                    continue
+                ok = w1.dim() == 3 and w1.shape[2] == 1 and w2.shape[1:] == w1.shape[1:] and K.q_eligible(w1.shape[1], w1.shape[0]) \
+                    and K.q_eligible(w2.shape[1], w2.shape[0]) and (w1.numel() % 64 == 0) \
+                    and (l1.conv1d.bias is None) == (l2.conv1d.bias is None)
+                if ok:
+                    partner[id(w1)] = w2
+        second = {id(w2) for w2 in partner.values()}
+        by_id = {id(w): (wqm, w) for wqm, w in owners}
+        ordered = []
+        for wqm, w in owners:
+            if id(w) in second:
+                continue
+            ordered.append((wqm, w))
+            if id(w) in partner:
+                ordered.append(by_id[id(partner[id(w)])])
+        owners = ordered
         n_gwq = sum((w.numel() + 63) // 64 * 64 for _, w in owners)
         self.gwq = torch.zeros(n_gwq, device=dev)                       # dL/dW_q arena (zeroed once per step)
         self.wq_store = torch.empty(n_gwq, device=dev)
         rows, off, blk = [], 0, 0
         self.weights = []
+        self.pairs = []
+        pending = None      # (pair codes, first wq, Co1) while the second member of a pair is being laid out
         for wqm, w in owners:
             shape, axis = tuple(w.shape), wqm.axis
             outer = 1
@@ -196,17 +230,49 @@ class QuantTables:
             gwq = self.gwq[off:off + w.numel()].view(shape)
             pw = axis == 0 and w.dim() == 3 and shape[2] == 1 and K.q_eligible(shape[1], shape[0])
             wc = None
-            if pw:
+            ldT = C
+            if pw and id(w) in partner:
+                # first of a pair: allocate the concatenated images, this layer's are views of rows / columns [0, Co1)
+                w2 = partner[id(w)]
+                Co1, Co2, Ci = shape[0], w2.shape[0], shape[1]
+                pc = K.WCodes()
+                pc.Co, pc.Ci = Co1 + Co2, Ci
+                pc.idx = torch.empty(Co1 + Co2, Ci, device=dev, dtype=torch.int8)
+                pc.idxT = torch.empty(Ci, Co1 + Co2, device=dev, dtype=torch.int8)
+                pc.dw = torch.empty(Co1 + Co2, device=dev)
+                pc.rw = torch.empty(Co1 + Co2, device=dev)
+                pair = _LinearPair()
+                pair.wc, pair.Co1 = pc, Co1
+                pair.gw = self.gwq[off:off + w.numel() + w2.numel()].view(Co1 + Co2, Ci)
+                pending = (pair, wq, 0)
+            if pw and pending is not None:
+                pair, wq_first, _ = pending
+                pc = pair.wc
+                r0 = 0 if wq_first is wq else pair.Co1
+                wc = K.WCodes()
+                wc.Co, wc.Ci = shape[0], shape[1]
+                wc.idx = pc.idx[r0:r0 + shape[0]]
+                wc.idxT = None                         # column block of pc.idxT (row stride Co1+Co2): paired kernels only
+                wc.dw, wc.rw = pc.dw[r0:r0 + shape[0]], pc.rw[r0:r0 + shape[0]]
+                ldT = pc.Co
+                idxT_ptr = pc.idxT.data_ptr() + r0
+                if wq_first is not wq:
+                    pair.partner = wq
+                    wq_first._fqss_pair = pair
+                    self.pairs.append(pair)
+                    pending = None
+            elif pw:
                 wc = K.WCodes()
                 wc.Co, wc.Ci = shape[0], shape[1]
                 wc.idx = torch.empty(shape[0], shape[1], device=dev, dtype=torch.int8)
                 wc.idxT = torch.empty(shape[1], shape[0], device=dev, dtype=torch.int8)
                 wc.dw = torch.empty(shape[0], device=dev)
                 wc.rw = torch.empty(shape[0], device=dev)
-            rows.append([w.data_ptr(), wq.data_ptr(), wc.idx.data_ptr() if pw else 0, wc.idxT.data_ptr() if pw else 0,
+                idxT_ptr = wc.idxT.data_ptr()
+            rows.append([w.data_ptr(), wq.data_ptr(), wc.idx.data_ptr() if pw else 0, idxT_ptr if pw else 0,
                          wc.dw.data_ptr() if pw else 0, wc.rw.data_ptr() if pw else 0, wqm.min_range.data_ptr(),
                          wqm.max_range.data_ptr(), gwq.data_ptr(), w.grad.data_ptr(), wqm.min_range.grad.data_ptr(),
-                         wqm.max_range.grad.data_ptr(), outer, C, inner, blk])
+                         wqm.max_range.grad.data_ptr(), outer, C, inner, blk, ldT])
             wq._fqss_gwq = gwq
             if pw:
                 wq._fqss_wcodes = wc
@@ -214,6 +280,7 @@ class QuantTables:
             self.weights.append((wqm, w, wq, wc))
             off += (w.numel() + 63) // 64 * 64
             blk += C
+        assert pending is None
         self.wq_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.total_channels = blk
 

@@ -109,11 +109,13 @@ int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmin, float* g
  * multi-tensor forms of the per-quantizer small work (csrc/multi.hip): ONE launch each, driven by a
  * device table of int64 words the host builds once.
  *   flush table  : n x 4  = {gacc, gmin, gmax, gslope} addresses (0 = absent)
- *   weight table : n x 16 = {w, wq, idx, idxT, dw, rw, qmin, qmax, gwq, gw, gmin, gmax, outer, C, inner,
- *                  first_block}; entries sorted by first_block, one workgroup per output channel;
- *                  idx/idxT/dw/rw only for pointwise-conv weights (0 otherwise);
+ *   weight table : n x FQSS_WQ_DESC_WORDS = {w, wq, idx, idxT, dw, rw, qmin, qmax, gwq, gw, gmin, gmax, outer, C,
+ *                  inner, first_block, ldT}; entries sorted by first_block, one workgroup per output channel;
+ *                  idx/idxT/dw/rw only for pointwise-conv weights (0 otherwise); ldT = row stride of idxT
+ *                  (C, or the summed C of layers whose codes are concatenated for the paired q-GEMMs);
  *                  bwd: gw += STE(gwq), gmin/gmax += range gradients  (gwq = accumulated dL/dW_q)
  * ------------------------------------------------------------------------------------------- */
+#define FQSS_WQ_DESC_WORDS 17
 int fqss_gacc_flush_multi(const int64_t* table, int n, fqss_stream_t stream);
 int fqss_wq_multi_fwd(const int64_t* table, int n, int total_channels, fqss_stream_t stream);
 int fqss_wq_multi_bwd(const int64_t* table, int n, int total_channels, fqss_stream_t stream);
@@ -155,6 +157,20 @@ int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* dw, float* g
 int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
                    float* gw, int B, int Ci, int Co, int M, int64_t ld_gz, int64_t ld_xc,
                    fqss_stream_t stream);
+/* Two pointwise convs on the SAME coded input (the res | skip convs of a TCN block, convtasnetq.py:41-42 /
+ * reference conv_tasnet ConvBlock) as ONE GEMM over the concatenated output channels: wi [Co1+Co2][Ci],
+ * wiT [Ci][Co1+Co2], dw/rw [Co1+Co2], gw [Co1+Co2][Ci]; the per-layer activations / gradients stay separate
+ * tensors.  bwd_x2 returns the SUM of both layers' input gradients (autograd's accumulation of the fork). */
+int fqss_qpw_fwd2(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                  const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int B,
+                  int Ci, int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2,
+                  fqss_stream_t stream);
+int fqss_qpw_bwd_x2(const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B,
+                    int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_gx,
+                    fqss_stream_t stream);
+int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t* xc, const float* qmin_x,
+                    const float* qmax_x, float* gw, int B, int Ci, int Co1, int Co2, int M, int64_t ld_gz1,
+                    int64_t ld_gz2, int64_t ld_xc, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  depthwise dilated Conv1d (groups = C): z[b][c][m] = bias[c] + sum_k w[c][k] x[b][c][m+k*dil-pad]

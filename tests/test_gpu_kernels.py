@@ -251,6 +251,35 @@ def test_qgemm_fwd_bwd(B, Ci, Co, M):
     close(gw.cpu().double(), gw_ref, rtol=1e-5, atol=3e-6 * float(gw_ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,Ci,Co1,Co2,M", [(2, 64, 32, 48, 77), (2, 512, 128, 128, 501), (1, 128, 512, 16, 260)])
+def test_qgemm_pair_matches_single_layers(B, Ci, Co1, Co2, M):
+    """the paired q-GEMMs (two layers on one input, concatenated codes) against the two single-layer launches"""
+    w1, wlo1, whi1, xlo, xhi, x, b1, _, _ = _q_setup(B, Ci, Co1, M, seed=1)
+    w2, wlo2, whi2, _, _, _, b2, _, _ = _q_setup(B, Ci, Co2, M, seed=2)
+    cu = lambda t: t.cuda().contiguous()
+    wc1, wc2 = K.wq_codes(cu(w1), cu(wlo1), cu(whi1)), K.wq_codes(cu(w2), cu(wlo2), cu(whi2))
+    pc = K.WCodes()
+    pc.Co, pc.Ci = Co1 + Co2, Ci
+    pc.idx = torch.cat([wc1.idx, wc2.idx], 0).contiguous()
+    pc.idxT = torch.cat([wc1.idxT, wc2.idxT], 1).contiguous()
+    pc.dw, pc.rw = torch.cat([wc1.dw, wc2.dw]), torch.cat([wc1.rw, wc2.rw])
+    _, xc = K.actq_fwd(padded(x), K.ACT_NONE, None, K.Q_QUANT, cu(xlo), cu(xhi), None, want_idx=True)
+    z1, z2 = K.qpw_fwd2(xc, pc, cu(b1), cu(b2), cu(xlo), cu(xhi), Co1)
+    assert torch.equal(z1.cpu(), K.qpw_fwd(xc, wc1, cu(b1), cu(xlo), cu(xhi)).cpu())      # exact integer sums: bit for bit
+    assert torch.equal(z2.cpu(), K.qpw_fwd(xc, wc2, cu(b2), cu(xlo), cu(xhi)).cpu())
+    g1, g2 = rnd(B, Co1, M, seed=5), rnd(B, Co2, M, seed=6)
+    gx = K.qpw_bwd_x2(padded(g1), padded(g2), pc)
+    ref = K.qpw_bwd_x(padded(g1), wc1).cpu().double() + K.qpw_bwd_x(padded(g2), wc2).cpu().double()
+    close(gx.cpu().double(), ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    gw = torch.zeros(Co1 + Co2, Ci, device="cuda")
+    K.qpw_bwd_w2(padded(g1), padded(g2), xc, cu(xlo), cu(xhi), gw)
+    gw1, gw2 = torch.zeros(Co1, Ci, device="cuda"), torch.zeros(Co2, Ci, device="cuda")
+    K.qpw_bwd_w(padded(g1), xc, cu(xlo), cu(xhi), gw1)
+    K.qpw_bwd_w(padded(g2), xc, cu(xlo), cu(xhi), gw2)
+    ref = torch.cat([gw1, gw2], 0).cpu().double()
+    close(gw.cpu().double(), ref, rtol=1e-5, atol=3e-6 * float(ref.abs().max()))
+
+
 def test_qgemm_exact_integer_maps():
     """A = I-like asymmetric integer codes: catches transposed fragments / wrong tr-read lane maps bit-exactly"""
     B, Ci, Co, M = 1, 64, 96, 160
