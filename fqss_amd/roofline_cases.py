@@ -51,34 +51,42 @@ def build(dev, calib=False):
                       flops=2.0 * 2 * NB * NH * n, rd=4.0 * (NH + 2 * NB) * n, wr=4.0 * 2 * NB * n, survey=4.0 * (NH + 2 * NB) * n,
                       fn=lambda: K.tgemm(w3, y, b3, pro=1, pro_stats=st[0], pro_gamma=ga, pro_beta=be, pro_eps=1e-8, M1=NB, r1=h, r2=acc)))
 
-    # ---- student q-GEMMs on 8-bit codes (csrc/qgemm.hip)
+    # ---- student q-GEMMs on 8-bit codes (csrc/qgemm.hip): conv1 of a block (128->512) and the paired res|skip
+    #      convs (512 -> 128+128, one GEMM over the concatenated channels)
     xc_b, xc_h = _codes(NB, dev), _codes(NH, dev)
-    gz_b, gz_h = _act(NB, dev), _act(NH, dev)
-    wc_up = K.wq_codes(torch.randn(NH, NB, 1, device=dev) * 0.05, -torch.ones(NH, 1, 1, device=dev) * 0.2, torch.ones(NH, 1, 1, device=dev) * 0.2)
-    wc_dn = K.wq_codes(torch.randn(NB, NH, 1, device=dev) * 0.05, -torch.ones(NB, 1, 1, device=dev) * 0.2, torch.ones(NB, 1, 1, device=dev) * 0.2)
-    bu, bd = torch.randn(NH, device=dev), torch.randn(NB, device=dev)
-    gw_up, gw_dn = torch.zeros(NH, NB, device=dev), torch.zeros(NB, NH, device=dev)
+    gz_b, gz_b2, gz_h = _act(NB, dev), _act(NB, dev), _act(NH, dev)
+    ones = lambda c: torch.ones(c, 1, 1, device=dev) * 0.2
+    wc_up = K.wq_codes(torch.randn(NH, NB, 1, device=dev) * 0.05, -ones(NH), ones(NH))
+    wr_, ws_ = (K.wq_codes(torch.randn(NB, NH, 1, device=dev) * 0.05, -ones(NB), ones(NB)) for _ in range(2))
+    pc = K.WCodes()
+    pc.Co, pc.Ci = 2 * NB, NH
+    pc.idx, pc.idxT = torch.cat([wr_.idx, ws_.idx], 0).contiguous(), torch.cat([wr_.idxT, ws_.idxT], 1).contiguous()
+    pc.dw, pc.rw = torch.cat([wr_.dw, ws_.dw]), torch.cat([wr_.rw, ws_.rw])
+    bu, bd, bd2 = torch.randn(NH, device=dev), torch.randn(NB, device=dev), torch.randn(NB, device=dev)
+    gw_up, gw_pair = torch.zeros(NH, NB, device=dev), torch.zeros(2 * NB, NH, device=dev)
     fl = 2.0 * NH * NB * n
     cases.append(dict(kernel="k_qwgrad", label="student wgrad 128->512 (fp32 gz x u8 codes)", bound="hbm", launches=24,
                       flops=fl, rd=(4.0 * NH + NB) * n, wr=4.0 * NH * NB, survey=4.0 * (NH + NB) * n, fn=lambda: K.qpw_bwd_w(gz_h, xc_b, lo, hi, gw_up)))
-    cases.append(dict(kernel="k_qwgrad", label="student wgrad 512->128 (fp32 gz x u8 codes)", bound="hbm", launches=48,
-                      flops=fl, rd=(4.0 * NB + NH) * n, wr=4.0 * NH * NB, survey=4.0 * (NH + NB) * n, fn=lambda: K.qpw_bwd_w(gz_b, xc_h, lo, hi, gw_dn)))
+    cases.append(dict(kernel="k_qwgrad", label="student wgrad res|skip pair 512->128+128 (fp32 gz x u8 codes)", bound="hbm", launches=24,
+                      flops=2 * fl, rd=(8.0 * NB + NH) * n, wr=8.0 * NH * NB, survey=4.0 * (NH + 2 * NB) * n,
+                      fn=lambda: K.qpw_bwd_w2(gz_b, gz_b2, xc_h, lo, hi, gw_pair)))
     cases.append(dict(kernel="k_qgemm<1>", label="student dgrad of 128->512 (int8 W^T x fp32 gz)", bound="hbm", launches=24,
                       flops=fl, rd=4.0 * NH * n, wr=4.0 * NB * n, survey=4.0 * (NH + NB) * n, fn=lambda: K.qpw_bwd_x(gz_h, wc_up)))
-    cases.append(dict(kernel="k_qgemm<1>", label="student dgrad of 512->128 (int8 W^T x fp32 gz)", bound="hbm", launches=48,
-                      flops=fl, rd=4.0 * NB * n, wr=4.0 * NH * n, survey=4.0 * (NH + NB) * n, fn=lambda: K.qpw_bwd_x(gz_b, wc_dn)))
+    cases.append(dict(kernel="k_qgemm<1>", label="student dgrad of the res|skip pair (K = 128+128 -> 512)", bound="hbm", launches=24,
+                      flops=2 * fl, rd=8.0 * NB * n, wr=4.0 * NH * n, survey=4.0 * (NH + 2 * NB) * n, fn=lambda: K.qpw_bwd_x2(gz_b, gz_b2, pc)))
     cases.append(dict(kernel="k_qgemm<0>", label="student fwd 128->512 (int8 W x u8 codes -> fp32)", bound="hbm", launches=24,
                       flops=fl, rd=1.0 * NB * n, wr=4.0 * NH * n, survey=4.0 * (NH + NB) * n, fn=lambda: K.qpw_fwd(xc_b, wc_up, bu, lo, hi)))
-    cases.append(dict(kernel="k_qgemm<0>", label="student fwd 512->128 (int8 W x u8 codes -> fp32)", bound="hbm", launches=48,
-                      flops=fl, rd=1.0 * NH * n, wr=4.0 * NB * n, survey=4.0 * (NH + NB) * n, fn=lambda: K.qpw_fwd(xc_h, wc_dn, bd, lo, hi)))
+    cases.append(dict(kernel="k_qgemm<0>", label="student fwd res|skip pair 512->128+128 (int8 W x u8 codes -> fp32)", bound="hbm", launches=24,
+                      flops=2 * fl, rd=1.0 * NH * n, wr=8.0 * NB * n, survey=4.0 * (NH + 2 * NB) * n,
+                      fn=lambda: K.qpw_fwd2(xc_h, pc, bd, bd2, lo, hi, NB)))
 
-    # ---- depthwise backward on codes and the activation-quantizer backward
+    # ---- depthwise layer backward (one launch, gz in LDS) and the activation-quantizer backward
     w_dw, gm = torch.randn(NH, 1, 3, device=dev), torch.ones(NH, device=dev)
     gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev)
-    gbb = torch.zeros(NH, device=dev)
-    cases.append(dict(kernel="k_dwq_bwd_z", label="student depthwise+PReLU+fq backward, C=512 (codes in, fp32 g in/out)", bound="hbm", launches=24,
+    gbb, gw_dw = torch.zeros(NH, device=dev), torch.zeros(NH, 1, 3, device=dev)
+    cases.append(dict(kernel="k_dwq_bwd", label="student depthwise+PReLU+fq backward, C=512 (codes + fp32 g in, fp32 gx out)", bound="hbm", launches=24,
                       flops=0.0, rd=5.0 * NH * n, wr=4.0 * NH * n, survey=12.0 * NH * n,
-                      fn=lambda: K.dwq_bwd_z(xc_h, lo, hi, w_dw, gm, gz_h, 4, 4, 1, slope, lo, hi, gacc, gbb)))
+                      fn=lambda: K.dwq_bwd(xc_h, lo, hi, w_dw, gm, gz_h, 4, 4, 1, slope, lo, hi, gacc, gbb, gw_dw)))
     z_h, z_b = _act(NH, dev), _act(NB, dev)
     gb_h, gb_b = torch.zeros(NH, device=dev), torch.zeros(NB, device=dev)
     cases.append(dict(kernel="k_actq_bwd", label="activation fake-quant backward (STE + range grads + bias grad), C=512", bound="hbm", launches=24,

@@ -20,7 +20,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ITERS = 10
 UNCALIBRATED_SCALE = {"k_qgemm<0>": 1.0}
-KERNELS = ("k_tgemm", "k_qwgrad", "k_qgemm<1>", "k_qgemm<0>", "k_dwq_bwd_z", "k_actq_bwd", "__amd_rocclr_copyBuffer")
+KERNELS = ("k_tgemm", "k_qwgrad", "k_qgemm<1>", "k_qgemm<0>", "k_dwq_bwd", "k_actq_bwd", "__amd_rocclr_copyBuffer")
 
 
 def run():
