@@ -32,6 +32,7 @@ _PROTOS = {
     "fqss_qpw_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_x": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_qpw_fwdq": [P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P],
     "fqss_qpw_fwd2": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_x2": [P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_w2": [P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],

@@ -80,6 +80,11 @@ struct QGemmArgs {
     const void* A2; int64_t lda2, sA2b;
     int K1;                          // dgrad: reduction rows >= K1 (the second layer's gz) come from B2
     const void* B2; int64_t ldb2, sB2b;
+    // fwd, optional: the layer's own activation + fake-quant fused into the epilogue -> u8 codes of the OUTPUT
+    // (z is still written: the backward needs the pre-quant value); rows >= M1 use the second range
+    unsigned char* Q1; unsigned char* Q2; int64_t ldq1, ldq2, sQ1b, sQ2b;
+    const float *qy_min1, *qy_max1, *qy_min2, *qy_max2;
+    int qact; const float* qslope;
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
@@ -292,6 +297,15 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     }
     float* Cb = g.C + (int64_t)b * g.sCb;
     float* C2b = (g.C2 != nullptr) ? g.C2 + (int64_t)b * g.sC2b : nullptr;
+    __shared__ uint32_t Qt[(MODE == 0) ? 4 : 1][32][8];   // per-wave 32 x 32 tile of output codes
+    const bool quant = (MODE == 0) && g.Q1 != nullptr;
+    QRange ry1{}, ry2{};
+    float qslope = 0.0f;
+    if (quant) {
+        ry1 = load_qrange(g.qy_min1, g.qy_max1);
+        ry2 = (g.Q2 != nullptr) ? load_qrange(g.qy_min2, g.qy_max2) : ry1;
+        qslope = (g.qact == FQSS_ACT_PRELU) ? *g.qslope : 0.0f;
+    }
     {
         // stage each 32x32 accumulator tile through LDS and store whole 128-B rows with 16 B per lane
         // (the lane-per-column layout of the MFMA result would need 16 strided 4-B stores per tile: that
@@ -332,6 +346,36 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                         dst[0] = t.x;
                         if (col + 1 < g.N) dst[1] = t.y;
                         if (col + 2 < g.N) dst[2] = t.z;
+                    }
+                }
+                if constexpr (MODE == 0) {
+                    if (quant) {   // this lane's 4 outputs -> 4 codes (the tile lies on one side of M1: M1 % 32 == 0)
+                        const QRange& ry = (i0 + wm * 64 + mi * 32 < g.M1) ? ry1 : ry2;
+                        const float tv[4] = {t.x, t.y, t.z, t.w};
+                        uint32_t pk = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float cq, u;
+                            bool inr;
+                            (void)fq_asym(act_apply(tv[e], g.qact, qslope), ry, cq, u, inr);
+                            pk |= ((uint32_t)cq & 255u) << (8 * e);
+                        }
+                        Qt[wave][rl][lane & 7] = pk;
+                    }
+                }
+            }
+            if constexpr (MODE == 0) {
+                if (quant) {   // 16 codes (16 B) per lane: lane -> (row = lane / 2, half row)
+                    const int rl = lane >> 1, hf = lane & 1;
+                    const int row = i0 + wm * 64 + mi * 32 + rl;
+                    const int col = j0 + wn * 32 + 16 * hf;
+                    const uint4 c16 = *reinterpret_cast<const uint4*>(&Qt[wave][rl][4 * hf]);
+                    const bool first = row < g.M1;
+                    const int64_t ldq = first ? g.ldq1 : g.ldq2;
+                    if (row < g.M && col < ldq) {
+                        unsigned char* qb = first ? g.Q1 + (int64_t)b * g.sQ1b + (int64_t)row * ldq
+                                                  : g.Q2 + (int64_t)b * g.sQ2b + (int64_t)(row - g.M1) * ldq;
+                        *reinterpret_cast<uint4*>(qb + col) = c16;
                     }
                 }
             }
@@ -521,9 +565,14 @@ extern "C" int fqss_wq_codes(const float* w, int8_t* idx, int8_t* idxT, float* d
     return launch_status("fqss_wq_codes");
 }
 
+struct QpwQuant {   // optional fused output quantizer of fqss_qpw_fwdq
+    int act; const float* slope; const float *min1, *max1, *min2, *max2; uint8_t *yc1, *yc2; int64_t ld1, ld2;
+};
+
 static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
                         const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int B, int Ci, int Co1,
-                        int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, fqss_stream_t stream) {
+                        int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, fqss_stream_t stream,
+                        const QpwQuant* qq = nullptr) {
     const int Co = Co1 + Co2;
     FQSS_REQUIRE(xc && wi && dw && rw && qmin_x && qmax_x && z1 && (Co2 == 0 || z2), "null tensor");
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_xc >= M && ld_z1 >= M && (Co2 == 0 || ld_z2 >= M), "bad shape");
@@ -538,6 +587,17 @@ static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, co
     g.sAb = 0; g.sBb = (int64_t)Ci * ld_xc; g.sCb = (int64_t)Co1 * ld_z1;
     g.M1 = Co1; g.C2 = z2; g.ldc2 = ld_z2; g.sC2b = (int64_t)Co2 * ld_z2; g.bias2 = bias2; g.K1 = Ci;
     g.dw = dw; g.rw = rw; g.bias = bias1; g.qmin_x = qmin_x; g.qmax_x = qmax_x; g.ksplit = 1; g.kchunk = Ci;
+    if (qq != nullptr) {
+        FQSS_REQUIRE(qq->min1 && qq->max1 && qq->yc1 && (Co2 == 0 || (qq->min2 && qq->max2 && qq->yc2)), "fused quantizer: null pointer");
+        FQSS_REQUIRE(Co2 == 0 || Co1 % 32 == 0, "fused quantizer of a pair needs Co1 % 32 == 0");
+        FQSS_REQUIRE(qq->ld1 % 16 == 0 && qq->ld1 >= M && aligned16(qq->yc1) && (Co2 == 0 || (qq->ld2 % 16 == 0 && qq->ld2 >= M && aligned16(qq->yc2))),
+                     "output code rows must be 16-B aligned");
+        FQSS_REQUIRE(qq->act != FQSS_ACT_PRELU || qq->slope, "PReLU needs a slope");
+        g.Q1 = qq->yc1; g.Q2 = qq->yc2; g.ldq1 = qq->ld1; g.ldq2 = qq->ld2;
+        g.sQ1b = (int64_t)Co1 * qq->ld1; g.sQ2b = (int64_t)Co2 * qq->ld2;
+        g.qy_min1 = qq->min1; g.qy_max1 = qq->max1; g.qy_min2 = qq->min2; g.qy_max2 = qq->max2;
+        g.qact = qq->act; g.qslope = qq->slope;
+    }
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
     hipLaunchKernelGGL((k_qgemm<0>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status(who);
@@ -554,6 +614,16 @@ extern "C" int fqss_qpw_fwd2(const uint8_t* xc, const int8_t* wi, const float* d
                              int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, fqss_stream_t stream) {
     FQSS_REQUIRE(Co2 > 0, "second layer missing");
     return qpw_fwd_impl("fqss_qpw_fwd2", xc, wi, dw, rw, bias1, bias2, qmin_x, qmax_x, z1, z2, B, Ci, Co1, Co2, M, ld_xc, ld_z1, ld_z2, stream);
+}
+
+extern "C" int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                             const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int act,
+                             const float* slope, const float* qmin1, const float* qmax1, const float* qmin2, const float* qmax2,
+                             uint8_t* yc1, uint8_t* yc2, int B, int Ci, int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1,
+                             int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2, fqss_stream_t stream) {
+    QpwQuant qq{act, slope, qmin1, qmax1, qmin2, qmax2, yc1, yc2, ld_yc1, ld_yc2};
+    return qpw_fwd_impl("fqss_qpw_fwdq", xc, wi, dw, rw, bias1, bias2, qmin_x, qmax_x, z1, z2, B, Ci, Co1, Co2, M, ld_xc, ld_z1, ld_z2,
+                        stream, &qq);
 }
 
 static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B,

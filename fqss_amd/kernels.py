@@ -285,6 +285,23 @@ def qpw_fwd2(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1):
     return z1, z2
 
 
+def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None):
+    """q-GEMM forward with the output quantizer(s) fused: -> (z1, yc1) or (z1, z2, yc1, yc2) for a pair (r = (qmin, qmax))"""
+    B, Ci, M = xc.shape
+    rm = rowmat(xc)
+    Co2 = wc.Co - Co1
+    assert rm is not None and Ci == wc.Ci and Co2 >= 0 and (Co2 == 0) == (r2 is None)
+    z1, yc1 = empty_act((B, Co1, M), xc.device), empty_codes((B, Co1, M), xc.device)
+    z2 = yc2 = None
+    if Co2:
+        z2, yc2 = empty_act((B, Co2, M), xc.device), empty_codes((B, Co2, M), xc.device)
+    _lib.call("fqss_qpw_fwdq", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias1), _p(bias2), _p(qmin_x), _p(qmax_x), _p(z1), _p(z2),
+              act, _p(slope), _p(r1[0]), _p(r1[1]), _p(r2[0]) if r2 else None, _p(r2[1]) if r2 else None, _p(yc1), _p(yc2),
+              B, Ci, Co1, Co2, M, rm[2], rowmat(z1)[2], rowmat(z2)[2] if Co2 else 0, rowmat(yc1)[2], rowmat(yc2)[2] if Co2 else 0,
+              _stream())
+    return (z1, z2, yc1, yc2) if Co2 else (z1, yc1)
+
+
 def qpw_bwd_x2(gz1, gz2, wc):
     """gx = W1q^T gz1 + W2q^T gz2 in one GEMM (K = Co1 + Co2)"""
     gz1, ld1 = _aligned_grad(gz1)

@@ -153,6 +153,11 @@ def _epilogue_fwd(z, act, slope, q):
     return K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws)
 
 
+def _fuse_out_quant(q):
+    """codes-only mode with a learned-range quantizer: the q-GEMM epilogue can emit the output codes itself"""
+    return q.qmode == Q_QUANT and FAST and not q.keep_out
+
+
 def _touch(*params):
     for p in params:
         if p is not None:
@@ -272,12 +277,19 @@ class LinearActQ(Function):
         # grid-valued operands (student, quantizing phase): exact bf16-MFMA GEMM on the codes
         ctx.xq = xq if (L.kind == "pw" and xq is not None and K.q_eligible(w.shape[1], w.shape[0])) else None
         ctx.wc = wc if (L.kind == "pw" and wc is not None and K.q_eligible(w.shape[1], w.shape[0])) else None
-        if ctx.xq is not None and ctx.wc is not None:
-            z = K.qpw_fwd(ctx.xq.idx, ctx.wc, bias, ctx.xq.qmin, ctx.xq.qmax)
-        else:
-            z = _lin_fwd(L, x, w, bias)
         ctx.plain = (q.qmode == Q_BYPASS and act == ACT_NONE)   # float linear op: no epilogue pass at all
-        out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
+        if ctx.xq is not None and ctx.wc is not None and _fuse_out_quant(q):
+            # the layer's own non-linearity + fake-quant ride in the GEMM epilogue: z (for the backward) and the
+            # output codes come out of one launch
+            z, q.idx = K.qpw_fwdq(ctx.xq.idx, ctx.wc, bias, None, ctx.xq.qmin, ctx.xq.qmax, ctx.wc.Co, act, slope, (q.qmin, q.qmax))
+            q.carrier = True
+            out = _carrier(K.empty_act(tuple(z.shape), z.device))
+        else:
+            if ctx.xq is not None and ctx.wc is not None:
+                z = K.qpw_fwd(ctx.xq.idx, ctx.wc, bias, ctx.xq.qmin, ctx.xq.qmax)
+            else:
+                z = _lin_fwd(L, x, w, bias)
+            out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
         ctx.x_shape = x.shape
         ctx.save_for_backward(None if (ctx.xq is not None and ctx.wc is not None) else x, w, None if ctx.plain else z, slope)
         ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
@@ -324,9 +336,16 @@ class LinearActQPair(Function):
     @staticmethod
     def forward(ctx, x, b1, b2, qmin1, qmax1, qmin2, qmax2, L1, L2, q1, q2, xq, pair):
         Co1 = pair.Co1
-        z1, z2 = K.qpw_fwd2(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1)
-        out1 = _epilogue_fwd(z1, ACT_NONE, None, q1)
-        out2 = _epilogue_fwd(z2, ACT_NONE, None, q2)
+        if _fuse_out_quant(q1) and _fuse_out_quant(q2) and Co1 % 32 == 0:
+            z1, z2, q1.idx, q2.idx = K.qpw_fwdq(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1, ACT_NONE, None,
+                                                (q1.qmin, q1.qmax), (q2.qmin, q2.qmax))
+            q1.carrier = q2.carrier = True
+            out1 = _carrier(K.empty_act(tuple(z1.shape), z1.device))
+            out2 = _carrier(K.empty_act(tuple(z2.shape), z2.device))
+        else:
+            z1, z2 = K.qpw_fwd2(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1)
+            out1 = _epilogue_fwd(z1, ACT_NONE, None, q1)
+            out2 = _epilogue_fwd(z2, ACT_NONE, None, q2)
         ctx.save_for_backward(z1, z2)
         ctx.L, ctx.q, ctx.b, ctx.xq, ctx.pair = (L1, L2), (q1, q2), (b1, b2), xq, pair
         return out1, out2

@@ -171,6 +171,15 @@ int fqss_qpw_bwd_x2(const float* gz1, const float* gz2, const int8_t* wiT, const
 int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t* xc, const float* qmin_x,
                     const float* qmax_x, float* gw, int B, int Ci, int Co1, int Co2, int M, int64_t ld_gz1,
                     int64_t ld_gz2, int64_t ld_xc, fqss_stream_t stream);
+/* fqss_qpw_fwd / fqss_qpw_fwd2 with the layer's own activation + output fake-quant fused into the epilogue
+ * (Conv1dQ / Conv1dNlQ: conv -> nl -> activation_fake_quantize, qat_layers.py:137-146, 202-212): writes the
+ * pre-quant z (kept for the backward) AND the u8 codes yc of fq(act(z)); Co2 = 0 for a single layer */
+int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                  const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int act,
+                  const float* slope, const float* qmin1, const float* qmax1, const float* qmin2,
+                  const float* qmax2, uint8_t* yc1, uint8_t* yc2, int B, int Ci, int Co1, int Co2, int M,
+                  int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2,
+                  fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  depthwise dilated Conv1d (groups = C): z[b][c][m] = bias[c] + sum_k w[c][k] x[b][c][m+k*dil-pad]

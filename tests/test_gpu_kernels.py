@@ -280,6 +280,34 @@ def test_qgemm_pair_matches_single_layers(B, Ci, Co1, Co2, M):
     close(gw.cpu().double(), ref, rtol=1e-5, atol=3e-6 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,Ci,Co1,Co2,M,act", [(2, 64, 32, 0, 77, 1), (2, 512, 128, 128, 501, 0), (1, 128, 512, 0, 260, 1), (2, 32, 64, 32, 100, 0)])
+def test_qgemm_fused_output_quantizer(B, Ci, Co1, Co2, M, act):
+    """fqss_qpw_fwdq: same z as the plain forward, and output codes bit-equal to the stand-alone quantizer on that z"""
+    cu = lambda t: t.cuda().contiguous()
+    w1, wlo1, whi1, xlo, xhi, x, b1, _, _ = _q_setup(B, Ci, Co1, M, seed=1)
+    wc = K.wq_codes(cu(w1), cu(wlo1), cu(whi1))
+    b2 = None
+    if Co2:
+        w2, wlo2, whi2, _, _, _, b2, _, _ = _q_setup(B, Ci, Co2, M, seed=2)
+        wc2 = K.wq_codes(cu(w2), cu(wlo2), cu(whi2))
+        pc = K.WCodes()
+        pc.Co, pc.Ci = Co1 + Co2, Ci
+        pc.idx, pc.idxT = torch.cat([wc.idx, wc2.idx], 0).contiguous(), torch.cat([wc.idxT, wc2.idxT], 1).contiguous()
+        pc.dw, pc.rw = torch.cat([wc.dw, wc2.dw]), torch.cat([wc.rw, wc2.rw])
+        wc = pc
+    _, xc = K.actq_fwd(padded(x), K.ACT_NONE, None, K.Q_QUANT, cu(xlo), cu(xhi), None, want_idx=True)
+    slope = torch.tensor([0.2], device="cuda") if act == 1 else None
+    r1 = (torch.tensor([-1.1], device="cuda"), torch.tensor([1.7], device="cuda"))
+    r2 = (torch.tensor([-0.4], device="cuda"), torch.tensor([2.9], device="cuda")) if Co2 else None
+    res = K.qpw_fwdq(xc, wc, cu(b1), cu(b2) if Co2 else None, cu(xlo), cu(xhi), Co1, act, slope, r1, r2)
+    zs, ycs = (res[:2], res[2:]) if Co2 else (res[:1], res[1:])
+    refz = K.qpw_fwd2(xc, wc, cu(b1), cu(b2), cu(xlo), cu(xhi), Co1) if Co2 else (K.qpw_fwd(xc, wc, cu(b1), cu(xlo), cu(xhi)),)
+    for z, yc, zr, r in zip(zs, ycs, refz, (r1, r2)):
+        assert torch.equal(z.cpu(), zr.cpu())
+        _, ref_idx = K.actq_fwd(zr, act, slope, K.Q_QUANT, r[0], r[1], None, want_idx=True)
+        assert torch.equal(yc.cpu()[..., :M], ref_idx.cpu()[..., :M])
+
+
 def test_qgemm_exact_integer_maps():
     """A = I-like asymmetric integer codes: catches transposed fragments / wrong tr-read lane maps bit-exactly"""
     B, Ci, Co, M = 1, 64, 96, 160
