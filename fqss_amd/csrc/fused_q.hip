@@ -237,20 +237,47 @@ __device__ __forceinline__ unsigned int load_codes4(const uint8_t* __restrict__ 
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
+// Interior groups (every tap of all 4 positions inside the row -- all but <= 2*pad positions per row): the 4 codes of
+// a tap are one unaligned dword load (gfx950 handles the misalignment in hardware) and need no zero-padding masks;
+// this path has ~1/3 of the instructions of the general one, and these kernels are VALU-issue bound.
+__device__ __forceinline__ unsigned int load_codes4_unaligned(const uint8_t* __restrict__ p) {
+    unsigned int w;
+    __builtin_memcpy(&w, p, 4);
+    return w;
+}
+__device__ __forceinline__ void dec4(unsigned int w, const QRange& r, float (&v)[4]) {
+    v[0] = dec(w & 255u, r);          // v_cvt_f32_ubyte0..3 + mul + add (two roundings, like the reference)
+    v[1] = dec((w >> 8) & 255u, r);
+    v[2] = dec((w >> 16) & 255u, r);
+    v[3] = dec(w >> 24, r);
+}
+
 // z[m..m+3] from the coded row (zero padding)
 __device__ __forceinline__ void dwq_z4(const uint8_t* __restrict__ xr, int m, int M, int ld_c, const float* wk, int K,
                                         int dil, int pad, float bv, const QRange& rx, float (&z)[4]) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m - pad >= 0 && m + 3 + pad < M) {
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-        if (k < K) {
-            const int s0 = m + k * dil - pad;
-            float v[4];
-            const unsigned int w = load_codes4(xr, s0, ld_c);
+        for (int k = 0; k < kTaps; ++k) {
+            if (k < K) {
+                float v[4];
+                dec4(load_codes4_unaligned(xr + (m + k * dil - pad)), rx, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? dec((w >> (8 * j)) & 255u, rx) : 0.0f;
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+            }
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+        for (int k = 0; k < kTaps; ++k) {
+            if (k < K) {
+                const int s0 = m + k * dil - pad;
+                float v[4];
+                const unsigned int w = load_codes4(xr, s0, ld_c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? dec((w >> (8 * j)) & 255u, rx) : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+            }
         }
     }
 #pragma unroll
@@ -385,20 +412,23 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
 //   phase 2: gx[m] = sum_k w[k] * gz[m + pad - k*dil] from LDS
 constexpr int kDwRowMax = 12 * 1024;   // 48 KiB of LDS
 
+template <int KT>   // taps known at compile time (3 on the training path) or 0: runtime K <= kTaps
 __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ g,
                                                   float* __restrict__ gx, float* gw, int C, int M, int K, int dil, int pad,
                                                   int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope_p,
                                                   const float* qmin_x, const float* qmax_x, const float* qmin,
                                                   const float* qmax, double* gacc, float* gbias, int want_gx) {
+    constexpr int NT = KT ? KT : kTaps;
+    if (KT) K = KT;
     extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
     __shared__ double red[(4 + kTaps) * 4];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     const int row = blockIdx.x, c = row % C;
-    float wk[kTaps], pw[kTaps];
+    float wk[NT], pw[NT];
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
+    for (int k = 0; k < NT; ++k) {
         wk[k] = (k < K) ? w[c * K + k] : 0.0f;
         pw[k] = 0.0f;
     }
@@ -407,53 +437,84 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
     const float* gr = g + (int64_t)row * ld_g;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
 
-    for (int m = 4 * threadIdx.x; m < M; m += 1024) {
-        float v[kTaps][4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // a pass covers 4096 positions: 4 float4 groups per thread, ALL their loads issued before the first is consumed
+    // (the straight loop exposed one HBM round trip per group: PMC showed the waves parked 46 % of the time)
+    for (int m0 = 4 * threadIdx.x; m0 < M; m0 += 4096) {
+        float4 gq[4];
+        unsigned int cw[4][NT];
+        bool inner[4];
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) {
-            if (k < K) {
-                const int s0 = m + k * dil - pad;
-                const unsigned int cw = load_codes4(xr, s0, (int)ld_xc);
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            inner[i] = (m - pad >= 0) && (m + 3 + pad < M);
+            if (m < M) gq[i] = *reinterpret_cast<const float4*>(gr + m);
+            if (inner[i]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[k][j] = (s0 + j >= 0 && s0 + j < M) ? dec((cw >> (8 * j)) & 255u, rx) : 0.0f;
-                    acc[j] = fmaf(wk[k], v[k][j], acc[j]);
+                for (int k = 0; k < NT; ++k)
+                    if (k < K) cw[i][k] = load_codes4_unaligned(xr + (m + k * dil - pad));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            if (m >= M) break;
+            float v[NT][4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (inner[i]) {   // no padding masks, one unaligned dword per tap
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    if (k < K) {
+                        dec4(cw[i][k], rx, v[k]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[k][j], acc[j]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    if (k < K) {
+                        const int s0 = m + k * dil - pad;
+                        const unsigned int cwk = load_codes4(xr, s0, (int)ld_xc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[k][j] = (s0 + j >= 0 && s0 + j < M) ? dec((cwk >> (8 * j)) & 255u, rx) : 0.0f;
+                            acc[j] = fmaf(wk[k], v[k][j], acc[j]);
+                        }
+                    }
                 }
             }
-        }
-        const float4 gv4 = *reinterpret_cast<const float4*>(gr + m);
-        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
-        float o[4];
+            const float gv[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+            float o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool valid = (m + j < M);
-            const float gj = valid ? gv[j] : 0.0f;
-            const float z = acc[j] + bv;
-            const float t = act_apply(z, act, slope);
-            float cq, u;
-            bool inr;
-            (void)fq_asym(t, ry, cq, u, inr);
-            const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
-            if (valid) {
-                p_du += gj * (inr ? (cq - u) : cq);
-                p_out += inr ? 0.0f : gj;
-            }
-            float gzj = gt;
-            if (act == FQSS_ACT_PRELU) {
-                const bool pos = z > 0.0f;
-                gzj = pos ? gt : slope * gt;
-                if (valid && !pos) p_slope += z * gt;
-            } else if (act == FQSS_ACT_RELU) {
-                gzj = (t > 0.0f) ? gt : 0.0f;
-            }
-            gzj = valid ? gzj : 0.0f;
-            o[j] = gzj;
-            p_bias += gzj;
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = (m + j < M);
+                const float gj = valid ? gv[j] : 0.0f;
+                const float z = acc[j] + bv;
+                const float t = act_apply(z, act, slope);
+                float cq, u;
+                bool inr;
+                (void)fq_asym(t, ry, cq, u, inr);
+                const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+                if (valid) {
+                    p_du += gj * (inr ? (cq - u) : cq);
+                    p_out += inr ? 0.0f : gj;
+                }
+                float gzj = gt;
+                if (act == FQSS_ACT_PRELU) {
+                    const bool pos = z > 0.0f;
+                    gzj = pos ? gt : slope * gt;
+                    if (valid && !pos) p_slope += z * gt;
+                } else if (act == FQSS_ACT_RELU) {
+                    gzj = (t > 0.0f) ? gt : 0.0f;
+                }
+                gzj = valid ? gzj : 0.0f;
+                o[j] = gzj;
+                p_bias += gzj;
 #pragma unroll
-            for (int k = 0; k < kTaps; ++k)
-                if (k < K) pw[k] = fmaf(gzj, v[k][j], pw[k]);   // v is 0 outside the row (zero padding)
+                for (int k = 0; k < NT; ++k)
+                    if (k < K) pw[k] = fmaf(gzj, v[k][j], pw[k]);   // v is 0 outside the row (zero padding)
+            }
+            *reinterpret_cast<float4*>(&sgz[m]) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<float4*>(&sgz[m]) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
 
@@ -463,7 +524,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
         for (int m = 4 * threadIdx.x; m < M; m += 1024) {
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < kTaps; ++k) {
+            for (int k = 0; k < NT; ++k) {
                 if (k < K) {
                     const int s0 = m + pad - k * dil;
                     if (aligned) {
@@ -488,11 +549,11 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
         }
     }
 
-    double v[4 + kTaps];
+    double v[4 + NT];
     v[0] = (double)p_du; v[1] = (double)p_out; v[2] = (double)p_slope; v[3] = (double)p_bias;
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) v[4 + k] = (double)pw[k];
-    block_sum<double, 4 + kTaps>(v, red);
+    for (int k = 0; k < NT; ++k) v[4 + k] = (double)pw[k];
+    block_sum<double, 4 + NT>(v, red);
     if (threadIdx.x == 0) {
         double* slot = gacc + 3 * (row % kSlots);
         const double dmax = v[0] / 255.0;
@@ -820,8 +881,12 @@ extern "C" int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float*
     FQSS_REQUIRE((int64_t)B * C < (1ll << 31), "too many rows");
     if (B == 0 || M == 0) return FQSS_OK;
     const size_t lds = (size_t)((M + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL(k_dwq_bwd, dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, K, dil,
-                       pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0);
+    if (K == 3)
+        hipLaunchKernelGGL(k_dwq_bwd<3>, dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, K,
+                           dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_dwq_bwd<0>, dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, K,
+                           dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0);
     return launch_status("fqss_dwq_bwd");
 }
 
