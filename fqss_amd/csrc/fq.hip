@@ -184,53 +184,86 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
     const int64_t nb = rows / C;  // batch entries per channel
     for (int64_t ch = blockIdx.y; ch < C; ch += gridDim.y) {
         float p_bias = 0.0f;
-        for (int64_t bi = 0; bi < nb; ++bi) {
-            const int64_t row = bi * C + ch;
-            const float* zr = z + row * ld_z;
-            const float* gr = g + row * ld_g;
-            float* or_ = gz + row * ld_gz;
-            for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cols; c0 += cstep) {
-                float zv[VEC], gv[VEC], o[VEC];
-                if constexpr (VEC == 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(zr + c0);
-                    const float4 b = *reinterpret_cast<const float4*>(gr + c0);
-                    zv[0] = a.x; zv[1] = a.y; zv[2] = a.z; zv[3] = a.w;
-                    gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
-                } else {
-                    zv[0] = zr[c0];
-                    gv[0] = gr[c0];
-                }
+        // one VEC-wide group: STE, activation backward, partial sums; returns the output group
+        auto group = [&](const float (&zv)[VEC], const float (&gv)[VEC], int64_t c0, float (&o)[VEC]) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const bool valid = (c0 + j < cols);
-                    const float gj = valid ? gv[j] : 0.0f;
-                    const float t = act_apply(zv[j], act, slope);
-                    float gt = gj;
-                    if (qmode == FQSS_Q_QUANT) {
-                        float c, u;
-                        bool inr;
-                        (void)fq_asym(t, r, c, u, inr);
-                        gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
-                        if (valid) {
-                            p_du += gj * (inr ? (c - u) : c);
-                            p_out += inr ? 0.0f : gj;
-                        }
+            for (int j = 0; j < VEC; ++j) {
+                const bool valid = (c0 + j < cols);
+                const float gj = valid ? gv[j] : 0.0f;
+                const float t = act_apply(zv[j], act, slope);
+                float gt = gj;
+                if (qmode == FQSS_Q_QUANT) {
+                    float c, u;
+                    bool inr;
+                    (void)fq_asym(t, r, c, u, inr);
+                    gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
+                    if (valid) {
+                        p_du += gj * (inr ? (c - u) : c);
+                        p_out += inr ? 0.0f : gj;
                     }
-                    float gzj = gt;
-                    if (act == FQSS_ACT_PRELU) {
-                        const bool pos = zv[j] > 0.0f;
-                        gzj = pos ? gt : slope * gt;
-                        if (valid && !pos) p_slope += zv[j] * gt;
-                    } else if (act == FQSS_ACT_RELU) {
-                        gzj = (t > 0.0f) ? gt : 0.0f;
-                    }
-                    o[j] = gzj;
-                    if (BIAS && valid) p_bias += gzj;
                 }
-                if constexpr (VEC == 4) {
-                    *reinterpret_cast<float4*>(or_ + c0) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    or_[c0] = o[0];
+                float gzj = gt;
+                if (act == FQSS_ACT_PRELU) {
+                    const bool pos = zv[j] > 0.0f;
+                    gzj = pos ? gt : slope * gt;
+                    if (valid && !pos) p_slope += zv[j] * gt;
+                } else if (act == FQSS_ACT_RELU) {
+                    gzj = (t > 0.0f) ? gt : 0.0f;
+                }
+                o[j] = gzj;
+                if (BIAS && valid) p_bias += gzj;
+            }
+        };
+        const int64_t c_first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+        if constexpr (VEC == 4) if (cstep >= cols) {
+            // every thread owns ONE column group of each of the channel's nb rows: the loads of 4 rows are issued
+            // before the first is consumed (the serial loop exposed one HBM round trip per batch entry)
+            if (c_first < cols) {
+                for (int64_t bi0 = 0; bi0 < nb; bi0 += 4) {
+                    float4 za[4], ga[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (bi0 + i < nb) {
+                            const int64_t row = (bi0 + i) * C + ch;
+                            za[i] = *reinterpret_cast<const float4*>(z + row * ld_z + c_first);
+                            ga[i] = *reinterpret_cast<const float4*>(g + row * ld_g + c_first);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (bi0 + i < nb) {
+                            const int64_t row = (bi0 + i) * C + ch;
+                            const float zv[VEC] = {za[i].x, za[i].y, za[i].z, za[i].w};
+                            const float gv[VEC] = {ga[i].x, ga[i].y, ga[i].z, ga[i].w};
+                            float o[VEC];
+                            group(zv, gv, c_first, o);
+                            *reinterpret_cast<float4*>(gz + row * ld_gz + c_first) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                }
+            }
+        }
+        if (VEC != 4 || cstep < cols) {
+            for (int64_t bi = 0; bi < nb; ++bi) {
+                const int64_t row = bi * C + ch;
+                const float* zr = z + row * ld_z;
+                const float* gr = g + row * ld_g;
+                float* or_ = gz + row * ld_gz;
+                for (int64_t c0 = c_first; c0 < cols; c0 += cstep) {
+                    float zv[VEC], gv[VEC], o[VEC];
+                    if constexpr (VEC == 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(zr + c0);
+                        const float4 b = *reinterpret_cast<const float4*>(gr + c0);
+                        zv[0] = a.x; zv[1] = a.y; zv[2] = a.z; zv[3] = a.w;
+                        gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+                    } else {
+                        zv[0] = zr[c0];
+                        gv[0] = gr[c0];
+                    }
+                    group(zv, gv, c0, o);
+                    if constexpr (VEC == 4) {
+                        *reinterpret_cast<float4*>(or_ + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        or_[c0] = o[0];
+                    }
                 }
             }
         }

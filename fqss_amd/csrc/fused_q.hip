@@ -149,23 +149,39 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict_
     const uint8_t* xr = xc + row * ld_xc;
     const float* gr = g + row * ld_g;
     float ds = 0.f, db = 0.f, p_du = 0.f, p_out = 0.f;
-    for (int m = threadIdx.x * 4; m < M; m += 256 * 4) {
-        const unsigned int w = *reinterpret_cast<const unsigned int*>(xr + m);
-        const float4 gv4 = *reinterpret_cast<const float4*>(gr + m);
-        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+    // 4 float4 groups per thread and pass, all loads issued before the first is consumed (one exposed HBM round
+    // trip per pass instead of one per group)
+    for (int m0 = threadIdx.x * 4; m0 < M; m0 += 4096) {
+        unsigned int wq_[4];
+        float4 gq[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (m + e < M) {
-                const float x = dec((w >> (8 * e)) & 255u, rx);
-                const float z = fmaf(x, scale, shift);
-                float cq, u;
-                bool inr;
-                (void)fq_asym(z, ry, cq, u, inr);
-                const float gz = inr ? div_by(gv[e] * ry.delta, ry.delta, ry.inv) : 0.0f;
-                p_du += gv[e] * (inr ? (cq - u) : cq);
-                p_out += inr ? 0.0f : gv[e];
-                ds = fmaf(gz, x, ds);
-                db += gz;
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            if (m < M) {
+                wq_[i] = *reinterpret_cast<const unsigned int*>(xr + m);
+                gq[i] = *reinterpret_cast<const float4*>(gr + m);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            if (m >= M) break;
+            const unsigned int w = wq_[i];
+            const float gv[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (m + e < M) {
+                    const float x = dec((w >> (8 * e)) & 255u, rx);
+                    const float z = fmaf(x, scale, shift);
+                    float cq, u;
+                    bool inr;
+                    (void)fq_asym(z, ry, cq, u, inr);
+                    const float gz = inr ? div_by(gv[e] * ry.delta, ry.delta, ry.inv) : 0.0f;
+                    p_du += gv[e] * (inr ? (cq - u) : cq);
+                    p_out += inr ? 0.0f : gv[e];
+                    ds = fmaf(gz, x, ds);
+                    db += gz;
+                }
             }
         }
     }
