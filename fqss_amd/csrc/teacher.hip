@@ -318,41 +318,65 @@ __global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const 
     const float* xr = x + (int64_t)row * ld_x;
     float* yr = y + (int64_t)row * ld_y;
     float s1 = 0.0f, s2 = 0.0f;
-    // consecutive lanes own consecutive float4 (coalesced 1-KiB wave loads/stores)
-    {
-        for (int m = threadIdx.x * 4; m < M; m += 256 * 4) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // The normalised row goes through LDS: every global load of the row is issued up front (consecutive lanes own
+    // consecutive float4), the taps then read LDS -- no exposed HBM round trip per group, no unaligned global loads
+    // for dilations 1 and 2.  Positions >= M hold zeros (the conv's zero padding applies AFTER the norm).
+    extern __shared__ __attribute__((aligned(16))) float sx[];   // [ceil4(M)]
+    for (int m0 = threadIdx.x * 4; m0 < M; m0 += 4096) {
+        float4 q[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k < K) {
-                    const int s0 = m + k * dil - pad;
-                    float v[4];
-                    if ((s0 & 3) == 0 && s0 >= 0 && s0 + 3 < ld_x) {
-                        const float4 t = *reinterpret_cast<const float4*>(xr + s0);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        for (int i = 0; i < 4; ++i)
+            if (m0 + 1024 * i < M) q[i] = *reinterpret_cast<const float4*>(xr + m0 + 1024 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            if (m >= M) break;
+            const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (m + j < M) ? fmaf(v[j], ga, gb) : 0.0f;
+            *reinterpret_cast<float4*>(&sx[m]) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+    __syncthreads();
+    const bool aligned = ((dil & 3) == 0) && ((pad & 3) == 0);
+    for (int m = threadIdx.x * 4; m < M; m += 1024) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < K) {
+                const int s0 = m + k * dil - pad;
+                if (aligned) {
+                    if (s0 >= 0 && s0 < M) {
+                        const float4 t = *reinterpret_cast<const float4*>(&sx[s0]);
+                        acc[0] = fmaf(wk[k], t.x, acc[0]);
+                        acc[1] = fmaf(wk[k], t.y, acc[1]);
+                        acc[2] = fmaf(wk[k], t.z, acc[2]);
+                        acc[3] = fmaf(wk[k], t.w, acc[3]);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? xr[s0 + j] : 0.0f;
+                        for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], 0.0f, acc[j]);   // same op sequence as a padded tap
                     }
+                } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float t = (s0 + j >= 0 && s0 + j < M) ? fmaf(v[j], ga, gb) : 0.0f;   // zero padding AFTER the norm
-                        acc[j] = fmaf(wk[k], t, acc[j]);
+                        const int sj = s0 + j;
+                        acc[j] = fmaf(wk[k], (sj >= 0 && sj < M) ? sx[sj] : 0.0f, acc[j]);
                     }
                 }
             }
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = acc[j] + bv;
-                o[j] = t > 0.f ? t : slope * t;
-                if (m + j < M) {
-                    s1 += o[j];
-                    s2 = fmaf(o[j], o[j], s2);
-                }
-            }
-            *reinterpret_cast<float4*>(yr + m) = make_float4(o[0], o[1], o[2], o[3]);
         }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = acc[j] + bv;
+            o[j] = t > 0.f ? t : slope * t;
+            if (m + j < M) {
+                s1 += o[j];
+                s2 = fmaf(o[j], o[j], s2);
+            }
+        }
+        *reinterpret_cast<float4*>(yr + m) = make_float4(o[0], o[1], o[2], o[3]);
     }
     double v[2] = {(double)s1, (double)s2};
     block_sum<double, 2>(v, red);
@@ -439,7 +463,8 @@ extern "C" int fqss_tdw(const float* x, const double* stats_in, const float* gam
                      (int64_t)B * C <= 65535 * 16ll && ld_x < (1ll << 30), "rows must be 16-B aligned");
     if (B == 0) return FQSS_OK;
     const int rows = B * C;
-    hipLaunchKernelGGL(k_tdw, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, stats_in, gamma, beta,
+    FQSS_REQUIRE(M <= 12 * 1024, "rows longer than 12288 positions do not fit the LDS row buffer");
+    hipLaunchKernelGGL(k_tdw, dim3((unsigned)rows), dim3(256), (size_t)((M + 3) & ~3) * sizeof(float), (hipStream_t)stream, x, stats_in, gamma, beta,
                        (double)C * (double)M, eps, w, bias, slope, y, stats_out, rows, C, M, K, dil, pad, (int)ld_x, (int)ld_y);
     return launch_status("fqss_tdw");
 }

@@ -109,8 +109,8 @@ class TeacherRunner:
 
     @torch.no_grad()
     def __call__(self, x):
-        if not self.ok:
-            return self.fmodel(x)
+        if not self.ok or (x.shape[-1] - self.fmodel.encoder.kernel_size[0]) // self.fmodel.encoder.stride[0] + 1 > 12 * 1024:
+            return self.fmodel(x)     # (the fused depthwise stage keeps a whole row of frames in LDS)
         if self._planes is None:
             self._prepare()
         m, mk, pl = self.fmodel, self.fmodel.masker, self._planes
