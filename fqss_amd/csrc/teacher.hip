@@ -69,6 +69,23 @@ __global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__
     }
 }
 
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
+struct TStage {          // one k-tile of global loads per thread: 3 planes x 2 x 16 B of the weight, 4 x 16 B of activations
+    u32x4t ra[3][2];
+    f32x4t rb[4];
+};
+__device__ __forceinline__ void t_load16(u32x4t& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void t_load16(f32x4t& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int N>
+__device__ __forceinline__ void t_wait(TStage& st) {
+    asm volatile("s_waitcnt vmcnt(%10)"
+                 : "+v"(st.ra[0][0]), "+v"(st.ra[0][1]), "+v"(st.ra[1][0]), "+v"(st.ra[1][1]), "+v"(st.ra[2][0]), "+v"(st.ra[2][1]),
+                   "+v"(st.rb[0]), "+v"(st.rb[1]), "+v"(st.rb[2]), "+v"(st.rb[3])
+                 : "n"(N)
+                 : "memory");
+}
+
 struct TGemmArgs {
     const unsigned short* A;   // [3][M][K] bf16 planes of the weight
     const float* B;            // [batch][K][ldb] fp32 activations
@@ -93,6 +110,7 @@ struct TGemmArgs {
     int tiles_m, tiles_n, batches;   // logical grid (launched 1-D in XCD-aware order, fqss_dev.h)
 };
 
+template <int PRO>   // prologue on the activation rows: 0 none | 1 GroupNorm affine | 2 PReLU
 __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     constexpr int A_BYTES = 3 * TBM * TLDK * 2, B_BYTES = 3 * TBK * TLDN * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
@@ -113,10 +131,20 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 
     if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
-    if (g.pro == 1) t_stats_finalize(g.pro_stats + (int64_t)b * kTSlots * kTSlotStride, g.pro_count, g.pro_eps, pms);
+    if (PRO == 1) t_stats_finalize(g.pro_stats + (int64_t)b * kTSlots * kTSlotStride, g.pro_count, g.pro_eps, pms);
     else __syncthreads();
-    const float pmean = (g.pro == 1) ? pms[0] : 0.f, prstd = (g.pro == 1) ? pms[1] : 1.f;
-    const float pslope = (g.pro == 2) ? *g.pro_slope : 0.0f;
+    const float pmean = (PRO == 1) ? pms[0] : 0.f, prstd = (PRO == 1) ? pms[1] : 1.f;
+    __shared__ float pco[2][512];   // GroupNorm-apply coefficients of the K input channels: t = x * pco[0][k] + pco[1][k]
+    if (PRO == 1) {
+        for (int k = tid; k < g.K; k += 256) {
+            const float pa = prstd * g.pro_gamma[k];
+            pco[0][k] = pa;
+            pco[1][k] = fmaf(-pa, pmean, g.pro_beta[k]);
+        }
+    }
+    __syncthreads();
+    float pslope = (PRO == 2) ? *g.pro_slope : 0.0f;
+    if (PRO == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pslope));   // not inside the hand-scheduled loop
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -130,50 +158,43 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     const int bk_row = tid >> 3, bk_c = (tid & 7) * 4;   // 4 float4 per thread at columns 32*q + bk_c
     const float* Bb = g.B + (int64_t)b * g.sBb;
     const int64_t plane = (int64_t)g.M * g.K;
-    uint4 ra[3][2];
-    float4 rb[4];
-    float p_a = 1.f, p_b = 0.f;
-
-    auto load_tiles = [&](int k0) {
+    // Two register stages of global loads: the tile stored at the end of iteration kt was requested two iterations
+    // earlier (PMC: with one stage the waves sat parked on vmcnt/barriers 40 % of the time).  Loads are unconditional
+    // -- addresses clamped into the operand, out-of-range k zeroed at use -- so no branch ever surrounds a load.
+    // The compiler sinks plain loads next to their first use (which would collapse the two stages into none), so the
+    // loads are issued through asm and retired by an explicit s_waitcnt that carries the stage's registers as
+    // in/out operands; nothing else in the loop touches vmcnt (the GroupNorm coefficients come from LDS).
+    const int a_row_c = min(i0 + a_row, g.M - 1);
+    const int n_last = (g.N - 1) & ~3;
+    auto load_tiles = [&](TStage& st, int k0) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (i0 + a_row < g.M && k0 + a_k + 8 * h < g.K)
-                    v = *reinterpret_cast<const uint4*>(g.A + p * plane + (int64_t)(i0 + a_row) * g.K + k0 + a_k + 8 * h);
-                ra[p][h] = v;
-            }
-        const int k = k0 + bk_row;
-        const bool ok = k < g.K;
-        if (g.pro == 1 && ok) {
-            p_a = prstd * g.pro_gamma[k];
-            p_b = fmaf(-p_a, pmean, g.pro_beta[k]);
-        }
+            for (int h = 0; h < 2; ++h)
+                t_load16(st.ra[p][h], g.A + p * plane + (int64_t)a_row_c * g.K + min(k0 + a_k + 8 * h, g.K - 8));
+        const int k = min(k0 + bk_row, g.K - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int n = j0 + 32 * q + bk_c;
-            if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bb + (int64_t)k * g.ldb + n);
-            rb[q] = v;
-        }
+        for (int q = 0; q < 4; ++q) t_load16(st.rb[q], Bb + (int64_t)k * g.ldb + min(j0 + 32 * q + bk_c, n_last));
     };
-    auto store_tiles = [&](int k0) {
+    auto store_tiles = [&](TStage& st, int k0) {
+        t_wait<10>(st);   // this stage has landed; the 10 younger requests of the other stage stay in flight
+        const int kc = min(k0 + bk_row, g.K - 1);
+        const float p_a = (PRO == 1) ? pco[0][kc] : 1.f, p_b = (PRO == 1) ? pco[1][kc] : 0.f;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            *reinterpret_cast<uint4*>(&As[p][a_row][a_k]) = ra[p][0];
-            *reinterpret_cast<uint4*>(&As[p][a_row][a_k + 8]) = ra[p][1];
+            *reinterpret_cast<u32x4t*>(&As[p][a_row][a_k]) = st.ra[p][0];
+            *reinterpret_cast<u32x4t*>(&As[p][a_row][a_k + 8]) = st.ra[p][1];
         }
-        const bool ok = (k0 + bk_row) < g.K;
+        const bool ok = (k0 + bk_row) < g.K;   // rows of B past K contribute zeros (A needs no mask: finite x 0)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float x[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+            const float x[4] = {st.rb[q][0], st.rb[q][1], st.rb[q][2], st.rb[q][3]};
             float h0[4], r1[4], r2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = x[e];
-                if (g.pro == 1) t = fmaf(t, p_a, p_b);
-                else if (g.pro == 2) t = t > 0.f ? t : pslope * t;
+                if (PRO == 1) t = fmaf(t, p_a, p_b);
+                else if (PRO == 2) t = t > 0.f ? t : pslope * t;
                 if (!ok) t = 0.f;
                 h0[e] = t;
                 r1[e] = t - t_tr(t);
@@ -192,13 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
             *reinterpret_cast<uint2*>(&Bs[2][bk_row][32 * q + bk_c]) = o3;
         }
     };
-
-    const int nkt = (g.K + TBK - 1) / TBK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tiles((kt + 1) * TBK);
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[3][2], bfr[3][2];
@@ -228,12 +243,37 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
                     for (int ni = 0; ni < 2; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[mi][ni], 0, 0, 0);
         }
+    };
+
+    const int nkt = (g.K + TBK - 1) / TBK;
+    TStage stA, stB;
+    load_tiles(stA, 0);
+    load_tiles(stB, TBK);
+    store_tiles(stA, 0);
+    load_tiles(stA, 2 * TBK);
+    __syncthreads();
+    // invariant at the top of iteration kt (even): LDS = tile kt, stB = tile kt+1, stA = tile kt+2 (requests in flight)
+    for (int kt = 0; kt < nkt; kt += 2) {
+        compute_tile();
         __syncthreads();
         if (kt + 1 < nkt) {
-            store_tiles((kt + 1) * TBK);
+            store_tiles(stB, (kt + 1) * TBK);
+            load_tiles(stB, (kt + 3) * TBK);
             __syncthreads();
+            compute_tile();
+            __syncthreads();
+            if (kt + 2 < nkt) {
+                store_tiles(stA, (kt + 2) * TBK);
+                load_tiles(stA, (kt + 4) * TBK);
+                __syncthreads();
+            }
         }
     }
+
+    // the trailing (clamped, unused) requests still target the stage registers, which the compiler considers dead
+    // from here on: drain them before anything else is allocated there
+    t_wait<0>(stA);
+    t_wait<0>(stB);
 
     // epilogue: bias + act (+ residual), 16-B/lane row stores via an LDS staging tile, statistics
     const float eslope = (g.act == FQSS_ACT_PRELU) ? *g.slope : 0.0f;
@@ -450,7 +490,10 @@ extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci,
     g.C1 = c1; g.R1 = r1; g.ldc1 = ld_c1; g.sC1b = (int64_t)M1 * ld_c1;
     g.C2 = c2; g.R2 = r2; g.ldc2 = ld_c2; g.sC2b = (int64_t)(Co - M1) * ld_c2;
     g.tiles_n = (int)cdiv(M, TBN); g.tiles_m = (int)cdiv(Co, TBM); g.batches = B;
-    hipLaunchKernelGGL(k_tgemm, dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
+    const dim3 grid(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m));
+    if (pro == 0) hipLaunchKernelGGL(k_tgemm<0>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (pro == 1) hipLaunchKernelGGL(k_tgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(k_tgemm<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_tgemm");
 }
 
