@@ -14,6 +14,8 @@ What is pinned (SURVEY.md §8(c) fixture plan F1-F7):
   loss.npz        wsdr.PairwiseWSDR (wsdr.py:46-95) + restated asteroid PIT -> w, kd, task, loss
   tiny_step.npz   tiny ConvTasNetQ: 53 full QAT steps (mysystem.py:124-151 semantics), observer
                   phase + quantizing phase: est, loss, grads, per-layer activations, final state
+  cfg1_step.npz   FULL-SIZE ConvTasNetQ at cfg 1 (B=2, T=8000), name-keyed deterministic weights: steps 1, 2,
+                  51, 52 -> loss / KD / task / weights / SI-SDRs / clipped grad norm / per-parameter grad norms
 
 Usage:  python tools/make_goldens.py [--out tests/golden]
 """
@@ -392,13 +394,79 @@ def gen_tiny_step(out, n_steps=53):
     print("tiny_step: final loss", float(loss), "keys", len(d))
 
 
+def cfg1_fill(model, prefix):
+    """Name-keyed deterministic fill of every non-range parameter (the reference's own init draws
+    from the global RNG in construction order).  The SAME function is restated in tests/helpers_cfg1.py."""
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("min_range") or k.endswith("max_range"):
+                continue
+            if p.numel() == 1:                                   # PReLU slope
+                p.fill_(0.25)
+            elif p.dim() == 1 and ("norm" in k.lower() or k.split(".")[-2].isdigit()) and k.endswith("weight"):
+                p.copy_(1.0 + keyed_randn(prefix + k, tuple(p.shape), 0.1))      # GroupNorm gain
+            elif p.dim() == 1:
+                p.copy_(keyed_randn(prefix + k, tuple(p.shape), 0.02))           # biases / GroupNorm shift
+            else:
+                fan = max(1, int(np.prod(p.shape[1:])))
+                p.copy_(keyed_randn(prefix + k, tuple(p.shape), 1.0 / np.sqrt(fan)))
+
+
+def gen_cfg1_step(out, n_steps=52):
+    """F7: the FULL-SIZE ConvTasNetQ (5.1 M parameters) at cfg 1 (B=2, T=8000): steps 1, 2 (observer phase) and 51, 52
+    (quantizing phase).  Weights come from cfg1_fill, so nothing but digests is stored."""
+    torch.set_num_threads(8)
+    d = {}
+    torch.manual_seed(0)
+    model = ConvTasNetQ(n_spks=2, kernel_size=16, stride=8)
+    fmodel = copy.deepcopy(model)
+    model = quantize_model(model, QCFG)
+    cfg1_fill(fmodel, "T.")
+    cfg1_fill(model, "S.")
+    model.train(); fmodel.eval()
+    d["param_names"] = np.array([k for k, _ in model.named_parameters()])
+    d["param_sum"] = np.array([float(p.double().sum()) for _, p in model.named_parameters()])
+    d["param_sumsq"] = np.array([float((p.double() ** 2).sum()) for _, p in model.named_parameters()])
+    d["tparam_names"] = np.array([k for k, _ in fmodel.named_parameters()])
+    d["tparam_sum"] = np.array([float(p.double().sum()) for _, p in fmodel.named_parameters()])
+    B, T = 2, 8000
+    x, tgt = synth_batch(B, T, seed=0)
+    d["x_sum"], d["tgt_sumsq"] = np.float64(x.double().sum()), np.float64((tgt.double() ** 2).sum())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    record = {1, 2, 51, 52}
+    for step in range(1, n_steps + 1):
+        opt.zero_grad()
+        est, fest, w, kd, task, loss, sdrs, sdrqs = common_step(model, fmodel, x, tgt)
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        if step in record:
+            p = f"s{step}."
+            d[p + "w"], d[p + "kd"], d[p + "task"], d[p + "loss"], d[p + "gnorm"] = npy(w), npy(kd), npy(task), npy(loss), npy(gnorm)
+            d[p + "sdr_teacher"], d[p + "sdr_student"] = npy(sdrs), npy(sdrqs)
+            if step in (1, 51):
+                d[p + "est"] = npy(est).astype(np.float32)
+                d[p + "fest_rms"] = np.float64(fest.double().pow(2).mean().sqrt())
+            # per-parameter gradient norms AFTER clipping (what the optimizer sees)
+            d[p + "grad_norm"] = np.array([float(q.grad.double().norm()) if q.grad is not None else -1.0
+                                           for _, q in model.named_parameters()])
+        opt.step()
+        if step in record or step % 10 == 0:
+            print("cfg1 step", step, "loss", float(loss), flush=True)
+    np.savez_compressed(os.path.join(out, "cfg1_step.npz"), **d)
+    torch.set_num_threads(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="generate just this fixture (e.g. cfg1)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
+    if a.only == "cfg1":
+        gen_cfg1_step(a.out)
+        return
     gen_fq_act(a.out); gen_fq_w(a.out); gen_observer(a.out); gen_process(a.out)
-    gen_layers(a.out); gen_loss(a.out); gen_tiny_step(a.out)
+    gen_layers(a.out); gen_loss(a.out); gen_tiny_step(a.out); gen_cfg1_step(a.out)
     for f in sorted(os.listdir(a.out)):
         print(f, os.path.getsize(os.path.join(a.out, f)))
 
