@@ -56,6 +56,29 @@ __device__ __forceinline__ void split3(float g, unsigned short& b1, unsigned sho
     b3 = f2bf_trunc(r2);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct QStage {          // one k-tile of global loads of one thread (which members are live depends on the mode)
+    f32x4 a[4];          // MODE 0/1: a[0] reinterpreted as 16 int8 codes; MODE 3: 16 fp32
+    f32x4 b[2];          // MODE 1/3: 8 fp32
+    u32x2 bq;            // MODE 0: 8 u8 codes
+};
+__device__ __forceinline__ void q_load16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void q_load8(u32x2& d, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int MODE, int N>
+__device__ __forceinline__ void q_wait(QStage& st) {
+    if constexpr (MODE == 0)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(st.a[0]), "+v"(st.bq) : "n"(N) : "memory");
+    else if constexpr (MODE == 1)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(st.a[0]), "+v"(st.b[0]), "+v"(st.b[1]) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%6)"
+                     : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.a[2]), "+v"(st.a[3]), "+v"(st.b[0]), "+v"(st.b[1])
+                     : "n"(N)
+                     : "memory");
+}
+
 struct QGemmArgs {
     // forward / dgrad: A = int8 weight codes [M][K] (k contiguous), B = per-batch [K][ldb] (n contiguous)
     // wgrad          : A = fp32 gz [M][lda] per batch (k = n contiguous), B = u8 codes [N][ldb] per batch
@@ -134,127 +157,118 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     }
 
     // ---------------------------------------------------------------- staging (global -> regs -> LDS)
-    uint4 ra_i8;            // MODE 0/1: 16 int8 weight codes
-    float4 ra_f[4];         // MODE 3: 16 fp32 values
-    uint4 rb_u8;            // MODE 0: 16 u8 activation codes (threads < 128)
-    float4 rb_f[2];         // MODE 1/3: 8 fp32 values
-    float rb_scale = 0.0f;  // MODE 1: delta_w of this thread's k row
-
+    // Two register stages of global loads: the tile stored at the end of iteration kt was requested two iterations
+    // earlier.  The loads are issued through asm (the compiler sinks plain loads to their first use, which would
+    // collapse the stages) and retired by an explicit s_waitcnt carrying the stage's registers; they are
+    // unconditional -- addresses clamped into the operand, out-of-range reduction rows zeroed at use (both operands
+    // are finite, so a clamped A value only ever meets a zero).
+    constexpr int NLOADS = (MODE == 0) ? 2 : (MODE == 1) ? 3 : 6;   // per thread and stage
     const int a_row = tid >> 1, a_k = (tid & 1) * 16;              // A tile: 128 rows x 32 k, 16 per thread
-    const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;             // fp32 B tile [k][n]: 32 k x 64 n, 8 per thread
-    const int bu_row = (tid & 127) >> 2, bu_n = (tid & 3) * 16;    // u8 B tile [k][n]: 32 k x 64 n, 16 per thread (<128)
-    const bool b_u8_active = tid < 128;
+    const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;             // B tile [k][n]: 32 k x 64 n, 8 per thread
+    const int a_row_c = min(i0 + a_row, g.M - 1);
 
-    auto load_tiles = [&](int k0) {
+    __shared__ float dws[(MODE == 1) ? 1024 : 1];   // dgrad: delta_w of the reduction rows
+    if constexpr (MODE == 1) {
+        for (int k = tid; k < g.K; k += 256) dws[k] = g.dw[k];
+    }
+
+    auto load_tiles = [&](QStage& st, int k0) {
         if constexpr (MODE < 2) {
-            const signed char* A = (const signed char*)g.A;
-            ra_i8 = make_uint4(0, 0, 0, 0);
-            if (i0 + a_row < g.M && k0 + a_k < kend)
-                ra_i8 = *reinterpret_cast<const uint4*>(A + (int64_t)(i0 + a_row) * g.lda + k0 + a_k);
+            q_load16(st.a[0], (const signed char*)g.A + (int64_t)a_row_c * g.lda + min(k0 + a_k, g.K - 16));
         } else {
-            const float* A = (const float*)g.A + (int64_t)b * g.sAb;
+            const float* A = (const float*)g.A + (int64_t)b * g.sAb + (int64_t)a_row_c * g.lda;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int k = k0 + a_k + 4 * q;
-                if (i0 + a_row < g.M && k < kend) {
-                    v = *reinterpret_cast<const float4*>(A + (int64_t)(i0 + a_row) * g.lda + k);
-                    if (k + 1 >= kend) v.y = 0.f;
-                    if (k + 2 >= kend) v.z = 0.f;
-                    if (k + 3 >= kend) v.w = 0.f;
-                }
-                ra_f[q] = v;
-            }
+            for (int q = 0; q < 4; ++q) q_load16(st.a[q], A + min(k0 + a_k + 4 * q, g.K - 4));
         }
+        const int kk = min(k0 + bk_row, g.K - 1);
         if constexpr (MODE == 0) {
-            const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb;
-            rb_u8 = make_uint4(0, 0, 0, 0);
-            if (b_u8_active && k0 + bu_row < kend && j0 + bu_n < g.N)
-                rb_u8 = *reinterpret_cast<const uint4*>(Bp + (int64_t)(k0 + bu_row) * g.ldb + j0 + bu_n);
-        } else if constexpr (MODE == 1 || MODE == 3) {
-            const int kk = k0 + bk_row;
-            const bool ok = (kk < kend);
+            const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb + (int64_t)kk * g.ldb;
+            q_load8(st.bq, Bp + min(j0 + bk_n, (int)g.ldb - 8));   // groups past the row (columns >= N) re-read its tail
+        } else {
             const float* Bp = (kk < g.K1) ? (const float*)g.B + (int64_t)b * g.sBb + (int64_t)kk * g.ldb
                                           : (const float*)g.B2 + (int64_t)b * g.sB2b + (int64_t)(kk - g.K1) * g.ldb2;
-            rb_scale = (ok && MODE == 1) ? g.dw[kk] : 0.0f;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int n = j0 + bk_n + 4 * q;
-                if (ok && n < g.N) v = *reinterpret_cast<const float4*>(Bp + n);
-                rb_f[q] = v;
-            }
+            const int ldk = (int)((kk < g.K1) ? g.ldb : g.ldb2);    // row length (multiple of 4, >= N): clamp inside the row;
+            q_load16(st.b[0], Bp + min(j0 + bk_n, ldk - 4));        // a clamped group only feeds output columns >= N
+            q_load16(st.b[1], Bp + min(j0 + bk_n + 4, ldk - 4));
         }
     };
 
-    auto store_u8x16 = [&](unsigned short* dst, uint4 v, bool is_signed) {
-        // 16 8-bit integers -> 16 bf16 (exact), two 16-B LDS stores
-        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
-        unsigned short o[16];
+    // n 8-bit integers (n = 16: one uint4, n = 8: one uint2) -> bf16 (exact), 16-B LDS stores
+    auto store_codes = [&](unsigned short* dst, const unsigned int* w, auto nw_tag, bool is_signed, bool zero) {
+        constexpr int NW = decltype(nw_tag)::value;
+        unsigned int o[2 * NW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NW; ++q) {
+            float f[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned int byte = (w[q] >> (8 * e)) & 0xFFu;
-                const float f = is_signed ? (float)(int)(signed char)byte : (float)byte;
-                o[4 * q + e] = f2bf_trunc(f);
+                f[e] = zero ? 0.0f : (is_signed ? (float)(int)(signed char)byte : (float)byte);
             }
-        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
-        *reinterpret_cast<uint4*>(dst + 8) =
-            make_uint4(o[8] | (o[9] << 16), o[10] | (o[11] << 16), o[12] | (o[13] << 16), o[14] | (o[15] << 16));
+            o[2 * q] = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+            o[2 * q + 1] = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
+        }
+#pragma unroll
+        for (int h = 0; h < NW / 2; ++h)
+            *reinterpret_cast<uint4*>(dst + 8 * h) = make_uint4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
     };
 
-    auto store_split3 = [&](unsigned short* d1, unsigned short* d2, unsigned short* d3, const float4* v, float scale,
-                            bool do_scale, auto nq_tag) {
+    auto store_split3 = [&](unsigned short* d1, unsigned short* d2, unsigned short* d3, const f32x4* v, float scale,
+                            bool do_scale, bool zero, auto nq_tag) {
         constexpr int NQ = decltype(nq_tag)::value;   // float4 count: 4 (16 values) or 2 (8 values)
-        unsigned short o1[16], o2[16], o3[16];
+        unsigned int o1[2 * NQ], o2[2 * NQ], o3[2 * NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            float h0[4], r1[4], r2[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = do_scale ? scale * x[e] : x[e];
-                split3(t, o1[4 * q + e], o2[4 * q + e], o3[4 * q + e]);
+                float t = do_scale ? scale * v[q][e] : v[q][e];
+                if (zero) t = 0.0f;
+                h0[e] = t;
+                r1[e] = t - bf_trunc(t);
+                r2[e] = r1[e] - bf_trunc(r1[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {   // bf16 pairs: v_perm picks the high halves of two fp32 words
+                o1[2 * q + e] = __builtin_amdgcn_perm(__float_as_uint(h0[2 * e + 1]), __float_as_uint(h0[2 * e]), 0x07060302u);
+                o2[2 * q + e] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * e + 1]), __float_as_uint(r1[2 * e]), 0x07060302u);
+                o3[2 * q + e] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * e + 1]), __float_as_uint(r2[2 * e]), 0x07060302u);
             }
         }
 #pragma unroll
-        for (int hsel = 0; hsel < NQ / 2; ++hsel) {
-            const int o = 8 * hsel;
-            *reinterpret_cast<uint4*>(d1 + o) = make_uint4(o1[o] | (o1[o + 1] << 16), o1[o + 2] | (o1[o + 3] << 16),
-                                                           o1[o + 4] | (o1[o + 5] << 16), o1[o + 6] | (o1[o + 7] << 16));
-            *reinterpret_cast<uint4*>(d2 + o) = make_uint4(o2[o] | (o2[o + 1] << 16), o2[o + 2] | (o2[o + 3] << 16),
-                                                           o2[o + 4] | (o2[o + 5] << 16), o2[o + 6] | (o2[o + 7] << 16));
-            *reinterpret_cast<uint4*>(d3 + o) = make_uint4(o3[o] | (o3[o + 1] << 16), o3[o + 2] | (o3[o + 3] << 16),
-                                                           o3[o + 4] | (o3[o + 5] << 16), o3[o + 6] | (o3[o + 7] << 16));
+        for (int h = 0; h < NQ / 2; ++h) {
+            *reinterpret_cast<uint4*>(d1 + 8 * h) = make_uint4(o1[4 * h], o1[4 * h + 1], o1[4 * h + 2], o1[4 * h + 3]);
+            *reinterpret_cast<uint4*>(d2 + 8 * h) = make_uint4(o2[4 * h], o2[4 * h + 1], o2[4 * h + 2], o2[4 * h + 3]);
+            *reinterpret_cast<uint4*>(d3 + 8 * h) = make_uint4(o3[4 * h], o3[4 * h + 1], o3[4 * h + 2], o3[4 * h + 3]);
         }
     };
 
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](QStage& st, int k0) {
+        q_wait<MODE, NLOADS>(st);   // this stage has landed; the NLOADS younger requests of the other stage stay in flight
+        const bool kz = (k0 + bk_row) >= g.K;   // reduction rows past K contribute zeros (B side)
         if constexpr (MODE < 2) {
-            store_u8x16(&As[0][a_row][a_k], ra_i8, true);
+            const unsigned int w[4] = {__float_as_uint(st.a[0][0]), __float_as_uint(st.a[0][1]), __float_as_uint(st.a[0][2]),
+                                       __float_as_uint(st.a[0][3])};
+            store_codes(&As[0][a_row][a_k], w, std::integral_constant<int, 4>{}, true, false);
         } else {
-            store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], ra_f, 1.0f, false,
+            store_split3(&As[0][a_row][a_k], &As[1][a_row][a_k], &As[2][a_row][a_k], st.a, 1.0f, false, false,
                          std::integral_constant<int, 4>{});
         }
         if constexpr (MODE == 0) {
-            if (b_u8_active) store_u8x16(&Bs[0][bu_row][bu_n], rb_u8, false);
-        } else if constexpr (MODE == 1 || MODE == 3) {
-            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], rb_f, rb_scale, MODE == 1,
+            const unsigned int w[2] = {st.bq[0], st.bq[1]};
+            store_codes(&Bs[0][bk_row][bk_n], w, std::integral_constant<int, 2>{}, false, kz);
+        } else {
+            const float sc = (MODE == 1) ? dws[min(k0 + bk_row, g.K - 1)] : 1.0f;
+            store_split3(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], &Bs[2][bk_row][bk_n], st.b, sc, MODE == 1, kz,
                          std::integral_constant<int, 2>{});
         }
     };
 
     // ---------------------------------------------------------------- main loop
     const int nkt = (kend - kbeg + QBK - 1) / QBK;
-    if (nkt > 0) {
-        load_tiles(kbeg);
-        store_tiles();
-    }
-    __syncthreads();
     // lane geometry of the transposed read: 16-lane group gq reads a 4(k) x 16(n) block
     const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * QBK);
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -281,12 +295,35 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi], 0, 0, 0);
             }
         }
+    };
+    QStage stA, stB;
+    __syncthreads();   // dws / rowc
+    load_tiles(stA, 0);
+    load_tiles(stB, QBK);
+    store_tiles(stA, 0);
+    load_tiles(stA, 2 * QBK);
+    __syncthreads();
+    // invariant at the top of iteration kt (even): LDS = tile kt, stB = tile kt+1, stA = tile kt+2 (requests in flight)
+    for (int kt = 0; kt < nkt; kt += 2) {
+        compute_tile();
         __syncthreads();
         if (kt + 1 < nkt) {
-            store_tiles();
+            store_tiles(stB, (kt + 1) * QBK);
+            load_tiles(stB, (kt + 3) * QBK);
             __syncthreads();
+            compute_tile();
+            __syncthreads();
+            if (kt + 2 < nkt) {
+                store_tiles(stA, (kt + 2) * QBK);
+                load_tiles(stA, (kt + 4) * QBK);
+                __syncthreads();
+            }
         }
     }
+    // the trailing (clamped, unused) requests still target the stage registers, which the compiler considers dead
+    // from here on: drain them before anything else is allocated there
+    q_wait<MODE, 0>(stA);
+    q_wait<MODE, 0>(stB);
 
     // ---------------------------------------------------------------- epilogue
     float dx = 0.f, mnx = 0.f;
@@ -635,6 +672,7 @@ static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, c
                  "q-GEMM dgrad needs Co % 16 == 0 and 16-B aligned gradient rows");
     FQSS_REQUIRE(Co2 == 0 || (ld_gz2 % 4 == 0 && aligned16(gz2) && ld_gz2 >= ((M + 3) & ~3)), "second gradient: 16-B aligned rows");
     FQSS_REQUIRE(aligned16(gx) && ld_gx % 4 == 0, "output rows must be 16-B aligned");
+    FQSS_REQUIRE(Co <= 1024, "dgrad stages delta_w of at most 1024 output channels in LDS");
     if (B == 0 || M == 0) return FQSS_OK;
     QGemmArgs g{};
     g.A = wiT; g.B = gz1; g.C = gx; g.M = Ci; g.N = M; g.K = Co;
