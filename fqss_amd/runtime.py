@@ -8,6 +8,8 @@ MI355X-first choices:
   * nothing on the step reads device memory from the host (the reference syncs ~400x per forward,
     qat_quant.py:235-238), so the whole step can be captured in a hipGraph.
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -65,6 +67,9 @@ class ParamArena:
         K.sumsq(self.flat_g, self.sumsq)
         K.adam_clip(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.sumsq, self.step_t, self.gnorm,
                     max_norm, grad_scale, lr, betas[0], betas[1], eps, t0=self.t0)
+
+
+TEACHER_STREAM = os.environ.get("FQSS_TEACHER_STREAM", "1") != "0"
 
 
 class TeacherRunner:
@@ -312,6 +317,7 @@ class KDTrainStep:
         for p in fmodel.parameters():
             p.requires_grad_(False)
         self.teacher = TeacherRunner(fmodel)     # fused inference chain for the frozen float teacher
+        self._tstream = None
         self.last = None
         self.tables = None          # QuantTables once the quantizing phase is reached
         self._graphs = None
@@ -326,9 +332,23 @@ class KDTrainStep:
         if t is not None:
             t.gwq.zero_()
             t.weights_forward()                # all 101 weight fake-quants (+ int8 codes): one launch
+        # The frozen teacher depends on nothing but x: it runs on a second stream next to the student's forward (its
+        # MFMA-bound GEMMs overlap the student's HBM-bound layers; inside a hipGraph capture this becomes a parallel
+        # branch of the graph) and joins before the loss.
+        cur = torch.cuda.current_stream()
+        if TEACHER_STREAM:
+            if self._tstream is None:
+                self._tstream = torch.cuda.Stream()
+            self._tstream.wait_stream(cur)
+            with torch.cuda.stream(self._tstream):
+                fest = self.teacher(x)
         with ops.fast_codes(True), ops.deferred(t):     # student: codes-only dataflow between quantizing layers
             est = self.model(x)
-        fest = self.teacher(x)
+        if TEACHER_STREAM:
+            cur.wait_stream(self._tstream)
+            fest.record_stream(cur)
+        else:
+            fest = self.teacher(x)
         out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
         with ops.deferred(t):
             est.backward(gest)

@@ -3,6 +3,8 @@ goldens and the oracle: per-LayerQ (gate G1, teacher-forced), tiny-model trainin
 within 1e-5 / 1e-3 dB, G3 quantizing phase statistically), and full-size (cfg-2) properties."""
 import copy
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -312,9 +314,11 @@ def test_full_size_step_properties():
     assert float(step.arena.flat_g.abs().max()) > 0
 
 
-def test_cfg1_full_size_vs_reference_goldens(golden):
-    """F7 of SURVEY 8(c): the FULL-SIZE ConvTasNetQ (5.1 M parameters, 24 TCN blocks) at cfg 1 (B=2, T=8000)
-    against digests of the real reference's run from the same name-keyed weights (tests/helpers_cfg1.py).
+@pytest.mark.parametrize("fixture,B,T_", [("cfg1_step", 2, 8000), ("cfg2_step", 8, 32000)])
+def test_full_size_vs_reference_goldens(golden, fixture, B, T_):
+    """F7 of SURVEY 8(c): the FULL-SIZE ConvTasNetQ (5.1 M parameters, 24 TCN blocks) at cfg 1 (B=2, T=8000) and at
+    cfg 2 (B=8, T=32000 -- the benchmark's own size) against digests of the real reference's run from the same
+    name-keyed weights (tests/helpers_cfg1.py).
       step 1      (float arithmetic, observers recording): G2 tolerances -- loss / KD / task 1e-5 relative, est 1e-4,
                   SDR weights 2.3e-4 (= 1e-3 dB), clipped global gradient norm 1e-4, EVERY per-parameter gradient norm 2e-3;
       step 2      (weights quantized after Adam's sign-like first update): 2e-4 / 5e-3 / median gradient norm 1e-2;
@@ -323,7 +327,9 @@ def test_cfg1_full_size_vs_reference_goldens(golden):
     from fqss_amd.data import synth_batch
     from fqss_amd.runtime import KDTrainStep
     from fqss_amd.smoke import build_pair
-    g = golden("cfg1_step")
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", fixture + ".npz")):
+        pytest.skip(fixture + ".npz not generated (tools/make_goldens.py --only cfg2 takes ~1 h of reference CPU time)")
+    g = golden(fixture)
     model, fmodel = build_pair("cuda", 0, n_spks=2, kernel_size=16, stride=8)
     cfg1_fill(fmodel, "T.")
     cfg1_fill(model, "S.")
@@ -331,7 +337,7 @@ def test_cfg1_full_size_vs_reference_goldens(golden):
     assert names == list(g["param_names"]) and [k for k, _ in fmodel.named_parameters()] == list(g["tparam_names"])
     np.testing.assert_allclose([float(p.detach().double().sum()) for _, p in model.named_parameters()], g["param_sum"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose([float(p.detach().double().sum()) for _, p in fmodel.named_parameters()], g["tparam_sum"], rtol=1e-9, atol=1e-9)
-    x, tgt = synth_batch(2, 8000, seed=0, device="cuda")
+    x, tgt = synth_batch(B, T_, seed=0, device="cuda")
     np.testing.assert_allclose(float(x.double().sum()), float(g["x_sum"]), rtol=1e-9)
     step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0)
     for s in range(1, 53):
@@ -349,7 +355,7 @@ def test_cfg1_full_size_vs_reference_goldens(golden):
                 np.testing.assert_allclose(r[k].item(), g[p + k], rtol=1e-5 * f, err_msg=p + k)
             np.testing.assert_allclose(r["w"].cpu().numpy(), g[p + "w"], rtol=2.3e-4 * f, err_msg=p)
             np.testing.assert_allclose(r["gnorm"].item(), g[p + "gnorm"], rtol=(1e-4 if s == 1 else 5e-3), err_msg=p)
-            if s == 1:
+            if s == 1 and p + "est" in g.files:
                 ref = g[p + "est"]
                 np.testing.assert_allclose(r["est"].cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), err_msg=p)
             coef = min(1.0, 5.0 / (float(g[p + "gnorm"]) + 1e-6))     # the fixture holds the clipped gradients' norms

@@ -1,5 +1,7 @@
 """Pins the oracle (oracle/fq_core.c + oracle/fqss_oracle.py) against golden vectors produced by
 the REAL reference (tools/make_goldens.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -194,12 +196,15 @@ def test_tiny_step_goldens(golden):
             np.testing.assert_allclose(s.p[k[len("s53.post_sd."):]].detach().numpy(), g[k], rtol=1e-3, atol=1e-5, err_msg=k)
 
 
-def test_cfg1_full_size_goldens(golden):
-    """the oracle at FULL model size (5.1 M parameters, cfg 1: B=2, T=8000) against the real reference's digests for
-    steps 1-2, from the same name-keyed weights (tests/helpers_cfg1.py <-> tools/make_goldens.py::cfg1_fill)"""
+@pytest.mark.parametrize("fixture,B,T_,steps", [("cfg1_step", 2, 8000, (1, 2)), ("cfg2_step", 8, 32000, (1,))])
+def test_full_size_goldens(golden, fixture, B, T_, steps):
+    """the oracle at FULL model size (5.1 M parameters; cfg 1: B=2, T=8000, and step 1 of cfg 2: B=8, T=32000) against
+    the real reference's digests, from the same name-keyed weights (tests/helpers_cfg1.py <-> tools/make_goldens.py)"""
     from fqss_amd.smoke import build_pair
     from tests.helpers_cfg1 import cfg1_fill
-    g = golden("cfg1_step")
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", fixture + ".npz")):
+        pytest.skip(fixture + ".npz not generated (tools/make_goldens.py --only cfg2 takes ~1 h of reference CPU time)")
+    g = golden(fixture)
     model, fmodel = build_pair("cpu", 0, n_spks=2, kernel_size=16, stride=8)
     cfg1_fill(fmodel, "T.")
     cfg1_fill(model, "S.")
@@ -209,9 +214,9 @@ def test_cfg1_full_size_goldens(golden):
     s = O.StudentConvTasNetQ(model.state_dict())
     t = O.TeacherConvTasNet(fmodel.state_dict())
     tr = O.Trainer(s, t)
-    x, tgt = O.synth_batch(2, 8000, seed=0)
+    x, tgt = O.synth_batch(B, T_, seed=0)
     np.testing.assert_allclose(float(x.double().sum()), float(g["x_sum"]), rtol=1e-9)
-    for step in (1, 2):
+    for step in steps:
         r = tr.step(x, tgt)
         p = f"s{step}."
         # step 2 runs on weights that were moved by Adam and then put on their 8-bit grids: among 5 M weights a few sit
@@ -221,6 +226,6 @@ def test_cfg1_full_size_goldens(golden):
         np.testing.assert_allclose(r["kd"].item(), g[p + "kd"], rtol=tol, err_msg=p)
         np.testing.assert_allclose(r["w"].numpy(), g[p + "w"], rtol=10 * tol, err_msg=p)
         np.testing.assert_allclose(float(r["gnorm"]), g[p + "gnorm"], rtol=10 * tol, err_msg=p)
-        if step == 1:
+        if step == 1 and p + "est" in g.files:
             ref = g[p + "est"]
             np.testing.assert_allclose(r["est"].detach().numpy(), ref, rtol=1e-5, atol=1e-6 * float(np.abs(ref).max()), err_msg=p)

@@ -16,6 +16,7 @@ What is pinned (SURVEY.md §8(c) fixture plan F1-F7):
                   phase + quantizing phase: est, loss, grads, per-layer activations, final state
   cfg1_step.npz   FULL-SIZE ConvTasNetQ at cfg 1 (B=2, T=8000), name-keyed deterministic weights: steps 1, 2,
                   51, 52 -> loss / KD / task / weights / SI-SDRs / clipped grad norm / per-parameter grad norms
+  cfg2_step.npz   the same at cfg 2 (B=8, T=32000: the benchmark's size), digests only (--only cfg2)
 
 Usage:  python tools/make_goldens.py [--out tests/golden]
 """
@@ -412,9 +413,10 @@ def cfg1_fill(model, prefix):
                 p.copy_(keyed_randn(prefix + k, tuple(p.shape), 1.0 / np.sqrt(fan)))
 
 
-def gen_cfg1_step(out, n_steps=52):
-    """F7: the FULL-SIZE ConvTasNetQ (5.1 M parameters) at cfg 1 (B=2, T=8000): steps 1, 2 (observer phase) and 51, 52
-    (quantizing phase).  Weights come from cfg1_fill, so nothing but digests is stored."""
+def gen_cfg1_step(out, n_steps=52, B=2, T=8000, fname="cfg1_step.npz", keep_est=True):
+    """F7: the FULL-SIZE ConvTasNetQ (5.1 M parameters) at cfg 1 (B=2, T=8000) -- or, with B=8 / T=32000, at cfg 2, the
+    benchmark's own size: steps 1, 2 (observer phase) and 51, 52 (quantizing phase).  Weights come from cfg1_fill, so
+    nothing but digests is stored."""
     torch.set_num_threads(8)
     d = {}
     torch.manual_seed(0)
@@ -429,7 +431,6 @@ def gen_cfg1_step(out, n_steps=52):
     d["param_sumsq"] = np.array([float((p.double() ** 2).sum()) for _, p in model.named_parameters()])
     d["tparam_names"] = np.array([k for k, _ in fmodel.named_parameters()])
     d["tparam_sum"] = np.array([float(p.double().sum()) for _, p in fmodel.named_parameters()])
-    B, T = 2, 8000
     x, tgt = synth_batch(B, T, seed=0)
     d["x_sum"], d["tgt_sumsq"] = np.float64(x.double().sum()), np.float64((tgt.double() ** 2).sum())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -443,8 +444,9 @@ def gen_cfg1_step(out, n_steps=52):
             p = f"s{step}."
             d[p + "w"], d[p + "kd"], d[p + "task"], d[p + "loss"], d[p + "gnorm"] = npy(w), npy(kd), npy(task), npy(loss), npy(gnorm)
             d[p + "sdr_teacher"], d[p + "sdr_student"] = npy(sdrs), npy(sdrqs)
-            if step in (1, 51):
+            if step in (1, 51) and keep_est:
                 d[p + "est"] = npy(est).astype(np.float32)
+            if step in (1, 51):
                 d[p + "fest_rms"] = np.float64(fest.double().pow(2).mean().sqrt())
             # per-parameter gradient norms AFTER clipping (what the optimizer sees)
             d[p + "grad_norm"] = np.array([float(q.grad.double().norm()) if q.grad is not None else -1.0
@@ -452,7 +454,7 @@ def gen_cfg1_step(out, n_steps=52):
         opt.step()
         if step in record or step % 10 == 0:
             print("cfg1 step", step, "loss", float(loss), flush=True)
-    np.savez_compressed(os.path.join(out, "cfg1_step.npz"), **d)
+    np.savez_compressed(os.path.join(out, fname), **d)
     torch.set_num_threads(1)
 
 
@@ -464,6 +466,9 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     if a.only == "cfg1":
         gen_cfg1_step(a.out)
+        return
+    if a.only == "cfg2":     # ~10 s per reference step on 8 cores
+        gen_cfg1_step(a.out, B=8, T=32000, fname="cfg2_step.npz", keep_est=False)
         return
     gen_fq_act(a.out); gen_fq_w(a.out); gen_observer(a.out); gen_process(a.out)
     gen_layers(a.out); gen_loss(a.out); gen_tiny_step(a.out); gen_cfg1_step(a.out)
