@@ -197,13 +197,30 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict_
     }
 }
 
+// The layer that PRODUCED this GroupNorm's input (a 1x1 conv + PReLU + fake-quant) needs, for its own backward, exactly
+// the gradient computed here pushed through its output quantizer (STE) and non-linearity.  With `pz` given the apply
+// pass does that on the spot -- it reads the producer's saved pre-quant z, writes gz of the PRODUCER instead of gx and
+// accumulates the producer's range / slope / bias partials -- which removes a whole 12 B/element pass (k_actq_bwd).
+struct GnProducer {
+    const float* pz; int64_t ld_pz;     // producer's pre-quant output (NULL: plain gx)
+    int act; const float* slope;        // its non-linearity
+    const float *qmin, *qmax;           // its output quantizer (== the ranges of xc)
+    double* gacc; float* gbias;         // its partial slots / bias gradient [C]
+};
+
 // backward pass 3: gx = gz*(gamma*rstd) + x*c2 + c3 with gz recomputed from (x codes, g)
 __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict__ xc, const float* __restrict__ g,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean_rstd, float* __restrict__ gx, int B,
                                                         int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx,
                                                         const double* ws, const float* qmin_x, const float* qmax_x,
-                                                        const float* qmin, const float* qmax) {
+                                                        const float* qmin, const float* qmax, GnProducer P) {
+    __shared__ double pred[3 * 4];
+    __shared__ float predf[4];
+    const bool fuse = P.pz != nullptr;
+    const QRange rp = fuse ? load_qrange(P.qmin, P.qmax) : QRange{0.f, 1.f, 1.f};
+    const float pslope = (fuse && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
+    float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const double* coef = ws + 2 * (int64_t)B * C;
     const int rows = B * C;
@@ -217,10 +234,14 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
         const uint8_t* xr = xc + (int64_t)row * ld_xc;
         const float* gr = g + (int64_t)row * ld_g;
         float* orow = gx + (int64_t)row * ld_gx;
+        float p_bias = 0.f;
         for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += cstep) {
             const unsigned int w = *reinterpret_cast<const unsigned int*>(xr + c0);
             const float4 gv4 = *reinterpret_cast<const float4*>(gr + c0);
+            float4 pz4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fuse) pz4 = *reinterpret_cast<const float4*>(P.pz + (int64_t)row * P.ld_pz + c0);
             const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+            const float pzv[4] = {pz4.x, pz4.y, pz4.z, pz4.w};
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -231,8 +252,47 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
                 (void)fq_asym(z, ry, cq, u, inr);
                 const float gz = inr ? div_by(gv[e] * ry.delta, ry.delta, ry.inv) : 0.0f;
                 o[e] = fmaf(gz, scale, fmaf(x, c2, c3));
+                if (fuse) {   // the producer's epilogue backward (same arithmetic as k_actq_bwd) on gj = gx
+                    const bool valid = (c0 + e < M);
+                    const float gj = valid ? o[e] : 0.0f;
+                    const float t = act_apply(pzv[e], P.act, pslope);
+                    float pc, pu;
+                    bool pin;
+                    (void)fq_asym(t, rp, pc, pu, pin);
+                    const float gt = pin ? div_by(gj * rp.delta, rp.delta, rp.inv) : 0.0f;
+                    if (valid) {
+                        p_du += gj * (pin ? (pc - pu) : pc);
+                        p_out += pin ? 0.0f : gj;
+                    }
+                    float gzj = gt;
+                    if (P.act == FQSS_ACT_PRELU) {
+                        const bool pos = pzv[e] > 0.0f;
+                        gzj = pos ? gt : pslope * gt;
+                        if (valid && !pos) p_slope += pzv[e] * gt;
+                    } else if (P.act == FQSS_ACT_RELU) {
+                        gzj = (t > 0.0f) ? gt : 0.0f;
+                    }
+                    o[e] = gzj;
+                    if (valid) p_bias += gzj;
+                }
             }
             *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (fuse && P.gbias != nullptr) {   // workgroup-uniform branch
+            float pb[1] = {p_bias};
+            block_sum<float, 1>(pb, predf);
+            if (threadIdx.x == 0) atomicAdd(&P.gbias[c], pb[0]);
+        }
+    }
+    if (fuse) {
+        double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
+        block_sum<double, 3>(v, pred);
+        if (threadIdx.x == 0) {
+            double* slot = P.gacc + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) % kSlots);
+            const double dmax = v[0] / 255.0;
+            atomicAdd(&slot[0], v[1] - dmax);   // workgroups share slots modulo kSlots: order-insensitive in fp64
+            atomicAdd(&slot[1], dmax);
+            if (P.act == FQSS_ACT_PRELU) atomicAdd(&slot[2], v[2]);
         }
     }
 }
@@ -808,10 +868,10 @@ extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float*
     return launch_status("fqss_gnq_fwd");
 }
 
-extern "C" int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
+static int gnq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
                             const float* gamma, const float* beta, const float* mean_rstd, float* gx, float* ggamma,
                             float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin,
-                            const float* qmax, double* gacc, double* ws, fqss_stream_t stream) {
+                            const float* qmax, double* gacc, double* ws, const GnProducer& P, fqss_stream_t stream) {
     FQSS_REQUIRE(xc && qmin_x && qmax_x && g && gamma && beta && mean_rstd && gx && ggamma && gbeta && qmin && qmax && gacc && ws,
                  "null pointer");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_g >= M && ld_gx >= M, "bad shape");
@@ -825,8 +885,28 @@ extern "C" int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float*
                        ggamma, gbeta);
     const int64_t rows = (int64_t)B * C;
     hipLaunchKernelGGL(k_gnq_bwd_apply, grid_rows(rows, M, 4), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C, M,
-                       ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax);
-    return launch_status("fqss_gnq_bwd");
+                       ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P);
+    return launch_status(who);
+}
+
+extern "C" int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
+                            const float* gamma, const float* beta, const float* mean_rstd, float* gx, float* ggamma,
+                            float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin,
+                            const float* qmax, double* gacc, double* ws, fqss_stream_t stream) {
+    return gnq_bwd_impl("fqss_gnq_bwd", xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, gx, ggamma, gbeta, B, C, M, ld_xc, ld_g,
+                        ld_gx, qmin, qmax, gacc, ws, GnProducer{}, stream);
+}
+
+extern "C" int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g, const float* gamma,
+                              const float* beta, const float* mean_rstd, float* gz, float* ggamma, float* gbeta, int B, int C,
+                              int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gz, const float* qmin, const float* qmax,
+                              double* gacc, double* ws, const float* pz, int64_t ld_pz, int pact, const float* pslope,
+                              double* pgacc, float* pgbias, fqss_stream_t stream) {
+    FQSS_REQUIRE(pz && pgacc && aligned16(pz) && ld_pz % 4 == 0 && ld_pz >= ((M + 3) & ~3), "producer z: 16-B aligned rows");
+    FQSS_REQUIRE(pact != FQSS_ACT_PRELU || pslope, "PReLU needs a slope");
+    GnProducer P{pz, ld_pz, pact, pslope, qmin_x, qmax_x, pgacc, pgbias};
+    return gnq_bwd_impl("fqss_gnq_bwd_p", xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, gz, ggamma, gbeta, B, C, M, ld_xc, ld_g,
+                        ld_gz, qmin, qmax, gacc, ws, P, stream);
 }
 
 extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,

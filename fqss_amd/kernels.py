@@ -360,13 +360,23 @@ def _aligned_grad(g):
     return g, ld
 
 
-def gnq_bwd(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, gacc, ggamma, gbeta):
+def gnq_bwd(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, gacc, ggamma, gbeta, producer=None):
+    """producer = (z, act, slope, gacc, gbias) of the layer that made xc: the result is then THAT layer's gz (its
+    output-quantizer / non-linearity backward applied on the fly, its partials accumulated) instead of gx"""
     B, C, M, ld_xc = _codes3(xc)
     g, ld_g = _aligned_grad(g)
     gx = empty_act((B, C, M), xc.device)
     ws = torch.empty(2 * B * C + 2 * B, device=xc.device, dtype=torch.float64)
-    _lib.call("fqss_gnq_bwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(g), _p(gamma), _p(beta), _p(mean_rstd), _p(gx),
-              _p(ggamma), _p(gbeta), B, C, M, ld_xc, ld_g, rowmat(gx)[2], _p(qmin), _p(qmax), _p(gacc), _p(ws), _stream())
+    if producer is None:
+        _lib.call("fqss_gnq_bwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(g), _p(gamma), _p(beta), _p(mean_rstd), _p(gx),
+                  _p(ggamma), _p(gbeta), B, C, M, ld_xc, ld_g, rowmat(gx)[2], _p(qmin), _p(qmax), _p(gacc), _p(ws), _stream())
+    else:
+        pz, pact, pslope, pgacc, pgbias = producer
+        rz = rowmat(pz)
+        assert tuple(pz.shape) == (B, C, M) and rz is not None
+        _lib.call("fqss_gnq_bwd_p", _p(xc), _p(qmin_x), _p(qmax_x), _p(g), _p(gamma), _p(beta), _p(mean_rstd), _p(gx),
+                  _p(ggamma), _p(gbeta), B, C, M, ld_xc, ld_g, rowmat(gx)[2], _p(qmin), _p(qmax), _p(gacc), _p(ws),
+                  _p(pz), rz[2], pact, _p(pslope), _p(pgacc), _p(pgbias), _stream())
     return gx
 
 

@@ -19,13 +19,14 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
         self.idx = None         # u8 codes of the output produced by this call (QUANT mode)
         self.carrier = False    # True: the fp32 output of this call is an uninitialised carrier (codes-only fast path)
         self.keep_out = False   # force a real fp32 output even in the fast path (model outputs)
+        self.prod = None        # _Producer: lets the NEXT layer's backward run this layer's epilogue backward (see below)
 
 
 class ActCodes:
@@ -43,7 +44,23 @@ def tag_codes(y, q):
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
         y._fqss_carrier = q.carrier
         q.idx = None
+        if q.prod is not None:
+            y._fqss_prod, q.prod = q.prod, None
     return y
+
+
+class _Producer:
+    """What the NEXT layer needs in order to run THIS layer's epilogue backward (output fake-quant STE + non-linearity)
+    inside its own backward kernel: handed over only along a HipSequential edge whose consumer is a GroupNormQ
+    (NEXT_IS_GROUPNORM), i.e. where the produced tensor provably has that single consumer."""
+    __slots__ = ("z", "act", "slope", "slope_param", "q", "bias_param", "bias", "fused")
+
+    def __init__(self, z, act, slope, slope_param, q, bias_param, bias):
+        self.z, self.act, self.slope, self.slope_param, self.q, self.bias_param, self.bias = z, act, slope, slope_param, q, bias_param, bias
+        self.fused = False   # set by the consumer's backward: the gradient it returned already IS this layer's gz
+
+
+NEXT_IS_GROUPNORM = False   # set by HipSequential around the forward of a module followed by a GroupNormQ
 
 
 def codes_of(x):
@@ -290,6 +307,10 @@ class LinearActQ(Function):
             else:
                 z = _lin_fwd(L, x, w, bias)
             out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
+        ctx.prod = None
+        if NEXT_IS_GROUPNORM and DEFER is not None and q.qmode == Q_QUANT and not ctx.plain and q.owner is not None \
+                and getattr(q.owner, "_fqss_deferred", False):
+            ctx.prod = q.prod = _Producer(z, act, slope, L.slope_param, q, L.b_param, bias)
         ctx.x_shape = x.shape
         ctx.save_for_backward(None if (ctx.xq is not None and ctx.wc is not None) else x, w, None if ctx.plain else z, slope)
         ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
@@ -301,7 +322,12 @@ class LinearActQ(Function):
     def backward(ctx, g):
         x, w, z, slope = ctx.saved_tensors
         L, act, q = ctx.L, ctx.act, ctx.q
-        if ctx.plain and not ctx.has_bias:
+        if ctx.prod is not None and ctx.prod.fused:
+            # the consumer's backward (fqss_gnq_bwd_p) already pushed its gradient through this layer's output quantizer
+            # and non-linearity and accumulated the range / slope / bias partials: g IS gz
+            gz, g_slope, g_min, g_max, g_bias = g, None, None, None, None
+            _touch(L.slope_param if act == ACT_PRELU else None, q.owner.min_range, q.owner.max_range, L.b_param)
+        elif ctx.plain and not ctx.has_bias:
             gz, g_slope, g_min, g_max, g_bias = g, None, None, None, None
         else:
             gz, g_slope, g_min, g_max, g_bias = _epilogue_bwd(
@@ -374,6 +400,7 @@ class GroupNormActQ(Function):
     def forward(ctx, x, gamma, beta, qmin, qmax, eps, q, gamma_param, beta_param, xq=None):
         ctx.q, ctx.gp, ctx.bp = q, gamma_param, beta_param
         ctx.coded = xq is not None and q.qmode == Q_QUANT
+        ctx.prod = getattr(x, "_fqss_prod", None) if ctx.coded else None
         if ctx.coded:
             q.carrier = FAST and not q.keep_out
             out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier)
@@ -392,7 +419,14 @@ class GroupNormActQ(Function):
             gamma, beta, mean_rstd, xc, xmin, xmax, qmin, qmax = ctx.saved_tensors
             gg, gg_direct = _grad_buf(ctx.gp, gamma)
             gb, gb_direct = _grad_buf(ctx.bp, gamma)
-            gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb)
+            producer = None
+            pr = ctx.prod
+            if pr is not None and ctx.needs_input_grad[0]:
+                pgb, direct = (None, True) if pr.bias is None else _grad_buf(pr.bias_param, pr.bias)
+                if direct and pr.q.gacc is not None:      # partials go straight into the arena / the quantizer's slots
+                    producer = (pr.z, pr.act, pr.slope, pr.q.gacc, pgb)
+                    pr.fused = True
+            gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb, producer=producer)
             _, g_min, g_max = _flush_ranges(q, None, None, ACT_NONE)
             return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
         x, gamma, z, mean_rstd = ctx.saved_tensors

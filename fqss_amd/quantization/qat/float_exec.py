@@ -36,6 +36,13 @@ class HipSequential(nn.Sequential):
                 x = QL.run_conv1d(m, x, m.weight, mods[i + 1], None)
                 i += 2
                 continue
-            x = apply_module(m, x)
+            # a Sequential edge has exactly one consumer: when it is a GroupNormQ, the producer hands over what that
+            # layer's backward needs to run the producer's epilogue backward on the fly (ops._Producer)
+            nxt = next((n for n in mods[i + 1:] if not isinstance(n, nn.Identity)), None)
+            QL.ops.NEXT_IS_GROUPNORM = isinstance(nxt, QL.GroupNormQ)
+            try:
+                x = apply_module(m, x)
+            finally:
+                QL.ops.NEXT_IS_GROUPNORM = False
             i += 1
         return x

@@ -223,6 +223,15 @@ int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, co
                  float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g,
                  int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, double* ws,
                  fqss_stream_t stream);
+/* fqss_gnq_bwd that ALSO runs the epilogue backward of the layer that produced xc (its pre-quant output pz, its
+ * non-linearity; its output quantizer is (qmin_x, qmax_x)): writes that producer's gz instead of gx and accumulates
+ * its range/slope partials (pgacc) and bias gradient (pgbias[C], nullable) -- replaces a separate fqss_actq_bwd pass */
+int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
+                   const float* gamma, const float* beta, const float* mean_rstd, float* gz, float* ggamma,
+                   float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gz,
+                   const float* qmin, const float* qmax, double* gacc, double* ws, const float* pz,
+                   int64_t ld_pz, int pact, const float* pslope, double* pgacc, float* pgbias,
+                   fqss_stream_t stream);
 int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
                  const float* bias, uint8_t* yc, float* yout, int B, int C, int M, int K, int dil,
                  int pad, int64_t ld_xc, int64_t ld_yc, int64_t ld_out, int act, const float* slope,

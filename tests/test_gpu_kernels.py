@@ -376,6 +376,22 @@ def test_gnq_coded(B, C, M):
     sc = float(g.abs().sum()) * 2e-5 + 1e-4
     np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=5e-3, atol=sc)
     np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=5e-3, atol=sc)
+    # fqss_gnq_bwd_p: the same backward that also runs the PRODUCER's epilogue backward (a conv + PReLU + fake-quant whose
+    # output codes are xc) == fqss_gnq_bwd followed by fqss_actq_bwd on the producer's pre-quant z
+    cu = lambda t: t.cuda()
+    slope = torch.tensor([0.3], device="cuda")
+    xv = x.cuda()
+    pz = padded(torch.where(xv > 0, xv, xv / 0.3) + 0.3 * float(delta) * rnd(B, C, M, seed=9).cuda())   # a z that quantizes to ~xc
+    pg_ref, pb_ref = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda"), torch.zeros(C, device="cuda")
+    gz_ref = K.actq_bwd(pz, gx, K.ACT_PRELU, slope, K.Q_QUANT, cu(xlo), cu(xhi), pg_ref, gbias=pb_ref, C=C)
+    gacc2, pg, pb = torch.zeros_like(gacc), torch.zeros_like(pg_ref), torch.zeros(C, device="cuda")
+    gg2, gb2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    gz = K.gnq_bwd(xc, cu(xlo), cu(xhi), padded(g), cu(gm), cu(bt), mr, cu(ylo), cu(yhi), gacc2, gg2, gb2,
+                   producer=(pz, K.ACT_PRELU, slope, pg, pb))
+    assert torch.equal(gz.cpu(), gz_ref.cpu())                       # same arithmetic, element for element
+    close(pb, pb_ref, rtol=1e-4, atol=1e-5 * float(pb_ref.abs().max()) + 1e-6)
+    np.testing.assert_allclose(pg.view(-1, 3).sum(0).cpu().numpy(), pg_ref.view(-1, 3).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
+    assert torch.equal(gg2.cpu(), gg.cpu()) and torch.equal(gacc2.view(-1, 3).sum(0).cpu(), gacc.view(-1, 3).sum(0).cpu())
 
 
 @pytest.mark.parametrize("B,C,M,dil", [(2, 32, 77, 1), (2, 32, 77, 4), (1, 512, 999, 128), (3, 7, 130, 2)])
