@@ -39,6 +39,8 @@ _PROTOS = {
     "fqss_decode": [P, P, I64, I64, I64, I64, P, P, P],
     "fqss_gnq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P],
     "fqss_gnq_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],
+    "fqss_ewq_bwd_p": [P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, P, P, I32,
+                       P, I64, I32, P, P, P, P, I64, P, I64, I32, P, P, P, P, I64, P],
     "fqss_gnq_bwd_p": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P, I64, I32, P, P, P, P],
     "fqss_dwq_fwd": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P],
     "fqss_dwq_bwd_z": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],

@@ -278,8 +278,8 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
             }
             *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (fuse && P.gbias != nullptr) {   // workgroup-uniform branch
-            float pb[1] = {p_bias};
+        if (fuse && P.gbias != nullptr) {   // workgroup-uniform branch; ONE atomic per row chunk (per-wave atomics on
+            float pb[1] = {p_bias};         // the same 512 addresses cost 1.6 ms/step: same-address atomics serialise)
             block_sum<float, 1>(pb, predf);
             if (threadIdx.x == 0) atomicAdd(&P.gbias[c], pb[0]);
         }
@@ -730,22 +730,64 @@ __global__ __launch_bounds__(256) void k_ewq_fwd(const uint8_t* __restrict__ ac,
 }
 
 // backward: recompute z from the input codes; gz = STE(act') ; range/slope partials to the gacc slots
+// An operand that is the fake-quantized output of a pointwise conv (res / skip conv of a TCN block) can have THAT
+// layer's epilogue backward done here (cf. GnProducer): its gz goes to `out`, its partials to its own slots / bias.
+struct EwProducer {
+    const float* pz; int ld_pz;      // producer's pre-quant output (NULL: operand not fused)
+    int act; const float* slope;
+    double* gacc; float* gbias;      // gbias [C] nullable
+    float* out; int ld_out;          // the producer's gz
+};
+
+__device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRange& rp, float pslope, float pz, float gj, bool valid,
+                                                 float& p_du, float& p_out, float& p_slope, float& p_bias) {
+    const float t = act_apply(pz, P.act, pslope);
+    float pc, pu;
+    bool pin;
+    (void)fq_asym(t, rp, pc, pu, pin);
+    const float gt = pin ? div_by(gj * rp.delta, rp.delta, rp.inv) : 0.0f;
+    if (valid) {
+        p_du += gj * (pin ? (pc - pu) : pc);
+        p_out += pin ? 0.0f : gj;
+    }
+    float gzj = gt;
+    if (P.act == FQSS_ACT_PRELU) {
+        const bool pos = pz > 0.0f;
+        gzj = pos ? gt : pslope * gt;
+        if (valid && !pos) p_slope += pz * gt;
+    } else if (P.act == FQSS_ACT_RELU) {
+        gzj = (t > 0.0f) ? gt : 0.0f;
+    }
+    if (valid) p_bias += gzj;
+    return gzj;
+}
+
 __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
                                                   const float* __restrict__ bf, float sb, const float* __restrict__ g,
                                                   float* __restrict__ gz, int rows, int cols, int ld_a, int ld_b, int ld_bf,
                                                   int ld_g, int ld_gz, int act, const float* slope_p, const float* amin,
                                                   const float* amax, const float* bmin, const float* bmax, const float* qmin,
-                                                  const float* qmax, double* gacc) {
+                                                  const float* qmax, double* gacc, EwProducer PA, EwProducer PB, int C) {
     __shared__ double red[3 * 4];
+    __shared__ float redf[2 * 4];
+    const bool fa = PA.pz != nullptr, fb = PB.pz != nullptr;
+    const float sla = (fa && PA.act == FQSS_ACT_PRELU) ? *PA.slope : 0.0f, slb = (fb && PB.act == FQSS_ACT_PRELU) ? *PB.slope : 0.0f;
+    float a_du = 0.f, a_out = 0.f, a_sl = 0.f, b_du = 0.f, b_out = 0.f, b_sl = 0.f;
     const QRange ra = load_qrange(amin, amax), ry = load_qrange(qmin, qmax);
     QRange rb{0.f, 1.f, 1.f};
     if (bc != nullptr) rb = load_qrange(bmin, bmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        float a_bias = 0.f, b_bias = 0.f;
         for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < cols; c0 += gridDim.x * 256 * 4) {
             const unsigned int wa = *reinterpret_cast<const unsigned int*>(ac + (int64_t)row * ld_a + c0);
             const unsigned int wb = bc ? *reinterpret_cast<const unsigned int*>(bc + (int64_t)row * ld_b + c0) : 0u;
+            float4 za4 = make_float4(0.f, 0.f, 0.f, 0.f), zb4 = za4;
+            if (fa) za4 = *reinterpret_cast<const float4*>(PA.pz + (int64_t)row * PA.ld_pz + c0);
+            if (fb) zb4 = *reinterpret_cast<const float4*>(PB.pz + (int64_t)row * PB.ld_pz + c0);
+            const float zav[4] = {za4.x, za4.y, za4.z, za4.w}, zbv[4] = {zb4.x, zb4.y, zb4.z, zb4.w};
+            float oa[4], ob[4];
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (bf != nullptr) {
                 const float4 t = *reinterpret_cast<const float4*>(bf + (int64_t)row * ld_bf + c0);
@@ -779,8 +821,21 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
                     gzj = (t > 0.0f) ? gt : 0.0f;
                 }
                 o[e] = gzj;
+                // d/da = gz, d/db = sb * gz (sb == 1 whenever b is fused): the producers' epilogue backward on it
+                if (fa) oa[e] = ew_producer_bwd(PA, ra, sla, zav[e], valid ? gzj : 0.0f, valid, a_du, a_out, a_sl, a_bias);
+                if (fb) ob[e] = ew_producer_bwd(PB, rb, slb, zbv[e], valid ? gzj : 0.0f, valid, b_du, b_out, b_sl, b_bias);
             }
-            *reinterpret_cast<float4*>(gz + (int64_t)row * ld_gz + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (gz != nullptr) *reinterpret_cast<float4*>(gz + (int64_t)row * ld_gz + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (fa) *reinterpret_cast<float4*>(PA.out + (int64_t)row * PA.ld_out + c0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+            if (fb) *reinterpret_cast<float4*>(PB.out + (int64_t)row * PB.ld_out + c0) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+        }
+        if ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr)) {   // workgroup-uniform; one atomic per row chunk
+            float pb[2] = {a_bias, b_bias};
+            block_sum<float, 2>(pb, redf);
+            if (threadIdx.x == 0) {
+                if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[row % C], pb[0]);
+                if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[row % C], pb[1]);
+            }
         }
     }
     double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
@@ -791,6 +846,22 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
         slot[0] += v[1] - dmax;
         slot[1] += dmax;
         slot[2] += v[2];
+    }
+    if (fa || fb) {
+        const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;   // < kSlots: one workgroup per slot, like above
+        double va[3] = {(double)a_du, (double)a_out, (double)a_sl}, vb[3] = {(double)b_du, (double)b_out, (double)b_sl};
+        block_sum<double, 3>(va, red);
+        block_sum<double, 3>(vb, red);
+        if (threadIdx.x == 0) {
+            if (fa) {
+                const double dmax = va[0] / 255.0;
+                PA.gacc[3 * sid] += va[1] - dmax; PA.gacc[3 * sid + 1] += dmax; PA.gacc[3 * sid + 2] += va[2];
+            }
+            if (fb) {
+                const double dmax = vb[0] / 255.0;
+                PB.gacc[3 * sid] += vb[1] - dmax; PB.gacc[3 * sid + 1] += dmax; PB.gacc[3 * sid + 2] += vb[2];
+            }
+        }
     }
 }
 
@@ -1006,14 +1077,16 @@ extern "C" int fqss_ewq_fwd(const uint8_t* ac, const float* amin, const float* a
     return launch_status("fqss_ewq_fwd");
 }
 
-extern "C" int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,
+static int ewq_bwd_impl(const char* who, const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,
                             const float* bmax, const float* bf, float sb, const float* g, float* gz, int64_t rows, int64_t cols,
                             int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_g, int64_t ld_gz, int act, const float* slope,
-                            const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
-    FQSS_REQUIRE(ac && amin && amax && g && gz && qmin && qmax && gacc, "null pointer");
+                            const float* qmin, const float* qmax, double* gacc, const EwProducer& PA, const EwProducer& PB, int C,
+                            fqss_stream_t stream) {
+    FQSS_REQUIRE(ac && amin && amax && g && (gz || (PA.pz && PB.pz)) && qmin && qmax && gacc, "null pointer");
+    if (gz == nullptr) ld_gz = 4 * ((cols + 3) / 4);
     FQSS_REQUIRE(!(bc && bf) && (!bc || (bmin && bmax)), "bad second operand");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && rows < (1ll << 30) && ld_a < (1ll << 30), "bad shape");
-    FQSS_REQUIRE(codes_ok(ac, ld_a) && (!bc || codes_ok(bc, ld_b)) && aligned16(g) && aligned16(gz) && ld_g % 4 == 0 &&
+    FQSS_REQUIRE(codes_ok(ac, ld_a) && (!bc || codes_ok(bc, ld_b)) && aligned16(g) && (!gz || aligned16(gz)) && ld_g % 4 == 0 &&
                      ld_gz % 4 == 0 && ld_g >= ((cols + 3) & ~3) && ld_gz >= ((cols + 3) & ~3), "rows must be 16-B aligned");
     FQSS_REQUIRE(!bf || (aligned16(bf) && ld_bf % 4 == 0 && ld_bf >= ((cols + 3) & ~3)), "bad fp32 operand rows");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
@@ -1024,6 +1097,37 @@ extern "C" int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* a
     if (gy > rows) gy = rows;
     hipLaunchKernelGGL(k_ewq_bwd, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
                        (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
-                       bmin, bmax, qmin, qmax, gacc);
-    return launch_status("fqss_ewq_bwd");
+                       bmin, bmax, qmin, qmax, gacc, PA, PB, C > 0 ? C : 1);
+    return launch_status(who);
+}
+
+extern "C" int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,
+                            const float* bmax, const float* bf, float sb, const float* g, float* gz, int64_t rows, int64_t cols,
+                            int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_g, int64_t ld_gz, int act, const float* slope,
+                            const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+    return ewq_bwd_impl("fqss_ewq_bwd", ac, amin, amax, bc, bmin, bmax, bf, sb, g, gz, rows, cols, ld_a, ld_b, ld_bf, ld_g, ld_gz, act,
+                        slope, qmin, qmax, gacc, EwProducer{}, EwProducer{}, 1, stream);
+}
+
+/* operands a / b that are outputs of pointwise convs: p?_z != NULL runs that producer's epilogue backward here (its gz ->
+ * p?_out, partials -> p?_gacc / p?_gbias[C]); gz (plain dL/d(a+sb*b)) may be NULL when both operands are fused */
+extern "C" int fqss_ewq_bwd_p(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,
+                              const float* bmax, float sb, const float* g, float* gz, int64_t rows, int64_t cols, int64_t ld_a,
+                              int64_t ld_b, int64_t ld_g, int64_t ld_gz, int act, const float* slope, const float* qmin,
+                              const float* qmax, double* gacc, int C, const float* pa_z, int64_t ld_paz, int pa_act,
+                              const float* pa_slope, double* pa_gacc, float* pa_gbias, float* pa_out, int64_t ld_pa_out,
+                              const float* pb_z, int64_t ld_pbz, int pb_act, const float* pb_slope, double* pb_gacc,
+                              float* pb_gbias, float* pb_out, int64_t ld_pb_out, fqss_stream_t stream) {
+    FQSS_REQUIRE(pa_z || pb_z, "no producer given");
+    FQSS_REQUIRE(!pb_z || (bc && sb == 1.0f), "operand b can only be fused for a coded b with sb == 1");
+    FQSS_REQUIRE(C > 0 && rows % C == 0, "rows must be batch x channels");
+    const int64_t c4 = (cols + 3) & ~3ll;
+    FQSS_REQUIRE(!pa_z || (pa_gacc && pa_out && aligned16(pa_z) && aligned16(pa_out) && ld_paz % 4 == 0 && ld_pa_out % 4 == 0 &&
+                           ld_paz >= c4 && ld_pa_out >= c4 && (pa_act != FQSS_ACT_PRELU || pa_slope)), "bad producer a");
+    FQSS_REQUIRE(!pb_z || (pb_gacc && pb_out && aligned16(pb_z) && aligned16(pb_out) && ld_pbz % 4 == 0 && ld_pb_out % 4 == 0 &&
+                           ld_pbz >= c4 && ld_pb_out >= c4 && (pb_act != FQSS_ACT_PRELU || pb_slope)), "bad producer b");
+    EwProducer PA{pa_z, (int)ld_paz, pa_act, pa_slope, pa_gacc, pa_gbias, pa_out, (int)ld_pa_out};
+    EwProducer PB{pb_z, (int)ld_pbz, pb_act, pb_slope, pb_gacc, pb_gbias, pb_out, (int)ld_pb_out};
+    return ewq_bwd_impl("fqss_ewq_bwd_p", ac, amin, amax, bc, bmin, bmax, nullptr, sb, g, gz, rows, cols, ld_a, ld_b, 0, ld_g, ld_gz,
+                        act, slope, qmin, qmax, gacc, PA, PB, C, stream);
 }

@@ -419,6 +419,29 @@ def ewq_fwd(ac, amin, amax, bc, bmin, bmax, bf, sb, act, slope, qmin, qmax, writ
     return out, yc
 
 
+def ewq_bwd_p(ac, amin, amax, bc, bmin, bmax, sb, g, act, slope, qmin, qmax, gacc, C, prod_a=None, prod_b=None):
+    """ewq_bwd with the epilogue backward of the layers that produced operand a and/or b fused in.
+    prod = (z, act, slope, gacc, gbias) -> returns (gz or None, gz_of_producer_a or None, gz_of_producer_b or None)"""
+    rows, cols, ld_a = _codes2(ac)
+    ld_b = _codes2(bc)[2] if bc is not None else 0
+    g, ld_g = _aligned_grad(g)
+    need_plain = prod_a is None or (bc is not None and prod_b is None)
+    gz = empty_act(tuple(ac.shape), ac.device) if need_plain else None
+    outs, args = [], []
+    for pr in (prod_a, prod_b):
+        if pr is None:
+            outs.append(None)
+            args += [None, 0, 0, None, None, None, None, 0]
+        else:
+            z, pact, pslope, pgacc, pgbias = pr
+            o = empty_act(tuple(ac.shape), ac.device)
+            outs.append(o)
+            args += [_p(z), rowmat(z)[2], pact, _p(pslope), _p(pgacc), _p(pgbias), _p(o), rowmat(o)[2]]
+    _lib.call("fqss_ewq_bwd_p", _p(ac), _p(amin), _p(amax), _p(bc), _p(bmin), _p(bmax), float(sb), _p(g), _p(gz), rows, cols, ld_a,
+              ld_b, ld_g, rowmat(gz)[2] if gz is not None else 0, act, _p(slope), _p(qmin), _p(qmax), _p(gacc), C, *args, _stream())
+    return gz, outs[0], outs[1]
+
+
 def ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, sb, g, act, slope, qmin, qmax, gacc):
     rows, cols, ld_a = _codes2(ac)
     ld_b = _codes2(bc)[2] if bc is not None else 0

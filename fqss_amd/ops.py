@@ -8,6 +8,8 @@ Parameter gradients: when a parameter carries ``_fqss_direct = True`` and a pre-
 (see fqss_amd.runtime.ParamArena) the kernels accumulate ("+=") straight into it and the Function
 returns ``None`` for that input; otherwise a fresh zero buffer is filled and returned to autograd.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -60,7 +62,17 @@ class _Producer:
         self.fused = False   # set by the consumer's backward: the gradient it returned already IS this layer's gz
 
 
+FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
+FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
 NEXT_IS_GROUPNORM = False   # set by HipSequential around the forward of a module followed by a GroupNormQ
+
+
+def _producer_args(pr):
+    """(z, act, slope, gacc, gbias) for the fused-producer kernels, or None when the partials cannot go in place"""
+    if pr is None or pr.q.gacc is None:
+        return None
+    pgb, direct = (None, True) if pr.bias is None else _grad_buf(pr.bias_param, pr.bias)
+    return (pr.z, pr.act, pr.slope, pr.q.gacc, pgb) if direct else None
 
 
 def codes_of(x):
@@ -308,7 +320,7 @@ class LinearActQ(Function):
                 z = _lin_fwd(L, x, w, bias)
             out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
         ctx.prod = None
-        if NEXT_IS_GROUPNORM and DEFER is not None and q.qmode == Q_QUANT and not ctx.plain and q.owner is not None \
+        if FUSE_GN and NEXT_IS_GROUPNORM and DEFER is not None and q.qmode == Q_QUANT and not ctx.plain and q.owner is not None \
                 and getattr(q.owner, "_fqss_deferred", False):
             ctx.prod = q.prod = _Producer(z, act, slope, L.slope_param, q, L.b_param, bias)
         ctx.x_shape = x.shape
@@ -360,7 +372,7 @@ class LinearActQPair(Function):
     Only in the quantizing phase with a runtime.QuantTables active (concatenated weight codes)."""
 
     @staticmethod
-    def forward(ctx, x, b1, b2, qmin1, qmax1, qmin2, qmax2, L1, L2, q1, q2, xq, pair):
+    def forward(ctx, x, b1, b2, qmin1, qmax1, qmin2, qmax2, L1, L2, q1, q2, xq, pair, sole_ew=False):
         Co1 = pair.Co1
         if _fuse_out_quant(q1) and _fuse_out_quant(q2) and Co1 % 32 == 0:
             z1, z2, q1.idx, q2.idx = K.qpw_fwdq(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1, ACT_NONE, None,
@@ -374,22 +386,34 @@ class LinearActQPair(Function):
             out2 = _epilogue_fwd(z2, ACT_NONE, None, q2)
         ctx.save_for_backward(z1, z2)
         ctx.L, ctx.q, ctx.b, ctx.xq, ctx.pair = (L1, L2), (q1, q2), (b1, b2), xq, pair
+        ctx.prods = (None, None)
+        if FUSE_EW and sole_ew and all(getattr(q.owner, "_fqss_deferred", False) for q in (q1, q2)):
+            # each output has ONE consumer, an element-wise LayerQ (residual AddQ / skip sum): that layer's backward
+            # kernel will also run this layer's output-quantizer backward (ops._Producer)
+            ctx.prods = (_Producer(z1, ACT_NONE, None, None, q1, L1.b_param, b1), _Producer(z2, ACT_NONE, None, None, q2, L2.b_param, b2))
+            q1.prod, q2.prod = ctx.prods
         return out1, out2
 
     @staticmethod
     def backward(ctx, g1, g2):
         z = ctx.saved_tensors
+        g_in = (g1, g2)
         gs, gz, gbias, gmin, gmax = [g1, g2], [], [], [], []
         for i in range(2):
             if gs[i] is None:      # an unused output (the last block's residual): its gradient is zero
                 gs[i] = K.empty_act(tuple(z[i].shape), z[i].device).zero_()
             L, q, b = ctx.L[i], ctx.q[i], ctx.b[i]
+            if ctx.prods[i] is not None and ctx.prods[i].fused and g_in[i] is not None:
+                # the consumer's backward already ran this layer's epilogue backward: the incoming gradient IS gz
+                _touch(q.owner.min_range, q.owner.max_range, L.b_param)
+                gz.append(gs[i]); gbias.append(None); gmin.append(None); gmax.append(None)
+                continue
             gzi, _, g_min, g_max, g_bias = _epilogue_bwd(z[i], gs[i], ACT_NONE, None, None, q, bias_param=L.b_param,
                                                           bias_like=b, C=z[i].shape[1])
             gz.append(gzi); gbias.append(g_bias); gmin.append(g_min); gmax.append(g_max)
         gx = K.qpw_bwd_x2(gz[0], gz[1], ctx.pair.wc) if ctx.needs_input_grad[0] else None
         K.qpw_bwd_w2(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
-        return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None
+        return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None, None
 
 
 class GroupNormActQ(Function):
@@ -419,13 +443,9 @@ class GroupNormActQ(Function):
             gamma, beta, mean_rstd, xc, xmin, xmax, qmin, qmax = ctx.saved_tensors
             gg, gg_direct = _grad_buf(ctx.gp, gamma)
             gb, gb_direct = _grad_buf(ctx.bp, gamma)
-            producer = None
-            pr = ctx.prod
-            if pr is not None and ctx.needs_input_grad[0]:
-                pgb, direct = (None, True) if pr.bias is None else _grad_buf(pr.bias_param, pr.bias)
-                if direct and pr.q.gacc is not None:      # partials go straight into the arena / the quantizer's slots
-                    producer = (pr.z, pr.act, pr.slope, pr.q.gacc, pgb)
-                    pr.fused = True
+            producer = _producer_args(ctx.prod) if ctx.needs_input_grad[0] else None
+            if producer is not None:
+                ctx.prod.fused = True
             gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb, producer=producer)
             _, g_min, g_max = _flush_ranges(q, None, None, ACT_NONE)
             return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
@@ -492,18 +512,35 @@ class EwQ(Function):
         ctx.save_for_backward(aq_.idx, aq_.qmin, aq_.qmax, bq_.idx if bq_ else None, bq_.qmin if bq_ else None,
                               bq_.qmax if bq_ else None, bf, slope, qmin, qmax)
         ctx.sb, ctx.act, ctx.q, ctx.sp, ctx.has_b = sb, act, q, slope_param, b is not None
+        # operands that are fresh outputs of pointwise convs with no other consumer (tagged by run_conv1d_pair)
+        ctx.prod_a = getattr(a, "_fqss_prod", None)
+        ctx.prod_b = getattr(b, "_fqss_prod", None) if (b is not None and bq_ is not None and sb == 1.0) else None
         return _carrier(out) if q.carrier else out
 
     @staticmethod
     def backward(ctx, g):
         ac, amin, amax, bc, bmin, bmax, bf, slope, qmin, qmax = ctx.saved_tensors
         q = ctx.q
-        gz = K.ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, ctx.sb, g, ctx.act, slope, qmin, qmax, q.gacc)
+        pa = _producer_args(ctx.prod_a) if ctx.needs_input_grad[0] else None
+        pb = _producer_args(ctx.prod_b) if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        if (pa is not None or pb is not None) and bf is None and ac.dim() == 3:
+            # the producers' epilogue backward (output fake-quant STE, range / bias partials) rides in this kernel
+            gz, gza, gzb = K.ewq_bwd_p(ac, amin, amax, bc, bmin, bmax, ctx.sb, g, ctx.act, slope, qmin, qmax, q.gacc, ac.shape[1],
+                                       prod_a=pa, prod_b=pb)
+            if pa is not None:
+                ctx.prod_a.fused = True
+            if pb is not None:
+                ctx.prod_b.fused = True
+        else:
+            gz, gza, gzb = K.ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, ctx.sb, g, ctx.act, slope, qmin, qmax, q.gacc), None, None
         g_slope, g_min, g_max = _flush_ranges(q, slope, ctx.sp, ctx.act)
-        ga = gz if ctx.needs_input_grad[0] else None
+        ga = (gza if gza is not None else gz) if ctx.needs_input_grad[0] else None
         gb = None
         if ctx.has_b and ctx.needs_input_grad[1]:
-            gb = gz if ctx.sb == 1.0 else K.axpby(gz, gz, 0.0, sa=float(ctx.sb))
+            if gzb is not None:
+                gb = gzb
+            else:
+                gb = gz if ctx.sb == 1.0 else K.axpby(gz, gz, 0.0, sa=float(ctx.sb))
         return ga, gb, g_slope, g_min, g_max, None, None, None, None, None, None
 
 

@@ -40,7 +40,10 @@ class ConvBlock(nn.Module):
     def forward(self, x):
         x_blk, x_res = ops.fork2(x)
         f = self.shared_block(x_blk)
-        fused = run_conv1d_pair(self.res_conv, self.skip_conv, f)   # one GEMM for both (quantizing phase, graph mode)
+        # one GEMM for both (quantizing phase, graph mode); `residual` is consumed only by self.add below and `skip_out`
+        # only by the skip sum of MaskGenerator.forward (or dropped): their AddQ backward also runs these convs'
+        # output-quantizer backward
+        fused = run_conv1d_pair(self.res_conv, self.skip_conv, f, sole_ew_consumers=True)
         if fused is not None:
             residual, skip_out = fused
         else:

@@ -184,10 +184,11 @@ def run_conv1d(conv, x, weight, nl, aq):
     return ops.tag_codes(y, q)
 
 
-def run_conv1d_pair(l1, l2, x):
+def run_conv1d_pair(l1, l2, x, sole_ew_consumers=False):
     """(l1(x), l2(x)) for two Conv1dQ layers fed by the same tensor, as ONE fused node (ops.LinearActQPair);
     None when the fused path does not apply (observer phase, eager mode, float layers): the caller then runs
-    the two layers one by one."""
+    the two layers one by one.  sole_ew_consumers: the caller guarantees that each output is consumed by exactly one
+    element-wise LayerQ (AddQ), whose backward kernel may then run this layer's output-quantizer backward."""
     if ops.DEFER is None or type(l1) is not Conv1dQ or type(l2) is not Conv1dQ:
         return None
     pre = getattr(l1.conv1d.weight, "_fqss_wq", None)
@@ -206,7 +207,8 @@ def run_conv1d_pair(l1, l2, x):
     L1, L2 = conv1d_geometry(l1.conv1d), conv1d_geometry(l2.conv1d)
     for L, conv in ((L1, l1.conv1d), (L2, l2.conv1d)):
         L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, None
-    y1, y2 = ops.LinearActQPair.apply(x, l1.conv1d.bias, l2.conv1d.bias, q1.qmin, q1.qmax, q2.qmin, q2.qmax, L1, L2, q1, q2, xq, pair)
+    y1, y2 = ops.LinearActQPair.apply(x, l1.conv1d.bias, l2.conv1d.bias, q1.qmin, q1.qmax, q2.qmin, q2.qmax, L1, L2, q1, q2, xq, pair,
+                                      sole_ew_consumers)
     aqs[0].after_forward(q1)
     aqs[1].after_forward(q2)
     return ops.tag_codes(y1, q1), ops.tag_codes(y2, q2)

@@ -254,6 +254,18 @@ int fqss_ewq_bwd(const uint8_t* ac, const float* amin, const float* amax, const 
                  int64_t rows, int64_t cols, int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_g,
                  int64_t ld_gz, int act, const float* slope, const float* qmin, const float* qmax,
                  double* gacc, fqss_stream_t stream);
+/* fqss_ewq_bwd for operands that are the fake-quantized outputs of pointwise convs (the res / skip convs of a TCN block
+ * feeding AddQ, convtasnetq.py:42, 111-112): p?_z != NULL additionally runs THAT layer's epilogue backward on
+ * dL/d(operand) -- its gz goes to p?_out, its range/slope partials to p?_gacc, its bias gradient to p?_gbias[C]
+ * (nullable).  The operand's quantizer is (amin,amax) / (bmin,bmax).  gz may be NULL when both operands are fused. */
+int fqss_ewq_bwd_p(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc,
+                   const float* bmin, const float* bmax, float sb, const float* g, float* gz, int64_t rows,
+                   int64_t cols, int64_t ld_a, int64_t ld_b, int64_t ld_g, int64_t ld_gz, int act,
+                   const float* slope, const float* qmin, const float* qmax, double* gacc, int C,
+                   const float* pa_z, int64_t ld_paz, int pa_act, const float* pa_slope, double* pa_gacc,
+                   float* pa_gbias, float* pa_out, int64_t ld_pa_out, const float* pb_z, int64_t ld_pbz,
+                   int pb_act, const float* pb_slope, double* pb_gacc, float* pb_gbias, float* pb_out,
+                   int64_t ld_pb_out, fqss_stream_t stream);
 /* gw[C][K] += */
 int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
                    float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_gz,
