@@ -87,12 +87,27 @@ def build(dev, calib=False):
     cases.append(dict(kernel="k_dwq_bwd", label="student depthwise+PReLU+fq backward, C=512 (codes + fp32 g in, fp32 gx out)", bound="hbm", launches=24,
                       flops=0.0, rd=5.0 * NH * n, wr=4.0 * NH * n, survey=12.0 * NH * n,
                       fn=lambda: K.dwq_bwd(xc_h, lo, hi, w_dw, gm, gz_h, 4, 4, 1, slope, lo, hi, gacc, gbb, gw_dw)))
-    z_h, z_b = _act(NH, dev), _act(NB, dev)
-    gb_h, gb_b = torch.zeros(NH, device=dev), torch.zeros(NB, device=dev)
-    cases.append(dict(kernel="k_actq_bwd", label="activation fake-quant backward (STE + range grads + bias grad), C=512", bound="hbm", launches=24,
-                      flops=0.0, rd=8.0 * NH * n, wr=4.0 * NH * n, survey=12.0 * NH * n,
-                      fn=lambda: K.actq_bwd(z_h, gz_h, 1, slope, 2, lo, hi, gacc, gbias=gb_h, C=NH)))
-    cases.append(dict(kernel="k_actq_bwd", label="activation fake-quant backward (STE + range grads + bias grad), C=128", bound="hbm", launches=48,
+    # ---- gLN backward with the producing conv's epilogue backward fused in (two passes), and the AddQ backward that
+    #      also runs the res / skip convs' output-quantizer backward
+    z_h, z_b, z_b2 = _act(NH, dev), _act(NB, dev), _act(NB, dev)
+    gm_, bt_ = torch.rand(NH, device=dev) + 0.5, torch.randn(NH, device=dev) * 0.1
+    _, _, mr = K.gnq_fwd(xc_h, lo, hi, gm_, bt_, 1e-8, lo, hi, False)
+    gg, gb2 = torch.zeros(NH, device=dev), torch.zeros(NH, device=dev)
+    pgacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev)
+    pgb = torch.zeros(NH, device=dev)
+    cases.append(dict(kernel="k_gnq_bwd_rows+coef+apply", label="gLN+fq backward (2 passes) with the producer conv's STE/PReLU/range/bias backward fused, C=512",
+                      bound="hbm", launches=24, flops=0.0, rd=14.0 * NH * n, wr=4.0 * NH * n, survey=20.0 * NH * n,
+                      fn=lambda: K.gnq_bwd(xc_h, lo, hi, gz_h, gm_, bt_, mr, lo, hi, gacc, gg, gb2, producer=(z_h, 1, slope, pgacc, pgb))))
+    cases.append(dict(kernel="k_gnq_bwd_rows+coef+apply", label="gLN+fq backward (2 passes, plain), C=512", bound="hbm", launches=24,
+                      flops=0.0, rd=10.0 * NH * n, wr=4.0 * NH * n, survey=16.0 * NH * n,
+                      fn=lambda: K.gnq_bwd(xc_h, lo, hi, gz_h, gm_, bt_, mr, lo, hi, gacc, gg, gb2)))
+    xc_b2 = _codes(NB, dev)
+    pga, pgb_a, pgb_b = torch.zeros_like(pgacc), torch.zeros(NB, device=dev), torch.zeros(NB, device=dev)
+    cases.append(dict(kernel="k_ewq_bwd", label="AddQ backward with one operand's conv output-quantizer backward fused, C=128", bound="hbm", launches=48,
+                      flops=0.0, rd=10.0 * NB * n, wr=8.0 * NB * n, survey=16.0 * NB * n,
+                      fn=lambda: K.ewq_bwd_p(xc_b, lo, hi, xc_b2, lo, hi, 1.0, gz_b, 0, None, lo, hi, gacc, NB, prod_b=(z_b, 0, None, pga, pgb_b))))
+    gb_b = torch.zeros(NB, device=dev)
+    cases.append(dict(kernel="k_actq_bwd", label="activation fake-quant backward (bottleneck / mask convs), C=128", bound="hbm", launches=4,
                       flops=0.0, rd=8.0 * NB * n, wr=4.0 * NB * n, survey=12.0 * NB * n,
                       fn=lambda: K.actq_bwd(z_b, gz_b, 0, None, 2, lo, hi, gacc, gbias=gb_b, C=NB)))
     for c in cases:
