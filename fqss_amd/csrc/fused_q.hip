@@ -778,8 +778,12 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
     if (bc != nullptr) rb = load_qrange(bmin, bmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
+    // fused launches use gridDim.y == C: the rows of a workgroup (row = y, y + C, ...) are the batch entries of ONE
+    // channel, so the producers' bias sums are reduced once per workgroup instead of once per row
+    const bool per_channel = (int)gridDim.y == C;
+    float a_bias = 0.f, b_bias = 0.f;
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-        float a_bias = 0.f, b_bias = 0.f;
+        if (!per_channel) a_bias = b_bias = 0.f;
         for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < cols; c0 += gridDim.x * 256 * 4) {
             const unsigned int wa = *reinterpret_cast<const unsigned int*>(ac + (int64_t)row * ld_a + c0);
             const unsigned int wb = bc ? *reinterpret_cast<const unsigned int*>(bc + (int64_t)row * ld_b + c0) : 0u;
@@ -829,13 +833,21 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
             if (fa) *reinterpret_cast<float4*>(PA.out + (int64_t)row * PA.ld_out + c0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
             if (fb) *reinterpret_cast<float4*>(PB.out + (int64_t)row * PB.ld_out + c0) = make_float4(ob[0], ob[1], ob[2], ob[3]);
         }
-        if ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr)) {   // workgroup-uniform; one atomic per row chunk
+        if (!per_channel && ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr))) {   // workgroup-uniform
             float pb[2] = {a_bias, b_bias};
             block_sum<float, 2>(pb, redf);
             if (threadIdx.x == 0) {
                 if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[row % C], pb[0]);
                 if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[row % C], pb[1]);
             }
+        }
+    }
+    if (per_channel && ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr))) {
+        float pb[2] = {a_bias, b_bias};
+        block_sum<float, 2>(pb, redf);
+        if (threadIdx.x == 0) {
+            if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[blockIdx.y], pb[0]);
+            if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[blockIdx.y], pb[1]);
         }
     }
     double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
@@ -1095,6 +1107,8 @@ static int ewq_bwd_impl(const char* who, const uint8_t* ac, const float* amin, c
     if (gx_ > 64) gx_ = 64;
     int64_t gy = kSlots / gx_;
     if (gy > rows) gy = rows;
+    if ((PA.pz || PB.pz) && C <= gy && C > 1) gy = C;   // one workgroup row per channel: bias sums reduced once per workgroup
+    else if ((PA.pz || PB.pz) && gy == C) gy = C - 1;    // never alias the per-channel mode by accident
     hipLaunchKernelGGL(k_ewq_bwd, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
                        (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
                        bmin, bmax, qmin, qmax, gacc, PA, PB, C > 0 ? C : 1);
