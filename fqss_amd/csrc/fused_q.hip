@@ -8,7 +8,11 @@
 // GroupNormQ drops from 53 to 17 HBM bytes per element (fwd+bwd), the depthwise Conv1dNlQ from 45 to 24.
 //
 //   fqss_gnq_fwd / fqss_gnq_bwd      GroupNorm(1,C) + fake-quant          (qat_layers.py:445-448, qat_quant.py:136-147)
-//   fqss_dwq_fwd / fqss_dwq_bwd_z    depthwise dilated conv + PReLU + fake-quant (convtasnetq.py:28-30)
+//   fqss_gnq_bwd_p                   ... whose second pass also runs the PRODUCING conv's epilogue backward
+//   fqss_dwq_fwd / fqss_dwq_bwd      depthwise dilated conv + PReLU + fake-quant (convtasnetq.py:28-30); the backward is
+//                                    one launch, one workgroup per row with gz in LDS (dwq_bwd_z / bwd_w: long rows)
+//   fqss_ewq_fwd / fqss_ewq_bwd(_p)  AddQ / NlQ / residual Sub on codes (qat_layers.py:69-71, 511-518, 1193); _p also
+//                                    runs the epilogue backward of the convs that produced the operands
 //   fqss_decode                      codes -> fp32 (fallback for consumers without a coded-input kernel)
 // Statistics of a coded tensor are exact integer sums (sum c, sum c^2 in int64).
 #include "fqss_dev.h"

@@ -15,9 +15,13 @@
 //     dgrad  gx[ci][n]   = sum_co Wi[co][ci] * (dw[co]*gz[co][n])
 //     wgrad  gW_q[co][ci]+= dx * sum_n gz[co][n]*c[ci][n] + min_x * sum_n gz[co][n]
 //
-// Tiles: 128x128x32 per 256-thread block, 4 waves of 64x64 (2x2 MFMA 32x32x16).  A/B fragments need 8
-// consecutive k per lane; operands that are n-contiguous in HBM (activations in fwd/dgrad) keep their
-// natural [k][n] image in LDS and are transposed on the fly by ds_read_b64_tr_b16.
+// fwd / dgrad (k_qgemm): 128x64x32 tiles per 256-thread workgroup, 4 waves of 64x32 (2 MFMA 32x32x16).  A/B fragments
+// need 8 consecutive k per lane; operands that are n-contiguous in HBM (activations, gradients) keep their natural
+// [k][n] image in LDS and are transposed on the fly by ds_read_b64_tr_b16.  Two hand-scheduled register stages of
+// global loads, XCD-aware tile order, LDS-staged 16-B/lane epilogue.  The forward epilogue can also apply the layer's
+// own non-linearity + fake-quant and emit the output codes (fqss_qpw_fwdq); two layers on one input (res | skip)
+// run as one GEMM over concatenated channels (fqss_qpw_*2).
+// wgrad (k_qwgrad): register-direct fragments, no LDS, 4-stage hand-scheduled load ring, float atomics.
 //
 // Reference replaced: F.conv1d(k=1) of Conv1dQ / Conv1dNlQ (qat_layers.py:137-146, 202-212) and its autograd.
 #include <type_traits>
