@@ -413,6 +413,7 @@ using namespace fqss;
 extern "C" int fqss_version(void) { return FQSS_VERSION; }
 
 extern "C" int fqss_selftest_div(const float* a, int64_t n, float b, uint64_t* mismatches, fqss_stream_t stream) {
+    if (n == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(a && mismatches && n >= 0, "bad args");
     if (n == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_selftest_div, dim3(2048), dim3(256), 0, (hipStream_t)stream, a, n, b, (unsigned long long*)mismatches);
@@ -423,6 +424,7 @@ extern "C" const char* fqss_last_error(void) { return fqss::g_err; }
 extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols, int64_t ld_z,
                              int64_t ld_out, int64_t ld_idx, int act, const float* slope, int qmode, const float* qmin,
                              const float* qmax, uint32_t* obs_ws, fqss_stream_t stream) {
+    if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(z && (out || (idx && qmode == FQSS_Q_QUANT)), "null tensor");
     FQSS_REQUIRE(!idx || ld_idx >= cols, "bad ld_idx");
     if (!out) ld_out = ld_z;
@@ -446,6 +448,7 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
 }
 
 extern "C" int fqss_obs_reset(uint32_t* obs_ws, int64_t n_pairs, fqss_stream_t stream) {
+    if (n_pairs == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(obs_ws && n_pairs >= 0, "bad args");
     if (n_pairs == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_obs_reset, dim3((unsigned)cdiv(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream, obs_ws,
@@ -464,6 +467,7 @@ extern "C" int fqss_observer_ema(float* qmin, float* qmax, uint32_t* obs_ws, dou
 
 extern "C" int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* obs_ws,
                            fqss_stream_t stream) {
+    if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(x && obs_ws && rows >= 0 && cols >= 0 && ld >= cols, "bad args");
     if (rows == 0 || cols == 0) return FQSS_OK;
     const bool vec = aligned16(x) && (ld % 4 == 0);
@@ -479,6 +483,7 @@ extern "C" int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t l
 extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64_t cols, int64_t ld_z,
                              int64_t ld_g, int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin,
                              const float* qmax, double* gacc, float* gbias, int64_t C, fqss_stream_t stream) {
+    if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(z && g && gz, "null tensor");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_g >= cols && ld_gz >= cols, "bad shape");
     FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");

@@ -926,6 +926,7 @@ static inline bool codes_ok(const void* p, int64_t ld) { return aligned16(p) && 
 
 extern "C" int fqss_decode(const uint8_t* codes, float* out, int64_t rows, int64_t cols, int64_t ld_c, int64_t ld_out,
                            const float* qmin, const float* qmax, fqss_stream_t stream) {
+    if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(codes && out && qmin && qmax, "null pointer");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_c >= cols && ld_out >= cols, "bad shape");
     FQSS_REQUIRE(codes_ok(codes, ld_c) && aligned16(out) && ld_out % 4 == 0, "decode needs 16-B aligned code rows / fp32 rows");
@@ -939,6 +940,7 @@ extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float*
                             const float* beta, uint8_t* yc, float* yout, float* mean_rstd, int B, int C, int M,
                             int64_t ld_xc, int64_t ld_yc, int64_t ld_out, float eps, const float* qmin, const float* qmax,
                             void* ws, fqss_stream_t stream) {
+    if (B == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && gamma && beta && yc && mean_rstd && qmin && qmax && ws, "null pointer");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_yc >= M, "bad shape");
     FQSS_REQUIRE(codes_ok(xc, ld_xc) && codes_ok(yc, ld_yc), "code rows must be 16-B aligned");
@@ -959,6 +961,7 @@ static int gnq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x,
                             const float* gamma, const float* beta, const float* mean_rstd, float* gx, float* ggamma,
                             float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin,
                             const float* qmax, double* gacc, double* ws, const GnProducer& P, fqss_stream_t stream) {
+    if (B == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && g && gamma && beta && mean_rstd && gx && ggamma && gbeta && qmin && qmax && gacc && ws,
                  "null pointer");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_g >= M && ld_gx >= M, "bad shape");
@@ -1000,6 +1003,7 @@ extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float*
                             uint8_t* yc, float* yout, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
                             int64_t ld_yc, int64_t ld_out, int act, const float* slope, const float* qmin, const float* qmax,
                             fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && w && yc && qmin && qmax, "null pointer");
     FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
     FQSS_REQUIRE(ld_xc >= M && ld_yc >= M && codes_ok(xc, ld_xc) && codes_ok(yc, ld_yc), "code rows must be 16-B aligned");
@@ -1017,6 +1021,7 @@ extern "C" int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const floa
                               const float* bias, const float* g, float* gz, int B, int C, int M, int K, int dil, int pad,
                               int64_t ld_xc, int64_t ld_g, int64_t ld_gz, int act, const float* slope, const float* qmin,
                               const float* qmax, double* gacc, float* gbias, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && w && g && gz && qmin && qmax && gacc, "null pointer");
     FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
     FQSS_REQUIRE(ld_xc >= M && codes_ok(xc, ld_xc) && aligned16(g) && aligned16(gz) && ld_g % 4 == 0 && ld_gz % 4 == 0 &&
@@ -1041,6 +1046,7 @@ extern "C" int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const floa
 
 extern "C" int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int B,
                               int C, int M, int K, int dil, int pad, int64_t ld_gz, int64_t ld_xc, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null pointer");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && pad >= 0, "bad shape");
     FQSS_REQUIRE(ld_gz >= ((M + 3) & ~3) && ld_gz % 4 == 0 && aligned16(gz) && codes_ok(xc, ld_xc) && ld_xc >= M,
@@ -1055,6 +1061,7 @@ extern "C" int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float*
                             const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
                             int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
                             double* gacc, float* gbias, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && w && g && qmin && qmax && gacc, "null pointer");
     FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
     FQSS_REQUIRE(M <= kDwRowMax, "row too long for the single-workgroup backward (use fqss_dwq_bwd_z / dwconv_bwd_x / dwq_bwd_w)");
@@ -1077,6 +1084,7 @@ extern "C" int fqss_ewq_fwd(const uint8_t* ac, const float* amin, const float* a
                             const float* bmax, const float* bf, float sb, uint8_t* yc, float* yout, int64_t rows, int64_t cols,
                             int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_y, int64_t ld_out, int act, const float* slope,
                             const float* qmin, const float* qmax, fqss_stream_t stream) {
+    if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(ac && amin && amax && yc && qmin && qmax, "null pointer");
     FQSS_REQUIRE(!(bc && bf), "second operand is either codes or fp32");
     FQSS_REQUIRE(!bc || (bmin && bmax), "coded second operand needs its ranges");
@@ -1098,6 +1106,7 @@ static int ewq_bwd_impl(const char* who, const uint8_t* ac, const float* amin, c
                             int64_t ld_a, int64_t ld_b, int64_t ld_bf, int64_t ld_g, int64_t ld_gz, int act, const float* slope,
                             const float* qmin, const float* qmax, double* gacc, const EwProducer& PA, const EwProducer& PB, int C,
                             fqss_stream_t stream) {
+    if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(ac && amin && amax && g && (gz || (PA.pz && PB.pz)) && qmin && qmax && gacc, "null pointer");
     if (gz == nullptr) ld_gz = 4 * ((cols + 3) / 4);
     FQSS_REQUIRE(!(bc && bf) && (!bc || (bmin && bmax)), "bad second operand");

@@ -614,6 +614,7 @@ static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, co
                         const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int B, int Ci, int Co1,
                         int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, fqss_stream_t stream,
                         const QpwQuant* qq = nullptr) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     const int Co = Co1 + Co2;
     FQSS_REQUIRE(xc && wi && dw && rw && qmin_x && qmax_x && z1 && (Co2 == 0 || z2), "null tensor");
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_xc >= M && ld_z1 >= M && (Co2 == 0 || ld_z2 >= M), "bad shape");
@@ -669,6 +670,7 @@ extern "C" int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* d
 
 static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B,
                           int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_gx, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     const int Co = Co1 + Co2;
     FQSS_REQUIRE(gz1 && wiT && dw && gx && (Co2 == 0 || gz2), "null tensor");
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_gz1 >= M && ld_gx >= M, "bad shape");
@@ -703,6 +705,7 @@ extern "C" int fqss_qpw_bwd_x2(const float* gz1, const float* gz2, const int8_t*
 static int qpw_bwd_w_impl(const char* who, const float* gz1, const float* gz2, const uint8_t* xc, const float* qmin_x,
                           const float* qmax_x, float* gw, int B, int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2,
                           int64_t ld_xc, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     const int Co = Co1 + Co2;
     FQSS_REQUIRE(gz1 && xc && qmin_x && qmax_x && gw && (Co2 == 0 || gz2), "null tensor");
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co1 > 0 && Co2 >= 0 && M >= 0 && ld_gz1 >= M && ld_xc >= M, "bad shape");
@@ -743,6 +746,7 @@ extern "C" int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t
 // plain fp32 pointwise conv z = W x + b on the bf16 matrix cores: both operands split exactly in three
 extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
                                   int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(x && w && z, "null tensor");
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= M && ld_z >= M, "bad shape");
     FQSS_REQUIRE(Ci % 4 == 0 && ld_x % 4 == 0 && aligned16(x) && aligned16(w) && ld_x >= ((M + 3) & ~3),

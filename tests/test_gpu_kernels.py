@@ -435,3 +435,36 @@ def test_dwq_coded(B, C, M, dil):
     np.testing.assert_allclose(gacc1.view(-1, 3).sum(0).cpu().numpy(), ga, rtol=1e-4, atol=1e-3 * sc)   # fp32 per-thread partials, other order
     assert K.dwq_bwd(xc, cu(xlo), cu(xhi), cu(w), cu(bias), padded(g), dil, dil, K.ACT_PRELU, cu(slope), cu(ylo), cu(yhi), gacc1, gb1, None,
                      want_gx=False) is None
+
+
+# ---------------------------------------------------------------------------------------------
+# degenerate inputs and argument validation through the C ABI (the library never faults on them)
+# ---------------------------------------------------------------------------------------------
+def test_empty_batches_are_noops_and_bad_arguments_are_refused():
+    from fqss_amd import _lib
+    dev = "cuda"
+    lo, hi = torch.tensor([-1.0], device=dev), torch.tensor([1.0], device=dev)
+    C, M = 16, 40
+    # B = 0: every launcher returns OK without touching memory
+    x0 = K.empty_act((0, C, M), dev)
+    assert K.actq_fwd(x0, K.ACT_NONE, None, K.Q_QUANT, lo, hi, None).shape[0] == 0
+    xc0 = K.empty_codes((0, C, M), dev)
+    w = torch.randn(32, C, 1, device=dev) * 0.1
+    wc = K.wq_codes(w, -torch.ones(32, 1, 1, device=dev), torch.ones(32, 1, 1, device=dev))
+    assert K.qpw_fwd(xc0, wc, None, lo, hi).shape == (0, 32, M)
+    gw = torch.zeros(32, C, device=dev)
+    K.qpw_bwd_w(K.empty_act((0, 32, M), dev), xc0, lo, hi, gw)
+    assert float(gw.abs().max()) == 0.0
+    assert K.qpw_bwd_x(K.empty_act((0, 32, M), dev), wc).shape == (0, C, M)
+    # refused, with a message, instead of a fault: unaligned code rows, Ci not a multiple of 16, null ranges
+    xc = K.empty_codes((1, C, M), dev)
+    z = K.empty_act((1, 32, M), dev)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    with pytest.raises(_lib.FqssError, match="aligned"):      # ld_xc = 41: rows not 16-B aligned
+        _lib.call("fqss_qpw_fwd", P(xc), P(wc.idx), P(wc.dw), P(wc.rw), None, P(lo), P(hi), P(z), 1, C, 32, M, M + 1, 48, st)
+    with pytest.raises(_lib.FqssError):                        # Ci = 24
+        _lib.call("fqss_qpw_fwd", P(xc), P(wc.idx), P(wc.dw), P(wc.rw), None, P(lo), P(hi), P(z), 1, 24, 32, M, 48, 48, st)
+    with pytest.raises(_lib.FqssError, match="null"):
+        _lib.call("fqss_qpw_fwd", P(xc), P(wc.idx), P(wc.dw), P(wc.rw), None, None, P(hi), P(z), 1, C, 32, M, 48, 48, st)
+    torch.cuda.synchronize()
