@@ -202,14 +202,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
                         p_out += inr ? 0.0f : gj;
                     }
                 }
-                float gzj = gt;
-                if (act == FQSS_ACT_PRELU) {
-                    const bool pos = zv[j] > 0.0f;
-                    gzj = pos ? gt : slope * gt;
-                    if (valid && !pos) p_slope += zv[j] * gt;
-                } else if (act == FQSS_ACT_RELU) {
-                    gzj = (t > 0.0f) ? gt : 0.0f;
-                }
+                float gzj = act_bwd(zv[j], gt, act, slope, valid, p_slope);
                 o[j] = gzj;
                 if (BIAS && valid) p_bias += gzj;
             }

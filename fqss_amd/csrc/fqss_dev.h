@@ -125,10 +125,22 @@ __device__ __forceinline__ float div_by(float a, float b, float y) {
     const float r = fmaf(-b, q, a);
     return fmaf(r, y, q);
 }
+// Branch-free: NONE / ReLU are PReLU (ATen: z > 0 ? z : slope * z) with slope 1 / 0, so the (wave-uniform) choice is one
+// scalar select the compiler hoists out of the caller's loops instead of two scalar branches per element (the GEMM
+// epilogues carried 160-280 s_cbranch for it).  1 * z is exact; ReLU yields -0 for z < 0, which no consumer can tell
+// from +0 (the quantizer subtracts the range minimum first, sums and products of zeros compare equal).
+__device__ __forceinline__ float act_neg_scale(int act, float slope) {
+    return act == FQSS_ACT_PRELU ? slope : (act == FQSS_ACT_RELU ? 0.0f : 1.0f);
+}
 __device__ __forceinline__ float act_apply(float z, int act, float slope) {
-    if (act == FQSS_ACT_PRELU) return z > 0.0f ? z : slope * z;  // ATen prelu kernel
-    if (act == FQSS_ACT_RELU) return z > 0.0f ? z : 0.0f;
-    return z;
+    return z > 0.0f ? z : act_neg_scale(act, slope) * z;
+}
+// activation backward, branch-free like act_apply: returns dL/dz for dL/dt = gt and accumulates the PReLU slope gradient
+// (adding 0.0f where the branchy form skipped the add leaves the sum unchanged)
+__device__ __forceinline__ float act_bwd(float z, float gt, int act, float slope, bool valid, float& p_slope) {
+    const bool neg = !(z > 0.0f);
+    p_slope += (act == FQSS_ACT_PRELU && valid && neg) ? z * gt : 0.0f;
+    return neg ? act_neg_scale(act, slope) * gt : gt;
 }
 // returns the de-quantised value, c = clamped integer index as float, u = pre-round coordinate
 __device__ __forceinline__ float fq_asym(float t, const QRange& r, float& c, float& u, bool& inr) {

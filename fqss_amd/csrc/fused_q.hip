@@ -268,14 +268,7 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
                         p_du += gj * (pin ? (pc - pu) : pc);
                         p_out += pin ? 0.0f : gj;
                     }
-                    float gzj = gt;
-                    if (P.act == FQSS_ACT_PRELU) {
-                        const bool pos = pzv[e] > 0.0f;
-                        gzj = pos ? gt : pslope * gt;
-                        if (valid && !pos) p_slope += pzv[e] * gt;
-                    } else if (P.act == FQSS_ACT_RELU) {
-                        gzj = (t > 0.0f) ? gt : 0.0f;
-                    }
+                    float gzj = act_bwd(pzv[e], gt, P.act, pslope, valid, p_slope);
                     o[e] = gzj;
                     if (valid) p_bias += gzj;
                 }
@@ -451,14 +444,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
                         p_du += gj * (inr ? (cq - u) : cq);
                         p_out += inr ? 0.0f : gj;
                     }
-                    float gzj = gt;
-                    if (act == FQSS_ACT_PRELU) {
-                        const bool pos = z[j] > 0.0f;
-                        gzj = pos ? gt : slope * gt;
-                        if (valid && !pos) p_slope += z[j] * gt;
-                    } else if (act == FQSS_ACT_RELU) {
-                        gzj = (t > 0.0f) ? gt : 0.0f;
-                    }
+                    float gzj = act_bwd(z[j], gt, act, slope, valid, p_slope);
                     o[j] = gzj;
                     if (valid) p_bias += gzj;
                 }
@@ -578,14 +564,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                     p_du += gj * (inr ? (cq - u) : cq);
                     p_out += inr ? 0.0f : gj;
                 }
-                float gzj = gt;
-                if (act == FQSS_ACT_PRELU) {
-                    const bool pos = z > 0.0f;
-                    gzj = pos ? gt : slope * gt;
-                    if (valid && !pos) p_slope += z * gt;
-                } else if (act == FQSS_ACT_RELU) {
-                    gzj = (t > 0.0f) ? gt : 0.0f;
-                }
+                float gzj = act_bwd(z, gt, act, slope, valid, p_slope);
                 gzj = valid ? gzj : 0.0f;
                 o[j] = gzj;
                 p_bias += gzj;
@@ -754,14 +733,7 @@ __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRan
         p_du += gj * (pin ? (pc - pu) : pc);
         p_out += pin ? 0.0f : gj;
     }
-    float gzj = gt;
-    if (P.act == FQSS_ACT_PRELU) {
-        const bool pos = pz > 0.0f;
-        gzj = pos ? gt : pslope * gt;
-        if (valid && !pos) p_slope += pz * gt;
-    } else if (P.act == FQSS_ACT_RELU) {
-        gzj = (t > 0.0f) ? gt : 0.0f;
-    }
+    float gzj = act_bwd(pz, gt, P.act, pslope, valid, p_slope);
     if (valid) p_bias += gzj;
     return gzj;
 }
@@ -820,14 +792,7 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
                     p_du += gj * (inr ? (cq - u) : cq);
                     p_out += inr ? 0.0f : gj;
                 }
-                float gzj = gt;
-                if (act == FQSS_ACT_PRELU) {
-                    const bool pos = z > 0.0f;
-                    gzj = pos ? gt : slope * gt;
-                    if (valid && !pos) p_slope += z * gt;
-                } else if (act == FQSS_ACT_RELU) {
-                    gzj = (t > 0.0f) ? gt : 0.0f;
-                }
+                float gzj = act_bwd(z, gt, act, slope, valid, p_slope);
                 o[e] = gzj;
                 // d/da = gz, d/db = sb * gz (sb == 1 whenever b is fused): the producers' epilogue backward on it
                 if (fa) oa[e] = ew_producer_bwd(PA, ra, sla, zav[e], valid ? gzj : 0.0f, valid, a_du, a_out, a_sl, a_bias);

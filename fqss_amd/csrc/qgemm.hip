@@ -353,8 +353,17 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         // store-issue-bound tail was 60 % of the forward kernel's time)
         __syncthreads();   // every wave is done with As/Bs
         float(*Tt)[LDT] = reinterpret_cast<float(*)[LDT]>(smem + wave * 32 * LDT * 4);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        const bool has_bias = g.bias != nullptr;
+        const float qns = act_neg_scale(g.qact, qslope);
+        const int c4 = (lane & 7) * 4;
+        const int col = j0 + wn * 32 + c4;
+        // PER_ROW = false: M1 % 32 == 0 (every shape of the real model), a 32-row tile lies on one side of the output
+        // split and the destination is selected once per tile; PER_ROW = true: the general case, selected per stored row
+        // (the per-element selects and branches of a single generic path were half the epilogue's code).  The fused
+        // output quantizer always has M1 % 32 == 0 (host check).
+        auto tile_epilogue = [&](int mi, auto PER_ROW) {
+            const int rowt = i0 + wm * 64 + mi * 32;
+            const bool tfirst = rowt < g.M1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -363,26 +372,25 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                 float v = S;
                 if constexpr (MODE == 0) {
                     v = rowc[0][rb] * (dx * S + mnx * rowc[1][rb]);
-                    if (g.bias != nullptr) v = v + rowc[2][rb];
+                    if (has_bias) v = v + rowc[2][rb];
                 } else if constexpr (MODE == 3) {
-                    if (g.bias != nullptr) v = S + rowc[2][rb];
+                    if (has_bias) v = S + rowc[2][rb];
                 }
                 Tt[rl][lr] = v;
             }
             // same-wave LDS round trip: program order + the compiler's lgkmcnt waits are sufficient
-            const int c4 = (lane & 7) * 4;
-            const int col = j0 + wn * 32 + c4;
+            const QRange ry = tfirst ? ry1 : ry2;
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int rl = pass * 8 + (lane >> 3);
-                const int row = i0 + wm * 64 + mi * 32 + rl;
+                const int row = rowt + rl;
                 const float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
                 if (row < g.M && col < g.N) {
-                    const bool first = row < g.M1;
+                    const bool first = decltype(PER_ROW)::value ? row < g.M1 : tfirst;
                     const int64_t ldc = first ? g.ldc : g.ldc2;
                     float* dst = (first ? Cb + (int64_t)row * ldc : C2b + (int64_t)(row - g.M1) * ldc) + col;
                     if (col + 3 < g.N || col + 3 < ldc) {
-                        *reinterpret_cast<float4*>(dst) = t;    // columns >= N fall into the row padding
+                        *reinterpret_cast<float4*>(dst) = t;   // columns >= N fall into the row padding
                     } else {
                         dst[0] = t.x;
                         if (col + 1 < g.N) dst[1] = t.y;
@@ -390,15 +398,14 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                     }
                 }
                 if constexpr (MODE == 0) {
-                    if (quant) {   // this lane's 4 outputs -> 4 codes (the tile lies on one side of M1: M1 % 32 == 0)
-                        const QRange& ry = (i0 + wm * 64 + mi * 32 < g.M1) ? ry1 : ry2;
+                    if (quant) {   // this lane's 4 outputs -> 4 codes
                         const float tv[4] = {t.x, t.y, t.z, t.w};
                         uint32_t pk = 0;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float cq, u;
                             bool inr;
-                            (void)fq_asym(act_apply(tv[e], g.qact, qslope), ry, cq, u, inr);
+                            (void)fq_asym(tv[e] > 0.0f ? tv[e] : qns * tv[e], ry, cq, u, inr);
                             pk |= ((uint32_t)cq & 255u) << (8 * e);
                         }
                         Qt[wave][rl][lane & 7] = pk;
@@ -408,18 +415,23 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             if constexpr (MODE == 0) {
                 if (quant) {   // 16 codes (16 B) per lane: lane -> (row = lane / 2, half row)
                     const int rl = lane >> 1, hf = lane & 1;
-                    const int row = i0 + wm * 64 + mi * 32 + rl;
-                    const int col = j0 + wn * 32 + 16 * hf;
+                    const int qcol = j0 + wn * 32 + 16 * hf;
                     const uint4 c16 = *reinterpret_cast<const uint4*>(&Qt[wave][rl][4 * hf]);
-                    const bool first = row < g.M1;
-                    const int64_t ldq = first ? g.ldq1 : g.ldq2;
-                    if (row < g.M && col < ldq) {
-                        unsigned char* qb = first ? g.Q1 + (int64_t)b * g.sQ1b + (int64_t)row * ldq
-                                                  : g.Q2 + (int64_t)b * g.sQ2b + (int64_t)(row - g.M1) * ldq;
-                        *reinterpret_cast<uint4*>(qb + col) = c16;
+                    const int64_t ldq = tfirst ? g.ldq1 : g.ldq2;
+                    if (rowt + rl < g.M && qcol < ldq) {
+                        unsigned char* qb = tfirst ? g.Q1 + (int64_t)b * g.sQ1b + (int64_t)(rowt + rl) * ldq
+                                                   : g.Q2 + (int64_t)b * g.sQ2b + (int64_t)(rowt + rl - g.M1) * ldq;
+                        *reinterpret_cast<uint4*>(qb + qcol) = c16;
                     }
                 }
             }
+        };
+        if ((g.M1 & 31) == 0 || g.M1 >= g.M) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) tile_epilogue(mi, std::false_type{});
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) tile_epilogue(mi, std::true_type{});
         }
     }
 }
@@ -622,7 +634,7 @@ static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, co
                  "q-GEMM needs Ci % 16 == 0, Ci <= 512 (exact fp32 integer sum) and 16-B aligned code rows");
     FQSS_REQUIRE(aligned16(z1) && ld_z1 % 4 == 0 && (Co2 == 0 || (aligned16(z2) && ld_z2 % 4 == 0)), "output rows must be 16-B aligned");
     FQSS_REQUIRE((bias1 == nullptr) == (bias2 == nullptr) || Co2 == 0, "paired layers: both or neither with bias");
-    if (B == 0 || M == 0) return FQSS_OK;
+    if (qq != nullptr) FQSS_REQUIRE(Co2 == 0 || Co1 % 32 == 0, "fused quantizer of a pair needs Co1 % 32 == 0");
     QGemmArgs g{};
     g.A = wi; g.B = xc; g.C = z1; g.M = Co; g.N = M; g.K = Ci;
     g.lda = Ci; g.ldb = ld_xc; g.ldc = ld_z1;
@@ -631,7 +643,6 @@ static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, co
     g.dw = dw; g.rw = rw; g.bias = bias1; g.qmin_x = qmin_x; g.qmax_x = qmax_x; g.ksplit = 1; g.kchunk = Ci;
     if (qq != nullptr) {
         FQSS_REQUIRE(qq->min1 && qq->max1 && qq->yc1 && (Co2 == 0 || (qq->min2 && qq->max2 && qq->yc2)), "fused quantizer: null pointer");
-        FQSS_REQUIRE(Co2 == 0 || Co1 % 32 == 0, "fused quantizer of a pair needs Co1 % 32 == 0");
         FQSS_REQUIRE(qq->ld1 % 16 == 0 && qq->ld1 >= M && aligned16(qq->yc1) && (Co2 == 0 || (qq->ld2 % 16 == 0 && qq->ld2 >= M && aligned16(qq->yc2))),
                      "output code rows must be 16-B aligned");
         FQSS_REQUIRE(qq->act != FQSS_ACT_PRELU || qq->slope, "PReLU needs a slope");

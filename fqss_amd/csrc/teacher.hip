@@ -275,38 +275,59 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     t_wait<0>(stA);
     t_wait<0>(stB);
 
-    // epilogue: bias + act (+ residual), 16-B/lane row stores via an LDS staging tile, statistics
-    const float eslope = (g.act == FQSS_ACT_PRELU) ? *g.slope : 0.0f;
+    // epilogue: bias + act (+ residual), 16-B/lane row stores via an LDS staging tile, statistics.
+    // Branch-free on purpose: with the activation and the output half selected per element through run-time branches
+    // and 64-bit pointer selects the compiler emitted ~3400 instructions here (160 scalar branches) and the epilogue
+    // took 47 % (T1) / 28 % (T3) of a workgroup's life (cycle-counter trace).  NONE / ReLU are PReLU with slope 1 / 0.
+    const float nscale = (g.act == FQSS_ACT_PRELU) ? *g.slope : (g.act == FQSS_ACT_RELU ? 0.0f : 1.0f);
     float(*Tt)[TLDT] = reinterpret_cast<float(*)[TLDT]>(smem + wave * 32 * TLDT * 4);
     float s1 = 0.0f, s2 = 0.0f;   // <= 64 values per thread: fp32 partials, widened to fp64 for the cross-thread sum
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    const bool want_stats = g.stats_out != nullptr;
+    const int c4 = (lane & 7) * 4;
+    // destination (and residual) of output row `row` at column 0: the first M1 rows go to C1, the rest to C2
+    auto row_base = [&](int row, float*& Crow, const float*& Rrow) {
+        const bool first = row < g.M1;
+        const int64_t off = (int64_t)b * (first ? g.sC1b : g.sC2b) + (int64_t)(first ? row : row - g.M1) * (first ? g.ldc1 : g.ldc2);
+        Crow = (first ? g.C1 : g.C2) + off;
+        const float* Rsel = first ? g.R1 : g.R2;
+        Rrow = (Rsel != nullptr) ? Rsel + off : nullptr;
+    };
+    // PER_ROW = false: M1 % 32 == 0, a 32-row tile lies on one side of the split and one base serves the whole tile
+    // (every shape of the real model); PER_ROW = true: the general case, selected per stored row
+    auto tile_epilogue = [&](int mi, auto PER_ROW) {
+        const int rowt = i0 + wm * 64 + mi * 32;
+        float* Cb;
+        const float* Rb;
+        row_base(rowt, Cb, Rb);
+        const int64_t ldc = (rowt < g.M1) ? g.ldc1 : g.ldc2;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Tt[rl][lr] = act_apply(acc[mi][ni][r] + rowb[wm * 64 + mi * 32 + rl], g.act, eslope);
+                const float v = acc[mi][ni][r] + rowb[wm * 64 + mi * 32 + rl];
+                Tt[rl][lr] = v > 0.0f ? v : nscale * v;
             }
-            const int c4 = (lane & 7) * 4;
             const int col = j0 + wn * 64 + ni * 32 + c4;
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int rl = pass * 8 + (lane >> 3);
-                const int row = i0 + wm * 64 + mi * 32 + rl;
                 float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
-                if (row < g.M && col < g.N) {
-                    const bool first = row < g.M1;
-                    const int rr = first ? row : row - g.M1;
-                    float* C = first ? g.C1 : g.C2;
-                    const float* R = first ? g.R1 : g.R2;
-                    const int64_t off = (int64_t)b * (first ? g.sC1b : g.sC2b) + (int64_t)rr * (first ? g.ldc1 : g.ldc2) + col;
-                    if (R != nullptr) {
-                        const float4 q = *reinterpret_cast<const float4*>(R + off);
+                if (rowt + rl < g.M && col < g.N) {
+                    float* Crow;
+                    const float* Rrow;
+                    if constexpr (decltype(PER_ROW)::value) {
+                        row_base(rowt + rl, Crow, Rrow);
+                    } else {
+                        Crow = Cb + (int64_t)rl * ldc;
+                        Rrow = Rb + (int64_t)rl * ldc;   // only dereferenced when Rb != nullptr
+                    }
+                    if (decltype(PER_ROW)::value ? Rrow != nullptr : Rb != nullptr) {
+                        const float4 q = *reinterpret_cast<const float4*>(Rrow + col);
                         t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
                     }
-                    *reinterpret_cast<float4*>(C + off) = t;
-                    if (g.stats_out != nullptr) {
+                    *reinterpret_cast<float4*>(Crow + col) = t;
+                    if (want_stats) {
                         const float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -318,6 +339,13 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
                 }
             }
         }
+    };
+    if ((g.M1 & 31) == 0 || g.M1 >= g.M) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) tile_epilogue(mi, std::false_type{});
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) tile_epilogue(mi, std::true_type{});
     }
     if (g.stats_out != nullptr) {
         double v[2] = {(double)s1, (double)s2};
