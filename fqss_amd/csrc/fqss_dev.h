@@ -125,6 +125,23 @@ __device__ __forceinline__ float div_by(float a, float b, float y) {
     const float r = fmaf(-b, q, a);
     return fmaf(r, y, q);
 }
+// Pins a wave-uniform value (typically a field of a by-value kernel-argument struct) in SGPRs.  Such fields live in the
+// kernarg segment; when two of them are selected per lane (`row < split ? g.ld1 : g.ld2`) the compiler selects the ADDRESS
+// and issues a per-lane global load from the kernarg segment followed by s_waitcnt vmcnt(0) -- a memory round trip in the
+// middle of a hand-pipelined loop (k_qgemm carried five of them).  Selecting between two pinned values is one v_cndmask.
+template <typename T>
+__device__ __forceinline__ T sgpr(T v) {
+    asm("" : "+s"(v));
+    return v;
+}
+// A 16-B store the optimiser cannot split: it turned `vec ? float4 store : up to 3 scalar stores` into one dwordx3 plus one
+// conditional dword per lane (two partial-line writes per 16 B) in every k_qgemm epilogue.  Stores only count on vmcnt, which
+// makes the compiler's own waits conservative, never wrong.
+__device__ __forceinline__ void store16(float* p, const float4& v) {
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const f32x4s t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(t) : "memory");
+}
 // Branch-free: NONE / ReLU are PReLU (ATen: z > 0 ? z : slope * z) with slope 1 / 0, so the (wave-uniform) choice is one
 // scalar select the compiler hoists out of the caller's loops instead of two scalar branches per element (the GEMM
 // epilogues carried 160-280 s_cbranch for it).  1 * z is exact; ReLU yields -0 for z < 0, which no consumer can tell
@@ -141,6 +158,22 @@ __device__ __forceinline__ float act_bwd(float z, float gt, int act, float slope
     const bool neg = !(z > 0.0f);
     p_slope += (act == FQSS_ACT_PRELU && valid && neg) ? z * gt : 0.0f;
     return neg ? act_neg_scale(act, slope) * gt : gt;
+}
+// Branching forms of the two helpers above, same results.  k_dwq_bwd keeps them: there the branch-free forms cost 13 more
+// VGPRs (73 -> 86, one wave per SIMD less) and 45 -> 52 us.
+__device__ __forceinline__ float act_apply_br(float z, int act, float slope) {
+    if (act == FQSS_ACT_PRELU) return z > 0.0f ? z : slope * z;
+    if (act == FQSS_ACT_RELU) return z > 0.0f ? z : 0.0f;
+    return z;
+}
+__device__ __forceinline__ float act_bwd_br(float z, float gt, int act, float slope, bool valid, float& p_slope) {
+    if (act == FQSS_ACT_PRELU) {
+        const bool pos = z > 0.0f;
+        if (valid && !pos) p_slope += z * gt;
+        return pos ? gt : slope * gt;
+    }
+    if (act == FQSS_ACT_RELU) return (z > 0.0f) ? gt : 0.0f;
+    return gt;
 }
 // returns the de-quantised value, c = clamped integer index as float, u = pre-round coordinate
 __device__ __forceinline__ float fq_asym(float t, const QRange& r, float& c, float& u, bool& inr) {

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                 const bool valid = (m + j < M);
                 const float gj = valid ? gv[j] : 0.0f;
                 const float z = acc[j] + bv;
-                const float t = act_apply(z, act, slope);
+                const float t = act_apply_br(z, act, slope);
                 float cq, u;
                 bool inr;
                 (void)fq_asym(t, ry, cq, u, inr);
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                     p_du += gj * (inr ? (cq - u) : cq);
                     p_out += inr ? 0.0f : gj;
                 }
-                float gzj = act_bwd(z, gt, act, slope, valid, p_slope);
+                float gzj = act_bwd_br(z, gt, act, slope, valid, p_slope);
                 gzj = valid ? gzj : 0.0f;
                 o[j] = gzj;
                 p_bias += gzj;
@@ -758,57 +758,85 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
     // channel, so the producers' bias sums are reduced once per workgroup instead of once per row
     const bool per_channel = (int)gridDim.y == C;
     float a_bias = 0.f, b_bias = 0.f;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-        if (!per_channel) a_bias = b_bias = 0.f;
-        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < cols; c0 += gridDim.x * 256 * 4) {
-            const unsigned int wa = *reinterpret_cast<const unsigned int*>(ac + (int64_t)row * ld_a + c0);
-            const unsigned int wb = bc ? *reinterpret_cast<const unsigned int*>(bc + (int64_t)row * ld_b + c0) : 0u;
-            float4 za4 = make_float4(0.f, 0.f, 0.f, 0.f), zb4 = za4;
-            if (fa) za4 = *reinterpret_cast<const float4*>(PA.pz + (int64_t)row * PA.ld_pz + c0);
-            if (fb) zb4 = *reinterpret_cast<const float4*>(PB.pz + (int64_t)row * PB.ld_pz + c0);
-            const float zav[4] = {za4.x, za4.y, za4.z, za4.w}, zbv[4] = {zb4.x, zb4.y, zb4.z, zb4.w};
-            float oa[4], ob[4];
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bf != nullptr) {
-                const float4 t = *reinterpret_cast<const float4*>(bf + (int64_t)row * ld_bf + c0);
-                bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-            }
-            const float4 g4 = *reinterpret_cast<const float4*>(g + (int64_t)row * ld_g + c0);
-            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-            float o[4];
+    struct EwIn {
+        unsigned int wa, wb;
+        float4 za, zb, bf4, g4;
+    };
+    auto load_group = [&](int row, int c0, EwIn& in) {
+        in.wa = *reinterpret_cast<const unsigned int*>(ac + (int64_t)row * ld_a + c0);
+        in.wb = bc ? *reinterpret_cast<const unsigned int*>(bc + (int64_t)row * ld_b + c0) : 0u;
+        in.za = in.zb = in.bf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fa) in.za = *reinterpret_cast<const float4*>(PA.pz + (int64_t)row * PA.ld_pz + c0);
+        if (fb) in.zb = *reinterpret_cast<const float4*>(PB.pz + (int64_t)row * PB.ld_pz + c0);
+        if (bf != nullptr) in.bf4 = *reinterpret_cast<const float4*>(bf + (int64_t)row * ld_bf + c0);
+        in.g4 = *reinterpret_cast<const float4*>(g + (int64_t)row * ld_g + c0);
+    };
+    auto do_group = [&](int row, int c0, const EwIn& in) {
+        const float zav[4] = {in.za.x, in.za.y, in.za.z, in.za.w}, zbv[4] = {in.zb.x, in.zb.y, in.zb.z, in.zb.w};
+        const float bv[4] = {in.bf4.x, in.bf4.y, in.bf4.z, in.bf4.w}, gv[4] = {in.g4.x, in.g4.y, in.g4.z, in.g4.w};
+        float o[4], oa[4], ob[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool valid = c0 + e < cols;
-                const float gj = valid ? gv[e] : 0.0f;
-                float z = dec((wa >> (8 * e)) & 255u, ra);
-                if (bc != nullptr) z = z + sb * dec((wb >> (8 * e)) & 255u, rb);
-                else if (bf != nullptr) z = z + sb * bv[e];
-                const float t = act_apply(z, act, slope);
-                float cq, u;
-                bool inr;
-                (void)fq_asym(t, ry, cq, u, inr);
-                const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
-                if (valid) {
-                    p_du += gj * (inr ? (cq - u) : cq);
-                    p_out += inr ? 0.0f : gj;
-                }
-                float gzj = act_bwd(z, gt, act, slope, valid, p_slope);
-                o[e] = gzj;
-                // d/da = gz, d/db = sb * gz (sb == 1 whenever b is fused): the producers' epilogue backward on it
-                if (fa) oa[e] = ew_producer_bwd(PA, ra, sla, zav[e], valid ? gzj : 0.0f, valid, a_du, a_out, a_sl, a_bias);
-                if (fb) ob[e] = ew_producer_bwd(PB, rb, slb, zbv[e], valid ? gzj : 0.0f, valid, b_du, b_out, b_sl, b_bias);
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = c0 + e < cols;
+            const float gj = valid ? gv[e] : 0.0f;
+            float z = dec((in.wa >> (8 * e)) & 255u, ra);
+            if (bc != nullptr) z = z + sb * dec((in.wb >> (8 * e)) & 255u, rb);
+            else if (bf != nullptr) z = z + sb * bv[e];
+            const float t = act_apply(z, act, slope);
+            float cq, u;
+            bool inr;
+            (void)fq_asym(t, ry, cq, u, inr);
+            const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+            if (valid) {
+                p_du += gj * (inr ? (cq - u) : cq);
+                p_out += inr ? 0.0f : gj;
             }
-            if (gz != nullptr) *reinterpret_cast<float4*>(gz + (int64_t)row * ld_gz + c0) = make_float4(o[0], o[1], o[2], o[3]);
-            if (fa) *reinterpret_cast<float4*>(PA.out + (int64_t)row * PA.ld_out + c0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
-            if (fb) *reinterpret_cast<float4*>(PB.out + (int64_t)row * PB.ld_out + c0) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+            float gzj = act_bwd(z, gt, act, slope, valid, p_slope);
+            o[e] = gzj;
+            // d/da = gz, d/db = sb * gz (sb == 1 whenever b is fused): the producers' epilogue backward on it
+            if (fa) oa[e] = ew_producer_bwd(PA, ra, sla, zav[e], valid ? gzj : 0.0f, valid, a_du, a_out, a_sl, a_bias);
+            if (fb) ob[e] = ew_producer_bwd(PB, rb, slb, zbv[e], valid ? gzj : 0.0f, valid, b_du, b_out, b_sl, b_bias);
         }
-        if (!per_channel && ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr))) {   // workgroup-uniform
-            float pb[2] = {a_bias, b_bias};
-            block_sum<float, 2>(pb, redf);
-            if (threadIdx.x == 0) {
-                if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[row % C], pb[0]);
-                if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[row % C], pb[1]);
+        if (gz != nullptr) *reinterpret_cast<float4*>(gz + (int64_t)row * ld_gz + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        if (fa) *reinterpret_cast<float4*>(PA.out + (int64_t)row * PA.ld_out + c0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        if (fb) *reinterpret_cast<float4*>(PB.out + (int64_t)row * PB.ld_out + c0) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+    };
+    const bool row_bias = !per_channel && ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr));   // workgroup-uniform
+    auto row_bias_flush = [&](int row) {
+        float pb[2] = {a_bias, b_bias};
+        block_sum<float, 2>(pb, redf);
+        if (threadIdx.x == 0) {
+            if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[row % C], pb[0]);
+            if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[row % C], pb[1]);
+        }
+        a_bias = b_bias = 0.f;
+    };
+    const int c_first = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if ((int64_t)gridDim.x * 1024 >= cols) {
+        // every thread owns ONE column group of each of the workgroup's rows: the loads of 4 rows are issued before
+        // the first is consumed (the serial row loop exposed one HBM round trip per row: 8 per workgroup at cfg 2)
+        const bool active = c_first < cols;
+        const int rstep = gridDim.y;
+        for (int row0 = blockIdx.y; row0 < rows; row0 += 4 * rstep) {
+            EwIn in[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (active && row0 + i * rstep < rows) load_group(row0 + i * rstep, c_first, in[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (row0 + i * rstep < rows) {
+                    if (active) do_group(row0 + i * rstep, c_first, in[i]);
+                    if (row_bias) row_bias_flush(row0 + i * rstep);
+                }
+        }
+    } else {
+        for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+            for (int c0 = c_first; c0 < cols; c0 += gridDim.x * 256 * 4) {
+                EwIn in;
+                load_group(row, c0, in);
+                do_group(row, c0, in);
             }
+            if (row_bias) row_bias_flush(row);
         }
     }
     if (per_channel && ((fa && PA.gbias != nullptr) || (fb && PB.gbias != nullptr))) {

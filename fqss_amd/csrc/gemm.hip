@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int bz = blockIdx.z;
     const int b = ATOMIC ? bz / g.ksplit : bz;

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     AsT As = reinterpret_cast<AsT>(smem);
     BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: everything derived from it stays in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     // group = one (batch, n-tile) activation panel, re-read by the tiles_m row tiles of the weight
@@ -176,6 +177,11 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         for (int k = tid; k < g.K; k += 256) dws[k] = g.dw[k];
     }
 
+    // the two halves of a paired B operand are selected per lane: keep their descriptors in SGPRs (see sgpr())
+    constexpr int BEL = (MODE == 0) ? 1 : 4;   // bytes per B element: codes / fp32 (the strides count elements)
+    const char* const gB1 = sgpr((const char*)g.B + (int64_t)b * g.sBb * BEL);
+    const char* const gB2 = (MODE == 0) ? gB1 : sgpr((const char*)g.B2 + (int64_t)b * g.sB2b * BEL);
+    const int64_t gldb1 = sgpr(g.ldb), gldb2 = (MODE == 0) ? gldb1 : sgpr(g.ldb2);
     auto load_tiles = [&](QStage& st, int k0) {
         if constexpr (MODE < 2) {
             q_load16(st.a[0], (const signed char*)g.A + (int64_t)a_row_c * g.lda + min(k0 + a_k, g.K - 16));
@@ -186,12 +192,12 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         }
         const int kk = min(k0 + bk_row, g.K - 1);
         if constexpr (MODE == 0) {
-            const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb + (int64_t)kk * g.ldb;
-            q_load8(st.bq, Bp + min(j0 + bk_n, (int)g.ldb - 8));   // groups past the row (columns >= N) re-read its tail
+            const unsigned char* Bp = (const unsigned char*)gB1 + (int64_t)kk * gldb1;
+            q_load8(st.bq, Bp + min(j0 + bk_n, (int)gldb1 - 8));   // groups past the row (columns >= N) re-read its tail
         } else {
-            const float* Bp = (kk < g.K1) ? (const float*)g.B + (int64_t)b * g.sBb + (int64_t)kk * g.ldb
-                                          : (const float*)g.B2 + (int64_t)b * g.sB2b + (int64_t)(kk - g.K1) * g.ldb2;
-            const int ldk = (int)((kk < g.K1) ? g.ldb : g.ldb2);    // row length (multiple of 4, >= N): clamp inside the row;
+            const bool h1 = kk < g.K1;
+            const int ldk = (int)(h1 ? gldb1 : gldb2);              // row length (multiple of 4, >= N): clamp inside the row;
+            const float* Bp = (const float*)(h1 ? gB1 : gB2) + (int64_t)(h1 ? kk : kk - g.K1) * ldk;
             q_load16(st.b[0], Bp + min(j0 + bk_n, ldk - 4));        // a clamped group only feeds output columns >= N
             q_load16(st.b[1], Bp + min(j0 + bk_n + 4, ldk - 4));
         }
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                     const int64_t ldc = first ? g.ldc : g.ldc2;
                     float* dst = (first ? Cb + (int64_t)row * ldc : C2b + (int64_t)(row - g.M1) * ldc) + col;
                     if (col + 3 < g.N || col + 3 < ldc) {
-                        *reinterpret_cast<float4*>(dst) = t;   // columns >= N fall into the row padding
+                        store16(dst, t);   // columns >= N fall into the row padding
                     } else {
                         dst[0] = t.x;
                         if (col + 1 < g.N) dst[1] = t.y;
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                 }
             }
         };
-        if ((g.M1 & 31) == 0 || g.M1 >= g.M) {
+        if (MODE != 0 || (g.M1 & 31) == 0 || g.M1 >= g.M) {   // only the forward GEMM has paired outputs
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) tile_epilogue(mi, std::false_type{});
         } else {
@@ -471,7 +477,8 @@ __device__ __forceinline__ void wg_wait(WgStage& st) {
 }
 
 __global__ __launch_bounds__(256, 2) void k_qwgrad(QGemmArgs g) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: everything derived from it stays in SGPRs
     const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
     // group = one (batch, n-slice): its tiles_m x tiles_n workgroups share the gz rows / code rows of that slice
     int slice, t;

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     __shared__ double red[2 * 4];
     __shared__ float pms[2];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: everything derived from it stays in SGPRs
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
     // group = one (sample, n-tile) activation panel, re-read by the tiles_m row tiles of the weight
     int panel, mt;
