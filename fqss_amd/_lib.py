@@ -67,6 +67,25 @@ _PROTOS = {
     "fqss_kd_loss": [P, P, P, I32, I64, F32, P, P, P, P, P, P],
     "fqss_sumsq": [P, I64, P, P],
     "fqss_adam_clip": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, F32, P, P, P, P],
+    "fqss_rowlin_fwd": [P, P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_rowlin_bwd_x": [P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_rowlin_bwd_w": [P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_colsum": [P, P, I64, I32, I64, P],
+    "fqss_layernorm_fwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P],
+    "fqss_layernorm_bwd": [P, P, P, P, P, P, P, I64, I32, I64, I64, I64, P],
+    "fqss_unary_fwd": [P, P, I64, I32, F64, P],
+    "fqss_unary_bwd": [P, P, P, I64, I32, F64, P],
+    "fqss_permute4": [P, P, I64, I64, I64, I32, I64, I64, I64, P],
+    "fqss_dp_segment_fwd": [P, P, I32, I32, I64, I64, I32, I32, P],
+    "fqss_dp_segment_bwd": [P, P, I32, I32, I64, I64, I32, I32, P],
+    "fqss_dp_merge_fwd": [P, P, P, I32, I32, I32, I32, I32, I64, I64, P],
+    "fqss_dp_merge_bwd": [P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
+    "fqss_ola2_fwd": [P, P, I64, I64, I64, P],
+    "fqss_ola2_bwd": [P, P, I64, I64, I64, P],
+    "fqss_attn_fwd": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, P, P, P],
+    "fqss_attn_bwd": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, I64, I64, I64, P],
+    "fqss_lstm_fwd": [P, P, P, P, P, P, I32, I32, I32, P],
+    "fqss_lstm_bwd": [P, P, P, P, P, I32, I32, I32, P],
 }
 _RESTYPE = {"fqss_last_error": C.c_char_p}
 

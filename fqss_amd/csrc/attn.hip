@@ -1,0 +1,234 @@
+// attn.hip -- the attention core of MultiheadAttentionQ (qat_layers.py:903-911): softmax(q k^T) v per (sequence, head) for
+// the short sequences of the dual-path models (L = chunk length 250 or number of chunks ~200, head_dim 16).
+//
+// One workgroup per (sequence b, head h).  K and V of the head (L x HD floats each, 16 KB at L = 250) sit in LDS; a thread
+// owns whole query rows (q row in registers), so every LDS operand fetch is a wave-wide broadcast (conflict-free) and no
+// cross-lane reduction is needed anywhere: s_ij, the row max, exp, the row sum and o_i = sum_j p_ij v_j all stay in the
+// owning lane.  fp32 FMA on the vector ALU: the problem is 2*L*L*HD = 2 MFLOP per head -- far too small and too skinny
+// (K = 16) to be worth MFMA tiles; the full layer is ~3 GFLOP.  Rows are [l*B + b][E] matrices (sequence-first), head h
+// is the column block [h*HD, (h+1)*HD): exactly the reference's reshape(L, B*nh, hd).permute(1, 0, 2) view, without the copy.
+//
+// The backward recomputes p_ij from the saved row statistics (max, sum) in two owner-computes phases -- thread <-> query row
+// for dq, thread <-> key row for dk / dv -- with q, k, v, dO of the head in LDS: no atomics, deterministic.
+//
+// The reference also runs `activation_fake_quantize_attn(attn)` / `_softmax(attn)` and DISCARDS their results (`attn - fq(attn)`,
+// :907, :909): only their observers see data during the first 50 calls.  obs_attn / obs_soft (optional) receive the running
+// min / max of the logits and of the probabilities for exactly that purpose.
+#include "fqss_dev.h"
+
+namespace fqss {
+
+template <int HD>
+__device__ __forceinline__ float dot_row(const float (&q)[HD], const float* __restrict__ k) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(q[d], k[d], s);
+    return s;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                   const float* __restrict__ v, float* __restrict__ o, float* __restrict__ stats,
+                                                   int L, int B, int nh, int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o,
+                                                   uint32_t* obs_attn, uint32_t* obs_soft) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + (size_t)L * HD;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    for (int e = threadIdx.x; e < L * HD; e += 256) {
+        const int j = e / HD, d = e % HD;
+        const int64_t row = (int64_t)j * B + b;
+        Ks[e] = k[row * ld_k + h * HD + d];
+        Vs[e] = v[row * ld_v + h * HD + d];
+    }
+    __syncthreads();
+    float smin_all = INFINITY, smax_all = -INFINITY, pmin_all = INFINITY, pmax_all = -INFINITY;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const int64_t row = (int64_t)i * B + b;
+        float qr[HD], acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { qr[d] = q[row * ld_q + h * HD + d]; acc[d] = 0.f; }
+        float m = -INFINITY, mn = INFINITY;
+        for (int j = 0; j < L; ++j) {
+            const float s = dot_row<HD>(qr, Ks + j * HD);
+            m = fmaxf(m, s);
+            mn = fminf(mn, s);
+        }
+        float l = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float p = expf(dot_row<HD>(qr, Ks + j * HD) - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, Vs[j * HD + d], acc[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[row * ld_o + h * HD + d] = acc[d] / l;
+        stats[((int64_t)blockIdx.x * L + i) * 2] = m;
+        stats[((int64_t)blockIdx.x * L + i) * 2 + 1] = l;
+        smin_all = fminf(smin_all, mn);
+        smax_all = fmaxf(smax_all, m);
+        pmax_all = fmaxf(pmax_all, 1.0f / l);
+        pmin_all = fminf(pmin_all, expf(mn - m) / l);
+    }
+    if (obs_attn != nullptr) {     // observer phase only (wave-uniform branch)
+        smin_all = wave_min(smin_all); smax_all = wave_max(smax_all);
+        pmin_all = wave_min(pmin_all); pmax_all = wave_max(pmax_all);
+        if ((threadIdx.x & 63) == 0 && smin_all <= smax_all) {
+            atomicMin(obs_attn, f2ord(smin_all)); atomicMax(obs_attn + 1, f2ord(smax_all));
+            atomicMin(obs_soft, f2ord(pmin_all)); atomicMax(obs_soft + 1, f2ord(pmax_all));
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                   const float* __restrict__ v, const float* __restrict__ o,
+                                                   const float* __restrict__ go, const float* __restrict__ stats,
+                                                   float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv, int L,
+                                                   int B, int nh, int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o,
+                                                   int64_t ld_go, int64_t ld_gq, int64_t ld_gk, int64_t ld_gv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;
+    float* Ks = Qs + (size_t)L * HD;
+    float* Vs = Ks + (size_t)L * HD;
+    float* Gs = Vs + (size_t)L * HD;
+    float* Ms = Gs + (size_t)L * HD;     // row max
+    float* Ls = Ms + L;                  // 1 / row sum
+    float* Ds = Ls + L;                  // D_i = sum_d dO_i[d] O_i[d]  (= sum_j p_ij dP_ij)
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    for (int e = threadIdx.x; e < L * HD; e += 256) {
+        const int j = e / HD, d = e % HD;
+        const int64_t row = (int64_t)j * B + b;
+        Qs[e] = q[row * ld_q + h * HD + d];
+        Ks[e] = k[row * ld_k + h * HD + d];
+        Vs[e] = v[row * ld_v + h * HD + d];
+        Gs[e] = go[row * ld_go + h * HD + d];
+    }
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const int64_t row = (int64_t)i * B + b;
+        float dsum = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dsum = fmaf(go[row * ld_go + h * HD + d], o[row * ld_o + h * HD + d], dsum);
+        Ms[i] = stats[((int64_t)blockIdx.x * L + i) * 2];
+        Ls[i] = 1.0f / stats[((int64_t)blockIdx.x * L + i) * 2 + 1];
+        Ds[i] = dsum;
+    }
+    __syncthreads();
+    // phase A: thread <-> query row i: dq_i = sum_j dS_ij k_j
+    for (int i = threadIdx.x; i < L; i += 256) {
+        float qr[HD], gr[HD], acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { qr[d] = Qs[i * HD + d]; gr[d] = Gs[i * HD + d]; acc[d] = 0.f; }
+        const float m = Ms[i], il = Ls[i], D = Ds[i];
+        for (int j = 0; j < L; ++j) {
+            const float p = expf(dot_row<HD>(qr, Ks + j * HD) - m) * il;
+            const float dS = p * (dot_row<HD>(gr, Vs + j * HD) - D);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(dS, Ks[j * HD + d], acc[d]);
+        }
+        const int64_t row = (int64_t)i * B + b;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) gq[row * ld_gq + h * HD + d] = acc[d];
+    }
+    // phase B: thread <-> key row j: dk_j = sum_i dS_ij q_i, dv_j = sum_i p_ij dO_i
+    for (int j = threadIdx.x; j < L; j += 256) {
+        float kr[HD], vr[HD], ak[HD], av[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { kr[d] = Ks[j * HD + d]; vr[d] = Vs[j * HD + d]; ak[d] = av[d] = 0.f; }
+        for (int i = 0; i < L; ++i) {
+            const float p = expf(dot_row<HD>(kr, Qs + i * HD) - Ms[i]) * Ls[i];
+            const float dS = p * (dot_row<HD>(vr, Gs + i * HD) - Ds[i]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                ak[d] = fmaf(dS, Qs[i * HD + d], ak[d]);
+                av[d] = fmaf(p, Gs[i * HD + d], av[d]);
+            }
+        }
+        const int64_t row = (int64_t)j * B + b;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            gk[row * ld_gk + h * HD + d] = ak[d];
+            gv[row * ld_gv + h * HD + d] = av[d];
+        }
+    }
+}
+
+template <typename KernelT>
+static int ensure_lds(KernelT kern, size_t bytes, const char* what) {
+    if (bytes > 160 * 1024) {
+        set_error("%s: sequence too long for the LDS-resident kernel (%zu bytes of LDS)", what, bytes);
+        return FQSS_EINVAL;
+    }
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            set_error("%s: hipFuncSetAttribute(%zu): %s", what, bytes, hipGetErrorString(e));
+            return FQSS_ELAUNCH;
+        }
+    }
+    return FQSS_OK;
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats, int L, int B, int nh,
+                             int hd, int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, uint32_t* obs_attn,
+                             uint32_t* obs_soft, fqss_stream_t stream) {
+    FQSS_REQUIRE(q && k && v && o && stats, "null tensor");
+    FQSS_REQUIRE(L > 0 && B > 0 && nh > 0 && (int64_t)B * nh < (1ll << 31), "bad shape");
+    FQSS_REQUIRE(ld_q >= nh * hd && ld_k >= nh * hd && ld_v >= nh * hd && ld_o >= nh * hd, "row stride below embed dim");
+    FQSS_REQUIRE((obs_attn == nullptr) == (obs_soft == nullptr), "observer workspaces come in pairs");
+    const size_t lds = (size_t)2 * L * hd * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)(B * nh)), block(256);
+#define FQSS_AF(HD_)                                                                                                        \
+    {                                                                                                                       \
+        int rc = ensure_lds(k_attn_fwd<HD_>, lds, "fqss_attn_fwd");                                                          \
+        if (rc != FQSS_OK) return rc;                                                                                       \
+        hipLaunchKernelGGL((k_attn_fwd<HD_>), grid, block, lds, s, q, k, v, o, stats, L, B, nh, ld_q, ld_k, ld_v, ld_o,      \
+                           obs_attn, obs_soft);                                                                             \
+    }
+    switch (hd) {
+        case 2: FQSS_AF(2) break;
+        case 4: FQSS_AF(4) break;
+        case 8: FQSS_AF(8) break;
+        case 16: FQSS_AF(16) break;
+        case 32: FQSS_AF(32) break;
+        default: set_error("fqss_attn_fwd: head_dim %d not built (2, 4, 8, 16, 32)", hd); return FQSS_EINVAL;
+    }
+#undef FQSS_AF
+    return launch_status("fqss_attn_fwd");
+}
+
+extern "C" int fqss_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* go,
+                             const float* stats, float* gq, float* gk, float* gv, int L, int B, int nh, int hd, int64_t ld_q,
+                             int64_t ld_k, int64_t ld_v, int64_t ld_o, int64_t ld_go, int64_t ld_gq, int64_t ld_gk,
+                             int64_t ld_gv, fqss_stream_t stream) {
+    FQSS_REQUIRE(q && k && v && o && go && stats && gq && gk && gv, "null tensor");
+    FQSS_REQUIRE(L > 0 && B > 0 && nh > 0 && (int64_t)B * nh < (1ll << 31), "bad shape");
+    const int E = nh * hd;
+    FQSS_REQUIRE(ld_q >= E && ld_k >= E && ld_v >= E && ld_o >= E && ld_go >= E && ld_gq >= E && ld_gk >= E && ld_gv >= E,
+                 "row stride below embed dim");
+    const size_t lds = ((size_t)4 * L * hd + 3 * (size_t)L) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)(B * nh)), block(256);
+#define FQSS_AB(HD_)                                                                                                        \
+    {                                                                                                                       \
+        int rc = ensure_lds(k_attn_bwd<HD_>, lds, "fqss_attn_bwd");                                                          \
+        if (rc != FQSS_OK) return rc;                                                                                       \
+        hipLaunchKernelGGL((k_attn_bwd<HD_>), grid, block, lds, s, q, k, v, o, go, stats, gq, gk, gv, L, B, nh, ld_q, ld_k,  \
+                           ld_v, ld_o, ld_go, ld_gq, ld_gk, ld_gv);                                                         \
+    }
+    switch (hd) {
+        case 2: FQSS_AB(2) break;
+        case 4: FQSS_AB(4) break;
+        case 8: FQSS_AB(8) break;
+        case 16: FQSS_AB(16) break;
+        case 32: FQSS_AB(32) break;
+        default: set_error("fqss_attn_bwd: head_dim %d not built (2, 4, 8, 16, 32)", hd); return FQSS_EINVAL;
+    }
+#undef FQSS_AB
+    return launch_status("fqss_attn_bwd");
+}

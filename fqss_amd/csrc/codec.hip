@@ -136,8 +136,10 @@ extern "C" int fqss_frames_conv_fwd(const float* x, const float* w, float* z, in
     else if (Ci == 2 && K == 16) FQSS_FC(2, 16);
     else if (Ci == 1 && K == 32) FQSS_FC(1, 32);
     else if (Ci == 2 && K == 32) FQSS_FC(2, 32);
+    else if (Ci == 1 && K == 2) FQSS_FC(1, 2);      // DPTNet encoder: 2-sample window, hop 1 (dptnetq.py:116)
+    else if (Ci == 2 && K == 2) FQSS_FC(2, 2);
     else {
-        set_error("fqss_frames_conv_fwd: unsupported (Ci=%d, K=%d); built for Ci in {1,2}, K in {16,32}", Ci, K);
+        set_error("fqss_frames_conv_fwd: unsupported (Ci=%d, K=%d); built for Ci in {1,2}, K in {2,16,32}", Ci, K);
         return FQSS_EINVAL;
     }
 #undef FQSS_FC
@@ -157,8 +159,11 @@ extern "C" int fqss_ola_convtr_fwd(const float* x, const float* w, float* out, i
     } else if (K == 32 && stride == 16) {
         dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
         hipLaunchKernelGGL((k_ola_convtr_fwd<32, 16>), grid, dim3(256), 0, s, x, w, out, C, M, ld_x, T);
+    } else if (K == 2 && stride == 1) {   // DPTNet's 2-sample window, hop 1 (input gradient of its encoder)
+        dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
+        hipLaunchKernelGGL((k_ola_convtr_fwd<2, 1>), grid, dim3(256), 0, s, x, w, out, C, M, ld_x, T);
     } else {
-        set_error("fqss_ola_convtr_fwd: unsupported (K=%d, stride=%d); built for (16,8) and (32,16)", K, stride);
+        set_error("fqss_ola_convtr_fwd: unsupported (K=%d, stride=%d); built for (2,1), (16,8) and (32,16)", K, stride);
         return FQSS_EINVAL;
     }
     return launch_status("fqss_ola_convtr_fwd");

@@ -1,0 +1,413 @@
+// dualpath.hip -- row-major ("channels-last") layers and data movement of the dual-path models (DPTNet, SURVEY.md §8
+// row a13).  Inside the dual-path blocks every tensor is a row matrix [L][B'][C] (sequence-first, feature dim C
+// contiguous: 64 floats = one 256-B line per (position, sequence)), so LayerNorm is one wavefront per row (C = 64 = one
+// lane per feature, reductions by DPP/shuffle only), the linears are plain row GEMMs (csrc/gemm.hip fqss_rowlin_*) and the
+// intra-/inter-chunk views differ by ONE transposing copy (fqss_permute4) instead of the reference's four
+// permute().contiguous() round trips per block (dptnetq.py:156, 197-204).
+//
+// Reference replaced: F.layer_norm in LayerNormQ (qat_layers.py:455-465); torch.tanh / torch.sigmoid of Conv1dNlQ
+// (dptnetq.py:286-287); q / sqrt(head_dim) (qat_layers.py:905); split_feature / merge_feature (dptnetq.py:232-276);
+// overlap_and_add with a 2-tap frame (dptnetq.py:17-58, 140); bias gradients (column sums) of the row linears.
+#include "fqss_dev.h"
+
+namespace fqss {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm rows
+// One wavefront per row, JC = ceil(C / 64) features per lane.  Two-pass statistics in registers (the row is loaded once).
+template <int JC>
+__global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        float* __restrict__ mean_rstd, int64_t R, int C, int64_t ld_x,
+                                                        int64_t ld_y, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    float ga[JC], be[JC];
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+        const int c = lane + 64 * j;
+        ga[j] = c < C ? gamma[c] : 0.f;
+        be[j] = c < C ? beta[c] : 0.f;
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = wave; r < R; r += nw) {
+        float v[JC], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < C ? x[r * ld_x + c] : 0.f;
+            s += v[j];
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            const float d = c < C ? v[j] - mean : 0.f;
+            q += d * d;
+        }
+        const float var = wave_sum(q) * invC;
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) y[r * ld_y + c] = ((v[j] - mean) * rstd) * ga[j] + be[j];
+        }
+        if (lane == 0) {
+            mean_rstd[2 * r] = mean;
+            mean_rstd[2 * r + 1] = rstd;
+        }
+    }
+}
+
+// gx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = gy * gamma; per-workgroup partial column sums for the
+// affine gradients (registers across the rows of a wave, LDS across the 4 waves, then one atomic per column and workgroup)
+template <int JC>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ gy, const float* __restrict__ x,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                        float* __restrict__ gx, float* __restrict__ ggamma,
+                                                        float* __restrict__ gbeta, int64_t R, int C, int64_t ld_gy,
+                                                        int64_t ld_x, int64_t ld_gx) {
+    __shared__ float red[2][4][64 * JC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nw = (int64_t)gridDim.x * 4;
+    float ga[JC], agg[JC], agb[JC];
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+        const int c = lane + 64 * j;
+        ga[j] = c < C ? gamma[c] : 0.f;
+        agg[j] = agb[j] = 0.f;
+    }
+    const float invC = 1.0f / (float)C;
+    for (int64_t r = wave; r < R; r += nw) {
+        const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
+        float xh[JC], dxh[JC], a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            const float g = c < C ? gy[r * ld_gy + c] : 0.f;
+            xh[j] = c < C ? (x[r * ld_x + c] - mean) * rstd : 0.f;
+            dxh[j] = g * ga[j];
+            a += dxh[j];
+            b += dxh[j] * xh[j];
+            agg[j] += g * xh[j];
+            agb[j] += g;
+        }
+        a = wave_sum(a) * invC;
+        b = wave_sum(b) * invC;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) gx[r * ld_gx + c] = rstd * ((dxh[j] - a) - xh[j] * b);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+        red[0][w][lane + 64 * j] = agg[j];
+        red[1][w][lane + 64 * j] = agb[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * 64 * JC; e += 256) {
+        const int which = e / (64 * JC), c = e % (64 * JC);
+        if (c < C) {
+            const float s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
+            atomicAdd((which == 0 ? ggamma : gbeta) + c, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[c] += sum_r g[r][c]: thread <-> column (coalesced rows), a workgroup sums a slab of rows, one atomic per column
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, float* __restrict__ out, int64_t R, int C,
+                                                 int64_t ld, int64_t rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += g[r * ld + c];
+        s1 += g[(r + 1) * ld + c];
+        s2 += g[(r + 2) * ld + c];
+        s3 += g[(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) s0 += g[r * ld + c];
+    atomicAdd(out + c, (s0 + s1) + (s2 + s3));
+}
+
+// ------------------------------------------------------------------------------------------------ unary maps
+// kind 0: tanh   1: sigmoid = 1 / (1 + exp(-x))   2: x / p (IEEE division: q / sqrt(head_dim))
+__global__ __launch_bounds__(256) void k_unary_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, int kind,
+                                                    float p) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        float r;
+        if (kind == 0) r = tanhf(v);
+        else if (kind == 1) r = 1.0f / (1.0f + expf(-v));
+        else r = v / p;
+        y[i] = r;
+    }
+}
+// ATen: tanh_backward = g * (1 - y*y); sigmoid_backward = g * (1 - y) * y; div by a scalar: g / p
+__global__ __launch_bounds__(256) void k_unary_bwd(const float* __restrict__ g, const float* __restrict__ y,
+                                                    float* __restrict__ gx, int64_t n, int kind, float p) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gv = g[i];
+        float r;
+        if (kind == 0) { const float t = y[i]; r = gv * (1.0f - t * t); }
+        else if (kind == 1) { const float t = y[i]; r = (gv * (1.0f - t)) * t; }
+        else r = gv / p;
+        gx[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ transposing copy
+// y[i0][i1][i2][c] = x[i0*s0 + i1*s1 + i2*s2 + c], c < C contiguous on both sides
+__global__ __launch_bounds__(256) void k_permute4(const float* __restrict__ x, float* __restrict__ y, int64_t n0, int64_t n1,
+                                                   int64_t n2, int C, int64_t s0, int64_t s1, int64_t s2) {
+    const int64_t total = n0 * n1 * n2 * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int64_t i2 = t % n2; t /= n2;
+        const int64_t i1 = t % n1;
+        const int64_t i0 = t / n1;
+        y[i] = x[i0 * s0 + i1 * s1 + i2 * s2 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chunking
+// split_feature (dptnetq.py:247-259) fused with the move to the intra-chunk row layout:
+//   seg[k][b*S + s][n] = fpad[b][n][(s>>1)*K + (s&1)*P + k],  fpad = P zeros | f[b][n][0..T) | rest zeros | P zeros
+__global__ __launch_bounds__(256) void k_dp_segment_fwd(const float* __restrict__ f, float* __restrict__ seg, int B, int N,
+                                                         int64_t T, int64_t ld_f, int K, int S) {
+    const int P = K / 2;
+    const int64_t total = (int64_t)K * B * S * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i % N);
+        int64_t t = i / N;
+        const int s = (int)(t % S); t /= S;
+        const int b = (int)(t % B);
+        const int k = (int)(t / B);
+        const int64_t j = (int64_t)(s >> 1) * K + (s & 1) * P + k - P;   // position in f
+        seg[i] = (j >= 0 && j < T) ? f[((int64_t)b * N + n) * ld_f + j] : 0.f;
+    }
+}
+// gf[b][n][t] = sum of the (at most two) chunk slots that hold position t
+__global__ __launch_bounds__(256) void k_dp_segment_bwd(const float* __restrict__ gseg, float* __restrict__ gf, int B, int N,
+                                                         int64_t T, int64_t ld_gf, int K, int S) {
+    const int P = K / 2;
+    const int64_t total = (int64_t)B * N * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i % T;
+        const int64_t bn = i / T;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        const int64_t j = t + P;                    // position in fpad
+        float v = 0.f;
+        {   // even chunk s = 2a covers fpad[a*K, a*K + K)
+            const int64_t a = j / K;
+            const int k = (int)(j - a * K);
+            if (2 * a < S) v += gseg[(((int64_t)k * B + b) * S + 2 * a) * N + n];
+        }
+        {   // odd chunk s = 2a+1 covers fpad[P + a*K, P + a*K + K)
+            const int64_t a = (j - P) / K;
+            const int k = (int)((j - P) - a * K);
+            if (2 * a + 1 < S) v += gseg[(((int64_t)k * B + b) * S + 2 * a + 1) * N + n];
+        }
+        gf[bn * ld_gf + t] = v;
+    }
+}
+
+// merge_feature (dptnetq.py:261-276) up to its AddQ: gathers the two half-overlapped streams from the inter-chunk row
+// layout o[s][b*K + k][spk*N + n] into channel-first a, b [B*nspk][N][Lm], Lm = (S/2)*K - P:
+//   a[t] = o[s = 2*((t+P)/K)    ][k = (t+P)%K]      b[t] = o[s = 2*(t/K) + 1][k = t%K]
+__global__ __launch_bounds__(256) void k_dp_merge_fwd(const float* __restrict__ o, float* __restrict__ a, float* __restrict__ b,
+                                                       int B, int nspk, int N, int K, int S, int64_t Lm, int64_t ld_ab) {
+    const int P = K / 2, C2 = nspk * N;
+    const int64_t total = (int64_t)B * nspk * N * Lm;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i % Lm;
+        int64_t r = i / Lm;
+        const int n = (int)(r % N); r /= N;
+        const int spk = (int)(r % nspk);
+        const int bb = (int)(r / nspk);
+        const int64_t row = ((int64_t)bb * nspk + spk) * N + n;
+        const int c = spk * N + n;
+        {
+            const int64_t q = (t + P) / K;
+            const int k = (int)((t + P) - q * K);
+            a[row * ld_ab + t] = o[((2 * q) * ((int64_t)B * K) + (int64_t)bb * K + k) * C2 + c];
+        }
+        {
+            const int64_t q = t / K;
+            const int k = (int)(t - q * K);
+            b[row * ld_ab + t] = o[((2 * q + 1) * ((int64_t)B * K) + (int64_t)bb * K + k) * C2 + c];
+        }
+    }
+}
+// go[s][b*K+k][c]: even s from ga (zero for the first P positions of chunk 0), odd s from gb (zero for the last P)
+__global__ __launch_bounds__(256) void k_dp_merge_bwd(const float* __restrict__ ga, const float* __restrict__ gb,
+                                                       float* __restrict__ go, int B, int nspk, int N, int K, int S,
+                                                       int64_t Lm, int64_t ld_ga, int64_t ld_gb) {
+    const int P = K / 2, C2 = nspk * N;
+    const int64_t total = (int64_t)S * B * K * C2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C2);
+        int64_t r = i / C2;
+        const int k = (int)(r % K); r /= K;
+        const int bb = (int)(r % B);
+        const int s = (int)(r / B);
+        const int spk = c / N, n = c - spk * N;
+        const int64_t row = ((int64_t)bb * nspk + spk) * N + n;
+        float v = 0.f;
+        if ((s & 1) == 0) {
+            const int64_t t = (int64_t)(s >> 1) * K + k - P;
+            if (t >= 0 && t < Lm) v = ga[row * ld_ga + t];
+        } else {
+            const int64_t t = (int64_t)(s >> 1) * K + k;
+            if (t < Lm) v = gb[row * ld_gb + t];
+        }
+        go[i] = v;
+    }
+}
+
+// overlap_and_add of 2-sample frames with hop 1 (dptnetq.py:140 with W = 2): y [N][2][L] -> out [N][L+1]
+__global__ __launch_bounds__(256) void k_ola2_fwd(const float* __restrict__ y, float* __restrict__ out, int64_t N, int64_t L,
+                                                   int64_t ld_y) {
+    const int64_t total = N * (L + 1);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i % (L + 1), n = i / (L + 1);
+        const float a = t < L ? y[(2 * n) * ld_y + t] : 0.f;
+        const float b = t >= 1 ? y[(2 * n + 1) * ld_y + t - 1] : 0.f;
+        out[i] = a + b;
+    }
+}
+__global__ __launch_bounds__(256) void k_ola2_bwd(const float* __restrict__ g, float* __restrict__ gy, int64_t N, int64_t L,
+                                                   int64_t ld_gy) {
+    const int64_t total = N * 2 * L;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i % L, r = i / L;       // r = 2n + tap
+        const int64_t n = r >> 1, tap = r & 1;
+        gy[r * ld_gy + t] = g[n * (L + 1) + t + tap];
+    }
+}
+
+static inline unsigned flat_grid(int64_t n) {
+    int64_t nb = cdiv(n, 256);
+    if (nb < 1) nb = 1;
+    if (nb > 16384) nb = 16384;
+    return (unsigned)nb;
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
+                                  int64_t R, int C, int64_t ld_x, int64_t ld_y, double eps, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gamma && beta && y && mean_rstd, "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 256 && ld_x >= C && ld_y >= C, "bad shape (C <= 256)");
+    if (R == 0) return FQSS_OK;
+    int64_t nb = cdiv(R, 4);
+    if (nb > 4096) nb = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    const float e = (float)eps;
+    if (C <= 64) hipLaunchKernelGGL((k_layernorm_fwd<1>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
+    else hipLaunchKernelGGL((k_layernorm_fwd<4>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
+    return launch_status("fqss_layernorm_fwd");
+}
+
+extern "C" int fqss_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean_rstd, float* gx,
+                                  float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy, int64_t ld_x, int64_t ld_gx,
+                                  fqss_stream_t stream) {
+    FQSS_REQUIRE(gy && x && gamma && mean_rstd && gx && ggamma && gbeta, "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 256 && ld_gy >= C && ld_x >= C && ld_gx >= C, "bad shape (C <= 256)");
+    if (R == 0) return FQSS_OK;
+    int64_t nb = cdiv(R, 4 * 16);       // ~16 rows per wave: 64*C atomics per workgroup stay rare
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 64) hipLaunchKernelGGL((k_layernorm_bwd<1>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
+    else hipLaunchKernelGGL((k_layernorm_bwd<4>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
+    return launch_status("fqss_layernorm_bwd");
+}
+
+extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && out && R >= 0 && C > 0 && ld >= C, "bad args");
+    if (R == 0) return FQSS_OK;
+    const int64_t gx = cdiv(C, 256);
+    int64_t gy = cdiv(1024, gx);
+    int64_t rpb = cdiv(R, gy);
+    if (rpb < 32) rpb = 32;
+    gy = cdiv(R, rpb);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, g, out, R, C, ld, rpb);
+    return launch_status("fqss_colsum");
+}
+
+extern "C" int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, double p, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && y && n >= 0 && kind >= 0 && kind <= 2, "bad args");
+    FQSS_REQUIRE(kind != 2 || p != 0.0, "division by zero");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_unary_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind, (float)p);
+    return launch_status("fqss_unary_fwd");
+}
+
+extern "C" int fqss_unary_bwd(const float* g, const float* y, float* gx, int64_t n, int kind, double p, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && gx && n >= 0 && kind >= 0 && kind <= 2 && (kind == 2 || y), "bad args");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_unary_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, g, y, gx, n, kind, (float)p);
+    return launch_status("fqss_unary_bwd");
+}
+
+extern "C" int fqss_permute4(const float* x, float* y, int64_t n0, int64_t n1, int64_t n2, int C, int64_t s0, int64_t s1,
+                             int64_t s2, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && y && n0 >= 0 && n1 >= 0 && n2 >= 0 && C > 0, "bad args");
+    const int64_t n = n0 * n1 * n2 * C;
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_permute4, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n0, n1, n2, C, s0, s1, s2);
+    return launch_status("fqss_permute4");
+}
+
+extern "C" int fqss_dp_segment_fwd(const float* f, float* seg, int B, int N, int64_t T, int64_t ld_f, int K, int S,
+                                   fqss_stream_t stream) {
+    FQSS_REQUIRE(f && seg && B > 0 && N > 0 && T > 0 && ld_f >= T && K >= 2 && K % 2 == 0 && S >= 2 && S % 2 == 0, "bad args");
+    FQSS_REQUIRE((int64_t)(S / 2) * K >= T + K / 2, "S chunks do not cover the signal");
+    hipLaunchKernelGGL(k_dp_segment_fwd, dim3(flat_grid((int64_t)K * B * S * N)), dim3(256), 0, (hipStream_t)stream, f, seg, B, N, T, ld_f, K, S);
+    return launch_status("fqss_dp_segment_fwd");
+}
+
+extern "C" int fqss_dp_segment_bwd(const float* gseg, float* gf, int B, int N, int64_t T, int64_t ld_gf, int K, int S,
+                                   fqss_stream_t stream) {
+    FQSS_REQUIRE(gseg && gf && B > 0 && N > 0 && T > 0 && ld_gf >= T && K >= 2 && K % 2 == 0 && S >= 2 && S % 2 == 0, "bad args");
+    hipLaunchKernelGGL(k_dp_segment_bwd, dim3(flat_grid((int64_t)B * N * T)), dim3(256), 0, (hipStream_t)stream, gseg, gf, B, N, T, ld_gf, K, S);
+    return launch_status("fqss_dp_segment_bwd");
+}
+
+extern "C" int fqss_dp_merge_fwd(const float* o, float* a, float* b, int B, int nspk, int N, int K, int S, int64_t Lm,
+                                 int64_t ld_ab, fqss_stream_t stream) {
+    FQSS_REQUIRE(o && a && b && B > 0 && nspk > 0 && N > 0 && K >= 2 && K % 2 == 0 && S >= 2 && S % 2 == 0, "bad args");
+    FQSS_REQUIRE(Lm == (int64_t)(S / 2) * K - K / 2 && ld_ab >= Lm, "Lm must be (S/2)*K - K/2");
+    hipLaunchKernelGGL(k_dp_merge_fwd, dim3(flat_grid((int64_t)B * nspk * N * Lm)), dim3(256), 0, (hipStream_t)stream, o, a, b, B, nspk, N, K, S, Lm, ld_ab);
+    return launch_status("fqss_dp_merge_fwd");
+}
+
+extern "C" int fqss_dp_merge_bwd(const float* ga, const float* gb, float* go, int B, int nspk, int N, int K, int S, int64_t Lm,
+                                 int64_t ld_ga, int64_t ld_gb, fqss_stream_t stream) {
+    FQSS_REQUIRE(ga && gb && go && B > 0 && nspk > 0 && N > 0 && K >= 2 && K % 2 == 0 && S >= 2 && S % 2 == 0, "bad args");
+    FQSS_REQUIRE(Lm == (int64_t)(S / 2) * K - K / 2 && ld_ga >= Lm && ld_gb >= Lm, "Lm must be (S/2)*K - K/2");
+    hipLaunchKernelGGL(k_dp_merge_bwd, dim3(flat_grid((int64_t)S * B * K * nspk * N)), dim3(256), 0, (hipStream_t)stream, ga, gb, go, B, nspk, N, K, S, Lm, ld_ga, ld_gb);
+    return launch_status("fqss_dp_merge_bwd");
+}
+
+extern "C" int fqss_ola2_fwd(const float* y, float* out, int64_t N, int64_t L, int64_t ld_y, fqss_stream_t stream) {
+    FQSS_REQUIRE(y && out && N >= 0 && L > 0 && ld_y >= L, "bad args");
+    if (N == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_ola2_fwd, dim3(flat_grid(N * (L + 1))), dim3(256), 0, (hipStream_t)stream, y, out, N, L, ld_y);
+    return launch_status("fqss_ola2_fwd");
+}
+
+extern "C" int fqss_ola2_bwd(const float* g, float* gy, int64_t N, int64_t L, int64_t ld_gy, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && gy && N >= 0 && L > 0 && ld_gy >= L, "bad args");
+    if (N == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_ola2_bwd, dim3(flat_grid(N * 2 * L)), dim3(256), 0, (hipStream_t)stream, g, gy, N, L, ld_gy);
+    return launch_status("fqss_ola2_bwd");
+}

@@ -26,6 +26,7 @@ struct GemmArgs {
     const float* B;
     float* C;
     const float* bias;  // [M] or null
+    const float* bias_col;  // [N] or null (row-major "channels-last" linears: the bias runs along C's columns)
     int M, N, K;        // per-batch problem
     int64_t sAb, sAi, sAk;
     int64_t sBb, sBk, sBj;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                 if (row < g.M && col < g.N) {
                     float v = acc[mi][ni][r];
                     if (g.bias != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias[row];
+                    if (g.bias_col != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias_col[col];
                     float* dst = Cb + (int64_t)row * g.sCi + col;
                     if constexpr (ATOMIC) atomicAdd(dst, v); else *dst = v;
                 }
@@ -240,10 +242,12 @@ static int launch_gemm(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, int
     if (!atomic) {
         if (a_kc && !b_kc) { if (vec) FQSS_GEMM(true, false, true, false); else FQSS_GEMM(true, false, false, false); }
         else if (!a_kc && !b_kc) { if (vec) FQSS_GEMM(false, false, true, false); else FQSS_GEMM(false, false, false, false); }
+        else if (a_kc && b_kc) { if (vec) FQSS_GEMM(true, true, true, false); else FQSS_GEMM(true, true, false, false); }
         else { set_error("%s: unsupported operand layout", what); return FQSS_EINVAL; }
     } else {
         if (a_kc && b_kc) { if (vec) FQSS_GEMM(true, true, true, true); else FQSS_GEMM(true, true, false, true); }
         else if (a_kc && !b_kc) { if (vec) FQSS_GEMM(true, false, true, true); else FQSS_GEMM(true, false, false, true); }
+        else if (!a_kc && !b_kc) { if (vec) FQSS_GEMM(false, false, true, true); else FQSS_GEMM(false, false, false, true); }
         else { set_error("%s: unsupported operand layout", what); return FQSS_EINVAL; }
     }
 #undef FQSS_GEMM
@@ -328,4 +332,60 @@ extern "C" int fqss_frames_wgrad(const float* a, const float* x, float* gw, int 
         if (rc != FQSS_OK) return rc;
     }
     return FQSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-major ("channels-last") linears of the dual-path models: x[R][Ci] (row stride ld_x) -> z[R][Co].
+// Reference replaced: F.linear in LinearQ / MultiheadAttentionQ / LSTMQ's input projection (qat_layers.py:521-536,
+// 889-901, 941-942, 590-591), the 1x1 Conv2dQ of DPT.output (dptnetq.py:187) and their autograd.
+//   fwd    z[r][o]   = sum_i x[r][i] w[o][i] + bias[o]      A = x  (k contiguous)  B = w^T (k contiguous)
+//   dgrad  gx[r][i]  = sum_o gz[r][o] w[o][i]               A = gz (k contiguous)  B = w   (j contiguous)
+//   wgrad  gw[o][i] += sum_r gz[r][o] x[r][i]               A = gz^T (i contiguous) B = x  (j contiguous), split-K + atomics
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int fqss_rowlin_fwd(const float* x, const float* w, const float* bias, float* z, int64_t R, int Ci, int Co,
+                               int64_t ld_x, int64_t ld_w, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && w && z, "null tensor");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_x >= Ci && ld_w >= Ci && ld_z >= Co, "bad shape");
+    GemmArgs g{};
+    g.A = x; g.B = w; g.C = z; g.bias = nullptr; g.bias_col = bias;
+    g.M = (int)R; g.N = Co; g.K = Ci;
+    g.sAb = 0; g.sAi = ld_x; g.sAk = 1;
+    g.sBb = 0; g.sBk = 1; g.sBj = ld_w;
+    g.sCb = 0; g.sCi = ld_z;
+    g.ksplit = 1; g.kchunk = Ci;
+    return launch_gemm(g, true, true, false, 1, (hipStream_t)stream, "fqss_rowlin_fwd");
+}
+
+extern "C" int fqss_rowlin_bwd_x(const float* gz, const float* w, float* gx, int64_t R, int Ci, int Co, int64_t ld_gz,
+                                 int64_t ld_w, int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && w && gx, "null tensor");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_w >= Ci && ld_gx >= Ci, "bad shape");
+    GemmArgs g{};
+    g.A = gz; g.B = w; g.C = gx; g.bias = nullptr; g.bias_col = nullptr;
+    g.M = (int)R; g.N = Ci; g.K = Co;
+    g.sAb = 0; g.sAi = ld_gz; g.sAk = 1;
+    g.sBb = 0; g.sBk = ld_w; g.sBj = 1;
+    g.sCb = 0; g.sCi = ld_gx;
+    g.ksplit = 1; g.kchunk = Co;
+    return launch_gemm(g, true, false, false, 1, (hipStream_t)stream, "fqss_rowlin_bwd_x");
+}
+
+extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,
+                                 int64_t ld_x, int64_t ld_gw, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && x && gw, "null tensor");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_x >= Ci && ld_gw >= Ci, "bad shape");
+    if (R == 0) return FQSS_OK;
+    GemmArgs g{};
+    g.A = gz; g.B = x; g.C = gw; g.bias = nullptr; g.bias_col = nullptr;
+    g.M = Co; g.N = Ci; g.K = (int)R;
+    g.sAb = 0; g.sAi = 1; g.sAk = ld_gz;   // A(i=o, k=r) = gz[r*ld + o]
+    g.sBb = 0; g.sBk = ld_x; g.sBj = 1;    // B(k=r, j=i) = x[r*ld + i]
+    g.sCb = 0; g.sCi = ld_gw;
+    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
+    int want = (int)cdiv(512, tiles);
+    int kchunk = (int)cdiv(cdiv(R, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    g.kchunk = kchunk;
+    g.ksplit = (int)cdiv(R, kchunk);
+    return launch_gemm(g, false, false, true, 1, (hipStream_t)stream, "fqss_rowlin_bwd_w");
 }

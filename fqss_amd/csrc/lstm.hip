@@ -1,0 +1,229 @@
+// lstm.hip -- the recurrence of LSTMQ (qat_layers.py:571-600: torch's fused bidirectional LSTM on fake-quantized weights,
+// zero initial state).  The input projection x W_ih^T + b_ih of BOTH directions is one row GEMM (fqss_rowlin_fwd, Co = 8H)
+// in front of this kernel and the weight / input gradients are row GEMMs behind the backward kernel; what is left here is the
+// strictly sequential part: per step one [NB x H] x [H x 4H] product and the cell update.
+//
+// MI355X mapping.  Sequences are independent, so a workgroup owns NB = 2 sequences of one direction for ALL S steps: no grid
+// synchronisation, the whole recurrence is one launch per layer (388 sequence-directions -> 194 workgroups on 256 CUs).
+// With H = 128 the recurrent matrix is 512 x 128 fp32 = 256 KB: too big for LDS (160 KB) but it fits the register file of
+// ONE workgroup -- 512 threads, thread j keeps row j of W_hh (128 VGPRs) for the whole kernel, so a step reads nothing from
+// memory but the pre-computed input projection (prefetched one step ahead).  h_{t-1} of the NB sequences lives in LDS and is
+// fetched by wave-wide broadcast reads (conflict-free).  The backward kernel holds the same matrix column-wise
+// (thread (k, gate block) keeps W_hh[block*H .. +H][k]) for dh_{t-1} = dgates_t W_hh.
+// A generic variant (template H = 0) streams W_hh from L2 instead; it serves odd sizes (tests) only.
+//
+// Saved for the backward: the four gate activations and the cell state per step (5H floats per step and sequence-direction).
+#include "fqss_dev.h"
+
+namespace fqss {
+
+constexpr int kNB = 2;   // sequences per workgroup
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// pre   [S][B][2][4H]  input projection incl. b_ih (gate order i, f, g, o)
+// whh   [2][4H][H], bhh [2][4H]
+// hout  [S][B][2H]     (forward | reverse halves)
+// gsav  [S][B][2][4H]  gate activations, csav [S][B][2][H] cell states
+template <int HT>
+__global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float* __restrict__ pre, const float* __restrict__ whh,
+                                                                      const float* __restrict__ bhh, float* __restrict__ hout,
+                                                                      float* __restrict__ gsav, float* __restrict__ csav, int S,
+                                                                      int B, int Hrt) {
+    const int H = HT > 0 ? HT : Hrt;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hs = smem;                 // [kNB][H]
+    float* gs = smem + kNB * H;       // [kNB][4H]
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * kNB;
+    const int j = threadIdx.x;        // gate row (j < 4H)
+    const bool jv = j < 4 * H;
+    const float* W = whh + ((int64_t)dir * 4 * H + (jv ? j : 0)) * H;
+    float wreg[HT > 0 ? HT : 1];
+    if constexpr (HT > 0) {
+#pragma unroll
+        for (int k = 0; k < HT; ++k) wreg[k] = W[k];
+    }
+    const float bj = jv ? bhh[dir * 4 * H + j] : 0.f;
+    for (int e = threadIdx.x; e < kNB * H; e += blockDim.x) hs[e] = 0.f;
+    float c = 0.f;                    // cell state of (nb, k) = (threadIdx / H, threadIdx % H) for threadIdx < kNB*H
+    const int cn = threadIdx.x / H, ck = threadIdx.x - cn * H;
+    const bool cell = threadIdx.x < kNB * H && (b0 + cn) < B;
+    __syncthreads();
+    float pcur[kNB], pnext[kNB];
+    {
+        const int t = dir == 0 ? 0 : S - 1;
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb)
+            pcur[nb] = (jv && b0 + nb < B) ? pre[(((int64_t)t * B + b0 + nb) * 2 + dir) * 4 * H + j] : 0.f;
+    }
+    for (int step = 0; step < S; ++step) {
+        const int t = dir == 0 ? step : S - 1 - step;
+        if (step + 1 < S) {
+            const int tn = dir == 0 ? step + 1 : S - 2 - step;
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb)
+                pnext[nb] = (jv && b0 + nb < B) ? pre[(((int64_t)tn * B + b0 + nb) * 2 + dir) * 4 * H + j] : 0.f;
+        }
+        if (jv) {
+            float acc[kNB];
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) acc[nb] = 0.f;
+            if constexpr (HT > 0) {
+#pragma unroll
+                for (int k = 0; k < HT; k += 4) {
+#pragma unroll
+                    for (int nb = 0; nb < kNB; ++nb) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hs + nb * HT + k);
+                        acc[nb] = fmaf(wreg[k], hv.x, acc[nb]);
+                        acc[nb] = fmaf(wreg[k + 1], hv.y, acc[nb]);
+                        acc[nb] = fmaf(wreg[k + 2], hv.z, acc[nb]);
+                        acc[nb] = fmaf(wreg[k + 3], hv.w, acc[nb]);
+                    }
+                }
+            } else {
+                for (int k = 0; k < H; ++k) {
+                    const float wv = W[k];
+#pragma unroll
+                    for (int nb = 0; nb < kNB; ++nb) acc[nb] = fmaf(wv, hs[nb * H + k], acc[nb]);
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) gs[nb * 4 * H + j] = pcur[nb] + (acc[nb] + bj);
+        }
+        __syncthreads();
+        if (cell) {
+            const float* g = gs + cn * 4 * H;
+            const float gi = sigmoidf_(g[ck]), gf = sigmoidf_(g[H + ck]), gg = tanhf(g[2 * H + ck]), go = sigmoidf_(g[3 * H + ck]);
+            c = gf * c + gi * gg;
+            const float h = go * tanhf(c);
+            hs[cn * H + ck] = h;
+            const int64_t sb = (int64_t)t * B + b0 + cn;
+            hout[sb * 2 * H + dir * H + ck] = h;
+            float* gsv = gsav + (sb * 2 + dir) * 4 * H;
+            gsv[ck] = gi; gsv[H + ck] = gf; gsv[2 * H + ck] = gg; gsv[3 * H + ck] = go;
+            csav[(sb * 2 + dir) * H + ck] = c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) pcur[nb] = pnext[nb];
+    }
+}
+
+// gout [S][B][2H] -> dG [S][B][2][4H] (gradient w.r.t. the gate pre-activations); everything else follows by GEMMs
+template <int HT>
+__global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float* __restrict__ gout, const float* __restrict__ whh,
+                                                                      const float* __restrict__ gsav, const float* __restrict__ csav,
+                                                                      float* __restrict__ dG, int S, int B, int Hrt) {
+    const int H = HT > 0 ? HT : Hrt;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dgs = smem;                   // [kNB][4H]
+    float* ps = smem + kNB * 4 * H;      // [4][kNB][H] partial dh_{t-1}
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * kNB;
+    const int tid = threadIdx.x;
+    const bool tv = tid < 4 * H;
+    const int part = tv ? tid / H : 0, k = tv ? tid - part * H : 0;
+    const float* Wc = whh + ((int64_t)dir * 4 * H + part * H) * H + k;   // column k of gate block `part`, row stride H
+    float wreg[HT > 0 ? HT : 1];
+    if constexpr (HT > 0) {
+#pragma unroll
+        for (int r = 0; r < HT; ++r) wreg[r] = Wc[(int64_t)r * HT];
+    }
+    for (int e = tid; e < 4 * kNB * H; e += blockDim.x) ps[e] = 0.f;
+    const int cn = tid / H, ck = tid - cn * H;
+    const bool cell = tid < kNB * H && (b0 + cn) < B;
+    float dc_rec = 0.f;
+    __syncthreads();
+    for (int step = S - 1; step >= 0; --step) {
+        const int t = dir == 0 ? step : S - 1 - step;
+        if (cell) {
+            const int64_t sb = (int64_t)t * B + b0 + cn;
+            const float dh = gout[sb * 2 * H + dir * H + ck] +
+                             ((ps[(0 * kNB + cn) * H + ck] + ps[(1 * kNB + cn) * H + ck]) + (ps[(2 * kNB + cn) * H + ck] + ps[(3 * kNB + cn) * H + ck]));
+            const float* gsv = gsav + (sb * 2 + dir) * 4 * H;
+            const float gi = gsv[ck], gf = gsv[H + ck], gg = gsv[2 * H + ck], go = gsv[3 * H + ck];
+            const float cc = csav[(sb * 2 + dir) * H + ck];
+            float cprev = 0.f;
+            if (step > 0) {
+                const int tp = dir == 0 ? step - 1 : S - step;
+                cprev = csav[((((int64_t)tp * B + b0 + cn) * 2) + dir) * H + ck];
+            }
+            const float tc = tanhf(cc);
+            const float dc = dc_rec + (dh * go) * (1.0f - tc * tc);
+            const float d_o = ((dh * tc) * (1.0f - go)) * go;
+            const float d_i = ((dc * gg) * (1.0f - gi)) * gi;
+            const float d_f = ((dc * cprev) * (1.0f - gf)) * gf;
+            const float d_g = (dc * gi) * (1.0f - gg * gg);
+            dc_rec = dc * gf;
+            float* d = dgs + cn * 4 * H;
+            d[ck] = d_i; d[H + ck] = d_f; d[2 * H + ck] = d_g; d[3 * H + ck] = d_o;
+            float* o = dG + (sb * 2 + dir) * 4 * H;
+            o[ck] = d_i; o[H + ck] = d_f; o[2 * H + ck] = d_g; o[3 * H + ck] = d_o;
+        }
+        __syncthreads();
+        if (tv) {
+            float acc[kNB];
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) acc[nb] = 0.f;
+            if constexpr (HT > 0) {
+#pragma unroll
+                for (int r = 0; r < HT; r += 4) {
+#pragma unroll
+                    for (int nb = 0; nb < kNB; ++nb) {
+                        const float4 dv = *reinterpret_cast<const float4*>(dgs + nb * 4 * HT + part * HT + r);
+                        acc[nb] = fmaf(wreg[r], dv.x, acc[nb]);
+                        acc[nb] = fmaf(wreg[r + 1], dv.y, acc[nb]);
+                        acc[nb] = fmaf(wreg[r + 2], dv.z, acc[nb]);
+                        acc[nb] = fmaf(wreg[r + 3], dv.w, acc[nb]);
+                    }
+                }
+            } else {
+                for (int r = 0; r < H; ++r) {
+                    const float wv = Wc[(int64_t)r * H];
+#pragma unroll
+                    for (int nb = 0; nb < kNB; ++nb) acc[nb] = fmaf(wv, dgs[nb * 4 * H + part * H + r], acc[nb]);
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) ps[(part * kNB + nb) * H + k] = acc[nb];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+extern "C" int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* hout, float* gsav, float* csav,
+                             int S, int B, int H, fqss_stream_t stream) {
+    FQSS_REQUIRE(pre && whh && bhh && hout && gsav && csav, "null tensor");
+    FQSS_REQUIRE(S > 0 && B > 0 && H > 0 && H <= 256, "bad shape (H <= 256)");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(B, kNB), 2);
+    const size_t lds = (size_t)(kNB * H + kNB * 4 * H) * sizeof(float);
+    if (H == 128) {
+        hipLaunchKernelGGL((k_lstm_fwd<128>), grid, dim3(512), lds, s, pre, whh, bhh, hout, gsav, csav, S, B, H);
+    } else {
+        const int threads = (int)cdiv(4 * H, 64) * 64;
+        hipLaunchKernelGGL((k_lstm_fwd<0>), grid, dim3(threads), lds, s, pre, whh, bhh, hout, gsav, csav, S, B, H);
+    }
+    return launch_status("fqss_lstm_fwd");
+}
+
+extern "C" int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
+                             int B, int H, fqss_stream_t stream) {
+    FQSS_REQUIRE(gout && whh && gsav && csav && dG, "null tensor");
+    FQSS_REQUIRE(S > 0 && B > 0 && H > 0 && H <= 256, "bad shape (H <= 256)");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv(B, kNB), 2);
+    const size_t lds = (size_t)(kNB * 4 * H + 4 * kNB * H) * sizeof(float);
+    if (H == 128) {
+        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds, s, gout, whh, gsav, csav, dG, S, B, H);
+    } else {
+        const int threads = (int)cdiv(4 * H, 64) * 64;
+        hipLaunchKernelGGL((k_lstm_bwd<0>), grid, dim3(threads), lds, s, gout, whh, gsav, csav, dG, S, B, H);
+    }
+    return launch_status("fqss_lstm_bwd");
+}

@@ -110,13 +110,16 @@ def minmax(x, obs_ws):
     _lib.call("fqss_minmax", _p(x), rows, cols, ld, _p(obs_ws), _stream())
 
 
-def actq_bwd(z, g, act, slope, qmode, qmin, qmax, gacc, gbias=None, C=0):
+def actq_bwd(z, g, act, slope, qmode, qmin, qmax, gacc, gbias=None, C=0, out=None):
+    """out: optional row-matrix view (e.g. a column block of a wider buffer) that receives gz"""
     _need_gpu(z, g)
     z, rows, cols, ld_z = as_rowmat(z)
     g, r2, c2, ld_g = as_rowmat(g)
     assert (rows, cols) == (r2, c2), "actq_bwd: z/g shape mismatch"
-    gz = empty_act(tuple(z.shape), z.device)
-    ld_gz = rowmat(gz)[2]
+    gz = empty_act(tuple(z.shape), z.device) if out is None else out
+    rm = rowmat(gz)
+    assert rm is not None and rm[:2] == (rows, cols), "actq_bwd: `out` must be a row-matrix view of z's shape"
+    ld_gz = rm[2]
     _lib.call("fqss_actq_bwd", _p(z), _p(g), _p(gz), rows, cols, ld_z, ld_g, ld_gz, act, _p(slope), qmode,
               _p(qmin), _p(qmax), _p(gacc), _p(gbias), C, _stream())
     return gz
@@ -679,3 +682,220 @@ def tdw(x, stats_in, gamma, beta, eps, w, bias, slope, stats_out, dil, pad):
 def tstats(x, ws):
     x, B, C, M, ld = _bcm(x)
     _lib.call("fqss_tstats", _p(x), B, C, M, ld, _p(ws), _stream())
+
+
+# ================================================================== dual-path models (cfg 3)
+UNARY_TANH, UNARY_SIGMOID, UNARY_DIVS = 0, 1, 2
+
+
+def _rows(t, C):
+    """a tensor whose last dim is C as a row matrix (tensor, R, ld); dense copy if its layout is foreign"""
+    assert t.shape[-1] == C
+    rm = rowmat(t)
+    if rm is None or rm[1] != C:
+        t = t.contiguous()
+        rm = rowmat(t)
+        if rm is None or rm[1] != C:
+            return t, t.numel() // C, C
+    return t, rm[0], rm[2]
+
+
+def rowlin_fwd(x, w, bias, out=None):
+    """z[..., o] = sum_i x[..., i] w[o][i] + bias[o]; `out`: a [..., Co] view (e.g. a column block) to write into"""
+    _need_gpu(x, w, bias)
+    Co, Ci = w.shape
+    x, R, ld_x = _rows(x, Ci)
+    assert w.stride(1) == 1
+    z = torch.empty(*x.shape[:-1], Co, device=x.device, dtype=torch.float32) if out is None else out
+    zz, Rz, ld_z = _rows(z, Co)
+    assert zz is z and Rz == R, "rowlin_fwd: `out` must be a row-matrix view"
+    _lib.call("fqss_rowlin_fwd", _p(x), _p(w), _p(bias), _p(z), R, Ci, Co, ld_x, w.stride(0), ld_z, _stream())
+    return z
+
+
+def rowlin_bwd_x(gz, w):
+    _need_gpu(gz, w)
+    Co, Ci = w.shape
+    gz, R, ld_gz = _rows(gz, Co)
+    gx = torch.empty(*gz.shape[:-1], Ci, device=gz.device, dtype=torch.float32)
+    _lib.call("fqss_rowlin_bwd_x", _p(gz), _p(w), _p(gx), R, Ci, Co, ld_gz, w.stride(0), Ci, _stream())
+    return gx
+
+
+def rowlin_bwd_w(gz, x, gw):
+    """gw[Co][Ci] += gz^T x over all rows (gw: caller-zeroed accumulator, may be a row-block view)"""
+    _need_gpu(gz, x, gw)
+    Co, Ci = gw.shape
+    gz, R, ld_gz = _rows(gz, Co)
+    x, R2, ld_x = _rows(x, Ci)
+    assert R == R2 and gw.stride(1) == 1
+    _lib.call("fqss_rowlin_bwd_w", _p(gz), _p(x), _p(gw), R, Ci, Co, ld_gz, ld_x, gw.stride(0), _stream())
+
+
+def colsum(g, out):
+    """out[C] += column sums of g[..., C]"""
+    _need_gpu(g, out)
+    C = out.numel()
+    g, R, ld = _rows(g, C)
+    _lib.call("fqss_colsum", _p(g), _p(out), R, C, ld, _stream())
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    _need_gpu(x, gamma, beta)
+    C = gamma.numel()
+    x, R, ld_x = _rows(x, C)
+    y = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    mean_rstd = torch.empty(R, 2, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean_rstd), R, C, ld_x, C, float(eps), _stream())
+    return y, mean_rstd
+
+
+def layernorm_bwd(gy, x, gamma, mean_rstd, ggamma, gbeta):
+    _need_gpu(gy, x, gamma, mean_rstd, ggamma, gbeta)
+    C = gamma.numel()
+    gy, R, ld_gy = _rows(gy, C)
+    x, _, ld_x = _rows(x, C)
+    gx = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_layernorm_bwd", _p(gy), _p(x), _p(gamma), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_gy, ld_x, C,
+              _stream())
+    return gx
+
+
+def unary_fwd(x, kind, p=1.0):
+    _need_gpu(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.call("fqss_unary_fwd", _p(x), _p(y), x.numel(), kind, float(p), _stream())
+    return y
+
+
+def unary_bwd(g, y, kind, p=1.0):
+    _need_gpu(g, y)
+    g = g.contiguous()
+    gx = torch.empty_like(g)
+    _lib.call("fqss_unary_bwd", _p(g), _p(y), _p(gx), g.numel(), kind, float(p), _stream())
+    return gx
+
+
+def permute4(x, dims_out, strides_in, C):
+    """y[i0][i1][i2][:C] = x[i0*s0 + i1*s1 + i2*s2 : +C]   (x dense, strides in elements)"""
+    _need_gpu(x)
+    x = x.contiguous()
+    n0, n1, n2 = dims_out
+    y = torch.empty(n0, n1, n2, C, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_permute4", _p(x), _p(y), n0, n1, n2, C, strides_in[0], strides_in[1], strides_in[2], _stream())
+    return y
+
+
+def dp_chunks(T, K):
+    """(rest, S) of split_feature (dptnetq.py:232-259) for a length-T feature map and chunk length K"""
+    P = K // 2
+    rest = K - (P + T % K) % K
+    return rest, 2 * (T + rest + P) // K
+
+
+def dp_segment_fwd(f, K):
+    """f [B][N][T] -> seg [K][B*S][N]"""
+    f, B, N, T, ld = _bcm(f)
+    _, S = dp_chunks(T, K)
+    seg = torch.empty(K, B * S, N, device=f.device, dtype=torch.float32)
+    _lib.call("fqss_dp_segment_fwd", _p(f), _p(seg), B, N, T, ld, K, S, _stream())
+    return seg
+
+
+def dp_segment_bwd(gseg, B, N, T, K):
+    _need_gpu(gseg)
+    gseg = gseg.contiguous()
+    _, S = dp_chunks(T, K)
+    gf = empty_act((B, N, T), gseg.device)
+    _lib.call("fqss_dp_segment_bwd", _p(gseg), _p(gf), B, N, T, rowmat(gf)[2], K, S, _stream())
+    return gf
+
+
+def dp_merge_fwd(o, B, nspk, N, K, S):
+    """o [S][B*K][nspk*N] -> a, b [B*nspk][N][Lm]"""
+    _need_gpu(o)
+    o = o.contiguous()
+    Lm = (S // 2) * K - K // 2
+    a = empty_act((B * nspk, N, Lm), o.device)
+    b = empty_act((B * nspk, N, Lm), o.device)
+    _lib.call("fqss_dp_merge_fwd", _p(o), _p(a), _p(b), B, nspk, N, K, S, Lm, rowmat(a)[2], _stream())
+    return a, b
+
+
+def dp_merge_bwd(ga, gb, B, nspk, N, K, S):
+    Lm = (S // 2) * K - K // 2
+    dev = (ga if ga is not None else gb).device
+    if ga is None:
+        ga = empty_act((B * nspk, N, Lm), dev).zero_()
+    if gb is None:
+        gb = empty_act((B * nspk, N, Lm), dev).zero_()
+    ga, _, _, _, ld_ga = _bcm(ga)
+    gb, _, _, _, ld_gb = _bcm(gb)
+    go = torch.empty(S, B * K, nspk * N, device=dev, dtype=torch.float32)
+    _lib.call("fqss_dp_merge_bwd", _p(ga), _p(gb), _p(go), B, nspk, N, K, S, Lm, ld_ga, ld_gb, _stream())
+    return go
+
+
+def ola2_fwd(y):
+    """y [N][2][L] -> [N][L+1]"""
+    y, N, two, L, ld = _bcm(y)
+    assert two == 2
+    out = torch.empty(N, L + 1, device=y.device, dtype=torch.float32)
+    _lib.call("fqss_ola2_fwd", _p(y), _p(out), N, L, ld, _stream())
+    return out
+
+
+def ola2_bwd(g):
+    _need_gpu(g)
+    g = g.contiguous()
+    N, L1 = g.shape
+    gy = empty_act((N, 2, L1 - 1), g.device)
+    _lib.call("fqss_ola2_bwd", _p(g), _p(gy), N, L1 - 1, rowmat(gy)[2], _stream())
+    return gy
+
+
+def attn_fwd(q, k, v, L, B, nh, obs_attn=None, obs_soft=None):
+    """q, k, v: [L*B rows][E] row matrices (views allowed) -> heads [L, B, E], stats"""
+    E = q.shape[-1]
+    q, _, ld_q = _rows(q, E)
+    k, _, ld_k = _rows(k, E)
+    v, _, ld_v = _rows(v, E)
+    o = torch.empty(L, B, E, device=q.device, dtype=torch.float32)
+    stats = torch.empty(B * nh, L, 2, device=q.device, dtype=torch.float32)
+    _lib.call("fqss_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(stats), L, B, nh, E // nh, ld_q, ld_k, ld_v, E, _p(obs_attn), _p(obs_soft),
+              _stream())
+    return o, stats
+
+
+def attn_bwd(q, k, v, o, go, stats, L, B, nh):
+    E = q.shape[-1]
+    q, _, ld_q = _rows(q, E)
+    k, _, ld_k = _rows(k, E)
+    v, _, ld_v = _rows(v, E)
+    o, _, ld_o = _rows(o, E)
+    go, _, ld_go = _rows(go, E)
+    gq = torch.empty(L, B, E, device=q.device, dtype=torch.float32)
+    gk, gv = torch.empty_like(gq), torch.empty_like(gq)
+    _lib.call("fqss_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(go), _p(stats), _p(gq), _p(gk), _p(gv), L, B, nh, E // nh, ld_q, ld_k, ld_v,
+              ld_o, ld_go, E, E, E, _stream())
+    return gq, gk, gv
+
+
+def lstm_fwd(pre, whh, bhh, S, B, H):
+    """pre [S, B, 8H] (fwd gates | reverse gates), whh [2, 4H, H], bhh [2, 4H] -> hout [S, B, 2H], (gsav, csav)"""
+    _need_gpu(pre, whh, bhh)
+    assert pre.is_contiguous() and whh.is_contiguous() and bhh.is_contiguous()
+    hout = torch.empty(S, B, 2 * H, device=pre.device, dtype=torch.float32)
+    gsav = torch.empty(S, B, 8 * H, device=pre.device, dtype=torch.float32)
+    csav = torch.empty(S, B, 2 * H, device=pre.device, dtype=torch.float32)
+    _lib.call("fqss_lstm_fwd", _p(pre), _p(whh), _p(bhh), _p(hout), _p(gsav), _p(csav), S, B, H, _stream())
+    return hout, gsav, csav
+
+
+def lstm_bwd(gout, whh, gsav, csav, S, B, H):
+    _need_gpu(gout, whh)
+    gout = gout.contiguous()
+    dG = torch.empty(S, B, 8 * H, device=gout.device, dtype=torch.float32)
+    _lib.call("fqss_lstm_bwd", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), S, B, H, _stream())
+    return dG

@@ -208,8 +208,8 @@ def _flush_ranges(q, slope, slope_param, act):
     return (None if s_direct else s_buf), (None if mn_direct else mn_buf), (None if mx_direct else mx_buf)
 
 
-def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=None, C=0):
-    """returns gz and the autograd gradients (g_slope, g_qmin, g_qmax, g_bias)"""
+def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=None, C=0, out=None):
+    """returns gz and the autograd gradients (g_slope, g_qmin, g_qmax, g_bias); out: row-matrix view that receives gz"""
     need_acc = (q.qmode == Q_QUANT) or (act == ACT_PRELU)
     gacc = None
     if need_acc:
@@ -217,7 +217,7 @@ def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=N
     gb, gb_direct = (None, True)
     if bias_like is not None:
         gb, gb_direct = _grad_buf(bias_param, bias_like)
-    gz = K.actq_bwd(z, g, act, slope, q.qmode, q.qmin, q.qmax, gacc, gbias=gb, C=C)
+    gz = K.actq_bwd(z, g, act, slope, q.qmode, q.qmin, q.qmax, gacc, gbias=gb, C=C, out=out)
     g_slope = g_min = g_max = None
     if need_acc and q.owner is not None and getattr(q.owner, "_fqss_deferred", False):
         _touch(slope_param if act == ACT_PRELU else None, q.owner.min_range if q.qmode == Q_QUANT else None,

@@ -1,0 +1,286 @@
+"""Autograd glue of the dual-path layers (DPTNet): row-major linears, LayerNorm rows, the attention
+core with its four input-side quantizers, the bidirectional LSTM, and the chunking data movement.  Like fqss_amd/ops.py:
+torch is memory / streams / autograd graph only, every op is a HIP kernel behind the C ABI (fqss_amd/kernels.py).
+
+The output fake-quantizer of a layer is applied as its own node (`ops.NlActQ`, the same fqss_actq_fwd/bwd launches the
+ConvTasNet path uses un-fused); inside the dual-path blocks tensors are sequence-first row matrices [L, B', C]."""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from . import ops
+
+
+def _param_grad(param, like):
+    """(buffer, direct) -- accumulate straight into the arena gradient when the tensor is a leaf parameter that has one"""
+    if isinstance(param, torch.nn.Parameter):
+        return ops._grad_buf(param, like)
+    return torch.zeros_like(like), False
+
+
+def touch(*ts):
+    """start the Adam clock of the leaf parameters behind these tensors (the parameter itself or a view of it): the arena
+    only steps parameters that were marked as having received a gradient (torch.optim.Adam: `grad is not None`)"""
+    for t in ts:
+        if t is None:
+            continue
+        base = t._base if (t._is_view() and t._base is not None) else t
+        if isinstance(base, torch.nn.Parameter):
+            base._fqss_touched = True
+
+
+class RowLinear(Function):
+    """z = x @ w^T + bias on the last dim -- F.linear of LinearQ / the MHA projections / the 1x1 Conv2dQ (qat_layers.py:521-536,
+    889-901, 941).  w is the (possibly fake-quantized) weight [Co, Ci]; bias a parameter or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.bias = bias
+        touch(w, bias)
+        return K.rowlin_fwd(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w = ctx.saved_tensors
+        gz = gz.contiguous()
+        gx = K.rowlin_bwd_x(gz, w) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw, direct = _param_grad(w, w)
+            K.rowlin_bwd_w(gz, x, gw)
+            gw = None if direct else gw
+        gb = None
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            gb, direct = _param_grad(ctx.bias, ctx.bias)
+            K.colsum(gz, gb)
+            gb = None if direct else gb
+        return gx, gw, gb
+
+
+class LayerNormRows(Function):
+    """F.layer_norm over the last dim (LayerNormQ, qat_layers.py:455-465), one wavefront per row"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean_rstd = K.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, beta, mean_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mean_rstd = ctx.saved_tensors
+        gg, d1 = _param_grad(gamma, gamma)
+        gb, d2 = _param_grad(beta, beta)
+        gx = K.layernorm_bwd(gy, x, gamma, mean_rstd, gg, gb)
+        return gx, (None if d1 else gg), (None if d2 else gb), None
+
+
+class Unary(Function):
+    """tanh / sigmoid (the gated output convs, dptnetq.py:286-287)"""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        y = K.unary_fwd(x, kind)
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return K.unary_bwd(g, y, ctx.kind), None
+
+
+class Permute4(Function):
+    """y[i0, i1, i2, :] = x viewed with element strides `sin`; the backward is the inverse move (`sback` over x's own dims)"""
+
+    @staticmethod
+    def forward(ctx, x, dims_out, sin, dims_in, sback):
+        ctx.dims_in, ctx.sback, ctx.C, ctx.xshape = dims_in, sback, x.shape[-1], tuple(x.shape)
+        return K.permute4(x.contiguous(), dims_out, sin, x.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.permute4(g.contiguous(), ctx.dims_in, ctx.sback, ctx.C).view(ctx.xshape), None, None, None, None
+
+
+def rows_to_cols(x, B, S):
+    """intra-chunk layout [K, B*S, N] -> inter-chunk layout [S, B*K, N]"""
+    Kc, BS, N = x.shape
+    assert BS == B * S
+    # out[s][b][k] = in[k][b*S + s]
+    y = Permute4.apply(x, (S, B, Kc), (N, S * N, BS * N), (Kc, B, S), (N, Kc * N, B * Kc * N))
+    return y.view(S, B * Kc, N)
+
+
+def cols_to_rows(x, B, Kc):
+    """inter-chunk layout [S, B*K, N] -> intra-chunk layout [K, B*S, N]"""
+    S, BK, N = x.shape
+    assert BK == B * Kc
+    y = Permute4.apply(x, (Kc, B, S), (N, Kc * N, BK * N), (S, B, Kc), (N, S * N, B * S * N))
+    return y.view(Kc, B * S, N)
+
+
+class Segment(Function):
+    """split_feature (dptnetq.py:232-259): f [B, N, T] -> intra-chunk rows [K, B*S, N]"""
+
+    @staticmethod
+    def forward(ctx, f, Kc):
+        ctx.shape, ctx.Kc = tuple(f.shape), Kc
+        return K.dp_segment_fwd(f, Kc)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, T = ctx.shape
+        return K.dp_segment_bwd(g, B, N, T, ctx.Kc), None
+
+
+class MergeStreams(Function):
+    """merge_feature (dptnetq.py:261-276) up to its Add: inter-chunk rows [S, B*K, nspk*N] -> a, b [B*nspk, N, Lm]"""
+
+    @staticmethod
+    def forward(ctx, o, B, nspk, N, Kc):
+        S = o.shape[0]
+        ctx.geom = (B, nspk, N, Kc, S)
+        return K.dp_merge_fwd(o, B, nspk, N, Kc, S)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return K.dp_merge_bwd(ga, gb, *ctx.geom), None, None, None, None
+
+
+class Ola2(Function):
+    """overlap_and_add of 2-sample frames, hop 1 (dptnetq.py:140): y [N, 2, L] -> [N, L+1]"""
+
+    @staticmethod
+    def forward(ctx, y):
+        return K.ola2_fwd(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.ola2_bwd(g)
+
+
+class MhaCore(Function):
+    """Everything of MultiheadAttentionQ.forward between the in-projection X [L, B, 3E] and the (not yet quantized) heads
+    [L, B, E] (qat_layers.py:890-911): the q / k / v quantizers (each observes the WHOLE X, each is used on its own third),
+    q / sqrt(head_dim), the `div` quantizer, softmax(q k^T) v.  aqs = (aq_q, aq_k, aq_v, aq_div, aq_attn, aq_softmax) quantizer
+    modules or None (float teacher); the last two only observe (their outputs are discarded by the reference)."""
+
+    @staticmethod
+    def forward(ctx, X, nh, aqs, *ranges):
+        L, B, E3 = X.shape
+        E = E3 // 3
+        hd = E // nh
+        X = X.contiguous()
+        ctx.geom = (L, B, E, nh, hd)
+        scale = math.sqrt(hd)
+        if aqs is None:
+            q = K.unary_fwd(X[..., :E], K.UNARY_DIVS, scale)
+            heads, stats = K.attn_fwd(q, X[..., E:2 * E], X[..., 2 * E:], L, B, nh)
+            ctx.qs = None
+            ctx.save_for_backward(X, q, heads, stats)
+            return heads
+        qs = [a.qctx() for a in aqs[:4]]
+        parts = []
+        for i in range(3):
+            blk = X[..., i * E:(i + 1) * E]
+            if qs[i].qmode == ops.Q_OBSERVE:
+                K.minmax(X, qs[i].obs_ws)                       # the observer sees all of X (qat_layers.py:890-900)
+                parts.append(blk)
+            elif qs[i].qmode == ops.Q_QUANT:
+                parts.append(K.actq_fwd(blk, ops.ACT_NONE, None, ops.Q_QUANT, qs[i].qmin, qs[i].qmax, None))
+            else:
+                parts.append(blk)
+            aqs[i].after_forward(qs[i])
+        qd = K.unary_fwd(parts[0], K.UNARY_DIVS, scale)
+        q = K.actq_fwd(qd, ops.ACT_NONE, None, qs[3].qmode, qs[3].qmin, qs[3].qmax, qs[3].obs_ws) if qs[3].qmode != ops.Q_BYPASS else qd
+        aqs[3].after_forward(qs[3])
+        # the two quantizers whose outputs the reference throws away: observers only
+        obs = [None, None]
+        for i in (4, 5):
+            m = aqs[i].next_mode() if hasattr(aqs[i], "next_mode") else ops.Q_BYPASS
+            obs[i - 4] = aqs[i]._obs_ws if m == ops.Q_OBSERVE else None
+        if (obs[0] is None) != (obs[1] is None):
+            raise RuntimeError("MultiheadAttentionQ: attn / softmax observers out of step")
+        heads, stats = K.attn_fwd(q, parts[1], parts[2], L, B, nh, obs[0], obs[1])
+        if obs[0] is not None:
+            K.observer_ema(aqs[4].min_range.data, aqs[4].max_range.data, aqs[4]._obs_ws, aqs[4].alpha)
+            K.observer_ema(aqs[5].min_range.data, aqs[5].max_range.data, aqs[5]._obs_ws, aqs[5].alpha)
+        ctx.qs = qs
+        ctx.save_for_backward(X, q, heads, stats, qd, parts[1], parts[2])
+        return heads
+
+    @staticmethod
+    def backward(ctx, gh):
+        L, B, E, nh, hd = ctx.geom
+        scale = math.sqrt(hd)
+        if ctx.qs is None:
+            X, q, heads, stats = ctx.saved_tensors
+            gX = torch.empty_like(X)
+            gq, gk, gv = K.attn_bwd(q, X[..., E:2 * E], X[..., 2 * E:], heads, gh, stats, L, B, nh)
+            gX[..., :E].copy_(K.unary_bwd(gq, None, K.UNARY_DIVS, scale))
+            gX[..., E:2 * E].copy_(gk)
+            gX[..., 2 * E:].copy_(gv)
+            return (gX, None, None)
+        X, q, heads, stats, qd, kq, vq = ctx.saved_tensors
+        qs = ctx.qs
+        gq, gk, gv = K.attn_bwd(q, kq, vq, heads, gh, stats, L, B, nh)
+        grads = [None] * 8
+        # div quantizer, then the division
+        if qs[3].qmode == ops.Q_QUANT:
+            gq, _, grads[6], grads[7], _ = ops._epilogue_bwd(qd, gq, ops.ACT_NONE, None, None, qs[3])
+        gq = K.unary_bwd(gq, None, K.UNARY_DIVS, scale)
+        gX = torch.empty_like(X)
+        for i, g in enumerate((gq, gk, gv)):
+            blk = gX[..., i * E:(i + 1) * E]
+            if qs[i].qmode == ops.Q_QUANT:
+                _, _, grads[2 * i], grads[2 * i + 1], _ = ops._epilogue_bwd(X[..., i * E:(i + 1) * E], g, ops.ACT_NONE, None, None, qs[i], out=blk)
+            else:
+                blk.copy_(g)
+        return (gX, None, None, *grads)
+
+
+class LstmBi(Function):
+    """Bidirectional single-layer LSTM with zero initial state on sequence-first input [S, B, I] (LSTMQ, qat_layers.py:571-600).
+    Weights arrive already fake-quantized (or float): w_ih [2][4H, I], w_hh [2][4H, H], biases are parameters."""
+
+    @staticmethod
+    def forward(ctx, x, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r):
+        S, B, I = x.shape
+        H = whh_f.shape[1]
+        x = x.contiguous()
+        wih = torch.cat([wih_f, wih_r], 0)                 # [8H, I]   (memory plumbing: 2 x 128 KB)
+        whh = torch.stack([whh_f, whh_r], 0).contiguous()  # [2, 4H, H]
+        bih = torch.cat([bih_f, bih_r], 0)
+        bhh = torch.stack([bhh_f, bhh_r], 0).contiguous()
+        pre = K.rowlin_fwd(x, wih, bih)                    # [S, B, 8H]: both directions' input projections, one GEMM
+        hout, gsav, csav = K.lstm_fwd(pre, whh, bhh, S, B, H)
+        ctx.save_for_backward(x, wih, whh, hout, gsav, csav)
+        ctx.params = (bih_f, bhh_f, bih_r, bhh_r)
+        touch(wih_f, whh_f, wih_r, whh_r)
+        return hout
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, wih, whh, hout, gsav, csav = ctx.saved_tensors
+        S, B, I = x.shape
+        H = whh.shape[2]
+        dG = K.lstm_bwd(gout, whh, gsav, csav, S, B, H)                  # [S, B, 8H]
+        gx = K.rowlin_bwd_x(dG, wih) if ctx.needs_input_grad[0] else None
+        gwih = torch.zeros_like(wih)
+        K.rowlin_bwd_w(dG, x, gwih)
+        gwhh = torch.zeros_like(whh)
+        if S > 1:
+            # forward direction: dG_f[t] with h_f[t-1];  reverse direction: dG_r[t] with h_r[t+1]
+            K.rowlin_bwd_w(dG[1:, :, :4 * H], hout[:-1, :, :H], gwhh[0])
+            K.rowlin_bwd_w(dG[:-1, :, 4 * H:], hout[1:, :, H:], gwhh[1])
+        gbs = []
+        for p, lo in zip(ctx.params, (0, 0, 4 * H, 4 * H)):      # b_ih and b_hh of a direction get the same column sums
+            buf, direct = _param_grad(p, p)
+            K.colsum(dG[..., lo:lo + 4 * H], buf)
+            gbs.append(None if direct else buf)
+        return gx, gwih[:4 * H], gwhh[0], gbs[0], gbs[1], gwih[4 * H:], gwhh[1], gbs[2], gbs[3]

@@ -4,6 +4,7 @@ import torch
 from ..qat_layers import LayerQ
 from ..qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
 from .convtasnetq import ConvTasNetQ
+from .dptnetq import DPTNetQ
 
 
 def set_mac_op(model, mode=False):
@@ -23,8 +24,10 @@ def create_model(model_cfg):
     if name == "ConvTasNet":
         return ConvTasNetQ(n_spks=model_cfg.get("n_src", 1), kernel_size=model_cfg.get("kernel_size", 32),
                            stride=model_cfg.get("stride", 16))
-    if name in ("DPTNet", "Sepformer", "ConvTasNetMusic", "HTDemucs"):
-        raise NotImplementedError(f"{name}: SURVEY.md §8 rows a13-a15 (later rounds); this build serves ConvTasNet")
+    if name == "DPTNet":
+        return DPTNetQ(n_spks=model_cfg.get("n_src", 2), kernel_size=model_cfg.get("kernel_size", 2))
+    if name in ("Sepformer", "ConvTasNetMusic", "HTDemucs"):
+        raise NotImplementedError(f"{name}: SURVEY.md §8 rows a14-a15 (later rounds); this build serves ConvTasNet and DPTNet")
     raise AssertionError("Model {} is not supported!".format(name))
 
 

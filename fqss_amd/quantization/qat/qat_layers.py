@@ -5,15 +5,18 @@ fake-quantizers under the reference's attribute names (=> identical state_dict k
 Mirrors quantization/qat/qat_layers.py of the reference: markers Add/Sub/Mul/Div/Const (:8-46),
 LayerQ (:49-59), AddQ/SubQ/MulQ (:62-101), Conv1dQ (:124-153), Conv1dNlQ (:188-219),
 GroupNormQ (:438-452), NlQ (:511-518), Conv1dEncoderQ (:993-1046), ResidualErrorBlock (:1105-1202),
-ConvTr1dDecoderQ (:1305-1361).  The classes only reachable from the DPTNet / Sepformer / HTDemucs
-configs (LSTMQ, MultiheadAttentionQ, Linear*, LayerNormQ, Conv2d*, ConvTranspose*Q, EmbeddingQ,
-BatchNormQ, Conv1dGnNlQ, LinearDecoderQ, ConvTr2dDecoderQ) are the next rows of SURVEY.md §8 and
-raise NotImplementedError until their kernels exist -- there is no ATen fallback.
+ConvTr1dDecoderQ (:1305-1361); and, for the dual-path models (DPTNet): LayerNormQ (:455-465),
+LinearQ (:521-536), LSTMQ (:571-600), MultiheadAttentionQ (:865-950), Conv2dQ (1x1), LinearDecoderQ (:1256-1296) with the
+nn.Linear branch of ResidualErrorBlock (:1178-1187), over the kernels of csrc/dualpath.hip, attn.hip, lstm.hip.
+The classes only reachable from the Sepformer / HTDemucs configs (LinearNlQ, Conv2dNlQ, ConvTranspose*Q, EmbeddingQ,
+BatchNormQ, Conv1dGnNlQ, ConvTr2dDecoderQ, ...) are later rows of SURVEY.md §8 and raise NotImplementedError until their
+kernels exist -- there is no ATen fallback.
 """
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, ops_dp
+from ... import kernels as K
 from .qat_quant import _BypassQuantizer, get_activation_quantizer, get_weight_quantizer
 
 
@@ -35,6 +38,9 @@ def _mul_any(x1, x2, qmin, qmax, q):
     if torch.is_tensor(x2) and x1.dim() == 4 and x2.dim() == 4 and x2.shape[1] == 1 and x1.shape[0] == x2.shape[0] \
             and x1.shape[2:] == x2.shape[2:]:
         return ops.MulActQ.apply(x1, x2.squeeze(1), qmin, qmax, q)
+    if torch.is_tensor(x2) and x1.dim() == 4 and x2.dim() == 4 and x1.shape[1] == 1 and x1.shape[0] == x2.shape[0] \
+            and x1.shape[2:] == x2.shape[2:]:
+        return ops.MulActQ.apply(x2, x1.squeeze(1), qmin, qmax, q)     # feat * mask (dptnetq.py:395): same product
     if torch.is_tensor(x2) and x1.shape == x2.shape:
         M = x1.shape[-1]
         y = ops.MulActQ.apply(x1.reshape(1, 1, -1, M), x2.reshape(1, -1, M), qmin, qmax, q)
@@ -126,6 +132,8 @@ class MulQ(LayerQ):
         q = aq.qctx()
         y = _mul_any(ops.real(x1), ops.real(x2), q.qmin, q.qmax, q)
         aq.after_forward(q)
+        if q.idx is not None and q.idx.shape != y.shape:
+            q.idx = q.idx.reshape(y.shape)       # same-shape products run on a [1, 1, rows, M] view (same row padding)
         return ops.tag_codes(y, q)
 
 
@@ -161,13 +169,17 @@ def conv1d_geometry(conv):
         return ops._Lin("pw")
     if g == conv.in_channels == conv.out_channels and s == 1 and 2 * p == d * (k - 1):
         return ops._Lin("dw", dil=d, pad=p)
-    if g == 1 and p == 0 and d == 1 and s > 1 and k % s == 0:
+    if g == 1 and p == 0 and d == 1 and k > 1 and k % s == 0:
         return ops._Lin("frames", stride=s)
     raise NotImplementedError(f"Conv1d(k={k}, s={s}, p={p}, d={d}, groups={g}) has no HIP kernel")
 
 
 def run_conv1d(conv, x, weight, nl, aq):
     """fq_act(nl(conv1d(x, weight) + bias)) through one fused autograd node"""
+    if isinstance(nl, (nn.Tanh, nn.Sigmoid)):
+        # gated output convs of the dual-path separator (dptnetq.py:286-287): conv, then the map, then the quantizer
+        z = run_conv1d(conv, x, weight, None, None)
+        return fq_node(aq, ops_dp.Unary.apply(ops.real(z), K.UNARY_TANH if isinstance(nl, nn.Tanh) else K.UNARY_SIGMOID))
     L = conv1d_geometry(conv)
     act, slope = _act_of(nl)
     L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, slope
@@ -325,15 +337,20 @@ class ResidualErrorBlock(LayerQ):
                  weight_n_bits=8, train_res_dec=False):
         super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_nl_quantizer=act_nl_quantizer,
                          act_n_bits=act_n_bits)
-        if type(decoder) is not nn.ConvTranspose1d:
-            raise NotImplementedError("ResidualErrorBlock: only the ConvTranspose1d decoder (ConvTasNet/Sepformer) has kernels")
+        if type(decoder) not in (nn.ConvTranspose1d, nn.Linear):
+            raise NotImplementedError("ResidualErrorBlock: only the ConvTranspose1d (ConvTasNet/Sepformer) and Linear (DPTNet) "
+                                      "decoders have kernels")
         if train_res_dec:
             raise NotImplementedError("train_res_dec=True (Sepformer/HTDemucs configs) is a later §8 row")
         self.decoder_type = type(decoder)
         self.train_res_dec = train_res_dec
-        self.residual_encoder = nn.Conv1d(decoder.out_channels, decoder.in_channels, decoder.kernel_size,
-                                          stride=decoder.stride, bias=decoder.bias is not None)
-        self.decoder_stride = decoder.stride
+        if self.decoder_type is nn.Linear:      # qat_layers.py:1111-1114
+            self.residual_encoder = nn.Linear(decoder.out_features, decoder.in_features, bias=decoder.bias is not None)
+            self.decoder_stride = None
+        else:
+            self.residual_encoder = nn.Conv1d(decoder.out_channels, decoder.in_channels, decoder.kernel_size,
+                                              stride=decoder.stride, bias=decoder.bias is not None)
+            self.decoder_stride = decoder.stride
         self.weight_fake_quantize = (get_weight_quantizer(gradient_based, self.residual_encoder.weight.shape, n_bits=weight_n_bits)
                                      if weight_quant else nn.Identity())
 
@@ -341,6 +358,13 @@ class ResidualErrorBlock(LayerQ):
         """reference signature is (Y, y_q, w_decoder); the two optional arguments let the owning
         decoder fuse its `activation_fake_quantize_residual` into the transposed-conv node"""
         enc = self.residual_encoder
+        if self.decoder_type is nn.Linear:      # qat_layers.py:1178-1187 (rows [..., E]); LinearDecoderQ inlines this sequence
+            Y_q = ops_dp.RowLinear.apply(ops.real(y_q), self._wq(enc.weight), enc.bias)
+            aq = self.activation_fake_quantize
+            q = aq.qctx()
+            Y1 = ops.AddActQ.apply(ops.real(Y), Y_q, q.qmin, q.qmax, -1.0, q)
+            aq.after_forward(q)
+            return ops_dp.RowLinear.apply(Y1, w_decoder, None)
         Y_q = run_conv1d(enc, y_q, self._wq(enc.weight), None, None)
         aq = self.activation_fake_quantize
         q = aq.qctx()
@@ -397,6 +421,244 @@ class ConvTr1dDecoderQ(LayerQ):
 
 
 # ---------------------------------------------------------------------------------------------
+# dual-path layers (DPTNet): row-major tensors [..., C]
+# ---------------------------------------------------------------------------------------------
+_FLAT_COLS = {}
+
+
+def _flat2d(t):
+    """a dense tensor as [rows, cols] with long rows (the element-wise kernels stream rows; 64-wide rows would idle 3/4 of
+    every workgroup): cols = the largest divisor of numel in [1024, 16384] that is a multiple of 4"""
+    n = t.numel()
+    if not t.is_contiguous() or n < 4096:
+        return None
+    c = _FLAT_COLS.get(n)
+    if c is None:
+        c = next((c for c in range(16384, 1020, -4) if n % c == 0), 0)
+        _FLAT_COLS[n] = c
+    return t.view(n // c, c) if c else None
+
+
+def fq_node(aq, x, nl=None):
+    """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl"""
+    act, slope = _act_of(nl)
+    q = aq.qctx() if aq is not None else ops.BYPASS
+    if q.qmode == ops.Q_BYPASS and act == ops.ACT_NONE:
+        return x
+    x = ops.real(x)
+    flat = _flat2d(x)
+    y = ops.NlActQ.apply(x if flat is None else flat, slope, q.qmin, q.qmax, act, q, slope)
+    if aq is not None:
+        aq.after_forward(q)
+    q.idx = None
+    return y if flat is None else y.view(x.shape)
+
+
+def run_linear(lin, x, weight, nl, aq):
+    return fq_node(aq, ops_dp.RowLinear.apply(ops.real(x), weight, lin.bias), nl)
+
+
+def run_layernorm(ln, x, aq):
+    if len(ln.normalized_shape) != 1 or not ln.elementwise_affine:
+        raise NotImplementedError("only LayerNorm over the last dim with affine parameters has a HIP kernel")
+    return fq_node(aq, ops_dp.LayerNormRows.apply(ops.real(x), ln.weight, ln.bias, ln.eps))
+
+
+def _lstm_check(lstm):
+    if lstm.num_layers != 1 or not lstm.bidirectional or lstm.batch_first or lstm.proj_size != 0 or not lstm.bias or lstm.dropout != 0:
+        raise NotImplementedError("only the single-layer bidirectional sequence-first LSTM of the dual-path models has HIP kernels")
+
+
+def run_lstm(lstm, x, weights, aq):
+    """weights: dict name -> (fake-quantized) weight for the four weight matrices"""
+    _lstm_check(lstm)
+    y = ops_dp.LstmBi.apply(ops.real(x), weights["weight_ih_l0"], weights["weight_hh_l0"], lstm.bias_ih_l0, lstm.bias_hh_l0,
+                            weights["weight_ih_l0_reverse"], weights["weight_hh_l0_reverse"], lstm.bias_ih_l0_reverse,
+                            lstm.bias_hh_l0_reverse)
+    return fq_node(aq, y)
+
+
+def _mha_check(mha, query, key, value):
+    if not (query is key and key is value):
+        raise NotImplementedError("MultiheadAttentionQ: only self-attention (query is key is value) has HIP kernels")
+    if mha.batch_first or mha.in_proj_weight is None or mha.bias_k is not None or mha.add_zero_attn or mha.dropout != 0:
+        raise NotImplementedError("MultiheadAttention variant without a HIP kernel")
+
+
+def run_mha(mha, x, w_in, w_out, aqs, aq_head, aq_out):
+    """x [L, B, E] -> [L, B, E]; aqs = (q, k, v, div, attn, softmax) quantizers or None for the float module"""
+    X = ops_dp.RowLinear.apply(ops.real(x), w_in, mha.in_proj_bias)
+    if aqs is None:
+        heads = ops_dp.MhaCore.apply(X, mha.num_heads, None)
+    else:
+        ranges = [r for a in aqs[:4] for r in (a.min_range, a.max_range)]
+        heads = ops_dp.MhaCore.apply(X, mha.num_heads, aqs, *ranges)
+    heads = fq_node(aq_head, heads)
+    return fq_node(aq_out, ops_dp.RowLinear.apply(heads, w_out, mha.out_proj.bias))
+
+
+class LayerNormQ(LayerQ):
+    def __init__(self, layernorm, gradient_based=True, act_quant=True, act_n_bits=8):
+        super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_n_bits=act_n_bits)
+        _expect(layernorm, nn.LayerNorm, "LayerNorm")
+        self.layernorm = layernorm
+
+    def forward(self, x):
+        return run_layernorm(self.layernorm, x, self.activation_fake_quantize)
+
+
+class LinearQ(LayerQ):
+    def __init__(self, linear, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(linear, nn.Linear, "Linear")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=linear.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.linear = linear
+
+    def forward(self, x):
+        return run_linear(self.linear, x, self._wq(self.linear.weight), None, self.activation_fake_quantize)
+
+
+class Conv2dQ(LayerQ):
+    """1x1 Conv2d (DPT.output[1], dptnetq.py:187).  forward() takes the reference's [B, C, H, W]; the dual-path model calls
+    forward_rows() with its row-major tensors [..., C] instead (same parameters, same quantizers, no layout change)."""
+
+    def __init__(self, conv2d, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(conv2d, nn.Conv2d, "Conv2d")
+        if conv2d.kernel_size != (1, 1) or conv2d.stride != (1, 1) or conv2d.padding != (0, 0) or conv2d.groups != 1:
+            raise NotImplementedError("Conv2dQ: only the 1x1 convolution of the dual-path output layer has HIP kernels")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=conv2d.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.conv2d = conv2d
+
+    def forward_rows(self, x):
+        c = self.conv2d
+        w = self._wq(c.weight).view(c.out_channels, c.in_channels)
+        return fq_node(self.activation_fake_quantize, ops_dp.RowLinear.apply(ops.real(x), w, c.bias))
+
+    def forward(self, x):
+        return run_conv2d_1x1(self.conv2d, x, self._wq(self.conv2d.weight), self.activation_fake_quantize)
+
+
+def run_conv2d_1x1(c, x, weight, aq):
+    B, C, H, W = x.shape
+    L = ops._Lin("pw", w_param=c.weight, b_param=c.bias)
+    ops_dp.touch(weight)
+    z = ops.LinearActQ.apply(ops.real(x).reshape(B, C, H * W), weight.view(c.out_channels, c.in_channels, 1), c.bias, None, None, None,
+                             L, ops.ACT_NONE, ops.BYPASS)
+    return fq_node(aq, z).reshape(B, c.out_channels, H, W)
+
+
+class LSTMQ(LayerQ):
+    def __init__(self, lstm, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_n_bits=act_n_bits)
+        _expect(lstm, nn.LSTM, "LSTM")
+        _lstm_check(lstm)
+        self.lstm = lstm
+        self.num_directions = 2 if lstm.bidirectional else 1
+        self.real_hidden_size = lstm.proj_size if lstm.proj_size > 0 else lstm.hidden_size
+        self.weight_quantizers_dict = nn.ModuleDict()
+        for name, w in zip(lstm._flat_weights_names, lstm._flat_weights):
+            if name.startswith("weight"):
+                self.weight_quantizers_dict[name] = (get_weight_quantizer(gradient_based, w.shape, n_bits=weight_n_bits)
+                                                     if weight_quant else nn.Identity())
+
+    def forward(self, x):
+        weights = {n: q(getattr(self.lstm, n)) for n, q in self.weight_quantizers_dict.items()}
+        return [run_lstm(self.lstm, x, weights, self.activation_fake_quantize)]
+
+
+class MultiheadAttentionQ(LayerQ):
+    def __init__(self, mha, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_n_bits=act_n_bits)
+        _expect(mha, nn.MultiheadAttention, "MultiheadAttention")
+        self.mha = mha
+        self.do, _ = mha.out_proj.weight.shape
+        self.head_dim = mha.embed_dim // mha.num_heads
+
+        def aq():
+            return get_activation_quantizer(gradient_based, n_bits=act_n_bits) if act_quant else _BypassQuantizer()
+
+        self.activation_fake_quantize_q = aq()
+        self.activation_fake_quantize_k = aq()
+        self.activation_fake_quantize_v = aq()
+        self.activation_fake_quantize_div = aq()
+        self.activation_fake_quantize_attn = aq()
+        self.activation_fake_quantize_softmax = aq()
+        self.activation_fake_quantize_head = aq()
+        self.weight_fake_quantize_in = (get_weight_quantizer(gradient_based, mha.in_proj_weight.shape, n_bits=weight_n_bits)
+                                        if weight_quant else nn.Identity())
+        self.weight_fake_quantize_out = (get_weight_quantizer(gradient_based, mha.out_proj.weight.shape, n_bits=weight_n_bits)
+                                         if weight_quant else nn.Identity())
+
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=False, is_causal=False):
+        _mha_check(self.mha, query, key, value)
+        if attn_mask is not None or key_padding_mask is not None:
+            raise NotImplementedError("MultiheadAttentionQ: masks are ignored by the reference's forward (qat_layers.py:878-946)")
+        aqs = (self.activation_fake_quantize_q, self.activation_fake_quantize_k, self.activation_fake_quantize_v,
+               self.activation_fake_quantize_div, self.activation_fake_quantize_attn, self.activation_fake_quantize_softmax)
+        if isinstance(aqs[0], _BypassQuantizer):
+            aqs = None
+        y = run_mha(self.mha, query, self.weight_fake_quantize_in(self.mha.in_proj_weight),
+                    self.weight_fake_quantize_out(self.mha.out_proj.weight), aqs, self.activation_fake_quantize_head,
+                    self.activation_fake_quantize)
+        return (y,)
+
+
+class LinearDecoderQ(LayerQ):
+    """decoder basis Linear(E, W, bias=False) over [..., E] rows + the LSB residual channel (n_combiner = 2).
+    forward() takes the reference's channels-last [B, S, L, E]; forward_cf() the channel-first [B*S, E, L] tensor the
+    dual-path model holds at that point (a 1x1 conv: no transposing copy of the largest activation of the network)."""
+
+    def __init__(self, decoder, n_combiner=1, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True,
+                 inout_nl_quant=False, act_n_bits=8, out_quant=True, out_act_n_bits=8, train_res_dec=False):
+        lin = decoder[0]
+        _expect(lin, nn.Linear, "Linear")
+        if lin.bias is not None:
+            raise NotImplementedError("LinearDecoderQ: the dual-path decoders are bias-free")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=out_quant,
+                         act_nl_quantizer=inout_nl_quant, weight_shape=lin.weight.shape, act_n_bits=out_act_n_bits,
+                         weight_n_bits=weight_n_bits)
+        self.linear = lin
+        self.n_combiner = n_combiner
+        if self.n_combiner >= 2:
+            self.residual_error_block = ResidualErrorBlock(lin, gradient_based, weight_quant, act_quant, act_n_bits=act_n_bits,
+                                                           weight_n_bits=weight_n_bits, train_res_dec=bool(train_res_dec))
+            self.activation_fake_quantize_residual = (get_activation_quantizer(gradient_based, n_bits=out_act_n_bits)
+                                                      if out_quant else _BypassQuantizer())
+
+    def _run(self, x, lin_fn):
+        w_dec = self._wq(self.linear.weight)
+        if self.n_combiner == 1:
+            return fq_node(self.activation_fake_quantize, lin_fn(x, w_dec))
+        x_dec, x_res = ops.fork2(x)
+        y = fq_node(self.activation_fake_quantize, lin_fn(x_dec, w_dec))
+        outs = [y]
+        rb = self.residual_error_block
+        for _ in range(1, self.n_combiner):
+            Y_q = lin_fn(y, rb._wq(rb.residual_encoder.weight))
+            aq = rb.activation_fake_quantize
+            q = aq.qctx()
+            Y1 = ops.AddActQ.apply(ops.real(x_res), Y_q, q.qmin, q.qmax, -1.0, q)
+            aq.after_forward(q)
+            y = fq_node(self.activation_fake_quantize_residual, lin_fn(Y1, w_dec))
+            outs.append(y)
+        return outs
+
+    def forward(self, x):
+        outs = self._run(x, lambda t, w: ops_dp.RowLinear.apply(ops.real(t), w, None))
+        return outs if self.n_combiner == 1 else torch.stack(outs)
+
+    def forward_cf(self, x):
+        """x [B', E, L] -> list of n_combiner tensors [B', W, L] (channel-first frames)"""
+        def pw(t, w):
+            L = ops._Lin("pw")
+            ops_dp.touch(w)
+            return ops.LinearActQ.apply(ops.real(t), w.view(w.shape[0], w.shape[1], 1), None, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
+        outs = self._run(x, pw)
+        return [outs] if self.n_combiner == 1 else outs
+
+
+# ---------------------------------------------------------------------------------------------
 # layers of the later §8 rows: constructing them fails loudly (no ATen fallback)
 # ---------------------------------------------------------------------------------------------
 def _later_row(name, row):
@@ -408,20 +670,14 @@ def _later_row(name, row):
 
 
 DivQ = _later_row("DivQ", "a15")
-Conv2dQ = _later_row("Conv2dQ", "a13/a15")
 Conv1dGnNlQ = _later_row("Conv1dGnNlQ", "a15")
 Conv2dNlQ = _later_row("Conv2dNlQ", "a15")
 ConvTranspose1dQ = _later_row("ConvTranspose1dQ", "a15")
 ConvTranspose2dQ = _later_row("ConvTranspose2dQ", "a15")
 ConvTranspose1dNlQ = _later_row("ConvTranspose1dNlQ", "a15")
 ConvTranspose2dNlQ = _later_row("ConvTranspose2dNlQ", "a15")
-LayerNormQ = _later_row("LayerNormQ", "a13")
 BatchNormQ = _later_row("BatchNormQ", "a15")
 EmbeddingQ = _later_row("EmbeddingQ", "a15")
-LinearQ = _later_row("LinearQ", "a13")
 LinearNlQ = _later_row("LinearNlQ", "a14")
-LSTMQ = _later_row("LSTMQ", "a13")
-MultiheadAttentionQ = _later_row("MultiheadAttentionQ", "a13")
 Conv2dEncoderQ = _later_row("Conv2dEncoderQ", "a15")
-LinearDecoderQ = _later_row("LinearDecoderQ", "a13")
 ConvTr2dDecoderQ = _later_row("ConvTr2dDecoderQ", "a15")

@@ -363,6 +363,91 @@ int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, cons
                    float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
                    int32_t* step_t, const int32_t* t0, float* gnorm_out, fqss_stream_t stream);
 
+/* =============================================================================================
+ * Dual-path models (DPTNet, cfg 3 -- SURVEY.md §8 row a13).  Inside the dual-path blocks tensors are
+ * sequence-first row matrices [L][B'][C] (feature dim contiguous).
+ * ============================================================================================= */
+
+/* Row-major linears (csrc/gemm.hip, fp32 MFMA): x [R][Ci] (row stride ld_x), w [Co][Ci] (row stride ld_w).
+ * replaces: F.linear of LinearQ (qat_layers.py:521-536), of MultiheadAttentionQ's in/out projections (:889-901, :941),
+ *           the input projection inside _VF.lstm (LSTMQ :590), the 1x1 Conv2dQ of DPT.output (dptnetq.py:187) + autograd
+ *   fwd   : z[r][o]   = sum_i x[r][i] w[o][i] + bias[o]   (bias optional)
+ *   bwd_x : gx[r][i]  = sum_o gz[r][o] w[o][i]
+ *   bwd_w : gw[o][i] += sum_r gz[r][o] x[r][i]                                                     */
+int fqss_rowlin_fwd(const float* x, const float* w, const float* bias, float* z, int64_t R, int Ci, int Co,
+                    int64_t ld_x, int64_t ld_w, int64_t ld_z, fqss_stream_t stream);
+int fqss_rowlin_bwd_x(const float* gz, const float* w, float* gx, int64_t R, int Ci, int Co, int64_t ld_gz,
+                      int64_t ld_w, int64_t ld_gx, fqss_stream_t stream);
+int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,
+                      int64_t ld_x, int64_t ld_gw, fqss_stream_t stream);
+/* out[c] += sum_r g[r][c]  (bias gradients of the row linears / LSTM) */
+int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream);
+
+/* LayerNorm over the last dim of a row matrix (C <= 256), one wavefront per row.
+ * replaces: F.layer_norm in LayerNormQ (qat_layers.py:455-465) + autograd.  mean_rstd: [R][2] saved for the backward.
+ * bwd: gx = ; ggamma[C] += ; gbeta[C] +=                                                            */
+int fqss_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
+                       int64_t R, int C, int64_t ld_x, int64_t ld_y, double eps, fqss_stream_t stream);
+int fqss_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean_rstd, float* gx,
+                       float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy, int64_t ld_x, int64_t ld_gx,
+                       fqss_stream_t stream);
+
+/* element-wise maps on dense tensors; kind: 0 tanh, 1 sigmoid, 2 division by the scalar p
+ * replaces: nn.Tanh / nn.Sigmoid inside Conv1dNlQ (dptnetq.py:286-287), q / sqrt(head_dim) (qat_layers.py:905).
+ * bwd takes the forward OUTPUT y (tanh, sigmoid); y may be NULL for kind 2.                          */
+#define FQSS_UNARY_TANH 0
+#define FQSS_UNARY_SIGMOID 1
+#define FQSS_UNARY_DIVS 2
+int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, double p, fqss_stream_t stream);
+int fqss_unary_bwd(const float* g, const float* y, float* gx, int64_t n, int kind, double p, fqss_stream_t stream);
+
+/* y[i0][i1][i2][c] = x[i0*s0 + i1*s1 + i2*s2 + c], c < C contiguous: the intra-chunk <-> inter-chunk change of view
+ * replaces: the permute().contiguous() pairs of DPT.forward / SingleTransformer.forward (dptnetq.py:156, 197-204) */
+int fqss_permute4(const float* x, float* y, int64_t n0, int64_t n1, int64_t n2, int C, int64_t s0, int64_t s1,
+                  int64_t s2, fqss_stream_t stream);
+
+/* split_feature (dptnetq.py:232-259) straight into the intra-chunk row layout:
+ *   f [B][N][T] (row stride ld_f) -> seg [K][B*S][N], S = 2*(T + rest + K/2)/K half-overlapped chunks of length K
+ * bwd: gf [B][N][T] = sum of the (<= 2) chunk slots holding each position                            */
+int fqss_dp_segment_fwd(const float* f, float* seg, int B, int N, int64_t T, int64_t ld_f, int K, int S,
+                        fqss_stream_t stream);
+int fqss_dp_segment_bwd(const float* gseg, float* gf, int B, int N, int64_t T, int64_t ld_gf, int K, int S,
+                        fqss_stream_t stream);
+/* merge_feature (dptnetq.py:261-276) up to its AddQ: o [S][B*K][nspk*N] (inter-chunk row layout) -> the two streams
+ * a, b [B*nspk][N][Lm], Lm = (S/2)*K - K/2, whose quantized sum is the merged signal; bwd scatters (ga, gb) back */
+int fqss_dp_merge_fwd(const float* o, float* a, float* b, int B, int nspk, int N, int K, int S, int64_t Lm,
+                      int64_t ld_ab, fqss_stream_t stream);
+int fqss_dp_merge_bwd(const float* ga, const float* gb, float* go, int B, int nspk, int N, int K, int S, int64_t Lm,
+                      int64_t ld_ga, int64_t ld_gb, fqss_stream_t stream);
+/* overlap_and_add of 2-sample frames with hop 1 (dptnetq.py:17-58 as called at :140 with W = 2):
+ *   y [N][2][L] (rows of stride ld_y) -> out [N][L+1];   bwd: gy[n][tap][t] = g[n][t + tap]           */
+int fqss_ola2_fwd(const float* y, float* out, int64_t N, int64_t L, int64_t ld_y, fqss_stream_t stream);
+int fqss_ola2_bwd(const float* g, float* gy, int64_t N, int64_t L, int64_t ld_gy, fqss_stream_t stream);
+
+/* Attention core of MultiheadAttentionQ (qat_layers.py:903-911): o = softmax(q k^T) v per (sequence b, head h).
+ * q, k, v, o: row matrices [l*B + b][nh*hd] (head h = column block h); q is the already scaled + quantized query.
+ * stats [B*nh][L][2] = (row max, row sum) saved for the backward, which recomputes the probabilities.
+ * obs_attn / obs_soft (both or neither): ordered-uint (min, max) of the logits / probabilities -- the reference's
+ * `activation_fake_quantize_attn/_softmax` observe them during the first 50 calls and discard their outputs. */
+int fqss_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats, int L, int B, int nh,
+                  int hd, int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, uint32_t* obs_attn,
+                  uint32_t* obs_soft, fqss_stream_t stream);
+int fqss_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* go,
+                  const float* stats, float* gq, float* gk, float* gv, int L, int B, int nh, int hd, int64_t ld_q,
+                  int64_t ld_k, int64_t ld_v, int64_t ld_o, int64_t ld_go, int64_t ld_gq, int64_t ld_gk,
+                  int64_t ld_gv, fqss_stream_t stream);
+
+/* Recurrence of the bidirectional single-layer LSTM inside LSTMQ (qat_layers.py:571-600, _VF.lstm with zero state).
+ *   pre  [S][B][2][4H] = x W_ih^T + b_ih of both directions (fqss_rowlin_fwd), gate order i, f, g, o
+ *   whh  [2][4H][H], bhh [2][4H];  hout [S][B][2H] (forward | reverse)
+ *   gsav [S][B][2][4H] gate activations, csav [S][B][2][H] cell states (saved for the backward)
+ * bwd: gout [S][B][2H] -> dG [S][B][2][4H] = dL/d(gate pre-activations); the caller finishes with row GEMMs:
+ *   gx = dG W_ih, gW_ih += dG^T x, gb_ih = gb_hh += colsum(dG), gW_hh[d] += dG_d[t]^T h_d[t -/+ 1]           */
+int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* hout, float* gsav, float* csav,
+                  int S, int B, int H, fqss_stream_t stream);
+int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
+                  int B, int H, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
