@@ -86,6 +86,10 @@ _PROTOS = {
     "fqss_attn_bwd": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, I64, I64, I64, P],
     "fqss_lstm_fwd": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_lstm_bwd": [P, P, P, P, P, I32, I32, I32, P],
+    "fqss_gnrows_fwd": [P, P, P, P, P, P, I64, I32, I64, I64, I32, I32, I32, F64, P],
+    "fqss_gnrows_bwd": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I32, I32, I32, P],
+    "fqss_bcast_add": [P, P, P, I64, I64, I32, P],
+    "fqss_bcast_sum": [P, P, I64, I64, I32, P],
 }
 _RESTYPE = {"fqss_last_error": C.c_char_p}
 

@@ -291,6 +291,160 @@ __global__ __launch_bounds__(256) void k_ola2_bwd(const float* __restrict__ g, f
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ gLN on row matrices
+// GroupNorm(1, C) of the Sepformer dual-path blocks (sepformerq.py:141-142, 159, 175) on the row layouts: the statistics run
+// over ALL rows of a sample; the sample of row r is b = (r % RB) / X  (intra-chunk rows [K][B*S][C]: RB = B*S, X = S;
+// inter-chunk rows [S][B*K][C]: RB = B*K, X = K).  Pass 1 reduces per-sample (sum, sum^2) in fp64 (one wavefront per row,
+// per-workgroup LDS slots, one fp64 atomic per sample and workgroup); pass 2 applies.  kMaxB samples per launch.
+constexpr int kMaxB = 16;
+
+__global__ __launch_bounds__(256) void k_gnrows_stats(const float* __restrict__ x, double* __restrict__ ws, int64_t R, int C,
+                                                       int64_t ld, int RB, int X, int B) {
+    __shared__ double acc[kMaxB][2];
+    if (threadIdx.x < 2 * kMaxB) acc[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < R; r += nw) {
+        float s = 0.f, q = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = x[r * ld + c];
+            s += v;
+            q += v * v;
+        }
+        double sd = wave_sum((double)s), qd = wave_sum((double)q);
+        if (lane == 0) {
+            const int b = (int)((r % RB) / X);
+            atomicAdd(&acc[b][0], sd);
+            atomicAdd(&acc[b][1], qd);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * B) atomicAdd(&ws[threadIdx.x], acc[threadIdx.x >> 1][threadIdx.x & 1]);
+}
+
+// mean_rstd[b] = (mean, 1/sqrt(var + eps)) from the fp64 sums; var = E[x^2] - mean^2 in fp64
+__global__ void k_gnrows_finalize(const double* __restrict__ ws, float* __restrict__ mean_rstd, int B, double n, float eps) {
+    const int b = threadIdx.x;
+    if (b < B) {
+        const double m = ws[2 * b] / n;
+        double var = ws[2 * b + 1] / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean_rstd[2 * b] = (float)m;
+        mean_rstd[2 * b + 1] = 1.0f / sqrtf((float)var + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gnrows_apply(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean_rstd,
+                                                       float* __restrict__ y, int64_t R, int C, int64_t ld_x, int64_t ld_y, int RB,
+                                                       int X) {
+    const int64_t total = R * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const int b = (int)((r % RB) / X);
+        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+        y[r * ld_y + c] = ((x[r * ld_x + c] - mean) * rstd) * gamma[c] + beta[c];
+    }
+}
+
+// backward pass 1: per-sample a = sum gy*gamma, b = sum gy*gamma*xhat (fp64 slots) and the per-channel affine gradients
+__global__ __launch_bounds__(256) void k_gnrows_bwd_reduce(const float* __restrict__ gy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                            double* __restrict__ ws, float* __restrict__ ggamma,
+                                                            float* __restrict__ gbeta, int64_t R, int C, int64_t ld_gy, int64_t ld_x,
+                                                            int RB, int X, int B, int64_t rows_per_block) {
+    __shared__ double acc[kMaxB][2];
+    if (threadIdx.x < 2 * kMaxB) acc[threadIdx.x >> 1][threadIdx.x & 1] = 0.0;
+    __syncthreads();
+    // thread <-> channel(s); the workgroup walks a slab of rows, so the channel sums stay in registers (C <= 1024)
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float gg[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f}, gam[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = threadIdx.x + 256 * j; gam[j] = c < C ? gamma[c] : 0.f; }
+    for (int64_t r = r0; r < r1; ++r) {
+        const int b = (int)((r % RB) / X);
+        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+        float a = 0.f, bb = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < C) {
+                const float g = gy[r * ld_gy + c];
+                const float xh = (x[r * ld_x + c] - mean) * rstd;
+                const float d = g * gam[j];
+                a += d;
+                bb += d * xh;
+                gg[j] += g * xh;
+                gb[j] += g;
+            }
+        }
+        double ad = wave_sum((double)a), bd = wave_sum((double)bb);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&acc[b][0], ad);
+            atomicAdd(&acc[b][1], bd);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < C) {
+            atomicAdd(ggamma + c, gg[j]);
+            atomicAdd(gbeta + c, gb[j]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * B) atomicAdd(&ws[threadIdx.x], acc[threadIdx.x >> 1][threadIdx.x & 1]);
+}
+
+__global__ __launch_bounds__(256) void k_gnrows_bwd_apply(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                           const double* __restrict__ ws, float* __restrict__ gx, int64_t R, int C,
+                                                           int64_t ld_gy, int64_t ld_x, int64_t ld_gx, int RB, int X, double n) {
+    const int64_t total = R * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const int b = (int)((r % RB) / X);
+        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+        const float a = (float)(ws[2 * b] / n), bb = (float)(ws[2 * b + 1] / n);
+        const float xh = (x[r * ld_x + c] - mean) * rstd;
+        gx[r * ld_gx + c] = rstd * ((gy[r * ld_gy + c] * gamma[c] - a) - xh * bb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ positional encoding
+// z[l][b][c] = x[l][b][c] + p[l][c]  (TransformerBlock.pos_add on sequence-first rows, sepformerq.py:117-118) and the batch
+// reduction its backward needs: out[l][c] = sum_b g[l][b][c]
+__global__ __launch_bounds__(256) void k_bcast_add(const float* __restrict__ x, const float* __restrict__ p, float* __restrict__ z,
+                                                    int64_t L, int64_t Bp, int C) {
+    const int64_t total = L * Bp * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t l = i / ((int64_t)Bp * C);
+        z[i] = x[i] + p[l * C + c];
+    }
+}
+__global__ __launch_bounds__(256) void k_bcast_sum(const float* __restrict__ g, float* __restrict__ out, int64_t L, int64_t Bp,
+                                                    int C) {
+    const int64_t total = L * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t l = i / C;
+        const float* gp = g + l * Bp * C + c;
+        float s0 = 0.f, s1 = 0.f;
+        int64_t b = 0;
+        for (; b + 1 < Bp; b += 2) {
+            s0 += gp[b * C];
+            s1 += gp[(b + 1) * C];
+        }
+        if (b < Bp) s0 += gp[b * C];
+        out[i] = s0 + s1;
+    }
+}
+
 static inline unsigned flat_grid(int64_t n) {
     int64_t nb = cdiv(n, 256);
     if (nb < 1) nb = 1;
@@ -410,4 +564,53 @@ extern "C" int fqss_ola2_bwd(const float* g, float* gy, int64_t N, int64_t L, in
     if (N == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_ola2_bwd, dim3(flat_grid(N * 2 * L)), dim3(256), 0, (hipStream_t)stream, g, gy, N, L, ld_gy);
     return launch_status("fqss_ola2_bwd");
+}
+
+extern "C" int fqss_gnrows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd, double* ws,
+                               int64_t R, int C, int64_t ld_x, int64_t ld_y, int RB, int X, int B, double eps,
+                               fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gamma && beta && y && mean_rstd && ws, "null tensor");
+    FQSS_REQUIRE(R > 0 && C > 0 && ld_x >= C && ld_y >= C && RB > 0 && X > 0 && B > 0 && B <= kMaxB && RB == B * X && R % RB == 0,
+                 "bad shape (rows = n * B * X, B <= 16)");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s);
+    int64_t nb = cdiv(R, 4 * 8);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_gnrows_stats, dim3((unsigned)nb), dim3(256), 0, s, x, ws, R, C, ld_x, RB, X, B);
+    const double n = (double)(R / B) * C;
+    hipLaunchKernelGGL(k_gnrows_finalize, dim3(1), dim3(64), 0, s, ws, mean_rstd, B, n, (float)eps);
+    hipLaunchKernelGGL(k_gnrows_apply, dim3(flat_grid(R * C)), dim3(256), 0, s, x, gamma, beta, mean_rstd, y, R, C, ld_x, ld_y, RB, X);
+    return launch_status("fqss_gnrows_fwd");
+}
+
+extern "C" int fqss_gnrows_bwd(const float* gy, const float* x, const float* gamma, const float* mean_rstd, float* gx,
+                               float* ggamma, float* gbeta, double* ws, int64_t R, int C, int64_t ld_gy, int64_t ld_x,
+                               int64_t ld_gx, int RB, int X, int B, fqss_stream_t stream) {
+    FQSS_REQUIRE(gy && x && gamma && mean_rstd && gx && ggamma && gbeta && ws, "null tensor");
+    FQSS_REQUIRE(R > 0 && C > 0 && C <= 1024 && ld_gy >= C && ld_x >= C && ld_gx >= C && RB > 0 && X > 0 && B > 0 && B <= kMaxB &&
+                     RB == B * X && R % RB == 0, "bad shape (rows = n * B * X, B <= 16, C <= 1024)");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s);
+    int64_t rpb = cdiv(R, 1024);
+    if (rpb < 8) rpb = 8;
+    hipLaunchKernelGGL(k_gnrows_bwd_reduce, dim3((unsigned)cdiv(R, rpb)), dim3(256), 0, s, gy, x, gamma, mean_rstd, ws, ggamma, gbeta, R,
+                       C, ld_gy, ld_x, RB, X, B, rpb);
+    const double n = (double)(R / B) * C;
+    hipLaunchKernelGGL(k_gnrows_bwd_apply, dim3(flat_grid(R * C)), dim3(256), 0, s, gy, x, gamma, mean_rstd, ws, gx, R, C, ld_gy, ld_x,
+                       ld_gx, RB, X, n);
+    return launch_status("fqss_gnrows_bwd");
+}
+
+extern "C" int fqss_bcast_add(const float* x, const float* p, float* z, int64_t L, int64_t Bp, int C, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && p && z && L >= 0 && Bp >= 0 && C > 0, "bad args");
+    if (L * Bp == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_bcast_add, dim3(flat_grid(L * Bp * C)), dim3(256), 0, (hipStream_t)stream, x, p, z, L, Bp, C);
+    return launch_status("fqss_bcast_add");
+}
+
+extern "C" int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp, int C, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && out && L >= 0 && Bp >= 0 && C > 0, "bad args");
+    if (L == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_bcast_sum, dim3(flat_grid(L * C)), dim3(256), 0, (hipStream_t)stream, g, out, L, Bp, C);
+    return launch_status("fqss_bcast_sum");
 }

@@ -899,3 +899,48 @@ def lstm_bwd(gout, whh, gsav, csav, S, B, H):
     dG = torch.empty(S, B, 8 * H, device=gout.device, dtype=torch.float32)
     _lib.call("fqss_lstm_bwd", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), S, B, H, _stream())
     return dG
+
+
+# ================================================================== Sepformer (cfg 4)
+def gnrows_fwd(x, gamma, beta, eps, RB, X, B):
+    """gLN over all rows of a sample of a row matrix [..., C]; sample of row r = (r % RB) // X"""
+    _need_gpu(x, gamma, beta)
+    C = gamma.numel()
+    x, R, ld_x = _rows(x, C)
+    y = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    mean_rstd = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gnrows_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean_rstd), _p(ws), R, C, ld_x, C, RB, X, B, float(eps), _stream())
+    return y, mean_rstd
+
+
+def gnrows_bwd(gy, x, gamma, mean_rstd, ggamma, gbeta, RB, X, B):
+    _need_gpu(gy, x, gamma, mean_rstd, ggamma, gbeta)
+    C = gamma.numel()
+    gy, R, ld_gy = _rows(gy, C)
+    x, _, ld_x = _rows(x, C)
+    gx = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    ws = torch.empty(2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gnrows_bwd", _p(gy), _p(x), _p(gamma), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), _p(ws), R, C, ld_gy, ld_x, C,
+              RB, X, B, _stream())
+    return gx
+
+
+def bcast_add(x, p):
+    """x [L, Bp, C] + p [L, C] broadcast over Bp"""
+    _need_gpu(x, p)
+    x, p = x.contiguous(), p.contiguous()
+    L, Bp, C = x.shape
+    z = torch.empty_like(x)
+    _lib.call("fqss_bcast_add", _p(x), _p(p), _p(z), L, Bp, C, _stream())
+    return z
+
+
+def bcast_sum(g):
+    """g [L, Bp, C] -> [L, C] summed over Bp"""
+    _need_gpu(g)
+    g = g.contiguous()
+    L, Bp, C = g.shape
+    out = torch.empty(L, C, device=g.device, dtype=torch.float32)
+    _lib.call("fqss_bcast_sum", _p(g), _p(out), L, Bp, C, _stream())
+    return out

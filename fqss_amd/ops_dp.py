@@ -284,3 +284,35 @@ class LstmBi(Function):
             K.colsum(dG[..., lo:lo + 4 * H], buf)
             gbs.append(None if direct else buf)
         return gx, gwih[:4 * H], gwhh[0], gbs[0], gbs[1], gwih[4 * H:], gwhh[1], gbs[2], gbs[3]
+
+
+class GroupNormRows(Function):
+    """GroupNorm(1, C) of a dual-path block on a row layout (sepformerq.py:159, 175): statistics over all rows of a sample;
+    geom = (RB, X, B): sample of row r = (r % RB) // X"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, geom):
+        y, mean_rstd = K.gnrows_fwd(x, gamma, beta, eps, *geom)
+        ctx.save_for_backward(x, gamma, mean_rstd)
+        ctx.geom, ctx.beta = geom, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean_rstd = ctx.saved_tensors
+        gg, d1 = _param_grad(gamma, gamma)
+        gb, d2 = _param_grad(ctx.beta, gamma)
+        gx = K.gnrows_bwd(gy, x, gamma, mean_rstd, gg, gb, *ctx.geom)
+        return gx, (None if d1 else gg), (None if d2 else gb), None, None
+
+
+class AddBcastRows(Function):
+    """x [L, B', C] + p [L, C] (positional encoding broadcast over the sequences, sepformerq.py:117-118)"""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        return K.bcast_add(x, p)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.needs_input_grad[0] else None), (K.bcast_sum(g) if ctx.needs_input_grad[1] else None)

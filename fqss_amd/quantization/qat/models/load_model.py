@@ -5,6 +5,7 @@ from ..qat_layers import LayerQ
 from ..qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
 from .convtasnetq import ConvTasNetQ
 from .dptnetq import DPTNetQ
+from .sepformerq import SepformerQ
 
 
 def set_mac_op(model, mode=False):
@@ -26,8 +27,11 @@ def create_model(model_cfg):
                            stride=model_cfg.get("stride", 16))
     if name == "DPTNet":
         return DPTNetQ(n_spks=model_cfg.get("n_src", 2), kernel_size=model_cfg.get("kernel_size", 2))
-    if name in ("Sepformer", "ConvTasNetMusic", "HTDemucs"):
-        raise NotImplementedError(f"{name}: SURVEY.md §8 rows a14-a15 (later rounds); this build serves ConvTasNet and DPTNet")
+    if name == "Sepformer":
+        return SepformerQ(n_spks=model_cfg.get("n_src", 2), kernel_size=model_cfg.get("kernel_size", 16),
+                          stride=model_cfg.get("stride", 8))
+    if name in ("ConvTasNetMusic", "HTDemucs"):
+        raise NotImplementedError(f"{name}: SURVEY.md §8 row a15 (later rounds); this build serves ConvTasNet, DPTNet and Sepformer")
     raise AssertionError("Model {} is not supported!".format(name))
 
 

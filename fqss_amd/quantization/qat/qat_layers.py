@@ -23,8 +23,16 @@ from .qat_quant import _BypassQuantizer, get_activation_quantizer, get_weight_qu
 # ---------------------------------------------------------------------------------------------
 # float marker modules (forward runs the same HIP kernels in BYPASS mode: the teacher path)
 # ---------------------------------------------------------------------------------------------
+def _is_row_bcast(x1, x2):
+    """[L, B', C] + [L, 1, C]: the positional-encoding add of the Sepformer transformer blocks on sequence-first rows"""
+    return torch.is_tensor(x2) and x1.dim() == 3 and x2.dim() == 3 and x2.shape[1] == 1 and x1.shape[1] != 1 \
+        and x1.shape[0] == x2.shape[0] and x1.shape[2] == x2.shape[2]
+
+
 class Add(nn.Module):
     def forward(self, x1, x2):
+        if _is_row_bcast(x1, x2):
+            return ops_dp.AddBcastRows.apply(ops.real(x1), ops.real(x2).reshape(x2.shape[0], x2.shape[2]))
         return ops.AddActQ.apply(x1, x2, None, None, 1.0, ops.BYPASS)
 
 
@@ -101,6 +109,8 @@ class AddQ(LayerQ):
 
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
+        if _is_row_bcast(x1, x2):
+            return fq_node(aq, ops_dp.AddBcastRows.apply(ops.real(x1), ops.real(x2).reshape(x2.shape[0], x2.shape[2])))
         q = aq.qctx()
         y = ops.ew_layer(x1, x2, 1.0, ops.ACT_NONE, None, q)
         aq.after_forward(q)
@@ -258,10 +268,17 @@ class GroupNormQ(LayerQ):
     def forward(self, x):
         return run_groupnorm(self.groupnorm, x, self.activation_fake_quantize)
 
+    def forward_rows(self, x, geom):
+        """the same layer on a dual-path row layout [L', B', C]; geom = (RB, X, B): sample of row r = (r % RB) // X"""
+        return run_groupnorm_rows(self.groupnorm, x, self.activation_fake_quantize, geom)
+
 
 def run_groupnorm(gn, x, aq):
     if gn.num_groups != 1 or not gn.affine:
         raise NotImplementedError("only GroupNorm(num_groups=1, affine=True) (gLN) has a HIP kernel")
+    if x.dim() == 4:       # [B, C, H, W] (Sepformer's dual-path blocks in the reference's layout): statistics over C*H*W
+        shp = x.shape
+        return ops.reshape_tagged(run_groupnorm(gn, ops.reshape_tagged(x, shp[0], shp[1], shp[2] * shp[3]), aq), *shp)
     q = aq.qctx() if aq is not None else ops.BYPASS
     xq = ops.codes_of(x)
     if not (xq is not None and q.qmode == ops.Q_QUANT):
@@ -270,6 +287,12 @@ def run_groupnorm(gn, x, aq):
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)
+
+
+def run_groupnorm_rows(gn, x, aq, geom):
+    if gn.num_groups != 1 or not gn.affine:
+        raise NotImplementedError("only GroupNorm(num_groups=1, affine=True) (gLN) has a HIP kernel")
+    return fq_node(aq, ops_dp.GroupNormRows.apply(ops.real(x), gn.weight, gn.bias, gn.eps, tuple(geom)))
 
 
 def run_nl(nl, x, aq):
@@ -340,8 +363,8 @@ class ResidualErrorBlock(LayerQ):
         if type(decoder) not in (nn.ConvTranspose1d, nn.Linear):
             raise NotImplementedError("ResidualErrorBlock: only the ConvTranspose1d (ConvTasNet/Sepformer) and Linear (DPTNet) "
                                       "decoders have kernels")
-        if train_res_dec:
-            raise NotImplementedError("train_res_dec=True (Sepformer/HTDemucs configs) is a later §8 row")
+        if train_res_dec and type(decoder) is not nn.ConvTranspose1d:
+            raise NotImplementedError("train_res_dec=True: only the ConvTranspose1d decoder (Sepformer) has kernels")
         self.decoder_type = type(decoder)
         self.train_res_dec = train_res_dec
         if self.decoder_type is nn.Linear:      # qat_layers.py:1111-1114
@@ -351,6 +374,11 @@ class ResidualErrorBlock(LayerQ):
             self.residual_encoder = nn.Conv1d(decoder.out_channels, decoder.in_channels, decoder.kernel_size,
                                               stride=decoder.stride, bias=decoder.bias is not None)
             self.decoder_stride = decoder.stride
+            if train_res_dec:       # the LSB channel gets its own trainable decoder (qat_layers.py:1137-1146; Sepformer)
+                self.residual_decoder = nn.ConvTranspose1d(decoder.in_channels, decoder.out_channels, decoder.kernel_size,
+                                                           stride=decoder.stride, bias=decoder.bias is not None)
+                self.weight_fake_quantize_dec = (get_weight_quantizer(gradient_based, self.residual_decoder.weight.shape, ch_out_idx=1,
+                                                                      n_bits=weight_n_bits) if weight_quant else nn.Identity())
         self.weight_fake_quantize = (get_weight_quantizer(gradient_based, self.residual_encoder.weight.shape, n_bits=weight_n_bits)
                                      if weight_quant else nn.Identity())
 
@@ -371,6 +399,11 @@ class ResidualErrorBlock(LayerQ):
         Y1 = ops.tag_codes(ops.ew_layer(Y, Y_q, -1.0, ops.ACT_NONE, None, q), q)
         aq.after_forward(q)
         Y1 = ops.real(Y1)
+        if self.train_res_dec:
+            decoder_conv_, w_decoder = self.residual_decoder, self.weight_fake_quantize_dec(self.residual_decoder.weight)
+            if decoder_conv is None:
+                return run_convtr1d(decoder_conv_, Y1, w_decoder, None)
+            return run_convtr1d(decoder_conv_, Y1, w_decoder, out_quantizer)
         if decoder_conv is None:
             L = ops._Lin("convtr", stride=self.decoder_stride[0])
             return ops.LinearActQ.apply(Y1, w_decoder, None, None, None, None, L, ops.ACT_NONE, ops.BYPASS)

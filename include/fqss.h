@@ -448,6 +448,22 @@ int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* h
 int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
                   int B, int H, fqss_stream_t stream);
 
+/* Sepformer (cfg 4 -- SURVEY.md §8 row a14): gLN and the positional-encoding add on the dual-path row layouts.
+ * GroupNorm(1, C) over ALL rows of a sample of a row matrix x [R][C]; the sample of row r is b = (r % RB) / X
+ * (intra-chunk rows [K][B*S][C]: RB = B*S, X = S; inter-chunk rows [S][B*K][C]: RB = B*K, X = K), B <= 16.
+ * replaces: nn.GroupNorm(1, F) of DualPathBlock on [B, F, K, S] (sepformerq.py:141-142, 159, 175) + autograd, without the
+ * permute().contiguous() round trips around it.  ws: 2*B doubles of scratch; mean_rstd [B][2] saved for the backward.
+ * bwd: gx = ; ggamma[C] += ; gbeta[C] +=                                                            */
+int fqss_gnrows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd, double* ws,
+                    int64_t R, int C, int64_t ld_x, int64_t ld_y, int RB, int X, int B, double eps, fqss_stream_t stream);
+int fqss_gnrows_bwd(const float* gy, const float* x, const float* gamma, const float* mean_rstd, float* gx,
+                    float* ggamma, float* gbeta, double* ws, int64_t R, int C, int64_t ld_gy, int64_t ld_x,
+                    int64_t ld_gx, int RB, int X, int B, fqss_stream_t stream);
+/* z[l][b][c] = x[l][b][c] + p[l][c]  (TransformerBlock.pos_add, sepformerq.py:117-118, sequence-first rows);
+ * out[l][c] = sum_b g[l][b][c]       (the gradient reaching the ConstQ-quantized positional encoding)        */
+int fqss_bcast_add(const float* x, const float* p, float* z, int64_t L, int64_t Bp, int C, fqss_stream_t stream);
+int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp, int C, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,7 +134,10 @@ class DQTable(QTable):
             pre = k[: -len(".min_range")]
             if self.p[k].dim() >= 2:
                 owner = pre.rsplit(".", 1)[0] + "."
-                axis = 1 if (owner + "convTr1d.weight") in self.p else 0
+                # ch_out_idx = 1 for transposed convs: the decoder (qat_layers.py:1317) and, with train_res_dec, the residual
+                # decoder's own quantizer (qat_layers.py:1141-1145)
+                axis = 1 if ((owner + "convTr1d.weight") in self.p and pre.endswith(".weight_fake_quantize")) or \
+                    (pre.endswith(".weight_fake_quantize_dec") and self.p.get(owner + "residual_decoder.weight", torch.zeros(1)).dim() == 3) else 0
                 self.wq[pre] = WeightRange(self.p, pre, axis)
             else:
                 self.aq[pre] = ActRange(self.p, pre)
