@@ -246,3 +246,4 @@ class SepformerQ(nn.Module):
                     quantize_modules(m, [name], p)
                 quantize_modules(m.end_conv, ["0", "1"], p)
                 quantize_modules(m, ["prelu"], p)
+                quantize_modules(m, ["mul"], p)

@@ -1,0 +1,311 @@
+"""GPU parity of the Sepformer (SURVEY.md §8 row a14 / cfg 4) product path against the oracle (oracle/sepformer_oracle.py) and the
+reference-generated fixtures (tests/golden/sep_*.npz, cfg4_step.npz)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import oracle.fqss_oracle as O
+import oracle.sepformer_oracle as S
+from tests.test_gpu_dptnet import QCFG, T, _leave_observer, close, dpt_fill, rnd
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(n_spks=2, kernel_size=16, stride=8, n_filters=16, n_repeats=1, n_heads=4, chunk_size=10)
+TINY_FFN = 32
+A = dict(gradient_based=True, act_quant=True)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    yield
+
+
+@pytest.mark.parametrize("B,X,n,C", [(2, 5, 6, 16), (1, 34, 250, 256), (3, 7, 10, 64)])
+def test_gnrows_kernels(B, X, n, C):
+    """gLN on a row layout [n][B*X][C] vs F.group_norm on the reference's [B, C, n, X] tensor"""
+    from fqss_amd import kernels as K
+    x4 = (rnd(B, C, n, X, seed=41) * 1.3 + 0.4).requires_grad_(True)
+    ga, be = (1 + 0.1 * rnd(C, seed=42)).requires_grad_(True), (0.1 * rnd(C, seed=43)).requires_grad_(True)
+    y4 = F.group_norm(x4, 1, ga, be, 1e-8)
+    g4 = rnd(B, C, n, X, seed=44)
+    y4.backward(g4)
+    to_rows = lambda t: t.detach().permute(2, 0, 3, 1).reshape(n, B * X, C).contiguous().cuda()
+    y, ms = K.gnrows_fwd(to_rows(x4), ga.detach().cuda(), be.detach().cuda(), 1e-8, B * X, X, B)
+    close(y, to_rows(y4).cpu(), 5e-6)
+    gg, gb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    gx = K.gnrows_bwd(to_rows(g4), to_rows(x4), ga.detach().cuda(), ms, gg, gb, B * X, X, B)
+    close(gx, to_rows(x4.grad).cpu(), 2e-5)
+    close(gg, ga.grad, 2e-5)
+    close(gb, be.grad, 2e-5)
+
+
+def _sd(g, name):
+    return {k[len(name) + 4:]: T(g[k]) for k in g.files if k.startswith(name + ".sd.")}
+
+
+def _idx_close(out, ref, lo, hi, max_frac):
+    delta = (hi - lo) / 255.0
+    a, b = np.rint((out - lo) / delta), np.rint((ref - lo) / delta)
+    assert np.abs(a - b).max() <= 1
+    assert float(np.mean(a != b)) <= max_frac, float(np.mean(a != b))
+    return int((a != b).sum())
+
+
+def test_sep_layer_pos_add(golden):
+    """ConstQ on the positional table + the broadcasting AddQ, on sequence-first rows"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    from fqss_amd.quantization.qat.models.sepformerq import PositionalEncoding
+    g = golden("sep_layers")
+    name = "pos_add"
+    sd = _sd(g, name)
+
+    class PosAdd(nn.Module):
+        def __init__(self, F_):
+            super().__init__()
+            self.pos = PositionalEncoding(F_)
+            self.pos.const = QL.ConstQ(self.pos.const, **A)
+            self.pos_add = QL.AddQ(QL.Add(), **A)
+
+        def forward(self, x):
+            return self.pos_add(x, self.pos(x))
+
+    L = PosAdd(sd["pos.pe"].shape[-1])
+    L.load_state_dict(sd, strict=True)
+    L = L.cuda().train()
+    _leave_observer(L)
+    x = T(g[name + ".in0"]).permute(1, 0, 2).contiguous().cuda().requires_grad_(True)       # [L, B', F]
+    y = L(x)
+    y.backward(T(g[name + ".gout"]).permute(1, 0, 2).contiguous().cuda())
+    lo, hi = float(sd["pos_add.activation_fake_quantize.min_range"]), float(sd["pos_add.activation_fake_quantize.max_range"])
+    nflip = _idx_close(y.detach().permute(1, 0, 2).cpu().numpy(), g[name + ".out"], lo, hi, 3e-3)
+    want = g[name + ".gin0"]
+    bad = np.abs(x.grad.permute(1, 0, 2).cpu().numpy() - want) > 2e-4 * np.abs(want).max() + 2e-4 * np.abs(want)
+    assert bad.mean() <= 2e-3 + 8.0 * nflip / want.size
+    params = dict(L.named_parameters())
+    for k in g.files:
+        if k.startswith(name + ".grad."):
+            w = g[k]
+            np.testing.assert_allclose(params[k[len(name) + 6:]].grad.cpu().numpy(), w, rtol=3e-3, atol=(3e-3 + 0.05 * nflip) * (np.abs(w).max() + 1e-6), err_msg=k)
+
+
+def test_sep_layer_groupnorm_4d_rows_and_reference_layout(golden):
+    from fqss_amd.quantization.qat import qat_layers as QL
+    g = golden("sep_layers")
+    name = "groupnormq_4d"
+    sd = _sd(g, name)
+    x4 = T(g[name + ".in0"])
+    B, C, Kc, S_ = x4.shape
+    lo, hi = float(sd["activation_fake_quantize.min_range"]), float(sd["activation_fake_quantize.max_range"])
+    for mode in ("rows", "nchw"):
+        L = QL.GroupNormQ(nn.GroupNorm(1, C, eps=1e-8), **A)
+        L.load_state_dict(sd, strict=True)
+        L = L.cuda().train()
+        _leave_observer(L)
+        if mode == "rows":
+            x = x4.permute(2, 0, 3, 1).reshape(Kc, B * S_, C).contiguous().cuda().requires_grad_(True)
+            y = L.forward_rows(x, (B * S_, S_, B))
+            y.backward(T(g[name + ".gout"]).permute(2, 0, 3, 1).reshape(Kc, B * S_, C).contiguous().cuda())
+            out = y.detach().cpu().view(Kc, B, S_, C).permute(1, 3, 0, 2).numpy()
+            gin = x.grad.cpu().view(Kc, B, S_, C).permute(1, 3, 0, 2).numpy()
+        else:
+            x = x4.cuda().requires_grad_(True)
+            y = L(x)
+            y.backward(T(g[name + ".gout"]).cuda())
+            out, gin = y.detach().cpu().numpy(), x.grad.cpu().numpy()
+        nflip = _idx_close(out, g[name + ".out"], lo, hi, 3e-3)
+        want = g[name + ".gin0"]
+        bad = np.abs(gin - want) > 2e-4 * np.abs(want).max() + 2e-4 * np.abs(want)
+        assert bad.mean() <= 2e-3 + 8.0 * nflip / want.size, (mode, bad.mean())
+        for k in g.files:
+            if k.startswith(name + ".grad."):
+                w = g[k]
+                got = dict(L.named_parameters())[k[len(name) + 6:]].grad.cpu().numpy()
+                np.testing.assert_allclose(got, w, rtol=3e-3, atol=(3e-3 + 0.05 * nflip) * (np.abs(w).max() + 1e-6), err_msg=mode + k)
+
+
+def test_sep_layer_relu_and_trainable_residual_decoder(golden):
+    from fqss_amd.quantization.qat import qat_layers as QL
+    g = golden("sep_layers")
+    for name in ("nlq_relu", "convtr1ddecoderq_trd"):
+        sd = _sd(g, name)
+        if name == "nlq_relu":
+            L = QL.NlQ(nn.ReLU(), **A)
+        else:
+            ci = sd["convTr1d.weight"].shape[0]
+            L = QL.ConvTr1dDecoderQ([nn.ConvTranspose1d(ci, 1, 16, stride=8, bias=False)], n_combiner=2, gradient_based=True,
+                                    weight_quant=True, weight_n_bits=8, act_quant=True, act_n_bits=8, out_quant=True, out_act_n_bits=8,
+                                    train_res_dec=True)
+        L.load_state_dict(sd, strict=True)
+        L = L.cuda().train()
+        _leave_observer(L)
+        x = T(g[name + ".in0"]).cuda().requires_grad_(True)
+        y = L(x)
+        y.backward(T(g[name + ".gout"]).cuda())
+        out, ref = y.detach().cpu().numpy(), g[name + ".out"]
+        keys = ["activation_fake_quantize"] + (["activation_fake_quantize_residual"] if name != "nlq_relu" else [])
+        nflip = 0
+        for ch, key in enumerate(keys):
+            o, r = (out[ch], ref[ch]) if len(keys) == 2 else (out, ref)
+            nflip += _idx_close(o, r, float(sd[key + ".min_range"]), float(sd[key + ".max_range"]), 6e-3)
+        want = g[name + ".gin0"]
+        bad = np.abs(x.grad.cpu().numpy() - want) > 2e-4 * np.abs(want).max() + 2e-4 * np.abs(want)
+        assert bad.mean() <= 2e-3 + 8.0 * nflip / want.size, (name, bad.mean())
+        for k in g.files:
+            if k.startswith(name + ".grad."):
+                w = g[k]
+                got = dict(L.named_parameters())[k[len(name) + 6:]].grad.cpu().numpy()
+                np.testing.assert_allclose(got, w, rtol=3e-3, atol=(3e-3 + 0.05 * nflip) * (np.abs(w).max() + 1e-6), err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ model
+def build_pair(seed=0, tiny=False, **kw):
+    from fqss_amd.quantization.qat.models.load_model import quantize_model
+    from fqss_amd.quantization.qat.models.sepformerq import MaskGenerator, SepformerQ
+    torch.manual_seed(seed)
+    model = SepformerQ(**kw)
+    if tiny:      # same narrow feed-forward as the fixture generator (tools/make_goldens_sepformer.py)
+        model.masker = MaskGenerator(kw["n_spks"], kw["n_filters"], n_repeats=kw["n_repeats"], n_heads=kw["n_heads"],
+                                     chunk_size=kw["chunk_size"], n_ffn=TINY_FFN)
+    fmodel = copy.deepcopy(model)
+    model = quantize_model(model, dict(QCFG))
+    return model.cuda().train(), fmodel.cuda().eval()
+
+
+def _tiny_pair(g, prefix="sd0."):
+    model, fmodel = build_pair(0, tiny=True, **TINY)
+    model.load_state_dict({k[len(prefix):]: T(g[k]) for k in g.files if k.startswith(prefix)}, strict=True)
+    fmodel.load_state_dict({k[4:]: T(g[k]) for k in g.files if k.startswith("fsd.")}, strict=True)
+    return model, fmodel
+
+
+def test_sep_state_dict_layout(golden):
+    g = golden("sep_tiny_step")
+    model, _ = _tiny_pair(g)
+    assert list(model.state_dict().keys()) == list(g["sd_keys"])
+
+
+def test_sep_teacher_forward_matches_oracle():
+    """float path of the full-size network (25.7 M parameters), B = 1, 1 s"""
+    _, fmodel = build_pair(1, n_spks=2, kernel_size=16, stride=8)
+    x, _ = O.synth_batch(1, 8000, seed=2)
+    with torch.no_grad():
+        y = fmodel(x.cuda()).cpu()
+    ref = S.TeacherSepformer({k: v.cpu() for k, v in fmodel.state_dict().items()})(x)
+    assert float((y - ref).norm() / ref.norm()) < 2e-4
+
+
+def _check_step(g, p, r, model, loss_rel, est_tol, grad_tol):
+    np.testing.assert_allclose(r["loss"].item(), g[p + "loss"], rtol=loss_rel, err_msg=p)
+    np.testing.assert_allclose(r["kd"].item(), g[p + "kd"], rtol=loss_rel, err_msg=p)
+    np.testing.assert_allclose(r["w"].cpu().numpy(), g[p + "w"], rtol=2.3e-4, err_msg=p)
+    np.testing.assert_allclose(r["est"].cpu().numpy(), g[p + "est"], rtol=1e-4, atol=est_tol, err_msg=p)
+    np.testing.assert_allclose(r["gnorm"].item(), g[p + "gnorm"], rtol=3e-4, err_msg=p)
+    coef = min(1.0, 5.0 / (float(g[p + "gnorm"]) + 1e-6))
+    n = 0
+    for name, prm in model.named_parameters():
+        k = p + "grad." + name
+        if k in g.files:
+            ref = g[k] / coef
+            err = np.linalg.norm(prm.grad.cpu().numpy() - ref) / (np.linalg.norm(ref) + 1e-12)
+            assert err <= grad_tol or np.linalg.norm(ref) < 1e-7, (k, err)
+            n += 1
+        else:
+            assert float(prm.grad.abs().max()) == 0.0, name
+    assert n >= 100
+
+
+def test_sep_tiny_training_vs_reference_goldens(golden):
+    from fqss_amd.runtime import KDTrainStep
+    g = golden("sep_tiny_step")
+    model, fmodel = _tiny_pair(g)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1.5e-4, clip=5.0)
+    x, tgt = T(g["x"]).cuda(), T(g["tgt"]).cuda()
+    for s in range(1, 54):
+        r = step(x, tgt)
+        if s == 1:
+            _check_step(g, "s1.", r, model, 2e-5, 5e-6, 3e-3)
+        elif f"s{s}.loss" in g.files:
+            assert abs(r["loss"].item() - float(g[f"s{s}.loss"])) <= 1.5, (s, r["loss"].item(), float(g[f"s{s}.loss"]))
+
+
+def _forced(g, s):
+    from fqss_amd.quantization.qat import qat_quant as QQ
+    model, fmodel = _tiny_pair(g, prefix=f"s{s}.post_sd.")
+    for m in model.modules():
+        if isinstance(m, QQ.GradientWeightFakeQuantize):
+            m.observer_mode = False
+        if isinstance(m, QQ.GradientActivationFakeQuantize):
+            m.n_iter = min(s, m.max_observations)
+    return model, fmodel
+
+
+def test_sep_tiny_step2_from_reference_state(golden):
+    from fqss_amd import kernels as K
+    from fqss_amd.runtime import KDTrainStep
+    g = golden("sep_tiny_step")
+    model, fmodel = _forced(g, 1)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1.5e-4, clip=5.0)
+    r = step._fwd_bwd(T(g["x"]).cuda(), T(g["tgt"]).cuda())
+    step.arena.sumsq.zero_()
+    K.sumsq(step.arena.flat_g, step.arena.sumsq)
+    r["gnorm"] = step.arena.sumsq.sqrt().float()
+    _check_step(g, "s2.", r, model, 5e-5, 2e-5, 4e-3)
+
+
+def test_sep_tiny_step51_from_reference_state(golden):
+    from fqss_amd import kernels as K
+    g = golden("sep_tiny_step")
+    model, fmodel = _forced(g, 50)
+    x, tgt = T(g["x"]).cuda(), T(g["tgt"]).cuda()
+    with torch.no_grad():
+        est, fest = model(x), fmodel(x)
+    out, w, sisdr, _ = K.kd_loss(est, fest, tgt, 0.1, want_grad=False)
+    np.testing.assert_allclose(fest.cpu().numpy(), g["s51.fest"], rtol=1e-4, atol=5e-6)
+    assert abs(out[0].item() - float(g["s51.loss"])) <= 0.2, (out[0].item(), float(g["s51.loss"]))
+
+
+def test_sep_full_size_vs_reference_goldens(golden):
+    """the FULL-SIZE SepformerQ (2 dual-path blocks x 2 x 8 transformer layers) vs digests of the real reference's run"""
+    from fqss_amd.data import synth_batch
+    from fqss_amd.runtime import KDTrainStep
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "cfg4_step.npz")):
+        pytest.skip("cfg4_step.npz not generated (tools/make_goldens_sepformer.py --only cfg4: ~15 min of reference CPU time)")
+    g = golden("cfg4_step")
+    B, T_ = int(g["B"]), int(g["T"])
+    model, fmodel = build_pair(0, n_spks=2, kernel_size=16, stride=8)
+    dpt_fill(fmodel, "T.")
+    dpt_fill(model, "S.")
+    assert [k for k, _ in model.named_parameters()] == list(g["param_names"])
+    np.testing.assert_allclose([float(p.detach().double().sum()) for _, p in model.named_parameters()], g["param_sum"], rtol=1e-9, atol=1e-9)
+    x, tgt = synth_batch(B, T_, seed=0, device="cuda")
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1.5e-4, clip=5.0)
+    for s in range(1, 53):
+        r = step(x, tgt)
+        p = f"s{s}."
+        if p + "loss" not in g.files:
+            continue
+        if s <= 2:
+            f = 1.0 if s == 1 else 30.0
+            for k in ("loss", "kd", "task"):
+                np.testing.assert_allclose(r[k].item(), g[p + k], rtol=2e-5 * f, err_msg=p + k)
+            np.testing.assert_allclose(r["gnorm"].item(), g[p + "gnorm"], rtol=(3e-4 if s == 1 else 1e-2), err_msg=p)
+            if s == 1:
+                ref = g[p + "est"]
+                np.testing.assert_allclose(r["est"].cpu().numpy(), ref, rtol=1e-4, atol=2e-4 * float(np.abs(ref).max()))
+                coef = min(1.0, 5.0 / (float(g[p + "gnorm"]) + 1e-6))
+                bad = []
+                for (name, prm), ref_n in zip(model.named_parameters(), g[p + "grad_norm"]):
+                    got = float(prm.grad.double().norm())
+                    if ref_n < 0:
+                        assert got == 0.0, name
+                    elif abs(got - ref_n / coef) > (1e-2 if prm.numel() == 1 else 4e-3) * (ref_n / coef) + 1e-6:
+                        bad.append((name, got, ref_n / coef))
+                assert not bad, bad[:5]
+        else:
+            assert abs(r["loss"].item() - float(g[p + "loss"])) <= 2.5, (s, r["loss"].item(), float(g[p + "loss"]))
