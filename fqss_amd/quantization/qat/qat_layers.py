@@ -461,13 +461,14 @@ _FLAT_COLS = {}
 
 def _flat2d(t):
     """a dense tensor as [rows, cols] with long rows (the element-wise kernels stream rows; 64-wide rows would idle 3/4 of
-    every workgroup): cols = the largest divisor of numel in [1024, 16384] that is a multiple of 4"""
+    every workgroup): cols = the largest divisor of numel in [1024, 16384] that is a multiple of 16 (rows of activation
+    buffers are padded to 16 floats: a multiple of 16 keeps the kernel's output dense, so the view back is free)"""
     n = t.numel()
     if not t.is_contiguous() or n < 4096:
         return None
     c = _FLAT_COLS.get(n)
     if c is None:
-        c = next((c for c in range(16384, 1020, -4) if n % c == 0), 0)
+        c = next((c for c in range(16384, 1008, -16) if n % c == 0), 0)
         _FLAT_COLS[n] = c
     return t.view(n // c, c) if c else None
 
@@ -484,7 +485,7 @@ def fq_node(aq, x, nl=None):
     if aq is not None:
         aq.after_forward(q)
     q.idx = None
-    return y if flat is None else y.view(x.shape)
+    return y if flat is None else y.reshape(x.shape)
 
 
 def run_linear(lin, x, weight, nl, aq):

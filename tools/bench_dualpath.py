@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""cfg 3 (DPTNet 2spk 8 kHz W8A8 QAT): time one QAT step of the full-size network on one MI355X.
-Not the round's bench line (bench.py stays on cfg 2, the configuration BASELINE.json quotes the metric on) -- a probe for
-DESIGN.md and for `rocprofv3 --kernel-trace --stats -- python3 tools/bench_dptnet.py`.
+"""cfg 3 / cfg 4 (DPTNet, Sepformer 2spk 8 kHz W8A8 QAT): time one QAT step of the full-size
+network on one MI355X.  Not the round's bench line (bench.py stays on cfg 2, the configuration BASELINE.json quotes the metric on)
+-- a probe for DESIGN.md and for `rocprofv3 --kernel-trace --stats -- python3 tools/bench_dualpath.py`.
 
-  python tools/bench_dptnet.py [--B 1] [--T 24000] [--steps 10] [--graph]
+  python tools/bench_dualpath.py [--model dptnet|sepformer] [--B 1] [--T 24000|32000] [--steps 10] [--graph]
 """
 import argparse
 import copy
@@ -19,6 +19,7 @@ import torch  # noqa: E402
 from fqss_amd.data import synth_batch  # noqa: E402
 from fqss_amd.quantization.qat import qat_quant as QQ  # noqa: E402
 from fqss_amd.quantization.qat.models.dptnetq import DPTNetQ  # noqa: E402
+from fqss_amd.quantization.qat.models.sepformerq import SepformerQ  # noqa: E402
 from fqss_amd.quantization.qat.models.load_model import quantize_model  # noqa: E402
 from fqss_amd.runtime import KDTrainStep  # noqa: E402
 from fqss_amd.smoke import QCFG  # noqa: E402
@@ -26,19 +27,22 @@ from fqss_amd.smoke import QCFG  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="dptnet", choices=("dptnet", "sepformer"))
     ap.add_argument("--B", type=int, default=1)
-    ap.add_argument("--T", type=int, default=24000)
+    ap.add_argument("--T", type=int, default=0, help="samples per mixture (default: 24000 = 3 s for DPTNet, 32000 = 4 s for Sepformer)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     torch.manual_seed(0)
-    model = DPTNetQ(n_spks=2, kernel_size=2)
+    a.T = a.T or (24000 if a.model == "dptnet" else 32000)
+    lr = 4e-4 if a.model == "dptnet" else 1.5e-4
+    model = DPTNetQ(n_spks=2, kernel_size=2) if a.model == "dptnet" else SepformerQ(n_spks=2, kernel_size=16, stride=8)
     fmodel = copy.deepcopy(model)
     model = quantize_model(model, dict(QCFG)).cuda().train()
     fmodel = fmodel.cuda().eval()
     x, tgt = synth_batch(a.B, a.T, seed=0, device="cuda")
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=4e-4, clip=5.0)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=lr, clip=5.0)
     t0 = time.time()
     for _ in range(3):                       # observer steps (weights observed at 1, quantized from 2)
         r = step(x, tgt)
@@ -59,7 +63,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.steps
-    print(json.dumps({"workload": f"DPTNet 2spk 8 kHz W8A8 QAT step, B={a.B}, T={a.T}", "ms_per_step": round(ms, 3),
+    print(json.dumps({"workload": f"{'DPTNet' if a.model == 'dptnet' else 'Sepformer'} 2spk 8 kHz W8A8 QAT step, B={a.B}, T={a.T}", "ms_per_step": round(ms, 3),
                       "samples_per_s": round(a.B / ms * 1e3, 2), "observer_phase_ms_per_step": round(obs_ms, 1),
                       "launch": "hipGraph replay" if a.graph else "eager", "loss_db": round(float(r["loss"]), 4),
                       "params": sum(p.numel() for p in model.parameters())}))
