@@ -34,10 +34,14 @@ struct GemmArgs {
     int ksplit, kchunk;  // split-K over blockIdx.z (ATOMIC only)
 };
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded LDS row (floats)
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // LDT: padded LDS row (floats); BM x BN is the LARGEST tile
 
-template <bool A_KC, bool B_KC, bool VEC, bool ATOMIC>
+// MI x NI = 32x32 MFMA tiles per wave (2 x 2 waves per workgroup): the workgroup tile is (64*MI) x (64*NI).
+//   (2,2) 128x128  the ConvTasNet shapes;   (2,1) 128x64  N = 64 outputs (DPTNet's feature dim: a 128-wide tile would be half
+//   empty);   (1,2) 64x128  problems with too few 128x128 tiles to fill 256 CUs (Sepformer: 8500 rows x 256 outputs = 134 tiles)
+template <bool A_KC, bool B_KC, bool VEC, bool ATOMIC, int MI, int NI>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    constexpr int BMt = 64 * MI, BNt = 64 * NI;
     __shared__ __attribute__((aligned(16))) float As[BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
 
@@ -50,18 +54,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     const int ks = ATOMIC ? bz % g.ksplit : 0;
     const int kbeg = ATOMIC ? ks * g.kchunk : 0;
     const int kend = ATOMIC ? min(g.K, kbeg + g.kchunk) : g.K;
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int i0 = blockIdx.y * BMt, j0 = blockIdx.x * BNt;
 
     const float* Ab = g.A + (int64_t)b * g.sAb;
     const float* Bb = g.B + (int64_t)b * g.sBb;
 
-    float ra[8], rb[8];
+    float ra[4 * MI], rb[4 * NI];
 
     auto load_tiles = [&](int k0) {
-        // ---------------- A tile: 128 (i) x 16 (k)
+        // ---------------- A tile: BMt (i) x 16 (k)
         if constexpr (VEC) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < MI; ++p) {
                 const int f = tid + 256 * p;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (A_KC) {
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                         if (k0 + k + 3 >= kend) v.w = 0.f;
                     }
                 } else {
-                    const int k = f >> 5, i = (f & 31) * 4;
+                    const int k = f / (16 * MI), i = (f % (16 * MI)) * 4;
                     if (k0 + k < kend && i0 + i < g.M) {
                         v = *reinterpret_cast<const float4*>(Ab + (int64_t)(k0 + k) * g.sAk + (i0 + i));
                         if (i0 + i + 1 >= g.M) v.y = 0.f;
@@ -85,19 +89,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < 4 * MI; ++p) {
                 const int e = tid + 256 * p;
                 int i, k;
-                if constexpr (A_KC) { i = e >> 4; k = e & 15; } else { k = e >> 7; i = e & 127; }
+                if constexpr (A_KC) { i = e >> 4; k = e & 15; } else { k = e / BMt; i = e % BMt; }
                 float v = 0.f;
                 if (i0 + i < g.M && k0 + k < kend) v = Ab[(int64_t)(i0 + i) * g.sAi + (int64_t)(k0 + k) * g.sAk];
                 ra[p] = v;
             }
         }
-        // ---------------- B tile: 16 (k) x 128 (j)
+        // ---------------- B tile: 16 (k) x BNt (j)
         if constexpr (VEC) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NI; ++p) {
                 const int f = tid + 256 * p;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (B_KC) {
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                         if (k0 + k + 3 >= kend) v.w = 0.f;
                     }
                 } else {
-                    const int k = f >> 5, j = (f & 31) * 4;
+                    const int k = f / (16 * NI), j = (f % (16 * NI)) * 4;
                     if (k0 + k < kend && j0 + j < g.N) {
                         v = *reinterpret_cast<const float4*>(Bb + (int64_t)(k0 + k) * g.sBk + (j0 + j));
                         if (j0 + j + 1 >= g.N) v.y = 0.f;
@@ -121,10 +125,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < 4 * NI; ++p) {
                 const int e = tid + 256 * p;
                 int j, k;
-                if constexpr (B_KC) { j = e >> 4; k = e & 15; } else { k = e >> 7; j = e & 127; }
+                if constexpr (B_KC) { j = e >> 4; k = e & 15; } else { k = e / BNt; j = e % BNt; }
                 float v = 0.f;
                 if (j0 + j < g.N && k0 + k < kend) v = Bb[(int64_t)(k0 + k) * g.sBk + (int64_t)(j0 + j) * g.sBj];
                 rb[p] = v;
@@ -135,43 +139,52 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     auto store_tiles = [&]() {
         if constexpr (VEC) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < MI; ++p) {
                 const int f = tid + 256 * p;
                 if constexpr (A_KC) {
                     const int i = f >> 2, k = (f & 3) * 4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) As[k + e][i] = ra[4 * p + e];
                 } else {
-                    const int k = f >> 5, i = (f & 31) * 4;
+                    const int k = f / (16 * MI), i = (f % (16 * MI)) * 4;
                     *reinterpret_cast<float4*>(&As[k][i]) = make_float4(ra[4 * p], ra[4 * p + 1], ra[4 * p + 2], ra[4 * p + 3]);
                 }
+            }
+#pragma unroll
+            for (int p = 0; p < NI; ++p) {
+                const int f = tid + 256 * p;
                 if constexpr (B_KC) {
                     const int j = f >> 2, k = (f & 3) * 4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Bs[k + e][j] = rb[4 * p + e];
                 } else {
-                    const int k = f >> 5, j = (f & 31) * 4;
+                    const int k = f / (16 * NI), j = (f % (16 * NI)) * 4;
                     *reinterpret_cast<float4*>(&Bs[k][j]) = make_float4(rb[4 * p], rb[4 * p + 1], rb[4 * p + 2], rb[4 * p + 3]);
                 }
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < 4 * MI; ++p) {
                 const int e = tid + 256 * p;
-                int i, k, j, k2;
-                if constexpr (A_KC) { i = e >> 4; k = e & 15; } else { k = e >> 7; i = e & 127; }
-                if constexpr (B_KC) { j = e >> 4; k2 = e & 15; } else { k2 = e >> 7; j = e & 127; }
+                int i, k;
+                if constexpr (A_KC) { i = e >> 4; k = e & 15; } else { k = e / BMt; i = e % BMt; }
                 As[k][i] = ra[p];
-                Bs[k2][j] = rb[p];
+            }
+#pragma unroll
+            for (int p = 0; p < 4 * NI; ++p) {
+                const int e = tid + 256 * p;
+                int j, k;
+                if constexpr (B_KC) { j = e >> 4; k = e & 15; } else { k = e / BNt; j = e % BNt; }
+                Bs[k][j] = rb[p];
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -186,14 +199,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
         if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);  // global loads fly under the MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[kk + lk][wm * 64 + lr];
-            const float a1 = As[kk + lk][wm * 64 + 32 + lr];
-            const float b0 = Bs[kk + lk][wn * 64 + lr];
-            const float b1 = Bs[kk + lk][wn * 64 + 32 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av[mi] = As[kk + lk][wm * (32 * MI) + mi * 32 + lr];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bv[ni] = Bs[kk + lk][wn * (32 * NI) + ni * 32 + lr];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
         if (kt + 1 < nkt) {
@@ -205,13 +220,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cb = g.C + (int64_t)b * g.sCb;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = j0 + wn * 64 + ni * 32 + lr;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = j0 + wn * (32 * NI) + ni * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const int row = i0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row < g.M && col < g.N) {
                     float v = acc[mi][ni][r];
                     if (g.bias != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias[row];
@@ -236,9 +251,19 @@ static int launch_gemm(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, int
     if (b_kc) vec = vec && (g.sBk == 1) && (g.sBj % 4 == 0) && (g.sBj >= rup4(g.K));
     else      vec = vec && (g.sBj == 1) && (g.sBk % 4 == 0) && (g.N % 4 == 0 || g.sBk >= rup4(g.N));
     if (atomic) vec = vec && (g.kchunk % 4 == 0);
-    dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)(batch * (atomic ? g.ksplit : 1)));
+    // tile shape: narrow outputs take the 128x64 tile; problems with too few 128x128 tiles to fill the chip take 64x128
+    const int64_t zdim = (int64_t)batch * (atomic ? g.ksplit : 1);
+    int mi = 2, ni = 2;
+    if (g.N <= 64) ni = 1;
+    else if (g.M <= 64 || (g.M > 128 && cdiv(g.M, BM) * cdiv(g.N, BN) * zdim < 2 * 256)) mi = 1;
+    dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim);
     dim3 block(256);
-#define FQSS_GEMM(AK, BKc, V, AT) hipLaunchKernelGGL((k_gemm_f32<AK, BKc, V, AT>), grid, block, 0, s, g)
+#define FQSS_GEMM(AK, BKc, V, AT)                                                                                     \
+    do {                                                                                                              \
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_f32<AK, BKc, V, AT, 2, 2>), grid, block, 0, s, g);        \
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_f32<AK, BKc, V, AT, 2, 1>), grid, block, 0, s, g);              \
+        else hipLaunchKernelGGL((k_gemm_f32<AK, BKc, V, AT, 1, 2>), grid, block, 0, s, g);                           \
+    } while (0)
     if (!atomic) {
         if (a_kc && !b_kc) { if (vec) FQSS_GEMM(true, false, true, false); else FQSS_GEMM(true, false, false, false); }
         else if (!a_kc && !b_kc) { if (vec) FQSS_GEMM(false, false, true, false); else FQSS_GEMM(false, false, false, false); }
