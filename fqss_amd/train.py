@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """`train.py -env <asteroid|speechbrain|tasnet|htdemucs> -y cfg.yaml` (reference: train.py:10-53).
-This build serves the asteroid env (ConvTasNet); the other envs are later rows of SURVEY.md §8."""
+This build serves the asteroid env (ConvTasNet, DPTNet) and the speechbrain env (Sepformer); tasnet / htdemucs are later rows
+of SURVEY.md §8."""
 import argparse
 
 import torch
@@ -22,8 +23,11 @@ def train():
     if args.env_name == "asteroid":
         from .train_env.asteroid_librimix import asteroid_librimix_trainer
         asteroid_librimix_trainer.train(args.yml_path, device)
-    elif args.env_name in ("speechbrain", "tasnet", "htdemucs"):
-        raise NotImplementedError(f"env {args.env_name}: SURVEY.md §8 rows a14/a15 (later rounds)")
+    elif args.env_name == "speechbrain":
+        from .train_env.speechbrain_librimix import speechbrain_librimix_trainer
+        speechbrain_librimix_trainer.train(args.yml_path, args.local_rank, args.distributed_launch, device)
+    elif args.env_name in ("tasnet", "htdemucs"):
+        raise NotImplementedError(f"env {args.env_name}: SURVEY.md §8 row a15 (later rounds)")
     else:
         assert False, "Training environment {} is not supported!".format(args.env_name)
     print("Training is done!")

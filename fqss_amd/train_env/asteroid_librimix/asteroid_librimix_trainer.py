@@ -54,13 +54,26 @@ def train(yml_path, device):
     opt = training_cfg.get("optim", {})
     system = System(model, fmodel, training_cfg.get("kd_lambda", 0), lr=opt.get("lr", 1e-3), clip=5.0, comm=comm)
     best, history = float("inf"), []
+    # schedulers of train_setup (asteroid_librimix_trainer.py:96-102): StepLR for `step_lr` (DPTNet config), ReduceLROnPlateau
+    # (factor 0.5) for `half_lr`; both act once per epoch on the stepper's learning rate
+    step_lr, half_lr = training_cfg.get("step_lr"), training_cfg.get("half_lr", False)
+    base_lr, plateau_best, plateau_bad = opt.get("lr", 1e-3), float("inf"), 0
     for epoch in range(training_cfg["epochs"]):
         for i, batch in enumerate(_batches(dataset_cfg, training_cfg, comm, dev, "train")):
             system.training_step(batch, i)
         val = torch.stack([system.validation_step(b, i) for i, b in enumerate(_batches(dataset_cfg, training_cfg, comm, dev, "val"))]).mean()
         comm.all_reduce_sum(val)
         val = val.item() / comm.world
-        history.append({"epoch": epoch, "loss": system.logged["loss"].item(), "val_loss": val})
+        history.append({"epoch": epoch, "loss": system.logged["loss"].item(), "val_loss": val, "lr": system.stepper.lr})
+        if half_lr:
+            if val < plateau_best - 1e-4 * abs(plateau_best):     # torch ReduceLROnPlateau defaults: rel threshold 1e-4
+                plateau_best, plateau_bad = val, 0
+            else:
+                plateau_bad += 1
+                if plateau_bad > training_cfg.get("patience", 5):
+                    system.stepper.lr, plateau_bad = system.stepper.lr * 0.5, 0
+        elif step_lr is not None:
+            system.stepper.lr = base_lr * step_lr.get("gamma", 0.98) ** ((epoch + 1) // step_lr.get("step_size", 2))
         if comm.rank == 0:
             print(json.dumps(history[-1]), flush=True)
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

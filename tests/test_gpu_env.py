@@ -26,3 +26,43 @@ def test_asteroid_env_trains_and_exports(tmp_path):
     assert os.path.exists(os.path.join(conf["work_dir"], "conf.yml"))
     with pytest.raises(RuntimeError):
         T.train(str(yml), "cpu")
+
+
+def test_asteroid_env_trains_dptnet(tmp_path):
+    """cfg 3 through the same env plugin: DPTNet from the YAML, StepLR (`step_lr`) on the stepper's learning rate"""
+    from fqss_amd.train_env.asteroid_librimix import asteroid_librimix_trainer as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = yaml.safe_load(open(os.path.join(root, "configs", "dptnet_2spks_8k_synthetic.yaml")))
+    conf["work_dir"] = str(tmp_path / "run")
+    conf["dataset_cfg"].update(segment=0.25, steps_per_epoch=3, val_steps=1)
+    conf["training_cfg"].update(epochs=4)
+    yml = tmp_path / "cfg.yaml"
+    yml.write_text(yaml.safe_dump(conf))
+    hist = T.train(str(yml), "cuda")
+    assert len(hist) == 4 and all(torch.isfinite(torch.tensor(h["loss"])) for h in hist)
+    assert abs(hist[0]["lr"] - 4e-4) < 1e-12 and abs(hist[2]["lr"] - 4e-4 * 0.98) < 1e-12 and abs(hist[3]["lr"] - 4e-4 * 0.98) < 1e-12
+    sd = torch.load(os.path.join(conf["work_dir"], "best_model.pth"))
+    assert "separator.DPT.row_transformer.0.transformer.lstm.weight_quantizers_dict.weight_hh_l0.min_range" in sd
+
+
+def test_speechbrain_env_trains_sepformer(tmp_path):
+    """cfg 4: `train(yml, local_rank, distributed_launch, device)` of the speechbrain env on the reference's YAML dialect
+    (!ref / !new: tags), one sample per GPU"""
+    from fqss_amd.train_env.speechbrain_librimix import speechbrain_librimix_trainer as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "configs", "sepformer_2spks_8k_synthetic.yaml")).read()
+    text = text.replace("work_dir: /tmp/fqss_sepformer_synth", f"work_dir: {tmp_path / 'run'}")
+    text = text.replace("training_signal_len: 32000", "training_signal_len: 4000").replace("steps_per_epoch: 60", "steps_per_epoch: 3")
+    text = text.replace("val_steps: 4", "val_steps: 1")
+    yml = tmp_path / "cfg.yaml"
+    yml.write_text(text)
+    hp = T.load_hparams(str(yml))
+    assert hp["num_spks"] == 2 and hp["save_folder"].endswith("run/save") and hp["lr_scheduler"]["patience"] == 3
+    hist = T.train(str(yml), 0, False, "cuda")
+    assert len(hist) == 2 and all(torch.isfinite(torch.tensor(h["train_loss"])) for h in hist)
+    sd = torch.load(os.path.join(str(tmp_path / "run"), "save", "best_model.pth"))
+    assert "decoder.residual_error_block.weight_fake_quantize_dec.min_range" in sd and "masker.layers.0.intra_transformer_block.pos.pe" in sd
+    with pytest.raises(NotImplementedError):
+        bad = tmp_path / "bad.yaml"
+        bad.write_text(text.replace("batch_size: 1\n", "batch_size: 2\n", 1))
+        T.train(str(bad), 0, False, "cuda")
