@@ -11,6 +11,8 @@
 // fetched by wave-wide broadcast reads (conflict-free).  The backward kernel holds the same matrix column-wise
 // (thread (k, gate block) keeps W_hh[block*H .. +H][k]) for dh_{t-1} = dgates_t W_hh.
 // A generic variant (template H = 0) streams W_hh from L2 instead; it serves odd sizes (tests) only.
+// Measured dead end: pairing the two sequences in v_pk_fma_f32 (h interleaved by sequence in LDS, weight splat) -- 433 -> 1141 us
+// forward: the splat pairs double the live registers of the 128-entry weight row and the loop stops being FMA-issue bound.
 //
 // Saved for the backward: the four gate activations and the cell state per step (5H floats per step and sequence-direction).
 #include "fqss_dev.h"
