@@ -188,7 +188,7 @@ def gen_tiny_step(out, n_steps=53):
 
     for step in range(1, n_steps + 1):
         acts, hooks = {}, []
-        if step in (1, 51):
+        if step == 51:      # per-layer inputs / outputs of the first fully quantizing step (teacher-forced G1 inside the network)
             for n, m in model.named_modules():
                 if isinstance(m, RL.LayerQ):
                     hooks.append(m.register_forward_hook(
