@@ -15,6 +15,8 @@
 // Reference replaced: F.conv1d(k=1) in Conv1dQ/Conv1dNlQ (qat_layers.py:137-146, 202-212) and its
 // autograd (convolution_backward), F.conv1d/F.conv_transpose1d weight gradients of the
 // encoder/decoder (qat_layers.py:1028-1039, 1330-1341, 1189-1202).
+#include <stdlib.h>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -359,6 +361,36 @@ extern "C" int fqss_frames_wgrad(const float* a, const float* x, float* gw, int 
     return FQSS_OK;
 }
 
+// split-bf16 variant (csrc/gemm_x3.hip): same problem description, 2-3x the fp32-MFMA throughput; `used` = false when its
+// 16-B vector loads do not apply (the caller then runs k_gemm_f32).  FQSS_ROWGEMM_X3=0 in the environment forces the fallback.
+namespace fqss {
+struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* bias_col;
+    int M, N, K;
+    int64_t sAi, sAk;
+    int64_t sBk, sBj;
+    int64_t sCi;
+    int ksplit, kchunk;
+};
+int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used);
+}  // namespace fqss
+
+static bool x3_enabled() {
+    static const bool on = [] { const char* e = getenv("FQSS_ROWGEMM_X3"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used) {
+    *used = false;
+    if (!x3_enabled()) return FQSS_OK;
+    GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk};
+    return launch_gemm_x3(h, a_kc, b_kc, atomic, s, what, used);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Row-major ("channels-last") linears of the dual-path models: x[R][Ci] (row stride ld_x) -> z[R][Co].
 // Reference replaced: F.linear in LinearQ / MultiheadAttentionQ / LSTMQ's input projection (qat_layers.py:521-536,
@@ -378,6 +410,9 @@ extern "C" int fqss_rowlin_fwd(const float* x, const float* w, const float* bias
     g.sBb = 0; g.sBk = 1; g.sBj = ld_w;
     g.sCb = 0; g.sCi = ld_z;
     g.ksplit = 1; g.kchunk = Ci;
+    bool used = false;
+    int rc = try_x3(g, true, true, false, (hipStream_t)stream, "fqss_rowlin_fwd", &used);
+    if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, true, true, false, 1, (hipStream_t)stream, "fqss_rowlin_fwd");
 }
 
@@ -392,6 +427,9 @@ extern "C" int fqss_rowlin_bwd_x(const float* gz, const float* w, float* gx, int
     g.sBb = 0; g.sBk = ld_w; g.sBj = 1;
     g.sCb = 0; g.sCi = ld_gx;
     g.ksplit = 1; g.kchunk = Co;
+    bool used = false;
+    int rc = try_x3(g, true, false, false, (hipStream_t)stream, "fqss_rowlin_bwd_x", &used);
+    if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, true, false, false, 1, (hipStream_t)stream, "fqss_rowlin_bwd_x");
 }
 
@@ -412,5 +450,8 @@ extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int
     if (kchunk < 64) kchunk = 64;
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(R, kchunk);
+    bool used = false;
+    int rc = try_x3(g, false, false, true, (hipStream_t)stream, "fqss_rowlin_bwd_w", &used);
+    if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, false, false, true, 1, (hipStream_t)stream, "fqss_rowlin_bwd_w");
 }
