@@ -62,30 +62,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     const float* Bb = g.B + (int64_t)b * g.sBb;
 
     float ra[4 * MI], rb[4 * NI];
+    int kl = 0;     // k0 of the tile held in ra / rb
 
     auto load_tiles = [&](int k0) {
+        kl = k0;
         // ---------------- A tile: BMt (i) x 16 (k)
         if constexpr (VEC) {
 #pragma unroll
             for (int p = 0; p < MI; ++p) {
                 const int f = tid + 256 * p;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                // unconditional loads from clamped addresses (validity is applied in store_tiles): a branch around a global
+                // load makes the compiler drain the loads before the MFMA section instead of after it
+                float4 v;
                 if constexpr (A_KC) {
                     const int i = f >> 2, k = (f & 3) * 4;
-                    if (i0 + i < g.M && k0 + k < kend) {
-                        v = *reinterpret_cast<const float4*>(Ab + (int64_t)(i0 + i) * g.sAi + (k0 + k));
-                        if (k0 + k + 1 >= kend) v.y = 0.f;
-                        if (k0 + k + 2 >= kend) v.z = 0.f;
-                        if (k0 + k + 3 >= kend) v.w = 0.f;
-                    }
+                    v = *reinterpret_cast<const float4*>(Ab + (int64_t)min(i0 + i, g.M - 1) * g.sAi + min(k0 + k, ((g.K + 3) & ~3) - 4));
                 } else {
                     const int k = f / (16 * MI), i = (f % (16 * MI)) * 4;
-                    if (k0 + k < kend && i0 + i < g.M) {
-                        v = *reinterpret_cast<const float4*>(Ab + (int64_t)(k0 + k) * g.sAk + (i0 + i));
-                        if (i0 + i + 1 >= g.M) v.y = 0.f;
-                        if (i0 + i + 2 >= g.M) v.z = 0.f;
-                        if (i0 + i + 3 >= g.M) v.w = 0.f;
-                    }
+                    v = *reinterpret_cast<const float4*>(Ab + (int64_t)min(k0 + k, g.K - 1) * g.sAk + min(i0 + i, ((g.M + 3) & ~3) - 4));
                 }
                 ra[4 * p + 0] = v.x; ra[4 * p + 1] = v.y; ra[4 * p + 2] = v.z; ra[4 * p + 3] = v.w;
             }
@@ -105,23 +99,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < NI; ++p) {
                 const int f = tid + 256 * p;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v;
                 if constexpr (B_KC) {
                     const int j = f >> 2, k = (f & 3) * 4;
-                    if (j0 + j < g.N && k0 + k < kend) {
-                        v = *reinterpret_cast<const float4*>(Bb + (int64_t)(j0 + j) * g.sBj + (k0 + k));
-                        if (k0 + k + 1 >= kend) v.y = 0.f;
-                        if (k0 + k + 2 >= kend) v.z = 0.f;
-                        if (k0 + k + 3 >= kend) v.w = 0.f;
-                    }
+                    v = *reinterpret_cast<const float4*>(Bb + (int64_t)min(j0 + j, g.N - 1) * g.sBj + min(k0 + k, ((g.K + 3) & ~3) - 4));
                 } else {
                     const int k = f / (16 * NI), j = (f % (16 * NI)) * 4;
-                    if (k0 + k < kend && j0 + j < g.N) {
-                        v = *reinterpret_cast<const float4*>(Bb + (int64_t)(k0 + k) * g.sBk + (j0 + j));
-                        if (j0 + j + 1 >= g.N) v.y = 0.f;
-                        if (j0 + j + 2 >= g.N) v.z = 0.f;
-                        if (j0 + j + 3 >= g.N) v.w = 0.f;
-                    }
+                    v = *reinterpret_cast<const float4*>(Bb + (int64_t)min(k0 + k, g.K - 1) * g.sBk + min(j0 + j, ((g.N + 3) & ~3) - 4));
                 }
                 rb[4 * p + 0] = v.x; rb[4 * p + 1] = v.y; rb[4 * p + 2] = v.z; rb[4 * p + 3] = v.w;
             }
@@ -145,11 +129,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                 const int f = tid + 256 * p;
                 if constexpr (A_KC) {
                     const int i = f >> 2, k = (f & 3) * 4;
+                    const bool iv = i0 + i < g.M;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) As[k + e][i] = ra[4 * p + e];
+                    for (int e = 0; e < 4; ++e) As[k + e][i] = (iv && kl + k + e < kend) ? ra[4 * p + e] : 0.f;
                 } else {
                     const int k = f / (16 * MI), i = (f % (16 * MI)) * 4;
-                    *reinterpret_cast<float4*>(&As[k][i]) = make_float4(ra[4 * p], ra[4 * p + 1], ra[4 * p + 2], ra[4 * p + 3]);
+                    const bool kv = kl + k < kend;
+                    *reinterpret_cast<float4*>(&As[k][i]) = make_float4((kv && i0 + i < g.M) ? ra[4 * p] : 0.f, (kv && i0 + i + 1 < g.M) ? ra[4 * p + 1] : 0.f,
+                                                                         (kv && i0 + i + 2 < g.M) ? ra[4 * p + 2] : 0.f, (kv && i0 + i + 3 < g.M) ? ra[4 * p + 3] : 0.f);
                 }
             }
 #pragma unroll
@@ -157,11 +144,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                 const int f = tid + 256 * p;
                 if constexpr (B_KC) {
                     const int j = f >> 2, k = (f & 3) * 4;
+                    const bool jv = j0 + j < g.N;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Bs[k + e][j] = rb[4 * p + e];
+                    for (int e = 0; e < 4; ++e) Bs[k + e][j] = (jv && kl + k + e < kend) ? rb[4 * p + e] : 0.f;
                 } else {
                     const int k = f / (16 * NI), j = (f % (16 * NI)) * 4;
-                    *reinterpret_cast<float4*>(&Bs[k][j]) = make_float4(rb[4 * p], rb[4 * p + 1], rb[4 * p + 2], rb[4 * p + 3]);
+                    const bool kv = kl + k < kend;
+                    *reinterpret_cast<float4*>(&Bs[k][j]) = make_float4((kv && j0 + j < g.N) ? rb[4 * p] : 0.f, (kv && j0 + j + 1 < g.N) ? rb[4 * p + 1] : 0.f,
+                                                                         (kv && j0 + j + 2 < g.N) ? rb[4 * p + 2] : 0.f, (kv && j0 + j + 3 < g.N) ? rb[4 * p + 3] : 0.f);
                 }
             }
         } else {
@@ -198,7 +188,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     __syncthreads();
     const int lr = lane & 31, lk = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);  // global loads fly under the MFMAs
+        // global loads fly under the MFMAs; the vector path issues them unconditionally (the last iteration re-reads a clamped tile)
+        if (VEC || kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float av[MI], bv[NI];
