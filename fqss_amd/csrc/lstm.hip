@@ -52,20 +52,24 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
     const int cn = threadIdx.x / H, ck = threadIdx.x - cn * H;
     const bool cell = threadIdx.x < kNB * H && (b0 + cn) < B;
     __syncthreads();
+    // the input projection of step t+1 is fetched while step t computes -- unconditionally, from clamped indices (a branch around
+    // a global load makes the compiler wait for it on the spot; out-of-range rows / gate slots read valid memory and are unused)
     float pcur[kNB], pnext[kNB];
+    const int jc = jv ? j : 4 * H - 1;
     {
         const int t = dir == 0 ? 0 : S - 1;
 #pragma unroll
         for (int nb = 0; nb < kNB; ++nb)
-            pcur[nb] = (jv && b0 + nb < B) ? pre[(((int64_t)t * B + b0 + nb) * 2 + dir) * 4 * H + j] : 0.f;
+            pcur[nb] = pre[(((int64_t)t * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
     }
     for (int step = 0; step < S; ++step) {
         const int t = dir == 0 ? step : S - 1 - step;
-        if (step + 1 < S) {
-            const int tn = dir == 0 ? step + 1 : S - 2 - step;
+        {
+            const int sn = min(step + 1, S - 1);
+            const int tn = dir == 0 ? sn : S - 1 - sn;
 #pragma unroll
             for (int nb = 0; nb < kNB; ++nb)
-                pnext[nb] = (jv && b0 + nb < B) ? pre[(((int64_t)tn * B + b0 + nb) * 2 + dir) * 4 * H + j] : 0.f;
+                pnext[nb] = pre[(((int64_t)tn * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
         }
         if (jv) {
             float acc[kNB];
@@ -136,21 +140,31 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
     const int cn = tid / H, ck = tid - cn * H;
     const bool cell = tid < kNB * H && (b0 + cn) < B;
     float dc_rec = 0.f;
+    // saved gate activations, cell state and incoming gradient of a step are fetched one step ahead (unconditional loads from
+    // clamped indices, see k_lstm_fwd): without the prefetch every step began with an exposed global-memory round trip
+    const int cnc = min(b0 + (cell ? cn : 0), B - 1), ckc = cell ? ck : 0;
+    float n_dh, n_i, n_f, n_g, n_o, n_c, n_cp;
+    auto fetch = [&](int step) {
+        const int sc = max(step, 0);
+        const int t = dir == 0 ? sc : S - 1 - sc;
+        const int64_t sb = (int64_t)t * B + cnc;
+        n_dh = gout[sb * 2 * H + dir * H + ckc];
+        const float* gsv = gsav + (sb * 2 + dir) * 4 * H;
+        n_i = gsv[ckc]; n_f = gsv[H + ckc]; n_g = gsv[2 * H + ckc]; n_o = gsv[3 * H + ckc];
+        n_c = csav[(sb * 2 + dir) * H + ckc];
+        const int sp = max(sc - 1, 0);
+        const int tp = dir == 0 ? sp : S - 1 - sp;
+        n_cp = csav[((((int64_t)tp * B + cnc) * 2) + dir) * H + ckc];
+    };
+    fetch(S - 1);
     __syncthreads();
     for (int step = S - 1; step >= 0; --step) {
         const int t = dir == 0 ? step : S - 1 - step;
+        const float c_dh = n_dh, gi = n_i, gf = n_f, gg = n_g, go = n_o, cc = n_c, cprev = step > 0 ? n_cp : 0.f;
         if (cell) {
             const int64_t sb = (int64_t)t * B + b0 + cn;
-            const float dh = gout[sb * 2 * H + dir * H + ck] +
+            const float dh = c_dh +
                              ((ps[(0 * kNB + cn) * H + ck] + ps[(1 * kNB + cn) * H + ck]) + (ps[(2 * kNB + cn) * H + ck] + ps[(3 * kNB + cn) * H + ck]));
-            const float* gsv = gsav + (sb * 2 + dir) * 4 * H;
-            const float gi = gsv[ck], gf = gsv[H + ck], gg = gsv[2 * H + ck], go = gsv[3 * H + ck];
-            const float cc = csav[(sb * 2 + dir) * H + ck];
-            float cprev = 0.f;
-            if (step > 0) {
-                const int tp = dir == 0 ? step - 1 : S - step;
-                cprev = csav[((((int64_t)tp * B + b0 + cn) * 2) + dir) * H + ck];
-            }
             const float tc = tanhf(cc);
             const float dc = dc_rec + (dh * go) * (1.0f - tc * tc);
             const float d_o = ((dh * tc) * (1.0f - go)) * go;
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
             float* o = dG + (sb * 2 + dir) * 4 * H;
             o[ck] = d_i; o[H + ck] = d_f; o[2 * H + ck] = d_g; o[3 * H + ck] = d_o;
         }
+        fetch(step - 1);
         __syncthreads();
         if (tv) {
             float acc[kNB];
