@@ -116,22 +116,32 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// out[c] += sum_r g[r][c]: thread <-> column (coalesced rows), a workgroup sums a slab of rows, one atomic per column
+// out[c] += sum_r g[r][c].  The 256 threads of a workgroup form RG = 256 / CW row groups of CW columns each (CW = the column
+// count rounded up to a power of two, at most 256): every lane is busy also for the 64-wide tensors of the dual-path blocks, a
+// row group streams whole rows (coalesced), the RG partial sums of a column meet in LDS, one atomic per column and workgroup.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, float* __restrict__ out, int64_t R, int C,
-                                                 int64_t ld, int64_t rows_per_block) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+                                                 int64_t ld, int64_t rows_per_block, int CW) {
+    __shared__ float red[256];
+    const int RG = 256 / CW;
+    const int cl = threadIdx.x % CW, rg = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int64_t r = r0;
-    for (; r + 3 < r1; r += 4) {
-        s0 += g[r * ld + c];
-        s1 += g[(r + 1) * ld + c];
-        s2 += g[(r + 2) * ld + c];
-        s3 += g[(r + 3) * ld + c];
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int64_t r = r0 + rg;
+        for (; r + RG < r1; r += 2 * RG) {
+            s0 += g[r * ld + c];
+            s1 += g[(r + RG) * ld + c];
+        }
+        if (r < r1) s0 += g[r * ld + c];
     }
-    for (; r < r1; ++r) s0 += g[r * ld + c];
-    atomicAdd(out + c, (s0 + s1) + (s2 + s3));
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float s = red[cl];
+        for (int k = 1; k < RG; ++k) s += red[k * CW + cl];
+        atomicAdd(out + c, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ unary maps
@@ -488,12 +498,14 @@ extern "C" int fqss_layernorm_bwd(const float* gy, const float* x, const float* 
 extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream) {
     FQSS_REQUIRE(g && out && R >= 0 && C > 0 && ld >= C, "bad args");
     if (R == 0) return FQSS_OK;
-    const int64_t gx = cdiv(C, 256);
+    int CW = 256;
+    while (CW / 2 >= C && CW > 8) CW /= 2;
+    const int64_t gx = cdiv(C, CW);
     int64_t gy = cdiv(1024, gx);
     int64_t rpb = cdiv(R, gy);
-    if (rpb < 32) rpb = 32;
+    if (rpb < 64) rpb = 64;
     gy = cdiv(R, rpb);
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, g, out, R, C, ld, rpb);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, g, out, R, C, ld, rpb, CW);
     return launch_status("fqss_colsum");
 }
 

@@ -21,7 +21,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
@@ -29,6 +29,7 @@ class QCtx:
         self.carrier = False    # True: the fp32 output of this call is an uninitialised carrier (codes-only fast path)
         self.keep_out = False   # force a real fp32 output even in the fast path (model outputs)
         self.prod = None        # _Producer: lets the NEXT layer's backward run this layer's epilogue backward (see below)
+        self.no_codes = False   # the caller has no coded consumer (dual-path row layers): do not emit the u8 codes at all
 
 
 class ActCodes:
@@ -175,6 +176,9 @@ def _grad_buf(param, like):
 
 
 def _epilogue_fwd(z, act, slope, q):
+    if q.qmode == Q_QUANT and q.no_codes:
+        q.carrier = False
+        return K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws)
     if q.qmode == Q_QUANT:
         q.carrier = FAST and not q.keep_out
         out, q.idx = K.actq_fwd(z, act, slope, q.qmode, q.qmin, q.qmax, q.obs_ws, want_idx=True, write_out=not q.carrier)

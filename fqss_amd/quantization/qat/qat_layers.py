@@ -481,6 +481,7 @@ def fq_node(aq, x, nl=None):
         return x
     x = ops.real(x)
     flat = _flat2d(x)
+    q.no_codes = True         # nobody downstream of these row layers reads u8 codes: skip the 1 B/element side output
     y = ops.NlActQ.apply(x if flat is None else flat, slope, q.qmin, q.qmax, act, q, slope)
     if aq is not None:
         aq.after_forward(q)
