@@ -14,6 +14,8 @@
 // The reference also runs `activation_fake_quantize_attn(attn)` / `_softmax(attn)` and DISCARDS their results (`attn - fq(attn)`,
 // :907, :909): only their observers see data during the first 50 calls.  obs_attn / obs_soft (optional) receive the running
 // min / max of the logits and of the probabilities for exactly that purpose.
+#include <stdlib.h>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -153,6 +155,134 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Matrix-core backward for the production shapes (head_dim 16 / 32, L <= 256): fp32 MFMA 32x32x2 (exact fp32 products and sums).
+// The VALU kernel above spends its time on LDS broadcast reads (every (i, j) pair fetches a K / V row for all 64 lanes); here a
+// 32 x 32 tile of logits costs head_dim/2 MFMAs.  Two owner-computes loops like above, and NO transposes through LDS: the MFMA
+// result layout (lane = column, 16 rows in registers) of
+//    S  = Q_it K_jt^T  is exactly the A-operand layout of  dS^T, P^T  for  dK_jt += dS^T Q_it,  dV_jt += P^T dO_it   (loop B),
+//    S^T = K_jt Q_it^T is exactly the A-operand layout of  dS        for  dQ_it += dS K_jt                          (loop A),
+// because the k index of an MFMA step may be any bijection as long as both operands use the same one (here: the row map of the
+// result registers).  Rows of the LDS images are padded to head_dim + 1 floats (A-operand reads walk down a column).
+typedef float f32x16a __attribute__((ext_vector_type(16)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_bwd_mfma(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const float* __restrict__ o,
+                                                        const float* __restrict__ go, const float* __restrict__ stats,
+                                                        float* __restrict__ gq, float* __restrict__ gk, float* __restrict__ gv, int L,
+                                                        int B, int nh, int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o,
+                                                        int64_t ld_go, int64_t ld_gq, int64_t ld_gk, int64_t ld_gv) {
+    constexpr int RS = HD + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NT = (L + 31) / 32, Lp = NT * 32;
+    float* Qs = smem;
+    float* Ks = Qs + (size_t)Lp * RS;
+    float* Vs = Ks + (size_t)Lp * RS;
+    float* Gs = Vs + (size_t)Lp * RS;
+    float* Ms = Gs + (size_t)Lp * RS;    // row max
+    float* Is = Ms + Lp;                 // 1 / row sum (0 for padded rows)
+    float* Ds = Is + Lp;                 // D_i = sum_d dO_i[d] O_i[d]
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    for (int e = threadIdx.x; e < Lp * HD; e += 256) {
+        const int j = e / HD, d = e % HD;
+        const int64_t row = (int64_t)min(j, L - 1) * B + b;
+        const bool ok = j < L;
+        const float qv = q[row * ld_q + h * HD + d], kv = k[row * ld_k + h * HD + d], vv = v[row * ld_v + h * HD + d],
+                    gvv = go[row * ld_go + h * HD + d];
+        Qs[j * RS + d] = ok ? qv : 0.f;
+        Ks[j * RS + d] = ok ? kv : 0.f;
+        Vs[j * RS + d] = ok ? vv : 0.f;
+        Gs[j * RS + d] = ok ? gvv : 0.f;
+    }
+    for (int i = threadIdx.x; i < Lp; i += 256) {
+        const int ic = min(i, L - 1);
+        const int64_t row = (int64_t)ic * B + b;
+        float dsum = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dsum = fmaf(go[row * ld_go + h * HD + d], o[row * ld_o + h * HD + d], dsum);
+        const float m = stats[((int64_t)blockIdx.x * L + ic) * 2], l = stats[((int64_t)blockIdx.x * L + ic) * 2 + 1];
+        Ms[i] = i < L ? m : 0.f;
+        Is[i] = i < L ? 1.0f / l : 0.f;
+        Ds[i] = i < L ? dsum : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, lk = lane >> 5;
+    const int cd = c < HD ? c : HD - 1;          // column of a B operand over head_dim (lanes >= HD compute unused columns)
+
+    // ---- loop A: the wave owns query tile `it`: dQ_it = sum_jt dS K_jt, via the transposed logits tile T = K_jt Q_it^T
+    for (int it = wave; it < NT; it += 4) {
+        const float m_c = Ms[it * 32 + c], il_c = Is[it * 32 + c], D_c = Ds[it * 32 + c];
+        f32x16a dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x16a T, dPt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { T[r] = 0.f; dPt[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) {
+                const float qa = Qs[(it * 32 + c) * RS + 2 * s + lk], ka = Ks[(jt * 32 + c) * RS + 2 * s + lk];
+                const float ga = Gs[(it * 32 + c) * RS + 2 * s + lk], va = Vs[(jt * 32 + c) * RS + 2 * s + lk];
+                T = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qa, T, 0, 0, 0);        // rows j, cols i
+                dPt = __builtin_amdgcn_mfma_f32_32x32x2f32(va, ga, dPt, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float p = j < L ? expf(T[r] - m_c) * il_c : 0.f;
+                const float dS = p * (dPt[r] - D_c);
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(dS, Ks[j * RS + cd], dq, 0, 0, 0);   // k index = j (this lane's row map)
+            }
+        }
+        if (c < HD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (i < L) gq[((int64_t)i * B + b) * ld_gq + h * HD + c] = dq[r];
+            }
+        }
+    }
+    // ---- loop B: the wave owns key tile `jt`: dK_jt = sum_it dS^T Q_it, dV_jt = sum_it P^T dO_it, via S = Q_it K_jt^T
+    for (int jt = wave; jt < NT; jt += 4) {
+        const bool jv = jt * 32 + c < L;
+        f32x16a dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+        for (int it = 0; it < NT; ++it) {
+            f32x16a S, dP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) {
+                const float qa = Qs[(it * 32 + c) * RS + 2 * s + lk], ka = Ks[(jt * 32 + c) * RS + 2 * s + lk];
+                const float ga = Gs[(it * 32 + c) * RS + 2 * s + lk], va = Vs[(jt * 32 + c) * RS + 2 * s + lk];
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, ka, S, 0, 0, 0);         // rows i, cols j
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, va, dP, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float p = jv ? expf(S[r] - Ms[i]) * Is[i] : 0.f;                 // Is = 0 for padded query rows
+                const float dS = p * (dP[r] - Ds[i]);
+                dk = __builtin_amdgcn_mfma_f32_32x32x2f32(dS, Qs[i * RS + cd], dk, 0, 0, 0);   // k index = i
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(p, Gs[i * RS + cd], dv, 0, 0, 0);
+            }
+        }
+        if (c < HD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (j < L) {
+                    gk[((int64_t)j * B + b) * ld_gk + h * HD + c] = dk[r];
+                    gv[((int64_t)j * B + b) * ld_gv + h * HD + c] = dv[r];
+                }
+            }
+        }
+    }
+}
+
 template <typename KernelT>
 static int ensure_lds(KernelT kern, size_t bytes, const char* what) {
     if (bytes > 160 * 1024) {
@@ -211,9 +341,26 @@ extern "C" int fqss_attn_bwd(const float* q, const float* k, const float* v, con
     const int E = nh * hd;
     FQSS_REQUIRE(ld_q >= E && ld_k >= E && ld_v >= E && ld_o >= E && ld_go >= E && ld_gq >= E && ld_gk >= E && ld_gv >= E,
                  "row stride below embed dim");
-    const size_t lds = ((size_t)4 * L * hd + 3 * (size_t)L) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)(B * nh)), block(256);
+    static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    if (use_mfma && (hd == 16 || hd == 32) && L <= 256) {
+        const int Lp = (L + 31) / 32 * 32;
+        const size_t ldsm = ((size_t)4 * Lp * (hd + 1) + 3 * (size_t)Lp) * sizeof(float);
+        if (hd == 16) {
+            int rc = ensure_lds(k_attn_bwd_mfma<16>, ldsm, "fqss_attn_bwd");
+            if (rc != FQSS_OK) return rc;
+            hipLaunchKernelGGL((k_attn_bwd_mfma<16>), grid, block, ldsm, s, q, k, v, o, go, stats, gq, gk, gv, L, B, nh, ld_q, ld_k, ld_v, ld_o,
+                               ld_go, ld_gq, ld_gk, ld_gv);
+        } else {
+            int rc = ensure_lds(k_attn_bwd_mfma<32>, ldsm, "fqss_attn_bwd");
+            if (rc != FQSS_OK) return rc;
+            hipLaunchKernelGGL((k_attn_bwd_mfma<32>), grid, block, ldsm, s, q, k, v, o, go, stats, gq, gk, gv, L, B, nh, ld_q, ld_k, ld_v, ld_o,
+                               ld_go, ld_gq, ld_gk, ld_gv);
+        }
+        return launch_status("fqss_attn_bwd");
+    }
+    const size_t lds = ((size_t)4 * L * hd + 3 * (size_t)L) * sizeof(float);
 #define FQSS_AB(HD_)                                                                                                        \
     {                                                                                                                       \
         int rc = ensure_lds(k_attn_bwd<HD_>, lds, "fqss_attn_bwd");                                                          \

@@ -136,7 +136,8 @@ def test_unary_and_data_movement_kernels(golden):
     close(sd.grad, sr.grad, 1e-7)
 
 
-@pytest.mark.parametrize("L,B,nh,hd", [(9, 5, 4, 4), (250, 6, 4, 16), (194, 3, 4, 16), (37, 4, 4, 2), (300, 2, 8, 32)])
+@pytest.mark.parametrize("L,B,nh,hd", [(9, 5, 4, 4), (250, 6, 4, 16), (194, 3, 4, 16), (37, 4, 4, 2), (300, 2, 8, 32), (250, 3, 8, 32), (34, 5, 8, 32),
+                                       (256, 2, 4, 16), (33, 2, 4, 16)])
 def test_attention_kernels(L, B, nh, hd):
     from fqss_amd import kernels as K
     E = nh * hd

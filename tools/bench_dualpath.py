@@ -3,7 +3,7 @@
 network on one MI355X.  Not the round's bench line (bench.py stays on cfg 2, the configuration BASELINE.json quotes the metric on)
 -- a probe for DESIGN.md and for `rocprofv3 --kernel-trace --stats -- python3 tools/bench_dualpath.py`.
 
-  python tools/bench_dualpath.py [--model dptnet|sepformer] [--B 1] [--T 24000|32000] [--steps 10] [--graph]
+  python tools/bench_dualpath.py [--model dptnet|sepformer] [--B 1] [--T 24000|32000] [--steps 10] [--no-graph] [--cpu-baseline]
 """
 import argparse
 import copy
@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--T", type=int, default=0, help="samples per mixture (default: 24000 = 3 s for DPTNet, 32000 = 4 s for Sepformer)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (Sepformer is host-launch-bound then)")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time ONE step of the oracle (CPU port of the reference path) on the host cores")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -54,7 +54,7 @@ def main():
             m.n_iter = m.max_observations
     for _ in range(a.warmup):
         r = step(x, tgt)
-    if a.graph:
+    if not a.no_graph:
         step.capture(x, tgt, warmup=1)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -117,7 +117,7 @@ def main():
                          f"segment length, torch CPU fp32"}
     print(json.dumps({"roofline": roofline, "cpu_baseline": cpu, "workload": f"{'DPTNet' if a.model == 'dptnet' else 'Sepformer'} 2spk 8 kHz W8A8 QAT step, B={a.B}, T={a.T}", "ms_per_step": round(ms, 3),
                       "samples_per_s": round(a.B / ms * 1e3, 2), "observer_phase_ms_per_step": round(obs_ms, 1),
-                      "launch": "hipGraph replay" if a.graph else "eager", "loss_db": round(float(r["loss"]), 4),
+                      "launch": "eager" if a.no_graph else "hipGraph replay", "loss_db": round(float(r["loss"]), 4),
                       "params": sum(p.numel() for p in model.parameters())}))
 
 
