@@ -20,6 +20,8 @@
 
 namespace fqss {
 
+typedef float f32x16a __attribute__((ext_vector_type(16)));
+
 template <int HD>
 __device__ __forceinline__ float dot_row(const float (&q)[HD], const float* __restrict__ k) {
     float s = 0.f;
@@ -155,6 +157,35 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
     }
 }
 
+// head h of a row matrix -> LDS image [Lp][HD + 1], rows >= L zero: 16-B loads when the rows allow it, several in flight per
+// thread (unconditional, clamped row; a loop that loads, waits and stores one scalar per iteration spent more time filling LDS
+// than the matrix cores spent on the tile products)
+template <int HD>
+__device__ __forceinline__ void fill_head(const float* __restrict__ src, int64_t ld, float* __restrict__ dst, int L, int Lp, int B, int b,
+                                          int h) {
+    constexpr int RS = HD + 1, V4 = HD / 4;
+    const bool vec = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    if (vec) {
+#pragma unroll 4
+        for (int f = threadIdx.x; f < Lp * V4; f += 256) {
+            const int j = f / V4, d = (f % V4) * 4;
+            const float4 t = *reinterpret_cast<const float4*>(src + ((int64_t)min(j, L - 1) * B + b) * ld + h * HD + d);
+            const bool ok = j < L;
+            dst[j * RS + d] = ok ? t.x : 0.f;
+            dst[j * RS + d + 1] = ok ? t.y : 0.f;
+            dst[j * RS + d + 2] = ok ? t.z : 0.f;
+            dst[j * RS + d + 3] = ok ? t.w : 0.f;
+        }
+    } else {
+#pragma unroll 4
+        for (int e = threadIdx.x; e < Lp * HD; e += 256) {
+            const int j = e / HD, d = e % HD;
+            const float t = src[((int64_t)min(j, L - 1) * B + b) * ld + h * HD + d];
+            dst[j * RS + d] = j < L ? t : 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Matrix-core backward for the production shapes (head_dim 16 / 32, L <= 256): fp32 MFMA 32x32x2 (exact fp32 products and sums).
 // The VALU kernel above spends its time on LDS broadcast reads (every (i, j) pair fetches a K / V row for all 64 lanes); here a
@@ -164,8 +195,6 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const float* __restrict__ q, c
 //    S^T = K_jt Q_it^T is exactly the A-operand layout of  dS        for  dQ_it += dS K_jt                          (loop A),
 // because the k index of an MFMA step may be any bijection as long as both operands use the same one (here: the row map of the
 // result registers).  Rows of the LDS images are padded to head_dim + 1 floats (A-operand reads walk down a column).
-typedef float f32x16a __attribute__((ext_vector_type(16)));
-
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const float* __restrict__ o,
@@ -184,17 +213,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const float* __restrict__
     float* Is = Ms + Lp;                 // 1 / row sum (0 for padded rows)
     float* Ds = Is + Lp;                 // D_i = sum_d dO_i[d] O_i[d]
     const int b = blockIdx.x / nh, h = blockIdx.x % nh;
-    for (int e = threadIdx.x; e < Lp * HD; e += 256) {
-        const int j = e / HD, d = e % HD;
-        const int64_t row = (int64_t)min(j, L - 1) * B + b;
-        const bool ok = j < L;
-        const float qv = q[row * ld_q + h * HD + d], kv = k[row * ld_k + h * HD + d], vv = v[row * ld_v + h * HD + d],
-                    gvv = go[row * ld_go + h * HD + d];
-        Qs[j * RS + d] = ok ? qv : 0.f;
-        Ks[j * RS + d] = ok ? kv : 0.f;
-        Vs[j * RS + d] = ok ? vv : 0.f;
-        Gs[j * RS + d] = ok ? gvv : 0.f;
-    }
+    fill_head<HD>(q, ld_q, Qs, L, Lp, B, b, h);
+    fill_head<HD>(k, ld_k, Ks, L, Lp, B, b, h);
+    fill_head<HD>(v, ld_v, Vs, L, Lp, B, b, h);
+    fill_head<HD>(go, ld_go, Gs, L, Lp, B, b, h);
     for (int i = threadIdx.x; i < Lp; i += 256) {
         const int ic = min(i, L - 1);
         const int64_t row = (int64_t)ic * B + b;
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const float* __restrict__
     const int cd = c < HD ? c : HD - 1;          // column of a B operand over head_dim (lanes >= HD compute unused columns)
 
     // ---- loop A: the wave owns query tile `it`: dQ_it = sum_jt dS K_jt, via the transposed logits tile T = K_jt Q_it^T
-    for (int it = wave; it < NT; it += 4) {
+    for (int it = blockIdx.y * 4 + wave; it < NT; it += 4 * gridDim.y) {
         const float m_c = Ms[it * 32 + c], il_c = Is[it * 32 + c], D_c = Ds[it * 32 + c];
         f32x16a dq;
 #pragma unroll
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const float* __restrict__
         }
     }
     // ---- loop B: the wave owns key tile `jt`: dK_jt = sum_it dS^T Q_it, dV_jt = sum_it P^T dO_it, via S = Q_it K_jt^T
-    for (int jt = wave; jt < NT; jt += 4) {
+    for (int jt = blockIdx.y * 4 + wave; jt < NT; jt += 4 * gridDim.y) {
         const bool jv = jt * 32 + c < L;
         f32x16a dk, dv;
 #pragma unroll
@@ -283,6 +305,94 @@ __global__ __launch_bounds__(256) void k_attn_bwd_mfma(const float* __restrict__
     }
 }
 
+// Matrix-core forward (head_dim 16 / 32, L <= 256).  A wave owns a 32-row query tile and works on TRANSPOSED logits tiles
+// T = K_jt Q_it^T (lane = query row i, 16 keys in registers), so the row max / row sum are in-lane reductions plus one exchange
+// between the two lane halves, and exp(T - m) is already the A operand of O_it += P V_jt.  Two passes over the keys (max, then
+// exp / sum / PV), like the VALU kernel: same arithmetic, same saved statistics.
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_fwd_mfma(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, float* __restrict__ o, float* __restrict__ stats,
+                                                        int L, int B, int nh, int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o,
+                                                        uint32_t* obs_attn, uint32_t* obs_soft) {
+    constexpr int RS = HD + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NT = (L + 31) / 32, Lp = NT * 32;
+    float* Qs = smem;
+    float* Ks = Qs + (size_t)Lp * RS;
+    float* Vs = Ks + (size_t)Lp * RS;
+    const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+    fill_head<HD>(q, ld_q, Qs, L, Lp, B, b, h);
+    fill_head<HD>(k, ld_k, Ks, L, Lp, B, b, h);
+    fill_head<HD>(v, ld_v, Vs, L, Lp, B, b, h);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, lk = lane >> 5;
+    const int cd = c < HD ? c : HD - 1;
+    float smin_all = INFINITY, smax_all = -INFINITY, pmin_all = INFINITY, pmax_all = -INFINITY;
+    for (int it = blockIdx.y * 4 + wave; it < NT; it += 4 * gridDim.y) {
+        float m = -INFINITY, mn = INFINITY;
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x16a T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s)
+                T = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(jt * 32 + c) * RS + 2 * s + lk], Qs[(it * 32 + c) * RS + 2 * s + lk], T, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (j < L) { m = fmaxf(m, T[r]); mn = fminf(mn, T[r]); }
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        mn = fminf(mn, __shfl_xor(mn, 32, 64));
+        float l = 0.f;
+        f32x16a acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x16a T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s)
+                T = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(jt * 32 + c) * RS + 2 * s + lk], Qs[(it * 32 + c) * RS + 2 * s + lk], T, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float p = j < L ? expf(T[r] - m) : 0.f;
+                l += p;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p, Vs[j * RS + cd], acc, 0, 0, 0);   // rows i, cols d; k index = j
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        const int i_own = it * 32 + c;
+        if (lk == 0 && i_own < L) {
+            stats[((int64_t)blockIdx.x * L + i_own) * 2] = m;
+            stats[((int64_t)blockIdx.x * L + i_own) * 2 + 1] = l;
+        }
+        if (i_own < L) {
+            smin_all = fminf(smin_all, mn); smax_all = fmaxf(smax_all, m);
+            pmax_all = fmaxf(pmax_all, 1.0f / l); pmin_all = fminf(pmin_all, expf(mn - m) / l);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int il = (r & 3) + 8 * (r >> 2) + 4 * lk;             // row of this register inside the tile
+            const float lr_ = __shfl(l, il, 64);                         // its row sum lives in the lane that owns that row
+            const int i = it * 32 + il;
+            if (c < HD && i < L) o[((int64_t)i * B + b) * ld_o + h * HD + c] = acc[r] / lr_;
+        }
+    }
+    if (obs_attn != nullptr) {
+        smin_all = wave_min(smin_all); smax_all = wave_max(smax_all);
+        pmin_all = wave_min(pmin_all); pmax_all = wave_max(pmax_all);
+        if (lane == 0 && smin_all <= smax_all) {
+            atomicMin(obs_attn, f2ord(smin_all)); atomicMax(obs_attn + 1, f2ord(smax_all));
+            atomicMin(obs_soft, f2ord(pmin_all)); atomicMax(obs_soft + 1, f2ord(pmax_all));
+        }
+    }
+}
+
 template <typename KernelT>
 static int ensure_lds(KernelT kern, size_t bytes, const char* what) {
     if (bytes > 160 * 1024) {
@@ -310,9 +420,25 @@ extern "C" int fqss_attn_fwd(const float* q, const float* k, const float* v, flo
     FQSS_REQUIRE(L > 0 && B > 0 && nh > 0 && (int64_t)B * nh < (1ll << 31), "bad shape");
     FQSS_REQUIRE(ld_q >= nh * hd && ld_k >= nh * hd && ld_v >= nh * hd && ld_o >= nh * hd, "row stride below embed dim");
     FQSS_REQUIRE((obs_attn == nullptr) == (obs_soft == nullptr), "observer workspaces come in pairs");
-    const size_t lds = (size_t)2 * L * hd * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)(B * nh)), block(256);
+    static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    if (use_mfma && (hd == 16 || hd == 32) && L <= 256) {
+        const int Lp = (L + 31) / 32 * 32;
+        const size_t ldsm = (size_t)3 * Lp * (hd + 1) * sizeof(float);
+        grid.y = (unsigned)cdiv(Lp / 32, 4);      // one 32-row tile per wave: (b, h) pairs alone leave CUs idle or wrap around (272 on 256)
+        if (hd == 16) {
+            int rc = ensure_lds(k_attn_fwd_mfma<16>, ldsm, "fqss_attn_fwd");
+            if (rc != FQSS_OK) return rc;
+            hipLaunchKernelGGL((k_attn_fwd_mfma<16>), grid, block, ldsm, s, q, k, v, o, stats, L, B, nh, ld_q, ld_k, ld_v, ld_o, obs_attn, obs_soft);
+        } else {
+            int rc = ensure_lds(k_attn_fwd_mfma<32>, ldsm, "fqss_attn_fwd");
+            if (rc != FQSS_OK) return rc;
+            hipLaunchKernelGGL((k_attn_fwd_mfma<32>), grid, block, ldsm, s, q, k, v, o, stats, L, B, nh, ld_q, ld_k, ld_v, ld_o, obs_attn, obs_soft);
+        }
+        return launch_status("fqss_attn_fwd");
+    }
+    const size_t lds = (size_t)2 * L * hd * sizeof(float);
 #define FQSS_AF(HD_)                                                                                                        \
     {                                                                                                                       \
         int rc = ensure_lds(k_attn_fwd<HD_>, lds, "fqss_attn_fwd");                                                          \
@@ -347,6 +473,7 @@ extern "C" int fqss_attn_bwd(const float* q, const float* k, const float* v, con
     if (use_mfma && (hd == 16 || hd == 32) && L <= 256) {
         const int Lp = (L + 31) / 32 * 32;
         const size_t ldsm = ((size_t)4 * Lp * (hd + 1) + 3 * (size_t)Lp) * sizeof(float);
+        grid.y = (unsigned)cdiv(Lp / 32, 4);
         if (hd == 16) {
             int rc = ensure_lds(k_attn_bwd_mfma<16>, ldsm, "fqss_attn_bwd");
             if (rc != FQSS_OK) return rc;
