@@ -423,7 +423,9 @@ extern "C" int fqss_attn_fwd(const float* q, const float* k, const float* v, flo
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)(B * nh)), block(256);
     static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
-    if (use_mfma && (hd == 16 || hd == 32) && L <= 256) {
+    // head_dim 16 stays on the VALU kernel in the forward: half of every 32-wide P V tile would be padding (measured 133 vs 113 us
+    // at the DPTNet shapes); the backward wins on the matrix cores for both widths
+    if (use_mfma && hd == 32 && L <= 256) {
         const int Lp = (L + 31) / 32 * 32;
         const size_t ldsm = (size_t)3 * Lp * (hd + 1) * sizeof(float);
         grid.y = (unsigned)cdiv(Lp / 32, 4);      // one 32-row tile per wave: (b, h) pairs alone leave CUs idle or wrap around (272 on 256)

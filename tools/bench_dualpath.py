@@ -84,7 +84,7 @@ def main():
     torch.cuda.synchronize()
     us = g0.elapsed_time(g1) / 20 * 1e3
     tf = 2.0 * R * Ci * Co / us * 1e-6
-    roofline = {"kernel": "k_gemm_f32 (fqss_rowlin_fwd)", "what": what, "shape": [R, Ci, Co], "bound": "mfma", "launch_us": round(us, 1),
+    roofline = {"kernel": "k_gemm_x3 (fqss_rowlin_fwd)", "what": what, "shape": [R, Ci, Co], "bound": "mfma", "launch_us": round(us, 1),
                 "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
     cpu = None
     if a.cpu_baseline:
