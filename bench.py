@@ -10,6 +10,10 @@ phase is passed in an untimed calibration before the warm-up).  Inputs are resid
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed live) and `cpu_baseline` (oracle/ = CPU port of the reference path, rank 0, N=1).
+
+`--workload cfg3` / `--workload cfg4` time the other two built configurations of BASELINE.json the same way (DPTNet 2spk,
+1 x 3 s per GPU; Sepformer 2spk, 1 x 4 s per GPU: SURVEY.md §8 rows a13 / a14) -- same step, same JSON shape; the default
+(cfg 2) is the configuration the metric is quoted on and the only line the driver records.
 """
 import argparse
 import json
@@ -34,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4"),
+                    help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s")
     return ap.parse_args()
 
 
@@ -82,9 +88,131 @@ def cpu_baseline(threads):
             "sample": f"full ConvTasNetQ QAT step, quantizing phase, batch 2 x 4 s, {k} timed steps ({dt:.2f} s/step), torch CPU fp32"}
 
 
+DUALPATH = {"cfg3": dict(name="DPTNet", cfg={"name": "DPTNet", "n_src": 2, "kernel_size": 2}, T=24000, lr=4e-4,
+                         gemm=(64, 1024, "LSTM input projection (both directions)")),
+            "cfg4": dict(name="Sepformer", cfg={"name": "Sepformer", "n_src": 2, "kernel_size": 16, "stride": 8}, T=32000, lr=1.5e-4,
+                         gemm=(256, 1024, "feed-forward 256 -> 1024"))}
+
+
+def rowgemm_roofline(rows, Ci, Co, what):
+    """the row GEMM that carries most of the MFMA work of the dual-path models, at this workload's shape: HIP events on
+    torch's current stream (the stream the kernel is launched on); peak = fp32 MFMA (the arithmetic it is equivalent to)"""
+    from fqss_amd import kernels as K
+    x, w, b = torch.randn(rows, Ci, device="cuda"), torch.randn(Co, Ci, device="cuda"), torch.randn(Co, device="cuda")
+    for _ in range(3):
+        K.rowlin_fwd(x, w, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        K.rowlin_fwd(x, w, b)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    tf = 2.0 * rows * Ci * Co / us * 1e-6
+    return {"kernel": "k_gemm_x3 (fqss_rowlin_fwd)", "what": what, "shape": [rows, Ci, Co], "bound": "mfma", "launch_us": round(us, 1),
+            "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
+
+
+def cpu_baseline_dualpath(which, model, fmodel, lr, T):
+    """oracle/ on the host cores, bounded: ONE quantizing-phase step on a 0.5 s excerpt (the oracle's LSTM / attention are
+    Python-level torch loops: a full 3-4 s step takes minutes), scaled to the workload's segment length"""
+    import oracle.fqss_oracle as O
+    from fqss_amd.data import synth_batch
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    fsd = {k: v.detach().cpu() for k, v in fmodel.state_dict().items()}
+    if which == "cfg3":
+        import oracle.dptnet_oracle as D
+        s_o, t_o = D.StudentDPTNetQ(sd), D.TeacherDPTNet(fsd)
+    else:
+        import oracle.sepformer_oracle as S
+        s_o, t_o = S.StudentSepformerQ(sd), S.TeacherSepformer(fsd)
+    s_o.leave_observer_phase()
+    cores = min(16, len(os.sched_getaffinity(0)))      # the GPU box's CPU share; more threads oversubscribe the tiny ops
+    torch.set_num_threads(cores)
+    tr = O.Trainer(s_o, t_o, lr=lr)
+    tr.step(*synth_batch(1, 800, seed=1))               # warm-up
+    Tc = min(T, 4000)
+    x, tgt = synth_batch(1, Tc, seed=0)
+    t0 = time.perf_counter()
+    tr.step(x, tgt)
+    sec = time.perf_counter() - t0
+    return {"value": round((Tc / T) / sec, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"one full QAT step of the oracle on 1 x {Tc} samples ({sec:.1f} s), scaled by {Tc}/{T} to the workload's "
+                      f"segment length, torch CPU fp32"}
+
+
+def main_dualpath(a):
+    """cfg 3 / cfg 4: one sample per GPU (the shipped per-GPU batch), same step and timing protocol as cfg 2"""
+    import copy
+    from fqss_amd.data import synth_batch
+    from fqss_amd.kernels import dp_chunks
+    from fqss_amd.parallel import Comm
+    from fqss_amd.quantization.qat.models.load_model import create_model, quantize_model
+    from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
+    from fqss_amd.runtime import KDTrainStep
+    from fqss_amd.smoke import QCFG
+    W = DUALPATH[a.workload]
+    comm = Comm.from_env("cuda")
+    assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
+    ldev = comm.local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(ldev)
+    dev = torch.device("cuda", ldev)
+    torch.manual_seed(0)                                    # same init on every rank
+    model = create_model(dict(W["cfg"]))
+    fmodel = copy.deepcopy(model).to(dev).eval()
+    model = quantize_model(model, dict(QCFG)).to(dev).train()
+    T = W["T"]
+    x, tgt = synth_batch(1, T, seed=100 + comm.rank, device=dev)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=W["lr"], clip=5.0, comm=comm)
+    step(x, tgt)                                            # untimed calibration: the 50-call observer phase
+    with torch.no_grad():
+        for _ in range(49):
+            model(x)
+    assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
+    step(x, tgt)
+    launch = "eager"
+    if not a.no_graph:
+        step.capture(x, tgt)
+        launch = "hipGraph replay"
+    for _ in range(a.warmup):
+        step(x, tgt)
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step(x, tgt)
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    comm.all_reduce_max(dt)
+    dt = dt.item()
+    sisdr = r["sisdr"].mean().reshape(1).double()
+    comm.all_reduce_sum(sisdr)
+    if comm.rank == 0:
+        ms = dt / a.steps * 1e3
+        L = (T - 1) if a.workload == "cfg3" else (T - 16) // 8 + 1
+        rows = 250 * dp_chunks(L, 250)[1]
+        out = {"metric": f"QAT-step samples/sec + SI-SDR, {W['name']} 2spk 8kHz W8A8", "value": round(comm.world * a.steps / dt, 3),
+               "unit": "samples/s", "n_gpus": comm.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{W['name']} 2spk 8 kHz W8A8 QAT step ({a.workload}), batch 1 x {T // 8000} s per GPU, quantizing phase",
+                          "global_batch": comm.world, "segment_samples": T, "parallelism": f"dp{comm.world}", "kd_lambda": 0.1,
+                          "optimizer": f"adam lr {W['lr']:g} + clip 5.0", "launch": launch},
+               "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
+               "params": sum(p.numel() for p in model.parameters()),
+               "roofline": rowgemm_roofline(rows, *W["gemm"])}
+        if comm.world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_dualpath(a.workload, model, fmodel, W["lr"], T)
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+    comm.close()
+
+
 def main():
     a = parse()
     assert torch.cuda.is_available(), "bench.py needs ROCm GPUs"
+    if a.workload != "cfg2":
+        return main_dualpath(a)
     from fqss_amd.data import synth_batch
     from fqss_amd.parallel import Comm
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
