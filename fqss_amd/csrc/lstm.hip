@@ -6,9 +6,10 @@
 // MI355X mapping.  Sequences are independent, so a workgroup owns NB = 2 sequences of one direction for ALL S steps: no grid
 // synchronisation, the whole recurrence is one launch per layer (388 sequence-directions -> 194 workgroups on 256 CUs).
 // With H = 128 the recurrent matrix is 512 x 128 fp32 = 256 KB: too big for LDS (160 KB) but it fits the register file of
-// ONE workgroup -- 512 threads, thread j keeps row j of W_hh (128 VGPRs) for the whole kernel, so a step reads nothing from
-// memory but the pre-computed input projection (prefetched one step ahead).  h_{t-1} of the NB sequences lives in LDS and is
-// fetched by wave-wide broadcast reads (conflict-free).  The backward kernel holds the same matrix column-wise
+// ONE workgroup -- 512 threads x 128 VGPRs of weights for the whole kernel, so a step reads nothing from memory but the
+// pre-computed input projection (prefetched one step ahead).  In the forward a quad of lanes shares four gate rows and each lane
+// keeps one k-quarter of them: a lane reads a quarter of h_{t-1} per step from LDS (all of it per lane = 512 KB of LDS reads per
+// step was the whole step time: 430 -> 359 us), partial sums meet by quad-permute DPP adds.  The backward kernel holds the same matrix column-wise
 // (thread (k, gate block) keeps W_hh[block*H .. +H][k]) for dh_{t-1} = dgates_t W_hh.
 // A generic variant (template H = 0) streams W_hh from L2 instead; it serves odd sizes (tests) only.
 // Measured dead end: pairing the two sequences in v_pk_fma_f32 (h interleaved by sequence in LDS, weight splat) -- 433 -> 1141 us
@@ -35,19 +36,29 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
     const int H = HT > 0 ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hs = smem;                 // [kNB][H]
-    float* gs = smem + kNB * H;       // [kNB][4H]
+    float* gs = smem + kNB * (H + 16);       // [kNB][4H]   (hs: [kNB][4 quarters][H/4 + 4] when H is compile-time)
     const int dir = blockIdx.y;
     const int b0 = blockIdx.x * kNB;
     const int j = threadIdx.x;        // gate row (j < 4H)
     const bool jv = j < 4 * H;
     const float* W = whh + ((int64_t)dir * 4 * H + (jv ? j : 0)) * H;
+    // HT > 0: a QUAD of lanes shares four gate rows (4q .. 4q+3), lane kq of the quad keeps the k-quarter [32 kq, 32 kq + 32) of
+    // each of them: the same 128 weight registers as "one row per thread", but a lane now reads a quarter of h per step instead
+    // of all of it (every lane fetching all 2 x 128 values was 512 KB of LDS reads per step = the whole step time at 128 B/clk);
+    // the four partial sums of a row meet by two quad-permute DPP adds
+    constexpr int KQ = HT > 0 ? HT / 4 : 1;                 // k values per lane and row
+    constexpr int HQS = KQ + 4;                             // quarter stride in LDS (floats): the 4 quarters hit different banks
+    const int q4 = j >> 2, kq = j & 3;
     float wreg[HT > 0 ? HT : 1];
     if constexpr (HT > 0) {
+        const float* Wq = whh + ((int64_t)dir * 4 * H + q4 * 4) * H + kq * KQ;
 #pragma unroll
-        for (int k = 0; k < HT; ++k) wreg[k] = W[k];
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) wreg[r * KQ + k] = Wq[(int64_t)r * H + k];
     }
     const float bj = jv ? bhh[dir * 4 * H + j] : 0.f;
-    for (int e = threadIdx.x; e < kNB * H; e += blockDim.x) hs[e] = 0.f;
+    for (int e = threadIdx.x; e < kNB * (H + 16); e += blockDim.x) hs[e] = 0.f;
     float c = 0.f;                    // cell state of (nb, k) = (threadIdx / H, threadIdx % H) for threadIdx < kNB*H
     const int cn = threadIdx.x / H, ck = threadIdx.x - cn * H;
     const bool cell = threadIdx.x < kNB * H && (b0 + cn) < B;
@@ -76,16 +87,37 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
 #pragma unroll
             for (int nb = 0; nb < kNB; ++nb) acc[nb] = 0.f;
             if constexpr (HT > 0) {
+                float part[4][kNB];
 #pragma unroll
-                for (int k = 0; k < HT; k += 4) {
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < kNB; ++nb) part[r][nb] = 0.f;
+#pragma unroll
+                for (int k = 0; k < KQ; k += 4) {
 #pragma unroll
                     for (int nb = 0; nb < kNB; ++nb) {
-                        const float4 hv = *reinterpret_cast<const float4*>(hs + nb * HT + k);
-                        acc[nb] = fmaf(wreg[k], hv.x, acc[nb]);
-                        acc[nb] = fmaf(wreg[k + 1], hv.y, acc[nb]);
-                        acc[nb] = fmaf(wreg[k + 2], hv.z, acc[nb]);
-                        acc[nb] = fmaf(wreg[k + 3], hv.w, acc[nb]);
+                        const float4 hv = *reinterpret_cast<const float4*>(hs + (nb * 4 + kq) * HQS + k);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            part[r][nb] = fmaf(wreg[r * KQ + k], hv.x, part[r][nb]);
+                            part[r][nb] = fmaf(wreg[r * KQ + k + 1], hv.y, part[r][nb]);
+                            part[r][nb] = fmaf(wreg[r * KQ + k + 2], hv.z, part[r][nb]);
+                            part[r][nb] = fmaf(wreg[r * KQ + k + 3], hv.w, part[r][nb]);
+                        }
                     }
+                }
+                // sum over the quad (lanes kq = 0..3), then lane kq keeps row 4q + kq = its own row j
+#pragma unroll
+                for (int nb = 0; nb < kNB; ++nb) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = part[r][nb];
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                        mine = (kq == r) ? t : mine;
+                    }
+                    acc[nb] = mine;
                 }
             } else {
                 for (int k = 0; k < H; ++k) {
@@ -103,7 +135,8 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
             const float gi = sigmoidf_(g[ck]), gf = sigmoidf_(g[H + ck]), gg = tanhf(g[2 * H + ck]), go = sigmoidf_(g[3 * H + ck]);
             c = gf * c + gi * gg;
             const float h = go * tanhf(c);
-            hs[cn * H + ck] = h;
+            if constexpr (HT > 0) hs[(cn * 4 + ck / KQ) * HQS + (ck % KQ)] = h;
+            else hs[cn * H + ck] = h;
             const int64_t sb = (int64_t)t * B + b0 + cn;
             hout[sb * 2 * H + dir * H + ck] = h;
             float* gsv = gsav + (sb * 2 + dir) * 4 * H;
@@ -219,7 +252,7 @@ extern "C" int fqss_lstm_fwd(const float* pre, const float* whh, const float* bh
     FQSS_REQUIRE(S > 0 && B > 0 && H > 0 && H <= 256, "bad shape (H <= 256)");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(B, kNB), 2);
-    const size_t lds = (size_t)(kNB * H + kNB * 4 * H) * sizeof(float);
+    const size_t lds = (size_t)(kNB * (H + 16) + kNB * 4 * H) * sizeof(float);
     if (H == 128) {
         hipLaunchKernelGGL((k_lstm_fwd<128>), grid, dim3(512), lds, s, pre, whh, bhh, hout, gsav, csav, S, B, H);
     } else {
