@@ -11,6 +11,8 @@
 // LDS image: planes[3][rows][BK = 32 bf16 + pad] per operand (k contiguous), so an MFMA operand is ONE 16-B read per lane.
 // Operands whose k dimension is strided in memory are transposed on the way in: a thread owns a 4 (rows) x 4 (k) block -- four
 // coalesced float4 loads along the contiguous dimension, then one 8-B LDS write per row and plane.
+// Measured dead end: k-tiles of 16 with two LDS buffers and one barrier per tile (split + store of tile kt+1 under the MFMAs of
+// tile kt) -- 5-12 % SLOWER than this single-buffered k-tile of 32 at the dual-path shapes (60 -> 66 us for 8500 x 256 x 1024).
 #include "fqss_dev.h"
 
 namespace fqss {
