@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, flo
 
 // ------------------------------------------------------------------------------------------------ unary maps
 // kind 0: tanh   1: sigmoid = 1 / (1 + exp(-x))   2: x / p (IEEE division: q / sqrt(head_dim))
+// kind 3: GELU (erf form, torch's default): 0.5 x (1 + erf(x / sqrt 2))      [HTDemucs layers, SURVEY §8 row a15]
 __global__ __launch_bounds__(256) void k_unary_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, int kind,
                                                     float p) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256) void k_unary_fwd(const float* __restrict__ x, 
         float r;
         if (kind == 0) r = tanhf(v);
         else if (kind == 1) r = 1.0f / (1.0f + expf(-v));
-        else r = v / p;
+        else if (kind == 2) r = v / p;
+        else r = (0.5f * v) * (1.0f + erff(v * 0.70710678118654752440f));
         y[i] = r;
     }
 }
@@ -165,7 +167,13 @@ __global__ __launch_bounds__(256) void k_unary_bwd(const float* __restrict__ g, 
         float r;
         if (kind == 0) { const float t = y[i]; r = gv * (1.0f - t * t); }
         else if (kind == 1) { const float t = y[i]; r = (gv * (1.0f - t)) * t; }
-        else r = gv / p;
+        else if (kind == 2) r = gv / p;
+        else {   // GELU: `y` holds the INPUT x; d/dx = Phi(x) + x phi(x)
+            const float x = y[i];
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            r = gv * (cdf + x * pdf);
+        }
         gx[i] = r;
     }
 }
@@ -455,6 +463,64 @@ __global__ __launch_bounds__(256) void k_bcast_sum(const float* __restrict__ g, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ GLU / divide / embedding
+// nn.GLU(dim=1) on channel-first tensors (HEncLayer / HDecLayer / DConv `rewrite` convs, hdemucsq.py:127, 314, demucsq.py:168):
+// x [B][2C][M] -> y [B][C][M] = a * sigmoid(b), a = first C channels, b = last C
+__global__ __launch_bounds__(256) void k_glu_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t B, int64_t C, int64_t M,
+                                                  int64_t ld_x, int64_t ld_y) {
+    const int64_t total = B * C * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i % M, bc = i / M, c = bc % C, b = bc / C;
+        const float a = x[(b * 2 * C + c) * ld_x + m], g = x[(b * 2 * C + C + c) * ld_x + m];
+        y[(b * C + c) * ld_y + m] = a * (1.0f / (1.0f + expf(-g)));
+    }
+}
+__global__ __launch_bounds__(256) void k_glu_bwd(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                                  int64_t B, int64_t C, int64_t M, int64_t ld_x, int64_t ld_gy, int64_t ld_gx) {
+    const int64_t total = B * C * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i % M, bc = i / M, c = bc % C, b = bc / C;
+        const float a = x[(b * 2 * C + c) * ld_x + m], g = x[(b * 2 * C + C + c) * ld_x + m];
+        const float s = 1.0f / (1.0f + expf(-g)), gv = gy[(b * C + c) * ld_gy + m];
+        gx[(b * 2 * C + c) * ld_gx + m] = gv * s;
+        gx[(b * 2 * C + C + c) * ld_gx + m] = ((gv * a) * (1.0f - s)) * s;
+    }
+}
+// torch.div(x1, x2) element-wise (DivQ) and its gradients g / x2, -g x1 / x2^2 (ATen: -grad * self / (other * other))
+__global__ __launch_bounds__(256) void k_div_fwd(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] / b[i];
+}
+__global__ __launch_bounds__(256) void k_div_bwd(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ ga, float* __restrict__ gb, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float bv = b[i], gv = g[i];
+        ga[i] = gv / bv;
+        gb[i] = (-gv * a[i]) / (bv * bv);
+    }
+}
+// F.embedding: out[i][:] = w[idx[i]][:]; gw[idx[i]][:] += g[i][:]
+__global__ __launch_bounds__(256) void k_embedding_fwd(const float* __restrict__ w, const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                        int64_t n, int D, int64_t V) {
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / D;
+        const int d = (int)(i - r * D);
+        const int64_t v = idx[r];
+        out[i] = (v >= 0 && v < V) ? w[v * D + d] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void k_embedding_bwd(const float* __restrict__ g, const int64_t* __restrict__ idx, float* __restrict__ gw,
+                                                        int64_t n, int D, int64_t V) {
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / D;
+        const int d = (int)(i - r * D);
+        const int64_t v = idx[r];
+        if (v >= 0 && v < V) atomicAdd(gw + v * D + d, g[i]);
+    }
+}
+
 static inline unsigned flat_grid(int64_t n) {
     int64_t nb = cdiv(n, 256);
     if (nb < 1) nb = 1;
@@ -510,7 +576,7 @@ extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t
 }
 
 extern "C" int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, double p, fqss_stream_t stream) {
-    FQSS_REQUIRE(x && y && n >= 0 && kind >= 0 && kind <= 2, "bad args");
+    FQSS_REQUIRE(x && y && n >= 0 && kind >= 0 && kind <= 3, "bad args");
     FQSS_REQUIRE(kind != 2 || p != 0.0, "division by zero");
     if (n == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_unary_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind, (float)p);
@@ -518,7 +584,7 @@ extern "C" int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, dou
 }
 
 extern "C" int fqss_unary_bwd(const float* g, const float* y, float* gx, int64_t n, int kind, double p, fqss_stream_t stream) {
-    FQSS_REQUIRE(g && gx && n >= 0 && kind >= 0 && kind <= 2 && (kind == 2 || y), "bad args");
+    FQSS_REQUIRE(g && gx && n >= 0 && kind >= 0 && kind <= 3 && (kind == 2 || y), "bad args");
     if (n == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_unary_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, g, y, gx, n, kind, (float)p);
     return launch_status("fqss_unary_bwd");
@@ -625,4 +691,47 @@ extern "C" int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp,
     if (L == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_bcast_sum, dim3(flat_grid(L * C)), dim3(256), 0, (hipStream_t)stream, g, out, L, Bp, C);
     return launch_status("fqss_bcast_sum");
+}
+
+extern "C" int fqss_glu_fwd(const float* x, float* y, int64_t B, int64_t C, int64_t M, int64_t ld_x, int64_t ld_y, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && y && B >= 0 && C > 0 && M >= 0 && ld_x >= M && ld_y >= M, "bad args");
+    if (B * M == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_glu_fwd, dim3(flat_grid(B * C * M)), dim3(256), 0, (hipStream_t)stream, x, y, B, C, M, ld_x, ld_y);
+    return launch_status("fqss_glu_fwd");
+}
+
+extern "C" int fqss_glu_bwd(const float* x, const float* gy, float* gx, int64_t B, int64_t C, int64_t M, int64_t ld_x, int64_t ld_gy,
+                            int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gy && gx && B >= 0 && C > 0 && M >= 0 && ld_x >= M && ld_gy >= M && ld_gx >= M, "bad args");
+    if (B * M == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_glu_bwd, dim3(flat_grid(B * C * M)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, B, C, M, ld_x, ld_gy, ld_gx);
+    return launch_status("fqss_glu_bwd");
+}
+
+extern "C" int fqss_div_fwd(const float* a, const float* b, float* y, int64_t n, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && b && y && n >= 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_div_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    return launch_status("fqss_div_fwd");
+}
+
+extern "C" int fqss_div_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && a && b && ga && gb && n >= 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_div_bwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, g, a, b, ga, gb, n);
+    return launch_status("fqss_div_bwd");
+}
+
+extern "C" int fqss_embedding_fwd(const float* w, const int64_t* idx, float* out, int64_t n, int D, int64_t V, fqss_stream_t stream) {
+    FQSS_REQUIRE(w && idx && out && n >= 0 && D > 0 && V > 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_embedding_fwd, dim3(flat_grid(n * D)), dim3(256), 0, (hipStream_t)stream, w, idx, out, n, D, V);
+    return launch_status("fqss_embedding_fwd");
+}
+
+extern "C" int fqss_embedding_bwd(const float* g, const int64_t* idx, float* gw, int64_t n, int D, int64_t V, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && idx && gw && n >= 0 && D > 0 && V > 0, "bad args");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_embedding_bwd, dim3(flat_grid(n * D)), dim3(256), 0, (hipStream_t)stream, g, idx, gw, n, D, V);
+    return launch_status("fqss_embedding_bwd");
 }

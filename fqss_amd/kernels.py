@@ -944,3 +944,59 @@ def bcast_sum(g):
     out = torch.empty(L, C, device=g.device, dtype=torch.float32)
     _lib.call("fqss_bcast_sum", _p(g), _p(out), L, Bp, C, _stream())
     return out
+
+
+# ================================================================== first layer kernels of cfg 5 (HTDemucs)
+UNARY_GELU = 3
+
+
+def glu_fwd(x):
+    """nn.GLU(dim=1) on [B, 2C, M] -> [B, C, M]"""
+    x, B, C2, M, ld_x = _bcm(x)
+    assert C2 % 2 == 0
+    y = empty_act((B, C2 // 2, M), x.device)
+    _lib.call("fqss_glu_fwd", _p(x), _p(y), B, C2 // 2, M, ld_x, rowmat(y)[2], _stream())
+    return y
+
+
+def glu_bwd(x, gy):
+    x, B, C2, M, ld_x = _bcm(x)
+    gy, _, _, _, ld_gy = _bcm(gy)
+    gx = empty_act((B, C2, M), x.device)
+    _lib.call("fqss_glu_bwd", _p(x), _p(gy), _p(gx), B, C2 // 2, M, ld_x, ld_gy, rowmat(gx)[2], _stream())
+    return gx
+
+
+def div_fwd(a, b):
+    _need_gpu(a, b)
+    assert a.shape == b.shape
+    a, b = a.contiguous(), b.contiguous()
+    y = torch.empty_like(a)
+    _lib.call("fqss_div_fwd", _p(a), _p(b), _p(y), a.numel(), _stream())
+    return y
+
+
+def div_bwd(g, a, b):
+    g = g.contiguous()
+    ga, gb = torch.empty_like(a), torch.empty_like(b)
+    _lib.call("fqss_div_bwd", _p(g), _p(a), _p(b), _p(ga), _p(gb), a.numel(), _stream())
+    return ga, gb
+
+
+def embedding_fwd(w, idx):
+    """w [V, D] fp32, idx int64 [...] -> [..., D]"""
+    _need_gpu(w)
+    assert idx.dtype == torch.int64 and idx.is_cuda and w.is_contiguous()
+    idx = idx.contiguous()
+    V, D = w.shape
+    out = torch.empty(*idx.shape, D, device=w.device, dtype=torch.float32)
+    _lib.call("fqss_embedding_fwd", _p(w), _p(idx), _p(out), idx.numel(), D, V, _stream())
+    return out
+
+
+def embedding_bwd(g, idx, gw):
+    """gw [V, D] += scatter of g [..., D] by idx"""
+    _need_gpu(g, gw)
+    g, idx = g.contiguous(), idx.contiguous()
+    V, D = gw.shape
+    _lib.call("fqss_embedding_bwd", _p(g), _p(idx), _p(gw), idx.numel(), D, V, _stream())

@@ -316,3 +316,67 @@ class AddBcastRows(Function):
     @staticmethod
     def backward(ctx, g):
         return (g if ctx.needs_input_grad[0] else None), (K.bcast_sum(g) if ctx.needs_input_grad[1] else None)
+
+
+# ---- first layers of cfg 5 (HTDemucs) -----------------------------------------------------------------
+class Gelu(Function):
+    """nn.GELU() (erf form)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return K.unary_fwd(x, K.UNARY_GELU)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return K.unary_bwd(g, x, K.UNARY_GELU)
+
+
+class Glu(Function):
+    """nn.GLU(dim=1) on channel-first [B, 2C, M]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.glu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return K.glu_bwd(x, g)
+
+
+class DivEw(Function):
+    """torch.div(x1, x2), same shape"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return K.div_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga, gb = K.div_bwd(g, a, b)
+        return (ga if ctx.needs_input_grad[0] else None), (gb if ctx.needs_input_grad[1] else None)
+
+
+class EmbeddingRows(Function):
+    """F.embedding(idx, w): w is the (possibly fake-quantized) table"""
+
+    @staticmethod
+    def forward(ctx, w, idx):
+        ctx.save_for_backward(idx)
+        ctx.w = w
+        touch(w)
+        return K.embedding_fwd(w.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gw, direct = _param_grad(ctx.w, ctx.w)
+        K.embedding_bwd(g, idx, gw)
+        return (None if direct else gw), None

@@ -63,7 +63,7 @@ class Mul(nn.Module):
 
 class Div(nn.Module):
     def forward(self, x1, x2):
-        raise NotImplementedError("Div: used by the HTDemucs config only (SURVEY.md §8 row a15, later round)")
+        return ops_dp.DivEw.apply(ops.real(x1), ops.real(x2))
 
 
 class Const(nn.Module):
@@ -186,10 +186,11 @@ def conv1d_geometry(conv):
 
 def run_conv1d(conv, x, weight, nl, aq):
     """fq_act(nl(conv1d(x, weight) + bias)) through one fused autograd node"""
-    if isinstance(nl, (nn.Tanh, nn.Sigmoid)):
-        # gated output convs of the dual-path separator (dptnetq.py:286-287): conv, then the map, then the quantizer
+    if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
+        # gated output convs of the dual-path separators (dptnetq.py:286-287), GELU / GLU convs of the HTDemucs layers
+        # (hdemucsq.py:126-127): conv, then the map, then the quantizer
         z = run_conv1d(conv, x, weight, None, None)
-        return fq_node(aq, ops_dp.Unary.apply(ops.real(z), K.UNARY_TANH if isinstance(nl, nn.Tanh) else K.UNARY_SIGMOID))
+        return fq_node(aq, apply_map(nl, ops.real(z)))
     L = conv1d_geometry(conv)
     act, slope = _act_of(nl)
     L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, slope
@@ -295,7 +296,28 @@ def run_groupnorm_rows(gn, x, aq, geom):
     return fq_node(aq, ops_dp.GroupNormRows.apply(ops.real(x), gn.weight, gn.bias, gn.eps, tuple(geom)))
 
 
+def apply_map(nl, x):
+    """the non-linearities that run as their own kernel in front of a quantizer"""
+    if isinstance(nl, nn.Tanh):
+        return ops_dp.Unary.apply(x, K.UNARY_TANH)
+    if isinstance(nl, nn.Sigmoid):
+        return ops_dp.Unary.apply(x, K.UNARY_SIGMOID)
+    if isinstance(nl, nn.GELU):
+        if getattr(nl, "approximate", "none") != "none":
+            raise NotImplementedError("GELU: only the erf form has a HIP kernel")
+        return ops_dp.Gelu.apply(x)
+    if isinstance(nl, nn.GLU):
+        if nl.dim != 1 or x.dim() < 3:
+            raise NotImplementedError("GLU: only dim=1 of a channel-first tensor has a HIP kernel")
+        shp = x.shape
+        y = ops_dp.Glu.apply(x.reshape(shp[0], shp[1], -1))
+        return y.reshape(shp[0], shp[1] // 2, *shp[2:])
+    raise NotImplementedError(type(nl).__name__)
+
+
 def run_nl(nl, x, aq):
+    if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
+        return fq_node(aq, apply_map(nl, ops.real(x)))
     act, slope = _act_of(nl)
     q = aq.qctx() if aq is not None else ops.BYPASS
     y = ops.ew_layer(x, None, 0.0, act, slope, q)
@@ -694,6 +716,51 @@ class LinearDecoderQ(LayerQ):
 
 
 # ---------------------------------------------------------------------------------------------
+# first layers of cfg 5 (HTDemucs): the model is not built yet
+# ---------------------------------------------------------------------------------------------
+class LinearNlQ(LayerQ):
+    """fq(nl(linear(x)))  (qat_layers.py:539-561; transformer feed-forward `linear1` + activation)"""
+
+    def __init__(self, linear, nl, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(linear, nn.Linear, "Linear")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=linear.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.linear = linear
+        self.nl = nl
+
+    def forward(self, x):
+        z = ops_dp.RowLinear.apply(ops.real(x), self._wq(self.linear.weight), self.linear.bias)
+        if isinstance(self.nl, (nn.GELU, nn.Tanh, nn.Sigmoid)):
+            return fq_node(self.activation_fake_quantize, apply_map(self.nl, z))
+        return fq_node(self.activation_fake_quantize, z, self.nl)
+
+
+class DivQ(LayerQ):
+    def __init__(self, div, gradient_based=True, act_quant=True, act_n_bits=8):
+        super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_n_bits=act_n_bits)
+        _expect(div, Div, "Div")
+        self.div = div
+
+    def forward(self, x1, x2):
+        if not torch.is_tensor(x2) or x1.shape != x2.shape:
+            raise NotImplementedError("DivQ: only same-shape tensor operands have a HIP kernel")
+        return fq_node(self.activation_fake_quantize, ops_dp.DivEw.apply(ops.real(x1), ops.real(x2)))
+
+
+class EmbeddingQ(LayerQ):
+    def __init__(self, embedding, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(embedding, nn.Embedding, "Embedding")
+        if embedding.padding_idx is not None or embedding.max_norm is not None or embedding.scale_grad_by_freq or embedding.sparse:
+            raise NotImplementedError("EmbeddingQ: only the plain lookup (no padding_idx / max_norm / sparse) has a HIP kernel")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=embedding.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.embedding = embedding
+
+    def forward(self, x):
+        return fq_node(self.activation_fake_quantize, ops_dp.EmbeddingRows.apply(self._wq(self.embedding.weight), x))
+
+
+# ---------------------------------------------------------------------------------------------
 # layers of the later §8 rows: constructing them fails loudly (no ATen fallback)
 # ---------------------------------------------------------------------------------------------
 def _later_row(name, row):
@@ -704,7 +771,6 @@ def _later_row(name, row):
     return _Unbuilt
 
 
-DivQ = _later_row("DivQ", "a15")
 Conv1dGnNlQ = _later_row("Conv1dGnNlQ", "a15")
 Conv2dNlQ = _later_row("Conv2dNlQ", "a15")
 ConvTranspose1dQ = _later_row("ConvTranspose1dQ", "a15")
@@ -712,7 +778,5 @@ ConvTranspose2dQ = _later_row("ConvTranspose2dQ", "a15")
 ConvTranspose1dNlQ = _later_row("ConvTranspose1dNlQ", "a15")
 ConvTranspose2dNlQ = _later_row("ConvTranspose2dNlQ", "a15")
 BatchNormQ = _later_row("BatchNormQ", "a15")
-EmbeddingQ = _later_row("EmbeddingQ", "a15")
-LinearNlQ = _later_row("LinearNlQ", "a14")
 Conv2dEncoderQ = _later_row("Conv2dEncoderQ", "a15")
 ConvTr2dDecoderQ = _later_row("ConvTr2dDecoderQ", "a15")

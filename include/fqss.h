@@ -464,6 +464,20 @@ int fqss_gnrows_bwd(const float* gy, const float* x, const float* gamma, const f
 int fqss_bcast_add(const float* x, const float* p, float* z, int64_t L, int64_t Bp, int C, fqss_stream_t stream);
 int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp, int C, fqss_stream_t stream);
 
+/* First layer kernels of cfg 5 (HTDemucs; the model itself is not built yet).
+ * GELU is kind FQSS_UNARY_GELU of fqss_unary_fwd/bwd (erf form; the backward takes the INPUT x in place of y).
+ * GLU over the channel dim of a channel-first tensor (nn.GLU(dim=1), hdemucsq.py:127,314; demucsq.py:168):
+ *   x [B][2C][M] -> y [B][C][M] = x[:, :C] * sigmoid(x[:, C:]);  bwd: gx [B][2C][M] =
+ * element-wise torch.div (DivQ) with its two gradients; F.embedding gather / scatter-add (EmbeddingQ, ScaledEmbedding).   */
+#define FQSS_UNARY_GELU 3
+int fqss_glu_fwd(const float* x, float* y, int64_t B, int64_t C, int64_t M, int64_t ld_x, int64_t ld_y, fqss_stream_t stream);
+int fqss_glu_bwd(const float* x, const float* gy, float* gx, int64_t B, int64_t C, int64_t M, int64_t ld_x, int64_t ld_gy,
+                 int64_t ld_gx, fqss_stream_t stream);
+int fqss_div_fwd(const float* a, const float* b, float* y, int64_t n, fqss_stream_t stream);
+int fqss_div_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, fqss_stream_t stream);
+int fqss_embedding_fwd(const float* w, const int64_t* idx, float* out, int64_t n, int D, int64_t V, fqss_stream_t stream);
+int fqss_embedding_bwd(const float* g, const int64_t* idx, float* gw, int64_t n, int D, int64_t V, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

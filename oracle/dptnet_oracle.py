@@ -194,8 +194,24 @@ class DQTable(QTable):
     def conv1d_nl_q(self, name, x, nl):
         w = self._W(name, self.p[name + ".conv1d.weight"])
         y = F.conv1d(x, w, self.p.get(name + ".conv1d.bias"))
-        y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": F.relu, None: (lambda t: t)}[nl](y)
+        y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": F.relu, "gelu": F.gelu, "glu": (lambda t: F.glu(t, 1)),
+             None: (lambda t: t)}[nl](y)
         return self._A(name, y)
+
+    # -- first layers of cfg 5 (HTDemucs) -----------------------------------------------------------
+    def linear_nl_q(self, name, x, nl):
+        """LinearNlQ (qat_layers.py:539-561)"""
+        w = self._W(name, self.p[name + ".linear.weight"])
+        y = F.linear(x, w, self.p.get(name + ".linear.bias"))
+        return self._A(name, {"relu": F.relu, "gelu": F.gelu}[nl](y))
+
+    def div_q(self, name, a, b):
+        """DivQ (qat_layers.py:104-113)"""
+        return self._A(name, torch.div(a, b))
+
+    def embedding_q(self, name, idx):
+        """EmbeddingQ (qat_layers.py:490-508): lookup in the per-row fake-quantized table"""
+        return self._A(name, F.embedding(idx, self._W(name, self.p[name + ".embedding.weight"])))
 
     def linear_decoder_q(self, name, x, n_combiner=2):
         w = self._W(name, self.p[name + ".linear.weight"])

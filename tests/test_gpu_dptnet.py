@@ -540,3 +540,69 @@ def test_dpt_full_size_vs_reference_goldens(golden):
                 assert not bad, bad[:5]
         else:
             assert abs(r["loss"].item() - float(g[p + "loss"])) <= 3.0, (s, r["loss"].item(), float(g[p + "loss"]))
+
+
+# ------------------------------------------------------------------------------------------------ first layers of row a15
+def _hd_layer(name, sd):
+    from fqss_amd.quantization.qat import qat_layers as QL
+    shp = lambda k: tuple(sd[k].shape)
+    if name in ("linearnlq_gelu", "linearnlq_relu"):
+        co, ci = shp("linear.weight")
+        return QL.LinearNlQ(nn.Linear(ci, co), nn.GELU() if name.endswith("gelu") else nn.ReLU(), **P)
+    if name == "nlq_gelu":
+        return QL.NlQ(nn.GELU(), **A)
+    if name == "conv1dnlq_glu":
+        co, ci, _ = shp("conv1d.weight")
+        return QL.Conv1dNlQ(nn.Conv1d(ci, co, 1), nn.GLU(dim=1), **P)
+    if name == "divq":
+        return QL.DivQ(QL.Div(), **A)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["linearnlq_gelu", "linearnlq_relu", "nlq_gelu", "conv1dnlq_glu", "divq"])
+def test_htdemucs_first_layers_teacher_forced(golden, name):
+    """SURVEY §8 row a15, layer level (the model is not built yet): GELU / GLU maps, LinearNlQ, DivQ against the reference"""
+    g = golden("hd_layers")
+    sd = {k[len(name) + 4:]: T(g[k]) for k in g.files if k.startswith(name + ".sd.")}
+    L = _hd_layer(name, sd)
+    L.load_state_dict(sd, strict=True)
+    L = L.cuda().train()
+    _leave_observer(L)
+    ins, i = [], 0
+    while f"{name}.in{i}" in g.files:
+        ins.append(T(g[f"{name}.in{i}"]).cuda().requires_grad_(True))
+        i += 1
+    y = L(*ins)
+    y.backward(T(g[f"{name}.gout"]).cuda())
+    lo, hi = float(sd["activation_fake_quantize.min_range"]), float(sd["activation_fake_quantize.max_range"])
+    delta = (hi - lo) / 255.0
+    a, b = np.rint((y.detach().cpu().numpy() - lo) / delta), np.rint((g[f"{name}.out"] - lo) / delta)
+    assert np.abs(a - b).max() <= 1 and float(np.mean(a != b)) <= 3e-3
+    nflip = int((a != b).sum())
+    for i, x in enumerate(ins):
+        want = g[f"{name}.gin{i}"]
+        bad = np.abs(x.grad.cpu().numpy() - want) > 2e-4 * np.abs(want).max() + 2e-4 * np.abs(want)
+        assert bad.mean() <= 2e-3 + 8.0 * nflip / want.size, (name, i, bad.mean())
+    params = dict(L.named_parameters())
+    for k in g.files:
+        if k.startswith(name + ".grad."):
+            w = g[k]
+            np.testing.assert_allclose(params[k[len(name) + 6:]].grad.cpu().numpy(), w, rtol=3e-3, atol=(3e-3 + 0.05 * nflip) * (np.abs(w).max() + 1e-6), err_msg=k)
+
+
+def test_htdemucs_embeddingq(golden):
+    from fqss_amd.quantization.qat import qat_layers as QL
+    g = golden("hd_layers")
+    sd = {k[len("embeddingq.sd."):]: T(g[k]) for k in g.files if k.startswith("embeddingq.sd.")}
+    V, Dm = sd["embedding.weight"].shape
+    L = QL.EmbeddingQ(nn.Embedding(V, Dm), **P)
+    L.load_state_dict(sd, strict=True)
+    L = L.cuda().train()
+    _leave_observer(L)
+    y = L(T(g["embeddingq.idx"]).cuda())
+    y.backward(T(g["embeddingq.gout"]).cuda())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["embeddingq.out"], rtol=0, atol=1e-6)
+    params = dict(L.named_parameters())
+    for k in g.files:
+        if k.startswith("embeddingq.grad."):
+            np.testing.assert_allclose(params[k[len("embeddingq.grad."):]].grad.cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)

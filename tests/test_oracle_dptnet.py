@@ -74,6 +74,24 @@ def test_dpt_layer_fixtures(golden):
     run(g, "lineardecoderq", lambda t, x: t.linear_decoder_q("L", x, 2))
 
 
+def test_htdemucs_first_layer_fixtures(golden):
+    """row a15, layer level: LinearNlQ (GELU / ReLU), NlQ(GELU), 1x1 Conv1dNlQ + GLU, DivQ, EmbeddingQ vs the reference"""
+    g = golden("hd_layers")
+    run(g, "linearnlq_gelu", lambda t, x: t.linear_nl_q("L", x, "gelu"))
+    run(g, "linearnlq_relu", lambda t, x: t.linear_nl_q("L", x, "relu"))
+    run(g, "nlq_gelu", lambda t, x: t._A("L", torch.nn.functional.gelu(x)))
+    run(g, "conv1dnlq_glu", lambda t, x: t.conv1d_nl_q("L", x, "glu"))
+    run(g, "divq", lambda t, a, b: t.div_q("L", a, b))
+    tab = D.DQTable({"L." + k: v for k, v in table(g, "embeddingq").items()})
+    tab.leave_observer_phase()
+    y = tab.embedding_q("L", T(g["embeddingq.idx"]))
+    y.backward(T(g["embeddingq.gout"]))
+    assert (y.detach() - T(g["embeddingq.out"])).abs().max().item() < 1e-6
+    for k, v in tab.p.items():
+        if "embeddingq.grad." + k[2:] in g.files:
+            np.testing.assert_allclose(v.grad.numpy(), g["embeddingq.grad." + k[2:]], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def test_dpt_observer_ranges(golden):
     """50 observer calls on one input: every range of the layer (incl. the MHA quantizers whose outputs are discarded)"""
     g = golden("dpt_layers")

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Golden vectors for the first LayerQ classes of SURVEY.md §8 row a15 (cfg 5: HTDemucs), generated from the REAL reference
+(layer level only: the model is not built yet).  hd_layers.npz: LinearNlQ with GELU and ReLU (qat_layers.py:539-561), NlQ(GELU),
+Conv1dNlQ 1x1 + GLU(dim=1) (the `rewrite` convs, hdemucsq.py:127, 314), DivQ, EmbeddingQ (qat_layers.py:490-508).
+Usage: python tools/make_goldens_htdemucs_layers.py"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_goldens as MG  # noqa: E402
+import make_goldens_dptnet as MD  # noqa: E402
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from quantization.qat import qat_layers as RL  # noqa: E402
+
+keyed_randn, fill, run_layer, P = MG.keyed_randn, MD.fill, MD.run_layer, MD.P
+
+
+def main():
+    out = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+    d = {}
+    x = keyed_randn("hd.x", (9, 5, 16), 0.9)
+    L = RL.LinearNlQ(nn.Linear(16, 24), nn.GELU(), **P); fill(L, "lng.")
+    run_layer("linearnlq_gelu", L, [x], d)
+    L = RL.LinearNlQ(nn.Linear(16, 24), nn.ReLU(), **P); fill(L, "lnr.")
+    run_layer("linearnlq_relu", L, [x], d)
+    L = RL.NlQ(nn.GELU(), gradient_based=True, act_quant=True)
+    run_layer("nlq_gelu", L, [keyed_randn("hd.xg", (3, 12, 37), 1.2)], d)
+    L = RL.Conv1dNlQ(nn.Conv1d(12, 24, 1), nn.GLU(dim=1), **P); fill(L, "glu.")
+    run_layer("conv1dnlq_glu", L, [keyed_randn("hd.xc", (3, 12, 37), 0.9)], d)
+    L = RL.DivQ(RL.Div(), gradient_based=True, act_quant=True)
+    run_layer("divq", L, [keyed_randn("hd.num", (3, 12, 37), 0.8), keyed_randn("hd.den", (3, 12, 37), 0.3).abs() + 0.5], d)
+    # EmbeddingQ: integer input, so run it by hand with the same protocol as run_layer
+    emb = RL.EmbeddingQ(nn.Embedding(11, 16), **P); fill(emb, "emb.")
+    idx = torch.tensor([[0, 3, 10, 3], [7, 1, 1, 5]])
+    emb.train()
+    from quantization.qat.models.load_model import enable_observer
+    from quantization.qat import qat_quant as RQ
+    enable_observer(emb, True)
+    with torch.no_grad():
+        for _ in range(50):
+            y_obs = emb(idx)
+    d["embeddingq.out_obs"] = MG.npy(y_obs)
+    with torch.no_grad():
+        for m in emb.modules():
+            if isinstance(m, RQ.GradientActivationFakeQuantize):
+                m.min_range.mul_(0.93); m.max_range.mul_(0.93)
+    y = emb(idx)
+    g = keyed_randn("embeddingq.gout", tuple(y.shape))
+    y.backward(g)
+    d["embeddingq.idx"], d["embeddingq.out"], d["embeddingq.gout"] = idx.numpy(), MG.npy(y), MG.npy(g)
+    for k, v in emb.state_dict().items():
+        d["embeddingq.sd." + k] = MG.npy(v)
+    for k, p in emb.named_parameters():
+        if p.grad is not None:
+            d["embeddingq.grad." + k] = MG.npy(p.grad)
+    np.savez_compressed(os.path.join(out, "hd_layers.npz"), **d)
+    print("hd_layers:", len(d), "arrays")
+
+
+if __name__ == "__main__":
+    main()
