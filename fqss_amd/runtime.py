@@ -311,6 +311,7 @@ class KDTrainStep:
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None):
         self.model, self.fmodel = model, fmodel
+        self._graphs = None
         self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
         self.comm = comm
         self.arena = ParamArena(list(model.parameters()))
@@ -320,9 +321,40 @@ class KDTrainStep:
         self._tstream = None
         self.last = None
         self.tables = None          # QuantTables once the quantizing phase is reached
-        self._graphs = None
+        self._eager_q = 0           # eager steps run in the quantizing phase (see maybe_capture)
         self.use_graph = True
         self._sx = self._st = None
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        """the learning rate is an argument of the captured clip+Adam launch: a scheduler step drops the graphs (the trainers
+        re-capture lazily, see maybe_capture)"""
+        if getattr(self, "_lr", None) != value:
+            self._graphs = None
+        self._lr = value
+
+    def can_capture(self):
+        from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
+        for m in self.model.modules():
+            if isinstance(m, GradientActivationFakeQuantize) and m.observer_mode and m.n_iter < m.max_observations:
+                return False
+            if isinstance(m, GradientWeightFakeQuantize) and m.observer_mode:
+                return False
+        return True
+
+    def maybe_capture(self, x, tgt):
+        """training loops: once the observer phase is over (and after every learning-rate change) record the step into hipGraphs
+        WITHOUT running it (warmup=0: no extra optimizer step); later calls with same-shaped batches replay.  At least one
+        quantizing-phase step must have run eagerly first: it builds the QuantTables and starts the Adam clocks of the activation
+        ranges (the captured clip+Adam launch does not activate parameters)"""
+        if self.use_graph and self._graphs is None and self._eager_q >= 1 and self.can_capture():
+            self.capture(x, tgt, warmup=0)
+        elif self._graphs is not None and (x.shape != self._sx.shape or tgt.shape != self._st.shape):
+            self._graphs = None          # a batch of another shape: back to eager launches
 
     # ---- the two halves of a step -----------------------------------------------------------
     def _fwd_bwd(self, x, tgt):
@@ -383,6 +415,8 @@ class KDTrainStep:
         if self._world() > 1:
             self.comm.all_reduce_sum(self.arena.flat_g)
         self._optimize()
+        if self.tables is not None:
+            self._eager_q += 1
         return self.last
 
     # ---- hipGraph capture -------------------------------------------------------------------
@@ -398,7 +432,7 @@ class KDTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):      # eager steps: activates every live parameter's Adam clock
+            for _ in range(warmup):              # eager steps: activates every live parameter's Adam clock (bench: warm caches)
                 self.last = self._fwd_bwd(self._sx, self._st)
                 if self._world() > 1:
                     self.comm.all_reduce_sum(self.arena.flat_g)
@@ -412,6 +446,18 @@ class KDTrainStep:
             self._optimize(activate=False)
         self._graphs = (g1, g2)
         return self
+
+    def replay_fwd_bwd(self, x=None, tgt=None):
+        """first half of a captured step (fwd + loss + bwd); the caller all-reduces and then calls replay_optimize() or skips"""
+        if x is not None and x.data_ptr() != self._sx.data_ptr():
+            self._sx.copy_(x)
+            self._st.copy_(tgt)
+        self._graphs[0].replay()
+        return self.last
+
+    def replay_optimize(self):
+        self.arena._host_step += 1
+        self._graphs[1].replay()
 
     def replay(self, x=None, tgt=None):
         if x is not None and x.data_ptr() != self._sx.data_ptr():

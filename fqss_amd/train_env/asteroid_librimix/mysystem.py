@@ -38,6 +38,7 @@ class System:
 
     def training_step(self, batch, batch_nb):
         """one optimiser step through the fused runtime; logs `loss` / `kd_loss` like the reference"""
+        self.stepper.maybe_capture(*batch)      # quantizing phase: the step replays as hipGraphs from here on
         r = self.stepper(*batch)
         self.logged.update(loss=r["loss"], kd_loss=r["kd_loss"])
         return r["loss"]

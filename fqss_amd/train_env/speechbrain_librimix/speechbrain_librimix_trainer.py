@@ -142,14 +142,20 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
     for epoch in range(1, int(hp["N_epochs"]) + 1):
         losses = []
         for x, tgt in _batches(hp, comm, dev, "train"):
-            r = step._fwd_bwd(x, tgt)
+            step.maybe_capture(x, tgt)        # quantizing phase: both halves of the step replay as hipGraphs
+            graphed = step._graphs is not None
+            r = step.replay_fwd_bwd(x, tgt) if graphed else step._fwd_bwd(x, tgt)
             # hard-threshold of easy items (threshold_byloss): a no-op at batch 1, see the module docstring
             flag.copy_((r["loss"] < upper).float().reshape(1))       # False for NaN / inf as well
             if comm.world > 1:
                 comm.all_reduce_sum(step.arena.flat_g)
                 comm.all_reduce_sum(flag)
             if flag.item() >= comm.world:        # the reference syncs here too (loss.detach().cpu(), :199)
-                step._optimize()
+                if graphed:
+                    step.replay_optimize()
+                else:
+                    step._optimize()
+                    step._eager_q += 1 if step.tables is not None else 0
                 losses.append(r["loss"].item())
             else:
                 nonfinite += 1

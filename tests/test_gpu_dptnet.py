@@ -606,3 +606,35 @@ def test_htdemucs_embeddingq(golden):
     for k in g.files:
         if k.startswith("embeddingq.grad."):
             np.testing.assert_allclose(params[k[len("embeddingq.grad."):]].grad.cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_lazy_capture_in_training_loops_matches_eager(golden):
+    """trainers call KDTrainStep.maybe_capture(): after the observer phase (and one eager quantizing step) the step is recorded
+    WITHOUT being run and replays from then on; a learning-rate change drops the graphs.  Same state in -> same losses out as
+    the all-eager twin (up to the fp32 atomics of the weight gradients)"""
+    from fqss_amd.runtime import KDTrainStep
+    g = golden("dpt_tiny_step")
+    x, tgt = T(g["x"]).cuda(), T(g["tgt"]).cuda()
+    runs = []
+    for lazy in (False, True):
+        model, fmodel = _forced(g, 50)
+        step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=4e-4, clip=5.0)
+        losses, graphed = [], []
+        for i in range(6):
+            if lazy:
+                step.maybe_capture(x, tgt)
+            graphed.append(step._graphs is not None)
+            if i == 4:
+                step.lr = 2e-4                  # scheduler step
+                assert step._graphs is None
+                if lazy:
+                    step.maybe_capture(x, tgt)
+                    assert step._graphs is not None
+            losses.append(step(x, tgt)["loss"].item())
+        runs.append((losses, graphed, step.arena.flat_p.clone()))
+    (l0, g0, p0), (l1, g1, p1) = runs
+    assert g0 == [False] * 6 and g1 == [False, True, True, True, True, True]
+    np.testing.assert_allclose(l0[0], l1[0], rtol=1e-6)
+    np.testing.assert_allclose(l0[1], l1[1], atol=0.05)          # dB: the first replayed step (fp32 atomics of step 1 already differ)
+    np.testing.assert_allclose(l0, l1, atol=0.1)                 # dB; chaotic after a few quantized updates
+    assert float((p0 - p1).abs().max()) < 5e-3
