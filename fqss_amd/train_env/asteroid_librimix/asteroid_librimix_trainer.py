@@ -64,7 +64,8 @@ def train(yml_path, device):
         val = torch.stack([system.validation_step(b, i) for i, b in enumerate(_batches(dataset_cfg, training_cfg, comm, dev, "val"))]).mean()
         comm.all_reduce_sum(val)
         val = val.item() / comm.world
-        history.append({"epoch": epoch, "loss": system.logged["loss"].item(), "val_loss": val, "lr": system.stepper.lr})
+        history.append({"epoch": epoch, "loss": system.logged["loss"].item(), "val_loss": val, "lr": system.stepper.lr,
+                        "launch": "hipGraph replay" if system.stepper._graphs is not None else "eager"})
         if half_lr:
             if val < plateau_best - 1e-4 * abs(plateau_best):     # torch ReduceLROnPlateau defaults: rel threshold 1e-4
                 plateau_best, plateau_bad = val, 0

@@ -165,7 +165,8 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
         comm.all_reduce_sum(val)
         val = val.item() / comm.world
         new_lr = sched(step.lr, epoch, val)
-        rec = {"epoch": epoch, "lr": step.lr, "train_loss": sum(losses) / max(1, len(losses)), "valid_si-snr": val}
+        rec = {"epoch": epoch, "lr": step.lr, "train_loss": sum(losses) / max(1, len(losses)), "valid_si-snr": val,
+               "launch": "hipGraph replay" if step._graphs is not None else "eager"}
         step.lr = new_lr
         history.append(rec)
         if comm.rank == 0:

@@ -34,12 +34,14 @@ def test_asteroid_env_trains_dptnet(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     conf = yaml.safe_load(open(os.path.join(root, "configs", "dptnet_2spks_8k_synthetic.yaml")))
     conf["work_dir"] = str(tmp_path / "run")
-    conf["dataset_cfg"].update(segment=0.25, steps_per_epoch=3, val_steps=1)
+    conf["dataset_cfg"].update(segment=0.25, steps_per_epoch=14, val_steps=1)
     conf["training_cfg"].update(epochs=4)
     yml = tmp_path / "cfg.yaml"
     yml.write_text(yaml.safe_dump(conf))
     hist = T.train(str(yml), "cuda")
     assert len(hist) == 4 and all(torch.isfinite(torch.tensor(h["loss"])) for h in hist)
+    # 56 steps: the 50-call observer phase ends inside epoch 4, one eager quantizing step, then the captured step replays
+    assert [h["launch"] for h in hist] == ["eager", "eager", "eager", "hipGraph replay"]
     assert abs(hist[0]["lr"] - 4e-4) < 1e-12 and abs(hist[2]["lr"] - 4e-4 * 0.98) < 1e-12 and abs(hist[3]["lr"] - 4e-4 * 0.98) < 1e-12
     sd = torch.load(os.path.join(conf["work_dir"], "best_model.pth"))
     assert "separator.DPT.row_transformer.0.transformer.lstm.weight_quantizers_dict.weight_hh_l0.min_range" in sd
