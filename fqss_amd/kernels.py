@@ -1000,3 +1000,22 @@ def embedding_bwd(g, idx, gw):
     g, idx = g.contiguous(), idx.contiguous()
     V, D = gw.shape
     _lib.call("fqss_embedding_bwd", _p(g), _p(idx), _p(gw), idx.numel(), D, V, _stream())
+
+
+def qrow_eligible(Ci):
+    return Ci % 16 == 0 and 16 <= Ci <= 2048
+
+
+def qrow_fwd(xc, wc, bias, qmin_x, qmax_x, out=None):
+    """u8 codes xc [..., Ci] (dense rows) x int8 weight codes (WCodes of a [Co, Ci] weight) -> z [..., Co] fp32 (exact integer
+    sums on the int8 matrix cores); `out`: optional [..., Co] row-matrix view to write into"""
+    Ci, Co = wc.Ci, wc.Co
+    assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci
+    rm = rowmat(xc)
+    assert rm is not None and rm[1] == Ci and rm[2] % 16 == 0, "activation codes need 16-B aligned rows"
+    z = torch.empty(*xc.shape[:-1], Co, device=xc.device, dtype=torch.float32) if out is None else out
+    zz, Rz, ld_z = _rows(z, Co)
+    assert zz is z and Rz == rm[0]
+    _lib.call("fqss_qrow_fwd", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias), _p(qmin_x), _p(qmax_x), _p(z), rm[0], Ci, Co, rm[2],
+              ld_z, _stream())
+    return z

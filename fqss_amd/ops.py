@@ -683,6 +683,9 @@ def fork2(x):
         if c is not None:
             a._fqss_q = b._fqss_q = c
             a._fqss_carrier = b._fqss_carrier = is_carrier(x)
+        rq = getattr(x, "_fqss_rowq", None)       # codes of a dual-path row tensor (read by ops_dp.row_linear only)
+        if rq is not None:
+            a._fqss_rowq = b._fqss_rowq = rq
         return a, b
     return x, x
 

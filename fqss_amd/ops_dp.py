@@ -60,6 +60,48 @@ class RowLinear(Function):
         return gx, gw, gb
 
 
+QROW = __import__("os").environ.get("FQSS_QROW", "1") != "0"    # student linears on codes (csrc/qrow.hip); 0: fp32-equivalent GEMM
+
+
+def qrow_operands(x, w):
+    """(activation codes, weight codes) when the int8 q-GEMM applies to z = x @ w^T: x carries the u8 codes of the quantizer that
+    produced it, w the int8 codes of its fake-quantizer (both set in the quantizing phase only), rows dense and 16-B aligned"""
+    if not QROW:
+        return None
+    # row layers tag their outputs with `_fqss_rowq` (kept apart from `_fqss_q`, which would route element-wise consumers onto
+    # ConvTasNet's coded kernels); NlQ outputs arrive through the generic tag
+    xq = getattr(x, "_fqss_rowq", None) or ops.codes_of(x)
+    wc = getattr(w, "_fqss_wcodes", None)
+    if xq is None or wc is None or ops.is_carrier(x) or xq.idx.shape != x.shape or not xq.idx.is_contiguous():
+        return None
+    if w.dim() != 2 or wc.Ci != x.shape[-1] or not K.qrow_eligible(wc.Ci):
+        return None
+    return xq, wc
+
+
+class RowLinearQ(Function):
+    """RowLinear whose forward runs on the operands' codes (exact integer sums, int8 MFMA); the backward is RowLinear's"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, xq, wc):
+        ctx.save_for_backward(x, w)
+        ctx.bias = bias
+        touch(w, bias)
+        return K.qrow_fwd(xq.idx, wc, bias, xq.qmin, xq.qmax)
+
+    @staticmethod
+    def backward(ctx, gz):
+        return RowLinear.backward(ctx, gz) + (None, None)
+
+
+def row_linear(x, w, bias):
+    """z = x @ w^T + bias on the last dim: on codes when both operands carry them, else the fp32-equivalent row GEMM"""
+    ops_ = qrow_operands(x, w)
+    if ops_ is not None:
+        return RowLinearQ.apply(x, w, bias, ops_[0], ops_[1])
+    return RowLinear.apply(ops.real(x), w, bias)
+
+
 class LayerNormRows(Function):
     """F.layer_norm over the last dim (LayerNormQ, qat_layers.py:455-465), one wavefront per row"""
 
@@ -249,15 +291,25 @@ class LstmBi(Function):
     Weights arrive already fake-quantized (or float): w_ih [2][4H, I], w_hh [2][4H, H], biases are parameters."""
 
     @staticmethod
-    def forward(ctx, x, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r):
+    def forward(ctx, x, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, xq=None, wc_f=None, wc_r=None):
         S, B, I = x.shape
         H = whh_f.shape[1]
         x = x.contiguous()
+        on_codes = QROW and xq is not None and wc_f is not None and wc_r is not None and K.qrow_eligible(I) \
+            and xq.idx.shape == x.shape and xq.idx.is_contiguous()
+        qf, qr = ((xq, wc_f), (xq, wc_r)) if on_codes else (None, None)
         wih = torch.cat([wih_f, wih_r], 0)                 # [8H, I]   (memory plumbing: 2 x 128 KB)
         whh = torch.stack([whh_f, whh_r], 0).contiguous()  # [2, 4H, H]
         bih = torch.cat([bih_f, bih_r], 0)
         bhh = torch.stack([bhh_f, bhh_r], 0).contiguous()
-        pre = K.rowlin_fwd(x, wih, bih)                    # [S, B, 8H]: both directions' input projections, one GEMM
+        if qf is not None and qr is not None:
+            # quantizing phase: x and both W_ih sit on 8-bit grids -> the projections run on the codes (int8 MFMA), one launch per
+            # direction into the two column blocks of `pre`
+            pre = torch.empty(S, B, 8 * H, device=x.device, dtype=torch.float32)
+            K.qrow_fwd(xq.idx, qf[1], bih_f, xq.qmin, xq.qmax, out=pre[..., :4 * H])
+            K.qrow_fwd(xq.idx, qr[1], bih_r, xq.qmin, xq.qmax, out=pre[..., 4 * H:])
+        else:
+            pre = K.rowlin_fwd(x, wih, bih)                # [S, B, 8H]: both directions' input projections, one GEMM
         hout, gsav, csav = K.lstm_fwd(pre, whh, bhh, S, B, H)
         ctx.save_for_backward(x, wih, whh, hout, gsav, csav)
         ctx.params = (bih_f, bhh_f, bih_r, bhh_r)
@@ -283,7 +335,7 @@ class LstmBi(Function):
             buf, direct = _param_grad(p, p)
             K.colsum(dG[..., lo:lo + 4 * H], buf)
             gbs.append(None if direct else buf)
-        return gx, gwih[:4 * H], gwhh[0], gbs[0], gbs[1], gwih[4 * H:], gwhh[1], gbs[2], gbs[3]
+        return gx, gwih[:4 * H], gwhh[0], gbs[0], gbs[1], gwih[4 * H:], gwhh[1], gbs[2], gbs[3], None, None, None
 
 
 class GroupNormRows(Function):

@@ -495,30 +495,35 @@ def _flat2d(t):
     return t.view(n // c, c) if c else None
 
 
-def fq_node(aq, x, nl=None):
-    """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl"""
+def fq_node(aq, x, nl=None, codes=False):
+    """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl.
+    codes=True: also emit the u8 codes and tag the result with them (the consumer is a row linear that can run on codes)"""
     act, slope = _act_of(nl)
     q = aq.qctx() if aq is not None else ops.BYPASS
     if q.qmode == ops.Q_BYPASS and act == ops.ACT_NONE:
         return x
     x = ops.real(x)
     flat = _flat2d(x)
-    q.no_codes = True         # nobody downstream of these row layers reads u8 codes: skip the 1 B/element side output
+    want = codes and ops_dp.QROW and q.qmode == ops.Q_QUANT
+    q.no_codes = not want     # no coded consumer downstream: skip the 1 B/element side output
     y = ops.NlActQ.apply(x if flat is None else flat, slope, q.qmin, q.qmax, act, q, slope)
     if aq is not None:
         aq.after_forward(q)
-    q.idx = None
-    return y if flat is None else y.reshape(x.shape)
+    idx, q.idx = q.idx, None
+    y = y if flat is None else y.reshape(x.shape)
+    if want and idx is not None and idx.is_contiguous() and y.is_contiguous():
+        y._fqss_rowq = ops.ActCodes(idx.view(x.shape), q.qmin.detach(), q.qmax.detach())
+    return y
 
 
 def run_linear(lin, x, weight, nl, aq):
-    return fq_node(aq, ops_dp.RowLinear.apply(ops.real(x), weight, lin.bias), nl)
+    return fq_node(aq, ops_dp.row_linear(x, weight, lin.bias), nl)
 
 
 def run_layernorm(ln, x, aq):
     if len(ln.normalized_shape) != 1 or not ln.elementwise_affine:
         raise NotImplementedError("only LayerNorm over the last dim with affine parameters has a HIP kernel")
-    return fq_node(aq, ops_dp.LayerNormRows.apply(ops.real(x), ln.weight, ln.bias, ln.eps))
+    return fq_node(aq, ops_dp.LayerNormRows.apply(ops.real(x), ln.weight, ln.bias, ln.eps), codes=True)
 
 
 def _lstm_check(lstm):
@@ -531,7 +536,8 @@ def run_lstm(lstm, x, weights, aq):
     _lstm_check(lstm)
     y = ops_dp.LstmBi.apply(ops.real(x), weights["weight_ih_l0"], weights["weight_hh_l0"], lstm.bias_ih_l0, lstm.bias_hh_l0,
                             weights["weight_ih_l0_reverse"], weights["weight_hh_l0_reverse"], lstm.bias_ih_l0_reverse,
-                            lstm.bias_hh_l0_reverse)
+                            lstm.bias_hh_l0_reverse, getattr(x, "_fqss_rowq", None),
+                            getattr(weights["weight_ih_l0"], "_fqss_wcodes", None), getattr(weights["weight_ih_l0_reverse"], "_fqss_wcodes", None))
     return fq_node(aq, y)
 
 
@@ -544,14 +550,14 @@ def _mha_check(mha, query, key, value):
 
 def run_mha(mha, x, w_in, w_out, aqs, aq_head, aq_out):
     """x [L, B, E] -> [L, B, E]; aqs = (q, k, v, div, attn, softmax) quantizers or None for the float module"""
-    X = ops_dp.RowLinear.apply(ops.real(x), w_in, mha.in_proj_bias)
+    X = ops_dp.row_linear(x, w_in, mha.in_proj_bias)
     if aqs is None:
         heads = ops_dp.MhaCore.apply(X, mha.num_heads, None)
     else:
         ranges = [r for a in aqs[:4] for r in (a.min_range, a.max_range)]
         heads = ops_dp.MhaCore.apply(X, mha.num_heads, aqs, *ranges)
-    heads = fq_node(aq_head, heads)
-    return fq_node(aq_out, ops_dp.RowLinear.apply(heads, w_out, mha.out_proj.bias))
+    heads = fq_node(aq_head, heads, codes=True)
+    return fq_node(aq_out, ops_dp.row_linear(heads, w_out, mha.out_proj.bias))
 
 
 class LayerNormQ(LayerQ):
@@ -729,7 +735,7 @@ class LinearNlQ(LayerQ):
         self.nl = nl
 
     def forward(self, x):
-        z = ops_dp.RowLinear.apply(ops.real(x), self._wq(self.linear.weight), self.linear.bias)
+        z = ops_dp.row_linear(x, self._wq(self.linear.weight), self.linear.bias)
         if isinstance(self.nl, (nn.GELU, nn.Tanh, nn.Sigmoid)):
             return fq_node(self.activation_fake_quantize, apply_map(self.nl, z))
         return fq_node(self.activation_fake_quantize, z, self.nl)

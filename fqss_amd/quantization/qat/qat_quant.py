@@ -20,6 +20,11 @@ from ... import kernels as K
 from ... import ops
 
 
+def ops_dp_qrow():
+    from ... import ops_dp
+    return ops_dp.QROW
+
+
 def _check_bits(n_bits):
     if n_bits != 8:
         raise NotImplementedError("fqss_amd kernels implement the 8-bit quantizers of the shipped FQSS configs")
@@ -118,6 +123,9 @@ class GradientWeightFakeQuantize(nn.Module):
         wq = ops.WeightFq.apply(x, self.min_range, self.max_range, self.axis, self, w_param if w_param is not None else x)
         if self.axis == 0 and x.dim() == 3 and x.shape[2] == 1 and K.q_eligible(x.shape[1], x.shape[0]):
             # pointwise-conv weight: also hand its int8 codes to the bf16-MFMA q-GEMMs (csrc/qgemm.hip)
+            wq._fqss_wcodes = K.wq_codes(x.detach(), self.min_range.detach(), self.max_range.detach())
+        elif self.axis == 0 and x.dim() == 2 and K.qrow_eligible(x.shape[1]) and ops_dp_qrow():
+            # row-major linear weight (LinearQ, attention projections, LSTM input projection): codes for csrc/qrow.hip
             wq._fqss_wcodes = K.wq_codes(x.detach(), self.min_range.detach(), self.max_range.detach())
         return wq
 

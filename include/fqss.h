@@ -464,6 +464,15 @@ int fqss_gnrows_bwd(const float* gy, const float* x, const float* gamma, const f
 int fqss_bcast_add(const float* x, const float* p, float* z, int64_t L, int64_t Bp, int C, fqss_stream_t stream);
 int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp, int C, fqss_stream_t stream);
 
+/* Row-major linear of the dual-path STUDENT on codes (csrc/qrow.hip, int8 MFMA, exact integer sums):
+ *   z[r][o] = dw[o] * (dx * sum_i wk[o][i] xc[r][i] + min_x * rw[o]) + bias[o]
+ * xc: u8 activation codes [R][Ci] (rows 16-B aligned) with the ranges (qmin_x, qmax_x) of the quantizer that produced them;
+ * wk / dw / rw: the weight's int8 codes, per-row step and code sum from fqss_wq_codes.  Ci a multiple of 16.
+ * replaces: F.linear on fake-quantized operands (qat_layers.py:521-536, 889-901, 941) in the quantizing phase.            */
+int fqss_qrow_fwd(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias,
+                  const float* qmin_x, const float* qmax_x, float* z, int64_t R, int Ci, int Co, int64_t ld_x,
+                  int64_t ld_z, fqss_stream_t stream);
+
 /* First layer kernels of cfg 5 (HTDemucs; the model itself is not built yet).
  * GELU is kind FQSS_UNARY_GELU of fqss_unary_fwd/bwd (erf form; the backward takes the INPUT x in place of y).
  * GLU over the channel dim of a channel-first tensor (nn.GLU(dim=1), hdemucsq.py:127,314; demucsq.py:168):

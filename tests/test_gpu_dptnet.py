@@ -638,3 +638,25 @@ def test_lazy_capture_in_training_loops_matches_eager(golden):
     np.testing.assert_allclose(l0[1], l1[1], atol=0.05)          # dB: the first replayed step (fp32 atomics of step 1 already differ)
     np.testing.assert_allclose(l0, l1, atol=0.1)                 # dB; chaotic after a few quantized updates
     assert float((p0 - p1).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize("R,Ci,Co", [(45, 16, 24), (1000, 64, 192), (777, 256, 1024), (8500, 1024, 256), (130, 64, 512)])
+def test_qrow_kernel_exact_integer_sums(R, Ci, Co):
+    """the int8-MFMA row q-GEMM: z = dw (dx S + min_x R) + b with S an exact integer, against the same formula in fp64"""
+    from fqss_amd import kernels as K
+    w = rnd(Co, Ci, seed=51, scale=0.2).cuda()
+    lo_w, hi_w = (-(w.abs().amax(1, keepdim=True)) * 0.9), (w.abs().amax(1, keepdim=True) * 0.95)
+    wc = K.wq_codes(w, lo_w.contiguous(), hi_w.contiguous())
+    xc = torch.randint(0, 256, (R, Ci), generator=torch.Generator().manual_seed(52), dtype=torch.uint8).cuda()
+    lo, hi = torch.tensor([-1.3], device="cuda"), torch.tensor([2.1], device="cuda")
+    b = rnd(Co, seed=53).cuda()
+    z = K.qrow_fwd(xc, wc, b, lo, hi)
+    S = xc.cpu().double() @ wc.idx.cpu().double().T
+    dx = (hi.cpu() - lo.cpu()) / 255.0
+    ref = wc.dw.cpu().double() * (dx.double() * S + lo.cpu().double() * wc.rw.cpu().double()) + b.cpu().double()
+    close(z, ref, 2e-6)
+    assert torch.equal(wc.rw.cpu(), wc.idx.cpu().float().sum(1))
+    # and it agrees with the fp32-equivalent GEMM on the de-quantised operands
+    x = dx.cuda() * xc.float() + lo
+    wq = wc.dw[:, None] * wc.idx.float()
+    close(z, K.rowlin_fwd(x, wq.contiguous(), b), 2e-5)
