@@ -97,6 +97,9 @@ _PROTOS = {
     "fqss_div_bwd": [P, P, P, P, P, I64, P],
     "fqss_embedding_fwd": [P, P, P, I64, I32, I64, P],
     "fqss_embedding_bwd": [P, P, P, I64, I32, I64, P],
+    "fqss_frames_gather": [P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
+    "fqss_frames_ola": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
+    "fqss_chan_sum": [P, P, I64, I64, I64, I64, P],
 }
 _RESTYPE = {"fqss_last_error": C.c_char_p}
 

@@ -1,0 +1,127 @@
+// conv_frames.hip -- frame gather / overlap-add kernels of the general (strided, dilated, zero-padded) convolutions of the
+// HTDemucs layers: Conv1d k8 s4 p2 and the dilated k3 convs of DConv (hdemucsq.py:72-162, demucsq.py:110-182),
+// Conv2d (8,1)/(4,1) along frequency and the 3x3 `rewrite` convs of the decoder (hdemucsq.py:261-347), and their transposed forms.
+//
+// A convolution is   frames = gather(x)  ->  pointwise GEMM (the existing fqss_pwconv_* / q-GEMM kernels)  and a transposed
+// convolution is   pointwise GEMM -> overlap-add(frames); each of the two data movements is the other's adjoint, so the four
+// passes (conv fwd / bwd-data, convT fwd / bwd-data) need exactly these two kernels.  Both are pure HBM streams:
+//   * k_frames_gather : one thread per FRAME element, consecutive lanes walk the innermost (time) axis of the output, so the
+//     store is fully coalesced and the loads are unit-stride (stride s_w for a strided 1-D conv; the k/s-fold re-read of a
+//     tap row comes from L2);
+//   * k_frames_ola    : one thread per SIGNAL element gathers its <= ceil(kh/sh)*ceil(kw/sw) contributing frame elements in a
+//     fixed order (tap row ascending, tap column ascending): the overlap-add is deterministic, no atomics.
+#include "fqss_dev.h"
+
+namespace fqss {
+
+struct FrameGeom {
+    int64_t B, C, H, W;          // the signal [B][C][H][W]
+    int64_t sb, sc, sh_;         // its strides in elements (unit stride along W)
+    int kh, kw, st_h, st_w, ph, pw, dh, dw;
+    int64_t Ho, Wo, ld;          // frames [B][C*kh*kw][Ho*Wo], row stride ld
+};
+
+__global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__ x, float* __restrict__ f, const FrameGeom g) {
+    const int64_t M = g.Ho * g.Wo, rows = g.B * g.C * g.kh * g.kw;
+    const int64_t total = rows * M;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i % M, r = i / M;
+        const int64_t wo = m % g.Wo, ho = m / g.Wo;
+        const int j = (int)(r % g.kw);
+        const int64_t r1 = r / g.kw;
+        const int ti = (int)(r1 % g.kh);
+        const int64_t bc = r1 / g.kh, c = bc % g.C, b = bc / g.C;
+        const int64_t h = ho * g.st_h - g.ph + (int64_t)ti * g.dh, w = wo * g.st_w - g.pw + (int64_t)j * g.dw;
+        float v = 0.0f;
+        if (h >= 0 && h < g.H && w >= 0 && w < g.W) v = x[b * g.sb + c * g.sc + h * g.sh_ + w];
+        f[r * g.ld + m] = v;
+    }
+}
+
+// y[b][c][h][w] = bias[c] + sum over taps (ti, j) with (h + ph - ti*dh) = ho*st_h, (w + pw - j*dw) = wo*st_w in range
+__global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
+                                                     const FrameGeom g) {
+    const int64_t M = g.Ho * g.Wo;
+    const int64_t total = g.B * g.C * g.H * g.W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t w = i % g.W, r0 = i / g.W, h = r0 % g.H, bc = r0 / g.H, c = bc % g.C, b = bc / g.C;
+        float acc = 0.0f;
+        for (int ti = 0; ti < g.kh; ++ti) {
+            const int64_t hn = h + g.ph - (int64_t)ti * g.dh;
+            if (hn < 0 || hn % g.st_h != 0) continue;
+            const int64_t ho = hn / g.st_h;
+            if (ho >= g.Ho) continue;
+            for (int j = 0; j < g.kw; ++j) {
+                const int64_t wn = w + g.pw - (int64_t)j * g.dw;
+                if (wn < 0 || wn % g.st_w != 0) continue;
+                const int64_t wo = wn / g.st_w;
+                if (wo >= g.Wo) continue;
+                acc += f[((bc * g.kh + ti) * g.kw + j) * g.ld + ho * g.Wo + wo];
+            }
+        }
+        if (bias != nullptr) acc += bias[c];
+        y[b * g.sb + c * g.sc + h * g.sh_ + w] = acc;
+    }
+}
+
+// out[c] += sum_{b, m} g[b][c][m]  (bias gradient of a transposed convolution); one workgroup per (c, b)
+__global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, float* __restrict__ out, int64_t C, int64_t M, int64_t ld) {
+    __shared__ float smem[4];
+    const int64_t c = blockIdx.x, b = blockIdx.y;
+    const float* row = g + (b * C + c) * ld;
+    float v[1] = {0.0f};
+    for (int64_t m = threadIdx.x; m < M; m += 256) v[0] += row[m];
+    block_sum<float, 1>(v, smem);
+    if (threadIdx.x == 0) atomicAdd(out + c, v[0]);
+}
+
+static int check_geom(const FrameGeom& g) {
+    FQSS_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0, "empty signal");
+    FQSS_REQUIRE(g.kh >= 1 && g.kw >= 1 && g.st_h >= 1 && g.st_w >= 1 && g.dh >= 1 && g.dw >= 1 && g.ph >= 0 && g.pw >= 0, "bad geometry");
+    FQSS_REQUIRE(g.Ho == (g.H + 2 * g.ph - (int64_t)g.dh * (g.kh - 1) - 1) / g.st_h + 1 && g.Ho >= 1, "Ho does not match the geometry");
+    FQSS_REQUIRE(g.Wo == (g.W + 2 * g.pw - (int64_t)g.dw * (g.kw - 1) - 1) / g.st_w + 1 && g.Wo >= 1, "Wo does not match the geometry");
+    FQSS_REQUIRE(g.H + 2 * g.ph >= (int64_t)g.dh * (g.kh - 1) + 1 && g.W + 2 * g.pw >= (int64_t)g.dw * (g.kw - 1) + 1, "signal shorter than the kernel");
+    FQSS_REQUIRE(g.ld >= g.Ho * g.Wo && g.sh_ >= g.W && g.sc >= g.sh_ * (g.H - 1) + g.W && g.sb >= g.sc * (g.C - 1) + g.W, "bad strides");
+    return FQSS_OK;
+}
+
+static inline unsigned stream_grid(int64_t n) {
+    int64_t b = cdiv(n, 256 * 4);
+    if (b < 1) b = 1;
+    if (b > 65536) b = 65536;
+    return (unsigned)b;
+}
+
+}  // namespace fqss
+
+using namespace fqss;
+
+#define FQSS_GEOM_ARGS                                                                                                               \
+    int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh, int kh, int kw, int st_h, int st_w, int ph, int pw, \
+        int dh, int dw, int64_t Ho, int64_t Wo, int64_t ld
+#define FQSS_GEOM_INIT \
+    FrameGeom g{B, C, H, W, sb, sc, sh, kh, kw, st_h, st_w, ph, pw, dh, dw, Ho, Wo, ld}
+
+extern "C" int fqss_frames_gather(const float* x, float* frames, FQSS_GEOM_ARGS, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && frames, "null pointer");
+    FQSS_GEOM_INIT;
+    if (int rc = check_geom(g)) return rc;
+    const int64_t n = B * C * kh * kw * Ho * Wo;
+    hipLaunchKernelGGL(k_frames_gather, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, x, frames, g);
+    return launch_status("fqss_frames_gather");
+}
+
+extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y, FQSS_GEOM_ARGS, fqss_stream_t stream) {
+    FQSS_REQUIRE(y && frames, "null pointer");
+    FQSS_GEOM_INIT;
+    if (int rc = check_geom(g)) return rc;
+    hipLaunchKernelGGL(k_frames_ola, dim3(stream_grid(B * C * H * W)), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+    return launch_status("fqss_frames_ola");
+}
+
+extern "C" int fqss_chan_sum(const float* g, float* out, int64_t B, int64_t C, int64_t M, int64_t ld, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && out, "null pointer");
+    FQSS_REQUIRE(B > 0 && C > 0 && M > 0 && ld >= M && B <= 65535, "bad shape");
+    hipLaunchKernelGGL(k_chan_sum, dim3((unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, g, out, C, M, ld);
+    return launch_status("fqss_chan_sum");
+}

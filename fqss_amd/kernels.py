@@ -1019,3 +1019,76 @@ def qrow_fwd(xc, wc, bias, qmin_x, qmax_x, out=None):
     _lib.call("fqss_qrow_fwd", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias), _p(qmin_x), _p(qmax_x), _p(z), rm[0], Ci, Co, rm[2],
               ld_z, _stream())
     return z
+
+
+# ------------------------------------------------------------------ general convolution geometry (HTDemucs layers)
+class ConvGeom:
+    """kernel / stride / zero padding / dilation of a 2-D convolution over [B, C, H, W] (1-D convs run with H = 1)"""
+    __slots__ = ("kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw")
+
+    def __init__(self, k, s=(1, 1), p=(0, 0), d=(1, 1)):
+        (self.kh, self.kw), (self.sh, self.sw), (self.ph, self.pw), (self.dh, self.dw) = k, s, p, d
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.ph - self.dh * (self.kh - 1) - 1) // self.sh + 1,
+                (W + 2 * self.pw - self.dw * (self.kw - 1) - 1) // self.sw + 1)
+
+    def args(self):
+        return (self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, self.dh, self.dw)
+
+
+def empty_sig(shape, device):
+    """[B, C, H, W] signal whose (H*W) planes are dense and padded to 16 floats: viewable as [B, C, H*W] rows"""
+    B, C, H, W = shape
+    return empty_act((B, C, H * W), device).view(B, C, H, W)
+
+
+def _sig4(x):
+    """-> (x, sb, sc, sh) of a [B, C, H, W] signal with unit W stride and non-overlapping planes; foreign layouts are copied"""
+    assert x.dim() == 4, "expected [B, C, H, W]"
+    B, C, H, W = x.shape
+    st = x.stride()
+    ok = (st[3] == 1 or W == 1) and (H == 1 or st[2] >= W) and (C == 1 or st[1] >= (st[2] * (H - 1) if H > 1 else 0) + W) \
+        and (B == 1 or st[0] >= (st[1] * (C - 1) if C > 1 else 0) + W)
+    if not ok:
+        c = empty_sig((B, C, H, W), x.device)
+        c.copy_(x)
+        x, st = c, c.stride()
+    sh = st[2] if H > 1 else W
+    sc = st[1] if C > 1 else sh * (H - 1) + W
+    sb = st[0] if B > 1 else sc * (C - 1) + W
+    return x, sb, sc, sh
+
+
+def frames_gather(x, geom):
+    """x [B, C, H, W] -> frames [B, C*kh*kw, Ho*Wo] (rows padded to 16 floats), Ho, Wo"""
+    _need_gpu(x)
+    B, C, H, W = x.shape
+    Ho, Wo = geom.out_hw(H, W)
+    if Ho < 1 or Wo < 1:
+        raise ValueError(f"convolution input {H}x{W} is shorter than the kernel")
+    x, sb, sc, sh = _sig4(x)
+    f = empty_act((B, C * geom.kh * geom.kw, Ho * Wo), x.device)
+    _lib.call("fqss_frames_gather", _p(x), _p(f), B, C, H, W, sb, sc, sh, *geom.args(), Ho, Wo, rowmat(f)[2], _stream())
+    return f, Ho, Wo
+
+
+def frames_ola(frames, bias, sig_shape, geom):
+    """adjoint of frames_gather (+ per-channel bias): frames [B, C*kh*kw, Ho*Wo] -> y [B, C, H, W]"""
+    _need_gpu(frames, bias)
+    B, C, H, W = sig_shape
+    Ho, Wo = geom.out_hw(H, W)
+    frames, Bf, R, M, ld = _bcm(frames)
+    assert Bf == B and R == C * geom.kh * geom.kw and M == Ho * Wo, "frames do not match the signal shape / geometry"
+    y = empty_sig((B, C, H, W), frames.device)
+    _, sb, sc, sh = _sig4(y)
+    _lib.call("fqss_frames_ola", _p(frames), _p(bias), _p(y), B, C, H, W, sb, sc, sh, *geom.args(), Ho, Wo, ld, _stream())
+    return y
+
+
+def chan_sum(g, out):
+    """out[C] += sum over batch and positions of g [B, C, M]"""
+    _need_gpu(g, out)
+    g, B, C, M, ld = _bcm(g)
+    assert out.numel() == C and out.is_contiguous()
+    _lib.call("fqss_chan_sum", _p(g), _p(out), B, C, M, ld, _stream())

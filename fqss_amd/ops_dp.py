@@ -432,3 +432,40 @@ class EmbeddingRows(Function):
         gw, direct = _param_grad(ctx.w, ctx.w)
         K.embedding_bwd(g, idx, gw)
         return (None if direct else gw), None
+
+
+# ----------------------------------------------------------------------------------------------
+# general convolution geometry (HTDemucs layers): the frame gather and its adjoint
+# ----------------------------------------------------------------------------------------------
+class FramesGather(Function):
+    """x [B, C, H, W] -> frames [B, C*kh*kw, Ho*Wo]; followed by a pointwise GEMM this is nn.Conv1d / nn.Conv2d (groups = 1)"""
+
+    @staticmethod
+    def forward(ctx, x, geom):
+        ctx.geom, ctx.shape = geom, tuple(x.shape)
+        f, _, _ = K.frames_gather(x, geom)
+        return f
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.frames_ola(g, None, ctx.shape, ctx.geom), None
+
+
+class FramesOla(Function):
+    """frames [B, C*kh*kw, Ho*Wo] (+ bias [C]) -> y [B, C, H, W]: the overlap-add half of nn.ConvTranspose1d / 2d"""
+
+    @staticmethod
+    def forward(ctx, frames, bias, sig_shape, geom):
+        ctx.geom, ctx.bias = geom, bias
+        return K.frames_ola(frames, bias, sig_shape, geom)
+
+    @staticmethod
+    def backward(ctx, g):
+        gb = None
+        if ctx.bias is not None and ctx.needs_input_grad[1]:
+            buf, direct = _param_grad(ctx.bias, ctx.bias)
+            B, C, H, W = g.shape
+            K.chan_sum(g.reshape(B, C, H * W), buf)
+            gb = None if direct else buf
+        gf, _, _ = K.frames_gather(g, ctx.geom)
+        return gf, gb, None, None

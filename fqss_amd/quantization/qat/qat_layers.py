@@ -179,8 +179,10 @@ def conv1d_geometry(conv):
         return ops._Lin("pw")
     if g == conv.in_channels == conv.out_channels and s == 1 and 2 * p == d * (k - 1):
         return ops._Lin("dw", dil=d, pad=p)
-    if g == 1 and p == 0 and d == 1 and k > 1 and k % s == 0:
+    if g == 1 and p == 0 and d == 1 and k > 1 and k % s == 0 and conv.in_channels <= 2 and k in (2, 16, 32):
         return ops._Lin("frames", stride=s)
+    if g == 1:
+        return ops._Lin("gather", stride=s, dil=d, pad=p)    # general geometry: frame gather + pointwise GEMM (conv_frames)
     raise NotImplementedError(f"Conv1d(k={k}, s={s}, p={p}, d={d}, groups={g}) has no HIP kernel")
 
 
@@ -192,6 +194,8 @@ def run_conv1d(conv, x, weight, nl, aq):
         z = run_conv1d(conv, x, weight, None, None)
         return fq_node(aq, apply_map(nl, ops.real(z)))
     L = conv1d_geometry(conv)
+    if L.kind == "gather":
+        return fq_node(aq, conv_frames(conv, x, weight), nl)
     act, slope = _act_of(nl)
     L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, slope
     q = aq.qctx() if aq is not None else ops.BYPASS
@@ -205,6 +209,63 @@ def run_conv1d(conv, x, weight, nl, aq):
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)
+
+
+def _pair(v):
+    return (1, v[0]) if len(v) == 1 else tuple(v)
+
+
+def _conv_geom(conv, one_d):
+    """ConvGeom of an nn.Conv1d / Conv2d / ConvTranspose1d / 2d (1-D layers run as [B, C, 1, T])"""
+    if conv.groups != 1 or conv.padding_mode != "zeros" or isinstance(conv.padding, str):
+        raise NotImplementedError(f"{type(conv).__name__}: only groups = 1 with explicit zero padding has a HIP path")
+    pad = (0, conv.padding[0]) if one_d else tuple(conv.padding)
+    return K.ConvGeom(_pair(conv.kernel_size), _pair(conv.stride) if not one_d else (1, conv.stride[0]), pad,
+                      _pair(conv.dilation) if not one_d else (1, conv.dilation[0]))
+
+
+def conv_frames(conv, x, weight):
+    """nn.Conv1d / nn.Conv2d (groups = 1, any kernel / stride / dilation / zero padding) of the HTDemucs layers (DConv's dilated k3
+    convs, the k8 s4 encoders, Conv2d (8,1) along frequency, the 3x3 decoder rewrites; hdemucsq.py:72-162, 261-347,
+    demucsq.py:110-182): frame gather (fqss_frames_gather) + the pointwise GEMM kernels over Ci*kh*kw channels; the data
+    gradient is the overlap-add (fqss_frames_ola) of the GEMM's.  Returns the float conv output, same rank as x."""
+    x = ops.real(x)
+    one_d = x.dim() == 3
+    geom = _conv_geom(conv, one_d)
+    x4 = x.unsqueeze(2) if one_d else x
+    B, C, H, W = x4.shape
+    Ho, Wo = geom.out_hw(H, W)
+    if geom.args() == (1, 1, 1, 1, 0, 0, 1, 1):
+        cols = x4.reshape(B, C, H * W)
+    else:
+        cols = ops_dp.FramesGather.apply(x4, geom)
+    Co = conv.out_channels
+    ops_dp.touch(weight)
+    L = ops._Lin("pw", b_param=conv.bias)
+    z = ops.LinearActQ.apply(cols, weight.reshape(Co, -1, 1), conv.bias, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
+    z = z.reshape(B, Co, Ho, Wo)
+    return z.squeeze(2) if one_d else z
+
+
+def convtr_frames(convtr, x, weight):
+    """nn.ConvTranspose1d / 2d (groups = 1): pointwise GEMM with the [Co*kh*kw, Ci] transposed weight, then the deterministic
+    overlap-add fqss_frames_ola (+ bias).  hdemucsq.py:303-347 (`conv_tr`), qat_layers.py:296-435.  Returns the float output."""
+    x = ops.real(x)
+    one_d = x.dim() == 3
+    geom = _conv_geom(convtr, one_d)
+    x4 = x.unsqueeze(2) if one_d else x
+    B, Ci, Hi, Wi = x4.shape
+    op = (0, convtr.output_padding[0]) if one_d else tuple(convtr.output_padding)
+    H = (Hi - 1) * geom.sh - 2 * geom.ph + geom.dh * (geom.kh - 1) + op[0] + 1
+    W = (Wi - 1) * geom.sw - 2 * geom.pw + geom.dw * (geom.kw - 1) + op[1] + 1
+    if geom.out_hw(H, W) != (Hi, Wi):
+        raise ValueError("ConvTranspose: output_padding must be smaller than the stride")
+    Co = convtr.out_channels
+    ops_dp.touch(weight)
+    wt = weight.reshape(Ci, -1).t().contiguous().unsqueeze(-1)           # [Co*kh*kw, Ci, 1]: a transposing copy of the (small) weight
+    frames = ops.LinearActQ.apply(x4.reshape(B, Ci, Hi * Wi), wt, None, None, None, None, ops._Lin("pw"), ops.ACT_NONE, ops.BYPASS)
+    y = ops_dp.FramesOla.apply(frames, convtr.bias, (B, Co, H, W), geom)
+    return y.squeeze(2) if one_d else y
 
 
 def run_conv1d_pair(l1, l2, x, sole_ew_consumers=False):
@@ -498,6 +559,8 @@ def _flat2d(t):
 def fq_node(aq, x, nl=None, codes=False):
     """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl.
     codes=True: also emit the u8 codes and tag the result with them (the consumer is a row linear that can run on codes)"""
+    if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
+        x, nl = apply_map(nl, ops.real(x)), None
     act, slope = _act_of(nl)
     q = aq.qctx() if aq is not None else ops.BYPASS
     if q.qmode == ops.Q_BYPASS and act == ops.ACT_NONE:
@@ -587,18 +650,21 @@ class Conv2dQ(LayerQ):
 
     def __init__(self, conv2d, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
         _expect(conv2d, nn.Conv2d, "Conv2d")
-        if conv2d.kernel_size != (1, 1) or conv2d.stride != (1, 1) or conv2d.padding != (0, 0) or conv2d.groups != 1:
-            raise NotImplementedError("Conv2dQ: only the 1x1 convolution of the dual-path output layer has HIP kernels")
+        self._is_1x1 = conv2d.kernel_size == (1, 1) and conv2d.stride == (1, 1) and conv2d.padding == (0, 0) and conv2d.groups == 1
         super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
                          weight_shape=conv2d.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
         self.conv2d = conv2d
 
     def forward_rows(self, x):
         c = self.conv2d
+        if not self._is_1x1:
+            raise NotImplementedError("Conv2dQ.forward_rows: only the 1x1 convolution runs on row-major tensors")
         w = self._wq(c.weight).view(c.out_channels, c.in_channels)
         return fq_node(self.activation_fake_quantize, ops_dp.RowLinear.apply(ops.real(x), w, c.bias))
 
     def forward(self, x):
+        if not self._is_1x1:
+            return fq_node(self.activation_fake_quantize, conv_frames(self.conv2d, x, self._wq(self.conv2d.weight)))
         return run_conv2d_1x1(self.conv2d, x, self._wq(self.conv2d.weight), self.activation_fake_quantize)
 
 
@@ -766,6 +832,24 @@ class EmbeddingQ(LayerQ):
         return fq_node(self.activation_fake_quantize, ops_dp.EmbeddingRows.apply(self._wq(self.embedding.weight), x))
 
 
+class Conv1dGnNlQ(LayerQ):
+    """fq(nl(GroupNorm(conv1d(x))))  (qat_layers.py:222-259; DConv of the HTDemucs layers, demucsq.py:163-169)"""
+
+    def __init__(self, conv1d, gn, nl, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(conv1d, nn.Conv1d, "Conv1d")
+        _expect(gn, nn.GroupNorm, "GroupNorm")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=conv1d.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.conv1d = conv1d
+        self.gn = gn
+        self.nl = nl
+
+    def forward(self, x):
+        y = run_conv1d(self.conv1d, x, self._wq(self.conv1d.weight), None, None)
+        z = run_groupnorm(self.gn, y, None)
+        return fq_node(self.activation_fake_quantize, z, self.nl)
+
+
 # ---------------------------------------------------------------------------------------------
 # layers of the later §8 rows: constructing them fails loudly (no ATen fallback)
 # ---------------------------------------------------------------------------------------------
@@ -777,12 +861,59 @@ def _later_row(name, row):
     return _Unbuilt
 
 
-Conv1dGnNlQ = _later_row("Conv1dGnNlQ", "a15")
-Conv2dNlQ = _later_row("Conv2dNlQ", "a15")
-ConvTranspose1dQ = _later_row("ConvTranspose1dQ", "a15")
-ConvTranspose2dQ = _later_row("ConvTranspose2dQ", "a15")
-ConvTranspose1dNlQ = _later_row("ConvTranspose1dNlQ", "a15")
-ConvTranspose2dNlQ = _later_row("ConvTranspose2dNlQ", "a15")
+class Conv2dNlQ(LayerQ):
+    """fq(nl(conv2d(x)))  (qat_layers.py:261-293; the frequency-branch encoder / rewrite convs of HTDemucs)"""
+
+    def __init__(self, conv2d, nl, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(conv2d, nn.Conv2d, "Conv2d")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=conv2d.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.conv2d = conv2d
+        self.nl = nl
+
+    def forward(self, x):
+        return fq_node(self.activation_fake_quantize, conv_frames(self.conv2d, x, self._wq(self.conv2d.weight)), self.nl)
+
+
+class _ConvTrQ(LayerQ):
+    """fq(nl(conv_transpose(x)))  (qat_layers.py:296-435): per-channel weight ranges along dim 1 (ch_out_idx = 1)"""
+    _attr, _typ = None, None
+
+    def __init__(self, convtr, nl=None, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        _expect(convtr, self._typ, self._typ.__name__)
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=convtr.weight.shape, ch_out_idx=1, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        setattr(self, self._attr, convtr)
+        if self._has_nl:
+            self.nl = nl
+
+    def forward(self, x):
+        c = getattr(self, self._attr)
+        return fq_node(self.activation_fake_quantize, convtr_frames(c, x, self._wq(c.weight)), self.nl if self._has_nl else None)
+
+
+class ConvTranspose1dQ(_ConvTrQ):
+    _attr, _typ, _has_nl = "convTr1d", nn.ConvTranspose1d, False
+
+    def __init__(self, convTr1d, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        super().__init__(convTr1d, None, gradient_based, weight_quant, act_quant, act_n_bits, weight_n_bits)
+
+
+class ConvTranspose2dQ(_ConvTrQ):
+    _attr, _typ, _has_nl = "convTr2d", nn.ConvTranspose2d, False
+
+    def __init__(self, convTr2d, gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8):
+        super().__init__(convTr2d, None, gradient_based, weight_quant, act_quant, act_n_bits, weight_n_bits)
+
+
+class ConvTranspose1dNlQ(_ConvTrQ):
+    _attr, _typ, _has_nl = "convTr1d", nn.ConvTranspose1d, True
+
+
+class ConvTranspose2dNlQ(_ConvTrQ):
+    _attr, _typ, _has_nl = "convTr2d", nn.ConvTranspose2d, True
+
+
 BatchNormQ = _later_row("BatchNormQ", "a15")
 Conv2dEncoderQ = _later_row("Conv2dEncoderQ", "a15")
 ConvTr2dDecoderQ = _later_row("ConvTr2dDecoderQ", "a15")

@@ -487,6 +487,22 @@ int fqss_div_bwd(const float* g, const float* a, const float* b, float* ga, floa
 int fqss_embedding_fwd(const float* w, const int64_t* idx, float* out, int64_t n, int D, int64_t V, fqss_stream_t stream);
 int fqss_embedding_bwd(const float* g, const int64_t* idx, float* gw, int64_t n, int D, int64_t V, fqss_stream_t stream);
 
+/* General convolution geometry of the HTDemucs layers: frames of a [B][C][H][W] signal (strides sb, sc, sh in
+ * elements, unit stride along W) for a kernel (kh, kw), stride (st_h, st_w), zero padding (ph, pw), dilation (dh, dw):
+ *   frames[b][(c*kh + i)*kw + j][ho*Wo + wo] = x[b][c][ho*st_h - ph + i*dh][wo*st_w - pw + j*dw]   (0 outside), row stride ld.
+ * fqss_frames_gather followed by a pointwise GEMM over C*kh*kw channels IS nn.Conv1d / nn.Conv2d with groups = 1
+ * (replaces F.conv1d / F.conv2d in Conv1dQ / Conv1dNlQ / Conv2dNlQ / Conv1dGnNlQ / Conv*EncoderQ, qat_layers.py:124-259, 262-300);
+ * fqss_frames_ola is its adjoint (deterministic gather-form overlap-add, optional per-channel bias): a pointwise GEMM followed
+ * by it IS nn.ConvTranspose1d / 2d (ConvTranspose*NlQ, ConvTr2dDecoderQ, qat_layers.py:303-435), and it is the data gradient of
+ * the convolution.  fqss_chan_sum: out[c] += sum_{b,m} g[b][c][m] (bias gradient of the transposed convolutions).           */
+int fqss_frames_gather(const float* x, float* frames, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh,
+                       int kh, int kw, int st_h, int st_w, int ph, int pw, int dh, int dw, int64_t Ho, int64_t Wo, int64_t ld,
+                       fqss_stream_t stream);
+int fqss_frames_ola(const float* frames, const float* bias, float* y, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc,
+                    int64_t sh, int kh, int kw, int st_h, int st_w, int ph, int pw, int dh, int dw, int64_t Ho, int64_t Wo, int64_t ld,
+                    fqss_stream_t stream);
+int fqss_chan_sum(const float* g, float* out, int64_t B, int64_t C, int64_t M, int64_t ld, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,10 @@ def mha_core(q, k, v, nhead):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+NL_MAPS = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": F.relu, "gelu": F.gelu, "glu": (lambda t: F.glu(t, 1)),
+           None: (lambda t: t)}
+
+
 class DQTable(QTable):
     """QTable whose quantizer discovery also knows the dual-path layers' extra quantizers: any range parameter of rank >= 2
     is a per-channel weight range (axis 0, or 1 for transposed convs), rank-1 ranges are activation ranges."""
@@ -136,7 +140,7 @@ class DQTable(QTable):
                 owner = pre.rsplit(".", 1)[0] + "."
                 # ch_out_idx = 1 for transposed convs: the decoder (qat_layers.py:1317) and, with train_res_dec, the residual
                 # decoder's own quantizer (qat_layers.py:1141-1145)
-                axis = 1 if ((owner + "convTr1d.weight") in self.p and pre.endswith(".weight_fake_quantize")) or \
+                axis = 1 if (((owner + "convTr1d.weight") in self.p or (owner + "convTr2d.weight") in self.p) and pre.endswith(".weight_fake_quantize")) or \
                     (pre.endswith(".weight_fake_quantize_dec") and self.p.get(owner + "residual_decoder.weight", torch.zeros(1)).dim() == 3) else 0
                 self.wq[pre] = WeightRange(self.p, pre, axis)
             else:
@@ -191,12 +195,30 @@ class DQTable(QTable):
         w = self._W(name, self.p[name + ".conv2d.weight"])
         return self._A(name, F.conv2d(x, w, self.p.get(name + ".conv2d.bias")))
 
-    def conv1d_nl_q(self, name, x, nl):
+    def conv1d_nl_q(self, name, x, nl, **geom):
+        """Conv1dQ / Conv1dNlQ (qat_layers.py:124-153); geom = stride / padding / dilation of the wrapped nn.Conv1d"""
         w = self._W(name, self.p[name + ".conv1d.weight"])
-        y = F.conv1d(x, w, self.p.get(name + ".conv1d.bias"))
-        y = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": F.relu, "gelu": F.gelu, "glu": (lambda t: F.glu(t, 1)),
-             None: (lambda t: t)}[nl](y)
-        return self._A(name, y)
+        y = F.conv1d(x, w, self.p.get(name + ".conv1d.bias"), **geom)
+        return self._A(name, NL_MAPS[nl](y))
+
+    def conv1d_gn_nl_q(self, name, x, nl, groups=1, eps=1e-5, **geom):
+        """Conv1dGnNlQ (qat_layers.py:222-259): fq(nl(GroupNorm(conv1d(x, fq_w(W))))), one activation quantizer at the end"""
+        w = self._W(name, self.p[name + ".conv1d.weight"])
+        y = F.conv1d(x, w, self.p.get(name + ".conv1d.bias"), **geom)
+        y = F.group_norm(y, groups, self.p[name + ".gn.weight"], self.p[name + ".gn.bias"], eps)
+        return self._A(name, NL_MAPS[nl](y))
+
+    def conv2d_nl_q(self, name, x, nl, **geom):
+        """Conv2dQ / Conv2dNlQ (qat_layers.py:156-186, 261-293)"""
+        w = self._W(name, self.p[name + ".conv2d.weight"])
+        return self._A(name, NL_MAPS[nl](F.conv2d(x, w, self.p.get(name + ".conv2d.bias"), **geom)))
+
+    def convtr_nl_q(self, name, x, nl, **geom):
+        """ConvTranspose1d/2d(Nl)Q (qat_layers.py:296-435): weight ranges per OUTPUT channel = dim 1 of the [Ci, Co, k..] weight"""
+        key = name + (".convTr1d" if x.dim() == 3 else ".convTr2d")
+        w = self._W(name, self.p[key + ".weight"])
+        fn = F.conv_transpose1d if x.dim() == 3 else F.conv_transpose2d
+        return self._A(name, NL_MAPS[nl](fn(x, w, self.p.get(key + ".bias"), **geom)))
 
     # -- first layers of cfg 5 (HTDemucs, SURVEY §8 row a15) -----------------------------------------------------------
     def linear_nl_q(self, name, x, nl):

@@ -556,10 +556,37 @@ def _hd_layer(name, sd):
         return QL.Conv1dNlQ(nn.Conv1d(ci, co, 1), nn.GLU(dim=1), **P)
     if name == "divq":
         return QL.DivQ(QL.Div(), **A)
+    if name == "conv1dq_k3_d2":
+        co, ci, k = shp("conv1d.weight")
+        return QL.Conv1dQ(nn.Conv1d(ci, co, k, dilation=2, padding=2), **P)
+    if name == "conv1dnlq_k8_s4_gelu":
+        co, ci, k = shp("conv1d.weight")
+        return QL.Conv1dNlQ(nn.Conv1d(ci, co, k, stride=4, padding=2), nn.GELU(), **P)
+    if name in ("conv1dgnnlq_gelu", "conv1dgnnlq_glu"):
+        co, ci, k = shp("conv1d.weight")
+        return QL.Conv1dGnNlQ(nn.Conv1d(ci, co, k, padding=k // 2), nn.GroupNorm(1, co), nn.GELU() if name.endswith("gelu") else nn.GLU(1), **P)
+    if name == "conv2dnlq_k8_s4_gelu":
+        co, ci = shp("conv2d.weight")[:2]
+        return QL.Conv2dNlQ(nn.Conv2d(ci, co, (8, 1), (4, 1), (2, 0)), nn.GELU(), **P)
+    if name in ("conv2dnlq_3x3_glu", "conv2dnlq_1x1_glu"):
+        co, ci, k, _ = shp("conv2d.weight")
+        return QL.Conv2dNlQ(nn.Conv2d(ci, co, k, 1, k // 2), nn.GLU(1), **P)
+    if name == "convtr2dnlq_k8_s4_gelu":
+        ci, co = shp("convTr2d.weight")[:2]
+        return QL.ConvTranspose2dNlQ(nn.ConvTranspose2d(ci, co, (8, 1), (4, 1)), nn.GELU(), **P)
+    if name == "convtr1dnlq_k8_s4_gelu":
+        ci, co = shp("convTr1d.weight")[:2]
+        return QL.ConvTranspose1dNlQ(nn.ConvTranspose1d(ci, co, 8, 4), nn.GELU(), **P)
+    if name == "convtr1dq_k5_s3_p1":
+        ci, co = shp("convTr1d.weight")[:2]
+        return QL.ConvTranspose1dQ(nn.ConvTranspose1d(ci, co, 5, 3, padding=1, output_padding=2), **P)
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["linearnlq_gelu", "linearnlq_relu", "nlq_gelu", "conv1dnlq_glu", "divq"])
+@pytest.mark.parametrize("name", ["linearnlq_gelu", "linearnlq_relu", "nlq_gelu", "conv1dnlq_glu", "divq", "conv1dq_k3_d2",
+                                  "conv1dnlq_k8_s4_gelu", "conv1dgnnlq_gelu", "conv1dgnnlq_glu", "conv2dnlq_k8_s4_gelu",
+                                  "conv2dnlq_3x3_glu", "conv2dnlq_1x1_glu", "convtr2dnlq_k8_s4_gelu", "convtr1dnlq_k8_s4_gelu",
+                                  "convtr1dq_k5_s3_p1"])
 def test_htdemucs_first_layers_teacher_forced(golden, name):
     """SURVEY §8 row a15, layer level (the model is not built yet): GELU / GLU maps, LinearNlQ, DivQ against the reference"""
     g = golden("hd_layers")

@@ -468,3 +468,40 @@ def test_empty_batches_are_noops_and_bad_arguments_are_refused():
     with pytest.raises(_lib.FqssError, match="null"):
         _lib.call("fqss_qpw_fwd", P(xc), P(wc.idx), P(wc.dw), P(wc.rw), None, None, P(hi), P(z), 1, C, 32, M, 48, 48, st)
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- general convolution geometry (row a15): frame gather / overlap-add
+FRAME_CASES = [  # B, C, H, W, k, s, p, d
+    (2, 6, 1, 53, (1, 8), (1, 4), (0, 2), (1, 1)),      # time-branch encoder conv k8 s4 p2
+    (2, 6, 1, 53, (1, 3), (1, 1), (0, 2), (1, 2)),      # DConv dilated k3
+    (2, 4, 22, 7, (8, 1), (4, 1), (2, 0), (1, 1)),      # frequency-branch encoder
+    (2, 4, 22, 7, (3, 3), (1, 1), (1, 1), (1, 1)),      # decoder rewrite
+    (1, 3, 9, 11, (3, 2), (2, 3), (1, 2), (2, 1)),      # everything at once
+    (3, 5, 1, 16, (1, 1), (1, 1), (0, 0), (1, 1)),
+]
+
+
+@pytest.mark.parametrize("B,C,H,W,k,s,p,d", FRAME_CASES)
+def test_frames_gather_and_ola(B, C, H, W, k, s, p, d):
+    geom = K.ConvGeom(k, s, p, d)
+    x = rnd(B, C, H, W, seed=5)
+    want = F.unfold(x, k, dilation=d, padding=p, stride=s)                     # [B, C*kh*kw, L]
+    for conv in (lambda t: t.cuda(), lambda t: K.empty_act((B, C, H, W), "cuda").copy_(t), lambda t: K.empty_sig((B, C, H, W), "cuda").copy_(t)):
+        f, Ho, Wo = K.frames_gather(conv(x), geom)
+        assert (Ho, Wo) == geom.out_hw(H, W) and tuple(f.shape) == tuple(want.shape)
+        assert torch.equal(f.cpu(), want)                                    # a gather: bit-exact
+    fr = rnd(*want.shape, seed=6)
+    bias = rnd(C, seed=7)
+    y = K.frames_ola(padded(fr), bias.cuda(), (B, C, H, W), geom)
+    close(y, F.fold(fr, (H, W), k, dilation=d, padding=p, stride=s) + bias[None, :, None, None], rtol=1e-6, atol=1e-6)
+    y0 = K.frames_ola(fr.cuda(), None, (B, C, H, W), geom)
+    close(y0, F.fold(fr, (H, W), k, dilation=d, padding=p, stride=s), rtol=1e-6, atol=1e-6)
+    out = torch.zeros(C, device="cuda")
+    K.chan_sum(padded(x.reshape(B, C, H * W)), out)
+    close(out, x.sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+
+
+def test_frames_geometry_is_checked():
+    from fqss_amd._lib import FqssError
+    with pytest.raises((ValueError, FqssError)):
+        K.frames_gather(torch.zeros(1, 2, 1, 3, device="cuda"), K.ConvGeom((1, 8), (1, 4)))

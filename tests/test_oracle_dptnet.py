@@ -82,6 +82,16 @@ def test_htdemucs_first_layer_fixtures(golden):
     run(g, "nlq_gelu", lambda t, x: t._A("L", torch.nn.functional.gelu(x)))
     run(g, "conv1dnlq_glu", lambda t, x: t.conv1d_nl_q("L", x, "glu"))
     run(g, "divq", lambda t, a, b: t.div_q("L", a, b))
+    run(g, "conv1dq_k3_d2", lambda t, x: t.conv1d_nl_q("L", x, None, dilation=2, padding=2))
+    run(g, "conv1dnlq_k8_s4_gelu", lambda t, x: t.conv1d_nl_q("L", x, "gelu", stride=4, padding=2))
+    run(g, "conv1dgnnlq_gelu", lambda t, x: t.conv1d_gn_nl_q("L", x, "gelu", padding=1))
+    run(g, "conv1dgnnlq_glu", lambda t, x: t.conv1d_gn_nl_q("L", x, "glu"))
+    run(g, "conv2dnlq_k8_s4_gelu", lambda t, x: t.conv2d_nl_q("L", x, "gelu", stride=(4, 1), padding=(2, 0)))
+    run(g, "conv2dnlq_3x3_glu", lambda t, x: t.conv2d_nl_q("L", x, "glu", padding=1))
+    run(g, "conv2dnlq_1x1_glu", lambda t, x: t.conv2d_nl_q("L", x, "glu"))
+    run(g, "convtr2dnlq_k8_s4_gelu", lambda t, x: t.convtr_nl_q("L", x, "gelu", stride=(4, 1)))
+    run(g, "convtr1dnlq_k8_s4_gelu", lambda t, x: t.convtr_nl_q("L", x, "gelu", stride=4))
+    run(g, "convtr1dq_k5_s3_p1", lambda t, x: t.convtr_nl_q("L", x, None, stride=3, padding=1, output_padding=2))
     tab = D.DQTable({"L." + k: v for k, v in table(g, "embeddingq").items()})
     tab.leave_observer_phase()
     y = tab.embedding_q("L", T(g["embeddingq.idx"]))

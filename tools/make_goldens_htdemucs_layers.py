@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Golden vectors for the first LayerQ classes of SURVEY.md §8 row a15 (cfg 5: HTDemucs), generated from the REAL reference
 (layer level only: the model is not built yet).  hd_layers.npz: LinearNlQ with GELU and ReLU (qat_layers.py:539-561), NlQ(GELU),
-Conv1dNlQ 1x1 + GLU(dim=1) (the `rewrite` convs, hdemucsq.py:127, 314), DivQ, EmbeddingQ (qat_layers.py:490-508).
+Conv1dNlQ 1x1 + GLU(dim=1) (the `rewrite` convs, hdemucsq.py:127, 314), DivQ, EmbeddingQ (qat_layers.py:490-508), Conv1dQ with a
+dilated k3 kernel, Conv1dNlQ k8 s4 p2 + GELU (time-branch encoder), Conv1dGnNlQ with GELU and with GLU (DConv, demucsq.py:163-169).
 Usage: python tools/make_goldens_htdemucs_layers.py"""
 import os
 import sys
@@ -34,6 +35,30 @@ def main():
     run_layer("conv1dnlq_glu", L, [keyed_randn("hd.xc", (3, 12, 37), 0.9)], d)
     L = RL.DivQ(RL.Div(), gradient_based=True, act_quant=True)
     run_layer("divq", L, [keyed_randn("hd.num", (3, 12, 37), 0.8), keyed_randn("hd.den", (3, 12, 37), 0.3).abs() + 0.5], d)
+    # general Conv1d geometries of the HTDemucs layers and DConv's conv + GroupNorm + non-linearity blocks
+    xt = keyed_randn("hd.xt", (2, 6, 53), 0.9)
+    L = RL.Conv1dQ(nn.Conv1d(6, 10, 3, dilation=2, padding=2), **P); fill(L, "ck3.")
+    run_layer("conv1dq_k3_d2", L, [xt], d)
+    L = RL.Conv1dNlQ(nn.Conv1d(6, 10, 8, stride=4, padding=2), nn.GELU(), **P); fill(L, "ck8.")
+    run_layer("conv1dnlq_k8_s4_gelu", L, [xt], d)
+    L = RL.Conv1dGnNlQ(nn.Conv1d(6, 12, 3, dilation=1, padding=1), nn.GroupNorm(1, 12), nn.GELU(), **P); fill(L, "cgn1.")
+    run_layer("conv1dgnnlq_gelu", L, [xt], d)
+    L = RL.Conv1dGnNlQ(nn.Conv1d(6, 12, 1), nn.GroupNorm(1, 12), nn.GLU(1), **P); fill(L, "cgn2.")
+    run_layer("conv1dgnnlq_glu", L, [xt], d)
+    # 2-D convolutions along frequency, the 3x3 decoder `rewrite`, and the transposed convolutions (hdemucsq.py:96-127, 303-347)
+    xf = keyed_randn("hd.xf", (2, 4, 22, 7), 0.9)
+    L = RL.Conv2dNlQ(nn.Conv2d(4, 6, (8, 1), (4, 1), (2, 0)), nn.GELU(), **P); fill(L, "c2a.")
+    run_layer("conv2dnlq_k8_s4_gelu", L, [xf], d)
+    L = RL.Conv2dNlQ(nn.Conv2d(4, 8, 3, 1, 1), nn.GLU(1), **P); fill(L, "c2b.")
+    run_layer("conv2dnlq_3x3_glu", L, [xf], d)
+    L = RL.Conv2dNlQ(nn.Conv2d(4, 8, 1), nn.GLU(1), **P); fill(L, "c2c.")
+    run_layer("conv2dnlq_1x1_glu", L, [xf], d)
+    L = RL.ConvTranspose2dNlQ(nn.ConvTranspose2d(4, 6, (8, 1), (4, 1)), nn.GELU(), **P); fill(L, "ct2.")
+    run_layer("convtr2dnlq_k8_s4_gelu", L, [keyed_randn("hd.xg2", (2, 4, 5, 7), 0.9)], d)
+    L = RL.ConvTranspose1dNlQ(nn.ConvTranspose1d(6, 4, 8, 4), nn.GELU(), **P); fill(L, "ct1.")
+    run_layer("convtr1dnlq_k8_s4_gelu", L, [keyed_randn("hd.xg1", (2, 6, 13), 0.9)], d)
+    L = RL.ConvTranspose1dQ(nn.ConvTranspose1d(6, 4, 5, 3, padding=1, output_padding=2), **P); fill(L, "ct0.")
+    run_layer("convtr1dq_k5_s3_p1", L, [keyed_randn("hd.xg1", (2, 6, 13), 0.9)], d)
     # EmbeddingQ: integer input, so run it by hand with the same protocol as run_layer
     emb = RL.EmbeddingQ(nn.Embedding(11, 16), **P); fill(emb, "emb.")
     idx = torch.tensor([[0, 3, 10, 3], [7, 1, 1, 5]])
