@@ -247,7 +247,10 @@ def conv_frames(conv, x, weight):
     return z.squeeze(2) if one_d else z
 
 
-def convtr_frames(convtr, x, weight):
+_OWN = object()
+
+
+def convtr_frames(convtr, x, weight, bias=_OWN):
     """nn.ConvTranspose1d / 2d (groups = 1): pointwise GEMM with the [Co*kh*kw, Ci] transposed weight, then the deterministic
     overlap-add fqss_frames_ola (+ bias).  hdemucsq.py:303-347 (`conv_tr`), qat_layers.py:296-435.  Returns the float output."""
     x = ops.real(x)
@@ -264,7 +267,7 @@ def convtr_frames(convtr, x, weight):
     ops_dp.touch(weight)
     wt = weight.reshape(Ci, -1).t().contiguous().unsqueeze(-1)           # [Co*kh*kw, Ci, 1]: a transposing copy of the (small) weight
     frames = ops.LinearActQ.apply(x4.reshape(B, Ci, Hi * Wi), wt, None, None, None, None, ops._Lin("pw"), ops.ACT_NONE, ops.BYPASS)
-    y = ops_dp.FramesOla.apply(frames, convtr.bias, (B, Co, H, W), geom)
+    y = ops_dp.FramesOla.apply(frames, convtr.bias if bias is _OWN else bias, (B, Co, H, W), geom)
     return y.squeeze(2) if one_d else y
 
 
@@ -443,23 +446,25 @@ class ResidualErrorBlock(LayerQ):
                  weight_n_bits=8, train_res_dec=False):
         super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_nl_quantizer=act_nl_quantizer,
                          act_n_bits=act_n_bits)
-        if type(decoder) not in (nn.ConvTranspose1d, nn.Linear):
-            raise NotImplementedError("ResidualErrorBlock: only the ConvTranspose1d (ConvTasNet/Sepformer) and Linear (DPTNet) "
-                                      "decoders have kernels")
-        if train_res_dec and type(decoder) is not nn.ConvTranspose1d:
-            raise NotImplementedError("train_res_dec=True: only the ConvTranspose1d decoder (Sepformer) has kernels")
+        if type(decoder) not in (nn.ConvTranspose1d, nn.ConvTranspose2d, nn.Linear):
+            raise AssertionError("Not supported residual block for type {}".format(type(decoder)))
+        if train_res_dec and type(decoder) is nn.Linear:
+            raise NotImplementedError("train_res_dec=True: only the transposed-convolution decoders have kernels")
         self.decoder_type = type(decoder)
         self.train_res_dec = train_res_dec
+        self.decoder_bias = decoder.bias        # the reference registers the decoder's bias a second time (state_dict key `decoder_bias`)
         if self.decoder_type is nn.Linear:      # qat_layers.py:1111-1114
             self.residual_encoder = nn.Linear(decoder.out_features, decoder.in_features, bias=decoder.bias is not None)
             self.decoder_stride = None
         else:
-            self.residual_encoder = nn.Conv1d(decoder.out_channels, decoder.in_channels, decoder.kernel_size,
-                                              stride=decoder.stride, bias=decoder.bias is not None)
+            conv_t, convtr_t = (nn.Conv1d, nn.ConvTranspose1d) if self.decoder_type is nn.ConvTranspose1d else (nn.Conv2d, nn.ConvTranspose2d)
+            self.residual_encoder = conv_t(decoder.out_channels, decoder.in_channels, decoder.kernel_size,
+                                           stride=decoder.stride, bias=decoder.bias is not None)
             self.decoder_stride = decoder.stride
-            if train_res_dec:       # the LSB channel gets its own trainable decoder (qat_layers.py:1137-1146; Sepformer)
-                self.residual_decoder = nn.ConvTranspose1d(decoder.in_channels, decoder.out_channels, decoder.kernel_size,
-                                                           stride=decoder.stride, bias=decoder.bias is not None)
+            object.__setattr__(self, "_decoder_geom", decoder)     # geometry donor of the shared-kernel decode (NOT a submodule: no state_dict keys)
+            if train_res_dec:       # the LSB channel gets its own trainable decoder (qat_layers.py:1137-1146, 1160-1168)
+                self.residual_decoder = convtr_t(decoder.in_channels, decoder.out_channels, decoder.kernel_size,
+                                                 stride=decoder.stride, bias=decoder.bias is not None)
                 self.weight_fake_quantize_dec = (get_weight_quantizer(gradient_based, self.residual_decoder.weight.shape, ch_out_idx=1,
                                                                       n_bits=weight_n_bits) if weight_quant else nn.Identity())
         self.weight_fake_quantize = (get_weight_quantizer(gradient_based, self.residual_encoder.weight.shape, n_bits=weight_n_bits)
@@ -476,6 +481,8 @@ class ResidualErrorBlock(LayerQ):
             Y1 = ops.AddActQ.apply(ops.real(Y), Y_q, q.qmin, q.qmax, -1.0, q)
             aq.after_forward(q)
             return ops_dp.RowLinear.apply(Y1, w_decoder, None)
+        if self.decoder_type is nn.ConvTranspose2d or not _is_mono_decoder(self._decoder_geom):
+            return self._forward_general(Y, y_q, w_decoder, out_quantizer)
         Y_q = run_conv1d(enc, y_q, self._wq(enc.weight), None, None)
         aq = self.activation_fake_quantize
         q = aq.qctx()
@@ -493,10 +500,38 @@ class ResidualErrorBlock(LayerQ):
         return run_convtr1d(decoder_conv, Y1, w_decoder, out_quantizer)
 
 
+    def _forward_general(self, Y, y_q, w_decoder, out_quantizer):
+        """stereo / biased / 2-D decoders of HTDemucs (qat_layers.py:1189-1216): the same sequence over the frame kernels.
+        Quirks kept: the residual encoder ignores the decoder's padding; the 1-D decode drops the bias, the 2-D decode uses
+        `residual_decoder.bias` (so the 2-D form needs train_res_dec=True, as the reference does)"""
+        enc, dec = self.residual_encoder, self._decoder_geom
+        Y_q = conv_frames(enc, y_q, self._wq(enc.weight))
+        Y = ops.real(Y)
+        shp = Y.shape
+        aq = self.activation_fake_quantize
+        q = aq.qctx()
+        Y1 = ops.tag_codes(ops.ew_layer(Y.reshape(shp[0], shp[1], -1), Y_q.reshape(shp[0], shp[1], -1), -1.0, ops.ACT_NONE, None, q), q)
+        aq.after_forward(q)
+        Y1 = ops.real(Y1).reshape(shp)
+        if self.decoder_type is nn.ConvTranspose2d:
+            if not self.train_res_dec:
+                raise AttributeError("'ResidualErrorBlock' object has no attribute 'residual_decoder'")     # qat_layers.py:1209
+            bias = self.residual_decoder.bias
+        else:
+            bias = None
+        w = self.weight_fake_quantize_dec(self.residual_decoder.weight) if self.train_res_dec else w_decoder
+        return fq_node(out_quantizer, convtr_frames(dec, Y1, w, bias=bias))
+
+
+def _is_mono_decoder(convtr):
+    """the ConvTasNet / Sepformer waveform decoder served by the dedicated overlap-add kernel (fqss_ola_convtr_fwd)"""
+    return isinstance(convtr, nn.ConvTranspose1d) and convtr.out_channels == 1 and convtr.padding[0] == 0 and convtr.output_padding[0] == 0 \
+        and convtr.dilation[0] == 1 and convtr.groups == 1 and convtr.bias is None
+
+
 def run_convtr1d(convtr, x, weight, aq):
-    if convtr.out_channels != 1 or convtr.padding[0] != 0 or convtr.output_padding[0] != 0 or convtr.dilation[0] != 1 \
-            or convtr.groups != 1 or convtr.bias is not None:
-        raise NotImplementedError("ConvTranspose1d: only the mono, bias-free, unpadded decoder has a HIP kernel")
+    if not _is_mono_decoder(convtr):
+        return fq_node(aq, convtr_frames(convtr, x, weight))
     L = ops._Lin("convtr", stride=convtr.stride[0], w_param=convtr.weight)
     q = aq.qctx() if aq is not None else ops.QCtx()
     q.keep_out = True          # waveform-side outputs are the model's outputs: always real fp32
@@ -914,6 +949,71 @@ class ConvTranspose2dNlQ(_ConvTrQ):
     _attr, _typ, _has_nl = "convTr2d", nn.ConvTranspose2d, True
 
 
+class Conv2dEncoderQ(LayerQ):
+    """first frequency-branch conv with the n_splitter-wide input (qat_layers.py:1049-1102): channels >= in_channels of the widened
+    kernel are drawn at random at construction, like Conv1dEncoderQ"""
+
+    def __init__(self, encoder, n_splitter=1, gradient_based=True, weight_quant=True, act_quant=True, inout_nl_quant=False,
+                 in_quant=False, act_n_bits=8, weight_n_bits=8, in_act_n_bits=8):
+        conv = encoder[0]
+        _expect(conv, nn.Conv2d, "Conv2d")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                         weight_shape=conv.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
+        self.in_quantizer = (get_activation_quantizer(gradient_based, nl=inout_nl_quant, n_bits=in_act_n_bits)
+                             if in_quant else nn.Identity())
+        self.nl = nn.Identity() if len(encoder) == 1 else encoder[1]
+        if n_splitter >= 2:
+            w = conv.weight.detach()
+            cin = conv.in_channels
+            wide = nn.Conv2d(n_splitter * cin, conv.out_channels, conv.kernel_size, stride=conv.stride, padding=conv.padding,
+                             bias=conv.bias is not None)
+            new_w = w.repeat(1, n_splitter, 1, 1)
+            for ch in range(1, n_splitter):
+                for c in range(cin):
+                    base = w[:, c, ...]
+                    new_w[:, ch * cin + c, ...] = torch.mean(base) + torch.randn_like(base) * (torch.std(base) ** ch)
+            with torch.no_grad():
+                wide.weight.copy_(new_w)
+                if conv.bias is not None:
+                    wide.bias.copy_(conv.bias)
+            conv = wide
+        self.conv2d = conv
+
+    def forward(self, x):
+        x = self.in_quantizer(x)
+        nl = None if isinstance(self.nl, nn.Identity) else self.nl
+        return fq_node(self.activation_fake_quantize, conv_frames(self.conv2d, x, self._wq(self.conv2d.weight)), nl)
+
+
+class ConvTr2dDecoderQ(LayerQ):
+    """last frequency-branch transposed conv with the n_combiner residual outputs (qat_layers.py:1364-1418)"""
+
+    def __init__(self, decoder, n_combiner=1, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True,
+                 inout_nl_quant=False, act_n_bits=8, out_quant=True, out_act_n_bits=8, train_res_dec=False):
+        conv = decoder[0]
+        _expect(conv, nn.ConvTranspose2d, "ConvTranspose2d")
+        super().__init__(gradient_based=gradient_based, weight_quant=weight_quant, act_quant=out_quant,
+                         act_nl_quantizer=inout_nl_quant, weight_shape=conv.weight.shape, ch_out_idx=1,
+                         act_n_bits=out_act_n_bits, weight_n_bits=weight_n_bits)
+        self.n_combiner = n_combiner
+        self.convTr2d = conv
+        if self.n_combiner >= 2:
+            self.residual_error_block = ResidualErrorBlock(conv, gradient_based, weight_quant=weight_quant, act_quant=act_quant,
+                                                           weight_n_bits=weight_n_bits, act_n_bits=act_n_bits,
+                                                           train_res_dec=bool(train_res_dec))
+            self.activation_fake_quantize_residual = (get_activation_quantizer(gradient_based, n_bits=out_act_n_bits)
+                                                      if out_quant else _BypassQuantizer())
+
+    def forward(self, x):
+        w_decoder = self._wq(self.convTr2d.weight)
+        y = fq_node(self.activation_fake_quantize, convtr_frames(self.convTr2d, x, w_decoder))
+        if self.n_combiner == 1:
+            return y
+        outs = [y]
+        for _ in range(1, self.n_combiner):
+            y = self.residual_error_block(x, y, w_decoder, self.convTr2d, self.activation_fake_quantize_residual)
+            outs.append(y)
+        return torch.stack(outs)
+
+
 BatchNormQ = _later_row("BatchNormQ", "a15")
-Conv2dEncoderQ = _later_row("Conv2dEncoderQ", "a15")
-ConvTr2dDecoderQ = _later_row("ConvTr2dDecoderQ", "a15")

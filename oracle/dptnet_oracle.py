@@ -141,7 +141,7 @@ class DQTable(QTable):
                 # ch_out_idx = 1 for transposed convs: the decoder (qat_layers.py:1317) and, with train_res_dec, the residual
                 # decoder's own quantizer (qat_layers.py:1141-1145)
                 axis = 1 if (((owner + "convTr1d.weight") in self.p or (owner + "convTr2d.weight") in self.p) and pre.endswith(".weight_fake_quantize")) or \
-                    (pre.endswith(".weight_fake_quantize_dec") and self.p.get(owner + "residual_decoder.weight", torch.zeros(1)).dim() == 3) else 0
+                    (pre.endswith(".weight_fake_quantize_dec") and self.p.get(owner + "residual_decoder.weight", torch.zeros(1)).dim() >= 3) else 0
                 self.wq[pre] = WeightRange(self.p, pre, axis)
             else:
                 self.aq[pre] = ActRange(self.p, pre)
@@ -219,6 +219,24 @@ class DQTable(QTable):
         w = self._W(name, self.p[key + ".weight"])
         fn = F.conv_transpose1d if x.dim() == 3 else F.conv_transpose2d
         return self._A(name, NL_MAPS[nl](fn(x, w, self.p.get(key + ".bias"), **geom)))
+
+    def convtr_decoder_q(self, name, x, n_combiner=2, train_res_dec=False, **geom):
+        """ConvTr1dDecoderQ / ConvTr2dDecoderQ with a general geometry (qat_layers.py:1305-1418) and the transposed-conv branches of
+        ResidualErrorBlock (:1189-1216).  Quirks kept: the residual encoder is called with the stride only; the 1-D decode of
+        the residual drops the bias, the 2-D decode uses `residual_decoder.bias`"""
+        p, two_d = self.p, x.dim() == 4
+        key = name + (".convTr2d" if two_d else ".convTr1d")
+        convT, conv = (F.conv_transpose2d, F.conv2d) if two_d else (F.conv_transpose1d, F.conv1d)
+        w = self._W(name, p[key + ".weight"])
+        y = self._A(name, convT(x, w, p.get(key + ".bias"), **geom))
+        if n_combiner == 1:
+            return y
+        rb = name + ".residual_error_block"
+        w_res = self._W(rb, p[rb + ".residual_encoder.weight"])
+        Y1 = self._A(rb, x - conv(y, w_res, p.get(rb + ".residual_encoder.bias"), stride=geom.get("stride", 1)))
+        wd = self.Wq(rb + ".weight_fake_quantize_dec", p[rb + ".residual_decoder.weight"]) if train_res_dec else w
+        y1 = convT(Y1, wd, p[rb + ".residual_decoder.bias"] if two_d else None, **geom)
+        return torch.stack([y, self.aq[name + ".activation_fake_quantize_residual"](y1)])
 
     # -- first layers of cfg 5 (HTDemucs, SURVEY §8 row a15) -----------------------------------------------------------
     def linear_nl_q(self, name, x, nl):

@@ -580,10 +580,23 @@ def _hd_layer(name, sd):
     if name == "convtr1dq_k5_s3_p1":
         ci, co = shp("convTr1d.weight")[:2]
         return QL.ConvTranspose1dQ(nn.ConvTranspose1d(ci, co, 5, 3, padding=1, output_padding=2), **P)
+    if name == "conv1dencoderq_k8_s4_gelu":
+        co, ci, k = shp("conv1d.weight")
+        return QL.Conv1dEncoderQ(nn.Sequential(nn.Conv1d(ci // 2, co, k, 4, 2), nn.GELU()), n_splitter=2, **P)
+    if name == "conv2dencoderq_k8_s4_gelu":
+        co, ci = shp("conv2d.weight")[:2]
+        return QL.Conv2dEncoderQ(nn.Sequential(nn.Conv2d(ci // 2, co, (8, 1), (4, 1), (2, 0)), nn.GELU()), n_splitter=2, **P)
+    if name == "convtr1ddecoderq_stereo":
+        ci, co = shp("convTr1d.weight")[:2]
+        return QL.ConvTr1dDecoderQ(nn.Sequential(nn.ConvTranspose1d(ci, co, 8, 4)), n_combiner=2, **P)
+    if name == "convtr2ddecoderq_resdec":
+        ci, co = shp("convTr2d.weight")[:2]
+        return QL.ConvTr2dDecoderQ(nn.Sequential(nn.ConvTranspose2d(ci, co, (8, 1), (4, 1))), n_combiner=2, train_res_dec=True, **P)
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["linearnlq_gelu", "linearnlq_relu", "nlq_gelu", "conv1dnlq_glu", "divq", "conv1dq_k3_d2",
+@pytest.mark.parametrize("name", ["conv1dencoderq_k8_s4_gelu", "conv2dencoderq_k8_s4_gelu", "convtr1ddecoderq_stereo", "convtr2ddecoderq_resdec",
+                                  "linearnlq_gelu", "linearnlq_relu", "nlq_gelu", "conv1dnlq_glu", "divq", "conv1dq_k3_d2",
                                   "conv1dnlq_k8_s4_gelu", "conv1dgnnlq_gelu", "conv1dgnnlq_glu", "conv2dnlq_k8_s4_gelu",
                                   "conv2dnlq_3x3_glu", "conv2dnlq_1x1_glu", "convtr2dnlq_k8_s4_gelu", "convtr1dnlq_k8_s4_gelu",
                                   "convtr1dq_k5_s3_p1"])
@@ -601,18 +614,23 @@ def test_htdemucs_first_layers_teacher_forced(golden, name):
         i += 1
     y = L(*ins)
     y.backward(T(g[f"{name}.gout"]).cuda())
-    lo, hi = float(sd["activation_fake_quantize.min_range"]), float(sd["activation_fake_quantize.max_range"])
-    delta = (hi - lo) / 255.0
-    a, b = np.rint((y.detach().cpu().numpy() - lo) / delta), np.rint((g[f"{name}.out"] - lo) / delta)
-    assert np.abs(a - b).max() <= 1 and float(np.mean(a != b)) <= 3e-3
-    nflip = int((a != b).sum())
+    nflip = 0
+    halves = [("activation_fake_quantize", slice(None))]
+    if "decoderq" in name:          # stacked (MSB, LSB) outputs, each behind its own quantizer
+        halves = [("activation_fake_quantize", 0), ("activation_fake_quantize_residual", 1)]
+    for qn, sel in halves:
+        lo, hi = float(sd[qn + ".min_range"]), float(sd[qn + ".max_range"])
+        delta = (hi - lo) / 255.0
+        a, b = np.rint((y.detach().cpu().numpy()[sel] - lo) / delta), np.rint((g[f"{name}.out"][sel] - lo) / delta)
+        assert np.abs(a - b).max() <= 1 and float(np.mean(a != b)) <= 3e-3, (name, qn)
+        nflip += int((a != b).sum())
     for i, x in enumerate(ins):
         want = g[f"{name}.gin{i}"]
         bad = np.abs(x.grad.cpu().numpy() - want) > 2e-4 * np.abs(want).max() + 2e-4 * np.abs(want)
         assert bad.mean() <= 2e-3 + 8.0 * nflip / want.size, (name, i, bad.mean())
     params = dict(L.named_parameters())
     for k in g.files:
-        if k.startswith(name + ".grad."):
+        if k.startswith(name + ".grad.") and not k.endswith(".decoder_bias"):        # (an alias of the decoder's bias)
             w = g[k]
             np.testing.assert_allclose(params[k[len(name) + 6:]].grad.cpu().numpy(), w, rtol=3e-3, atol=(3e-3 + 0.05 * nflip) * (np.abs(w).max() + 1e-6), err_msg=k)
 

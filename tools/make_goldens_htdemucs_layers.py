@@ -59,6 +59,16 @@ def main():
     run_layer("convtr1dnlq_k8_s4_gelu", L, [keyed_randn("hd.xg1", (2, 6, 13), 0.9)], d)
     L = RL.ConvTranspose1dQ(nn.ConvTranspose1d(6, 4, 5, 3, padding=1, output_padding=2), **P); fill(L, "ct0.")
     run_layer("convtr1dq_k5_s3_p1", L, [keyed_randn("hd.xg1", (2, 6, 13), 0.9)], d)
+    # 8-bit I/O blocks of HTDemucs: widened first convs of both branches, last transposed convs with the residual (LSB) output
+    torch.manual_seed(11)
+    L = RL.Conv1dEncoderQ(nn.Sequential(nn.Conv1d(2, 6, 8, 4, 2), nn.GELU()), n_splitter=2, **P); fill(L, "e1.")
+    run_layer("conv1dencoderq_k8_s4_gelu", L, [keyed_randn("hd.xe1", (2, 4, 53), 0.9)], d)
+    L = RL.Conv2dEncoderQ(nn.Sequential(nn.Conv2d(4, 6, (8, 1), (4, 1), (2, 0)), nn.GELU()), n_splitter=2, **P); fill(L, "e2.")
+    run_layer("conv2dencoderq_k8_s4_gelu", L, [keyed_randn("hd.xe2", (2, 8, 22, 7), 0.9)], d)
+    L = RL.ConvTr1dDecoderQ(nn.Sequential(nn.ConvTranspose1d(6, 4, 8, 4)), n_combiner=2, **P); fill(L, "d1.")
+    run_layer("convtr1ddecoderq_stereo", L, [keyed_randn("hd.xd1", (2, 6, 13), 0.9)], d)
+    L = RL.ConvTr2dDecoderQ(nn.Sequential(nn.ConvTranspose2d(6, 4, (8, 1), (4, 1))), n_combiner=2, train_res_dec=True, **P); fill(L, "d2.")
+    run_layer("convtr2ddecoderq_resdec", L, [keyed_randn("hd.xd2", (2, 6, 5, 7), 0.9)], d)
     # EmbeddingQ: integer input, so run it by hand with the same protocol as run_layer
     emb = RL.EmbeddingQ(nn.Embedding(11, 16), **P); fill(emb, "emb.")
     idx = torch.tensor([[0, 3, 10, 3], [7, 1, 1, 5]])
