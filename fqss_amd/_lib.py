@@ -100,6 +100,8 @@ _PROTOS = {
     "fqss_frames_gather": [P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_frames_ola": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_chan_sum": [P, P, I64, I64, I64, I64, P],
+    "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
+    "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
 }
 _RESTYPE = {"fqss_last_error": C.c_char_p}
 

@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__
 // y[b][c][h][w] = bias[c] + sum over taps (ti, j) with (h + ph - ti*dh) = ho*st_h, (w + pw - j*dw) = wo*st_w in range
 __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
                                                      const FrameGeom g) {
-    const int64_t M = g.Ho * g.Wo;
     const int64_t total = g.B * g.C * g.H * g.W;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t w = i % g.W, r0 = i / g.W, h = r0 % g.H, bc = r0 / g.H, c = bc % g.C, b = bc / g.C;

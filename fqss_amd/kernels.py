@@ -1092,3 +1092,46 @@ def chan_sum(g, out):
     g, B, C, M, ld = _bcm(g)
     assert out.numel() == C and out.is_contiguous()
     _lib.call("fqss_chan_sum", _p(g), _p(out), B, C, M, ld, _stream())
+
+
+# ------------------------------------------------------------------ streaming attention (long sequences, cross attention)
+def _row_strides(t, batch_first):
+    """(sl, sb) element strides of a [L, B, E] (or batch-first [B, L, E]) view with unit stride along E"""
+    assert t.dim() == 3 and (t.stride(2) == 1 or t.shape[2] == 1), "expected a [., ., E] view with unit column stride"
+    return (t.stride(1), t.stride(0)) if batch_first else (t.stride(0), t.stride(1))
+
+
+def _stride_array(ts, batch_first):
+    import ctypes
+    vals = [s for t in ts for s in _row_strides(t, batch_first)]
+    return (ctypes.c_int64 * len(vals))(*vals)
+
+
+def attn_long_fwd(q, k, v, nh, batch_first, obs_attn=None, obs_soft=None):
+    """q [Lq, B, E], k / v [Lk, B, E] views (batch_first: [B, L, E]) -> heads (same layout as q, dense), stats [B*nh, Lq, 2]"""
+    _need_gpu(q, k, v)
+    B, Lq = (q.shape[0], q.shape[1]) if batch_first else (q.shape[1], q.shape[0])
+    Lk = k.shape[1] if batch_first else k.shape[0]
+    E = q.shape[2]
+    assert k.shape[2] == E and v.shape == k.shape and E % nh == 0 and (k.shape[0] if batch_first else k.shape[1]) == B
+    o = torch.empty(q.shape, device=q.device, dtype=torch.float32)
+    stats = torch.empty(B * nh, Lq, 2, device=q.device, dtype=torch.float32)
+    _lib.call("fqss_attn_long_fwd", _p(q), _p(k), _p(v), _p(o), _p(stats), Lq, Lk, B, nh, E // nh, _stride_array((q, k, v, o), batch_first),
+              _p(obs_attn), _p(obs_soft), _stream())
+    return o, stats
+
+
+def attn_long_bwd(q, k, v, o, go, stats, nh, batch_first):
+    _need_gpu(q, k, v, o, go)
+    B, Lq = (q.shape[0], q.shape[1]) if batch_first else (q.shape[1], q.shape[0])
+    Lk = k.shape[1] if batch_first else k.shape[0]
+    E = q.shape[2]
+    if go.stride(2) != 1:
+        go = go.contiguous()
+    gq = torch.empty(q.shape, device=q.device, dtype=torch.float32)
+    gk = torch.empty(k.shape, device=q.device, dtype=torch.float32)
+    gv = torch.empty(k.shape, device=q.device, dtype=torch.float32)
+    dsum = torch.empty(B * nh, Lq, device=q.device, dtype=torch.float32)
+    _lib.call("fqss_attn_long_bwd", _p(q), _p(k), _p(v), _p(o), _p(go), _p(stats), _p(gq), _p(gk), _p(gv), _p(dsum), Lq, Lk, B, nh, E // nh,
+              _stride_array((q, k, v, o, go, gq, gk, gv), batch_first), _stream())
+    return gq, gk, gv

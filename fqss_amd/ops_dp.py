@@ -469,3 +469,84 @@ class FramesOla(Function):
             gb = None if direct else buf
         gf, _, _ = K.frames_gather(g, ctx.geom)
         return gf, gb, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# general attention core (HTDemucs transformer): cross attention, batch-first rows, long sequences
+# ----------------------------------------------------------------------------------------------
+class MhaCoreX(Function):
+    """MultiheadAttentionQ.forward between the in-projections and the (not yet quantized) heads for query != key (value is key),
+    batch-first or sequence-first rows and any sequence lengths (qat_layers.py:878-911): Xq = in_proj(query) and Xkv = in_proj(key)
+    are both the full [.., 3E] projections (the q / k / v quantizers observe ALL of their X, each is used on its own third; in the
+    reference Xk and Xv are the same numbers when value is key).  Xkv None: self-attention (one projection).
+    aqs = (aq_q, aq_k, aq_v, aq_div, aq_attn, aq_softmax) or None for the float module."""
+
+    @staticmethod
+    def forward(ctx, Xq, Xkv, nh, batch_first, aqs, *ranges):
+        same = Xkv is None
+        Xq = Xq.contiguous()
+        Xkv = Xq if same else Xkv.contiguous()
+        E = Xq.shape[-1] // 3
+        hd = E // nh
+        scale = math.sqrt(hd)
+        ctx.cfg = (same, E, nh, batch_first, scale)
+        srcs = (Xq, Xkv, Xkv)
+        if aqs is None:
+            q = K.unary_fwd(Xq[..., :E], K.UNARY_DIVS, scale)
+            heads, stats = K.attn_long_fwd(q, Xkv[..., E:2 * E], Xkv[..., 2 * E:], nh, batch_first)
+            ctx.qs = None
+            ctx.save_for_backward(Xq, Xkv, q, heads, stats)
+            return heads
+        qs = [a.qctx() for a in aqs[:4]]
+        parts = []
+        for i in range(3):
+            blk = srcs[i][..., i * E:(i + 1) * E]
+            if qs[i].qmode == ops.Q_OBSERVE:
+                K.minmax(srcs[i], qs[i].obs_ws)
+                parts.append(blk)
+            elif qs[i].qmode == ops.Q_QUANT:
+                parts.append(K.actq_fwd(blk, ops.ACT_NONE, None, ops.Q_QUANT, qs[i].qmin, qs[i].qmax, None))
+            else:
+                parts.append(blk)
+            aqs[i].after_forward(qs[i])
+        qd = K.unary_fwd(parts[0], K.UNARY_DIVS, scale)
+        q = K.actq_fwd(qd, ops.ACT_NONE, None, qs[3].qmode, qs[3].qmin, qs[3].qmax, qs[3].obs_ws) if qs[3].qmode != ops.Q_BYPASS else qd
+        aqs[3].after_forward(qs[3])
+        obs = [None, None]
+        for i in (4, 5):
+            m = aqs[i].next_mode() if hasattr(aqs[i], "next_mode") else ops.Q_BYPASS
+            obs[i - 4] = aqs[i]._obs_ws if m == ops.Q_OBSERVE else None
+        if (obs[0] is None) != (obs[1] is None):
+            raise RuntimeError("MultiheadAttentionQ: attn / softmax observers out of step")
+        heads, stats = K.attn_long_fwd(q, parts[1], parts[2], nh, batch_first, obs[0], obs[1])
+        if obs[0] is not None:
+            K.observer_ema(aqs[4].min_range.data, aqs[4].max_range.data, aqs[4]._obs_ws, aqs[4].alpha)
+            K.observer_ema(aqs[5].min_range.data, aqs[5].max_range.data, aqs[5]._obs_ws, aqs[5].alpha)
+        ctx.qs = qs
+        ctx.save_for_backward(Xq, Xkv, q, heads, stats, qd, parts[1], parts[2])
+        return heads
+
+    @staticmethod
+    def backward(ctx, gh):
+        same, E, nh, batch_first, scale = ctx.cfg
+        if ctx.qs is None:
+            Xq, Xkv, q, heads, stats = ctx.saved_tensors
+            kq, vq, qs = Xkv[..., E:2 * E], Xkv[..., 2 * E:], None
+        else:
+            Xq, Xkv, q, heads, stats, qd, kq, vq = ctx.saved_tensors
+            qs = ctx.qs
+        gq, gk, gv = K.attn_long_bwd(q, kq, vq, heads, gh, stats, nh, batch_first)
+        grads = [None] * 8
+        if qs is not None and qs[3].qmode == ops.Q_QUANT:
+            gq, _, grads[6], grads[7], _ = ops._epilogue_bwd(qd, gq, ops.ACT_NONE, None, None, qs[3])
+        gq = K.unary_bwd(gq, None, K.UNARY_DIVS, scale)
+        gXq = torch.empty_like(Xq) if same else torch.zeros_like(Xq)
+        gXkv = gXq if same else torch.zeros_like(Xkv)
+        srcs, dsts = (Xq, Xkv, Xkv), (gXq, gXkv, gXkv)
+        for i, g in enumerate((gq, gk, gv)):
+            blk = dsts[i][..., i * E:(i + 1) * E]
+            if qs is not None and qs[i].qmode == ops.Q_QUANT:
+                _, _, grads[2 * i], grads[2 * i + 1], _ = ops._epilogue_bwd(srcs[i][..., i * E:(i + 1) * E], g, ops.ACT_NONE, None, None, qs[i], out=blk)
+            else:
+                blk.copy_(g)
+        return (gXq, None if same else gXkv, None, None, None, *grads)

@@ -658,6 +658,23 @@ def run_mha(mha, x, w_in, w_out, aqs, aq_head, aq_out):
     return fq_node(aq_out, ops_dp.row_linear(heads, w_out, mha.out_proj.bias))
 
 
+def run_mha_x(mha, query, key, value, w_in, w_out, aqs, aq_head, aq_out):
+    """general form of run_mha: key is value but may differ from query (cross attention), batch-first or sequence-first rows"""
+    if value is not key:
+        raise NotImplementedError("MultiheadAttentionQ: value must be the key tensor (self- or cross-attention)")
+    if mha.in_proj_weight is None or mha.bias_k is not None or mha.add_zero_attn or mha.dropout != 0:
+        raise NotImplementedError("MultiheadAttention variant without a HIP kernel")
+    Xq = ops_dp.row_linear(query, w_in, mha.in_proj_bias)
+    Xkv = None if key is query else ops_dp.row_linear(key, w_in, mha.in_proj_bias)
+    if aqs is None:
+        heads = ops_dp.MhaCoreX.apply(Xq, Xkv, mha.num_heads, bool(mha.batch_first), None)
+    else:
+        ranges = [r for a in aqs[:4] for r in (a.min_range, a.max_range)]
+        heads = ops_dp.MhaCoreX.apply(Xq, Xkv, mha.num_heads, bool(mha.batch_first), aqs, *ranges)
+    heads = fq_node(aq_head, heads, codes=True)
+    return fq_node(aq_out, ops_dp.row_linear(heads, w_out, mha.out_proj.bias))
+
+
 class LayerNormQ(LayerQ):
     def __init__(self, layernorm, gradient_based=True, act_quant=True, act_n_bits=8):
         super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_n_bits=act_n_bits)
@@ -755,13 +772,20 @@ class MultiheadAttentionQ(LayerQ):
                                          if weight_quant else nn.Identity())
 
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None, need_weights=False, is_causal=False):
-        _mha_check(self.mha, query, key, value)
         if attn_mask is not None or key_padding_mask is not None:
             raise NotImplementedError("MultiheadAttentionQ: masks are ignored by the reference's forward (qat_layers.py:878-946)")
         aqs = (self.activation_fake_quantize_q, self.activation_fake_quantize_k, self.activation_fake_quantize_v,
                self.activation_fake_quantize_div, self.activation_fake_quantize_attn, self.activation_fake_quantize_softmax)
         if isinstance(aqs[0], _BypassQuantizer):
             aqs = None
+        L = query.shape[1] if self.mha.batch_first else query.shape[0]
+        if not (query is key and key is value) or self.mha.batch_first or L > 512 or self.head_dim > 32:
+            # cross attention / batch-first rows / long sequences (HTDemucs transformer): the streaming attention core
+            y = run_mha_x(self.mha, query, key, value, self.weight_fake_quantize_in(self.mha.in_proj_weight),
+                          self.weight_fake_quantize_out(self.mha.out_proj.weight), aqs, self.activation_fake_quantize_head,
+                          self.activation_fake_quantize)
+            return (y,)
+        _mha_check(self.mha, query, key, value)
         y = run_mha(self.mha, query, self.weight_fake_quantize_in(self.mha.in_proj_weight),
                     self.weight_fake_quantize_out(self.mha.out_proj.weight), aqs, self.activation_fake_quantize_head,
                     self.activation_fake_quantize)

@@ -503,6 +503,17 @@ int fqss_frames_ola(const float* frames, const float* bias, float* y, int64_t B,
                     fqss_stream_t stream);
 int fqss_chan_sum(const float* g, float* out, int64_t B, int64_t C, int64_t M, int64_t ld, fqss_stream_t stream);
 
+/* Streaming attention core for long sequences and cross attention (HTDemucs transformer, htdemucsq.py:138-329; the arithmetic of
+ * MultiheadAttentionQ.forward between the quantized q / k / v and the heads, qat_layers.py:903-911, with Lq != Lk allowed).
+ * Rows are x[l*sl + b*sb + h*hd + d]; `strides` is a HOST array of (sl, sb) element-stride pairs: q, k, v, o for the forward,
+ * q, k, v, o, go, gq, gk, gv for the backward.  stats [B*nh][Lq][2] = (row max, row sum); dsum: workspace of B*nh*Lq floats.
+ * obs_attn / obs_soft: optional observer workspaces (min / max of the logits and of the probabilities), as fqss_attn_fwd.  */
+int fqss_attn_long_fwd(const float* q, const float* k, const float* v, float* o, float* stats, int Lq, int Lk, int B, int nh, int hd,
+                       const int64_t* strides, uint32_t* obs_attn, uint32_t* obs_soft, fqss_stream_t stream);
+int fqss_attn_long_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* stats, float* gq,
+                       float* gk, float* gv, float* dsum, int Lq, int Lk, int B, int nh, int hd, const int64_t* strides,
+                       fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

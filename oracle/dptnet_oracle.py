@@ -169,19 +169,26 @@ class DQTable(QTable):
             W[n] = self.p[f"{name}.lstm.{n}"]
         return self._A(name, lstm_bidir(x, W))
 
-    def mha_q(self, name, x, nhead=4):
+    def mha_q(self, name, x, nhead=4, key=None, batch_first=False):
+        """MultiheadAttentionQ.forward (qat_layers.py:878-946); key (= value) None: self-attention.  Each of the q / k / v quantizers
+        runs on the FULL [.., 3E] projection of its input and only its own third is used"""
         p = self.p
         Wi = self.Wq(name + ".weight_fake_quantize_in", p[name + ".mha.in_proj_weight"])
         Wo = self.Wq(name + ".weight_fake_quantize_out", p[name + ".mha.out_proj.weight"])
+        key = x if key is None else key
+        if batch_first:
+            x, key = x.transpose(1, 0), key.transpose(1, 0)
         L, B, E = x.shape
+        Lk = key.shape[0]
         hd = E // nhead
-        X = F.linear(x, Wi, p[name + ".mha.in_proj_bias"])
-        Q = self.A(name + ".activation_fake_quantize_q", X)[..., :E]
-        K = self.A(name + ".activation_fake_quantize_k", X)[..., E:2 * E]
-        V = self.A(name + ".activation_fake_quantize_v", X)[..., 2 * E:]
+        Xq = F.linear(x, Wi, p[name + ".mha.in_proj_bias"])
+        Xk = Xq if key is x else F.linear(key, Wi, p[name + ".mha.in_proj_bias"])
+        Q = self.A(name + ".activation_fake_quantize_q", Xq)[..., :E]
+        K = self.A(name + ".activation_fake_quantize_k", Xk)[..., E:2 * E]
+        V = self.A(name + ".activation_fake_quantize_v", Xk)[..., 2 * E:]
         q = Q.reshape(L, B * nhead, hd).permute(1, 0, 2)
-        k = K.reshape(L, B * nhead, hd).permute(1, 0, 2)
-        v = V.reshape(L, B * nhead, hd).permute(1, 0, 2)
+        k = K.reshape(Lk, B * nhead, hd).permute(1, 0, 2)
+        v = V.reshape(Lk, B * nhead, hd).permute(1, 0, 2)
         q = self.A(name + ".activation_fake_quantize_div", q / math.sqrt(hd))
         attn = torch.bmm(q, k.transpose(-2, -1))
         self.A(name + ".activation_fake_quantize_attn", attn.detach())       # result discarded in the reference (:907)
@@ -189,6 +196,8 @@ class DQTable(QTable):
         self.A(name + ".activation_fake_quantize_softmax", attn.detach())    # result discarded (:909)
         heads = self.A(name + ".activation_fake_quantize_head", torch.bmm(attn, v))
         y = F.linear(heads.transpose(1, 0).reshape(L * B, E), Wo, p[name + ".mha.out_proj.bias"]).reshape(L, B, E)
+        if batch_first:
+            y = y.transpose(1, 0)
         return self._A(name, y)
 
     def conv2d_q(self, name, x):

@@ -505,3 +505,38 @@ def test_frames_geometry_is_checked():
     from fqss_amd._lib import FqssError
     with pytest.raises((ValueError, FqssError)):
         K.frames_gather(torch.zeros(1, 2, 1, 3, device="cuda"), K.ConvGeom((1, 8), (1, 4)))
+
+
+# ---------------------------------------------------------------- streaming attention core (row a15): long sequences, cross attention
+@pytest.mark.parametrize("Lq,Lk,B,nh,hd,bf", [(300, 517, 2, 2, 48, True), (257, 257, 1, 3, 64, False), (33, 70, 2, 4, 4, True), (700, 64, 1, 2, 16, False)])
+def test_attn_long(Lq, Lk, B, nh, hd, bf):
+    E = nh * hd
+    shp = lambda L: (B, L, E) if bf else (L, B, E)
+    q, k, v = rnd(*shp(Lq), seed=1, scale=0.4), rnd(*shp(Lk), seed=2, scale=0.9), rnd(*shp(Lk), seed=3)
+    go = rnd(*shp(Lq), seed=4)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+
+    def heads(t, L):
+        t = t if bf else t.transpose(0, 1)                       # -> [B, L, E]
+        return t.reshape(B, L, nh, hd).permute(0, 2, 1, 3)      # [B, nh, L, hd]
+    s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2)
+    p = torch.softmax(s, -1)
+    o = (p @ heads(vr, Lk)).permute(0, 2, 1, 3).reshape(B, Lq, E)
+    o = o if bf else o.transpose(0, 1)
+    o.backward(go)
+    # operands as column blocks of a wider projection (the layout MhaCoreX passes)
+    wide = lambda t: torch.cat([t, t, t], -1).cuda()
+    Xq, Xk = wide(q), wide(k)
+    Xk[..., 2 * E:] = v.cuda()
+    obs_a, obs_s = (torch.tensor([-1, 0], dtype=torch.int32, device="cuda") for _ in range(2))
+    out, stats = K.attn_long_fwd(Xq[..., :E], Xk[..., E:2 * E], Xk[..., 2 * E:], nh, bf, obs_a, obs_s)
+    close(out, o, rtol=2e-5, atol=2e-5)
+    ws = torch.zeros(2, device="cuda")
+    K.observer_ema(ws[:1], ws[1:], obs_a, 0.0)                  # alpha 0: (min, max) of this call
+    close(ws, torch.stack([s.min(), s.max()]), rtol=1e-5, atol=1e-5)
+    K.observer_ema(ws[:1], ws[1:], obs_s, 0.0)
+    close(ws, torch.stack([p.min(), p.max()]), rtol=1e-4, atol=1e-7)
+    gq, gk, gv = K.attn_long_bwd(Xq[..., :E], Xk[..., E:2 * E], Xk[..., 2 * E:], out, go.cuda(), stats, nh, bf)
+    close(gq, qr.grad, rtol=1e-4, atol=2e-5)
+    close(gk, kr.grad, rtol=1e-4, atol=2e-5)
+    close(gv, vr.grad, rtol=1e-4, atol=2e-5)

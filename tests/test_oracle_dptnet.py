@@ -92,6 +92,8 @@ def test_htdemucs_first_layer_fixtures(golden):
     run(g, "convtr2dnlq_k8_s4_gelu", lambda t, x: t.convtr_nl_q("L", x, "gelu", stride=(4, 1)))
     run(g, "convtr1dnlq_k8_s4_gelu", lambda t, x: t.convtr_nl_q("L", x, "gelu", stride=4))
     run(g, "convtr1dq_k5_s3_p1", lambda t, x: t.convtr_nl_q("L", x, None, stride=3, padding=1, output_padding=2))
+    run(g, "mhaq_bf_self", lambda t, x: t.mha_q("L", x, 4, batch_first=True), wrapped=True)
+    run(g, "mhaq_bf_cross", lambda t, x, k: t.mha_q("L", x, 4, key=k, batch_first=True), wrapped=True)
     run(g, "conv1dencoderq_k8_s4_gelu", lambda t, x: t.conv1d_nl_q("L", x, "gelu", stride=4, padding=2))
     run(g, "conv2dencoderq_k8_s4_gelu", lambda t, x: t.conv2d_nl_q("L", x, "gelu", stride=(4, 1), padding=(2, 0)))
     run(g, "convtr1ddecoderq_stereo", lambda t, x: t.convtr_decoder_q("L", x, 2, stride=4))

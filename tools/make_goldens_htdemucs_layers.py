@@ -21,6 +21,17 @@ from quantization.qat import qat_layers as RL  # noqa: E402
 keyed_randn, fill, run_layer, P = MG.keyed_randn, MD.fill, MD.run_layer, MD.P
 
 
+class Cross(nn.Module):
+    """MultiheadAttentionQ(query, key, key)[0] for the generic layer runner"""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, q, k):
+        return self.m(q, k, k)[0]
+
+
 def main():
     out = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
     d = {}
@@ -69,6 +80,11 @@ def main():
     run_layer("convtr1ddecoderq_stereo", L, [keyed_randn("hd.xd1", (2, 6, 13), 0.9)], d)
     L = RL.ConvTr2dDecoderQ(nn.Sequential(nn.ConvTranspose2d(6, 4, (8, 1), (4, 1))), n_combiner=2, train_res_dec=True, **P); fill(L, "d2.")
     run_layer("convtr2ddecoderq_resdec", L, [keyed_randn("hd.xd2", (2, 6, 5, 7), 0.9)], d)
+    # attention of the HTDemucs transformer: batch-first rows, self-attention on a long-ish sequence and cross attention (Lq != Lk)
+    L = MD.First(RL.MultiheadAttentionQ(nn.MultiheadAttention(16, 4, dropout=0.0, batch_first=True), **P), 3); fill(L, "mhs.")
+    run_layer("mhaq_bf_self", L, [keyed_randn("hd.xs", (2, 45, 16), 0.9)], d)
+    L = Cross(RL.MultiheadAttentionQ(nn.MultiheadAttention(16, 4, dropout=0.0, batch_first=True), **P)); fill(L, "mhc.")
+    run_layer("mhaq_bf_cross", L, [keyed_randn("hd.xq", (2, 37, 16), 0.9), keyed_randn("hd.xk", (2, 21, 16), 0.9)], d)
     # EmbeddingQ: integer input, so run it by hand with the same protocol as run_layer
     emb = RL.EmbeddingQ(nn.Embedding(11, 16), **P); fill(emb, "emb.")
     idx = torch.tensor([[0, 3, 10, 3], [7, 1, 1, 5]])
