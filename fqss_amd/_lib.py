@@ -100,6 +100,16 @@ _PROTOS = {
     "fqss_frames_gather": [P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_frames_ola": [P, P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_chan_sum": [P, P, I64, I64, I64, I64, P],
+    "fqss_chan_op": [P, P, P, I64, I64, I64, I64, I64, I32, P],
+    "fqss_chan_scale_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "fqss_col_scale_fwd": [P, P, P, I64, I32, I64, I64, P],
+    "fqss_col_scale_bwd": [P, P, P, P, P, I64, I32, I64, I64, I64, P],
+    "fqss_sample_meanstd": [P, P, P, I64, I64, P],
+    "fqss_sample_norm": [P, P, P, I64, I64, I32, P],
+    "fqss_stft": [P, P, P, P, I64, I64, I64, I32, I32, I32, I32, P],
+    "fqss_istft": [P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, I32, P],
+    "fqss_istft_bwd": [P, P, P, P, P, I64, I64, I64, I32, I32, I32, I32, P],
+    "fqss_transpose2d": [P, P, I64, I64, I64, P],
     "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
     "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
 }

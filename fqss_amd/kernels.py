@@ -1135,3 +1135,128 @@ def attn_long_bwd(q, k, v, o, go, stats, nh, batch_first):
     _lib.call("fqss_attn_long_bwd", _p(q), _p(k), _p(v), _p(o), _p(go), _p(stats), _p(gq), _p(gk), _p(gv), _p(dsum), Lq, Lk, B, nh, E // nh,
               _stride_array((q, k, v, o, go, gq, gk, gv), batch_first), _stream())
     return gq, gk, gv
+
+
+# ------------------------------------------------------------------ HTDemucs small ops (csrc/hd_ops.hip)
+def chan_op(x, s, mode):
+    """x [B, C, M] (*|+) s [C]: mode 0 multiply, 1 add"""
+    _need_gpu(x, s)
+    x, B, C, M, ld = _bcm(x)
+    assert s.numel() == C and s.is_contiguous()
+    y = empty_act((B, C, M), x.device)
+    _lib.call("fqss_chan_op", _p(x), _p(s), _p(y), B, C, M, ld, rowmat(y)[2], mode, _stream())
+    return y
+
+
+def chan_scale_bwd(g, x, s, gs):
+    """-> gx = g * s[c]; gs[c] += sum g * x"""
+    _need_gpu(g, x, s, gs)
+    g, B, C, M, ld_g = _bcm(g)
+    x, _, _, _, ld_x = _bcm(x)
+    gx = empty_act((B, C, M), g.device)
+    _lib.call("fqss_chan_scale_bwd", _p(g), _p(x), _p(s), _p(gx), _p(gs), B, C, M, ld_g, ld_x, rowmat(gx)[2], _stream())
+    return gx
+
+
+def col_scale_fwd(x, s):
+    """x [..., C] * s [C]"""
+    _need_gpu(x, s)
+    C = s.numel()
+    xr, R, ld = _rows(x, C)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_col_scale_fwd", _p(xr), _p(s), _p(y), R, C, ld, C, _stream())
+    return y
+
+
+def col_scale_bwd(g, x, s, gs):
+    _need_gpu(g, x, s, gs)
+    C = s.numel()
+    gr, R, ld_g = _rows(g, C)
+    xr, _, ld_x = _rows(x, C)
+    gx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_col_scale_bwd", _p(gr), _p(xr), _p(s), _p(gx), _p(gs), R, C, ld_g, ld_x, C, _stream())
+    return gx
+
+
+def sample_meanstd(x):
+    """x [B, ...] dense -> ms [B, 2] = (mean, unbiased std) over all other dims"""
+    _need_gpu(x)
+    x = x.contiguous()
+    B = x.shape[0]
+    ws = torch.zeros(B, 2, device=x.device, dtype=torch.float64)
+    ms = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_sample_meanstd", _p(x), _p(ws), _p(ms), B, x.numel() // B, _stream())
+    return ms
+
+
+def sample_norm(x, ms, inverse):
+    """(x - mean_b) / (1e-5 + std_b), or x * std_b + mean_b when inverse"""
+    _need_gpu(x, ms)
+    x = x.contiguous()
+    B = x.shape[0]
+    assert tuple(ms.shape) == (B, 2) and ms.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.call("fqss_sample_norm", _p(x), _p(ms), _p(y), B, x.numel() // B, 1 if inverse else 0, _stream())
+    return y
+
+
+# ------------------------------------------------------------------ spectrogram pair (csrc/stft.hip)
+_FFT_TABLES = {}
+
+
+def fft_tables(n_fft, hop, device):
+    """(window, twiddles, envelope) of the n_fft-point periodic Hann STFT; the window is torch's own (bit-identical values),
+    the twiddles exp(-2 pi i k / N) are rounded from fp64"""
+    key = (n_fft, hop, str(device))
+    t = _FFT_TABLES.get(key)
+    if t is None:
+        import numpy as np
+        win = torch.hann_window(n_fft)
+        ang = -2.0 * np.pi * np.arange(n_fft // 2, dtype=np.float64) / n_fft
+        tw = torch.from_numpy(np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32))
+        env = (win * win).view(n_fft // hop, hop).sum(0)
+        t = _FFT_TABLES[key] = (win.to(device), tw.contiguous().to(device), env.contiguous().to(device))
+    return t
+
+
+def transpose2d(x):
+    """x [..., R, C] dense -> [..., C, R] dense"""
+    _need_gpu(x)
+    x = x.contiguous()
+    R, C = x.shape[-2], x.shape[-1]
+    y = torch.empty(*x.shape[:-2], C, R, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_transpose2d", _p(x), _p(y), x.numel() // (R * C), R, C, _stream())
+    return y
+
+
+def stft(x, n_fft, hop, T, pad):
+    """x [rows, L] -> z [rows, 2, T, n_fft/2] (re / im planes, Nyquist bin dropped), `_spec` framing (htdemucsq.py:931-950)"""
+    _need_gpu(x)
+    x, rows, L, ld = as_rowmat(x)
+    win, tw, _ = fft_tables(n_fft, hop, x.device)
+    z = torch.empty(rows, 2, T, n_fft // 2, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_stft", _p(x), _p(z), _p(win), _p(tw), rows, L, ld, n_fft, hop, T, pad, _stream())
+    return z
+
+
+def istft(z, n_fft, hop, pad, length):
+    """z [rows, 2, T, n_fft/2] -> y [rows, length]  (`_ispec`, htdemucsq.py:952-960)"""
+    _need_gpu(z)
+    z = z.contiguous()
+    rows, _, T, half = z.shape
+    assert half == n_fft // 2
+    win, tw, env = fft_tables(n_fft, hop, z.device)
+    frames = torch.empty(rows, T, n_fft, device=z.device, dtype=torch.float32)
+    y = empty_act((rows, length), z.device)
+    _lib.call("fqss_istft", _p(z), _p(frames), _p(y), _p(win), _p(env), _p(tw), rows, length, rowmat(y)[2], n_fft, hop, T, pad,
+              _stream())
+    return y
+
+
+def istft_bwd(g, n_fft, hop, pad, T):
+    _need_gpu(g)
+    g, rows, length, ld = as_rowmat(g)
+    win, tw, env = fft_tables(n_fft, hop, g.device)
+    gz = torch.empty(rows, 2, T, n_fft // 2, device=g.device, dtype=torch.float32)
+    _lib.call("fqss_istft_bwd", _p(g), _p(gz), _p(win), _p(env), _p(tw), rows, length, ld, n_fft, hop, T, pad, _stream())
+    return gz

@@ -514,6 +514,37 @@ int fqss_attn_long_bwd(const float* q, const float* k, const float* v, const flo
                        float* gk, float* gv, float* dsum, int Lq, int Lk, int B, int nh, int hd, const int64_t* strides,
                        fqss_stream_t stream);
 
+/* Small streaming kernels of the HTDemucs layers (csrc/hd_ops.hip).
+ * fqss_chan_op: y[b][c][m] = x[b][c][m] * s[c] (mode 0: LayerScale on channel-first tensors, demucsq.py:19-39) or + s[c] (mode 1:
+ *   the frequency-embedding add, htdemucsq.py:1063-1068, c = channel x frequency); fqss_chan_scale_bwd: gx = g * s[c],
+ *   gs[c] += sum g * x (gs caller-zeroed).  fqss_col_scale_fwd/bwd: the same on channel-last rows [R][C] (transformer gamma_1/2).
+ * fqss_sample_meanstd: ms[b] = (mean, unbiased std) of x[b][:n] (ws: 2*B doubles, zeroed by the caller);
+ * fqss_sample_norm: dir 0: (x - mean_b) / (1e-5 + std_b), dir 1: x * std_b + mean_b  (htdemucsq.py:1003-1014, 1034-1035).   */
+int fqss_chan_op(const float* x, const float* s, float* y, int64_t B, int64_t C, int64_t M, int64_t ld_x, int64_t ld_y, int mode,
+                 fqss_stream_t stream);
+int fqss_chan_scale_bwd(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t B, int64_t C, int64_t M,
+                        int64_t ld_g, int64_t ld_x, int64_t ld_gx, fqss_stream_t stream);
+int fqss_col_scale_fwd(const float* x, const float* s, float* y, int64_t R, int C, int64_t ld_x, int64_t ld_y, fqss_stream_t stream);
+int fqss_col_scale_bwd(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t R, int C, int64_t ld_g, int64_t ld_x,
+                       int64_t ld_gx, fqss_stream_t stream);
+int fqss_sample_meanstd(const float* x, double* ws, float* ms, int64_t B, int64_t n, fqss_stream_t stream);
+int fqss_sample_norm(const float* x, const float* ms, float* y, int64_t B, int64_t n, int dir, fqss_stream_t stream);
+
+/* Spectrogram pair of HTDemucsQ (csrc/stft.hip; replaces demucs.spec.spectro / ispectro = torch.stft / istft as called by
+ * HTDemucsQ._spec / _ispec, htdemucsq.py:931-960).  win [N]: periodic Hann window; tw [N/2] complex: exp(-2 pi i k / N);
+ * env [hop]: sum over the N/hop overlapping frames of win^2.  Spectra are [rows][2 (re, im)][T][N/2] with the Nyquist bin dropped.
+ * fqss_stft: frames f = 0 .. T-1 of the signal reflect-padded by `pad` on the left (and as needed on the right), scaled by
+ *   1/sqrt(N).  fqss_istft: y[j], j < length, of the inverse with 2 zero frames either side, window-envelope division and the
+ *   crop by N/2 + pad; `frames` is a workspace of rows*T*N floats.  fqss_istft_bwd: its adjoint (gradient wrt the spectrum).
+ * fqss_transpose2d: y[b][c][r] = x[b][r][c] (dense), the layout change between [.., T, Fr] and the model's [.., Fr, T].         */
+int fqss_stft(const float* x, float* z, const float* win, const float* tw, int64_t rows, int64_t L, int64_t ld_x, int N, int hop, int T,
+              int pad, fqss_stream_t stream);
+int fqss_istft(const float* z, float* frames, float* y, const float* win, const float* env, const float* tw, int64_t rows, int64_t length,
+               int64_t ld_y, int N, int hop, int T, int pad, fqss_stream_t stream);
+int fqss_istft_bwd(const float* g, float* gz, const float* win, const float* env, const float* tw, int64_t rows, int64_t length,
+                   int64_t ld_g, int N, int hop, int T, int pad, fqss_stream_t stream);
+int fqss_transpose2d(const float* x, float* y, int64_t batch, int64_t R, int64_t C, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -540,3 +540,76 @@ def test_attn_long(Lq, Lk, B, nh, hd, bf):
     close(gq, qr.grad, rtol=1e-4, atol=2e-5)
     close(gk, kr.grad, rtol=1e-4, atol=2e-5)
     close(gv, vr.grad, rtol=1e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------- HTDemucs small ops and the spectrogram pair (row a15)
+def test_chan_and_col_scale():
+    x, s, g = rnd(3, 5, 77, seed=1), rnd(5, seed=2), rnd(3, 5, 77, seed=3)
+    close(K.chan_op(padded(x), s.cuda(), 0), x * s[None, :, None], rtol=0, atol=0)
+    close(K.chan_op(padded(x), s.cuda(), 1), x + s[None, :, None], rtol=0, atol=0)
+    gs = torch.zeros(5, device="cuda")
+    gx = K.chan_scale_bwd(padded(g), padded(x), s.cuda(), gs)
+    close(gx, g * s[None, :, None], rtol=0, atol=0)
+    close(gs, (g * x).sum((0, 2)), rtol=1e-5, atol=1e-5)
+    xr, sr, gr = rnd(7, 9, 24, seed=4), rnd(24, seed=5), rnd(7, 9, 24, seed=6)
+    close(K.col_scale_fwd(xr.cuda(), sr.cuda()), xr * sr, rtol=0, atol=0)
+    gs = torch.zeros(24, device="cuda")
+    gx = K.col_scale_bwd(gr.cuda(), xr.cuda(), sr.cuda(), gs)
+    close(gx, gr * sr, rtol=0, atol=0)
+    close(gs, (gr * xr).sum((0, 1)), rtol=1e-5, atol=1e-5)
+
+
+def test_sample_norm():
+    x = rnd(3, 4, 50, 7, seed=8, scale=2.0) + 0.3
+    ms = K.sample_meanstd(x.cuda())
+    mean, std = x.mean((1, 2, 3)), x.std((1, 2, 3))
+    close(ms, torch.stack([mean, std], 1), rtol=1e-6, atol=1e-6)
+    y = K.sample_norm(x.cuda(), ms, False)
+    close(y, (x - mean.view(3, 1, 1, 1)) / (1e-5 + std.view(3, 1, 1, 1)), rtol=1e-5, atol=1e-6)
+    close(K.sample_norm(y, ms, True), x, rtol=1e-5, atol=1e-5)
+
+
+def _ref_spec(x, nfft):
+    """HTDemucsQ._spec (htdemucsq.py:931-950) with demucs.spec.spectro = torch.stft(normalized, centred, reflect, Hann)"""
+    hl = nfft // 4
+    le = -(-x.shape[-1] // hl)
+    pad = hl // 2 * 3
+    xp = F.pad(x, (pad, pad + le * hl - x.shape[-1]), mode="reflect")
+    z = torch.stft(xp, nfft, hl, window=torch.hann_window(nfft), win_length=nfft, normalized=True, center=True, return_complex=True,
+                   pad_mode="reflect")[..., :-1, :]
+    assert z.shape[-1] == le + 4
+    return z[..., 2:2 + le]
+
+
+def _ref_ispec(z, nfft, length):
+    """HTDemucsQ._ispec (htdemucsq.py:952-960) with demucs.spec.ispectro = torch.istft"""
+    hl = nfft // 4
+    z = F.pad(F.pad(z, (0, 0, 0, 1)), (2, 2))
+    pad = hl // 2 * 3
+    le = hl * -(-length // hl) + 2 * pad
+    x = torch.istft(z, nfft, hl, window=torch.hann_window(nfft), win_length=nfft, normalized=True, length=le, center=True)
+    return x[..., pad:pad + length]
+
+
+@pytest.mark.parametrize("nfft,L,rows", [(64, 333, 3), (4096, 20000, 2), (256, 1024, 1)])
+def test_stft_istft(nfft, L, rows):
+    hl = nfft // 4
+    le, pad = -(-L // hl), hl // 2 * 3
+    x = rnd(rows, L, seed=9)
+    want = _ref_spec(x, nfft)                                        # [rows, nfft/2, le] complex
+    z = K.stft(padded(x), nfft, hl, le, pad)                         # [rows, 2, le, nfft/2]
+    zt = K.transpose2d(z)                                            # [rows, 2, nfft/2, le]
+    close(zt[:, 0], want.real, rtol=1e-4, atol=2e-5)
+    close(zt[:, 1], want.imag, rtol=1e-4, atol=2e-5)
+    # inverse on a random spectrum, and its adjoint
+    zr = torch.complex(rnd(rows, nfft // 2, le, seed=10), rnd(rows, nfft // 2, le, seed=11)).requires_grad_(True)
+    y_ref = _ref_ispec(zr, nfft, L)
+    g = rnd(rows, L, seed=12)
+    y_ref.backward(g)
+    planes = torch.stack([zr.detach().real, zr.detach().imag], 1).cuda()                # [rows, 2, nfft/2, le]
+    y = K.istft(K.transpose2d(planes), nfft, hl, pad, L)
+    close(y, y_ref, rtol=1e-4, atol=2e-5)
+    gz = K.transpose2d(K.istft_bwd(padded(g), nfft, hl, pad, le))
+    close(gz[:, 0], zr.grad.real, rtol=1e-4, atol=2e-5)
+    # torch's complex gradient convention: grad = dL/dRe + i dL/dIm
+    close(gz[:, 1], zr.grad.imag, rtol=1e-4, atol=2e-5)
