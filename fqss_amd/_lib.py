@@ -61,6 +61,7 @@ _PROTOS = {
     "fqss_mul_bcast_fwd": [P, P, P, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_mul_bcast_bwd": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, P],
     "fqss_splitter2": [P, P, I32, I64, P, P],
+    "fqss_splitter2_raw": [P, P, I32, I64, P, P],
     "fqss_frames_conv_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I32, I64, P],
     "fqss_ola_convtr_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I64, P],
     "fqss_frames_wgrad": [P, P, P, I32, I32, I32, I32, I64, I64, I32, I32, P],
@@ -110,6 +111,7 @@ _PROTOS = {
     "fqss_istft": [P, P, P, P, P, P, I64, I64, I64, I32, I32, I32, I32, P],
     "fqss_istft_bwd": [P, P, P, P, P, I64, I64, I64, I32, I32, I32, I32, P],
     "fqss_transpose2d": [P, P, I64, I64, I64, P],
+    "fqss_hd_kd_loss": [P, P, P, P, P, P, P, P, I32, I32, I64, F32, P],
     "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
     "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
 }

@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd(const float* __restrict__
             Ks[e] = k[(int64_t)(j0 + j) * g.k.sl + (int64_t)b * g.k.sb + h * HD + d];
             Vs[e] = v[(int64_t)(j0 + j) * g.v.sl + (int64_t)b * g.v.sb + h * HD + d];
         }
+        // padding keys of the last tile: their probability is exp(-inf) = 0, but 0 * (stale LDS contents) must stay 0
+        for (int e = nj * HD + threadIdx.x; e < kTK * HD; e += 256) { Ks[e] = 0.f; Vs[e] = 0.f; }
         __syncthreads();
         float s[kTK];
         float tmax = -INFINITY;

@@ -35,6 +35,24 @@ __global__ __launch_bounds__(256) void k_splitter2(const float* __restrict__ x, 
     }
 }
 
+// preprocess(x, n_splitter=2, normalize=False) (process.py:26-36; the time branch of HTDemucsQ.pre_process): the threshold is
+// max|x| and x is NOT divided by it; delta = thr / 128
+__global__ __launch_bounds__(256) void k_splitter2_raw(const float* __restrict__ x, float* __restrict__ out, int B, int64_t T,
+                                                        const uint32_t* obs) {
+    const float mn = ord2f(obs[0]), mx = ord2f(obs[1]);
+    const float thr = fmaxf(fabsf(mn), fabsf(mx));
+    const float delta = thr / 128.0f;
+    const int64_t n = (int64_t)B * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / T, t = i - b * T;
+        const float v = x[i];
+        const float q0 = fminf(fmaxf(floorf(v / delta), -128.0f), 127.0f) * delta;
+        const float r = ((2.0f * (v - q0)) * thr) / delta - thr;      // process.py:35 op order
+        out[(b * 2 + 0) * T + t] = q0;
+        out[(b * 2 + 1) * T + t] = fminf(fmaxf(floorf(r / delta), -128.0f), 127.0f) * delta;
+    }
+}
+
 // z[n][co][m] = sum_{ci,k} w[co][ci][k] * x[n][ci][m*STRIDE + k] ; block = 64 frames x all Co (4 waves split Co)
 template <int CI, int K>
 __global__ __launch_bounds__(256) void k_frames_conv_fwd(const float* __restrict__ x, const float* __restrict__ w,
@@ -121,6 +139,16 @@ extern "C" int fqss_splitter2(const float* x, float* out, int B, int64_t T, cons
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(k_splitter2, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, B, T, obs_ws);
     return launch_status("fqss_splitter2");
+}
+
+extern "C" int fqss_splitter2_raw(const float* x, float* out, int B, int64_t T, const uint32_t* obs_ws, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && out && obs_ws, "null tensor");
+    FQSS_REQUIRE(B >= 0 && T >= 0, "bad shape");
+    if (B == 0 || T == 0) return FQSS_OK;
+    int64_t nb = cdiv((int64_t)B * T, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_splitter2_raw, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, out, B, T, obs_ws);
+    return launch_status("fqss_splitter2_raw");
 }
 
 extern "C" int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci, int Co, int64_t T, int K,

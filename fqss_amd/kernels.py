@@ -565,8 +565,9 @@ def mul_bcast_bwd(gz, mask, feat):
 
 
 # ------------------------------------------------------------------ K10-K13  codec
-def splitter2(x):
-    """x [B,1,T] or [B,T] -> [B,2,T] (process.preprocess, n_splitter=2)"""
+def splitter2(x, normalize=True):
+    """x [B,1,T] or [B,T] -> [B,2,T] (process.preprocess, n_splitter=2); multi-channel inputs [B, A, ...] flatten to [B, A*...]:
+    the [B, 2, A*...] result IS torch.cat([msb, lsb], dim=1)"""
     _need_gpu(x)
     x2 = x.reshape(x.shape[0], -1).contiguous()
     B, T = x2.shape
@@ -574,7 +575,7 @@ def splitter2(x):
     obs_reset(ws)
     minmax(x2, ws)
     out = torch.empty(B, 2, T, device=x.device, dtype=torch.float32)
-    _lib.call("fqss_splitter2", _p(x2), _p(out), B, T, _p(ws), _stream())
+    _lib.call("fqss_splitter2" if normalize else "fqss_splitter2_raw", _p(x2), _p(out), B, T, _p(ws), _stream())
     return out
 
 
@@ -1260,3 +1261,18 @@ def istft_bwd(g, n_fft, hop, pad, T):
     gz = torch.empty(rows, 2, T, n_fft // 2, device=g.device, dtype=torch.float32)
     _lib.call("fqss_istft_bwd", _p(g), _p(gz), _p(win), _p(env), _p(tw), rows, length, ld, n_fft, hop, T, pad, _stream())
     return gz
+
+
+def hd_kd_loss(est, fest, src, weights, kd_lambda, want_grad=True):
+    """htdemucs solver loss (solver.py:333-366): est / fest / src [B, S, C, T] -> (loss [1], task [S], kd [S], w [B, S], dloss/dest)"""
+    _need_gpu(est, fest, src, weights)
+    est, fest, src = est.contiguous(), fest.contiguous(), src.contiguous()
+    B, S = est.shape[0], est.shape[1]
+    N = est.numel() // (B * S)
+    assert fest.shape == est.shape and src.shape == est.shape and weights.numel() == S
+    sums = torch.zeros(B * S * 5, device=est.device, dtype=torch.float64)
+    out = torch.empty(1 + 2 * S + B * S, device=est.device, dtype=torch.float32)
+    coef = torch.empty(B * S * 2, device=est.device, dtype=torch.float32)
+    g = torch.empty_like(est) if want_grad else None
+    _lib.call("fqss_hd_kd_loss", _p(est), _p(fest), _p(src), _p(weights), _p(sums), _p(out), _p(coef), _p(g), B, S, N, float(kd_lambda), _stream())
+    return out[:1], out[1:1 + S], out[1 + S:1 + 2 * S], out[1 + 2 * S:].view(B, S), g

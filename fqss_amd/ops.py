@@ -705,3 +705,19 @@ class KDLoss(Function):
     def backward(ctx, g_loss, g_kd, g_w, g_s):
         (gest,) = ctx.saved_tensors
         return gest * g_loss, None, None, None
+
+
+class HdKDLoss(Function):
+    """loss of the htdemucs solver (solver.py:333-366): (1 - lambda) L1(est, src) + lambda w L1(est, fest) per source, source-weighted"""
+
+    @staticmethod
+    def forward(ctx, est, fest, src, weights, kd_lambda):
+        loss, task, kd, w, g = K.hd_kd_loss(est, fest, src, weights, kd_lambda, want_grad=True)
+        ctx.save_for_backward(g)
+        ctx.mark_non_differentiable(task, kd, w)
+        return loss.reshape(()), task, kd, w
+
+    @staticmethod
+    def backward(ctx, gl, *_):
+        (g,) = ctx.saved_tensors
+        return g * gl, None, None, None, None

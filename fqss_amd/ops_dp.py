@@ -550,3 +550,68 @@ class MhaCoreX(Function):
             else:
                 blk.copy_(g)
         return (gXq, None if same else gXkv, None, None, None, *grads)
+
+
+# ----------------------------------------------------------------------------------------------
+# LayerScale / frequency-embedding streams (csrc/hd_ops.hip)
+# ----------------------------------------------------------------------------------------------
+class ChanScale(Function):
+    """x [B, C, M] * s [C]  (LayerScale on channel-first tensors, demucsq.py:36-39)"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        s = s.contiguous()
+        ctx.save_for_backward(x, s)
+        ctx.s_in = s
+        return K.chan_op(x, s, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        gs = torch.zeros_like(s)
+        gx = K.chan_scale_bwd(g, x, s, gs)
+        return gx, gs
+
+
+class ColScale(Function):
+    """x [..., C] * s [C]  (LayerScale on channel-last rows: transformer gamma_1 / gamma_2)"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        s = s.contiguous()
+        ctx.save_for_backward(x, s)
+        return K.col_scale_fwd(x, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        gs = torch.zeros_like(s)
+        gx = K.col_scale_bwd(g, x, s, gs)
+        return gx, gs
+
+
+class ChanAdd(Function):
+    """x [B, C, M] + e [C]  (the frequency embedding added along batch and time, htdemucsq.py:1063-1068)"""
+
+    @staticmethod
+    def forward(ctx, x, e):
+        return K.chan_op(x, e.contiguous(), 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ge = torch.zeros(g.shape[1], device=g.device, dtype=torch.float32)
+        K.chan_sum(g, ge)
+        return g, ge
+
+
+class ScalarMul(Function):
+    """x * python scalar (ScaledEmbedding, mul_freq: hdemucsq.py:67-69, htdemucsq.py:1068)"""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.c = float(c)
+        return K.axpby(x, x, 0.0, sa=ctx.c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.axpby(g, g, 0.0, sa=ctx.c), None

@@ -20,9 +20,15 @@ def preprocess(x, n_splitter=1, n_bits=8, sign=True, normalize=True):
         x = x.unsqueeze(1)
     if n_splitter <= 1:
         return x
-    if n_splitter != 2 or n_bits != 8 or not sign or not normalize or x.shape[1] != 1:
-        raise NotImplementedError("the splitter kernel serves n_splitter=2, 8 bit, signed, normalised, mono (all FQSS speech configs)")
-    return ops.splitter2(x)
+    if n_splitter != 2 or n_bits != 8 or not sign:
+        raise NotImplementedError("the splitter kernel serves n_splitter=2, 8 bit, signed")
+    if normalize and x.shape[1] == 1 and x.dim() == 3:
+        return ops.splitter2(x)
+    # multi-channel / multi-dimensional inputs (HTDemucs: [B, A, Fr, T] spectrogram, [B, A, T] waveform): the flattened
+    # [B, 2, A*...] result is torch.cat([msb, lsb], dim=1)
+    with torch.no_grad():
+        y = K.splitter2(x, normalize=normalize)
+    return y.view(x.shape[0], 2 * x.shape[1], *x.shape[2:])
 
 
 def postprocess(x, n_combiner=1, n_bits=8, sign=True):

@@ -5,6 +5,7 @@ from ..qat_layers import LayerQ
 from ..qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
 from .convtasnetq import ConvTasNetQ
 from .dptnetq import DPTNetQ
+from .htdemucsq import HTDemucsQ
 from .sepformerq import SepformerQ
 
 
@@ -30,8 +31,14 @@ def create_model(model_cfg):
     if name == "Sepformer":
         return SepformerQ(n_spks=model_cfg.get("n_src", 2), kernel_size=model_cfg.get("kernel_size", 16),
                           stride=model_cfg.get("stride", 8))
-    if name in ("ConvTasNetMusic", "HTDemucs"):
-        raise NotImplementedError(f"{name}: SURVEY.md §8 row a15 (later rounds); this build serves ConvTasNet, DPTNet and Sepformer")
+    if name == "HTDemucs":
+        path = model_cfg.get("model_path", None)
+        if path:
+            return HTDemucsQ(**_load_any(path)["kwargs"])
+        return HTDemucsQ(sources=model_cfg.get("sources", ["drums", "bass", "other", "vocals"]))
+    if name == "ConvTasNetMusic":
+        raise NotImplementedError(f"{name}: the tasnet_musdbhq environment is outside SURVEY.md §8; this build serves ConvTasNet, DPTNet, "
+                                  "Sepformer and HTDemucs")
     raise AssertionError("Model {} is not supported!".format(name))
 
 

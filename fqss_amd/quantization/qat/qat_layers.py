@@ -41,6 +41,18 @@ class Sub(nn.Module):
         return ops.AddActQ.apply(x1, x2, None, None, -1.0, ops.BYPASS)
 
 
+def _mul_special(x1, x2):
+    """the products of the HTDemucs layers that are not tensor x tensor: LayerScale (x * scale[:, None] channel-first, x * scale
+    channel-last; demucsq.py:36-39) and x * python scalar (ScaledEmbedding, mul_freq); None when x2 is an ordinary operand"""
+    if not torch.is_tensor(x2):
+        return ops_dp.ScalarMul.apply(ops.real(x1), float(x2))
+    if x2.dim() == 2 and x2.shape[1] == 1 and x1.dim() == 3 and x1.shape[1] == x2.shape[0]:
+        return ops_dp.ChanScale.apply(ops.real(x1), x2.reshape(-1))
+    if x2.dim() == 1 and x1.dim() >= 2 and x1.shape[-1] == x2.shape[0] and x1.shape != x2.shape:
+        return ops_dp.ColScale.apply(ops.real(x1), x2)
+    return None
+
+
 def _mul_any(x1, x2, qmin, qmax, q):
     """mask[B,S,C,M] * feat[B,1,C,M] (ConvTasNet masking) or same-shape multiply"""
     if torch.is_tensor(x2) and x1.dim() == 4 and x2.dim() == 4 and x2.shape[1] == 1 and x1.shape[0] == x2.shape[0] \
@@ -58,7 +70,8 @@ def _mul_any(x1, x2, qmin, qmax, q):
 
 class Mul(nn.Module):
     def forward(self, x1, x2):
-        return _mul_any(x1, x2, None, None, ops.BYPASS)
+        y = _mul_special(x1, x2)
+        return y if y is not None else _mul_any(x1, x2, None, None, ops.BYPASS)
 
 
 class Div(nn.Module):
@@ -139,6 +152,9 @@ class MulQ(LayerQ):
 
     def forward(self, x1, x2):
         aq = self.activation_fake_quantize
+        y = _mul_special(x1, x2)
+        if y is not None:
+            return fq_node(aq, y)
         q = aq.qctx()
         y = _mul_any(ops.real(x1), ops.real(x2), q.qmin, q.qmax, q)
         aq.after_forward(q)

@@ -326,6 +326,8 @@ int fqss_mul_bcast_bwd(const float* gz, const float* mask, const float* feat, fl
 /* x [B][T] -> out [B][2][T]; obs_ws must hold the global min/max of x (fqss_minmax) */
 int fqss_splitter2(const float* x, float* out, int B, int64_t T, const uint32_t* obs_ws,
                    fqss_stream_t stream);
+/* the same with normalize=False (process.py:26-27: threshold = max|x|, x is not divided by it; HTDemucs time branch) */
+int fqss_splitter2_raw(const float* x, float* out, int B, int64_t T, const uint32_t* obs_ws, fqss_stream_t stream);
 /* z[n][co][m] = sum_{ci,k} w[co][ci][k] * x[n][ci][m*stride+k]   (x: [N][Ci][T] dense)        */
 int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci, int Co,
                          int64_t T, int K, int stride, int M, int64_t ld_z, fqss_stream_t stream);
@@ -544,6 +546,12 @@ int fqss_istft(const float* z, float* frames, float* y, const float* win, const 
 int fqss_istft_bwd(const float* g, float* gz, const float* win, const float* env, const float* tw, int64_t rows, int64_t length,
                    int64_t ld_g, int N, int hop, int T, int pad, fqss_stream_t stream);
 int fqss_transpose2d(const float* x, float* y, int64_t batch, int64_t R, int64_t C, fqss_stream_t stream);
+
+/* Training loss of the htdemucs environment (csrc/hd_loss.hip; solver.py:333-366 with demucs' new_sdr): L1 task loss + SDR-weighted
+ * L1 distillation loss per source, source weights wt [S].  est / fest / src [B][S][N] dense.  sums: B*S*5 doubles zeroed by the
+ * caller; out: [loss, task_s.., kd_s.., w_bs..] = 1 + 2S + B*S floats; coef: B*S*2 floats of scratch; gest (optional) = dloss/dest. */
+int fqss_hd_kd_loss(const float* est, const float* fest, const float* src, const float* wt, double* sums, float* out, float* coef,
+                    float* gest, int B, int S, int64_t N, float kd_lambda, fqss_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -613,3 +613,19 @@ def test_stft_istft(nfft, L, rows):
     close(gz[:, 0], zr.grad.real, rtol=1e-4, atol=2e-5)
     # torch's complex gradient convention: grad = dL/dRe + i dL/dIm
     close(gz[:, 1], zr.grad.imag, rtol=1e-4, atol=2e-5)
+
+
+def test_attn_long_short_key_tile_ignores_stale_lds():
+    """Lk below one LDS tile: the padding keys carry probability 0, whatever the tile held before (a NaN-filled launch first)"""
+    B, nh, hd, Lq, Lk = 2, 2, 8, 9, 20
+    E = nh * hd
+    bad = torch.full((B, 64, E), float("nan"), device="cuda")
+    K.attn_long_fwd(bad, bad, bad, nh, True)
+    q, k, v = rnd(B, Lq, E, seed=1).cuda(), rnd(B, Lk, E, seed=2).cuda(), rnd(B, Lk, E, seed=3).cuda()
+    o, stats = K.attn_long_fwd(q, k, v, nh, True)
+    assert torch.isfinite(o).all()
+    h = lambda t, L: t.reshape(B, L, nh, hd).permute(0, 2, 1, 3)
+    want = (torch.softmax(h(q, Lq) @ h(k, Lk).transpose(-1, -2), -1) @ h(v, Lk)).permute(0, 2, 1, 3).reshape(B, Lq, E)
+    close(o, want, rtol=2e-5, atol=2e-5)
+    gq, gk, gv = K.attn_long_bwd(q, k, v, o, rnd(B, Lq, E, seed=4).cuda(), stats, nh, True)
+    assert torch.isfinite(gq).all() and torch.isfinite(gk).all() and torch.isfinite(gv).all()
