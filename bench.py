@@ -38,8 +38,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4"),
-                    help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s")
+    ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5"),
+                    help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s; "
+                         "cfg5 HTDemucs 4 x 10 s stereo 44.1 kHz")
+    ap.add_argument("--hd-batch", type=int, default=4, help="cfg5: samples per GPU (htdemucs.yaml: 32 over 8 GPUs)")
+    ap.add_argument("--hd-seconds", type=float, default=10.0, help="cfg5: segment length in seconds (htdemucs.yaml: 10)")
     return ap.parse_args()
 
 
@@ -208,8 +211,124 @@ def main_dualpath(a):
     comm.close()
 
 
+def attn_roofline(B, nh, L, hd):
+    """the streaming attention core (csrc/attn_long.hip) at the spectrogram branch's self-attention shape: HIP events on torch's
+    current stream; 4 L^2 hd flops per (batch, head); priced against the fp32 MFMA peak its GEMM-shaped arithmetic could reach"""
+    from fqss_amd import kernels as K
+    E = nh * hd
+    q, k, v = (torch.randn(B, L, E, device="cuda") * 0.3 for _ in range(3))
+    for _ in range(2):
+        K.attn_long_fwd(q, k, v, nh, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        K.attn_long_fwd(q, k, v, nh, True)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 5 * 1e3
+    tf = 4.0 * L * L * hd * B * nh / us * 1e-6
+    return {"kernel": "k_attn_long_fwd<%d>" % hd, "what": "self-attention of the spectrogram branch", "shape": [B, nh, L, hd], "bound": "mfma",
+            "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
+
+
+def cpu_baseline_htdemucs(model, fmodel, B, T):
+    """oracle/htdemucs_oracle.py on the host cores, bounded: ONE quantizing-phase step (student fwd + bwd, teacher fwd, loss) on a
+    1 x 1 s excerpt, scaled by the excerpt's share of the workload's samples"""
+    import oracle.htdemucs_oracle as H
+    cores = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    fsd = {k: v.detach().cpu() for k, v in fmodel.state_dict().items()}
+    kw = dict(n_src=model.n_srcs, audio_channels=model.audio_channels, nfft=model.nfft, depth=model.depth,
+              t_layers=model.crosstransformer.num_layers, t_heads=model.crosstransformer.layers[0].self_attn.mha.num_heads,
+              bottom=bool(model.bottom_channels))
+    s_o, t_o = H.HTDemucsOracle(sd, quantized=True, **kw), H.HTDemucsOracle(fsd, quantized=False, **kw)
+    s_o.leave_observer_phase()
+    Tc = min(T, 44100)
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(1, model.n_srcs, model.audio_channels, Tc, generator=g) * 0.1
+    mix = src.sum(1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        fest = t_o.forward(mix)
+    est = s_o.forward(mix)
+    loss = H.solver_loss(est, fest, src)[0]
+    loss.backward()
+    sec = time.perf_counter() - t0
+    return {"value": round((Tc / T) / sec, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"one QAT step of the oracle (student fwd + bwd, teacher fwd, loss; no optimizer) on 1 x {Tc} samples ({sec:.1f} s), "
+                      f"scaled by {Tc}/{T} to the workload's segment length, torch CPU fp32"}
+
+
+def main_htdemucs(a):
+    """cfg 5: HTDemucs, stereo 44.1 kHz, 4 sources, the shipped per-GPU batch (32 / 8 GPUs) x 10 s; step = student fwd + teacher
+    fwd + solver loss + bwd (+ all-reduce) + Adam (htdemucs.yaml: lr 3e-4, no clipping), same timing protocol as cfg 2"""
+    import copy
+    from fqss_amd.parallel import Comm
+    from fqss_amd.quantization.qat.models.load_model import quantize_model
+    from fqss_amd.quantization.qat.models.htdemucsq import HTDemucsQ
+    from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
+    from fqss_amd.runtime import KDTrainStep
+    comm = Comm.from_env("cuda")
+    assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
+    ldev = comm.local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(ldev)
+    dev = torch.device("cuda", ldev)
+    torch.manual_seed(0)
+    B, T = a.hd_batch, int(round(a.hd_seconds * 44100))
+    model = HTDemucsQ(sources=["drums", "bass", "other", "vocals"], bottom_channels=512, segment=a.hd_seconds)
+    fmodel = copy.deepcopy(model).to(dev).eval()
+    qcfg = dict(qat=True, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True, act_n_bits=8, in_quant=False,
+                in_act_n_bits=8, out_quant=True, out_act_n_bits=8, n_splitter=2, n_combiner=2, observer=True)
+    model = quantize_model(model, qcfg).to(dev).train()
+    g = torch.Generator().manual_seed(42 + comm.rank)
+    src = (torch.randn(B, 4, 2, T, generator=g) * 0.1).to(dev)            # synthetic stereo Gaussian stems (SURVEY.md §8(d))
+    mix = src.sum(1)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, comm=comm, loss="l1_sdr", batched_quantizers=False)
+    step(mix, src)                                          # untimed calibration: the 50-call observer phase
+    with torch.no_grad():
+        for _ in range(49):
+            model(mix)
+    assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
+    step(mix, src)
+    launch = "eager"
+    if not a.no_graph:
+        step.capture(mix, src)
+        launch = "hipGraph replay"
+    for _ in range(a.warmup):
+        step(mix, src)
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = step(mix, src)
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    comm.all_reduce_max(dt)
+    dt = dt.item()
+    if comm.rank == 0:
+        ms = dt / a.steps * 1e3
+        Fr, le = 8, -(-T // 1024)
+        out = {"metric": "QAT-step samples/sec, HTDemucs 4 stems stereo 44.1kHz W8A8", "value": round(comm.world * B * a.steps / dt, 3),
+               "unit": "samples/s", "n_gpus": comm.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"HTDemucs 4-stem stereo 44.1 kHz W8A8 QAT step (cfg5), batch {B} x {a.hd_seconds:g} s per GPU, "
+                                      "quantizing phase, bottom_channels 512", "global_batch": comm.world * B, "segment_samples": T,
+                          "parallelism": f"dp{comm.world}", "kd_lambda": 0.1, "optimizer": "adam lr 0.0003, no clipping", "launch": launch},
+               "loss": round(r["loss"].item(), 6), "params": sum(p.numel() for p in model.parameters()),
+               "roofline": attn_roofline(B, 8, Fr * le, 64)}
+        if comm.world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_htdemucs(model, fmodel, B, T)
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+    comm.close()
+
+
 def main():
     a = parse()
+    if a.workload == "cfg5":
+        return main_htdemucs(a)
     assert torch.cuda.is_available(), "bench.py needs ROCm GPUs"
     if a.workload != "cfg2":
         return main_dualpath(a)

@@ -535,14 +535,15 @@ using namespace fqss;
 extern "C" int fqss_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
                                   int64_t R, int C, int64_t ld_x, int64_t ld_y, double eps, fqss_stream_t stream) {
     FQSS_REQUIRE(x && gamma && beta && y && mean_rstd, "null tensor");
-    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 256 && ld_x >= C && ld_y >= C, "bad shape (C <= 256)");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_x >= C && ld_y >= C, "bad shape (C <= 512)");
     if (R == 0) return FQSS_OK;
     int64_t nb = cdiv(R, 4);
     if (nb > 4096) nb = 4096;
     hipStream_t s = (hipStream_t)stream;
     const float e = (float)eps;
     if (C <= 64) hipLaunchKernelGGL((k_layernorm_fwd<1>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
-    else hipLaunchKernelGGL((k_layernorm_fwd<4>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
+    else if (C <= 256) hipLaunchKernelGGL((k_layernorm_fwd<4>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
+    else hipLaunchKernelGGL((k_layernorm_fwd<8>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);   // HTDemucs transformer: 384 / 512
     return launch_status("fqss_layernorm_fwd");
 }
 
@@ -550,14 +551,15 @@ extern "C" int fqss_layernorm_bwd(const float* gy, const float* x, const float* 
                                   float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy, int64_t ld_x, int64_t ld_gx,
                                   fqss_stream_t stream) {
     FQSS_REQUIRE(gy && x && gamma && mean_rstd && gx && ggamma && gbeta, "null tensor");
-    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 256 && ld_gy >= C && ld_x >= C && ld_gx >= C, "bad shape (C <= 256)");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_gy >= C && ld_x >= C && ld_gx >= C, "bad shape (C <= 512)");
     if (R == 0) return FQSS_OK;
     int64_t nb = cdiv(R, 4 * 16);       // ~16 rows per wave: 64*C atomics per workgroup stay rare
     if (nb < 1) nb = 1;
     if (nb > 2048) nb = 2048;
     hipStream_t s = (hipStream_t)stream;
     if (C <= 64) hipLaunchKernelGGL((k_layernorm_bwd<1>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
-    else hipLaunchKernelGGL((k_layernorm_bwd<4>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
+    else if (C <= 256) hipLaunchKernelGGL((k_layernorm_bwd<4>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
+    else hipLaunchKernelGGL((k_layernorm_bwd<8>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
     return launch_status("fqss_layernorm_bwd");
 }
 

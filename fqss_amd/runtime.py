@@ -309,8 +309,13 @@ class KDTrainStep:
     left the observer phase; the step has no host sync, so replay needs no Python at all.  At N>1 the
     RCCL all-reduce of the flat gradient buffer runs between the two graphs."""
 
-    def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None):
+    def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None, loss="sisdr_pit", source_weights=None,
+                 batched_quantizers=True):
+        """loss: "sisdr_pit" = the asteroid / speechbrain KD loss (mysystem.py:124-151); "l1_sdr" = the htdemucs solver's
+        (solver.py:333-366: L1 task + SDR-weighted L1 distillation, per-source weights).  clip <= 0: no clipping (htdemucs.yaml:84).
+        batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow)"""
         self.model, self.fmodel = model, fmodel
+        self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
         self._graphs = None
         self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
         self.comm = comm
@@ -381,15 +386,24 @@ class KDTrainStep:
             fest.record_stream(cur)
         else:
             fest = self.teacher(x)
-        out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
+        if self.loss_kind == "l1_sdr":
+            if self.source_weights is None:
+                self.source_weights = torch.ones(tgt.shape[1], device=tgt.device)
+            loss, task, kd, w, gest = K.hd_kd_loss(est.detach(), fest, tgt, self.source_weights, self.kd_lambda, want_grad=True)
+            res = dict(loss=loss, task=task, kd=kd, w=w, gnorm=a.gnorm, est=est.detach())
+        else:
+            out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
+            res = dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
         with ops.deferred(t):
             est.backward(gest)
         if t is not None:
             t.finish_backward()                # weight STE + every range/slope gradient: two launches
-        return dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
+        return res
 
     def _quant_tables(self):
         """batched per-quantizer work becomes available once every observer has finished"""
+        if not self.batched_quantizers:
+            return None
         if self.tables is None:
             from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
             for m in self.model.modules():

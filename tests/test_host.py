@@ -93,7 +93,34 @@ def test_graph_rewrite_and_state_dict_layout(golden):
     assert len(full.state_dict()) == 948
     assert sum(p.numel() for p in full.parameters()) == 5133123
     with pytest.raises(NotImplementedError):
-        create_model({"name": "HTDemucs"})
+        create_model({"name": "ConvTasNetMusic"})
+
+
+def test_htdemucs_graph_rewrite_and_state_dict_layout(golden):
+    """cfg 5: the HTDemucs module tree quantizes into the reference's key set, in the reference's order (hd_tiny_step.npz holds the
+    reference's float and quantized state_dicts of the tiny configuration); full-size parameter count of the float model"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    from fqss_amd.quantization.qat.models.htdemucsq import HTDemucsQ
+    from fqss_amd.quantization.qat.models.load_model import create_model, quantize_model
+    g = golden("hd_tiny_step")
+    kw = dict(sources=["a", "b"], audio_channels=2, channels=8, nfft=2048, depth=4, bottom_channels=16, t_layers=3, t_heads=2)
+    f = HTDemucsQ(**kw)
+    assert list(f.state_dict().keys()) == [k[4:] for k in g.files if k.startswith("fsd.")]
+    q = dict(qat=True, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True, act_n_bits=8, in_quant=False,
+             in_act_n_bits=8, out_quant=True, out_act_n_bits=8, n_splitter=2, n_combiner=2, observer=True)
+    m = quantize_model(HTDemucsQ(**kw), q)
+    ref = [k[4:] for k in g.files if k.startswith("sd0.")]
+    assert list(m.state_dict().keys()) == ref
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == g["sd0." + k].shape, k
+    assert isinstance(m.encoder[0].conv, QL.Conv2dEncoderQ) and isinstance(m.tencoder[0].conv, QL.Conv1dEncoderQ)
+    assert isinstance(m.decoder[3].conv_tr, QL.ConvTr2dDecoderQ) and m.decoder[3].conv_tr.residual_error_block.train_res_dec
+    assert isinstance(m.tdecoder[3].conv_tr, QL.ConvTr1dDecoderQ) and not m.tdecoder[3].conv_tr.residual_error_block.train_res_dec
+    assert isinstance(m.encoder[1].dconv.layers[0][0], QL.Conv1dGnNlQ) and isinstance(m.encoder[1].dconv.layers[0][6].mul, QL.MulQ)
+    assert isinstance(m.crosstransformer.layers[1].cross_attn, QL.MultiheadAttentionQ)
+    assert isinstance(m.crosstransformer.layers[0].norm_out.const, QL.ConstQ)
+    full = create_model({"name": "HTDemucs"})
+    assert sum(p.numel() for p in full.parameters()) == 26899536          # (measured on the reference: HTDemucsQ() defaults, 4 sources)
 
 
 def test_dptnet_graph_rewrite_and_state_dict_layout(golden):
