@@ -27,6 +27,19 @@ struct AttnGeom {
 };
 
 constexpr int kTK = 32;   // keys (or queries, in the dk/dv pass) per LDS tile
+constexpr int kAcc = 4;   // partial sums per dot product in the backward passes
+
+template <int N>
+__device__ __forceinline__ float tree_sum(const float (&v)[N]) {
+    float t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = v[i];
+#pragma unroll
+    for (int w = N / 2; w > 0; w /= 2)
+#pragma unroll
+        for (int i = 0; i < w; ++i) t[i] += t[i + w];
+    return t[0];
+}
 
 template <int HD>
 __global__ __launch_bounds__(256) void k_attn_long_fwd(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
@@ -127,13 +140,22 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_q(const float* __restrict
             Vs[e] = v[(int64_t)(j0 + j) * g.v.sl + (int64_t)b * g.v.sb + h * HD + d];
         }
         __syncthreads();
+        // each dot product is split over 2 * kAcc partial sums: 16 independent FMA chains per lane (one wave per SIMD at this register
+        // budget: the dependent 64-long chains of the plain form left the FMA pipe idle 3 cycles in 4)
         for (int j = 0; j < nj; ++j) {
-            float s = 0.f, dp = 0.f;
+            const float* k0 = Ks + j * HD;
+            const float* v0 = Vs + j * HD;
+            float sa[2 * kAcc], pa[2 * kAcc];
 #pragma unroll
-            for (int d = 0; d < HD; ++d) { s = fmaf(qr[d], Ks[j * HD + d], s); dp = fmaf(gor[d], Vs[j * HD + d], dp); }
-            const float ds = (expf(s - m) * rl) * (dp - D);
+            for (int a = 0; a < 2 * kAcc; ++a) sa[a] = pa[a] = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] = fmaf(ds, Ks[j * HD + d], acc[d]);
+            for (int d = 0; d < HD; ++d) {
+                sa[d % (2 * kAcc)] = fmaf(qr[d], k0[d], sa[d % (2 * kAcc)]);
+                pa[d % (2 * kAcc)] = fmaf(gor[d], v0[d], pa[d % (2 * kAcc)]);
+            }
+            const float ds0 = (expf(tree_sum<2 * kAcc>(sa) - m) * rl) * (tree_sum<2 * kAcc>(pa) - D);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(ds0, k0[d], acc[d]);
         }
     }
     if (live) {
@@ -176,14 +198,24 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv(const float* __restric
             Ds[threadIdx.x] = dsum[(int64_t)bh * g.Lq + i0 + threadIdx.x];
         }
         __syncthreads();
-        for (int i = 0; i < ni; ++i) {
-            float s = 0.f, dp = 0.f;
+        for (int i = 0; i < ni; ++i) {            // one query row per iteration (the four 64-wide register arrays leave no room for two)
+            const float* q0 = Qs + i * HD;
+            const float* g0 = Gs + i * HD;
+            float sa[2 * kAcc], pa[2 * kAcc];
 #pragma unroll
-            for (int d = 0; d < HD; ++d) { s = fmaf(Qs[i * HD + d], kr[d], s); dp = fmaf(Gs[i * HD + d], vr[d], dp); }
-            const float p = expf(s - Ms[i]) * Rs[i];
-            const float ds = p * (dp - Ds[i]);
+            for (int a = 0; a < 2 * kAcc; ++a) sa[a] = pa[a] = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) { av[d] = fmaf(p, Gs[i * HD + d], av[d]); ak[d] = fmaf(ds, Qs[i * HD + d], ak[d]); }
+            for (int d = 0; d < HD; ++d) {
+                sa[d % (2 * kAcc)] = fmaf(q0[d], kr[d], sa[d % (2 * kAcc)]);
+                pa[d % (2 * kAcc)] = fmaf(g0[d], vr[d], pa[d % (2 * kAcc)]);
+            }
+            const float p0 = expf(tree_sum<2 * kAcc>(sa) - Ms[i]) * Rs[i];
+            const float ds0 = p0 * (tree_sum<2 * kAcc>(pa) - Ds[i]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                av[d] = fmaf(p0, g0[d], av[d]);
+                ak[d] = fmaf(ds0, q0[d], ak[d]);
+            }
         }
     }
     if (live) {

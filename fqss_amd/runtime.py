@@ -429,7 +429,7 @@ class KDTrainStep:
         if self._world() > 1:
             self.comm.all_reduce_sum(self.arena.flat_g)
         self._optimize()
-        if self.tables is not None:
+        if self.tables is not None or (not self.batched_quantizers and self.can_capture()):
             self._eager_q += 1
         return self.last
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """`train.py -env <asteroid|speechbrain|tasnet|htdemucs> -y cfg.yaml` (reference: train.py:10-53).
-This build serves the asteroid env (ConvTasNet, DPTNet) and the speechbrain env (Sepformer); tasnet / htdemucs are later rows
-of SURVEY.md §8."""
+This build serves the asteroid env (ConvTasNet, DPTNet), the speechbrain env (Sepformer) and the htdemucs env (HTDemucs); the tasnet
+env is outside SURVEY.md §8."""
 import argparse
 
 import torch
@@ -26,8 +26,14 @@ def train():
     elif args.env_name == "speechbrain":
         from .train_env.speechbrain_librimix import speechbrain_librimix_trainer
         speechbrain_librimix_trainer.train(args.yml_path, args.local_rank, args.distributed_launch, device)
-    elif args.env_name in ("tasnet", "htdemucs"):
-        raise NotImplementedError(f"env {args.env_name}: SURVEY.md §8 row a15 (later rounds)")
+    elif args.env_name == "htdemucs":
+        import sys
+        from .train_env.htdemucs_musdbhq import train as htdemucs_musdbhq_trainer
+        # the reference hands the device to its hydra entry point as an override (train.py:44-46); -y selects the YAML here
+        sys.argv[1:] = ["+device=" + device, "+yml_path=" + args.yml_path]
+        htdemucs_musdbhq_trainer.main()
+    elif args.env_name == "tasnet":
+        raise NotImplementedError("env tasnet (ConvTasNetMusic on MUSDB) is outside SURVEY.md §8")
     else:
         assert False, "Training environment {} is not supported!".format(args.env_name)
     print("Training is done!")

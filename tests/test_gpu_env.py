@@ -68,3 +68,26 @@ def test_speechbrain_env_trains_sepformer(tmp_path):
         bad = tmp_path / "bad.yaml"
         bad.write_text(text.replace("batch_size: 1\n", "batch_size: 2\n", 1))
         T.train(str(bad), 0, False, "cuda")
+
+
+def test_htdemucs_env_trains(tmp_path, monkeypatch):
+    """cfg 5: `main()` of the htdemucs env with hydra-style overrides on sys.argv, a tiny HTDemucs on synthetic stems: the observer
+    phase ends inside epoch 2 and the step is captured; best.th holds the reference's package keys"""
+    import sys
+    from fqss_amd.train_env.htdemucs_musdbhq import train as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = yaml.safe_load(open(os.path.join(root, "configs", "htdemucs_synthetic.yaml")))
+    conf["work_dir"] = str(tmp_path / "run")
+    conf["dset"].update(segment=0.05, sources=["a", "b"], steps_per_epoch=28, valid_steps=1)
+    conf.update(epochs=2, batch_size=2, weights=[1.0, 1.0])
+    conf["htdemucs"] = dict(nfft=2048, channels=8, bottom_channels=16, t_layers=3, t_heads=2)
+    yml = tmp_path / "cfg.yaml"
+    yml.write_text(yaml.safe_dump(conf))
+    monkeypatch.setattr(sys, "argv", ["train.py", "+device=cuda", f"+yml_path={yml}", "optim.lr=0.0002"])
+    hist = T.main()
+    assert len(hist) == 2 and all(torch.isfinite(torch.tensor(h["train"]["loss"])) and torch.isfinite(torch.tensor(h["valid"]["loss"])) for h in hist)
+    assert [h["train"]["launch"] for h in hist] == ["eager", "hipGraph replay"]
+    pkg = torch.load(os.path.join(conf["work_dir"], "best.th"))
+    assert set(pkg) == {"state", "kwargs", "history"} and pkg["kwargs"]["nfft"] == 2048
+    assert "decoder.3.conv_tr.residual_error_block.weight_fake_quantize_dec.min_range" in pkg["state"]
+    assert "crosstransformer.layers.1.cross_attn.activation_fake_quantize_head.max_range" in pkg["state"]
