@@ -1276,3 +1276,32 @@ def hd_kd_loss(est, fest, src, weights, kd_lambda, want_grad=True):
     g = torch.empty_like(est) if want_grad else None
     _lib.call("fqss_hd_kd_loss", _p(est), _p(fest), _p(src), _p(weights), _p(sums), _p(out), _p(coef), _p(g), B, S, N, float(kd_lambda), _stream())
     return out[:1], out[1:1 + S], out[1 + S:1 + 2 * S], out[1 + 2 * S:].view(B, S), g
+
+
+# ------------------------------------------------------------------ evaluation side (csrc/infer.hip)
+def sisnr_matrix(est, ref, want_map=False):
+    """est, ref [S, L] -> SI-SNR matrix [S, S] in dB (est row x ref row) and, optionally, the swap_channel_order map [S, 2]"""
+    _need_gpu(est, ref)
+    est, S, L, ld_e = as_rowmat(est)
+    ref, S2, L2, ld_r = as_rowmat(ref)
+    assert (S, L) == (S2, L2), "sisnr_matrix: shape mismatch"
+    mom = torch.zeros(S * S * 5, device=est.device, dtype=torch.float64)
+    db = torch.empty(S, S, device=est.device, dtype=torch.float32)
+    mp = torch.empty(S, 2, device=est.device, dtype=torch.int32) if want_map else None
+    _lib.call("fqss_sisnr_matrix", _p(est), _p(ref), _p(mom), _p(db), _p(mp), S, L, ld_e, ld_r, _stream())
+    return (db, mp) if want_map else db
+
+
+def infer_ola(chunk, mp, out, sum_weight, start, n, seg):
+    """out[d, c, start:start+n] += w * sign_d * chunk[src_d, c, :n]; sum_weight[start:start+n] += w  (triangular w over `seg`)"""
+    _need_gpu(chunk, out, sum_weight)
+    S, C = out.shape[0], (out.shape[1] if out.dim() == 3 else 1)
+    assert chunk.is_contiguous() and out.is_contiguous() and sum_weight.is_contiguous() and chunk.numel() == S * C * chunk.shape[-1]
+    _lib.call("fqss_infer_ola", _p(chunk), _p(mp), _p(out), _p(sum_weight), S, C, n, seg, start, chunk.shape[-1], out.shape[-1], _stream())
+
+
+def infer_normalize(out, sum_weight):
+    _need_gpu(out, sum_weight)
+    assert out.is_contiguous()
+    L = out.shape[-1]
+    _lib.call("fqss_infer_normalize", _p(out), _p(sum_weight), out.numel() // L, L, L, _stream())

@@ -553,6 +553,16 @@ int fqss_transpose2d(const float* x, float* y, int64_t batch, int64_t R, int64_t
 int fqss_hd_kd_loss(const float* est, const float* fest, const float* src, const float* wt, double* sums, float* out, float* coef,
                     float* gest, int B, int S, int64_t N, float kd_lambda, fqss_stream_t stream);
 
+/* Evaluation side (csrc/infer.hip): the SI-SNR matrix between S estimates and S targets (torchmetrics'
+ * ScaleInvariantSignalNoiseRatio restated: zero-mean SI-SDR, eps 2^-23) with the re-ordering decision of swap_channel_order
+ * (process.py:105-125) as map[d] = (source estimate, sign); the triangular weighted overlap-add of process.model_infer
+ * (:160-183) and its final normalisation.  mom: S*S*5 doubles zeroed by the caller.                                          */
+int fqss_sisnr_matrix(const float* est, const float* ref, double* mom, float* db, int* map, int S, int64_t L, int64_t ld_e, int64_t ld_r,
+                      fqss_stream_t stream);
+int fqss_infer_ola(const float* chunk, const int* map, float* out, float* sum_weight, int S, int C, int64_t n, int64_t seg, int64_t start,
+                   int64_t ld_chunk, int64_t ld_out, fqss_stream_t stream);
+int fqss_infer_normalize(float* out, const float* sum_weight, int64_t rows, int64_t L, int64_t ld, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

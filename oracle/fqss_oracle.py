@@ -390,3 +390,60 @@ def synth_batch(B, T, seed=0):
     fir = torch.tensor([0.1, 0.25, 0.3, 0.25, 0.1]).view(1, 1, 5)
     s = F.conv1d(s.view(B * 2, 1, T + 4), fir).view(B, 2, T)
     return s.sum(1, keepdim=True), s
+
+
+# ------------------------------------------------------------------------------------------
+# evaluation side: process.py:105-194
+# ------------------------------------------------------------------------------------------
+def si_snr(preds, target):
+    """torchmetrics~=ScaleInvariantSignalNoiseRatio (third party, absent from /root/reference; call sites process.py:119, 137):
+    its published form -- scale_invariant_signal_distortion_ratio(zero_mean=True), eps = finfo(float32).eps, mean over rows"""
+    eps = torch.finfo(preds.dtype).eps
+    target = target - target.mean(dim=-1, keepdim=True)
+    preds = preds - preds.mean(dim=-1, keepdim=True)
+    alpha = (torch.sum(preds * target, dim=-1, keepdim=True) + eps) / (torch.sum(target ** 2, dim=-1, keepdim=True) + eps)
+    ts = alpha * target
+    val = (torch.sum(ts ** 2, dim=-1) + eps) / (torch.sum((ts - preds) ** 2, dim=-1) + eps)
+    return (10 * torch.log10(val)).mean()
+
+
+def swap_channel_order(sep, clean):
+    """process.py:105-125"""
+    n_src = clean.shape[0]
+    if n_src == 1:
+        return sep
+    new = sep.clone()
+    for src in range(n_src):
+        ch = sep[src:src + 1, :]
+        best, best_i = -float("inf"), 0
+        for i in range(n_src):
+            v = si_snr(ch, clean[i])
+            if v > best:
+                best, best_i = v, i
+        new[best_i, ...] = ch if src == best_i else -ch
+    return new
+
+
+def model_infer(fwd, mix, n_srcs, segment=None, overlap=0.25, target=None):
+    """process.py:156-194 over a callable `fwd(x [1, C, L]) -> [1, S, (C,) L]`"""
+    if not segment:
+        with torch.no_grad():
+            out = fwd(mix.unsqueeze(0)).detach()[0]
+        return F.pad(out, (0, mix.size(-1) - out.size(-1)))
+    channels, length = mix.shape
+    out = torch.zeros(*((n_srcs, channels, length) if channels > 1 else (n_srcs, length)))
+    sum_weight = torch.zeros(length)
+    stride = int((1 - overlap) * segment)
+    weight = torch.cat([torch.arange(1, segment // 2 + 1), torch.arange(segment - segment // 2, 0, -1)])
+    weight = weight / weight.max()
+    for start in range(0, length, stride):
+        stop = min(start + segment, length)
+        chunk = mix[..., start:stop]
+        n = chunk.size(-1)
+        co = model_infer(fwd, F.pad(chunk, (0, segment - n)), n_srcs)[..., :n]
+        if target is not None and n_srcs > 1:
+            co = swap_channel_order(co, target[..., start:start + n])
+        out[..., start:stop] += weight[:n] * co
+        sum_weight[start:stop] += weight[:n]
+    return out / sum_weight
+

@@ -91,3 +91,20 @@ def test_htdemucs_env_trains(tmp_path, monkeypatch):
     assert set(pkg) == {"state", "kwargs", "history"} and pkg["kwargs"]["nfft"] == 2048
     assert "decoder.3.conv_tr.residual_error_block.weight_fake_quantize_dec.min_range" in pkg["state"]
     assert "crosstransformer.layers.1.cross_attn.activation_fake_quantize_head.max_range" in pkg["state"]
+
+
+def test_val_cli_on_synthetic_mixtures(tmp_path):
+    """`val.py -y cfg.yaml` (val.py:184-226): quantized model from the YAML (+ a checkpoint written by the asteroid env), chunked
+    inference, SI-SDR and its improvement over the mixture"""
+    from fqss_amd import val as V
+    from fqss_amd.quantization.qat.models.load_model import create_pretrained_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = yaml.safe_load(open(os.path.join(root, "configs", "convtasnet_2spks_8k_synthetic.yaml")))
+    ckpt = tmp_path / "best_model.pth"
+    torch.save(create_pretrained_model(dict(conf["model_cfg"], model_path=None)).state_dict(), ckpt)
+    conf["model_cfg"]["model_path"] = str(ckpt)
+    conf["testing_cfg"] = dict(n_items=2, length_samples=12000, segment_samples=8000, overlap=0.25)
+    yml = tmp_path / "val.yaml"
+    yml.write_text(yaml.safe_dump(conf))
+    sisdr, imp = V.val(["-y", str(yml)])
+    assert torch.isfinite(torch.tensor([sisdr, imp])).all()

@@ -1,0 +1,43 @@
+"""Pins the evaluation-side oracle functions (oracle/fqss_oracle.py: si_snr, swap_channel_order, model_infer; SURVEY.md §8(f)
+rank 1) against vectors produced by the REAL reference's process.py (tools/make_goldens_infer.py).  CPU only."""
+import numpy as np
+import torch
+
+import oracle.fqss_oracle as O
+
+torch.set_num_threads(2)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _student(g):
+    s = O.StudentConvTasNetQ({k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")}, layers_per_stack=2)
+    s.enable_observer(False)
+    s.leave_observer_phase()
+    return s
+
+
+def test_sisnr_and_swap(golden):
+    g = golden("infer")
+    est, clean = T(g["swap.in"]), T(g["clean"])
+    got = np.array([[float(O.si_snr(est[p:p + 1], clean[q])) for q in range(2)] for p in range(2)])
+    np.testing.assert_allclose(got, g["sisnr"], rtol=1e-5, atol=1e-4)
+    assert torch.equal(O.swap_channel_order(est, clean), T(g["swap.out"]))
+
+
+def test_model_infer(golden):
+    g = golden("infer")
+    s = _student(g)
+    fwd = lambda x: s.forward(x)
+    mix, clean = T(g["mix"]), T(g["clean"])
+    with torch.no_grad():
+        whole = O.model_infer(fwd, mix, 2)
+        chunked = O.model_infer(fwd, mix, 2, segment=1000, overlap=0.25, target=clean)
+        chunked_nt = O.model_infer(fwd, mix, 2, segment=1000, overlap=0.25)
+    for got, key in ((whole, "whole"), (chunked, "chunked"), (chunked_nt, "chunked_nt")):
+        want = g[key]
+        err = np.abs(got.numpy() - want)
+        # eval mode quantizes: fp32 noise flips a few 8-bit bins, each moving a handful of output samples by one output step
+        assert err.max() <= 0.02 * np.abs(want).max() and np.mean(err > 1e-6) < 0.02, (key, err.max(), np.mean(err > 1e-6))
