@@ -14,6 +14,8 @@
 // nn.MultiheadAttention as well as the batch-first [B, T, E] tensors of the HTDemucs transformer without a transposing copy.
 // As in attn.hip, obs_attn / obs_soft (optional, observer phase) receive the min / max of the logits and of the probabilities: the
 // reference runs two quantizers on them and discards the results (qat_layers.py:907-909).
+#include <stdlib.h>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -226,6 +228,309 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Matrix-core forms (head_dim a multiple of 32: the HTDemucs transformer with bottom_channels 512 has 64).  fp32 MFMA 32x32x2: the
+// same fmaf arithmetic as the vector kernels at the matrix pipe's rate.  A wave owns a 32-row query tile and keeps its Q fragment in
+// registers; a workgroup (4 waves = 128 queries) streams 32-key K / V tiles through LDS.  Scores are computed TRANSPOSED,
+// T = K_tile Q^T: lane (c, half) holds query c and 16 of the 32 keys, so the row max / sum of the online softmax are in-lane
+// reductions plus one exchange between the lane halves, and exp(T - m) is already the A operand of O += P V_tile.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }     // row of accumulator register r
+
+// a 32-row tile of one head moves global -> registers -> LDS in two steps, so the loads of tile t+1 are in flight while tile t is
+// being multiplied (one wave per SIMD or two: the global latency of ~1 us would otherwise sit between every pair of barriers)
+template <int HD>
+struct TileRegs {
+    float v[32 * HD / 256];
+};
+template <int HD>
+__device__ __forceinline__ void tile_fetch(const float* __restrict__ x, const RowView rv, int b, int h, int r0, int nrows, TileRegs<HD>& t) {
+#pragma unroll
+    for (int u = 0; u < 32 * HD / 256; ++u) {
+        const int e = threadIdx.x + 256 * u, j = e / HD, d = e % HD;
+        t.v[u] = j < nrows ? x[(int64_t)(r0 + j) * rv.sl + (int64_t)b * rv.sb + h * HD + d] : 0.f;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void tile_store(const TileRegs<HD>& t, float* dst) {
+    constexpr int RS = HD + 1;
+#pragma unroll
+    for (int u = 0; u < 32 * HD / 256; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        dst[(e / HD) * RS + e % HD] = t.v[u];
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_fwd_mfma(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             float* __restrict__ o, float* __restrict__ stats, const AttnGeom g,
+                                                             uint32_t* obs_attn, uint32_t* obs_soft) {
+    constexpr int RS = HD + 1, NS = HD / 2, ND = HD / 32;
+    __shared__ float Ks[32 * RS];
+    __shared__ float Vs[32 * RS];
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    const int i_own = it * 32 + c;
+    const bool live = i_own < g.Lq;
+    const float* qp = q + (int64_t)(live ? i_own : g.Lq - 1) * g.q.sl + (int64_t)b * g.q.sb + h * HD;
+    float qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = qp[2 * s + lk];
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
+    float m = -INFINITY, l = 0.f, smin = INFINITY;
+    TileRegs<HD> kt, vt;
+    tile_fetch<HD>(k, g.k, b, h, 0, min(32, g.Lk), kt);
+    tile_fetch<HD>(v, g.v, b, h, 0, min(32, g.Lk), vt);
+    for (int j0 = 0; j0 < g.Lk; j0 += 32) {
+        const int nj = min(32, g.Lk - j0);
+        __syncthreads();
+        tile_store<HD>(kt, Ks);
+        tile_store<HD>(vt, Vs);
+        __syncthreads();
+        if (j0 + 32 < g.Lk) {
+            tile_fetch<HD>(k, g.k, b, h, j0 + 32, min(32, g.Lk - j0 - 32), kt);
+            tile_fetch<HD>(v, g.v, b, h, j0 + 32, min(32, g.Lk - j0 - 32), vt);
+        }
+        f32x16 T0, T1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = T1[r] = 0.f;
+        // the LDS operands of a whole phase are fetched into distinct registers first: left to itself the compiler recycles one
+        // register pair and puts a full LDS round trip (s_waitcnt lgkmcnt(0)) in front of every pair of MFMAs
+        float ka[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ka[s] = Ks[c * RS + 2 * s + lk];
+        __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks the reads back next to their MFMAs)
+#pragma unroll
+        for (int s = 0; s < NS; s += 2) {        // two accumulators: consecutive MFMAs do not wait on each other
+            T0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qf[s], T0, 0, 0, 0);
+            T1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s + 1], qf[s + 1], T1, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t = T0[r] + T1[r];
+            const bool ok = tile_row(r, lk) < nj;
+            T0[r] = ok ? t : -INFINITY;
+            tmax = fmaxf(tmax, T0[r]);
+            smin = fminf(smin, ok ? t : INFINITY);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float sc = expf(m - m_new);            // 0 on the first tile
+        if (__any(sc != 1.0f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = __shfl(sc, tile_row(r, lk), 64);     // the factor of the query that owns accumulator row r
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) acc[nd][r] *= f;
+            }
+        }
+        l *= sc;
+        m = m_new;
+        float vb[16][ND], pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) vb[r][nd] = Vs[tile_row(r, lk) * RS + c + 32 * nd];
+            pr[r] = expf(T0[r] - m);
+            l += pr[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) acc[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[r], vb[r][nd], acc[nd], 0, 0, 0);
+    }
+    l += __shfl_xor(l, 32, 64);
+    smin = fminf(smin, __shfl_xor(smin, 32, 64));
+    if (lk == 0 && live) {
+        stats[((int64_t)bh * g.Lq + i_own) * 2] = m;
+        stats[((int64_t)bh * g.Lq + i_own) * 2 + 1] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = tile_row(r, lk);
+        const float lr = __shfl(l, il, 64);
+        const int i = it * 32 + il;
+        if (i < g.Lq) {
+            float* op = o + (int64_t)i * g.o.sl + (int64_t)b * g.o.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) op[32 * nd] = acc[nd][r] / lr;
+        }
+    }
+    if (obs_attn != nullptr) {
+        float smin_all = live ? smin : INFINITY, smax_all = live ? m : -INFINITY;
+        float pmax_all = live ? 1.0f / l : -INFINITY, pmin_all = live ? expf(smin - m) / l : INFINITY;
+        smin_all = wave_min(smin_all); smax_all = wave_max(smax_all);
+        pmin_all = wave_min(pmin_all); pmax_all = wave_max(pmax_all);
+        if (lane == 0 && smin_all <= smax_all) {
+            atomicMin(obs_attn, f2ord(smin_all)); atomicMax(obs_attn + 1, f2ord(smax_all));
+            atomicMin(obs_soft, f2ord(pmin_all)); atomicMax(obs_soft + 1, f2ord(pmax_all));
+        }
+    }
+}
+
+// dq on the matrix cores: per 32-key tile  T = K Q^T,  U = V dO^T  (both transposed: lane = query, registers = keys, so the softmax
+// statistics m, 1/l and D = dO . o of the lane's query apply in-lane),  dS = P (U - D),  dq += dS K  (dS is already the A operand).
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd_q_mfma(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                               const float* __restrict__ o, const float* __restrict__ go,
+                                                               const float* __restrict__ stats, float* __restrict__ gq, float* __restrict__ dsum,
+                                                               const AttnGeom g) {
+    constexpr int RS = HD + 1, NS = HD / 2, ND = HD / 32;
+    __shared__ float Ks[32 * RS];
+    __shared__ float Vs[32 * RS];
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    const int i_own = it * 32 + c;
+    const bool live = i_own < g.Lq;
+    const int ic = live ? i_own : g.Lq - 1;
+    const float* qp = q + (int64_t)ic * g.q.sl + (int64_t)b * g.q.sb + h * HD;
+    const float* gp = go + (int64_t)ic * g.go.sl + (int64_t)b * g.go.sb + h * HD;
+    const float* op = o + (int64_t)ic * g.o.sl + (int64_t)b * g.o.sb + h * HD;
+    float qf[NS], gf[NS], D = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        qf[s] = qp[2 * s + lk];
+        gf[s] = gp[2 * s + lk];
+        D = fmaf(gf[s], op[2 * s + lk], D);
+    }
+    D += __shfl_xor(D, 32, 64);
+    const float m = stats[((int64_t)bh * g.Lq + ic) * 2], rl = 1.0f / stats[((int64_t)bh * g.Lq + ic) * 2 + 1];
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
+    TileRegs<HD> kt, vt;
+    tile_fetch<HD>(k, g.k, b, h, 0, min(32, g.Lk), kt);
+    tile_fetch<HD>(v, g.v, b, h, 0, min(32, g.Lk), vt);
+    for (int j0 = 0; j0 < g.Lk; j0 += 32) {
+        const int nj = min(32, g.Lk - j0);
+        __syncthreads();
+        tile_store<HD>(kt, Ks);
+        tile_store<HD>(vt, Vs);
+        __syncthreads();
+        if (j0 + 32 < g.Lk) {
+            tile_fetch<HD>(k, g.k, b, h, j0 + 32, min(32, g.Lk - j0 - 32), kt);
+            tile_fetch<HD>(v, g.v, b, h, j0 + 32, min(32, g.Lk - j0 - 32), vt);
+        }
+        f32x16 T, U;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[r] = U[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            T = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[c * RS + 2 * s + lk], qf[s], T, 0, 0, 0);
+            U = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[c * RS + 2 * s + lk], gf[s], U, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = tile_row(r, lk) < nj ? expf(T[r] - m) * rl : 0.f;
+            const float ds = p * (U[r] - D);
+            const float* kr = Ks + tile_row(r, lk) * RS + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) acc[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, kr[32 * nd], acc[nd], 0, 0, 0);
+        }
+    }
+    if (lk == 0 && live) dsum[(int64_t)bh * g.Lq + i_own] = D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = it * 32 + tile_row(r, lk);
+        if (i < g.Lq) {
+            float* gp2 = gq + (int64_t)i * g.gq.sl + (int64_t)b * g.gq.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) gp2[32 * nd] = acc[nd][r];
+        }
+    }
+}
+
+// dk / dv on the matrix cores: a wave owns 32 keys (K, V fragments in registers), 32-query tiles of q, dO and the row statistics
+// stream through LDS:  T' = Q K^T,  U' = dO V^T  (lane = key, registers = queries),  P = exp(T' - m_i) / l_i,  dS = P (U' - D_i),
+// dv += P^T dO,  dk += dS^T Q  (P / dS in this layout ARE the A operands of the two transposed products).
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd_kv_mfma(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                const float* __restrict__ go, const float* __restrict__ stats,
+                                                                const float* __restrict__ dsum, float* __restrict__ gk, float* __restrict__ gv,
+                                                                const AttnGeom g) {
+    constexpr int RS = HD + 1, NS = HD / 2, ND = HD / 32;
+    __shared__ float Qs[32 * RS];
+    __shared__ float Gs[32 * RS];
+    __shared__ float Ms[32], Rs[32], Ds[32];
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int jt = blockIdx.x * 4 + wave;
+    const int j_own = jt * 32 + c;
+    const int jc = j_own < g.Lk ? j_own : g.Lk - 1;
+    const float* kp = k + (int64_t)jc * g.k.sl + (int64_t)b * g.k.sb + h * HD;
+    const float* vp = v + (int64_t)jc * g.v.sl + (int64_t)b * g.v.sb + h * HD;
+    float kf[NS], vf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { kf[s] = kp[2 * s + lk]; vf[s] = vp[2 * s + lk]; }
+    f32x16 ak[ND], av[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ak[nd][r] = av[nd][r] = 0.f;
+    TileRegs<HD> qt, gt;
+    tile_fetch<HD>(q, g.q, b, h, 0, min(32, g.Lq), qt);
+    tile_fetch<HD>(go, g.go, b, h, 0, min(32, g.Lq), gt);
+    for (int i0 = 0; i0 < g.Lq; i0 += 32) {
+        const int ni = min(32, g.Lq - i0);
+        __syncthreads();
+        tile_store<HD>(qt, Qs);
+        tile_store<HD>(gt, Gs);
+        if (threadIdx.x < 32) {
+            const bool ok = threadIdx.x < ni;
+            const int64_t si = (int64_t)bh * g.Lq + i0 + (ok ? threadIdx.x : 0);
+            Ms[threadIdx.x] = ok ? stats[si * 2] : 0.f;
+            Rs[threadIdx.x] = ok ? 1.0f / stats[si * 2 + 1] : 0.f;      // padding queries: probability 0
+            Ds[threadIdx.x] = ok ? dsum[si] : 0.f;
+        }
+        __syncthreads();
+        if (i0 + 32 < g.Lq) {
+            tile_fetch<HD>(q, g.q, b, h, i0 + 32, min(32, g.Lq - i0 - 32), qt);
+            tile_fetch<HD>(go, g.go, b, h, i0 + 32, min(32, g.Lq - i0 - 32), gt);
+        }
+        f32x16 T, U;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[r] = U[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            T = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[c * RS + 2 * s + lk], kf[s], T, 0, 0, 0);
+            U = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[c * RS + 2 * s + lk], vf[s], U, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile_row(r, lk);
+            const float p = expf(T[r] - Ms[row]) * Rs[row];
+            const float ds = p * (U[r] - Ds[row]);
+            const float* gr = Gs + row * RS + c;
+            const float* qr = Qs + row * RS + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                av[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(p, gr[32 * nd], av[nd], 0, 0, 0);
+                ak[nd] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qr[32 * nd], ak[nd], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + tile_row(r, lk);
+        if (j < g.Lk) {
+            float* gkp = gk + (int64_t)j * g.gk.sl + (int64_t)b * g.gk.sb + h * HD + c;
+            float* gvp = gv + (int64_t)j * g.gv.sl + (int64_t)b * g.gv.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) { gkp[32 * nd] = ak[nd][r]; gvp[32 * nd] = av[nd][r]; }
+        }
+    }
+}
+
 static int check_attn(int Lq, int Lk, int B, int nh, int hd, const int64_t* st, int n) {
     FQSS_REQUIRE(Lq > 0 && Lk > 0 && B > 0 && nh > 0 && (int64_t)B * nh <= 65535, "bad shape");
     for (int t = 0; t < n; ++t) FQSS_REQUIRE(st[2 * t] >= (int64_t)nh * hd && st[2 * t + 1] >= (int64_t)nh * hd, "row stride below embed dim");
@@ -255,6 +560,13 @@ extern "C" int fqss_attn_long_fwd(const float* q, const float* k, const float* v
     FQSS_REQUIRE((obs_attn == nullptr) == (obs_soft == nullptr), "observer workspaces come in pairs");
     if (int rc = check_attn(Lq, Lk, B, nh, hd, strides, 4)) return rc;
     AttnGeom g{Lq, Lk, B, nh, {strides[0], strides[1]}, {strides[2], strides[3]}, {strides[4], strides[5]}, {strides[6], strides[7]}, {}, {}, {}, {}};
+    static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    if (use_mfma && (hd == 32 || hd == 64)) {
+        dim3 gm((unsigned)cdiv(Lq, 128), (unsigned)(B * nh));
+        if (hd == 32) hipLaunchKernelGGL((k_attn_long_fwd_mfma<32>), gm, dim3(256), 0, (hipStream_t)stream, q, k, v, o, stats, g, obs_attn, obs_soft);
+        else hipLaunchKernelGGL((k_attn_long_fwd_mfma<64>), gm, dim3(256), 0, (hipStream_t)stream, q, k, v, o, stats, g, obs_attn, obs_soft);
+        return launch_status("fqss_attn_long_fwd");
+    }
     dim3 grid((unsigned)cdiv(Lq, 256), (unsigned)(B * nh));
 #define CALL(HD_) hipLaunchKernelGGL((k_attn_long_fwd<HD_>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, stats, g, obs_attn, obs_soft);
     FQSS_HD_SWITCH(hd, CALL)
@@ -270,6 +582,19 @@ extern "C" int fqss_attn_long_bwd(const float* q, const float* k, const float* v
     if (int rc = check_attn(Lq, Lk, B, nh, hd, strides, 8)) return rc;
     const int64_t* s = strides;
     AttnGeom g{Lq, Lk, B, nh, {s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]}, {s[6], s[7]}, {s[8], s[9]}, {s[10], s[11]}, {s[12], s[13]}, {s[14], s[15]}};
+    static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    if (use_mfma && (hd == 32 || hd == 64)) {
+        dim3 gq_((unsigned)cdiv(Lq, 128), (unsigned)(B * nh)), gk_((unsigned)cdiv(Lk, 128), (unsigned)(B * nh));
+        hipStream_t st = (hipStream_t)stream;
+        if (hd == 32) {
+            hipLaunchKernelGGL((k_attn_long_bwd_q_mfma<32>), gq_, dim3(256), 0, st, q, k, v, o, go, stats, gq, dsum, g);
+            hipLaunchKernelGGL((k_attn_long_bwd_kv_mfma<32>), gk_, dim3(256), 0, st, q, k, v, go, stats, dsum, gk, gv, g);
+        } else {
+            hipLaunchKernelGGL((k_attn_long_bwd_q_mfma<64>), gq_, dim3(256), 0, st, q, k, v, o, go, stats, gq, dsum, g);
+            hipLaunchKernelGGL((k_attn_long_bwd_kv_mfma<64>), gk_, dim3(256), 0, st, q, k, v, go, stats, dsum, gk, gv, g);
+        }
+        return launch_status("fqss_attn_long_bwd");
+    }
     dim3 grid_q((unsigned)cdiv(Lq, 256), (unsigned)(B * nh)), grid_k((unsigned)cdiv(Lk, 256), (unsigned)(B * nh));
 #define CALL(HD_)                                                                                                                       \
     hipLaunchKernelGGL((k_attn_long_bwd_q<HD_>), grid_q, dim3(256), 0, (hipStream_t)stream, q, k, v, o, go, stats, gq, dsum, g);         \
