@@ -227,7 +227,7 @@ def attn_roofline(B, nh, L, hd):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 5 * 1e3
     tf = 4.0 * L * L * hd * B * nh / us * 1e-6
-    return {"kernel": "k_attn_long_fwd<%d>" % hd, "what": "self-attention of the spectrogram branch", "shape": [B, nh, L, hd], "bound": "mfma",
+    return {"kernel": "k_attn_long_fwd_mfma<%d>" % hd, "what": "self-attention of the spectrogram branch", "shape": [B, nh, L, hd], "bound": "mfma",
             "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
 
 
