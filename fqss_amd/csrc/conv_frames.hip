@@ -21,45 +21,58 @@ struct FrameGeom {
     int64_t Ho, Wo, ld;          // frames [B][C*kh*kw][Ho*Wo], row stride ld
 };
 
+// grid: x = chunks of the frame row (m = ho*Wo + wo), y = frame rows (b, c, tap); everything but (ho, wo) is uniform per workgroup
 __global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__ x, float* __restrict__ f, const FrameGeom g) {
-    const int64_t M = g.Ho * g.Wo, rows = g.B * g.C * g.kh * g.kw;
-    const int64_t total = rows * M;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i % M, r = i / M;
-        const int64_t wo = m % g.Wo, ho = m / g.Wo;
+    const int M = (int)(g.Ho * g.Wo), Wo = (int)g.Wo;
+    const int64_t rows = g.B * g.C * g.kh * g.kw;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
         const int j = (int)(r % g.kw);
         const int64_t r1 = r / g.kw;
         const int ti = (int)(r1 % g.kh);
         const int64_t bc = r1 / g.kh, c = bc % g.C, b = bc / g.C;
-        const int64_t h = ho * g.st_h - g.ph + (int64_t)ti * g.dh, w = wo * g.st_w - g.pw + (int64_t)j * g.dw;
-        float v = 0.0f;
-        if (h >= 0 && h < g.H && w >= 0 && w < g.W) v = x[b * g.sb + c * g.sc + h * g.sh_ + w];
-        f[r * g.ld + m] = v;
+        const float* xp = x + b * g.sb + c * g.sc;
+        float* fp = f + r * g.ld;
+        const int h0 = ti * g.dh - g.ph, w0 = j * g.dw - g.pw;
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+            const int ho = m / Wo, wo = m - ho * Wo;
+            const int h = ho * g.st_h + h0, w = wo * g.st_w + w0;
+            float v = 0.0f;
+            if (h >= 0 && h < (int)g.H && w >= 0 && w < (int)g.W) v = xp[(int64_t)h * g.sh_ + w];
+            fp[m] = v;
+        }
     }
 }
 
 // y[b][c][h][w] = bias[c] + sum over taps (ti, j) with (h + ph - ti*dh) = ho*st_h, (w + pw - j*dw) = wo*st_w in range
+// grid: x = chunks of the plane (h*W + w), y = planes (b, c)
 __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
                                                      const FrameGeom g) {
-    const int64_t total = g.B * g.C * g.H * g.W;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t w = i % g.W, r0 = i / g.W, h = r0 % g.H, bc = r0 / g.H, c = bc % g.C, b = bc / g.C;
-        float acc = 0.0f;
-        for (int ti = 0; ti < g.kh; ++ti) {
-            const int64_t hn = h + g.ph - (int64_t)ti * g.dh;
-            if (hn < 0 || hn % g.st_h != 0) continue;
-            const int64_t ho = hn / g.st_h;
-            if (ho >= g.Ho) continue;
-            for (int j = 0; j < g.kw; ++j) {
-                const int64_t wn = w + g.pw - (int64_t)j * g.dw;
-                if (wn < 0 || wn % g.st_w != 0) continue;
-                const int64_t wo = wn / g.st_w;
-                if (wo >= g.Wo) continue;
-                acc += f[((bc * g.kh + ti) * g.kw + j) * g.ld + ho * g.Wo + wo];
+    const int HW = (int)(g.H * g.W), W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
+    const int64_t planes = g.B * g.C;
+    for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
+        const int64_t c = bc % g.C, b = bc / g.C;
+        const float bv = bias != nullptr ? bias[c] : 0.0f;
+        const float* fb = f + bc * g.kh * g.kw * g.ld;
+        float* yp = y + b * g.sb + c * g.sc;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+            const int h = i / W, w = i - h * W;
+            float acc = 0.0f;
+            for (int ti = 0; ti < g.kh; ++ti) {
+                const int hn = h + g.ph - ti * g.dh;
+                if (hn < 0) continue;
+                const int ho = hn / g.st_h;
+                if (ho * g.st_h != hn || ho >= Ho) continue;
+                for (int j = 0; j < g.kw; ++j) {
+                    const int wn = w + g.pw - j * g.dw;
+                    if (wn < 0) continue;
+                    const int wo = wn / g.st_w;
+                    if (wo * g.st_w != wn || wo >= Wo) continue;
+                    acc += fb[(int64_t)(ti * g.kw + j) * g.ld + ho * Wo + wo];
+                }
             }
+            if (bias != nullptr) acc += bv;
+            yp[(int64_t)h * g.sh_ + w] = acc;
         }
-        if (bias != nullptr) acc += bias[c];
-        y[b * g.sb + c * g.sc + h * g.sh_ + w] = acc;
     }
 }
 
@@ -84,6 +97,18 @@ static int check_geom(const FrameGeom& g) {
     return FQSS_OK;
 }
 
+// x covers a row / plane in chunks of 1024 positions (4 per thread), y walks the rows; ~16 k workgroups at most
+static inline dim3 plane_grid(int64_t positions, int64_t rows) {
+    int64_t gx = cdiv(positions, 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    int64_t gy = 16384 / gx;
+    if (gy < 1) gy = 1;
+    if (gy > rows) gy = rows;
+    if (gy > 65535) gy = 65535;
+    return dim3((unsigned)gx, (unsigned)gy, 1);
+}
+
 static inline unsigned stream_grid(int64_t n) {
     int64_t b = cdiv(n, 256 * 4);
     if (b < 1) b = 1;
@@ -105,8 +130,8 @@ extern "C" int fqss_frames_gather(const float* x, float* frames, FQSS_GEOM_ARGS,
     FQSS_REQUIRE(x && frames, "null pointer");
     FQSS_GEOM_INIT;
     if (int rc = check_geom(g)) return rc;
-    const int64_t n = B * C * kh * kw * Ho * Wo;
-    hipLaunchKernelGGL(k_frames_gather, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, x, frames, g);
+    FQSS_REQUIRE(Ho * Wo < (1ll << 31) && H * W < (1ll << 31), "plane too large for 32-bit position arithmetic");
+    hipLaunchKernelGGL(k_frames_gather, plane_grid(Ho * Wo, B * C * kh * kw), dim3(256), 0, (hipStream_t)stream, x, frames, g);
     return launch_status("fqss_frames_gather");
 }
 
@@ -114,7 +139,8 @@ extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y,
     FQSS_REQUIRE(y && frames, "null pointer");
     FQSS_GEOM_INIT;
     if (int rc = check_geom(g)) return rc;
-    hipLaunchKernelGGL(k_frames_ola, dim3(stream_grid(B * C * H * W)), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+    FQSS_REQUIRE(Ho * Wo < (1ll << 31) && H * W < (1ll << 31), "plane too large for 32-bit position arithmetic");
+    hipLaunchKernelGGL(k_frames_ola, plane_grid(H * W, B * C), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
     return launch_status("fqss_frames_ola");
 }
 
