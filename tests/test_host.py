@@ -215,3 +215,32 @@ def test_data_parallel_plumbing_world2():
     assert [(o[1], o[2]) for o in out] == [(0, 8), (8, 16)]           # disjoint batch shards
     assert all(o[3] == 3.0 and o[4] == 3000.0 for o in out)          # sum over ranks
     assert all(o[5] == 1.0 and o[6] == 3.0 for o in out)
+
+
+def test_checkpoint_interchange_lightning_ckpt(tmp_path):
+    """a Lightning `.ckpt` of the asteroid env ({"state_dict": {"model.<key>", "fmodel.<key>"}}) loads through
+    `load_pretrain`'s order-based mapping with the teacher's entries dropped (convtasnetq.py:225-237); `create_pretrained_model`
+    falls back to it when the strict load fails (load_model.py:76-102); a mismatching checkpoint is refused"""
+    import torch
+    from fqss_amd.quantization.qat.models.load_model import create_model, create_pretrained_model, quantize_model
+    from fqss_amd.smoke import QCFG
+    cfg = {"name": "ConvTasNet", "n_src": 2, "kernel_size": 16, "stride": 8}
+    torch.manual_seed(3)
+    src = quantize_model(create_model(cfg), dict(QCFG))
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    ck = {"state_dict": {**{"model." + k: v.clone() for k, v in src.state_dict().items()},
+                         **{"fmodel." + k: v.clone() for k, v in create_model(cfg).state_dict().items()}}}
+    path = tmp_path / "epoch=3.ckpt"
+    torch.save(ck, path)
+    dst = quantize_model(create_model(cfg), dict(QCFG))
+    dst.load_pretrain(str(path))
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    via = create_pretrained_model(dict(cfg, model_path=str(path), quantization=dict(QCFG)))
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), via.state_dict().values()))
+    bad = {"state_dict": {k: v for i, (k, v) in enumerate(ck["state_dict"].items()) if i > 0}}
+    torch.save(bad, tmp_path / "bad.ckpt")
+    with pytest.raises(AssertionError):
+        dst.load_pretrain(str(tmp_path / "bad.ckpt"))
