@@ -125,8 +125,58 @@ def reduce(fetch_csv, write_csv, manifest_json, out_json):
             c["algorithmic_write_bytes"] / 1e6, c["traffic_over_algorithmic"]))
 
 
+GROUPS = {"k_gnq_bwd_rows+coef+apply": ("k_gnq_bwd_rows", "k_gnq_bwd_coef", "k_gnq_bwd_apply")}
+# (label, algorithmic read / write bytes per element of the [8, 512, 3999] tensor, launches per step) in the probe's launch order
+GROUP_CASES = {"k_gnq_bwd_rows+coef+apply": (
+    ("gLN+fq backward (2 passes) with the producer conv's STE/PReLU/range/bias backward fused, C=512", 14.0, 4.0, 24),
+    ("gLN+fq backward (2 passes, plain), C=512", 10.0, 4.0, 24))}
+
+
+def reduce_groups(fetch_csv, write_csv, out_json, elems=8 * 512 * 3999, iters=ITERS):
+    """multi-kernel roofline cases: the PMC rows of the member kernels are summed per invocation (the probe launches each case
+    `iters` times back to back).  Read scale x2: the members stream fp32 rows 16 B per lane (128-B requests, tallied at 64 B on
+    gfx950, MI355X_MICROARCH.md HBM section); the u8 code rows they also read are 1/9 .. 1/13 of the bytes, so x2 overstates the
+    traffic by at most that share -- the conservative reading."""
+    def rows(path, counter):
+        out = []
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") == counter:
+                    val = float(r.get("Counter_Value_KiB", r.get("Counter_Value")))
+                    out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], val))
+        return sorted(out)
+    doc = json.load(open(out_json))
+    for group, members in GROUPS.items():
+        per_case = []
+        for path, counter in ((fetch_csv, "FETCH_SIZE"), (write_csv, "WRITE_SIZE")):
+            seq = [(k, v) for _, k, v in rows(path, counter) if any(m in k for m in members)]
+            inv, cur = [], 0.0
+            for k, v in seq:
+                cur += v
+                if members[-1] in k:          # the last member closes an invocation
+                    inv.append(cur)
+                    cur = 0.0
+            per_case.append([sum(inv[i * iters:(i + 1) * iters]) / iters for i in range(len(GROUP_CASES[group]))])
+        tot = n = 0.0
+        doc["cases"] = [c for c in doc["cases"] if c["kernel"] != group]
+        for (label, rd, wr, launches), f, w in zip(GROUP_CASES[group], *per_case):
+            rb, wb = round(f * 1024.0 * 2.0), round(w * 1024.0)
+            doc["cases"].append(dict(kernel=group, label=label, launches_per_step=launches, calibration_shape=False,
+                                     algorithmic_read_bytes=rd * elems, algorithmic_write_bytes=wr * elems, FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
+                                     read_scale=2.0, read_scale_source="x2 (fp32 rows streamed in 128-B requests; sum over the member kernels)",
+                                     read_bytes=rb, write_bytes=wb, traffic_over_algorithmic=round((rb + wb) / ((rd + wr) * elems), 3)))
+            tot += launches * (rb + wb)
+            n += launches
+            print("%-100s read %7.1f MB (alg %6.1f)  write %6.1f MB (alg %6.1f)" % (label[:100], rb / 1e6, rd * elems / 1e6, wb / 1e6, wr * elems / 1e6))
+        doc["per_launch_bytes"][group] = round(tot / n)
+    with open(out_json, "w") as f:
+        json.dump(doc, f, indent=1)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 6 and sys.argv[1] == "--reduce":
+    if len(sys.argv) >= 5 and sys.argv[1] == "--reduce-groups":
+        reduce_groups(*sys.argv[2:5])
+    elif len(sys.argv) >= 6 and sys.argv[1] == "--reduce":
         reduce(*sys.argv[2:6])
     else:
         run()
