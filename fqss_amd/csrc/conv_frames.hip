@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, f
     const int64_t c = blockIdx.x, b = blockIdx.y;
     const float* row = g + (b * C + c) * ld;
     float v[1] = {0.0f};
-    for (int64_t m = threadIdx.x; m < M; m += 256) v[0] += row[m];
+    for (int64_t m = (int64_t)blockIdx.z * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.z * 256) v[0] += row[m];   // z: chunks of a long row
     block_sum<float, 1>(v, smem);
     if (threadIdx.x == 0) atomicAdd(out + c, v[0]);
 }
@@ -147,6 +147,11 @@ extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y,
 extern "C" int fqss_chan_sum(const float* g, float* out, int64_t B, int64_t C, int64_t M, int64_t ld, fqss_stream_t stream) {
     FQSS_REQUIRE(g && out, "null pointer");
     FQSS_REQUIRE(B > 0 && C > 0 && M > 0 && ld >= M && B <= 65535, "bad shape");
-    hipLaunchKernelGGL(k_chan_sum, dim3((unsigned)C, (unsigned)B), dim3(256), 0, (hipStream_t)stream, g, out, C, M, ld);
+    int64_t gz = cdiv(M, 16384);          // few channels x few samples must still fill 256 CUs
+    const int64_t want = cdiv(2048, C * B);
+    if (gz > want) gz = want;
+    if (gz < 1) gz = 1;
+    if (gz > 1024) gz = 1024;
+    hipLaunchKernelGGL(k_chan_sum, dim3((unsigned)C, (unsigned)B, (unsigned)gz), dim3(256), 0, (hipStream_t)stream, g, out, C, M, ld);
     return launch_status("fqss_chan_sum");
 }
