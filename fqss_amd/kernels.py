@@ -1305,3 +1305,22 @@ def infer_normalize(out, sum_weight):
     assert out.is_contiguous()
     L = out.shape[-1]
     _lib.call("fqss_infer_normalize", _p(out), _p(sum_weight), out.numel() // L, L, L, _stream())
+
+
+# ------------------------------------------------------------------ affine form of the quantizers (csrc/export_q.hip)
+def fq_affine(x, scale, zero_point, axis, qmin, qmax, want_codes=False):
+    """torch.fake_quantize_per_(tensor|channel)_affine on the device; scale [C] fp32, zero_point [C] int32 (C = 1: per tensor, axis
+    ignored) -> y (and the int32 codes when want_codes)"""
+    _need_gpu(x, scale)
+    x = x.contiguous()
+    C = scale.numel()
+    if C == 1:
+        outer, inner = 1, x.numel()
+    else:
+        outer, C2, inner = _w_layout(x.shape, axis)
+        assert C2 == C, "fq_affine: scale does not match the channel axis"
+    y = torch.empty_like(x)
+    codes = torch.empty(x.shape, device=x.device, dtype=torch.int32) if want_codes else None
+    _lib.call("fqss_fq_affine", _p(x), _p(y), _p(codes), outer, C, inner, _p(scale.contiguous()), _p(zero_point.contiguous()), int(qmin), int(qmax),
+              _stream())
+    return (y, codes) if want_codes else y

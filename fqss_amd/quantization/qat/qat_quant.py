@@ -152,3 +152,72 @@ def get_weight_quantizer(gradient_based=True, weight_shape=(1, 1, 1), n_bits=8, 
 
 def get_dym_activation_quantizer(n_bits=8, factor=0.99):
     raise NotImplementedError("dynamic activation quantizer: no call site in the FQSS training path")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# true-integer export: the affine (scale, zero-point) wrappers of the reference, qat_quant.py:15-72
+# ---------------------------------------------------------------------------------------------------------------------------
+class TorchWeightFakeQuantize(nn.Module):
+    """per-channel symmetric weight quantizer in torch's affine form (qat_quant.py:15-37): scale = max(|min|, |max|) / 2^(n-1),
+    zero point 0; `integer(w)` returns the int8 codes a true-integer kernel consumes"""
+
+    def __init__(self, quantizer):
+        super().__init__()
+        mn, mx = quantizer.min_range.detach(), quantizer.max_range.detach()
+        max_abs = torch.maximum(torch.abs(mn), torch.abs(mx))
+        scales = max_abs / (2 ** (quantizer.n_bits - int(quantizer.sign)))
+        self.scales = scales.flatten()
+        self.zero_points = torch.zeros_like(self.scales)
+        self.axis, self.sign, self.n_bits = quantizer.axis, quantizer.sign, quantizer.n_bits
+
+    def _lim(self):
+        return (-2 ** (self.n_bits - 1), 2 ** (self.n_bits - 1) - 1) if self.sign else (0, 2 ** self.n_bits - 1)
+
+    def forward(self, x, w_param=None):
+        return K.fq_affine(x, self.scales.to(x.device), self.zero_points.to(x.device).int(), self.axis, *self._lim())
+
+    def integer(self, x):
+        _, codes = K.fq_affine(x, self.scales.to(x.device), self.zero_points.to(x.device).int(), self.axis, *self._lim(), want_codes=True)
+        return codes.to(torch.int8 if self.sign else torch.uint8)
+
+
+class TorchActivationFakeQuantize(nn.Module):
+    """per-tensor asymmetric activation quantizer in torch's affine form (qat_quant.py:40-56), quirks included: the zero point is
+    |round(min / scale)| whatever the sign of min"""
+
+    def __init__(self, quantizer):
+        super().__init__()
+        mn, mx = quantizer.min_range.detach().cpu(), quantizer.max_range.detach().cpu()
+        self.scale = float((mx - mn) / (2 ** quantizer.n_bits - 1))
+        zp = int(torch.round(mn / self.scale))
+        self.zero_point = -zp if mn < 0 else zp
+        self.n_bits = quantizer.n_bits
+
+    def _args(self, dev):
+        return torch.tensor([self.scale], device=dev), torch.tensor([self.zero_point], device=dev, dtype=torch.int32)
+
+    def forward(self, x):
+        x = ops.real(x)
+        return K.fq_affine(x, *self._args(x.device), 0, 0, 2 ** self.n_bits - 1)
+
+    def integer(self, x):
+        x = ops.real(x)
+        return K.fq_affine(x, *self._args(x.device), 0, 0, 2 ** self.n_bits - 1, want_codes=True)[1].to(torch.uint8)
+
+    # the LayerQ forwards drive their quantizer through qctx(): an exported model runs un-fused, layer by layer
+    def qctx(self):
+        raise NotImplementedError("TorchActivationFakeQuantize: exported models evaluate through `forward`, not the fused training kernels")
+
+
+def export_integer_state(model):
+    """{quantizer path: affine parameters} + {weight path: int8 codes} of a trained model: what a true-integer (int8 MFMA) deployment
+    loads.  Weights are located through the LayerQ that owns the quantizer (its float submodule's `.weight`)."""
+    out = {}
+    for name, m in model.named_modules():
+        if isinstance(m, GradientActivationFakeQuantize):
+            t = TorchActivationFakeQuantize(m)
+            out[name] = {"scale": t.scale, "zero_point": t.zero_point, "quant_min": 0, "quant_max": 2 ** t.n_bits - 1}
+        elif isinstance(m, GradientWeightFakeQuantize):
+            t = TorchWeightFakeQuantize(m)
+            out[name] = {"scales": t.scales.cpu(), "zero_points": t.zero_points.cpu(), "axis": t.axis, "quant_min": t._lim()[0], "quant_max": t._lim()[1]}
+    return out

@@ -128,3 +128,27 @@ def replace_encoderq(model, modules_to_replace, params_dict):
 
 def replace_decoderq(model, modules_to_replace, params_dict):
     _replace_io(model, modules_to_replace, params_dict, quant_decoderq)
+
+
+# true-integer export (reference qat_utils.py:246-255, 334-351): swap a learned quantizer for its affine torch-form wrapper
+def torch_weight_quantizer(quantizer):
+    from .qat_quant import TorchWeightFakeQuantize
+    return TorchWeightFakeQuantize(quantizer)
+
+
+def torch_activation_quantizer(quantizer):
+    from .qat_quant import TorchActivationFakeQuantize
+    return TorchActivationFakeQuantize(quantizer)
+
+
+def torch_dym_activation_quantizer(quantizer):
+    raise NotImplementedError("dynamic activation quantizer: no call site in the FQSS training path")
+
+
+def replace_weight_quantizer(model, module_to_replace, module):
+    _set_module(model, module_to_replace, torch_weight_quantizer(module))
+
+
+def replace_activation_quantizer(model, module_to_replace, module):
+    _set_module(model, module_to_replace, torch_activation_quantizer(module))
+

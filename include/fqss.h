@@ -563,6 +563,13 @@ int fqss_infer_ola(const float* chunk, const int* map, float* out, float* sum_we
                    int64_t ld_chunk, int64_t ld_out, fqss_stream_t stream);
 int fqss_infer_normalize(float* out, const float* sum_weight, int64_t rows, int64_t L, int64_t ld, fqss_stream_t stream);
 
+/* Affine (scale, zero-point) form of the learned quantizers for the true-integer export (csrc/export_q.hip; SURVEY.md §8(f) rank 3;
+ * replaces torch.fake_quantize_per_tensor_affine / per_channel_affine inside TorchWeightFakeQuantize / TorchActivationFakeQuantize /
+ * TorchDymActivationFakeQuantize, qat_quant.py:15-72).  x viewed as [outer][C][inner]; scale / zp [C] on the device (C = 1: per
+ * tensor); y (optional) the de-quantized values, codes (optional, int32) the integers q in [qmin, qmax].                       */
+int fqss_fq_affine(const float* x, float* y, int* codes, int64_t outer, int64_t C, int64_t inner, const float* scale, const int* zp, int qmin,
+                   int qmax, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

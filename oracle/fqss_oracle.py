@@ -447,3 +447,32 @@ def model_infer(fwd, mix, n_srcs, segment=None, overlap=0.25, target=None):
         sum_weight[start:stop] += weight[:n]
     return out / sum_weight
 
+
+# ------------------------------------------------------------------------------------------
+# true-integer export: qat_quant.py:15-56
+# ------------------------------------------------------------------------------------------
+def fq_affine(x, scale, zero_point, axis, qmin, qmax):
+    """torch.fake_quantize_per_(tensor|channel)_affine restated: q = clamp(zp + nearbyint(x * (1 / scale)), qmin, qmax),
+    y = (q - zp) * scale, all in fp32 -> (y, integer codes)"""
+    scale = torch.as_tensor(scale, dtype=torch.float32).reshape(-1)
+    zp = torch.as_tensor(zero_point, dtype=torch.float32).reshape(-1)
+    if scale.numel() > 1:
+        shape = [-1 if i == axis else 1 for i in range(x.dim())]
+        scale, zp = scale.reshape(shape), zp.reshape(shape)
+    q = torch.clamp(zp + torch.round(x * (1.0 / scale)), qmin, qmax)
+    return (q - zp) * scale, q.to(torch.int32)
+
+
+def weight_export(w, lo, hi, axis, n_bits=8):
+    """TorchWeightFakeQuantize (qat_quant.py:15-37): scales = max(|min|, |max|) / 2^(n-1), zero point 0"""
+    scales = (torch.maximum(lo.abs(), hi.abs()) / 2 ** (n_bits - 1)).flatten()
+    return fq_affine(w, scales, torch.zeros_like(scales), axis, -2 ** (n_bits - 1), 2 ** (n_bits - 1) - 1) + (scales,)
+
+
+def act_export(x, lo, hi, n_bits=8):
+    """TorchActivationFakeQuantize (qat_quant.py:40-56), incl. its zero-point quirk (|round(min / scale)|)"""
+    scale = float((torch.tensor(hi) - torch.tensor(lo)) / (2 ** n_bits - 1))
+    zp = int(torch.round(torch.tensor(lo) / scale))
+    zp = -zp if lo < 0 else zp
+    return fq_affine(x, [scale], [zp], 0, 0, 2 ** n_bits - 1) + (scale, zp)
+

@@ -41,3 +41,18 @@ def test_model_infer(golden):
         err = np.abs(got.numpy() - want)
         # eval mode quantizes: fp32 noise flips a few 8-bit bins, each moving a handful of output samples by one output step
         assert err.max() <= 0.02 * np.abs(want).max() and np.mean(err > 1e-6) < 0.02, (key, err.max(), np.mean(err > 1e-6))
+
+
+def test_export_wrappers(golden):
+    """the affine (scale, zero-point) export form vs the REAL reference's TorchWeightFakeQuantize /
+    TorchActivationFakeQuantize (tests/golden/export.npz, tools/make_goldens_export.py): values and integer codes bit-exact"""
+    g = golden("export")
+    for tag in ("w0", "w1", "w2d"):
+        y, codes, scales = O.weight_export(T(g[tag + ".w"]), T(g[tag + ".min"]), T(g[tag + ".max"]), int(g[tag + ".axis"]))
+        assert torch.equal(scales, T(g[tag + ".scales"])) and torch.equal(y, T(g[tag + ".y"]))
+        assert torch.equal(codes.to(torch.int8), T(g[tag + ".codes"]))
+    for tag in ("a0", "a1", "a2", "a3"):
+        lo, hi = (float(v) for v in g[tag + ".range"])
+        y, codes, scale, zp = O.act_export(T(g[tag + ".x"]), lo, hi)
+        assert scale == float(g[tag + ".scale"]) and zp == int(g[tag + ".zero_point"])
+        assert torch.equal(y, T(g[tag + ".y"])) and int(codes.min()) >= 0 and int(codes.max()) <= 255
