@@ -116,6 +116,7 @@ _PROTOS = {
     "fqss_infer_ola": [P, P, P, P, I32, I32, I64, I64, I64, I64, I64, P],
     "fqss_infer_normalize": [P, P, I64, I64, I64, P],
     "fqss_fq_affine": [P, P, P, I64, I64, I64, P, P, I32, I32, P],
+    "fqss_snr_mix": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
     "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
     "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
 }

@@ -1324,3 +1324,17 @@ def fq_affine(x, scale, zero_point, axis, qmin, qmax, want_codes=False):
     _lib.call("fqss_fq_affine", _p(x), _p(y), _p(codes), outer, C, inner, _p(scale.contiguous()), _p(zero_point.contiguous()), int(qmin), int(qmax),
               _stream())
     return (y, codes) if want_codes else y
+
+
+# ------------------------------------------------------------------ data side (csrc/data_ops.hip)
+def snr_mix(a, b, snr, mode=0, clip=True):
+    """rows of a / b [B, T] mixed at snr [B] dB: generate_2mix_snr (mode 0) / generate_mix_noise (mode 1) + max_clip (process.py:57-103)"""
+    _need_gpu(a, b, snr)
+    a, B, T, ld_a = as_rowmat(a)
+    b, B2, T2, ld_b = as_rowmat(b)
+    assert (B, T) == (B2, T2) and snr.numel() == B
+    ws = torch.zeros(2 * B, device=a.device, dtype=torch.float64)
+    peak = torch.zeros(B, device=a.device, dtype=torch.int32)
+    out = torch.empty(B, T, device=a.device, dtype=torch.float32)
+    _lib.call("fqss_snr_mix", _p(a), _p(b), _p(snr.contiguous()), _p(ws), _p(peak), _p(out), B, T, ld_a, ld_b, T, mode, 1 if clip else 0, _stream())
+    return out

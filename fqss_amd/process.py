@@ -108,3 +108,28 @@ def metric_evaluation(sep_waveform, clean_waveforms, sample_rate=16000):
     metrics outside the hot path: reported as NaN"""
     db = K.sisnr_matrix(sep_waveform.reshape(clean_waveforms.shape[0], -1), clean_waveforms.reshape(clean_waveforms.shape[0], -1))
     return db.max(dim=1).values.mean().item(), float("nan"), float("nan")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# data side (SURVEY.md §8(f) rank 4): the SNR augmentation of the LibriMix dataset on the device, batched
+# ---------------------------------------------------------------------------------------------------------------------------
+def generate_2mix_snr(signal1, signal2, snr, clip=True):
+    """process.generate_2mix_snr (process.py:77-91) for one pair [T] or a batch [B, T]; snr: a number or a [B] tensor (dB)"""
+    one = signal1.dim() == 1
+    a, b = signal1.reshape(-1, signal1.shape[-1]), signal2.reshape(-1, signal2.shape[-1])
+    s = snr if torch.is_tensor(snr) else torch.full((a.shape[0],), float(snr), device=a.device)
+    out = K.snr_mix(a, b, s.to(a.device, torch.float32), 0, clip)
+    return out[0] if one else out
+
+
+def generate_3mix_snr(signal1, signal2, signal3, snr1_23, snr2_3):
+    return generate_2mix_snr(signal1, generate_2mix_snr(signal2, signal3, snr2_3), snr1_23)
+
+
+def generate_mix_noise(sig, noise, snr):
+    """process.generate_mix_noise (process.py:98-103)"""
+    one = sig.dim() == 1
+    a, b = sig.reshape(-1, sig.shape[-1]), noise.reshape(-1, noise.shape[-1])
+    s = snr if torch.is_tensor(snr) else torch.full((a.shape[0],), float(snr), device=a.device)
+    out = K.snr_mix(a, b, s.to(a.device, torch.float32), 1, True)
+    return out[0] if one else out

@@ -570,6 +570,12 @@ int fqss_infer_normalize(float* out, const float* sum_weight, int64_t rows, int6
 int fqss_fq_affine(const float* x, float* y, int* codes, int64_t outer, int64_t C, int64_t inner, const float* scale, const int* zp, int qmin,
                    int qmax, fqss_stream_t stream);
 
+/* Data side (csrc/data_ops.hip): the SNR augmentation of the LibriMix dataset, batched on the device --
+ * process.generate_2mix_snr (mode 0) / generate_mix_noise (mode 1) followed by max_clip(0.9) (process.py:57-103), one (a, b, snr) triple
+ * per row.  ws: 2*B doubles, peak: B uint32, both zeroed by the caller; clip = 0 skips max_clip.                                  */
+int fqss_snr_mix(const float* a, const float* b, const float* snr, double* ws, uint32_t* peak, float* out, int64_t B, int64_t T, int64_t ld_a,
+                 int64_t ld_b, int64_t ld_o, int mode, int clip, fqss_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -476,3 +476,28 @@ def act_export(x, lo, hi, n_bits=8):
     zp = -zp if lo < 0 else zp
     return fq_affine(x, [scale], [zp], 0, 0, 2 ** n_bits - 1) + (scale, zp)
 
+
+# ------------------------------------------------------------------------------------------
+# data side: process.py:57-103
+# ------------------------------------------------------------------------------------------
+def max_clip(x, max_check=0.9, clip=0.9):
+    m = x.abs().max()
+    return x * (clip / m) if m >= max_check else x
+
+
+def generate_2mix_snr(s1, s2, snr, clip=True):
+    E1, E2 = torch.mean(s1 ** 2), torch.mean(s2 ** 2)
+    if E1 > 0.0 and E2 > 0.0:
+        if 10 * torch.log10(E1 / E2) < snr:
+            s2 = s2 * torch.sqrt((E1 / E2) * (10 ** (-snr / 10)))
+        else:
+            s1 = s1 * torch.sqrt((E2 / E1) * (10 ** (snr / 10)))
+    mix = s1 + s2
+    return max_clip(mix) if clip else mix
+
+
+def generate_mix_noise(sig, noise, snr):
+    Es, En = torch.mean(sig ** 2), torch.mean(noise ** 2)
+    gain = torch.sqrt((Es / En) / (10 ** (snr / 10))) if Es > 0 else 1.0
+    return max_clip(sig + gain * noise)
+

@@ -59,3 +59,20 @@ def test_model_infer_matches_the_reference(golden):
     assert np.isfinite(s)
     with pytest.raises(RuntimeError):
         model_infer(m, mix, device="cpu")
+
+
+def test_data_side_augmentation_batched(golden):
+    """process.generate_2mix_snr / generate_3mix_snr / generate_mix_noise + max_clip, batched on the device
+    (fqss_snr_mix), against the REAL reference's process.py run item by item"""
+    from fqss_amd.process import generate_2mix_snr, generate_3mix_snr, generate_mix_noise
+    g = golden("data_aug")
+    s = T(g["s"]).cuda()
+    i, j, snr = g["cases"][:, 0].astype(int), g["cases"][:, 1].astype(int), T(g["cases"][:, 2]).cuda()
+    a, b = s[i], s[j]
+    # 10^(snr/10), the energy means and the peak come out of different reduction orders: 2e-6 relative
+    np.testing.assert_allclose(generate_2mix_snr(a, b, snr).cpu().numpy(), g["mix2"], rtol=5e-6, atol=2e-7)
+    np.testing.assert_allclose(generate_2mix_snr(a, b, snr, clip=False).cpu().numpy(), g["mix2_noclip"], rtol=5e-6, atol=2e-7)
+    np.testing.assert_allclose(generate_mix_noise(a, b, snr.abs() + 6.0).cpu().numpy(), g["noise"], rtol=5e-6, atol=2e-7)
+    np.testing.assert_allclose(generate_3mix_snr(s[0], s[1], s[2], 1.5, -2.0).cpu().numpy(), g["mix3"], rtol=5e-6, atol=2e-7)
+    np.testing.assert_allclose(generate_2mix_snr(torch.zeros(4000, device="cuda"), s[1], 3.0).cpu().numpy(), g["zero"], rtol=5e-6, atol=2e-7)
+    assert float(generate_2mix_snr(a, b, snr).abs().max()) <= 0.9 + 1e-6

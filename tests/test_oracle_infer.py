@@ -56,3 +56,17 @@ def test_export_wrappers(golden):
         y, codes, scale, zp = O.act_export(T(g[tag + ".x"]), lo, hi)
         assert scale == float(g[tag + ".scale"]) and zp == int(g[tag + ".zero_point"])
         assert torch.equal(y, T(g[tag + ".y"])) and int(codes.min()) >= 0 and int(codes.max()) <= 255
+
+
+def test_data_side_augmentation(golden):
+    """the SNR augmentation vs the REAL reference's process.py (tests/golden/data_aug.npz)"""
+    g = golden("data_aug")
+    s = T(g["s"])
+    for n, (i, j, snr) in enumerate(g["cases"]):
+        a, b = s[int(i)], s[int(j)]
+        np.testing.assert_allclose(O.generate_2mix_snr(a, b, float(snr)).numpy(), g["mix2"][n], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(O.generate_2mix_snr(a, b, float(snr), clip=False).numpy(), g["mix2_noclip"][n], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(O.generate_mix_noise(a, b, abs(float(snr)) + 6.0).numpy(), g["noise"][n], rtol=1e-6, atol=1e-7)
+    m3 = O.generate_2mix_snr(s[0], O.generate_2mix_snr(s[1], s[2], -2.0), 1.5)
+    np.testing.assert_allclose(m3.numpy(), g["mix3"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(O.generate_2mix_snr(torch.zeros(4000), s[1], 3.0).numpy(), g["zero"], rtol=1e-6, atol=1e-7)
