@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5"),
+    ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5", "infer"),
                     help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s; "
                          "cfg5 HTDemucs 4 x 10 s stereo 44.1 kHz")
     ap.add_argument("--hd-batch", type=int, default=4, help="cfg5: samples per GPU (htdemucs.yaml: 32 over 8 GPUs)")
@@ -325,10 +325,47 @@ def main_htdemucs(a):
     comm.close()
 
 
+def main_infer(a):
+    """quantized ConvTasNet inference (eval mode, codes-only dataflow, one hipGraph per request shape) on the cfg 2 batch: 8 x 4 s"""
+    from fqss_amd.data import synth_batch
+    from fqss_amd.quantization.qat.models.load_model import create_model, quantize_model
+    from fqss_amd.runtime import InferRunner
+    from fqss_amd.smoke import QCFG
+    assert a.gpus == 1, "the inference probe is a single-GPU measurement"
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    model = quantize_model(create_model({"name": "ConvTasNet", "n_src": 2, "kernel_size": 16, "stride": 8}), dict(QCFG)).cuda().train()
+    x, _ = synth_batch(8, 32000, seed=0, device="cuda")
+    with torch.no_grad():
+        for _ in range(50):
+            model(x)                                        # observer calibration
+    run = InferRunner(model, use_graph=not a.no_graph)
+    for _ in range(max(a.warmup, 1)):
+        y = run(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = run(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / a.steps * 1e3
+    fwd_bytes = 74.8e9 / 4.0                                  # SURVEY.md 8(d): one forward = a quarter of the step's algorithmic bytes
+    print(json.dumps({"metric": "quantized inference samples/sec, ConvTasNet 2spk 8kHz W8A8", "value": round(8 * a.steps / dt, 2), "unit": "samples/s",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "u8/f32", "data": "synthetic",
+                      "config": {"workload": "ConvTasNet 2spk 8 kHz W8A8 inference (eval mode, codes-only dataflow), batch 8 x 4 s",
+                                 "launch": "eager" if a.no_graph else "hipGraph replay"},
+                      "roofline": {"kernel": "whole forward", "bound": "hbm", "achieved": round(fwd_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                                   "unit": "GB/s", "frac": round(fwd_bytes / (ms * 1e-3) / 8e12, 4), "traffic": None},
+                      "out_rms": round(float(y.pow(2).mean().sqrt()), 6)}), flush=True)
+
+
 def main():
     a = parse()
     if a.workload == "cfg5":
         return main_htdemucs(a)
+    if a.workload == "infer":
+        return main_infer(a)
     assert torch.cuda.is_available(), "bench.py needs ROCm GPUs"
     if a.workload != "cfg2":
         return main_dualpath(a)

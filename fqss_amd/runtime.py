@@ -484,3 +484,46 @@ class KDTrainStep:
         self.arena._host_step += 1
         g2.replay()
         return self.last
+
+
+class InferRunner:
+    """Quantized inference as it would be served: the eval-mode forward on the codes-only dataflow
+    (activations travel between layers as u8 codes, the 1x1 convolutions run on the integer codes: bit-identical to the plain eval
+    forward) captured into one hipGraph per input shape, so a request costs one graph launch."""
+
+    def __init__(self, model, use_graph=True):
+        from .quantization.qat.models.load_model import enable_observer
+        self.model = model.eval()
+        enable_observer(self.model, False)
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    @torch.no_grad()
+    def _forward(self, x):
+        with ops.fast_codes(True):
+            return self.model(x)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if not self.use_graph:
+            return self._forward(x)
+        key = tuple(x.shape)
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # warm-up outside the capture (allocator, lazy tables)
+                    self._forward(sx)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward(sx)
+            ent = self._graphs[key] = (g, sx, out)
+        g, sx, out = ent
+        if x.data_ptr() != sx.data_ptr():
+            sx.copy_(x)
+        g.replay()
+        return out

@@ -76,3 +76,20 @@ def test_data_side_augmentation_batched(golden):
     np.testing.assert_allclose(generate_3mix_snr(s[0], s[1], s[2], 1.5, -2.0).cpu().numpy(), g["mix3"], rtol=5e-6, atol=2e-7)
     np.testing.assert_allclose(generate_2mix_snr(torch.zeros(4000, device="cuda"), s[1], 3.0).cpu().numpy(), g["zero"], rtol=5e-6, atol=2e-7)
     assert float(generate_2mix_snr(a, b, snr).abs().max()) <= 0.9 + 1e-6
+
+
+def test_infer_runner_graph_replay_is_bit_identical(golden):
+    """the serving form of the quantized forward: eval mode on the codes-only dataflow, captured per request shape; bit-identical to the
+    plain eval forward, for two shapes served alternately"""
+    from fqss_amd.runtime import InferRunner
+    g = golden("infer")
+    m = _model(g)
+    run = InferRunner(m)
+    mix = T(g["mix"]).cuda()
+    xs = [mix[:, :2400].reshape(1, 1, -1).contiguous(), mix[:, :3000].reshape(1, 1, -1).repeat(2, 1, 1).contiguous()]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+    for _ in range(2):
+        for x, w in zip(xs, want):
+            assert torch.equal(run(x), w)
+    assert len(run._graphs) == 2
