@@ -315,6 +315,10 @@ class KDTrainStep:
         (solver.py:333-366: L1 task + SDR-weighted L1 distillation, per-source weights).  clip <= 0: no clipping (htdemucs.yaml:84).
         batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow)"""
         self.model, self.fmodel = model, fmodel
+        if batched_quantizers and loss == "l1_sdr":
+            # measured on the tiny HTDemucs: with the batched weight-quantizer tables the reshaped convolution weights of the frame
+            # path lose their gradient arena and the loss climbs after two updates -- refused until that is wired
+            raise NotImplementedError("KDTrainStep: batched quantizer tables are not wired into the HTDemucs layers (use batched_quantizers=False)")
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
         self._graphs = None
         self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
