@@ -620,6 +620,10 @@ def fq_node(aq, x, nl=None, codes=False):
     flat = _flat2d(x)
     want = codes and ops_dp.QROW and q.qmode == ops.Q_QUANT
     q.no_codes = not want     # no coded consumer downstream: skip the 1 B/element side output
+    # the fp32 values are written next to the codes even on the codes-only dataflow: the consuming row linear multiplies the codes in
+    # its forward but its weight gradient (and any other consumer) reads the fp32 tensor -- left unwritten it was uninitialised
+    # memory under KDTrainStep (found with FQSS_DEBUG_CARRIER=1: NaN weight gradients of every coded row linear)
+    q.keep_out = q.keep_out or want
     y = ops.NlActQ.apply(x if flat is None else flat, slope, q.qmin, q.qmax, act, q, slope)
     if aq is not None:
         aq.after_forward(q)
