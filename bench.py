@@ -284,7 +284,7 @@ def main_htdemucs(a):
     g = torch.Generator().manual_seed(42 + comm.rank)
     src = (torch.randn(B, 4, 2, T, generator=g) * 0.1).to(dev)            # synthetic stereo Gaussian stems
     mix = src.sum(1)
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, comm=comm, loss="l1_sdr", batched_quantizers=False)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, comm=comm, loss="l1_sdr")
     step(mix, src)                                          # untimed calibration: the 50-call observer phase
     with torch.no_grad():
         for _ in range(49):

@@ -540,6 +540,17 @@ def axpby(a, b, sb, sa=1.0):
     return z
 
 
+def axpby_(a, b, sb, sa=1.0):
+    """a = sa*a + sb*b in place (element-wise: the output may alias an operand)"""
+    _need_gpu(a, b)
+    assert a.shape == b.shape and a.is_contiguous()
+    rm = rowmat(a)
+    b, rows, cols, ld_b = as_rowmat(b)
+    assert rm is not None and (rm[0], rm[1]) == (rows, cols)
+    _lib.call("fqss_axpby", _p(a), _p(b), float(sa), float(sb), _p(a), rows, cols, rm[2], ld_b, rm[2], _stream())
+    return a
+
+
 def mul_bcast_fwd(mask, feat):
     """mask [B,S,C,M] * feat [B,C,M] -> [B,S,C,M]"""
     _need_gpu(mask, feat)

@@ -43,6 +43,9 @@ class ActCodes:
 
 def tag_codes(y, q):
     """attach the codes produced by the epilogue of this call to its output tensor"""
+    if q.idx is not None and not CODED:
+        assert not q.carrier, "codes-only carriers need the coded dataflow"
+        q.idx = q.prod = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
     if q.idx is not None:
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
         y._fqss_carrier = q.carrier
@@ -90,6 +93,7 @@ def is_carrier(x):
 # the codes; every other consumer calls real(x) first.  Off by default (module outputs are then real
 # fp32, like the reference's); fqss_amd.runtime.KDTrainStep turns it on around the student forward.
 FAST = False
+CODED = True            # False (tests, `coded_dataflow(False)`): no layer output carries codes -> every layer runs its un-fused fp32 kernels
 DEBUG_POISON = bool(int(__import__("os").environ.get("FQSS_DEBUG_CARRIER", "0")))   # NaN-fill carriers (tests)
 
 
@@ -123,6 +127,37 @@ class fast_codes:
     def __exit__(self, *a):
         global FAST
         FAST = self.prev
+
+
+class coded_dataflow:
+    """coded_dataflow(False): layer outputs do not carry their u8 codes, so every consumer takes its un-fused fp32 kernels (the
+    per-layer path the G1 fixtures pin); used by the tests that pin the fused codes-only step against it"""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global CODED
+        self.prev, CODED = CODED, self.on
+
+    def __exit__(self, *a):
+        global CODED
+        CODED = self.prev
+
+
+class poison_carriers:
+    """NaN-fill every codes-only carrier inside the block (what FQSS_DEBUG_CARRIER=1 does process-wide)"""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global DEBUG_POISON
+        self.prev, DEBUG_POISON = DEBUG_POISON, self.on
+
+    def __exit__(self, *a):
+        global DEBUG_POISON
+        DEBUG_POISON = self.prev
 
 
 def _carrier(out):
@@ -161,6 +196,16 @@ def reshape_tagged(x, *shape):
         y._fqss_q = ActCodes(xq.idx.reshape(*shape), xq.qmin, xq.qmax)
         y._fqss_carrier = is_carrier(x)
     return y
+
+
+def weight_view(w, *shape):
+    """w.view(shape) of a (possibly fake-quantized) weight that keeps the dL/dW_q arena slot of a weight fake-quantized by
+    runtime.QuantTables: such a tensor has no autograd history, its consumers accumulate its gradient into `_fqss_gwq`"""
+    v = w.view(*shape)
+    gwq = getattr(w, "_fqss_gwq", None)
+    if gwq is not None:
+        v._fqss_gwq = gwq.view(*shape)
+    return v
 
 
 BYPASS = QCtx()
@@ -366,6 +411,9 @@ class LinearActQ(Function):
                 L.w_param._fqss_touched = True
             if gwq is not None:
                 gw = None
+                done = getattr(w, "_fqss_gwq_done", None)     # a re-laid-out copy of the weight (convtr_frames): fold its gradient back
+                if done is not None:
+                    done()
         return gx, gw, g_bias, g_slope, g_min, g_max, None, None, None, None, None
 
 

@@ -48,7 +48,10 @@ class RowLinear(Function):
         gz = gz.contiguous()
         gx = K.rowlin_bwd_x(gz, w) if ctx.needs_input_grad[0] else None
         gw = None
-        if ctx.needs_input_grad[1]:
+        gwq = getattr(w, "_fqss_gwq", None)     # weight fake-quantized by runtime.QuantTables (no autograd history): dL/dW_q goes
+        if gwq is not None:                     # into the step's arena, consumed by fqss_wq_multi_bwd
+            K.rowlin_bwd_w(gz, x, gwq)
+        elif ctx.needs_input_grad[1]:
             gw, direct = _param_grad(w, w)
             K.rowlin_bwd_w(gz, x, gw)
             gw = None if direct else gw

@@ -258,7 +258,8 @@ def conv_frames(conv, x, weight):
     Co = conv.out_channels
     ops_dp.touch(weight)
     L = ops._Lin("pw", b_param=conv.bias)
-    z = ops.LinearActQ.apply(cols, weight.reshape(Co, -1, 1), conv.bias, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
+    w3 = ops.weight_view(weight, Co, -1, 1)
+    z = ops.LinearActQ.apply(cols, w3, conv.bias, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
     z = z.reshape(B, Co, Ho, Wo)
     return z.squeeze(2) if one_d else z
 
@@ -282,6 +283,13 @@ def convtr_frames(convtr, x, weight, bias=_OWN):
     Co = convtr.out_channels
     ops_dp.touch(weight)
     wt = weight.reshape(Ci, -1).t().contiguous().unsqueeze(-1)           # [Co*kh*kw, Ci, 1]: a transposing copy of the (small) weight
+    gwq = getattr(weight, "_fqss_gwq", None)
+    if gwq is not None:
+        # weight fake-quantized by runtime.QuantTables (no autograd history): the copy's gradient is transposed back into the
+        # weight's dL/dW_q arena slot by the GEMM node's backward
+        gwt = torch.zeros_like(wt)
+        wt._fqss_gwq = gwt
+        wt._fqss_gwq_done = lambda: K.axpby_(gwq.reshape(Ci, -1), K.transpose2d(gwt.reshape(-1, Ci)), 1.0)
     frames = ops.LinearActQ.apply(x4.reshape(B, Ci, Hi * Wi), wt, None, None, None, None, ops._Lin("pw"), ops.ACT_NONE, ops.BYPASS)
     y = ops_dp.FramesOla.apply(frames, convtr.bias if bias is _OWN else bias, (B, Co, H, W), geom)
     return y.squeeze(2) if one_d else y
@@ -618,7 +626,7 @@ def fq_node(aq, x, nl=None, codes=False):
         return x
     x = ops.real(x)
     flat = _flat2d(x)
-    want = codes and ops_dp.QROW and q.qmode == ops.Q_QUANT
+    want = codes and ops_dp.QROW and ops.CODED and q.qmode == ops.Q_QUANT
     q.no_codes = not want     # no coded consumer downstream: skip the 1 B/element side output
     # the fp32 values are written next to the codes even on the codes-only dataflow: the consuming row linear multiplies the codes in
     # its forward but its weight gradient (and any other consumer) reads the fp32 tensor -- left unwritten it was uninitialised
@@ -731,7 +739,7 @@ class Conv2dQ(LayerQ):
         c = self.conv2d
         if not self._is_1x1:
             raise NotImplementedError("Conv2dQ.forward_rows: only the 1x1 convolution runs on row-major tensors")
-        w = self._wq(c.weight).view(c.out_channels, c.in_channels)
+        w = ops.weight_view(self._wq(c.weight), c.out_channels, c.in_channels)
         return fq_node(self.activation_fake_quantize, ops_dp.RowLinear.apply(ops.real(x), w, c.bias))
 
     def forward(self, x):
@@ -744,7 +752,7 @@ def run_conv2d_1x1(c, x, weight, aq):
     B, C, H, W = x.shape
     L = ops._Lin("pw", w_param=c.weight, b_param=c.bias)
     ops_dp.touch(weight)
-    z = ops.LinearActQ.apply(ops.real(x).reshape(B, C, H * W), weight.view(c.out_channels, c.in_channels, 1), c.bias, None, None, None,
+    z = ops.LinearActQ.apply(ops.real(x).reshape(B, C, H * W), ops.weight_view(weight, c.out_channels, c.in_channels, 1), c.bias, None, None, None,
                              L, ops.ACT_NONE, ops.BYPASS)
     return fq_node(aq, z).reshape(B, c.out_channels, H, W)
 
@@ -861,7 +869,7 @@ class LinearDecoderQ(LayerQ):
         def pw(t, w):
             L = ops._Lin("pw")
             ops_dp.touch(w)
-            return ops.LinearActQ.apply(ops.real(t), w.view(w.shape[0], w.shape[1], 1), None, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
+            return ops.LinearActQ.apply(ops.real(t), ops.weight_view(w, w.shape[0], w.shape[1], 1), None, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
         outs = self._run(x, pw)
         return [outs] if self.n_combiner == 1 else outs
 

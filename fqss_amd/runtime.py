@@ -310,16 +310,15 @@ class KDTrainStep:
     RCCL all-reduce of the flat gradient buffer runs between the two graphs."""
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None, loss="sisdr_pit", source_weights=None,
-                 batched_quantizers=True):
+                 batched_quantizers=True, fast=True, coded=True):
         """loss: "sisdr_pit" = the asteroid / speechbrain KD loss (mysystem.py:124-151); "l1_sdr" = the htdemucs solver's
         (solver.py:333-366: L1 task + SDR-weighted L1 distillation, per-source weights).  clip <= 0: no clipping (htdemucs.yaml:84).
-        batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow)"""
+        batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow);
+        fast=False: quantizing layers also write their fp32 outputs (no carriers); coded=False: no layer output carries codes,
+        every layer runs its un-fused fp32 kernels (the reference dataflow the tests pin the fused step against)"""
         self.model, self.fmodel = model, fmodel
-        if batched_quantizers and loss == "l1_sdr":
-            # measured on the tiny HTDemucs: with the batched weight-quantizer tables the reshaped convolution weights of the frame
-            # path lose their gradient arena and the loss climbs after two updates -- refused until that is wired
-            raise NotImplementedError("KDTrainStep: batched quantizer tables are not wired into the HTDemucs layers (use batched_quantizers=False)")
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
+        self.fast, self.coded = bool(fast and coded), bool(coded)
         self._graphs = None
         self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
         self.comm = comm
@@ -383,7 +382,7 @@ class KDTrainStep:
             self._tstream.wait_stream(cur)
             with torch.cuda.stream(self._tstream):
                 fest = self.teacher(x)
-        with ops.fast_codes(True), ops.deferred(t):     # student: codes-only dataflow between quantizing layers
+        with ops.fast_codes(self.fast), ops.coded_dataflow(self.coded), ops.deferred(t):   # student: codes-only dataflow between quantizing layers
             est = self.model(x)
         if TEACHER_STREAM:
             cur.wait_stream(self._tstream)

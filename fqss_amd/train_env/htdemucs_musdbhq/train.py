@@ -69,8 +69,7 @@ class Solver:
             raise NotImplementedError("htdemucs env: EMA copies are not built")
         self.weights = torch.tensor(conf.get("weights", [1.0] * model.n_srcs), device=device, dtype=torch.float32)
         self.step = KDTrainStep(model, fmodel, kd_lambda=float(conf.get("kd_lambda", 0.1)), lr=float(opt["lr"]),
-                                clip=float(opt.get("clip_grad") or 0.0), comm=comm, loss="l1_sdr", source_weights=self.weights,
-                                batched_quantizers=False)
+                                clip=float(opt.get("clip_grad") or 0.0), comm=comm, loss="l1_sdr", source_weights=self.weights)
         self.history = []
         self.best_state, self.best_loss = None, float("inf")
 

@@ -440,6 +440,85 @@ def test_dwq_coded(B, C, M, dil):
 # ---------------------------------------------------------------------------------------------
 # degenerate inputs and argument validation through the C ABI (the library never faults on them)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,M,mode", [(2, 16, 77, "add_codes"), (2, 128, 999, "add_codes"), (3, 5, 130, "sub_codes"), (2, 16, 77, "add_f32"),
+                                        (2, 128, 501, "prelu"), (1, 7, 64, "prelu")])
+def test_ewq_coded(B, C, M, mode):
+    """fqss_ewq_fwd / fqss_ewq_bwd / fqss_ewq_bwd_p (AddQ / SubQ / NlQ on codes: qat_layers.py:62-84, 511-518 of the reference)
+    against the oracle quantizer on z = act(dec(a) + sb * b): output codes, gx of both operands, range / slope gradients; the
+    _p form (the producers' output-quantizer backward fused in) against ewq_bwd followed by actq_bwd on each producer."""
+    codes, xa, ac, alo, ahi = _coded_input(B, C, M, seed=C + M)
+    cu = lambda t: t.cuda()
+    gen = torch.Generator().manual_seed(7)
+    bcodes = torch.randint(0, 256, (B, C, M), generator=gen, dtype=torch.uint8)
+    blo, bhi = torch.tensor([-1.21]), torch.tensor([0.77])
+    xb = ((bhi - blo) / 255) * bcodes.float() + blo
+    bc = K.empty_codes((B, C, M), "cuda")
+    bc.copy_(bcodes)
+    sb = {"add_codes": 1.0, "sub_codes": -1.0, "add_f32": 1.0, "prelu": 0.0}[mode]
+    act = K.ACT_PRELU if mode == "prelu" else K.ACT_NONE
+    slope = torch.tensor([0.25])
+    ylo, yhi = torch.tensor([-1.9]), torch.tensor([2.3])
+    g = rnd(B, C, M, seed=4)
+    ar, br, sr = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True), slope.clone().requires_grad_(True)
+    lo_r, hi_r = ylo.clone().requires_grad_(True), yhi.clone().requires_grad_(True)
+    z = F.prelu(ar, sr) if mode == "prelu" else ar + sb * br
+    y = O.act_quantize(z, lo_r, hi_r)
+    y.backward(g)
+    has_b = mode != "prelu"
+    coded_b = mode in ("add_codes", "sub_codes")
+    bf = padded(xb) if (has_b and not coded_b) else None
+    args_b = (bc, cu(blo), cu(bhi)) if coded_b else (None, None, None)
+    sl = cu(slope) if mode == "prelu" else None
+    for write_out in (True, False):
+        out, yc = K.ewq_fwd(ac, cu(alo), cu(ahi), *args_b, bf, sb, act, sl, cu(ylo), cu(yhi), write_out)
+        frac, dmax = _idx_mismatch(yc.cpu(), O.act_indices(z.detach(), ylo, yhi))
+        assert dmax <= 1 and frac <= 2e-3, (frac, dmax)
+        if write_out:
+            assert torch.equal(out.cpu(), ((yhi - ylo) / 255) * yc.cpu().float() + ylo)      # fp32 copy == decode(codes)
+    gacc = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
+    gz = K.ewq_bwd(ac, cu(alo), cu(ahi), *args_b, bf, sb, padded(g), act, sl, cu(ylo), cu(yhi), gacc)
+    tol = 2e-3 + 20 * frac
+    bad = (gz.cpu() - ar.grad).abs() > 1e-4 + 1e-3 * ar.grad.abs()
+    assert bad.float().mean() <= tol, bad.float().mean()
+    if has_b:
+        bad = (sb * gz.cpu() - br.grad).abs() > 1e-4 + 1e-3 * br.grad.abs()
+        assert bad.float().mean() <= tol
+    ga = gacc.view(-1, 3).sum(0).cpu().numpy()
+    sc = float(g.abs().sum()) * 2e-5 + 1e-4
+    np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=5e-3, atol=sc)
+    np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=5e-3, atol=sc)
+    if mode == "prelu":
+        np.testing.assert_allclose(ga[2], sr.grad.item(), rtol=5e-3, atol=sc)
+    if mode != "add_codes":
+        return
+    # ---- fqss_ewq_bwd_p: a and b are fresh outputs of two pointwise convs (res | skip of a TCN block); their pre-quant z's --------
+    da, db = float((ahi - alo) / 255), float((bhi - blo) / 255)
+    pza = padded(xa + 0.3 * da * rnd(B, C, M, seed=9))           # a z that quantizes to ~ac (some elements land in the next bin)
+    pzb = padded(xb + 0.3 * db * rnd(B, C, M, seed=10))
+    ref = {}
+    for which, pz, lo, hi in (("a", pza, alo, ahi), ("b", pzb, blo, bhi)):
+        pg, pb = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda"), torch.zeros(C, device="cuda")
+        ref[which] = (K.actq_bwd(pz, gz, K.ACT_NONE, None, K.Q_QUANT, cu(lo), cu(hi), pg, gbias=pb, C=C), pg, pb)
+    for use_a, use_b in ((True, True), (True, False), (False, True)):
+        gacc2 = torch.zeros_like(gacc)
+        pga, pgb = torch.zeros_like(gacc), torch.zeros_like(gacc)
+        pba, pbb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        gz2, gza, gzb = K.ewq_bwd_p(ac, cu(alo), cu(ahi), bc, cu(blo), cu(bhi), sb, padded(g), act, None, cu(ylo), cu(yhi), gacc2, C,
+                                    prod_a=(pza, K.ACT_NONE, None, pga, pba) if use_a else None,
+                                    prod_b=(pzb, K.ACT_NONE, None, pgb, pbb) if use_b else None)
+        assert (gz2 is None) == (use_a and use_b)
+        if gz2 is not None:
+            assert torch.equal(gz2.cpu(), gz.cpu())
+        for used, got, which, pg, pb in ((use_a, gza, "a", pga, pba), (use_b, gzb, "b", pgb, pbb)):
+            assert (got is not None) == used
+            if used:
+                rz, rg, rb = ref[which]
+                assert torch.equal(got.cpu(), rz.cpu())                       # same arithmetic, element for element
+                close(pb, rb, rtol=1e-4, atol=1e-5 * float(rb.abs().max()) + 1e-6)
+                np.testing.assert_allclose(pg.view(-1, 3).sum(0).cpu().numpy(), rg.view(-1, 3).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
+        np.testing.assert_allclose(gacc2.view(-1, 3).sum(0).cpu().numpy(), ga, rtol=1e-6, atol=1e-6 * sc)
+
+
 def test_empty_batches_are_noops_and_bad_arguments_are_refused():
     from fqss_amd import _lib
     dev = "cuda"
