@@ -32,17 +32,19 @@ _PROTOS = {
     "fqss_qpw_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_x": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
-    "fqss_qpw_fwdq": [P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P],
+    "fqss_qpw_fwdq": [P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P],
+    "fqss_qpw_stat_slots": [I32, I32],
+    "fqss_dwq_stat_slots": [I32, I32],
     "fqss_qpw_fwd2": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_x2": [P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_w2": [P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_decode": [P, P, I64, I64, I64, I64, P, P, P],
-    "fqss_gnq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P],
+    "fqss_gnq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P, I32, P],
     "fqss_gnq_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],
     "fqss_ewq_bwd_p": [P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, P, P, I32,
                        P, I64, I32, P, P, P, P, I64, P, I64, I32, P, P, P, P, I64, P],
     "fqss_gnq_bwd_p": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P, I64, I32, P, P, P, P],
-    "fqss_dwq_fwd": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P],
+    "fqss_dwq_fwd": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P],
     "fqss_dwq_bwd_z": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],
     "fqss_ewq_fwd": [P, P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I64, I32, P, P, P, P],
     "fqss_ewq_bwd": [P, P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
@@ -163,3 +165,14 @@ def call(name, *args):
     rc = fn(*args)
     if rc != 0:
         raise FqssError(f"{name} failed ({rc}): {load().fqss_last_error().decode()}")
+
+
+def query(name, *args):
+    """entry points that return a count instead of a status (fqss_*_stat_slots)"""
+    fn = _bound.get(name)
+    if fn is None:
+        fn = getattr(load(), name)
+        fn.argtypes = _PROTOS[name]
+        fn.restype = C.c_int
+        _bound[name] = fn
+    return fn(*args)

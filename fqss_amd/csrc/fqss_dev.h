@@ -184,5 +184,20 @@ __device__ __forceinline__ float fq_asym(float t, const QRange& r, float& c, flo
     return r.delta * c + r.lo;  // two roundings (mul, add): contraction is off
 }
 
+// The forward-only forms of fq_asym (these streaming kernels are VALU-issue bound: ~5 cycles per wave instruction and SIMD,
+// measured; every instruction per element counts): the clamped code alone, packed with v_cvt_pk_u8_f32 (exact: the code is an
+// integer in [0, 255]); the de-quantised value only where a caller stores it.
+__device__ __forceinline__ float fq_code(float t, const QRange& r) {
+    return __builtin_amdgcn_fmed3f(rintf(div_by(t - r.lo, r.delta, r.inv)), 0.0f, 255.0f);
+}
+__device__ __forceinline__ unsigned int pack_code(float c, unsigned int byte, unsigned int word) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(c, byte, word);
+}
+// exact integer statistics of 4 packed codes: sum c, sum c^2 (v_dot4_u32_u8)
+__device__ __forceinline__ void code_stats4(unsigned int word, unsigned int& s, unsigned int& ss) {
+    s = __builtin_amdgcn_udot4(word, 0x01010101u, s, false);
+    ss = __builtin_amdgcn_udot4(word, word, ss, false);
+}
+
 #endif  // __HIPCC__
 }  // namespace fqss

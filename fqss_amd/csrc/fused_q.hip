@@ -23,6 +23,12 @@ constexpr int kGnSlots = 64;       // partial-sum slots per sample (one per stat
 constexpr int kSlots = FQSS_GACC_SLOTS;
 
 __device__ __forceinline__ float dec(unsigned int c, const QRange& r) { return r.delta * (float)c + r.lo; }
+__device__ __forceinline__ void dec4(unsigned int w, const QRange& r, float (&v)[4]) {
+    v[0] = dec(w & 255u, r);          // v_cvt_f32_ubyte0..3 + mul + add (two roundings, like the reference)
+    v[1] = dec((w >> 8) & 255u, r);
+    v[2] = dec((w >> 16) & 255u, r);
+    v[3] = dec(w >> 24, r);
+}
 
 // ---------------------------------------------------------------------------------------------
 // codes -> fp32
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ c, f
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(1, C) on coded input
 // ---------------------------------------------------------------------------------------------
-// stats: exact integer partial sums of one sample per workgroup slot: ws[(b*kGnSlots + blk)*2 + {0,1}] (int64 as double bits)
+// stats: exact integer partial sums of one sample per workgroup slot: ws[(b*gridDim.x + blk)*2 + {0,1}] (int64)
 __global__ __launch_bounds__(256) void k_gnq_stats(const uint8_t* __restrict__ xc, int C, int M, int64_t ld_c,
                                                     long long* ws) {
     __shared__ long long red[2 * 4];
@@ -70,67 +76,82 @@ __global__ __launch_bounds__(256) void k_gnq_stats(const uint8_t* __restrict__ x
     long long v[2] = {s, ss};
     block_sum<long long, 2>(v, red);
     if (threadIdx.x == 0) {
-        ws[((int64_t)b * kGnSlots + blockIdx.x) * 2] = v[0];
-        ws[((int64_t)b * kGnSlots + blockIdx.x) * 2 + 1] = v[1];
+        ws[((int64_t)b * gridDim.x + blockIdx.x) * 2] = v[0];
+        ws[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 1] = v[1];
     }
 }
 
-// mean / rstd of the DECODED tensor from the exact integer sums: one tiny workgroup per sample
-__global__ __launch_bounds__(64) void k_gnq_finalize(const long long* ws, int nslots, int64_t n, float eps, float* mean_rstd,
-                                                      const float* qmin_x, const float* qmax_x) {
-    const QRange rx = load_qrange(qmin_x, qmax_x);
-    const int b = blockIdx.x, lane = threadIdx.x;
-    long long s = 0, ss = 0;
-    if (lane < nslots) {
-        s = ws[((int64_t)b * kGnSlots + lane) * 2];
-        ss = ws[((int64_t)b * kGnSlots + lane) * 2 + 1];
+// mean / rstd of the DECODED tensor of sample b from the exact integer partial sums ws[b][nslots][2] (written by k_gnq_stats or by
+// the epilogue of the kernel that produced the codes: q-GEMM, depthwise layer).  Every workgroup of the apply pass does this for
+// its own sample (nslots <= 1024: 16 KB from L2): no separate finalize launch.  Block-uniform result in mr[0..1].
+__device__ __forceinline__ void gnq_sample_stats(const long long* __restrict__ ws, int nslots, int b, int64_t n, float eps,
+                                                 const QRange& rx, long long* red, float* mr) {
+    long long v[2] = {0, 0};
+    for (int i = threadIdx.x; i < nslots; i += 256) {
+        v[0] += ws[((int64_t)b * nslots + i) * 2];
+        v[1] += ws[((int64_t)b * nslots + i) * 2 + 1];
     }
-    s = wave_sum(s);
-    ss = wave_sum(ss);
-    if (lane == 0) {
-        const double mc = (double)s / (double)n;
-        double vc = (double)ss / (double)n - mc * mc;
+    block_sum<long long, 2>(v, red);
+    if (threadIdx.x == 0) {
+        const double mc = (double)v[0] / (double)n;
+        double vc = (double)v[1] / (double)n - mc * mc;
         if (vc < 0.0) vc = 0.0;
         const double d = (double)rx.delta;
-        mean_rstd[2 * b] = (float)(d * mc + (double)rx.lo);
-        mean_rstd[2 * b + 1] = (float)(1.0 / sqrt(d * d * vc + (double)eps));
+        mr[0] = (float)(d * mc + (double)rx.lo);
+        mr[1] = (float)(1.0 / sqrt(d * d * vc + (double)eps));
     }
+    __syncthreads();
 }
 
 // y = fq( decode(x)*scale + shift ) -> codes (and fp32 out when asked); 16 elements per thread
 __global__ __launch_bounds__(256) void k_gnq_apply(const uint8_t* __restrict__ xc, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, uint8_t* __restrict__ yc,
-                                                    float* __restrict__ yout, const float* __restrict__ mean_rstd, int B, int C,
+                                                    float* __restrict__ yout, float* __restrict__ mean_rstd,
+                                                    const long long* __restrict__ ws, int nslots, float eps, int B, int C,
                                                     int M, int64_t ld_xc, int64_t ld_yc, int64_t ld_o, const float* qmin_x,
                                                     const float* qmax_x, const float* qmin, const float* qmax) {
+    __shared__ long long red[2 * 4];
+    __shared__ float mr[2];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const int rows = B * C;
     const int cstep = gridDim.x * 256 * 16;
+    int b_have = -1;
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
         const int b = row / C, c = row - b * C;
-        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+        // this thread's codes are requested before the statistics are reduced: the two round trips overlap
+        const int c_first = (blockIdx.x * 256 + threadIdx.x) * 16;
+        uint4 v0 = make_uint4(0, 0, 0, 0);
+        const uint8_t* xr = xc + (int64_t)row * ld_xc;
+        if (c_first < M) v0 = *reinterpret_cast<const uint4*>(xr + c_first);
+        if (b != b_have) {    // block-uniform
+            gnq_sample_stats(ws, nslots, b, (int64_t)C * M, eps, rx, red, mr);
+            b_have = b;
+            if (c == 0 && blockIdx.x == 0 && threadIdx.x == 0) {   // saved for the backward
+                mean_rstd[2 * b] = mr[0];
+                mean_rstd[2 * b + 1] = mr[1];
+            }
+        }
+        const float mean = mr[0], rstd = mr[1];
         const float scale = rstd * gamma[c];
         const float shift = fmaf(-scale, mean, beta[c]);
-        const uint8_t* xr = xc + (int64_t)row * ld_xc;
-        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 16; c0 < M; c0 += cstep) {
-            const uint4 v = *reinterpret_cast<const uint4*>(xr + c0);
+        for (int c0 = c_first; c0 < M; c0 += cstep) {
+            const uint4 v = (c0 == c_first) ? v0 : *reinterpret_cast<const uint4*>(xr + c0);
             const unsigned int w[4] = {v.x, v.y, v.z, v.w};
             unsigned int o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                float xv[4], cq[4];
+                dec4(w[q], rx, xv);
                 unsigned int pk = 0;
-                float fo[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float z = fmaf(dec((w[q] >> (8 * e)) & 255u, rx), scale, shift);
-                    float cq, u;
-                    bool inr;
-                    fo[e] = fq_asym(z, ry, cq, u, inr);
-                    pk |= ((unsigned int)cq & 255u) << (8 * e);
+                    cq[e] = fq_code(fmaf(xv[e], scale, shift), ry);
+                    pk = pack_code(cq[e], e, pk);
                 }
                 o[q] = pk;
-                if (yout != nullptr && c0 + 4 * q < M)
-                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + c0 + 4 * q) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+                if (yout != nullptr && c0 + 4 * q < M)   // (block-uniform pointer test: the fp32 copy costs nothing when not asked for)
+                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + c0 + 4 * q) =
+                        make_float4(ry.delta * cq[0] + ry.lo, ry.delta * cq[1] + ry.lo, ry.delta * cq[2] + ry.lo, ry.delta * cq[3] + ry.lo);
             }
             *reinterpret_cast<uint4*>(yc + (int64_t)row * ld_yc + c0) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -212,7 +233,12 @@ struct GnProducer {
     double* gacc; float* gbias;         // its partial slots / bias gradient [C]
 };
 
-// backward pass 3: gx = gz*(gamma*rstd) + x*c2 + c3 with gz recomputed from (x codes, g)
+// backward pass 3: gx = gz*(gamma*rstd) + x*c2 + c3 with gz recomputed from (x codes, g).
+// Grid (C, B): one workgroup per row, so the row constants need no integer division; a pass covers 4096 positions, 4 float4 groups
+// per thread with ALL their loads issued before the first is consumed.  (The first form -- 4 elements per thread and iteration,
+// row = f(blockIdx.y) with a division -- spent more than half of its VALU instructions on per-iteration overhead: these
+// kernels are VALU-issue bound, measured ~5 cycles per wave instruction and SIMD.)
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict__ xc, const float* __restrict__ g,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean_rstd, float* __restrict__ gx, int B,
@@ -221,73 +247,80 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
                                                         const float* qmin, const float* qmax, GnProducer P) {
     __shared__ double pred[3 * 4];
     __shared__ float predf[4];
-    const bool fuse = P.pz != nullptr;
-    const QRange rp = fuse ? load_qrange(P.qmin, P.qmax) : QRange{0.f, 1.f, 1.f};
-    const float pslope = (fuse && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
-    float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
+    const QRange rp = FUSE ? load_qrange(P.qmin, P.qmax) : QRange{0.f, 1.f, 1.f};
+    const float pslope = (FUSE && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
+    float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const double* coef = ws + 2 * (int64_t)B * C;
-    const int rows = B * C;
-    const int cstep = gridDim.x * 256 * 4;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
-        const int b = row / C, c = row - b * C;
-        const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
-        const float scale = rstd * gamma[c];
-        const float shift = fmaf(-scale, mean, beta[c]);
-        const float c2 = (float)coef[2 * b], c3 = (float)coef[2 * b + 1];
-        const uint8_t* xr = xc + (int64_t)row * ld_xc;
-        const float* gr = g + (int64_t)row * ld_g;
-        float* orow = gx + (int64_t)row * ld_gx;
-        float p_bias = 0.f;
-        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += cstep) {
-            const unsigned int w = *reinterpret_cast<const unsigned int*>(xr + c0);
-            const float4 gv4 = *reinterpret_cast<const float4*>(gr + c0);
-            float4 pz4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fuse) pz4 = *reinterpret_cast<const float4*>(P.pz + (int64_t)row * P.ld_pz + c0);
-            const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
-            const float pzv[4] = {pz4.x, pz4.y, pz4.z, pz4.w};
-            float o[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int64_t row = (int64_t)b * C + c;
+    const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
+    const float scale = rstd * gamma[c];
+    const float shift = fmaf(-scale, mean, beta[c]);
+    const float c2 = (float)coef[2 * b], c3 = (float)coef[2 * b + 1];
+    const uint8_t* xr = xc + row * ld_xc;
+    const float* gr = g + row * ld_g;
+    const float* pzr = FUSE ? P.pz + row * P.ld_pz : nullptr;
+    float* orow = gx + row * ld_gx;
+    for (int m0 = threadIdx.x * 4; m0 < M; m0 += 4096) {
+        unsigned int wq_[4];
+        float4 gq[4], pq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            if (m < M) {
+                wq_[i] = *reinterpret_cast<const unsigned int*>(xr + m);
+                gq[i] = *reinterpret_cast<const float4*>(gr + m);
+                if (FUSE) pq[i] = *reinterpret_cast<const float4*>(pzr + m);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            if (m >= M) break;
+            const float gv[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
+            const float pzv[4] = {FUSE ? pq[i].x : 0.f, FUSE ? pq[i].y : 0.f, FUSE ? pq[i].z : 0.f, FUSE ? pq[i].w : 0.f};
+            float xv[4], o[4];
+            dec4(wq_[i], rx, xv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x = dec((w >> (8 * e)) & 255u, rx);
+                const float x = xv[e];
                 const float z = fmaf(x, scale, shift);
                 float cq, u;
                 bool inr;
                 (void)fq_asym(z, ry, cq, u, inr);
                 const float gz = inr ? div_by(gv[e] * ry.delta, ry.delta, ry.inv) : 0.0f;
                 o[e] = fmaf(gz, scale, fmaf(x, c2, c3));
-                if (fuse) {   // the producer's epilogue backward (same arithmetic as k_actq_bwd) on gj = gx
-                    const bool valid = (c0 + e < M);
+                if (FUSE) {   // the producer's epilogue backward (same arithmetic as k_actq_bwd) on gj = gx
+                    const bool valid = (m + e < M);
                     const float gj = valid ? o[e] : 0.0f;
                     const float t = act_apply(pzv[e], P.act, pslope);
                     float pc, pu;
                     bool pin;
                     (void)fq_asym(t, rp, pc, pu, pin);
                     const float gt = pin ? div_by(gj * rp.delta, rp.delta, rp.inv) : 0.0f;
-                    if (valid) {
-                        p_du += gj * (pin ? (pc - pu) : pc);
-                        p_out += pin ? 0.0f : gj;
-                    }
-                    float gzj = act_bwd(pzv[e], gt, P.act, pslope, valid, p_slope);
+                    p_du += gj * (pin ? (pc - pu) : pc);     // gj is 0 outside the row
+                    p_out += pin ? 0.0f : gj;
+                    const float gzj = act_bwd(pzv[e], gt, P.act, pslope, valid, p_slope);
                     o[e] = gzj;
-                    if (valid) p_bias += gzj;
+                    p_bias += valid ? gzj : 0.0f;
                 }
             }
-            *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(orow + m) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (fuse && P.gbias != nullptr) {   // workgroup-uniform branch; ONE atomic per row chunk (per-wave atomics on
-            float pb[1] = {p_bias};         // the same 512 addresses cost 1.6 ms/step: same-address atomics serialise)
+    }
+    if (FUSE) {
+        if (P.gbias != nullptr) {   // ONE atomic per row (per-wave atomics on the same 512 addresses cost 1.6 ms/step)
+            float pb[1] = {p_bias};
             block_sum<float, 1>(pb, predf);
             if (threadIdx.x == 0) atomicAdd(&P.gbias[c], pb[0]);
         }
-    }
-    if (fuse) {
         double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
         block_sum<double, 3>(v, pred);
         if (threadIdx.x == 0) {
-            double* slot = P.gacc + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) % kSlots);
+            double* slot = P.gacc + 3 * (row % kSlots);
             const double dmax = v[0] / 255.0;
-            atomicAdd(&slot[0], v[1] - dmax);   // workgroups share slots modulo kSlots: order-insensitive in fp64
+            atomicAdd(&slot[0], v[1] - dmax);   // rows share slots modulo kSlots: order-insensitive in fp64
             atomicAdd(&slot[1], dmax);
             if (P.act == FQSS_ACT_PRELU) atomicAdd(&slot[2], v[2]);
         }
@@ -310,6 +343,20 @@ __device__ __forceinline__ unsigned int load_codes4(const uint8_t* __restrict__ 
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
+// Row-edge groups: the 4 codes xr[s0..s0+3] for ANY s0 as four byte loads at positions clamped into [0, M) -- unconditional, so
+// the compiler issues all of a thread's edge loads back to back (the conditional word loads of load_codes4 cost the first and the
+// last wave of every row one exposed round trip per tap and group: 12-24 in a row, which set the run time of the whole kernel);
+// the caller masks the positions outside [0, M).
+__device__ __forceinline__ unsigned int load_codes4_clamped(const uint8_t* __restrict__ xr, int s0, int M) {
+    unsigned int w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = min(max(s0 + j, 0), M - 1);
+        w |= (unsigned int)xr[p] << (8 * j);
+    }
+    return w;
+}
+
 // Interior groups (every tap of all 4 positions inside the row -- all but <= 2*pad positions per row): the 4 codes of
 // a tap are one unaligned dword load (gfx950 handles the misalignment in hardware) and need no zero-padding masks;
 // this path has ~1/3 of the instructions of the general one, and these kernels are VALU-issue bound.
@@ -317,12 +364,6 @@ __device__ __forceinline__ unsigned int load_codes4_unaligned(const uint8_t* __r
     unsigned int w;
     __builtin_memcpy(&w, p, 4);
     return w;
-}
-__device__ __forceinline__ void dec4(unsigned int w, const QRange& r, float (&v)[4]) {
-    v[0] = dec(w & 255u, r);          // v_cvt_f32_ubyte0..3 + mul + add (two roundings, like the reference)
-    v[1] = dec((w >> 8) & 255u, r);
-    v[2] = dec((w >> 16) & 255u, r);
-    v[3] = dec(w >> 24, r);
 }
 
 // z[m..m+3] from the coded row (zero padding)
@@ -340,14 +381,17 @@ __device__ __forceinline__ void dwq_z4(const uint8_t* __restrict__ xr, int m, in
             }
         }
     } else {
+        unsigned int wv[kTaps];
+#pragma unroll
+        for (int k = 0; k < kTaps; ++k)
+            if (k < K) wv[k] = load_codes4_clamped(xr, m + k * dil - pad, M);
 #pragma unroll
         for (int k = 0; k < kTaps; ++k) {
             if (k < K) {
                 const int s0 = m + k * dil - pad;
                 float v[4];
-                const unsigned int w = load_codes4(xr, s0, ld_c);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? dec((w >> (8 * j)) & 255u, rx) : 0.0f;
+                for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? dec((wv[k] >> (8 * j)) & 255u, rx) : 0.0f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
             }
@@ -357,42 +401,86 @@ __device__ __forceinline__ void dwq_z4(const uint8_t* __restrict__ xr, int m, in
     for (int j = 0; j < 4; ++j) z[j] = acc[j] + bv;
 }
 
+// 16 outputs per thread.  Interior threads (every tap of all 16 positions inside the row) fetch each tap's 16 codes with ONE
+// unaligned 16-B load, all taps requested before the first is decoded: one exposed HBM round trip per thread (the first form,
+// four sequential groups of per-tap dword loads, ran at 1.2 TB/s: latency-bound).  `stats` (optional): exact integer (sum c,
+// sum c^2) of the output codes, one slot per (row, column chunk): stats[((b*C + c)*gridDim.x + blockIdx.x)*2 + {0,1}] -- the
+// GroupNorm that consumes the codes then needs no statistics pass of its own.
+template <int KT>   // taps known at compile time (3 on the training path) or 0: runtime K <= kTaps
 __global__ __launch_bounds__(256) void k_dwq_fwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
                                                   const float* __restrict__ bias, uint8_t* __restrict__ yc,
                                                   float* __restrict__ yout, int rows, int C, int M, int K, int dil, int pad,
                                                   int ld_xc, int ld_yc, int ld_o, int act, const float* slope_p,
                                                   const float* qmin_x, const float* qmax_x, const float* qmin,
-                                                  const float* qmax) {
+                                                  const float* qmax, long long* stats) {
+    constexpr int NT = KT ? KT : kTaps;
+    if (KT) K = KT;
+    __shared__ unsigned int sred[2 * 4];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
         const int c = row % C;
-        float wk[kTaps];
+        float wk[NT];
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
+        for (int k = 0; k < NT; ++k) wk[k] = (k < K) ? w[c * K + k] : 0.0f;
         const float bv = bias ? bias[c] : 0.0f;
         const uint8_t* xr = xc + (int64_t)row * ld_xc;
         uint8_t* yr = yc + (int64_t)row * ld_yc;
+        unsigned int st_s = 0, st_ss = 0;
         for (int m0 = (blockIdx.x * 256 + threadIdx.x) * 16; m0 < M; m0 += gridDim.x * 256 * 16) {
+            const bool inner = (m0 - pad >= 0) && (m0 + 15 + pad < M);
+            uint4 cw[NT];
+            if (inner) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+                    if (k < K) __builtin_memcpy(&cw[k], xr + (m0 + k * dil - pad), 16);
+            }
             unsigned int o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + 4 * q;
                 float z[4], fo[4];
-                dwq_z4(xr, m, M, ld_xc, wk, K, dil, pad, bv, rx, z);
+                if (inner) {
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        if (k < K) {
+                            const unsigned int wq4[4] = {cw[k].x, cw[k].y, cw[k].z, cw[k].w};
+                            float v[4];
+                            dec4(wq4[q], rx, v);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = acc[j] + bv;
+                } else {
+                    dwq_z4(xr, m, M, ld_xc, wk, K, dil, pad, bv, rx, z);
+                }
                 unsigned int pk = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float cq, u;
-                    bool inr;
-                    fo[j] = fq_asym(act_apply(z[j], act, slope), ry, cq, u, inr);
-                    pk |= ((unsigned int)cq & 255u) << (8 * j);
+                    fo[j] = fq_code(act_apply(z[j], act, slope), ry);
+                    pk = pack_code(fo[j], j, pk);
                 }
                 o[q] = pk;
+                // statistics over the positions < M only (the last group of a row may hang over)
+                const unsigned int live = (m + 3 < M) ? 0xFFFFFFFFu : ((m < M) ? (0xFFFFFFFFu >> (8 * (4 - (M - m)))) : 0u);
+                code_stats4(pk & live, st_s, st_ss);
                 if (yout != nullptr && m < M)
-                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + m) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + m) =
+                        make_float4(ry.delta * fo[0] + ry.lo, ry.delta * fo[1] + ry.lo, ry.delta * fo[2] + ry.lo, ry.delta * fo[3] + ry.lo);
             }
             *reinterpret_cast<uint4*>(yr + m0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (stats != nullptr) {   // workgroup-uniform.  < 2^32: a workgroup's share of a row is at most 2^16 positions (host check)
+            unsigned int v[2] = {st_s, st_ss};
+            block_sum<unsigned int, 2>(v, sred);
+            if (threadIdx.x == 0) {
+                long long* slot = stats + 2 * ((int64_t)row * gridDim.x + blockIdx.x);
+                slot[0] = (long long)v[0];
+                slot[1] = (long long)v[1];
+            }
         }
     }
 }
@@ -518,6 +606,10 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
 #pragma unroll
                 for (int k = 0; k < NT; ++k)
                     if (k < K) cw[i][k] = load_codes4_unaligned(xr + (m + k * dil - pad));
+            } else if (m < M) {   // row edge: clamped byte loads, requested with the rest
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+                    if (k < K) cw[i][k] = load_codes4_clamped(xr, m + k * dil - pad, M);
             }
         }
 #pragma unroll
@@ -539,7 +631,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                 for (int k = 0; k < NT; ++k) {
                     if (k < K) {
                         const int s0 = m + k * dil - pad;
-                        const unsigned int cwk = load_codes4(xr, s0, (int)ld_xc);
+                        const unsigned int cwk = cw[i][k];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             v[k][j] = (s0 + j >= 0 && s0 + j < M) ? dec((cwk >> (8 * j)) & 255u, rx) : 0.0f;
@@ -698,14 +790,13 @@ __global__ __launch_bounds__(256) void k_ewq_fwd(const uint8_t* __restrict__ ac,
                     float z = dec((wa[q] >> (8 * e)) & 255u, ra);
                     if (bc != nullptr) z = z + sb * dec((wb[q] >> (8 * e)) & 255u, rb);
                     else if (bf != nullptr) z = z + sb * bv[e];
-                    float cq, u;
-                    bool inr;
-                    fo[e] = fq_asym(act_apply(z, act, slope), ry, cq, u, inr);
-                    pk |= ((unsigned int)cq & 255u) << (8 * e);
+                    fo[e] = fq_code(act_apply(z, act, slope), ry);
+                    pk = pack_code(fo[e], e, pk);
                 }
                 o[q] = pk;
                 if (yout != nullptr && c0 + 4 * q < cols)
-                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + c0 + 4 * q) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+                    *reinterpret_cast<float4*>(yout + (int64_t)row * ld_o + c0 + 4 * q) =
+                        make_float4(ry.delta * fo[0] + ry.lo, ry.delta * fo[1] + ry.lo, ry.delta * fo[2] + ry.lo, ry.delta * fo[3] + ry.lo);
             }
             *reinterpret_cast<uint4*>(yc + (int64_t)row * ld_y + c0) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -754,9 +845,9 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
     if (bc != nullptr) rb = load_qrange(bmin, bmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f;
-    // fused launches use gridDim.y == C: the rows of a workgroup (row = y, y + C, ...) are the batch entries of ONE
-    // channel, so the producers' bias sums are reduced once per workgroup instead of once per row
-    const bool per_channel = (int)gridDim.y == C;
+    // fused launches use gridDim.y % C == 0: the rows of a workgroup (row = y, y + gridDim.y, ...) are batch entries of ONE
+    // channel (y % C), so the producers' bias sums are reduced once per workgroup instead of once per row
+    const bool per_channel = ((int)gridDim.y % C) == 0;
     float a_bias = 0.f, b_bias = 0.f;
     struct EwIn {
         unsigned int wa, wb;
@@ -843,8 +934,8 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
         float pb[2] = {a_bias, b_bias};
         block_sum<float, 2>(pb, redf);
         if (threadIdx.x == 0) {
-            if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[blockIdx.y], pb[0]);
-            if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[blockIdx.y], pb[1]);
+            if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[blockIdx.y % C], pb[0]);
+            if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[blockIdx.y % C], pb[1]);
         }
     }
     double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
@@ -932,21 +1023,22 @@ extern "C" int fqss_decode(const uint8_t* codes, float* out, int64_t rows, int64
 extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma,
                             const float* beta, uint8_t* yc, float* yout, float* mean_rstd, int B, int C, int M,
                             int64_t ld_xc, int64_t ld_yc, int64_t ld_out, float eps, const float* qmin, const float* qmax,
-                            void* ws, fqss_stream_t stream) {
+                            void* ws, const int64_t* stats, int nslots, fqss_stream_t stream) {
     if (B == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
-    FQSS_REQUIRE(xc && qmin_x && qmax_x && gamma && beta && yc && mean_rstd && qmin && qmax && ws, "null pointer");
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && gamma && beta && yc && mean_rstd && qmin && qmax && (ws || stats), "null pointer");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_yc >= M, "bad shape");
     FQSS_REQUIRE(codes_ok(xc, ld_xc) && codes_ok(yc, ld_yc), "code rows must be 16-B aligned");
     FQSS_REQUIRE(!yout || (aligned16(yout) && ld_out % 4 == 0 && ld_out >= ((M + 3) & ~3)), "bad fp32 output rows");
-    if (B == 0) return FQSS_OK;
+    FQSS_REQUIRE(!stats || (nslots > 0 && nslots <= 1024), "supplied statistics: 1 .. 1024 partial-sum slots per sample");
     hipStream_t s = (hipStream_t)stream;
-    const int nslots = C < kGnSlots ? C : kGnSlots;
-    hipLaunchKernelGGL(k_gnq_stats, dim3((unsigned)nslots, (unsigned)B), dim3(256), 0, s, xc, C, M, ld_xc, (long long*)ws);
-    hipLaunchKernelGGL(k_gnq_finalize, dim3((unsigned)B), dim3(64), 0, s, (const long long*)ws, nslots, (int64_t)C * M, eps,
-                       mean_rstd, qmin_x, qmax_x);
+    if (stats == nullptr) {   // the statistics were not produced with the codes: one pass over them
+        nslots = C < kGnSlots ? C : kGnSlots;
+        hipLaunchKernelGGL(k_gnq_stats, dim3((unsigned)nslots, (unsigned)B), dim3(256), 0, s, xc, C, M, ld_xc, (long long*)ws);
+        stats = (const int64_t*)ws;
+    }
     const int64_t rows = (int64_t)B * C;
-    hipLaunchKernelGGL(k_gnq_apply, grid_rows(rows, M, 16), dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd, B, C, M,
-                       ld_xc, ld_yc, ld_out, qmin_x, qmax_x, qmin, qmax);
+    hipLaunchKernelGGL(k_gnq_apply, grid_rows(rows, M, 16), dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd,
+                       (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_yc, ld_out, qmin_x, qmax_x, qmin, qmax);
     return launch_status("fqss_gnq_fwd");
 }
 
@@ -966,9 +1058,12 @@ static int gnq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x,
                        ld_xc, ld_g, ws, qmin_x, qmax_x, qmin, qmax, gacc);
     hipLaunchKernelGGL(k_gnq_bwd_coef, dim3((unsigned)(B + cdiv(C, 256))), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
                        ggamma, gbeta);
-    const int64_t rows = (int64_t)B * C;
-    hipLaunchKernelGGL(k_gnq_bwd_apply, grid_rows(rows, M, 4), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C, M,
-                       ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P);
+    if (P.pz != nullptr)
+        hipLaunchKernelGGL(k_gnq_bwd_apply<true>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C,
+                           M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P);
+    else
+        hipLaunchKernelGGL(k_gnq_bwd_apply<false>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C,
+                           M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P);
     return launch_status(who);
 }
 
@@ -995,19 +1090,41 @@ extern "C" int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const floa
 extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
                             uint8_t* yc, float* yout, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
                             int64_t ld_yc, int64_t ld_out, int act, const float* slope, const float* qmin, const float* qmax,
-                            fqss_stream_t stream) {
+                            int64_t* stats, fqss_stream_t stream) {
     if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && w && yc && qmin && qmax, "null pointer");
     FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
     FQSS_REQUIRE(ld_xc >= M && ld_yc >= M && codes_ok(xc, ld_xc) && codes_ok(yc, ld_yc), "code rows must be 16-B aligned");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     FQSS_REQUIRE(!yout || (aligned16(yout) && ld_out % 4 == 0 && ld_out >= ((M + 3) & ~3)), "bad fp32 output rows");
-    if (B == 0 || M == 0) return FQSS_OK;
     const int64_t rows = (int64_t)B * C;
     FQSS_REQUIRE(rows < (1ll << 30) && ld_xc < (1ll << 30), "tensor too large for the 32-bit row kernels");
-    hipLaunchKernelGGL(k_dwq_fwd, grid_rows(rows, M, 16), dim3(256), 0, (hipStream_t)stream, xc, w, bias, yc, yout, (int)rows,
-                       C, M, K, dil, pad, (int)ld_xc, (int)ld_yc, (int)ld_out, act, slope, qmin_x, qmax_x, qmin, qmax);
+    dim3 grid = grid_rows(rows, M, 16);
+    if (stats != nullptr) {
+        // one slot per (row, column chunk): every row gets its own workgroups; the caller sized stats as [B][C * chunks][2]
+        FQSS_REQUIRE(fqss_dwq_stat_slots(C, M) > 0, "output statistics: too many slots per sample (C * ceil(M / 4096) <= 1024)");
+        grid = dim3((unsigned)cdiv(M, 4096), (unsigned)rows, 1);
+        FQSS_REQUIRE(rows <= 65535 * 16, "output statistics: too many rows");
+        if (rows > 65535) grid.y = 65535;   // (rows strided over y keep their own slots: indexed by row)
+    }
+    if (K == 3)
+        hipLaunchKernelGGL(k_dwq_fwd<3>, grid, dim3(256), 0, (hipStream_t)stream, xc, w, bias, yc, yout, (int)rows, C, M, K, dil,
+                           pad, (int)ld_xc, (int)ld_yc, (int)ld_out, act, slope, qmin_x, qmax_x, qmin, qmax, (long long*)stats);
+    else
+        hipLaunchKernelGGL(k_dwq_fwd<0>, grid, dim3(256), 0, (hipStream_t)stream, xc, w, bias, yc, yout, (int)rows, C, M, K, dil,
+                           pad, (int)ld_xc, (int)ld_yc, (int)ld_out, act, slope, qmin_x, qmax_x, qmin, qmax, (long long*)stats);
     return launch_status("fqss_dwq_fwd");
+}
+
+/* partial-sum slots per sample of the statistics fqss_dwq_fwd / fqss_qpw_fwdq can emit next to their output codes (0: that shape
+ * cannot, the GroupNorm computes them itself) */
+extern "C" int fqss_dwq_stat_slots(int C, int M) {
+    const int64_t n = (int64_t)C * cdiv(M, 4096);
+    return (C > 0 && M > 0 && n <= 1024) ? (int)n : 0;
+}
+extern "C" int fqss_qpw_stat_slots(int Co, int M) {
+    const int64_t n = cdiv(Co, 128) * cdiv(M, 64);
+    return (Co > 0 && M > 0 && n <= 1024) ? (int)n : 0;
 }
 
 extern "C" int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
@@ -1113,8 +1230,10 @@ static int ewq_bwd_impl(const char* who, const uint8_t* ac, const float* amin, c
     if (gx_ > 64) gx_ = 64;
     int64_t gy = kSlots / gx_;
     if (gy > rows) gy = rows;
-    if ((PA.pz || PB.pz) && C <= gy && C > 1) gy = C;   // one workgroup row per channel: bias sums reduced once per workgroup
-    else if ((PA.pz || PB.pz) && gy == C) gy = C - 1;    // never alias the per-channel mode by accident
+    // fused: C workgroup rows (each workgroup then serves one channel: bias sums reduced once per workgroup)
+    // (more workgroup rows -- 4 C instead of C -- measured SLOWER, 33 -> 43 us: the per-workgroup reductions and atomics dominate)
+    if ((PA.pz || PB.pz) && C <= gy && C > 1) gy = C;
+    else if ((PA.pz || PB.pz) && C > 1 && gy % C == 0) gy -= 1;    // never alias the per-channel mode by accident
     hipLaunchKernelGGL(k_ewq_bwd, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
                        (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
                        bmin, bmax, qmin, qmax, gacc, PA, PB, C > 0 ? C : 1);

@@ -112,6 +112,9 @@ struct QGemmArgs {
     unsigned char* Q1; unsigned char* Q2; int64_t ldq1, ldq2, sQ1b, sQ2b;
     const float *qy_min1, *qy_max1, *qy_min2, *qy_max2;
     int qact; const float* qslope;
+    // fwd + fused quantizer, optional: exact integer statistics (sum c, sum c^2) of the output codes Q1, one slot per workgroup:
+    // stats[(b * tiles_m * tiles_n + mt * tiles_n + nt) * 2 + {0,1}] -- what the GroupNorm that consumes Q1 needs (fused_q.hip)
+    long long* stats;
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     float* C2b = (g.C2 != nullptr) ? g.C2 + (int64_t)b * g.sC2b : nullptr;
     __shared__ uint32_t Qt[(MODE == 0) ? 4 : 1][32][8];   // per-wave 32 x 32 tile of output codes
     const bool quant = (MODE == 0) && g.Q1 != nullptr;
+    unsigned int st_s = 0, st_ss = 0;     // statistics of this lane's output codes (< 2^32 for a whole 128 x 64 tile)
     QRange ry1{}, ry2{};
     float qslope = 0.0f;
     if (quant) {
@@ -408,13 +412,13 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                         const float tv[4] = {t.x, t.y, t.z, t.w};
                         uint32_t pk = 0;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float cq, u;
-                            bool inr;
-                            (void)fq_asym(tv[e] > 0.0f ? tv[e] : qns * tv[e], ry, cq, u, inr);
-                            pk |= ((uint32_t)cq & 255u) << (8 * e);
-                        }
+                        for (int e = 0; e < 4; ++e) pk = pack_code(fq_code(tv[e] > 0.0f ? tv[e] : qns * tv[e], ry), e, pk);
                         Qt[wave][rl][lane & 7] = pk;
+                        if (g.stats != nullptr) {   // statistics over the live positions (row < M, column < N) only
+                            const int nl = g.N - col;
+                            const uint32_t live = (row < g.M && nl > 0) ? (nl >= 4 ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - nl)))) : 0u;
+                            code_stats4(pk & live, st_s, st_ss);
+                        }
                     }
                 }
             }
@@ -438,6 +442,20 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         } else {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) tile_epilogue(mi, std::true_type{});
+        }
+        if constexpr (MODE == 0) {
+            if (quant && g.stats != nullptr) {   // workgroup-uniform: one (sum c, sum c^2) slot per workgroup, plain stores
+                __shared__ unsigned int sst[2][4];
+                st_s = wave_sum(st_s);
+                st_ss = wave_sum(st_ss);
+                if (lane == 0) { sst[0][wave] = st_s; sst[1][wave] = st_ss; }
+                __syncthreads();
+                if (tid == 0) {
+                    long long* slot = g.stats + 2 * (((int64_t)b * g.tiles_m + mt) * g.tiles_n + (panel % g.tiles_n));
+                    slot[0] = (long long)sst[0][0] + sst[0][1] + sst[0][2] + sst[0][3];
+                    slot[1] = (long long)sst[1][0] + sst[1][1] + sst[1][2] + sst[1][3];
+                }
+            }
         }
     }
 }
@@ -627,6 +645,7 @@ extern "C" int fqss_wq_codes(const float* w, int8_t* idx, int8_t* idxT, float* d
 
 struct QpwQuant {   // optional fused output quantizer of fqss_qpw_fwdq
     int act; const float* slope; const float *min1, *max1, *min2, *max2; uint8_t *yc1, *yc2; int64_t ld1, ld2;
+    long long* stats;   // optional: integer statistics of yc1 per workgroup (single-output launches only)
 };
 
 static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
@@ -657,6 +676,8 @@ static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, co
         g.sQ1b = (int64_t)Co1 * qq->ld1; g.sQ2b = (int64_t)Co2 * qq->ld2;
         g.qy_min1 = qq->min1; g.qy_max1 = qq->max1; g.qy_min2 = qq->min2; g.qy_max2 = qq->max2;
         g.qact = qq->act; g.qslope = qq->slope;
+        FQSS_REQUIRE(!qq->stats || Co2 == 0, "output statistics: single-output launches only");
+        g.stats = qq->stats;
     }
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
     hipLaunchKernelGGL((k_qgemm<0>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
@@ -680,8 +701,8 @@ extern "C" int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* d
                              const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int act,
                              const float* slope, const float* qmin1, const float* qmax1, const float* qmin2, const float* qmax2,
                              uint8_t* yc1, uint8_t* yc2, int B, int Ci, int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1,
-                             int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2, fqss_stream_t stream) {
-    QpwQuant qq{act, slope, qmin1, qmax1, qmin2, qmax2, yc1, yc2, ld_yc1, ld_yc2};
+                             int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2, int64_t* stats1, fqss_stream_t stream) {
+    QpwQuant qq{act, slope, qmin1, qmax1, qmin2, qmax2, yc1, yc2, ld_yc1, ld_yc2, (long long*)stats1};
     return qpw_fwd_impl("fqss_qpw_fwdq", xc, wi, dw, rw, bias1, bias2, qmin_x, qmax_x, z1, z2, B, Ci, Co1, Co2, M, ld_xc, ld_z1, ld_z2,
                         stream, &qq);
 }

@@ -288,8 +288,9 @@ def qpw_fwd2(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1):
     return z1, z2
 
 
-def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None):
-    """q-GEMM forward with the output quantizer(s) fused: -> (z1, yc1) or (z1, z2, yc1, yc2) for a pair (r = (qmin, qmax))"""
+def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None, stats=None):
+    """q-GEMM forward with the output quantizer(s) fused: -> (z1, yc1) or (z1, z2, yc1, yc2) for a pair (r = (qmin, qmax));
+    stats (single output only): a CodeStats from new_stats("qpw", ...) that receives the integer statistics of yc1"""
     B, Ci, M = xc.shape
     rm = rowmat(xc)
     Co2 = wc.Co - Co1
@@ -301,7 +302,7 @@ def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None)
     _lib.call("fqss_qpw_fwdq", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias1), _p(bias2), _p(qmin_x), _p(qmax_x), _p(z1), _p(z2),
               act, _p(slope), _p(r1[0]), _p(r1[1]), _p(r2[0]) if r2 else None, _p(r2[1]) if r2 else None, _p(yc1), _p(yc2),
               B, Ci, Co1, Co2, M, rm[2], rowmat(z1)[2], rowmat(z2)[2] if Co2 else 0, rowmat(yc1)[2], rowmat(yc2)[2] if Co2 else 0,
-              _stream())
+              _p(stats.ws) if stats is not None else None, _stream())
     return (z1, z2, yc1, yc2) if Co2 else (z1, yc1)
 
 
@@ -343,14 +344,41 @@ def decode(xc, qmin, qmax):
     return out
 
 
-def gnq_fwd(xc, qmin_x, qmax_x, gamma, beta, eps, qmin, qmax, write_out):
+class CodeStats:
+    """exact integer statistics (sum c, sum c^2) of a coded activation as [B][nslots][2] int64 partial sums, emitted by the
+    epilogue of the kernel that produced the codes (fqss_qpw_fwdq, fqss_dwq_fwd) for a consuming GroupNormQ"""
+    __slots__ = ("ws", "nslots")
+
+    def __init__(self, ws, nslots):
+        self.ws, self.nslots = ws, nslots
+
+
+_STAT_SLOTS = {}
+
+
+def stat_slots(kind, C, M):
+    key = (kind, C, M)
+    v = _STAT_SLOTS.get(key)
+    if v is None:
+        v = _STAT_SLOTS[key] = _lib.query("fqss_qpw_stat_slots" if kind == "qpw" else "fqss_dwq_stat_slots", C, M)
+    return v
+
+
+def new_stats(kind, B, C, M, device):
+    """CodeStats buffer for the codes [B, C, M] a q-GEMM ("qpw") / depthwise layer ("dwq") is about to produce, or None"""
+    n = stat_slots(kind, C, M)
+    return CodeStats(torch.empty(B * n * 2, device=device, dtype=torch.int64), n) if n else None
+
+
+def gnq_fwd(xc, qmin_x, qmax_x, gamma, beta, eps, qmin, qmax, write_out, stats=None):
     B, C, M, ld_xc = _codes3(xc)
     yc = empty_codes((B, C, M), xc.device)
     out = empty_act((B, C, M), xc.device)      # carrier; written only when write_out
     mean_rstd = torch.empty(B, 2, device=xc.device, dtype=torch.float32)
-    ws = torch.empty(2 * 64 * B, device=xc.device, dtype=torch.int64)
+    ws = torch.empty(2 * 64 * B, device=xc.device, dtype=torch.int64) if stats is None else None
     _lib.call("fqss_gnq_fwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(gamma), _p(beta), _p(yc), _p(out) if write_out else None,
-              _p(mean_rstd), B, C, M, ld_xc, rowmat(yc)[2], rowmat(out)[2], float(eps), _p(qmin), _p(qmax), _p(ws), _stream())
+              _p(mean_rstd), B, C, M, ld_xc, rowmat(yc)[2], rowmat(out)[2], float(eps), _p(qmin), _p(qmax), _p(ws),
+              _p(stats.ws) if stats is not None else None, stats.nslots if stats is not None else 0, _stream())
     return out, yc, mean_rstd
 
 
@@ -383,12 +411,14 @@ def gnq_bwd(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, gacc, gga
     return gx
 
 
-def dwq_fwd(xc, qmin_x, qmax_x, w, bias, dil, pad, act, slope, qmin, qmax, write_out):
+def dwq_fwd(xc, qmin_x, qmax_x, w, bias, dil, pad, act, slope, qmin, qmax, write_out, stats=None):
+    """stats: a CodeStats from new_stats("dwq", ...) that receives the integer statistics of the output codes"""
     B, C, M, ld_xc = _codes3(xc)
     yc = empty_codes((B, C, M), xc.device)
     out = empty_act((B, C, M), xc.device)
     _lib.call("fqss_dwq_fwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(w), _p(bias), _p(yc), _p(out) if write_out else None,
-              B, C, M, w.shape[-1], dil, pad, ld_xc, rowmat(yc)[2], rowmat(out)[2], act, _p(slope), _p(qmin), _p(qmax), _stream())
+              B, C, M, w.shape[-1], dil, pad, ld_xc, rowmat(yc)[2], rowmat(out)[2], act, _p(slope), _p(qmin), _p(qmax),
+              _p(stats.ws) if stats is not None else None, _stream())
     return out, yc
 
 

@@ -21,7 +21,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
@@ -30,6 +30,7 @@ class QCtx:
         self.keep_out = False   # force a real fp32 output even in the fast path (model outputs)
         self.prod = None        # _Producer: lets the NEXT layer's backward run this layer's epilogue backward (see below)
         self.no_codes = False   # the caller has no coded consumer (dual-path row layers): do not emit the u8 codes at all
+        self.stats = None       # kernels.CodeStats of the output codes, emitted by the producing kernel for a GroupNormQ consumer
 
 
 class ActCodes:
@@ -45,13 +46,15 @@ def tag_codes(y, q):
     """attach the codes produced by the epilogue of this call to its output tensor"""
     if q.idx is not None and not CODED:
         assert not q.carrier, "codes-only carriers need the coded dataflow"
-        q.idx = q.prod = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
+        q.idx = q.prod = q.stats = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
     if q.idx is not None:
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
         y._fqss_carrier = q.carrier
         q.idx = None
         if q.prod is not None:
             y._fqss_prod, q.prod = q.prod, None
+        if q.stats is not None:
+            y._fqss_stats, q.stats = q.stats, None
     return y
 
 
@@ -68,6 +71,7 @@ class _Producer:
 
 FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
+FUSE_STATS = os.environ.get("FQSS_FUSE_STATS", "1") != "0"   # gLN statistics from the epilogue of the kernel that makes its input codes
 NEXT_IS_GROUPNORM = False   # set by HipSequential around the forward of a module followed by a GroupNormQ
 
 
@@ -359,7 +363,10 @@ class LinearActQ(Function):
         if ctx.xq is not None and ctx.wc is not None and _fuse_out_quant(q):
             # the layer's own non-linearity + fake-quant ride in the GEMM epilogue: z (for the backward) and the
             # output codes come out of one launch
-            z, q.idx = K.qpw_fwdq(ctx.xq.idx, ctx.wc, bias, None, ctx.xq.qmin, ctx.xq.qmax, ctx.wc.Co, act, slope, (q.qmin, q.qmax))
+            # ... and, for a GroupNormQ consumer, the integer statistics of those codes (no statistics pass in the gLN)
+            q.stats = K.new_stats("qpw", x.shape[0], ctx.wc.Co, x.shape[-1], x.device) if (FUSE_STATS and NEXT_IS_GROUPNORM) else None
+            z, q.idx = K.qpw_fwdq(ctx.xq.idx, ctx.wc, bias, None, ctx.xq.qmin, ctx.xq.qmax, ctx.wc.Co, act, slope, (q.qmin, q.qmax),
+                                  stats=q.stats)
             q.carrier = True
             out = _carrier(K.empty_act(tuple(z.shape), z.device))
         else:
@@ -479,7 +486,8 @@ class GroupNormActQ(Function):
         ctx.prod = getattr(x, "_fqss_prod", None) if ctx.coded else None
         if ctx.coded:
             q.carrier = FAST and not q.keep_out
-            out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier)
+            out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier,
+                                              stats=getattr(x, "_fqss_stats", None))
             ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
             return _carrier(out) if q.carrier else out
         z, mean_rstd = K.gn_fwd(x, gamma, beta, eps)
@@ -516,7 +524,9 @@ class DwConvQ(Function):
     @staticmethod
     def forward(ctx, x, w, bias, slope, qmin, qmax, L, act, q, xq):
         q.carrier = FAST and not q.keep_out
-        out, q.idx = K.dwq_fwd(xq.idx, xq.qmin, xq.qmax, w, bias, L.dil, L.pad, act, slope, qmin, qmax, write_out=not q.carrier)
+        q.stats = K.new_stats("dwq", x.shape[0], x.shape[1], x.shape[2], x.device) if (FUSE_STATS and NEXT_IS_GROUPNORM) else None
+        out, q.idx = K.dwq_fwd(xq.idx, xq.qmin, xq.qmax, w, bias, L.dil, L.pad, act, slope, qmin, qmax, write_out=not q.carrier,
+                               stats=q.stats)
         ctx.save_for_backward(w, bias, slope, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
         ctx.L, ctx.act, ctx.q = L, act, q
         return _carrier(out) if q.carrier else out

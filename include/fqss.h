@@ -179,7 +179,12 @@ int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* dw, const fl
                   const float* slope, const float* qmin1, const float* qmax1, const float* qmin2,
                   const float* qmax2, uint8_t* yc1, uint8_t* yc2, int B, int Ci, int Co1, int Co2, int M,
                   int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2,
-                  fqss_stream_t stream);
+                  int64_t* stats1, fqss_stream_t stream);
+/* stats1 (nullable, Co2 = 0 only): exact integer statistics (sum c, sum c^2) of the output codes yc1, one slot per workgroup,
+ * [B][fqss_qpw_stat_slots(Co1, M)][2] int64 -- handed to fqss_gnq_fwd when the consumer is a GroupNormQ ("stats can
+ * be produced by the previous kernel's epilogue").  fqss_*_stat_slots return 0 when that shape cannot emit them. */
+int fqss_qpw_stat_slots(int Co, int M);
+int fqss_dwq_stat_slots(int C, int M);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  depthwise dilated Conv1d (groups = C): z[b][c][m] = bias[c] + sum_k w[c][k] x[b][c][m+k*dil-pad]
@@ -217,7 +222,9 @@ int fqss_decode(const uint8_t* codes, float* out, int64_t rows, int64_t cols, in
 int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma,
                  const float* beta, uint8_t* yc, float* yout, float* mean_rstd, int B, int C, int M,
                  int64_t ld_xc, int64_t ld_yc, int64_t ld_out, float eps, const float* qmin,
-                 const float* qmax, void* ws, fqss_stream_t stream);
+                 const float* qmax, void* ws, const int64_t* stats, int nslots, fqss_stream_t stream);
+/* stats / nslots: the integer statistics of xc as [B][nslots][2] partial sums when its producer emitted them (fqss_qpw_fwdq,
+ * fqss_dwq_fwd); NULL: one statistics pass over xc into ws.  mean / rstd are finished inside the apply pass either way. */
 int fqss_gnq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
                  const float* gamma, const float* beta, const float* mean_rstd, float* gx,
                  float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g,
@@ -235,7 +242,8 @@ int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const float* qmax_x, 
 int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
                  const float* bias, uint8_t* yc, float* yout, int B, int C, int M, int K, int dil,
                  int pad, int64_t ld_xc, int64_t ld_yc, int64_t ld_out, int act, const float* slope,
-                 const float* qmin, const float* qmax, fqss_stream_t stream);
+                 const float* qmin, const float* qmax, int64_t* stats, fqss_stream_t stream);
+/* stats (nullable): integer statistics of yc, [B][fqss_dwq_stat_slots(C, M)][2] int64 (see fqss_qpw_fwdq) */
 /* gz = dL/d(conv output) recomputed from the input codes; gacc slots += range/slope partials; gbias[C] += */
 int fqss_dwq_bwd_z(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
                    const float* bias, const float* g, float* gz, int B, int C, int M, int K, int dil,

@@ -519,6 +519,54 @@ def test_ewq_coded(B, C, M, mode):
         np.testing.assert_allclose(gacc2.view(-1, 3).sum(0).cpu().numpy(), ga, rtol=1e-6, atol=1e-6 * sc)
 
 
+@pytest.mark.parametrize("B,C,M", [(2, 32, 77), (2, 512, 999), (3, 128, 4100), (1, 24, 130)])
+def test_code_statistics_from_the_producing_kernels(B, C, M):
+    """SURVEY K7 ("stats can be produced by the previous kernel's epilogue"): the q-GEMM / depthwise forward emit the exact integer
+    (sum c, sum c^2) of their output codes as per-workgroup slots; fqss_gnq_fwd fed with them returns bit for bit what it
+    returns after its own statistics pass (qat_layers.py:445-448 on the codes of qat_quant.py:136-147)."""
+    cu = lambda t: t.cuda().contiguous()
+    gm, bt = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    ylo, yhi = torch.tensor([-2.1]), torch.tensor([2.4])
+    # ---- depthwise producer
+    codes, x, xc, xlo, xhi = _coded_input(B, C, M, seed=C + 1)
+    w, bias, slope = rnd(C, 1, 3, seed=2, scale=0.5), rnd(C, seed=3, scale=0.1), torch.tensor([0.25])
+    dlo, dhi = torch.tensor([-1.3]), torch.tensor([2.2])
+    st = K.new_stats("dwq", B, C, M, "cuda")
+    assert st is not None and st.nslots == C * ((M + 4095) // 4096)
+    _, yc = K.dwq_fwd(xc, cu(xlo), cu(xhi), cu(w), cu(bias), 2, 2, K.ACT_PRELU, cu(slope), cu(dlo), cu(dhi), False, stats=st)
+    _, yc0 = K.dwq_fwd(xc, cu(xlo), cu(xhi), cu(w), cu(bias), 2, 2, K.ACT_PRELU, cu(slope), cu(dlo), cu(dhi), False)
+    assert torch.equal(yc.cpu(), yc0.cpu())
+    cc = yc.cpu().long()
+    sums = st.ws.view(B, st.nslots, 2).sum(1).cpu()
+    assert torch.equal(sums[:, 0], cc.sum((1, 2))) and torch.equal(sums[:, 1], (cc * cc).sum((1, 2)))
+    a = K.gnq_fwd(yc, cu(dlo), cu(dhi), cu(gm), cu(bt), 1e-8, cu(ylo), cu(yhi), True, stats=st)
+    b_ = K.gnq_fwd(yc, cu(dlo), cu(dhi), cu(gm), cu(bt), 1e-8, cu(ylo), cu(yhi), True)
+    for u, v in zip(a, b_):
+        assert torch.equal(u.cpu()[..., :M] if u.dim() == 3 else u.cpu(), v.cpu()[..., :M] if v.dim() == 3 else v.cpu())
+    # ---- q-GEMM producer (C input channels -> 2C outputs, PReLU + fake-quant fused)
+    if C % 16 == 0:
+        Co = 2 * C
+        wq, wlo, whi, xlo2, xhi2, x2, b2, _, _ = _q_setup(B, C, Co, M, seed=C + 5)
+        wc = K.wq_codes(cu(wq), cu(wlo), cu(whi))
+        _, xc2 = K.actq_fwd(padded(x2), K.ACT_NONE, None, K.Q_QUANT, cu(xlo2), cu(xhi2), None, want_idx=True)
+        st = K.new_stats("qpw", B, Co, M, "cuda")
+        assert st is not None and st.nslots == ((Co + 127) // 128) * ((M + 63) // 64)
+        sl = torch.tensor([0.2], device="cuda")
+        r1 = (torch.tensor([-1.1], device="cuda"), torch.tensor([1.7], device="cuda"))
+        z, yc = K.qpw_fwdq(xc2, wc, cu(b2), None, cu(xlo2), cu(xhi2), Co, K.ACT_PRELU, sl, r1, stats=st)
+        z0, yc0 = K.qpw_fwdq(xc2, wc, cu(b2), None, cu(xlo2), cu(xhi2), Co, K.ACT_PRELU, sl, r1)
+        assert torch.equal(yc.cpu()[..., :M], yc0.cpu()[..., :M]) and torch.equal(z.cpu(), z0.cpu())
+        cc = yc.cpu()[..., :M].long()
+        sums = st.ws.view(B, st.nslots, 2).sum(1).cpu()
+        assert torch.equal(sums[:, 0], cc.sum((1, 2))) and torch.equal(sums[:, 1], (cc * cc).sum((1, 2)))
+        gm2, bt2 = 1 + 0.1 * rnd(Co, seed=4), 0.1 * rnd(Co, seed=5)
+        a = K.gnq_fwd(yc, r1[0], r1[1], cu(gm2), cu(bt2), 1e-8, cu(ylo), cu(yhi), True, stats=st)
+        b_ = K.gnq_fwd(yc, r1[0], r1[1], cu(gm2), cu(bt2), 1e-8, cu(ylo), cu(yhi), True)
+        for u, v in zip(a, b_):
+            assert torch.equal(u.cpu()[..., :M] if u.dim() == 3 else u.cpu(), v.cpu()[..., :M] if v.dim() == 3 else v.cpu())
+    assert K.new_stats("dwq", 1, 2048, 4000, "cuda") is None          # too many slots: the gLN computes its own statistics
+
+
 def test_empty_batches_are_noops_and_bad_arguments_are_refused():
     from fqss_amd import _lib
     dev = "cuda"

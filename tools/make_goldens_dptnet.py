@@ -221,7 +221,7 @@ def gen_tiny_step(out, n_steps=53):
 
 
 def gen_cfg3_step(out, n_steps=52, B=1, T=8000, fname="cfg3_step.npz"):
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("FQSS_GOLDEN_THREADS", "8")))
     d = {}
     torch.manual_seed(0)
     model = RD.DPTNetQ(n_spks=2, kernel_size=2)
@@ -265,13 +265,14 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     ap.add_argument("--only", default="")
     ap.add_argument("--T", type=int, default=8000)
+    ap.add_argument("--fname", default="cfg3_step.npz", help="cfg3 digest file (cfg3_full_step.npz for the BASELINE size: --T 24000)")
     a = ap.parse_args()
     if a.only in ("", "layers"):
         gen_layers(a.out)
     if a.only in ("", "tiny"):
         gen_tiny_step(a.out)
     if a.only in ("", "cfg3"):
-        gen_cfg3_step(a.out, T=a.T)
+        gen_cfg3_step(a.out, T=a.T, fname=a.fname)
 
 
 if __name__ == "__main__":
