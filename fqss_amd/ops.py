@@ -202,6 +202,48 @@ def reshape_tagged(x, *shape):
     return y
 
 
+# ---- backward segments ------------------------------------------------------------------------------
+# At world > 1 runtime.KDTrainStep splits the backward at the model's cut points into separately launched segments, so that the
+# gradient all-reduce of a finished segment (RCCL, side stream) overlaps the backward of the next one (the reference: DDP's
+# bucketed all-reduce overlapped with backward, asteroid_librimix_trainer.py:125-135).  cut() is the identity otherwise.
+CUTS = None
+
+
+class cut_recorder:
+    def __enter__(self):
+        global CUTS
+        self.prev, CUTS = CUTS, []
+        return CUTS
+
+    def __exit__(self, *a):
+        global CUTS
+        CUTS = self.prev
+
+
+_TAGS = ("_fqss_q", "_fqss_carrier", "_fqss_prod", "_fqss_stats", "_fqss_rowq")
+
+
+def cut(*tensors, late=False):
+    """a point where the backward may be split: returns fresh autograd leaves (same storage, same code tags); the recorder keeps
+    (original tensors, leaves, late) so the stepper can push the leaves' gradients into the original graph later.  late=True: a
+    side edge that skips over all segments (ConvTasNet: the encoder output feeding the mask multiply at the end of the network);
+    its gradient is pushed with the LAST backward segment, together with that segment's own roots"""
+    if CUTS is None or not torch.is_grad_enabled():
+        return tensors
+    leaves = []
+    for t in tensors:
+        if t is None or not t.requires_grad:
+            leaves.append(t)
+            continue
+        leaf = t.detach().requires_grad_(True)
+        for a in _TAGS:
+            if hasattr(t, a):
+                setattr(leaf, a, getattr(t, a))
+        leaves.append(leaf)
+    CUTS.append((tensors, tuple(leaves), late))
+    return tuple(leaves)
+
+
 def weight_view(w, *shape):
     """w.view(shape) of a (possibly fake-quantized) weight that keeps the dL/dW_q arena slot of a weight fake-quantized by
     runtime.QuantTables: such a tensor has no autograd history, its consumers accumulate its gradient into `_fqss_gwq`"""

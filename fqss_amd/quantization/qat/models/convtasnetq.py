@@ -78,11 +78,16 @@ class MaskGenerator(nn.Module):
             raise ValueError(f"Unsupported activation {msk_activate}")
         self.mask_net = HipSequential(nn.PReLU(), nn.Conv1d(num_feats, input_dim * n_srcs, 1), act)
 
+    fqss_cut_every = 0     # > 0: a backward cut point (ops.cut) after every that many TCN blocks, set by fqss_segments()
+
     def forward(self, x):
         batch = x.shape[0]
         feats = self.bottleneck(x)
         feats, output = self.TCN[0](feats)
+        ce = self.fqss_cut_every
         for i, layer in enumerate(self.TCN[1:]):
+            if ce and (i + 1) % ce == 0:
+                feats, output = ops.cut(feats, output)       # blocks 0 .. i are one backward segment
             feats, skip = layer(feats)
             output = self.adds[i](output, skip)
         output = self.mask_net(output)
@@ -114,11 +119,33 @@ class ConvTasNetQ(nn.Module):
         batch = x.shape[0]
         feats = apply_module(self.encoder, x)                                  # [B, F, M]
         f_mask, f_mul = ops.fork2(feats)
+        if self.masker.fqss_cut_every:
+            (f_mul,) = ops.cut(f_mul, late=True)       # this edge jumps over every backward segment of the TCN stack
         masked = self.mul(self.masker(f_mask), ops.reshape_tagged(f_mul, batch, 1, self.enc_num_feats, -1))  # [B, S, F, M]
         masked = ops.reshape_tagged(masked, batch * self.n_srcs, self.enc_num_feats, -1)
         out = apply_module(self.decoder, masked)                               # [D, B*S, 1, L] or [B*S, 1, L]
         out = out.reshape((self.n_combiner, batch, self.n_srcs, 1, -1))
         return self.post_process(out)
+
+    def fqss_segments(self, n):
+        """Split the network into <= n backward segments (forward order) and arm the cut points between them: returns the module
+        lists whose parameters become final when the corresponding segment's backward has run.  runtime.KDTrainStep lays the
+        gradient arena out in this order and all-reduces a segment's slice while the next segment's backward runs."""
+        tcn, adds = self.masker.TCN, self.masker.adds
+        nb = len(tcn)
+        n = max(1, min(int(n), nb))
+        every = -(-nb // n)
+        self.masker.fqss_cut_every = every if n > 1 else 0
+        segs = []
+        for s0 in range(0, nb, every):
+            s1 = min(nb, s0 + every)
+            mods = [tcn[i] for i in range(s0, s1)] + [adds[i - 1] for i in range(max(s0, 1), s1)]
+            if s0 == 0:
+                mods = [self.encoder, self.masker.bottleneck] + mods
+            if s1 == nb:
+                mods = mods + [self.masker.mask_net, self.mul, self.decoder]
+            segs.append(mods)
+        return segs
 
     def load_pretrain(self, weights_path):
         """order-based key mapping of a checkpoint with the same number of entries (reference :225-237)"""

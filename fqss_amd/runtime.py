@@ -156,7 +156,9 @@ class QuantTables:
     fake-quant forward (+ int8 codes), its backward, and the range/slope gradient flush (csrc/multi.hip).
     Built once the observer phase is over and the parameters live in a ParamArena (stable addresses)."""
 
-    def __init__(self, model, arena):
+    def __init__(self, model, arena, segments=None):
+        """segments: list of parameter-id sets (forward order) -> finish_backward(k) only handles the quantizers whose parameters lie
+        in segment k (the gradient all-reduce of a segment needs its weight / range / slope gradients final)"""
         import torch.nn as nn
         from .quantization.qat.qat_layers import LayerQ
         from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
@@ -288,15 +290,43 @@ class QuantTables:
         assert pending is None
         self.wq_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.total_channels = blk
+        # ---- per-segment views of the two finish tables (descriptor 15 = first block is renumbered per table) -----------------
+        self.seg_tables = None
+        if segments is not None and len(segments) > 1:
+            self.seg_tables = []
+            flush_rows = self.flush_table.tolist()
+            for ids in segments:
+                wrows, b0, members = [], 0, []
+                for r, (wqm, w, _, _) in zip(rows, self.weights):
+                    if id(w) in ids:
+                        r = list(r)
+                        r[15] = b0
+                        b0 += r[13]
+                        wrows.append(r)
+                        members.append((wqm, w))
+                frows = [r for r, m in zip(flush_rows, aqs) if id(m.min_range) in ids]
+                self.seg_tables.append((torch.tensor(wrows, dtype=torch.int64, device=dev).reshape(-1, len(rows[0])), b0,
+                                        torch.tensor(frows, dtype=torch.int64, device=dev).reshape(-1, 4), members))
+            assert sum(t[0].shape[0] for t in self.seg_tables) == len(rows), "a weight quantizer belongs to no backward segment"
+            assert sum(t[2].shape[0] for t in self.seg_tables) == len(flush_rows), "an activation quantizer belongs to no backward segment"
 
     def weights_forward(self):
         K.wq_multi_fwd(self.wq_table, self.total_channels)
 
-    def finish_backward(self):
-        """after autograd: weight STE/range gradients from the dL/dW_q arena, then every range/slope flush"""
-        K.wq_multi_bwd(self.wq_table, self.total_channels)
-        K.gacc_flush_multi(self.flush_table)
-        for wqm, w, _, _ in self.weights:
+    def finish_backward(self, seg=None):
+        """after autograd (of backward segment `seg`, or of the whole network): weight STE/range gradients from the dL/dW_q arena,
+        then the range/slope flushes"""
+        if seg is None or self.seg_tables is None:
+            K.wq_multi_bwd(self.wq_table, self.total_channels)
+            K.gacc_flush_multi(self.flush_table)
+            members = [(wqm, w) for wqm, w, _, _ in self.weights]
+        else:
+            wt, nch, ft, members = self.seg_tables[seg]
+            if wt.shape[0]:
+                K.wq_multi_bwd(wt, nch)
+            if ft.shape[0]:
+                K.gacc_flush_multi(ft)
+        for wqm, w in members:
             w._fqss_touched = wqm.min_range._fqss_touched = wqm.max_range._fqss_touched = True
 
 
@@ -310,19 +340,54 @@ class KDTrainStep:
     RCCL all-reduce of the flat gradient buffer runs between the two graphs."""
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None, loss="sisdr_pit", source_weights=None,
-                 batched_quantizers=True, fast=True, coded=True):
+                 batched_quantizers=True, fast=True, coded=True, buckets=None, sync_observer_ranges=True):
         """loss: "sisdr_pit" = the asteroid / speechbrain KD loss (mysystem.py:124-151); "l1_sdr" = the htdemucs solver's
         (solver.py:333-366: L1 task + SDR-weighted L1 distillation, per-source weights).  clip <= 0: no clipping (htdemucs.yaml:84).
         batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow);
         fast=False: quantizing layers also write their fp32 outputs (no carriers); coded=False: no layer output carries codes,
-        every layer runs its un-fused fp32 kernels (the reference dataflow the tests pin the fused step against)"""
+        every layer runs its un-fused fp32 kernels (the reference dataflow the tests pin the fused step against).
+        buckets (world > 1, models with `fqss_segments`): the backward runs as that many separately launched segments and the
+        gradient all-reduce of a finished segment overlaps the next segment's backward (default 4; 1 = one all-reduce after the
+        whole backward).  sync_observer_ranges (world > 1): average the activation ranges over the ranks once, when the 50-call
+        observer phase ends -- a documented deviation: the reference's DDP never re-synchronises the
+        observer's .data writes (qat_quant.py:230-232), so its replicas quantize on different grids from then on."""
         self.model, self.fmodel = model, fmodel
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
         self.fast, self.coded = bool(fast and coded), bool(coded)
         self._graphs = None
         self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
         self.comm = comm
-        self.arena = ParamArena(list(model.parameters()))
+        # ---- backward segments = gradient buckets (world > 1 only: a single rank has nothing to overlap) -------------------
+        self.segments = None        # [(arena lo, arena hi)] per segment in FORWARD order
+        self._seg_ids = None
+        self._ranges_synced = not (sync_observer_ranges and self._world() > 1)
+        params = list(model.parameters())
+        nb = (4 if buckets is None else int(buckets)) if self._world() > 1 else (int(buckets) if buckets else 1)
+        if nb > 1 and hasattr(model, "fqss_segments"):
+            segs = model.fqss_segments(nb)
+            if len(segs) > 1:
+                seen, ordered, self._seg_ids = set(), [], []
+                for mods in segs:
+                    ids = set()
+                    for m in mods:
+                        for p in m.parameters():
+                            if id(p) not in seen:
+                                seen.add(id(p))
+                                ordered.append(p)
+                            ids.add(id(p))
+                    self._seg_ids.append(ids)
+                rest = [p for p in params if id(p) not in seen]       # anything the model did not assign: with the first segment
+                self._seg_ids[0] |= {id(p) for p in rest}
+                params = rest + ordered
+        self.arena = ParamArena(params)
+        if self._seg_ids is not None:
+            off = {id(p): (o, o + (p.numel() + 63) // 64 * 64) for p, o in zip(self.arena.params, self.arena.offsets)}
+            self.segments = []
+            for ids in self._seg_ids:
+                spans = [off[i] for i in ids if i in off]
+                self.segments.append((min(a for a, _ in spans), max(b for _, b in spans)))
+            assert all(self.segments[k][1] == self.segments[k + 1][0] for k in range(len(self.segments) - 1)), self.segments
+        self._cstream = None
         for p in fmodel.parameters():
             p.requires_grad_(False)
         self.teacher = TeacherRunner(fmodel)     # fused inference chain for the frozen float teacher
@@ -365,7 +430,8 @@ class KDTrainStep:
             self._graphs = None          # a batch of another shape: back to eager launches
 
     # ---- the two halves of a step -----------------------------------------------------------
-    def _fwd_bwd(self, x, tgt):
+    def _forward_loss(self, x, tgt):
+        """zero the gradient arenas, weight fake-quants, student + teacher forward, loss and dloss/dest -> (res, est, gest, cuts)"""
         a = self.arena
         a.zero_grad()
         t = self._quant_tables()
@@ -382,8 +448,13 @@ class KDTrainStep:
             self._tstream.wait_stream(cur)
             with torch.cuda.stream(self._tstream):
                 fest = self.teacher(x)
+        cuts = []
         with ops.fast_codes(self.fast), ops.coded_dataflow(self.coded), ops.deferred(t):   # student: codes-only dataflow between quantizing layers
-            est = self.model(x)
+            if self.segments is not None:
+                with ops.cut_recorder() as cuts:
+                    est = self.model(x)
+            else:
+                est = self.model(x)
         if TEACHER_STREAM:
             cur.wait_stream(self._tstream)
             fest.record_stream(cur)
@@ -397,11 +468,50 @@ class KDTrainStep:
         else:
             out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
             res = dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
+        return res, est, gest, cuts
+
+    def _backward_segment(self, k, est, gest, cuts):
+        """backward segment k (k = 0: the END of the network ... k = len(cuts): its start) + that segment's quantizer finish"""
+        t = self.tables
+        regular = [c for c in cuts if not c[2]]
+        nseg = len(regular) + 1
         with ops.deferred(t):
-            est.backward(gest)
+            if k == 0:
+                est.backward(gest)
+            else:
+                roots = [regular[nseg - 1 - k]] + ([c for c in cuts if c[2]] if k == nseg - 1 else [])
+                pairs = [(o, l.grad) for orig, leaves, _ in roots for o, l in zip(orig, leaves)
+                         if o is not None and o.requires_grad and l.grad is not None]
+                torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         if t is not None:
-            t.finish_backward()                # weight STE + every range/slope gradient: two launches
+            t.finish_backward(None if nseg == 1 else nseg - 1 - k)     # weight STE + range/slope gradients of this segment
+
+    def _fwd_bwd(self, x, tgt):
+        """fwd + loss + the whole backward, no exchange (single rank; tests)"""
+        res, est, gest, cuts = self._forward_loss(x, tgt)
+        for k in range(self._nseg(cuts)):
+            self._backward_segment(k, est, gest, cuts)
         return res
+
+    @staticmethod
+    def _nseg(cuts):
+        return sum(1 for c in cuts if not c[2]) + 1
+
+    def _reduce_segment(self, k, nseg):
+        """all-reduce(SUM) the gradient slice of backward segment k on the communication stream, behind everything enqueued on the
+        current stream so far (RCCL over xGMI; the 1/world factor is folded into the clip+Adam kernel)"""
+        if self._world() <= 1:
+            return
+        lo, hi = (0, self.arena.numel) if self.segments is None or nseg == 1 else self.segments[nseg - 1 - k]
+        if self._cstream is None:
+            self._cstream = torch.cuda.Stream()
+        self._cstream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._cstream):
+            self.comm.all_reduce_sum(self.arena.flat_g[lo:hi])
+
+    def _join_reduces(self):
+        if self._world() > 1 and self._cstream is not None:
+            torch.cuda.current_stream().wait_stream(self._cstream)
 
     def _quant_tables(self):
         """batched per-quantizer work becomes available once every observer has finished"""
@@ -414,7 +524,7 @@ class KDTrainStep:
                     return None
                 if isinstance(m, GradientWeightFakeQuantize) and m.observer_mode:
                     return None
-            self.tables = QuantTables(self.model, self.arena)
+            self.tables = QuantTables(self.model, self.arena, segments=self._seg_ids)
         return self.tables
 
     def _world(self):
@@ -425,12 +535,28 @@ class KDTrainStep:
             self.arena._activate_touched()
         self.arena.clip_adam_step(self.lr, self.clip, 1.0 / self._world(), activate=False)
 
+    def _maybe_sync_ranges(self):
+        """world > 1: once, when the observer phase is over, every rank takes the mean of the observed activation ranges"""
+        if not self._ranges_synced and self.can_capture():
+            self.comm.sync_observer_ranges(self.model)
+            self._ranges_synced = True
+
+    def _step_eager(self, x, tgt):
+        """fwd + loss, then per backward segment: backward -> all-reduce of its gradient slice on the communication stream, which
+        overlaps the next segment's backward; the optimizer waits for the last exchange"""
+        res, est, gest, cuts = self._forward_loss(x, tgt)
+        nseg = self._nseg(cuts)
+        for k in range(nseg):
+            self._backward_segment(k, est, gest, cuts)
+            self._reduce_segment(k, nseg)
+        self._join_reduces()
+        return res
+
     def __call__(self, x, tgt):
+        self._maybe_sync_ranges()
         if self._graphs is not None and self.use_graph:
             return self.replay(x, tgt)
-        self.last = self._fwd_bwd(x, tgt)
-        if self._world() > 1:
-            self.comm.all_reduce_sum(self.arena.flat_g)
+        self.last = self._step_eager(x, tgt)
         self._optimize()
         if self.tables is not None or (not self.batched_quantizers and self.can_capture()):
             self._eager_q += 1
@@ -444,32 +570,45 @@ class KDTrainStep:
                 assert not (m.observer_mode and m.n_iter < m.max_observations), "capture() needs the observer phase to be over"
             if isinstance(m, GradientWeightFakeQuantize):
                 assert not m.observer_mode, "capture() needs the weight observers to have run"
+        self._maybe_sync_ranges()
         self._sx, self._st = x.clone(), tgt.clone()
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(warmup):              # eager steps: activates every live parameter's Adam clock (bench: warm caches)
-                self.last = self._fwd_bwd(self._sx, self._st)
-                if self._world() > 1:
-                    self.comm.all_reduce_sum(self.arena.flat_g)
+                self.last = self._step_eager(self._sx, self._st)
                 self._optimize()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self.last = self._fwd_bwd(self._sx, self._st)
-        with torch.cuda.graph(g2, pool=g1.pool()):
+        # one hipGraph per backward segment (the first also holds fwd + loss) and one for clip + Adam: at world > 1 the exchange of
+        # a segment's gradients is launched between two replays and overlaps the next one (no collective inside a graph)
+        graphs = [torch.cuda.CUDAGraph()]
+        with torch.cuda.graph(graphs[0]):
+            self.last, est, gest, cuts = self._forward_loss(self._sx, self._st)
+            self._backward_segment(0, est, gest, cuts)
+        for k in range(1, self._nseg(cuts)):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, pool=graphs[0].pool()):
+                self._backward_segment(k, est, gest, cuts)
+            graphs.append(gk)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=graphs[0].pool()):
             self._optimize(activate=False)
-        self._graphs = (g1, g2)
+        self._graphs = (graphs, g2)
+        del est, gest, cuts
         return self
 
     def replay_fwd_bwd(self, x=None, tgt=None):
-        """first half of a captured step (fwd + loss + bwd); the caller all-reduces and then calls replay_optimize() or skips"""
+        """first half of a captured step (fwd + loss + bwd, gradients exchanged); the caller then calls replay_optimize() or skips"""
         if x is not None and x.data_ptr() != self._sx.data_ptr():
             self._sx.copy_(x)
             self._st.copy_(tgt)
-        self._graphs[0].replay()
+        graphs = self._graphs[0]
+        for k, gk in enumerate(graphs):
+            gk.replay()
+            self._reduce_segment(k, len(graphs))
+        self._join_reduces()
         return self.last
 
     def replay_optimize(self):
@@ -477,15 +616,8 @@ class KDTrainStep:
         self._graphs[1].replay()
 
     def replay(self, x=None, tgt=None):
-        if x is not None and x.data_ptr() != self._sx.data_ptr():
-            self._sx.copy_(x)
-            self._st.copy_(tgt)
-        g1, g2 = self._graphs
-        g1.replay()
-        if self._world() > 1:
-            self.comm.all_reduce_sum(self.arena.flat_g)
-        self.arena._host_step += 1
-        g2.replay()
+        self.replay_fwd_bwd(x, tgt)
+        self.replay_optimize()
         return self.last
 
 

@@ -144,11 +144,12 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
         for x, tgt in _batches(hp, comm, dev, "train"):
             step.maybe_capture(x, tgt)        # quantizing phase: both halves of the step replay as hipGraphs
             graphed = step._graphs is not None
-            r = step.replay_fwd_bwd(x, tgt) if graphed else step._fwd_bwd(x, tgt)
+            step._maybe_sync_ranges()
+            # fwd + loss + bwd with the gradient exchange of the data-parallel ranks (both forms all-reduce the flat gradient)
+            r = step.replay_fwd_bwd(x, tgt) if graphed else step._step_eager(x, tgt)
             # hard-threshold of easy items (threshold_byloss): a no-op at batch 1, see the module docstring
             flag.copy_((r["loss"] < upper).float().reshape(1))       # False for NaN / inf as well
             if comm.world > 1:
-                comm.all_reduce_sum(step.arena.flat_g)
                 comm.all_reduce_sum(flag)
             if flag.item() >= comm.world:        # the reference syncs here too (loss.detach().cpu(), :199)
                 if graphed:

@@ -32,7 +32,14 @@ def cfg5_fill(model, prefix):
             p.copy_(v.to(p.device))
 
 
-def cfg5_batch():
-    src = keyed_randn("cfg5.src", (1, 4, 2, T_SAMPLES), 0.3)
-    src = torch.nn.functional.avg_pool1d(src.reshape(8, 1, T_SAMPLES), 5, 1, 2).reshape(1, 4, 2, T_SAMPLES) * 2.0
+def cfg5_kw(seconds=1):
+    """constructor arguments of the fixture model; `segment` = the excerpt length so the eval-mode teacher is not zero-padded"""
+    return dict(KW, segment=seconds)
+
+
+def cfg5_batch(seconds=1):
+    """1 x `seconds` s of stereo 44.1 kHz stems (seconds = 10: the BASELINE workload's segment length, cfg5_full_step.npz)"""
+    T = T_SAMPLES * seconds
+    src = keyed_randn("cfg5.src" if seconds == 1 else f"cfg5.src.{seconds}s", (1, 4, 2, T), 0.3)
+    src = torch.nn.functional.avg_pool1d(src.reshape(8, 1, T), 5, 1, 2).reshape(1, 4, 2, T) * 2.0
     return src.sum(1), src

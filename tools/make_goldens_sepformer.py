@@ -129,8 +129,8 @@ def gen_tiny_step(out, n_steps=53):
     print("sep_tiny_step: final loss", last, "keys", len(d))
 
 
-def gen_cfg4_step(out, n_steps=52, B=1, T=16000):
-    torch.set_num_threads(8)
+def gen_cfg4_step(out, n_steps=52, B=1, T=16000, fname="cfg4_step.npz"):
+    torch.set_num_threads(int(os.environ.get("FQSS_GOLDEN_THREADS", "8")))
     d = {}
     torch.manual_seed(0)
     model = RS.SepformerQ(n_spks=2, kernel_size=16, stride=8)
@@ -145,7 +145,7 @@ def gen_cfg4_step(out, n_steps=52, B=1, T=16000):
     x, tgt = MG.synth_batch(B, T, seed=0)
     d["x_sum"] = np.float64(x.double().sum())
     _steps(model, fmodel, x, tgt, n_steps, {1, 2, 51, 52}, d, full=True)
-    np.savez_compressed(os.path.join(out, "cfg4_step.npz"), **d)
+    np.savez_compressed(os.path.join(out, fname), **d)
     torch.set_num_threads(1)
 
 
@@ -154,13 +154,14 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     ap.add_argument("--only", default="")
     ap.add_argument("--T", type=int, default=16000)
+    ap.add_argument("--fname", default="cfg4_step.npz", help="cfg4 digest file (cfg4_full_step.npz for the BASELINE size: --T 32000)")
     a = ap.parse_args()
     if a.only in ("", "layers"):
         gen_layers(a.out)
     if a.only in ("", "tiny"):
         gen_tiny_step(a.out)
     if a.only in ("", "cfg4"):
-        gen_cfg4_step(a.out, T=a.T)
+        gen_cfg4_step(a.out, T=a.T, fname=a.fname)
 
 
 if __name__ == "__main__":
