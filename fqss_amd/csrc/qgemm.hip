@@ -24,6 +24,7 @@
 // wgrad (k_qwgrad): register-direct fragments, no LDS, 4-stage hand-scheduled load ring, float atomics.
 //
 // Reference replaced: F.conv1d(k=1) of Conv1dQ / Conv1dNlQ (qat_layers.py:137-146, 202-212) and its autograd.
+#include <cstdlib>
 #include <type_traits>
 
 #include "fqss_dev.h"
@@ -607,6 +608,171 @@ __global__ __launch_bounds__(256, 2) void k_qwgrad(QGemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad, LDS-tiled (round 2): the register-direct kernel above is VALU-issue bound (PMC: 47 % of wave time issuing, 39 % stalled
+// on issue; ~5 cycles per wave instruction and SIMD): every wave splits its own gz fragment and converts its own code fragments,
+// so inside a 2 x 2 workgroup each gz value is split twice and each code converted twice.  Here the workgroup converts a
+// 64 (co) x 128 (ci) x 64 (n) stage ONCE -- coalesced 16-B global loads (full 256-B / 64-B row pieces), exact 3-way bf16 split /
+// u8 -> bf16 at LDS-store time -- and the four waves read k-contiguous fragments with ds_read_b128 (both operands are
+// n-contiguous and n is the reduction index: no transposed reads).  Half the VALU work per position of the first form; a ring of four
+// register stages of asm-issued loads stays in flight across the barriers.  Same arithmetic: exact products, fp32 accumulation.
+// Measured (cfg-2 shapes, cold operands): 39 -> 31 us (128->512: 2.2 TB/s) and 59 -> 47 us (pair).  Ablation of the 31 us: the
+// operand stream alone 17 us (4.1 TB/s: at the practical HBM rate), + conversion 1.5, + MFMAs 6, + the 2.1 M float atomics of the
+// split-n reduction 7.6 -- the three do not overlap the stream yet (one 8-wave workgroup per CU).  The pair shape re-reads each
+// operand tile four times through L2 (64 x 128 tiles over 256 x 512 outputs): its stream alone is 23 us.
+constexpr int W2_TM = 64, W2_TN = 128, W2_TK = 64, W2_LD = 72, W2_RING = 4;   // 72 bf16 = 144 B rows: conflict-free ds_read_b128 over 16 rows
+struct W2Stage {
+    f32x4 a[2];   // 2 rows x 4 consecutive gz values
+    u32x4 b;      // 16 consecutive codes of one row
+};
+template <int N>
+__device__ __forceinline__ void w2_wait(W2Stage& st) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b) : "n"(N) : "memory");
+}
+
+// 512 threads = 8 waves as 2 (co) x 4 (ci), each a 32 x 32 output tile: two waves per SIMD, so one wave's conversion (VALU) runs
+// beside the other's MFMAs (a 4-wave form, one wave per SIMD, serialised the two phases: 34 us instead of the 39 us it replaced)
+__global__ __launch_bounds__(512, 1) void k_qwgrad2(QGemmArgs g) {
+    // two LDS stage buffers: a wave converts stage s+1 into one while it (and its SIMD partner) multiply stage s out of the other,
+    // ONE barrier per stage.  (Single-buffered, two barriers per stage put all eight waves into the same phase at the same time:
+    // VALU and matrix pipe took turns -- PMC: 49 % of the wave time waiting -- and the kernel ran at 30 / 45 us.)
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][3][W2_TM][W2_LD];   // 2 x 27,648 B: the three bf16 pieces of gz
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][W2_TN][W2_LD];      // 2 x 18,432 B: codes as bf16
+    __shared__ float rsum[W2_TM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3, lr = lane & 31, lh = lane >> 5;
+    int slice, t;
+    if (!xcd_tile(g.batches * g.ksplit, g.tiles_m * g.tiles_n, slice, t)) return;
+    const int b = slice / g.ksplit, ks_id = slice % g.ksplit;
+    const int kbeg = ks_id * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int row0 = (t / g.tiles_n) * W2_TM, col0 = (t % g.tiles_n) * W2_TN;
+    const int nst = (kend - kbeg + W2_TK - 1) / W2_TK;
+
+    // loader geometry: A 16 threads per row (4 values each), rows ar and ar + 32; B 4 threads per row (16 codes each), row br
+    const int ar = tid >> 4, ac = (tid & 15) * 4;
+    const int br = tid >> 2, bc = (tid & 3) * 16;
+    const float* Ap[2];
+    bool aok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + ar + 32 * i;
+        aok[i] = row < g.M;
+        const int rc = aok[i] ? row : 0;
+        Ap[i] = (rc < g.M1) ? (const float*)g.A + (int64_t)b * g.sAb + (int64_t)rc * g.lda
+                            : (const float*)g.A2 + (int64_t)b * g.sA2b + (int64_t)(rc - g.M1) * g.lda2;
+    }
+    const unsigned char* Bp = (const unsigned char*)g.B + (int64_t)b * g.sBb + (int64_t)min(col0 + br, g.N - 1) * g.ldb;
+    const int ka_last = (kend - 1) & ~3, kb_last = (kend - 1) & ~15;   // loads are unconditional: clamped into the row, masked at use
+
+    auto load = [&](W2Stage& st, int s) {
+        const int k = kbeg + s * W2_TK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wg_load16(st.a[i], Ap[i] + min(k + ac, ka_last));
+        wg_load16(st.b, Bp + min(k + bc, kb_last));
+    };
+    float rs_part[2] = {0.f, 0.f};
+    auto convert_store = [&](W2Stage& st, int s) {
+        const int buf = s & 1;
+        const int k = kbeg + s * W2_TK + ac;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (aok[i] && k + e < kend) ? st.a[i][e] : 0.0f;
+            rs_part[i] += (x[0] + x[1]) + (x[2] + x[3]);
+            uint32_t o1[2], o2[2], o3[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a0 = x[2 * e], a1 = x[2 * e + 1];
+                const float r0 = a0 - bf_trunc(a0), r1 = a1 - bf_trunc(a1);
+                const float s0 = r0 - bf_trunc(r0), s1 = r1 - bf_trunc(r1);
+                o1[e] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+                o2[e] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                o3[e] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+            }
+            const int row = ar + 32 * i;
+            *reinterpret_cast<uint2*>(&As[buf][0][row][ac]) = make_uint2(o1[0], o1[1]);
+            *reinterpret_cast<uint2*>(&As[buf][1][row][ac]) = make_uint2(o2[0], o2[1]);
+            *reinterpret_cast<uint2*>(&As[buf][2][row][ac]) = make_uint2(o3[0], o3[1]);
+        }
+        {   // codes need no mask: finite, and beyond kend they only ever meet a zero
+            uint32_t o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w = st.b[q];
+                const float f0 = (float)(w & 0xFFu), f1 = (float)((w >> 8) & 0xFFu);
+                const float f2 = (float)((w >> 16) & 0xFFu), f3 = (float)(w >> 24);
+                o[2 * q] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                o[2 * q + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+            }
+            *reinterpret_cast<uint4*>(&Bs[buf][br][bc]) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(&Bs[buf][br][bc + 8]) = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < W2_TK / 16; ++ks) {
+            const int kk = ks * 16 + 8 * lh;
+            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[buf][wc * 32 + lr][kk]);
+            bf16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(&As[buf][p][wr * 32 + lr][kk]);
+#pragma unroll
+            for (int p = 2; p >= 0; --p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p], bfr, acc, 0, 0, 0);   // smallest pieces first
+        }
+    };
+
+    // ring of W2_RING register stages (24 KB of requests per stage and workgroup): with two stages the loop ran at one memory
+    // round trip per stage (1.5-1.9 us: 47 us for the pair shape); four keep ~96 KB per CU in flight
+    W2Stage st[W2_RING];
+#pragma unroll
+    for (int i = 0; i < W2_RING; ++i) load(st[i], i);
+    w2_wait<3 * (W2_RING - 1)>(st[0]);
+    convert_store(st[0], 0);
+    load(st[0], W2_RING);
+    __syncthreads();
+    const bool first_half = wave < 4;   // waves 4-7 (the SIMD partners of 0-3) take the two halves of a stage in the other order
+    for (int s = 0; s < nst; s += W2_RING) {   // host: kchunk is a multiple of W2_RING stages; stages past nst are fully masked
+#pragma unroll
+        for (int i = 0; i < W2_RING; ++i) {
+            // between two barriers every wave multiplies stage s+i (buffer (s+i) & 1) and converts stage s+i+1 into the other buffer
+            W2Stage& nx = st[(i + 1) % W2_RING];
+            if (first_half) compute((s + i) & 1);
+            w2_wait<3 * (W2_RING - 1)>(nx);      // the oldest stage in flight has landed
+            convert_store(nx, s + i + 1);
+            load(nx, s + i + 1 + W2_RING);
+            if (!first_half) compute((s + i) & 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W2_RING; ++i) w2_wait<0>(st[i]);   // drain the trailing (clamped, unused) requests before their registers are reused
+
+    // gz row sums (min_x term): the 16 threads of a row group hold the partials of rows ar and ar + 32
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = rs_part[i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((tid & 15) == 0) rsum[ar + 32 * i] = v;
+    }
+    __syncthreads();
+    const float lo = *g.qmin_x, hi = *g.qmax_x;
+    const float dx = (hi - lo) / 255.0f, mnx = lo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = row0 + wr * 32 + rl;
+        const int col = col0 + wc * 32 + lr;
+        if (row < g.M && col < g.N) atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * acc[r] + mnx * rsum[wr * 32 + rl]);
+    }
+}
+
 // per-channel weight codes for the q-GEMMs: idx [Co][Ci], idxT [Ci][Co], dw[Co], rw[Co] (one block per channel)
 __global__ __launch_bounds__(256) void k_wq_codes(const float* __restrict__ w, signed char* __restrict__ idx,
                                                    signed char* __restrict__ idxT, float* dw, float* rw, int Co, int Ci,
@@ -762,11 +928,19 @@ static int qpw_bwd_w_impl(const char* who, const float* gz1, const float* gz2, c
     const int64_t tiles = cdiv(Co, 64) * cdiv(Ci, 128) * B;
     int want = (int)((FQSS_WGRAD_BLOCKS + tiles / 2) / tiles);
     if (want < 1) want = 1;
-    int kchunk = (int)cdiv(cdiv(M, want), 32 * WG_STAGES) * 32 * WG_STAGES;   // whole rounds of the load ring
-    g.kchunk = kchunk;
-    g.ksplit = (int)cdiv(M, kchunk);
     g.tiles_n = (int)cdiv(Ci, 128); g.tiles_m = (int)cdiv(Co, 64); g.batches = B;
-    hipLaunchKernelGGL(k_qwgrad, dim3(xcd_grid((int64_t)B * g.ksplit, (int64_t)g.tiles_m * g.tiles_n)), dim3(256), 0, (hipStream_t)stream, g);
+    static const bool reg_direct = getenv("FQSS_WGRAD_REGDIRECT") != nullptr;   // the round-1 kernel, kept for A/B measurements
+    if (reg_direct) {
+        int kchunk = (int)cdiv(cdiv(M, want), 32 * WG_STAGES) * 32 * WG_STAGES;   // whole rounds of the load ring
+        g.kchunk = kchunk;
+        g.ksplit = (int)cdiv(M, kchunk);
+        hipLaunchKernelGGL(k_qwgrad, dim3(xcd_grid((int64_t)B * g.ksplit, (int64_t)g.tiles_m * g.tiles_n)), dim3(256), 0, (hipStream_t)stream, g);
+    } else {
+        int kchunk = (int)cdiv(cdiv(M, want), W2_RING * W2_TK) * W2_RING * W2_TK;   // whole rounds of the stage ring
+        g.kchunk = kchunk;
+        g.ksplit = (int)cdiv(M, kchunk);
+        hipLaunchKernelGGL(k_qwgrad2, dim3(xcd_grid((int64_t)B * g.ksplit, (int64_t)g.tiles_m * g.tiles_n)), dim3(512), 0, (hipStream_t)stream, g);
+    }
     return launch_status(who);
 }
 
