@@ -499,13 +499,15 @@ def dpt_fill(mod, prefix):
                 p.copy_(keyed_randn(prefix + k, tuple(p.shape), 1.0 / np.sqrt(fan)).to(p.device))
 
 
-def test_dpt_full_size_vs_reference_goldens(golden):
+@pytest.mark.parametrize("fixture", ["cfg3_step", "cfg3_full_step"])
+def test_dpt_full_size_vs_reference_goldens(golden, fixture):
     """the FULL-SIZE DPTNetQ (6 dual-path layers, 2.8 M parameters) against digests of the real reference's 52-step run from the
     same name-keyed weights: step 1 at G2 tolerances incl. every per-parameter gradient norm, step 2 (weights quantized after
-    Adam's sign-like first update) loosely, steps 51-52 (all quantizers live) statistically"""
+    Adam's sign-like first update) loosely, steps 51-52 (all quantizers live) statistically.  cfg3_step: 1 x 1 s; cfg3_full_step:
+    1 x 3 s = the BASELINE workload of cfg 3 (T = 24000, `tools/make_goldens_dptnet.py --only cfg3 --T 24000`)"""
     from fqss_amd.data import synth_batch
     from fqss_amd.runtime import KDTrainStep
-    g = golden("cfg3_step")
+    g = golden(fixture)
     B, T_ = int(g["B"]), int(g["T"])
     model, fmodel = build_pair(0)
     dpt_fill(fmodel, "T.")

@@ -270,13 +270,13 @@ def test_sep_tiny_step51_from_reference_state(golden):
     assert abs(out[0].item() - float(g["s51.loss"])) <= 0.2, (out[0].item(), float(g["s51.loss"]))
 
 
-def test_sep_full_size_vs_reference_goldens(golden):
-    """the FULL-SIZE SepformerQ (2 dual-path blocks x 2 x 8 transformer layers) vs digests of the real reference's run"""
+@pytest.mark.parametrize("fixture", ["cfg4_step", "cfg4_full_step"])
+def test_sep_full_size_vs_reference_goldens(golden, fixture):
+    """the FULL-SIZE SepformerQ (2 dual-path blocks x 2 x 8 transformer layers) vs digests of the real reference's run.  cfg4_step:
+    1 x 2 s; cfg4_full_step: 1 x 4 s = the BASELINE workload of cfg 4 (T = 32000, `make_goldens_sepformer.py --only cfg4 --T 32000`)"""
     from fqss_amd.data import synth_batch
     from fqss_amd.runtime import KDTrainStep
-    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "cfg4_step.npz")):
-        pytest.skip("cfg4_step.npz not generated (tools/make_goldens_sepformer.py --only cfg4: ~15 min of reference CPU time)")
-    g = golden("cfg4_step")
+    g = golden(fixture)
     B, T_ = int(g["B"]), int(g["T"])
     model, fmodel = build_pair(0, n_spks=2, kernel_size=16, stride=8)
     dpt_fill(fmodel, "T.")
