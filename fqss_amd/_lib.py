@@ -77,6 +77,7 @@ _PROTOS = {
     "fqss_layernorm_fwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P],
     "fqss_layernorm_bwd": [P, P, P, P, P, P, P, I64, I32, I64, I64, I64, P],
     "fqss_unary_fwd": [P, P, I64, I32, F64, P],
+    "fqss_unary2_fwd": [P, P, I64, I32, F64, F64, P],
     "fqss_unary_bwd": [P, P, P, I64, I32, F64, P],
     "fqss_permute4": [P, P, I64, I64, I64, I32, I64, I64, I64, P],
     "fqss_dp_segment_fwd": [P, P, I32, I32, I64, I64, I32, I32, P],
@@ -119,6 +120,7 @@ _PROTOS = {
     "fqss_infer_normalize": [P, P, I64, I64, I64, P],
     "fqss_fq_affine": [P, P, P, I64, I64, I64, P, P, I32, I32, P],
     "fqss_snr_mix": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I32, I32, P],
+    "fqss_resample_fir": [P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P],
     "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
     "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
 }

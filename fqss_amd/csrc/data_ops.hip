@@ -63,9 +63,44 @@ __global__ __launch_bounds__(256) void k_max_clip(float* __restrict__ x, const u
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (int64_t)gridDim.x * 256) x[r * ld + i] *= gain;
 }
 
+// Polyphase sinc resampler (librimix_dataset.py:54, 111-165: torchaudio.transforms.Resample(16000, 8000) on every clip read):
+//   y[r][n * nw + p] = sum_k h[p][k] * xpad[r][n * og + k],  xpad = x with `width` zeros in front (and zeros behind), K = 2 width + og
+// with og / nw the reduced rate ratio (2 / 1 for 16 -> 8 kHz).  The taps h (sinc * Hann window, torchaudio's published
+// _get_sinc_resample_kernel) are computed on the host in fp64; the stream is read once (the K-fold tap overlap is served by L1 / L2).
+__global__ __launch_bounds__(256) void k_resample_fir(const float* __restrict__ x, const float* __restrict__ h, float* __restrict__ y,
+                                                       int64_t L, int64_t Lout, int64_t ld_x, int64_t ld_y, int og, int nw, int width, int K) {
+    const int64_t r = blockIdx.y;
+    const float* xr = x + r * ld_x;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < Lout; o += (int64_t)gridDim.x * 256) {
+        const int64_t n = o / nw;
+        const int p = (int)(o - n * nw);
+        const int64_t base = n * og - width;
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const int64_t i = base + k;
+            const float v = (i >= 0 && i < L) ? xr[i] : 0.0f;
+            acc = fmaf(h[p * K + k], v, acc);
+        }
+        y[r * ld_y + o] = acc;
+    }
+}
+
 }  // namespace fqss
 
 using namespace fqss;
+
+extern "C" int fqss_resample_fir(const float* x, const float* h, float* y, int64_t rows, int64_t L, int64_t Lout, int64_t ld_x,
+                                 int64_t ld_y, int orig, int newf, int width, fqss_stream_t stream) {
+    if (rows == 0 || Lout == 0) return FQSS_OK;
+    FQSS_REQUIRE(x && h && y, "null pointer");
+    FQSS_REQUIRE(rows > 0 && rows <= 65535 && L > 0 && Lout > 0 && ld_x >= L && ld_y >= Lout && orig > 0 && newf > 0 && width >= 0, "bad shape");
+    FQSS_REQUIRE(Lout <= (newf * L + orig - 1) / orig, "output longer than ceil(new * L / orig)");
+    int64_t gx = cdiv(Lout, 1024);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(k_resample_fir, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, h, y, L, Lout, ld_x, ld_y,
+                       orig, newf, width, 2 * width + orig);
+    return launch_status("fqss_resample_fir");
+}
 
 // a, b, out: B rows of T samples; snr [B] (dB) on the device; ws: 2*B doubles and peak: B uint32, both zeroed by the caller
 extern "C" int fqss_snr_mix(const float* a, const float* b, const float* snr, double* ws, uint32_t* peak, float* out, int64_t B, int64_t T,

@@ -147,15 +147,21 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, flo
 // ------------------------------------------------------------------------------------------------ unary maps
 // kind 0: tanh   1: sigmoid = 1 / (1 + exp(-x))   2: x / p (IEEE division: q / sqrt(head_dim))
 // kind 3: GELU (erf form, torch's default): 0.5 x (1 + erf(x / sqrt 2))      [HTDemucs layers, SURVEY §8 row a15]
+// kinds 4-7: the value maps of the public STE helpers of qat_quant.py:88-107 (round / floor / sign / clip(p, p2)); their backward is
+// the identity (times a scale), so they have no k_unary_bwd case
 __global__ __launch_bounds__(256) void k_unary_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n, int kind,
-                                                    float p) {
+                                                    float p, float p2) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float v = x[i];
         float r;
         if (kind == 0) r = tanhf(v);
         else if (kind == 1) r = 1.0f / (1.0f + expf(-v));
         else if (kind == 2) r = v / p;
-        else r = (0.5f * v) * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (kind == 3) r = (0.5f * v) * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (kind == 4) r = rintf(v);                                        // torch.round: half to even (round_ste)
+        else if (kind == 5) r = floorf(v);                                       // floor_ste
+        else if (kind == 6) r = (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); // torch.sign (grad_sign)
+        else r = fminf(fmaxf(v, p), p2);                                         // torch.clip(x, p, p2) (clip_ste)
         y[i] = r;
     }
 }
@@ -581,8 +587,15 @@ extern "C" int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, dou
     FQSS_REQUIRE(x && y && n >= 0 && kind >= 0 && kind <= 3, "bad args");
     FQSS_REQUIRE(kind != 2 || p != 0.0, "division by zero");
     if (n == 0) return FQSS_OK;
-    hipLaunchKernelGGL(k_unary_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind, (float)p);
+    hipLaunchKernelGGL(k_unary_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind, (float)p, 0.0f);
     return launch_status("fqss_unary_fwd");
+}
+
+extern "C" int fqss_unary2_fwd(const float* x, float* y, int64_t n, int kind, double p, double p2, fqss_stream_t stream) {
+    if (n == 0) return FQSS_OK;
+    FQSS_REQUIRE(x && y && n >= 0 && kind >= 0 && kind <= FQSS_UNARY_CLIP, "bad args");
+    hipLaunchKernelGGL(k_unary_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind, (float)p, (float)p2);
+    return launch_status("fqss_unary2_fwd");
 }
 
 extern "C" int fqss_unary_bwd(const float* g, const float* y, float* gx, int64_t n, int kind, double p, fqss_stream_t stream) {

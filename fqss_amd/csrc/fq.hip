@@ -428,7 +428,12 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
     if (rows == 0 || cols == 0) return FQSS_OK;
-    const bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0);
+    // The 16-B path stores whole float4 / packed-code groups: the last group of a row may write up to 3 elements past `cols`.  That is
+    // only this row's own padding when cols % 4 == 0 (nothing past cols is written) or when fewer than 4 elements separate cols from the
+    // row stride (an activation buffer padded by its owner); a column-block VIEW of a wider matrix (ld - cols >= 4) would have its
+    // neighbour's columns clobbered, so it takes the element path.
+    const bool tail_ok = (cols % 4 == 0) || (out == nullptr) || (ld_out - cols < 4);
+    const bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0) && tail_ok;
     hipStream_t s = (hipStream_t)stream;
     if (vec) {
         hipLaunchKernelGGL(k_actq_fwd<4>, grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,
@@ -486,7 +491,9 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     FQSS_REQUIRE(!gbias || (C > 0 && rows % C == 0), "gbias needs C dividing rows");
     if (rows == 0 || cols == 0) return FQSS_OK;
     if (!gbias || C <= 0) C = rows;   // no channel semantics: every row is its own "channel"
-    const bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0);
+    // (same rule as fqss_actq_fwd: a float4 store past `cols` must land in this row's own padding, never in a neighbouring column block)
+    const bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0) &&
+                     ((cols % 4 == 0) || (ld_gz - cols < 4));
     hipStream_t s = (hipStream_t)stream;
     const int v = vec ? 4 : 1;
     int64_t gx = cdiv(cols, 256 * (int64_t)v);

@@ -811,6 +811,18 @@ def unary_fwd(x, kind, p=1.0):
     return y
 
 
+UNARY_ROUND, UNARY_FLOOR, UNARY_SIGN, UNARY_CLIP = 4, 5, 6, 7
+
+
+def unary2_fwd(x, kind, p=0.0, p2=0.0):
+    """value maps of the STE helpers: round (half to even) / floor / sign / clip(x, p, p2)"""
+    _need_gpu(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.call("fqss_unary2_fwd", _p(x), _p(y), x.numel(), kind, float(p), float(p2), _stream())
+    return y
+
+
 def unary_bwd(g, y, kind, p=1.0):
     _need_gpu(g, y)
     g = g.contiguous()
@@ -1379,3 +1391,46 @@ def snr_mix(a, b, snr, mode=0, clip=True):
     out = torch.empty(B, T, device=a.device, dtype=torch.float32)
     _lib.call("fqss_snr_mix", _p(a), _p(b), _p(snr.contiguous()), _p(ws), _p(peak), _p(out), B, T, ld_a, ld_b, T, mode, 1 if clip else 0, _stream())
     return out
+
+
+# ------------------------------------------------------------------ data side: polyphase sinc resampler (librimix_dataset.py:54)
+_RESAMPLE_TAPS = {}
+
+
+def sinc_resample_taps(orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """(taps [new][2 * width + orig] fp64, width, orig, new) with the rates reduced by their gcd -- torchaudio's published
+    `_get_sinc_resample_kernel` (sinc_interp_hann), restated; computed on the host in fp64"""
+    import math
+    import numpy as np
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base / orig
+    taps = np.where(t == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t)) * window * scale
+    return taps, width, orig, new
+
+
+def resample(x, orig_freq, new_freq):
+    """x [..., L] fp32 on the device -> [..., ceil(new * L / orig)] (torchaudio.transforms.Resample semantics)"""
+    _need_gpu(x)
+    if int(orig_freq) == int(new_freq):
+        return x
+    key = (int(orig_freq), int(new_freq), x.device)
+    ent = _RESAMPLE_TAPS.get(key)
+    if ent is None:
+        taps, width, orig, new = sinc_resample_taps(orig_freq, new_freq)
+        ent = _RESAMPLE_TAPS[key] = (torch.from_numpy(taps).to(torch.float32).contiguous().to(x.device), width, orig, new)
+    h, width, orig, new = ent
+    L = x.shape[-1]
+    rows = x.numel() // L
+    xs = x.reshape(rows, L).contiguous()
+    Lout = (new * L + orig - 1) // orig
+    y = torch.empty(rows, Lout, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_resample_fir", _p(xs), _p(h), _p(y), rows, L, Lout, L, Lout, orig, new, width, _stream())
+    return y.reshape(*x.shape[:-1], Lout)

@@ -150,7 +150,7 @@ class ConvTasNetQ(nn.Module):
     def load_pretrain(self, weights_path):
         """order-based key mapping of a checkpoint with the same number of entries (reference :225-237)"""
         own = self.state_dict()
-        loaded = torch.load(weights_path, map_location="cpu")
+        loaded = torch.load(weights_path, map_location="cpu", weights_only=False)   # trusted local checkpoint
         loaded = loaded.get("state_dict", loaded)
         loaded = {k: v for k, v in loaded.items() if not k.startswith("fmodel.")}
         assert len(own) == len(loaded), ("Error: mismatch models weights. Please check if the model configurations "

@@ -265,7 +265,7 @@ class DPTNetQ(nn.Module):
 
     def load_pretrain(self, weights_path):
         own = self.state_dict()
-        loaded = torch.load(weights_path, map_location="cpu")
+        loaded = torch.load(weights_path, map_location="cpu", weights_only=False)   # trusted local checkpoint
         loaded = loaded.get("state_dict", loaded)
         loaded = {k: v for k, v in loaded.items() if not k.startswith("fmodel.")}
         assert len(own) == len(loaded), ("Error: mismatch models weights. Please check if the model configurations "

@@ -55,10 +55,17 @@ def quantize_model(model, quant_cfg):
     return model
 
 
+def load_checkpoint(path):
+    """a TRUSTED local checkpoint (the reference calls plain torch.load): `weights_only=False`, because reference / demucs-style
+    packages ({'state', 'kwargs', ...}) pickle non-tensor objects (e.g. fractions.Fraction for `segment`) that torch >= 2.6 refuses
+    by default"""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def _load_any(path):
     if path.startswith("https"):
         return torch.hub.load_state_dict_from_url(path, map_location="cpu", check_hash=True)
-    return torch.load(path, map_location="cpu")
+    return load_checkpoint(path)
 
 
 def create_pretrained_model(model_cfg):
@@ -74,9 +81,9 @@ def create_pretrained_model(model_cfg):
                 sd = sd[key]
                 break
         model.load_state_dict(sd, strict=True)
-    except Exception:
+    except (RuntimeError, KeyError, TypeError):       # key / shape mismatch: the reference's order-based fallback (load_model.py:92-100)
         try:
             model.load_pretrain(path)
-        except Exception:
+        except (AssertionError, RuntimeError, KeyError):
             raise SystemExit("Error: mismatch models weights. Please check if the model configurations match to model weights!")
     return model

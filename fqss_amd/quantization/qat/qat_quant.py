@@ -30,6 +30,45 @@ def _check_bits(n_bits):
         raise NotImplementedError("fqss_amd kernels implement the 8-bit quantizers of the shipped FQSS configs")
 
 
+# ---- public STE helpers (qat_quant.py:88-107 of the reference): `(f(x) - x).detach() + x` -> value f(x), gradient of x ------------
+class _Ste(torch.autograd.Function):
+    """y = f(x) (one HIP map) with the gradient of `gscale * x`: the straight-through estimators users build new quantizers from"""
+
+    @staticmethod
+    def forward(ctx, x, kind, p, p2, gscale):
+        ctx.gscale = float(gscale)
+        return K.unary2_fwd(ops.real(x), kind, p, p2) if kind >= 0 else ops.real(x).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.gscale == 1.0 else K.axpby(g, g, 0.0, sa=ctx.gscale)), None, None, None, None
+
+
+def round_ste(x):
+    """(torch.round(x) - x).detach() + x  (qat_quant.py:88-89)"""
+    return _Ste.apply(x, K.UNARY_ROUND, 0.0, 0.0, 1.0)
+
+
+def floor_ste(x):
+    """(torch.floor(x) - x).detach() + x  (:92-93)"""
+    return _Ste.apply(x, K.UNARY_FLOOR, 0.0, 0.0, 1.0)
+
+
+def grad_sign(x, scale=1.0):
+    """value sign(x), gradient scale * g  (:96-98)"""
+    return _Ste.apply(x, K.UNARY_SIGN, 0.0, 0.0, scale)
+
+
+def grad_scale(x, scale):
+    """value x, gradient scale * g  (:101-103)"""
+    return _Ste.apply(x, -1, 0.0, 0.0, scale)
+
+
+def clip_ste(x, min_val=-1.0, max_val=1.0):
+    """value clip(x, min_val, max_val), identity gradient  (:106-107)"""
+    return _Ste.apply(x, K.UNARY_CLIP, min_val, max_val, 1.0)
+
+
 def linear_quantize(x, min_range, max_range, n_bits, sign=True, sym=False, scale_grad=False):
     """Functional form (differentiable w.r.t. x, min_range, max_range) on device tensors."""
     _check_bits(n_bits)

@@ -340,7 +340,8 @@ class KDTrainStep:
     RCCL all-reduce of the flat gradient buffer runs between the two graphs."""
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None, loss="sisdr_pit", source_weights=None,
-                 batched_quantizers=True, fast=True, coded=True, buckets=None, sync_observer_ranges=True):
+                 batched_quantizers=True, fast=True, coded=True, buckets=None, sync_observer_ranges=True,
+                 betas=(0.9, 0.999)):
         """loss: "sisdr_pit" = the asteroid / speechbrain KD loss (mysystem.py:124-151); "l1_sdr" = the htdemucs solver's
         (solver.py:333-366: L1 task + SDR-weighted L1 distillation, per-source weights).  clip <= 0: no clipping (htdemucs.yaml:84).
         batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow);
@@ -355,7 +356,7 @@ class KDTrainStep:
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
         self.fast, self.coded = bool(fast and coded), bool(coded)
         self._graphs = None
-        self.kd_lambda, self.lr, self.clip = kd_lambda, lr, clip
+        self.kd_lambda, self.lr, self.clip, self.betas = kd_lambda, lr, clip, tuple(betas)
         self.comm = comm
         # ---- backward segments = gradient buckets (world > 1 only: a single rank has nothing to overlap) -------------------
         self.segments = None        # [(arena lo, arena hi)] per segment in FORWARD order
@@ -533,7 +534,7 @@ class KDTrainStep:
     def _optimize(self, activate=True):
         if activate:
             self.arena._activate_touched()
-        self.arena.clip_adam_step(self.lr, self.clip, 1.0 / self._world(), activate=False)
+        self.arena.clip_adam_step(self.lr, self.clip, 1.0 / self._world(), betas=self.betas, activate=False)
 
     def _maybe_sync_ranges(self):
         """world > 1: once, when the observer phase is over, every rank takes the mean of the observed activation ranges"""

@@ -52,7 +52,12 @@ def train(yml_path, device):
                 yaml.safe_dump(blk, out)
 
     opt = training_cfg.get("optim", {})
-    system = System(model, fmodel, training_cfg.get("kd_lambda", 0), lr=opt.get("lr", 1e-3), clip=5.0, comm=comm)
+    # make_optimizer(**training_cfg["optim"]) of the reference (asteroid_librimix_trainer.py:94): the fused clip + Adam kernel serves
+    # Adam without weight decay (every shipped config); anything else is refused rather than silently ignored
+    if str(opt.get("optimizer", "adam")).lower() != "adam" or float(opt.get("weight_decay", 0) or 0) != 0:
+        raise NotImplementedError(f"asteroid env: optim {opt!r}: only adam with weight_decay 0 has a fused kernel")
+    betas = tuple(opt.get("betas", (0.9, 0.999)))
+    system = System(model, fmodel, training_cfg.get("kd_lambda", 0), lr=opt.get("lr", 1e-3), clip=5.0, comm=comm, betas=betas)
     best, history = float("inf"), []
     # schedulers of train_setup (asteroid_librimix_trainer.py:96-102): StepLR for `step_lr` (DPTNet config), ReduceLROnPlateau
     # (factor 0.5) for `half_lr`; both act once per epoch on the stepper's learning rate

@@ -13,12 +13,17 @@ from .wsdr import KDObjective, si_sdr
 class System:
     default_monitor = "val_loss"
 
-    def __init__(self, model, fmodel, kd_lambda, lr=1e-3, clip=5.0, comm=None):
+    def __init__(self, model, fmodel, kd_lambda, lr=1e-3, clip=5.0, comm=None, betas=(0.9, 0.999)):
+        if not kd_lambda > 0:
+            # the reference falls back to the plain PIT SI-SDR loss without a teacher (mysystem.py:153-156); that loss has no HIP
+            # kernel here (the fused step is the KD objective of :124-151): refused instead of building a half-initialised System
+            raise NotImplementedError("asteroid env: the QAT training path is the KD step (training_cfg.kd_lambda > 0); the teacher-free "
+                                      "PIT SI-SDR loss of kd_lambda = 0 is not built")
         self.model = model
-        self.fmodel = fmodel if kd_lambda > 0 else None
+        self.fmodel = fmodel
         self.kd_lambda = kd_lambda
         self.objective = KDObjective(kd_lambda)
-        self.stepper = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip, comm=comm) if kd_lambda > 0 else None
+        self.stepper = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip, comm=comm, betas=betas)
         self.logged = {}
 
     def forward(self, *a, **k):

@@ -69,7 +69,8 @@ class Solver:
             raise NotImplementedError("htdemucs env: EMA copies are not built")
         self.weights = torch.tensor(conf.get("weights", [1.0] * model.n_srcs), device=device, dtype=torch.float32)
         self.step = KDTrainStep(model, fmodel, kd_lambda=float(conf.get("kd_lambda", 0.1)), lr=float(opt["lr"]),
-                                clip=float(opt.get("clip_grad") or 0.0), comm=comm, loss="l1_sdr", source_weights=self.weights)
+                                clip=float(opt.get("clip_grad") or 0.0), comm=comm, loss="l1_sdr", source_weights=self.weights,
+                                betas=(float(opt.get("momentum", 0.9)), float(opt.get("beta2", 0.999))))
         self.history = []
         self.best_state, self.best_loss = None, float("inf")
 
@@ -141,7 +142,7 @@ def get_solver(conf):
     model = HTDemucsQ(**kwargs)
     model._init_kwargs = kwargs
     if mc.get("model_path"):
-        sd = torch.load(mc["model_path"], map_location="cpu")
+        sd = torch.load(mc["model_path"], map_location="cpu", weights_only=False)   # trusted local package ({"state", "kwargs"})
         model.load_state_dict(sd.get("state", sd), strict=True)
     fmodel = copy.deepcopy(model).to(dev).eval() if float(conf.get("kd_lambda", 0.1)) > 0 else None
     if fmodel is None:

@@ -409,6 +409,13 @@ int fqss_layernorm_bwd(const float* gy, const float* x, const float* gamma, cons
 #define FQSS_UNARY_SIGMOID 1
 #define FQSS_UNARY_DIVS 2
 int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, double p, fqss_stream_t stream);
+/* the value maps of the public STE helpers round_ste / floor_ste / grad_sign / clip_ste (qat_quant.py:88-107): torch.round (half
+ * to even), floor, sign, clip(x, p, p2); their backward is the identity times a scale (no kernel of its own)                     */
+#define FQSS_UNARY_ROUND 4
+#define FQSS_UNARY_FLOOR 5
+#define FQSS_UNARY_SIGN 6
+#define FQSS_UNARY_CLIP 7
+int fqss_unary2_fwd(const float* x, float* y, int64_t n, int kind, double p, double p2, fqss_stream_t stream);
 int fqss_unary_bwd(const float* g, const float* y, float* gx, int64_t n, int kind, double p, fqss_stream_t stream);
 
 /* y[i0][i1][i2][c] = x[i0*s0 + i1*s1 + i2*s2 + c], c < C contiguous: the intra-chunk <-> inter-chunk change of view
@@ -583,6 +590,14 @@ int fqss_fq_affine(const float* x, float* y, int* codes, int64_t outer, int64_t 
  * per row.  ws: 2*B doubles, peak: B uint32, both zeroed by the caller; clip = 0 skips max_clip.                                  */
 int fqss_snr_mix(const float* a, const float* b, const float* snr, double* ws, uint32_t* peak, float* out, int64_t B, int64_t T, int64_t ld_a,
                  int64_t ld_b, int64_t ld_o, int mode, int clip, fqss_stream_t stream);
+/* Polyphase sinc resampler of the LibriMix dataset (librimix_dataset.py:54: torchaudio.transforms.Resample(sample_rate, resample *
+ * sample_rate), applied to every clip read at :111-165; torchaudio is third party and absent: the taps follow its published
+ * _get_sinc_resample_kernel -- sinc x Hann window, lowpass_filter_width 6, rolloff 0.99 -- and are computed by the host in fp64).
+ * x [rows][L] -> y [rows][Lout], Lout <= ceil(new * L / orig); orig / new = the REDUCED ratio (2 / 1 for 16 -> 8 kHz);
+ * h [new][2 * width + orig] fp32 taps.                                                                                           */
+int fqss_resample_fir(const float* x, const float* h, float* y, int64_t rows, int64_t L, int64_t Lout, int64_t ld_x, int64_t ld_y,
+                      int orig, int newf, int width, fqss_stream_t stream);
+
 
 #ifdef __cplusplus
 }

@@ -501,3 +501,30 @@ def generate_mix_noise(sig, noise, snr):
     gain = torch.sqrt((Es / En) / (10 ** (snr / 10))) if Es > 0 else 1.0
     return max_clip(sig + gain * noise)
 
+
+
+# ---- data side: polyphase sinc resampler (test infrastructure) --------------------------------------------------------------------------
+def resample_sinc(x, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.transforms.Resample(orig_freq, new_freq) as the reference applies it to every LibriMix clip
+    (train_env/asteroid_librimix/librimix_dataset.py:54, 111-165).  torchaudio (requirements.txt: torchaudio) is third party and absent:
+    this restates its published `_get_sinc_resample_kernel` + `_apply_sinc_resample_kernel` (sinc_interp_hann) in float64 --
+    PARITY UNPINNED against torchaudio itself.  x [..., L] -> [..., ceil(new * L / orig)]"""
+    import math
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base_freq / orig)
+    shape = x.shape
+    w = x.reshape(-1, shape[-1]).double()
+    L = w.shape[1]
+    w = torch.nn.functional.pad(w, (width, width + orig))
+    y = torch.nn.functional.conv1d(w[:, None], kernels, stride=orig)          # [rows, new, n]
+    y = y.transpose(1, 2).reshape(w.shape[0], -1)
+    target = math.ceil(new * L / orig)
+    return y[..., :target].reshape(*shape[:-1], target)

@@ -201,3 +201,28 @@ def test_fast_division_is_bitwise_ieee():
                 a[512:768] = torch.nextafter(edges, torch.full_like(edges, -1e9))
             _lib.call("fqss_selftest_div", a.data_ptr(), n, delta, mism.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert int(mism.item()) == 0
+
+
+def test_public_ste_helpers_match_the_reference_formulas():
+    """round_ste / floor_ste / grad_sign / grad_scale / clip_ste (qat_quant.py:88-107: `(f(x) - x).detach() + x`): value f(x) bit for
+    bit (torch.round is half-to-even), gradient of x (times the scale)"""
+    from fqss_amd.quantization.qat import qat_quant as QQ
+    gen = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(1000, generator=gen) * 3, torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 0.0, -0.0, 1.0, -2.0])])
+    g = torch.randn(x.numel(), generator=gen)
+    cases = [(QQ.round_ste, lambda t: (torch.round(t) - t).detach() + t),
+             (QQ.floor_ste, lambda t: (torch.floor(t) - t).detach() + t),
+             (lambda t: QQ.grad_sign(t, 0.3), lambda t: (torch.sign(t) - t * 0.3).detach() + t * 0.3),
+             (lambda t: QQ.grad_scale(t, 0.25), lambda t: (t - t * 0.25).detach() + t * 0.25),
+             (lambda t: QQ.clip_ste(t, -1.2, 0.7), lambda t: (torch.clip(t, min=-1.2, max=0.7) - t).detach() + t)]
+    for ours, ref in cases:
+        xd = x.clone().cuda().requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        y, yr = ours(xd), ref(xr)
+        y.backward(g.cuda())
+        yr.backward(g)
+        # values: the reference's `(f - x) + x` re-rounds f(x) through x's magnitude; the helper returns f(x) itself
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=0, atol=4e-7 * 8)
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-7, atol=0)
+    assert torch.equal(QQ.round_ste(x.cuda()).cpu(), torch.round(x))
+    assert torch.equal(QQ.floor_ste(x.cuda()).cpu(), torch.floor(x))

@@ -93,3 +93,55 @@ def test_infer_runner_graph_replay_is_bit_identical(golden):
         for x, w in zip(xs, want):
             assert torch.equal(run(x), w)
     assert len(run._graphs) == 2
+
+
+def test_polyphase_resampler_and_librimix_batches(tmp_path):
+    """SURVEY 8(f) rank 4, the rest of the data side: the 16 -> 8 kHz resampler of the LibriMix dataset (librimix_dataset.py:54, one
+    launch for a whole batch of clips) against the oracle's fp64 restatement of torchaudio's published sinc kernel, and the CSV-driven
+    batch assembler (same item contract as librimix_dataset.py:93-170) on synthetic PCM16 files"""
+    import wave
+    import pandas as pd
+    import oracle.fqss_oracle as O
+    from fqss_amd import kernels as K
+    from fqss_amd.train_env.asteroid_librimix.librimix_dataset import LibriMix
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 24001, generator=gen) * 0.1
+    for orig, new in ((16000, 8000), (44100, 16000), (8000, 16000)):
+        y = K.resample(x.cuda(), orig, new).cpu()
+        ref = O.resample_sinc(x, orig, new)
+        assert y.shape == ref.shape
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=0, atol=3e-7)
+    # a tone below / above the new Nyquist frequency: kept / removed
+    t = torch.arange(16000) / 16000.0
+    keep, kill = torch.sin(2 * np.pi * 1000 * t), torch.sin(2 * np.pi * 5000 * t)
+    yk = K.resample(torch.stack([keep, kill]).cuda(), 16000, 8000).cpu()
+    assert abs(float(yk[0, 100:-100].pow(2).mean().sqrt()) - 2 ** -0.5) < 1e-2 and float(yk[1, 100:-100].abs().max()) < 2e-2
+    # ---- a tiny on-disk LibriMix: 3 utterances (one too short), 2 sources, 16 kHz PCM16
+    def write(path, sig):
+        with wave.open(str(path), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes((np.clip(sig, -1, 1 - 2 ** -15) * 32768).astype("<i2").tobytes())
+    rows, rs = [], np.random.RandomState(0)
+    for i, n in enumerate((20000, 9000, 26000)):
+        s1, s2 = 0.2 * rs.randn(n).astype(np.float32), 0.1 * rs.randn(n).astype(np.float32)
+        paths = [tmp_path / f"s1_{i}.wav", tmp_path / f"s2_{i}.wav", tmp_path / f"mix_{i}.wav"]
+        for p_, sig in zip(paths, (s1, s2, s1 + s2)):
+            write(p_, sig)
+        rows.append({"mixture_ID": i, "mixture_path": str(paths[2]), "source_1_path": str(paths[0]), "source_2_path": str(paths[1]), "length": n})
+    pd.DataFrame(rows).to_csv(tmp_path / "mixture_train_mix_clean.csv", index=False)
+    ds = LibriMix(str(tmp_path), task="sep_clean", sample_rate=16000, resample=0.5, n_src=2, segment=1)
+    assert len(ds) == 2                                             # the 9000-sample utterance is dropped (< 1 s)
+    mix, src = ds[0]
+    assert mix.shape == (1, 8000) and src.shape == (2, 8000) and mix.is_cuda
+    # without augmentation the mixture file is the sum of the sources (to PCM16 rounding) -- and resampling is linear
+    np.testing.assert_allclose(mix[0].cpu().numpy(), src.sum(0).cpu().numpy(), atol=3e-4)
+    mixes, srcs = ds.batch([0, 1, 1])
+    assert mixes.shape == (3, 1, 8000) and srcs.shape == (3, 2, 8000)
+    ds_aug = LibriMix(str(tmp_path), task="sep_clean", sample_rate=16000, resample=0.5, n_src=2, segment=1,
+                      augmentation_cfg={"distribution": "uniform", "param0": -2.5, "param1": 2.5, "prob": 1.0})
+    mixes, srcs = ds_aug.batch([0, 1])
+    e = lambda v: v.pow(2).mean(-1)
+    # generate_2mix_snr rescales ONE source so that the pair sits at the drawn SNR in [-2.5, 2.5] dB: the mixture is a1 s1 + a2 s2
+    a = torch.linalg.lstsq(srcs.transpose(1, 2), mixes.transpose(1, 2)).solution.squeeze(-1)      # [B, 2] gains
+    snr = 10 * torch.log10(e(srcs[:, 0] * a[:, :1]) / e(srcs[:, 1] * a[:, 1:]))
+    assert bool(((snr >= -2.6) & (snr <= 2.6)).all()) and bool((a.min(1).values <= 1.0 + 1e-4).all()), (snr, a)

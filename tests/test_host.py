@@ -65,6 +65,17 @@ def test_quantizer_api_surface():
     assert w.min_range.shape == (1, 3, 1) and w.axis == 1
     with pytest.raises(NotImplementedError):
         QQ.GradientActivationFakeQuantize(True, n_bits=4)
+    # the public helper names users extend the library with (qat_quant.py:88-107, qat_utils.py:12-255)
+    from fqss_amd.quantization.qat import qat_utils as QU
+    for name in ("round_ste", "floor_ste", "grad_sign", "grad_scale", "clip_ste", "linear_quantize"):
+        assert callable(getattr(QQ, name)), name
+    for name in ("quant_encoderq", "quant_decoderq", "quant_conv1d", "quant_conv2d", "quant_convtr1d", "quant_convtr2d", "quant_conv1d_nl",
+                 "quant_conv1d_gn_nl", "quant_conv2d_nl", "quant_convtr1d_nl", "quant_convtr2d_nl", "quant_groupnorm", "quant_layernorm",
+                 "quant_batchnorm", "quant_embedding", "quant_nl", "quant_linear", "quant_linear_nl", "quant_mha", "quant_lstm", "quant_add",
+                 "quant_sub", "quant_mul", "quant_div", "quant_const", "torch_weight_quantizer", "torch_activation_quantizer",
+                 "quantize_known_modules", "quantize_modules", "replace_encoderq", "replace_decoderq", "replace_weight_quantizer",
+                 "replace_activation_quantizer"):
+        assert callable(getattr(QU, name)), name
 
 
 def test_graph_rewrite_and_state_dict_layout(golden):
