@@ -46,25 +46,39 @@ def parse():
     return ap.parse_args()
 
 
-def dominant_kernel_roofline(dev):
-    """Times the step's heaviest kernels live at their cfg-2 launch shapes (fqss_amd/roofline_cases.py)
-    with HIP events on the launch stream, and reports the one with the largest time per step as
-    `roofline` (launch-weighted over its shapes).  `traffic` = HBM bytes per launch from the rocprofv3
-    PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/roofline_probe.py);
-    null when no measurement of that kernel is committed."""
+def dominant_kernel_roofline(dev, ms_step):
+    """Times the step's kernels live at their cfg-2 launch shapes (fqss_amd/roofline_cases.py: one case = ONE kernel launch, operands
+    rotating over > 256 MiB) with HIP events on the launch stream.  `roofline` = the SINGLE kernel (one kernel symbol, launch-weighted
+    over its shapes in the step) with the largest time per step; the two multi-launch gLN-backward operations are timed too but only
+    listed (`group_of_launches`).  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (raw
+    counters: 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 rule of MI355X_MICROARCH.md; `traffic_x1` = FETCH_SIZE + WRITE_SIZE); null when
+    no measurement of that kernel is committed.  Also returns the step-level traffic figures."""
     from fqss_amd import roofline_cases as RC
     cases = RC.build(dev)
     times = [RC.time_case(c) for c in cases]
     groups = RC.summarize(cases, times)
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             pmc = json.load(f).get("per_launch_bytes", {})
     except (OSError, ValueError):
         pmc = {}
-    dom = RC.roofline_object(groups[0], traffic=pmc.get(groups[0]["kernel"]))
-    others = [{k: v for k, v in RC.roofline_object(g, traffic=pmc.get(g["kernel"])).items() if k != "shapes"} for g in groups[1:]]
-    return dom, others
+
+    def obj(g, shapes):
+        t = pmc.get(g["kernel"])
+        o = RC.roofline_object(g, traffic=t["x2"] if t else None)
+        o["traffic_x1"] = t["x1"] if t else None
+        if not shapes:
+            o.pop("shapes")
+        return o
+    singles = [g for g in groups if not g["group"]]
+    dom = obj(singles[0], True)
+    others = [obj(g, False) for g in groups if g is not singles[0]]
+    step_bytes = RC.step_traffic_bytes(cases)
+    step = {"step_traffic_GB": round(step_bytes / 1e9, 2),
+            "step_traffic_frac_of_hbm_peak": round(step_bytes / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+            "isolated_kernel_ms_sum": round(sum(g["ms_step"] for g in groups), 3)}
+    return dom, others, step
 
 
 def cpu_baseline(threads):
@@ -666,10 +680,13 @@ def main():
                        "kd_lambda": 0.1, "optimizer": "adam lr 1e-3 + clip 5.0",
                        "launch": launch},
             "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
+            # SURVEY.md 8(d) convention (4 B x (in + out) of every LayerQ boundary tensor, x4 for bwd + teacher): 74.8 GB/step ...
             "step_algorithmic_GB": 74.8,
             "step_algorithmic_frac_of_hbm_peak": round(74.8 / (ms * 1e-3) / HBM_PEAK_GBS, 4),
         }
-        out["roofline"], out["roofline_other_kernels"] = dominant_kernel_roofline(dev)
+        # ... and the bytes this build actually has to move (every kernel's operands read once / results written once at their real width)
+        out["roofline"], out["roofline_other_kernels"], step = dominant_kernel_roofline(dev, ms)
+        out.update(step)
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_threads)
         print(json.dumps(out), flush=True)
