@@ -109,14 +109,17 @@ __global__ __launch_bounds__(256) void k_gnq_apply(const uint8_t* __restrict__ x
                                                     float* __restrict__ yout, float* __restrict__ mean_rstd,
                                                     const long long* __restrict__ ws, int nslots, float eps, int B, int C,
                                                     int M, int64_t ld_xc, int64_t ld_yc, int64_t ld_o, const float* qmin_x,
-                                                    const float* qmax_x, const float* qmin, const float* qmax) {
+                                                    const float* qmax_x, const float* qmin, const float* qmax, int rpw) {
     __shared__ long long red[2 * 4];
     __shared__ float mr[2];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const int rows = B * C;
     const int cstep = gridDim.x * 256 * 16;
     int b_have = -1;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    // a workgroup owns `rpw` CONSECUTIVE rows (same sample unless a sample boundary falls inside): the statistics reduction -- as
+    // many instructions as the quantizing of a whole 4000-element row -- is paid once per workgroup, not once per row
+    for (int r0 = blockIdx.y * rpw; r0 < rows; r0 += gridDim.y * rpw)
+    for (int row = r0; row < min(rows, r0 + rpw); ++row) {
         const int b = row / C, c = row - b * C;
         // this thread's codes are requested before the statistics are reduced: the two round trips overlap
         const int c_first = (blockIdx.x * 256 + threadIdx.x) * 16;
@@ -1037,8 +1040,10 @@ extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float*
         stats = (const int64_t*)ws;
     }
     const int64_t rows = (int64_t)B * C;
-    hipLaunchKernelGGL(k_gnq_apply, grid_rows(rows, M, 16), dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd,
-                       (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_yc, ld_out, qmin_x, qmax_x, qmin, qmax);
+    const int rpw = (rows >= 2048 && M <= 4096) ? 4 : 1;     // rows per workgroup (keep >= 2 workgroups per CU)
+    dim3 grid = grid_rows(cdiv(rows, rpw), M, 16);
+    hipLaunchKernelGGL(k_gnq_apply, grid, dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd,
+                       (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_yc, ld_out, qmin_x, qmax_x, qmin, qmax, rpw);
     return launch_status("fqss_gnq_fwd");
 }
 
