@@ -907,17 +907,20 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
     };
     const int c_first = (blockIdx.x * 256 + threadIdx.x) * 4;
     if ((int64_t)gridDim.x * 1024 >= cols) {
-        // every thread owns ONE column group of each of the workgroup's rows: the loads of 4 rows are issued before
-        // the first is consumed (the serial row loop exposed one HBM round trip per row: 8 per workgroup at cfg 2)
+        // every thread owns ONE column group of each of the workgroup's rows: the loads of 8 rows are issued before the first is
+        // consumed, UNCONDITIONALLY (row / column clamped into the tensor, the results of clamped groups dropped): a branch around a
+        // load makes the compiler retire the loads in flight first, and the kernel is latency-bound (2 waves per SIMD, PMC: 64 % of
+        // the wave time waiting on memory)
+        constexpr int NR = 8;
         const bool active = c_first < cols;
+        const int c_ld = active ? c_first : 0;
         const int rstep = gridDim.y;
-        for (int row0 = blockIdx.y; row0 < rows; row0 += 4 * rstep) {
-            EwIn in[4];
+        for (int row0 = blockIdx.y; row0 < rows; row0 += NR * rstep) {
+            EwIn in[NR];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (active && row0 + i * rstep < rows) load_group(row0 + i * rstep, c_first, in[i]);
+            for (int i = 0; i < NR; ++i) load_group(min(row0 + i * rstep, rows - 1), c_ld, in[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NR; ++i)
                 if (row0 + i * rstep < rows) {
                     if (active) do_group(row0 + i * rstep, c_first, in[i]);
                     if (row_bias) row_bias_flush(row0 + i * rstep);
