@@ -15,6 +15,8 @@
 //                                    runs the epilogue backward of the convs that produced the operands
 //   fqss_decode                      codes -> fp32 (fallback for consumers without a coded-input kernel)
 // Statistics of a coded tensor are exact integer sums (sum c, sum c^2 in int64).
+#include <cstdlib>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict_
                                                        const float* __restrict__ mean_rstd, int C, int M, int64_t ld_xc,
                                                        int64_t ld_g, double* ws, const float* qmin_x, const float* qmax_x,
                                                        const float* qmin, const float* qmax, double* gacc) {
-    __shared__ double red[4 * 4];
+    __shared__ float redf[4 * 4];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const int b = blockIdx.y, c = blockIdx.x;
     const int64_t row = (int64_t)b * C + c;
@@ -213,8 +215,11 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict_
             }
         }
     }
-    double v[4] = {(double)ds, (double)db, (double)p_du, (double)p_out};
-    block_sum<double, 4>(v, red);
+    double v[4];
+    {
+        const float pf[4] = {ds, db, p_du, p_out};
+        block_sum_f32w<4>(pf, redf, v);
+    }
     if (threadIdx.x == 0) {
         ws[2 * row] = v[0];
         ws[2 * row + 1] = v[1];
@@ -248,8 +253,7 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
                                                         int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx,
                                                         const double* ws, const float* qmin_x, const float* qmax_x,
                                                         const float* qmin, const float* qmax, GnProducer P) {
-    __shared__ double pred[3 * 4];
-    __shared__ float predf[4];
+    __shared__ float predf[4 * 4];
     const QRange rp = FUSE ? load_qrange(P.qmin, P.qmax) : QRange{0.f, 1.f, 1.f};
     const float pslope = (FUSE && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
@@ -313,13 +317,13 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
         }
     }
     if (FUSE) {
-        if (P.gbias != nullptr) {   // ONE atomic per row (per-wave atomics on the same 512 addresses cost 1.6 ms/step)
-            float pb[1] = {p_bias};
-            block_sum<float, 1>(pb, predf);
-            if (threadIdx.x == 0) atomicAdd(&P.gbias[c], pb[0]);
+        double v[4];
+        {
+            const float pf[4] = {p_du, p_out, p_slope, p_bias};
+            block_sum_f32w<4>(pf, predf, v);
         }
-        double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
-        block_sum<double, 3>(v, pred);
+        // ONE atomic per row (per-wave atomics on the same 512 addresses cost 1.6 ms/step)
+        if (threadIdx.x == 0 && P.gbias != nullptr) atomicAdd(&P.gbias[c], (float)v[3]);
         if (threadIdx.x == 0) {
             double* slot = P.gacc + 3 * (row % kSlots);
             const double dmax = v[0] / 255.0;
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
     constexpr int NT = KT ? KT : kTaps;
     if (KT) K = KT;
     extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
-    __shared__ double red[(4 + kTaps) * 4];
+    __shared__ float redf[(4 + kTaps) * 4];
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     const int row = blockIdx.x, c = row % C;
@@ -704,10 +708,13 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
     }
 
     double v[4 + NT];
-    v[0] = (double)p_du; v[1] = (double)p_out; v[2] = (double)p_slope; v[3] = (double)p_bias;
+    {
+        float pf[4 + NT];
+        pf[0] = p_du; pf[1] = p_out; pf[2] = p_slope; pf[3] = p_bias;
 #pragma unroll
-    for (int k = 0; k < NT; ++k) v[4 + k] = (double)pw[k];
-    block_sum<double, 4 + NT>(v, red);
+        for (int k = 0; k < NT; ++k) pf[4 + k] = pw[k];
+        block_sum_f32w<4 + NT>(pf, redf, v);
+    }
     if (threadIdx.x == 0) {
         double* slot = gacc + 3 * (row % kSlots);
         const double dmax = v[0] / 255.0;
@@ -838,7 +845,6 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
                                                   int ld_g, int ld_gz, int act, const float* slope_p, const float* amin,
                                                   const float* amax, const float* bmin, const float* bmax, const float* qmin,
                                                   const float* qmax, double* gacc, EwProducer PA, EwProducer PB, int C) {
-    __shared__ double red[3 * 4];
     __shared__ float redf[2 * 4];
     const bool fa = PA.pz != nullptr, fb = PB.pz != nullptr;
     const float sla = (fa && PA.act == FQSS_ACT_PRELU) ? *PA.slope : 0.0f, slb = (fb && PB.act == FQSS_ACT_PRELU) ? *PB.slope : 0.0f;
@@ -944,29 +950,37 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
             if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[blockIdx.y % C], pb[1]);
         }
     }
-    double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
-    block_sum<double, 3>(v, red);
-    if (threadIdx.x == 0) {
-        double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
-        const double dmax = v[0] / 255.0;
-        slot[0] += v[1] - dmax;
-        slot[1] += dmax;
-        slot[2] += v[2];
+    // Reduction tail: fp32 sums over the 64 lanes of a wave (shuffles only), then ONE fp64 atomic per wave and value into the
+    // workgroup's own slot.  (The first form -- block_sum<double> per group of values: 64-bit shuffles, LDS, two barriers each --
+    // cost 4.5-5 us of this 30 us kernel, measured by ablation.)
+    const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;   // < kSlots: one workgroup per slot
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    {
+        const float du = wave_sum(p_du), po = wave_sum(p_out), ps = wave_sum(p_slope);
+        if (lane0) {
+            double* slot = gacc + 3 * sid;
+            const double dmax = (double)du / 255.0;
+            atomicAdd(&slot[0], (double)po - dmax);
+            atomicAdd(&slot[1], dmax);
+            if (act == FQSS_ACT_PRELU) atomicAdd(&slot[2], (double)ps);
+        }
     }
-    if (fa || fb) {
-        const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;   // < kSlots: one workgroup per slot, like above
-        double va[3] = {(double)a_du, (double)a_out, (double)a_sl}, vb[3] = {(double)b_du, (double)b_out, (double)b_sl};
-        block_sum<double, 3>(va, red);
-        block_sum<double, 3>(vb, red);
-        if (threadIdx.x == 0) {
-            if (fa) {
-                const double dmax = va[0] / 255.0;
-                PA.gacc[3 * sid] += va[1] - dmax; PA.gacc[3 * sid + 1] += dmax; PA.gacc[3 * sid + 2] += va[2];
-            }
-            if (fb) {
-                const double dmax = vb[0] / 255.0;
-                PB.gacc[3 * sid] += vb[1] - dmax; PB.gacc[3 * sid + 1] += dmax; PB.gacc[3 * sid + 2] += vb[2];
-            }
+    if (fa) {
+        const float du = wave_sum(a_du), po = wave_sum(a_out), ps = wave_sum(a_sl);
+        if (lane0) {
+            const double dmax = (double)du / 255.0;
+            atomicAdd(&PA.gacc[3 * sid], (double)po - dmax);
+            atomicAdd(&PA.gacc[3 * sid + 1], dmax);
+            if (PA.act == FQSS_ACT_PRELU) atomicAdd(&PA.gacc[3 * sid + 2], (double)ps);
+        }
+    }
+    if (fb) {
+        const float du = wave_sum(b_du), po = wave_sum(b_out), ps = wave_sum(b_sl);
+        if (lane0) {
+            const double dmax = (double)du / 255.0;
+            atomicAdd(&PB.gacc[3 * sid], (double)po - dmax);
+            atomicAdd(&PB.gacc[3 * sid + 1], dmax);
+            if (PB.act == FQSS_ACT_PRELU) atomicAdd(&PB.gacc[3 * sid + 2], (double)ps);
         }
     }
 }
