@@ -111,23 +111,43 @@ DUALPATH = {"cfg3": dict(name="DPTNet", cfg={"name": "DPTNet", "n_src": 2, "kern
                          gemm=(256, 1024, "feed-forward 256 -> 1024"))}
 
 
-def rowgemm_roofline(rows, Ci, Co, what):
-    """the row GEMM that carries most of the MFMA work of the dual-path models, at this workload's shape: HIP events on
-    torch's current stream (the stream the kernel is launched on); peak = fp32 MFMA (the arithmetic it is equivalent to)"""
-    from fqss_amd import kernels as K
-    x, w, b = torch.randn(rows, Ci, device="cuda"), torch.randn(Co, Ci, device="cuda"), torch.randn(Co, device="cuda")
+def _time_launches(fn, iters=20):
     for _ in range(3):
-        K.rowlin_fwd(x, w, b)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20):
-        K.rowlin_fwd(x, w, b)
+    for _ in range(iters):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
+    """`roofline` of a dual-path workload = the kernel with the largest time per step in the committed steady-state table
+    (profiles/r02_cfg3_step_table.txt: k_lstm_fwd<128>, 18.6 % of the step; profiles/r02_cfg4_step_table.txt: the weight-gradient
+    instance of k_gemm_x3, 14.1 %), timed live at this workload's shape with HIP events on torch's current stream; priced against
+    the fp32 peak (157.3 TFLOP/s: vector = matrix rate for f32) whose arithmetic it performs."""
+    from fqss_amd import kernels as K
+    if which == "cfg3":
+        S, Bq, H = seqs[0], seqs[1], 128            # intra-chunk BiLSTM: 250 steps x (chunks) sequences, both directions in one launch
+        pre = torch.randn(S, Bq, 8 * H, device="cuda") * 0.1
+        whh, bhh = torch.randn(2, 4 * H, H, device="cuda") * 0.05, torch.zeros(2, 4 * H, device="cuda")
+        us = _time_launches(lambda: K.lstm_fwd(pre, whh, bhh, S, Bq, H), 10)
+        flops = 2.0 * 2 * (4 * H) * H * S * Bq       # the recurrent product h W_hh^T of both directions
+        tf = flops / us * 1e-6
+        return {"kernel": "k_lstm_fwd<128>", "what": "BiLSTM recurrence of the intra-chunk path (both directions)", "shape": [S, Bq, H],
+                "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 24, "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+                "frac": round(tf / 157.3, 3), "traffic": None,
+                "note": "fp32 FMA issue + 2 barriers per time step bound; with 194 / 250 sequences per launch an MFMA form (>= 16 sequences per "
+                        "workgroup) leaves < 16 workgroups on 256 CUs and is slower (DESIGN.md 7)"}
+    x, gz = torch.randn(rows, Ci, device="cuda"), torch.randn(rows, Co, device="cuda")
+    gw = torch.zeros(Co, Ci, device="cuda")
+    us = _time_launches(lambda: K.rowlin_bwd_w(gz, x, gw))
     tf = 2.0 * rows * Ci * Co / us * 1e-6
-    return {"kernel": "k_gemm_x3 (fqss_rowlin_fwd)", "what": what, "shape": [rows, Ci, Co], "bound": "mfma", "launch_us": round(us, 1),
-            "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
+    return {"kernel": "k_gemm_x3<false, false, true, 1, 2> (fqss_rowlin_bwd_w)", "what": "weight gradient of the " + what, "shape": [rows, Ci, Co],
+            "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 129, "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": round(tf / 157.3, 3), "traffic": None}
 
 
 def cpu_baseline_dualpath(which, model, fmodel, lr, T):
@@ -217,7 +237,7 @@ def main_dualpath(a):
                           "optimizer": f"adam lr {W['lr']:g} + clip 5.0", "launch": launch},
                "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
                "params": sum(p.numel() for p in model.parameters()),
-               "roofline": rowgemm_roofline(rows, *W["gemm"])}
+               "roofline": dominant_kernel_roofline_dualpath(a.workload, rows, *W["gemm"], seqs=(250, dp_chunks(L, 250)[1]))}
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dualpath(a.workload, model, fmodel, W["lr"], T)
         print(json.dumps(out), flush=True)
@@ -442,7 +462,7 @@ def main():
                           "optimizer": f"adam lr {W['lr']:g} + clip 5.0", "launch": launch},
                "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
                "params": sum(p.numel() for p in model.parameters()),
-               "roofline": rowgemm_roofline(rows, *W["gemm"])}
+               "roofline": dominant_kernel_roofline_dualpath(a.workload, rows, *W["gemm"], seqs=(250, dp_chunks(L, 250)[1]))}
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dualpath(a.workload, model, fmodel, W["lr"], T)
         print(json.dumps(out), flush=True)
