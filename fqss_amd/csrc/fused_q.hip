@@ -252,19 +252,51 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
                                                         const float* __restrict__ mean_rstd, float* __restrict__ gx, int B,
                                                         int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx,
                                                         const double* ws, const float* qmin_x, const float* qmax_x,
-                                                        const float* qmin, const float* qmax, GnProducer P) {
+                                                        const float* qmin, const float* qmax, GnProducer P, float* ggamma,
+                                                        float* gbeta) {
     __shared__ float predf[4 * 4];
     const QRange rp = FUSE ? load_qrange(P.qmin, P.qmax) : QRange{0.f, 1.f, 1.f};
     const float pslope = (FUSE && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
-    const double* coef = ws + 2 * (int64_t)B * C;
     const int c = blockIdx.x, b = blockIdx.y;
     const int64_t row = (int64_t)b * C + c;
     const float mean = mean_rstd[2 * b], rstd = mean_rstd[2 * b + 1];
     const float scale = rstd * gamma[c];
     const float shift = fmaf(-scale, mean, beta[c]);
-    const float c2 = (float)coef[2 * b], c3 = (float)coef[2 * b + 1];
+    // The per-sample coefficients c2, c3 need sum_c gamma_c (ds, db)[b][c] over the row sums of pass 1: every workgroup reduces the
+    // C pairs of ITS sample itself (16 B x C from L2, fixed order: deterministic) instead of a separate coefficient launch; the
+    // workgroups of sample 0 also finish the gamma / beta gradients of their channel (a B-term sum).
+    __shared__ double cred[2 * 4];
+    __shared__ float c23[2];
+    {
+        double sv[2] = {0.0, 0.0};
+        for (int cc = threadIdx.x; cc < C; cc += 256) {
+            const double gmm = (double)gamma[cc];
+            sv[0] += gmm * ws[2 * ((int64_t)b * C + cc)];
+            sv[1] += gmm * ws[2 * ((int64_t)b * C + cc) + 1];
+        }
+        block_sum<double, 2>(sv, cred);
+        if (threadIdx.x == 0) {
+            const double md = (double)mean, rd = (double)rstd;
+            const double inv_n = 1.0 / ((double)C * (double)M);
+            const double c2d = (sv[1] * md - sv[0]) * rd * rd * rd * inv_n;
+            c23[0] = (float)c2d;
+            c23[1] = (float)(-c2d * md - sv[1] * rd * inv_n);
+            if (b == 0) {
+                double gg = 0.0, gb = 0.0;
+                for (int bb = 0; bb < B; ++bb) {
+                    const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
+                    gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
+                    gb += db;
+                }
+                ggamma[c] += (float)gg;
+                gbeta[c] += (float)gb;
+            }
+        }
+        __syncthreads();
+    }
+    const float c2 = c23[0], c3 = c23[1];
     const uint8_t* xr = xc + row * ld_xc;
     const float* gr = g + row * ld_g;
     const float* pzr = FUSE ? P.pz + row * P.ld_pz : nullptr;
@@ -985,43 +1017,6 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
     }
 }
 
-// shared with stream_ops.hip's GroupNorm backward
-__global__ void k_gnq_bwd_coef(const float* __restrict__ gamma, const float* __restrict__ mean_rstd, int B, int C, int M,
-                               double* ws, float* ggamma, float* gbeta) {
-    __shared__ double red[2 * 4];
-    const int b = blockIdx.x;
-    double* coef = ws + 2 * (int64_t)B * C;
-    if (b < B) {
-        double s_ds = 0.0, s_db = 0.0;
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const double gmm = (double)gamma[c];
-            s_ds += gmm * ws[2 * ((int64_t)b * C + c)];
-            s_db += gmm * ws[2 * ((int64_t)b * C + c) + 1];
-        }
-        double v[2] = {s_ds, s_db};
-        block_sum<double, 2>(v, red);
-        if (threadIdx.x == 0) {
-            const double mean = (double)mean_rstd[2 * b], rstd = (double)mean_rstd[2 * b + 1];
-            const double inv_n = 1.0 / ((double)C * (double)M);
-            const double c2 = (v[1] * mean - v[0]) * rstd * rstd * rstd * inv_n;
-            coef[2 * b] = c2;
-            coef[2 * b + 1] = -c2 * mean - v[1] * rstd * inv_n;
-        }
-    } else {
-        const int c = (b - B) * 256 + threadIdx.x;
-        if (c < C) {
-            double gg = 0.0, gb = 0.0;
-            for (int bb = 0; bb < B; ++bb) {
-                const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
-                gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
-                gb += db;
-            }
-            ggamma[c] += (float)gg;
-            gbeta[c] += (float)gb;
-        }
-    }
-}
-
 }  // namespace fqss
 
 using namespace fqss;
@@ -1078,14 +1073,12 @@ static int gnq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x,
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_gnq_bwd_rows, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, C, M,
                        ld_xc, ld_g, ws, qmin_x, qmax_x, qmin, qmax, gacc);
-    hipLaunchKernelGGL(k_gnq_bwd_coef, dim3((unsigned)(B + cdiv(C, 256))), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
-                       ggamma, gbeta);
     if (P.pz != nullptr)
         hipLaunchKernelGGL(k_gnq_bwd_apply<true>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C,
-                           M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P);
+                           M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P, ggamma, gbeta);
     else
         hipLaunchKernelGGL(k_gnq_bwd_apply<false>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C,
-                           M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P);
+                           M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P, ggamma, gbeta);
     return launch_status(who);
 }
 

@@ -115,11 +115,11 @@ def build(dev, sets=3):
          lambda i: K.actq_bwd(z_b[i % sets], gz_b[i % sets], 0, None, 2, lo, hi, gacc, gbias=gb_b, C=NB))
     case("k_axpby", "gradient sum at the residual fork, C=128", "hbm", 24, 8.0 * NB * n, 4.0 * NB * n, 12.0 * NB * n,
          lambda i: K.axpby(gz_b[i % sets], gz_b2[i % sets], 1.0))
-    # ---- the two-pass gLN backward (rows + coefficients + apply: three launches, timed as a whole; never picked as `roofline`)
-    case("k_gnq_bwd_rows+coef+apply<true>", "gLN+fq backward (2 passes) with the producer conv's STE/PReLU/range/bias backward fused, C=512", "hbm", 24,
+    # ---- the two-pass gLN backward (rows + apply: two launches, timed as a whole; never picked as `roofline`)
+    case("k_gnq_bwd_rows+apply<true>", "gLN+fq backward (2 passes) with the producer conv's STE/PReLU/range/bias backward fused, C=512", "hbm", 24,
          14.0 * NH * n, 4.0 * NH * n, 20.0 * NH * n,
          lambda i: K.gnq_bwd(xc_h[i % sets], lo, hi, gz_h[i % sets], gm_, bt_, mr, lo, hi, gacc, gg, gb2, producer=(z_h[i % sets], 1, slope, pgacc, gbb)), group=True)
-    case("k_gnq_bwd_rows+coef+apply<false>", "gLN+fq backward (2 passes, plain), C=512", "hbm", 25, 10.0 * NH * n, 4.0 * NH * n, 16.0 * NH * n,
+    case("k_gnq_bwd_rows+apply<false>", "gLN+fq backward (2 passes, plain), C=512", "hbm", 25, 10.0 * NH * n, 4.0 * NH * n, 16.0 * NH * n,
          lambda i: K.gnq_bwd(xc_h[i % sets], lo, hi, gz_h[i % sets], gm_, bt_, mr, lo, hi, gacc, gg, gb2), group=True)
     return cases
 

@@ -37,8 +37,8 @@ def run():
 
 def _members(kernel):
     """kernel-name substrings of a case's launches, in launch order"""
-    if kernel.startswith("k_gnq_bwd_rows+coef+apply"):
-        return ["k_gnq_bwd_rows", "k_gnq_bwd_coef", "k_gnq_bwd_apply"]
+    if kernel.startswith("k_gnq_bwd_rows+apply"):
+        return ["k_gnq_bwd_rows", "k_gnq_bwd_apply"]
     return [kernel.split("<")[0] if kernel.startswith(("k_dwq", "k_tgemm")) else kernel]
 
 
