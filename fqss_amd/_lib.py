@@ -31,6 +31,7 @@ _PROTOS = {
     "fqss_wq_codes": [P, P, P, P, P, I32, I32, P, P, P],
     "fqss_qpw_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_bwd_x": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_qpw_bwd_x_add": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_fwdq": [P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P],
     "fqss_qpw_stat_slots": [I32, I32],

@@ -395,7 +395,15 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             for (int pass = 0; pass < 4; ++pass) {
                 const int rl = pass * 8 + (lane >> 3);
                 const int row = rowt + rl;
-                const float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
+                float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
+                if constexpr (MODE == 1) {
+                    // dgrad, optional: + an addend of the output's shape (the gradient of the other branch of a residual fork: the sum
+                    // that autograd would take in a pass of its own); rows are padded to a multiple of 4, so the float4 is in bounds
+                    if (C2b != nullptr && row < g.M && col < g.N) {
+                        const float4 r = *reinterpret_cast<const float4*>(C2b + (int64_t)row * g.ldc2 + col);
+                        t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+                    }
+                }
                 if (row < g.M && col < g.N) {
                     const bool first = decltype(PER_ROW)::value ? row < g.M1 : tfirst;
                     const int64_t ldc = first ? g.ldc : g.ldc2;
@@ -874,7 +882,8 @@ extern "C" int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* d
 }
 
 static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B,
-                          int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_gx, fqss_stream_t stream) {
+                          int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_gx, fqss_stream_t stream,
+                          const float* addend = nullptr, int64_t ld_add = 0) {
     if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     const int Co = Co1 + Co2;
     FQSS_REQUIRE(gz1 && wiT && dw && gx && (Co2 == 0 || gz2), "null tensor");
@@ -891,6 +900,10 @@ static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, c
     g.sAb = 0; g.sBb = (int64_t)Co1 * ld_gz1; g.sCb = (int64_t)Ci * ld_gx;
     g.M1 = Ci; g.K1 = Co1; g.B2 = gz2; g.ldb2 = ld_gz2; g.sB2b = (int64_t)Co2 * ld_gz2;
     g.dw = dw; g.ksplit = 1; g.kchunk = Co;
+    if (addend != nullptr) {
+        FQSS_REQUIRE(aligned16(addend) && ld_add % 4 == 0 && ld_add >= ((M + 3) & ~3), "addend rows must be 16-B aligned and padded to 4");
+        g.C2 = const_cast<float*>(addend); g.ldc2 = ld_add; g.sC2b = (int64_t)Ci * ld_add;
+    }
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Ci, QBM); g.batches = B;
     hipLaunchKernelGGL((k_qgemm<1>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status(who);
@@ -899,6 +912,14 @@ static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, c
 extern "C" int fqss_qpw_bwd_x(const float* gz, const int8_t* wiT, const float* dw, float* gx, int B, int Ci, int Co,
                               int M, int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream) {
     return qpw_bwd_x_impl("fqss_qpw_bwd_x", gz, nullptr, wiT, dw, gx, B, Ci, Co, 0, M, ld_gz, 0, ld_gx, stream);
+}
+
+/* fqss_qpw_bwd_x that also adds `addend` [B][Ci][ld_add] (the gradient arriving over the other branch of a residual fork) in its
+ * epilogue: gx = W_q^T gz + addend */
+extern "C" int fqss_qpw_bwd_x_add(const float* gz, const int8_t* wiT, const float* dw, const float* addend, float* gx, int B, int Ci, int Co,
+                                  int M, int64_t ld_gz, int64_t ld_add, int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(addend, "null addend");
+    return qpw_bwd_x_impl("fqss_qpw_bwd_x_add", gz, nullptr, wiT, dw, gx, B, Ci, Co, 0, M, ld_gz, 0, ld_gx, stream, addend, ld_add);
 }
 
 extern "C" int fqss_qpw_bwd_x2(const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B, int Ci,

@@ -254,7 +254,8 @@ def qpw_fwd(xc, wc, bias, qmin_x, qmax_x):
     return z
 
 
-def qpw_bwd_x(gz, wc):
+def qpw_bwd_x(gz, wc, add=None):
+    """gx = W_q^T gz (+ add: a tensor of gx's shape summed in the epilogue -- the gradient of the other branch of a residual fork)"""
     assert wc.idxT is not None, "this layer's codes live in a concatenated pair image: use qpw_bwd_x2"
     gz, B, Co, M, ld_gz = _bcm(gz)
     if ld_gz % 4 != 0 or gz.data_ptr() % 16 != 0:
@@ -262,7 +263,12 @@ def qpw_bwd_x(gz, wc):
         c.copy_(gz)
         gz, ld_gz = c, rowmat(c)[2]
     gx = empty_act((B, wc.Ci, M), gz.device)
-    _lib.call("fqss_qpw_bwd_x", _p(gz), _p(wc.idxT), _p(wc.dw), _p(gx), B, wc.Ci, Co, M, ld_gz, rowmat(gx)[2], _stream())
+    if add is not None:
+        assert tuple(add.shape) == (B, wc.Ci, M)
+        add, ld_add = _aligned_grad(add)
+        _lib.call("fqss_qpw_bwd_x_add", _p(gz), _p(wc.idxT), _p(wc.dw), _p(add), _p(gx), B, wc.Ci, Co, M, ld_gz, ld_add, rowmat(gx)[2], _stream())
+    else:
+        _lib.call("fqss_qpw_bwd_x", _p(gz), _p(wc.idxT), _p(wc.dw), _p(gx), B, wc.Ci, Co, M, ld_gz, rowmat(gx)[2], _stream())
     return gx
 
 

@@ -422,6 +422,7 @@ class LinearActQ(Function):
                 and getattr(q.owner, "_fqss_deferred", False):
             ctx.prod = q.prod = _Producer(z, act, slope, L.slope_param, q, L.b_param, bias)
         ctx.x_shape = x.shape
+        ctx.fork = getattr(x, "_fqss_fork", None) if (ctx.wc is not None and ctx.wc.idxT is not None) else None
         ctx.save_for_backward(None if (ctx.xq is not None and ctx.wc is not None) else x, w, None if ctx.plain else z, slope)
         ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
         ctx.bias_like = bias
@@ -445,7 +446,12 @@ class LinearActQ(Function):
                 bias_like=ctx.bias_like if ctx.has_bias else None, C=ctx.C)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)
+            fk = ctx.fork
+            if ctx.wc is not None and fk is not None and fk.other is not None and tuple(fk.other.shape) == tuple(ctx.x_shape):
+                gx = K.qpw_bwd_x(gz, ctx.wc, add=fk.other)     # + the gradient of the fork's other branch: no separate sum pass
+                fk.fused = True
+            else:
+                gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)
         gw = None
         gwq = getattr(w, "_fqss_gwq", None)    # deferred mode: dL/dW_q accumulates in the step's arena
         if ctx.needs_input_grad[1] or gwq is not None:
@@ -619,6 +625,7 @@ class EwQ(Function):
         # operands that are fresh outputs of pointwise convs with no other consumer (tagged by run_conv1d_pair)
         ctx.prod_a = getattr(a, "_fqss_prod", None)
         ctx.prod_b = getattr(b, "_fqss_prod", None) if (b is not None and bq_ is not None and sb == 1.0) else None
+        ctx.fork_a = getattr(a, "_fqss_fork", None)      # operand a is one branch of a residual fork (ops._ForkState)
         return _carrier(out) if q.carrier else out
 
     @staticmethod
@@ -639,6 +646,8 @@ class EwQ(Function):
             gz, gza, gzb = K.ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, ctx.sb, g, ctx.act, slope, qmin, qmax, q.gacc), None, None
         g_slope, g_min, g_max = _flush_ranges(q, slope, ctx.sp, ctx.act)
         ga = (gza if gza is not None else gz) if ctx.needs_input_grad[0] else None
+        if ga is not None and ctx.fork_a is not None:
+            ctx.fork_a.other = ga        # the fork's first branch (a q-GEMM dgrad) may add it in its epilogue
         gb = None
         if ctx.has_b and ctx.needs_input_grad[1]:
             if gzb is not None:
@@ -759,26 +768,45 @@ def splitter2(x):
         return K.splitter2(x)
 
 
+class _ForkState:
+    """lets the dgrad q-GEMM of the fork's FIRST branch add the gradient of the SECOND branch in its epilogue (FUSE_FORK): the second
+    branch's backward (an element-wise LayerQ, created later in the forward => run earlier in the backward) leaves its gradient in
+    `other`; the first branch's LinearActQ.backward consumes it and sets `fused`, and Fork2.backward then passes g1 through"""
+    __slots__ = ("other", "fused")
+
+    def __init__(self):
+        self.other, self.fused = None, False
+
+
+FUSE_FORK = os.environ.get("FQSS_FUSE_FORK", "1") != "0"
+
+
 class Fork2(Function):
     """identity with two consumers: the two incoming gradients are summed by the padded HIP axpby
     (autograd's own accumulation would densify the row stride and push consumers onto the scalar path)"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, fk):
+        ctx.fk = fk
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
     def backward(ctx, g1, g2):
+        fk = ctx.fk
+        fused, fk.fused, fk.other = fk.fused, False, None
         if g1 is None:
-            return g2
-        if g2 is None:
-            return g1
-        return K.axpby(g1, g2, 1.0)
+            return g2, None
+        if g2 is None or fused:        # fused: g1 already holds the sum (fqss_qpw_bwd_x_add)
+            return g1, None
+        return K.axpby(g1, g2, 1.0), None
 
 
 def fork2(x):
     if torch.is_grad_enabled() and x.requires_grad:
-        a, b = Fork2.apply(x)
+        fk = _ForkState()
+        a, b = Fork2.apply(x, fk)
+        if FUSE_FORK:
+            a._fqss_fork = b._fqss_fork = fk
         c = codes_of(x)
         if c is not None:
             a._fqss_q = b._fqss_q = c

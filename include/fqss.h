@@ -161,6 +161,9 @@ int fqss_qpw_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, cons
  * reference conv_tasnet ConvBlock) as ONE GEMM over the concatenated output channels: wi [Co1+Co2][Ci],
  * wiT [Ci][Co1+Co2], dw/rw [Co1+Co2], gw [Co1+Co2][Ci]; the per-layer activations / gradients stay separate
  * tensors.  bwd_x2 returns the SUM of both layers' input gradients (autograd's accumulation of the fork). */
+/* fqss_qpw_bwd_x + an addend of the output's shape in the epilogue (gradient of the other branch of a residual fork) */
+int fqss_qpw_bwd_x_add(const float* gz, const int8_t* wiT, const float* dw, const float* addend, float* gx, int B, int Ci,
+                       int Co, int M, int64_t ld_gz, int64_t ld_add, int64_t ld_gx, fqss_stream_t stream);
 int fqss_qpw_fwd2(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
                   const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, int B,
                   int Ci, int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2,
