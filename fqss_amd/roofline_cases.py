@@ -113,7 +113,7 @@ def build(dev, sets=3):
     gb_b = torch.zeros(NB, device=dev)
     case("k_actq_bwd", "activation fake-quant backward (bottleneck / mask convs), C=128", "hbm", 4, 8.0 * NB * n, 4.0 * NB * n, 12.0 * NB * n,
          lambda i: K.actq_bwd(z_b[i % sets], gz_b[i % sets], 0, None, 2, lo, hi, gacc, gbias=gb_b, C=NB))
-    case("k_axpby", "gradient sum at the residual fork, C=128", "hbm", 24, 8.0 * NB * n, 4.0 * NB * n, 12.0 * NB * n,
+    case("k_axpby", "gradient sum at a fork (decoder / encoder side; the residual forks are summed in the dgrad epilogue), C=128", "hbm", 4, 8.0 * NB * n, 4.0 * NB * n, 12.0 * NB * n,
          lambda i: K.axpby(gz_b[i % sets], gz_b2[i % sets], 1.0))
     # ---- the two-pass gLN backward (rows + apply: two launches, timed as a whole; never picked as `roofline`)
     case("k_gnq_bwd_rows+apply<true>", "gLN+fq backward (2 passes) with the producer conv's STE/PReLU/range/bias backward fused, C=512", "hbm", 24,
