@@ -124,8 +124,42 @@ _PROTOS = {
     "fqss_resample_fir": [P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P],
     "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
     "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
+    # descriptor-struct forms (csrc/desc_api.hip); the structs are below
+    "fqss_workspace_bytes": [C.c_char_p, P, I32],
+    "fqss_add_fq_fwd": [P, P, P, P, F32, P, P, P, P, C.c_size_t, P],
+    "fqss_add_fq_bwd": [P, P, P, P, F32, P, P, P, P, P, P, C.c_size_t, P],
+    "fqss_pwconv_fq_fwd": [P, P, P, P, P, P, P, P, P, P, P, P, C.c_size_t, P],
+    "fqss_gln_fq_fwd": [P, P, P, P, F32, P, P, P, P, P, C.c_size_t, P, I32, P],
+    "fqss_tgemm_desc": [P, P],
 }
-_RESTYPE = {"fqss_last_error": C.c_char_p}
+_RESTYPE = {"fqss_last_error": C.c_char_p, "fqss_workspace_bytes": C.c_int64}
+
+DT_F32, DT_U8, DT_I8, DT_F64, DT_U16, DT_I64 = range(6)
+
+
+class FqssTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dtype", C.c_int), ("ndim", C.c_int), ("shape", C.c_int64 * 4), ("stride", C.c_int64 * 4)]
+
+
+class FqssQParams(C.Structure):
+    _fields_ = [("qmin", C.c_void_p), ("qmax", C.c_void_p), ("act", C.c_int), ("slope", C.c_void_p), ("gacc", C.c_void_p)]
+
+
+class FqssWCodes(C.Structure):
+    _fields_ = [("idx", C.c_void_p), ("idxT", C.c_void_p), ("dw", C.c_void_p), ("rw", C.c_void_p), ("Co", C.c_int), ("Ci", C.c_int)]
+
+
+class FqssProducer(C.Structure):
+    _fields_ = [("z", C.POINTER(FqssTensor)), ("act", C.c_int), ("slope", C.c_void_p), ("gacc", C.c_void_p), ("gbias", C.c_void_p),
+                ("out", C.POINTER(FqssTensor))]
+
+
+class FqssTGemmDesc(C.Structure):
+    _fields_ = [("planes", C.POINTER(FqssTensor)), ("x", C.POINTER(FqssTensor)), ("pro", C.c_int), ("pro_stats", C.c_void_p),
+                ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p), ("pro_eps", C.c_float), ("pro_slope", C.c_void_p),
+                ("bias", C.c_void_p), ("act", C.c_int), ("slope", C.c_void_p), ("stats_out", C.c_void_p), ("M1", C.c_int),
+                ("c1", C.POINTER(FqssTensor)), ("r1", C.POINTER(FqssTensor)), ("c2", C.POINTER(FqssTensor)),
+                ("r2", C.POINTER(FqssTensor))]
 
 EXPORTS = tuple(_PROTOS)
 
@@ -171,11 +205,11 @@ def call(name, *args):
 
 
 def query(name, *args):
-    """entry points that return a count instead of a status (fqss_*_stat_slots)"""
+    """entry points that return a count instead of a status (fqss_*_stat_slots, fqss_workspace_bytes)"""
     fn = _bound.get(name)
     if fn is None:
         fn = getattr(load(), name)
         fn.argtypes = _PROTOS[name]
-        fn.restype = C.c_int
+        fn.restype = _RESTYPE.get(name, C.c_int)
         _bound[name] = fn
     return fn(*args)

@@ -601,6 +601,81 @@ int fqss_snr_mix(const float* a, const float* b, const float* snr, double* ws, u
 int fqss_resample_fir(const float* x, const float* h, float* y, int64_t rows, int64_t L, int64_t Lout, int64_t ld_x, int64_t ld_y,
                       int orig, int newf, int width, fqss_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Descriptor-struct forms of the long entry points ("fqss_<op>_{fwd,bwd}(const FqssTensor* in..,
+ * FqssTensor* out.., const FqssQParams*, void* workspace, size_t ws_bytes, void* hip_stream)").  Same kernels, same
+ * results as the flat forms above (tests/test_gpu_desc_api.py compares them bit for bit); the library validates dtype,
+ * rank, innermost-contiguity and the workspace size from the descriptors before it launches anything.
+ * ------------------------------------------------------------------------------------------- */
+#define FQSS_DT_F32 0
+#define FQSS_DT_U8 1  /* activation codes */
+#define FQSS_DT_I8 2  /* weight codes */
+#define FQSS_DT_F64 3
+#define FQSS_DT_U16 4 /* bf16 planes of the frozen teacher weights */
+#define FQSS_DT_I64 5
+typedef struct FqssTensor {
+    void* data;        /* caller-owned device pointer */
+    int dtype;         /* FQSS_DT_* */
+    int ndim;          /* 1..4 */
+    int64_t shape[4];
+    int64_t stride[4]; /* elements; the innermost stride must be 1 */
+} FqssTensor;
+typedef struct FqssQParams { /* one activation quantizer (GradientActivationFakeQuantize, qat_quant.py:171-249) */
+    const float* qmin;       /* device scalars min_range / max_range */
+    const float* qmax;
+    int act;                 /* FQSS_ACT_* in front of the quantizer */
+    const float* slope;      /* PReLU slope (device scalar) or NULL */
+    double* gacc;            /* backward only: range / slope gradient partials (+=), or NULL */
+} FqssQParams;
+typedef struct FqssWCodes { /* per-channel int8 weight codes of a pointwise conv, from fqss_wq_codes / fqss_wq_multi_fwd */
+    const int8_t* idx;      /* [Co][Ci] */
+    const int8_t* idxT;     /* [Ci][Co] */
+    const float* dw;        /* [Co] step */
+    const float* rw;        /* [Co] integer row sums */
+    int Co, Ci;
+} FqssWCodes;
+typedef struct FqssProducer { /* a pointwise conv whose output-quantizer backward rides in its consumer's backward kernel */
+    const FqssTensor* z;      /* its pre-quant output [B][C][M] fp32 */
+    int act;
+    const float* slope;
+    double* gacc;             /* its range / slope partials (+=) */
+    float* gbias;             /* [C] (+=) or NULL */
+    FqssTensor* out;          /* receives dL/dz of that layer */
+} FqssProducer;
+typedef struct FqssTGemmDesc { /* one launch of the teacher chain's GEMM (fqss_tgemm) */
+    const FqssTensor* planes;  /* [3][Co][Ci] u16 */
+    const FqssTensor* x;       /* [B][Ci][M] fp32 */
+    int pro;                   /* 0 none | 1 GroupNorm affine | 2 PReLU on the input */
+    const double* pro_stats; const float* pro_gamma; const float* pro_beta; float pro_eps; const float* pro_slope;
+    const float* bias; int act; const float* slope;
+    double* stats_out;         /* nullable */
+    int M1;                    /* rows [0,M1) -> c1 (+r1), the rest -> c2 (+r2) */
+    FqssTensor* c1; const FqssTensor* r1; FqssTensor* c2; const FqssTensor* r2;
+} FqssTGemmDesc;
+
+/* bytes of caller-provided workspace an op needs for activations of `shape` = {B, C, M}; ops: "gln_fq_fwd", "gln_fq_bwd",
+ * "pwconv_fq_fwd" (C = Co: the optional code-statistics slots), "dwconv_fq_fwd" (same), "add_fq_fwd", "add_fq_bwd",
+ * "tgemm" (0).  Unknown op / bad shape: -1 (fqss_last_error says which). */
+int64_t fqss_workspace_bytes(const char* op, const int64_t* shape, int ndim);
+/* AddQ / Sub / NlQ on codes (fqss_ewq_fwd): b / qb NULL for the unary form; b of dtype F32 is a real operand; y_out nullable */
+int fqss_add_fq_fwd(const FqssTensor* a, const FqssQParams* qa, const FqssTensor* b, const FqssQParams* qb, float sb,
+                    FqssTensor* y, FqssTensor* y_out, const FqssQParams* q, void* ws, size_t ws_bytes, fqss_stream_t stream);
+/* its backward (fqss_ewq_bwd, or fqss_ewq_bwd_p when pa / pb name producers; then b must be codes and gz may be NULL) */
+int fqss_add_fq_bwd(const FqssTensor* a, const FqssQParams* qa, const FqssTensor* b, const FqssQParams* qb, float sb,
+                    const FqssTensor* g, FqssTensor* gz, const FqssQParams* q, const FqssProducer* pa, const FqssProducer* pb,
+                    void* ws, size_t ws_bytes, fqss_stream_t stream);
+/* Conv1dQ / Conv1dNlQ 1x1 on codes with the output quantizer fused (fqss_qpw_fwdq); w holds Co1 + Co2 rows; the second
+ * layer's tensors are NULL for a single conv.  ws: when ws_bytes >= fqss_workspace_bytes("pwconv_fq_fwd") > 0 and Co2 = 0 the
+ * statistics slots of y1 are written there ([B][slots][2] int64) for fqss_gln_fq_fwd */
+int fqss_pwconv_fq_fwd(const FqssTensor* x, const FqssQParams* qx, const FqssWCodes* w, const float* bias1, const float* bias2,
+                       FqssTensor* z1, FqssTensor* z2, FqssTensor* y1, FqssTensor* y2, const FqssQParams* q1,
+                       const FqssQParams* q2, void* ws, size_t ws_bytes, fqss_stream_t stream);
+/* GroupNormQ on codes (fqss_gnq_fwd); stats / nslots as there (then ws may be NULL) */
+int fqss_gln_fq_fwd(const FqssTensor* x, const FqssQParams* qx, const float* gamma, const float* beta, float eps, FqssTensor* y,
+                    FqssTensor* y_out, float* mean_rstd, const FqssQParams* q, void* ws, size_t ws_bytes, const int64_t* stats,
+                    int nslots, fqss_stream_t stream);
+int fqss_tgemm_desc(const FqssTGemmDesc* d, fqss_stream_t stream);
+
 
 #ifdef __cplusplus
 }

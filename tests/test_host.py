@@ -17,7 +17,7 @@ def test_c_abi_exports_every_declared_symbol():
     """the library loads and exports exactly what include/fqss.h declares (and _lib binds all of it)"""
     from fqss_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "fqss.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(fqss_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(fqss_\w+)\s*\(", hdr, flags=re.M))
     assert declared and declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     if not os.path.exists(_lib.SO_PATH):
         subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
