@@ -12,8 +12,14 @@
 // step was the whole step time: 430 -> 359 us), partial sums meet by quad-permute DPP adds.  The backward kernel holds the same matrix column-wise
 // (thread (k, gate block) keeps W_hh[block*H .. +H][k]) for dh_{t-1} = dgates_t W_hh.
 // A generic variant (template H = 0) streams W_hh from L2 instead; it serves odd sizes (tests) only.
-// Measured dead end: pairing the two sequences in v_pk_fma_f32 (h interleaved by sequence in LDS, weight splat) -- 433 -> 1141 us
-// forward: the splat pairs double the live registers of the 128-entry weight row and the loop stops being FMA-issue bound.
+// Measured dead ends (round 1 and 2): v_pk_fma_f32, pairing either the two sequences (weight splat: 433 -> 1141 us, the splat pairs
+// double the live registers) or two consecutive k (weights and h naturally pairwise in registers, half the FMA instructions, no extra
+// moves: 383 -> 376 us) -- a wave64 v_pk_fma_f32 occupies the SIMD for two plain FMAs' time here, the step stays at ~3,650 cycles:
+// 2 waves x (256 FMA + ~210 other) VALU issues x 4 cycles per SIMD.  An MFMA form does not pay either: v_mfma_f32_4x4x1 (the only fp32
+// shape whose N = 4 is not mostly padding at 2 sequences) has the plain-FMA rate at N = 2, and more sequences per workgroup do not
+// shorten a step (there are <= 250 sequences for 256 CUs: one workgroup per CU already; the recurrence is latency-, not throughput-bound).
+// What did help in round 2: each gate row applies its own sigmoid / tanh (all 8 waves, instead of the cell threads doing five
+// transcendentals per element on 4 waves) and the input projection is requested four steps ahead (409 -> 383 us per layer at S = 250).
 //
 // Saved for the backward: the four gate activations and the cell state per step (5H floats per step and sequence-direction).
 #include "fqss_dev.h"
@@ -63,25 +69,23 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
     const int cn = threadIdx.x / H, ck = threadIdx.x - cn * H;
     const bool cell = threadIdx.x < kNB * H && (b0 + cn) < B;
     __syncthreads();
-    // the input projection of step t+1 is fetched while step t computes -- unconditionally, from clamped indices (a branch around
-    // a global load makes the compiler wait for it on the spot; out-of-range rows / gate slots read valid memory and are unused)
-    float pcur[kNB], pnext[kNB];
+    // The input projection of a step is requested kPF steps before it is used (a ring of registers): a step is ~1 us of work, a
+    // global-memory round trip is about as long, and with a one-step lookahead every step ended waiting for it.  Unconditional
+    // loads from clamped indices (a branch around a global load makes the compiler wait for it on the spot; out-of-range rows /
+    // gate slots read valid memory and are unused).
+    constexpr int kPF = 4;
+    float pf[kPF][kNB];
     const int jc = jv ? j : 4 * H - 1;
-    {
-        const int t = dir == 0 ? 0 : S - 1;
+    auto fetch = [&](float (&dst)[kNB], int step) {
+        const int sn = min(step, S - 1);
+        const int tn = dir == 0 ? sn : S - 1 - sn;
 #pragma unroll
-        for (int nb = 0; nb < kNB; ++nb)
-            pcur[nb] = pre[(((int64_t)t * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
-    }
-    for (int step = 0; step < S; ++step) {
+        for (int nb = 0; nb < kNB; ++nb) dst[nb] = pre[(((int64_t)tn * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
+    };
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) fetch(pf[u], u);
+    auto one_step = [&](int step, const float (&pcur)[kNB]) {
         const int t = dir == 0 ? step : S - 1 - step;
-        {
-            const int sn = min(step + 1, S - 1);
-            const int tn = dir == 0 ? sn : S - 1 - sn;
-#pragma unroll
-            for (int nb = 0; nb < kNB; ++nb)
-                pnext[nb] = pre[(((int64_t)tn * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
-        }
         if (jv) {
             float acc[kNB];
 #pragma unroll
@@ -126,27 +130,46 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
                     for (int nb = 0; nb < kNB; ++nb) acc[nb] = fmaf(wv, hs[nb * H + k], acc[nb]);
                 }
             }
+            // every gate row applies its OWN non-linearity here, all waves busy and the kNB sequences of a lane independent (the cell
+            // threads used to do all four per element: 3 sigmoids + 2 tanh as one dependent chain on half of the waves, the longest
+            // part of a step), and writes the saved activation itself: one contiguous 4H row per sequence
+            const bool is_g = (j >= 2 * H) && (j < 3 * H);      // gate order i, f, g, o; wave-uniform for H % 64 == 0
 #pragma unroll
-            for (int nb = 0; nb < kNB; ++nb) gs[nb * 4 * H + j] = pcur[nb] + (acc[nb] + bj);
+            for (int nb = 0; nb < kNB; ++nb) {
+                const float pre_act = pcur[nb] + (acc[nb] + bj);
+                const float a = is_g ? tanhf(pre_act) : sigmoidf_(pre_act);
+                gs[nb * 4 * H + j] = a;
+                if (b0 + nb < B) gsav[((((int64_t)t * B + b0 + nb) * 2) + dir) * 4 * H + j] = a;
+            }
         }
         __syncthreads();
         if (cell) {
             const float* g = gs + cn * 4 * H;
-            const float gi = sigmoidf_(g[ck]), gf = sigmoidf_(g[H + ck]), gg = tanhf(g[2 * H + ck]), go = sigmoidf_(g[3 * H + ck]);
+            const float gi = g[ck], gf = g[H + ck], gg = g[2 * H + ck], go = g[3 * H + ck];
             c = gf * c + gi * gg;
             const float h = go * tanhf(c);
             if constexpr (HT > 0) hs[(cn * 4 + ck / KQ) * HQS + (ck % KQ)] = h;
             else hs[cn * H + ck] = h;
             const int64_t sb = (int64_t)t * B + b0 + cn;
             hout[sb * 2 * H + dir * H + ck] = h;
-            float* gsv = gsav + (sb * 2 + dir) * 4 * H;
-            gsv[ck] = gi; gsv[H + ck] = gf; gsv[2 * H + ck] = gg; gsv[3 * H + ck] = go;
             csav[(sb * 2 + dir) * H + ck] = c;
         }
         __syncthreads();
+    };
+    int step = 0;
+    for (; step + kPF <= S; step += kPF) {
 #pragma unroll
-        for (int nb = 0; nb < kNB; ++nb) pcur[nb] = pnext[nb];
+        for (int u = 0; u < kPF; ++u) {
+            float pc[kNB];
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) pc[nb] = pf[u][nb];
+            fetch(pf[u], step + u + kPF);
+            one_step(step + u, pc);
+        }
     }
+#pragma unroll
+    for (int u = 0; u < kPF - 1; ++u)       // the last S % kPF steps: already in the ring
+        if (step + u < S) one_step(step + u, pf[u]);
 }
 
 // gout [S][B][2H] -> dG [S][B][2][4H] (gradient w.r.t. the gate pre-activations); everything else follows by GEMMs
