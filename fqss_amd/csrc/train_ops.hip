@@ -249,6 +249,19 @@ extern "C" int fqss_kd_loss(const float* est, const float* fest, const float* tg
     return launch_status("fqss_kd_loss");
 }
 
+extern "C" int fqss_kd_moments(const float* est, const float* fest, const float* tgt, int B, int64_t T, double* stats,
+                               fqss_stream_t stream) {
+    FQSS_REQUIRE(est && fest && tgt && stats, "null tensor");
+    FQSS_REQUIRE(B > 0 && T > 0, "bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * kStatStride * B, s) != hipSuccess) return launch_status("fqss_kd_moments(memset)");
+    int64_t nb = cdiv(T, 256 * 8);
+    if (nb > 64) nb = 64;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_kd_moments, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, est, fest, tgt, T, stats);
+    return launch_status("fqss_kd_moments");
+}
+
 extern "C" int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_t stream) {
     FQSS_REQUIRE(g && sumsq && n >= 0, "bad args");
     if (n == 0) return FQSS_OK;

@@ -677,6 +677,19 @@ def kd_loss(est, fest, tgt, kd_lambda, want_grad=True):
     return out, w, sisdr, gest
 
 
+def kd_moments(est, fest, tgt):
+    """the 24 fp64 second-order moments per sample that the streaming pass of fqss_kd_loss accumulates ([B, 32], slots as in
+    csrc/train_ops.hip: sums 0..5 of e0 e1 f0 f1 t0 t1, self products 6..11, e_i.t_j 12..15, e_i.f_j 16..19, f_i.t_j 20..23)"""
+    _need_gpu(est, fest, tgt)
+    est, fest, tgt = est.contiguous(), fest.contiguous(), tgt.contiguous()
+    B, S, T = est.shape
+    assert S == 2, "the moment kernel is built for n_src = 2"
+    dev = est.device
+    stats = torch.empty(B, 32, device=dev, dtype=torch.float64)
+    _lib.call("fqss_kd_moments", _p(est), _p(fest), _p(tgt), B, T, _p(stats), _stream())
+    return stats
+
+
 def sumsq(g, acc):
     _lib.call("fqss_sumsq", _p(g), g.numel(), _p(acc), _stream())
 

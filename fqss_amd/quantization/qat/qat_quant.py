@@ -248,6 +248,29 @@ class TorchActivationFakeQuantize(nn.Module):
         raise NotImplementedError("TorchActivationFakeQuantize: exported models evaluate through `forward`, not the fused training kernels")
 
 
+class TorchDymActivationFakeQuantize(nn.Module):
+    """dynamic per-call activation quantizer in torch's affine form (qat_quant.py:56-72): the range is factor * (min, max) of the
+    tensor at hand, found by the device min/max reduction; scale and zero point are host scalars, as in the reference"""
+
+    def __init__(self, quantizer):
+        super().__init__()
+        self.n_bits = quantizer.n_bits
+        self.factor = getattr(quantizer, "factor", 1.0)
+
+    def forward(self, x):
+        x = ops.real(x)
+        ws = torch.tensor([-1, 0], dtype=torch.int32, device=x.device)
+        K.minmax(x, ws)
+        mn, mx = torch.zeros(1, device=x.device), torch.zeros(1, device=x.device)
+        K.observer_ema(mn, mx, ws, 0.0)           # alpha = 0: takes the observed pair
+        mn, mx = self.factor * float(mn), self.factor * float(mx)
+        scale = float((mx - mn) / (2 ** self.n_bits - 1))
+        zp = int(round(mn / scale))               # python rounds half to even like torch.round
+        zp = -zp if mn < 0 else zp
+        return K.fq_affine(x, torch.tensor([scale], device=x.device), torch.tensor([zp], device=x.device, dtype=torch.int32), 0, 0,
+                           2 ** self.n_bits - 1)
+
+
 def export_integer_state(model):
     """{quantizer path: affine parameters} + {weight path: int8 codes} of a trained model: what a true-integer (int8 MFMA) deployment
     loads.  Weights are located through the LayerQ that owns the quantizer (its float submodule's `.weight`)."""

@@ -142,7 +142,8 @@ def torch_activation_quantizer(quantizer):
 
 
 def torch_dym_activation_quantizer(quantizer):
-    raise NotImplementedError("dynamic activation quantizer: no call site in the FQSS training path")
+    from .qat_quant import TorchDymActivationFakeQuantize
+    return TorchDymActivationFakeQuantize(quantizer)
 
 
 def replace_weight_quantizer(model, module_to_replace, module):
@@ -152,3 +153,6 @@ def replace_weight_quantizer(model, module_to_replace, module):
 def replace_activation_quantizer(model, module_to_replace, module):
     _set_module(model, module_to_replace, torch_activation_quantizer(module))
 
+
+def replace_dym_activation_quantizer(model, module_to_replace, module):
+    _set_module(model, module_to_replace, torch_dym_activation_quantizer(module))

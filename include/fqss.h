@@ -360,6 +360,12 @@ int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, i
                  float kd_lambda, double* stats, float* out, float* w_out, float* sisdr_out,
                  float* gest, fqss_stream_t stream);
 
+/* the streaming pass of fqss_kd_loss alone: stats[b][0..23] = the 24 fp64 second-order moments of sample b (sums of e0 e1 f0 f1 t0 t1,
+ * their self products, e_i.t_j, e_i.f_j, f_i.t_j; row stride 32) -- what the evaluation forms of SDR / PairwiseWSDR
+ * (wsdr.py:10-95) are computed from */
+int fqss_kd_moments(const float* est, const float* fest, const float* tgt, int B, int64_t T, double* stats,
+                    fqss_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K16  global-norm clip + Adam over one flat fp32 parameter buffer
  * replaces: pl.Trainer(gradient_clip_val=5.0) + torch.optim.Adam (asteroid_librimix_trainer.py:94,132)

@@ -74,8 +74,14 @@ def test_quantizer_api_surface():
                  "quant_batchnorm", "quant_embedding", "quant_nl", "quant_linear", "quant_linear_nl", "quant_mha", "quant_lstm", "quant_add",
                  "quant_sub", "quant_mul", "quant_div", "quant_const", "torch_weight_quantizer", "torch_activation_quantizer",
                  "quantize_known_modules", "quantize_modules", "replace_encoderq", "replace_decoderq", "replace_weight_quantizer",
-                 "replace_activation_quantizer"):
+                 "replace_activation_quantizer", "torch_dym_activation_quantizer", "replace_dym_activation_quantizer"):
         assert callable(getattr(QU, name)), name
+    # the loss names of train_env/asteroid_librimix/wsdr.py:10-102
+    from fqss_amd.train_env.asteroid_librimix import wsdr
+    for name in ("SDR", "PairwiseWSDR", "sisdr", "sdr", "pairwise_wsisdr", "pairwise_wsdsdr"):
+        assert callable(getattr(wsdr, name)), name
+    with pytest.raises(AssertionError):
+        wsdr.PairwiseWSDR("sdr")
 
 
 def test_graph_rewrite_and_state_dict_layout(golden):
