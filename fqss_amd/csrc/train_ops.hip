@@ -73,9 +73,18 @@ __device__ PairSdr pair_sdr(double Sx, double Sy, double Sxx, double Syy, double
 }
 
 // one block; thread b < B handles sample b. coef[b][i][8] = {A, Bt, jt, Bf, jf, mean_e, -, -}, means[b][6]
+// per_sample = 0: the asteroid objective (mysystem.py:124-151): -10 log10 of the batch MEANS of the task / KD ratios.
+// per_sample = 1: the speechbrain objective (speechbrain_librimix_trainer.py:99-115, 141-149; wsdr.py PitWrapper over cal_w_si_snr):
+//   loss_b = -10 log10((1-lam) task_b + lam kd_b + eps) per sample, then the mean over the samples with loss_b > threshold (all of
+//   them when none is above, or when the threshold is off).  The KD weights follow the reference's broadcast `si_snr[1, C, C] *
+//   weights[1, B]`: at B = 1 the sample's w, at B = 2 (= n_src) the weight of STUDENT SOURCE j is w[j], in both samples (the host refuses
+//   B > 2, where that broadcast raises).  The reference projects the teacher / target on the student there (roles swapped): the ratio
+//   is symmetric up to eps / energy ~ 1e-11, the same pair_sdr serves both.
 __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_lambda, double* stats, float* out,
-                                                    float* w_out, float* sisdr_out) {
+                                                    float* w_out, float* sisdr_out, int per_sample, int use_threshold, float threshold) {
     __shared__ double red[2 * 16];
+    __shared__ double sh_w[2];
+    __shared__ int sh_keep;
     const int b = threadIdx.x;
     const double Td = (double)T;
     double task_b = 0.0, kd_b = 0.0, wb = 0.0;
@@ -101,11 +110,24 @@ __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_la
         const double t0 = -0.5 * (st[0][0].sdr + st[1][1].sdr), t1 = -0.5 * (st[1][0].sdr + st[0][1].sdr);
         pt = t1 < t0 ? 1 : 0;
         task_b = -(pt ? t1 : t0);
-        const double k0 = -0.5 * wb * (sf[0][0].sdr + sf[1][1].sdr), k1 = -0.5 * wb * (sf[1][0].sdr + sf[0][1].sdr);
-        pf = k1 < k0 ? 1 : 0;
-        kd_b = -(pf ? k1 : k0);
         w_out[b] = (float)wb;
         sisdr_out[b] = (float)(-sdrqs);
+        if (per_sample && b < 2) sh_w[b] = wb;
+    }
+    if (per_sample) {
+        if (threadIdx.x == 0) sh_keep = 0;
+        __syncthreads();
+    }
+    double wsrc[2] = {wb, wb};      // KD weight of student source 0 / 1 in this sample
+    if (per_sample && B == 2) {
+        wsrc[0] = sh_w[0];
+        wsrc[1] = sh_w[1];
+    }
+    if (b < B) {
+        const double k0 = -0.5 * (wsrc[0] * sf[0][0].sdr + wsrc[1] * sf[1][1].sdr);
+        const double k1 = -0.5 * (wsrc[1] * sf[1][0].sdr + wsrc[0] * sf[0][1].sdr);
+        pf = k1 < k0 ? 1 : 0;
+        kd_b = -(pf ? k1 : k0);
     }
     double v[2] = {task_b, kd_b};
     block_sum<double, 2>(v, red);
@@ -117,27 +139,53 @@ __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_la
     __syncthreads();
     const double task = sh_task, kd = sh_kd;
     const double lam = (double)kd_lambda;
-    const double arg = (1.0 - lam) * task + lam * kd + kEps;
-    if (threadIdx.x == 0) {
-        out[0] = (float)(-10.0 * log10(arg));
-        out[1] = (float)(-10.0 * log10(kd + kEps));
-        out[2] = (float)task;
-        out[3] = (float)kd;
-    }
-    if (b < B) {
+    double gt = 0.0, gk[2] = {0.0, 0.0};     // d loss / d (task ratio of a pair), d loss / d (kd ratio of student source j's pair)
+    if (!per_sample) {
+        const double arg = (1.0 - lam) * task + lam * kd + kEps;
+        if (threadIdx.x == 0) {
+            out[0] = (float)(-10.0 * log10(arg));
+            out[1] = (float)(-10.0 * log10(kd + kEps));
+            out[2] = (float)task;
+            out[3] = (float)kd;
+        }
         // dL/d arg = -10/(ln10 * arg); d arg/d sdr_task(b, pair) = (1-lam)/(2B); d arg/d sdr_kd = lam*w_b/(2B)
         const double dL = -10.0 / (log(10.0) * arg);
-        const double gt = dL * (1.0 - lam) / (2.0 * (double)B);
-        const double gk = dL * lam * wb / (2.0 * (double)B);
+        gt = dL * (1.0 - lam) / (2.0 * (double)B);
+        gk[0] = gk[1] = dL * lam * wb / (2.0 * (double)B);
+    } else {
+        const double arg_b = (1.0 - lam) * task_b + lam * kd_b + kEps;
+        const double loss_b = (b < B) ? -10.0 * log10(arg_b) : 0.0;
+        const bool above = (b < B) && (!use_threshold || loss_b > (double)threshold);
+        if (above) atomicAdd(&sh_keep, 1);
+        __syncthreads();
+        const int nkeep = sh_keep;
+        const bool keep = (b < B) && (nkeep == 0 || above);       // nothing above the threshold: the loss stays as it is (:146-147)
+        const double cnt = (double)(nkeep == 0 ? B : nkeep);
+        double lv[2] = {keep ? loss_b : 0.0, 0.0};
+        block_sum<double, 2>(lv, red);
+        if (threadIdx.x == 0) {
+            out[0] = (float)(lv[0] / cnt);
+            out[1] = (float)(-10.0 * log10(kd + kEps));
+            out[2] = (float)task;
+            out[3] = (float)kd;
+        }
+        if (keep) {
+            const double dL = -10.0 / (log(10.0) * arg_b) / cnt;
+            gt = dL * (1.0 - lam) / 2.0;
+            gk[0] = dL * lam * wsrc[0] / 2.0;
+            gk[1] = dL * lam * wsrc[1] / 2.0;
+        }
+    }
+    if (b < B) {
         double* m = stats + (int64_t)b * kStatStride;
         double cf[2][5];
         for (int i = 0; i < 2; ++i) {
             // target index paired with estimate i: perm p has est p[j] on tgt j -> est i sits on tgt j with p[j]==i
             const int jt = pt ? 1 - i : i, jf = pf ? 1 - i : i;
-            cf[i][0] = gt * st[i][jt].cx + gk * sf[i][jf].cx;  // coefficient of e~_i
-            cf[i][1] = gt * st[i][jt].cy;                      // coefficient of t~_jt
+            cf[i][0] = gt * st[i][jt].cx + gk[i] * sf[i][jf].cx;  // coefficient of e~_i
+            cf[i][1] = gt * st[i][jt].cy;                         // coefficient of t~_jt
             cf[i][2] = (double)jt;
-            cf[i][3] = gk * sf[i][jf].cy;                      // coefficient of f~_jf
+            cf[i][3] = gk[i] * sf[i][jf].cy;                      // coefficient of f~_jf
             cf[i][4] = (double)jf;
         }
         // means for the zero-mean views, then the coefficient table (overwrites the moment slots)
@@ -229,24 +277,41 @@ __global__ void k_step_end(int32_t* step_t, const double* sumsq, float grad_scal
 
 using namespace fqss;
 
-extern "C" int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, int64_t T, float kd_lambda,
-                            double* stats, float* out, float* w_out, float* sisdr_out, float* gest,
-                            fqss_stream_t stream) {
-    FQSS_REQUIRE(est && fest && tgt && stats && out && w_out && sisdr_out, "null tensor");
-    FQSS_REQUIRE(B > 0 && B <= 1024 && T > 0, "B must be in 1..1024");
+static int kd_loss_impl(const char* who, const float* est, const float* fest, const float* tgt, int B, int64_t T, float kd_lambda,
+                        double* stats, float* out, float* w_out, float* sisdr_out, float* gest, int per_sample, int use_threshold,
+                        float threshold, fqss_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, sizeof(double) * kStatStride * B, s) != hipSuccess) return launch_status("fqss_kd_loss(memset)");
+    if (hipMemsetAsync(stats, 0, sizeof(double) * kStatStride * B, s) != hipSuccess) return launch_status(who);
     int64_t nb = cdiv(T, 256 * 8);
     if (nb > 64) nb = 64;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_kd_moments, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, est, fest, tgt, T, stats);
-    hipLaunchKernelGGL(k_kd_final, dim3(1), dim3(1024), 0, s, B, T, kd_lambda, stats, out, w_out, sisdr_out);
+    hipLaunchKernelGGL(k_kd_final, dim3(1), dim3(1024), 0, s, B, T, kd_lambda, stats, out, w_out, sisdr_out, per_sample, use_threshold,
+                       threshold);
     if (gest) {
         int64_t ng = cdiv(T, 256 * 4);
         if (ng > 256) ng = 256;
         hipLaunchKernelGGL(k_kd_grad, dim3((unsigned)ng, (unsigned)(2 * B)), dim3(256), 0, s, est, fest, tgt, T, stats, gest);
     }
-    return launch_status("fqss_kd_loss");
+    return launch_status(who);
+}
+
+extern "C" int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, int64_t T, float kd_lambda,
+                            double* stats, float* out, float* w_out, float* sisdr_out, float* gest,
+                            fqss_stream_t stream) {
+    FQSS_REQUIRE(est && fest && tgt && stats && out && w_out && sisdr_out, "null tensor");
+    FQSS_REQUIRE(B > 0 && B <= 1024 && T > 0, "B must be in 1..1024");
+    return kd_loss_impl("fqss_kd_loss", est, fest, tgt, B, T, kd_lambda, stats, out, w_out, sisdr_out, gest, 0, 0, 0.0f, stream);
+}
+
+extern "C" int fqss_kd_loss_per_sample(const float* est, const float* fest, const float* tgt, int B, int64_t T, float kd_lambda,
+                                       int use_threshold, float threshold, double* stats, float* out, float* w_out, float* sisdr_out,
+                                       float* gest, fqss_stream_t stream) {
+    FQSS_REQUIRE(est && fest && tgt && stats && out && w_out && sisdr_out, "null tensor");
+    FQSS_REQUIRE(T > 0 && B > 0, "bad shape");
+    FQSS_REQUIRE(B <= 2, "the per-sample KD weights broadcast [1, n_src, n_src] * [1, B]: B must be 1 or n_src = 2 (the reference raises otherwise)");
+    return kd_loss_impl("fqss_kd_loss_per_sample", est, fest, tgt, B, T, kd_lambda, stats, out, w_out, sisdr_out, gest, 1,
+                        use_threshold ? 1 : 0, threshold, stream);
 }
 
 extern "C" int fqss_kd_moments(const float* est, const float* fest, const float* tgt, int B, int64_t T, double* stats,

@@ -661,7 +661,8 @@ def frames_wgrad(a, x, gw, stride):
 
 
 # ------------------------------------------------------------------ K15 / K16
-def kd_loss(est, fest, tgt, kd_lambda, want_grad=True):
+def kd_loss(est, fest, tgt, kd_lambda, want_grad=True, per_sample=False, threshold=None):
+    """per_sample: the speechbrain env's objective (log per sample, mean over the samples whose loss exceeds `threshold`), B <= 2"""
     _need_gpu(est, fest, tgt)
     est, fest, tgt = est.contiguous(), fest.contiguous(), tgt.contiguous()
     B, S, T = est.shape
@@ -672,8 +673,12 @@ def kd_loss(est, fest, tgt, kd_lambda, want_grad=True):
     w = torch.empty(B, device=dev, dtype=torch.float32)
     sisdr = torch.empty(B, device=dev, dtype=torch.float32)
     gest = torch.empty_like(est) if want_grad else None
-    _lib.call("fqss_kd_loss", _p(est), _p(fest), _p(tgt), B, T, float(kd_lambda), _p(stats), _p(out), _p(w),
-              _p(sisdr), _p(gest), _stream())
+    if per_sample:
+        _lib.call("fqss_kd_loss_per_sample", _p(est), _p(fest), _p(tgt), B, T, float(kd_lambda), int(threshold is not None),
+                  float(threshold or 0.0), _p(stats), _p(out), _p(w), _p(sisdr), _p(gest), _stream())
+    else:
+        _lib.call("fqss_kd_loss", _p(est), _p(fest), _p(tgt), B, T, float(kd_lambda), _p(stats), _p(out), _p(w),
+                  _p(sisdr), _p(gest), _stream())
     return out, w, sisdr, gest
 
 

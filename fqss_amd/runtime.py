@@ -341,8 +341,10 @@ class KDTrainStep:
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None, loss="sisdr_pit", source_weights=None,
                  batched_quantizers=True, fast=True, coded=True, buckets=None, sync_observer_ranges=True,
-                 betas=(0.9, 0.999)):
-        """loss: "sisdr_pit" = the asteroid / speechbrain KD loss (mysystem.py:124-151); "l1_sdr" = the htdemucs solver's
+                 betas=(0.9, 0.999), loss_threshold=None):
+        """loss: "sisdr_pit" = the asteroid KD loss (mysystem.py:124-151); "sisdr_pit_per_sample" = the speechbrain env's form of it
+        (speechbrain_librimix_trainer.py:99-115, 141-149: log per sample, mean over the samples whose loss exceeds `loss_threshold`;
+        per-GPU batch 1 or 2, see fqss_kd_loss_per_sample); "l1_sdr" = the htdemucs solver's
         (solver.py:333-366: L1 task + SDR-weighted L1 distillation, per-source weights).  clip <= 0: no clipping (htdemucs.yaml:84).
         batched_quantizers=False keeps every quantizer on its own launches (no QuantTables / codes-only dataflow);
         fast=False: quantizing layers also write their fp32 outputs (no carriers); coded=False: no layer output carries codes,
@@ -354,6 +356,9 @@ class KDTrainStep:
         observer's .data writes (qat_quant.py:230-232), so its replicas quantize on different grids from then on."""
         self.model, self.fmodel = model, fmodel
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
+        if loss not in ("sisdr_pit", "sisdr_pit_per_sample", "l1_sdr"):
+            raise ValueError(f"unknown loss {loss!r}")
+        self.loss_threshold = loss_threshold       # per-sample objective only: samples at or below it leave the batch mean
         self.fast, self.coded = bool(fast and coded), bool(coded)
         self._graphs = None
         self.kd_lambda, self.lr, self.clip, self.betas = kd_lambda, lr, clip, tuple(betas)
@@ -467,7 +472,9 @@ class KDTrainStep:
             loss, task, kd, w, gest = K.hd_kd_loss(est.detach(), fest, tgt, self.source_weights, self.kd_lambda, want_grad=True)
             res = dict(loss=loss, task=task, kd=kd, w=w, gnorm=a.gnorm, est=est.detach())
         else:
-            out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True)
+            # "sisdr_pit_per_sample": the speechbrain env's objective (log per sample, thresholded mean; csrc/train_ops.hip)
+            out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True,
+                                            per_sample=self.loss_kind == "sisdr_pit_per_sample", threshold=self.loss_threshold)
             res = dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=w, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
         return res, est, gest, cuts
 

@@ -6,10 +6,11 @@ Same YAML keys as the reference's configs/sepformer_2spks_8k.yaml (work_dir, mod
 batch_size, lr, clip_grad_norm, loss_upper_lim, training_signal_len, seed, kd_lambda, threshold_byloss, threshold, lr_scheduler);
 `!ref <key>` references are resolved, `!new:` / `!name:` object tags (loggers, augmenters, speechbrain callables) are read as
 plain mappings and ignored.  Step semantics kept:
-  * KD objective per sample, then the mean over the batch (:99-115): with the shipped per-GPU batch of 1 this is the fused KD-loss
-    kernel of the asteroid env term for term; batch_size > 1 per GPU is refused (the per-sample log is not built);
-  * `threshold_byloss`: at batch 1 `loss[loss > th]` either keeps the sample or is empty, and an empty selection leaves the loss
-    as it is (:150-155) -- a no-op, reproduced as such;
+  * KD objective per sample, then the mean over the batch (:99-115): `KDTrainStep(loss="sisdr_pit_per_sample")`, the per-sample form of
+    the fused KD-loss kernel (fqss_kd_loss_per_sample).  Per-GPU batch 1 (shipped) or 2: the reference broadcasts the KD weights as
+    `[1, n_src, n_src] * [1, B]`, which only exists for B in (1, n_src) -- larger batches are refused here as they fail there;
+  * `threshold_byloss`: `loss[loss > th]` -- samples at or below the threshold leave the batch mean; an empty selection leaves the
+    loss as it is (:141-149), which at batch 1 makes the option a no-op; the kernel applies it on the device;
   * a step whose loss is not below `loss_upper_lim` (NaN / inf) is skipped and counted (:157-176); under data parallelism the
     decision is taken collectively so that every rank applies or skips the same update;
   * clip_grad_norm, Adam(lr), `ReduceLROnPlateau(factor, patience, dont_halve_until_epoch)` on the validation loss (restated
@@ -114,8 +115,9 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
     if device == "cpu":
         raise RuntimeError("fqss_amd is MI355X-only (no CPU fallback); the CPU checker lives in oracle/")
     hp = load_hparams(yml_path)
-    if int(hp.get("batch_size", 1)) != 1:
-        raise NotImplementedError("speechbrain env: only the shipped per-GPU batch_size 1 is built (per-sample KD objective)")
+    if int(hp.get("batch_size", 1)) not in (1, 2):
+        raise ValueError("speechbrain env: per-GPU batch_size must be 1 or n_src = 2 (the reference's KD weights broadcast "
+                         "[1, n_src, n_src] * [1, B] and raise for any other batch)")
     set_seed(hp.get("seed", 0))
     comm = Comm.from_env("cuda")
     dev = torch.device("cuda", comm.local_rank)
@@ -134,7 +136,9 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
     lr = float(hp.get("lr", 1.5e-4))
     clip = float(hp.get("clip_grad_norm", 5))
     upper = float(hp.get("loss_upper_lim", 999999))
-    step = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip if clip >= 0 else 1e30, comm=comm)
+    threshold = float(hp["threshold"]) if hp.get("threshold_byloss") and "threshold" in hp else None
+    step = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip if clip >= 0 else 1e30, comm=comm,
+                       loss="sisdr_pit_per_sample", loss_threshold=threshold)
     sch = hp.get("lr_scheduler") or {}
     sched = ReduceLROnPlateau(sch.get("factor", 0.5), sch.get("patience", 2), sch.get("dont_halve_until_epoch", 65))
     history, best, nonfinite = [], float("inf"), 0
@@ -147,7 +151,7 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
             step._maybe_sync_ranges()
             # fwd + loss + bwd with the gradient exchange of the data-parallel ranks (both forms all-reduce the flat gradient)
             r = step.replay_fwd_bwd(x, tgt) if graphed else step._step_eager(x, tgt)
-            # hard-threshold of easy items (threshold_byloss): a no-op at batch 1, see the module docstring
+            # (the hard threshold of easy items, threshold_byloss, is applied inside the loss kernel)
             flag.copy_((r["loss"] < upper).float().reshape(1))       # False for NaN / inf as well
             if comm.world > 1:
                 comm.all_reduce_sum(flag)

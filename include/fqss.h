@@ -360,6 +360,13 @@ int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, i
                  float kd_lambda, double* stats, float* out, float* w_out, float* sisdr_out,
                  float* gest, fqss_stream_t stream);
 
+/* the speechbrain env's form of the objective (speechbrain_librimix_trainer.py:99-115, 141-149; wsdr.py:60-116 of that env): the log
+ * is taken PER SAMPLE, out[0] = mean of loss_b over the samples with loss_b > threshold (all samples when use_threshold = 0 or none is
+ * above).  KD weights as the reference broadcasts them ([1, n_src, n_src] * [1, B]): B = 1 the sample's w; B = 2 student source j
+ * carries w[j] in both samples; B > 2: FQSS_EINVAL (the reference raises).  Everything else as fqss_kd_loss. */
+int fqss_kd_loss_per_sample(const float* est, const float* fest, const float* tgt, int B, int64_t T,
+                            float kd_lambda, int use_threshold, float threshold, double* stats, float* out,
+                            float* w_out, float* sisdr_out, float* gest, fqss_stream_t stream);
 /* the streaming pass of fqss_kd_loss alone: stats[b][0..23] = the 24 fp64 second-order moments of sample b (sums of e0 e1 f0 f1 t0 t1,
  * their self products, e_i.t_j, e_i.f_j, f_i.t_j; row stride 32) -- what the evaluation forms of SDR / PairwiseWSDR
  * (wsdr.py:10-95) are computed from */

@@ -354,6 +354,63 @@ def kd_loss(est, fest, tgt, kd_lambda=0.1):
     return loss, kd, task, w, sdrs, sdrqs
 
 
+def _w_si_snr_matrix(student, other, weights):
+    """One sample of the speechbrain env's PitWrapper(cal_w_si_snr) (train_env/speechbrain_librimix/wsdr.py:14-58, 77-94), operands
+    [S, T].  The trainer passes the STUDENT as `source` (speechbrain_librimix_trainer.py:112-113), so the other signal is projected on
+    the student; the wrapper repeats the operands so that entry [i, j] pairs other_i with student_j, and `weights` [n] multiplies
+    along the LAST axis (`si_snr[1, S, S] * weights[1, n]`): n must be 1 or S, anything else raises like the reference's broadcast."""
+    src = student - student.mean(dim=1, keepdim=True)          # `source`  -> s_target
+    est = other - other.mean(dim=1, keepdim=True)              # `estimate_source`
+    dot = est @ src.t()                                        # [i, j] = <other_i, student_j>
+    energy = (src ** 2).sum(dim=1) + EPS                       # [j]
+    S = src.shape[0]
+    ratio = torch.empty(S, S, dtype=src.dtype)
+    for i in range(S):
+        for j in range(S):
+            proj = dot[i, j] * src[j] / energy[j]
+            noise = est[i] - proj
+            ratio[i, j] = (proj ** 2).sum() / ((noise ** 2).sum() + EPS)
+    if weights is None:
+        return -ratio
+    if weights.numel() not in (1, S):
+        raise RuntimeError(f"The size of tensor a ({S}) must match the size of tensor b ({weights.numel()}) at non-singleton dimension 2")
+    return -ratio * weights.reshape(1, -1)
+
+
+def _fast_pit(loss_mat):
+    """min over the permutations p of mean_i loss_mat[i, p[i]], the first one on ties (wsdr.py:66-75 of the speechbrain env)"""
+    best = None
+    n = loss_mat.shape[0]
+    for p in itertools.permutations(range(n)):
+        c = torch.stack([loss_mat[i, p[i]] for i in range(n)]).mean()
+        if best is None or best > c:
+            best = c
+    return best
+
+
+def kd_loss_speechbrain(est, fest, tgt, kd_lambda=0.1, threshold=None):
+    """Separation.compute_kd_objectives + the thresholded batch mean of fit_batch (speechbrain_librimix_trainer.py:99-115, 141-149),
+    operands [B, S, T].  `hparams.loss` (speechbrain.nnet.losses.get_si_snr_with_pitwrapper) is third-party and absent: restated from
+    its published behaviour as the PIT'd negative SI-SNR in dB -- `neg_sisdr_pit` above; parity unpinned for it.  Every sample's KD term
+    is given the WHOLE weight vector w [B], as the reference does.  Returns (loss, per-sample losses, w)."""
+    B = len(est)
+    with torch.no_grad():
+        sdrs = torch.stack([neg_sisdr_pit(fest[b:b + 1], tgt[b:b + 1]) for b in range(B)])
+        sdrqs = torch.stack([neg_sisdr_pit(est[b:b + 1].detach(), tgt[b:b + 1]) for b in range(B)])
+        w = 10 ** ((sdrs - sdrqs) / 10)
+    kd = torch.stack([-_fast_pit(_w_si_snr_matrix(est[b], fest[b], w)) for b in range(B)])
+    task = torch.stack([-_fast_pit(_w_si_snr_matrix(est[b], tgt[b], None)) for b in range(B)])
+    per_sample = -10 * torch.log10((1 - kd_lambda) * task + kd_lambda * kd + EPS)
+    loss = per_sample
+    if threshold is not None:
+        keep = per_sample[per_sample > threshold]
+        if keep.nelement() > 0:
+            loss = keep.mean()
+    # nothing above the threshold: the reference leaves the [B] tensor as it is -- at B = 1 that IS the loss; at B > 1 its
+    # `if loss < loss_upper_lim` cannot be evaluated.  The mean over all samples is returned here for that case.
+    return loss.mean(), per_sample, w
+
+
 def kd_step(student, teacher, x, tgt, kd_lambda=0.1):
     est = student(x)
     with torch.no_grad():

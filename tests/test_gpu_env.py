@@ -64,9 +64,14 @@ def test_speechbrain_env_trains_sepformer(tmp_path):
     assert len(hist) == 2 and all(torch.isfinite(torch.tensor(h["train_loss"])) for h in hist)
     sd = torch.load(os.path.join(str(tmp_path / "run"), "save", "best_model.pth"))
     assert "decoder.residual_error_block.weight_fake_quantize_dec.min_range" in sd and "masker.layers.0.intra_transformer_block.pos.pe" in sd
-    with pytest.raises(NotImplementedError):
+    # per-GPU batch 2 = n_src: the per-sample objective with the reference's weight broadcast; batch 3 fails like the reference
+    two = tmp_path / "two.yaml"
+    two.write_text(text.replace("batch_size: 1\n", "batch_size: 2\n", 1).replace(str(tmp_path / "run"), str(tmp_path / "run2")))
+    hist2 = T.train(str(two), 0, False, "cuda")
+    assert len(hist2) == 2 and all(torch.isfinite(torch.tensor(h["train_loss"])) for h in hist2)
+    with pytest.raises(ValueError, match="batch_size must be 1 or n_src"):
         bad = tmp_path / "bad.yaml"
-        bad.write_text(text.replace("batch_size: 1\n", "batch_size: 2\n", 1))
+        bad.write_text(text.replace("batch_size: 1\n", "batch_size: 3\n", 1))
         T.train(str(bad), 0, False, "cuda")
 
 

@@ -187,6 +187,35 @@ def test_kd_loss_golden_and_oracle(golden):
     np.testing.assert_allclose(gest.cpu().numpy(), e.grad.numpy(), rtol=5e-4, atol=1e-9)
 
 
+def test_kd_loss_per_sample_speechbrain_objective():
+    """fqss_kd_loss_per_sample against the oracle's restatement of the speechbrain env's objective (log per sample, thresholded mean,
+    the reference's weight broadcast): loss, weights and dL/d est at B = 1 and B = 2; B = 3 is refused like the reference's broadcast"""
+    x, s = O.synth_batch(3, 16000, seed=4)
+    e_all = s + 0.3 * rnd(3, 2, 16000, seed=7, scale=0.05)
+    e_all[1] = s[1, [1, 0]] + 0.05 * rnd(2, 16000, seed=9, scale=0.05)       # a swapped, much easier sample
+    f_all = s + 0.2 * rnd(3, 2, 16000, seed=8, scale=0.05)
+    for B in (1, 2):
+        e, f, t = e_all[:B], f_all[:B], s[:B]
+        _, per, _ = O.kd_loss_speechbrain(e, f, t)
+        ths = [None, -30.0, 1e9] + ([0.5 * (per[0] + per[1]).item()] if B == 2 else [])
+        for th in ths:
+            er = e.clone().requires_grad_(True)
+            loss, per_r, w_r = O.kd_loss_speechbrain(er, f, t, threshold=th)
+            loss.backward()
+            out, w, sisdr, gest = K.kd_loss(e.cuda(), f.cuda(), t.cuda(), 0.1, per_sample=True, threshold=th)
+            np.testing.assert_allclose(out[0].item(), loss.item(), rtol=1e-5, err_msg=f"B={B} th={th}")
+            np.testing.assert_allclose(w.cpu().numpy(), w_r.numpy(), rtol=2e-5)
+            gr = er.grad.numpy()      # near its zero crossings the oracle's fp32 autograd carries noise of ~1e-5 of the gradient's scale
+            np.testing.assert_allclose(gest.cpu().numpy(), gr, rtol=5e-4, atol=2e-5 * float(np.abs(gr).max()), err_msg=f"B={B} th={th}")
+    with pytest.raises(_lib_error(), match="B must be 1 or n_src"):
+        K.kd_loss(e_all.cuda(), f_all.cuda(), s.cuda(), 0.1, per_sample=True)
+
+
+def _lib_error():
+    from fqss_amd import _lib
+    return _lib.FqssError
+
+
 def test_adam_clip_vs_torch():
     n = 100003
     p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.05)

@@ -165,6 +165,31 @@ def test_loss_goldens(golden):
     np.testing.assert_allclose(-O.pairwise_sisdr(T(g["est"]), T(g["tgt"]), take_log=True).numpy(), g["pw_neg_sisdr"], rtol=1e-6)
 
 
+def test_speechbrain_objective_restatement(golden):
+    """the per-sample objective of the speechbrain env (speechbrain_librimix_trainer.py:99-115, 141-149): at the shipped batch of 1 it is
+    the asteroid objective of the golden `loss` fixture (the SI-SNR ratio is symmetric in its operands up to eps / energy); the
+    threshold keeps or ignores samples; a weight vector that is neither 1 nor n_src long raises like the reference's broadcast"""
+    g = golden("loss")
+    est, fest, tgt = T(g["est"]), T(g["fest"]), T(g["tgt"])
+    for b in range(len(est)):
+        e = est[b:b + 1].clone().requires_grad_(True)
+        ref, *_ = O.kd_loss(e, fest[b:b + 1], tgt[b:b + 1])
+        (gref,) = torch.autograd.grad(ref, e)
+        e2 = est[b:b + 1].clone().requires_grad_(True)
+        loss, per, w = O.kd_loss_speechbrain(e2, fest[b:b + 1], tgt[b:b + 1], threshold=-30.0)
+        (g2,) = torch.autograd.grad(loss, e2)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-6)
+        np.testing.assert_allclose(g2.numpy(), gref.numpy(), rtol=1e-4, atol=1e-10)
+    l2, per2, w2 = O.kd_loss_speechbrain(est[:2], fest[:2], tgt[:2])
+    np.testing.assert_allclose(l2.item(), per2.mean().item(), rtol=1e-7)
+    th = 0.5 * (per2[0] + per2[1]).item()           # between the two samples: only the harder one is kept
+    l2t, _, _ = O.kd_loss_speechbrain(est[:2], fest[:2], tgt[:2], threshold=th)
+    np.testing.assert_allclose(l2t.item(), per2.max().item(), rtol=1e-7)
+    if len(est) >= 3:
+        with pytest.raises(RuntimeError, match="must match the size"):
+            O.kd_loss_speechbrain(est[:3], fest[:3], tgt[:3])
+
+
 # ---------------------------------------------------------------- F6 tiny model, 53 QAT steps
 def test_tiny_step_goldens(golden):
     g = golden("tiny_step")
