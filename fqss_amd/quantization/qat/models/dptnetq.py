@@ -166,13 +166,18 @@ class DPT(nn.Module):
         self.col_transformer = nn.ModuleList([SingleTransformer(input_size, hidden_size, dropout) for _ in range(num_layers)])
         self.output = HipSequential(nn.PReLU(), nn.Conv2d(input_size, output_size, 1))
 
+    fqss_cut_every = 0     # > 0: a backward cut point (ops.cut) in front of every that many (row, col) transformer pairs
+
     def forward(self, seg, B):
         """seg [K, B*S, N] intra-chunk rows -> [S, B*K, output_size] inter-chunk rows"""
         Kc, BS, N = seg.shape
         S = BS // B
         x = seg
         n = len(self.row_transformer)
+        ce = self.fqss_cut_every
         for i in range(n):
+            if ce and i and i % ce == 0:
+                (x,) = ops.cut(x)                # the transformer pairs before this one are a backward segment of their own
             x = self.row_transformer[i](x)
             x = ops_dp.rows_to_cols(x, B, S)
             x = self.col_transformer[i](x)
@@ -255,6 +260,8 @@ class DPTNetQ(nn.Module):
             B = x.shape[0]
             w = self.encoder(x)                                                   # [B, E, L]
             w_mask, w_mul = ops.fork2(w)
+            if self.separator.DPT.fqss_cut_every:
+                (w_mul,) = ops.cut(w_mul, late=True)       # this edge jumps over every backward segment of the separator
             g = self.separator(apply_module(self.enc_LN, w_mask))                 # [B*S, N, L]
             m = self.mask_conv1x1(g)                                              # [B*S, E, L]
             E, L = self.enc_dim, m.shape[-1]
@@ -262,6 +269,26 @@ class DPTNetQ(nn.Module):
             est = self.decoder.forward_cf(ops.real(sw).reshape(B * self.n_srcs, E, L))   # n_combiner x [B*S, T]
             out = est[0] if len(est) == 1 else torch.stack(est)
             return self.post_process(out.reshape(self.n_combiner, B, self.n_srcs, 1, -1))
+
+    def fqss_segments(self, n):
+        """Backward segments = gradient buckets (runtime.KDTrainStep, see ConvTasNetQ.fqss_segments): groups of (row, col) transformer
+        pairs; returns the module lists in forward order."""
+        dpt, sep = self.separator.DPT, self.separator
+        nl = len(dpt.row_transformer)
+        n = max(1, min(int(n), nl))
+        every = -(-nl // n)
+        dpt.fqss_cut_every = every if n > 1 else 0
+        if n == 1:
+            return [[self]]
+        segs = []
+        for s0 in range(0, nl, every):
+            mods = []
+            for i in range(s0, min(nl, s0 + every)):
+                mods += [dpt.row_transformer[i], dpt.col_transformer[i]]
+            segs.append(mods)
+        segs[0] = [self.encoder, self.enc_LN, sep.BN] + segs[0]
+        segs[-1] = segs[-1] + [dpt.output, sep.add, sep.output, sep.output_gate, sep.mul, self.mask_conv1x1, self.mul, self.decoder]
+        return segs
 
     def load_pretrain(self, weights_path):
         own = self.state_dict()

@@ -728,6 +728,12 @@ class HTDemucsQ(nn.Module):
                 x = self._add_freq_emb(x, emb)
             x, keep = ops.fork2(ops.real(x))
             saved.append(keep)
+        if self.fqss_cuts[0]:
+            # backward cut: everything above is the LAST backward segment; the U-Net skips jump over the segments in between and
+            # are pushed with it (late cuts)
+            x, xt = ops.cut(x, xt)
+            saved = list(ops.cut(*saved, late=True))
+            saved_t = list(ops.cut(*saved_t, late=True))
         if self.crosstransformer:
             if self.bottom_channels:
                 b, c, f, t = x.shape
@@ -737,6 +743,11 @@ class HTDemucsQ(nn.Module):
             if self.bottom_channels:
                 x = ops.real(run(self.channel_downsampler, ops.real(x).reshape(b, -1, f * t))).reshape(b, c, f, t)
                 xt = run(self.channel_downsampler_t, xt)
+        if self.fqss_cuts[1]:
+            x, xt = ops.cut(x, xt)
+            if not self.fqss_cuts[0]:
+                saved = list(ops.cut(*saved, late=True))
+                saved_t = list(ops.cut(*saved_t, late=True))
         for idx, decode in enumerate(self.decoder):
             skip = saved.pop(-1)
             x, pre = decode(x, skip, lengths.pop(-1))
@@ -753,6 +764,28 @@ class HTDemucsQ(nn.Module):
         x = ops.real(x).reshape(self.n_combiner, self.B, self.n_srcs, -1, Fq, T)
         xt = ops.real(xt).reshape(self.n_combiner, self.B, self.n_srcs, -1, xt.shape[-1])
         return self.post_process(x, xt)
+
+    fqss_cuts = (False, False)      # backward cut points (encoders | cross-transformer | decoders), set by fqss_segments()
+
+    def fqss_segments(self, n):
+        """Backward segments = gradient buckets (runtime.KDTrainStep, see ConvTasNetQ.fqss_segments): both encoder stacks, the
+        cross-transformer with its channel up / down samplers, both decoder stacks (n >= 3); encoders + transformer | decoders (n = 2).
+        Parameters outside these modules stay with the first segment (runtime: the last one whose gradients become final)."""
+        n = int(n)
+        xf = [m for m in (getattr(self, "channel_upsampler", None), getattr(self, "channel_upsampler_t", None), self.crosstransformer,
+                          getattr(self, "channel_downsampler", None), getattr(self, "channel_downsampler_t", None))
+              if isinstance(m, nn.Module)]
+        enc = [self.encoder, self.tencoder] + [m for m in (self.freq_emb, getattr(self, "mul_freq", None), getattr(self, "add_freq", None))
+                                               if isinstance(m, nn.Module)]
+        dec = [self.decoder, self.tdecoder]
+        if n >= 3 and xf:
+            self.fqss_cuts = (True, True)
+            return [enc, xf, dec]
+        if n >= 2:
+            self.fqss_cuts = (False, True)
+            return [enc + xf, dec]
+        self.fqss_cuts = (False, False)
+        return [[self]]
 
     def _add_freq_emb(self, x, emb):
         """add_freq(x, emb.t()[None, :, :, None].expand_as(x))  (htdemucsq.py:1063-1068): the [Fr, C] table is added along batch and

@@ -113,6 +113,8 @@ class DualPathBlock(nn.Module):
         self.intra_add = Add()
         self.inter_add = Add()
 
+    fqss_cut_inside = False     # a backward cut point (ops.cut) between the intra and the inter half, set by SepformerQ.fqss_segments()
+
     def forward(self, x, B):
         """x [K, B*S, F] intra-chunk rows -> same layout"""
         Kc, BS, _ = x.shape
@@ -120,6 +122,8 @@ class DualPathBlock(nn.Module):
         x_in, x_res = ops.fork2(x)
         intra = self.intra_transformer_block(x_in)
         intra = self.intra_add(_gln_rows(self.intra_norm, intra, (B * S, S, B)), x_res)
+        if self.fqss_cut_inside:
+            (intra,) = ops.cut(intra)
         i_in, i_res = ops.fork2(intra)
         inter = self.inter_transformer_block(ops_dp.rows_to_cols(ops.real(i_in), B, S))          # [S, B*K, F]
         inter = _gln_rows(self.inter_norm, inter, (B * Kc, Kc, B))
@@ -142,6 +146,8 @@ class MaskGenerator(nn.Module):
         self.net_gate = HipSequential(nn.Conv1d(n_filters, n_filters, 1, bias=True), nn.Sigmoid())
         self.mul = Mul()
 
+    fqss_cut_between = False    # backward cut points between the dual-path blocks, set by SepformerQ.fqss_segments()
+
     @staticmethod
     def _gated(seq, x):
         conv, nl = seq[0], seq[1]
@@ -156,7 +162,9 @@ class MaskGenerator(nn.Module):
         xc = apply_module(self.conv1d, apply_module(self.norm, x))
         seg = ops_dp.Segment.apply(ops.real(xc), Kc)                           # [K, B*S, F]
         S = seg.shape[1] // B
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
+            if i and self.fqss_cut_between:
+                (seg,) = ops.cut(seg)           # the dual-path blocks before this one are a backward segment of their own
             seg = layer(seg, B)
         y = ops_dp.rows_to_cols(ops.real(run(self.prelu, seg)), B, S)          # [S, B*K, F]
         conv = self.conv2d
@@ -196,10 +204,37 @@ class SepformerQ(nn.Module):
             batch = x.shape[0]
             feats = self.encoder(x)                                            # [B, F, M]
             f_mask, f_mul = ops.fork2(feats)
+            if self.masker.fqss_cut_between:
+                (f_mul,) = ops.cut(f_mul, late=True)       # this edge jumps over every backward segment of the masker
             masked = self.mul(self.masker(f_mask), ops.reshape_tagged(f_mul, batch, 1, self.enc_num_feats, -1))
             masked = ops.reshape_tagged(masked, batch * self.n_srcs, self.enc_num_feats, -1)
             out = apply_module(self.decoder, masked)
             return self.post_process(out.reshape((self.n_combiner, batch, self.n_srcs, 1, -1)))
+
+    def fqss_segments(self, n):
+        """Backward segments = gradient buckets (runtime.KDTrainStep, see ConvTasNetQ.fqss_segments): the dual-path blocks (n >= 2), each
+        split again between its intra and inter transformer stacks (n >= 2 * blocks); returns the module lists in forward order."""
+        mk = self.masker
+        blocks = list(mk.layers)
+        n = int(n)
+        inside = n >= 2 * len(blocks)
+        between = n >= 2 and len(blocks) > 1
+        mk.fqss_cut_between = between or inside
+        for blk in blocks:
+            blk.fqss_cut_inside = inside
+        if not (between or inside):
+            return [[self]]
+        segs = []
+        for blk in blocks:
+            first = [blk.intra_transformer_block, blk.intra_norm, blk.intra_add]
+            second = [blk.inter_transformer_block, blk.inter_norm, blk.inter_add]
+            if inside:
+                segs += [first, second]
+            else:
+                segs.append(first + second)
+        segs[0] = [self.encoder, mk.norm, mk.conv1d] + segs[0]
+        segs[-1] = segs[-1] + [mk.prelu, mk.conv2d, mk.net_out, mk.net_gate, mk.mul, mk.end_conv, self.mul, self.decoder]
+        return segs
 
     def load_pretrain(self, weights_path):
         own = self.state_dict()

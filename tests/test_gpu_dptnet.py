@@ -749,3 +749,11 @@ def test_coded_row_linear_gradients_do_not_read_carriers(monkeypatch):
         grads.append((lin.linear.weight.grad.clone(), xi.grad.clone()))
     np.testing.assert_allclose(grads[0][0].cpu().numpy(), grads[1][0].cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(grads[0][1].cpu().numpy(), grads[1][1].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_dptnet_backward_segments_match_the_single_pass_backward():
+    """gradient buckets for cfg 3 (DPTNetQ.fqss_segments): the full-size network's backward as 3 segments of two (row, col) transformer
+    pairs each, the encoder -> mask-multiply edge as a late cut, against the one-pass backward"""
+    from tests.helpers_segments import check_backward_segments
+    x, tgt = O.synth_batch(1, 8000, seed=4)
+    check_backward_segments(lambda: build_pair(2), x.cuda(), tgt.cuda(), nb=3, nseg=3)

@@ -313,3 +313,11 @@ def test_sep_full_size_vs_reference_goldens(golden, fixture):
             # make every run of this build land somewhere else in that band (observed 4.1 .. 9.6 dB at step 51)
             assert abs(r["loss"].item() - float(g[p + "loss"])) <= 6.0, (s, r["loss"].item(), float(g[p + "loss"]))
             assert r["loss"].item() < float(g["s1.loss"]) - 8.0          # ... while the run as a whole trains (25.5 dB at step 1)
+
+
+def test_sepformer_backward_segments_match_the_single_pass_backward():
+    """gradient buckets for cfg 4 (SepformerQ.fqss_segments): the full-size network's backward as 4 segments -- the intra and inter
+    transformer stacks of its two dual-path blocks, the encoder -> mask-multiply edge as a late cut -- against the one-pass backward"""
+    from tests.helpers_segments import check_backward_segments
+    x, tgt = O.synth_batch(1, 8000, seed=4)
+    check_backward_segments(lambda: build_pair(2, n_spks=2, kernel_size=16, stride=8), x.cuda(), tgt.cuda(), nb=4, nseg=4)
