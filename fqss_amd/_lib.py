@@ -79,6 +79,8 @@ _PROTOS = {
     "fqss_colsum": [P, P, I64, I32, I64, P],
     "fqss_layernorm_fwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P],
     "fqss_layernorm_bwd": [P, P, P, P, P, P, P, I64, I32, I64, I64, I64, P],
+    "fqss_layernormq_fwd": [P, P, P, P, P, P, I64, I32, I64, I64, I64, F64, P, P, P],
+    "fqss_layernormq_bwd": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, P, P, P, P],
     "fqss_unary_fwd": [P, P, I64, I32, F64, P],
     "fqss_unary2_fwd": [P, P, I64, I32, F64, F64, P],
     "fqss_unary_bwd": [P, P, P, I64, I32, F64, P],

@@ -14,11 +14,16 @@ namespace fqss {
 
 // ------------------------------------------------------------------------------------------------ LayerNorm rows
 // One wavefront per row, JC = ceil(C / 64) features per lane.  Two-pass statistics in registers (the row is loaded once).
-template <int JC>
+// Q: LayerNormQ's output quantizer in the same pass (qat_layers.py:455-465 + qat_quant.py:136-147): y receives fq(LN(x)), yc (nullable)
+// its u8 codes; the pre-quant value is never stored -- the backward recomputes it from x, mean, rstd with the same operations.
+template <int JC, bool Q>
 __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean_rstd, int64_t R, int C, int64_t ld_x,
-                                                        int64_t ld_y, float eps) {
+                                                        int64_t ld_y, float eps, const float* __restrict__ qmin,
+                                                        const float* __restrict__ qmax, unsigned char* __restrict__ yc, int64_t ld_yc) {
+    QRange qr{0.0f, 1.0f, 1.0f};
+    if (Q) qr = load_qrange(qmin, qmax);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     float ga[JC], be[JC];
@@ -50,7 +55,16 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
             const int c = lane + 64 * j;
-            if (c < C) y[r * ld_y + c] = ((v[j] - mean) * rstd) * ga[j] + be[j];
+            if (c < C) {
+                const float z = ((v[j] - mean) * rstd) * ga[j] + be[j];
+                if (Q) {
+                    const float code = fq_code(z, qr);
+                    y[r * ld_y + c] = qr.delta * code + qr.lo;
+                    if (yc != nullptr) yc[r * ld_yc + c] = (unsigned char)code;
+                } else {
+                    y[r * ld_y + c] = z;
+                }
+            }
         }
         if (lane == 0) {
             mean_rstd[2 * r] = mean;
@@ -61,20 +75,28 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
 
 // gx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = gy * gamma; per-workgroup partial column sums for the
 // affine gradients (registers across the rows of a wave, LDS across the 4 waves, then one atomic per column and workgroup)
-template <int JC>
+// Q: gy is dL/d fq(LN(x)): the quantizer's STE (and its range-gradient partials, one gacc slot per workgroup like k_actq_bwd) runs on
+// the pre-quant value recomputed from x -- no separate fqss_actq_bwd pass, no stored z.
+template <int JC, bool Q>
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ gy, const float* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                         float* __restrict__ gx, float* __restrict__ ggamma,
                                                         float* __restrict__ gbeta, int64_t R, int C, int64_t ld_gy,
-                                                        int64_t ld_x, int64_t ld_gx) {
+                                                        int64_t ld_x, int64_t ld_gx, const float* __restrict__ beta,
+                                                        const float* __restrict__ qmin, const float* __restrict__ qmax, double* gacc) {
     __shared__ float red[2][4][64 * JC];
+    __shared__ double redq[2 * 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + w, nw = (int64_t)gridDim.x * 4;
-    float ga[JC], agg[JC], agb[JC];
+    QRange qr{0.0f, 1.0f, 1.0f};
+    if (Q) qr = load_qrange(qmin, qmax);
+    float p_du = 0.0f, p_out = 0.0f;      // sum g*(c - m*u), sum g*(1-m)   (k_actq_bwd)
+    float ga[JC], be[JC], agg[JC], agb[JC];
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
         const int c = lane + 64 * j;
         ga[j] = c < C ? gamma[c] : 0.f;
+        be[j] = (Q && c < C) ? beta[c] : 0.f;
         agg[j] = agb[j] = 0.f;
     }
     const float invC = 1.0f / (float)C;
@@ -84,8 +106,18 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
             const int c = lane + 64 * j;
-            const float g = c < C ? gy[r * ld_gy + c] : 0.f;
+            float g = c < C ? gy[r * ld_gy + c] : 0.f;
             xh[j] = c < C ? (x[r * ld_x + c] - mean) * rstd : 0.f;
+            if (Q) {
+                float code, u;
+                bool inr;
+                (void)fq_asym(xh[j] * ga[j] + be[j], qr, code, u, inr);      // the forward's z, operation for operation
+                if (c < C) {
+                    p_du += g * (inr ? (code - u) : code);
+                    p_out += inr ? 0.0f : g;
+                }
+                g = inr ? div_by(g * qr.delta, qr.delta, qr.inv) : 0.0f;
+            }
             dxh[j] = g * ga[j];
             a += dxh[j];
             b += dxh[j] * xh[j];
@@ -111,6 +143,16 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         if (c < C) {
             const float s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
             atomicAdd((which == 0 ? ggamma : gbeta) + c, s);
+        }
+    }
+    if (Q) {
+        double v[2] = {(double)p_du, (double)p_out};
+        block_sum<double, 2>(v, redq);
+        if (threadIdx.x == 0) {
+            double* slot = gacc + 3 * (int64_t)blockIdx.x;
+            const double dmax = v[0] / 255.0;
+            slot[0] += v[1] - dmax;
+            slot[1] += dmax;
         }
     }
 }
@@ -538,19 +580,67 @@ static inline unsigned flat_grid(int64_t n) {
 
 using namespace fqss;
 
-extern "C" int fqss_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
-                                  int64_t R, int C, int64_t ld_x, int64_t ld_y, double eps, fqss_stream_t stream) {
-    FQSS_REQUIRE(x && gamma && beta && y && mean_rstd, "null tensor");
-    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_x >= C && ld_y >= C, "bad shape (C <= 512)");
+static int layernorm_fwd_impl(const char* who, const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc,
+                              float* mean_rstd, int64_t R, int C, int64_t ld_x, int64_t ld_y, int64_t ld_yc, double eps,
+                              const float* qmin, const float* qmax, fqss_stream_t stream) {
     if (R == 0) return FQSS_OK;
     int64_t nb = cdiv(R, 4);
     if (nb > 4096) nb = 4096;
     hipStream_t s = (hipStream_t)stream;
     const float e = (float)eps;
-    if (C <= 64) hipLaunchKernelGGL((k_layernorm_fwd<1>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
-    else if (C <= 256) hipLaunchKernelGGL((k_layernorm_fwd<4>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);
-    else hipLaunchKernelGGL((k_layernorm_fwd<8>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e);   // HTDemucs transformer: 384 / 512
-    return launch_status("fqss_layernorm_fwd");
+#define FQSS_LN_FWD(JC, Q) \
+    hipLaunchKernelGGL((k_layernorm_fwd<JC, Q>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
+                       qmax, yc, ld_yc)
+    if (qmin != nullptr) {
+        if (C <= 64) FQSS_LN_FWD(1, true);
+        else if (C <= 256) FQSS_LN_FWD(4, true);
+        else FQSS_LN_FWD(8, true);
+    } else {
+        if (C <= 64) FQSS_LN_FWD(1, false);
+        else if (C <= 256) FQSS_LN_FWD(4, false);
+        else FQSS_LN_FWD(8, false);   // HTDemucs transformer: 384 / 512
+    }
+#undef FQSS_LN_FWD
+    return launch_status(who);
+}
+
+extern "C" int fqss_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
+                                  int64_t R, int C, int64_t ld_x, int64_t ld_y, double eps, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gamma && beta && y && mean_rstd, "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_x >= C && ld_y >= C, "bad shape (C <= 512)");
+    return layernorm_fwd_impl("fqss_layernorm_fwd", x, gamma, beta, y, nullptr, mean_rstd, R, C, ld_x, ld_y, 0, eps, nullptr, nullptr, stream);
+}
+
+extern "C" int fqss_layernormq_fwd(const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc, float* mean_rstd,
+                                   int64_t R, int C, int64_t ld_x, int64_t ld_y, int64_t ld_yc, double eps, const float* qmin,
+                                   const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gamma && beta && y && mean_rstd && qmin && qmax, "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_x >= C && ld_y >= C && (yc == nullptr || ld_yc >= C), "bad shape (C <= 512)");
+    return layernorm_fwd_impl("fqss_layernormq_fwd", x, gamma, beta, y, yc, mean_rstd, R, C, ld_x, ld_y, ld_yc, eps, qmin, qmax, stream);
+}
+
+static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, const float* gamma, const float* beta,
+                              const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy,
+                              int64_t ld_x, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+    if (R == 0) return FQSS_OK;
+    int64_t nb = cdiv(R, 4 * 16);       // ~16 rows per wave: 64*C atomics per workgroup stay rare
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
+    hipStream_t s = (hipStream_t)stream;
+#define FQSS_LN_BWD(JC, Q) \
+    hipLaunchKernelGGL((k_layernorm_bwd<JC, Q>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
+                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc)
+    if (qmin != nullptr) {
+        if (C <= 64) FQSS_LN_BWD(1, true);
+        else if (C <= 256) FQSS_LN_BWD(4, true);
+        else FQSS_LN_BWD(8, true);
+    } else {
+        if (C <= 64) FQSS_LN_BWD(1, false);
+        else if (C <= 256) FQSS_LN_BWD(4, false);
+        else FQSS_LN_BWD(8, false);
+    }
+#undef FQSS_LN_BWD
+    return launch_status(who);
 }
 
 extern "C" int fqss_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean_rstd, float* gx,
@@ -558,15 +648,17 @@ extern "C" int fqss_layernorm_bwd(const float* gy, const float* x, const float* 
                                   fqss_stream_t stream) {
     FQSS_REQUIRE(gy && x && gamma && mean_rstd && gx && ggamma && gbeta, "null tensor");
     FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_gy >= C && ld_x >= C && ld_gx >= C, "bad shape (C <= 512)");
-    if (R == 0) return FQSS_OK;
-    int64_t nb = cdiv(R, 4 * 16);       // ~16 rows per wave: 64*C atomics per workgroup stay rare
-    if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;
-    hipStream_t s = (hipStream_t)stream;
-    if (C <= 64) hipLaunchKernelGGL((k_layernorm_bwd<1>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
-    else if (C <= 256) hipLaunchKernelGGL((k_layernorm_bwd<4>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
-    else hipLaunchKernelGGL((k_layernorm_bwd<8>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx);
-    return launch_status("fqss_layernorm_bwd");
+    return layernorm_bwd_impl("fqss_layernorm_bwd", gy, x, gamma, nullptr, mean_rstd, gx, ggamma, gbeta, R, C, ld_gy, ld_x, ld_gx, nullptr,
+                              nullptr, nullptr, stream);
+}
+
+extern "C" int fqss_layernormq_bwd(const float* g, const float* x, const float* gamma, const float* beta, const float* mean_rstd,
+                                   float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g, int64_t ld_x, int64_t ld_gx,
+                                   const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && x && gamma && beta && mean_rstd && gx && ggamma && gbeta && qmin && qmax && gacc, "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_g >= C && ld_x >= C && ld_gx >= C, "bad shape (C <= 512)");
+    return layernorm_bwd_impl("fqss_layernormq_bwd", g, x, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, ld_g, ld_x, ld_gx, qmin, qmax,
+                              gacc, stream);
 }
 
 extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream) {

@@ -827,6 +827,30 @@ def layernorm_bwd(gy, x, gamma, mean_rstd, ggamma, gbeta):
     return gx
 
 
+def layernormq_fwd(x, gamma, beta, eps, qmin, qmax, want_codes):
+    """y = fq(LN(x)) (+ its u8 codes) in one pass; the pre-quant value is not stored"""
+    _need_gpu(x, gamma, beta, qmin, qmax)
+    C = gamma.numel()
+    x, R, ld_x = _rows(x, C)
+    y = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    yc = torch.empty(*x.shape, device=x.device, dtype=torch.uint8) if want_codes else None
+    mean_rstd = torch.empty(R, 2, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_layernormq_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(yc), _p(mean_rstd), R, C, ld_x, C, C, float(eps), _p(qmin),
+              _p(qmax), _stream())
+    return y, yc, mean_rstd
+
+
+def layernormq_bwd(g, x, gamma, beta, mean_rstd, ggamma, gbeta, qmin, qmax, gacc):
+    _need_gpu(g, x, gamma, beta, mean_rstd, ggamma, gbeta)
+    C = gamma.numel()
+    g, R, ld_g = _rows(g, C)
+    x, _, ld_x = _rows(x, C)
+    gx = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    _lib.call("fqss_layernormq_bwd", _p(g), _p(x), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_g, ld_x, C,
+              _p(qmin), _p(qmax), _p(gacc), _stream())
+    return gx
+
+
 def unary_fwd(x, kind, p=1.0):
     _need_gpu(x)
     x = x.contiguous()

@@ -123,6 +123,29 @@ class LayerNormRows(Function):
         return gx, (None if d1 else gg), (None if d2 else gb), None
 
 
+class LayerNormRowsQ(Function):
+    """fq(F.layer_norm(x)) -- LayerNormQ in the quantizing phase as ONE kernel each way (csrc/dualpath.hip, k_layernorm_fwd/bwd<., true>):
+    the pre-quant value is never stored, the backward recomputes it from x and the row statistics and runs the quantizer's STE and
+    range-gradient partial sums in the same pass as the LayerNorm backward"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, qmin, qmax, q, want_codes):
+        y, q.idx, mean_rstd = K.layernormq_fwd(x, gamma, beta, eps, qmin, qmax, want_codes)
+        ctx.save_for_backward(x, gamma, beta, mean_rstd, qmin, qmax)
+        ctx.q = q
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean_rstd, qmin, qmax = ctx.saved_tensors
+        q = ctx.q
+        gg, d1 = _param_grad(gamma, gamma)
+        gb, d2 = _param_grad(beta, beta)
+        gx = K.layernormq_bwd(g.contiguous(), x, gamma, beta, mean_rstd, gg, gb, qmin, qmax, q.gacc)
+        _, g_min, g_max = ops._flush_ranges(q, None, None, ops.ACT_NONE)
+        return gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None
+
+
 class Unary(Function):
     """tanh / sigmoid (the gated output convs, dptnetq.py:286-287)"""
 

@@ -615,13 +615,15 @@ def _flat2d(t):
     return t.view(n // c, c) if c else None
 
 
-def fq_node(aq, x, nl=None, codes=False):
+def fq_node(aq, x, nl=None, codes=False, q=None):
     """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl.
-    codes=True: also emit the u8 codes and tag the result with them (the consumer is a row linear that can run on codes)"""
+    codes=True: also emit the u8 codes and tag the result with them (the consumer is a row linear that can run on codes);
+    q: the quantizer's context when the caller already drew it (aq.qctx() advances the observer's call count)"""
     if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
         x, nl = apply_map(nl, ops.real(x)), None
     act, slope = _act_of(nl)
-    q = aq.qctx() if aq is not None else ops.BYPASS
+    if q is None:
+        q = aq.qctx() if aq is not None else ops.BYPASS
     if q.qmode == ops.Q_BYPASS and act == ops.ACT_NONE:
         return x
     x = ops.real(x)
@@ -649,7 +651,22 @@ def run_linear(lin, x, weight, nl, aq):
 def run_layernorm(ln, x, aq):
     if len(ln.normalized_shape) != 1 or not ln.elementwise_affine:
         raise NotImplementedError("only LayerNorm over the last dim with affine parameters has a HIP kernel")
-    return fq_node(aq, ops_dp.LayerNormRows.apply(ops.real(x), ln.weight, ln.bias, ln.eps), codes=True)
+    q = None
+    if aq is not None and FUSE_LNQ:
+        q = aq.qctx()
+        if q.qmode == ops.Q_QUANT and q.gacc is not None:
+            # quantizing phase: LayerNorm + output quantizer as one kernel each way (ops_dp.LayerNormRowsQ)
+            want = ops_dp.QROW and ops.CODED
+            y = ops_dp.LayerNormRowsQ.apply(ops.real(x), ln.weight, ln.bias, ln.eps, q.qmin, q.qmax, q, want)
+            aq.after_forward(q)
+            idx, q.idx = q.idx, None
+            if idx is not None:
+                y._fqss_rowq = ops.ActCodes(idx.view(y.shape), q.qmin.detach(), q.qmax.detach())
+            return y
+    return fq_node(aq, ops_dp.LayerNormRows.apply(ops.real(x), ln.weight, ln.bias, ln.eps), codes=True, q=q)
+
+
+FUSE_LNQ = __import__("os").environ.get("FQSS_FUSE_LNQ", "1") != "0"     # 0: LayerNorm and its quantizer as separate launches (A/B, tests)
 
 
 def _lstm_check(lstm):

@@ -417,6 +417,16 @@ int fqss_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int fqss_layernorm_bwd(const float* gy, const float* x, const float* gamma, const float* mean_rstd, float* gx,
                        float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy, int64_t ld_x, int64_t ld_gx,
                        fqss_stream_t stream);
+/* LayerNormQ = LayerNorm + its output quantizer in ONE pass each way (qat_layers.py:455-465, qat_quant.py:136-147): forward writes
+ * y = fq(LN(x)) and (yc nullable) its u8 codes, the pre-quant value is not stored; backward takes g = dL/dy, recomputes the pre-quant
+ * value from x / mean_rstd, applies the STE, adds the range-gradient partials to gacc (FQSS_GACC_SLOTS x 3, as fqss_actq_bwd) and
+ * runs the LayerNorm backward -- replaces fqss_layernorm_fwd + fqss_actq_fwd and fqss_actq_bwd + fqss_layernorm_bwd */
+int fqss_layernormq_fwd(const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc, float* mean_rstd,
+                        int64_t R, int C, int64_t ld_x, int64_t ld_y, int64_t ld_yc, double eps, const float* qmin,
+                        const float* qmax, fqss_stream_t stream);
+int fqss_layernormq_bwd(const float* g, const float* x, const float* gamma, const float* beta, const float* mean_rstd,
+                        float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g, int64_t ld_x,
+                        int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream);
 
 /* element-wise maps on dense tensors; kind: 0 tanh, 1 sigmoid, 2 division by the scalar p
  * replaces: nn.Tanh / nn.Sigmoid inside Conv1dNlQ (dptnetq.py:286-287), q / sqrt(head_dim) (qat_layers.py:905).

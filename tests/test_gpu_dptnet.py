@@ -757,3 +757,44 @@ def test_dptnet_backward_segments_match_the_single_pass_backward():
     from tests.helpers_segments import check_backward_segments
     x, tgt = O.synth_batch(1, 8000, seed=4)
     check_backward_segments(lambda: build_pair(2), x.cuda(), tgt.cuda(), nb=3, nseg=3)
+
+
+@pytest.mark.parametrize("C", [64, 256, 384])
+def test_layernormq_one_kernel_each_way_equals_the_two_node_form(C, monkeypatch):
+    """LayerNormQ in the quantizing phase: LayerNorm + output quantizer as ONE kernel each way (ops_dp.LayerNormRowsQ,
+    fqss_layernormq_fwd/bwd) against the separate fqss_layernorm_* + fqss_actq_* launches -- same arithmetic, so the output, its codes
+    and dL/dx are bit-identical; the affine and range gradients differ by summation order only"""
+    from fqss_amd import ops
+    from fqss_amd.quantization.qat import qat_layers as QL
+    res = []
+    x0 = rnd(37, 11, C, seed=5, scale=1.3)
+    g0 = rnd(37, 11, C, seed=6)
+    for fuse in (False, True):
+        monkeypatch.setattr(QL, "FUSE_LNQ", fuse)
+        torch.manual_seed(0)
+        ln = nn.LayerNorm(C)
+        with torch.no_grad():
+            ln.weight.copy_(rnd(C, seed=7, scale=0.3) + 1.0)
+            ln.bias.copy_(rnd(C, seed=8, scale=0.2))
+        L = QL.LayerNormQ(ln).cuda()
+        aq = L.activation_fake_quantize
+        aq.n_iter = aq.max_observations
+        with torch.no_grad():
+            aq.min_range.fill_(-1.1)          # clips a few percent of the values on both sides
+            aq.max_range.fill_(1.4)
+        x = x0.cuda().requires_grad_(True)
+        with ops.coded_dataflow(True):
+            y = L(x)
+        codes = getattr(y, "_fqss_rowq", None)
+        y.backward(g0.cuda())
+        res.append((y.detach(), codes.idx.clone() if codes is not None else None, x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone(),
+                    aq.min_range.grad.clone(), aq.max_range.grad.clone()))
+    (y0, c0, gx0, gg0, gb0, gmn0, gmx0), (y1, c1, gx1, gg1, gb1, gmn1, gmx1) = res
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    assert c0 is not None and c1 is not None and torch.equal(c0, c1)
+    frac = float(((c1 == 0) | (c1 == 255)).float().mean())
+    assert 0.01 < frac < 0.6, frac
+    close(gg1, gg0, 1e-5)
+    close(gb1, gb0, 1e-5)
+    close(gmn1, gmn0, 1e-5)
+    close(gmx1, gmx0, 1e-5)
