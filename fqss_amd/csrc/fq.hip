@@ -279,6 +279,86 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
     }
 }
 
+// k_actq_bwd for the output of a ROW linear (z = x W^T + b as [R][F], features contiguous): also accumulates the bias gradient
+// gbias[f] += sum_r gz[r][f] -- the column sums a separate fqss_colsum pass over gz produced (dual-path models: 85 / 129 launches per
+// step).  A workgroup owns a 64-feature slice (16 threads x 4 features = one 256-B piece of every row) and one part of the rows:
+// a thread keeps its 4 features for all its rows, so the sums live in registers; the 16 row lanes meet in LDS, then ONE global atomic
+// per feature and workgroup.  The grid bounds how many workgroups share a feature (<= 256: same-address atomics serialise -- a flat
+// [rows'][16384] view with 2,048 workgroups per feature cost 25 us per launch in atomics alone).
+__global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restrict__ z, const float* __restrict__ g, float* __restrict__ gz,
+                                                           int64_t R, int F, int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act,
+                                                           const float* __restrict__ slope_p, int qmode, const float* __restrict__ qmin,
+                                                           const float* __restrict__ qmax, double* gacc, float* gbias,
+                                                           int64_t rows_per_part) {
+    __shared__ double red[3 * 4];
+    __shared__ float cb[16][64];
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    QRange r{0.0f, 1.0f, 1.0f};
+    if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
+    float p_du = 0.0f, p_out = 0.0f, p_slope = 0.0f;
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int f0 = blockIdx.x * 64 + tx * 4;                       // host: F % 4 == 0
+    const int64_t r_beg = (int64_t)blockIdx.y * rows_per_part, r_end = min(R, r_beg + rows_per_part);
+    if (f0 < F) {
+        for (int64_t row0 = r_beg + ty; row0 < r_end; row0 += 64) {
+            float4 za[4], ga[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = min(row0 + 16 * i, r_end - 1);     // clamped: loads stay unconditional, extra rows are masked below
+                za[i] = *reinterpret_cast<const float4*>(z + row * ld_z + f0);
+                ga[i] = *reinterpret_cast<const float4*>(g + row * ld_g + f0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = row0 + 16 * i;
+                if (row < r_end) {
+                    const float zv[4] = {za[i].x, za[i].y, za[i].z, za[i].w};
+                    const float gv[4] = {ga[i].x, ga[i].y, ga[i].z, ga[i].w};
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gj = gv[j];
+                        const float t = act_apply(zv[j], act, slope);
+                        float gt = gj;
+                        if (qmode == FQSS_Q_QUANT) {
+                            float c, u;
+                            bool inr;
+                            (void)fq_asym(t, r, c, u, inr);
+                            gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
+                            p_du += gj * (inr ? (c - u) : c);
+                            p_out += inr ? 0.0f : gj;
+                        }
+                        o[j] = act_bwd(zv[j], gt, act, slope, true, p_slope);
+                        pb[j] += o[j];
+                    }
+                    *reinterpret_cast<float4*>(gz + row * ld_gz + f0) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[ty][tx * 4 + j] = pb[j];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < F) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += cb[k][threadIdx.x];
+        atomicAdd(&gbias[blockIdx.x * 64 + threadIdx.x], sum);
+    }
+    if (qmode == FQSS_Q_QUANT || act == FQSS_ACT_PRELU) {
+        double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
+        block_sum<double, 3>(v, red);
+        if (threadIdx.x == 0) {
+            double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+            const double dmax = v[0] / 255.0;
+            slot[0] += (qmode == FQSS_Q_QUANT) ? v[1] - dmax : 0.0;
+            slot[1] += (qmode == FQSS_Q_QUANT) ? dmax : 0.0;
+            slot[2] += v[2];
+        }
+    }
+}
+
 // =============================================================================================
 // per-channel symmetric weight quantizer; tensor layout [outer][C][inner]
 // =============================================================================================
@@ -512,6 +592,32 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     }
 #undef FQSS_LAUNCH_BWD
     return launch_status("fqss_actq_bwd");
+}
+
+extern "C" int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g,
+                                     int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin, const float* qmax,
+                                     double* gacc, float* gbias, fqss_stream_t stream) {
+    if (R == 0 || F == 0) return FQSS_OK;
+    FQSS_REQUIRE(z && g && gz && gbias, "null tensor");
+    FQSS_REQUIRE(R > 0 && F > 0 && ld_z >= F && ld_g >= F && ld_gz >= F, "bad shape");
+    FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
+    FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");
+    FQSS_REQUIRE(F % 4 == 0 && aligned16(z) && aligned16(g) && aligned16(gz) && ld_z % 4 == 0 && ld_g % 4 == 0 && ld_gz % 4 == 0,
+                 "feature count and row strides must be multiples of 4 floats, rows 16-B aligned");
+    const int64_t slices = cdiv(F, 64);
+    FQSS_REQUIRE(slices <= kGaccSlots, "too many features");
+    int64_t parts = 1024 / slices;                   // ~1024 workgroups over the chip ...
+    if (parts > 256) parts = 256;                    // ... at most 256 of them adding to the same feature
+    if (parts > kGaccSlots / slices) parts = kGaccSlots / slices;
+    if (parts > cdiv(R, 64)) parts = cdiv(R, 64);    // at least one full round of rows per workgroup
+    if (parts < 1) parts = 1;
+    const int64_t rows_per_part = cdiv(R, parts);
+    parts = cdiv(R, rows_per_part);
+    hipLaunchKernelGGL(k_actq_bwd_colbias, dim3((unsigned)slices, (unsigned)parts), dim3(256), 0, (hipStream_t)stream, z, g, gz, R, F, ld_z,
+                       ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, gbias, rows_per_part);
+    return launch_status("fqss_actq_bwd_colbias");
 }
 
 extern "C" int fqss_wq_observe(const float* w, int64_t outer, int64_t C, int64_t inner, float* qmin, float* qmax,

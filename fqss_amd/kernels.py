@@ -125,6 +125,23 @@ def actq_bwd(z, g, act, slope, qmode, qmin, qmax, gacc, gbias=None, C=0, out=Non
     return gz
 
 
+def actq_bwd_colbias(z, g, act, slope, qmode, qmin, qmax, gacc, gbias):
+    """actq_bwd over a row linear's output [..., F] that also adds the bias gradient (column sums of gz) into gbias [F]"""
+    _need_gpu(z, g, gbias)
+    F = z.shape[-1]
+    z, R, ld_z = _rows(z, F)
+    g, R2, ld_g = _rows(g, F)
+    assert R == R2, "actq_bwd_colbias: z/g shape mismatch"
+    gz = torch.empty(*z.shape, device=z.device, dtype=torch.float32)
+    _lib.call("fqss_actq_bwd_colbias", _p(z), _p(g), _p(gz), R, F, ld_z, ld_g, F, act, _p(slope), qmode, _p(qmin), _p(qmax), _p(gacc),
+              _p(gbias), _stream())
+    return gz
+
+
+def colbias_ok(F):
+    return F % 4 == 0 and F <= 64 * 2048
+
+
 # ------------------------------------------------------------------ K2
 def _w_layout(shape, axis):
     outer = 1

@@ -63,6 +63,45 @@ class RowLinear(Function):
         return gx, gw, gb
 
 
+def _rowlinear_wgrad(ctx_needs_w, x, w, gz):
+    """dL/dW of z = x @ w^T: into the step's dL/dW_q arena when w was fake-quantized by runtime.QuantTables, else the autograd way"""
+    gwq = getattr(w, "_fqss_gwq", None)
+    if gwq is not None:
+        K.rowlin_bwd_w(gz, x, gwq)
+        return None
+    if ctx_needs_w:
+        gw, direct = _param_grad(w, w)
+        K.rowlin_bwd_w(gz, x, gw)
+        return None if direct else gw
+    return None
+
+
+class RowLinearActQ(Function):
+    """fq(act(x @ w^T + bias)) -- LinearQ / LinearNlQ (ReLU, PReLU) in the quantizing phase as ONE autograd node: the forward is the row
+    GEMM (on codes when both operands carry them) + the quantizer pass; the backward runs the quantizer's STE, its range partials AND
+    the bias gradient (column sums) in one pass over the gradient (fqss_actq_bwd_colbias), then the two GEMMs -- no fqss_colsum pass."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, slope, qmin, qmax, act, q, qops, slope_param, flat):
+        touch(w, bias)
+        z = K.qrow_fwd(qops[0].idx, qops[1], bias, qops[0].qmin, qops[0].qmax) if qops is not None else K.rowlin_fwd(x, w, bias)
+        y = ops._epilogue_fwd(z.view(flat) if flat is not None else z, act, slope, q).view(z.shape)     # long rows for the streaming pass
+        ctx.save_for_backward(x, w, z, slope)
+        ctx.bias, ctx.q, ctx.act, ctx.sp = bias, q, act, slope_param
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, z, slope = ctx.saved_tensors
+        q = ctx.q
+        gb, gb_direct = _param_grad(ctx.bias, ctx.bias)
+        gz = K.actq_bwd_colbias(z, g.contiguous(), ctx.act, slope, q.qmode, q.qmin, q.qmax, q.gacc, gb)
+        g_slope, g_min, g_max = ops._flush_ranges(q, slope, ctx.sp, ctx.act)
+        gx = K.rowlin_bwd_x(gz, w) if ctx.needs_input_grad[0] else None
+        gw = _rowlinear_wgrad(ctx.needs_input_grad[1], x, w, gz)
+        return gx, gw, (None if gb_direct else gb), g_slope, g_min, g_max, None, None, None, None, None
+
+
 QROW = __import__("os").environ.get("FQSS_QROW", "1") != "0"    # student linears on codes (csrc/qrow.hip); 0: fp32-equivalent GEMM
 
 

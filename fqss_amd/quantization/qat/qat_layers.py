@@ -12,6 +12,8 @@ The classes only reachable from the Sepformer / HTDemucs configs (LinearNlQ, Con
 BatchNormQ, Conv1dGnNlQ, ConvTr2dDecoderQ, ...) are later rows of SURVEY.md §8 and raise NotImplementedError until their
 kernels exist -- there is no ATen fallback.
 """
+import math
+
 import torch
 import torch.nn as nn
 
@@ -644,8 +646,33 @@ def fq_node(aq, x, nl=None, codes=False, q=None):
     return y
 
 
+FUSE_ROWQ = __import__("os").environ.get("FQSS_FUSE_ROWQ", "1") != "0"    # 0: row linear, quantizer and bias sums as separate nodes (A/B, tests)
+
+
 def run_linear(lin, x, weight, nl, aq):
-    return fq_node(aq, ops_dp.row_linear(x, weight, lin.bias), nl)
+    return linear_fq(x, weight, lin.bias, nl, aq)
+
+
+def linear_fq(x, weight, bias, nl, aq):
+    """fq(nl(x @ weight^T + bias)) on row-major tensors: LinearQ / LinearNlQ and the attention output projection"""
+    q = None
+    if aq is not None and FUSE_ROWQ and bias is not None and weight.dim() == 2 and (nl is None or isinstance(nl, (nn.ReLU, nn.PReLU))):
+        q = aq.qctx()
+        if q.qmode == ops.Q_QUANT and q.gacc is not None and K.colbias_ok(weight.shape[0]):
+            # quantizing phase: one node for linear + quantizer, the bias gradient rides in the quantizer's backward pass
+            act, slope = _act_of(nl)
+            qops = ops_dp.qrow_operands(x, weight)
+            q.no_codes, q.carrier = True, False
+            n = x.numel() // x.shape[-1] * weight.shape[0]
+            cols = _FLAT_COLS.get(n)
+            if cols is None:
+                cols = _FLAT_COLS[n] = next((c for c in range(16384, 1008, -16) if n % c == 0), 0) if n >= 4096 else 0
+            y = ops_dp.RowLinearActQ.apply(x if qops is not None else ops.real(x), weight, bias, slope, q.qmin, q.qmax, act, q, qops, slope,
+                                           (n // cols, cols) if cols else None)
+            aq.after_forward(q)
+            q.idx = None
+            return y
+    return fq_node(aq, ops_dp.row_linear(x, weight, bias), nl, q=q)
 
 
 def run_layernorm(ln, x, aq):
@@ -700,7 +727,7 @@ def run_mha(mha, x, w_in, w_out, aqs, aq_head, aq_out):
         ranges = [r for a in aqs[:4] for r in (a.min_range, a.max_range)]
         heads = ops_dp.MhaCore.apply(X, mha.num_heads, aqs, *ranges)
     heads = fq_node(aq_head, heads, codes=True)
-    return fq_node(aq_out, ops_dp.row_linear(heads, w_out, mha.out_proj.bias))
+    return linear_fq(heads, w_out, mha.out_proj.bias, None, aq_out)
 
 
 def run_mha_x(mha, query, key, value, w_in, w_out, aqs, aq_head, aq_out):
@@ -717,7 +744,7 @@ def run_mha_x(mha, query, key, value, w_in, w_out, aqs, aq_head, aq_out):
         ranges = [r for a in aqs[:4] for r in (a.min_range, a.max_range)]
         heads = ops_dp.MhaCoreX.apply(Xq, Xkv, mha.num_heads, bool(mha.batch_first), aqs, *ranges)
     heads = fq_node(aq_head, heads, codes=True)
-    return fq_node(aq_out, ops_dp.row_linear(heads, w_out, mha.out_proj.bias))
+    return linear_fq(heads, w_out, mha.out_proj.bias, None, aq_out)
 
 
 class LayerNormQ(LayerQ):

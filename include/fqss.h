@@ -87,6 +87,13 @@ int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64
  * gacc = 0: hands the fp64 range/slope partials of fqss_actq_bwd over to fp32 parameter gradients */
 int fqss_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope, fqss_stream_t stream);
 
+/* fqss_actq_bwd for the output of a ROW linear, z [R][F] with the features contiguous (F % 4 == 0, 16-B aligned rows): also accumulates
+ * the linear's bias gradient gbias[f] += sum_r gz[r][f] -- replaces fqss_actq_bwd + fqss_colsum of LinearQ / LinearNlQ
+ * (qat_layers.py:521-561) and of the attention output projection */
+int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g,
+                          int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin,
+                          const float* qmax, double* gacc, float* gbias, fqss_stream_t stream);
+
 /* running min/max of a plain tensor into obs_ws (used by the splitter's global max, process.py:24) */
 int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* obs_ws,
                 fqss_stream_t stream);

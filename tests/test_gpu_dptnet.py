@@ -798,3 +798,40 @@ def test_layernormq_one_kernel_each_way_equals_the_two_node_form(C, monkeypatch)
     close(gb1, gb0, 1e-5)
     close(gmn1, gmn0, 1e-5)
     close(gmx1, gmx0, 1e-5)
+
+
+@pytest.mark.parametrize("Ci,Co,relu", [(64, 256, True), (256, 64, False), (64, 1024, True), (96, 200, False)])
+def test_linearq_one_node_equals_the_separate_nodes(Ci, Co, relu, monkeypatch):
+    """LinearQ / LinearNlQ in the quantizing phase as ONE autograd node whose quantizer backward also sums the bias gradient
+    (ops_dp.RowLinearActQ, fqss_actq_bwd_colbias) against row linear + quantizer node + fqss_colsum: output and dL/dx bit-identical,
+    bias / weight / range gradients equal up to summation order.  (200 features: the last 64-feature slice of the kernel is partial.)"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    res = []
+    x0 = rnd(50, 20, Ci, seed=5, scale=1.0)
+    g0 = rnd(50, 20, Co, seed=6)
+    for fuse in (False, True):
+        monkeypatch.setattr(QL, "FUSE_ROWQ", fuse)
+        torch.manual_seed(0)
+        lin = nn.Linear(Ci, Co)
+        with torch.no_grad():
+            lin.bias.copy_(rnd(Co, seed=8, scale=0.2))
+        L = (QL.LinearNlQ(lin, nn.ReLU()) if relu else QL.LinearQ(lin)).cuda()
+        x = x0.cuda().requires_grad_(True)
+        with torch.no_grad():
+            L(x)                                   # observer call: weight ranges recorded, activation range from the data
+        aq = L.activation_fake_quantize
+        aq.n_iter = aq.max_observations
+        with torch.no_grad():
+            aq.min_range.fill_(-0.2 if relu else -0.9)
+            aq.max_range.fill_(1.1)
+        y = L(x)
+        y.backward(g0.cuda())
+        res.append((y.detach(), x.grad.clone(), lin.bias.grad.clone(), lin.weight.grad.clone(), aq.min_range.grad.clone(),
+                    aq.max_range.grad.clone()))
+    (y0, gx0, gb0, gw0, gmn0, gmx0), (y1, gx1, gb1, gw1, gmn1, gmx1) = res
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    assert float(gb0.abs().max()) > 0
+    close(gb1, gb0, 1e-5)
+    close(gw1, gw0, 1e-5)
+    close(gmn1, gmn0, 1e-5)
+    close(gmx1, gmx0, 1e-5)
