@@ -80,6 +80,8 @@ __device__ PairSdr pair_sdr(double Sx, double Sy, double Sxx, double Syy, double
 //   weights[1, B]`: at B = 1 the sample's w, at B = 2 (= n_src) the weight of STUDENT SOURCE j is w[j], in both samples (the host refuses
 //   B > 2, where that broadcast raises).  The reference projects the teacher / target on the student there (roles swapped): the ratio
 //   is symmetric up to eps / energy ~ 1e-11, the same pair_sdr serves both.
+// per_sample = 2: the teacher-free loss of kd_lambda = 0 (mysystem.py:153-156: asteroid's PITLossWrapper(pairwise_neg_sisdr), restated in
+//   oracle/fqss_oracle.py::neg_sisdr_pit): mean_b min_perm mean_src -10 log10(sdr(e_p(i), t_i) + eps); the teacher slots are ignored.
 __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_lambda, double* stats, float* out,
                                                     float* w_out, float* sisdr_out, int per_sample, int use_threshold, float threshold) {
     __shared__ double red[2 * 16];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_la
     __shared__ int sh_keep;
     const int b = threadIdx.x;
     const double Td = (double)T;
-    double task_b = 0.0, kd_b = 0.0, wb = 0.0;
+    double task_b = 0.0, kd_b = 0.0, wb = 0.0, pit_db = 0.0;
     int pt = 0, pf = 0;  // selected permutation (0: identity, 1: swapped) for task / kd
     PairSdr st[2][2], sf[2][2];
     if (b < B) {
@@ -110,16 +112,20 @@ __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_la
         const double t0 = -0.5 * (st[0][0].sdr + st[1][1].sdr), t1 = -0.5 * (st[1][0].sdr + st[0][1].sdr);
         pt = t1 < t0 ? 1 : 0;
         task_b = -(pt ? t1 : t0);
+        if (per_sample == 2) {      // the PIT runs over the mean of the dB values here, not over the mean ratio
+            pt = le1 < le0 ? 1 : 0;
+            pit_db = pt ? le1 : le0;
+        }
         w_out[b] = (float)wb;
         sisdr_out[b] = (float)(-sdrqs);
-        if (per_sample && b < 2) sh_w[b] = wb;
+        if (per_sample == 1 && b < 2) sh_w[b] = wb;
     }
-    if (per_sample) {
+    if (per_sample == 1) {
         if (threadIdx.x == 0) sh_keep = 0;
         __syncthreads();
     }
     double wsrc[2] = {wb, wb};      // KD weight of student source 0 / 1 in this sample
-    if (per_sample && B == 2) {
+    if (per_sample == 1 && B == 2) {
         wsrc[0] = sh_w[0];
         wsrc[1] = sh_w[1];
     }
@@ -140,7 +146,22 @@ __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_la
     const double task = sh_task, kd = sh_kd;
     const double lam = (double)kd_lambda;
     double gt = 0.0, gk[2] = {0.0, 0.0};     // d loss / d (task ratio of a pair), d loss / d (kd ratio of student source j's pair)
-    if (!per_sample) {
+    double gti[2] = {0.0, 0.0};              // mode 2: d loss / d (ratio of the pair of estimate i): the log is taken per pair
+    if (per_sample == 2) {
+        double lv[2] = {(b < B) ? pit_db : 0.0, 0.0};
+        block_sum<double, 2>(lv, red);
+        if (threadIdx.x == 0) {
+            out[0] = (float)(lv[0] / (double)B);
+            out[1] = 0.0f;
+            out[2] = (float)task;
+            out[3] = 0.0f;
+        }
+        if (b < B)
+            for (int i = 0; i < 2; ++i) {
+                const int jt = pt ? 1 - i : i;
+                gti[i] = -10.0 / (log(10.0) * (st[i][jt].sdr + kEps)) * 0.5 / (double)B;
+            }
+    } else if (!per_sample) {
         const double arg = (1.0 - lam) * task + lam * kd + kEps;
         if (threadIdx.x == 0) {
             out[0] = (float)(-10.0 * log10(arg));
@@ -182,8 +203,9 @@ __global__ __launch_bounds__(1024) void k_kd_final(int B, int64_t T, float kd_la
         for (int i = 0; i < 2; ++i) {
             // target index paired with estimate i: perm p has est p[j] on tgt j -> est i sits on tgt j with p[j]==i
             const int jt = pt ? 1 - i : i, jf = pf ? 1 - i : i;
-            cf[i][0] = gt * st[i][jt].cx + gk[i] * sf[i][jf].cx;  // coefficient of e~_i
-            cf[i][1] = gt * st[i][jt].cy;                         // coefficient of t~_jt
+            const double gti_ = (per_sample == 2) ? gti[i] : gt;
+            cf[i][0] = gti_ * st[i][jt].cx + gk[i] * sf[i][jf].cx;  // coefficient of e~_i
+            cf[i][1] = gti_ * st[i][jt].cy;                         // coefficient of t~_jt
             cf[i][2] = (double)jt;
             cf[i][3] = gk[i] * sf[i][jf].cy;                      // coefficient of f~_jf
             cf[i][4] = (double)jf;
@@ -312,6 +334,13 @@ extern "C" int fqss_kd_loss_per_sample(const float* est, const float* fest, cons
     FQSS_REQUIRE(B <= 2, "the per-sample KD weights broadcast [1, n_src, n_src] * [1, B]: B must be 1 or n_src = 2 (the reference raises otherwise)");
     return kd_loss_impl("fqss_kd_loss_per_sample", est, fest, tgt, B, T, kd_lambda, stats, out, w_out, sisdr_out, gest, 1,
                         use_threshold ? 1 : 0, threshold, stream);
+}
+
+extern "C" int fqss_pit_sisdr_loss(const float* est, const float* tgt, int B, int64_t T, double* stats, float* out, float* w_out,
+                                   float* sisdr_out, float* gest, fqss_stream_t stream) {
+    FQSS_REQUIRE(est && tgt && stats && out && w_out && sisdr_out, "null tensor");
+    FQSS_REQUIRE(B > 0 && B <= 1024 && T > 0, "B must be in 1..1024");
+    return kd_loss_impl("fqss_pit_sisdr_loss", est, tgt, tgt, B, T, 0.0f, stats, out, w_out, sisdr_out, gest, 2, 0, 0.0f, stream);
 }
 
 extern "C" int fqss_kd_moments(const float* est, const float* fest, const float* tgt, int B, int64_t T, double* stats,

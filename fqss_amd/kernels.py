@@ -699,6 +699,20 @@ def kd_loss(est, fest, tgt, kd_lambda, want_grad=True, per_sample=False, thresho
     return out, w, sisdr, gest
 
 
+def pit_sisdr_loss(est, tgt, want_grad=True):
+    """the teacher-free PIT SI-SDR loss (kd_lambda = 0): (out, sisdr [B], gest); out[0] = loss in dB (mean over the batch)"""
+    _need_gpu(est, tgt)
+    est, tgt = est.contiguous(), tgt.contiguous()
+    B, S, T = est.shape
+    assert S == 2, "the PIT kernel is built for n_src = 2"
+    dev = est.device
+    stats = torch.empty(B, 32, device=dev, dtype=torch.float64)
+    out, w, sisdr = torch.empty(4, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+    gest = torch.empty_like(est) if want_grad else None
+    _lib.call("fqss_pit_sisdr_loss", _p(est), _p(tgt), B, T, _p(stats), _p(out), _p(w), _p(sisdr), _p(gest), _stream())
+    return out, sisdr, gest
+
+
 def kd_moments(est, fest, tgt):
     """the 24 fp64 second-order moments per sample that the streaming pass of fqss_kd_loss accumulates ([B, 32], slots as in
     csrc/train_ops.hip: sums 0..5 of e0 e1 f0 f1 t0 t1, self products 6..11, e_i.t_j 12..15, e_i.f_j 16..19, f_i.t_j 20..23)"""

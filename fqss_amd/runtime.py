@@ -448,7 +448,10 @@ class KDTrainStep:
         # MFMA-bound GEMMs overlap the student's HBM-bound layers; inside a hipGraph capture this becomes a parallel
         # branch of the graph) and joins before the loss.
         cur = torch.cuda.current_stream()
-        if TEACHER_STREAM:
+        teacher_free = self.loss_kind != "l1_sdr" and not self.kd_lambda > 0        # kd_lambda = 0: plain PIT SI-SDR loss, no teacher
+        if teacher_free:
+            fest = None
+        elif TEACHER_STREAM:
             if self._tstream is None:
                 self._tstream = torch.cuda.Stream()
             self._tstream.wait_stream(cur)
@@ -461,7 +464,9 @@ class KDTrainStep:
                     est = self.model(x)
             else:
                 est = self.model(x)
-        if TEACHER_STREAM:
+        if teacher_free:
+            pass
+        elif TEACHER_STREAM:
             cur.wait_stream(self._tstream)
             fest.record_stream(cur)
         else:
@@ -471,6 +476,10 @@ class KDTrainStep:
                 self.source_weights = torch.ones(tgt.shape[1], device=tgt.device)
             loss, task, kd, w, gest = K.hd_kd_loss(est.detach(), fest, tgt, self.source_weights, self.kd_lambda, want_grad=True)
             res = dict(loss=loss, task=task, kd=kd, w=w, gnorm=a.gnorm, est=est.detach())
+        elif teacher_free:
+            # mysystem.py:153-156: PITLossWrapper(pairwise_neg_sisdr) on the student alone
+            out, sisdr, gest = K.pit_sisdr_loss(est.detach(), tgt, want_grad=True)
+            res = dict(loss=out[0], kd_loss=out[1], task=out[2], kd=out[3], w=None, sisdr=sisdr, gnorm=a.gnorm, est=est.detach())
         else:
             # "sisdr_pit_per_sample": the speechbrain env's objective (log per sample, thresholded mean; csrc/train_ops.hip)
             out, w, sisdr, gest = K.kd_loss(est.detach(), fest, tgt, self.kd_lambda, want_grad=True,

@@ -14,11 +14,8 @@ class System:
     default_monitor = "val_loss"
 
     def __init__(self, model, fmodel, kd_lambda, lr=1e-3, clip=5.0, comm=None, betas=(0.9, 0.999)):
-        if not kd_lambda > 0:
-            # the reference falls back to the plain PIT SI-SDR loss without a teacher (mysystem.py:153-156); that loss has no HIP
-            # kernel here (the fused step is the KD objective of :124-151): refused instead of building a half-initialised System
-            raise NotImplementedError("asteroid env: the QAT training path is the KD step (training_cfg.kd_lambda > 0); the teacher-free "
-                                      "PIT SI-SDR loss of kd_lambda = 0 is not built")
+        # kd_lambda = 0: the reference trains on the plain PIT SI-SDR loss without the teacher (mysystem.py:153-156); KDTrainStep then
+        # runs fqss_pit_sisdr_loss and never calls the teacher
         self.model = model
         self.fmodel = fmodel
         self.kd_lambda = kd_lambda

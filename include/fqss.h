@@ -374,6 +374,11 @@ int fqss_kd_loss(const float* est, const float* fest, const float* tgt, int B, i
 int fqss_kd_loss_per_sample(const float* est, const float* fest, const float* tgt, int B, int64_t T,
                             float kd_lambda, int use_threshold, float threshold, double* stats, float* out,
                             float* w_out, float* sisdr_out, float* gest, fqss_stream_t stream);
+/* the teacher-free loss of kd_lambda = 0 (mysystem.py:153-156: PITLossWrapper(pairwise_neg_sisdr, pit_from="pw_mtx") for n_src = 2):
+ * out[0] = mean_b min_perm mean_src -10 log10(si_sdr(est_p(i), tgt_i) + eps), out[2] = the mean task ratio (logging), gest = dL/dest;
+ * sisdr_out[b] = the sample's best-permutation SI-SDR in dB; buffers as fqss_kd_loss */
+int fqss_pit_sisdr_loss(const float* est, const float* tgt, int B, int64_t T, double* stats, float* out, float* w_out,
+                        float* sisdr_out, float* gest, fqss_stream_t stream);
 /* the streaming pass of fqss_kd_loss alone: stats[b][0..23] = the 24 fp64 second-order moments of sample b (sums of e0 e1 f0 f1 t0 t1,
  * their self products, e_i.t_j, e_i.f_j, f_i.t_j; row stride 32) -- what the evaluation forms of SDR / PairwiseWSDR
  * (wsdr.py:10-95) are computed from */

@@ -26,6 +26,13 @@ def test_asteroid_env_trains_and_exports(tmp_path):
     assert os.path.exists(os.path.join(conf["work_dir"], "conf.yml"))
     with pytest.raises(RuntimeError):
         T.train(str(yml), "cpu")
+    # kd_lambda = 0: the teacher-free PIT SI-SDR loss of mysystem.py:153-156 (fqss_pit_sisdr_loss; the teacher is never run)
+    conf["work_dir"] = str(tmp_path / "run0")
+    conf["training_cfg"].update(kd_lambda=0, epochs=1)
+    yml0 = tmp_path / "cfg0.yaml"
+    yml0.write_text(yaml.safe_dump(conf))
+    hist0 = T.train(str(yml0), "cuda")
+    assert len(hist0) == 1 and torch.isfinite(torch.tensor(hist0[0]["loss"]))
 
 
 def test_asteroid_env_trains_dptnet(tmp_path):

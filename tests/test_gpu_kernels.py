@@ -211,6 +211,23 @@ def test_kd_loss_per_sample_speechbrain_objective():
         K.kd_loss(e_all.cuda(), f_all.cuda(), s.cuda(), 0.1, per_sample=True)
 
 
+def test_pit_sisdr_loss_teacher_free():
+    """fqss_pit_sisdr_loss (kd_lambda = 0, mysystem.py:153-156) against the oracle's neg_sisdr_pit: loss 1e-5, per-sample SI-SDR 1e-3 dB,
+    dL/d est; one sample has its sources swapped so both permutations are exercised"""
+    x, s = O.synth_batch(4, 16000, seed=5)
+    e = s + 0.3 * rnd(4, 2, 16000, seed=7, scale=0.05)
+    e[2] = s[2, [1, 0]] + 0.1 * rnd(2, 16000, seed=9, scale=0.05)
+    er = e.clone().requires_grad_(True)
+    loss = O.neg_sisdr_pit(er, s)
+    loss.backward()
+    out, sisdr, gest = K.pit_sisdr_loss(e.cuda(), s.cuda())
+    np.testing.assert_allclose(out[0].item(), loss.item(), rtol=1e-5)
+    per = torch.stack([-O.neg_sisdr_pit(e[b:b + 1], s[b:b + 1]) for b in range(4)])
+    np.testing.assert_allclose(sisdr.cpu().numpy(), per.numpy(), atol=1e-3)
+    gr = er.grad.numpy()
+    np.testing.assert_allclose(gest.cpu().numpy(), gr, rtol=5e-4, atol=2e-5 * float(np.abs(gr).max()))
+
+
 def _lib_error():
     from fqss_amd import _lib
     return _lib.FqssError
