@@ -14,6 +14,7 @@ import torch
 
 from . import kernels as K
 from . import ops
+from . import ops_dp
 
 
 class ParamArena:
@@ -180,16 +181,30 @@ class QuantTables:
         self.flush_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.aqs = aqs
         # ---- weight quantizers --------------------------------------------------------------------
+        from .quantization.qat.qat_layers import LSTMQ, MultiheadAttentionQ
+
+        def fits(wqm, w):
+            return isinstance(wqm, GradientWeightFakeQuantize) and isinstance(w, torch.nn.Parameter) and tuple(wqm.min_range.shape) == tuple(
+                1 if d != wqm.axis else w.shape[d] for d in range(w.dim()))
+
         owners = []
         for layer in model.modules():
             wqm = getattr(layer, "weight_fake_quantize", None)
             if isinstance(wqm, GradientWeightFakeQuantize):
-                for cand in ("conv1d", "convTr1d", "residual_encoder"):
+                # convolutions (channel-first and frame path) and the row-major linears of the dual-path / transformer layers
+                for cand in ("conv1d", "convTr1d", "residual_encoder", "linear", "conv2d"):
                     conv = getattr(layer, cand, None)
-                    if conv is not None and hasattr(conv, "weight") and tuple(wqm.min_range.shape) == tuple(
-                            1 if d != wqm.axis else conv.weight.shape[d] for d in range(conv.weight.dim())):
+                    if conv is not None and fits(wqm, getattr(conv, "weight", None)):
                         owners.append((wqm, conv.weight))
                         break
+            if isinstance(layer, MultiheadAttentionQ):
+                for wqm, w in ((layer.weight_fake_quantize_in, layer.mha.in_proj_weight), (layer.weight_fake_quantize_out, layer.mha.out_proj.weight)):
+                    if fits(wqm, w):
+                        owners.append((wqm, w))
+            if isinstance(layer, LSTMQ):
+                for name, wqm in layer.weight_quantizers_dict.items():
+                    if fits(wqm, getattr(layer.lstm, name, None)):
+                        owners.append((wqm, getattr(layer.lstm, name)))
         # layers declared as same-input pairs by their parent (`fqss_linear_pairs`) get adjacent storage: one
         # concatenated code image [Co1+Co2][Ci] (+ transposed, scales, row sums) and one dL/dW_q block, so that the
         # paired q-GEMMs (ops.LinearActQPair) see them as a single weight
@@ -236,6 +251,8 @@ class QuantTables:
             wq = self.wq_store[off:off + w.numel()].view(shape)
             gwq = self.gwq[off:off + w.numel()].view(shape)
             pw = axis == 0 and w.dim() == 3 and shape[2] == 1 and K.q_eligible(shape[1], shape[0])
+            # row-major linear weight [Co, Ci]: the same code image serves the int8 row GEMM (csrc/qrow.hip)
+            pw = pw or (axis == 0 and w.dim() == 2 and ops_dp.QROW and K.qrow_eligible(shape[1]))
             wc = None
             ldT = C
             if pw and id(w) in partner:

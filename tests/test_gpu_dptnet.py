@@ -835,3 +835,11 @@ def test_linearq_one_node_equals_the_separate_nodes(Ci, Co, relu, monkeypatch):
     close(gw1, gw0, 1e-5)
     close(gmn1, gmn0, 1e-5)
     close(gmx1, gmx0, 1e-5)
+
+
+def test_dptnet_batched_quantizer_tables_cover_every_weight():
+    """QuantTables on the tiny DPTNet: all 36 weight quantizers (convolutions, LinearQ, attention projections, the four LSTM matrices
+    of every LSTMQ, the 1x1 Conv2dQ, the linear decoder) run from the tables -- output bit-identical, every gradient equal"""
+    from tests.helpers_segments import check_batched_tables
+    x, tgt = O.synth_batch(1, 4000, seed=3)
+    check_batched_tables(lambda: build_pair(0, **TINY), x.cuda(), tgt.cuda(), 36, step_kw=dict(kd_lambda=0.1, clip=0.0))
