@@ -389,13 +389,29 @@ class LstmBi(Function):
         H = whh.shape[2]
         dG = K.lstm_bwd(gout, whh, gsav, csav, S, B, H)                  # [S, B, 8H]
         gx = K.rowlin_bwd_x(dG, wih) if ctx.needs_input_grad[0] else None
-        gwih = torch.zeros_like(wih)
-        K.rowlin_bwd_w(dG, x, gwih)
-        gwhh = torch.zeros_like(whh)
+        # weights fake-quantized by runtime.QuantTables carry no autograd history: their dL/dW_q is accumulated straight into the step's
+        # arena slot by the wgrad GEMM of that direction; otherwise one GEMM for both directions' W_ih into a fresh buffer
+        slots = [getattr(w, "_fqss_gwq", None) for w in ctx.weights]      # wih_f, whh_f, wih_r, whh_r
+        if slots[0] is not None and slots[2] is not None:
+            K.rowlin_bwd_w(dG[..., :4 * H], x, slots[0])
+            K.rowlin_bwd_w(dG[..., 4 * H:], x, slots[2])
+            gws = [None, None, None, None]
+        else:
+            gwih = torch.zeros_like(wih)
+            K.rowlin_bwd_w(dG, x, gwih)
+            gws = [gwih[:4 * H], None, gwih[4 * H:], None]
+        ghh = [slots[1] if slots[1] is not None else torch.zeros_like(whh[0]), slots[3] if slots[3] is not None else torch.zeros_like(whh[1])]
         if S > 1:
             # forward direction: dG_f[t] with h_f[t-1];  reverse direction: dG_r[t] with h_r[t+1]
-            K.rowlin_bwd_w(dG[1:, :, :4 * H], hout[:-1, :, :H], gwhh[0])
-            K.rowlin_bwd_w(dG[:-1, :, 4 * H:], hout[1:, :, H:], gwhh[1])
+            K.rowlin_bwd_w(dG[1:, :, :4 * H], hout[:-1, :, :H], ghh[0])
+            K.rowlin_bwd_w(dG[:-1, :, 4 * H:], hout[1:, :, H:], ghh[1])
+        gws[1] = None if slots[1] is not None else ghh[0]
+        gws[3] = None if slots[3] is not None else ghh[1]
+        if (slots[0] is None) != (slots[2] is None):       # (mixed: one direction's W_ih in the tables, the other not)
+            for i in (0, 2):
+                if slots[i] is not None:
+                    K.axpby_(slots[i], gws[i], 1.0)
+                    gws[i] = None
         # b_ih and b_hh of a direction get the same column sums of dG: ONE pass over dG for all four (it is the largest tensor of the
         # layer: four passes were 4 x 28 us per LSTM at cfg 3), then four 4H-element adds
         cs = torch.zeros(8 * H, device=dG.device, dtype=torch.float32)
@@ -405,13 +421,6 @@ class LstmBi(Function):
             buf, direct = _param_grad(p, p)
             K.axpby_(buf, cs[lo:lo + 4 * H], 1.0)
             gbs.append(None if direct else buf)
-        # weights fake-quantized by runtime.QuantTables carry no autograd history: their dL/dW_q goes into the step's arena slot
-        gws = [gwih[:4 * H], gwhh[0], gwih[4 * H:], gwhh[1]]
-        for i, w in enumerate(ctx.weights):
-            gwq = getattr(w, "_fqss_gwq", None)
-            if gwq is not None:
-                K.axpby_(gwq, gws[i], 1.0)
-                gws[i] = None
         return gx, gws[0], gws[1], gbs[0], gbs[1], gws[2], gws[3], gbs[2], gbs[3], None, None, None
 
 
