@@ -366,8 +366,13 @@ struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
     int64_t sBk, sBj;
     int64_t sCi;
     int ksplit, kchunk;
+    const void* Bq;
+    const float* scale_k;
+    const float* qmin_x;
+    const float* qmax_x;
 };
 int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used);
+int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what);
 }  // namespace fqss
 
 static bool x3_enabled() {
@@ -378,7 +383,7 @@ static bool x3_enabled() {
 static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used) {
     *used = false;
     if (!x3_enabled()) return FQSS_OK;
-    GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk};
+    GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk, nullptr, nullptr, nullptr, nullptr};
     return launch_gemm_x3(h, a_kc, b_kc, atomic, s, what, used);
 }
 
@@ -422,6 +427,51 @@ extern "C" int fqss_rowlin_bwd_x(const float* gz, const float* w, float* gx, int
     int rc = try_x3(g, true, false, false, (hipStream_t)stream, "fqss_rowlin_bwd_x", &used);
     if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, true, false, false, 1, (hipStream_t)stream, "fqss_rowlin_bwd_x");
+}
+
+// The student's row-major gradient GEMMs on codes (csrc/gemm_x3.hip, coded-B forms): the 8-bit operand is ONE exact bf16 plane, so the
+// product count is three instead of six.
+//   fqss_qrow_bwd_x: gx[r][i]  = sum_o gz[r][o] * (dw[o] * wi[o][i])        (wi int8 [Co][Ci], dense rows)
+//   fqss_qrow_bwd_w: gw[o][i] += sum_r gz[r][o] * (dx * c[r][i] + min_x)    (c u8 [R][ld_xc])
+extern "C" int fqss_qrow_bwd_x(const float* gz, const int8_t* wi, const float* dw, float* gx, int64_t R, int Ci, int Co, int64_t ld_gz,
+                               int64_t ld_gx, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && wi && dw && gx, "null tensor");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_gx >= Ci, "bad shape");
+    FQSS_REQUIRE(Ci % 4 == 0 && Co % 4 == 0 && ld_gz % 4 == 0 && aligned16(gz) && ((uintptr_t)wi & 3) == 0 && aligned16(dw),
+                 "coded dgrad: Ci, Co and the gz row stride must be multiples of 4, operands aligned");
+    if (R == 0) return FQSS_OK;
+    GemmArgs3 g{};
+    g.A = gz; g.B = nullptr; g.C = gx; g.bias = nullptr; g.bias_col = nullptr;
+    g.M = (int)R; g.N = Ci; g.K = Co;
+    g.sAi = ld_gz; g.sAk = 1;
+    g.sBk = Ci; g.sBj = 1;
+    g.sCi = ld_gx;
+    g.ksplit = 1; g.kchunk = Co;
+    g.Bq = wi; g.scale_k = dw;
+    return launch_gemm_x3q(g, 2, (hipStream_t)stream, "fqss_qrow_bwd_x");
+}
+
+extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R, int Ci,
+                               int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream) {
+    FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null tensor");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_xc >= Ci && ld_gw >= Ci, "bad shape");
+    FQSS_REQUIRE(Ci % 4 == 0 && Co % 4 == 0 && ld_gz % 4 == 0 && ld_xc % 4 == 0 && aligned16(gz) && ((uintptr_t)xc & 3) == 0,
+                 "coded wgrad: Ci, Co and the row strides must be multiples of 4, operands aligned");
+    if (R == 0) return FQSS_OK;
+    GemmArgs3 g{};
+    g.A = gz; g.B = nullptr; g.C = gw; g.bias = nullptr; g.bias_col = nullptr;
+    g.M = Co; g.N = Ci; g.K = (int)R;
+    g.sAi = 1; g.sAk = ld_gz;      // A(i=o, k=r) = gz[r*ld + o]
+    g.sBk = ld_xc; g.sBj = 1;      // B(k=r, j=i) = c[r*ld + i]
+    g.sCi = ld_gw;
+    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
+    int want = (int)cdiv(512, tiles);
+    int kchunk = (int)cdiv(cdiv(R, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    g.kchunk = kchunk;
+    g.ksplit = (int)cdiv(R, kchunk);
+    g.Bq = xc; g.qmin_x = qmin_x; g.qmax_x = qmax_x;
+    return launch_gemm_x3q(g, 1, (hipStream_t)stream, "fqss_qrow_bwd_w");
 }
 
 extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,

@@ -13,6 +13,8 @@
 // coalesced float4 loads along the contiguous dimension, then one 8-B LDS write per row and plane.
 // Measured dead end: k-tiles of 16 with two LDS buffers and one barrier per tile (split + store of tile kt+1 under the MFMAs of
 // tile kt) -- 5-12 % SLOWER than this single-buffered k-tile of 32 at the dual-path shapes (60 -> 66 us for 8500 x 256 x 1024).
+#include <type_traits>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -31,6 +33,11 @@ struct GemmArgs3 {
     int64_t sBk, sBj;
     int64_t sCi;
     int ksplit, kchunk;
+    // coded B operand (BQ != 0, see k_gemm_x3): 8-bit codes, ONE exact bf16 plane instead of three
+    const void* Bq;          // BQ = 1: u8 activation codes x [K = R][N = Ci];  BQ = 2: int8 weight codes [K = Co][N = Ci]
+    const float* scale_k;    // BQ = 2: delta_w[k], multiplied into A(i, k) before the split
+    const float* qmin_x;     // BQ = 1: range of the activation quantizer (device scalars): C = dx * sum A c + min_x * sum_k A
+    const float* qmax_x;
 };
 
 constexpr int XBK = 32, XLDK = 40;   // 40 shorts = 80 B row stride (as csrc/teacher.hip: conflict-light 16-B reads)
@@ -52,6 +59,9 @@ __device__ __forceinline__ void x_split3(float g, unsigned short& b1, unsigned s
 template <int ROWS, bool KC>
 struct TileIO {
     float4 v[4];
+    float4 sv_;                          // KC: scale of this thread's 4 k columns (coded-B dgrad), else unused
+    float rs_[4] = {0.f, 0.f, 0.f, 0.f};  // !KC: running sums over k of this thread's 4 rows (coded-B wgrad)
+    const float* sc_ = nullptr;
     int k0_, kend_, r0_, nrows_;
 
     __device__ __forceinline__ void load(const float* __restrict__ base, int64_t sr, int64_t sk, int r0, int nrows, int k0, int kend, int K) {
@@ -65,6 +75,7 @@ struct TileIO {
                 const int rc = min(r0 + r, nrows - 1), kc = min(k0 + k, kmax);
                 v[p] = *reinterpret_cast<const float4*>(base + (int64_t)rc * sr + kc);
             }
+            if (sc_ != nullptr) sv_ = *reinterpret_cast<const float4*>(sc_ + min(k0 + (tid & 7) * 4, kmax));
         } else {
             // 4 (rows) x 4 (k) block per thread: rb = block along the rows (contiguous in memory), kb = block along k
             const int rb = tid % (ROWS / 4), kb = min(tid / (ROWS / 4), XBK / 4 - 1);
@@ -78,14 +89,15 @@ struct TileIO {
         }
     }
 
-    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) const {
+    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) {
         const int tid = threadIdx.x;
         if constexpr (KC) {
 #pragma unroll
             for (int p = 0; p < ROWS / 32; ++p) {
                 const int f = tid + 256 * p, r = f >> 3, k = (f & 7) * 4;
                 const bool rv = r0_ + r < nrows_;
-                const float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+                if (sc_ != nullptr) { e[0] *= sv_.x; e[1] *= sv_.y; e[2] *= sv_.z; e[3] *= sv_.w; }
                 unsigned short h[3][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) x_split3((rv && k0_ + k + q < kend_) ? e[q] : 0.f, h[0][q], h[1][q], h[2][q]);
@@ -103,7 +115,11 @@ struct TileIO {
                 const bool rv = r0_ + rb * 4 + rr < nrows_;
                 unsigned short h[3][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x_split3((rv && k0_ + kb * 4 + q < kend_) ? e[q][rr] : 0.f, h[0][q], h[1][q], h[2][q]);
+                for (int q = 0; q < 4; ++q) {
+                    const float t = (rv && k0_ + kb * 4 + q < kend_) ? e[q][rr] : 0.f;
+                    rs_[rr] += t;
+                    x_split3(t, h[0][q], h[1][q], h[2][q]);
+                }
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     *reinterpret_cast<uint2*>(&pl[s][rb * 4 + rr][kb * 4]) =
@@ -113,7 +129,51 @@ struct TileIO {
     }
 };
 
-template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI>
+// B tile of 8-bit codes [k][j], j contiguous in memory: a thread owns a 4 (rows j) x 4 (k) block -- four 4-B loads -- and stores ONE
+// bf16 plane (an integer of at most 8 significant bits is exact in bf16)
+template <int ROWS, bool SIGNED>
+struct TileIOQ {
+    unsigned int v[4];
+    int k0_, kend_, r0_, nrows_;
+
+    __device__ __forceinline__ void load(const void* __restrict__ base, int64_t /*sr*/, int64_t sk, int r0, int nrows, int k0, int kend, int K) {
+        const int tid = threadIdx.x;
+        k0_ = k0; kend_ = kend; r0_ = r0; nrows_ = nrows;
+        const int rb = tid % (ROWS / 4), kb = min(tid / (ROWS / 4), XBK / 4 - 1);
+        const int rmax = ((nrows + 3) & ~3) - 4;
+        const int rc = min(r0 + rb * 4, rmax);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kc = min(k0 + kb * 4 + e, K - 1);
+            v[e] = *reinterpret_cast<const unsigned int*>((const unsigned char*)base + (int64_t)kc * sk + rc);
+        }
+    }
+
+    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) const {
+        const int tid = threadIdx.x;
+        if (tid / (ROWS / 4) >= XBK / 4) return;
+        const int rb = tid % (ROWS / 4), kb = tid / (ROWS / 4);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const bool rv = r0_ + rb * 4 + rr < nrows_;
+            unsigned short h[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned int byte = (v[q] >> (8 * rr)) & 0xFFu;
+                const float f = SIGNED ? (float)(int)(signed char)byte : (float)byte;
+                h[q] = (rv && k0_ + kb * 4 + q < kend_) ? x_bf(f) : (unsigned short)0;
+            }
+            *reinterpret_cast<uint2*>(&pl[0][rb * 4 + rr][kb * 4]) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        }
+    }
+};
+
+// BQ = 0: fp32 x fp32 (six products).  BQ = 1 / 2: the B operand arrives as 8-bit codes of a quantizer -- one exact bf16 plane, THREE
+// products -- which is what the student's row-major gradient GEMMs can use (the q-GEMMs of csrc/qgemm.hip in row-major form):
+//   1  wgrad  gw[o][i] += sum_r gz[r][o] x[r][i],  x = dx c + min_x:  A = gz^T, B = activation codes; the epilogue applies
+//             dx * acc + min_x * sum_r gz[r][o] (the k-sums of A's rows accumulate next to the split)
+//   2  dgrad  gx[r][i]  = sum_o gz[r][o] w_q[o][i], w_q = dw[o] wi:   A = gz scaled by dw[k] before the split, B = int8 weight codes
+template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0>
 __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     constexpr int BMt = 64 * MI, BNt = 64 * NI;
     __shared__ __attribute__((aligned(16))) unsigned short As[3][128][XLDK];
@@ -127,8 +187,18 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     const int kend = ATOMIC ? min(g.K, kbeg + g.kchunk) : g.K;
     const int i0 = blockIdx.y * BMt, j0 = blockIdx.x * BNt;
 
+    static_assert(BQ == 0 || !B_KC, "coded B tiles are j-contiguous");
     TileIO<BMt, A_KC> ta;
-    TileIO<BNt, B_KC> tb;
+    std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, TileIO<BNt, B_KC>> tb;
+    if constexpr (BQ == 2) ta.sc_ = g.scale_k;
+    auto load_b = [&](int k0) {
+        if constexpr (BQ != 0) tb.load(g.Bq, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
+        else tb.load(g.B, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
+    };
+    __shared__ float rsum_s[(BQ == 1) ? 128 : 1];
+    if constexpr (BQ == 1) {
+        if (threadIdx.x < 128) rsum_s[threadIdx.x] = 0.0f;
+    }
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -140,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     const int nkt = (kend - kbeg + XBK - 1) / XBK;
     if (nkt > 0) {
         ta.load(g.A, g.sAi, g.sAk, i0, g.M, kbeg, kend, g.K);
-        tb.load(g.B, g.sBj, g.sBk, j0, g.N, kbeg, kend, g.K);
+        load_b(kbeg);
         ta.store(As);
         tb.store(Bs);
     }
@@ -149,23 +219,27 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     for (int kt = 0; kt < nkt; ++kt) {
         // global loads of the next tile fly under the MFMAs (issued unconditionally: the last iteration re-reads a clamped tile)
         ta.load(g.A, g.sAi, g.sAk, i0, g.M, kbeg + (kt + 1) * XBK, kend, g.K);
-        tb.load(g.B, g.sBj, g.sBk, j0, g.N, kbeg + (kt + 1) * XBK, kend, g.K);
+        load_b(kbeg + (kt + 1) * XBK);
 #pragma unroll
         for (int kstep = 0; kstep < XBK / 16; ++kstep) {
-            bf16x8 af[3][MI], bfr[3][NI];
+            constexpr int NPB = BQ ? 1 : 3;     // planes of B
+            bf16x8 af[3][MI], bfr[NPB][NI];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     af[p][mi] = *reinterpret_cast<const bf16x8*>(&As[p][wm * (32 * MI) + mi * 32 + lr][kstep * 16 + 8 * lh]);
+                if (p < NPB) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    bfr[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[p][wn * (32 * NI) + ni * 32 + lr][kstep * 16 + 8 * lh]);
+                    for (int ni = 0; ni < NI; ++ni)
+                        bfr[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[p][wn * (32 * NI) + ni * 32 + lr][kstep * 16 + 8 * lh]);
+                }
             }
-            // smallest partial products first: l.h, h.l, m.m, m.h, h.m, h.h
-            constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+            // smallest partial products first: l.h, h.l, m.m, m.h, h.m, h.h   (coded B: l.c, m.c, h.c)
+            constexpr int NPROD = BQ ? 3 : 6;
+            constexpr int IA[6] = {2, BQ ? 1 : 0, BQ ? 0 : 1, 1, 0, 0}, IB[6] = {0, BQ ? 0 : 2, BQ ? 0 : 1, 0, 1, 0};
 #pragma unroll
-            for (int sp = 0; sp < 6; ++sp)
+            for (int sp = 0; sp < NPROD; ++sp)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -180,6 +254,19 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
         }
     }
 
+    float dx = 1.0f, mnx = 0.0f;
+    if constexpr (BQ == 1) {
+        // k-sums of A's rows: the threads of a row block (same rb, different kb) meet in LDS
+        if (threadIdx.x / (BMt / 4) < XBK / 4) {
+            const int rb = threadIdx.x % (BMt / 4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) atomicAdd(&rsum_s[rb * 4 + rr], ta.rs_[rr]);
+        }
+        __syncthreads();
+        const float lo = *g.qmin_x, hi = *g.qmax_x;
+        dx = (hi - lo) / 255.0f;
+        mnx = lo;
+    }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -191,6 +278,7 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
                 const int row = i0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M && col < g.N) {
                     float v = acc[mi][ni][r];
+                    if constexpr (BQ == 1) v = dx * v + mnx * rsum_s[row - i0];
                     if (g.bias != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias[row];
                     if (g.bias_col != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias_col[col];
                     float* dst = g.C + (int64_t)row * g.sCi + col;
@@ -234,6 +322,27 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
     else return FQSS_OK;
 #undef FQSS_X3
     *used = true;
+    return launch_status(what);
+}
+
+// coded-B forms (BQ = 1 wgrad, 2 dgrad); the caller has checked shapes and alignment
+int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what) {
+    if (g.M <= 0 || g.N <= 0) return FQSS_OK;
+    const bool atomic = bq == 1;
+    const int64_t zdim = atomic ? g.ksplit : 1;
+    int mi = 2, ni = 2;
+    if (g.N <= 64) ni = 1;
+    else if (g.M <= 64 || (g.M > 128 && cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 2 * 256)) mi = 1;
+    dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
+#define FQSS_X3Q(AK, AT, Q)                                                                                      \
+    do {                                                                                                         \
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 2, Q>), grid, block, 0, s, g);  \
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 1, Q>), grid, block, 0, s, g);        \
+        else hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 1, 2, Q>), grid, block, 0, s, g);                     \
+    } while (0)
+    if (bq == 1) FQSS_X3Q(false, true, 1);
+    else FQSS_X3Q(true, false, 2);
+#undef FQSS_X3Q
     return launch_status(what);
 }
 

@@ -1154,6 +1154,31 @@ def qrow_fwd(xc, wc, bias, qmin_x, qmax_x, out=None):
     return z
 
 
+def qrow_bwd_ok(Ci, Co):
+    return Ci % 4 == 0 and Co % 4 == 0
+
+
+def qrow_bwd_x(gz, wc):
+    """dL/dx of z = x @ w_q^T from the weight's int8 codes: gx[..., Ci] = gz[..., Co] @ (dw * wi)  (three bf16 products per k)"""
+    _need_gpu(gz)
+    Ci, Co = wc.Ci, wc.Co
+    gz, R, ld_gz = _rows(gz, Co)
+    gx = torch.empty(*gz.shape[:-1], Ci, device=gz.device, dtype=torch.float32)
+    _lib.call("fqss_qrow_bwd_x", _p(gz), _p(wc.idx), _p(wc.dw), _p(gx), R, Ci, Co, ld_gz, Ci, _stream())
+    return gx
+
+
+def qrow_bwd_w(gz, xc, qmin_x, qmax_x, gw):
+    """gw [Co, Ci] += gz^T @ dec(xc) from the activation's u8 codes (dense rows)"""
+    _need_gpu(gz, gw)
+    Co, Ci = gw.shape
+    assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci and gw.is_contiguous()
+    gz, R, ld_gz = _rows(gz, Co)
+    rm = rowmat(xc)
+    assert rm is not None and rm[0] == R and rm[1] == Ci
+    _lib.call("fqss_qrow_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), R, Ci, Co, ld_gz, rm[2], Ci, _stream())
+
+
 # ------------------------------------------------------------------ general convolution geometry (HTDemucs layers, SURVEY §8 row a15)
 class ConvGeom:
     """kernel / stride / zero padding / dilation of a 2-D convolution over [B, C, H, W] (1-D convs run with H = 1)"""

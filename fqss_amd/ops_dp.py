@@ -31,6 +31,26 @@ def touch(*ts):
             base._fqss_touched = True
 
 
+QROW_BWD = __import__("os").environ.get("FQSS_QROW_BWD", "1") != "0"    # gradient GEMMs of coded linears on the codes; 0: fp32 x fp32 (A/B, tests)
+
+
+def _rowlinear_dgrad(gz, w):
+    """dL/dx of z = x @ w^T: from the weight's int8 codes when it carries them (three bf16 products per k), else fp32 x fp32 (six)"""
+    wc = getattr(w, "_fqss_wcodes", None)
+    if QROW_BWD and wc is not None and w.dim() == 2 and wc.idx.is_contiguous() and K.qrow_bwd_ok(wc.Ci, wc.Co):
+        return K.qrow_bwd_x(gz, wc)
+    return K.rowlin_bwd_x(gz, w)
+
+
+def _rowlinear_wgrad_into(gz, x, xq, buf):
+    """buf [Co, Ci] += gz^T x: from the activation's u8 codes when the forward ran on them"""
+    if QROW_BWD and xq is not None and buf.dim() == 2 and buf.is_contiguous() and xq.idx.is_contiguous() \
+            and xq.idx.shape[-1] == buf.shape[1] and K.qrow_bwd_ok(buf.shape[1], buf.shape[0]):
+        K.qrow_bwd_w(gz, xq.idx, xq.qmin, xq.qmax, buf)
+    else:
+        K.rowlin_bwd_w(gz, x, buf)
+
+
 class RowLinear(Function):
     """z = x @ w^T + bias on the last dim -- F.linear of LinearQ / the MHA projections / the 1x1 Conv2dQ (qat_layers.py:521-536,
     889-901, 941).  w is the (possibly fake-quantized) weight [Co, Ci]; bias a parameter or None."""
@@ -46,14 +66,15 @@ class RowLinear(Function):
     def backward(ctx, gz):
         x, w = ctx.saved_tensors
         gz = gz.contiguous()
-        gx = K.rowlin_bwd_x(gz, w) if ctx.needs_input_grad[0] else None
+        xq = getattr(ctx, "xq", None)           # RowLinearQ: the codes the forward multiplied
+        gx = _rowlinear_dgrad(gz, w) if ctx.needs_input_grad[0] else None
         gw = None
         gwq = getattr(w, "_fqss_gwq", None)     # weight fake-quantized by runtime.QuantTables (no autograd history): dL/dW_q goes
         if gwq is not None:                     # into the step's arena, consumed by fqss_wq_multi_bwd
-            K.rowlin_bwd_w(gz, x, gwq)
+            _rowlinear_wgrad_into(gz, x, xq, gwq)
         elif ctx.needs_input_grad[1]:
             gw, direct = _param_grad(w, w)
-            K.rowlin_bwd_w(gz, x, gw)
+            _rowlinear_wgrad_into(gz, x, xq, gw)
             gw = None if direct else gw
         gb = None
         if ctx.bias is not None and ctx.needs_input_grad[2]:
@@ -63,15 +84,15 @@ class RowLinear(Function):
         return gx, gw, gb
 
 
-def _rowlinear_wgrad(ctx_needs_w, x, w, gz):
+def _rowlinear_wgrad(ctx_needs_w, x, w, gz, xq=None):
     """dL/dW of z = x @ w^T: into the step's dL/dW_q arena when w was fake-quantized by runtime.QuantTables, else the autograd way"""
     gwq = getattr(w, "_fqss_gwq", None)
     if gwq is not None:
-        K.rowlin_bwd_w(gz, x, gwq)
+        _rowlinear_wgrad_into(gz, x, xq, gwq)
         return None
     if ctx_needs_w:
         gw, direct = _param_grad(w, w)
-        K.rowlin_bwd_w(gz, x, gw)
+        _rowlinear_wgrad_into(gz, x, xq, gw)
         return None if direct else gw
     return None
 
@@ -88,6 +109,7 @@ class RowLinearActQ(Function):
         y = ops._epilogue_fwd(z.view(flat) if flat is not None else z, act, slope, q).view(z.shape)     # long rows for the streaming pass
         ctx.save_for_backward(x, w, z, slope)
         ctx.bias, ctx.q, ctx.act, ctx.sp = bias, q, act, slope_param
+        ctx.xq = qops[0] if qops is not None else None
         return y
 
     @staticmethod
@@ -97,8 +119,8 @@ class RowLinearActQ(Function):
         gb, gb_direct = _param_grad(ctx.bias, ctx.bias)
         gz = K.actq_bwd_colbias(z, g.contiguous(), ctx.act, slope, q.qmode, q.qmin, q.qmax, q.gacc, gb)
         g_slope, g_min, g_max = ops._flush_ranges(q, slope, ctx.sp, ctx.act)
-        gx = K.rowlin_bwd_x(gz, w) if ctx.needs_input_grad[0] else None
-        gw = _rowlinear_wgrad(ctx.needs_input_grad[1], x, w, gz)
+        gx = _rowlinear_dgrad(gz, w) if ctx.needs_input_grad[0] else None
+        gw = _rowlinear_wgrad(ctx.needs_input_grad[1], x, w, gz, ctx.xq)
         return gx, gw, (None if gb_direct else gb), g_slope, g_min, g_max, None, None, None, None, None
 
 
@@ -127,7 +149,7 @@ class RowLinearQ(Function):
     @staticmethod
     def forward(ctx, x, w, bias, xq, wc):
         ctx.save_for_backward(x, w)
-        ctx.bias = bias
+        ctx.bias, ctx.xq = bias, xq
         touch(w, bias)
         return K.qrow_fwd(xq.idx, wc, bias, xq.qmin, xq.qmax)
 

@@ -527,6 +527,15 @@ int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp, int C, fqs
 int fqss_qrow_fwd(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias,
                   const float* qmin_x, const float* qmax_x, float* z, int64_t R, int Ci, int Co, int64_t ld_x,
                   int64_t ld_z, fqss_stream_t stream);
+/* the gradient GEMMs of such a linear on the same codes (csrc/gemm_x3.hip, coded-B forms): the 8-bit operand is one exact bf16 plane,
+ * three MFMA products per k instead of the six of the fp32 x fp32 form.
+ *   fqss_qrow_bwd_x: gx[r][i]  = sum_o gz[r][o] * (dw[o] * wi[o][i])       wi int8 [Co][Ci] dense
+ *   fqss_qrow_bwd_w: gw[o][i] += sum_r gz[r][o] * (dx * c[r][i] + min_x)   c u8 [R][ld_xc], (dx, min_x) from the range scalars
+ * Ci, Co and the row strides are multiples of 4, operands 16-B (codes 4-B) aligned */
+int fqss_qrow_bwd_x(const float* gz, const int8_t* wi, const float* dw, float* gx, int64_t R, int Ci, int Co,
+                    int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
+int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw,
+                    int64_t R, int Ci, int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream);
 
 /* First layer kernels of cfg 5 (HTDemucs; the model itself is not built yet).
  * GELU is kind FQSS_UNARY_GELU of fqss_unary_fwd/bwd (erf form; the backward takes the INPUT x in place of y).

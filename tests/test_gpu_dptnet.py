@@ -843,3 +843,36 @@ def test_dptnet_batched_quantizer_tables_cover_every_weight():
     from tests.helpers_segments import check_batched_tables
     x, tgt = O.synth_batch(1, 4000, seed=3)
     check_batched_tables(lambda: build_pair(0, **TINY), x.cuda(), tgt.cuda(), 36, step_kw=dict(kd_lambda=0.1, clip=0.0))
+
+
+@pytest.mark.parametrize("R,Ci,Co", [(8500, 256, 1024), (8500, 1024, 256), (4850, 64, 256), (777, 64, 192), (300, 256, 768)])
+def test_coded_gradient_row_gemms(R, Ci, Co):
+    """fqss_qrow_bwd_x / fqss_qrow_bwd_w (the student's row-major dgrad / wgrad on the 8-bit codes: one exact bf16 plane, three products
+    per k) against fp64 and against the fp32 x fp32 form on the de-quantized operands: same fp32-grade accuracy"""
+    from fqss_amd import kernels as K
+    torch.manual_seed(R + Ci)
+    dev = "cuda"
+    gz = torch.randn(R, Co, device=dev) * torch.exp(torch.randn(R, Co, device=dev)) * 1e-3
+    w = torch.randn(Co, Ci, device=dev) * 0.05
+    rng = torch.full((Co, 1), 0.17, device=dev)
+    wc = K.wq_codes(w, -rng, rng)
+    wq = (wc.idx.float() * wc.dw[:, None]).contiguous()                       # the fake-quantized weight, exactly
+    xc = torch.randint(0, 256, (R, Ci), device=dev, dtype=torch.uint8)
+    lo, hi = torch.tensor([-1.3], device=dev), torch.tensor([2.1], device=dev)
+    x = (xc.float() * ((hi - lo) / 255.0) + lo).contiguous()
+    # dgrad
+    gx = K.qrow_bwd_x(gz, wc)
+    gx_f = K.rowlin_bwd_x(gz, wq)
+    ref = gz.double() @ wq.double()
+    nrm = float(ref.norm())
+    assert float((gx.double() - ref).norm()) <= 1e-6 * nrm and float((gx_f.double() - ref).norm()) <= 1e-6 * nrm
+    assert float((gx - gx_f).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # wgrad (accumulating)
+    gw = torch.full((Co, Ci), 0.5, device=dev)
+    K.qrow_bwd_w(gz, xc, lo, hi, gw)
+    gw_f = torch.full((Co, Ci), 0.5, device=dev)
+    K.rowlin_bwd_w(gz, x, gw_f)
+    ref = 0.5 + gz.double().t() @ (xc.double() * ((hi - lo).double() / 255.0) + lo.double())
+    nrm = float((ref - 0.5).norm())
+    assert float((gw.double() - ref).norm()) <= 2e-6 * nrm, float((gw.double() - ref).norm()) / nrm
+    assert float((gw_f.double() - ref).norm()) <= 2e-6 * nrm
