@@ -401,6 +401,7 @@ class LstmBi(Function):
         ctx.save_for_backward(x, wih, whh, hout, gsav, csav)
         ctx.params = (bih_f, bhh_f, bih_r, bhh_r)
         ctx.weights = (wih_f, whh_f, wih_r, whh_r)
+        ctx.xq = xq if on_codes else None
         touch(wih_f, whh_f, wih_r, whh_r)
         return hout
 
@@ -415,8 +416,8 @@ class LstmBi(Function):
         # arena slot by the wgrad GEMM of that direction; otherwise one GEMM for both directions' W_ih into a fresh buffer
         slots = [getattr(w, "_fqss_gwq", None) for w in ctx.weights]      # wih_f, whh_f, wih_r, whh_r
         if slots[0] is not None and slots[2] is not None:
-            K.rowlin_bwd_w(dG[..., :4 * H], x, slots[0])
-            K.rowlin_bwd_w(dG[..., 4 * H:], x, slots[2])
+            _rowlinear_wgrad_into(dG[..., :4 * H], x, ctx.xq, slots[0])      # on the input's codes when the projection ran on them
+            _rowlinear_wgrad_into(dG[..., 4 * H:], x, ctx.xq, slots[2])
             gws = [None, None, None, None]
         else:
             gwih = torch.zeros_like(wih)
