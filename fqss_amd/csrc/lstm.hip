@@ -179,18 +179,28 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
                                                                       float* __restrict__ dG, int S, int B, int Hrt) {
     const int H = HT > 0 ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dgs = smem;                   // [kNB][4H]
-    float* ps = smem + kNB * 4 * H;      // [4][kNB][H] partial dh_{t-1}
+    float* dgs = smem;                   // [kNB][4H]   (HT > 0: [kNB][4 blocks][4 quarters][HT/4 + 4])
+    float* ps = smem + (HT > 0 ? kNB * 16 * (HT / 4 + 4) : kNB * 4 * H);      // [4][kNB][H] partial dh_{t-1}
     const int dir = blockIdx.y;
     const int b0 = blockIdx.x * kNB;
     const int tid = threadIdx.x;
     const bool tv = tid < 4 * H;
     const int part = tv ? tid / H : 0, k = tv ? tid - part * H : 0;
     const float* Wc = whh + ((int64_t)dir * 4 * H + part * H) * H + k;   // column k of gate block `part`, row stride H
+    // HT > 0: a QUAD of lanes shares the four columns 4q .. 4q+3 of its gate block, lane kq of the quad keeps the row quarter
+    // [32 kq, 32 kq + 32) of each of them -- the same 128 weight registers as "one column per thread", but a lane reads a quarter of the
+    // block's dgates per step instead of all of them (64 -> 16 ds_read_b128 per wave and step: the LDS pipe of the CU was the longest
+    // part of a step, as in the forward); the four partial sums of a column meet by two quad-permute DPP adds
+    constexpr int RQ = HT > 0 ? HT / 4 : 1;                 // rows per lane and column
+    constexpr int DQS = RQ + 4;                             // quarter stride of the dgate image in LDS (floats): quarters on different banks
+    const int q4 = k >> 2, kq = k & 3;
     float wreg[HT > 0 ? HT : 1];
     if constexpr (HT > 0) {
+        const float* Wq = whh + ((int64_t)dir * 4 * H + part * H + kq * RQ) * H + q4 * 4;
 #pragma unroll
-        for (int r = 0; r < HT; ++r) wreg[r] = Wc[(int64_t)r * HT];
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) wreg[cc * RQ + r] = Wq[(int64_t)r * HT + cc];
     }
     for (int e = tid; e < 4 * kNB * H; e += blockDim.x) ps[e] = 0.f;
     const int cn = tid / H, ck = tid - cn * H;
@@ -228,8 +238,13 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
             const float d_f = ((dc * cprev) * (1.0f - gf)) * gf;
             const float d_g = (dc * gi) * (1.0f - gg * gg);
             dc_rec = dc * gf;
-            float* d = dgs + cn * 4 * H;
-            d[ck] = d_i; d[H + ck] = d_f; d[2 * H + ck] = d_g; d[3 * H + ck] = d_o;
+            if constexpr (HT > 0) {
+                float* d = dgs + cn * 16 * DQS + (ck / RQ) * DQS + (ck % RQ);        // [nb][gate block][row quarter][RQ + pad]
+                d[0] = d_i; d[4 * DQS] = d_f; d[8 * DQS] = d_g; d[12 * DQS] = d_o;
+            } else {
+                float* d = dgs + cn * 4 * H;
+                d[ck] = d_i; d[H + ck] = d_f; d[2 * H + ck] = d_g; d[3 * H + ck] = d_o;
+            }
             float* o = dG + (sb * 2 + dir) * 4 * H;
             o[ck] = d_i; o[H + ck] = d_f; o[2 * H + ck] = d_g; o[3 * H + ck] = d_o;
         }
@@ -240,16 +255,37 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
 #pragma unroll
             for (int nb = 0; nb < kNB; ++nb) acc[nb] = 0.f;
             if constexpr (HT > 0) {
+                float pc[4][kNB];
 #pragma unroll
-                for (int r = 0; r < HT; r += 4) {
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int nb = 0; nb < kNB; ++nb) pc[cc][nb] = 0.f;
+#pragma unroll
+                for (int r = 0; r < RQ; r += 4) {
 #pragma unroll
                     for (int nb = 0; nb < kNB; ++nb) {
-                        const float4 dv = *reinterpret_cast<const float4*>(dgs + nb * 4 * HT + part * HT + r);
-                        acc[nb] = fmaf(wreg[r], dv.x, acc[nb]);
-                        acc[nb] = fmaf(wreg[r + 1], dv.y, acc[nb]);
-                        acc[nb] = fmaf(wreg[r + 2], dv.z, acc[nb]);
-                        acc[nb] = fmaf(wreg[r + 3], dv.w, acc[nb]);
+                        const float4 dv = *reinterpret_cast<const float4*>(dgs + nb * 16 * DQS + (part * 4 + kq) * DQS + r);
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            pc[cc][nb] = fmaf(wreg[cc * RQ + r], dv.x, pc[cc][nb]);
+                            pc[cc][nb] = fmaf(wreg[cc * RQ + r + 1], dv.y, pc[cc][nb]);
+                            pc[cc][nb] = fmaf(wreg[cc * RQ + r + 2], dv.z, pc[cc][nb]);
+                            pc[cc][nb] = fmaf(wreg[cc * RQ + r + 3], dv.w, pc[cc][nb]);
+                        }
                     }
+                }
+                // sum over the quad (lanes kq = 0..3), then lane kq keeps column 4q + kq = its own column k
+#pragma unroll
+                for (int nb = 0; nb < kNB; ++nb) {
+                    float mine = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        float t = pc[cc][nb];
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                        t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                        mine = (kq == cc) ? t : mine;
+                    }
+                    acc[nb] = mine;
                 }
             } else {
                 for (int r = 0; r < H; ++r) {
@@ -293,7 +329,8 @@ extern "C" int fqss_lstm_bwd(const float* gout, const float* whh, const float* g
     dim3 grid((unsigned)cdiv(B, kNB), 2);
     const size_t lds = (size_t)(kNB * 4 * H + 4 * kNB * H) * sizeof(float);
     if (H == 128) {
-        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds, s, gout, whh, gsav, csav, dG, S, B, H);
+        const size_t lds128 = (size_t)(kNB * 16 * (128 / 4 + 4) + 4 * kNB * H) * sizeof(float);   // padded dgate image + partial dh
+        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds128, s, gout, whh, gsav, csav, dG, S, B, H);
     } else {
         const int threads = (int)cdiv(4 * H, 64) * 64;
         hipLaunchKernelGGL((k_lstm_bwd<0>), grid, dim3(threads), lds, s, gout, whh, gsav, csav, dG, S, B, H);
