@@ -19,7 +19,9 @@
 // shape whose N = 4 is not mostly padding at 2 sequences) has the plain-FMA rate at N = 2, and more sequences per workgroup do not
 // shorten a step (there are <= 250 sequences for 256 CUs: one workgroup per CU already; the recurrence is latency-, not throughput-bound).
 // What did help in round 2: each gate row applies its own sigmoid / tanh (all 8 waves, instead of the cell threads doing five
-// transcendentals per element on 4 waves) and the input projection is requested four steps ahead (409 -> 383 us per layer at S = 250).
+// transcendentals per element on 4 waves) and the input projection is requested four steps ahead (409 -> 383 us per layer at S = 250);
+// in the backward the quad / row-quarter split of the dgate image (the forward's trick: 64 -> 16 LDS reads per wave and step) and the
+// same four-step register ring for the saved activations: cfg 3 38.6 -> 37.2 ms per step.
 //
 // Saved for the backward: the four gate activations and the cell state per step (5H floats per step and sequence-direction).
 #include "fqss_dev.h"
@@ -209,24 +211,28 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
     // saved gate activations, cell state and incoming gradient of a step are fetched one step ahead (unconditional loads from
     // clamped indices, see k_lstm_fwd): without the prefetch every step began with an exposed global-memory round trip
     const int cnc = min(b0 + (cell ? cn : 0), B - 1), ckc = cell ? ck : 0;
-    float n_dh, n_i, n_f, n_g, n_o, n_c, n_cp;
-    auto fetch = [&](int step) {
+    // ... four steps ahead since round 2 (a ring of registers, as in k_lstm_fwd): a step is about as long as a global-memory round trip
+    struct BSt { float dh, i, f, g, o, c, cp; };
+    constexpr int kPF = 4;
+    BSt pf[kPF];
+    auto fetch = [&](BSt& d, int step) {
         const int sc = max(step, 0);
         const int t = dir == 0 ? sc : S - 1 - sc;
         const int64_t sb = (int64_t)t * B + cnc;
-        n_dh = gout[sb * 2 * H + dir * H + ckc];
+        d.dh = gout[sb * 2 * H + dir * H + ckc];
         const float* gsv = gsav + (sb * 2 + dir) * 4 * H;
-        n_i = gsv[ckc]; n_f = gsv[H + ckc]; n_g = gsv[2 * H + ckc]; n_o = gsv[3 * H + ckc];
-        n_c = csav[(sb * 2 + dir) * H + ckc];
+        d.i = gsv[ckc]; d.f = gsv[H + ckc]; d.g = gsv[2 * H + ckc]; d.o = gsv[3 * H + ckc];
+        d.c = csav[(sb * 2 + dir) * H + ckc];
         const int sp = max(sc - 1, 0);
         const int tp = dir == 0 ? sp : S - 1 - sp;
-        n_cp = csav[((((int64_t)tp * B + cnc) * 2) + dir) * H + ckc];
+        d.cp = csav[((((int64_t)tp * B + cnc) * 2) + dir) * H + ckc];
     };
-    fetch(S - 1);
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) fetch(pf[u], S - 1 - u);
     __syncthreads();
-    for (int step = S - 1; step >= 0; --step) {
+    auto one_step = [&](int step, const BSt& v) {
         const int t = dir == 0 ? step : S - 1 - step;
-        const float c_dh = n_dh, gi = n_i, gf = n_f, gg = n_g, go = n_o, cc = n_c, cprev = step > 0 ? n_cp : 0.f;
+        const float c_dh = v.dh, gi = v.i, gf = v.f, gg = v.g, go = v.o, cc = v.c, cprev = step > 0 ? v.cp : 0.f;
         if (cell) {
             const int64_t sb = (int64_t)t * B + b0 + cn;
             const float dh = c_dh +
@@ -248,7 +254,6 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
             float* o = dG + (sb * 2 + dir) * 4 * H;
             o[ck] = d_i; o[H + ck] = d_f; o[2 * H + ck] = d_g; o[3 * H + ck] = d_o;
         }
-        fetch(step - 1);
         __syncthreads();
         if (tv) {
             float acc[kNB];
@@ -298,7 +303,19 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
             for (int nb = 0; nb < kNB; ++nb) ps[(part * kNB + nb) * H + k] = acc[nb];
         }
         __syncthreads();
+    };
+    int done = 0;                               // steps S-1, S-2, ... are processed in rounds of the ring
+    for (; done + kPF <= S; done += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            const BSt cur = pf[u];
+            fetch(pf[u], S - 1 - (done + u + kPF));
+            one_step(S - 1 - (done + u), cur);
+        }
     }
+#pragma unroll
+    for (int u = 0; u < kPF - 1; ++u)           // the last S % kPF steps: already in the ring
+        if (done + u < S) one_step(S - 1 - (done + u), pf[u]);
 }
 
 }  // namespace fqss
