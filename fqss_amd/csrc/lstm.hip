@@ -35,7 +35,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // pre   [S][B][2][4H]  input projection incl. b_ih (gate order i, f, g, o)
 // whh   [2][4H][H], bhh [2][4H]
 // hout  [S][B][2H]     (forward | reverse halves)
-// gsav  [S][B][2][4H]  gate activations, csav [S][B][2][H] cell states
+// gsav  [S][B][2][4H]  gate activations, csav [S][B][2][2][H] cell states c | tanh(c) (the backward needs both: no tanh in its loop)
 template <int HT>
 __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float* __restrict__ pre, const float* __restrict__ whh,
                                                                       const float* __restrict__ bhh, float* __restrict__ hout,
@@ -149,12 +149,14 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
             const float* g = gs + cn * 4 * H;
             const float gi = g[ck], gf = g[H + ck], gg = g[2 * H + ck], go = g[3 * H + ck];
             c = gf * c + gi * gg;
-            const float h = go * tanhf(c);
+            const float tc = tanhf(c);
+            const float h = go * tc;
             if constexpr (HT > 0) hs[(cn * 4 + ck / KQ) * HQS + (ck % KQ)] = h;
             else hs[cn * H + ck] = h;
             const int64_t sb = (int64_t)t * B + b0 + cn;
             hout[sb * 2 * H + dir * H + ck] = h;
-            csav[(sb * 2 + dir) * H + ck] = c;
+            csav[(sb * 2 + dir) * 2 * H + ck] = c;
+            csav[(sb * 2 + dir) * 2 * H + H + ck] = tc;
         }
         __syncthreads();
     };
@@ -222,10 +224,10 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
         d.dh = gout[sb * 2 * H + dir * H + ckc];
         const float* gsv = gsav + (sb * 2 + dir) * 4 * H;
         d.i = gsv[ckc]; d.f = gsv[H + ckc]; d.g = gsv[2 * H + ckc]; d.o = gsv[3 * H + ckc];
-        d.c = csav[(sb * 2 + dir) * H + ckc];
+        d.c = csav[(sb * 2 + dir) * 2 * H + H + ckc];      // tanh(c_t), saved by the forward
         const int sp = max(sc - 1, 0);
         const int tp = dir == 0 ? sp : S - 1 - sp;
-        d.cp = csav[((((int64_t)tp * B + cnc) * 2) + dir) * H + ckc];
+        d.cp = csav[((((int64_t)tp * B + cnc) * 2) + dir) * 2 * H + ckc];
     };
 #pragma unroll
     for (int u = 0; u < kPF; ++u) fetch(pf[u], S - 1 - u);
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
             const int64_t sb = (int64_t)t * B + b0 + cn;
             const float dh = c_dh +
                              ((ps[(0 * kNB + cn) * H + ck] + ps[(1 * kNB + cn) * H + ck]) + (ps[(2 * kNB + cn) * H + ck] + ps[(3 * kNB + cn) * H + ck]));
-            const float tc = tanhf(cc);
+            const float tc = cc;                   // tanh(c_t)
             const float dc = dc_rec + (dh * go) * (1.0f - tc * tc);
             const float d_o = ((dh * tc) * (1.0f - go)) * go;
             const float d_i = ((dc * gg) * (1.0f - gi)) * gi;

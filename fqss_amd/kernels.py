@@ -1021,7 +1021,7 @@ def lstm_fwd(pre, whh, bhh, S, B, H):
     assert pre.is_contiguous() and whh.is_contiguous() and bhh.is_contiguous()
     hout = torch.empty(S, B, 2 * H, device=pre.device, dtype=torch.float32)
     gsav = torch.empty(S, B, 8 * H, device=pre.device, dtype=torch.float32)
-    csav = torch.empty(S, B, 2 * H, device=pre.device, dtype=torch.float32)
+    csav = torch.empty(S, B, 2, 2 * H, device=pre.device, dtype=torch.float32)      # per direction: c | tanh(c)
     _lib.call("fqss_lstm_fwd", _p(pre), _p(whh), _p(bhh), _p(hout), _p(gsav), _p(csav), S, B, H, _stream())
     return hout, gsav, csav
 
