@@ -99,6 +99,44 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
     }
 }
 
+// k_actq_fwd (QUANT mode) for NARROW matrices [R][F], F <= 512 features per row: the kernel above gives a row to a whole workgroup, so
+// a 64-wide matrix keeps 16 of its 256 lanes busy (the q / k / v / div quantizers of the attention layers work on [rows][64 | 256] column
+// blocks: 44 us where 12 suffice).  Here a workgroup takes 64-feature slices x 16 rows per pass like k_actq_bwd_colbias.
+__global__ __launch_bounds__(256) void k_actq_fwd_narrow(const float* __restrict__ z, float* __restrict__ out, uint8_t* __restrict__ idx,
+                                                          int64_t R, int F, int64_t ld_z, int64_t ld_o, int64_t ld_i, int act,
+                                                          const float* __restrict__ slope_p, const float* __restrict__ qmin,
+                                                          const float* __restrict__ qmax, int64_t rows_per_part) {
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    const QRange r = load_qrange(qmin, qmax);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int f0 = blockIdx.x * 64 + tx * 4;
+    const int64_t r_beg = (int64_t)blockIdx.y * rows_per_part, r_end = min(R, r_beg + rows_per_part);
+    if (f0 >= F) return;
+    for (int64_t row0 = r_beg + ty; row0 < r_end; row0 += 64) {
+        float4 za[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) za[i] = *reinterpret_cast<const float4*>(z + min(row0 + 16 * i, r_end - 1) * ld_z + f0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + 16 * i;
+            if (row < r_end) {
+                const float zv[4] = {za[i].x, za[i].y, za[i].z, za[i].w};
+                float o[4];
+                unsigned int packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float c, u;
+                    bool inr;
+                    o[j] = fq_asym(act_apply(zv[j], act, slope), r, c, u, inr);
+                    packed = pack_code(c, j, packed);
+                }
+                if (out != nullptr) *reinterpret_cast<float4*>(out + row * ld_o + f0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (idx != nullptr) *reinterpret_cast<unsigned int*>(idx + row * ld_i + f0) = packed;
+            }
+        }
+    }
+}
+
 __global__ void k_obs_reset(uint32_t* obs, int64_t n_pairs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pairs) {
@@ -337,14 +375,16 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
             }
         }
     }
+    if (gbias != nullptr) {      // (workgroup-uniform)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cb[ty][tx * 4 + j] = pb[j];
-    __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < F) {
-        float sum = 0.0f;
+        for (int j = 0; j < 4; ++j) cb[ty][tx * 4 + j] = pb[j];
+        __syncthreads();
+        if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < F) {
+            float sum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sum += cb[k][threadIdx.x];
-        atomicAdd(&gbias[blockIdx.x * 64 + threadIdx.x], sum);
+            for (int k = 0; k < 16; ++k) sum += cb[k][threadIdx.x];
+            atomicAdd(&gbias[blockIdx.x * 64 + threadIdx.x], sum);
+        }
     }
     if (qmode == FQSS_Q_QUANT || act == FQSS_ACT_PRELU) {
         double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
@@ -515,6 +555,18 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     const bool tail_ok = (cols % 4 == 0) || (out == nullptr) || (ld_out - cols < 4);
     const bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0) && tail_ok;
     hipStream_t s = (hipStream_t)stream;
+    if (vec && qmode == FQSS_Q_QUANT && cols % 4 == 0 && cols <= 512 && rows >= 1024 &&
+        (!idx || ((ld_idx & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0))) {
+        // narrow matrix: row-tiled kernel (64-feature slices x row parts), every lane busy
+        const int64_t slices = cdiv(cols, 64);
+        int64_t parts = 2048 / slices;
+        if (parts > cdiv(rows, 64)) parts = cdiv(rows, 64);
+        const int64_t rows_per_part = cdiv(rows, parts);
+        parts = cdiv(rows, rows_per_part);
+        hipLaunchKernelGGL(k_actq_fwd_narrow, dim3((unsigned)slices, (unsigned)parts), dim3(256), 0, s, z, out, idx, rows, (int)cols, ld_z,
+                           ld_out, ld_idx, act, slope, qmin, qmax, rows_per_part);
+        return launch_status("fqss_actq_fwd");
+    }
     if (vec) {
         hipLaunchKernelGGL(k_actq_fwd<4>, grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z,
                            ld_out, ld_idx, act, slope, qmode, qmin, qmax, obs_ws);
@@ -570,6 +622,10 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");
     FQSS_REQUIRE(!gbias || (C > 0 && rows % C == 0), "gbias needs C dividing rows");
     if (rows == 0 || cols == 0) return FQSS_OK;
+    if (!gbias && cols % 4 == 0 && cols <= 512 && rows >= 1024 && aligned16(z) && aligned16(g) && aligned16(gz) && ld_z % 4 == 0 &&
+        ld_g % 4 == 0 && ld_gz % 4 == 0)
+        // narrow matrix (see k_actq_fwd_narrow): the row-tiled kernel of fqss_actq_bwd_colbias, without the bias sums
+        return fqss_actq_bwd_colbias(z, g, gz, rows, (int)cols, ld_z, ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, nullptr, stream);
     if (!gbias || C <= 0) C = rows;   // no channel semantics: every row is its own "channel"
     // (same rule as fqss_actq_fwd: a float4 store past `cols` must land in this row's own padding, never in a neighbouring column block)
     const bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0) &&
@@ -598,7 +654,7 @@ extern "C" int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, 
                                      int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin, const float* qmax,
                                      double* gacc, float* gbias, fqss_stream_t stream) {
     if (R == 0 || F == 0) return FQSS_OK;
-    FQSS_REQUIRE(z && g && gz && gbias, "null tensor");
+    FQSS_REQUIRE(z && g && gz, "null tensor");     // gbias may be NULL: the row-tiled pass alone (narrow matrices, see fqss_actq_bwd)
     FQSS_REQUIRE(R > 0 && F > 0 && ld_z >= F && ld_g >= F && ld_gz >= F, "bad shape");
     FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
