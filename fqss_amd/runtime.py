@@ -631,6 +631,17 @@ class KDTrainStep:
             self._optimize(activate=False)
         self._graphs = (graphs, g2)
         del est, gest, cuts
+        # single rank, one segment: nothing has to happen between the two halves, so the whole step is ALSO captured as one graph
+        # (replay() then costs one launch; replay_fwd_bwd / replay_optimize keep serving the trainers that may skip an update)
+        self._graph_all = None
+        if self._world() == 1 and len(graphs) == 1 and os.environ.get("FQSS_ONE_GRAPH", "1") != "0":
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=graphs[0].pool()):
+                self.last_all, est, gest, cuts = self._forward_loss(self._sx, self._st)
+                self._backward_segment(0, est, gest, cuts)
+                self._optimize(activate=False)
+            self._graph_all = ga
+            del est, gest, cuts
         return self
 
     def replay_fwd_bwd(self, x=None, tgt=None):
@@ -650,6 +661,13 @@ class KDTrainStep:
         self._graphs[1].replay()
 
     def replay(self, x=None, tgt=None):
+        if getattr(self, "_graph_all", None) is not None:
+            if x is not None and x.data_ptr() != self._sx.data_ptr():
+                self._sx.copy_(x)
+                self._st.copy_(tgt)
+            self.arena._host_step += 1
+            self._graph_all.replay()
+            return self.last_all
         self.replay_fwd_bwd(x, tgt)
         self.replay_optimize()
         return self.last
