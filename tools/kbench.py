@@ -72,8 +72,9 @@ case("gnq_bwd plain C=512", (1 + 4 + 1 + 4 + 4) * MBh, lambda: (codes(NH), act(N
      lambda s: K.gnq_bwd(s[0], lo, hi, s[1], gm_, bt_, mr, lo, hi, gacc, gg, gb2))
 case("gnq_bwd_p (conv1 producer) C=512", (1 + 4 + 1 + 4 + 4 + 4) * MBh, lambda: (codes(NH), act(NH), act(NH)),
      lambda s: K.gnq_bwd(s[0], lo, hi, s[1], gm_, bt_, mr, lo, hi, gacc, gg, gb2, producer=(s[2], 1, slope, pga, gbb)))
-case("dwq_fwd C=512 dil 4", 2 * MBh, lambda: (codes(NH),),
-     lambda s: K.dwq_fwd(s[0], lo, hi, w_dw, b_dw, 4, 4, 1, slope, lo, hi, False))
+for _d in (4, 128):
+    case(f"dwq_fwd C=512 dil {_d} (+gLN statistics)", 2 * MBh, lambda: (codes(NH),),
+         lambda s, _d=_d: K.dwq_fwd(s[0], lo, hi, w_dw, b_dw, _d, _d, 1, slope, lo, hi, False, stats=K.new_stats("dwq", B, NH, M, dev)))
 case("dwq_bwd C=512 dil 4", 9 * MBh, lambda: (codes(NH), act(NH)),
      lambda s: K.dwq_bwd(s[0], lo, hi, w_dw, b_dw, s[1], 4, 4, 1, slope, lo, hi, gacc, gbb, gw_dw))
 case("qpw_fwdq conv1 128->512 (+PReLU+fq)", MBb + 5 * MBh, lambda: (codes(NB),),
