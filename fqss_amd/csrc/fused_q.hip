@@ -855,22 +855,34 @@ struct EwProducer {
     float* out; int ld_out;          // the producer's gz
 };
 
+// PLAIN: no non-linearity anywhere (AddQ of the res / skip convs: the case of every launch of the ConvTasNet step).  These kernels are
+// VALU-issue bound: act_apply / act_bwd as identities and the per-element validity selects (a masked-out position already carries
+// gj = 0, which zeroes every sum it enters) were ~25 of the ~86 instructions per element.
+template <bool PLAIN>
 __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRange& rp, float pslope, float pz, float gj, bool valid,
                                                  float& p_du, float& p_out, float& p_slope, float& p_bias) {
-    const float t = act_apply(pz, P.act, pslope);
+    const float t = PLAIN ? pz : act_apply(pz, P.act, pslope);
     float pc, pu;
     bool pin;
     (void)fq_asym(t, rp, pc, pu, pin);
     const float gt = pin ? div_by(gj * rp.delta, rp.delta, rp.inv) : 0.0f;
-    if (valid) {
+    if constexpr (PLAIN) {      // gj == 0 where the position is masked out
         p_du += gj * (pin ? (pc - pu) : pc);
         p_out += pin ? 0.0f : gj;
+        p_bias += gt;
+        return gt;
+    } else {
+        if (valid) {
+            p_du += gj * (pin ? (pc - pu) : pc);
+            p_out += pin ? 0.0f : gj;
+        }
+        float gzj = act_bwd(pz, gt, P.act, pslope, valid, p_slope);
+        if (valid) p_bias += gzj;
+        return gzj;
     }
-    float gzj = act_bwd(pz, gt, P.act, pslope, valid, p_slope);
-    if (valid) p_bias += gzj;
-    return gzj;
 }
 
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
                                                   const float* __restrict__ bf, float sb, const float* __restrict__ g,
                                                   float* __restrict__ gz, int rows, int cols, int ld_a, int ld_b, int ld_bf,
@@ -914,20 +926,27 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
             float z = dec((in.wa >> (8 * e)) & 255u, ra);
             if (bc != nullptr) z = z + sb * dec((in.wb >> (8 * e)) & 255u, rb);
             else if (bf != nullptr) z = z + sb * bv[e];
-            const float t = act_apply(z, act, slope);
+            const float t = PLAIN ? z : act_apply(z, act, slope);
             float cq, u;
             bool inr;
             (void)fq_asym(t, ry, cq, u, inr);
             const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
-            if (valid) {
+            float gzj;
+            if constexpr (PLAIN) {      // gj == 0 where the position is masked out: it drops out of every sum by itself
                 p_du += gj * (inr ? (cq - u) : cq);
                 p_out += inr ? 0.0f : gj;
+                gzj = gt;
+            } else {
+                if (valid) {
+                    p_du += gj * (inr ? (cq - u) : cq);
+                    p_out += inr ? 0.0f : gj;
+                }
+                gzj = act_bwd(z, gt, act, slope, valid, p_slope);
             }
-            float gzj = act_bwd(z, gt, act, slope, valid, p_slope);
             o[e] = gzj;
             // d/da = gz, d/db = sb * gz (sb == 1 whenever b is fused): the producers' epilogue backward on it
-            if (fa) oa[e] = ew_producer_bwd(PA, ra, sla, zav[e], valid ? gzj : 0.0f, valid, a_du, a_out, a_sl, a_bias);
-            if (fb) ob[e] = ew_producer_bwd(PB, rb, slb, zbv[e], valid ? gzj : 0.0f, valid, b_du, b_out, b_sl, b_bias);
+            if (fa) oa[e] = ew_producer_bwd<PLAIN>(PA, ra, sla, zav[e], (PLAIN || valid) ? gzj : 0.0f, valid, a_du, a_out, a_sl, a_bias);
+            if (fb) ob[e] = ew_producer_bwd<PLAIN>(PB, rb, slb, zbv[e], (PLAIN || valid) ? gzj : 0.0f, valid, b_du, b_out, b_sl, b_bias);
         }
         if (gz != nullptr) *reinterpret_cast<float4*>(gz + (int64_t)row * ld_gz + c0) = make_float4(o[0], o[1], o[2], o[3]);
         if (fa) *reinterpret_cast<float4*>(PA.out + (int64_t)row * PA.ld_out + c0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
@@ -1249,9 +1268,15 @@ static int ewq_bwd_impl(const char* who, const uint8_t* ac, const float* amin, c
     // (more workgroup rows -- 4 C instead of C -- measured SLOWER, 33 -> 43 us: the per-workgroup reductions and atomics dominate)
     if ((PA.pz || PB.pz) && C <= gy && C > 1) gy = C;
     else if ((PA.pz || PB.pz) && C > 1 && gy % C == 0) gy -= 1;    // never alias the per-channel mode by accident
-    hipLaunchKernelGGL(k_ewq_bwd, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
-                       (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
-                       bmin, bmax, qmin, qmax, gacc, PA, PB, C > 0 ? C : 1);
+    const bool plain = act == FQSS_ACT_NONE && bf == nullptr && (!PA.pz || PA.act == FQSS_ACT_NONE) && (!PB.pz || PB.act == FQSS_ACT_NONE);
+    if (plain)
+        hipLaunchKernelGGL(k_ewq_bwd<true>, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
+                           (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
+                           bmin, bmax, qmin, qmax, gacc, PA, PB, C > 0 ? C : 1);
+    else
+        hipLaunchKernelGGL(k_ewq_bwd<false>, dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, ac, bc, bf, sb, g, gz,
+                           (int)rows, (int)cols, (int)ld_a, (int)ld_b, (int)ld_bf, (int)ld_g, (int)ld_gz, act, slope, amin, amax,
+                           bmin, bmax, qmin, qmax, gacc, PA, PB, C > 0 ? C : 1);
     return launch_status(who);
 }
 
