@@ -141,7 +141,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
                 const float pre_act = pcur[nb] + (acc[nb] + bj);
                 const float a = is_g ? tanhf(pre_act) : sigmoidf_(pre_act);
                 gs[nb * 4 * H + j] = a;
-                if (b0 + nb < B) gsav[((((int64_t)t * B + b0 + nb) * 2) + dir) * 4 * H + j] = a;
+                if (gsav != nullptr && b0 + nb < B) gsav[((((int64_t)t * B + b0 + nb) * 2) + dir) * 4 * H + j] = a;   // (NULL: inference)
             }
         }
         __syncthreads();
@@ -155,8 +155,10 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
             else hs[cn * H + ck] = h;
             const int64_t sb = (int64_t)t * B + b0 + cn;
             hout[sb * 2 * H + dir * H + ck] = h;
-            csav[(sb * 2 + dir) * 2 * H + ck] = c;
-            csav[(sb * 2 + dir) * 2 * H + H + ck] = tc;
+            if (csav != nullptr) {
+                csav[(sb * 2 + dir) * 2 * H + ck] = c;
+                csav[(sb * 2 + dir) * 2 * H + H + ck] = tc;
+            }
         }
         __syncthreads();
     };
@@ -326,7 +328,7 @@ using namespace fqss;
 
 extern "C" int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* hout, float* gsav, float* csav,
                              int S, int B, int H, fqss_stream_t stream) {
-    FQSS_REQUIRE(pre && whh && bhh && hout && gsav && csav, "null tensor");
+    FQSS_REQUIRE(pre && whh && bhh && hout && ((gsav == nullptr) == (csav == nullptr)), "null tensor (gsav / csav: both or neither)");
     FQSS_REQUIRE(S > 0 && B > 0 && H > 0 && H <= 256, "bad shape (H <= 256)");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(B, kNB), 2);

@@ -1015,13 +1015,14 @@ def attn_bwd(q, k, v, o, go, stats, L, B, nh):
     return gq, gk, gv
 
 
-def lstm_fwd(pre, whh, bhh, S, B, H):
-    """pre [S, B, 8H] (fwd gates | reverse gates), whh [2, 4H, H], bhh [2, 4H] -> hout [S, B, 2H], (gsav, csav)"""
+def lstm_fwd(pre, whh, bhh, S, B, H, save=True):
+    """pre [S, B, 8H] (fwd gates | reverse gates), whh [2, 4H, H], bhh [2, 4H] -> hout [S, B, 2H], (gsav, csav); save=False (no
+    backward will follow: the frozen teacher): nothing is saved, (None, None)"""
     _need_gpu(pre, whh, bhh)
     assert pre.is_contiguous() and whh.is_contiguous() and bhh.is_contiguous()
     hout = torch.empty(S, B, 2 * H, device=pre.device, dtype=torch.float32)
-    gsav = torch.empty(S, B, 8 * H, device=pre.device, dtype=torch.float32)
-    csav = torch.empty(S, B, 2, 2 * H, device=pre.device, dtype=torch.float32)      # per direction: c | tanh(c)
+    gsav = torch.empty(S, B, 8 * H, device=pre.device, dtype=torch.float32) if save else None
+    csav = torch.empty(S, B, 2, 2 * H, device=pre.device, dtype=torch.float32) if save else None      # per direction: c | tanh(c)
     _lib.call("fqss_lstm_fwd", _p(pre), _p(whh), _p(bhh), _p(hout), _p(gsav), _p(csav), S, B, H, _stream())
     return hout, gsav, csav
 

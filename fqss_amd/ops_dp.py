@@ -397,7 +397,7 @@ class LstmBi(Function):
             K.qrow_fwd(xq.idx, qr[1], bih_r, xq.qmin, xq.qmax, out=pre[..., 4 * H:])
         else:
             pre = K.rowlin_fwd(x, wih, bih)                # [S, B, 8H]: both directions' input projections, one GEMM
-        hout, gsav, csav = K.lstm_fwd(pre, whh, bhh, S, B, H)
+        hout, gsav, csav = K.lstm_fwd(pre, whh, bhh, S, B, H, save=any(ctx.needs_input_grad))      # (the frozen teacher runs under no_grad: nothing to save)
         ctx.save_for_backward(x, wih, whh, hout, gsav, csav)
         ctx.params = (bih_f, bhh_f, bih_r, bhh_r)
         ctx.weights = (wih_f, whh_f, wih_r, whh_r)

@@ -495,7 +495,7 @@ int fqss_attn_bwd(const float* q, const float* k, const float* v, const float* o
 /* Recurrence of the bidirectional single-layer LSTM inside LSTMQ (qat_layers.py:571-600, _VF.lstm with zero state).
  *   pre  [S][B][2][4H] = x W_ih^T + b_ih of both directions (fqss_rowlin_fwd), gate order i, f, g, o
  *   whh  [2][4H][H], bhh [2][4H];  hout [S][B][2H] (forward | reverse)
- *   gsav [S][B][2][4H] gate activations, csav [S][B][2][2][H] cell states c | tanh(c) (saved for the backward)
+ *   gsav [S][B][2][4H] gate activations, csav [S][B][2][2][H] cell states c | tanh(c) (saved for the backward; both NULL: inference, nothing saved)
  * bwd: gout [S][B][2H] -> dG [S][B][2][4H] = dL/d(gate pre-activations); the caller finishes with row GEMMs:
  *   gx = dG W_ih, gW_ih += dG^T x, gb_ih = gb_hh += colsum(dG), gW_hh[d] += dG_d[t]^T h_d[t -/+ 1]           */
 int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* hout, float* gsav, float* csav,
