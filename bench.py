@@ -450,243 +450,6 @@ def main():
     dt = dt.item()
     sisdr = r["sisdr"].mean().reshape(1).double()
     comm.all_reduce_sum(sisdr)
-    if comm.rank == 0:
-        ms = dt / a.steps * 1e3
-        L = (T - 1) if a.workload == "cfg3" else (T - 16) // 8 + 1
-        rows = 250 * dp_chunks(L, 250)[1]
-        out = {"metric": f"QAT-step samples/sec + SI-SDR, {W['name']} 2spk 8kHz W8A8", "value": round(comm.world * a.steps / dt, 3),
-               "unit": "samples/s", "n_gpus": comm.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{W['name']} 2spk 8 kHz W8A8 QAT step ({a.workload}), batch 1 x {T // 8000} s per GPU, quantizing phase",
-                          "global_batch": comm.world, "segment_samples": T, "parallelism": f"dp{comm.world}", "kd_lambda": 0.1,
-                          "optimizer": f"adam lr {W['lr']:g} + clip 5.0", "launch": launch},
-               "si_sdr_db": round(sisdr.item() / comm.world, 4), "loss_db": round(r["loss"].item(), 4),
-               "params": sum(p.numel() for p in model.parameters()),
-               "roofline": dominant_kernel_roofline_dualpath(a.workload, rows, *W["gemm"], seqs=(250, dp_chunks(L, 250)[1]))}
-        if comm.world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_dualpath(a.workload, model, fmodel, W["lr"], T)
-        print(json.dumps(out), flush=True)
-    comm.barrier()
-    comm.close()
-
-
-def attn_roofline(B, nh, L, hd):
-    """the streaming attention core (csrc/attn_long.hip) at the spectrogram branch's self-attention shape: HIP events on torch's
-    current stream; 4 L^2 hd flops per (batch, head); priced against the fp32 MFMA peak its GEMM-shaped arithmetic could reach"""
-    from fqss_amd import kernels as K
-    E = nh * hd
-    q, k, v = (torch.randn(B, L, E, device="cuda") * 0.3 for _ in range(3))
-    for _ in range(2):
-        K.attn_long_fwd(q, k, v, nh, True)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        K.attn_long_fwd(q, k, v, nh, True)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 5 * 1e3
-    tf = 4.0 * L * L * hd * B * nh / us * 1e-6
-    return {"kernel": "k_attn_long_fwd_mfma<%d>" % hd, "what": "self-attention of the spectrogram branch", "shape": [B, nh, L, hd], "bound": "mfma",
-            "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
-
-
-def cpu_baseline_htdemucs(model, fmodel, B, T):
-    """oracle/htdemucs_oracle.py on the host cores, bounded: ONE quantizing-phase step (student fwd + bwd, teacher fwd, loss) on a
-    1 x 1 s excerpt, scaled by the excerpt's share of the workload's samples"""
-    import oracle.htdemucs_oracle as H
-    cores = min(16, len(os.sched_getaffinity(0)))
-    torch.set_num_threads(cores)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    fsd = {k: v.detach().cpu() for k, v in fmodel.state_dict().items()}
-    kw = dict(n_src=model.n_srcs, audio_channels=model.audio_channels, nfft=model.nfft, depth=model.depth,
-              t_layers=model.crosstransformer.num_layers, t_heads=model.crosstransformer.layers[0].self_attn.mha.num_heads,
-              bottom=bool(model.bottom_channels))
-    s_o, t_o = H.HTDemucsOracle(sd, quantized=True, **kw), H.HTDemucsOracle(fsd, quantized=False, **kw)
-    s_o.leave_observer_phase()
-    Tc = min(T, 44100)
-    g = torch.Generator().manual_seed(0)
-    src = torch.randn(1, model.n_srcs, model.audio_channels, Tc, generator=g) * 0.1
-    mix = src.sum(1)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        fest = t_o.forward(mix)
-    est = s_o.forward(mix)
-    loss = H.solver_loss(est, fest, src)[0]
-    loss.backward()
-    sec = time.perf_counter() - t0
-    return {"value": round((Tc / T) / sec, 5), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"one QAT step of the oracle (student fwd + bwd, teacher fwd, loss; no optimizer) on 1 x {Tc} samples ({sec:.1f} s), "
-                      f"scaled by {Tc}/{T} to the workload's segment length, torch CPU fp32"}
-
-
-def main_htdemucs(a):
-    """cfg 5: HTDemucs, stereo 44.1 kHz, 4 sources, the shipped per-GPU batch (32 / 8 GPUs) x 10 s; step = student fwd + teacher
-    fwd + solver loss + bwd (+ all-reduce) + Adam (htdemucs.yaml: lr 3e-4, no clipping), same timing protocol as cfg 2"""
-    import copy
-    from fqss_amd.parallel import Comm
-    from fqss_amd.quantization.qat.models.load_model import quantize_model
-    from fqss_amd.quantization.qat.models.htdemucsq import HTDemucsQ
-    from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
-    from fqss_amd.runtime import KDTrainStep
-    comm = Comm.from_env("cuda")
-    assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
-    ldev = comm.local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(ldev)
-    dev = torch.device("cuda", ldev)
-    torch.manual_seed(0)
-    B, T = a.hd_batch, int(round(a.hd_seconds * 44100))
-    model = HTDemucsQ(sources=["drums", "bass", "other", "vocals"], bottom_channels=512, segment=a.hd_seconds)
-    fmodel = copy.deepcopy(model).to(dev).eval()
-    qcfg = dict(qat=True, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True, act_n_bits=8, in_quant=False,
-                in_act_n_bits=8, out_quant=True, out_act_n_bits=8, n_splitter=2, n_combiner=2, observer=True)
-    model = quantize_model(model, qcfg).to(dev).train()
-    g = torch.Generator().manual_seed(42 + comm.rank)
-    src = (torch.randn(B, 4, 2, T, generator=g) * 0.1).to(dev)            # synthetic stereo Gaussian stems (SURVEY.md §8(d))
-    mix = src.sum(1)
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, comm=comm, loss="l1_sdr")
-    step(mix, src)                                          # untimed calibration: the 50-call observer phase
-    with torch.no_grad():
-        for _ in range(49):
-            model(mix)
-    assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
-    step(mix, src)
-    launch = "eager"
-    if not a.no_graph:
-        step.capture(mix, src)
-        launch = "hipGraph replay"
-    for _ in range(a.warmup):
-        step(mix, src)
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        r = step(mix, src)
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    comm.all_reduce_max(dt)
-    dt = dt.item()
-    if comm.rank == 0:
-        ms = dt / a.steps * 1e3
-        Fr, le = 8, -(-T // 1024)
-        out = {"metric": "QAT-step samples/sec, HTDemucs 4 stems stereo 44.1kHz W8A8", "value": round(comm.world * B * a.steps / dt, 3),
-               "unit": "samples/s", "n_gpus": comm.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"HTDemucs 4-stem stereo 44.1 kHz W8A8 QAT step (cfg5), batch {B} x {a.hd_seconds:g} s per GPU, "
-                                      "quantizing phase, bottom_channels 512", "global_batch": comm.world * B, "segment_samples": T,
-                          "parallelism": f"dp{comm.world}", "kd_lambda": 0.1, "optimizer": "adam lr 0.0003, no clipping", "launch": launch},
-               "loss": round(r["loss"].item(), 6), "params": sum(p.numel() for p in model.parameters()),
-               "roofline": attn_roofline(B, 8, Fr * le, 64)}
-        if comm.world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_htdemucs(model, fmodel, B, T)
-        print(json.dumps(out), flush=True)
-    comm.barrier()
-    comm.close()
-
-
-def main_infer(a):
-    """quantized ConvTasNet inference (eval mode, codes-only dataflow, one hipGraph per request shape) on the cfg 2 batch: 8 x 4 s"""
-    from fqss_amd.data import synth_batch
-    from fqss_amd.quantization.qat.models.load_model import create_model, quantize_model
-    from fqss_amd.runtime import InferRunner
-    from fqss_amd.smoke import QCFG
-    assert a.gpus == 1, "the inference probe is a single-GPU measurement"
-    torch.cuda.set_device(0)
-    torch.manual_seed(0)
-    model = quantize_model(create_model({"name": "ConvTasNet", "n_src": 2, "kernel_size": 16, "stride": 8}), dict(QCFG)).cuda().train()
-    x, _ = synth_batch(8, 32000, seed=0, device="cuda")
-    with torch.no_grad():
-        for _ in range(50):
-            model(x)                                        # observer calibration
-    run = InferRunner(model, use_graph=not a.no_graph)
-    for _ in range(max(a.warmup, 1)):
-        y = run(x)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        y = run(x)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms = dt / a.steps * 1e3
-    fwd_bytes = 74.8e9 / 4.0                                  # SURVEY.md 8(d): one forward = a quarter of the step's algorithmic bytes
-    print(json.dumps({"metric": "quantized inference samples/sec, ConvTasNet 2spk 8kHz W8A8", "value": round(8 * a.steps / dt, 2), "unit": "samples/s",
-                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-                      "vs_baseline": None, "dtype": "u8/f32", "data": "synthetic",
-                      "config": {"workload": "ConvTasNet 2spk 8 kHz W8A8 inference (eval mode, codes-only dataflow), batch 8 x 4 s",
-                                 "launch": "eager" if a.no_graph else "hipGraph replay"},
-                      "roofline": {"kernel": "whole forward", "bound": "hbm", "achieved": round(fwd_bytes / (ms * 1e-3) / 1e9, 1), "peak": 8000.0,
-                                   "unit": "GB/s", "frac": round(fwd_bytes / (ms * 1e-3) / 8e12, 4), "traffic": None},
-                      "out_rms": round(float(y.pow(2).mean().sqrt()), 6)}), flush=True)
-
-
-def main():
-    a = parse()
-    if a.workload == "cfg5":
-        return main_htdemucs(a)
-    if a.workload == "infer":
-        return main_infer(a)
-    assert torch.cuda.is_available(), "bench.py needs ROCm GPUs"
-    if a.workload != "cfg2":
-        return main_dualpath(a)
-    from fqss_amd.data import synth_batch
-    from fqss_amd.parallel import Comm
-    from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
-    from fqss_amd.runtime import KDTrainStep
-    from fqss_amd.smoke import build_pair
-
-    comm = Comm.from_env("cuda")
-    assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
-    ldev = comm.local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(ldev)
-    dev = torch.device("cuda", ldev)
-
-    model, fmodel = build_pair(dev, 0, n_spks=2, kernel_size=16, stride=8)   # same init on every rank
-    x, tgt = synth_batch(B_PER_GPU, T_SAMPLES, seed=100 + comm.rank, device=dev)   # per-rank shard (weak scaling)
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=comm)
-
-    # untimed calibration: leave the 50-call observer phase (1 full step + 49 observer forwards), then
-    # every timed step runs the quantizers
-    step(x, tgt)
-    with torch.no_grad():
-        for _ in range(49):
-            model(x)
-    assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
-
-    step(x, tgt)                       # first quantizing step, eager (starts the activation ranges' Adam clocks)
-    launch = "eager"
-    if not a.no_graph:
-        step.capture(x, tgt)           # whole step -> hipGraphs; every later call is a replay
-        launch = "hipGraph replay"
-        if comm.world > 1:
-            # RCCL between two graph replays cannot be exercised on the 1-GPU dev box: self-calibrate (untimed)
-            # and keep whichever launch mode is faster on THIS node; all ranks take the same decision.
-            t = []
-            for mode in (True, False):
-                step.use_graph = mode
-                step(x, tgt)
-                comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(2):
-                    step(x, tgt)
-                torch.cuda.synchronize()
-                d = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-                comm.all_reduce_max(d)
-                t.append(d.item())
-            step.use_graph = t[0] <= t[1]
-            launch = "hipGraph replay" if step.use_graph else "eager (graph replay slower on this node)"
-    for _ in range(a.warmup):
-        step(x, tgt)
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        r = step(x, tgt)
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    comm.all_reduce_max(dt)
-    dt = dt.item()
-    sisdr = r["sisdr"].mean().reshape(1).double()
-    comm.all_reduce_sum(sisdr)
 
     if comm.rank == 0:
         ms = dt / a.steps * 1e3
