@@ -617,17 +617,20 @@ class KDTrainStep:
         torch.cuda.synchronize()
         # one hipGraph per backward segment (the first also holds fwd + loss) and one for clip + Adam: at world > 1 the exchange of
         # a segment's gradients is launched between two replays and overlaps the next one (no collective inside a graph)
+        # (at world > 1 the process group's watchdog thread polls its events while this thread captures: only THIS thread's calls are
+        # checked against the capture then -- torch's default mode lets a query from any thread invalidate it)
+        mode = dict(capture_error_mode="thread_local") if self._world() > 1 else {}
         graphs = [torch.cuda.CUDAGraph()]
-        with torch.cuda.graph(graphs[0]):
+        with torch.cuda.graph(graphs[0], **mode):
             self.last, est, gest, cuts = self._forward_loss(self._sx, self._st)
             self._backward_segment(0, est, gest, cuts)
         for k in range(1, self._nseg(cuts)):
             gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk, pool=graphs[0].pool()):
+            with torch.cuda.graph(gk, pool=graphs[0].pool(), **mode):
                 self._backward_segment(k, est, gest, cuts)
             graphs.append(gk)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=graphs[0].pool()):
+        with torch.cuda.graph(g2, pool=graphs[0].pool(), **mode):
             self._optimize(activate=False)
         self._graphs = (graphs, g2)
         del est, gest, cuts
