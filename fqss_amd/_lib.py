@@ -51,6 +51,8 @@ _PROTOS = {
     "fqss_ewq_fwd": [P, P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I64, I32, P, P, P, P],
     "fqss_ewq_bwd": [P, P, P, P, P, P, P, F32, P, P, I64, I64, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
     "fqss_dwq_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
+    "fqss_mulq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, P, P, P],
+    "fqss_mulq_bwd": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P, P, P, I64, I32, P, P, P, P],
     "fqss_dwq_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],
     "fqss_split3_planes": [P, P, I64, P],
     "fqss_tgemm": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],

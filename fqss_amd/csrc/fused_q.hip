@@ -1036,6 +1036,144 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MulQ on codes: masked[b][s][c][:] = fq( dec(mask[b][s][c][:]) * dec(feat[b][c][:]) )  -- the masking product of
+// ConvTasNetQ.forward (convtasnetq.py:277, qat_layers.py:134-153 `MulQ`).  A workgroup row is one (b, c) row of feat and
+// serves its S mask rows: feat is read (and decoded) once.  Same arithmetic as decode -> fqss_mul_bcast_fwd -> fqss_actq_fwd
+// (one fp32 product of the two de-quantised values, then the quantizer), so the codes are bit-identical to that chain's.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMulqSMax = 4;
+
+template <int S>
+__global__ __launch_bounds__(256) void k_mulq_fwd(const uint8_t* __restrict__ mc, const uint8_t* __restrict__ fc,
+                                                   uint8_t* __restrict__ yc, float* __restrict__ yout, int rows, int C, int M,
+                                                   int64_t ld_m, int64_t ld_f, int64_t ld_y, int64_t ld_o, const float* mmin,
+                                                   const float* mmax, const float* fmin, const float* fmax, const float* qmin,
+                                                   const float* qmax) {
+    const QRange rm = load_qrange(mmin, mmax), rf = load_qrange(fmin, fmax), ry = load_qrange(qmin, qmax);
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = row / C, c = row - b * C;
+        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 16; c0 < M; c0 += gridDim.x * 256 * 16) {
+            const uint4 vf = *reinterpret_cast<const uint4*>(fc + (int64_t)row * ld_f + c0);
+            uint4 vm[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s)      // all mask rows requested before the first is used
+                vm[s] = *reinterpret_cast<const uint4*>(mc + ((int64_t)(b * S + s) * C + c) * ld_m + c0);
+            const unsigned int wf[4] = {vf.x, vf.y, vf.z, vf.w};
+            float xf[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dec4(wf[q], rf, xf[q]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t orow = (int64_t)(b * S + s) * C + c;
+                const unsigned int wm[4] = {vm[s].x, vm[s].y, vm[s].z, vm[s].w};
+                unsigned int o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float xm[4], cq[4];
+                    dec4(wm[q], rm, xm);
+                    unsigned int pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cq[e] = fq_code(xm[e] * xf[q][e], ry);
+                        pk = pack_code(cq[e], e, pk);
+                    }
+                    o[q] = pk;
+                    if (yout != nullptr && c0 + 4 * q < M)
+                        *reinterpret_cast<float4*>(yout + orow * ld_o + c0 + 4 * q) =
+                            make_float4(ry.delta * cq[0] + ry.lo, ry.delta * cq[1] + ry.lo, ry.delta * cq[2] + ry.lo, ry.delta * cq[3] + ry.lo);
+                }
+                *reinterpret_cast<uint4*>(yc + orow * ld_y + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// backward: z recomputed from the codes, gz = STE(g); gmask = gz * feat (or, with the mask's producer fused -- the mask conv's
+// non-linearity + output quantizer, cf. EwProducer -- that layer's gz), gfeat = sum_s gz_s * mask_s in ascending s (the order
+// of fqss_mul_bcast_bwd); range partials of this layer (and of the producer) to the gacc slots.
+template <int S, bool PROD>
+__global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc, const uint8_t* __restrict__ fc,
+                                                   const float* __restrict__ g, float* __restrict__ gmask, float* __restrict__ gfeat,
+                                                   int rows, int C, int M, int64_t ld_m, int64_t ld_f, int64_t ld_g,
+                                                   int64_t ld_gm, int64_t ld_gf, const float* mmin, const float* mmax,
+                                                   const float* fmin, const float* fmax, const float* qmin, const float* qmax,
+                                                   double* gacc, EwProducer P) {
+    __shared__ float redf[S * 4];
+    const QRange rm = load_qrange(mmin, mmax), rf = load_qrange(fmin, fmax), ry = load_qrange(qmin, qmax);
+    const float pslope = (PROD && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
+    float p_du = 0.f, p_out = 0.f, a_du = 0.f, a_out = 0.f, a_sl = 0.f;
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = row / C, c = row - b * C;
+        float a_bias[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
+        for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += gridDim.x * 256 * 4) {
+            const unsigned int wf = *reinterpret_cast<const unsigned int*>(fc + (int64_t)row * ld_f + c0);
+            unsigned int wm[S];
+            float4 g4[S], z4[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t mrow = (int64_t)(b * S + s) * C + c;
+                wm[s] = *reinterpret_cast<const unsigned int*>(mc + mrow * ld_m + c0);
+                g4[s] = *reinterpret_cast<const float4*>(g + mrow * ld_g + c0);
+                if (PROD) z4[s] = *reinterpret_cast<const float4*>(P.pz + mrow * P.ld_pz + c0);
+            }
+            float xf[4], gf[4] = {0.f, 0.f, 0.f, 0.f};
+            dec4(wf, rf, xf);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int64_t mrow = (int64_t)(b * S + s) * C + c;
+                const float gv[4] = {g4[s].x, g4[s].y, g4[s].z, g4[s].w};
+                const float pzv[4] = {PROD ? z4[s].x : 0.f, PROD ? z4[s].y : 0.f, PROD ? z4[s].z : 0.f, PROD ? z4[s].w : 0.f};
+                float xm[4], o[4];
+                dec4(wm[s], rm, xm);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = c0 + e < M;
+                    const float gj = valid ? gv[e] : 0.0f;       // the row padding of g holds anything
+                    float cq, u;
+                    bool inr;
+                    (void)fq_asym(xm[e] * xf[e], ry, cq, u, inr);
+                    const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+                    p_du += gj * (inr ? (cq - u) : cq);
+                    p_out += inr ? 0.0f : gj;
+                    gf[e] += gt * xm[e];
+                    const float gm = gt * xf[e];
+                    o[e] = PROD ? ew_producer_bwd<false>(P, rm, pslope, pzv[e], gm, valid, a_du, a_out, a_sl, a_bias[s]) : gm;
+                }
+                *reinterpret_cast<float4*>(gmask + mrow * ld_gm + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if (gfeat != nullptr) *reinterpret_cast<float4*>(gfeat + (int64_t)row * ld_gf + c0) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+        }
+        if (PROD && P.gbias != nullptr) {       // one sum per (row, s): channel s * C + c of the producer
+            block_sum<float, S>(a_bias, redf);
+            if (threadIdx.x == 0)
+                for (int s = 0; s < S; ++s) atomicAdd(&P.gbias[s * C + c], a_bias[s]);
+        }
+    }
+    const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;   // < kSlots: one workgroup per slot
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    {
+        const float du = wave_sum(p_du), po = wave_sum(p_out);
+        if (lane0) {
+            const double dmax = (double)du / 255.0;
+            atomicAdd(&gacc[3 * sid], (double)po - dmax);
+            atomicAdd(&gacc[3 * sid + 1], dmax);
+        }
+    }
+    if (PROD) {
+        const float du = wave_sum(a_du), po = wave_sum(a_out), ps = wave_sum(a_sl);
+        if (lane0) {
+            const double dmax = (double)du / 255.0;
+            atomicAdd(&P.gacc[3 * sid], (double)po - dmax);
+            atomicAdd(&P.gacc[3 * sid + 1], dmax);
+            if (P.act == FQSS_ACT_PRELU) atomicAdd(&P.gacc[3 * sid + 2], (double)ps);
+        }
+    }
+}
+
 }  // namespace fqss
 
 using namespace fqss;
@@ -1309,4 +1447,70 @@ extern "C" int fqss_ewq_bwd_p(const uint8_t* ac, const float* amin, const float*
     EwProducer PB{pb_z, (int)ld_pbz, pb_act, pb_slope, pb_gacc, pb_gbias, pb_out, (int)ld_pb_out};
     return ewq_bwd_impl("fqss_ewq_bwd_p", ac, amin, amax, bc, bmin, bmax, nullptr, sb, g, gz, rows, cols, ld_a, ld_b, 0, ld_g, ld_gz,
                         act, slope, qmin, qmax, gacc, PA, PB, C, stream);
+}
+
+extern "C" int fqss_mulq_fwd(const uint8_t* mc, const float* mmin, const float* mmax, const uint8_t* fc, const float* fmin,
+                             const float* fmax, uint8_t* yc, float* yout, int B, int S, int C, int M, int64_t ld_m, int64_t ld_f,
+                             int64_t ld_y, int64_t ld_out, const float* qmin, const float* qmax, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
+    FQSS_REQUIRE(mc && mmin && mmax && fc && fmin && fmax && yc && qmin && qmax, "null pointer");
+    FQSS_REQUIRE(B > 0 && S >= 1 && S <= kMulqSMax && C > 0 && M > 0 && (int64_t)B * S * C < (1ll << 31), "bad shape (1 .. 4 sources)");
+    FQSS_REQUIRE(codes_ok(mc, ld_m) && codes_ok(fc, ld_f) && codes_ok(yc, ld_y) && ld_m >= M && ld_f >= M && ld_y >= M,
+                 "code rows must be 16-B aligned");
+    FQSS_REQUIRE(!yout || (aligned16(yout) && ld_out % 4 == 0 && ld_out >= ((M + 3) & ~3)), "bad fp32 output rows");
+    const int64_t rows = (int64_t)B * C;
+#define FQSS_MULQ_FWD(S_)                                                                                                          \
+    hipLaunchKernelGGL(k_mulq_fwd<S_>, grid_rows(rows, M, 16), dim3(256), 0, (hipStream_t)stream, mc, fc, yc, yout, (int)rows, C, M, ld_m, \
+                       ld_f, ld_y, ld_out, mmin, mmax, fmin, fmax, qmin, qmax)
+    switch (S) {
+        case 1: FQSS_MULQ_FWD(1); break;
+        case 2: FQSS_MULQ_FWD(2); break;
+        case 3: FQSS_MULQ_FWD(3); break;
+        default: FQSS_MULQ_FWD(4); break;
+    }
+#undef FQSS_MULQ_FWD
+    return launch_status("fqss_mulq_fwd");
+}
+
+extern "C" int fqss_mulq_bwd(const uint8_t* mc, const float* mmin, const float* mmax, const uint8_t* fc, const float* fmin,
+                             const float* fmax, const float* g, float* gmask, float* gfeat, int B, int S, int C, int M, int64_t ld_m,
+                             int64_t ld_f, int64_t ld_g, int64_t ld_gm, int64_t ld_gf, const float* qmin, const float* qmax,
+                             double* gacc, const float* pz, int64_t ld_pz, int pact, const float* pslope, double* pgacc, float* pgbias,
+                             fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
+    FQSS_REQUIRE(mc && mmin && mmax && fc && fmin && fmax && g && gmask && qmin && qmax && gacc, "null pointer");
+    FQSS_REQUIRE(B > 0 && S >= 1 && S <= kMulqSMax && C > 0 && M > 0 && (int64_t)B * S * C < (1ll << 31), "bad shape (1 .. 4 sources)");
+    const int64_t m4 = (M + 3) & ~3;
+    FQSS_REQUIRE(codes_ok(mc, ld_m) && codes_ok(fc, ld_f) && ld_m >= M && ld_f >= M, "code rows must be 16-B aligned");
+    FQSS_REQUIRE(aligned16(g) && aligned16(gmask) && (!gfeat || aligned16(gfeat)) && ld_g % 4 == 0 && ld_gm % 4 == 0 && ld_g >= m4 &&
+                     ld_gm >= m4 && (!gfeat || (ld_gf % 4 == 0 && ld_gf >= m4)), "fp32 rows must be 16-B aligned");
+    FQSS_REQUIRE(!pz || (aligned16(pz) && ld_pz % 4 == 0 && ld_pz >= m4 && pgacc), "bad producer operand");
+    FQSS_REQUIRE(!pz || pact == FQSS_ACT_NONE || pact == FQSS_ACT_RELU || (pact == FQSS_ACT_PRELU && pslope), "producer non-linearity: none / ReLU / PReLU");
+    const int64_t rows = (int64_t)B * C;
+    int64_t gx_ = cdiv(M, 256 * 4);
+    if (gx_ > 64) gx_ = 64;
+    int64_t gy = kSlots / gx_;
+    if (gy > rows) gy = rows;
+    EwProducer P{};
+    P.pz = pz; P.ld_pz = (int)ld_pz; P.act = pact; P.slope = pslope; P.gacc = pgacc; P.gbias = pgbias; P.out = nullptr; P.ld_out = 0;
+#define FQSS_MULQ_BWD(S_, PR_)                                                                                                       \
+    hipLaunchKernelGGL((k_mulq_bwd<S_, PR_>), dim3((unsigned)gx_, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, mc, fc, g, gmask,   \
+                       gfeat, (int)rows, C, M, ld_m, ld_f, ld_g, ld_gm, ld_gf, mmin, mmax, fmin, fmax, qmin, qmax, gacc, P)
+    if (pz != nullptr) {
+        switch (S) {
+            case 1: FQSS_MULQ_BWD(1, true); break;
+            case 2: FQSS_MULQ_BWD(2, true); break;
+            case 3: FQSS_MULQ_BWD(3, true); break;
+            default: FQSS_MULQ_BWD(4, true); break;
+        }
+    } else {
+        switch (S) {
+            case 1: FQSS_MULQ_BWD(1, false); break;
+            case 2: FQSS_MULQ_BWD(2, false); break;
+            case 3: FQSS_MULQ_BWD(3, false); break;
+            default: FQSS_MULQ_BWD(4, false); break;
+        }
+    }
+#undef FQSS_MULQ_BWD
+    return launch_status("fqss_mulq_bwd");
 }

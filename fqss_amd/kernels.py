@@ -628,6 +628,36 @@ def mul_bcast_bwd(gz, mask, feat):
     return gmask, gfeat
 
 
+def mulq_fwd(mc, mmin, mmax, fc, fmin, fmax, qmin, qmax, write_out):
+    """codes of fq(mask [B,S,C,M] * feat [B,C,M]) from the operands' codes; returns (carrier / fp32 out, codes [B,S,C,M])"""
+    B, S, C, M = mc.shape
+    assert tuple(fc.shape) == (B, C, M) and 1 <= S <= 4
+    ld_m, ld_f = _codes2(mc)[2], _codes2(fc)[2]
+    yc = empty_codes((B, S, C, M), mc.device)
+    out = empty_act((B, S, C, M), mc.device)
+    _lib.call("fqss_mulq_fwd", _p(mc), _p(mmin), _p(mmax), _p(fc), _p(fmin), _p(fmax), _p(yc), _p(out) if write_out else None,
+              B, S, C, M, ld_m, ld_f, rowmat(yc)[2], rowmat(out)[2], _p(qmin), _p(qmax), _stream())
+    return out, yc
+
+
+def mulq_bwd(mc, mmin, mmax, fc, fmin, fmax, g, qmin, qmax, gacc, want_gfeat=True, prod=None):
+    """backward of mulq_fwd: (gmask [B,S,C,M], gfeat [B,C,M] | None); prod = (z, act, slope, gacc, gbias) of the layer that produced
+    the mask: its epilogue backward runs in the same launch and gmask is THAT layer's gz"""
+    B, S, C, M = mc.shape
+    ld_m, ld_f = _codes2(mc)[2], _codes2(fc)[2]
+    g, ld_g = _aligned_grad(g)
+    gmask = empty_act((B, S, C, M), mc.device)
+    gfeat = empty_act((B, C, M), mc.device) if want_gfeat else None
+    pargs = [None, 0, 0, None, None, None]
+    if prod is not None:
+        z, pact, pslope, pgacc, pgbias = prod
+        pargs = [_p(z), rowmat(z)[2], pact, _p(pslope), _p(pgacc), _p(pgbias)]
+    _lib.call("fqss_mulq_bwd", _p(mc), _p(mmin), _p(mmax), _p(fc), _p(fmin), _p(fmax), _p(g), _p(gmask), _p(gfeat), B, S, C, M,
+              ld_m, ld_f, ld_g, rowmat(gmask)[2], rowmat(gfeat)[2] if gfeat is not None else 0, _p(qmin), _p(qmax), _p(gacc),
+              *pargs, _stream())
+    return gmask, gfeat
+
+
 # ------------------------------------------------------------------ K10-K13  codec
 def splitter2(x, normalize=True):
     """x [B,1,T] or [B,T] -> [B,2,T] (process.preprocess, n_splitter=2); multi-channel inputs [B, A, ...] flatten to [B, A*...]:

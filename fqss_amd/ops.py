@@ -73,6 +73,8 @@ FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
 FUSE_STATS = os.environ.get("FQSS_FUSE_STATS", "1") != "0"   # gLN statistics from the epilogue of the kernel that makes its input codes
 NEXT_IS_GROUPNORM = False   # set by HipSequential around the forward of a module followed by a GroupNormQ
+NEXT_TAKES_PRODUCER = False  # set by HipSequential around its last module when the sequence's output has ONE consumer, a coded MulQ
+FUSE_MULQ_PROD = os.environ.get("FQSS_FUSE_MULQ_PROD", "1") != "0"
 
 
 def _producer_args(pr):
@@ -199,6 +201,9 @@ def reshape_tagged(x, *shape):
     if xq is not None:
         y._fqss_q = ActCodes(xq.idx.reshape(*shape), xq.qmin, xq.qmax)
         y._fqss_carrier = is_carrier(x)
+        pr = getattr(x, "_fqss_prod", None)
+        if pr is not None:
+            y._fqss_prod = pr        # a reshape is not a second consumer: the producer record travels with the codes
     return y
 
 
@@ -418,7 +423,8 @@ class LinearActQ(Function):
                 z = _lin_fwd(L, x, w, bias)
             out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
         ctx.prod = None
-        if FUSE_GN and NEXT_IS_GROUPNORM and DEFER is not None and q.qmode == Q_QUANT and not ctx.plain and q.owner is not None \
+        if ((FUSE_GN and NEXT_IS_GROUPNORM) or (FUSE_MULQ_PROD and NEXT_TAKES_PRODUCER and act in (ACT_NONE, ACT_RELU, ACT_PRELU))) \
+                and DEFER is not None and q.qmode == Q_QUANT and not ctx.plain and q.owner is not None \
                 and getattr(q.owner, "_fqss_deferred", False):
             ctx.prod = q.prod = _Producer(z, act, slope, L.slope_param, q, L.b_param, bias)
         ctx.x_shape = x.shape
@@ -711,6 +717,35 @@ class MulActQ(Function):
         gz, _, g_min, g_max, _ = _plain_or_bwd(z, g, ctx.q)
         gmask, gfeat = K.mul_bcast_bwd(gz, mask, feat)
         return gmask, gfeat, g_min, g_max, None
+
+
+class MulQCoded(Function):
+    """out = fq(mask[B,S,C,M] * feat[B,1,C,M]) on coded operands, codes -> codes (MulQ of ConvTasNetQ.forward in the quantizing
+    phase): one launch instead of decode x 2 + product + quantizer, nothing saved but the operands' codes; the backward
+    recomputes the product (csrc/fused_q.hip fqss_mulq_fwd / fqss_mulq_bwd)."""
+
+    @staticmethod
+    def forward(ctx, mask, feat, qmin, qmax, q, mq, fq_):
+        B, S, C, M = mask.shape
+        q.carrier = FAST and not q.keep_out
+        fidx = fq_.idx.reshape(B, C, M)
+        out, q.idx = K.mulq_fwd(mq.idx, mq.qmin, mq.qmax, fidx, fq_.qmin, fq_.qmax, qmin, qmax, write_out=not q.carrier)
+        ctx.save_for_backward(mq.idx, mq.qmin, mq.qmax, fidx, fq_.qmin, fq_.qmax, qmin, qmax)
+        ctx.q, ctx.feat_shape = q, feat.shape
+        ctx.prod = getattr(mask, "_fqss_prod", None)     # the mask is the fresh output of a pointwise conv with no other consumer
+        return _carrier(out) if q.carrier else out
+
+    @staticmethod
+    def backward(ctx, g):
+        mc, mmin, mmax, fc, fmin, fmax, qmin, qmax = ctx.saved_tensors
+        q = ctx.q
+        pa = _producer_args(ctx.prod) if ctx.needs_input_grad[0] else None
+        gmask, gfeat = K.mulq_bwd(mc, mmin, mmax, fc, fmin, fmax, g, qmin, qmax, q.gacc, want_gfeat=ctx.needs_input_grad[1], prod=pa)
+        if pa is not None:
+            ctx.prod.fused = True
+        _, g_min, g_max = _flush_ranges(q, None, None, ACT_NONE)
+        return (gmask if ctx.needs_input_grad[0] else None, gfeat.reshape(ctx.feat_shape) if gfeat is not None else None,
+                g_min, g_max, None, None, None)
 
 
 class NlActQ(Function):

@@ -40,9 +40,13 @@ class HipSequential(nn.Sequential):
             # layer's backward needs to run the producer's epilogue backward on the fly (ops._Producer)
             nxt = next((n for n in mods[i + 1:] if not isinstance(n, nn.Identity)), None)
             QL.ops.NEXT_IS_GROUPNORM = isinstance(nxt, QL.GroupNormQ)
+            # the owner of the sequence may vouch for its OUTPUT instead (fqss_sole_consumer: the mask network, whose output only
+            # feeds the masking MulQ): the last layer then hands its producer record to that consumer
+            QL.ops.NEXT_TAKES_PRODUCER = nxt is None and getattr(self, "fqss_sole_consumer", False)
             try:
                 x = apply_module(m, x)
             finally:
                 QL.ops.NEXT_IS_GROUPNORM = False
+                QL.ops.NEXT_TAKES_PRODUCER = False
             i += 1
         return x

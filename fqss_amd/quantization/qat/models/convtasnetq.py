@@ -77,6 +77,7 @@ class MaskGenerator(nn.Module):
         else:
             raise ValueError(f"Unsupported activation {msk_activate}")
         self.mask_net = HipSequential(nn.PReLU(), nn.Conv1d(num_feats, input_dim * n_srcs, 1), act)
+        self.mask_net.fqss_sole_consumer = True     # its output only feeds ConvTasNetQ.mul (see HipSequential.forward)
 
     fqss_cut_every = 0     # > 0: a backward cut point (ops.cut) after every that many TCN blocks, set by fqss_segments()
 

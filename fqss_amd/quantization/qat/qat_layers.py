@@ -13,6 +13,7 @@ BatchNormQ, Conv1dGnNlQ, ConvTr2dDecoderQ, ...) are later rows of SURVEY.md §8 
 kernels exist -- there is no ATen fallback.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -68,6 +69,24 @@ def _mul_any(x1, x2, qmin, qmax, q):
         y = ops.MulActQ.apply(x1.reshape(1, 1, -1, M), x2.reshape(1, -1, M), qmin, qmax, q)
         return y.reshape(x1.shape)
     raise NotImplementedError(f"MulQ broadcast {tuple(x1.shape)} x {getattr(x2, 'shape', x2)} has no HIP kernel yet")
+
+
+FUSE_MULQ = os.environ.get("FQSS_FUSE_MULQ", "1") != "0"
+
+
+def _mul_coded(x1, x2, q):
+    """mask[B,S,C,M] * feat[B,1,C,M] (either order) with both operands on codes, in the quantizing phase: the codes -> codes kernel
+    (ops.MulQCoded); None when it does not apply"""
+    if not (FUSE_MULQ and torch.is_tensor(x2) and x1.dim() == 4 and x2.dim() == 4 and q.qmode == ops.Q_QUANT and q.gacc is not None):
+        return None
+    if x1.shape[1] == 1 and x2.shape[1] != 1:
+        x1, x2 = x2, x1
+    if not (x2.shape[1] == 1 and x1.shape[0] == x2.shape[0] and x1.shape[2:] == x2.shape[2:] and 1 <= x1.shape[1] <= 4):
+        return None
+    mq, fq_ = ops.codes_of(x1), ops.codes_of(x2)
+    if mq is None or fq_ is None or K.rowmat(mq.idx) is None or K.rowmat(fq_.idx) is None:
+        return None
+    return ops.MulQCoded.apply(x1, x2, q.qmin, q.qmax, q, mq, fq_)
 
 
 class Mul(nn.Module):
@@ -158,7 +177,9 @@ class MulQ(LayerQ):
         if y is not None:
             return fq_node(aq, y)
         q = aq.qctx()
-        y = _mul_any(ops.real(x1), ops.real(x2), q.qmin, q.qmax, q)
+        y = _mul_coded(x1, x2, q)
+        if y is None:
+            y = _mul_any(ops.real(x1), ops.real(x2), q.qmin, q.qmax, q)
         aq.after_forward(q)
         if q.idx is not None and q.idx.shape != y.shape:
             q.idx = q.idx.reshape(y.shape)       # same-shape products run on a [1, 1, rows, M] view (same row padding)

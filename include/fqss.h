@@ -284,6 +284,21 @@ int fqss_ewq_bwd_p(const uint8_t* ac, const float* amin, const float* amax, cons
                    float* pa_gbias, float* pa_out, int64_t ld_pa_out, const float* pb_z, int64_t ld_pbz,
                    int pb_act, const float* pb_slope, double* pb_gacc, float* pb_gbias, float* pb_out,
                    int64_t ld_pb_out, fqss_stream_t stream);
+/* MulQ on codes: masked[b][s][c][:] = fq(mask[b][s][c][:] * feat[b][c][:]) -- the masking product of ConvTasNetQ.forward
+ * (quantization/qat/models/convtasnetq.py:277 `self.mul(...)`, qat_layers.py:134-153 `MulQ`).  mc: [B*S*C rows], fc: [B*C rows],
+ * 1 <= S <= 4.  Same arithmetic as fqss_decode x 2 -> fqss_mul_bcast_fwd -> fqss_actq_fwd: bit-identical codes.  yout nullable. */
+int fqss_mulq_fwd(const uint8_t* mc, const float* mmin, const float* mmax, const uint8_t* fc, const float* fmin,
+                  const float* fmax, uint8_t* yc, float* yout, int B, int S, int C, int M, int64_t ld_m, int64_t ld_f,
+                  int64_t ld_y, int64_t ld_out, const float* qmin, const float* qmax, fqss_stream_t stream);
+/* its backward (= fqss_actq_bwd + fqss_mul_bcast_bwd on recomputed values): gmask [B*S*C rows], gfeat [B*C rows] (nullable),
+ * range partials to gacc.  pz != NULL: the mask is the fake-quantized output of a pointwise conv (its quantizer = (mmin, mmax))
+ * whose epilogue backward runs here as in fqss_ewq_bwd_p: gmask then receives THAT layer's gz, its partials go to pgacc, its
+ * bias gradient to pgbias[S*C] (nullable); pact: FQSS_ACT_NONE / RELU / PRELU. */
+int fqss_mulq_bwd(const uint8_t* mc, const float* mmin, const float* mmax, const uint8_t* fc, const float* fmin,
+                  const float* fmax, const float* g, float* gmask, float* gfeat, int B, int S, int C, int M, int64_t ld_m,
+                  int64_t ld_f, int64_t ld_g, int64_t ld_gm, int64_t ld_gf, const float* qmin, const float* qmax,
+                  double* gacc, const float* pz, int64_t ld_pz, int pact, const float* pslope, double* pgacc,
+                  float* pgbias, fqss_stream_t stream);
 /* gw[C][K] += */
 int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x,
                    float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_gz,

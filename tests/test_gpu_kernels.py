@@ -601,6 +601,71 @@ def test_ewq_coded(B, C, M, mode):
         np.testing.assert_allclose(gacc2.view(-1, 3).sum(0).cpu().numpy(), ga, rtol=1e-6, atol=1e-6 * sc)
 
 
+@pytest.mark.parametrize("B,S,C,M", [(2, 2, 16, 77), (2, 2, 64, 3999), (1, 3, 8, 130), (3, 1, 5, 64), (1, 4, 12, 4100)])
+def test_mulq_coded(B, S, C, M):
+    """fqss_mulq_fwd / fqss_mulq_bwd (MulQ of ConvTasNetQ.forward on codes: qat_layers.py:134-153, convtasnetq.py:277 of the reference):
+    codes bit-identical to the chain decode -> fqss_mul_bcast_fwd -> fqss_actq_fwd and within the oracle quantizer's bins; the
+    backward element for element what fqss_actq_bwd + fqss_mul_bcast_bwd return on the materialised product; the fused-producer form
+    (the mask conv's ReLU + output quantizer backward in the same launch) against fqss_actq_bwd on its result."""
+    cu = lambda t: t.cuda()
+    gen = torch.Generator().manual_seed(B + 10 * S + C + M)
+    mcodes = torch.randint(0, 256, (B, S, C, M), generator=gen, dtype=torch.uint8)
+    fcodes = torch.randint(0, 256, (B, C, M), generator=gen, dtype=torch.uint8)
+    mlo, mhi = torch.tensor([0.0]), torch.tensor([1.37])            # a ReLU mask
+    flo, fhi = torch.tensor([-1.21]), torch.tensor([0.77])
+    ylo, yhi = torch.tensor([-0.9]), torch.tensor([0.6])
+    xm = ((mhi - mlo) / 255) * mcodes.float() + mlo
+    xf = ((fhi - flo) / 255) * fcodes.float() + flo
+    mc, fc = K.empty_codes((B, S, C, M), "cuda"), K.empty_codes((B, C, M), "cuda")
+    mc.copy_(mcodes)
+    fc.copy_(fcodes)
+    g = rnd(B, S, C, M, seed=4)
+    mr, fr = xm.clone().requires_grad_(True), xf.clone().requires_grad_(True)
+    lo_r, hi_r = ylo.clone().requires_grad_(True), yhi.clone().requires_grad_(True)
+    z = mr * fr.unsqueeze(1)
+    O.act_quantize(z, lo_r, hi_r).backward(g)
+    # the un-fused chain on the GPU
+    xm_g, xf_g = K.decode(mc, cu(mlo), cu(mhi)), K.decode(fc, cu(flo), cu(fhi))
+    assert torch.equal(xm_g.cpu(), xm) and torch.equal(xf_g.cpu(), xf)
+    z_g = K.mul_bcast_fwd(xm_g, xf_g)
+    _, yc_ref = K.actq_fwd(z_g, K.ACT_NONE, None, K.Q_QUANT, cu(ylo), cu(yhi), None, want_idx=True)
+    for write_out in (True, False):
+        out, yc = K.mulq_fwd(mc, cu(mlo), cu(mhi), fc, cu(flo), cu(fhi), cu(ylo), cu(yhi), write_out)
+        assert torch.equal(yc.cpu(), yc_ref.cpu().reshape(B, S, C, M))
+        frac, dmax = _idx_mismatch(yc.cpu(), O.act_indices(z.detach(), ylo, yhi))
+        assert dmax <= 1 and frac <= 2e-3, (frac, dmax)
+        if write_out:
+            assert torch.equal(out.cpu(), ((yhi - ylo) / 255) * yc.cpu().float() + ylo)
+    gacc_ref = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda")
+    gz_ref = K.actq_bwd(z_g, padded(g), K.ACT_NONE, None, K.Q_QUANT, cu(ylo), cu(yhi), gacc_ref)
+    gm_ref, gf_ref = K.mul_bcast_bwd(gz_ref, xm_g, xf_g)
+    gacc = torch.zeros_like(gacc_ref)
+    gm, gf = K.mulq_bwd(mc, cu(mlo), cu(mhi), fc, cu(flo), cu(fhi), padded(g), cu(ylo), cu(yhi), gacc)
+    assert torch.equal(gm.cpu(), gm_ref.cpu()) and torch.equal(gf.cpu(), gf_ref.cpu())
+    sc = float(g.abs().sum()) * 2e-5 + 1e-4
+    ga = gacc.view(-1, 3).sum(0).cpu().numpy()
+    np.testing.assert_allclose(ga, gacc_ref.view(-1, 3).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
+    np.testing.assert_allclose(ga[0], lo_r.grad.item(), rtol=5e-3, atol=sc)
+    np.testing.assert_allclose(ga[1], hi_r.grad.item(), rtol=5e-3, atol=sc)
+    tol = 2e-3 + 20 * frac
+    assert ((gm.cpu() - mr.grad).abs() > 1e-4 + 1e-3 * mr.grad.abs()).float().mean() <= tol
+    assert ((gf.cpu() - fr.grad).abs() > 2e-4 + 2e-3 * fr.grad.abs()).float().mean() <= S * tol
+    gm2, gf2 = K.mulq_bwd(mc, cu(mlo), cu(mhi), fc, cu(flo), cu(fhi), padded(g), cu(ylo), cu(yhi), torch.zeros_like(gacc), want_gfeat=False)
+    assert gf2 is None and torch.equal(gm2.cpu(), gm.cpu())
+    # ---- the mask as the fresh output of a pointwise conv + ReLU + quantizer: that layer's epilogue backward in the same launch
+    dm = float((mhi - mlo) / 255)
+    pz = padded((xm + 0.3 * dm * rnd(B, S, C, M, seed=9) - 0.2 * (mcodes == 0).float()).reshape(B, S * C, M))   # code 0 <- negative pre-activations
+    pg_ref, pb_ref = torch.zeros_like(gacc), torch.zeros(S * C, device="cuda")
+    gzp_ref = K.actq_bwd(pz, gm.reshape(B, S * C, M), K.ACT_RELU, None, K.Q_QUANT, cu(mlo), cu(mhi), pg_ref, gbias=pb_ref, C=S * C)
+    pg, pb, gacc3 = torch.zeros_like(gacc), torch.zeros(S * C, device="cuda"), torch.zeros_like(gacc)
+    gzp, gf3 = K.mulq_bwd(mc, cu(mlo), cu(mhi), fc, cu(flo), cu(fhi), padded(g), cu(ylo), cu(yhi), gacc3,
+                          prod=(pz, K.ACT_RELU, None, pg, pb))
+    assert torch.equal(gzp.cpu().reshape(B, S * C, M), gzp_ref.cpu()) and torch.equal(gf3.cpu(), gf.cpu())
+    close(pb, pb_ref, rtol=1e-4, atol=1e-5 * float(pb_ref.abs().max()) + 1e-6)
+    np.testing.assert_allclose(pg.view(-1, 3).sum(0).cpu().numpy(), pg_ref.view(-1, 3).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * sc)
+    np.testing.assert_allclose(gacc3.view(-1, 3).sum(0).cpu().numpy(), ga, rtol=1e-6, atol=1e-6 * sc)
+
+
 @pytest.mark.parametrize("B,C,M", [(2, 32, 77), (2, 512, 999), (3, 128, 4100), (1, 24, 130)])
 def test_code_statistics_from_the_producing_kernels(B, C, M):
     """SURVEY K7 ("stats can be produced by the previous kernel's epilogue"): the q-GEMM / depthwise forward emit the exact integer
