@@ -9,6 +9,8 @@
 // Reference replaced: process.preprocess (process.py:16-37); F.conv1d(k=16,s=8) of Conv1dEncoderQ /
 // ResidualErrorBlock (qat_layers.py:1028-1039, 1189-1192); F.conv_transpose1d of ConvTr1dDecoderQ /
 // ResidualErrorBlock (qat_layers.py:1330-1341, 1194-1202) and their autograd.
+#include <cstdlib>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -127,6 +129,147 @@ __global__ __launch_bounds__(256) void k_ola_convtr_fwd(const float* __restrict_
     }
 }
 
+
+// the four codes of a word de-quantised like csrc/fused_q.hip's dec4 (delta * c + min in two roundings)
+__device__ __forceinline__ void ola_dec4(unsigned int w, const QRange& r, float (&v)[4]) {
+    v[0] = r.delta * (float)(w & 255u) + r.lo;
+    v[1] = r.delta * (float)((w >> 8) & 255u) + r.lo;
+    v[2] = r.delta * (float)((w >> 16) & 255u) + r.lo;
+    v[3] = r.delta * (float)(w >> 24) + r.lo;
+}
+
+// The same transposed conv + overlap-add with FOUR frames per lane (a workgroup covers 256 frames, 252 output slots): the operand
+// row is read 16 B (or 4 codes) per lane instead of 4 B, and it may arrive as
+//   MODE 0  fp32 values,
+//   MODE 1  u8 codes of a per-tensor quantizer (de-quantised on load: the student's MulQ / residual outputs never exist in fp32),
+//   MODE 2  fp32 mask[n][c][m] * fp32 feat[n / NS][c][m] (the float teacher's masking product, formed on load).
+// Same summation order as k_ola_convtr_fwd (a wave takes the channels c = wave, wave + 4, ...; partials added r-major, wave-minor):
+// bit-identical results.  The first form spent 58-92 us on 131 MB (16 FMAs per 4-B load, 63 frames per workgroup).
+template <int K, int S, int MODE>
+__global__ __launch_bounds__(256) void k_ola_convtr4(const void* __restrict__ xv_, const float* __restrict__ feat,
+                                                      const float* __restrict__ w, float* __restrict__ out, int C, int M,
+                                                      int64_t ld_x, int64_t ld_f, int NS, int64_t T, const float* qmin,
+                                                      const float* qmax) {
+    constexpr int R = K / S;
+    static_assert(R >= 1 && R <= 4, "at most 4 overlapping frames");
+    constexpr int NF = 256, FB = NF - 4, PL = NF + 4;   // frames / output slots per workgroup; padded row of partials (16-B aligned)
+    extern __shared__ __attribute__((aligned(16))) float P_[];        // [4][K][PL]
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q0 = blockIdx.x * FB;          // first output slot of this workgroup
+    const int m0 = q0 - 4 + 4 * lane;        // this lane's frames m0 .. m0 + 3 (a multiple of 4: aligned vector loads)
+    const bool in_row = m0 >= 0 && m0 < M;   // rows are padded to 16 elements, so the whole group is readable
+    bool fv[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fv[f] = in_row && (m0 + f < M);
+    QRange rx{0.f, 1.f, 1.f};
+    if (MODE == 1) rx = load_qrange(qmin, qmax);
+    float acc[4][K];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[f][k] = 0.0f;
+    const int mld = in_row ? m0 : 0;
+    const float* xf = (const float*)xv_ + (int64_t)n * C * ld_x + mld;
+    const uint8_t* xc = (const uint8_t*)xv_ + (int64_t)n * C * ld_x + mld;
+    const float* ff = (MODE == 2) ? feat + (int64_t)(n / NS) * C * ld_f + mld : nullptr;
+    // the taps [C][K] are staged in LDS once per workgroup (the partial-sum buffer, not yet in use, lends the space): per channel a
+    // wave reads them as K/4 broadcast ds_read_b128 instead of one scalar-memory round trip
+    float* W = P_;
+    const bool w_lds = (int64_t)C * K <= (int64_t)4 * K * PL;
+    if (w_lds) {
+        for (int i = threadIdx.x; i < C * K; i += 256) W[i] = w[i];
+        __syncthreads();
+    }
+    // One wave per SIMD at the decoder's sizes (N x ceil(M / 252) x 4 waves = 1,024): nothing else hides a load's latency, so the
+    // operand rows go through a two-deep software pipeline of PF channels each, raw (no conversion before the data is needed).
+    constexpr int PF = 8;
+    struct Raw {
+        float4 a, b;
+        unsigned int c;
+    };
+    auto issue = [&](int g, Raw (&r)[PF]) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int c = min(wave + 4 * (g * PF + i), C - 1);     // clamped: a few redundant loads instead of a branch around a load
+            if (MODE == 1) {
+                r[i].c = *reinterpret_cast<const unsigned int*>(xc + (int64_t)c * ld_x);
+            } else {
+                r[i].a = *reinterpret_cast<const float4*>(xf + (int64_t)c * ld_x);
+                if (MODE == 2) r[i].b = *reinterpret_cast<const float4*>(ff + (int64_t)c * ld_f);
+            }
+        }
+    };
+    auto consume = [&](int g, const Raw (&r)[PF]) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int c = wave + 4 * (g * PF + i);
+            if (c >= C) break;     // wave-uniform
+            float v[4];
+            if (MODE == 1) {
+                ola_dec4(r[i].c, rx, v);
+            } else {
+                v[0] = r[i].a.x; v[1] = r[i].a.y; v[2] = r[i].a.z; v[3] = r[i].a.w;
+                if (MODE == 2) {
+                    v[0] *= r[i].b.x; v[1] *= r[i].b.y; v[2] *= r[i].b.z; v[3] *= r[i].b.w;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) v[f] = fv[f] ? v[f] : 0.0f;
+            float wk[K];
+            if (w_lds) {
+#pragma unroll
+                for (int k4 = 0; k4 < K / 4; ++k4) {
+                    const float4 t = *reinterpret_cast<const float4*>(&W[c * K + 4 * k4]);
+                    wk[4 * k4] = t.x; wk[4 * k4 + 1] = t.y; wk[4 * k4 + 2] = t.z; wk[4 * k4 + 3] = t.w;
+                }
+            } else {
+                const float* wr = w + (int64_t)c * K;  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < K; ++k) wk[k] = wr[k];
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f][k] = fmaf(v[f], wk[k], acc[f][k]);
+        }
+    };
+    const int nch = (C - wave + 3) / 4;              // channels of this wave
+    const int ng = (nch + PF - 1) / PF;
+    {
+        Raw ra[PF], rb[PF];
+        issue(0, ra);
+        for (int g = 0; g < ng; g += 2) {
+            issue(g + 1, rb);
+            consume(g, ra);
+            issue(g + 2, ra);
+            consume(g + 1, rb);
+        }
+    }
+    if (w_lds) __syncthreads();      // every wave is done with the taps before the partial sums overwrite them
+    float* P = P_ + (int64_t)wave * K * PL;
+#pragma unroll
+    for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(&P[k * PL + 4 * lane]) = make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
+    __syncthreads();
+    const int nslots = M + R - 1;
+    for (int e = threadIdx.x; e < FB * S; e += 256) {
+        const int ql = e / S, j = e - ql * S;
+        const int q = q0 + ql;
+        if (q < nslots) {
+            float v = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int fl = ql + 4 - r;       // local index of frame q - r
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) v += P_[((int64_t)wv * K + r * S + j) * PL + fl];
+            }
+            const int64_t t = (int64_t)q * S + j;
+            if (t < T) out[(int64_t)n * T + t] = v;
+        }
+    }
+}
+
 }  // namespace fqss
 
 using namespace fqss;
@@ -174,25 +317,67 @@ extern "C" int fqss_frames_conv_fwd(const float* x, const float* w, float* z, in
     return launch_status("fqss_frames_conv_fwd");
 }
 
-extern "C" int fqss_ola_convtr_fwd(const float* x, const float* w, float* out, int N, int C, int M, int64_t ld_x, int K,
-                                   int stride, int64_t T, fqss_stream_t stream) {
+// mode 0: fp32 x; 1: u8 codes x + (qmin, qmax); 2: fp32 x * feat[n / NS]
+static int ola_convtr_impl(const char* who, int mode, const void* x, const float* feat, const float* w, float* out, int N, int C, int M,
+                           int64_t ld_x, int64_t ld_f, int NS, int K, int stride, int64_t T, const float* qmin, const float* qmax,
+                           fqss_stream_t stream) {
     FQSS_REQUIRE(x && w && out, "null tensor");
     FQSS_REQUIRE(N >= 0 && N <= 65535 && C > 0 && M >= 0 && ld_x >= M && K > 0 && stride > 0, "bad shape");
     FQSS_REQUIRE(M == 0 || T == (int64_t)(M - 1) * stride + K, "T must equal (M-1)*stride + K");
+    FQSS_REQUIRE(mode != 1 || (qmin && qmax && (aligned16(x) && ld_x % 16 == 0)), "coded operand: ranges + 16-B aligned code rows");
+    FQSS_REQUIRE(mode != 2 || (feat && NS >= 1 && N % NS == 0 && ld_f >= M), "masking form: feat [N / NS][C][M]");
     if (N == 0 || M == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (K == 16 && stride == 8) {
+    const bool k16 = K == 16 && stride == 8, k32 = K == 32 && stride == 16;
+    // the 4-frames-per-lane form needs vector-aligned rows whose padding is readable (activation rows: ld a multiple of 4 >= M rounded up)
+    const int64_t m4 = (M + 3) & ~(int64_t)3;
+    static const bool wide_on = [] { const char* e = getenv("FQSS_OLA_WIDE"); return !(e && e[0] == '0'); }();   // A/B switch (fp32 operand only)
+    bool wide = (k16 || k32) && ld_x >= m4 && (wide_on || mode != 0);
+    if (mode != 1) wide = wide && aligned16(x) && ld_x % 4 == 0;
+    if (mode == 2) wide = wide && aligned16(feat) && ld_f % 4 == 0 && ld_f >= m4;
+    if (wide) {
+        dim3 grid((unsigned)cdiv((int64_t)M + K / stride - 1, 252), (unsigned)N);
+        const size_t lds = (size_t)4 * K * 260 * sizeof(float);
+#define FQSS_OLA4(K_, S_, MODE_)                                                                                                    \
+    hipLaunchKernelGGL((k_ola_convtr4<K_, S_, MODE_>), grid, dim3(256), lds, s, x, feat, w, out, C, M, ld_x, ld_f, NS > 0 ? NS : 1, T, \
+                       qmin, qmax)
+        if (k16) {
+            if (mode == 0) FQSS_OLA4(16, 8, 0); else if (mode == 1) FQSS_OLA4(16, 8, 1); else FQSS_OLA4(16, 8, 2);
+        } else {
+            if (mode == 0) FQSS_OLA4(32, 16, 0); else if (mode == 1) FQSS_OLA4(32, 16, 1); else FQSS_OLA4(32, 16, 2);
+        }
+#undef FQSS_OLA4
+        return launch_status(who);
+    }
+    FQSS_REQUIRE(mode == 0, "coded / masking operands need 16-B aligned rows and a (16, 8) or (32, 16) window");
+    const float* xf = (const float*)x;
+    if (k16) {
         dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
-        hipLaunchKernelGGL((k_ola_convtr_fwd<16, 8>), grid, dim3(256), 0, s, x, w, out, C, M, ld_x, T);
-    } else if (K == 32 && stride == 16) {
+        hipLaunchKernelGGL((k_ola_convtr_fwd<16, 8>), grid, dim3(256), 0, s, xf, w, out, C, M, ld_x, T);
+    } else if (k32) {
         dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
-        hipLaunchKernelGGL((k_ola_convtr_fwd<32, 16>), grid, dim3(256), 0, s, x, w, out, C, M, ld_x, T);
+        hipLaunchKernelGGL((k_ola_convtr_fwd<32, 16>), grid, dim3(256), 0, s, xf, w, out, C, M, ld_x, T);
     } else if (K == 2 && stride == 1) {   // DPTNet's 2-sample window, hop 1 (input gradient of its encoder)
         dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
-        hipLaunchKernelGGL((k_ola_convtr_fwd<2, 1>), grid, dim3(256), 0, s, x, w, out, C, M, ld_x, T);
+        hipLaunchKernelGGL((k_ola_convtr_fwd<2, 1>), grid, dim3(256), 0, s, xf, w, out, C, M, ld_x, T);
     } else {
-        set_error("fqss_ola_convtr_fwd: unsupported (K=%d, stride=%d); built for (2,1), (16,8) and (32,16)", K, stride);
+        set_error("%s: unsupported (K=%d, stride=%d); built for (2,1), (16,8) and (32,16)", who, K, stride);
         return FQSS_EINVAL;
     }
-    return launch_status("fqss_ola_convtr_fwd");
+    return launch_status(who);
+}
+
+extern "C" int fqss_ola_convtr_fwd(const float* x, const float* w, float* out, int N, int C, int M, int64_t ld_x, int K,
+                                   int stride, int64_t T, fqss_stream_t stream) {
+    return ola_convtr_impl("fqss_ola_convtr_fwd", 0, x, nullptr, w, out, N, C, M, ld_x, 0, 1, K, stride, T, nullptr, nullptr, stream);
+}
+
+extern "C" int fqss_ola_convtr_fwd_q(const uint8_t* xc, const float* qmin, const float* qmax, const float* w, float* out, int N, int C,
+                                     int M, int64_t ld_x, int K, int stride, int64_t T, fqss_stream_t stream) {
+    return ola_convtr_impl("fqss_ola_convtr_fwd_q", 1, xc, nullptr, w, out, N, C, M, ld_x, 0, 1, K, stride, T, qmin, qmax, stream);
+}
+
+extern "C" int fqss_ola_convtr_mul_fwd(const float* mask, const float* feat, const float* w, float* out, int N, int NS, int C, int M,
+                                       int64_t ld_m, int64_t ld_f, int K, int stride, int64_t T, fqss_stream_t stream) {
+    return ola_convtr_impl("fqss_ola_convtr_mul_fwd", 2, mask, feat, w, out, N, C, M, ld_m, ld_f, NS, K, stride, T, nullptr, nullptr, stream);
 }

@@ -696,6 +696,34 @@ def ola_convtr_fwd(x, w, stride):
     return out
 
 
+def ola_convtr_fwd_q(xc, qmin, qmax, w, stride):
+    """ola_convtr_fwd on the u8 codes of x [N,C,M] (de-quantised on load)"""
+    N, C, M, ld_x = _codes3(xc)
+    K = w.shape[-1]
+    T = (M - 1) * stride + K
+    out = torch.empty(N, 1, T, device=xc.device, dtype=torch.float32)
+    _lib.call("fqss_ola_convtr_fwd_q", _p(xc), _p(qmin), _p(qmax), _p(w.contiguous()), _p(out), N, C, M, ld_x, K, stride, T, _stream())
+    return out
+
+
+def ola_convtr_ok(w, stride):
+    """window shapes the coded / masking forms of the decoder are built for"""
+    return (w.shape[-1], stride) in ((16, 8), (32, 16)) and (w.dim() == 2 or w.shape[1] == 1)
+
+
+def ola_convtr_mul_fwd(mask, feat, w, stride):
+    """decoder of the float model on mask [B,S,C,M] * feat [B,C,M] formed on load -> [B*S,1,T]"""
+    _need_gpu(mask, feat, w)
+    B, S, C, M = mask.shape
+    mask, _, _, ld_m = as_rowmat(mask)
+    feat, _, _, ld_f = as_rowmat(feat)
+    K = w.shape[-1]
+    T = (M - 1) * stride + K
+    out = torch.empty(B * S, 1, T, device=mask.device, dtype=torch.float32)
+    _lib.call("fqss_ola_convtr_mul_fwd", _p(mask), _p(feat), _p(w.contiguous()), _p(out), B * S, S, C, M, ld_m, ld_f, K, stride, T, _stream())
+    return out
+
+
 def frames_wgrad(a, x, gw, stride):
     """gw[C][Ci][K] += sum_{n,m} a[n][c][m] * x[n][ci][m*stride+k]"""
     _need_gpu(a, x, gw)

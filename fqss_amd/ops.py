@@ -407,6 +407,8 @@ class LinearActQ(Function):
         ctx.xq = xq if (L.kind == "pw" and xq is not None and K.q_eligible(w.shape[1], w.shape[0])) else None
         ctx.wc = wc if (L.kind == "pw" and wc is not None and K.q_eligible(w.shape[1], w.shape[0])) else None
         ctx.plain = (q.qmode == Q_BYPASS and act == ACT_NONE)   # float linear op: no epilogue pass at all
+        # decoder on a coded input (MulQ's output, the residual block's quantized error): de-quantised inside the overlap-add kernel
+        ctx.xq_tr = xq if (L.kind == "convtr" and xq is not None and bias is None and K.ola_convtr_ok(w, L.stride)) else None
         if ctx.xq is not None and ctx.wc is not None and _fuse_out_quant(q):
             # the layer's own non-linearity + fake-quant ride in the GEMM epilogue: z (for the backward) and the
             # output codes come out of one launch
@@ -419,6 +421,8 @@ class LinearActQ(Function):
         else:
             if ctx.xq is not None and ctx.wc is not None:
                 z = K.qpw_fwd(ctx.xq.idx, ctx.wc, bias, ctx.xq.qmin, ctx.xq.qmax)
+            elif ctx.xq_tr is not None:
+                z = K.ola_convtr_fwd_q(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax, w, L.stride)
             else:
                 z = _lin_fwd(L, x, w, bias)
             out = z if ctx.plain else _epilogue_fwd(z, act, slope, q)
@@ -429,7 +433,8 @@ class LinearActQ(Function):
             ctx.prod = q.prod = _Producer(z, act, slope, L.slope_param, q, L.b_param, bias)
         ctx.x_shape = x.shape
         ctx.fork = getattr(x, "_fqss_fork", None) if (ctx.wc is not None and ctx.wc.idxT is not None) else None
-        ctx.save_for_backward(None if (ctx.xq is not None and ctx.wc is not None) else x, w, None if ctx.plain else z, slope)
+        ctx.save_for_backward(None if ((ctx.xq is not None and ctx.wc is not None) or ctx.xq_tr is not None) else x, w,
+                              None if ctx.plain else z, slope)
         ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
         ctx.bias_like = bias
         ctx.C = z.shape[1]
@@ -467,6 +472,8 @@ class LinearActQ(Function):
             if ctx.xq is not None:
                 K.qpw_bwd_w(gz, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
             else:
+                if x is None:        # coded decoder input: its values are needed once more, for dL/dW
+                    x = K.decode(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax)
                 _lin_bwd_w(L, gz, x, gw)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True

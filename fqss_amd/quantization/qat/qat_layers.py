@@ -72,6 +72,7 @@ def _mul_any(x1, x2, qmin, qmax, q):
 
 
 FUSE_MULQ = os.environ.get("FQSS_FUSE_MULQ", "1") != "0"
+FUSE_DECQ = os.environ.get("FQSS_FUSE_DECQ", "1") != "0"    # decoder reads its coded input directly
 
 
 def _mul_coded(x1, x2, q):
@@ -535,7 +536,8 @@ class ResidualErrorBlock(LayerQ):
         q = aq.qctx()
         Y1 = ops.tag_codes(ops.ew_layer(Y, Y_q, -1.0, ops.ACT_NONE, None, q), q)
         aq.after_forward(q)
-        Y1 = ops.real(Y1)
+        if decoder_conv is None and not self.train_res_dec:
+            Y1 = ops.real(Y1)
         if self.train_res_dec:
             decoder_conv_, w_decoder = self.residual_decoder, self.weight_fake_quantize_dec(self.residual_decoder.weight)
             if decoder_conv is None:
@@ -582,7 +584,12 @@ def run_convtr1d(convtr, x, weight, aq):
     L = ops._Lin("convtr", stride=convtr.stride[0], w_param=convtr.weight)
     q = aq.qctx() if aq is not None else ops.QCtx()
     q.keep_out = True          # waveform-side outputs are the model's outputs: always real fp32
-    y = ops.LinearActQ.apply(ops.real(x), weight, None, None, q.qmin, q.qmax, L, ops.ACT_NONE, q)
+    xq = ops.codes_of(x) if (FUSE_DECQ and x.dim() == 3 and K.ola_convtr_ok(weight, convtr.stride[0])) else None
+    if xq is not None and (K.rowmat(xq.idx) is None or K.rowmat(xq.idx)[2] % 16 != 0):
+        xq = None
+    if xq is None:
+        x = ops.real(x)        # no coded-input kernel for this case: decode a carrier first
+    y = ops.LinearActQ.apply(x, weight, None, None, q.qmin, q.qmax, L, ops.ACT_NONE, q, xq)
     if aq is not None:
         aq.after_forward(q)
     return ops.tag_codes(y, q)

@@ -142,8 +142,12 @@ class TeacherRunner:
                              pro_eps=sb[5].eps, M1=nfeat, r1=h, r2=acc)
         mask = K.tgemm(pl["mask"], acc, mk.mask_net[1].bias, act=K.ACT_RELU, pro=2, pro_slope=mk.mask_net[0].weight)
         F_ = feats.shape[1]
-        masked = K.mul_bcast_fwd(mask.reshape(B, m.n_srcs, F_, -1), feats)
-        dec = K.ola_convtr_fwd(masked.reshape(B * m.n_srcs, F_, -1), m.decoder.weight, stride)
+        if K.ola_convtr_ok(m.decoder.weight, stride) and os.environ.get("FQSS_FUSE_TMUL", "1") != "0":
+            # the masking product is formed inside the decoder kernel (no [B, S, F, M] intermediate): same values, same sums
+            dec = K.ola_convtr_mul_fwd(mask.reshape(B, m.n_srcs, F_, -1), feats, m.decoder.weight, stride)
+        else:
+            masked = K.mul_bcast_fwd(mask.reshape(B, m.n_srcs, F_, -1), feats)
+            dec = K.ola_convtr_fwd(masked.reshape(B * m.n_srcs, F_, -1), m.decoder.weight, stride)
         return dec.reshape(B, m.n_srcs, -1)
 
 

@@ -367,6 +367,15 @@ int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci
 /* out[n][t] = sum_{c} sum_{m*stride+k=t} x[n][c][m] * w[c][k]   (w: [C][K], out: [N][T] dense) */
 int fqss_ola_convtr_fwd(const float* x, const float* w, float* out, int N, int C, int M,
                         int64_t ld_x, int K, int stride, int64_t T, fqss_stream_t stream);
+/* the same on an operand that arrives as the u8 codes of a per-tensor quantizer (de-quantised on load: the decoder input of the
+ * student -- MulQ's output, the residual block's quantized error -- never exists in fp32; qat_layers.py:1305-1361, 1105-1202);
+ * bit-identical to fqss_decode + fqss_ola_convtr_fwd.  Code rows 16-B aligned, (K, stride) in {(16, 8), (32, 16)} */
+int fqss_ola_convtr_fwd_q(const uint8_t* xc, const float* qmin, const float* qmax, const float* w, float* out, int N,
+                          int C, int M, int64_t ld_x, int K, int stride, int64_t T, fqss_stream_t stream);
+/* the float model's masking product formed on load: x[n][c][m] = mask[n][c][m] * feat[n / NS][c][m] (convtasnetq.py:277-279 of the
+ * float teacher: `masked = mask * feats` then the decoder); bit-identical to fqss_mul_bcast_fwd + fqss_ola_convtr_fwd */
+int fqss_ola_convtr_mul_fwd(const float* mask, const float* feat, const float* w, float* out, int N, int NS, int C, int M,
+                            int64_t ld_m, int64_t ld_f, int K, int stride, int64_t T, fqss_stream_t stream);
 /* gw[c][ci][k] += sum_{n,m} a[n][c][m] * x[n][ci][m*stride+k]    (a: [N][C][M] ld_a; x dense) */
 int fqss_frames_wgrad(const float* a, const float* x, float* gw, int N, int C, int Ci, int M,
                       int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream);

@@ -146,16 +146,31 @@ def test_frames_conv_and_wgrad(N, Ci, Co, M, K_, S):
         close(gx, xr.grad, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("N,C,M,K_,S", [(4, 24, 77, 16, 8), (2, 512, 999, 16, 8), (1, 8, 1, 16, 8), (2, 16, 63, 16, 8), (2, 16, 64, 32, 16)])
+@pytest.mark.parametrize("N,C,M,K_,S", [(4, 24, 77, 16, 8), (2, 512, 999, 16, 8), (1, 8, 1, 16, 8), (2, 16, 63, 16, 8), (2, 16, 64, 32, 16),
+                                        (2, 30, 253, 16, 8), (1, 7, 757, 32, 16)])
 def test_ola_convtr(N, C, M, K_, S):
     x, w = rnd(N, C, M, seed=1), rnd(C, 1, K_, seed=2, scale=0.2)
     g = rnd(N, 1, (M - 1) * S + K_, seed=3)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y = F.conv_transpose1d(xr, wr, None, stride=S)
     y.backward(g)
-    for conv in (padded, lambda t: t.cuda()):
+    outs = []
+    for conv in (padded, lambda t: t.cuda()):      # padded rows: four frames per lane; dense rows of odd length: one frame per lane
         out = K.ola_convtr_fwd(conv(x), w.cuda(), S)
         close(out, y, rtol=1e-4, atol=1e-4)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])           # same summation order in both forms
+    # the coded-input form (student decoder) and the masking form (teacher decoder) against their un-fused chains, bit for bit
+    gen = torch.Generator().manual_seed(N + C + M)
+    codes = torch.randint(0, 256, (N, C, M), generator=gen, dtype=torch.uint8)
+    lo, hi = torch.tensor([-0.83]).cuda(), torch.tensor([1.21]).cuda()
+    xc = K.empty_codes((N, C, M), "cuda")
+    xc.copy_(codes)
+    assert torch.equal(K.ola_convtr_fwd_q(xc, lo, hi, w.cuda(), S), K.ola_convtr_fwd(K.decode(xc, lo, hi), w.cuda(), S))
+    if N % 2 == 0:
+        mask, feat = padded(rnd(N // 2, 2, C, M, seed=5)), padded(rnd(N // 2, C, M, seed=6))
+        ref = K.ola_convtr_fwd(K.mul_bcast_fwd(mask, feat).reshape(N, C, M), w.cuda(), S)
+        assert torch.equal(K.ola_convtr_mul_fwd(mask, feat, w.cuda(), S), ref)
     # decoder backward = framing conv of the output gradient with the same taps
     gx = K.frames_conv_fwd(g.cuda(), w.cuda().reshape(C, 1, K_), S)
     close(gx, xr.grad, rtol=1e-5, atol=1e-5)

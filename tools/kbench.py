@@ -85,6 +85,23 @@ case("qpw_bwd_x conv1 (512->128)", 4 * MBh + 4 * MBb, lambda: (act(NH),), lambda
 case("qpw_bwd_x2 pair (256->512)", 8 * MBb + 4 * MBh, lambda: (act(NB), act(NB)), lambda s: K.qpw_bwd_x2(s[0], s[1], pc))
 case("qpw_bwd_w conv1", 4 * MBh + MBb, lambda: (act(NH), codes(NB)), lambda s: K.qpw_bwd_w(s[0], s[1], lo, hi, gw_up))
 case("qpw_bwd_w2 pair", 8 * MBb + MBh, lambda: (act(NB), act(NB), codes(NH)), lambda s: K.qpw_bwd_w2(s[0], s[1], s[2], lo, hi, gw_pair))
+# the waveform side (decoder [16, 512, 3999] -> [16, 1, 32000]; masking product)
+w_dec = torch.randn(NH, 1, 16, device=dev) * 0.1
+act2 = lambda: K.empty_act((2 * B, NH, M), dev).normal_()
+codes2 = lambda: K.empty_codes((2 * B, NH, M), dev).random_(0, 256)
+case("ola_convtr_fwd fp32 (decoder)", 8 * MBh, lambda: (act2(),), lambda s: K.ola_convtr_fwd(s[0], w_dec, 8))
+case("ola_convtr_fwd_q codes (decoder)", 2 * MBh, lambda: (codes2(),), lambda s: K.ola_convtr_fwd_q(s[0], lo, hi, w_dec, 8))
+case("ola_convtr_mul_fwd (teacher mask x feats)", 12 * MBh, lambda: (act2().view(B, 2, NH, M), act(NH)),
+     lambda s: K.ola_convtr_mul_fwd(s[0], s[1], w_dec, 8))
+case("mulq_fwd S=2", 5 * MBh, lambda: (codes2().view(B, 2, NH, M), codes(NH)),
+     lambda s: K.mulq_fwd(s[0], lo, hi, s[1], lo, hi, lo, hi, False))
+case("mulq_bwd S=2 (+producer)", (2 + 1 + 8 + 8 + 8 + 4) * MBh, lambda: (codes2().view(B, 2, NH, M), codes(NH), act2().view(B, 2, NH, M), act2()),
+     lambda s: K.mulq_bwd(s[0], lo, hi, s[1], lo, hi, s[2], lo, hi, gacc, prod=(s[3], K.ACT_RELU, None, pga, None)))
+case("frames_conv_fwd (decoder dgrad) 1->512", 8 * MBh, lambda: (torch.randn(2 * B, 1, 32000, device=dev),),
+     lambda s: K.frames_conv_fwd(s[0], w_dec.view(NH, 1, 16), 8))
+gw_dec = torch.zeros(NH, 1, 16, device=dev)
+case("frames_wgrad (decoder) a fp32", 8 * MBh, lambda: (act2(), torch.randn(2 * B, 1, 32000, device=dev)),
+     lambda s: K.frames_wgrad(s[0], s[1], gw_dec, 8))
 case("axpby C=128", 12 * MBb, lambda: (act(NB), act(NB)), lambda s: K.axpby(s[0], s[1], 1.0))
 
 
