@@ -176,10 +176,9 @@ __global__ __launch_bounds__(256) void k_ola_convtr4(const void* __restrict__ xv
     const float* ff = (MODE == 2) ? feat + (int64_t)(n / NS) * C * ld_f + mld : nullptr;
     // the taps [C][K] are staged in LDS once per workgroup (the partial-sum buffer, not yet in use, lends the space): per channel a
     // wave reads them as K/4 broadcast ds_read_b128 instead of one scalar-memory round trip
-    float* W = P_;
     const bool w_lds = (int64_t)C * K <= (int64_t)4 * K * PL;
     if (w_lds) {
-        for (int i = threadIdx.x; i < C * K; i += 256) W[i] = w[i];
+        for (int i = threadIdx.x; i < C * K; i += 256) P_[i] = w[i];
         __syncthreads();
     }
     // One wave per SIMD at the decoder's sizes (N x ceil(M / 252) x 4 waves = 1,024): nothing else hides a load's latency, so the
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(256) void k_ola_convtr4(const void* __restrict__ xv
             if (w_lds) {
 #pragma unroll
                 for (int k4 = 0; k4 < K / 4; ++k4) {
-                    const float4 t = *reinterpret_cast<const float4*>(&W[c * K + 4 * k4]);
+                    const float4 t = *reinterpret_cast<const float4*>(&P_[c * K + 4 * k4]);
                     wk[4 * k4] = t.x; wk[4 * k4 + 1] = t.y; wk[4 * k4 + 2] = t.z; wk[4 * k4 + 3] = t.w;
                 }
             } else {
@@ -267,6 +266,105 @@ __global__ __launch_bounds__(256) void k_ola_convtr4(const void* __restrict__ xv
             const int64_t t = (int64_t)q * S + j;
             if (t < T) out[(int64_t)n * T + t] = v;
         }
+    }
+}
+
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+// Weight gradient of the single-channel framing conv / the mono decoder: gw[c][k] += sum_{n,m} a[n][c][m] * sig[n][m*S + k]
+// (qat_layers.py:1028-1039, 1330-1341 of the reference through autograd) = a [C x M] . frames(sig) [M x K] product per signal, on the
+// fp32 matrix cores (v_mfma_f32_16x16x4_f32: bit for bit a k-ordered fmaf chain, so the contract of the VALU form holds).  A wave owns
+// 64 channels (4 tiles of 16) of one signal; the operand row is read VL values per lane ALONG m -- 2 x float4, or 16 codes as one
+// dwordx4 (CODED: the student decoder's input) -- and, the sum over m being order-free, element j of lane group g is the k-slice
+// m = m0 + VL g + j of MFMA step j; the matching frame taps sig[(m0 + VL g + j) S + tap] are one 4-B load per step (64 B contiguous per
+// lane group).  The four waves of a workgroup interleave their steps (adjacent 128-B lines of every row) and add their tiles in
+// LDS before the atomics.  The generic fp32 GEMM spent 67-78 us on this shape (16 columns, strided 4-B signal loads), a VALU form
+// with four frames per lane 70-100 (its per-lane signal windows are 64 cache lines per load instruction).
+template <int K, int S, bool CODED>
+__global__ __launch_bounds__(256) void k_frames_wgrad_mfma(const void* __restrict__ a_, const float* __restrict__ sig,
+                                                            float* __restrict__ gw, int C, int M, int64_t ld_a, int64_t T, int mchunk,
+                                                            const float* qmin, const float* qmax) {
+    constexpr int TC = 4, NT = K / 16;
+    constexpr int VL = CODED ? 16 : 8;       // operand values per lane and iteration
+    constexpr int FI = 4 * VL;               // frames per iteration
+    static_assert(K % 16 == 0, "whole 16-tap tiles");
+    __shared__ float red[4][TC * NT * 4][64];
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = blockIdx.x * 16 * TC;
+    const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+    QRange ra{0.f, 1.f, 1.f};
+    if (CODED) ra = load_qrange(qmin, qmax);
+    f32x4m acc[TC][NT];
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    const float* sn = sig + (int64_t)n * T;
+    int64_t arow[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) arow[t] = ((int64_t)n * C + min(c0 + 16 * t + li, C - 1)) * ld_a;
+    for (int mb = mbeg + FI * wave; mb < mend; mb += 4 * FI) {
+        const int m0 = mb + VL * lk;                       // this lane's VL frames m0 .. m0 + VL - 1
+        float av[TC][VL];
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+            if (CODED) {
+                const int cl = (int)min((int64_t)m0, ld_a - 16);      // rows are padded to 16 codes: a group is inside or wholly past M
+                const uint4 cw = *reinterpret_cast<const uint4*>((const uint8_t*)a_ + arow[t] + cl);
+                const unsigned int wq[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float d[4];
+                    ola_dec4(wq[q], ra, d);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[t][4 * q + e] = d[e];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cl = (int)min((int64_t)m0 + 4 * q, ld_a - 4);
+                    const float4 v = *reinterpret_cast<const float4*>((const float*)a_ + arow[t] + cl);
+                    av[t][4 * q] = v.x; av[t][4 * q + 1] = v.y; av[t][4 * q + 2] = v.z; av[t][4 * q + 3] = v.w;
+                }
+            }
+        }
+        float bv[VL][NT];
+#pragma unroll
+        for (int j = 0; j < VL; ++j)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                // frames past the end only ever meet a zeroed operand: clamped, not branched
+                const int64_t idx = min((int64_t)(m0 + j) * S + 16 * u + li, T - 1);
+                bv[j][u] = sn[idx];
+            }
+#pragma unroll
+        for (int j = 0; j < VL; ++j) {
+            const bool ok = m0 + j < mend;
+#pragma unroll
+            for (int t = 0; t < TC; ++t) {
+                const float x = ok ? av[t][j] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, bv[j][u], acc[t][u], 0, 0, 0);
+            }
+        }
+    }
+    // the four waves' tiles meet in LDS; register r of lane (li, lk) is (channel 4 lk + r, tap li) of its 16 x 16 tile
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(t * NT + u) * 4 + r][lane] = acc[t][u][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < TC * NT * 4 * 64; e += 256) {
+        const int q = e >> 6, l = e & 63;
+        const float v = (red[0][q][l] + red[1][q][l]) + (red[2][q][l] + red[3][q][l]);
+        const int t = q / (NT * 4), u = (q / 4) % NT, r = q & 3;
+        const int c = c0 + 16 * t + 4 * (l >> 4) + r;
+        if (c < C) atomicAdd(&gw[(int64_t)c * K + 16 * u + (l & 15)], v);
     }
 }
 
@@ -380,4 +478,53 @@ extern "C" int fqss_ola_convtr_fwd_q(const uint8_t* xc, const float* qmin, const
 extern "C" int fqss_ola_convtr_mul_fwd(const float* mask, const float* feat, const float* w, float* out, int N, int NS, int C, int M,
                                        int64_t ld_m, int64_t ld_f, int K, int stride, int64_t T, fqss_stream_t stream) {
     return ola_convtr_impl("fqss_ola_convtr_mul_fwd", 2, mask, feat, w, out, N, C, M, ld_m, ld_f, NS, K, stride, T, nullptr, nullptr, stream);
+}
+
+// Ci = 1 forms of fqss_frames_wgrad: a fp32 (coded = 0) or u8 codes; returns false when the shape is not served
+static bool frames_wgrad1_launch(int coded, const void* a, const float* sig, float* gw, int N, int C, int M, int64_t ld_a, int64_t T, int K,
+                                 int stride, const float* qmin, const float* qmax, hipStream_t s) {
+    const bool k16 = K == 16 && stride == 8, k32 = K == 32 && stride == 16;
+    if (!(k16 || k32) || T < 1 || N > 65535) return false;
+    if (coded ? !(aligned16(a) && ld_a % 16 == 0 && ld_a >= 16) : !(aligned16(a) && ld_a % 4 == 0 && ld_a >= 4)) return false;
+    const int fi4 = 4 * 4 * (coded ? 16 : 8);      // frames per workgroup step
+    const int64_t gx = cdiv(C, 64);
+    // >= 512 workgroups (two waves per SIMD): split the frame range when N x channel groups is small; the partial sums meet in the atomics
+    int msplit = (int)cdiv(512, (int64_t)N * gx);
+    if (msplit < 1) msplit = 1;
+    if (msplit > 16) msplit = 16;
+    int mchunk = (int)(cdiv(cdiv(M, msplit), fi4) * fi4);
+    msplit = (int)cdiv(M, mchunk);
+    dim3 grid((unsigned)gx, (unsigned)N, (unsigned)msplit);
+#define FQSS_FW1(K_, S_, CD_) \
+    hipLaunchKernelGGL((k_frames_wgrad_mfma<K_, S_, CD_>), grid, dim3(256), 0, s, a, sig, gw, C, M, ld_a, T, mchunk, qmin, qmax)
+    if (k16) { if (coded) FQSS_FW1(16, 8, true); else FQSS_FW1(16, 8, false); }
+    else     { if (coded) FQSS_FW1(32, 16, true); else FQSS_FW1(32, 16, false); }
+#undef FQSS_FW1
+    return true;
+}
+
+extern "C" int fqss_frames_wgrad1(const float* a, const float* sig, float* gw, int N, int C, int M, int64_t ld_a, int64_t T, int K,
+                                  int stride, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && sig && gw, "null tensor");
+    FQSS_REQUIRE(N >= 0 && C > 0 && M >= 0 && ld_a >= M && K > 0 && stride > 0, "bad shape");
+    FQSS_REQUIRE(M == 0 || (int64_t)(M - 1) * stride + K <= T, "frames exceed the signal");
+    if (M == 0 || N == 0) return FQSS_OK;
+    if (!frames_wgrad1_launch(0, a, sig, gw, N, C, M, ld_a, T, K, stride, nullptr, nullptr, (hipStream_t)stream)) {
+        set_error("fqss_frames_wgrad1: needs (K, stride) in {(16, 8), (32, 16)} and 16-B aligned rows");
+        return FQSS_EINVAL;
+    }
+    return launch_status("fqss_frames_wgrad1");
+}
+
+extern "C" int fqss_frames_wgrad1_q(const uint8_t* ac, const float* qmin, const float* qmax, const float* sig, float* gw, int N, int C,
+                                    int M, int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream) {
+    FQSS_REQUIRE(ac && qmin && qmax && sig && gw, "null tensor");
+    FQSS_REQUIRE(N >= 0 && C > 0 && M >= 0 && ld_a >= M && K > 0 && stride > 0, "bad shape");
+    FQSS_REQUIRE(M == 0 || (int64_t)(M - 1) * stride + K <= T, "frames exceed the signal");
+    if (M == 0 || N == 0) return FQSS_OK;
+    if (!frames_wgrad1_launch(1, ac, sig, gw, N, C, M, ld_a, T, K, stride, qmin, qmax, (hipStream_t)stream)) {
+        set_error("fqss_frames_wgrad1_q: needs (K, stride) in {(16, 8), (32, 16)} and 16-B aligned code rows");
+        return FQSS_EINVAL;
+    }
+    return launch_status("fqss_frames_wgrad1_q");
 }

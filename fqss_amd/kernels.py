@@ -1,5 +1,7 @@
 """Thin torch-tensor front end of the C ABI: shape/stride checks on the host, then one ctypes
 call per kernel on torch's current HIP stream.  No arithmetic happens in this file."""
+import os
+
 import torch
 
 from . import _lib
@@ -732,7 +734,26 @@ def frames_wgrad(a, x, gw, stride):
     _, Ci, T = x.shape
     K = gw.shape[-1]
     assert gw.is_contiguous() and gw.numel() == C * Ci * K
+    if Ci == 1 and _frames_wgrad1_ok(x, T, K, stride) and ld_a % 4 == 0 and a.data_ptr() % 16 == 0:
+        _lib.call("fqss_frames_wgrad1", _p(a), _p(x), _p(gw), N, C, M, ld_a, T, K, stride, _stream())
+        return
     _lib.call("fqss_frames_wgrad", _p(a), _p(x), _p(gw), N, C, Ci, M, ld_a, T, K, stride, _stream())
+
+
+def _frames_wgrad1_ok(sig, T, K, stride):
+    return (K, stride) in ((16, 8), (32, 16)) and os.environ.get("FQSS_FRAMES_WGRAD1", "1") != "0"
+
+
+def frames_wgrad1_q(ac, qmin, qmax, sig, gw, stride):
+    """gw[C][1][K] += sum_{n,m} dec(ac)[n][c][m] * sig[n][0][m*stride+k]; False when the shape is not served (caller decodes)"""
+    N, C, M, ld_a = _codes3(ac)
+    sig = sig.contiguous()
+    T = sig.shape[-1]
+    K = gw.shape[-1]
+    if not (_frames_wgrad1_ok(sig, T, K, stride) and sig.numel() == N * T and gw.is_contiguous() and gw.numel() == C * K):
+        return False
+    _lib.call("fqss_frames_wgrad1_q", _p(ac), _p(qmin), _p(qmax), _p(sig), _p(gw), N, C, M, ld_a, T, K, stride, _stream())
+    return True
 
 
 # ------------------------------------------------------------------ K15 / K16

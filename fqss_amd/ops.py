@@ -472,9 +472,12 @@ class LinearActQ(Function):
             if ctx.xq is not None:
                 K.qpw_bwd_w(gz, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
             else:
-                if x is None:        # coded decoder input: its values are needed once more, for dL/dW
-                    x = K.decode(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax)
-                _lin_bwd_w(L, gz, x, gw)
+                if x is None and K.frames_wgrad1_q(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax, gz, gw, L.stride):
+                    pass             # coded decoder input: dL/dW straight from the codes
+                else:
+                    if x is None:
+                        x = K.decode(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax)
+                    _lin_bwd_w(L, gz, x, gw)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
             if gwq is not None:

@@ -379,6 +379,13 @@ int fqss_ola_convtr_mul_fwd(const float* mask, const float* feat, const float* w
 /* gw[c][ci][k] += sum_{n,m} a[n][c][m] * x[n][ci][m*stride+k]    (a: [N][C][M] ld_a; x dense) */
 int fqss_frames_wgrad(const float* a, const float* x, float* gw, int N, int C, int Ci, int M,
                       int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream);
+/* the Ci = 1 case (residual encoder Conv1d(1, C, K, stride); the mono decoder's weight gradient with a = its input, sig = dL/dout)
+ * as a dedicated fp32-MFMA kernel: gw[c][k] += sum_{n,m} a[n][c][m] * sig[n][m*stride + k]; (K, stride) in {(16, 8), (32, 16)}, rows
+ * of a 16-B aligned (FQSS_EINVAL otherwise: callers fall back to fqss_frames_wgrad).  _q: a as u8 codes (qmin, qmax). */
+int fqss_frames_wgrad1(const float* a, const float* sig, float* gw, int N, int C, int M, int64_t ld_a, int64_t T, int K,
+                       int stride, fqss_stream_t stream);
+int fqss_frames_wgrad1_q(const uint8_t* ac, const float* qmin, const float* qmax, const float* sig, float* gw, int N, int C,
+                         int M, int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K15  SDR-weighted KD loss with 2-speaker PIT, forward + backward in one call

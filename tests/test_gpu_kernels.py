@@ -1,5 +1,7 @@
 """GPU parity of every linear/streaming kernel behind the C ABI against torch fp32 on the CPU
 (the same ATen ops the reference calls).  Tolerances are fp32 summation-order noise (gate G1)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -167,6 +169,15 @@ def test_ola_convtr(N, C, M, K_, S):
     xc = K.empty_codes((N, C, M), "cuda")
     xc.copy_(codes)
     assert torch.equal(K.ola_convtr_fwd_q(xc, lo, hi, w.cuda(), S), K.ola_convtr_fwd(K.decode(xc, lo, hi), w.cuda(), S))
+    # ... and its weight gradient straight from the codes against the generic GEMM on the decoded operand
+    gw_q, gw_r = torch.zeros(C, 1, K_, device="cuda"), torch.zeros(C, 1, K_, device="cuda")
+    assert K.frames_wgrad1_q(xc, lo, hi, g.cuda(), gw_q, S)
+    os.environ["FQSS_FRAMES_WGRAD1"] = "0"
+    try:
+        K.frames_wgrad(K.decode(xc, lo, hi), g.cuda(), gw_r, S)
+    finally:
+        del os.environ["FQSS_FRAMES_WGRAD1"]
+    close(gw_q, gw_r, rtol=1e-4, atol=1e-5 * float(gw_r.abs().max()) + 1e-5)
     if N % 2 == 0:
         mask, feat = padded(rnd(N // 2, 2, C, M, seed=5)), padded(rnd(N // 2, C, M, seed=6))
         ref = K.ola_convtr_fwd(K.mul_bcast_fwd(mask, feat).reshape(N, C, M), w.cuda(), S)

@@ -102,6 +102,8 @@ case("frames_conv_fwd (decoder dgrad) 1->512", 8 * MBh, lambda: (torch.randn(2 *
 gw_dec = torch.zeros(NH, 1, 16, device=dev)
 case("frames_wgrad (decoder) a fp32", 8 * MBh, lambda: (act2(), torch.randn(2 * B, 1, 32000, device=dev)),
      lambda s: K.frames_wgrad(s[0], s[1], gw_dec, 8))
+case("frames_wgrad1_q (decoder) a codes", 2 * MBh, lambda: (codes2(), torch.randn(2 * B, 1, 32000, device=dev)),
+     lambda s: K.frames_wgrad1_q(s[0], lo, hi, s[1], gw_dec, 8))
 case("axpby C=128", 12 * MBb, lambda: (act(NB), act(NB)), lambda s: K.axpby(s[0], s[1], 1.0))
 
 
