@@ -69,6 +69,7 @@ _PROTOS = {
     "fqss_splitter2": [P, P, I32, I64, P, P],
     "fqss_splitter2_raw": [P, P, I32, I64, P, P],
     "fqss_frames_conv_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I32, I64, P],
+    "fqss_frames_conv_add_fwd": [P, P, P, I64, P, I32, I32, I32, I64, I32, I32, I32, I64, P],
     "fqss_ola_convtr_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I64, P],
     "fqss_frames_wgrad1": [P, P, P, I32, I32, I32, I64, I64, I32, I32, P],
     "fqss_frames_wgrad1_q": [P, P, P, P, P, I32, I32, I32, I64, I64, I32, I32, P],

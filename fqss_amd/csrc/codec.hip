@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_splitter2_raw(const float* __restrict__
 template <int CI, int K>
 __global__ __launch_bounds__(256) void k_frames_conv_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ z, int Co, int64_t T, int stride, int M,
-                                                          int64_t ld_z) {
+                                                          int64_t ld_z, const float* __restrict__ add, int64_t ld_add) {
     constexpr int CK = CI * K;
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -78,16 +78,106 @@ __global__ __launch_bounds__(256) void k_frames_conv_fwd(const float* __restrict
         float acc = 0.0f;
 #pragma unroll
         for (int j = 0; j < CK; ++j) acc = fmaf(xr[j], wr[j], acc);
-        if (m < M) z[((int64_t)n * Co + co) * ld_z + m] = acc;
+        if (m < M) {
+            // + the other gradient of a two-consumer tensor (the decoder input also feeds the residual block): no separate sum pass
+            if (add != nullptr) acc += add[((int64_t)n * Co + co) * ld_add + m];
+            z[((int64_t)n * Co + co) * ld_z + m] = acc;
+        }
+    }
+}
+
+// The same with FOUR frames per lane (a workgroup covers 256 frames x all Co): the output row -- and the optional addend row -- move
+// 16 B per lane (1-KB runs per row instead of 256 B), the taps come from LDS (staged once per workgroup) instead of one scalar-memory
+// round trip per output channel.  Same j-ordered fmaf chain per output: bit-identical to k_frames_conv_fwd.
+template <int CI, int K, int S>
+__global__ __launch_bounds__(256) void k_frames_conv4(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ z, int Co, int64_t T, int M, int64_t ld_z,
+                                                       const float* __restrict__ add, int64_t ld_add, int co_tile) {
+    constexpr int CK = CI * K, SW = 3 * S + K;
+    static_assert(SW % 4 == 0 && CK % 4 == 0, "whole float4s");
+    extern __shared__ __attribute__((aligned(16))) float Wl[];     // [co_tile][CK]: the taps of co_tile output channels at a time (<= 48 KB)
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = (blockIdx.x * 64 + lane) * 4;
+    const bool live = m0 < M;
+    const int mld = live ? m0 : 0;
+    float xr[CI][SW];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const float* xp = x + ((int64_t)n * CI + ci) * T;
+#pragma unroll
+        for (int j = 0; j < SW / 4; ++j) {
+            // groups past the end of the signal belong to frames >= M, whose results are not stored: clamped, not branched
+            const int64_t idx = min((int64_t)mld * S + 4 * j, T - 4);
+            const float4 t = *reinterpret_cast<const float4*>(xp + idx);
+            xr[ci][4 * j] = t.x; xr[ci][4 * j + 1] = t.y; xr[ci][4 * j + 2] = t.z; xr[ci][4 * j + 3] = t.w;
+        }
+    }
+    constexpr int PF = 8;      // output channels per group: the addend rows of a group are requested before its FMAs start
+    const int ct = co_tile < 0 ? Co : co_tile;
+    for (int cb = 0; cb < Co; cb += ct) {
+        const int ce = min(Co, cb + ct);
+        if (co_tile > 0) {
+        if (cb > 0) __syncthreads();       // every wave is done with the previous tile's taps
+        for (int i = threadIdx.x; i < (ce - cb) * CK; i += 256) Wl[i] = w[(int64_t)cb * CK + i];
+        __syncthreads();
+        }
+        for (int cg = cb + wave; cg < ce; cg += 4 * PF) {
+            float4 a4[PF];
+            if (add != nullptr) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const int64_t row = (int64_t)n * Co + min(cg + 4 * i, ce - 1);
+                    a4[i] = *reinterpret_cast<const float4*>(add + row * ld_add + mld);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int co = cg + 4 * i;
+                if (co >= ce) break;       // wave-uniform
+                float wk[CK];
+                if (co_tile < 0) {           // taps straight from memory (wave-uniform): the A/B form
+                    const float* wr = w + (int64_t)co * CK;
+#pragma unroll
+                    for (int j = 0; j < CK; ++j) wk[j] = wr[j];
+                } else {
+#pragma unroll
+                for (int j4 = 0; j4 < CK / 4; ++j4) {
+                    const float4 t = *reinterpret_cast<const float4*>(&Wl[(co - cb) * CK + 4 * j4]);
+                    wk[4 * j4] = t.x; wk[4 * j4 + 1] = t.y; wk[4 * j4 + 2] = t.z; wk[4 * j4 + 3] = t.w;
+                }
+                }
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) acc[f] = fmaf(xr[ci][f * S + k], wk[ci * K + k], acc[f]);
+                if (live) {
+                    const int64_t row = (int64_t)n * Co + co;
+                    if (add != nullptr) {
+                        acc[0] += a4[i].x; acc[1] += a4[i].y; acc[2] += a4[i].z; acc[3] += a4[i].w;
+                    }
+                    *reinterpret_cast<float4*>(z + row * ld_z + m0) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // row padding absorbs m0 + 3 >= M
+                }
+            }
+        }
     }
 }
 
 // out[n][t] = sum_c sum_{m*S+k=t} x[n][c][m] * w[c][k] ; R = K/S frames overlap on every output slot.
 // A block owns FB = 64-(R-1) output slots (S samples each); its 64 lanes hold the 64 frames that
 // touch them; the 4 waves split the channel reduction; partial P[k][frame] go through LDS.
-template <int K, int S>
-__global__ __launch_bounds__(256) void k_ola_convtr_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ out, int C, int M, int64_t ld_x, int64_t T) {
+// MODE 0: fp32 x; 1: x as u8 codes of a per-tensor quantizer, de-quantised on load (delta * c + min in two roundings, like
+// fqss_decode: the student's MulQ / residual outputs never exist in fp32); 2: fp32 mask[n][c][m] * feat[n / NS][c][m] formed on load
+// (the float teacher's masking product).  Same sums as decode / product followed by the MODE 0 kernel, bit for bit.
+template <int K, int S, int MODE>
+__global__ __launch_bounds__(256) void k_ola_convtr_fwd(const void* __restrict__ x_, const float* __restrict__ feat,
+                                                         const float* __restrict__ w, float* __restrict__ out, int C, int M,
+                                                         int64_t ld_x, int64_t ld_f, int NS, int64_t T, const float* qmin,
+                                                         const float* qmax) {
     constexpr int R = K / S;
     constexpr int FB = 64 - (R - 1);
     constexpr int PL = 65;  // padded frame dimension
@@ -98,12 +188,21 @@ __global__ __launch_bounds__(256) void k_ola_convtr_fwd(const float* __restrict_
     const int q0 = blockIdx.x * FB;      // first output slot of this block
     const int m = q0 - (R - 1) + lane;   // frame held by this lane
     const bool mv = (m >= 0) && (m < M);
+    const int mc = mv ? m : 0;           // a readable position of the row (its value is dropped)
+    QRange rx{0.f, 1.f, 1.f};
+    if (MODE == 1) rx = load_qrange(qmin, qmax);
     float acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-    const float* xn = x + (int64_t)n * C * ld_x;
+    const float* xf = (const float*)x_ + (int64_t)n * C * ld_x + mc;
+    const uint8_t* xc = (const uint8_t*)x_ + (int64_t)n * C * ld_x + mc;
+    const float* ff = (MODE == 2) ? feat + (int64_t)(n / NS) * C * ld_f + mc : nullptr;
     for (int c = wave; c < C; c += 4) {
-        const float xv = mv ? xn[(int64_t)c * ld_x + m] : 0.0f;
+        float xv;
+        if (MODE == 1) xv = rx.delta * (float)xc[(int64_t)c * ld_x] + rx.lo;
+        else if (MODE == 2) xv = xf[(int64_t)c * ld_x] * ff[(int64_t)c * ld_f];
+        else xv = xf[(int64_t)c * ld_x];
+        xv = mv ? xv : 0.0f;
         const float* wr = w + (int64_t)c * K;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[k] = fmaf(xv, wr[k], acc[k]);
@@ -137,138 +236,6 @@ __device__ __forceinline__ void ola_dec4(unsigned int w, const QRange& r, float 
     v[2] = r.delta * (float)((w >> 16) & 255u) + r.lo;
     v[3] = r.delta * (float)(w >> 24) + r.lo;
 }
-
-// The same transposed conv + overlap-add with FOUR frames per lane (a workgroup covers 256 frames, 252 output slots): the operand
-// row is read 16 B (or 4 codes) per lane instead of 4 B, and it may arrive as
-//   MODE 0  fp32 values,
-//   MODE 1  u8 codes of a per-tensor quantizer (de-quantised on load: the student's MulQ / residual outputs never exist in fp32),
-//   MODE 2  fp32 mask[n][c][m] * fp32 feat[n / NS][c][m] (the float teacher's masking product, formed on load).
-// Same summation order as k_ola_convtr_fwd (a wave takes the channels c = wave, wave + 4, ...; partials added r-major, wave-minor):
-// bit-identical results.  The first form spent 58-92 us on 131 MB (16 FMAs per 4-B load, 63 frames per workgroup).
-template <int K, int S, int MODE>
-__global__ __launch_bounds__(256) void k_ola_convtr4(const void* __restrict__ xv_, const float* __restrict__ feat,
-                                                      const float* __restrict__ w, float* __restrict__ out, int C, int M,
-                                                      int64_t ld_x, int64_t ld_f, int NS, int64_t T, const float* qmin,
-                                                      const float* qmax) {
-    constexpr int R = K / S;
-    static_assert(R >= 1 && R <= 4, "at most 4 overlapping frames");
-    constexpr int NF = 256, FB = NF - 4, PL = NF + 4;   // frames / output slots per workgroup; padded row of partials (16-B aligned)
-    extern __shared__ __attribute__((aligned(16))) float P_[];        // [4][K][PL]
-    const int n = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q0 = blockIdx.x * FB;          // first output slot of this workgroup
-    const int m0 = q0 - 4 + 4 * lane;        // this lane's frames m0 .. m0 + 3 (a multiple of 4: aligned vector loads)
-    const bool in_row = m0 >= 0 && m0 < M;   // rows are padded to 16 elements, so the whole group is readable
-    bool fv[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) fv[f] = in_row && (m0 + f < M);
-    QRange rx{0.f, 1.f, 1.f};
-    if (MODE == 1) rx = load_qrange(qmin, qmax);
-    float acc[4][K];
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[f][k] = 0.0f;
-    const int mld = in_row ? m0 : 0;
-    const float* xf = (const float*)xv_ + (int64_t)n * C * ld_x + mld;
-    const uint8_t* xc = (const uint8_t*)xv_ + (int64_t)n * C * ld_x + mld;
-    const float* ff = (MODE == 2) ? feat + (int64_t)(n / NS) * C * ld_f + mld : nullptr;
-    // the taps [C][K] are staged in LDS once per workgroup (the partial-sum buffer, not yet in use, lends the space): per channel a
-    // wave reads them as K/4 broadcast ds_read_b128 instead of one scalar-memory round trip
-    const bool w_lds = (int64_t)C * K <= (int64_t)4 * K * PL;
-    if (w_lds) {
-        for (int i = threadIdx.x; i < C * K; i += 256) P_[i] = w[i];
-        __syncthreads();
-    }
-    // One wave per SIMD at the decoder's sizes (N x ceil(M / 252) x 4 waves = 1,024): nothing else hides a load's latency, so the
-    // operand rows go through a two-deep software pipeline of PF channels each, raw (no conversion before the data is needed).
-    constexpr int PF = 8;
-    struct Raw {
-        float4 a, b;
-        unsigned int c;
-    };
-    auto issue = [&](int g, Raw (&r)[PF]) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int c = min(wave + 4 * (g * PF + i), C - 1);     // clamped: a few redundant loads instead of a branch around a load
-            if (MODE == 1) {
-                r[i].c = *reinterpret_cast<const unsigned int*>(xc + (int64_t)c * ld_x);
-            } else {
-                r[i].a = *reinterpret_cast<const float4*>(xf + (int64_t)c * ld_x);
-                if (MODE == 2) r[i].b = *reinterpret_cast<const float4*>(ff + (int64_t)c * ld_f);
-            }
-        }
-    };
-    auto consume = [&](int g, const Raw (&r)[PF]) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int c = wave + 4 * (g * PF + i);
-            if (c >= C) break;     // wave-uniform
-            float v[4];
-            if (MODE == 1) {
-                ola_dec4(r[i].c, rx, v);
-            } else {
-                v[0] = r[i].a.x; v[1] = r[i].a.y; v[2] = r[i].a.z; v[3] = r[i].a.w;
-                if (MODE == 2) {
-                    v[0] *= r[i].b.x; v[1] *= r[i].b.y; v[2] *= r[i].b.z; v[3] *= r[i].b.w;
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < 4; ++f) v[f] = fv[f] ? v[f] : 0.0f;
-            float wk[K];
-            if (w_lds) {
-#pragma unroll
-                for (int k4 = 0; k4 < K / 4; ++k4) {
-                    const float4 t = *reinterpret_cast<const float4*>(&P_[c * K + 4 * k4]);
-                    wk[4 * k4] = t.x; wk[4 * k4 + 1] = t.y; wk[4 * k4 + 2] = t.z; wk[4 * k4 + 3] = t.w;
-                }
-            } else {
-                const float* wr = w + (int64_t)c * K;  // wave-uniform
-#pragma unroll
-                for (int k = 0; k < K; ++k) wk[k] = wr[k];
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[f][k] = fmaf(v[f], wk[k], acc[f][k]);
-        }
-    };
-    const int nch = (C - wave + 3) / 4;              // channels of this wave
-    const int ng = (nch + PF - 1) / PF;
-    {
-        Raw ra[PF], rb[PF];
-        issue(0, ra);
-        for (int g = 0; g < ng; g += 2) {
-            issue(g + 1, rb);
-            consume(g, ra);
-            issue(g + 2, ra);
-            consume(g + 1, rb);
-        }
-    }
-    if (w_lds) __syncthreads();      // every wave is done with the taps before the partial sums overwrite them
-    float* P = P_ + (int64_t)wave * K * PL;
-#pragma unroll
-    for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(&P[k * PL + 4 * lane]) = make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
-    __syncthreads();
-    const int nslots = M + R - 1;
-    for (int e = threadIdx.x; e < FB * S; e += 256) {
-        const int ql = e / S, j = e - ql * S;
-        const int q = q0 + ql;
-        if (q < nslots) {
-            float v = 0.0f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int fl = ql + 4 - r;       // local index of frame q - r
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) v += P_[((int64_t)wv * K + r * S + j) * PL + fl];
-            }
-            const int64_t t = (int64_t)q * S + j;
-            if (t < T) out[(int64_t)n * T + t] = v;
-        }
-    }
-}
-
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
@@ -392,15 +359,38 @@ extern "C" int fqss_splitter2_raw(const float* x, float* out, int B, int64_t T, 
     return launch_status("fqss_splitter2_raw");
 }
 
-extern "C" int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci, int Co, int64_t T, int K,
-                                    int stride, int M, int64_t ld_z, fqss_stream_t stream) {
+static int frames_conv_impl(const char* who, const float* x, const float* w, float* z, int N, int Ci, int Co, int64_t T, int K,
+                            int stride, int M, int64_t ld_z, const float* add, int64_t ld_add, fqss_stream_t stream) {
     FQSS_REQUIRE(x && w && z, "null tensor");
     FQSS_REQUIRE(N >= 0 && N <= 65535 && Ci > 0 && Co > 0 && K > 0 && stride > 0 && M >= 0 && ld_z >= M, "bad shape");
     FQSS_REQUIRE(M == 0 || (int64_t)(M - 1) * stride + K <= T, "frames exceed the signal");
+    FQSS_REQUIRE(!add || ld_add >= M, "bad addend rows");
     if (N == 0 || M == 0) return FQSS_OK;
-    dim3 grid((unsigned)cdiv(M, 64), (unsigned)N), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define FQSS_FC(CI_, K_) hipLaunchKernelGGL((k_frames_conv_fwd<CI_, K_>), grid, block, 0, s, x, w, z, Co, T, stride, M, ld_z)
+    {   // four frames per lane: vector-aligned rows with readable / writable padding, dense 16-B aligned signals
+        // A/B switch, bit (Ci - 1)
+        static const int wide_ci = [] { const char* e = getenv("FQSS_FRAMES_WIDE"); return e ? atoi(e) : 3; }();
+        const bool wide_on = Ci <= 2 && ((wide_ci >> (Ci - 1)) & 1);
+        const int64_t m4 = (M + 3) & ~(int64_t)3;
+        const bool k16 = K == 16 && stride == 8, k32 = K == 32 && stride == 16;
+        int co_tile = (int)((48 * 1024) / ((size_t)Ci * K * sizeof(float))) & ~3;      // output channels whose taps fit 48 KB of LDS
+        if (co_tile > Co) co_tile = (Co + 3) & ~3;
+        size_t lds = (size_t)co_tile * Ci * K * sizeof(float);
+        static const int taps_lds = [] { const char* e = getenv("FQSS_TAPS_LDS"); return e ? atoi(e) : 1; }();   // A/B switch
+        if (!taps_lds) { co_tile = -1; lds = 0; }       // taps by wave-uniform loads from memory       // taps from memory (see k_ola_convtr4); the LDS form only for experiments
+        if (wide_on && (k16 || k32) && (Ci == 1 || Ci == 2) && aligned16(x) && T % 4 == 0 && T >= 4 && aligned16(z) && ld_z % 4 == 0 &&
+            ld_z >= m4 && (!add || (aligned16(add) && ld_add % 4 == 0 && ld_add >= m4))) {
+            dim3 grid4((unsigned)cdiv(M, 256), (unsigned)N);
+#define FQSS_FC4(CI_, K_, S_) \
+    hipLaunchKernelGGL((k_frames_conv4<CI_, K_, S_>), grid4, dim3(256), lds, s, x, w, z, Co, T, M, ld_z, add, ld_add, co_tile)
+            if (k16) { if (Ci == 1) FQSS_FC4(1, 16, 8); else FQSS_FC4(2, 16, 8); }
+            else     { if (Ci == 1) FQSS_FC4(1, 32, 16); else FQSS_FC4(2, 32, 16); }
+#undef FQSS_FC4
+            return launch_status(who);
+        }
+    }
+    dim3 grid((unsigned)cdiv(M, 64), (unsigned)N), block(256);
+#define FQSS_FC(CI_, K_) hipLaunchKernelGGL((k_frames_conv_fwd<CI_, K_>), grid, block, 0, s, x, w, z, Co, T, stride, M, ld_z, add, ld_add)
     if (Ci == 1 && K == 16) FQSS_FC(1, 16);
     else if (Ci == 2 && K == 16) FQSS_FC(2, 16);
     else if (Ci == 1 && K == 32) FQSS_FC(1, 32);
@@ -408,11 +398,22 @@ extern "C" int fqss_frames_conv_fwd(const float* x, const float* w, float* z, in
     else if (Ci == 1 && K == 2) FQSS_FC(1, 2);      // DPTNet encoder: 2-sample window, hop 1 (dptnetq.py:116)
     else if (Ci == 2 && K == 2) FQSS_FC(2, 2);
     else {
-        set_error("fqss_frames_conv_fwd: unsupported (Ci=%d, K=%d); built for Ci in {1,2}, K in {2,16,32}", Ci, K);
+        set_error("%s: unsupported (Ci=%d, K=%d); built for Ci in {1,2}, K in {2,16,32}", who, Ci, K);
         return FQSS_EINVAL;
     }
 #undef FQSS_FC
-    return launch_status("fqss_frames_conv_fwd");
+    return launch_status(who);
+}
+
+extern "C" int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci, int Co, int64_t T, int K,
+                                    int stride, int M, int64_t ld_z, fqss_stream_t stream) {
+    return frames_conv_impl("fqss_frames_conv_fwd", x, w, z, N, Ci, Co, T, K, stride, M, ld_z, nullptr, 0, stream);
+}
+
+extern "C" int fqss_frames_conv_add_fwd(const float* x, const float* w, const float* add, int64_t ld_add, float* z, int N, int Ci, int Co,
+                                        int64_t T, int K, int stride, int M, int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(add, "null addend");
+    return frames_conv_impl("fqss_frames_conv_add_fwd", x, w, z, N, Ci, Co, T, K, stride, M, ld_z, add, ld_add, stream);
 }
 
 // mode 0: fp32 x; 1: u8 codes x + (qmin, qmax); 2: fp32 x * feat[n / NS]
@@ -422,46 +423,26 @@ static int ola_convtr_impl(const char* who, int mode, const void* x, const float
     FQSS_REQUIRE(x && w && out, "null tensor");
     FQSS_REQUIRE(N >= 0 && N <= 65535 && C > 0 && M >= 0 && ld_x >= M && K > 0 && stride > 0, "bad shape");
     FQSS_REQUIRE(M == 0 || T == (int64_t)(M - 1) * stride + K, "T must equal (M-1)*stride + K");
-    FQSS_REQUIRE(mode != 1 || (qmin && qmax && (aligned16(x) && ld_x % 16 == 0)), "coded operand: ranges + 16-B aligned code rows");
+    FQSS_REQUIRE(mode != 1 || (qmin && qmax), "coded operand needs its ranges");
     FQSS_REQUIRE(mode != 2 || (feat && NS >= 1 && N % NS == 0 && ld_f >= M), "masking form: feat [N / NS][C][M]");
     if (N == 0 || M == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool k16 = K == 16 && stride == 8, k32 = K == 32 && stride == 16;
-    // the 4-frames-per-lane form needs vector-aligned rows whose padding is readable (activation rows: ld a multiple of 4 >= M rounded up)
-    const int64_t m4 = (M + 3) & ~(int64_t)3;
-    static const bool wide_on = [] { const char* e = getenv("FQSS_OLA_WIDE"); return !(e && e[0] == '0'); }();   // A/B switch (fp32 operand only)
-    bool wide = (k16 || k32) && ld_x >= m4 && (wide_on || mode != 0);
-    if (mode != 1) wide = wide && aligned16(x) && ld_x % 4 == 0;
-    if (mode == 2) wide = wide && aligned16(feat) && ld_f % 4 == 0 && ld_f >= m4;
-    if (wide) {
-        dim3 grid((unsigned)cdiv((int64_t)M + K / stride - 1, 252), (unsigned)N);
-        const size_t lds = (size_t)4 * K * 260 * sizeof(float);
-#define FQSS_OLA4(K_, S_, MODE_)                                                                                                    \
-    hipLaunchKernelGGL((k_ola_convtr4<K_, S_, MODE_>), grid, dim3(256), lds, s, x, feat, w, out, C, M, ld_x, ld_f, NS > 0 ? NS : 1, T, \
-                       qmin, qmax)
-        if (k16) {
-            if (mode == 0) FQSS_OLA4(16, 8, 0); else if (mode == 1) FQSS_OLA4(16, 8, 1); else FQSS_OLA4(16, 8, 2);
-        } else {
-            if (mode == 0) FQSS_OLA4(32, 16, 0); else if (mode == 1) FQSS_OLA4(32, 16, 1); else FQSS_OLA4(32, 16, 2);
-        }
-#undef FQSS_OLA4
-        return launch_status(who);
-    }
-    FQSS_REQUIRE(mode == 0, "coded / masking operands need 16-B aligned rows and a (16, 8) or (32, 16) window");
-    const float* xf = (const float*)x;
-    if (k16) {
-        dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
-        hipLaunchKernelGGL((k_ola_convtr_fwd<16, 8>), grid, dim3(256), 0, s, xf, w, out, C, M, ld_x, T);
-    } else if (k32) {
-        dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
-        hipLaunchKernelGGL((k_ola_convtr_fwd<32, 16>), grid, dim3(256), 0, s, xf, w, out, C, M, ld_x, T);
-    } else if (K == 2 && stride == 1) {   // DPTNet's 2-sample window, hop 1 (input gradient of its encoder)
-        dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
-        hipLaunchKernelGGL((k_ola_convtr_fwd<2, 1>), grid, dim3(256), 0, s, xf, w, out, C, M, ld_x, T);
-    } else {
+    dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
+    if (NS < 1) NS = 1;
+#define FQSS_OLA(K_, S_)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (mode == 0) hipLaunchKernelGGL((k_ola_convtr_fwd<K_, S_, 0>), grid, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax); \
+        else if (mode == 1) hipLaunchKernelGGL((k_ola_convtr_fwd<K_, S_, 1>), grid, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax); \
+        else hipLaunchKernelGGL((k_ola_convtr_fwd<K_, S_, 2>), grid, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax); \
+    } while (0)
+    if (K == 16 && stride == 8) FQSS_OLA(16, 8);
+    else if (K == 32 && stride == 16) FQSS_OLA(32, 16);
+    else if (K == 2 && stride == 1) FQSS_OLA(2, 1);   // DPTNet's 2-sample window, hop 1 (input gradient of its encoder)
+    else {
         set_error("%s: unsupported (K=%d, stride=%d); built for (2,1), (16,8) and (32,16)", who, K, stride);
         return FQSS_EINVAL;
     }
+#undef FQSS_OLA
     return launch_status(who);
 }
 

@@ -118,9 +118,14 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     typedef unsigned short (*BsT)[TBK][TLDN];
     AsT As = reinterpret_cast<AsT>(smem);
     BsT Bs = reinterpret_cast<BsT>(smem + A_BYTES);
-    __shared__ float rowb[TBM];
-    __shared__ double red[2 * 4];
-    __shared__ float pms[2];
+    // The small per-workgroup arrays live INSIDE the tile buffer, which is idle when they are in use (pms: before the first tile is
+    // stored; rowb / red: in the epilogue, behind its 4 x 4,608-B staging tiles): as separate arrays they brought the PRO = 1 instance to
+    // 66,120 B of static LDS, and a kernel above 64 KB made LDS-resident data of kernels running on ANOTHER stream unreliable
+    // (tools/stress_streams.py; csrc/codec.hip k_ola_convtr4).  With them folded in every instance is <= 65,536 B.
+    float* rowb = reinterpret_cast<float*>(smem + 4 * 32 * TLDT * 4);                     // [TBM]
+    double* red = reinterpret_cast<double*>(smem + 4 * 32 * TLDT * 4 + TBM * 4);          // [2 * 4]
+    float* pms = reinterpret_cast<float*>(smem);                                          // [2]
+    static_assert(4 * 32 * TLDT * 4 + TBM * 4 + 64 <= A_BYTES + B_BYTES, "epilogue scratch fits the tile buffer");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: everything derived from it stays in SGPRs
@@ -131,7 +136,6 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     const int b = panel / g.tiles_n, i0 = mt * TBM, j0 = (panel % g.tiles_n) * TBN;
     const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 
-    if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
     if (PRO == 1) t_stats_finalize(g.pro_stats + (int64_t)b * kTSlots * kTSlotStride, g.pro_count, g.pro_eps, pms);
     else __syncthreads();
     const float pmean = (PRO == 1) ? pms[0] : 0.f, prstd = (PRO == 1) ? pms[1] : 1.f;
@@ -275,6 +279,9 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     // from here on: drain them before anything else is allocated there
     t_wait<0>(stA);
     t_wait<0>(stB);
+    // (every wave has passed the barrier behind the last tile's fragment reads: the tile buffer is free)
+    if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
+    __syncthreads();
 
     // epilogue: bias + act (+ residual), 16-B/lane row stores via an LDS staging tile, statistics.
     // Branch-free on purpose: with the activation and the output half selected per element through run-time branches

@@ -675,14 +675,20 @@ def splitter2(x, normalize=True):
     return out
 
 
-def frames_conv_fwd(x, w, stride):
-    """x [N,Ci,T] dense, w [Co,Ci,K] -> z [N,Co,M]"""
+def frames_conv_fwd(x, w, stride, add=None):
+    """x [N,Ci,T] dense, w [Co,Ci,K] -> z [N,Co,M] (+ add [N,Co,M])"""
     _need_gpu(x, w)
     x = x.contiguous()
     N, Ci, T = x.shape
     Co, _, K = w.shape
     M = (T - K) // stride + 1
     z = empty_act((N, Co, M), x.device)
+    if add is not None:
+        assert tuple(add.shape) == (N, Co, M)
+        add, _, _, ld_add = as_rowmat(add)
+        _lib.call("fqss_frames_conv_add_fwd", _p(x), _p(w.contiguous()), _p(add), ld_add, _p(z), N, Ci, Co, T, K, stride, M,
+                  rowmat(z)[2], _stream())
+        return z
     _lib.call("fqss_frames_conv_fwd", _p(x), _p(w.contiguous()), _p(z), N, Ci, Co, T, K, stride, M, rowmat(z)[2], _stream())
     return z
 
@@ -710,7 +716,7 @@ def ola_convtr_fwd_q(xc, qmin, qmax, w, stride):
 
 def ola_convtr_ok(w, stride):
     """window shapes the coded / masking forms of the decoder are built for"""
-    return (w.shape[-1], stride) in ((16, 8), (32, 16)) and (w.dim() == 2 or w.shape[1] == 1)
+    return (w.shape[-1], stride) in ((16, 8), (32, 16), (2, 1)) and (w.dim() == 2 or w.shape[1] == 1)
 
 
 def ola_convtr_mul_fwd(mask, feat, w, stride):

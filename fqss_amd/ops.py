@@ -432,7 +432,7 @@ class LinearActQ(Function):
                 and getattr(q.owner, "_fqss_deferred", False):
             ctx.prod = q.prod = _Producer(z, act, slope, L.slope_param, q, L.b_param, bias)
         ctx.x_shape = x.shape
-        ctx.fork = getattr(x, "_fqss_fork", None) if (ctx.wc is not None and ctx.wc.idxT is not None) else None
+        ctx.fork = getattr(x, "_fqss_fork", None) if ((ctx.wc is not None and ctx.wc.idxT is not None) or L.kind == "convtr") else None
         ctx.save_for_backward(None if ((ctx.xq is not None and ctx.wc is not None) or ctx.xq_tr is not None) else x, w,
                               None if ctx.plain else z, slope)
         ctx.L, ctx.act, ctx.q, ctx.has_bias = L, act, q, bias is not None
@@ -460,6 +460,9 @@ class LinearActQ(Function):
             fk = ctx.fork
             if ctx.wc is not None and fk is not None and fk.other is not None and tuple(fk.other.shape) == tuple(ctx.x_shape):
                 gx = K.qpw_bwd_x(gz, ctx.wc, add=fk.other)     # + the gradient of the fork's other branch: no separate sum pass
+                fk.fused = True
+            elif L.kind == "convtr" and fk is not None and fk.other is not None and tuple(fk.other.shape) == tuple(ctx.x_shape):
+                gx = K.frames_conv_fwd(gz, w.reshape(w.shape[0], 1, w.shape[2]), L.stride, add=fk.other)   # decoder: same, in its dgrad
                 fk.fused = True
             else:
                 gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)

@@ -364,6 +364,10 @@ int fqss_splitter2_raw(const float* x, float* out, int B, int64_t T, const uint3
 /* z[n][co][m] = sum_{ci,k} w[co][ci][k] * x[n][ci][m*stride+k]   (x: [N][Ci][T] dense)        */
 int fqss_frames_conv_fwd(const float* x, const float* w, float* z, int N, int Ci, int Co,
                          int64_t T, int K, int stride, int M, int64_t ld_z, fqss_stream_t stream);
+/* the same + add[n][co][m]: as the decoder's input gradient it sums in the gradient that the decoder input receives from its other
+ * consumer (ResidualErrorBlock's Y - Y_q, qat_layers.py:1193), which autograd would add in a pass of its own */
+int fqss_frames_conv_add_fwd(const float* x, const float* w, const float* add, int64_t ld_add, float* z, int N, int Ci,
+                             int Co, int64_t T, int K, int stride, int M, int64_t ld_z, fqss_stream_t stream);
 /* out[n][t] = sum_{c} sum_{m*stride+k=t} x[n][c][m] * w[c][k]   (w: [C][K], out: [N][T] dense) */
 int fqss_ola_convtr_fwd(const float* x, const float* w, float* out, int N, int C, int M,
                         int64_t ld_x, int K, int stride, int64_t T, fqss_stream_t stream);

@@ -99,6 +99,11 @@ case("mulq_bwd S=2 (+producer)", (2 + 1 + 8 + 8 + 8 + 4) * MBh, lambda: (codes2(
      lambda s: K.mulq_bwd(s[0], lo, hi, s[1], lo, hi, s[2], lo, hi, gacc, prod=(s[3], K.ACT_RELU, None, pga, None)))
 case("frames_conv_fwd (decoder dgrad) 1->512", 8 * MBh, lambda: (torch.randn(2 * B, 1, 32000, device=dev),),
      lambda s: K.frames_conv_fwd(s[0], w_dec.view(NH, 1, 16), 8))
+case("frames_conv_fwd + addend (decoder dgrad at the fork)", 12 * MBh, lambda: (torch.randn(2 * B, 1, 32000, device=dev), act2()),
+     lambda s: K.frames_conv_fwd(s[0], w_dec.view(NH, 1, 16), 8, add=s[1]))
+w_enc2 = torch.randn(NH, 2, 16, device=dev) * 0.1
+case("frames_conv_fwd encoder 2->512", 4 * MBh, lambda: (torch.randn(B, 2, 32000, device=dev),),
+     lambda s: K.frames_conv_fwd(s[0], w_enc2, 8))
 gw_dec = torch.zeros(NH, 1, 16, device=dev)
 case("frames_wgrad (decoder) a fp32", 8 * MBh, lambda: (act2(), torch.randn(2 * B, 1, 32000, device=dev)),
      lambda s: K.frames_wgrad(s[0], s[1], gw_dec, 8))
