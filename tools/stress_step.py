@@ -70,6 +70,32 @@ def main():
         ok = torch.equal(r["est"], est0) and abs(float(r["loss"]) - loss0) <= 1e-6 * abs(loss0)
         bad += 0 if ok else 1
     print({"workload": which, "rounds": rounds, "mismatching": bad})
+    if os.environ.get("BWD"):
+        # the BACKWARD next to a busy second stream (at world > 1 the gradient all-reduce runs beside it): gradients of a step whose
+        # whole duration is shadowed by teacher passes on another stream vs the quiet step; fp32 atomics set the noise floor
+        R.TEACHER_STREAM = False
+        g0 = None
+        floor = 0.0
+        for i in range(3):
+            step(x, tgt)
+            torch.cuda.synchronize()
+            g = step.arena.flat_g.clone()
+            if g0 is None:
+                g0 = g
+            else:
+                floor = max(floor, float((g - g0).abs().max() / g0.abs().max()))
+        side = torch.cuda.Stream()
+        worst = 0.0
+        for i in range(rounds):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    step.teacher(x)
+            step(x, tgt)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            worst = max(worst, float((step.arena.flat_g - g0).abs().max() / g0.abs().max()))
+        print({"workload": which, "gradient noise floor (quiet vs quiet)": floor, "worst next to a busy stream": worst})
 
 
 if __name__ == "__main__":
