@@ -55,13 +55,9 @@ __device__ __forceinline__ const long long* find_desc(const long long* table, in
     return table + (int64_t)lo * kWqFields;
 }
 
-// One WAVE per channel, four channels per workgroup: a channel of a 1x1 conv is 128 .. 512 elements, and a 256-thread workgroup per
-// channel spent its time in the descriptor search and the block reduction (104 us for the backward over 33 k channels; no barrier here)
-__global__ __launch_bounds__(256) void k_wq_multi_fwd(const long long* __restrict__ table, int n, int total) {
-    const int blk = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blk >= total) return;
-    const int lane = threadIdx.x & 63;
-    const long long* d = find_desc(table, n, blk);
+__global__ __launch_bounds__(256) void k_wq_multi_fwd(const long long* __restrict__ table, int n) {
+    __shared__ float red[4];
+    const long long* d = find_desc(table, n, blockIdx.x);
     const float* w = reinterpret_cast<const float*>(d[0]);
     float* wq = reinterpret_cast<float*>(d[1]);
     signed char* idx = reinterpret_cast<signed char*>(d[2]);
@@ -71,14 +67,14 @@ __global__ __launch_bounds__(256) void k_wq_multi_fwd(const long long* __restric
     const float* qmin = reinterpret_cast<const float*>(d[6]);
     const float* qmax = reinterpret_cast<const float*>(d[7]);
     const int outer = (int)d[12], C = (int)d[13], inner = (int)d[14];
-    const int c = blk - (int)d[15];
+    const int c = blockIdx.x - (int)d[15];
     const int64_t ldT = d[16];
     const float a = fmaxf(fabsf(qmin[c]), fabsf(qmax[c]));
     const float delta = (2.0f * a) / 255.0f;
     const float inv = 1.0f / delta;
     float s = 0.0f;
     const int nel = outer * inner;
-    for (int e = lane; e < nel; e += 64) {
+    for (int e = threadIdx.x; e < nel; e += 256) {
         const int o = e / inner, i = e - o * inner;
         const int64_t k = ((int64_t)o * C + c) * inner + i;
         const float X = rintf(div_by(w[k], delta, inv));
@@ -91,19 +87,18 @@ __global__ __launch_bounds__(256) void k_wq_multi_fwd(const long long* __restric
         }
     }
     if (idx) {
-        s = wave_sum(s);          // integers below 2^24: exact in any order
-        if (lane == 0) {
+        float v[1] = {s};
+        block_sum<float, 1>(v, red);
+        if (threadIdx.x == 0) {
             dw[c] = delta;
-            rw[c] = s;
+            rw[c] = v[0];
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_wq_multi_bwd(const long long* __restrict__ table, int n, int total) {
-    const int blk = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blk >= total) return;
-    const int lane = threadIdx.x & 63;
-    const long long* d = find_desc(table, n, blk);
+__global__ __launch_bounds__(256) void k_wq_multi_bwd(const long long* __restrict__ table, int n) {
+    __shared__ double red[4];
+    const long long* d = find_desc(table, n, blockIdx.x);
     const float* w = reinterpret_cast<const float*>(d[0]);
     const float* qmin = reinterpret_cast<const float*>(d[6]);
     const float* qmax = reinterpret_cast<const float*>(d[7]);
@@ -112,14 +107,14 @@ __global__ __launch_bounds__(256) void k_wq_multi_bwd(const long long* __restric
     float* gmin = reinterpret_cast<float*>(d[10]);
     float* gmax = reinterpret_cast<float*>(d[11]);
     const int outer = (int)d[12], C = (int)d[13], inner = (int)d[14];
-    const int c = blk - (int)d[15];
+    const int c = blockIdx.x - (int)d[15];
     const float lo = qmin[c], hi = qmax[c];
     const float a = fmaxf(fabsf(lo), fabsf(hi));
     const float delta = (2.0f * a) / 255.0f;
     const float inv = 1.0f / delta;
     float p = 0.0f;
     const int nel = outer * inner;
-    for (int e = lane; e < nel; e += 64) {
+    for (int e = threadIdx.x; e < nel; e += 256) {
         const int o = e / inner, i = e - o * inner;
         const int64_t k = ((int64_t)o * C + c) * inner + i;
         const float u = div_by(w[k], delta, inv);
@@ -130,9 +125,10 @@ __global__ __launch_bounds__(256) void k_wq_multi_bwd(const long long* __restric
         gw[k] += inr ? div_by(gk * delta, delta, inv) : 0.0f;
         p += gk * (inr ? (q - u) : q);
     }
-    const double psum = wave_sum((double)p);
-    if (lane == 0) {
-        const double D = psum * (2.0 / 255.0);
+    double v[1] = {(double)p};
+    block_sum<double, 1>(v, red);
+    if (threadIdx.x == 0) {
+        const double D = v[0] * (2.0 / 255.0);
         const float al = fabsf(lo), ah = fabsf(hi);
         const double wl = al > ah ? 1.0 : (al == ah ? 0.5 : 0.0);
         const double wh = ah > al ? 1.0 : (al == ah ? 0.5 : 0.0);
@@ -157,15 +153,15 @@ extern "C" int fqss_gacc_flush_multi(const int64_t* table, int n, fqss_stream_t 
 extern "C" int fqss_wq_multi_fwd(const int64_t* table, int n, int total_channels, fqss_stream_t stream) {
     FQSS_REQUIRE(table && n >= 0 && total_channels >= 0, "bad args");
     if (n == 0 || total_channels == 0) return FQSS_OK;
-    hipLaunchKernelGGL(k_wq_multi_fwd, dim3((unsigned)((total_channels + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)table, n, total_channels);
+    hipLaunchKernelGGL(k_wq_multi_fwd, dim3((unsigned)total_channels), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)table, n);
     return launch_status("fqss_wq_multi_fwd");
 }
 
 extern "C" int fqss_wq_multi_bwd(const int64_t* table, int n, int total_channels, fqss_stream_t stream) {
     FQSS_REQUIRE(table && n >= 0 && total_channels >= 0, "bad args");
     if (n == 0 || total_channels == 0) return FQSS_OK;
-    hipLaunchKernelGGL(k_wq_multi_bwd, dim3((unsigned)((total_channels + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)table, n, total_channels);
+    hipLaunchKernelGGL(k_wq_multi_bwd, dim3((unsigned)total_channels), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)table, n);
     return launch_status("fqss_wq_multi_bwd");
 }
