@@ -181,7 +181,17 @@ __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x, int
     }
     vmin = wave_min(vmin);
     vmax = wave_max(vmax);
+    // one atomic pair per WORKGROUP (same-address atomics cost ~12 ns each: per wave they were 25 of the 45 us the splitter's 1-MB
+    // max scan took at the head of every step)
+    __shared__ float wmn[4], wmx[4];
     if ((threadIdx.x & 63) == 0) {
+        wmn[threadIdx.x >> 6] = vmin;
+        wmx[threadIdx.x >> 6] = vmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        vmin = fminf(fminf(wmn[0], wmn[1]), fminf(wmn[2], wmn[3]));
+        vmax = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
         const uint32_t kmin = f2ord(vmin), kmax = f2ord(vmax);
         if (kmin < __hip_atomic_load(&obs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&obs[0], kmin);
         if (kmax > __hip_atomic_load(&obs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&obs[1], kmax);
