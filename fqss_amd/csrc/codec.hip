@@ -239,6 +239,90 @@ __device__ __forceinline__ void ola_dec4(unsigned int w, const QRange& r, float 
 
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
+// The (16, 8) decoder on the fp32 matrix cores: frames x taps = sum over channels of x[c][frame] * w[c][tap] as v_mfma_f32_16x16x4_f32
+// steps of four channels (bit for bit a k-ordered fmaf chain).  A lane owns FOUR consecutive frames of one channel -- one float4, or four
+// codes in one dword -- and they feed four accumulator tiles (tile j = frames mb + 4 i + j, i = 0 .. 15), so the operand row is read
+// in 256-B runs and each element once; the taps of the step's four channels are one 4-B load per lane.  A workgroup covers 64 frames (60
+// output slots); its four waves split the channels and meet in LDS for the overlap-add, as in k_ola_convtr_fwd.  Operand modes as there.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ola_mfma16(const void* __restrict__ x_, const float* __restrict__ feat,
+                                                     const float* __restrict__ w, float* __restrict__ out, int C, int M,
+                                                     int64_t ld_x, int64_t ld_f, int NS, int64_t T, const float* qmin,
+                                                     const float* qmax) {
+    constexpr int K = 16, S = 8, R = 2, FB = 60, PL = 65, U = 8;
+    __shared__ float P[4][K][PL];
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q0 = blockIdx.x * FB, mb = q0 - 4;      // first output slot / first frame of this workgroup (a multiple of 4)
+    const int m0 = mb + 4 * li;                       // this lane's frames m0 .. m0 + 3
+    const bool in_row = m0 >= 0 && m0 < M;            // rows are padded to 4 elements: the group is readable or wholly outside
+    const int mld = in_row ? m0 : 0;
+    bool fv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fv[j] = in_row && m0 + j < M;
+    QRange rx{0.f, 1.f, 1.f};
+    if (MODE == 1) rx = load_qrange(qmin, qmax);
+    const int cw = ((C + 15) / 16) * 4;               // channels per wave, a multiple of the MFMA's 4
+    const int c_beg = wave * cw, c_end = min(C, c_beg + cw);
+    f32x4m acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    const int64_t xb = (int64_t)n * C * ld_x + mld, fb = (MODE == 2) ? (int64_t)(n / NS) * C * ld_f + mld : 0;
+    for (int c0 = c_beg; c0 < c_end; c0 += 4 * U) {
+        float4 xa[U], xf2[U];
+        unsigned int xc[U];
+        float wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                 // the loads of U steps are issued before the first is used
+            const int c = min(c0 + 4 * u + lk, C - 1);
+            if (MODE == 1) xc[u] = *reinterpret_cast<const unsigned int*>((const uint8_t*)x_ + xb + (int64_t)c * ld_x);
+            else xa[u] = *reinterpret_cast<const float4*>((const float*)x_ + xb + (int64_t)c * ld_x);
+            if (MODE == 2) xf2[u] = *reinterpret_cast<const float4*>(feat + fb + (int64_t)c * ld_f);
+            wv[u] = w[(int64_t)c * K + li];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool cok = c0 + 4 * u + lk < c_end;  // channels past this wave's range contribute zeros
+            float v[4];
+            if (MODE == 1) {
+                ola_dec4(xc[u], rx, v);
+            } else {
+                v[0] = xa[u].x; v[1] = xa[u].y; v[2] = xa[u].z; v[3] = xa[u].w;
+                if (MODE == 2) {
+                    v[0] *= xf2[u].x; v[1] *= xf2[u].y; v[2] *= xf2[u].z; v[3] *= xf2[u].w;
+                }
+            }
+            const float wk = cok ? wv[u] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32((fv[j] && cok) ? v[j] : 0.0f, wk, acc[j], 0, 0, 0);
+        }
+    }
+    // register r of lane (li, lk) in tile j is (frame mb + 4 (4 lk + r) + j, tap li)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[wave][li][4 * (4 * lk + r) + j] = acc[j][r];
+    __syncthreads();
+    const int nslots = M + R - 1;
+    for (int e = threadIdx.x; e < FB * S; e += 256) {
+        const int ql = e / S, jj = e - ql * S;
+        const int q = q0 + ql;
+        if (q < nslots) {
+            float v = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int fl = ql + 4 - r;       // local index of frame q - r
+#pragma unroll
+                for (int wv2 = 0; wv2 < 4; ++wv2) v += P[wv2][r * S + jj][fl];
+            }
+            const int64_t t = (int64_t)q * S + jj;
+            if (t < T) out[(int64_t)n * T + t] = v;
+        }
+    }
+}
+
 // Weight gradient of the single-channel framing conv / the mono decoder: gw[c][k] += sum_{n,m} a[n][c][m] * sig[n][m*S + k]
 // (qat_layers.py:1028-1039, 1330-1341 of the reference through autograd) = a [C x M] . frames(sig) [M x K] product per signal, on the
 // fp32 matrix cores (v_mfma_f32_16x16x4_f32: bit for bit a k-ordered fmaf chain, so the contract of the VALU form holds).  A wave owns
@@ -427,8 +511,21 @@ static int ola_convtr_impl(const char* who, int mode, const void* x, const float
     FQSS_REQUIRE(mode != 2 || (feat && NS >= 1 && N % NS == 0 && ld_f >= M), "masking form: feat [N / NS][C][M]");
     if (N == 0 || M == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
     if (NS < 1) NS = 1;
+    {   // (16, 8) window on vector-aligned rows: the matrix-core form
+        static const bool mfma_on = [] { const char* e = getenv("FQSS_OLA_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
+        const int64_t m4 = (M + 3) & ~(int64_t)3;
+        bool ok = mfma_on && K == 16 && stride == 8 && ld_x >= m4 && aligned16(x) && (mode == 1 ? ld_x % 16 == 0 : ld_x % 4 == 0);
+        if (mode == 2) ok = ok && aligned16(feat) && ld_f % 4 == 0 && ld_f >= m4;
+        if (ok) {
+            dim3 gridm((unsigned)cdiv((int64_t)M + 1, 60), (unsigned)N);
+            if (mode == 0) hipLaunchKernelGGL(k_ola_mfma16<0>, gridm, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax);
+            else if (mode == 1) hipLaunchKernelGGL(k_ola_mfma16<1>, gridm, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax);
+            else hipLaunchKernelGGL(k_ola_mfma16<2>, gridm, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax);
+            return launch_status(who);
+        }
+    }
+    dim3 grid((unsigned)cdiv(M + 1, 63), (unsigned)N);
 #define FQSS_OLA(K_, S_)                                                                                                                  \
     do {                                                                                                                                  \
         if (mode == 0) hipLaunchKernelGGL((k_ola_convtr_fwd<K_, S_, 0>), grid, dim3(256), 0, s, x, feat, w, out, C, M, ld_x, ld_f, NS, T, qmin, qmax); \

@@ -159,11 +159,11 @@ def test_ola_convtr(N, C, M, K_, S):
     y = F.conv_transpose1d(xr, wr, None, stride=S)
     y.backward(g)
     outs = []
-    for conv in (padded, lambda t: t.cuda()):      # padded rows: four frames per lane; dense rows of odd length: one frame per lane
+    for conv in (padded, lambda t: t.cuda()):      # padded rows: the matrix-core form for (16, 8); dense rows of odd length: one frame per lane
         out = K.ola_convtr_fwd(conv(x), w.cuda(), S)
         close(out, y, rtol=1e-4, atol=1e-4)
         outs.append(out)
-    assert torch.equal(outs[0], outs[1])           # same summation order in both forms
+    close(outs[0], outs[1], rtol=1e-5, atol=1e-5)  # (16, 8) on aligned rows: matrix-core form, another summation order
     # the coded-input form (student decoder) and the masking form (teacher decoder) against their un-fused chains, bit for bit
     gen = torch.Generator().manual_seed(N + C + M)
     codes = torch.randint(0, 256, (N, C, M), generator=gen, dtype=torch.uint8)
