@@ -72,6 +72,7 @@ _PROTOS = {
     "fqss_frames_conv_add_fwd": [P, P, P, I64, P, I32, I32, I32, I64, I32, I32, I32, I64, P],
     "fqss_ola_convtr_fwd": [P, P, P, I32, I32, I32, I64, I32, I32, I64, P],
     "fqss_frames_wgrad1": [P, P, P, I32, I32, I32, I64, I64, I32, I32, P],
+    "fqss_frames_wgrad1s": [P, P, I64, P, I64, I32, I32, I32, I64, I64, I32, I32, P],
     "fqss_frames_wgrad1_q": [P, P, P, P, P, I32, I32, I32, I64, I64, I32, I32, P],
     "fqss_ola_convtr_fwd_q": [P, P, P, P, P, I32, I32, I32, I64, I32, I32, I64, P],
     "fqss_ola_convtr_mul_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, I32, I32, I64, P],

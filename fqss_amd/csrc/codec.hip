@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_ola_mfma16(const void* __restrict__ x_,
 template <int K, int S, bool CODED>
 __global__ __launch_bounds__(256) void k_frames_wgrad_mfma(const void* __restrict__ a_, const float* __restrict__ sig,
                                                             float* __restrict__ gw, int C, int M, int64_t ld_a, int64_t T, int mchunk,
-                                                            const float* qmin, const float* qmax) {
+                                                            const float* qmin, const float* qmax, int64_t sig_ns, int64_t ld_gw) {
     constexpr int TC = 4, NT = K / 16;
     constexpr int VL = CODED ? 16 : 8;       // operand values per lane and iteration
     constexpr int FI = 4 * VL;               // frames per iteration
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_frames_wgrad_mfma(const void* __restric
     for (int t = 0; t < TC; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) acc[t][u] = f32x4m{0.f, 0.f, 0.f, 0.f};
-    const float* sn = sig + (int64_t)n * T;
+    const float* sn = sig + (int64_t)n * sig_ns;     // (one input channel of a [N][Ci][T] signal: sig_ns = Ci T, gw rows Ci K apart)
     int64_t arow[TC];
 #pragma unroll
     for (int t = 0; t < TC; ++t) arow[t] = ((int64_t)n * C + min(c0 + 16 * t + li, C - 1)) * ld_a;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_frames_wgrad_mfma(const void* __restric
         const float v = (red[0][q][l] + red[1][q][l]) + (red[2][q][l] + red[3][q][l]);
         const int t = q / (NT * 4), u = (q / 4) % NT, r = q & 3;
         const int c = c0 + 16 * t + 4 * (l >> 4) + r;
-        if (c < C) atomicAdd(&gw[(int64_t)c * K + 16 * u + (l & 15)], v);
+        if (c < C) atomicAdd(&gw[(int64_t)c * ld_gw + 16 * u + (l & 15)], v);
     }
 }
 
@@ -560,7 +560,9 @@ extern "C" int fqss_ola_convtr_mul_fwd(const float* mask, const float* feat, con
 
 // Ci = 1 forms of fqss_frames_wgrad: a fp32 (coded = 0) or u8 codes; returns false when the shape is not served
 static bool frames_wgrad1_launch(int coded, const void* a, const float* sig, float* gw, int N, int C, int M, int64_t ld_a, int64_t T, int K,
-                                 int stride, const float* qmin, const float* qmax, hipStream_t s) {
+                                 int stride, const float* qmin, const float* qmax, hipStream_t s, int64_t sig_ns = 0, int64_t ld_gw = 0) {
+    if (sig_ns <= 0) sig_ns = T;
+    if (ld_gw <= 0) ld_gw = K;
     const bool k16 = K == 16 && stride == 8, k32 = K == 32 && stride == 16;
     if (!(k16 || k32) || T < 1 || N > 65535) return false;
     if (coded ? !(aligned16(a) && ld_a % 16 == 0 && ld_a >= 16) : !(aligned16(a) && ld_a % 4 == 0 && ld_a >= 4)) return false;
@@ -574,7 +576,7 @@ static bool frames_wgrad1_launch(int coded, const void* a, const float* sig, flo
     msplit = (int)cdiv(M, mchunk);
     dim3 grid((unsigned)gx, (unsigned)N, (unsigned)msplit);
 #define FQSS_FW1(K_, S_, CD_) \
-    hipLaunchKernelGGL((k_frames_wgrad_mfma<K_, S_, CD_>), grid, dim3(256), 0, s, a, sig, gw, C, M, ld_a, T, mchunk, qmin, qmax)
+    hipLaunchKernelGGL((k_frames_wgrad_mfma<K_, S_, CD_>), grid, dim3(256), 0, s, a, sig, gw, C, M, ld_a, T, mchunk, qmin, qmax, sig_ns, ld_gw)
     if (k16) { if (coded) FQSS_FW1(16, 8, true); else FQSS_FW1(16, 8, false); }
     else     { if (coded) FQSS_FW1(32, 16, true); else FQSS_FW1(32, 16, false); }
 #undef FQSS_FW1
@@ -592,6 +594,21 @@ extern "C" int fqss_frames_wgrad1(const float* a, const float* sig, float* gw, i
         return FQSS_EINVAL;
     }
     return launch_status("fqss_frames_wgrad1");
+}
+
+/* one input channel ci of a multi-channel framing conv: sig = x + ci T with sig_ns = Ci T between signals, gw = gw0 + ci K with rows
+ * ld_gw = Ci K apart (the student encoder's two splitter channels: Conv1dEncoderQ, qat_layers.py:993-1046) */
+extern "C" int fqss_frames_wgrad1s(const float* a, const float* sig, int64_t sig_ns, float* gw, int64_t ld_gw, int N, int C, int M,
+                                   int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && sig && gw, "null tensor");
+    FQSS_REQUIRE(N >= 0 && C > 0 && M >= 0 && ld_a >= M && K > 0 && stride > 0 && sig_ns >= T && ld_gw >= K, "bad shape");
+    FQSS_REQUIRE(M == 0 || (int64_t)(M - 1) * stride + K <= T, "frames exceed the signal");
+    if (M == 0 || N == 0) return FQSS_OK;
+    if (!frames_wgrad1_launch(0, a, sig, gw, N, C, M, ld_a, T, K, stride, nullptr, nullptr, (hipStream_t)stream, sig_ns, ld_gw)) {
+        set_error("fqss_frames_wgrad1s: needs (K, stride) in {(16, 8), (32, 16)} and 16-B aligned rows");
+        return FQSS_EINVAL;
+    }
+    return launch_status("fqss_frames_wgrad1s");
 }
 
 extern "C" int fqss_frames_wgrad1_q(const uint8_t* ac, const float* qmin, const float* qmax, const float* sig, float* gw, int N, int C,

@@ -740,8 +740,13 @@ def frames_wgrad(a, x, gw, stride):
     _, Ci, T = x.shape
     K = gw.shape[-1]
     assert gw.is_contiguous() and gw.numel() == C * Ci * K
-    if Ci == 1 and _frames_wgrad1_ok(x, T, K, stride) and ld_a % 4 == 0 and a.data_ptr() % 16 == 0:
-        _lib.call("fqss_frames_wgrad1", _p(a), _p(x), _p(gw), N, C, M, ld_a, T, K, stride, _stream())
+    if _frames_wgrad1_ok(x, T, K, stride) and ld_a % 4 == 0 and a.data_ptr() % 16 == 0:
+        if Ci == 1:
+            _lib.call("fqss_frames_wgrad1", _p(a), _p(x), _p(gw), N, C, M, ld_a, T, K, stride, _stream())
+        else:       # one matrix-core launch per input channel (the encoder's splitter channels)
+            for ci in range(Ci):
+                _lib.call("fqss_frames_wgrad1s", _p(a), x.data_ptr() + 4 * ci * T, Ci * T, gw.data_ptr() + 4 * ci * K, Ci * K, N, C, M,
+                          ld_a, T, K, stride, _stream())
         return
     _lib.call("fqss_frames_wgrad", _p(a), _p(x), _p(gw), N, C, Ci, M, ld_a, T, K, stride, _stream())
 

@@ -388,6 +388,9 @@ int fqss_frames_wgrad(const float* a, const float* x, float* gw, int N, int C, i
  * of a 16-B aligned (FQSS_EINVAL otherwise: callers fall back to fqss_frames_wgrad).  _q: a as u8 codes (qmin, qmax). */
 int fqss_frames_wgrad1(const float* a, const float* sig, float* gw, int N, int C, int M, int64_t ld_a, int64_t T, int K,
                        int stride, fqss_stream_t stream);
+/* one input channel of a multi-channel framing conv: sig = x + ci * T (signals sig_ns = Ci * T apart), gw = gw0 + ci * K (rows ld_gw = Ci * K apart) */
+int fqss_frames_wgrad1s(const float* a, const float* sig, int64_t sig_ns, float* gw, int64_t ld_gw, int N, int C, int M,
+                        int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream);
 int fqss_frames_wgrad1_q(const uint8_t* ac, const float* qmin, const float* qmax, const float* sig, float* gw, int N, int C,
                          int M, int64_t ld_a, int64_t T, int K, int stride, fqss_stream_t stream);
 
