@@ -43,10 +43,17 @@ def build(which, dev):
     return R.KDTrainStep(model, fmodel, lr=0.0, clip=0.0, loss="l1_sdr"), src.sum(1), src
 
 
-def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-    rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+def run(which="cfg2", rounds=10):
+    """-> number of rounds whose output / loss differ from the one-stream step"""
     from fqss_amd import runtime as R
+    saved = R.TEACHER_STREAM
+    try:
+        return _run(which, rounds, R)
+    finally:
+        R.TEACHER_STREAM = saved
+
+
+def _run(which, rounds, R):
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
     dev = torch.device("cuda", 0)
     step, x, tgt = build(which, dev)
@@ -70,7 +77,9 @@ def main():
         ok = torch.equal(r["est"], est0) and abs(float(r["loss"]) - loss0) <= 1e-6 * abs(loss0)
         bad += 0 if ok else 1
     print({"workload": which, "rounds": rounds, "mismatching": bad})
-    if os.environ.get("BWD"):
+    if not os.environ.get("BWD"):
+        return bad
+    if True:
         # the BACKWARD next to a busy second stream (at world > 1 the gradient all-reduce runs beside it): gradients of a step whose
         # whole duration is shadowed by teacher passes on another stream vs the quiet step; fp32 atomics set the noise floor
         R.TEACHER_STREAM = False
@@ -96,7 +105,8 @@ def main():
             torch.cuda.synchronize()
             worst = max(worst, float((step.arena.flat_g - g0).abs().max() / g0.abs().max()))
         print({"workload": which, "gradient noise floor (quiet vs quiet)": floor, "worst next to a busy stream": worst})
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    run(sys.argv[1] if len(sys.argv) > 1 else "cfg2", int(sys.argv[2]) if len(sys.argv) > 2 else 10)
