@@ -126,10 +126,16 @@ def build(dev, sets=3):
 
 def step_traffic_bytes(cases):
     """algorithmic HBM bytes of ONE step summed over the launch list above (the TCN stack: every kernel x its launches per step), plus the
-    encoder / decoder / loss / optimizer passes outside the stack (fp32 tensors of the 8 x 512 x 3999 and 8 x 2 x 32000 sizes, read or
-    written once per pass; 14 such passes of N_H elements and the 7 x 4 B x 5.13 M of clip + Adam)"""
+    passes outside the stack, in bytes per N_H = 8 x 512 x 3999 positions (the [16, 512, M] tensors of the masking product / decoder /
+    residual block count twice):
+      forward  ~55 B: student encoder z + its quantizer 10, MulQ on codes 5, two decoder launches on codes 4, residual encoder 8, its
+               Sub 12, teacher encoder 4 + masking product formed inside the decoder 12;
+      backward ~140 B: decoder dgrad 8 + wgrad from codes 2 (twice: main and residual), Sub backward 26 and its negation 16, residual encoder
+               dgrad 8 + wgrad 8, decoder dgrad with the fork's addend 16, MulQ backward (+ mask conv epilogue) 31, encoder-side quantizer
+               backward + fork sum 24;
+    and the 7 x 4 B x 5.13 M of clip + Adam.  (Round 1 / early round 2 counted 14 x 4 B here: the un-fused chain really moved ~300 B.)"""
     stack = sum(c["launches"] * c["bytes"] for c in cases)
-    outside = 14 * 4.0 * NH * N + 7 * 4.0 * 5.13e6
+    outside = 195.0 * NH * N + 7 * 4.0 * 5.13e6
     return stack + outside
 
 
