@@ -461,7 +461,7 @@ static int frames_conv_impl(const char* who, const float* x, const float* w, flo
         if (co_tile > Co) co_tile = (Co + 3) & ~3;
         size_t lds = (size_t)co_tile * Ci * K * sizeof(float);
         static const int taps_lds = [] { const char* e = getenv("FQSS_TAPS_LDS"); return e ? atoi(e) : 1; }();   // A/B switch
-        if (!taps_lds) { co_tile = -1; lds = 0; }       // taps by wave-uniform loads from memory       // taps from memory (see k_ola_convtr4); the LDS form only for experiments
+        if (!taps_lds) { co_tile = -1; lds = 0; }       // taps by wave-uniform loads from memory
         if (wide_on && (k16 || k32) && (Ci == 1 || Ci == 2) && aligned16(x) && T % 4 == 0 && T >= 4 && aligned16(z) && ld_z % 4 == 0 &&
             ld_z >= m4 && (!add || (aligned16(add) && ld_add % 4 == 0 && ld_add >= m4))) {
             dim3 grid4((unsigned)cdiv(M, 256), (unsigned)N);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     // The small per-workgroup arrays live INSIDE the tile buffer, which is idle when they are in use (pms: before the first tile is
     // stored; rowb / red: in the epilogue, behind its 4 x 4,608-B staging tiles): as separate arrays they brought the PRO = 1 instance to
     // 66,120 B of static LDS, and a kernel above 64 KB made LDS-resident data of kernels running on ANOTHER stream unreliable
-    // (tools/stress_streams.py; csrc/codec.hip k_ola_convtr4).  With them folded in every instance is <= 65,536 B.
+    // (tools/stress_streams.py).  With them folded in every instance is <= 65,536 B.
     float* rowb = reinterpret_cast<float*>(smem + 4 * 32 * TLDT * 4);                     // [TBM]
     double* red = reinterpret_cast<double*>(smem + 4 * 32 * TLDT * 4 + TBM * 4);          // [2 * 4]
     float* pms = reinterpret_cast<float*>(smem);                                          // [2]
