@@ -245,14 +245,15 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
                     bool inr;
                     (void)fq_asym(t, r, c, u, inr);
                     gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
-                    if (valid) {
-                        p_du += gj * (inr ? (c - u) : c);
-                        p_out += inr ? 0.0f : gj;
-                    }
+                    // selects, not a branch around the sums (a masked-out position may hold anything, so its term is dropped, not
+                    // multiplied by 0): the branchy form of these sums in k_mulq_bwd was right alone and off by one term in a few
+                    // lanes per launch next to a second stream; every such sum is written branch-free since
+                    p_du += valid ? gj * (inr ? (c - u) : c) : 0.0f;
+                    p_out += (valid && !inr) ? gj : 0.0f;
                 }
                 float gzj = act_bwd(zv[j], gt, act, slope, valid, p_slope);
                 o[j] = gzj;
-                if (BIAS && valid) p_bias += gzj;
+                if (BIAS) p_bias += valid ? gzj : 0.0f;
             }
         };
         const int64_t c_first = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;

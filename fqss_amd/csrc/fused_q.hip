@@ -567,13 +567,11 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
                     bool inr;
                     (void)fq_asym(t, ry, cq, u, inr);
                     const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
-                    if (valid) {
-                        p_du += gj * (inr ? (cq - u) : cq);
-                        p_out += inr ? 0.0f : gj;
-                    }
+                    p_du += valid ? gj * (inr ? (cq - u) : cq) : 0.0f;      // (selects, not branches: fq.hip k_actq_bwd)
+                    p_out += (valid && !inr) ? gj : 0.0f;
                     float gzj = act_bwd(z[j], gt, act, slope, valid, p_slope);
                     o[j] = gzj;
-                    if (valid) p_bias += gzj;
+                    p_bias += valid ? gzj : 0.0f;
                 }
                 *reinterpret_cast<float4*>(gz + row * ld_gz + m) = make_float4(o[0], o[1], o[2], o[3]);
             }
@@ -691,10 +689,8 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                 bool inr;
                 (void)fq_asym(t, ry, cq, u, inr);
                 const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
-                if (valid) {
-                    p_du += gj * (inr ? (cq - u) : cq);
-                    p_out += inr ? 0.0f : gj;
-                }
+                p_du += valid ? gj * (inr ? (cq - u) : cq) : 0.0f;
+                p_out += (valid && !inr) ? gj : 0.0f;
                 float gzj = act_bwd_br(z, gt, act, slope, valid, p_slope);
                 gzj = valid ? gzj : 0.0f;
                 o[j] = gzj;
@@ -872,12 +868,10 @@ __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRan
         p_bias += gt;
         return gt;
     } else {
-        if (valid) {
-            p_du += gj * (pin ? (pc - pu) : pc);
-            p_out += pin ? 0.0f : gj;
-        }
+        p_du += valid ? gj * (pin ? (pc - pu) : pc) : 0.0f;          // (selects, not branches: fq.hip k_actq_bwd)
+        p_out += (valid && !pin) ? gj : 0.0f;
         float gzj = act_bwd(pz, gt, P.act, pslope, valid, p_slope);
-        if (valid) p_bias += gzj;
+        p_bias += valid ? gzj : 0.0f;
         return gzj;
     }
 }
@@ -937,10 +931,8 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
                 p_out += inr ? 0.0f : gj;
                 gzj = gt;
             } else {
-                if (valid) {
-                    p_du += gj * (inr ? (cq - u) : cq);
-                    p_out += inr ? 0.0f : gj;
-                }
+                p_du += valid ? gj * (inr ? (cq - u) : cq) : 0.0f;
+                p_out += (valid && !inr) ? gj : 0.0f;
                 gzj = act_bwd(z, gt, act, slope, valid, p_slope);
             }
             o[e] = gzj;
@@ -1104,11 +1096,16 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
     const QRange rm = load_qrange(mmin, mmax), rf = load_qrange(fmin, fmax), ry = load_qrange(qmin, qmax);
     const float pslope = (PROD && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
     float p_du = 0.f, p_out = 0.f, a_du = 0.f, a_out = 0.f, a_sl = 0.f;
+    // gridDim.y % C == 0 (the launch's choice whenever C fits): the rows of a workgroup (row = y, y + gridDim.y, ...) are batch entries of
+    // ONE channel, so the producer's bias sums are carried across them and added once per workgroup -- B times fewer atomics, and
+    // a sum whose value does not depend on the order in which B partial sums of opposite signs arrive (seen as 1e-4 of run-to-run
+    // movement in this one gradient when a second stream perturbed the order, tools/stress_step.py BWD=1)
+    const bool per_channel = ((int)gridDim.y % C) == 0;
+    float a_bias[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
         const int b = row / C, c = row - b * C;
-        float a_bias[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
         for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += gridDim.x * 256 * 4) {
             const unsigned int wf = *reinterpret_cast<const unsigned int*>(fc + (int64_t)row * ld_f + c0);
             unsigned int wm[S];
@@ -1147,10 +1144,20 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
             }
             if (gfeat != nullptr) *reinterpret_cast<float4*>(gfeat + (int64_t)row * ld_gf + c0) = make_float4(gf[0], gf[1], gf[2], gf[3]);
         }
-        if (PROD && P.gbias != nullptr) {       // one sum per (row, s): channel s * C + c of the producer
+        if (PROD && P.gbias != nullptr && !per_channel) {       // one sum per (row, s): channel s * C + c of the producer
             block_sum<float, S>(a_bias, redf);
             if (threadIdx.x == 0)
                 for (int s = 0; s < S; ++s) atomicAdd(&P.gbias[s * C + c], a_bias[s]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
+        }
+    }
+    if (PROD && P.gbias != nullptr && per_channel) {
+        // wave sums straight to the atomics (no LDS exchange needed: four waves, one atomic each)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float t = wave_sum(a_bias[s]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&P.gbias[s * C + (int)(blockIdx.y % C)], t);
         }
     }
     const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;   // < kSlots: one workgroup per slot

@@ -43,17 +43,18 @@ def build(which, dev):
     return R.KDTrainStep(model, fmodel, lr=0.0, clip=0.0, loss="l1_sdr"), src.sum(1), src
 
 
-def run(which="cfg2", rounds=10):
-    """-> number of rounds whose output / loss differ from the one-stream step"""
+def run(which="cfg2", rounds=10, bwd=None):
+    """-> number of rounds whose output / loss differ from the one-stream step; with bwd (or BWD=1 in the environment) -> (that number,
+    gradient noise floor quiet-vs-quiet, worst gradient deviation of a step shadowed by a busy second stream), both relative to max|g|"""
     from fqss_amd import runtime as R
     saved = R.TEACHER_STREAM
     try:
-        return _run(which, rounds, R)
+        return _run(which, rounds, R, bool(os.environ.get("BWD")) if bwd is None else bwd)
     finally:
         R.TEACHER_STREAM = saved
 
 
-def _run(which, rounds, R):
+def _run(which, rounds, R, bwd):
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
     dev = torch.device("cuda", 0)
     step, x, tgt = build(which, dev)
@@ -77,7 +78,7 @@ def _run(which, rounds, R):
         ok = torch.equal(r["est"], est0) and abs(float(r["loss"]) - loss0) <= 1e-6 * abs(loss0)
         bad += 0 if ok else 1
     print({"workload": which, "rounds": rounds, "mismatching": bad})
-    if not os.environ.get("BWD"):
+    if not bwd:
         return bad
     if True:
         # the BACKWARD next to a busy second stream (at world > 1 the gradient all-reduce runs beside it): gradients of a step whose
@@ -103,9 +104,20 @@ def _run(which, rounds, R):
             step(x, tgt)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            worst = max(worst, float((step.arena.flat_g - g0).abs().max() / g0.abs().max()))
+            dev_ = float((step.arena.flat_g - g0).abs().max() / g0.abs().max())
+            if dev_ > max(20 * floor, 2e-6):          # which parameters moved, and by how much of their own scale
+                names = {id(p): n for n, p in step.model.named_parameters()}
+                rows = []
+                for p_, off in zip(step.arena.params, step.arena.offsets):
+                    a, b = step.arena.flat_g[off:off + p_.numel()], g0[off:off + p_.numel()]
+                    d = float((a - b).abs().max())
+                    if d > 20 * floor * float(g0.abs().max()):
+                        rows.append((d / (float(b.abs().max()) + 1e-30), names.get(id(p_), "?"), int(((a - b).abs() > 0).sum()), p_.numel()))
+                rows.sort(reverse=True)
+                print("round", i, "deviation", dev_, [(round(r, 6), n, k, m) for r, n, k, m in rows[:8]])
+            worst = max(worst, dev_)
         print({"workload": which, "gradient noise floor (quiet vs quiet)": floor, "worst next to a busy stream": worst})
-    return bad
+    return bad, floor, worst
 
 
 if __name__ == "__main__":
