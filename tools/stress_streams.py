@@ -45,13 +45,14 @@ def main(argv=()):
     os.makedirs(os.path.dirname(so), exist_ok=True)
     probe = None
     try:
-        if not os.path.exists(so):
+        src = os.path.join(root, "tools", "ubench", "longsum.hip")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so,
                                    os.path.join(root, "tools", "ubench", "longsum.hip")])
         lib = ctypes.CDLL(so)
         lib.probe_longsum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         def probe(blocks=2048, rounds=1):
-            o = torch.empty(blocks * 256 * 2, device=dev)
+            o = torch.empty(blocks * 256 * 3, device=dev)
             lib.probe_longsum(xbig.data_ptr(), o.data_ptr(), xbig.numel(), blocks, rounds,
                               torch.cuda.current_stream().cuda_stream)
             return o
