@@ -78,8 +78,10 @@ FUSE_DECQ = os.environ.get("FQSS_FUSE_DECQ", "1") != "0"    # decoder reads its 
 def _mul_coded(x1, x2, q):
     """mask[B,S,C,M] * feat[B,1,C,M] (either order) with both operands on codes, in the quantizing phase: the codes -> codes kernel
     (ops.MulQCoded); None when it does not apply"""
-    if not (FUSE_MULQ and torch.is_tensor(x2) and x1.dim() == 4 and x2.dim() == 4 and q.qmode == ops.Q_QUANT and q.gacc is not None):
+    if not (FUSE_MULQ and torch.is_tensor(x2) and x1.dim() == 4 and x2.dim() == 4 and q.qmode == ops.Q_QUANT):
         return None
+    if q.gacc is None and torch.is_grad_enabled() and (x1.requires_grad or x2.requires_grad):
+        return None        # a backward would need the range-gradient slots (inference has none and needs none)
     if x1.shape[1] == 1 and x2.shape[1] != 1:
         x1, x2 = x2, x1
     if not (x2.shape[1] == 1 and x1.shape[0] == x2.shape[0] and x1.shape[2:] == x2.shape[2:] and 1 <= x1.shape[1] <= 4):
