@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-teacher-ahead", action="store_true",
+                    help="cfg2: run the frozen teacher beside the student's forward of the SAME step (round-2 schedule) instead of one batch ahead")
     ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5", "infer"),
                     help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s; "
                          "cfg5 HTDemucs 4 x 10 s stereo 44.1 kHz")
@@ -417,7 +419,12 @@ def main():
 
     model, fmodel = build_pair(dev, 0, n_spks=2, kernel_size=16, stride=8)   # same init on every rank
     x, tgt = synth_batch(B_PER_GPU, T_SAMPLES, seed=100 + comm.rank, device=dev)   # per-rank shard (weak scaling)
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=comm)
+    # a second, different batch: the timed loop alternates the two, so the teacher's look-ahead (its forward of batch n+1 runs on the
+    # teacher stream beside the whole of step n) works on a mixture that is NOT the one the step is training on
+    x2, tgt2 = synth_batch(B_PER_GPU, T_SAMPLES, seed=200 + comm.rank, device=dev)
+    X, TG = (x, x2), (tgt, tgt2)
+    ahead = not a.no_teacher_ahead
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=comm, teacher_ahead=ahead)
 
     # untimed calibration: leave the 50-call observer phase (1 full step + 49 observer forwards), then
     # every timed step runs the quantizers
@@ -436,13 +443,18 @@ def main():
             # the backward replays as one hipGraph per gradient bucket; each bucket's RCCL all-reduce is launched between two
             # replays on the communication stream and overlaps the next bucket's backward (no collective inside a graph)
             launch = f"hipGraph replay, {len(step._graphs[0])} backward segments, bucketed all-reduce overlapped"
+        if ahead:
+            launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
+    it = 0
     for _ in range(a.warmup):
-        step(x, tgt)
+        step(X[it & 1], TG[it & 1], x_next=X[(it + 1) & 1])
+        it += 1
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        r = step(x, tgt)
+        r = step(X[it & 1], TG[it & 1], x_next=X[(it + 1) & 1])      # one student fwd + bwd + update AND one teacher forward per step
+        it += 1
     torch.cuda.synchronize()
     comm.barrier()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)

@@ -868,11 +868,21 @@ __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRan
         p_bias += gt;
         return gt;
     } else {
+#ifdef FQSS_BRANCHY_SUMS      // diagnostic build only (tools/diag_streams.py): the round-2 form with a branch around the additions
+        if (valid) {
+            p_du += gj * (pin ? (pc - pu) : pc);
+            p_out += pin ? 0.0f : gj;
+        }
+        float gzj = act_bwd(pz, gt, P.act, pslope, valid, p_slope);
+        if (valid) p_bias += gzj;
+        return gzj;
+#else
         p_du += valid ? gj * (pin ? (pc - pu) : pc) : 0.0f;          // (selects, not branches: fq.hip k_actq_bwd)
         p_out += (valid && !pin) ? gj : 0.0f;
         float gzj = act_bwd(pz, gt, P.act, pslope, valid, p_slope);
         p_bias += valid ? gzj : 0.0f;
         return gzj;
+#endif
     }
 }
 
@@ -1085,6 +1095,11 @@ __global__ __launch_bounds__(256) void k_mulq_fwd(const uint8_t* __restrict__ mc
 // backward: z recomputed from the codes, gz = STE(g); gmask = gz * feat (or, with the mask's producer fused -- the mask conv's
 // non-linearity + output quantizer, cf. EwProducer -- that layer's gz), gfeat = sum_s gz_s * mask_s in ascending s (the order
 // of fqss_mul_bcast_bwd); range partials of this layer (and of the producer) to the gacc slots.
+#ifdef FQSS_DIAG     // diagnostic build only: per-lane bias partials and per-wave placement / timing of k_mulq_bwd (tools/diag_streams.py)
+__device__ float* g_diag_lane = nullptr;                  // [workgroup][256][4]
+__device__ unsigned long long* g_diag_wave = nullptr;     // [workgroup][4 waves][4]: HW_ID | XCC_ID << 32, start, end (s_memtime), end (s_memrealtime)
+#endif
+
 template <int S, bool PROD>
 __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc, const uint8_t* __restrict__ fc,
                                                    const float* __restrict__ g, float* __restrict__ gmask, float* __restrict__ gfeat,
@@ -1104,6 +1119,12 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
     float a_bias[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
+#ifdef FQSS_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
+    float diag_bias[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) diag_bias[s] = 0.f;
+#endif
     for (int row = blockIdx.y; row < rows; row += gridDim.y) {
         const int b = row / C, c = row - b * C;
         for (int c0 = (blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += gridDim.x * 256 * 4) {
@@ -1139,6 +1160,9 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
                     gf[e] += gt * xm[e];
                     const float gm = gt * xf[e];
                     o[e] = PROD ? ew_producer_bwd<false>(P, rm, pslope, pzv[e], gm, valid, a_du, a_out, a_sl, a_bias[s]) : gm;
+#ifdef FQSS_DIAG
+                    diag_bias[s] += valid ? o[e] : 0.0f;      // the same sum, select form, in the same wave
+#endif
                 }
                 *reinterpret_cast<float4*>(gmask + mrow * ld_gm + c0) = make_float4(o[0], o[1], o[2], o[3]);
             }
@@ -1152,6 +1176,24 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
             for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
         }
     }
+#ifdef FQSS_DIAG
+    if (g_diag_lane != nullptr) {
+        const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+        for (int s = 0; s < S && s < 2; ++s) {
+            g_diag_lane[(wg * 256 + threadIdx.x) * 4 + s] = a_bias[s];
+            g_diag_lane[(wg * 256 + threadIdx.x) * 4 + 2 + s] = diag_bias[s];
+        }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* w = g_diag_wave + (wg * 4 + (threadIdx.x >> 6)) * 4;
+            const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            w[0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            w[1] = diag_t0;
+            w[2] = __builtin_amdgcn_s_memtime();
+            w[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
     if (PROD && P.gbias != nullptr && per_channel) {
         // wave sums straight to the atomics (no LDS exchange needed: four waves, one atomic each)
 #pragma unroll
@@ -1186,6 +1228,14 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
 using namespace fqss;
 
 static inline bool codes_ok(const void* p, int64_t ld) { return aligned16(p) && (ld % 16 == 0); }
+
+#ifdef FQSS_DIAG
+extern "C" int fqss_diag_set(float* lane, unsigned long long* wave) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_lane), &lane, sizeof(lane)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_wave), &wave, sizeof(wave)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 extern "C" int fqss_decode(const uint8_t* codes, float* out, int64_t rows, int64_t cols, int64_t ld_c, int64_t ld_out,
                            const float* qmin, const float* qmax, fqss_stream_t stream) {
@@ -1498,6 +1548,7 @@ extern "C" int fqss_mulq_bwd(const uint8_t* mc, const float* mmin, const float* 
     if (gx_ > 64) gx_ = 64;
     int64_t gy = kSlots / gx_;
     if (gy > rows) gy = rows;
+    if (gy >= C) gy = gy / C * C;     // a multiple of C whenever C fits: the kernel's order-independent per-channel bias sums (per_channel)
     EwProducer P{};
     P.pz = pz; P.ld_pz = (int)ld_pz; P.act = pact; P.slope = pslope; P.gacc = pgacc; P.gbias = pgbias; P.out = nullptr; P.ld_out = 0;
 #define FQSS_MULQ_BWD(S_, PR_)                                                                                                       \

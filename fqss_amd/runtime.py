@@ -362,7 +362,7 @@ class KDTrainStep:
 
     def __init__(self, model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=None, loss="sisdr_pit", source_weights=None,
                  batched_quantizers=True, fast=True, coded=True, buckets=None, sync_observer_ranges=True,
-                 betas=(0.9, 0.999), loss_threshold=None):
+                 betas=(0.9, 0.999), loss_threshold=None, teacher_ahead=False):
         """loss: "sisdr_pit" = the asteroid KD loss (mysystem.py:124-151); "sisdr_pit_per_sample" = the speechbrain env's form of it
         (speechbrain_librimix_trainer.py:99-115, 141-149: log per sample, mean over the samples whose loss exceeds `loss_threshold`;
         per-GPU batch 1 or 2, see fqss_kd_loss_per_sample); "l1_sdr" = the htdemucs solver's
@@ -374,8 +374,17 @@ class KDTrainStep:
         gradient all-reduce of a finished segment overlaps the next segment's backward (default 4; 1 = one all-reduce after the
         whole backward).  sync_observer_ranges (world > 1): average the activation ranges over the ranks once, when the 50-call
         observer phase ends -- a documented deviation: the reference's DDP never re-synchronises the
-        observer's .data writes (qat_quant.py:230-232), so its replicas quantize on different grids from then on."""
+        observer's .data writes (qat_quant.py:230-232), so its replicas quantize on different grids from then on.
+        teacher_ahead: the frozen teacher's forward of the NEXT batch (`step(x, tgt, x_next=...)`) runs on the teacher stream beside
+        this whole step -- forward AND backward -- instead of beside the student's forward only: it depends on nothing the step
+        changes (mysystem.py:132-133 runs it under no_grad on the raw mixture), so a loader that knows the next batch can hide it
+        behind the student's VALU / HBM-bound kernels.  Still one teacher forward per step; the step that finds no look-ahead
+        result for its mixture (the first one, or a caller that did not announce it) runs the teacher beside its own forward as
+        before.  Same values either way (tests/test_gpu_kdstep_path.py)."""
         self.model, self.fmodel = model, fmodel
+        self.teacher_ahead = bool(teacher_ahead)
+        self._ahead = None          # (mixture tensor, its version, teacher output) announced by the previous step
+        self._tgraph = None         # captured teacher forward (teacher_ahead + hipGraph replay)
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
         if loss not in ("sisdr_pit", "sisdr_pit_per_sample", "l1_sdr"):
             raise ValueError(f"unknown loss {loss!r}")
@@ -457,8 +466,16 @@ class KDTrainStep:
             self._graphs = None          # a batch of another shape: back to eager launches
 
     # ---- the two halves of a step -----------------------------------------------------------
-    def _forward_loss(self, x, tgt):
-        """zero the gradient arenas, weight fake-quants, student + teacher forward, loss and dloss/dest -> (res, est, gest, cuts)"""
+    def _take_ahead(self, x):
+        """the teacher output the previous step computed for exactly this mixture tensor, or None"""
+        ah, self._ahead = self._ahead, None
+        if ah is not None and ah[0] is x and ah[1] == x._version:
+            return ah[2]
+        return None
+
+    def _forward_loss(self, x, tgt, x_next=None, fest_given=None, join_teacher=True):
+        """zero the gradient arenas, weight fake-quants, student + teacher forward, loss and dloss/dest -> (res, est, gest, cuts).
+        fest_given: the teacher's output for x, already computed (look-ahead); x_next: start the teacher on the next mixture now"""
         a = self.arena
         a.zero_grad()
         t = self._quant_tables()
@@ -470,14 +487,28 @@ class KDTrainStep:
         # branch of the graph) and joins before the loss.
         cur = torch.cuda.current_stream()
         teacher_free = self.loss_kind != "l1_sdr" and not self.kd_lambda > 0        # kd_lambda = 0: plain PIT SI-SDR loss, no teacher
+        ahead = fest_given is not None
         if teacher_free:
             fest = None
+        elif ahead:
+            fest = fest_given
+            if self._tstream is not None and join_teacher:      # computed on the teacher stream during the previous step (joined BEFORE the next look-ahead is enqueued there)
+                cur.wait_stream(self._tstream)
+                fest.record_stream(cur)
         elif TEACHER_STREAM:
             if self._tstream is None:
                 self._tstream = torch.cuda.Stream()
             self._tstream.wait_stream(cur)
             with torch.cuda.stream(self._tstream):
                 fest = self.teacher(x)
+        if x_next is not None and not teacher_free:
+            # look-ahead: the next step's teacher forward, enqueued behind this step's own (if any) on the teacher stream; nothing in
+            # this step waits for it -- the step that consumes it does
+            if self._tstream is None:
+                self._tstream = torch.cuda.Stream()
+            self._tstream.wait_stream(cur)
+            with torch.cuda.stream(self._tstream):
+                self._ahead = (x_next, x_next._version, self.teacher(x_next))
         cuts = []
         with ops.fast_codes(self.fast), ops.coded_dataflow(self.coded), ops.deferred(t):   # student: codes-only dataflow between quantizing layers
             if self.segments is not None:
@@ -485,7 +516,7 @@ class KDTrainStep:
                     est = self.model(x)
             else:
                 est = self.model(x)
-        if teacher_free:
+        if teacher_free or ahead:
             pass
         elif TEACHER_STREAM:
             cur.wait_stream(self._tstream)
@@ -524,9 +555,9 @@ class KDTrainStep:
         if t is not None:
             t.finish_backward(None if nseg == 1 else nseg - 1 - k)     # weight STE + range/slope gradients of this segment
 
-    def _fwd_bwd(self, x, tgt):
+    def _fwd_bwd(self, x, tgt, x_next=None, fest_given=None):
         """fwd + loss + the whole backward, no exchange (single rank; tests)"""
-        res, est, gest, cuts = self._forward_loss(x, tgt)
+        res, est, gest, cuts = self._forward_loss(x, tgt, x_next, fest_given)
         for k in range(self._nseg(cuts)):
             self._backward_segment(k, est, gest, cuts)
         return res
@@ -579,10 +610,11 @@ class KDTrainStep:
             self.comm.sync_observer_ranges(self.model)
             self._ranges_synced = True
 
-    def _step_eager(self, x, tgt):
+    def _step_eager(self, x, tgt, x_next=None):
         """fwd + loss, then per backward segment: backward -> all-reduce of its gradient slice on the communication stream, which
         overlaps the next segment's backward; the optimizer waits for the last exchange"""
-        res, est, gest, cuts = self._forward_loss(x, tgt)
+        fest = self._take_ahead(x) if self.teacher_ahead else None
+        res, est, gest, cuts = self._forward_loss(x, tgt, x_next if self.teacher_ahead else None, fest)
         nseg = self._nseg(cuts)
         for k in range(nseg):
             self._backward_segment(k, est, gest, cuts)
@@ -590,11 +622,12 @@ class KDTrainStep:
         self._join_reduces()
         return res
 
-    def __call__(self, x, tgt):
+    def __call__(self, x, tgt, x_next=None):
+        """x_next (teacher_ahead=True only): the mixture tensor the NEXT call will be given -- the same tensor object, unmodified"""
         self._maybe_sync_ranges()
         if self._graphs is not None and self.use_graph:
-            return self.replay(x, tgt)
-        self.last = self._step_eager(x, tgt)
+            return self.replay(x, tgt, x_next)
+        self.last = self._step_eager(x, tgt, x_next)
         self._optimize()
         if self.tables is not None or (not self.batched_quantizers and self.can_capture()):
             self._eager_q += 1
@@ -624,9 +657,25 @@ class KDTrainStep:
         # (at world > 1 the process group's watchdog thread polls its events while this thread captures: only THIS thread's calls are
         # checked against the capture then -- torch's default mode lets a query from any thread invalidate it)
         mode = dict(capture_error_mode="thread_local") if self._world() > 1 else {}
+        # teacher_ahead: the teacher's forward is a graph of its OWN (own memory pool: it replays on the teacher stream WHILE the step's
+        # graphs replay) from the static look-ahead mixture _sxn into _fest_next; the step's graphs read the static copy _fest_cur
+        fest_cur = None
+        self._tgraph = None
+        self._ahead_key = None
+        if self.teacher_ahead and (self.loss_kind == "l1_sdr" or self.kd_lambda > 0):
+            if self._tstream is None:
+                self._tstream = torch.cuda.Stream()
+            self._sxn = x.clone()
+            tg = torch.cuda.CUDAGraph()
+            self._tstream.wait_stream(cur)
+            with torch.cuda.graph(tg, stream=self._tstream, **mode):
+                self._fest_next = self.teacher(self._sxn)
+            cur.wait_stream(self._tstream)
+            self._fest_cur = fest_cur = torch.empty_like(self._fest_next)
+            self._tgraph = tg
         graphs = [torch.cuda.CUDAGraph()]
         with torch.cuda.graph(graphs[0], **mode):
-            self.last, est, gest, cuts = self._forward_loss(self._sx, self._st)
+            self.last, est, gest, cuts = self._forward_loss(self._sx, self._st, None, fest_cur, False)
             self._backward_segment(0, est, gest, cuts)
         for k in range(1, self._nseg(cuts)):
             gk = torch.cuda.CUDAGraph()
@@ -644,18 +693,51 @@ class KDTrainStep:
         if self._world() == 1 and len(graphs) == 1 and os.environ.get("FQSS_ONE_GRAPH", "1") != "0":
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=graphs[0].pool()):
-                self.last_all, est, gest, cuts = self._forward_loss(self._sx, self._st)
+                self.last_all, est, gest, cuts = self._forward_loss(self._sx, self._st, None, fest_cur, False)
                 self._backward_segment(0, est, gest, cuts)
                 self._optimize(activate=False)
             self._graph_all = ga
             del est, gest, cuts
         return self
 
-    def replay_fwd_bwd(self, x=None, tgt=None):
-        """first half of a captured step (fwd + loss + bwd, gradients exchanged); the caller then calls replay_optimize() or skips"""
+    def _stage(self, x, tgt, x_next):
+        """inputs of a replay into the static buffers; teacher_ahead: hand the teacher output of this mixture (the previous replay's
+        look-ahead, or a teacher replay right now if nobody announced the mixture) to the step's graphs, then start the teacher graph
+        on the next mixture on the teacher stream"""
+        if self._tgraph is None:
+            if x is not None and x.data_ptr() != self._sx.data_ptr():
+                self._sx.copy_(x)
+                self._st.copy_(tgt)
+            return
+        cur, ts = torch.cuda.current_stream(), self._tstream
+        src = self._sx if x is None else x
+        key = self._ahead_key
+        if not (key is not None and key[0] is src and key[1] == src._version):
+            eager = self._take_ahead(src)          # an eager step (before the capture) may have looked ahead for this mixture
+            ts.wait_stream(cur)
+            with torch.cuda.stream(ts):
+                if eager is not None:
+                    self._fest_next.copy_(eager)
+                else:
+                    if src.data_ptr() != self._sxn.data_ptr():
+                        self._sxn.copy_(src)
+                    self._tgraph.replay()
+        cur.wait_stream(ts)
+        self._fest_cur.copy_(self._fest_next)
         if x is not None and x.data_ptr() != self._sx.data_ptr():
             self._sx.copy_(x)
             self._st.copy_(tgt)
+        self._ahead_key = None
+        if x_next is not None:
+            self._sxn.copy_(x_next)
+            ts.wait_stream(cur)
+            with torch.cuda.stream(ts):
+                self._tgraph.replay()
+            self._ahead_key = (x_next, x_next._version)
+
+    def replay_fwd_bwd(self, x=None, tgt=None, x_next=None):
+        """first half of a captured step (fwd + loss + bwd, gradients exchanged); the caller then calls replay_optimize() or skips"""
+        self._stage(x, tgt, x_next)
         graphs = self._graphs[0]
         for k, gk in enumerate(graphs):
             gk.replay()
@@ -667,15 +749,13 @@ class KDTrainStep:
         self.arena._host_step += 1
         self._graphs[1].replay()
 
-    def replay(self, x=None, tgt=None):
+    def replay(self, x=None, tgt=None, x_next=None):
         if getattr(self, "_graph_all", None) is not None:
-            if x is not None and x.data_ptr() != self._sx.data_ptr():
-                self._sx.copy_(x)
-                self._st.copy_(tgt)
+            self._stage(x, tgt, x_next)
             self.arena._host_step += 1
             self._graph_all.replay()
             return self.last_all
-        self.replay_fwd_bwd(x, tgt)
+        self.replay_fwd_bwd(x, tgt, x_next)
         self.replay_optimize()
         return self.last
 
