@@ -59,27 +59,43 @@ def dominant_kernel_roofline(dev, ms_step):
     cases = RC.build(dev)
     times = [RC.time_case(c) for c in cases]
     groups = RC.summarize(cases, times)
-    pmc = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            pmc = json.load(f).get("per_launch_bytes", {})
-    except (OSError, ValueError):
-        pmc = {}
+    pmc, pmc_file = {}, None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc, pmc_file = json.load(f).get("per_launch_bytes", {}), "profiles/" + name
+            break
+        except (OSError, ValueError):
+            continue
+
+    # bf16 MFMA products ISSUED per fp32-grade product (the exact-split contract): teacher 6 (3 x 3 split, 6 leading terms), gradient
+    # GEMMs 3 (fp32 gradient in three exact pieces x 8-bit codes), forward 1 (codes x codes); priced against the dense bf16 peak
+    issued = {"k_tgemm<0>": 6, "k_tgemm<1>": 6, "k_qgemm<1>": 3, "k_qwgrad2": 3, "k_qgemm<0>": 1}
 
     def obj(g, shapes):
         t = pmc.get(g["kernel"])
         o = RC.roofline_object(g, traffic=t["x2"] if t else None)
         o["traffic_x1"] = t["x1"] if t else None
+        if g["kernel"] in issued and g["flops"] > 0:
+            tf = issued[g["kernel"]] * g["flops"] / g["launches"] / (g["ms_step"] / g["launches"] * 1e-3) / 1e12
+            o["issued_bf16_TFLOPs"] = round(tf, 1)
+            o["frac_of_issued_peak"] = round(tf / 2500.0, 4)       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
         if not shapes:
             o.pop("shapes")
         return o
     singles = [g for g in groups if not g["group"]]
     dom = obj(singles[0], True)
+    near = [g["kernel"] for g in singles[1:] if g["ms_step"] >= 0.97 * singles[0]["ms_step"]]
+    if near:
+        dom["tie_break"] = ("single kernels within 3 % of the largest time per step: " + ", ".join(near) +
+                            "; the one with the largest isolated time in THIS run is reported")
     others = [obj(g, False) for g in groups if g is not singles[0]]
+    missing = [g["kernel"] for g in groups if g["kernel"] not in pmc]
     step_bytes = RC.step_traffic_bytes(cases)
     step = {"step_traffic_GB": round(step_bytes / 1e9, 2),
             "step_traffic_frac_of_hbm_peak": round(step_bytes / (ms_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
-            "isolated_kernel_ms_sum": round(sum(g["ms_step"] for g in groups), 3)}
+            "isolated_kernel_ms_sum": round(sum(g["ms_step"] for g in groups), 3),
+            "pmc_source": pmc_file, "pmc_missing_kernels": missing}
     return dom, others, step
 
 

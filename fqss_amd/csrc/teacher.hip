@@ -69,6 +69,12 @@ __global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__
     }
 }
 
+// FQSS_TDIAG (diagnostic builds only, tools/r03_bisect.sh; default 0 = the product): bit 0 no MFMAs | 1 plain ds_read_b64 instead of the
+// transposed reads | 2 no LDS stores of the staged tiles | 3 no global loads in the main loop | 4 no epilogue (results are then garbage:
+// these builds only serve as the AGGRESSOR of tools/ubench/pkadd_next_to_mfma.hip)
+#ifndef FQSS_TDIAG
+#define FQSS_TDIAG 0
+#endif
 typedef float f32x4t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
 struct TStage {          // one k-tile of global loads per thread: 3 planes x 2 x 16 B of the weight, 4 x 16 B of activations
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     const int a_row_c = min(i0 + a_row, g.M - 1);
     const int n_last = (g.N - 1) & ~3;
     auto load_tiles = [&](TStage& st, int k0) {
+        if (FQSS_TDIAG & 8) return;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     };
     auto store_tiles = [&](TStage& st, int k0) {
         t_wait<10>(st);   // this stage has landed; the 10 younger requests of the other stage stay in flight
+        if (FQSS_TDIAG & 4) return;
         const int kc = min(k0 + bk_row, g.K - 1);
         const float p_a = (PRO == 1) ? pco[0][kc] : 1.f, p_b = (PRO == 1) ? pco[1][kc] : 0.f;
 #pragma unroll
@@ -232,8 +240,13 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
                     const int kr = ks * 16 + 8 * (gq >> 1) + tq;
                     const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
                     union { bf16x8 v; s16x4 h[2]; } u;
-                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
-                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                    if (FQSS_TDIAG & 2) {
+                        u.h[0] = *reinterpret_cast<const s16x4*>(&Bs[p][kr][nc]);
+                        u.h[1] = *reinterpret_cast<const s16x4*>(&Bs[p][kr + 4][nc]);
+                    } else {
+                        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
+                        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                    }
                     bfr[p][ni] = u.v;
                 }
             }
@@ -246,7 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[mi][ni], 0, 0, 0);
+                        if (!(FQSS_TDIAG & 1)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[mi][ni], 0, 0, 0);
+                        else acc[mi][ni][sp] += (float)af[IA[sp]][mi][0] + (float)bfr[IB[sp]][ni][0];      // keeps the fragment reads alive
         }
     };
 
@@ -279,6 +293,10 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     // from here on: drain them before anything else is allocated there
     t_wait<0>(stA);
     t_wait<0>(stB);
+    if (FQSS_TDIAG & 16) {      // no epilogue: one store keeps the accumulators alive
+        if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.678f) g.C1[0] = 1.0f;
+        return;
+    }
     // (every wave has passed the barrier behind the last tile's fragment reads: the tile buffer is free)
     if (tid < TBM) rowb[tid] = (g.bias != nullptr && i0 + tid < g.M) ? g.bias[i0 + tid] : 0.0f;
     __syncthreads();

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Convergence fixture (north_star "SI-SDR within 0.1 dB of the reference"): the REAL reference
+(/root/reference, imported through tools/ref_shim.py -- build container only) trains the tiny ConvTasNetQ of tiny_step.npz with
+the KD step of mysystem.py:124-151 (Adam 1e-3, clip 5.0) over a STREAM of never-repeating seeded batches
+(fqss_amd.data.synth_batch_2band: two spectrally distinct speakers), N_STEPS steps, under several CPU configurations that only
+change the fp32 summation order (threads 1 / 8, mkldnn on / off).  Stored: per-step loss and mean student SI-SDR of every run,
+and the reference's OWN spread between those runs over the last 50 steps -- the floor any other backend is compared against.
+    python tools/make_goldens_long.py            -> tests/golden/tiny_train_long.npz"""
+import copy
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import make_goldens as MG  # noqa: E402  (installs the shim, imports the reference)
+
+import torch  # noqa: E402
+
+from fqss_amd.data import synth_batch_2band  # noqa: E402  (data generator only: no kernels)
+
+N_STEPS, B, T, SEED0 = 400, 4, 1600, 5000
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def run(threads, mkldnn):
+    g = np.load(os.path.join(GOLD, "tiny_step.npz"))
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    kw = dict(n_spks=2, kernel_size=16, stride=8, n_filters=32, bn_chan=16, hid_chan=32, n_blocks=2, n_repeats=1)
+    model = MG.ConvTasNetQ(**kw)
+    fmodel = copy.deepcopy(model)
+    model = MG.quantize_model(model, MG.QCFG)
+    model.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0.")})
+    fmodel.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fsd.")})
+    model.train(); fmodel.eval()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss_t, sdr_t, tsdr_t = [], [], []
+    with torch.backends.mkldnn.flags(enabled=mkldnn):
+        for step in range(N_STEPS):
+            x, tgt = synth_batch_2band(B, T, seed=SEED0 + step)
+            opt.zero_grad()
+            est, fest, w, kd, task, loss, sdrs, sdrqs = MG.common_step(model, fmodel, x, tgt)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            loss_t.append(float(loss)); sdr_t.append(float(-sdrqs.mean())); tsdr_t.append(float(-sdrs.mean()))
+            if step % 50 == 0 or step == N_STEPS - 1:
+                print(f"threads {threads} mkldnn {mkldnn} step {step} loss {float(loss):.3f} si-sdr {sdr_t[-1]:.3f} (teacher {tsdr_t[-1]:.3f})", flush=True)
+    return np.array(loss_t, np.float32), np.array(sdr_t, np.float32), np.array(tsdr_t, np.float32)
+
+
+def main():
+    variants = [(1, True), (8, True), (1, False), (4, False)]
+    d = dict(n_steps=np.int64(N_STEPS), batch=np.int64(B), samples=np.int64(T), seed0=np.int64(SEED0),
+             variants=np.array([f"threads={t},mkldnn={m}" for t, m in variants]))
+    L, S = [], []
+    for t, m in variants:
+        lo, sd, ts = run(t, m)
+        L.append(lo); S.append(sd)
+        d["teacher_sisdr"] = ts
+    d["loss"], d["sisdr"] = np.stack(L), np.stack(S)
+    tail = d["sisdr"][:, -50:].mean(1)
+    d["tail_sisdr"] = tail
+    d["spread_db"] = np.float32(tail.max() - tail.min())
+    d["tail_loss"] = d["loss"][:, -50:].mean(1)
+    print("last-50 mean SI-SDR per variant", tail, "spread", d["spread_db"], "first-50", d["sisdr"][:, :50].mean(1))
+    np.savez_compressed(os.path.join(GOLD, "tiny_train_long.npz"), **d)
+
+
+if __name__ == "__main__":
+    main()

@@ -36,10 +36,17 @@ def run():
 
 
 def _members(kernel):
-    """kernel-name substrings of a case's launches, in launch order"""
+    """kernel SYMBOLS (the name up to its template arguments) of a case's launches, in launch order.  The manifest names carry the
+    template arguments that matter for reading the table ("k_qgemm<1>"); the profiler prints the full instantiation
+    ("fqss::k_qgemm<1, 3>(...)"), so the match is on the symbol, bounded on both sides ("k_qwgrad" must not match "k_qwgrad2")"""
     if kernel.startswith("k_gnq_bwd_rows+apply"):
         return ["k_gnq_bwd_rows", "k_gnq_bwd_apply"]
-    return [kernel.split("<")[0] if kernel.startswith(("k_dwq", "k_tgemm")) else kernel]
+    return [kernel.split("<")[0]]
+
+
+def _is(symbol, name):
+    i = name.find("fqss::" + symbol)
+    return i >= 0 and name[i + 6 + len(symbol):i + 7 + len(symbol)] in ("<", "(", "")
 
 
 def _sequence(path, counter):
@@ -53,22 +60,25 @@ def _sequence(path, counter):
 
 
 def _assign(rows, manifest):
-    """consume the dispatch sequence case by case (the probe launches the cases in manifest order): KiB per invocation"""
+    """consume the dispatch sequence case by case (the probe launches the cases in manifest order): KiB per invocation.  A case whose
+    kernels are not found where the manifest says they were launched is an ERROR (round 2 lost 11 of 15 kernels silently here)"""
     out, pos = [], 0
     for m in manifest:
         mem = _members(m["kernel"])
         vals = []
-        for _ in range(m["iters"]):
-            tot, k = 0.0, 0
-            while pos < len(rows) and k < len(mem):
-                _, name, v = rows[pos]
-                pos += 1
-                if mem[k] in name:
-                    tot += v
-                    k += 1
-            if k == len(mem):
-                vals.append(tot)
-        out.append(sum(vals) / len(vals) if vals else None)
+        for it in range(m["iters"]):
+            tot = 0.0
+            for sym in mem:
+                q = pos
+                while q < len(rows) and not _is(sym, rows[q][1]):
+                    q += 1
+                if q == len(rows):
+                    raise SystemExit(f"roofline_probe --reduce: no dispatch of fqss::{sym} for case {m['label']!r} (launch {it} of {m['iters']}); "
+                                     f"next dispatches: {[r[1][:60] for r in rows[pos:pos + 4]]}")
+                tot += rows[q][2]
+                pos = q + 1
+            vals.append(tot)
+        out.append(sum(vals) / len(vals))
     return out
 
 

@@ -39,25 +39,18 @@ def main(argv=()):
     pz2 = K.empty_act((B, S * C, M), dev); pz2.normal_(generator=g)
     pga = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev)
     # platform probe (tools/ubench/longsum.hip, built on the spot): per-lane accumulators that live as long as the kernel, nothing shared
-    import ctypes, subprocess
+    import ctypes
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    so = os.path.join(root, "gpurun_out", "liblongsum.so")
-    os.makedirs(os.path.dirname(so), exist_ok=True)
-    probe = None
-    try:
-        src = os.path.join(root, "tools", "ubench", "longsum.hip")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so,
-                                   os.path.join(root, "tools", "ubench", "longsum.hip")])
-        lib = ctypes.CDLL(so)
-        lib.probe_longsum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        def probe(blocks=2048, rounds=1):
-            o = torch.empty(blocks * 256 * 3, device=dev)
-            lib.probe_longsum(xbig.data_ptr(), o.data_ptr(), xbig.numel(), blocks, rounds,
-                              torch.cuda.current_stream().cuda_stream)
-            return o
-    except Exception as e:      # no compiler on this machine: the probe is skipped
-        print("longsum probe unavailable:", e)
+    so = os.path.join(root, "tools", "ubench", "liblongsum.so")       # built by __graft_entry__.build() (make -C tools/ubench)
+    if not os.path.exists(so):
+        raise RuntimeError(f"{so} missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    lib = ctypes.CDLL(so)
+    lib.probe_longsum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+    def probe(blocks=2048, rounds=1):
+        o = torch.empty(blocks * 256 * 3, device=dev)
+        lib.probe_longsum(xbig.data_ptr(), o.data_ptr(), xbig.numel(), blocks, rounds, torch.cuda.current_stream().cuda_stream)
+        return o
     xbig = torch.randn(32 * 1024 * 1024, device=dev, generator=g)
     CASES = {
         "dwq_bwd": lambda: K.dwq_bwd(codes1, lo, hi, w_dw, b_dw, act1, 4, 4, 1, slope, lo, hi, gacc, gbb, gw_dw),
