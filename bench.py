@@ -451,6 +451,8 @@ def main():
     assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
 
     step(x, tgt)                       # first quantizing step, eager (starts the activation ranges' Adam clocks)
+    if os.environ.get("FQSS_MAIN_PRIO"):      # experiment knob: the step's own stream at a higher priority than the teacher's
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["FQSS_MAIN_PRIO"])))
     launch = "eager"
     if not a.no_graph:
         step.capture(x, tgt)           # whole step -> hipGraphs; every later call is a replay

@@ -14,6 +14,8 @@
 // (v_mfma_f32_32x32x16_bf16) -- the result is fp32-grade (same error class as an fp32 fma chain).
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -545,9 +547,22 @@ extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci,
     g.C2 = c2; g.R2 = r2; g.ldc2 = ld_c2; g.sC2b = (int64_t)(Co - M1) * ld_c2;
     g.tiles_n = (int)cdiv(M, TBN); g.tiles_m = (int)cdiv(Co, TBM); g.batches = B;
     const dim3 grid(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m));
-    if (pro == 0) hipLaunchKernelGGL(k_tgemm<0>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else if (pro == 1) hipLaunchKernelGGL(k_tgemm<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(k_tgemm<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    // FQSS_TGEMM_PAD_LDS=<bytes> (experiment knob, read once): unused dynamic LDS that caps the workgroups per CU -- with > 16 KB on top
+    // of the 60-64 KB tile buffer only ONE teacher workgroup fits a CU, which leaves half of every SIMD's registers to the student's
+    // waves when the teacher runs on its own stream beside the step
+    static const size_t pad = [] {
+        const char* e = getenv("FQSS_TGEMM_PAD_LDS");
+        const size_t v = e ? (size_t)atol(e) : 0;
+        if (v) {
+            hipFuncSetAttribute((const void*)k_tgemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+            hipFuncSetAttribute((const void*)k_tgemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+            hipFuncSetAttribute((const void*)k_tgemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+        }
+        return v;
+    }();
+    if (pro == 0) hipLaunchKernelGGL(k_tgemm<0>, grid, dim3(256), pad, (hipStream_t)stream, g);
+    else if (pro == 1) hipLaunchKernelGGL(k_tgemm<1>, grid, dim3(256), pad, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(k_tgemm<2>, grid, dim3(256), pad, (hipStream_t)stream, g);
     return launch_status("fqss_tgemm");
 }
 

@@ -71,6 +71,11 @@ class ParamArena:
 
 
 TEACHER_STREAM = os.environ.get("FQSS_TEACHER_STREAM", "1") != "0"
+TEACHER_PRIO = int(os.environ.get("FQSS_TEACHER_PRIO", "0"))        # experiment knob: priority of the teacher stream (0 = default / lowest)
+
+
+def _teacher_stream():
+    return torch.cuda.Stream(priority=TEACHER_PRIO)
 
 
 class TeacherRunner:
@@ -497,7 +502,7 @@ class KDTrainStep:
                 fest.record_stream(cur)
         elif TEACHER_STREAM:
             if self._tstream is None:
-                self._tstream = torch.cuda.Stream()
+                self._tstream = _teacher_stream()
             self._tstream.wait_stream(cur)
             with torch.cuda.stream(self._tstream):
                 fest = self.teacher(x)
@@ -505,7 +510,7 @@ class KDTrainStep:
             # look-ahead: the next step's teacher forward, enqueued behind this step's own (if any) on the teacher stream; nothing in
             # this step waits for it -- the step that consumes it does
             if self._tstream is None:
-                self._tstream = torch.cuda.Stream()
+                self._tstream = _teacher_stream()
             self._tstream.wait_stream(cur)
             with torch.cuda.stream(self._tstream):
                 self._ahead = (x_next, x_next._version, self.teacher(x_next))
@@ -664,7 +669,7 @@ class KDTrainStep:
         self._ahead_key = None
         if self.teacher_ahead and (self.loss_kind == "l1_sdr" or self.kd_lambda > 0):
             if self._tstream is None:
-                self._tstream = torch.cuda.Stream()
+                self._tstream = _teacher_stream()
             self._sxn = x.clone()
             tg = torch.cuda.CUDAGraph()
             self._tstream.wait_stream(cur)

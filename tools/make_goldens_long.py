@@ -24,22 +24,35 @@ N_STEPS, B, T, SEED0 = 400, 4, 1600, 5000
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
-def run(threads, mkldnn):
-    g = np.load(os.path.join(GOLD, "tiny_step.npz"))
-    torch.set_num_threads(threads)
+def build(which):
+    """(student, teacher, lr) from the initial weights of the model family's tiny step fixture"""
     torch.manual_seed(0)
-    kw = dict(n_spks=2, kernel_size=16, stride=8, n_filters=32, bn_chan=16, hid_chan=32, n_blocks=2, n_repeats=1)
-    model = MG.ConvTasNetQ(**kw)
+    if which == "convtasnet":
+        g = np.load(os.path.join(GOLD, "tiny_step.npz"))
+        kw = dict(n_spks=2, kernel_size=16, stride=8, n_filters=32, bn_chan=16, hid_chan=32, n_blocks=2, n_repeats=1)
+        model, lr = MG.ConvTasNetQ(**kw), 1e-3
+    else:
+        import make_goldens_dptnet as MD
+        g = np.load(os.path.join(GOLD, "dpt_tiny_step.npz"))
+        model, lr = MD.RD.DPTNetQ(**MD.TINY_KW), 4e-4
     fmodel = copy.deepcopy(model)
     model = MG.quantize_model(model, MG.QCFG)
     model.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0.")})
     fmodel.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fsd.")})
     model.train(); fmodel.eval()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    return model, fmodel, lr
+
+
+def run(threads, mkldnn, which="convtasnet", N_STEPS=N_STEPS, B=B, T=T):
+    torch.set_num_threads(threads)
+    model, fmodel, lr = build(which)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
     loss_t, sdr_t, tsdr_t = [], [], []
     with torch.backends.mkldnn.flags(enabled=mkldnn):
         for step in range(N_STEPS):
             x, tgt = synth_batch_2band(B, T, seed=SEED0 + step)
+            if which != "convtasnet":
+                x = x
             opt.zero_grad()
             est, fest, w, kd, task, loss, sdrs, sdrqs = MG.common_step(model, fmodel, x, tgt)
             loss.backward()
@@ -51,13 +64,13 @@ def run(threads, mkldnn):
     return np.array(loss_t, np.float32), np.array(sdr_t, np.float32), np.array(tsdr_t, np.float32)
 
 
-def main():
+def main(which="convtasnet", n_steps=N_STEPS, batch=B, samples=T, fname="tiny_train_long.npz"):
     variants = [(1, True), (8, True), (1, False), (4, False)]
-    d = dict(n_steps=np.int64(N_STEPS), batch=np.int64(B), samples=np.int64(T), seed0=np.int64(SEED0),
+    d = dict(n_steps=np.int64(n_steps), batch=np.int64(batch), samples=np.int64(samples), seed0=np.int64(SEED0),
              variants=np.array([f"threads={t},mkldnn={m}" for t, m in variants]))
     L, S = [], []
     for t, m in variants:
-        lo, sd, ts = run(t, m)
+        lo, sd, ts = run(t, m, which, n_steps, batch, samples)
         L.append(lo); S.append(sd)
         d["teacher_sisdr"] = ts
     d["loss"], d["sisdr"] = np.stack(L), np.stack(S)
@@ -66,8 +79,11 @@ def main():
     d["spread_db"] = np.float32(tail.max() - tail.min())
     d["tail_loss"] = d["loss"][:, -50:].mean(1)
     print("last-50 mean SI-SDR per variant", tail, "spread", d["spread_db"], "first-50", d["sisdr"][:, :50].mean(1))
-    np.savez_compressed(os.path.join(GOLD, "tiny_train_long.npz"), **d)
+    np.savez_compressed(os.path.join(GOLD, fname), **d)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "dptnet":      # reduced length: the reference's LSTM / attention layers are slow on the CPU
+        main("dptnet", 160, 2, 400, "dpt_train_long.npz")
+    else:
+        main()

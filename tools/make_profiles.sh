@@ -2,7 +2,7 @@
 # Regenerates the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root); summaries land in gpurun_out/.
 # Counters are collected in their own passes (never combined with trace domains).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf $O && mkdir -p $O
