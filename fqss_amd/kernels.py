@@ -59,7 +59,9 @@ def rowmat(t):
             return None
         rows *= n
     if ld is None:
-        ld = max(cols, 1)
+        # a single row: any row stride >= cols describes it; keep the buffer's own (padded, 16-B aligned) one when the tensor is a view
+        # of a padded buffer -- the C side checks row alignment even for one row (a [1, 1, M] output of the tiny HTDemucs's DConv)
+        ld = t.stride(-2) if t.dim() >= 2 and t.stride(-2) >= cols else max(cols, 1)
     return rows, cols, ld
 
 

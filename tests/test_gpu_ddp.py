@@ -34,21 +34,22 @@ def _run_ranks(tmp_path, scenario, world=2):
     return [torch.load(o, weights_only=False) for o in outs]
 
 
-@pytest.mark.parametrize("scenario", ["step_eager", "step_graph"])
-def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(golden, tmp_path, scenario):
+@pytest.mark.parametrize("scenario", ["step_eager", "step_graph", "step_graph:dptnet", "step_graph:sepformer", "step_graph:htdemucs"])
+def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(tmp_path, scenario):
+    """ConvTasNet (2 buckets, eager and replay) and the DDP configurations themselves -- cfg 4 `speechbrain_librimix_trainer.py:592`,
+    cfg 5 `htdemucs_musdbhq/distrib.py:51-59` (find_unused_parameters=True), cfg 3 for the dual-path LSTM family: 3-4 gradient
+    buckets through capture + replay, the grad-less MHA range parameters of SURVEY A.2 Q1 (zeros in the flat buffer, skipped by
+    Adam), the per-sample objective of the speechbrain env, the l1_sdr loss without clipping."""
     from fqss_amd import ops
     from fqss_amd.runtime import KDTrainStep
-    from tests.ddp_worker import shard
-    from tests.test_gpu_model import T, _leave_observer, _tiny_pair
+    from tests.ddp_worker import family, shard
     ranks = _run_ranks(tmp_path, scenario)
-    g = golden("tiny_step")
-    x, tgt = T(g["x"]).cuda(), T(g["tgt"]).cuda()
+    fam = scenario.split(":")[1] if ":" in scenario else "convtasnet"
+    model, fmodel, x, tgt, kw, nb = family(fam)
     shards = [shard(x, tgt, r, 2) for r in range(2)]
     # 1-rank reference: per step, the gradients of every shard (each with its own input normalisation and loss), averaged, then ONE
     # clip + Adam -- 1/world enters as the gradient scale exactly as it does on the ranks
-    model, fmodel = _tiny_pair(g, prefix="s50.post_sd.")
-    _leave_observer(model)
-    ref = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0)
+    ref = KDTrainStep(model, fmodel, **kw)
     losses = [[], []]
     with ops.poison_carriers(True):
         for _ in range(3):
@@ -59,16 +60,60 @@ def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(golden, tm
             ref.arena.flat_g.copy_(gsum)
             ref.arena.clip_adam_step(ref.lr, ref.clip, grad_scale=0.5)
     want = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    print(scenario, "gradient buckets (bytes):", ranks[0]["bucket_bytes"], "losses", ranks[0]["losses"], losses[0])
+    assert 2 <= len(ranks[0]["bucket_bytes"]) <= nb
     for r in range(2):
         # step 1 starts from identical state: same loss to fp32 noise; later steps feel the (chaotic) quantized forward of updated weights
-        np.testing.assert_allclose(ranks[r]["losses"][0], losses[r][0], rtol=1e-6)
-        np.testing.assert_allclose(ranks[r]["losses"], losses[r], atol=0.05)
+        np.testing.assert_allclose(ranks[r]["losses"][0], losses[r][0], rtol=2e-6)
+        # (tiny DPTNet / Sepformer / HTDemucs: a handful of flipped bins move a later loss by a few tenths of a dB -- the B1 gates)
+        np.testing.assert_allclose(ranks[r]["losses"], losses[r], atol=0.05 if fam == "convtasnet" else 0.3, rtol=1e-2 if fam != "htdemucs" else 5e-2)
+    lr = kw["lr"]
+    unused, worst, n_off, n_all = 0, 0.0, 0, 1
     for k, v in want.items():
         a, b = ranks[0]["params"][k], ranks[1]["params"][k]
         assert torch.equal(a, b), k                                        # the replicas stay bit-identical to each other
         # Adam moves a parameter by ~lr per step: fp32-noise-level gradient differences (atomics order) stay far below that
-        assert float((a - v).abs().max()) <= 3e-4 + 1e-3 * float(v.abs().max()), (k, float((a - v).abs().max()))
-    assert abs(ranks[0]["gnorm"] - ref.arena.gnorm.item()) <= 1e-2 * ref.arena.gnorm.item()
+        d, tol = (a - v).abs(), 0.3 * lr + 1e-3 * float(v.abs().max())
+        if fam == "convtasnet":
+            assert float(d.max()) <= tol, (k, float(d.max()))
+        else:
+            # deeper / attention networks: a gradient element at the fp32-noise level may take the other sign in the segmented run,
+            # and Adam turns a sign into +-lr per step -- rare elements, bounded by the three steps taken
+            worst = max(worst, float(d.max()) / lr)
+            n_off += int((d > tol).sum())
+            n_all += d.numel()
+            assert float(d.max()) <= 6.5 * lr + 1e-3 * float(v.abs().max()), (k, float(d.max()))
+    print(scenario, "parameters off by more than 0.3 lr:", n_off, "of", n_all, "worst", worst, "lr")
+    assert n_off <= 0.01 * n_all, (n_off, n_all)
+    if fam in ("dptnet", "sepformer"):
+        # the attention core's `attn` / `softmax` quantizers only observe, their ranges never receive a gradient
+        for k, p in model.named_parameters():
+            if ("fake_quantize_attn" in k or "fake_quantize_softmax" in k) and k.endswith("_range"):
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                unused += 1
+        assert unused >= 8
+    if kw["clip"] > 0:      # (the norm of the THIRD step's gradient: behind two updates of a chaotic quantized net for the deeper families)
+        assert abs(ranks[0]["gnorm"] - ref.arena.gnorm.item()) <= (1e-2 if fam == "convtasnet" else 0.2) * ref.arena.gnorm.item()
+
+
+def test_replicas_keep_their_own_observer_ranges_like_the_reference(tmp_path):
+    """`sync_observer_ranges=False` = the reference's behaviour (qat_quant.py:230-232 writes .data during the observer phase, DDP
+    only averages gradients): the activation ranges of the replicas differ when the phase ends and nothing re-synchronises them;
+    the quantizing steps that follow run on per-rank grids, the range PARAMETERS move by the same averaged gradients (their
+    difference persists), and every other parameter stays bit-identical over the ranks."""
+    ranks = _run_ranks(tmp_path, "observer_nosync")
+    differing = 0
+    for k, v0 in ranks[0]["before"].items():
+        v1 = ranks[1]["before"][k]
+        differing += int(not torch.equal(v0, v1))
+        for r in range(2):
+            assert torch.equal(ranks[r]["after"][k], ranks[r]["before"][k]), k       # no synchronisation happened
+    assert differing > 20
+    still = sum(int(not torch.equal(ranks[0]["after_steps"][k], ranks[1]["after_steps"][k])) for k in ranks[0]["after_steps"])
+    assert still > 20
+    for k, v in ranks[0]["weights"].items():
+        assert torch.equal(v, ranks[1]["weights"][k]), k
+    assert all(np.isfinite(ranks[r]["losses"]).all() for r in range(2))
 
 
 def test_observer_ranges_are_synchronised_once_over_the_ranks(tmp_path):

@@ -198,6 +198,8 @@ def test_rowmat_layouts():
     assert rowmat(b.unsqueeze(1)) == (12, 77, 80)
     assert rowmat(torch.empty(4, 800).t()) is None and rowmat(torch.empty(2, 3, 77)[:, :, ::2]) is None
     assert rowmat(torch.empty(4, 1, 800)) == (4, 800, 800)
+    # one row inside a padded buffer keeps the buffer's aligned row stride (the C side checks alignment even for a single row)
+    assert rowmat(empty_act((1, 1, 77), "cpu")) == (1, 77, 80) and rowmat(torch.empty(1, 1, 77)) == (1, 77, 77)
 
 
 def _ddp_worker(rank, world, port, q):
