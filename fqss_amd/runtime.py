@@ -388,6 +388,8 @@ class KDTrainStep:
         before.  Same values either way (tests/test_gpu_kdstep_path.py)."""
         self.model, self.fmodel = model, fmodel
         self.teacher_ahead = bool(teacher_ahead)
+        self.grad_at = None         # l1_sdr only, tests: evaluate dloss/dest at this output instead of the step's own (a parity gate against
+                                    # reference gradients must not inherit the sign noise of |est - target| ~ 0 samples)
         self._ahead = None          # (mixture tensor, its version, teacher output) announced by the previous step
         self._tgraph = None         # captured teacher forward (teacher_ahead + hipGraph replay)
         self.loss_kind, self.source_weights, self.batched_quantizers = loss, source_weights, batched_quantizers
@@ -532,6 +534,8 @@ class KDTrainStep:
             if self.source_weights is None:
                 self.source_weights = torch.ones(tgt.shape[1], device=tgt.device)
             loss, task, kd, w, gest = K.hd_kd_loss(est.detach(), fest, tgt, self.source_weights, self.kd_lambda, want_grad=True)
+            if self.grad_at is not None:       # tests: dloss/dest taken at a given output (the L1 loss has a sign gradient)
+                gest = K.hd_kd_loss(self.grad_at, fest, tgt, self.source_weights, self.kd_lambda, want_grad=True)[4]
             res = dict(loss=loss, task=task, kd=kd, w=w, gnorm=a.gnorm, est=est.detach())
         elif teacher_free:
             # mysystem.py:153-156: PITLossWrapper(pairwise_neg_sisdr) on the student alone
