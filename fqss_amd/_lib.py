@@ -185,12 +185,42 @@ class FqssError(RuntimeError):
 
 
 _lib = None
+BACKEND = "hip"           # "hip": csrc/libfqss_hip.so on MI355X (the product) | "cpu": csrc/cpu/libfqss_cpu.so (cfg 1: `--use_cpu`)
+CPU_SO_PATH = os.path.join(_HERE, "csrc", "cpu", "libfqss_cpu.so")
+_cpu = None
+
+
+def set_backend(name):
+    """`--use_cpu` (reference train.py:31) selects the CPU backend behind the same C ABI: a build-owned plain-C++ library that serves the
+    entry points of the un-fused ConvTasNet QAT step (BASELINE.json configs[0]).  It is chosen EXPLICITLY, never as a fallback: with the
+    HIP backend selected a CPU tensor or a missing .so still raises."""
+    global BACKEND
+    if name not in ("hip", "cpu"):
+        raise FqssError(f"unknown backend {name!r}")
+    if name == "cpu":
+        load_cpu()
+    BACKEND = name
+    _bound.clear()
+    from . import ops
+    ops.CODED = name != "cpu"        # the CPU backend has the fp32 per-layer kernels only: no layer output carries codes there
+
+
+def load_cpu():
+    global _cpu
+    if _cpu is None:
+        if not os.path.exists(CPU_SO_PATH):
+            raise FqssError(f"{CPU_SO_PATH} not found: build it with `make -C fqss_amd/csrc/cpu` (or __graft_entry__.build())")
+        _cpu = C.CDLL(CPU_SO_PATH)
+        _cpu.fqss_last_error.restype = C.c_char_p
+    return _cpu
 
 
 def load(strict=False):
     """Load the HIP library; fail LOUDLY when it is missing (no CPU fallback exists).
     strict=True additionally requires every symbol declared in include/fqss.h to be exported."""
     global _lib
+    if BACKEND == "cpu" and not strict:
+        return load_cpu()
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise FqssError(
@@ -208,24 +238,26 @@ def load(strict=False):
 _bound = {}
 
 
-def call(name, *args):
+def _bind(name):
     fn = _bound.get(name)
     if fn is None:
-        fn = getattr(load(), name)       # AttributeError (loud) if the symbol is not exported
+        lib = load()
+        if not hasattr(lib, name):
+            raise FqssError(f"{name} is not built for the {BACKEND} backend" + (
+                " (the CPU backend serves the un-fused ConvTasNet QAT step only: cfg 1 of BASELINE.json)" if BACKEND == "cpu" else ""))
+        fn = getattr(lib, name)
         fn.argtypes = _PROTOS[name]
         fn.restype = _RESTYPE.get(name, C.c_int)
         _bound[name] = fn
-    rc = fn(*args)
+    return fn
+
+
+def call(name, *args):
+    rc = _bind(name)(*args)
     if rc != 0:
         raise FqssError(f"{name} failed ({rc}): {load().fqss_last_error().decode()}")
 
 
 def query(name, *args):
     """entry points that return a count instead of a status (fqss_*_stat_slots, fqss_workspace_bytes)"""
-    fn = _bound.get(name)
-    if fn is None:
-        fn = getattr(load(), name)
-        fn.argtypes = _PROTOS[name]
-        fn.restype = _RESTYPE.get(name, C.c_int)
-        _bound[name] = fn
-    return fn(*args)
+    return _bind(name)(*args)

@@ -19,13 +19,17 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return None if _lib.BACKEND == "cpu" else torch.cuda.current_stream().cuda_stream
 
 
 def _need_gpu(*ts):
+    """tensors must live where the SELECTED backend computes: ROCm device memory for the HIP library (the product; a CPU tensor raises --
+    there is no fallback), host memory for the CPU backend of `--use_cpu` (_lib.set_backend)"""
+    cpu = _lib.BACKEND == "cpu"
     for t in ts:
-        if t is not None and not t.is_cuda:
-            raise _lib.FqssError("fqss_amd ops need ROCm device tensors (no CPU fallback; see oracle/ for the CPU checker)")
+        if t is not None and t.is_cuda == cpu:
+            raise _lib.FqssError("the CPU backend (--use_cpu) takes host tensors" if cpu else
+                                 "fqss_amd ops need ROCm device tensors (no CPU fallback; see oracle/ for the CPU checker)")
         if t is not None and t.dtype not in (torch.float32,):
             raise _lib.FqssError(f"fp32 tensor expected, got {t.dtype}")
 
@@ -261,7 +265,7 @@ def wq_codes(w, qmin, qmax):
 
 
 def q_eligible(Ci, Co):
-    return Ci % 16 == 0 and Co % 16 == 0 and Ci <= 512
+    return _lib.BACKEND != "cpu" and Ci % 16 == 0 and Co % 16 == 0 and Ci <= 512
 
 
 def qpw_fwd(xc, wc, bias, qmin_x, qmax_x):

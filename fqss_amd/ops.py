@@ -458,12 +458,11 @@ class LinearActQ(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             fk = ctx.fork
-            if ctx.wc is not None and fk is not None and fk.other is not None and tuple(fk.other.shape) == tuple(ctx.x_shape):
-                gx = K.qpw_bwd_x(gz, ctx.wc, add=fk.other)     # + the gradient of the fork's other branch: no separate sum pass
-                fk.fused = True
-            elif L.kind == "convtr" and fk is not None and fk.other is not None and tuple(fk.other.shape) == tuple(ctx.x_shape):
-                gx = K.frames_conv_fwd(gz, w.reshape(w.shape[0], 1, w.shape[2]), L.stride, add=fk.other)   # decoder: same, in its dgrad
-                fk.fused = True
+            other = fk[0].take(fk[1], ctx.x_shape) if (fk is not None and (ctx.wc is not None or L.kind == "convtr")) else None
+            if ctx.wc is not None and other is not None:
+                gx = K.qpw_bwd_x(gz, ctx.wc, add=other)     # + the gradient of the fork's other branch: no separate sum pass
+            elif L.kind == "convtr" and other is not None:
+                gx = K.frames_conv_fwd(gz, w.reshape(w.shape[0], 1, w.shape[2]), L.stride, add=other)   # decoder: same, in its dgrad
             else:
                 gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)
         gw = None
@@ -666,7 +665,7 @@ class EwQ(Function):
         g_slope, g_min, g_max = _flush_ranges(q, slope, ctx.sp, ctx.act)
         ga = (gza if gza is not None else gz) if ctx.needs_input_grad[0] else None
         if ga is not None and ctx.fork_a is not None:
-            ctx.fork_a.other = ga        # the fork's first branch (a q-GEMM dgrad) may add it in its epilogue
+            ctx.fork_a[0].leave(ga, ctx.fork_a[1])      # the conv on the fork's other branch may add it in its dgrad epilogue
         gb = None
         if ctx.has_b and ctx.needs_input_grad[1]:
             if gzb is not None:
@@ -817,13 +816,32 @@ def splitter2(x):
 
 
 class _ForkState:
-    """lets the dgrad q-GEMM of the fork's FIRST branch add the gradient of the SECOND branch in its epilogue (FUSE_FORK): the second
+    """lets the dgrad q-GEMM of ONE branch of a two-way fork add the gradient of the OTHER branch in its epilogue (FUSE_FORK): the other
     branch's backward (an element-wise LayerQ, created later in the forward => run earlier in the backward) leaves its gradient in
-    `other`; the first branch's LinearActQ.backward consumes it and sets `fused`, and Fork2.backward then passes g1 through"""
-    __slots__ = ("other", "fused")
+    `other` (tagged with its branch index, ACCUMULATED if that branch has several such consumers); the conv's LinearActQ.backward
+    consumes it only if it sits on the opposite branch and records which branch it was; Fork2.backward then passes the fused
+    branch's gradient through -- after checking that what was added really is the other branch's complete gradient."""
+    __slots__ = ("other", "other_branch", "fused_branch", "n_other")
 
     def __init__(self):
-        self.other, self.fused = None, False
+        self.other, self.other_branch, self.fused_branch, self.n_other = None, None, None, 0
+
+    def leave(self, g, branch):
+        """an element-wise consumer on `branch` hands over its input gradient"""
+        if self.other is None:
+            self.other, self.other_branch, self.n_other = g, branch, 1
+        elif self.other_branch == branch:
+            self.other, self.n_other = K.axpby(self.other, g, 1.0), self.n_other + 1
+        else:                       # consumers on BOTH branches left gradients: nothing to fuse
+            self.other, self.other_branch, self.n_other = None, -1, 0
+
+    def take(self, branch, shape):
+        """the conv on `branch` asks for the opposite branch's gradient to add in its dgrad epilogue (None: sum the usual way)"""
+        if self.other is None or self.other_branch in (None, -1, branch) or self.fused_branch is not None \
+                or tuple(self.other.shape) != tuple(shape):
+            return None
+        self.fused_branch = branch
+        return self.other
 
 
 FUSE_FORK = os.environ.get("FQSS_FUSE_FORK", "1") != "0"
@@ -841,12 +859,20 @@ class Fork2(Function):
     @staticmethod
     def backward(ctx, g1, g2):
         fk = ctx.fk
-        fused, fk.fused, fk.other = fk.fused, False, None
-        if g1 is None:
-            return g2, None
-        if g2 is None or fused:        # fused: g1 already holds the sum (fqss_qpw_bwd_x_add)
-            return g1, None
-        return K.axpby(g1, g2, 1.0), None
+        fb, other, n_other = fk.fused_branch, fk.other, fk.n_other
+        fk.fused_branch, fk.other, fk.other_branch, fk.n_other = None, None, None, 0
+        gs = (g1, g2)
+        if fb is None:
+            if g1 is None:
+                return g2, None
+            if g2 is None:
+                return g1, None
+            return K.axpby(g1, g2, 1.0), None
+        gf, go = gs[fb], gs[1 - fb]              # gf already holds (its own gradient + `other`)
+        if go is None or (n_other == 1 and go.data_ptr() == other.data_ptr()):
+            return gf, None                      # `other` WAS the opposite branch's complete gradient (fqss_qpw_bwd_x_add)
+        # the opposite branch had further consumers (autograd summed them with `other` into `go`): add what the epilogue missed
+        return K.axpby(K.axpby(gf, go, 1.0), other, -1.0), None
 
 
 def fork2(x):
@@ -854,7 +880,7 @@ def fork2(x):
         fk = _ForkState()
         a, b = Fork2.apply(x, fk)
         if FUSE_FORK:
-            a._fqss_fork = b._fqss_fork = fk
+            a._fqss_fork, b._fqss_fork = (fk, 0), (fk, 1)
         c = codes_of(x)
         if c is not None:
             a._fqss_q = b._fqss_q = c

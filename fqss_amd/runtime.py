@@ -12,6 +12,7 @@ import os
 
 import torch
 
+from . import _lib
 from . import kernels as K
 from . import ops
 from . import ops_dp
@@ -22,7 +23,7 @@ class ParamArena:
         params = [p for p in params if p.requires_grad]
         assert params, "no trainable parameters"
         dev = params[0].device
-        assert dev.type == "cuda", "ParamArena needs ROCm device parameters"
+        assert dev.type == ("cpu" if _lib.BACKEND == "cpu" else "cuda"), "ParamArena: parameters must live where the selected backend computes"
         offs, n = [], 0
         for p in params:
             offs.append(n)
@@ -387,6 +388,11 @@ class KDTrainStep:
         result for its mixture (the first one, or a caller that did not announce it) runs the teacher beside its own forward as
         before.  Same values either way (tests/test_gpu_kdstep_path.py)."""
         self.model, self.fmodel = model, fmodel
+        self.cpu = _lib.BACKEND == "cpu"
+        if self.cpu:
+            # cfg 1 (`--use_cpu`): the CPU backend serves the un-fused per-layer entry points only -- no codes-only dataflow, no batched
+            # tables, no streams / graphs, the teacher as the plain module forward
+            batched_quantizers = fast = coded = teacher_ahead = False
         self.teacher_ahead = bool(teacher_ahead)
         self.grad_at = None         # l1_sdr only, tests: evaluate dloss/dest at this output instead of the step's own (a parity gate against
                                     # reference gradients must not inherit the sign noise of |est - target| ~ 0 samples)
@@ -434,11 +440,13 @@ class KDTrainStep:
         for p in fmodel.parameters():
             p.requires_grad_(False)
         self.teacher = TeacherRunner(fmodel)     # fused inference chain for the frozen float teacher
+        if self.cpu:
+            self.teacher.ok = False
         self._tstream = None
         self.last = None
         self.tables = None          # QuantTables once the quantizing phase is reached
         self._eager_q = 0           # eager steps run in the quantizing phase (see maybe_capture)
-        self.use_graph = True
+        self.use_graph = not self.cpu
         self._sx = self._st = None
 
     @property
@@ -492,9 +500,10 @@ class KDTrainStep:
         # The frozen teacher depends on nothing but x: it runs on a second stream next to the student's forward (its
         # MFMA-bound GEMMs overlap the student's HBM-bound layers; inside a hipGraph capture this becomes a parallel
         # branch of the graph) and joins before the loss.
-        cur = torch.cuda.current_stream()
+        cur = None if self.cpu else torch.cuda.current_stream()
         teacher_free = self.loss_kind != "l1_sdr" and not self.kd_lambda > 0        # kd_lambda = 0: plain PIT SI-SDR loss, no teacher
         ahead = fest_given is not None
+        two_streams = TEACHER_STREAM and not self.cpu
         if teacher_free:
             fest = None
         elif ahead:
@@ -502,7 +511,7 @@ class KDTrainStep:
             if self._tstream is not None and join_teacher:      # computed on the teacher stream during the previous step (joined BEFORE the next look-ahead is enqueued there)
                 cur.wait_stream(self._tstream)
                 fest.record_stream(cur)
-        elif TEACHER_STREAM:
+        elif two_streams:
             if self._tstream is None:
                 self._tstream = _teacher_stream()
             self._tstream.wait_stream(cur)
@@ -525,7 +534,7 @@ class KDTrainStep:
                 est = self.model(x)
         if teacher_free or ahead:
             pass
-        elif TEACHER_STREAM:
+        elif two_streams:
             cur.wait_stream(self._tstream)
             fest.record_stream(cur)
         else:

@@ -30,16 +30,24 @@ def _batches(dataset_cfg, training_cfg, comm, device, split):
 
 
 def train(yml_path, device):
-    if device == "cpu":
-        raise RuntimeError("fqss_amd is MI355X-only (no CPU fallback); the CPU checker lives in oracle/")
+    cpu = device == "cpu"
+    if cpu:
+        # `--use_cpu` (reference train.py:31; BASELINE.json configs[0]: "CPU, batch 2, 1 s ... plumbing, no GPU"): the same trainer over
+        # the CPU backend of the C ABI (csrc/cpu/libfqss_cpu.so: the un-fused per-layer entry points of the ConvTasNet step).  Chosen
+        # explicitly here, never as a fallback; oracle/ is not involved.
+        from ... import _lib
+        _lib.set_backend("cpu")
     with open(yml_path) as f:
         conf = yaml.safe_load(f)
     work_dir, model_cfg, dataset_cfg = conf["work_dir"], conf["model_cfg"], conf["dataset_cfg"]
     training_cfg = conf["training_cfg"]
     set_seed(training_cfg.get("seed", 0))
-    comm = Comm.from_env("cuda")
-    dev = torch.device("cuda", comm.local_rank)
-    torch.cuda.set_device(dev)
+    comm = Comm.from_env("cpu" if cpu else "cuda")
+    dev = torch.device("cpu") if cpu else torch.device("cuda", comm.local_rank)
+    if not cpu:
+        torch.cuda.set_device(dev)
+    elif model_cfg.get("name") != "ConvTasNet":
+        raise NotImplementedError("--use_cpu: the CPU backend serves the ConvTasNet step (cfg 1 of BASELINE.json) only")
 
     model_cfg.update({"model_path": training_cfg.get("pretrained", None)})
     model, fmodel = create_pretrained_model(model_cfg)
