@@ -87,19 +87,34 @@ class LibriMix:
         return x
 
     def _augment(self, sources, noise):
-        """sources [B, n_src, T], noise [B, T] or None -> mixtures [B, T] (:139-153)"""
-        cfg, n = self.augmentation_cfg, sources.shape[1]
-        if self.task == "enh_single":
-            return augmentation_2mix(sources[:, 0], noise, cfg)
-        if self.task in ("sep_clean", "sep_noisy") and n in (2, 3):
-            if n == 2:
-                mix = augmentation_2mix(sources[:, 0], sources[:, 1], cfg)
-            else:
-                mix = augmentation_3mix(sources[:, 0], sources[:, 1], sources[:, 2], cfg)
+        """sources [B, n_src, T], noise [B, T] or None -> mixtures [B, T] (:139-153).  The reference augments inside __getitem__, i.e.
+        every item draws its OWN SNR(s) from the host RNG (train_utils.py:30-52), in item order: one draw for a 2-mix, two for a 3-mix,
+        then one for the noise of sep_noisy -- the same draws, item by item, handed to the batched device kernel as [B] tensors"""
+        from ...process import generate_2mix_snr, generate_3mix_snr
+        cfg, n, B = self.augmentation_cfg, sources.shape[1], sources.shape[0]
+        if cfg.get("distribution") != "uniform":
+            raise AssertionError("Augmentation is not supoorted!")
+        lo, hi = cfg.get("param0"), cfg.get("param1")
+        if self.task not in ("enh_single", "sep_clean", "sep_noisy") or (self.task != "enh_single" and n not in (2, 3)):
+            raise AssertionError("Augmetation is not supported!")
+        draws = []
+        for _ in range(B):                       # item order, like B calls of the reference's __getitem__
+            d = [np.random.uniform(low=lo, high=hi)]
+            if self.task != "enh_single" and n == 3:
+                d.append(np.random.uniform(low=lo, high=hi))
             if self.task == "sep_noisy":
-                mix = generate_mix_noise(mix, noise, np.random.uniform(low=6, high=18))
-            return mix
-        raise AssertionError("Augmetation is not supported!")
+                d.append(np.random.uniform(low=6, high=18))
+            draws.append(d)
+        col = lambda j: torch.tensor([d[j] for d in draws], dtype=torch.float32, device=sources.device)
+        if self.task == "enh_single":
+            return generate_2mix_snr(sources[:, 0], noise, col(0))
+        if n == 2:
+            mix = generate_2mix_snr(sources[:, 0], sources[:, 1], col(0))
+        else:
+            mix = generate_3mix_snr(sources[:, 0], sources[:, 1], sources[:, 2], col(0), col(1))
+        if self.task == "sep_noisy":
+            mix = generate_mix_noise(mix, noise, col(-1))
+        return mix
 
     def batch(self, indices):
         """(mixtures [B, 1, T'], sources [B, n_src, T']) on the device: every clip of the batch is resampled by one launch"""

@@ -88,7 +88,9 @@ class SDR:
         noise2 = ee - 2.0 * a * et + proj2 if self.sdr_type == "sisdr" else ee - 2.0 * et + tt
         sdr = proj2 / (noise2 + self.EPS)
         if weights is not None:
-            sdr = sdr * weights[:, None]
+            # the reference multiplies its [B, n_src] ratios by weights[:, None, None] (wsdr.py:37): that BROADCASTS to [B, B, n_src]
+            # -- every sample's ratio meets every sample's weight -- and the mean runs over all of it; reproduced as written
+            sdr = sdr[None, :, :] * weights[:, None, None]
         sdr = torch.mean(sdr)
         return (10.0 * torch.log10(sdr + self.EPS) if self.take_log else sdr).float()
 

@@ -181,7 +181,7 @@ def test_wsdr_loss_names_match_their_formulas():
         noise = e - proj if kind == "sisdr" else e - t
         r = (proj ** 2).sum(-1) / ((noise ** 2).sum(-1) + EPS)
         if weights is not None:
-            r = r * weights.double()[:, None]
+            r = r * weights.double()[:, None, None]       # the reference's own broadcast (wsdr.py:37): [B, n_src] x [B, 1, 1] -> [B, B, n_src]
         r = r.mean()
         return 10 * torch.log10(r + EPS) if take_log else r
 
