@@ -5,6 +5,7 @@ a fused tuple such as (Conv1d, PReLU) becomes ONE LayerQ at the first path and n
 (:273-287)."""
 import copy
 
+import torch
 import torch.nn as nn
 
 from . import qat_layers as QL
@@ -156,3 +157,103 @@ def replace_activation_quantizer(model, module_to_replace, module):
 
 def replace_dym_activation_quantizer(model, module_to_replace, module):
     _set_module(model, module_to_replace, torch_dym_activation_quantizer(module))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Integer checkpoint (SURVEY.md 8(f) rank 3; the reference only sketches the export: qat_utils.py:334-351 swaps quantizers for their
+# torch affine twins and keeps fp32 weights).  Here the trained model is STORED as what a W8A8 deployment loads: int8 weight codes +
+# per-channel steps on the training grid (delta = 2 max(|min|, |max|) / 255, codes in [-128, 127]: qat_quant.py:126-135), every
+# activation quantizer's range (the 8-bit grid delta = (max - min) / 255) next to its torch affine form (scale, zero point), and
+# the few float tensors that are not quantized (biases, norms, PReLU slopes).  Loading rebuilds W_q = delta * code -- bit for bit the
+# weight the QAT forward multiplies with -- so the eval output of a model restored from the integer file equals the original's.
+# ---------------------------------------------------------------------------------------------------------------------------------
+INT_CKPT_FORMAT = "fqss-int8-v1"
+
+
+def weight_quantizer_owners(model):
+    """[(weight quantizer, weight parameter, parameter name)] of every GradientWeightFakeQuantize of the model: through the LayerQ that
+    owns it (its float submodule's `.weight`), the attention projections and the LSTM matrices"""
+    from .qat_quant import GradientWeightFakeQuantize
+    names = {id(p): n for n, p in model.named_parameters()}
+    out = []
+
+    def fits(wqm, w):
+        return isinstance(wqm, GradientWeightFakeQuantize) and isinstance(w, nn.Parameter) and tuple(wqm.min_range.shape) == tuple(
+            1 if d != wqm.axis else w.shape[d] for d in range(w.dim()))
+
+    for layer in model.modules():
+        wqm = getattr(layer, "weight_fake_quantize", None)
+        if isinstance(wqm, GradientWeightFakeQuantize):
+            for cand in ("conv1d", "convTr1d", "residual_encoder", "residual_decoder", "linear", "conv2d", "convTr2d"):
+                conv = getattr(layer, cand, None)
+                if conv is not None and fits(wqm, getattr(conv, "weight", None)):
+                    out.append((wqm, conv.weight, names[id(conv.weight)]))
+                    break
+        if isinstance(layer, QL.MultiheadAttentionQ):
+            for wqm, w in ((layer.weight_fake_quantize_in, layer.mha.in_proj_weight), (layer.weight_fake_quantize_out, layer.mha.out_proj.weight)):
+                if fits(wqm, w):
+                    out.append((wqm, w, names[id(w)]))
+        if isinstance(layer, QL.LSTMQ):
+            for pname, wqm in layer.weight_quantizers_dict.items():
+                if fits(wqm, getattr(layer.lstm, pname, None)):
+                    w = getattr(layer.lstm, pname)
+                    out.append((wqm, w, names[id(w)]))
+    return out
+
+
+def integer_state(model):
+    """the model as integers: {"format", "weights": {parameter name: codes int8, delta [C], axis, min/max range}, "activations":
+    {quantizer path: min, max, scale, zero_point}, "float": every other state_dict entry, "keys": the state_dict's key order}"""
+    from ... import kernels as K
+    from .qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize, TorchActivationFakeQuantize
+    sd = model.state_dict()
+    weights, covered = {}, set()
+    qname = {id(m): n for n, m in model.named_modules()}
+    for wqm, w, pname in weight_quantizer_owners(model):
+        if wqm.observer_mode:
+            raise ValueError(f"{pname}: its weight observer never ran (nothing to export before the first training forward)")
+        wq, codes = K.wq_fwd(w.detach(), wqm.axis, wqm.min_range.detach(), wqm.max_range.detach(), want_idx=True)
+        a = torch.maximum(wqm.min_range.detach().abs(), wqm.max_range.detach().abs())
+        weights[pname] = {"codes": codes.cpu(), "delta": ((2.0 * a) / 255.0).flatten().cpu(), "axis": wqm.axis,
+                          "min_range": wqm.min_range.detach().cpu(), "max_range": wqm.max_range.detach().cpu(), "quantizer": qname[id(wqm)]}
+        covered |= {pname, qname[id(wqm)] + ".min_range", qname[id(wqm)] + ".max_range"}
+    acts = {}
+    for name, m in model.named_modules():
+        if isinstance(m, GradientActivationFakeQuantize):
+            t = TorchActivationFakeQuantize(m)
+            acts[name] = {"min_range": m.min_range.detach().cpu(), "max_range": m.max_range.detach().cpu(), "scale": t.scale,
+                          "zero_point": t.zero_point, "n_iter": int(m.n_iter)}
+            covered |= {name + ".min_range", name + ".max_range"}
+    return {"format": INT_CKPT_FORMAT, "weights": weights, "activations": acts,
+            "float": {k: v.detach().cpu() for k, v in sd.items() if k not in covered}, "keys": list(sd.keys())}
+
+
+def save_integer_checkpoint(model, path):
+    torch.save(integer_state(model), path)
+
+
+def load_integer_checkpoint(model, path_or_state):
+    """restore a quantized model (same architecture, already through quantize_model) from an integer checkpoint: weights become
+    delta * code, ranges are set, observers are switched off (weight observers have run, activation quantizers quantize)"""
+    from .qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
+    st = path_or_state if isinstance(path_or_state, dict) else torch.load(path_or_state, weights_only=True)
+    if st.get("format") != INT_CKPT_FORMAT:
+        raise ValueError(f"not an integer checkpoint of format {INT_CKPT_FORMAT}")
+    sd = dict(st["float"])
+    for pname, e in st["weights"].items():
+        shape = [1] * e["codes"].dim()
+        shape[e["axis"]] = -1
+        sd[pname] = e["delta"].reshape(shape) * e["codes"].float()          # W_q = delta * code: one exact fp32 product per element
+        sd[e["quantizer"] + ".min_range"], sd[e["quantizer"] + ".max_range"] = e["min_range"], e["max_range"]
+    for name, e in st["activations"].items():
+        sd[name + ".min_range"], sd[name + ".max_range"] = e["min_range"], e["max_range"]
+    missing = [k for k in st["keys"] if k not in sd]
+    assert not missing, missing
+    model.load_state_dict({k: sd[k] for k in st["keys"]}, strict=True)
+    by_name = dict(model.named_modules())
+    for m in model.modules():
+        if isinstance(m, GradientWeightFakeQuantize):
+            m.observer_mode = False
+    for name, e in st["activations"].items():
+        by_name[name].n_iter = e["n_iter"]
+    return model
