@@ -18,6 +18,34 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+import ctypes as _C
+
+DESC_ABI = os.environ.get("FQSS_FLAT_ABI", "0") == "0"   # the long entry points go through their descriptor-struct forms (include/fqss.h)
+_DT = {torch.float32: _lib.DT_F32, torch.uint8: _lib.DT_U8, torch.int8: _lib.DT_I8, torch.float64: _lib.DT_F64, torch.int16: _lib.DT_U16,
+       torch.int64: _lib.DT_I64}
+
+
+def _desc(t, dtype=None):
+    """FqssTensor descriptor of a tensor (None -> None); the caller keeps it alive across the call"""
+    if t is None:
+        return None
+    d = _lib.FqssTensor()
+    d.data, d.dtype, d.ndim = t.data_ptr(), _DT[t.dtype] if dtype is None else dtype, t.dim()
+    for i in range(t.dim()):
+        d.shape[i], d.stride[i] = t.shape[i], t.stride(i)
+    return d
+
+
+def _ref(x):
+    return _C.byref(x) if x is not None else None
+
+
+def _qparams(qmin, qmax, act=0, slope=None, gacc=None):
+    q = _lib.FqssQParams()
+    q.qmin, q.qmax, q.act, q.slope, q.gacc = _p(qmin), _p(qmax), act, _p(slope), _p(gacc)
+    return q
+
+
 def _stream():
     return None if _lib.BACKEND == "cpu" else torch.cuda.current_stream().cuda_stream
 
@@ -330,6 +358,16 @@ def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None,
     z2 = yc2 = None
     if Co2:
         z2, yc2 = empty_act((B, Co2, M), xc.device), empty_codes((B, Co2, M), xc.device)
+    if DESC_ABI:
+        w = _lib.FqssWCodes()
+        w.idx, w.idxT, w.dw, w.rw, w.Co, w.Ci = _p(wc.idx), _p(wc.idxT), _p(wc.dw), _p(wc.rw), wc.Co, wc.Ci
+        dx, dz1, dz2, dy1, dy2 = _desc(xc), _desc(z1), _desc(z2), _desc(yc1), _desc(yc2)
+        qx, q1 = _qparams(qmin_x, qmax_x), _qparams(r1[0], r1[1], act, slope)
+        q2 = _qparams(r2[0], r2[1], act, slope) if r2 else None
+        ws, nws = (_p(stats.ws), stats.ws.numel() * stats.ws.element_size()) if stats is not None else (None, 0)
+        _lib.call("fqss_pwconv_fq_fwd", _ref(dx), _ref(qx), _ref(w), _p(bias1), _p(bias2), _ref(dz1), _ref(dz2), _ref(dy1), _ref(dy2),
+                  _ref(q1), _ref(q2), ws, nws, _stream())
+        return (z1, z2, yc1, yc2) if Co2 else (z1, yc1)
     _lib.call("fqss_qpw_fwdq", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias1), _p(bias2), _p(qmin_x), _p(qmax_x), _p(z1), _p(z2),
               act, _p(slope), _p(r1[0]), _p(r1[1]), _p(r2[0]) if r2 else None, _p(r2[1]) if r2 else None, _p(yc1), _p(yc2),
               B, Ci, Co1, Co2, M, rm[2], rowmat(z1)[2], rowmat(z2)[2] if Co2 else 0, rowmat(yc1)[2], rowmat(yc2)[2] if Co2 else 0,
@@ -501,6 +539,24 @@ def ewq_bwd_p(ac, amin, amax, bc, bmin, bmax, sb, g, act, slope, qmin, qmax, gac
             o = empty_act(tuple(ac.shape), ac.device)
             outs.append(o)
             args += [_p(z), rowmat(z)[2], pact, _p(pslope), _p(pgacc), _p(pgbias), _p(o), rowmat(o)[2]]
+    if DESC_ABI and ac.dim() == 3 and ac.shape[1] == C:
+        # descriptor form (fqss_add_fq_bwd): tensors / quantizers / producers as structs instead of 38 positional arguments
+        keep = [_desc(ac), _desc(bc), _desc(g), _desc(gz)]
+        qa, qb, qo = _qparams(amin, amax), (_qparams(bmin, bmax) if bc is not None else None), _qparams(qmin, qmax, act, slope, gacc)
+        prods = []
+        for pr, o in zip((prod_a, prod_b), outs):
+            if pr is None:
+                prods.append(None)
+                continue
+            z, pact, pslope, pgacc, pgbias = pr
+            dz, do = _desc(z), _desc(o)
+            keep += [dz, do]
+            P = _lib.FqssProducer()
+            P.z, P.out, P.act, P.slope, P.gacc, P.gbias = _C.pointer(dz), _C.pointer(do), pact, _p(pslope), _p(pgacc), _p(pgbias)
+            prods.append(P)
+        _lib.call("fqss_add_fq_bwd", _ref(keep[0]), _ref(qa), _ref(keep[1]), _ref(qb), float(sb), _ref(keep[2]), _ref(keep[3]), _ref(qo),
+                  _ref(prods[0]), _ref(prods[1]), None, 0, _stream())
+        return gz, outs[0], outs[1]
     _lib.call("fqss_ewq_bwd_p", _p(ac), _p(amin), _p(amax), _p(bc), _p(bmin), _p(bmax), float(sb), _p(g), _p(gz), rows, cols, ld_a,
               ld_b, ld_g, rowmat(gz)[2] if gz is not None else 0, act, _p(slope), _p(qmin), _p(qmax), _p(gacc), C, *args, _stream())
     return gz, outs[0], outs[1]
@@ -858,6 +914,20 @@ def tgemm(planes, x, bias, act=ACT_NONE, slope=None, pro=0, pro_stats=None, pro_
     M1 = Co if M1 is None else M1
     c1 = empty_act((B, M1, M), x.device)
     c2 = empty_act((B, Co - M1, M), x.device) if M1 < Co else None
+    if DESC_ABI and (r1 is None or rowmat(r1)[2] == rowmat(c1)[2]) and (r2 is None or rowmat(r2)[2] == rowmat(c2)[2]):
+        td = _lib.FqssTGemmDesc()
+        dpl, dx, dc1, dr1, dc2, dr2 = _desc(planes.view(3, Co, Ci), _lib.DT_U16), _desc(x), _desc(c1), _desc(r1), _desc(c2), _desc(r2)
+        td.planes, td.x, td.c1 = _C.pointer(dpl), _C.pointer(dx), _C.pointer(dc1)
+        if dr1 is not None:
+            td.r1 = _C.pointer(dr1)
+        if dc2 is not None:
+            td.c2 = _C.pointer(dc2)
+        if dr2 is not None:
+            td.r2 = _C.pointer(dr2)
+        td.pro, td.pro_stats, td.pro_gamma, td.pro_beta, td.pro_eps, td.pro_slope = pro, _p(pro_stats), _p(pro_gamma), _p(pro_beta), float(pro_eps), _p(pro_slope)
+        td.bias, td.act, td.slope, td.stats_out, td.M1 = _p(bias), act, _p(slope), _p(stats_out), M1
+        _lib.call("fqss_tgemm_desc", _ref(td), _stream())
+        return (c1, c2) if c2 is not None else c1
     _lib.call("fqss_tgemm", _p(planes), _p(x), B, Ci, Co, M, ld_x, pro, _p(pro_stats), _p(pro_gamma), _p(pro_beta),
               float(pro_eps), _p(pro_slope), _p(bias), act, _p(slope), _p(stats_out), M1, _p(c1), _p(r1), rowmat(c1)[2],
               _p(c2), _p(r2), rowmat(c2)[2] if c2 is not None else 0, _stream())

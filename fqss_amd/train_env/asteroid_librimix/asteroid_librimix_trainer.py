@@ -30,6 +30,16 @@ def _batches(dataset_cfg, training_cfg, comm, device, split):
 
 
 def train(yml_path, device):
+    from ... import _lib
+    prev = _lib.BACKEND
+    try:
+        return _train(yml_path, device)
+    finally:
+        if _lib.BACKEND != prev:          # `--use_cpu` switched the process to the CPU backend: hand it back as it was found
+            _lib.set_backend(prev)
+
+
+def _train(yml_path, device):
     cpu = device == "cpu"
     if cpu:
         # `--use_cpu` (reference train.py:31; BASELINE.json configs[0]: "CPU, batch 2, 1 s ... plumbing, no GPU"): the same trainer over
