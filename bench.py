@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-teacher-ahead", action="store_true",
-                    help="cfg2: run the frozen teacher beside the student's forward of the SAME step (round-2 schedule) instead of one batch ahead")
+                    help="run the frozen teacher beside the student's forward of the SAME step (round-2 schedule) instead of one batch ahead")
     ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5", "infer"),
                     help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s; "
                          "cfg5 HTDemucs 4 x 10 s stereo 44.1 kHz")
@@ -218,7 +218,10 @@ def main_dualpath(a):
     model = quantize_model(model, dict(QCFG)).to(dev).train()
     T = W["T"]
     x, tgt = synth_batch(1, T, seed=100 + comm.rank, device=dev)
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=W["lr"], clip=5.0, comm=comm)
+    x2, tgt2 = synth_batch(1, T, seed=200 + comm.rank, device=dev)      # the timed loop alternates two batches (teacher look-ahead, as cfg 2)
+    X, TG = (x, x2), (tgt, tgt2)
+    ahead = not a.no_teacher_ahead
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=W["lr"], clip=5.0, comm=comm, teacher_ahead=ahead)
     step(x, tgt)                                            # untimed calibration: the 50-call observer phase
     with torch.no_grad():
         for _ in range(49):
@@ -229,13 +232,18 @@ def main_dualpath(a):
     if not a.no_graph:
         step.capture(x, tgt)
         launch = "hipGraph replay"
+    if ahead and not a.no_graph:
+        launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
+    it = 0
     for _ in range(a.warmup):
-        step(x, tgt)
+        step(X[it & 1], TG[it & 1], x_next=X[(it + 1) & 1])
+        it += 1
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        r = step(x, tgt)
+        r = step(X[it & 1], TG[it & 1], x_next=X[(it + 1) & 1])
+        it += 1
     torch.cuda.synchronize()
     comm.barrier()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
@@ -336,7 +344,10 @@ def main_htdemucs(a):
     g = torch.Generator().manual_seed(42 + comm.rank)
     src = (torch.randn(B, 4, 2, T, generator=g) * 0.1).to(dev)            # synthetic stereo Gaussian stems
     mix = src.sum(1)
-    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, comm=comm, loss="l1_sdr")
+    src2 = (torch.randn(B, 4, 2, T, generator=g) * 0.1).to(dev)           # second batch: the timed loop alternates the two (teacher look-ahead)
+    MIX, SRC = (mix, src2.sum(1)), (src, src2)
+    ahead = not a.no_teacher_ahead
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, comm=comm, loss="l1_sdr", teacher_ahead=ahead)
     step(mix, src)                                          # untimed calibration: the 50-call observer phase
     with torch.no_grad():
         for _ in range(49):
@@ -347,13 +358,18 @@ def main_htdemucs(a):
     if not a.no_graph:
         step.capture(mix, src)
         launch = "hipGraph replay"
+    if ahead and not a.no_graph:
+        launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
+    it = 0
     for _ in range(a.warmup):
-        step(mix, src)
+        step(MIX[it & 1], SRC[it & 1], x_next=MIX[(it + 1) & 1])
+        it += 1
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        r = step(mix, src)
+        r = step(MIX[it & 1], SRC[it & 1], x_next=MIX[(it + 1) & 1])
+        it += 1
     torch.cuda.synchronize()
     comm.barrier()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)

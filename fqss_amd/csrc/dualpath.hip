@@ -576,6 +576,108 @@ static inline unsigned flat_grid(int64_t n) {
     return (unsigned)nb;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Attention-core prologue of MultiheadAttentionQ in the quantizing phase as ONE pass each way (qat_layers.py:890-905): the in-projection
+// X [R][3E] is cut in thirds, each third goes through its own quantizer (q / k / v), the query is divided by sqrt(head_dim) and goes
+// through the `div` quantizer.  Replaces three narrow fqss_actq_fwd + fqss_unary_fwd + fqss_actq_fwd (and their five backward
+// launches): same op sequence per element -- fq_asym, one IEEE division, fq_asym -- so q / k / v are bit-identical to the un-fused chain.
+// The backward recomputes the intermediate values from X: nothing but X is saved.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mha_prep_fwd(const float* __restrict__ X, float* __restrict__ q, float* __restrict__ k,
+                                                       float* __restrict__ v, int64_t R, int E, int64_t ld_x, float scale,
+                                                       const float* qmin_q, const float* qmax_q, const float* qmin_k, const float* qmax_k,
+                                                       const float* qmin_v, const float* qmax_v, const float* qmin_d, const float* qmax_d) {
+    const QRange rq = load_qrange(qmin_q, qmax_q), rk = load_qrange(qmin_k, qmax_k), rv = load_qrange(qmin_v, qmax_v),
+                 rd = load_qrange(qmin_d, qmax_d);
+    const int e4 = E >> 2;
+    const int64_t n4 = R * e4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / e4;
+        const int f = (int)(i - row * e4) * 4;
+        const float* xr = X + row * ld_x + f;
+        const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + E),
+                     c = *reinterpret_cast<const float4*>(xr + 2 * E);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w};
+        float oq[4], ok[4], ov[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cc, u;
+            bool inr;
+            const float qp = fq_asym(av[j], rq, cc, u, inr);
+            oq[j] = fq_asym(qp / scale, rd, cc, u, inr);
+            ok[j] = fq_asym(bv[j], rk, cc, u, inr);
+            ov[j] = fq_asym(cv[j], rv, cc, u, inr);
+        }
+        const int64_t o = row * E + f;
+        *reinterpret_cast<float4*>(q + o) = make_float4(oq[0], oq[1], oq[2], oq[3]);
+        *reinterpret_cast<float4*>(k + o) = make_float4(ok[0], ok[1], ok[2], ok[3]);
+        *reinterpret_cast<float4*>(v + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
+// STE + range partials of one quantizer at one element (the arithmetic of k_actq_bwd, ACT_NONE)
+__device__ __forceinline__ float mha_ste(float t, float g, const QRange& r, float& p_du, float& p_out) {
+    float c, u;
+    bool inr;
+    (void)fq_asym(t, r, c, u, inr);
+    p_du += g * (inr ? (c - u) : c);
+    p_out += inr ? 0.0f : g;
+    return inr ? div_by(g * r.delta, r.delta, r.inv) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_mha_prep_bwd(const float* __restrict__ X, const float* __restrict__ gq, const float* __restrict__ gk,
+                                                       const float* __restrict__ gv, float* __restrict__ gX, int64_t R, int E, int64_t ld_x,
+                                                       int64_t ld_gx, float scale, const float* qmin_q, const float* qmax_q,
+                                                       const float* qmin_k, const float* qmax_k, const float* qmin_v, const float* qmax_v,
+                                                       const float* qmin_d, const float* qmax_d, double* gacc_q, double* gacc_k,
+                                                       double* gacc_v, double* gacc_d) {
+    __shared__ double red[8 * 4];
+    const QRange rq = load_qrange(qmin_q, qmax_q), rk = load_qrange(qmin_k, qmax_k), rv = load_qrange(qmin_v, qmax_v),
+                 rd = load_qrange(qmin_d, qmax_d);
+    float du[4] = {0.f, 0.f, 0.f, 0.f}, po[4] = {0.f, 0.f, 0.f, 0.f};      // q, k, v, div
+    const int e4 = E >> 2;
+    const int64_t n4 = R * e4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / e4;
+        const int f = (int)(i - row * e4) * 4;
+        const float* xr = X + row * ld_x + f;
+        const int64_t o = row * E + f;
+        const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + E),
+                     c = *reinterpret_cast<const float4*>(xr + 2 * E);
+        const float4 g0 = *reinterpret_cast<const float4*>(gq + o), g1 = *reinterpret_cast<const float4*>(gk + o),
+                     g2 = *reinterpret_cast<const float4*>(gv + o);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w};
+        const float gqv[4] = {g0.x, g0.y, g0.z, g0.w}, gkv[4] = {g1.x, g1.y, g1.z, g1.w}, gvv[4] = {g2.x, g2.y, g2.z, g2.w};
+        float oa[4], ob[4], oc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cc, u;
+            bool inr;
+            const float qp = fq_asym(av[j], rq, cc, u, inr);              // the value the div quantizer saw: (fq_q(x)) / scale
+            const float gd = mha_ste(qp / scale, gqv[j], rd, du[3], po[3]);
+            oa[j] = mha_ste(av[j], gd / scale, rq, du[0], po[0]);         // d(q / s) = g / s (fqss_unary_bwd), then the q quantizer's STE
+            ob[j] = mha_ste(bv[j], gkv[j], rk, du[1], po[1]);
+            oc[j] = mha_ste(cv[j], gvv[j], rv, du[2], po[2]);
+        }
+        float* gr = gX + row * ld_gx + f;
+        *reinterpret_cast<float4*>(gr) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+        *reinterpret_cast<float4*>(gr + E) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+        *reinterpret_cast<float4*>(gr + 2 * E) = make_float4(oc[0], oc[1], oc[2], oc[3]);
+    }
+    double v[8] = {(double)du[0], (double)po[0], (double)du[1], (double)po[1], (double)du[2], (double)po[2], (double)du[3], (double)po[3]};
+    block_sum<double, 8>(v, red);
+    if (threadIdx.x == 0) {
+        double* accs[4] = {gacc_q, gacc_k, gacc_v, gacc_d};
+        for (int t = 0; t < 4; ++t) {          // one slot per workgroup (grid <= FQSS_GACC_SLOTS), as k_actq_bwd
+            double* slot = accs[t] + 3 * (int64_t)blockIdx.x;
+            const double dmax = v[2 * t] / 255.0;
+            slot[0] += v[2 * t + 1] - dmax;
+            slot[1] += dmax;
+        }
+    }
+}
+
 }  // namespace fqss
 
 using namespace fqss;
@@ -673,6 +775,37 @@ extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t
     gy = cdiv(R, rpb);
     hipLaunchKernelGGL(k_colsum, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, g, out, R, C, ld, rpb, CW);
     return launch_status("fqss_colsum");
+}
+
+
+extern "C" int fqss_mha_prep_fwd(const float* X, float* q, float* k, float* v, int64_t R, int E, int64_t ld_x, double scale,
+                                 const float* const* ranges, fqss_stream_t stream) {
+    if (R == 0) return FQSS_OK;
+    FQSS_REQUIRE(X && q && k && v && ranges && R > 0 && E > 0 && E % 4 == 0 && ld_x >= 3 * (int64_t)E && ld_x % 4 == 0, "bad shape");
+    FQSS_REQUIRE(aligned16(X) && aligned16(q) && aligned16(k) && aligned16(v), "rows must be 16-B aligned");
+    FQSS_REQUIRE(scale != 0.0, "division by zero");
+    for (int i = 0; i < 8; ++i) FQSS_REQUIRE(ranges[i], "null range (q, k, v, div: min, max each)");
+    hipLaunchKernelGGL(k_mha_prep_fwd, dim3(flat_grid(R * (E / 4))), dim3(256), 0, (hipStream_t)stream, X, q, k, v, R, E, ld_x, (float)scale,
+                       ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5], ranges[6], ranges[7]);
+    return launch_status("fqss_mha_prep_fwd");
+}
+
+extern "C" int fqss_mha_prep_bwd(const float* X, const float* gq, const float* gk, const float* gv, float* gX, int64_t R, int E,
+                                 int64_t ld_x, int64_t ld_gx, double scale, const float* const* ranges, double* const* gaccs,
+                                 fqss_stream_t stream) {
+    if (R == 0) return FQSS_OK;
+    FQSS_REQUIRE(X && gq && gk && gv && gX && ranges && gaccs && R > 0 && E > 0 && E % 4 == 0, "bad shape");
+    FQSS_REQUIRE(ld_x >= 3 * (int64_t)E && ld_gx >= 3 * (int64_t)E && ld_x % 4 == 0 && ld_gx % 4 == 0, "bad row strides");
+    FQSS_REQUIRE(aligned16(X) && aligned16(gq) && aligned16(gk) && aligned16(gv) && aligned16(gX), "rows must be 16-B aligned");
+    FQSS_REQUIRE(scale != 0.0, "division by zero");
+    for (int i = 0; i < 8; ++i) FQSS_REQUIRE(ranges[i], "null range (q, k, v, div: min, max each)");
+    for (int i = 0; i < 4; ++i) FQSS_REQUIRE(gaccs[i], "null gacc (q, k, v, div)");
+    unsigned grid = flat_grid(R * (E / 4));
+    if (grid > FQSS_GACC_SLOTS) grid = FQSS_GACC_SLOTS;
+    hipLaunchKernelGGL(k_mha_prep_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, gq, gk, gv, gX, R, E, ld_x, ld_gx, (float)scale,
+                       ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5], ranges[6], ranges[7], gaccs[0], gaccs[1], gaccs[2],
+                       gaccs[3]);
+    return launch_status("fqss_mha_prep_bwd");
 }
 
 extern "C" int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, double p, fqss_stream_t stream) {

@@ -1048,6 +1048,32 @@ def layernormq_bwd(g, x, gamma, beta, mean_rstd, ggamma, gbeta, qmin, qmax, gacc
     return gx
 
 
+def _ptr_array(ts):
+    return (_C.c_void_p * len(ts))(*[_p(t) for t in ts])
+
+
+def mha_prep_fwd(X, E, scale, ranges):
+    """X [..., 3E] in-projection -> (q, k, v) [..., E]: the q / k / v quantizers on the thirds, q / scale, the div quantizer -- one pass.
+    ranges: [(qmin, qmax)] of the q, k, v, div quantizers"""
+    _need_gpu(X)
+    assert X.is_contiguous() and X.shape[-1] == 3 * E
+    R = X.numel() // (3 * E)
+    q, k, v = (torch.empty(*X.shape[:-1], E, device=X.device) for _ in range(3))
+    _lib.call("fqss_mha_prep_fwd", _p(X), _p(q), _p(k), _p(v), R, E, 3 * E, float(scale), _ptr_array([t for r in ranges for t in r]), _stream())
+    return q, k, v
+
+
+def mha_prep_bwd(X, gq, gk, gv, E, scale, ranges, gaccs):
+    """gradients of (q, k, v) -> gX [..., 3E]; the four quantizers' range partials go to gaccs (q, k, v, div)"""
+    _need_gpu(X, gq, gk, gv)
+    R = X.numel() // (3 * E)
+    gq, gk, gv = gq.contiguous(), gk.contiguous(), gv.contiguous()
+    gX = torch.empty_like(X)
+    _lib.call("fqss_mha_prep_bwd", _p(X), _p(gq), _p(gk), _p(gv), _p(gX), R, E, 3 * E, 3 * E, float(scale),
+              _ptr_array([t for r in ranges for t in r]), _ptr_array(gaccs), _stream())
+    return gX
+
+
 def unary_fwd(x, kind, p=1.0):
     _need_gpu(x)
     x = x.contiguous()

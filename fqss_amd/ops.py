@@ -308,6 +308,18 @@ def _flush_ranges(q, slope, slope_param, act):
     return (None if s_direct else s_buf), (None if mn_direct else mn_buf), (None if mx_direct else mx_buf)
 
 
+def _ranges_after(q, gacc):
+    """what _epilogue_bwd does behind its kernel, for a quantizer (no non-linearity) whose range partials ANOTHER kernel left in gacc:
+    deferred tables -> mark the range parameters touched; else flush into the parameters' gradients -> (g_min, g_max) for autograd"""
+    if q.owner is not None and getattr(q.owner, "_fqss_deferred", False):
+        _touch(None, q.owner.min_range, q.owner.max_range)
+        return None, None
+    mn_buf, mn_direct = _grad_buf(q.owner.min_range if q.owner is not None else None, q.qmin)
+    mx_buf, mx_direct = _grad_buf(q.owner.max_range if q.owner is not None else None, q.qmax)
+    K.gacc_flush(gacc, mn_buf, mx_buf, None)
+    return (None if mn_direct else mn_buf), (None if mx_direct else mx_buf)
+
+
 def _epilogue_bwd(z, g, act, slope, slope_param, q, bias_param=None, bias_like=None, C=0, out=None):
     """returns gz and the autograd gradients (g_slope, g_qmin, g_qmax, g_bias); out: row-matrix view that receives gz"""
     need_acc = (q.qmode == Q_QUANT) or (act == ACT_PRELU)

@@ -293,6 +293,9 @@ class Ola2(Function):
         return K.ola2_bwd(g)
 
 
+FUSE_MHA_PREP = __import__("os").environ.get("FQSS_FUSE_MHA_PREP", "1") != "0"   # q / k / v / div quantizers + the division as one pass each way
+
+
 class MhaCore(Function):
     """Everything of MultiheadAttentionQ.forward between the in-projection X [L, B, 3E] and the (not yet quantized) heads
     [L, B, E] (qat_layers.py:890-911): the q / k / v quantizers (each observes the WHOLE X, each is used on its own third),
@@ -314,6 +317,20 @@ class MhaCore(Function):
             ctx.save_for_backward(X, q, heads, stats)
             return heads
         qs = [a.qctx() for a in aqs[:4]]
+        ctx.fused = FUSE_MHA_PREP and all(c.qmode == ops.Q_QUANT for c in qs) and E % 4 == 0
+        if ctx.fused:
+            # quantizing phase: the three quantizers on the thirds, q / sqrt(head_dim) and the div quantizer in ONE pass (fqss_mha_prep_fwd)
+            q, kq, vq = K.mha_prep_fwd(X, E, scale, [(c.qmin, c.qmax) for c in qs])
+            for i in range(4):
+                aqs[i].after_forward(qs[i])
+            for i in (4, 5):
+                m = aqs[i].next_mode() if hasattr(aqs[i], "next_mode") else ops.Q_BYPASS
+                if m == ops.Q_OBSERVE:
+                    raise RuntimeError("MultiheadAttentionQ: attn / softmax observers out of step with the q / k / v quantizers")
+            heads, stats = K.attn_fwd(q, kq, vq, L, B, nh, None, None)
+            ctx.qs = qs
+            ctx.save_for_backward(X, q, heads, stats, kq, vq)
+            return heads
         parts = []
         for i in range(3):
             blk = X[..., i * E:(i + 1) * E]
@@ -355,6 +372,16 @@ class MhaCore(Function):
             gX[..., E:2 * E].copy_(gk)
             gX[..., 2 * E:].copy_(gv)
             return (gX, None, None)
+        if ctx.fused:
+            X, q, heads, stats, kq, vq = ctx.saved_tensors
+            qs = ctx.qs
+            gq, gk, gv = K.attn_bwd(q, kq, vq, heads, gh, stats, L, B, nh)
+            gaccs = [c.gacc if c.gacc is not None else torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=X.device) for c in qs]
+            gX = K.mha_prep_bwd(X, gq, gk, gv, E, scale, [(c.qmin, c.qmax) for c in qs], gaccs)
+            grads = []
+            for c, ga in zip(qs, gaccs):
+                grads += list(ops._ranges_after(c, ga))
+            return (gX, None, None, *grads)
         X, q, heads, stats, qd, kq, vq = ctx.saved_tensors
         qs = ctx.qs
         gq, gk, gv = K.attn_bwd(q, kq, vq, heads, gh, stats, L, B, nh)

@@ -530,6 +530,17 @@ int fqss_attn_bwd(const float* q, const float* k, const float* v, const float* o
                   int64_t ld_k, int64_t ld_v, int64_t ld_o, int64_t ld_go, int64_t ld_gq, int64_t ld_gk,
                   int64_t ld_gv, fqss_stream_t stream);
 
+/* The prologue of that core in the quantizing phase as one pass each way (qat_layers.py:890-905): X [R][3E] (the in-projection, row stride
+ * ld_x) -> q = fq_div(fq_q(X[:, :E]) / scale), k = fq_k(X[:, E:2E]), v = fq_v(X[:, 2E:]), each dense [R][E]; bit-identical to three
+ * fqss_actq_fwd on the thirds + fqss_unary_fwd(DIVS) + fqss_actq_fwd.  ranges: host array of 8 device pointers (min, max of the q, k,
+ * v, div quantizers).  bwd: (gq, gk, gv) -> gX [R][3E] through the STEs and the division, the intermediate values recomputed from X;
+ * gaccs: host array of 4 device pointers, range-gradient partials of q, k, v, div (FQSS_GACC_SLOTS x 3 each, "+=" as fqss_actq_bwd) */
+int fqss_mha_prep_fwd(const float* X, float* q, float* k, float* v, int64_t R, int E, int64_t ld_x, double scale,
+                      const float* const* ranges, fqss_stream_t stream);
+int fqss_mha_prep_bwd(const float* X, const float* gq, const float* gk, const float* gv, float* gX, int64_t R, int E,
+                      int64_t ld_x, int64_t ld_gx, double scale, const float* const* ranges, double* const* gaccs,
+                      fqss_stream_t stream);
+
 /* Recurrence of the bidirectional single-layer LSTM inside LSTMQ (qat_layers.py:571-600, _VF.lstm with zero state).
  *   pre  [S][B][2][4H] = x W_ih^T + b_ih of both directions (fqss_rowlin_fwd), gate order i, f, g, o
  *   whh  [2][4H][H], bhh [2][4H];  hout [S][B][2H] (forward | reverse)

@@ -946,3 +946,34 @@ def test_attn_long_short_key_tile_ignores_stale_lds():
     close(o, want, rtol=2e-5, atol=2e-5)
     gq, gk, gv = K.attn_long_bwd(q, k, v, o, rnd(B, Lq, E, seed=4).cuda(), stats, nh, True)
     assert torch.isfinite(gq).all() and torch.isfinite(gk).all() and torch.isfinite(gv).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,B,E,nh", [(250, 7, 64, 4), (63, 33, 256, 8), (5, 3, 16, 1)])
+def test_mha_prep_matches_the_unfused_quantizer_chain(L, B, E, nh):
+    """fqss_mha_prep_fwd / _bwd (the q / k / v / div quantizers and q / sqrt(head_dim) of MultiheadAttentionQ, qat_layers.py:890-905, as
+    one pass each way) against the chain it replaces -- three fqss_actq_fwd on the thirds, fqss_unary_fwd(DIVS), fqss_actq_fwd and
+    their backward launches: q / k / v and the input gradient bit for bit, the four quantizers' range partials to summation order"""
+    import math
+    from fqss_amd import kernels as K
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(L * 1000 + E)
+    X = torch.randn(L, B, 3 * E, device=dev, generator=g) * 1.3
+    scale = math.sqrt(E // nh)
+    rng = [(torch.tensor([lo], device=dev), torch.tensor([hi], device=dev)) for lo, hi in ((-2.1, 2.4), (-1.0, 3.0), (-2.9, 1.1), (-0.4, 0.6))]
+    q, k, v = K.mha_prep_fwd(X, E, scale, rng)
+    parts = [K.actq_fwd(X[..., i * E:(i + 1) * E], K.ACT_NONE, None, K.Q_QUANT, rng[i][0], rng[i][1], None) for i in range(3)]
+    qd = K.unary_fwd(parts[0], K.UNARY_DIVS, scale)
+    q_ref = K.actq_fwd(qd, K.ACT_NONE, None, K.Q_QUANT, rng[3][0], rng[3][1], None)
+    assert torch.equal(q, q_ref) and torch.equal(k, parts[1]) and torch.equal(v, parts[2])
+    gq, gk, gv = (torch.randn(L, B, E, device=dev, generator=g) for _ in range(3))
+    gaccs = [torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev) for _ in range(4)]
+    gX = K.mha_prep_bwd(X, gq, gk, gv, E, scale, rng, gaccs)
+    refs = [torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev) for _ in range(4)]
+    g2 = K.unary_bwd(K.actq_bwd(qd, gq, K.ACT_NONE, None, K.Q_QUANT, rng[3][0], rng[3][1], refs[3]), None, K.UNARY_DIVS, scale)
+    want = [K.actq_bwd(X[..., i * E:(i + 1) * E].contiguous(), gi, K.ACT_NONE, None, K.Q_QUANT, rng[i][0], rng[i][1], refs[i])
+            for i, gi in enumerate((g2, gk, gv))]
+    for i in range(3):
+        assert torch.equal(gX[..., i * E:(i + 1) * E], want[i]), i
+    for a, b in zip(gaccs, refs):
+        np.testing.assert_allclose(a.view(-1, 3).sum(0).cpu().numpy(), b.view(-1, 3).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-6)

@@ -161,6 +161,21 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&c1, (size_t)B * Co * ld * 4)); CK(hipMalloc(&bias, Co * 4)); CK(hipMemset(bias, 0, Co * 4));
         CK(hipMalloc(&slope, 4)); CK(hipMemset(slope, 0, 4)); CK(hipMalloc(&st, B * 32 * 16 * 8)); CK(hipMemset(st, 0, B * 32 * 16 * 8));
     }
+    if (!strcmp(bg, "rate")) {      // what bf16-MFMA rate do these loops sustain alone?  (the practical matrix-pipe ceiling of this part)
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int which = 0; which < 3; ++which) {
+            float ms = 0.f; double flop = 0.0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, s1));
+                if (which == 0) { hipLaunchKernelGGL(k_mfma_hog, dim3(4096), dim3(256), 64 * 1024, s1, out, 3000); flop = 4096.0 * 4 * 3000 * 4 * 32768; }
+                if (which == 1) { hipLaunchKernelGGL(k_gemm_skel, dim3(2016), dim3(256), 0, s1, out, 64); flop = 2016.0 * 4 * 64 * 48 * 32768; }
+                if (which == 2) { hipLaunchKernelGGL(k_mfma_asm<false>, dim3(2048), dim3(256), 0, s1, out, 3000); flop = 2048.0 * 4 * 3000 * 8 * 32768; }
+                CK(hipEventRecord(e1, s1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            printf("%s: %.3f ms, %.0f TFLOP/s bf16\n", which == 0 ? "k_mfma_hog (LDS-fed, 4 accumulators)" : which == 1 ? "k_gemm_skel (GEMM skeleton, 24 MFMA per 12 fragment reads)" : "k_mfma_asm (registers only)", ms, flop / ms * 1e-9);
+        }
+        return 0;
+    }
     const victim_t victims[7] = {k_victim<0, 0, 3>, k_victim<0, 2, 1>, k_victim<0, 1, 2>, k_victim<0, 2, 3>, k_victim<0, 0, 1>, k_victim<1, 2, 1>, k_victim<2, 2, 1>};
     const char* names[7] = {"v_pk_add_f32 (default)", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_add_f32 op_sel:[1,0] op_sel_hi:[0,1]",
                             "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,1]", "v_pk_add_f32 op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]",
