@@ -1,27 +1,73 @@
-"""Single-GPU cost of the data-parallel step's schedule (no exchange): cfg-2 step time with 1 vs 4 backward segments (one hipGraph each)."""
+"""Single-GPU anatomy of the data-parallel step's schedule (no exchange): for cfg 2 / cfg 4 / cfg 5 the gradient buckets (bytes per
+backward segment), the duration of every segment's hipGraph, and -- what decides how much of the exchange is exposed -- the compute
+time that still runs AFTER a bucket is ready (the remaining segments), against the time a ring all-reduce of that bucket needs on
+xGMI (2 (N-1)/N x bytes over ~7 x 153 GB/s of per-link bandwidth, one direction; MI355X_MICROARCH.md / the task statement).  Also the
+cost of cutting the backward into segments at all (1 graph vs n graphs).
+    python tools/bench_buckets.py [cfg2] [cfg4] [cfg5]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from fqss_amd.data import synth_batch
+from tools.stress_step import build
 from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
 from fqss_amd.runtime import KDTrainStep
-from fqss_amd.smoke import build_pair
-x, tgt = synth_batch(8, 32000, seed=100, device="cuda")
-for nb in (1, 4, 1, 4):
-    model, fmodel = build_pair("cuda", 0, n_spks=2, kernel_size=16, stride=8)
-    step = KDTrainStep(model, fmodel, buckets=nb)
-    step(x, tgt)
-    for m in model.modules():
+
+XGMI_RING_GBS = 7 * 153.0 / 7        # a ring all-reduce moves every byte over ONE link per hop: 153 GB/s per direction
+
+
+def make(which, nb):
+    step, x, tgt = build(which, torch.device("cuda", 0))
+    kw = dict(loss="l1_sdr", clip=0.0) if which == "cfg5" else {}
+    s = KDTrainStep(step.model, step.fmodel, lr=1e-4, buckets=nb, **kw)
+    s(x, tgt)
+    for m in s.model.modules():
         if isinstance(m, GradientActivationFakeQuantize):
             m.n_iter = m.max_observations
-    step(x, tgt); step(x, tgt)
-    step.capture(x, tgt)
-    for _ in range(3):
-        step(x, tgt)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20):
-        step(x, tgt)
-    torch.cuda.synchronize()
-    print(f"buckets {nb}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step ({len(step._graphs[0])} backward graphs)", flush=True)
-    del step, model, fmodel
-    torch.cuda.empty_cache()
+    s(x, tgt); s(x, tgt)
+    s.capture(x, tgt)
+    return s, x, tgt
+
+
+def main(workloads):
+    for which in workloads:
+        res = {}
+        for nb in (1, 4):
+            s, x, tgt = make(which, nb)
+            for _ in range(3):
+                s(x, tgt)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n = 10 if which != "cfg5" else 4
+            for _ in range(n):
+                s(x, tgt)
+            torch.cuda.synchronize()
+            res[nb] = (time.perf_counter() - t0) / n * 1e3
+            if nb == 4:
+                graphs, g2 = s._graphs
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(graphs) + 2)]
+                s._stage(x, tgt, None)
+                ev[0].record()
+                for k, gk in enumerate(graphs):
+                    gk.replay()
+                    ev[k + 1].record()
+                g2.replay()
+                ev[-1].record()
+                torch.cuda.synchronize()
+                seg_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(len(graphs))]
+                opt_ms = ev[-2].elapsed_time(ev[-1])
+                segs = s.segments if s.segments is not None else [(0, s.arena.numel)]
+                nseg = len(graphs)
+                print(f"{which}: {s.arena.numel * 4 / 1e6:.1f} MB of gradients in {nseg} buckets; step {res[1]:.2f} ms as one backward graph, "
+                      f"{res[4]:.2f} ms as {nseg} segment graphs; clip + Adam {opt_ms:.2f} ms", flush=True)
+                for k in range(nseg):      # backward segment k = forward segment nseg-1-k
+                    lo, hi = segs[nseg - 1 - k]
+                    mb = (hi - lo) * 4 / 1e6
+                    after = sum(seg_ms[k + 1:])
+                    ring8 = 2 * 7 / 8 * mb / 1e3 / 153.0 * 1e3     # ms: 2 (N-1)/N x bytes at one link's 153 GB/s (N = 8)
+                    print(f"   bucket {k} (ready after {'fwd + loss + ' if k == 0 else ''}segment {k}: {seg_ms[k]:.2f} ms): {mb:7.2f} MB, "
+                          f"ring all-reduce at 8 ranks ~{ring8:.3f} ms, backward still to run behind it {after:.2f} ms "
+                          f"-> exposed ~{max(0.0, ring8 - after):.3f} ms", flush=True)
+            del s
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or ["cfg2", "cfg4", "cfg5"])
