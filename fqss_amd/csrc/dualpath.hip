@@ -16,53 +16,115 @@ namespace fqss {
 // One wavefront per row, JC = ceil(C / 64) features per lane.  Two-pass statistics in registers (the row is loaded once).
 // Q: LayerNormQ's output quantizer in the same pass (qat_layers.py:455-465 + qat_quant.py:136-147): y receives fq(LN(x)), yc (nullable)
 // its u8 codes; the pre-quant value is never stored -- the backward recomputes it from x, mean, rstd with the same operations.
-template <int JC, bool Q>
+// VEC (JC % 4 == 0, rows 16-B aligned): a lane owns 4 CONSECUTIVE features per 256-feature group and moves them as one float4 -- 1 KB per
+// wave instruction instead of 256 B; the kernels are bound by the number of memory instructions in flight per row, not by bytes (an extra
+// operand stream cost the 4-B form 17 us of 40).
+template <int JC, bool VEC>
+__device__ __forceinline__ int ln_col(int lane, int j) {
+    return VEC ? ((j >> 2) * 256 + lane * 4 + (j & 3)) : (lane + 64 * j);
+}
+template <int JC, bool VEC>
+__device__ __forceinline__ void ln_load(const float* __restrict__ row, int lane, int C, float (&v)[JC]) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int jj = 0; jj < JC / 4; ++jj) {
+            const int c = jj * 256 + lane * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) t = *reinterpret_cast<const float4*>(row + c);
+            v[4 * jj] = t.x; v[4 * jj + 1] = t.y; v[4 * jj + 2] = t.z; v[4 * jj + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < C ? row[c] : 0.f;
+        }
+    }
+}
+template <int JC, bool VEC>
+__device__ __forceinline__ void ln_store(float* __restrict__ row, int lane, int C, const float (&v)[JC]) {
+    if constexpr (VEC) {
+#pragma unroll
+        for (int jj = 0; jj < JC / 4; ++jj) {
+            const int c = jj * 256 + lane * 4;
+            if (c < C) *reinterpret_cast<float4*>(row + c) = make_float4(v[4 * jj], v[4 * jj + 1], v[4 * jj + 2], v[4 * jj + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) row[c] = v[j];
+        }
+    }
+}
+
+template <int JC, bool Q, bool VEC>
 __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean_rstd, int64_t R, int C, int64_t ld_x,
                                                         int64_t ld_y, float eps, const float* __restrict__ qmin,
-                                                        const float* __restrict__ qmax, unsigned char* __restrict__ yc, int64_t ld_yc) {
+                                                        const float* __restrict__ qmax, unsigned char* __restrict__ yc, int64_t ld_yc,
+                                                        const float* __restrict__ xadd, int64_t ld_a, float* __restrict__ xsum,
+                                                        int64_t ld_s) {
+    // xadd / xsum (both or neither): the row that is normalised is x + xadd -- the residual add in front of a pre-norm transformer
+    // sub-layer -- and the sum is also written out (it is the residual stream of the NEXT add and the backward's input)
     QRange qr{0.0f, 1.0f, 1.0f};
     if (Q) qr = load_qrange(qmin, qmax);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     float ga[JC], be[JC];
-#pragma unroll
-    for (int j = 0; j < JC; ++j) {
-        const int c = lane + 64 * j;
-        ga[j] = c < C ? gamma[c] : 0.f;
-        be[j] = c < C ? beta[c] : 0.f;
-    }
+    ln_load<JC, VEC>(gamma, lane, C, ga);
+    ln_load<JC, VEC>(beta, lane, C, be);
     const float invC = 1.0f / (float)C;
     for (int64_t r = wave; r < R; r += nw) {
         float v[JC], s = 0.f;
+        ln_load<JC, VEC>(x + r * ld_x, lane, C, v);
+        if (xadd != nullptr) {
+            float a2[JC];
+            ln_load<JC, VEC>(xadd + r * ld_a, lane, C, a2);
 #pragma unroll
-        for (int j = 0; j < JC; ++j) {
-            const int c = lane + 64 * j;
-            v[j] = c < C ? x[r * ld_x + c] : 0.f;
-            s += v[j];
+            for (int j = 0; j < JC; ++j) v[j] = v[j] + a2[j];
+            ln_store<JC, VEC>(xsum + r * ld_s, lane, C, v);
         }
+#pragma unroll
+        for (int j = 0; j < JC; ++j) s += v[j];
         const float mean = wave_sum(s) * invC;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
-            const int c = lane + 64 * j;
-            const float d = c < C ? v[j] - mean : 0.f;
+            const float d = ln_col<JC, VEC>(lane, j) < C ? v[j] - mean : 0.f;
             q += d * d;
         }
         const float var = wave_sum(q) * invC;
         const float rstd = 1.0f / sqrtf(var + eps);
+        float o[JC];
+        unsigned char oc[JC];
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
-            const int c = lane + 64 * j;
-            if (c < C) {
-                const float z = ((v[j] - mean) * rstd) * ga[j] + be[j];
-                if (Q) {
-                    const float code = fq_code(z, qr);
-                    y[r * ld_y + c] = qr.delta * code + qr.lo;
-                    if (yc != nullptr) yc[r * ld_yc + c] = (unsigned char)code;
-                } else {
-                    y[r * ld_y + c] = z;
+            const float z = ((v[j] - mean) * rstd) * ga[j] + be[j];
+            if (Q) {
+                const float code = fq_code(z, qr);
+                o[j] = qr.delta * code + qr.lo;
+                oc[j] = (unsigned char)code;
+            } else {
+                o[j] = z;
+            }
+        }
+        ln_store<JC, VEC>(y + r * ld_y, lane, C, o);
+        if (Q && yc != nullptr) {
+            if (VEC && (ld_yc & 3) == 0) {      // four codes per lane and group: one 4-B store
+#pragma unroll
+                for (int jj = 0; jj < JC / 4; ++jj) {
+                    const int c = jj * 256 + lane * 4;
+                    if (c < C)
+                        *reinterpret_cast<unsigned int*>(yc + r * ld_yc + c) = (unsigned int)oc[4 * jj] | ((unsigned int)oc[4 * jj + 1] << 8) |
+                                                                               ((unsigned int)oc[4 * jj + 2] << 16) | ((unsigned int)oc[4 * jj + 3] << 24);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < JC; ++j) {
+                    const int c = ln_col<JC, VEC>(lane, j);
+                    if (c < C) yc[r * ld_yc + c] = oc[j];
                 }
             }
         }
@@ -77,13 +139,16 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
 // affine gradients (registers across the rows of a wave, LDS across the 4 waves, then one atomic per column and workgroup)
 // Q: gy is dL/d fq(LN(x)): the quantizer's STE (and its range-gradient partials, one gacc slot per workgroup like k_actq_bwd) runs on
 // the pre-quant value recomputed from x -- no separate fqss_actq_bwd pass, no stored z.
-template <int JC, bool Q>
+template <int JC, bool Q, bool VEC>
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ gy, const float* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                         float* __restrict__ gx, float* __restrict__ ggamma,
                                                         float* __restrict__ gbeta, int64_t R, int C, int64_t ld_gy,
                                                         int64_t ld_x, int64_t ld_gx, const float* __restrict__ beta,
-                                                        const float* __restrict__ qmin, const float* __restrict__ qmax, double* gacc) {
+                                                        const float* __restrict__ qmin, const float* __restrict__ qmax, double* gacc,
+                                                        const float* __restrict__ gadd, int64_t ld_ga) {
+    // gadd (nullable): the gradient arriving on the residual stream behind the fused add (k_layernorm_fwd's xadd form): gx = LN' + gadd is
+    // then the gradient of BOTH addends -- the sum autograd would take at the fork in a pass of its own
     __shared__ float red[2][4][64 * JC];
     __shared__ double redq[2 * 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -92,30 +157,28 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     if (Q) qr = load_qrange(qmin, qmax);
     float p_du = 0.0f, p_out = 0.0f;      // sum g*(c - m*u), sum g*(1-m)   (k_actq_bwd)
     float ga[JC], be[JC], agg[JC], agb[JC];
+    ln_load<JC, VEC>(gamma, lane, C, ga);
 #pragma unroll
-    for (int j = 0; j < JC; ++j) {
-        const int c = lane + 64 * j;
-        ga[j] = c < C ? gamma[c] : 0.f;
-        be[j] = (Q && c < C) ? beta[c] : 0.f;
-        agg[j] = agb[j] = 0.f;
-    }
+    for (int j = 0; j < JC; ++j) be[j] = agg[j] = agb[j] = 0.f;
+    if (Q) ln_load<JC, VEC>(beta, lane, C, be);
     const float invC = 1.0f / (float)C;
     for (int64_t r = wave; r < R; r += nw) {
         const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
-        float xh[JC], dxh[JC], a = 0.f, b = 0.f;
+        float gv[JC], xv[JC], av[JC], xh[JC], dxh[JC], a = 0.f, b = 0.f;
+        ln_load<JC, VEC>(gy + r * ld_gy, lane, C, gv);
+        ln_load<JC, VEC>(x + r * ld_x, lane, C, xv);
+        if (gadd != nullptr) ln_load<JC, VEC>(gadd + r * ld_ga, lane, C, av);
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
-            const int c = lane + 64 * j;
-            float g = c < C ? gy[r * ld_gy + c] : 0.f;
-            xh[j] = c < C ? (x[r * ld_x + c] - mean) * rstd : 0.f;
+            const bool live = ln_col<JC, VEC>(lane, j) < C;
+            float g = gv[j];
+            xh[j] = live ? (xv[j] - mean) * rstd : 0.f;
             if (Q) {
                 float code, u;
                 bool inr;
                 (void)fq_asym(xh[j] * ga[j] + be[j], qr, code, u, inr);      // the forward's z, operation for operation
-                if (c < C) {
-                    p_du += g * (inr ? (code - u) : code);
-                    p_out += inr ? 0.0f : g;
-                }
+                p_du += live ? g * (inr ? (code - u) : code) : 0.0f;
+                p_out += (live && !inr) ? g : 0.0f;
                 g = inr ? div_by(g * qr.delta, qr.delta, qr.inv) : 0.0f;
             }
             dxh[j] = g * ga[j];
@@ -126,16 +189,19 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         }
         a = wave_sum(a) * invC;
         b = wave_sum(b) * invC;
+        float o[JC];
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
-            const int c = lane + 64 * j;
-            if (c < C) gx[r * ld_gx + c] = rstd * ((dxh[j] - a) - xh[j] * b);
+            o[j] = rstd * ((dxh[j] - a) - xh[j] * b);
+            if (gadd != nullptr) o[j] = o[j] + av[j];
         }
+        ln_store<JC, VEC>(gx + r * ld_gx, lane, C, o);
     }
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
-        red[0][w][lane + 64 * j] = agg[j];
-        red[1][w][lane + 64 * j] = agb[j];
+        const int c = ln_col<JC, VEC>(lane, j);       // < 64 * JC
+        red[0][w][c] = agg[j];
+        red[1][w][c] = agb[j];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * 64 * JC; e += 256) {
@@ -684,24 +750,25 @@ using namespace fqss;
 
 static int layernorm_fwd_impl(const char* who, const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc,
                               float* mean_rstd, int64_t R, int C, int64_t ld_x, int64_t ld_y, int64_t ld_yc, double eps,
-                              const float* qmin, const float* qmax, fqss_stream_t stream) {
+                              const float* qmin, const float* qmax, fqss_stream_t stream, const float* xadd = nullptr, int64_t ld_a = 0,
+                              float* xsum = nullptr, int64_t ld_s = 0) {
     if (R == 0) return FQSS_OK;
     int64_t nb = cdiv(R, 4);
     if (nb > 4096) nb = 4096;
     hipStream_t s = (hipStream_t)stream;
     const float e = (float)eps;
-#define FQSS_LN_FWD(JC, Q) \
-    hipLaunchKernelGGL((k_layernorm_fwd<JC, Q>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
-                       qmax, yc, ld_yc)
-    if (qmin != nullptr) {
-        if (C <= 64) FQSS_LN_FWD(1, true);
-        else if (C <= 256) FQSS_LN_FWD(4, true);
-        else FQSS_LN_FWD(8, true);
-    } else {
-        if (C <= 64) FQSS_LN_FWD(1, false);
-        else if (C <= 256) FQSS_LN_FWD(4, false);
-        else FQSS_LN_FWD(8, false);   // HTDemucs transformer: 384 / 512
-    }
+    // float4 form: every row (and gamma / beta) 16-B aligned, C a multiple of 4
+    const bool vec = C % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
+                     (xadd == nullptr || (ld_a % 4 == 0 && ld_s % 4 == 0 && aligned16(xadd) && aligned16(xsum)));
+#define FQSS_LN_FWD(JC, Q, V) \
+    hipLaunchKernelGGL((k_layernorm_fwd<JC, Q, V>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
+                       qmax, yc, ld_yc, xadd, ld_a, xsum, ld_s)
+#define FQSS_LN_FWD_Q(Q) \
+    if (C <= 64) FQSS_LN_FWD(1, Q, false); \
+    else if (C <= 256) { if (vec) FQSS_LN_FWD(4, Q, true); else FQSS_LN_FWD(4, Q, false); } \
+    else { if (vec) FQSS_LN_FWD(8, Q, true); else FQSS_LN_FWD(8, Q, false); }      /* HTDemucs transformer: 384 / 512 */
+    if (qmin != nullptr) { FQSS_LN_FWD_Q(true) } else { FQSS_LN_FWD_Q(false) }
+#undef FQSS_LN_FWD_Q
 #undef FQSS_LN_FWD
     return launch_status(who);
 }
@@ -723,24 +790,24 @@ extern "C" int fqss_layernormq_fwd(const float* x, const float* gamma, const flo
 
 static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, const float* gamma, const float* beta,
                               const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy,
-                              int64_t ld_x, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+                              int64_t ld_x, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream,
+                              const float* gadd = nullptr, int64_t ld_ga = 0) {
     if (R == 0) return FQSS_OK;
     int64_t nb = cdiv(R, 4 * 16);       // ~16 rows per wave: 64*C atomics per workgroup stay rare
     if (nb < 1) nb = 1;
     if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
     hipStream_t s = (hipStream_t)stream;
-#define FQSS_LN_BWD(JC, Q) \
-    hipLaunchKernelGGL((k_layernorm_bwd<JC, Q>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
-                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc)
-    if (qmin != nullptr) {
-        if (C <= 64) FQSS_LN_BWD(1, true);
-        else if (C <= 256) FQSS_LN_BWD(4, true);
-        else FQSS_LN_BWD(8, true);
-    } else {
-        if (C <= 64) FQSS_LN_BWD(1, false);
-        else if (C <= 256) FQSS_LN_BWD(4, false);
-        else FQSS_LN_BWD(8, false);
-    }
+    const bool vec = C % 4 == 0 && ld_gy % 4 == 0 && ld_x % 4 == 0 && ld_gx % 4 == 0 && aligned16(gy) && aligned16(x) && aligned16(gx) &&
+                     aligned16(gamma) && (beta == nullptr || aligned16(beta)) && (gadd == nullptr || (ld_ga % 4 == 0 && aligned16(gadd)));
+#define FQSS_LN_BWD(JC, Q, V) \
+    hipLaunchKernelGGL((k_layernorm_bwd<JC, Q, V>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
+                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc, gadd, ld_ga)
+#define FQSS_LN_BWD_Q(Q) \
+    if (C <= 64) FQSS_LN_BWD(1, Q, false); \
+    else if (C <= 256) { if (vec) FQSS_LN_BWD(4, Q, true); else FQSS_LN_BWD(4, Q, false); } \
+    else { if (vec) FQSS_LN_BWD(8, Q, true); else FQSS_LN_BWD(8, Q, false); }
+    if (qmin != nullptr) { FQSS_LN_BWD_Q(true) } else { FQSS_LN_BWD_Q(false) }
+#undef FQSS_LN_BWD_Q
 #undef FQSS_LN_BWD
     return launch_status(who);
 }
@@ -761,6 +828,32 @@ extern "C" int fqss_layernormq_bwd(const float* g, const float* x, const float* 
     FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_g >= C && ld_x >= C && ld_gx >= C, "bad shape (C <= 512)");
     return layernorm_bwd_impl("fqss_layernormq_bwd", g, x, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, ld_g, ld_x, ld_gx, qmin, qmax,
                               gacc, stream);
+}
+
+
+/* the residual add in FRONT of a pre-norm sub-layer fused into its LayerNorm(Q) (sepformerq.py:69-82: `x = x + mha(norm1(x))`, then
+ * `norm2(x)` ...): s = a + b is written once (the residual stream), y = LN(s) or fq(LN(s)) (qmin / qmax / yc NULL: plain) */
+extern "C" int fqss_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, float* s, float* y, uint8_t* yc,
+                                      float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_s, int64_t ld_y,
+                                      int64_t ld_yc, double eps, const float* qmin, const float* qmax, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && b && gamma && beta && s && y && mean_rstd && ((qmin == nullptr) == (qmax == nullptr)), "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_a >= C && ld_b >= C && ld_s >= C && ld_y >= C && (yc == nullptr || (qmin && ld_yc >= C)),
+                 "bad shape (C <= 512)");
+    return layernorm_fwd_impl("fqss_add_layernorm_fwd", a, gamma, beta, y, yc, mean_rstd, R, C, ld_a, ld_y, ld_yc, eps, qmin, qmax, stream, b,
+                              ld_b, s, ld_s);
+}
+
+/* its backward: g = dL/dy, gs = dL/ds arriving over the residual stream (nullable); gx = LayerNorm(Q) backward at s + gs: the gradient
+ * of a AND of b; ggamma / gbeta "+=", the quantizer's range partials to gacc (qmin / qmax / gacc NULL: plain) */
+extern "C" int fqss_add_layernorm_bwd(const float* g, const float* gs, const float* s, const float* gamma, const float* beta,
+                                      const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g,
+                                      int64_t ld_gs, int64_t ld_s, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc,
+                                      fqss_stream_t stream) {
+    FQSS_REQUIRE(g && s && gamma && mean_rstd && gx && ggamma && gbeta, "null tensor");
+    FQSS_REQUIRE((qmin == nullptr) == (qmax == nullptr) && (qmin == nullptr || (gacc && beta)), "quantizer: ranges, beta and gacc together");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_g >= C && ld_s >= C && ld_gx >= C && (gs == nullptr || ld_gs >= C), "bad shape (C <= 512)");
+    return layernorm_bwd_impl("fqss_add_layernorm_bwd", g, s, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, ld_g, ld_s, ld_gx, qmin, qmax,
+                              gacc, stream, gs, ld_gs);
 }
 
 extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream) {

@@ -1048,6 +1048,36 @@ def layernormq_bwd(g, x, gamma, beta, mean_rstd, ggamma, gbeta, qmin, qmax, gacc
     return gx
 
 
+def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=False):
+    """s = a + b; y = LN(s) or fq(LN(s)) -> (s, y, codes or None, mean_rstd)"""
+    _need_gpu(a, b, gamma, beta)
+    C = gamma.numel()
+    a, R, ld_a = _rows(a, C)
+    b, Rb, ld_b = _rows(b, C)
+    assert R == Rb and a.shape == b.shape
+    s = torch.empty(*a.shape, device=a.device, dtype=torch.float32)
+    y = torch.empty(*a.shape, device=a.device, dtype=torch.float32)
+    yc = torch.empty(*a.shape, device=a.device, dtype=torch.uint8) if (want_codes and qmin is not None) else None
+    mean_rstd = torch.empty(R, 2, device=a.device, dtype=torch.float32)
+    _lib.call("fqss_add_layernorm_fwd", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C, C, C,
+              float(eps), _p(qmin), _p(qmax), _stream())
+    return s, y, yc, mean_rstd
+
+
+def add_layernorm_bwd(g, gs, s, gamma, beta, mean_rstd, ggamma, gbeta, qmin=None, qmax=None, gacc=None):
+    _need_gpu(g, gs, s, gamma, mean_rstd, ggamma, gbeta)
+    C = gamma.numel()
+    g, R, ld_g = _rows(g, C)
+    s, _, ld_s = _rows(s, C)
+    ld_gs = 0
+    if gs is not None:
+        gs, _, ld_gs = _rows(gs, C)
+    gx = torch.empty(*s.shape, device=s.device, dtype=torch.float32)
+    _lib.call("fqss_add_layernorm_bwd", _p(g), _p(gs), _p(s), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_g,
+              ld_gs, ld_s, C, _p(qmin), _p(qmax), _p(gacc), _stream())
+    return gx
+
+
 def _ptr_array(ts):
     return (_C.c_void_p * len(ts))(*[_p(t) for t in ts])
 

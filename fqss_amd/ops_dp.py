@@ -207,6 +207,36 @@ class LayerNormRowsQ(Function):
         return gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None
 
 
+class AddLayerNormRows(Function):
+    """(y, s) = (LN(a + b) or fq(LN(a + b)), a + b): the float residual add in front of a pre-norm transformer sub-layer fused into its
+    LayerNorm / LayerNormQ -- one kernel each way (fqss_add_layernorm_fwd/bwd).  The backward adds the gradient that arrives over the
+    residual stream `s` in its epilogue and hands the SAME tensor to both addends: the fork's sum costs no pass of its own.
+    q = None: plain LayerNorm (float teacher, or a LayerNormQ outside the quantizing phase is not routed here)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps, qmin, qmax, q, want_codes):
+        s, y, idx, mean_rstd = K.add_layernorm_fwd(a, b, gamma, beta, eps, qmin, qmax, want_codes)
+        if q is not None:
+            q.idx = idx
+        ctx.save_for_backward(s, gamma, beta, mean_rstd, qmin, qmax)
+        ctx.q = q
+        return y, s
+
+    @staticmethod
+    def backward(ctx, gy, gs):
+        s, gamma, beta, mean_rstd, qmin, qmax = ctx.saved_tensors
+        q = ctx.q
+        gg, d1 = _param_grad(gamma, gamma)
+        gb, d2 = _param_grad(beta, beta)
+        if gy is None:                       # the normalised branch is unused: only the residual stream carries a gradient
+            return gs, gs, None, None, None, None, None, None, None
+        gx = K.add_layernorm_bwd(gy.contiguous(), gs, s, gamma, beta, mean_rstd, gg, gb, qmin, qmax, q.gacc if q is not None else None)
+        g_min = g_max = None
+        if q is not None:
+            _, g_min, g_max = ops._flush_ranges(q, None, None, ops.ACT_NONE)
+        return gx, gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None
+
+
 class Unary(Function):
     """tanh / sigmoid (the gated output convs, dptnetq.py:286-287)"""
 

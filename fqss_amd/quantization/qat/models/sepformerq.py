@@ -66,19 +66,23 @@ class TransformerLayer(nn.Module):
         self.norm1 = nn.LayerNorm(n_filters, eps=EPS_T)
         self.norm2 = nn.LayerNorm(n_filters, eps=EPS_T)
 
-    def forward(self, x):
-        """x [L, B', F] sequence-first (the reference holds it batch-first and permutes around the attention, :77-79)"""
-        x_n, x_res = ops.fork2(x)
-        q = run(self.norm1, x_n)
+    def forward(self, x, add=None):
+        """x [L, B', F] sequence-first (the reference holds it batch-first and permutes around the attention, :77-79).
+        `add`: a tensor that is still to be ADDED to x (the previous layer's feed-forward output): the float residual adds of the
+        reference (`x = x + attn`, `x = x + ffn`, :78-82) are folded into the LayerNorm that follows them (QL.add_layernorm: one kernel
+        each way instead of add + norm, and no separate gradient sum at the fork).  Returns (residual stream, pending addend)."""
+        if add is None:
+            x_n, x_res = ops.fork2(x)
+            q = run(self.norm1, x_n)
+        else:
+            q, x_res = QL.add_layernorm(self.norm1, x, add)
         a = _float_mha(self.mha, q) if isinstance(self.mha, nn.MultiheadAttention) else self.mha(q, q, q)[0]
-        x = _fadd(x_res, a)
-        x_n, x_res = ops.fork2(x)
-        h = run(self.norm2, x_n)
+        h, x_res = QL.add_layernorm(self.norm2, x_res, a)
         for m in self.ffn:
             if isinstance(m, (nn.Dropout, nn.Identity)):
                 continue
             h = QL.fq_node(None, h, m) if isinstance(m, nn.ReLU) else run(m, h)
-        return _fadd(x_res, h)
+        return x_res, h
 
 
 class TransformerBlock(nn.Module):
@@ -92,9 +96,10 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x):
         x = self.pos_add(x, self.pos(x))
+        add = None
         for layer in self.layers:
-            x = layer(x)
-        return run(self.norm, x)
+            x, add = layer(x, add)
+        return QL.add_layernorm(self.norm, x, add)[0]        # the last layer's `x + ffn` and the block's final norm
 
 
 def _gln_rows(gn, x, geom):

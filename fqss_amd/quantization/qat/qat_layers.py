@@ -723,6 +723,35 @@ def run_layernorm(ln, x, aq):
     return fq_node(aq, ops_dp.LayerNormRows.apply(ops.real(x), ln.weight, ln.bias, ln.eps), codes=True, q=q)
 
 
+def add_layernorm(norm, a, b):
+    """(norm(a + b), a + b) for the float residual add that feeds a pre-norm sub-layer (`x = x + sublayer(...)` followed by `norm(x)`):
+    fused into ONE kernel each way (ops_dp.AddLayerNormRows) for an nn.LayerNorm and for a LayerNormQ in the quantizing phase; any
+    other state (observer phase, per-module quantizers without a gacc arena, FQSS_FUSE_ADDLN=0) takes the un-fused pair"""
+    ln = norm.layernorm if isinstance(norm, LayerNormQ) else norm
+    a, b = ops.real(a), ops.real(b)
+    if FUSE_ADDLN and isinstance(ln, nn.LayerNorm) and len(ln.normalized_shape) == 1 and ln.elementwise_affine:
+        if not isinstance(norm, LayerNormQ):
+            y, s = ops_dp.AddLayerNormRows.apply(a, b, ln.weight, ln.bias, ln.eps, None, None, None, False)
+            return y, s
+        aq = norm.activation_fake_quantize
+        if FUSE_LNQ and getattr(aq, "observer_mode", None) is not None and not (aq.observer_mode and aq.n_iter < aq.max_observations) \
+                and getattr(aq, "_gacc", None) is not None:
+            q = aq.qctx()
+            if q.qmode == ops.Q_QUANT and q.gacc is not None:
+                want = ops_dp.QROW and ops.CODED
+                y, s = ops_dp.AddLayerNormRows.apply(a, b, ln.weight, ln.bias, ln.eps, q.qmin, q.qmax, q, want)
+                aq.after_forward(q)
+                idx, q.idx = q.idx, None
+                if idx is not None:
+                    y._fqss_rowq = ops.ActCodes(idx.view(y.shape), q.qmin.detach(), q.qmax.detach())
+                return y, s
+            raise RuntimeError("add_layernorm: quantizer state changed between the check and qctx()")
+    s = ops.AddActQ.apply(a, b, None, None, 1.0, ops.BYPASS)
+    s_n, s_res = ops.fork2(s)
+    return norm(s_n), s_res
+
+
+FUSE_ADDLN = __import__("os").environ.get("FQSS_FUSE_ADDLN", "1") != "0"   # residual add + LayerNorm(Q) as one kernel each way
 FUSE_LNQ = __import__("os").environ.get("FQSS_FUSE_LNQ", "1") != "0"     # 0: LayerNorm and its quantizer as separate launches (A/B, tests)
 
 

@@ -478,6 +478,19 @@ int fqss_layernormq_bwd(const float* g, const float* x, const float* gamma, cons
                         float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g, int64_t ld_x,
                         int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream);
 
+/* The residual add in front of a pre-norm transformer sub-layer fused into its LayerNorm / LayerNormQ (sepformerq.py:69-82, the float
+ * `+` of `x = x + sublayer(norm(x))` followed by the next norm): s = a + b is written once (the residual stream), y = LN(s) or, with
+ * qmin / qmax, fq(LN(s)) (+ codes yc, nullable).  bwd: g = dL/dy, gs = dL/ds arriving over the residual stream (nullable); gx = the
+ * LayerNorm(Q) backward at s, + gs: the gradient of a AND of b (the sum autograd takes at the fork); replaces fqss_axpby + fqss_layernorm[q]_fwd
+ * and fqss_layernorm[q]_bwd + fqss_axpby */
+int fqss_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, float* s, float* y, uint8_t* yc,
+                           float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_s, int64_t ld_y, int64_t ld_yc,
+                           double eps, const float* qmin, const float* qmax, fqss_stream_t stream);
+int fqss_add_layernorm_bwd(const float* g, const float* gs, const float* s, const float* gamma, const float* beta,
+                           const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g,
+                           int64_t ld_gs, int64_t ld_s, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc,
+                           fqss_stream_t stream);
+
 /* element-wise maps on dense tensors; kind: 0 tanh, 1 sigmoid, 2 division by the scalar p
  * replaces: nn.Tanh / nn.Sigmoid inside Conv1dNlQ (dptnetq.py:286-287), q / sqrt(head_dim) (qat_layers.py:905).
  * bwd takes the forward OUTPUT y (tanh, sigmoid); y may be NULL for kind 2.                          */
