@@ -27,6 +27,7 @@ _PROTOS = {
     "fqss_wq_multi_bwd": [P, I32, I32, P],
     "fqss_pwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_fwd_x3": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_pwconv_fwd_x3s": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_wq_codes": [P, P, P, P, P, I32, I32, P, P, P],

@@ -531,6 +531,440 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_mfma(const float* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same three passes on the bf16 matrix cores (16x the fp32 MFMA rate): every fp32 operand -- q, k, v, dO, and the probabilities
+// and dS computed in between -- is split EXACTLY into three bf16 pieces (8 mantissa bits each) and the six partial products above
+// 2^-24 of each product are accumulated in fp32, smallest first: the arithmetic of csrc/gemm_x3.hip, fp32-grade results at 6/16 of
+// the fp32-MFMA instruction time.  v_mfma_f32_32x32x16_bf16 takes 8 consecutive k per lane:
+//   * tiles live in LDS as three bf16 planes [32 rows][HD + 8]; the A operand of T = K Q^T is one 16-B read per plane and k-step;
+//     lane c supplies row kappa(c) of the tile, a fixed permutation chosen so that accumulator register r of lane half lk holds the
+//     logit of tile row krow(r, lk) = 16 (r >> 3) + 8 lk + (r & 7): registers 8s .. 8s+7 of a lane are then the 8 consecutive k of
+//     k-step s, i.e. exp(T - m) (and dS) in registers ARE the A operands of the second product, as in the fp32 form;
+//   * the lane's own row (q; k / v in the dk/dv pass; dO) is the B operand, split once into registers;
+//   * the B operand of the second product (V, K, dO, Q as [row = k][d = n]) comes out of the same planes through the transposing
+//     LDS read ds_read_tr16_b64 (the idiom of csrc/qgemm.hip).
+// Needs 16-B aligned rows (float4 global loads); the fp32-MFMA kernels above remain for everything else (FQSS_ATTN_MFMA=f32 forces them).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int krow(int r, int lk) { return 16 * (r >> 3) + 8 * lk + (r & 7); }
+__device__ __forceinline__ int kappa(int c) { return (c & 16) + 8 * ((c >> 2) & 1) + (c & 3) + 4 * ((c >> 3) & 1); }
+__device__ __forceinline__ float al_trunc(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
+
+// exp(x) for x <= 0 (a logit minus the row maximum) as v_exp_f32(x log2 e): the rounding of the product is |x| 2^-24 relative in the
+// result, far below the fp32 noise of the dot products; -inf -> 0
+__device__ __forceinline__ float al_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+struct Frag3 {
+    bf16x8 p[3];      // head, middle, tail
+};
+// 8 fp32 values -> three bf16x8 (v_perm picks the high halves of two fp32 words = truncation; the remainders are exact)
+__device__ __forceinline__ Frag3 split8(const float (&x)[8]) {
+    union { bf16x8 v; unsigned int w[4]; } h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = x[2 * q], b = x[2 * q + 1];
+        const float ar = a - al_trunc(a), br = b - al_trunc(b);
+        const float al = ar - al_trunc(ar), bl = br - al_trunc(br);
+        h.w[q] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        m.w[q] = __builtin_amdgcn_perm(__float_as_uint(br), __float_as_uint(ar), 0x07060302u);
+        l.w[q] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+    }
+    Frag3 f;
+    f.p[0] = h.v; f.p[1] = m.v; f.p[2] = l.v;
+    return f;
+}
+
+// the six products, smallest first: (A piece, B piece) = l.h, h.l, m.m, m.h, h.m, h.h
+#define FQSS_X3_PRODUCTS(ACC, A, B)                                                                   \
+    do {                                                                                                \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[2], (B).p[0], ACC, 0, 0, 0);               \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[0], (B).p[2], ACC, 0, 0, 0);               \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[1], (B).p[1], ACC, 0, 0, 0);               \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[1], (B).p[0], ACC, 0, 0, 0);               \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[0], (B).p[1], ACC, 0, 0, 0);               \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[0], (B).p[0], ACC, 0, 0, 0);               \
+    } while (0)
+
+// a 32-row tile of one head: global (float4, rows clamped into the operand) -> registers -> three bf16 planes in LDS
+template <int HD>
+struct Tile3 {
+    static constexpr int LD = HD + 8, NV = HD / 32;
+    float4 v[NV];
+    int nrows_;
+    __device__ __forceinline__ void fetch(const float* __restrict__ x, const RowView rv, int b, int h, int r0, int nrows) {
+        nrows_ = nrows;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = threadIdx.x + 256 * u, j = e / (HD / 4), d = (e % (HD / 4)) * 4;
+            v[u] = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + min(j, nrows - 1)) * rv.sl + (int64_t)b * rv.sb + h * HD + d);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*pl)[32][LD]) const {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = threadIdx.x + 256 * u, j = e / (HD / 4), d = (e % (HD / 4)) * 4;
+            const bool ok = j < nrows_;
+            const float x[4] = {ok ? v[u].x : 0.f, ok ? v[u].y : 0.f, ok ? v[u].z : 0.f, ok ? v[u].w : 0.f};
+            unsigned int w[3][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float a = x[2 * q], c = x[2 * q + 1];
+                const float ar = a - al_trunc(a), cr = c - al_trunc(c);
+                const float al = ar - al_trunc(ar), cl = cr - al_trunc(cr);
+                w[0][q] = __builtin_amdgcn_perm(__float_as_uint(c), __float_as_uint(a), 0x07060302u);
+                w[1][q] = __builtin_amdgcn_perm(__float_as_uint(cr), __float_as_uint(ar), 0x07060302u);
+                w[2][q] = __builtin_amdgcn_perm(__float_as_uint(cl), __float_as_uint(al), 0x07060302u);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(&pl[p][j][d]) = make_uint2(w[p][0], w[p][1]);
+        }
+    }
+};
+
+// A operand of a first product: row kappa(c) of the tile, k-step ks
+template <int LD>
+__device__ __forceinline__ Frag3 frag_rows(const unsigned short (*pl)[32][LD], int kap, int ks, int lk) {
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const bf16x8*>(&pl[p][kap][16 * ks + 8 * lk]);
+    return f;
+}
+// B operand of a second product: B[k = tile row 16 ks + 8 lh + 0..7][n = d0 + (lane & 31)] through the transposing read
+template <int LD>
+__device__ __forceinline__ Frag3 frag_cols(const unsigned short (*pl)[32][LD], int ks, int d0, int lane) {
+    const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int kr = ks * 16 + 8 * (gq >> 1) + tq, nc = d0 + 16 * (gq & 1) + 4 * tp;
+    Frag3 f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        union { bf16x8 v; s16x4 h[2]; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&pl[p][kr][nc]));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&pl[p][kr + 4][nc]));
+        f.p[p] = u.v;
+    }
+    return f;
+}
+// the lane's own row as a B operand: x[16 ks + 8 lk + 0..7]
+__device__ __forceinline__ Frag3 frag_own(const float* __restrict__ row, int ks, int lk) {
+    const float4 a = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * lk), b = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * lk + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return split8(x);
+}
+
+template <int HD, bool OBS>
+__global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           float* __restrict__ o, float* __restrict__ stats, const AttnGeom g,
+                                                           uint32_t* obs_attn, uint32_t* obs_soft) {
+    constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Kp[3][32][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vp[3][32][LD];
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    const int i_own = it * 32 + c;
+    const bool live = i_own < g.Lq;
+    const float* qp = q + (int64_t)(live ? i_own : g.Lq - 1) * g.q.sl + (int64_t)b * g.q.sb + h * HD;
+    Frag3 qb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qb[ks] = frag_own(qp, ks, lk);
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
+    float m = -INFINITY, l = 0.f, smin = INFINITY;
+    const int kap = kappa(c);
+    Tile3<HD> kt, vt;
+    kt.fetch(k, g.k, b, h, 0, min(32, g.Lk));
+    vt.fetch(v, g.v, b, h, 0, min(32, g.Lk));
+    for (int j0 = 0; j0 < g.Lk; j0 += 32) {
+        const int nj = min(32, g.Lk - j0);
+        __syncthreads();
+        kt.store(Kp);
+        vt.store(Vp);
+        __syncthreads();
+        if (j0 + 32 < g.Lk) {
+            kt.fetch(k, g.k, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+            vt.fetch(v, g.v, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+        }
+        f32x16 T0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = 0.f;
+        Frag3 ka[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka[ks] = frag_rows<LD>(Kp, kap, ks, lk);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) FQSS_X3_PRODUCTS(T0, ka[ks], qb[ks]);
+        if (nj < 32) {                                // the last tile: padding keys leave the softmax
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T0[r] = krow(r, lk) < nj ? T0[r] : -INFINITY;
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, T0[r]);
+        if (OBS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) smin = fminf(smin, T0[r] == -INFINITY ? INFINITY : T0[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float sc = al_exp(m - m_new);          // 0 on the first tile
+        if (__any(sc != 1.0f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = __shfl(sc, tile_row(r, lk), 64);     // the factor of the query that owns accumulator row r
+#pragma unroll
+                for (int nd = 0; nd < ND; ++nd) acc[nd][r] *= f;
+            }
+        }
+        l *= sc;
+        m = m_new;
+        Frag3 pa[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pr[e] = al_exp(T0[8 * s2 + e] - m);
+                l += pr[e];
+            }
+            pa[s2] = split8(pr);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const Frag3 vb = frag_cols<LD>(Vp, s2, 32 * nd, lane);
+                FQSS_X3_PRODUCTS(acc[nd], pa[s2], vb);
+            }
+    }
+    l += __shfl_xor(l, 32, 64);
+    smin = fminf(smin, __shfl_xor(smin, 32, 64));
+    if (lk == 0 && live) {
+        stats[((int64_t)bh * g.Lq + i_own) * 2] = m;
+        stats[((int64_t)bh * g.Lq + i_own) * 2 + 1] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = tile_row(r, lk);
+        const float lr = __shfl(l, il, 64);
+        const int i = it * 32 + il;
+        if (i < g.Lq) {
+            float* op = o + (int64_t)i * g.o.sl + (int64_t)b * g.o.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) op[32 * nd] = acc[nd][r] / lr;
+        }
+    }
+    if (OBS) {
+        float smin_all = live ? smin : INFINITY, smax_all = live ? m : -INFINITY;
+        float pmax_all = live ? 1.0f / l : -INFINITY, pmin_all = live ? expf(smin - m) / l : INFINITY;
+        smin_all = wave_min(smin_all); smax_all = wave_max(smax_all);
+        pmin_all = wave_min(pmin_all); pmax_all = wave_max(pmax_all);
+        if (lane == 0 && smin_all <= smax_all) {
+            atomicMin(obs_attn, f2ord(smin_all)); atomicMax(obs_attn + 1, f2ord(smax_all));
+            atomicMin(obs_soft, f2ord(pmin_all)); atomicMax(obs_soft + 1, f2ord(pmax_all));
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd_q_x3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             const float* __restrict__ o, const float* __restrict__ go,
+                                                             const float* __restrict__ stats, float* __restrict__ gq, float* __restrict__ dsum,
+                                                             const AttnGeom g) {
+    constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Kp[3][32][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vp[3][32][LD];
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    const int i_own = it * 32 + c;
+    const bool live = i_own < g.Lq;
+    const int ic = live ? i_own : g.Lq - 1;
+    const float* qp = q + (int64_t)ic * g.q.sl + (int64_t)b * g.q.sb + h * HD;
+    const float* gp = go + (int64_t)ic * g.go.sl + (int64_t)b * g.go.sb + h * HD;
+    const float* op = o + (int64_t)ic * g.o.sl + (int64_t)b * g.o.sb + h * HD;
+    Frag3 qb[KS], gb[KS];
+    float D = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qb[ks] = frag_own(qp, ks, lk);
+        gb[ks] = frag_own(gp, ks, lk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D = fmaf(gp[16 * ks + 8 * lk + e], op[16 * ks + 8 * lk + e], D);
+    }
+    D += __shfl_xor(D, 32, 64);
+    const float m = stats[((int64_t)bh * g.Lq + ic) * 2], rl = 1.0f / stats[((int64_t)bh * g.Lq + ic) * 2 + 1];
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
+    const int kap = kappa(c);
+    Tile3<HD> kt, vt;
+    kt.fetch(k, g.k, b, h, 0, min(32, g.Lk));
+    vt.fetch(v, g.v, b, h, 0, min(32, g.Lk));
+    for (int j0 = 0; j0 < g.Lk; j0 += 32) {
+        const int nj = min(32, g.Lk - j0);
+        __syncthreads();
+        kt.store(Kp);
+        vt.store(Vp);
+        __syncthreads();
+        if (j0 + 32 < g.Lk) {
+            kt.fetch(k, g.k, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+            vt.fetch(v, g.v, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+        }
+        f32x16 T0, U0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = U0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const Frag3 ka = frag_rows<LD>(Kp, kap, ks, lk), va = frag_rows<LD>(Vp, kap, ks, lk);
+            FQSS_X3_PRODUCTS(T0, ka, qb[ks]);
+            FQSS_X3_PRODUCTS(U0, va, gb[ks]);
+        }
+        if (nj < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T0[r] = krow(r, lk) < nj ? T0[r] : -INFINITY;      // probability 0
+        }
+        Frag3 da[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s2 + e;
+                ds[e] = al_exp(T0[r] - m) * rl * (U0[r] - D);
+            }
+            da[s2] = split8(ds);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const Frag3 kb = frag_cols<LD>(Kp, s2, 32 * nd, lane);
+                FQSS_X3_PRODUCTS(acc[nd], da[s2], kb);
+            }
+    }
+    if (lk == 0 && live) dsum[(int64_t)bh * g.Lq + i_own] = D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = it * 32 + tile_row(r, lk);
+        if (i < g.Lq) {
+            float* gp2 = gq + (int64_t)i * g.gq.sl + (int64_t)b * g.gq.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) gp2[32 * nd] = acc[nd][r];
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd_kv_x3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                              const float* __restrict__ go, const float* __restrict__ stats,
+                                                              const float* __restrict__ dsum, float* __restrict__ gk, float* __restrict__ gv,
+                                                              const AttnGeom g) {
+    constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Qp[3][32][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Gp[3][32][LD];
+    __shared__ float Ms[32], Rs[32], Ds[32];
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int jt = blockIdx.x * 4 + wave;
+    const int j_own = jt * 32 + c;
+    const int jc = j_own < g.Lk ? j_own : g.Lk - 1;
+    const float* kp = k + (int64_t)jc * g.k.sl + (int64_t)b * g.k.sb + h * HD;
+    const float* vp = v + (int64_t)jc * g.v.sl + (int64_t)b * g.v.sb + h * HD;
+    Frag3 kb[KS], vb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { kb[ks] = frag_own(kp, ks, lk); vb[ks] = frag_own(vp, ks, lk); }
+    f32x16 ak[ND], av[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ak[nd][r] = av[nd][r] = 0.f;
+    const int kap = kappa(c);
+    Tile3<HD> qt, gt;
+    qt.fetch(q, g.q, b, h, 0, min(32, g.Lq));
+    gt.fetch(go, g.go, b, h, 0, min(32, g.Lq));
+    for (int i0 = 0; i0 < g.Lq; i0 += 32) {
+        const int ni = min(32, g.Lq - i0);
+        __syncthreads();
+        qt.store(Qp);
+        gt.store(Gp);
+        if (threadIdx.x < 32) {
+            const bool ok = threadIdx.x < ni;
+            const int64_t si = (int64_t)bh * g.Lq + i0 + (ok ? threadIdx.x : 0);
+            Ms[threadIdx.x] = ok ? stats[si * 2] : 0.f;
+            Rs[threadIdx.x] = ok ? 1.0f / stats[si * 2 + 1] : 0.f;      // padding queries: probability 0
+            Ds[threadIdx.x] = ok ? dsum[si] : 0.f;
+        }
+        __syncthreads();
+        if (i0 + 32 < g.Lq) {
+            qt.fetch(q, g.q, b, h, i0 + 32, min(32, g.Lq - i0 - 32));
+            gt.fetch(go, g.go, b, h, i0 + 32, min(32, g.Lq - i0 - 32));
+        }
+        f32x16 T0, U0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = U0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const Frag3 qa = frag_rows<LD>(Qp, kap, ks, lk), ga = frag_rows<LD>(Gp, kap, ks, lk);
+            FQSS_X3_PRODUCTS(T0, qa, kb[ks]);
+            FQSS_X3_PRODUCTS(U0, ga, vb[ks]);
+        }
+        Frag3 pa[2], da[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pv[8], ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s2 + e, row = krow(r, lk);
+                pv[e] = al_exp(T0[r] - Ms[row]) * Rs[row];
+                ds[e] = pv[e] * (U0[r] - Ds[row]);
+            }
+            pa[s2] = split8(pv);
+            da[s2] = split8(ds);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const Frag3 gr = frag_cols<LD>(Gp, s2, 32 * nd, lane), qr = frag_cols<LD>(Qp, s2, 32 * nd, lane);
+                FQSS_X3_PRODUCTS(av[nd], pa[s2], gr);
+                FQSS_X3_PRODUCTS(ak[nd], da[s2], qr);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + tile_row(r, lk);
+        if (j < g.Lk) {
+            float* gkp = gk + (int64_t)j * g.gk.sl + (int64_t)b * g.gk.sb + h * HD + c;
+            float* gvp = gv + (int64_t)j * g.gv.sl + (int64_t)b * g.gv.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) { gkp[32 * nd] = ak[nd][r]; gvp[32 * nd] = av[nd][r]; }
+        }
+    }
+}
+
+// 0: vector ALU, 1: fp32 MFMA, 2: split-bf16 MFMA (default where head_dim and alignment allow)
+static int attn_mfma_mode() {
+    static const int mode = [] {
+        const char* e = getenv("FQSS_ATTN_MFMA");
+        if (e && e[0] == '0') return 0;
+        if (e && (e[0] == 'f' || e[0] == '1')) return 1;
+        return 2;
+    }();
+    return mode;
+}
+static bool rows_aligned16(const void* const* ptrs, int np, const int64_t* st, int ns) {
+    for (int t = 0; t < np; ++t) if (!aligned16(ptrs[t])) return false;
+    for (int t = 0; t < ns; ++t) if (st[t] % 4 != 0) return false;
+    return true;
+}
+
 static int check_attn(int Lq, int Lk, int B, int nh, int hd, const int64_t* st, int n) {
     FQSS_REQUIRE(Lq > 0 && Lk > 0 && B > 0 && nh > 0 && (int64_t)B * nh <= 65535, "bad shape");
     for (int t = 0; t < n; ++t) FQSS_REQUIRE(st[2 * t] >= (int64_t)nh * hd && st[2 * t + 1] >= (int64_t)nh * hd, "row stride below embed dim");
@@ -560,7 +994,20 @@ extern "C" int fqss_attn_long_fwd(const float* q, const float* k, const float* v
     FQSS_REQUIRE((obs_attn == nullptr) == (obs_soft == nullptr), "observer workspaces come in pairs");
     if (int rc = check_attn(Lq, Lk, B, nh, hd, strides, 4)) return rc;
     AttnGeom g{Lq, Lk, B, nh, {strides[0], strides[1]}, {strides[2], strides[3]}, {strides[4], strides[5]}, {strides[6], strides[7]}, {}, {}, {}, {}};
-    static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    const int mode = attn_mfma_mode();
+    const bool use_mfma = mode != 0;
+    if (mode == 2 && (hd == 32 || hd == 64)) {
+        const void* ptrs[3] = {q, k, v};
+        if (rows_aligned16(ptrs, 3, strides, 6)) {
+            dim3 gm((unsigned)cdiv(Lq, 128), (unsigned)(B * nh));
+            const bool obs = obs_attn != nullptr;
+#define FQSS_AL_FWD(HD_, OBS_) hipLaunchKernelGGL((k_attn_long_fwd_x3<HD_, OBS_>), gm, dim3(256), 0, (hipStream_t)stream, q, k, v, o, stats, g, obs_attn, obs_soft)
+            if (hd == 32) { if (obs) FQSS_AL_FWD(32, true); else FQSS_AL_FWD(32, false); }
+            else { if (obs) FQSS_AL_FWD(64, true); else FQSS_AL_FWD(64, false); }
+#undef FQSS_AL_FWD
+            return launch_status("fqss_attn_long_fwd");
+        }
+    }
     if (use_mfma && (hd == 32 || hd == 64)) {
         dim3 gm((unsigned)cdiv(Lq, 128), (unsigned)(B * nh));
         if (hd == 32) hipLaunchKernelGGL((k_attn_long_fwd_mfma<32>), gm, dim3(256), 0, (hipStream_t)stream, q, k, v, o, stats, g, obs_attn, obs_soft);
@@ -582,7 +1029,23 @@ extern "C" int fqss_attn_long_bwd(const float* q, const float* k, const float* v
     if (int rc = check_attn(Lq, Lk, B, nh, hd, strides, 8)) return rc;
     const int64_t* s = strides;
     AttnGeom g{Lq, Lk, B, nh, {s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]}, {s[6], s[7]}, {s[8], s[9]}, {s[10], s[11]}, {s[12], s[13]}, {s[14], s[15]}};
-    static const bool use_mfma = [] { const char* e = getenv("FQSS_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    const int mode = attn_mfma_mode();
+    const bool use_mfma = mode != 0;
+    if (mode == 2 && (hd == 32 || hd == 64)) {
+        const void* ptrs[5] = {q, k, v, o, go};
+        if (rows_aligned16(ptrs, 5, strides, 10)) {
+            dim3 gq_((unsigned)cdiv(Lq, 128), (unsigned)(B * nh)), gk_((unsigned)cdiv(Lk, 128), (unsigned)(B * nh));
+            hipStream_t st = (hipStream_t)stream;
+            if (hd == 32) {
+                hipLaunchKernelGGL((k_attn_long_bwd_q_x3<32>), gq_, dim3(256), 0, st, q, k, v, o, go, stats, gq, dsum, g);
+                hipLaunchKernelGGL((k_attn_long_bwd_kv_x3<32>), gk_, dim3(256), 0, st, q, k, v, go, stats, dsum, gk, gv, g);
+            } else {
+                hipLaunchKernelGGL((k_attn_long_bwd_q_x3<64>), gq_, dim3(256), 0, st, q, k, v, o, go, stats, gq, dsum, g);
+                hipLaunchKernelGGL((k_attn_long_bwd_kv_x3<64>), gk_, dim3(256), 0, st, q, k, v, go, stats, dsum, gk, gv, g);
+            }
+            return launch_status("fqss_attn_long_bwd");
+        }
+    }
     if (use_mfma && (hd == 32 || hd == 64)) {
         dim3 gq_((unsigned)cdiv(Lq, 128), (unsigned)(B * nh)), gk_((unsigned)cdiv(Lk, 128), (unsigned)(B * nh));
         hipStream_t st = (hipStream_t)stream;

@@ -276,6 +276,9 @@ static int launch_gemm(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, int
 
 using namespace fqss;
 
+// split-bf16 form of the same problem (csrc/gemm_x3.hip, defined below); *used = false when its 16-B vector loads do not apply
+static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used, int batch = 1);
+
 extern "C" int fqss_pwconv_fwd(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
                                int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
     FQSS_REQUIRE(x && w && z, "null tensor");
@@ -301,6 +304,9 @@ extern "C" int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int
     g.sBb = (int64_t)Co * ld_gz; g.sBk = ld_gz; g.sBj = 1;
     g.sCb = (int64_t)Ci * ld_gx; g.sCi = ld_gx;
     g.ksplit = 1; g.kchunk = Co;
+    bool used = false;
+    int rc = try_x3(g, false, false, false, (hipStream_t)stream, "fqss_pwconv_bwd_x", &used, B);
+    if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, false, false, false, B, (hipStream_t)stream, "fqss_pwconv_bwd_x");
 }
 
@@ -323,6 +329,9 @@ extern "C" int fqss_pwconv_bwd_w(const float* gz, const float* x, float* gw, int
     if (kchunk < 64) kchunk = 64;
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(M, kchunk);
+    bool used = false;
+    int rc = try_x3(g, true, true, true, (hipStream_t)stream, "fqss_pwconv_bwd_w", &used, B);
+    if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, true, true, true, B, (hipStream_t)stream, "fqss_pwconv_bwd_w");
 }
 
@@ -370,6 +379,8 @@ struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
     const float* scale_k;
     const float* qmin_x;
     const float* qmax_x;
+    int batch;
+    int64_t sAb, sBb, sCb;
 };
 int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used);
 int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what);
@@ -380,10 +391,12 @@ static bool x3_enabled() {
     return on;
 }
 
-static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used) {
+static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used, int batch) {
     *used = false;
     if (!x3_enabled()) return FQSS_OK;
-    GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk, nullptr, nullptr, nullptr, nullptr};
+    if (batch > 1 && (g.sAb % 4 != 0 || g.sBb % 4 != 0)) return FQSS_OK;      // every batch's operand 16-B aligned
+    GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk, nullptr, nullptr, nullptr, nullptr,
+                batch, g.sAb, g.sBb, g.sCb};
     return launch_gemm_x3(h, a_kc, b_kc, atomic, s, what, used);
 }
 

@@ -38,6 +38,10 @@ struct GemmArgs3 {
     const float* scale_k;    // BQ = 2: delta_w[k], multiplied into A(i, k) before the split
     const float* qmin_x;     // BQ = 1: range of the activation quantizer (device scalars): C = dx * sum A c + min_x * sum_k A
     const float* qmax_x;
+    // batched problems (the channel-first pointwise convs of csrc/gemm.hip): blockIdx.z = batch * ksplit + k-slice; a split-K
+    // launch adds every batch into the same C (sCb = 0: the weight gradient)
+    int batch;
+    int64_t sAb, sBb, sCb;
 };
 
 constexpr int XBK = 32, XLDK = 40;   // 40 shorts = 80 B row stride (as csrc/teacher.hip: conflict-light 16-B reads)
@@ -182,7 +186,11 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ks = ATOMIC ? blockIdx.z : 0;
+    const int zb = ATOMIC ? (int)blockIdx.z / g.ksplit : (int)blockIdx.z;
+    const int ks = ATOMIC ? (int)blockIdx.z - zb * g.ksplit : 0;
+    g.A += (int64_t)zb * g.sAb;
+    g.B += (int64_t)zb * g.sBb;
+    g.C += (int64_t)zb * g.sCb;
     const int kbeg = ATOMIC ? ks * g.kchunk : 0;
     const int kend = ATOMIC ? min(g.K, kbeg + g.kchunk) : g.K;
     const int i0 = blockIdx.y * BMt, j0 = blockIdx.x * BNt;
@@ -305,7 +313,8 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
     *used = false;
     if (g.M <= 0 || g.N <= 0) return FQSS_OK;
     if (!x3_ok(g, a_kc, b_kc, atomic)) return FQSS_OK;     // caller falls back to k_gemm_f32
-    const int64_t zdim = atomic ? g.ksplit : 1;
+    const int64_t zdim = (int64_t)(g.batch > 0 ? g.batch : 1) * (atomic ? g.ksplit : 1);
+    if (zdim > 65535) return FQSS_OK;
     int mi = 2, ni = 2;
     if (g.N <= 64) ni = 1;
     else if (g.M <= 64 || (g.M > 128 && cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 2 * 256)) mi = 1;
@@ -319,6 +328,8 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
     if (!atomic && a_kc && b_kc) FQSS_X3(true, true, false);          // fwd:   x [R][Ci], w [Co][Ci]
     else if (!atomic && a_kc && !b_kc) FQSS_X3(true, false, false);   // dgrad: gz [R][Co], w [Co][Ci] (j contiguous)
     else if (atomic && !a_kc && !b_kc) FQSS_X3(false, false, true);   // wgrad: gz^T, x (both row-index contiguous)
+    else if (!atomic && !a_kc && !b_kc) FQSS_X3(false, false, false); // channel-first dgrad: W^T (i contiguous), gz [Co][M]
+    else if (atomic && a_kc && b_kc) FQSS_X3(true, true, true);       // channel-first wgrad: gz [Co][M], x [Ci][M] (both k contiguous)
     else return FQSS_OK;
 #undef FQSS_X3
     *used = true;

@@ -124,7 +124,7 @@ struct QGemmArgs {
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
-//      3 plain fp32 x fp32 (A split3 x B split3 = 9 exact products)       (wgrad: k_qwgrad below)
+//      3 plain fp32 x fp32 (A split3 x B split3 = 9 exact products; GP = 2: the six above 2^-24)   (wgrad: k_qwgrad below)
 // GP (dgrad only): bf16 pieces of the fp32 gradient operand.  3 = exact products (a = h1 + h2 + h3, truncations): the default.  2 = an
 // OPT-IN fast form (FQSS_GRAD_PIECES=2): a ~ h1 + RNE_bf16(a - h1), 16-17 significant bits, |error| <= 2^-16 |a|, unbiased; one third
 // fewer MFMAs and LDS bytes: -1.7 / -5.5 us (dgrad), -4 / -6 us (wgrad) = -0.4 ms per cfg-2 step.  Measured against fp64
@@ -134,7 +134,8 @@ struct QGemmArgs {
 template <int MODE, int GP = 3>
 __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     static_assert(MODE == 0 || MODE == 1 || MODE == 3, "unknown q-GEMM mode");
-    static_assert(GP == 3 || (GP == 2 && MODE == 1), "two gradient pieces: dgrad only");
+    static_assert(GP == 3 || (GP == 2 && MODE != 0), "two gradient pieces: dgrad only");
+    constexpr bool SIX = MODE == 3 && GP == 2;              // fp32 x fp32 with the six products above 2^-24 instead of all nine
     constexpr int NA = (MODE == 3) ? 3 : 1;                 // A images
     constexpr int NB = (MODE == 1) ? GP : (MODE == 3) ? 3 : 1;    // B images
     constexpr int BROWS = QBK, BLD = LDN;
@@ -328,6 +329,8 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             for (int sp = 0; sp < NA * NB; ++sp) {
                 // smallest pieces first: (3,3) ... (1,1) so that the large products are added last
                 const int ia = (NA == 3) ? 2 - (sp / NB) : 0, ib = (NB > 1) ? NB - 1 - (sp % NB) : 0;
+                // SIX: m.l, l.m and l.l lie below 2^-24 of the product (under the fp32 rounding of the sum), as csrc/gemm_x3.hip
+                if (SIX && ia + ib >= 3) continue;
                 bf16x8 af[2], bfr;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
@@ -1034,9 +1037,11 @@ extern "C" int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t
     return qpw_bwd_w_impl("fqss_qpw_bwd_w2", gz1, gz2, xc, qmin_x, qmax_x, gw, B, Ci, Co1, Co2, M, ld_gz1, ld_gz2, ld_xc, stream);
 }
 
-// plain fp32 pointwise conv z = W x + b on the bf16 matrix cores: both operands split exactly in three
-extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
-                                  int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+// plain fp32 pointwise conv z = W x + b on the bf16 matrix cores: both operands split exactly in three; all nine partial products
+// (every product exact: fqss_pwconv_fwd_x3, the ConvTasNet-family gates at 1e-5) or the six above 2^-24 (fqss_pwconv_fwd_x3s: the
+// arithmetic of csrc/gemm_x3.hip, one third fewer MFMAs -- the frame-path GEMMs of HTDemucs)
+static int pwconv_fwd_x3_impl(const char* who, bool six, const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
+                              int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
     if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(x && w && z, "null tensor");
     FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= M && ld_z >= M, "bad shape");
@@ -1050,6 +1055,17 @@ extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* b
     g.sAb = 0; g.sBb = (int64_t)Ci * ld_x; g.sCb = (int64_t)Co * ld_z;
     g.bias = bias; g.ksplit = 1; g.kchunk = Ci; g.M1 = Co; g.K1 = Ci;
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
-    hipLaunchKernelGGL((k_qgemm<3>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
-    return launch_status("fqss_pwconv_fwd_x3");
+    if (six) hipLaunchKernelGGL((k_qgemm<3, 2>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((k_qgemm<3>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status(who);
+}
+
+extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
+                                  int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    return pwconv_fwd_x3_impl("fqss_pwconv_fwd_x3", false, x, w, bias, z, B, Ci, Co, M, ld_x, ld_z, stream);
+}
+
+extern "C" int fqss_pwconv_fwd_x3s(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,
+                                   int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    return pwconv_fwd_x3_impl("fqss_pwconv_fwd_x3s", true, x, w, bias, z, B, Ci, Co, M, ld_x, ld_z, stream);
 }

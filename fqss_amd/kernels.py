@@ -243,14 +243,16 @@ def _bcm(t):
     return t, t.shape[0], t.shape[1], t.shape[2], ld
 
 
-def pwconv_fwd(x, w, bias):
+def pwconv_fwd(x, w, bias, six=False):
+    """six: the six-product split GEMM (fqss_pwconv_fwd_x3s) instead of the nine exact products"""
     _need_gpu(x, w, bias)
     x, B, Ci, M, ld_x = _bcm(x)
     Co = w.shape[0]
     assert w.is_contiguous() and w.numel() == Co * Ci
     z = empty_act((B, Co, M), x.device)
     # bf16-MFMA 3x3 exact split when rows are 16-B aligned, fp32-MFMA kernel otherwise
-    fn = "fqss_pwconv_fwd_x3" if (USE_X3 and Ci % 4 == 0 and ld_x % 4 == 0 and x.data_ptr() % 16 == 0) else "fqss_pwconv_fwd"
+    fn = "fqss_pwconv_fwd" if not (USE_X3 and Ci % 4 == 0 and ld_x % 4 == 0 and x.data_ptr() % 16 == 0) else \
+        "fqss_pwconv_fwd_x3s" if six else "fqss_pwconv_fwd_x3"
     _lib.call(fn, _p(x), _p(w), _p(bias), _p(z), B, Ci, Co, M, ld_x, rowmat(z)[2], _stream())
     return z
 

@@ -361,16 +361,17 @@ def _plain_or_bwd(z, g, q):
 # ----------------------------------------------------------------------------------------------
 class _Lin:
     """geometry of the linear op in front of the epilogue"""
-    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param")
+    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param", "six")
 
-    def __init__(self, kind, stride=1, dil=1, pad=0, w_param=None, b_param=None, slope_param=None):
+    def __init__(self, kind, stride=1, dil=1, pad=0, w_param=None, b_param=None, slope_param=None, six=False):
         self.kind, self.stride, self.dil, self.pad = kind, stride, dil, pad
+        self.six = six          # "pw": forward on the six-product split GEMM (K.pwconv_fwd)
         self.w_param, self.b_param, self.slope_param = w_param, b_param, slope_param
 
 
 def _lin_fwd(L, x, w, bias):
     if L.kind == "pw":
-        return K.pwconv_fwd(x, w, bias)
+        return K.pwconv_fwd(x, w, bias, L.six)
     if L.kind == "dw":
         return K.dwconv_fwd(x, w, bias, L.dil, L.pad)
     if L.kind == "frames":       # strided framing conv (encoder), no bias in the networks served

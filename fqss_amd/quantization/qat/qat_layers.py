@@ -283,7 +283,7 @@ def conv_frames(conv, x, weight):
         cols = ops_dp.FramesGather.apply(x4, geom)
     Co = conv.out_channels
     ops_dp.touch(weight)
-    L = ops._Lin("pw", b_param=conv.bias)
+    L = ops._Lin("pw", b_param=conv.bias, six=True)
     w3 = ops.weight_view(weight, Co, -1, 1)
     z = ops.LinearActQ.apply(cols, w3, conv.bias, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
     z = z.reshape(B, Co, Ho, Wo)
@@ -316,7 +316,7 @@ def convtr_frames(convtr, x, weight, bias=_OWN):
         gwt = torch.zeros_like(wt)
         wt._fqss_gwq = gwt
         wt._fqss_gwq_done = lambda: K.axpby_(gwq.reshape(Ci, -1), K.transpose2d(gwt.reshape(-1, Ci)), 1.0)
-    frames = ops.LinearActQ.apply(x4.reshape(B, Ci, Hi * Wi), wt, None, None, None, None, ops._Lin("pw"), ops.ACT_NONE, ops.BYPASS)
+    frames = ops.LinearActQ.apply(x4.reshape(B, Ci, Hi * Wi), wt, None, None, None, None, ops._Lin("pw", six=True), ops.ACT_NONE, ops.BYPASS)
     y = ops_dp.FramesOla.apply(frames, convtr.bias if bias is _OWN else bias, (B, Co, H, W), geom)
     return y.squeeze(2) if one_d else y
 

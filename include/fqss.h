@@ -138,6 +138,12 @@ int fqss_pwconv_fwd(const float* x, const float* w, const float* bias, float* z,
  * at 9/16 of the fp32-MFMA cost.  Needs Ci % 4 == 0 and 16-B aligned rows (csrc/qgemm.hip).        */
 int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
                        int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
+/* the same with the SIX partial products above 2^-24 of each product (what fqss_rowlin_* and the
+ * fp32 gradient GEMMs compute): one third fewer MFMAs, error of the order of one fp32 rounding per
+ * product.  The general conv layers of HTDemucs (qat_layers.conv_frames / convtr_frames;
+ * reference hdemucsq.py:72-162, 261-347) run on it, student and teacher.                          */
+int fqss_pwconv_fwd_x3s(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
+                        int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
 /* gx[b] = W^T * gz[b] */
 int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci, int Co, int M,
                       int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);

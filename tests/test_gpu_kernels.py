@@ -54,6 +54,7 @@ def test_pwconv(B, Ci, Co, M, pad):
     close(z, y, msg="fwd")
     z2 = K.pwconv_fwd(xd, w.cuda(), None)
     close(z2, F.conv1d(x, w), msg="fwd nobias")
+    close(K.pwconv_fwd(xd, w.cuda(), b.cuda(), six=True), y, msg="fwd, six products")
     gx = K.pwconv_bwd_x(gzd, w.cuda(), Ci)
     close(gx, xr.grad, msg="dgrad")
     gw = torch.zeros(Co, Ci, 1, device="cuda")
@@ -71,6 +72,27 @@ def test_pwconv_exact_integers():
     assert torch.equal(z.cpu(), y)
     gx = K.pwconv_bwd_x(y.cuda(), w.cuda(), Ci)
     assert torch.equal(gx.cpu(), torch.einsum("oc,bom->bcm", w[:, :, 0], y))
+
+
+def test_pwconv_split_gemms_against_fp64():
+    """the channel-first pointwise GEMMs on the bf16 matrix cores (nine exact products, six products, and the batched k_gemm_x3 forms
+    of the two gradients) against fp64: all at the level of an fp32 GEMM (torch's own result measured beside them)"""
+    B, Ci, Co, M = 3, 384, 768, 1336
+    x, w, gz = rnd(B, Ci, M, seed=11), rnd(Co, Ci, 1, seed=12, scale=Ci ** -0.5), rnd(B, Co, M, seed=13)
+    xd, wd, gzd = x.cuda(), w.cuda(), gz.cuda()
+    x64, w64, gz64 = xd.double(), wd.double()[:, :, 0], gzd.double()
+    def err(a, ref):
+        return float((a.double() - ref).norm() / ref.norm())
+    y64 = torch.einsum("oc,bcm->bom", w64, x64)
+    e9, e6, et = err(K.pwconv_fwd(xd, wd, None), y64), err(K.pwconv_fwd(xd, wd, None, six=True), y64), err(F.conv1d(xd, wd), y64)
+    gx64 = torch.einsum("oc,bom->bcm", w64, gz64)
+    egx, egxt = err(K.pwconv_bwd_x(gzd, wd, Ci), gx64), err(torch.einsum("oc,bom->bcm", wd[:, :, 0], gzd), gx64)
+    gw = torch.zeros(Co, Ci, 1, device="cuda")
+    K.pwconv_bwd_w(gzd, xd, gw)
+    gw64 = torch.einsum("bom,bcm->oc", gz64, x64)
+    egw, egwt = err(gw[:, :, 0], gw64), err(torch.einsum("bom,bcm->oc", gzd, xd), gw64)
+    print(f"fwd: nine {e9:.2e} six {e6:.2e} torch {et:.2e}; dgrad {egx:.2e} torch {egxt:.2e}; wgrad {egw:.2e} torch {egwt:.2e}")
+    assert e9 <= 3e-7 and e6 <= 6e-7 and egx <= 6e-7 and egw <= 1e-6
 
 
 @pytest.mark.parametrize("B,C,M,dil", [(2, 32, 77, 1), (2, 32, 77, 4), (1, 512, 999, 128), (3, 7, 130, 2)])
