@@ -661,6 +661,8 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restric
     constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
     __shared__ __attribute__((aligned(16))) unsigned short Kp[3][32][LD];
     __shared__ __attribute__((aligned(16))) unsigned short Vp[3][32][LD];
+    __shared__ __attribute__((aligned(16))) float scs[4][32];
+    constexpr float kLazy = 8.0f;
     const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
     const int it = blockIdx.x * 4 + wave;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restric
     for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
-    float m = -INFINITY, l = 0.f, smin = INFINITY;
+    float m = -INFINITY, l = 0.f, smin = INFINITY, mtrue = -INFINITY;
     const int kap = kappa(c);
     Tile3<HD> kt, vt;
     kt.fetch(k, g.k, b, h, 0, min(32, g.Lk));
@@ -710,18 +712,32 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restric
             for (int r = 0; r < 16; ++r) smin = fminf(smin, T0[r] == -INFINITY ? INFINITY : T0[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);
-        const float sc = al_exp(m - m_new);          // 0 on the first tile
-        if (__any(sc != 1.0f)) {
+        if (OBS) mtrue = fmaxf(mtrue, tmax);
+        // lazy reference maximum: m only moves when the tile's maximum exceeds it by more than kLazy (probabilities stay below
+        // e^kLazy, far inside fp32; o = acc / l and the saved (m, l) are the same function of the logits for ANY reference value),
+        // so that after the first few tiles the rescaling pass below is skipped
+        const bool move = tmax > m + kLazy;          // first tile: m = -inf
+        if (__any(move)) {
+            const float m_new = move ? tmax : m;
+            const float sc = al_exp(m - m_new);      // 1 for the queries that keep their reference, 0 on the first tile
+            l *= sc;
+            m = m_new;
+            if (j0 > 0) {
+                // the factor of the query that owns accumulator row r: rows tile_row(r, lk) = 4 consecutive ones per r >> 2
+                if (lk == 0) scs[wave][c] = sc;
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float f = __shfl(sc, tile_row(r, lk), 64);     // the factor of the query that owns accumulator row r
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 f = *reinterpret_cast<const float4*>(&scs[wave][8 * r4 + 4 * lk]);
+                    const float ff[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-                for (int nd = 0; nd < ND; ++nd) acc[nd][r] *= f;
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int nd = 0; nd < ND; ++nd) acc[nd][4 * r4 + e] *= ff[e];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        l *= sc;
-        m = m_new;
         Frag3 pa[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -759,8 +775,8 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restric
         }
     }
     if (OBS) {
-        float smin_all = live ? smin : INFINITY, smax_all = live ? m : -INFINITY;
-        float pmax_all = live ? 1.0f / l : -INFINITY, pmin_all = live ? expf(smin - m) / l : INFINITY;
+        float smin_all = live ? smin : INFINITY, smax_all = live ? mtrue : -INFINITY;
+        float pmax_all = live ? expf(mtrue - m) / l : -INFINITY, pmin_all = live ? expf(smin - m) / l : INFINITY;
         smin_all = wave_min(smin_all); smax_all = wave_max(smax_all);
         pmin_all = wave_min(pmin_all); pmax_all = wave_max(pmax_all);
         if (lane == 0 && smin_all <= smax_all) {

@@ -386,6 +386,14 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
 int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what);
 }  // namespace fqss
 
+// workgroups a row-major weight gradient aims for: every k-slice ADDS its whole Co x Ci tile with float atomics, so the slice count
+// is a trade between atomic traffic (measured: half of the kernel at 125 slices for a 256 x 256 gradient) and occupancy -- 512, and
+// 256 for outputs of at most four 128 x 128 tiles (tools/kprobe.py sweep: 256 x 256 coded 43 -> 32 us)
+static int rowgrad_wgs(int tiles) {
+    static const int n = [] { const char* e = getenv("FQSS_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v; }();
+    return n > 0 ? n : (tiles <= 4 ? 256 : 512);
+}
+
 static bool x3_enabled() {
     static const bool on = [] { const char* e = getenv("FQSS_ROWGEMM_X3"); return !(e && e[0] == '0'); }();
     return on;
@@ -478,7 +486,7 @@ extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* 
     g.sBk = ld_xc; g.sBj = 1;      // B(k=r, j=i) = c[r*ld + i]
     g.sCi = ld_gw;
     const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
-    int want = (int)cdiv(512, tiles);
+    int want = (int)cdiv(rowgrad_wgs(tiles), tiles);
     int kchunk = (int)cdiv(cdiv(R, want), 64) * 64;
     if (kchunk < 64) kchunk = 64;
     g.kchunk = kchunk;
@@ -499,7 +507,7 @@ extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int
     g.sBb = 0; g.sBk = ld_x; g.sBj = 1;    // B(k=r, j=i) = x[r*ld + i]
     g.sCb = 0; g.sCi = ld_gw;
     const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
-    int want = (int)cdiv(512, tiles);
+    int want = (int)cdiv(rowgrad_wgs(tiles), tiles);
     int kchunk = (int)cdiv(cdiv(R, want), 64) * 64;
     if (kchunk < 64) kchunk = 64;
     g.kchunk = kchunk;

@@ -13,6 +13,7 @@
 // coalesced float4 loads along the contiguous dimension, then one 8-B LDS write per row and plane.
 // Measured dead end: k-tiles of 16 with two LDS buffers and one barrier per tile (split + store of tile kt+1 under the MFMAs of
 // tile kt) -- 5-12 % SLOWER than this single-buffered k-tile of 32 at the dual-path shapes (60 -> 66 us for 8500 x 256 x 1024).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "fqss_dev.h"
@@ -318,6 +319,14 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
     int mi = 2, ni = 2;
     if (g.N <= 64) ni = 1;
     else if (g.M <= 64 || (g.M > 128 && cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 2 * 256)) mi = 1;
+    // split-K weight gradients keep the 128-row tile: the split of the gradient operand is the cost that matters (these kernels are
+    // bound by vector-ALU issue, ~20 VALU per MFMA with 64-row tiles) and a taller tile shares it among twice the MFMAs
+    // (measured over the cfg 3 / 4 / 5 shapes, tools/kprobe.py: 512 x 512 float 91 -> 74 us, coded 71 -> 61 us)
+    if (atomic && g.M > 64 && g.N > 64) mi = 2;
+    // forward / data-gradient tiles: 64-row tiles only while the 128 x 128 grid would leave CUs idle (< 320 tiles: measured over the
+    // cfg 3 / 4 / 5 shapes, tools/kprobe.py -- at 432 tiles the 128-row tile is 13 .. 30 % faster, at 250 the 64-row tile 10 .. 15 %);
+    // the float data gradient (weight tile transposed on the way into LDS) always takes 128 rows
+    if (!atomic && g.M > 128 && g.N > 64) mi = (a_kc && !b_kc) ? 2 : (cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 320 ? 1 : 2);
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3(AK, BKc, AT)                                                                                  \
     do {                                                                                                      \
@@ -344,6 +353,11 @@ int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what)
     int mi = 2, ni = 2;
     if (g.N <= 64) ni = 1;
     else if (g.M <= 64 || (g.M > 128 && cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 2 * 256)) mi = 1;
+    // split-K weight gradients keep the 128-row tile: the split of the gradient operand is the cost that matters (these kernels are
+    // bound by vector-ALU issue, ~20 VALU per MFMA with 64-row tiles) and a taller tile shares it among twice the MFMAs
+    // (measured over the cfg 3 / 4 / 5 shapes, tools/kprobe.py: 512 x 512 float 91 -> 74 us, coded 71 -> 61 us)
+    if (atomic && g.M > 64 && g.N > 64) mi = 2;
+    if (!atomic && g.M > 128 && g.N > 64) mi = cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 320 ? 1 : 2;
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3Q(AK, AT, Q)                                                                                      \
     do {                                                                                                         \
