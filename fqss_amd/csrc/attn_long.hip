@@ -591,14 +591,16 @@ __device__ __forceinline__ Frag3 split8(const float (&x)[8]) {
 // a 32-row tile of one head: global (float4, rows clamped into the operand) -> registers -> three bf16 planes in LDS
 template <int HD>
 struct Tile3 {
-    static constexpr int LD = HD + 8, NV = HD / 32;
+    // head_dim 16: the planes are 32 columns wide, columns 16 .. 31 zero (x3_zero_planes), so that the second products still run on the
+    // 32 x 32 MFMA; half of the threads move the tile
+    static constexpr int LD = (HD < 32 ? 32 : HD) + 8, NV = HD < 32 ? 1 : HD / 32;
     float4 v[NV];
     int nrows_;
     __device__ __forceinline__ void fetch(const float* __restrict__ x, const RowView rv, int b, int h, int r0, int nrows) {
         nrows_ = nrows;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int e = threadIdx.x + 256 * u, j = e / (HD / 4), d = (e % (HD / 4)) * 4;
+            const int e = min((int)threadIdx.x + 256 * u, 8 * HD - 1), j = e / (HD / 4), d = (e % (HD / 4)) * 4;
             v[u] = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + min(j, nrows - 1)) * rv.sl + (int64_t)b * rv.sb + h * HD + d);
         }
     }
@@ -606,6 +608,7 @@ struct Tile3 {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int e = threadIdx.x + 256 * u, j = e / (HD / 4), d = (e % (HD / 4)) * 4;
+            if (HD < 32 && e >= 8 * HD) break;
             const bool ok = j < nrows_;
             const float x[4] = {ok ? v[u].x : 0.f, ok ? v[u].y : 0.f, ok ? v[u].z : 0.f, ok ? v[u].w : 0.f};
             unsigned int w[3][2];
@@ -623,6 +626,16 @@ struct Tile3 {
         }
     }
 };
+
+template <int HD, int LD>
+__device__ __forceinline__ void x3_zero_planes(unsigned short (*pl)[32][LD]) {
+    if constexpr (HD < 32) {
+        for (int e = threadIdx.x; e < 3 * 32 * (LD - HD); e += 256) {
+            const int p = e / (32 * (LD - HD)), r = (e / (LD - HD)) % 32, c = HD + e % (LD - HD);
+            pl[p][r][c] = 0;
+        }
+    }
+}
 
 // A operand of a first product: row kappa(c) of the tile, k-step ks
 template <int LD>
@@ -658,11 +671,12 @@ template <int HD, bool OBS>
 __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                            float* __restrict__ o, float* __restrict__ stats, const AttnGeom g,
                                                            uint32_t* obs_attn, uint32_t* obs_soft) {
-    constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
+    constexpr int LD = Tile3<HD>::LD, KS = HD / 16, ND = HD < 32 ? 1 : HD / 32;
     __shared__ __attribute__((aligned(16))) unsigned short Kp[3][32][LD];
     __shared__ __attribute__((aligned(16))) unsigned short Vp[3][32][LD];
     __shared__ __attribute__((aligned(16))) float scs[4][32];
     constexpr float kLazy = 8.0f;
+    x3_zero_planes<HD, LD>(Vp);
     const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
     const int it = blockIdx.x * 4 + wave;
@@ -771,7 +785,8 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restric
         if (i < g.Lq) {
             float* op = o + (int64_t)i * g.o.sl + (int64_t)b * g.o.sb + h * HD + c;
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) op[32 * nd] = acc[nd][r] / lr;
+            for (int nd = 0; nd < ND; ++nd)
+                if (HD >= 32 || c < HD) op[32 * nd] = acc[nd][r] / lr;
         }
     }
     if (OBS) {
@@ -791,9 +806,10 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_q_x3(const float* __restr
                                                              const float* __restrict__ o, const float* __restrict__ go,
                                                              const float* __restrict__ stats, float* __restrict__ gq, float* __restrict__ dsum,
                                                              const AttnGeom g) {
-    constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
+    constexpr int LD = Tile3<HD>::LD, KS = HD / 16, ND = HD < 32 ? 1 : HD / 32;
     __shared__ __attribute__((aligned(16))) unsigned short Kp[3][32][LD];
     __shared__ __attribute__((aligned(16))) unsigned short Vp[3][32][LD];
+    x3_zero_planes<HD, LD>(Kp);
     const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
     const int it = blockIdx.x * 4 + wave;
@@ -872,7 +888,8 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_q_x3(const float* __restr
         if (i < g.Lq) {
             float* gp2 = gq + (int64_t)i * g.gq.sl + (int64_t)b * g.gq.sb + h * HD + c;
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) gp2[32 * nd] = acc[nd][r];
+            for (int nd = 0; nd < ND; ++nd)
+                if (HD >= 32 || c < HD) gp2[32 * nd] = acc[nd][r];
         }
     }
 }
@@ -882,10 +899,12 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_x3(const float* __rest
                                                               const float* __restrict__ go, const float* __restrict__ stats,
                                                               const float* __restrict__ dsum, float* __restrict__ gk, float* __restrict__ gv,
                                                               const AttnGeom g) {
-    constexpr int LD = HD + 8, KS = HD / 16, ND = HD / 32;
+    constexpr int LD = Tile3<HD>::LD, KS = HD / 16, ND = HD < 32 ? 1 : HD / 32;
     __shared__ __attribute__((aligned(16))) unsigned short Qp[3][32][LD];
     __shared__ __attribute__((aligned(16))) unsigned short Gp[3][32][LD];
     __shared__ float Ms[32], Rs[32], Ds[32];
+    x3_zero_planes<HD, LD>(Qp);
+    x3_zero_planes<HD, LD>(Gp);
     const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
     const int jt = blockIdx.x * 4 + wave;
@@ -960,7 +979,8 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_x3(const float* __rest
             float* gkp = gk + (int64_t)j * g.gk.sl + (int64_t)b * g.gk.sb + h * HD + c;
             float* gvp = gv + (int64_t)j * g.gv.sl + (int64_t)b * g.gv.sb + h * HD + c;
 #pragma unroll
-            for (int nd = 0; nd < ND; ++nd) { gkp[32 * nd] = ak[nd][r]; gvp[32 * nd] = av[nd][r]; }
+            for (int nd = 0; nd < ND; ++nd)
+                if (HD >= 32 || c < HD) { gkp[32 * nd] = ak[nd][r]; gvp[32 * nd] = av[nd][r]; }
         }
     }
 }
@@ -1012,13 +1032,14 @@ extern "C" int fqss_attn_long_fwd(const float* q, const float* k, const float* v
     AttnGeom g{Lq, Lk, B, nh, {strides[0], strides[1]}, {strides[2], strides[3]}, {strides[4], strides[5]}, {strides[6], strides[7]}, {}, {}, {}, {}};
     const int mode = attn_mfma_mode();
     const bool use_mfma = mode != 0;
-    if (mode == 2 && (hd == 32 || hd == 64)) {
+    if (mode == 2 && (hd == 16 || hd == 32 || hd == 64)) {
         const void* ptrs[3] = {q, k, v};
         if (rows_aligned16(ptrs, 3, strides, 6)) {
             dim3 gm((unsigned)cdiv(Lq, 128), (unsigned)(B * nh));
             const bool obs = obs_attn != nullptr;
 #define FQSS_AL_FWD(HD_, OBS_) hipLaunchKernelGGL((k_attn_long_fwd_x3<HD_, OBS_>), gm, dim3(256), 0, (hipStream_t)stream, q, k, v, o, stats, g, obs_attn, obs_soft)
-            if (hd == 32) { if (obs) FQSS_AL_FWD(32, true); else FQSS_AL_FWD(32, false); }
+            if (hd == 16) { if (obs) FQSS_AL_FWD(16, true); else FQSS_AL_FWD(16, false); }
+            else if (hd == 32) { if (obs) FQSS_AL_FWD(32, true); else FQSS_AL_FWD(32, false); }
             else { if (obs) FQSS_AL_FWD(64, true); else FQSS_AL_FWD(64, false); }
 #undef FQSS_AL_FWD
             return launch_status("fqss_attn_long_fwd");
@@ -1047,12 +1068,15 @@ extern "C" int fqss_attn_long_bwd(const float* q, const float* k, const float* v
     AttnGeom g{Lq, Lk, B, nh, {s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]}, {s[6], s[7]}, {s[8], s[9]}, {s[10], s[11]}, {s[12], s[13]}, {s[14], s[15]}};
     const int mode = attn_mfma_mode();
     const bool use_mfma = mode != 0;
-    if (mode == 2 && (hd == 32 || hd == 64)) {
+    if (mode == 2 && (hd == 16 || hd == 32 || hd == 64)) {
         const void* ptrs[5] = {q, k, v, o, go};
         if (rows_aligned16(ptrs, 5, strides, 10)) {
             dim3 gq_((unsigned)cdiv(Lq, 128), (unsigned)(B * nh)), gk_((unsigned)cdiv(Lk, 128), (unsigned)(B * nh));
             hipStream_t st = (hipStream_t)stream;
-            if (hd == 32) {
+            if (hd == 16) {
+                hipLaunchKernelGGL((k_attn_long_bwd_q_x3<16>), gq_, dim3(256), 0, st, q, k, v, o, go, stats, gq, dsum, g);
+                hipLaunchKernelGGL((k_attn_long_bwd_kv_x3<16>), gk_, dim3(256), 0, st, q, k, v, go, stats, dsum, gk, gv, g);
+            } else if (hd == 32) {
                 hipLaunchKernelGGL((k_attn_long_bwd_q_x3<32>), gq_, dim3(256), 0, st, q, k, v, o, go, stats, gq, dsum, g);
                 hipLaunchKernelGGL((k_attn_long_bwd_kv_x3<32>), gk_, dim3(256), 0, st, q, k, v, go, stats, dsum, gk, gv, g);
             } else {

@@ -1212,9 +1212,21 @@ def ola2_bwd(g):
     return gy
 
 
+ATTN_STREAM = os.environ.get("FQSS_ATTN_STREAM", "1") != "0"
+
+
+def _attn_stream_ok(ts, E, nh):
+    """the split-bf16 streaming attention (csrc/attn_long.hip) also serves the 250-step sequences of the dual-path models: [L, B, E]
+    views with 16-B aligned rows, head_dim 16 / 32 / 64 (measured against the LDS-resident kernels of csrc/attn.hip: DESIGN.md 7/7b)"""
+    return ATTN_STREAM and (E // nh) in (16, 32, 64) and all(t.dim() == 3 and t.stride(2) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0
+                                                          and t.stride(1) % 4 == 0 for t in ts)
+
+
 def attn_fwd(q, k, v, L, B, nh, obs_attn=None, obs_soft=None):
     """q, k, v: [L*B rows][E] row matrices (views allowed) -> heads [L, B, E], stats"""
     E = q.shape[-1]
+    if _attn_stream_ok((q, k, v), E, nh):
+        return attn_long_fwd(q, k, v, nh, False, obs_attn, obs_soft)
     q, _, ld_q = _rows(q, E)
     k, _, ld_k = _rows(k, E)
     v, _, ld_v = _rows(v, E)
@@ -1227,6 +1239,10 @@ def attn_fwd(q, k, v, L, B, nh, obs_attn=None, obs_soft=None):
 
 def attn_bwd(q, k, v, o, go, stats, L, B, nh):
     E = q.shape[-1]
+    if _attn_stream_ok((q, k, v, o), E, nh) and go.dim() == 3:
+        if not (go.stride(2) == 1 and go.data_ptr() % 16 == 0 and go.stride(0) % 4 == 0 and go.stride(1) % 4 == 0):
+            go = go.contiguous()
+        return attn_long_bwd(q, k, v, o, go, stats, nh, False)
     q, _, ld_q = _rows(q, E)
     k, _, ld_k = _rows(k, E)
     v, _, ld_v = _rows(v, E)

@@ -847,7 +847,8 @@ def test_frames_geometry_is_checked():
 
 # ---------------------------------------------------------------- streaming attention core (row a15): long sequences, cross attention
 @pytest.mark.parametrize("Lq,Lk,B,nh,hd,bf", [(300, 517, 2, 2, 48, True), (257, 257, 1, 3, 64, False), (33, 70, 2, 4, 4, True), (700, 64, 1, 2, 16, False),
-                                              (1, 1, 1, 1, 64, True), (5, 37, 2, 2, 32, True), (40, 3, 1, 2, 32, False), (129, 95, 2, 1, 64, True)])
+                                              (1, 1, 1, 1, 64, True), (5, 37, 2, 2, 32, True), (40, 3, 1, 2, 32, False), (129, 95, 2, 1, 64, True),
+                                              (250, 250, 3, 4, 16, False), (70, 33, 2, 2, 16, True)])
 def test_attn_long(Lq, Lk, B, nh, hd, bf):
     E = nh * hd
     shp = lambda L: (B, L, E) if bf else (L, B, E)
