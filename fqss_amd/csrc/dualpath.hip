@@ -58,7 +58,20 @@ __device__ __forceinline__ void ln_store(float* __restrict__ row, int lane, int 
     }
 }
 
-template <int JC, bool Q, bool VEC>
+// G = lanes per row: 64, or 16 for rows of at most 64 features (the 64-wide dual-path blocks of DPTNet): a wave then normalises FOUR rows
+// at once, 16 lanes x float4 each -- the one-row form left 3/4 of every memory instruction's lanes on 4-B accesses
+template <int G>
+__device__ __forceinline__ float ln_group_sum(float v) {
+    if constexpr (G == 64) {
+        return wave_sum(v);
+    } else {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+}
+
+template <int JC, bool Q, bool VEC, int G = 64>
 __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean_rstd, int64_t R, int C, int64_t ld_x,
@@ -70,13 +83,17 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
     // sub-layer -- and the sum is also written out (it is the residual stream of the NEXT add and the backward's input)
     QRange qr{0.0f, 1.0f, 1.0f};
     if (Q) qr = load_qrange(qmin, qmax);
-    const int lane = threadIdx.x & 63;
+    static_assert(G == 64 || (G == 16 && JC == 4 && VEC), "narrow rows: 16 lanes x float4");
+    constexpr int RPW = 64 / G;                              // rows per wave
+    const int lane = (threadIdx.x & 63) % G, rw = (threadIdx.x & 63) / G;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     float ga[JC], be[JC];
     ln_load<JC, VEC>(gamma, lane, C, ga);
     ln_load<JC, VEC>(beta, lane, C, be);
     const float invC = 1.0f / (float)C;
-    for (int64_t r = wave; r < R; r += nw) {
+    for (int64_t r0 = wave * RPW; r0 < R; r0 += nw * RPW) {
+        const bool row_ok = r0 + rw < R;                     // (a wave's last group of rows may be short: those lanes re-read row R-1)
+        const int64_t r = row_ok ? r0 + rw : R - 1;
         float v[JC], s = 0.f;
         ln_load<JC, VEC>(x + r * ld_x, lane, C, v);
         if (xadd != nullptr) {
@@ -84,18 +101,18 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
             ln_load<JC, VEC>(xadd + r * ld_a, lane, C, a2);
 #pragma unroll
             for (int j = 0; j < JC; ++j) v[j] = v[j] + a2[j];
-            ln_store<JC, VEC>(xsum + r * ld_s, lane, C, v);
+            if (row_ok) ln_store<JC, VEC>(xsum + r * ld_s, lane, C, v);
         }
 #pragma unroll
         for (int j = 0; j < JC; ++j) s += v[j];
-        const float mean = wave_sum(s) * invC;
+        const float mean = ln_group_sum<G>(s) * invC;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
             const float d = ln_col<JC, VEC>(lane, j) < C ? v[j] - mean : 0.f;
             q += d * d;
         }
-        const float var = wave_sum(q) * invC;
+        const float var = ln_group_sum<G>(q) * invC;
         const float rstd = 1.0f / sqrtf(var + eps);
         float o[JC];
         unsigned char oc[JC];
@@ -110,8 +127,8 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
                 o[j] = z;
             }
         }
-        ln_store<JC, VEC>(y + r * ld_y, lane, C, o);
-        if (Q && yc != nullptr) {
+        if (row_ok) ln_store<JC, VEC>(y + r * ld_y, lane, C, o);
+        if (Q && yc != nullptr && row_ok) {
             if (VEC && (ld_yc & 3) == 0) {      // four codes per lane and group: one 4-B store
 #pragma unroll
                 for (int jj = 0; jj < JC / 4; ++jj) {
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
                 }
             }
         }
-        if (lane == 0) {
+        if (lane == 0 && row_ok) {
             mean_rstd[2 * r] = mean;
             mean_rstd[2 * r + 1] = rstd;
         }
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
 // affine gradients (registers across the rows of a wave, LDS across the 4 waves, then one atomic per column and workgroup)
 // Q: gy is dL/d fq(LN(x)): the quantizer's STE (and its range-gradient partials, one gacc slot per workgroup like k_actq_bwd) runs on
 // the pre-quant value recomputed from x -- no separate fqss_actq_bwd pass, no stored z.
-template <int JC, bool Q, bool VEC>
+template <int JC, bool Q, bool VEC, int G = 64>
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ gy, const float* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                         float* __restrict__ gx, float* __restrict__ ggamma,
@@ -151,7 +168,9 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     // then the gradient of BOTH addends -- the sum autograd would take at the fork in a pass of its own
     __shared__ float red[2][4][64 * JC];
     __shared__ double redq[2 * 4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    static_assert(G == 64 || (G == 16 && JC == 4 && VEC), "narrow rows: 16 lanes x float4");
+    constexpr int RPW = 64 / G;
+    const int lane = (threadIdx.x & 63) % G, rw = (threadIdx.x & 63) / G, w = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + w, nw = (int64_t)gridDim.x * 4;
     QRange qr{0.0f, 1.0f, 1.0f};
     if (Q) qr = load_qrange(qmin, qmax);
@@ -162,10 +181,16 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     for (int j = 0; j < JC; ++j) be[j] = agg[j] = agb[j] = 0.f;
     if (Q) ln_load<JC, VEC>(beta, lane, C, be);
     const float invC = 1.0f / (float)C;
-    for (int64_t r = wave; r < R; r += nw) {
+    for (int64_t r0 = wave * RPW; r0 < R; r0 += nw * RPW) {
+        const bool row_ok = r0 + rw < R;
+        const int64_t r = row_ok ? r0 + rw : R - 1;
         const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
         float gv[JC], xv[JC], av[JC], xh[JC], dxh[JC], a = 0.f, b = 0.f;
         ln_load<JC, VEC>(gy + r * ld_gy, lane, C, gv);
+        if (RPW > 1 && !row_ok) {
+#pragma unroll
+            for (int jz = 0; jz < JC; ++jz) gv[jz] = 0.f;          // no contribution to the column sums / range partials
+        }
         ln_load<JC, VEC>(x + r * ld_x, lane, C, xv);
         if (gadd != nullptr) ln_load<JC, VEC>(gadd + r * ld_ga, lane, C, av);
 #pragma unroll
@@ -187,26 +212,37 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
             agg[j] += g * xh[j];
             agb[j] += g;
         }
-        a = wave_sum(a) * invC;
-        b = wave_sum(b) * invC;
+        a = ln_group_sum<G>(a) * invC;
+        b = ln_group_sum<G>(b) * invC;
         float o[JC];
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
             o[j] = rstd * ((dxh[j] - a) - xh[j] * b);
             if (gadd != nullptr) o[j] = o[j] + av[j];
         }
-        ln_store<JC, VEC>(gx + r * ld_gx, lane, C, o);
+        if (row_ok) ln_store<JC, VEC>(gx + r * ld_gx, lane, C, o);
     }
+    if constexpr (RPW > 1) {      // the row groups of a wave hold partial sums of the same columns
 #pragma unroll
-    for (int j = 0; j < JC; ++j) {
-        const int c = ln_col<JC, VEC>(lane, j);       // < 64 * JC
-        red[0][w][c] = agg[j];
-        red[1][w][c] = agb[j];
+        for (int j = 0; j < JC; ++j)
+#pragma unroll
+            for (int o = G; o < 64; o <<= 1) {
+                agg[j] += __shfl_xor(agg[j], o, 64);
+                agb[j] += __shfl_xor(agb[j], o, 64);
+            }
+    }
+    if (rw == 0) {
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int c = ln_col<JC, VEC>(lane, j);       // < 64 * JC
+            red[0][w][c] = agg[j];
+            red[1][w][c] = agb[j];
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * 64 * JC; e += 256) {
         const int which = e / (64 * JC), c = e % (64 * JC);
-        if (c < C) {
+        if (c < C && c < G * JC) {
             const float s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
             atomicAdd((which == 0 ? ggamma : gbeta) + c, s);
         }
@@ -753,18 +789,20 @@ static int layernorm_fwd_impl(const char* who, const float* x, const float* gamm
                               const float* qmin, const float* qmax, fqss_stream_t stream, const float* xadd = nullptr, int64_t ld_a = 0,
                               float* xsum = nullptr, int64_t ld_s = 0) {
     if (R == 0) return FQSS_OK;
-    int64_t nb = cdiv(R, 4);
-    if (nb > 4096) nb = 4096;
     hipStream_t s = (hipStream_t)stream;
     const float e = (float)eps;
     // float4 form: every row (and gamma / beta) 16-B aligned, C a multiple of 4
     const bool vec = C % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
                      (xadd == nullptr || (ld_a % 4 == 0 && ld_s % 4 == 0 && aligned16(xadd) && aligned16(xsum)));
-#define FQSS_LN_FWD(JC, Q, V) \
-    hipLaunchKernelGGL((k_layernorm_fwd<JC, Q, V>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
+    const bool narrow = vec && C <= 64;                 // four rows per wave
+    int64_t nb = cdiv(R, narrow ? 16 : 4);
+    if (nb > 4096) nb = 4096;
+#define FQSS_LN_FWD(JC, Q, ...) \
+    hipLaunchKernelGGL((k_layernorm_fwd<JC, Q, __VA_ARGS__>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
                        qmax, yc, ld_yc, xadd, ld_a, xsum, ld_s)
 #define FQSS_LN_FWD_Q(Q) \
-    if (C <= 64) FQSS_LN_FWD(1, Q, false); \
+    if (narrow) FQSS_LN_FWD(4, Q, true, 16); \
+    else if (C <= 64) FQSS_LN_FWD(1, Q, false); \
     else if (C <= 256) { if (vec) FQSS_LN_FWD(4, Q, true); else FQSS_LN_FWD(4, Q, false); } \
     else { if (vec) FQSS_LN_FWD(8, Q, true); else FQSS_LN_FWD(8, Q, false); }      /* HTDemucs transformer: 384 / 512 */
     if (qmin != nullptr) { FQSS_LN_FWD_Q(true) } else { FQSS_LN_FWD_Q(false) }
@@ -793,17 +831,19 @@ static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, 
                               int64_t ld_x, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream,
                               const float* gadd = nullptr, int64_t ld_ga = 0) {
     if (R == 0) return FQSS_OK;
-    int64_t nb = cdiv(R, 4 * 16);       // ~16 rows per wave: 64*C atomics per workgroup stay rare
-    if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
     hipStream_t s = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ld_gy % 4 == 0 && ld_x % 4 == 0 && ld_gx % 4 == 0 && aligned16(gy) && aligned16(x) && aligned16(gx) &&
                      aligned16(gamma) && (beta == nullptr || aligned16(beta)) && (gadd == nullptr || (ld_ga % 4 == 0 && aligned16(gadd)));
-#define FQSS_LN_BWD(JC, Q, V) \
-    hipLaunchKernelGGL((k_layernorm_bwd<JC, Q, V>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
+    const bool narrow = vec && C <= 64;
+    int64_t nb = cdiv(R, narrow ? 4 * 8 * 4 : 4 * 16);       // ~16 rows per wave (narrow: 8 groups of 4): 64*C atomics per workgroup stay rare
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
+#define FQSS_LN_BWD(JC, Q, ...) \
+    hipLaunchKernelGGL((k_layernorm_bwd<JC, Q, __VA_ARGS__>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
                        ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc, gadd, ld_ga)
 #define FQSS_LN_BWD_Q(Q) \
-    if (C <= 64) FQSS_LN_BWD(1, Q, false); \
+    if (narrow) FQSS_LN_BWD(4, Q, true, 16); \
+    else if (C <= 64) FQSS_LN_BWD(1, Q, false); \
     else if (C <= 256) { if (vec) FQSS_LN_BWD(4, Q, true); else FQSS_LN_BWD(4, Q, false); } \
     else { if (vec) FQSS_LN_BWD(8, Q, true); else FQSS_LN_BWD(8, Q, false); }
     if (qmin != nullptr) { FQSS_LN_BWD_Q(true) } else { FQSS_LN_BWD_Q(false) }

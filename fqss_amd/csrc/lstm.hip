@@ -182,7 +182,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
 template <int HT>
 __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float* __restrict__ gout, const float* __restrict__ whh,
                                                                       const float* __restrict__ gsav, const float* __restrict__ csav,
-                                                                      float* __restrict__ dG, int S, int B, int Hrt) {
+                                                                      float* __restrict__ dG, float* __restrict__ gbias, int S, int B, int Hrt) {
     const int H = HT > 0 ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dgs = smem;                   // [kNB][4H]   (HT > 0: [kNB][4 blocks][4 quarters][HT/4 + 4])
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
     const int cn = tid / H, ck = tid - cn * H;
     const bool cell = tid < kNB * H && (b0 + cn) < B;
     float dc_rec = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};       // column sums of this thread's dgates over the steps: the bias gradient (gbias)
     // saved gate activations, cell state and incoming gradient of a step are fetched one step ahead (unconditional loads from
     // clamped indices, see k_lstm_fwd): without the prefetch every step began with an exposed global-memory round trip
     const int cnc = min(b0 + (cell ? cn : 0), B - 1), ckc = cell ? ck : 0;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
             const float d_f = ((dc * cprev) * (1.0f - gf)) * gf;
             const float d_g = (dc * gi) * (1.0f - gg * gg);
             dc_rec = dc * gf;
+            bsum[0] += d_i; bsum[1] += d_f; bsum[2] += d_g; bsum[3] += d_o;
             if constexpr (HT > 0) {
                 float* d = dgs + cn * 16 * DQS + (ck / RQ) * DQS + (ck % RQ);        // [nb][gate block][row quarter][RQ + pad]
                 d[0] = d_i; d[4 * DQS] = d_f; d[8 * DQS] = d_g; d[12 * DQS] = d_o;
@@ -320,6 +322,10 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
 #pragma unroll
     for (int u = 0; u < kPF - 1; ++u)           // the last S % kPF steps: already in the ring
         if (done + u < S) one_step(S - 1 - (done + u), pf[u]);
+    if (gbias != nullptr && cell) {
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) atomicAdd(gbias + (dir * 4 + gt) * H + ck, bsum[gt]);
+    }
 }
 
 }  // namespace fqss
@@ -342,8 +348,8 @@ extern "C" int fqss_lstm_fwd(const float* pre, const float* whh, const float* bh
     return launch_status("fqss_lstm_fwd");
 }
 
-extern "C" int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
-                             int B, int H, fqss_stream_t stream) {
+static int lstm_bwd_impl(const char* who, const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* gbias,
+                         int S, int B, int H, fqss_stream_t stream) {
     FQSS_REQUIRE(gout && whh && gsav && csav && dG, "null tensor");
     FQSS_REQUIRE(S > 0 && B > 0 && H > 0 && H <= 256, "bad shape (H <= 256)");
     hipStream_t s = (hipStream_t)stream;
@@ -351,10 +357,23 @@ extern "C" int fqss_lstm_bwd(const float* gout, const float* whh, const float* g
     const size_t lds = (size_t)(kNB * 4 * H + 4 * kNB * H) * sizeof(float);
     if (H == 128) {
         const size_t lds128 = (size_t)(kNB * 16 * (128 / 4 + 4) + 4 * kNB * H) * sizeof(float);   // padded dgate image + partial dh
-        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds128, s, gout, whh, gsav, csav, dG, S, B, H);
+        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds128, s, gout, whh, gsav, csav, dG, gbias, S, B, H);
     } else {
         const int threads = (int)cdiv(4 * H, 64) * 64;
-        hipLaunchKernelGGL((k_lstm_bwd<0>), grid, dim3(threads), lds, s, gout, whh, gsav, csav, dG, S, B, H);
+        hipLaunchKernelGGL((k_lstm_bwd<0>), grid, dim3(threads), lds, s, gout, whh, gsav, csav, dG, gbias, S, B, H);
     }
-    return launch_status("fqss_lstm_bwd");
+    return launch_status(who);
+}
+
+extern "C" int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
+                             int B, int H, fqss_stream_t stream) {
+    return lstm_bwd_impl("fqss_lstm_bwd", gout, whh, gsav, csav, dG, nullptr, S, B, H, stream);
+}
+
+// the same, and the column sums of dG (= the gradient of b_ih and of b_hh, [2][4H]) ADDED into gbias: the cell threads keep them in
+// registers over the steps (a separate pass over dG, the largest tensor of the layer, was 34 us per LSTM at cfg 3)
+extern "C" int fqss_lstm_bwd_b(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* gbias, int S,
+                               int B, int H, fqss_stream_t stream) {
+    FQSS_REQUIRE(gbias, "null tensor");
+    return lstm_bwd_impl("fqss_lstm_bwd_b", gout, whh, gsav, csav, dG, gbias, S, B, H, stream);
 }

@@ -554,9 +554,9 @@ extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci,
         const char* e = getenv("FQSS_TGEMM_PAD_LDS");
         const size_t v = e ? (size_t)atol(e) : 0;
         if (v) {
-            hipFuncSetAttribute((const void*)k_tgemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
-            hipFuncSetAttribute((const void*)k_tgemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
-            hipFuncSetAttribute((const void*)k_tgemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+            (void)hipFuncSetAttribute((const void*)k_tgemm<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+            (void)hipFuncSetAttribute((const void*)k_tgemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+            (void)hipFuncSetAttribute((const void*)k_tgemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
         }
         return v;
     }();

@@ -1267,11 +1267,16 @@ def lstm_fwd(pre, whh, bhh, S, B, H, save=True):
     return hout, gsav, csav
 
 
-def lstm_bwd(gout, whh, gsav, csav, S, B, H):
+def lstm_bwd(gout, whh, gsav, csav, S, B, H, gbias=None):
+    """gbias ([8H] zeros): receives the column sums of dG (the bias gradients) from the same launch"""
     _need_gpu(gout, whh)
     gout = gout.contiguous()
     dG = torch.empty(S, B, 8 * H, device=gout.device, dtype=torch.float32)
-    _lib.call("fqss_lstm_bwd", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), S, B, H, _stream())
+    if gbias is None:
+        _lib.call("fqss_lstm_bwd", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), S, B, H, _stream())
+    else:
+        assert gbias.numel() == 8 * H and gbias.is_contiguous()
+        _lib.call("fqss_lstm_bwd_b", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), _p(gbias), S, B, H, _stream())
     return dG
 
 

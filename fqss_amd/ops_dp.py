@@ -467,7 +467,9 @@ class LstmBi(Function):
         x, wih, whh, hout, gsav, csav = ctx.saved_tensors
         S, B, I = x.shape
         H = whh.shape[2]
-        dG = K.lstm_bwd(gout, whh, gsav, csav, S, B, H)                  # [S, B, 8H]
+        # (the bias gradients -- column sums of dG, the same for b_ih and b_hh of a direction -- come out of the same launch)
+        cs = torch.zeros(8 * H, device=gout.device, dtype=torch.float32)
+        dG = K.lstm_bwd(gout, whh, gsav, csav, S, B, H, cs)              # [S, B, 8H]
         gx = K.rowlin_bwd_x(dG, wih) if ctx.needs_input_grad[0] else None
         # weights fake-quantized by runtime.QuantTables carry no autograd history: their dL/dW_q is accumulated straight into the step's
         # arena slot by the wgrad GEMM of that direction; otherwise one GEMM for both directions' W_ih into a fresh buffer
@@ -492,10 +494,6 @@ class LstmBi(Function):
                 if slots[i] is not None:
                     K.axpby_(slots[i], gws[i], 1.0)
                     gws[i] = None
-        # b_ih and b_hh of a direction get the same column sums of dG: ONE pass over dG for all four (it is the largest tensor of the
-        # layer: four passes were 4 x 28 us per LSTM at cfg 3), then four 4H-element adds
-        cs = torch.zeros(8 * H, device=dG.device, dtype=torch.float32)
-        K.colsum(dG, cs)
         gbs = []
         for p, lo in zip(ctx.params, (0, 0, 4 * H, 4 * H)):
             buf, direct = _param_grad(p, p)

@@ -570,6 +570,11 @@ int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* h
                   int S, int B, int H, fqss_stream_t stream);
 int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
                   int B, int H, fqss_stream_t stream);
+/* fqss_lstm_bwd that also ADDS the column sums of dG over (step, sequence) into gbias [2][4H] (caller-zeroed): the gradient of
+ * b_ih and b_hh of each direction (torch's LSTM backward, reached from qat_layers.py:571-600), kept in registers by the
+ * threads that produce dG */
+int fqss_lstm_bwd_b(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* gbias, int S,
+                    int B, int H, fqss_stream_t stream);
 
 /* Sepformer (cfg 4 -- SURVEY.md §8 row a14): gLN and the positional-encoding add on the dual-path row layouts.
  * GroupNorm(1, C) over ALL rows of a sample of a row matrix x [R][C]; the sample of row r is b = (r % RB) / X
