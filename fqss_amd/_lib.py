@@ -107,6 +107,7 @@ _PROTOS = {
     "fqss_add_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I64, I64, F64, P, P, P],
     "fqss_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I64, P, P, P, P],
     "fqss_mha_prep_fwd": [P, P, P, P, I64, I32, I64, F64, P, P],
+    "fqss_mha_prep_fwd_c": [P, P, P, P, I64, I32, I64, F64, P, P],
     "fqss_mha_prep_bwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P, P, P],
     "fqss_lstm_fwd": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_lstm_bwd": [P, P, P, P, P, I32, I32, I32, P],
@@ -146,6 +147,8 @@ _PROTOS = {
     "fqss_resample_fir": [P, P, P, I64, I64, I64, I64, I64, I32, I32, I32, P],
     "fqss_attn_long_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P],
     "fqss_attn_long_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
+    "fqss_attn_long_fwd_c": [P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
+    "fqss_attn_long_bwd_c": [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P],
     # descriptor-struct forms (csrc/desc_api.hip); the structs are below
     "fqss_workspace_bytes": [C.c_char_p, P, I32],
     "fqss_add_fq_fwd": [P, P, P, P, F32, P, P, P, P, C.c_size_t, P],

@@ -985,6 +985,441 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_x3(const float* __rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// CODED operands (the student in its quantizing phase): q, k, v arrive as the 8-bit codes of their quantizers, x = delta c + lo
+// (csrc/dualpath.hip fqss_mha_prep_fwd_c).  An integer code is ONE exact bf16 plane, and terms that are constant along the softmax
+// axis drop out of it:
+//   s_ij = q_i . k_j = dk (q_i . ck_j) + lo_k sum_d q_id            -> s'_ij = (dk q_i) . ck_j       3 products (q: 3 pieces, ck: 1)
+//   o_i  = sum_j p_ij v_j = dv (sum_j p_ij cv_j) + lo_v              (sum_j p_ij = 1)                 3 products (p: 3, cv: 1)
+//   dp_ij - D_i = dv (dO_i . cv_j) - D'_i,  D'_i = D_i - lo_v sum_d dO_id                            3 products (dO: 3, cv: 1)
+//   dq_i = dk sum_j ds_ij ck_j + lo_k sum_j ds_ij                                                     3 products (ds: 3, ck: 1)
+//   dk_j = dq' sum_i ds_ij cq_i + lo_q sum_i ds_ij   (dq', lo_q: the q quantizer's grid)              3 products (ds: 3, cq: 1)
+//   dv_j = sum_i p_ij dO_i                                                                            6 products (no codes)
+//   dk/dv pass: s'_ij = dk (dq' (cq_i . ck_j) + lo_q sum_d ck_jd): ONE product, exact integers
+// so the forward issues 24 MFMAs per 32 x 32 tile instead of 48, dq 36 instead of 72, dk/dv 52 instead of 96, the K / V / Q tiles
+// are 1 B per element in HBM and one plane in LDS, and their 3-way split disappears.  The saved statistics (m, l) refer to s'.
+// Same tiling, lane <-> row maps, lazy reference maximum and LDS idioms as the split-bf16 kernels above.
+// ------------------------------------------------------------------------------------------------------------------
+#define FQSS_X3_A1_B3(ACC, A1, B)                                                                     \
+    do {                                                                                                \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A1), (B).p[2], ACC, 0, 0, 0);                   \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A1), (B).p[1], ACC, 0, 0, 0);                   \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A1), (B).p[0], ACC, 0, 0, 0);                   \
+    } while (0)
+#define FQSS_X3_A3_B1(ACC, A, B1)                                                                     \
+    do {                                                                                                \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[2], (B1), ACC, 0, 0, 0);                   \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[1], (B1), ACC, 0, 0, 0);                   \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).p[0], (B1), ACC, 0, 0, 0);                   \
+    } while (0)
+
+// 8 codes (two 32-bit words) -> 8 floats / one exact bf16x8
+__device__ __forceinline__ void codes_to_f(uint2 w, float (&c)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c[e] = (float)((w.x >> (8 * e)) & 0xFFu);
+        c[4 + e] = (float)((w.y >> (8 * e)) & 0xFFu);
+    }
+}
+__device__ __forceinline__ bf16x8 codes_to_bf(uint2 w) {
+    float c[8];
+    codes_to_f(w, c);
+    union { bf16x8 v; unsigned int u[4]; } r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.u[q] = __builtin_amdgcn_perm(__float_as_uint(c[2 * q + 1]), __float_as_uint(c[2 * q]), 0x07060302u);
+    return r.v;
+}
+
+// a 32-row tile of codes of one head: global (8 B per thread, rows clamped) -> registers -> ONE bf16 plane in LDS
+template <int HD>
+struct TileC {
+    static constexpr int LD = (HD < 32 ? 32 : HD) + 8;
+    uint2 v;
+    int nrows_;
+    __device__ __forceinline__ void fetch(const unsigned char* __restrict__ x, const RowView rv, int b, int h, int r0, int nrows) {
+        nrows_ = nrows;
+        const int e = min((int)threadIdx.x, 4 * HD - 1), j = e / (HD / 8), d = (e % (HD / 8)) * 8;
+        v = *reinterpret_cast<const uint2*>(x + (int64_t)(r0 + min(j, nrows - 1)) * rv.sl + (int64_t)b * rv.sb + h * HD + d);
+    }
+    __device__ __forceinline__ void store(unsigned short (*pl)[LD]) const {
+        const int e = threadIdx.x, j = e / (HD / 8), d = (e % (HD / 8)) * 8;
+        if (e >= 4 * HD) return;
+        union { bf16x8 b; uint4 u; } r;
+        r.b = codes_to_bf(j < nrows_ ? v : make_uint2(0u, 0u));
+        *reinterpret_cast<uint4*>(&pl[j][d]) = r.u;
+    }
+};
+template <int HD, int LD>
+__device__ __forceinline__ void x3_zero_plane1(unsigned short (*pl)[LD]) {
+    if constexpr (HD < 32) {
+        for (int e = threadIdx.x; e < 32 * (LD - HD); e += 256) pl[e / (LD - HD)][HD + e % (LD - HD)] = 0;
+    }
+}
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_rows1(const unsigned short (*pl)[LD], int kap, int ks, int lk) {
+    return *reinterpret_cast<const bf16x8*>(&pl[kap][16 * ks + 8 * lk]);
+}
+template <int LD>
+__device__ __forceinline__ bf16x8 frag_cols1(const unsigned short (*pl)[LD], int ks, int d0, int lane) {
+    const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int kr = ks * 16 + 8 * (gq >> 1) + tq, nc = d0 + 16 * (gq & 1) + 4 * tp;
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&pl[kr][nc]));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&pl[kr + 4][nc]));
+    return u.v;
+}
+// the lane's own query row from its codes: (dq' c + lo_q) * dk, split in three (the same operations in the forward and in the dq pass)
+__device__ __forceinline__ Frag3 own_q_scaled(const unsigned char* __restrict__ row, int ks, int lk, const QRange rq, float dk) {
+    float c[8];
+    codes_to_f(*reinterpret_cast<const uint2*>(row + 16 * ks + 8 * lk), c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = (rq.delta * c[e] + rq.lo) * dk;
+    return split8(c);
+}
+
+struct AttnRanges {       // device scalars: the grids of q (behind the division), k, v
+    const float *q_lo, *q_hi, *k_lo, *k_hi, *v_lo, *v_hi;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_fwd_c(const unsigned char* __restrict__ qc, const unsigned char* __restrict__ kc,
+                                                          const unsigned char* __restrict__ vc, float* __restrict__ o, float* __restrict__ stats,
+                                                          const AttnGeom g, const AttnRanges rg) {
+    constexpr int LD = TileC<HD>::LD, KS = HD / 16, ND = HD < 32 ? 1 : HD / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Kp[32][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vp[32][LD];
+    __shared__ __attribute__((aligned(16))) float scs[4][32];
+    constexpr float kLazy = 8.0f;
+    x3_zero_plane1<HD, LD>(Vp);
+    const QRange rq = load_qrange(rg.q_lo, rg.q_hi), rk = load_qrange(rg.k_lo, rg.k_hi), rv = load_qrange(rg.v_lo, rg.v_hi);
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    const int i_own = it * 32 + c;
+    const bool live = i_own < g.Lq;
+    const unsigned char* qp = qc + (int64_t)(live ? i_own : g.Lq - 1) * g.q.sl + (int64_t)b * g.q.sb + h * HD;
+    Frag3 qb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qb[ks] = own_q_scaled(qp, ks, lk, rq, rk.delta);
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int kap = kappa(c);
+    TileC<HD> kt, vt;
+    kt.fetch(kc, g.k, b, h, 0, min(32, g.Lk));
+    vt.fetch(vc, g.v, b, h, 0, min(32, g.Lk));
+    for (int j0 = 0; j0 < g.Lk; j0 += 32) {
+        const int nj = min(32, g.Lk - j0);
+        __syncthreads();
+        kt.store(Kp);
+        vt.store(Vp);
+        __syncthreads();
+        if (j0 + 32 < g.Lk) {
+            kt.fetch(kc, g.k, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+            vt.fetch(vc, g.v, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+        }
+        f32x16 T0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ka = frag_rows1<LD>(Kp, kap, ks, lk);
+            FQSS_X3_A1_B3(T0, ka, qb[ks]);
+        }
+        if (nj < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T0[r] = krow(r, lk) < nj ? T0[r] : -INFINITY;
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, T0[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const bool move = tmax > m + kLazy;
+        if (__any(move)) {
+            const float m_new = move ? tmax : m;
+            const float sc = al_exp(m - m_new);
+            l *= sc;
+            m = m_new;
+            if (j0 > 0) {
+                if (lk == 0) scs[wave][c] = sc;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 f = *reinterpret_cast<const float4*>(&scs[wave][8 * r4 + 4 * lk]);
+                    const float ff[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int nd = 0; nd < ND; ++nd) acc[nd][4 * r4 + e] *= ff[e];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        Frag3 pa[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pr[e] = al_exp(T0[8 * s2 + e] - m);
+                l += pr[e];
+            }
+            pa[s2] = split8(pr);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const bf16x8 vb = frag_cols1<LD>(Vp, s2, 32 * nd, lane);
+                FQSS_X3_A3_B1(acc[nd], pa[s2], vb);
+            }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (lk == 0 && live) {
+        stats[((int64_t)bh * g.Lq + i_own) * 2] = m;
+        stats[((int64_t)bh * g.Lq + i_own) * 2 + 1] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = tile_row(r, lk);
+        const float lr = __shfl(l, il, 64);
+        const int i = it * 32 + il;
+        if (i < g.Lq) {
+            float* op = o + (int64_t)i * g.o.sl + (int64_t)b * g.o.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+                if (HD >= 32 || c < HD) op[32 * nd] = rv.delta * (acc[nd][r] / lr) + rv.lo;
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd_q_c(const unsigned char* __restrict__ qc, const unsigned char* __restrict__ kc,
+                                                            const unsigned char* __restrict__ vc, const float* __restrict__ o,
+                                                            const float* __restrict__ go, const float* __restrict__ stats, float* __restrict__ gq,
+                                                            float* __restrict__ dsum, const AttnGeom g, const AttnRanges rg) {
+    constexpr int LD = TileC<HD>::LD, KS = HD / 16, ND = HD < 32 ? 1 : HD / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Kp[32][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Vp[32][LD];
+    __shared__ __attribute__((aligned(16))) float scs[4][32];
+    x3_zero_plane1<HD, LD>(Kp);
+    const QRange rq = load_qrange(rg.q_lo, rg.q_hi), rk = load_qrange(rg.k_lo, rg.k_hi), rv = load_qrange(rg.v_lo, rg.v_hi);
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    const int i_own = it * 32 + c;
+    const bool live = i_own < g.Lq;
+    const int ic = live ? i_own : g.Lq - 1;
+    const unsigned char* qp = qc + (int64_t)ic * g.q.sl + (int64_t)b * g.q.sb + h * HD;
+    const float* gp = go + (int64_t)ic * g.go.sl + (int64_t)b * g.go.sb + h * HD;
+    const float* op = o + (int64_t)ic * g.o.sl + (int64_t)b * g.o.sb + h * HD;
+    Frag3 qb[KS], gb[KS];
+    float D = 0.f, gs = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qb[ks] = own_q_scaled(qp, ks, lk, rq, rk.delta);
+        gb[ks] = frag_own(gp, ks, lk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = gp[16 * ks + 8 * lk + e];
+            D = fmaf(gg, op[16 * ks + 8 * lk + e], D);
+            gs += gg;
+        }
+    }
+    D += __shfl_xor(D, 32, 64);
+    gs += __shfl_xor(gs, 32, 64);
+    const float Dp = D - rv.lo * gs;               // D' = D - lo_v sum_d dO
+    const float m = stats[((int64_t)bh * g.Lq + ic) * 2], rl = 1.0f / stats[((int64_t)bh * g.Lq + ic) * 2 + 1];
+    f32x16 acc[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nd][r] = 0.f;
+    float dss = 0.f;                               // sum_j ds_ij of this lane's query (its half of the keys)
+    const int kap = kappa(c);
+    TileC<HD> kt, vt;
+    kt.fetch(kc, g.k, b, h, 0, min(32, g.Lk));
+    vt.fetch(vc, g.v, b, h, 0, min(32, g.Lk));
+    for (int j0 = 0; j0 < g.Lk; j0 += 32) {
+        const int nj = min(32, g.Lk - j0);
+        __syncthreads();
+        kt.store(Kp);
+        vt.store(Vp);
+        __syncthreads();
+        if (j0 + 32 < g.Lk) {
+            kt.fetch(kc, g.k, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+            vt.fetch(vc, g.v, b, h, j0 + 32, min(32, g.Lk - j0 - 32));
+        }
+        f32x16 T0, U0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = U0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ka = frag_rows1<LD>(Kp, kap, ks, lk), va = frag_rows1<LD>(Vp, kap, ks, lk);
+            FQSS_X3_A1_B3(T0, ka, qb[ks]);
+            FQSS_X3_A1_B3(U0, va, gb[ks]);
+        }
+        if (nj < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T0[r] = krow(r, lk) < nj ? T0[r] : -INFINITY;
+        }
+        Frag3 da[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s2 + e;
+                ds[e] = al_exp(T0[r] - m) * rl * (rv.delta * U0[r] - Dp);
+                dss += ds[e];
+            }
+            da[s2] = split8(ds);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const bf16x8 kb = frag_cols1<LD>(Kp, s2, 32 * nd, lane);
+                FQSS_X3_A3_B1(acc[nd], da[s2], kb);
+            }
+    }
+    dss += __shfl_xor(dss, 32, 64);
+    if (lk == 0 && live) dsum[(int64_t)bh * g.Lq + i_own] = Dp;
+    if (lk == 0) scs[wave][c] = dss;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = tile_row(r, lk);
+        const int i = it * 32 + il;
+        const float sj = scs[wave][il];
+        if (i < g.Lq) {
+            float* gp2 = gq + (int64_t)i * g.gq.sl + (int64_t)b * g.gq.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+                if (HD >= 32 || c < HD) gp2[32 * nd] = rk.delta * acc[nd][r] + rk.lo * sj;
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn_long_bwd_kv_c(const unsigned char* __restrict__ qc, const unsigned char* __restrict__ kc,
+                                                             const unsigned char* __restrict__ vc, const float* __restrict__ go,
+                                                             const float* __restrict__ stats, const float* __restrict__ dsum,
+                                                             float* __restrict__ gk, float* __restrict__ gv, const AttnGeom g, const AttnRanges rg) {
+    constexpr int LD = TileC<HD>::LD, KS = HD / 16, ND = HD < 32 ? 1 : HD / 32;
+    static_assert(LD == Tile3<HD>::LD, "one row stride for both tile kinds");
+    __shared__ __attribute__((aligned(16))) unsigned short Qp[32][LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Gp[3][32][LD];
+    __shared__ float Ms[32], Rs[32], Ds[32];
+    __shared__ __attribute__((aligned(16))) float scs[4][32];
+    x3_zero_plane1<HD, LD>(Qp);
+    x3_zero_planes<HD, LD>(Gp);
+    const QRange rq = load_qrange(rg.q_lo, rg.q_hi), rk = load_qrange(rg.k_lo, rg.k_hi), rv = load_qrange(rg.v_lo, rg.v_hi);
+    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
+    const int jt = blockIdx.x * 4 + wave;
+    const int j_own = jt * 32 + c;
+    const int jc = j_own < g.Lk ? j_own : g.Lk - 1;
+    const unsigned char* kp = kc + (int64_t)jc * g.k.sl + (int64_t)b * g.k.sb + h * HD;
+    const unsigned char* vp = vc + (int64_t)jc * g.v.sl + (int64_t)b * g.v.sb + h * HD;
+    bf16x8 kb[KS], vb[KS];
+    float sk = 0.f;                                 // sum_d ck_jd
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const uint2 wk = *reinterpret_cast<const uint2*>(kp + 16 * ks + 8 * lk), wv = *reinterpret_cast<const uint2*>(vp + 16 * ks + 8 * lk);
+        float cf[8];
+        codes_to_f(wk, cf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sk += cf[e];
+        kb[ks] = codes_to_bf(wk);
+        vb[ks] = codes_to_bf(wv);
+    }
+    sk += __shfl_xor(sk, 32, 64);
+    const float t_c0 = rk.delta * rq.delta, t_c1 = rk.delta * (rq.lo * sk);     // s'_ij = t_c0 I_ij + t_c1
+    f32x16 ak[ND], av[ND];
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ak[nd][r] = av[nd][r] = 0.f;
+    float dss = 0.f;                                // sum_i ds_ij of this lane's key (its half of the queries)
+    const int kap = kappa(c);
+    TileC<HD> qt;
+    Tile3<HD> gt;
+    qt.fetch(qc, g.q, b, h, 0, min(32, g.Lq));
+    gt.fetch(go, g.go, b, h, 0, min(32, g.Lq));
+    for (int i0 = 0; i0 < g.Lq; i0 += 32) {
+        const int ni = min(32, g.Lq - i0);
+        __syncthreads();
+        qt.store(Qp);
+        gt.store(Gp);
+        if (threadIdx.x < 32) {
+            const bool ok = threadIdx.x < ni;
+            const int64_t si = (int64_t)bh * g.Lq + i0 + (ok ? threadIdx.x : 0);
+            Ms[threadIdx.x] = ok ? stats[si * 2] : INFINITY;             // padding queries: exp(-inf) = 0
+            Rs[threadIdx.x] = ok ? 1.0f / stats[si * 2 + 1] : 0.f;
+            Ds[threadIdx.x] = ok ? dsum[si] : 0.f;
+        }
+        __syncthreads();
+        if (i0 + 32 < g.Lq) {
+            qt.fetch(qc, g.q, b, h, i0 + 32, min(32, g.Lq - i0 - 32));
+            gt.fetch(go, g.go, b, h, i0 + 32, min(32, g.Lq - i0 - 32));
+        }
+        f32x16 T0, U0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T0[r] = U0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = frag_rows1<LD>(Qp, kap, ks, lk);
+            const Frag3 ga = frag_rows<LD>(Gp, kap, ks, lk);
+            T0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb[ks], T0, 0, 0, 0);
+            FQSS_X3_A3_B1(U0, ga, vb[ks]);
+        }
+        Frag3 pa[2], da[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pv[8], ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s2 + e, row = krow(r, lk);
+                pv[e] = al_exp((t_c0 * T0[r] + t_c1) - Ms[row]) * Rs[row];
+                ds[e] = pv[e] * (rv.delta * U0[r] - Ds[row]);
+                dss += ds[e];
+            }
+            pa[s2] = split8(pv);
+            da[s2] = split8(ds);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) {
+                const Frag3 gr = frag_cols<LD>(Gp, s2, 32 * nd, lane);
+                const bf16x8 qr = frag_cols1<LD>(Qp, s2, 32 * nd, lane);
+                FQSS_X3_PRODUCTS(av[nd], pa[s2], gr);
+                FQSS_X3_A3_B1(ak[nd], da[s2], qr);
+            }
+    }
+    dss += __shfl_xor(dss, 32, 64);
+    if (lk == 0) scs[wave][c] = dss;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int jl = tile_row(r, lk);
+        const int j = jt * 32 + jl;
+        const float sj = scs[wave][jl];
+        if (j < g.Lk) {
+            float* gkp = gk + (int64_t)j * g.gk.sl + (int64_t)b * g.gk.sb + h * HD + c;
+            float* gvp = gv + (int64_t)j * g.gv.sl + (int64_t)b * g.gv.sb + h * HD + c;
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+                if (HD >= 32 || c < HD) { gkp[32 * nd] = rq.delta * ak[nd][r] + rq.lo * sj; gvp[32 * nd] = av[nd][r]; }
+        }
+    }
+}
+
 // 0: vector ALU, 1: fp32 MFMA, 2: split-bf16 MFMA (default where head_dim and alignment allow)
 static int attn_mfma_mode() {
     static const int mode = [] {
@@ -1105,4 +1540,56 @@ extern "C" int fqss_attn_long_bwd(const float* q, const float* k, const float* v
     FQSS_HD_SWITCH(hd, CALL)
 #undef CALL
     return launch_status("fqss_attn_long_bwd");
+}
+
+// ---- coded operands (see k_attn_long_fwd_c): strides in ELEMENTS of each tensor (bytes for the code tensors)
+static int check_coded(const void* const* codes, const int64_t* st, int hd) {
+    FQSS_REQUIRE(hd == 16 || hd == 32 || hd == 64, "coded attention: head_dim 16, 32 or 64");
+    for (int t = 0; t < 3; ++t) {
+        FQSS_REQUIRE(((uintptr_t)codes[t] & 7) == 0 && st[2 * t] % 8 == 0 && st[2 * t + 1] % 8 == 0, "coded attention: code rows must be 8-B aligned");
+    }
+    return FQSS_OK;
+}
+
+// ranges: device scalars {q_min, q_max (the grid q is on: the division's quantizer), k_min, k_max, v_min, v_max}
+// strides: (sl, sb) pairs for qc, kc, vc, o
+extern "C" int fqss_attn_long_fwd_c(const uint8_t* qc, const uint8_t* kc, const uint8_t* vc, const float* const* ranges, float* o, float* stats,
+                                    int Lq, int Lk, int B, int nh, int hd, const int64_t* strides, fqss_stream_t stream) {
+    FQSS_REQUIRE(qc && kc && vc && ranges && o && stats && strides, "null tensor");
+    for (int t = 0; t < 6; ++t) FQSS_REQUIRE(ranges[t], "null range");
+    if (int rc = check_attn(Lq, Lk, B, nh, hd, strides, 4)) return rc;
+    const void* codes[3] = {qc, kc, vc};
+    if (int rc = check_coded(codes, strides, hd)) return rc;
+    AttnGeom g{Lq, Lk, B, nh, {strides[0], strides[1]}, {strides[2], strides[3]}, {strides[4], strides[5]}, {strides[6], strides[7]}, {}, {}, {}, {}};
+    const AttnRanges rg{ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5]};
+    dim3 gm((unsigned)cdiv(Lq, 128), (unsigned)(B * nh));
+    hipStream_t st = (hipStream_t)stream;
+    if (hd == 16) hipLaunchKernelGGL((k_attn_long_fwd_c<16>), gm, dim3(256), 0, st, qc, kc, vc, o, stats, g, rg);
+    else if (hd == 32) hipLaunchKernelGGL((k_attn_long_fwd_c<32>), gm, dim3(256), 0, st, qc, kc, vc, o, stats, g, rg);
+    else hipLaunchKernelGGL((k_attn_long_fwd_c<64>), gm, dim3(256), 0, st, qc, kc, vc, o, stats, g, rg);
+    return launch_status("fqss_attn_long_fwd_c");
+}
+
+// strides: (sl, sb) pairs for qc, kc, vc, o, go, gq, gk, gv;  dsum: workspace of B*nh*Lq floats.  gq / gk / gv: dL/dq, dL/dk, dL/dv
+// with respect to the de-quantized VALUES (what fqss_mha_prep_bwd takes)
+extern "C" int fqss_attn_long_bwd_c(const uint8_t* qc, const uint8_t* kc, const uint8_t* vc, const float* const* ranges, const float* o,
+                                    const float* go, const float* stats, float* gq, float* gk, float* gv, float* dsum, int Lq, int Lk, int B,
+                                    int nh, int hd, const int64_t* strides, fqss_stream_t stream) {
+    FQSS_REQUIRE(qc && kc && vc && ranges && o && go && stats && gq && gk && gv && dsum && strides, "null tensor");
+    for (int t = 0; t < 6; ++t) FQSS_REQUIRE(ranges[t], "null range");
+    if (int rc = check_attn(Lq, Lk, B, nh, hd, strides, 8)) return rc;
+    const void* codes[3] = {qc, kc, vc};
+    if (int rc = check_coded(codes, strides, hd)) return rc;
+    const int64_t* s = strides;
+    FQSS_REQUIRE(aligned16(o) && aligned16(go) && s[6] % 4 == 0 && s[7] % 4 == 0 && s[8] % 4 == 0 && s[9] % 4 == 0, "o / go rows must be 16-B aligned");
+    AttnGeom g{Lq, Lk, B, nh, {s[0], s[1]}, {s[2], s[3]}, {s[4], s[5]}, {s[6], s[7]}, {s[8], s[9]}, {s[10], s[11]}, {s[12], s[13]}, {s[14], s[15]}};
+    const AttnRanges rg{ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5]};
+    dim3 gq_((unsigned)cdiv(Lq, 128), (unsigned)(B * nh)), gk_((unsigned)cdiv(Lk, 128), (unsigned)(B * nh));
+    hipStream_t st = (hipStream_t)stream;
+#define FQSS_AL_BWD_C(HD_)                                                                                                          \
+    hipLaunchKernelGGL((k_attn_long_bwd_q_c<HD_>), gq_, dim3(256), 0, st, qc, kc, vc, o, go, stats, gq, dsum, g, rg);               \
+    hipLaunchKernelGGL((k_attn_long_bwd_kv_c<HD_>), gk_, dim3(256), 0, st, qc, kc, vc, go, stats, dsum, gk, gv, g, rg);
+    if (hd == 16) { FQSS_AL_BWD_C(16) } else if (hd == 32) { FQSS_AL_BWD_C(32) } else { FQSS_AL_BWD_C(64) }
+#undef FQSS_AL_BWD_C
+    return launch_status("fqss_attn_long_bwd_c");
 }

@@ -718,6 +718,43 @@ __global__ __launch_bounds__(256) void k_mha_prep_fwd(const float* __restrict__ 
     }
 }
 
+// the same quantizer chain, emitting the 8-bit CODES of q (on the division quantizer's grid), k and v: what the coded attention kernels
+// (csrc/attn_long.hip, fqss_attn_long_fwd_c) consume -- 3 B per feature instead of 12
+__global__ __launch_bounds__(256) void k_mha_prep_fwd_c(const float* __restrict__ X, unsigned char* __restrict__ q, unsigned char* __restrict__ k,
+                                                       unsigned char* __restrict__ v, int64_t R, int E, int64_t ld_x, float scale,
+                                                       const float* qmin_q, const float* qmax_q, const float* qmin_k, const float* qmax_k,
+                                                       const float* qmin_v, const float* qmax_v, const float* qmin_d, const float* qmax_d) {
+    const QRange rq = load_qrange(qmin_q, qmax_q), rk = load_qrange(qmin_k, qmax_k), rv = load_qrange(qmin_v, qmax_v),
+                 rd = load_qrange(qmin_d, qmax_d);
+    const int e4 = E >> 2;
+    const int64_t n4 = R * e4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / e4;
+        const int f = (int)(i - row * e4) * 4;
+        const float* xr = X + row * ld_x + f;
+        const float4 a = *reinterpret_cast<const float4*>(xr), b = *reinterpret_cast<const float4*>(xr + E),
+                     c = *reinterpret_cast<const float4*>(xr + 2 * E);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w};
+        unsigned int wq = 0, wk = 0, wv = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cc, u;
+            bool inr;
+            const float qp = fq_asym(av[j], rq, cc, u, inr);
+            (void)fq_asym(qp / scale, rd, cc, u, inr);
+            wq |= (unsigned int)cc << (8 * j);
+            (void)fq_asym(bv[j], rk, cc, u, inr);
+            wk |= (unsigned int)cc << (8 * j);
+            (void)fq_asym(cv[j], rv, cc, u, inr);
+            wv |= (unsigned int)cc << (8 * j);
+        }
+        const int64_t o = row * E + f;
+        *reinterpret_cast<unsigned int*>(q + o) = wq;
+        *reinterpret_cast<unsigned int*>(k + o) = wk;
+        *reinterpret_cast<unsigned int*>(v + o) = wv;
+    }
+}
+
 // STE + range partials of one quantizer at one element (the arithmetic of k_actq_bwd, ACT_NONE)
 __device__ __forceinline__ float mha_ste(float t, float g, const QRange& r, float& p_du, float& p_out) {
     float c, u;
@@ -921,6 +958,18 @@ extern "C" int fqss_mha_prep_fwd(const float* X, float* q, float* k, float* v, i
     hipLaunchKernelGGL(k_mha_prep_fwd, dim3(flat_grid(R * (E / 4))), dim3(256), 0, (hipStream_t)stream, X, q, k, v, R, E, ld_x, (float)scale,
                        ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5], ranges[6], ranges[7]);
     return launch_status("fqss_mha_prep_fwd");
+}
+
+extern "C" int fqss_mha_prep_fwd_c(const float* X, uint8_t* qc, uint8_t* kc, uint8_t* vc, int64_t R, int E, int64_t ld_x, double scale,
+                                   const float* const* ranges, fqss_stream_t stream) {
+    if (R == 0) return FQSS_OK;
+    FQSS_REQUIRE(X && qc && kc && vc && ranges && R > 0 && E > 0 && E % 4 == 0 && ld_x >= 3 * (int64_t)E && ld_x % 4 == 0, "bad shape");
+    FQSS_REQUIRE(aligned16(X) && ((uintptr_t)qc & 3) == 0 && ((uintptr_t)kc & 3) == 0 && ((uintptr_t)vc & 3) == 0, "rows must be aligned");
+    FQSS_REQUIRE(scale != 0.0, "division by zero");
+    for (int i = 0; i < 8; ++i) FQSS_REQUIRE(ranges[i], "null range (q, k, v, div: min, max each)");
+    hipLaunchKernelGGL(k_mha_prep_fwd_c, dim3(flat_grid(R * (E / 4))), dim3(256), 0, (hipStream_t)stream, X, qc, kc, vc, R, E, ld_x, (float)scale,
+                       ranges[0], ranges[1], ranges[2], ranges[3], ranges[4], ranges[5], ranges[6], ranges[7]);
+    return launch_status("fqss_mha_prep_fwd_c");
 }
 
 extern "C" int fqss_mha_prep_bwd(const float* X, const float* gq, const float* gk, const float* gv, float* gX, int64_t R, int E,

@@ -1095,6 +1095,16 @@ def mha_prep_fwd(X, E, scale, ranges):
     return q, k, v
 
 
+def mha_prep_fwd_c(X, E, scale, ranges):
+    """mha_prep_fwd emitting the u8 CODES of q (on the div quantizer's grid), k, v: the operands of attn_long_fwd_c / _bwd_c"""
+    _need_gpu(X)
+    assert X.is_contiguous() and X.shape[-1] == 3 * E
+    R = X.numel() // (3 * E)
+    qc, kc, vc = (torch.empty(*X.shape[:-1], E, device=X.device, dtype=torch.uint8) for _ in range(3))
+    _lib.call("fqss_mha_prep_fwd_c", _p(X), _p(qc), _p(kc), _p(vc), R, E, 3 * E, float(scale), _ptr_array([t for r in ranges for t in r]), _stream())
+    return qc, kc, vc
+
+
 def mha_prep_bwd(X, gq, gk, gv, E, scale, ranges, gaccs):
     """gradients of (q, k, v) -> gX [..., 3E]; the four quantizers' range partials go to gaccs (q, k, v, div)"""
     _need_gpu(X, gq, gk, gv)
@@ -1538,6 +1548,47 @@ def attn_long_bwd(q, k, v, o, go, stats, nh, batch_first):
     dsum = torch.empty(B * nh, Lq, device=q.device, dtype=torch.float32)
     _lib.call("fqss_attn_long_bwd", _p(q), _p(k), _p(v), _p(o), _p(go), _p(stats), _p(gq), _p(gk), _p(gv), _p(dsum), Lq, Lk, B, nh, E // nh,
               _stride_array((q, k, v, o, go, gq, gk, gv), batch_first), _stream())
+    return gq, gk, gv
+
+
+ATTN_CODED = os.environ.get("FQSS_ATTN_CODED", "1") != "0"
+
+
+def attn_coded_ok(E, nh):
+    return ATTN_CODED and (E // nh) in (16, 32, 64) and E % 8 == 0
+
+
+def attn_long_fwd_c(qc, kc, vc, ranges, nh, batch_first):
+    """the attention core from the u8 codes of q, k, v ([L, B, E] or [B, L, E] dense); ranges: [(qmin, qmax)] of the grids q (div), k, v
+    are on (device scalars) -> heads (float, layout of qc), stats [B*nh, Lq, 2]"""
+    _need_gpu(*[t for r in ranges for t in r])
+    assert qc.is_cuda and kc.is_cuda and vc.is_cuda
+    B, Lq = (qc.shape[0], qc.shape[1]) if batch_first else (qc.shape[1], qc.shape[0])
+    Lk = kc.shape[1] if batch_first else kc.shape[0]
+    E = qc.shape[2]
+    assert qc.dtype == torch.uint8 and kc.dtype == torch.uint8 and vc.dtype == torch.uint8 and kc.shape == vc.shape and kc.shape[2] == E
+    o = torch.empty(qc.shape, device=qc.device, dtype=torch.float32)
+    stats = torch.empty(B * nh, Lq, 2, device=qc.device, dtype=torch.float32)
+    _lib.call("fqss_attn_long_fwd_c", _p(qc), _p(kc), _p(vc), _ptr_array([t for r in ranges for t in r]), _p(o), _p(stats), Lq, Lk, B, nh, E // nh,
+              _stride_array((qc, kc, vc, o), batch_first), _stream())
+    return o, stats
+
+
+def attn_long_bwd_c(qc, kc, vc, ranges, o, go, stats, nh, batch_first):
+    """-> (gq, gk, gv): gradients with respect to the de-quantized q, k, v values"""
+    _need_gpu(o, go)
+    assert qc.is_cuda and kc.is_cuda and vc.is_cuda and qc.dtype == torch.uint8 and kc.dtype == torch.uint8 and vc.dtype == torch.uint8
+    B, Lq = (qc.shape[0], qc.shape[1]) if batch_first else (qc.shape[1], qc.shape[0])
+    Lk = kc.shape[1] if batch_first else kc.shape[0]
+    E = qc.shape[2]
+    if not (go.stride(2) == 1 and go.data_ptr() % 16 == 0 and go.stride(0) % 4 == 0 and go.stride(1) % 4 == 0):
+        go = go.contiguous()
+    gq = torch.empty(qc.shape, device=qc.device, dtype=torch.float32)
+    gk = torch.empty(kc.shape, device=qc.device, dtype=torch.float32)
+    gv = torch.empty(kc.shape, device=qc.device, dtype=torch.float32)
+    dsum = torch.empty(B * nh, Lq, device=qc.device, dtype=torch.float32)
+    _lib.call("fqss_attn_long_bwd_c", _p(qc), _p(kc), _p(vc), _ptr_array([t for r in ranges for t in r]), _p(o), _p(go), _p(stats), _p(gq), _p(gk),
+              _p(gv), _p(dsum), Lq, Lk, B, nh, E // nh, _stride_array((qc, kc, vc, o, go, gq, gk, gv), batch_first), _stream())
     return gq, gk, gv
 
 

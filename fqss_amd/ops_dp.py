@@ -350,14 +350,20 @@ class MhaCore(Function):
         ctx.fused = FUSE_MHA_PREP and all(c.qmode == ops.Q_QUANT for c in qs) and E % 4 == 0
         if ctx.fused:
             # quantizing phase: the three quantizers on the thirds, q / sqrt(head_dim) and the div quantizer in ONE pass (fqss_mha_prep_fwd)
-            q, kq, vq = K.mha_prep_fwd(X, E, scale, [(c.qmin, c.qmax) for c in qs])
+            ctx.coded = K.attn_coded_ok(E, nh)
+            prep = K.mha_prep_fwd_c if ctx.coded else K.mha_prep_fwd
+            q, kq, vq = prep(X, E, scale, [(c.qmin, c.qmax) for c in qs])
             for i in range(4):
                 aqs[i].after_forward(qs[i])
             for i in (4, 5):
                 m = aqs[i].next_mode() if hasattr(aqs[i], "next_mode") else ops.Q_BYPASS
                 if m == ops.Q_OBSERVE:
                     raise RuntimeError("MultiheadAttentionQ: attn / softmax observers out of step with the q / k / v quantizers")
-            heads, stats = K.attn_fwd(q, kq, vq, L, B, nh, None, None)
+            if ctx.coded:
+                # q, kq, vq are the quantizers' u8 CODES: the attention core runs on them (fqss_attn_long_fwd_c)
+                heads, stats = K.attn_long_fwd_c(q, kq, vq, [(qs[3].qmin, qs[3].qmax), (qs[1].qmin, qs[1].qmax), (qs[2].qmin, qs[2].qmax)], nh, False)
+            else:
+                heads, stats = K.attn_fwd(q, kq, vq, L, B, nh, None, None)
             ctx.qs = qs
             ctx.save_for_backward(X, q, heads, stats, kq, vq)
             return heads
@@ -405,7 +411,11 @@ class MhaCore(Function):
         if ctx.fused:
             X, q, heads, stats, kq, vq = ctx.saved_tensors
             qs = ctx.qs
-            gq, gk, gv = K.attn_bwd(q, kq, vq, heads, gh, stats, L, B, nh)
+            if ctx.coded:
+                gq, gk, gv = K.attn_long_bwd_c(q, kq, vq, [(qs[3].qmin, qs[3].qmax), (qs[1].qmin, qs[1].qmax), (qs[2].qmin, qs[2].qmax)], heads, gh,
+                                               stats, nh, False)
+            else:
+                gq, gk, gv = K.attn_bwd(q, kq, vq, heads, gh, stats, L, B, nh)
             gaccs = [c.gacc if c.gacc is not None else torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=X.device) for c in qs]
             gX = K.mha_prep_bwd(X, gq, gk, gv, E, scale, [(c.qmin, c.qmax) for c in qs], gaccs)
             grads = []
@@ -662,6 +672,24 @@ class MhaCoreX(Function):
             ctx.save_for_backward(Xq, Xkv, q, heads, stats)
             return heads
         qs = [a.qctx() for a in aqs[:4]]
+        ctx.coded = FUSE_MHA_PREP and all(c.qmode == ops.Q_QUANT for c in qs) and E % 4 == 0 and K.attn_coded_ok(E, nh)
+        if ctx.coded:
+            # quantizing phase: the quantizer chain of MhaCore's fused form emits the u8 CODES of q / k / v (for a cross attention the
+            # chain runs on both projections: q from the query's, k / v from the key's) and the core runs on them (fqss_attn_long_fwd_c)
+            rng = [(c.qmin, c.qmax) for c in qs]
+            qc, kc, vc = K.mha_prep_fwd_c(Xq, E, scale, rng)
+            if not same:
+                _, kc, vc = K.mha_prep_fwd_c(Xkv, E, scale, rng)
+            for i in range(4):
+                aqs[i].after_forward(qs[i])
+            for i in (4, 5):
+                m = aqs[i].next_mode() if hasattr(aqs[i], "next_mode") else ops.Q_BYPASS
+                if m == ops.Q_OBSERVE:
+                    raise RuntimeError("MultiheadAttentionQ: attn / softmax observers out of step with the q / k / v quantizers")
+            heads, stats = K.attn_long_fwd_c(qc, kc, vc, [rng[3], rng[1], rng[2]], nh, batch_first)
+            ctx.qs = qs
+            ctx.save_for_backward(Xq, Xkv, qc, kc, vc, heads, stats)
+            return heads
         parts = []
         for i in range(3):
             blk = srcs[i][..., i * E:(i + 1) * E]
@@ -693,6 +721,22 @@ class MhaCoreX(Function):
     @staticmethod
     def backward(ctx, gh):
         same, E, nh, batch_first, scale = ctx.cfg
+        if ctx.qs is not None and ctx.coded:
+            Xq, Xkv, qc, kc, vc, heads, stats = ctx.saved_tensors
+            qs = ctx.qs
+            rng = [(c.qmin, c.qmax) for c in qs]
+            gq, gk, gv = K.attn_long_bwd_c(qc, kc, vc, [rng[3], rng[1], rng[2]], heads, gh, stats, nh, batch_first)
+            gaccs = [c.gacc if c.gacc is not None else torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=Xq.device) for c in qs]
+            if same:
+                gXq, gXkv = K.mha_prep_bwd(Xq, gq, gk, gv, E, scale, rng, gaccs), None
+            else:
+                zq, zk = torch.zeros_like(gq), torch.zeros_like(gk)
+                gXq = K.mha_prep_bwd(Xq, gq, zq, zq, E, scale, rng, gaccs)          # (its k / v thirds: gradient 0)
+                gXkv = K.mha_prep_bwd(Xkv, zk, gk, gv, E, scale, rng, gaccs)
+            grads = []
+            for c, ga in zip(qs, gaccs):
+                grads += list(ops._ranges_after(c, ga))
+            return (gXq, gXkv, None, None, None, *grads)
         if ctx.qs is None:
             Xq, Xkv, q, heads, stats = ctx.saved_tensors
             kq, vq, qs = Xkv[..., E:2 * E], Xkv[..., 2 * E:], None

@@ -559,6 +559,21 @@ int fqss_mha_prep_fwd(const float* X, float* q, float* k, float* v, int64_t R, i
 int fqss_mha_prep_bwd(const float* X, const float* gq, const float* gk, const float* gv, float* gX, int64_t R, int E,
                       int64_t ld_x, int64_t ld_gx, double scale, const float* const* ranges, double* const* gaccs,
                       fqss_stream_t stream);
+/* fqss_mha_prep_fwd emitting the 8-bit CODES of q (on the division quantizer's grid), k, v ([R][E] u8 each) instead of the
+ * de-quantized values: the operands of the coded attention kernels below */
+int fqss_mha_prep_fwd_c(const float* X, uint8_t* qc, uint8_t* kc, uint8_t* vc, int64_t R, int E, int64_t ld_x, double scale,
+                        const float* const* ranges, fqss_stream_t stream);
+/* softmax(q k^T) v of MultiheadAttentionQ's core (qat_layers.py:878-911) in its quantizing phase, from the CODES of q, k, v
+ * (x = delta c + min of each quantizer; ranges = device scalars {q_min, q_max, k_min, k_max, v_min, v_max}): an integer code is one
+ * exact bf16 plane and terms constant along the softmax axis drop out, so the products need 3 (or 1) MFMAs where the float form
+ * needs 6 (csrc/attn_long.hip).  Same row addressing as fqss_attn_long_fwd / _bwd (strides in elements of each tensor: bytes for
+ * the codes); head_dim 16 / 32 / 64, code rows 8-B aligned.  stats / dsum: as fqss_attn_long_*; the statistics refer to the
+ * logits without their per-query constant.  gq / gk / gv are gradients with respect to the de-quantized values. */
+int fqss_attn_long_fwd_c(const uint8_t* qc, const uint8_t* kc, const uint8_t* vc, const float* const* ranges, float* o, float* stats,
+                         int Lq, int Lk, int B, int nh, int hd, const int64_t* strides, fqss_stream_t stream);
+int fqss_attn_long_bwd_c(const uint8_t* qc, const uint8_t* kc, const uint8_t* vc, const float* const* ranges, const float* o,
+                         const float* go, const float* stats, float* gq, float* gk, float* gv, float* dsum, int Lq, int Lk, int B,
+                         int nh, int hd, const int64_t* strides, fqss_stream_t stream);
 
 /* Recurrence of the bidirectional single-layer LSTM inside LSTMQ (qat_layers.py:571-600, _VF.lstm with zero state).
  *   pre  [S][B][2][4H] = x W_ih^T + b_ih of both directions (fqss_rowlin_fwd), gate order i, f, g, o

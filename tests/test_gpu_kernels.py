@@ -882,6 +882,37 @@ def test_attn_long(Lq, Lk, B, nh, hd, bf):
     close(gv, vr.grad, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("Lq,Lk,B,nh,hd,bf", [(250, 250, 3, 4, 16, False), (300, 517, 2, 2, 64, True), (129, 95, 2, 3, 32, False), (5, 37, 2, 2, 32, True),
+                                              (1, 1, 1, 1, 64, True), (33, 70, 1, 2, 16, True)])
+def test_attn_long_coded(Lq, Lk, B, nh, hd, bf):
+    """the attention core from the 8-bit CODES of q, k, v (fqss_attn_long_fwd_c / _bwd_c) against torch on the de-quantized values:
+    the output, and the gradients with respect to those values"""
+    E = nh * hd
+    shp = lambda L: (B, L, E) if bf else (L, B, E)
+    g = torch.Generator().manual_seed(7)
+    qc, kc, vc = (torch.randint(0, 256, shp(L), generator=g, dtype=torch.uint8) for L in (Lq, Lk, Lk))
+    rng = [(-0.61, 0.73), (-1.3, 0.9), (-0.8, 1.7)]
+    deq = lambda c, lo, hi: (torch.tensor((hi - lo), dtype=torch.float32) / 255.0) * c.float() + lo
+    q, k, v = (deq(c, *r) for c, r in zip((qc, kc, vc), rng))
+    go = rnd(*shp(Lq), seed=4)
+    qr, kr, vr = (t.clone().double().requires_grad_(True) for t in (q, k, v))
+
+    def heads(t, L):
+        t = t if bf else t.transpose(0, 1)
+        return t.reshape(B, L, nh, hd).permute(0, 2, 1, 3)
+    p = torch.softmax(heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2), -1)
+    o = (p @ heads(vr, Lk)).permute(0, 2, 1, 3).reshape(B, Lq, E)
+    o = o if bf else o.transpose(0, 1)
+    o.backward(go.double())
+    ranges = [(torch.tensor([lo], device="cuda"), torch.tensor([hi], device="cuda")) for lo, hi in rng]
+    out, stats = K.attn_long_fwd_c(qc.cuda(), kc.cuda(), vc.cuda(), ranges, nh, bf)
+    close(out, o.float(), rtol=2e-5, atol=2e-5)
+    gq, gk, gv = K.attn_long_bwd_c(qc.cuda(), kc.cuda(), vc.cuda(), ranges, out, go.cuda(), stats, nh, bf)
+    close(gq, qr.grad.float(), rtol=1e-4, atol=2e-5)
+    close(gk, kr.grad.float(), rtol=1e-4, atol=2e-5)
+    close(gv, vr.grad.float(), rtol=1e-4, atol=2e-5)
+
+
 # ---------------------------------------------------------------- HTDemucs small ops and the spectrogram pair (row a15)
 def test_chan_and_col_scale():
     x, s, g = rnd(3, 5, 77, seed=1), rnd(5, seed=2), rnd(3, 5, 77, seed=3)
