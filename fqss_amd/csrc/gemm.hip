@@ -381,7 +381,9 @@ struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
     const float* qmax_x;
     int batch;
     int64_t sAb, sBb, sCb;
+    int imp_taps, imp_dil, imp_pad, imp_len;
 };
+int launch_gemm_x3_imp(const GemmArgs3& g, bool wgrad, hipStream_t s, const char* what);
 int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used);
 int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what);
 }  // namespace fqss
@@ -404,7 +406,7 @@ static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStrea
     if (!x3_enabled()) return FQSS_OK;
     if (batch > 1 && (g.sAb % 4 != 0 || g.sBb % 4 != 0)) return FQSS_OK;      // every batch's operand 16-B aligned
     GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk, nullptr, nullptr, nullptr, nullptr,
-                batch, g.sAb, g.sBb, g.sCb};
+                batch, g.sAb, g.sBb, g.sCb, 0, 0, 0, 0};
     return launch_gemm_x3(h, a_kc, b_kc, atomic, s, what, used);
 }
 
@@ -516,4 +518,58 @@ extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int
     int rc = try_x3(g, false, false, true, (hipStream_t)stream, "fqss_rowlin_bwd_w", &used);
     if (rc != FQSS_OK || used) return rc;
     return launch_gemm(g, false, false, true, 1, (hipStream_t)stream, "fqss_rowlin_bwd_w");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stride-1 1-D convolution (any kernel width / dilation / zero padding, groups = 1) WITHOUT the frame image: the split-bf16 GEMM of
+// csrc/gemm_x3.hip reads its B operand straight from the signal, one shifted row per (channel, tap).  Replaces, for the k = 3
+// convolutions of HTDemucs (DConv and the rewrite convs, hdemucsq.py:72-162, demucsq.py:110-182): fqss_frames_gather + the pointwise GEMM
+// in the forward (the gather wrote 3x the activation and the GEMM read it back), GEMM + fqss_frames_ola in the data gradient (the same
+// entry with the taps flipped and the weight transposed by the caller), GEMM over the saved frames in the weight gradient.
+//   x [B][Ci][M] (row stride ld_x), w [Co][Ci * taps] (row stride ld_w, a multiple of 4), z [B][Co][Mo],  Mo = M + 2 pad - dil (taps - 1)
+//   z[b][co][m] = bias[co] + sum_{ci, t} w[co][ci * taps + t] x[b][ci][m + t dil - pad]
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int fqss_conv1d_s1_fwd(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co, int M, int Mo, int taps,
+                                  int dil, int pad, int64_t ld_x, int64_t ld_w, int64_t ld_z, fqss_stream_t stream) {
+    if (B == 0 || Mo <= 0) return FQSS_OK;
+    FQSS_REQUIRE(x && w && z, "null tensor");
+    FQSS_REQUIRE(B > 0 && Ci > 0 && Co > 0 && M > 0 && taps > 0 && dil > 0 && pad >= 0 && ld_x >= M && ld_z >= Mo, "bad shape");
+    FQSS_REQUIRE(Mo == M + 2 * pad - dil * (taps - 1), "output length does not match the geometry");
+    FQSS_REQUIRE(ld_w % 4 == 0 && ld_w >= rup4((int64_t)Ci * taps) && aligned16(w), "implicit conv: weight rows 16-B aligned, padded to a multiple of 4");
+    GemmArgs3 g{};
+    g.A = w; g.B = x; g.C = z; g.bias = bias; g.bias_col = nullptr;
+    g.M = Co; g.N = Mo; g.K = Ci * taps;
+    g.sAi = ld_w; g.sAk = 1;
+    g.sBk = ld_x; g.sBj = 1;
+    g.sCi = ld_z;
+    g.ksplit = 1; g.kchunk = g.K;
+    g.batch = B; g.sAb = 0; g.sBb = (int64_t)Ci * ld_x; g.sCb = (int64_t)Co * ld_z;
+    g.imp_taps = taps; g.imp_dil = dil; g.imp_pad = pad; g.imp_len = M;
+    return launch_gemm_x3_imp(g, false, (hipStream_t)stream, "fqss_conv1d_s1_fwd");
+}
+
+// gw[co][ci * taps + t] += sum_{b, m} gz[b][co][m] x[b][ci][m + t dil - pad]   (gw: caller-zeroed accumulator, [Co][Ci * taps])
+extern "C" int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, int B, int Ci, int Co, int M, int Mo, int taps, int dil,
+                                    int pad, int64_t ld_gz, int64_t ld_x, fqss_stream_t stream) {
+    if (B == 0 || Mo <= 0) return FQSS_OK;
+    FQSS_REQUIRE(gz && x && gw, "null tensor");
+    FQSS_REQUIRE(B > 0 && Ci > 0 && Co > 0 && M > 0 && taps > 0 && dil > 0 && pad >= 0 && ld_x >= M && ld_gz >= Mo, "bad shape");
+    FQSS_REQUIRE(Mo == M + 2 * pad - dil * (taps - 1), "output length does not match the geometry");
+    FQSS_REQUIRE(aligned16(gz) && ld_gz % 4 == 0 && ld_gz >= rup4(Mo), "implicit conv wgrad: 16-B aligned gradient rows");
+    GemmArgs3 g{};
+    g.A = gz; g.B = x; g.C = gw; g.bias = nullptr; g.bias_col = nullptr;
+    g.M = Co; g.N = Ci * taps; g.K = Mo;
+    g.sAi = ld_gz; g.sAk = 1;
+    g.sBk = 1; g.sBj = ld_x;                  // (B rows = (channel, tap): the implicit loader steps channels by sBj)
+    g.sCi = (int64_t)Ci * taps;
+    const int tiles = (int)(cdiv(Co, BM) * cdiv((int64_t)Ci * taps, BN));
+    int want = (int)cdiv(512, (int64_t)tiles * B);
+    if (want < 1) want = 1;
+    int kchunk = (int)cdiv(cdiv(Mo, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    g.kchunk = kchunk;
+    g.ksplit = (int)cdiv(Mo, kchunk);
+    g.batch = B; g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_x; g.sCb = 0;
+    g.imp_taps = taps; g.imp_dil = dil; g.imp_pad = pad; g.imp_len = M;
+    return launch_gemm_x3_imp(g, true, (hipStream_t)stream, "fqss_conv1d_s1_bwd_w");
 }

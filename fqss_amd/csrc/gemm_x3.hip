@@ -43,6 +43,10 @@ struct GemmArgs3 {
     // launch adds every batch into the same C (sCb = 0: the weight gradient)
     int batch;
     int64_t sAb, sBb, sCb;
+    // implicit B operand of a stride-1 1-D convolution (IMP kernels): the reduction / column index r of B stands for (channel, tap) =
+    // (r / taps, r % taps) and B's element is x[channel][pos + tap * dil - pad], zero outside [0, len) -- the frames of
+    // fqss_frames_gather are never written
+    int imp_taps, imp_dil, imp_pad, imp_len;
 };
 
 constexpr int XBK = 32, XLDK = 40;   // 40 shorts = 80 B row stride (as csrc/teacher.hip: conflict-light 16-B reads)
@@ -134,6 +138,59 @@ struct TileIO {
     }
 };
 
+// Implicit-convolution form of TileIO (see GemmArgs3::imp_*): the same register image, filled by 4-B loads from shifted, clamped
+// positions (a tap's shift breaks the 16-B alignment of the row) with the zero padding applied on the way in.
+//   KC = false (forward / data gradient: B(k, j) = x[k / taps][j + (k % taps) dil - pad]):   k <-> (channel, tap), rows j = positions
+//   KC = true  (weight gradient:         B(k, j) = x[j / taps][k + (j % taps) dil - pad]):   rows j <-> (channel, tap), k = positions
+struct __attribute__((packed, aligned(4))) F4U {      // four floats at a 4-B aligned address: the compiler picks the widest legal load
+    float x, y, z, w;
+};
+// four consecutive positions col0 .. col0+3 of a signal row, zero outside [0, len): one (unaligned) vector load in the interior, clamped
+// scalar loads on the two edges of the row
+__device__ __forceinline__ float4 imp_load4(const float* __restrict__ row, int col0, int len) {
+    if (col0 >= 0 && col0 + 3 < len) {
+        const F4U t = *reinterpret_cast<const F4U*>(row + col0);
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    float e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = col0 + q;
+        const float t = row[min(max(col, 0), len - 1)];
+        e[q] = (col >= 0 && col < len) ? t : 0.f;
+    }
+    return make_float4(e[0], e[1], e[2], e[3]);
+}
+
+template <int ROWS, bool KC>
+struct TileIOI : TileIO<ROWS, KC> {
+    int taps_ = 1, dil_ = 1, pad_ = 0, len_ = 0;
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t sr, int64_t sk, int r0, int nrows, int k0, int kend, int K) {
+        const int tid = threadIdx.x;
+        this->k0_ = k0; this->kend_ = kend; this->r0_ = r0; this->nrows_ = nrows;
+        if constexpr (KC) {
+            const int kmax = ((K + 3) & ~3) - 4;
+#pragma unroll
+            for (int p = 0; p < ROWS / 32; ++p) {
+                const int f = tid + 256 * p, r = f >> 3, k = (f & 7) * 4;
+                const int rc = min(r0 + r, nrows - 1), kc = min(k0 + k, kmax);
+                const int ci = rc / taps_, sh = (rc - ci * taps_) * dil_ - pad_;
+                this->v[p] = imp_load4(base + (int64_t)ci * sr, kc + sh, len_);
+            }
+        } else {
+            const int rb = tid % (ROWS / 4), kb = min(tid / (ROWS / 4), XBK / 4 - 1);
+            const int rmax = ((nrows + 3) & ~3) - 4;
+            const int rc = min(r0 + rb * 4, rmax);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kc = min(k0 + kb * 4 + e, K - 1);
+                const int ci = kc / taps_, sh = (kc - ci * taps_) * dil_ - pad_;
+                this->v[e] = imp_load4(base + (int64_t)ci * sk, rc + sh, len_);
+            }
+        }
+    }
+};
+
 // B tile of 8-bit codes [k][j], j contiguous in memory: a thread owns a 4 (rows j) x 4 (k) block -- four 4-B loads -- and stores ONE
 // bf16 plane (an integer of at most 8 significant bits is exact in bf16)
 template <int ROWS, bool SIGNED>
@@ -178,7 +235,7 @@ struct TileIOQ {
 //   1  wgrad  gw[o][i] += sum_r gz[r][o] x[r][i],  x = dx c + min_x:  A = gz^T, B = activation codes; the epilogue applies
 //             dx * acc + min_x * sum_r gz[r][o] (the k-sums of A's rows accumulate next to the split)
 //   2  dgrad  gx[r][i]  = sum_o gz[r][o] w_q[o][i], w_q = dw[o] wi:   A = gz scaled by dw[k] before the split, B = int8 weight codes
-template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0>
+template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0, bool IMP = false>
 __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     constexpr int BMt = 64 * MI, BNt = 64 * NI;
     __shared__ __attribute__((aligned(16))) unsigned short As[3][128][XLDK];
@@ -197,9 +254,11 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     const int i0 = blockIdx.y * BMt, j0 = blockIdx.x * BNt;
 
     static_assert(BQ == 0 || !B_KC, "coded B tiles are j-contiguous");
+    static_assert(!IMP || BQ == 0, "implicit convolution: float operands");
     TileIO<BMt, A_KC> ta;
-    std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, TileIO<BNt, B_KC>> tb;
+    std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, std::conditional_t<IMP, TileIOI<BNt, B_KC>, TileIO<BNt, B_KC>>> tb;
     if constexpr (BQ == 2) ta.sc_ = g.scale_k;
+    if constexpr (IMP) { tb.taps_ = g.imp_taps; tb.dil_ = g.imp_dil; tb.pad_ = g.imp_pad; tb.len_ = g.imp_len; }
     auto load_b = [&](int k0) {
         if constexpr (BQ != 0) tb.load(g.Bq, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
         else tb.load(g.B, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
@@ -342,6 +401,27 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
     else return FQSS_OK;
 #undef FQSS_X3
     *used = true;
+    return launch_status(what);
+}
+
+// implicit stride-1 convolution forms: forward / data gradient (A = weight [Co][Ci * taps], k contiguous; B implicit, positions
+// contiguous) and weight gradient (A = gz [Co][positions]; B implicit with (channel, tap) rows; split-K + atomics, batches added)
+int launch_gemm_x3_imp(const GemmArgs3& g, bool wgrad, hipStream_t s, const char* what) {
+    if (g.M <= 0 || g.N <= 0) return FQSS_OK;
+    const int64_t zdim = (int64_t)(g.batch > 0 ? g.batch : 1) * (wgrad ? g.ksplit : 1);
+    if (zdim > 65535) { set_error("%s: too many batches x k-slices", what); return FQSS_EINVAL; }
+    int mi = 2, ni = 2;
+    if (g.N <= 64) ni = 1;
+    else if (g.M <= 64) mi = 1;
+    dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
+#define FQSS_X3I(BKc, AT)                                                                                              \
+    do {                                                                                                               \
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 2, 0, true>), grid, block, 0, s, g);  \
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 1, 0, true>), grid, block, 0, s, g);        \
+        else hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 1, 2, 0, true>), grid, block, 0, s, g);                     \
+    } while (0)
+    if (wgrad) FQSS_X3I(true, true); else FQSS_X3I(false, false);
+#undef FQSS_X3I
     return launch_status(what);
 }
 

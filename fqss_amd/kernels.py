@@ -257,6 +257,41 @@ def pwconv_fwd(x, w, bias, six=False):
     return z
 
 
+CONV_IMPLICIT = os.environ.get("FQSS_CONV_IMPLICIT", "1") != "0"
+CONV_IMPLICIT_MAX_CO = int(os.environ.get("FQSS_CONV_IMPLICIT_MAX_CO", "64"))
+
+
+def conv1d_s1_ok(Ci, taps):
+    """stride-1 1-D convolutions run without a frame image (fqss_conv1d_s1_*) when the weight rows are 16-B aligned"""
+    return CONV_IMPLICIT and taps > 1 and (Ci * taps) % 4 == 0
+
+
+def conv1d_s1_fwd(x, w2, bias, taps, dil, pad):
+    """x [B, Ci, M], w2 [Co, Ci * taps] (flattened conv weight; row stride a multiple of 4: a padded view is fine) -> z [B, Co, Mo],
+    Mo = M + 2 pad - dil (taps - 1)"""
+    _need_gpu(x, w2, bias)
+    x, B, Ci, M, ld_x = _bcm(x)
+    Co = w2.shape[0]
+    assert w2.dim() == 2 and w2.shape[1] == Ci * taps and w2.stride(1) == 1
+    if w2.stride(0) % 4 != 0 or w2.data_ptr() % 16 != 0:       # rows to 16 B (a tiny weight: Co x Ci*taps)
+        wp = torch.zeros(Co, (Ci * taps + 3) // 4 * 4, device=w2.device, dtype=torch.float32)
+        wp[:, :Ci * taps] = w2
+        w2 = wp[:, :Ci * taps]
+    Mo = M + 2 * pad - dil * (taps - 1)
+    z = empty_act((B, Co, Mo), x.device)
+    _lib.call("fqss_conv1d_s1_fwd", _p(x), _p(w2), _p(bias), _p(z), B, Ci, Co, M, Mo, taps, dil, pad, ld_x, w2.stride(0), rowmat(z)[2], _stream())
+    return z
+
+
+def conv1d_s1_bwd_w(gz, x, gw, taps, dil, pad):
+    """gw [Co, Ci * taps] (accumulator) += the weight gradient of conv1d_s1_fwd"""
+    _need_gpu(gz, x, gw)
+    gz, B, Co, Mo, ld_gz = _bcm(gz)
+    x, _, Ci, M, ld_x = _bcm(x)
+    assert gw.is_contiguous() and gw.numel() == Co * Ci * taps and Mo == M + 2 * pad - dil * (taps - 1)
+    _lib.call("fqss_conv1d_s1_bwd_w", _p(gz), _p(x), _p(gw), B, Ci, Co, M, Mo, taps, dil, pad, ld_gz, ld_x, _stream())
+
+
 def pwconv_bwd_x(gz, w, Ci):
     _need_gpu(gz, w)
     gz, B, Co, M, ld_gz = _bcm(gz)

@@ -361,17 +361,20 @@ def _plain_or_bwd(z, g, q):
 # ----------------------------------------------------------------------------------------------
 class _Lin:
     """geometry of the linear op in front of the epilogue"""
-    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param", "six")
+    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param", "six", "taps")
 
-    def __init__(self, kind, stride=1, dil=1, pad=0, w_param=None, b_param=None, slope_param=None, six=False):
+    def __init__(self, kind, stride=1, dil=1, pad=0, w_param=None, b_param=None, slope_param=None, six=False, taps=1):
         self.kind, self.stride, self.dil, self.pad = kind, stride, dil, pad
         self.six = six          # "pw": forward on the six-product split GEMM (K.pwconv_fwd)
+        self.taps = taps        # "conv1": stride-1 1-D convolution as an implicit GEMM (K.conv1d_s1_*), weight [Co, Ci * taps, 1]
         self.w_param, self.b_param, self.slope_param = w_param, b_param, slope_param
 
 
 def _lin_fwd(L, x, w, bias):
     if L.kind == "pw":
         return K.pwconv_fwd(x, w, bias, L.six)
+    if L.kind == "conv1":
+        return K.conv1d_s1_fwd(x, w.reshape(w.shape[0], -1), bias, L.taps, L.dil, L.pad)
     if L.kind == "dw":
         return K.dwconv_fwd(x, w, bias, L.dil, L.pad)
     if L.kind == "frames":       # strided framing conv (encoder), no bias in the networks served
@@ -386,6 +389,11 @@ def _lin_fwd(L, x, w, bias):
 def _lin_bwd_x(L, gz, w, x_shape):
     if L.kind == "pw":
         return K.pwconv_bwd_x(gz, w, x_shape[1])
+    if L.kind == "conv1":
+        # the transposed convolution of a stride-1 conv is a stride-1 conv: taps flipped, weight [Ci][Co * taps], pad' = dil (taps - 1) - pad
+        Co, Ci, T = w.shape[0], x_shape[1], L.taps
+        wt = w.reshape(Co, Ci, T).flip(2).permute(1, 0, 2).reshape(Ci, Co * T).contiguous()
+        return K.conv1d_s1_fwd(gz, wt, None, T, L.dil, L.dil * (T - 1) - L.pad)
     if L.kind == "dw":
         return K.dwconv_bwd_x(gz, w, L.dil, L.pad)
     if L.kind == "frames":
@@ -401,6 +409,8 @@ def _lin_bwd_x(L, gz, w, x_shape):
 def _lin_bwd_w(L, gz, x, gw):
     if L.kind == "pw":
         K.pwconv_bwd_w(gz, x, gw)
+    elif L.kind == "conv1":
+        K.conv1d_s1_bwd_w(gz, x, gw, L.taps, L.dil, L.pad)
     elif L.kind == "dw":
         K.dwconv_bwd_w(gz, x, gw, L.dil, L.pad)
     elif L.kind == "frames":

@@ -277,13 +277,19 @@ def conv_frames(conv, x, weight):
     x4 = x.unsqueeze(2) if one_d else x
     B, C, H, W = x4.shape
     Ho, Wo = geom.out_hw(H, W)
+    Co = conv.out_channels
+    L = ops._Lin("pw", b_param=conv.bias, six=True)
     if geom.args() == (1, 1, 1, 1, 0, 0, 1, 1):
         cols = x4.reshape(B, C, H * W)
+    elif one_d and geom.sw == 1 and K.conv1d_s1_ok(C, geom.kw) and geom.dw * (geom.kw - 1) - geom.pw >= 0 and Co <= K.CONV_IMPLICIT_MAX_CO:
+        # stride-1 Conv1d with FEW output channels (DConv's dilated k3 convs, C -> C / 8): implicit GEMM, no frame image
+        # (fqss_conv1d_s1_*).  Measured per shape (tools/conv1_probe.py): forward 1.3-1.9x, data gradient 2-4x faster than gather + GEMM
+        # (+ overlap-add); the wide rewrite convs (C -> 2C) stay on the frame image, whose GEMM kernel is the faster one there
+        cols = x4.reshape(B, C, W)
+        L = ops._Lin("conv1", dil=geom.dw, pad=geom.pw, b_param=conv.bias, taps=geom.kw)
     else:
         cols = ops_dp.FramesGather.apply(x4, geom)
-    Co = conv.out_channels
     ops_dp.touch(weight)
-    L = ops._Lin("pw", b_param=conv.bias, six=True)
     w3 = ops.weight_view(weight, Co, -1, 1)
     z = ops.LinearActQ.apply(cols, w3, conv.bias, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
     z = z.reshape(B, Co, Ho, Wo)

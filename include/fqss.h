@@ -144,6 +144,17 @@ int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float*
  * reference hdemucsq.py:72-162, 261-347) run on it, student and teacher.                          */
 int fqss_pwconv_fwd_x3s(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
                         int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
+/* Stride-1 1-D convolution, any kernel width / dilation / zero padding (groups = 1), as an IMPLICIT GEMM on the bf16 matrix cores
+ * (six-product split, csrc/gemm_x3.hip): the B operand is read straight from the signal, one shifted row per (channel, tap) -- no
+ * frame image.  replaces: nn.Conv1d of the HTDemucs DConv / rewrite layers (hdemucsq.py:72-162, demucsq.py:110-182) and its autograd:
+ *   fwd   z[b][co][m] = bias[co] + sum_{ci,t} w[co][ci*taps + t] x[b][ci][m + t*dil - pad],  Mo = M + 2 pad - dil (taps - 1)
+ *   dgrad the same entry on gz with the caller's flipped / transposed weight [Ci][Co*taps] and pad' = dil (taps - 1) - pad
+ *   wgrad gw[co][ci*taps + t] += sum_{b,m} gz[b][co][m] x[b][ci][m + t*dil - pad]      (gw caller-zeroed)
+ * weight rows (stride ld_w) and gz rows 16-B aligned.                                                                                */
+int fqss_conv1d_s1_fwd(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co, int M, int Mo, int taps,
+                       int dil, int pad, int64_t ld_x, int64_t ld_w, int64_t ld_z, fqss_stream_t stream);
+int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, int B, int Ci, int Co, int M, int Mo, int taps, int dil,
+                         int pad, int64_t ld_gz, int64_t ld_x, fqss_stream_t stream);
 /* gx[b] = W^T * gz[b] */
 int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci, int Co, int M,
                       int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);

@@ -74,6 +74,27 @@ def test_pwconv_exact_integers():
     assert torch.equal(gx.cpu(), torch.einsum("oc,bom->bcm", w[:, :, 0], y))
 
 
+@pytest.mark.parametrize("B,Ci,Co,M,taps,dil,pad", [(2, 48, 6, 1000, 3, 1, 1), (3, 16, 96, 431, 3, 2, 2), (1, 8, 40, 77, 3, 1, 0), (2, 4, 130, 300, 5, 3, 6),
+                                                     (4, 48, 96, 5000, 3, 2, 2), (1, 384, 48, 1723, 3, 1, 1), (2, 12, 7, 33, 3, 2, 4)])
+def test_conv1d_stride1_implicit_gemm(B, Ci, Co, M, taps, dil, pad):
+    """stride-1 Conv1d without a frame image (fqss_conv1d_s1_fwd / _bwd_w, the data gradient as the same entry on the flipped,
+    transposed weight) against F.conv1d and its autograd"""
+    x, w, b = rnd(B, Ci, M, seed=1), rnd(Co, Ci, taps, seed=2, scale=(Ci * taps) ** -0.5), rnd(Co, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv1d(xr, wr, b, padding=pad, dilation=dil)
+    gz = rnd(*y.shape, seed=4)
+    y.backward(gz)
+    for conv in (padded, lambda t: t.cuda()):
+        xd, gzd, wd = conv(x), conv(gz), w.cuda().reshape(Co, Ci * taps)
+        close(K.conv1d_s1_fwd(xd, wd, b.cuda(), taps, dil, pad), y, msg="fwd")
+        wt = w.cuda().flip(2).permute(1, 0, 2).reshape(Ci, Co * taps).contiguous()
+        close(K.conv1d_s1_fwd(gzd, wt, None, taps, dil, dil * (taps - 1) - pad), xr.grad, msg="dgrad")
+        if gzd.stride(-2) % 4 == 0:
+            gw = torch.zeros(Co, Ci * taps, device="cuda")
+            K.conv1d_s1_bwd_w(gzd, xd, gw, taps, dil, pad)
+            close(gw.reshape(Co, Ci, taps), wr.grad, rtol=2e-4, atol=2e-3 * (B * M) ** 0.5 / 30, msg="wgrad")
+
+
 def test_pwconv_split_gemms_against_fp64():
     """the channel-first pointwise GEMMs on the bf16 matrix cores (nine exact products, six products, and the batched k_gemm_x3 forms
     of the two gradients) against fp64: all at the level of an fp32 GEMM (torch's own result measured beside them)"""
