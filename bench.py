@@ -143,8 +143,8 @@ def _time_launches(fn, iters=20):
 
 def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
     """`roofline` of a dual-path workload = the kernel with the largest time per step in the committed steady-state table
-    (profiles/r02_cfg3_step_table.txt: k_lstm_fwd<128>, 18.6 % of the step; profiles/r02_cfg4_step_table.txt: the weight-gradient
-    instance of k_gemm_x3, 14.1 %), timed live at this workload's shape with HIP events on torch's current stream; priced against
+    (profiles/r03_cfg3_step_table.txt: k_lstm_fwd<128>, 24 % of the GPU time; profiles/r03_cfg4_step_table.txt: the coded weight-gradient
+    instance of k_gemm_x3, 15 %), timed live at this workload's shape with HIP events on torch's current stream; priced against
     the fp32 peak (157.3 TFLOP/s: vector = matrix rate for f32) whose arithmetic it performs."""
     from fqss_amd import kernels as K
     if which == "cfg3":
@@ -159,13 +159,20 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
                 "frac": round(tf / 157.3, 3), "traffic": None,
                 "note": "fp32 FMA issue + 2 barriers per time step bound; with 194 / 250 sequences per launch an MFMA form (>= 16 sequences per "
                         "workgroup) leaves < 16 workgroups on 256 CUs and is slower (DESIGN.md 7)"}
-    x, gz = torch.randn(rows, Ci, device="cuda"), torch.randn(rows, Co, device="cuda")
+    # cfg 4 (profiles/r03_cfg4_step_table.txt): the weight gradient of the student's coded linears, k_gemm_x3<false, false, true, 2, 2, 1> --
+    # A = gz^T (fp32, three bf16 pieces), B = the input's u8 codes (one exact plane): three products per k
+    gz = torch.randn(rows, Co, device="cuda")
+    xc = torch.randint(0, 256, (rows, Ci), device="cuda", dtype=torch.uint8)
+    lo, hi = torch.tensor([-1.0], device="cuda"), torch.tensor([1.0], device="cuda")
     gw = torch.zeros(Co, Ci, device="cuda")
-    us = _time_launches(lambda: K.rowlin_bwd_w(gz, x, gw))
+    us = _time_launches(lambda: K.qrow_bwd_w(gz, xc, lo, hi, gw))
     tf = 2.0 * rows * Ci * Co / us * 1e-6
-    return {"kernel": "k_gemm_x3<false, false, true, 1, 2> (fqss_rowlin_bwd_w)", "what": "weight gradient of the " + what, "shape": [rows, Ci, Co],
-            "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 129, "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(tf / 157.3, 3), "traffic": None}
+    return {"kernel": "k_gemm_x3<false, false, true, 2, 2, 1> (fqss_qrow_bwd_w)", "what": "weight gradient of the " + what + " on the input's codes",
+            "shape": [rows, Ci, Co], "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 128, "achieved": round(tf, 1), "peak": 157.3,
+            "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None, "issued_bf16_TFLOPs": round(3 * tf, 1),
+            "frac_of_issued_peak": round(3 * tf / 2500.0, 4),
+            "note": "fp32 arithmetic priced against the fp32 matrix peak; executed as 3 bf16 products per term (issued rate against the 2.5 PF "
+                    "dense bf16 peak beside it); bound by vector-ALU issue of the operand split and by the split-K atomics (DESIGN.md 7e (4))"}
 
 
 def cpu_baseline_dualpath(which, model, fmodel, lr, T):
@@ -271,24 +278,50 @@ def main_dualpath(a):
     comm.close()
 
 
-def attn_roofline(B, nh, L, hd):
-    """the streaming attention core (csrc/attn_long.hip) at the spectrogram branch's self-attention shape: HIP events on torch's
-    current stream; 4 L^2 hd flops per (batch, head); priced against the fp32 MFMA peak its GEMM-shaped arithmetic could reach"""
-    from fqss_amd import kernels as K
-    E = nh * hd
-    q, k, v = (torch.randn(B, L, E, device="cuda") * 0.3 for _ in range(3))
+def _events_us(fn, n=5):
     for _ in range(2):
-        K.attn_long_fwd(q, k, v, nh, True)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
-        K.attn_long_fwd(q, k, v, nh, True)
+    for _ in range(n):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 5 * 1e3
-    tf = 4.0 * L * L * hd * B * nh / us * 1e-6
-    return {"kernel": "k_attn_long_fwd_mfma<%d>" % hd, "what": "self-attention of the spectrogram branch", "shape": [B, nh, L, hd], "bound": "mfma",
-            "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None}
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def htdemucs_roofline(B, nh, L, hd):
+    """cfg 5: the kernel with the largest time per step in the committed table (profiles/r03_cfg5_step_table.txt) is k_qgemm<3, 2>, the
+    six-product pointwise GEMM of the general conv layers (67 launches over ~20 shapes): timed live at its heaviest shape -- the
+    level-0 rewrite conv of the waveform branch, 4 x (48 x 3 -> 96) x 110250 frames -- with HIP events on torch's current stream;
+    the streaming attention core (round 2's roofline kernel) in its two forms beside it"""
+    from fqss_amd import kernels as K
+    Kk, Co, M = 144, 96, 110250
+    f = K.empty_act((B, Kk, M), "cuda")
+    f.normal_()
+    w, b = torch.randn(Co, Kk, 1, device="cuda") * 0.1, torch.zeros(Co, device="cuda")
+    us = _events_us(lambda: K.pwconv_fwd(f, w, b, six=True))
+    tf = 2.0 * B * Co * Kk * M / us * 1e-6
+    by = 4.0 * B * M * (Kk + Co)
+    E = nh * hd
+    q, k, v = (torch.randn(B, L, E, device="cuda") * 0.3 for _ in range(3))
+    ua = _events_us(lambda: K.attn_long_fwd(q, k, v, nh, True))
+    qc, kc, vc = (torch.randint(0, 256, (B, L, E), device="cuda", dtype=torch.uint8) for _ in range(3))
+    rng = [(torch.tensor([-0.9], device="cuda"), torch.tensor([0.8], device="cuda")) for _ in range(3)]
+    uc = _events_us(lambda: K.attn_long_fwd_c(qc, kc, vc, rng, nh, True))
+    ta = 4.0 * L * L * hd * B * nh * 1e-6
+    return {"kernel": "k_qgemm<3, 2> (fqss_pwconv_fwd_x3s)", "what": "pointwise GEMM over the frames of the level-0 rewrite conv (48 x 3 -> 96)",
+            "shape": [B, Kk, Co, M], "bound": "mfma", "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": round(tf / 157.3, 3), "traffic": None, "algorithmic_bytes_per_launch": int(by), "hbm_frac": round(by / us * 1e-3 / 8000.0, 3),
+            "issued_bf16_TFLOPs": round(6 * tf, 1), "frac_of_issued_peak": round(6 * tf / 2500.0, 4),
+            "other_kernels": [
+                {"kernel": "k_attn_long_fwd_x3<%d, false>" % hd, "what": "self-attention of the spectrogram branch, float operands (teacher)",
+                 "shape": [B, nh, L, hd], "launch_us": round(ua, 1), "achieved": round(ta / ua, 1), "frac": round(ta / ua / 157.3, 3),
+                 "issued_bf16_TFLOPs": round(6 * ta / ua, 1)},
+                {"kernel": "k_attn_long_fwd_c<%d>" % hd, "what": "the same on the u8 codes of q, k, v (student)", "shape": [B, nh, L, hd],
+                 "launch_us": round(uc, 1), "achieved": round(ta / uc, 1), "frac": round(ta / uc / 157.3, 3), "issued_bf16_TFLOPs": round(3 * ta / uc, 1)}],
+            "note": "fp32 arithmetic priced against the fp32 matrix peak (the attention exceeds what fp32 MFMA could reach because it runs "
+                    "as exact bf16 pieces); issued bf16 rate against the 2.5 PF dense peak beside it"}
 
 
 def cpu_baseline_htdemucs(model, fmodel, B, T):
@@ -385,7 +418,7 @@ def main_htdemucs(a):
                                       "quantizing phase, bottom_channels 512", "global_batch": comm.world * B, "segment_samples": T,
                           "parallelism": f"dp{comm.world}", "kd_lambda": 0.1, "optimizer": "adam lr 0.0003, no clipping", "launch": launch},
                "loss": round(r["loss"].item(), 6), "params": sum(p.numel() for p in model.parameters()),
-               "roofline": attn_roofline(B, 8, Fr * le, 64)}
+               "roofline": htdemucs_roofline(B, 8, Fr * le, 64)}
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_htdemucs(model, fmodel, B, T)
         print(json.dumps(out), flush=True)
