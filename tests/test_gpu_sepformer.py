@@ -330,3 +330,38 @@ def test_sepformer_batched_quantizer_tables_cover_every_weight():
     from tests.helpers_segments import check_batched_tables
     x, tgt = O.synth_batch(1, 4000, seed=3)
     check_batched_tables(lambda: build_pair(0, tiny=True, **TINY), x.cuda(), tgt.cuda(), 72, step_kw=dict(kd_lambda=0.1, clip=0.0))
+
+
+def test_attention_forms_agree_on_a_quantizing_layer(monkeypatch):
+    """B2-style gate for round 3's attention paths at LAYER level (a whole random-init network turns one flipped 8-bit bin into a 6 %
+    difference of its output -- SURVEY A.4 -- whichever two forms are compared): one MultiheadAttentionQ (64 features, 4 heads: head_dim
+    16; 250 x 40 rows) in its quantizing phase, forward + backward, with the attention core (a) on the u8 CODES of q / k / v
+    (fqss_attn_long_fwd_c / _bwd_c behind fqss_mha_prep_fwd_c), (b) on the de-quantized values through the split-bf16 streaming
+    kernels, (c) through the LDS-resident kernels of csrc/attn.hip: same output, input gradient and parameter gradients up to fp32 noise
+    and the few bins it flips in the layer's own output quantizers."""
+    from fqss_amd import kernels as K
+    from fqss_amd.quantization.qat import qat_layers as QL
+    from fqss_amd.quantization.qat import qat_quant as QQ
+    L, B, E, nh = 250, 40, 64, 4
+    x0, g0 = rnd(L, B, E, seed=1).cuda(), rnd(L, B, E, seed=2).cuda()
+    res = {}
+    for form, (coded, stream) in (("coded", (True, True)), ("split-bf16", (False, True)), ("lds-resident", (False, False))):
+        monkeypatch.setattr(K, "ATTN_CODED", coded)
+        monkeypatch.setattr(K, "ATTN_STREAM", stream)
+        torch.manual_seed(11)
+        layer = QL.MultiheadAttentionQ(nn.MultiheadAttention(E, nh)).cuda().train()
+        with torch.no_grad():
+            layer(x0, x0, x0)                                     # observer call: ranges from the data
+        for m in layer.modules():
+            if isinstance(m, QQ.GradientActivationFakeQuantize):
+                m.n_iter = m.max_observations
+        x = x0.clone().requires_grad_(True)
+        y = layer(x, x, x)[0]
+        y.backward(g0)
+        res[form] = (y.detach().clone(), x.grad.clone(), torch.cat([p.grad.reshape(-1) for p in layer.parameters() if p.grad is not None]))
+        monkeypatch.undo()
+    ref = res["lds-resident"]
+    for form in ("coded", "split-bf16"):
+        e = [float((a - b).norm() / b.norm()) for a, b in zip(res[form], ref)]
+        print(form, "output / input gradient / parameter gradients:", e)
+        assert e[0] <= 2e-3 and e[1] <= 5e-3 and e[2] <= 5e-3, (form, e)
