@@ -119,6 +119,7 @@ _PROTOS = {
     "fqss_bcast_add": [P, P, P, I64, I64, I32, P],
     "fqss_bcast_sum": [P, P, I64, I64, I32, P],
     "fqss_qrow_fwd": [P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, P],
+    "fqss_qrow_fwdq": [P, P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, P, P, P, P],
     "fqss_qrow_bwd_x": [P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_qrow_bwd_w": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_glu_fwd": [P, P, I64, I64, I64, I64, I64, P],

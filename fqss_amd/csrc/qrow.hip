@@ -29,6 +29,14 @@ struct QRowArgs {
     float* z;             // [R][ld_z]
     int64_t R, ld_x, ld_z;
     int Ci, Co;
+    // fused output quantizer (fqss_qrow_fwdq; y null: plain fqss_qrow_fwd): y = fq(act(z)) with the layer's own activation quantizer,
+    // operation for operation what fqss_actq_fwd computes from z -- the separate pass over z disappears
+    float* y;
+    int64_t ld_y;
+    int act;
+    const float* slope;
+    const float* qy_min;
+    const float* qy_max;
 };
 
 // workgroup tile 128 (rows r) x 128 (outputs o), 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32); K in chunks of 64 bytes
@@ -100,6 +108,12 @@ __global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
     // epilogue: rows r = A index, columns o = B index.  z = dw[o] * (dx * S + min_x * R[o]) + b[o],  S = S' + 128 R[o]
     const float lo = *g.qmin, hi = *g.qmax;
     const float dx = (hi - lo) / 255.0f;
+    QRange ry{0.0f, 1.0f, 1.0f};
+    float slope = 0.0f;
+    if (g.y != nullptr) {
+        ry = load_qrange(g.qy_min, g.qy_max);
+        if (g.act == FQSS_ACT_PRELU) slope = *g.slope;
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int o = o0 + wn * 64 + ni * 32 + lr;
@@ -115,6 +129,11 @@ __global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
                     float v = dwo * (dx * S + lo * rwo);
                     if (g.bias) v = v + bo;
                     g.z[row * g.ld_z + o] = v;
+                    if (g.y != nullptr) {
+                        float c, u;
+                        bool inr;
+                        g.y[row * g.ld_y + o] = fq_asym(act_apply(v, g.act, slope), ry, c, u, inr);
+                    }
                 }
             }
     }
@@ -132,8 +151,25 @@ extern "C" int fqss_qrow_fwd(const uint8_t* xc, const int8_t* wk, const float* d
                  "bad shape (Ci a multiple of 16, <= 2048; code rows 16-B aligned)");
     FQSS_REQUIRE(aligned16(xc) && aligned16(wk), "code images must be 16-B aligned");
     if (R == 0) return FQSS_OK;
-    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co};
+    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, nullptr, 0, FQSS_ACT_NONE, nullptr, nullptr, nullptr};
     dim3 grid((unsigned)cdiv(Co, 128), (unsigned)cdiv(R, 128));
     hipLaunchKernelGGL(k_qrow_fwd, grid, dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qrow_fwd");
+}
+
+// fqss_qrow_fwd + the layer's output quantizer in the epilogue: z (kept for the backward's STE) AND y = fq(act(z)) from one launch
+extern "C" int fqss_qrow_fwdq(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias,
+                              const float* qmin_x, const float* qmax_x, float* z, float* y, int64_t R, int Ci, int Co, int64_t ld_x,
+                              int64_t ld_z, int64_t ld_y, int act, const float* slope, const float* qmin_y, const float* qmax_y,
+                              fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && wk && dw && rw && qmin_x && qmax_x && z && y && qmin_y && qmax_y, "null tensor");
+    FQSS_REQUIRE(R >= 0 && Ci >= 16 && Ci % 16 == 0 && Ci <= 2048 && Co > 0 && ld_x >= Ci && ld_x % 16 == 0 && ld_z >= Co && ld_y >= Co,
+                 "bad shape (Ci a multiple of 16, <= 2048; code rows 16-B aligned)");
+    FQSS_REQUIRE(aligned16(xc) && aligned16(wk), "code images must be 16-B aligned");
+    FQSS_REQUIRE(act == FQSS_ACT_NONE || act == FQSS_ACT_RELU || (act == FQSS_ACT_PRELU && slope), "activation: none, ReLU or PReLU (with its slope)");
+    if (R == 0) return FQSS_OK;
+    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, y, ld_y, act, slope, qmin_y, qmax_y};
+    dim3 grid((unsigned)cdiv(Co, 128), (unsigned)cdiv(R, 128));
+    hipLaunchKernelGGL(k_qrow_fwd, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_qrow_fwdq");
 }

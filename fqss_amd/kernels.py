@@ -1445,6 +1445,19 @@ def qrow_fwd(xc, wc, bias, qmin_x, qmax_x, out=None):
     return z
 
 
+def qrow_fwdq(xc, wc, bias, qmin_x, qmax_x, act, slope, qmin_y, qmax_y):
+    """qrow_fwd with the layer's output quantizer in the GEMM epilogue -> (z, y = fq(act(z))), both [..., Co] fp32"""
+    Ci, Co = wc.Ci, wc.Co
+    assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci
+    rm = rowmat(xc)
+    assert rm is not None and rm[1] == Ci and rm[2] % 16 == 0, "activation codes need 16-B aligned rows"
+    z = torch.empty(*xc.shape[:-1], Co, device=xc.device, dtype=torch.float32)
+    y = torch.empty_like(z)
+    _lib.call("fqss_qrow_fwdq", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias), _p(qmin_x), _p(qmax_x), _p(z), _p(y), rm[0], Ci, Co, rm[2],
+              Co, Co, act, _p(slope), _p(qmin_y), _p(qmax_y), _stream())
+    return z, y
+
+
 def qrow_bwd_ok(Ci, Co):
     return Ci % 4 == 0 and Co % 4 == 0
 

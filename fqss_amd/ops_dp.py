@@ -105,8 +105,13 @@ class RowLinearActQ(Function):
     @staticmethod
     def forward(ctx, x, w, bias, slope, qmin, qmax, act, q, qops, slope_param, flat):
         touch(w, bias)
-        z = K.qrow_fwd(qops[0].idx, qops[1], bias, qops[0].qmin, qops[0].qmax) if qops is not None else K.rowlin_fwd(x, w, bias)
-        y = ops._epilogue_fwd(z.view(flat) if flat is not None else z, act, slope, q).view(z.shape)     # long rows for the streaming pass
+        if qops is not None and FUSE_QROWQ and q.qmode == ops.Q_QUANT and q.no_codes:
+            # the output quantizer rides in the int8 GEMM's epilogue: no pass over z (fqss_qrow_fwdq)
+            z, y = K.qrow_fwdq(qops[0].idx, qops[1], bias, qops[0].qmin, qops[0].qmax, act, slope, q.qmin, q.qmax)
+            q.carrier = False
+        else:
+            z = K.qrow_fwd(qops[0].idx, qops[1], bias, qops[0].qmin, qops[0].qmax) if qops is not None else K.rowlin_fwd(x, w, bias)
+            y = ops._epilogue_fwd(z.view(flat) if flat is not None else z, act, slope, q).view(z.shape)     # long rows for the streaming pass
         ctx.save_for_backward(x, w, z, slope)
         ctx.bias, ctx.q, ctx.act, ctx.sp = bias, q, act, slope_param
         ctx.xq = qops[0] if qops is not None else None
@@ -125,6 +130,7 @@ class RowLinearActQ(Function):
 
 
 QROW = __import__("os").environ.get("FQSS_QROW", "1") != "0"    # student linears on codes (csrc/qrow.hip); 0: fp32-equivalent GEMM
+FUSE_QROWQ = __import__("os").environ.get("FQSS_FUSE_QROWQ", "1") != "0"    # their output quantizer in the GEMM epilogue (fqss_qrow_fwdq)
 
 
 def qrow_operands(x, w):

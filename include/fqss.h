@@ -626,6 +626,13 @@ int fqss_bcast_sum(const float* g, float* out, int64_t L, int64_t Bp, int C, fqs
 int fqss_qrow_fwd(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias,
                   const float* qmin_x, const float* qmax_x, float* z, int64_t R, int Ci, int Co, int64_t ld_x,
                   int64_t ld_z, fqss_stream_t stream);
+/* fqss_qrow_fwd with the layer's OUTPUT quantizer in the epilogue: z (kept for the backward) and y = fq(act(z)) -- what
+ * fqss_actq_fwd(z, QUANT) computes -- from one launch.  LinearQ / LinearNlQ / the attention output projection in the quantizing
+ * phase (qat_layers.py:521-561, 941-950). */
+int fqss_qrow_fwdq(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias,
+                   const float* qmin_x, const float* qmax_x, float* z, float* y, int64_t R, int Ci, int Co, int64_t ld_x,
+                   int64_t ld_z, int64_t ld_y, int act, const float* slope, const float* qmin_y, const float* qmax_y,
+                   fqss_stream_t stream);
 /* the gradient GEMMs of such a linear on the same codes (csrc/gemm_x3.hip, coded-B forms): the 8-bit operand is one exact bf16 plane,
  * three MFMA products per k instead of the six of the fp32 x fp32 form.
  *   fqss_qrow_bwd_x: gx[r][i]  = sum_o gz[r][o] * (dw[o] * wi[o][i])       wi int8 [Co][Ci] dense

@@ -722,6 +722,13 @@ def test_qrow_kernel_exact_integer_sums(R, Ci, Co):
     x = dx.cuda() * xc.float() + lo
     wq = wc.dw[:, None] * wc.idx.float()
     close(z, K.rowlin_fwd(x, wq.contiguous(), b), 2e-5)
+    # the output quantizer in the GEMM epilogue (fqss_qrow_fwdq) = fqss_qrow_fwd + fqss_actq_fwd, bit for bit
+    from fqss_amd import ops
+    qlo, qhi, slope = torch.tensor([-0.7], device="cuda"), torch.tensor([1.9], device="cuda"), torch.tensor([0.2], device="cuda")
+    for act, sl in ((ops.ACT_NONE, None), (ops.ACT_RELU, None), (ops.ACT_PRELU, slope)):
+        z2, y2 = K.qrow_fwdq(xc, wc, b, lo, hi, act, sl, qlo, qhi)
+        assert torch.equal(z2, z)
+        assert torch.equal(y2, K.actq_fwd(z, act, sl, ops.Q_QUANT, qlo, qhi, None)), act
 
 
 def test_coded_row_linear_gradients_do_not_read_carriers(monkeypatch):
