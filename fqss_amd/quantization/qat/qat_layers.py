@@ -657,9 +657,14 @@ def fq_node(aq, x, nl=None, codes=False, q=None):
     """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl.
     codes=True: also emit the u8 codes and tag the result with them (the consumer is a row linear that can run on codes);
     q: the quantizer's context when the caller already drew it (aq.qctx() advances the observer's call count)"""
-    if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
+    gelu = FUSE_GELUQ and ops.CODED and isinstance(nl, nn.GELU) and getattr(nl, "approximate", "none") == "none"
+    if gelu:
+        nl = None             # GELU rides in the quantizer's own pass each way (act = ACT_GELU: fqss_actq_fwd / _bwd)
+    elif isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
         x, nl = apply_map(nl, ops.real(x)), None
     act, slope = _act_of(nl)
+    if gelu:
+        act = K.ACT_GELU
     if q is None:
         q = aq.qctx() if aq is not None else ops.BYPASS
     if q.qmode == ops.Q_BYPASS and act == ops.ACT_NONE:
@@ -682,6 +687,7 @@ def fq_node(aq, x, nl=None, codes=False, q=None):
     return y
 
 
+FUSE_GELUQ = __import__("os").environ.get("FQSS_FUSE_GELUQ", "1") != "0"   # 0: GELU as its own pass in front of the quantizer (A/B, tests)
 FUSE_ROWQ = __import__("os").environ.get("FQSS_FUSE_ROWQ", "1") != "0"    # 0: row linear, quantizer and bias sums as separate nodes (A/B, tests)
 
 

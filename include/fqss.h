@@ -44,6 +44,7 @@ extern "C" {
 #define FQSS_ACT_NONE 0
 #define FQSS_ACT_PRELU 1 /* one shared slope, nn.PReLU() */
 #define FQSS_ACT_RELU 2
+#define FQSS_ACT_GELU 3 /* nn.GELU(), erf form: fqss_actq_fwd / fqss_actq_bwd only (the HTDemucs layers) */
 
 typedef void* fqss_stream_t;
 

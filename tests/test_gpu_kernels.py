@@ -95,6 +95,33 @@ def test_conv1d_stride1_implicit_gemm(B, Ci, Co, M, taps, dil, pad):
             close(gw.reshape(Co, Ci, taps), wr.grad, rtol=2e-4, atol=2e-3 * (B * M) ** 0.5 / 30, msg="wgrad")
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 1000), (5, 4099), (2048, 64)])
+def test_gelu_in_the_quantizer_pass(rows, cols):
+    """act = ACT_GELU: fq(GELU(z)) and its backward in ONE pass each way = the GELU map (k_unary_fwd / _bwd) followed by the quantizer
+    pass, bit for bit; all three quantizer modes"""
+    from fqss_amd import ops
+    z, g = rnd(rows, cols, seed=1, scale=1.5).cuda(), rnd(rows, cols, seed=2).cuda()
+    lo, hi = torch.tensor([-0.15], device="cuda"), torch.tensor([2.2], device="cuda")
+    t = K.unary_fwd(z, K.UNARY_GELU)
+    for qmode in (ops.Q_QUANT, ops.Q_BYPASS):
+        y = K.actq_fwd(z, K.ACT_GELU, None, qmode, lo, hi, None)
+        assert torch.equal(y, K.actq_fwd(t, K.ACT_NONE, None, qmode, lo, hi, None)), qmode
+        ga, gb = (torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda") for _ in range(2))
+        gz = K.actq_bwd(z, g, K.ACT_GELU, None, qmode, lo, hi, ga)
+        gt = K.actq_bwd(t, g, K.ACT_NONE, None, qmode, lo, hi, gb)
+        assert torch.equal(gz, K.unary_bwd(gt, z, K.UNARY_GELU))
+        if qmode == ops.Q_QUANT:
+            gmn, gmx, hmn, hmx = (torch.zeros(1, device="cuda") for _ in range(4))
+            K.gacc_flush(ga, gmn, gmx, None)
+            K.gacc_flush(gb, hmn, hmx, None)
+            close(gmn, hmn, rtol=1e-6, atol=1e-6)
+            close(gmx, hmx, rtol=1e-6, atol=1e-6)
+    obs_a, obs_b = (torch.tensor([-1, 0], dtype=torch.int32, device="cuda") for _ in range(2))
+    K.actq_fwd(z, K.ACT_GELU, None, ops.Q_OBSERVE, lo, hi, obs_a)
+    K.actq_fwd(t, K.ACT_NONE, None, ops.Q_OBSERVE, lo, hi, obs_b)
+    assert torch.equal(obs_a, obs_b)
+
+
 def test_pwconv_split_gemms_against_fp64():
     """the channel-first pointwise GEMMs on the bf16 matrix cores (nine exact products, six products, and the batched k_gemm_x3 forms
     of the two gradients) against fp64: all at the level of an fp32 GEMM (torch's own result measured beside them)"""
