@@ -1,5 +1,5 @@
-"""which ATen element-wise / copy ops does one HTDemucs (cfg 5) quantizing step still issue, and from where?  torch.profiler on the CPU side
-(op name, input shapes, innermost fqss_amd frame).  Dev tool (GPU box): python tools/aten_probe.py"""
+"""which ATen copies / fills / adds on large tensors does one HTDemucs (cfg 5) quantizing step still issue, and from where?  The tensor
+methods that launch them are wrapped and the innermost fqss_amd frames recorded.  Dev tool (GPU box): python tools/aten_probe.py"""
 import collections
 import copy
 import os
@@ -34,24 +34,32 @@ def main():
     step(mix, src)
     step(mix, src)
     torch.cuda.synchronize()
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU], record_shapes=True, with_stack=True) as prof:
-        step(mix, src)
-        torch.cuda.synchronize()
-    seen = collections.Counter()
-    numel = collections.Counter()
-    for ev in prof.events():
-        if not ev.name.startswith("aten::") or ev.name in ("aten::empty", "aten::empty_like", "aten::empty_strided", "aten::view", "aten::reshape",
-                                                           "aten::as_strided", "aten::slice", "aten::select", "aten::unsqueeze", "aten::squeeze",
-                                                           "aten::permute", "aten::transpose", "aten::t", "aten::expand", "aten::detach", "aten::alias",
-                                                           "aten::_unsafe_view", "aten::narrow", "aten::resize_", "aten::result_type", "aten::to",
-                                                           "aten::item", "aten::_local_scalar_dense", "aten::is_nonzero", "aten::lift_fresh", "aten::flatten",
-                                                           "aten::unflatten", "aten::chunk", "aten::split", "aten::unbind", "aten::view_as", "aten::contiguous"):
-            continue
-        frame = next((s for s in ev.stack if "fqss_amd" in s and "autograd/function" not in s), "?")
-        shapes = str([s for s in (ev.input_shapes or []) if s][:2])
-        key = (ev.name, frame.split("fqss_amd/")[-1][:70], shapes[:60])
-        seen[key] += 1
-    for k, v in seen.most_common(60):
+    # Python-level call sites of the big copies: wrap the tensor methods that launch them
+    import traceback
+    sites = collections.Counter()
+
+    def wrap(owner, name):
+        real = getattr(owner, name)
+
+        def f(*a, **k):
+            t = a[0] if a and isinstance(a[0], torch.Tensor) else None
+            if name == "cat":
+                t = a[0][0]
+            if t is not None and t.is_cuda and t.numel() >= (1 << 20) and not (name == "contiguous" and t.is_contiguous()):
+                fr = [x for x in traceback.extract_stack()[:-1] if "fqss_amd" in x.filename]
+                where = " <- ".join(f"{os.path.basename(x.filename)}:{x.lineno}" for x in fr[-3:])
+                sites[(name, tuple(t.shape), where)] += 1
+            return real(*a, **k)
+        setattr(owner, name, f)
+    for nm in ("contiguous", "clone", "copy_", "zero_", "fill_", "add_", "add", "mul", "sub", "__add__", "__mul__", "__sub__", "__iadd__"):
+        wrap(torch.Tensor, nm)
+    for nm in ("cat", "zeros_like", "zeros", "stack"):
+        wrap(torch, nm)
+    import torch.nn.functional as F
+    wrap(F, "pad")
+    step(mix, src)
+    torch.cuda.synchronize()
+    for k, v in sites.most_common(70):
         print(v, k)
 
 
