@@ -87,6 +87,7 @@ _PROTOS = {
     "fqss_sumsq": [P, I64, P, P],
     "fqss_adam_clip": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, F32, P, P, P, P],
     "fqss_rowlin_fwd": [P, P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_rowlin_fwd_w3": [P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_rowlin_bwd_x": [P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_rowlin_bwd_w": [P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_colsum": [P, P, I64, I32, I64, P],

@@ -382,6 +382,9 @@ struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
     int batch;
     int64_t sAb, sBb, sCb;
     int imp_taps, imp_dil, imp_pad, imp_len;
+    const unsigned short* Bp;
+    int64_t ldp;
+    int scalar_stores;
 };
 int launch_gemm_x3_imp(const GemmArgs3& g, bool wgrad, hipStream_t s, const char* what);
 int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used);
@@ -406,7 +409,7 @@ static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStrea
     if (!x3_enabled()) return FQSS_OK;
     if (batch > 1 && (g.sAb % 4 != 0 || g.sBb % 4 != 0)) return FQSS_OK;      // every batch's operand 16-B aligned
     GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk, nullptr, nullptr, nullptr, nullptr,
-                batch, g.sAb, g.sBb, g.sCb, 0, 0, 0, 0};
+                batch, g.sAb, g.sBb, g.sCb, 0, 0, 0, 0, nullptr, 0, 0};
     return launch_gemm_x3(h, a_kc, b_kc, atomic, s, what, used);
 }
 
@@ -572,4 +575,30 @@ extern "C" int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, 
     g.batch = B; g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_x; g.sCb = 0;
     g.imp_taps = taps; g.imp_dil = dil; g.imp_pad = pad; g.imp_len = M;
     return launch_gemm_x3_imp(g, true, (hipStream_t)stream, "fqss_conv1d_s1_bwd_w");
+}
+
+// fqss_rowlin_fwd with the weight given as its three exact bf16 planes [3][Co][Ci] (fqss_split3_planes): the weight tile is copied into
+// LDS instead of being split by every workgroup that touches it -- for weights that do not change between launches (the frozen float
+// teacher: its row GEMMs are bound by the vector-ALU issue of that split).  Same result bits as fqss_rowlin_fwd.
+extern "C" int fqss_rowlin_fwd_w3(const float* x, const uint16_t* w3, const float* bias, float* z, int64_t R, int Ci, int Co, int64_t ld_x,
+                                  int64_t ld_z, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && w3 && z, "null tensor");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_x >= Ci && ld_z >= Co, "bad shape");
+    FQSS_REQUIRE(Ci % 32 == 0 && aligned16(w3) && aligned16(x) && ld_x % 4 == 0, "pre-split weight: Ci a multiple of 32, 16-B aligned rows");
+    if (R == 0) return FQSS_OK;
+    GemmArgs3 g{};
+    g.A = x; g.B = nullptr; g.C = z; g.bias = nullptr; g.bias_col = bias;
+    g.M = (int)R; g.N = Co; g.K = Ci;
+    g.sAi = ld_x; g.sAk = 1;
+    g.sBk = 1; g.sBj = Ci;
+    g.sCi = ld_z;
+    g.ksplit = 1; g.kchunk = Ci;
+    g.batch = 1;
+    g.Bp = w3; g.ldp = Ci;
+    g.B = x;            // (alignment checks of the shared launcher: B is not read)
+    bool used = false;
+    int rc = launch_gemm_x3(g, true, true, false, (hipStream_t)stream, "fqss_rowlin_fwd_w3", &used);
+    if (rc != FQSS_OK) return rc;
+    if (!used) { set_error("fqss_rowlin_fwd_w3: operands not eligible for the split-bf16 GEMM"); return FQSS_EINVAL; }
+    return FQSS_OK;
 }

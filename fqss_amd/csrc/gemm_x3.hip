@@ -47,6 +47,11 @@ struct GemmArgs3 {
     // (r / taps, r % taps) and B's element is x[channel][pos + tap * dil - pad], zero outside [0, len) -- the frames of
     // fqss_frames_gather are never written
     int imp_taps, imp_dil, imp_pad, imp_len;
+    // B operand already split (BPL kernels): three bf16 planes [3][N][ldp] of a [N][K] k-contiguous matrix (fqss_split3_planes of a
+    // weight that does not change between launches: the frozen teacher's linears) -- the tile is copied, not split
+    const unsigned short* Bp;
+    int64_t ldp;
+    int scalar_stores;       // 1: the lane-per-column epilogue (FQSS_X3_STAGED=0, A/B measurements)
 };
 
 constexpr int XBK = 32, XLDK = 40;   // 40 shorts = 80 B row stride (as csrc/teacher.hip: conflict-light 16-B reads)
@@ -142,6 +147,31 @@ struct TileIO {
 // positions (a tap's shift breaks the 16-B alignment of the row) with the zero padding applied on the way in.
 //   KC = false (forward / data gradient: B(k, j) = x[k / taps][j + (k % taps) dil - pad]):   k <-> (channel, tap), rows j = positions
 //   KC = true  (weight gradient:         B(k, j) = x[j / taps][k + (j % taps) dil - pad]):   rows j <-> (channel, tap), k = positions
+// B tile from pre-split planes (see GemmArgs3::Bp): a thread copies 16-B chunks (8 k of one row and plane) global -> registers -> LDS;
+// K % 32 == 0, rows clamped on load and zeroed on store
+template <int ROWS>
+struct TileIOP {
+    static constexpr int NCH = 3 * ROWS * (XBK / 8) / 256;     // chunks per thread: 6 (128 rows) or 3 (64)
+    uint4 v[NCH];
+    int r0_, nrows_;
+    __device__ __forceinline__ void load(const unsigned short* __restrict__ planes, int64_t plane_stride, int64_t ldp, int r0, int nrows, int k0, int K) {
+        r0_ = r0; nrows_ = nrows;
+        const int kb = min(k0, K - XBK);
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int f = threadIdx.x + 256 * u, p = f / (ROWS * 4), rem = f % (ROWS * 4), r = rem >> 2, c = rem & 3;
+            v[u] = *reinterpret_cast<const uint4*>(planes + p * plane_stride + (int64_t)min(r0 + r, nrows - 1) * ldp + kb + 8 * c);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) const {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int f = threadIdx.x + 256 * u, p = f / (ROWS * 4), rem = f % (ROWS * 4), r = rem >> 2, c = rem & 3;
+            *reinterpret_cast<uint4*>(&pl[p][r][8 * c]) = (r0_ + r < nrows_) ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+};
+
 struct __attribute__((packed, aligned(4))) F4U {      // four floats at a 4-B aligned address: the compiler picks the widest legal load
     float x, y, z, w;
 };
@@ -235,7 +265,7 @@ struct TileIOQ {
 //   1  wgrad  gw[o][i] += sum_r gz[r][o] x[r][i],  x = dx c + min_x:  A = gz^T, B = activation codes; the epilogue applies
 //             dx * acc + min_x * sum_r gz[r][o] (the k-sums of A's rows accumulate next to the split)
 //   2  dgrad  gx[r][i]  = sum_o gz[r][o] w_q[o][i], w_q = dw[o] wi:   A = gz scaled by dw[k] before the split, B = int8 weight codes
-template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0, bool IMP = false>
+template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0, bool IMP = false, bool BPL = false>
 __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     constexpr int BMt = 64 * MI, BNt = 64 * NI;
     __shared__ __attribute__((aligned(16))) unsigned short As[3][128][XLDK];
@@ -256,11 +286,14 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     static_assert(BQ == 0 || !B_KC, "coded B tiles are j-contiguous");
     static_assert(!IMP || BQ == 0, "implicit convolution: float operands");
     TileIO<BMt, A_KC> ta;
-    std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, std::conditional_t<IMP, TileIOI<BNt, B_KC>, TileIO<BNt, B_KC>>> tb;
+    static_assert(!BPL || (BQ == 0 && !IMP && B_KC && !ATOMIC), "pre-split B: the forward form");
+    std::conditional_t<BPL, TileIOP<BNt>,
+                       std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, std::conditional_t<IMP, TileIOI<BNt, B_KC>, TileIO<BNt, B_KC>>>> tb;
     if constexpr (BQ == 2) ta.sc_ = g.scale_k;
     if constexpr (IMP) { tb.taps_ = g.imp_taps; tb.dil_ = g.imp_dil; tb.pad_ = g.imp_pad; tb.len_ = g.imp_len; }
     auto load_b = [&](int k0) {
-        if constexpr (BQ != 0) tb.load(g.Bq, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
+        if constexpr (BPL) tb.load(g.Bp, (int64_t)g.N * g.ldp, g.ldp, j0, g.N, k0, g.K);
+        else if constexpr (BQ != 0) tb.load(g.Bq, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
         else tb.load(g.B, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
     };
     __shared__ float rsum_s[(BQ == 1) ? 128 : 1];
@@ -336,6 +369,57 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
         mnx = lo;
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if constexpr (!ATOMIC) {
+        // plain stores: each 32 x 32 accumulator tile goes through a wave-private LDS tile and leaves as whole 128-B rows, 16 B per lane
+        // (the lane-per-column layout needs 16 strided 4-B stores per tile: that store-issue-bound tail was most of this kernel's time at
+        // the skinny reductions of the dual-path linears, K = 256: 8 k-tiles of MFMAs against 64 scalar stores per thread).  Needs
+        // 16-B aligned output rows; the scalar path below serves everything else.
+        if (!g.scalar_stores && (g.sCi & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0) {
+            constexpr int TLD = 36;                                    // floats per staged row (16-B aligned, conflict-light)
+            static_assert(4 * 32 * TLD * 4 <= (int)sizeof(As), "staging tiles fit the A planes");
+            float(*Tt)[TLD] = reinterpret_cast<float(*)[TLD]>(reinterpret_cast<float*>(&As[0][0][0]) + wave * 32 * TLD);
+            const int c4 = (lane & 7) * 4, rq = lane >> 3;            // a lane moves 4 columns of rows rq, rq + 8, rq + 16, rq + 24
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    // (a 32 x 32 tile wholly outside the matrix -- the narrow outputs of the implicit convolutions -- stores nothing)
+                    if (i0 + wm * (32 * MI) + mi * 32 >= g.M || j0 + wn * (32 * NI) + ni * 32 >= g.N) continue;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Tt[(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[mi][ni][r];
+                    __builtin_amdgcn_wave_barrier();
+                    const int col = j0 + wn * (32 * NI) + ni * 32 + c4;
+                    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.bias_col != nullptr && col + 3 < g.N) bc = *reinterpret_cast<const float4*>(g.bias_col + col);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rl = rq + 8 * it, row = i0 + wm * (32 * MI) + mi * 32 + rl;
+                        float4 v = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
+                        if (row < g.M) {
+                            const float br = g.bias != nullptr ? g.bias[row] : 0.f;
+                            float* dst = g.C + (int64_t)row * g.sCi + col;
+                            if (col + 3 < g.N) {
+                                if (g.bias != nullptr) { v.x = v.x + br; v.y = v.y + br; v.z = v.z + br; v.w = v.w + br; }
+                                if (g.bias_col != nullptr) { v.x = v.x + bc.x; v.y = v.y + bc.y; v.z = v.z + bc.z; v.w = v.w + bc.w; }
+                                *reinterpret_cast<float4*>(dst) = v;
+                            } else {
+                                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    if (col + q < g.N) {
+                                        float t = e[q];
+                                        if (g.bias != nullptr) t = t + br;
+                                        if (g.bias_col != nullptr) t = t + g.bias_col[col + q];
+                                        dst[q] = t;
+                                    }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -369,7 +453,14 @@ static bool x3_ok(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic) {
     return ok;
 }
 
-int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used) {
+static int x3_scalar_stores() {
+    static const int v = [] { const char* e = getenv("FQSS_X3_STAGED"); return (e && e[0] == '0') ? 1 : 0; }();
+    return v;
+}
+
+int launch_gemm_x3(const GemmArgs3& g_in, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used) {
+    GemmArgs3 g = g_in;
+    g.scalar_stores = x3_scalar_stores();
     *used = false;
     if (g.M <= 0 || g.N <= 0) return FQSS_OK;
     if (!x3_ok(g, a_kc, b_kc, atomic)) return FQSS_OK;     // caller falls back to k_gemm_f32
@@ -393,7 +484,11 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
         else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 1>), grid, block, 0, s, g);          \
         else hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 1, 2>), grid, block, 0, s, g);                       \
     } while (0)
-    if (!atomic && a_kc && b_kc) FQSS_X3(true, true, false);          // fwd:   x [R][Ci], w [Co][Ci]
+    if (!atomic && a_kc && b_kc && g.Bp != nullptr) {                  // fwd on the weight's pre-split planes
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, true, false, 2, 2, 0, false, true>), grid, block, 0, s, g);
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, true, false, 2, 1, 0, false, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_x3<true, true, false, 1, 2, 0, false, true>), grid, block, 0, s, g);
+    } else if (!atomic && a_kc && b_kc) FQSS_X3(true, true, false);   // fwd:   x [R][Ci], w [Co][Ci]
     else if (!atomic && a_kc && !b_kc) FQSS_X3(true, false, false);   // dgrad: gz [R][Co], w [Co][Ci] (j contiguous)
     else if (atomic && !a_kc && !b_kc) FQSS_X3(false, false, true);   // wgrad: gz^T, x (both row-index contiguous)
     else if (!atomic && !a_kc && !b_kc) FQSS_X3(false, false, false); // channel-first dgrad: W^T (i contiguous), gz [Co][M]
@@ -406,7 +501,9 @@ int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStr
 
 // implicit stride-1 convolution forms: forward / data gradient (A = weight [Co][Ci * taps], k contiguous; B implicit, positions
 // contiguous) and weight gradient (A = gz [Co][positions]; B implicit with (channel, tap) rows; split-K + atomics, batches added)
-int launch_gemm_x3_imp(const GemmArgs3& g, bool wgrad, hipStream_t s, const char* what) {
+int launch_gemm_x3_imp(const GemmArgs3& g_in, bool wgrad, hipStream_t s, const char* what) {
+    GemmArgs3 g = g_in;
+    g.scalar_stores = x3_scalar_stores();
     if (g.M <= 0 || g.N <= 0) return FQSS_OK;
     const int64_t zdim = (int64_t)(g.batch > 0 ? g.batch : 1) * (wgrad ? g.ksplit : 1);
     if (zdim > 65535) { set_error("%s: too many batches x k-slices", what); return FQSS_EINVAL; }
@@ -426,7 +523,9 @@ int launch_gemm_x3_imp(const GemmArgs3& g, bool wgrad, hipStream_t s, const char
 }
 
 // coded-B forms (BQ = 1 wgrad, 2 dgrad); the caller has checked shapes and alignment
-int launch_gemm_x3q(const GemmArgs3& g, int bq, hipStream_t s, const char* what) {
+int launch_gemm_x3q(const GemmArgs3& g_in, int bq, hipStream_t s, const char* what) {
+    GemmArgs3 g = g_in;
+    g.scalar_stores = x3_scalar_stores();
     if (g.M <= 0 || g.N <= 0) return FQSS_OK;
     const bool atomic = bq == 1;
     const int64_t zdim = atomic ? g.ksplit : 1;

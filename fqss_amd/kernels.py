@@ -1010,8 +1010,32 @@ def rowlin_fwd(x, w, bias, out=None):
     z = torch.empty(*x.shape[:-1], Co, device=x.device, dtype=torch.float32) if out is None else out
     zz, Rz, ld_z = _rows(z, Co)
     assert zz is z and Rz == R, "rowlin_fwd: `out` must be a row-matrix view"
-    _lib.call("fqss_rowlin_fwd", _p(x), _p(w), _p(bias), _p(z), R, Ci, Co, ld_x, w.stride(0), ld_z, _stream())
+    w3 = _frozen_weight_planes(w, Ci, x, ld_x)
+    if w3 is not None:
+        _lib.call("fqss_rowlin_fwd_w3", _p(x), _p(w3), _p(bias), _p(z), R, Ci, Co, ld_x, ld_z, _stream())
+    else:
+        _lib.call("fqss_rowlin_fwd", _p(x), _p(w), _p(bias), _p(z), R, Ci, Co, ld_x, w.stride(0), ld_z, _stream())
     return z
+
+
+W3_CACHE = os.environ.get("FQSS_W3_CACHE", "0") != "0"    # opt-in: measured neutral, the default stays the on-the-fly split
+
+
+def _frozen_weight_planes(w, Ci, x, ld_x):
+    """the three exact bf16 planes of a FROZEN weight (a parameter used under torch.no_grad(): the float teacher's linears), split once
+    and kept on the tensor until it is written to (`_version`): fqss_rowlin_fwd_w3 copies the weight tile instead of splitting it in
+    every workgroup; None for every other weight (the student's fake-quantized weights are new tensors every step)"""
+    if not W3_CACHE or _lib.BACKEND == "cpu" or torch.is_grad_enabled() or not isinstance(w, torch.nn.Parameter) or not w.is_contiguous():
+        return None
+    if Ci % 32 != 0 or ld_x % 4 != 0 or x.data_ptr() % 16 != 0:
+        return None
+    c = getattr(w, "_fqss_w3", None)
+    if c is None or c[0] != w._version:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        c = (w._version, split3_planes(w.detach()))
+        w._fqss_w3 = c
+    return c[1]
 
 
 def rowlin_bwd_x(gz, w):

@@ -470,6 +470,11 @@ int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, cons
  *   bwd_w : gw[o][i] += sum_r gz[r][o] x[r][i]                                                     */
 int fqss_rowlin_fwd(const float* x, const float* w, const float* bias, float* z, int64_t R, int Ci, int Co,
                     int64_t ld_x, int64_t ld_w, int64_t ld_z, fqss_stream_t stream);
+/* fqss_rowlin_fwd with the weight given as its three exact bf16 planes [3][Co][Ci] (fqss_split3_planes): for weights that do not
+ * change between launches (the frozen float teacher, mysystem.py:132-133) the weight tile is copied into LDS instead of being split
+ * by every workgroup.  Same result bits.  Ci % 32 == 0, 16-B aligned activation rows. */
+int fqss_rowlin_fwd_w3(const float* x, const uint16_t* w3, const float* bias, float* z, int64_t R, int Ci, int Co, int64_t ld_x,
+                       int64_t ld_z, fqss_stream_t stream);
 int fqss_rowlin_bwd_x(const float* gz, const float* w, float* gx, int64_t R, int Ci, int Co, int64_t ld_gz,
                       int64_t ld_w, int64_t ld_gx, fqss_stream_t stream);
 int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,

@@ -122,6 +122,23 @@ def test_gelu_in_the_quantizer_pass(rows, cols):
     assert torch.equal(obs_a, obs_b)
 
 
+@pytest.mark.parametrize("R,Ci,Co", [(1000, 64, 192), (8500, 256, 1024), (130, 1024, 256), (77, 32, 40)])
+def test_rowlin_fwd_on_presplit_weight_planes(R, Ci, Co, monkeypatch):
+    """fqss_rowlin_fwd_w3 (weight as three bf16 planes, split once) = fqss_rowlin_fwd, bit for bit; and kernels.rowlin_fwd picks it
+    (opt-in: FQSS_W3_CACHE=1) for a frozen parameter under no_grad, re-splitting after the parameter is written to"""
+    monkeypatch.setattr(K, "W3_CACHE", True)
+    x, b = rnd(R, Ci, seed=1).cuda(), rnd(Co, seed=3).cuda()
+    w = torch.nn.Parameter(rnd(Co, Ci, seed=2, scale=Ci ** -0.5).cuda())
+    ref = K.rowlin_fwd(x, w, b)                         # grad mode: the on-the-fly split
+    assert getattr(w, "_fqss_w3", None) is None
+    with torch.no_grad():
+        z = K.rowlin_fwd(x, w, b)
+        assert w._fqss_w3[0] == w._version and torch.equal(z, ref)
+        w.mul_(0.5)
+        z2 = K.rowlin_fwd(x, w, b)
+    assert w._fqss_w3[0] == w._version and torch.equal(z2, K.rowlin_fwd(x, w, b))
+
+
 def test_pwconv_split_gemms_against_fp64():
     """the channel-first pointwise GEMMs on the bf16 matrix cores (nine exact products, six products, and the batched k_gemm_x3 forms
     of the two gradients) against fp64: all at the level of an fp32 GEMM (torch's own result measured beside them)"""
