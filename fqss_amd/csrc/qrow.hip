@@ -114,6 +114,67 @@ __global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
         ry = load_qrange(g.qy_min, g.qy_max);
         if (g.act == FQSS_ACT_PRELU) slope = *g.slope;
     }
+    // results leave through a wave-private LDS tile as whole 128-B rows, 16 B per lane (the lane-per-column layout of the MFMA result needs
+    // 16 strided 4-B stores per 32 x 32 tile and operand: this kernel is bound by writing z -- and now y); 16-B aligned output rows
+    // only, the scalar form below serves the rest
+    __shared__ __attribute__((aligned(16))) float Tz[4][32][36];
+    const bool rows16 = (g.ld_z & 3) == 0 && (reinterpret_cast<uintptr_t>(g.z) & 15u) == 0 &&
+                        (g.y == nullptr || ((g.ld_y & 3) == 0 && (reinterpret_cast<uintptr_t>(g.y) & 15u) == 0));
+    if (rows16) {
+        const int c4 = (lane & 7) * 4, rq = lane >> 3;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int ob = o0 + wn * 64 + ni * 32;
+            if (ob >= g.Co) continue;
+            const int o = ob + lr;
+            const bool ov = o < g.Co;
+            const float dwo = ov ? g.dw[o] : 0.f, rwo = ov ? g.rw[o] : 0.f, bo = (ov && g.bias) ? g.bias[o] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int64_t rb = r0 + wm * 64 + mi * 32;
+                if (rb >= g.R) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float S = (float)acc[mi][ni][r] + 128.0f * rwo;
+                    float v = dwo * (dx * S + lo * rwo);
+                    if (g.bias) v = v + bo;
+                    Tz[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = rq + 8 * it;
+                    const int64_t row = rb + rl;
+                    const float4 v = *reinterpret_cast<const float4*>(&Tz[wave][rl][c4]);
+                    if (row < g.R) {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+                        float yq[4];
+                        if (g.y != nullptr) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float c, u;
+                                bool inr;
+                                yq[q] = fq_asym(act_apply(e[q], g.act, slope), ry, c, u, inr);
+                            }
+                        }
+                        if (ob + c4 + 3 < g.Co) {
+                            *reinterpret_cast<float4*>(g.z + row * g.ld_z + ob + c4) = v;
+                            if (g.y != nullptr) *reinterpret_cast<float4*>(g.y + row * g.ld_y + ob + c4) = make_float4(yq[0], yq[1], yq[2], yq[3]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (ob + c4 + q < g.Co) {
+                                    g.z[row * g.ld_z + ob + c4 + q] = e[q];
+                                    if (g.y != nullptr) g.y[row * g.ld_y + ob + c4 + q] = yq[q];
+                                }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int o = o0 + wn * 64 + ni * 32 + lr;
