@@ -78,11 +78,16 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
                                                         int64_t ld_y, float eps, const float* __restrict__ qmin,
                                                         const float* __restrict__ qmax, unsigned char* __restrict__ yc, int64_t ld_yc,
                                                         const float* __restrict__ xadd, int64_t ld_a, float* __restrict__ xsum,
-                                                        int64_t ld_s) {
+                                                        int64_t ld_s, const float* __restrict__ qs_min, const float* __restrict__ qs_max) {
     // xadd / xsum (both or neither): the row that is normalised is x + xadd -- the residual add in front of a pre-norm transformer
     // sub-layer -- and the sum is also written out (it is the residual stream of the NEXT add and the backward's input)
+    // qs_min / qs_max (nullable, with xadd): the add is an AddQ (the post-norm layers of DPTNet, dptnetq.py:84-97): xsum receives the
+    // PRE-quant sum z = x + xadd (what the backward's STE needs) and the row that is normalised is fq_s(z)
     QRange qr{0.0f, 1.0f, 1.0f};
     if (Q) qr = load_qrange(qmin, qmax);
+    QRange qs{0.0f, 1.0f, 1.0f};
+    const bool QS = qs_min != nullptr;
+    if (QS) qs = load_qrange(qs_min, qs_max);
     static_assert(G == 64 || (G == 16 && JC == 4 && VEC), "narrow rows: 16 lanes x float4");
     constexpr int RPW = 64 / G;                              // rows per wave
     const int lane = (threadIdx.x & 63) % G, rw = (threadIdx.x & 63) / G;
@@ -102,6 +107,15 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < JC; ++j) v[j] = v[j] + a2[j];
             if (row_ok) ln_store<JC, VEC>(xsum + r * ld_s, lane, C, v);
+            if (QS) {
+#pragma unroll
+                for (int j = 0; j < JC; ++j) {
+                    float c, u;
+                    bool inr;
+                    const float t = fq_asym(v[j], qs, c, u, inr);
+                    v[j] = ln_col<JC, VEC>(lane, j) < C ? t : 0.f;      // (columns past C stay 0: they enter the row sums)
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < JC; ++j) s += v[j];
@@ -163,9 +177,12 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
                                                         float* __restrict__ gbeta, int64_t R, int C, int64_t ld_gy,
                                                         int64_t ld_x, int64_t ld_gx, const float* __restrict__ beta,
                                                         const float* __restrict__ qmin, const float* __restrict__ qmax, double* gacc,
-                                                        const float* __restrict__ gadd, int64_t ld_ga) {
+                                                        const float* __restrict__ gadd, int64_t ld_ga, const float* __restrict__ qs_min,
+                                                        const float* __restrict__ qs_max, double* gacc_s) {
     // gadd (nullable): the gradient arriving on the residual stream behind the fused add (k_layernorm_fwd's xadd form): gx = LN' + gadd is
     // then the gradient of BOTH addends -- the sum autograd would take at the fork in a pass of its own
+    // qs_min / qs_max / gacc_s (nullable): the add was an AddQ: x holds the PRE-quant sum z, the normalised row is fq_s(z) and gx passes
+    // through that quantizer's STE (range partials to gacc_s, one slot per workgroup)
     __shared__ float red[2][4][64 * JC];
     __shared__ double redq[2 * 4];
     static_assert(G == 64 || (G == 16 && JC == 4 && VEC), "narrow rows: 16 lanes x float4");
@@ -175,6 +192,10 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     QRange qr{0.0f, 1.0f, 1.0f};
     if (Q) qr = load_qrange(qmin, qmax);
     float p_du = 0.0f, p_out = 0.0f;      // sum g*(c - m*u), sum g*(1-m)   (k_actq_bwd)
+    float s_du = 0.0f, s_out = 0.0f;      // the same for the sum quantizer
+    QRange qs{0.0f, 1.0f, 1.0f};
+    const bool QS = qs_min != nullptr;
+    if (QS) qs = load_qrange(qs_min, qs_max);
     float ga[JC], be[JC], agg[JC], agb[JC];
     ln_load<JC, VEC>(gamma, lane, C, ga);
 #pragma unroll
@@ -193,6 +214,20 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         }
         ln_load<JC, VEC>(x + r * ld_x, lane, C, xv);
         if (gadd != nullptr) ln_load<JC, VEC>(gadd + r * ld_ga, lane, C, av);
+        float scu[JC];            // sum quantizer: c - u (in range) or c (clamped); NaN-free marker for "clamped" is s_in[j]
+        bool s_in[JC];
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            scu[j] = 0.f;
+            s_in[j] = true;
+            if (QS) {
+                float c, u;
+                bool inr;
+                xv[j] = fq_asym(xv[j], qs, c, u, inr);      // the row the forward normalised
+                s_in[j] = inr;
+                scu[j] = inr ? (c - u) : c;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < JC; ++j) {
             const bool live = ln_col<JC, VEC>(lane, j) < C;
@@ -219,6 +254,13 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         for (int j = 0; j < JC; ++j) {
             o[j] = rstd * ((dxh[j] - a) - xh[j] * b);
             if (gadd != nullptr) o[j] = o[j] + av[j];
+            if (QS) {
+                const bool live = row_ok && ln_col<JC, VEC>(lane, j) < C;
+                const float gq = o[j];
+                s_du += live ? gq * scu[j] : 0.0f;
+                s_out += (live && !s_in[j]) ? gq : 0.0f;
+                o[j] = s_in[j] ? div_by(gq * qs.delta, qs.delta, qs.inv) : 0.0f;
+            }
         }
         if (row_ok) ln_store<JC, VEC>(gx + r * ld_gx, lane, C, o);
     }
@@ -252,6 +294,17 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         block_sum<double, 2>(v, redq);
         if (threadIdx.x == 0) {
             double* slot = gacc + 3 * (int64_t)blockIdx.x;
+            const double dmax = v[0] / 255.0;
+            slot[0] += v[1] - dmax;
+            slot[1] += dmax;
+        }
+    }
+    if (QS) {
+        __syncthreads();
+        double v[2] = {(double)s_du, (double)s_out};
+        block_sum<double, 2>(v, redq);
+        if (threadIdx.x == 0) {
+            double* slot = gacc_s + 3 * (int64_t)blockIdx.x;
             const double dmax = v[0] / 255.0;
             slot[0] += v[1] - dmax;
             slot[1] += dmax;
@@ -824,7 +877,7 @@ using namespace fqss;
 static int layernorm_fwd_impl(const char* who, const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc,
                               float* mean_rstd, int64_t R, int C, int64_t ld_x, int64_t ld_y, int64_t ld_yc, double eps,
                               const float* qmin, const float* qmax, fqss_stream_t stream, const float* xadd = nullptr, int64_t ld_a = 0,
-                              float* xsum = nullptr, int64_t ld_s = 0) {
+                              float* xsum = nullptr, int64_t ld_s = 0, const float* qs_min = nullptr, const float* qs_max = nullptr) {
     if (R == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
     const float e = (float)eps;
@@ -836,7 +889,7 @@ static int layernorm_fwd_impl(const char* who, const float* x, const float* gamm
     if (nb > 4096) nb = 4096;
 #define FQSS_LN_FWD(JC, Q, ...) \
     hipLaunchKernelGGL((k_layernorm_fwd<JC, Q, __VA_ARGS__>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
-                       qmax, yc, ld_yc, xadd, ld_a, xsum, ld_s)
+                       qmax, yc, ld_yc, xadd, ld_a, xsum, ld_s, qs_min, qs_max)
 #define FQSS_LN_FWD_Q(Q) \
     if (narrow) FQSS_LN_FWD(4, Q, true, 16); \
     else if (C <= 64) FQSS_LN_FWD(1, Q, false); \
@@ -866,7 +919,8 @@ extern "C" int fqss_layernormq_fwd(const float* x, const float* gamma, const flo
 static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, const float* gamma, const float* beta,
                               const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy,
                               int64_t ld_x, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream,
-                              const float* gadd = nullptr, int64_t ld_ga = 0) {
+                              const float* gadd = nullptr, int64_t ld_ga = 0, const float* qs_min = nullptr, const float* qs_max = nullptr,
+                              double* gacc_s = nullptr) {
     if (R == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ld_gy % 4 == 0 && ld_x % 4 == 0 && ld_gx % 4 == 0 && aligned16(gy) && aligned16(x) && aligned16(gx) &&
@@ -877,7 +931,7 @@ static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, 
     if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
 #define FQSS_LN_BWD(JC, Q, ...) \
     hipLaunchKernelGGL((k_layernorm_bwd<JC, Q, __VA_ARGS__>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
-                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc, gadd, ld_ga)
+                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc, gadd, ld_ga, qs_min, qs_max, gacc_s)
 #define FQSS_LN_BWD_Q(Q) \
     if (narrow) FQSS_LN_BWD(4, Q, true, 16); \
     else if (C <= 64) FQSS_LN_BWD(1, Q, false); \
@@ -931,6 +985,31 @@ extern "C" int fqss_add_layernorm_bwd(const float* g, const float* gs, const flo
     FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_g >= C && ld_s >= C && ld_gx >= C && (gs == nullptr || ld_gs >= C), "bad shape (C <= 512)");
     return layernorm_bwd_impl("fqss_add_layernorm_bwd", g, s, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, ld_g, ld_s, ld_gx, qmin, qmax,
                               gacc, stream, gs, ld_gs);
+}
+
+/* the same pair for a QUANTIZED add in front of the norm -- y = LN(Q)(fq_s(a + b)), the post-norm layers of DPTNet (dptnetq.py:84-97:
+ * AddQ then LayerNormQ): z receives the PRE-quant sum (the backward's input), qs_min / qs_max are the AddQ's range; the backward's gx
+ * (the gradient of a AND of b) has passed the AddQ's STE, its range partials go to gacc_s */
+extern "C" int fqss_addq_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, float* z, float* y, uint8_t* yc,
+                                       float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_z, int64_t ld_y,
+                                       int64_t ld_yc, double eps, const float* qmin, const float* qmax, const float* qs_min,
+                                       const float* qs_max, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && b && gamma && beta && z && y && mean_rstd && qs_min && qs_max && ((qmin == nullptr) == (qmax == nullptr)), "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_a >= C && ld_b >= C && ld_z >= C && ld_y >= C && (yc == nullptr || (qmin && ld_yc >= C)),
+                 "bad shape (C <= 512)");
+    return layernorm_fwd_impl("fqss_addq_layernorm_fwd", a, gamma, beta, y, yc, mean_rstd, R, C, ld_a, ld_y, ld_yc, eps, qmin, qmax, stream, b,
+                              ld_b, z, ld_z, qs_min, qs_max);
+}
+
+extern "C" int fqss_addq_layernorm_bwd(const float* g, const float* gs, const float* z, const float* gamma, const float* beta,
+                                       const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g,
+                                       int64_t ld_gs, int64_t ld_z, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc,
+                                       const float* qs_min, const float* qs_max, double* gacc_s, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && z && gamma && mean_rstd && gx && ggamma && gbeta && qs_min && qs_max && gacc_s, "null tensor");
+    FQSS_REQUIRE((qmin == nullptr) == (qmax == nullptr) && (qmin == nullptr || (gacc && beta)), "quantizer: ranges, beta and gacc together");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_g >= C && ld_z >= C && ld_gx >= C && (gs == nullptr || ld_gs >= C), "bad shape (C <= 512)");
+    return layernorm_bwd_impl("fqss_addq_layernorm_bwd", g, z, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, ld_g, ld_z, ld_gx, qmin, qmax,
+                              gacc, stream, gs, ld_gs, qs_min, qs_max, gacc_s);
 }
 
 extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream) {

@@ -1110,8 +1110,9 @@ def layernormq_bwd(g, x, gamma, beta, mean_rstd, ggamma, gbeta, qmin, qmax, gacc
     return gx
 
 
-def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=False):
-    """s = a + b; y = LN(s) or fq(LN(s)) -> (s, y, codes or None, mean_rstd)"""
+def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=False, qs=None):
+    """s = a + b; y = LN(s) or fq(LN(s)) -> (s, y, codes or None, mean_rstd); qs = (min, max) of an AddQ's quantizer: y = LN(Q)(fq_s(s)),
+    s stays the pre-quant sum (fqss_addq_layernorm_fwd)"""
     _need_gpu(a, b, gamma, beta)
     C = gamma.numel()
     a, R, ld_a = _rows(a, C)
@@ -1121,12 +1122,16 @@ def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=F
     y = torch.empty(*a.shape, device=a.device, dtype=torch.float32)
     yc = torch.empty(*a.shape, device=a.device, dtype=torch.uint8) if (want_codes and qmin is not None) else None
     mean_rstd = torch.empty(R, 2, device=a.device, dtype=torch.float32)
-    _lib.call("fqss_add_layernorm_fwd", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C, C, C,
-              float(eps), _p(qmin), _p(qmax), _stream())
+    if qs is not None:
+        _lib.call("fqss_addq_layernorm_fwd", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C, C, C,
+                  float(eps), _p(qmin), _p(qmax), _p(qs[0]), _p(qs[1]), _stream())
+    else:
+        _lib.call("fqss_add_layernorm_fwd", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C, C, C,
+                  float(eps), _p(qmin), _p(qmax), _stream())
     return s, y, yc, mean_rstd
 
 
-def add_layernorm_bwd(g, gs, s, gamma, beta, mean_rstd, ggamma, gbeta, qmin=None, qmax=None, gacc=None):
+def add_layernorm_bwd(g, gs, s, gamma, beta, mean_rstd, ggamma, gbeta, qmin=None, qmax=None, gacc=None, qs=None, gacc_s=None):
     _need_gpu(g, gs, s, gamma, mean_rstd, ggamma, gbeta)
     C = gamma.numel()
     g, R, ld_g = _rows(g, C)
@@ -1135,8 +1140,12 @@ def add_layernorm_bwd(g, gs, s, gamma, beta, mean_rstd, ggamma, gbeta, qmin=None
     if gs is not None:
         gs, _, ld_gs = _rows(gs, C)
     gx = torch.empty(*s.shape, device=s.device, dtype=torch.float32)
-    _lib.call("fqss_add_layernorm_bwd", _p(g), _p(gs), _p(s), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_g,
-              ld_gs, ld_s, C, _p(qmin), _p(qmax), _p(gacc), _stream())
+    if qs is not None:
+        _lib.call("fqss_addq_layernorm_bwd", _p(g), _p(gs), _p(s), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_g,
+                  ld_gs, ld_s, C, _p(qmin), _p(qmax), _p(gacc), _p(qs[0]), _p(qs[1]), _p(gacc_s), _stream())
+    else:
+        _lib.call("fqss_add_layernorm_bwd", _p(g), _p(gs), _p(s), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_g,
+                  ld_gs, ld_s, C, _p(qmin), _p(qmax), _p(gacc), _stream())
     return gx
 
 

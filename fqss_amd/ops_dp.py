@@ -217,30 +217,38 @@ class AddLayerNormRows(Function):
     """(y, s) = (LN(a + b) or fq(LN(a + b)), a + b): the float residual add in front of a pre-norm transformer sub-layer fused into its
     LayerNorm / LayerNormQ -- one kernel each way (fqss_add_layernorm_fwd/bwd).  The backward adds the gradient that arrives over the
     residual stream `s` in its epilogue and hands the SAME tensor to both addends: the fork's sum costs no pass of its own.
-    q = None: plain LayerNorm (float teacher, or a LayerNormQ outside the quantizing phase is not routed here)."""
+    q = None: plain LayerNorm (float teacher, or a LayerNormQ outside the quantizing phase is not routed here).
+    qs (an AddQ's quantizer context in its quantizing phase, else None): the add is quantized -- y = LN(Q)(fq_s(a + b)), the post-norm
+    layers of DPTNet (fqss_addq_layernorm_fwd/bwd); s is then the PRE-quant sum and is not an output anyone else may consume."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, eps, qmin, qmax, q, want_codes):
-        s, y, idx, mean_rstd = K.add_layernorm_fwd(a, b, gamma, beta, eps, qmin, qmax, want_codes)
+    def forward(ctx, a, b, gamma, beta, eps, qmin, qmax, q, want_codes, qs=None, qs_min=None, qs_max=None):
+        s, y, idx, mean_rstd = K.add_layernorm_fwd(a, b, gamma, beta, eps, qmin, qmax, want_codes, qs=None if qs is None else (qs.qmin, qs.qmax))
         if q is not None:
             q.idx = idx
         ctx.save_for_backward(s, gamma, beta, mean_rstd, qmin, qmax)
-        ctx.q = q
+        ctx.q, ctx.qs = q, qs
         return y, s
 
     @staticmethod
     def backward(ctx, gy, gs):
         s, gamma, beta, mean_rstd, qmin, qmax = ctx.saved_tensors
-        q = ctx.q
+        q, qs = ctx.q, ctx.qs
         gg, d1 = _param_grad(gamma, gamma)
         gb, d2 = _param_grad(beta, beta)
         if gy is None:                       # the normalised branch is unused: only the residual stream carries a gradient
-            return gs, gs, None, None, None, None, None, None, None
-        gx = K.add_layernorm_bwd(gy.contiguous(), gs, s, gamma, beta, mean_rstd, gg, gb, qmin, qmax, q.gacc if q is not None else None)
-        g_min = g_max = None
+            assert qs is None
+            return gs, gs, None, None, None, None, None, None, None, None, None, None
+        if qs is not None:
+            gs = None                        # (the pre-quant sum has no other consumer)
+        gx = K.add_layernorm_bwd(gy.contiguous(), gs, s, gamma, beta, mean_rstd, gg, gb, qmin, qmax, q.gacc if q is not None else None,
+                                 qs=None if qs is None else (qs.qmin, qs.qmax), gacc_s=None if qs is None else qs.gacc)
+        g_min = g_max = gs_min = gs_max = None
         if q is not None:
             _, g_min, g_max = ops._flush_ranges(q, None, None, ops.ACT_NONE)
-        return gx, gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None
+        if qs is not None:
+            _, gs_min, gs_max = ops._flush_ranges(qs, None, None, ops.ACT_NONE)
+        return gx, gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None, None, gs_min, gs_max
 
 
 class Unary(Function):

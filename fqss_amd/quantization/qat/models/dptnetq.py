@@ -103,11 +103,17 @@ class TransformerEncoderLayer(nn.Module):
             src2 = _float_mha(self.self_attn, s_att)
         else:
             src2 = self.self_attn(s_att, s_att, s_att)[0]
-        src = run(self.norm1, self.add_norm1(s_res, src2))
+        src = self._add_norm(self.add_norm1, self.norm1, s_res, src2)
         s_rnn, s_res = ops.fork2(src)
         h = QL.fq_node(None, run(self.lstm, s_rnn), self._relu)         # F.relu between LSTMQ and LinearQ: no quantizer
         src2 = run(self.linear, h)
-        return run(self.norm2, self.add_norm2(s_res, src2))
+        return self._add_norm(self.add_norm2, self.norm2, s_res, src2)
+
+    @staticmethod
+    def _add_norm(add, norm, a, b):
+        if isinstance(add, QL.LayerQ) and isinstance(norm, QL.LayerQ):
+            return QL.addq_layernorm(add, norm, a, b)          # quantizing phase: one kernel each way (fqss_addq_layernorm_*)
+        return run(norm, add(a, b))
 
 
 class Encoder(nn.Module):

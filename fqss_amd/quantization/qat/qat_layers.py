@@ -763,6 +763,33 @@ def add_layernorm(norm, a, b):
     return norm(s_n), s_res
 
 
+def addq_layernorm(add, norm, a, b):
+    """norm(add(a, b)) for the post-norm layers of DPTNet (dptnetq.py:84-97: `src = norm(add_norm(src, src2))`): with an AddQ and a
+    LayerNormQ both in their quantizing phase (deferred range tables) the quantized add rides in the LayerNorm kernels each way
+    (ops_dp.AddLayerNormRows with a sum quantizer: fqss_addq_layernorm_fwd/bwd) -- no axpby, no quantizer pass, no fork sum; any other
+    state runs the two modules"""
+    if FUSE_ADDLN and FUSE_LNQ and isinstance(add, AddQ) and isinstance(norm, LayerNormQ) and not _is_row_bcast(a, b):
+        ln, aq, aqs = norm.layernorm, norm.activation_fake_quantize, add.activation_fake_quantize
+        ok = isinstance(ln, nn.LayerNorm) and len(ln.normalized_shape) == 1 and ln.elementwise_affine and a.shape == b.shape
+        for t in (aq, aqs):
+            ok = ok and getattr(t, "observer_mode", None) is not None and not (t.observer_mode and t.n_iter < t.max_observations) \
+                and getattr(t, "_gacc", None) is not None
+        if ok:
+            q, qs = aq.qctx(), aqs.qctx()
+            if q.qmode == ops.Q_QUANT and qs.qmode == ops.Q_QUANT and q.gacc is not None and qs.gacc is not None:
+                want = ops_dp.QROW and ops.CODED
+                y, _ = ops_dp.AddLayerNormRows.apply(ops.real(a), ops.real(b), ln.weight, ln.bias, ln.eps, q.qmin, q.qmax, q, want, qs, qs.qmin, qs.qmax)
+                aqs.after_forward(qs)
+                aq.after_forward(q)
+                idx, q.idx = q.idx, None
+                if idx is not None:
+                    y._fqss_rowq = ops.ActCodes(idx.view(y.shape), q.qmin.detach(), q.qmax.detach())
+                return y
+            raise RuntimeError("addq_layernorm: quantizer state changed between the check and qctx()")
+    y = norm(add(a, b))
+    return y[0] if isinstance(y, (list, tuple)) else y
+
+
 FUSE_ADDLN = __import__("os").environ.get("FQSS_FUSE_ADDLN", "1") != "0"   # residual add + LayerNorm(Q) as one kernel each way
 FUSE_LNQ = __import__("os").environ.get("FQSS_FUSE_LNQ", "1") != "0"     # 0: LayerNorm and its quantizer as separate launches (A/B, tests)
 

@@ -513,6 +513,17 @@ int fqss_add_layernorm_bwd(const float* g, const float* gs, const float* s, cons
                            const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g,
                            int64_t ld_gs, int64_t ld_s, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc,
                            fqss_stream_t stream);
+/* the same pair for a QUANTIZED add in front of the norm: y = LN(Q)(fq_s(a + b)) -- AddQ followed by LayerNormQ in the post-norm
+ * layers of DPTNet (dptnetq.py:84-97).  z receives the PRE-quant sum a + b (the backward's input); qs_min / qs_max: the AddQ's range.
+ * The backward's gx (the gradient of a AND of b) has passed the AddQ's STE; its range partials go to gacc_s. */
+int fqss_addq_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, float* z, float* y, uint8_t* yc,
+                            float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_z, int64_t ld_y,
+                            int64_t ld_yc, double eps, const float* qmin, const float* qmax, const float* qs_min,
+                            const float* qs_max, fqss_stream_t stream);
+int fqss_addq_layernorm_bwd(const float* g, const float* gs, const float* z, const float* gamma, const float* beta,
+                            const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g,
+                            int64_t ld_gs, int64_t ld_z, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc,
+                            const float* qs_min, const float* qs_max, double* gacc_s, fqss_stream_t stream);
 
 /* element-wise maps on dense tensors; kind: 0 tanh, 1 sigmoid, 2 division by the scalar p
  * replaces: nn.Tanh / nn.Sigmoid inside Conv1dNlQ (dptnetq.py:286-287), q / sqrt(head_dim) (qat_layers.py:905).

@@ -731,6 +731,39 @@ def test_qrow_kernel_exact_integer_sums(R, Ci, Co):
         assert torch.equal(y2, K.actq_fwd(z, act, sl, ops.Q_QUANT, qlo, qhi, None)), act
 
 
+@pytest.mark.parametrize("R,C", [(48500, 64), (1000, 256), (77, 16)])
+def test_addq_layernormq_fused_matches_the_two_modules(R, C, monkeypatch):
+    """B2-style gate: norm(add(a, b)) with AddQ + LayerNormQ in their quantizing phase as ONE kernel each way (fqss_addq_layernorm_fwd /
+    _bwd: the quantized add inside the LayerNorm kernels) against the two modules run one after the other: output bit-identical,
+    the gradients of both addends, of gamma / beta and of the four range parameters within fp32 summation noise"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    a0, b0, g0 = rnd(R, 1, C, seed=1).cuda(), rnd(R, 1, C, seed=2, scale=0.7).cuda(), rnd(R, 1, C, seed=3).cuda()
+    res = {}
+    for kind in ("fused", "unfused"):
+        monkeypatch.setattr(QL, "FUSE_ADDLN", kind == "fused")
+        torch.manual_seed(3)
+        add, ln = QL.AddQ(QL.Add(), **{k: v for k, v in A.items() if k != "weight_quant"}).cuda(), QL.LayerNormQ(nn.LayerNorm(C), **A).cuda()
+        with torch.no_grad():
+            ln.layernorm.weight.copy_(rnd(C, seed=4).cuda() * 0.3 + 1.0)
+            ln.layernorm.bias.copy_(rnd(C, seed=5).cuda() * 0.1)
+            for _ in range(50):
+                ln(add(a0, b0))
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = QL.addq_layernorm(add, ln, a, b)
+        y.backward(g0)
+        res[kind] = (y.detach(), a.grad, b.grad, ln.layernorm.weight.grad, ln.layernorm.bias.grad,
+                     add.activation_fake_quantize.min_range.grad, add.activation_fake_quantize.max_range.grad,
+                     ln.activation_fake_quantize.min_range.grad, ln.activation_fake_quantize.max_range.grad)
+        monkeypatch.undo()
+    f, u = res["fused"], res["unfused"]
+    assert torch.equal(f[0], u[0])
+    for i, name in enumerate(("da", "db", "dgamma", "dbeta", "add min", "add max", "ln min", "ln max"), start=1):
+        assert f[i] is not None and u[i] is not None, name
+        err = float((f[i] - u[i]).norm() / (u[i].norm() + 1e-12))
+        assert err <= 2e-5, (name, err)
+    assert torch.equal(f[1], f[2])
+
+
 def test_coded_row_linear_gradients_do_not_read_carriers(monkeypatch):
     """regression: under the codes-only dataflow of KDTrainStep (ops.fast_codes) a row quantizer feeding a linear on codes must still
     write its fp32 values -- the linear's weight gradient reads them.  Carriers are NaN-poisoned here (ops.DEBUG_POISON)."""
