@@ -117,6 +117,7 @@ _PROTOS = {
     "fqss_lstm_fwd": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_lstm_bwd": [P, P, P, P, P, I32, I32, I32, P],
     "fqss_lstm_bwd_b": [P, P, P, P, P, P, I32, I32, I32, P],
+    "fqss_lstm_bwd_b4": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_gnrows_fwd": [P, P, P, P, P, P, I64, I32, I64, I64, I32, I32, I32, F64, P],
     "fqss_gnrows_bwd": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I32, I32, I32, P],
     "fqss_bcast_add": [P, P, P, I64, I64, I32, P],

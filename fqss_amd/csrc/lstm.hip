@@ -30,6 +30,10 @@ namespace fqss {
 
 constexpr int kNB = 2;   // sequences per workgroup
 
+struct LstmBiasGrads {      // gradient buffers of b_ih / b_hh, forward and reverse direction ([4H] each; null: not wanted)
+    float *ih_f, *hh_f, *ih_r, *hh_r;
+};
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // pre   [S][B][2][4H]  input projection incl. b_ih (gate order i, f, g, o)
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
 template <int HT>
 __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float* __restrict__ gout, const float* __restrict__ whh,
                                                                       const float* __restrict__ gsav, const float* __restrict__ csav,
-                                                                      float* __restrict__ dG, float* __restrict__ gbias, int S, int B, int Hrt) {
+                                                                      float* __restrict__ dG, float* __restrict__ gbias, const LstmBiasGrads gb4, int S, int B, int Hrt) {
     const int H = HT > 0 ? HT : Hrt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dgs = smem;                   // [kNB][4H]   (HT > 0: [kNB][4 blocks][4 quarters][HT/4 + 4])
@@ -322,9 +326,16 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
 #pragma unroll
     for (int u = 0; u < kPF - 1; ++u)           // the last S % kPF steps: already in the ring
         if (done + u < S) one_step(S - 1 - (done + u), pf[u]);
-    if (gbias != nullptr && cell) {
+    // gbias: ONE [2][4H] buffer (fqss_lstm_bwd_b);  gb4 (fqss_lstm_bwd_b4): the four bias parameters' own gradient buffers, [4H] each
+    if (cell) {
+        float* p0 = dir == 0 ? gb4.ih_f : gb4.ih_r;
+        float* p1 = dir == 0 ? gb4.hh_f : gb4.hh_r;
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) atomicAdd(gbias + (dir * 4 + gt) * H + ck, bsum[gt]);
+        for (int gt = 0; gt < 4; ++gt) {
+            if (gbias != nullptr) atomicAdd(gbias + (dir * 4 + gt) * H + ck, bsum[gt]);
+            if (p0 != nullptr) atomicAdd(p0 + gt * H + ck, bsum[gt]);
+            if (p1 != nullptr) atomicAdd(p1 + gt * H + ck, bsum[gt]);
+        }
     }
 }
 
@@ -349,7 +360,7 @@ extern "C" int fqss_lstm_fwd(const float* pre, const float* whh, const float* bh
 }
 
 static int lstm_bwd_impl(const char* who, const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* gbias,
-                         int S, int B, int H, fqss_stream_t stream) {
+                         int S, int B, int H, fqss_stream_t stream, LstmBiasGrads gb4 = LstmBiasGrads{nullptr, nullptr, nullptr, nullptr}) {
     FQSS_REQUIRE(gout && whh && gsav && csav && dG, "null tensor");
     FQSS_REQUIRE(S > 0 && B > 0 && H > 0 && H <= 256, "bad shape (H <= 256)");
     hipStream_t s = (hipStream_t)stream;
@@ -357,10 +368,10 @@ static int lstm_bwd_impl(const char* who, const float* gout, const float* whh, c
     const size_t lds = (size_t)(kNB * 4 * H + 4 * kNB * H) * sizeof(float);
     if (H == 128) {
         const size_t lds128 = (size_t)(kNB * 16 * (128 / 4 + 4) + 4 * kNB * H) * sizeof(float);   // padded dgate image + partial dh
-        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds128, s, gout, whh, gsav, csav, dG, gbias, S, B, H);
+        hipLaunchKernelGGL((k_lstm_bwd<128>), grid, dim3(512), lds128, s, gout, whh, gsav, csav, dG, gbias, gb4, S, B, H);
     } else {
         const int threads = (int)cdiv(4 * H, 64) * 64;
-        hipLaunchKernelGGL((k_lstm_bwd<0>), grid, dim3(threads), lds, s, gout, whh, gsav, csav, dG, gbias, S, B, H);
+        hipLaunchKernelGGL((k_lstm_bwd<0>), grid, dim3(threads), lds, s, gout, whh, gsav, csav, dG, gbias, gb4, S, B, H);
     }
     return launch_status(who);
 }
@@ -376,4 +387,12 @@ extern "C" int fqss_lstm_bwd_b(const float* gout, const float* whh, const float*
                                int B, int H, fqss_stream_t stream) {
     FQSS_REQUIRE(gbias, "null tensor");
     return lstm_bwd_impl("fqss_lstm_bwd_b", gout, whh, gsav, csav, dG, gbias, S, B, H, stream);
+}
+
+// ... and with the sums ADDED straight into the four bias parameters' own gradient buffers (gb[0..3] = b_ih, b_hh forward, b_ih, b_hh
+// reverse; [4H] each, e.g. their slots of a flat gradient arena): no [8H] intermediate, no four adds behind the kernel
+extern "C" int fqss_lstm_bwd_b4(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* const* gb,
+                                int S, int B, int H, fqss_stream_t stream) {
+    FQSS_REQUIRE(gb && gb[0] && gb[1] && gb[2] && gb[3], "null tensor");
+    return lstm_bwd_impl("fqss_lstm_bwd_b4", gout, whh, gsav, csav, dG, nullptr, S, B, H, stream, LstmBiasGrads{gb[0], gb[1], gb[2], gb[3]});
 }

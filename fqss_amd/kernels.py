@@ -1346,12 +1346,16 @@ def lstm_fwd(pre, whh, bhh, S, B, H, save=True):
     return hout, gsav, csav
 
 
-def lstm_bwd(gout, whh, gsav, csav, S, B, H, gbias=None):
-    """gbias ([8H] zeros): receives the column sums of dG (the bias gradients) from the same launch"""
+def lstm_bwd(gout, whh, gsav, csav, S, B, H, gbias=None, gb4=None):
+    """gbias ([8H] zeros): receives the column sums of dG (the bias gradients) from the same launch; gb4: instead, the four bias
+    parameters' own gradient buffers (b_ih, b_hh forward, b_ih, b_hh reverse; [4H] each, accumulated into)"""
     _need_gpu(gout, whh)
     gout = gout.contiguous()
     dG = torch.empty(S, B, 8 * H, device=gout.device, dtype=torch.float32)
-    if gbias is None:
+    if gb4 is not None:
+        assert len(gb4) == 4 and all(t.numel() == 4 * H and t.is_contiguous() for t in gb4)
+        _lib.call("fqss_lstm_bwd_b4", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), _ptr_array(list(gb4)), S, B, H, _stream())
+    elif gbias is None:
         _lib.call("fqss_lstm_bwd", _p(gout), _p(whh), _p(gsav), _p(csav), _p(dG), S, B, H, _stream())
     else:
         assert gbias.numel() == 8 * H and gbias.is_contiguous()

@@ -491,9 +491,10 @@ class LstmBi(Function):
         x, wih, whh, hout, gsav, csav = ctx.saved_tensors
         S, B, I = x.shape
         H = whh.shape[2]
-        # (the bias gradients -- column sums of dG, the same for b_ih and b_hh of a direction -- come out of the same launch)
-        cs = torch.zeros(8 * H, device=gout.device, dtype=torch.float32)
-        dG = K.lstm_bwd(gout, whh, gsav, csav, S, B, H, cs)              # [S, B, 8H]
+        # (the bias gradients -- column sums of dG, the same for b_ih and b_hh of a direction -- come out of the same launch, added
+        #  straight into the four parameters' gradient buffers)
+        gbufs = [_param_grad(p, p) for p in ctx.params]
+        dG = K.lstm_bwd(gout, whh, gsav, csav, S, B, H, gb4=[g for g, _ in gbufs])      # [S, B, 8H]
         gx = K.rowlin_bwd_x(dG, wih) if ctx.needs_input_grad[0] else None
         # weights fake-quantized by runtime.QuantTables carry no autograd history: their dL/dW_q is accumulated straight into the step's
         # arena slot by the wgrad GEMM of that direction; otherwise one GEMM for both directions' W_ih into a fresh buffer
@@ -518,11 +519,7 @@ class LstmBi(Function):
                 if slots[i] is not None:
                     K.axpby_(slots[i], gws[i], 1.0)
                     gws[i] = None
-        gbs = []
-        for p, lo in zip(ctx.params, (0, 0, 4 * H, 4 * H)):
-            buf, direct = _param_grad(p, p)
-            K.axpby_(buf, cs[lo:lo + 4 * H], 1.0)
-            gbs.append(None if direct else buf)
+        gbs = [None if direct else buf for buf, direct in gbufs]
         return gx, gws[0], gws[1], gbs[0], gbs[1], gws[2], gws[3], gbs[2], gbs[3], None, None, None
 
 

@@ -618,6 +618,10 @@ int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const 
  * threads that produce dG */
 int fqss_lstm_bwd_b(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* gbias, int S,
                     int B, int H, fqss_stream_t stream);
+/* ... with the sums added straight into the four bias parameters' own gradient buffers: gb[0..3] = b_ih, b_hh of the forward
+ * direction, b_ih, b_hh of the reverse direction ([4H] each, "+=") */
+int fqss_lstm_bwd_b4(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* const* gb, int S,
+                     int B, int H, fqss_stream_t stream);
 
 /* Sepformer (cfg 4 -- SURVEY.md §8 row a14): gLN and the positional-encoding add on the dual-path row layouts.
  * GroupNorm(1, C) over ALL rows of a sample of a row matrix x [R][C]; the sample of row r is b = (r % RB) / X
