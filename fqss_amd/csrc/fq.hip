@@ -43,7 +43,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
-template <int VEC, bool GELU = false>
+// POSTRELU (template): act = FQSS_ACT_POST_RELU: no map in FRONT of the quantizer, a ReLU BEHIND it -- relu(fq(z)), the `F.relu` between LSTMQ
+// and LinearQ of DPTNet's transformer layer (dptnetq.py:84-97) -- in the quantizer's pass each way
+template <int VEC, bool GELU = false, bool POSTRELU = false>
 __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, float* __restrict__ out,
                                                    uint8_t* __restrict__ idx, int64_t rows, int64_t cols,
                                                    int64_t ld_z, int64_t ld_o, int64_t ld_i, int act,
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
             unsigned int packed = 0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float t = GELU ? gelu_fwd_f(v[j]) : act_apply(v[j], act, slope);
+                const float t = GELU ? gelu_fwd_f(v[j]) : (POSTRELU ? v[j] : act_apply(v[j], act, slope));
                 if (qmode == FQSS_Q_QUANT) {
                     float c, u;
                     bool inr;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
                         vmax = fmaxf(vmax, t);
                     }
                 }
+                if (POSTRELU) o[j] = o[j] > 0.0f ? o[j] : 0.0f;
             }
             if constexpr (VEC == 4) {
                 if (out != nullptr) *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void k_minmax(const float* __restrict__ x, int
 // block reduction + one fp32 atomic per (column chunk, channel).
 constexpr int kGaccSlots = FQSS_GACC_SLOTS;
 
-template <int VEC, bool BIAS, bool GELU = false>
+template <int VEC, bool BIAS, bool GELU = false, bool POSTRELU = false>
 __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, const float* __restrict__ g,
                                                    float* __restrict__ gz, int64_t rows, int64_t cols,
                                                    int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act,
@@ -247,20 +250,24 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
             for (int j = 0; j < VEC; ++j) {
                 const bool valid = (c0 + j < cols);
                 const float gj = valid ? gv[j] : 0.0f;
-                const float t = GELU ? gelu_fwd_f(zv[j]) : act_apply(zv[j], act, slope);
+                const float t = GELU ? gelu_fwd_f(zv[j]) : (POSTRELU ? zv[j] : act_apply(zv[j], act, slope));
                 float gt = gj;
                 if (qmode == FQSS_Q_QUANT) {
                     float c, u;
                     bool inr;
-                    (void)fq_asym(t, r, c, u, inr);
-                    gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
+                    const float yq = fq_asym(t, r, c, u, inr);
+                    if (POSTRELU && !(yq > 0.0f)) gt = 0.0f;
+                    const float gin = POSTRELU ? gt : gj;       // (POSTRELU: the gradient behind the ReLU's mask)
+                    gt = inr ? div_by(gin * r.delta, r.delta, r.inv) : 0.0f;
                     // selects, not a branch around the sums (a masked-out position may hold anything, so its term is dropped, not
                     // multiplied by 0): the branchy form of these sums in k_mulq_bwd was right alone and off by one term in a few
                     // lanes per launch next to a second stream; every such sum is written branch-free since
-                    p_du += valid ? gj * (inr ? (c - u) : c) : 0.0f;
-                    p_out += (valid && !inr) ? gj : 0.0f;
+                    p_du += valid ? gin * (inr ? (c - u) : c) : 0.0f;
+                    p_out += (valid && !inr) ? gin : 0.0f;
+                } else if (POSTRELU && !(t > 0.0f)) {
+                    gt = 0.0f;
                 }
-                float gzj = GELU ? gt * gelu_grad_f(zv[j]) : act_bwd(zv[j], gt, act, slope, valid, p_slope);
+                float gzj = GELU ? gt * gelu_grad_f(zv[j]) : (POSTRELU ? gt : act_bwd(zv[j], gt, act, slope, valid, p_slope));
                 o[j] = gzj;
                 if (BIAS) p_bias += valid ? gzj : 0.0f;
             }
@@ -563,7 +570,7 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     if (!out) ld_out = ld_z;
     FQSS_REQUIRE(!idx || (ld_idx & 3) != 0 || (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, "idx rows must be 4-B aligned");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_out >= cols, "bad shape");
-    FQSS_REQUIRE(act >= 0 && act <= FQSS_ACT_GELU && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(act >= 0 && act <= FQSS_ACT_POST_RELU && qmode >= 0 && qmode <= 2, "bad act/qmode");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
@@ -575,7 +582,7 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     const bool tail_ok = (cols % 4 == 0) || (out == nullptr) || (ld_out - cols < 4);
     const bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0) && tail_ok;
     hipStream_t s = (hipStream_t)stream;
-    if (vec && act != FQSS_ACT_GELU && qmode == FQSS_Q_QUANT && cols % 4 == 0 && cols <= 512 && rows >= 1024 &&
+    if (vec && act < FQSS_ACT_GELU && qmode == FQSS_Q_QUANT && cols % 4 == 0 && cols <= 512 && rows >= 1024 &&
         (!idx || ((ld_idx & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0))) {
         // narrow matrix: row-tiled kernel (64-feature slices x row parts), every lane busy
         const int64_t slices = cdiv(cols, 64);
@@ -587,7 +594,14 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
                            ld_out, ld_idx, act, slope, qmin, qmax, rows_per_part);
         return launch_status("fqss_actq_fwd");
     }
-    if (act == FQSS_ACT_GELU) {
+    if (act == FQSS_ACT_POST_RELU) {
+        if (vec)
+            hipLaunchKernelGGL((k_actq_fwd<4, false, true>), grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z, ld_out, ld_idx,
+                               act, slope, qmode, qmin, qmax, obs_ws);
+        else
+            hipLaunchKernelGGL((k_actq_fwd<1, false, true>), grid_rows(rows, cols, 1), dim3(256), 0, s, z, out, idx, rows, cols, ld_z, ld_out, ld_idx,
+                               act, slope, qmode, qmin, qmax, obs_ws);
+    } else if (act == FQSS_ACT_GELU) {
         if (vec)
             hipLaunchKernelGGL((k_actq_fwd<4, true>), grid_rows(rows, cols, 4), dim3(256), 0, s, z, out, idx, rows, cols, ld_z, ld_out, ld_idx, act,
                                slope, qmode, qmin, qmax, obs_ws);
@@ -643,14 +657,14 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     if (rows == 0 || cols == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(z && g && gz, "null tensor");
     FQSS_REQUIRE(rows >= 0 && cols >= 0 && ld_z >= cols && ld_g >= cols && ld_gz >= cols, "bad shape");
-    FQSS_REQUIRE(act >= 0 && act <= FQSS_ACT_GELU && qmode >= 0 && qmode <= 2, "bad act/qmode");
-    FQSS_REQUIRE(act != FQSS_ACT_GELU || !gbias, "GELU: no bias-gradient form");
+    FQSS_REQUIRE(act >= 0 && act <= FQSS_ACT_POST_RELU && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(act < FQSS_ACT_GELU || !gbias, "GELU / POST_RELU: no bias-gradient form");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");
     FQSS_REQUIRE(!gbias || (C > 0 && rows % C == 0), "gbias needs C dividing rows");
     if (rows == 0 || cols == 0) return FQSS_OK;
-    if (!gbias && act != FQSS_ACT_GELU && cols % 4 == 0 && cols <= 512 && rows >= 1024 && aligned16(z) && aligned16(g) && aligned16(gz) && ld_z % 4 == 0 &&
+    if (!gbias && act < FQSS_ACT_GELU && cols % 4 == 0 && cols <= 512 && rows >= 1024 && aligned16(z) && aligned16(g) && aligned16(gz) && ld_z % 4 == 0 &&
         ld_g % 4 == 0 && ld_gz % 4 == 0)
         // narrow matrix (see k_actq_fwd_narrow): the row-tiled kernel of fqss_actq_bwd_colbias, without the bias sums
         return fqss_actq_bwd_colbias(z, g, gz, rows, (int)cols, ld_z, ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, nullptr, stream);
@@ -669,7 +683,12 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
 #define FQSS_LAUNCH_BWD(V, Bi)                                                                                       \
     hipLaunchKernelGGL((k_actq_bwd<V, Bi>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act,     \
                        slope, qmode, qmin, qmax, gacc, gbias, C)
-    if (act == FQSS_ACT_GELU) {
+    if (act == FQSS_ACT_POST_RELU) {
+        if (vec) hipLaunchKernelGGL((k_actq_bwd<4, false, false, true>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act, slope, qmode,
+                                    qmin, qmax, gacc, gbias, C);
+        else hipLaunchKernelGGL((k_actq_bwd<1, false, false, true>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act, slope, qmode,
+                                qmin, qmax, gacc, gbias, C);
+    } else if (act == FQSS_ACT_GELU) {
         if (vec) hipLaunchKernelGGL((k_actq_bwd<4, false, true>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act, slope, qmode, qmin,
                                     qmax, gacc, gbias, C);
         else hipLaunchKernelGGL((k_actq_bwd<1, false, true>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act, slope, qmode, qmin,

@@ -9,6 +9,7 @@ from . import _lib
 Q_BYPASS, Q_OBSERVE, Q_QUANT = 0, 1, 2
 ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
 ACT_GELU = 3          # nn.GELU (erf form) in front of a quantizer: fqss_actq_fwd / fqss_actq_bwd only (qat_layers.fq_node)
+ACT_POST_RELU = 4     # a ReLU BEHIND the quantizer, relu(fq(x)): fqss_actq_fwd / fqss_actq_bwd only (qat_layers.fq_node(post_relu=True))
 
 GACC_DOUBLES = 2048 * 3   # FQSS_GACC_SLOTS x (dmin, dmax, dslope)
 USE_X3 = True            # route plain fp32 pointwise convs through the bf16 3x3-split GEMM

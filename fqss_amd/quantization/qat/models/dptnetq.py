@@ -105,7 +105,10 @@ class TransformerEncoderLayer(nn.Module):
             src2 = self.self_attn(s_att, s_att, s_att)[0]
         src = self._add_norm(self.add_norm1, self.norm1, s_res, src2)
         s_rnn, s_res = ops.fork2(src)
-        h = QL.fq_node(None, run(self.lstm, s_rnn), self._relu)         # F.relu between LSTMQ and LinearQ: no quantizer
+        if isinstance(self.lstm, QL.LSTMQ):
+            h = self.lstm(s_rnn, post_relu=True)[0]                      # F.relu between LSTMQ and LinearQ: in the output quantizer's pass
+        else:
+            h = QL.fq_node(None, run(self.lstm, s_rnn), self._relu)     # (float model)
         src2 = run(self.linear, h)
         return self._add_norm(self.add_norm2, self.norm2, s_res, src2)
 

@@ -653,10 +653,27 @@ def _flat2d(t):
     return t.view(n // c, c) if c else None
 
 
-def fq_node(aq, x, nl=None, codes=False, q=None):
+def fq_node(aq, x, nl=None, codes=False, q=None, post_relu=False):
     """fq_act(nl(x)) as its own autograd node (fqss_actq_fwd/bwd); float modules (aq None) only apply nl.
     codes=True: also emit the u8 codes and tag the result with them (the consumer is a row linear that can run on codes);
-    q: the quantizer's context when the caller already drew it (aq.qctx() advances the observer's call count)"""
+    q: the quantizer's context when the caller already drew it (aq.qctx() advances the observer's call count);
+    post_relu: relu(fq_act(x)) -- a ReLU BEHIND the quantizer (the F.relu between LSTMQ and LinearQ, dptnetq.py:92) in the same pass
+    (act = ACT_POST_RELU); nl must be None"""
+    if post_relu:
+        assert nl is None and not codes
+        if q is None:
+            q = aq.qctx() if aq is not None else ops.BYPASS
+        if q.qmode == ops.Q_BYPASS or not (FUSE_POSTRELU and ops.CODED):
+            y = x if q.qmode == ops.Q_BYPASS else fq_node(aq, x, q=q)
+            return fq_node(None, y, nn.ReLU())
+        x = ops.real(x)
+        flat = _flat2d(x)
+        q.no_codes = True
+        y = ops.NlActQ.apply(x if flat is None else flat, None, q.qmin, q.qmax, K.ACT_POST_RELU, q, None)
+        if aq is not None:
+            aq.after_forward(q)
+        q.idx = None
+        return y if flat is None else y.reshape(x.shape)
     gelu = FUSE_GELUQ and ops.CODED and isinstance(nl, nn.GELU) and getattr(nl, "approximate", "none") == "none"
     if gelu:
         nl = None             # GELU rides in the quantizer's own pass each way (act = ACT_GELU: fqss_actq_fwd / _bwd)
@@ -687,6 +704,7 @@ def fq_node(aq, x, nl=None, codes=False, q=None):
     return y
 
 
+FUSE_POSTRELU = __import__("os").environ.get("FQSS_FUSE_POSTRELU", "1") != "0"   # 0: the ReLU behind LSTMQ's quantizer as its own pass
 FUSE_GELUQ = __import__("os").environ.get("FQSS_FUSE_GELUQ", "1") != "0"   # 0: GELU as its own pass in front of the quantizer (A/B, tests)
 FUSE_ROWQ = __import__("os").environ.get("FQSS_FUSE_ROWQ", "1") != "0"    # 0: row linear, quantizer and bias sums as separate nodes (A/B, tests)
 
@@ -799,14 +817,14 @@ def _lstm_check(lstm):
         raise NotImplementedError("only the single-layer bidirectional sequence-first LSTM of the dual-path models has HIP kernels")
 
 
-def run_lstm(lstm, x, weights, aq):
-    """weights: dict name -> (fake-quantized) weight for the four weight matrices"""
+def run_lstm(lstm, x, weights, aq, post_relu=False):
+    """weights: dict name -> (fake-quantized) weight for the four weight matrices; post_relu: relu(fq(lstm(x)))"""
     _lstm_check(lstm)
     y = ops_dp.LstmBi.apply(ops.real(x), weights["weight_ih_l0"], weights["weight_hh_l0"], lstm.bias_ih_l0, lstm.bias_hh_l0,
                             weights["weight_ih_l0_reverse"], weights["weight_hh_l0_reverse"], lstm.bias_ih_l0_reverse,
                             lstm.bias_hh_l0_reverse, getattr(x, "_fqss_rowq", None),
                             getattr(weights["weight_ih_l0"], "_fqss_wcodes", None), getattr(weights["weight_ih_l0_reverse"], "_fqss_wcodes", None))
-    return fq_node(aq, y)
+    return fq_node(aq, y, post_relu=True) if post_relu else fq_node(aq, y)
 
 
 def _mha_check(mha, query, key, value):
@@ -913,9 +931,10 @@ class LSTMQ(LayerQ):
                 self.weight_quantizers_dict[name] = (get_weight_quantizer(gradient_based, w.shape, n_bits=weight_n_bits)
                                                      if weight_quant else nn.Identity())
 
-    def forward(self, x):
+    def forward(self, x, post_relu=False):
+        """post_relu (not in the reference's signature): the caller's F.relu on the output, folded into the output quantizer's pass"""
         weights = {n: q(getattr(self.lstm, n)) for n, q in self.weight_quantizers_dict.items()}
-        return [run_lstm(self.lstm, x, weights, self.activation_fake_quantize)]
+        return [run_lstm(self.lstm, x, weights, self.activation_fake_quantize, post_relu)]
 
 
 class MultiheadAttentionQ(LayerQ):

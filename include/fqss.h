@@ -45,6 +45,7 @@ extern "C" {
 #define FQSS_ACT_PRELU 1 /* one shared slope, nn.PReLU() */
 #define FQSS_ACT_RELU 2
 #define FQSS_ACT_GELU 3 /* nn.GELU(), erf form: fqss_actq_fwd / fqss_actq_bwd only (the HTDemucs layers) */
+#define FQSS_ACT_POST_RELU 4 /* a ReLU BEHIND the quantizer, relu(fq(z)): fqss_actq_fwd / fqss_actq_bwd only (dptnetq.py:92) */
 
 typedef void* fqss_stream_t;
 

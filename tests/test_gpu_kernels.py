@@ -139,6 +139,29 @@ def test_rowlin_fwd_on_presplit_weight_planes(R, Ci, Co, monkeypatch):
     assert w._fqss_w3[0] == w._version and torch.equal(z2, K.rowlin_fwd(x, w, b))
 
 
+@pytest.mark.parametrize("rows,cols", [(37, 1000), (2048, 256)])
+def test_relu_behind_the_quantizer_in_its_pass(rows, cols):
+    """act = ACT_POST_RELU: relu(fq(z)) and its backward in ONE pass each way = the quantizer pass followed by a ReLU pass, bit for bit"""
+    from fqss_amd import ops
+    z, g = rnd(rows, cols, seed=1, scale=1.5).cuda(), rnd(rows, cols, seed=2).cuda()
+    lo, hi = torch.tensor([-0.9], device="cuda"), torch.tensor([1.7], device="cuda")
+    for qmode in (ops.Q_QUANT, ops.Q_OBSERVE):
+        oa, ob = (torch.tensor([-1, 0], dtype=torch.int32, device="cuda") for _ in range(2))
+        y1 = K.actq_fwd(z, K.ACT_NONE, None, qmode, lo, hi, ob)
+        y = K.actq_fwd(z, K.ACT_POST_RELU, None, qmode, lo, hi, oa)
+        assert torch.equal(y, K.actq_fwd(y1, K.ACT_RELU, None, ops.Q_BYPASS, lo, hi, None)) and torch.equal(oa, ob)
+        ga, gb = (torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda") for _ in range(2))
+        gz = K.actq_bwd(z, g, K.ACT_POST_RELU, None, qmode, lo, hi, ga)
+        g1 = K.actq_bwd(y1, g, K.ACT_RELU, None, ops.Q_BYPASS, lo, hi, None)
+        assert torch.equal(gz, K.actq_bwd(z, g1, K.ACT_NONE, None, qmode, lo, hi, gb))
+        if qmode == ops.Q_QUANT:
+            r = [torch.zeros(1, device="cuda") for _ in range(4)]
+            K.gacc_flush(ga, r[0], r[1], None)
+            K.gacc_flush(gb, r[2], r[3], None)
+            close(r[0], r[2], rtol=3e-4, atol=1e-6)      # (fp32 per-thread partial sums, grouped differently by the two launch shapes)
+            close(r[1], r[3], rtol=3e-4, atol=1e-6)
+
+
 def test_pwconv_split_gemms_against_fp64():
     """the channel-first pointwise GEMMs on the bf16 matrix cores (nine exact products, six products, and the batched k_gemm_x3 forms
     of the two gradients) against fp64: all at the level of an fp32 GEMM (torch's own result measured beside them)"""
