@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
     __shared__ double red[3 * 4];
     __shared__ float cb[16][64];
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    const bool post = act == FQSS_ACT_POST_RELU;
     QRange r{0.0f, 1.0f, 1.0f};
     if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
     float p_du = 0.0f, p_out = 0.0f, p_slope = 0.0f;
@@ -383,18 +384,21 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float gj = gv[j];
-                        const float t = act_apply(zv[j], act, slope);
+                        float gj = gv[j];
+                        const float t = post ? zv[j] : act_apply(zv[j], act, slope);
                         float gt = gj;
                         if (qmode == FQSS_Q_QUANT) {
                             float c, u;
                             bool inr;
-                            (void)fq_asym(t, r, c, u, inr);
+                            const float yq = fq_asym(t, r, c, u, inr);
+                            if (post && !(yq > 0.0f)) gj = 0.0f;          // FQSS_ACT_POST_RELU: the ReLU sits BEHIND the quantizer
                             gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
                             p_du += gj * (inr ? (c - u) : c);
                             p_out += inr ? 0.0f : gj;
+                        } else if (post && !(t > 0.0f)) {
+                            gt = 0.0f;
                         }
-                        o[j] = act_bwd(zv[j], gt, act, slope, true, p_slope);
+                        o[j] = post ? gt : act_bwd(zv[j], gt, act, slope, true, p_slope);
                         pb[j] += o[j];
                     }
                     *reinterpret_cast<float4*>(gz + row * ld_gz + f0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -708,7 +712,7 @@ extern "C" int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, 
     if (R == 0 || F == 0) return FQSS_OK;
     FQSS_REQUIRE(z && g && gz, "null tensor");     // gbias may be NULL: the row-tiled pass alone (narrow matrices, see fqss_actq_bwd)
     FQSS_REQUIRE(R > 0 && F > 0 && ld_z >= F && ld_g >= F && ld_gz >= F, "bad shape");
-    FQSS_REQUIRE(act >= 0 && act <= 2 && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(((act >= 0 && act <= 2) || act == FQSS_ACT_POST_RELU) && qmode >= 0 && qmode <= 2, "bad act/qmode");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");

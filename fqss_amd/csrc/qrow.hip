@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
         ry = load_qrange(g.qy_min, g.qy_max);
         if (g.act == FQSS_ACT_PRELU) slope = *g.slope;
     }
+    const bool post = g.y != nullptr && g.act == FQSS_ACT_POST_RELU;      // y = relu(fq(z)): the ReLU BEHIND the quantizer
     // results leave through a wave-private LDS tile as whole 128-B rows, 16 B per lane (the lane-per-column layout of the MFMA result needs
     // 16 strided 4-B stores per 32 x 32 tile and operand: this kernel is bound by writing z -- and now y); 16-B aligned output rows
     // only, the scalar form below serves the rest
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
                             for (int q = 0; q < 4; ++q) {
                                 float c, u;
                                 bool inr;
-                                yq[q] = fq_asym(act_apply(e[q], g.act, slope), ry, c, u, inr);
+                                { const float yv = fq_asym(post ? e[q] : act_apply(e[q], g.act, slope), ry, c, u, inr); yq[q] = (post && !(yv > 0.0f)) ? 0.0f : yv; }
                             }
                         }
                         if (ob + c4 + 3 < g.Co) {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
                     if (g.y != nullptr) {
                         float c, u;
                         bool inr;
-                        g.y[row * g.ld_y + o] = fq_asym(act_apply(v, g.act, slope), ry, c, u, inr);
+                        { const float yv = fq_asym(post ? v : act_apply(v, g.act, slope), ry, c, u, inr); g.y[row * g.ld_y + o] = (post && !(yv > 0.0f)) ? 0.0f : yv; }
                     }
                 }
             }
@@ -227,7 +228,8 @@ extern "C" int fqss_qrow_fwdq(const uint8_t* xc, const int8_t* wk, const float* 
     FQSS_REQUIRE(R >= 0 && Ci >= 16 && Ci % 16 == 0 && Ci <= 2048 && Co > 0 && ld_x >= Ci && ld_x % 16 == 0 && ld_z >= Co && ld_y >= Co,
                  "bad shape (Ci a multiple of 16, <= 2048; code rows 16-B aligned)");
     FQSS_REQUIRE(aligned16(xc) && aligned16(wk), "code images must be 16-B aligned");
-    FQSS_REQUIRE(act == FQSS_ACT_NONE || act == FQSS_ACT_RELU || (act == FQSS_ACT_PRELU && slope), "activation: none, ReLU or PReLU (with its slope)");
+    FQSS_REQUIRE(act == FQSS_ACT_NONE || act == FQSS_ACT_RELU || act == FQSS_ACT_POST_RELU || (act == FQSS_ACT_PRELU && slope),
+                 "activation: none, ReLU, PReLU (with its slope) or a ReLU behind the quantizer");
     if (R == 0) return FQSS_OK;
     QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, y, ld_y, act, slope, qmin_y, qmax_y};
     dim3 grid((unsigned)cdiv(Co, 128), (unsigned)cdiv(R, 128));

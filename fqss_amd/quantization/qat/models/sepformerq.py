@@ -78,10 +78,16 @@ class TransformerLayer(nn.Module):
             q, x_res = QL.add_layernorm(self.norm1, x, add)
         a = _float_mha(self.mha, q) if isinstance(self.mha, nn.MultiheadAttention) else self.mha(q, q, q)[0]
         h, x_res = QL.add_layernorm(self.norm2, x_res, a)
-        for m in self.ffn:
-            if isinstance(m, (nn.Dropout, nn.Identity)):
+        mods = [m for m in self.ffn if not isinstance(m, (nn.Dropout, nn.Identity))]
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, QL.LinearQ) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                h = m(h, post_relu=True)          # LinearQ -> nn.ReLU: the ReLU rides in the output quantizer's pass each way
+                i += 2
                 continue
             h = QL.fq_node(None, h, m) if isinstance(m, nn.ReLU) else run(m, h)
+            i += 1
         return x_res, h
 
 

@@ -709,18 +709,22 @@ FUSE_GELUQ = __import__("os").environ.get("FQSS_FUSE_GELUQ", "1") != "0"   # 0: 
 FUSE_ROWQ = __import__("os").environ.get("FQSS_FUSE_ROWQ", "1") != "0"    # 0: row linear, quantizer and bias sums as separate nodes (A/B, tests)
 
 
-def run_linear(lin, x, weight, nl, aq):
-    return linear_fq(x, weight, lin.bias, nl, aq)
+def run_linear(lin, x, weight, nl, aq, post_relu=False):
+    return linear_fq(x, weight, lin.bias, nl, aq, post_relu)
 
 
-def linear_fq(x, weight, bias, nl, aq):
-    """fq(nl(x @ weight^T + bias)) on row-major tensors: LinearQ / LinearNlQ and the attention output projection"""
+def linear_fq(x, weight, bias, nl, aq, post_relu=False):
+    """fq(nl(x @ weight^T + bias)) on row-major tensors: LinearQ / LinearNlQ and the attention output projection;
+    post_relu: relu(fq(...)) -- the caller's F.relu / nn.ReLU on the layer's output, in the quantizer's pass (act = ACT_POST_RELU)"""
     q = None
+    post_relu = post_relu and nl is None and FUSE_POSTRELU and ops.CODED
     if aq is not None and FUSE_ROWQ and bias is not None and weight.dim() == 2 and (nl is None or isinstance(nl, (nn.ReLU, nn.PReLU))):
         q = aq.qctx()
         if q.qmode == ops.Q_QUANT and q.gacc is not None and K.colbias_ok(weight.shape[0]):
             # quantizing phase: one node for linear + quantizer, the bias gradient rides in the quantizer's backward pass
             act, slope = _act_of(nl)
+            if post_relu:
+                act = K.ACT_POST_RELU
             qops = ops_dp.qrow_operands(x, weight)
             q.no_codes, q.carrier = True, False
             n = x.numel() // x.shape[-1] * weight.shape[0]
@@ -732,6 +736,8 @@ def linear_fq(x, weight, bias, nl, aq):
             aq.after_forward(q)
             q.idx = None
             return y
+    if post_relu:
+        return fq_node(aq, ops_dp.row_linear(x, weight, bias), q=q, post_relu=True)
     return fq_node(aq, ops_dp.row_linear(x, weight, bias), nl, q=q)
 
 
@@ -880,8 +886,9 @@ class LinearQ(LayerQ):
                          weight_shape=linear.weight.shape, act_n_bits=act_n_bits, weight_n_bits=weight_n_bits)
         self.linear = linear
 
-    def forward(self, x):
-        return run_linear(self.linear, x, self._wq(self.linear.weight), None, self.activation_fake_quantize)
+    def forward(self, x, post_relu=False):
+        """post_relu (not in the reference's signature): the caller's nn.ReLU on the output, folded into the output quantizer's pass"""
+        return run_linear(self.linear, x, self._wq(self.linear.weight), None, self.activation_fake_quantize, post_relu)
 
 
 class Conv2dQ(LayerQ):

@@ -365,3 +365,42 @@ def test_attention_forms_agree_on_a_quantizing_layer(monkeypatch):
         e = [float((a - b).norm() / b.norm()) for a, b in zip(res[form], ref)]
         print(form, "output / input gradient / parameter gradients:", e)
         assert e[0] <= 2e-3 and e[1] <= 5e-3 and e[2] <= 5e-3, (form, e)
+
+
+@pytest.mark.parametrize("coded_input", [True, False])
+def test_relu_behind_a_linear_rides_in_its_quantizer(coded_input, monkeypatch):
+    """B2-style gate: LinearQ -> nn.ReLU (the feed-forward pair of the Sepformer layer, sepformerq.py:63) with the ReLU folded into the
+    output quantizer's pass (act = ACT_POST_RELU: in the int8 GEMM's epilogue when the input carries codes, else in the quantizer
+    pass; the backward in fqss_actq_bwd_colbias) against linear + quantizer followed by a ReLU pass: output bit-identical, gradients
+    of the input, the weight, the bias and the ranges within fp32 summation noise"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    R, Ci, Co = 4000, 64, 256
+    x0, g0 = rnd(R, 1, Ci, seed=1).cuda(), rnd(R, 1, Co, seed=2).cuda()
+    res = {}
+    for kind in ("fused", "unfused"):
+        monkeypatch.setattr(QL, "FUSE_POSTRELU", kind == "fused")
+        torch.manual_seed(5)
+        ln = QL.LayerNormQ(nn.LayerNorm(Ci), gradient_based=True, act_quant=True).cuda()
+        lin = QL.LinearQ(nn.Linear(Ci, Co), gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8).cuda()
+        relu = nn.ReLU()
+
+        def fwd(x):
+            h = ln(x) if coded_input else x
+            if kind == "fused":
+                return lin(h, post_relu=True)
+            return QL.fq_node(None, lin(h), relu)
+        with torch.no_grad():
+            for _ in range(50):
+                fwd(x0)
+        x = x0.clone().requires_grad_(True)
+        y = fwd(x)
+        y.backward(g0)
+        aq = lin.activation_fake_quantize
+        res[kind] = (y.detach(), x.grad, lin.linear.weight.grad, lin.linear.bias.grad, aq.min_range.grad, aq.max_range.grad)
+        monkeypatch.undo()
+    f, u = res["fused"], res["unfused"]
+    assert torch.equal(f[0], u[0]) and float((f[0] == 0).float().mean()) > 0.2
+    for i, name in enumerate(("dx", "dW", "db", "min", "max"), start=1):
+        assert f[i] is not None and u[i] is not None, name
+        err = float((f[i] - u[i]).norm() / (u[i].norm() + 1e-12))
+        assert err <= 1e-4, (name, err)
