@@ -16,6 +16,8 @@ _PROTOS = {
     "fqss_obs_reset": [P, I64, P],
     "fqss_observer_ema": [P, P, P, F64, P],
     "fqss_actq_bwd": [P, P, P, I64, I64, I64, I64, I64, I32, P, I32, P, P, P, P, I64, P],
+    "fqss_gluq_fwd": [P, P, I64, I64, I64, I64, I64, I32, P, P, P, P],
+    "fqss_gluq_bwd": [P, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, P, P],
     "fqss_actq_bwd_colbias": [P, P, P, I64, I32, I64, I64, I64, I32, P, I32, P, P, P, P, P],
     "fqss_minmax": [P, I64, I64, I64, P, P],
     "fqss_wq_observe": [P, I64, I64, I64, P, P, P],

@@ -149,6 +149,105 @@ __global__ __launch_bounds__(256) void k_actq_fwd_narrow(const float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// fq(GLU(z)): nn.GLU(dim = 1) of a channel-first tensor [B][2C][M] in front of a quantizer (Conv1dNlQ / Conv2dNlQ with nl = GLU in the
+// HTDemucs layers, hdemucsq.py:126-127, 303-347) in ONE pass each way: t = z[b][c] * sigmoid(z[b][C + c]), out = fq(t) -- the
+// operations of k_glu_fwd / k_glu_bwd (csrc/dualpath.hip) followed by k_actq_fwd / k_actq_bwd, without the [B][C][M] round trip in
+// between.  16-B aligned rows (float4 per lane; the tail of a row lies in its own padding).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gluq_fwd(const float* __restrict__ z, float* __restrict__ out, int64_t B, int64_t C, int64_t M,
+                                                   int64_t ld_z, int64_t ld_o, int qmode, const float* __restrict__ qmin,
+                                                   const float* __restrict__ qmax, uint32_t* obs) {
+    QRange r{0.0f, 1.0f, 1.0f};
+    if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int64_t row = blockIdx.y; row < B * C; row += gridDim.y) {
+        const int64_t b = row / C, c = row - b * C;
+        const float* pa = z + (b * 2 * C + c) * ld_z;
+        const float* pg = z + (b * 2 * C + C + c) * ld_z;
+        float* po = out + row * ld_o;
+        for (int64_t m0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; m0 < M; m0 += (int64_t)gridDim.x * 1024) {
+            const float4 a4 = *reinterpret_cast<const float4*>(pa + m0), g4 = *reinterpret_cast<const float4*>(pg + m0);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = av[j] * (1.0f / (1.0f + expf(-gv[j])));
+                if (qmode == FQSS_Q_QUANT) {
+                    float cc, u;
+                    bool inr;
+                    o[j] = fq_asym(t, r, cc, u, inr);
+                } else {
+                    o[j] = t;
+                    if (qmode == FQSS_Q_OBSERVE && m0 + j < M) {
+                        vmin = fminf(vmin, t);
+                        vmax = fmaxf(vmax, t);
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(po + m0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (qmode == FQSS_Q_OBSERVE) {
+        vmin = wave_min(vmin);
+        vmax = wave_max(vmax);
+        if ((threadIdx.x & 63) == 0) {
+            const uint32_t kmin = f2ord(vmin), kmax = f2ord(vmax);
+            if (kmin < __hip_atomic_load(&obs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&obs[0], kmin);
+            if (kmax > __hip_atomic_load(&obs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&obs[1], kmax);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gluq_bwd(const float* __restrict__ z, const float* __restrict__ g, float* __restrict__ gz, int64_t B,
+                                                   int64_t C, int64_t M, int64_t ld_z, int64_t ld_g, int64_t ld_gz, int qmode,
+                                                   const float* __restrict__ qmin, const float* __restrict__ qmax, double* gacc) {
+    __shared__ double red[2 * 4];
+    QRange r{0.0f, 1.0f, 1.0f};
+    if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
+    float p_du = 0.0f, p_out = 0.0f;
+    for (int64_t row = blockIdx.y; row < B * C; row += gridDim.y) {
+        const int64_t b = row / C, c = row - b * C;
+        const int64_t ra = b * 2 * C + c, rg = ra + C;
+        for (int64_t m0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; m0 < M; m0 += (int64_t)gridDim.x * 1024) {
+            const float4 a4 = *reinterpret_cast<const float4*>(z + ra * ld_z + m0), g4 = *reinterpret_cast<const float4*>(z + rg * ld_z + m0);
+            const float4 y4 = *reinterpret_cast<const float4*>(g + row * ld_g + m0);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+            float oa[4], og[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool valid = m0 + j < M;
+                const float sg = 1.0f / (1.0f + expf(-gv[j]));
+                const float gj = valid ? yv[j] : 0.0f;
+                float gt = gj;
+                if (qmode == FQSS_Q_QUANT) {
+                    float cc, u;
+                    bool inr;
+                    (void)fq_asym(av[j] * sg, r, cc, u, inr);
+                    gt = inr ? div_by(gj * r.delta, r.delta, r.inv) : 0.0f;
+                    p_du += valid ? gj * (inr ? (cc - u) : cc) : 0.0f;
+                    p_out += (valid && !inr) ? gj : 0.0f;
+                }
+                oa[j] = gt * sg;
+                og[j] = ((gt * av[j]) * (1.0f - sg)) * sg;
+            }
+            *reinterpret_cast<float4*>(gz + ra * ld_gz + m0) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+            *reinterpret_cast<float4*>(gz + rg * ld_gz + m0) = make_float4(og[0], og[1], og[2], og[3]);
+        }
+    }
+    if (qmode == FQSS_Q_QUANT) {
+        double v[2] = {(double)p_du, (double)p_out};
+        block_sum<double, 2>(v, red);
+        if (threadIdx.x == 0) {
+            double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+            const double dmax = v[0] / 255.0;
+            slot[0] += v[1] - dmax;
+            slot[1] += dmax;
+        }
+    }
+}
+
 __global__ void k_obs_reset(uint32_t* obs, int64_t n_pairs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pairs) {
@@ -762,4 +861,40 @@ extern "C" int fqss_wq_bwd(const float* w, const float* g, float* gw, float* gmi
     hipLaunchKernelGGL(k_wq_bwd, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, w, g, gw, gmin, gmax, outer, C,
                        inner, qmin, qmax, accumulate);
     return launch_status("fqss_wq_bwd");
+}
+
+static bool gluq_rows_ok(const void* a, const void* b, int64_t lda, int64_t ldb, int64_t M) {
+    return aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && lda >= ((M + 3) & ~(int64_t)3) && ldb >= ((M + 3) & ~(int64_t)3);
+}
+
+extern "C" int fqss_gluq_fwd(const float* z, float* out, int64_t B, int64_t C, int64_t M, int64_t ld_z, int64_t ld_out, int qmode,
+                             const float* qmin, const float* qmax, uint32_t* obs_ws, fqss_stream_t stream) {
+    if (B * C * M == 0) return FQSS_OK;
+    FQSS_REQUIRE(z && out && B > 0 && C > 0 && M > 0 && qmode >= 0 && qmode <= 2, "bad args");
+    FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
+    FQSS_REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
+    FQSS_REQUIRE(gluq_rows_ok(z, out, ld_z, ld_out, M), "rows must be 16-B aligned and padded to a multiple of 4");
+    int64_t gx = cdiv(M, 1024);
+    if (gx > 64) gx = 64;
+    int64_t gy = 4096 / gx;
+    if (gy > B * C) gy = B * C;
+    hipLaunchKernelGGL(k_gluq_fwd, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, z, out, B, C, M, ld_z, ld_out, qmode, qmin,
+                       qmax, obs_ws);
+    return launch_status("fqss_gluq_fwd");
+}
+
+extern "C" int fqss_gluq_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t C, int64_t M, int64_t ld_z, int64_t ld_g,
+                             int64_t ld_gz, int qmode, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+    if (B * C * M == 0) return FQSS_OK;
+    FQSS_REQUIRE(z && g && gz && B > 0 && C > 0 && M > 0 && qmode >= 0 && qmode <= 2, "bad args");
+    FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax && gacc), "QUANT needs ranges and gacc");
+    FQSS_REQUIRE(gluq_rows_ok(z, g, ld_z, ld_g, M) && gluq_rows_ok(z, gz, ld_z, ld_gz, M), "rows must be 16-B aligned and padded to a multiple of 4");
+    int64_t gx = cdiv(M, 1024);
+    if (gx > 64) gx = 64;
+    int64_t gy = kGaccSlots / gx;
+    if (gy > B * C) gy = B * C;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(k_gluq_bwd, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, z, g, gz, B, C, M, ld_z, ld_g, ld_gz, qmode,
+                       qmin, qmax, gacc);
+    return launch_status("fqss_gluq_bwd");
 }

@@ -1430,6 +1430,35 @@ def glu_bwd(x, gy):
     return gx
 
 
+def gluq_rows_ok(x):
+    """fq(GLU(x)) in one pass needs 16-B aligned rows padded to a multiple of 4 (activation buffers of empty_act are)"""
+    rm = rowmat(x) if x.dim() == 3 else None
+    return rm is not None and rm[2] % 4 == 0 and x.data_ptr() % 16 == 0 and rm[2] >= (x.shape[-1] + 3) // 4 * 4
+
+
+def gluq_fwd(x, qmode, qmin, qmax, obs_ws):
+    """x [B, 2C, M] -> fq(GLU(x)) [B, C, M] (qmode QUANT), GLU(x) with the observer's min / max (OBSERVE) or plain GLU (BYPASS)"""
+    _need_gpu(x)
+    x, B, C2, M, ld_x = _bcm(x)
+    assert C2 % 2 == 0
+    y = empty_act((B, C2 // 2, M), x.device)
+    _lib.call("fqss_gluq_fwd", _p(x), _p(y), B, C2 // 2, M, ld_x, rowmat(y)[2], qmode, _p(qmin), _p(qmax), _p(obs_ws), _stream())
+    return y
+
+
+def gluq_bwd(x, g, qmode, qmin, qmax, gacc):
+    _need_gpu(x, g)
+    x, B, C2, M, ld_x = _bcm(x)
+    g, _, _, _, ld_g = _bcm(g)
+    if ld_g % 4 != 0 or g.data_ptr() % 16 != 0:
+        gp = empty_act(tuple(g.shape), g.device)
+        gp.copy_(g)
+        g, ld_g = gp, rowmat(gp)[2]
+    gx = empty_act((B, C2, M), x.device)
+    _lib.call("fqss_gluq_bwd", _p(x), _p(g), _p(gx), B, C2 // 2, M, ld_x, ld_g, rowmat(gx)[2], qmode, _p(qmin), _p(qmax), _p(gacc), _stream())
+    return gx
+
+
 def div_fwd(a, b):
     _need_gpu(a, b)
     assert a.shape == b.shape

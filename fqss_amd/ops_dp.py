@@ -585,6 +585,33 @@ class Glu(Function):
         return K.glu_bwd(x, g)
 
 
+class GluActQ(Function):
+    """fq(nn.GLU(dim=1)(x)) on channel-first [B, 2C, M] as ONE pass each way (fqss_gluq_fwd / _bwd): the GLU map of a Conv*NlQ layer
+    inside its activation quantizer's pass (quantizing or observer phase; the float modules keep the plain map)"""
+
+    @staticmethod
+    def forward(ctx, x, qmin, qmax, q):
+        y = K.gluq_fwd(x, q.qmode, q.qmin, q.qmax, q.obs_ws)
+        q.carrier, q.idx = False, None
+        ctx.save_for_backward(x)
+        ctx.q = q
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        q = ctx.q
+        quant = q.qmode == ops.Q_QUANT
+        gacc = None
+        if quant:
+            gacc = q.gacc if q.gacc is not None else torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=x.device)
+        gx = K.gluq_bwd(x, g, q.qmode, q.qmin, q.qmax, gacc)
+        g_min = g_max = None
+        if quant:
+            g_min, g_max = ops._ranges_after(q, gacc)
+        return gx, g_min, g_max, None
+
+
 class DivEw(Function):
     """torch.div(x1, x2), same shape"""
 

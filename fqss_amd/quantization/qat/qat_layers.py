@@ -674,6 +674,18 @@ def fq_node(aq, x, nl=None, codes=False, q=None, post_relu=False):
             aq.after_forward(q)
         q.idx = None
         return y if flat is None else y.reshape(x.shape)
+    if FUSE_GLUQ and ops.CODED and isinstance(nl, nn.GLU) and nl.dim == 1 and aq is not None and not codes and torch.is_tensor(x) and x.dim() >= 3:
+        # GLU rides in the quantizer's own pass each way (fqss_gluq_fwd / _bwd) in the quantizing and the observer phase
+        if q is None:
+            q = aq.qctx()
+        xr = ops.real(x)
+        x3 = xr.reshape(xr.shape[0], xr.shape[1], -1)
+        if q.qmode != ops.Q_BYPASS and K.gluq_rows_ok(x3):
+            q.no_codes = True
+            y = ops_dp.GluActQ.apply(x3, q.qmin, q.qmax, q)
+            aq.after_forward(q)
+            q.idx = None
+            return y.reshape(xr.shape[0], xr.shape[1] // 2, *xr.shape[2:])
     gelu = FUSE_GELUQ and ops.CODED and isinstance(nl, nn.GELU) and getattr(nl, "approximate", "none") == "none"
     if gelu:
         nl = None             # GELU rides in the quantizer's own pass each way (act = ACT_GELU: fqss_actq_fwd / _bwd)
@@ -705,6 +717,7 @@ def fq_node(aq, x, nl=None, codes=False, q=None, post_relu=False):
 
 
 FUSE_POSTRELU = __import__("os").environ.get("FQSS_FUSE_POSTRELU", "1") != "0"   # 0: the ReLU behind LSTMQ's quantizer as its own pass
+FUSE_GLUQ = __import__("os").environ.get("FQSS_FUSE_GLUQ", "1") != "0"     # 0: GLU as its own pass in front of the quantizer (A/B, tests)
 FUSE_GELUQ = __import__("os").environ.get("FQSS_FUSE_GELUQ", "1") != "0"   # 0: GELU as its own pass in front of the quantizer (A/B, tests)
 FUSE_ROWQ = __import__("os").environ.get("FQSS_FUSE_ROWQ", "1") != "0"    # 0: row linear, quantizer and bias sums as separate nodes (A/B, tests)
 

@@ -84,6 +84,14 @@ int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64
                   int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act, const float* slope, int qmode,
                   const float* qmin, const float* qmax, double* gacc, float* gbias, int64_t C,
                   fqss_stream_t stream);
+/* fq(GLU(z)): nn.GLU(dim = 1) of a channel-first tensor z [B][2C][M] in front of an activation quantizer (Conv1dNlQ / Conv2dNlQ /
+ * ConvTranspose*NlQ with nl = GLU in the HTDemucs layers, qat_layers.py:198-293, hdemucsq.py:126-127), one pass each way:
+ * out [B][C][M] = fq(z[b][c] * sigmoid(z[b][C + c])); backward gz [B][2C][M] from g [B][C][M], range partials to gacc (QUANT).
+ * Rows 16-B aligned and padded to a multiple of 4 floats.  qmode as fqss_actq_fwd. */
+int fqss_gluq_fwd(const float* z, float* out, int64_t B, int64_t C, int64_t M, int64_t ld_z, int64_t ld_out, int qmode,
+                  const float* qmin, const float* qmax, uint32_t* obs_ws, fqss_stream_t stream);
+int fqss_gluq_bwd(const float* z, const float* g, float* gz, int64_t B, int64_t C, int64_t M, int64_t ld_z, int64_t ld_g,
+                  int64_t ld_gz, int qmode, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream);
 
 /* out_k += (float) sum_slots gacc[slot][k] for the non-null outputs (k = 0 min, 1 max, 2 slope), then
  * gacc = 0: hands the fp64 range/slope partials of fqss_actq_bwd over to fp32 parameter gradients */

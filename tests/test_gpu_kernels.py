@@ -162,6 +162,30 @@ def test_relu_behind_the_quantizer_in_its_pass(rows, cols):
             close(r[1], r[3], rtol=3e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,M", [(3, 5, 1001), (2, 48, 4100), (1, 7, 64)])
+def test_glu_in_the_quantizer_pass(B, C, M):
+    """fqss_gluq_fwd / _bwd: fq(GLU(z)) in one pass each way = k_glu_fwd / _bwd around the quantizer pass, bit for bit (outputs, input
+    gradient, observer extrema; the range partials within fp32 summation noise)"""
+    from fqss_amd import ops
+    z, g = padded(rnd(B, 2 * C, M, seed=1, scale=1.5)), padded(rnd(B, C, M, seed=2))
+    lo, hi = torch.tensor([-0.4], device="cuda"), torch.tensor([1.1], device="cuda")
+    t = K.glu_fwd(z)
+    for qmode in (ops.Q_QUANT, ops.Q_OBSERVE):
+        oa, ob = (torch.tensor([-1, 0], dtype=torch.int32, device="cuda") for _ in range(2))
+        y = K.gluq_fwd(z, qmode, lo, hi, oa)
+        assert torch.equal(y, K.actq_fwd(t, K.ACT_NONE, None, qmode, lo, hi, ob)) and torch.equal(oa, ob)
+        ga, gb = (torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device="cuda") for _ in range(2))
+        gz = K.gluq_bwd(z, g, qmode, lo, hi, ga)
+        gt = K.actq_bwd(t, g, K.ACT_NONE, None, qmode, lo, hi, gb)
+        assert torch.equal(gz, K.glu_bwd(z, gt))
+        if qmode == ops.Q_QUANT:
+            r = [torch.zeros(1, device="cuda") for _ in range(4)]
+            K.gacc_flush(ga, r[0], r[1], None)
+            K.gacc_flush(gb, r[2], r[3], None)
+            close(r[0], r[2], rtol=3e-4, atol=1e-6)
+            close(r[1], r[3], rtol=3e-4, atol=1e-6)
+
+
 def test_pwconv_split_gemms_against_fp64():
     """the channel-first pointwise GEMMs on the bf16 matrix cores (nine exact products, six products, and the batched k_gemm_x3 forms
     of the two gradients) against fp64: all at the level of an fp32 GEMM (torch's own result measured beside them)"""
