@@ -6,5 +6,5 @@ timeout -k 10 900 python -m pytest tests/test_gpu_htdemucs.py tests/test_gpu_dpt
 tail -2 gpurun_out/r13_hd.log
 python bench.py --workload cfg5 --steps 6 --warmup 3 --no-cpu-baseline > gpurun_out/r13_cfg5.json 2> gpurun_out/r13_cfg5.err || { tail -20 gpurun_out/r13_cfg5.err; exit 1; }
 python -c "import json;d=json.loads(open('gpurun_out/r13_cfg5.json').read().strip().splitlines()[-1]);print('cfg5',d['ms_per_step'])"
-FQSS_FUSE_GLUQ=0 python bench.py --workload cfg5 --steps 6 --warmup 3 --no-cpu-baseline > gpurun_out/r13_cfg5b.json 2> gpurun_out/r13_cfg5b.err
-python -c "import json;d=json.loads(open('gpurun_out/r13_cfg5b.json').read().strip().splitlines()[-1]);print('cfg5 GLU as its own pass',d['ms_per_step'])"
+true
+true
