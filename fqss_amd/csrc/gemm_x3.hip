@@ -389,8 +389,8 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
                     for (int r = 0; r < 16; ++r) Tt[(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[mi][ni][r];
                     __builtin_amdgcn_wave_barrier();
                     const int col = j0 + wn * (32 * NI) + ni * 32 + c4;
-                    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (g.bias_col != nullptr && col + 3 < g.N) bc = *reinterpret_cast<const float4*>(g.bias_col + col);
+                    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);      // (scalar loads: a bias vector may sit at any 4-B aligned address)
+                    if (g.bias_col != nullptr && col + 3 < g.N) bc = make_float4(g.bias_col[col], g.bias_col[col + 1], g.bias_col[col + 2], g.bias_col[col + 3]);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int rl = rq + 8 * it, row = i0 + wm * (32 * MI) + mi * 32 + rl;
