@@ -8,6 +8,8 @@
 // Reference replaced: F.layer_norm in LayerNormQ (qat_layers.py:455-465); torch.tanh / torch.sigmoid of Conv1dNlQ
 // (dptnetq.py:286-287); q / sqrt(head_dim) (qat_layers.py:905); split_feature / merge_feature (dptnetq.py:232-276);
 // overlap_and_add with a 2-tap frame (dptnetq.py:17-58, 140); bias gradients (column sums) of the row linears.
+#include <stdlib.h>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -926,7 +928,12 @@ static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, 
     const bool vec = C % 4 == 0 && ld_gy % 4 == 0 && ld_x % 4 == 0 && ld_gx % 4 == 0 && aligned16(gy) && aligned16(x) && aligned16(gx) &&
                      aligned16(gamma) && (beta == nullptr || aligned16(beta)) && (gadd == nullptr || (ld_ga % 4 == 0 && aligned16(gadd)));
     const bool narrow = vec && C <= 64;
-    int64_t nb = cdiv(R, narrow ? 4 * 8 * 4 : 4 * 16);       // ~16 rows per wave (narrow: 8 groups of 4): 64*C atomics per workgroup stay rare
+    // rows per wave: a trade between waves in flight (16 k rows x 256 features at 16 rows per wave leave ONE wave per SIMD: the pass is
+    // latency-bound) and the 2 C atomics per workgroup.  Measured at the step level (FQSS_LN_BWD_ROWS sweep): 8 rows per wave for the wide
+    // rows (cfg 4 29.0 -> 28.7 ms; 4: 28.8, 2: 29.6), 8 groups of four for the 64-wide rows of cfg 3 (fewer is slower there)
+    static const int rpw_env = [] { const char* e = getenv("FQSS_LN_BWD_ROWS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int rpw = rpw_env > 0 ? rpw_env : (narrow ? 16 : 8);
+    int64_t nb = cdiv(R, narrow ? 4 * (rpw / 2 > 0 ? rpw / 2 : 1) * 4 : 4 * rpw);
     if (nb < 1) nb = 1;
     if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
 #define FQSS_LN_BWD(JC, Q, ...) \
