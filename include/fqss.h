@@ -60,7 +60,8 @@ int fqss_selftest_div(const float* a, int64_t n, float b, uint64_t* mismatches, 
  *           autograd of both; nn.PReLU / F.relu in front (qat_layers.py:211, 517)
  * ------------------------------------------------------------------------------------------- */
 
-/* out = fq(act(z)).  idx (optional, u8 [rows][ld_idx]) receives the integer bin index (the codes
+/* out = fq(act(z)); act: FQSS_ACT_NONE / PRELU / RELU, FQSS_ACT_GELU (erf form, nn.GELU of the HTDemucs layers) or
+ * FQSS_ACT_POST_RELU (out = relu(fq(z)): the ReLU sits BEHIND the quantizer, dptnetq.py:92).  idx (optional, u8 [rows][ld_idx]) receives the integer bin index (the codes
  * the q-GEMMs / coded layers consume); with idx given, out may be NULL (codes-only fast path).  OBSERVE: out = act(z) and obs_ws[0..1] (ordered-uint min / max) are updated. */
 int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_t cols,
                   int64_t ld_z, int64_t ld_out, int64_t ld_idx, int act, const float* slope, int qmode,
