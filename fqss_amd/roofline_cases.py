@@ -194,3 +194,48 @@ def roofline_object(g, traffic=None):
     else:
         out.update(achieved=round(gbps, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBS, 4))
     return out
+
+
+def build_other(dev, sets=2):
+    """the kernels named by the `roofline` objects of cfg 3 / 4 / 5 (bench.py) at their live shapes, for the same PMC passes
+    (tools/roofline_probe.py --set other): same dict layout as build()"""
+    cases = []
+
+    def case(kernel, label, bound, launches, rd, wr, fn, flops=0.0):
+        cases.append(dict(kernel=kernel, label=label, bound=bound, launches=launches, flops=flops, rd=float(rd), wr=float(wr), bytes=float(rd + wr),
+                          survey=float(rd + wr), fn=fn, group=False))
+    R = range(sets)
+    # cfg 3: BiLSTM recurrence of the intra-chunk path, S = 250 steps x 194 sequences, H = 128 (saves its gate activations for the BPTT)
+    S, Bq, H = 250, 194, 128
+    pre = [torch.randn(S, Bq, 8 * H, device=dev) * 0.1 for _ in R]
+    whh, bhh = torch.randn(2, 4 * H, H, device=dev) * 0.05, torch.zeros(2, 4 * H, device=dev)
+    n = S * Bq
+    case("k_lstm_fwd<128>", "cfg 3: BiLSTM recurrence 250 steps x 194 sequences (both directions), saving gates and cell states", "mfma", 24,
+         4.0 * n * 8 * H, 4.0 * n * (2 * H + 8 * H + 4 * H), lambda i: K.lstm_fwd(pre[i % sets], whh, bhh, S, Bq, H), flops=2.0 * 2 * 4 * H * H * n)
+    # cfg 4: weight gradient of the student's coded feed-forward linear, 16 000 rows x 256 -> 1024
+    rows, Ci, Co = 16000, 256, 1024
+    gz = [torch.randn(rows, Co, device=dev) for _ in R]
+    xc = [torch.randint(0, 256, (rows, Ci), device=dev, dtype=torch.uint8) for _ in R]
+    lo, hi = torch.tensor([-1.0], device=dev), torch.tensor([1.0], device=dev)
+    gw = torch.zeros(Co, Ci, device=dev)
+    case("k_gemm_x3", "cfg 4: coded weight gradient 16000 x 256 -> 1024 (gz fp32, input codes u8, split-K atomics into gw)", "mfma", 128,
+         4.0 * rows * Co + rows * Ci, 4.0 * Co * Ci, lambda i: K.qrow_bwd_w(gz[i % sets], xc[i % sets], lo, hi, gw), flops=2.0 * rows * Ci * Co)
+    # cfg 5: six-product pointwise GEMM over the frames of the level-0 rewrite conv, 4 x (144 -> 96) x 110250
+    Bh, Kk, Cq, Mh = 4, 144, 96, 110250
+    f = [K.empty_act((Bh, Kk, Mh), dev).normal_() for _ in R]
+    w, b = torch.randn(Cq, Kk, 1, device=dev) * 0.1, torch.zeros(Cq, device=dev)
+    case("k_qgemm<3>", "cfg 5: frame GEMM of the level-0 rewrite conv 4 x (48 x 3 -> 96) x 110250, six bf16 products", "mfma", 67,
+         4.0 * Bh * Kk * Mh, 4.0 * Bh * Cq * Mh, lambda i: K.pwconv_fwd(f[i % sets], w, b, six=True), flops=2.0 * Bh * Cq * Kk * Mh)
+    # cfg 5: streaming attention, spectrogram branch self-attention 4 x 8 heads x 3448^2 x 64: float operands (teacher), coded (student)
+    Ba, nh, L, hd = 4, 8, 3448, 64
+    E = nh * hd
+    q, k, v = ([torch.randn(Ba, L, E, device=dev) * 0.3 for _ in R] for _ in range(3))
+    qc, kc, vc = ([torch.randint(0, 256, (Ba, L, E), device=dev, dtype=torch.uint8) for _ in R] for _ in range(3))
+    rng = [(torch.tensor([-0.9], device=dev), torch.tensor([0.8], device=dev)) for _ in range(3)]
+    na = Ba * L * E
+    fa = 4.0 * L * L * hd * Ba * nh
+    case("k_attn_long_fwd_x3<64>", "cfg 5: attention forward, float operands split in bf16 pieces (q, k, v read once, o + stats written)", "mfma", 10,
+         4.0 * 3 * na, 4.0 * na + 8.0 * Ba * nh * L, lambda i: K.attn_long_fwd(q[i % sets], k[i % sets], v[i % sets], nh, True), flops=fa)
+    case("k_attn_long_fwd_c<64>", "cfg 5: attention forward on the u8 codes of q, k, v", "mfma", 10,
+         3.0 * na, 4.0 * na + 8.0 * Ba * nh * L, lambda i: K.attn_long_fwd_c(qc[i % sets], kc[i % sets], vc[i % sets], rng, nh, True), flops=fa)
+    return cases

@@ -22,3 +22,9 @@ python3 tools/roofline_probe.py --reduce "$(find $O/rl_fetch -name '*counter_col
 rm -rf $O/rl_fetch $O/rl_write
 python3 bench.py > $O/${R}_bench_line.json 2> $O/bench2.err
 ls -la $O
+# the roofline kernels of cfg 3 / 4 / 5 under the same two counter passes
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/rl2_fetch -- python3 tools/roofline_probe.py --set other > $O/rl2_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/rl2_write -- python3 tools/roofline_probe.py --set other > $O/rl2_write.log 2>&1
+python3 tools/roofline_probe.py --reduce "$(find $O/rl2_fetch -name '*counter_collection.csv' | head -1)" "$(find $O/rl2_write -name '*counter_collection.csv' | head -1)" \
+    gpurun_out/rl_manifest.json $O/${R}_pmc_traffic_cfg345.json > $O/${R}_pmc_traffic_cfg345.txt
+rm -rf $O/rl2_fetch $O/rl2_write

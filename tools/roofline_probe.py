@@ -18,11 +18,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ITERS = 6
 
 
-def run():
+def run(which="cfg2"):
     import torch
     from fqss_amd import roofline_cases as RC
     dev = torch.device("cuda", 0)
-    cases = RC.build(dev)
+    cases = RC.build(dev) if which == "cfg2" else RC.build_other(dev)      # --set other: the roofline kernels of cfg 3 / 4 / 5
     torch.cuda.synchronize()
     manifest = []
     for c in cases:
@@ -41,6 +41,8 @@ def _members(kernel):
     ("fqss::k_qgemm<1, 3>(...)"), so the match is on the symbol, bounded on both sides ("k_qwgrad" must not match "k_qwgrad2")"""
     if kernel.startswith("k_gnq_bwd_rows+apply"):
         return ["k_gnq_bwd_rows", "k_gnq_bwd_apply"]
+    if kernel == "k_qgemm<3>":
+        return ["k_qgemm"]
     return [kernel.split("<")[0]]
 
 
@@ -112,5 +114,7 @@ def reduce(fetch_csv, write_csv, manifest_json, out_json):
 if __name__ == "__main__":
     if len(sys.argv) >= 6 and sys.argv[1] == "--reduce":
         reduce(*sys.argv[2:6])
+    elif len(sys.argv) >= 3 and sys.argv[1] == "--set":
+        run(sys.argv[2])
     else:
         run()
