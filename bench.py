@@ -141,6 +141,22 @@ def _time_launches(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def _pmc_other(key, shape_token):
+    """HBM bytes per launch (2 FETCH_SIZE + WRITE_SIZE, separate --pmc passes) of a cfg 3 / 4 / 5 roofline kernel from the newest committed
+    profiles/r*_pmc_traffic_cfg345.json (tools/roofline_probe.py --set other); the case must have been measured at THIS shape
+    (`shape_token` occurs in its label), else None"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic_cfg345.json")), reverse=True):
+        try:
+            cases = json.load(open(path))["cases"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for c in cases:
+            if c.get("kernel") == key and shape_token in c.get("label", ""):
+                return int(c["traffic_x2"])
+    return None
+
+
 def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
     """`roofline` of a dual-path workload = the kernel with the largest time per step in the committed steady-state table
     (profiles/r03_cfg3_step_table.txt: k_lstm_fwd<128>, 24 % of the GPU time; profiles/r03_cfg4_step_table.txt: the coded weight-gradient
@@ -156,7 +172,7 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
         tf = flops / us * 1e-6
         return {"kernel": "k_lstm_fwd<128>", "what": "BiLSTM recurrence of the intra-chunk path (both directions)", "shape": [S, Bq, H],
                 "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 24, "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-                "frac": round(tf / 157.3, 3), "traffic": None,
+                "frac": round(tf / 157.3, 3), "traffic": _pmc_other("k_lstm_fwd<128>", f"{S} steps x {Bq} sequences"),
                 "note": "fp32 FMA issue + 2 barriers per time step bound; with 194 / 250 sequences per launch an MFMA form (>= 16 sequences per "
                         "workgroup) leaves < 16 workgroups on 256 CUs and is slower (DESIGN.md 7)"}
     # cfg 4 (profiles/r03_cfg4_step_table.txt): the weight gradient of the student's coded linears, k_gemm_x3<false, false, true, 2, 2, 1> --
@@ -169,7 +185,8 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
     tf = 2.0 * rows * Ci * Co / us * 1e-6
     return {"kernel": "k_gemm_x3<false, false, true, 2, 2, 1> (fqss_qrow_bwd_w)", "what": "weight gradient of the " + what + " on the input's codes",
             "shape": [rows, Ci, Co], "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 128, "achieved": round(tf, 1), "peak": 157.3,
-            "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": None, "issued_bf16_TFLOPs": round(3 * tf, 1),
+            "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": _pmc_other("k_gemm_x3", f"{rows} x {Ci} -> {Co}"),
+            "issued_bf16_TFLOPs": round(3 * tf, 1),
             "frac_of_issued_peak": round(3 * tf / 2500.0, 4),
             "note": "fp32 arithmetic priced against the fp32 matrix peak; executed as 3 bf16 products per term (issued rate against the 2.5 PF "
                     "dense bf16 peak beside it); bound by vector-ALU issue of the operand split and by the split-K atomics (DESIGN.md 7e (4))"}
@@ -312,7 +329,8 @@ def htdemucs_roofline(B, nh, L, hd):
     ta = 4.0 * L * L * hd * B * nh * 1e-6
     return {"kernel": "k_qgemm<3, 2> (fqss_pwconv_fwd_x3s)", "what": "pointwise GEMM over the frames of the level-0 rewrite conv (48 x 3 -> 96)",
             "shape": [B, Kk, Co, M], "bound": "mfma", "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(tf / 157.3, 3), "traffic": None, "algorithmic_bytes_per_launch": int(by), "hbm_frac": round(by / us * 1e-3 / 8000.0, 3),
+            "frac": round(tf / 157.3, 3), "traffic": _pmc_other("k_qgemm<3>", f"{B} x (48 x 3 -> {Co}) x {M}"), "algorithmic_bytes_per_launch": int(by),
+            "hbm_frac": round(by / us * 1e-3 / 8000.0, 3),
             "issued_bf16_TFLOPs": round(6 * tf, 1), "frac_of_issued_peak": round(6 * tf / 2500.0, 4),
             "other_kernels": [
                 {"kernel": "k_attn_long_fwd_x3<%d, false>" % hd, "what": "self-attention of the spectrogram branch, float operands (teacher)",

@@ -549,6 +549,22 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_mfma(const float* __re
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id; every XCD has its own 4 MB L2.  With blockIdx.x = query block the 27
+// blocks that stream the SAME K / V of a head land on 8 different L2s, and 32 heads x 1.8 MB do not fit any of them: PMC showed 4.7x the
+// algorithmic bytes fetched (profiles/r03_pmc_traffic_cfg345.txt).  Remapped: linear id l -> XCD l % 8, slot l / 8; the heads h with
+// h % 8 == XCD are walked block by block inside that XCD.  (Grids whose head count is not a multiple of 8 keep the plain map.)
+__device__ __forceinline__ void al_block(int& bx, int& by) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    if ((ny & 7) == 0) {
+        const int lin = blockIdx.y * nx + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        by = (slot / nx) * 8 + xcd;
+        bx = slot - (slot / nx) * nx;
+    } else {
+        bx = blockIdx.x;
+        by = blockIdx.y;
+    }
+}
+
 __device__ __forceinline__ int krow(int r, int lk) { return 16 * (r >> 3) + 8 * lk + (r & 7); }
 __device__ __forceinline__ int kappa(int c) { return (c & 16) + 8 * ((c >> 2) & 1) + (c & 3) + 4 * ((c >> 3) & 1); }
 __device__ __forceinline__ float al_trunc(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
@@ -677,9 +693,11 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_x3(const float* __restric
     __shared__ __attribute__((aligned(16))) float scs[4][32];
     constexpr float kLazy = 8.0f;
     x3_zero_planes<HD, LD>(Vp);
-    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    int bx, bh;
+    al_block(bx, bh);          // XCD-aware: the query (key) blocks of one head share an XCD's L2
+    const int b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
-    const int it = blockIdx.x * 4 + wave;
+    const int it = bx * 4 + wave;
     const int i_own = it * 32 + c;
     const bool live = i_own < g.Lq;
     const float* qp = q + (int64_t)(live ? i_own : g.Lq - 1) * g.q.sl + (int64_t)b * g.q.sb + h * HD;
@@ -810,9 +828,11 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_q_x3(const float* __restr
     __shared__ __attribute__((aligned(16))) unsigned short Kp[3][32][LD];
     __shared__ __attribute__((aligned(16))) unsigned short Vp[3][32][LD];
     x3_zero_planes<HD, LD>(Kp);
-    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    int bx, bh;
+    al_block(bx, bh);          // XCD-aware: the query (key) blocks of one head share an XCD's L2
+    const int b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
-    const int it = blockIdx.x * 4 + wave;
+    const int it = bx * 4 + wave;
     const int i_own = it * 32 + c;
     const bool live = i_own < g.Lq;
     const int ic = live ? i_own : g.Lq - 1;
@@ -905,9 +925,11 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_x3(const float* __rest
     __shared__ float Ms[32], Rs[32], Ds[32];
     x3_zero_planes<HD, LD>(Qp);
     x3_zero_planes<HD, LD>(Gp);
-    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    int bx, bh;
+    al_block(bx, bh);          // XCD-aware: the query (key) blocks of one head share an XCD's L2
+    const int b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
-    const int jt = blockIdx.x * 4 + wave;
+    const int jt = bx * 4 + wave;
     const int j_own = jt * 32 + c;
     const int jc = j_own < g.Lk ? j_own : g.Lk - 1;
     const float* kp = k + (int64_t)jc * g.k.sl + (int64_t)b * g.k.sb + h * HD;
@@ -1093,9 +1115,11 @@ __global__ __launch_bounds__(256) void k_attn_long_fwd_c(const unsigned char* __
     constexpr float kLazy = 8.0f;
     x3_zero_plane1<HD, LD>(Vp);
     const QRange rq = load_qrange(rg.q_lo, rg.q_hi), rk = load_qrange(rg.k_lo, rg.k_hi), rv = load_qrange(rg.v_lo, rg.v_hi);
-    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    int bx, bh;
+    al_block(bx, bh);          // XCD-aware: the query (key) blocks of one head share an XCD's L2
+    const int b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
-    const int it = blockIdx.x * 4 + wave;
+    const int it = bx * 4 + wave;
     const int i_own = it * 32 + c;
     const bool live = i_own < g.Lq;
     const unsigned char* qp = qc + (int64_t)(live ? i_own : g.Lq - 1) * g.q.sl + (int64_t)b * g.q.sb + h * HD;
@@ -1208,9 +1232,11 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_q_c(const unsigned char* 
     __shared__ __attribute__((aligned(16))) float scs[4][32];
     x3_zero_plane1<HD, LD>(Kp);
     const QRange rq = load_qrange(rg.q_lo, rg.q_hi), rk = load_qrange(rg.k_lo, rg.k_hi), rv = load_qrange(rg.v_lo, rg.v_hi);
-    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    int bx, bh;
+    al_block(bx, bh);          // XCD-aware: the query (key) blocks of one head share an XCD's L2
+    const int b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
-    const int it = blockIdx.x * 4 + wave;
+    const int it = bx * 4 + wave;
     const int i_own = it * 32 + c;
     const bool live = i_own < g.Lq;
     const int ic = live ? i_own : g.Lq - 1;
@@ -1319,9 +1345,11 @@ __global__ __launch_bounds__(256) void k_attn_long_bwd_kv_c(const unsigned char*
     x3_zero_plane1<HD, LD>(Qp);
     x3_zero_planes<HD, LD>(Gp);
     const QRange rq = load_qrange(rg.q_lo, rg.q_hi), rk = load_qrange(rg.k_lo, rg.k_hi), rv = load_qrange(rg.v_lo, rg.v_hi);
-    const int bh = blockIdx.y, b = bh / g.nh, h = bh % g.nh;
+    int bx, bh;
+    al_block(bx, bh);          // XCD-aware: the query (key) blocks of one head share an XCD's L2
+    const int b = bh / g.nh, h = bh % g.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, lk = lane >> 5;
-    const int jt = blockIdx.x * 4 + wave;
+    const int jt = bx * 4 + wave;
     const int j_own = jt * 32 + c;
     const int jc = j_own < g.Lk ? j_own : g.Lk - 1;
     const unsigned char* kp = kc + (int64_t)jc * g.k.sl + (int64_t)b * g.k.sb + h * HD;

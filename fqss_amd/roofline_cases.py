@@ -212,13 +212,13 @@ def build_other(dev, sets=2):
     n = S * Bq
     case("k_lstm_fwd<128>", "cfg 3: BiLSTM recurrence 250 steps x 194 sequences (both directions), saving gates and cell states", "mfma", 24,
          4.0 * n * 8 * H, 4.0 * n * (2 * H + 8 * H + 4 * H), lambda i: K.lstm_fwd(pre[i % sets], whh, bhh, S, Bq, H), flops=2.0 * 2 * 4 * H * H * n)
-    # cfg 4: weight gradient of the student's coded feed-forward linear, 16 000 rows x 256 -> 1024
-    rows, Ci, Co = 16000, 256, 1024
+    # cfg 4: weight gradient of the student's coded feed-forward linear, 8 500 rows (250 x 34 chunks) x 256 -> 1024
+    rows, Ci, Co = 8500, 256, 1024
     gz = [torch.randn(rows, Co, device=dev) for _ in R]
     xc = [torch.randint(0, 256, (rows, Ci), device=dev, dtype=torch.uint8) for _ in R]
     lo, hi = torch.tensor([-1.0], device=dev), torch.tensor([1.0], device=dev)
     gw = torch.zeros(Co, Ci, device=dev)
-    case("k_gemm_x3", "cfg 4: coded weight gradient 16000 x 256 -> 1024 (gz fp32, input codes u8, split-K atomics into gw)", "mfma", 128,
+    case("k_gemm_x3", "cfg 4: coded weight gradient 8500 x 256 -> 1024 (gz fp32, input codes u8, split-K atomics into gw)", "mfma", 128,
          4.0 * rows * Co + rows * Ci, 4.0 * Co * Ci, lambda i: K.qrow_bwd_w(gz[i % sets], xc[i % sets], lo, hi, gw), flops=2.0 * rows * Ci * Co)
     # cfg 5: six-product pointwise GEMM over the frames of the level-0 rewrite conv, 4 x (144 -> 96) x 110250
     Bh, Kk, Cq, Mh = 4, 144, 96, 110250
