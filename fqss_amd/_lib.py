@@ -92,6 +92,7 @@ _PROTOS = {
     "fqss_rowlin_fwd_w3": [P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_rowlin_bwd_x": [P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_rowlin_bwd_w": [P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_rowlin_bwd_w_batched": [P, P, P, I64, I32, I32, I64, I64, I64, I32, I64, I64, I64, P],
     "fqss_colsum": [P, P, I64, I32, I64, P],
     "fqss_layernorm_fwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P],
     "fqss_layernorm_bwd": [P, P, P, P, P, P, P, I64, I32, I64, I64, I64, P],

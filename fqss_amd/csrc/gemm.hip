@@ -500,27 +500,41 @@ extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* 
     return launch_gemm_x3q(g, 1, (hipStream_t)stream, "fqss_qrow_bwd_w");
 }
 
-extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,
-                                 int64_t ld_x, int64_t ld_gw, fqss_stream_t stream) {
+static int rowlin_bwd_w_impl(const char* who, const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,
+                             int64_t ld_x, int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_x, int64_t sb_gw, fqss_stream_t stream) {
     FQSS_REQUIRE(gz && x && gw, "null tensor");
-    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_x >= Ci && ld_gw >= Ci, "bad shape");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_x >= Ci && ld_gw >= Ci && batch >= 1, "bad shape");
     if (R == 0) return FQSS_OK;
     GemmArgs g{};
     g.A = gz; g.B = x; g.C = gw; g.bias = nullptr; g.bias_col = nullptr;
     g.M = Co; g.N = Ci; g.K = (int)R;
-    g.sAb = 0; g.sAi = 1; g.sAk = ld_gz;   // A(i=o, k=r) = gz[r*ld + o]
-    g.sBb = 0; g.sBk = ld_x; g.sBj = 1;    // B(k=r, j=i) = x[r*ld + i]
-    g.sCb = 0; g.sCi = ld_gw;
-    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
+    g.sAb = sb_gz; g.sAi = 1; g.sAk = ld_gz;   // A(i=o, k=r) = gz[r*ld + o]
+    g.sBb = sb_x; g.sBk = ld_x; g.sBj = 1;     // B(k=r, j=i) = x[r*ld + i]
+    g.sCb = sb_gw; g.sCi = ld_gw;
+    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN)) * batch;
     int want = (int)cdiv(rowgrad_wgs(tiles), tiles);
     int kchunk = (int)cdiv(cdiv(R, want), 64) * 64;
     if (kchunk < 64) kchunk = 64;
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(R, kchunk);
     bool used = false;
-    int rc = try_x3(g, false, false, true, (hipStream_t)stream, "fqss_rowlin_bwd_w", &used);
+    int rc = try_x3(g, false, false, true, (hipStream_t)stream, who, &used, batch);
     if (rc != FQSS_OK || used) return rc;
-    return launch_gemm(g, false, false, true, 1, (hipStream_t)stream, "fqss_rowlin_bwd_w");
+    return launch_gemm(g, false, false, true, batch, (hipStream_t)stream, who);
+}
+
+extern "C" int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,
+                                 int64_t ld_x, int64_t ld_gw, fqss_stream_t stream) {
+    return rowlin_bwd_w_impl("fqss_rowlin_bwd_w", gz, x, gw, R, Ci, Co, ld_gz, ld_x, ld_gw, 1, 0, 0, 0, stream);
+}
+
+// `batch` weight gradients of the same shape in ONE launch: problem p reads gz + p sb_gz, x + p sb_x and adds into gw + p sb_gw (element
+// strides, any sign) -- the two directions' W_hh gradients of a bidirectional LSTM (dG[1:, :, :4H] with h[:-1, :, :H] and dG[:-1, :, 4H:]
+// with h[1:, :, H:]: the same tensors, shifted)
+extern "C" int fqss_rowlin_bwd_w_batched(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz, int64_t ld_x,
+                                         int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_x, int64_t sb_gw, fqss_stream_t stream) {
+    FQSS_REQUIRE(batch >= 1 && batch <= 64, "bad batch");
+    return rowlin_bwd_w_impl("fqss_rowlin_bwd_w_batched", gz, x, gw, R, Ci, Co, ld_gz, ld_x, ld_gw, batch, sb_gz, sb_x, sb_gw, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -1058,6 +1058,30 @@ def rowlin_bwd_w(gz, x, gw):
     _lib.call("fqss_rowlin_bwd_w", _p(gz), _p(x), _p(gw), R, Ci, Co, ld_gz, ld_x, gw.stride(0), _stream())
 
 
+PAIR_WGRAD = os.environ.get("FQSS_PAIR_WGRAD", "1") != "0"    # A/B switch: the two directions' W_hh gradients in one launch
+
+
+def rowlin_bwd_w_pair(gz0, x0, gw0, gz1, x1, gw1):
+    """two weight gradients of the same shape in one launch when the operands are views of the same tensors (constant element offsets
+    between problem 0 and 1) and both accumulators live in one allocation; else two launches"""
+    _need_gpu(gz0, x0, gw0, gz1, x1, gw1)
+    Co, Ci = gw0.shape
+    a0, R, ld_gz = _rows(gz0, Co)
+    a1, R1, ld_gz1 = _rows(gz1, Co)
+    b0, Rb, ld_x = _rows(x0, Ci)
+    b1, Rb1, ld_x1 = _rows(x1, Ci)
+    same = (R == R1 == Rb == Rb1 and ld_gz == ld_gz1 and ld_x == ld_x1 and gw0.shape == gw1.shape and gw0.stride() == gw1.stride() and gw0.stride(1) == 1
+            and a0 is gz0 and a1 is gz1 and b0 is x0 and b1 is x1)
+    if same and PAIR_WGRAD:
+        d = [(t1.data_ptr() - t0.data_ptr()) for t0, t1 in ((a0, a1), (b0, b1), (gw0, gw1))]
+        if all(v % 16 == 0 for v in d) and abs(d[2]) < (1 << 40):
+            _lib.call("fqss_rowlin_bwd_w_batched", _p(a0), _p(b0), _p(gw0), R, Ci, Co, ld_gz, ld_x, gw0.stride(0), 2, d[0] // 4, d[1] // 4, d[2] // 4,
+                      _stream())
+            return
+    rowlin_bwd_w(gz0, x0, gw0)
+    rowlin_bwd_w(gz1, x1, gw1)
+
+
 def colsum(g, out):
     """out[C] += column sums of g[..., C]"""
     _need_gpu(g, out)

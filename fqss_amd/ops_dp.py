@@ -510,8 +510,7 @@ class LstmBi(Function):
         ghh = [slots[1] if slots[1] is not None else torch.zeros_like(whh[0]), slots[3] if slots[3] is not None else torch.zeros_like(whh[1])]
         if S > 1:
             # forward direction: dG_f[t] with h_f[t-1];  reverse direction: dG_r[t] with h_r[t+1]
-            K.rowlin_bwd_w(dG[1:, :, :4 * H], hout[:-1, :, :H], ghh[0])
-            K.rowlin_bwd_w(dG[:-1, :, 4 * H:], hout[1:, :, H:], ghh[1])
+            K.rowlin_bwd_w_pair(dG[1:, :, :4 * H], hout[:-1, :, :H], ghh[0], dG[:-1, :, 4 * H:], hout[1:, :, H:], ghh[1])    # one launch for both
         gws[1] = None if slots[1] is not None else ghh[0]
         gws[3] = None if slots[3] is not None else ghh[1]
         if (slots[0] is None) != (slots[2] is None):       # (mixed: one direction's W_ih in the tables, the other not)

@@ -489,6 +489,11 @@ int fqss_rowlin_bwd_x(const float* gz, const float* w, float* gx, int64_t R, int
                       int64_t ld_w, int64_t ld_gx, fqss_stream_t stream);
 int fqss_rowlin_bwd_w(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,
                       int64_t ld_x, int64_t ld_gw, fqss_stream_t stream);
+/* `batch` weight gradients of one shape in ONE launch: problem p reads gz + p*sb_gz, x + p*sb_x and adds into gw + p*sb_gw (element
+ * strides of either sign) -- the W_hh gradients of the two directions of a bidirectional LSTM (torch's LSTM backward,
+ * qat_layers.py:571-600): the same dG / h tensors, shifted by one step and one column block */
+int fqss_rowlin_bwd_w_batched(const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz, int64_t ld_x,
+                              int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_x, int64_t sb_gw, fqss_stream_t stream);
 /* out[c] += sum_r g[r][c]  (bias gradients of the row linears / LSTM) */
 int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream);
 

@@ -67,6 +67,24 @@ def test_rowlin_kernels(R, Ci, Co):
     assert float(wide[:, :Co].abs().max()) == 0 and float(wide[:, 2 * Co:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("S,B,H", [(9, 5, 12), (250, 3, 128), (33, 4, 64)])
+def test_rowlin_bwd_w_pair_on_shifted_views(S, B, H, monkeypatch):
+    """the two directions' W_hh gradients of a bidirectional LSTM in one batched launch == two launches == fp64"""
+    from fqss_amd import kernels as K
+    dG, h = rnd(S, B, 8 * H, seed=5), rnd(S, B, 2 * H, seed=6)
+    dGd, hd = dG.cuda(), h.cuda()
+    want = [(dG[1:, :, :4 * H].double().reshape(-1, 4 * H).T @ h[:-1, :, :H].double().reshape(-1, H)),
+            (dG[:-1, :, 4 * H:].double().reshape(-1, 4 * H).T @ h[1:, :, H:].double().reshape(-1, H))]
+    for on in (True, False):
+        monkeypatch.setattr(K, "PAIR_WGRAD", on)
+        flat = torch.zeros(3 * 4 * H * H + 8, device="cuda")
+        g0, g1 = flat[:4 * H * H].view(4 * H, H), flat[2 * 4 * H * H + 8:].view(4 * H, H)       # two slots of one arena, a gap between them
+        K.rowlin_bwd_w_pair(dGd[1:, :, :4 * H], hd[:-1, :, :H], g0, dGd[:-1, :, 4 * H:], hd[1:, :, H:], g1)
+        close(g0, want[0], 5e-6, msg=f"fwd dir, pair={on}")
+        close(g1, want[1], 5e-6, msg=f"rev dir, pair={on}")
+        assert float(flat[4 * H * H:2 * 4 * H * H + 8].abs().max()) == 0
+
+
 @pytest.mark.parametrize("C", [8, 16, 64, 200])
 def test_layernorm_kernels(C):
     from fqss_amd import kernels as K
