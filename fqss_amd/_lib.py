@@ -129,6 +129,7 @@ _PROTOS = {
     "fqss_qrow_fwdq": [P, P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, P, P, P, P],
     "fqss_qrow_bwd_x": [P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_qrow_bwd_w": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_qrow_bwd_w_batched": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, I64, I64, I64, P],
     "fqss_glu_fwd": [P, P, I64, I64, I64, I64, I64, P],
     "fqss_glu_bwd": [P, P, P, I64, I64, I64, I64, I64, I64, P],
     "fqss_div_fwd": [P, P, P, I64, P],

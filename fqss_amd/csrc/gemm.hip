@@ -477,12 +477,14 @@ extern "C" int fqss_qrow_bwd_x(const float* gz, const int8_t* wi, const float* d
     return launch_gemm_x3q(g, 2, (hipStream_t)stream, "fqss_qrow_bwd_x");
 }
 
-extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R, int Ci,
-                               int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream) {
+static int qrow_bwd_w_impl(const char* who, const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R,
+                           int Ci, int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_xc, int64_t sb_gw,
+                           fqss_stream_t stream) {
     FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null tensor");
-    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_xc >= Ci && ld_gw >= Ci, "bad shape");
-    FQSS_REQUIRE(Ci % 4 == 0 && Co % 4 == 0 && ld_gz % 4 == 0 && ld_xc % 4 == 0 && aligned16(gz) && ((uintptr_t)xc & 3) == 0,
-                 "coded wgrad: Ci, Co and the row strides must be multiples of 4, operands aligned");
+    FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_xc >= Ci && ld_gw >= Ci && batch >= 1 && batch <= 64, "bad shape");
+    FQSS_REQUIRE(Ci % 4 == 0 && Co % 4 == 0 && ld_gz % 4 == 0 && ld_xc % 4 == 0 && aligned16(gz) && ((uintptr_t)xc & 3) == 0 && sb_gz % 4 == 0 &&
+                     sb_xc % 4 == 0,
+                 "coded wgrad: Ci, Co, the row strides and the problem strides must be multiples of 4, operands aligned");
     if (R == 0) return FQSS_OK;
     GemmArgs3 g{};
     g.A = gz; g.B = nullptr; g.C = gw; g.bias = nullptr; g.bias_col = nullptr;
@@ -490,14 +492,29 @@ extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* 
     g.sAi = 1; g.sAk = ld_gz;      // A(i=o, k=r) = gz[r*ld + o]
     g.sBk = ld_xc; g.sBj = 1;      // B(k=r, j=i) = c[r*ld + i]
     g.sCi = ld_gw;
-    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN));
+    g.batch = batch; g.sAb = sb_gz; g.sBb = sb_xc; g.sCb = sb_gw;
+    const int tiles = (int)(cdiv(Co, BM) * cdiv(Ci, BN)) * batch;
     int want = (int)cdiv(rowgrad_wgs(tiles), tiles);
     int kchunk = (int)cdiv(cdiv(R, want), 64) * 64;
     if (kchunk < 64) kchunk = 64;
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(R, kchunk);
     g.Bq = xc; g.qmin_x = qmin_x; g.qmax_x = qmax_x;
-    return launch_gemm_x3q(g, 1, (hipStream_t)stream, "fqss_qrow_bwd_w");
+    return launch_gemm_x3q(g, 1, (hipStream_t)stream, who);
+}
+
+extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R, int Ci,
+                               int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream) {
+    return qrow_bwd_w_impl("fqss_qrow_bwd_w", gz, xc, qmin_x, qmax_x, gw, R, Ci, Co, ld_gz, ld_xc, ld_gw, 1, 0, 0, 0, stream);
+}
+
+// `batch` coded weight gradients of one shape and one input range in ONE launch (problem p: gz + p sb_gz, xc + p sb_xc bytes, gw + p sb_gw):
+// the two directions' W_ih gradients of a bidirectional LSTM -- two column blocks of dG against the same input codes
+extern "C" int fqss_qrow_bwd_w_batched(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R, int Ci,
+                                       int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_xc,
+                                       int64_t sb_gw, fqss_stream_t stream) {
+    return qrow_bwd_w_impl("fqss_qrow_bwd_w_batched", gz, xc, qmin_x, qmax_x, gw, R, Ci, Co, ld_gz, ld_xc, ld_gw, batch, sb_gz, sb_xc, sb_gw,
+                           stream);
 }
 
 static int rowlin_bwd_w_impl(const char* who, const float* gz, const float* x, float* gw, int64_t R, int Ci, int Co, int64_t ld_gz,

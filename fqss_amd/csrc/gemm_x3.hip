@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     g.A += (int64_t)zb * g.sAb;
     g.B += (int64_t)zb * g.sBb;
     g.C += (int64_t)zb * g.sCb;
+    if constexpr (BQ != 0) g.Bq = static_cast<const unsigned char*>(g.Bq) + (int64_t)zb * g.sBb;      // (codes: 1 B per element)
     const int kbeg = ATOMIC ? ks * g.kchunk : 0;
     const int kend = ATOMIC ? min(g.K, kbeg + g.kchunk) : g.K;
     const int i0 = blockIdx.y * BMt, j0 = blockIdx.x * BNt;
@@ -528,7 +529,9 @@ int launch_gemm_x3q(const GemmArgs3& g_in, int bq, hipStream_t s, const char* wh
     g.scalar_stores = x3_scalar_stores();
     if (g.M <= 0 || g.N <= 0) return FQSS_OK;
     const bool atomic = bq == 1;
-    const int64_t zdim = atomic ? g.ksplit : 1;
+    if (g.batch < 1) g.batch = 1;
+    FQSS_REQUIRE(atomic || g.batch == 1, "coded data gradient: one problem per launch");
+    const int64_t zdim = atomic ? (int64_t)g.ksplit * g.batch : 1;
     int mi = 2, ni = 2;
     if (g.N <= 64) ni = 1;
     else if (g.M <= 64 || (g.M > 128 && cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 2 * 256)) mi = 1;

@@ -1575,6 +1575,24 @@ def qrow_bwd_w(gz, xc, qmin_x, qmax_x, gw):
     _lib.call("fqss_qrow_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), R, Ci, Co, ld_gz, rm[2], Ci, _stream())
 
 
+def qrow_bwd_w_pair(gz0, gz1, xc, qmin_x, qmax_x, gw0, gw1):
+    """two coded weight gradients against the SAME input codes in one launch (gz0 / gz1: two column blocks of one tensor)"""
+    _need_gpu(gz0, gz1, gw0, gw1)
+    Co, Ci = gw0.shape
+    a0, R, ld0 = _rows(gz0, Co)
+    a1, R1, ld1 = _rows(gz1, Co)
+    d = [a1.data_ptr() - a0.data_ptr(), gw1.data_ptr() - gw0.data_ptr()]
+    if not (PAIR_WGRAD and a0 is gz0 and a1 is gz1 and R == R1 and ld0 == ld1 and gw0.shape == gw1.shape and gw0.is_contiguous() and gw1.is_contiguous()
+            and d[0] % 16 == 0 and d[1] % 4 == 0):
+        qrow_bwd_w(gz0, xc, qmin_x, qmax_x, gw0)
+        qrow_bwd_w(gz1, xc, qmin_x, qmax_x, gw1)
+        return
+    assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci
+    rm = rowmat(xc)
+    assert rm is not None and rm[0] == R and rm[1] == Ci
+    _lib.call("fqss_qrow_bwd_w_batched", _p(a0), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw0), R, Ci, Co, ld0, rm[2], Ci, 2, d[0] // 4, 0, d[1] // 4, _stream())
+
+
 # ------------------------------------------------------------------ general convolution geometry (HTDemucs layers, SURVEY §8 row a15)
 class ConvGeom:
     """kernel / stride / zero padding / dilation of a 2-D convolution over [B, C, H, W] (1-D convs run with H = 1)"""

@@ -51,6 +51,15 @@ def _rowlinear_wgrad_into(gz, x, xq, buf):
         K.rowlin_bwd_w(gz, x, buf)
 
 
+def _rowlinear_wgrad_pair_into(gz0, gz1, x, xq, buf0, buf1):
+    """both directions' W_ih gradients of a bidirectional LSTM (two column blocks of dG against one input): one launch"""
+    if QROW_BWD and xq is not None and all(b.dim() == 2 and b.is_contiguous() for b in (buf0, buf1)) and xq.idx.is_contiguous() \
+            and xq.idx.shape[-1] == buf0.shape[1] and K.qrow_bwd_ok(buf0.shape[1], buf0.shape[0]):
+        K.qrow_bwd_w_pair(gz0, gz1, xq.idx, xq.qmin, xq.qmax, buf0, buf1)
+    else:
+        K.rowlin_bwd_w_pair(gz0, x, buf0, gz1, x, buf1)
+
+
 class RowLinear(Function):
     """z = x @ w^T + bias on the last dim -- F.linear of LinearQ / the MHA projections / the 1x1 Conv2dQ (qat_layers.py:521-536,
     889-901, 941).  w is the (possibly fake-quantized) weight [Co, Ci]; bias a parameter or None."""
@@ -500,8 +509,7 @@ class LstmBi(Function):
         # arena slot by the wgrad GEMM of that direction; otherwise one GEMM for both directions' W_ih into a fresh buffer
         slots = [getattr(w, "_fqss_gwq", None) for w in ctx.weights]      # wih_f, whh_f, wih_r, whh_r
         if slots[0] is not None and slots[2] is not None:
-            _rowlinear_wgrad_into(dG[..., :4 * H], x, ctx.xq, slots[0])      # on the input's codes when the projection ran on them
-            _rowlinear_wgrad_into(dG[..., 4 * H:], x, ctx.xq, slots[2])
+            _rowlinear_wgrad_pair_into(dG[..., :4 * H], dG[..., 4 * H:], x, ctx.xq, slots[0], slots[2])      # on the input's codes when the projection ran on them
             gws = [None, None, None, None]
         else:
             gwih = torch.zeros_like(wih)

@@ -678,6 +678,12 @@ int fqss_qrow_bwd_x(const float* gz, const int8_t* wi, const float* dw, float* g
                     int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
 int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw,
                     int64_t R, int Ci, int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream);
+/* `batch` coded weight gradients of one shape and one input range in ONE launch: problem p reads gz + p*sb_gz (floats), xc + p*sb_xc
+ * (bytes) and adds into gw + p*sb_gw (floats) -- the W_ih gradients of the two directions of LSTMQ (qat_layers.py:571-600): two column
+ * blocks of dG against the same input codes */
+int fqss_qrow_bwd_w_batched(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R, int Ci,
+                            int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_xc, int64_t sb_gw,
+                            fqss_stream_t stream);
 
 /* First layer kernels of cfg 5 (HTDemucs; the model itself is not built yet).
  * GELU is kind FQSS_UNARY_GELU of fqss_unary_fwd/bwd (erf form; the backward takes the INPUT x in place of y).
