@@ -54,7 +54,15 @@ struct GemmArgs3 {
     int scalar_stores;       // 1: the lane-per-column epilogue (FQSS_X3_STAGED=0, A/B measurements)
 };
 
-constexpr int XBK = 32, XLDK = 40;   // 40 shorts = 80 B row stride (as csrc/teacher.hip: conflict-light 16-B reads)
+#ifndef FQSS_X3_PF
+#define FQSS_X3_PF 1     // operand tiles in flight per workgroup (register images)
+#endif
+// LDS rows are 32 bf16 = 64 B with NO padding; the four 16-B chunks of a row are stored XOR-swizzled by (row >> 2) & 3, so that the
+// sixteen rows a quarter-wave reads with one ds_read_b128 -- same logical chunk -- fall on sixteen different 16-B bank groups (rows r and
+// r + 4 are 256 B apart: the swizzle separates them; rows r .. r + 3 are 64 B apart).  The padded layout of rounds 1-3 (80-B rows) cost
+// 61 KB for a 128 x 128 float tile pair = two workgroups per CU; 49 KB lets a third one in.
+constexpr int XBK = 32, XLDK = 32;
+__device__ __forceinline__ int xsw(int row, int k) { return (((k >> 3) ^ (row >> 2)) & 3) * 8 + (k & 7); }
 
 __device__ __forceinline__ unsigned short x_bf(float f) { return (unsigned short)(__float_as_uint(f) >> 16); }
 __device__ __forceinline__ float x_tr(float f) { return __uint_as_float(__float_as_uint(f) & 0xFFFF0000u); }
@@ -103,7 +111,7 @@ struct TileIO {
         }
     }
 
-    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) {
+    __device__ __forceinline__ void store(unsigned short (*pl)[ROWS][XLDK]) {
         const int tid = threadIdx.x;
         if constexpr (KC) {
 #pragma unroll
@@ -117,7 +125,7 @@ struct TileIO {
                 for (int q = 0; q < 4; ++q) x_split3((rv && k0_ + k + q < kend_) ? e[q] : 0.f, h[0][q], h[1][q], h[2][q]);
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    *reinterpret_cast<uint2*>(&pl[s][r][k]) = make_uint2((unsigned)h[s][0] | ((unsigned)h[s][1] << 16), (unsigned)h[s][2] | ((unsigned)h[s][3] << 16));
+                    *reinterpret_cast<uint2*>(&pl[s][r][xsw(r, k)]) = make_uint2((unsigned)h[s][0] | ((unsigned)h[s][1] << 16), (unsigned)h[s][2] | ((unsigned)h[s][3] << 16));
             }
         } else {
             if (tid / (ROWS / 4) >= XBK / 4) return;      // 64-row tiles: only half the threads hold a block
@@ -136,7 +144,7 @@ struct TileIO {
                 }
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    *reinterpret_cast<uint2*>(&pl[s][rb * 4 + rr][kb * 4]) =
+                    *reinterpret_cast<uint2*>(&pl[s][rb * 4 + rr][xsw(rb * 4 + rr, kb * 4)]) =
                         make_uint2((unsigned)h[s][0] | ((unsigned)h[s][1] << 16), (unsigned)h[s][2] | ((unsigned)h[s][3] << 16));
             }
         }
@@ -153,9 +161,9 @@ template <int ROWS>
 struct TileIOP {
     static constexpr int NCH = 3 * ROWS * (XBK / 8) / 256;     // chunks per thread: 6 (128 rows) or 3 (64)
     uint4 v[NCH];
-    int r0_, nrows_;
+    int r0_, nrows_;     // (a tile past K: nrows_ = 0, stored as zeros)
     __device__ __forceinline__ void load(const unsigned short* __restrict__ planes, int64_t plane_stride, int64_t ldp, int r0, int nrows, int k0, int K) {
-        r0_ = r0; nrows_ = nrows;
+        r0_ = r0; nrows_ = k0 < K ? nrows : 0;
         const int kb = min(k0, K - XBK);
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
@@ -163,11 +171,11 @@ struct TileIOP {
             v[u] = *reinterpret_cast<const uint4*>(planes + p * plane_stride + (int64_t)min(r0 + r, nrows - 1) * ldp + kb + 8 * c);
         }
     }
-    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) const {
+    __device__ __forceinline__ void store(unsigned short (*pl)[ROWS][XLDK]) const {
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int f = threadIdx.x + 256 * u, p = f / (ROWS * 4), rem = f % (ROWS * 4), r = rem >> 2, c = rem & 3;
-            *reinterpret_cast<uint4*>(&pl[p][r][8 * c]) = (r0_ + r < nrows_) ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(&pl[p][r][xsw(r, 8 * c)]) = (r0_ + r < nrows_) ? v[u] : make_uint4(0u, 0u, 0u, 0u);
         }
     }
 };
@@ -241,7 +249,7 @@ struct TileIOQ {
         }
     }
 
-    __device__ __forceinline__ void store(unsigned short (*pl)[128][XLDK]) const {
+    __device__ __forceinline__ void store(unsigned short (*pl)[ROWS][XLDK]) const {
         const int tid = threadIdx.x;
         if (tid / (ROWS / 4) >= XBK / 4) return;
         const int rb = tid % (ROWS / 4), kb = tid / (ROWS / 4);
@@ -255,7 +263,7 @@ struct TileIOQ {
                 const float f = SIGNED ? (float)(int)(signed char)byte : (float)byte;
                 h[q] = (rv && k0_ + kb * 4 + q < kend_) ? x_bf(f) : (unsigned short)0;
             }
-            *reinterpret_cast<uint2*>(&pl[0][rb * 4 + rr][kb * 4]) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2*>(&pl[0][rb * 4 + rr][xsw(rb * 4 + rr, kb * 4)]) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
         }
     }
 };
@@ -268,8 +276,16 @@ struct TileIOQ {
 template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0, bool IMP = false, bool BPL = false>
 __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     constexpr int BMt = 64 * MI, BNt = 64 * NI;
-    __shared__ __attribute__((aligned(16))) unsigned short As[3][128][XLDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][128][XLDK];
+    // LDS: three bf16 planes of the A tile, three (one for 8-bit codes) of the B tile, sized by the tile: the 64-row and the coded forms
+    // leave room for a third / fourth workgroup per CU (128 x 128 float: 49 KB -> 3 per CU; 128 x 128 coded 33 KB -> 4; 64 x 128 coded
+    // 20 KB -> 7) -- these short-K GEMMs are bound by the latency of a k-tile, not by its MFMAs, and a launch of 536 workgroups
+    // on 512 slots ran in two rounds
+    constexpr int kPlanesB = BQ ? 1 : 3;
+    constexpr int kBytesA = 3 * BMt * XLDK * 2, kBytesB = kPlanesB * BNt * XLDK * 2, kBytesStage = 4 * 32 * 36 * 4;
+    constexpr int kBytesLds = kBytesA + kBytesB > kBytesStage ? kBytesA + kBytesB : kBytesStage;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kBytesLds];
+    unsigned short(*As)[BMt][XLDK] = reinterpret_cast<unsigned short(*)[BMt][XLDK]>(lds_raw);
+    unsigned short(*Bs)[BNt][XLDK] = reinterpret_cast<unsigned short(*)[BNt][XLDK]>(lds_raw + kBytesA);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -286,16 +302,25 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
 
     static_assert(BQ == 0 || !B_KC, "coded B tiles are j-contiguous");
     static_assert(!IMP || BQ == 0, "implicit convolution: float operands");
-    TileIO<BMt, A_KC> ta;
+    // PF register images of the operands in flight: the tile of step kt + PF is requested while step kt computes.  One image (rounds 1-3)
+    // gave a load one k-tile's time to arrive; the short-K row GEMMs with one workgroup per CU (266 workgroups of 4 waves: one wave per
+    // SIMD, nothing to switch to) then waited out most of an HBM round trip per k-tile.
+    constexpr int PF = FQSS_X3_PF;
+    using TileA = TileIO<BMt, A_KC>;
     static_assert(!BPL || (BQ == 0 && !IMP && B_KC && !ATOMIC), "pre-split B: the forward form");
-    std::conditional_t<BPL, TileIOP<BNt>,
-                       std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, std::conditional_t<IMP, TileIOI<BNt, B_KC>, TileIO<BNt, B_KC>>>> tb;
-    if constexpr (BQ == 2) ta.sc_ = g.scale_k;
-    if constexpr (IMP) { tb.taps_ = g.imp_taps; tb.dil_ = g.imp_dil; tb.pad_ = g.imp_pad; tb.len_ = g.imp_len; }
-    auto load_b = [&](int k0) {
-        if constexpr (BPL) tb.load(g.Bp, (int64_t)g.N * g.ldp, g.ldp, j0, g.N, k0, g.K);
-        else if constexpr (BQ != 0) tb.load(g.Bq, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
-        else tb.load(g.B, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
+    using TileB = std::conditional_t<BPL, TileIOP<BNt>,
+                                     std::conditional_t<BQ != 0, TileIOQ<BNt, BQ == 2>, std::conditional_t<IMP, TileIOI<BNt, B_KC>, TileIO<BNt, B_KC>>>>;
+    TileA ta[PF];
+    TileB tb[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        if constexpr (BQ == 2) ta[s].sc_ = g.scale_k;
+        if constexpr (IMP) { tb[s].taps_ = g.imp_taps; tb[s].dil_ = g.imp_dil; tb[s].pad_ = g.imp_pad; tb[s].len_ = g.imp_len; }
+    }
+    auto load_b = [&](TileB& t, int k0) {
+        if constexpr (BPL) t.load(g.Bp, (int64_t)g.N * g.ldp, g.ldp, j0, g.N, k0, g.K);
+        else if constexpr (BQ != 0) t.load(g.Bq, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
+        else t.load(g.B, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
     };
     __shared__ float rsum_s[(BQ == 1) ? 128 : 1];
     if constexpr (BQ == 1) {
@@ -309,19 +334,27 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nkt = (kend - kbeg + XBK - 1) / XBK;
+    // the k loop runs whole rounds of PF tiles: a tile past the end is loaded from clamped addresses and STORED AS ZEROS (the stores
+    // apply k < kend), so no branch surrounds a global load (see TileIO) and the surplus MFMAs add nothing
+    const int nkt = (kend - kbeg + XBK - 1) / XBK, nkt_r = (nkt + PF - 1) / PF * PF;
     if (nkt > 0) {
-        ta.load(g.A, g.sAi, g.sAk, i0, g.M, kbeg, kend, g.K);
-        load_b(kbeg);
-        ta.store(As);
-        tb.store(Bs);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            ta[s].load(g.A, g.sAi, g.sAk, i0, g.M, kbeg + s * XBK, kend, g.K);
+            load_b(tb[s], kbeg + s * XBK);
+        }
+        ta[0].store(As);
+        tb[0].store(Bs);
     }
     __syncthreads();
     const int lr = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
-        // global loads of the next tile fly under the MFMAs (issued unconditionally: the last iteration re-reads a clamped tile)
-        ta.load(g.A, g.sAi, g.sAk, i0, g.M, kbeg + (kt + 1) * XBK, kend, g.K);
-        load_b(kbeg + (kt + 1) * XBK);
+    for (int kt0 = 0; kt0 < nkt_r; kt0 += PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        const int kt = kt0 + s;
+        // image s was stored for this step: it takes the tile of step kt + PF, whose loads fly under PF steps of MFMAs
+        ta[s].load(g.A, g.sAi, g.sAk, i0, g.M, kbeg + (kt + PF) * XBK, kend, g.K);
+        load_b(tb[s], kbeg + (kt + PF) * XBK);
 #pragma unroll
         for (int kstep = 0; kstep < XBK / 16; ++kstep) {
             constexpr int NPB = BQ ? 1 : 3;     // planes of B
@@ -330,11 +363,11 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    af[p][mi] = *reinterpret_cast<const bf16x8*>(&As[p][wm * (32 * MI) + mi * 32 + lr][kstep * 16 + 8 * lh]);
+                    af[p][mi] = *reinterpret_cast<const bf16x8*>(&As[p][wm * (32 * MI) + mi * 32 + lr][xsw(lr, kstep * 16 + 8 * lh)]);
                 if (p < NPB) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        bfr[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[p][wn * (32 * NI) + ni * 32 + lr][kstep * 16 + 8 * lh]);
+                        bfr[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[p][wn * (32 * NI) + ni * 32 + lr][xsw(lr, kstep * 16 + 8 * lh)]);
                 }
             }
             // smallest partial products first: l.h, h.l, m.m, m.h, h.m, h.h   (coded B: l.c, m.c, h.c)
@@ -349,11 +382,12 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[mi][ni], 0, 0, 0);
         }
         __syncthreads();
-        if (kt + 1 < nkt) {
-            ta.store(As);
-            tb.store(Bs);
+        if (kt + 1 < nkt_r) {
+            ta[(s + 1) % PF].store(As);
+            tb[(s + 1) % PF].store(Bs);
             __syncthreads();
         }
+      }
     }
 
     float dx = 1.0f, mnx = 0.0f;
@@ -362,7 +396,12 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
         if (threadIdx.x / (BMt / 4) < XBK / 4) {
             const int rb = threadIdx.x % (BMt / 4);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) atomicAdd(&rsum_s[rb * 4 + rr], ta.rs_[rr]);
+            for (int rr = 0; rr < 4; ++rr) {
+                float t = ta[0].rs_[rr];
+#pragma unroll
+                for (int s = 1; s < PF; ++s) t += ta[s].rs_[rr];
+                atomicAdd(&rsum_s[rb * 4 + rr], t);
+            }
         }
         __syncthreads();
         const float lo = *g.qmin_x, hi = *g.qmax_x;
@@ -377,8 +416,8 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
         // 16-B aligned output rows; the scalar path below serves everything else.
         if (!g.scalar_stores && (g.sCi & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0) {
             constexpr int TLD = 36;                                    // floats per staged row (16-B aligned, conflict-light)
-            static_assert(4 * 32 * TLD * 4 <= (int)sizeof(As), "staging tiles fit the A planes");
-            float(*Tt)[TLD] = reinterpret_cast<float(*)[TLD]>(reinterpret_cast<float*>(&As[0][0][0]) + wave * 32 * TLD);
+            static_assert(4 * 32 * TLD * 4 <= kBytesLds, "staging tiles fit the operand planes");
+            float(*Tt)[TLD] = reinterpret_cast<float(*)[TLD]>(reinterpret_cast<float*>(lds_raw) + wave * 32 * TLD);
             const int c4 = (lane & 7) * 4, rq = lane >> 3;            // a lane moves 4 columns of rows rq, rq + 8, rq + 16, rq + 24
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -454,6 +493,19 @@ static bool x3_ok(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic) {
     return ok;
 }
 
+// A/B switches of the tile rules (tools/kprobe.py): FQSS_X3_LDS_PAD = bytes of unused dynamic LDS per workgroup (caps the workgroups per
+// CU; -1: every form padded to 61,440 B, the size before the planes were sized by the tile), FQSS_X3_MI = 1 / 2 forces the 64- / 128-row tile where both exist
+static unsigned x3_lds_pad(int mi, int ni, bool coded) {
+    static const int v = [] { const char* e = getenv("FQSS_X3_LDS_PAD"); return e ? atoi(e) : 0; }();
+    if (v >= 0) return (unsigned)v;
+    const int used = max(3 * 64 * mi * XLDK * 2 + (coded ? 1 : 3) * 64 * ni * XLDK * 2, 4 * 32 * 36 * 4);     // < 0: pad every form to the 61,440 B of rounds 1-3
+    return used < 61440 ? (unsigned)(61440 - used) : 0u;
+}
+static int x3_force_mi() {
+    static const int v = [] { const char* e = getenv("FQSS_X3_MI"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 static int x3_scalar_stores() {
     static const int v = [] { const char* e = getenv("FQSS_X3_STAGED"); return (e && e[0] == '0') ? 1 : 0; }();
     return v;
@@ -476,19 +528,23 @@ int launch_gemm_x3(const GemmArgs3& g_in, bool a_kc, bool b_kc, bool atomic, hip
     if (atomic && g.M > 64 && g.N > 64) mi = 2;
     // forward / data-gradient tiles: 64-row tiles only while the 128 x 128 grid would leave CUs idle (< 320 tiles: measured over the
     // cfg 3 / 4 / 5 shapes, tools/kprobe.py -- at 432 tiles the 128-row tile is 13 .. 30 % faster, at 250 the 64-row tile 10 .. 15 %);
-    // the float data gradient (weight tile transposed on the way into LDS) always takes 128 rows
-    if (!atomic && g.M > 128 && g.N > 64) mi = (a_kc && !b_kc) ? 2 : (cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 320 ? 1 : 2);
+    // the float data gradient (weight tile transposed on the way into LDS) takes 128 rows unless that leaves CUs without a workgroup
+    if (!atomic && g.M > 128 && g.N > 64) {
+        const int64_t t2 = cdiv(g.M, 128) * cdiv(g.N, 128) * zdim;
+        mi = (a_kc && !b_kc) ? (t2 < 256 ? 1 : 2) : (t2 < 320 ? 1 : 2);
+    }
+    if (x3_force_mi() && ni == 2 && g.M > 64) mi = x3_force_mi() == 1 ? 1 : 2;
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3(AK, BKc, AT)                                                                                  \
     do {                                                                                                      \
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 2>), grid, block, 0, s, g);    \
-        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 1>), grid, block, 0, s, g);          \
-        else hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 1, 2>), grid, block, 0, s, g);                       \
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 2>), grid, block, x3_lds_pad(2, 2, false), s, g);    \
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 1>), grid, block, x3_lds_pad(2, 1, false), s, g);          \
+        else hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 1, 2>), grid, block, x3_lds_pad(1, 2, false), s, g);                       \
     } while (0)
     if (!atomic && a_kc && b_kc && g.Bp != nullptr) {                  // fwd on the weight's pre-split planes
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, true, false, 2, 2, 0, false, true>), grid, block, 0, s, g);
-        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, true, false, 2, 1, 0, false, true>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((k_gemm_x3<true, true, false, 1, 2, 0, false, true>), grid, block, 0, s, g);
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, true, false, 2, 2, 0, false, true>), grid, block, x3_lds_pad(2, 2, false), s, g);
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, true, false, 2, 1, 0, false, true>), grid, block, x3_lds_pad(2, 1, false), s, g);
+        else hipLaunchKernelGGL((k_gemm_x3<true, true, false, 1, 2, 0, false, true>), grid, block, x3_lds_pad(1, 2, false), s, g);
     } else if (!atomic && a_kc && b_kc) FQSS_X3(true, true, false);   // fwd:   x [R][Ci], w [Co][Ci]
     else if (!atomic && a_kc && !b_kc) FQSS_X3(true, false, false);   // dgrad: gz [R][Co], w [Co][Ci] (j contiguous)
     else if (atomic && !a_kc && !b_kc) FQSS_X3(false, false, true);   // wgrad: gz^T, x (both row-index contiguous)
@@ -514,9 +570,9 @@ int launch_gemm_x3_imp(const GemmArgs3& g_in, bool wgrad, hipStream_t s, const c
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3I(BKc, AT)                                                                                              \
     do {                                                                                                               \
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 2, 0, true>), grid, block, 0, s, g);  \
-        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 1, 0, true>), grid, block, 0, s, g);        \
-        else hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 1, 2, 0, true>), grid, block, 0, s, g);                     \
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 2, 0, true>), grid, block, x3_lds_pad(2, 2, false), s, g);  \
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 1, 0, true>), grid, block, x3_lds_pad(2, 1, false), s, g);        \
+        else hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 1, 2, 0, true>), grid, block, x3_lds_pad(1, 2, false), s, g);                     \
     } while (0)
     if (wgrad) FQSS_X3I(true, true); else FQSS_X3I(false, false);
 #undef FQSS_X3I
@@ -540,12 +596,13 @@ int launch_gemm_x3q(const GemmArgs3& g_in, int bq, hipStream_t s, const char* wh
     // (measured over the cfg 3 / 4 / 5 shapes, tools/kprobe.py: 512 x 512 float 91 -> 74 us, coded 71 -> 61 us)
     if (atomic && g.M > 64 && g.N > 64) mi = 2;
     if (!atomic && g.M > 128 && g.N > 64) mi = cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 320 ? 1 : 2;
+    if (x3_force_mi() && ni == 2 && g.M > 64) mi = x3_force_mi() == 1 ? 1 : 2;
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3Q(AK, AT, Q)                                                                                      \
     do {                                                                                                         \
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 2, Q>), grid, block, 0, s, g);  \
-        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 1, Q>), grid, block, 0, s, g);        \
-        else hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 1, 2, Q>), grid, block, 0, s, g);                     \
+        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 2, Q>), grid, block, x3_lds_pad(2, 2, true), s, g);  \
+        else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 1, Q>), grid, block, x3_lds_pad(2, 1, true), s, g);        \
+        else hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 1, 2, Q>), grid, block, x3_lds_pad(1, 2, true), s, g);                     \
     } while (0)
     if (bq == 1) FQSS_X3Q(false, true, 1);
     else FQSS_X3Q(true, false, 2);

@@ -40,7 +40,7 @@ struct QRowArgs {
 };
 
 // workgroup tile 128 (rows r) x 128 (outputs o), 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32); K in chunks of 64 bytes
-__global__ __launch_bounds__(256) void k_qrow_fwd(QRowArgs g) {
+__global__ __launch_bounds__(256, 3) void k_qrow_fwd(QRowArgs g) {     // (.., 3 waves per SIMD): <= 168 registers, a third workgroup per CU
     __shared__ __attribute__((aligned(16))) uint8_t As[128][QLD];
     __shared__ __attribute__((aligned(16))) uint8_t Bs[128][QLD];
     const int tid = threadIdx.x, lane = tid & 63;

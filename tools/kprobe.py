@@ -19,8 +19,9 @@ def cases():
     o, st = K.attn_long_fwd(q, k, v, nh, True)
     out.append(("attn_long fwd 3448^2", lambda: K.attn_long_fwd(q, k, v, nh, True)))
     out.append(("attn_long bwd 3448^2", lambda: K.attn_long_bwd(q, k, v, o, go, st, nh, True)))
-    for name, R, Ci, Co in (("sepformer ffn0", 16000, 256, 1024), ("sepformer out_proj", 16000, 256, 256), ("sepformer ffn3", 16000, 1024, 256),
-                            ("dptnet lstm proj", 48500, 64, 1024), ("htdemucs 512", 13792, 512, 512)):
+    for name, R, Ci, Co in (("sepformer ffn0", 8500, 256, 1024), ("sepformer out_proj", 8500, 256, 256), ("sepformer ffn3", 8500, 1024, 256),
+                            ("sepformer in_proj", 8500, 256, 768), ("dptnet lstm proj", 48500, 64, 1024), ("dptnet ffn", 48500, 256, 64),
+                            ("htdemucs 512", 13792, 512, 512), ("htdemucs ffn", 13792, 512, 2048)):
         x, w, b = torch.randn(R, Ci, device=dev), torch.randn(Co, Ci, device=dev), torch.randn(Co, device=dev)
         g, gw = torch.randn(R, Co, device=dev), torch.zeros(Co, Ci, device=dev)
         xc = torch.randint(0, 256, (R, Ci), device=dev, dtype=torch.uint8)
