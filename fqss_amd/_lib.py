@@ -19,6 +19,7 @@ _PROTOS = {
     "fqss_gluq_fwd": [P, P, I64, I64, I64, I64, I64, I32, P, P, P, P],
     "fqss_gluq_bwd": [P, P, P, I64, I64, I64, I64, I64, I64, I32, P, P, P, P],
     "fqss_actq_bwd_colbias": [P, P, P, I64, I32, I64, I64, I64, I32, P, I32, P, P, P, P, P],
+    "fqss_actq2_bwd_colbias": [P, P, P, I64, I32, I64, I64, I64, P, P, P, P, P, P, P, P],
     "fqss_minmax": [P, I64, I64, I64, P, P],
     "fqss_wq_observe": [P, I64, I64, I64, P, P, P],
     "fqss_wq_fwd": [P, P, P, I64, I64, I64, P, P, P],
@@ -127,6 +128,7 @@ _PROTOS = {
     "fqss_bcast_sum": [P, P, I64, I64, I32, P],
     "fqss_qrow_fwd": [P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_qrow_fwdq": [P, P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, P, P, P, P],
+    "fqss_qrow_fwdq2": [P, P, P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, I64, P, P, P, P, P],
     "fqss_qrow_bwd_x": [P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_qrow_bwd_w": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_qrow_bwd_w_batched": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, I64, I64, I64, P],

@@ -453,14 +453,17 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
                                                            int64_t R, int F, int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act,
                                                            const float* __restrict__ slope_p, int qmode, const float* __restrict__ qmin,
                                                            const float* __restrict__ qmax, double* gacc, float* gbias,
-                                                           int64_t rows_per_part) {
+                                                           int64_t rows_per_part, const float* __restrict__ qmin2 = nullptr,
+                                                           const float* __restrict__ qmax2 = nullptr, double* gacc2 = nullptr) {
     __shared__ double red[3 * 4];
     __shared__ float cb[16][64];
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     const bool post = act == FQSS_ACT_POST_RELU;
-    QRange r{0.0f, 1.0f, 1.0f};
+    const bool two = act == FQSS_ACT_RELU_Q;         // y = fq2(relu(fq(z))): NlQ(ReLU) behind the linear's own quantizer (host: qmode QUANT)
+    QRange r{0.0f, 1.0f, 1.0f}, r2{0.0f, 1.0f, 1.0f};
     if (qmode == FQSS_Q_QUANT) r = load_qrange(qmin, qmax);
-    float p_du = 0.0f, p_out = 0.0f, p_slope = 0.0f;
+    if (two) r2 = load_qrange(qmin2, qmax2);
+    float p_du = 0.0f, p_out = 0.0f, p_slope = 0.0f, p2_du = 0.0f, p2_out = 0.0f;
     float pb[4] = {0.f, 0.f, 0.f, 0.f};
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int f0 = blockIdx.x * 64 + tx * 4;                       // host: F % 4 == 0
@@ -484,6 +487,24 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float gj = gv[j];
+                        if (two) {
+                            // forward recomputed: y1 = fq(z), t2 = relu(y1), y2 = fq2(t2); backward in the order of the two modules:
+                            // NlQ (fqss_actq_bwd, act = ReLU, input y1), then the linear's quantizer (this kernel's plain form)
+                            float c1, u1, c2, u2;
+                            bool in1, in2;
+                            const float y1 = fq_asym(zv[j], r, c1, u1, in1);
+                            (void)fq_asym(act_apply(y1, FQSS_ACT_RELU, 0.0f), r2, c2, u2, in2);
+                            const float gt2 = in2 ? div_by(gj * r2.delta, r2.delta, r2.inv) : 0.0f;
+                            p2_du += gj * (in2 ? (c2 - u2) : c2);
+                            p2_out += in2 ? 0.0f : gj;
+                            float unused = 0.0f;
+                            const float g1 = act_bwd(y1, gt2, FQSS_ACT_RELU, 0.0f, true, unused);
+                            o[j] = in1 ? div_by(g1 * r.delta, r.delta, r.inv) : 0.0f;
+                            p_du += g1 * (in1 ? (c1 - u1) : c1);
+                            p_out += in1 ? 0.0f : g1;
+                            pb[j] += o[j];
+                            continue;
+                        }
                         const float t = post ? zv[j] : act_apply(zv[j], act, slope);
                         float gt = gj;
                         if (qmode == FQSS_Q_QUANT) {
@@ -525,6 +546,17 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
             slot[0] += (qmode == FQSS_Q_QUANT) ? v[1] - dmax : 0.0;
             slot[1] += (qmode == FQSS_Q_QUANT) ? dmax : 0.0;
             slot[2] += v[2];
+        }
+    }
+    if (two) {      // (workgroup-uniform) NlQ's range partials into ITS slots
+        __syncthreads();
+        double v[3] = {(double)p2_du, (double)p2_out, 0.0};
+        block_sum<double, 3>(v, red);
+        if (threadIdx.x == 0) {
+            double* slot = gacc2 + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+            const double dmax = v[0] / 255.0;
+            slot[0] += v[1] - dmax;
+            slot[1] += dmax;
         }
     }
 }
@@ -805,13 +837,32 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     return launch_status("fqss_actq_bwd");
 }
 
+static int actq_bwd_colbias_impl(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act,
+                                 const float* slope, int qmode, const float* qmin, const float* qmax, double* gacc, float* gbias,
+                                 const float* qmin2, const float* qmax2, double* gacc2, fqss_stream_t stream);
+
 extern "C" int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g,
                                      int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin, const float* qmax,
                                      double* gacc, float* gbias, fqss_stream_t stream) {
+    FQSS_REQUIRE(act != FQSS_ACT_RELU_Q, "two quantizers: fqss_actq2_bwd_colbias");
+    return actq_bwd_colbias_impl(z, g, gz, R, F, ld_z, ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, gbias, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int fqss_actq2_bwd_colbias(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g, int64_t ld_gz,
+                                      const float* qmin1, const float* qmax1, const float* qmin2, const float* qmax2, double* gacc1,
+                                      double* gacc2, float* gbias, fqss_stream_t stream) {
+    FQSS_REQUIRE(qmin1 && qmax1 && qmin2 && qmax2 && gacc1 && gacc2, "two quantizers: ranges and partial slots of both");
+    return actq_bwd_colbias_impl(z, g, gz, R, F, ld_z, ld_g, ld_gz, FQSS_ACT_RELU_Q, nullptr, FQSS_Q_QUANT, qmin1, qmax1, gacc1, gbias, qmin2, qmax2,
+                                 gacc2, stream);
+}
+
+static int actq_bwd_colbias_impl(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g, int64_t ld_gz, int act,
+                                 const float* slope, int qmode, const float* qmin, const float* qmax, double* gacc, float* gbias,
+                                 const float* qmin2, const float* qmax2, double* gacc2, fqss_stream_t stream) {
     if (R == 0 || F == 0) return FQSS_OK;
     FQSS_REQUIRE(z && g && gz, "null tensor");     // gbias may be NULL: the row-tiled pass alone (narrow matrices, see fqss_actq_bwd)
     FQSS_REQUIRE(R > 0 && F > 0 && ld_z >= F && ld_g >= F && ld_gz >= F, "bad shape");
-    FQSS_REQUIRE(((act >= 0 && act <= 2) || act == FQSS_ACT_POST_RELU) && qmode >= 0 && qmode <= 2, "bad act/qmode");
+    FQSS_REQUIRE(((act >= 0 && act <= 2) || act == FQSS_ACT_POST_RELU || act == FQSS_ACT_RELU_Q) && qmode >= 0 && qmode <= 2, "bad act/qmode");
     FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");
@@ -827,7 +878,7 @@ extern "C" int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, 
     const int64_t rows_per_part = cdiv(R, parts);
     parts = cdiv(R, rows_per_part);
     hipLaunchKernelGGL(k_actq_bwd_colbias, dim3((unsigned)slices, (unsigned)parts), dim3(256), 0, (hipStream_t)stream, z, g, gz, R, F, ld_z,
-                       ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, gbias, rows_per_part);
+                       ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, gbias, rows_per_part, qmin2, qmax2, gacc2);
     return launch_status("fqss_actq_bwd_colbias");
 }
 

@@ -886,8 +886,12 @@ __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRan
     }
 }
 
+#ifndef FQSS_EWQ_NR
+#define FQSS_EWQ_NR 8        // rows of loads in flight per thread (x FQSS_EWQ_WAVES waves per SIMD)
+#define FQSS_EWQ_WAVES 2
+#endif
 template <bool PLAIN>
-__global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
+__global__ __launch_bounds__(256, FQSS_EWQ_WAVES) void k_ewq_bwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
                                                   const float* __restrict__ bf, float sb, const float* __restrict__ g,
                                                   float* __restrict__ gz, int rows, int cols, int ld_a, int ld_b, int ld_bf,
                                                   int ld_g, int ld_gz, int act, const float* slope_p, const float* amin,
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void k_ewq_bwd(const uint8_t* __restrict__ ac,
         // consumed, UNCONDITIONALLY (row / column clamped into the tensor, the results of clamped groups dropped): a branch around a
         // load makes the compiler retire the loads in flight first, and the kernel is latency-bound (2 waves per SIMD, PMC: 64 % of
         // the wave time waiting on memory)
-        constexpr int NR = 8;
+        constexpr int NR = FQSS_EWQ_NR;
         const bool active = c_first < cols;
         const int c_ld = active ? c_first : 0;
         const int rstep = gridDim.y;

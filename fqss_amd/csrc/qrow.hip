@@ -37,6 +37,11 @@ struct QRowArgs {
     const float* slope;
     const float* qy_min;
     const float* qy_max;
+    // act = FQSS_ACT_RELU_Q: a second quantizer behind the first and a ReLU (NlQ(ReLU) after a LinearQ): y = fq2(relu(fq(z))), codes to yc
+    const float* qy2_min;
+    const float* qy2_max;
+    uint8_t* yc;
+    int64_t ld_yc;
 };
 
 // workgroup tile 128 (rows r) x 128 (outputs o), 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32); K in chunks of 64 bytes
@@ -114,7 +119,10 @@ __global__ __launch_bounds__(256, 3) void k_qrow_fwd(QRowArgs g) {     // (.., 3
         ry = load_qrange(g.qy_min, g.qy_max);
         if (g.act == FQSS_ACT_PRELU) slope = *g.slope;
     }
-    const bool post = g.y != nullptr && g.act == FQSS_ACT_POST_RELU;      // y = relu(fq(z)): the ReLU BEHIND the quantizer
+    const bool two = g.y != nullptr && g.act == FQSS_ACT_RELU_Q;          // y = fq2(relu(fq(z))) + codes (host: 16-B rows only)
+    const bool post = g.y != nullptr && (g.act == FQSS_ACT_POST_RELU || two);      // y = relu(fq(z)): the ReLU BEHIND the quantizer
+    QRange ry2{0.0f, 1.0f, 1.0f};
+    if (two) ry2 = load_qrange(g.qy2_min, g.qy2_max);
     // results leave through a wave-private LDS tile as whole 128-B rows, 16 B per lane (the lane-per-column layout of the MFMA result needs
     // 16 strided 4-B stores per 32 x 32 tile and operand: this kernel is bound by writing z -- and now y); 16-B aligned output rows
     // only, the scalar form below serves the rest
@@ -156,6 +164,17 @@ __global__ __launch_bounds__(256, 3) void k_qrow_fwd(QRowArgs g) {     // (.., 3
                                 float c, u;
                                 bool inr;
                                 { const float yv = fq_asym(post ? e[q] : act_apply(e[q], g.act, slope), ry, c, u, inr); yq[q] = (post && !(yv > 0.0f)) ? 0.0f : yv; }
+                            }
+                            if (two) {       // (workgroup-uniform) NlQ's quantizer on relu(fq(z)); host: Co % 4 == 0
+                                unsigned int pk = 0;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    float c, u;
+                                    bool inr;
+                                    yq[q] = fq_asym(yq[q], ry2, c, u, inr);
+                                    pk = pack_code(c, q, pk);
+                                }
+                                if (ob + c4 + 3 < g.Co) *reinterpret_cast<unsigned int*>(g.yc + row * g.ld_yc + ob + c4) = pk;
                             }
                         }
                         if (ob + c4 + 3 < g.Co) {
@@ -213,7 +232,7 @@ extern "C" int fqss_qrow_fwd(const uint8_t* xc, const int8_t* wk, const float* d
                  "bad shape (Ci a multiple of 16, <= 2048; code rows 16-B aligned)");
     FQSS_REQUIRE(aligned16(xc) && aligned16(wk), "code images must be 16-B aligned");
     if (R == 0) return FQSS_OK;
-    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, nullptr, 0, FQSS_ACT_NONE, nullptr, nullptr, nullptr};
+    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, nullptr, 0, FQSS_ACT_NONE, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     dim3 grid((unsigned)cdiv(Co, 128), (unsigned)cdiv(R, 128));
     hipLaunchKernelGGL(k_qrow_fwd, grid, dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qrow_fwd");
@@ -231,8 +250,26 @@ extern "C" int fqss_qrow_fwdq(const uint8_t* xc, const int8_t* wk, const float* 
     FQSS_REQUIRE(act == FQSS_ACT_NONE || act == FQSS_ACT_RELU || act == FQSS_ACT_POST_RELU || (act == FQSS_ACT_PRELU && slope),
                  "activation: none, ReLU, PReLU (with its slope) or a ReLU behind the quantizer");
     if (R == 0) return FQSS_OK;
-    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, y, ld_y, act, slope, qmin_y, qmax_y};
+    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, y, ld_y, act, slope, qmin_y, qmax_y, nullptr, nullptr, nullptr, 0};
     dim3 grid((unsigned)cdiv(Co, 128), (unsigned)cdiv(R, 128));
     hipLaunchKernelGGL(k_qrow_fwd, grid, dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_qrow_fwdq");
+}
+
+extern "C" int fqss_qrow_fwdq2(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias,
+                               const float* qmin_x, const float* qmax_x, float* z, float* y, uint8_t* yc, int64_t R, int Ci, int Co,
+                               int64_t ld_x, int64_t ld_z, int64_t ld_y, int64_t ld_yc, const float* qmin1, const float* qmax1,
+                               const float* qmin2, const float* qmax2, fqss_stream_t stream) {
+    FQSS_REQUIRE(xc && wk && dw && rw && qmin_x && qmax_x && z && y && yc && qmin1 && qmax1 && qmin2 && qmax2, "null tensor");
+    FQSS_REQUIRE(R >= 0 && Ci >= 16 && Ci % 16 == 0 && Ci <= 2048 && Co > 0 && Co % 4 == 0 && ld_x >= Ci && ld_x % 16 == 0 && ld_z >= Co &&
+                     ld_y >= Co && ld_yc >= Co,
+                 "bad shape (Ci a multiple of 16, <= 2048; Co a multiple of 4; code rows 16-B aligned)");
+    FQSS_REQUIRE(aligned16(xc) && aligned16(wk) && aligned16(z) && aligned16(y) && ld_z % 4 == 0 && ld_y % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(yc) & 3u) == 0 && ld_yc % 4 == 0,
+                 "code images and output rows must be 16-B aligned, code rows 4-B aligned");
+    if (R == 0) return FQSS_OK;
+    QRowArgs g{xc, wk, dw, rw, bias, qmin_x, qmax_x, z, R, ld_x, ld_z, Ci, Co, y, ld_y, FQSS_ACT_RELU_Q, nullptr, qmin1, qmax1, qmin2, qmax2, yc, ld_yc};
+    dim3 grid((unsigned)cdiv(Co, 128), (unsigned)cdiv(R, 128));
+    hipLaunchKernelGGL(k_qrow_fwd, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_qrow_fwdq2");
 }

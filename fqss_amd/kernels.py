@@ -176,6 +176,19 @@ def actq_bwd_colbias(z, g, act, slope, qmode, qmin, qmax, gacc, gbias):
     return gz
 
 
+def actq2_bwd_colbias(z, g, qmin1, qmax1, qmin2, qmax2, gacc1, gacc2, gbias):
+    """backward of qrow_fwdq2's epilogue (NlQ(ReLU) behind a LinearQ's quantizer) in one pass: gz + bias column sums + both range partials"""
+    _need_gpu(z, g, gbias)
+    F = z.shape[-1]
+    z, R, ld_z = _rows(z, F)
+    g, R2, ld_g = _rows(g, F)
+    assert R == R2, "actq2_bwd_colbias: z/g shape mismatch"
+    gz = torch.empty(*z.shape, device=z.device, dtype=torch.float32)
+    _lib.call("fqss_actq2_bwd_colbias", _p(z), _p(g), _p(gz), R, F, ld_z, ld_g, F, _p(qmin1), _p(qmax1), _p(qmin2), _p(qmax2), _p(gacc1), _p(gacc2),
+              _p(gbias), _stream())
+    return gz
+
+
 def colbias_ok(F):
     return F % 4 == 0 and F <= 64 * 2048
 
@@ -1548,6 +1561,20 @@ def qrow_fwdq(xc, wc, bias, qmin_x, qmax_x, act, slope, qmin_y, qmax_y):
     _lib.call("fqss_qrow_fwdq", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias), _p(qmin_x), _p(qmax_x), _p(z), _p(y), rm[0], Ci, Co, rm[2],
               Co, Co, act, _p(slope), _p(qmin_y), _p(qmax_y), _stream())
     return z, y
+
+
+def qrow_fwdq2(xc, wc, bias, qmin_x, qmax_x, qmin1, qmax1, qmin2, qmax2):
+    """qrow_fwd with BOTH quantizers of LinearQ -> NlQ(ReLU) in the GEMM epilogue -> (z, y = fq2(relu(fq1(z))), u8 codes of y)"""
+    Ci, Co = wc.Ci, wc.Co
+    assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci and Co % 4 == 0
+    rm = rowmat(xc)
+    assert rm is not None and rm[1] == Ci and rm[2] % 16 == 0, "activation codes need 16-B aligned rows"
+    z = torch.empty(*xc.shape[:-1], Co, device=xc.device, dtype=torch.float32)
+    y = torch.empty_like(z)
+    yc = torch.empty(*xc.shape[:-1], Co, device=xc.device, dtype=torch.uint8)
+    _lib.call("fqss_qrow_fwdq2", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias), _p(qmin_x), _p(qmax_x), _p(z), _p(y), _p(yc), rm[0], Ci, Co,
+              rm[2], Co, Co, Co, _p(qmin1), _p(qmax1), _p(qmin2), _p(qmax2), _stream())
+    return z, y, yc
 
 
 def qrow_bwd_ok(Ci, Co):

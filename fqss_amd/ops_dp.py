@@ -138,6 +138,33 @@ class RowLinearActQ(Function):
         return gx, gw, (None if gb_direct else gb), g_slope, g_min, g_max, None, None, None, None, None
 
 
+class RowLinearNlQ2(Function):
+    """fq2(relu(fq1(x @ w^T + bias))) -- a LinearQ followed by NlQ(ReLU) (the feed-forward block of the Sepformer layer, sepformerq.py:64)
+    with both quantizers in their quantizing phase and both GEMM operands on codes: ONE launch forward (int8 GEMM, both quantizers in
+    its epilogue, z + y + the codes of y) and one pass + two GEMMs backward.  The fp32 image of fq1(z) is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, qmin1, qmax1, qmin2, qmax2, q1, q2, qops):
+        touch(w, bias)
+        z, y, yc = K.qrow_fwdq2(qops[0].idx, qops[1], bias, qops[0].qmin, qops[0].qmax, qmin1, qmax1, qmin2, qmax2)
+        ctx.save_for_backward(x, w, z, qmin1, qmax1, qmin2, qmax2)
+        ctx.bias, ctx.q1, ctx.q2, ctx.xq = bias, q1, q2, qops[0]
+        q2.idx = yc
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, z, qmin1, qmax1, qmin2, qmax2 = ctx.saved_tensors
+        q1, q2 = ctx.q1, ctx.q2
+        gb, gb_direct = _param_grad(ctx.bias, ctx.bias)
+        gz = K.actq2_bwd_colbias(z, g.contiguous(), qmin1, qmax1, qmin2, qmax2, q1.gacc, q2.gacc, gb)
+        g_min1, g_max1 = ops._ranges_after(q1, q1.gacc)
+        g_min2, g_max2 = ops._ranges_after(q2, q2.gacc)
+        gx = _rowlinear_dgrad(gz, w) if ctx.needs_input_grad[0] else None
+        gw = _rowlinear_wgrad(ctx.needs_input_grad[1], x, w, gz, ctx.xq)
+        return gx, gw, (None if gb_direct else gb), g_min1, g_max1, g_min2, g_max2, None, None, None
+
+
 QROW = __import__("os").environ.get("FQSS_QROW", "1") != "0"    # student linears on codes (csrc/qrow.hip); 0: fp32-equivalent GEMM
 FUSE_QROWQ = __import__("os").environ.get("FQSS_FUSE_QROWQ", "1") != "0"    # their output quantizer in the GEMM epilogue (fqss_qrow_fwdq)
 

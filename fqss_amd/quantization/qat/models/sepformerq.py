@@ -82,6 +82,10 @@ class TransformerLayer(nn.Module):
         i = 0
         while i < len(mods):
             m = mods[i]
+            if isinstance(m, QL.LinearQ) and i + 1 < len(mods) and isinstance(mods[i + 1], QL.NlQ) and isinstance(mods[i + 1].nl, nn.ReLU):
+                h = QL.linear_then_relu_q(m, mods[i + 1], h)          # LinearQ -> NlQ(ReLU): both quantizers in the GEMM's epilogue
+                i += 2
+                continue
             if isinstance(m, QL.LinearQ) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 h = m(h, post_relu=True)          # LinearQ -> nn.ReLU: the ReLU rides in the output quantizer's pass each way
                 i += 2

@@ -726,6 +726,38 @@ def run_linear(lin, x, weight, nl, aq, post_relu=False):
     return linear_fq(x, weight, lin.bias, nl, aq, post_relu)
 
 
+FUSE_NLQ2 = os.environ.get("FQSS_FUSE_NLQ2", "1") != "0"    # LinearQ -> NlQ(ReLU): both quantizers in the int8 GEMM's epilogue
+
+
+def _quantizing(aq):
+    """a GradientActivationFakeQuantize past its observer phase with partial-sum slots (what qctx() WILL answer, without advancing it)"""
+    return (getattr(aq, "observer_mode", None) is not None and not (aq.observer_mode and aq.n_iter < aq.max_observations)
+            and getattr(aq, "_gacc", None) is not None)
+
+
+def linear_then_relu_q(lq, nlq, x):
+    """nlq(lq(x)) for a LinearQ followed by NlQ(ReLU) (the Sepformer feed-forward block): one launch forward, one pass backward when both
+    quantizers quantize and the GEMM runs on codes (ops_dp.RowLinearNlQ2); any other state takes the two modules as they are"""
+    aq1, aq2 = lq.activation_fake_quantize, nlq.activation_fake_quantize
+    lin = lq.linear
+    if (FUSE_NLQ2 and FUSE_ROWQ and ops.CODED and isinstance(nlq.nl, nn.ReLU) and lin.bias is not None and lin.out_features % 4 == 0
+            and K.colbias_ok(lin.out_features) and _quantizing(aq1) and _quantizing(aq2)):
+        weight = lq._wq(lin.weight)
+        qops = ops_dp.qrow_operands(x, weight) if weight.dim() == 2 else None
+        if qops is not None and ops_dp.FUSE_QROWQ:
+            q1, q2 = aq1.qctx(), aq2.qctx()
+            if q1.qmode != ops.Q_QUANT or q2.qmode != ops.Q_QUANT or q1.gacc is None or q2.gacc is None:
+                raise RuntimeError("linear_then_relu_q: quantizer state changed between the check and qctx()")
+            y = ops_dp.RowLinearNlQ2.apply(x, weight, lin.bias, q1.qmin, q1.qmax, q2.qmin, q2.qmax, q1, q2, qops)
+            aq1.after_forward(q1)
+            aq2.after_forward(q2)
+            idx, q2.idx = q2.idx, None
+            y._fqss_rowq = ops.ActCodes(idx.view(y.shape), q2.qmin.detach(), q2.qmax.detach())
+            return y
+        return nlq(run_linear(lin, x, weight, None, aq1))
+    return nlq(lq(x))
+
+
 def linear_fq(x, weight, bias, nl, aq, post_relu=False):
     """fq(nl(x @ weight^T + bias)) on row-major tensors: LinearQ / LinearNlQ and the attention output projection;
     post_relu: relu(fq(...)) -- the caller's F.relu / nn.ReLU on the layer's output, in the quantizer's pass (act = ACT_POST_RELU)"""

@@ -45,7 +45,8 @@ extern "C" {
 #define FQSS_ACT_PRELU 1 /* one shared slope, nn.PReLU() */
 #define FQSS_ACT_RELU 2
 #define FQSS_ACT_GELU 3 /* nn.GELU(), erf form: fqss_actq_fwd / fqss_actq_bwd only (the HTDemucs layers) */
-#define FQSS_ACT_POST_RELU 4 /* a ReLU BEHIND the quantizer, relu(fq(z)): fqss_actq_fwd / fqss_actq_bwd only (dptnetq.py:92) */
+#define FQSS_ACT_POST_RELU 4
+#define FQSS_ACT_RELU_Q 5     /* fq2(relu(fq(z))): a LinearQ followed by NlQ(ReLU), both quantizers live (fqss_qrow_fwdq2 / fqss_actq2_bwd_colbias only) */ /* a ReLU BEHIND the quantizer, relu(fq(z)): fqss_actq_fwd / fqss_actq_bwd only (dptnetq.py:92) */
 
 typedef void* fqss_stream_t;
 
@@ -104,6 +105,11 @@ int fqss_gacc_flush(double* gacc, float* gmin, float* gmax, float* gslope, fqss_
 int fqss_actq_bwd_colbias(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g,
                           int64_t ld_gz, int act, const float* slope, int qmode, const float* qmin,
                           const float* qmax, double* gacc, float* gbias, fqss_stream_t stream);
+/* backward of fqss_qrow_fwdq2's epilogue in one pass over (z, g): NlQ's STE + ReLU (range partials -> gacc2), the linear's STE (range
+ * partials -> gacc1), gz and the bias column sums -- fqss_actq_bwd(act = ReLU) followed by fqss_actq_bwd_colbias, fused */
+int fqss_actq2_bwd_colbias(const float* z, const float* g, float* gz, int64_t R, int F, int64_t ld_z, int64_t ld_g, int64_t ld_gz,
+                           const float* qmin1, const float* qmax1, const float* qmin2, const float* qmax2, double* gacc1, double* gacc2,
+                           float* gbias, fqss_stream_t stream);
 
 /* running min/max of a plain tensor into obs_ws (used by the splitter's global max, process.py:24) */
 int fqss_minmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* obs_ws,
@@ -669,6 +675,12 @@ int fqss_qrow_fwdq(const uint8_t* xc, const int8_t* wk, const float* dw, const f
                    const float* qmin_x, const float* qmax_x, float* z, float* y, int64_t R, int Ci, int Co, int64_t ld_x,
                    int64_t ld_z, int64_t ld_y, int act, const float* slope, const float* qmin_y, const float* qmax_y,
                    fqss_stream_t stream);
+/* LinearQ -> NlQ(ReLU) of a feed-forward block (sepformerq.py:64 `ffn`, qat_layers.py:521-536 and 409-432) from ONE launch:
+ * z (kept for the backward), y = fq2(relu(fq1(z))) and its u8 codes yc -- operation for operation what fqss_qrow_fwdq followed by
+ * fqss_actq_fwd(act = ReLU) compute; the fp32 image of fq1(z) is never stored.  q1 = the linear's own output quantizer, q2 = NlQ's */
+int fqss_qrow_fwdq2(const uint8_t* xc, const int8_t* wk, const float* dw, const float* rw, const float* bias, const float* qmin_x,
+                    const float* qmax_x, float* z, float* y, uint8_t* yc, int64_t R, int Ci, int Co, int64_t ld_x, int64_t ld_z, int64_t ld_y,
+                    int64_t ld_yc, const float* qmin1, const float* qmax1, const float* qmin2, const float* qmax2, fqss_stream_t stream);
 /* the gradient GEMMs of such a linear on the same codes (csrc/gemm_x3.hip, coded-B forms): the 8-bit operand is one exact bf16 plane,
  * three MFMA products per k instead of the six of the fp32 x fp32 form.
  *   fqss_qrow_bwd_x: gx[r][i]  = sum_o gz[r][o] * (dw[o] * wi[o][i])       wi int8 [Co][Ci] dense

@@ -404,3 +404,49 @@ def test_relu_behind_a_linear_rides_in_its_quantizer(coded_input, monkeypatch):
         assert f[i] is not None and u[i] is not None, name
         err = float((f[i] - u[i]).norm() / (u[i].norm() + 1e-12))
         assert err <= 1e-4, (name, err)
+
+
+def test_linear_then_relu_quantizer_in_one_launch(monkeypatch):
+    """B2-style gate: LinearQ -> NlQ(ReLU) -> LinearQ (the feed-forward block of the QUANTIZED Sepformer layer, sepformerq.py:64: the
+    reference's quantize_model wraps the ReLU in its own quantizer) with both quantizers in the int8 GEMM's epilogue
+    (fqss_qrow_fwdq2) and one backward pass (fqss_actq2_bwd_colbias) against the two modules as they are: output and the codes handed
+    to the next linear bit-identical, every gradient (input, weights, biases, all three quantizers' ranges) within fp32 summation noise"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    R, Ci, Ch = 4000, 64, 256
+    x0, g0 = rnd(R, 1, Ci, seed=1).cuda(), rnd(R, 1, Ci, seed=2).cuda()
+    res = {}
+    for kind in ("fused", "unfused"):
+        monkeypatch.setattr(QL, "FUSE_NLQ2", kind == "fused")
+        torch.manual_seed(5)
+        ln = QL.LayerNormQ(nn.LayerNorm(Ci), gradient_based=True, act_quant=True).cuda()
+        l1 = QL.LinearQ(nn.Linear(Ci, Ch), gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8).cuda()
+        nl = QL.NlQ(nn.ReLU(), gradient_based=True, act_quant=True).cuda()
+        l2 = QL.LinearQ(nn.Linear(Ch, Ci), gradient_based=True, weight_quant=True, act_quant=True, act_n_bits=8, weight_n_bits=8).cuda()
+        seen = {}
+
+        def fwd(x):
+            h = QL.linear_then_relu_q(l1, nl, ln(x))
+            seen["h"] = h
+            return l2(h)
+        with torch.no_grad():
+            for _ in range(50):
+                fwd(x0)
+        x = x0.clone().requires_grad_(True)
+        y = fwd(x)
+        h = seen["h"]
+        codes = getattr(h, "_fqss_rowq", None) or getattr(h, "_fqss_q", None)
+        assert codes is not None, "the feed-forward's second linear must find the codes of its input"
+        y.backward(g0)
+        grads = [x.grad, l1.linear.weight.grad, l1.linear.bias.grad, l2.linear.weight.grad, l2.linear.bias.grad]
+        for m in (l1, nl, l2):
+            grads += [m.activation_fake_quantize.min_range.grad, m.activation_fake_quantize.max_range.grad]
+        res[kind] = (y.detach(), h.detach().clone(), codes.idx.clone().view(-1), grads)
+        monkeypatch.undo()
+    f, u = res["fused"], res["unfused"]
+    assert torch.equal(f[0], u[0]) and torch.equal(f[1], u[1]) and torch.equal(f[2], u[2])
+    assert float((f[1] == f[1].min()).float().mean()) > 0.2          # the ReLU bites
+    names = ("dx", "dW1", "db1", "dW2", "db2", "min1", "max1", "min_nl", "max_nl", "min2", "max2")
+    for name, a, b in zip(names, f[3], u[3]):
+        assert a is not None and b is not None, name
+        err = float((a - b).norm() / (b.norm() + 1e-12))
+        assert err <= 3e-4, (name, err)
