@@ -887,8 +887,8 @@ __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRan
 }
 
 #ifndef FQSS_EWQ_NR
-#define FQSS_EWQ_NR 8        // rows of loads in flight per thread (x FQSS_EWQ_WAVES waves per SIMD)
-#define FQSS_EWQ_WAVES 2
+#define FQSS_EWQ_NR 4        // rows of loads in flight per thread (x FQSS_EWQ_WAVES waves per SIMD; 8 x 2 before: 196 VGPRs)
+#define FQSS_EWQ_WAVES 3
 #endif
 template <bool PLAIN>
 __global__ __launch_bounds__(256, FQSS_EWQ_WAVES) void k_ewq_bwd(const uint8_t* __restrict__ ac, const uint8_t* __restrict__ bc,
