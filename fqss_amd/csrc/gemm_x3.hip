@@ -8,7 +8,8 @@
 // contiguous, optional row / column bias, optional split-K with atomics.  It serves the row-major linears of the dual-path
 // models (fqss_rowlin_fwd / bwd_x / bwd_w) whenever the 16-B vector path applies; k_gemm_f32 remains the general fallback.
 //
-// LDS image: planes[3][rows][BK = 32 bf16 + pad] per operand (k contiguous), so an MFMA operand is ONE 16-B read per lane.
+// LDS image: planes[3][rows][BK = 32 bf16] per operand (k contiguous, the 16-B chunks of a row XOR-swizzled instead of padded: see
+// XLDK / xsw below), so an MFMA operand is ONE 16-B read per lane; an operand that arrives as 8-bit codes keeps one plane.
 // Operands whose k dimension is strided in memory are transposed on the way in: a thread owns a 4 (rows) x 4 (k) block -- four
 // coalesced float4 loads along the contiguous dimension, then one 8-B LDS write per row and plane.
 // Measured dead end: k-tiles of 16 with two LDS buffers and one barrier per tile (split + store of tile kt+1 under the MFMAs of

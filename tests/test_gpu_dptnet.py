@@ -747,6 +747,34 @@ def test_qrow_kernel_exact_integer_sums(R, Ci, Co):
         z2, y2 = K.qrow_fwdq(xc, wc, b, lo, hi, act, sl, qlo, qhi)
         assert torch.equal(z2, z)
         assert torch.equal(y2, K.actq_fwd(z, act, sl, ops.Q_QUANT, qlo, qhi, None)), act
+    # two quantizers and a ReLU in the epilogue (fqss_qrow_fwdq2: LinearQ -> NlQ(ReLU)) = the chain of the three passes, bit for bit
+    if Co % 4 == 0:
+        q2lo, q2hi = torch.tensor([-0.1], device="cuda"), torch.tensor([1.5], device="cuda")
+        z3, y3, c3 = K.qrow_fwdq2(xc, wc, b, lo, hi, qlo, qhi, q2lo, q2hi)
+        y1 = K.actq_fwd(z, ops.ACT_NONE, None, ops.Q_QUANT, qlo, qhi, None)
+        want = K.actq_fwd(y1, ops.ACT_RELU, None, ops.Q_QUANT, q2lo, q2hi, None)
+        assert torch.equal(z3, z) and torch.equal(y3, want)
+        d2 = (q2hi - q2lo) / 255.0
+        assert torch.equal(c3.float(), torch.round((want - q2lo) / d2).clamp(0, 255))
+
+
+@pytest.mark.parametrize("R,Ci,Co", [(3000, 64, 512), (129, 16, 8)])
+def test_qrow_bwd_w_pair_is_two_coded_weight_gradients(R, Ci, Co, monkeypatch):
+    """both directions' W_ih gradients of LSTMQ on the input's codes (two column blocks of dG, one launch) == two launches == fp64"""
+    from fqss_amd import kernels as K
+    dG = rnd(R, 2 * Co, seed=61).cuda()
+    xc = torch.randint(0, 256, (R, Ci), generator=torch.Generator().manual_seed(62), dtype=torch.uint8).cuda()
+    lo, hi = torch.tensor([-0.8], device="cuda"), torch.tensor([1.7], device="cuda")
+    x = ((hi - lo) / 255.0).double().cpu() * xc.cpu().double() + lo.double().cpu()
+    want = [dG[:, :Co].cpu().double().T @ x, dG[:, Co:].cpu().double().T @ x]
+    for on in (True, False):
+        monkeypatch.setattr(K, "PAIR_WGRAD", on)
+        flat = torch.zeros(2 * Co * Ci + 64, device="cuda")
+        g0, g1 = flat[:Co * Ci].view(Co, Ci), flat[Co * Ci + 64:].view(Co, Ci)
+        K.qrow_bwd_w_pair(dG[:, :Co], dG[:, Co:], xc, lo, hi, g0, g1)
+        close(g0, want[0], 1e-5, msg=f"forward direction, pair={on}")
+        close(g1, want[1], 1e-5, msg=f"reverse direction, pair={on}")
+        assert float(flat[Co * Ci:Co * Ci + 64].abs().max()) == 0
 
 
 @pytest.mark.parametrize("R,C", [(48500, 64), (1000, 256), (77, 16)])
