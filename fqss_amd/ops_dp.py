@@ -490,6 +490,26 @@ class MhaCore(Function):
         return (gX, None, None, *grads)
 
 
+def _lstm_pack(wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, on_codes):
+    """the two directions' matrices side by side, as the kernels take them: wih [8H, I], whh [2, 4H, H], bih [8H], bhh [2, 4H] (memory
+    plumbing: four small copies).  A FROZEN module (the float teacher: no gradient anywhere, parameters never rewritten) keeps the
+    packed copies on its first parameter, keyed by the parameters' versions; the student's projections on codes never read bih"""
+    ps = (wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r)
+    frozen = not torch.is_grad_enabled() and all(isinstance(p, torch.nn.Parameter) and not p.requires_grad for p in ps)
+    if frozen:
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = getattr(wih_f, "_fqss_lstm_pack", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    wih = torch.cat([wih_f, wih_r], 0)
+    whh = torch.stack([whh_f, whh_r], 0).contiguous()
+    bih = None if on_codes else torch.cat([bih_f, bih_r], 0)
+    bhh = torch.stack([bhh_f, bhh_r], 0).contiguous()
+    if frozen and not (wih.is_cuda and torch.cuda.is_current_stream_capturing()):      # (never keep memory of a graph's private pool)
+        wih_f._fqss_lstm_pack = (key, (wih, whh, bih, bhh))
+    return wih, whh, bih, bhh
+
+
 class LstmBi(Function):
     """Bidirectional single-layer LSTM with zero initial state on sequence-first input [S, B, I] (LSTMQ, qat_layers.py:571-600).
     Weights arrive already fake-quantized (or float): w_ih [2][4H, I], w_hh [2][4H, H], biases are parameters."""
@@ -502,10 +522,7 @@ class LstmBi(Function):
         on_codes = QROW and xq is not None and wc_f is not None and wc_r is not None and K.qrow_eligible(I) \
             and xq.idx.shape == x.shape and xq.idx.is_contiguous()
         qf, qr = ((xq, wc_f), (xq, wc_r)) if on_codes else (None, None)
-        wih = torch.cat([wih_f, wih_r], 0)                 # [8H, I]   (memory plumbing: 2 x 128 KB)
-        whh = torch.stack([whh_f, whh_r], 0).contiguous()  # [2, 4H, H]
-        bih = torch.cat([bih_f, bih_r], 0)
-        bhh = torch.stack([bhh_f, bhh_r], 0).contiguous()
+        wih, whh, bih, bhh = _lstm_pack(wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, on_codes)
         if qf is not None and qr is not None:
             # quantizing phase: x and both W_ih sit on 8-bit grids -> the projections run on the codes (int8 MFMA), one launch per
             # direction into the two column blocks of `pre`
