@@ -131,6 +131,7 @@ _PROTOS = {
     "fqss_qrow_fwdq2": [P, P, P, P, P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, I64, P, P, P, P, P],
     "fqss_qrow_bwd_x": [P, P, P, P, I64, I32, I32, I64, I64, P],
     "fqss_qrow_bwd_w": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
+    "fqss_qrow_bwd_wb": [P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_qrow_bwd_w_batched": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, I64, I64, I64, P],
     "fqss_glu_fwd": [P, P, I64, I64, I64, I64, I64, P],
     "fqss_glu_bwd": [P, P, P, I64, I64, I64, I64, I64, I64, P],

@@ -385,6 +385,7 @@ struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
     const unsigned short* Bp;
     int64_t ldp;
     int scalar_stores;
+    float* rowsum_out;
 };
 int launch_gemm_x3_imp(const GemmArgs3& g, bool wgrad, hipStream_t s, const char* what);
 int launch_gemm_x3(const GemmArgs3& g, bool a_kc, bool b_kc, bool atomic, hipStream_t s, const char* what, bool* used);
@@ -479,7 +480,7 @@ extern "C" int fqss_qrow_bwd_x(const float* gz, const int8_t* wi, const float* d
 
 static int qrow_bwd_w_impl(const char* who, const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R,
                            int Ci, int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, int batch, int64_t sb_gz, int64_t sb_xc, int64_t sb_gw,
-                           fqss_stream_t stream) {
+                           fqss_stream_t stream, float* gbias = nullptr) {
     FQSS_REQUIRE(gz && xc && qmin_x && qmax_x && gw, "null tensor");
     FQSS_REQUIRE(R >= 0 && R < (1ll << 31) && Ci > 0 && Co > 0 && ld_gz >= Co && ld_xc >= Ci && ld_gw >= Ci && batch >= 1 && batch <= 64, "bad shape");
     FQSS_REQUIRE(Ci % 4 == 0 && Co % 4 == 0 && ld_gz % 4 == 0 && ld_xc % 4 == 0 && aligned16(gz) && ((uintptr_t)xc & 3) == 0 && sb_gz % 4 == 0 &&
@@ -500,12 +501,21 @@ static int qrow_bwd_w_impl(const char* who, const float* gz, const uint8_t* xc, 
     g.kchunk = kchunk;
     g.ksplit = (int)cdiv(R, kchunk);
     g.Bq = xc; g.qmin_x = qmin_x; g.qmax_x = qmax_x;
+    g.rowsum_out = gbias;
     return launch_gemm_x3q(g, 1, (hipStream_t)stream, who);
 }
 
 extern "C" int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, int64_t R, int Ci,
                                int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream) {
     return qrow_bwd_w_impl("fqss_qrow_bwd_w", gz, xc, qmin_x, qmax_x, gw, R, Ci, Co, ld_gz, ld_xc, ld_gw, 1, 0, 0, 0, stream);
+}
+
+// fqss_qrow_bwd_w that also ADDS the bias gradient gbias[o] += sum_r gz[r][o]: the kernel keeps these row sums of its A operand anyway
+// (the min_x term of the coded product), so the separate column-sum pass over gz (fqss_colsum) disappears
+extern "C" int fqss_qrow_bwd_wb(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, float* gbias, int64_t R,
+                                int Ci, int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream) {
+    FQSS_REQUIRE(gbias, "null bias gradient");
+    return qrow_bwd_w_impl("fqss_qrow_bwd_wb", gz, xc, qmin_x, qmax_x, gw, R, Ci, Co, ld_gz, ld_xc, ld_gw, 1, 0, 0, 0, stream, gbias);
 }
 
 // `batch` coded weight gradients of one shape and one input range in ONE launch (problem p: gz + p sb_gz, xc + p sb_xc bytes, gw + p sb_gw):

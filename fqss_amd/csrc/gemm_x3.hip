@@ -53,6 +53,7 @@ struct GemmArgs3 {
     const unsigned short* Bp;
     int64_t ldp;
     int scalar_stores;       // 1: the lane-per-column epilogue (FQSS_X3_STAGED=0, A/B measurements)
+    float* rowsum_out;       // BQ = 1, optional: sum_k A(i, k) is ADDED here ([M]: the bias gradient of the linear whose weight gradient this is)
 };
 
 #ifndef FQSS_X3_PF
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
         const float lo = *g.qmin_x, hi = *g.qmax_x;
         dx = (hi - lo) / 255.0f;
         mnx = lo;
+        // (the first column tile of every k-slice hands its row sums on: the bias gradient, summed over the slices by the atomics)
+        if (g.rowsum_out != nullptr && blockIdx.x == 0 && threadIdx.x < BMt && i0 + (int)threadIdx.x < g.M)
+            atomicAdd(&g.rowsum_out[i0 + threadIdx.x], rsum_s[threadIdx.x]);
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if constexpr (!ATOMIC) {

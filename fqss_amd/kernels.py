@@ -1591,15 +1591,19 @@ def qrow_bwd_x(gz, wc):
     return gx
 
 
-def qrow_bwd_w(gz, xc, qmin_x, qmax_x, gw):
-    """gw [Co, Ci] += gz^T @ dec(xc) from the activation's u8 codes (dense rows)"""
-    _need_gpu(gz, gw)
+def qrow_bwd_w(gz, xc, qmin_x, qmax_x, gw, gbias=None):
+    """gw [Co, Ci] += gz^T @ dec(xc) from the activation's u8 codes (dense rows); gbias [Co] (optional) += column sums of gz"""
+    _need_gpu(gz, gw, gbias)
     Co, Ci = gw.shape
     assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci and gw.is_contiguous()
     gz, R, ld_gz = _rows(gz, Co)
     rm = rowmat(xc)
     assert rm is not None and rm[0] == R and rm[1] == Ci
-    _lib.call("fqss_qrow_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), R, Ci, Co, ld_gz, rm[2], Ci, _stream())
+    if gbias is not None:
+        assert gbias.numel() == Co and gbias.is_contiguous()
+        _lib.call("fqss_qrow_bwd_wb", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), _p(gbias), R, Ci, Co, ld_gz, rm[2], Ci, _stream())
+    else:
+        _lib.call("fqss_qrow_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), R, Ci, Co, ld_gz, rm[2], Ci, _stream())
 
 
 def qrow_bwd_w_pair(gz0, gz1, xc, qmin_x, qmax_x, gw0, gw1):

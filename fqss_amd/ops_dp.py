@@ -42,13 +42,19 @@ def _rowlinear_dgrad(gz, w):
     return K.rowlin_bwd_x(gz, w)
 
 
-def _rowlinear_wgrad_into(gz, x, xq, buf):
-    """buf [Co, Ci] += gz^T x: from the activation's u8 codes when the forward ran on them"""
+WGRAD_BIAS = __import__("os").environ.get("FQSS_WGRAD_BIAS", "1") != "0"    # the bias gradient out of the coded weight-gradient launch
+
+
+def _rowlinear_wgrad_into(gz, x, xq, buf, gbias=None):
+    """buf [Co, Ci] += gz^T x: from the activation's u8 codes when the forward ran on them.  gbias (optional, [Co]): the linear's bias
+    gradient buffer -- the coded launch adds the column sums of gz into it on the side; returns True when it did"""
     if QROW_BWD and xq is not None and buf.dim() == 2 and buf.is_contiguous() and xq.idx.is_contiguous() \
             and xq.idx.shape[-1] == buf.shape[1] and K.qrow_bwd_ok(buf.shape[1], buf.shape[0]):
-        K.qrow_bwd_w(gz, xq.idx, xq.qmin, xq.qmax, buf)
-    else:
-        K.rowlin_bwd_w(gz, x, buf)
+        with_bias = WGRAD_BIAS and gbias is not None and gbias.is_contiguous() and gbias.numel() == buf.shape[0]
+        K.qrow_bwd_w(gz, xq.idx, xq.qmin, xq.qmax, buf, gbias if with_bias else None)
+        return with_bias
+    K.rowlin_bwd_w(gz, x, buf)
+    return False
 
 
 def _rowlinear_wgrad_pair_into(gz0, gz1, x, xq, buf0, buf1):
@@ -78,19 +84,19 @@ class RowLinear(Function):
         xq = getattr(ctx, "xq", None)           # RowLinearQ: the codes the forward multiplied
         gx = _rowlinear_dgrad(gz, w) if ctx.needs_input_grad[0] else None
         gw = None
+        gb, gb_direct, gb_done = None, True, False
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            gb, gb_direct = _param_grad(ctx.bias, ctx.bias)
         gwq = getattr(w, "_fqss_gwq", None)     # weight fake-quantized by runtime.QuantTables (no autograd history): dL/dW_q goes
         if gwq is not None:                     # into the step's arena, consumed by fqss_wq_multi_bwd
-            _rowlinear_wgrad_into(gz, x, xq, gwq)
+            gb_done = _rowlinear_wgrad_into(gz, x, xq, gwq, gb)
         elif ctx.needs_input_grad[1]:
             gw, direct = _param_grad(w, w)
-            _rowlinear_wgrad_into(gz, x, xq, gw)
+            gb_done = _rowlinear_wgrad_into(gz, x, xq, gw, gb)
             gw = None if direct else gw
-        gb = None
-        if ctx.bias is not None and ctx.needs_input_grad[2]:
-            gb, direct = _param_grad(ctx.bias, ctx.bias)
+        if gb is not None and not gb_done:
             K.colsum(gz, gb)
-            gb = None if direct else gb
-        return gx, gw, gb
+        return gx, gw, (None if gb_direct else gb)
 
 
 def _rowlinear_wgrad(ctx_needs_w, x, w, gz, xq=None):

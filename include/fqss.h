@@ -690,6 +690,10 @@ int fqss_qrow_bwd_x(const float* gz, const int8_t* wi, const float* dw, float* g
                     int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
 int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw,
                     int64_t R, int Ci, int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream);
+/* fqss_qrow_bwd_w that also adds the bias gradient gbias[o] += sum_r gz[r][o] (the kernel keeps these sums for the min_x term of the coded
+ * product anyway): replaces the `fqss_colsum` pass behind F.linear's autograd (qat_layers.py:521-536) */
+int fqss_qrow_bwd_wb(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, float* gbias, int64_t R, int Ci,
+                     int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream);
 /* `batch` coded weight gradients of one shape and one input range in ONE launch: problem p reads gz + p*sb_gz (floats), xc + p*sb_xc
  * (bytes) and adds into gw + p*sb_gw (floats) -- the W_ih gradients of the two directions of LSTMQ (qat_layers.py:571-600): two column
  * blocks of dG against the same input codes */

@@ -962,3 +962,8 @@ def test_coded_gradient_row_gemms(R, Ci, Co):
     nrm = float((ref - 0.5).norm())
     assert float((gw.double() - ref).norm()) <= 2e-6 * nrm, float((gw.double() - ref).norm()) / nrm
     assert float((gw_f.double() - ref).norm()) <= 2e-6 * nrm
+    # the same launch with the bias gradient on the side (fqss_qrow_bwd_wb): gw unchanged, gbias += column sums of gz
+    gw_b, gb = torch.full((Co, Ci), 0.5, device=dev), torch.full((Co,), 0.25, device=dev)
+    K.qrow_bwd_w(gz, xc, lo, hi, gw_b, gb)
+    assert float((gw_b.double() - ref).norm()) <= 2e-6 * nrm
+    close(gb, 0.25 + gz.double().sum(0), 5e-6)
