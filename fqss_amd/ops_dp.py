@@ -322,13 +322,28 @@ class Permute4(Function):
         return K.permute4(g.contiguous(), ctx.dims_in, ctx.sback, ctx.C).view(ctx.xshape), None, None, None, None
 
 
+PERMUTE_CODES = __import__("os").environ.get("FQSS_PERMUTE_CODES", "1") != "0"    # the u8 codes of a row tensor travel through the layout change
+
+
+def _codes_along(x, y, dims_out, strides_in):
+    """x -> y was a Permute4 of rows of N features; when x carries the u8 codes of the quantizer that made it (`_fqss_rowq`), move them the
+    same way (the same kernel on a 4-codes-per-float view: N / 4 floats per row) and tag y -- the linear that follows then runs on codes"""
+    xq = getattr(x, "_fqss_rowq", None)
+    N = x.shape[-1]
+    if not PERMUTE_CODES or xq is None or N % 4 or xq.idx.shape != x.shape or not xq.idx.is_contiguous():
+        return y
+    idx = K.permute4(xq.idx.view(torch.float32), dims_out, tuple(s // 4 for s in strides_in), N // 4)
+    y._fqss_rowq = ops.ActCodes(idx.view(torch.uint8).view(y.shape), xq.qmin, xq.qmax)
+    return y
+
+
 def rows_to_cols(x, B, S):
     """intra-chunk layout [K, B*S, N] -> inter-chunk layout [S, B*K, N]"""
     Kc, BS, N = x.shape
     assert BS == B * S
     # out[s][b][k] = in[k][b*S + s]
     y = Permute4.apply(x, (S, B, Kc), (N, S * N, BS * N), (Kc, B, S), (N, Kc * N, B * Kc * N))
-    return y.view(S, B * Kc, N)
+    return _codes_along(x, y.view(S, B * Kc, N), (S, B, Kc), (N, S * N, BS * N))
 
 
 def cols_to_rows(x, B, Kc):
@@ -336,7 +351,7 @@ def cols_to_rows(x, B, Kc):
     S, BK, N = x.shape
     assert BK == B * Kc
     y = Permute4.apply(x, (Kc, B, S), (N, Kc * N, BK * N), (S, B, Kc), (N, S * N, B * S * N))
-    return y.view(Kc, B * S, N)
+    return _codes_along(x, y.view(Kc, B * S, N), (Kc, B, S), (N, Kc * N, BK * N))
 
 
 class Segment(Function):
