@@ -538,11 +538,13 @@ int launch_gemm_x3(const GemmArgs3& g_in, bool a_kc, bool b_kc, bool atomic, hip
         const int64_t t2 = cdiv(g.M, 128) * cdiv(g.N, 128) * zdim;
         mi = (a_kc && !b_kc) ? (t2 < 256 ? 1 : 2) : (t2 < 320 ? 1 : 2);
     }
-    if (x3_force_mi() && ni == 2 && g.M > 64) mi = x3_force_mi() == 1 ? 1 : 2;
+    if (x3_force_mi() && ni == 2 && g.M > 64) mi = x3_force_mi() == 2 ? 2 : 1;
+    if (x3_force_mi() == 3 && ni == 2 && g.M > 64 && !(a_kc && b_kc && g.Bp != nullptr)) ni = 1;      // 64 x 64 tiles (sweeps)
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3(AK, BKc, AT)                                                                                  \
     do {                                                                                                      \
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 2>), grid, block, x3_lds_pad(2, 2, false), s, g);    \
+        if (mi == 1 && ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 1, 1>), grid, block, x3_lds_pad(1, 1, false), s, g);    \
+        else if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 2>), grid, block, x3_lds_pad(2, 2, false), s, g);    \
         else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 2, 1>), grid, block, x3_lds_pad(2, 1, false), s, g);          \
         else hipLaunchKernelGGL((k_gemm_x3<AK, BKc, AT, 1, 2>), grid, block, x3_lds_pad(1, 2, false), s, g);                       \
     } while (0)
@@ -601,11 +603,13 @@ int launch_gemm_x3q(const GemmArgs3& g_in, int bq, hipStream_t s, const char* wh
     // (measured over the cfg 3 / 4 / 5 shapes, tools/kprobe.py: 512 x 512 float 91 -> 74 us, coded 71 -> 61 us)
     if (atomic && g.M > 64 && g.N > 64) mi = 2;
     if (!atomic && g.M > 128 && g.N > 64) mi = cdiv(g.M, 128) * cdiv(g.N, 128) * zdim < 320 ? 1 : 2;
-    if (x3_force_mi() && ni == 2 && g.M > 64) mi = x3_force_mi() == 1 ? 1 : 2;
+    if (x3_force_mi() && ni == 2 && g.M > 64) mi = x3_force_mi() == 2 ? 2 : 1;
+    if (x3_force_mi() == 3 && ni == 2 && g.M > 64) ni = 1;
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3Q(AK, AT, Q)                                                                                      \
     do {                                                                                                         \
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 2, Q>), grid, block, x3_lds_pad(2, 2, true), s, g);  \
+        if (mi == 1 && ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 1, 1, Q>), grid, block, x3_lds_pad(1, 1, true), s, g);  \
+        else if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 2, Q>), grid, block, x3_lds_pad(2, 2, true), s, g);  \
         else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 2, 1, Q>), grid, block, x3_lds_pad(2, 1, true), s, g);        \
         else hipLaunchKernelGGL((k_gemm_x3<AK, false, AT, 1, 2, Q>), grid, block, x3_lds_pad(1, 2, true), s, g);                     \
     } while (0)
