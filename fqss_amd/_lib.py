@@ -115,6 +115,8 @@ _PROTOS = {
     "fqss_add_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I64, P, P, P, P],
     "fqss_addq_layernorm_fwd": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I64, I64, F64, P, P, P, P, P],
     "fqss_addq_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, I64, P, P, P, P, P, P, P],
+    "fqss_addq_layernorm_fwd_map": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, F64, P, P, P, P, I64, I64, I64, I64, I64, P],
+    "fqss_addq_layernorm_bwd_map": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, P, P, P, P, P, P, I64, I64, I64, I64, I64, P],
     "fqss_mha_prep_fwd": [P, P, P, P, I64, I32, I64, F64, P, P],
     "fqss_mha_prep_fwd_c": [P, P, P, P, I64, I32, I64, F64, P, P],
     "fqss_mha_prep_bwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P, P, P],

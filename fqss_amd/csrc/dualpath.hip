@@ -73,6 +73,18 @@ __device__ __forceinline__ float ln_group_sum(float v) {
     }
 }
 
+// Row map of a LayerNorm's OUTPUT (forward: y and its codes; backward: where dL/dy of row r lives): row r = (i0 * d1 + i1) * d2 + i2 of
+// the input goes to row i0 * t0 + i1 * t1 + i2 * t2 -- the intra- <-> inter-chunk layout change of the dual-path models
+// ([K][B*S] <-> [S][B*K], dptnetq.py:313-327) done by the kernel that writes the rows anyway.  d2 == 0: identity.
+struct RowMap {
+    int64_t d1, d2, t0, t1, t2;
+};
+__device__ __forceinline__ int64_t map_row(const RowMap& m, int64_t r) {
+    if (m.d2 == 0) return r;
+    const int64_t q = r / m.d2, i2 = r - q * m.d2, i0 = q / m.d1, i1 = q - i0 * m.d1;
+    return i0 * m.t0 + i1 * m.t1 + i2 * m.t2;
+}
+
 template <int JC, bool Q, bool VEC, int G = 64>
 __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
@@ -80,7 +92,8 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
                                                         int64_t ld_y, float eps, const float* __restrict__ qmin,
                                                         const float* __restrict__ qmax, unsigned char* __restrict__ yc, int64_t ld_yc,
                                                         const float* __restrict__ xadd, int64_t ld_a, float* __restrict__ xsum,
-                                                        int64_t ld_s, const float* __restrict__ qs_min, const float* __restrict__ qs_max) {
+                                                        int64_t ld_s, const float* __restrict__ qs_min, const float* __restrict__ qs_max,
+                                                        RowMap om) {
     // xadd / xsum (both or neither): the row that is normalised is x + xadd -- the residual add in front of a pre-norm transformer
     // sub-layer -- and the sum is also written out (it is the residual stream of the NEXT add and the backward's input)
     // qs_min / qs_max (nullable, with xadd): the add is an AddQ (the post-norm layers of DPTNet, dptnetq.py:84-97): xsum receives the
@@ -143,21 +156,22 @@ __global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__
                 o[j] = z;
             }
         }
-        if (row_ok) ln_store<JC, VEC>(y + r * ld_y, lane, C, o);
+        const int64_t ro = map_row(om, r);                   // (y and its codes may leave in another row order: RowMap)
+        if (row_ok) ln_store<JC, VEC>(y + ro * ld_y, lane, C, o);
         if (Q && yc != nullptr && row_ok) {
             if (VEC && (ld_yc & 3) == 0) {      // four codes per lane and group: one 4-B store
 #pragma unroll
                 for (int jj = 0; jj < JC / 4; ++jj) {
                     const int c = jj * 256 + lane * 4;
                     if (c < C)
-                        *reinterpret_cast<unsigned int*>(yc + r * ld_yc + c) = (unsigned int)oc[4 * jj] | ((unsigned int)oc[4 * jj + 1] << 8) |
+                        *reinterpret_cast<unsigned int*>(yc + ro * ld_yc + c) = (unsigned int)oc[4 * jj] | ((unsigned int)oc[4 * jj + 1] << 8) |
                                                                                ((unsigned int)oc[4 * jj + 2] << 16) | ((unsigned int)oc[4 * jj + 3] << 24);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < JC; ++j) {
                     const int c = ln_col<JC, VEC>(lane, j);
-                    if (c < C) yc[r * ld_yc + c] = oc[j];
+                    if (c < C) yc[ro * ld_yc + c] = oc[j];
                 }
             }
         }
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
                                                         int64_t ld_x, int64_t ld_gx, const float* __restrict__ beta,
                                                         const float* __restrict__ qmin, const float* __restrict__ qmax, double* gacc,
                                                         const float* __restrict__ gadd, int64_t ld_ga, const float* __restrict__ qs_min,
-                                                        const float* __restrict__ qs_max, double* gacc_s) {
+                                                        const float* __restrict__ qs_max, double* gacc_s, RowMap gm) {
     // gadd (nullable): the gradient arriving on the residual stream behind the fused add (k_layernorm_fwd's xadd form): gx = LN' + gadd is
     // then the gradient of BOTH addends -- the sum autograd would take at the fork in a pass of its own
     // qs_min / qs_max / gacc_s (nullable): the add was an AddQ: x holds the PRE-quant sum z, the normalised row is fq_s(z) and gx passes
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         const int64_t r = row_ok ? r0 + rw : R - 1;
         const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
         float gv[JC], xv[JC], av[JC], xh[JC], dxh[JC], a = 0.f, b = 0.f;
-        ln_load<JC, VEC>(gy + r * ld_gy, lane, C, gv);
+        ln_load<JC, VEC>(gy + map_row(gm, r) * ld_gy, lane, C, gv);      // (the forward wrote y through the same RowMap)
         if (RPW > 1 && !row_ok) {
 #pragma unroll
             for (int jz = 0; jz < JC; ++jz) gv[jz] = 0.f;          // no contribution to the column sums / range partials
@@ -879,7 +893,8 @@ using namespace fqss;
 static int layernorm_fwd_impl(const char* who, const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc,
                               float* mean_rstd, int64_t R, int C, int64_t ld_x, int64_t ld_y, int64_t ld_yc, double eps,
                               const float* qmin, const float* qmax, fqss_stream_t stream, const float* xadd = nullptr, int64_t ld_a = 0,
-                              float* xsum = nullptr, int64_t ld_s = 0, const float* qs_min = nullptr, const float* qs_max = nullptr) {
+                              float* xsum = nullptr, int64_t ld_s = 0, const float* qs_min = nullptr, const float* qs_max = nullptr,
+                              RowMap om = RowMap{0, 0, 0, 0, 0}) {
     if (R == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
     const float e = (float)eps;
@@ -891,7 +906,7 @@ static int layernorm_fwd_impl(const char* who, const float* x, const float* gamm
     if (nb > 4096) nb = 4096;
 #define FQSS_LN_FWD(JC, Q, ...) \
     hipLaunchKernelGGL((k_layernorm_fwd<JC, Q, __VA_ARGS__>), dim3((unsigned)nb), dim3(256), 0, s, x, gamma, beta, y, mean_rstd, R, C, ld_x, ld_y, e, qmin, \
-                       qmax, yc, ld_yc, xadd, ld_a, xsum, ld_s, qs_min, qs_max)
+                       qmax, yc, ld_yc, xadd, ld_a, xsum, ld_s, qs_min, qs_max, om)
 #define FQSS_LN_FWD_Q(Q) \
     if (narrow) FQSS_LN_FWD(4, Q, true, 16); \
     else if (C <= 64) FQSS_LN_FWD(1, Q, false); \
@@ -922,7 +937,7 @@ static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, 
                               const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_gy,
                               int64_t ld_x, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream,
                               const float* gadd = nullptr, int64_t ld_ga = 0, const float* qs_min = nullptr, const float* qs_max = nullptr,
-                              double* gacc_s = nullptr) {
+                              double* gacc_s = nullptr, RowMap gm = RowMap{0, 0, 0, 0, 0}) {
     if (R == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ld_gy % 4 == 0 && ld_x % 4 == 0 && ld_gx % 4 == 0 && aligned16(gy) && aligned16(x) && aligned16(gx) &&
@@ -938,7 +953,7 @@ static int layernorm_bwd_impl(const char* who, const float* gy, const float* x, 
     if (nb > 2048) nb = 2048;           // (also the number of gacc slots)
 #define FQSS_LN_BWD(JC, Q, ...) \
     hipLaunchKernelGGL((k_layernorm_bwd<JC, Q, __VA_ARGS__>), dim3((unsigned)nb), dim3(256), 0, s, gy, x, gamma, mean_rstd, gx, ggamma, gbeta, R, C, \
-                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc, gadd, ld_ga, qs_min, qs_max, gacc_s)
+                       ld_gy, ld_x, ld_gx, beta, qmin, qmax, gacc, gadd, ld_ga, qs_min, qs_max, gacc_s, gm)
 #define FQSS_LN_BWD_Q(Q) \
     if (narrow) FQSS_LN_BWD(4, Q, true, 16); \
     else if (C <= 64) FQSS_LN_BWD(1, Q, false); \
@@ -1017,6 +1032,33 @@ extern "C" int fqss_addq_layernorm_bwd(const float* g, const float* gs, const fl
     FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_g >= C && ld_z >= C && ld_gx >= C && (gs == nullptr || ld_gs >= C), "bad shape (C <= 512)");
     return layernorm_bwd_impl("fqss_addq_layernorm_bwd", g, z, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, ld_g, ld_z, ld_gx, qmin, qmax,
                               gacc, stream, gs, ld_gs, qs_min, qs_max, gacc_s);
+}
+
+/* fqss_addq_layernorm_fwd / _bwd with the dual-path layout change folded in: y (and yc) row (i0 * d1 + i1) * d2 + i2 is WRITTEN at row
+ * i0 * t0 + i1 * t1 + i2 * t2 (dense rows of C), and the backward reads dL/dy of row r from there -- the transposing copy between the
+ * intra- and the inter-chunk transformer (fqss_permute4 each way, plus one for the codes) disappears.  The map must be a permutation
+ * of the R rows (host: d1 * d2 divides R, t's as of a transposed [i2][i1][i0] / [i0 ...] layout; checked: every t >= 1). */
+extern "C" int fqss_addq_layernorm_fwd_map(const float* a, const float* b, const float* gamma, const float* beta, float* z, float* y,
+                                           uint8_t* yc, float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_z, double eps,
+                                           const float* qmin, const float* qmax, const float* qs_min, const float* qs_max, int64_t d1, int64_t d2,
+                                           int64_t t0, int64_t t1, int64_t t2, fqss_stream_t stream) {
+    FQSS_REQUIRE(a && b && gamma && beta && z && y && mean_rstd && qs_min && qs_max && ((qmin == nullptr) == (qmax == nullptr)), "null tensor");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_a >= C && ld_b >= C && ld_z >= C && (yc == nullptr || qmin), "bad shape (C <= 512)");
+    FQSS_REQUIRE(d1 >= 1 && d2 >= 1 && t0 >= 1 && t1 >= 1 && t2 >= 1 && R % (d1 * d2) == 0, "row map: d1 * d2 must divide the row count");
+    return layernorm_fwd_impl("fqss_addq_layernorm_fwd_map", a, gamma, beta, y, yc, mean_rstd, R, C, ld_a, C, C, eps, qmin, qmax, stream, b, ld_b,
+                              z, ld_z, qs_min, qs_max, RowMap{d1, d2, t0, t1, t2});
+}
+
+extern "C" int fqss_addq_layernorm_bwd_map(const float* g, const float* z, const float* gamma, const float* beta, const float* mean_rstd,
+                                           float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_z, int64_t ld_gx,
+                                           const float* qmin, const float* qmax, double* gacc, const float* qs_min, const float* qs_max,
+                                           double* gacc_s, int64_t d1, int64_t d2, int64_t t0, int64_t t1, int64_t t2, fqss_stream_t stream) {
+    FQSS_REQUIRE(g && z && gamma && mean_rstd && gx && ggamma && gbeta && qs_min && qs_max && gacc_s, "null tensor");
+    FQSS_REQUIRE((qmin == nullptr) == (qmax == nullptr) && (qmin == nullptr || (gacc && beta)), "quantizer: ranges, beta and gacc together");
+    FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_z >= C && ld_gx >= C, "bad shape (C <= 512)");
+    FQSS_REQUIRE(d1 >= 1 && d2 >= 1 && t0 >= 1 && t1 >= 1 && t2 >= 1 && R % (d1 * d2) == 0, "row map: d1 * d2 must divide the row count");
+    return layernorm_bwd_impl("fqss_addq_layernorm_bwd_map", g, z, gamma, beta, mean_rstd, gx, ggamma, gbeta, R, C, C, ld_z, ld_gx, qmin, qmax,
+                              gacc, stream, nullptr, 0, qs_min, qs_max, gacc_s, RowMap{d1, d2, t0, t1, t2});
 }
 
 extern "C" int fqss_colsum(const float* g, float* out, int64_t R, int C, int64_t ld, fqss_stream_t stream) {

@@ -1148,19 +1148,25 @@ def layernormq_bwd(g, x, gamma, beta, mean_rstd, ggamma, gbeta, qmin, qmax, gacc
     return gx
 
 
-def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=False, qs=None):
+def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=False, qs=None, rmap=None):
     """s = a + b; y = LN(s) or fq(LN(s)) -> (s, y, codes or None, mean_rstd); qs = (min, max) of an AddQ's quantizer: y = LN(Q)(fq_s(s)),
-    s stays the pre-quant sum (fqss_addq_layernorm_fwd)"""
+    s stays the pre-quant sum (fqss_addq_layernorm_fwd).  rmap = (out_shape, d1, d2, t0, t1, t2) (with qs only): y and its codes leave in
+    another row order -- row (i0*d1 + i1)*d2 + i2 at dense row i0*t0 + i1*t1 + i2*t2 of a tensor of `out_shape`"""
     _need_gpu(a, b, gamma, beta)
     C = gamma.numel()
     a, R, ld_a = _rows(a, C)
     b, Rb, ld_b = _rows(b, C)
     assert R == Rb and a.shape == b.shape
     s = torch.empty(*a.shape, device=a.device, dtype=torch.float32)
-    y = torch.empty(*a.shape, device=a.device, dtype=torch.float32)
-    yc = torch.empty(*a.shape, device=a.device, dtype=torch.uint8) if (want_codes and qmin is not None) else None
+    yshape = tuple(a.shape) if rmap is None else tuple(rmap[0])
+    y = torch.empty(*yshape, device=a.device, dtype=torch.float32)
+    yc = torch.empty(*yshape, device=a.device, dtype=torch.uint8) if (want_codes and qmin is not None) else None
     mean_rstd = torch.empty(R, 2, device=a.device, dtype=torch.float32)
-    if qs is not None:
+    if rmap is not None:
+        assert qs is not None and y.numel() == a.numel() and yshape[-1] == C
+        _lib.call("fqss_addq_layernorm_fwd_map", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C,
+                  float(eps), _p(qmin), _p(qmax), _p(qs[0]), _p(qs[1]), *[int(v) for v in rmap[1:]], _stream())
+    elif qs is not None:
         _lib.call("fqss_addq_layernorm_fwd", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C, C, C,
                   float(eps), _p(qmin), _p(qmax), _p(qs[0]), _p(qs[1]), _stream())
     else:
@@ -1169,16 +1175,25 @@ def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=F
     return s, y, yc, mean_rstd
 
 
-def add_layernorm_bwd(g, gs, s, gamma, beta, mean_rstd, ggamma, gbeta, qmin=None, qmax=None, gacc=None, qs=None, gacc_s=None):
+def add_layernorm_bwd(g, gs, s, gamma, beta, mean_rstd, ggamma, gbeta, qmin=None, qmax=None, gacc=None, qs=None, gacc_s=None, rmap=None):
+    """rmap (as in add_layernorm_fwd): g is dense in the forward's OUTPUT row order"""
     _need_gpu(g, gs, s, gamma, mean_rstd, ggamma, gbeta)
     C = gamma.numel()
-    g, R, ld_g = _rows(g, C)
+    if rmap is not None:
+        g = g.contiguous()
+        R, ld_g = g.numel() // C, C
+    else:
+        g, R, ld_g = _rows(g, C)
     s, _, ld_s = _rows(s, C)
     ld_gs = 0
     if gs is not None:
         gs, _, ld_gs = _rows(gs, C)
     gx = torch.empty(*s.shape, device=s.device, dtype=torch.float32)
-    if qs is not None:
+    if rmap is not None:
+        assert qs is not None and gs is None and g.numel() == s.numel()
+        _lib.call("fqss_addq_layernorm_bwd_map", _p(g), _p(s), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_s, C,
+                  _p(qmin), _p(qmax), _p(gacc), _p(qs[0]), _p(qs[1]), _p(gacc_s), *[int(v) for v in rmap[1:]], _stream())
+    elif qs is not None:
         _lib.call("fqss_addq_layernorm_bwd", _p(g), _p(gs), _p(s), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), R, C, ld_g,
                   ld_gs, ld_s, C, _p(qmin), _p(qmax), _p(gacc), _p(qs[0]), _p(qs[1]), _p(gacc_s), _stream())
     else:

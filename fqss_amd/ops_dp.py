@@ -264,12 +264,14 @@ class AddLayerNormRows(Function):
     layers of DPTNet (fqss_addq_layernorm_fwd/bwd); s is then the PRE-quant sum and is not an output anyone else may consume."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, eps, qmin, qmax, q, want_codes, qs=None, qs_min=None, qs_max=None):
-        s, y, idx, mean_rstd = K.add_layernorm_fwd(a, b, gamma, beta, eps, qmin, qmax, want_codes, qs=None if qs is None else (qs.qmin, qs.qmax))
+    def forward(ctx, a, b, gamma, beta, eps, qmin, qmax, q, want_codes, qs=None, qs_min=None, qs_max=None, rmap=None):
+        """rmap (with qs): see kernels.add_layernorm_fwd -- y leaves in the row order of the NEXT layer's layout (layout_map)"""
+        s, y, idx, mean_rstd = K.add_layernorm_fwd(a, b, gamma, beta, eps, qmin, qmax, want_codes, qs=None if qs is None else (qs.qmin, qs.qmax),
+                                                   rmap=rmap)
         if q is not None:
             q.idx = idx
         ctx.save_for_backward(s, gamma, beta, mean_rstd, qmin, qmax)
-        ctx.q, ctx.qs = q, qs
+        ctx.q, ctx.qs, ctx.rmap = q, qs, rmap
         return y, s
 
     @staticmethod
@@ -280,17 +282,17 @@ class AddLayerNormRows(Function):
         gb, d2 = _param_grad(beta, beta)
         if gy is None:                       # the normalised branch is unused: only the residual stream carries a gradient
             assert qs is None
-            return gs, gs, None, None, None, None, None, None, None, None, None, None
+            return gs, gs, None, None, None, None, None, None, None, None, None, None, None
         if qs is not None:
             gs = None                        # (the pre-quant sum has no other consumer)
         gx = K.add_layernorm_bwd(gy.contiguous(), gs, s, gamma, beta, mean_rstd, gg, gb, qmin, qmax, q.gacc if q is not None else None,
-                                 qs=None if qs is None else (qs.qmin, qs.qmax), gacc_s=None if qs is None else qs.gacc)
+                                 qs=None if qs is None else (qs.qmin, qs.qmax), gacc_s=None if qs is None else qs.gacc, rmap=ctx.rmap)
         g_min = g_max = gs_min = gs_max = None
         if q is not None:
             _, g_min, g_max = ops._flush_ranges(q, None, None, ops.ACT_NONE)
         if qs is not None:
             _, gs_min, gs_max = ops._flush_ranges(qs, None, None, ops.ACT_NONE)
-        return gx, gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None, None, gs_min, gs_max
+        return gx, gx, (None if d1 else gg), (None if d2 else gb), None, g_min, g_max, None, None, None, gs_min, gs_max, None
 
 
 class Unary(Function):
@@ -335,6 +337,21 @@ def _codes_along(x, y, dims_out, strides_in):
     idx = K.permute4(xq.idx.view(torch.float32), dims_out, tuple(s // 4 for s in strides_in), N // 4)
     y._fqss_rowq = ops.ActCodes(idx.view(torch.uint8).view(y.shape), xq.qmin, xq.qmax)
     return y
+
+
+def layout_map(shape, to, B):
+    """the row map (kernels.add_layernorm_fwd) of rows_to_cols (to = "cols": shape [K, B*S, N]) / cols_to_rows ("rows": [S, B*K, N])"""
+    n0, n1, N = shape
+    m = n1 // B
+    assert n1 == B * m and to in ("cols", "rows")
+    # in row r = (i0 = k or s) * (B * m) + b * m + (i2 = s or k)  ->  out row i2 * (B * n0) + b * n0 + i0
+    return ((m, B * n0, N), B, m, 1, n0, B * n0)
+
+
+def change_layout(x, to, B):
+    """rows_to_cols / cols_to_rows by name (the un-fused form of layout_map)"""
+    n0, n1, _ = x.shape
+    return rows_to_cols(x, B, n1 // B) if to == "cols" else cols_to_rows(x, B, n1 // B)
 
 
 def rows_to_cols(x, B, S):

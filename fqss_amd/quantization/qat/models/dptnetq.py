@@ -96,8 +96,9 @@ class TransformerEncoderLayer(nn.Module):
         self.add_norm2 = Add()
         self._relu = nn.ReLU()
 
-    def forward(self, src):
-        """src [L, B', N] sequence-first (dptnetq.py:84-97)"""
+    def forward(self, src, then=None):
+        """src [L, B', N] sequence-first (dptnetq.py:84-97).  then = ("cols" | "rows", B): the dual-path layout change DPT.forward applies to
+        this layer's output -- folded into the last AddQ + LayerNormQ kernel where that runs fused, applied behind it otherwise"""
         s_att, s_res = ops.fork2(src)
         if isinstance(self.self_attn, nn.MultiheadAttention):
             src2 = _float_mha(self.self_attn, s_att)
@@ -110,13 +111,14 @@ class TransformerEncoderLayer(nn.Module):
         else:
             h = QL.fq_node(None, run(self.lstm, s_rnn), self._relu)     # (float model)
         src2 = run(self.linear, h)
-        return self._add_norm(self.add_norm2, self.norm2, s_res, src2)
+        return self._add_norm(self.add_norm2, self.norm2, s_res, src2, then)
 
     @staticmethod
-    def _add_norm(add, norm, a, b):
+    def _add_norm(add, norm, a, b, then=None):
         if isinstance(add, QL.LayerQ) and isinstance(norm, QL.LayerQ):
-            return QL.addq_layernorm(add, norm, a, b)          # quantizing phase: one kernel each way (fqss_addq_layernorm_*)
-        return run(norm, add(a, b))
+            return QL.addq_layernorm(add, norm, a, b, then)    # quantizing phase: one kernel each way (fqss_addq_layernorm_*)
+        y = run(norm, add(a, b))
+        return y if then is None else ops_dp.change_layout(y, then[0], then[1])
 
 
 class Encoder(nn.Module):
@@ -162,9 +164,9 @@ class SingleTransformer(nn.Module):
         self.transformer = TransformerEncoderLayer(d_model=input_size, nhead=4, hidden_size=hidden_size,
                                                    dim_feedforward=hidden_size * 2, dropout=dropout)
 
-    def forward(self, x):
+    def forward(self, x, then=None):
         """x is ALREADY sequence-first [L, B', N] here (the reference permutes a batch-first tensor, :156)"""
-        return self.transformer(x)
+        return self.transformer(x, then)
 
 
 class DPT(nn.Module):
@@ -187,11 +189,8 @@ class DPT(nn.Module):
         for i in range(n):
             if ce and i and i % ce == 0:
                 (x,) = ops.cut(x)                # the transformer pairs before this one are a backward segment of their own
-            x = self.row_transformer[i](x)
-            x = ops_dp.rows_to_cols(x, B, S)
-            x = self.col_transformer[i](x)
-            if i + 1 < n:
-                x = ops_dp.cols_to_rows(x, B, Kc)
+            x = self.row_transformer[i](x, ("cols", B))                       # -> [S, B*K, N] (rows_to_cols)
+            x = self.col_transformer[i](x, ("rows", B) if i + 1 < n else None)     # -> [K, B*S, N] (cols_to_rows)
         x = run(self.output[0], x)
         conv = self.output[1]
         if isinstance(conv, nn.Conv2d):

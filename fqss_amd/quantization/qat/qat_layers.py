@@ -832,7 +832,10 @@ def add_layernorm(norm, a, b):
     return norm(s_n), s_res
 
 
-def addq_layernorm(add, norm, a, b):
+FUSE_LN_LAYOUT = os.environ.get("FQSS_FUSE_LN_LAYOUT", "1") != "0"    # the dual-path layout change inside the AddQ + LayerNormQ kernels
+
+
+def addq_layernorm(add, norm, a, b, then=None):
     """norm(add(a, b)) for the post-norm layers of DPTNet (dptnetq.py:84-97: `src = norm(add_norm(src, src2))`): with an AddQ and a
     LayerNormQ both in their quantizing phase (deferred range tables) the quantized add rides in the LayerNorm kernels each way
     (ops_dp.AddLayerNormRows with a sum quantizer: fqss_addq_layernorm_fwd/bwd) -- no axpby, no quantizer pass, no fork sum; any other
@@ -847,16 +850,20 @@ def addq_layernorm(add, norm, a, b):
             q, qs = aq.qctx(), aqs.qctx()
             if q.qmode == ops.Q_QUANT and qs.qmode == ops.Q_QUANT and q.gacc is not None and qs.gacc is not None:
                 want = ops_dp.QROW and ops.CODED
-                y, _ = ops_dp.AddLayerNormRows.apply(ops.real(a), ops.real(b), ln.weight, ln.bias, ln.eps, q.qmin, q.qmax, q, want, qs, qs.qmin, qs.qmax)
+                # then = (to, B): the layout change that follows this layer (DPT.forward) is done by the kernel that writes y anyway
+                rmap = ops_dp.layout_map(tuple(a.shape), then[0], then[1]) if (then is not None and FUSE_LN_LAYOUT and a.dim() == 3) else None
+                y, _ = ops_dp.AddLayerNormRows.apply(ops.real(a), ops.real(b), ln.weight, ln.bias, ln.eps, q.qmin, q.qmax, q, want, qs, qs.qmin, qs.qmax,
+                                                     rmap)
                 aqs.after_forward(qs)
                 aq.after_forward(q)
                 idx, q.idx = q.idx, None
                 if idx is not None:
                     y._fqss_rowq = ops.ActCodes(idx.view(y.shape), q.qmin.detach(), q.qmax.detach())
-                return y
+                return y if (then is None or rmap is not None) else ops_dp.change_layout(y, then[0], then[1])
             raise RuntimeError("addq_layernorm: quantizer state changed between the check and qctx()")
     y = norm(add(a, b))
-    return y[0] if isinstance(y, (list, tuple)) else y
+    y = y[0] if isinstance(y, (list, tuple)) else y
+    return y if then is None else ops_dp.change_layout(y, then[0], then[1])
 
 
 FUSE_ADDLN = __import__("os").environ.get("FQSS_FUSE_ADDLN", "1") != "0"   # residual add + LayerNorm(Q) as one kernel each way

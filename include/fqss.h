@@ -545,6 +545,17 @@ int fqss_addq_layernorm_bwd(const float* g, const float* gs, const float* z, con
                             const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_g,
                             int64_t ld_gs, int64_t ld_z, int64_t ld_gx, const float* qmin, const float* qmax, double* gacc,
                             const float* qs_min, const float* qs_max, double* gacc_s, fqss_stream_t stream);
+/* the same pair with the dual-path layout change folded in (dptnetq.py:313-327: `permute().contiguous()` between the intra- and the
+ * inter-chunk transformer): y / yc row (i0*d1 + i1)*d2 + i2 is written at dense row i0*t0 + i1*t1 + i2*t2, the backward reads dL/dy
+ * of row r from there (g dense, C floats per row) */
+int fqss_addq_layernorm_fwd_map(const float* a, const float* b, const float* gamma, const float* beta, float* z, float* y, uint8_t* yc,
+                                float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_z, double eps, const float* qmin,
+                                const float* qmax, const float* qs_min, const float* qs_max, int64_t d1, int64_t d2, int64_t t0, int64_t t1,
+                                int64_t t2, fqss_stream_t stream);
+int fqss_addq_layernorm_bwd_map(const float* g, const float* z, const float* gamma, const float* beta, const float* mean_rstd, float* gx,
+                                float* ggamma, float* gbeta, int64_t R, int C, int64_t ld_z, int64_t ld_gx, const float* qmin,
+                                const float* qmax, double* gacc, const float* qs_min, const float* qs_max, double* gacc_s, int64_t d1,
+                                int64_t d2, int64_t t0, int64_t t1, int64_t t2, fqss_stream_t stream);
 
 /* element-wise maps on dense tensors; kind: 0 tanh, 1 sigmoid, 2 division by the scalar p
  * replaces: nn.Tanh / nn.Sigmoid inside Conv1dNlQ (dptnetq.py:286-287), q / sqrt(head_dim) (qat_layers.py:905).

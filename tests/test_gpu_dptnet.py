@@ -810,6 +810,45 @@ def test_addq_layernormq_fused_matches_the_two_modules(R, C, monkeypatch):
     assert torch.equal(f[1], f[2])
 
 
+@pytest.mark.parametrize("to,n0,B,m,C", [("cols", 250, 1, 194, 64), ("rows", 194, 1, 250, 64), ("cols", 10, 2, 7, 16)])
+def test_layout_change_inside_the_addq_layernormq_kernels(to, n0, B, m, C, monkeypatch):
+    """the intra- <-> inter-chunk layout change behind a DPTNet layer (rows_to_cols / cols_to_rows, dptnetq.py:313-327) done by the fused
+    AddQ + LayerNormQ kernels through their row map (fqss_addq_layernorm_fwd_map / _bwd_map) against the same kernels followed by the
+    transposing copy: output, the codes that travel with it and every gradient BIT-identical (the arithmetic per row is unchanged)"""
+    from fqss_amd.quantization.qat import qat_layers as QL
+    a0, b0 = rnd(n0, B * m, C, seed=1).cuda(), rnd(n0, B * m, C, seed=2, scale=0.7).cuda()
+    g0 = rnd(m, B * n0, C, seed=3).cuda()
+    res = {}
+    for kind in ("fused", "copy"):
+        monkeypatch.setattr(QL, "FUSE_LN_LAYOUT", kind == "fused")
+        torch.manual_seed(3)
+        add, ln = QL.AddQ(QL.Add(), **{k: v for k, v in A.items() if k != "weight_quant"}).cuda(), QL.LayerNormQ(nn.LayerNorm(C), **A).cuda()
+        with torch.no_grad():
+            ln.layernorm.weight.copy_(rnd(C, seed=4).cuda() * 0.3 + 1.0)
+            ln.layernorm.bias.copy_(rnd(C, seed=5).cuda() * 0.1)
+            for _ in range(50):
+                ln(add(a0, b0))
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = QL.addq_layernorm(add, ln, a, b, (to, B))
+        assert tuple(y.shape) == (m, B * n0, C)
+        codes = getattr(y, "_fqss_rowq", None)
+        assert codes is not None and tuple(codes.idx.shape) == tuple(y.shape)
+        y.backward(g0)
+        res[kind] = (y.detach(), codes.idx.clone(), a.grad, b.grad, ln.layernorm.weight.grad, ln.layernorm.bias.grad,
+                     add.activation_fake_quantize.min_range.grad, add.activation_fake_quantize.max_range.grad,
+                     ln.activation_fake_quantize.min_range.grad, ln.activation_fake_quantize.max_range.grad)
+        monkeypatch.undo()
+    # and the map is the layout change: y[i2][b * n0 + i0] = LN row (i0, b, i2)
+    lo, hi = float(res["fused"][0].min()), float(res["fused"][0].max())
+    assert hi > lo
+    for i, (f, u) in enumerate(zip(res["fused"], res["copy"])):
+        assert f is not None and u is not None, i
+        if i < 4:
+            assert torch.equal(f, u), i
+        else:       # column / range sums: the same terms, grouped by workgroup in another row order
+            assert float((f - u).norm() / (u.norm() + 1e-12)) <= 2e-5, i
+
+
 def test_coded_row_linear_gradients_do_not_read_carriers(monkeypatch):
     """regression: under the codes-only dataflow of KDTrainStep (ops.fast_codes) a row quantizer feeding a linear on codes must still
     write its fp32 values -- the linear's weight gradient reads them.  Carriers are NaN-poisoned here (ops.DEBUG_POISON)."""
