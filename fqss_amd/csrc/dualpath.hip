@@ -1042,7 +1042,9 @@ extern "C" int fqss_addq_layernorm_fwd_map(const float* a, const float* b, const
                                            uint8_t* yc, float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_z, double eps,
                                            const float* qmin, const float* qmax, const float* qs_min, const float* qs_max, int64_t d1, int64_t d2,
                                            int64_t t0, int64_t t1, int64_t t2, fqss_stream_t stream) {
-    FQSS_REQUIRE(a && b && gamma && beta && z && y && mean_rstd && qs_min && qs_max && ((qmin == nullptr) == (qmax == nullptr)), "null tensor");
+    FQSS_REQUIRE(a && b && gamma && beta && z && y && mean_rstd && ((qs_min == nullptr) == (qs_max == nullptr)) &&
+                     ((qmin == nullptr) == (qmax == nullptr)),
+                 "null tensor");      // (qs NULL: a plain add in front of the norm -- the float teacher's layers, forward only)
     FQSS_REQUIRE(R >= 0 && C > 0 && C <= 512 && ld_a >= C && ld_b >= C && ld_z >= C && (yc == nullptr || qmin), "bad shape (C <= 512)");
     FQSS_REQUIRE(d1 >= 1 && d2 >= 1 && t0 >= 1 && t1 >= 1 && t2 >= 1 && R % (d1 * d2) == 0, "row map: d1 * d2 must divide the row count");
     return layernorm_fwd_impl("fqss_addq_layernorm_fwd_map", a, gamma, beta, y, yc, mean_rstd, R, C, ld_a, C, C, eps, qmin, qmax, stream, b, ld_b,

@@ -1163,9 +1163,10 @@ def add_layernorm_fwd(a, b, gamma, beta, eps, qmin=None, qmax=None, want_codes=F
     yc = torch.empty(*yshape, device=a.device, dtype=torch.uint8) if (want_codes and qmin is not None) else None
     mean_rstd = torch.empty(R, 2, device=a.device, dtype=torch.float32)
     if rmap is not None:
-        assert qs is not None and y.numel() == a.numel() and yshape[-1] == C
+        assert y.numel() == a.numel() and yshape[-1] == C
         _lib.call("fqss_addq_layernorm_fwd_map", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C,
-                  float(eps), _p(qmin), _p(qmax), _p(qs[0]), _p(qs[1]), *[int(v) for v in rmap[1:]], _stream())
+                  float(eps), _p(qmin), _p(qmax), _p(qs[0] if qs is not None else None), _p(qs[1] if qs is not None else None),
+                  *[int(v) for v in rmap[1:]], _stream())
     elif qs is not None:
         _lib.call("fqss_addq_layernorm_fwd", _p(a), _p(b), _p(gamma), _p(beta), _p(s), _p(y), _p(yc), _p(mean_rstd), R, C, ld_a, ld_b, C, C, C,
                   float(eps), _p(qmin), _p(qmax), _p(qs[0]), _p(qs[1]), _stream())

@@ -117,6 +117,13 @@ class TransformerEncoderLayer(nn.Module):
     def _add_norm(add, norm, a, b, then=None):
         if isinstance(add, QL.LayerQ) and isinstance(norm, QL.LayerQ):
             return QL.addq_layernorm(add, norm, a, b, then)    # quantizing phase: one kernel each way (fqss_addq_layernorm_*)
+        if (isinstance(add, QL.Add) and isinstance(norm, nn.LayerNorm) and QL.FUSE_ADDLN and len(norm.normalized_shape) == 1
+                and norm.elementwise_affine and a.shape == b.shape and a.dim() == 3):
+            # float model: add + LayerNorm as one kernel; under no_grad (the frozen teacher) it also writes the next layer's layout
+            a, b = ops.real(a), ops.real(b)
+            rmap = ops_dp.layout_map(tuple(a.shape), then[0], then[1]) if (then is not None and QL.FUSE_LN_LAYOUT and not torch.is_grad_enabled()) else None
+            y, _ = ops_dp.AddLayerNormRows.apply(a, b, norm.weight, norm.bias, norm.eps, None, None, None, False, None, None, None, rmap)
+            return y if (then is None or rmap is not None) else ops_dp.change_layout(y, then[0], then[1])
         y = run(norm, add(a, b))
         return y if then is None else ops_dp.change_layout(y, then[0], then[1])
 

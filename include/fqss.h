@@ -547,7 +547,7 @@ int fqss_addq_layernorm_bwd(const float* g, const float* gs, const float* z, con
                             const float* qs_min, const float* qs_max, double* gacc_s, fqss_stream_t stream);
 /* the same pair with the dual-path layout change folded in (dptnetq.py:313-327: `permute().contiguous()` between the intra- and the
  * inter-chunk transformer): y / yc row (i0*d1 + i1)*d2 + i2 is written at dense row i0*t0 + i1*t1 + i2*t2, the backward reads dL/dy
- * of row r from there (g dense, C floats per row) */
+ * of row r from there (g dense, C floats per row); the forward also takes qs_min = qs_max = NULL: a plain add (the float teacher) */
 int fqss_addq_layernorm_fwd_map(const float* a, const float* b, const float* gamma, const float* beta, float* z, float* y, uint8_t* yc,
                                 float* mean_rstd, int64_t R, int C, int64_t ld_a, int64_t ld_b, int64_t ld_z, double eps, const float* qmin,
                                 const float* qmax, const float* qs_min, const float* qs_max, int64_t d1, int64_t d2, int64_t t0, int64_t t1,
