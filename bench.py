@@ -256,6 +256,8 @@ def main_dualpath(a):
     if not a.no_graph:
         step.capture(x, tgt)
         launch = "hipGraph replay"
+        if comm.world > 1:
+            launch = f"hipGraph replay, {len(step._graphs[0])} backward segments, bucketed all-reduce overlapped"
     if ahead and not a.no_graph:
         launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
     it = 0
@@ -409,6 +411,8 @@ def main_htdemucs(a):
     if not a.no_graph:
         step.capture(mix, src)
         launch = "hipGraph replay"
+        if comm.world > 1:
+            launch = f"hipGraph replay, {len(step._graphs[0])} backward segments, bucketed all-reduce overlapped"
     if ahead and not a.no_graph:
         launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
     it = 0
