@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
             // every thread owns ONE column group of each of the channel's nb rows: the loads of 4 rows are issued
             // before the first is consumed (the serial loop exposed one HBM round trip per batch entry)
             if (c_first < cols) {
-                for (int64_t bi0 = 0; bi0 < nb; bi0 += 4) {
+                // (gridDim.z > 1: the channel's nb rows are dealt to the z-slices in groups of four -- a [N][C][<= 1024] tensor with
+                //  N in the hundreds (DConv on the rows of a spectrogram, hdemucsq.py:72-162) ran C workgroups of N / 4 serial passes)
+                for (int64_t bi0 = 4 * (int64_t)blockIdx.z; bi0 < nb; bi0 += 4 * (int64_t)gridDim.z) {
                     float4 za[4], ga[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
             }
         }
         if (VEC != 4 || cstep < cols) {
-            for (int64_t bi = 0; bi < nb; ++bi) {
+            for (int64_t bi = blockIdx.z; bi < nb; bi += gridDim.z) {
                 const int64_t row = bi * C + ch;
                 const float* zr = z + row * ld_z;
                 const float* gr = g + row * ld_g;
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
         double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
         block_sum<double, 3>(v, red);
         if (threadIdx.x == 0) {
-            double* slot = gacc + 3 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x);
+            double* slot = gacc + 3 * (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
             const double dmax = v[0] / 255.0;
             slot[0] += (qmode == FQSS_Q_QUANT) ? v[1] - dmax : 0.0;
             slot[1] += (qmode == FQSS_Q_QUANT) ? dmax : 0.0;
@@ -814,7 +816,16 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
     int64_t gy = kGaccSlots / gx;
     if (gy > C) gy = C;
     if (gy < 1) gy = 1;
-    dim3 grid((unsigned)gx, (unsigned)gy);
+    // few columns and few channels but many rows per channel: slices of the rows in grid.z (<= kGaccSlots workgroups: one partial slot each)
+    int64_t gzs = 1;
+    if (gbias && gx * gy < 1024 && rows / C >= 8) {
+        gzs = 1024 / (gx * gy);
+        if (gzs > cdiv(rows / C, 4)) gzs = cdiv(rows / C, 4);
+        if (gzs > kGaccSlots / (gx * gy)) gzs = kGaccSlots / (gx * gy);
+        if (gzs > 65535) gzs = 65535;
+        if (gzs < 1) gzs = 1;
+    }
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gzs);
 #define FQSS_LAUNCH_BWD(V, Bi)                                                                                       \
     hipLaunchKernelGGL((k_actq_bwd<V, Bi>), grid, dim3(256), 0, s, z, g, gz, rows, cols, ld_z, ld_g, ld_gz, act,     \
                        slope, qmode, qmin, qmax, gacc, gbias, C)

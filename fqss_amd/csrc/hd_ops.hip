@@ -21,21 +21,42 @@ __global__ __launch_bounds__(256) void k_chan_op(const float* __restrict__ x, co
     }
 }
 // gx[r][m] = g[r][m] * s[r % C];  gs[r % C] += sum_m g[r][m] * x[r][m]
+// A workgroup owns ONE channel (blockIdx.y), a column range (x) and a slice of the channel's R / C rows (z): the sum stays in registers
+// over all of them -- one reduction and one atomic per workgroup.  (The first form, one row per workgroup with a reduction and an atomic
+// per row, ran LayerScale's backward on the [B * F][C][T] tensors of the spectrogram DConv at 0.85 TB/s: 98 k same-address atomics.)
 __global__ __launch_bounds__(256) void k_chan_scale_bwd(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ s,
                                                          float* __restrict__ gx, float* __restrict__ gs, int64_t R, int64_t C, int64_t M,
                                                          int64_t ld_g, int64_t ld_x, int64_t ld_gx) {
     __shared__ float smem[4];
-    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-        const float sv = s[r % C];
-        float acc[1] = {0.f};
-        for (int64_t m = threadIdx.x; m < M; m += 256) {
-            const float gv = g[r * ld_g + m];
-            gx[r * ld_gx + m] = gv * sv;
-            acc[0] += gv * x[r * ld_x + m];
+    const int64_t c = blockIdx.y, nb = R / C;
+    const float sv = s[c];
+    float acc[1] = {0.f};
+    const int64_t mstep = (int64_t)gridDim.x * 1024;
+    for (int64_t bi = blockIdx.z; bi < nb; bi += gridDim.z) {
+        const int64_t r = bi * C + c;
+        const float* gr = g + r * ld_g;
+        const float* xr = x + r * ld_x;
+        float* orow = gx + r * ld_gx;
+        for (int64_t m0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; m0 < M; m0 += mstep) {
+            float gv[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {       // four independent (clamped) loads before the first use
+                const int64_t m = min(m0 + 256 * u, M - 1);
+                gv[u] = gr[m];
+                xv[u] = xr[m];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t m = m0 + 256 * u;
+                if (m < M) {
+                    orow[m] = gv[u] * sv;
+                    acc[0] += gv[u] * xv[u];
+                }
+            }
         }
-        block_sum<float, 1>(acc, smem);
-        if (threadIdx.x == 0) atomicAdd(gs + r % C, acc[0]);
     }
+    block_sum<float, 1>(acc, smem);
+    if (threadIdx.x == 0) atomicAdd(gs + c, acc[0]);
 }
 // channel-last rows: y[r][c] = x[r][c] * s[c]
 __global__ __launch_bounds__(256) void k_col_scale_fwd(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t R,
@@ -127,8 +148,15 @@ extern "C" int fqss_chan_scale_bwd(const float* g, const float* x, const float* 
     FQSS_REQUIRE(g && x && s && gx && gs, "null pointer");
     FQSS_REQUIRE(B > 0 && C > 0 && M > 0 && ld_g >= M && ld_x >= M && ld_gx >= M, "bad shape");
     const int64_t R = B * C;
-    hipLaunchKernelGGL(k_chan_scale_bwd, dim3((unsigned)(R > 65535 ? 65535 : R)), dim3(256), 0, (hipStream_t)stream, g, x, s, gx, gs, R, C, M, ld_g,
-                       ld_x, ld_gx);
+    FQSS_REQUIRE(C <= 65535, "too many channels");
+    int64_t gxb = cdiv(M, 1024);
+    if (gxb > 256) gxb = 256;
+    int64_t gzb = 2048 / (gxb * C);                 // ~2,048 workgroups over the chip
+    if (gzb > B) gzb = B;
+    if (gzb > 65535) gzb = 65535;
+    if (gzb < 1) gzb = 1;
+    hipLaunchKernelGGL(k_chan_scale_bwd, dim3((unsigned)gxb, (unsigned)C, (unsigned)gzb), dim3(256), 0, (hipStream_t)stream, g, x, s, gx, gs, R, C, M,
+                       ld_g, ld_x, ld_gx);
     return launch_status("fqss_chan_scale_bwd");
 }
 
