@@ -574,10 +574,14 @@ int launch_gemm_x3_imp(const GemmArgs3& g_in, bool wgrad, hipStream_t s, const c
     int mi = 2, ni = 2;
     if (g.N <= 64) ni = 1;
     else if (g.M <= 64) mi = 1;
+    // narrow outputs (the DConv convolutions, C / 8 channels): 64 x 128 tiles of one batch leave half the chip without a workgroup
+    // (4 x 1 x 32 = 128 of them at [B F][C][431]) -- 64 x 64 tiles there
+    if (!wgrad && mi == 1 && ni == 2 && cdiv(g.N, 128) * cdiv(g.M, 64) * zdim < 256 && x3_force_mi() != 1) ni = 1;
     dim3 grid((unsigned)cdiv(g.N, 64 * ni), (unsigned)cdiv(g.M, 64 * mi), (unsigned)zdim), block(256);
 #define FQSS_X3I(BKc, AT)                                                                                              \
     do {                                                                                                               \
-        if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 2, 0, true>), grid, block, x3_lds_pad(2, 2, false), s, g);  \
+        if (mi == 1 && ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 1, 1, 0, true>), grid, block, x3_lds_pad(1, 1, false), s, g);  \
+        else if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 2, 0, true>), grid, block, x3_lds_pad(2, 2, false), s, g);  \
         else if (ni == 1) hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 2, 1, 0, true>), grid, block, x3_lds_pad(2, 1, false), s, g);        \
         else hipLaunchKernelGGL((k_gemm_x3<true, BKc, AT, 1, 2, 0, true>), grid, block, x3_lds_pad(1, 2, false), s, g);                     \
     } while (0)

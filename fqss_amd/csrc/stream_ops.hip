@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, i
     double s = 0.0, ss = 0.0;
     for (int c = blockIdx.x; c < C; c += gridDim.x) {
         const float* xr = x + ((int64_t)b * C + c) * ld;
-        for (int m = threadIdx.x * VEC; m < M; m += 256 * VEC) {
+        // (gridDim.z column slices: 6 channels x 4 samples of 880 k positions each were 24 workgroups)
+        for (int m = ((int)blockIdx.z * 256 + (int)threadIdx.x) * VEC; m < M; m += (int)gridDim.z * 256 * VEC) {
             if constexpr (VEC == 4) {
                 const float4 t = *reinterpret_cast<const float4*>(xr + m);
                 const float v[4] = {t.x, t.y, t.z, t.w};
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_rows(const float* __restrict__ g
     const float* gr = gz + row * ld_gz;
     const float* xr = x + row * ld_x;
     double ds = 0.0, db = 0.0;
-    for (int m = threadIdx.x * VEC; m < M; m += 256 * VEC) {
+    for (int m = ((int)blockIdx.z * 256 + (int)threadIdx.x) * VEC; m < M; m += (int)gridDim.z * 256 * VEC) {
         if constexpr (VEC == 4) {
             const float4 a = *reinterpret_cast<const float4*>(gr + m);
             const float4 t = *reinterpret_cast<const float4*>(xr + m);
@@ -328,8 +329,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd_rows(const float* __restrict__ g
     double v[2] = {ds, db};
     block_sum<double, 2>(v, red);
     if (threadIdx.x == 0) {
-        ws[2 * row] = v[0];
-        ws[2 * row + 1] = v[1];
+        if (gridDim.z == 1) {
+            ws[2 * row] = v[0];
+            ws[2 * row + 1] = v[1];
+        } else {                    // column slices: the host zeroed the row sums
+            atomicAdd(&ws[2 * row], v[0]);
+            atomicAdd(&ws[2 * row + 1], v[1]);
+        }
     }
 }
 
@@ -507,6 +513,16 @@ extern "C" int fqss_dwconv_bwd_w(const float* gz, const float* x, float* gw, int
     return launch_status("fqss_dwconv_bwd_w");
 }
 
+// column slices (grid.z) of the per-row GroupNorm passes when rows alone leave the chip empty: ~1,024 workgroups, >= 4 passes each
+static int gn_col_slices(int64_t row_wgs, int M, int vec) {
+    if (row_wgs >= 512) return 1;
+    int64_t zs = 1024 / (row_wgs > 0 ? row_wgs : 1);
+    const int64_t zmax = cdiv(M, 256 * vec * 4);
+    if (zs > zmax) zs = zmax;
+    if (zs > 65535) zs = 65535;
+    return zs < 1 ? 1 : (int)zs;
+}
+
 extern "C" int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd, int B,
                            int C, int M, int64_t ld_x, int64_t ld_z, float eps, double* ws, fqss_stream_t stream) {
     FQSS_REQUIRE(x && gamma && beta && z && mean_rstd && ws, "null tensor");
@@ -516,10 +532,11 @@ extern "C" int fqss_gn_fwd(const float* x, const float* gamma, const float* beta
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s) != hipSuccess) return launch_status("fqss_gn_fwd(memset)");
     const bool vec_x = aligned16(x) && ld_x % 4 == 0;
     int nb = C < 64 ? C : 64;
+    const int zs = gn_col_slices((int64_t)nb * B, M, vec_x ? 4 : 1);
     if (vec_x)
-        hipLaunchKernelGGL(k_gn_stats<4>, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, x, C, M, ld_x, ws);
+        hipLaunchKernelGGL(k_gn_stats<4>, dim3((unsigned)nb, (unsigned)B, (unsigned)zs), dim3(256), 0, s, x, C, M, ld_x, ws);
     else
-        hipLaunchKernelGGL(k_gn_stats<1>, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, x, C, M, ld_x, ws);
+        hipLaunchKernelGGL(k_gn_stats<1>, dim3((unsigned)nb, (unsigned)B, (unsigned)zs), dim3(256), 0, s, x, C, M, ld_x, ws);
     const int64_t rows = (int64_t)B * C;
     if (vec_x && aligned16(z) && ld_z % 4 == 0)
         hipLaunchKernelGGL(k_gn_apply<4>, grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
@@ -538,10 +555,12 @@ extern "C" int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, 
     if (B == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = FQSS_VEC_OK2(gz, ld_gz, x, ld_x);
+    const int zs = gn_col_slices((int64_t)C * B, M, vec ? 4 : 1);
+    if (zs > 1 && hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)B * C, s) != hipSuccess) return launch_status("fqss_gn_bwd(memset)");
     if (vec)
-        hipLaunchKernelGGL(k_gn_bwd_rows<4>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
+        hipLaunchKernelGGL(k_gn_bwd_rows<4>, dim3((unsigned)C, (unsigned)B, (unsigned)zs), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
     else
-        hipLaunchKernelGGL(k_gn_bwd_rows<1>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
+        hipLaunchKernelGGL(k_gn_bwd_rows<1>, dim3((unsigned)C, (unsigned)B, (unsigned)zs), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
     hipLaunchKernelGGL(k_gn_bwd_coef, dim3((unsigned)(B + cdiv(C, 256))), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
                        ggamma, gbeta);
     const int64_t rows = (int64_t)B * C;
