@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void k_frames_conv_fwd(const float* __restrict
 template <int CI, int K, int S>
 __global__ __launch_bounds__(256) void k_frames_conv4(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ z, int Co, int64_t T, int M, int64_t ld_z,
-                                                       const float* __restrict__ add, int64_t ld_add, int co_tile) {
+                                                       const float* __restrict__ add, int64_t ld_add, int co_tile, int co_per) {
+    // co_per: output channels per grid.z slice (256 frames x ALL 512 channels per workgroup were 128 workgroups for 8 x 3,999 frames)
     constexpr int CK = CI * K, SW = 3 * S + K;
     static_assert(SW % 4 == 0 && CK % 4 == 0, "whole float4s");
     extern __shared__ __attribute__((aligned(16))) float Wl[];     // [co_tile][CK]: the taps of co_tile output channels at a time (<= 48 KB)
@@ -116,10 +117,11 @@ __global__ __launch_bounds__(256) void k_frames_conv4(const float* __restrict__ 
     }
     constexpr int PF = 8;      // output channels per group: the addend rows of a group are requested before its FMAs start
     const int ct = co_tile < 0 ? Co : co_tile;
-    for (int cb = 0; cb < Co; cb += ct) {
-        const int ce = min(Co, cb + ct);
+    const int co_lo = (int)blockIdx.z * co_per, co_hi = min(Co, co_lo + co_per);
+    for (int cb = co_lo; cb < co_hi; cb += ct) {
+        const int ce = min(co_hi, cb + ct);
         if (co_tile > 0) {
-        if (cb > 0) __syncthreads();       // every wave is done with the previous tile's taps
+        if (cb > co_lo) __syncthreads();   // every wave is done with the previous tile's taps
         for (int i = threadIdx.x; i < (ce - cb) * CK; i += 256) Wl[i] = w[(int64_t)cb * CK + i];
         __syncthreads();
         }
@@ -464,9 +466,16 @@ static int frames_conv_impl(const char* who, const float* x, const float* w, flo
         if (!taps_lds) { co_tile = -1; lds = 0; }       // taps by wave-uniform loads from memory
         if (wide_on && (k16 || k32) && (Ci == 1 || Ci == 2) && aligned16(x) && T % 4 == 0 && T >= 4 && aligned16(z) && ld_z % 4 == 0 &&
             ld_z >= m4 && (!add || (aligned16(add) && ld_add % 4 == 0 && ld_add >= m4))) {
-            dim3 grid4((unsigned)cdiv(M, 256), (unsigned)N);
+            // slices of the output channels in grid.z until ~512 workgroups are in flight (>= 32 channels per slice)
+            int64_t zs = cdiv(512, cdiv(M, 256) * (int64_t)N);
+            if (zs > Co / 32) zs = Co / 32;
+            if (zs < 1) zs = 1;
+            const int co_per = (int)(cdiv(cdiv(Co, zs), 4) * 4);
+            zs = cdiv(Co, co_per);
+            if (co_tile > co_per) { co_tile = co_per; lds = (size_t)co_tile * Ci * K * sizeof(float); }
+            dim3 grid4((unsigned)cdiv(M, 256), (unsigned)N, (unsigned)zs);
 #define FQSS_FC4(CI_, K_, S_) \
-    hipLaunchKernelGGL((k_frames_conv4<CI_, K_, S_>), grid4, dim3(256), lds, s, x, w, z, Co, T, M, ld_z, add, ld_add, co_tile)
+    hipLaunchKernelGGL((k_frames_conv4<CI_, K_, S_>), grid4, dim3(256), lds, s, x, w, z, Co, T, M, ld_z, add, ld_add, co_tile, co_per)
             if (k16) { if (Ci == 1) FQSS_FC4(1, 16, 8); else FQSS_FC4(2, 16, 8); }
             else     { if (Ci == 1) FQSS_FC4(1, 32, 16); else FQSS_FC4(2, 32, 16); }
 #undef FQSS_FC4
