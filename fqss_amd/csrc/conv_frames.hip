@@ -76,6 +76,58 @@ __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f,
     }
 }
 
+// The same sums for signals of FEW LONG ROWS (the 1-D transposed convolutions: H = 1, W = 27 k .. 441 k), row by row: same terms in the
+// same order (tap row, then tap column ascending) as k_frames_ola, bit for bit.  grid: x = chunks of a signal row (w), y = planes (b, c), z = slices of the rows (h):
+// the tap rows that reach row h are found once per row; SW = the column stride when it is 1, 2 or 4 (0: any) so that the
+// divisibility test of a column is a mask, and with dw = 1 only the taps j = (w + pw) mod SW, + SW, ... are visited (k8 s4: two of
+// eight; the flattened form divides per element and tap: 146 -> 65 us at [4][48][110250]).  On planes of many short rows (the
+// spectrogram, 431 columns) the flattened k_frames_ola is the faster one (dense lanes): measured 1.1-1.6x.
+template <int SW>
+__global__ __launch_bounds__(256) void k_frames_ola_rows(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
+                                                     const FrameGeom g) {
+    const int W = (int)g.W, H = (int)g.H, Ho = (int)g.Ho, Wo = (int)g.Wo;
+    const int stw = SW ? SW : g.st_w;
+    const int64_t planes = g.B * g.C;
+    for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
+        const int64_t c = bc % g.C, b = bc / g.C;
+        const float bv = bias != nullptr ? bias[c] : 0.0f;
+        const float* fb = f + bc * g.kh * g.kw * g.ld;
+        float* yp = y + b * g.sb + c * g.sc;
+        for (int h = blockIdx.z; h < H; h += gridDim.z) {
+            float* yr = yp + (int64_t)h * g.sh_;
+            for (int w = blockIdx.x * 256 + threadIdx.x; w < W; w += gridDim.x * 256) {
+                float acc = 0.0f;
+                for (int ti = 0; ti < g.kh; ++ti) {                       // (uniform per row)
+                    const int hn = h + g.ph - ti * g.dh;
+                    if (hn < 0) continue;
+                    const int ho = hn / g.st_h;
+                    if (ho * g.st_h != hn || ho >= Ho) continue;
+                    const float* fr = fb + (int64_t)ti * g.kw * g.ld + (int64_t)ho * Wo;
+                    if (SW && g.dw == 1) {
+                        const int wp = w + g.pw;
+                        for (int j = wp & (SW - 1); j < g.kw; j += SW) {
+                            const int wn = wp - j;
+                            if (wn < 0) break;                            // (larger j only make it more negative)
+                            const int wo = SW == 1 ? wn : (SW == 2 ? wn >> 1 : wn >> 2);
+                            if (wo < Wo) acc += fr[(int64_t)j * g.ld + wo];
+                        }
+                    } else {
+                        for (int j = 0; j < g.kw; ++j) {
+                            const int wn = w + g.pw - j * g.dw;
+                            if (wn < 0) continue;
+                            const int wo = wn / stw;
+                            if (wo * stw != wn || wo >= Wo) continue;
+                            acc += fr[(int64_t)j * g.ld + wo];
+                        }
+                    }
+                }
+                if (bias != nullptr) acc += bv;
+                yr[w] = acc;
+            }
+        }
+    }
+}
+
 // out[c] += sum_{b, m} g[b][c][m]  (bias gradient of a transposed convolution); one workgroup per (c, b)
 __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, float* __restrict__ out, int64_t C, int64_t M, int64_t ld) {
     __shared__ float smem[4];
@@ -109,6 +161,23 @@ static inline dim3 plane_grid(int64_t positions, int64_t rows) {
     return dim3((unsigned)gx, (unsigned)gy, 1);
 }
 
+// x covers a row of `width` positions in chunks of `chunk`, y walks `rows` (planes / frame rows), z the `depth` rows of a plane:
+// ~16 k workgroups at most, at least ~2 k when the problem has them
+static inline dim3 row_grid(int64_t width, int64_t chunk, int64_t rows, int64_t depth) {
+    int64_t gx = cdiv(width, chunk);
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    int64_t gy = 16384 / gx;
+    if (gy < 1) gy = 1;
+    if (gy > rows) gy = rows;
+    if (gy > 65535) gy = 65535;
+    int64_t gz = 16384 / (gx * gy);
+    if (gz < 1) gz = 1;
+    if (gz > depth) gz = depth;
+    if (gz > 65535) gz = 65535;
+    return dim3((unsigned)gx, (unsigned)gy, (unsigned)gz);
+}
+
 static inline unsigned stream_grid(int64_t n) {
     int64_t b = cdiv(n, 256 * 4);
     if (b < 1) b = 1;
@@ -140,6 +209,14 @@ extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y,
     FQSS_GEOM_INIT;
     if (int rc = check_geom(g)) return rc;
     FQSS_REQUIRE(Ho * Wo < (1ll << 31) && H * W < (1ll << 31), "plane too large for 32-bit position arithmetic");
+    if (H == 1 && W >= 4096) {          // few long rows: the row form (no division per element and tap)
+        const dim3 grid = row_grid(W, 256, B * C, H);
+        if (st_w == 1) hipLaunchKernelGGL(k_frames_ola_rows<1>, grid, dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+        else if (st_w == 2) hipLaunchKernelGGL(k_frames_ola_rows<2>, grid, dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+        else if (st_w == 4) hipLaunchKernelGGL(k_frames_ola_rows<4>, grid, dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+        else hipLaunchKernelGGL(k_frames_ola_rows<0>, grid, dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+        return launch_status("fqss_frames_ola");
+    }
     hipLaunchKernelGGL(k_frames_ola, plane_grid(H * W, B * C), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
     return launch_status("fqss_frames_ola");
 }
