@@ -22,8 +22,18 @@ struct FrameGeom {
 };
 
 // grid: x = chunks of the frame row (m = ho*Wo + wo), y = frame rows (b, c, tap); everything but (ho, wo) is uniform per workgroup
+// q = n / d, r = n % d for 0 <= n < 2^24 (host check) by a float reciprocal and one correction step -- the integer division by a
+// run-time divisor is ~25 instructions per element in kernels that move one element per thread
+__device__ __forceinline__ void div_small(int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+}
+
 __global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__ x, float* __restrict__ f, const FrameGeom g) {
     const int M = (int)(g.Ho * g.Wo), Wo = (int)g.Wo;
+    const float inv_wo = 1.0f / (float)Wo;
     const int64_t rows = g.B * g.C * g.kh * g.kw;
     for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
         const int j = (int)(r % g.kw);
@@ -34,7 +44,8 @@ __global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__
         float* fp = f + r * g.ld;
         const int h0 = ti * g.dh - g.ph, w0 = j * g.dw - g.pw;
         for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
-            const int ho = m / Wo, wo = m - ho * Wo;
+            int ho, wo;
+            div_small(m, Wo, inv_wo, ho, wo);
             const int h = ho * g.st_h + h0, w = wo * g.st_w + w0;
             float v = 0.0f;
             if (h >= 0 && h < (int)g.H && w >= 0 && w < (int)g.W) v = xp[(int64_t)h * g.sh_ + w];
@@ -48,6 +59,11 @@ __global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__
 __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
                                                      const FrameGeom g) {
     const int HW = (int)(g.H * g.W), W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
+    const float inv_w = 1.0f / (float)W;
+    // tap rows: with dh = 1 and a power-of-two row stride only ti = (h + ph) mod st_h, + st_h, ... reach row h (k8 s4: two of eight),
+    // in the same ascending order -- no division per element and tap row
+    const bool fast_h = g.dh == 1 && (g.st_h & (g.st_h - 1)) == 0;
+    const int sh_shift = __builtin_ctz((unsigned)g.st_h), ti_step = fast_h ? g.st_h : 1;
     const int64_t planes = g.B * g.C;
     for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
         const int64_t c = bc % g.C, b = bc / g.C;
@@ -55,12 +71,13 @@ __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f,
         const float* fb = f + bc * g.kh * g.kw * g.ld;
         float* yp = y + b * g.sb + c * g.sc;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
-            const int h = i / W, w = i - h * W;
+            int h, w;
+            div_small(i, W, inv_w, h, w);
             float acc = 0.0f;
-            for (int ti = 0; ti < g.kh; ++ti) {
+            for (int ti = fast_h ? ((h + g.ph) & (g.st_h - 1)) : 0; ti < g.kh; ti += ti_step) {
                 const int hn = h + g.ph - ti * g.dh;
                 if (hn < 0) continue;
-                const int ho = hn / g.st_h;
+                const int ho = fast_h ? (hn >> sh_shift) : hn / g.st_h;
                 if (ho * g.st_h != hn || ho >= Ho) continue;
                 for (int j = 0; j < g.kw; ++j) {
                     const int wn = w + g.pw - j * g.dw;
@@ -199,7 +216,7 @@ extern "C" int fqss_frames_gather(const float* x, float* frames, FQSS_GEOM_ARGS,
     FQSS_REQUIRE(x && frames, "null pointer");
     FQSS_GEOM_INIT;
     if (int rc = check_geom(g)) return rc;
-    FQSS_REQUIRE(Ho * Wo < (1ll << 31) && H * W < (1ll << 31), "plane too large for 32-bit position arithmetic");
+    FQSS_REQUIRE(Ho * Wo < (1ll << 24) && H * W < (1ll << 31), "frame plane too large (positions are split by a float reciprocal: < 2^24)");
     hipLaunchKernelGGL(k_frames_gather, plane_grid(Ho * Wo, B * C * kh * kw), dim3(256), 0, (hipStream_t)stream, x, frames, g);
     return launch_status("fqss_frames_gather");
 }
@@ -209,6 +226,7 @@ extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y,
     FQSS_GEOM_INIT;
     if (int rc = check_geom(g)) return rc;
     FQSS_REQUIRE(Ho * Wo < (1ll << 31) && H * W < (1ll << 31), "plane too large for 32-bit position arithmetic");
+    FQSS_REQUIRE(H == 1 || H * W < (1ll << 24), "signal plane too large (positions are split by a float reciprocal: < 2^24)");
     if (H == 1 && W >= 4096) {          // few long rows: the row form (no division per element and tap)
         const dim3 grid = row_grid(W, 256, B * C, H);
         if (st_w == 1) hipLaunchKernelGGL(k_frames_ola_rows<1>, grid, dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
