@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_rows(const float* __restrict__ g
 //   c2 = (db_sum*mean - ds_sum) * rstd^3 / N ; c3 = -c2*mean - db_sum*rstd/N
 //   ggamma[c] += sum_b (ds[b][c] - db[b][c]*mean_b)*rstd_b ; gbeta[c] += sum_b db[b][c]
 __global__ __launch_bounds__(256) void k_gn_bwd_coef(const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                      int B, int C, int M, double* ws, float* ggamma, float* gbeta) {
+                                                      int B, int C, int M, double* ws, float* ggamma, float* gbeta, int nbs) {
     __shared__ double red[2 * 4];
     const int b = blockIdx.x;
     double* coef = ws + 2 * (int64_t)B * C;
@@ -366,17 +366,26 @@ __global__ __launch_bounds__(256) void k_gn_bwd_coef(const float* __restrict__ g
             coef[2 * b + 1] = c3;
         }
     } else {
-        // extra blocks (blockIdx.x >= B): parameter gradients, one thread per channel
-        const int c = (b - B) * 256 + threadIdx.x;
+        // extra blocks (blockIdx.x >= B): parameter gradients, one thread per channel and -- with many samples (the [B F][C][T]
+        // GroupNorms of the spectrogram DConv: 2,048 of them were ONE workgroup's serial loop, 460 us) -- one slice of the samples
+        // per workgroup (nbs slices, float atomics; nbs = 1: the plain += of the small-batch models, order fixed)
+        const int e = b - B, ncb = (C + 255) / 256;
+        const int c = (e % ncb) * 256 + threadIdx.x, bs = e / ncb;
+        const int per = (B + nbs - 1) / nbs, b0 = bs * per, b1 = min(B, b0 + per);
         if (c < C) {
             double gg = 0.0, gb = 0.0;
-            for (int bb = 0; bb < B; ++bb) {
+            for (int bb = b0; bb < b1; ++bb) {
                 const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
                 gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
                 gb += db;
             }
-            ggamma[c] += (float)gg;
-            gbeta[c] += (float)gb;
+            if (nbs == 1) {
+                ggamma[c] += (float)gg;
+                gbeta[c] += (float)gb;
+            } else {
+                atomicAdd(&ggamma[c], (float)gg);
+                atomicAdd(&gbeta[c], (float)gb);
+            }
         }
     }
 }
@@ -561,8 +570,9 @@ extern "C" int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, 
         hipLaunchKernelGGL(k_gn_bwd_rows<4>, dim3((unsigned)C, (unsigned)B, (unsigned)zs), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
     else
         hipLaunchKernelGGL(k_gn_bwd_rows<1>, dim3((unsigned)C, (unsigned)B, (unsigned)zs), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
-    hipLaunchKernelGGL(k_gn_bwd_coef, dim3((unsigned)(B + cdiv(C, 256))), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
-                       ggamma, gbeta);
+    const int nbs = B <= 16 ? 1 : (int)(cdiv(B, 16) > 64 ? 64 : cdiv(B, 16));      // sample slices of the parameter-gradient sums
+    hipLaunchKernelGGL(k_gn_bwd_coef, dim3((unsigned)(B + cdiv(C, 256) * nbs)), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
+                       ggamma, gbeta, nbs);
     const int64_t rows = (int64_t)B * C;
     if (vec && aligned16(gx) && ld_gx % 4 == 0)
         hipLaunchKernelGGL(k_gn_bwd_apply<4>, grid_rows(rows, M, 4), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
