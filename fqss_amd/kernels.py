@@ -99,6 +99,42 @@ def rowmat(t):
     return rows, cols, ld
 
 
+def _rowmat_collapsed(t):
+    """(rows, cols, ld) with several trailing dims merged into the columns: a view whose last k dims are dense and whose leading dims
+    share one stride -- a crop along an inner dim of a channel-first tensor, [B, C, F', T] out of [B, C, F, T] -- is a row matrix of
+    B * C rows of F' * T columns with row stride F * T; else None"""
+    nd = t.dim()
+    for k in range(nd - 2, 0, -1):            # columns = dims k .. nd-1
+        cols, dense = 1, True
+        for d in range(nd - 1, k - 1, -1):
+            if t.shape[d] != 1 and t.stride(d) != cols:
+                dense = False
+                break
+            cols *= t.shape[d]
+        if not dense:
+            return None
+        rows, ld, ok = 1, None, True
+        for d in range(k - 1, -1, -1):
+            n = t.shape[d]
+            if n == 1:
+                continue
+            if ld is None:
+                ld = t.stride(d)
+                if ld < cols:
+                    ok = False
+                    break
+            elif t.stride(d) != ld * rows:
+                ok = False
+                break
+            rows *= n
+        if ok and ld is not None:
+            return rows, cols, ld
+    return None
+
+
+ROWMAT_COLLAPSE = os.environ.get("FQSS_ROWMAT_COLLAPSE", "1") != "0"    # element-wise kernels take cropped channel-first views without a dense copy
+
+
 def as_rowmat(t):
     """return (tensor, rows, cols, ld); copies into a padded buffer only if the layout is foreign"""
     rm = rowmat(t)
@@ -121,14 +157,23 @@ def empty_codes(shape, device):
 def actq_fwd(z, act, slope, qmode, qmin, qmax, obs_ws, want_idx=False, dense_idx=False, write_out=True):
     """write_out=False (QUANT + want_idx only): the fp32 result is an UNINITIALISED carrier, only codes are written"""
     _need_gpu(z, slope, qmin, qmax)
-    z, rows, cols, ld_z = as_rowmat(z)
-    out = empty_act(tuple(z.shape), z.device)
-    _, _, _, ld_o = (out,) + rowmat(out)
+    rc = _rowmat_collapsed(z) if (ROWMAT_COLLAPSE and z.dim() >= 3 and rowmat(z) is None) else None
     skip_out = (not write_out) and want_idx and qmode == Q_QUANT
-    idx, ld_i = None, cols
-    if want_idx:
-        idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if dense_idx else empty_codes(tuple(z.shape), z.device)
-        ld_i = rowmat(idx)[2]
+    if rc is not None:
+        # a cropped channel-first view ([B, C, F', T] out of [B, C, F, T]): rows of F' T columns at row stride F T, no dense copy; the
+        # outputs are dense, un-padded tensors of z's shape (the same rows / columns with ld = columns)
+        rows, cols, ld_z = rc
+        out = torch.empty(z.shape, device=z.device, dtype=torch.float32)
+        ld_o = ld_i = cols
+        idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if want_idx else None
+    else:
+        z, rows, cols, ld_z = as_rowmat(z)
+        out = empty_act(tuple(z.shape), z.device)
+        _, _, _, ld_o = (out,) + rowmat(out)
+        idx, ld_i = None, cols
+        if want_idx:
+            idx = torch.empty(z.shape, device=z.device, dtype=torch.uint8) if dense_idx else empty_codes(tuple(z.shape), z.device)
+            ld_i = rowmat(idx)[2]
     _lib.call("fqss_actq_fwd", _p(z), None if skip_out else _p(out), _p(idx), rows, cols, ld_z, ld_o, ld_i, act,
               _p(slope), qmode, _p(qmin), _p(qmax), _p(obs_ws), _stream())
     return (out, idx) if want_idx else out
@@ -151,13 +196,21 @@ def minmax(x, obs_ws):
 def actq_bwd(z, g, act, slope, qmode, qmin, qmax, gacc, gbias=None, C=0, out=None):
     """out: optional row-matrix view (e.g. a column block of a wider buffer) that receives gz"""
     _need_gpu(z, g)
-    z, rows, cols, ld_z = as_rowmat(z)
-    g, r2, c2, ld_g = as_rowmat(g)
-    assert (rows, cols) == (r2, c2), "actq_bwd: z/g shape mismatch"
-    gz = empty_act(tuple(z.shape), z.device) if out is None else out
-    rm = rowmat(gz)
-    assert rm is not None and rm[:2] == (rows, cols), "actq_bwd: `out` must be a row-matrix view of z's shape"
-    ld_gz = rm[2]
+    rcz = rcg = None
+    if ROWMAT_COLLAPSE and gbias is None and out is None and z.dim() >= 3 and z.shape == g.shape and (rowmat(z) is None or rowmat(g) is None):
+        rcz, rcg = _rowmat_collapsed(z), _rowmat_collapsed(g)       # (see actq_fwd: cropped channel-first views, no dense copy)
+    if rcz is not None and rcg is not None and rcz[:2] == rcg[:2]:
+        (rows, cols, ld_z), ld_g = rcz, rcg[2]
+        gz = torch.empty(z.shape, device=z.device, dtype=torch.float32)
+        ld_gz = cols
+    else:
+        z, rows, cols, ld_z = as_rowmat(z)
+        g, r2, c2, ld_g = as_rowmat(g)
+        assert (rows, cols) == (r2, c2), "actq_bwd: z/g shape mismatch"
+        gz = empty_act(tuple(z.shape), z.device) if out is None else out
+        rm = rowmat(gz)
+        assert rm is not None and rm[:2] == (rows, cols), "actq_bwd: `out` must be a row-matrix view of z's shape"
+        ld_gz = rm[2]
     _lib.call("fqss_actq_bwd", _p(z), _p(g), _p(gz), rows, cols, ld_z, ld_g, ld_gz, act, _p(slope), qmode,
               _p(qmin), _p(qmax), _p(gacc), _p(gbias), C, _stream())
     return gz
