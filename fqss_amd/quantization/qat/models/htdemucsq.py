@@ -75,8 +75,9 @@ class _Window(torch.autograd.Function):
             return out
         shape = list(x.shape)
         shape[dim] = pad_to
-        out = K.empty_act(tuple(shape), x.device).zero_()
+        out = K.empty_act(tuple(shape), x.device)
         out.narrow(dim, 0, x.shape[dim]).copy_(x)
+        out.narrow(dim, x.shape[dim], pad_to - x.shape[dim]).zero_()      # (only the appended tail is filled, not the whole tensor first)
         ctx.cfg = (dim, 0, x.shape[dim], None)
         return out
 
@@ -90,8 +91,12 @@ class _Window(torch.autograd.Function):
             return out, None, None, None, None
         shape = list(g.shape)
         shape[dim] = full
-        out = torch.zeros(shape, device=g.device, dtype=g.dtype)
+        out = torch.empty(shape, device=g.device, dtype=g.dtype)
         out.narrow(dim, start, length).copy_(g)
+        if start > 0:                         # the two margins get their zeros, the window is written once
+            out.narrow(dim, 0, start).zero_()
+        if start + length < full:
+            out.narrow(dim, start + length, full - start - length).zero_()
         return out, None, None, None, None
 
 
