@@ -1320,10 +1320,13 @@ def unary_bwd(g, y, kind, p=1.0):
     return gx
 
 
-def permute4(x, dims_out, strides_in, C):
-    """y[i0][i1][i2][:C] = x[i0*s0 + i1*s1 + i2*s2 : +C]   (x dense, strides in elements)"""
+def permute4(x, dims_out, strides_in, C, dense=True):
+    """y[i0][i1][i2][:C] = x[i0*s0 + i1*s1 + i2*s2 : +C]   (strides in elements; dense: they assume a contiguous x -- else they are x's
+    own strides and only its last dim must have unit stride: a view of a row-padded buffer is read in place)"""
     _need_gpu(x)
-    x = x.contiguous()
+    if dense or x.stride(-1) != 1:
+        assert dense, "permute4: explicit strides need a unit stride along the last dim"
+        x = x.contiguous()
     n0, n1, n2 = dims_out
     y = torch.empty(n0, n1, n2, C, device=x.device, dtype=torch.float32)
     _lib.call("fqss_permute4", _p(x), _p(y), n0, n1, n2, C, strides_in[0], strides_in[1], strides_in[2], _stream())

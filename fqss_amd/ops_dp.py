@@ -315,13 +315,14 @@ class Permute4(Function):
     """y[i0, i1, i2, :] = x viewed with element strides `sin`; the backward is the inverse move (`sback` over x's own dims)"""
 
     @staticmethod
-    def forward(ctx, x, dims_out, sin, dims_in, sback):
+    def forward(ctx, x, dims_out, sin, dims_in, sback, dense=True):
+        """dense=False: `sin` are x's own strides (a view of a row-padded buffer is read in place, no contiguous() copy first)"""
         ctx.dims_in, ctx.sback, ctx.C, ctx.xshape = dims_in, sback, x.shape[-1], tuple(x.shape)
-        return K.permute4(x.contiguous(), dims_out, sin, x.shape[-1])
+        return K.permute4(x.contiguous() if dense else x, dims_out, sin, x.shape[-1], dense)
 
     @staticmethod
     def backward(ctx, g):
-        return K.permute4(g.contiguous(), ctx.dims_in, ctx.sback, ctx.C).view(ctx.xshape), None, None, None, None
+        return K.permute4(g.contiguous(), ctx.dims_in, ctx.sback, ctx.C).view(ctx.xshape), None, None, None, None, None
 
 
 PERMUTE_CODES = __import__("os").environ.get("FQSS_PERMUTE_CODES", "1") != "0"    # the u8 codes of a row tensor travel through the layout change

@@ -125,11 +125,17 @@ class _Transpose(torch.autograd.Function):
         return K.transpose2d(g)
 
 
+SWAP_IN_PLACE = __import__("os").environ.get("FQSS_SWAP_IN_PLACE", "1") != "0"    # swap_mid reads a row-padded view in place (A/B)
+
+
 def swap_mid(x):
     """[B, P, Q, T] -> [B, Q, P, T] dense (T-long contiguous chunks move: fqss_permute4)"""
-    x = ops.real(x).contiguous()
+    x = ops.real(x)
+    if x.stride(-1) != 1 or not SWAP_IN_PLACE:
+        x = x.contiguous()
     B, P, Q, T = x.shape
-    return ops_dp.Permute4.apply(x, (B, Q, P), (P * Q * T, T, Q * T), (B, P, Q), (P * Q * T, T, P * T))
+    sB, sP, sQ, _ = x.stride()          # (a view of a row-padded buffer -- DConv's output reshaped -- is read in place)
+    return ops_dp.Permute4.apply(x, (B, Q, P), (sB, sQ, sP), (B, P, Q), (P * Q * T, T, P * T), False)
 
 
 def _fadd(a, b):
