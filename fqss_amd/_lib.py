@@ -69,6 +69,8 @@ _PROTOS = {
     "fqss_dwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_gn_fwd": [P, P, P, P, P, I32, I32, I32, I64, I64, F32, P, P],
     "fqss_gn_bwd": [P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P],
+    "fqss_gnq_fwd_f": [P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P],
+    "fqss_gnq_bwd_f": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],
     "fqss_axpby": [P, P, F32, F32, P, I64, I64, I64, I64, I64, P],
     "fqss_mul_bcast_fwd": [P, P, P, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_mul_bcast_bwd": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, P],

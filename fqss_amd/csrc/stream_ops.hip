@@ -270,11 +270,17 @@ __device__ __forceinline__ void gn_mean_rstd(const double* ws, int b, int64_t n,
 }
 
 // y = x*scale + shift ; scale = rstd*gamma[c] ; shift = beta[c] - scale*mean   (ATen GroupNorm kernel form)
-template <int VEC>
+// Q: GroupNormQ on a float input in the quantizing phase -- z receives fq(GroupNorm(x)) (the arithmetic of this kernel followed by
+// fqss_actq_fwd, value for value); the pre-quant z is never stored, the backward recomputes it from x
+template <int VEC, bool Q = false>
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ z,
                                                    float* mean_rstd, int B, int C, int M, int64_t ld_x, int64_t ld_z,
-                                                   float eps, const double* ws) {
+                                                   float eps, const double* ws, const float* qmin = nullptr, const float* qmax = nullptr,
+                                                   uint8_t* __restrict__ yc = nullptr, int64_t ld_yc = 0) {
+    // yc (Q only, nullable): the u8 codes of the output, rows of ld_yc bytes (VEC = 4: ld_yc % 4 == 0, 4-B aligned rows)
+    QRange qr{0.0f, 1.0f, 1.0f};
+    if (Q) qr = load_qrange(qmin, qmax);
     const int64_t rows = (int64_t)B * C;
     const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
     for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
@@ -292,23 +298,62 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, c
         for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < M; c0 += cstep) {
             if constexpr (VEC == 4) {
                 const float4 t = *reinterpret_cast<const float4*>(xr + c0);
-                *reinterpret_cast<float4*>(zr + c0) = make_float4(fmaf(t.x, scale, shift), fmaf(t.y, scale, shift),
-                                                                  fmaf(t.z, scale, shift), fmaf(t.w, scale, shift));
+                float o[4] = {fmaf(t.x, scale, shift), fmaf(t.y, scale, shift), fmaf(t.z, scale, shift), fmaf(t.w, scale, shift)};
+                if constexpr (Q) {
+                    unsigned int pk = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float cq, u;
+                        bool inr;
+                        o[j] = fq_asym(o[j], qr, cq, u, inr);
+                        pk = pack_code(cq, j, pk);
+                    }
+                    if (yc != nullptr) *reinterpret_cast<unsigned int*>(yc + row * ld_yc + c0) = pk;      // (row padding absorbs c0 + 3 >= M)
+                }
+                *reinterpret_cast<float4*>(zr + c0) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
-                zr[c0] = fmaf(xr[c0], scale, shift);
+                float o = fmaf(xr[c0], scale, shift);
+                if constexpr (Q) {
+                    float cq, u;
+                    bool inr;
+                    o = fq_asym(o, qr, cq, u, inr);
+                    if (yc != nullptr) yc[row * ld_yc + c0] = (uint8_t)cq;
+                }
+                zr[c0] = o;
             }
         }
     }
 }
 
 // backward pass 1: per (b,c) row sums  ds = sum gz*x, db = sum gz   -> ws[(b*C+c)*2 + {0,1}]
-template <int VEC>
+// Q: gz is dL/d fq(GroupNorm(x)): the quantizer's STE runs on the pre-quant value recomputed from x (scale / shift as in k_gn_apply)
+// and its range partials go to gacc (slots shared modulo kGaccSlots, fp64 atomics: order-insensitive) -- no fqss_actq_bwd pass, no z
+template <int VEC, bool Q = false>
 __global__ __launch_bounds__(256) void k_gn_bwd_rows(const float* __restrict__ gz, const float* __restrict__ x, int C,
-                                                      int M, int64_t ld_gz, int64_t ld_x, double* ws) {
-    __shared__ double red[2 * 4];
+                                                      int M, int64_t ld_gz, int64_t ld_x, double* ws, const float* __restrict__ gamma = nullptr,
+                                                      const float* __restrict__ beta = nullptr, const float* __restrict__ mean_rstd = nullptr,
+                                                      const float* qmin = nullptr, const float* qmax = nullptr, double* gacc = nullptr) {
+    __shared__ double red[4 * 4];
     const int64_t row = (int64_t)blockIdx.y * C + blockIdx.x;
     const float* gr = gz + row * ld_gz;
     const float* xr = x + row * ld_x;
+    QRange qr{0.0f, 1.0f, 1.0f};
+    float scale = 1.0f, shift = 0.0f, p_du = 0.0f, p_out = 0.0f;
+    if (Q) {
+        qr = load_qrange(qmin, qmax);
+        const float mean = mean_rstd[2 * blockIdx.y], rstd = mean_rstd[2 * blockIdx.y + 1];
+        scale = rstd * gamma[blockIdx.x];
+        shift = fmaf(-scale, mean, beta[blockIdx.x]);
+    }
+    // the STE of one element: returns dL/dz and adds the element's range partials
+    auto ste = [&](float g, float xv) {
+        float cq, u;
+        bool inr;
+        (void)fq_asym(fmaf(xv, scale, shift), qr, cq, u, inr);
+        p_du += g * (inr ? (cq - u) : cq);
+        p_out += inr ? 0.0f : g;
+        return inr ? div_by(g * qr.delta, qr.delta, qr.inv) : 0.0f;
+    };
     double ds = 0.0, db = 0.0;
     for (int m = ((int)blockIdx.z * 256 + (int)threadIdx.x) * VEC; m < M; m += (int)gridDim.z * 256 * VEC) {
         if constexpr (VEC == 4) {
@@ -318,12 +363,24 @@ __global__ __launch_bounds__(256) void k_gn_bwd_rows(const float* __restrict__ g
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (m + j < M) {
-                    ds += (double)gv[j] * (double)xv[j];
-                    db += (double)gv[j];
+                    const float gj = Q ? ste(gv[j], xv[j]) : gv[j];
+                    ds += (double)gj * (double)xv[j];
+                    db += (double)gj;
                 }
         } else {
-            ds += (double)gr[m] * (double)xr[m];
-            db += (double)gr[m];
+            const float gj = Q ? ste(gr[m], xr[m]) : gr[m];
+            ds += (double)gj * (double)xr[m];
+            db += (double)gj;
+        }
+    }
+    if constexpr (Q) {
+        double pv[2] = {(double)p_du, (double)p_out};
+        block_sum<double, 2>(pv, red + 8);
+        if (threadIdx.x == 0) {
+            double* slot = gacc + 3 * (row % FQSS_GACC_SLOTS);
+            const double dmax = pv[0] / 255.0;
+            atomicAdd(&slot[0], pv[1] - dmax);
+            atomicAdd(&slot[1], dmax);
         }
     }
     double v[2] = {ds, db};
@@ -391,12 +448,15 @@ __global__ __launch_bounds__(256) void k_gn_bwd_coef(const float* __restrict__ g
 }
 
 // backward pass 3: gx = gz*(gamma_c*rstd) + x*c2 + c3
-template <int VEC>
+template <int VEC, bool Q = false>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ gz, const float* __restrict__ x,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ mean_rstd, float* __restrict__ gx,
                                                        int B, int C, int M, int64_t ld_gz, int64_t ld_x, int64_t ld_gx,
-                                                       const double* ws) {
+                                                       const double* ws, const float* __restrict__ beta = nullptr, const float* qmin = nullptr,
+                                                       const float* qmax = nullptr) {
+    QRange qr{0.0f, 1.0f, 1.0f};
+    if (Q) qr = load_qrange(qmin, qmax);
     const double* coef = ws + 2 * (int64_t)B * C;
     const int64_t rows = (int64_t)B * C;
     const int64_t cstep = (int64_t)gridDim.x * 256 * VEC;
@@ -404,18 +464,28 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
         const int b = (int)(row / C), c = (int)(row % C);
         const float c1 = mean_rstd[2 * b + 1] * gamma[c];
         const float c2 = (float)coef[2 * b], c3 = (float)coef[2 * b + 1];
+        const float shift = Q ? fmaf(-c1, mean_rstd[2 * b], beta[c]) : 0.0f;      // (c1 is k_gn_apply's scale)
+        // Q: dL/dz of an element from dL/dy -- the STE on the recomputed pre-quant value (the partial sums were taken in pass 1)
+        auto ste = [&](float g, float xv) {
+            float cq, u;
+            bool inr;
+            (void)fq_asym(fmaf(xv, c1, shift), qr, cq, u, inr);
+            return inr ? div_by(g * qr.delta, qr.delta, qr.inv) : 0.0f;
+        };
         const float* gr = gz + row * ld_gz;
         const float* xr = x + row * ld_x;
         float* orow = gx + row * ld_gx;
         for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; c0 < M; c0 += cstep) {
             if constexpr (VEC == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(gr + c0);
+                float4 a = *reinterpret_cast<const float4*>(gr + c0);
                 const float4 t = *reinterpret_cast<const float4*>(xr + c0);
+                if constexpr (Q) { a.x = ste(a.x, t.x); a.y = ste(a.y, t.y); a.z = ste(a.z, t.z); a.w = ste(a.w, t.w); }
                 *reinterpret_cast<float4*>(orow + c0) =
                     make_float4(fmaf(a.x, c1, fmaf(t.x, c2, c3)), fmaf(a.y, c1, fmaf(t.y, c2, c3)),
                                 fmaf(a.z, c1, fmaf(t.z, c2, c3)), fmaf(a.w, c1, fmaf(t.w, c2, c3)));
             } else {
-                orow[c0] = fmaf(gr[c0], c1, fmaf(xr[c0], c2, c3));
+                const float a = Q ? ste(gr[c0], xr[c0]) : gr[c0];
+                orow[c0] = fmaf(a, c1, fmaf(xr[c0], c2, c3));
             }
         }
     }
@@ -532,13 +602,34 @@ static int gn_col_slices(int64_t row_wgs, int M, int vec) {
     return zs < 1 ? 1 : (int)zs;
 }
 
+static int gn_fwd_impl(const char* who, const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd, int B, int C, int M,
+                       int64_t ld_x, int64_t ld_z, float eps, double* ws, const float* qmin, const float* qmax, fqss_stream_t stream,
+                       uint8_t* yc = nullptr, int64_t ld_yc = 0);
+
 extern "C" int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd, int B,
                            int C, int M, int64_t ld_x, int64_t ld_z, float eps, double* ws, fqss_stream_t stream) {
+    return gn_fwd_impl("fqss_gn_fwd", x, gamma, beta, z, mean_rstd, B, C, M, ld_x, ld_z, eps, ws, nullptr, nullptr, stream);
+}
+
+// GroupNormQ on a FLOAT input in the quantizing phase: y = fq(GroupNorm(1, C)(x)) from the statistics pass + ONE apply pass (the
+// pre-quant value is not stored) -- fqss_gn_fwd followed by fqss_actq_fwd, value for value
+extern "C" int fqss_gnq_fwd_f(const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc, float* mean_rstd, int B, int C, int M,
+                              int64_t ld_x, int64_t ld_y, int64_t ld_yc, float eps, double* ws, const float* qmin, const float* qmax,
+                              fqss_stream_t stream) {
+    FQSS_REQUIRE(qmin && qmax, "null range");
+    FQSS_REQUIRE(yc == nullptr || (ld_yc >= M && ld_yc % 4 == 0 && (reinterpret_cast<uintptr_t>(yc) & 3u) == 0 && ld_yc >= ((M + 3) & ~3)),
+                 "code rows: 4-B aligned, padded to a multiple of 4");
+    return gn_fwd_impl("fqss_gnq_fwd_f", x, gamma, beta, y, mean_rstd, B, C, M, ld_x, ld_y, eps, ws, qmin, qmax, stream, yc, ld_yc);
+}
+
+static int gn_fwd_impl(const char* who, const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd, int B, int C, int M,
+                       int64_t ld_x, int64_t ld_z, float eps, double* ws, const float* qmin, const float* qmax, fqss_stream_t stream, uint8_t* yc,
+                       int64_t ld_yc) {
     FQSS_REQUIRE(x && gamma && beta && z && mean_rstd && ws, "null tensor");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_x >= M && ld_z >= M, "bad shape");
     if (B == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s) != hipSuccess) return launch_status("fqss_gn_fwd(memset)");
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s) != hipSuccess) return launch_status(who);
     const bool vec_x = aligned16(x) && ld_x % 4 == 0;
     int nb = C < 64 ? C : 64;
     const int zs = gn_col_slices((int64_t)nb * B, M, vec_x ? 4 : 1);
@@ -547,38 +638,70 @@ extern "C" int fqss_gn_fwd(const float* x, const float* gamma, const float* beta
     else
         hipLaunchKernelGGL(k_gn_stats<1>, dim3((unsigned)nb, (unsigned)B, (unsigned)zs), dim3(256), 0, s, x, C, M, ld_x, ws);
     const int64_t rows = (int64_t)B * C;
-    if (vec_x && aligned16(z) && ld_z % 4 == 0)
-        hipLaunchKernelGGL(k_gn_apply<4>, grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
-                           ld_x, ld_z, eps, ws);
+    const bool v4 = vec_x && aligned16(z) && ld_z % 4 == 0;
+    if (qmin != nullptr) {
+        if (v4) hipLaunchKernelGGL((k_gn_apply<4, true>), grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M, ld_x, ld_z, eps, ws, qmin, qmax, yc, ld_yc);
+        else hipLaunchKernelGGL((k_gn_apply<1, true>), grid_rows(rows, M, 1), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M, ld_x, ld_z, eps, ws, qmin, qmax, yc, ld_yc);
+    } else if (v4)
+        hipLaunchKernelGGL((k_gn_apply<4, false>), grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
+                           ld_x, ld_z, eps, ws, nullptr, nullptr, nullptr, 0);
     else
-        hipLaunchKernelGGL(k_gn_apply<1>, grid_rows(rows, M, 1), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
-                           ld_x, ld_z, eps, ws);
-    return launch_status("fqss_gn_fwd");
+        hipLaunchKernelGGL((k_gn_apply<1, false>), grid_rows(rows, M, 1), dim3(256), 0, s, x, gamma, beta, z, mean_rstd, B, C, M,
+                           ld_x, ld_z, eps, ws, nullptr, nullptr, nullptr, 0);
+    return launch_status(who);
 }
+
+static int gn_bwd_impl(const char* who, const float* gz, const float* x, const float* gamma, const float* beta, const float* mean_rstd, float* gx,
+                       float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz, int64_t ld_x, int64_t ld_gx, double* ws, const float* qmin,
+                       const float* qmax, double* gacc, fqss_stream_t stream);
 
 extern "C" int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd, float* gx,
                            float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz, int64_t ld_x,
                            int64_t ld_gx, double* ws, fqss_stream_t stream) {
+    return gn_bwd_impl("fqss_gn_bwd", gz, x, gamma, nullptr, mean_rstd, gx, ggamma, gbeta, B, C, M, ld_gz, ld_x, ld_gx, ws, nullptr, nullptr, nullptr,
+                       stream);
+}
+
+// backward of fqss_gnq_fwd_f: g = dL/dy; the quantizer's STE runs on the pre-quant value recomputed from x in the two data passes of
+// the GroupNorm backward (range partials to gacc, FQSS_GACC_SLOTS x 3 as fqss_actq_bwd) -- no fqss_actq_bwd pass, no stored z
+extern "C" int fqss_gnq_bwd_f(const float* g, const float* x, const float* gamma, const float* beta, const float* mean_rstd, float* gx,
+                              float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_g, int64_t ld_x, int64_t ld_gx, double* ws,
+                              const float* qmin, const float* qmax, double* gacc, fqss_stream_t stream) {
+    FQSS_REQUIRE(beta && qmin && qmax && gacc, "null quantizer argument");
+    return gn_bwd_impl("fqss_gnq_bwd_f", g, x, gamma, beta, mean_rstd, gx, ggamma, gbeta, B, C, M, ld_g, ld_x, ld_gx, ws, qmin, qmax, gacc, stream);
+}
+
+static int gn_bwd_impl(const char* who, const float* gz, const float* x, const float* gamma, const float* beta, const float* mean_rstd, float* gx,
+                       float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz, int64_t ld_x, int64_t ld_gx, double* ws, const float* qmin,
+                       const float* qmax, double* gacc, fqss_stream_t stream) {
     FQSS_REQUIRE(gz && x && gamma && mean_rstd && gx && ggamma && gbeta && ws, "null tensor");
     FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_gz >= M && ld_x >= M && ld_gx >= M, "bad shape");
     if (B == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = FQSS_VEC_OK2(gz, ld_gz, x, ld_x);
     const int zs = gn_col_slices((int64_t)C * B, M, vec ? 4 : 1);
-    if (zs > 1 && hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)B * C, s) != hipSuccess) return launch_status("fqss_gn_bwd(memset)");
-    if (vec)
-        hipLaunchKernelGGL(k_gn_bwd_rows<4>, dim3((unsigned)C, (unsigned)B, (unsigned)zs), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
+    if (zs > 1 && hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)B * C, s) != hipSuccess) return launch_status(who);
+    const dim3 rgrid((unsigned)C, (unsigned)B, (unsigned)zs);
+    if (qmin != nullptr) {
+        if (vec) hipLaunchKernelGGL((k_gn_bwd_rows<4, true>), rgrid, dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws, gamma, beta, mean_rstd, qmin, qmax, gacc);
+        else hipLaunchKernelGGL((k_gn_bwd_rows<1, true>), rgrid, dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws, gamma, beta, mean_rstd, qmin, qmax, gacc);
+    } else if (vec)
+        hipLaunchKernelGGL((k_gn_bwd_rows<4, false>), rgrid, dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(k_gn_bwd_rows<1>, dim3((unsigned)C, (unsigned)B, (unsigned)zs), dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws);
+        hipLaunchKernelGGL((k_gn_bwd_rows<1, false>), rgrid, dim3(256), 0, s, gz, x, C, M, ld_gz, ld_x, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     const int nbs = B <= 16 ? 1 : (int)(cdiv(B, 16) > 64 ? 64 : cdiv(B, 16));      // sample slices of the parameter-gradient sums
     hipLaunchKernelGGL(k_gn_bwd_coef, dim3((unsigned)(B + cdiv(C, 256) * nbs)), dim3(256), 0, s, gamma, mean_rstd, B, C, M, ws,
                        ggamma, gbeta, nbs);
     const int64_t rows = (int64_t)B * C;
-    if (vec && aligned16(gx) && ld_gx % 4 == 0)
-        hipLaunchKernelGGL(k_gn_bwd_apply<4>, grid_rows(rows, M, 4), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
-                           M, ld_gz, ld_x, ld_gx, ws);
+    const bool v4 = vec && aligned16(gx) && ld_gx % 4 == 0;
+    if (qmin != nullptr) {
+        if (v4) hipLaunchKernelGGL((k_gn_bwd_apply<4, true>), grid_rows(rows, M, 4), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C, M, ld_gz, ld_x, ld_gx, ws, beta, qmin, qmax);
+        else hipLaunchKernelGGL((k_gn_bwd_apply<1, true>), grid_rows(rows, M, 1), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C, M, ld_gz, ld_x, ld_gx, ws, beta, qmin, qmax);
+    } else if (v4)
+        hipLaunchKernelGGL((k_gn_bwd_apply<4, false>), grid_rows(rows, M, 4), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
+                           M, ld_gz, ld_x, ld_gx, ws, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(k_gn_bwd_apply<1>, grid_rows(rows, M, 1), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
-                           M, ld_gz, ld_x, ld_gx, ws);
-    return launch_status("fqss_gn_bwd");
+        hipLaunchKernelGGL((k_gn_bwd_apply<1, false>), grid_rows(rows, M, 1), dim3(256), 0, s, gz, x, gamma, mean_rstd, gx, B, C,
+                           M, ld_gz, ld_x, ld_gx, ws, nullptr, nullptr, nullptr);
+    return launch_status(who);
 }

@@ -750,6 +750,31 @@ def gn_bwd(gz, x, gamma, mean_rstd, ggamma, gbeta):
     return gx
 
 
+def gnq_fwd_f(x, gamma, beta, eps, qmin, qmax, want_idx=True):
+    """fq(GroupNorm(1, C)(x)) on a float input, the quantizer inside the apply pass -> (y, codes or None, mean_rstd)"""
+    _need_gpu(x, gamma, beta, qmin, qmax)
+    x, B, C, M, ld_x = _bcm(x)
+    y = empty_act((B, C, M), x.device)
+    idx = empty_codes((B, C, M), x.device) if want_idx else None
+    mean_rstd = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gnq_fwd_f", _p(x), _p(gamma), _p(beta), _p(y), _p(idx), _p(mean_rstd), B, C, M, ld_x, rowmat(y)[2],
+              rowmat(idx)[2] if idx is not None else 0, float(eps), _p(ws), _p(qmin), _p(qmax), _stream())
+    return y, idx, mean_rstd
+
+
+def gnq_bwd_f(g, x, gamma, beta, mean_rstd, qmin, qmax, gacc, ggamma, gbeta):
+    """backward of gnq_fwd_f: the STE and its range partials inside the GroupNorm backward's own passes"""
+    _need_gpu(g, x, gamma, beta, mean_rstd, ggamma, gbeta)
+    g, B, C, M, ld_g = _bcm(g)
+    x, _, _, _, ld_x = _bcm(x)
+    gx = empty_act((B, C, M), x.device)
+    ws = torch.empty(2 * B * C + 2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gnq_bwd_f", _p(g), _p(x), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma), _p(gbeta), B, C, M, ld_g, ld_x, rowmat(gx)[2],
+              _p(ws), _p(qmin), _p(qmax), _p(gacc), _stream())
+    return gx
+
+
 # ------------------------------------------------------------------ K8 / K9 / K14
 def axpby(a, b, sb, sa=1.0):
     """z = sa*a + sb*b"""

@@ -564,6 +564,9 @@ class LinearActQPair(Function):
         return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None, None
 
 
+FUSE_GNQ_F = os.environ.get("FQSS_FUSE_GNQ_F", "1") != "0"    # GroupNormQ on a float input: the quantizer inside the GroupNorm's own passes
+
+
 class GroupNormActQ(Function):
     """out = fq(GroupNorm(1, C)(x))  -- GroupNormQ.  With coded input in the quantizing phase the layer
     runs codes -> codes (csrc/fused_q.hip) and saves nothing but the input codes and the statistics."""
@@ -579,6 +582,15 @@ class GroupNormActQ(Function):
                                               stats=getattr(x, "_fqss_stats", None))
             ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
             return _carrier(out) if q.carrier else out
+        ctx.fused_f = FUSE_GNQ_F and q.qmode == Q_QUANT and q.gacc is not None and x.dim() == 3
+        if ctx.fused_f:
+            # float input, quantizing phase: the quantizer inside the GroupNorm's apply pass (fqss_gnq_fwd_f): y AND its codes from one
+            # pass, no pre-quant z (the un-fused chain in the codes-only dataflow: z, a quantizer pass for the codes, a decode pass for
+            # the float consumer behind it)
+            out, q.idx, mean_rstd = K.gnq_fwd_f(x, gamma, beta, eps, qmin, qmax, want_idx=not q.no_codes)
+            q.carrier = False
+            ctx.save_for_backward(x, gamma, beta, mean_rstd, qmin, qmax)
+            return out
         z, mean_rstd = K.gn_fwd(x, gamma, beta, eps)
         plain = q.qmode == Q_BYPASS
         out = z if plain else _epilogue_fwd(z, ACT_NONE, None, q)
@@ -597,6 +609,13 @@ class GroupNormActQ(Function):
                 ctx.prod.fused = True
             gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb, producer=producer)
             _, g_min, g_max = _flush_ranges(q, None, None, ACT_NONE)
+            return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
+        if ctx.fused_f:
+            x, gamma, beta, mean_rstd, qmin, qmax = ctx.saved_tensors
+            gg, gg_direct = _grad_buf(ctx.gp, gamma)
+            gb, gb_direct = _grad_buf(ctx.bp, gamma)
+            gx = K.gnq_bwd_f(g.contiguous(), x, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb)
+            g_min, g_max = _ranges_after(q, q.gacc)
             return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
         x, gamma, z, mean_rstd = ctx.saved_tensors
         gz, _, g_min, g_max, _ = _plain_or_bwd(z, g, q)

@@ -254,6 +254,16 @@ int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z,
 int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd,
                 float* gx, float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz,
                 int64_t ld_x, int64_t ld_gx, double* ws, fqss_stream_t stream);
+/* GroupNormQ (qat_layers.py:427-452: GroupNorm(1, C) + its output quantizer) on a FLOAT input in the quantizing phase as the GroupNorm's own
+ * passes: y = fq(GroupNorm(x)) from the statistics pass and ONE apply pass (fqss_gn_fwd + fqss_actq_fwd value for value; the pre-quant z is
+ * not stored), and its backward with the STE and the range partials (gacc: FQSS_GACC_SLOTS x 3, as fqss_actq_bwd) inside the two data passes
+ * of fqss_gn_bwd.  ws: 2 B doubles (forward) / 2 B C + 2 B doubles (backward) */
+int fqss_gnq_fwd_f(const float* x, const float* gamma, const float* beta, float* y, uint8_t* yc /* codes of y, nullable */, float* mean_rstd,
+                   int B, int C, int M, int64_t ld_x, int64_t ld_y, int64_t ld_yc, float eps, double* ws, const float* qmin, const float* qmax,
+                   fqss_stream_t stream);
+int fqss_gnq_bwd_f(const float* g, const float* x, const float* gamma, const float* beta, const float* mean_rstd, float* gx, float* ggamma,
+                   float* gbeta, int B, int C, int M, int64_t ld_g, int64_t ld_x, int64_t ld_gx, double* ws, const float* qmin,
+                   const float* qmax, double* gacc, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6q/K7q  "codes-only" streaming layers (csrc/fused_q.hip): input = u8 codes + its quantizer ranges,
