@@ -582,7 +582,7 @@ class GroupNormActQ(Function):
                                               stats=getattr(x, "_fqss_stats", None))
             ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
             return _carrier(out) if q.carrier else out
-        ctx.fused_f = FUSE_GNQ_F and q.qmode == Q_QUANT and q.gacc is not None and x.dim() == 3
+        ctx.fused_f = FUSE_GNQ_F and q.qmode == Q_QUANT and q.gacc is not None and x.dim() == 3 and x.is_cuda      # (the CPU backend: un-fused)
         if ctx.fused_f:
             # float input, quantizing phase: the quantizer inside the GroupNorm's apply pass (fqss_gnq_fwd_f): y AND its codes from one
             # pass, no pre-quant z (the un-fused chain in the codes-only dataflow: z, a quantizer pass for the codes, a decode pass for
