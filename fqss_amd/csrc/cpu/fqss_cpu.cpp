@@ -68,6 +68,7 @@ int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t rows, int64_
                   int act, const float* slope_p, int qmode, const float* qmin, const float* qmax, uint32_t* obs_ws, fqss_stream_t) {
     if (rows == 0 || cols == 0) return FQSS_OK;
     REQUIRE(z && (out || idx) && rows >= 0 && cols >= 0 && ld_z >= cols, "bad args");
+    REQUIRE(act >= 0 && act <= FQSS_ACT_RELU, "act not served by the CPU backend (NONE / PReLU / ReLU only)");
     REQUIRE(act != FQSS_ACT_PRELU || slope_p, "PReLU needs a slope");
     REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
@@ -142,6 +143,7 @@ int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t rows, int64
                   fqss_stream_t) {
     if (rows == 0 || cols == 0) return FQSS_OK;
     REQUIRE(z && g && gz && ld_z >= cols && ld_g >= cols && ld_gz >= cols, "bad args");
+    REQUIRE(act >= 0 && act <= FQSS_ACT_RELU, "act not served by the CPU backend (NONE / PReLU / ReLU only)");
     REQUIRE(act != FQSS_ACT_PRELU || slope_p, "PReLU needs a slope");
     REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     REQUIRE((qmode != FQSS_Q_QUANT && act != FQSS_ACT_PRELU) || gacc, "range/slope grads need gacc");

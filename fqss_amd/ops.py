@@ -861,12 +861,14 @@ class _ForkState:
     """lets the dgrad q-GEMM of ONE branch of a two-way fork add the gradient of the OTHER branch in its epilogue (FUSE_FORK): the other
     branch's backward (an element-wise LayerQ, created later in the forward => run earlier in the backward) leaves its gradient in
     `other` (tagged with its branch index, ACCUMULATED if that branch has several such consumers); the conv's LinearActQ.backward
-    consumes it only if it sits on the opposite branch and records which branch it was; Fork2.backward then passes the fused
-    branch's gradient through -- after checking that what was added really is the other branch's complete gradient."""
-    __slots__ = ("other", "other_branch", "fused_branch", "n_other")
+    consumes it only if it sits on the opposite branch and records which branch it was -- and WHAT it added (`taken`, a snapshot:
+    a further element-wise consumer of that branch whose backward runs AFTER the conv's keeps accumulating into `other`, which must not
+    change what Fork2.backward subtracts); Fork2.backward then passes the fused branch's gradient through -- after checking that what
+    was added really is the other branch's complete gradient."""
+    __slots__ = ("other", "other_branch", "fused_branch", "n_other", "taken", "n_taken")
 
     def __init__(self):
-        self.other, self.other_branch, self.fused_branch, self.n_other = None, None, None, 0
+        self.other, self.other_branch, self.fused_branch, self.n_other, self.taken, self.n_taken = None, None, None, 0, None, 0
 
     def leave(self, g, branch):
         """an element-wise consumer on `branch` hands over its input gradient"""
@@ -882,7 +884,7 @@ class _ForkState:
         if self.other is None or self.other_branch in (None, -1, branch) or self.fused_branch is not None \
                 or tuple(self.other.shape) != tuple(shape):
             return None
-        self.fused_branch = branch
+        self.fused_branch, self.taken, self.n_taken = branch, self.other, self.n_other
         return self.other
 
 
@@ -901,8 +903,8 @@ class Fork2(Function):
     @staticmethod
     def backward(ctx, g1, g2):
         fk = ctx.fk
-        fb, other, n_other = fk.fused_branch, fk.other, fk.n_other
-        fk.fused_branch, fk.other, fk.other_branch, fk.n_other = None, None, None, 0
+        fb, other, n_other, n_left = fk.fused_branch, fk.taken, fk.n_taken, fk.n_other
+        fk.fused_branch, fk.other, fk.other_branch, fk.n_other, fk.taken, fk.n_taken = None, None, None, 0, None, 0
         gs = (g1, g2)
         if fb is None:
             if g1 is None:
@@ -911,9 +913,10 @@ class Fork2(Function):
                 return g1, None
             return K.axpby(g1, g2, 1.0), None
         gf, go = gs[fb], gs[1 - fb]              # gf already holds (its own gradient + `other`)
-        if go is None or (n_other == 1 and go.data_ptr() == other.data_ptr()):
+        if go is None or (n_other == 1 and n_left == 1 and go.data_ptr() == other.data_ptr()):
             return gf, None                      # `other` WAS the opposite branch's complete gradient (fqss_qpw_bwd_x_add)
-        # the opposite branch had further consumers (autograd summed them with `other` into `go`): add what the epilogue missed
+        # the opposite branch had further consumers -- before or AFTER the conv's backward took its snapshot -- and autograd summed all
+        # of them into `go`: add what the epilogue missed (go - the snapshot that was added)
         return K.axpby(K.axpby(gf, go, 1.0), other, -1.0), None
 
 

@@ -77,7 +77,24 @@ class LibriMix:
             sources = [read_wav(row[f"source_{i + 1}_path"], start, stop) for i in range(self.n_src)]
         augment = bool(self.augmentation_cfg) and np.random.uniform() < self.augmentation_cfg.get("prob", 1)
         mixture = None if augment else read_wav(row["mixture_path"], start, stop)
-        return sources, noise, mixture, augment
+        # the item's SNR draws come right behind its probability draw, as inside the reference's __getitem__ (:139-153 calling
+        # train_utils.py:30-52): prob_i, snr_i (two for a 3-mix), noise_snr_i -- so a seeded np.random stream is consumed in the
+        # reference's order for any batch size
+        return sources, noise, mixture, augment, (self._draw_snrs() if augment else None)
+
+    def _draw_snrs(self):
+        cfg, n = self.augmentation_cfg, (1 if self.task == "enh_both" else self.n_src)
+        if cfg.get("distribution") != "uniform":
+            raise AssertionError("Augmentation is not supoorted!")
+        lo, hi = cfg.get("param0"), cfg.get("param1")
+        if self.task not in ("enh_single", "sep_clean", "sep_noisy") or (self.task != "enh_single" and n not in (2, 3)):
+            raise AssertionError("Augmetation is not supported!")
+        d = [np.random.uniform(low=lo, high=hi)]
+        if self.task != "enh_single" and n == 3:
+            d.append(np.random.uniform(low=lo, high=hi))
+        if self.task == "sep_noisy":
+            d.append(np.random.uniform(low=6, high=18))
+        return d
 
     # ---- device side: resample + mix -----------------------------------------------------------------------------------
     def _to_device(self, clips):
@@ -86,25 +103,11 @@ class LibriMix:
             x = K.resample(x, self.sample_rate, int(self.resample * self.sample_rate))
         return x
 
-    def _augment(self, sources, noise):
-        """sources [B, n_src, T], noise [B, T] or None -> mixtures [B, T] (:139-153).  The reference augments inside __getitem__, i.e.
-        every item draws its OWN SNR(s) from the host RNG (train_utils.py:30-52), in item order: one draw for a 2-mix, two for a 3-mix,
-        then one for the noise of sep_noisy -- the same draws, item by item, handed to the batched device kernel as [B] tensors"""
+    def _augment(self, sources, noise, draws):
+        """sources [B, n_src, T], noise [B, T] or None, draws = the items' SNR draws (_read_item) -> mixtures [B, T] (:139-153),
+        handed to the batched device kernel as [B] tensors"""
         from ...process import generate_2mix_snr, generate_3mix_snr
-        cfg, n, B = self.augmentation_cfg, sources.shape[1], sources.shape[0]
-        if cfg.get("distribution") != "uniform":
-            raise AssertionError("Augmentation is not supoorted!")
-        lo, hi = cfg.get("param0"), cfg.get("param1")
-        if self.task not in ("enh_single", "sep_clean", "sep_noisy") or (self.task != "enh_single" and n not in (2, 3)):
-            raise AssertionError("Augmetation is not supported!")
-        draws = []
-        for _ in range(B):                       # item order, like B calls of the reference's __getitem__
-            d = [np.random.uniform(low=lo, high=hi)]
-            if self.task != "enh_single" and n == 3:
-                d.append(np.random.uniform(low=lo, high=hi))
-            if self.task == "sep_noisy":
-                d.append(np.random.uniform(low=6, high=18))
-            draws.append(d)
+        n = sources.shape[1]
         col = lambda j: torch.tensor([d[j] for d in draws], dtype=torch.float32, device=sources.device)
         if self.task == "enh_single":
             return generate_2mix_snr(sources[:, 0], noise, col(0))
@@ -136,7 +139,7 @@ class LibriMix:
             mixture[plain] = x[B * ns + (B if has_noise else 0):]
         aug = [i for i, it in enumerate(items) if it[3]]
         if aug:
-            mixture[aug] = self._augment(sources[aug], noise[aug] if has_noise else None)
+            mixture[aug] = self._augment(sources[aug], noise[aug] if has_noise else None, [items[i][4] for i in aug])
         return mixture.unsqueeze(1), sources
 
     def __getitem__(self, idx):

@@ -303,3 +303,41 @@ def test_pmc_reduce_matches_kernel_symbols_and_fails_loudly():
     assert rp._assign(rows, man) == [12.0, 12.0]
     with pytest.raises(SystemExit):
         rp._assign(rows, [dict(kernel="k_qwgrad2", label="wgrad", iters=1)])
+
+
+def test_residual_fork_bookkeeping_with_a_late_consumer(monkeypatch):
+    """ops._ForkState / Fork2.backward -- the dgrad q-GEMM of one fork branch adds the OTHER branch's gradient
+    in its epilogue.  Topology the GPU gates never build: TWO element-wise consumers on the other branch with the conv's backward
+    ordered BETWEEN them (EwQ#2 leaves o2, the conv fuses own + o2, EwQ#1 leaves o1).  Fork2.backward must subtract what the conv
+    really added (the snapshot o2), not the later-accumulated o1 + o2.  Bookkeeping only: K.axpby is replaced by the torch
+    expression it computes."""
+    from fqss_amd import ops
+    monkeypatch.setattr(ops.K, "axpby", lambda a, b, sb, sa=1.0: sa * a + sb * b)
+    own, o1, o2 = torch.randn(3, 5), torch.randn(3, 5), torch.randn(3, 5)
+
+    class Ctx:
+        pass
+
+    def run(order):
+        fk = ops._ForkState()
+        fused = None
+        for ev in order:
+            if ev == "o1":
+                fk.leave(o1, 1)
+            elif ev == "o2":
+                fk.leave(o2, 1)
+            else:
+                fused = fk.take(0, own.shape)
+        g0 = own + fused if fused is not None else own               # the conv's dgrad (+ epilogue add)
+        g1 = (o1 + o2) if ("o1" in order and "o2" in order) else (o2 if "o2" in order else o1)   # autograd's own sum on branch 1
+        if order in (["o2", "conv"], ["o1", "conv"]):
+            g1 = o2 if order[0] == "o2" else o1                      # single consumer: autograd hands over the very tensor
+        ctx = Ctx()
+        ctx.fk = fk
+        g, _ = ops.Fork2.backward(ctx, g0, g1)
+        assert fk.other is None and fk.taken is None and fk.fused_branch is None
+        return g, (own + g1)
+
+    for order in (["o2", "conv", "o1"], ["o2", "o1", "conv"], ["o2", "conv"], ["conv", "o2", "o1"], ["o1", "conv"]):
+        g, want = run(order)
+        torch.testing.assert_close(g, want, msg=str(order))

@@ -5,7 +5,15 @@ the KD step of mysystem.py:124-151 (Adam 1e-3, clip 5.0) over a STREAM of never-
 (fqss_amd.data.synth_batch_2band: two spectrally distinct speakers), N_STEPS steps, under several CPU configurations that only
 change the fp32 summation order (threads 1 / 8, mkldnn on / off).  Stored: per-step loss and mean student SI-SDR of every run,
 and the reference's OWN spread between those runs over the last 50 steps -- the floor any other backend is compared against.
-    python tools/make_goldens_long.py            -> tests/golden/tiny_train_long.npz"""
+    python tools/make_goldens_long.py            -> tests/golden/tiny_train_long.npz
+    python tools/make_goldens_long.py dptnet     -> dpt_train_long.npz
+Round 4: the same gate at the REAL model size and for the two remaining families --
+    python tools/make_goldens_long.py cfg1       -> cfg1_train_long.npz   FULL-SIZE ConvTasNetQ (5.1 M parameters, cfg1_fill weights),
+                                                    B = 2, T = 8000, 300 steps, three CPU configurations
+    python tools/make_goldens_long.py sepformer  -> sep_train_long.npz    tiny SepformerQ of sep_tiny_step.npz, B = 1 (the speechbrain
+                                                    env's per-sample objective == the asteroid objective at B = 1), Adam 1.5e-4, clip 5
+    python tools/make_goldens_long.py htdemucs   -> hd_train_long.npz     tiny HTDemucsQ of hd_tiny_step.npz, solver.py:333-366 l1 + SDR-weighted
+                                                    l1 KD, Adam 3e-4, NO clipping (htdemucs.yaml:77-84), stereo two-stem stream"""
 import copy
 import os
 import sys
@@ -14,11 +22,12 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import make_goldens_htdemucs as MH  # noqa: E402  (FIRST: it hands the shim's demucs.spec its spectro / ispectro before htdemucsq.py binds them)
 import make_goldens as MG  # noqa: E402  (installs the shim, imports the reference)
 
 import torch  # noqa: E402
 
-from fqss_amd.data import synth_batch_2band  # noqa: E402  (data generator only: no kernels)
+from fqss_amd.data import synth_batch_2band, synth_stems  # noqa: E402  (data generators only: no kernels)
 
 N_STEPS, B, T, SEED0 = 400, 4, 1600, 5000
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
@@ -31,6 +40,29 @@ def build(which):
         g = np.load(os.path.join(GOLD, "tiny_step.npz"))
         kw = dict(n_spks=2, kernel_size=16, stride=8, n_filters=32, bn_chan=16, hid_chan=32, n_blocks=2, n_repeats=1)
         model, lr = MG.ConvTasNetQ(**kw), 1e-3
+    elif which == "cfg1":
+        model = MG.ConvTasNetQ(n_spks=2, kernel_size=16, stride=8)
+        fmodel = copy.deepcopy(model)
+        model = MG.quantize_model(model, MG.QCFG)
+        MG.cfg1_fill(fmodel, "T."); MG.cfg1_fill(model, "S.")
+        model.train(); fmodel.eval()
+        return model, fmodel, 1e-3
+    elif which == "sepformer":
+        import make_goldens_sepformer as MS
+        g = np.load(os.path.join(GOLD, "sep_tiny_step.npz"))
+        model = MS.RS.SepformerQ(**MS.TINY_KW)
+        model.masker = MS.RS.MaskGenerator(MS.TINY_KW["n_spks"], MS.TINY_KW["n_filters"], n_repeats=MS.TINY_KW["n_repeats"],
+                                           n_heads=MS.TINY_KW["n_heads"], chunk_size=MS.TINY_KW["chunk_size"], n_ffn=MS.TINY_FFN)
+        lr = MS.LR
+    elif which == "htdemucs":
+        g = np.load(os.path.join(GOLD, "hd_tiny_step.npz"))
+        model = MH.HTDemucsQ(**MH.TINY_KW)
+        fmodel = copy.deepcopy(model)
+        model = MH.quantize_model(model, MH.QCFG)
+        model.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd0.")})
+        fmodel.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fsd.")})
+        model.train(); fmodel.eval()
+        return model, fmodel, 3e-4
     else:
         import make_goldens_dptnet as MD
         g = np.load(os.path.join(GOLD, "dpt_tiny_step.npz"))
@@ -50,22 +82,29 @@ def run(threads, mkldnn, which="convtasnet", N_STEPS=N_STEPS, B=B, T=T):
     loss_t, sdr_t, tsdr_t = [], [], []
     with torch.backends.mkldnn.flags(enabled=mkldnn):
         for step in range(N_STEPS):
-            x, tgt = synth_batch_2band(B, T, seed=SEED0 + step)
-            if which != "convtasnet":
-                x = x
             opt.zero_grad()
-            est, fest, w, kd, task, loss, sdrs, sdrqs = MG.common_step(model, fmodel, x, tgt)
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
-            opt.step()
-            loss_t.append(float(loss)); sdr_t.append(float(-sdrqs.mean())); tsdr_t.append(float(-sdrs.mean()))
+            if which == "htdemucs":
+                mix, src = synth_stems(B, 2, 2, T, seed=SEED0 + step)
+                est, fest, w, task, kd, loss = MH.kd_step(model, fmodel, mix, src)
+                loss.backward()                          # htdemucs.yaml: no gradient clipping
+                opt.step()
+                with torch.no_grad():
+                    sdrq, sdrt = MH.new_sdr(src, est.detach()).mean(), MH.new_sdr(src, fest).mean()
+                loss_t.append(float(loss)); sdr_t.append(float(sdrq)); tsdr_t.append(float(sdrt))
+            else:
+                x, tgt = synth_batch_2band(B, T, seed=SEED0 + step)
+                est, fest, w, kd, task, loss, sdrs, sdrqs = MG.common_step(model, fmodel, x, tgt)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+                opt.step()
+                loss_t.append(float(loss)); sdr_t.append(float(-sdrqs.mean())); tsdr_t.append(float(-sdrs.mean()))
             if step % 50 == 0 or step == N_STEPS - 1:
                 print(f"threads {threads} mkldnn {mkldnn} step {step} loss {float(loss):.3f} si-sdr {sdr_t[-1]:.3f} (teacher {tsdr_t[-1]:.3f})", flush=True)
     return np.array(loss_t, np.float32), np.array(sdr_t, np.float32), np.array(tsdr_t, np.float32)
 
 
-def main(which="convtasnet", n_steps=N_STEPS, batch=B, samples=T, fname="tiny_train_long.npz"):
-    variants = [(1, True), (8, True), (1, False), (4, False)]
+def main(which="convtasnet", n_steps=N_STEPS, batch=B, samples=T, fname="tiny_train_long.npz", variants=None):
+    variants = variants or [(1, True), (8, True), (1, False), (4, False)]
     d = dict(n_steps=np.int64(n_steps), batch=np.int64(batch), samples=np.int64(samples), seed0=np.int64(SEED0),
              variants=np.array([f"threads={t},mkldnn={m}" for t, m in variants]))
     L, S = [], []
@@ -85,5 +124,11 @@ def main(which="convtasnet", n_steps=N_STEPS, batch=B, samples=T, fname="tiny_tr
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dptnet":      # reduced length: the reference's LSTM / attention layers are slow on the CPU
         main("dptnet", 160, 2, 400, "dpt_train_long.npz")
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg1":      # ~1 s per reference step on 8 cores: three configurations, 300 steps each
+        main("cfg1", 300, 2, 8000, "cfg1_train_long.npz", variants=[(8, True), (8, False), (4, True)])
+    elif len(sys.argv) > 1 and sys.argv[1] == "sepformer":
+        main("sepformer", 200, 1, 800, "sep_train_long.npz", variants=[(8, True), (1, True), (4, False)])
+    elif len(sys.argv) > 1 and sys.argv[1] == "htdemucs":
+        main("htdemucs", 150, 2, 2100, "hd_train_long.npz", variants=[(8, True), (1, True), (4, False)])
     else:
         main()
