@@ -11,9 +11,14 @@ phase is passed in an untimed calibration before the warm-up).  Inputs are resid
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed live) and `cpu_baseline` (oracle/ = CPU port of the reference path, rank 0, N=1).
 
-`--workload cfg3` / `--workload cfg4` time the other two built configurations of BASELINE.json the same way (DPTNet 2spk,
-1 x 3 s per GPU; Sepformer 2spk, 1 x 4 s per GPU: SURVEY.md §8 rows a13 / a14) -- same step, same JSON shape; the default
-(cfg 2) is the configuration the metric is quoted on and the only line the driver records.
+`--workload cfg3` / `cfg4` / `cfg5` time the other built configurations of BASELINE.json the same way (DPTNet 2spk, 1 x 3 s per
+GPU; Sepformer 2spk, 1 x 4 s per GPU; HTDemucs 4 x 10 s stereo 44.1 kHz per GPU: SURVEY.md §8 rows a13 / a14 / a15) -- same step, same
+JSON shape.  The default run (cfg 2, N = 1) keeps cfg 2 as the headline -- it is the configuration the metric is quoted on -- and
+APPENDS those three legs to the same JSON line as `other_workloads` (5 warm-up + 10 timed replays each, same process, each model
+freed before the next), so that the driver's own run carries all four workloads.
+
+Every `roofline` object is priced by fqss_amd/roofline_cases.priced(): floor = max(ISSUED flops / dense peak of the matrix dtype the
+kernel executes (bf16 2.5 PF, i8 5 PF; fp32 vector 157.3 TF), algorithmic bytes / 8 TB/s); frac = floor / measured time (<= 1).
 """
 import argparse
 import json
@@ -43,6 +48,10 @@ def parse():
     ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5", "infer"),
                     help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s; "
                          "cfg5 HTDemucs 4 x 10 s stereo 44.1 kHz")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="cfg2 at N=1 only: skip the cfg 3 / 4 / 5 legs that the default run appends as `other_workloads`")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed replays of each `other_workloads` leg")
+    ap.add_argument("--other-warmup", type=int, default=5, help="warm-up replays of each `other_workloads` leg")
     ap.add_argument("--hd-batch", type=int, default=4, help="cfg5: samples per GPU (htdemucs.yaml: 32 over 8 GPUs)")
     ap.add_argument("--hd-seconds", type=float, default=10.0, help="cfg5: segment length in seconds (htdemucs.yaml: 10)")
     return ap.parse_args()
@@ -60,7 +69,7 @@ def dominant_kernel_roofline(dev, ms_step):
     times = [RC.time_case(c) for c in cases]
     groups = RC.summarize(cases, times)
     pmc, pmc_file = {}, None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc, pmc_file = json.load(f).get("per_launch_bytes", {}), "profiles/" + name
@@ -68,18 +77,10 @@ def dominant_kernel_roofline(dev, ms_step):
         except (OSError, ValueError):
             continue
 
-    # bf16 MFMA products ISSUED per fp32-grade product (the exact-split contract): teacher 6 (3 x 3 split, 6 leading terms), gradient
-    # GEMMs 3 (fp32 gradient in three exact pieces x 8-bit codes), forward 1 (codes x codes); priced against the dense bf16 peak
-    issued = {"k_tgemm<0>": 6, "k_tgemm<1>": 6, "k_qgemm<1>": 3, "k_qwgrad2": 3, "k_qgemm<0>": 1}
-
     def obj(g, shapes):
         t = pmc.get(g["kernel"])
         o = RC.roofline_object(g, traffic=t["x2"] if t else None)
         o["traffic_x1"] = t["x1"] if t else None
-        if g["kernel"] in issued and g["flops"] > 0:
-            tf = issued[g["kernel"]] * g["flops"] / g["launches"] / (g["ms_step"] / g["launches"] * 1e-3) / 1e12
-            o["issued_bf16_TFLOPs"] = round(tf, 1)
-            o["frac_of_issued_peak"] = round(tf / 2500.0, 4)       # MI355X_MICROARCH.md: ~2.5 PF dense bf16
         if not shapes:
             o.pop("shapes")
         return o
@@ -101,7 +102,7 @@ def dominant_kernel_roofline(dev, ms_step):
 
 def cpu_baseline(threads):
     """oracle/ (CPU port of the reference path, fqss_oracle.Trainer) on the host cores of THIS box:
-    bounded sample = full ConvTasNet, quantizing phase, batch 2 x 4 s, 1 warm + 2 timed steps."""
+    bounded sample = full ConvTasNet, quantizing phase, batch 2 x 4 s, 1 warm + 3 timed steps (>= 3)."""
     import oracle.fqss_oracle as O
     from fqss_amd.smoke import build_pair
     n = threads or min(32, os.cpu_count() or 1)
@@ -115,7 +116,7 @@ def cpu_baseline(threads):
     s.leave_observer_phase()
     tr.step(x, tgt)                 # warm
     t0 = time.perf_counter()
-    k = 2
+    k = 3
     for _ in range(k):
         tr.step(x, tgt)
     dt = (time.perf_counter() - t0) / k
@@ -159,37 +160,41 @@ def _pmc_other(key, shape_token):
 
 def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
     """`roofline` of a dual-path workload = the kernel with the largest time per step in the committed steady-state table
-    (profiles/r03_cfg3_step_table.txt: k_lstm_fwd<128>, 24 % of the GPU time; profiles/r03_cfg4_step_table.txt: the coded weight-gradient
-    instance of k_gemm_x3, 15 %), timed live at this workload's shape with HIP events on torch's current stream; priced against
-    the fp32 peak (157.3 TFLOP/s: vector = matrix rate for f32) whose arithmetic it performs."""
+    (profiles/r*_cfg3_step_table.txt: k_lstm_fwd<128>; profiles/r*_cfg4_step_table.txt: the coded weight-gradient instance of
+    k_gemm_x3), timed live at this workload's shape with HIP events on torch's current stream (the stream these launches go to) and
+    priced by roofline_cases.priced(): the LSTM recurrence is fp32 FMA on the vector ALU (157.3 TF), the coded weight gradient issues
+    three bf16 MFMA products per term (2.5 PF dense)."""
     from fqss_amd import kernels as K
+    from fqss_amd import roofline_cases as RC
     if which == "cfg3":
         S, Bq, H = seqs[0], seqs[1], 128            # intra-chunk BiLSTM: 250 steps x (chunks) sequences, both directions in one launch
         pre = torch.randn(S, Bq, 8 * H, device="cuda") * 0.1
         whh, bhh = torch.randn(2, 4 * H, H, device="cuda") * 0.05, torch.zeros(2, 4 * H, device="cuda")
         us = _time_launches(lambda: K.lstm_fwd(pre, whh, bhh, S, Bq, H), 10)
         flops = 2.0 * 2 * (4 * H) * H * S * Bq       # the recurrent product h W_hh^T of both directions
-        tf = flops / us * 1e-6
-        return {"kernel": "k_lstm_fwd<128>", "what": "BiLSTM recurrence of the intra-chunk path (both directions)", "shape": [S, Bq, H],
-                "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 24, "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-                "frac": round(tf / 157.3, 3), "traffic": _pmc_other("k_lstm_fwd<128>", f"{S} steps x {Bq} sequences"),
-                "note": "fp32 FMA issue + 2 barriers per time step bound; with 194 / 250 sequences per launch an MFMA form (>= 16 sequences per "
-                        "workgroup) leaves < 16 workgroups on 256 CUs and is slower (DESIGN.md 7)"}
-    # cfg 4 (profiles/r03_cfg4_step_table.txt): the weight gradient of the student's coded linears, k_gemm_x3<false, false, true, 2, 2, 1> --
+        n = S * Bq
+        nbytes = 4.0 * n * 8 * H + 4.0 * n * (2 * H + 8 * H + 4 * H)      # input projection read; h, gates, cell states written (roofline_cases.build_other)
+        o = {"kernel": "k_lstm_fwd<128>", "what": "BiLSTM recurrence of the intra-chunk path (both directions)", "shape": [S, Bq, H],
+             "launch_us": round(us, 1), "launches_per_step": 24, "algorithmic_bytes_per_launch": int(nbytes)}
+        o.update(RC.priced(flops, 1, "f32", nbytes, us))
+        o["traffic"] = _pmc_other("k_lstm_fwd<128>", f"{S} steps x {Bq} sequences")
+        o["note"] = ("a chain of 250 dependent time steps: fp32 FMA issue + 2 barriers per step, latency-bound at 194 sequence pairs "
+                     "(DESIGN.md 7); neither roofline binds it")
+        return o
+    # cfg 4 (profiles/r*_cfg4_step_table.txt): the weight gradient of the student's coded linears, k_gemm_x3<false, false, true, 2, 2, 1> --
     # A = gz^T (fp32, three bf16 pieces), B = the input's u8 codes (one exact plane): three products per k
     gz = torch.randn(rows, Co, device="cuda")
     xc = torch.randint(0, 256, (rows, Ci), device="cuda", dtype=torch.uint8)
     lo, hi = torch.tensor([-1.0], device="cuda"), torch.tensor([1.0], device="cuda")
     gw = torch.zeros(Co, Ci, device="cuda")
     us = _time_launches(lambda: K.qrow_bwd_w(gz, xc, lo, hi, gw))
-    tf = 2.0 * rows * Ci * Co / us * 1e-6
-    return {"kernel": "k_gemm_x3<false, false, true, 2, 2, 1> (fqss_qrow_bwd_w)", "what": "weight gradient of the " + what + " on the input's codes",
-            "shape": [rows, Ci, Co], "bound": "mfma", "launch_us": round(us, 1), "launches_per_step": 128, "achieved": round(tf, 1), "peak": 157.3,
-            "unit": "TFLOP/s", "frac": round(tf / 157.3, 3), "traffic": _pmc_other("k_gemm_x3", f"{rows} x {Ci} -> {Co}"),
-            "issued_bf16_TFLOPs": round(3 * tf, 1),
-            "frac_of_issued_peak": round(3 * tf / 2500.0, 4),
-            "note": "fp32 arithmetic priced against the fp32 matrix peak; executed as 3 bf16 products per term (issued rate against the 2.5 PF "
-                    "dense bf16 peak beside it); bound by vector-ALU issue of the operand split and by the split-K atomics (DESIGN.md 7e (4))"}
+    nbytes = 4.0 * rows * Co + rows * Ci + 4.0 * Co * Ci
+    o = {"kernel": "k_gemm_x3<false, false, true, 2, 2, 1> (fqss_qrow_bwd_w)", "what": "weight gradient of the " + what + " on the input's codes",
+         "shape": [rows, Ci, Co], "launch_us": round(us, 1), "launches_per_step": 128, "algorithmic_bytes_per_launch": int(nbytes)}
+    o.update(RC.priced(2.0 * rows * Ci * Co, 3, "bf16", nbytes, us))
+    o["traffic"] = _pmc_other("k_gemm_x3", f"{rows} x {Ci} -> {Co}")
+    o["note"] = "bound by vector-ALU issue of the operand split and by the split-K atomics (DESIGN.md 7e (4)), not by either roofline"
+    return o
 
 
 def cpu_baseline_dualpath(which, model, fmodel, lr, T):
@@ -220,8 +225,9 @@ def cpu_baseline_dualpath(which, model, fmodel, lr, T):
                       f"segment length, torch CPU fp32"}
 
 
-def main_dualpath(a):
-    """cfg 3 / cfg 4: one sample per GPU (the shipped per-GPU batch), same step and timing protocol as cfg 2"""
+def main_dualpath(a, comm=None):
+    """cfg 3 / cfg 4: one sample per GPU (the shipped per-GPU batch), same step and timing protocol as cfg 2.  With `comm` given (the
+    `other_workloads` legs of the default run) the JSON object is RETURNED instead of printed and the communicator stays open."""
     import copy
     from fqss_amd.data import synth_batch
     from fqss_amd.kernels import dp_chunks
@@ -231,7 +237,8 @@ def main_dualpath(a):
     from fqss_amd.runtime import KDTrainStep
     from fqss_amd.smoke import QCFG
     W = DUALPATH[a.workload]
-    comm = Comm.from_env("cuda")
+    leg = comm is not None
+    comm = comm or Comm.from_env("cuda")
     assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
     ldev = comm.local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(ldev)
@@ -292,9 +299,12 @@ def main_dualpath(a):
                "roofline": dominant_kernel_roofline_dualpath(a.workload, rows, *W["gemm"], seqs=(250, dp_chunks(L, 250)[1]))}
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_dualpath(a.workload, model, fmodel, W["lr"], T)
+        if leg:
+            return out
         print(json.dumps(out), flush=True)
     comm.barrier()
-    comm.close()
+    if not leg:
+        comm.close()
 
 
 def _events_us(fn, n=5):
@@ -320,7 +330,7 @@ def htdemucs_roofline(B, nh, L, hd):
     f.normal_()
     w, b = torch.randn(Co, Kk, 1, device="cuda") * 0.1, torch.zeros(Co, device="cuda")
     us = _events_us(lambda: K.pwconv_fwd(f, w, b, six=True))
-    tf = 2.0 * B * Co * Kk * M / us * 1e-6
+    from fqss_amd import roofline_cases as RC
     by = 4.0 * B * M * (Kk + Co)
     E = nh * hd
     q, k, v = (torch.randn(B, L, E, device="cuda") * 0.3 for _ in range(3))
@@ -328,20 +338,21 @@ def htdemucs_roofline(B, nh, L, hd):
     qc, kc, vc = (torch.randint(0, 256, (B, L, E), device="cuda", dtype=torch.uint8) for _ in range(3))
     rng = [(torch.tensor([-0.9], device="cuda"), torch.tensor([0.8], device="cuda")) for _ in range(3)]
     uc = _events_us(lambda: K.attn_long_fwd_c(qc, kc, vc, rng, nh, True))
-    ta = 4.0 * L * L * hd * B * nh * 1e-6
-    return {"kernel": "k_qgemm<3, 2> (fqss_pwconv_fwd_x3s)", "what": "pointwise GEMM over the frames of the level-0 rewrite conv (48 x 3 -> 96)",
-            "shape": [B, Kk, Co, M], "bound": "mfma", "launch_us": round(us, 1), "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(tf / 157.3, 3), "traffic": _pmc_other("k_qgemm<3>", f"{B} x (48 x 3 -> {Co}) x {M}"), "algorithmic_bytes_per_launch": int(by),
-            "hbm_frac": round(by / us * 1e-3 / 8000.0, 3),
-            "issued_bf16_TFLOPs": round(6 * tf, 1), "frac_of_issued_peak": round(6 * tf / 2500.0, 4),
-            "other_kernels": [
-                {"kernel": "k_attn_long_fwd_x3<%d, false>" % hd, "what": "self-attention of the spectrogram branch, float operands (teacher)",
-                 "shape": [B, nh, L, hd], "launch_us": round(ua, 1), "achieved": round(ta / ua, 1), "frac": round(ta / ua / 157.3, 3),
-                 "issued_bf16_TFLOPs": round(6 * ta / ua, 1)},
-                {"kernel": "k_attn_long_fwd_c<%d>" % hd, "what": "the same on the u8 codes of q, k, v (student)", "shape": [B, nh, L, hd],
-                 "launch_us": round(uc, 1), "achieved": round(ta / uc, 1), "frac": round(ta / uc / 157.3, 3), "issued_bf16_TFLOPs": round(3 * ta / uc, 1)}],
-            "note": "fp32 arithmetic priced against the fp32 matrix peak (the attention exceeds what fp32 MFMA could reach because it runs "
-                    "as exact bf16 pieces); issued bf16 rate against the 2.5 PF dense peak beside it"}
+    fa = 4.0 * L * L * hd * B * nh
+    na = B * L * E
+    o = {"kernel": "k_qgemm<3, 2> (fqss_pwconv_fwd_x3s)", "what": "pointwise GEMM over the frames of the level-0 rewrite conv (48 x 3 -> 96)",
+         "shape": [B, Kk, Co, M], "launch_us": round(us, 1), "algorithmic_bytes_per_launch": int(by)}
+    o.update(RC.priced(2.0 * B * Co * Kk * M, 6, "bf16", by, us))
+    o["traffic"] = _pmc_other("k_qgemm<3>", f"{B} x (48 x 3 -> {Co}) x {M}")
+    oa = {"kernel": "k_attn_long_fwd_x3<%d, false>" % hd, "what": "self-attention of the spectrogram branch, float operands (teacher)",
+          "shape": [B, nh, L, hd], "launch_us": round(ua, 1)}
+    oa.update(RC.priced(fa, 6, "bf16", 4.0 * 3 * na + 4.0 * na + 8.0 * B * nh * L, ua))
+    oc = {"kernel": "k_attn_long_fwd_c<%d>" % hd, "what": "the same on the u8 codes of q, k, v (student)", "shape": [B, nh, L, hd], "launch_us": round(uc, 1)}
+    oc.update(RC.priced(fa, 3, "bf16", 3.0 * na + 4.0 * na + 8.0 * B * nh * L, uc))
+    o["other_kernels"] = [oa, oc]
+    o["note"] = ("fp32-grade arithmetic executed as exact bf16 partial products (6 per term for float operands, 3 on codes): priced on the "
+                 "issued products against the 2.5 PF dense bf16 peak")
+    return o
 
 
 def cpu_baseline_htdemucs(model, fmodel, B, T):
@@ -373,16 +384,18 @@ def cpu_baseline_htdemucs(model, fmodel, B, T):
                       f"scaled by {Tc}/{T} to the workload's segment length, torch CPU fp32"}
 
 
-def main_htdemucs(a):
+def main_htdemucs(a, comm=None):
     """cfg 5: HTDemucs, stereo 44.1 kHz, 4 sources, the shipped per-GPU batch (32 / 8 GPUs) x 10 s; step = student fwd + teacher
-    fwd + solver loss + bwd (+ all-reduce) + Adam (htdemucs.yaml: lr 3e-4, no clipping), same timing protocol as cfg 2"""
+    fwd + solver loss + bwd (+ all-reduce) + Adam (htdemucs.yaml: lr 3e-4, no clipping), same timing protocol as cfg 2; `comm`: as
+    main_dualpath"""
     import copy
     from fqss_amd.parallel import Comm
     from fqss_amd.quantization.qat.models.load_model import quantize_model
     from fqss_amd.quantization.qat.models.htdemucsq import HTDemucsQ
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
     from fqss_amd.runtime import KDTrainStep
-    comm = Comm.from_env("cuda")
+    leg = comm is not None
+    comm = comm or Comm.from_env("cuda")
     assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
     ldev = comm.local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(ldev)
@@ -443,9 +456,12 @@ def main_htdemucs(a):
                "roofline": htdemucs_roofline(B, 8, Fr * le, 64)}
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_htdemucs(model, fmodel, B, T)
+        if leg:
+            return out
         print(json.dumps(out), flush=True)
     comm.barrier()
-    comm.close()
+    if not leg:
+        comm.close()
 
 
 def main_infer(a):
@@ -573,6 +589,28 @@ def main():
         out.update(step)
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_threads)
+        if comm.world == 1 and not a.no_other_workloads:
+            # the other three BASELINE configurations in the SAME driver-run line: the cfg-2 model, its graphs and
+            # its memory pools are released first, each leg frees its own before the next
+            import copy
+            import gc
+            del step, model, fmodel, r
+            legs = []
+            for w in ("cfg3", "cfg4", "cfg5"):
+                gc.collect()
+                torch.cuda.empty_cache()
+                torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+                b = copy.copy(a)
+                b.workload, b.steps, b.warmup = w, a.other_steps, a.other_warmup
+                t_leg = time.perf_counter()
+                o = main_htdemucs(b, comm) if w == "cfg5" else main_dualpath(b, comm)
+                leg = {"workload": o["config"]["workload"], "metric": o["metric"], "steps": o["steps"], "warmup": o["warmup"],
+                       "ms_per_step": o["ms_per_step"], "value": o["value"], "unit": o["unit"], "launch": o["config"]["launch"],
+                       "roofline": o["roofline"], "leg_wall_s": round(time.perf_counter() - t_leg, 1)}
+                if "cpu_baseline" in o:
+                    leg["cpu_baseline"] = o["cpu_baseline"]
+                legs.append(leg)
+            out["other_workloads"] = legs
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()

@@ -62,6 +62,9 @@ _PROTOS = {
     "fqss_dwq_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],
     "fqss_split3_planes": [P, P, I64, P],
     "fqss_tgemm": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],
+    "fqss_tgemm_tiled": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],
+    "fqss_tgemm_tiled_ok": [I32, I32, I32],
+    "fqss_split3_tiles": [P, P, I32, I32, P],
     "fqss_tdw": [P, P, P, P, F32, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_tstats": [P, I32, I32, I32, I64, P, P],
     "fqss_dwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],

@@ -71,6 +71,27 @@ __global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__
     }
 }
 
+// The same three planes in the ORDER k_tgemm2 consumes them: [row tile of 256][k-tile of 32][plane][256 rows][4 chunks of 8 k], the
+// 16-B chunks of a row XOR-swizzled by (row >> 2) & 3 -- one k-tile of one row tile is 48 KB of CONTIGUOUS memory, so a wave's LDS-DMA
+// instruction reads 1 KB of whole cache lines (the [3][Co][Ci] planes gave it sixteen 64-B half lines: twice the address work per
+// byte on the CU's vector-memory path, which is what bounds this kernel once the MFMAs are hidden).  Frozen weights: packed once.
+__global__ __launch_bounds__(256) void k_split3_tiles(const float* __restrict__ w, unsigned short* __restrict__ tiles, int Co, int Ci) {
+    const int nkt = Ci / TBK;
+    const int64_t n = (int64_t)Co * Ci;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int e = (int)(i & 7), pc = (int)(i >> 3) & 3, row = (int)(i >> 5) & 255;
+        const int64_t tile = i >> 13;                       // (mt * nkt + kt)
+        const int kt = (int)(tile % nkt), mt = (int)(tile / nkt);
+        const int c = pc ^ ((row >> 2) & 3);
+        unsigned short a, b, d;
+        t_split3(w[(int64_t)(mt * 256 + row) * Ci + kt * TBK + c * 8 + e], a, b, d);
+        const int64_t o = tile * (3 * 8192) + row * 32 + pc * 8 + e;
+        tiles[o] = a;
+        tiles[o + 8192] = b;
+        tiles[o + 2 * 8192] = d;
+    }
+}
+
 // FQSS_TDIAG (diagnostic builds only, tools/r03_bisect.sh; default 0 = the product): bit 0 no MFMAs | 1 plain ds_read_b64 instead of the
 // transposed reads | 2 no LDS stores of the staged tiles | 3 no global loads in the main loop | 4 no epilogue (results are then garbage:
 // these builds only serve as the AGGRESSOR of tools/ubench/pkadd_next_to_mfma.hip)
@@ -386,6 +407,385 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_tgemm2 (round 4): the same GEMM restructured so that memory, split and MFMA overlap INSIDE a workgroup (VERDICT r03 next #1;
+// the round-3 ablation of k_tgemm: 43 us with its MFMAs removed, 54.5 without its epilogue, 62-70 in full, floor 20).
+//   * one workgroup = 8 waves (4 x 2, wave tile 64 x 64) owns ALL rows of a 256-row weight tile for a 128-column activation panel:
+//     the activation panel is read and split ONCE per 256 output rows (k_tgemm: once per 128), half the split VALU per MFMA;
+//   * the pre-split weight planes go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no ds_write): 6 wave
+//     instructions per wave and k-tile, into an UNPADDED image whose 16-B chunks are XOR-swizzled by (row >> 2) & 3 -- applied on the
+//     per-lane SOURCE address (the DMA writes lane-linear), and again by the fragment reads: conflict-free ds_read_b128;
+//   * both operands double-buffered in LDS (2 x (48 KB + 30 KB)): ONE barrier per k-tile instead of two; the DMA of tile kt+1 and the
+//     register loads of tile kt+2 are in flight while tile kt is multiplied, retired by counted s_waitcnt vmcnt(N) (never 0 in the
+//     loop); every vector-memory operation of the loop is issued through asm, so the counts are exact by construction;
+//   * the workgroup loops over the 256-row tiles of the weight (T1: two, the mask conv: four), so the GroupNorm prologue, the
+//     statistics reduction and the launch are paid once per panel, and one tile's result stores drain under the next tile's loads.
+// LDS: 163,840 B (everything the CU has): 2 x 49,152 (A) + 2 x 30,720 (B) + 4,096 (GroupNorm coefficients); the epilogue's
+// staging tiles live in the second A stage.  One workgroup per CU, grid = panels (256 at the benchmark's size).
+#ifndef FQSS_T2_RES_PREFETCH
+#define FQSS_T2_RES_PREFETCH 0
+#endif
+// FQSS_T2_ABL (timing experiments only, tools/r04_abl.sh; default 0 = the product; results are garbage otherwise): bit 0 no MFMAs |
+// 1 no fragment reads | 2 no split / LDS store of the activations | 3 no weight DMA | 4 no activation loads | 5 no result stores
+#ifndef FQSS_T2_ABL
+#define FQSS_T2_ABL 0
+#endif
+constexpr int T2BM = 256, T2BN = 128;
+constexpr int T2_A_STAGE = 3 * T2BM * TBK * 2;            // 49,152: [plane][256 rows][32 k] bf16, 64-B rows, swizzled chunks
+constexpr int T2_B_STAGE = 3 * TBK * TLDN * 2;            // 30,720: [plane][32 k][128 + 32 pad] bf16 (the layout of k_tgemm)
+constexpr int T2_B_OFF = 2 * T2_A_STAGE;
+constexpr int T2_PCO_OFF = T2_B_OFF + 2 * T2_B_STAGE;     // 159,744
+constexpr int T2_SMEM = T2_PCO_OFF + 2 * 512 * 4;         // 163,840
+constexpr int T2_EPI_OFF = T2_A_STAGE;                    // epilogue staging (8 x 4,608 B) + red inside A stage 1
+static_assert(4 * 32 * TLDT * 4 + 2 * 8 * 8 <= T2_A_STAGE, "epilogue scratch fits one A stage");
+
+struct T2Stage {           // one k-tile of activations per thread: 8 consecutive columns of one k-row
+    f32x4t rb[2];
+};
+template <int N>
+__device__ __forceinline__ void t2_wait(T2Stage& st) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(st.rb[0]), "+v"(st.rb[1]) : "n"(N) : "memory");
+}
+// LDS-DMA of 16 B per lane: LDS destination = lds_dst (wave-uniform byte address, through M0) + 16 * lane; M0 is written in the
+// statement that reads it (the compiler reserves it and does not preserve it around asm)
+__device__ __forceinline__ void t2_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// LDS-DMA with a scalar base: source = sbase (wave-uniform, SGPR pair) + voff (per lane, bytes); the 12 pieces a wave moves per k-tile
+// are 1 KB apart, so they share ONE lane-offset register and differ in scalar adds only
+// 16-B load with a scalar base + a 32-bit lane offset: the loader's addresses for 16 k-tiles x 8 rows are scalar adds on ONE register
+// (as 64-bit per-lane pointers the compiler precomputed and spilled them: a scratch reload in the counted stream ends in a vmcnt(0))
+__device__ __forceinline__ void t_load16s(f32x4t& d, const void* sbase, unsigned voff) {
+    // s_nop 4: the compiler may have produced the scalar base by a VALU instruction (v_readlane of a spilled SGPR) right in front of
+    // the statement; a vector-memory instruction that reads such an SGPR needs five wait states, and nothing pads the inside of an asm
+    // statement (without it: wrong tiles and one memory fault, profiles/r04_tgemm2_notes.txt)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void t2_dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int T, int N, class F>
+__device__ __forceinline__ void t2_unroll(F& f) {      // f(integral_constant<T>) ... f(integral_constant<N - 1>), straight-line
+    if constexpr (T < N) {
+        f(std::integral_constant<int, T>{});
+        t2_unroll<T + 1, N>(f);
+    }
+}
+
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem2);
+    float* pco = reinterpret_cast<float*>(smem2 + T2_PCO_OFF);                         // [2][512]
+    double* red = reinterpret_cast<double*>(smem2 + T2_EPI_OFF + 4 * 32 * TLDT * 4);   // [2 * 8]
+    float* pms = reinterpret_cast<float*>(smem2);                                      // [2] (before the first tile lands)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int panel = blockIdx.x;
+    const int b = panel / g.tiles_n, j0 = (panel % g.tiles_n) * T2BN;
+
+    if (PRO == 1) {
+        t_stats_finalize(g.pro_stats + (int64_t)b * kTSlots * kTSlotStride, g.pro_count, g.pro_eps, pms);
+        const float pmean = pms[0], prstd = pms[1];
+        for (int k = tid; k < g.K; k += 512) {
+            const float pa = prstd * g.pro_gamma[k];
+            pco[k] = pa;
+            pco[512 + k] = fmaf(-pa, pmean, g.pro_beta[k]);
+        }
+    }
+    // Without a GroupNorm prologue the coefficient table is free: the bias vector lives there (<= 1024 rows), so that the row tiles
+    // after the first start without a global load -- a load behind the previous tile's result stores would have to wait for them
+    // (vmcnt retires in order), which is exactly the overlap the row-tile loop is for.
+    const bool bias_in_lds = (PRO != 1) && g.M <= 1024;
+    if (bias_in_lds)
+        for (int i = tid; i < g.M; i += 512) pco[i] = g.bias != nullptr ? g.bias[i] : 0.0f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // pms / pco written; nothing of the compiler's in flight
+    const int nkt = g.K / TBK;           // a multiple of 4 (host: K % 128 == 0)
+    const int n_last = (g.N - 1) & ~3;
+    float s1 = 0.0f, s2 = 0.0f;
+    const bool want_stats = g.stats_out != nullptr;
+
+    if (wave >= 6) {
+        // =============================== weight waves (2): LDS-DMA of the weight tiles ==============================================
+        // 24 pieces of 1 KB per wave and k-tile, source and destination lane-linear (one lane-offset register, scalar adds), tile kt+1
+        // requested while the compute waves multiply tile kt, retired by vmcnt(0) in front of the barrier that publishes it.  Nothing
+        // else lives on this wave's counter: a wait for these DMAs behind activation loads (HBM, microseconds) would retire those
+        // too -- vmcnt retires in order -- and behind the compute waves' result stores it would drain them.
+        const int dw = wave - 6;
+        const unsigned voff = lane * 16;
+        auto dma_tile = [&](int64_t tile, int stage) {        // tile = row tile * nkt + k-tile
+            if (FQSS_T2_ABL & 8) return;
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(g.A) + tile * (3 * 8192 * 2) + dw * (24 * 1024);
+#pragma unroll
+            for (int j = 0; j < 24; ++j) t2_dma16s(src + j * 1024, voff, lds_base + stage * T2_A_STAGE + dw * (24 * 1024) + j * 1024);
+        };
+        for (int mt = 0; mt < g.tiles_m; ++mt) {
+            const int64_t t0 = (int64_t)mt * nkt;
+            // tile 0 into stage 0: the compute waves may still be in the previous row tile's epilogue (staging tiles in A stage 1)
+            dma_tile(t0, 0);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int kt = 0; kt < nkt - 1; ++kt) {
+                dma_tile(t0 + kt + 1, (kt + 1) & 1);         // every wave left stage (kt + 1) & 1 at the previous barrier
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");         // the compute waves' barrier behind the last tile
+        }
+    } else if (wave >= 4) {
+        // =============================== activation waves (2): the fp32 panel -> three bf16 planes in LDS ===========================
+        // Per k-tile and wave: 8 x 16 B of activations per lane, the exact 3-way split of 32 values, 24 ds_write_b64.  The loads come
+        // from HBM (microseconds under load) and a tile is 16 KB per workgroup, so THREE tiles are kept in flight in a register ring
+        // (48 KB per CU; ablation profiles/r04_tgemm2_ablation.txt: with 1-2 tiles in flight the memory skeleton alone ran at 9 GB/s
+        // per CU).  These waves issue no other vector-memory operation.
+        const int lt = tid - 256;
+        float pslope = (PRO == 2) ? *g.pro_slope : 0.0f;
+        if (PRO == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pslope));
+        // thread -> k-rows (lt >> 5) + 4 q (q < 8), columns 4 (lt & 31) .. + 4: a wave instruction reads two whole 512-B row segments
+        // (clamped into the row: columns past N are never stored)
+        const int bk_row = lt >> 5, bk_c = (lt & 31) * 4;
+        const unsigned bvoff = (unsigned)((bk_row * (int)g.ldb + min(j0 + bk_c, n_last)) * 4);     // < 2^32: ld_x < 2^28 (host)
+        const float* bbase = g.B + (int64_t)b * g.sBb;                                          // wave-uniform
+        const int64_t bstep = (int64_t)TBK * g.ldb, brow4 = 4 * g.ldb;
+        struct LStage { f32x4t rb[8]; };
+        auto load_b = [&](LStage& st, int t) {
+            if (FQSS_T2_ABL & 16) return;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t_load16s(st.rb[q], bbase + t * bstep + q * brow4, bvoff);
+        };
+        auto store_b = [&](LStage& st, int t) {
+            if (FQSS_T2_ABL & 4) return;
+            unsigned char* bs = smem2 + T2_B_OFF + (t & 1) * T2_B_STAGE + (bk_row * TLDN + bk_c) * 2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kc = t * TBK + bk_row + 4 * q;
+                const float p_a = (PRO == 1) ? pco[kc] : 1.f, p_b = (PRO == 1) ? pco[512 + kc] : 0.f;
+                float h0[4], r1[4], r2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = st.rb[q][e];
+                    if (PRO == 1) v = fmaf(v, p_a, p_b);
+                    else if (PRO == 2) v = v > 0.f ? v : pslope * v;
+                    h0[e] = v;
+                    r1[e] = v - t_tr(v);
+                    r2[e] = r1[e] - t_tr(r1[e]);
+                }
+                uint2 o1, o2, o3;
+                o1.x = __builtin_amdgcn_perm(__float_as_uint(h0[1]), __float_as_uint(h0[0]), 0x07060302u);
+                o1.y = __builtin_amdgcn_perm(__float_as_uint(h0[3]), __float_as_uint(h0[2]), 0x07060302u);
+                o2.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+                o2.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+                o3.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+                o3.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2) = o1;
+                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2 + TBK * TLDN * 2) = o2;
+                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2 + 2 * TBK * TLDN * 2) = o3;
+                __builtin_amdgcn_sched_barrier(0);       // one row at a time: interleaved, the eight rows' temporaries do not fit beside the ring
+            }
+        };
+        // One step = tile T: wait for it (the requests of the up to two younger tiles stay in flight), split it into LDS stage T & 1,
+        // re-arm its registers with tile T + 3, publish (the compute waves arrive when they are done reading stage (T - 1) & 1, the
+        // weight waves when the DMA of tile T has landed).  The whole k-loop is STRAIGHT-LINE code, generated per k-tile count: a
+        // register that an asm load is still filling must never meet a control-flow merge -- the copy the register allocator may
+        // place there reads it before the data has landed (a run-time loop / branch around these steps returned wrong tiles for K = 128).
+        auto row_tile = [&](auto NKT) {
+            constexpr int nk = decltype(NKT)::value;
+            LStage R0, R1, R2;            // tile t travels in R[t % 3]; the prologue only touches B stage 0
+            load_b(R0, 0); load_b(R1, 1); load_b(R2, 2);
+            auto step = [&](auto T) {
+                constexpr int t = decltype(T)::value;
+                constexpr int younger = (nk - 1 - t) < 2 ? (nk - 1 - t) : 2;
+                LStage& st = (t % 3) == 0 ? R0 : (t % 3) == 1 ? R1 : R2;
+                asm volatile("s_waitcnt vmcnt(%8)"
+                             : "+v"(st.rb[0]), "+v"(st.rb[1]), "+v"(st.rb[2]), "+v"(st.rb[3]), "+v"(st.rb[4]), "+v"(st.rb[5]), "+v"(st.rb[6]), "+v"(st.rb[7])
+                             : "n"(8 * younger)
+                             : "memory");
+                store_b(st, t);
+                if (t + 3 <= nk - 1) load_b(st, t + 3);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            };
+            t2_unroll<0, nk>(step);
+            asm volatile("s_barrier" ::: "memory");                        // the compute waves' barrier behind the last tile
+        };
+        for (int mt = 0; mt < g.tiles_m; ++mt) {
+            if (nkt == 4) row_tile(std::integral_constant<int, 4>{});
+            else if (nkt == 8) row_tile(std::integral_constant<int, 8>{});
+            else if (nkt == 12) row_tile(std::integral_constant<int, 12>{});
+            else row_tile(std::integral_constant<int, 16>{});
+        }
+    } else {
+        // =============================== compute waves (4 = 2 x 2, wave tile 128 x 64): fragment reads and MFMAs ====================
+        // One compute wave and one memory wave per SIMD (two waves per SIMD: 256 registers each).  96 MFMAs per k-tile and wave: the
+        // matrix pipe of a SIMD is fed by ONE wave, back to back (8 independent accumulators), with no vector-memory instruction in
+        // its k-loop; the memory wave's instructions issue in the MFMAs' shadow.
+        const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+        const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+        const float nscale = (g.act == FQSS_ACT_PRELU) ? *g.slope : (g.act == FQSS_ACT_RELU ? 0.0f : 1.0f);
+        const bool has_bias = g.bias != nullptr;
+        f32x16 acc[4][2];
+        auto compute_tile = [&](int stage) {
+            const unsigned char* as = smem2 + stage * T2_A_STAGE;
+            typedef unsigned short (*BsT)[TBK][TLDN];
+            BsT Bs = reinterpret_cast<BsT>(smem2 + T2_B_OFF + stage * T2_B_STAGE);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // the three planes of the wave's 64 columns, once per 16-deep k-step; the rows in two halves of 64 (24 MFMAs each), so
+                // that 12 fragments are live at a time instead of 18 (128 accumulator registers leave room for one set in flight)
+                bf16x8 bfr[3][2];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int kr = ks * 16 + 8 * (gq >> 1) + tq;
+                        const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
+                        union { bf16x8 v; s16x4 h[2]; } u;
+                        if (FQSS_T2_ABL & 2) { bfr[p][ni] = bf16x8{}; asm volatile("" : "+v"(bfr[p][ni])); continue; }
+                        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
+                        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                        bfr[p][ni] = u.v;
+                    }
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    bf16x8 af[3][2];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            const int row = wm * 128 + (2 * mh + mi) * 32 + lr;
+                            if (FQSS_T2_ABL & 2) { af[p][mi] = bf16x8{}; asm volatile("" : "+v"(af[p][mi])); continue; }
+                            af[p][mi] = *reinterpret_cast<const bf16x8*>(as + p * (T2BM * TBK * 2) + row * 64 + (((2 * ks + lh) ^ ((row >> 2) & 3)) << 4));
+                        }
+                    constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};     // the six products, smallest pieces first (k_tgemm)
+#pragma unroll
+                    for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+                                if (!(FQSS_T2_ABL & 1))
+                                    acc[2 * mh + mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[2 * mh + mi][ni], 0, 0, 0);
+                                else asm volatile("" : "+v"(acc[2 * mh + mi][ni]) : "v"(af[IA[sp]][mi]), "v"(bfr[IB[sp]][ni]));
+                }
+            }
+        };
+        float(*Tt)[TLDT] = reinterpret_cast<float(*)[TLDT]>(smem2 + T2_EPI_OFF + wave * 32 * TLDT * 4);
+
+        for (int mt = 0; mt < g.tiles_m; ++mt) {
+            const int i0 = mt * T2BM;
+            const int rowt0 = i0 + wm * 128;
+            // The accumulators START at the bias (one fp32 add per element less in the epilogue; the sum is bias + products instead of
+            // products + bias: a different, equally valid fp32 rounding order).
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // rows (r & 3) + 8 (r >> 2) + 4 lh of the 32-row tile; plain loads: the compiler waits for them itself
+                    const int br = rowt0 + mi * 32 + 8 * q + 4 * lh;
+                    const float4 bv = bias_in_lds ? *reinterpret_cast<const float4*>(pco + br)
+                                                  : (has_bias ? *reinterpret_cast<const float4*>(g.bias + br) : make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni][4 * q + 0] = bv.x;
+                        acc[mi][ni][4 * q + 1] = bv.y;
+                        acc[mi][ni][4 * q + 2] = bv.z;
+                        acc[mi][ni][4 * q + 3] = bv.w;
+                    }
+                }
+            }
+            // the loaders' prologue barrier: weight tile 0 and activation tile 0 are in stage 0.  No vmcnt wait here: this wave's result
+            // stores of the previous row tile stay in flight under the next tile's MFMAs.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int kt = 0; kt < nkt - 1; ++kt) {
+                compute_tile(kt & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // done reading stage kt & 1; tile kt+1 is published
+            }
+            compute_tile(1);
+            // every wave is done reading A stage 1 before the staging tiles (which live there) are written
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+            // ---- the epilogue's per-lane addresses hang off `el`, a copy of the lane id the optimiser cannot see through: otherwise it
+            // hoists ~60 registers of loop-invariant store / residual addresses above the k-loop
+            int el = lane;
+            asm volatile("" : "+v"(el));
+            const int e_c4 = (el & 7) * 4, e_r8 = el >> 3, e_lr = el & 31, e_lh = el >> 5;
+            // act (+ residual), 16-B/lane row stores through a wave-private LDS tile (k_tgemm's epilogue, 4 waves x 8 tiles).  The
+            // residual rows are PLAIN loads: an asm load's destination may be spilled by the compiler before the data has landed
+            // (it was, with the residuals requested in front of the last tile's MFMAs), and nothing here is counted by hand.
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int rowt = rowt0 + mi * 32;                 // M1 % 32 == 0 (checked by the host): one side of the split per 32-row tile
+                const bool first = rowt < g.M1;
+                const int64_t ldc = first ? g.ldc1 : g.ldc2;
+                const int64_t off = (int64_t)b * (first ? g.sC1b : g.sC2b) + (int64_t)(first ? rowt : rowt - g.M1) * ldc;
+                float* Cb = (first ? g.C1 : g.C2) + off;
+                const float* Rsel = first ? g.R1 : g.R2;
+                const bool hres = Rsel != nullptr;
+                float4 res[2][4];
+                if (hres) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int pass = 0; pass < 4; ++pass)
+                            res[ni][pass] = *reinterpret_cast<const float4*>(Rsel + off + (int64_t)(pass * 8 + e_r8) * ldc + min(j0 + wn * 64 + ni * 32 + e_c4, n_last));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * e_lh;
+                        const float v = acc[mi][ni][r];
+                        Tt[rl][e_lr] = v > 0.0f ? v : nscale * v;
+                    }
+                    const int col = j0 + wn * 64 + ni * 32 + e_c4;
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int rl = pass * 8 + e_r8;
+                        float4 t = *reinterpret_cast<const float4*>(&Tt[rl][e_c4]);
+                        if (hres) {
+                            const float4 q = res[ni][pass];
+                            t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                        }
+                        if (col < g.N) {
+                            if (!(FQSS_T2_ABL & 32)) store16(Cb + (int64_t)rl * ldc + col, t);
+                            else asm volatile("" : : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+                            if (want_stats) {
+                                const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (col + e < g.N) {
+                                        s1 += v[e];
+                                        s2 = fmaf(v[e], v[e], s2);
+                                    }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        // (red lives in A stage 1 next to the staging tiles: a barrier separates the last wave's staging reads from it; the loader
+        // waves contribute zeros)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        double v[2] = {(double)s1, (double)s2};
+        block_sum<double, 2>(v, red);
+        if (tid == 0) {
+            double* so = g.stats_out + ((int64_t)b * kTSlots + (panel & (kTSlots - 1))) * kTSlotStride;
+            atomicAdd(&so[0], v[0]);
+            atomicAdd(&so[1], v[1]);
+        }
+    }
+}
+
 // T2: y = PReLU( dwconv( GN(x) ) + bias ), statistics of y.  One workgroup per (sample, channel) row,
 // 16 outputs per thread; the GroupNorm coefficients are computed once per workgroup.
 __global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const double* __restrict__ stats_in,
@@ -523,20 +923,30 @@ extern "C" int fqss_split3_planes(const float* w, uint16_t* planes, int64_t n, f
     return launch_status("fqss_split3_planes");
 }
 
-extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci, int Co, int M, int64_t ld_x, int pro,
-                          const double* pro_stats, const float* pro_gamma, const float* pro_beta, float pro_eps,
-                          const float* pro_slope, const float* bias, int act, const float* slope, double* stats_out, int M1,
-                          float* c1, const float* r1, int64_t ld_c1, float* c2, const float* r2, int64_t ld_c2,
-                          fqss_stream_t stream) {
-    FQSS_REQUIRE(planes && x && c1, "null tensor");
-    FQSS_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= ((M + 3) & ~3) && ld_x % 4 == 0 && aligned16(x), "bad input rows");
-    FQSS_REQUIRE(Ci % 8 == 0 && aligned16(planes), "planes need Ci % 8 == 0 and 16-B alignment");
-    FQSS_REQUIRE(M1 > 0 && M1 <= Co && (M1 == Co || c2), "bad output split");
-    FQSS_REQUIRE(aligned16(c1) && ld_c1 % 4 == 0 && ld_c1 >= ((M + 3) & ~3) && (!c2 || (aligned16(c2) && ld_c2 % 4 == 0 && ld_c2 >= ((M + 3) & ~3))),
+// tiled = false: `planes` is the [3][Co][Ci] image of fqss_split3_planes (k_tgemm, any shape); tiled = true: the image of
+// fqss_split3_tiles (k_tgemm2, whole 256-row tiles only)
+static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, const float* x, int B, int Ci, int Co, int M, int64_t ld_x, int pro,
+                        const double* pro_stats, const float* pro_gamma, const float* pro_beta, float pro_eps, const float* pro_slope,
+                        const float* bias, int act, const float* slope, double* stats_out, int M1, float* c1, const float* r1, int64_t ld_c1,
+                        float* c2, const float* r2, int64_t ld_c2, fqss_stream_t stream) {
+#define TG_REQUIRE(cond, msg)                    \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::fqss::set_error("%s: %s", fn, msg); \
+            return FQSS_EINVAL;                  \
+        }                                        \
+    } while (0)
+    TG_REQUIRE(planes && x && c1, "null tensor");
+    TG_REQUIRE(B >= 0 && Ci > 0 && Co > 0 && M >= 0 && ld_x >= ((M + 3) & ~3) && ld_x % 4 == 0 && aligned16(x), "bad input rows");
+    TG_REQUIRE(Ci % 8 == 0 && aligned16(planes), "planes need Ci % 8 == 0 and 16-B alignment");
+    TG_REQUIRE(M1 > 0 && M1 <= Co && (M1 == Co || c2), "bad output split");
+    TG_REQUIRE(aligned16(c1) && ld_c1 % 4 == 0 && ld_c1 >= ((M + 3) & ~3) && (!c2 || (aligned16(c2) && ld_c2 % 4 == 0 && ld_c2 >= ((M + 3) & ~3))),
                  "output rows must be 16-B aligned");
-    FQSS_REQUIRE((!r1 || aligned16(r1)) && (!r2 || aligned16(r2)), "residual rows must be 16-B aligned");
-    FQSS_REQUIRE(pro >= 0 && pro <= 2 && (pro != 1 || (pro_stats && pro_gamma && pro_beta)) && (pro != 2 || pro_slope), "bad prologue");
-    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    TG_REQUIRE((!r1 || aligned16(r1)) && (!r2 || aligned16(r2)), "residual rows must be 16-B aligned");
+    TG_REQUIRE(pro >= 0 && pro <= 2 && (pro != 1 || (pro_stats && pro_gamma && pro_beta)) && (pro != 2 || pro_slope), "bad prologue");
+    TG_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    TG_REQUIRE(!tiled || ld_x < (1ll << 28), "rows too long for the tiled form's 32-bit lane offsets");
+    TG_REQUIRE(!tiled || fqss_tgemm_tiled_ok(Ci, Co, M1), "the tiled form needs Co % 256 == 0, Ci % 128 == 0, Ci <= 512, M1 % 32 == 0");
     if (B == 0 || M == 0) return FQSS_OK;
     TGemmArgs g{};
     g.A = planes; g.B = x; g.M = Co; g.N = M; g.K = Ci; g.ldb = ld_x; g.sBb = (int64_t)Ci * ld_x;
@@ -546,6 +956,21 @@ extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci,
     g.C1 = c1; g.R1 = r1; g.ldc1 = ld_c1; g.sC1b = (int64_t)M1 * ld_c1;
     g.C2 = c2; g.R2 = r2; g.ldc2 = ld_c2; g.sC2b = (int64_t)(Co - M1) * ld_c2;
     g.tiles_n = (int)cdiv(M, TBN); g.tiles_m = (int)cdiv(Co, TBM); g.batches = B;
+    if (tiled) {
+        static const bool attr_ok = [] {
+            bool ok = hipFuncSetAttribute((const void*)k_tgemm2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_SMEM) == hipSuccess;
+            ok = ok && hipFuncSetAttribute((const void*)k_tgemm2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_SMEM) == hipSuccess;
+            ok = ok && hipFuncSetAttribute((const void*)k_tgemm2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_SMEM) == hipSuccess;
+            return ok;
+        }();
+        TG_REQUIRE(attr_ok, "k_tgemm2 needs 160 KB of dynamic LDS");
+        g.tiles_m = Co / T2BM;
+        const dim3 grid2((unsigned)(g.tiles_n * B));
+        if (pro == 0) hipLaunchKernelGGL(k_tgemm2<0>, grid2, dim3(512), T2_SMEM, (hipStream_t)stream, g);
+        else if (pro == 1) hipLaunchKernelGGL(k_tgemm2<1>, grid2, dim3(512), T2_SMEM, (hipStream_t)stream, g);
+        else hipLaunchKernelGGL(k_tgemm2<2>, grid2, dim3(512), T2_SMEM, (hipStream_t)stream, g);
+        return launch_status(fn);
+    }
     const dim3 grid(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m));
     // FQSS_TGEMM_PAD_LDS=<bytes> (experiment knob, read once): unused dynamic LDS that caps the workgroups per CU -- with > 16 KB on top
     // of the 60-64 KB tile buffer only ONE teacher workgroup fits a CU, which leaves half of every SIMD's registers to the student's
@@ -563,7 +988,38 @@ extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci,
     if (pro == 0) hipLaunchKernelGGL(k_tgemm<0>, grid, dim3(256), pad, (hipStream_t)stream, g);
     else if (pro == 1) hipLaunchKernelGGL(k_tgemm<1>, grid, dim3(256), pad, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(k_tgemm<2>, grid, dim3(256), pad, (hipStream_t)stream, g);
-    return launch_status("fqss_tgemm");
+    return launch_status(fn);
+#undef TG_REQUIRE
+}
+
+extern "C" int fqss_tgemm_tiled_ok(int Ci, int Co, int M1) {
+    return Co > 0 && Co % T2BM == 0 && Ci % (4 * TBK) == 0 && Ci >= 4 * TBK && Ci <= 512 && M1 > 0 && M1 % 32 == 0;
+}
+
+extern "C" int fqss_split3_tiles(const float* w, uint16_t* tiles, int Co, int Ci, fqss_stream_t stream) {
+    FQSS_REQUIRE(w && tiles && Co > 0 && Co % T2BM == 0 && Ci > 0 && Ci % TBK == 0 && aligned16(tiles), "whole 256 x 32 tiles only");
+    int64_t nb = cdiv((int64_t)Co * Ci, 256);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_split3_tiles, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, tiles, Co, Ci);
+    return launch_status("fqss_split3_tiles");
+}
+
+extern "C" int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci, int Co, int M, int64_t ld_x, int pro,
+                          const double* pro_stats, const float* pro_gamma, const float* pro_beta, float pro_eps,
+                          const float* pro_slope, const float* bias, int act, const float* slope, double* stats_out, int M1,
+                          float* c1, const float* r1, int64_t ld_c1, float* c2, const float* r2, int64_t ld_c2,
+                          fqss_stream_t stream) {
+    return tgemm_launch(false, "fqss_tgemm", planes, x, B, Ci, Co, M, ld_x, pro, pro_stats, pro_gamma, pro_beta, pro_eps, pro_slope, bias, act, slope,
+                        stats_out, M1, c1, r1, ld_c1, c2, r2, ld_c2, stream);
+}
+
+extern "C" int fqss_tgemm_tiled(const uint16_t* tiles, const float* x, int B, int Ci, int Co, int M, int64_t ld_x, int pro,
+                                const double* pro_stats, const float* pro_gamma, const float* pro_beta, float pro_eps,
+                                const float* pro_slope, const float* bias, int act, const float* slope, double* stats_out, int M1,
+                                float* c1, const float* r1, int64_t ld_c1, float* c2, const float* r2, int64_t ld_c2,
+                                fqss_stream_t stream) {
+    return tgemm_launch(true, "fqss_tgemm_tiled", tiles, x, B, Ci, Co, M, ld_x, pro, pro_stats, pro_gamma, pro_beta, pro_eps, pro_slope, bias, act, slope,
+                        stats_out, M1, c1, r1, ld_c1, c2, r2, ld_c2, stream);
 }
 
 extern "C" int fqss_tdw(const float* x, const double* stats_in, const float* gamma, const float* beta, float eps,

@@ -1025,7 +1025,16 @@ def split3_planes(w2d):
     w2d = w2d.contiguous()
     planes = torch.empty(3, *w2d.shape, device=w2d.device, dtype=torch.int16)
     _lib.call("fqss_split3_planes", _p(w2d), _p(planes), w2d.numel(), _stream())
+    Co, Ci = w2d.shape
+    if Co % 256 == 0 and Ci % 128 == 0 and Ci <= 512 and TGEMM_TILED:
+        # the image k_tgemm2 streams by LDS-DMA ([Co/256][Ci/32][3][256][32], swizzled); rides on the planes tensor
+        tiles = torch.empty(3 * Co * Ci, device=w2d.device, dtype=torch.int16)
+        _lib.call("fqss_split3_tiles", _p(w2d), _p(tiles), Co, Ci, _stream())
+        planes._fqss_tiles = tiles
     return planes
+
+
+TGEMM_TILED = os.environ.get("FQSS_TGEMM_V1", "0") == "0"     # FQSS_TGEMM_V1=1: the round-3 kernel everywhere (A/B)
 
 
 TSTAT_SLOTS, TSTAT_STRIDE = 32, 16   # FQSS_TSTAT_SLOTS / FQSS_TSTAT_STRIDE (include/fqss.h)
@@ -1044,6 +1053,12 @@ def tgemm(planes, x, bias, act=ACT_NONE, slope=None, pro=0, pro_stats=None, pro_
     M1 = Co if M1 is None else M1
     c1 = empty_act((B, M1, M), x.device)
     c2 = empty_act((B, Co - M1, M), x.device) if M1 < Co else None
+    tiles = getattr(planes, "_fqss_tiles", None)
+    if tiles is not None and M1 % 32 == 0:
+        _lib.call("fqss_tgemm_tiled", _p(tiles), _p(x), B, Ci, Co, M, ld_x, pro, _p(pro_stats), _p(pro_gamma), _p(pro_beta),
+                  float(pro_eps), _p(pro_slope), _p(bias), act, _p(slope), _p(stats_out), M1, _p(c1), _p(r1), rowmat(c1)[2],
+                  _p(c2), _p(r2), rowmat(c2)[2] if c2 is not None else 0, _stream())
+        return (c1, c2) if c2 is not None else c1
     if DESC_ABI and (r1 is None or rowmat(r1)[2] == rowmat(c1)[2]) and (r2 is None or rowmat(r2)[2] == rowmat(c2)[2]):
         td = _lib.FqssTGemmDesc()
         dpl, dx, dc1, dr1, dc2, dr2 = _desc(planes.view(3, Co, Ci), _lib.DT_U16), _desc(x), _desc(c1), _desc(r1), _desc(c2), _desc(r2)

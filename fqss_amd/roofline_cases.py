@@ -17,8 +17,39 @@ from . import kernels as K
 B, M = 8, 3999
 NB, NH = 128, 512          # bottleneck / hidden channels of the TCN blocks
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
-MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (the arithmetic of these GEMMs is fp32-exact)
+# Dense peaks of the instruction a kernel EXECUTES (MI355X_MICROARCH.md, chip-level table; never the 2:1-sparsity figures): a kernel that
+# computes an fp32-grade product as k exact bf16 partial products is priced on its k-fold ISSUED flops against the bf16 peak, not on
+# its algorithmic flops against the fp32 peak (that basis allows fractions above 1).
+PEAK_TFLOPS = {"bf16": 2500.0, "i8": 5000.0, "f32": 157.3}
 N = B * M
+
+
+def priced(flops, products, dtype, nbytes, us):
+    """`roofline` numbers of ONE launch: flops = algorithmic flop, products = partial products issued per algorithmic product on the
+    `dtype` matrix (or, "f32", vector) pipe, nbytes = algorithmic HBM bytes, us = measured launch duration.
+    floor = max(issued flops / that dtype's dense peak, bytes / 8 TB/s); `bound` names the larger floor, `achieved` / `peak` / `unit`
+    are that resource's, frac = floor / measured time = achieved / peak <= 1 for anything physical; the other resource's fraction
+    rides beside it."""
+    sec = us * 1e-6
+    issued = flops * products
+    t_m = issued / (PEAK_TFLOPS[dtype] * 1e12) if flops > 0 else 0.0
+    t_h = nbytes / (HBM_PEAK_GBS * 1e9)
+    gbps, tf = nbytes / sec / 1e9, issued / sec / 1e12
+    o = {"hbm_frac": round(gbps / HBM_PEAK_GBS, 4), "algorithmic_GBps": round(gbps, 1), "floor_us": round(max(t_m, t_h) * 1e6, 2)}
+    if flops > 0:
+        o.update(mfma_dtype=dtype, products_per_term=products, issued_TFLOPs=round(tf, 1), issued_frac=round(tf / PEAK_TFLOPS[dtype], 4))
+    if t_m > t_h:
+        o.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_TFLOPS[dtype], unit="TFLOP/s", frac=round(tf / PEAK_TFLOPS[dtype], 4))
+    else:
+        o.update(bound="hbm", achieved=round(gbps, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBS, 4))
+    return o
+
+
+# partial products issued per algorithmic product, and on which pipe (csrc/teacher.hip: 3 x 3 bf16 split, 6 leading terms; csrc/qgemm.hip:
+# fp32 gradient in three exact bf16 pieces x one exact plane of 8-bit codes; forward: codes x codes, one bf16 product)
+ISSUED = {"k_tgemm<0>": ("bf16", 6), "k_tgemm<1>": ("bf16", 6), "k_qgemm<1>": ("bf16", 3), "k_qwgrad2": ("bf16", 3), "k_qgemm<0>": ("bf16", 1),
+          "k_lstm_fwd<128>": ("f32", 1), "k_gemm_x3": ("bf16", 3), "k_qgemm<3>": ("bf16", 6), "k_attn_long_fwd_x3<64>": ("bf16", 6),
+          "k_attn_long_fwd_c<64>": ("bf16", 3)}
 
 
 def _act(C, dev):
@@ -177,22 +208,18 @@ def summarize(cases, times_ms):
 
 
 def roofline_object(g, traffic=None):
-    """the `roofline` JSON object of one kernel: launch-weighted averages over its shapes"""
+    """the `roofline` JSON object of one kernel: launch-weighted averages over its shapes, priced by priced()"""
     n = g["launches"]
     ms = g["ms_step"] / n
-    gbps = g["bytes"] / n / (ms * 1e-3) / 1e9
-    out = {"kernel": g["kernel"], "bound": g["bound"], "launch_us": round(ms * 1e3, 2), "launches_per_step": n,
+    dtype, prod = ISSUED.get(g["kernel"], ("f32", 1))
+    out = {"kernel": g["kernel"], "launch_us": round(ms * 1e3, 2), "launches_per_step": n,
            "ms_per_step": round(g["ms_step"], 3), "algorithmic_bytes_per_launch": round(g["bytes"] / n),
-           "algorithmic_GBps": round(gbps, 1), "survey_convention_GBps": round(g["survey"] / n / (ms * 1e-3) / 1e9, 1),
-           "traffic": traffic, "shapes": g["shapes"]}
+           "survey_convention_GBps": round(g["survey"] / n / (ms * 1e-3) / 1e9, 1)}
+    out.update(priced(g["flops"] / n, prod, dtype, g["bytes"] / n, ms * 1e3))
+    out["traffic"] = traffic
+    out["shapes"] = g["shapes"]
     if g["group"]:
         out["group_of_launches"] = True
-    if g["bound"] == "mfma":
-        tf = g["flops"] / n / (ms * 1e-3) / 1e12
-        out.update(achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                   hbm_frac=round(gbps / HBM_PEAK_GBS, 4))
-    else:
-        out.update(achieved=round(gbps, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBS, 4))
     return out
 
 

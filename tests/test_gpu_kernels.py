@@ -1143,3 +1143,64 @@ def test_mha_prep_matches_the_unfused_quantizer_chain(L, B, E, nh):
         assert torch.equal(gX[..., i * E:(i + 1) * E], want[i]), i
     for a, b in zip(gaccs, refs):
         np.testing.assert_allclose(a.view(-1, 3).sum(0).cpu().numpy(), b.view(-1, 3).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("Co,Ci,pro,act,split,B,M", [
+    (256, 512, 1, 0, 128, 3, 300),      # T3 of the teacher chain: GroupNorm prologue, res | skip split, both residuals, ragged last tile
+    (512, 128, 0, 1, 512, 2, 391),      # T1: PReLU + GroupNorm statistics, two 256-row tiles per workgroup
+    (1024, 128, 2, 2, 1024, 1, 130),    # mask conv: PReLU prologue, ReLU, four row tiles
+    (256, 64, 1, 0, 256, 2, 128),       # two k-tiles only (the loop's peeled head and tail meet), one output
+    (128, 512, 1, 0, 128, 2, 200),      # bottleneck conv: fewer than 256 rows -> the round-3 kernel (k_tgemm) keeps serving it
+    (256, 128, 0, 0, 256, 2, 260),      # one row tile, four k-tiles (the activation ring never re-arms)
+    (512, 512, 1, 2, 512, 1, 140),      # two row tiles behind a GroupNorm prologue (bias from global memory), 16 k-tiles
+    (512, 256, 2, 0, 512, 2, 129),      # eight k-tiles: one re-arming group
+])
+def test_teacher_gemm_against_fp64(Co, Ci, pro, act, split, B, M):
+    """fqss_tgemm (csrc/teacher.hip: k_tgemm2, the 256-row form with the weight planes moved by LDS-DMA, and k_tgemm for the other
+    shapes) against fp64 math on the fp32 operands: the six-product bf16 split is fp32-grade, so the result must sit within a few fp32
+    roundings of the exact sum; the GroupNorm statistics of the epilogue against fp64 sums of what was written."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(Co + Ci + M)
+    R = lambda *s: torch.randn(*s, generator=g)
+    w, bias = R(Co, Ci) / Ci ** 0.5, R(Co) * 0.1
+    x = K.empty_act((B, Ci, M), dev)
+    x.copy_(R(B, Ci, M).to(dev) * 1.5 + 0.3)
+    gamma, beta = (1.0 + 0.2 * R(Ci)).to(dev), (0.1 * R(Ci)).to(dev)
+    slope_in, slope_out = torch.tensor([0.2], device=dev), torch.tensor([0.3], device=dev)
+    planes = K.split3_planes(w.to(dev))
+    st_in = K.tstat_buffer(1, B, dev)[0]
+    K.tstats(x, st_in)
+    so = K.tstat_buffer(1, B, dev)[0]
+    r1 = K.empty_act((B, split, M), dev)
+    r1.copy_(R(B, split, M).to(dev))
+    r2 = None
+    if split < Co:
+        r2 = K.empty_act((B, Co - split, M), dev)
+        r2.copy_(R(B, Co - split, M).to(dev))
+    use_res = pro == 1 and Co == 256 and Ci == 512
+    out = K.tgemm(planes, x, bias.to(dev), act=act, slope=slope_out if act == 1 else None, pro=pro, pro_stats=st_in if pro == 1 else None,
+                  pro_gamma=gamma if pro == 1 else None, pro_beta=beta if pro == 1 else None, pro_eps=1e-8,
+                  pro_slope=slope_in if pro == 2 else None, stats_out=so if act == 1 else None, M1=split,
+                  r1=r1 if use_res else None, r2=r2 if use_res else None)
+    c = torch.cat(list(out), 1) if isinstance(out, tuple) else out
+    xd = x.double().cpu()
+    if pro == 1:
+        mu = xd.mean(dim=(1, 2), keepdim=True)
+        var = (xd * xd).mean(dim=(1, 2), keepdim=True) - mu * mu
+        xd = (xd - mu) / torch.sqrt(var + 1e-8) * gamma.double().cpu().view(1, -1, 1) + beta.double().cpu().view(1, -1, 1)
+    elif pro == 2:
+        xd = torch.where(xd > 0, xd, 0.2 * xd)
+    ref = torch.einsum("oc,bcm->bom", w.double(), xd) + bias.double().view(1, -1, 1)
+    if act == 1:
+        ref = torch.where(ref > 0, ref, float(slope_out.item()) * ref)
+    elif act == 2:
+        ref = ref.clamp(min=0)
+    if use_res:
+        ref = ref + torch.cat([r1, r2], 1).double().cpu()
+    err = float((c.double().cpu() - ref).abs().max())
+    assert err <= 4e-6 * float(ref.abs().max()), (err, float(ref.abs().max()))
+    if act == 1:
+        s = so.double().cpu()[:, :, :2].sum(1)
+        cd = c.double().cpu()
+        np.testing.assert_allclose(s[:, 0].numpy(), cd.sum(dim=(1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(s[:, 1].numpy(), (cd * cd).sum(dim=(1, 2)).numpy(), rtol=1e-5)

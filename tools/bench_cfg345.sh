@@ -2,7 +2,7 @@
 # The other configurations' evidence (GPU box, repo root): bench line WITH the cpu_baseline leg, rocprofv3 kernel stats of the same
 # command, the eager per-step kernel table.  bash tools/bench_cfg345.sh [r03]
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 mkdir -p $O

@@ -2,14 +2,14 @@
 # Regenerates the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root); summaries land in gpurun_out/.
 # Counters are collected in their own passes (never combined with trace domains).
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 bench.py --no-cpu-baseline > $O/bench_line.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 bench.py --no-cpu-baseline --no-other-workloads > $O/bench_line.json 2> $O/bench.err
 cp "$(find $O/bench -name '*kernel_stats.csv' | head -1)" $O/${R}_bench_kernel_stats.csv
 rm -rf $O/bench
-rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-workloads --no-graph > $O/trace.log 2>&1
 python3 tools/trace_summary.py "$(find $O/trace -name '*kernel_trace.csv' | head -1)" 2 > $O/${R}_step_eager_steady_state.txt
 rm -rf $O/trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rl_stats -- python3 tools/roofline_probe.py > $O/rl_stats.log 2>&1
