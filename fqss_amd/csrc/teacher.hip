@@ -71,24 +71,24 @@ __global__ __launch_bounds__(256) void k_split3_planes(const float* __restrict__
     }
 }
 
-// The same three planes in the ORDER k_tgemm2 consumes them: [row tile of 256][k-tile of 32][plane][256 rows][4 chunks of 8 k], the
-// 16-B chunks of a row XOR-swizzled by (row >> 2) & 3 -- one k-tile of one row tile is 48 KB of CONTIGUOUS memory, so a wave's LDS-DMA
-// instruction reads 1 KB of whole cache lines (the [3][Co][Ci] planes gave it sixteen 64-B half lines: twice the address work per
-// byte on the CU's vector-memory path, which is what bounds this kernel once the MFMAs are hidden).  Frozen weights: packed once.
+// The same three planes in the ORDER k_tgemm2 consumes them: [row tile of 256][k-tile of 16][plane][256 rows][2 chunks of 8 k], the two
+// 16-B chunks of a row swapped where (row >> 3) & 1 (conflict-free ds_read_b128 of the 32 x 16 fragments) -- one k-tile of one row tile
+// is 24 KB of CONTIGUOUS memory, so a wave's LDS-DMA instruction reads 1 KB of whole cache lines (the [3][Co][Ci] planes gave it
+// 32-B pieces of 32 rows: several times the address work per byte on the CU's vector-memory path).  Frozen weights: packed once.
 __global__ __launch_bounds__(256) void k_split3_tiles(const float* __restrict__ w, unsigned short* __restrict__ tiles, int Co, int Ci) {
-    const int nkt = Ci / TBK;
+    const int nkt = Ci / 16;
     const int64_t n = (int64_t)Co * Ci;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int e = (int)(i & 7), pc = (int)(i >> 3) & 3, row = (int)(i >> 5) & 255;
-        const int64_t tile = i >> 13;                       // (mt * nkt + kt)
+        const int e = (int)(i & 7), pc = (int)(i >> 3) & 1, row = (int)(i >> 4) & 255;
+        const int64_t tile = i >> 12;                       // (mt * nkt + kt)
         const int kt = (int)(tile % nkt), mt = (int)(tile / nkt);
-        const int c = pc ^ ((row >> 2) & 3);
+        const int c = pc ^ ((row >> 3) & 1);
         unsigned short a, b, d;
-        t_split3(w[(int64_t)(mt * 256 + row) * Ci + kt * TBK + c * 8 + e], a, b, d);
-        const int64_t o = tile * (3 * 8192) + row * 32 + pc * 8 + e;
+        t_split3(w[(int64_t)(mt * 256 + row) * Ci + kt * 16 + c * 8 + e], a, b, d);
+        const int64_t o = tile * (3 * 4096) + row * 16 + pc * 8 + e;
         tiles[o] = a;
-        tiles[o + 8192] = b;
-        tiles[o + 2 * 8192] = d;
+        tiles[o + 4096] = b;
+        tiles[o + 2 * 4096] = d;
     }
 }
 
@@ -410,62 +410,49 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_tgemm2 (round 4): the same GEMM restructured so that memory, split and MFMA overlap INSIDE a workgroup (VERDICT r03 next #1;
 // the round-3 ablation of k_tgemm: 43 us with its MFMAs removed, 54.5 without its epilogue, 62-70 in full, floor 20).
-//   * one workgroup = 8 waves (4 x 2, wave tile 64 x 64) owns ALL rows of a 256-row weight tile for a 128-column activation panel:
-//     the activation panel is read and split ONCE per 256 output rows (k_tgemm: once per 128), half the split VALU per MFMA;
-//   * the pre-split weight planes go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no ds_write): 6 wave
-//     instructions per wave and k-tile, into an UNPADDED image whose 16-B chunks are XOR-swizzled by (row >> 2) & 3 -- applied on the
-//     per-lane SOURCE address (the DMA writes lane-linear), and again by the fragment reads: conflict-free ds_read_b128;
-//   * both operands double-buffered in LDS (2 x (48 KB + 30 KB)): ONE barrier per k-tile instead of two; the DMA of tile kt+1 and the
-//     register loads of tile kt+2 are in flight while tile kt is multiplied, retired by counted s_waitcnt vmcnt(N) (never 0 in the
-//     loop); every vector-memory operation of the loop is issued through asm, so the counts are exact by construction;
-//   * the workgroup loops over the 256-row tiles of the weight (T1: two, the mask conv: four), so the GroupNorm prologue, the
-//     statistics reduction and the launch are paid once per panel, and one tile's result stores drain under the next tile's loads.
-// LDS: 163,840 B (everything the CU has): 2 x 49,152 (A) + 2 x 30,720 (B) + 4,096 (GroupNorm coefficients); the epilogue's
-// staging tiles live in the second A stage.  One workgroup per CU, grid = panels (256 at the benchmark's size).
-#ifndef FQSS_T2_RES_PREFETCH
-#define FQSS_T2_RES_PREFETCH 0
-#endif
-// FQSS_T2_ABL (timing experiments only, tools/r04_abl.sh; default 0 = the product; results are garbage otherwise): bit 0 no MFMAs |
-// 1 no fragment reads | 2 no split / LDS store of the activations | 3 no weight DMA | 4 no activation loads | 5 no result stores
+//   * one workgroup owns ALL rows of a 256-row weight tile for a 128-column activation panel: the panel is read and split ONCE per
+//     256 output rows (k_tgemm: once per 128);
+//   * eight waves in three ROLES, one compute wave + one memory wave per SIMD (256 registers each):
+//       waves 0-3  compute: fragment reads + 48 MFMAs per 16-deep k-tile (wave tile 128 x 64, 8 independent accumulators), no
+//                  vector-memory instruction in the k-loop;
+//       waves 4-5  activations: fp32 panel -> registers (six tiles in flight: HBM latency) -> exact 3-way split -> LDS;
+//       waves 6-7  weights: the pre-split planes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) from
+//                  a TILED image (k_split3_tiles) whose 1-KB pieces are whole cache lines, swizzle baked in;
+//     each role has its own vmcnt counter (a wave's vector-memory operations retire in order: a wait for an L2-fed DMA behind HBM
+//     loads retires those too, and behind result stores it drains them), every counted operation is issued through asm;
+//   * a ring of FOUR LDS slots of one 16-deep k-tile each (A 24 KB + B 15 KB): in iteration i the compute waves read slot i & 3, tile
+//     i+1 is already published, tile i+2 is landing (waited for at the end of the iteration) and tile i+3 is being requested --
+//     with two slots a tile had to be requested, land and be published inside ONE iteration, and the DMA's issue + latency
+//     (~4,000 cycles) was longer than the 3,072 cycles of MFMAs it was supposed to hide behind; ONE barrier per k-tile;
+//   * the workgroup loops over the 256-row tiles of the weight (T1: two, the mask conv: four): the memory waves run ahead into the
+//     next row tile while the compute waves store the previous one's results.
+// LDS: 163,840 B (everything the CU has): 4 x (24,576 + 15,360) + 4,096 (GroupNorm coefficients | bias); the epilogue's staging
+// tiles live in slot 3 (the slot of the row tile's LAST k-tile).  One workgroup per CU, grid = panels (256 at the benchmark's size).
 #ifndef FQSS_T2_ABL
 #define FQSS_T2_ABL 0
 #endif
-constexpr int T2BM = 256, T2BN = 128;
-constexpr int T2_A_STAGE = 3 * T2BM * TBK * 2;            // 49,152: [plane][256 rows][32 k] bf16, 64-B rows, swizzled chunks
-constexpr int T2_B_STAGE = 3 * TBK * TLDN * 2;            // 30,720: [plane][32 k][128 + 32 pad] bf16 (the layout of k_tgemm)
-constexpr int T2_B_OFF = 2 * T2_A_STAGE;
-constexpr int T2_PCO_OFF = T2_B_OFF + 2 * T2_B_STAGE;     // 159,744
+// FQSS_T2_ABL (timing experiments only, tools/r04_abl.sh; default 0 = the product; results are garbage otherwise): bit 0 no MFMAs |
+// 1 no fragment reads | 2 no split / LDS store of the activations | 3 no weight DMA | 4 no activation loads | 5 no result stores
+constexpr int T2BM = 256, T2BN = 128, T2BK = 16;
+constexpr int T2_A_SLOT = 3 * T2BM * T2BK * 2;            // 24,576: [plane][256 rows][16 k] bf16, 32-B rows, swizzled chunks
+constexpr int T2_B_SLOT = 3 * T2BK * TLDN * 2;            // 15,360: [plane][16 k][128 + 32 pad] bf16 (the row layout of k_tgemm)
+constexpr int T2_B_OFF = 4 * T2_A_SLOT;                   // 98,304
+constexpr int T2_PCO_OFF = T2_B_OFF + 4 * T2_B_SLOT;      // 159,744
 constexpr int T2_SMEM = T2_PCO_OFF + 2 * 512 * 4;         // 163,840
-constexpr int T2_EPI_OFF = T2_A_STAGE;                    // epilogue staging (8 x 4,608 B) + red inside A stage 1
-static_assert(4 * 32 * TLDT * 4 + 2 * 8 * 8 <= T2_A_STAGE, "epilogue scratch fits one A stage");
+constexpr int T2_EPI_OFF = 3 * T2_A_SLOT;                 // epilogue staging (4 x 4,608 B) + red inside A slot 3
+static_assert(4 * 32 * TLDT * 4 + 2 * 8 * 8 <= T2_A_SLOT, "epilogue scratch fits one A slot");
 
-struct T2Stage {           // one k-tile of activations per thread: 8 consecutive columns of one k-row
-    f32x4t rb[2];
-};
-template <int N>
-__device__ __forceinline__ void t2_wait(T2Stage& st) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(st.rb[0]), "+v"(st.rb[1]) : "n"(N) : "memory");
-}
-// LDS-DMA of 16 B per lane: LDS destination = lds_dst (wave-uniform byte address, through M0) + 16 * lane; M0 is written in the
-// statement that reads it (the compiler reserves it and does not preserve it around asm)
-__device__ __forceinline__ void t2_dma16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-// LDS-DMA with a scalar base: source = sbase (wave-uniform, SGPR pair) + voff (per lane, bytes); the 12 pieces a wave moves per k-tile
-// are 1 KB apart, so they share ONE lane-offset register and differ in scalar adds only
-// 16-B load with a scalar base + a 32-bit lane offset: the loader's addresses for 16 k-tiles x 8 rows are scalar adds on ONE register
+// 16-B load with a scalar base + a 32-bit lane offset: the loader's addresses for 32 k-tiles x 4 rows are scalar adds on ONE register
 // (as 64-bit per-lane pointers the compiler precomputed and spilled them: a scratch reload in the counted stream ends in a vmcnt(0))
 __device__ __forceinline__ void t_load16s(f32x4t& d, const void* sbase, unsigned voff) {
     // s_nop 4: the compiler may have produced the scalar base by a VALU instruction (v_readlane of a spilled SGPR) right in front of
     // the statement; a vector-memory instruction that reads such an SGPR needs five wait states, and nothing pads the inside of an asm
-    // statement (without it: wrong tiles and one memory fault, profiles/r04_tgemm2_notes.txt)
+    // statement (without it: wrong tiles and one memory fault)
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
+// LDS-DMA of 16 B per lane with a scalar base: source = sbase (wave-uniform, SGPR pair) + voff (per lane, bytes), LDS destination =
+// lds_dst (wave-uniform byte address, through M0) + 16 * lane; M0 is written in the statement that reads it (the compiler reserves it
+// and does not preserve it around asm).  The pieces a wave moves are 1 KB apart: ONE lane-offset register, scalar adds.
 __device__ __forceinline__ void t2_dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -482,18 +469,39 @@ __device__ __forceinline__ void t2_unroll(F& f) {      // f(integral_constant<T>
     }
 }
 
+// every barrier of k_tgemm2 goes through T2_SYNC(<s_waitcnt in front of it, or "">).  FQSS_T2_STAMP (diagnostic builds, tools/t2_stamps.py):
+// workgroup 0 records, per wave and barrier, the cycle counter before the wait, before the barrier and behind it.
+#ifdef FQSS_T2_STAMP
+__device__ unsigned long long g_t2_stamp[8][160][3];
+#define T2_SYNC(W)                                                                                       \
+    do {                                                                                                 \
+        const bool st_on = blockIdx.x == 0 && lane == 0 && sidx < 160;                                   \
+        if (st_on) g_t2_stamp[wave][sidx][0] = __builtin_amdgcn_s_memtime();                             \
+        asm volatile(W ::: "memory");                                                                    \
+        if (st_on) g_t2_stamp[wave][sidx][1] = __builtin_amdgcn_s_memtime();                             \
+        asm volatile("s_barrier" ::: "memory");                                                          \
+        if (st_on) g_t2_stamp[wave][sidx][2] = __builtin_amdgcn_s_memtime();                             \
+        ++sidx;                                                                                          \
+    } while (0)
+#else
+#define T2_SYNC(W) asm volatile(W "\n\ts_barrier" ::: "memory")
+#endif
+
 template <int PRO>
 __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem2);
     float* pco = reinterpret_cast<float*>(smem2 + T2_PCO_OFF);                         // [2][512]
     double* red = reinterpret_cast<double*>(smem2 + T2_EPI_OFF + 4 * 32 * TLDT * 4);   // [2 * 8]
-    float* pms = reinterpret_cast<float*>(smem2);                                      // [2] (before the first tile lands)
+    float* pms = reinterpret_cast<float*>(red);                                        // [2] (slot 3: no tile lands there before barrier P)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int panel = blockIdx.x;
     const int b = panel / g.tiles_n, j0 = (panel % g.tiles_n) * T2BN;
+#ifdef FQSS_T2_STAMP
+    int sidx = 0;
+#endif
 
     if (PRO == 1) {
         t_stats_finalize(g.pro_stats + (int64_t)b * kTSlots * kTSlotStride, g.pro_count, g.pro_eps, pms);
@@ -505,69 +513,77 @@ __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
         }
     }
     // Without a GroupNorm prologue the coefficient table is free: the bias vector lives there (<= 1024 rows), so that the row tiles
-    // after the first start without a global load -- a load behind the previous tile's result stores would have to wait for them
-    // (vmcnt retires in order), which is exactly the overlap the row-tile loop is for.
+    // after the first start without a global load -- a load behind the previous tile's result stores would have to wait for them.
     const bool bias_in_lds = (PRO != 1) && g.M <= 1024;
     if (bias_in_lds)
         for (int i = tid; i < g.M; i += 512) pco[i] = g.bias != nullptr ? g.bias[i] : 0.0f;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // pms / pco written; nothing of the compiler's in flight
-    const int nkt = g.K / TBK;           // a multiple of 4 (host: K % 128 == 0)
+    T2_SYNC("s_waitcnt vmcnt(0) lgkmcnt(0)");   // pms / pco written; nothing of the compiler's in flight
+    const int nkt = g.K / T2BK;          // a multiple of 8 (host: K % 128 == 0)
     const int n_last = (g.N - 1) & ~3;
     float s1 = 0.0f, s2 = 0.0f;
     const bool want_stats = g.stats_out != nullptr;
 
+    // Barriers of one row tile, the same count in every role: P (tiles 0 and 1 published), one per iteration i = 0 .. nkt - 2 (tile i + 2
+    // published), L (behind the last tile's fragment reads: the staging tiles may be written).
     if (wave >= 6) {
         // =============================== weight waves (2): LDS-DMA of the weight tiles ==============================================
-        // 24 pieces of 1 KB per wave and k-tile, source and destination lane-linear (one lane-offset register, scalar adds), tile kt+1
-        // requested while the compute waves multiply tile kt, retired by vmcnt(0) in front of the barrier that publishes it.  Nothing
-        // else lives on this wave's counter: a wait for these DMAs behind activation loads (HBM, microseconds) would retire those
-        // too -- vmcnt retires in order -- and behind the compute waves' result stores it would drain them.
+        // 12 pieces of 1 KB per wave and k-tile, source and destination lane-linear.  In iteration i tile i + 3 is requested (its slot
+        // was read in iteration i - 1) and tile i + 2 -- requested one iteration earlier -- is waited for (the 12 younger requests
+        // stay in flight) in front of the barrier that publishes it.
         const int dw = wave - 6;
         const unsigned voff = lane * 16;
-        auto dma_tile = [&](int64_t tile, int stage) {        // tile = row tile * nkt + k-tile
+#ifdef FQSS_T2_MPRIO
+        __builtin_amdgcn_s_setprio(FQSS_T2_MPRIO);
+#endif
+        auto dma_tile = [&](int64_t tile) {                   // tile = row tile * nkt + k-tile -> slot k-tile & 3
             if (FQSS_T2_ABL & 8) return;
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(g.A) + tile * (3 * 8192 * 2) + dw * (24 * 1024);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(g.A) + tile * (3 * 4096 * 2) + dw * (12 * 1024);
+            const unsigned dst = lds_base + (unsigned)(tile & 3) * T2_A_SLOT + dw * (12 * 1024);      // nkt % 4 == 0: tile & 3 == k-tile & 3
 #pragma unroll
-            for (int j = 0; j < 24; ++j) t2_dma16s(src + j * 1024, voff, lds_base + stage * T2_A_STAGE + dw * (24 * 1024) + j * 1024);
+            for (int j = 0; j < 12; ++j) t2_dma16s(src + j * 1024, voff, dst + j * 1024);
         };
         for (int mt = 0; mt < g.tiles_m; ++mt) {
             const int64_t t0 = (int64_t)mt * nkt;
-            // tile 0 into stage 0: the compute waves may still be in the previous row tile's epilogue (staging tiles in A stage 1)
-            dma_tile(t0, 0);
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            for (int kt = 0; kt < nkt - 1; ++kt) {
-                dma_tile(t0 + kt + 1, (kt + 1) & 1);         // every wave left stage (kt + 1) & 1 at the previous barrier
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            // tiles 0 .. 2 into slots 0 .. 2: the compute waves may still be in the previous row tile's epilogue (staging in slot 3)
+            dma_tile(t0); dma_tile(t0 + 1); dma_tile(t0 + 2);
+            T2_SYNC("s_waitcnt vmcnt(12)");             // P: tiles 0, 1
+            for (int i = 0; i < nkt - 3; ++i) {
+                dma_tile(t0 + i + 3);
+                T2_SYNC("s_waitcnt vmcnt(12)");         // tile i + 2
             }
-            asm volatile("s_barrier" ::: "memory");         // the compute waves' barrier behind the last tile
+            T2_SYNC("s_waitcnt vmcnt(0)");              // i = nkt - 3: tile nkt - 1
+            T2_SYNC("");                                   // i = nkt - 2
+            T2_SYNC("");                                   // L
         }
     } else if (wave >= 4) {
         // =============================== activation waves (2): the fp32 panel -> three bf16 planes in LDS ===========================
-        // Per k-tile and wave: 8 x 16 B of activations per lane, the exact 3-way split of 32 values, 24 ds_write_b64.  The loads come
-        // from HBM (microseconds under load) and a tile is 16 KB per workgroup, so THREE tiles are kept in flight in a register ring
-        // (48 KB per CU; ablation profiles/r04_tgemm2_ablation.txt: with 1-2 tiles in flight the memory skeleton alone ran at 9 GB/s
-        // per CU).  These waves issue no other vector-memory operation.
+        // Per k-tile and wave: 4 x 16 B of activations per lane, the exact 3-way split of 16 values, 12 ds_write_b64.  The loads come
+        // from HBM (microseconds under load) and a tile is 8 KB per workgroup, so SIX tiles are kept in flight in a register ring
+        // (48 KB per CU; with one or two 16-KB tiles in flight the memory skeleton alone ran at 9 GB/s per CU).
         const int lt = tid - 256;
+#ifdef FQSS_T2_MPRIO
+        __builtin_amdgcn_s_setprio(FQSS_T2_MPRIO);
+#endif
         float pslope = (PRO == 2) ? *g.pro_slope : 0.0f;
         if (PRO == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pslope));
-        // thread -> k-rows (lt >> 5) + 4 q (q < 8), columns 4 (lt & 31) .. + 4: a wave instruction reads two whole 512-B row segments
+        // thread -> k-rows (lt >> 5) + 4 q (q < 4), columns 4 (lt & 31) .. + 4: a wave instruction reads two whole 512-B row segments
         // (clamped into the row: columns past N are never stored)
         const int bk_row = lt >> 5, bk_c = (lt & 31) * 4;
         const unsigned bvoff = (unsigned)((bk_row * (int)g.ldb + min(j0 + bk_c, n_last)) * 4);     // < 2^32: ld_x < 2^28 (host)
         const float* bbase = g.B + (int64_t)b * g.sBb;                                          // wave-uniform
-        const int64_t bstep = (int64_t)TBK * g.ldb, brow4 = 4 * g.ldb;
-        struct LStage { f32x4t rb[8]; };
+        const int64_t bstep = (int64_t)T2BK * g.ldb, brow4 = 4 * g.ldb;
+        struct LStage { f32x4t rb[4]; };
         auto load_b = [&](LStage& st, int t) {
             if (FQSS_T2_ABL & 16) return;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t_load16s(st.rb[q], bbase + t * bstep + q * brow4, bvoff);
+            for (int q = 0; q < 4; ++q) t_load16s(st.rb[q], bbase + t * bstep + q * brow4, bvoff);
         };
         auto store_b = [&](LStage& st, int t) {
             if (FQSS_T2_ABL & 4) return;
-            unsigned char* bs = smem2 + T2_B_OFF + (t & 1) * T2_B_STAGE + (bk_row * TLDN + bk_c) * 2;
+            unsigned char* bs = smem2 + T2_B_OFF + (t & 3) * T2_B_SLOT + (bk_row * TLDN + bk_c) * 2;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int kc = t * TBK + bk_row + 4 * q;
+            for (int q = 0; q < 4; ++q) {
+                const int kc = t * T2BK + bk_row + 4 * q;
                 const float p_a = (PRO == 1) ? pco[kc] : 1.f, p_b = (PRO == 1) ? pco[512 + kc] : 0.f;
                 float h0[4], r1[4], r2[4];
 #pragma unroll
@@ -587,96 +603,100 @@ __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
                 o3.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
                 o3.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
                 *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2) = o1;
-                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2 + TBK * TLDN * 2) = o2;
-                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2 + 2 * TBK * TLDN * 2) = o3;
-                __builtin_amdgcn_sched_barrier(0);       // one row at a time: interleaved, the eight rows' temporaries do not fit beside the ring
+                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2 + T2BK * TLDN * 2) = o2;
+                *reinterpret_cast<uint2*>(bs + q * 4 * TLDN * 2 + 2 * T2BK * TLDN * 2) = o3;
             }
         };
-        // One step = tile T: wait for it (the requests of the up to two younger tiles stay in flight), split it into LDS stage T & 1,
-        // re-arm its registers with tile T + 3, publish (the compute waves arrive when they are done reading stage (T - 1) & 1, the
-        // weight waves when the DMA of tile T has landed).  The whole k-loop is STRAIGHT-LINE code, generated per k-tile count: a
-        // register that an asm load is still filling must never meet a control-flow merge -- the copy the register allocator may
-        // place there reads it before the data has landed (a run-time loop / branch around these steps returned wrong tiles for K = 128).
+        // One step = tile T: wait for it (the requests of the up to five younger tiles stay in flight), split it into LDS slot T & 3,
+        // re-arm its registers with tile T + 6.  The whole k-loop is STRAIGHT-LINE code, generated per k-tile count: a register that an
+        // asm load is still filling must never meet a control-flow merge -- the copy the register allocator may place there reads it
+        // before the data has landed (a run-time loop / branch around these steps returned wrong tiles for K = 128).
         auto row_tile = [&](auto NKT) {
             constexpr int nk = decltype(NKT)::value;
-            LStage R0, R1, R2;            // tile t travels in R[t % 3]; the prologue only touches B stage 0
-            load_b(R0, 0); load_b(R1, 1); load_b(R2, 2);
-            auto step = [&](auto T) {
+            LStage R0, R1, R2, R3, R4, R5;       // tile t travels in R[t % 6]
+            load_b(R0, 0); load_b(R1, 1); load_b(R2, 2); load_b(R3, 3); load_b(R4, 4); load_b(R5, 5);
+            auto put = [&](auto T) {
                 constexpr int t = decltype(T)::value;
-                constexpr int younger = (nk - 1 - t) < 2 ? (nk - 1 - t) : 2;
-                LStage& st = (t % 3) == 0 ? R0 : (t % 3) == 1 ? R1 : R2;
-                asm volatile("s_waitcnt vmcnt(%8)"
-                             : "+v"(st.rb[0]), "+v"(st.rb[1]), "+v"(st.rb[2]), "+v"(st.rb[3]), "+v"(st.rb[4]), "+v"(st.rb[5]), "+v"(st.rb[6]), "+v"(st.rb[7])
-                             : "n"(8 * younger)
-                             : "memory");
+                constexpr int younger = (nk - 1 - t) < 5 ? (nk - 1 - t) : 5;
+                LStage& st = (t % 6) == 0 ? R0 : (t % 6) == 1 ? R1 : (t % 6) == 2 ? R2 : (t % 6) == 3 ? R3 : (t % 6) == 4 ? R4 : R5;
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(st.rb[0]), "+v"(st.rb[1]), "+v"(st.rb[2]), "+v"(st.rb[3]) : "n"(4 * younger) : "memory");
                 store_b(st, t);
-                if (t + 3 <= nk - 1) load_b(st, t + 3);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t + 6 <= nk - 1) load_b(st, t + 6);
             };
-            t2_unroll<0, nk>(step);
-            asm volatile("s_barrier" ::: "memory");                        // the compute waves' barrier behind the last tile
+            // tiles 0 and 1 into slots 0 and 1 (the compute waves may still be in the previous row tile's epilogue: staging in slot 3)
+            put(std::integral_constant<int, 0>{});
+            put(std::integral_constant<int, 1>{});
+            T2_SYNC("s_waitcnt lgkmcnt(0)");            // P
+            auto step = [&](auto I) {                          // iteration i: tile i + 2 into slot (i + 2) & 3, read last in iteration i - 2
+                constexpr int i = decltype(I)::value;
+                if constexpr (i + 2 <= nk - 1) put(std::integral_constant<int, i + 2>{});
+                T2_SYNC("s_waitcnt lgkmcnt(0)");
+            };
+            t2_unroll<0, nk - 1>(step);                        // iterations 0 .. nkt - 2
+            T2_SYNC("");           // L
         };
         for (int mt = 0; mt < g.tiles_m; ++mt) {
-            if (nkt == 4) row_tile(std::integral_constant<int, 4>{});
-            else if (nkt == 8) row_tile(std::integral_constant<int, 8>{});
-            else if (nkt == 12) row_tile(std::integral_constant<int, 12>{});
-            else row_tile(std::integral_constant<int, 16>{});
+            if (nkt == 8) row_tile(std::integral_constant<int, 8>{});
+            else if (nkt == 16) row_tile(std::integral_constant<int, 16>{});
+            else if (nkt == 24) row_tile(std::integral_constant<int, 24>{});
+            else row_tile(std::integral_constant<int, 32>{});
         }
     } else {
         // =============================== compute waves (4 = 2 x 2, wave tile 128 x 64): fragment reads and MFMAs ====================
-        // One compute wave and one memory wave per SIMD (two waves per SIMD: 256 registers each).  96 MFMAs per k-tile and wave: the
-        // matrix pipe of a SIMD is fed by ONE wave, back to back (8 independent accumulators), with no vector-memory instruction in
-        // its k-loop; the memory wave's instructions issue in the MFMAs' shadow.
         const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
         const int gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
         const float nscale = (g.act == FQSS_ACT_PRELU) ? *g.slope : (g.act == FQSS_ACT_RELU ? 0.0f : 1.0f);
         const bool has_bias = g.bias != nullptr;
+#ifdef FQSS_T2_PRIO
+        __builtin_amdgcn_s_setprio(FQSS_T2_PRIO);
+#endif
         f32x16 acc[4][2];
-        auto compute_tile = [&](int stage) {
-            const unsigned char* as = smem2 + stage * T2_A_STAGE;
-            typedef unsigned short (*BsT)[TBK][TLDN];
-            BsT Bs = reinterpret_cast<BsT>(smem2 + T2_B_OFF + stage * T2_B_STAGE);
+        // fragments of one k-tile: the three planes of the wave's 64 columns (B, 6 fragments) and of 64 of its 128 rows (A, 6 fragments
+        // per half): 24 MFMAs per half.  12 + 6 fragments of the NEXT tile are requested before the barrier that ends the current one
+        // (that tile was published one barrier earlier), so their LDS latency and the barrier overlap (cycle stamps, profiles/
+        // r04_t2_stamps_t3.txt: read-after-barrier cost 620 of 2,160 cycles per tile).
+        auto rd_b = [&](bf16x8 (&bfr)[3][2], int slot) {
+            typedef unsigned short (*BsT)[T2BK][TLDN];
+            BsT Bs = reinterpret_cast<BsT>(smem2 + T2_B_OFF + slot * T2_B_SLOT);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // the three planes of the wave's 64 columns, once per 16-deep k-step; the rows in two halves of 64 (24 MFMAs each), so
-                // that 12 fragments are live at a time instead of 18 (128 accumulator registers leave room for one set in flight)
-                bf16x8 bfr[3][2];
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const int kr = ks * 16 + 8 * (gq >> 1) + tq;
-                        const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
-                        union { bf16x8 v; s16x4 h[2]; } u;
-                        if (FQSS_T2_ABL & 2) { bfr[p][ni] = bf16x8{}; asm volatile("" : "+v"(bfr[p][ni])); continue; }
-                        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
-                        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
-                        bfr[p][ni] = u.v;
-                    }
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh) {
-                    bf16x8 af[3][2];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-#pragma unroll
-                        for (int mi = 0; mi < 2; ++mi) {
-                            const int row = wm * 128 + (2 * mh + mi) * 32 + lr;
-                            if (FQSS_T2_ABL & 2) { af[p][mi] = bf16x8{}; asm volatile("" : "+v"(af[p][mi])); continue; }
-                            af[p][mi] = *reinterpret_cast<const bf16x8*>(as + p * (T2BM * TBK * 2) + row * 64 + (((2 * ks + lh) ^ ((row >> 2) & 3)) << 4));
-                        }
-                    constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};     // the six products, smallest pieces first (k_tgemm)
-#pragma unroll
-                    for (int sp = 0; sp < 6; ++sp)
-#pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < 2; ++ni)
-                                if (!(FQSS_T2_ABL & 1))
-                                    acc[2 * mh + mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[2 * mh + mi][ni], 0, 0, 0);
-                                else asm volatile("" : "+v"(acc[2 * mh + mi][ni]) : "v"(af[IA[sp]][mi]), "v"(bfr[IB[sp]][ni]));
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int kr = 8 * (gq >> 1) + tq;
+                    const int nc = wn * 64 + ni * 32 + 16 * (gq & 1) + 4 * tp;
+                    union { bf16x8 v; s16x4 h[2]; } u;
+                    if (FQSS_T2_ABL & 2) { bfr[p][ni] = bf16x8{}; asm volatile("" : "+v"(bfr[p][ni])); continue; }
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                    bfr[p][ni] = u.v;
                 }
-            }
         };
+        auto rd_a = [&](bf16x8 (&af)[3][2], int slot, int mh) {
+            const unsigned char* as = smem2 + slot * T2_A_SLOT;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int row = wm * 128 + (2 * mh + mi) * 32 + lr;
+                    if (FQSS_T2_ABL & 2) { af[p][mi] = bf16x8{}; asm volatile("" : "+v"(af[p][mi])); continue; }
+                    af[p][mi] = *reinterpret_cast<const bf16x8*>(as + p * (T2BM * T2BK * 2) + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4));
+                }
+        };
+        auto mm = [&](bf16x8 (&af)[3][2], bf16x8 (&bfr)[3][2], auto MH) {
+            constexpr int mh = decltype(MH)::value;
+            constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};     // the six products, smallest pieces first (k_tgemm)
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (!(FQSS_T2_ABL & 1))
+                            acc[2 * mh + mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[IA[sp]][mi], bfr[IB[sp]][ni], acc[2 * mh + mi][ni], 0, 0, 0);
+                        else asm volatile("" : "+v"(acc[2 * mh + mi][ni]) : "v"(af[IA[sp]][mi]), "v"(bfr[IB[sp]][ni]));
+        };
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
         float(*Tt)[TLDT] = reinterpret_cast<float(*)[TLDT]>(smem2 + T2_EPI_OFF + wave * 32 * TLDT * 4);
 
         for (int mt = 0; mt < g.tiles_m; ++mt) {
@@ -701,16 +721,32 @@ __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
                     }
                 }
             }
-            // the loaders' prologue barrier: weight tile 0 and activation tile 0 are in stage 0.  No vmcnt wait here: this wave's result
-            // stores of the previous row tile stay in flight under the next tile's MFMAs.
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            for (int kt = 0; kt < nkt - 1; ++kt) {
-                compute_tile(kt & 1);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // done reading stage kt & 1; tile kt+1 is published
+            // P: tiles 0 and 1 are published.  No vmcnt wait here: this wave's result stores of the previous row tile stay in flight
+            // under the next tile's MFMAs.
+            T2_SYNC("s_waitcnt lgkmcnt(0)");
+            bf16x8 bA[3][2], bB[3][2], a0[3][2], a1[3][2];
+            rd_b(bA, 0);
+            rd_a(a0, 0, 0);
+            for (int i = 0; i < nkt; i += 2) {
+                // tile i (slot i & 3; B in bA, the first 64 rows in a0); the barrier behind it publishes tile i + 2.  No lgkmcnt wait in
+                // front of it: every read of slot i & 3 has been consumed by an issued MFMA, the reads in flight target slot (i + 1) & 3.
+                rd_a(a1, i & 3, 1);
+                mm(a0, bA, H0{});
+                mm(a1, bA, H1{});
+                rd_b(bB, (i + 1) & 3);
+                rd_a(a0, (i + 1) & 3, 0);
+                T2_SYNC("");
+                // tile i + 1 (B in bB); behind the row tile's last k-tile the barrier is L: every wave is done reading slot 3 before the
+                // staging tiles (which live there) are written
+                rd_a(a1, (i + 1) & 3, 1);
+                mm(a0, bB, H0{});
+                mm(a1, bB, H1{});
+                if (i + 2 < nkt) {
+                    rd_b(bA, (i + 2) & 3);
+                    rd_a(a0, (i + 2) & 3, 0);
+                }
+                T2_SYNC("s_waitcnt lgkmcnt(0)");
             }
-            compute_tile(1);
-            // every wave is done reading A stage 1 before the staging tiles (which live there) are written
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
             // ---- the epilogue's per-lane addresses hang off `el`, a copy of the lane id the optimiser cannot see through: otherwise it
             // hoists ~60 registers of loop-invariant store / residual addresses above the k-loop
@@ -773,9 +809,9 @@ __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
         }
     }
     if (want_stats) {
-        // (red lives in A stage 1 next to the staging tiles: a barrier separates the last wave's staging reads from it; the loader
+        // (red lives in A slot 3 next to the staging tiles: a barrier separates the last wave's staging reads from it; the memory
         // waves contribute zeros)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        T2_SYNC("s_waitcnt lgkmcnt(0)");
         double v[2] = {(double)s1, (double)s2};
         block_sum<double, 2>(v, red);
         if (tid == 0) {
@@ -992,12 +1028,18 @@ static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, cons
 #undef TG_REQUIRE
 }
 
+#ifdef FQSS_T2_STAMP
+extern "C" int fqss_debug_t2_stamps(unsigned long long* out) {      // host buffer [8][160][3]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_t2_stamp), sizeof(unsigned long long) * 8 * 160 * 3) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int fqss_tgemm_tiled_ok(int Ci, int Co, int M1) {
     return Co > 0 && Co % T2BM == 0 && Ci % (4 * TBK) == 0 && Ci >= 4 * TBK && Ci <= 512 && M1 > 0 && M1 % 32 == 0;
 }
 
 extern "C" int fqss_split3_tiles(const float* w, uint16_t* tiles, int Co, int Ci, fqss_stream_t stream) {
-    FQSS_REQUIRE(w && tiles && Co > 0 && Co % T2BM == 0 && Ci > 0 && Ci % TBK == 0 && aligned16(tiles), "whole 256 x 32 tiles only");
+    FQSS_REQUIRE(w && tiles && Co > 0 && Co % T2BM == 0 && Ci > 0 && Ci % T2BK == 0 && aligned16(tiles), "whole 256 x 16 tiles only");
     int64_t nb = cdiv((int64_t)Co * Ci, 256);
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_split3_tiles, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, tiles, Co, Ci);

@@ -374,8 +374,8 @@ int fqss_tgemm(const uint16_t* planes, const float* x, int B, int Ci, int Co, in
                int M1, float* c1, const float* r1, int64_t ld_c1, float* c2, const float* r2,
                int64_t ld_c2, fqss_stream_t stream);
 /* The same GEMM on a TILED weight image (round 4, k_tgemm2): fqss_split3_tiles lays the three bf16 planes out as
- * [Co/256][Ci/32][3][256][32] (one k-tile of one 256-row tile = 48 KB contiguous, 16-B chunks of a row XOR-swizzled by
- * (row >> 2) & 3) so that the kernel moves them global -> LDS by LDS-DMA in whole cache lines.  Needs fqss_tgemm_tiled_ok(Ci, Co,
+ * [Co/256][Ci/16][3][256][16] (one k-tile of one 256-row tile = 24 KB contiguous, the two 16-B chunks of a row swapped where
+ * (row >> 3) & 1) so that the kernel moves them global -> LDS by LDS-DMA in whole cache lines.  Needs fqss_tgemm_tiled_ok(Ci, Co,
  * M1) (Co % 256 == 0, Ci % 128 == 0, Ci <= 512, M1 % 32 == 0); every other argument as fqss_tgemm.  The accumulation starts
  * at the bias (fqss_tgemm adds it last): the two forms agree to fp32 rounding, not bit for bit. */
 int fqss_tgemm_tiled_ok(int Ci, int Co, int M1);
