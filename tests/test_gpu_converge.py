@@ -88,3 +88,96 @@ def test_tiny_dptnet_trains_to_the_reference_sisdr(golden):
     tl_ref = ref_loss[:, -50:].mean(1)
     assert abs(float(loss[-50:].mean()) - float(tl_ref.mean())) <= max(0.1, float(tl_ref.max() - tl_ref.min())), (float(loss[-50:].mean()), tl_ref)
     assert tail - float(sisdr[:10].mean()) >= 8.0
+
+
+def _tail_gate(name, sisdr, loss, gl, first_n, gain_db):
+    """shared tail rules of the gates below: finite, observer-phase trajectory within max(0.1 dB, 3 x the reference's own spread), tail
+    means (last 50 steps) of SI-SDR and loss within max(0.1 dB, the reference's spread between its CPU configurations)"""
+    ref, ref_loss = gl["sisdr"], gl["loss"]
+    assert np.isfinite(sisdr).all() and np.isfinite(loss).all()
+    early = slice(0, 50)
+    spread_early = float(np.abs(ref[:, early] - ref[:, early].mean(0)).max())
+    dev_early = float(np.abs(sisdr[early] - ref[:, early].mean(0)).max())
+    assert dev_early <= max(0.1, 3 * spread_early), (dev_early, spread_early)
+    tail_ref = ref[:, -50:].mean(1)
+    spread = float(tail_ref.max() - tail_ref.min())
+    tail = float(sisdr[-50:].mean())
+    tl_ref = ref_loss[:, -50:].mean(1)
+    print(f"{name}: tail SI-SDR {tail:.3f} dB vs reference {tail_ref} (spread {spread:.3f}); loss tail {float(loss[-50:].mean()):.4f} vs {tl_ref}; "
+          f"observer-phase deviation {dev_early:.4f} (reference spread {spread_early:.4f})")
+    assert abs(tail - float(tail_ref.mean())) <= max(0.1, spread), (tail, tail_ref, spread)
+    assert abs(float(loss[-50:].mean()) - float(tl_ref.mean())) <= max(0.1, float(tl_ref.max() - tl_ref.min())), (float(loss[-50:].mean()), tl_ref)
+    if gain_db is not None:
+        assert tail - float(sisdr[:first_n].mean()) >= gain_db
+
+
+def test_full_size_convtasnet_trains_to_the_reference_sisdr(golden):
+    """G3-ii at the REAL model size (VERDICT r03 missing #2; north_star "SI-SDR within 0.1 dB of the reference"): the FULL 5.1 M-parameter
+    ConvTasNetQ from the name-keyed cfg1_fill weights (tests/helpers_cfg1.py), cfg-1 shape (B = 2, T = 8000), 300 steps of a stream of
+    never-repeating batches -- tests/golden/cfg1_train_long.npz is the imported reference's own trajectory under three CPU
+    configurations (tools/make_goldens_long.py cfg1; its spread over the last 50 steps: 0.37 dB).  The HIP step runs as bench.py runs
+    it: fused codes-only dataflow, batched tables, hipGraph replay from step 52, the teacher one batch ahead on its own stream (the
+    256-row teacher GEMM of round 4 included)."""
+    from fqss_amd.runtime import KDTrainStep
+    from fqss_amd.smoke import build_pair
+    from tests.helpers_cfg1 import cfg1_fill
+    gl = golden("cfg1_train_long")
+    n, B, T, seed0 = int(gl["n_steps"]), int(gl["batch"]), int(gl["samples"]), int(gl["seed0"])
+    model, fmodel = build_pair("cuda", 0, n_spks=2, kernel_size=16, stride=8)
+    cfg1_fill(fmodel, "T.")
+    cfg1_fill(model, "S.")
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, teacher_ahead=True)
+    sisdr, loss = _run_stream(step, n, B, T, seed0)
+    assert step._graphs is not None, "the quantizing phase must have run as hipGraph replays"
+    np.testing.assert_allclose(loss[:2], gl["loss"][0, :2], rtol=5e-5)
+    # the reference goes -10 dB -> +0.8 dB in the observer phase and settles around -4 dB once every quantizer is live
+    _tail_gate("full-size convtasnet", sisdr, loss, gl, 10, 4.0)
+
+
+def test_tiny_sepformer_trains_to_the_reference_sisdr(golden):
+    """the same gate for the Sepformer family (cfg 4) under the speechbrain env's PER-SAMPLE objective (speechbrain_librimix_trainer.py:
+    99-115; at the shipped per-GPU batch of 1 it is term for term the asteroid objective the reference fixture was generated with):
+    tiny SepformerQ of sep_tiny_step.npz, 200 steps of a stream of 1 x 800-sample batches, Adam 1.5e-4, clip 5"""
+    from fqss_amd.runtime import KDTrainStep
+    from tests.test_gpu_sepformer import _tiny_pair
+    g0, gl = golden("sep_tiny_step"), golden("sep_train_long")
+    n, B, T, seed0 = int(gl["n_steps"]), int(gl["batch"]), int(gl["samples"]), int(gl["seed0"])
+    model, fmodel = _tiny_pair(g0)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1.5e-4, clip=5.0, loss="sisdr_pit_per_sample", teacher_ahead=True)
+    sisdr, loss = _run_stream(step, n, B, T, seed0)
+    assert step._graphs is not None
+    _tail_gate("tiny sepformer", sisdr, loss, gl, 10, 6.0)
+
+
+def test_tiny_htdemucs_trains_to_the_reference_loss(golden):
+    """... and for HTDemucs (cfg 5) under the solver's objective (solver.py:333-366: L1 task + SDR-weighted L1 distillation, Adam 3e-4,
+    NO clipping): tiny HTDemucsQ of hd_tiny_step.npz over 150 steps of a stream of stereo two-stem mixtures (fqss_amd.data.synth_stems).
+    The reference's three CPU configurations agree to 1e-6 here (the L1 objective is far less chaotic than SI-SDR in dB), so the
+    rule "within max(0.1 dB, the reference's spread)" is applied to the loss as an amplitude ratio: 0.1 dB = 1.16 %."""
+    from fqss_amd.data import synth_stems
+    from fqss_amd.runtime import KDTrainStep
+    from tests.test_gpu_htdemucs import _models
+    g0, gl = golden("hd_tiny_step"), golden("hd_train_long")
+    n, B, T, seed0 = int(gl["n_steps"]), int(gl["batch"]), int(gl["samples"]), int(gl["seed0"])
+    model, fmodel = _models(g0)
+    step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=3e-4, clip=0.0, loss="l1_sdr", teacher_ahead=True)
+    out = []
+    nxt = synth_stems(B, 2, 2, T, seed0, "cuda")
+    for i in range(n):
+        mix, src = nxt
+        nxt = synth_stems(B, 2, 2, T, seed0 + i + 1, "cuda")
+        step.maybe_capture(mix, src)
+        r = step(mix, src, x_next=nxt[0])
+        out.append(r["loss"].reshape(()).clone())
+    torch.cuda.synchronize()
+    loss = torch.stack(out).cpu().numpy()
+    assert step._graphs is not None and np.isfinite(loss).all()
+    ref = gl["loss"]
+    db = lambda a, b: 20.0 * abs(np.log10(a / b))
+    # observer phase (steps 1-50: float arithmetic up to the weight grids): step for step
+    worst = max(db(float(loss[i]), float(ref[:, i].mean())) for i in range(50))
+    tail, tail_ref = float(loss[-50:].mean()), float(ref[:, -50:].mean())
+    print(f"tiny htdemucs: loss tail {tail:.6f} vs reference {ref[:, -50:].mean(1)} ({db(tail, tail_ref):.4f} dB); worst observer-phase step {worst:.4f} dB")
+    assert worst <= 0.1, worst
+    assert db(tail, tail_ref) <= 0.1, (tail, tail_ref)
+    assert tail < float(loss[:10].mean())                     # it trains: 0.0777 -> 0.0731 in the reference

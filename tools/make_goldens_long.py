@@ -9,7 +9,7 @@ and the reference's OWN spread between those runs over the last 50 steps -- the 
     python tools/make_goldens_long.py dptnet     -> dpt_train_long.npz
 Round 4: the same gate at the REAL model size and for the two remaining families --
     python tools/make_goldens_long.py cfg1       -> cfg1_train_long.npz   FULL-SIZE ConvTasNetQ (5.1 M parameters, cfg1_fill weights),
-                                                    B = 2, T = 8000, 300 steps, three CPU configurations
+                                                    B = 2, T = 8000, 300 steps, six CPU configurations
     python tools/make_goldens_long.py sepformer  -> sep_train_long.npz    tiny SepformerQ of sep_tiny_step.npz, B = 1 (the speechbrain
                                                     env's per-sample objective == the asteroid objective at B = 1), Adam 1.5e-4, clip 5
     python tools/make_goldens_long.py htdemucs   -> hd_train_long.npz     tiny HTDemucsQ of hd_tiny_step.npz, solver.py:333-366 l1 + SDR-weighted
@@ -125,7 +125,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dptnet":      # reduced length: the reference's LSTM / attention layers are slow on the CPU
         main("dptnet", 160, 2, 400, "dpt_train_long.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg1":      # ~1 s per reference step on 8 cores: three configurations, 300 steps each
-        main("cfg1", 300, 2, 8000, "cfg1_train_long.npz", variants=[(8, True), (8, False), (4, True)])
+        main("cfg1", 300, 2, 8000, "cfg1_train_long.npz", variants=[(8, True), (8, False), (4, True), (2, True), (6, True), (4, False)])
     elif len(sys.argv) > 1 and sys.argv[1] == "sepformer":
         main("sepformer", 200, 1, 800, "sep_train_long.npz", variants=[(8, True), (1, True), (4, False)])
     elif len(sys.argv) > 1 and sys.argv[1] == "htdemucs":
