@@ -1019,6 +1019,46 @@ def adam_clip(p, g, m, v, sumsq_acc, step_t, gnorm_out, max_norm, grad_scale, lr
               _stream())
 
 
+# ------------------------------------------------------------------ BatchNorm under BatchNormQ (csrc/batchnorm.hip)
+def bn_moments(x):
+    """[B, C, M] -> fp64 [C, 2]: (sum, sum of squares) per channel"""
+    _need_gpu(x)
+    x, B, C, M, ld = _bcm(x)
+    out = torch.zeros(C, 2, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_bn_moments", _p(x), _p(out), B, C, M, ld, _stream())
+    return out
+
+
+def bn_apply(x, a, b):
+    """y = x * a[c] + b[c]"""
+    _need_gpu(x, a, b)
+    x, B, C, M, ld = _bcm(x)
+    y = empty_act((B, C, M), x.device)
+    _lib.call("fqss_bn_apply", _p(x), _p(a.contiguous()), _p(b.contiguous()), _p(y), B, C, M, ld, rowmat(y)[2], _stream())
+    return y
+
+
+def bn_bwd_reduce(g, x):
+    """-> fp64 [C, 2]: (sum g, sum g x) per channel"""
+    _need_gpu(g, x)
+    x, B, C, M, ld_x = _bcm(x)
+    g, _, _, _, ld_g = _bcm(g)
+    out = torch.zeros(C, 2, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_bn_bwd_reduce", _p(g), _p(x), _p(out), B, C, M, ld_g, ld_x, _stream())
+    return out
+
+
+def bn_bwd_apply(g, x, c1, c2, c3):
+    """gx = g * c1[c] + x * c2[c] + c3[c]"""
+    _need_gpu(g, x, c1, c2, c3)
+    x, B, C, M, ld_x = _bcm(x)
+    g, _, _, _, ld_g = _bcm(g)
+    gx = empty_act((B, C, M), x.device)
+    _lib.call("fqss_bn_bwd_apply", _p(g), _p(x), _p(c1.contiguous()), _p(c2.contiguous()), _p(c3.contiguous()), _p(gx), B, C, M, ld_g, ld_x,
+              rowmat(gx)[2], _stream())
+    return gx
+
+
 # ------------------------------------------------------------------ fused float-teacher chain (csrc/teacher.hip)
 def split3_planes(w2d):
     """fp32 [Co, Ci] -> three exact bf16 planes [3, Co, Ci] (uint16 storage)"""

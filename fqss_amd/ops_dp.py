@@ -951,3 +951,53 @@ class ScalarMul(Function):
     @staticmethod
     def backward(ctx, g):
         return K.axpby(g, g, 0.0, sa=ctx.c), None
+
+
+class BatchNormFn(Function):
+    """nn.BatchNorm1d / nn.BatchNorm2d on a channel-first [B, C, M] view (csrc/batchnorm.hip); the reference runs the ATen op inside
+    BatchNormQ (qat_layers.py:472-486).  Training mode: batch statistics (biased variance for the normalisation, unbiased for the
+    running estimate, momentum as nn.BatchNorm does it); eval mode: the running statistics.  The C-sized arithmetic is torch on
+    C-element tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, training):
+        B, C, M = x.shape
+        n = B * M
+        dev = x.device
+        if training or bn.running_mean is None:
+            mom = K.bn_moments(x)
+            mean = mom[:, 0] / n
+            var = (mom[:, 1] / n - mean * mean).clamp_(min=0.0)             # biased
+            if training and bn.track_running_stats and bn.running_mean is not None:
+                with torch.no_grad():
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked += 1
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1.0 - m).add_(mean.float(), alpha=m)
+                    bn.running_var.mul_(1.0 - m).add_((var * (n / max(n - 1, 1))).float(), alpha=m)
+        else:
+            mean, var = bn.running_mean.double(), bn.running_var.double()
+        invstd = 1.0 / torch.sqrt(var + bn.eps)
+        w = weight.double() if weight is not None else torch.ones(C, device=dev, dtype=torch.float64)
+        b = bias.double() if bias is not None else torch.zeros(C, device=dev, dtype=torch.float64)
+        a = invstd * w
+        y = K.bn_apply(x, a.float(), (b - mean * a).float())
+        ctx.save_for_backward(x, mean, invstd, w)
+        ctx.batch_stats, ctx.n, ctx.has_w, ctx.has_b = bool(training or bn.running_mean is None), n, weight is not None, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, invstd, w = ctx.saved_tensors
+        n = ctx.n
+        red = K.bn_bwd_reduce(g, x)
+        sg, sgx = red[:, 0], red[:, 1]
+        ggamma = invstd * (sgx - mean * sg)                 # sum g xhat
+        c1 = w * invstd
+        if ctx.batch_stats:
+            c2 = -c1 * invstd * ggamma / n
+            c3 = c1 * (-sg / n + mean * invstd * ggamma / n)
+        else:
+            c2, c3 = torch.zeros_like(c1), torch.zeros_like(c1)
+        gx = K.bn_bwd_apply(g, x, c1.float(), c2.float(), c3.float())
+        return gx, (ggamma.float() if ctx.has_w else None), (sg.float() if ctx.has_b else None), None, None

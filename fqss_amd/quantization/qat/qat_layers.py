@@ -8,9 +8,9 @@ GroupNormQ (:438-452), NlQ (:511-518), Conv1dEncoderQ (:993-1046), ResidualError
 ConvTr1dDecoderQ (:1305-1361); and, for the dual-path models (DPTNet): LayerNormQ (:455-465),
 LinearQ (:521-536), LSTMQ (:571-600), MultiheadAttentionQ (:865-950), Conv2dQ (1x1), LinearDecoderQ (:1256-1296) with the
 nn.Linear branch of ResidualErrorBlock (:1178-1187), over the kernels of csrc/dualpath.hip, attn.hip, lstm.hip.
-The classes only reachable from the Sepformer / HTDemucs configs (LinearNlQ, Conv2dNlQ, ConvTranspose*Q, EmbeddingQ,
-BatchNormQ, Conv1dGnNlQ, ConvTr2dDecoderQ, ...) are later rows of SURVEY.md §8 and raise NotImplementedError until their
-kernels exist -- there is no ATen fallback.
+The Sepformer / HTDemucs classes (LinearNlQ, Conv2dNlQ, ConvTranspose*Q, Conv1dGnNlQ, ConvTr2dDecoderQ, ...) and BatchNormQ follow
+further down on the kernels of csrc/conv_frames.hip, hd_ops.hip, batchnorm.hip; variants of these layers that no FQSS configuration takes
+ raise NotImplementedError at construction -- there is no ATen fallback.
 """
 import math
 import os
@@ -1288,4 +1288,25 @@ class ConvTr2dDecoderQ(LayerQ):
         return torch.stack(outs)
 
 
-BatchNormQ = _later_row("BatchNormQ", "a15")
+class BatchNormQ(LayerQ):
+    """y = fq_act(batchnorm(x))  (qat_layers.py:472-486 of the reference; quantize_modules maps nn.BatchNorm1d / nn.BatchNorm2d here,
+    qat_utils.py:163, 381-382).  None of the shipped configurations builds one; csrc/batchnorm.hip + ops_dp.BatchNormFn."""
+
+    def __init__(self, batchnorm, gradient_based=True, act_quant=True, act_n_bits=8):
+        super().__init__(gradient_based=gradient_based, act_quant=act_quant, act_n_bits=act_n_bits)
+        if not isinstance(batchnorm, nn.BatchNorm1d) and not isinstance(batchnorm, nn.BatchNorm2d):
+            raise Exception(f'Quantizing wrong layer instead of BatchNorm got:{type(batchnorm)}')
+        self.batchnorm = batchnorm
+
+    def forward(self, x):
+        bn = self.batchnorm
+        x = ops.real(x)
+        shp = x.shape
+        if x.dim() == 2:                                   # BatchNorm1d on [B, C]
+            x3 = x.reshape(shp[0], shp[1], 1)
+        elif x.dim() == 4:                                 # BatchNorm2d on [B, C, H, W]
+            x3 = x.reshape(shp[0], shp[1], shp[2] * shp[3])
+        else:
+            x3 = x
+        y = ops_dp.BatchNormFn.apply(x3, bn.weight, bn.bias, bn, bn.training)
+        return fq_node(self.activation_fake_quantize, y.reshape(shp) if y.shape != shp else y)

@@ -391,6 +391,22 @@ int fqss_tdw(const float* x, const double* stats_in, const float* gamma, const f
 int fqss_tstats(const float* x, int B, int C, int M, int64_t ld, double* ws, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * BatchNorm1d / BatchNorm2d under BatchNormQ (csrc/batchnorm.hip) on channel-first [B][C][M] tensors (M = H*W for the 2-D form).
+ * replaces: nn.BatchNorm1d/2d inside BatchNormQ (qat_layers.py:472-486; qat_utils.py:163, 381-382) + autograd
+ *   fqss_bn_moments:    out[c] += (sum x, sum x^2) over (b, m), fp64 [C][2], caller zeroes       (batch statistics, training mode)
+ *   fqss_bn_apply:      y = x * a[c] + b[c]
+ *   fqss_bn_bwd_reduce: out[c] += (sum g, sum g x), fp64 [C][2], caller zeroes
+ *   fqss_bn_bwd_apply:  gx = g * c1[c] + x * c2[c] + c3[c]
+ * ------------------------------------------------------------------------------------------- */
+int fqss_bn_moments(const float* x, double* out, int B, int C, int M, int64_t ld_x, fqss_stream_t stream);
+int fqss_bn_apply(const float* x, const float* a, const float* b, float* y, int B, int C, int M, int64_t ld_x,
+                  int64_t ld_y, fqss_stream_t stream);
+int fqss_bn_bwd_reduce(const float* g, const float* x, double* out, int B, int C, int M, int64_t ld_g, int64_t ld_x,
+                       fqss_stream_t stream);
+int fqss_bn_bwd_apply(const float* g, const float* x, const float* c1, const float* c2, const float* c3, float* gx,
+                      int B, int C, int M, int64_t ld_g, int64_t ld_x, int64_t ld_gx, fqss_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K8/K9/K14  element-wise producers
  * replaces: torch.add / torch.sub / torch.mul in AddQ, ResidualErrorBlock, MulQ
  *           (qat_layers.py:69-71, 1193, 93-96), postprocess (process.py:44-47)

@@ -70,17 +70,54 @@ def main():
             fam = scenario.split(":")[1] if ":" in scenario else "convtasnet"
             model, fmodel, x, tgt, kw, nb = family(fam)
             xr, tr = shard(x, tgt, rank, world)
-            step = KDTrainStep(model, fmodel, comm=comm, buckets=nb, **kw)
+            # "step_graph_ahead": bench.py's schedule at world > 1: the teacher's forward of the NEXT batch as its own hipGraph
+            # on the teacher stream beside the bucketed step (the next batch is the same shard here, so the 1-rank reference still applies)
+            ahead = scenario.startswith("step_graph_ahead")
+            step = KDTrainStep(model, fmodel, comm=comm, buckets=nb, teacher_ahead=ahead, **kw)
             assert step.segments is not None and 2 <= len(step.segments) <= nb, (step.segments, nb)     # (tiny nets have fewer cut points)
-            losses = [step(xr, tr)["loss"].item()]
+            nxt = dict(x_next=xr) if ahead else {}
+            losses = [step(xr, tr, **nxt)["loss"].item()]
+            # the gradient every rank holds behind step 1's exchange (SUM over the ranks; 1/world is folded into clip + Adam), from
+            # identical state: the tight check of the exchange itself, before any update has made the comparison chaotic
+            res["g1"] = {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters() if v.grad is not None}
             if scenario.startswith("step_graph"):
                 step.capture(xr, tr, warmup=0)
                 assert len(step._graphs[0]) == len(step.segments)
             for _ in range(2):
-                losses.append(step(xr, tr)["loss"].item())
+                losses.append(step(xr, tr, **nxt)["loss"].item())
             res["losses"] = losses
             res["params"] = {k: v.detach().cpu() for k, v in model.named_parameters()}
             res["gnorm"] = step.arena.gnorm.item()
+            res["bucket_bytes"] = [4 * (hi - lo) for lo, hi in step.segments]
+        elif scenario == "bench2":
+            # bench.py --gpus 2 on the FULL-SIZE cfg-2 model: the same calls in the same order -- calibration, one
+            # eager quantizing step, capture into one hipGraph per gradient bucket, replays with the teacher one batch ahead over two
+            # alternating batches -- so that the first real RCCL run has only the transport left to prove
+            from fqss_amd.data import synth_batch
+            from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
+            from fqss_amd.smoke import build_pair
+            dev = torch.device("cuda", 0)
+            model, fmodel = build_pair(dev, 0, n_spks=2, kernel_size=16, stride=8)
+            Bq, Tq = 8, 32000
+            x, tgt = synth_batch(Bq, Tq, seed=100 + rank, device=dev)
+            x2, tgt2 = synth_batch(Bq, Tq, seed=200 + rank, device=dev)
+            X, TG = (x, x2), (tgt, tgt2)
+            step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=comm, teacher_ahead=True)
+            step(x, tgt)
+            with torch.no_grad():
+                for _ in range(49):
+                    model(x)
+            assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
+            step(x, tgt)
+            step.capture(x, tgt)
+            res["n_graphs"] = len(step._graphs[0])
+            losses, it = [], 0
+            for _ in range(3):
+                r = step(X[it & 1], TG[it & 1], x_next=X[(it + 1) & 1])
+                losses.append(r["loss"].item())
+                it += 1
+            res["losses"] = losses
+            res["flat_p"] = step.arena.flat_p.detach().cpu().clone()
             res["bucket_bytes"] = [4 * (hi - lo) for lo, hi in step.segments]
         else:
             # observer phase on per-rank data, then the one-time synchronisation of the observed activation ranges -- or, with

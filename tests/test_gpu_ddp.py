@@ -24,7 +24,7 @@ def _run_ranks(tmp_path, scenario, world=2):
     logs = []
     for p in ps:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=600)
         except subprocess.TimeoutExpired:
             for q in ps:
                 q.kill()
@@ -34,7 +34,8 @@ def _run_ranks(tmp_path, scenario, world=2):
     return [torch.load(o, weights_only=False) for o in outs]
 
 
-@pytest.mark.parametrize("scenario", ["step_eager", "step_graph", "step_graph:dptnet", "step_graph:sepformer", "step_graph:htdemucs"])
+@pytest.mark.parametrize("scenario", ["step_eager", "step_graph", "step_graph_ahead", "step_graph:dptnet", "step_graph:sepformer", "step_graph:htdemucs",
+                                      "step_graph_ahead:sepformer"])
 def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(tmp_path, scenario):
     """ConvTasNet (2 buckets, eager and replay) and the DDP configurations themselves -- cfg 4 `speechbrain_librimix_trainer.py:592`,
     cfg 5 `htdemucs_musdbhq/distrib.py:51-59` (find_unused_parameters=True), cfg 3 for the dual-path LSTM family: 3-4 gradient
@@ -51,14 +52,30 @@ def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(tmp_path, 
     # clip + Adam -- 1/world enters as the gradient scale exactly as it does on the ranks
     ref = KDTrainStep(model, fmodel, **kw)
     losses = [[], []]
+    g1 = None
     with ops.poison_carriers(True):
-        for _ in range(3):
+        for it in range(3):
             gsum = torch.zeros_like(ref.arena.flat_g)
             for r, (xs, ts) in enumerate(shards):
                 losses[r].append(ref._fwd_bwd(xs, ts)["loss"].item())
                 gsum += ref.arena.flat_g
+            if it == 0:      # (the arenas are laid out in bucket order on the ranks: compared per parameter, through the .grad views)
+                ref.arena.flat_g.copy_(gsum)
+                g1 = {k: v.grad.detach().cpu().clone() for k, v in model.named_parameters() if v.grad is not None}
             ref.arena.flat_g.copy_(gsum)
             ref.arena.clip_adam_step(ref.lr, ref.clip, grad_scale=0.5)
+    # TIGHT: step 1 starts from identical state, so the gradient every rank holds behind the bucketed exchange must be the
+    # sum of the per-shard gradients of the one-rank run element for element -- a mis-scaled or missing bucket cannot hide in Adam's
+    # +-lr steps here.  Whole-vector error and the worst element, relative to the gradient's largest entry.
+    gn = float(torch.sqrt(sum((v.double() ** 2).sum() for v in g1.values())))
+    for r in range(2):
+        assert set(ranks[r]["g1"]) == set(g1)
+        err = float(torch.sqrt(sum(((ranks[r]["g1"][k] - v).double() ** 2).sum() for k, v in g1.items())))
+        assert err <= 1e-4 * gn, (r, err, gn)
+        for k, v in g1.items():      # every tensor: its own norm, plus a floor at the whole gradient's noise level for the near-zero ones
+            dk = float((ranks[r]["g1"][k] - v).norm())
+            assert dk <= 1e-3 * float(v.norm()) + 2e-6 * gn, (r, k, dk, float(v.norm()))
+    assert all(torch.equal(ranks[0]["g1"][k], ranks[1]["g1"][k]) for k in g1)
     want = {k: v.detach().cpu() for k, v in model.named_parameters()}
     print(scenario, "gradient buckets (bytes):", ranks[0]["bucket_bytes"], "losses", ranks[0]["losses"], losses[0])
     assert 2 <= len(ranks[0]["bucket_bytes"]) <= nb
@@ -132,3 +149,15 @@ def test_observer_ranges_are_synchronised_once_over_the_ranks(tmp_path):
             np.testing.assert_allclose(ranks[r]["after"][k].numpy(), mean.numpy(), rtol=1e-6, atol=1e-7)
         assert torch.equal(ranks[0]["after"][k], ranks[1]["after"][k]), k
     assert diff > 20          # the per-rank observations did differ (tiny model: 52 range tensors)
+
+
+def test_full_size_cfg2_two_ranks_replay_like_bench(tmp_path):
+    """`bench.py --gpus 2` on the FULL-SIZE cfg-2 model (8 x 4 s per rank), two ranks on this one GPU over gloo: calibration, capture into one
+    hipGraph per gradient bucket, three replays with the teacher one batch ahead over alternating batches.  The replicas must stay
+    bit-identical (every rank applies the same reduced gradient) and the loss finite: what is left for the first run on a real node is
+    the RCCL transport."""
+    ranks = _run_ranks(tmp_path, "bench2")
+    assert ranks[0]["n_graphs"] == ranks[1]["n_graphs"] >= 2
+    assert torch.equal(ranks[0]["flat_p"], ranks[1]["flat_p"])
+    assert all(np.isfinite(l) for r in ranks for l in r["losses"])
+    print("bench2: buckets (bytes)", ranks[0]["bucket_bytes"], "losses", ranks[0]["losses"], ranks[1]["losses"])
