@@ -44,6 +44,11 @@ static inline dim3 grid_rows(int64_t rows, int64_t cols, int vec, int64_t max_bl
 constexpr int kXcds = 8;
 static inline unsigned xcd_grid(int64_t groups, int64_t per_group) { return (unsigned)(cdiv(groups, kXcds) * kXcds * per_group); }
 
+// the data-gradient q-GEMM on the LDS ring (csrc/qgemm_ring.hip), dispatched from csrc/qgemm.hip where its shape rules hold
+bool qdgrad_ring_ok(int Ci, int Co1, int Co2);
+int qdgrad_ring(const char* who, const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, const float* addend, float* gx, int B,
+                int Ci, int Co1, int Co2, int M, int64_t ld_gz1, int64_t ld_gz2, int64_t ld_add, int64_t ld_gx, fqss_stream_t stream);
+
 // ---------------------------------------------------------------- device side
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool xcd_tile(int groups, int per_group, int& group, int& idx) {

@@ -1,9 +1,11 @@
-"""Single-GPU anatomy of the data-parallel step's schedule (no exchange): for cfg 2 / cfg 4 / cfg 5 the gradient buckets (bytes per
-backward segment), the duration of every segment's hipGraph, and -- what decides how much of the exchange is exposed -- the compute
-time that still runs AFTER a bucket is ready (the remaining segments), against the time a ring all-reduce of that bucket needs on
-xGMI (2 (N-1)/N x bytes over ~7 x 153 GB/s of per-link bandwidth, one direction; MI355X_MICROARCH.md / the task statement).  Also the
-cost of cutting the backward into segments at all (1 graph vs n graphs).
-    python tools/bench_buckets.py [cfg2] [cfg4] [cfg5]"""
+"""Single-GPU anatomy of the data-parallel step's schedule (no exchange): for cfg 2 / 3 / 4 / 5 AT THEIR bench.py BATCH the gradient buckets
+(bytes per backward segment), the duration of every segment's hipGraph, and -- what decides how much of the exchange is exposed -- the
+compute time that still runs AFTER a bucket is ready (the remaining segments), against a MODEL of a ring all-reduce of that bucket over
+8 ranks on xGMI: LATENCY + bandwidth, t = 2 (N-1) alpha + 2 (N-1)/N x bytes / 153 GB/s with alpha = 5 us per ring step (2 (N-1) = 14 steps:
+70 us per all-reduce; the floor VERDICT r03 asked for was 30 us) -- one link's 153 GB/s per direction (MI355X_MICROARCH.md / the task
+statement).  The model has never been checked against RCCL on a node (no multi-GPU box on this pool).  Also the cost of cutting the
+backward into segments at all (1 graph vs n graphs).
+    python tools/bench_buckets.py [cfg2] [cfg3] [cfg4] [cfg5]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,11 +13,12 @@ from tools.stress_step import build
 from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
 from fqss_amd.runtime import KDTrainStep
 
-XGMI_RING_GBS = 7 * 153.0 / 7        # a ring all-reduce moves every byte over ONE link per hop: 153 GB/s per direction
+XGMI_RING_GBS = 153.0                # a ring all-reduce moves every byte over ONE link per hop: 153 GB/s per direction
+RING_ALPHA_US, N_RANKS = 5.0, 8      # per ring step (launch + hop latency): 2 (N - 1) steps per all-reduce
 
 
 def make(which, nb):
-    step, x, tgt = build(which, torch.device("cuda", 0))
+    step, x, tgt = build(which, torch.device("cuda", 0), hd_batch=4, hd_seconds=10.0)      # bench.py's shapes
     kw = dict(loss="l1_sdr", clip=0.0) if which == "cfg5" else {}
     s = KDTrainStep(step.model, step.fmodel, lr=1e-4, buckets=nb, **kw)
     s(x, tgt)
@@ -61,13 +64,14 @@ def main(workloads):
                     lo, hi = segs[nseg - 1 - k]
                     mb = (hi - lo) * 4 / 1e6
                     after = sum(seg_ms[k + 1:])
-                    ring8 = 2 * 7 / 8 * mb / 1e3 / 153.0 * 1e3     # ms: 2 (N-1)/N x bytes at one link's 153 GB/s (N = 8)
+                    lat = 2 * (N_RANKS - 1) * RING_ALPHA_US * 1e-3                              # ms
+                    ring8 = lat + 2 * (N_RANKS - 1) / N_RANKS * mb / 1e3 / XGMI_RING_GBS * 1e3  # ms
                     print(f"   bucket {k} (ready after {'fwd + loss + ' if k == 0 else ''}segment {k}: {seg_ms[k]:.2f} ms): {mb:7.2f} MB, "
-                          f"ring all-reduce at 8 ranks ~{ring8:.3f} ms, backward still to run behind it {after:.2f} ms "
-                          f"-> exposed ~{max(0.0, ring8 - after):.3f} ms", flush=True)
+                          f"ring all-reduce at 8 ranks ~{ring8:.3f} ms ({lat:.3f} latency + bandwidth), backward still to run behind it "
+                          f"{after:.2f} ms -> exposed ~{max(0.0, ring8 - after):.3f} ms", flush=True)
             del s
             torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["cfg2", "cfg4", "cfg5"])
+    main(sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"])

@@ -10,7 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def build(which, dev):
+def build(which, dev, hd_batch=2, hd_seconds=4.0):
+    """hd_batch / hd_seconds: the cfg-5 shape (the stress gates use 2 x 4 s; bench.py's is 4 x 10 s: tools/bench_buckets.py passes it)"""
     from fqss_amd import runtime as R
     from fqss_amd.data import synth_batch
     if which == "cfg2":
@@ -32,8 +33,8 @@ def build(which, dev):
     from fqss_amd.quantization.qat.models.htdemucsq import HTDemucsQ
     from fqss_amd.quantization.qat.models.load_model import quantize_model
     torch.manual_seed(0)
-    B, T = 2, 44100 * 4
-    model = HTDemucsQ(sources=["drums", "bass", "other", "vocals"], bottom_channels=512, segment=4.0)
+    B, T = hd_batch, int(round(44100 * hd_seconds))
+    model = HTDemucsQ(sources=["drums", "bass", "other", "vocals"], bottom_channels=512, segment=hd_seconds)
     fmodel = copy.deepcopy(model).to(dev).eval()
     qcfg = dict(qat=True, gradient_based=True, weight_quant=True, weight_n_bits=8, act_quant=True, act_n_bits=8, in_quant=False,
                 in_act_n_bits=8, out_quant=True, out_act_n_bits=8, n_splitter=2, n_combiner=2, observer=True)

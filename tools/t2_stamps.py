@@ -14,18 +14,21 @@ from fqss_amd import roofline_cases as RC
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "t3"
-    key = "k_tgemm<1>" if which == "t3" else "k_tgemm<0>"
-    case = [c for c in RC.build(torch.device("cuda", 0)) if c["kernel"] == key][0]
+    # t3 / t1: the teacher GEMMs (libfqss built with -DFQSS_T2_STAMP); dx / dx2: the student's dgrad 128->512 / res|skip pair on the
+    # ring (csrc/qgemm_ring.hip built with -DFQSS_R_STAMP)
+    key, nth, sym = {"t3": ("k_tgemm<1>", 0, "fqss_debug_t2_stamps"), "t1": ("k_tgemm<0>", 0, "fqss_debug_t2_stamps"),
+                     "dx": ("k_qgemm<1>", 0, "fqss_debug_r_stamps"), "dx2": ("k_qgemm<1>", 1, "fqss_debug_r_stamps")}[which]
+    case = [c for c in RC.build(torch.device("cuda", 0)) if c["kernel"] == key][nth]
     for i in range(6):
         case["fn"](i)
     torch.cuda.synchronize()
     buf = np.zeros((8, 160, 3), dtype=np.uint64)
-    rc = _lib.load().fqss_debug_t2_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+    rc = getattr(_lib.load(), sym)(buf.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
     t = buf.astype(np.int64)
     nb = int((t[0, :, 2] > 0).sum())
     t0 = t[:, 0, 0].min()
-    role = ["C0", "C1", "C2", "C3", "A4", "A5", "W6", "W7"]
+    role = ["C0", "C1", "C2", "C3", "A4", "A5", "W6", "W7"]      # compute x 4, activation / gradient x 2, weight x 2
     print(f"{which}: {nb} barriers; columns per wave: work-done / wait-done relative to the barrier's release (cycles, negative = earlier)")
     print("bar  release(+cyc)  period | " + "  ".join(f"{r:>13s}" for r in role))
     prev = None
