@@ -65,6 +65,7 @@ _PROTOS = {
     "fqss_tgemm_tiled": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],
     "fqss_tgemm_tiled_ok": [I32, I32, I32],
     "fqss_split3_tiles": [P, P, I32, I32, P],
+    "fqss_gndwq_fwd": [P, P, P, P, P, F32, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P],
     "fqss_bn_moments": [P, P, I32, I32, I32, I64, P],
     "fqss_bn_apply": [P, P, P, P, I32, I32, I32, I64, I64, P],
     "fqss_bn_bwd_reduce": [P, P, P, I32, I32, I32, I64, I64, P],

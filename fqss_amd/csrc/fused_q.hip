@@ -524,6 +524,111 @@ __global__ __launch_bounds__(256) void k_dwq_fwd(const uint8_t* __restrict__ xc,
     }
 }
 
+// gLN + fake-quant FOLLOWED BY depthwise conv + PReLU + fake-quant, both on codes, as ONE launch (round 4; the teacher's k_tdw does the
+// same in float): a workgroup takes `rpw` consecutive rows; per row it normalises + re-quantises the 16 input codes of every thread
+// (k_gnq_apply's arithmetic, codes written to HBM -- the backward of both layers reads them -- AND to an LDS row), then runs the
+// 3-tap FIR + PReLU + quantizer of k_dwq_fwd<3> out of that LDS row.  One launch and one 4-KB re-read per row less; every value is
+// computed by the op sequences of the two kernels it replaces (gate: tests/test_gpu_kernels.py::test_gn_dw_fused_bit_identical).
+// Rows of at most 4096 positions (256 threads x 16), K = 3, statistics of the INPUT codes supplied by their producer.
+__global__ __launch_bounds__(256) void k_gndwq_fwd(const uint8_t* __restrict__ xc, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    uint8_t* __restrict__ y1, float* __restrict__ mean_rstd, const long long* __restrict__ ws,
+                                                    int nslots, float eps, int B, int C, int M, int64_t ld_xc, int64_t ld_y1,
+                                                    const float* qmin_x, const float* qmax_x, const float* qmin1, const float* qmax1,
+                                                    const float* __restrict__ w, const float* __restrict__ bias, int dil, int pad, int act,
+                                                    const float* slope_p, uint8_t* __restrict__ y2, int64_t ld_y2, const float* qmin2,
+                                                    const float* qmax2, long long* stats2, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf[];      // [padl + 4096 + pad + 16]
+    __shared__ long long red[2 * 4];
+    __shared__ float mr[2];
+    __shared__ unsigned int sred[2 * 4];
+    const QRange rx = load_qrange(qmin_x, qmax_x), r1 = load_qrange(qmin1, qmax1), r2 = load_qrange(qmin2, qmax2);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    const int rows = B * C, padl = (pad + 15) & ~15;
+    const int m0 = threadIdx.x * 16;
+    int b_have = -1;
+    for (int r0 = blockIdx.x * rpw; r0 < rows; r0 += gridDim.x * rpw)
+    for (int row = r0; row < min(rows, r0 + rpw); ++row) {
+        const int b = row / C, c = row - b * C;
+        uint4 v0 = make_uint4(0, 0, 0, 0);
+        if (m0 < M) v0 = *reinterpret_cast<const uint4*>(xc + (int64_t)row * ld_xc + m0);
+        if (b != b_have) {    // block-uniform
+            gnq_sample_stats(ws, nslots, b, (int64_t)C * M, eps, rx, red, mr);
+            b_have = b;
+            if (c == 0 && threadIdx.x == 0) {   // saved for the GroupNorm's backward
+                mean_rstd[2 * b] = mr[0];
+                mean_rstd[2 * b + 1] = mr[1];
+            }
+        }
+        const float scale = mr[1] * gamma[c];
+        const float shift = fmaf(-scale, mr[0], beta[c]);
+        if (m0 < M) {        // ---- GroupNorm + quantizer: k_gnq_apply's arithmetic
+            const unsigned int wv[4] = {v0.x, v0.y, v0.z, v0.w};
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float xv[4];
+                dec4(wv[q], rx, xv);
+                unsigned int pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk = pack_code(fq_code(fmaf(xv[e], scale, shift), r1), e, pk);
+                o[q] = pk;
+            }
+            const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(y1 + (int64_t)row * ld_y1 + m0) = ov;
+            *reinterpret_cast<uint4*>(rowbuf + padl + m0) = ov;
+        }
+        __syncthreads();
+        // ---- depthwise 3-tap FIR + PReLU + quantizer: k_dwq_fwd<3>'s arithmetic, taps from the LDS row
+        float wk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wk[k] = w[c * 3 + k];
+        const float bv = bias ? bias[c] : 0.0f;
+        unsigned int st_s = 0, st_ss = 0;
+        if (m0 < M) {
+            const bool inner = (m0 - pad >= 0) && (m0 + 15 + pad < M);
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 4 * q;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int s0 = m + k * dil - pad;
+                    float v[4];
+                    if (inner) {
+                        const int a = padl + s0;                               // >= 0: inner
+                        const unsigned int lo = *reinterpret_cast<const unsigned int*>(rowbuf + (a & ~3));
+                        const unsigned int hi = *reinterpret_cast<const unsigned int*>(rowbuf + (a & ~3) + 4);
+                        dec4(__builtin_amdgcn_alignbyte(hi, lo, (unsigned)(a & 3)), r1, v);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? dec((unsigned int)rowbuf[padl + s0 + j], r1) : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+                }
+                unsigned int pk = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk = pack_code(fq_code(act_apply(acc[j] + bv, act, slope), r2), j, pk);
+                o[q] = pk;
+                const unsigned int live = (m + 3 < M) ? 0xFFFFFFFFu : ((m < M) ? (0xFFFFFFFFu >> (8 * (4 - (M - m)))) : 0u);
+                code_stats4(pk & live, st_s, st_ss);
+            }
+            *reinterpret_cast<uint4*>(y2 + (int64_t)row * ld_y2 + m0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (stats2 != nullptr) {   // one slot per row; block_sum's barriers also protect the LDS row against the next row's stores
+            unsigned int v[2] = {st_s, st_ss};
+            block_sum<unsigned int, 2>(v, sred);
+            if (threadIdx.x == 0) {
+                stats2[2 * (int64_t)row] = (long long)v[0];
+                stats2[2 * (int64_t)row + 1] = (long long)v[1];
+            }
+        } else {
+            __syncthreads();
+        }
+    }
+}
+
 // backward: recompute z, STE + PReLU -> gz (fp32), bias row-sums, range/slope partials (gacc slots)
 template <int NQ>   // float4 groups per thread and pass: a workgroup covers NQ * 1024 consecutive positions
 __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ xc, const float* __restrict__ w,
@@ -1318,6 +1423,30 @@ extern "C" int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const floa
     GnProducer P{pz, ld_pz, pact, pslope, qmin_x, qmax_x, pgacc, pgbias};
     return gnq_bwd_impl("fqss_gnq_bwd_p", xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, gz, ggamma, gbeta, B, C, M, ld_xc, ld_g,
                         ld_gz, qmin, qmax, gacc, ws, P, stream);
+}
+
+/* GroupNormQ followed by a depthwise Conv1dNlQ, both in their quantizing phase, codes -> codes -> codes in one launch (k_gndwq_fwd):
+ * y1 = the GroupNorm's output codes (range 1), y2 = the depthwise layer's (range 2); stats = the producer's statistics of xc ([B][nslots][2]),
+ * stats2 (nullable) = [B][C][2] statistics of y2 for a GroupNormQ behind it.  M <= 4096, K = 3; bit-identical to fqss_gnq_fwd + fqss_dwq_fwd. */
+extern "C" int fqss_gndwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma, const float* beta, float eps,
+                              const int64_t* stats, int nslots, float* mean_rstd, uint8_t* y1, const float* qmin1, const float* qmax1,
+                              const float* w, const float* bias, int dil, int pad, int act, const float* slope, uint8_t* y2,
+                              const float* qmin2, const float* qmax2, int64_t* stats2, int B, int C, int M, int64_t ld_xc, int64_t ld_y1,
+                              int64_t ld_y2, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && gamma && beta && stats && mean_rstd && y1 && qmin1 && qmax1 && w && y2 && qmin2 && qmax2, "null pointer");
+    FQSS_REQUIRE(B > 0 && C > 0 && M > 0 && M <= 4096 && dil > 0 && pad == dil && pad <= 2048, "rows of at most 4096 positions, 3 taps");
+    FQSS_REQUIRE(nslots > 0 && nslots <= 1024, "supplied statistics: 1 .. 1024 partial-sum slots per sample");
+    FQSS_REQUIRE(ld_xc >= M && ld_y1 >= M && ld_y2 >= M && codes_ok(xc, ld_xc) && codes_ok(y1, ld_y1) && codes_ok(y2, ld_y2), "code rows must be 16-B aligned");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    const int64_t rows = (int64_t)B * C;
+    FQSS_REQUIRE(rows < (1ll << 30), "tensor too large");
+    const int rpw = rows >= 2048 ? 4 : 1;
+    const size_t smem = (size_t)(((pad + 15) & ~15) + 4096 + pad + 16);
+    hipLaunchKernelGGL(k_gndwq_fwd, dim3((unsigned)cdiv(rows, rpw)), dim3(256), smem, (hipStream_t)stream, xc, gamma, beta, y1, mean_rstd,
+                       (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_y1, qmin_x, qmax_x, qmin1, qmax1, w, bias, dil, pad, act, slope, y2,
+                       ld_y2, qmin2, qmax2, (long long*)stats2, rpw);
+    return launch_status("fqss_gndwq_fwd");
 }
 
 extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,

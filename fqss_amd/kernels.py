@@ -556,6 +556,36 @@ def gnq_fwd(xc, qmin_x, qmax_x, gamma, beta, eps, qmin, qmax, write_out, stats=N
     return out, yc, mean_rstd
 
 
+def gnq_fwd_deferred(xc):
+    """the buffers fqss_gnq_fwd would fill -- (carrier, codes, mean_rstd) -- WITHOUT the launch: the depthwise layer behind the GroupNormQ
+    runs both layers as one kernel (gndwq_fwd) and fills them; anything else that reads them first must launch gnq_fwd_into"""
+    B, C, M, _ = _codes3(xc)
+    return (empty_act((B, C, M), xc.device), empty_codes((B, C, M), xc.device),
+            torch.empty(B, 2, device=xc.device, dtype=torch.float32))
+
+
+def gnq_fwd_into(xc, qmin_x, qmax_x, gamma, beta, eps, qmin, qmax, stats, yc, mean_rstd):
+    """fqss_gnq_fwd into buffers allocated by gnq_fwd_deferred (codes only: the carrier stays a carrier)"""
+    B, C, M, ld_xc = _codes3(xc)
+    _lib.call("fqss_gnq_fwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(gamma), _p(beta), _p(yc), None, _p(mean_rstd), B, C, M, ld_xc,
+              rowmat(yc)[2], 0, float(eps), _p(qmin), _p(qmax), None, _p(stats.ws), stats.nslots, _stream())
+
+
+def gndwq_fwd(d, w, bias, dil, pad, act, slope, qmin2, qmax2, want_stats2):
+    """GroupNormQ (deferred record d of ops.GroupNormActQ) + depthwise Conv1dNlQ in ONE launch -> (carrier, codes, CodeStats or None) of
+    the depthwise layer; fills the GroupNorm's codes and mean / rstd on the way"""
+    xc = d["xc"]
+    B, C, M, ld_xc = _codes3(xc)
+    y2 = empty_codes((B, C, M), xc.device)
+    out2 = empty_act((B, C, M), xc.device)
+    st2 = CodeStats(torch.empty(B * C * 2, device=xc.device, dtype=torch.int64), C) if want_stats2 and C <= 1024 else None
+    _lib.call("fqss_gndwq_fwd", _p(xc), _p(d["qmin_x"]), _p(d["qmax_x"]), _p(d["gamma"]), _p(d["beta"]), float(d["eps"]), _p(d["stats"].ws),
+              d["stats"].nslots, _p(d["mean_rstd"]), _p(d["yc"]), _p(d["qmin"]), _p(d["qmax"]), _p(w), _p(bias), dil, pad, act, _p(slope),
+              _p(y2), _p(qmin2), _p(qmax2), _p(st2.ws) if st2 is not None else None, B, C, M, ld_xc, rowmat(d["yc"])[2], rowmat(y2)[2],
+              _stream())
+    return out2, y2, st2
+
+
 def _aligned_grad(g):
     g, _, _, ld = as_rowmat(g)
     if ld % 4 != 0 or g.data_ptr() % 16 != 0:

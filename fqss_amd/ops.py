@@ -21,7 +21,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
@@ -31,6 +31,7 @@ class QCtx:
         self.prod = None        # _Producer: lets the NEXT layer's backward run this layer's epilogue backward (see below)
         self.no_codes = False   # the caller has no coded consumer (dual-path row layers): do not emit the u8 codes at all
         self.stats = None       # kernels.CodeStats of the output codes, emitted by the producing kernel for a GroupNormQ consumer
+        self.defer = None       # GroupNormQ in front of a depthwise layer: its launch record, run by that layer's kernel (GroupNormActQ)
 
 
 class ActCodes:
@@ -55,6 +56,8 @@ def tag_codes(y, q):
             y._fqss_prod, q.prod = q.prod, None
         if q.stats is not None:
             y._fqss_stats, q.stats = q.stats, None
+        if q.defer is not None:
+            y._fqss_defer, q.defer = q.defer, None
     return y
 
 
@@ -73,6 +76,22 @@ FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
 FUSE_STATS = os.environ.get("FQSS_FUSE_STATS", "1") != "0"   # gLN statistics from the epilogue of the kernel that makes its input codes
 NEXT_IS_GROUPNORM = False   # set by HipSequential around the forward of a module followed by a GroupNormQ
+NEXT_IS_DW3 = False         # ... around the forward of a GroupNormQ followed by a 3-tap depthwise Conv1dNlQ (one launch for both: FUSE_GN_DW)
+# OPT-IN (FQSS_FUSE_GN_DW=1), measured and NOT the default: the one-launch form is bit-identical (tests/test_gpu_kernels.py::
+# test_gn_dw_fused_bit_identical) and SLOWER -- 39.5 us against 34.5 us for fqss_gnq_fwd + fqss_dwq_fwd at the cfg-2 shape (tools/
+# gndw_probe.py), the cfg-2 step unchanged (15.17 vs 15.16 ms on one box): both passes are bound by vector-ALU issue, so a fusion saves
+# the launch and a 16-MB re-read but not the instructions, and the LDS row (two barriers per row, two aligned reads + a byte-align per
+# four codes instead of one unaligned global load) adds some.  VERDICT r03 item 1(d) asked for this fusion.
+FUSE_GN_DW = __import__("os").environ.get("FQSS_FUSE_GN_DW", "0") != "0"
+
+
+def flush_defer(x):
+    """a GroupNormQ output whose launch was left to a depthwise consumer that cannot take it after all: launch it now"""
+    d = getattr(x, "_fqss_defer", None)
+    if d is not None and not d["done"]:
+        K.gnq_fwd_into(d["xc"], d["qmin_x"], d["qmax_x"], d["gamma"], d["beta"], d["eps"], d["qmin"], d["qmax"], d["stats"], d["yc"], d["mean_rstd"])
+        d["done"] = True
+
 NEXT_TAKES_PRODUCER = False  # set by HipSequential around its last module when the sequence's output has ONE consumer, a coded MulQ
 FUSE_MULQ_PROD = os.environ.get("FQSS_FUSE_MULQ_PROD", "1") != "0"
 
@@ -187,6 +206,7 @@ class Materialize(Function):
 def real(x):
     """the fp32 values of x (decodes a carrier; no-op for ordinary tensors)"""
     if torch.is_tensor(x) and is_carrier(x):
+        flush_defer(x)
         xq = codes_of(x)
         y = Materialize.apply(x, xq)
         y._fqss_q, y._fqss_carrier = xq, False
@@ -225,7 +245,7 @@ class cut_recorder:
         CUTS = self.prev
 
 
-_TAGS = ("_fqss_q", "_fqss_carrier", "_fqss_prod", "_fqss_stats", "_fqss_rowq")
+_TAGS = ("_fqss_q", "_fqss_carrier", "_fqss_prod", "_fqss_stats", "_fqss_rowq", "_fqss_defer")
 
 
 def cut(*tensors, late=False):
@@ -578,8 +598,14 @@ class GroupNormActQ(Function):
         ctx.prod = getattr(x, "_fqss_prod", None) if ctx.coded else None
         if ctx.coded:
             q.carrier = FAST and not q.keep_out
-            out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier,
-                                              stats=getattr(x, "_fqss_stats", None))
+            st = getattr(x, "_fqss_stats", None)
+            if FUSE_GN_DW and NEXT_IS_DW3 and q.carrier and st is not None and x.shape[-1] <= 4096:
+                # the 3-tap depthwise layer behind this GroupNorm runs both as ONE kernel (fqss_gndwq_fwd): buffers now, launch there
+                out, q.idx, mean_rstd = K.gnq_fwd_deferred(xq.idx)
+                q.defer = dict(xc=xq.idx, qmin_x=xq.qmin, qmax_x=xq.qmax, gamma=gamma, beta=beta, eps=eps, qmin=qmin, qmax=qmax, stats=st,
+                               yc=q.idx, mean_rstd=mean_rstd, done=False)
+            else:
+                out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier, stats=st)
             ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
             return _carrier(out) if q.carrier else out
         ctx.fused_f = FUSE_GNQ_F and q.qmode == Q_QUANT and q.gacc is not None and x.dim() == 3 and x.is_cuda      # (the CPU backend: un-fused)
@@ -632,9 +658,16 @@ class DwConvQ(Function):
     @staticmethod
     def forward(ctx, x, w, bias, slope, qmin, qmax, L, act, q, xq):
         q.carrier = FAST and not q.keep_out
-        q.stats = K.new_stats("dwq", x.shape[0], x.shape[1], x.shape[2], x.device) if (FUSE_STATS and NEXT_IS_GROUPNORM) else None
-        out, q.idx = K.dwq_fwd(xq.idx, xq.qmin, xq.qmax, w, bias, L.dil, L.pad, act, slope, qmin, qmax, write_out=not q.carrier,
-                               stats=q.stats)
+        d = getattr(x, "_fqss_defer", None)
+        if d is not None and not d["done"] and q.carrier and w.shape[-1] == 3 and L.pad == L.dil:
+            # the GroupNormQ in front left its launch to this layer: gLN + quantizer + depthwise + PReLU + quantizer as one kernel
+            out, q.idx, q.stats = K.gndwq_fwd(d, w, bias, L.dil, L.pad, act, slope, qmin, qmax, FUSE_STATS and NEXT_IS_GROUPNORM)
+            d["done"] = True
+        else:
+            flush_defer(x)
+            q.stats = K.new_stats("dwq", x.shape[0], x.shape[1], x.shape[2], x.device) if (FUSE_STATS and NEXT_IS_GROUPNORM) else None
+            out, q.idx = K.dwq_fwd(xq.idx, xq.qmin, xq.qmax, w, bias, L.dil, L.pad, act, slope, qmin, qmax, write_out=not q.carrier,
+                                   stats=q.stats)
         ctx.save_for_backward(w, bias, slope, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
         ctx.L, ctx.act, ctx.q = L, act, q
         return _carrier(out) if q.carrier else out

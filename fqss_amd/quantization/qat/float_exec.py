@@ -40,6 +40,9 @@ class HipSequential(nn.Sequential):
             # layer's backward needs to run the producer's epilogue backward on the fly (ops._Producer)
             nxt = next((n for n in mods[i + 1:] if not isinstance(n, nn.Identity)), None)
             QL.ops.NEXT_IS_GROUPNORM = isinstance(nxt, QL.GroupNormQ)
+            # a GroupNormQ whose one consumer is a 3-tap depthwise Conv1dNlQ (the TCN block's gLN -> depthwise conv): that layer's kernel
+            # runs the GroupNorm too (ops.GroupNormActQ leaves its launch record on the tensor; run_conv1d launches it if it cannot fuse)
+            QL.ops.NEXT_IS_DW3 = isinstance(m, QL.GroupNormQ) and QL.is_depthwise3(nxt)
             # the owner of the sequence may vouch for its OUTPUT instead (fqss_sole_consumer: the mask network, whose output only
             # feeds the masking MulQ): the last layer then hands its producer record to that consumer
             QL.ops.NEXT_TAKES_PRODUCER = nxt is None and getattr(self, "fqss_sole_consumer", False)
@@ -47,6 +50,7 @@ class HipSequential(nn.Sequential):
                 x = apply_module(m, x)
             finally:
                 QL.ops.NEXT_IS_GROUPNORM = False
+                QL.ops.NEXT_IS_DW3 = False
                 QL.ops.NEXT_TAKES_PRODUCER = False
             i += 1
         return x

@@ -228,6 +228,13 @@ def conv1d_geometry(conv):
     raise NotImplementedError(f"Conv1d(k={k}, s={s}, p={p}, d={d}, groups={g}) has no HIP kernel")
 
 
+def is_depthwise3(m):
+    """a Conv1dNlQ / Conv1dQ wrapping a 3-tap depthwise 'same' convolution (the TCN block's dilated conv)"""
+    conv = getattr(m, "conv1d", None)
+    return (isinstance(m, (Conv1dNlQ, Conv1dQ)) and isinstance(conv, nn.Conv1d) and conv.kernel_size[0] == 3 and conv.stride[0] == 1
+            and conv.groups == conv.in_channels == conv.out_channels and conv.padding[0] == conv.dilation[0])
+
+
 def run_conv1d(conv, x, weight, nl, aq):
     """fq_act(nl(conv1d(x, weight) + bias)) through one fused autograd node"""
     if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
@@ -245,6 +252,7 @@ def run_conv1d(conv, x, weight, nl, aq):
     if L.kind == "dw" and xq is not None and q.qmode == ops.Q_QUANT and conv.kernel_size[0] <= 8:
         y = ops.DwConvQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q, xq)
     else:
+        ops.flush_defer(x)
         if not (L.kind == "pw" and xq is not None and wc is not None):
             x = ops.real(x)             # no coded-input kernel for this case: decode a carrier first
         y = ops.LinearActQ.apply(x, weight, conv.bias, slope, q.qmin, q.qmax, L, act, q, xq, wc)

@@ -1204,3 +1204,36 @@ def test_teacher_gemm_against_fp64(Co, Ci, pro, act, split, B, M):
         cd = c.double().cpu()
         np.testing.assert_allclose(s[:, 0].numpy(), cd.sum(dim=(1, 2)).numpy(), rtol=1e-5, atol=1e-3)
         np.testing.assert_allclose(s[:, 1].numpy(), (cd * cd).sum(dim=(1, 2)).numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,M,dil", [(2, 24, 3999, 1), (1, 16, 3999, 128), (3, 8, 777, 4), (2, 600, 130, 2), (1, 4, 4096, 64)])
+def test_gn_dw_fused_bit_identical(B, C, M, dil):
+    """fqss_gndwq_fwd (round 4): GroupNormQ + 3-tap depthwise Conv1dNlQ (PReLU), both quantizing, as ONE launch -- against the two
+    launches it replaces (fqss_gnq_fwd, fqss_dwq_fwd): the GroupNorm's output codes, its mean / rstd, the depthwise layer's output
+    codes and the integer statistics of those codes, bit for bit (dilations 1 .. 128: unaligned taps out of the LDS row, the
+    zero-padded row ends, rows shorter than a workgroup's 4096 positions, several rows per workgroup)."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(B * 1000 + C + M + dil)
+    xc = K.empty_codes((B, C, M), dev)
+    xc.copy_(torch.randint(0, 256, (B, C, M), generator=g, dtype=torch.uint8).to(dev))
+    T1 = lambda v: torch.tensor([v], device=dev)
+    lo, hi, lo1, hi1, lo2, hi2 = T1(-1.7), T1(2.9), T1(-2.2), T1(2.4), T1(-0.6), T1(1.9)
+    gamma, beta = (1.0 + 0.3 * torch.randn(C, generator=g)).to(dev), (0.2 * torch.randn(C, generator=g)).to(dev)
+    w, bias = (torch.randn(C, 1, 3, generator=g) * 0.6).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    slope = T1(0.2)
+    xi = xc.to(torch.int64)
+    st = K.CodeStats(torch.stack([xi.sum(dim=(1, 2)), (xi * xi).sum(dim=(1, 2))], 1).reshape(-1).contiguous(), 1)
+    _, yc1, mr = K.gnq_fwd(xc, lo, hi, gamma, beta, 1e-8, lo1, hi1, write_out=False, stats=st)
+    std = K.new_stats("dwq", B, C, M, dev)
+    _, yc2 = K.dwq_fwd(yc1, lo1, hi1, w, bias, dil, dil, K.ACT_PRELU, slope, lo2, hi2, write_out=False, stats=std)
+    _, y1, mr_f = K.gnq_fwd_deferred(xc)
+    d = dict(xc=xc, qmin_x=lo, qmax_x=hi, gamma=gamma, beta=beta, eps=1e-8, qmin=lo1, qmax=hi1, stats=st, yc=y1, mean_rstd=mr_f, done=False)
+    _, y2, st2 = K.gndwq_fwd(d, w, bias, dil, dil, K.ACT_PRELU, slope, lo2, hi2, True)
+    assert torch.equal(y1, yc1) and torch.equal(mr_f, mr)
+    assert torch.equal(y2, yc2)
+    if std is not None and st2 is not None:
+        a = std.ws.view(B, -1, 2).sum(1)
+        b = st2.ws.view(B, -1, 2).sum(1)
+        assert torch.equal(a, b)
+        yi = yc2.to(torch.int64)
+        assert torch.equal(b[:, 0], yi.sum(dim=(1, 2))) and torch.equal(b[:, 1], (yi * yi).sum(dim=(1, 2)))
