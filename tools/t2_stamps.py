@@ -16,7 +16,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "t3"
     # t3 / t1: the teacher GEMMs (libfqss built with -DFQSS_T2_STAMP); dx / dx2: the student's dgrad 128->512 / res|skip pair on the
     # ring (csrc/qgemm_ring.hip built with -DFQSS_R_STAMP)
-    key, nth, sym = {"t3": ("k_tgemm<1>", 0, "fqss_debug_t2_stamps"), "t1": ("k_tgemm<0>", 0, "fqss_debug_t2_stamps"),
+    key, nth, sym = {"t3": ("k_tgemm2<1>", 0, "fqss_debug_t2_stamps"), "t1": ("k_tgemm2<0>", 0, "fqss_debug_t2_stamps"),
                      "dx": ("k_qgemm<1>", 0, "fqss_debug_r_stamps"), "dx2": ("k_qgemm<1>", 1, "fqss_debug_r_stamps")}[which]
     case = [c for c in RC.build(torch.device("cuda", 0)) if c["kernel"] == key][nth]
     for i in range(6):
