@@ -132,6 +132,7 @@ _PROTOS = {
     "fqss_mha_prep_bwd": [P, P, P, P, P, I64, I32, I64, I64, F64, P, P, P],
     "fqss_lstm_fwd": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_lstm_bwd": [P, P, P, P, P, I32, I32, I32, P],
+    "fqss_lstm_gate_fn": [P, P, P, I64, P],
     "fqss_lstm_bwd_b": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_lstm_bwd_b4": [P, P, P, P, P, P, I32, I32, I32, P],
     "fqss_gnrows_fwd": [P, P, P, P, P, P, I64, I32, I64, I64, I32, I32, I32, F64, P],

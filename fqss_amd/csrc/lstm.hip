@@ -24,11 +24,19 @@
 // same four-step register ring for the saved activations: cfg 3 38.6 -> 37.2 ms per step.
 //
 // Saved for the backward: the four gate activations and the cell state per step (5H floats per step and sequence-direction).
+#include <cstdlib>
+
 #include "fqss_dev.h"
 
 namespace fqss {
 
 constexpr int kNB = 2;   // sequences per workgroup
+
+// timing experiments only (make variant SRC=lstm DEFS=-DFQSS_LSTM_ABL=n; never in the product library): 1 no FMAs, 2 no LDS reads of h,
+// 4 no gate transcendentals, 8 no tanh(c), 16 no global stores, 32 no input-projection loads
+#ifndef FQSS_LSTM_ABL
+#define FQSS_LSTM_ABL 0
+#endif
 
 struct LstmBiasGrads {      // gradient buffers of b_ih / b_hh, forward and reverse direction ([4H] each; null: not wanted)
     float *ih_f, *hh_f, *ih_r, *hh_r;
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
         const int sn = min(step, S - 1);
         const int tn = dir == 0 ? sn : S - 1 - sn;
 #pragma unroll
-        for (int nb = 0; nb < kNB; ++nb) dst[nb] = pre[(((int64_t)tn * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
+        for (int nb = 0; nb < kNB; ++nb)
+            dst[nb] = (FQSS_LSTM_ABL & 32) != 0 ? 0.25f : pre[(((int64_t)tn * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + jc];
     };
 #pragma unroll
     for (int u = 0; u < kPF; ++u) fetch(pf[u], u);
@@ -106,7 +115,13 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
                 for (int k = 0; k < KQ; k += 4) {
 #pragma unroll
                     for (int nb = 0; nb < kNB; ++nb) {
-                        const float4 hv = *reinterpret_cast<const float4*>(hs + (nb * 4 + kq) * HQS + k);
+                        float4 hv;
+                        if constexpr ((FQSS_LSTM_ABL & 2) != 0) hv = make_float4(wreg[k], wreg[k + 1], wreg[k + 2], wreg[k + 3]);
+                        else hv = *reinterpret_cast<const float4*>(hs + (nb * 4 + kq) * HQS + k);
+                        if constexpr ((FQSS_LSTM_ABL & 1) != 0) {
+                            part[k & 3][nb] += (hv.x + hv.y) + (hv.z + hv.w);
+                            continue;
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             part[r][nb] = fmaf(wreg[r * KQ + k], hv.x, part[r][nb]);
@@ -143,9 +158,9 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
 #pragma unroll
             for (int nb = 0; nb < kNB; ++nb) {
                 const float pre_act = pcur[nb] + (acc[nb] + bj);
-                const float a = is_g ? tanhf(pre_act) : sigmoidf_(pre_act);
+                const float a = (FQSS_LSTM_ABL & 4) != 0 ? pre_act * 0.01f : (is_g ? tanhf(pre_act) : sigmoidf_(pre_act));
                 gs[nb * 4 * H + j] = a;
-                if (gsav != nullptr && b0 + nb < B) gsav[((((int64_t)t * B + b0 + nb) * 2) + dir) * 4 * H + j] = a;   // (NULL: inference)
+                if ((FQSS_LSTM_ABL & 16) == 0 && gsav != nullptr && b0 + nb < B) gsav[((((int64_t)t * B + b0 + nb) * 2) + dir) * 4 * H + j] = a;   // (NULL: inference)
             }
         }
         __syncthreads();
@@ -153,13 +168,13 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
             const float* g = gs + cn * 4 * H;
             const float gi = g[ck], gf = g[H + ck], gg = g[2 * H + ck], go = g[3 * H + ck];
             c = gf * c + gi * gg;
-            const float tc = tanhf(c);
+            const float tc = (FQSS_LSTM_ABL & 8) != 0 ? c * 0.5f : tanhf(c);
             const float h = go * tc;
             if constexpr (HT > 0) hs[(cn * 4 + ck / KQ) * HQS + (ck % KQ)] = h;
             else hs[cn * H + ck] = h;
             const int64_t sb = (int64_t)t * B + b0 + cn;
-            hout[sb * 2 * H + dir * H + ck] = h;
-            if (csav != nullptr) {
+            if ((FQSS_LSTM_ABL & 16) == 0 || step == S - 1) hout[sb * 2 * H + dir * H + ck] = h;
+            if ((FQSS_LSTM_ABL & 16) == 0 && csav != nullptr) {
                 csav[(sb * 2 + dir) * 2 * H + ck] = c;
                 csav[(sb * 2 + dir) * 2 * H + H + ck] = tc;
             }
@@ -180,6 +195,170 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_fwd(const float
 #pragma unroll
     for (int u = 0; u < kPF - 1; ++u)       // the last S % kPF steps: already in the ring
         if (step + u < S) one_step(step + u, pf[u]);
+}
+
+// Gate non-linearities of the H = 128 forward: ONE short dependent chain for both kinds (a step's critical path runs through it
+// twice: gate, then tanh(c)), fp32-grade results.  e = 2^t on v_exp_f32 with t = -x log2(e) (sigmoid) or -2 |x| log2(e) (tanh), the
+// rounding of that product and of the constant carried as a first-order factor (1 + t_lo ln 2) folded into the FMAs that form
+// 1 +- e; the quotient n / (1 + e) (n = 1: sigmoid, n = 1 - e: tanh) as v_rcp_f32 and one residual correction; tanh below |x| = 0.36,
+// where 1 - e cancels, is x + x^3 P(x^2) (P: the degree-3 interpolant of (tanh(sqrt u) / sqrt u - 1) / u on the Chebyshev nodes of
+// [0, 0.36^2], 2.3e-9 relative in exact arithmetic).  Arguments are clamped to +-87 (the results there are already 0 / 1 / +-1 to
+// fp32).  Measured against float64 (tools/lstm_gate_err.py, tests/test_gpu_dptnet.py::test_lstm_gate_functions): sigmoid <= 3.5 ulp
+// (<= 1.5 for x > 0), tanh <= 2.6 ulp, either within 1.0e-7 of the exact value -- v_exp_f32 itself is good to ~1.5 ulp.
+__device__ __forceinline__ float gate_fn(float x, bool th) {
+    const float a = fabsf(x);
+    const float z = __builtin_amdgcn_fmed3f(th ? a : x, -87.0f, 87.0f);
+    const float kh = th ? -2.8853900432586669921875f : -1.44269502162933349609375f;      // fl(-2 log2 e), fl(-log2 e)
+    const float kl = th ? -3.851925849e-08f : -1.925962925e-08f;                             // the constants' own rounding
+    const float t = kh * z;
+    const float tl = fmaf(kl, z, fmaf(kh, z, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float corr = fmaf(tl, 0.693147182464599609375f, 1.0f);
+    const float d = fmaf(e, corr, 1.0f);
+    const float n = th ? fmaf(-e, corr, 1.0f) : 1.0f;
+    const float r = __builtin_amdgcn_rcpf(d);
+    float q = n * r;
+    q = fmaf(fmaf(-d, q, n), r, q);
+    if (!th) return q;
+    const float u = a * a;
+    float p = fmaf(u, 0.019728317856788635f, -0.0537986196577549f);
+    p = fmaf(u, p, 0.13332897424697876f);
+    p = fmaf(u, p, -0.3333333134651184f);
+    const float small = fmaf(a * u, p, a);
+    return copysignf(a < 0.36f ? small : q, x);
+}
+
+__global__ void k_lstm_gate_fn(const float* __restrict__ x, float* __restrict__ sg, float* __restrict__ th, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        sg[i] = gate_fn(x[i], false);
+        th[i] = gate_fn(x[i], true);
+    }
+}
+
+// The H = 128 forward, round 4.  What a step of the round-2 form costs (`profiles/r04_lstm_ablation.txt`, ~3,300 cycles at S = 250 x 194
+// sequences; `profiles/r04_lstm_pmc_v1_vs_quad.txt`): 359 vector instructions per wave and step, 256 of them the FMAs (~1,300 cycles: two
+// waves per SIMD issue FMAs at the SIMD's rate, tools/ubench/dpp_fma_rate.hip), the gate non-linearities ~670 (libm's expf / tanhf and an
+// IEEE division: ~40 instructions each, two per lane), the LDS reads of h ~650 in front of the FMAs, tanh(c) + stores + loads ~430, the
+// two barriers and the LDS round trips of the cell update ~480.  It is the NUMBER of non-FMA instructions that the time follows (~5 cycles
+// of the SIMD each, the two waves of a SIMD hardly overlapping there), not the depth of the dependent chains.  Measured on the way:
+//   * sixteen waves, an OCT of lanes per four rows (64 weight registers, 4 waves per SIMD): 425 us against 390 -- the FMAs are no faster
+//     (two waves already saturate the SIMD), the reduction and the barrier grow;
+//   * the four gates of a hidden unit in ONE quad, the cell update inside the quad by quad broadcasts, one barrier per step: 361-378 us --
+//     every lane then evaluates tanh(c) (4 x the evaluations), 422 instructions per wave and step instead of 359; the same with the chain
+//     dealt out between the FMAs by hand (a scheduling barrier per k): 464 us, all eight LDS reads of a phase are in flight at once;
+//   * `v_fmac_f32_dpp row_newbcast` to share h across 16 lanes instead of LDS reads: 18 x slower than a plain FMA on this part.
+// This form (329 us at the same shape, -15 %): the round-2 layout (a quad shares four gate rows, the gate kind is wave-uniform), gate
+// functions of 10-20 instructions (above), and the two sequences HALF A STEP APART: a phase is [the cell update of the OTHER sequence, on
+// two waves] and [this sequence's 128 FMAs per lane on all waves], then this sequence's gate function; one barrier per phase, two per
+// step as before, and a phase reads half of the h bytes in one burst.  Same sums in the same order as the round-2 form; the gate
+// functions differ from libm's by <= 4 ulp (tests/test_gpu_dptnet.py::test_lstm_gate_functions).
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_lstm_fwd_st(const float* __restrict__ pre, const float* __restrict__ whh, const float* __restrict__ bhh,
+                                                       float* __restrict__ hout, float* __restrict__ gsav, float* __restrict__ csav, int S, int B) {
+    static_assert(kNB == 2 && H % 64 == 0, "two sequences half a step apart; wave-uniform gate kinds and cell roles");
+    constexpr int KQ = H / 4, HQS = KQ + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hs = smem;                              // [kNB][4 quarters][HQS]
+    float* gs = smem + kNB * 4 * HQS;              // [kNB][4H]
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * kNB;
+    const int j = threadIdx.x;                     // gate row
+    const int q4 = j >> 2, kq = j & 3;
+    float wreg[H];
+    {
+        const float* Wq = whh + ((int64_t)dir * 4 * H + q4 * 4) * H + kq * KQ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) wreg[r * KQ + k] = Wq[(int64_t)r * H + k];
+    }
+    const float bj = bhh[dir * 4 * H + j];
+    for (int e = threadIdx.x; e < kNB * 4 * HQS; e += blockDim.x) hs[e] = 0.f;
+    // cell roles: threads [0, H) keep sequence 1's cell state, threads [H, 2H) sequence 0's (whole waves; each role's update sits
+    // in the phase of the OTHER sequence's FMAs)
+    const int crole = j < H ? 1 : (j < 2 * H ? 0 : -1);
+    const int ck = j & (H - 1);
+    const bool cell_ok = crole >= 0 && b0 + crole < B;
+    float c = 0.f;
+    __syncthreads();
+    constexpr int kPF = 4;
+    float pf[kPF][kNB];
+    auto fetch = [&](float (&dst)[kNB], int step) {
+        const int sn = min(step, S - 1);
+        const int tn = dir == 0 ? sn : S - 1 - sn;
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb) dst[nb] = pre[(((int64_t)tn * B + min(b0 + nb, B - 1)) * 2 + dir) * 4 * H + j];
+    };
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) fetch(pf[u], u);
+    const bool is_g = (j >= 2 * H) && (j < 3 * H);           // gate order i, f, g, o; wave-uniform
+    auto time_of = [&](int step) { return dir == 0 ? step : S - 1 - step; };
+    auto cell_update = [&](int nb, int step) {               // by the threads whose role is nb (wave-uniform branch at the call)
+        const int t = time_of(step);
+        const float* g = gs + nb * 4 * H;
+        const float gi = g[ck], gf = g[H + ck], gg = g[2 * H + ck], go = g[3 * H + ck];
+        c = gf * c + gi * gg;
+        const float tc = gate_fn(c, true);
+        const float h = go * tc;
+        hs[(nb * 4 + ck / KQ) * HQS + (ck % KQ)] = h;
+        const int64_t sb = (int64_t)t * B + b0 + nb;
+        hout[sb * 2 * H + dir * H + ck] = h;
+        if (csav != nullptr) {
+            csav[(sb * 2 + dir) * 2 * H + ck] = c;
+            csav[(sb * 2 + dir) * 2 * H + H + ck] = tc;
+        }
+    };
+    auto gates = [&](int nb, int step, float pcur) {         // W_hh h_{t-1} of sequence nb, its gate function, the saved activation
+        const int t = time_of(step);
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KQ; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(hs + (nb * 4 + kq) * HQS + k);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                part[r] = fmaf(wreg[r * KQ + k], hv.x, part[r]);
+                part[r] = fmaf(wreg[r * KQ + k + 1], hv.y, part[r]);
+                part[r] = fmaf(wreg[r * KQ + k + 2], hv.z, part[r]);
+                part[r] = fmaf(wreg[r * KQ + k + 3], hv.w, part[r]);
+            }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = part[r];
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+            v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+            mine = (kq == r) ? v : mine;
+        }
+        const float pre_act = pcur + (mine + bj);
+        const float a = is_g ? gate_fn(pre_act, true) : gate_fn(pre_act, false);
+        gs[nb * 4 * H + j] = a;
+        if (gsav != nullptr && b0 + nb < B) gsav[((((int64_t)t * B + b0 + nb) * 2) + dir) * 4 * H + j] = a;
+    };
+    auto one_step = [&](int step, const float (&pcur)[kNB]) {
+        if (crole == 1 && cell_ok && step > 0) cell_update(1, step - 1);
+        gates(0, step, pcur[0]);
+        __syncthreads();
+        if (crole == 0 && cell_ok) cell_update(0, step);
+        gates(1, step, pcur[1]);
+        __syncthreads();
+    };
+    int step = 0;
+    for (; step + kPF <= S; step += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            float pc[kNB];
+#pragma unroll
+            for (int nb = 0; nb < kNB; ++nb) pc[nb] = pf[u][nb];
+            fetch(pf[u], step + u + kPF);
+            one_step(step + u, pc);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kPF - 1; ++u)
+        if (step + u < S) one_step(step + u, pf[u]);
+    if (crole == 1 && cell_ok) cell_update(1, S - 1);
 }
 
 // gout [S][B][2H] -> dG [S][B][2][4H] (gradient w.r.t. the gate pre-activations); everything else follows by GEMMs
@@ -350,13 +529,27 @@ extern "C" int fqss_lstm_fwd(const float* pre, const float* whh, const float* bh
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv(B, kNB), 2);
     const size_t lds = (size_t)(kNB * (H + 16) + kNB * 4 * H) * sizeof(float);
-    if (H == 128) {
+    // FQSS_LSTM_V1=1 (read per call: tests and A/B runs toggle it): the round-2 form of the H = 128 forward
+    const char* v1 = getenv("FQSS_LSTM_V1");
+    if (H == 128 && !(v1 && atoi(v1) != 0)) {
+        const size_t lds2 = (size_t)(kNB * 4 * (H / 4 + 4) + kNB * 4 * H) * sizeof(float);
+        hipLaunchKernelGGL(k_lstm_fwd_st<128>, grid, dim3(512), lds2, s, pre, whh, bhh, hout, gsav, csav, S, B);
+    } else if (H == 128) {
         hipLaunchKernelGGL((k_lstm_fwd<128>), grid, dim3(512), lds, s, pre, whh, bhh, hout, gsav, csav, S, B, H);
     } else {
         const int threads = (int)cdiv(4 * H, 64) * 64;
         hipLaunchKernelGGL((k_lstm_fwd<0>), grid, dim3(threads), lds, s, pre, whh, bhh, hout, gsav, csav, S, B, H);
     }
     return launch_status("fqss_lstm_fwd");
+}
+
+// test hook: the gate functions of the H = 128 forward on a vector of arguments (tests/test_gpu_dptnet.py measures them against float64)
+extern "C" int fqss_lstm_gate_fn(const float* x, float* sigmoid_out, float* tanh_out, int64_t n, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && sigmoid_out && tanh_out, "null tensor");
+    FQSS_REQUIRE(n >= 0, "bad size");
+    if (n == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_lstm_gate_fn, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, sigmoid_out, tanh_out, n);
+    return launch_status("fqss_lstm_gate_fn");
 }
 
 static int lstm_bwd_impl(const char* who, const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, float* gbias,

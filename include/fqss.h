@@ -691,6 +691,9 @@ int fqss_lstm_fwd(const float* pre, const float* whh, const float* bhh, float* h
                   int S, int B, int H, fqss_stream_t stream);
 int fqss_lstm_bwd(const float* gout, const float* whh, const float* gsav, const float* csav, float* dG, int S,
                   int B, int H, fqss_stream_t stream);
+/* Test hook: the H = 128 forward's own gate functions (short dependent chains on v_exp_f32 / v_rcp_f32 in place of libm's
+ * expf / tanhf and an IEEE division; <= 4 ulp from the exact value) over n arguments: sigmoid_out[i], tanh_out[i] of x[i] */
+int fqss_lstm_gate_fn(const float* x, float* sigmoid_out, float* tanh_out, int64_t n, fqss_stream_t stream);
 /* fqss_lstm_bwd that also ADDS the column sums of dG over (step, sequence) into gbias [2][4H] (caller-zeroed): the gradient of
  * b_ih and b_hh of each direction (torch's LSTM backward, reached from qat_layers.py:571-600), kept in registers by the
  * threads that produce dG */

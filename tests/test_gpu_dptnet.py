@@ -189,8 +189,43 @@ def test_attention_kernels(L, B, nh, hd):
     np.testing.assert_allclose([dec(w[2]), dec(w[3])], [float(p.min()), float(p.max())], rtol=1e-4, atol=1e-12)
 
 
+def test_lstm_gate_functions():
+    """the H = 128 recurrence's own sigmoid / tanh (one short chain on the hardware's exp2 / rcp, csrc/lstm.hip gate_fn) against float64:
+    <= 4 ulp of the exact value and within 1.2e-7 of it, the limits beyond the range in which the result is not yet 0 / 1 / +-1"""
+    from fqss_amd import _lib
+    n = 1 << 22
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.linspace(-87, 87, n), torch.randn(n, generator=g) * 3, torch.randn(n, generator=g) * 0.2,
+                   torch.tensor([0.0, -0.0, 0.36, -0.36, 1e-30, -1e-30])])
+    far = torch.tensor([88.0, -88.0, 200.0, -200.0, 1e30, -1e30, float("inf"), -float("inf")])
+
+    def run(v):
+        vd = v.cuda()
+        sg, th = torch.empty_like(vd), torch.empty_like(vd)
+        _lib.call("fqss_lstm_gate_fn", vd.data_ptr(), sg.data_ptr(), th.data_ptr(), vd.numel(), torch.cuda.current_stream().cuda_stream)
+        return sg.cpu(), th.cpu()
+
+    sg, th = run(x)
+    x64 = x.double()
+    for got, want, name in ((sg, torch.sigmoid(x64), "sigmoid"), (th, torch.tanh(x64), "tanh")):
+        assert torch.isfinite(got).all(), name
+        ulp = torch.clamp(2.0 ** torch.floor(torch.log2(want.abs().clamp_min(2.0 ** -126))), min=2.0 ** -126) * 2.0 ** -23
+        err = (got.double() - want).abs() / ulp
+        # measured (tools/lstm_gate_err.py): sigmoid <= 3.5 ulp (<= 1.5 for x > 0), tanh <= 2.6 ulp, either within 1.0e-7 of the exact value
+        assert float(err.max()) <= 4.0, (name, float(err.max()), float(x[err.argmax()]))
+        assert float((got.double() - want).abs().max()) <= 1.2e-7, name
+    assert float(th[-6]) == 0.0 and float(th[-5]) == 0.0 and float(sg[-6]) == 0.5
+    sg, th = run(far)
+    assert th.tolist() == [1.0, -1.0] * 4
+    assert sg[0::2].tolist() == [1.0] * 4 and float(sg[1::2].max()) <= 2e-38 and float(sg[1::2].min()) >= 0.0
+
+
+@pytest.mark.parametrize("v1", ["0", "1"])
 @pytest.mark.parametrize("S,B,I,H", [(9, 5, 16, 12), (40, 7, 64, 128), (250, 3, 64, 128)])
-def test_lstm_kernels(S, B, I, H):
+def test_lstm_kernels(S, B, I, H, v1, monkeypatch):
+    if v1 == "1" and H != 128:
+        pytest.skip("FQSS_LSTM_V1 only selects among the H = 128 forward kernels")
+    monkeypatch.setenv("FQSS_LSTM_V1", v1)
     from fqss_amd import ops_dp
     names = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
              "bias_ih_l0_reverse", "bias_hh_l0_reverse")
