@@ -6,13 +6,27 @@ all-reduce, nothing else synchronised (observer ranges diverge per rank, SURVEY.
 Here the whole gradient is ONE flat fp32 buffer (20.5 MB for ConvTasNet), so the exchange is a
 single all-reduce(SUM) and the 1/world factor is folded into the clip+Adam kernel.
 """
+import datetime
 import os
+import sys
 
 import torch
 import torch.distributed as dist
 
 
+class CommError(RuntimeError):
+    """a collective of the gradient / range exchange failed or timed out on this rank ("When the exchange fails")"""
+
+
 class Comm:
+    """What happens when the exchange fails (a peer died, a link error, a hang): the collective raises on the surviving ranks -- at once
+    when the transport notices (gloo: the peer's socket closes; RCCL: the communicator is aborted by its watchdog, which
+    TORCH_NCCL_ASYNC_ERROR_HANDLING=1, set below unless the caller chose otherwise, arms), after FQSS_DIST_TIMEOUT_S (default 600 s) at
+    the latest -- and is re-raised as CommError naming the rank and the operation.  Nothing is retried and nothing is restarted in
+    place: a step whose gradients were not averaged must not reach the optimizer, and a process that has initialised the GPU must never
+    be replaced by another (no exec on this pool); the rank exits non-zero, torch.distributed.run ends the job, and the job resumes
+    from the last checkpoint (process.py) as a NEW launch."""
+
     def __init__(self, rank=0, world=1, local_rank=0, backend=None):
         self.rank, self.world, self.local_rank, self.backend = rank, world, local_rank, backend
 
@@ -28,28 +42,38 @@ class Comm:
             backend = os.environ.get("FQSS_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
             if device_type == "cuda":
                 torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            timeout = datetime.timedelta(seconds=float(os.environ.get("FQSS_DIST_TIMEOUT_S", "600")))
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
             return cls(rank, world, local, backend)
         return cls(rank, world, local, dist.get_backend() if dist.is_initialized() else None)
 
+    def _run(self, what, fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except RuntimeError as e:           # DistBackendError / DistNetworkError are RuntimeErrors
+            msg = f"fqss_amd.parallel: {what} failed on rank {self.rank} of {self.world} ({self.backend}): {e}"
+            print(msg, file=sys.stderr, flush=True)
+            raise CommError(msg) from e
+
     def all_reduce_sum(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self._run("all_reduce(SUM)", dist.all_reduce, t, op=dist.ReduceOp.SUM)
         return t
 
     def all_reduce_max(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self._run("all_reduce(MAX)", dist.all_reduce, t, op=dist.ReduceOp.MAX)
         return t
 
     def broadcast(self, t, src=0):
         if self.world > 1:
-            dist.broadcast(t, src)
+            self._run("broadcast", dist.broadcast, t, src)
         return t
 
     def barrier(self):
         if self.world > 1:
-            dist.barrier()
+            self._run("barrier", dist.barrier)
 
     def shard(self, n_items):
         """contiguous shard [lo, hi) of n_items for this rank (batch-sharded data parallel)"""
@@ -66,7 +90,7 @@ class Comm:
         if not rs:
             return
         flat = torch.cat([torch.cat([m.min_range.data, m.max_range.data]) for m in rs])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        self._run("all_reduce(SUM) of the observer ranges", dist.all_reduce, flat, op=dist.ReduceOp.SUM)
         flat /= self.world
         for i, m in enumerate(rs):
             m.min_range.data.copy_(flat[2 * i:2 * i + 1])
