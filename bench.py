@@ -160,7 +160,7 @@ def _pmc_other(key, shape_token):
 
 def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
     """`roofline` of a dual-path workload = the kernel with the largest time per step in the committed steady-state table
-    (profiles/r*_cfg3_step_table.txt: k_lstm_fwd<128>; profiles/r*_cfg4_step_table.txt: the coded weight-gradient instance of
+    (profiles/r*_cfg3_step_table.txt: k_lstm_fwd_st<128>; profiles/r*_cfg4_step_table.txt: the coded weight-gradient instance of
     k_gemm_x3), timed live at this workload's shape with HIP events on torch's current stream (the stream these launches go to) and
     priced by roofline_cases.priced(): the LSTM recurrence is fp32 FMA on the vector ALU (157.3 TF), the coded weight gradient issues
     three bf16 MFMA products per term (2.5 PF dense)."""
@@ -174,12 +174,12 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
         flops = 2.0 * 2 * (4 * H) * H * S * Bq       # the recurrent product h W_hh^T of both directions
         n = S * Bq
         nbytes = 4.0 * n * 8 * H + 4.0 * n * (2 * H + 8 * H + 4 * H)      # input projection read; h, gates, cell states written (roofline_cases.build_other)
-        o = {"kernel": "k_lstm_fwd<128>", "what": "BiLSTM recurrence of the intra-chunk path (both directions)", "shape": [S, Bq, H],
+        o = {"kernel": "k_lstm_fwd_st<128>", "what": "BiLSTM recurrence of the intra-chunk path (both directions)", "shape": [S, Bq, H],
              "launch_us": round(us, 1), "launches_per_step": 24, "algorithmic_bytes_per_launch": int(nbytes)}
         o.update(RC.priced(flops, 1, "f32", nbytes, us))
-        o["traffic"] = _pmc_other("k_lstm_fwd<128>", f"{S} steps x {Bq} sequences")
-        o["note"] = ("a chain of 250 dependent time steps: fp32 FMA issue + 2 barriers per step, latency-bound at 194 sequence pairs "
-                     "(DESIGN.md 7); neither roofline binds it")
+        o["traffic"] = _pmc_other("k_lstm_fwd_st<128>", f"{S} steps x {Bq} sequences")
+        o["note"] = ("a chain of 250 dependent time steps on 194 of 256 CUs: bound by the issue of ~360 vector instructions per wave and step "
+                     "(256 of them the FMAs) + 2 barriers per step (DESIGN.md 7, 9); neither roofline binds it")
         return o
     # cfg 4 (profiles/r*_cfg4_step_table.txt): the weight gradient of the student's coded linears, k_gemm_x3<false, false, true, 2, 2, 1> --
     # A = gz^T (fp32, three bf16 pieces), B = the input's u8 codes (one exact plane): three products per k

@@ -248,7 +248,8 @@ __global__ void k_lstm_gate_fn(const float* __restrict__ x, float* __restrict__ 
 //     every lane then evaluates tanh(c) (4 x the evaluations), 422 instructions per wave and step instead of 359; the same with the chain
 //     dealt out between the FMAs by hand (a scheduling barrier per k): 464 us, all eight LDS reads of a phase are in flight at once;
 //   * `v_fmac_f32_dpp row_newbcast` to share h across 16 lanes instead of LDS reads: 18 x slower than a plain FMA on this part.
-// This form (329 us at the same shape, -15 %): the round-2 layout (a quad shares four gate rows, the gate kind is wave-uniform), gate
+// This form (339 us at the same shape on the probe's random operands, -13 %; inside the cfg-3 step the launches average 298 us against
+// 303 -- profiles/r04_cfg3_step_table.txt -- : the model's narrow pre-activations keep libm on its short paths): the round-2 layout (a quad shares four gate rows, the gate kind is wave-uniform), gate
 // functions of 10-20 instructions (above), and the two sequences HALF A STEP APART: a phase is [the cell update of the OTHER sequence, on
 // two waves] and [this sequence's 128 FMAs per lane on all waves], then this sequence's gate function; one barrier per phase, two per
 // step as before, and a phase reads half of the h bytes in one burst.  Same sums in the same order as the round-2 form; the gate

@@ -48,7 +48,7 @@ def priced(flops, products, dtype, nbytes, us):
 # partial products issued per algorithmic product, and on which pipe (csrc/teacher.hip: 3 x 3 bf16 split, 6 leading terms; csrc/qgemm.hip:
 # fp32 gradient in three exact bf16 pieces x one exact plane of 8-bit codes; forward: codes x codes, one bf16 product)
 ISSUED = {"k_tgemm2<0>": ("bf16", 6), "k_tgemm2<1>": ("bf16", 6), "k_qgemm<1>": ("bf16", 3), "k_qwgrad2": ("bf16", 3), "k_qgemm<0>": ("bf16", 1),
-          "k_lstm_fwd<128>": ("f32", 1), "k_gemm_x3": ("bf16", 3), "k_qgemm<3>": ("bf16", 6), "k_attn_long_fwd_x3<64>": ("bf16", 6),
+          "k_lstm_fwd_st<128>": ("f32", 1), "k_gemm_x3": ("bf16", 3), "k_qgemm<3>": ("bf16", 6), "k_attn_long_fwd_x3<64>": ("bf16", 6),
           "k_attn_long_fwd_c<64>": ("bf16", 3)}
 
 
@@ -237,7 +237,7 @@ def build_other(dev, sets=2):
     pre = [torch.randn(S, Bq, 8 * H, device=dev) * 0.1 for _ in R]
     whh, bhh = torch.randn(2, 4 * H, H, device=dev) * 0.05, torch.zeros(2, 4 * H, device=dev)
     n = S * Bq
-    case("k_lstm_fwd<128>", "cfg 3: BiLSTM recurrence 250 steps x 194 sequences (both directions), saving gates and cell states", "mfma", 24,
+    case("k_lstm_fwd_st<128>", "cfg 3: BiLSTM recurrence 250 steps x 194 sequences (both directions), saving gates and cell states", "mfma", 24,
          4.0 * n * 8 * H, 4.0 * n * (2 * H + 8 * H + 4 * H), lambda i: K.lstm_fwd(pre[i % sets], whh, bhh, S, Bq, H), flops=2.0 * 2 * 4 * H * H * n)
     # cfg 4: weight gradient of the student's coded feed-forward linear, 8 500 rows (250 x 34 chunks) x 256 -> 1024
     rows, Ci, Co = 8500, 256, 1024
