@@ -1166,16 +1166,8 @@ class Conv1dGnNlQ(LayerQ):
 
 
 # ---------------------------------------------------------------------------------------------
-# layers of the later §8 rows: constructing them fails loudly (no ATen fallback)
+# layers of the later §8 rows (HTDemucs)
 # ---------------------------------------------------------------------------------------------
-def _later_row(name, row):
-    class _Unbuilt(LayerQ):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"{name}: kernels for SURVEY.md §8 row {row} are not built yet (no ATen fallback)")
-    _Unbuilt.__name__ = _Unbuilt.__qualname__ = name
-    return _Unbuilt
-
-
 class Conv2dNlQ(LayerQ):
     """fq(nl(conv2d(x)))  (qat_layers.py:261-293; the frequency-branch encoder / rewrite convs of HTDemucs)"""
 
