@@ -107,7 +107,7 @@ def test_tiny_convtasnet_trains_to_the_reference_sisdr(golden):
     _gate("tiny convtasnet", S, L, gl, 20, 8.0)                   # -16.5 dB -> -5 dB in the reference
     # the 300-step average of the quantizing phase (a tighter statistic than the 50-step tail) under the same rule
     long_ref, long_hip = gl["sisdr"][:, 100:].mean(1), S[:, 100:].mean(1)
-    tol = max(0.1, float(long_ref.max() - long_ref.min()), float(long_hip.max() - long_hip.min()))
+    tol = max(0.1, 2 * float(long_ref.max() - long_ref.min()), float(long_hip.max() - long_hip.min()))     # (round 3's rule: 2 x spread)
     assert abs(float(long_hip.mean()) - float(long_ref.mean())) <= tol, (long_hip, long_ref)
 
 
