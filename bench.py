@@ -263,7 +263,7 @@ def main_dualpath(a, comm=None):
     if not a.no_graph:
         step.capture(x, tgt)
         launch = "hipGraph replay"
-        if comm.world > 1:
+        if comm.active:
             launch = f"hipGraph replay, {len(step._graphs[0])} backward segments, bucketed all-reduce overlapped"
     if ahead and not a.no_graph:
         launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
@@ -424,7 +424,7 @@ def main_htdemucs(a, comm=None):
     if not a.no_graph:
         step.capture(mix, src)
         launch = "hipGraph replay"
-        if comm.world > 1:
+        if comm.active:
             launch = f"hipGraph replay, {len(step._graphs[0])} backward segments, bucketed all-reduce overlapped"
     if ahead and not a.no_graph:
         launch += "; teacher forward of batch n+1 as its own hipGraph on a second stream beside step n"
@@ -501,6 +501,13 @@ def main_infer(a):
 
 def main():
     a = parse()
+    # `python bench.py --gpus N` on its own (no torch.distributed.run around it): start the N ranks here, as the reference's entry points
+    # do (asteroid_librimix_trainer.py:125-135, tasnet_musdbhq_trainer.py:17-30) -- BEFORE anything in this process touches the GPU; this
+    # parent only waits and hands the first failing rank's exit code on (fqss_amd/launch.py).  Under a launcher (WORLD_SIZE set) this
+    # process IS a rank.
+    from fqss_amd.launch import already_launched, spawn_ranks
+    if a.gpus > 1 and not already_launched():
+        sys.exit(spawn_ranks(a.gpus))
     if a.workload == "cfg5":
         return main_htdemucs(a)
     if a.workload == "infer":
@@ -544,7 +551,7 @@ def main():
     if not a.no_graph:
         step.capture(x, tgt)           # whole step -> hipGraphs; every later call is a replay
         launch = "hipGraph replay"
-        if comm.world > 1:
+        if comm.active:
             # the backward replays as one hipGraph per gradient bucket; each bucket's RCCL all-reduce is launched between two
             # replays on the communication stream and overlaps the next bucket's backward (no collective inside a graph)
             launch = f"hipGraph replay, {len(step._graphs[0])} backward segments, bucketed all-reduce overlapped"
@@ -603,7 +610,11 @@ def main():
                 b = copy.copy(a)
                 b.workload, b.steps, b.warmup = w, a.other_steps, a.other_warmup
                 t_leg = time.perf_counter()
-                o = main_htdemucs(b, comm) if w == "cfg5" else main_dualpath(b, comm)
+                try:                                        # a failing leg must not lose the cfg-2 line measured above
+                    o = main_htdemucs(b, comm) if w == "cfg5" else main_dualpath(b, comm)
+                except Exception as e:                      # noqa: BLE001
+                    legs.append({"workload": w, "error": f"{type(e).__name__}: {e}"[:400], "leg_wall_s": round(time.perf_counter() - t_leg, 1)})
+                    continue
                 leg = {"workload": o["config"]["workload"], "metric": o["metric"], "steps": o["steps"], "warmup": o["warmup"],
                        "ms_per_step": o["ms_per_step"], "value": o["value"], "unit": o["unit"], "launch": o["config"]["launch"],
                        "roofline": o["roofline"], "leg_wall_s": round(time.perf_counter() - t_leg, 1)}

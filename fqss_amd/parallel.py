@@ -19,23 +19,32 @@ class CommError(RuntimeError):
 
 
 class Comm:
-    """What happens when the exchange fails (a peer died, a link error, a hang): the collective raises on the surviving ranks -- at once
-    when the transport notices (gloo: the peer's socket closes; RCCL: the communicator is aborted by its watchdog, which
-    TORCH_NCCL_ASYNC_ERROR_HANDLING=1, set below unless the caller chose otherwise, arms), after FQSS_DIST_TIMEOUT_S (default 600 s) at
-    the latest -- and is re-raised as CommError naming the rank and the operation.  Nothing is retried and nothing is restarted in
-    place: a step whose gradients were not averaged must not reach the optimizer, and a process that has initialised the GPU must never
+    """What happens when the exchange fails (a peer died, a link error, a hang).  gloo (CPU ranks, the GPU tests' transport): the
+    collective is synchronous, it raises on the surviving ranks as soon as the peer's socket closes (after FQSS_DIST_TIMEOUT_S,
+    default 600 s, at the latest) and is re-raised as CommError naming the rank and the operation.  RCCL ("nccl"): `dist.all_reduce` only
+    ENQUEUES the collective on the communication stream, so `_run` sees enqueue-time errors only (-> CommError); a failure while the
+    collective is in flight is found by the process group's watchdog, and TORCH_NCCL_ASYNC_ERROR_HANDLING=1 (TearDown mode, set below
+    unless the caller chose otherwise) makes it abort the communicator and END THE PROCESS with SIGABRT -- no Python exception, no
+    CommError; launch.spawn_ranks / torch.distributed.run see the non-zero exit and end the other ranks.  Either way nothing is retried
+    and nothing is restarted in place: a step whose gradients were not averaged must not reach the optimizer, and a process that has initialised the GPU must never
     be replaced by another (no exec on this pool); the rank exits non-zero, torch.distributed.run ends the job, and the job resumes
     from the last checkpoint (process.py) as a NEW launch."""
 
-    def __init__(self, rank=0, world=1, local_rank=0, backend=None):
+    def __init__(self, rank=0, world=1, local_rank=0, backend=None, force=False):
         self.rank, self.world, self.local_rank, self.backend = rank, world, local_rank, backend
+        # force: issue the collectives even at world 1 (FQSS_FORCE_DIST=1) -- a one-rank RCCL communicator really executes its
+        # all-reduce kernels on the communication stream, which is how the exchange schedule (bucket graphs, stream ordering, capture
+        # next to the process group's watchdog) is exercised on a one-GPU box (tests/test_gpu_ddp.py)
+        self.force = bool(force)
+        self.active = world > 1 or self.force
 
     @classmethod
     def from_env(cls, device_type="cuda"):
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if world > 1 and not dist.is_initialized():
+        force = os.environ.get("FQSS_FORCE_DIST", "0") == "1"
+        if (world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             # RCCL ("nccl" on ROCm) on GPUs; FQSS_DIST_BACKEND=gloo lets several ranks share one GPU in tests
@@ -45,8 +54,8 @@ class Comm:
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
             timeout = datetime.timedelta(seconds=float(os.environ.get("FQSS_DIST_TIMEOUT_S", "600")))
             dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
-            return cls(rank, world, local, backend)
-        return cls(rank, world, local, dist.get_backend() if dist.is_initialized() else None)
+            return cls(rank, world, local, backend, force)
+        return cls(rank, world, local, dist.get_backend() if dist.is_initialized() else None, force and dist.is_initialized())
 
     def _run(self, what, fn, *a, **kw):
         try:
@@ -57,22 +66,22 @@ class Comm:
             raise CommError(msg) from e
 
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if self.active:
             self._run("all_reduce(SUM)", dist.all_reduce, t, op=dist.ReduceOp.SUM)
         return t
 
     def all_reduce_max(self, t):
-        if self.world > 1:
+        if self.active:
             self._run("all_reduce(MAX)", dist.all_reduce, t, op=dist.ReduceOp.MAX)
         return t
 
     def broadcast(self, t, src=0):
-        if self.world > 1:
+        if self.active:
             self._run("broadcast", dist.broadcast, t, src)
         return t
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             self._run("barrier", dist.barrier)
 
     def shard(self, n_items):
@@ -83,7 +92,7 @@ class Comm:
     def sync_observer_ranges(self, model):
         """optional (NOT reference behaviour): average the activation ranges over ranks once the
         50-call observer phase ends, so every rank quantizes on the same grid"""
-        if self.world <= 1:
+        if not self.active:
             return
         from .quantization.qat.qat_quant import GradientActivationFakeQuantize
         rs = [m for m in model.modules() if isinstance(m, GradientActivationFakeQuantize)]

@@ -409,9 +409,11 @@ class KDTrainStep:
         # ---- backward segments = gradient buckets (world > 1 only: a single rank has nothing to overlap) -------------------
         self.segments = None        # [(arena lo, arena hi)] per segment in FORWARD order
         self._seg_ids = None
-        self._ranges_synced = not (sync_observer_ranges and self._world() > 1)
+        self._ranges_synced = not (sync_observer_ranges and self._exchange())
         params = list(model.parameters())
-        nb = (4 if buckets is None else int(buckets)) if self._world() > 1 else (int(buckets) if buckets else 1)
+        # FQSS_FORCE_BUCKETS=1 with a forced one-rank communicator (FQSS_FORCE_DIST=1): the bucketed schedule of world > 1 at world 1
+        force_b = os.environ.get("FQSS_FORCE_BUCKETS", "0") == "1" and self._exchange()
+        nb = (4 if buckets is None else int(buckets)) if (self._world() > 1 or force_b) else (int(buckets) if buckets else 1)
         if nb > 1 and hasattr(model, "fqss_segments"):
             segs = model.fqss_segments(nb)
             if len(segs) > 1:
@@ -587,7 +589,7 @@ class KDTrainStep:
     def _reduce_segment(self, k, nseg):
         """all-reduce(SUM) the gradient slice of backward segment k on the communication stream, behind everything enqueued on the
         current stream so far (RCCL over xGMI; the 1/world factor is folded into the clip+Adam kernel)"""
-        if self._world() <= 1:
+        if not self._exchange():
             return
         lo, hi = (0, self.arena.numel) if self.segments is None or nseg == 1 else self.segments[nseg - 1 - k]
         if self._cstream is None:
@@ -597,7 +599,7 @@ class KDTrainStep:
             self.comm.all_reduce_sum(self.arena.flat_g[lo:hi])
 
     def _join_reduces(self):
-        if self._world() > 1 and self._cstream is not None:
+        if self._exchange() and self._cstream is not None:
             torch.cuda.current_stream().wait_stream(self._cstream)
 
     def _quant_tables(self):
@@ -616,6 +618,10 @@ class KDTrainStep:
 
     def _world(self):
         return self.comm.world if self.comm is not None else 1
+
+    def _exchange(self):
+        """collectives are issued: world > 1, or a forced one-rank communicator (parallel.Comm.force)"""
+        return self.comm is not None and getattr(self.comm, "active", self.comm.world > 1)
 
     def _optimize(self, activate=True):
         if activate:
@@ -674,7 +680,7 @@ class KDTrainStep:
         # a segment's gradients is launched between two replays and overlaps the next one (no collective inside a graph)
         # (at world > 1 the process group's watchdog thread polls its events while this thread captures: only THIS thread's calls are
         # checked against the capture then -- torch's default mode lets a query from any thread invalidate it)
-        mode = dict(capture_error_mode="thread_local") if self._world() > 1 else {}
+        mode = dict(capture_error_mode="thread_local") if self._exchange() else {}
         # teacher_ahead: the teacher's forward is a graph of its OWN (own memory pool: it replays on the teacher stream WHILE the step's
         # graphs replay) from the static look-ahead mixture _sxn into _fest_next; the step's graphs read the static copy _fest_cur
         fest_cur = None
@@ -708,7 +714,7 @@ class KDTrainStep:
         # single rank, one segment: nothing has to happen between the two halves, so the whole step is ALSO captured as one graph
         # (replay() then costs one launch; replay_fwd_bwd / replay_optimize keep serving the trainers that may skip an update)
         self._graph_all = None
-        if self._world() == 1 and len(graphs) == 1 and os.environ.get("FQSS_ONE_GRAPH", "1") != "0":
+        if not self._exchange() and len(graphs) == 1 and os.environ.get("FQSS_ONE_GRAPH", "1") != "0":
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=graphs[0].pool()):
                 self.last_all, est, gest, cuts = self._forward_loss(self._sx, self._st, None, fest_cur, False)

@@ -53,6 +53,9 @@ def main():
     rank, world, port, out, scenario = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                       FQSS_DIST_BACKEND="gloo")
+    if scenario == "rccl1":
+        # ONE rank, RCCL ("nccl"), the world > 1 schedule forced on: process group, bucket graphs, the all-reduces really issued
+        os.environ.update(FQSS_DIST_BACKEND="nccl", FQSS_FORCE_DIST="1", FQSS_FORCE_BUCKETS="1")
     import torch
     from fqss_amd import ops
     from fqss_amd.parallel import Comm
@@ -119,6 +122,59 @@ def main():
             res["losses"] = losses
             res["flat_p"] = step.arena.flat_p.detach().cpu().clone()
             res["bucket_bytes"] = [4 * (hi - lo) for lo, hi in step.segments]
+        elif scenario == "rccl1":
+            # RCCL executes once.  Full-size cfg 2 on a one-rank "nccl" communicator with the bucketed schedule
+            # forced on: four backward-segment graphs, the all-reduce of every bucket issued through RCCL on the communication stream
+            # BETWEEN two replays (all-reduce(SUM) over one rank = identity), capture next to the process group's watchdog thread
+            # (capture_error_mode="thread_local").  The exchanged gradient must equal the un-exchanged one of the same state.
+            import torch.distributed as dist
+            from fqss_amd.data import synth_batch
+            from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
+            from fqss_amd.smoke import build_pair
+            assert comm.backend == "nccl" and comm.active and comm.world == 1 and dist.get_backend() == "nccl"
+            calls = []
+            inner = comm.all_reduce_sum
+            comm.all_reduce_sum = lambda t: (calls.append((t.numel(), torch.cuda.current_stream().cuda_stream)), inner(t))[1]
+            dev = torch.device("cuda", 0)
+            model, fmodel = build_pair(dev, 0, n_spks=2, kernel_size=16, stride=8)
+            x, tgt = synth_batch(8, 32000, seed=100, device=dev)
+            step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, comm=comm, teacher_ahead=True)
+            assert step.segments is not None and len(step.segments) == 4
+            step(x, tgt)
+            with torch.no_grad():
+                for _ in range(49):
+                    model(x)
+            assert all(m.n_iter >= 50 for m in model.modules() if isinstance(m, GradientActivationFakeQuantize))
+            step(x, tgt)                                  # eager quantizing step: 4 buckets through RCCL already
+            res["eager_calls"] = len(calls)
+            main = torch.cuda.current_stream().cuda_stream
+            assert all(s != main for _, s in calls)     # every collective was enqueued on the communication stream
+            ref = step._fwd_bwd(x, tgt)                   # same state, NO exchange: the reference gradient
+            g_ref, loss_ref = step.arena.flat_g.detach().clone(), ref["loss"].item()
+            step.capture(x, tgt, warmup=0)
+            res["n_graphs"] = len(step._graphs[0])
+            step.arena.flat_g.fill_(float("nan"))
+            del calls[:]
+            r = step.replay_fwd_bwd(x, tgt)
+            torch.cuda.synchronize()
+            res["replay_calls"] = [n for n, _ in calls]
+            res["bucket_elems"] = [hi - lo for lo, hi in step.segments]
+            res["loss_ref"], res["loss_replay"] = loss_ref, r["loss"].item()
+            g = step.arena.flat_g.detach()
+            res["finite"] = bool(torch.isfinite(g).all())
+            res["g_err"] = float((g - g_ref).norm() / g_ref.norm())
+            worst = 0.0
+            for p, o in zip(step.arena.params, step.arena.offsets):
+                a, b = g[o:o + p.numel()], g_ref[o:o + p.numel()]
+                nb_ = float(b.norm())
+                if nb_ > 1e-9:
+                    worst = max(worst, float((a - b).norm()) / nb_)
+            res["g_worst"] = worst
+            p0 = step.arena.flat_p.detach().clone()
+            x2, tgt2 = synth_batch(8, 32000, seed=200, device=dev)
+            X, TG = (x, x2), (tgt, tgt2)
+            res["losses"] = [step(X[i & 1], TG[i & 1], x_next=X[(i + 1) & 1])["loss"].item() for i in range(3)]
+            res["moved"] = float((step.arena.flat_p - p0).abs().max())
         else:
             # observer phase on per-rank data, then the one-time synchronisation of the observed activation ranges -- or, with
             # "observer_nosync", the reference's behaviour (qat_quant.py:230-232 writes .data, DDP never re-synchronises): every rank

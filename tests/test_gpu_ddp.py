@@ -163,3 +163,37 @@ def test_full_size_cfg2_two_ranks_replay_like_bench(tmp_path):
     assert torch.equal(ranks[0]["flat_p"], ranks[1]["flat_p"])
     assert all(np.isfinite(l) for r in ranks for l in r["losses"])
     print("bench2: buckets (bytes)", ranks[0]["bucket_bytes"], "losses", ranks[0]["losses"], ranks[1]["losses"])
+
+
+def test_rccl_executes_the_bucketed_exchange_at_world_one(tmp_path):
+    """RCCL itself (backend "nccl"), on the one GPU this pool has: a one-rank communicator with the world > 1 schedule forced on
+    (FQSS_FORCE_DIST=1, FQSS_FORCE_BUCKETS=1) -- full-size cfg 2, four backward-segment graphs, the four bucket all-reduces issued
+    through RCCL on the communication stream between the replays, captured next to the process group's watchdog.  all-reduce(SUM)
+    over one rank is the identity, so the exchanged gradient must equal the un-exchanged gradient of the same state: a collective that
+    ran before its bucket was written, or a replay that did not wait for it, shows up as NaN (the arena is poisoned) or a wrong slice.
+    Reference: NCCL under DDP (train_env/htdemucs_musdbhq/distrib.py:51-59, asteroid_librimix_trainer.py:125-135)."""
+    r, = _run_ranks(tmp_path, "rccl1", world=1)
+    print("rccl1:", {k: v for k, v in r.items()})
+    assert r["n_graphs"] == 4 and r["eager_calls"] >= 4
+    assert r["replay_calls"] == list(reversed(r["bucket_elems"]))        # one collective per bucket, last segment first, whole slices
+    assert r["finite"] and abs(r["loss_replay"] - r["loss_ref"]) <= 1e-6 * abs(r["loss_ref"])
+    assert r["g_err"] <= 1e-4 and r["g_worst"] <= 2e-4, (r["g_err"], r["g_worst"])
+    assert all(np.isfinite(r["losses"])) and r["moved"] > 0
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (the driver's own command form): bench.py starts the two ranks itself
+    (fqss_amd/launch.py; reference: pl.Trainer(strategy="ddp", devices="auto"), asteroid_librimix_trainer.py:125-135, and the tasnet env's
+    Popen per GPU, tasnet_musdbhq_trainer.py:17-30) before touching the GPU, rank 0 prints the ONE JSON line.  Both ranks share GPU 0
+    here, so the transport is gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(FQSS_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 16 and o["scaling"] == "weak"
+    assert "4 backward segments" in o["config"]["launch"] and o["value"] > 0 and "roofline" in o

@@ -271,6 +271,54 @@ def test_exchange_failure_raises_and_ends_the_rank():
     assert ps[0].exitcode == 7 and ps[1].exitcode == 3
 
 
+_RANK_SCRIPT = """
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "allreduce":
+    import torch
+    from fqss_amd.parallel import Comm
+    os.environ["FQSS_DIST_BACKEND"] = "gloo"
+    c = Comm.from_env("cpu")
+    t = torch.tensor([float(r + 1)])
+    c.all_reduce_sum(t)
+    c.barrier()
+    if r == 0:
+        print("SUM", t.item(), "WORLD", c.world, flush=True)
+    else:
+        print("this line must not reach the parent's stdout", flush=True)
+    c.close()
+elif mode == "die":
+    if r == 1:
+        sys.exit(5)
+    time.sleep(120)          # a rank that would wait forever for its dead peer: the launcher must end it
+"""
+
+
+def test_launcher_starts_ranks_and_propagates_a_failing_rank(tmp_path):
+    """fqss_amd/launch.spawn_ranks (what `bench.py --gpus N` and `python -m fqss_amd.train` use when no launcher is around them; reference:
+    tasnet_musdbhq_trainer.py:17-57 -- one Popen per GPU, every rank ended when one dies): rank environment, rendezvous over gloo,
+    rank 0 alone owns stdout; a rank that exits non-zero ends the others and its code is the launcher's."""
+    import subprocess
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    drive = ("import sys; from fqss_amd.launch import spawn_ranks, already_launched; assert not already_launched(); "
+             "sys.exit(spawn_ranks(2, [sys.executable, %r, sys.argv[1]], grace_s=3.0))" % str(script))
+    p = subprocess.run([sys.executable, "-c", drive, "allreduce"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if not l.startswith("[Gloo]")]       # (gloo announces its connections on stdout)
+    assert lines == ["SUM 3.0 WORLD 2"], p.stdout
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", drive, "die"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 5 and "rank 1 of 2 exited with 5" in p.stderr, (p.returncode, p.stderr[-500:])
+    assert time.time() - t0 < 60          # rank 0 did not sleep its 120 s out
+
+
 def test_checkpoint_interchange_lightning_ckpt(tmp_path):
     """a Lightning `.ckpt` of the asteroid env ({"state_dict": {"model.<key>", "fmodel.<key>"}}) loads through
     `load_pretrain`'s order-based mapping with the teacher's entries dropped (convtasnetq.py:225-237); `create_pretrained_model`
