@@ -46,6 +46,8 @@ _PROTOS = {
     "fqss_qpw_fwd2": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_x2": [P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_w2": [P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
+    "fqss_qpw_bwd_w_group_ws": [P, I32],
+    "fqss_qpw_bwd_w_group": [P, I32, P, I64, P],
     "fqss_decode": [P, P, I64, I64, I64, I64, P, P, P],
     "fqss_gnq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P, I32, P],
     "fqss_gnq_bwd": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],
@@ -184,7 +186,7 @@ _PROTOS = {
     "fqss_gln_fq_fwd": [P, P, P, P, F32, P, P, P, P, P, C.c_size_t, P, I32, P],
     "fqss_tgemm_desc": [P, P],
 }
-_RESTYPE = {"fqss_last_error": C.c_char_p, "fqss_workspace_bytes": C.c_int64}
+_RESTYPE = {"fqss_last_error": C.c_char_p, "fqss_workspace_bytes": C.c_int64, "fqss_qpw_bwd_w_group_ws": C.c_int64}
 
 DT_F32, DT_U8, DT_I8, DT_F64, DT_U16, DT_I64 = range(6)
 
@@ -199,6 +201,12 @@ class FqssQParams(C.Structure):
 
 class FqssWCodes(C.Structure):
     _fields_ = [("idx", C.c_void_p), ("idxT", C.c_void_p), ("dw", C.c_void_p), ("rw", C.c_void_p), ("Co", C.c_int), ("Ci", C.c_int)]
+
+
+class FqssWgradJob(C.Structure):
+    _fields_ = [("gz1", C.c_void_p), ("gz2", C.c_void_p), ("xc", C.c_void_p), ("qmin_x", C.c_void_p), ("qmax_x", C.c_void_p),
+                ("gw", C.c_void_p), ("B", C.c_int32), ("Ci", C.c_int32), ("Co1", C.c_int32), ("Co2", C.c_int32), ("M", C.c_int32),
+                ("ld_gz1", C.c_int64), ("ld_gz2", C.c_int64), ("ld_xc", C.c_int64)]
 
 
 class FqssProducer(C.Structure):

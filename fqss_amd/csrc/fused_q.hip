@@ -163,6 +163,70 @@ __global__ __launch_bounds__(256) void k_gnq_apply(const uint8_t* __restrict__ x
     }
 }
 
+// The same layer as a TABLE LOOKUP (round 5).  Per (b, c) row `scale` / `shift` are constants and the input is a u8 code, so the
+// output code is a 256-entry function of the input code: thread t evaluates fq_code(fmaf(dec(t), scale, shift), ry) ONCE per row for
+// code t = threadIdx.x (the arithmetic of k_gnq_apply, hence bit-identical), the bytes go to a 256-B LDS table (64 dwords = one per
+// bank: any two lanes on one bank read the same dword, which the LDS broadcasts -- conflict-free for every input), and the row is
+// out = T[in]: bfe + ds_read_u8 + or per element instead of ~25 VALU instructions (these kernels are VALU-issue bound).
+// A workgroup owns RPW consecutive rows of ONE sample (host: C % RPW == 0): all their code loads are issued first, the tables of
+// all RPW rows are computed while they fly, one barrier.  Rows longer than 4096 positions loop.
+template <int RPW>
+__global__ __launch_bounds__(256) void k_gnq_apply_t(const uint8_t* __restrict__ xc, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, uint8_t* __restrict__ yc,
+                                                      float* __restrict__ yout, float* __restrict__ mean_rstd,
+                                                      const long long* __restrict__ ws, int nslots, float eps, int B, int C,
+                                                      int M, int64_t ld_xc, int64_t ld_yc, int64_t ld_o, const float* qmin_x,
+                                                      const float* qmax_x, const float* qmin, const float* qmax) {
+    __shared__ long long red[2 * 4];
+    __shared__ float mr[2];
+    __shared__ __attribute__((aligned(16))) uint8_t tab[RPW][256];
+    const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
+    const int row0 = blockIdx.x * RPW;                 // rows row0 .. row0 + RPW - 1, all of sample b
+    const int b = row0 / C, c0 = row0 - b * C;
+    const int m_first = threadIdx.x * 16;
+    uint4 v0[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        v0[r] = make_uint4(0, 0, 0, 0);
+        if (m_first < M) v0[r] = *reinterpret_cast<const uint4*>(xc + (int64_t)(row0 + r) * ld_xc + m_first);
+    }
+    gnq_sample_stats(ws, nslots, b, (int64_t)C * M, eps, rx, red, mr);
+    if (c0 == 0 && threadIdx.x == 0) {   // saved for the backward
+        mean_rstd[2 * b] = mr[0];
+        mean_rstd[2 * b + 1] = mr[1];
+    }
+    const float mean = mr[0], rstd = mr[1];
+    const float xt = dec(threadIdx.x, rx);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const float scale = rstd * gamma[c0 + r];
+        const float shift = fmaf(-scale, mean, beta[c0 + r]);
+        tab[r][threadIdx.x] = (uint8_t)fq_code(fmaf(xt, scale, shift), ry);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const uint8_t* xr = xc + (int64_t)(row0 + r) * ld_xc;
+        uint8_t* yr = yc + (int64_t)(row0 + r) * ld_yc;
+        for (int m = m_first; m < M; m += 4096) {
+            const uint4 v = (m == m_first) ? v0[r] : *reinterpret_cast<const uint4*>(xr + m);
+            const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned int t0 = tab[r][w[q] & 255u], t1 = tab[r][(w[q] >> 8) & 255u], t2 = tab[r][(w[q] >> 16) & 255u],
+                                   t3 = tab[r][w[q] >> 24];
+                o[q] = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);
+                if (yout != nullptr && m + 4 * q < M)   // (block-uniform pointer test)
+                    *reinterpret_cast<float4*>(yout + (int64_t)(row0 + r) * ld_o + m + 4 * q) =
+                        make_float4(ry.delta * (float)t0 + ry.lo, ry.delta * (float)t1 + ry.lo, ry.delta * (float)t2 + ry.lo,
+                                    ry.delta * (float)t3 + ry.lo);
+            }
+            *reinterpret_cast<uint4*>(yr + m) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // backward pass 1: per (b,c) row: recompute z and the STE, ds = sum gz*x, db = sum gz; range partials to gacc slots
 __global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict__ xc, const float* __restrict__ g,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1375,6 +1439,19 @@ extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float*
         stats = (const int64_t*)ws;
     }
     const int64_t rows = (int64_t)B * C;
+    // FQSS_GNQ_APPLY_V1=1: the per-element form of rounds 1-4 (kept for the bit-identity gate, tests/test_gpu_kernels.py)
+    const char* e_v1 = getenv("FQSS_GNQ_APPLY_V1");      // read per call: a test flips it inside one process
+    const bool v1 = e_v1 && e_v1[0] == '1';
+    if (!v1 && rows < (1ll << 30)) {   // code-indexed LDS tables, RPW rows of one sample per workgroup (>= 2 workgroups per CU kept)
+#define FQSS_GNQ_T(RPW)                                                                                                              \
+    hipLaunchKernelGGL(k_gnq_apply_t<RPW>, dim3((unsigned)(rows / RPW)), dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd,      \
+                       (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_yc, ld_out, qmin_x, qmax_x, qmin, qmax)
+        if (rows >= 2048 && C % 4 == 0) FQSS_GNQ_T(4);
+        else if (rows >= 1024 && C % 2 == 0) FQSS_GNQ_T(2);
+        else FQSS_GNQ_T(1);
+#undef FQSS_GNQ_T
+        return launch_status("fqss_gnq_fwd");
+    }
     const int rpw = (rows >= 2048 && M <= 4096) ? 4 : 1;     // rows per workgroup (keep >= 2 workgroups per CU)
     dim3 grid = grid_rows(cdiv(rows, rpw), M, 16);
     hipLaunchKernelGGL(k_gnq_apply, grid, dim3(256), 0, s, xc, gamma, beta, yc, yout, mean_rstd,

@@ -828,6 +828,244 @@ __global__ __launch_bounds__(512, 1) void k_qwgrad2(QGemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad, GROUPED (round 5): the weight gradients of SEVERAL layers in one launch, no atomics, bit-reproducible.
+//
+// The weight gradients of a backward segment feed nothing but the optimizer, so they need not run where autograd reaches them: the
+// host queues (gz, codes, gw) per layer and launches them together when the segment is done (runtime.QuantTables.finish_backward).
+// One launch = up to WGR_MAXJOBS layers.  A layer's output is cut into the 64 x 128 tiles of k_qwgrad2; its reduction index (batch x
+// frames) into 64-frame STAGES; eight tiles form a tile GROUP (conv1 128 -> 512: its 8 row tiles; the res | skip pair: 2 row tiles x 4
+// column tiles), and the work list is the sequence of (layer, tile group, stage) UNITS.  The grid is 32 TEAMS of 8 workgroups, one
+// workgroup per CU, the 8 of a team on ONE XCD (they stream the same gz rows / code rows at about the same time: the re-reads come
+// from that XCD's L2, as with k_qwgrad2's xcd_tile order).  Team t owns the contiguous unit range [t * chunk, (t + 1) * chunk)
+// (stream-K): its member m accumulates tile m of every group it meets, over the stages of the range that fall into that group --
+// hundreds of stages per workgroup, so the ~9 us of fixed cost per launch and the ramp of the load ring are paid once per launch
+// instead of once per layer.  A group cut by a range boundary is finished by 2-3 teams: each publishes its partial tile to a slab
+// slot (thread-major float4 rows, write-through `sc1` stores, every wave's vmcnt(0), workgroup barrier, ONE agent-scope ticket add
+// per workgroup -- the split-K seam recipe of MI355X_MICROARCH.md), and the workgroup whose ticket came last sums the slots IN PART
+// ORDER (sc1 loads) and adds the result to gw with plain read-modify-writes: no float atomics, and the same bits every run
+// (k_qwgrad2 issues 2.1 M float atomics per launch: 7.6 of its 31 us, and the source of the step's run-to-run noise).
+constexpr int WGR_MAXJOBS = 16, WGR_TEAM = 8, WGR_TEAMS = 32, WGR_SLOT_FLOATS = W2_TM * W2_TN;
+struct WJob {
+    const float* A; const float* A2; const unsigned char* Bc; float* C; const float* qmin; const float* qmax;
+    int64_t lda, lda2, ldb, sAb, sA2b, sBb;
+    int M, M1, N, K;                      // Co1 + Co2, Co1, Ci, frames
+    int tiles_n, ntiles, spb, nstages;    // column tiles, tiles, stages per batch, stages per tile (= batches * spb)
+    int ubeg, tile0;                      // first unit of this job; global index of its tile 0 (ticket / slab addressing)
+};
+struct WGroupArgs {
+    int njobs, chunk, total, slots;       // units per team, units in all, slab slots per tile
+    unsigned* tickets; float* slabs;
+    WJob j[WGR_MAXJOBS];
+};
+__device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld16_sc1(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory"); }
+
+template <int GP>
+__global__ __launch_bounds__(512, 1) void k_qwgrad_group(WGroupArgs ga) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][GP][W2_TM][W2_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][W2_TN][W2_LD];
+    __shared__ float rsum[W2_TM];
+    __shared__ unsigned ticket_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3, lr = lane & 31, lh = lane >> 5;
+    const int L = blockIdx.x, xcd = L % kXcds, slot = L / kXcds;                 // 32 workgroups per XCD: 4 teams of 8
+    const int team = (slot / WGR_TEAM) * kXcds + xcd, member = slot % WGR_TEAM;
+    const int ar = tid >> 4, ac = (tid & 15) * 4;      // loader geometry of k_qwgrad2
+    const int br = tid >> 2, bc = (tid & 3) * 16;
+    const bool first_half = wave < 4;
+
+    int u0 = team * ga.chunk;
+    const int u1 = min(ga.total, u0 + ga.chunk);
+    while (u0 < u1) {
+        int jn = 0;
+        for (int q = 1; q < ga.njobs; ++q) jn = (ga.j[q].ubeg <= u0) ? q : jn;
+        const WJob& J = ga.j[jn];
+        const int rel = u0 - J.ubeg, grp = rel / J.nstages, s0 = rel - grp * J.nstages;
+        const int n = min(J.nstages - s0, u1 - u0);
+        const int g0 = J.ubeg + grp * J.nstages;                                   // the group's unit range -> which teams share it
+        const int t_first = g0 / ga.chunk, nparts = (g0 + J.nstages - 1) / ga.chunk - t_first + 1, part = team - t_first;
+        u0 += n;
+        const int tile = grp * WGR_TEAM + member;
+        if (tile >= J.ntiles) continue;                                            // (workgroup-uniform)
+        const int row0 = (tile / J.tiles_n) * W2_TM, col0 = (tile % J.tiles_n) * W2_TN;
+        const int K = J.K, spb = J.spb, nb = J.nstages / J.spb;
+        const int ka_last = (K - 1) & ~3, kb_last = (K - 1) & ~15;
+        // ---- loader / converter state: the stage sequence runs over (batch, 64-frame chunk)
+        const float* Arow[2];
+        int64_t asb[2];
+        bool aok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + ar + 32 * i;
+            aok[i] = row < J.M;
+            const int rc = aok[i] ? row : 0;
+            Arow[i] = (rc < J.M1) ? J.A + (int64_t)rc * J.lda : J.A2 + (int64_t)(rc - J.M1) * J.lda2;
+            asb[i] = (rc < J.M1) ? J.sAb : J.sA2b;
+        }
+        const unsigned char* Brow = J.Bc + (int64_t)min(col0 + br, J.N - 1) * J.ldb;
+        const int64_t sBb = J.sBb;
+        int lb = s0 / spb, lk = (s0 - lb * spb) * W2_TK;      // loader position
+        int ck = lk, cr = 0;                                   // converter: frame position inside its batch, relative stage
+        const float* Ap[2] = {Arow[0] + lb * asb[0], Arow[1] + lb * asb[1]};
+        const unsigned char* Bp = Brow + lb * sBb;
+        auto load = [&](W2Stage& st) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wg_load16(st.a[i], Ap[i] + min(lk + ac, ka_last));
+            wg_load16(st.b, Bp + min(lk + bc, kb_last));
+            lk += W2_TK;
+            if (lk >= spb * W2_TK) {       // next batch (clamped: stages behind the range are requested but never used)
+                lk = 0;
+                lb = min(lb + 1, nb - 1);
+                Ap[0] = Arow[0] + lb * asb[0];
+                Ap[1] = Arow[1] + lb * asb[1];
+                Bp = Brow + lb * sBb;
+            }
+        };
+        float rs_part[2] = {0.f, 0.f};
+        auto convert_store = [&](W2Stage& st, int buf) {
+            const bool live = cr < n;
+            const int k = ck + ac;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (aok[i] && live && k + e < K) ? st.a[i][e] : 0.0f;
+                rs_part[i] += (x[0] + x[1]) + (x[2] + x[3]);
+                uint32_t o1[2], o2[2], o3[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float a0 = x[2 * e], a1 = x[2 * e + 1];
+                    const float r0 = a0 - bf_trunc(a0), r1 = a1 - bf_trunc(a1);
+                    o1[e] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+                    if constexpr (GP == 3) {
+                        const float q0 = r0 - bf_trunc(r0), q1 = r1 - bf_trunc(r1);
+                        o2[e] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                        o3[e] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                    } else {
+                        o2[e] = __builtin_amdgcn_perm(bf_rne_word(r1), bf_rne_word(r0), 0x07060302u);
+                    }
+                }
+                const int row = ar + 32 * i;
+                *reinterpret_cast<uint2*>(&As[buf][0][row][ac]) = make_uint2(o1[0], o1[1]);
+                *reinterpret_cast<uint2*>(&As[buf][1][row][ac]) = make_uint2(o2[0], o2[1]);
+                if constexpr (GP == 3) *reinterpret_cast<uint2*>(&As[buf][2][row][ac]) = make_uint2(o3[0], o3[1]);
+            }
+            {   // codes need no mask: finite, and where gz is masked they only ever meet a zero
+                uint32_t o[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t w = st.b[q];
+                    const float f0 = (float)(w & 0xFFu), f1 = (float)((w >> 8) & 0xFFu);
+                    const float f2 = (float)((w >> 16) & 0xFFu), f3 = (float)(w >> 24);
+                    o[2 * q] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                    o[2 * q + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+                }
+                *reinterpret_cast<uint4*>(&Bs[buf][br][bc]) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(&Bs[buf][br][bc + 8]) = make_uint4(o[4], o[5], o[6], o[7]);
+            }
+            ++cr;
+            ck += W2_TK;
+            if (ck >= spb * W2_TK) ck = 0;
+        };
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        auto compute = [&](int buf) {
+#pragma unroll
+            for (int ks = 0; ks < W2_TK / 16; ++ks) {
+                const int kk = ks * 16 + 8 * lh;
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[buf][wc * 32 + lr][kk]);
+                bf16x8 af[GP];
+#pragma unroll
+                for (int p = 0; p < GP; ++p) af[p] = *reinterpret_cast<const bf16x8*>(&As[buf][p][wr * 32 + lr][kk]);
+#pragma unroll
+                for (int p = GP - 1; p >= 0; --p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p], bfr, acc, 0, 0, 0);
+            }
+        };
+        W2Stage st[W2_RING];
+#pragma unroll
+        for (int i = 0; i < W2_RING; ++i) load(st[i]);
+        w2_wait<3 * (W2_RING - 1)>(st[0]);
+        convert_store(st[0], 0);
+        load(st[0]);
+        __syncthreads();
+        for (int s = 0; s < n; s += W2_RING) {      // stages at or behind n are converted to zeros (cr >= n)
+#pragma unroll
+            for (int i = 0; i < W2_RING; ++i) {
+                W2Stage& nx = st[(i + 1) % W2_RING];
+                if (first_half) compute(i & 1);
+                w2_wait<3 * (W2_RING - 1)>(nx);
+                convert_store(nx, (i + 1) & 1);
+                load(nx);
+                if (!first_half) compute(i & 1);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W2_RING; ++i) w2_wait<0>(st[i]);
+        // ---- this workgroup's share of the tile: dx * S + min_x * rowsum(gz)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = rs_part[i];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 15) == 0) rsum[ar + 32 * i] = v;
+        }
+        __syncthreads();
+        const float lo = *J.qmin, hi = *J.qmax;
+        const float dx = (hi - lo) / 255.0f, mnx = lo;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = dx * acc[r] + mnx * rsum[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        bool finish = nparts == 1;
+        if (!finish) {
+            float* sl = ga.slabs + ((int64_t)(J.tile0 + tile) * ga.slots + part) * WGR_SLOT_FLOATS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st16_sc1(sl + ((int64_t)q * 512 + tid) * 4, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) ticket_s = __hip_atomic_fetch_add(&ga.tickets[J.tile0 + tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            finish = ticket_s == (unsigned)(nparts - 1);
+            if (finish) {       // the last to arrive: every part is published; sum them in part order (its own included: same bits whoever is last)
+                const float* s0p = ga.slabs + (int64_t)(J.tile0 + tile) * ga.slots * WGR_SLOT_FLOATS;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.0f;
+                for (int p = 0; p < nparts; ++p) {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ld16_sc1(t[q], s0p + (int64_t)p * WGR_SLOT_FLOATS + ((int64_t)q * 512 + tid) * 4);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : : "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * q + e] += t[q][e];
+                }
+                if (tid == 0) __hip_atomic_store(&ga.tickets[J.tile0 + tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+            }
+        }
+        if (finish) {       // gw += tile: this workgroup is the tile's only writer; all 16 reads first (one round trip, not 16)
+            const int col = col0 + wc * 32 + lr;
+            const int Mr = J.M, Nc = J.N;
+            float* const Cp = J.C;
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                old[r] = (row < Mr && col < Nc) ? Cp[(int64_t)row * Nc + col] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < Mr && col < Nc) Cp[(int64_t)row * Nc + col] = old[r] + v[r];
+            }
+        }
+        __syncthreads();     // rsum / ticket_s / the LDS stages are reused by the next segment
+    }
+}
+
 // per-channel weight codes for the q-GEMMs: idx [Co][Ci], idxT [Ci][Co], dw[Co], rw[Co] (one block per channel)
 __global__ __launch_bounds__(256) void k_wq_codes(const float* __restrict__ w, signed char* __restrict__ idx,
                                                    signed char* __restrict__ idxT, float* dw, float* rw, int Co, int Ci,
@@ -1038,6 +1276,82 @@ extern "C" int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t
                                fqss_stream_t stream) {
     FQSS_REQUIRE(Co2 > 0, "second layer missing");
     return qpw_bwd_w_impl("fqss_qpw_bwd_w2", gz1, gz2, xc, qmin_x, qmax_x, gw, B, Ci, Co1, Co2, M, ld_gz1, ld_gz2, ld_xc, stream);
+}
+
+// ---- grouped weight gradients (k_qwgrad_group): workspace = [64 KB of tickets, zero when first used, left zero][slab slots]
+constexpr int64_t WGR_TICKET_BYTES = 65536;
+static int wgr_plan(const FqssWgradJob* jobs, int n0, int n, WGroupArgs& ga, int64_t& slab_bytes) {
+    int u = 0, t = 0, max_st = 0;
+    ga.njobs = n;
+    for (int q = 0; q < n; ++q) {
+        const FqssWgradJob& f = jobs[n0 + q];
+        WJob& J = ga.j[q];
+        const int Co = f.Co1 + f.Co2;
+        J.A = f.gz1; J.A2 = f.gz2; J.Bc = f.xc; J.C = f.gw; J.qmin = f.qmin_x; J.qmax = f.qmax_x;
+        J.lda = f.ld_gz1; J.lda2 = f.ld_gz2; J.ldb = f.ld_xc;
+        J.sAb = (int64_t)f.Co1 * f.ld_gz1; J.sA2b = (int64_t)f.Co2 * f.ld_gz2; J.sBb = (int64_t)f.Ci * f.ld_xc;
+        J.M = Co; J.M1 = f.Co1; J.N = f.Ci; J.K = f.M;
+        J.tiles_n = (int)cdiv(f.Ci, W2_TN);
+        J.ntiles = (int)cdiv(Co, W2_TM) * J.tiles_n;
+        J.spb = (int)cdiv(f.M, W2_TK);
+        J.nstages = f.B * J.spb;
+        J.ubeg = u; J.tile0 = t;
+        u += (int)cdiv(J.ntiles, WGR_TEAM) * J.nstages;
+        t += J.ntiles;
+        if (J.nstages > max_st) max_st = J.nstages;
+    }
+    ga.total = u;
+    ga.chunk = (int)cdiv(u, WGR_TEAMS);
+    ga.slots = (max_st - 1) / ga.chunk + 2;
+    slab_bytes = (int64_t)t * ga.slots * WGR_SLOT_FLOATS * 4;
+    return t;
+}
+static int wgr_check(const FqssWgradJob* jobs, int njobs) {
+    FQSS_REQUIRE(jobs && njobs > 0, "no jobs");
+    for (int q = 0; q < njobs; ++q) {
+        const FqssWgradJob& f = jobs[q];
+        FQSS_REQUIRE(f.gz1 && f.xc && f.qmin_x && f.qmax_x && f.gw && (f.Co2 == 0 || f.gz2), "null tensor");
+        FQSS_REQUIRE(f.B > 0 && f.Ci > 0 && f.Co1 > 0 && f.Co2 >= 0 && f.M > 0 && f.ld_gz1 >= f.M && f.ld_xc >= f.M, "bad shape");
+        FQSS_REQUIRE(f.ld_gz1 % 4 == 0 && f.ld_xc % 16 == 0 && aligned16(f.gz1) && aligned16(f.xc) && f.ld_gz1 >= ((f.M + 3) & ~3),
+                     "q-GEMM wgrad needs 16-B aligned gradient and code rows");
+        FQSS_REQUIRE(f.Co2 == 0 || (f.ld_gz2 % 4 == 0 && aligned16(f.gz2) && f.ld_gz2 >= ((f.M + 3) & ~3)), "second gradient: 16-B aligned rows");
+        FQSS_REQUIRE((int64_t)f.B * cdiv(f.M, W2_TK) * cdiv(cdiv(f.Co1 + f.Co2, W2_TM) * cdiv(f.Ci, W2_TN), WGR_TEAM) < (1ll << 26), "job too large");
+        for (int p = 0; p < q; ++p) FQSS_REQUIRE(jobs[p].gw != f.gw, "two jobs of one call accumulate into the same gw (plain read-modify-write)");
+    }
+    return FQSS_OK;
+}
+
+extern "C" int64_t fqss_qpw_bwd_w_group_ws(const FqssWgradJob* jobs, int njobs) {
+    if (wgr_check(jobs, njobs) != FQSS_OK) return -1;
+    int64_t need = 0;
+    for (int n0 = 0; n0 < njobs; n0 += WGR_MAXJOBS) {
+        WGroupArgs ga{};
+        int64_t sb = 0;
+        const int t = wgr_plan(jobs, n0, njobs - n0 < WGR_MAXJOBS ? njobs - n0 : WGR_MAXJOBS, ga, sb);
+        if ((int64_t)t * 4 > WGR_TICKET_BYTES) { set_error("fqss_qpw_bwd_w_group_ws: more than 16384 tiles in one launch"); return -1; }
+        if (sb > need) need = sb;
+    }
+    return WGR_TICKET_BYTES + need;
+}
+
+extern "C" int fqss_qpw_bwd_w_group(const FqssWgradJob* jobs, int njobs, void* ws, int64_t ws_bytes, fqss_stream_t stream) {
+    if (njobs == 0) return FQSS_OK;
+    if (int rc = wgr_check(jobs, njobs)) return rc;
+    FQSS_REQUIRE(ws && aligned16(ws), "workspace: 16-B aligned device memory (fqss_qpw_bwd_w_group_ws bytes, zero-filled when first used)");
+    for (int n0 = 0; n0 < njobs; n0 += WGR_MAXJOBS) {
+        WGroupArgs ga{};
+        int64_t sb = 0;
+        const int t = wgr_plan(jobs, n0, njobs - n0 < WGR_MAXJOBS ? njobs - n0 : WGR_MAXJOBS, ga, sb);
+        FQSS_REQUIRE((int64_t)t * 4 <= WGR_TICKET_BYTES && WGR_TICKET_BYTES + sb <= ws_bytes, "workspace too small (fqss_qpw_bwd_w_group_ws)");
+        ga.tickets = (unsigned*)ws;
+        ga.slabs = (float*)((char*)ws + WGR_TICKET_BYTES);
+        if (grad_pieces() == 3)
+            hipLaunchKernelGGL(k_qwgrad_group<3>, dim3(WGR_TEAMS * WGR_TEAM), dim3(512), 0, (hipStream_t)stream, ga);
+        else
+            hipLaunchKernelGGL(k_qwgrad_group<2>, dim3(WGR_TEAMS * WGR_TEAM), dim3(512), 0, (hipStream_t)stream, ga);
+        if (int rc = launch_status("fqss_qpw_bwd_w_group")) return rc;
+    }
+    return FQSS_OK;
 }
 
 // plain fp32 pointwise conv z = W x + b on the bf16 matrix cores: both operands split exactly in three; all nine partial products

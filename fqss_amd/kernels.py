@@ -504,6 +504,43 @@ def qpw_bwd_w2(gz1, gz2, xc, qmin_x, qmax_x, gw):
               _stream())
 
 
+class WgradQueue:
+    """Weight-gradient launches of quantized 1x1 convolutions, queued during a backward segment and run together by ONE grouped
+    launch per <= 16 layers (fqss_qpw_bwd_w_group: no float atomics, bit-reproducible): their results feed nothing but the
+    optimizer.  The queue keeps gz / codes alive until flush(); the workspace (arrival tickets + slab slots) belongs to the queue and
+    is allocated once -- flush() of a later step (and of a hipGraph capture) finds it in place."""
+
+    def __init__(self):
+        self.jobs, self.ws = [], None
+
+    def push(self, gz1, gz2, xc, qmin_x, qmax_x, gw):
+        gz1, ld1 = _aligned_grad(gz1)
+        ld2 = 0
+        if gz2 is not None:
+            gz2, ld2 = _aligned_grad(gz2)
+        assert gw.is_contiguous()
+        self.jobs.append((gz1, gz2, xc, qmin_x, qmax_x, gw, ld1, ld2))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        n = len(self.jobs)
+        arr = (_lib.FqssWgradJob * n)()
+        for j, (gz1, gz2, xc, lo, hi, gw, ld1, ld2) in zip(arr, self.jobs):
+            B, Co1, M = gz1.shape
+            j.gz1, j.gz2, j.xc, j.qmin_x, j.qmax_x, j.gw = _p(gz1), _p(gz2), _p(xc), _p(lo), _p(hi), _p(gw)
+            j.B, j.Ci, j.Co1, j.Co2, j.M = B, xc.shape[1], Co1, (gz2.shape[1] if gz2 is not None else 0), M
+            j.ld_gz1, j.ld_gz2, j.ld_xc = ld1, ld2, rowmat(xc)[2]
+            assert gw.numel() == (j.Co1 + j.Co2) * j.Ci
+        need = _lib.query("fqss_qpw_bwd_w_group_ws", arr, n)
+        if need < 0:
+            raise _lib.FqssError("fqss_qpw_bwd_w_group_ws: " + _lib.load().fqss_last_error().decode())
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.zeros(need, dtype=torch.uint8, device=self.jobs[0][0].device)      # tickets start at zero; every launch leaves them zero
+        _lib.call("fqss_qpw_bwd_w_group", arr, n, _p(self.ws), self.ws.numel(), _stream())
+        self.jobs = []
+
+
 def _codes3(xc):
     """u8 codes [B,C,M] with 16-B aligned rows -> (B, C, M, ld)"""
     rm = rowmat(xc)

@@ -515,7 +515,11 @@ class LinearActQ(Function):
             # (deferred) into the arena consumed by fqss_wq_multi_bwd
             gw = gwq if gwq is not None else torch.zeros_like(w)
             if ctx.xq is not None:
-                K.qpw_bwd_w(gz, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
+                wq = getattr(DEFER, "wgrad_queue", None) if (gwq is not None and getattr(w, "_fqss_gwq_done", None) is None) else None
+                if wq is not None:     # the segment's weight gradients run together when it is done (runtime.QuantTables.finish_backward)
+                    wq.push(gz, None, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
+                else:
+                    K.qpw_bwd_w(gz, ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, gw)
             else:
                 if x is None and K.frames_wgrad1_q(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax, gz, gw, L.stride):
                     pass             # coded decoder input: dL/dW straight from the codes
@@ -580,7 +584,11 @@ class LinearActQPair(Function):
                                                           bias_like=b, C=z[i].shape[1])
             gz.append(gzi); gbias.append(g_bias); gmin.append(g_min); gmax.append(g_max)
         gx = K.qpw_bwd_x2(gz[0], gz[1], ctx.pair.wc) if ctx.needs_input_grad[0] else None
-        K.qpw_bwd_w2(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
+        wq = getattr(DEFER, "wgrad_queue", None)
+        if wq is not None:
+            wq.push(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
+        else:
+            K.qpw_bwd_w2(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
         return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None, None
 
 

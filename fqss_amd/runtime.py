@@ -317,6 +317,9 @@ class QuantTables:
         assert pending is None
         self.wq_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.total_channels = blk
+        # grouped, atomics-free weight gradients of the quantized 1x1 convolutions (csrc/qgemm.hip k_qwgrad_group); FQSS_GROUP_WGRAD=0:
+        # one k_qwgrad2 launch per layer where autograd reaches it (rounds 2-4)
+        self.wgrad_queue = K.WgradQueue() if os.environ.get("FQSS_GROUP_WGRAD", "1") != "0" else None
         # ---- per-segment views of the two finish tables (descriptor 15 = first block is renumbered per table) -----------------
         self.seg_tables = None
         if segments is not None and len(segments) > 1:
@@ -339,10 +342,16 @@ class QuantTables:
 
     def weights_forward(self):
         K.wq_multi_fwd(self.wq_table, self.total_channels)
+        if self.wgrad_queue is not None:
+            self.wgrad_queue.jobs = []        # (a backward that never reached finish_backward leaves nothing behind)
 
     def finish_backward(self, seg=None):
         """after autograd (of backward segment `seg`, or of the whole network): weight STE/range gradients from the dL/dW_q arena,
         then the range/slope flushes"""
+        if self.wgrad_queue is not None:
+            # the weight gradients of this segment's quantized 1x1 convolutions, queued by their autograd nodes (ops.LinearActQ /
+            # LinearActQPair): ONE grouped launch per <= 16 layers, before the weight STE below reads the dL/dW_q arena
+            self.wgrad_queue.flush()
         if seg is None or self.seg_tables is None:
             K.wq_multi_bwd(self.wq_table, self.total_channels)
             K.gacc_flush_multi(self.flush_table)

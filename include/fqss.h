@@ -215,6 +215,25 @@ int fqss_qpw_bwd_x2(const float* gz1, const float* gz2, const int8_t* wiT, const
 int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t* xc, const float* qmin_x,
                     const float* qmax_x, float* gw, int B, int Ci, int Co1, int Co2, int M, int64_t ld_gz1,
                     int64_t ld_gz2, int64_t ld_xc, fqss_stream_t stream);
+
+/* Weight gradients of SEVERAL quantized 1x1 convolutions in ONE launch (csrc/qgemm.hip k_qwgrad_group; round 5): the gradients of
+ * a backward segment's Conv1dQ / Conv1dNlQ weights feed nothing but the optimizer (autograd of F.conv1d in qat_layers.py:137-146,
+ * 202-212), so the host may queue them and run them together.  Per job gw [Co1+Co2][Ci] += sum_b [gz1; gz2][b] x[b]^T exactly as
+ * fqss_qpw_bwd_w / _w2 (Co2 = 0, gz2 = NULL: a single layer).  No float atomics: tiles cut by the work split are reduced through
+ * slab slots in a fixed order, so two runs give the same bits.  `jobs` is a HOST array (copied into the launch, <= 16 jobs per
+ * launch, more are split); two jobs of one call must not share gw.  ws: device memory of fqss_qpw_bwd_w_group_ws(jobs, njobs)
+ * bytes, 16-B aligned, ZERO-FILLED before its first use (its first 64 KB are arrival tickets that every launch leaves zero);
+ * launches that share a workspace must be ordered (one stream). */
+typedef struct FqssWgradJob {
+    const float* gz1; const float* gz2;          /* [B][Co1][ld_gz1], [B][Co2][ld_gz2] (NULL when Co2 == 0) */
+    const uint8_t* xc;                           /* input codes [B][Ci][ld_xc] */
+    const float* qmin_x; const float* qmax_x;    /* the input quantizer's range (device scalars) */
+    float* gw;                                   /* [Co1+Co2][Ci] dense, accumulated */
+    int32_t B, Ci, Co1, Co2, M;
+    int64_t ld_gz1, ld_gz2, ld_xc;
+} FqssWgradJob;
+int64_t fqss_qpw_bwd_w_group_ws(const FqssWgradJob* jobs, int njobs);      /* -1: bad job list (fqss_last_error) */
+int fqss_qpw_bwd_w_group(const FqssWgradJob* jobs, int njobs, void* ws, int64_t ws_bytes, fqss_stream_t stream);
 /* fqss_qpw_fwd / fqss_qpw_fwd2 with the layer's own activation + output fake-quant fused into the epilogue
  * (Conv1dQ / Conv1dNlQ: conv -> nl -> activation_fake_quantize, qat_layers.py:137-146, 202-212): writes the
  * pre-quant z (kept for the backward) AND the u8 codes yc of fq(act(z)); Co2 = 0 for a single layer */
