@@ -62,6 +62,9 @@ _PROTOS = {
     "fqss_mulq_fwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, P, P, P],
     "fqss_mulq_bwd": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P, P, P, I64, I32, P, P, P, P],
     "fqss_dwq_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P],
+    "fqss_dwq_bwd_gn": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, I64, I32, P, P, P, P, P, P, P, P],
+    "fqss_gnq_bwd_rows": [P, P, P, P, P, P, P, I32, I32, I32, I64, I64, P, P, P, P, P],
+    "fqss_gnq_bwd_apply": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, I64, I32, P, P, P, P],
     "fqss_split3_planes": [P, P, I64, P],
     "fqss_tgemm": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],
     "fqss_tgemm_tiled": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],
@@ -201,6 +204,16 @@ class FqssQParams(C.Structure):
 
 class FqssWCodes(C.Structure):
     _fields_ = [("idx", C.c_void_p), ("idxT", C.c_void_p), ("dw", C.c_void_p), ("rw", C.c_void_p), ("Co", C.c_int), ("Ci", C.c_int)]
+
+
+class FqssGnAfter(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean_rstd", C.c_void_p), ("ws", C.c_void_p), ("qmin", C.c_void_p),
+                ("qmax", C.c_void_p), ("ggamma", C.c_void_p), ("gbeta", C.c_void_p)]
+
+
+class FqssGnBefore(C.Structure):
+    _fields_ = [("xc0", C.c_void_p), ("ld_xc0", C.c_int64), ("qmin0", C.c_void_p), ("qmax0", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("mean_rstd", C.c_void_p), ("ws", C.c_void_p), ("gacc", C.c_void_p)]
 
 
 class FqssWgradJob(C.Structure):

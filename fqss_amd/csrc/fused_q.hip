@@ -772,20 +772,107 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
 //   phase 2: gx[m] = sum_k w[k] * gz[m + pad - k*dil] from LDS
 constexpr int kDwRowMax = 12 * 1024;   // 48 KiB of LDS
 
-template <int KT>   // taps known at compile time (3 on the training path) or 0: runtime K <= kTaps
+// Round 5: the two GroupNormQ layers around a TCN block's depthwise layer hand half of their backward to this kernel (VERDICT r04
+// next #1b -- their two-pass backward runs at the practical HBM rate, so only fewer bytes make it faster):
+//   GA ("gLN after"): the GroupNormQ that CONSUMES this layer's output.  Its backward APPLY pass -- gx = gz * (gamma rstd) + x c2 + c3
+//       with gz = the incoming gradient pushed through ITS output quantizer -- is a function of the incoming gradient and of the CODE
+//       of this layer's output, which phase 1 recomputes anyway: the apply runs on g as it is loaded (per row a 256-entry table
+//       {fma(x, c2, c3), in-range flag} indexed by that code), and k_gnq_bwd_apply<false> with its 65 MB read + 65 MB write is gone.
+//       The per-sample coefficients c2 / c3 and the gamma / beta gradients are finished in this kernel's prologue exactly as there.
+//   GB ("gLN before"): the GroupNormQ that PRODUCED this layer's input.  Its backward ROWS pass -- per row sum gz x, sum gz and the
+//       range partials of its output quantizer, gz = gx pushed through that quantizer -- needs gx (produced here, a row per
+//       workgroup) and the GroupNorm's INPUT code (one more byte per element, a 256-entry table {x, c - u | c, in-range} per row):
+//       phase 2 takes the sums while gx is in registers, same thread -> element order as k_gnq_bwd_rows, and that launch (65 + 16 MB
+//       read) is gone.  Both are bit-identical to the separate kernels in everything but the order of the fp64 slot atomics.
+struct DwGnAfter {
+    const float *gamma, *beta, *mean_rstd;   // [C], [C], [B][2] of that GroupNormQ
+    const double* ws;                        // [B*C][2]: (ds, db) of its rows pass (k_gnq_bwd_rows)
+    const float *qmin, *qmax;                // its OUTPUT quantizer
+    float *ggamma, *gbeta;                   // [C], "+=" (workgroups of sample 0)
+    int B;
+};
+struct DwGnBefore {
+    const uint8_t* xc0; int64_t ld_xc0;      // ITS input codes [B*C][ld_xc0] ...
+    const float *qmin0, *qmax0;              // ... and their range
+    const float *gamma, *beta, *mean_rstd;
+    double* ws;                              // out [B*C][2]: (ds, db) for its apply pass
+    double* gacc;                            // partial slots of its output quantizer (= this layer's input range)
+};
+
+template <int KT, bool GA = false, bool GB = false>   // taps known at compile time (3 on the training path) or 0: runtime K <= kTaps
 __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ g,
                                                   float* __restrict__ gx, float* gw, int C, int M, int K, int dil, int pad,
                                                   int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope_p,
                                                   const float* qmin_x, const float* qmax_x, const float* qmin,
-                                                  const float* qmax, double* gacc, float* gbias, int want_gx) {
+                                                  const float* qmax, double* gacc, float* gbias, int want_gx, DwGnAfter GAd,
+                                                  DwGnBefore GBd) {
     constexpr int NT = KT ? KT : kTaps;
     if (KT) K = KT;
     extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
     __shared__ float redf[(4 + kTaps) * 4];
+    __shared__ __attribute__((aligned(16))) float2 tabA[GA ? 256 : 1];   // GA: {fma(x, c2, c3), in-range} per code of THIS layer's output
+    __shared__ __attribute__((aligned(16))) float4 tabB[GB ? 256 : 1];   // GB: {x, c - u | c, in-range, -} per code of the GroupNorm's input
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     const int row = blockIdx.x, c = row % C;
+    QRange r2 = QRange{0.f, 1.f, 1.f};
+    float scale2 = 0.f;
+    if constexpr (GA) {
+        // ---- prologue of k_gnq_bwd_apply: c2 / c3 of this sample from the rows pass' sums, gamma / beta gradients by sample 0
+        __shared__ double cred[2 * 4];
+        __shared__ float c23[2];
+        const int b = row / C;
+        r2 = load_qrange(GAd.qmin, GAd.qmax);
+        const float mean = GAd.mean_rstd[2 * b], rstd = GAd.mean_rstd[2 * b + 1];
+        scale2 = rstd * GAd.gamma[c];
+        const float shift2 = fmaf(-scale2, mean, GAd.beta[c]);
+        double sv[2] = {0.0, 0.0};
+        for (int cc = threadIdx.x; cc < C; cc += 256) {
+            const double gmm = (double)GAd.gamma[cc];
+            sv[0] += gmm * GAd.ws[2 * ((int64_t)b * C + cc)];
+            sv[1] += gmm * GAd.ws[2 * ((int64_t)b * C + cc) + 1];
+        }
+        block_sum<double, 2>(sv, cred);
+        if (threadIdx.x == 0) {
+            const double md = (double)mean, rd = (double)rstd;
+            const double inv_n = 1.0 / ((double)C * (double)M);
+            const double c2d = (sv[1] * md - sv[0]) * rd * rd * rd * inv_n;
+            c23[0] = (float)c2d;
+            c23[1] = (float)(-c2d * md - sv[1] * rd * inv_n);
+            if (b == 0) {
+                double gg = 0.0, gb = 0.0;
+                for (int bb = 0; bb < GAd.B; ++bb) {
+                    const double ds = GAd.ws[2 * ((int64_t)bb * C + c)], db = GAd.ws[2 * ((int64_t)bb * C + c) + 1];
+                    gg += (ds - db * (double)GAd.mean_rstd[2 * bb]) * (double)GAd.mean_rstd[2 * bb + 1];
+                    gb += db;
+                }
+                GAd.ggamma[c] += (float)gg;
+                GAd.gbeta[c] += (float)gb;
+            }
+        }
+        __syncthreads();
+        {   // the table over the codes of this layer's output (= that GroupNorm's input, range ry)
+            const float x2 = dec(threadIdx.x, ry);
+            float cq2, u2;
+            bool in2;
+            (void)fq_asym(fmaf(x2, scale2, shift2), r2, cq2, u2, in2);
+            tabA[threadIdx.x] = make_float2(fmaf(x2, c23[0], c23[1]), in2 ? 1.0f : 0.0f);
+        }
+    }
+    if constexpr (GB) {
+        const int b = row / C;
+        const QRange r0 = load_qrange(GBd.qmin0, GBd.qmax0);
+        const float mean = GBd.mean_rstd[2 * b], rstd = GBd.mean_rstd[2 * b + 1];
+        const float scale1 = rstd * GBd.gamma[c];
+        const float shift1 = fmaf(-scale1, mean, GBd.beta[c]);
+        const float x0 = dec(threadIdx.x, r0);
+        float cq1, u1;
+        bool in1;
+        (void)fq_asym(fmaf(x0, scale1, shift1), rx, cq1, u1, in1);     // that GroupNorm's output quantizer = this layer's input range
+        tabB[threadIdx.x] = make_float4(x0, in1 ? (cq1 - u1) : cq1, in1 ? 1.0f : 0.0f, 0.0f);
+    }
+    if constexpr (GA || GB) __syncthreads();
     float wk[NT], pw[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
@@ -851,12 +938,17 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool valid = (m + j < M);
-                const float gj = valid ? gv[j] : 0.0f;
                 const float z = acc[j] + bv;
                 const float t = act_apply_br(z, act, slope);
                 float cq, u;
                 bool inr;
                 (void)fq_asym(t, ry, cq, u, inr);
+                float gj = valid ? gv[j] : 0.0f;
+                if constexpr (GA) {     // the consuming GroupNormQ's backward apply, on the code this layer's forward wrote
+                    const float2 e2 = tabA[(unsigned int)cq & 255u];
+                    const float gz2 = (e2.y != 0.0f) ? div_by(gv[j] * r2.delta, r2.delta, r2.inv) : 0.0f;
+                    gj = valid ? fmaf(gz2, scale2, e2.x) : 0.0f;
+                }
                 const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
                 p_du += valid ? gj * (inr ? (cq - u) : cq) : 0.0f;
                 p_out += (valid && !inr) ? gj : 0.0f;
@@ -873,10 +965,14 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
     }
     __syncthreads();
 
+    float q_ds = 0.f, q_db = 0.f, q_du = 0.f, q_out = 0.f;      // GB: the producing GroupNormQ's row sums / range partials
     if (want_gx) {
         float* xo = gx + (int64_t)row * ld_gx;
         const bool aligned = ((dil & 3) == 0) && ((pad & 3) == 0);
+        const uint8_t* x0r = GB ? GBd.xc0 + (int64_t)row * GBd.ld_xc0 : nullptr;
         for (int m = 4 * threadIdx.x; m < M; m += 1024) {
+            unsigned int w0 = 0;
+            if constexpr (GB) w0 = *reinterpret_cast<const unsigned int*>(x0r + m);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
@@ -901,6 +997,33 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                 }
             }
             *reinterpret_cast<float4*>(xo + m) = make_float4(a[0], a[1], a[2], a[3]);
+            if constexpr (GB) {     // k_gnq_bwd_rows' arithmetic on gx while it is in registers (same thread -> element order)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (m + j < M) {
+                        const float4 e1 = tabB[(w0 >> (8 * j)) & 255u];
+                        const bool in1 = e1.z != 0.0f;
+                        const float gz1 = in1 ? div_by(a[j] * rx.delta, rx.delta, rx.inv) : 0.0f;
+                        q_du += a[j] * e1.y;
+                        q_out += in1 ? 0.0f : a[j];
+                        q_ds = fmaf(gz1, e1.x, q_ds);
+                        q_db += gz1;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (GB) {
+        double qv[4];
+        const float qf[4] = {q_ds, q_db, q_du, q_out};
+        block_sum_f32w<4>(qf, redf, qv);
+        if (threadIdx.x == 0) {
+            GBd.ws[2 * (int64_t)row] = qv[0];
+            GBd.ws[2 * (int64_t)row + 1] = qv[1];
+            double* slot = GBd.gacc + 3 * (row % kSlots);
+            const double dmax = qv[2] / 255.0;
+            atomicAdd(&slot[0], qv[3] - dmax);
+            atomicAdd(&slot[1], dmax);
         }
     }
 
@@ -1462,17 +1585,21 @@ extern "C" int fqss_gnq_fwd(const uint8_t* xc, const float* qmin_x, const float*
 static int gnq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g,
                             const float* gamma, const float* beta, const float* mean_rstd, float* gx, float* ggamma,
                             float* gbeta, int B, int C, int M, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin,
-                            const float* qmax, double* gacc, double* ws, const GnProducer& P, fqss_stream_t stream) {
+                            const float* qmax, double* gacc, double* ws, const GnProducer& P, fqss_stream_t stream, int passes = 3) {
     if (B == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
-    FQSS_REQUIRE(xc && qmin_x && qmax_x && g && gamma && beta && mean_rstd && gx && ggamma && gbeta && qmin && qmax && gacc && ws,
-                 "null pointer");
-    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_g >= M && ld_gx >= M, "bad shape");
-    FQSS_REQUIRE(codes_ok(xc, ld_xc) && aligned16(g) && aligned16(gx) && ld_g % 4 == 0 && ld_gx % 4 == 0 &&
-                     ld_g >= ((M + 3) & ~3), "rows must be 16-B aligned");
+    // passes: 1 = the rows pass alone (gx / ggamma / gbeta unused), 2 = the apply pass alone (ws given, gacc unused), 3 = both
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && g && gamma && beta && mean_rstd && qmin && qmax && ws, "null pointer");
+    FQSS_REQUIRE(!(passes & 1) || gacc, "rows pass: null gacc");
+    FQSS_REQUIRE(!(passes & 2) || (gx && ggamma && gbeta), "apply pass: null output");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_xc >= M && ld_g >= M && (!(passes & 2) || ld_gx >= M), "bad shape");
+    FQSS_REQUIRE(codes_ok(xc, ld_xc) && aligned16(g) && ld_g % 4 == 0 && ld_g >= ((M + 3) & ~3), "rows must be 16-B aligned");
+    FQSS_REQUIRE(!(passes & 2) || (aligned16(gx) && ld_gx % 4 == 0 && ld_gx >= M), "gx rows must be 16-B aligned");
     if (B == 0) return FQSS_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gnq_bwd_rows, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, C, M,
-                       ld_xc, ld_g, ws, qmin_x, qmax_x, qmin, qmax, gacc);
+    if (passes & 1)
+        hipLaunchKernelGGL(k_gnq_bwd_rows, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, C, M,
+                           ld_xc, ld_g, ws, qmin_x, qmax_x, qmin, qmax, gacc);
+    if (!(passes & 2)) return launch_status(who);
     if (P.pz != nullptr)
         hipLaunchKernelGGL(k_gnq_bwd_apply<true>, dim3((unsigned)C, (unsigned)B), dim3(256), 0, s, xc, g, gamma, beta, mean_rstd, gx, B, C,
                            M, ld_xc, ld_g, ld_gx, ws, qmin_x, qmax_x, qmin, qmax, P, ggamma, gbeta);
@@ -1500,6 +1627,30 @@ extern "C" int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const floa
     GnProducer P{pz, ld_pz, pact, pslope, qmin_x, qmax_x, pgacc, pgbias};
     return gnq_bwd_impl("fqss_gnq_bwd_p", xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, gz, ggamma, gbeta, B, C, M, ld_xc, ld_g,
                         ld_gz, qmin, qmax, gacc, ws, P, stream);
+}
+
+/* The two passes of fqss_gnq_bwd / fqss_gnq_bwd_p as entry points of their own (round 5): a depthwise layer next to the GroupNormQ may
+ * take one of them into its own backward (fqss_dwq_bwd_gn).  ws [B*C][2] doubles: written by the rows pass, read by the apply pass. */
+extern "C" int fqss_gnq_bwd_rows(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g, const float* gamma,
+                                 const float* beta, const float* mean_rstd, int B, int C, int M, int64_t ld_xc, int64_t ld_g,
+                                 const float* qmin, const float* qmax, double* gacc, double* ws, fqss_stream_t stream) {
+    return gnq_bwd_impl("fqss_gnq_bwd_rows", xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, nullptr, nullptr, nullptr, B, C, M, ld_xc, ld_g,
+                        0, qmin, qmax, gacc, ws, GnProducer{}, stream, 1);
+}
+
+extern "C" int fqss_gnq_bwd_apply(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g, const float* gamma,
+                                  const float* beta, const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int B, int C, int M,
+                                  int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin, const float* qmax, const double* ws,
+                                  const float* pz, int64_t ld_pz, int pact, const float* pslope, double* pgacc, float* pgbias,
+                                  fqss_stream_t stream) {
+    GnProducer P{};
+    if (pz != nullptr) {
+        FQSS_REQUIRE(pgacc && aligned16(pz) && ld_pz % 4 == 0 && ld_pz >= ((M + 3) & ~3), "producer z: 16-B aligned rows");
+        FQSS_REQUIRE(pact != FQSS_ACT_PRELU || pslope, "PReLU needs a slope");
+        P = GnProducer{pz, ld_pz, pact, pslope, qmin_x, qmax_x, pgacc, pgbias};
+    }
+    return gnq_bwd_impl("fqss_gnq_bwd_apply", xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, gx, ggamma, gbeta, B, C, M, ld_xc, ld_g, ld_gx,
+                        qmin, qmax, nullptr, const_cast<double*>(ws), P, stream, 2);
 }
 
 /* GroupNormQ followed by a depthwise Conv1dNlQ, both in their quantizing phase, codes -> codes -> codes in one launch (k_gndwq_fwd):
@@ -1606,10 +1757,10 @@ extern "C" int fqss_dwq_bwd_w(const float* gz, const uint8_t* xc, const float* q
     return launch_status("fqss_dwq_bwd_w");
 }
 
-extern "C" int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
-                            const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
-                            int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
-                            double* gacc, float* gbias, fqss_stream_t stream) {
+static int dwq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
+                        const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
+                        int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
+                        double* gacc, float* gbias, const FqssGnAfter* ga, const FqssGnBefore* gb, fqss_stream_t stream) {
     if (B == 0 || M == 0) return FQSS_OK;   // empty input: nothing to do (a 0-element tensor has a null data pointer)
     FQSS_REQUIRE(xc && qmin_x && qmax_x && w && g && qmin && qmax && gacc, "null pointer");
     FQSS_REQUIRE(B >= 0 && C > 0 && M >= 0 && K > 0 && K <= kTaps && dil > 0 && 2 * pad == dil * (K - 1), "bad conv geometry");
@@ -1620,13 +1771,52 @@ extern "C" int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float*
     FQSS_REQUIRE((int64_t)B * C < (1ll << 31), "too many rows");
     if (B == 0 || M == 0) return FQSS_OK;
     const size_t lds = (size_t)((M + 3) & ~3) * sizeof(float);
-    if (K == 3)
-        hipLaunchKernelGGL(k_dwq_bwd<3>, dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, K,
-                           dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_dwq_bwd<0>, dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, K,
-                           dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0);
-    return launch_status("fqss_dwq_bwd");
+    DwGnAfter A{};
+    DwGnBefore Bf{};
+    if (ga != nullptr) {
+        FQSS_REQUIRE(K == 3, "GroupNormQ hand-over: the 3-tap depthwise layer only");
+        FQSS_REQUIRE(ga->gamma && ga->beta && ga->mean_rstd && ga->ws && ga->qmin && ga->qmax && ga->ggamma && ga->gbeta, "gn_after: null pointer");
+        A = DwGnAfter{ga->gamma, ga->beta, ga->mean_rstd, ga->ws, ga->qmin, ga->qmax, ga->ggamma, ga->gbeta, B};
+    }
+    if (gb != nullptr) {
+        FQSS_REQUIRE(K == 3 && gx, "GroupNormQ hand-over: the 3-tap depthwise layer only, with gx");
+        FQSS_REQUIRE(gb->xc0 && gb->qmin0 && gb->qmax0 && gb->gamma && gb->beta && gb->mean_rstd && gb->ws && gb->gacc, "gn_before: null pointer");
+        FQSS_REQUIRE(gb->ld_xc0 >= M && codes_ok(gb->xc0, gb->ld_xc0), "gn_before: code rows must be 16-B aligned");
+        Bf = DwGnBefore{gb->xc0, gb->ld_xc0, gb->qmin0, gb->qmax0, gb->gamma, gb->beta, gb->mean_rstd, gb->ws, gb->gacc};
+    }
+#define FQSS_DWQ_BWD(KT, GA_, GB_)                                                                                                          \
+    hipLaunchKernelGGL((k_dwq_bwd<KT, GA_, GB_>), dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, \
+                       K, dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0, A, Bf)
+    if (K == 3) {
+        if (ga && gb) FQSS_DWQ_BWD(3, true, true);
+        else if (ga) FQSS_DWQ_BWD(3, true, false);
+        else if (gb) FQSS_DWQ_BWD(3, false, true);
+        else FQSS_DWQ_BWD(3, false, false);
+    } else {
+        FQSS_DWQ_BWD(0, false, false);
+    }
+#undef FQSS_DWQ_BWD
+    return launch_status(who);
+}
+
+extern "C" int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
+                            const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
+                            int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
+                            double* gacc, float* gbias, fqss_stream_t stream) {
+    return dwq_bwd_impl("fqss_dwq_bwd", xc, qmin_x, qmax_x, w, bias, g, gx, gw, B, C, M, K, dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin,
+                        qmax, gacc, gbias, nullptr, nullptr, stream);
+}
+
+/* fqss_dwq_bwd with the GroupNormQ layers around the depthwise layer handing over half of their backward (k_dwq_bwd<3, GA, GB>):
+ * after (nullable): g is the gradient w.r.t. the OUTPUT of the GroupNormQ that consumes this layer's output, whose rows pass
+ * (fqss_gnq_bwd_rows) has run: its apply pass happens on load.  before (nullable): the rows pass of the GroupNormQ that produced xc
+ * is taken on gx: ws / gacc of that layer are written here, its apply pass (fqss_gnq_bwd_apply) follows. */
+extern "C" int fqss_dwq_bwd_gn(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
+                               const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
+                               int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
+                               double* gacc, float* gbias, const FqssGnAfter* after, const FqssGnBefore* before, fqss_stream_t stream) {
+    return dwq_bwd_impl("fqss_dwq_bwd_gn", xc, qmin_x, qmax_x, w, bias, g, gx, gw, B, C, M, K, dil, pad, ld_xc, ld_g, ld_gx, act, slope,
+                        qmin, qmax, gacc, gbias, after, before, stream);
 }
 
 extern "C" int fqss_ewq_fwd(const uint8_t* ac, const float* amin, const float* amax, const uint8_t* bc, const float* bmin,

@@ -652,6 +652,34 @@ def gnq_bwd(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, gacc, gga
     return gx
 
 
+def gnq_bwd_rows(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, gacc):
+    """first pass of gnq_bwd alone -> (g as the kernels read it, ws [B*C][2] doubles): the depthwise layer in front of this GroupNormQ
+    runs the second pass on load (dwq_bwd(after=...))"""
+    B, C, M, ld_xc = _codes3(xc)
+    g, ld_g = _aligned_grad(g)
+    ws = torch.empty(2 * B * C, device=xc.device, dtype=torch.float64)
+    _lib.call("fqss_gnq_bwd_rows", _p(xc), _p(qmin_x), _p(qmax_x), _p(g), _p(gamma), _p(beta), _p(mean_rstd), B, C, M, ld_xc, ld_g,
+              _p(qmin), _p(qmax), _p(gacc), _p(ws), _stream())
+    return g, ws
+
+
+def gnq_bwd_apply(xc, qmin_x, qmax_x, g, gamma, beta, mean_rstd, qmin, qmax, ws, ggamma, gbeta, producer=None):
+    """second pass of gnq_bwd alone, the row sums `ws` coming from the depthwise layer behind this GroupNormQ (dwq_bwd(before=...))"""
+    B, C, M, ld_xc = _codes3(xc)
+    g, ld_g = _aligned_grad(g)
+    gx = empty_act((B, C, M), xc.device)
+    pz, pact, pslope, pgacc, pgbias = producer if producer is not None else (None, 0, None, None, None)
+    ld_pz = 0
+    if pz is not None:
+        rz = rowmat(pz)
+        assert tuple(pz.shape) == (B, C, M) and rz is not None
+        ld_pz = rz[2]
+    _lib.call("fqss_gnq_bwd_apply", _p(xc), _p(qmin_x), _p(qmax_x), _p(g), _p(gamma), _p(beta), _p(mean_rstd), _p(gx), _p(ggamma),
+              _p(gbeta), B, C, M, ld_xc, ld_g, rowmat(gx)[2], _p(qmin), _p(qmax), _p(ws), _p(pz), ld_pz, pact, _p(pslope), _p(pgacc),
+              _p(pgbias), _stream())
+    return gx
+
+
 def dwq_fwd(xc, qmin_x, qmax_x, w, bias, dil, pad, act, slope, qmin, qmax, write_out, stats=None):
     """stats: a CodeStats from new_stats("dwq", ...) that receives the integer statistics of the output codes"""
     B, C, M, ld_xc = _codes3(xc)
@@ -750,12 +778,33 @@ def ewq_bwd(ac, amin, amax, bc, bmin, bmax, bf, sb, g, act, slope, qmin, qmax, g
 DWQ_ROW_MAX = 12 * 1024   # kDwRowMax (csrc/fused_q.hip)
 
 
-def dwq_bwd(xc, qmin_x, qmax_x, w, bias, g, dil, pad, act, slope, qmin, qmax, gacc, gbias, gw, want_gx=True):
-    """whole backward of the coded depthwise layer in one launch: returns gx (or None); gw / gbias / gacc are "+=" """
+def dwq_bwd(xc, qmin_x, qmax_x, w, bias, g, dil, pad, act, slope, qmin, qmax, gacc, gbias, gw, want_gx=True, after=None, before=None):
+    """whole backward of the coded depthwise layer in one launch: returns gx (or None); gw / gbias / gacc are "+=".
+    after = dict(gamma, beta, mean_rstd, ws, qmin, qmax, ggamma, gbeta) of the GroupNormQ that consumes this layer's output: g is the
+    gradient w.r.t. THAT layer's output and its apply pass runs on load; before = dict(xc0, qmin0, qmax0, gamma, beta, mean_rstd, gacc)
+    of the GroupNormQ that produced xc: its rows pass runs on gx, the row sums land in before["ws"] (csrc/fused_q.hip k_dwq_bwd<3, GA, GB>)"""
     B, C, M, ld_xc = _codes3(xc)
     assert M <= DWQ_ROW_MAX
     g, ld_g = _aligned_grad(g)
     gx = empty_act((B, C, M), xc.device) if want_gx else None
+    if after is not None or before is not None:
+        a = b = None
+        if after is not None:
+            a = _lib.FqssGnAfter()
+            a.gamma, a.beta, a.mean_rstd, a.ws = _p(after["gamma"]), _p(after["beta"]), _p(after["mean_rstd"]), _p(after["ws"])
+            a.qmin, a.qmax, a.ggamma, a.gbeta = _p(after["qmin"]), _p(after["qmax"]), _p(after["ggamma"]), _p(after["gbeta"])
+            assert after["ws"].numel() == 2 * B * C and after["ws"].dtype == torch.float64
+        if before is not None:
+            b = _lib.FqssGnBefore()
+            x0 = before["xc0"]
+            assert tuple(x0.shape) == (B, C, M) and want_gx
+            before["ws"] = torch.empty(2 * B * C, device=xc.device, dtype=torch.float64)
+            b.xc0, b.ld_xc0, b.qmin0, b.qmax0 = _p(x0), _codes3(x0)[3], _p(before["qmin0"]), _p(before["qmax0"])
+            b.gamma, b.beta, b.mean_rstd, b.ws, b.gacc = _p(before["gamma"]), _p(before["beta"]), _p(before["mean_rstd"]), _p(before["ws"]), _p(before["gacc"])
+        _lib.call("fqss_dwq_bwd_gn", _p(xc), _p(qmin_x), _p(qmax_x), _p(w), _p(bias), _p(g), _p(gx), _p(gw), B, C, M, w.shape[-1], dil, pad,
+                  ld_xc, ld_g, rowmat(gx)[2] if gx is not None else 0, act, _p(slope), _p(qmin), _p(qmax), _p(gacc), _p(gbias), _ref(a), _ref(b),
+                  _stream())
+        return gx
     _lib.call("fqss_dwq_bwd", _p(xc), _p(qmin_x), _p(qmax_x), _p(w), _p(bias), _p(g), _p(gx), _p(gw), B, C, M, w.shape[-1], dil, pad,
               ld_xc, ld_g, rowmat(gx)[2] if gx is not None else 0, act, _p(slope), _p(qmin), _p(qmax), _p(gacc), _p(gbias), _stream())
     return gx

@@ -21,7 +21,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer", "hand")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
@@ -32,6 +32,7 @@ class QCtx:
         self.no_codes = False   # the caller has no coded consumer (dual-path row layers): do not emit the u8 codes at all
         self.stats = None       # kernels.CodeStats of the output codes, emitted by the producing kernel for a GroupNormQ consumer
         self.defer = None       # GroupNormQ in front of a depthwise layer: its launch record, run by that layer's kernel (GroupNormActQ)
+        self.hand = None        # _GnHand: backward hand-over between a GroupNormQ and the depthwise layer next to it
 
 
 class ActCodes:
@@ -47,7 +48,7 @@ def tag_codes(y, q):
     """attach the codes produced by the epilogue of this call to its output tensor"""
     if q.idx is not None and not CODED:
         assert not q.carrier, "codes-only carriers need the coded dataflow"
-        q.idx = q.prod = q.stats = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
+        q.idx = q.prod = q.stats = q.hand = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
     if q.idx is not None:
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
         y._fqss_carrier = q.carrier
@@ -58,6 +59,8 @@ def tag_codes(y, q):
             y._fqss_stats, q.stats = q.stats, None
         if q.defer is not None:
             y._fqss_defer, q.defer = q.defer, None
+        if q.hand is not None:
+            y._fqss_hand, q.hand = q.hand, None
     return y
 
 
@@ -72,6 +75,23 @@ class _Producer:
         self.fused = False   # set by the consumer's backward: the gradient it returned already IS this layer's gz
 
 
+class _GnHand:
+    """Backward hand-over between a GroupNormQ and the 3-tap depthwise Conv1dNlQ next to it along a HipSequential edge (one consumer),
+    both quantizing (round 5; csrc/fused_q.hip k_dwq_bwd<3, GA, GB>).  The GroupNorm's two-pass backward is bound by its bytes, and the
+    depthwise backward owns a whole (b, c) row per workgroup:
+      kind "after"  (tagged on the DEPTHWISE layer's output, found by the GroupNormQ that consumes it): that GroupNormQ's backward
+                    runs its rows pass only, leaves `rec` (its parameters + row sums) here and returns the INCOMING gradient
+                    unchanged; the depthwise backward applies the second pass while it loads that gradient;
+      kind "before" (tagged on the GROUPNORM's output, found by the depthwise layer that consumes it): `fwd` holds what the
+                    GroupNorm's rows pass needs; the depthwise backward takes that pass on the gx it produces and leaves the row
+                    sums in `rec`; the GroupNorm's backward then only runs its apply pass."""
+    __slots__ = ("kind", "fwd", "rec")
+
+    def __init__(self, kind, fwd=None):
+        self.kind, self.fwd, self.rec = kind, fwd, None
+
+
+FUSE_GN_BWD_DW = os.environ.get("FQSS_FUSE_GN_BWD_DW", "1") != "0"
 FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
 FUSE_STATS = os.environ.get("FQSS_FUSE_STATS", "1") != "0"   # gLN statistics from the epilogue of the kernel that makes its input codes
@@ -245,7 +265,7 @@ class cut_recorder:
         CUTS = self.prev
 
 
-_TAGS = ("_fqss_q", "_fqss_carrier", "_fqss_prod", "_fqss_stats", "_fqss_rowq", "_fqss_defer")
+_TAGS = ("_fqss_q", "_fqss_carrier", "_fqss_prod", "_fqss_stats", "_fqss_rowq", "_fqss_defer", "_fqss_hand")
 
 
 def cut(*tensors, late=False):
@@ -604,7 +624,10 @@ class GroupNormActQ(Function):
         ctx.q, ctx.gp, ctx.bp = q, gamma_param, beta_param
         ctx.coded = xq is not None and q.qmode == Q_QUANT
         ctx.prod = getattr(x, "_fqss_prod", None) if ctx.coded else None
+        ctx.hand_in = ctx.hand_out = None
         if ctx.coded:
+            h = getattr(x, "_fqss_hand", None)
+            ctx.hand_in = h if (h is not None and h.kind == "after") else None     # x comes out of a depthwise layer that takes our apply pass
             q.carrier = FAST and not q.keep_out
             st = getattr(x, "_fqss_stats", None)
             if FUSE_GN_DW and NEXT_IS_DW3 and q.carrier and st is not None and x.shape[-1] <= 4096:
@@ -615,6 +638,10 @@ class GroupNormActQ(Function):
             else:
                 out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier, stats=st)
             ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
+            if FUSE_GN_BWD_DW and NEXT_IS_DW3 and q.gacc is not None and x.dim() == 3 and x.shape[-1] <= K.DWQ_ROW_MAX:
+                # the depthwise layer behind this GroupNorm takes our backward's rows pass (ops._GnHand "before")
+                ctx.hand_out = q.hand = _GnHand("before", dict(xc0=xq.idx, qmin0=xq.qmin, qmax0=xq.qmax, gamma=gamma, beta=beta,
+                                                                mean_rstd=mean_rstd, gacc=q.gacc))
             return _carrier(out) if q.carrier else out
         ctx.fused_f = FUSE_GNQ_F and q.qmode == Q_QUANT and q.gacc is not None and x.dim() == 3 and x.is_cuda      # (the CPU backend: un-fused)
         if ctx.fused_f:
@@ -641,7 +668,18 @@ class GroupNormActQ(Function):
             producer = _producer_args(ctx.prod) if ctx.needs_input_grad[0] else None
             if producer is not None:
                 ctx.prod.fused = True
-            gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb, producer=producer)
+            hi, ho = ctx.hand_in, ctx.hand_out
+            if hi is not None and producer is None and gg_direct and gb_direct and ctx.needs_input_grad[0]:
+                # rows pass here; the apply pass runs inside the depthwise layer's backward, on this gradient as it loads it: what
+                # goes back to autograd is the INCOMING gradient, not dL/dx (the edge has that one consumer)
+                gx, ws = K.gnq_bwd_rows(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc)
+                hi.rec = dict(gamma=gamma, beta=beta, mean_rstd=mean_rstd, ws=ws, qmin=qmin, qmax=qmax, ggamma=gg, gbeta=gb)
+            elif ho is not None and ho.rec is not None:
+                # the depthwise layer behind us took the rows pass on the gradient it produced (row sums + our range partials)
+                gx = K.gnq_bwd_apply(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, ho.rec["ws"], gg, gb, producer=producer)
+                ho.rec = None
+            else:
+                gx = K.gnq_bwd(xc, xmin, xmax, g, gamma, beta, mean_rstd, qmin, qmax, q.gacc, gg, gb, producer=producer)
             _, g_min, g_max = _flush_ranges(q, None, None, ACT_NONE)
             return gx, (None if gg_direct else gg), (None if gb_direct else gb), g_min, g_max, None, None, None, None, None
         if ctx.fused_f:
@@ -678,6 +716,12 @@ class DwConvQ(Function):
                                    stats=q.stats)
         ctx.save_for_backward(w, bias, slope, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
         ctx.L, ctx.act, ctx.q = L, act, q
+        ctx.hand_a = ctx.hand_b = None
+        if FUSE_GN_BWD_DW and w.shape[-1] == 3 and x.shape[-1] <= K.DWQ_ROW_MAX and q.gacc is not None:
+            h = getattr(x, "_fqss_hand", None)
+            ctx.hand_b = h if (h is not None and h.kind == "before") else None
+            if NEXT_IS_GROUPNORM and q.qmode == Q_QUANT:
+                ctx.hand_a = q.hand = _GnHand("after")       # the GroupNormQ behind this layer may leave its apply pass to our backward
         return _carrier(out) if q.carrier else out
 
     @staticmethod
@@ -694,8 +738,15 @@ class DwConvQ(Function):
             gw = gwq if gwq is not None else torch.zeros_like(w)
         if xc.shape[-1] <= K.DWQ_ROW_MAX:
             # one launch: gz stays in LDS (csrc/fused_q.hip k_dwq_bwd)
+            after = before = None
+            if ctx.hand_a is not None and ctx.hand_a.rec is not None:
+                after, ctx.hand_a.rec = ctx.hand_a.rec, None      # g is the gradient w.r.t. that GroupNormQ's OUTPUT
+            if ctx.hand_b is not None and ctx.needs_input_grad[0]:
+                before = dict(ctx.hand_b.fwd)
             gx = K.dwq_bwd(xc, xmin, xmax, w, bias, g, L.dil, L.pad, act, slope, qmin, qmax, q.gacc, gb, gw,
-                           want_gx=ctx.needs_input_grad[0])
+                           want_gx=ctx.needs_input_grad[0], after=after, before=before)
+            if before is not None:
+                ctx.hand_b.rec = dict(ws=before["ws"])
         else:
             gz = K.dwq_bwd_z(xc, xmin, xmax, w, bias, g, L.dil, L.pad, act, slope, qmin, qmax, q.gacc, gb)
             gx = K.dwconv_bwd_x(gz, w, L.dil, L.pad) if ctx.needs_input_grad[0] else None

@@ -381,6 +381,38 @@ int fqss_dwq_bwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, co
                  int dil, int pad, int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope,
                  const float* qmin, const float* qmax, double* gacc, float* gbias, fqss_stream_t stream);
 
+/* ---- GroupNormQ <-> depthwise Conv1dNlQ backward hand-over (round 5; csrc/fused_q.hip k_dwq_bwd<3, GA, GB>).  In a TCN block the
+ * depthwise layer sits between two GroupNormQ layers (convtasnetq.py:28-30, 37-42; qat_layers.py:438-452).  Their two-pass backward
+ * is bound by its bytes; the depthwise layer's backward owns a whole (b, c) row per workgroup and recomputes its output code anyway,
+ * so it takes the APPLY pass of the GroupNormQ behind it (on the incoming gradient, as it is loaded) and the ROWS pass of the
+ * GroupNormQ in front of it (on gx, as it is produced).  Bit-identical to the separate passes except for the order of fp64 slot
+ * atomics.  fqss_gnq_bwd_rows / fqss_gnq_bwd_apply are the two passes of fqss_gnq_bwd(_p) on their own; ws [B*C][2] doubles. */
+typedef struct FqssGnAfter {          /* the GroupNormQ that consumes the depthwise layer's output */
+    const float* gamma; const float* beta; const float* mean_rstd;   /* [C], [C], [B][2] */
+    const double* ws;                 /* its rows pass' (ds, db) per row */
+    const float* qmin; const float* qmax;                            /* its output quantizer */
+    float* ggamma; float* gbeta;      /* [C], accumulated */
+} FqssGnAfter;
+typedef struct FqssGnBefore {         /* the GroupNormQ that produced the depthwise layer's input */
+    const uint8_t* xc0; int64_t ld_xc0; const float* qmin0; const float* qmax0;   /* ITS input codes [B*C][ld_xc0] and their range */
+    const float* gamma; const float* beta; const float* mean_rstd;
+    double* ws;                       /* out: (ds, db) per row for fqss_gnq_bwd_apply */
+    double* gacc;                     /* partial slots of its output quantizer */
+} FqssGnBefore;
+int fqss_gnq_bwd_rows(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g, const float* gamma,
+                      const float* beta, const float* mean_rstd, int B, int C, int M, int64_t ld_xc, int64_t ld_g,
+                      const float* qmin, const float* qmax, double* gacc, double* ws, fqss_stream_t stream);
+/* pz NULL: plain gx; else the producer form of fqss_gnq_bwd_p */
+int fqss_gnq_bwd_apply(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* g, const float* gamma,
+                       const float* beta, const float* mean_rstd, float* gx, float* ggamma, float* gbeta, int B, int C, int M,
+                       int64_t ld_xc, int64_t ld_g, int64_t ld_gx, const float* qmin, const float* qmax, const double* ws,
+                       const float* pz, int64_t ld_pz, int pact, const float* pslope, double* pgacc, float* pgbias,
+                       fqss_stream_t stream);
+int fqss_dwq_bwd_gn(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
+                    const float* g, float* gx, float* gw, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,
+                    int64_t ld_g, int64_t ld_gx, int act, const float* slope, const float* qmin, const float* qmax,
+                    double* gacc, float* gbias, const FqssGnAfter* after, const FqssGnBefore* before, fqss_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fused float-teacher chain (csrc/teacher.hip): inference only, frozen weights pre-split into three
  * exact bf16 planes; per TCN block T1 (fqss_tgemm: conv + PReLU + stats), T2 (fqss_tdw: GN-apply +

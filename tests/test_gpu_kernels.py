@@ -1304,6 +1304,65 @@ def test_gnq_apply_code_table_bit_identical(B, C, M, write_out, monkeypatch):
     assert len(torch.unique(res["0", False][0])) > min(40, M // 2)          # (a constant output would pass trivially)
 
 
+@pytest.mark.parametrize("B,C,M,dil", [(2, 24, 3999, 1), (1, 16, 3999, 128), (3, 8, 777, 4), (2, 300, 130, 2), (1, 4, 4096, 64), (2, 5, 1023, 8)])
+@pytest.mark.parametrize("which", ["after", "before", "both"])
+def test_depthwise_backward_takes_the_groupnorm_passes(B, C, M, dil, which):
+    """k_dwq_bwd<3, GA, GB> (round 5, VERDICT r04 next #1b): gLN -> depthwise Conv1dNlQ (PReLU) -> gLN on codes, backward.  The depthwise
+    layer's backward takes the APPLY pass of the GroupNormQ behind it (on the incoming gradient, by a per-row table over its own output
+    code) and / or the ROWS pass of the GroupNormQ in front of it (on the gx it produces, by a per-row table over that GroupNorm's
+    input code) -- against the chain of separate launches (fqss_gnq_bwd, fqss_dwq_bwd, fqss_gnq_bwd): every gradient tensor BIT for
+    bit (same per-element arithmetic, same thread -> element order), the gamma / beta gradients bit for bit, the fp64 range partials
+    and the fp32-atomic weight / bias sums to their summation-order noise.  Reference: convtasnetq.py:28-30, qat_layers.py:438-452."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(B * 1000 + C + M + dil)
+    T1 = lambda v: torch.tensor([v], device=dev)
+    lo0, hi0, lo1, hi1, lo2, hi2, lo3, hi3 = T1(-1.7), T1(2.9), T1(-2.2), T1(2.4), T1(-0.6), T1(1.9), T1(-1.5), T1(1.2)
+    rnd_ = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev)
+    gamma1, beta1, gamma2, beta2 = 1.0 + rnd_(C, s=0.3), rnd_(C, s=0.2), 1.0 + rnd_(C, s=0.3), rnd_(C, s=0.2)
+    w, bias, slope = rnd_(C, 1, 3, s=0.6), rnd_(C, s=0.1), T1(0.2)
+    x0c = K.empty_codes((B, C, M), dev)
+    x0c.copy_(torch.randint(0, 256, (B, C, M), generator=g, dtype=torch.uint8).to(dev))
+    _, y1c, mr1 = K.gnq_fwd(x0c, lo0, hi0, gamma1, beta1, 1e-8, lo1, hi1, write_out=False)
+    std = K.new_stats("dwq", B, C, M, dev)
+    _, y2c = K.dwq_fwd(y1c, lo1, hi1, w, bias, dil, dil, K.ACT_PRELU, slope, lo2, hi2, write_out=False, stats=std)
+    _, y3c, mr2 = K.gnq_fwd(y2c, lo2, hi2, gamma2, beta2, 1e-8, lo3, hi3, write_out=False, stats=std)
+    g3 = K.empty_act((B, C, M), dev).copy_(rnd_(B, C, M, s=1e-2))
+    mk = lambda: dict(gacc1=torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev), gacc2=torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev),
+                      gacc3=torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev), gg1=rnd_(C, s=0.1), gb1=rnd_(C, s=0.1), gg2=rnd_(C, s=0.1),
+                      gb2=rnd_(C, s=0.1), gbias=torch.zeros(C, device=dev), gw=torch.zeros(C, 1, 3, device=dev))
+    R = mk()
+    F = {k: v.clone() for k, v in R.items()}
+    # the separate launches
+    gx2 = K.gnq_bwd(y2c, lo2, hi2, g3, gamma2, beta2, mr2, lo3, hi3, R["gacc3"], R["gg2"], R["gb2"])
+    gx1 = K.dwq_bwd(y1c, lo1, hi1, w, bias, gx2, dil, dil, K.ACT_PRELU, slope, lo2, hi2, R["gacc2"], R["gbias"], R["gw"])
+    gx0 = K.gnq_bwd(x0c, lo0, hi0, gx1, gamma1, beta1, mr1, lo1, hi1, R["gacc1"], R["gg1"], R["gb1"])
+    # the hand-over forms
+    after = before = None
+    if which in ("after", "both"):
+        gin, ws2 = K.gnq_bwd_rows(y2c, lo2, hi2, g3, gamma2, beta2, mr2, lo3, hi3, F["gacc3"])
+        after = dict(gamma=gamma2, beta=beta2, mean_rstd=mr2, ws=ws2, qmin=lo3, qmax=hi3, ggamma=F["gg2"], gbeta=F["gb2"])
+    else:
+        gin = K.gnq_bwd(y2c, lo2, hi2, g3, gamma2, beta2, mr2, lo3, hi3, F["gacc3"], F["gg2"], F["gb2"])
+    if which in ("before", "both"):
+        before = dict(xc0=x0c, qmin0=lo0, qmax0=hi0, gamma=gamma1, beta=beta1, mean_rstd=mr1, gacc=F["gacc1"])
+    fx1 = K.dwq_bwd(y1c, lo1, hi1, w, bias, gin, dil, dil, K.ACT_PRELU, slope, lo2, hi2, F["gacc2"], F["gbias"], F["gw"], after=after, before=before)
+    if before is not None:
+        fx0 = K.gnq_bwd_apply(x0c, lo0, hi0, fx1, gamma1, beta1, mr1, lo1, hi1, before["ws"], F["gg1"], F["gb1"])
+    else:
+        fx0 = K.gnq_bwd(x0c, lo0, hi0, fx1, gamma1, beta1, mr1, lo1, hi1, F["gacc1"], F["gg1"], F["gb1"])
+    torch.cuda.synchronize()
+    assert torch.equal(fx1, gx1), float((fx1 - gx1).abs().max())
+    assert torch.equal(fx0, gx0), float((fx0 - gx0).abs().max())
+    for k in ("gg1", "gb1", "gg2", "gb2"):
+        assert torch.equal(F[k], R[k]), k
+    for k in ("gacc1", "gacc2", "gacc3"):
+        a, b = F[k].view(-1, 3).sum(0), R[k].view(-1, 3).sum(0)
+        assert float((a - b).abs().max()) <= 1e-9 * max(1.0, float(b.abs().max())), (k, a, b)
+        assert float(b.abs().max()) > 0
+    for k in ("gbias", "gw"):
+        assert float((F[k] - R[k]).abs().max()) <= 1e-5 * max(1e-6, float(R[k].abs().max())), k
+
+
 @pytest.mark.parametrize("B,C,M,dil", [(2, 24, 3999, 1), (1, 16, 3999, 128), (3, 8, 777, 4), (2, 600, 130, 2), (1, 4, 4096, 64)])
 def test_gn_dw_fused_bit_identical(B, C, M, dil):
     """fqss_gndwq_fwd (round 4): GroupNormQ + 3-tap depthwise Conv1dNlQ (PReLU), both quantizing, as ONE launch -- against the two
