@@ -883,6 +883,15 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
     const uint8_t* xr = xc + (int64_t)row * ld_xc;
     const float* gr = g + (int64_t)row * ld_g;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
+    // GB: the GroupNorm-input codes of this thread's first four phase-2 groups are requested NOW (4 registers): loaded inside that
+    // loop they cost one exposed memory round trip per iteration of a workgroup that lives ~20 us
+    unsigned int w0pre[4] = {0u, 0u, 0u, 0u};
+    if constexpr (GB) {
+        const uint8_t* x0p = GBd.xc0 + (int64_t)row * GBd.ld_xc0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * (int)threadIdx.x + 1024 * i < M) w0pre[i] = *reinterpret_cast<const unsigned int*>(x0p + 4 * threadIdx.x + 1024 * i);
+    }
 
     // a pass covers 4096 positions: 4 float4 groups per thread, ALL their loads issued before the first is consumed
     // (the straight loop exposed one HBM round trip per group: PMC showed the waves parked 46 % of the time)
@@ -970,9 +979,10 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
         float* xo = gx + (int64_t)row * ld_gx;
         const bool aligned = ((dil & 3) == 0) && ((pad & 3) == 0);
         const uint8_t* x0r = GB ? GBd.xc0 + (int64_t)row * GBd.ld_xc0 : nullptr;
-        for (int m = 4 * threadIdx.x; m < M; m += 1024) {
+        int it = 0;
+        for (int m = 4 * threadIdx.x; m < M; m += 1024, ++it) {
             unsigned int w0 = 0;
-            if constexpr (GB) w0 = *reinterpret_cast<const unsigned int*>(x0r + m);
+            if constexpr (GB) w0 = (it < 4) ? w0pre[it] : *reinterpret_cast<const unsigned int*>(x0r + m);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < NT; ++k) {

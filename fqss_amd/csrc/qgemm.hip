@@ -833,7 +833,7 @@ __global__ __launch_bounds__(512, 1) void k_qwgrad2(QGemmArgs g) {
 //
 // The weight gradients of a backward segment feed nothing but the optimizer, so they need not run where autograd reaches them: the
 // host queues (gz, codes, gw) per layer and launches them together when the segment is done (runtime.QuantTables.finish_backward).
-// One launch = up to WGR_MAXJOBS layers.  A layer's output is cut into the 64 x 128 tiles of k_qwgrad2; its reduction index (batch x
+// One launch = up to WGR_MAXJOBS layers (the job table travels in the kernel arguments: 25 x 136 B < 4 KB).  A layer's output is cut into the 64 x 128 tiles of k_qwgrad2; its reduction index (batch x
 // frames) into 64-frame STAGES; eight tiles form a tile GROUP (conv1 128 -> 512: its 8 row tiles; the res | skip pair: 2 row tiles x 4
 // column tiles), and the work list is the sequence of (layer, tile group, stage) UNITS.  The grid is 32 TEAMS of 8 workgroups, one
 // workgroup per CU, the 8 of a team on ONE XCD (they stream the same gz rows / code rows at about the same time: the re-reads come
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(512, 1) void k_qwgrad2(QGemmArgs g) {
 // per workgroup -- the split-K seam recipe of MI355X_MICROARCH.md), and the workgroup whose ticket came last sums the slots IN PART
 // ORDER (sc1 loads) and adds the result to gw with plain read-modify-writes: no float atomics, and the same bits every run
 // (k_qwgrad2 issues 2.1 M float atomics per launch: 7.6 of its 31 us, and the source of the step's run-to-run noise).
-constexpr int WGR_MAXJOBS = 16, WGR_TEAM = 8, WGR_TEAMS = 32, WGR_SLOT_FLOATS = W2_TM * W2_TN;
+constexpr int WGR_MAXJOBS = 25, WGR_TEAM = 8, WGR_TEAMS = 32, WGR_SLOT_FLOATS = W2_TM * W2_TN;
 struct WJob {
     const float* A; const float* A2; const unsigned char* Bc; float* C; const float* qmin; const float* qmax;
     int64_t lda, lda2, ldb, sAb, sA2b, sBb;
@@ -858,6 +858,7 @@ struct WGroupArgs {
     unsigned* tickets; float* slabs;
     WJob j[WGR_MAXJOBS];
 };
+static_assert(sizeof(WGroupArgs) <= 4096, "the job table travels in the kernel arguments");
 __device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void ld16_sc1(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory"); }
 
@@ -1324,10 +1325,11 @@ static int wgr_check(const FqssWgradJob* jobs, int njobs) {
 extern "C" int64_t fqss_qpw_bwd_w_group_ws(const FqssWgradJob* jobs, int njobs) {
     if (wgr_check(jobs, njobs) != FQSS_OK) return -1;
     int64_t need = 0;
-    for (int n0 = 0; n0 < njobs; n0 += WGR_MAXJOBS) {
+    const int per = (int)cdiv(njobs, cdiv(njobs, WGR_MAXJOBS));     // launches of equal size (50 jobs: 25 + 25, not 25 + 25 or 48 + 2)
+    for (int n0 = 0; n0 < njobs; n0 += per) {
         WGroupArgs ga{};
         int64_t sb = 0;
-        const int t = wgr_plan(jobs, n0, njobs - n0 < WGR_MAXJOBS ? njobs - n0 : WGR_MAXJOBS, ga, sb);
+        const int t = wgr_plan(jobs, n0, njobs - n0 < per ? njobs - n0 : per, ga, sb);
         if ((int64_t)t * 4 > WGR_TICKET_BYTES) { set_error("fqss_qpw_bwd_w_group_ws: more than 16384 tiles in one launch"); return -1; }
         if (sb > need) need = sb;
     }
@@ -1338,10 +1340,11 @@ extern "C" int fqss_qpw_bwd_w_group(const FqssWgradJob* jobs, int njobs, void* w
     if (njobs == 0) return FQSS_OK;
     if (int rc = wgr_check(jobs, njobs)) return rc;
     FQSS_REQUIRE(ws && aligned16(ws), "workspace: 16-B aligned device memory (fqss_qpw_bwd_w_group_ws bytes, zero-filled when first used)");
-    for (int n0 = 0; n0 < njobs; n0 += WGR_MAXJOBS) {
+    const int per = (int)cdiv(njobs, cdiv(njobs, WGR_MAXJOBS));
+    for (int n0 = 0; n0 < njobs; n0 += per) {
         WGroupArgs ga{};
         int64_t sb = 0;
-        const int t = wgr_plan(jobs, n0, njobs - n0 < WGR_MAXJOBS ? njobs - n0 : WGR_MAXJOBS, ga, sb);
+        const int t = wgr_plan(jobs, n0, njobs - n0 < per ? njobs - n0 : per, ga, sb);
         FQSS_REQUIRE((int64_t)t * 4 <= WGR_TICKET_BYTES && WGR_TICKET_BYTES + sb <= ws_bytes, "workspace too small (fqss_qpw_bwd_w_group_ws)");
         ga.tickets = (unsigned*)ws;
         ga.slabs = (float*)((char*)ws + WGR_TICKET_BYTES);

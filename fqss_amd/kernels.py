@@ -506,7 +506,7 @@ def qpw_bwd_w2(gz1, gz2, xc, qmin_x, qmax_x, gw):
 
 class WgradQueue:
     """Weight-gradient launches of quantized 1x1 convolutions, queued during a backward segment and run together by ONE grouped
-    launch per <= 16 layers (fqss_qpw_bwd_w_group: no float atomics, bit-reproducible): their results feed nothing but the
+    launch per <= 25 layers (fqss_qpw_bwd_w_group: no float atomics, bit-reproducible): their results feed nothing but the
     optimizer.  The queue keeps gz / codes alive until flush(); the workspace (arrival tickets + slab slots) belongs to the queue and
     is allocated once -- flush() of a later step (and of a hipGraph capture) finds it in place."""
 

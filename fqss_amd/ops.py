@@ -92,6 +92,7 @@ class _GnHand:
 
 
 FUSE_GN_BWD_DW = os.environ.get("FQSS_FUSE_GN_BWD_DW", "1") != "0"
+_GN_HAND = os.environ.get("FQSS_GN_HAND", "both")          # experiments: "after" / "before" alone
 FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
 FUSE_STATS = os.environ.get("FQSS_FUSE_STATS", "1") != "0"   # gLN statistics from the epilogue of the kernel that makes its input codes
@@ -638,7 +639,7 @@ class GroupNormActQ(Function):
             else:
                 out, q.idx, mean_rstd = K.gnq_fwd(xq.idx, xq.qmin, xq.qmax, gamma, beta, eps, qmin, qmax, write_out=not q.carrier, stats=st)
             ctx.save_for_backward(gamma, beta, mean_rstd, xq.idx, xq.qmin, xq.qmax, qmin, qmax)
-            if FUSE_GN_BWD_DW and NEXT_IS_DW3 and q.gacc is not None and x.dim() == 3 and x.shape[-1] <= K.DWQ_ROW_MAX:
+            if FUSE_GN_BWD_DW and _GN_HAND != "after" and NEXT_IS_DW3 and q.gacc is not None and x.dim() == 3 and x.shape[-1] <= K.DWQ_ROW_MAX:
                 # the depthwise layer behind this GroupNorm takes our backward's rows pass (ops._GnHand "before")
                 ctx.hand_out = q.hand = _GnHand("before", dict(xc0=xq.idx, qmin0=xq.qmin, qmax0=xq.qmax, gamma=gamma, beta=beta,
                                                                 mean_rstd=mean_rstd, gacc=q.gacc))
@@ -720,7 +721,7 @@ class DwConvQ(Function):
         if FUSE_GN_BWD_DW and w.shape[-1] == 3 and x.shape[-1] <= K.DWQ_ROW_MAX and q.gacc is not None:
             h = getattr(x, "_fqss_hand", None)
             ctx.hand_b = h if (h is not None and h.kind == "before") else None
-            if NEXT_IS_GROUPNORM and q.qmode == Q_QUANT:
+            if NEXT_IS_GROUPNORM and q.qmode == Q_QUANT and _GN_HAND != "before":
                 ctx.hand_a = q.hand = _GnHand("after")       # the GroupNormQ behind this layer may leave its apply pass to our backward
         return _carrier(out) if q.carrier else out
 

@@ -350,7 +350,7 @@ class QuantTables:
         then the range/slope flushes"""
         if self.wgrad_queue is not None:
             # the weight gradients of this segment's quantized 1x1 convolutions, queued by their autograd nodes (ops.LinearActQ /
-            # LinearActQPair): ONE grouped launch per <= 16 layers, before the weight STE below reads the dL/dW_q arena
+            # LinearActQPair): ONE grouped launch per <= 25 layers, before the weight STE below reads the dL/dW_q arena
             self.wgrad_queue.flush()
         if seg is None or self.seg_tables is None:
             K.wq_multi_bwd(self.wq_table, self.total_channels)

@@ -220,7 +220,7 @@ int fqss_qpw_bwd_w2(const float* gz1, const float* gz2, const uint8_t* xc, const
  * a backward segment's Conv1dQ / Conv1dNlQ weights feed nothing but the optimizer (autograd of F.conv1d in qat_layers.py:137-146,
  * 202-212), so the host may queue them and run them together.  Per job gw [Co1+Co2][Ci] += sum_b [gz1; gz2][b] x[b]^T exactly as
  * fqss_qpw_bwd_w / _w2 (Co2 = 0, gz2 = NULL: a single layer).  No float atomics: tiles cut by the work split are reduced through
- * slab slots in a fixed order, so two runs give the same bits.  `jobs` is a HOST array (copied into the launch, <= 16 jobs per
+ * slab slots in a fixed order, so two runs give the same bits.  `jobs` is a HOST array (copied into the launch, <= 25 jobs per
  * launch, more are split); two jobs of one call must not share gw.  ws: device memory of fqss_qpw_bwd_w_group_ws(jobs, njobs)
  * bytes, 16-B aligned, ZERO-FILLED before its first use (its first 64 KB are arrival tickets that every launch leaves zero);
  * launches that share a workspace must be ordered (one stream). */

@@ -431,7 +431,7 @@ def test_grouped_weight_gradients(case):
     fqss_qpw_bwd_w, but over chains of up to 18 k terms per workgroup where that kernel's 64-way split-n adds 1 k-term chains), against the per-layer kernel, accumulating into a non-zero gw, and bit-identical from run to run (the
     per-layer kernel's 2.1 M float atomics are not).  Cases: one TCN block (conv1 128 -> 512 + the res | skip pair, cfg-2 shapes),
     a backward segment of three blocks, ragged shapes (Co / Ci / M off the tile sizes, B = 3, a job smaller than one tile, a pair
-    whose halves differ), and 19 jobs (two launches).  Reference: autograd of F.conv1d in Conv1dQ / Conv1dNlQ, qat_layers.py:137-146."""
+    whose halves differ), and 29 jobs (two launches).  Reference: autograd of F.conv1d in Conv1dQ / Conv1dNlQ, qat_layers.py:137-146."""
     dev = "cuda"
     g = torch.Generator().manual_seed({"block": 1, "segment": 2, "ragged": 3, "many": 4}[case])
     if case == "block":
@@ -441,7 +441,7 @@ def test_grouped_weight_gradients(case):
     elif case == "ragged":
         shapes = [(3, 48, 80, 0, 777), (3, 16, 32, 0, 50), (2, 144, 64, 32, 1030), (1, 256, 200, 0, 63), (3, 128, 128, 128, 64), (2, 512, 128, 0, 4001)]
     else:
-        shapes = [(2, 32 + 16 * (i % 5), 64 + 32 * (i % 3), 0 if i % 4 else 64, 500 + 97 * i) for i in range(19)]
+        shapes = [(2, 32 + 16 * (i % 5), 64 + 32 * (i % 3), 0 if i % 4 else 64, 500 + 97 * i) for i in range(29)]
     lo, hi = torch.tensor([-1.3], device=dev), torch.tensor([2.1], device=dev)
     jobs, refs, gws = [], [], []
     for (B, Ci, Co1, Co2, M) in shapes:
