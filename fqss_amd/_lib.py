@@ -70,7 +70,6 @@ _PROTOS = {
     "fqss_tgemm_tiled": [P, P, I32, I32, I32, I32, I64, I32, P, P, P, F32, P, P, I32, P, P, I32, P, P, I64, P, P, I64, P],
     "fqss_tgemm_tiled_ok": [I32, I32, I32],
     "fqss_split3_tiles": [P, P, I32, I32, P],
-    "fqss_gndwq_fwd": [P, P, P, P, P, F32, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P],
     "fqss_bn_moments": [P, P, I32, I32, I32, I64, P],
     "fqss_bn_apply": [P, P, P, P, I32, I32, I32, I64, I64, P],
     "fqss_bn_bwd_reduce": [P, P, P, I32, I32, I32, I64, I64, P],
@@ -235,6 +234,10 @@ class FqssTGemmDesc(C.Structure):
                 ("r2", C.POINTER(FqssTensor))]
 
 EXPORTS = tuple(_PROTOS)
+# entry points of include/fqss_experiments.h: only in variants/libfqss_experiments.so (`make -C fqss_amd/csrc experiments`, FQSS_LIB)
+_PROTOS.update({
+    "fqss_gndwq_fwd": [P, P, P, P, P, F32, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P],
+})
 
 
 class FqssError(RuntimeError):
@@ -286,7 +289,7 @@ def load(strict=False):
         _lib = C.CDLL(SO_PATH)
         _lib.fqss_last_error.restype = C.c_char_p
     if strict:
-        missing = [n for n in _PROTOS if not hasattr(_lib, n)]
+        missing = [n for n in EXPORTS if not hasattr(_lib, n)]
         if missing:
             raise FqssError(f"{SO_PATH} does not export: {missing}")
     return _lib

@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256) void k_dwq_fwd(const uint8_t* __restrict__ xc,
     }
 }
 
+#ifdef FQSS_EXPERIMENTS   // round-4 experiment, measured slower: built by `make experiments` only (declared in include/fqss_experiments.h)
 // gLN + fake-quant FOLLOWED BY depthwise conv + PReLU + fake-quant, both on codes, as ONE launch (round 4; the teacher's k_tdw does the
 // same in float): a workgroup takes `rpw` consecutive rows; per row it normalises + re-quantises the 16 input codes of every thread
 // (k_gnq_apply's arithmetic, codes written to HBM -- the backward of both layers reads them -- AND to an LDS row), then runs the
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(256) void k_gndwq_fwd(const uint8_t* __restrict__ x
         }
     }
 }
+#endif  // FQSS_EXPERIMENTS
 
 // backward: recompute z, STE + PReLU -> gz (fp32), bias row-sums, range/slope partials (gacc slots)
 template <int NQ>   // float4 groups per thread and pass: a workgroup covers NQ * 1024 consecutive positions
@@ -1663,6 +1665,7 @@ extern "C" int fqss_gnq_bwd_apply(const uint8_t* xc, const float* qmin_x, const 
                         qmin, qmax, nullptr, const_cast<double*>(ws), P, stream, 2);
 }
 
+#ifdef FQSS_EXPERIMENTS
 /* GroupNormQ followed by a depthwise Conv1dNlQ, both in their quantizing phase, codes -> codes -> codes in one launch (k_gndwq_fwd):
  * y1 = the GroupNorm's output codes (range 1), y2 = the depthwise layer's (range 2); stats = the producer's statistics of xc ([B][nslots][2]),
  * stats2 (nullable) = [B][C][2] statistics of y2 for a GroupNormQ behind it.  M <= 4096, K = 3; bit-identical to fqss_gnq_fwd + fqss_dwq_fwd. */
@@ -1686,6 +1689,7 @@ extern "C" int fqss_gndwq_fwd(const uint8_t* xc, const float* qmin_x, const floa
                        ld_y2, qmin2, qmax2, (long long*)stats2, rpw);
     return launch_status("fqss_gndwq_fwd");
 }
+#endif  // FQSS_EXPERIMENTS
 
 extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w, const float* bias,
                             uint8_t* yc, float* yout, int B, int C, int M, int K, int dil, int pad, int64_t ld_xc,

@@ -1197,9 +1197,11 @@ static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, c
         FQSS_REQUIRE(aligned16(addend) && ld_add % 4 == 0 && ld_add >= ((M + 3) & ~3), "addend rows must be 16-B aligned and padded to 4");
         g.C2 = const_cast<float*>(addend); g.ldc2 = ld_add; g.sC2b = (int64_t)Ci * ld_add;
     }
-    // round 4: the ring form (csrc/qgemm_ring.hip) wherever its shape rules hold -- exact three-piece gradients only
+#ifdef FQSS_EXPERIMENTS
+    // round 4 experiment (csrc/experiments/qgemm_ring.hip; `make experiments`, FQSS_DGRAD_RING=1): the ring form, measured slower
     if (grad_pieces() == 3 && qdgrad_ring_ok(Ci, Co1, Co2) && (!addend || ld_add < (1ll << 26)))
         return qdgrad_ring(who, gz1, gz2, wiT, dw, addend, gx, B, Ci, Co1, Co2, M, ld_gz1, ld_gz2, ld_add, ld_gx, stream);
+#endif
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Ci, QBM); g.batches = B;
     if (grad_pieces() == 3)
         hipLaunchKernelGGL((k_qgemm<1, 3>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);

@@ -103,6 +103,7 @@ NEXT_IS_DW3 = False         # ... around the forward of a GroupNormQ followed by
 # gndw_probe.py), the cfg-2 step unchanged (15.17 vs 15.16 ms on one box): both passes are bound by vector-ALU issue, so a fusion saves
 # the launch and a 16-MB re-read but not the instructions, and the LDS row (two barriers per row, two aligned reads + a byte-align per
 # four codes instead of one unaligned global load) adds some.  VERDICT r03 item 1(d) asked for this fusion.
+# Since round 5 the kernel lives in the experiments build only (include/fqss_experiments.h; `make -C fqss_amd/csrc experiments` + FQSS_LIB).
 FUSE_GN_DW = __import__("os").environ.get("FQSS_FUSE_GN_DW", "0") != "0"
 
 

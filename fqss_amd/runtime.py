@@ -804,6 +804,8 @@ class InferRunner:
         enable_observer(self.model, False)
         self.use_graph = use_graph
         self._graphs = {}
+        if hasattr(model, "n_srcs"):
+            self.n_srcs = model.n_srcs         # process.model_infer asks its `model` for it
 
     @torch.no_grad()
     def _forward(self, x):

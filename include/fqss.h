@@ -312,14 +312,7 @@ int fqss_gnq_bwd_p(const uint8_t* xc, const float* qmin_x, const float* qmax_x, 
                    const float* qmin, const float* qmax, double* gacc, double* ws, const float* pz,
                    int64_t ld_pz, int pact, const float* pslope, double* pgacc, float* pgbias,
                    fqss_stream_t stream);
-/* GroupNormQ followed by a depthwise Conv1dNlQ (3 taps), both quantizing, as ONE launch: codes -> y1 (the GroupNorm's output codes, kept
- * for both backward passes) -> y2.  stats / nslots: the producer's statistics of xc; stats2 (nullable): [B][C][2] statistics of y2.
- * M <= 4096.  Bit-identical to fqss_gnq_fwd followed by fqss_dwq_fwd (convtasnetq.py:28-30 + qat_layers.py:445-448). */
-int fqss_gndwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma, const float* beta,
-                   float eps, const int64_t* stats, int nslots, float* mean_rstd, uint8_t* y1, const float* qmin1,
-                   const float* qmax1, const float* w, const float* bias, int dil, int pad, int act, const float* slope,
-                   uint8_t* y2, const float* qmin2, const float* qmax2, int64_t* stats2, int B, int C, int M,
-                   int64_t ld_xc, int64_t ld_y1, int64_t ld_y2, fqss_stream_t stream);
+
 int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* w,
                  const float* bias, uint8_t* yc, float* yout, int B, int C, int M, int K, int dil,
                  int pad, int64_t ld_xc, int64_t ld_yc, int64_t ld_out, int act, const float* slope,

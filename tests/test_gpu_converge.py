@@ -13,9 +13,12 @@ holds one HIP run to max(0.1 dB, the reference's max - min over three or four ru
 reason (it did: tiny Sepformer at 0.23 dB).  The gates below run the stream SEVERAL times and compare sets with sets:
 
   * observer phase (deterministic up to summation order): every run, step for step, within max(0.1 dB, 3 x the reference's spread);
-  * rule "mean": |mean of the HIP tails - mean of the reference tails| <= max(0.1 dB, the reference's max - min, the HIP runs' max - min,
-    three standard errors of the difference of the two means) -- the two sets are no further apart than either is wide -- for the
-    SI-SDR tail (last 50 steps) and the loss tail;
+  * rule "mean": |mean of the HIP tails - mean of the reference tails| <= max(0.1 dB, the reference's max - min, the HIP runs' max - min
+    CAPPED at 1.5 x the reference's, three standard errors of the difference of the two means with the HIP variance capped alike) --
+    for the SI-SDR tail (last 50 steps) and the loss tail.  Noise is a property to bound, not a tolerance to borrow (VERDICT r04
+    weak #1): the HIP runs' own max - min must stay below a COMMITTED per-family cap (HIP_SPREAD_CAP: ~1.6 x what
+    profiles/r04_converge_repeat.txt measured over six runs), and with four or more runs below 2.5 x the reference's spread -- a
+    build that got noisier FAILS instead of widening its own gate;
   * rule "envelope" (full-size ConvTasNet, whose reference runs split by backend: see that test): every 50-step window of the
     quantizing phase, on the run-averaged trajectory, no further from the SET of reference runs than those runs are from each other;
   * it trains: the tail is better than the first steps by a family-specific margin.
@@ -56,6 +59,11 @@ def _run_streams(make_step, runs, n, B, T, seed0):
     return np.stack(S), np.stack(L)
 
 
+# max - min of the HIP runs' 50-step SI-SDR tails that a family may show (dB): ~1.6 x the six-run measurements of
+# profiles/r04_converge_repeat.txt (0.46 / 0.10 / 0.29); a committed constant, not derived from the runs under test
+HIP_SPREAD_CAP = {"tiny convtasnet": 0.75, "tiny dptnet": 0.2, "tiny sepformer": 0.5, "full-size convtasnet": 0.75}
+
+
 def _gate(name, S, L, gl, first_n, gain_db, rule="mean"):
     """S, L: [runs, steps] SI-SDR and loss of the HIP runs; gl: the reference fixture ([configurations, steps]); rules: module docstring"""
     ref, ref_loss = gl["sisdr"], gl["loss"]
@@ -69,10 +77,16 @@ def _gate(name, S, L, gl, first_n, gain_db, rule="mean"):
     ltails, ltail_ref = L[:, -50:].mean(1), ref_loss[:, -50:].mean(1)
     print(f"{name}: SI-SDR tails {np.round(tails, 3)} (mean {tails.mean():.3f}) vs reference {np.round(tail_ref, 3)} (mean {tail_ref.mean():.3f}); "
           f"loss tails {np.round(ltails, 4)} vs {np.round(ltail_ref, 4)}; observer-phase deviation {dev_early:.4f} (reference spread {spread_early:.4f})")
+    cap = HIP_SPREAD_CAP[name]
+    assert rng(tails) <= cap, f"{name}: the HIP runs' SI-SDR tails spread by {rng(tails):.3f} dB, more than the committed cap {cap} dB"
+    if len(tails) >= 4:
+        assert rng(tails) <= 2.5 * max(rng(tail_ref), 0.04), (name, rng(tails), rng(tail_ref))     # (0.04 dB: a floor for three- / four-run reference sets)
     if rule == "mean":
         for hip, rf, what in ((tails, tail_ref, "SI-SDR"), (ltails, ltail_ref, "loss")):
-            se = float(np.sqrt(rf.var(ddof=1) / len(rf) + (hip.var(ddof=1) / len(hip) if len(hip) > 1 else 0.0)))
-            tol = max(0.1, rng(rf), rng(hip), 3.0 * se)           # ... or three standard errors of the difference of the two means
+            own = min(rng(hip), 1.5 * rng(rf))                   # the HIP set's own width counts, but only up to 1.5 x the reference's
+            hv = min(float(hip.var(ddof=1)), (0.75 * rng(rf)) ** 2) / len(hip) if len(hip) > 1 else 0.0
+            se = float(np.sqrt(rf.var(ddof=1) / len(rf) + hv))
+            tol = max(0.1, rng(rf), own, 3.0 * se)                # ... or three standard errors of the difference of the two means
             assert abs(float(hip.mean()) - float(rf.mean())) <= tol, (what, hip, rf, tol)
             # no single run strays: three times that width from the reference's mean is far outside anything measured
             assert float(np.abs(hip - rf.mean()).max()) <= 3 * tol, (what, hip, rf, tol)
@@ -107,7 +121,7 @@ def test_tiny_convtasnet_trains_to_the_reference_sisdr(golden):
     _gate("tiny convtasnet", S, L, gl, 20, 8.0)                   # -16.5 dB -> -5 dB in the reference
     # the 300-step average of the quantizing phase (a tighter statistic than the 50-step tail) under the same rule
     long_ref, long_hip = gl["sisdr"][:, 100:].mean(1), S[:, 100:].mean(1)
-    tol = max(0.1, 2 * float(long_ref.max() - long_ref.min()), float(long_hip.max() - long_hip.min()))     # (round 3's rule: 2 x spread)
+    tol = max(0.1, 2 * float(long_ref.max() - long_ref.min()))     # (round 3's rule: 2 x the REFERENCE's spread; the HIP runs' own width no longer counts)
     assert abs(float(long_hip.mean()) - float(long_ref.mean())) <= tol, (long_hip, long_ref)
 
 
@@ -181,7 +195,8 @@ def test_tiny_htdemucs_trains_to_the_reference_loss(golden):
     """... and for HTDemucs (cfg 5) under the solver's objective (solver.py:333-366: L1 task + SDR-weighted L1 distillation, Adam 3e-4,
     NO clipping): tiny HTDemucsQ of hd_tiny_step.npz over 150 steps of a stream of stereo two-stem mixtures (fqss_amd.data.synth_stems).
     The reference's three CPU configurations agree to 1e-6 here (the L1 objective is far less chaotic than SI-SDR in dB), so the
-    rule is applied to the loss as an amplitude ratio (0.1 dB = 1.16 %), on the mean of two HIP runs, widened to their own spread."""
+    rule is applied to the loss as an amplitude ratio (0.1 dB = 1.16 %), on the mean of two HIP runs; the two runs may be at most 0.05 dB
+    apart (a committed cap: a noisier build fails, it does not widen the gate)."""
     from fqss_amd.data import synth_stems
     from fqss_amd.runtime import KDTrainStep
     from tests.test_gpu_htdemucs import _models
@@ -213,5 +228,6 @@ def test_tiny_htdemucs_trains_to_the_reference_loss(golden):
     print(f"tiny htdemucs: loss tails {tails} vs reference {ref[:, -50:].mean(1)} ({db(float(tails.mean()), tail_ref):.4f} dB; the two runs "
           f"{own:.4f} dB apart); worst observer-phase step {worst:.4f} dB")
     assert worst <= 0.1, worst
-    assert db(float(tails.mean()), tail_ref) <= max(0.1, own), (tails, tail_ref)
+    assert own <= 0.05, f"the two HIP runs are {own:.4f} dB apart (0.0003 dB measured in round 4; committed cap 0.05 dB)"
+    assert db(float(tails.mean()), tail_ref) <= 0.1, (tails, tail_ref)
     assert float(tails.mean()) < float(loss[:, :10].mean())          # it trains: 0.0777 -> 0.0731 in the reference

@@ -119,3 +119,43 @@ def test_val_cli_on_synthetic_mixtures(tmp_path):
     yml.write_text(yaml.safe_dump(conf))
     sisdr, imp = V.val(["-y", str(yml)])
     assert torch.isfinite(torch.tensor([sisdr, imp])).all()
+
+
+def test_infer_cli_separates_a_wav_file(tmp_path):
+    """`infer.py -y cfg.yaml -a mix.wav --normalize` (infer.py:25-87): wav in, one peak-normalised 16-bit wav per source out, chunked
+    inference on the serving path (runtime.InferRunner: codes-only forward as a hipGraph per chunk shape) -- equal to the plain
+    eval-mode `process.model_infer` of the same model up to the 16-bit file format"""
+    from scipy.io import wavfile
+    from fqss_amd import infer as I
+    from fqss_amd.data import synth_batch
+    from fqss_amd.process import model_infer
+    from fqss_amd.quantization.qat.models.load_model import create_pretrained_model, enable_observer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    conf = yaml.safe_load(open(os.path.join(root, "configs", "convtasnet_2spks_8k_synthetic.yaml")))
+    ckpt = tmp_path / "best_model.pth"
+    torch.save(create_pretrained_model(dict(conf["model_cfg"], model_path=None)).state_dict(), ckpt)
+    conf["model_cfg"]["model_path"] = str(ckpt)
+    conf["work_dir"] = str(tmp_path / "out")
+    conf["testing_cfg"] = dict(segment_samples=8000, overlap=0.25)
+    yml = tmp_path / "infer.yaml"
+    yml.write_text(yaml.safe_dump(conf))
+    mix, _ = synth_batch(1, 20000, seed=77, device="cpu")
+    pcm = (mix[0, 0].clamp(-1, 1) * 32767.0).round().to(torch.int16).numpy()
+    wav = tmp_path / "mix.wav"
+    wavfile.write(str(wav), 8000, pcm)
+    paths = I.infer(["-y", str(yml), "-a", str(wav), "--normalize"])
+    assert [os.path.basename(p) for p in paths] == ["output0.wav", "output1.wav"]
+    # the same through the plain module path
+    model = create_pretrained_model(conf["model_cfg"])
+    enable_observer(model, False)
+    model.to("cuda").eval()
+    x = torch.from_numpy(pcm.astype("float32") / 32768.0).reshape(1, -1).cuda()
+    m, sd = x.mean(), x.std()
+    ref = model_infer(model, (x - m) / sd, n_srcs=2, segment=8000, overlap=0.25, device="cuda") * sd + m
+    for k, p in enumerate(paths):
+        fs, a = wavfile.read(p)
+        assert fs == 8000 and a.dtype.name == "int16" and a.shape == (20000,)
+        got = torch.from_numpy(a.astype("float32") / 32768.0)
+        want = (ref[k] / ref[k].abs().max()).reshape(-1).cpu()
+        assert abs(float(got.abs().max()) - 1.0) <= 1e-3                     # peak-normalised (process.normalize_audio)
+        assert float((got - want).abs().max()) <= 2.0 / 32768.0, float((got - want).abs().max())
