@@ -137,6 +137,7 @@ def test_infer_cli_separates_a_wav_file(tmp_path):
     conf["model_cfg"]["model_path"] = str(ckpt)
     conf["work_dir"] = str(tmp_path / "out")
     conf["testing_cfg"] = dict(segment_samples=8000, overlap=0.25)
+    conf["dataset_cfg"]["resample"] = 1                  # (the file below is already at the model's 8 kHz)
     yml = tmp_path / "infer.yaml"
     yml.write_text(yaml.safe_dump(conf))
     mix, _ = synth_batch(1, 20000, seed=77, device="cpu")
