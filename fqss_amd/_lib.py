@@ -150,6 +150,7 @@ _PROTOS = {
     "fqss_qrow_bwd_w": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_qrow_bwd_wb": [P, P, P, P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_qrow_bwd_w_batched": [P, P, P, P, P, I64, I32, I32, I64, I64, I64, I32, I64, I64, I64, P],
+    "fqss_qrow_bwd_w_group": [P, I32, P],
     "fqss_glu_fwd": [P, P, I64, I64, I64, I64, I64, P],
     "fqss_glu_bwd": [P, P, P, I64, I64, I64, I64, I64, I64, P],
     "fqss_div_fwd": [P, P, P, I64, P],
@@ -213,6 +214,12 @@ class FqssGnAfter(C.Structure):
 class FqssGnBefore(C.Structure):
     _fields_ = [("xc0", C.c_void_p), ("ld_xc0", C.c_int64), ("qmin0", C.c_void_p), ("qmax0", C.c_void_p), ("gamma", C.c_void_p),
                 ("beta", C.c_void_p), ("mean_rstd", C.c_void_p), ("ws", C.c_void_p), ("gacc", C.c_void_p)]
+
+
+class FqssRowWgradJob(C.Structure):
+    _fields_ = [("gz", C.c_void_p), ("xc", C.c_void_p), ("qmin_x", C.c_void_p), ("qmax_x", C.c_void_p), ("gw", C.c_void_p),
+                ("gbias", C.c_void_p), ("R", C.c_int64), ("Ci", C.c_int32), ("Co", C.c_int32), ("ld_gz", C.c_int64),
+                ("ld_xc", C.c_int64), ("ld_gw", C.c_int64)]
 
 
 class FqssWgradJob(C.Structure):

@@ -275,8 +275,10 @@ struct TileIOQ {
 //   1  wgrad  gw[o][i] += sum_r gz[r][o] x[r][i],  x = dx c + min_x:  A = gz^T, B = activation codes; the epilogue applies
 //             dx * acc + min_x * sum_r gz[r][o] (the k-sums of A's rows accumulate next to the split)
 //   2  dgrad  gx[r][i]  = sum_o gz[r][o] w_q[o][i], w_q = dw[o] wi:   A = gz scaled by dw[k] before the split, B = int8 weight codes
+// (the body is a device function of (problem, tile coordinates): k_gemm_x3 runs it on its own grid, k_gemm_x3_wq_multi on the tiles of
+// several problems in one launch)
 template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0, bool IMP = false, bool BPL = false>
-__global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
+__device__ __forceinline__ void x3_body(GemmArgs3 g, const int bx, const int by, const int bz) {
     constexpr int BMt = 64 * MI, BNt = 64 * NI;
     // LDS: three bf16 planes of the A tile, three (one for 8-bit codes) of the B tile, sized by the tile: the 64-row and the coded forms
     // leave room for a third / fourth workgroup per CU (128 x 128 float: 49 KB -> 3 per CU; 128 x 128 coded 33 KB -> 4; 64 x 128 coded
@@ -292,15 +294,15 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int zb = ATOMIC ? (int)blockIdx.z / g.ksplit : (int)blockIdx.z;
-    const int ks = ATOMIC ? (int)blockIdx.z - zb * g.ksplit : 0;
+    const int zb = ATOMIC ? bz / g.ksplit : bz;
+    const int ks = ATOMIC ? bz - zb * g.ksplit : 0;
     g.A += (int64_t)zb * g.sAb;
     g.B += (int64_t)zb * g.sBb;
     g.C += (int64_t)zb * g.sCb;
     if constexpr (BQ != 0) g.Bq = static_cast<const unsigned char*>(g.Bq) + (int64_t)zb * g.sBb;      // (codes: 1 B per element)
     const int kbeg = ATOMIC ? ks * g.kchunk : 0;
     const int kend = ATOMIC ? min(g.K, kbeg + g.kchunk) : g.K;
-    const int i0 = blockIdx.y * BMt, j0 = blockIdx.x * BNt;
+    const int i0 = by * BMt, j0 = bx * BNt;
 
     static_assert(BQ == 0 || !B_KC, "coded B tiles are j-contiguous");
     static_assert(!IMP || BQ == 0, "implicit convolution: float operands");
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
         dx = (hi - lo) / 255.0f;
         mnx = lo;
         // (the first column tile of every k-slice hands its row sums on: the bias gradient, summed over the slices by the atomics)
-        if (g.rowsum_out != nullptr && blockIdx.x == 0 && threadIdx.x < BMt && i0 + (int)threadIdx.x < g.M)
+        if (g.rowsum_out != nullptr && bx == 0 && threadIdx.x < BMt && i0 + (int)threadIdx.x < g.M)
             atomicAdd(&g.rowsum_out[i0 + threadIdx.x], rsum_s[threadIdx.x]);
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -483,6 +485,46 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
                 }
             }
         }
+}
+
+template <bool A_KC, bool B_KC, bool ATOMIC, int MI, int NI, int BQ = 0, bool IMP = false, bool BPL = false>
+__global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
+    x3_body<A_KC, B_KC, ATOMIC, MI, NI, BQ, IMP, BPL>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several coded weight gradients (BQ = 1: gw[o][i] += sum_r gz[r][o] x[r][i] on the input's codes) in ONE launch (round 5).  The weight
+// gradients of a backward segment's row-major linears feed nothing but the optimizer, so the host queues them and runs them together
+// (ops_dp.RowWgradQueue, runtime.QuantTables.finish_backward).  Why it pays: one such GEMM is 16 output tiles x 16 k-slices = 256
+// workgroups -- ONE per CU, each a serial chain of ~17 k-tiles (load -> split -> LDS -> barrier -> MFMA, ~1 us each: these short-K
+// GEMMs are bound by that latency) -- so a launch takes ~37 us at 0.12 of its roofline with nothing to overlap the
+// chain with.  32 problems in one grid are 4096+ workgroups: three to four resident per CU overlap their chains, the k-split can be
+// coarser (fewer float atomics), and the ~8 us of fixed cost per launch is paid once.  The job table travels in the kernel arguments.
+constexpr int X3W_MAXJOBS = 32;
+struct X3WJob {
+    const float* A; const void* Bq; float* C; float* rowsum_out; const float* qmin; const float* qmax;
+    int64_t sAk, sBk, sCi;
+    int M, N, K, ksplit, kchunk, gx, gy, start;      // grid of this problem (gx x gy tiles x ksplit slices), its first workgroup
+};
+struct X3WMulti {
+    int n, total;
+    X3WJob j[X3W_MAXJOBS];
+};
+static_assert(sizeof(X3WMulti) <= 4096, "the job table travels in the kernel arguments");
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void k_gemm_x3_wq_multi(X3WMulti m) {
+    int p = 0;
+    for (int q = 1; q < m.n; ++q) p = (m.j[q].start <= (int)blockIdx.x) ? q : p;
+    const X3WJob& J = m.j[p];
+    const int local = (int)blockIdx.x - J.start, gx = J.gx, gy = J.gy;
+    const int bx = local % gx, t = local / gx, by = t % gy, bz = t / gy;
+    GemmArgs3 g{};
+    g.A = J.A; g.C = J.C; g.M = J.M; g.N = J.N; g.K = J.K;
+    g.sAi = 1; g.sAk = J.sAk; g.sBk = J.sBk; g.sBj = 1; g.sCi = J.sCi;
+    g.ksplit = J.ksplit; g.kchunk = J.kchunk;
+    g.Bq = J.Bq; g.qmin_x = J.qmin; g.qmax_x = J.qmax; g.rowsum_out = J.rowsum_out;
+    g.batch = 1;
+    x3_body<false, false, true, MI, NI, 1>(g, bx, by, bz);
 }
 
 static inline int64_t rup4x(int64_t v) { return (v + 3) & ~(int64_t)3; }
@@ -624,3 +666,62 @@ int launch_gemm_x3q(const GemmArgs3& g_in, int bq, hipStream_t s, const char* wh
 }
 
 }  // namespace fqss
+
+using namespace fqss;
+
+/* fqss_qrow_bwd_wb for SEVERAL linears in one launch per <= 32 jobs of one tile shape (k_gemm_x3_wq_multi). */
+extern "C" int fqss_qrow_bwd_w_group(const FqssRowWgradJob* jobs, int njobs, fqss_stream_t stream) {
+    if (njobs == 0) return FQSS_OK;
+    FQSS_REQUIRE(jobs && njobs > 0, "no jobs");
+    for (int q = 0; q < njobs; ++q) {
+        const FqssRowWgradJob& f = jobs[q];
+        FQSS_REQUIRE(f.gz && f.xc && f.qmin_x && f.qmax_x && f.gw, "null tensor");
+        FQSS_REQUIRE(f.R > 0 && f.R < (1ll << 31) && f.Ci > 0 && f.Co > 0 && f.ld_gz >= f.Co && f.ld_xc >= f.Ci && f.ld_gw >= f.Ci, "bad shape");
+        FQSS_REQUIRE(f.Ci % 4 == 0 && f.Co % 4 == 0 && f.ld_gz % 4 == 0 && f.ld_xc % 4 == 0 && aligned16(f.gz) && ((uintptr_t)f.xc & 3) == 0,
+                     "coded wgrad: Ci, Co and the row strides must be multiples of 4, operands aligned");
+    }
+    // one launch per tile shape (the rule of launch_gemm_x3q for split-K weight gradients) and per 32 jobs
+    for (int shape = 0; shape < 4; ++shape) {
+        const int mi = (shape & 1) ? 2 : 1, ni = (shape & 2) ? 2 : 1;
+        int idx[1024], cnt = 0;
+        for (int q = 0; q < njobs && cnt < 1024; ++q) {
+            const FqssRowWgradJob& f = jobs[q];
+            const int jni = f.Ci <= 64 ? 1 : 2;
+            const int jmi = (f.Co > 64 && f.Ci > 64) ? 2 : ((jni == 2 && f.Co <= 64) ? 1 : 2);
+            if (jmi == mi && jni == ni) idx[cnt++] = q;
+        }
+        for (int n0 = 0; n0 < cnt; n0 += X3W_MAXJOBS) {
+            const int n = cnt - n0 < X3W_MAXJOBS ? cnt - n0 : X3W_MAXJOBS;
+            int64_t tiles = 0;
+            for (int q = 0; q < n; ++q) tiles += cdiv(jobs[idx[n0 + q]].Co, 64 * mi) * cdiv(jobs[idx[n0 + q]].Ci, 64 * ni);
+            // aim for ~12 workgroups per CU over the launch; every k-slice ADDS its whole tile with float atomics, so no finer than needed
+            int want = (int)cdiv(3072, tiles);
+            X3WMulti m{};
+            m.n = n;
+            int start = 0;
+            for (int q = 0; q < n; ++q) {
+                const FqssRowWgradJob& f = jobs[idx[n0 + q]];
+                X3WJob& J = m.j[q];
+                J.A = f.gz; J.Bq = f.xc; J.C = f.gw; J.rowsum_out = f.gbias; J.qmin = f.qmin_x; J.qmax = f.qmax_x;
+                J.sAk = f.ld_gz; J.sBk = f.ld_xc; J.sCi = f.ld_gw;
+                J.M = f.Co; J.N = f.Ci; J.K = (int)f.R;
+                int kchunk = (int)cdiv(cdiv(f.R, want), 64) * 64;
+                if (kchunk < 256) kchunk = 256;
+                J.kchunk = kchunk;
+                J.ksplit = (int)cdiv(f.R, kchunk);
+                J.gx = (int)cdiv(f.Ci, 64 * ni); J.gy = (int)cdiv(f.Co, 64 * mi);
+                J.start = start;
+                start += J.gx * J.gy * J.ksplit;
+            }
+            m.total = start;
+            const dim3 grid((unsigned)start), block(256);
+            hipStream_t s = (hipStream_t)stream;
+            if (mi == 2 && ni == 2) hipLaunchKernelGGL((k_gemm_x3_wq_multi<2, 2>), grid, block, 0, s, m);
+            else if (mi == 2) hipLaunchKernelGGL((k_gemm_x3_wq_multi<2, 1>), grid, block, 0, s, m);
+            else if (ni == 2) hipLaunchKernelGGL((k_gemm_x3_wq_multi<1, 2>), grid, block, 0, s, m);
+            else hipLaunchKernelGGL((k_gemm_x3_wq_multi<1, 1>), grid, block, 0, s, m);
+            if (int rc = launch_status("fqss_qrow_bwd_w_group")) return rc;
+        }
+    }
+    return FQSS_OK;
+}

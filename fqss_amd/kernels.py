@@ -1874,6 +1874,35 @@ def qrow_bwd_w(gz, xc, qmin_x, qmax_x, gw, gbias=None):
         _lib.call("fqss_qrow_bwd_w", _p(gz), _p(xc), _p(qmin_x), _p(qmax_x), _p(gw), R, Ci, Co, ld_gz, rm[2], Ci, _stream())
 
 
+class RowWgradQueue:
+    """coded weight gradients of row-major linears queued over a backward segment and run by ONE launch per <= 32 of them
+    (fqss_qrow_bwd_w_group): a single such GEMM is 256 workgroups of latency-bound k-tile chains, thousands overlap them"""
+
+    def __init__(self):
+        self.jobs = []
+
+    def push(self, gz, xc, qmin_x, qmax_x, gw, gbias=None):
+        _need_gpu(gz, gw, gbias)
+        Co, Ci = gw.shape
+        assert xc.dtype == torch.uint8 and xc.shape[-1] == Ci and gw.is_contiguous()
+        gz, R, ld_gz = _rows(gz, Co)
+        rm = rowmat(xc)
+        assert rm is not None and rm[0] == R and rm[1] == Ci
+        assert gbias is None or (gbias.numel() == Co and gbias.is_contiguous())
+        self.jobs.append((gz, xc, qmin_x, qmax_x, gw, gbias, R, Ci, Co, ld_gz, rm[2]))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        n = len(self.jobs)
+        arr = (_lib.FqssRowWgradJob * n)()
+        for j, (gz, xc, lo, hi, gw, gb, R, Ci, Co, ld_gz, ld_xc) in zip(arr, self.jobs):
+            j.gz, j.xc, j.qmin_x, j.qmax_x, j.gw, j.gbias = _p(gz), _p(xc), _p(lo), _p(hi), _p(gw), _p(gb)
+            j.R, j.Ci, j.Co, j.ld_gz, j.ld_xc, j.ld_gw = R, Ci, Co, ld_gz, ld_xc, Ci
+        _lib.call("fqss_qrow_bwd_w_group", arr, n, _stream())
+        self.jobs = []
+
+
 def qrow_bwd_w_pair(gz0, gz1, xc, qmin_x, qmax_x, gw0, gw1):
     """two coded weight gradients against the SAME input codes in one launch (gz0 / gz1: two column blocks of one tensor)"""
     _need_gpu(gz0, gz1, gw0, gw1)

@@ -45,13 +45,20 @@ def _rowlinear_dgrad(gz, w):
 WGRAD_BIAS = __import__("os").environ.get("FQSS_WGRAD_BIAS", "1") != "0"    # the bias gradient out of the coded weight-gradient launch
 
 
-def _rowlinear_wgrad_into(gz, x, xq, buf, gbias=None):
+def _rowlinear_wgrad_into(gz, x, xq, buf, gbias=None, defer=False):
     """buf [Co, Ci] += gz^T x: from the activation's u8 codes when the forward ran on them.  gbias (optional, [Co]): the linear's bias
-    gradient buffer -- the coded launch adds the column sums of gz into it on the side; returns True when it did"""
+    gradient buffer -- the coded launch adds the column sums of gz into it on the side; returns True when it did.
+    defer: buf (and gbias) are accumulation buffers that outlive this backward node (the step's dL/dW_q arena, a parameter's own
+    gradient): with a runtime.QuantTables active the launch is queued and runs with the segment's other weight gradients
+    (kernels.RowWgradQueue: one grouped launch instead of one 256-workgroup launch per linear)"""
     if QROW_BWD and xq is not None and buf.dim() == 2 and buf.is_contiguous() and xq.idx.is_contiguous() \
             and xq.idx.shape[-1] == buf.shape[1] and K.qrow_bwd_ok(buf.shape[1], buf.shape[0]):
         with_bias = WGRAD_BIAS and gbias is not None and gbias.is_contiguous() and gbias.numel() == buf.shape[0]
-        K.qrow_bwd_w(gz, xq.idx, xq.qmin, xq.qmax, buf, gbias if with_bias else None)
+        rq = getattr(ops.DEFER, "row_wgrad_queue", None) if defer else None
+        if rq is not None:
+            rq.push(gz, xq.idx, xq.qmin, xq.qmax, buf, gbias if with_bias else None)
+        else:
+            K.qrow_bwd_w(gz, xq.idx, xq.qmin, xq.qmax, buf, gbias if with_bias else None)
         return with_bias
     K.rowlin_bwd_w(gz, x, buf)
     return False
@@ -89,7 +96,7 @@ class RowLinear(Function):
             gb, gb_direct = _param_grad(ctx.bias, ctx.bias)
         gwq = getattr(w, "_fqss_gwq", None)     # weight fake-quantized by runtime.QuantTables (no autograd history): dL/dW_q goes
         if gwq is not None:                     # into the step's arena, consumed by fqss_wq_multi_bwd
-            gb_done = _rowlinear_wgrad_into(gz, x, xq, gwq, gb)
+            gb_done = _rowlinear_wgrad_into(gz, x, xq, gwq, gb if gb_direct else None, defer=True)
         elif ctx.needs_input_grad[1]:
             gw, direct = _param_grad(w, w)
             gb_done = _rowlinear_wgrad_into(gz, x, xq, gw, gb)
@@ -103,7 +110,7 @@ def _rowlinear_wgrad(ctx_needs_w, x, w, gz, xq=None):
     """dL/dW of z = x @ w^T: into the step's dL/dW_q arena when w was fake-quantized by runtime.QuantTables, else the autograd way"""
     gwq = getattr(w, "_fqss_gwq", None)
     if gwq is not None:
-        _rowlinear_wgrad_into(gz, x, xq, gwq)
+        _rowlinear_wgrad_into(gz, x, xq, gwq, defer=True)
         return None
     if ctx_needs_w:
         gw, direct = _param_grad(w, w)

@@ -320,6 +320,8 @@ class QuantTables:
         # grouped, atomics-free weight gradients of the quantized 1x1 convolutions (csrc/qgemm.hip k_qwgrad_group); FQSS_GROUP_WGRAD=0:
         # one k_qwgrad2 launch per layer where autograd reaches it (rounds 2-4)
         self.wgrad_queue = K.WgradQueue() if os.environ.get("FQSS_GROUP_WGRAD", "1") != "0" else None
+        # ... and of the row-major linears of the dual-path / transformer models (csrc/gemm_x3.hip k_gemm_x3_wq_multi)
+        self.row_wgrad_queue = K.RowWgradQueue() if os.environ.get("FQSS_GROUP_WGRAD", "1") != "0" else None
         # ---- per-segment views of the two finish tables (descriptor 15 = first block is renumbered per table) -----------------
         self.seg_tables = None
         if segments is not None and len(segments) > 1:
@@ -344,6 +346,8 @@ class QuantTables:
         K.wq_multi_fwd(self.wq_table, self.total_channels)
         if self.wgrad_queue is not None:
             self.wgrad_queue.jobs = []        # (a backward that never reached finish_backward leaves nothing behind)
+        if self.row_wgrad_queue is not None:
+            self.row_wgrad_queue.jobs = []
 
     def finish_backward(self, seg=None):
         """after autograd (of backward segment `seg`, or of the whole network): weight STE/range gradients from the dL/dW_q arena,
@@ -352,6 +356,8 @@ class QuantTables:
             # the weight gradients of this segment's quantized 1x1 convolutions, queued by their autograd nodes (ops.LinearActQ /
             # LinearActQPair): ONE grouped launch per <= 25 layers, before the weight STE below reads the dL/dW_q arena
             self.wgrad_queue.flush()
+        if self.row_wgrad_queue is not None:
+            self.row_wgrad_queue.flush()
         if seg is None or self.seg_tables is None:
             K.wq_multi_bwd(self.wq_table, self.total_channels)
             K.gacc_flush_multi(self.flush_table)

@@ -798,6 +798,19 @@ int fqss_qrow_bwd_w(const float* gz, const uint8_t* xc, const float* qmin_x, con
  * product anyway): replaces the `fqss_colsum` pass behind F.linear's autograd (qat_layers.py:521-536) */
 int fqss_qrow_bwd_wb(const float* gz, const uint8_t* xc, const float* qmin_x, const float* qmax_x, float* gw, float* gbias, int64_t R, int Ci,
                      int Co, int64_t ld_gz, int64_t ld_xc, int64_t ld_gw, fqss_stream_t stream);
+
+/* The coded weight gradients of SEVERAL row-major linears in one launch per <= 32 jobs (csrc/gemm_x3.hip k_gemm_x3_wq_multi; round 5):
+ * per job exactly fqss_qrow_bwd_wb (gbias nullable: fqss_qrow_bwd_w) -- gw[o][i] += sum_r gz[r][o] (dx c[r][i] + min_x), gbias[o] +=
+ * sum_r gz[r][o].  The weight gradients of LinearQ / LinearNlQ / the attention projections (autograd of F.linear, qat_layers.py:
+ * 521-568, 865-950) feed nothing but the optimizer, so the host may queue them over a backward segment; one launch of thousands of
+ * workgroups overlaps the latency-bound k-tile chains that a single 256-workgroup launch serialises.  `jobs` is a HOST array. */
+typedef struct FqssRowWgradJob {
+    const float* gz; const uint8_t* xc; const float* qmin_x; const float* qmax_x;
+    float* gw; float* gbias;
+    int64_t R; int32_t Ci, Co;
+    int64_t ld_gz, ld_xc, ld_gw;
+} FqssRowWgradJob;
+int fqss_qrow_bwd_w_group(const FqssRowWgradJob* jobs, int njobs, fqss_stream_t stream);
 /* `batch` coded weight gradients of one shape and one input range in ONE launch: problem p reads gz + p*sb_gz (floats), xc + p*sb_xc
  * (bytes) and adds into gw + p*sb_gw (floats) -- the W_ih gradients of the two directions of LSTMQ (qat_layers.py:571-600): two column
  * blocks of dG against the same input codes */

@@ -487,6 +487,41 @@ def test_grouped_weight_gradients(case):
     q.jobs = []
 
 
+def test_grouped_row_weight_gradients():
+    """fqss_qrow_bwd_w_group (round 5): the coded weight gradients (+ bias column sums) of several row-major linears in one launch per
+    tile shape -- the Sepformer layer's four linears, DPTNet's 64-wide ones (a second tile shape), ragged sizes, 40 jobs (two launches)
+    -- against fp64 and against fqss_qrow_bwd_wb one by one.  Reference: autograd of F.linear in LinearQ / MultiheadAttentionQ
+    (qat_layers.py:521-568, 889-901)."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    shapes = [(8500, 256, 768), (8500, 256, 256), (8500, 256, 1024), (8500, 1024, 256), (16500, 64, 256), (16500, 64, 64), (777, 48, 36),
+              (130, 128, 200)] + [(1000 + 37 * i, 64 + 32 * (i % 4), 32 + 32 * (i % 7)) for i in range(32)]
+    lo, hi = torch.tensor([-1.3], device=dev), torch.tensor([2.1], device=dev)
+    q = K.RowWgradQueue()
+    refs, outs, biases, jobs = [], [], [], []
+    for k, (R, Ci, Co) in enumerate(shapes):
+        gz = (torch.randn(R, Co, generator=g) * torch.exp(torch.randn(R, Co, generator=g)) * 1e-3).to(dev)
+        xc = torch.randint(0, 256, (R, Ci), generator=g, dtype=torch.uint8).to(dev)
+        gw0, gb0 = (torch.randn(Co, Ci, generator=g) * 1e-3).to(dev), (torch.randn(Co, generator=g) * 1e-3).to(dev)
+        x64 = xc.double() * ((hi - lo).double() / 255.0) + lo.double()
+        refs.append((gz.double().t() @ x64, gz.double().sum(0)))
+        gw, gb = gw0.clone(), (gb0.clone() if k % 3 != 2 else None)
+        q.push(gz, xc, lo, hi, gw, gb)
+        outs.append((gw, gb, gw0, gb0))
+        jobs.append((gz, xc))
+    q.flush()
+    torch.cuda.synchronize()
+    for k, ((rw, rb), (gw, gb, gw0, gb0)) in enumerate(zip(refs, outs)):
+        ew = float(((gw.double() - gw0.double()) - rw).norm()) / float(rw.norm())
+        assert ew <= 2e-6, (k, shapes[k], ew)
+        if gb is not None:
+            eb = float(((gb.double() - gb0.double()) - rb).norm()) / float(rb.norm())
+            assert eb <= 2e-6, (k, shapes[k], eb)
+        one, oneb = torch.zeros_like(gw), torch.zeros(gw.shape[0], device=dev)
+        K.qrow_bwd_w(jobs[k][0], jobs[k][1], lo, hi, one, oneb)
+        assert float((one.double() - (gw.double() - gw0.double())).norm()) <= 2e-6 * float(rw.norm()), k
+
+
 def test_pit_sisdr_loss_teacher_free():
     """fqss_pit_sisdr_loss (kd_lambda = 0, mysystem.py:153-156) against the oracle's neg_sisdr_pit: loss 1e-5, per-sample SI-SDR 1e-3 dB,
     dL/d est; one sample has its sources swapped so both permutations are exercised"""
