@@ -69,7 +69,7 @@ def dominant_kernel_roofline(dev, ms_step):
     times = [RC.time_case(c) for c in cases]
     groups = RC.summarize(cases, times)
     pmc, pmc_file = {}, None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc, pmc_file = json.load(f).get("per_launch_bytes", {}), "profiles/" + name
@@ -181,19 +181,36 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
         o["note"] = ("a chain of 250 dependent time steps on 194 of 256 CUs: bound by the issue of ~360 vector instructions per wave and step "
                      "(256 of them the FMAs) + 2 barriers per step (DESIGN.md 7, 9); neither roofline binds it")
         return o
-    # cfg 4 (profiles/r*_cfg4_step_table.txt): the weight gradient of the student's coded linears, k_gemm_x3<false, false, true, 2, 2, 1> --
-    # A = gz^T (fp32, three bf16 pieces), B = the input's u8 codes (one exact plane): three products per k
+    # cfg 4 (profiles/r05_cfg4_step_table.txt): since round 5 the coded weight gradients run as four grouped launches (2.0 ms per step
+    # together) and the kernel with the largest time per step is the coded DATA gradient of the student's linears,
+    # k_gemm_x3<true, false, false, 1, 2, 2> (fqss_qrow_bwd_x): A = gz (fp32, three bf16 pieces, scaled by delta_w), B = the weight's int8
+    # codes (one exact plane): three products per k.  Timed at its heaviest shape, the feed-forward's 256 -> 1024 linear
     gz = torch.randn(rows, Co, device="cuda")
-    xc = torch.randint(0, 256, (rows, Ci), device="cuda", dtype=torch.uint8)
-    lo, hi = torch.tensor([-1.0], device="cuda"), torch.tensor([1.0], device="cuda")
-    gw = torch.zeros(Co, Ci, device="cuda")
-    us = _time_launches(lambda: K.qrow_bwd_w(gz, xc, lo, hi, gw))
-    nbytes = 4.0 * rows * Co + rows * Ci + 4.0 * Co * Ci
-    o = {"kernel": "k_gemm_x3<false, false, true, 2, 2, 1> (fqss_qrow_bwd_w)", "what": "weight gradient of the " + what + " on the input's codes",
-         "shape": [rows, Ci, Co], "launch_us": round(us, 1), "launches_per_step": 128, "algorithmic_bytes_per_launch": int(nbytes)}
+    wc = K.wq_codes(torch.randn(Co, Ci, 1, device="cuda") * 0.05, -torch.ones(Co, 1, 1, device="cuda") * 0.2, torch.ones(Co, 1, 1, device="cuda") * 0.2)
+    us = _time_launches(lambda: K.qrow_bwd_x(gz, wc))
+    nbytes = 4.0 * rows * Co + Co * Ci + 4.0 * rows * Ci
+    o = {"kernel": "k_gemm_x3<true, false, false, 1, 2, 2> (fqss_qrow_bwd_x)", "what": "data gradient of the " + what + " from the weight's int8 codes",
+         "shape": [rows, Ci, Co], "launch_us": round(us, 1), "launches_per_step": 96, "algorithmic_bytes_per_launch": int(nbytes)}
     o.update(RC.priced(2.0 * rows * Ci * Co, 3, "bf16", nbytes, us))
-    o["traffic"] = _pmc_other("k_gemm_x3", f"{rows} x {Ci} -> {Co}")
-    o["note"] = "bound by vector-ALU issue of the operand split and by the split-K atomics (DESIGN.md 7e (4)), not by either roofline"
+    o["traffic"] = _pmc_other("k_gemm_x3", f"dgrad {rows} x {Co} -> {Ci}")
+    # ... and the grouped weight gradients beside it: one launch = the four linears of 8 transformer layers (32 jobs)
+    q = K.RowWgradQueue()
+    lo, hi = torch.tensor([-1.0], device="cuda"), torch.tensor([1.0], device="cuda")
+    shapes = [(256, 768), (256, 256), (256, 1024), (1024, 256)] * 8
+    ops_ = [(torch.randn(rows, co, device="cuda"), torch.randint(0, 256, (rows, ci), device="cuda", dtype=torch.uint8), torch.zeros(co, ci, device="cuda"),
+             torch.zeros(co, device="cuda")) for ci, co in shapes]
+
+    def grouped():
+        for a, c, gw_, gb_ in ops_:
+            q.push(a, c, lo, hi, gw_, gb_)
+        q.flush()
+    ug = _time_launches(grouped, 5)
+    gb = sum(4.0 * rows * co + rows * ci + 4.0 * co * ci for ci, co in shapes)
+    og = {"kernel": "k_gemm_x3_wq_multi<2, 2> (fqss_qrow_bwd_w_group)", "what": "coded weight gradients of 32 linears (8 transformer layers) in one launch",
+          "launch_us": round(ug, 1), "launches_per_step": 4, "algorithmic_bytes_per_launch": int(gb)}
+    og.update(RC.priced(sum(2.0 * rows * ci * co for ci, co in shapes), 3, "bf16", gb, ug))
+    o["other_kernels"] = [og]
+    o["note"] = "bound by vector-ALU issue of the operand split and by the latency of a k-tile (DESIGN.md 7e (4), (7)), not by either roofline"
     return o
 
 
@@ -220,9 +237,9 @@ def cpu_baseline_dualpath(which, model, fmodel, lr, T):
     t0 = time.perf_counter()
     tr.step(x, tgt)
     sec = time.perf_counter() - t0
-    return {"value": round((Tc / T) / sec, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"one full QAT step of the oracle on 1 x {Tc} samples ({sec:.1f} s), scaled by {Tc}/{T} to the workload's "
-                      f"segment length, torch CPU fp32"}
+    return {"value": round((Tc / T) / sec, 4), "unit": "samples/s", "cores": cores, "kind": "port", "extrapolated": Tc != T,
+            "sample": f"EXTRAPOLATED: one full QAT step of the oracle on a 1 x {Tc}-sample excerpt ({sec:.1f} s), scaled linearly by {Tc}/{T} "
+                      f"to the workload's segment length (a full-length oracle step takes minutes), torch CPU fp32"}
 
 
 def main_dualpath(a, comm=None):
@@ -379,9 +396,9 @@ def cpu_baseline_htdemucs(model, fmodel, B, T):
     loss = H.solver_loss(est, fest, src)[0]
     loss.backward()
     sec = time.perf_counter() - t0
-    return {"value": round((Tc / T) / sec, 5), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"one QAT step of the oracle (student fwd + bwd, teacher fwd, loss; no optimizer) on 1 x {Tc} samples ({sec:.1f} s), "
-                      f"scaled by {Tc}/{T} to the workload's segment length, torch CPU fp32"}
+    return {"value": round((Tc / T) / sec, 5), "unit": "samples/s", "cores": cores, "kind": "port", "extrapolated": Tc != T,
+            "sample": f"EXTRAPOLATED: one QAT step of the oracle (student fwd + bwd, teacher fwd, loss; no optimizer) on a 1 x {Tc}-sample "
+                      f"excerpt ({sec:.1f} s), scaled linearly by {Tc}/{T} to the workload's segment length, torch CPU fp32"}
 
 
 def main_htdemucs(a, comm=None):

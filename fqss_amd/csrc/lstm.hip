@@ -219,7 +219,9 @@ __device__ __forceinline__ float gate_fn(float x, bool th) {
     const float r = __builtin_amdgcn_rcpf(d);
     float q = n * r;
     q = fmaf(fmaf(-d, q, n), r, q);
-    if (!th) return q;
+    // v_med3_f32 returns min3 when an input is NaN: the clamp above would launder a NaN pre-activation into sigmoid ~ 1.7e-38.  A NaN
+    // must stay a NaN (libm's did): one v_cmp_u + v_cndmask off the critical chain
+    if (!th) return (x != x) ? x : q;
     const float u = a * a;
     float p = fmaf(u, 0.019728317856788635f, -0.0537986196577549f);
     p = fmaf(u, p, 0.13332897424697876f);

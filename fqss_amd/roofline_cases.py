@@ -47,7 +47,8 @@ def priced(flops, products, dtype, nbytes, us):
 
 # partial products issued per algorithmic product, and on which pipe (csrc/teacher.hip: 3 x 3 bf16 split, 6 leading terms; csrc/qgemm.hip:
 # fp32 gradient in three exact bf16 pieces x one exact plane of 8-bit codes; forward: codes x codes, one bf16 product)
-ISSUED = {"k_tgemm2<0>": ("bf16", 6), "k_tgemm2<1>": ("bf16", 6), "k_qgemm<1>": ("bf16", 3), "k_qwgrad2": ("bf16", 3), "k_qgemm<0>": ("bf16", 1),
+ISSUED = {"k_tgemm2<0>": ("bf16", 6), "k_tgemm2<1>": ("bf16", 6), "k_qgemm<1>": ("bf16", 3), "k_qwgrad2": ("bf16", 3), "k_qwgrad_group": ("bf16", 3),
+          "k_qgemm<0>": ("bf16", 1), "k_gemm_x3_wq_multi": ("bf16", 3),
           "k_lstm_fwd_st<128>": ("f32", 1), "k_gemm_x3": ("bf16", 3), "k_qgemm<3>": ("bf16", 6), "k_attn_long_fwd_x3<64>": ("bf16", 6),
           "k_attn_long_fwd_c<64>": ("bf16", 3)}
 
@@ -104,10 +105,24 @@ def build(dev, sets=3):
     pc.dw, pc.rw = torch.cat([wr_.dw, ws_.dw]), torch.cat([wr_.rw, ws_.rw])
     bu, bd, bd2 = torch.randn(NH, device=dev), torch.randn(NB, device=dev), torch.randn(NB, device=dev)
     gw_up, gw_pair = torch.zeros(NH, NB, device=dev), torch.zeros(2 * NB, NH, device=dev)
-    case("k_qwgrad2", "student wgrad 128->512 (fp32 gz x u8 codes)", "hbm", 24, (4.0 * NH + NB) * n, 4.0 * NH * NB, 4.0 * (NH + NB) * n,
-         lambda i: K.qpw_bwd_w(gz_h[i % sets], xc_b[i % sets], lo, hi, gw_up), flops=fl)
-    case("k_qwgrad2", "student wgrad res|skip pair 512->128+128 (fp32 gz x u8 codes)", "hbm", 24, (8.0 * NB + NH) * n, 8.0 * NH * NB, 4.0 * (NH + 2 * NB) * n,
-         lambda i: K.qpw_bwd_w2(gz_b[i % sets], gz_b2[i % sets], xc_h[i % sets], lo, hi, gw_pair), flops=2 * fl)
+    # round 5: the weight gradients of the step's 50 quantized 1x1 convolutions run as TWO grouped launches of 25 layers (k_qwgrad_group:
+    # 32 teams of 8 workgroups over the (layer, tile group, 64-frame stage) work list, slab reduction in part order, no atomics); the case
+    # is one such launch -- 12 TCN blocks (conv1 128 -> 512 + the res | skip pair) + one 512 -> 128 layer, every layer on its own operands
+    wq_jobs = []
+    for bi in range(12):       # (own operands per layer, 1.4 GB: inside one launch nothing may be served from the 256 MB Infinity Cache twice)
+        wq_jobs.append((_act(NH, dev), None, _codes(NB, dev), torch.zeros(NH, NB, device=dev)))
+        wq_jobs.append((_act(NB, dev), _act(NB, dev), _codes(NH, dev), torch.zeros(2 * NB, NH, device=dev)))
+    wq_jobs.append((gz_b[0], None, xc_h[0], torch.zeros(NB, NH, device=dev)))
+    wq_queue = K.WgradQueue()
+
+    def grouped(i):
+        for a, b, c, gw_ in wq_jobs:
+            wq_queue.push(a, b, c, lo, hi, gw_)
+        wq_queue.flush()
+    g_rd = 12 * ((4.0 * NH + NB) * n + (8.0 * NB + NH) * n) + (4.0 * NB + NH) * n
+    g_wr = 4.0 * (12 * 3 + 1) * NH * NB
+    case("k_qwgrad_group", "student weight gradients of 25 quantized 1x1 convs in one launch (12 x (128->512 + res|skip pair) + 512->128; fp32 gz x u8 codes)",
+         "hbm", 2, g_rd, g_wr, 4.0 * (12 * ((NH + NB) + (NH + 2 * NB)) + (NH + NB)) * n, grouped, flops=(12 * 3 + 1) * fl)
     case("k_qgemm<1>", "student dgrad of 128->512 (int8 W^T x fp32 gz)", "hbm", 24, 4.0 * NH * n, 4.0 * NB * n, 4.0 * (NH + NB) * n,
          lambda i: K.qpw_bwd_x(gz_h[i % sets], wc_up), flops=fl)
     case("k_qgemm<1>", "student dgrad of the res|skip pair (K = 128+128 -> 512)", "hbm", 24, 8.0 * NB * n, 4.0 * NH * n, 4.0 * (NH + 2 * NB) * n,
@@ -126,14 +141,23 @@ def build(dev, sets=3):
     std = K.new_stats("dwq", B, NH, M, dev)
     K.dwq_fwd(xc_h[0], lo, hi, w_dw, b_dw, 4, 4, 1, slope, lo, hi, False, stats=std)
     _, _, mr = K.gnq_fwd(xc_h[0], lo, hi, gm_, bt_, 1e-8, lo, hi, False)
-    case("k_gnq_apply", "gLN + fake-quant forward, statistics from the producer, C=512 (codes in / out)", "hbm", 49, 1.0 * NH * n, 1.0 * NH * n, 8.0 * NH * n,
+    case("k_gnq_apply_t", "gLN + fake-quant forward by a per-row code table, statistics from the producer, C=512 (codes in / out)", "hbm", 49, 1.0 * NH * n, 1.0 * NH * n, 8.0 * NH * n,
          lambda i: K.gnq_fwd(xc_h[i % sets], lo, hi, gm_, bt_, 1e-8, lo, hi, False, stats=std))
     case("k_dwq_fwd<3>", "depthwise + PReLU + fake-quant + gLN statistics forward, C=512 (codes in / out)", "hbm", 24, 1.0 * NH * n, 1.0 * NH * n, 8.0 * NH * n,
          lambda i: K.dwq_fwd(xc_h[i % sets], lo, hi, w_dw, b_dw, 4, 4, 1, slope, lo, hi, False, stats=std))
     case("k_ewq_fwd", "AddQ forward, C=128 (codes + codes -> codes)", "hbm", 49, 2.0 * NB * n, 1.0 * NB * n, 12.0 * NB * n,
          lambda i: K.ewq_fwd(xc_b[i % sets], lo, hi, xc_b2[i % sets], lo, hi, None, 1.0, 0, None, lo, hi, False))
-    case("k_dwq_bwd<3>", "depthwise + PReLU + fake-quant backward, C=512 (codes + fp32 g in, fp32 gx out)", "hbm", 24, 5.0 * NH * n, 4.0 * NH * n, 12.0 * NH * n,
-         lambda i: K.dwq_bwd(xc_h[i % sets], lo, hi, w_dw, b_dw, gz_h[i % sets], 4, 4, 1, slope, lo, hi, gacc, gbb, gw_dw))
+    # round 5: the depthwise backward takes the apply pass of the GroupNormQ behind it (on load) and the rows pass of the one in front
+    # (on the gx it produces): g + its own input codes + that GroupNorm's input codes in, gx out
+    _, ws_rows = K.gnq_bwd_rows(xc_h[0], lo, hi, gz_h[0], gm_, bt_, mr, lo, hi, gacc)
+    gacc_b = torch.zeros_like(gacc)
+
+    def dwq_bwd_gn(i):
+        after = dict(gamma=gm_, beta=bt_, mean_rstd=mr, ws=ws_rows, qmin=lo, qmax=hi, ggamma=gg, gbeta=gb2)
+        before = dict(xc0=xc_h[(i + 1) % sets], qmin0=lo, qmax0=hi, gamma=gm_, beta=bt_, mean_rstd=mr, gacc=gacc_b)
+        return K.dwq_bwd(xc_h[i % sets], lo, hi, w_dw, b_dw, gz_h[i % sets], 4, 4, 1, slope, lo, hi, gacc, gbb, gw_dw, after=after, before=before)
+    case("k_dwq_bwd<3, GA, GB>", "depthwise + PReLU + fake-quant backward + the apply pass of the gLN behind it + the rows pass of the gLN in front, "
+         "C=512 (fp32 g + 2 x codes in, fp32 gx out)", "hbm", 24, 6.0 * NH * n, 4.0 * NH * n, 28.0 * NH * n, dwq_bwd_gn)
     pgb_a, pgb_b = torch.zeros(NB, device=dev), torch.zeros(NB, device=dev)
     case("k_ewq_bwd", "AddQ backward with BOTH operands' conv output-quantizer backward fused (residual add), C=128", "hbm", 24, 14.0 * NB * n, 8.0 * NB * n,
          20.0 * NB * n, lambda i: K.ewq_bwd_p(xc_b[i % sets], lo, hi, xc_b2[i % sets], lo, hi, 1.0, gz_b[i % sets], 0, None, lo, hi, gacc, NB,
@@ -146,11 +170,15 @@ def build(dev, sets=3):
          lambda i: K.actq_bwd(z_b[i % sets], gz_b[i % sets], 0, None, 2, lo, hi, gacc, gbias=gb_b, C=NB))
     case("k_axpby", "gradient sum at a fork (decoder / encoder side; the residual forks are summed in the dgrad epilogue), C=128", "hbm", 4, 8.0 * NB * n, 4.0 * NB * n, 12.0 * NB * n,
          lambda i: K.axpby(gz_b[i % sets], gz_b2[i % sets], 1.0))
-    # ---- the two-pass gLN backward (rows + apply: two launches, timed as a whole; never picked as `roofline`)
-    case("k_gnq_bwd_rows+apply<true>", "gLN+fq backward (2 passes) with the producer conv's STE/PReLU/range/bias backward fused, C=512", "hbm", 24,
-         14.0 * NH * n, 4.0 * NH * n, 20.0 * NH * n,
-         lambda i: K.gnq_bwd(xc_h[i % sets], lo, hi, gz_h[i % sets], gm_, bt_, mr, lo, hi, gacc, gg, gb2, producer=(z_h[i % sets], 1, slope, pgacc, gbb)), group=True)
-    case("k_gnq_bwd_rows+apply<false>", "gLN+fq backward (2 passes, plain), C=512", "hbm", 25, 10.0 * NH * n, 4.0 * NH * n, 16.0 * NH * n,
+    # ---- what is left of the two-pass gLN backward (round 5): the rows pass of the gLN behind the depthwise layer (its apply pass runs
+    # inside k_dwq_bwd), the apply pass of the gLN in front of it (its rows pass runs there) with conv1's epilogue backward fused, and
+    # the one gLN of the bottleneck with both passes of its own (two launches, timed as a whole; never picked as `roofline`)
+    case("k_gnq_bwd_rows", "gLN+fq backward, rows pass alone (row sums + range partials; codes + fp32 g in), C=512", "hbm", 25, 5.0 * NH * n, 16.0 * B * NH, 8.0 * NH * n,
+         lambda i: K.gnq_bwd_rows(xc_h[i % sets], lo, hi, gz_h[i % sets], gm_, bt_, mr, lo, hi, gacc))
+    case("k_gnq_bwd_apply<true>", "gLN+fq backward, apply pass alone with the producer conv's STE/PReLU/range/bias backward fused, C=512", "hbm", 24,
+         9.0 * NH * n, 4.0 * NH * n, 12.0 * NH * n,
+         lambda i: K.gnq_bwd_apply(xc_h[i % sets], lo, hi, gz_h[i % sets], gm_, bt_, mr, lo, hi, ws_rows, gg, gb2, producer=(z_h[i % sets], 1, slope, pgacc, gbb)))
+    case("k_gnq_bwd_rows+apply<false>", "gLN+fq backward (2 passes, plain: the bottleneck's gLN), C=512", "hbm", 1, 10.0 * NH * n, 4.0 * NH * n, 16.0 * NH * n,
          lambda i: K.gnq_bwd(xc_h[i % sets], lo, hi, gz_h[i % sets], gm_, bt_, mr, lo, hi, gacc, gg, gb2), group=True)
     return cases
 
@@ -245,8 +273,9 @@ def build_other(dev, sets=2):
     xc = [torch.randint(0, 256, (rows, Ci), device=dev, dtype=torch.uint8) for _ in R]
     lo, hi = torch.tensor([-1.0], device=dev), torch.tensor([1.0], device=dev)
     gw = torch.zeros(Co, Ci, device=dev)
-    case("k_gemm_x3", "cfg 4: coded weight gradient 8500 x 256 -> 1024 (gz fp32, input codes u8, split-K atomics into gw)", "mfma", 128,
-         4.0 * rows * Co + rows * Ci, 4.0 * Co * Ci, lambda i: K.qrow_bwd_w(gz[i % sets], xc[i % sets], lo, hi, gw), flops=2.0 * rows * Ci * Co)
+    wc4 = K.wq_codes(torch.randn(Co, Ci, 1, device=dev) * 0.05, -torch.ones(Co, 1, 1, device=dev) * 0.2, torch.ones(Co, 1, 1, device=dev) * 0.2)
+    case("k_gemm_x3", "cfg 4: coded data gradient, dgrad 8500 x 1024 -> 256 (gz fp32, weight codes int8)", "mfma", 96,
+         4.0 * rows * Co + Co * Ci, 4.0 * rows * Ci, lambda i: K.qrow_bwd_x(gz[i % sets], wc4), flops=2.0 * rows * Ci * Co)
     # cfg 5: six-product pointwise GEMM over the frames of the level-0 rewrite conv, 4 x (144 -> 96) x 110250
     Bh, Kk, Cq, Mh = 4, 144, 96, 110250
     f = [K.empty_act((Bh, Kk, Mh), dev).normal_() for _ in R]

@@ -215,6 +215,8 @@ def test_lstm_gate_functions():
         assert float(err.max()) <= 4.0, (name, float(err.max()), float(x[err.argmax()]))
         assert float((got.double() - want).abs().max()) <= 1.2e-7, name
     assert float(th[-6]) == 0.0 and float(th[-5]) == 0.0 and float(sg[-6]) == 0.5
+    sg, th = run(torch.tensor([float("nan"), 1.0]))         # a NaN pre-activation stays a NaN in BOTH functions
+    assert bool(torch.isnan(sg[0])) and bool(torch.isnan(th[0])) and bool(torch.isfinite(sg[1])) and bool(torch.isfinite(th[1]))
     sg, th = run(far)
     assert th.tolist() == [1.0, -1.0] * 4
     assert sg[0::2].tolist() == [1.0] * 4 and float(sg[1::2].max()) <= 2e-38 and float(sg[1::2].min()) >= 0.0

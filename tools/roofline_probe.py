@@ -43,6 +43,8 @@ def _members(kernel):
         return ["k_gnq_bwd_rows", "k_gnq_bwd_apply"]
     if kernel == "k_qgemm<3>":
         return ["k_qgemm"]
+    if kernel == "k_dwq_bwd<3, GA, GB>":
+        return ["k_dwq_bwd"]
     return [kernel.split("<")[0]]
 
 
