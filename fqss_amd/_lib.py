@@ -80,6 +80,7 @@ _PROTOS = {
     "fqss_dwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_dwconv_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_gn_fwd": [P, P, P, P, P, I32, I32, I32, I64, I64, F32, P, P],
+    "fqss_gn_fwd_tail": [P, P, P, P, I32, I32, I32, I64, I64, F32, P, I32, P, P, I64, P],
     "fqss_gn_bwd": [P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P],
     "fqss_gnq_fwd_f": [P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, F32, P, P, P, P],
     "fqss_gnq_bwd_f": [P, P, P, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P, P, P, P, P],

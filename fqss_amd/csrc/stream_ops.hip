@@ -325,6 +325,59 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, c
     }
 }
 
+// Forward-only tails of a GroupNorm for a network that runs without autograd (the frozen float TEACHER of HTDemucs: every DConv layer is
+// conv -> GroupNorm -> GELU -> 1x1 conv -> GroupNorm -> GLU -> LayerScale, added to the residual; demucsq.py:163-182).  The un-fused
+// chain moves the 2C-channel tensor through apply, GLU, LayerScale and the add (7 passes of it per layer); here the second pass of the
+// GroupNorm carries what follows, in the arithmetic of the separate kernels (k_gn_apply, k_unary_fwd / k_glu_fwd, k_chan_op, k_axpby):
+//   TAIL = 1:  y = gelu(gn(x))                                         rows = B * C
+//   TAIL = 2:  y[b][c] = (a * sigmoid(g)) * ls[c] + res[b][c],  a = gn(x)[b][c], g = gn(x)[b][c + C/2]     rows = B * C/2
+template <int TAIL>
+__global__ __launch_bounds__(256) void k_gn_tail(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ y, int B, int C, int M, int64_t ld_x, int64_t ld_y, float eps,
+                                                  const double* ws, const float* __restrict__ ls, const float* __restrict__ res, int64_t ld_res,
+                                                  int res_vec) {
+    // res_vec = 0: the residual's rows are dense with a length that is no multiple of 4 (a module INPUT, e.g. [B, 48, 110250]): 4-B loads
+    const int Co = TAIL == 2 ? C / 2 : C;
+    const int64_t rows = (int64_t)B * Co;
+    const int64_t cstep = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = (int)(row / Co), c = (int)(row % Co);
+        float mean, rstd;
+        gn_mean_rstd(ws, b, (int64_t)C * M, eps, mean, rstd);
+        const float sa = rstd * gamma[c], sha = fmaf(-sa, mean, beta[c]);
+        const float* xa = x + ((int64_t)b * C + c) * ld_x;
+        float* yr = y + row * ld_y;
+        if constexpr (TAIL == 1) {
+            for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += cstep) {
+                const float4 t = *reinterpret_cast<const float4*>(xa + c0);
+                const float v[4] = {fmaf(t.x, sa, sha), fmaf(t.y, sa, sha), fmaf(t.z, sa, sha), fmaf(t.w, sa, sha)};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (0.5f * v[j]) * (1.0f + erff(v[j] * 0.70710678118654752440f));
+                *reinterpret_cast<float4*>(yr + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            const float sg = rstd * gamma[c + Co], shg = fmaf(-sg, mean, beta[c + Co]);
+            const float* xg = x + ((int64_t)b * C + c + Co) * ld_x;
+            const float* rr = res + row * ld_res;
+            const float lsv = ls[c];
+            for (int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; c0 < M; c0 += cstep) {
+                const float4 ta = *reinterpret_cast<const float4*>(xa + c0), tg = *reinterpret_cast<const float4*>(xg + c0);
+                float4 tr;
+                if (res_vec) tr = *reinterpret_cast<const float4*>(rr + c0);
+                else tr = make_float4(rr[min(c0, (int64_t)M - 1)], rr[min(c0 + 1, (int64_t)M - 1)], rr[min(c0 + 2, (int64_t)M - 1)], rr[min(c0 + 3, (int64_t)M - 1)]);
+                const float a[4] = {fmaf(ta.x, sa, sha), fmaf(ta.y, sa, sha), fmaf(ta.z, sa, sha), fmaf(ta.w, sa, sha)};
+                const float g[4] = {fmaf(tg.x, sg, shg), fmaf(tg.y, sg, shg), fmaf(tg.z, sg, shg), fmaf(tg.w, sg, shg)};
+                const float r[4] = {tr.x, tr.y, tr.z, tr.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = r[j] + (a[j] * (1.0f / (1.0f + expf(-g[j])))) * lsv;
+                *reinterpret_cast<float4*>(yr + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
 // backward pass 1: per (b,c) row sums  ds = sum gz*x, db = sum gz   -> ws[(b*C+c)*2 + {0,1}]
 // Q: gz is dL/d fq(GroupNorm(x)): the quantizer's STE runs on the pre-quant value recomputed from x (scale / shift as in k_gn_apply)
 // and its range partials go to gacc (slots shared modulo kGaccSlots, fp64 atomics: order-insensitive) -- no fqss_actq_bwd pass, no z
@@ -654,6 +707,32 @@ static int gn_fwd_impl(const char* who, const float* x, const float* gamma, cons
 static int gn_bwd_impl(const char* who, const float* gz, const float* x, const float* gamma, const float* beta, const float* mean_rstd, float* gx,
                        float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz, int64_t ld_x, int64_t ld_gx, double* ws, const float* qmin,
                        const float* qmax, double* gacc, fqss_stream_t stream);
+
+/* Forward-only GroupNorm(1, C) with what follows it fused into the apply pass (k_gn_tail; inference paths: the frozen teacher):
+ * tail 1: y [B][C][M] = gelu(gn(x));  tail 2: y [B][C/2][M] = glu(gn(x)) * ls[c] + res (ls [C/2], res [B][C/2][ld_res]).
+ * Rows 16-B aligned; ws: 2 * B doubles. */
+extern "C" int fqss_gn_fwd_tail(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int M, int64_t ld_x, int64_t ld_y,
+                                float eps, double* ws, int tail, const float* ls, const float* res, int64_t ld_res, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && gamma && beta && y && ws, "null tensor");
+    FQSS_REQUIRE(B >= 0 && B <= 65535 && C > 0 && M > 0 && ld_x >= M && ld_y >= M, "bad shape");
+    FQSS_REQUIRE(tail == 1 || (tail == 2 && C % 2 == 0 && ls && res && ld_res >= M), "tail: 1 (GELU) or 2 (GLU * scale + residual; C even)");
+    FQSS_REQUIRE(aligned16(x) && aligned16(y) && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= ((M + 3) & ~3) && ld_y >= ((M + 3) & ~3),
+                 "x / y rows must be 16-B aligned and padded to 4");
+    const int res_vec = (tail == 2 && aligned16(res) && ld_res % 4 == 0 && ld_res >= ((M + 3) & ~3)) ? 1 : 0;
+    if (B == 0) return FQSS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, s) != hipSuccess) return launch_status("fqss_gn_fwd_tail");
+    const int nb = C < 64 ? C : 64;
+    const int zs = gn_col_slices((int64_t)nb * B, M, 4);
+    hipLaunchKernelGGL(k_gn_stats<4>, dim3((unsigned)nb, (unsigned)B, (unsigned)zs), dim3(256), 0, s, x, C, M, ld_x, ws);
+    const int64_t rows = (int64_t)B * (tail == 2 ? C / 2 : C);
+    if (tail == 1)
+        hipLaunchKernelGGL(k_gn_tail<1>, grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, y, B, C, M, ld_x, ld_y, eps, ws, ls, res, ld_res, 0);
+    else
+        hipLaunchKernelGGL(k_gn_tail<2>, grid_rows(rows, M, 4), dim3(256), 0, s, x, gamma, beta, y, B, C, M, ld_x, ld_y, eps, ws, ls, res, ld_res, res_vec);
+    return launch_status("fqss_gn_fwd_tail");
+}
+
 
 extern "C" int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd, float* gx,
                            float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz, int64_t ld_x,

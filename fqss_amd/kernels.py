@@ -855,6 +855,25 @@ def gn_fwd(x, gamma, beta, eps):
     return z, mean_rstd
 
 
+def gn_fwd_tail(x, gamma, beta, eps, tail, ls=None, res=None):
+    """forward-only GroupNorm(1, C) + what follows it in ONE apply pass (no autograd: the frozen teacher).  tail 1: gelu(gn(x));
+    tail 2: glu(gn(x)) * ls[:, None] + res -> [B, C/2, M]; None when the operands do not meet the kernel's 16-B row rule"""
+    _need_gpu(x, gamma, beta, ls, res)
+    x, B, C, M, ld_x = _bcm(x)
+    if x.data_ptr() % 16 or ld_x % 4:
+        return None
+    ld_r = 0
+    if tail == 2:
+        res, Br, Cr, Mr, ld_r = _bcm(res)
+        if (Br, Cr, Mr) != (B, C // 2, M) or ls.numel() != C // 2 or not ls.is_contiguous():
+            return None          # (a residual whose rows are not 16-B aligned -- a module input of odd length -- is read with 4-B loads)
+    y = empty_act((B, C // 2 if tail == 2 else C, M), x.device)
+    ws = torch.empty(2 * B, device=x.device, dtype=torch.float64)
+    _lib.call("fqss_gn_fwd_tail", _p(x), _p(gamma), _p(beta), _p(y), B, C, M, ld_x, rowmat(y)[2], float(eps), _p(ws), tail, _p(ls), _p(res), ld_r,
+              _stream())
+    return y
+
+
 def gn_bwd(gz, x, gamma, mean_rstd, ggamma, gbeta):
     _need_gpu(gz, x, gamma, mean_rstd, ggamma, gbeta)
     gz, B, C, M, ld_gz = _bcm(gz)

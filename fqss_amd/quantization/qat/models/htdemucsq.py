@@ -159,6 +159,9 @@ class LayerScale(nn.Module):
         return self.mul(x, self.scale if self.channel_last else self.scale[:, None])
 
 
+FUSE_TEACHER_DCONV = __import__("os").environ.get("FQSS_FUSE_TEACHER_DCONV", "1") != "0"
+
+
 class DConv(nn.Module):
     """residual branches of dilated convs on [B', C, T] (demucsq.py:110-182; no LSTM / attention variants)"""
 
@@ -185,12 +188,36 @@ class DConv(nn.Module):
 
     def forward(self, x):
         for layer, add in zip(self.layers, self.adds):
+            if FUSE_TEACHER_DCONV and not torch.is_grad_enabled():
+                y = self._forward_nograd(layer, x)
+                if y is not None:
+                    x = y
+                    continue
             x_in, x_res = ops.fork2(x)
             h = x_in
             for m in layer:
                 h = run(m, h)
             x = add(x_res, h)
         return x
+
+    @staticmethod
+    def _forward_nograd(layer, x):
+        """the float layer without autograd (the frozen teacher, mysystem.py:132-133 / solver.py:333-340 run it under no_grad): the two
+        GroupNorm apply passes carry what follows them -- GELU; GLU, LayerScale and the residual add (fqss_gn_fwd_tail) -- four
+        element-wise launches per layer instead of eight, value for value the module path"""
+        mods = list(layer)
+        if len(mods) != 7 or not (type(mods[0]) is nn.Conv1d and type(mods[1]) is nn.GroupNorm and type(mods[2]) is nn.GELU
+                                  and type(mods[3]) is nn.Conv1d and type(mods[4]) is nn.GroupNorm and type(mods[5]) is nn.GLU
+                                  and type(mods[6]) is LayerScale) or mods[1].num_groups != 1 or mods[4].num_groups != 1 \
+                or getattr(mods[2], "approximate", "none") != "none" or mods[5].dim != 1 or mods[6].channel_last or x.dim() != 3:
+            return None
+        x = ops.real(x)
+        h = ops.real(run(mods[0], x))
+        h = K.gn_fwd_tail(h, mods[1].weight, mods[1].bias, mods[1].eps, 1)
+        if h is None:
+            return None
+        h = ops.real(run(mods[3], h))
+        return K.gn_fwd_tail(h, mods[4].weight, mods[4].bias, mods[4].eps, 2, ls=mods[6].scale, res=x)
 
 
 class ScaledEmbedding(nn.Module):

@@ -269,6 +269,13 @@ int fqss_dwconv_bwd_w(const float* gz, const float* x, float* gw, int B, int C, 
 int fqss_gn_fwd(const float* x, const float* gamma, const float* beta, float* z, float* mean_rstd,
                 int B, int C, int M, int64_t ld_x, int64_t ld_z, float eps, double* ws,
                 fqss_stream_t stream);
+/* Forward-only GroupNorm(1, C) whose apply pass carries what follows it (csrc/stream_ops.hip k_gn_tail; round 5) -- for networks run
+ * without autograd: the frozen float teacher's DConv layers of HTDemucs (demucsq.py:163-182: GroupNorm -> GELU, and GroupNorm -> GLU ->
+ * LayerScale -> + residual).  tail 1: y [B][C][M] = gelu(gn(x)); tail 2: y [B][C/2][M] = (a * sigmoid(g)) * ls[c] + res[b][c] with
+ * a / g the two channel halves of gn(x).  Value for value the separate kernels (fqss_gn_fwd, fqss_unary_fwd / fqss_glu_fwd,
+ * fqss_chan_op, fqss_axpby).  ws: 2 * B doubles. */
+int fqss_gn_fwd_tail(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int M, int64_t ld_x, int64_t ld_y,
+                     float eps, double* ws, int tail, const float* ls, const float* res, int64_t ld_res, fqss_stream_t stream);
 /* gx = ; ggamma[C] += ; gbeta[C] += */
 int fqss_gn_bwd(const float* gz, const float* x, const float* gamma, const float* mean_rstd,
                 float* gx, float* ggamma, float* gbeta, int B, int C, int M, int64_t ld_gz,
