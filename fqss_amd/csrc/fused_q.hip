@@ -16,6 +16,7 @@
 //   fqss_decode                      codes -> fp32 (fallback for consumers without a coded-input kernel)
 // Statistics of a coded tensor are exact integer sums (sum c, sum c^2 in int64).
 #include <cstdlib>
+#include <type_traits>
 
 #include "fqss_dev.h"
 
@@ -946,31 +947,39 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
             }
             const float gv[4] = {gq[i].x, gq[i].y, gq[i].z, gq[i].w};
             float o[4];
+            // ALL = every position of the group lies inside the row (all but the row's last group): the per-element validity selects
+            // (5 of them) drop out of the instruction stream; the hand-over forms also take the branch-free activation helpers -- the
+            // branching ones compiled to ~18 scalar branches per element with their exec-mask bookkeeping and register copies
+            auto elems = [&](auto ALL_) {
+                constexpr bool ALL = decltype(ALL_)::value;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool valid = (m + j < M);
-                const float z = acc[j] + bv;
-                const float t = act_apply_br(z, act, slope);
-                float cq, u;
-                bool inr;
-                (void)fq_asym(t, ry, cq, u, inr);
-                float gj = valid ? gv[j] : 0.0f;
-                if constexpr (GA) {     // the consuming GroupNormQ's backward apply, on the code this layer's forward wrote
-                    const float2 e2 = tabA[(unsigned int)cq & 255u];
-                    const float gz2 = (e2.y != 0.0f) ? div_by(gv[j] * r2.delta, r2.delta, r2.inv) : 0.0f;
-                    gj = valid ? fmaf(gz2, scale2, e2.x) : 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    const bool valid = ALL ? true : (m + j < M);
+                    const float z = acc[j] + bv;
+                    const float t = (GA || GB) ? act_apply(z, act, slope) : act_apply_br(z, act, slope);
+                    float cq, u;
+                    bool inr;
+                    (void)fq_asym(t, ry, cq, u, inr);
+                    float gj = valid ? gv[j] : 0.0f;
+                    if constexpr (GA) {     // the consuming GroupNormQ's backward apply, on the code this layer's forward wrote
+                        const float2 e2 = tabA[(unsigned int)cq & 255u];
+                        const float gz2 = (e2.y != 0.0f) ? div_by(gv[j] * r2.delta, r2.delta, r2.inv) : 0.0f;
+                        gj = valid ? fmaf(gz2, scale2, e2.x) : 0.0f;
+                    }
+                    const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+                    p_du += valid ? gj * (inr ? (cq - u) : cq) : 0.0f;
+                    p_out += (valid && !inr) ? gj : 0.0f;
+                    float gzj = (GA || GB) ? act_bwd(z, gt, act, slope, valid, p_slope) : act_bwd_br(z, gt, act, slope, valid, p_slope);
+                    gzj = valid ? gzj : 0.0f;
+                    o[j] = gzj;
+                    p_bias += gzj;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        if (k < K) pw[k] = fmaf(gzj, v[k][j], pw[k]);   // v is 0 outside the row (zero padding)
                 }
-                const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
-                p_du += valid ? gj * (inr ? (cq - u) : cq) : 0.0f;
-                p_out += (valid && !inr) ? gj : 0.0f;
-                float gzj = act_bwd_br(z, gt, act, slope, valid, p_slope);
-                gzj = valid ? gzj : 0.0f;
-                o[j] = gzj;
-                p_bias += gzj;
-#pragma unroll
-                for (int k = 0; k < NT; ++k)
-                    if (k < K) pw[k] = fmaf(gzj, v[k][j], pw[k]);   // v is 0 outside the row (zero padding)
-            }
+            };
+            if (m + 3 < M) elems(std::true_type{});
+            else elems(std::false_type{});
             *reinterpret_cast<float4*>(&sgz[m]) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
