@@ -694,8 +694,10 @@ extern "C" int fqss_qrow_bwd_w_group(const FqssRowWgradJob* jobs, int njobs, fqs
             const int n = cnt - n0 < X3W_MAXJOBS ? cnt - n0 : X3W_MAXJOBS;
             int64_t tiles = 0;
             for (int q = 0; q < n; ++q) tiles += cdiv(jobs[idx[n0 + q]].Co, 64 * mi) * cdiv(jobs[idx[n0 + q]].Ci, 64 * ni);
-            // aim for ~12 workgroups per CU over the launch; every k-slice ADDS its whole tile with float atomics, so no finer than needed
-            int want = (int)cdiv(3072, tiles);
+            // aim for ~6 workgroups per CU over the launch (sweep on cfg 4, profiles/r05_ab_steps.txt: 512 .. 6144 within 2.5 %, 1536 best); every
+            // k-slice ADDS its whole tile with float atomics, so no finer than needed
+            static const int wgs = [] { const char* e = getenv("FQSS_ROWGROUP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1536; }();
+            int want = (int)cdiv(wgs, tiles);
             X3WMulti m{};
             m.n = n;
             int start = 0;

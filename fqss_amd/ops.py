@@ -403,12 +403,13 @@ def _plain_or_bwd(z, g, q):
 # ----------------------------------------------------------------------------------------------
 class _Lin:
     """geometry of the linear op in front of the epilogue"""
-    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param", "six", "taps")
+    __slots__ = ("kind", "stride", "dil", "pad", "w_param", "b_param", "slope_param", "six", "taps", "wc_dgrad")
 
     def __init__(self, kind, stride=1, dil=1, pad=0, w_param=None, b_param=None, slope_param=None, six=False, taps=1):
         self.kind, self.stride, self.dil, self.pad = kind, stride, dil, pad
         self.six = six          # "pw": forward on the six-product split GEMM (K.pwconv_fwd)
         self.taps = taps        # "conv1": stride-1 1-D convolution as an implicit GEMM (K.conv1d_s1_*), weight [Co, Ci * taps, 1]
+        self.wc_dgrad = None    # "pw", float input: int8 codes of the (fake-quantized) weight for the DATA gradient alone (three products per k)
         self.w_param, self.b_param, self.slope_param = w_param, b_param, slope_param
 
 
@@ -461,6 +462,9 @@ def _lin_bwd_w(L, gz, x, gw):
         K.frames_wgrad(x, gz, gw, L.stride)
     else:
         raise NotImplementedError(L.kind)
+
+
+FRAME_CODES_DGRAD = os.environ.get("FQSS_FRAME_CODES_DGRAD", "1") != "0"
 
 
 class LinearActQ(Function):
@@ -528,8 +532,15 @@ class LinearActQ(Function):
                 gx = K.qpw_bwd_x(gz, ctx.wc, add=other)     # + the gradient of the fork's other branch: no separate sum pass
             elif L.kind == "convtr" and other is not None:
                 gx = K.frames_conv_fwd(gz, w.reshape(w.shape[0], 1, w.shape[2]), L.stride, add=other)   # decoder: same, in its dgrad
+            elif ctx.wc is not None:
+                gx = K.qpw_bwd_x(gz, ctx.wc)
+            elif L.kind == "pw" and L.wc_dgrad is not None and FRAME_CODES_DGRAD and gz.dim() == 3:
+                # round 5 (cfg 5): the frame-path convolutions of HTDemucs read FLOAT inputs, but their weight is fake-quantized: W_q =
+                # dw * Wi with int8 Wi, so the data gradient W_q^T gz is the q-GEMM of the ConvTasNet path (k_qgemm<1>: gz in three exact
+                # bf16 pieces x ONE exact plane of codes = three products per k instead of the six of the float x float form)
+                gx = K.qpw_bwd_x(gz, L.wc_dgrad)
             else:
-                gx = K.qpw_bwd_x(gz, ctx.wc) if ctx.wc is not None else _lin_bwd_x(L, gz, w, ctx.x_shape)
+                gx = _lin_bwd_x(L, gz, w, ctx.x_shape)
         gw = None
         gwq = getattr(w, "_fqss_gwq", None)    # deferred mode: dL/dW_q accumulates in the step's arena
         if ctx.needs_input_grad[1] or gwq is not None:

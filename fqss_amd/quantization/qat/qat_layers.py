@@ -299,6 +299,8 @@ def conv_frames(conv, x, weight):
         cols = ops_dp.FramesGather.apply(x4, geom)
     ops_dp.touch(weight)
     w3 = ops.weight_view(weight, Co, -1, 1)
+    if L.kind == "pw":
+        L.wc_dgrad = getattr(weight, "_fqss_wcodes_dgrad", None)      # runtime.QuantTables: int8 image of the fake-quantized conv weight
     z = ops.LinearActQ.apply(cols, w3, conv.bias, None, None, None, L, ops.ACT_NONE, ops.BYPASS)
     z = z.reshape(B, Co, Ho, Wo)
     return z.squeeze(2) if one_d else z

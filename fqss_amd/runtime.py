@@ -263,6 +263,9 @@ class QuantTables:
             pw = axis == 0 and w.dim() == 3 and shape[2] == 1 and K.q_eligible(shape[1], shape[0])
             # row-major linear weight [Co, Ci]: the same code image serves the int8 row GEMM (csrc/qrow.hip)
             pw = pw or (axis == 0 and w.dim() == 2 and ops_dp.QROW and K.qrow_eligible(shape[1]))
+            # convolution weights [Co, Ci, k] / [Co, Ci, kh, kw] of the frame path (HTDemucs): the same code image over Ci * k "channels"
+            # serves the DATA gradient alone (ops.LinearActQ: W_q^T gz on k_qgemm<1>); the forward reads float inputs
+            fr = (not pw) and axis == 0 and w.dim() in (3, 4) and shape[0] % 16 == 0 and shape[0] <= 1024 and ops.FRAME_CODES_DGRAD
             wc = None
             ldT = C
             if pw and id(w) in partner:
@@ -295,21 +298,24 @@ class QuantTables:
                     wq_first._fqss_pair = pair
                     self.pairs.append(pair)
                     pending = None
-            elif pw:
+            elif pw or fr:
                 wc = K.WCodes()
-                wc.Co, wc.Ci = shape[0], shape[1]
-                wc.idx = torch.empty(shape[0], shape[1], device=dev, dtype=torch.int8)
-                wc.idxT = torch.empty(shape[1], shape[0], device=dev, dtype=torch.int8)
+                wc.Co, wc.Ci = shape[0], (inner if fr else shape[1])
+                wc.idx = torch.empty(wc.Co, wc.Ci, device=dev, dtype=torch.int8)
+                wc.idxT = torch.empty(wc.Ci, wc.Co, device=dev, dtype=torch.int8)
                 wc.dw = torch.empty(shape[0], device=dev)
                 wc.rw = torch.empty(shape[0], device=dev)
                 idxT_ptr = wc.idxT.data_ptr()
-            rows.append([w.data_ptr(), wq.data_ptr(), wc.idx.data_ptr() if pw else 0, idxT_ptr if pw else 0,
-                         wc.dw.data_ptr() if pw else 0, wc.rw.data_ptr() if pw else 0, wqm.min_range.data_ptr(),
+            coded = pw or fr
+            rows.append([w.data_ptr(), wq.data_ptr(), wc.idx.data_ptr() if coded else 0, idxT_ptr if coded else 0,
+                         wc.dw.data_ptr() if coded else 0, wc.rw.data_ptr() if coded else 0, wqm.min_range.data_ptr(),
                          wqm.max_range.data_ptr(), gwq.data_ptr(), w.grad.data_ptr(), wqm.min_range.grad.data_ptr(),
                          wqm.max_range.grad.data_ptr(), outer, C, inner, blk, ldT])
             wq._fqss_gwq = gwq
             if pw:
                 wq._fqss_wcodes = wc
+            elif fr:
+                wq._fqss_wcodes_dgrad = wc
             w._fqss_wq = wq
             self.weights.append((wqm, w, wq, wc))
             off += (w.numel() + 63) // 64 * 64
