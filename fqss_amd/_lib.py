@@ -31,6 +31,7 @@ _PROTOS = {
     "fqss_pwconv_fwd": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_fwd_x3": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_fwd_x3s": [P, P, P, P, I32, I32, I32, I32, I64, I64, P],
+    "fqss_pwconv_fwd_wq": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_conv1d_s1_fwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_conv1d_s1_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_pwconv_bwd_x": [P, P, P, I32, I32, I32, I32, I64, I64, P],

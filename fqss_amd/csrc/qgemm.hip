@@ -133,11 +133,16 @@ struct QGemmArgs {
 // bench.py never sets it.
 template <int MODE, int GP = 3>
 __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
-    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "unknown q-GEMM mode");
-    static_assert(GP == 3 || (GP == 2 && MODE != 0), "two gradient pieces: dgrad only");
+    // MODE 4 (round 5): forward of a layer whose WEIGHT is on the int8 grid while its input is a plain float tensor (the frame-path
+    // convolutions of HTDemucs): A = int8 weight codes, B = fp32 x in three exact bf16 pieces -- the loop of MODE 1 without its
+    // delta_w scaling of the reduction rows -- and z = dw[co] * S + b[co] in the epilogue: three products per k instead of six
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3 || MODE == 4, "unknown q-GEMM mode");
+    static_assert(GP == 3 || (GP == 2 && MODE != 0 && MODE != 4), "two gradient pieces: dgrad only");
+    constexpr bool ACODES = MODE < 2 || MODE == 4;          // A arrives as int8 codes
+    constexpr int WMODE = MODE == 4 ? 1 : MODE;             // register image / wait form of the load stages
     constexpr bool SIX = MODE == 3 && GP == 2;              // fp32 x fp32 with the six products above 2^-24 instead of all nine
     constexpr int NA = (MODE == 3) ? 3 : 1;                 // A images
-    constexpr int NB = (MODE == 1) ? GP : (MODE == 3) ? 3 : 1;    // B images
+    constexpr int NB = (MODE == 1) ? GP : (MODE == 3 || MODE == 4) ? 3 : 1;    // B images
     constexpr int BROWS = QBK, BLD = LDN;
     constexpr int A_BYTES = NA * QBM * LDK * 2, B_BYTES = NB * BROWS * BLD * 2;
     constexpr int T_BYTES = 4 * 32 * LDT * 4;   // epilogue staging: one 32x32 fp32 tile per wave
@@ -168,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     // per-row epilogue coefficients of this block's 128 rows, staged once in LDS (fetching them per output
     // element from global memory was ~60 % of the forward kernel's time)
     __shared__ float rowc[3][QBM];
-    if constexpr (MODE == 0 || MODE == 3) {
+    if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
         if (tid < QBM) {
             const int row = i0 + tid;
             const bool ok = row < g.M;
-            rowc[0][tid] = (MODE == 0 && ok) ? g.dw[row] : 1.0f;
+            rowc[0][tid] = ((MODE == 0 || MODE == 4) && ok) ? g.dw[row] : 1.0f;
             rowc[1][tid] = (MODE == 0 && ok) ? g.rw[row] : 0.0f;
             rowc[2][tid] = (ok && g.bias != nullptr) ? (row < g.M1 ? g.bias[row] : g.bias2[row - g.M1]) : 0.0f;
         }
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     // collapse the stages) and retired by an explicit s_waitcnt carrying the stage's registers; they are
     // unconditional -- addresses clamped into the operand, out-of-range reduction rows zeroed at use (both operands
     // are finite, so a clamped A value only ever meets a zero).
-    constexpr int NLOADS = (MODE == 0) ? 2 : (MODE == 1) ? 3 : 6;   // per thread and stage
+    constexpr int NLOADS = (MODE == 0) ? 2 : (WMODE == 1) ? 3 : 6;   // per thread and stage
     const int a_row = tid >> 1, a_k = (tid & 1) * 16;              // A tile: 128 rows x 32 k, 16 per thread
     const int bk_row = tid >> 3, bk_n = (tid & 7) * 8;             // B tile [k][n]: 32 k x 64 n, 8 per thread
     const int a_row_c = min(i0 + a_row, g.M - 1);
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     const char* const gB2 = (MODE == 0) ? gB1 : sgpr((const char*)g.B2 + (int64_t)b * g.sB2b * BEL);
     const int64_t gldb1 = sgpr(g.ldb), gldb2 = (MODE == 0) ? gldb1 : sgpr(g.ldb2);
     auto load_tiles = [&](QStage& st, int k0) {
-        if constexpr (MODE < 2) {
+        if constexpr (ACODES) {
             q_load16(st.a[0], (const signed char*)g.A + (int64_t)a_row_c * g.lda + min(k0 + a_k, g.K - 16));
         } else {
             const float* A = (const float*)g.A + (int64_t)b * g.sAb + (int64_t)a_row_c * g.lda;
@@ -295,9 +300,9 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     };
 
     auto store_tiles = [&](QStage& st, int k0) {
-        q_wait<MODE, NLOADS>(st);   // this stage has landed; the NLOADS younger requests of the other stage stay in flight
+        q_wait<WMODE, NLOADS>(st);   // this stage has landed; the NLOADS younger requests of the other stage stay in flight
         const bool kz = (k0 + bk_row) >= g.K;   // reduction rows past K contribute zeros (B side)
-        if constexpr (MODE < 2) {
+        if constexpr (ACODES) {
             const unsigned int w[4] = {__float_as_uint(st.a[0][0]), __float_as_uint(st.a[0][1]), __float_as_uint(st.a[0][2]),
                                        __float_as_uint(st.a[0][3])};
             store_codes(&As[0][a_row][a_k], w, std::integral_constant<int, 4>{}, true, false);
@@ -378,8 +383,8 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     }
     // the trailing (clamped, unused) requests still target the stage registers, which the compiler considers dead
     // from here on: drain them before anything else is allocated there
-    q_wait<MODE, 0>(stA);
-    q_wait<MODE, 0>(stB);
+    q_wait<WMODE, 0>(stA);
+    q_wait<WMODE, 0>(stB);
 
     // ---------------------------------------------------------------- epilogue
     float dx = 0.f, mnx = 0.f;
@@ -428,6 +433,9 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                     if (has_bias) v = v + rowc[2][rb];
                 } else if constexpr (MODE == 3) {
                     if (has_bias) v = S + rowc[2][rb];
+                } else if constexpr (MODE == 4) {
+                    v = rowc[0][rb] * S;
+                    if (has_bias) v = v + rowc[2][rb];
                 }
                 Tt[rl][lr] = v;
             }
@@ -1380,6 +1388,27 @@ static int pwconv_fwd_x3_impl(const char* who, bool six, const float* x, const f
     if (six) hipLaunchKernelGGL((k_qgemm<3, 2>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL((k_qgemm<3>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status(who);
+}
+
+/* z[b] = (dw[co] * Wi[co][:]) x[b] + bias: pointwise conv of a FLOAT input with a fake-quantized weight given as its int8 codes
+ * (k_qgemm<4>: x in three exact bf16 pieces x one exact plane of codes: three products per k; fqss_pwconv_fwd_x3s needs six) */
+extern "C" int fqss_pwconv_fwd_wq(const float* x, const int8_t* wi, const float* dw, const float* bias, float* z, int B, int Ci, int Co, int M,
+                                  int64_t ld_x, int64_t ld_z, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;
+    FQSS_REQUIRE(x && wi && dw && z, "null tensor");
+    FQSS_REQUIRE(B >= 0 && Ci >= 16 && Co > 0 && M >= 0 && ld_x >= M && ld_z >= M, "bad shape");
+    FQSS_REQUIRE(Ci % 16 == 0 && ld_x % 4 == 0 && aligned16(x) && aligned16(wi) && ld_x >= ((M + 3) & ~3),
+                 "coded-weight forward needs Ci % 16 == 0 and 16-B aligned activation rows");
+    FQSS_REQUIRE(aligned16(z) && ld_z % 4 == 0, "output rows must be 16-B aligned");
+    QGemmArgs g{};
+    g.A = wi; g.B = x; g.C = z; g.M = Co; g.N = M; g.K = Ci;
+    g.lda = Ci; g.ldb = ld_x; g.ldc = ld_z;
+    g.sAb = 0; g.sBb = (int64_t)Ci * ld_x; g.sCb = (int64_t)Co * ld_z;
+    g.dw = dw; g.bias = bias; g.ksplit = 1; g.kchunk = Ci; g.M1 = Co; g.K1 = Ci;
+    g.B2 = x; g.ldb2 = ld_x; g.sB2b = g.sBb;
+    g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
+    hipLaunchKernelGGL((k_qgemm<4>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status("fqss_pwconv_fwd_wq");
 }
 
 extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,

@@ -325,6 +325,18 @@ def pwconv_fwd(x, w, bias, six=False):
     return z
 
 
+def pwconv_fwd_wq(x, wc, bias):
+    """pointwise conv of a FLOAT input with a fake-quantized weight given as its int8 codes (WCodes: idx [Co][Ci], dw [Co]); None when the
+    operands do not meet the kernel's alignment rules (the caller then runs the float x float form)"""
+    _need_gpu(x, bias)
+    x, B, Ci, M, ld_x = _bcm(x)
+    if Ci != wc.Ci or Ci % 16 or Ci < 16 or ld_x % 4 or x.data_ptr() % 16 or not wc.idx.is_contiguous():
+        return None
+    z = empty_act((B, wc.Co, M), x.device)
+    _lib.call("fqss_pwconv_fwd_wq", _p(x), _p(wc.idx), _p(wc.dw), _p(bias), _p(z), B, Ci, wc.Co, M, ld_x, rowmat(z)[2], _stream())
+    return z
+
+
 CONV_IMPLICIT = os.environ.get("FQSS_CONV_IMPLICIT", "1") != "0"
 CONV_IMPLICIT_MAX_CO = int(os.environ.get("FQSS_CONV_IMPLICIT_MAX_CO", "64"))
 

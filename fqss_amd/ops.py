@@ -413,8 +413,16 @@ class _Lin:
         self.w_param, self.b_param, self.slope_param = w_param, b_param, slope_param
 
 
+FRAME_CODES_FWD = os.environ.get("FQSS_FRAME_CODES_FWD", "1") != "0"
+
+
 def _lin_fwd(L, x, w, bias):
     if L.kind == "pw":
+        if L.wc_dgrad is not None and FRAME_CODES_FWD and x.dim() == 3:
+            # the weight is on its int8 grid (runtime.QuantTables), the input a plain float tensor: three products per k (k_qgemm<4>)
+            z = K.pwconv_fwd_wq(x, L.wc_dgrad, bias)
+            if z is not None:
+                return z
         return K.pwconv_fwd(x, w, bias, L.six)
     if L.kind == "conv1":
         return K.conv1d_s1_fwd(x, w.reshape(w.shape[0], -1), bias, L.taps, L.dil, L.pad)

@@ -161,6 +161,11 @@ int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float*
  * reference hdemucsq.py:72-162, 261-347) run on it, student and teacher.                          */
 int fqss_pwconv_fwd_x3s(const float* x, const float* w, const float* bias, float* z, int B, int Ci,
                         int Co, int M, int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
+/* z[b] = (dw[co] * Wi[co][:]) x[b] + bias: the same pointwise conv when the weight is fake-quantized and given as its int8 codes
+ * (fqss_wq_codes / fqss_wq_multi_fwd: wi [Co][Ci] dense, dw [Co]) while x is a plain float tensor -- the frame-path convolutions of
+ * HTDemucs' student (Conv1dNlQ / Conv2dNlQ on de-quantized inputs, qat_layers.py:188-293): three bf16 products per k instead of six */
+int fqss_pwconv_fwd_wq(const float* x, const int8_t* wi, const float* dw, const float* bias, float* z, int B, int Ci, int Co, int M,
+                       int64_t ld_x, int64_t ld_z, fqss_stream_t stream);
 /* Stride-1 1-D convolution, any kernel width / dilation / zero padding (groups = 1), as an IMPLICIT GEMM on the bf16 matrix cores
  * (six-product split, csrc/gemm_x3.hip): the B operand is read straight from the signal, one shifted row per (channel, tap) -- no
  * frame image.  replaces: nn.Conv1d of the HTDemucs DConv / rewrite layers (hdemucsq.py:72-162, demucsq.py:110-182) and its autograd:

@@ -522,6 +522,31 @@ def test_grouped_row_weight_gradients():
         assert float((one.double() - (gw.double() - gw0.double())).norm()) <= 2e-6 * float(rw.norm()), k
 
 
+@pytest.mark.parametrize("B,Ci,Co,M", [(2, 384, 96, 2757), (1, 432, 192, 1000), (3, 32, 48, 130), (2, 768, 384, 431), (1, 3456, 768, 216)])
+def test_pointwise_conv_float_input_coded_weight(B, Ci, Co, M):
+    """fqss_pwconv_fwd_wq (round 5, k_qgemm<4>): z = (dw Wi) x + b for a FLOAT input and a fake-quantized weight given as int8 codes --
+    x in three exact bf16 pieces x one exact plane of codes -- against fp64 on the de-quantized weight (fp32-grade: 2e-6 of the maximum),
+    and its data gradient on the same codes (fqss_qpw_bwd_x).  The frame-path convolutions of HTDemucs' student (qat_layers.py:188-293)."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(Ci + Co + M)
+    w = (torch.randn(Co, Ci, 1, generator=g) * 0.05).to(dev)
+    ones = torch.ones(Co, 1, 1, device=dev) * 0.2
+    wc = K.wq_codes(w, -ones, ones)
+    x = K.empty_act((B, Ci, M), dev).copy_((torch.randn(B, Ci, M, generator=g) * torch.exp(torch.randn(B, Ci, M, generator=g) * 0.5)).to(dev))
+    bias = (torch.randn(Co, generator=g) * 0.1).to(dev)
+    z = K.pwconv_fwd_wq(x, wc, bias)
+    assert z is not None
+    wq64 = wc.idx.double() * wc.dw.double()[:, None]
+    ref = torch.einsum("oc,bcm->bom", wq64, x[..., :M].double()) + bias.double()[None, :, None]
+    err = float((z[..., :M].double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-6, err
+    gz = K.empty_act((B, Co, M), dev).copy_((torch.randn(B, Co, M, generator=g) * 1e-2).to(dev))
+    if Co <= 1024 and Co % 16 == 0:
+        gx = K.qpw_bwd_x(gz, wc)
+        refx = torch.einsum("oc,bom->bcm", wq64, gz[..., :M].double())
+        assert float((gx[..., :M].double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max())
+
+
 def test_pit_sisdr_loss_teacher_free():
     """fqss_pit_sisdr_loss (kd_lambda = 0, mysystem.py:153-156) against the oracle's neg_sisdr_pit: loss 1e-5, per-sample SI-SDR 1e-3 dB,
     dL/d est; one sample has its sources swapped so both permutations are exercised"""
