@@ -802,7 +802,8 @@ struct DwGnBefore {
     double* gacc;                            // partial slots of its output quantizer (= this layer's input range)
 };
 
-template <int KT, bool GA = false, bool GB = false>   // taps known at compile time (3 on the training path) or 0: runtime K <= kTaps
+template <int KT, bool GA = false, bool GB = false, int ACTC = -1>   // KT: taps known at compile time (3 on the training path) or 0: runtime K <= kTaps;
+                                                                       // ACTC >= 0: the activation known at compile time (PReLU in the TCN blocks)
 __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ g,
                                                   float* __restrict__ gx, float* gw, int C, int M, int K, int dil, int pad,
@@ -812,6 +813,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
                                                   DwGnBefore GBd) {
     constexpr int NT = KT ? KT : kTaps;
     if (KT) K = KT;
+    if (ACTC >= 0) act = ACTC;
     extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
     __shared__ float redf[(4 + kTaps) * 4];
     __shared__ __attribute__((aligned(16))) float2 tabA[GA ? 256 : 1];   // GA: {fma(x, c2, c3), in-range} per code of THIS layer's output
@@ -1807,11 +1809,12 @@ static int dwq_bwd_impl(const char* who, const uint8_t* xc, const float* qmin_x,
         FQSS_REQUIRE(gb->ld_xc0 >= M && codes_ok(gb->xc0, gb->ld_xc0), "gn_before: code rows must be 16-B aligned");
         Bf = DwGnBefore{gb->xc0, gb->ld_xc0, gb->qmin0, gb->qmax0, gb->gamma, gb->beta, gb->mean_rstd, gb->ws, gb->gacc};
     }
-#define FQSS_DWQ_BWD(KT, GA_, GB_)                                                                                                          \
-    hipLaunchKernelGGL((k_dwq_bwd<KT, GA_, GB_>), dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, \
+#define FQSS_DWQ_BWD(KT, GA_, GB_, ...)                                                                                                          \
+    hipLaunchKernelGGL((k_dwq_bwd<KT, GA_, GB_, ##__VA_ARGS__>), dim3((unsigned)(B * C)), dim3(256), lds, (hipStream_t)stream, xc, w, bias, g, gx, gw, C, M, \
                        K, dil, pad, ld_xc, ld_g, ld_gx, act, slope, qmin_x, qmax_x, qmin, qmax, gacc, gbias, gx != nullptr ? 1 : 0, A, Bf)
     if (K == 3) {
-        if (ga && gb) FQSS_DWQ_BWD(3, true, true);
+        if (ga && gb && act == FQSS_ACT_PRELU) FQSS_DWQ_BWD(3, true, true, FQSS_ACT_PRELU);      // the TCN block's layer
+        else if (ga && gb) FQSS_DWQ_BWD(3, true, true);
         else if (ga) FQSS_DWQ_BWD(3, true, false);
         else if (gb) FQSS_DWQ_BWD(3, false, true);
         else FQSS_DWQ_BWD(3, false, false);

@@ -10,6 +10,7 @@ and the reference's OWN spread between those runs over the last 50 steps -- the 
 Round 4: the same gate at the REAL model size and for the two remaining families --
     python tools/make_goldens_long.py cfg1       -> cfg1_train_long.npz   FULL-SIZE ConvTasNetQ (5.1 M parameters, cfg1_fill weights),
                                                     B = 2, T = 8000, 300 steps, six CPU configurations
+    python tools/make_goldens_long.py cfg1_lr1e-4 -> cfg1_train_long_lr1e-4.npz   (round 5) the same at lr 1e-4, four CPU configurations
     python tools/make_goldens_long.py sepformer  -> sep_train_long.npz    tiny SepformerQ of sep_tiny_step.npz, B = 1 (the speechbrain
                                                     env's per-sample objective == the asteroid objective at B = 1), Adam 1.5e-4, clip 5
     python tools/make_goldens_long.py htdemucs   -> hd_train_long.npz     tiny HTDemucsQ of hd_tiny_step.npz, solver.py:333-366 l1 + SDR-weighted
@@ -75,9 +76,11 @@ def build(which):
     return model, fmodel, lr
 
 
-def run(threads, mkldnn, which="convtasnet", N_STEPS=N_STEPS, B=B, T=T):
+def run(threads, mkldnn, which="convtasnet", N_STEPS=N_STEPS, B=B, T=T, lr_override=None):
     torch.set_num_threads(threads)
     model, fmodel, lr = build(which)
+    if lr_override is not None:
+        lr = lr_override
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     loss_t, sdr_t, tsdr_t = [], [], []
     with torch.backends.mkldnn.flags(enabled=mkldnn):
@@ -103,13 +106,15 @@ def run(threads, mkldnn, which="convtasnet", N_STEPS=N_STEPS, B=B, T=T):
     return np.array(loss_t, np.float32), np.array(sdr_t, np.float32), np.array(tsdr_t, np.float32)
 
 
-def main(which="convtasnet", n_steps=N_STEPS, batch=B, samples=T, fname="tiny_train_long.npz", variants=None):
+def main(which="convtasnet", n_steps=N_STEPS, batch=B, samples=T, fname="tiny_train_long.npz", variants=None, lr=None):
     variants = variants or [(1, True), (8, True), (1, False), (4, False)]
     d = dict(n_steps=np.int64(n_steps), batch=np.int64(batch), samples=np.int64(samples), seed0=np.int64(SEED0),
              variants=np.array([f"threads={t},mkldnn={m}" for t, m in variants]))
+    if lr is not None:
+        d["lr"] = np.float64(lr)
     L, S = [], []
     for t, m in variants:
-        lo, sd, ts = run(t, m, which, n_steps, batch, samples)
+        lo, sd, ts = run(t, m, which, n_steps, batch, samples, lr)
         L.append(lo); S.append(sd)
         d["teacher_sisdr"] = ts
     d["loss"], d["sisdr"] = np.stack(L), np.stack(S)
@@ -126,6 +131,11 @@ if __name__ == "__main__":
         main("dptnet", 160, 2, 400, "dpt_train_long.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg1":      # ~1 s per reference step on 8 cores: three configurations, 300 steps each
         main("cfg1", 300, 2, 8000, "cfg1_train_long.npz", variants=[(8, True), (8, False), (4, True), (2, True), (6, True), (4, False)])
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg1_lr1e-4":
+        # round 5 (VERDICT r04 next #5d): the same full-size model at lr 1e-4, a regime in which the quantized student's SI-SDR keeps
+        # RISING through step 300 (at the env's 1e-3 it drifts down once every quantizer is live): the "within 0.1 dB" claim where it can
+        # be resolved.  Four configurations (threads 8 / 4, oneDNN on / off)
+        main("cfg1", 300, 2, 8000, "cfg1_train_long_lr1e-4.npz", variants=[(8, True), (8, False), (4, True), (4, False)], lr=1e-4)
     elif len(sys.argv) > 1 and sys.argv[1] == "sepformer":
         main("sepformer", 200, 1, 800, "sep_train_long.npz", variants=[(8, True), (1, True), (4, False)])
     elif len(sys.argv) > 1 and sys.argv[1] == "htdemucs":
