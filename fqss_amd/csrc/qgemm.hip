@@ -853,13 +853,14 @@ __global__ __launch_bounds__(512, 1) void k_qwgrad2(QGemmArgs g) {
 // per workgroup -- the split-K seam recipe of MI355X_MICROARCH.md), and the workgroup whose ticket came last sums the slots IN PART
 // ORDER (sc1 loads) and adds the result to gw with plain read-modify-writes: no float atomics, and the same bits every run
 // (k_qwgrad2 issues 2.1 M float atomics per launch: 7.6 of its 31 us, and the source of the step's run-to-run noise).
-constexpr int WGR_MAXJOBS = 25, WGR_TEAM = 8, WGR_TEAMS = 32, WGR_SLOT_FLOATS = W2_TM * W2_TN;
+constexpr int WGR_MAXJOBS = 25, WGR_TEAM = 8, WGR_TEAMS = 32, WGR_SLOT_FLOATS = W2_TM * 256;     // (slots sized for the wide tile)
 struct WJob {
     const float* A; const float* A2; const unsigned char* Bc; float* C; const float* qmin; const float* qmax;
     int64_t lda, lda2, ldb, sAb, sA2b, sBb;
     int M, M1, N, K;                      // Co1 + Co2, Co1, Ci, frames
     int tiles_n, ntiles, spb, nstages;    // column tiles, tiles, stages per batch, stages per tile (= batches * spb)
     int ubeg, tile0;                      // first unit of this job; global index of its tile 0 (ticket / slab addressing)
+    int wide;                             // 64 x 256 tiles (Ci >= 256) instead of 64 x 128
 };
 struct WGroupArgs {
     int njobs, chunk, total, slots;       // units per team, units in all, slab slots per tile
@@ -870,21 +871,243 @@ static_assert(sizeof(WGroupArgs) <= 4096, "the job table travels in the kernel a
 __device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void ld16_sc1(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory"); }
 
-template <int GP>
-__global__ __launch_bounds__(512, 1) void k_qwgrad_group(WGroupArgs ga) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][GP][W2_TM][W2_LD];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][W2_TN][W2_LD];
-    __shared__ float rsum[W2_TM];
-    __shared__ unsigned ticket_s;
+// One segment = the stages [s0, s0 + n) of ONE tile, accumulated by one workgroup, then published / finished.
+//   WIDE = false: 64 (co) x 128 (ci) tile, 8 waves as 2 x 4, each a 32 x 32 output tile (the stage layout of k_qwgrad2);
+//   WIDE = true : 64 x 256 tile, 8 waves as 2 x 4, each 32 x 64 (two B fragments share every A fragment).  Why: the stage loop is bound
+//                 by LDS traffic -- per 64-frame stage a 32 x 32 wave tile reads 12 KB of gz pieces + 4 KB of codes for 12 MFMAs (128 KB
+//                 per workgroup and stage = ~1000 cycles of the LDS pipe against ~400 of MFMA issue); the wide tile reads 20 KB for 24
+//                 MFMAs.  Used for layers with Ci >= 256 (the res | skip pair: 4 x 2 tiles = ONE tile group, its gz row tiles read
+//                 twice instead of four times); LDS 2 x (27.6 + 36.9) KB.
+template <int GP, bool WIDE>
+__device__ __forceinline__ void wgr_segment(const WGroupArgs& ga, const WJob& J, const int tile, const int s0, const int n, const int nparts,
+                                            const int part, unsigned short* As_raw, unsigned short* Bs_raw, float* rsum, unsigned* ticket_s) {
+    constexpr int TN = WIDE ? 256 : 128, NBF = WIDE ? 2 : 1;      // tile width, B fragments (and code loads) per wave (thread)
+    typedef unsigned short (*AsT)[GP][W2_TM][W2_LD];
+    typedef unsigned short (*BsT)[TN][W2_LD];
+    AsT As = reinterpret_cast<AsT>(As_raw);
+    BsT Bs = reinterpret_cast<BsT>(Bs_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3, lr = lane & 31, lh = lane >> 5;
+    const int ar = tid >> 4, ac = (tid & 15) * 4;      // loader geometry of k_qwgrad2: A 16 threads per row, rows ar and ar + 32
+    const int br = tid >> 2, bc = (tid & 3) * 16;      // B 4 threads per row (16 codes each), rows br (and br + 128)
+    const bool first_half = wave < 4;
+    const int row0 = (tile / J.tiles_n) * W2_TM, col0 = (tile % J.tiles_n) * TN;
+    const int K = J.K, spb = J.spb, nb = J.nstages / J.spb;
+    const int ka_last = (K - 1) & ~3, kb_last = (K - 1) & ~15;
+    // ---- loader / converter state: the stage sequence runs over (batch, 64-frame chunk)
+    const float* Arow[2];
+    int64_t asb[2];
+    bool aok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + ar + 32 * i;
+        aok[i] = row < J.M;
+        const int rc = aok[i] ? row : 0;
+        Arow[i] = (rc < J.M1) ? J.A + (int64_t)rc * J.lda : J.A2 + (int64_t)(rc - J.M1) * J.lda2;
+        asb[i] = (rc < J.M1) ? J.sAb : J.sA2b;
+    }
+    const unsigned char* Brow[NBF];
+#pragma unroll
+    for (int f = 0; f < NBF; ++f) Brow[f] = J.Bc + (int64_t)min(col0 + br + 128 * f, J.N - 1) * J.ldb;
+    const int64_t sBb = J.sBb;
+    int lb = s0 / spb, lk = (s0 - lb * spb) * W2_TK;      // loader position
+    int ck = lk, cr = 0;                                   // converter: frame position inside its batch, relative stage
+    const float* Ap[2] = {Arow[0] + lb * asb[0], Arow[1] + lb * asb[1]};
+    int64_t boff = lb * sBb;
+    struct Stage { f32x4 a[2]; u32x4 b[NBF]; };
+    auto load = [&](Stage& st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wg_load16(st.a[i], Ap[i] + min(lk + ac, ka_last));
+#pragma unroll
+        for (int f = 0; f < NBF; ++f) wg_load16(st.b[f], Brow[f] + boff + min(lk + bc, kb_last));
+        lk += W2_TK;
+        if (lk >= spb * W2_TK) {       // next batch (clamped: stages behind the range are requested but never used)
+            lk = 0;
+            lb = min(lb + 1, nb - 1);
+            Ap[0] = Arow[0] + lb * asb[0];
+            Ap[1] = Arow[1] + lb * asb[1];
+            boff = lb * sBb;
+        }
+    };
+    constexpr int NLD = 2 + NBF;       // loads per thread and stage
+    auto wait_oldest = [&](Stage& st) {
+        if constexpr (WIDE) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b[0]), "+v"(st.b[NBF - 1]) : "n"(NLD * (W2_RING - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b[0]) : "n"(NLD * (W2_RING - 1)) : "memory");
+    };
+    auto wait_all = [&](Stage& st) {
+        if constexpr (WIDE) asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b[0]), "+v"(st.b[NBF - 1]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.b[0]) : : "memory");
+    };
+    float rs_part[2] = {0.f, 0.f};
+    auto convert_store = [&](Stage& st, int buf) {
+        const bool live = cr < n;
+        const int k = ck + ac;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (aok[i] && live && k + e < K) ? st.a[i][e] : 0.0f;
+            rs_part[i] += (x[0] + x[1]) + (x[2] + x[3]);
+            uint32_t o1[2], o2[2], o3[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float a0 = x[2 * e], a1 = x[2 * e + 1];
+                const float r0 = a0 - bf_trunc(a0), r1 = a1 - bf_trunc(a1);
+                o1[e] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+                if constexpr (GP == 3) {
+                    const float q0 = r0 - bf_trunc(r0), q1 = r1 - bf_trunc(r1);
+                    o2[e] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                    o3[e] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                } else {
+                    o2[e] = __builtin_amdgcn_perm(bf_rne_word(r1), bf_rne_word(r0), 0x07060302u);
+                }
+            }
+            const int row = ar + 32 * i;
+            *reinterpret_cast<uint2*>(&As[buf][0][row][ac]) = make_uint2(o1[0], o1[1]);
+            *reinterpret_cast<uint2*>(&As[buf][1][row][ac]) = make_uint2(o2[0], o2[1]);
+            if constexpr (GP == 3) *reinterpret_cast<uint2*>(&As[buf][2][row][ac]) = make_uint2(o3[0], o3[1]);
+        }
+#pragma unroll
+        for (int f = 0; f < NBF; ++f) {   // codes need no mask: finite, and where gz is masked they only ever meet a zero
+            uint32_t o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w = st.b[f][q];
+                const float f0 = (float)(w & 0xFFu), f1 = (float)((w >> 8) & 0xFFu);
+                const float f2 = (float)((w >> 16) & 0xFFu), f3 = (float)(w >> 24);
+                o[2 * q] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                o[2 * q + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+            }
+            *reinterpret_cast<uint4*>(&Bs[buf][br + 128 * f][bc]) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(&Bs[buf][br + 128 * f][bc + 8]) = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+        ++cr;
+        ck += W2_TK;
+        if (ck >= spb * W2_TK) ck = 0;
+    };
+    f32x16 acc[NBF];
+#pragma unroll
+    for (int f = 0; f < NBF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < W2_TK / 16; ++ks) {
+            const int kk = ks * 16 + 8 * lh;
+            bf16x8 bfr[NBF];
+#pragma unroll
+            for (int f = 0; f < NBF; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(&Bs[buf][wc * (32 * NBF) + 32 * f + lr][kk]);
+            bf16x8 af[GP];
+#pragma unroll
+            for (int p = 0; p < GP; ++p) af[p] = *reinterpret_cast<const bf16x8*>(&As[buf][p][wr * 32 + lr][kk]);
+#pragma unroll
+            for (int p = GP - 1; p >= 0; --p)      // smallest pieces first
+#pragma unroll
+                for (int f = 0; f < NBF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p], bfr[f], acc[f], 0, 0, 0);
+        }
+    };
+    Stage st[W2_RING];
+#pragma unroll
+    for (int i = 0; i < W2_RING; ++i) load(st[i]);
+    wait_oldest(st[0]);
+    convert_store(st[0], 0);
+    load(st[0]);
+    __syncthreads();
+    for (int s = 0; s < n; s += W2_RING) {      // stages at or behind n are converted to zeros (cr >= n)
+#pragma unroll
+        for (int i = 0; i < W2_RING; ++i) {
+            Stage& nx = st[(i + 1) % W2_RING];
+            if (first_half) compute(i & 1);
+            wait_oldest(nx);
+            convert_store(nx, (i + 1) & 1);
+            load(nx);
+            if (!first_half) compute(i & 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W2_RING; ++i) wait_all(st[i]);
+    // ---- this workgroup's share of the tile: dx * S + min_x * rowsum(gz)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = rs_part[i];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((tid & 15) == 0) rsum[ar + 32 * i] = v;
+    }
+    __syncthreads();
+    const float lo = *J.qmin, hi = *J.qmax;
+    const float dx = (hi - lo) / 255.0f, mnx = lo;
+    constexpr int NV = 16 * NBF;
+    float v[NV];
+#pragma unroll
+    for (int f = 0; f < NBF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[16 * f + r] = dx * acc[f][r] + mnx * rsum[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    bool finish = nparts == 1;
+    constexpr int SLOT = W2_TM * TN;       // floats per slab slot of this tile shape (the launch's slots are sized for the widest)
+    if (!finish) {
+        float* sl = ga.slabs + ((int64_t)(J.tile0 + tile) * ga.slots + part) * WGR_SLOT_FLOATS;
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) st16_sc1(sl + ((int64_t)q * 512 + tid) * 4, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *ticket_s = __hip_atomic_fetch_add(&ga.tickets[J.tile0 + tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        finish = *ticket_s == (unsigned)(nparts - 1);
+        if (finish) {       // the last to arrive: every part is published; sum them in part order (its own included: same bits whoever is last)
+            const float* s0p = ga.slabs + (int64_t)(J.tile0 + tile) * ga.slots * WGR_SLOT_FLOATS;
+#pragma unroll
+            for (int r = 0; r < NV; ++r) v[r] = 0.0f;
+            for (int p = 0; p < nparts; ++p) {
+#pragma unroll
+                for (int h = 0; h < NBF; ++h) {      // four 16-B loads in flight at a time
+                    f32x4 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ld16_sc1(t[q], s0p + (int64_t)p * WGR_SLOT_FLOATS + ((int64_t)(4 * h + q) * 512 + tid) * 4);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : : "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[16 * h + 4 * q + e] += t[q][e];
+                }
+            }
+            if (tid == 0) __hip_atomic_store(&ga.tickets[J.tile0 + tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+        }
+    }
+    static_assert(SLOT <= WGR_SLOT_FLOATS, "slab slots are sized for the wide tile");
+    if (finish) {       // gw += tile: this workgroup is the tile's only writer; all reads first (one round trip, not 16)
+        const int Mr = J.M, Nc = J.N;
+        float* const Cp = J.C;
+        float old[NV];
+#pragma unroll
+        for (int f = 0; f < NBF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = col0 + wc * (32 * NBF) + 32 * f + lr;
+                old[16 * f + r] = (row < Mr && col < Nc) ? Cp[(int64_t)row * Nc + col] : 0.0f;
+            }
+#pragma unroll
+        for (int f = 0; f < NBF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = col0 + wc * (32 * NBF) + 32 * f + lr;
+                if (row < Mr && col < Nc) Cp[(int64_t)row * Nc + col] = old[16 * f + r] + v[16 * f + r];
+            }
+    }
+    __syncthreads();     // rsum / ticket_s / the LDS stages are reused by the next segment
+}
+
+template <int GP>
+__global__ __launch_bounds__(512, 1) void k_qwgrad_group(WGroupArgs ga) {
+    // two stage buffers of the WIDE tile (the narrow one uses the front of each): gz pieces 2 x GP x 9,216 B, codes 2 x 36,864 B
+    __shared__ __attribute__((aligned(16))) unsigned short As_raw[2 * GP * W2_TM * W2_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs_raw[2 * 256 * W2_LD];
+    __shared__ float rsum[W2_TM];
+    __shared__ unsigned ticket_s;
     const int L = blockIdx.x, xcd = L % kXcds, slot = L / kXcds;                 // 32 workgroups per XCD: 4 teams of 8
     const int team = (slot / WGR_TEAM) * kXcds + xcd, member = slot % WGR_TEAM;
-    const int ar = tid >> 4, ac = (tid & 15) * 4;      // loader geometry of k_qwgrad2
-    const int br = tid >> 2, bc = (tid & 3) * 16;
-    const bool first_half = wave < 4;
-
     int u0 = team * ga.chunk;
     const int u1 = min(ga.total, u0 + ga.chunk);
     while (u0 < u1) {
@@ -898,180 +1121,8 @@ __global__ __launch_bounds__(512, 1) void k_qwgrad_group(WGroupArgs ga) {
         u0 += n;
         const int tile = grp * WGR_TEAM + member;
         if (tile >= J.ntiles) continue;                                            // (workgroup-uniform)
-        const int row0 = (tile / J.tiles_n) * W2_TM, col0 = (tile % J.tiles_n) * W2_TN;
-        const int K = J.K, spb = J.spb, nb = J.nstages / J.spb;
-        const int ka_last = (K - 1) & ~3, kb_last = (K - 1) & ~15;
-        // ---- loader / converter state: the stage sequence runs over (batch, 64-frame chunk)
-        const float* Arow[2];
-        int64_t asb[2];
-        bool aok[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = row0 + ar + 32 * i;
-            aok[i] = row < J.M;
-            const int rc = aok[i] ? row : 0;
-            Arow[i] = (rc < J.M1) ? J.A + (int64_t)rc * J.lda : J.A2 + (int64_t)(rc - J.M1) * J.lda2;
-            asb[i] = (rc < J.M1) ? J.sAb : J.sA2b;
-        }
-        const unsigned char* Brow = J.Bc + (int64_t)min(col0 + br, J.N - 1) * J.ldb;
-        const int64_t sBb = J.sBb;
-        int lb = s0 / spb, lk = (s0 - lb * spb) * W2_TK;      // loader position
-        int ck = lk, cr = 0;                                   // converter: frame position inside its batch, relative stage
-        const float* Ap[2] = {Arow[0] + lb * asb[0], Arow[1] + lb * asb[1]};
-        const unsigned char* Bp = Brow + lb * sBb;
-        auto load = [&](W2Stage& st) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wg_load16(st.a[i], Ap[i] + min(lk + ac, ka_last));
-            wg_load16(st.b, Bp + min(lk + bc, kb_last));
-            lk += W2_TK;
-            if (lk >= spb * W2_TK) {       // next batch (clamped: stages behind the range are requested but never used)
-                lk = 0;
-                lb = min(lb + 1, nb - 1);
-                Ap[0] = Arow[0] + lb * asb[0];
-                Ap[1] = Arow[1] + lb * asb[1];
-                Bp = Brow + lb * sBb;
-            }
-        };
-        float rs_part[2] = {0.f, 0.f};
-        auto convert_store = [&](W2Stage& st, int buf) {
-            const bool live = cr < n;
-            const int k = ck + ac;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float x[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = (aok[i] && live && k + e < K) ? st.a[i][e] : 0.0f;
-                rs_part[i] += (x[0] + x[1]) + (x[2] + x[3]);
-                uint32_t o1[2], o2[2], o3[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float a0 = x[2 * e], a1 = x[2 * e + 1];
-                    const float r0 = a0 - bf_trunc(a0), r1 = a1 - bf_trunc(a1);
-                    o1[e] = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
-                    if constexpr (GP == 3) {
-                        const float q0 = r0 - bf_trunc(r0), q1 = r1 - bf_trunc(r1);
-                        o2[e] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-                        o3[e] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-                    } else {
-                        o2[e] = __builtin_amdgcn_perm(bf_rne_word(r1), bf_rne_word(r0), 0x07060302u);
-                    }
-                }
-                const int row = ar + 32 * i;
-                *reinterpret_cast<uint2*>(&As[buf][0][row][ac]) = make_uint2(o1[0], o1[1]);
-                *reinterpret_cast<uint2*>(&As[buf][1][row][ac]) = make_uint2(o2[0], o2[1]);
-                if constexpr (GP == 3) *reinterpret_cast<uint2*>(&As[buf][2][row][ac]) = make_uint2(o3[0], o3[1]);
-            }
-            {   // codes need no mask: finite, and where gz is masked they only ever meet a zero
-                uint32_t o[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t w = st.b[q];
-                    const float f0 = (float)(w & 0xFFu), f1 = (float)((w >> 8) & 0xFFu);
-                    const float f2 = (float)((w >> 16) & 0xFFu), f3 = (float)(w >> 24);
-                    o[2 * q] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
-                    o[2 * q + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
-                }
-                *reinterpret_cast<uint4*>(&Bs[buf][br][bc]) = make_uint4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<uint4*>(&Bs[buf][br][bc + 8]) = make_uint4(o[4], o[5], o[6], o[7]);
-            }
-            ++cr;
-            ck += W2_TK;
-            if (ck >= spb * W2_TK) ck = 0;
-        };
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        auto compute = [&](int buf) {
-#pragma unroll
-            for (int ks = 0; ks < W2_TK / 16; ++ks) {
-                const int kk = ks * 16 + 8 * lh;
-                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[buf][wc * 32 + lr][kk]);
-                bf16x8 af[GP];
-#pragma unroll
-                for (int p = 0; p < GP; ++p) af[p] = *reinterpret_cast<const bf16x8*>(&As[buf][p][wr * 32 + lr][kk]);
-#pragma unroll
-                for (int p = GP - 1; p >= 0; --p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p], bfr, acc, 0, 0, 0);
-            }
-        };
-        W2Stage st[W2_RING];
-#pragma unroll
-        for (int i = 0; i < W2_RING; ++i) load(st[i]);
-        w2_wait<3 * (W2_RING - 1)>(st[0]);
-        convert_store(st[0], 0);
-        load(st[0]);
-        __syncthreads();
-        for (int s = 0; s < n; s += W2_RING) {      // stages at or behind n are converted to zeros (cr >= n)
-#pragma unroll
-            for (int i = 0; i < W2_RING; ++i) {
-                W2Stage& nx = st[(i + 1) % W2_RING];
-                if (first_half) compute(i & 1);
-                w2_wait<3 * (W2_RING - 1)>(nx);
-                convert_store(nx, (i + 1) & 1);
-                load(nx);
-                if (!first_half) compute(i & 1);
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < W2_RING; ++i) w2_wait<0>(st[i]);
-        // ---- this workgroup's share of the tile: dx * S + min_x * rowsum(gz)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float v = rs_part[i];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if ((tid & 15) == 0) rsum[ar + 32 * i] = v;
-        }
-        __syncthreads();
-        const float lo = *J.qmin, hi = *J.qmax;
-        const float dx = (hi - lo) / 255.0f, mnx = lo;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = dx * acc[r] + mnx * rsum[wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-        bool finish = nparts == 1;
-        if (!finish) {
-            float* sl = ga.slabs + ((int64_t)(J.tile0 + tile) * ga.slots + part) * WGR_SLOT_FLOATS;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) st16_sc1(sl + ((int64_t)q * 512 + tid) * 4, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) ticket_s = __hip_atomic_fetch_add(&ga.tickets[J.tile0 + tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            finish = ticket_s == (unsigned)(nparts - 1);
-            if (finish) {       // the last to arrive: every part is published; sum them in part order (its own included: same bits whoever is last)
-                const float* s0p = ga.slabs + (int64_t)(J.tile0 + tile) * ga.slots * WGR_SLOT_FLOATS;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = 0.0f;
-                for (int p = 0; p < nparts; ++p) {
-                    f32x4 t[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ld16_sc1(t[q], s0p + (int64_t)p * WGR_SLOT_FLOATS + ((int64_t)q * 512 + tid) * 4);
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : : "memory");
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 * q + e] += t[q][e];
-                }
-                if (tid == 0) __hip_atomic_store(&ga.tickets[J.tile0 + tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
-            }
-        }
-        if (finish) {       // gw += tile: this workgroup is the tile's only writer; all 16 reads first (one round trip, not 16)
-            const int col = col0 + wc * 32 + lr;
-            const int Mr = J.M, Nc = J.N;
-            float* const Cp = J.C;
-            float old[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                old[r] = (row < Mr && col < Nc) ? Cp[(int64_t)row * Nc + col] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < Mr && col < Nc) Cp[(int64_t)row * Nc + col] = old[r] + v[r];
-            }
-        }
-        __syncthreads();     // rsum / ticket_s / the LDS stages are reused by the next segment
+        if (J.wide) wgr_segment<GP, true>(ga, J, tile, s0, n, nparts, part, As_raw, Bs_raw, rsum, &ticket_s);
+        else wgr_segment<GP, false>(ga, J, tile, s0, n, nparts, part, As_raw, Bs_raw, rsum, &ticket_s);
     }
 }
 
@@ -1302,7 +1353,9 @@ static int wgr_plan(const FqssWgradJob* jobs, int n0, int n, WGroupArgs& ga, int
         J.lda = f.ld_gz1; J.lda2 = f.ld_gz2; J.ldb = f.ld_xc;
         J.sAb = (int64_t)f.Co1 * f.ld_gz1; J.sA2b = (int64_t)f.Co2 * f.ld_gz2; J.sBb = (int64_t)f.Ci * f.ld_xc;
         J.M = Co; J.M1 = f.Co1; J.N = f.Ci; J.K = f.M;
-        J.tiles_n = (int)cdiv(f.Ci, W2_TN);
+        static const bool no_wide = getenv("FQSS_WGRAD_WIDE") != nullptr && getenv("FQSS_WGRAD_WIDE")[0] == '0';      // A/B knob
+        J.wide = (f.Ci >= 256 && !no_wide) ? 1 : 0;
+        J.tiles_n = (int)cdiv(f.Ci, J.wide ? 256 : W2_TN);
         J.ntiles = (int)cdiv(Co, W2_TM) * J.tiles_n;
         J.spb = (int)cdiv(f.M, W2_TK);
         J.nstages = f.B * J.spb;

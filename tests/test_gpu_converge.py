@@ -61,7 +61,8 @@ def _run_streams(make_step, runs, n, B, T, seed0):
 
 # max - min of the HIP runs' 50-step SI-SDR tails that a family may show (dB): ~1.6 x the six-run measurements of
 # profiles/r04_converge_repeat.txt (0.46 / 0.10 / 0.29); a committed constant, not derived from the runs under test
-HIP_SPREAD_CAP = {"tiny convtasnet": 0.75, "tiny dptnet": 0.2, "tiny sepformer": 0.5, "full-size convtasnet": 0.75}
+HIP_SPREAD_CAP = {"tiny convtasnet": 0.75, "tiny dptnet": 0.2, "tiny sepformer": 0.5, "full-size convtasnet": 0.75,
+                  "full-size convtasnet lr 1e-4": 0.3}
 
 
 def _gate(name, S, L, gl, first_n, gain_db, rule="mean"):
@@ -176,6 +177,30 @@ def test_full_size_convtasnet_trains_to_the_reference_sisdr(golden):
     S, L = _run_streams(make, 3, n, B, T, seed0)
     np.testing.assert_allclose(L[:, :2], np.broadcast_to(gl["loss"][0, :2], (3, 2)), rtol=5e-5)
     _gate("full-size convtasnet", S, L, gl, 10, 4.0, rule="envelope")
+
+
+def test_full_size_convtasnet_at_lr_1e4_within_a_tenth_of_a_db(golden):
+    """The north_star's "SI-SDR within 0.1 dB of the reference" where it can be RESOLVED (VERDICT r04 next #5d): the same full-size
+    ConvTasNetQ, stream and step as the test above at lr 1e-4, a regime in which the quantized student keeps improving through step
+    300 (at the env's 1e-3 its SI-SDR drifts down once every quantizer is live and the reference's own backends split by 0.3-0.5 dB).
+    tests/golden/cfg1_train_long_lr1e-4.npz: the imported reference under four CPU configurations (tools/make_goldens_long.py
+    cfg1_lr1e-4).  Rule "mean" with the HIP spread capped (module docstring); three HIP runs."""
+    from fqss_amd.runtime import KDTrainStep
+    from fqss_amd.smoke import build_pair
+    from tests.helpers_cfg1 import cfg1_fill
+    gl = golden("cfg1_train_long_lr1e-4")
+    n, B, T, seed0, lr = int(gl["n_steps"]), int(gl["batch"]), int(gl["samples"]), int(gl["seed0"]), float(gl["lr"])
+    assert lr == 1e-4
+
+    def make():
+        model, fmodel = build_pair("cuda", 0, n_spks=2, kernel_size=16, stride=8)
+        cfg1_fill(fmodel, "T.")
+        cfg1_fill(model, "S.")
+        return KDTrainStep(model, fmodel, kd_lambda=0.1, lr=lr, clip=5.0, teacher_ahead=True)
+
+    S, L = _run_streams(make, 3, n, B, T, seed0)
+    np.testing.assert_allclose(L[:, :2], np.broadcast_to(gl["loss"][0, :2], (3, 2)), rtol=5e-5)
+    _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0)
 
 
 def test_tiny_sepformer_trains_to_the_reference_sisdr(golden):
