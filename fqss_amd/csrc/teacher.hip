@@ -137,6 +137,7 @@ struct TGemmArgs {
     float* C1; const float* R1; int64_t ldc1, sC1b;
     float* C2; const float* R2; int64_t ldc2, sC2b;
     int tiles_m, tiles_n, batches;   // logical grid (launched 1-D in XCD-aware order, fqss_dev.h)
+    int stagger;                     // k_tgemm2: cycles by which every second workgroup starts late (0: none; see its header)
 };
 
 template <int PRO>   // prologue on the activation rows: 0 none | 1 GroupNorm affine | 2 PReLU
@@ -499,6 +500,13 @@ __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int panel = blockIdx.x;
     const int b = panel / g.tiles_n, j0 = (panel % g.tiles_n) * T2BN;
+    // Phase stagger (round 5): the 256 workgroups (one per CU) run in lockstep -- k-loop (matrix pipes busy, HBM nearly idle), then the
+    // epilogue (every workgroup storing its 128 KB tile at once: HBM-write bound, matrix pipes dark; 44 % of T1 by its barrier stamps).
+    // Starting every second workgroup late by roughly half an epilogue puts one half's stores under the other half's MFMAs.
+    if (g.stagger > 0 && (panel & 1)) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
+    }
 #ifdef FQSS_T2_STAMP
     int sidx = 0;
 #endif
@@ -1001,6 +1009,8 @@ static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, cons
         }();
         TG_REQUIRE(attr_ok, "k_tgemm2 needs 160 KB of dynamic LDS");
         g.tiles_m = Co / T2BM;
+        static const int stagger = [] { const char* e = getenv("FQSS_T2_STAGGER"); return e ? atoi(e) : 0; }();
+        g.stagger = stagger;
         const dim3 grid2((unsigned)(g.tiles_n * B));
         if (pro == 0) hipLaunchKernelGGL(k_tgemm2<0>, grid2, dim3(512), T2_SMEM, (hipStream_t)stream, g);
         else if (pro == 1) hipLaunchKernelGGL(k_tgemm2<1>, grid2, dim3(512), T2_SMEM, (hipStream_t)stream, g);
