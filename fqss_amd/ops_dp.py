@@ -64,11 +64,20 @@ def _rowlinear_wgrad_into(gz, x, xq, buf, gbias=None, defer=False):
     return False
 
 
+LSTM_WIH_GROUP = __import__("os").environ.get("FQSS_LSTM_WIH_GROUP", "1") != "0"
+
+
 def _rowlinear_wgrad_pair_into(gz0, gz1, x, xq, buf0, buf1):
     """both directions' W_ih gradients of a bidirectional LSTM (two column blocks of dG against one input): one launch"""
     if QROW_BWD and xq is not None and all(b.dim() == 2 and b.is_contiguous() for b in (buf0, buf1)) and xq.idx.is_contiguous() \
             and xq.idx.shape[-1] == buf0.shape[1] and K.qrow_bwd_ok(buf0.shape[1], buf0.shape[0]):
-        K.qrow_bwd_w_pair(gz0, gz1, xq.idx, xq.qmin, xq.qmax, buf0, buf1)
+        rq = getattr(ops.DEFER, "row_wgrad_queue", None) if LSTM_WIH_GROUP else None
+        if rq is not None and gz0.data_ptr() % 16 == 0 and gz1.data_ptr() % 16 == 0:
+            # (buf0 / buf1 are the step's dL/dW_q arena slots: the two weight gradients join the segment's grouped launch)
+            rq.push(gz0, xq.idx, xq.qmin, xq.qmax, buf0)
+            rq.push(gz1, xq.idx, xq.qmin, xq.qmax, buf1)
+        else:
+            K.qrow_bwd_w_pair(gz0, gz1, xq.idx, xq.qmin, xq.qmax, buf0, buf1)
     else:
         K.rowlin_bwd_w_pair(gz0, x, buf0, gz1, x, buf1)
 
