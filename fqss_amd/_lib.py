@@ -246,6 +246,7 @@ EXPORTS = tuple(_PROTOS)
 # entry points of include/fqss_experiments.h: only in variants/libfqss_experiments.so (`make -C fqss_amd/csrc experiments`, FQSS_LIB)
 _PROTOS.update({
     "fqss_gndwq_fwd": [P, P, P, P, P, F32, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P],
+    "fqss_gndwq_fwd_v1": [P, P, P, P, P, F32, P, I32, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I32, I32, I32, I64, I64, I64, P],
 })
 
 

@@ -696,6 +696,120 @@ __global__ __launch_bounds__(256) void k_gndwq_fwd(const uint8_t* __restrict__ x
 }
 #endif  // FQSS_EXPERIMENTS
 
+#ifdef FQSS_EXPERIMENTS   // round-5 experiment (the table form of the fused forward): bit-identical, STILL slower than the two launches (39.6 vs 33.5 us)
+// gLN + fake-quant FOLLOWED BY the 3-tap depthwise conv + PReLU + fake-quant, codes -> codes -> codes, as ONE launch -- round 5, on
+// code tables (the round-4 form above computed both layers per element and lost to the two launches: both halves were bound by vector
+// issue).  Per (b, c) row the GroupNorm's output code is a function T of the input code (k_gnq_apply_t), and what the FIR needs of it
+// -- its de-quantised value -- is another: V[c] = delta1 * T[c] + min1.  A workgroup takes RPW consecutive rows of one sample; per row
+// thread t evaluates T[t] and V[t] once (256-B + 1-KB LDS tables), the row's INPUT codes go to an LDS row, and then
+//   y1[m] = T[x[m]]                                   (one byte lookup per element, stored for the backward of both layers)
+//   z[m]  = fma(w2, V[x[m + d]], fma(w1, V[x[m]], w0 * V[x[m - d]])) + b     (three float lookups instead of three decodes)
+//   y2[m] = fq(PReLU(z[m]))                           (k_dwq_fwd<3>'s arithmetic), + the integer statistics of y2 for the next gLN.
+// Every value is what fqss_gnq_fwd + fqss_dwq_fwd compute (tests/test_gpu_kernels.py::test_gn_dw_fused_bit_identical); ~20 vector
+// instructions per element instead of 3 + 27, one launch and one 16-MB re-read less.  Rows of at most 4096 positions, K = 3.
+__global__ __launch_bounds__(256) void k_gndwq_fwd_t(const uint8_t* __restrict__ xc, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      uint8_t* __restrict__ y1, float* __restrict__ mean_rstd, const long long* __restrict__ ws,
+                                                      int nslots, float eps, int B, int C, int M, int64_t ld_xc, int64_t ld_y1,
+                                                      const float* qmin_x, const float* qmax_x, const float* qmin1, const float* qmax1,
+                                                      const float* __restrict__ w, const float* __restrict__ bias, int dil, int pad, int act,
+                                                      const float* slope_p, uint8_t* __restrict__ y2, int64_t ld_y2, const float* qmin2,
+                                                      const float* qmax2, long long* stats2, int rpw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf[];      // [padl + 4096 + pad + 16]: the row's INPUT codes
+    __shared__ long long red[2 * 4];
+    __shared__ float mr[2];
+    __shared__ unsigned int sred[2 * 4];
+    __shared__ __attribute__((aligned(16))) uint8_t tabC[256];
+    __shared__ __attribute__((aligned(16))) float tabV[256];
+    const QRange rx = load_qrange(qmin_x, qmax_x), r1 = load_qrange(qmin1, qmax1), r2 = load_qrange(qmin2, qmax2);
+    const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
+    const int rows = B * C, padl = (pad + 15) & ~15;
+    const int m0 = threadIdx.x * 16;
+    const float xt = dec(threadIdx.x, rx);
+    int b_have = -1;
+    for (int r0 = blockIdx.x * rpw; r0 < rows; r0 += gridDim.x * rpw)
+    for (int row = r0; row < min(rows, r0 + rpw); ++row) {
+        const int b = row / C, c = row - b * C;
+        uint4 v0 = make_uint4(0, 0, 0, 0);
+        if (m0 < M) v0 = *reinterpret_cast<const uint4*>(xc + (int64_t)row * ld_xc + m0);
+        if (b != b_have) {    // block-uniform
+            gnq_sample_stats(ws, nslots, b, (int64_t)C * M, eps, rx, red, mr);
+            b_have = b;
+            if (c == 0 && threadIdx.x == 0) {   // saved for the GroupNorm's backward
+                mean_rstd[2 * b] = mr[0];
+                mean_rstd[2 * b + 1] = mr[1];
+            }
+        }
+        const float scale = mr[1] * gamma[c];
+        const float shift = fmaf(-scale, mr[0], beta[c]);
+        {
+            const float c1 = fq_code(fmaf(xt, scale, shift), r1);      // k_gnq_apply's arithmetic, once per code
+            tabC[threadIdx.x] = (uint8_t)c1;
+            tabV[threadIdx.x] = r1.delta * c1 + r1.lo;                   // dec() of that code, as k_dwq_fwd reads it
+        }
+        if (m0 < M) *reinterpret_cast<uint4*>(rowbuf + padl + m0) = v0;
+        __syncthreads();
+        float wk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wk[k] = w[c * 3 + k];
+        const float bv = bias ? bias[c] : 0.0f;
+        unsigned int st_s = 0, st_ss = 0;
+        if (m0 < M) {
+            {   // ---- the GroupNorm's output codes (for the backward of both layers)
+                const unsigned int wv[4] = {v0.x, v0.y, v0.z, v0.w};
+                unsigned int o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = (unsigned int)tabC[wv[q] & 255u] | ((unsigned int)tabC[(wv[q] >> 8) & 255u] << 8) |
+                           ((unsigned int)tabC[(wv[q] >> 16) & 255u] << 16) | ((unsigned int)tabC[wv[q] >> 24] << 24);
+                *reinterpret_cast<uint4*>(y1 + (int64_t)row * ld_y1 + m0) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            const bool inner = (m0 - pad >= 0) && (m0 + 15 + pad < M);
+            unsigned int o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + 4 * q;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int s0 = m + k * dil - pad;
+                    float v[4];
+                    if (inner) {
+                        const int a = padl + s0;                               // >= 0: inner
+                        const unsigned int lo = *reinterpret_cast<const unsigned int*>(rowbuf + (a & ~3));
+                        const unsigned int hi = *reinterpret_cast<const unsigned int*>(rowbuf + (a & ~3) + 4);
+                        const unsigned int cw = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(a & 3));
+                        v[0] = tabV[cw & 255u]; v[1] = tabV[(cw >> 8) & 255u]; v[2] = tabV[(cw >> 16) & 255u]; v[3] = tabV[cw >> 24];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (s0 + j >= 0 && s0 + j < M) ? tabV[rowbuf[padl + s0 + j]] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(wk[k], v[j], acc[j]);
+                }
+                unsigned int pk = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk = pack_code(fq_code(act_apply(acc[j] + bv, act, slope), r2), j, pk);
+                o[q] = pk;
+                const unsigned int live = (m + 3 < M) ? 0xFFFFFFFFu : ((m < M) ? (0xFFFFFFFFu >> (8 * (4 - (M - m)))) : 0u);
+                code_stats4(pk & live, st_s, st_ss);
+            }
+            *reinterpret_cast<uint4*>(y2 + (int64_t)row * ld_y2 + m0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (stats2 != nullptr) {   // one slot per row; block_sum's barriers also protect the LDS row and tables against the next row's stores
+            unsigned int v[2] = {st_s, st_ss};
+            block_sum<unsigned int, 2>(v, sred);
+            if (threadIdx.x == 0) {
+                stats2[2 * (int64_t)row] = (long long)v[0];
+                stats2[2 * (int64_t)row + 1] = (long long)v[1];
+            }
+        } else {
+            __syncthreads();
+        }
+    }
+}
+
+#endif  // FQSS_EXPERIMENTS
+
 // backward: recompute z, STE + PReLU -> gz (fp32), bias row-sums, range/slope partials (gacc slots)
 template <int NQ>   // float4 groups per thread and pass: a workgroup covers NQ * 1024 consecutive positions
 __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ xc, const float* __restrict__ w,
@@ -1677,10 +1791,38 @@ extern "C" int fqss_gnq_bwd_apply(const uint8_t* xc, const float* qmin_x, const 
 }
 
 #ifdef FQSS_EXPERIMENTS
+/* GroupNormQ followed by a 3-tap depthwise Conv1dNlQ, both in their quantizing phase, codes -> codes -> codes in ONE launch on code tables
+ * (k_gndwq_fwd_t, round 5): y1 = the GroupNorm's output codes (range 1), y2 = the depthwise layer's (range 2); stats = the producer's
+ * statistics of xc ([B][nslots][2]), stats2 (nullable) = [B][C][2] statistics of y2 for a GroupNormQ behind it.  M <= 4096, K = 3;
+ * bit-identical to fqss_gnq_fwd + fqss_dwq_fwd. */
+extern "C" int fqss_gndwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma, const float* beta, float eps,
+                              const int64_t* stats, int nslots, float* mean_rstd, uint8_t* y1, const float* qmin1, const float* qmax1,
+                              const float* w, const float* bias, int dil, int pad, int act, const float* slope, uint8_t* y2,
+                              const float* qmin2, const float* qmax2, int64_t* stats2, int B, int C, int M, int64_t ld_xc, int64_t ld_y1,
+                              int64_t ld_y2, fqss_stream_t stream) {
+    if (B == 0 || M == 0) return FQSS_OK;
+    FQSS_REQUIRE(xc && qmin_x && qmax_x && gamma && beta && stats && mean_rstd && y1 && qmin1 && qmax1 && w && y2 && qmin2 && qmax2, "null pointer");
+    FQSS_REQUIRE(B > 0 && C > 0 && M > 0 && M <= 4096 && dil > 0 && pad == dil && pad <= 2048, "rows of at most 4096 positions, 3 taps");
+    FQSS_REQUIRE(nslots > 0 && nslots <= 1024, "supplied statistics: 1 .. 1024 partial-sum slots per sample");
+    FQSS_REQUIRE(ld_xc >= M && ld_y1 >= M && ld_y2 >= M && codes_ok(xc, ld_xc) && codes_ok(y1, ld_y1) && codes_ok(y2, ld_y2), "code rows must be 16-B aligned");
+    FQSS_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
+    const int64_t rows = (int64_t)B * C;
+    FQSS_REQUIRE(rows < (1ll << 30), "tensor too large");
+    const int rpw = (rows >= 2048 && C % 4 == 0) ? 4 : ((rows >= 1024 && C % 2 == 0) ? 2 : 1);     // rows of ONE sample per workgroup
+    const size_t smem = (size_t)(((pad + 15) & ~15) + 4096 + pad + 16);
+    hipLaunchKernelGGL(k_gndwq_fwd_t, dim3((unsigned)cdiv(rows, rpw)), dim3(256), smem, (hipStream_t)stream, xc, gamma, beta, y1, mean_rstd,
+                       (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_y1, qmin_x, qmax_x, qmin1, qmax1, w, bias, dil, pad, act, slope, y2,
+                       ld_y2, qmin2, qmax2, (long long*)stats2, rpw);
+    return launch_status("fqss_gndwq_fwd");
+}
+
+#endif  // FQSS_EXPERIMENTS
+
+#ifdef FQSS_EXPERIMENTS
 /* GroupNormQ followed by a depthwise Conv1dNlQ, both in their quantizing phase, codes -> codes -> codes in one launch (k_gndwq_fwd):
  * y1 = the GroupNorm's output codes (range 1), y2 = the depthwise layer's (range 2); stats = the producer's statistics of xc ([B][nslots][2]),
  * stats2 (nullable) = [B][C][2] statistics of y2 for a GroupNormQ behind it.  M <= 4096, K = 3; bit-identical to fqss_gnq_fwd + fqss_dwq_fwd. */
-extern "C" int fqss_gndwq_fwd(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma, const float* beta, float eps,
+extern "C" int fqss_gndwq_fwd_v1(const uint8_t* xc, const float* qmin_x, const float* qmax_x, const float* gamma, const float* beta, float eps,
                               const int64_t* stats, int nslots, float* mean_rstd, uint8_t* y1, const float* qmin1, const float* qmax1,
                               const float* w, const float* bias, int dil, int pad, int act, const float* slope, uint8_t* y2,
                               const float* qmin2, const float* qmax2, int64_t* stats2, int B, int C, int M, int64_t ld_xc, int64_t ld_y1,
@@ -1698,7 +1840,7 @@ extern "C" int fqss_gndwq_fwd(const uint8_t* xc, const float* qmin_x, const floa
     hipLaunchKernelGGL(k_gndwq_fwd, dim3((unsigned)cdiv(rows, rpw)), dim3(256), smem, (hipStream_t)stream, xc, gamma, beta, y1, mean_rstd,
                        (const long long*)stats, nslots, eps, B, C, M, ld_xc, ld_y1, qmin_x, qmax_x, qmin1, qmax1, w, bias, dil, pad, act, slope, y2,
                        ld_y2, qmin2, qmax2, (long long*)stats2, rpw);
-    return launch_status("fqss_gndwq_fwd");
+    return launch_status("fqss_gndwq_fwd_v1");
 }
 #endif  // FQSS_EXPERIMENTS
 

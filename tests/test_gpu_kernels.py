@@ -1425,9 +1425,9 @@ def test_depthwise_backward_takes_the_groupnorm_passes(B, C, M, dil, which):
 
 @pytest.mark.parametrize("B,C,M,dil", [(2, 24, 3999, 1), (1, 16, 3999, 128), (3, 8, 777, 4), (2, 600, 130, 2), (1, 4, 4096, 64)])
 def test_gn_dw_fused_bit_identical(B, C, M, dil):
-    """(EXPERIMENT, include/fqss_experiments.h: not in the product library since round 5 -- runs when FQSS_LIB points at
-    `make -C fqss_amd/csrc experiments`' variants/libfqss_experiments.so, skipped otherwise.)
-    fqss_gndwq_fwd (round 4): GroupNormQ + 3-tap depthwise Conv1dNlQ (PReLU), both quantizing, as ONE launch -- against the two
+    """(EXPERIMENT, include/fqss_experiments.h: not in the product library -- runs when FQSS_LIB points at `make -C fqss_amd/csrc
+    experiments`' variants/libfqss_experiments.so, skipped otherwise.)  fqss_gndwq_fwd (round 5: on per-row code tables, k_gndwq_fwd_t;
+    the per-element form of round 4 is fqss_gndwq_fwd_v1): GroupNormQ + 3-tap depthwise Conv1dNlQ (PReLU), both quantizing, as ONE launch -- against the two
     launches it replaces (fqss_gnq_fwd, fqss_dwq_fwd): the GroupNorm's output codes, its mean / rstd, the depthwise layer's output
     codes and the integer statistics of those codes, bit for bit (dilations 1 .. 128: unaligned taps out of the LDS row, the
     zero-padded row ends, rows shorter than a workgroup's 4096 positions, several rows per workgroup)."""
