@@ -42,6 +42,7 @@ _PROTOS = {
     "fqss_qpw_bwd_x_add": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_qpw_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_fwdq": [P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P],
+    "fqss_qpw_fwdq_add": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P, P],
     "fqss_qpw_stat_slots": [I32, I32],
     "fqss_dwq_stat_slots": [I32, I32],
     "fqss_qpw_fwd2": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
@@ -206,6 +207,11 @@ class FqssQParams(C.Structure):
 
 class FqssWCodes(C.Structure):
     _fields_ = [("idx", C.c_void_p), ("idxT", C.c_void_p), ("dw", C.c_void_p), ("rw", C.c_void_p), ("Co", C.c_int), ("Ci", C.c_int)]
+
+
+class FqssAddAfter(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("ld_a", C.c_int64), ("amin", C.c_void_p), ("amax", C.c_void_p), ("qmin", C.c_void_p),
+                ("qmax", C.c_void_p), ("y", C.c_void_p), ("ld_y", C.c_int64)]
 
 
 class FqssGnAfter(C.Structure):

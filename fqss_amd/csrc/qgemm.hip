@@ -89,6 +89,9 @@ __device__ __forceinline__ void q_wait(QStage& st) {
                      : "memory");
 }
 
+// de-quantised value of a code: two roundings (mul, add), the form of fused_q.hip
+__device__ __forceinline__ float dec(unsigned int c, const QRange& r) { return r.delta * (float)c + r.lo; }
+
 struct QGemmArgs {
     // forward / dgrad: A = int8 weight codes [M][K] (k contiguous), B = per-batch [K][ldb] (n contiguous)
     // wgrad          : A = fp32 gz [M][lda] per batch (k = n contiguous), B = u8 codes [N][ldb] per batch
@@ -121,6 +124,13 @@ struct QGemmArgs {
     // fwd + fused quantizer, optional: exact integer statistics (sum c, sum c^2) of the output codes Q1, one slot per workgroup:
     // stats[(b * tiles_m * tiles_n + mt * tiles_n + nt) * 2 + {0,1}] -- what the GroupNorm that consumes Q1 needs (fused_q.hip)
     long long* stats;
+    // fwd + fused quantizer, optional (round 5): the AddQ that is the ONLY consumer of output 1 / 2 (the residual add and the skip sum
+    // of a TCN block, convtasnetq.py ConvBlock / MaskGenerator) evaluated on the finished output codes: S = fq_s(dec_a(AD) + dec_y(Q)),
+    // op for op what k_ewq_fwd computes from the same codes (fused_q.hip), written beside Q -- the AddQ's own launch disappears
+    const unsigned char* AD1; const unsigned char* AD2; int64_t ldad1, ldad2;
+    unsigned char* S1; unsigned char* S2; int64_t lds1, lds2;
+    const float *ad_min1, *ad_max1, *ad_min2, *ad_max2;      // ranges of the other operand's codes
+    const float *s_min1, *s_max1, *s_min2, *s_max2;          // ranges of the AddQ's own quantizer
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
@@ -399,11 +409,14 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
     const bool quant = (MODE == 0) && g.Q1 != nullptr;
     unsigned int st_s = 0, st_ss = 0;     // statistics of this lane's output codes (< 2^32 for a whole 128 x 64 tile)
     QRange ry1{}, ry2{};
+    QRange rad1{}, rad2{}, rs1{}, rs2{};     // fused AddQ behind output 1 / 2: the other operand's range, the sum's range
     float qslope = 0.0f;
     if (quant) {
         ry1 = load_qrange(g.qy_min1, g.qy_max1);
         ry2 = (g.Q2 != nullptr) ? load_qrange(g.qy_min2, g.qy_max2) : ry1;
         qslope = (g.qact == FQSS_ACT_PRELU) ? *g.qslope : 0.0f;
+        if (g.S1 != nullptr) { rad1 = load_qrange(g.ad_min1, g.ad_max1); rs1 = load_qrange(g.s_min1, g.s_max1); }
+        if (g.S2 != nullptr) { rad2 = load_qrange(g.ad_min2, g.ad_max2); rs2 = load_qrange(g.s_min2, g.s_max2); }
     }
     {
         // stage each 32x32 accumulator tile through LDS and store whole 128-B rows with 16 B per lane
@@ -422,6 +435,18 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
         auto tile_epilogue = [&](int mi, auto PER_ROW) {
             const int rowt = i0 + wm * 64 + mi * 32;
             const bool tfirst = rowt < g.M1;
+            // fused AddQ: request this lane's 16 codes of the other operand now, they are used behind the tile's own codes
+            uint4 ad16 = make_uint4(0u, 0u, 0u, 0u);
+            const unsigned char* const adp = (MODE == 0 && quant) ? (tfirst ? g.AD1 : g.AD2) : nullptr;
+            if constexpr (MODE == 0) {
+                if (adp != nullptr) {
+                    const int64_t ldad = tfirst ? g.ldad1 : g.ldad2;
+                    const int orow = rowt + (lane >> 1) - (tfirst ? 0 : g.M1), ocol = j0 + wn * 32 + 16 * (lane & 1);
+                    const int rows_o = tfirst ? g.M1 : g.M - g.M1;
+                    if (rowt + (lane >> 1) < g.M && ocol < ldad)
+                        ad16 = *reinterpret_cast<const uint4*>(adp + ((int64_t)b * rows_o + orow) * ldad + ocol);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -491,6 +516,28 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
                         unsigned char* qb = tfirst ? g.Q1 + (int64_t)b * g.sQ1b + (int64_t)(rowt + rl) * ldq
                                                    : g.Q2 + (int64_t)b * g.sQ2b + (int64_t)(rowt + rl - g.M1) * ldq;
                         *reinterpret_cast<uint4*>(qb + qcol) = c16;
+                    }
+                    if (adp != nullptr) {   // wave-uniform.  S = fq(dec(a) + dec(y)): k_ewq_fwd's arithmetic (sb = 1, no activation)
+                        const QRange ra = tfirst ? rad1 : rad2, rs = tfirst ? rs1 : rs2;
+                        const unsigned int wa[4] = {ad16.x, ad16.y, ad16.z, ad16.w}, wy[4] = {c16.x, c16.y, c16.z, c16.w};
+                        unsigned int o[4];
+#pragma unroll
+                        for (int w4 = 0; w4 < 4; ++w4) {
+                            unsigned int pk = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float z = dec((wa[w4] >> (8 * e)) & 255u, ra);
+                                z = z + 1.0f * dec((wy[w4] >> (8 * e)) & 255u, ry);
+                                pk = pack_code(fq_code(z, rs), e, pk);
+                            }
+                            o[w4] = pk;
+                        }
+                        const int64_t lds_ = tfirst ? g.lds1 : g.lds2;
+                        const int rows_o = tfirst ? g.M1 : g.M - g.M1;
+                        if (rowt + rl < g.M && qcol < lds_) {
+                            unsigned char* sb_ = (tfirst ? g.S1 : g.S2) + ((int64_t)b * rows_o + (rowt + rl - (tfirst ? 0 : g.M1))) * lds_;
+                            *reinterpret_cast<uint4*>(sb_ + qcol) = make_uint4(o[0], o[1], o[2], o[3]);
+                        }
                     }
                 }
             }
@@ -1172,6 +1219,7 @@ extern "C" int fqss_wq_codes(const float* w, int8_t* idx, int8_t* idxT, float* d
 struct QpwQuant {   // optional fused output quantizer of fqss_qpw_fwdq
     int act; const float* slope; const float *min1, *max1, *min2, *max2; uint8_t *yc1, *yc2; int64_t ld1, ld2;
     long long* stats;   // optional: integer statistics of yc1 per workgroup (single-output launches only)
+    const FqssAddAfter *add1, *add2;   // optional: the AddQ behind output 1 / 2 (fqss_qpw_fwdq_add)
 };
 
 static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
@@ -1204,6 +1252,23 @@ static int qpw_fwd_impl(const char* who, const uint8_t* xc, const int8_t* wi, co
         g.qact = qq->act; g.qslope = qq->slope;
         FQSS_REQUIRE(!qq->stats || Co2 == 0, "output statistics: single-output launches only");
         g.stats = qq->stats;
+        const FqssAddAfter* ad[2] = {qq->add1, qq->add2};
+        for (int i = 0; i < 2; ++i) {
+            const FqssAddAfter* a = ad[i];
+            if (a == nullptr) continue;
+            FQSS_REQUIRE(i == 0 || Co2 > 0, "fused AddQ behind a second output that does not exist");
+            FQSS_REQUIRE(qq->act == FQSS_ACT_NONE, "fused AddQ: the conv in front of it has no activation (Conv1dQ)");
+            FQSS_REQUIRE(a->a && a->y && a->amin && a->amax && a->qmin && a->qmax, "fused AddQ: null pointer");
+            FQSS_REQUIRE(a->ld_a % 16 == 0 && a->ld_a >= M && a->ld_y % 16 == 0 && a->ld_y >= M && aligned16(a->a) && aligned16(a->y),
+                         "fused AddQ: code rows must be 16-B aligned");
+            if (i == 0) {
+                g.AD1 = a->a; g.ldad1 = a->ld_a; g.S1 = a->y; g.lds1 = a->ld_y;
+                g.ad_min1 = a->amin; g.ad_max1 = a->amax; g.s_min1 = a->qmin; g.s_max1 = a->qmax;
+            } else {
+                g.AD2 = a->a; g.ldad2 = a->ld_a; g.S2 = a->y; g.lds2 = a->ld_y;
+                g.ad_min2 = a->amin; g.ad_max2 = a->amax; g.s_min2 = a->qmin; g.s_max2 = a->qmax;
+            }
+        }
     }
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
     hipLaunchKernelGGL((k_qgemm<0>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
@@ -1228,9 +1293,21 @@ extern "C" int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* d
                              const float* slope, const float* qmin1, const float* qmax1, const float* qmin2, const float* qmax2,
                              uint8_t* yc1, uint8_t* yc2, int B, int Ci, int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1,
                              int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2, int64_t* stats1, fqss_stream_t stream) {
-    QpwQuant qq{act, slope, qmin1, qmax1, qmin2, qmax2, yc1, yc2, ld_yc1, ld_yc2, (long long*)stats1};
+    QpwQuant qq{act, slope, qmin1, qmax1, qmin2, qmax2, yc1, yc2, ld_yc1, ld_yc2, (long long*)stats1, nullptr, nullptr};
     return qpw_fwd_impl("fqss_qpw_fwdq", xc, wi, dw, rw, bias1, bias2, qmin_x, qmax_x, z1, z2, B, Ci, Co1, Co2, M, ld_xc, ld_z1, ld_z2,
                         stream, &qq);
+}
+
+// ... and with the AddQ layers that are the only consumers of the outputs evaluated in the same epilogue (add1 behind output 1, add2
+// behind output 2, either NULL): their sum codes are written beside yc1 / yc2, bit-identical to fqss_ewq_fwd on those codes
+extern "C" int fqss_qpw_fwdq_add(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                                 const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, const float* qmin1,
+                                 const float* qmax1, const float* qmin2, const float* qmax2, uint8_t* yc1, uint8_t* yc2, int B, int Ci,
+                                 int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2,
+                                 const FqssAddAfter* add1, const FqssAddAfter* add2, fqss_stream_t stream) {
+    QpwQuant qq{FQSS_ACT_NONE, nullptr, qmin1, qmax1, qmin2, qmax2, yc1, yc2, ld_yc1, ld_yc2, nullptr, add1, add2};
+    return qpw_fwd_impl("fqss_qpw_fwdq_add", xc, wi, dw, rw, bias1, bias2, qmin_x, qmax_x, z1, z2, B, Ci, Co1, Co2, M, ld_xc, ld_z1,
+                        ld_z2, stream, &qq);
 }
 
 static int qpw_bwd_x_impl(const char* who, const float* gz1, const float* gz2, const int8_t* wiT, const float* dw, float* gx, int B,

@@ -464,9 +464,11 @@ def qpw_fwd2(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1):
     return z1, z2
 
 
-def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None, stats=None):
+def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None, stats=None, adds=None):
     """q-GEMM forward with the output quantizer(s) fused: -> (z1, yc1) or (z1, z2, yc1, yc2) for a pair (r = (qmin, qmax));
-    stats (single output only): a CodeStats from new_stats("qpw", ...) that receives the integer statistics of yc1"""
+    stats (single output only): a CodeStats from new_stats("qpw", ...) that receives the integer statistics of yc1.
+    adds (no activation): (add1 | None, add2 | None), add = (a_codes, amin, amax, qmin, qmax) -- the AddQ that alone consumes that
+    output runs in the epilogue (fqss_qpw_fwdq_add); its sum codes are appended to the result as a pair (s1 | None, s2 | None)"""
     B, Ci, M = xc.shape
     rm = rowmat(xc)
     Co2 = wc.Co - Co1
@@ -475,6 +477,24 @@ def qpw_fwdq(xc, wc, bias1, bias2, qmin_x, qmax_x, Co1, act, slope, r1, r2=None,
     z2 = yc2 = None
     if Co2:
         z2, yc2 = empty_act((B, Co2, M), xc.device), empty_codes((B, Co2, M), xc.device)
+    if adds is not None and any(a is not None for a in adds):
+        assert act == ACT_NONE and stats is None and (adds[1] is None or Co2)
+        sums, recs = [], []
+        for a, Co in zip(adds, (Co1, Co2)):
+            if a is None:
+                sums.append(None); recs.append(None)
+                continue
+            ac, amin, amax, qmin, qmax = a
+            assert tuple(ac.shape) == (B, Co, M) and rowmat(ac) is not None
+            sc = empty_codes((B, Co, M), xc.device)
+            r = _lib.FqssAddAfter()
+            r.a, r.ld_a, r.amin, r.amax, r.qmin, r.qmax, r.y, r.ld_y = _p(ac), rowmat(ac)[2], _p(amin), _p(amax), _p(qmin), _p(qmax), _p(sc), rowmat(sc)[2]
+            sums.append(sc); recs.append(r)
+        _lib.call("fqss_qpw_fwdq_add", _p(xc), _p(wc.idx), _p(wc.dw), _p(wc.rw), _p(bias1), _p(bias2), _p(qmin_x), _p(qmax_x), _p(z1), _p(z2),
+                  _p(r1[0]), _p(r1[1]), _p(r2[0]) if r2 else None, _p(r2[1]) if r2 else None, _p(yc1), _p(yc2),
+                  B, Ci, Co1, Co2, M, rm[2], rowmat(z1)[2], rowmat(z2)[2] if Co2 else 0, rowmat(yc1)[2], rowmat(yc2)[2] if Co2 else 0,
+                  _ref(recs[0]) if recs[0] is not None else None, _ref(recs[1]) if recs[1] is not None else None, _stream())
+        return ((z1, z2, yc1, yc2) if Co2 else (z1, yc1)) + (tuple(sums),)
     if DESC_ABI:
         w = _lib.FqssWCodes()
         w.idx, w.idxT, w.dw, w.rw, w.Co, w.Ci = _p(wc.idx), _p(wc.idxT), _p(wc.dw), _p(wc.rw), wc.Co, wc.Ci

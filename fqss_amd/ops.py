@@ -21,7 +21,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer", "hand")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer", "hand", "presum")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
@@ -33,6 +33,7 @@ class QCtx:
         self.stats = None       # kernels.CodeStats of the output codes, emitted by the producing kernel for a GroupNormQ consumer
         self.defer = None       # GroupNormQ in front of a depthwise layer: its launch record, run by that layer's kernel (GroupNormActQ)
         self.hand = None        # _GnHand: backward hand-over between a GroupNormQ and the depthwise layer next to it
+        self.presum = None      # _PreSum: the AddQ that consumes this output was already evaluated by the producing GEMM
 
 
 class ActCodes:
@@ -48,7 +49,7 @@ def tag_codes(y, q):
     """attach the codes produced by the epilogue of this call to its output tensor"""
     if q.idx is not None and not CODED:
         assert not q.carrier, "codes-only carriers need the coded dataflow"
-        q.idx = q.prod = q.stats = q.hand = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
+        q.idx = q.prod = q.stats = q.hand = q.presum = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
     if q.idx is not None:
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
         y._fqss_carrier = q.carrier
@@ -61,6 +62,8 @@ def tag_codes(y, q):
             y._fqss_defer, q.defer = q.defer, None
         if q.hand is not None:
             y._fqss_hand, q.hand = q.hand, None
+        if q.presum is not None:
+            y._fqss_presum, q.presum = q.presum, None
     return y
 
 
@@ -95,6 +98,17 @@ FUSE_GN_BWD_DW = os.environ.get("FQSS_FUSE_GN_BWD_DW", "1") != "0"
 _GN_HAND = os.environ.get("FQSS_GN_HAND", "both")          # experiments: "after" / "before" alone
 FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
+# round 5: the forward of the AddQ behind each output of a res | skip pair runs in the pair GEMM's epilogue (fqss_qpw_fwdq_add)
+FUSE_ADD_FWD = os.environ.get("FQSS_FUSE_ADD_FWD", "1") != "0"
+
+
+class _PreSum:
+    """Codes of fq(dec(a) + dec(y)) that the GEMM which produced y already wrote for the AddQ `owner` (its quantizer module) whose
+    other operand has the codes tensor `a_idx`; rides on y as `_fqss_presum`, EwQ.forward takes it when exactly that layer arrives"""
+    __slots__ = ("codes", "a_idx", "owner")
+
+    def __init__(self, codes, a_idx, owner):
+        self.codes, self.a_idx, self.owner = codes, a_idx, owner
 FUSE_STATS = os.environ.get("FQSS_FUSE_STATS", "1") != "0"   # gLN statistics from the epilogue of the kernel that makes its input codes
 NEXT_IS_GROUPNORM = False   # set by HipSequential around the forward of a module followed by a GroupNormQ
 NEXT_IS_DW3 = False         # ... around the forward of a GroupNormQ followed by a 3-tap depthwise Conv1dNlQ (one launch for both: FUSE_GN_DW)
@@ -585,11 +599,19 @@ class LinearActQPair(Function):
     Only in the quantizing phase with a runtime.QuantTables active (concatenated weight codes)."""
 
     @staticmethod
-    def forward(ctx, x, b1, b2, qmin1, qmax1, qmin2, qmax2, L1, L2, q1, q2, xq, pair, sole_ew=False):
+    def forward(ctx, x, b1, b2, qmin1, qmax1, qmin2, qmax2, L1, L2, q1, q2, xq, pair, sole_ew=False, adds=None):
         Co1 = pair.Co1
         if _fuse_out_quant(q1) and _fuse_out_quant(q2) and Co1 % 32 == 0:
-            z1, z2, q1.idx, q2.idx = K.qpw_fwdq(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1, ACT_NONE, None,
-                                                (q1.qmin, q1.qmax), (q2.qmin, q2.qmax))
+            kadds = None
+            if adds is not None and FUSE_ADD_FWD:
+                # adds[i] = (codes of the other operand, the AddQ's quantizer module): that AddQ is the only consumer of output i and
+                # runs in this GEMM's epilogue; its own forward finds the finished codes on the tensor (_fqss_presum, EwQ.forward)
+                kadds = tuple(None if a is None else (a[0].idx, a[0].qmin, a[0].qmax, a[1].min_range, a[1].max_range) for a in adds)
+            res = K.qpw_fwdq(xq.idx, pair.wc, b1, b2, xq.qmin, xq.qmax, Co1, ACT_NONE, None, (q1.qmin, q1.qmax), (q2.qmin, q2.qmax),
+                             adds=kadds)
+            z1, z2, q1.idx, q2.idx = res[:4]
+            if kadds is not None and len(res) == 5:
+                q1.presum, q2.presum = (None if sc is None else _PreSum(sc, a[0].idx, a[1]) for sc, a in zip(res[4], adds))
             q1.carrier = q2.carrier = True
             out1 = _carrier(K.empty_act(tuple(z1.shape), z1.device))
             out2 = _carrier(K.empty_act(tuple(z2.shape), z2.device))
@@ -630,7 +652,7 @@ class LinearActQPair(Function):
             wq.push(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
         else:
             K.qpw_bwd_w2(gz[0], gz[1], ctx.xq.idx, ctx.xq.qmin, ctx.xq.qmax, ctx.pair.gw)
-        return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None, None
+        return gx, gbias[0], gbias[1], gmin[0], gmax[0], gmin[1], gmax[1], None, None, None, None, None, None, None, None
 
 
 FUSE_GNQ_F = os.environ.get("FQSS_FUSE_GNQ_F", "1") != "0"    # GroupNormQ on a float input: the quantizer inside the GroupNorm's own passes
@@ -790,8 +812,12 @@ class EwQ(Function):
     def forward(ctx, a, b, slope, qmin, qmax, sb, act, q, aq_, bq_, slope_param):
         q.carrier = FAST and not q.keep_out
         bf = None if (b is None or bq_ is not None) else b
-        out, q.idx = K.ewq_fwd(aq_.idx, aq_.qmin, aq_.qmax, bq_.idx if bq_ else None, bq_.qmin if bq_ else None,
-                               bq_.qmax if bq_ else None, bf, sb, act, slope, qmin, qmax, write_out=not q.carrier)
+        pre = getattr(b, "_fqss_presum", None) if bq_ is not None else None
+        if (pre is not None and q.carrier and pre.owner is q.owner and pre.a_idx is aq_.idx and sb == 1.0 and act == ACT_NONE):
+            out, q.idx = K.empty_act(tuple(aq_.idx.shape), aq_.idx.device), pre.codes      # evaluated by b's producer (LinearActQPair)
+        else:
+            out, q.idx = K.ewq_fwd(aq_.idx, aq_.qmin, aq_.qmax, bq_.idx if bq_ else None, bq_.qmin if bq_ else None,
+                                   bq_.qmax if bq_ else None, bf, sb, act, slope, qmin, qmax, write_out=not q.carrier)
         ctx.save_for_backward(aq_.idx, aq_.qmin, aq_.qmax, bq_.idx if bq_ else None, bq_.qmin if bq_ else None,
                               bq_.qmax if bq_ else None, bf, slope, qmin, qmax)
         ctx.sb, ctx.act, ctx.q, ctx.sp, ctx.has_b = sb, act, q, slope_param, b is not None

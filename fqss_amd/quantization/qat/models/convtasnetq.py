@@ -37,13 +37,16 @@ class ConvBlock(nn.Module):
 
     fqss_linear_pairs = (("res_conv", "skip_conv"),)   # same-input 1x1 convs: runtime.QuantTables concatenates their codes
 
-    def forward(self, x):
+    def forward(self, x, skip_sum=None, skip_add=None):
+        """-> (x + res_conv(f), skip_conv(f)); skip_sum / skip_add: the running skip sum and the Add layer the caller applies to
+        (skip_sum, <second output>) next -- known here so that both adds can run in the res | skip GEMM's epilogue"""
         x_blk, x_res = ops.fork2(x)
         f = self.shared_block(x_blk)
         # one GEMM for both (quantizing phase, graph mode); `residual` is consumed only by self.add below and `skip_out`
         # only by the skip sum of MaskGenerator.forward (or dropped): their AddQ backward also runs these convs'
-        # output-quantizer backward
-        fused = run_conv1d_pair(self.res_conv, self.skip_conv, f, sole_ew_consumers=True)
+        # output-quantizer backward, and their AddQ forward runs in the GEMM's epilogue
+        fused = run_conv1d_pair(self.res_conv, self.skip_conv, f, sole_ew_consumers=True,
+                                adds=((x_res, self.add), (skip_sum, skip_add) if skip_add is not None else None))
         if fused is not None:
             residual, skip_out = fused
         else:
@@ -89,7 +92,7 @@ class MaskGenerator(nn.Module):
         for i, layer in enumerate(self.TCN[1:]):
             if ce and (i + 1) % ce == 0:
                 feats, output = ops.cut(feats, output)       # blocks 0 .. i are one backward segment
-            feats, skip = layer(feats)
+            feats, skip = layer(feats, skip_sum=output, skip_add=self.adds[i])
             output = self.adds[i](output, skip)
         output = self.mask_net(output)
         return ops.reshape_tagged(output, batch, self.n_srcs, self.input_dim, -1)

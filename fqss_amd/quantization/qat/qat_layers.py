@@ -337,11 +337,27 @@ def convtr_frames(convtr, x, weight, bias=_OWN):
     return y.squeeze(2) if one_d else y
 
 
-def run_conv1d_pair(l1, l2, x, sole_ew_consumers=False):
+def _add_after(add_layer, other, like_shape):
+    """(codes of `other`, the AddQ's quantizer) when `add_layer(other, <conv output>)` can run in the conv's GEMM epilogue: a
+    quantizing AddQ on a coded operand of the output's shape; else None (the AddQ then launches its own kernel)"""
+    if other is None or type(add_layer) is not AddQ:
+        return None
+    aq = add_layer.activation_fake_quantize
+    if not hasattr(aq, "next_mode") or (aq.observer_mode and aq.n_iter < aq.max_observations):
+        return None
+    oq = ops.codes_of(other)
+    if oq is None or tuple(oq.idx.shape) != tuple(like_shape):
+        return None
+    return oq, aq
+
+
+def run_conv1d_pair(l1, l2, x, sole_ew_consumers=False, adds=None):
     """(l1(x), l2(x)) for two Conv1dQ layers fed by the same tensor, as ONE fused node (ops.LinearActQPair);
     None when the fused path does not apply (observer phase, eager mode, float layers): the caller then runs
     the two layers one by one.  sole_ew_consumers: the caller guarantees that each output is consumed by exactly one
-    element-wise LayerQ (AddQ), whose backward kernel may then run this layer's output-quantizer backward."""
+    element-wise LayerQ (AddQ), whose backward kernel may then run this layer's output-quantizer backward.
+    adds = ((other1, add_layer1), (other2, add_layer2)) (entries may be None; needs sole_ew_consumers): the caller will call
+    add_layer_i(other_i, output_i) next -- the forward of that AddQ then runs in this GEMM's epilogue."""
     if ops.DEFER is None or type(l1) is not Conv1dQ or type(l2) is not Conv1dQ:
         return None
     pre = getattr(l1.conv1d.weight, "_fqss_wq", None)
@@ -360,8 +376,14 @@ def run_conv1d_pair(l1, l2, x, sole_ew_consumers=False):
     L1, L2 = conv1d_geometry(l1.conv1d), conv1d_geometry(l2.conv1d)
     for L, conv in ((L1, l1.conv1d), (L2, l2.conv1d)):
         L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, None
+    after = None
+    if adds is not None and sole_ew_consumers and ops.FUSE_ADD_FWD:
+        after = tuple(None if a is None else _add_after(a[1], a[0], (xq.idx.shape[0], conv.out_channels, xq.idx.shape[2]))
+                      for a, conv in zip(adds, (l1.conv1d, l2.conv1d)))
+        if all(a is None for a in after):
+            after = None
     y1, y2 = ops.LinearActQPair.apply(x, l1.conv1d.bias, l2.conv1d.bias, q1.qmin, q1.qmax, q2.qmin, q2.qmax, L1, L2, q1, q2, xq, pair,
-                                      sole_ew_consumers)
+                                      sole_ew_consumers, after)
     aqs[0].after_forward(q1)
     aqs[1].after_forward(q2)
     return ops.tag_codes(y1, q1), ops.tag_codes(y2, q2)

@@ -253,6 +253,22 @@ int fqss_qpw_fwdq(const uint8_t* xc, const int8_t* wi, const float* dw, const fl
  * be produced by the previous kernel's epilogue").  fqss_*_stat_slots return 0 when that shape cannot emit them. */
 int fqss_qpw_stat_slots(int Co, int M);
 int fqss_dwq_stat_slots(int C, int M);
+/* fqss_qpw_fwdq (no activation) with the AddQ layers that are the ONLY consumers of its outputs evaluated in the same epilogue:
+ * replaces `self.add(x_res, residual)` of the TCN block and `output = self.adds[i](output, skip)` of the mask generator
+ * (/root/reference/quantization/qat/models/convtasnetq.py:41, 110; AddQ: qat_layers.py:62-72) as launches of their own.
+ * add1 sits behind output 1, add2 behind output 2, either may be NULL.  y = fq_q(dec_a(a) + dec(yc)), a [B][Co][ld_a] u8 codes of
+ * the other operand under (amin, amax), (qmin, qmax) the AddQ's quantizer, y [B][Co][ld_y]: the codes fqss_ewq_fwd returns for the
+ * same operands, bit for bit (tests/test_gpu_kernels.py::test_pair_forward_with_fused_adds). */
+typedef struct {
+    const uint8_t* a; int64_t ld_a;
+    const float *amin, *amax, *qmin, *qmax;
+    uint8_t* y; int64_t ld_y;
+} FqssAddAfter;
+int fqss_qpw_fwdq_add(const uint8_t* xc, const int8_t* wi, const float* dw, const float* rw, const float* bias1,
+                      const float* bias2, const float* qmin_x, const float* qmax_x, float* z1, float* z2, const float* qmin1,
+                      const float* qmax1, const float* qmin2, const float* qmax2, uint8_t* yc1, uint8_t* yc2, int B, int Ci,
+                      int Co1, int Co2, int M, int64_t ld_xc, int64_t ld_z1, int64_t ld_z2, int64_t ld_yc1, int64_t ld_yc2,
+                      const FqssAddAfter* add1, const FqssAddAfter* add2, fqss_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  depthwise dilated Conv1d (groups = C): z[b][c][m] = bias[c] + sum_k w[c][k] x[b][c][m+k*dil-pad]

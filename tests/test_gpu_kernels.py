@@ -690,6 +690,49 @@ def test_qgemm_fused_output_quantizer(B, Ci, Co1, Co2, M, act):
         assert torch.equal(yc.cpu()[..., :M], ref_idx.cpu()[..., :M])
 
 
+@pytest.mark.parametrize("B,Ci,Co1,Co2,M,which", [(2, 512, 128, 128, 501, 3), (2, 64, 32, 32, 77, 1), (1, 128, 64, 96, 260, 2), (3, 32, 32, 64, 1000, 3)])
+def test_pair_forward_with_fused_adds(B, Ci, Co1, Co2, M, which):
+    """fqss_qpw_fwdq_add: the AddQ behind output 1 (residual add) and / or output 2 (skip sum) evaluated in the pair GEMM's epilogue
+    -- z and output codes unchanged, sum codes bit-equal to fqss_ewq_fwd on the same operands (convtasnetq.py:41, 110)"""
+    cu = lambda t: t.cuda().contiguous()
+    w1, wlo1, whi1, xlo, xhi, x, b1, _, _ = _q_setup(B, Ci, Co1, M, seed=1)
+    w2, wlo2, whi2, _, _, _, b2, _, _ = _q_setup(B, Ci, Co2, M, seed=2)
+    wc1, wc2 = K.wq_codes(cu(w1), cu(wlo1), cu(whi1)), K.wq_codes(cu(w2), cu(wlo2), cu(whi2))
+    pc = K.WCodes()
+    pc.Co, pc.Ci = Co1 + Co2, Ci
+    pc.idx, pc.idxT = torch.cat([wc1.idx, wc2.idx], 0).contiguous(), torch.cat([wc1.idxT, wc2.idxT], 1).contiguous()
+    pc.dw, pc.rw = torch.cat([wc1.dw, wc2.dw]), torch.cat([wc1.rw, wc2.rw])
+    _, xc = K.actq_fwd(padded(x), K.ACT_NONE, None, K.Q_QUANT, cu(xlo), cu(xhi), None, want_idx=True)
+    dev = torch.device("cuda")
+    t = lambda v: torch.tensor([v], device=dev)
+    r1, r2 = (t(-1.1), t(1.7)), (t(-0.4), t(2.9))
+    gen = torch.Generator().manual_seed(9)
+    adds = []
+    for i, Co in enumerate((Co1, Co2)):
+        if not (which >> i) & 1:
+            adds.append(None)
+            continue
+        ac = K.empty_codes((B, Co, M), dev)
+        ac.copy_(torch.randint(0, 256, (B, Co, M), generator=gen, dtype=torch.uint8))
+        lo, hi = -2.3 + i, 1.9 + i
+        ylo, yhi = (float(v) for v in (r1, r2)[i])
+        adds.append((ac, t(lo), t(hi), t(lo + ylo + 0.8), t(hi + yhi - 1.5)))     # the sum saturates at both ends in places
+    plain = K.qpw_fwdq(xc, pc, cu(b1), cu(b2), cu(xlo), cu(xhi), Co1, K.ACT_NONE, None, r1, r2)
+    res = K.qpw_fwdq(xc, pc, cu(b1), cu(b2), cu(xlo), cu(xhi), Co1, K.ACT_NONE, None, r1, r2, adds=tuple(adds))
+    assert len(res) == 5
+    for a, b in zip(plain[:2], res[:2]):
+        assert torch.equal(a, b)
+    for a, b in zip(plain[2:], res[2:4]):
+        assert torch.equal(a[..., :M], b[..., :M])
+    for ad, sc, yc, r in zip(adds, res[4], res[2:4], (r1, r2)):
+        if ad is None:
+            assert sc is None
+            continue
+        _, ref = K.ewq_fwd(ad[0], ad[1], ad[2], yc, r[0], r[1], None, 1.0, K.ACT_NONE, None, ad[3], ad[4], write_out=False)
+        assert torch.equal(sc[..., :M], ref[..., :M])
+        assert 0 in ref[..., :M].unique().tolist() and 255 in ref[..., :M].unique().tolist()
+
+
 def test_qgemm_exact_integer_maps():
     """A = I-like asymmetric integer codes: catches transposed fragments / wrong tr-read lane maps bit-exactly"""
     B, Ci, Co, M = 1, 64, 96, 160
