@@ -105,6 +105,8 @@ _PROTOS = {
     "fqss_pit_sisdr_loss": [P, P, I32, I64, P, P, P, P, P, P],
     "fqss_kd_loss_per_sample": [P, P, P, I32, I64, F32, I32, F32, P, P, P, P, P, P],
     "fqss_sumsq": [P, I64, P, P],
+    "fqss_set_deterministic": [I32, P, I64, P],
+    "fqss_det_finish": [P, I64, P, P],
     "fqss_adam_clip": [P, P, P, P, I64, P, F32, F32, F32, F32, F32, F32, P, P, P, P],
     "fqss_rowlin_fwd": [P, P, P, P, I64, I32, I32, I64, I64, I64, P],
     "fqss_rowlin_fwd_w3": [P, P, P, P, I64, I32, I32, I64, I64, P],

@@ -11,6 +11,7 @@
 // ResidualErrorBlock (qat_layers.py:1330-1341, 1194-1202) and their autograd.
 #include <cstdlib>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void k_frames_wgrad_mfma(const void* __restric
         const float v = (red[0][q][l] + red[1][q][l]) + (red[2][q][l] + red[3][q][l]);
         const int t = q / (NT * 4), u = (q / 4) % NT, r = q & 3;
         const int c = c0 + 16 * t + 4 * (l >> 4) + r;
-        if (c < C) atomicAdd(&gw[(int64_t)c * ld_gw + 16 * u + (l & 15)], v);
+        if (c < C) grad_add(&gw[(int64_t)c * ld_gw + 16 * u + (l & 15)], v);
     }
 }
 

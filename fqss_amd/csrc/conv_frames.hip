@@ -10,6 +10,7 @@
 //     tap row comes from L2);
 //   * k_frames_ola    : one thread per SIGNAL element gathers its <= ceil(kh/sh)*ceil(kw/sw) contributing frame elements in a
 //     fixed order (tap row ascending, tap column ascending): the overlap-add is deterministic, no atomics.
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, f
     float v[1] = {0.0f};
     for (int64_t m = (int64_t)blockIdx.z * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.z * 256) v[0] += row[m];   // z: chunks of a long row
     block_sum<float, 1>(v, smem);
-    if (threadIdx.x == 0) atomicAdd(out + c, v[0]);
+    if (threadIdx.x == 0) grad_add(out + c, v[0]);
 }
 
 static int check_geom(const FrameGeom& g) {

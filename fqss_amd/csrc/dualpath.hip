@@ -10,6 +10,7 @@
 // overlap_and_add with a 2-tap frame (dptnetq.py:17-58, 140); bias gradients (column sums) of the row linears.
 #include <stdlib.h>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
         const int which = e / (64 * JC), c = e % (64 * JC);
         if (c < C && c < G * JC) {
             const float s = (red[which][0][c] + red[which][1][c]) + (red[which][2][c] + red[which][3][c]);
-            atomicAdd((which == 0 ? ggamma : gbeta) + c, s);
+            grad_add((which == 0 ? ggamma : gbeta) + c, s);
         }
     }
     if (Q) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, flo
     if (rg == 0 && c < C) {
         float s = red[cl];
         for (int k = 1; k < RG; ++k) s += red[k * CW + cl];
-        atomicAdd(out + c, s);
+        grad_add(out + c, s);
     }
 }
 
@@ -628,8 +629,8 @@ __global__ __launch_bounds__(256) void k_gnrows_bwd_reduce(const float* __restri
     for (int j = 0; j < 4; ++j) {
         const int c = threadIdx.x + 256 * j;
         if (c < C) {
-            atomicAdd(ggamma + c, gg[j]);
-            atomicAdd(gbeta + c, gb[j]);
+            grad_add(ggamma + c, gg[j]);
+            grad_add(gbeta + c, gb[j]);
         }
     }
     __syncthreads();
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256) void k_embedding_bwd(const float* __restrict__
         const int64_t r = i / D;
         const int d = (int)(i - r * D);
         const int64_t v = idx[r];
-        if (v >= 0 && v < V) atomicAdd(gw + v * D + d, g[i]);
+        if (v >= 0 && v < V) grad_add(gw + v * D + d, g[i]);
     }
 }
 

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
         if constexpr (BIAS) {
             float pb[1] = {p_bias};
             block_sum<float, 1>(pb, redf);
-            if (threadIdx.x == 0) atomicAdd(&gbias[ch], pb[0]);
+            if (threadIdx.x == 0) grad_add(&gbias[ch], pb[0]);
         }
     }
     if (qmode == FQSS_Q_QUANT || act == FQSS_ACT_PRELU) {
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd_colbias(const float* __restric
             float sum = 0.0f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) sum += cb[k][threadIdx.x];
-            atomicAdd(&gbias[blockIdx.x * 64 + threadIdx.x], sum);
+            grad_add(&gbias[blockIdx.x * 64 + threadIdx.x], sum);
         }
     }
     if (qmode == FQSS_Q_QUANT || act == FQSS_ACT_PRELU) {

@@ -165,10 +165,14 @@ __device__ __forceinline__ T sgpr(T v) {
 // A 16-B store the optimiser cannot split: it turned `vec ? float4 store : up to 3 scalar stores` into one dwordx3 plus one
 // conditional dword per lane (two partial-line writes per 16 B) in every k_qgemm epilogue.  Stores only count on vmcnt, which
 // makes the compiler's own waits conservative, never wrong.
+// s_nop 1 (round 5): a VMEM store of more than 8 bytes reads its data registers a moment after issue, and a VALU write of one of those
+// registers needs wait states in between (LLVM's hazard recognizer inserts them for the compiler's own stores: 1, 2 on gfx940+) -- an
+// asm statement is opaque to it, and the register allocator does hand the data registers to the very next address computation
+// (seen in k_qwgrad_group, csrc/qgemm.hip st16_sc1: the next address stored in place of the data whenever the memory pipe was busy).
 __device__ __forceinline__ void store16(float* p, const float4& v) {
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
 }
 // Branch-free: NONE / ReLU are PReLU (ATen: z > 0 ? z : slope * z) with slope 1 / 0, so the (wave-uniform) choice is one
 // scalar select the compiler hoists out of the caller's loops instead of two scalar branches per element (the GEMM
@@ -228,4 +232,45 @@ __device__ __forceinline__ void code_stats4(unsigned int word, unsigned int& s, 
 }
 
 #endif  // __HIPCC__
+
+// ---------------------------------------------------------------- FQSS_DETERMINISTIC=1 (round 5; DESIGN.md 2, "bit-reproducible steps")
+// The fp32 atomics that are left in the step -- one add per (sample, channel) row into a bias / depthwise-weight gradient, the split
+// adds of the frame-path weight gradients -- make those gradients depend on the ORDER the workgroups retire in (1e-7 relative, run to
+// run).  In deterministic mode every such add goes, instead, into an integer shadow of the gradient arena it targets: the value as a 2-word fixed
+// point number (hi = rint(v 2^30), lo = rint((v - hi 2^-30) 2^80): exact for every fp32 with 2^-56 <= |v| < 2^33, 8e-25 absolute below),
+// added with 64-bit INTEGER atomics -- exact and commutative, so the sum does not depend on the order -- and fqss_det_finish rounds
+// the sums once into the fp32 arena (fixed thread -> element map).  A TU that uses grad_add defines FQSS_USES_GRAD_ADD in front of
+// this header: it then owns a copy of the control block and registers its setter (fqss_set_deterministic reaches every copy).
+constexpr int kDetSlots = 3;             // 0: the parameter-gradient arena, 1: the dL/dW_q arena of runtime.QuantTables, 2: temporaries
+struct DetCtl { long long* shadow[kDetSlots]; const float* base[kDetSlots]; long long n[kDetSlots]; };
+typedef void (*det_setter_t)(const DetCtl*);
+void det_register(det_setter_t fn);      // train_ops.hip
+#if defined(__HIPCC__) && defined(FQSS_USES_GRAD_ADD)
+static __device__ DetCtl d_det_ctl;
+namespace {
+struct DetRegistrar {
+    DetRegistrar() {
+        det_register([](const DetCtl* c) { (void)hipMemcpyToSymbol(HIP_SYMBOL(d_det_ctl), c, sizeof(DetCtl)); });
+    }
+} det_registrar_;
+}  // namespace
+__device__ __forceinline__ void grad_add(float* addr, float v) {
+    if (d_det_ctl.shadow[0] != nullptr && fabsf(v) < 0x1p33f) {     // (NaN / inf / huge: the plain add below)
+#pragma unroll
+        for (int s = 0; s < kDetSlots; ++s) {
+            long long* const sh = d_det_ctl.shadow[s];
+            const long long i = addr - d_det_ctl.base[s];
+            if (sh != nullptr && (unsigned long long)i < (unsigned long long)d_det_ctl.n[s]) {
+                const double dv = (double)v;
+                const long long hi = __double2ll_rn(dv * 0x1p30);
+                const long long lo = __double2ll_rn((dv - (double)hi * 0x1p-30) * 0x1p80);
+                if (hi != 0) atomicAdd(reinterpret_cast<unsigned long long*>(sh + 2 * i), (unsigned long long)hi);
+                if (lo != 0) atomicAdd(reinterpret_cast<unsigned long long*>(sh + 2 * i + 1), (unsigned long long)lo);
+                return;
+            }
+        }
+    }
+    atomicAdd(addr, v);
+}
+#endif
 }  // namespace fqss

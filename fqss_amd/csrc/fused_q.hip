@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
             block_sum_f32w<4>(pf, predf, v);
         }
         // ONE atomic per row (per-wave atomics on the same 512 addresses cost 1.6 ms/step)
-        if (threadIdx.x == 0 && P.gbias != nullptr) atomicAdd(&P.gbias[c], (float)v[3]);
+        if (threadIdx.x == 0 && P.gbias != nullptr) grad_add(&P.gbias[c], (float)v[3]);
         if (threadIdx.x == 0) {
             double* slot = P.gacc + 3 * (row % kSlots);
             const double dmax = v[0] / 255.0;
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_z(const uint8_t* __restrict__ x
         if (gbias != nullptr) {
             float pb[1] = {p_bias};
             block_sum<float, 1>(pb, redf);
-            if (threadIdx.x == 0) atomicAdd(&gbias[c], pb[0]);
+            if (threadIdx.x == 0) grad_add(&gbias[c], pb[0]);
         }
     }
     double v[3] = {(double)p_du, (double)p_out, (double)p_slope};
@@ -1178,9 +1179,9 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
         atomicAdd(&slot[0], v[1] - dmax);   // rows share slots modulo kSlots: few adders per address, order-insensitive in fp64
         atomicAdd(&slot[1], dmax);
         if (act == FQSS_ACT_PRELU) atomicAdd(&slot[2], v[2]);
-        if (gbias != nullptr) atomicAdd(&gbias[c], (float)v[3]);
+        if (gbias != nullptr) grad_add(&gbias[c], (float)v[3]);
         if (gw != nullptr)
-            for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[4 + k]);
+            for (int k = 0; k < K; ++k) grad_add(&gw[c * K + k], (float)v[4 + k]);
     }
 }
 
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_dwq_bwd_w(const float* __restrict__ gz,
     for (int k = 0; k < kTaps; ++k) v[k] = (double)p[k];
     block_sum<double, kTaps>(v, red);
     if (threadIdx.x == 0)
-        for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[k]);
+        for (int k = 0; k < K; ++k) grad_add(&gw[c * K + k], (float)v[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1392,8 +1393,8 @@ __global__ __launch_bounds__(256, FQSS_EWQ_WAVES) void k_ewq_bwd(const uint8_t* 
         float pb[2] = {a_bias, b_bias};
         block_sum<float, 2>(pb, redf);
         if (threadIdx.x == 0) {
-            if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[row % C], pb[0]);
-            if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[row % C], pb[1]);
+            if (fa && PA.gbias != nullptr) grad_add(&PA.gbias[row % C], pb[0]);
+            if (fb && PB.gbias != nullptr) grad_add(&PB.gbias[row % C], pb[1]);
         }
         a_bias = b_bias = 0.f;
     };
@@ -1432,8 +1433,8 @@ __global__ __launch_bounds__(256, FQSS_EWQ_WAVES) void k_ewq_bwd(const uint8_t* 
         float pb[2] = {a_bias, b_bias};
         block_sum<float, 2>(pb, redf);
         if (threadIdx.x == 0) {
-            if (fa && PA.gbias != nullptr) atomicAdd(&PA.gbias[blockIdx.y % C], pb[0]);
-            if (fb && PB.gbias != nullptr) atomicAdd(&PB.gbias[blockIdx.y % C], pb[1]);
+            if (fa && PA.gbias != nullptr) grad_add(&PA.gbias[blockIdx.y % C], pb[0]);
+            if (fb && PB.gbias != nullptr) grad_add(&PB.gbias[blockIdx.y % C], pb[1]);
         }
     }
     // Reduction tail: fp32 sums over the 64 lanes of a wave (shuffles only), then ONE fp64 atomic per wave and value into the
@@ -1604,7 +1605,7 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
         if (PROD && P.gbias != nullptr && !per_channel) {       // one sum per (row, s): channel s * C + c of the producer
             block_sum<float, S>(a_bias, redf);
             if (threadIdx.x == 0)
-                for (int s = 0; s < S; ++s) atomicAdd(&P.gbias[s * C + c], a_bias[s]);
+                for (int s = 0; s < S; ++s) grad_add(&P.gbias[s * C + c], a_bias[s]);
 #pragma unroll
             for (int s = 0; s < S; ++s) a_bias[s] = 0.f;
         }
@@ -1632,7 +1633,7 @@ __global__ __launch_bounds__(256) void k_mulq_bwd(const uint8_t* __restrict__ mc
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const float t = wave_sum(a_bias[s]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&P.gbias[s * C + (int)(blockIdx.y % C)], t);
+            if ((threadIdx.x & 63) == 0) grad_add(&P.gbias[s * C + (int)(blockIdx.y % C)], t);
         }
     }
     const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;   // < kSlots: one workgroup per slot

@@ -17,6 +17,7 @@
 // encoder/decoder (qat_layers.py:1028-1039, 1330-1341, 1189-1202).
 #include <stdlib.h>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                     if (g.bias != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias[row];
                     if (g.bias_col != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias_col[col];
                     float* dst = Cb + (int64_t)row * g.sCi + col;
-                    if constexpr (ATOMIC) atomicAdd(dst, v); else *dst = v;
+                    if constexpr (ATOMIC) grad_add(dst, v); else *dst = v;
                 }
             }
         }

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -327,9 +328,7 @@ __device__ __forceinline__ void x3_body(GemmArgs3 g, const int bx, const int by,
         else t.load(g.B, g.sBj, g.sBk, j0, g.N, k0, kend, g.K);
     };
     __shared__ float rsum_s[(BQ == 1) ? 128 : 1];
-    if constexpr (BQ == 1) {
-        if (threadIdx.x < 128) rsum_s[threadIdx.x] = 0.0f;
-    }
+    __shared__ float rsum_p[(BQ == 1) ? XBK / 4 : 1][(BQ == 1) ? 128 : 1];     // per k-block partial row sums (summed in k-block order)
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -397,15 +396,23 @@ __device__ __forceinline__ void x3_body(GemmArgs3 g, const int bx, const int by,
     float dx = 1.0f, mnx = 0.0f;
     if constexpr (BQ == 1) {
         // k-sums of A's rows: the threads of a row block (same rb, different kb) meet in LDS
+        // (a fixed order instead of LDS float atomics since round 5: the sums enter the result, and FQSS_DETERMINISTIC=1 promises its bits)
         if (threadIdx.x / (BMt / 4) < XBK / 4) {
-            const int rb = threadIdx.x % (BMt / 4);
+            const int rb = threadIdx.x % (BMt / 4), kb = threadIdx.x / (BMt / 4);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 float t = ta[0].rs_[rr];
 #pragma unroll
                 for (int s = 1; s < PF; ++s) t += ta[s].rs_[rr];
-                atomicAdd(&rsum_s[rb * 4 + rr], t);
+                rsum_p[kb][rb * 4 + rr] = t;
             }
+        }
+        __syncthreads();
+        if (threadIdx.x < BMt) {
+            float t = rsum_p[0][threadIdx.x];
+#pragma unroll
+            for (int kb = 1; kb < XBK / 4; ++kb) t += rsum_p[kb][threadIdx.x];
+            rsum_s[threadIdx.x] = t;
         }
         __syncthreads();
         const float lo = *g.qmin_x, hi = *g.qmax_x;
@@ -413,7 +420,7 @@ __device__ __forceinline__ void x3_body(GemmArgs3 g, const int bx, const int by,
         mnx = lo;
         // (the first column tile of every k-slice hands its row sums on: the bias gradient, summed over the slices by the atomics)
         if (g.rowsum_out != nullptr && bx == 0 && threadIdx.x < BMt && i0 + (int)threadIdx.x < g.M)
-            atomicAdd(&g.rowsum_out[i0 + threadIdx.x], rsum_s[threadIdx.x]);
+            grad_add(&g.rowsum_out[i0 + threadIdx.x], rsum_s[threadIdx.x]);
     }
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if constexpr (!ATOMIC) {
@@ -481,7 +488,7 @@ __device__ __forceinline__ void x3_body(GemmArgs3 g, const int bx, const int by,
                     if (g.bias != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias[row];
                     if (g.bias_col != nullptr && (!ATOMIC || kbeg == 0)) v = v + g.bias_col[col];
                     float* dst = g.C + (int64_t)row * g.sCi + col;
-                    if constexpr (ATOMIC) atomicAdd(dst, v); else *dst = v;
+                    if constexpr (ATOMIC) grad_add(dst, v); else *dst = v;
                 }
             }
         }

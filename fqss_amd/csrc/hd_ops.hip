@@ -5,6 +5,7 @@
 //   * the mean / std normalisation of HTDemucsQ.pre_process / post_process (htdemucsq.py:1003-1014, 1034-1035): per-sample
 //     mean and unbiased std over all other dims, (x - mean) / (1e-5 + std) and its inverse x * std + mean.
 // All HBM streams: one pass, 16-B accesses where rows are aligned, wave shuffles + one atomic per workgroup for the sums.
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void k_chan_scale_bwd(const float* __restrict_
         }
     }
     block_sum<float, 1>(acc, smem);
-    if (threadIdx.x == 0) atomicAdd(gs + c, acc[0]);
+    if (threadIdx.x == 0) grad_add(gs + c, acc[0]);
 }
 // channel-last rows: y[r][c] = x[r][c] * s[c]
 __global__ __launch_bounds__(256) void k_col_scale_fwd(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t R,
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void k_col_scale_bwd(const float* __restrict__
             gx[r * ld_gx + c] = gv * sv;
             acc += gv * x[r * ld_x + c];
         }
-        atomicAdd(gs + c, acc);
+        grad_add(gs + c, acc);
     }
 }
 

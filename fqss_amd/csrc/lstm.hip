@@ -26,6 +26,7 @@
 // Saved for the backward: the four gate activations and the cell state per step (5H floats per step and sequence-direction).
 #include <cstdlib>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -514,9 +515,9 @@ __global__ __launch_bounds__(HT > 0 ? 4 * HT : 1024) void k_lstm_bwd(const float
         float* p1 = dir == 0 ? gb4.hh_f : gb4.hh_r;
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) {
-            if (gbias != nullptr) atomicAdd(gbias + (dir * 4 + gt) * H + ck, bsum[gt]);
-            if (p0 != nullptr) atomicAdd(p0 + gt * H + ck, bsum[gt]);
-            if (p1 != nullptr) atomicAdd(p1 + gt * H + ck, bsum[gt]);
+            if (gbias != nullptr) grad_add(gbias + (dir * 4 + gt) * H + ck, bsum[gt]);
+            if (p0 != nullptr) grad_add(p0 + gt * H + ck, bsum[gt]);
+            if (p1 != nullptr) grad_add(p1 + gt * H + ck, bsum[gt]);
         }
     }
 }

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_qwgrad(QGemmArgs g) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int col = col0 + 32 * t + lr;
-            if (row < g.M && col < g.N) atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * acc[t][r] + mnx * rsum);
+            if (row < g.M && col < g.N) grad_add(&g.C[(int64_t)row * g.ldc + col], dx * acc[t][r] + mnx * rsum);
         }
     }
 }
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void k_qwgrad2(QGemmArgs g) {
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int row = row0 + wr * 32 + rl;
         const int col = col0 + wc * 32 + lr;
-        if (row < g.M && col < g.N) atomicAdd(&g.C[(int64_t)row * g.ldc + col], dx * acc[r] + mnx * rsum[wr * 32 + rl]);
+        if (row < g.M && col < g.N) grad_add(&g.C[(int64_t)row * g.ldc + col], dx * acc[r] + mnx * rsum[wr * 32 + rl]);
     }
 }
 
@@ -915,7 +916,12 @@ struct WGroupArgs {
     WJob j[WGR_MAXJOBS];
 };
 static_assert(sizeof(WGroupArgs) <= 4096, "the job table travels in the kernel arguments");
-__device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+// (s_nop 1: see store16 in fqss_dev.h -- the wait states behind a > 8-byte store that the compiler cannot insert for an asm statement;
+//  without them the NEXT slab address, computed into the registers that held this store's data, was written to the slab in place of
+//  the data's first dwords -- 1e31-sized "gradients" in a 16-lane pattern, whenever the memory pipe was slow to fetch the store data)
+__device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void ld16_sc1(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory"); }
 
 // One segment = the stages [s0, s0 + n) of ONE tile, accumulated by one workgroup, then published / finished.
@@ -1142,6 +1148,9 @@ __device__ __forceinline__ void wgr_segment(const WGroupArgs& ga, const WJob& J,
                 const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = col0 + wc * (32 * NBF) + 32 * f + lr;
                 if (row < Mr && col < Nc) Cp[(int64_t)row * Nc + col] = old[16 * f + r] + v[16 * f + r];
             }
+        // the stores above retire before this workgroup's next segment starts its load ring: that ring is retired with COUNTED waits
+        // (wait_oldest), and stores do not retire in one order with loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();     // rsum / ticket_s / the LDS stages are reused by the next segment
 }

@@ -5,6 +5,7 @@
 //
 // Reference replaced: convtasnetq.py:28-30 (depthwise F.conv1d), nn.GroupNorm(1,C,eps=1e-8)
 // (qat_layers.py:445-448), torch.add/sub/mul (qat_layers.py:69-71, 93-96, 1193), and their autograd.
+#define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd_w(const float* __restrict__ 
     for (int k = 0; k < kMaxTaps; ++k) v[k] = (double)p[k];
     block_sum<double, kMaxTaps>(v, red);
     if (threadIdx.x == 0)
-        for (int k = 0; k < K; ++k) atomicAdd(&gw[c * K + k], (float)v[k]);
+        for (int k = 0; k < K; ++k) grad_add(&gw[c * K + k], (float)v[k]);
 }
 
 // =============================================================================================
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_coef(const float* __restrict__ g
                 ggamma[c] += (float)gg;
                 gbeta[c] += (float)gb;
             } else {
-                atomicAdd(&ggamma[c], (float)gg);
-                atomicAdd(&gbeta[c], (float)gb);
+                grad_add(&ggamma[c], (float)gg);
+                grad_add(&gbeta[c], (float)gb);
             }
         }
     }

@@ -8,6 +8,8 @@
 // Reference replaced: System.common_step (mysystem.py:124-151), PairwiseWSDR (wsdr.py:56-95),
 // asteroid PITLossWrapper("pw_mtx") for n_src=2 (third-party, restated in oracle/fqss_oracle.py),
 // pl gradient_clip_val=5.0 + torch.optim.Adam (asteroid_librimix_trainer.py:94,132).
+#include <vector>
+
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -354,6 +356,47 @@ extern "C" int fqss_kd_moments(const float* est, const float* fest, const float*
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_kd_moments, dim3((unsigned)nb, (unsigned)B), dim3(256), 0, s, est, fest, tgt, T, stats);
     return launch_status("fqss_kd_moments");
+}
+
+// ---- FQSS_DETERMINISTIC=1 (fqss_dev.h: grad_add): the control blocks of every TU, the finish pass
+static std::vector<det_setter_t>& det_setters() {
+    static std::vector<det_setter_t> v;      // built on first use: TUs register from their static initialisers, in any order
+    return v;
+}
+void fqss::det_register(det_setter_t fn) { det_setters().push_back(fn); }
+
+// g[i] += the integer sums of its two shadow words, rounded once (thread i -> element i: no order to depend on); shadow cleared
+__global__ __launch_bounds__(256) void k_det_finish(float* __restrict__ g, long long* __restrict__ sh, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const longlong2 w = *reinterpret_cast<const longlong2*>(sh + 2 * i);
+        if (w.x != 0 || w.y != 0) {
+            const double v = (double)w.x * 0x1p-30 + (double)w.y * 0x1p-80;
+            g[i] = g[i] + (float)v;
+            *reinterpret_cast<longlong2*>(sh + 2 * i) = make_longlong2(0, 0);
+        }
+    }
+}
+
+static DetCtl g_det_ctl{};      // host copy of the control block (slot 0 must be set for the mode to be on)
+
+extern "C" int fqss_set_deterministic(int slot, const float* grad_base, int64_t n, void* shadow) {
+    FQSS_REQUIRE(slot >= 0 && slot < kDetSlots, "slot: 0 (parameter gradients), 1 (dL/dW_q arena) or 2 (temporaries)");
+    FQSS_REQUIRE((shadow == nullptr) || (grad_base != nullptr && n > 0 && aligned16(shadow)), "bad args");
+    g_det_ctl.shadow[slot] = (long long*)shadow;
+    g_det_ctl.base[slot] = shadow ? grad_base : nullptr;
+    g_det_ctl.n[slot] = shadow ? (long long)n : 0;
+    if (hipDeviceSynchronize() != hipSuccess) return launch_status("fqss_set_deterministic");     // no kernel may be reading the old block
+    for (det_setter_t fn : det_setters()) fn(&g_det_ctl);
+    return launch_status("fqss_set_deterministic");
+}
+
+extern "C" int fqss_det_finish(float* grad_base, int64_t n, void* shadow, fqss_stream_t stream) {
+    FQSS_REQUIRE(grad_base && shadow && n >= 0 && aligned16(shadow), "bad args");
+    if (n == 0) return FQSS_OK;
+    int64_t nb = cdiv(n, 256 * 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_det_finish, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, grad_base, (long long*)shadow, n);
+    return launch_status("fqss_det_finish");
 }
 
 extern "C" int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_t stream) {

@@ -1175,6 +1175,72 @@ def kd_moments(est, fest, tgt):
     return stats
 
 
+class DetMode:
+    """FQSS_DETERMINISTIC=1: the fp32 gradient atomics of the step become integer atomics on fixed-point shadows of the arenas they
+    target (csrc/fqss_dev.h grad_add; include/fqss.h fqss_set_deterministic) -- slot 0 the parameter gradients, slot 1 the dL/dW_q
+    arena, slot 2 a pool for the temporary weight-gradient accumulators of the un-fused (observer-phase) layers -- and `finish(slot)`
+    rounds the sums once into the fp32 arena.  One DetMode owns the device-wide control block at a time: `activate()` (device
+    synchronisation: outside graph capture) before the first backward that should run under it."""
+    owner = None
+    SLOTS = 3
+
+    def __init__(self):
+        self.arenas = [None] * self.SLOTS
+        self.shadows = [None] * self.SLOTS
+        self._top = 0           # bump pointer into the slot-2 pool (floats)
+
+    def attach(self, slot, arena):
+        assert arena.dtype == torch.float32 and arena.is_contiguous()
+        self.arenas[slot] = arena
+        self.shadows[slot] = torch.zeros(2 * arena.numel(), dtype=torch.int64, device=arena.device)
+        if slot == 0 and self.arenas[2] is None:
+            self.attach(2, torch.zeros(arena.numel(), device=arena.device))
+            return
+        if DetMode.owner is self:
+            DetMode.owner = None
+        self.activate()
+
+    def activate(self):
+        if DetMode.owner is self:
+            return
+        for slot in range(self.SLOTS):
+            a, sh = self.arenas[slot], self.shadows[slot]
+            _lib.call("fqss_set_deterministic", slot, _p(a), a.numel() if a is not None else 0, _p(sh))
+        DetMode.owner = self
+
+    def finish(self, slot):
+        if self.arenas[slot] is not None:
+            assert DetMode.owner is self, "another DetMode owns the control block: activate() outside graph capture first"
+            _lib.call("fqss_det_finish", _p(self.arenas[slot]), self.arenas[slot].numel(), _p(self.shadows[slot]), _stream())
+
+    # ---- temporaries (a weight gradient that autograd carries on instead of an arena slot)
+    def begin_backward(self):
+        self._top = 0
+
+    def temp_like(self, w):
+        """zeroed fp32 accumulator of w's shape inside the slot-2 pool (None when the pool is exhausted: the caller's own buffer then)"""
+        n = (w.numel() + 63) // 64 * 64
+        pool = self.arenas[2]
+        if self._top + n > pool.numel():
+            return None
+        t = pool[self._top:self._top + w.numel()].view(w.shape)
+        self._top += n
+        t.zero_()
+        return t
+
+    def finish_temp(self, t):
+        pool = self.arenas[2]
+        off = (t.data_ptr() - pool.data_ptr()) // 4
+        assert 0 <= off < pool.numel() and DetMode.owner is self
+        _lib.call("fqss_det_finish", _p(t), t.numel(), self.shadows[2].data_ptr() + 16 * off, _stream())
+
+    @staticmethod
+    def off():
+        for slot in range(DetMode.SLOTS):
+            _lib.call("fqss_set_deterministic", slot, None, 0, None)
+        DetMode.owner = None
+
+
 def sumsq(g, acc):
     _lib.call("fqss_sumsq", _p(g), g.numel(), _p(acc), _stream())
 

@@ -327,6 +327,23 @@ def _grad_buf(param, like):
     return torch.zeros_like(like), False
 
 
+def _wgrad_temp(w):
+    """zeroed accumulator for a weight gradient that autograd carries on (un-fused layers: no arena slot to add into).  Under
+    FQSS_DETERMINISTIC=1 it is cut from the DetMode's pool, so that the wgrad kernel's split adds land on the integer shadow"""
+    d = K.DetMode.owner
+    t = d.temp_like(w) if d is not None else None
+    return t if t is not None else torch.zeros_like(w)
+
+
+def _wgrad_temp_done(gw, gwq):
+    """behind the kernels that added into a _wgrad_temp: round its integer sums into it before autograd hands it on"""
+    d = K.DetMode.owner
+    if d is not None and gwq is None and gw is not None:
+        pool = d.arenas[2]
+        if pool.data_ptr() <= gw.data_ptr() < pool.data_ptr() + 4 * pool.numel():
+            d.finish_temp(gw)
+
+
 def _epilogue_fwd(z, act, slope, q):
     if q.qmode == Q_QUANT and q.no_codes:
         q.carrier = False
@@ -568,7 +585,7 @@ class LinearActQ(Function):
         if ctx.needs_input_grad[1] or gwq is not None:
             # w here is the fake-quantized weight (a non-leaf): its gradient goes back through autograd, or
             # (deferred) into the arena consumed by fqss_wq_multi_bwd
-            gw = gwq if gwq is not None else torch.zeros_like(w)
+            gw = gwq if gwq is not None else _wgrad_temp(w)
             if ctx.xq is not None:
                 wq = getattr(DEFER, "wgrad_queue", None) if (gwq is not None and getattr(w, "_fqss_gwq_done", None) is None) else None
                 if wq is not None:     # the segment's weight gradients run together when it is done (runtime.QuantTables.finish_backward)
@@ -582,6 +599,7 @@ class LinearActQ(Function):
                     if x is None:
                         x = K.decode(ctx.xq_tr.idx, ctx.xq_tr.qmin, ctx.xq_tr.qmax)
                     _lin_bwd_w(L, gz, x, gw)
+            _wgrad_temp_done(gw, gwq)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
             if gwq is not None:
@@ -778,7 +796,7 @@ class DwConvQ(Function):
         gwq = getattr(w, "_fqss_gwq", None)
         want_gw = ctx.needs_input_grad[1] or gwq is not None
         if want_gw:
-            gw = gwq if gwq is not None else torch.zeros_like(w)
+            gw = gwq if gwq is not None else _wgrad_temp(w)
         if xc.shape[-1] <= K.DWQ_ROW_MAX:
             # one launch: gz stays in LDS (csrc/fused_q.hip k_dwq_bwd)
             after = before = None
@@ -797,6 +815,7 @@ class DwConvQ(Function):
                 K.dwq_bwd_w(gz, xc, xmin, xmax, gw, L.dil, L.pad)
         g_slope, g_min, g_max = _flush_ranges(q, slope, L.slope_param, act)
         if want_gw:
+            _wgrad_temp_done(gw, gwq)
             if L.w_param is not None and w is L.w_param:
                 L.w_param._fqss_touched = True
             if gwq is not None:

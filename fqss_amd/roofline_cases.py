@@ -130,8 +130,12 @@ def build(dev, sets=3):
     stq = K.new_stats("qpw", B, NH, M, dev)
     case("k_qgemm<0>", "student fwd 128->512 + PReLU + fake-quant + gLN statistics (codes in; fp32 z + codes out)", "hbm", 24, 1.0 * NB * n, 5.0 * NH * n,
          4.0 * (NH + NB) * n, lambda i: K.qpw_fwdq(xc_b[i % sets], wc_up, bu, None, lo, hi, NH, 1, slope, (lo, hi), stats=stq), flops=fl)
-    case("k_qgemm<0>", "student fwd res|skip pair 512->128+128 + fake-quant (codes in; fp32 z + codes out)", "hbm", 24, 1.0 * NH * n, 10.0 * NB * n,
-         4.0 * (NH + 2 * NB) * n, lambda i: K.qpw_fwdq(xc_h[i % sets], pc, bd, bd2, lo, hi, NB, 0, None, (lo, hi), (lo, hi)), flops=2 * fl)
+    # round 5: the residual AddQ and the skip-sum AddQ behind the two outputs run in this GEMM's epilogue (+ their other operands' codes in,
+    # + their sum codes out; SURVEY convention: + 12 B per element and AddQ, the figure the separate k_ewq_fwd launches carried)
+    case("k_qgemm<0>", "student fwd res|skip pair 512->128+128 + fake-quant + the two AddQ behind it (codes in; fp32 z + codes + sum codes out)", "hbm", 24,
+         1.0 * (NH + 2 * NB) * n, 12.0 * NB * n, 4.0 * (NH + 2 * NB) * n + 2 * 12.0 * NB * n * 47 / 48,     # (47 fused AddQ in 24 launches: the first block has no skip sum yet)
+         lambda i: K.qpw_fwdq(xc_h[i % sets], pc, bd, bd2, lo, hi, NB, 0, None, (lo, hi), (lo, hi),
+                              adds=((xc_b[i % sets], lo, hi, lo, hi), (xc_b2[i % sets], lo, hi, lo, hi))), flops=2 * fl)
 
     # ---- codes-only streaming layers (csrc/fused_q.hip)
     gm_, bt_ = torch.rand(NH, device=dev) + 0.5, torch.randn(NH, device=dev) * 0.1
@@ -145,7 +149,7 @@ def build(dev, sets=3):
          lambda i: K.gnq_fwd(xc_h[i % sets], lo, hi, gm_, bt_, 1e-8, lo, hi, False, stats=std))
     case("k_dwq_fwd<3>", "depthwise + PReLU + fake-quant + gLN statistics forward, C=512 (codes in / out)", "hbm", 24, 1.0 * NH * n, 1.0 * NH * n, 8.0 * NH * n,
          lambda i: K.dwq_fwd(xc_h[i % sets], lo, hi, w_dw, b_dw, 4, 4, 1, slope, lo, hi, False, stats=std))
-    case("k_ewq_fwd", "AddQ forward, C=128 (codes + codes -> codes)", "hbm", 49, 2.0 * NB * n, 1.0 * NB * n, 12.0 * NB * n,
+    case("k_ewq_fwd", "AddQ forward as a launch of its own, C=128 (codes + codes -> codes): the adds without a pair GEMM in front", "hbm", 2, 2.0 * NB * n, 1.0 * NB * n, 12.0 * NB * n,
          lambda i: K.ewq_fwd(xc_b[i % sets], lo, hi, xc_b2[i % sets], lo, hi, None, 1.0, 0, None, lo, hi, False))
     # round 5: the depthwise backward takes the apply pass of the GroupNormQ behind it (on load) and the rows pass of the one in front
     # (on the gx it produces): g + its own input codes + that GroupNorm's input codes in, gx out

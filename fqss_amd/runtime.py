@@ -325,6 +325,7 @@ class QuantTables:
         self.total_channels = blk
         # grouped, atomics-free weight gradients of the quantized 1x1 convolutions (csrc/qgemm.hip k_qwgrad_group); FQSS_GROUP_WGRAD=0:
         # one k_qwgrad2 launch per layer where autograd reaches it (rounds 2-4)
+        self.det = None     # kernels.DetMode of the owning step (FQSS_DETERMINISTIC=1)
         self.wgrad_queue = K.WgradQueue() if os.environ.get("FQSS_GROUP_WGRAD", "1") != "0" else None
         # ... and of the row-major linears of the dual-path / transformer models (csrc/gemm_x3.hip k_gemm_x3_wq_multi)
         self.row_wgrad_queue = K.RowWgradQueue() if os.environ.get("FQSS_GROUP_WGRAD", "1") != "0" else None
@@ -364,6 +365,8 @@ class QuantTables:
             self.wgrad_queue.flush()
         if self.row_wgrad_queue is not None:
             self.row_wgrad_queue.flush()
+        if self.det is not None:
+            self.det.finish(1)      # FQSS_DETERMINISTIC=1: the depthwise / frame-path weight gradients' integer sums -> the dL/dW_q arena
         if seg is None or self.seg_tables is None:
             K.wq_multi_bwd(self.wq_table, self.total_channels)
             K.gacc_flush_multi(self.flush_table)
@@ -452,6 +455,11 @@ class KDTrainStep:
                 self._seg_ids[0] |= {id(p) for p in rest}
                 params = rest + ordered
         self.arena = ParamArena(params)
+        # FQSS_DETERMINISTIC=1: bit-reproducible gradients (kernels.DetMode; no effect on the values beyond fp32 summation order)
+        self.det = None
+        if os.environ.get("FQSS_DETERMINISTIC", "0") == "1" and not self.cpu:
+            self.det = K.DetMode()
+            self.det.attach(0, self.arena.flat_g)
         if self._seg_ids is not None:
             off = {id(p): (o, o + (p.numel() + 63) // 64 * 64) for p, o in zip(self.arena.params, self.arena.offsets)}
             self.segments = []
@@ -585,6 +593,11 @@ class KDTrainStep:
         t = self.tables
         regular = [c for c in cuts if not c[2]]
         nseg = len(regular) + 1
+        if self.det is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                self.det.activate()     # (no-op unless another step's DetMode has taken the device-wide control block since)
+            if k == 0:
+                self.det.begin_backward()
         with ops.deferred(t):
             if k == 0:
                 est.backward(gest)
@@ -595,6 +608,8 @@ class KDTrainStep:
                 torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
         if t is not None:
             t.finish_backward(None if nseg == 1 else nseg - 1 - k)     # weight STE + range/slope gradients of this segment
+        if self.det is not None:
+            self.det.finish(0)      # the integer sums of this segment's bias / row-sum gradients -> the fp32 arena, before its exchange
 
     def _fwd_bwd(self, x, tgt, x_next=None, fest_given=None):
         """fwd + loss + the whole backward, no exchange (single rank; tests)"""
@@ -635,6 +650,9 @@ class KDTrainStep:
                 if isinstance(m, GradientWeightFakeQuantize) and m.observer_mode:
                     return None
             self.tables = QuantTables(self.model, self.arena, segments=self._seg_ids)
+            if self.det is not None:
+                self.det.attach(1, self.tables.gwq)
+                self.tables.det = self.det
         return self.tables
 
     def _world(self):

@@ -579,6 +579,18 @@ int fqss_kd_moments(const float* est, const float* fest, const float* tgt, int B
  * K16  global-norm clip + Adam over one flat fp32 parameter buffer
  * replaces: pl.Trainer(gradient_clip_val=5.0) + torch.optim.Adam (asteroid_librimix_trainer.py:94,132)
  * ------------------------------------------------------------------------------------------- */
+/* FQSS_DETERMINISTIC=1 (round 5): bit-reproducible gradients.  fqss_set_deterministic(slot, grad_base, n, shadow) switches every fp32
+ * gradient atomic whose target lies in the n-float arena at grad_base (bias / depthwise-weight row sums, the frame-path weight
+ * gradients' split adds) to 64-bit INTEGER atomics on a two-word fixed-point shadow of that arena (shadow: 16 * n bytes, zeroed by
+ * the caller, 16-B aligned) -- exact and commutative, so the sums no longer depend on the order workgroups retire in;
+ * fqss_det_finish (after the backward, before clip + Adam) rounds the sums once into the arena and clears the shadow.
+ * Three arenas can be covered: slot 0 (the parameter gradients; must be set for the mode to be on), slot 1 (the dL/dW_q arena) and
+ * slot 2 (a pool the host cuts temporary accumulators from; fqss_det_finish accepts any sub-range: base + off, n, shadow + 16 * off).
+ * shadow = NULL clears a slot.  Synchronises the device; call outside graph capture.
+ * Not a reference interface: the mode exists so that the convergence gates can separate arithmetic differences from run-to-run
+ * noise (tests/test_gpu_converge.py; mysystem.py:124-151 is the step whose gradients these are). */
+int fqss_set_deterministic(int slot, const float* grad_base, int64_t n, void* shadow);
+int fqss_det_finish(float* grad_base, int64_t n, void* shadow, fqss_stream_t stream);
 /* sumsq[0] += sum g^2  (fp64) */
 int fqss_sumsq(const float* g, int64_t n, double* sumsq, fqss_stream_t stream);
 /* step_t: device int32 global step counter (incremented by the call -> graph-replay safe).

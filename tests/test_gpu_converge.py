@@ -131,6 +131,29 @@ def test_tiny_convtasnet_trains_to_the_reference_sisdr(golden):
     assert abs(float(long_hip.mean()) - float(long_ref.mean())) <= tol, (long_hip, long_ref)
 
 
+def test_deterministic_mode_repeats_its_bits_and_trains_to_the_reference(golden, monkeypatch):
+    """FQSS_DETERMINISTIC=1 (the fp32 gradient atomics become integer atomics on a fixed-point shadow of the
+    gradient arenas, csrc/fqss_dev.h grad_add) -- two runs of the 400-step stream from the same state give the SAME trajectory and the
+    same parameters, bit for bit, through observer phase, capture and replay; and ONE such run passes the family's gate (no HIP spread
+    to account for: the mean rule compares a single sample with the reference set)"""
+    from fqss_amd.runtime import KDTrainStep
+    from tests.test_gpu_model import _tiny_pair
+    monkeypatch.setenv("FQSS_DETERMINISTIC", "1")
+    g0, gl = golden("tiny_step"), golden("tiny_train_long")
+    n, B, T, seed0 = int(gl["n_steps"]), int(gl["batch"]), int(gl["samples"]), int(gl["seed0"])
+    out = []
+    for _ in range(2):
+        model, fmodel = _tiny_pair(g0)
+        step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, teacher_ahead=True)
+        assert step.det is not None
+        s, l = _run_stream(step, n, B, T, seed0)
+        assert step._graphs is not None
+        out.append((s, l, step.arena.flat_p.clone()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][2], out[1][2])
+    _gate("tiny convtasnet", out[0][0][None], out[0][1][None], gl, 20, 8.0)
+
+
 def test_tiny_dptnet_trains_to_the_reference_sisdr(golden):
     """the same gate at reduced length for the dual-path family (cfg 3): tiny DPTNetQ of dpt_tiny_step.npz, 160 steps of a stream of
     2 x 400-sample batches, Adam 4e-4 (asteroid DPTNet yaml), LSTM + attention + chunking on the HIP path; three HIP runs"""

@@ -37,6 +37,19 @@ def _run_ranks(tmp_path, scenario, world=2):
 @pytest.mark.parametrize("scenario", ["step_eager", "step_graph", "step_graph_ahead", "step_graph:dptnet", "step_graph:sepformer", "step_graph:htdemucs",
                                       "step_graph_ahead:sepformer"])
 def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(tmp_path, scenario):
+    _two_rank_check(tmp_path, scenario, later_atol=None)
+
+
+@pytest.mark.parametrize("scenario", ["step_graph", "step_graph:dptnet", "step_graph:sepformer", "step_graph:htdemucs"])
+def test_two_rank_later_steps_in_deterministic_mode(tmp_path, scenario, monkeypatch):
+    """under FQSS_DETERMINISTIC=1 (integer-shadow gradient sums, include/fqss.h fqss_set_deterministic) the
+    run-to-run noise of the fp32 atomics is gone from both sides of the comparison, so the later steps of the two-rank run are held to
+    0.3 dB of the one-rank run on the averaged gradients for EVERY family (1.0 dB without the mode for the deeper ones)"""
+    monkeypatch.setenv("FQSS_DETERMINISTIC", "1")
+    _two_rank_check(tmp_path, scenario, later_atol=0.3)
+
+
+def _two_rank_check(tmp_path, scenario, later_atol):
     """ConvTasNet (2 buckets, eager and replay) and the DDP configurations themselves -- cfg 4 `speechbrain_librimix_trainer.py:592`,
     cfg 5 `htdemucs_musdbhq/distrib.py:51-59` (find_unused_parameters=True), cfg 3 for the dual-path LSTM family: 3-4 gradient
     buckets through capture + replay, the grad-less MHA range parameters of SURVEY A.2 Q1 (zeros in the flat buffer, skipped by
@@ -85,7 +98,10 @@ def test_two_rank_step_equals_one_rank_step_on_the_averaged_gradients(tmp_path, 
         # (tiny DPTNet / Sepformer / HTDemucs: a handful of flipped bins behind an update move a later loss by several tenths of a dB --
         # the B1 gates; with the split-K atomics a run is a sample: 0.61 dB was seen once at step 3 of tiny Sepformer.  The tight check
         # of this test is the step-1 gradient above; steps 2-3 only have to stay in the neighbourhood)
-        np.testing.assert_allclose(ranks[r]["losses"], losses[r], atol=0.05 if fam == "convtasnet" else 1.0, rtol=1e-2 if fam != "htdemucs" else 5e-2)
+        if later_atol is None:
+            np.testing.assert_allclose(ranks[r]["losses"], losses[r], atol=0.05 if fam == "convtasnet" else 1.0, rtol=1e-2 if fam != "htdemucs" else 5e-2)
+        else:
+            np.testing.assert_allclose(ranks[r]["losses"], losses[r], atol=min(later_atol, 0.05 if fam == "convtasnet" else later_atol), rtol=0)
     lr = kw["lr"]
     unused, worst, n_off, n_all = 0, 0.0, 0, 1
     for k, v in want.items():
@@ -160,9 +176,22 @@ def test_full_size_cfg2_two_ranks_replay_like_bench(tmp_path):
     the RCCL transport."""
     ranks = _run_ranks(tmp_path, "bench2")
     assert ranks[0]["n_graphs"] == ranks[1]["n_graphs"] >= 2
+    assert all(np.isfinite(l) for r in ranks for l in r["losses"]), [r["losses"] for r in ranks]
+    assert torch.isfinite(ranks[0]["flat_p"]).all()
     assert torch.equal(ranks[0]["flat_p"], ranks[1]["flat_p"])
-    assert all(np.isfinite(l) for r in ranks for l in r["losses"])
     print("bench2: buckets (bytes)", ranks[0]["bucket_bytes"], "losses", ranks[0]["losses"], ranks[1]["losses"])
+    # ... and the run is the SAME run whatever else the GPU is doing (round 5): two processes on one card slow each other's memory
+    # pipes down, which is what exposed the missing wait states behind the asm 16-B stores (csrc/fqss_dev.h store16, csrc/qgemm.hip
+    # st16_sc1: the grouped weight-gradient kernel then wrote its next slab ADDRESS in place of a few slab values, and ~4 runs in 10
+    # came back with losses of 4.7 ... 10 instead of 3.29 here, some with NaN parameters -- profiles/r05_store_hazard.txt).  The
+    # per-layer weight-gradient kernels (FQSS_GROUP_WGRAD=0: no slabs) give the reference trajectory.
+    os.environ["FQSS_GROUP_WGRAD"] = "0"
+    try:
+        ref = _run_ranks(tmp_path, "bench2")
+    finally:
+        del os.environ["FQSS_GROUP_WGRAD"]
+    for r in range(2):
+        np.testing.assert_allclose(ranks[r]["losses"], ref[r]["losses"], rtol=2e-2)
 
 
 def test_rccl_executes_the_bucketed_exchange_at_world_one(tmp_path):

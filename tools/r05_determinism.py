@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which parameter gradients of the cfg-2 step differ in their BITS between two runs from the same state (fp32 atomics left in the step)?
-    python tools/r05_determinism.py [tiny]"""
+    python tools/r05_determinism.py [tiny]            (FQSS_DETERMINISTIC=1 in the environment: the same under the deterministic mode)"""
 import os
 import sys
 
@@ -29,6 +29,7 @@ for r in range(3):
     torch.cuda.synchronize()
     runs.append((res["loss"].item(), step.arena.flat_g.clone()))
 names = {id(p): n for n, p in model.named_parameters()}
+print("FQSS_DETERMINISTIC =", os.environ.get("FQSS_DETERMINISTIC", "0"))
 print("loss", [r[0] for r in runs])
 bad = {}
 for p, o in zip(step.arena.params, step.arena.offsets):
