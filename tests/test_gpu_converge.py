@@ -60,8 +60,12 @@ def _run_streams(make_step, runs, n, B, T, seed0):
 
 
 # max - min of the HIP runs' 50-step SI-SDR tails that a family may show (dB): ~1.6 x the six-run measurements of
-# profiles/r04_converge_repeat.txt (0.46 / 0.10 / 0.29); a committed constant, not derived from the runs under test
-HIP_SPREAD_CAP = {"tiny convtasnet": 0.75, "tiny dptnet": 0.2, "tiny sepformer": 0.5, "full-size convtasnet": 0.75,
+# profiles/r04_converge_repeat.txt (0.46 / 0.10 / 0.29); a committed constant, not derived from the runs under test.
+# full-size ConvTasNet at lr 1e-3: round 5 first committed 0.75 on the strength of ONE three-run set (0.35); a second set (-4.25, -3.34,
+# -3.91: 0.91, profiles/r05_converge_gates.txt) showed that to be an under-estimate -- the six tails have sd 0.34 dB (the reference's six
+# configurations: 0.20), i.e. an expected three-run range of 0.57 and 0.75 exceeded about once in eight sets.  1.2 = 1.3 x the six-run
+# range; the run-to-run sigma rule below (>= 4 runs) and the mean rule are unchanged.
+HIP_SPREAD_CAP = {"tiny convtasnet": 0.75, "tiny dptnet": 0.2, "tiny sepformer": 0.5, "full-size convtasnet": 1.2,
                   "full-size convtasnet lr 1e-4": 0.3}
 
 
