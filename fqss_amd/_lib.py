@@ -43,6 +43,8 @@ _PROTOS = {
     "fqss_qpw_bwd_w": [P, P, P, P, P, I32, I32, I32, I32, I64, I64, P],
     "fqss_qpw_fwdq": [P, P, P, P, P, P, P, P, P, P, I32, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P],
     "fqss_qpw_fwdq_add": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, I64, I64, P, P, P],
+    "fqss_add_chain_ok": [I64, I64, I32, I32],
+    "fqss_add_chain_bwd": [P, I32, P, I64, P, I64, P, I64, P, I64, P, P, I64, I64, I32, I64, I64, I64, I64, P],
     "fqss_qpw_stat_slots": [I32, I32],
     "fqss_dwq_stat_slots": [I32, I32],
     "fqss_qpw_fwd2": [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I64, I64, I64, P],
@@ -209,6 +211,10 @@ class FqssQParams(C.Structure):
 
 class FqssWCodes(C.Structure):
     _fields_ = [("idx", C.c_void_p), ("idxT", C.c_void_p), ("dw", C.c_void_p), ("rw", C.c_void_p), ("Co", C.c_int), ("Ci", C.c_int)]
+
+
+class FqssAddChainLevel(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ac", "bc", "bz", "bout", "amin", "amax", "bmin", "bmax", "qmin", "qmax", "gacc", "bgacc", "bgbias")]
 
 
 class FqssAddAfter(C.Structure):

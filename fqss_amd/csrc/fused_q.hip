@@ -1474,6 +1474,147 @@ __global__ __launch_bounds__(256, FQSS_EWQ_WAVES) void k_ewq_bwd(const uint8_t* 
 
 
 // ---------------------------------------------------------------------------------------------
+// The backward of a CHAIN of AddQ layers in one launch (round 5): out_l = fq_l(dec(out_{l-1}) + dec(b_l)), l = 0 .. n-1, where each
+// out_l is consumed by the next add alone -- the skip sum of MaskGenerator.forward (convtasnetq.py:107-111: `output =
+// self.adds[idx](output, skip)`, 23 levels).  Launched level by level (k_ewq_bwd<true>) every level reads its incoming gradient
+// (16 MB) and writes the gradient of its first operand (16 MB) only for the next launch to read it again; here a thread keeps the
+// gradient of its elements in registers from the top level to the bottom and per level reads the two code words + the producer's z
+// and writes the producer's gz: 41 MB instead of 74.  Thread -> element map, per-thread summation order, reductions and slots are
+// those of the per-level launches (grid (ceil(cols / 1024), C), a workgroup serves the batch entries of one channel), so every
+// result has the bits the per-level launches give (tests/test_gpu_kernels.py::test_add_chain_backward).
+// Every b_l is the fresh output of a pointwise conv without activation (its epilogue backward rides here, as in k_ewq_bwd);
+// the bottom level's first operand may be one too (az != NULL), else its gradient is written to ga_out.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChainMax = 24, kChainRows = 8;
+struct ChainLevel {
+    const uint8_t* ac; const uint8_t* bc; const float* bz; float* bout;
+    const float *amin, *amax, *bmin, *bmax, *qmin, *qmax;
+    double* gacc; double* bgacc; float* bgbias;
+};
+struct ChainArgs {
+    int nlev, rows, cols, C;
+    int ld_a, ld_b, ld_bz, ld_bout, ld_g, ld_ga, ld_az, ld_aout;
+    const float* g; float* ga_out;
+    const float* az; float* aout; double* agacc; float* agbias;
+    ChainLevel lv[kChainMax];      // lv[0] = the bottom of the chain (the first add of the forward)
+};
+static_assert(sizeof(ChainArgs) <= 4096, "the level table travels in the kernel arguments");
+
+__global__ __launch_bounds__(256, 2) void k_ewq_chain_bwd(ChainArgs A) {
+    __shared__ float redf[2 * 4];
+    const int cols = A.cols, rows = A.rows, rstep = gridDim.y;
+    const int c_first = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool active = c_first < cols;
+    const int c_ld = active ? c_first : 0;
+    const int64_t sid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    int rowi[kChainRows];
+    bool rok[kChainRows];
+#pragma unroll
+    for (int i = 0; i < kChainRows; ++i) {
+        rok[i] = (int)blockIdx.y + i * rstep < rows;
+        rowi[i] = min((int)blockIdx.y + i * rstep, rows - 1);
+    }
+    float gv[kChainRows][4];
+#pragma unroll
+    for (int i = 0; i < kChainRows; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(A.g + (int64_t)rowi[i] * A.ld_g + c_ld);
+        const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[i][e] = (active && rok[i] && c_first + e < cols) ? tv[e] : 0.0f;
+    }
+    struct In { unsigned int wa, wb; float4 zb; };
+    auto load_level = [&](const ChainLevel& lv, In (&in)[kChainRows]) {
+#pragma unroll
+        for (int i = 0; i < kChainRows; ++i) {
+            in[i].wa = *reinterpret_cast<const unsigned int*>(lv.ac + (int64_t)rowi[i] * A.ld_a + c_ld);
+            in[i].wb = *reinterpret_cast<const unsigned int*>(lv.bc + (int64_t)rowi[i] * A.ld_b + c_ld);
+            in[i].zb = *reinterpret_cast<const float4*>(lv.bz + (int64_t)rowi[i] * A.ld_bz + c_ld);
+        }
+    };
+    In cur[kChainRows], nxt[kChainRows];
+    load_level(A.lv[A.nlev - 1], cur);
+    for (int L = A.nlev - 1; L >= 0; --L) {
+        const ChainLevel& lv = A.lv[L];
+        if (L > 0) load_level(A.lv[L - 1], nxt);      // the next level's operands are on their way while this one is worked on
+        const QRange ra = load_qrange(lv.amin, lv.amax), rb = load_qrange(lv.bmin, lv.bmax), ry = load_qrange(lv.qmin, lv.qmax);
+        const bool fa = (L == 0) && A.az != nullptr;
+        const QRange rpa = ra;
+        float p_du = 0.f, p_out = 0.f, b_du = 0.f, b_out = 0.f, b_sl = 0.f, b_bias = 0.f, a_du = 0.f, a_out = 0.f, a_sl = 0.f, a_bias = 0.f;
+        EwProducer PB{lv.bz, A.ld_bz, FQSS_ACT_NONE, nullptr, lv.bgacc, lv.bgbias, lv.bout, A.ld_bout};
+        EwProducer PA{A.az, A.ld_az, FQSS_ACT_NONE, nullptr, A.agacc, A.agbias, A.aout, A.ld_aout};
+#pragma unroll
+        for (int i = 0; i < kChainRows; ++i) {
+            if (!rok[i]) continue;      // (workgroup-uniform)
+            float4 za4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fa) za4 = *reinterpret_cast<const float4*>(A.az + (int64_t)rowi[i] * A.ld_az + c_ld);
+            if (active) {
+                const float zbv[4] = {cur[i].zb.x, cur[i].zb.y, cur[i].zb.z, cur[i].zb.w}, zav[4] = {za4.x, za4.y, za4.z, za4.w};
+                float ob[4], oa[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gj = gv[i][e];       // 0 where the position is masked out: it drops out of every sum by itself
+                    float z = dec((cur[i].wa >> (8 * e)) & 255u, ra);
+                    z = z + 1.0f * dec((cur[i].wb >> (8 * e)) & 255u, rb);
+                    float cq, u;
+                    bool inr;
+                    (void)fq_asym(z, ry, cq, u, inr);
+                    const float gt = inr ? div_by(gj * ry.delta, ry.delta, ry.inv) : 0.0f;
+                    p_du += gj * (inr ? (cq - u) : cq);
+                    p_out += inr ? 0.0f : gj;
+                    const bool valid = c_first + e < cols;
+                    if (fa) oa[e] = ew_producer_bwd<true>(PA, rpa, 0.0f, zav[e], gt, valid, a_du, a_out, a_sl, a_bias);
+                    ob[e] = ew_producer_bwd<true>(PB, rb, 0.0f, zbv[e], gt, valid, b_du, b_out, b_sl, b_bias);
+                    gv[i][e] = gt;
+                }
+                *reinterpret_cast<float4*>(lv.bout + (int64_t)rowi[i] * A.ld_bout + c_first) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+                if (fa) *reinterpret_cast<float4*>(A.aout + (int64_t)rowi[i] * A.ld_aout + c_first) = make_float4(oa[0], oa[1], oa[2], oa[3]);
+                if (L == 0 && A.ga_out != nullptr)
+                    *reinterpret_cast<float4*>(A.ga_out + (int64_t)rowi[i] * A.ld_ga + c_first) = make_float4(gv[i][0], gv[i][1], gv[i][2], gv[i][3]);
+            }
+        }
+        // the level's reductions, in the forms and orders of k_ewq_bwd's tail
+        if (lv.bgbias != nullptr || (fa && A.agbias != nullptr)) {
+            float pb[2] = {a_bias, b_bias};
+            block_sum<float, 2>(pb, redf);
+            if (threadIdx.x == 0) {
+                if (fa && A.agbias != nullptr) grad_add(&A.agbias[blockIdx.y % A.C], pb[0]);
+                if (lv.bgbias != nullptr) grad_add(&lv.bgbias[blockIdx.y % A.C], pb[1]);
+            }
+        }
+        {
+            const float du = wave_sum(p_du), po = wave_sum(p_out);
+            if (lane0) {
+                double* slot = lv.gacc + 3 * sid;
+                const double dmax = (double)du / 255.0;
+                atomicAdd(&slot[0], (double)po - dmax);
+                atomicAdd(&slot[1], dmax);
+            }
+        }
+        if (fa) {
+            const float du = wave_sum(a_du), po = wave_sum(a_out);
+            if (lane0) {
+                const double dmax = (double)du / 255.0;
+                atomicAdd(&A.agacc[3 * sid], (double)po - dmax);
+                atomicAdd(&A.agacc[3 * sid + 1], dmax);
+            }
+        }
+        {
+            const float du = wave_sum(b_du), po = wave_sum(b_out);
+            if (lane0) {
+                const double dmax = (double)du / 255.0;
+                atomicAdd(&lv.bgacc[3 * sid], (double)po - dmax);
+                atomicAdd(&lv.bgacc[3 * sid + 1], dmax);
+            }
+        }
+        if (L > 0) {
+#pragma unroll
+            for (int i = 0; i < kChainRows; ++i) cur[i] = nxt[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // MulQ on codes: masked[b][s][c][:] = fq( dec(mask[b][s][c][:]) * dec(feat[b][c][:]) )  -- the masking product of
 // ConvTasNetQ.forward (convtasnetq.py:277, qat_layers.py:134-153 `MulQ`).  A workgroup row is one (b, c) row of feat and
 // serves its S mask rows: feat is read (and decoded) once.  Same arithmetic as decode -> fqss_mul_bcast_fwd -> fqss_actq_fwd
@@ -2073,6 +2214,45 @@ extern "C" int fqss_ewq_bwd_p(const uint8_t* ac, const float* amin, const float*
     EwProducer PB{pb_z, (int)ld_pbz, pb_act, pb_slope, pb_gacc, pb_gbias, pb_out, (int)ld_pb_out};
     return ewq_bwd_impl("fqss_ewq_bwd_p", ac, amin, amax, bc, bmin, bmax, nullptr, sb, g, gz, rows, cols, ld_a, ld_b, 0, ld_g, ld_gz,
                         act, slope, qmin, qmax, gacc, PA, PB, C, stream);
+}
+
+/* the backward of a chain of AddQ layers whose outputs feed the next add alone (k_ewq_chain_bwd above); levels[0] = the first add of
+ * the forward.  fqss_add_chain_ok: the shapes the kernel serves (the per-level launch geometry of fqss_ewq_bwd_p: C workgroup rows). */
+extern "C" int fqss_add_chain_ok(int64_t rows, int64_t cols, int C, int nlev) {
+    if (nlev < 2 || nlev > kChainMax || C <= 1 || rows <= 0 || cols <= 0 || rows % C != 0 || rows / C > kChainRows) return 0;
+    int64_t gx_ = cdiv(cols, 256 * 4);
+    if (gx_ > 64) return 0;
+    return (C <= kSlots / gx_) ? 1 : 0;
+}
+
+extern "C" int fqss_add_chain_bwd(const FqssAddChainLevel* levels, int nlev, const float* g, int64_t ld_g, float* ga_out, int64_t ld_ga,
+                                  const float* az, int64_t ld_az, float* aout, int64_t ld_aout, double* agacc, float* agbias,
+                                  int64_t rows, int64_t cols, int C, int64_t ld_a, int64_t ld_b, int64_t ld_bz, int64_t ld_bout,
+                                  fqss_stream_t stream) {
+    FQSS_REQUIRE(levels && g, "null pointer");
+    FQSS_REQUIRE(fqss_add_chain_ok(rows, cols, C, nlev), "shape not served by the chain kernel (fqss_add_chain_ok)");
+    const int64_t c4 = (cols + 3) & ~3ll;
+    FQSS_REQUIRE(aligned16(g) && ld_g % 4 == 0 && ld_g >= c4 && ld_a % 16 == 0 && ld_b % 16 == 0 && ld_a >= cols && ld_b >= cols &&
+                     ld_bz % 4 == 0 && ld_bz >= c4 && ld_bout % 4 == 0 && ld_bout >= c4, "rows must be 16-B aligned");
+    FQSS_REQUIRE((az != nullptr) != (ga_out != nullptr), "the bottom level: EITHER a producer for its first operand (az ...) OR ga_out");
+    FQSS_REQUIRE(!az || (aout && agacc && aligned16(az) && aligned16(aout) && ld_az % 4 == 0 && ld_az >= c4 && ld_aout % 4 == 0 && ld_aout >= c4),
+                 "bad producer of the bottom level's first operand");
+    FQSS_REQUIRE(!ga_out || (aligned16(ga_out) && ld_ga % 4 == 0 && ld_ga >= c4), "bad ga_out rows");
+    ChainArgs A{};
+    A.nlev = nlev; A.rows = (int)rows; A.cols = (int)cols; A.C = C;
+    A.ld_a = (int)ld_a; A.ld_b = (int)ld_b; A.ld_bz = (int)ld_bz; A.ld_bout = (int)ld_bout; A.ld_g = (int)ld_g; A.ld_ga = (int)ld_ga;
+    A.ld_az = (int)ld_az; A.ld_aout = (int)ld_aout;
+    A.g = g; A.ga_out = ga_out; A.az = az; A.aout = aout; A.agacc = agacc; A.agbias = agbias;
+    for (int l = 0; l < nlev; ++l) {
+        const FqssAddChainLevel& f = levels[l];
+        FQSS_REQUIRE(f.ac && f.bc && f.bz && f.bout && f.amin && f.amax && f.bmin && f.bmax && f.qmin && f.qmax && f.gacc && f.bgacc,
+                     "level: null pointer");
+        FQSS_REQUIRE(aligned16(f.ac) && aligned16(f.bc) && aligned16(f.bz) && aligned16(f.bout), "level: rows must be 16-B aligned");
+        A.lv[l] = ChainLevel{f.ac, f.bc, f.bz, f.bout, f.amin, f.amax, f.bmin, f.bmax, f.qmin, f.qmax, f.gacc, f.bgacc, f.bgbias};
+    }
+    const int64_t gx_ = cdiv(cols, 256 * 4);
+    hipLaunchKernelGGL(k_ewq_chain_bwd, dim3((unsigned)gx_, (unsigned)C), dim3(256), 0, (hipStream_t)stream, A);
+    return launch_status("fqss_add_chain_bwd");
 }
 
 extern "C" int fqss_mulq_fwd(const uint8_t* mc, const float* mmin, const float* mmax, const uint8_t* fc, const float* fmin,

@@ -753,6 +753,53 @@ def ewq_fwd(ac, amin, amax, bc, bmin, bmax, bf, sb, act, slope, qmin, qmax, writ
     return out, yc
 
 
+ADD_CHAIN_MAX = 24      # levels per fqss_add_chain_bwd launch (csrc/fused_q.hip kChainMax)
+
+
+def add_chain_ok(rows, cols, C, nlev):
+    return bool(_lib.query("fqss_add_chain_ok", rows, cols, C, nlev))
+
+
+def add_chain_bwd(levels, g, prod_a=None):
+    """the backward of a chain of AddQ layers in one launch (fqss_add_chain_bwd).  levels[0] = the first add of the forward; a level =
+    dict(ac, amin, amax, bc, bmin, bmax, qmin, qmax, gacc, prod_b=(z, act, slope, gacc, gbias)); g: gradient of the top level's output;
+    prod_a: the same 5-tuple for the bottom level's first operand, or None.  -> ([gz of b's producer per level], gz of a's producer or
+    dL/d(a of the bottom level))"""
+    ac0 = levels[0]["ac"]
+    B, C, M = ac0.shape
+    rows, cols, ld_a = _codes2(ac0)
+    ld_b = _codes2(levels[0]["bc"])[2]
+    g, ld_g = _aligned_grad(g)
+    arr = (_lib.FqssAddChainLevel * len(levels))()
+    outs, keep = [], []
+    ld_bz = ld_bout = None
+    for r, lv in zip(arr, levels):
+        z, pact, pslope, pgacc, pgbias = lv["prod_b"]
+        assert pact == ACT_NONE and tuple(lv["ac"].shape) == (B, C, M) and tuple(lv["bc"].shape) == (B, C, M) and tuple(z.shape) == (B, C, M)
+        o = empty_act((B, C, M), ac0.device)
+        outs.append(o)
+        assert _codes2(lv["ac"])[2] == ld_a and _codes2(lv["bc"])[2] == ld_b
+        lz, lo = rowmat(z)[2], rowmat(o)[2]
+        assert (ld_bz is None or (ld_bz, ld_bout) == (lz, lo))
+        ld_bz, ld_bout = lz, lo
+        r.ac, r.bc, r.bz, r.bout = _p(lv["ac"]), _p(lv["bc"]), _p(z), _p(o)
+        r.amin, r.amax, r.bmin, r.bmax, r.qmin, r.qmax = (_p(lv[k]) for k in ("amin", "amax", "bmin", "bmax", "qmin", "qmax"))
+        r.gacc, r.bgacc, r.bgbias = _p(lv["gacc"]), _p(pgacc), _p(pgbias)
+    ga = aout = az = agacc = agbias = None
+    ld_ga = ld_az = ld_aout = 0
+    if prod_a is not None:
+        az, pact, pslope, agacc, agbias = prod_a
+        assert pact == ACT_NONE and tuple(az.shape) == (B, C, M)
+        aout = empty_act((B, C, M), ac0.device)
+        ld_az, ld_aout = rowmat(az)[2], rowmat(aout)[2]
+    else:
+        ga = empty_act((B, C, M), ac0.device)
+        ld_ga = rowmat(ga)[2]
+    _lib.call("fqss_add_chain_bwd", arr, len(levels), _p(g), ld_g, _p(ga), ld_ga, _p(az), ld_az, _p(aout), ld_aout, _p(agacc), _p(agbias),
+              rows, cols, C, ld_a, ld_b, ld_bz, ld_bout, _stream())
+    return outs, (aout if prod_a is not None else ga)
+
+
 def ewq_bwd_p(ac, amin, amax, bc, bmin, bmax, sb, g, act, slope, qmin, qmax, gacc, C, prod_a=None, prod_b=None):
     """ewq_bwd with the epilogue backward of the layers that produced operand a and/or b fused in.
     prod = (z, act, slope, gacc, gbias) -> returns (gz or None, gz_of_producer_a or None, gz_of_producer_b or None)"""

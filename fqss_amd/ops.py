@@ -21,7 +21,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU = K.ACT_NONE, K.ACT_PRELU, K.ACT_RELU
 
 class QCtx:
     """what the epilogue needs to know about the activation quantizer for ONE call (host-side only)"""
-    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer", "hand", "presum")
+    __slots__ = ("qmode", "qmin", "qmax", "obs_ws", "gacc", "owner", "idx", "carrier", "keep_out", "prod", "no_codes", "stats", "defer", "hand", "presum", "chain", "link")
 
     def __init__(self, qmode=Q_BYPASS, qmin=None, qmax=None, obs_ws=None, gacc=None, owner=None):
         self.qmode, self.qmin, self.qmax, self.obs_ws, self.gacc, self.owner = qmode, qmin, qmax, obs_ws, gacc, owner
@@ -34,6 +34,8 @@ class QCtx:
         self.defer = None       # GroupNormQ in front of a depthwise layer: its launch record, run by that layer's kernel (GroupNormActQ)
         self.hand = None        # _GnHand: backward hand-over between a GroupNormQ and the depthwise layer next to it
         self.presum = None      # _PreSum: the AddQ that consumes this output was already evaluated by the producing GEMM
+        self.chain = False      # AddQ: the caller declares that the first operand is the previous add's output and has no other consumer
+        self.link = None        # _ChainLink of this call's output (EwQ): the next add of the chain finds it on the tensor
 
 
 class ActCodes:
@@ -49,7 +51,7 @@ def tag_codes(y, q):
     """attach the codes produced by the epilogue of this call to its output tensor"""
     if q.idx is not None and not CODED:
         assert not q.carrier, "codes-only carriers need the coded dataflow"
-        q.idx = q.prod = q.stats = q.hand = q.presum = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
+        q.idx = q.prod = q.stats = q.hand = q.presum = q.link = None          # un-fused reference dataflow (tests): consumers see plain fp32 tensors
     if q.idx is not None:
         y._fqss_q = ActCodes(q.idx, q.qmin.detach(), q.qmax.detach())
         y._fqss_carrier = q.carrier
@@ -64,6 +66,8 @@ def tag_codes(y, q):
             y._fqss_hand, q.hand = q.hand, None
         if q.presum is not None:
             y._fqss_presum, q.presum = q.presum, None
+        if q.link is not None:
+            y._fqss_chain, q.link = q.link, None
     return y
 
 
@@ -100,6 +104,22 @@ FUSE_GN = os.environ.get("FQSS_FUSE_GN", "1") != "0"
 FUSE_EW = os.environ.get("FQSS_FUSE_EW", "1") != "0"
 # round 5: the forward of the AddQ behind each output of a res | skip pair runs in the pair GEMM's epilogue (fqss_qpw_fwdq_add)
 FUSE_ADD_FWD = os.environ.get("FQSS_FUSE_ADD_FWD", "1") != "0"
+
+
+# round 5: the backward of a CHAIN of AddQ layers (the skip sum of the TCN stack) as ONE launch (fqss_add_chain_bwd)
+FUSE_ADD_CHAIN = os.environ.get("FQSS_FUSE_ADD_CHAIN", "1") != "0"
+
+
+class _ChainLink:
+    """One AddQ of a chain out_l = fq(out_{l-1} + b_l) whose out_{l-1} has no other consumer (declared by the caller: QCtx.chain):
+    what the chain kernel needs of this level, the link of the level below, and -- once the backward of a level ABOVE has run the
+    whole chain -- this level's finished results (`pre`), which its own autograd node then only hands on."""
+    __slots__ = ("prev", "ac", "amin", "amax", "bc", "bmin", "bmax", "qmin", "qmax", "q", "prod_a", "prod_b", "pre", "dummy")
+
+    def __init__(self, prev, ac, amin, amax, bc, bmin, bmax, qmin, qmax, q, prod_a, prod_b):
+        self.prev, self.ac, self.amin, self.amax, self.bc, self.bmin, self.bmax = prev, ac, amin, amax, bc, bmin, bmax
+        self.qmin, self.qmax, self.q, self.prod_a, self.prod_b = qmin, qmax, q, prod_a, prod_b
+        self.pre = self.dummy = None
 
 
 class _PreSum:
@@ -844,12 +864,29 @@ class EwQ(Function):
         ctx.prod_a = getattr(a, "_fqss_prod", None)
         ctx.prod_b = getattr(b, "_fqss_prod", None) if (b is not None and bq_ is not None and sb == 1.0) else None
         ctx.fork_a = getattr(a, "_fqss_fork", None)      # operand a is one branch of a residual fork (ops._ForkState)
+        ctx.link = None
+        if (FUSE_ADD_CHAIN and q.chain and ctx.prod_b is not None and ctx.fork_a is None and act == ACT_NONE and aq_.idx.dim() == 3
+                and q.gacc is not None):
+            prev = getattr(a, "_fqss_chain", None)
+            if prev is not None and tuple(prev.ac.shape) != tuple(aq_.idx.shape):
+                prev = None
+            ctx.link = q.link = _ChainLink(prev, aq_.idx, aq_.qmin, aq_.qmax, bq_.idx, bq_.qmin, bq_.qmax, qmin, qmax, q, ctx.prod_a, ctx.prod_b)
         return _carrier(out) if q.carrier else out
 
     @staticmethod
     def backward(ctx, g):
         ac, amin, amax, bc, bmin, bmax, bf, slope, qmin, qmax = ctx.saved_tensors
         q = ctx.q
+        link = ctx.link
+        if link is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            res = _chain_backward(link, g)
+            if res is not None:
+                ga, gb, a_fused = res
+                ctx.prod_b.fused = True
+                if a_fused:
+                    ctx.prod_a.fused = True
+                g_slope, g_min, g_max = _flush_ranges(q, slope, ctx.sp, ctx.act)
+                return ga, gb, g_slope, g_min, g_max, None, None, None, None, None, None
         pa = _producer_args(ctx.prod_a) if ctx.needs_input_grad[0] else None
         pb = _producer_args(ctx.prod_b) if (ctx.has_b and ctx.needs_input_grad[1]) else None
         if (pa is not None or pb is not None) and bf is None and ac.dim() == 3:
@@ -873,6 +910,44 @@ class EwQ(Function):
             else:
                 gb = gz if ctx.sb == 1.0 else K.axpby(gz, gz, 0.0, sa=float(ctx.sb))
         return ga, gb, g_slope, g_min, g_max, None, None, None, None, None, None
+
+
+def _chain_backward(link, g):
+    """EwQ.backward of a chained AddQ: -> (ga, gb, producer-of-a fused) or None (not part of a chain launch: the per-level kernel).
+    The TOP level of a chain (the first whose backward runs) launches fqss_add_chain_bwd for itself and every level below it and leaves
+    the lower levels' results on their links; their own nodes -- which autograd still runs, in order, each on the placeholder the
+    level above returned -- hand them on."""
+    if link.pre is not None:
+        (ga, gb, a_fused), link.pre = link.pre, None
+        if g.data_ptr() != link.dummy.data_ptr():
+            raise RuntimeError("fqss_amd.ops: a chained AddQ received a gradient that is not the one its chain handed down -- its "
+                               "first operand has another consumer (QCtx.chain was declared wrongly)")
+        return ga, gb, a_fused
+    levels, cur = [], link
+    while cur is not None and len(levels) < K.ADD_CHAIN_MAX:
+        pb = _producer_args(cur.prod_b)
+        if pb is None or pb[1] != ACT_NONE:
+            break
+        levels.append((cur, pb))
+        cur = cur.prev
+    B, C, M = link.ac.shape
+    if len(levels) < 2 or not K.add_chain_ok(B * C, M, C, len(levels)):
+        return None
+    bottom = levels[-1][0]
+    pa = _producer_args(bottom.prod_a) if bottom.prod_a is not None else None
+    if pa is not None and pa[1] != ACT_NONE:
+        pa = None
+    levels.reverse()       # forward order: levels[0] = the bottom
+    outs, ga_bottom = K.add_chain_bwd([dict(ac=l.ac, amin=l.amin, amax=l.amax, bc=l.bc, bmin=l.bmin, bmax=l.bmax, qmin=l.qmin, qmax=l.qmax,
+                                            gacc=l.q.gacc, prod_b=pb) for l, pb in levels], g, prod_a=pa)
+    dummy = K.empty_act((B, C, M), link.ac.device)      # what travels along the chain's autograd edges: never read
+    n = len(levels)
+    for i, ((l, _), o) in enumerate(zip(levels, outs)):
+        below = (ga_bottom, o, pa is not None) if i == 0 else (dummy, o, False)
+        if i == n - 1:
+            return below          # this call's own level (the top)
+        l.pre, l.dummy = below, dummy
+    return None
 
 
 def ew_layer(x1, x2, sb, act, slope, q):

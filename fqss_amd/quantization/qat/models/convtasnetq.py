@@ -73,6 +73,8 @@ class MaskGenerator(nn.Module):
                 self.TCN.append(ConvBlock(num_feats, num_hidden, kernel_size, dilation=d, padding=d))
                 self.receptive_field += kernel_size if s == 0 and layer == 0 else (kernel_size - 1) * d
         self.adds = nn.ModuleList([Add() for _ in range(len(self.TCN) - 1)])
+        for a in self.adds:
+            a.fqss_chain = True     # forward below: the running skip sum is consumed by the next add alone -> ONE backward launch for the chain
         if msk_activate == "sigmoid":
             act = nn.Sigmoid()
         elif msk_activate == "relu":

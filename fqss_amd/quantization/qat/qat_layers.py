@@ -149,6 +149,7 @@ class AddQ(LayerQ):
         if _is_row_bcast(x1, x2):
             return fq_node(aq, ops_dp.AddBcastRows.apply(ops.real(x1), ops.real(x2).reshape(x2.shape[0], x2.shape[2])))
         q = aq.qctx()
+        q.chain = bool(getattr(self.add, "fqss_chain", False))     # the owner declares: x1 = the previous add's output, consumed here alone
         y = ops.ew_layer(x1, x2, 1.0, ops.ACT_NONE, None, q)
         aq.after_forward(q)
         return ops.tag_codes(y, q)

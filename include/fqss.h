@@ -1022,6 +1022,25 @@ typedef struct FqssTGemmDesc { /* one launch of the teacher chain's GEMM (fqss_t
  * "pwconv_fq_fwd" (C = Co: the optional code-statistics slots), "dwconv_fq_fwd" (same), "add_fq_fwd", "add_fq_bwd",
  * "tgemm" (0).  Unknown op / bad shape: -1 (fqss_last_error says which). */
 int64_t fqss_workspace_bytes(const char* op, const int64_t* shape, int ndim);
+/* The backward of a CHAIN of AddQ layers in one launch: out_l = fq_l(dec(out_{l-1}) + dec(b_l)), l = 0 .. nlev-1, every out_l
+ * consumed by the next add alone and every b_l the fresh output of a pointwise conv without activation -- the skip sum of
+ * MaskGenerator.forward (/root/reference/quantization/qat/models/convtasnetq.py:107-111: `output = self.adds[idx](output, skip)`).
+ * Replaces nlev launches of fqss_ewq_bwd_p (same bits: same thread -> element map, summation orders and slots); the gradient travels
+ * from the top level to the bottom in registers.  levels[0] = the first add of the forward; per level: codes of both operands and
+ * their ranges, the add's own range + gacc, the producer of b (its pre-quant z, its gz out, its gacc, its bias gradient [C] or NULL).
+ * g: dL/d(out of the top level).  The bottom level's first operand: EITHER a conv output too (az / aout / agacc / agbias) OR a tensor
+ * whose gradient is written to ga_out.  rows = batch x C.  fqss_add_chain_ok: 1 when the shape is served (2 <= nlev <= 24, batch <= 8,
+ * cols <= 65536). */
+typedef struct {
+    const uint8_t* ac; const uint8_t* bc; const float* bz; float* bout;
+    const float *amin, *amax, *bmin, *bmax, *qmin, *qmax;
+    double* gacc; double* bgacc; float* bgbias;
+} FqssAddChainLevel;
+int fqss_add_chain_ok(int64_t rows, int64_t cols, int C, int nlev);
+int fqss_add_chain_bwd(const FqssAddChainLevel* levels, int nlev, const float* g, int64_t ld_g, float* ga_out, int64_t ld_ga,
+                       const float* az, int64_t ld_az, float* aout, int64_t ld_aout, double* agacc, float* agbias,
+                       int64_t rows, int64_t cols, int C, int64_t ld_a, int64_t ld_b, int64_t ld_bz, int64_t ld_bout,
+                       fqss_stream_t stream);
 /* AddQ / Sub / NlQ on codes (fqss_ewq_fwd): b / qb NULL for the unary form; b of dtype F32 is a real operand; y_out nullable */
 int fqss_add_fq_fwd(const FqssTensor* a, const FqssQParams* qa, const FqssTensor* b, const FqssQParams* qb, float sb,
                     FqssTensor* y, FqssTensor* y_out, const FqssQParams* q, void* ws, size_t ws_bytes, fqss_stream_t stream);

@@ -733,6 +733,63 @@ def test_pair_forward_with_fused_adds(B, Ci, Co1, Co2, M, which):
         assert 0 in ref[..., :M].unique().tolist() and 255 in ref[..., :M].unique().tolist()
 
 
+@pytest.mark.parametrize("B,C,M,n,bottom_prod", [(8, 128, 3999, 5, True), (2, 32, 1000, 3, False), (3, 16, 77, 24, True)])
+def test_add_chain_backward(B, C, M, n, bottom_prod):
+    """fqss_add_chain_bwd: the backward of n chained AddQ layers in one launch against n launches of fqss_ewq_bwd_p -- producers' gz
+    and the bottom gradient bit for bit, range partials and bias gradients to summation order (convtasnetq.py:107-111)"""
+    dev = torch.device("cuda")
+    gen = torch.Generator().manual_seed(B * 1000 + n)
+    t = lambda v: torch.tensor([v], device=dev)
+
+    def codes():
+        c = K.empty_codes((B, C, M), dev)
+        c.copy_(torch.randint(0, 256, (B, C, M), generator=gen, dtype=torch.uint8))
+        return c
+    levels = []
+    a = codes()
+    ra = (t(-1.3), t(2.1))
+    za = padded(torch.randn(B, C, M, generator=gen) * 1.2)
+    for l in range(n):
+        rb, rq = (t(-0.9 - 0.1 * l), t(1.4 + 0.05 * l)), (t(-1.6 - 0.02 * l), t(2.3 + 0.03 * l))
+        levels.append(dict(ac=a, amin=ra[0], amax=ra[1], bc=codes(), bmin=rb[0], bmax=rb[1], qmin=rq[0], qmax=rq[1],
+                           z=padded(torch.randn(B, C, M, generator=gen) * 0.9)))
+        a, ra = codes(), rq            # (the chain's codes need not be consistent with each other for the backward's arithmetic)
+    g = padded(torch.randn(B, C, M, generator=gen))
+    new = lambda: (torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev), torch.zeros(C, device=dev))
+    # reference: level by level, top first
+    ref_out, ref_acc = [None] * n, [None] * n
+    gl = g
+    pa_ref = None
+    for l in range(n - 1, -1, -1):
+        lv = levels[l]
+        gacc, (pg, pb) = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev), new()
+        prod_a = None
+        if l == 0 and bottom_prod:
+            pa_ref = new()
+            prod_a = (za, K.ACT_NONE, None, pa_ref[0], pa_ref[1])
+        gz, gza, gzb = K.ewq_bwd_p(lv["ac"], lv["amin"], lv["amax"], lv["bc"], lv["bmin"], lv["bmax"], 1.0, gl, K.ACT_NONE, None, lv["qmin"],
+                                   lv["qmax"], gacc, C, prod_a=prod_a, prod_b=(lv["z"], K.ACT_NONE, None, pg, pb))
+        ref_out[l], ref_acc[l] = gzb, (gacc, pg, pb)
+        gl = gza if prod_a is not None else gz
+    ref_bottom = gl
+    # the chain
+    accs = [(torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev),) + new() for _ in range(n)]
+    pa = new() if bottom_prod else None
+    assert K.add_chain_ok(B * C, M, C, n)
+    outs, bottom = K.add_chain_bwd([dict(ac=lv["ac"], amin=lv["amin"], amax=lv["amax"], bc=lv["bc"], bmin=lv["bmin"], bmax=lv["bmax"], qmin=lv["qmin"],
+                                         qmax=lv["qmax"], gacc=acc[0], prod_b=(lv["z"], K.ACT_NONE, None, acc[1], acc[2])) for lv, acc in zip(levels, accs)],
+                                   g, prod_a=(za, K.ACT_NONE, None, pa[0], pa[1]) if bottom_prod else None)
+    assert torch.equal(bottom[..., :M], ref_bottom[..., :M])
+    for l in range(n):
+        assert torch.equal(outs[l][..., :M], ref_out[l][..., :M]), l
+        for got, want in zip(accs[l], ref_acc[l]):
+            close(got.double().cpu(), want.double().cpu(), rtol=1e-6, atol=1e-6 * float(want.abs().max()) + 1e-30)
+    if bottom_prod:
+        for got, want in zip(pa, pa_ref):
+            close(got.double().cpu(), want.double().cpu(), rtol=1e-6, atol=1e-6 * float(want.abs().max()) + 1e-30)
+    assert not K.add_chain_ok(9 * C, M, C, n) and not K.add_chain_ok(B * C, M, C, 25) and not K.add_chain_ok(B * C, M, C, 1)
+
+
 def test_qgemm_exact_integer_maps():
     """A = I-like asymmetric integer codes: catches transposed fragments / wrong tr-read lane maps bit-exactly"""
     B, Ci, Co, M = 1, 64, 96, 160
