@@ -166,9 +166,14 @@ def build(dev, sets=3):
     case("k_ewq_bwd", "AddQ backward with BOTH operands' conv output-quantizer backward fused (residual add), C=128", "hbm", 24, 14.0 * NB * n, 8.0 * NB * n,
          20.0 * NB * n, lambda i: K.ewq_bwd_p(xc_b[i % sets], lo, hi, xc_b2[i % sets], lo, hi, 1.0, gz_b[i % sets], 0, None, lo, hi, gacc, NB,
                                                prod_a=(z_b[i % sets], 0, None, pgacc, pgb_a), prod_b=(z_b2[i % sets], 0, None, pgacc2, pgb_b)))
-    case("k_ewq_bwd", "AddQ backward with one operand's conv output-quantizer backward fused (skip sum), C=128", "hbm", 24, 10.0 * NB * n, 8.0 * NB * n,
-         16.0 * NB * n, lambda i: K.ewq_bwd_p(xc_b[i % sets], lo, hi, xc_b2[i % sets], lo, hi, 1.0, gz_b[i % sets], 0, None, lo, hi, gacc, NB,
-                                               prod_b=(z_b[i % sets], 0, None, pgacc, pgb_b)))
+    # round 5: the 23 AddQ of the skip sum run their backward as ONE launch (k_ewq_chain_bwd): the gradient stays in registers from the top
+    # level to the bottom; per level two code words + the skip conv's z in, that conv's gz out (every level on buffers of its own: 0.9 GB,
+    # nothing may be served from the Infinity Cache twice)
+    NL = 23
+    ch_levels = [dict(ac=_codes(NB, dev), amin=lo, amax=hi, bc=_codes(NB, dev), bmin=lo, bmax=hi, qmin=lo, qmax=hi,
+                      gacc=torch.zeros_like(gacc), prod_b=(_act(NB, dev), 0, None, torch.zeros_like(pgacc), torch.zeros(NB, device=dev))) for _ in range(NL)]
+    case("k_ewq_chain_bwd", "backward of the skip sum's 23 chained AddQ in one launch, each with its conv's output-quantizer backward, C=128", "hbm", 1,
+         (NL * 6.0 + 4.0) * NB * n, (NL * 4.0 + 4.0) * NB * n, NL * 16.0 * NB * n, lambda i: K.add_chain_bwd(ch_levels, gz_b[i % sets]))
     gb_b = torch.zeros(NB, device=dev)
     case("k_actq_bwd", "activation fake-quant backward (bottleneck / mask convs), C=128", "hbm", 4, 8.0 * NB * n, 4.0 * NB * n, 12.0 * NB * n,
          lambda i: K.actq_bwd(z_b[i % sets], gz_b[i % sets], 0, None, 2, lo, hi, gacc, gbias=gb_b, C=NB))
