@@ -830,6 +830,190 @@ __global__ __launch_bounds__(512, 2) void k_tgemm2(TGemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_tgemm_k128 (round 5): the teacher's T1 -- 1x1 conv 128 -> 512 + bias + PReLU + GroupNorm statistics -- with
+// the WEIGHTS IN REGISTERS.  K = 128 makes a wave's whole weight slab small: 32 rows x 128 k x 3 bf16 planes = 24 KB = 96 VGPRs per
+// lane in MFMA A-fragment order, loaded once per workgroup from the tiled image of fqss_split3_tiles.  What is left per 64-column
+// tile is the activation side only -- 32 KB of fp32 in, split exactly in three into 55 KB of LDS, 96 MFMAs per wave straight through
+// the whole K (no k-loop pipeline, no ring), a 128 x 64 result out -- so a workgroup needs 74 KB of LDS and 256 registers: TWO fit
+// a CU, and one's loads / split / result stores run under the other's MFMAs, which is the overlap k_tgemm2's barrier stamps asked for
+// (its epilogues were 44 % of T1 with the matrix pipes dark: one workgroup per CU, all in the same phase).
+// Grid: (column groups) x (Co / 128 row blocks); a workgroup walks the column tiles group, group + G, ... of ITS row block; the four
+// row blocks of a column group sit on one XCD (xcd_tile), so an activation tile comes from HBM once.  Same six exact partial
+// products, smallest first, as k_tgemm / k_tgemm2; the accumulation runs over k in the same order.
+// ---------------------------------------------------------------------------------------------------------------------------
+// FQSS_K1_ABL (timing experiments only: make variant SRC=teacher NAME=.. DEFS=-DFQSS_K1_ABL=n, tools/r05_t1_probe.py; never the product):
+// 1 no MFMAs | 2 no split / LDS stores of the activation tile | 4 no result stores | 8 no activation loads | 16 no LDS fragment reads
+#ifndef FQSS_K1_ABL
+#define FQSS_K1_ABL 0
+#endif
+constexpr int K1_BN = 64, K1_LDN = 72, K1_ROWS = 128;
+struct K1X { f32x4t v[8]; };
+__device__ __forceinline__ void k1_wait(K1X& x) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7]) : : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void k_tgemm_k128(TGemmArgs g, int ngroups, int tiles_n64) {
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][128][K1_LDN];    // 55,296 B: one 128 (k) x 64 (n) activation tile, three planes
+    __shared__ __attribute__((aligned(16))) float Tst[4][32][TLDT];               // 18,432 B: a wave-private staging tile each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5, gq = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    int group, rb;
+    if (!xcd_tile(ngroups, g.M / K1_ROWS, group, rb)) return;
+    const int i0 = rb * K1_ROWS + wave * 32;      // this wave's 32 output rows
+    // ---- the wave's weight slab, in A-fragment order: lane (row lr, half lh) holds k = 16 s + 8 lh .. + 7 of every plane
+    bf16x8 wf[8][3];
+    {
+        const int row = i0 + lr, mt = row >> 8, r256 = row & 255, pc = lh ^ ((r256 >> 3) & 1);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                wf[s8][p] = *reinterpret_cast<const bf16x8*>(g.A + ((int64_t)(mt * 8 + s8) * 3 + p) * 4096 + r256 * 16 + pc * 8);
+    }
+    __shared__ float rowb[K1_ROWS];      // bias of the workgroup's rows (added in the epilogue: 16 registers fewer than accumulators that start at it)
+    if (tid < K1_ROWS) rowb[tid] = (g.bias != nullptr) ? g.bias[rb * K1_ROWS + tid] : 0.0f;
+    __syncthreads();
+    const float nscale = (g.act == FQSS_ACT_PRELU) ? *g.slope : (g.act == FQSS_ACT_RELU ? 0.0f : 1.0f);
+    const int n_last = (g.N - 1) & ~3;
+    const int xk = tid >> 4, xc = (tid & 15) * 4;          // loader: 16 threads per k row, 16 rows per pass, 8 passes
+    const int ntiles = g.batches * tiles_n64;
+    float(*Tt)[TLDT] = Tst[wave];
+    const int c4 = (lane & 7) * 4;
+    K1X xr;
+    auto load_x = [&](int ct) {
+        const int b = ct / tiles_n64, j0 = (ct - b * tiles_n64) * K1_BN;
+        const float* Bb = g.B + (int64_t)b * g.sBb + min(j0 + xc, n_last);
+        if (FQSS_K1_ABL & 8) return;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t_load16(xr.v[q], Bb + (int64_t)(q * 16 + xk) * g.ldb);
+    };
+    float s1 = 0.0f, s2 = 0.0f;
+    int sb = -1;                                   // the sample the statistics in (s1, s2) belong to
+    auto flush_stats = [&]() {
+        if (g.stats_out != nullptr && sb >= 0) {
+            const double a = wave_sum((double)s1), q = wave_sum((double)s2);
+            if (lane == 0) {
+                double* so = g.stats_out + ((int64_t)sb * kTSlots + ((group * 4 + wave) & (kTSlots - 1))) * kTSlotStride;
+                atomicAdd(&so[0], a);
+                atomicAdd(&so[1], q);
+            }
+        }
+        s1 = s2 = 0.0f;
+    };
+    int ct = group;
+    if (ct < ntiles) load_x(ct);
+    if (g.stagger > 0 && ((g.stagger & 1) ? ((blockIdx.x >> 3) & 1) : (blockIdx.x >= gridDim.x / 2))) {
+        // experiment knob (FQSS_T1_STAGGER=<cycles>; odd: every second workgroup of an XCD, even: the second half of the grid): start late,
+        // so that the two workgroups of a CU are in opposite phases (one's memory side under the other's MFMAs)
+        const long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < g.stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    for (; ct < ntiles; ct += ngroups) {
+        const int b = ct / tiles_n64, j0 = (ct - b * tiles_n64) * K1_BN;
+        if (b != sb) {
+            flush_stats();
+            sb = b;
+        }
+        // ---- this tile's activations: exact three-way split into the LDS tile (every wave has passed the barrier behind the
+        // previous tile's fragment reads)
+        k1_wait(xr);
+#pragma unroll
+        for (int q = 0; q < ((FQSS_K1_ABL & 2) ? 0 : 8); ++q) {
+            const float x[4] = {xr.v[q][0], xr.v[q][1], xr.v[q][2], xr.v[q][3]};
+            float r1[4], r2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r1[e] = x[e] - t_tr(x[e]);
+                r2[e] = r1[e] - t_tr(r1[e]);
+            }
+            uint2 o1, o2, o3;
+            o1.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+            o1.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+            o2.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+            o2.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+            o3.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+            o3.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+            *reinterpret_cast<uint2*>(&Bs[0][q * 16 + xk][xc]) = o1;
+            *reinterpret_cast<uint2*>(&Bs[1][q * 16 + xk][xc]) = o2;
+            *reinterpret_cast<uint2*>(&Bs[2][q * 16 + xk][xc]) = o3;
+        }
+        if (ct + ngroups < ntiles) load_x(ct + ngroups);     // the next tile's activations travel under this tile's MFMAs
+        __syncthreads();
+        // ---- 8 x 16 deep: 12 MFMAs per step (six partial products x two 32-column tiles), A from registers
+        f32x16 acc[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
+        // (the fragments of step ks + 1 are requested before the MFMAs of step ks: with two waves per SIMD the LDS round trip was not
+        //  hidden otherwise -- ablation, tools/r05_t1_probe.py: 36 us per launch, 26 with the fragment reads removed)
+        // Two fragment buffers of one 32-column tile and one k-step each (3 planes x 4 registers): while the six MFMAs of one run, the
+        // fragments of the next are on their way -- 24 registers, what the un-pipelined form held for both column tiles of a step (the
+        // kernel sits at the 256-register limit of two waves per SIMD, and a spill next to the asm loads in flight is not an option).
+        auto read_frags = [&](bf16x8 (&bfr)[3], int ks, int ni) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int kr = ks * 16 + 8 * (gq >> 1) + tq;
+                const int nc = ni * 32 + 16 * (gq & 1) + 4 * tp;
+                union { bf16x8 v; s16x4 h[2]; } u;
+                if (FQSS_K1_ABL & 16) {
+                    u.v = wf[ks][p];
+                } else {
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr][nc]));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(&Bs[p][kr + 4][nc]));
+                }
+                bfr[p] = u.v;
+            }
+        };
+        auto mfma_tile = [&](const bf16x8 (&bfr)[3], int ks, int ni) {
+            constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int sp = 0; sp < 6; ++sp) {
+                if (!(FQSS_K1_ABL & 1)) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][IA[sp]], bfr[IB[sp]], acc[ni], 0, 0, 0);
+                else acc[ni][sp] += (float)wf[ks][IA[sp]][0] + (float)bfr[IB[sp]][0];
+            }
+        };
+        bf16x8 fr[2][3];
+        read_frags(fr[0], 0, 0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {          // u = 8 ni + ks: one 32-column tile through the whole K, then the other
+            if (u + 1 < 16) read_frags(fr[(u + 1) & 1], (u + 1) & 7, (u + 1) >> 3);
+            mfma_tile(fr[u & 1], u & 7, u >> 3);
+        }
+        __syncthreads();      // every wave is done with the LDS tile: the next iteration may overwrite it
+        // ---- act, 16-B/lane row stores through the wave's staging tile, statistics (no workgroup barrier in here)
+        float* Cb = g.C1 + (int64_t)b * g.sC1b + (int64_t)i0 * g.ldc1;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = acc[ni][r] + rowb[wave * 32 + rl];
+                Tt[rl][lr] = v > 0.0f ? v : nscale * v;
+            }
+            const int col = j0 + ni * 32 + c4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int rl = pass * 8 + (lane >> 3);
+                const float4 t = *reinterpret_cast<const float4*>(&Tt[rl][c4]);
+                if (col < g.N) {
+                    if (!(FQSS_K1_ABL & 4)) store16(Cb + (int64_t)rl * g.ldc1 + col, t);
+                    const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < g.N) {
+                            s1 += v[e];
+                            s2 = fmaf(v[e], v[e], s2);
+                        }
+                }
+            }
+        }
+    }
+    flush_stats();
+}
+
 // T2: y = PReLU( dwconv( GN(x) ) + bias ), statistics of y.  One workgroup per (sample, channel) row,
 // 16 outputs per thread; the GroupNorm coefficients are computed once per workgroup.
 __global__ __launch_bounds__(256) void k_tdw(const float* __restrict__ x, const double* __restrict__ stats_in,
@@ -1008,6 +1192,17 @@ static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, cons
             return ok;
         }();
         TG_REQUIRE(attr_ok, "k_tgemm2 needs 160 KB of dynamic LDS");
+        static const bool k128 = [] { const char* e = getenv("FQSS_T1_K128"); return !(e && e[0] == '0'); }();
+        if (k128 && pro == 0 && Ci == 128 && Co % K1_ROWS == 0 && M1 == Co && r1 == nullptr && r2 == nullptr && (stats_out == nullptr || B <= 64)) {
+            // T1 of the TCN teacher: weights in registers, two workgroups per CU (k_tgemm_k128)
+            const int tiles_n64 = (int)cdiv(M, K1_BN), ntiles = tiles_n64 * B;
+            int ngroups = 128;                                  // x 4 row blocks = 512 workgroups = two per CU
+            while (ngroups > 8 && ngroups * 2 > ntiles) ngroups >>= 1;
+            static const int t1_stagger = [] { const char* e = getenv("FQSS_T1_STAGGER"); return e ? atoi(e) : 0; }();
+            g.stagger = t1_stagger;
+            hipLaunchKernelGGL(k_tgemm_k128, dim3(xcd_grid(ngroups, Co / K1_ROWS)), dim3(256), 0, (hipStream_t)stream, g, ngroups, tiles_n64);
+            return launch_status(fn);
+        }
         g.tiles_m = Co / T2BM;
         static const int stagger = [] { const char* e = getenv("FQSS_T2_STAGGER"); return e ? atoi(e) : 0; }();
         g.stagger = stagger;

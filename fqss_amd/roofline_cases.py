@@ -47,7 +47,7 @@ def priced(flops, products, dtype, nbytes, us):
 
 # partial products issued per algorithmic product, and on which pipe (csrc/teacher.hip: 3 x 3 bf16 split, 6 leading terms; csrc/qgemm.hip:
 # fp32 gradient in three exact bf16 pieces x one exact plane of 8-bit codes; forward: codes x codes, one bf16 product)
-ISSUED = {"k_tgemm2<0>": ("bf16", 6), "k_tgemm2<1>": ("bf16", 6), "k_qgemm<1>": ("bf16", 3), "k_qwgrad2": ("bf16", 3), "k_qwgrad_group": ("bf16", 3),
+ISSUED = {"k_tgemm_k128": ("bf16", 6), "k_tgemm2<0>": ("bf16", 6), "k_tgemm2<1>": ("bf16", 6), "k_qgemm<1>": ("bf16", 3), "k_qwgrad2": ("bf16", 3), "k_qwgrad_group": ("bf16", 3),
           "k_qgemm<0>": ("bf16", 1), "k_gemm_x3_wq_multi": ("bf16", 3),
           "k_lstm_fwd_st<128>": ("f32", 1), "k_gemm_x3": ("bf16", 3), "k_qgemm<3>": ("bf16", 6), "k_attn_long_fwd_x3<64>": ("bf16", 6),
           "k_attn_long_fwd_c<64>": ("bf16", 3)}
@@ -85,7 +85,7 @@ def build(dev, sets=3):
     K.tstats(y_[0], st[0])
     ga, be = torch.ones(NH, device=dev), torch.zeros(NH, device=dev)
     fl = 2.0 * NH * NB * n
-    case("k_tgemm2<0>", "teacher T1: 1x1 conv 128->512 + PReLU + GroupNorm statistics", "mfma", 24, 4.0 * NB * n, 4.0 * NH * n, 4.0 * (NB + NH) * n,
+    case("k_tgemm_k128", "teacher T1: 1x1 conv 128->512 + PReLU + GroupNorm statistics (weights in registers, two workgroups per CU)", "mfma", 24, 4.0 * NB * n, 4.0 * NH * n, 4.0 * (NB + NH) * n,
          lambda i: K.tgemm(w1, h_[i % sets], b1, act=K.ACT_PRELU, slope=slope, stats_out=st[1]), flops=fl)
     case("k_tgemm2<1>", "teacher T3: GroupNorm-apply + res|skip 1x1 convs 512->256 + residual adds", "mfma", 24, 4.0 * (NH + 2 * NB) * n, 4.0 * 2 * NB * n,
          4.0 * (NH + 2 * NB) * n,

@@ -1376,6 +1376,8 @@ def test_mha_prep_matches_the_unfused_quantizer_chain(L, B, E, nh):
     (256, 64, 1, 0, 256, 2, 128),       # two k-tiles only (the loop's peeled head and tail meet), one output
     (128, 512, 1, 0, 128, 2, 200),      # bottleneck conv: fewer than 256 rows -> the round-3 kernel (k_tgemm) keeps serving it
     (256, 128, 0, 0, 256, 2, 260),      # one row tile, four k-tiles (the activation ring never re-arms)
+    (512, 128, 0, 1, 512, 3, 1000),     # T1 again (k_tgemm_k128: weights in registers): several column tiles per workgroup, samples change under way
+    (128, 128, 0, 1, 128, 2, 70),       # ... one row block, a ragged second column tile, fewer tiles than column groups
     (512, 512, 1, 2, 512, 1, 140),      # two row tiles behind a GroupNorm prologue (bias from global memory), 16 k-tiles
     (512, 256, 2, 0, 512, 2, 129),      # eight k-tiles: one re-arming group
 ])
