@@ -1174,6 +1174,7 @@ static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, cons
     TG_REQUIRE(pro >= 0 && pro <= 2 && (pro != 1 || (pro_stats && pro_gamma && pro_beta)) && (pro != 2 || pro_slope), "bad prologue");
     TG_REQUIRE(act != FQSS_ACT_PRELU || slope, "PReLU needs a slope");
     TG_REQUIRE(!tiled || ld_x < (1ll << 28), "rows too long for the tiled form's 32-bit lane offsets");
+    TG_REQUIRE(!tiled || bias == nullptr || aligned16(bias), "the tiled form reads the bias in 16-B pieces");
     TG_REQUIRE(!tiled || fqss_tgemm_tiled_ok(Ci, Co, M1), "the tiled form needs Co % 256 == 0, Ci % 128 == 0, Ci <= 512, M1 % 32 == 0");
     if (B == 0 || M == 0) return FQSS_OK;
     TGemmArgs g{};

@@ -1371,15 +1371,17 @@ def test_mha_prep_matches_the_unfused_quantizer_chain(L, B, E, nh):
 
 @pytest.mark.parametrize("Co,Ci,pro,act,split,B,M", [
     (256, 512, 1, 0, 128, 3, 300),      # T3 of the teacher chain: GroupNorm prologue, res | skip split, both residuals, ragged last tile
-    (512, 128, 0, 1, 512, 2, 391),      # T1: PReLU + GroupNorm statistics, two 256-row tiles per workgroup
-    (1024, 128, 2, 2, 1024, 1, 130),    # mask conv: PReLU prologue, ReLU, four row tiles
-    (256, 64, 1, 0, 256, 2, 128),       # two k-tiles only (the loop's peeled head and tail meet), one output
+    (512, 128, 0, 1, 512, 2, 391),      # T1: PReLU + GroupNorm statistics (k_tgemm_k128 since round 5; k_tgemm2<0> behind FQSS_T1_K128=0)
+    (1024, 128, 2, 2, 1024, 1, 130),    # mask conv: PReLU prologue, ReLU, four row tiles (k_tgemm2<2>: eight k-tiles of 16)
+    (256, 64, 1, 0, 256, 2, 128),       # Ci = 64 < 128: not a shape of the tiled form -> k_tgemm, two 32-deep k-tiles (its peeled head and tail meet)
+    (256, 256, 0, 1, 256, 2, 200),      # no prologue at Ci = 256: k_tgemm2<0> (Ci = 128 goes to k_tgemm_k128)
+    (256, 384, 1, 0, 256, 2, 150),      # 24 k-tiles of 16: the longest straight-line loader instantiation of k_tgemm2 but one (Ci = 512)
     (128, 512, 1, 0, 128, 2, 200),      # bottleneck conv: fewer than 256 rows -> the round-3 kernel (k_tgemm) keeps serving it
-    (256, 128, 0, 0, 256, 2, 260),      # one row tile, four k-tiles (the activation ring never re-arms)
+    (256, 128, 0, 0, 256, 2, 260),      # Ci = 128 without a prologue: k_tgemm_k128 (two row blocks of 128), no statistics, no activation
     (512, 128, 0, 1, 512, 3, 1000),     # T1 again (k_tgemm_k128: weights in registers): several column tiles per workgroup, samples change under way
     (128, 128, 0, 1, 128, 2, 70),       # ... one row block, a ragged second column tile, fewer tiles than column groups
     (512, 512, 1, 2, 512, 1, 140),      # two row tiles behind a GroupNorm prologue (bias from global memory), 16 k-tiles
-    (512, 256, 2, 0, 512, 2, 129),      # eight k-tiles: one re-arming group
+    (512, 256, 2, 0, 512, 2, 129),      # sixteen k-tiles of 16 behind a PReLU prologue
 ])
 def test_teacher_gemm_against_fp64(Co, Ci, pro, act, split, B, M):
     """fqss_tgemm (csrc/teacher.hip: k_tgemm2, the 256-row form with the weight planes moved by LDS-DMA, and k_tgemm for the other

@@ -6,7 +6,7 @@ mkdir -p $R/gpurun_out/lstm_pmc
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" "SQ_IFETCH SQ_WAIT_IFETCH SQ_INSTS_VALU_TRANS_F32"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/lstm_pmc/p$i -o p$i --output-format csv -- python3 $R/tools/lstm_probe.py 3 > $R/gpurun_out/lstm_pmc/p$i.log 2>&1 || echo "pass $i failed" >> $R/gpurun_out/lstm_pmc/fail.txt
+  timeout -k 10 200 rocprofv3 --pmc $set -d $R/gpurun_out/lstm_pmc/p$i -o p$i --output-format csv -- python3 $R/tools/lstm_probe.py 3 > $R/gpurun_out/lstm_pmc/p$i.log 2>&1 || echo "pass $i failed" >> $R/gpurun_out/lstm_pmc/fail.txt
 done
 python3 - <<'PY'
 import csv, glob, os, collections
