@@ -662,7 +662,8 @@ def test_qgemm_pair_matches_single_layers(B, Ci, Co1, Co2, M):
     close(gw.cpu().double(), ref, rtol=1e-5, atol=3e-6 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("B,Ci,Co1,Co2,M,act", [(2, 64, 32, 0, 77, 1), (2, 512, 128, 128, 501, 0), (1, 128, 512, 0, 260, 1), (2, 32, 64, 32, 100, 0)])
+@pytest.mark.parametrize("B,Ci,Co1,Co2,M,act", [(2, 64, 32, 0, 77, 1), (2, 512, 128, 128, 501, 0), (1, 128, 512, 0, 260, 1), (2, 32, 64, 32, 100, 0),
+                                                (3, 128, 512, 0, 1000, 1), (2, 128, 128, 0, 70, 0), (8, 128, 512, 0, 3999, 1)])   # k_qfwd_k128 (Ci = 128, Co % 128 == 0)
 def test_qgemm_fused_output_quantizer(B, Ci, Co1, Co2, M, act):
     """fqss_qpw_fwdq: same z as the plain forward, and output codes bit-equal to the stand-alone quantizer on that z"""
     cu = lambda t: t.cuda().contiguous()
