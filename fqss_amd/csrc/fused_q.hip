@@ -1317,7 +1317,9 @@ __device__ __forceinline__ float ew_producer_bwd(const EwProducer& P, const QRan
 }
 
 #ifndef FQSS_EWQ_NR
-#define FQSS_EWQ_NR 4        // rows of loads in flight per thread (x FQSS_EWQ_WAVES waves per SIMD; 8 x 2 before: 196 VGPRs)
+#define FQSS_EWQ_NR 2        // rows of loads in flight per thread (x FQSS_EWQ_WAVES waves per SIMD; 8 x 2 first: 196 VGPRs; round 5, the fused
+                             // residual-add launch alone, us: 8 x 2 24.4, 8 x 3 32.0, 4 x 3 24.9, 3 x 3 23.6, 2 x 3 22.0, 2 x 4 22.3, 1 x 3 21.4, 1 x 4 21.2 --
+                             // the step within +-0.03 ms for every row but 8 x 3 (+0.4); same per-thread summation order whatever NR)
 #define FQSS_EWQ_WAVES 3
 #endif
 template <bool PLAIN>
