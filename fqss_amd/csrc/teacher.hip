@@ -1197,7 +1197,12 @@ static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, cons
         if (k128 && pro == 0 && Ci == 128 && Co % K1_ROWS == 0 && M1 == Co && r1 == nullptr && r2 == nullptr && (stats_out == nullptr || B <= 64)) {
             // T1 of the TCN teacher: weights in registers, two workgroups per CU (k_tgemm_k128)
             const int tiles_n64 = (int)cdiv(M, K1_BN), ntiles = tiles_n64 * B;
-            int ngroups = 128;                                  // x 4 row blocks = 512 workgroups = two per CU
+            // 64 column groups x 4 row blocks = 256 workgroups = ONE per CU although two fit: alone on the chip the launch is slower
+            // that way (45 us against 36 at 128 groups), but the step is faster (13.00 against 13.07 ms, FQSS_T1_GROUPS=64 / 128 interleaved
+            // on one box; 48: 13.00, 32: 13.08, 16: 13.05, 192: 13.11) -- the teacher runs one batch ahead on its own stream with 10 ms
+            // of slack, and what it should leave free is the second workgroup slot of every CU for the student's kernels
+            static const int want_groups = [] { const char* e = getenv("FQSS_T1_GROUPS"); const int v = e ? atoi(e) : 64; return v >= 8 ? v / 8 * 8 : 64; }();
+            int ngroups = want_groups;
             while (ngroups > 8 && ngroups * 2 > ntiles) ngroups >>= 1;
             static const int t1_stagger = [] { const char* e = getenv("FQSS_T1_STAGGER"); return e ? atoi(e) : 0; }();
             g.stagger = t1_stagger;
