@@ -733,4 +733,69 @@ int fqss_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, cons
     return FQSS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ data side (LibriMix dataset, librimix_dataset.py:54, 139-153)
+// the op sequences of csrc/data_ops.hip: energies in fp64, gains in fp32 (process.py:77-103), max_clip(0.9) (process.py:57-62)
+int fqss_snr_mix(const float* a, const float* b, const float* snr, double* ws, uint32_t* peak, float* out, int64_t B, int64_t T, int64_t ld_a,
+                 int64_t ld_b, int64_t ld_o, int mode, int clip, fqss_stream_t) {
+    REQUIRE(a && b && snr && ws && peak && out, "null pointer");
+    REQUIRE(B > 0 && T > 0 && ld_a >= T && ld_b >= T && ld_o >= T && (mode == 0 || mode == 1), "bad shape");
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < B; ++r) {
+        double ea = 0.0, eb = 0.0;
+        for (int64_t i = 0; i < T; ++i) {
+            const double x = a[r * ld_a + i], y = b[r * ld_b + i];
+            ea += x * x;
+            eb += y * y;
+        }
+        ws[2 * r] += ea;
+        ws[2 * r + 1] += eb;
+        const float Ea = (float)(ws[2 * r] / (double)T), Eb = (float)(ws[2 * r + 1] / (double)T);
+        float ga = 1.0f, gb = 1.0f;
+        if (mode == 0) {
+            if (Ea > 0.0f && Eb > 0.0f) {
+                const float now = 10.0f * log10f(Ea / Eb);
+                if (now < snr[r]) gb = sqrtf((Ea / Eb) * powf(10.0f, -snr[r] / 10.0f));
+                else ga = sqrtf((Eb / Ea) * powf(10.0f, snr[r] / 10.0f));
+            }
+        } else if (Ea > 0.0f) {
+            gb = sqrtf((Ea / Eb) / powf(10.0f, snr[r] / 10.0f));
+        }
+        float mx = 0.0f;
+        for (int64_t i = 0; i < T; ++i) {
+            const float m = a[r * ld_a + i] * ga + b[r * ld_b + i] * gb;
+            out[r * ld_o + i] = m;
+            mx = fmaxf(mx, fabsf(m));
+        }
+        memcpy(&peak[r], &mx, 4);
+        if (clip && mx >= 0.9f) {
+            const float gain = 0.9f / mx;
+            for (int64_t i = 0; i < T; ++i) out[r * ld_o + i] *= gain;
+        }
+    }
+    return FQSS_OK;
+}
+
+// y[r][n * newf + p] = sum_k h[p][k] * xpad[r][n * orig + k]: one fma per tap, in tap order (the HIP kernel's chain)
+int fqss_resample_fir(const float* x, const float* h, float* y, int64_t rows, int64_t L, int64_t Lout, int64_t ld_x, int64_t ld_y, int orig,
+                      int newf, int width, fqss_stream_t) {
+    if (rows == 0 || Lout == 0) return FQSS_OK;
+    REQUIRE(x && h && y, "null pointer");
+    REQUIRE(rows > 0 && L > 0 && Lout > 0 && ld_x >= L && ld_y >= Lout && orig > 0 && newf > 0 && width >= 0, "bad shape");
+    REQUIRE(Lout <= ((int64_t)newf * L + orig - 1) / orig, "output longer than ceil(new * L / orig)");
+    const int K = 2 * width + orig;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t o = 0; o < Lout; ++o) {
+            const int64_t n = o / newf, base = n * orig - width;
+            const int p = (int)(o - n * newf);
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                const int64_t i = base + k;
+                acc = fmaf(h[p * K + k], (i >= 0 && i < L) ? x[r * ld_x + i] : 0.0f, acc);
+            }
+            y[r * ld_y + o] = acc;
+        }
+    return FQSS_OK;
+}
+
 }  // extern "C"
