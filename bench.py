@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg3", "cfg4", "cfg5", "infer"),
                     help="cfg2 ConvTasNet 8 x 4 s (default, the metric's configuration); cfg3 DPTNet 1 x 3 s; cfg4 Sepformer 1 x 4 s; "
                          "cfg5 HTDemucs 4 x 10 s stereo 44.1 kHz")
+    ap.add_argument("--no-det-leg", action="store_true", help="skip the FQSS_DETERMINISTIC=1 leg (`deterministic_ms_per_step`)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="cfg2 at N=1 only: skip the cfg 3 / 4 / 5 legs that the default run appends as `other_workloads`")
     ap.add_argument("--other-steps", type=int, default=10, help="timed replays of each `other_workloads` leg")
@@ -248,7 +249,7 @@ def main_dualpath(a, comm=None):
     import copy
     from fqss_amd.data import synth_batch
     from fqss_amd.kernels import dp_chunks
-    from fqss_amd.parallel import Comm
+    from fqss_amd.parallel import Comm, local_device
     from fqss_amd.quantization.qat.models.load_model import create_model, quantize_model
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
     from fqss_amd.runtime import KDTrainStep
@@ -257,7 +258,7 @@ def main_dualpath(a, comm=None):
     leg = comm is not None
     comm = comm or Comm.from_env("cuda")
     assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
-    ldev = comm.local_rank % max(1, torch.cuda.device_count())
+    ldev = local_device(comm.local_rank)
     torch.cuda.set_device(ldev)
     dev = torch.device("cuda", ldev)
     torch.manual_seed(0)                                    # same init on every rank
@@ -406,7 +407,7 @@ def main_htdemucs(a, comm=None):
     fwd + solver loss + bwd (+ all-reduce) + Adam (htdemucs.yaml: lr 3e-4, no clipping), same timing protocol as cfg 2; `comm`: as
     main_dualpath"""
     import copy
-    from fqss_amd.parallel import Comm
+    from fqss_amd.parallel import Comm, local_device
     from fqss_amd.quantization.qat.models.load_model import quantize_model
     from fqss_amd.quantization.qat.models.htdemucsq import HTDemucsQ
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
@@ -414,7 +415,7 @@ def main_htdemucs(a, comm=None):
     leg = comm is not None
     comm = comm or Comm.from_env("cuda")
     assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
-    ldev = comm.local_rank % max(1, torch.cuda.device_count())
+    ldev = local_device(comm.local_rank)
     torch.cuda.set_device(ldev)
     dev = torch.device("cuda", ldev)
     torch.manual_seed(0)
@@ -516,6 +517,82 @@ def main_infer(a):
                       "out_rms": round(float(y.pow(2).mean().sqrt()), 6)}), flush=True)
 
 
+def exchange_report(step, comm, ldev, run_step, it, reps=10):
+    """the `dist` object of the JSON line: what the gradient exchange ran on and what it cost.  Every rank runs
+    `reps` more replays (outside the timed region) with two timing events around the optimizer's wait for the communication stream:
+    exposed_comm_ms = (all exchanges joined) - (end of the last backward segment), the MAX over ranks of each rank's median.
+    Reference: DDP's bucketed all-reduce under pl.Trainer(strategy="ddp") (asteroid_librimix_trainer.py:125-135), distrib.py:30-59."""
+    import torch.distributed as dist
+    prop = torch.cuda.get_device_properties(ldev)
+    mine = {"rank": comm.rank, "local_rank": comm.local_rank, "device": ldev, "name": prop.name,
+            "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", ""))[:18]}
+    nseg = len(step._graphs[0]) if step._graphs is not None else 1
+    segs = step.segments if (step.segments is not None and nseg > 1) else [(0, step.arena.numel)]
+    info = {"backend": comm.backend if comm.active else None, "world": comm.world,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if comm.active and comm.backend == "nccl" else None,
+            "buckets_MB": [round(4e-6 * (hi - lo), 3) for lo, hi in segs][::-1],        # in exchange order (the network's end first)
+            "exposed_comm_ms": 0.0, "devices": [mine]}
+    if not comm.active or step._graphs is None:
+        return info
+    step.comm_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ms = []
+    for _ in range(reps):
+        run_step(it)
+        it += 1
+        torch.cuda.synchronize()
+        ms.append(step.comm_events[0].elapsed_time(step.comm_events[1]))
+    step.comm_events = None
+    t = torch.tensor([sorted(ms)[len(ms) // 2]], device=torch.device("cuda", ldev), dtype=torch.float64)
+    comm.all_reduce_max(t)
+    info["exposed_comm_ms"] = round(t.item(), 4)
+    devs = [None] * comm.world
+    dist.all_gather_object(devs, mine)
+    info["devices"] = devs
+    if len({(d["pci_bus_id"], d["uuid"], d["device"]) for d in devs}) != comm.world:
+        info["warning"] = "two ranks report the same device"
+    return info
+
+
+def deterministic_leg(a, dev, steps=10, warmup=5):
+    """`deterministic_ms_per_step`: the same cfg-2 step under FQSS_DETERMINISTIC=1 -- every fp32 gradient atomic an
+    integer atomic on a fixed-point shadow, one rounding pass per arena (kernels.DetMode) -- on a fresh model, 10 timed replays"""
+    import gc
+    from fqss_amd import kernels as K
+    from fqss_amd.data import synth_batch
+    from fqss_amd.runtime import KDTrainStep
+    from fqss_amd.smoke import build_pair
+    prev = os.environ.get("FQSS_DETERMINISTIC")
+    os.environ["FQSS_DETERMINISTIC"] = "1"
+    try:
+        model, fmodel = build_pair(dev, 0, n_spks=2, kernel_size=16, stride=8)
+        X = [synth_batch(B_PER_GPU, T_SAMPLES, seed=100 + 100 * i, device=dev) for i in range(2)]
+        step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0, teacher_ahead=not a.no_teacher_ahead)
+        assert step.det is not None
+        step(*X[0])
+        with torch.no_grad():
+            for _ in range(49):
+                model(X[0][0])
+        step(*X[0])
+        step.capture(*X[0])
+        for it in range(warmup):
+            step(*X[it & 1], x_next=X[(it + 1) & 1][0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(warmup, warmup + steps):
+            step(*X[it & 1], x_next=X[(it + 1) & 1][0])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return {"deterministic_ms_per_step": round(ms, 3), "deterministic_steps": steps}
+    finally:
+        K.DetMode.off()
+        if prev is None:
+            os.environ.pop("FQSS_DETERMINISTIC", None)
+        else:
+            os.environ["FQSS_DETERMINISTIC"] = prev
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 def main():
     a = parse()
     # `python bench.py --gpus N` on its own (no torch.distributed.run around it): start the N ranks here, as the reference's entry points
@@ -533,14 +610,14 @@ def main():
     if a.workload != "cfg2":
         return main_dualpath(a)
     from fqss_amd.data import synth_batch
-    from fqss_amd.parallel import Comm
+    from fqss_amd.parallel import Comm, local_device
     from fqss_amd.quantization.qat.qat_quant import GradientActivationFakeQuantize
     from fqss_amd.runtime import KDTrainStep
     from fqss_amd.smoke import build_pair
 
     comm = Comm.from_env("cuda")
     assert comm.world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={comm.world}"
-    ldev = comm.local_rank % max(1, torch.cuda.device_count())
+    ldev = local_device(comm.local_rank)
     torch.cuda.set_device(ldev)
     dev = torch.device("cuda", ldev)
 
@@ -591,6 +668,7 @@ def main():
     dt = dt.item()
     sisdr = r["sisdr"].mean().reshape(1).double()
     comm.all_reduce_sum(sisdr)
+    dist_info = exchange_report(step, comm, ldev, lambda i: step(X[i & 1], TG[i & 1], x_next=X[(i + 1) & 1]), it)
 
     if comm.rank == 0:
         ms = dt / a.steps * 1e3
@@ -608,9 +686,12 @@ def main():
             "step_algorithmic_GB": 74.8,
             "step_algorithmic_frac_of_hbm_peak": round(74.8 / (ms * 1e-3) / HBM_PEAK_GBS, 4),
         }
+        out["dist"] = dist_info
         # ... and the bytes this build actually has to move (every kernel's operands read once / results written once at their real width)
         out["roofline"], out["roofline_other_kernels"], step = dominant_kernel_roofline(dev, ms)
         out.update(step)
+        if comm.world == 1 and not a.no_det_leg and not a.no_graph:
+            out.update(deterministic_leg(a, dev))
         if comm.world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_threads)
         if comm.world == 1 and not a.no_other_workloads:

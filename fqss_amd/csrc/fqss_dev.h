@@ -243,14 +243,14 @@ __device__ __forceinline__ void code_stats4(unsigned int word, unsigned int& s, 
 // this header: it then owns a copy of the control block and registers its setter (fqss_set_deterministic reaches every copy).
 constexpr int kDetSlots = 3;             // 0: the parameter-gradient arena, 1: the dL/dW_q arena of runtime.QuantTables, 2: temporaries
 struct DetCtl { long long* shadow[kDetSlots]; const float* base[kDetSlots]; long long n[kDetSlots]; };
-typedef void (*det_setter_t)(const DetCtl*);
+typedef int (*det_setter_t)(const DetCtl*);      // 0 or the hipError_t of the copy into that TU's control block
 void det_register(det_setter_t fn);      // train_ops.hip
 #if defined(__HIPCC__) && defined(FQSS_USES_GRAD_ADD)
 static __device__ DetCtl d_det_ctl;
 namespace {
 struct DetRegistrar {
     DetRegistrar() {
-        det_register([](const DetCtl* c) { (void)hipMemcpyToSymbol(HIP_SYMBOL(d_det_ctl), c, sizeof(DetCtl)); });
+        det_register([](const DetCtl* c) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_det_ctl), c, sizeof(DetCtl)); });
     }
 } det_registrar_;
 }  // namespace

@@ -687,6 +687,7 @@ extern "C" int fqss_qrow_bwd_w_group(const FqssRowWgradJob* jobs, int njobs, fqs
         FQSS_REQUIRE(f.Ci % 4 == 0 && f.Co % 4 == 0 && f.ld_gz % 4 == 0 && f.ld_xc % 4 == 0 && aligned16(f.gz) && ((uintptr_t)f.xc & 3) == 0,
                      "coded wgrad: Ci, Co and the row strides must be multiples of 4, operands aligned");
     }
+    FQSS_REQUIRE(njobs <= 1024, "at most 1024 jobs per call (the per-shape index list): flush the queue more often");
     // one launch per tile shape (the rule of launch_gemm_x3q for split-K weight gradients) and per 32 jobs
     for (int shape = 0; shape < 4; ++shape) {
         const int mi = (shape & 1) ? 2 : 1, ni = (shape & 2) ? 2 : 1;

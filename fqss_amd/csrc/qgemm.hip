@@ -919,8 +919,14 @@ static_assert(sizeof(WGroupArgs) <= 4096, "the job table travels in the kernel a
 // (s_nop 1: see store16 in fqss_dev.h -- the wait states behind a > 8-byte store that the compiler cannot insert for an asm statement;
 //  without them the NEXT slab address, computed into the registers that held this store's data, was written to the slab in place of
 //  the data's first dwords -- 1e31-sized "gradients" in a 16-lane pattern, whenever the memory pipe was slow to fetch the store data)
+// (FQSS_NO_STORE_NOP: the pre-fix form, for tools/r06_store_hazard.sh only -- it proves that the regression test
+//  tests/test_gpu_kernels.py::test_grouped_weight_gradients_beside_a_memory_hog fails on the hazard; never defined in the product build)
 __device__ __forceinline__ void st16_sc1(float* p, const f32x4& v) {
+#ifdef FQSS_NO_STORE_NOP
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#else
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#endif
 }
 __device__ __forceinline__ void ld16_sc1(f32x4& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory"); }
 

@@ -386,7 +386,13 @@ extern "C" int fqss_set_deterministic(int slot, const float* grad_base, int64_t 
     g_det_ctl.base[slot] = shadow ? grad_base : nullptr;
     g_det_ctl.n[slot] = shadow ? (long long)n : 0;
     if (hipDeviceSynchronize() != hipSuccess) return launch_status("fqss_set_deterministic");     // no kernel may be reading the old block
-    for (det_setter_t fn : det_setters()) fn(&g_det_ctl);
+    for (det_setter_t fn : det_setters()) {
+        const int rc = fn(&g_det_ctl);
+        if (rc != 0) {      // a TU still on the old control block would mix float and integer atomics on one arena: refuse loudly
+            set_error("fqss_set_deterministic: hipMemcpyToSymbol: %s", hipGetErrorString((hipError_t)rc));
+            return FQSS_ELAUNCH;
+        }
+    }
     return launch_status("fqss_set_deterministic");
 }
 

@@ -551,6 +551,14 @@ class WgradQueue:
         if gz2 is not None:
             gz2, ld2 = _aligned_grad(gz2)
         assert gw.is_contiguous()
+        if any(j[5].data_ptr() == gw.data_ptr() for j in self.jobs):
+            # a layer applied twice in one backward: the grouped launch owns each gw exclusively (no atomics), so the second
+            # contribution takes the per-layer kernel right away (its adds are atomic and commute with the queued launch)
+            if gz2 is not None:
+                qpw_bwd_w2(gz1, gz2, xc, qmin_x, qmax_x, gw)
+            else:
+                qpw_bwd_w(gz1, xc, qmin_x, qmax_x, gw)
+            return
         self.jobs.append((gz1, gz2, xc, qmin_x, qmax_x, gw, ld1, ld2))
 
     def flush(self):
@@ -2063,7 +2071,10 @@ class RowWgradQueue:
         for j, (gz, xc, lo, hi, gw, gb, R, Ci, Co, ld_gz, ld_xc) in zip(arr, self.jobs):
             j.gz, j.xc, j.qmin_x, j.qmax_x, j.gw, j.gbias = _p(gz), _p(xc), _p(lo), _p(hi), _p(gw), _p(gb)
             j.R, j.Ci, j.Co, j.ld_gz, j.ld_xc, j.ld_gw = R, Ci, Co, ld_gz, ld_xc, Ci
-        _lib.call("fqss_qrow_bwd_w_group", arr, n, _stream())
+        for n0 in range(0, n, 1024):            # (the entry point takes at most 1024 jobs: its per-shape index list)
+            m = min(1024, n - n0)
+            sub = (_lib.FqssRowWgradJob * m).from_buffer(arr, n0 * _C.sizeof(_lib.FqssRowWgradJob))
+            _lib.call("fqss_qrow_bwd_w_group", sub, m, _stream())
         self.jobs = []
 
 

@@ -14,6 +14,19 @@ import torch
 import torch.distributed as dist
 
 
+def local_device(local_rank):
+    """index of the GPU rank `local_rank` of this node computes on: its own.  A launch with more ranks than visible devices is refused --
+    two RCCL ranks on one card cannot form a communicator, and silently doubling up would report a node's throughput from half its GPUs
+    -- except under FQSS_DIST_BACKEND=gloo, where the tests deliberately run two ranks on GPU 0 (tests/test_gpu_ddp.py)."""
+    n = torch.cuda.device_count()
+    if local_rank < n:
+        return local_rank
+    if n > 0 and os.environ.get("FQSS_DIST_BACKEND") == "gloo":
+        return local_rank % n
+    raise RuntimeError(f"fqss_amd.parallel: LOCAL_RANK {local_rank} but {n} visible GPU(s): one rank per GPU "
+                       "(check --gpus / HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)")
+
+
 class CommError(RuntimeError):
     """a collective of the gradient / range exchange failed or timed out on this rank ("When the exchange fails")"""
 
@@ -50,7 +63,7 @@ class Comm:
             # RCCL ("nccl" on ROCm) on GPUs; FQSS_DIST_BACKEND=gloo lets several ranks share one GPU in tests
             backend = os.environ.get("FQSS_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
             if device_type == "cuda":
-                torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+                torch.cuda.set_device(local_device(local))
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
             timeout = datetime.timedelta(seconds=float(os.environ.get("FQSS_DIST_TIMEOUT_S", "600")))
             dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)

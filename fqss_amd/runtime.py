@@ -468,6 +468,7 @@ class KDTrainStep:
                 self.segments.append((min(a for a, _ in spans), max(b for _, b in spans)))
             assert all(self.segments[k][1] == self.segments[k + 1][0] for k in range(len(self.segments) - 1)), self.segments
         self._cstream = None
+        self.comm_events = None     # bench.py: (end of the last backward segment, all exchanges joined) as timing events of a replay
         for p in fmodel.parameters():
             p.requires_grad_(False)
         self.teacher = TeacherRunner(fmodel)     # fused inference chain for the frozen float teacher
@@ -508,8 +509,17 @@ class KDTrainStep:
         ranges (the captured clip+Adam launch does not activate parameters)"""
         if self.use_graph and self._graphs is None and self._eager_q >= 1 and self.can_capture():
             self.capture(x, tgt, warmup=0)
-        elif self._graphs is not None and (x.shape != self._sx.shape or tgt.shape != self._st.shape):
-            self._graphs = None          # a batch of another shape: back to eager launches
+        elif self._graphs is not None and not self._fits(x, tgt):
+            # a batch of another shape (a file-backed loader's short utterance) runs eagerly (__call__); only when the NEW shape stays
+            # (three steps in a row) are the graphs dropped and recorded again -- a capture costs seconds, an eager step milliseconds
+            self._odd = getattr(self, "_odd", 0) + 1
+            if self._odd >= 3:
+                self._graphs, self._odd = None, 0
+        elif self._graphs is not None:
+            self._odd = 0
+
+    def _fits(self, x, tgt):
+        return x.shape == self._sx.shape and tgt.shape == self._st.shape
 
     # ---- the two halves of a step -----------------------------------------------------------
     def _take_ahead(self, x):
@@ -688,8 +698,8 @@ class KDTrainStep:
     def __call__(self, x, tgt, x_next=None):
         """x_next (teacher_ahead=True only): the mixture tensor the NEXT call will be given -- the same tensor object, unmodified"""
         self._maybe_sync_ranges()
-        if self._graphs is not None and self.use_graph:
-            return self.replay(x, tgt, x_next)
+        if self._graphs is not None and self.use_graph and self._fits(x, tgt):
+            return self.replay(x, tgt, x_next if (x_next is not None and x_next.shape == x.shape) else None)
         self.last = self._step_eager(x, tgt, x_next)
         self._optimize()
         if self.tables is not None or (not self.batched_quantizers and self.can_capture()):
@@ -698,6 +708,13 @@ class KDTrainStep:
 
     # ---- hipGraph capture -------------------------------------------------------------------
     def capture(self, x, tgt, warmup=2):
+        # a prefetching loader's reader thread allocates and launches on its own stream: not while this thread records a graph (the
+        # default capture mode faults on another thread's hipMalloc / event calls)
+        from .loader import DEVICE_WORK_LOCK
+        with DEVICE_WORK_LOCK:
+            return self._capture(x, tgt, warmup)
+
+    def _capture(self, x, tgt, warmup=2):
         from .quantization.qat.qat_quant import GradientActivationFakeQuantize, GradientWeightFakeQuantize
         for m in self.model.modules():
             if isinstance(m, GradientActivationFakeQuantize):
@@ -802,10 +819,15 @@ class KDTrainStep:
         """first half of a captured step (fwd + loss + bwd, gradients exchanged); the caller then calls replay_optimize() or skips"""
         self._stage(x, tgt, x_next)
         graphs = self._graphs[0]
+        ev = self.comm_events
         for k, gk in enumerate(graphs):
             gk.replay()
+            if ev is not None and k == len(graphs) - 1:
+                ev[0].record()                  # the backward is over: whatever the optimizer still waits for is exposed exchange time
             self._reduce_segment(k, len(graphs))
         self._join_reduces()
+        if ev is not None:
+            ev[1].record()
         return self.last
 
     def replay_optimize(self):

@@ -58,25 +58,30 @@ class LibriMix:
         else:
             self.seg_len = None
         self.n_src = n_src
+        # the columns a batch needs, as plain lists: `df.iloc[idx]` builds a Series per item (~100 us), which a 13 ms step notices
+        cols = ["length", "mixture_path"] + [f"source_{i + 1}_path" for i in range(n_src) if f"source_{i + 1}_path" in self.df] + \
+               (["noise_path"] if "noise_path" in self.df else [])
+        self._col = {k: self.df[k].tolist() for k in cols}
+        self._clean_mix = self.df_clean["mixture_path"].tolist() if task == "enh_both" else None
 
     def __len__(self):
         return len(self.df)
 
     # ---- host side: which clips, which segment -------------------------------------------------------------------------
     def _read_item(self, idx):
-        row = self.df.iloc[idx]
+        col = self._col
         if self.seg_len is not None:
-            start = random.randint(0, row["length"] - self.seg_len)
+            start = random.randint(0, int(col["length"][idx]) - self.seg_len)
             stop = start + self.seg_len
         else:
             start, stop = 0, None
-        noise = read_wav(row["noise_path"], start, stop) if self.task in ("enh_single", "sep_noisy") else None
+        noise = read_wav(col["noise_path"][idx], start, stop) if self.task in ("enh_single", "sep_noisy") else None
         if self.task == "enh_both":
-            sources = [read_wav(self.df_clean.iloc[idx]["mixture_path"], start, stop)]
+            sources = [read_wav(self._clean_mix[idx], start, stop)]
         else:
-            sources = [read_wav(row[f"source_{i + 1}_path"], start, stop) for i in range(self.n_src)]
+            sources = [read_wav(col[f"source_{i + 1}_path"][idx], start, stop) for i in range(self.n_src)]
         augment = bool(self.augmentation_cfg) and np.random.uniform() < self.augmentation_cfg.get("prob", 1)
-        mixture = None if augment else read_wav(row["mixture_path"], start, stop)
+        mixture = None if augment else read_wav(col["mixture_path"][idx], start, stop)
         # the item's SNR draws come right behind its probability draw, as inside the reference's __getitem__ (:139-153 calling
         # train_utils.py:30-52): prob_i, snr_i (two for a 3-mix), noise_snr_i -- so a seeded np.random stream is consumed in the
         # reference's order for any batch size
@@ -97,8 +102,23 @@ class LibriMix:
         return d
 
     # ---- device side: resample + mix -----------------------------------------------------------------------------------
-    def _to_device(self, clips):
-        x = torch.from_numpy(np.stack(clips)).to(self.device)
+    def stage_elems(self, batch_size):
+        """float32 elements of the pinned staging buffer a batch of `batch_size` items needs (0: variable-length items, no staging)"""
+        per_item = (1 if self.task == "enh_both" else self.n_src) + 2          # sources + noise + mixture
+        return 0 if self.seg_len is None else batch_size * per_item * self.seg_len
+
+    def _to_device(self, clips, stage=None):
+        n, L = len(clips), len(clips[0])
+        if stage is not None and stage.numel() >= n * L:
+            # through the caller's pinned buffer: the host->device copy is asynchronous on the current stream (a prefetching reader's
+            # side stream), the buffer is the caller's to keep alive until that copy has run
+            host = stage[:n * L].view(n, L)
+            hv = host.numpy()
+            for i, c in enumerate(clips):
+                hv[i] = c
+            x = host.to(self.device, non_blocking=True)
+        else:
+            x = torch.from_numpy(np.stack(clips)).to(self.device)
         if self.resample != 1:
             x = K.resample(x, self.sample_rate, int(self.resample * self.sample_rate))
         return x
@@ -119,8 +139,9 @@ class LibriMix:
             mix = generate_mix_noise(mix, noise, col(-1))
         return mix
 
-    def batch(self, indices):
-        """(mixtures [B, 1, T'], sources [B, n_src, T']) on the device: every clip of the batch is resampled by one launch"""
+    def batch(self, indices, stage=None):
+        """(mixtures [B, 1, T'], sources [B, n_src, T']) on the device: every clip of the batch is resampled by one launch, enqueued
+        on the calling thread's current stream; stage: an optional pinned float32 buffer (>= stage_elems(B)) for the upload"""
         items = [self._read_item(i) for i in indices]
         if len({len(it[0][0]) for it in items}) != 1:
             raise ValueError("batch(): items of different lengths (segment=None): use one item per batch")
@@ -131,14 +152,18 @@ class LibriMix:
             clips += [it[1] for it in items]
         plain = [i for i, it in enumerate(items) if not it[3]]
         clips += [items[i][2] for i in plain]
-        x = self._to_device(clips)
+        x = self._to_device(clips, stage)
         sources = x[:B * ns].reshape(B, ns, -1)
         noise = x[B * ns:B * ns + B] if has_noise else None
-        mixture = torch.empty(B, sources.shape[-1], device=x.device)
-        if plain:
-            mixture[plain] = x[B * ns + (B if has_noise else 0):]
+        rest = x[B * ns + (B if has_noise else 0):]
         aug = [i for i, it in enumerate(items) if it[3]]
-        if aug:
+        if not aug:                                   # every mixture comes from its file: no gather, no index tensors
+            return rest.unsqueeze(1), sources
+        if not plain:
+            mixture = self._augment(sources, noise, [it[4] for it in items])
+        else:
+            mixture = torch.empty(B, sources.shape[-1], device=x.device)
+            mixture[plain] = rest
             mixture[aug] = self._augment(sources[aug], noise[aug] if has_noise else None, [items[i][4] for i in aug])
         return mixture.unsqueeze(1), sources
 

@@ -13,14 +13,15 @@ from .wsdr import KDObjective, si_sdr
 class System:
     default_monitor = "val_loss"
 
-    def __init__(self, model, fmodel, kd_lambda, lr=1e-3, clip=5.0, comm=None, betas=(0.9, 0.999)):
+    def __init__(self, model, fmodel, kd_lambda, lr=1e-3, clip=5.0, comm=None, betas=(0.9, 0.999), teacher_ahead=False):
         # kd_lambda = 0: the reference trains on the plain PIT SI-SDR loss without the teacher (mysystem.py:153-156); KDTrainStep then
         # runs fqss_pit_sisdr_loss and never calls the teacher
         self.model = model
         self.fmodel = fmodel
         self.kd_lambda = kd_lambda
         self.objective = KDObjective(kd_lambda)
-        self.stepper = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip, comm=comm, betas=betas)
+        self.stepper = KDTrainStep(model, fmodel, kd_lambda=kd_lambda, lr=lr, clip=clip, comm=comm, betas=betas,
+                                   teacher_ahead=teacher_ahead)
         self.logged = {}
 
     def forward(self, *a, **k):
@@ -38,10 +39,11 @@ class System:
             return loss, kd_db
         return -si_sdr(est, targets).mean(), 0
 
-    def training_step(self, batch, batch_nb):
-        """one optimiser step through the fused runtime; logs `loss` / `kd_loss` like the reference"""
+    def training_step(self, batch, batch_nb, x_next=None):
+        """one optimiser step through the fused runtime; logs `loss` / `kd_loss` like the reference.  x_next: the mixture of the
+        NEXT call (a prefetching loader has it on the device already): the teacher starts on it beside this step"""
         self.stepper.maybe_capture(*batch)      # quantizing phase: the step replays as hipGraphs from here on
-        r = self.stepper(*batch)
+        r = self.stepper(*batch, x_next=x_next if self.stepper.teacher_ahead else None)
         self.logged.update(loss=r["loss"], kd_loss=r["kd_loss"])
         return r["loss"]
 

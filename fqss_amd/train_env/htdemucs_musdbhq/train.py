@@ -21,7 +21,7 @@ import sys
 import torch
 import yaml
 
-from ...parallel import Comm
+from ...parallel import Comm, local_device
 from ...quantization.qat.models.load_model import quantize_model
 from ...quantization.qat.models.htdemucsq import HTDemucsQ
 from ...runtime import KDTrainStep
@@ -132,7 +132,7 @@ def get_solver(conf):
     if device != "cuda" or not torch.cuda.is_available():
         raise RuntimeError("the htdemucs env of this build trains on ROCm devices only (no CPU fallback; oracle/ is the CPU checker)")
     comm = Comm.from_env("cuda")
-    torch.cuda.set_device(comm.local_rank % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(local_device(comm.local_rank))
     dev = torch.device("cuda", torch.cuda.current_device())
     set_seed(conf.get("seed", 42))
     mc = conf["model_cfg"]

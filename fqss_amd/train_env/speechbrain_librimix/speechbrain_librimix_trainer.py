@@ -15,7 +15,9 @@ plain mappings and ignored.  Step semantics kept:
     decision is taken collectively so that every rank applies or skips the same update;
   * clip_grad_norm, Adam(lr), `ReduceLROnPlateau(factor, patience, dont_halve_until_epoch)` on the validation loss (restated
     from speechbrain 0.5.14's published behaviour: third-party, parity unpinned).
-Data: `dataset_cfg.name: synthetic` (seeded 2-speaker mixtures); the LibriMix CSV reader is the reference's CPU data side."""
+Data: `dataset_cfg.name: librimix` is the reference's configuration (configs/sepformer_2spks_8k.yaml:27-39): `prepare_librimix` writes
+the CSVs into `save_folder`, `SbLibriMix` (prepare_data.py) serves whole utterances with the train-time speed perturbation / re-mix /
+random cut of `compute_forward` on the device, a batch ahead of the step (fqss_amd/loader.py); `synthetic`: seeded 2-speaker mixtures."""
 import json
 import os
 import re
@@ -24,6 +26,7 @@ import torch
 import yaml
 
 from ...data import synth_batch
+from ...loader import Prefetcher, epoch_batches
 from ...parallel import Comm
 from ...quantization.qat.models.load_model import create_model, quantize_model
 from ...runtime import KDTrainStep
@@ -101,14 +104,58 @@ class ReduceLROnPlateau:
         return new
 
 
-def _batches(hp, comm, device, split):
-    ds = hp["dataset_cfg"]
-    if ds.get("name") != "synthetic":
-        raise NotImplementedError("only dataset_cfg.name == 'synthetic' is built in; the LibriMix reader is a later §8(f) row")
-    T = int(hp.get("training_signal_len", 32000))
-    n = int(ds.get("steps_per_epoch" if split == "train" else "val_steps", 20 if split == "train" else 4))
-    for i in range(n):
-        yield synth_batch(int(hp["batch_size"]), T, seed=(0 if split == "train" else 10_000) + i * comm.world + comm.rank, device=device)
+class _Data:
+    """train / valid batches per epoch.  librimix: `dataio_prep` + `fit()`'s loaders (:482-573, 660-668; dataloader_opts: batch_size,
+    no shuffle key -> speechbrain's train loader keeps file order unless `shuffle` is set; DistributedSampler shares under DDP)"""
+
+    def __init__(self, hp, comm, device):
+        self.hp, self.comm, self.device = hp, comm, device
+        ds = hp["dataset_cfg"]
+        self.synthetic = ds.get("name") == "synthetic"
+        self.loader_wait_s = 0.0
+        if self.synthetic:
+            return
+        if ds.get("name") != "librimix":
+            raise NotImplementedError(f"speechbrain env: dataset_cfg.name {ds.get('name')!r} (librimix | synthetic)")
+        from .prepare_data import SbLibriMix, prepare_librimix
+        n_spks, noisy = int(hp.get("num_spks", hp["model_cfg"].get("n_src", 2))), bool(ds.get("noisy", False))
+        save = hp.get("save_folder") or os.path.join(hp["work_dir"], "save")
+        if comm.rank == 0:                      # run_on_main(prepare_librimix, ...) (:601-610)
+            prepare_librimix(ds["data_folder"], save, n_spks=n_spks, skip_prep=ds.get("skip_prep", False), librimix_addnoise=noisy)
+        comm.barrier()
+        sp = hp.get("speedperturb") or {}
+        common = dict(n_src=n_spks, sample_rate=ds.get("sample_rate", 16000), resample=ds.get("resample", 1), noisy=noisy, device=device,
+                      data_root=ds["data_folder"])
+        self.sets = {
+            "train": SbLibriMix(os.path.join(save, f"libri{n_spks}mix_train-360.csv"), train=True, speeds=sp.get("speeds", (95, 100, 105)),
+                                use_speedperturb=bool(hp.get("use_speedperturb", False)), perturb_prob=sp.get("perturb_prob", 1.0),
+                                limit_training_signal_len=bool(hp.get("limit_training_signal_len", False)),
+                                training_signal_len=int(hp.get("training_signal_len", 32000)), **common),
+            "val": SbLibriMix(os.path.join(save, f"libri{n_spks}mix_dev.csv"), **common)}
+        for k in ("use_wavedrop", "use_rand_shift"):
+            if hp.get(k):
+                raise NotImplementedError(f"speechbrain env: {k} (off in every shipped config) has no device kernel")
+
+    def batches(self, split, epoch):
+        hp, comm = self.hp, self.comm
+        ds = hp["dataset_cfg"]
+        if self.synthetic:
+            T = int(hp.get("training_signal_len", 32000))
+            n = int(ds.get("steps_per_epoch" if split == "train" else "val_steps", 20 if split == "train" else 4))
+            for i in range(n):
+                yield synth_batch(int(hp["batch_size"]), T, seed=(0 if split == "train" else 10_000) + i * comm.world + comm.rank,
+                                  device=self.device)
+            return
+        opts = hp.get("dataloader_opts") or {}
+        bs = int(opts.get("batch_size", hp["batch_size"]))
+        batches = epoch_batches(len(self.sets[split]), bs, shuffle=bool(opts.get("shuffle", False)) and split == "train", drop_last=False,
+                                rank=comm.rank, world=comm.world, seed=hp.get("seed", 0), epoch=epoch)
+        limit = ds.get("steps_per_epoch" if split == "train" else "val_steps")        # optional cap (smoke runs), not a reference key
+        if limit is not None:
+            batches = batches[:int(limit)]
+        pf = Prefetcher(self.sets[split], batches, self.device, depth=int(hp.get("prefetch_depth", 2)))
+        yield from pf
+        self.loader_wait_s += pf.wait_s
 
 
 def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
@@ -143,11 +190,13 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
     sched = ReduceLROnPlateau(sch.get("factor", 0.5), sch.get("patience", 2), sch.get("dont_halve_until_epoch", 65))
     history, best, nonfinite = [], float("inf"), 0
     flag = torch.zeros(1, device=dev)
+    data = _Data(hp, comm, dev)
     for epoch in range(1, int(hp["N_epochs"]) + 1):
         losses = []
-        for x, tgt in _batches(hp, comm, dev, "train"):
+        for x, tgt in data.batches("train", epoch):
             step.maybe_capture(x, tgt)        # quantizing phase: both halves of the step replay as hipGraphs
-            graphed = step._graphs is not None
+            # (an utterance shorter than training_signal_len gives a batch of another shape: that step runs eagerly)
+            graphed = step._graphs is not None and x.shape == step._sx.shape
             step._maybe_sync_ranges()
             # fwd + loss + bwd with the gradient exchange of the data-parallel ranks (both forms all-reduce the flat gradient)
             r = step.replay_fwd_bwd(x, tgt) if graphed else step._step_eager(x, tgt)
@@ -166,7 +215,7 @@ def train(yml_path, local_rank=0, distributed_launch=False, device="cuda"):
                 nonfinite += 1
                 print(f"Warning: Loss is {r['loss'].item()}, skipping this sample! nonfinite_count={nonfinite}")
         with torch.no_grad():
-            val = torch.stack([-si_sdr(model(x), tgt).mean() for x, tgt in _batches(hp, comm, dev, "val")]).mean().reshape(1)
+            val = torch.stack([-si_sdr(model(x), tgt).mean() for x, tgt in data.batches("val", epoch)]).mean().reshape(1)
         comm.all_reduce_sum(val)
         val = val.item() / comm.world
         new_lr = sched(step.lr, epoch, val)

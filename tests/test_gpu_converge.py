@@ -76,6 +76,9 @@ def _gate(name, S, L, gl, first_n, gain_db, rule="mean", early_mult=3.0):
     early = slice(0, 50)
     spread_early = float(np.abs(ref[:, early] - ref[:, early].mean(0)).max())
     dev_early = float(np.abs(S[:, early] - ref[:, early].mean(0)).max())
+    k_dev = int(np.abs(S[:, early] - ref[:, early].mean(0)).max(0).argmax())
+    print(f"{name}: largest observer-phase deviation at step {k_dev}: reference SI-SDR there {np.round(ref[:, k_dev], 3)}, HIP {np.round(S[:, k_dev], 3)}; "
+          f"loss there: reference {np.round(ref_loss[:, k_dev], 4)}, HIP {np.round(L[:, k_dev], 4)}")
     assert dev_early <= max(0.1, early_mult * spread_early), (dev_early, spread_early)
     rng = lambda v: float(v.max() - v.min())
     tails, tail_ref = S[:, -50:].mean(1), ref[:, -50:].mean(1)
@@ -231,6 +234,40 @@ def test_full_size_convtasnet_at_lr_1e4_within_a_tenth_of_a_db(golden):
     # (the first steps sit at -32 .. -20 dB, where SI-SDR in dB magnifies fp32-level differences of the estimate: the reference's own
     #  four configurations spread by 0.47 dB there, the HIP runs by up to 1.35 from their mean -- 5 x the reference's spread allowed)
     _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0, early_mult=5.0)
+
+
+@pytest.mark.parametrize("which", ["lr 1e-3", "lr 1e-4"])
+def test_full_size_convtasnet_gates_in_deterministic_mode(golden, monkeypatch, which):
+    """the two full-size gates measured in the mode that has no noise -- FQSS_DETERMINISTIC=1 (every fp32 gradient
+    atomic an integer atomic on a fixed-point shadow: two runs of the stream are bit-identical, tools/r05_det_stream.py), ONE run each,
+    so the HIP set has no spread of its own to lend to the tolerance: rule "envelope" at the env's lr 1e-3 (every 50-step window no
+    further from the set of reference runs than they are from each other), rule "mean" at lr 1e-4 (|tail - reference mean| <= max(0.1 dB,
+    the reference's max - min, 3 standard errors of the reference mean))."""
+    from fqss_amd import kernels as K
+    from fqss_amd.runtime import KDTrainStep
+    from fqss_amd.smoke import build_pair
+    from tests.helpers_cfg1 import cfg1_fill
+    monkeypatch.setenv("FQSS_DETERMINISTIC", "1")
+    gl = golden("cfg1_train_long" if which == "lr 1e-3" else "cfg1_train_long_lr1e-4")
+    n, B, T, seed0 = int(gl["n_steps"]), int(gl["batch"]), int(gl["samples"]), int(gl["seed0"])
+    lr = 1e-3 if which == "lr 1e-3" else float(gl["lr"])
+
+    def make():
+        model, fmodel = build_pair("cuda", 0, n_spks=2, kernel_size=16, stride=8)
+        cfg1_fill(fmodel, "T.")
+        cfg1_fill(model, "S.")
+        step = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=lr, clip=5.0, teacher_ahead=True)
+        assert step.det is not None
+        return step
+
+    try:
+        S, L = _run_streams(make, 1, n, B, T, seed0)
+    finally:
+        K.DetMode.off()
+    if which == "lr 1e-3":
+        _gate("full-size convtasnet", S, L, gl, 10, 4.0, rule="envelope")
+    else:
+        _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0, early_mult=5.0)
 
 
 def test_tiny_sepformer_trains_to_the_reference_sisdr(golden):

@@ -226,3 +226,30 @@ def test_bench_starts_its_own_ranks(tmp_path):
     o = json.loads(lines[0])
     assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 16 and o["scaling"] == "weak"
     assert "4 backward segments" in o["config"]["launch"] and o["value"] > 0 and "roofline" in o
+    # what the exchange ran on and what it cost: backend, world, one entry per rank, the four bucket sizes in
+    # exchange order, the exposed exchange time from rank events
+    d = o["dist"]
+    assert d["backend"] == "gloo" and d["world"] == 2 and d["rccl_version"] is None and len(d["devices"]) == 2
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and "warning" in d          # both ranks on GPU 0 here: the line says so
+    assert len(d["buckets_MB"]) == 4 and abs(sum(d["buckets_MB"]) - 20.6) < 0.5 and d["exposed_comm_ms"] >= 0.0
+
+
+def test_bench_over_rccl_on_every_visible_gpu(tmp_path):
+    """`python bench.py --gpus N` for N = the GPUs of this box over RCCL (backend "nccl"), N > 1 only: one rank per device, the JSON
+    line's `dist` object names N distinct devices and the RCCL version.  On this pool's one-GPU boxes the test skips; the driver's
+    8-GPU node runs it (its first sight of xGMI traffic).  Reference: pl.Trainer(strategy="ddp"), asteroid_librimix_trainer.py:125-135."""
+    import json
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one visible GPU: RCCL between devices cannot run here (world-1 RCCL: test_rccl_executes_the_bucketed_exchange_at_world_one)")
+    n = min(n, 6)                                # (the pool's process guard: at most 6 processes on the cards)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "FQSS_DIST_BACKEND")}
+    env.update(PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    o = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    d = o["dist"]
+    assert o["n_gpus"] == n and d["backend"] == "nccl" and d["rccl_version"] and d["world"] == n
+    assert len({x["device"] for x in d["devices"]}) == n and "warning" not in d
+    assert torch.isfinite(torch.tensor(o["loss_db"])) and o["value"] > 0

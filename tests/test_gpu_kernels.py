@@ -479,12 +479,61 @@ def test_grouped_weight_gradients(case):
         else:
             K.qpw_bwd_w(g1, xc, lo, hi, one)
         assert float((one.double() - got).norm()) <= 4e-6 * float(ref.norm()), (case, j)
-    # bad job lists fail loudly
-    with pytest.raises(_lib_error()):
-        q.push(jobs[0][0], jobs[0][1], jobs[0][2], lo, hi, runs[0][0])
-        q.push(jobs[0][0], jobs[0][1], jobs[0][2], lo, hi, runs[0][0])          # two jobs, one gw
+    # one gw pushed twice (a layer applied twice in one backward): the second contribution runs on the per-layer kernel at once, the
+    # sum is both (the queue used to refuse this at flush, the per-layer path always accumulated it)
+    twice = gws[0].clone()
+    q.push(jobs[0][0], jobs[0][1], jobs[0][2], lo, hi, twice)
+    q.push(jobs[0][0], jobs[0][1], jobs[0][2], lo, hi, twice)
+    assert len(q.jobs) == 1
+    q.flush()
+    torch.cuda.synchronize()
+    got2 = twice.double() - gws[0].double()
+    assert float((got2 - 2 * refs[0]).norm()) <= 4e-6 * float(refs[0].norm())
+
+
+def test_grouped_weight_gradients_beside_a_memory_hog():
+    """Deterministic kernel-level regression for the round-5 store hazard (the only other test of it is a two-process run
+    at rtol 2e-2 that fails only some of the time): k_qwgrad_group hands tiles cut by a team boundary over through slab slots written
+    with hand-written 16-byte stores (csrc/qgemm.hip st16_sc1).  Without the wait states behind such a store the NEXT slab address
+    landed in the slab in place of data whenever the memory pipe was slow to fetch the store data (profiles/r05_store_hazard.txt).
+    Here the grouped launch of a three-block backward segment (cfg-2 shapes) runs 30 times while
+    two other streams keep HBM saturated with 1 GB copies; the kernel uses no atomics, so every run must reproduce the bits of a run
+    on an idle GPU -- not a tolerance.  tools/r06_store_hazard.sh runs this very test against a library built WITHOUT the wait states (wide and narrow tiles: FQSS_WGRAD_WIDE
+    is read once per process)."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(2)
+    shapes = [(8, 128, 512, 0, 3999), (8, 512, 128, 128, 3999)] * 3
+    lo, hi = torch.tensor([-1.3], device=dev), torch.tensor([2.1], device=dev)
+    jobs = []
+    for (B, Ci, Co1, Co2, M) in shapes:
+        mk = lambda C: K.empty_act((B, C, M), dev).copy_((torch.randn(B, C, M, generator=g) * 1e-3).to(dev))
+        xc = K.empty_codes((B, Ci, M), dev)
+        xc.copy_(torch.randint(0, 256, (B, Ci, M), generator=g, dtype=torch.uint8).to(dev))
+        jobs.append((mk(Co1), mk(Co2) if Co2 else None, xc, Co1 + Co2, Ci))
+    q = K.WgradQueue()
+
+    def run():
+        outs = [torch.zeros(co, ci, device=dev) for *_, co, ci in jobs]
+        for (g1, g2, xc, _, _), gw in zip(jobs, outs):
+            q.push(g1, g2, xc, lo, hi, gw)
         q.flush()
-    q.jobs = []
+        return outs
+
+    alone = run()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(o).all() for o in alone)
+    src, dst = torch.empty(2, 1 << 28, device=dev), torch.empty(2, 1 << 28, device=dev)        # 2 x 1 GiB each way
+    hogs = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bad = 0
+    for rep in range(30):
+        for k, hs in enumerate(hogs):
+            with torch.cuda.stream(hs):
+                for _ in range(3):
+                    dst[k].copy_(src[k], non_blocking=True)
+        outs = run()
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(a, b)) for a, b in zip(alone, outs))
+    assert bad == 0, f"{bad} of {30 * len(jobs)} weight gradients differ from the idle-GPU run"
 
 
 def test_grouped_row_weight_gradients():
