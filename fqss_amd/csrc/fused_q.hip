@@ -917,9 +917,12 @@ struct DwGnBefore {
     double* gacc;                            // partial slots of its output quantizer (= this layer's input range)
 };
 
+#ifndef FQSS_DWB_WAVES
+#define FQSS_DWB_WAVES 1
+#endif
 template <int KT, bool GA = false, bool GB = false, int ACTC = -1>   // KT: taps known at compile time (3 on the training path) or 0: runtime K <= kTaps;
                                                                        // ACTC >= 0: the activation known at compile time (PReLU in the TCN blocks)
-__global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
+__global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ g,
                                                   float* __restrict__ gx, float* gw, int C, int M, int K, int dil, int pad,
                                                   int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope_p,
@@ -936,6 +939,35 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     const int row = blockIdx.x, c = row % C;
+    // a pass covers 4096 positions: 4 float4 groups per thread, ALL their loads issued before the first is consumed
+    // (the straight loop exposed one HBM round trip per group: PMC showed the waves parked 46 % of the time)
+    const uint8_t* xr = xc + (int64_t)row * ld_xc;
+    const float* gr = g + (int64_t)row * ld_g;
+    float4 gq[4];
+    unsigned int cw[4][NT];
+    bool inner[4];
+    auto issue_loads = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 1024 * i;
+            inner[i] = (m - pad >= 0) && (m + 3 + pad < M);
+            if (m < M) gq[i] = *reinterpret_cast<const float4*>(gr + m);
+            if (inner[i]) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+                    if (k < K) cw[i][k] = load_codes4_unaligned(xr + (m + k * dil - pad));
+            } else if (m < M) {   // row edge: clamped byte loads, requested with the rest
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+                    if (k < K) cw[i][k] = load_codes4_clamped(xr, m + k * dil - pad, M);
+            }
+        }
+    };
+#ifdef FQSS_DWB_EARLY
+    // the first pass' operands are requested BEFORE the hand-over prologues (coefficient sums, two barriers, the code tables): they
+    // depend on nothing computed there, and a workgroup lives ~20 us of which the prologue's 2-3 us then cover the HBM round trip
+    issue_loads(4 * (int)threadIdx.x);
+#endif
     QRange r2 = QRange{0.f, 1.f, 1.f};
     float scale2 = 0.f;
     if constexpr (GA) {
@@ -1000,8 +1032,6 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
         pw[k] = 0.0f;
     }
     const float bv = bias ? bias[c] : 0.0f;
-    const uint8_t* xr = xc + (int64_t)row * ld_xc;
-    const float* gr = g + (int64_t)row * ld_g;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
     // GB: the GroupNorm-input codes of this thread's first four phase-2 groups are requested NOW (4 registers): loaded inside that
     // loop they cost one exposed memory round trip per iteration of a workgroup that lives ~20 us
@@ -1013,27 +1043,12 @@ __global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc,
             if (4 * (int)threadIdx.x + 1024 * i < M) w0pre[i] = *reinterpret_cast<const unsigned int*>(x0p + 4 * threadIdx.x + 1024 * i);
     }
 
-    // a pass covers 4096 positions: 4 float4 groups per thread, ALL their loads issued before the first is consumed
-    // (the straight loop exposed one HBM round trip per group: PMC showed the waves parked 46 % of the time)
     for (int m0 = 4 * threadIdx.x; m0 < M; m0 += 4096) {
-        float4 gq[4];
-        unsigned int cw[4][NT];
-        bool inner[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 1024 * i;
-            inner[i] = (m - pad >= 0) && (m + 3 + pad < M);
-            if (m < M) gq[i] = *reinterpret_cast<const float4*>(gr + m);
-            if (inner[i]) {
-#pragma unroll
-                for (int k = 0; k < NT; ++k)
-                    if (k < K) cw[i][k] = load_codes4_unaligned(xr + (m + k * dil - pad));
-            } else if (m < M) {   // row edge: clamped byte loads, requested with the rest
-#pragma unroll
-                for (int k = 0; k < NT; ++k)
-                    if (k < K) cw[i][k] = load_codes4_clamped(xr, m + k * dil - pad, M);
-            }
-        }
+#ifdef FQSS_DWB_EARLY
+        if (m0 != 4 * (int)threadIdx.x) issue_loads(m0);
+#else
+        issue_loads(m0);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + 1024 * i;

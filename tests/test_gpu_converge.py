@@ -12,7 +12,8 @@ Sepformer; 0.12 over three configurations), while the six-run MEANS sit 0.05 / 0
 holds one HIP run to max(0.1 dB, the reference's max - min over three or four runs) therefore fails a few times in a hundred for no
 reason (it did: tiny Sepformer at 0.23 dB).  The gates below run the stream SEVERAL times and compare sets with sets:
 
-  * observer phase (deterministic up to summation order): every run, step for step, within max(0.1 dB, 3 x the reference's spread);
+  * observer phase (deterministic up to summation order): every run, step for step, within max(0.1 dB, 3 x the reference's spread)
+    on the steps where the reference's SI-SDR is above -20 dB, on the loss (max(0.01 dB, 3 x the reference's deviation)) below that;
   * rule "mean": |mean of the HIP tails - mean of the reference tails| <= max(0.1 dB, the reference's max - min, the HIP runs' max - min
     CAPPED at 1.5 x the reference's, three standard errors of the difference of the two means with the HIP variance capped alike) --
     for the SI-SDR tail (last 50 steps) and the loss tail.  Noise is a property to bound, not a tolerance to borrow (VERDICT r04
@@ -73,13 +74,30 @@ def _gate(name, S, L, gl, first_n, gain_db, rule="mean", early_mult=3.0):
     """S, L: [runs, steps] SI-SDR and loss of the HIP runs; gl: the reference fixture ([configurations, steps]); rules: module docstring"""
     ref, ref_loss = gl["sisdr"], gl["loss"]
     assert np.isfinite(S).all() and np.isfinite(L).all()
-    early = slice(0, 50)
-    spread_early = float(np.abs(ref[:, early] - ref[:, early].mean(0)).max())
-    dev_early = float(np.abs(S[:, early] - ref[:, early].mean(0)).max())
-    k_dev = int(np.abs(S[:, early] - ref[:, early].mean(0)).max(0).argmax())
-    print(f"{name}: largest observer-phase deviation at step {k_dev}: reference SI-SDR there {np.round(ref[:, k_dev], 3)}, HIP {np.round(S[:, k_dev], 3)}; "
-          f"loss there: reference {np.round(ref_loss[:, k_dev], 4)}, HIP {np.round(L[:, k_dev], 4)}")
+    # observer phase (steps 0-49: deterministic up to summation order).  SI-SDR in dB is compared where it is a measurement: below -20 dB
+    # the estimate holds < 1 % of the target's energy and the dB figure magnifies fp32-level differences of that sliver (full-size model at
+    # lr 1e-4, step 8: the reference's four configurations read -31.28 .. -31.79 dB while their LOSSES agree to 3e-4 relative) -- those
+    # steps are held to the loss instead (itself a dB figure: -10 log10 of the weighted SDR mix): |L - mean reference L| <= max(3 x the
+    # reference's own deviation, 0.01 dB = a tenth of the north_star's SI-SDR bar).  Calibration on the fixture itself, leave-one-out: a
+    # reference configuration sits up to 0.0043 dB from the mean of the other three on those steps (lr 1e-4), the HIP runs up to 0.0061
+    # from the mean of the four (profiles/r06_converge_gates.txt).  (Round 5 widened the dB rule to 5 x the reference's spread for that
+    # one test; this replaces it: 3 x everywhere, on the quantity that resolves.)
+    early = np.arange(50)
+    loud = ref[:, early].min(0) >= -20.0
+    ref_m, refl_m = ref[:, early].mean(0), ref_loss[:, early].mean(0)
+    spread_early = float(np.abs(ref[:, early] - ref_m)[:, loud].max()) if loud.any() else 0.0
+    dev_early = float(np.abs(S[:, early] - ref_m)[:, loud].max()) if loud.any() else 0.0
+    k_dev = int(np.where(loud, np.abs(S[:, early] - ref_m).max(0), -1.0).argmax())
+    print(f"{name}: observer phase: {int(loud.sum())} steps at >= -20 dB, largest SI-SDR deviation there {dev_early:.4f} dB at step {k_dev} "
+          f"(reference spread {spread_early:.4f}); reference SI-SDR at that step {np.round(ref[:, k_dev], 3)}, HIP {np.round(S[:, k_dev], 3)}")
     assert dev_early <= max(0.1, early_mult * spread_early), (dev_early, spread_early)
+    if (~loud).any():
+        dl_ref = np.abs(ref_loss[:, early] - refl_m).max(0)
+        dl = np.abs(L[:, early] - refl_m).max(0)
+        tol = np.maximum(3.0 * dl_ref, 0.01)
+        k_q = int(np.where(~loud, dl / tol, -1.0).argmax())
+        print(f"{name}: observer phase: {int((~loud).sum())} steps below -20 dB held to the loss: worst at step {k_q}: |dL| {dl[k_q]:.5f} of {tol[k_q]:.5f} allowed")
+        assert bool((dl <= tol)[~loud].all()), (k_q, dl[k_q], tol[k_q])
     rng = lambda v: float(v.max() - v.min())
     tails, tail_ref = S[:, -50:].mean(1), ref[:, -50:].mean(1)
     ltails, ltail_ref = L[:, -50:].mean(1), ref_loss[:, -50:].mean(1)
@@ -231,9 +249,7 @@ def test_full_size_convtasnet_at_lr_1e4_within_a_tenth_of_a_db(golden):
     S, L = _run_streams(make, 3, n, B, T, seed0)
     # (step 2 follows Adam's sign-like first update: 5.5e-5 measured here, 3e-5 at lr 1e-3)
     np.testing.assert_allclose(L[:, :2], np.broadcast_to(gl["loss"][0, :2], (3, 2)), rtol=1e-4)
-    # (the first steps sit at -32 .. -20 dB, where SI-SDR in dB magnifies fp32-level differences of the estimate: the reference's own
-    #  four configurations spread by 0.47 dB there, the HIP runs by up to 1.35 from their mean -- 5 x the reference's spread allowed)
-    _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0, early_mult=5.0)
+    _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0)
 
 
 @pytest.mark.parametrize("which", ["lr 1e-3", "lr 1e-4"])
@@ -267,7 +283,7 @@ def test_full_size_convtasnet_gates_in_deterministic_mode(golden, monkeypatch, w
     if which == "lr 1e-3":
         _gate("full-size convtasnet", S, L, gl, 10, 4.0, rule="envelope")
     else:
-        _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0, early_mult=5.0)
+        _gate("full-size convtasnet lr 1e-4", S, L, gl, 10, 4.0)
 
 
 def test_tiny_sepformer_trains_to_the_reference_sisdr(golden):
