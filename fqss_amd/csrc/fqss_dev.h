@@ -87,13 +87,47 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Sum over the 64 lanes of a wave on the DPP crossbar (round 6): six v_add with a lane-permuted source -- pairs, quads, half rows, rows
+// (quad_perm / row_half_mirror / row_mirror), then row 0 into 1 and 2 into 3 (row_bcast:15), then rows 0-1 into 3 (row_bcast:31).  The
+// total is valid in LANE 63 ONLY.  No LDS traffic and ~8-cycle steps, where __shfl_xor is a ds_bpermute_b32 round trip per step (the
+// cycle stamps of k_dwq_bwd put its two block reductions at 7 of the workgroup's 20 us, profiles/r06_dwb_stamps.txt).  A fixed tree:
+// the same bits every run; NOT the xor butterfly's association, so sums differ from the round-5 library's in the last bit.
+// All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK = 0xf, typename T>
+__device__ __forceinline__ T dpp_get(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, dpp_i32<CTRL, ROW_MASK>(__builtin_bit_cast(int, v)));
+    } else {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)dpp_i32<CTRL, ROW_MASK>((int)(unsigned)b), hi = (unsigned)dpp_i32<CTRL, ROW_MASK>((int)(unsigned)(b >> 32));
+        return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+    }
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum63(T v) {
+#ifdef FQSS_NO_DPP_SUMS
+    return wave_sum(v);
+#else
+    v += dpp_get<0xB1>(v);          // quad_perm:[1,0,3,2]
+    v += dpp_get<0x4E>(v);          // quad_perm:[2,3,0,1]
+    v += dpp_get<0x141>(v);         // row_half_mirror
+    v += dpp_get<0x140>(v);         // row_mirror: every lane of a 16-lane row holds the row's sum
+    v += dpp_get<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    v += dpp_get<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3
+    return v;
+#endif
+}
+
 // block-wide sum of N values per thread; result valid in thread 0.  smem: N * (blockDim/64) T's.
 template <typename T, int N>
 __device__ __forceinline__ void block_sum(T (&v)[N], T* smem) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
-    if (lane == 0) {
+    for (int i = 0; i < N; ++i) v[i] = wave_sum63(v[i]);
+    if (lane == 63) {
 #pragma unroll
         for (int i = 0; i < N; ++i) smem[i * nw + w] = v[i];
     }
@@ -117,8 +151,8 @@ __device__ __forceinline__ void block_sum_f32w(const float (&p)[N], float* smem,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const float s = wave_sum(p[i]);
-        if (lane == 0) smem[i * nw + w] = s;
+        const float s = wave_sum63(p[i]);
+        if (lane == 63) smem[i * nw + w] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -246,7 +280,7 @@ struct DetCtl { long long* shadow[kDetSlots]; const float* base[kDetSlots]; long
 typedef int (*det_setter_t)(const DetCtl*);      // 0 or the hipError_t of the copy into that TU's control block
 void det_register(det_setter_t fn);      // train_ops.hip
 #if defined(__HIPCC__) && defined(FQSS_USES_GRAD_ADD)
-static __device__ DetCtl d_det_ctl;
+static __constant__ DetCtl d_det_ctl;     // (constant address space: the tail-of-kernel reads of grad_add are scalar-cache hits, not memory round trips)
 namespace {
 struct DetRegistrar {
     DetRegistrar() {
@@ -254,6 +288,15 @@ struct DetRegistrar {
     }
 } det_registrar_;
 }  // namespace
+// det_preload(): "is the mode on", read at the START of a kernel whose tail issues grad_adds from one thread: the control block lives in
+// global memory, and a load of it in the tail is a full memory round trip per grad_add behind the last barrier, with the workgroup's
+// registers and LDS still allocated (k_dwq_bwd: four of them, ~3 us of a 20-us workgroup).  grad_add(addr, v, on) takes the answer.
+__device__ __forceinline__ bool det_preload() { return d_det_ctl.shadow[0] != nullptr; }
+__device__ __forceinline__ void grad_add(float* addr, float v);
+__device__ __forceinline__ void grad_add(float* addr, float v, bool det_on) {
+    if (det_on) grad_add(addr, v);
+    else atomicAdd(addr, v);
+}
 __device__ __forceinline__ void grad_add(float* addr, float v) {
     if (d_det_ctl.shadow[0] != nullptr && fabsf(v) < 0x1p33f) {     // (NaN / inf / huge: the plain add below)
 #pragma unroll

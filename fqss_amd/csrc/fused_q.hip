@@ -229,6 +229,16 @@ __global__ __launch_bounds__(256) void k_gnq_apply_t(const uint8_t* __restrict__
     }
 }
 
+// the per-sample coefficients of a GroupNormQ's backward apply pass from its two C-term sums (every consumer workgroup reduces the C pairs
+// of its sample itself; finishing them once in the PRODUCER of the row sums behind a ticket per row was tried in round 6 and costs the
+// producers ten times what the consumers gain: profiles/r06_dwb_stamps.txt)
+__device__ __forceinline__ void gn_coef_from_sums(const double (&sv)[2], float mean, float rstd, int C, int M, double& c2d, double& c3d) {
+    const double md = (double)mean, rd = (double)rstd;
+    const double inv_n = 1.0 / ((double)C * (double)M);
+    c2d = (sv[1] * md - sv[0]) * rd * rd * rd * inv_n;
+    c3d = -c2d * md - sv[1] * rd * inv_n;
+}
+
 // backward pass 1: per (b,c) row: recompute z and the STE, ds = sum gz*x, db = sum gz; range partials to gacc slots
 __global__ __launch_bounds__(256) void k_gnq_bwd_rows(const uint8_t* __restrict__ xc, const float* __restrict__ g,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
                                                         const float* qmin, const float* qmax, GnProducer P, float* ggamma,
                                                         float* gbeta) {
     __shared__ float predf[4 * 4];
+    const bool det_on = det_preload();
     const QRange rp = FUSE ? load_qrange(P.qmin, P.qmax) : QRange{0.f, 1.f, 1.f};
     const float pslope = (FUSE && P.act == FQSS_ACT_PRELU) ? *P.slope : 0.0f;
     float p_du = 0.f, p_out = 0.f, p_slope = 0.f, p_bias = 0.f;
@@ -335,6 +346,17 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
     // workgroups of sample 0 also finish the gamma / beta gradients of their channel (a B-term sum).
     __shared__ double cred[2 * 4];
     __shared__ float c23[2];
+    float c2, c3;
+    auto gamma_beta_grads = [&]() {     // the workgroups of sample 0 finish the gamma / beta gradients of their channel (a B-term sum)
+        double gg = 0.0, gb = 0.0;
+        for (int bb = 0; bb < B; ++bb) {
+            const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
+            gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
+            gb += db;
+        }
+        ggamma[c] += (float)gg;
+        gbeta[c] += (float)gb;
+    };
     {
         double sv[2] = {0.0, 0.0};
         for (int cc = threadIdx.x; cc < C; cc += 256) {
@@ -344,25 +366,16 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
         }
         block_sum<double, 2>(sv, cred);
         if (threadIdx.x == 0) {
-            const double md = (double)mean, rd = (double)rstd;
-            const double inv_n = 1.0 / ((double)C * (double)M);
-            const double c2d = (sv[1] * md - sv[0]) * rd * rd * rd * inv_n;
+            double c2d, c3d;
+            gn_coef_from_sums(sv, mean, rstd, C, M, c2d, c3d);
             c23[0] = (float)c2d;
-            c23[1] = (float)(-c2d * md - sv[1] * rd * inv_n);
-            if (b == 0) {
-                double gg = 0.0, gb = 0.0;
-                for (int bb = 0; bb < B; ++bb) {
-                    const double ds = ws[2 * ((int64_t)bb * C + c)], db = ws[2 * ((int64_t)bb * C + c) + 1];
-                    gg += (ds - db * (double)mean_rstd[2 * bb]) * (double)mean_rstd[2 * bb + 1];
-                    gb += db;
-                }
-                ggamma[c] += (float)gg;
-                gbeta[c] += (float)gb;
-            }
+            c23[1] = (float)c3d;
+            if (b == 0) gamma_beta_grads();
         }
         __syncthreads();
+        c2 = c23[0];
+        c3 = c23[1];
     }
-    const float c2 = c23[0], c3 = c23[1];
     const uint8_t* xr = xc + row * ld_xc;
     const float* gr = g + row * ld_g;
     const float* pzr = FUSE ? P.pz + row * P.ld_pz : nullptr;
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256) void k_gnq_bwd_apply(const uint8_t* __restrict
             block_sum_f32w<4>(pf, predf, v);
         }
         // ONE atomic per row (per-wave atomics on the same 512 addresses cost 1.6 ms/step)
-        if (threadIdx.x == 0 && P.gbias != nullptr) grad_add(&P.gbias[c], (float)v[3]);
+        if (threadIdx.x == 0 && P.gbias != nullptr) grad_add(&P.gbias[c], (float)v[3], det_on);
         if (threadIdx.x == 0) {
             double* slot = P.gacc + 3 * (row % kSlots);
             const double dmax = v[0] / 255.0;
@@ -920,6 +933,19 @@ struct DwGnBefore {
 #ifndef FQSS_DWB_WAVES
 #define FQSS_DWB_WAVES 1
 #endif
+#ifndef FQSS_DWB_ABL
+#define FQSS_DWB_ABL 0      // timing ablations (tools only): 1 no coefficient sums in the GA prologue, 2 no phase 2, 4 no final reductions, 8 no phase-1 arithmetic
+#endif
+// FQSS_DWB_STAMPS (tools/dwb_stamps.py only): wave 0 of every workgroup records s_memtime at its phase boundaries; the eight deltas
+// (16 shader cycles per unit) replace the row's two doubles in GBd.ws
+#ifdef FQSS_DWB_STAMPS
+#define DWB_STAMP(k) do { if (threadIdx.x == 0) stamp_[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DWB_STAMP(k) do { } while (0)
+#endif
+#ifndef FQSS_DWB_GPP
+#define FQSS_DWB_GPP 2      // float4 groups per thread and pass (a pass = 1024 x GPP positions; the thread -> element order does not depend on it)
+#endif
 template <int KT, bool GA = false, bool GB = false, int ACTC = -1>   // KT: taps known at compile time (3 on the training path) or 0: runtime K <= kTaps;
                                                                        // ACTC >= 0: the activation known at compile time (PReLU in the TCN blocks)
 __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
@@ -933,9 +959,21 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
     if (KT) K = KT;
     if (ACTC >= 0) act = ACTC;
     extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
-    __shared__ float redf[(4 + kTaps) * 4];
+    __shared__ __attribute__((aligned(16))) float redf[(8 + kTaps) * 4];
+#ifndef FQSS_DWB_NO_PLANES
+    // one 4-byte plane per table column: a lookup by a data-dependent code then touches ONE bank per lane and column (the 8-B / 16-B
+    // entries made every lookup a 2- / 4-bank access: LDS conflict rate 1.59, profiles/r05_sq_counters.txt)
+    __shared__ float tabA0[GA ? 256 : 1], tabA1[GA ? 256 : 1];            // GA: fma(x, c2, c3) | in-range, per code of THIS layer's output
+    __shared__ float tabB0[GB ? 256 : 1], tabB1[GB ? 256 : 1], tabB2[GB ? 256 : 1];   // GB: x | c - u or c | in-range, per code of the GroupNorm's input
+#else
     __shared__ __attribute__((aligned(16))) float2 tabA[GA ? 256 : 1];   // GA: {fma(x, c2, c3), in-range} per code of THIS layer's output
     __shared__ __attribute__((aligned(16))) float4 tabB[GB ? 256 : 1];   // GB: {x, c - u | c, in-range, -} per code of the GroupNorm's input
+#endif
+#ifdef FQSS_DWB_STAMPS
+    unsigned long long stamp_[9];
+#endif
+    DWB_STAMP(0);
+    const bool det_on = det_preload();
     const QRange rx = load_qrange(qmin_x, qmax_x), ry = load_qrange(qmin, qmax);
     const float slope = (act == FQSS_ACT_PRELU) ? *slope_p : 0.0f;
     const int row = blockIdx.x, c = row % C;
@@ -943,12 +981,13 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
     // (the straight loop exposed one HBM round trip per group: PMC showed the waves parked 46 % of the time)
     const uint8_t* xr = xc + (int64_t)row * ld_xc;
     const float* gr = g + (int64_t)row * ld_g;
-    float4 gq[4];
-    unsigned int cw[4][NT];
-    bool inner[4];
+    constexpr int GPP = FQSS_DWB_GPP;
+    float4 gq[GPP];
+    unsigned int cw[GPP][NT];
+    bool inner[GPP];
     auto issue_loads = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < GPP; ++i) {
             const int m = m0 + 1024 * i;
             inner[i] = (m - pad >= 0) && (m + 3 + pad < M);
             if (m < M) gq[i] = *reinterpret_cast<const float4*>(gr + m);
@@ -979,37 +1018,47 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
         const float mean = GAd.mean_rstd[2 * b], rstd = GAd.mean_rstd[2 * b + 1];
         scale2 = rstd * GAd.gamma[c];
         const float shift2 = fmaf(-scale2, mean, GAd.beta[c]);
-        double sv[2] = {0.0, 0.0};
-        for (int cc = threadIdx.x; cc < C; cc += 256) {
-            const double gmm = (double)GAd.gamma[cc];
-            sv[0] += gmm * GAd.ws[2 * ((int64_t)b * C + cc)];
-            sv[1] += gmm * GAd.ws[2 * ((int64_t)b * C + cc) + 1];
-        }
-        block_sum<double, 2>(sv, cred);
-        if (threadIdx.x == 0) {
-            const double md = (double)mean, rd = (double)rstd;
-            const double inv_n = 1.0 / ((double)C * (double)M);
-            const double c2d = (sv[1] * md - sv[0]) * rd * rd * rd * inv_n;
-            c23[0] = (float)c2d;
-            c23[1] = (float)(-c2d * md - sv[1] * rd * inv_n);
-            if (b == 0) {
-                double gg = 0.0, gb = 0.0;
-                for (int bb = 0; bb < GAd.B; ++bb) {
-                    const double ds = GAd.ws[2 * ((int64_t)bb * C + c)], db = GAd.ws[2 * ((int64_t)bb * C + c) + 1];
-                    gg += (ds - db * (double)GAd.mean_rstd[2 * bb]) * (double)GAd.mean_rstd[2 * bb + 1];
-                    gb += db;
-                }
-                GAd.ggamma[c] += (float)gg;
-                GAd.gbeta[c] += (float)gb;
+        auto gamma_beta_grads = [&]() {
+            double gg = 0.0, gb = 0.0;
+            for (int bb = 0; bb < GAd.B; ++bb) {
+                const double ds = GAd.ws[2 * ((int64_t)bb * C + c)], db = GAd.ws[2 * ((int64_t)bb * C + c) + 1];
+                gg += (ds - db * (double)GAd.mean_rstd[2 * bb]) * (double)GAd.mean_rstd[2 * bb + 1];
+                gb += db;
             }
+            GAd.ggamma[c] += (float)gg;
+            GAd.gbeta[c] += (float)gb;
+        };
+        float c2v, c3v;
+        {
+            double sv[2] = {0.0, 0.0};
+            for (int cc = threadIdx.x; cc < ((FQSS_DWB_ABL & 1) ? 0 : C); cc += 256) {
+                const double gmm = (double)GAd.gamma[cc];
+                sv[0] += gmm * GAd.ws[2 * ((int64_t)b * C + cc)];
+                sv[1] += gmm * GAd.ws[2 * ((int64_t)b * C + cc) + 1];
+            }
+            block_sum<double, 2>(sv, cred);
+            if (threadIdx.x == 0) {
+                double c2d, c3d;
+                gn_coef_from_sums(sv, mean, rstd, C, M, c2d, c3d);
+                c23[0] = (float)c2d;
+                c23[1] = (float)c3d;
+                if (b == 0) gamma_beta_grads();
+            }
+            __syncthreads();
+            c2v = c23[0];
+            c3v = c23[1];
         }
-        __syncthreads();
         {   // the table over the codes of this layer's output (= that GroupNorm's input, range ry)
             const float x2 = dec(threadIdx.x, ry);
             float cq2, u2;
             bool in2;
             (void)fq_asym(fmaf(x2, scale2, shift2), r2, cq2, u2, in2);
-            tabA[threadIdx.x] = make_float2(fmaf(x2, c23[0], c23[1]), in2 ? 1.0f : 0.0f);
+#ifndef FQSS_DWB_NO_PLANES
+            tabA0[threadIdx.x] = fmaf(x2, c2v, c3v);
+            tabA1[threadIdx.x] = in2 ? 1.0f : 0.0f;
+#else
+            tabA[threadIdx.x] = make_float2(fmaf(x2, c2v, c3v), in2 ? 1.0f : 0.0f);
+#endif
         }
     }
     if constexpr (GB) {
@@ -1022,9 +1071,16 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
         float cq1, u1;
         bool in1;
         (void)fq_asym(fmaf(x0, scale1, shift1), rx, cq1, u1, in1);     // that GroupNorm's output quantizer = this layer's input range
+#ifndef FQSS_DWB_NO_PLANES
+        tabB0[threadIdx.x] = x0;
+        tabB1[threadIdx.x] = in1 ? (cq1 - u1) : cq1;
+        tabB2[threadIdx.x] = in1 ? 1.0f : 0.0f;
+#else
         tabB[threadIdx.x] = make_float4(x0, in1 ? (cq1 - u1) : cq1, in1 ? 1.0f : 0.0f, 0.0f);
+#endif
     }
     if constexpr (GA || GB) __syncthreads();
+    DWB_STAMP(1);      // prologue done
     float wk[NT], pw[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
@@ -1043,16 +1099,23 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
             if (4 * (int)threadIdx.x + 1024 * i < M) w0pre[i] = *reinterpret_cast<const unsigned int*>(x0p + 4 * threadIdx.x + 1024 * i);
     }
 
-    for (int m0 = 4 * threadIdx.x; m0 < M; m0 += 4096) {
+    for (int m0 = 4 * threadIdx.x; m0 < M; m0 += 1024 * GPP) {
 #ifdef FQSS_DWB_EARLY
         if (m0 != 4 * (int)threadIdx.x) issue_loads(m0);
 #else
         issue_loads(m0);
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < GPP; ++i) {
             const int m = m0 + 1024 * i;
             if (m >= M) break;
+            if constexpr (FQSS_DWB_ABL & 8) {
+                float4 t = gq[i];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) t.x += __uint_as_float(cw[i][k]);
+                *reinterpret_cast<float4*>(&sgz[m]) = t;
+                continue;
+            }
             float v[NT][4], acc[4] = {0.f, 0.f, 0.f, 0.f};
             if (inner[i]) {   // no padding masks, one unaligned dword per tap
 #pragma unroll
@@ -1094,7 +1157,12 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
                     (void)fq_asym(t, ry, cq, u, inr);
                     float gj = valid ? gv[j] : 0.0f;
                     if constexpr (GA) {     // the consuming GroupNormQ's backward apply, on the code this layer's forward wrote
+#ifndef FQSS_DWB_NO_PLANES
+                        const unsigned int ca = (unsigned int)cq & 255u;
+                        const float2 e2 = make_float2(tabA0[ca], tabA1[ca]);
+#else
                         const float2 e2 = tabA[(unsigned int)cq & 255u];
+#endif
                         const float gz2 = (e2.y != 0.0f) ? div_by(gv[j] * r2.delta, r2.delta, r2.inv) : 0.0f;
                         gj = valid ? fmaf(gz2, scale2, e2.x) : 0.0f;
                     }
@@ -1115,10 +1183,12 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
             *reinterpret_cast<float4*>(&sgz[m]) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+    DWB_STAMP(2);      // phase 1 done (loads + arithmetic)
     __syncthreads();
+    DWB_STAMP(3);      // barrier passed
 
     float q_ds = 0.f, q_db = 0.f, q_du = 0.f, q_out = 0.f;      // GB: the producing GroupNormQ's row sums / range partials
-    if (want_gx) {
+    if (want_gx && !(FQSS_DWB_ABL & 2)) {
         float* xo = gx + (int64_t)row * ld_gx;
         const bool aligned = ((dil & 3) == 0) && ((pad & 3) == 0);
         const uint8_t* x0r = GB ? GBd.xc0 + (int64_t)row * GBd.ld_xc0 : nullptr;
@@ -1154,7 +1224,12 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (m + j < M) {
+#ifndef FQSS_DWB_NO_PLANES
+                        const unsigned int cb = (w0 >> (8 * j)) & 255u;
+                        const float4 e1 = make_float4(tabB0[cb], tabB1[cb], tabB2[cb], 0.0f);
+#else
                         const float4 e1 = tabB[(w0 >> (8 * j)) & 255u];
+#endif
                         const bool in1 = e1.z != 0.0f;
                         const float gz1 = in1 ? div_by(a[j] * rx.delta, rx.delta, rx.inv) : 0.0f;
                         q_du += a[j] * e1.y;
@@ -1166,11 +1241,28 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
             }
         }
     }
-    if constexpr (GB) {
-        double qv[4];
-        const float qf[4] = {q_ds, q_db, q_du, q_out};
-        block_sum_f32w<4>(qf, redf, qv);
-        if (threadIdx.x == 0) {
+    DWB_STAMP(4);      // phase 2 done
+    if constexpr (FQSS_DWB_ABL & 4) {
+        if (p_du + p_out + p_slope + p_bias + pw[0] + q_ds + q_db + q_du + q_out == 1.2345f) gacc[0] = 1.0;
+        return;
+    }
+    // ONE block reduction for the layer's own partials and (GB) the producing GroupNormQ's: one barrier pair and one serial section of
+    // thread 0 instead of two (each value keeps its own summation tree: same bits as two reductions)
+    constexpr int NQ = GB ? 4 : 0;
+    double v[4 + NT + (GB ? 4 : 1)];
+    {
+        float pf[4 + NT + (GB ? 4 : 1)];
+        pf[0] = p_du; pf[1] = p_out; pf[2] = p_slope; pf[3] = p_bias;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) pf[4 + k] = pw[k];
+        if constexpr (GB) { pf[4 + NT] = q_ds; pf[5 + NT] = q_db; pf[6 + NT] = q_du; pf[7 + NT] = q_out; }
+        else pf[4 + NT] = 0.f;
+        block_sum_f32w<4 + NT + (GB ? 4 : 1)>(pf, redf, v);
+    }
+    DWB_STAMP(5);
+    if (threadIdx.x == 0) {
+        if constexpr (GB) {
+            const double* qv = v + 4 + NT;
             GBd.ws[2 * (int64_t)row] = qv[0];
             GBd.ws[2 * (int64_t)row + 1] = qv[1];
             double* slot = GBd.gacc + 3 * (row % kSlots);
@@ -1178,26 +1270,32 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
             atomicAdd(&slot[0], qv[3] - dmax);
             atomicAdd(&slot[1], dmax);
         }
-    }
-
-    double v[4 + NT];
-    {
-        float pf[4 + NT];
-        pf[0] = p_du; pf[1] = p_out; pf[2] = p_slope; pf[3] = p_bias;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) pf[4 + k] = pw[k];
-        block_sum_f32w<4 + NT>(pf, redf, v);
-    }
-    if (threadIdx.x == 0) {
         double* slot = gacc + 3 * (row % kSlots);
         const double dmax = v[0] / 255.0;
         atomicAdd(&slot[0], v[1] - dmax);   // rows share slots modulo kSlots: few adders per address, order-insensitive in fp64
         atomicAdd(&slot[1], dmax);
         if (act == FQSS_ACT_PRELU) atomicAdd(&slot[2], v[2]);
-        if (gbias != nullptr) grad_add(&gbias[c], (float)v[3]);
+        if (gbias != nullptr) grad_add(&gbias[c], (float)v[3], det_on);
         if (gw != nullptr)
-            for (int k = 0; k < K; ++k) grad_add(&gw[c * K + k], (float)v[4 + k]);
+            for (int k = 0; k < K; ++k) grad_add(&gw[c * K + k], (float)v[4 + k], det_on);
     }
+    (void)NQ;
+#ifdef FQSS_DWB_STAMPS
+    DWB_STAMP(6);
+    if constexpr (GB) {
+        if (threadIdx.x == 0) {
+            unsigned long long w0_ = 0, w1_ = 0;
+            for (int k = 0; k < 6; ++k) {
+                unsigned long long d = (stamp_[k + 1] - stamp_[k]) >> 4;
+                d = d > 65535 ? 65535 : d;
+                if (k < 4) w0_ |= d << (16 * k); else w1_ |= d << (16 * (k - 4));
+            }
+            w1_ |= ((stamp_[0] >> 8) & 0xffffffffull) << 32;        // start time in units of 256 cycles (relative order of the workgroups)
+            reinterpret_cast<unsigned long long*>(GBd.ws)[2 * (int64_t)row] = w0_;
+            reinterpret_cast<unsigned long long*>(GBd.ws)[2 * (int64_t)row + 1] = w1_;
+        }
+    }
+#endif
 }
 
 // gw[c][k] += sum_{b,m} gz[b][c][m] * decode(x[b][c][m + k*dil - pad])   ; grid (C, B), 4 m per thread
