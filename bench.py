@@ -70,7 +70,7 @@ def dominant_kernel_roofline(dev, ms_step):
     times = [RC.time_case(c) for c in cases]
     groups = RC.summarize(cases, times)
     pmc, pmc_file = {}, None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):       # the newest committed PMC table
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc, pmc_file = json.load(f).get("per_launch_bytes", {}), "profiles/" + name

@@ -24,12 +24,44 @@ PEAK_TFLOPS = {"bf16": 2500.0, "i8": 5000.0, "f32": 157.3}
 N = B * M
 
 
-def priced(flops, products, dtype, nbytes, us):
+# Vector-issue floor (round 6; VERDICT r05 next #1c): a wave64 fp32 VALU instruction occupies its SIMD for 2.3-2.7 cycles once two or
+# more waves share it (tools/ubench/pk_rate.hip, profiles/r06_pk_rate.txt: v_fma / v_mul / v_add_f32 alone; packed forms take 4.1-4.4
+# for two elements) -- 2.5 cycles at the 2.4 GHz property clock is the rate a kernel's SQ_INSTS_VALU count is priced at.
+VALU_CYCLES_PER_INST, SHADER_GHZ = 2.5, 2.4
+VALU_PEAK_PER_US = SHADER_GHZ * 1e3 / VALU_CYCLES_PER_INST       # wave instructions per SIMD and microsecond
+
+
+def valu_counts():
+    """{kernel symbol: SQ_INSTS_VALU per SIMD and launch} from the newest committed counter table (profiles/r*_sq_counters.txt, written by
+    tools/r06_pmc.sh: the launches of THIS file's cases under rocprofv3 --pmc)"""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    for path in sorted(glob.glob(os.path.join(root, "r*_sq_counters.txt")), reverse=True):
+        out = {}
+        for line in open(path):
+            m = re.match(r"(k_\w+(?:<[^>]*>)?)\s+n=.*?VALU/SIMD\s+(\d+)", line)
+            if m:
+                out[m.group(1)] = (float(m.group(2)), os.path.join("profiles", os.path.basename(path)))
+        if out:
+            return out
+    return {}
+
+
+# case name -> the instantiation the counter table lists it under
+VALU_ALIAS = {"k_dwq_bwd<3, GA, GB>": "k_dwq_bwd<3, true, true, 1>", "k_qgemm<0>": "k_qgemm<0, 3>", "k_qgemm<1>": "k_qgemm<1, 3>",
+              "k_qwgrad_group": "k_qwgrad_group<3>", "k_gnq_apply_t": "k_gnq_apply_t<4>", "k_ewq_bwd": "k_ewq_bwd<true>",
+              "k_actq_bwd": "k_actq_bwd<4, true, false, false>", "k_axpby": "k_axpby<4>"}
+
+
+def priced(flops, products, dtype, nbytes, us, valu=None):
     """`roofline` numbers of ONE launch: flops = algorithmic flop, products = partial products issued per algorithmic product on the
-    `dtype` matrix (or, "f32", vector) pipe, nbytes = algorithmic HBM bytes, us = measured launch duration.
-    floor = max(issued flops / that dtype's dense peak, bytes / 8 TB/s); `bound` names the larger floor, `achieved` / `peak` / `unit`
-    are that resource's, frac = floor / measured time = achieved / peak <= 1 for anything physical; the other resource's fraction
-    rides beside it."""
+    `dtype` matrix (or, "f32", vector) pipe, nbytes = algorithmic HBM bytes, us = measured launch duration, valu = (vector instructions
+    per SIMD and launch from the PMC table, its file) or None.
+    floor = max(issued flops / that dtype's dense peak, bytes / 8 TB/s, vector instructions x 2.5 cycles); `bound` names the largest
+    floor ("mfma" | "hbm" | "valu"), `achieved` / `peak` / `unit` are that resource's, frac = floor / measured time = achieved / peak
+    <= 1 for anything physical; the other resources' fractions ride beside it."""
     sec = us * 1e-6
     issued = flops * products
     t_m = issued / (PEAK_TFLOPS[dtype] * 1e12) if flops > 0 else 0.0
@@ -38,7 +70,14 @@ def priced(flops, products, dtype, nbytes, us):
     o = {"hbm_frac": round(gbps / HBM_PEAK_GBS, 4), "algorithmic_GBps": round(gbps, 1), "floor_us": round(max(t_m, t_h) * 1e6, 2)}
     if flops > 0:
         o.update(mfma_dtype=dtype, products_per_term=products, issued_TFLOPs=round(tf, 1), issued_frac=round(tf / PEAK_TFLOPS[dtype], 4))
-    if t_m > t_h:
+    t_v = 0.0
+    if valu is not None:
+        t_v = valu[0] / VALU_PEAK_PER_US * 1e-6
+        o.update(valu_insts_per_simd=round(valu[0]), valu_floor_us=round(t_v * 1e6, 2), valu_frac=round(t_v / sec, 4), valu_source=valu[1])
+        o["floor_us"] = round(max(t_m, t_h, t_v) * 1e6, 2)
+    if t_v > t_m and t_v > t_h:
+        o.update(bound="valu", achieved=round(valu[0] / us, 1), peak=VALU_PEAK_PER_US, unit="wave-instructions/us/SIMD", frac=round(t_v / sec, 4))
+    elif t_m > t_h:
         o.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_TFLOPS[dtype], unit="TFLOP/s", frac=round(tf / PEAK_TFLOPS[dtype], 4))
     else:
         o.update(bound="hbm", achieved=round(gbps, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBS, 4))
@@ -252,7 +291,9 @@ def roofline_object(g, traffic=None):
     out = {"kernel": g["kernel"], "launch_us": round(ms * 1e3, 2), "launches_per_step": n,
            "ms_per_step": round(g["ms_step"], 3), "algorithmic_bytes_per_launch": round(g["bytes"] / n),
            "survey_convention_GBps": round(g["survey"] / n / (ms * 1e-3) / 1e9, 1)}
-    out.update(priced(g["flops"] / n, prod, dtype, g["bytes"] / n, ms * 1e3))
+    vc = valu_counts()
+    valu = vc.get(VALU_ALIAS.get(g["kernel"], g["kernel"])) if len(g["shapes"]) == 1 else None      # (a count belongs to ONE launch shape)
+    out.update(priced(g["flops"] / n, prod, dtype, g["bytes"] / n, ms * 1e3, valu))
     out["traffic"] = traffic
     out["shapes"] = g["shapes"]
     if g["group"]:
