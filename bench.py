@@ -180,7 +180,7 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
         o.update(RC.priced(flops, 1, "f32", nbytes, us))
         o["traffic"] = _pmc_other("k_lstm_fwd_st<128>", f"{S} steps x {Bq} sequences")
         o["note"] = ("a chain of 250 dependent time steps on 194 of 256 CUs: bound by the issue of ~360 vector instructions per wave and step "
-                     "(256 of them the FMAs) + 2 barriers per step (DESIGN.md 7, 9); neither roofline binds it")
+                     "(256 of them the FMAs) + 2 barriers per step (docs/history/DESIGN_rounds_1-5.md 7, 9); neither roofline binds it")
         return o
     # cfg 4 (profiles/r05_cfg4_step_table.txt): since round 5 the coded weight gradients run as four grouped launches (2.0 ms per step
     # together) and the kernel with the largest time per step is the coded DATA gradient of the student's linears,
@@ -211,7 +211,7 @@ def dominant_kernel_roofline_dualpath(which, rows, Ci, Co, what, seqs):
           "launch_us": round(ug, 1), "launches_per_step": 4, "algorithmic_bytes_per_launch": int(gb)}
     og.update(RC.priced(sum(2.0 * rows * ci * co for ci, co in shapes), 3, "bf16", gb, ug))
     o["other_kernels"] = [og]
-    o["note"] = "bound by vector-ALU issue of the operand split and by the latency of a k-tile (DESIGN.md 7e (4), (7)), not by either roofline"
+    o["note"] = "bound by vector-ALU issue of the operand split and by the latency of a k-tile (docs/history/DESIGN_rounds_1-5.md 7e (4), (7)), not by either roofline"
     return o
 
 

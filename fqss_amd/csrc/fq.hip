@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
                     gt = inr ? div_by(gin * r.delta, r.delta, r.inv) : 0.0f;
                     // selects, not a branch around the sums (a masked-out position may hold anything, so its term is dropped, not
                     // multiplied by 0): the branchy form of these sums in k_mulq_bwd was right alone and off by one term in a few
-                    // lanes per launch next to a second stream; every such sum is written branch-free since
+                    // lanes per launch next to a second stream (docs/history/DESIGN_rounds_1-5.md 9); every such sum is written branch-free since
                     p_du += valid ? gin * (inr ? (c - u) : c) : 0.0f;
                     p_out += (valid && !inr) ? gin : 0.0f;
                 } else if (POSTRELU && !(t > 0.0f)) {

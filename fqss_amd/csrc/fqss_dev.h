@@ -267,7 +267,7 @@ __device__ __forceinline__ void code_stats4(unsigned int word, unsigned int& s, 
 
 #endif  // __HIPCC__
 
-// ---------------------------------------------------------------- FQSS_DETERMINISTIC=1 (round 5; DESIGN.md 2, "bit-reproducible steps")
+// ---------------------------------------------------------------- FQSS_DETERMINISTIC=1 (round 5; docs/history/DESIGN_rounds_1-5.md 2, "bit-reproducible steps")
 // The fp32 atomics that are left in the step -- one add per (sample, channel) row into a bias / depthwise-weight gradient, the split
 // adds of the frame-path weight gradients -- make those gradients depend on the ORDER the workgroups retire in (1e-7 relative, run to
 // run).  In deterministic mode every such add goes, instead, into an integer shadow of the gradient arena it targets: the value as a 2-word fixed

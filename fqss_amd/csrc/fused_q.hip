@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gnq_apply(const uint8_t* __restrict__ x
 // output code is a 256-entry function of the input code: thread t evaluates fq_code(fmaf(dec(t), scale, shift), ry) ONCE per row for
 // code t = threadIdx.x (the arithmetic of k_gnq_apply, hence bit-identical), the bytes go to a 256-B LDS table (64 dwords = one per
 // bank: any two lanes on one bank read the same dword, which the LDS broadcasts -- conflict-free for every input), and the row is
-// out = T[in]: bfe + ds_read_u8 + or per element instead of ~25 VALU instructions (these kernels are VALU-issue bound).
+// out = T[in]: bfe + ds_read_u8 + or per element instead of ~25 VALU instructions (these kernels are VALU-issue bound, docs/history/DESIGN_rounds_1-5.md 4).
 // A workgroup owns RPW consecutive rows of ONE sample (host: C % RPW == 0): all their code loads are issued first, the tables of
 // all RPW rows are computed while they fly, one barrier.  Rows longer than 4096 positions loop.
 template <int RPW>

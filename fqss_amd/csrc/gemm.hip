@@ -621,7 +621,7 @@ extern "C" int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, 
 
 // fqss_rowlin_fwd with the weight given as its three exact bf16 planes [3][Co][Ci] (fqss_split3_planes): the weight tile is copied into
 // LDS instead of being split by every workgroup that touches it -- for weights that do not change between launches (the frozen float
-// teacher: its row GEMMs are bound by the vector-ALU issue of that split).  Same result bits as fqss_rowlin_fwd.
+// teacher: its row GEMMs are bound by the vector-ALU issue of that split, docs/history/DESIGN_rounds_1-5.md 7e (4)).  Same result bits as fqss_rowlin_fwd.
 extern "C" int fqss_rowlin_fwd_w3(const float* x, const uint16_t* w3, const float* bias, float* z, int64_t R, int Ci, int Co, int64_t ld_x,
                                   int64_t ld_z, fqss_stream_t stream) {
     FQSS_REQUIRE(x && w3 && z, "null tensor");

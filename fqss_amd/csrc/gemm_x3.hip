@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_gemm_x3(GemmArgs3 g) {
 // gradients of a backward segment's row-major linears feed nothing but the optimizer, so the host queues them and runs them together
 // (ops_dp.RowWgradQueue, runtime.QuantTables.finish_backward).  Why it pays: one such GEMM is 16 output tiles x 16 k-slices = 256
 // workgroups -- ONE per CU, each a serial chain of ~17 k-tiles (load -> split -> LDS -> barrier -> MFMA, ~1 us each: these short-K
-// GEMMs are bound by that latency) -- so a launch takes ~37 us at 0.12 of its roofline with nothing to overlap the
+// GEMMs are bound by that latency, docs/history/DESIGN_rounds_1-5.md 7e (7)) -- so a launch takes ~37 us at 0.12 of its roofline with nothing to overlap the
 // chain with.  32 problems in one grid are 4096+ workgroups: three to four resident per CU overlap their chains, the k-split can be
 // coarser (fewer float atomics), and the ~8 us of fixed cost per launch is paid once.  The job table travels in the kernel arguments.
 constexpr int X3W_MAXJOBS = 32;

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_tgemm(TGemmArgs g) {
     // The small per-workgroup arrays live INSIDE the tile buffer, which is idle when they are in use (pms: before the first tile is
     // stored; rowb / red: in the epilogue, behind its 4 x 4,608-B staging tiles): as separate arrays they brought the PRO = 1 instance to
     // 66,120 B of static LDS, and a kernel above 64 KB made LDS-resident data of kernels running on ANOTHER stream unreliable
-    // (tools/stress_streams.py).  With them folded in every instance is <= 65,536 B.
+    // (tools/stress_streams.py, docs/history/DESIGN_rounds_1-5.md 9).  With them folded in every instance is <= 65,536 B.
     float* rowb = reinterpret_cast<float*>(smem + 4 * 32 * TLDT * 4);                     // [TBM]
     double* red = reinterpret_cast<double*>(smem + 4 * 32 * TLDT * 4 + TBM * 4);          // [2 * 4]
     float* pms = reinterpret_cast<float*>(smem);                                          // [2]
@@ -1221,7 +1221,7 @@ static int tgemm_launch(bool tiled, const char* fn, const uint16_t* planes, cons
     const dim3 grid(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m));
     // FQSS_TGEMM_PAD_LDS=<bytes> (experiment knob, read once): unused dynamic LDS that caps the workgroups per CU -- with > 16 KB on top
     // of the 60-64 KB tile buffer only ONE teacher workgroup fits a CU, which leaves half of every SIMD's registers to the student's
-    // waves when the teacher runs on its own stream beside the step
+    // waves when the teacher runs on its own stream beside the step (docs/history/DESIGN_rounds_1-5.md 9)
     static const size_t pad = [] {
         const char* e = getenv("FQSS_TGEMM_PAD_LDS");
         const size_t v = e ? (size_t)atol(e) : 0;

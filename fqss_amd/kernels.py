@@ -1453,7 +1453,7 @@ def rowlin_fwd(x, w, bias, out=None):
     return z
 
 
-W3_CACHE = os.environ.get("FQSS_W3_CACHE", "0") != "0"    # opt-in: measured neutral, the default stays the on-the-fly split
+W3_CACHE = os.environ.get("FQSS_W3_CACHE", "0") != "0"    # opt-in: measured neutral (docs/history/DESIGN_rounds_1-5.md 7e (4)), the default stays the on-the-fly split
 
 
 def _frozen_weight_planes(w, Ci, x, ld_x):
@@ -1774,7 +1774,7 @@ ATTN_STREAM = os.environ.get("FQSS_ATTN_STREAM", "1") != "0"
 
 def _attn_stream_ok(ts, E, nh):
     """the split-bf16 streaming attention (csrc/attn_long.hip) also serves the 250-step sequences of the dual-path models: [L, B, E]
-    views with 16-B aligned rows, head_dim 16 / 32 / 64 (measured against the LDS-resident kernels of csrc/attn.hip: DESIGN.md 7/7b)"""
+    views with 16-B aligned rows, head_dim 16 / 32 / 64 (measured against the LDS-resident kernels of csrc/attn.hip: docs/history/DESIGN_rounds_1-5.md 7/7b)"""
     return ATTN_STREAM and (E // nh) in (16, 32, 64) and all(t.dim() == 3 and t.stride(2) == 1 and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0
                                                           and t.stride(1) % 4 == 0 for t in ts)
 

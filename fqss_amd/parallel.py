@@ -28,7 +28,7 @@ def local_device(local_rank):
 
 
 class CommError(RuntimeError):
-    """a collective of the gradient / range exchange failed or timed out on this rank ("When the exchange fails")"""
+    """a collective of the gradient / range exchange failed or timed out on this rank (docs/history/DESIGN_rounds_1-5.md 6, "When the exchange fails")"""
 
 
 class Comm:

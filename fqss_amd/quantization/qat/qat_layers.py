@@ -10,7 +10,7 @@ LinearQ (:521-536), LSTMQ (:571-600), MultiheadAttentionQ (:865-950), Conv2dQ (1
 nn.Linear branch of ResidualErrorBlock (:1178-1187), over the kernels of csrc/dualpath.hip, attn.hip, lstm.hip.
 The Sepformer / HTDemucs classes (LinearNlQ, Conv2dNlQ, ConvTranspose*Q, Conv1dGnNlQ, ConvTr2dDecoderQ, ...) and BatchNormQ follow
 further down on the kernels of csrc/conv_frames.hip, hd_ops.hip, batchnorm.hip; variants of these layers that no FQSS configuration takes
- raise NotImplementedError at construction -- there is no ATen fallback.
+(see docs/history/DESIGN_rounds_1-5.md 8) raise NotImplementedError at construction -- there is no ATen fallback.
 """
 import math
 import os

@@ -1,11 +1,11 @@
 /* fqss_experiments.h -- entry points of measured, parity-green, SLOWER experiments.  They are NOT part of libfqss_hip.so (the product):
  * `make -C fqss_amd/csrc experiments` builds variants/libfqss_experiments.so with -DFQSS_EXPERIMENTS, which tools/ and the opt-in
- * tests load through FQSS_LIB.  DESIGN.md 9 has the measurements.
+ * tests load through FQSS_LIB.  docs/history/DESIGN_rounds_1-5.md 9 has the measurements.
  *   fqss_gndwq_fwd_v1       GroupNormQ + 3-tap depthwise Conv1dNlQ as one launch, per-element arithmetic (round 4): bit-identical, 39.5 us
  *                           against 34.5 us for the two launches
  *   fqss_gndwq_fwd          the same on per-row code tables (round 5, k_gndwq_fwd_t: T[code] for the GroupNorm's output, V[code] for its
  *                           de-quantised value in the FIR): bit-identical, 39.6 us against 33.5 us -- the fused form is not bound by its
- *                           vector instructions
+ *                           vector instructions (docs/history/DESIGN_rounds_1-5.md 9)
  *   FQSS_DGRAD_RING=1       the student's data-gradient q-GEMM on an LDS-DMA weight ring (csrc/experiments/qgemm_ring.hip): 33.6 / 48.9 us
  *                           against 25.8 / 41.9 us of k_qgemm<1> */
 #pragma once

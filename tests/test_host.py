@@ -255,7 +255,7 @@ def _ddp_dying_peer(rank, world, port, q):
 
 
 def test_exchange_failure_raises_and_ends_the_rank():
-    """DESIGN.md 6 "When the exchange fails" (VERDICT r03 next #7): a peer that dies makes the next collective raise CommError on the
+    """docs/history/DESIGN_rounds_1-5.md 6 "When the exchange fails" (VERDICT r03 next #7): a peer that dies makes the next collective raise CommError on the
     survivor (rank and operation named) within the configured timeout; the rank ends non-zero -- no retry, no hang"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -418,7 +418,7 @@ def test_checkpoint_interchange_lightning_ckpt(tmp_path):
 
 
 def test_library_has_no_packed_fp32_op_with_a_swapped_second_source():
-    """gfx950 erratum guard (tools/ubench/pk_opsel_repro.hip): v_pk_add/mul/fma_f32 whose LOW result takes the HIGH half of
+    """gfx950 erratum guard (docs/history/DESIGN_rounds_1-5.md 9, tools/ubench/pk_opsel_repro.hip): v_pk_add/mul/fma_f32 whose LOW result takes the HIGH half of
     the second source (op_sel[1] = 1) returns wrong values in lanes 48-63 while another stream's bf16-MFMA GEMM is resident on the
     same CU -- the cause of both two-stream events of round 2 (the deleted four-frames-per-lane decoder carried 128-256 of them,
     the branchy bias sums of k_mulq_bwd two).  hipcc's SLP vectorizer makes them out of scalar code; the library is built with

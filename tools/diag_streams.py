@@ -1,4 +1,4 @@
-"""Two-stream investigation of DESIGN.md 9.  Runs the DIAGNOSTIC twin of the library
+"""Two-stream investigation of docs/history/DESIGN_rounds_1-5.md 9.  Runs the DIAGNOSTIC twin of the library
 (`make -C fqss_amd/csrc diag`: k_mulq_bwd with the round-2 "branchy" bias sums, a shadow sum in select form inside the same wave,
 per-lane partials and per-wave placement / clock records) as the victim on the main stream while a background runs on a second
 stream, and reports for every launch that differs from the quiet launch: which workgroup / wave / lanes, whether the shadow sum

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rewrites the measured columns of DESIGN.md §4's kernel table from profiles/r05_bench_line.json (every figure from ONE bench line).
+"""Rewrites the measured columns of docs/history/DESIGN_rounds_1-5.md §4's kernel table from profiles/r05_bench_line.json (every figure from ONE bench line).
     python tools/r05_design_table.py            (idempotent; rows are found by their kernel name)"""
 import json
 import os

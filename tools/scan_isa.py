@@ -1,7 +1,7 @@
 """Disassembles the gfx950 code objects inside a built shared library (the .hip_fatbin section: one clang offload bundle per
 translation unit) and lists packed fp32 VALU instructions whose LOW result takes the HIGH half of the second source
 (op_sel[1] = 1): the forms that return wrong values in lanes 48-63 next to another stream's bf16-MFMA GEMM on gfx950
-(tools/ubench/pk_opsel_repro.hip).  Used by tests/test_host.py; `python tools/scan_isa.py <lib.so>` prints a census."""
+(tools/ubench/pk_opsel_repro.hip, docs/history/DESIGN_rounds_1-5.md 9).  Used by tests/test_host.py; `python tools/scan_isa.py <lib.so>` prints a census."""
 import os
 import re
 import struct

@@ -3,7 +3,7 @@ background, BG=teacher|mm|conv|ola|mulq|dwq): every launch must return what it r
 did not.  SKIP=name[,name] replaces teacher kernels by cached results (to find an aggressor), DIAG=case prints where a case went wrong.
 History: a four-frames-per-lane decoder kernel (k_ola_convtr4, removed) passed every test alone and failed here in 8-12 rounds of 12 -- a few
 hundred outputs per launch off by about one product term whenever its workgroups were scheduled between the teacher's k_tgemm workgroups;
-cause not found; the one-frame-per-lane kernel with the same operand modes passes.
+cause not found; the one-frame-per-lane kernel with the same operand modes passes (docs/history/DESIGN_rounds_1-5.md 9).
     python tools/stress_streams.py [case ...]"""
 import torch, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -6,7 +6,7 @@
 // Victim: one packed add per step per lane (inline asm), checked bit for bit against two scalar v_add_f32 of the same operands; no LDS,
 // no atomics before the end.  Aggressor: the skeleton of a 128 x 128 x 32-tiled bf16 GEMM (LDS fragment reads + 48 MFMAs per k-tile
 // between workgroup barriers, 4 k-tiles per workgroup); it touches no memory the victim uses.  hipcc's SLP vectorizer emits these forms
-// for code like `acc0 += t1; acc1 += t0;` -- build with -fno-slp-vectorize (see fqss_amd/csrc/Makefile).
+// for code like `acc0 += t1; acc1 += t0;` -- build with -fno-slp-vectorize (see fqss_amd/csrc/Makefile, docs/history/DESIGN_rounds_1-5.md 9).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// Reproducer for DESIGN.md 9 (round 3): on gfx950 a packed fp32 add whose SECOND source has its halves swapped,
+// Reproducer for docs/history/DESIGN_rounds_1-5.md 9 (round 3): on gfx950 a packed fp32 add whose SECOND source has its halves swapped,
 //     v_pk_add_f32 vD, vA, vB op_sel:[0,1] op_sel_hi:[1,0]          (D.lo = A.lo + B.hi, D.hi = A.hi + B.lo)
 // returns a wrong sum in lanes 48-63 while a kernel on ANOTHER stream is resident on the same CUs; alone it is exact.
 //   hipcc --offload-arch=gfx950 -O3 -o pkadd_next_to_mfma pkadd_next_to_mfma.hip -ldl
@@ -161,7 +161,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&c1, (size_t)B * Co * ld * 4)); CK(hipMalloc(&bias, Co * 4)); CK(hipMemset(bias, 0, Co * 4));
         CK(hipMalloc(&slope, 4)); CK(hipMemset(slope, 0, 4)); CK(hipMalloc(&st, B * 32 * 16 * 8)); CK(hipMemset(st, 0, B * 32 * 16 * 8));
     }
-    if (!strcmp(bg, "rate")) {      // what bf16-MFMA rate do these loops sustain alone?  (the practical matrix-pipe ceiling of this part)
+    if (!strcmp(bg, "rate")) {      // what bf16-MFMA rate do these loops sustain alone?  (docs/history/DESIGN_rounds_1-5.md 4: the practical matrix-pipe ceiling of this part)
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int which = 0; which < 3; ++which) {
             float ms = 0.f; double flop = 0.0;
