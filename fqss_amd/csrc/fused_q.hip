@@ -2120,6 +2120,8 @@ extern "C" int fqss_dwq_fwd(const uint8_t* xc, const float* qmin_x, const float*
         grid = dim3((unsigned)cdiv(M, 4096), (unsigned)rows, 1);
         FQSS_REQUIRE(rows <= 65535 * 16, "output statistics: too many rows");
         if (rows > 65535) grid.y = 65535;   // (rows strided over y keep their own slots: indexed by row)
+        static const int rpw = getenv("FQSS_DWF_RPW") ? atoi(getenv("FQSS_DWF_RPW")) : 1;       // A/B knob: rows per workgroup
+        if (rpw > 1) grid.y = (unsigned)cdiv(rows, rpw);
     }
     if (K == 3)
         hipLaunchKernelGGL(k_dwq_fwd<3>, grid, dim3(256), 0, (hipStream_t)stream, xc, w, bias, yc, yout, (int)rows, C, M, K, dil,
