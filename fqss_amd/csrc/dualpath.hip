@@ -68,9 +68,8 @@ __device__ __forceinline__ float ln_group_sum(float v) {
     if constexpr (G == 64) {
         return wave_sum(v);
     } else {
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
+        static_assert(G == 16, "rows of 16 lanes (four rows per wave)");
+        return row16_sum(v);
     }
 }
 

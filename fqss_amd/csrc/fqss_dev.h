@@ -70,23 +70,6 @@ __device__ __forceinline__ float ord2f(uint32_t k) {
     return __uint_as_float(u);
 }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // Sum over the 64 lanes of a wave on the DPP crossbar (round 6): six v_add with a lane-permuted source -- pairs, quads, half rows, rows
 // (quad_perm / row_half_mirror / row_mirror), then row 0 into 1 and 2 into 3 (row_bcast:15), then rows 0-1 into 3 (row_bcast:31).  The
 // total is valid in LANE 63 ONLY.  No LDS traffic and ~8-cycle steps, where __shfl_xor is a ds_bpermute_b32 round trip per step (the
@@ -109,7 +92,9 @@ __device__ __forceinline__ T dpp_get(T v) {
 template <typename T>
 __device__ __forceinline__ T wave_sum63(T v) {
 #ifdef FQSS_NO_DPP_SUMS
-    return wave_sum(v);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 #else
     v += dpp_get<0xB1>(v);          // quad_perm:[1,0,3,2]
     v += dpp_get<0x4E>(v);          // quad_perm:[2,3,0,1]
@@ -119,6 +104,49 @@ __device__ __forceinline__ T wave_sum63(T v) {
     v += dpp_get<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3
     return v;
 #endif
+}
+
+// lane 63's value in every lane (v_readlane_b32: through a scalar register)
+template <typename T>
+__device__ __forceinline__ T from_lane63(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    } else {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+        return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+    }
+}
+// the wave's sum / minimum / maximum in EVERY lane: the DPP tree + one readlane (round 6: these were six ds_bpermute round trips, in
+// front of the first normalised element of every LayerNorm row and of every softmax row)
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    return from_lane63(wave_sum63(v));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep(float v) {      // rows outside ROW_MASK read back their own value (min / max: the identity)
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, dpp_get<0xB1>(v)); v = fminf(v, dpp_get<0x4E>(v)); v = fminf(v, dpp_get<0x141>(v)); v = fminf(v, dpp_get<0x140>(v));
+    v = fminf(v, dpp_keep<0x142, 0xa>(v)); v = fminf(v, dpp_keep<0x143, 0xc>(v));
+    return from_lane63(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_get<0xB1>(v)); v = fmaxf(v, dpp_get<0x4E>(v)); v = fmaxf(v, dpp_get<0x141>(v)); v = fmaxf(v, dpp_get<0x140>(v));
+    v = fmaxf(v, dpp_keep<0x142, 0xa>(v)); v = fmaxf(v, dpp_keep<0x143, 0xc>(v));
+    return from_lane63(v);
+}
+// sum over each 16-lane row of the wave, valid in every lane of its row (four DPP steps)
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    v += dpp_get<0x140>(v);
+    return v;
 }
 
 // block-wide sum of N values per thread; result valid in thread 0.  smem: N * (blockDim/64) T's.
