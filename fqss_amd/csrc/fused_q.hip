@@ -930,9 +930,6 @@ struct DwGnBefore {
     double* gacc;                            // partial slots of its output quantizer (= this layer's input range)
 };
 
-#ifndef FQSS_DWB_WAVES
-#define FQSS_DWB_WAVES 1
-#endif
 #ifndef FQSS_DWB_ABL
 #define FQSS_DWB_ABL 0      // timing ablations (tools only): 1 no coefficient sums in the GA prologue, 2 no phase 2, 4 no final reductions, 8 no phase-1 arithmetic
 #endif
@@ -948,7 +945,7 @@ struct DwGnBefore {
 #endif
 template <int KT, bool GA = false, bool GB = false, int ACTC = -1>   // KT: taps known at compile time (3 on the training path) or 0: runtime K <= kTaps;
                                                                        // ACTC >= 0: the activation known at compile time (PReLU in the TCN blocks)
-__global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void k_dwq_bwd(const uint8_t* __restrict__ xc, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ g,
                                                   float* __restrict__ gx, float* gw, int C, int M, int K, int dil, int pad,
                                                   int64_t ld_xc, int64_t ld_g, int64_t ld_gx, int act, const float* slope_p,
@@ -960,15 +957,10 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
     if (ACTC >= 0) act = ACTC;
     extern __shared__ __attribute__((aligned(16))) float sgz[];   // [ceil4(M)]
     __shared__ __attribute__((aligned(16))) float redf[(8 + kTaps) * 4];
-#ifndef FQSS_DWB_NO_PLANES
     // one 4-byte plane per table column: a lookup by a data-dependent code then touches ONE bank per lane and column (the 8-B / 16-B
     // entries made every lookup a 2- / 4-bank access: LDS conflict rate 1.59, profiles/r05_sq_counters.txt)
     __shared__ float tabA0[GA ? 256 : 1], tabA1[GA ? 256 : 1];            // GA: fma(x, c2, c3) | in-range, per code of THIS layer's output
     __shared__ float tabB0[GB ? 256 : 1], tabB1[GB ? 256 : 1], tabB2[GB ? 256 : 1];   // GB: x | c - u or c | in-range, per code of the GroupNorm's input
-#else
-    __shared__ __attribute__((aligned(16))) float2 tabA[GA ? 256 : 1];   // GA: {fma(x, c2, c3), in-range} per code of THIS layer's output
-    __shared__ __attribute__((aligned(16))) float4 tabB[GB ? 256 : 1];   // GB: {x, c - u | c, in-range, -} per code of the GroupNorm's input
-#endif
 #ifdef FQSS_DWB_STAMPS
     unsigned long long stamp_[9];
 #endif
@@ -1002,11 +994,6 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
             }
         }
     };
-#ifdef FQSS_DWB_EARLY
-    // the first pass' operands are requested BEFORE the hand-over prologues (coefficient sums, two barriers, the code tables): they
-    // depend on nothing computed there, and a workgroup lives ~20 us of which the prologue's 2-3 us then cover the HBM round trip
-    issue_loads(4 * (int)threadIdx.x);
-#endif
     QRange r2 = QRange{0.f, 1.f, 1.f};
     float scale2 = 0.f;
     if constexpr (GA) {
@@ -1053,12 +1040,8 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
             float cq2, u2;
             bool in2;
             (void)fq_asym(fmaf(x2, scale2, shift2), r2, cq2, u2, in2);
-#ifndef FQSS_DWB_NO_PLANES
             tabA0[threadIdx.x] = fmaf(x2, c2v, c3v);
             tabA1[threadIdx.x] = in2 ? 1.0f : 0.0f;
-#else
-            tabA[threadIdx.x] = make_float2(fmaf(x2, c2v, c3v), in2 ? 1.0f : 0.0f);
-#endif
         }
     }
     if constexpr (GB) {
@@ -1071,13 +1054,9 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
         float cq1, u1;
         bool in1;
         (void)fq_asym(fmaf(x0, scale1, shift1), rx, cq1, u1, in1);     // that GroupNorm's output quantizer = this layer's input range
-#ifndef FQSS_DWB_NO_PLANES
         tabB0[threadIdx.x] = x0;
         tabB1[threadIdx.x] = in1 ? (cq1 - u1) : cq1;
         tabB2[threadIdx.x] = in1 ? 1.0f : 0.0f;
-#else
-        tabB[threadIdx.x] = make_float4(x0, in1 ? (cq1 - u1) : cq1, in1 ? 1.0f : 0.0f, 0.0f);
-#endif
     }
     if constexpr (GA || GB) __syncthreads();
     DWB_STAMP(1);      // prologue done
@@ -1100,11 +1079,7 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
     }
 
     for (int m0 = 4 * threadIdx.x; m0 < M; m0 += 1024 * GPP) {
-#ifdef FQSS_DWB_EARLY
-        if (m0 != 4 * (int)threadIdx.x) issue_loads(m0);
-#else
         issue_loads(m0);
-#endif
 #pragma unroll
         for (int i = 0; i < GPP; ++i) {
             const int m = m0 + 1024 * i;
@@ -1157,12 +1132,8 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
                     (void)fq_asym(t, ry, cq, u, inr);
                     float gj = valid ? gv[j] : 0.0f;
                     if constexpr (GA) {     // the consuming GroupNormQ's backward apply, on the code this layer's forward wrote
-#ifndef FQSS_DWB_NO_PLANES
                         const unsigned int ca = (unsigned int)cq & 255u;
                         const float2 e2 = make_float2(tabA0[ca], tabA1[ca]);
-#else
-                        const float2 e2 = tabA[(unsigned int)cq & 255u];
-#endif
                         const float gz2 = (e2.y != 0.0f) ? div_by(gv[j] * r2.delta, r2.delta, r2.inv) : 0.0f;
                         gj = valid ? fmaf(gz2, scale2, e2.x) : 0.0f;
                     }
@@ -1224,12 +1195,8 @@ __global__ __launch_bounds__(256, FQSS_DWB_WAVES) void k_dwq_bwd(const uint8_t* 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (m + j < M) {
-#ifndef FQSS_DWB_NO_PLANES
                         const unsigned int cb = (w0 >> (8 * j)) & 255u;
                         const float4 e1 = make_float4(tabB0[cb], tabB1[cb], tabB2[cb], 0.0f);
-#else
-                        const float4 e1 = tabB[(w0 >> (8 * j)) & 255u];
-#endif
                         const bool in1 = e1.z != 0.0f;
                         const float gz1 = in1 ? div_by(a[j] * rx.delta, rx.delta, rx.inv) : 0.0f;
                         q_du += a[j] * e1.y;
