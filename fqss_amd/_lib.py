@@ -121,6 +121,7 @@ _PROTOS = {
     "fqss_layernormq_fwd": [P, P, P, P, P, P, I64, I32, I64, I64, I64, F64, P, P, P],
     "fqss_layernormq_bwd": [P, P, P, P, P, P, P, P, I64, I32, I64, I64, I64, P, P, P, P],
     "fqss_unary_fwd": [P, P, I64, I32, F64, P],
+    "fqss_unary_rows_fwd": [P, P, I64, I32, I64, I64, I32, F64, P],
     "fqss_unary2_fwd": [P, P, I64, I32, F64, F64, P],
     "fqss_unary_bwd": [P, P, P, I64, I32, F64, P],
     "fqss_permute4": [P, P, I64, I64, I64, I32, I64, I64, I64, P],

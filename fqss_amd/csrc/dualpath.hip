@@ -378,6 +378,27 @@ __global__ __launch_bounds__(256) void k_unary_fwd(const float* __restrict__ x, 
         y[i] = r;
     }
 }
+// the same maps on a ROW-STRIDED input (a column block of a wider matrix: the q third of an attention in-projection [R][3E]), dense output:
+// the value read in place instead of through a `.contiguous()` copy (round 6: 32 such copies per Sepformer step).  cols % 4 == 0,
+// 16-B aligned rows; grid (column chunks, rows)
+__global__ __launch_bounds__(256) void k_unary_rows_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int cols, int64_t ld_x,
+                                                         int64_t ld_y, int kind, float p) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= cols) return;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float4 v4 = *reinterpret_cast<const float4*>(x + r * ld_x + c);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kind == 0) o[j] = tanhf(v[j]);
+            else if (kind == 1) o[j] = 1.0f / (1.0f + expf(-v[j]));
+            else if (kind == 2) o[j] = v[j] / p;
+            else o[j] = (0.5f * v[j]) * (1.0f + erff(v[j] * 0.70710678118654752440f));
+        }
+        *reinterpret_cast<float4*>(y + r * ld_y + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
 // ATen: tanh_backward = g * (1 - y*y); sigmoid_backward = g * (1 - y) * y; div by a scalar: g / p
 __global__ __launch_bounds__(256) void k_unary_bwd(const float* __restrict__ g, const float* __restrict__ y,
                                                     float* __restrict__ gx, int64_t n, int kind, float p) {
@@ -1126,6 +1147,18 @@ extern "C" int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, dou
     if (n == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_unary_fwd, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, kind, (float)p, 0.0f);
     return launch_status("fqss_unary_fwd");
+}
+
+extern "C" int fqss_unary_rows_fwd(const float* x, float* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, int kind, double p,
+                                   fqss_stream_t stream) {
+    FQSS_REQUIRE(x && y && rows >= 0 && cols >= 0 && kind >= 0 && kind <= 3, "bad args");
+    FQSS_REQUIRE(kind != 2 || p != 0.0, "division by zero");
+    FQSS_REQUIRE(cols % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= cols && ld_y >= cols && aligned16(x) && aligned16(y),
+                 "rows of 4-float groups, 16-B aligned");
+    if (rows == 0 || cols == 0) return FQSS_OK;
+    const dim3 grid((unsigned)cdiv(cols, 1024), (unsigned)(rows < 65535 ? rows : 65535));
+    hipLaunchKernelGGL(k_unary_rows_fwd, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ld_x, ld_y, kind, (float)p);
+    return launch_status("fqss_unary_rows_fwd");
 }
 
 extern "C" int fqss_unary2_fwd(const float* x, float* y, int64_t n, int kind, double p, double p2, fqss_stream_t stream) {

@@ -1660,8 +1660,32 @@ def mha_prep_bwd(X, gq, gk, gv, E, scale, ranges, gaccs):
     return gX
 
 
+def as_rowmat_view(x):
+    """(rows, cols, ld) when x [..., cols] is a row matrix whose rows are cols contiguous floats, `ld` apart, 16-B aligned and 4-float
+    grouped (a last-dim slice of a contiguous tensor); else None"""
+    if x.dim() < 2 or x.stride(-1) != 1 or x.shape[-1] % 4 != 0 or x.data_ptr() % 16 != 0:
+        return None
+    ld = x.stride(-2)
+    if ld % 4 != 0 or ld < x.shape[-1]:
+        return None
+    exp = ld
+    for d in range(x.dim() - 2, -1, -1):        # the leading dims must collapse into one row index
+        if x.stride(d) != exp:
+            return None
+        exp *= x.shape[d]
+    return x.numel() // x.shape[-1], x.shape[-1], ld
+
+
 def unary_fwd(x, kind, p=1.0):
     _need_gpu(x)
+    if not x.is_contiguous() and _lib.BACKEND != "cpu" and os.environ.get("FQSS_UNARY_INPLACE", "1") != "0":      # (A/B knob)
+        # a column block of a wider row matrix (the q third of an attention in-projection): read in place, written dense
+        rm = as_rowmat_view(x)
+        if rm is not None:
+            rows, cols, ld = rm
+            y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+            _lib.call("fqss_unary_rows_fwd", _p(x), _p(y), rows, cols, ld, cols, kind, float(p), _stream())
+            return y
     x = x.contiguous()
     y = torch.empty_like(x)
     _lib.call("fqss_unary_fwd", _p(x), _p(y), x.numel(), kind, float(p), _stream())

@@ -694,6 +694,11 @@ int fqss_addq_layernorm_bwd_map(const float* g, const float* z, const float* gam
 #define FQSS_UNARY_SIGMOID 1
 #define FQSS_UNARY_DIVS 2
 int fqss_unary_fwd(const float* x, float* y, int64_t n, int kind, double p, fqss_stream_t stream);
+/* the same maps on a row-strided input x [rows][cols] (row stride ld_x: a column block of a wider matrix, read in place), y [rows][cols]
+ * with row stride ld_y; cols, ld_x, ld_y multiples of 4, 16-B aligned rows.  replaces: `q = q / math.sqrt(head_dim)` on the q third of the
+ * in-projection in the float MultiheadAttention (qat_layers.py:889-901 with the quantizers off: the teacher) without the slice copy */
+int fqss_unary_rows_fwd(const float* x, float* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, int kind, double p,
+                        fqss_stream_t stream);
 /* the value maps of the public STE helpers round_ste / floor_ste / grad_sign / clip_ste (qat_quant.py:88-107): torch.round (half
  * to even), floor, sign, clip(x, p, p2); their backward is the identity times a scale (no kernel of its own)                     */
 #define FQSS_UNARY_ROUND 4

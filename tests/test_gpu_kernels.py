@@ -1613,3 +1613,20 @@ def test_gn_dw_fused_bit_identical(B, C, M, dil):
         assert torch.equal(a, b)
         yi = yc2.to(torch.int64)
         assert torch.equal(b[:, 0], yi.sum(dim=(1, 2))) and torch.equal(b[:, 1], (yi * yi).sum(dim=(1, 2)))
+
+
+def test_unary_maps_read_a_column_block_in_place():
+    """fqss_unary_rows_fwd (round 6): the float MultiheadAttention's `q / sqrt(head_dim)` (qat_layers.py:889-901 with the quantizers off: the
+    teacher of cfg 3 / 4 / 5) on the q THIRD of the in-projection [L, B, 3E] read in place -- equal, bit for bit, to the map of a
+    `.contiguous()` copy of the slice, for every map kind and for views that do not qualify (odd width: the copy path)"""
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(37, 5, 3 * 64, generator=g).cuda()
+    for kind, p in ((K.UNARY_TANH, 1.0), (K.UNARY_SIGMOID, 1.0), (K.UNARY_DIVS, 4.0), (K.UNARY_GELU, 1.0)):
+        for lo in (0, 64, 128):
+            v = X[..., lo:lo + 64]
+            assert not v.is_contiguous() and K.as_rowmat_view(v) == (37 * 5, 64, 192)
+            assert torch.equal(K.unary_fwd(v, kind, p), K.unary_fwd(v.contiguous(), kind, p))
+    odd = X[..., 1:63]                                   # not 16-B aligned, not a multiple of 4: the copy path
+    assert K.as_rowmat_view(odd) is None
+    assert torch.equal(K.unary_fwd(odd, K.UNARY_DIVS, 3.0), K.unary_fwd(odd.contiguous(), K.UNARY_DIVS, 3.0))
+    assert torch.equal(K.unary_fwd(X[..., :64], K.UNARY_DIVS, 8.0), X[..., :64] / 8.0)       # (a power of two: exact either way)
