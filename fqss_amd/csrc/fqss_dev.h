@@ -327,11 +327,12 @@ __device__ __forceinline__ void grad_add(float* addr, float v, bool det_on) {
 }
 __device__ __forceinline__ void grad_add(float* addr, float v) {
     if (d_det_ctl.shadow[0] != nullptr && fabsf(v) < 0x1p33f) {     // (NaN / inf / huge: the plain add below)
+        const DetCtl c = d_det_ctl;      // the whole block in ONE batch of scalar loads (nine dependent ones cost a workgroup's tail ~3 us)
 #pragma unroll
         for (int s = 0; s < kDetSlots; ++s) {
-            long long* const sh = d_det_ctl.shadow[s];
-            const long long i = addr - d_det_ctl.base[s];
-            if (sh != nullptr && (unsigned long long)i < (unsigned long long)d_det_ctl.n[s]) {
+            long long* const sh = c.shadow[s];
+            const long long i = addr - c.base[s];
+            if (sh != nullptr && (unsigned long long)i < (unsigned long long)c.n[s]) {
                 const double dv = (double)v;
                 const long long hi = __double2ll_rn(dv * 0x1p30);
                 const long long lo = __double2ll_rn((dv - (double)hi * 0x1p-30) * 0x1p80);
