@@ -540,7 +540,10 @@ class WgradQueue:
     """Weight-gradient launches of quantized 1x1 convolutions, queued during a backward segment and run together by ONE grouped
     launch per <= 25 layers (fqss_qpw_bwd_w_group: no float atomics, bit-reproducible): their results feed nothing but the
     optimizer.  The queue keeps gz / codes alive until flush(); the workspace (arrival tickets + slab slots) belongs to the queue and
-    is allocated once -- flush() of a later step (and of a hipGraph capture) finds it in place."""
+    is allocated once -- flush() of a later step (and of a hipGraph capture) finds it in place.
+    Memory: holding every gz of a backward segment until its flush costs the eager cfg-2 step ~2 GB of peak memory with one segment
+    (50 x 8 x 512 | 128 x 4000 fp32 gradients; 0.5 GB per segment with the four data-parallel segments); inside a captured graph the
+    pool reuses it across replays.  On a 288-GB part that buys the two-launch form; a caller short of memory flushes more often."""
 
     def __init__(self):
         self.jobs, self.ws = [], None

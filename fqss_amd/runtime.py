@@ -815,8 +815,15 @@ class KDTrainStep:
                 self._tgraph.replay()
             self._ahead_key = (x_next, x_next._version)
 
+    def _own_det(self):
+        """FQSS_DETERMINISTIC=1: the device-wide control block must point at THIS step's shadows while its graphs replay -- another step's
+        activate() since the capture would leave the replayed grad_adds on plain fp32 atomics without a word"""
+        if self.det is not None and K.DetMode.owner is not self.det:
+            self.det.activate()
+
     def replay_fwd_bwd(self, x=None, tgt=None, x_next=None):
         """first half of a captured step (fwd + loss + bwd, gradients exchanged); the caller then calls replay_optimize() or skips"""
+        self._own_det()
         self._stage(x, tgt, x_next)
         graphs = self._graphs[0]
         ev = self.comm_events
@@ -836,6 +843,7 @@ class KDTrainStep:
 
     def replay(self, x=None, tgt=None, x_next=None):
         if getattr(self, "_graph_all", None) is not None:
+            self._own_det()
             self._stage(x, tgt, x_next)
             self.arena._host_step += 1
             self._graph_all.replay()

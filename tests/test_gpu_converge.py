@@ -187,6 +187,45 @@ def test_deterministic_mode_repeats_its_bits_and_trains_to_the_reference(golden,
     _gate("tiny convtasnet", out[0][0][None], out[0][1][None], gl, 20, 8.0)
 
 
+def test_deterministic_replays_survive_another_steps_activation(golden, monkeypatch):
+    """the deterministic-mode control block is device-wide; a graph captured under step A's block and replayed after step
+    B has activated ITS block used to fall back to fp32 atomics without a word.  Now a replay re-activates its own block first: A's
+    stream interleaved with B's stays bit-identical to A's stream run alone."""
+    from fqss_amd import kernels as K
+    from fqss_amd.data import synth_batch_2band
+    from fqss_amd.runtime import KDTrainStep
+    from tests.test_gpu_model import _tiny_pair
+    monkeypatch.setenv("FQSS_DETERMINISTIC", "1")
+    g0, gl = golden("tiny_step"), golden("tiny_train_long")
+    B, T, seed0 = int(gl["batch"]), int(gl["samples"]), int(gl["seed0"])
+
+    def run(interleave):
+        model, fmodel = _tiny_pair(g0)
+        a = KDTrainStep(model, fmodel, kd_lambda=0.1, lr=1e-3, clip=5.0)
+        other = None
+        losses = []
+        for i in range(70):
+            x, tgt = synth_batch_2band(B, T, seed0 + i, "cuda")
+            a.maybe_capture(x, tgt)
+            losses.append(a(x, tgt)["loss"].reshape(()).clone())
+            if interleave and i >= 55:          # A replays as graphs by now; B's steps take the control block in between
+                if other is None:
+                    mb, fb = _tiny_pair(g0)
+                    other = KDTrainStep(mb, fb, kd_lambda=0.1, lr=1e-3, clip=5.0)
+                other(x, tgt)
+                assert K.DetMode.owner is other.det
+        assert a._graphs is not None
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), a.arena.flat_p.clone()
+
+    try:
+        la, pa = run(False)
+        lb, pb = run(True)
+    finally:
+        K.DetMode.off()
+    assert torch.equal(la, lb) and torch.equal(pa, pb)
+
+
 def test_tiny_dptnet_trains_to_the_reference_sisdr(golden):
     """the same gate at reduced length for the dual-path family (cfg 3): tiny DPTNetQ of dpt_tiny_step.npz, 160 steps of a stream of
     2 x 400-sample batches, Adam 4e-4 (asteroid DPTNet yaml), LSTM + attention + chunking on the HIP path; three HIP runs"""
