@@ -160,9 +160,13 @@ __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ g, f
 static int check_geom(const FrameGeom& g) {
     FQSS_REQUIRE(g.B > 0 && g.C > 0 && g.H > 0 && g.W > 0, "empty signal");
     FQSS_REQUIRE(g.kh >= 1 && g.kw >= 1 && g.st_h >= 1 && g.st_w >= 1 && g.dh >= 1 && g.dw >= 1 && g.ph >= 0 && g.pw >= 0, "bad geometry");
-    FQSS_REQUIRE(g.Ho == (g.H + 2 * g.ph - (int64_t)g.dh * (g.kh - 1) - 1) / g.st_h + 1 && g.Ho >= 1, "Ho does not match the geometry");
-    FQSS_REQUIRE(g.Wo == (g.W + 2 * g.pw - (int64_t)g.dw * (g.kw - 1) - 1) / g.st_w + 1 && g.Wo >= 1, "Wo does not match the geometry");
+    // (The frame grid is the caller's: for a convolution it is the geometry's own, Ho = (H + 2 ph - dh (kh - 1) - 1) / st_h + 1; when the
+    // signal is a WINDOW of a transposed convolution's output -- cut at the back, padded at the front -- it is that convolution's input
+    // grid.  Both kernels bound every index on both sides: the gather reads zeros outside the signal, the overlap-add drops what lands
+    // there, frames outside the grid are neither produced nor read.)
     FQSS_REQUIRE(g.H + 2 * g.ph >= (int64_t)g.dh * (g.kh - 1) + 1 && g.W + 2 * g.pw >= (int64_t)g.dw * (g.kw - 1) + 1, "signal shorter than the kernel");
+    FQSS_REQUIRE(g.Ho >= 1 && g.Wo >= 1, "empty frame grid");
+    FQSS_REQUIRE(g.Ho <= (g.H + 2 * g.ph - 1) / g.st_h + 1 + g.kh && g.Wo <= (g.W + 2 * g.pw - 1) / g.st_w + 1 + g.kw, "frame grid far past the signal");
     FQSS_REQUIRE(g.ld >= g.Ho * g.Wo && g.sh_ >= g.W && g.sc >= g.sh_ * (g.H - 1) + g.W && g.sb >= g.sc * (g.C - 1) + g.W, "bad strides");
     return FQSS_OK;
 }

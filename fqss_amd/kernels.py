@@ -132,6 +132,12 @@ def _rowmat_collapsed(t):
     return None
 
 
+def rowmat_collapsed_ok(t):
+    """a view the element-wise kernels read in place as a row matrix (as_rowmat): 16-B aligned rows of dense trailing dims"""
+    rm = _rowmat_collapsed(t) if ROWMAT_COLLAPSE else None
+    return rm is not None and rm[2] % 4 == 0 and t.data_ptr() % 16 == 0 and t.dtype == torch.float32
+
+
 ROWMAT_COLLAPSE = os.environ.get("FQSS_ROWMAT_COLLAPSE", "1") != "0"    # element-wise kernels take cropped channel-first views without a dense copy
 
 
@@ -1679,8 +1685,35 @@ def as_rowmat_view(x):
     return x.numel() // x.shape[-1], x.shape[-1], ld
 
 
+def padded_dense(x):
+    """(rows, ld) when x is a row matrix -- trailing dims dense, leading dims one stride: [B, C, M] or [B, C, F, T] out of empty_act --
+    whose rows are padded by less than LD_ALIGN floats and which lies inside its storage up to the last row's padding: an element-wise
+    map may then run over the whole buffer, padding included (the padding holds no data by contract); else None"""
+    if x.dim() < 2 or x.stride(-1) != 1 or x.data_ptr() % 16 != 0:
+        return None
+    rm = rowmat(x) or _rowmat_collapsed(x)
+    if rm is None:
+        return None
+    rows, cols, ld = rm
+    if ld <= cols or ld - cols >= LD_ALIGN or ld % 4 != 0:
+        return None
+    if (x.storage_offset() + rows * ld) * 4 > x.untyped_storage().nbytes():
+        return None
+    return rows, ld
+
+
+def _like_padded(x, rows, ld):
+    return torch.empty(rows * ld, device=x.device, dtype=torch.float32).as_strided(x.shape, x.stride())
+
+
 def unary_fwd(x, kind, p=1.0):
     _need_gpu(x)
+    if not x.is_contiguous() and _lib.BACKEND != "cpu":
+        pd = padded_dense(x)
+        if pd is not None:      # a row-padded activation ([B, C, 110250] / [B, C, F * 431] of HTDemucs): mapped where it lies, padding and all
+            y = _like_padded(x, *pd)
+            _lib.call("fqss_unary_fwd", _p(x), _p(y), pd[0] * pd[1], kind, float(p), _stream())
+            return y
     if not x.is_contiguous() and _lib.BACKEND != "cpu" and os.environ.get("FQSS_UNARY_INPLACE", "1") != "0":      # (A/B knob)
         # a column block of a wider row matrix (the q third of an attention in-projection): read in place, written dense
         rm = as_rowmat_view(x)
@@ -1709,6 +1742,17 @@ def unary2_fwd(x, kind, p=0.0, p2=0.0):
 
 def unary_bwd(g, y, kind, p=1.0):
     _need_gpu(g, y)
+    if y is not None and not y.is_contiguous() and _lib.BACKEND != "cpu":
+        pd = padded_dense(y)
+        if pd is not None:
+            if g.shape != y.shape or g.stride() != y.stride() or padded_dense(g) != pd:      # (the gradient arrives dense or in another layout: into y's)
+                gp = _like_padded(y, *pd)
+                gp.copy_(g)
+                g = gp
+            gx = _like_padded(y, *pd)
+            _lib.call("fqss_unary_bwd", _p(g), _p(y), _p(gx), pd[0] * pd[1], kind, float(p), _stream())
+            return gx
+        y = y.contiguous()
     g = g.contiguous()
     gx = torch.empty_like(g)
     _lib.call("fqss_unary_bwd", _p(g), _p(y), _p(gx), g.numel(), kind, float(p), _stream())
@@ -2162,11 +2206,15 @@ def _sig4(x):
     return x, sb, sc, sh
 
 
-def frames_gather(x, geom):
-    """x [B, C, H, W] -> frames [B, C*kh*kw, Ho*Wo] (rows padded to 16 floats), Ho, Wo"""
+def frames_gather(x, geom, out_hw=None):
+    """x [B, C, H, W] -> frames [B, C*kh*kw, Ho*Wo] (rows padded to 16 floats), Ho, Wo.
+    out_hw: a frame grid other than the geometry's (the adjoint of an overlap-add that wrote a window of its signal, frames_ola): frame
+    positions that reach past the signal read zeros, frames past the grid are not produced"""
     _need_gpu(x)
     B, C, H, W = x.shape
     Ho, Wo = geom.out_hw(H, W)
+    if out_hw is not None:
+        Ho, Wo = out_hw
     if Ho < 1 or Wo < 1:
         raise ValueError(f"convolution input {H}x{W} is shorter than the kernel")
     x, sb, sc, sh = _sig4(x)
@@ -2175,11 +2223,16 @@ def frames_gather(x, geom):
     return f, Ho, Wo
 
 
-def frames_ola(frames, bias, sig_shape, geom):
-    """adjoint of frames_gather (+ per-channel bias): frames [B, C*kh*kw, Ho*Wo] -> y [B, C, H, W]"""
+def frames_ola(frames, bias, sig_shape, geom, out_hw=None):
+    """adjoint of frames_gather (+ per-channel bias): frames [B, C*kh*kw, Ho*Wo] -> y [B, C, H, W].
+    out_hw: the frame grid when it is not the geometry's for this H x W (the signal is a window of a transposed convolution's output: cut
+    at the back, or padded at the front by more than the kernel reaches): contributions that land outside the signal are dropped, frames
+    the grid does not hold contribute nothing"""
     _need_gpu(frames, bias)
     B, C, H, W = sig_shape
     Ho, Wo = geom.out_hw(H, W)
+    if out_hw is not None:
+        Ho, Wo = out_hw
     frames, Bf, R, M, ld = _bcm(frames)
     assert Bf == B and R == C * geom.kh * geom.kw and M == Ho * Wo, "frames do not match the signal shape / geometry"
     y = empty_sig((B, C, H, W), frames.device)

@@ -667,7 +667,8 @@ class Gelu(Function):
 
     @staticmethod
     def forward(ctx, x):
-        x = x.contiguous()
+        if K.padded_dense(x) is None:       # (a row-padded activation is mapped where it lies: kernels.unary_fwd)
+            x = x.contiguous()
         ctx.save_for_backward(x)
         return K.unary_fwd(x, K.UNARY_GELU)
 
@@ -773,9 +774,9 @@ class FramesOla(Function):
     """frames [B, C*kh*kw, Ho*Wo] (+ bias [C]) -> y [B, C, H, W]: the overlap-add half of nn.ConvTranspose1d / 2d"""
 
     @staticmethod
-    def forward(ctx, frames, bias, sig_shape, geom):
-        ctx.geom, ctx.bias = geom, bias
-        return K.frames_ola(frames, bias, sig_shape, geom)
+    def forward(ctx, frames, bias, sig_shape, geom, out_hw=None):
+        ctx.geom, ctx.bias, ctx.out_hw = geom, bias, out_hw
+        return K.frames_ola(frames, bias, sig_shape, geom, out_hw)
 
     @staticmethod
     def backward(ctx, g):
@@ -785,8 +786,8 @@ class FramesOla(Function):
             B, C, H, W = g.shape
             K.chan_sum(g.reshape(B, C, H * W), buf)
             gb = None if direct else buf
-        gf, _, _ = K.frames_gather(g, ctx.geom)
-        return gf, gb, None, None
+        gf, _, _ = K.frames_gather(g, ctx.geom, ctx.out_hw)
+        return gf, gb, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

@@ -33,9 +33,11 @@ from ..qat_utils import quantize_modules, replace_decoderq, replace_encoderq
 # ----------------------------------------------------------------------------------------------------------------------
 # float members on the HIP kernels (BYPASS mode), quantized members as they are
 # ----------------------------------------------------------------------------------------------------------------------
-def run(m, *xs):
+def run(m, *xs, window=None):
+    """window: the slice of a transposed convolution's output the caller keeps (QL.convtr_frames); modules that cannot take it return the
+    whole output and the caller crops"""
     if isinstance(m, QL.LayerQ):
-        y = m(*xs)
+        y = m(*xs, window=window) if (window is not None and isinstance(m, QL._ConvTrQ)) else m(*xs)
         return y[0] if isinstance(y, (list, tuple)) else y
     x = xs[0]
     if isinstance(m, (nn.Identity, nn.Dropout)):
@@ -43,7 +45,7 @@ def run(m, *xs):
     if isinstance(m, (nn.Conv1d, nn.Conv2d)):
         return QL.conv_frames(m, x, m.weight)
     if isinstance(m, (nn.ConvTranspose1d, nn.ConvTranspose2d)):
-        return QL.convtr_frames(m, x, m.weight)
+        return QL.convtr_frames(m, x, m.weight, window=window)
     if isinstance(m, MyGroupNorm):
         return m(x)
     if isinstance(m, nn.GroupNorm):
@@ -70,6 +72,10 @@ class _Window(torch.autograd.Function):
         ctx.cfg = (dim, start, length, x.shape[dim])
         if pad_to is None:
             v = x.narrow(dim, start, length)
+            if CROP_VIEWS and dim == x.dim() - 2 and x.dim() == 4 and K.rowmat_collapsed_ok(v):
+                # a crop along the frequency axis of [B, C, F, T]: planes of F' * T dense floats at the old plane stride -- the element-wise
+                # kernels behind a decoder layer (the next layer's skip add, the activation quantizer) read such a view in place
+                return v
             out = K.empty_act(tuple(v.shape), x.device) if dim == x.dim() - 1 else torch.empty(v.shape, device=x.device, dtype=x.dtype)
             out.copy_(v)
             return out
@@ -98,6 +104,10 @@ class _Window(torch.autograd.Function):
         if start + length < full:
             out.narrow(dim, start + length, full - start - length).zero_()
         return out, None, None, None, None
+
+
+CROP_VIEWS = __import__("os").environ.get("FQSS_CROP_VIEWS", "1") != "0"      # (A/B knob: "0" = every crop is a dense copy)
+FOLD_CROP = __import__("os").environ.get("FQSS_FOLD_CROP", "1") != "0"        # (A/B knob: "0" = transposed convolutions write their whole output)
 
 
 def crop(x, dim, start, length):
@@ -336,14 +346,24 @@ class HDecLayer(nn.Module):
             y = x
             assert skip is None
         y_pre = y            # (`pre` only feeds an `empty` time decoder: not reached with the FQSS configuration)
-        z = run(self.conv_tr, y)
+        # the crop behind the transposed convolution (hdemucsq.py:340-345) is handed to it as a window: GELU and the fake-quant in
+        # between are element-wise, so cropping first gives the same numbers without the margins ever being written
+        window = None
+        if FOLD_CROP:
+            full = (y.shape[-2 if self.freq else -1] - 1) * self.stride + self.kernel_size
+            if self.freq and self.pad:
+                window = (-2, self.pad, full - 2 * self.pad)
+            elif not self.freq:
+                window = (-1, self.pad, length)
+        z = run(self.conv_tr, y, window=window)
         if not self.last:
             z = run(self.gelu, z)
         if self.freq:
-            if self.pad:
+            if self.pad and not (window is not None and z.shape[-2] == window[2]):
                 z = crop(z, -2, self.pad, z.shape[-2] - 2 * self.pad)
-        else:
+        elif not (window is not None and z.shape[-1] == length):
             z = crop(z, -1, self.pad, length)
+        if not self.freq:
             assert z.shape[-1] == length, (z.shape[-1], length)
         return z, y_pre
 

@@ -310,9 +310,12 @@ def conv_frames(conv, x, weight):
 _OWN = object()
 
 
-def convtr_frames(convtr, x, weight, bias=_OWN):
+def convtr_frames(convtr, x, weight, bias=_OWN, window=None):
     """nn.ConvTranspose1d / 2d (groups = 1): pointwise GEMM with the [Co*kh*kw, Ci] transposed weight, then the deterministic
-    overlap-add fqss_frames_ola (+ bias).  hdemucsq.py:303-347 (`conv_tr`), qat_layers.py:296-435.  Returns the float output."""
+    overlap-add fqss_frames_ola (+ bias).  hdemucsq.py:303-347 (`conv_tr`), qat_layers.py:296-435.  Returns the float output.
+    window = (dim, start, length), dim -2 | -1: only out[..., start : start + length (, :)] is wanted (the crop behind every decoder
+    layer of HTDemucs, hdemucsq.py:340-345) -- the overlap-add writes just that window (a crop at the front is a padding of the transposed
+    convolution, one at the back a shorter signal), its adjoint gathers from the window's gradient: no dense copy either way."""
     x = ops.real(x)
     one_d = x.dim() == 3
     geom = _conv_geom(convtr, one_d)
@@ -323,6 +326,15 @@ def convtr_frames(convtr, x, weight, bias=_OWN):
     W = (Wi - 1) * geom.sw - 2 * geom.pw + geom.dw * (geom.kw - 1) + op[1] + 1
     if geom.out_hw(H, W) != (Hi, Wi):
         raise ValueError("ConvTranspose: output_padding must be smaller than the stride")
+    if window is not None:
+        dim, start, length = window
+        full = H if dim == -2 else W
+        if dim not in (-2, -1) or (one_d and dim == -2) or start < 0 or length < 1 or start + length > full:
+            raise ValueError(f"convtr_frames: window {window} outside the output ({H} x {W})")
+        if dim == -2:
+            geom, H = K.ConvGeom((geom.kh, geom.kw), (geom.sh, geom.sw), (geom.ph + start, geom.pw), (geom.dh, geom.dw)), length
+        else:
+            geom, W = K.ConvGeom((geom.kh, geom.kw), (geom.sh, geom.sw), (geom.ph, geom.pw + start), (geom.dh, geom.dw)), length
     Co = convtr.out_channels
     ops_dp.touch(weight)
     wt = weight.reshape(Ci, -1).t().contiguous().unsqueeze(-1)           # [Co*kh*kw, Ci, 1]: a transposing copy of the (small) weight
@@ -334,7 +346,7 @@ def convtr_frames(convtr, x, weight, bias=_OWN):
         wt._fqss_gwq = gwt
         wt._fqss_gwq_done = lambda: K.axpby_(gwq.reshape(Ci, -1), K.transpose2d(gwt.reshape(-1, Ci)), 1.0)
     frames = ops.LinearActQ.apply(x4.reshape(B, Ci, Hi * Wi), wt, None, None, None, None, ops._Lin("pw", six=True), ops.ACT_NONE, ops.BYPASS)
-    y = ops_dp.FramesOla.apply(frames, convtr.bias if bias is _OWN else bias, (B, Co, H, W), geom)
+    y = ops_dp.FramesOla.apply(frames, convtr.bias if bias is _OWN else bias, (B, Co, H, W), geom, (Hi, Wi))
     return y.squeeze(2) if one_d else y
 
 
@@ -1219,9 +1231,15 @@ class _ConvTrQ(LayerQ):
         if self._has_nl:
             self.nl = nl
 
-    def forward(self, x):
+    def forward(self, x, window=None):
+        """window (convtr_frames): the caller keeps only that slice of the output.  Taken into the transposed convolution when the output
+        quantizer is past its observer phase (the observers see the WHOLE output, qat_layers.py:296-435 + hdemucsq.py:340-345; fake-quant
+        and the non-linearity are element-wise and commute with the crop); the caller crops whatever comes back un-cropped."""
         c = getattr(self, self._attr)
-        return fq_node(self.activation_fake_quantize, convtr_frames(c, x, self._wq(c.weight)), self.nl if self._has_nl else None)
+        aq = self.activation_fake_quantize
+        if window is not None and getattr(aq, "observer_mode", False) and aq.n_iter < aq.max_observations:
+            window = None
+        return fq_node(aq, convtr_frames(c, x, self._wq(c.weight), window=window), self.nl if self._has_nl else None)
 
 
 class ConvTranspose1dQ(_ConvTrQ):
