@@ -125,6 +125,7 @@ _PROTOS = {
     "fqss_unary2_fwd": [P, P, I64, I32, F64, F64, P],
     "fqss_unary_bwd": [P, P, P, I64, I32, F64, P],
     "fqss_permute4": [P, P, I64, I64, I64, I32, I64, I64, I64, P],
+    "fqss_permute4_ld": [P, P, I64, I64, I64, I32, I64, I64, I64, I64, P],
     "fqss_dp_segment_fwd": [P, P, I32, I32, I64, I64, I32, I32, P],
     "fqss_dp_segment_bwd": [P, P, I32, I32, I64, I64, I32, I32, P],
     "fqss_dp_merge_fwd": [P, P, P, I32, I32, I32, I32, I32, I64, I64, P],

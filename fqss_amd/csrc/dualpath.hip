@@ -433,6 +433,35 @@ __global__ __launch_bounds__(256) void k_permute4(const float* __restrict__ x, f
     }
 }
 
+// ... with the output rows `ld_y` floats apart (ld_y % 4 == 0, y 16-B aligned: a row-padded activation, so that everything behind the
+// move -- and every gradient coming back -- has 16-B aligned rows): a thread moves 4 consecutive c with one 16-B store; the loads are
+// one (possibly unaligned) 16-B request where the whole group lies inside the row.  Padding columns c >= C receive zeros.
+struct __attribute__((packed, aligned(4))) P4U { float x, y, z, w; };
+__global__ __launch_bounds__(256) void k_permute4_ld(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int n1, int n2, int C,
+                                                      int64_t s0, int64_t s1, int64_t s2, int64_t ld_y) {
+    const int groups = (int)(ld_y >> 2);
+    const int64_t total = rows * groups;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / groups;
+        const int c = (int)(i - r * groups) * 4;
+        const int64_t t = r / n2;
+        const int i2 = (int)(r - t * n2);
+        const int64_t i0 = t / n1;
+        const int i1 = (int)(t - i0 * n1);
+        const float* xr = x + i0 * s0 + (int64_t)i1 * s1 + (int64_t)i2 * s2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 3 < C) {
+            const P4U u = *reinterpret_cast<const P4U*>(xr + c);
+            v = make_float4(u.x, u.y, u.z, u.w);
+        } else {
+            if (c < C) v.x = xr[c];
+            if (c + 1 < C) v.y = xr[c + 1];
+            if (c + 2 < C) v.z = xr[c + 2];
+        }
+        *reinterpret_cast<float4*>(y + r * ld_y + c) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ chunking
 // split_feature (dptnetq.py:247-259) fused with the move to the intra-chunk row layout:
 //   seg[k][b*S + s][n] = fpad[b][n][(s>>1)*K + (s&1)*P + k],  fpad = P zeros | f[b][n][0..T) | rest zeros | P zeros
@@ -1182,6 +1211,16 @@ extern "C" int fqss_permute4(const float* x, float* y, int64_t n0, int64_t n1, i
     if (n == 0) return FQSS_OK;
     hipLaunchKernelGGL(k_permute4, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n0, n1, n2, C, s0, s1, s2);
     return launch_status("fqss_permute4");
+}
+
+extern "C" int fqss_permute4_ld(const float* x, float* y, int64_t n0, int64_t n1, int64_t n2, int C, int64_t s0, int64_t s1,
+                                int64_t s2, int64_t ld_y, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && y && n0 >= 0 && n1 >= 0 && n2 >= 0 && C > 0, "bad args");
+    FQSS_REQUIRE(ld_y >= C && ld_y % 4 == 0 && aligned16(y) && n1 < (1ll << 31) && n2 < (1ll << 31), "padded output rows: 16-B aligned, a multiple of 4 floats apart");
+    const int64_t rows = n0 * n1 * n2;
+    if (rows == 0) return FQSS_OK;
+    hipLaunchKernelGGL(k_permute4_ld, dim3(flat_grid(rows * (ld_y / 4))), dim3(256), 0, (hipStream_t)stream, x, y, rows, (int)n1, (int)n2, C, s0, s1, s2, ld_y);
+    return launch_status("fqss_permute4_ld");
 }
 
 extern "C" int fqss_dp_segment_fwd(const float* f, float* seg, int B, int N, int64_t T, int64_t ld_f, int K, int S,

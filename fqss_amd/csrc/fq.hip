@@ -44,6 +44,20 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// a 4-float group of a row with `left` columns remaining: one 16-B store, or -- the row's last, partial group -- only its live elements
+// (nothing past the last column is written: the output may be a column block of a wider matrix)
+template <int N>
+__device__ __forceinline__ void store_group4(float* p, const float (&o)[N], int64_t left) {
+    static_assert(N == 4, "16-B groups");
+    if (left >= 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        p[0] = o[0];
+        if (left > 1) p[1] = o[1];
+        if (left > 2) p[2] = o[2];
+    }
+}
+
 // POSTRELU (template): act = FQSS_ACT_POST_RELU: no map in FRONT of the quantizer, a ReLU BEHIND it -- relu(fq(z)), the `F.relu` between LSTMQ
 // and LinearQ of DPTNet's transformer layer (dptnetq.py:84-97) -- in the quantizer's pass each way
 template <int VEC, bool GELU = false, bool POSTRELU = false>
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(256) void k_actq_fwd(const float* __restrict__ z, f
                 if (POSTRELU) o[j] = o[j] > 0.0f ? o[j] : 0.0f;
             }
             if constexpr (VEC == 4) {
-                if (out != nullptr) *reinterpret_cast<float4*>(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (out != nullptr) store_group4(orow + c0, o, cols - c0);
                 if (qmode == FQSS_Q_QUANT && idx != nullptr && (ld_i & 3) == 0)
                     *reinterpret_cast<unsigned int*>(idx + row * ld_i + c0) = packed;
             } else {
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
                             const float gv[VEC] = {ga[i].x, ga[i].y, ga[i].z, ga[i].w};
                             float o[VEC];
                             group(zv, gv, c_first, o);
-                            *reinterpret_cast<float4*>(gz + row * ld_gz + c_first) = make_float4(o[0], o[1], o[2], o[3]);
+                            store_group4(gz + row * ld_gz + c_first, o, cols - c_first);
                         }
                 }
             }
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(256) void k_actq_bwd(const float* __restrict__ z, c
                     }
                     group(zv, gv, c0, o);
                     if constexpr (VEC == 4) {
-                        *reinterpret_cast<float4*>(or_ + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                        store_group4(or_ + c0, o, cols - c0);
                     } else {
                         or_[c0] = o[0];
                     }
@@ -713,12 +727,14 @@ extern "C" int fqss_actq_fwd(const float* z, float* out, uint8_t* idx, int64_t r
     FQSS_REQUIRE(qmode != FQSS_Q_QUANT || (qmin && qmax), "QUANT needs ranges");
     FQSS_REQUIRE(qmode != FQSS_Q_OBSERVE || obs_ws, "OBSERVE needs obs_ws");
     if (rows == 0 || cols == 0) return FQSS_OK;
-    // The 16-B path stores whole float4 / packed-code groups: the last group of a row may write up to 3 elements past `cols`.  That is
-    // only this row's own padding when cols % 4 == 0 (nothing past cols is written) or when fewer than 4 elements separate cols from the
-    // row stride (an activation buffer padded by its owner); a column-block VIEW of a wider matrix (ld - cols >= 4) would have its
-    // neighbour's columns clobbered, so it takes the element path.
-    const bool tail_ok = (cols % 4 == 0) || (out == nullptr) || (ld_out - cols < 4);
-    const bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0) && tail_ok;
+    // The 16-B path reads whole float4 groups (the last group of a row stays inside its stride) and stores a row's last, partial group
+    // element by element (store_group4: the output may be a column block of a wider matrix).  Round 6; before, "fewer than 4 floats of
+    // row padding" was required and every activation padded to 64 B by more -- [B, C, 110250] -> 110256 -- took the one-element path.
+    // (The packed codes of a partial group go out as one word: code rows are padded by their owner, kernels.empty_codes.)
+    bool vec = aligned16(z) && (!out || aligned16(out)) && (ld_z % 4 == 0) && (ld_out % 4 == 0);
+#ifdef FQSS_OLD_TAIL_RULE      // (A/B builds only: `make variant SRC=fq NAME=oldtail DEFS=-DFQSS_OLD_TAIL_RULE`)
+    vec = vec && ((cols % 4 == 0) || (out == nullptr) || (ld_out - cols < 4));
+#endif
     hipStream_t s = (hipStream_t)stream;
     if (vec && act < FQSS_ACT_GELU && qmode == FQSS_Q_QUANT && cols % 4 == 0 && cols <= 512 && rows >= 1024 &&
         (!idx || ((ld_idx & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0))) {
@@ -807,9 +823,13 @@ extern "C" int fqss_actq_bwd(const float* z, const float* g, float* gz, int64_t 
         // narrow matrix (see k_actq_fwd_narrow): the row-tiled kernel of fqss_actq_bwd_colbias, without the bias sums
         return fqss_actq_bwd_colbias(z, g, gz, rows, (int)cols, ld_z, ld_g, ld_gz, act, slope, qmode, qmin, qmax, gacc, nullptr, stream);
     if (!gbias || C <= 0) C = rows;   // no channel semantics: every row is its own "channel"
-    // (same rule as fqss_actq_fwd: a float4 store past `cols` must land in this row's own padding, never in a neighbouring column block)
-    const bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0) &&
-                     ((cols % 4 == 0) || (ld_gz - cols < 4));
+    // (16-B groups whenever the rows are 16-B aligned: the loads of a row's last group stay inside its stride, the store of a partial
+    // group writes its live elements only -- round 6; the rule before, "fewer than 4 floats of padding", sent every activation whose
+    // rows are padded to 64 B by more than that -- [B, C, 110250] -> 110256 -- down the one-element path)
+    bool vec = aligned16(z) && aligned16(g) && aligned16(gz) && (ld_z % 4 == 0) && (ld_g % 4 == 0) && (ld_gz % 4 == 0);
+#ifdef FQSS_OLD_TAIL_RULE
+    vec = vec && ((cols % 4 == 0) || (ld_gz - cols < 4));
+#endif
     hipStream_t s = (hipStream_t)stream;
     const int v = vec ? 4 : 1;
     int64_t gx = cdiv(cols, 256 * (int64_t)v);

@@ -1759,14 +1759,20 @@ def unary_bwd(g, y, kind, p=1.0):
     return gx
 
 
-def permute4(x, dims_out, strides_in, C, dense=True):
+def permute4(x, dims_out, strides_in, C, dense=True, pad_out=False):
     """y[i0][i1][i2][:C] = x[i0*s0 + i1*s1 + i2*s2 : +C]   (strides in elements; dense: they assume a contiguous x -- else they are x's
-    own strides and only its last dim must have unit stride: a view of a row-padded buffer is read in place)"""
+    own strides and only its last dim must have unit stride: a view of a row-padded buffer is read in place).
+    pad_out: y is a row-padded activation (empty_act: rows 16-B aligned) instead of a dense tensor -- for C % 4 != 0 every element-wise
+    kernel behind the move then takes its 16-B form (fqss_permute4_ld)"""
     _need_gpu(x)
     if dense or x.stride(-1) != 1:
         assert dense, "permute4: explicit strides need a unit stride along the last dim"
         x = x.contiguous()
     n0, n1, n2 = dims_out
+    if pad_out and C % 4 != 0 and _lib.BACKEND != "cpu":
+        y = empty_act((n0, n1, n2, C), x.device)
+        _lib.call("fqss_permute4_ld", _p(x), _p(y), n0, n1, n2, C, strides_in[0], strides_in[1], strides_in[2], y.stride(-2), _stream())
+        return y
     y = torch.empty(n0, n1, n2, C, device=x.device, dtype=torch.float32)
     _lib.call("fqss_permute4", _p(x), _p(y), n0, n1, n2, C, strides_in[0], strides_in[1], strides_in[2], _stream())
     return y

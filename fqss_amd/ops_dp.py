@@ -331,14 +331,23 @@ class Permute4(Function):
     """y[i0, i1, i2, :] = x viewed with element strides `sin`; the backward is the inverse move (`sback` over x's own dims)"""
 
     @staticmethod
-    def forward(ctx, x, dims_out, sin, dims_in, sback, dense=True):
-        """dense=False: `sin` are x's own strides (a view of a row-padded buffer is read in place, no contiguous() copy first)"""
-        ctx.dims_in, ctx.sback, ctx.C, ctx.xshape = dims_in, sback, x.shape[-1], tuple(x.shape)
-        return K.permute4(x.contiguous() if dense else x, dims_out, sin, x.shape[-1], dense)
+    def forward(ctx, x, dims_out, sin, dims_in, sback, dense=True, back_perm=None, pad_fwd=False, pad_bwd=False):
+        """dense=False: `sin` are x's own strides (a view of a row-padded buffer is read in place, no contiguous() copy first).
+        back_perm: for each of the three input dims the output dim it came from -- the backward then reads a row-padded gradient in
+        place through ITS strides instead of a dense copy through `sback`.  pad_fwd / pad_bwd: the output / the gradient handed back
+        is a row-padded activation (K.permute4 pad_out) -- the side on which rows of C floats are streamed by element-wise kernels."""
+        ctx.dims_in, ctx.sback, ctx.C, ctx.xshape, ctx.back_perm, ctx.pad_bwd = dims_in, sback, x.shape[-1], tuple(x.shape), back_perm, pad_bwd
+        return K.permute4(x.contiguous() if dense else x, dims_out, sin, x.shape[-1], dense, pad_out=pad_fwd)
 
     @staticmethod
     def backward(ctx, g):
-        return K.permute4(g.contiguous(), ctx.dims_in, ctx.sback, ctx.C).view(ctx.xshape), None, None, None, None, None
+        bp = ctx.back_perm
+        if bp is not None and g.dim() == 4 and g.stride(-1) == 1 and not g.is_contiguous():
+            st = g.stride()
+            gx = K.permute4(g, ctx.dims_in, (st[bp[0]], st[bp[1]], st[bp[2]]), ctx.C, dense=False, pad_out=ctx.pad_bwd)
+        else:
+            gx = K.permute4(g.contiguous(), ctx.dims_in, ctx.sback, ctx.C, pad_out=ctx.pad_bwd)
+        return (gx if tuple(gx.shape) == ctx.xshape else gx.view(ctx.xshape)), None, None, None, None, None, None, None, None
 
 
 PERMUTE_CODES = __import__("os").environ.get("FQSS_PERMUTE_CODES", "1") != "0"    # the u8 codes of a row tensor travel through the layout change

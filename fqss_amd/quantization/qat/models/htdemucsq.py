@@ -37,7 +37,7 @@ def run(m, *xs, window=None):
     """window: the slice of a transposed convolution's output the caller keeps (QL.convtr_frames); modules that cannot take it return the
     whole output and the caller crops"""
     if isinstance(m, QL.LayerQ):
-        y = m(*xs, window=window) if (window is not None and isinstance(m, QL._ConvTrQ)) else m(*xs)
+        y = m(*xs, window=window) if (window is not None and isinstance(m, (QL._ConvTrQ, QL.ConvTr1dDecoderQ, QL.ConvTr2dDecoderQ))) else m(*xs)
         return y[0] if isinstance(y, (list, tuple)) else y
     x = xs[0]
     if isinstance(m, (nn.Identity, nn.Dropout)):
@@ -138,14 +138,22 @@ class _Transpose(torch.autograd.Function):
 SWAP_IN_PLACE = __import__("os").environ.get("FQSS_SWAP_IN_PLACE", "1") != "0"    # swap_mid reads a row-padded view in place (A/B)
 
 
-def swap_mid(x):
-    """[B, P, Q, T] -> [B, Q, P, T] dense (T-long contiguous chunks move: fqss_permute4)"""
+SWAP_PAD_ROWS = __import__("os").environ.get("FQSS_SWAP_PAD_ROWS", "1") != "0"   # (A/B knob)
+
+
+def swap_mid(x, rows_out=None):
+    """[B, P, Q, T] -> [B, Q, P, T] (T-long contiguous chunks move: fqss_permute4).  rows_out True: the result is streamed as rows of T
+    floats (DConv over [B F, C, T]): a row-padded activation, rows 16-B aligned, so the element-wise kernels behind it take their 16-B
+    forms (T = 431); False: the INPUT was such rows (DConv's output), the result dense planes -- the gradient handed back is row-padded.
+    None: dense both ways."""
     x = ops.real(x)
     if x.stride(-1) != 1 or not SWAP_IN_PLACE:
         x = x.contiguous()
     B, P, Q, T = x.shape
     sB, sP, sQ, _ = x.stride()          # (a view of a row-padded buffer -- DConv's output reshaped -- is read in place)
-    return ops_dp.Permute4.apply(x, (B, Q, P), (sB, sQ, sP), (B, P, Q), (P * Q * T, T, P * T), False)
+    pad = SWAP_PAD_ROWS and rows_out is not None
+    return ops_dp.Permute4.apply(x, (B, Q, P), (sB, sQ, sP), (B, P, Q), (P * Q * T, T, P * T), False, (0, 2, 1) if pad else None,
+                                 pad and rows_out, pad and not rows_out)
 
 
 def _fadd(a, b):
@@ -253,8 +261,8 @@ class ScaledEmbedding(nn.Module):
 def _dconv_freq(dconv, y):
     """DConv over time with the frequency axis folded into the batch (hdemucsq.py:150-156)"""
     B, C, Fr, T = y.shape
-    z = dconv(swap_mid(y).reshape(B * Fr, C, T))
-    return swap_mid(ops.real(z).reshape(B, Fr, C, T))
+    z = dconv(swap_mid(y, True).reshape(B * Fr, C, T))
+    return swap_mid(ops.real(z).reshape(B, Fr, C, T), False)
 
 
 class HEncLayer(nn.Module):

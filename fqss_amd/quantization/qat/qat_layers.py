@@ -571,9 +571,10 @@ class ResidualErrorBlock(LayerQ):
         self.weight_fake_quantize = (get_weight_quantizer(gradient_based, self.residual_encoder.weight.shape, n_bits=weight_n_bits)
                                      if weight_quant else nn.Identity())
 
-    def forward(self, Y, y_q, w_decoder, decoder_conv=None, out_quantizer=None):
+    def forward(self, Y, y_q, w_decoder, decoder_conv=None, out_quantizer=None, window=None):
         """reference signature is (Y, y_q, w_decoder); the two optional arguments let the owning
-        decoder fuse its `activation_fake_quantize_residual` into the transposed-conv node"""
+        decoder fuse its `activation_fake_quantize_residual` into the transposed-conv node; window (convtr_frames): the slice of the
+        decoded error the caller keeps (the general form only; the caller checks the output quantizer's phase)"""
         enc = self.residual_encoder
         if self.decoder_type is nn.Linear:      # qat_layers.py:1178-1187 (rows [..., E]); LinearDecoderQ inlines this sequence
             Y_q = ops_dp.RowLinear.apply(ops.real(y_q), self._wq(enc.weight), enc.bias)
@@ -583,7 +584,7 @@ class ResidualErrorBlock(LayerQ):
             aq.after_forward(q)
             return ops_dp.RowLinear.apply(Y1, w_decoder, None)
         if self.decoder_type is nn.ConvTranspose2d or not _is_mono_decoder(self._decoder_geom):
-            return self._forward_general(Y, y_q, w_decoder, out_quantizer)
+            return self._forward_general(Y, y_q, w_decoder, out_quantizer, window)
         Y_q = run_conv1d(enc, y_q, self._wq(enc.weight), None, None)
         aq = self.activation_fake_quantize
         q = aq.qctx()
@@ -602,7 +603,7 @@ class ResidualErrorBlock(LayerQ):
         return run_convtr1d(decoder_conv, Y1, w_decoder, out_quantizer)
 
 
-    def _forward_general(self, Y, y_q, w_decoder, out_quantizer):
+    def _forward_general(self, Y, y_q, w_decoder, out_quantizer, window=None):
         """stereo / biased / 2-D decoders of HTDemucs (qat_layers.py:1189-1216): the same sequence over the frame kernels.
         Quirks kept: the residual encoder ignores the decoder's padding; the 1-D decode drops the bias, the 2-D decode uses
         `residual_decoder.bias` (so the 2-D form needs train_res_dec=True, as the reference does)"""
@@ -622,7 +623,22 @@ class ResidualErrorBlock(LayerQ):
         else:
             bias = None
         w = self.weight_fake_quantize_dec(self.residual_decoder.weight) if self.train_res_dec else w_decoder
-        return fq_node(out_quantizer, convtr_frames(dec, Y1, w, bias=bias))
+        return fq_node(out_quantizer, convtr_frames(dec, Y1, w, bias=bias, window=window))
+
+
+def _observing(aq):
+    return bool(getattr(aq, "observer_mode", False)) and aq.n_iter < aq.max_observations
+
+
+def _decoder_window(layer, window, convtr):
+    """the window a two-channel decoder layer hands to its residual decode, or None: two outputs (a third channel would re-encode the
+    cropped second one), both output quantizers past their observer phase, the general (frame) form of the transposed convolution"""
+    if window is None or layer.n_combiner != 2 or _observing(layer.activation_fake_quantize) \
+            or _observing(layer.activation_fake_quantize_residual):
+        return None
+    if isinstance(convtr, nn.ConvTranspose1d) and _is_mono_decoder(convtr):
+        return None
+    return window
 
 
 def _is_mono_decoder(convtr):
@@ -665,16 +681,22 @@ class ConvTr1dDecoderQ(LayerQ):
             self.activation_fake_quantize_residual = (get_activation_quantizer(gradient_based, n_bits=out_act_n_bits)
                                                       if out_quant else _BypassQuantizer())
 
-    def forward(self, x):
+    def forward(self, x, window=None):
+        """window (convtr_frames): HTDemucs keeps a slice of the last time-branch layer's outputs (hdemucsq.py:340-345).  With two output
+        channels past their observer phase the residual decode writes just that slice and the first channel -- which the residual block
+        re-encodes whole -- is cropped by the stacking copy; else the window is ignored (the caller crops)."""
         w_decoder = self._wq(self.convTr1d.weight)
         if self.n_combiner == 1:
             return run_convtr1d(self.convTr1d, x, w_decoder, self.activation_fake_quantize)
+        window = _decoder_window(self, window, self.convTr1d)
         x_dec, x_res = ops.fork2(x)
         y = run_convtr1d(self.convTr1d, x_dec, w_decoder, self.activation_fake_quantize)
         outs = [y]
         for _ in range(1, self.n_combiner):
-            y = self.residual_error_block(x_res, y, w_decoder, self.convTr1d, self.activation_fake_quantize_residual)
+            y = self.residual_error_block(x_res, y, w_decoder, self.convTr1d, self.activation_fake_quantize_residual, window=window)
             outs.append(y)
+        if window is not None:
+            outs[0] = ops.real(outs[0]).narrow(*window[:2], window[2])
         return torch.stack(outs)
 
 
@@ -1237,7 +1259,7 @@ class _ConvTrQ(LayerQ):
         and the non-linearity are element-wise and commute with the crop); the caller crops whatever comes back un-cropped."""
         c = getattr(self, self._attr)
         aq = self.activation_fake_quantize
-        if window is not None and getattr(aq, "observer_mode", False) and aq.n_iter < aq.max_observations:
+        if window is not None and _observing(aq):
             window = None
         return fq_node(aq, convtr_frames(c, x, self._wq(c.weight), window=window), self.nl if self._has_nl else None)
 
@@ -1319,15 +1341,19 @@ class ConvTr2dDecoderQ(LayerQ):
             self.activation_fake_quantize_residual = (get_activation_quantizer(gradient_based, n_bits=out_act_n_bits)
                                                       if out_quant else _BypassQuantizer())
 
-    def forward(self, x):
+    def forward(self, x, window=None):
+        """window: as ConvTr1dDecoderQ.forward"""
         w_decoder = self._wq(self.convTr2d.weight)
         y = fq_node(self.activation_fake_quantize, convtr_frames(self.convTr2d, x, w_decoder))
         if self.n_combiner == 1:
             return y
+        window = _decoder_window(self, window, self.convTr2d)
         outs = [y]
         for _ in range(1, self.n_combiner):
-            y = self.residual_error_block(x, y, w_decoder, self.convTr2d, self.activation_fake_quantize_residual)
+            y = self.residual_error_block(x, y, w_decoder, self.convTr2d, self.activation_fake_quantize_residual, window=window)
             outs.append(y)
+        if window is not None:
+            outs[0] = ops.real(outs[0]).narrow(*window[:2], window[2])
         return torch.stack(outs)
 
 

@@ -712,6 +712,11 @@ int fqss_unary_bwd(const float* g, const float* y, float* gx, int64_t n, int kin
  * replaces: the permute().contiguous() pairs of DPT.forward / SingleTransformer.forward (dptnetq.py:156, 197-204) */
 int fqss_permute4(const float* x, float* y, int64_t n0, int64_t n1, int64_t n2, int C, int64_t s0, int64_t s1,
                   int64_t s2, fqss_stream_t stream);
+/* ... into row-padded output: y[((i0 n1 + i1) n2 + i2) ld_y + c], ld_y >= C a multiple of 4, y 16-B aligned; the padding columns are
+ * zero-filled.  (The [B, F, C, T] image HTDemucs' frequency-branch DConv works on, hdemucsq.py:126-143 / demucsq.py:168-182, T = 431: with
+ * padded rows every element-wise kernel behind the move and every gradient coming back runs its 16-B form.) */
+int fqss_permute4_ld(const float* x, float* y, int64_t n0, int64_t n1, int64_t n2, int C, int64_t s0, int64_t s1,
+                     int64_t s2, int64_t ld_y, fqss_stream_t stream);
 
 /* split_feature (dptnetq.py:232-259) straight into the intra-chunk row layout:
  *   f [B][N][T] (row stride ld_f) -> seg [K][B*S][N], S = 2*(T + rest + K/2)/K half-overlapped chunks of length K

@@ -63,6 +63,8 @@ def main():
             return real(name, *a)
         fr = [x for x in traceback.extract_stack()[:-1] if "fqss_amd" in x.filename and "_lib.py" not in x.filename]
         where = " <- ".join(f"{os.path.basename(x.filename)}:{x.lineno}" for x in fr[-4:])
+        if os.environ.get("KSITES_ARGS"):      # the small integer arguments (rows, columns, row strides): which launches take an unaligned form
+            where += "  " + str(tuple(v for v in a if isinstance(v, int) and 0 <= v < (1 << 24)))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = real(name, *a)
