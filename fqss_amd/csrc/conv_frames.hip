@@ -244,6 +244,51 @@ extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y,
     return launch_status("fqss_frames_ola");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Halo-packed signal of a stride-1 convolution (round 6): xp[b][c] = one plane of `plane` floats = Hp rows of Wp floats, the signal's
+// element (h, w) at row h + ph, column w + pw, zeros everywhere else (the halo IS the convolution's zero padding, the tail of the plane
+// slack for the last row's taps).  On this image every tap of a stride-1 convolution is a constant shift of the flat plane, so the
+// GEMM kernels read their B operand straight from it (k_qgemm<.., IMP>, k_gemm_x3<.., IMP>) and the frame image -- kh kw times the
+// signal, written by fqss_frames_gather and read back -- is never made; the pack moves the signal once.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_pack(const float* __restrict__ x, float* __restrict__ xp, int64_t planes, int C, int H, int W,
+                                                    int64_t sb, int64_t sc, int64_t sh_, int ph, int pw, int Wp, int64_t plane) {
+    const int groups = (int)(plane >> 2);
+    const float inv_wp = 1.0f / (float)Wp;
+    for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
+        const int64_t b = bc / C, c = bc - b * C;
+        const float* xb = x + b * sb + c * sc;
+        float* op = xp + bc * plane;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < groups; i += gridDim.x * 256) {
+            int hp, wp;
+            div_small(4 * i, Wp, inv_wp, hp, wp);       // (Wp % 4 == 0: a group never straddles rows)
+            const int h = hp - ph;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (h >= 0 && h < H) {
+                const float* xr = xb + (int64_t)h * sh_;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int w = wp + q - pw;
+                    if (w >= 0 && w < W) v[q] = xr[w];
+                }
+            }
+            *reinterpret_cast<float4*>(op + 4 * (int64_t)i) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+extern "C" int fqss_halo_pack(const float* x, float* xp, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh,
+                              int ph, int pw, int64_t Wp, int64_t plane, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && xp, "null pointer");
+    FQSS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && ph >= 0 && pw >= 0, "bad shape");
+    FQSS_REQUIRE(Wp % 4 == 0 && Wp >= W + 2 * pw && plane % 4 == 0 && plane >= (H + 2 * ph) * Wp && plane < (1ll << 24) && aligned16(xp),
+                 "packed planes: rows of Wp % 4 == 0 floats, plane % 4 == 0 and < 2^24");
+    FQSS_REQUIRE(sh >= W && sc >= sh * (H - 1) + W && (B == 1 || sb >= sc * (C - 1) + W), "bad strides");
+    hipLaunchKernelGGL(k_halo_pack, plane_grid(plane, B * C), dim3(256), 0, (hipStream_t)stream, x, xp, B * C, (int)C, (int)H, (int)W, sb, sc, sh, ph, pw,
+                       (int)Wp, plane);
+    return launch_status("fqss_halo_pack");
+}
+
 extern "C" int fqss_chan_sum(const float* g, float* out, int64_t B, int64_t C, int64_t M, int64_t ld, fqss_stream_t stream) {
     FQSS_REQUIRE(g && out, "null pointer");
     FQSS_REQUIRE(B > 0 && C > 0 && M > 0 && ld >= M && B <= 65535, "bad shape");

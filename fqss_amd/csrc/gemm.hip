@@ -383,6 +383,7 @@ struct GemmArgs3 {          // keep in sync with csrc/gemm_x3.hip
     int batch;
     int64_t sAb, sBb, sCb;
     int imp_taps, imp_dil, imp_pad, imp_len;
+    int imp_kw, imp_rowshift;
     const unsigned short* Bp;
     int64_t ldp;
     int scalar_stores;
@@ -411,7 +412,7 @@ static int try_x3(const GemmArgs& g, bool a_kc, bool b_kc, bool atomic, hipStrea
     if (!x3_enabled()) return FQSS_OK;
     if (batch > 1 && (g.sAb % 4 != 0 || g.sBb % 4 != 0)) return FQSS_OK;      // every batch's operand 16-B aligned
     GemmArgs3 h{g.A, g.B, g.C, g.bias, g.bias_col, g.M, g.N, g.K, g.sAi, g.sAk, g.sBk, g.sBj, g.sCi, g.ksplit, g.kchunk, nullptr, nullptr, nullptr, nullptr,
-                batch, g.sAb, g.sBb, g.sCb, 0, 0, 0, 0, nullptr, 0, 0};
+                batch, g.sAb, g.sBb, g.sCb, 0, 0, 0, 0, 0, 0, nullptr, 0, 0};
     return launch_gemm_x3(h, a_kc, b_kc, atomic, s, what, used);
 }
 
@@ -617,6 +618,33 @@ extern "C" int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, 
     g.batch = B; g.sAb = (int64_t)Co * ld_gz; g.sBb = (int64_t)Ci * ld_x; g.sCb = 0;
     g.imp_taps = taps; g.imp_dil = dil; g.imp_pad = pad; g.imp_len = M;
     return launch_gemm_x3_imp(g, true, (hipStream_t)stream, "fqss_conv1d_s1_bwd_w");
+}
+
+// ... and of a stride-1 2-D convolution on halo-packed operands (fqss_halo_pack, csrc/conv_frames.hip): gzp [B][Co][plane_g] the packed
+// gradient of the output, xp [B][Ci][plane_x] the packed input; gw[co][ci * taps + t] += sum_{b, m} gzp[b][co][m] *
+// xp[b][ci][m + (t / kw) row_step + (t % kw) col_step - off] (zero outside the plane).  Same kernel, tap shifts in two dimensions.
+extern "C" int fqss_conv2_bwd_w(const float* gzp, const float* xp, float* gw, int B, int Ci, int Co, int taps, int kw, int row_step, int col_step,
+                                int off, int64_t plane_g, int64_t plane_x, fqss_stream_t stream) {
+    if (B == 0) return FQSS_OK;
+    FQSS_REQUIRE(gzp && xp && gw, "null tensor");
+    FQSS_REQUIRE(B > 0 && Ci > 0 && Co > 0 && taps >= 1 && kw >= 1 && taps % kw == 0 && plane_g > 0 && plane_x > 0 && plane_x < (1ll << 30), "bad shape");
+    FQSS_REQUIRE(aligned16(gzp) && plane_g % 4 == 0, "implicit conv wgrad: 16-B aligned gradient planes");
+    GemmArgs3 g{};
+    g.A = gzp; g.B = xp; g.C = gw; g.bias = nullptr; g.bias_col = nullptr;
+    g.M = Co; g.N = Ci * taps; g.K = (int)plane_g;
+    g.sAi = plane_g; g.sAk = 1;
+    g.sBk = 1; g.sBj = plane_x;
+    g.sCi = (int64_t)Ci * taps;
+    const int tiles = (int)(cdiv(Co, BM) * cdiv((int64_t)Ci * taps, BN));
+    int want = (int)cdiv(512, (int64_t)tiles * B);
+    if (want < 1) want = 1;
+    int kchunk = (int)cdiv(cdiv(plane_g, want), 64) * 64;
+    if (kchunk < 64) kchunk = 64;
+    g.kchunk = kchunk;
+    g.ksplit = (int)cdiv(plane_g, kchunk);
+    g.batch = B; g.sAb = (int64_t)Co * plane_g; g.sBb = (int64_t)Ci * plane_x; g.sCb = 0;
+    g.imp_taps = taps; g.imp_dil = col_step; g.imp_pad = off; g.imp_len = (int)plane_x; g.imp_kw = kw; g.imp_rowshift = row_step;
+    return launch_gemm_x3_imp(g, true, (hipStream_t)stream, "fqss_conv2_bwd_w");
 }
 
 // fqss_rowlin_fwd with the weight given as its three exact bf16 planes [3][Co][Ci] (fqss_split3_planes): the weight tile is copied into

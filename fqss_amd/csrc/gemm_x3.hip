@@ -49,6 +49,10 @@ struct GemmArgs3 {
     // (r / taps, r % taps) and B's element is x[channel][pos + tap * dil - pad], zero outside [0, len) -- the frames of
     // fqss_frames_gather are never written
     int imp_taps, imp_dil, imp_pad, imp_len;
+    // ... and of a stride-1 2-D convolution on a halo-packed signal (round 6, fqss_halo_pack: planes of (H + 2 ph) rows of Wp floats,
+    // zero halo): tap t = (t / imp_kw, t % imp_kw) reads pos + (t / imp_kw) * imp_rowshift + (t % imp_kw) * dil - pad of the flat plane.
+    // imp_kw = 0: one row of taps (the 1-D form above)
+    int imp_kw, imp_rowshift;
     // B operand already split (BPL kernels): three bf16 planes [3][N][ldp] of a [N][K] k-contiguous matrix (fqss_split3_planes of a
     // weight that does not change between launches: the frozen teacher's linears) -- the tile is copied, not split
     const unsigned short* Bp;
@@ -205,7 +209,12 @@ __device__ __forceinline__ float4 imp_load4(const float* __restrict__ row, int c
 
 template <int ROWS, bool KC>
 struct TileIOI : TileIO<ROWS, KC> {
-    int taps_ = 1, dil_ = 1, pad_ = 0, len_ = 0;
+    int taps_ = 1, dil_ = 1, pad_ = 0, len_ = 0, kw_ = 0, rowshift_ = 0;
+    __device__ __forceinline__ int shift_of(int t) const {
+        if (kw_ <= 0) return t * dil_ - pad_;
+        const int th = t / kw_;
+        return th * rowshift_ + (t - th * kw_) * dil_ - pad_;
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, int64_t sr, int64_t sk, int r0, int nrows, int k0, int kend, int K) {
         const int tid = threadIdx.x;
         this->k0_ = k0; this->kend_ = kend; this->r0_ = r0; this->nrows_ = nrows;
@@ -215,7 +224,7 @@ struct TileIOI : TileIO<ROWS, KC> {
             for (int p = 0; p < ROWS / 32; ++p) {
                 const int f = tid + 256 * p, r = f >> 3, k = (f & 7) * 4;
                 const int rc = min(r0 + r, nrows - 1), kc = min(k0 + k, kmax);
-                const int ci = rc / taps_, sh = (rc - ci * taps_) * dil_ - pad_;
+                const int ci = rc / taps_, sh = shift_of(rc - ci * taps_);
                 this->v[p] = imp_load4(base + (int64_t)ci * sr, kc + sh, len_);
             }
         } else {
@@ -225,7 +234,7 @@ struct TileIOI : TileIO<ROWS, KC> {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kc = min(k0 + kb * 4 + e, K - 1);
-                const int ci = kc / taps_, sh = (kc - ci * taps_) * dil_ - pad_;
+                const int ci = kc / taps_, sh = shift_of(kc - ci * taps_);
                 this->v[e] = imp_load4(base + (int64_t)ci * sk, rc + sh, len_);
             }
         }
@@ -320,7 +329,10 @@ __device__ __forceinline__ void x3_body(GemmArgs3 g, const int bx, const int by,
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
         if constexpr (BQ == 2) ta[s].sc_ = g.scale_k;
-        if constexpr (IMP) { tb[s].taps_ = g.imp_taps; tb[s].dil_ = g.imp_dil; tb[s].pad_ = g.imp_pad; tb[s].len_ = g.imp_len; }
+        if constexpr (IMP) {
+            tb[s].taps_ = g.imp_taps; tb[s].dil_ = g.imp_dil; tb[s].pad_ = g.imp_pad; tb[s].len_ = g.imp_len;
+            tb[s].kw_ = g.imp_kw; tb[s].rowshift_ = g.imp_rowshift;
+        }
     }
     auto load_b = [&](TileB& t, int k0) {
         if constexpr (BPL) t.load(g.Bp, (int64_t)g.N * g.ldp, g.ldp, j0, g.N, k0, g.K);

@@ -74,6 +74,7 @@ struct QStage {          // one k-tile of global loads of one thread (which memb
     f32x4 a[4];          // MODE 0/1: a[0] reinterpreted as 16 int8 codes; MODE 3: 16 fp32
     f32x4 b[2];          // MODE 1/3: 8 fp32
     u32x2 bq;            // MODE 0: 8 u8 codes
+    int kch;             // IMP dgrad: the channel (reduction row / taps) of this thread's B row -- the index of its delta_w
 };
 __device__ __forceinline__ void q_load16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void q_load8(u32x2& d, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
@@ -132,6 +133,13 @@ struct QGemmArgs {
     unsigned char* S1; unsigned char* S2; int64_t lds1, lds2;
     const float *ad_min1, *ad_max1, *ad_min2, *ad_max2;      // ranges of the other operand's codes
     const float *s_min1, *s_max1, *s_min2, *s_max2;          // ranges of the AddQ's own quantizer
+    // IMP kernels (round 6): the B operand of a stride-1 convolution read straight from a halo-packed signal (fqss_halo_pack: per channel
+    // one plane of ldb floats, (H + 2 ph) rows of Wp floats, zero halo) -- reduction row k = (channel, tap) = (k / taps, k % taps),
+    // B(k, n) = plane[channel][n + base + (tap / kw) * row_step + (tap % kw) * col_step], n = h * Wp + w over the OUTPUT grid (its
+    // columns w >= W hold junk the caller never reads).  No masks: the halo holds the zero padding.  The frame image of
+    // fqss_frames_gather -- taps x the signal, written and read back -- is never made.  imp_cmax: last column group a load may start at.
+    int imp_taps, imp_kw, imp_base, imp_row_step, imp_col_step, imp_cmax;
+    float imp_inv_taps, imp_inv_kw;
 };
 
 // MODE 0 fwd (int8 A codes, u8 B codes)            1 dgrad (int8 A codes, fp32 B split3)
@@ -142,8 +150,9 @@ struct QGemmArgs {
 // (tests/test_gpu_kernels.py::test_gradient_gemms_two_piece_split): the exact form sits at 1.6e-7 .. 3.3e-7 of the result's norm, the
 // two-piece form at 4.9e-6 (dgrad) / 8.1e-6 (wgrad) -- 25x the exact form's error, which is why it is not the default and why
 // bench.py never sets it.
-template <int MODE, int GP = 3>
+template <int MODE, int GP = 3, bool IMP = false>
 __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
+    static_assert(!IMP || MODE == 1 || MODE == 3 || MODE == 4, "implicit convolution: float B operands");
     // MODE 4 (round 5): forward of a layer whose WEIGHT is on the int8 grid while its input is a plain float tensor (the frame-path
     // convolutions of HTDemucs): A = int8 weight codes, B = fp32 x in three exact bf16 pieces -- the loop of MODE 1 without its
     // delta_w scaling of the reduction rows -- and z = dw[co] * S + b[co] in the epilogue: three products per k instead of six
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
 
     __shared__ float dws[(MODE == 1) ? 1024 : 1];   // dgrad: delta_w of the reduction rows
     if constexpr (MODE == 1) {
-        for (int k = tid; k < g.K; k += 256) dws[k] = g.dw[k];
+        for (int k = tid; k < (IMP ? g.K / g.imp_taps : g.K); k += 256) dws[k] = g.dw[k];     // (IMP: one per output channel of the conv)
     }
 
     // the two halves of a paired B operand are selected per lane: keep their descriptors in SGPRs (see sgpr())
@@ -224,7 +233,23 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             for (int q = 0; q < 4; ++q) q_load16(st.a[q], A + min(k0 + a_k + 4 * q, g.K - 4));
         }
         const int kk = min(k0 + bk_row, g.K - 1);
-        if constexpr (MODE == 0) {
+        if constexpr (IMP) {
+            // (channel, tap row, tap column) of reduction row kk: two divisions by run-time constants through float reciprocals + one
+            // correction step (kk < 2^16: exact)
+            int ci = (int)((float)kk * g.imp_inv_taps);
+            int t = kk - ci * g.imp_taps;
+            if (t < 0) { ci -= 1; t += g.imp_taps; }
+            if (t >= g.imp_taps) { ci += 1; t -= g.imp_taps; }
+            int th = (int)((float)t * g.imp_inv_kw);
+            int tw = t - th * g.imp_kw;
+            if (tw < 0) { th -= 1; tw += g.imp_kw; }
+            if (tw >= g.imp_kw) { th += 1; tw -= g.imp_kw; }
+            st.kch = ci;
+            const float* Bp = (const float*)gB1 + (int64_t)ci * gldb1 + (g.imp_base + th * g.imp_row_step + tw * g.imp_col_step);
+            const int c0 = min(j0 + bk_n, g.imp_cmax);               // (4-B aligned 16-B requests: a tap's shift breaks the alignment)
+            q_load16(st.b[0], Bp + c0);
+            q_load16(st.b[1], Bp + c0 + 4);
+        } else if constexpr (MODE == 0) {
             const unsigned char* Bp = (const unsigned char*)gB1 + (int64_t)kk * gldb1;
             q_load8(st.bq, Bp + min(j0 + bk_n, (int)gldb1 - 8));   // groups past the row (columns >= N) re-read its tail
         } else {
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(QGemmArgs g) {
             const unsigned int w[2] = {st.bq[0], st.bq[1]};
             store_codes(&Bs[0][bk_row][bk_n], w, std::integral_constant<int, 2>{}, false, kz);
         } else {
-            const float sc = (MODE == 1) ? dws[min(k0 + bk_row, g.K - 1)] : 1.0f;
+            const float sc = (MODE == 1) ? dws[IMP ? st.kch : min(k0 + bk_row, g.K - 1)] : 1.0f;
             if constexpr (NB == 2)
                 store_split2(&Bs[0][bk_row][bk_n], &Bs[1][bk_row][bk_n], st.b, sc, kz);
             else
@@ -1554,6 +1579,69 @@ extern "C" int fqss_pwconv_fwd_wq(const float* x, const int8_t* wi, const float*
     g.tiles_n = (int)cdiv(M, QBN); g.tiles_m = (int)cdiv(Co, QBM); g.batches = B;
     hipLaunchKernelGGL((k_qgemm<4>), dim3(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m)), dim3(256), 0, (hipStream_t)stream, g);
     return launch_status("fqss_pwconv_fwd_wq");
+}
+
+// ---- stride-1 convolutions on a halo-packed signal (fqss_halo_pack; csrc/conv_frames.hip), no frame image: k_qgemm<.., IMP>.
+// One description serves the forward and the data gradient: the caller gives the tap -> shift map (base, row_step, col_step over taps
+// = kh x kw) of the flat plane; N = rows_out * Wp output positions (pitch Wp: the columns past the real width hold junk).
+static int conv2_impl(const char* who, int mode, const void* A, const float* Bsig, const float* dw, const float* bias, float* C, int B, int Cr, int M,
+                      int taps, int kw, int base, int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out,
+                      fqss_stream_t stream) {
+    if (B == 0 || N == 0) return FQSS_OK;
+    FQSS_REQUIRE(A && Bsig && C && (mode == 3 || dw), "null tensor");
+    FQSS_REQUIRE(B > 0 && Cr > 0 && M > 0 && taps >= 1 && kw >= 1 && taps % kw == 0 && N > 0 && plane_out >= N, "bad shape");
+    const int64_t K = (int64_t)Cr * taps;
+    FQSS_REQUIRE(K < (1 << 16), "reduction too long for the reciprocal division of the implicit loader");
+    FQSS_REQUIRE(mode == 3 ? (K % 4 == 0) : (K % 16 == 0), "implicit convolution: (channels x taps) % 16 == 0 for coded weights, % 4 == 0 for float ones");
+    FQSS_REQUIRE(mode != 1 || Cr <= 1024, "dgrad stages delta_w of at most 1024 output channels in LDS");
+    FQSS_REQUIRE(aligned16(A) && (reinterpret_cast<uintptr_t>(Bsig) & 3) == 0 && aligned16(C) && plane_out % 4 == 0 && plane_in % 4 == 0, "alignment");
+    // every shift a tap can take, and the last column a 16-B x 2 request may start at: all loads stay inside the channel's plane
+    const int th_max = taps / kw - 1;
+    int smin = base, smax = base;
+    for (int th = 0; th <= th_max; th += (th_max > 0 ? th_max : 1)) {
+        for (int tw = 0; tw <= kw - 1; tw += (kw > 1 ? kw - 1 : 1)) {
+            const int sft = base + th * row_step + tw * col_step;
+            if (sft < smin) smin = sft;
+            if (sft > smax) smax = sft;
+        }
+    }
+    FQSS_REQUIRE(smin >= 0, "implicit convolution: a tap reaches in front of the packed plane");
+    const int64_t cmax = plane_in - smax - 8;
+    FQSS_REQUIRE(cmax >= N - 8 && cmax >= 0, "implicit convolution: the packed plane is too short for the last row's taps");
+    QGemmArgs g{};
+    g.A = A; g.B = Bsig; g.C = C; g.M = M; g.N = (int)N; g.K = (int)K;
+    g.lda = K; g.ldb = plane_in; g.ldc = plane_out;
+    g.sAb = 0; g.sBb = (int64_t)Cr * plane_in; g.sCb = (int64_t)M * plane_out;
+    g.dw = dw; g.bias = bias; g.ksplit = 1; g.kchunk = (int)K; g.M1 = M; g.K1 = (int)K;
+    g.B2 = Bsig; g.ldb2 = plane_in; g.sB2b = g.sBb;
+    g.imp_taps = taps; g.imp_kw = kw; g.imp_base = base; g.imp_row_step = row_step; g.imp_col_step = col_step; g.imp_cmax = (int)cmax;
+    g.imp_inv_taps = 1.0f / (float)taps; g.imp_inv_kw = 1.0f / (float)kw;
+    g.tiles_n = (int)cdiv(N, QBN); g.tiles_m = (int)cdiv(M, QBM); g.batches = B;
+    const dim3 grid(xcd_grid((int64_t)g.tiles_n * B, g.tiles_m));
+    if (mode == 4) hipLaunchKernelGGL((k_qgemm<4, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else if (mode == 3) hipLaunchKernelGGL((k_qgemm<3, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((k_qgemm<1, 3, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+    return launch_status(who);
+}
+
+/* z[b][co][n] = bias[co] + dw[co] * sum_{ci, t} Wi[co][ci * taps + t] * xp[b][ci][n + base + (t / kw) row_step + (t % kw) col_step]:
+ * the forward of a stride-1 convolution whose weight is on its int8 grid, on a halo-packed float signal (three products per term);
+ * with flipped taps and the weight regrouped as [Ci][Co * taps] by the caller, its data gradient (fqss_conv2_bwd_x_wq: delta_w scales
+ * the reduction rows instead of the output rows) */
+extern "C" int fqss_conv2_fwd_wq(const float* xp, const int8_t* wi, const float* dw, const float* bias, float* z, int B, int Ci, int Co, int taps,
+                                 int kw, int base, int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out,
+                                 fqss_stream_t stream) {
+    return conv2_impl("fqss_conv2_fwd_wq", 4, wi, xp, dw, bias, z, B, Ci, Co, taps, kw, base, row_step, col_step, N, plane_in, plane_out, stream);
+}
+extern "C" int fqss_conv2_bwd_x_wq(const float* gzp, const int8_t* wiT, const float* dw, float* gx, int B, int Ci, int Co, int taps, int kw,
+                                   int base, int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out, fqss_stream_t stream) {
+    return conv2_impl("fqss_conv2_bwd_x_wq", 1, wiT, gzp, dw, nullptr, gx, B, Co, Ci, taps, kw, base, row_step, col_step, N, plane_in, plane_out,
+                      stream);
+}
+/* ... with a float weight w [Co][Ci * taps] (the six-product split of fqss_pwconv_fwd_x3s: the float teacher's convolutions) */
+extern "C" int fqss_conv2_fwd_x3s(const float* xp, const float* w, const float* bias, float* z, int B, int Ci, int Co, int taps, int kw, int base,
+                                  int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out, fqss_stream_t stream) {
+    return conv2_impl("fqss_conv2_fwd_x3s", 3, w, xp, nullptr, bias, z, B, Ci, Co, taps, kw, base, row_step, col_step, N, plane_in, plane_out, stream);
 }
 
 extern "C" int fqss_pwconv_fwd_x3(const float* x, const float* w, const float* bias, float* z, int B, int Ci, int Co,

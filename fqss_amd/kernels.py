@@ -2212,6 +2212,90 @@ def _sig4(x):
     return x, sb, sc, sh
 
 
+# ---- stride-1 convolutions on halo-packed planes (fqss_halo_pack / fqss_conv2_*): no frame image
+CONV_HALO = os.environ.get("FQSS_CONV_HALO", "1") != "0"      # (A/B knob: "0" = every general convolution gathers frames)
+
+
+class HaloPlan:
+    """planes of a stride-1 convolution (ConvGeom, H x W input): xp [B, Ci, plane_x] = (H + 2 ph) rows of Wp floats with the input at
+    (ph, pw); the packed output gradient gzp [B, Co, plane_g] = (Ho + 2 phg) rows with halo (phg, pwg) = ((kh-1) dh - ph, (kw-1) dw - pw);
+    outputs come back on grids of pitch Wp ([.., Ho, Wp] / [.., H, Wp]) and are returned as their [.., :Wo] / [.., :W] views"""
+    __slots__ = ("geom", "H", "W", "Ho", "Wo", "phg", "pwg", "Wp", "plane_x", "plane_g", "taps")
+
+    def __init__(self, H, W, geom):
+        assert geom.sh == 1 and geom.sw == 1
+        self.geom, self.H, self.W = geom, H, W
+        self.Ho, self.Wo = geom.out_hw(H, W)
+        self.phg, self.pwg = (geom.kh - 1) * geom.dh - geom.ph, (geom.kw - 1) * geom.dw - geom.pw
+        self.Wp = (max(W + 2 * geom.pw, self.Wo + 2 * max(self.pwg, 0)) + 3) // 4 * 4
+        slack = (geom.kw - 1) * geom.dw + 8
+        self.plane_x = ((H + 2 * geom.ph) * self.Wp + slack + 15) // 16 * 16
+        self.plane_g = ((self.Ho + 2 * max(self.phg, 0)) * self.Wp + slack + 15) // 16 * 16
+        self.taps = geom.kh * geom.kw
+
+    def ok(self, Ci, Co, coded):
+        """shapes the implicit kernels serve: padding no wider than the kernel reaches, planes below 2^24 floats, reductions below
+        2^16 rows aligned for the weight loads (16 int8 codes / 4 floats per request)"""
+        k1, k2 = Ci * self.taps, Co * self.taps
+        al = 16 if coded else 4
+        return (CONV_HALO and _lib.BACKEND != "cpu" and self.Ho >= 1 and self.Wo >= 1 and self.phg >= 0 and self.pwg >= 0
+                and max(self.plane_x, self.plane_g) < (1 << 24) and max(k1, k2) < (1 << 16) and k1 % al == 0 and k2 % al == 0
+                and (not coded or Co <= 1024))
+
+
+def halo_pack(x4, ph, pw, Wp, plane):
+    """x4 [B, C, H, W] (unit W stride) -> [B, C, plane]: rows of Wp floats, x at (ph, pw), zeros elsewhere"""
+    _need_gpu(x4)
+    x4, sb, sc, sh = _sig4(x4)
+    B, C, H, W = x4.shape
+    xp = torch.empty(B, C, plane, device=x4.device, dtype=torch.float32)
+    _lib.call("fqss_halo_pack", _p(x4), _p(xp), B, C, H, W, sb, sc, sh, ph, pw, Wp, plane, _stream())
+    return xp
+
+
+def conv2_fwd(xp, plan, Co, wc, w2, bias):
+    """z [B, Co, Ho, Wo] (a view of a pitch-Wp buffer) = conv(xp); wc: WCodes of the fake-quantized weight (idx [Co][Ci * taps]) or None:
+    w2 float [Co][Ci * taps]"""
+    g = plan.geom
+    B, Ci = xp.shape[0], xp.shape[1]
+    zb = torch.empty(B, Co, plan.Ho, plan.Wp, device=xp.device, dtype=torch.float32)
+    N = plan.Ho * plan.Wp
+    if wc is not None:
+        _lib.call("fqss_conv2_fwd_wq", _p(xp), _p(wc.idx), _p(wc.dw), _p(bias), _p(zb), B, Ci, Co, plan.taps, g.kw, 0, g.dh * plan.Wp, g.dw, N,
+                  plan.plane_x, N, _stream())
+    else:
+        assert w2.is_contiguous() and w2.shape == (Co, Ci * plan.taps)
+        _lib.call("fqss_conv2_fwd_x3s", _p(xp), _p(w2), _p(bias), _p(zb), B, Ci, Co, plan.taps, g.kw, 0, g.dh * plan.Wp, g.dw, N, plan.plane_x, N,
+                  _stream())
+    return zb[..., :plan.Wo]
+
+
+def conv2_bwd_x(gzp, plan, Ci, wcT, dw, w2T):
+    """gx [B, Ci, H, W] (a view of a pitch-Wp buffer) from the packed gradient; wcT int8 [Ci][Co * taps] + dw [Co], or w2T float"""
+    g = plan.geom
+    B, Co = gzp.shape[0], gzp.shape[1]
+    gb = torch.empty(B, Ci, plan.H, plan.Wp, device=gzp.device, dtype=torch.float32)
+    N = plan.H * plan.Wp
+    base = (g.kh - 1) * g.dh * plan.Wp + (g.kw - 1) * g.dw
+    if wcT is not None:
+        _lib.call("fqss_conv2_bwd_x_wq", _p(gzp), _p(wcT), _p(dw), _p(gb), B, Ci, Co, plan.taps, g.kw, base, -g.dh * plan.Wp, -g.dw, N,
+                  plan.plane_g, N, _stream())
+    else:
+        _lib.call("fqss_conv2_fwd_x3s", _p(gzp), _p(w2T), None, _p(gb), B, Co, Ci, plan.taps, g.kw, base, -g.dh * plan.Wp, -g.dw, N,
+                  plan.plane_g, N, _stream())
+    return gb[..., :plan.W]
+
+
+def conv2_bwd_w(gzp, xp, gw2, plan):
+    """gw2 [Co][Ci * taps] += sum over batch and positions (caller-zeroed accumulator)"""
+    g = plan.geom
+    B, Co = gzp.shape[0], gzp.shape[1]
+    Ci = xp.shape[1]
+    assert gw2.is_contiguous() and gw2.numel() == Co * Ci * plan.taps
+    _lib.call("fqss_conv2_bwd_w", _p(gzp), _p(xp), _p(gw2), B, Ci, Co, plan.taps, g.kw, g.dh * plan.Wp, g.dw, plan.phg * plan.Wp + plan.pwg,
+              plan.plane_g, plan.plane_x, _stream())
+
+
 def frames_gather(x, geom, out_hw=None):
     """x [B, C, H, W] -> frames [B, C*kh*kw, Ho*Wo] (rows padded to 16 floats), Ho, Wo.
     out_hw: a frame grid other than the geometry's (the adjoint of an overlap-add that wrote a window of its signal, frames_ola): frame

@@ -779,6 +779,53 @@ class FramesGather(Function):
         return K.frames_ola(g, None, ctx.shape, ctx.geom), None
 
 
+class ConvHalo(Function):
+    """nn.Conv1d / nn.Conv2d with stride 1 (any kernel / dilation / zero padding, groups = 1) and a WIDE output on a halo-packed signal
+    (K.halo_pack, csrc/conv_frames.hip): forward, data gradient and weight gradient are implicit GEMMs that read the packed planes in
+    place (k_qgemm<.., IMP>, k_gemm_x3<.., IMP>) -- no frame image, no overlap-add.  The `rewrite` convolutions of the HTDemucs decoder
+    layers (hdemucsq.py:303-347).  w [Co, Ci, kh, kw]; wc: the int8 codes of a weight fake-quantized by runtime.QuantTables (three
+    products per term) or None (float weight: six, the arithmetic of the frame path's fqss_pwconv_fwd_x3s)."""
+
+    @staticmethod
+    def forward(ctx, x4, w, bias, plan, wc):
+        g = plan.geom
+        Co, Ci = w.shape[0], x4.shape[1]
+        xp = K.halo_pack(x4, g.ph, g.pw, plan.Wp, plan.plane_x)
+        w2 = None if wc is not None else w.reshape(Co, -1).contiguous()
+        z = K.conv2_fwd(xp, plan, Co, wc, w2, bias)
+        touch(w)
+        ctx.plan, ctx.wc, ctx.bias, ctx.Ci = plan, wc, bias, Ci
+        ctx.save_for_backward(xp, w)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        xp, w = ctx.saved_tensors
+        plan, wc, Ci = ctx.plan, ctx.wc, ctx.Ci
+        Co, T = w.shape[0], plan.taps
+        gzp = K.halo_pack(gz, plan.phg, plan.pwg, plan.Wp, plan.plane_g)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if wc is not None:      # [Co][Ci * taps] codes regrouped per input channel: the data gradient's weight image (a few KB)
+                wcT = wc.idx.view(Co, Ci, T).permute(1, 0, 2).reshape(Ci, Co * T).contiguous()
+                gx = K.conv2_bwd_x(gzp, plan, Ci, wcT, wc.dw, None)
+            else:
+                gx = K.conv2_bwd_x(gzp, plan, Ci, None, None, w.reshape(Co, Ci, T).permute(1, 0, 2).reshape(Ci, Co * T).contiguous())
+        gw = gb = None
+        gwq = getattr(w, "_fqss_gwq", None)
+        if ctx.needs_input_grad[1] or gwq is not None:
+            gw = gwq if gwq is not None else ops._wgrad_temp(w)
+            K.conv2_bwd_w(gzp, xp, gw.view(Co, -1), plan)
+            ops._wgrad_temp_done(gw, gwq)
+            if gwq is not None:
+                gw = None
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            buf, direct = _param_grad(ctx.bias, ctx.bias)
+            K.chan_sum(gzp, buf)            # (the halo holds zeros)
+            gb = None if direct else buf
+        return gx, gw, gb, None, None
+
+
 class FramesOla(Function):
     """frames [B, C*kh*kw, Ho*Wo] (+ bias [C]) -> y [B, C, H, W]: the overlap-add half of nn.ConvTranspose1d / 2d"""
 

@@ -297,6 +297,14 @@ def conv_frames(conv, x, weight):
         cols = x4.reshape(B, C, W)
         L = ops._Lin("conv1", dil=geom.dw, pad=geom.pw, b_param=conv.bias, taps=geom.kw)
     else:
+        if geom.sh == 1 and geom.sw == 1:
+            # stride-1 convolutions with WIDE outputs (the 3 x 3 / k = 3 `rewrite` convs of the decoder layers, C -> 2C): implicit GEMMs on
+            # the halo-packed signal (ops_dp.ConvHalo) -- the frame image would be 9 x / 3 x the activation, written and read back
+            wc = getattr(weight, "_fqss_wcodes_dgrad", None) if (ops.FRAME_CODES_FWD and ops.FRAME_CODES_DGRAD) else None
+            plan = K.HaloPlan(H, W, geom)
+            if plan.ok(C, Co, wc is not None) and (wc is None or (wc.idx.is_contiguous() and wc.Ci == C * plan.taps)):
+                z = ops_dp.ConvHalo.apply(x4, ops.weight_view(weight, Co, C, geom.kh, geom.kw), conv.bias, plan, wc)    # (keeps the arena slot)
+                return z.squeeze(2) if one_d else z
         cols = ops_dp.FramesGather.apply(x4, geom)
     ops_dp.touch(weight)
     w3 = ops.weight_view(weight, Co, -1, 1)

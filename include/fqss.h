@@ -177,6 +177,31 @@ int fqss_conv1d_s1_fwd(const float* x, const float* w, const float* bias, float*
                        int dil, int pad, int64_t ld_x, int64_t ld_w, int64_t ld_z, fqss_stream_t stream);
 int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, int B, int Ci, int Co, int M, int Mo, int taps, int dil,
                          int pad, int64_t ld_gz, int64_t ld_x, fqss_stream_t stream);
+/* Stride-1 convolutions of ANY kernel shape (3 x 3, 1 x 3, k with dilation; groups = 1) with WIDE outputs, on a HALO-PACKED signal, as
+ * implicit GEMMs (round 6): fqss_halo_pack lays the signal out as xp [B][C][plane] -- per channel (H + 2 ph) rows of Wp floats, element
+ * (h, w) at row h + ph, column w + pw, zeros everywhere else (the halo is the zero padding; Wp % 4 == 0, Wp >= W + 2 pw; plane % 4 == 0
+ * with room for the last row's taps) -- so that every tap is a constant shift of the flat plane and the GEMM kernels read their B
+ * operand straight from it (csrc/qgemm.hip k_qgemm<.., IMP>, csrc/gemm_x3.hip): the frame image of fqss_frames_gather (kh kw times
+ * the signal, written and read back) and the overlap-add of its data gradient are never made.
+ * replaces: nn.Conv2d(C, 2C, 3, 1, 1) / nn.Conv1d(C, 2C, 3, 1, 1) of the HTDemucs decoder layers (`rewrite`, hdemucsq.py:303-347) and
+ * their autograd, student (weight on its int8 grid: _wq) and float teacher (_x3s).
+ *   fwd    z[b][co][n] = bias[co] + sum_{ci,t} W[co][ci*taps + t] xp[b][ci][n + base + (t / kw) row_step + (t % kw) col_step]
+ *          n = h Wp + w over rows_out rows of pitch Wp (N = rows_out * Wp; columns w >= the real width hold junk the caller never reads);
+ *          a plain convolution: base 0, row_step dh Wp, col_step dw
+ *   dgrad  the same sum over (co, t) on the packed gradient gzp (halo (kh-1) dh - ph, (kw-1) dw - pw) with the caller's regrouped
+ *          weight codes [Ci][Co*taps]: base (kh-1) dh Wp + (kw-1) dw, row_step -dh Wp, col_step -dw
+ *   wgrad  gw[co][ci*taps + t] += sum_{b,m} gzp[b][co][m] xp[b][ci][m + (t / kw) row_step + (t % kw) col_step - off]   (gw caller-zeroed;
+ *          off = the gradient's own halo offset, (ph_g Wp + pw_g); zero outside the plane) */
+int fqss_halo_pack(const float* x, float* xp, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh,
+                   int ph, int pw, int64_t Wp, int64_t plane, fqss_stream_t stream);
+int fqss_conv2_fwd_wq(const float* xp, const int8_t* wi, const float* dw, const float* bias, float* z, int B, int Ci, int Co, int taps,
+                      int kw, int base, int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out, fqss_stream_t stream);
+int fqss_conv2_fwd_x3s(const float* xp, const float* w, const float* bias, float* z, int B, int Ci, int Co, int taps, int kw, int base,
+                       int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out, fqss_stream_t stream);
+int fqss_conv2_bwd_x_wq(const float* gzp, const int8_t* wiT, const float* dw, float* gx, int B, int Ci, int Co, int taps, int kw,
+                        int base, int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out, fqss_stream_t stream);
+int fqss_conv2_bwd_w(const float* gzp, const float* xp, float* gw, int B, int Ci, int Co, int taps, int kw, int row_step, int col_step,
+                     int off, int64_t plane_g, int64_t plane_x, fqss_stream_t stream);
 /* gx[b] = W^T * gz[b] */
 int fqss_pwconv_bwd_x(const float* gz, const float* w, float* gx, int B, int Ci, int Co, int M,
                       int64_t ld_gz, int64_t ld_gx, fqss_stream_t stream);
