@@ -11,6 +11,7 @@
 //   * k_frames_ola    : one thread per SIGNAL element gathers its <= ceil(kh/sh)*ceil(kw/sw) contributing frame elements in a
 //     fixed order (tap row ascending, tap column ascending): the overlap-add is deterministic, no atomics.
 #define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
+#include <cstdlib>
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -55,6 +56,58 @@ __global__ __launch_bounds__(256) void k_frames_gather(const float* __restrict__
     }
 }
 
+// ... four consecutive frame positions per thread and ONE 16-B store (frame rows are 16-B aligned, ld % 4 == 0: the positions past M
+// land in the row's own padding, as zeros): one division per group while it stays inside a frame-grid row, and with unit column
+// stride one (unaligned) 16-B load where the whole group lies inside the signal.  Round 6: the one-element form above moved 2.5 TB/s.
+struct __attribute__((packed, aligned(4))) G4U { float x, y, z, w; };
+__global__ __launch_bounds__(256) void k_frames_gather4(const float* __restrict__ x, float* __restrict__ f, const FrameGeom g) {
+    const int M = (int)(g.Ho * g.Wo), Wo = (int)g.Wo, H = (int)g.H, W = (int)g.W;
+    const float inv_wo = 1.0f / (float)Wo;
+    const int64_t rows = g.B * g.C * g.kh * g.kw;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const int j = (int)(r % g.kw);
+        const int64_t r1 = r / g.kw;
+        const int ti = (int)(r1 % g.kh);
+        const int64_t bc = r1 / g.kh, c = bc % g.C, b = bc / g.C;
+        const float* xp = x + b * g.sb + c * g.sc;
+        float* fp = f + r * g.ld;
+        const int h0 = ti * g.dh - g.ph, w0 = j * g.dw - g.pw;
+        for (int m0 = (blockIdx.x * 256 + threadIdx.x) * 4; m0 < M; m0 += gridDim.x * 1024) {
+            int ho, wo;
+            div_small(m0, Wo, inv_wo, ho, wo);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (wo + 3 < Wo && m0 + 3 < M) {          // the group inside one row of the frame grid
+                const int h = ho * g.st_h + h0;
+                if (h >= 0 && h < H) {
+                    const float* xr = xp + (int64_t)h * g.sh_;
+                    const int w = wo * g.st_w + w0;
+                    if (g.st_w == 1 && w >= 0 && w + 3 < W) {
+                        const G4U t = *reinterpret_cast<const G4U*>(xr + w);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int we = w + e * g.st_w;
+                            if (we >= 0 && we < W) v[e] = xr[we];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (m0 + e < M) {
+                        int he, we;
+                        div_small(m0 + e, Wo, inv_wo, he, we);
+                        const int h = he * g.st_h + h0, w = we * g.st_w + w0;
+                        if (h >= 0 && h < H && w >= 0 && w < W) v[e] = xp[(int64_t)h * g.sh_ + w];
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(fp + m0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // y[b][c][h][w] = bias[c] + sum over taps (ti, j) with (h + ph - ti*dh) = ho*st_h, (w + pw - j*dw) = wo*st_w in range
 // grid: x = chunks of the plane (h*W + w), y = planes (b, c)
 __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
@@ -90,6 +143,68 @@ __global__ __launch_bounds__(256) void k_frames_ola(const float* __restrict__ f,
             }
             if (bias != nullptr) acc += bv;
             yp[(int64_t)h * g.sh_ + w] = acc;
+        }
+    }
+}
+
+// k_frames_ola for kernels that are ONE COLUMN wide with unit column stride (the frequency-branch transposed convolutions of HTDemucs,
+// (8, 1) / (4, 1): kw = 1, st_w = 1, pw = 0): four consecutive columns per thread -- the tap rows that reach row h are the same for all
+// four, each contributes one (unaligned) 16-B load, the result is one 16-B store.  Same terms in the same order as k_frames_ola.
+__global__ __launch_bounds__(256) void k_frames_ola_col4(const float* __restrict__ f, const float* __restrict__ bias, float* __restrict__ y,
+                                                          const FrameGeom g) {
+    const int HW = (int)(g.H * g.W), W = (int)g.W, Ho = (int)g.Ho, Wo = (int)g.Wo;
+    const float inv_w = 1.0f / (float)W;
+    const bool fast_h = g.dh == 1 && (g.st_h & (g.st_h - 1)) == 0;
+    const int sh_shift = __builtin_ctz((unsigned)g.st_h), ti_step = fast_h ? g.st_h : 1;
+    const int64_t planes = g.B * g.C;
+    for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
+        const int64_t c = bc % g.C, b = bc / g.C;
+        const float bv = bias != nullptr ? bias[c] : 0.0f;
+        const float* fb = f + bc * g.kh * g.ld;
+        float* yp = y + b * g.sb + c * g.sc;
+        for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < HW; i0 += gridDim.x * 1024) {
+            int h, w;
+            div_small(i0, W, inv_w, h, w);
+            const int n = min(4, min(W - w, HW - i0));      // columns of this group inside row h (the rest: the next group's)
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ti = fast_h ? ((h + g.ph) & (g.st_h - 1)) : 0; ti < g.kh; ti += ti_step) {
+                const int hn = h + g.ph - ti * g.dh;
+                if (hn < 0) continue;
+                const int ho = fast_h ? (hn >> sh_shift) : hn / g.st_h;
+                if (ho * g.st_h != hn || ho >= Ho) continue;
+                const float* fr = fb + (int64_t)ti * g.ld + (int64_t)ho * Wo + w;
+                if (n == 4 && w + 3 < Wo) {
+                    const G4U t = *reinterpret_cast<const G4U*>(fr);
+                    acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < n && w + e < Wo) acc[e] += fr[e];
+                }
+            }
+            float* yr = yp + (int64_t)h * g.sh_ + w;
+            if (bias != nullptr) { acc[0] += bv; acc[1] += bv; acc[2] += bv; acc[3] += bv; }
+            if (n == 4) {
+                G4U o; o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
+                *reinterpret_cast<G4U*>(yr) = o;
+            } else {
+                for (int e = 0; e < n; ++e) yr[e] = acc[e];
+                // the group straddles a row end: its remaining positions belong to row h + 1 -- done one by one, k_frames_ola's way
+                for (int e = n; e < 4 && i0 + e < HW; ++e) {
+                    int h2, w2;
+                    div_small(i0 + e, W, inv_w, h2, w2);
+                    float a = 0.0f;
+                    for (int ti = fast_h ? ((h2 + g.ph) & (g.st_h - 1)) : 0; ti < g.kh; ti += ti_step) {
+                        const int hn = h2 + g.ph - ti * g.dh;
+                        if (hn < 0) continue;
+                        const int ho = fast_h ? (hn >> sh_shift) : hn / g.st_h;
+                        if (ho * g.st_h != hn || ho >= Ho) continue;
+                        if (w2 < Wo) a += fb[(int64_t)ti * g.ld + (int64_t)ho * Wo + w2];
+                    }
+                    if (bias != nullptr) a += bv;
+                    yp[(int64_t)h2 * g.sh_ + w2] = a;
+                }
+            }
         }
     }
 }
@@ -222,7 +337,11 @@ extern "C" int fqss_frames_gather(const float* x, float* frames, FQSS_GEOM_ARGS,
     FQSS_GEOM_INIT;
     if (int rc = check_geom(g)) return rc;
     FQSS_REQUIRE(Ho * Wo < (1ll << 24) && H * W < (1ll << 31), "frame plane too large (positions are split by a float reciprocal: < 2^24)");
-    hipLaunchKernelGGL(k_frames_gather, plane_grid(Ho * Wo, B * C * kh * kw), dim3(256), 0, (hipStream_t)stream, x, frames, g);
+    static const bool one = getenv("FQSS_GATHER_V1") != nullptr;       // (A/B knob: the one-element kernel)
+    if (!one && ld % 4 == 0 && aligned16(frames))
+        hipLaunchKernelGGL(k_frames_gather4, plane_grid(Ho * Wo, B * C * kh * kw), dim3(256), 0, (hipStream_t)stream, x, frames, g);
+    else
+        hipLaunchKernelGGL(k_frames_gather, plane_grid(Ho * Wo, B * C * kh * kw), dim3(256), 0, (hipStream_t)stream, x, frames, g);
     return launch_status("fqss_frames_gather");
 }
 
@@ -240,7 +359,11 @@ extern "C" int fqss_frames_ola(const float* frames, const float* bias, float* y,
         else hipLaunchKernelGGL(k_frames_ola_rows<0>, grid, dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
         return launch_status("fqss_frames_ola");
     }
-    hipLaunchKernelGGL(k_frames_ola, plane_grid(H * W, B * C), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+    static const bool one = getenv("FQSS_OLA_V1") != nullptr;       // (A/B knob: the one-element kernel)
+    if (!one && kw == 1 && st_w == 1 && pw == 0 && W >= 8)
+        hipLaunchKernelGGL(k_frames_ola_col4, plane_grid(H * W, B * C), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
+    else
+        hipLaunchKernelGGL(k_frames_ola, plane_grid(H * W, B * C), dim3(256), 0, (hipStream_t)stream, frames, bias, y, g);
     return launch_status("fqss_frames_ola");
 }
 
