@@ -769,14 +769,15 @@ class FramesGather(Function):
     """x [B, C, H, W] -> frames [B, C*kh*kw, Ho*Wo]; followed by a pointwise GEMM this is nn.Conv1d / nn.Conv2d (groups = 1)"""
 
     @staticmethod
-    def forward(ctx, x, geom):
-        ctx.geom, ctx.shape = geom, tuple(x.shape)
-        f, _, _ = K.frames_gather(x, geom)
+    def forward(ctx, x, geom, out_hw=None):
+        """out_hw: the frame grid of the signal zero-padded at the back (K.frames_gather): the pad is never materialised"""
+        ctx.geom, ctx.shape, ctx.out_hw = geom, tuple(x.shape), out_hw
+        f, _, _ = K.frames_gather(x, geom, out_hw)
         return f
 
     @staticmethod
     def backward(ctx, g):
-        return K.frames_ola(g, None, ctx.shape, ctx.geom), None
+        return K.frames_ola(g, None, ctx.shape, ctx.geom, ctx.out_hw), None, None
 
 
 class ConvHalo(Function):

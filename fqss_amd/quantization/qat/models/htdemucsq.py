@@ -265,6 +265,12 @@ def _dconv_freq(dconv, y):
     return swap_mid(ops.real(z).reshape(B, Fr, C, T), False)
 
 
+def _takes_pad(m):
+    """a convolution whose frame gather can stand in for the zero padding in front of it (QL.conv_frames pad_to): general geometry"""
+    conv = m.conv1d if isinstance(m, QL.Conv1dNlQ) else m
+    return isinstance(m, (QL.Conv1dNlQ, nn.Conv1d)) and isinstance(conv, nn.Conv1d) and QL.conv1d_geometry(conv).kind == "gather"
+
+
 class HEncLayer(nn.Module):
     def __init__(self, chin, chout, kernel_size=8, stride=4, norm_groups=1, empty=False, freq=True, dconv=True, norm=True, context=0,
                  dconv_kw={}, pad=True, rewrite=True):
@@ -293,11 +299,15 @@ class HEncLayer(nn.Module):
         if not self.freq and x.dim() == 4:
             B, C, Fr, T = x.shape
             x = x.reshape(B, -1, T)
+        pad_to = None
         if not self.freq:
             le = x.shape[-1]
             if le % self.stride:
-                x = pad_right(x, le + self.stride - le % self.stride)
-        y = run(self.conv, x)
+                pad_to = le + self.stride - le % self.stride
+                if not (FOLD_CROP and _takes_pad(self.conv)):
+                    x, pad_to = pad_right(x, pad_to), None
+        y = run(self.conv, x) if pad_to is None else (self.conv(x, pad_to=pad_to) if isinstance(self.conv, QL.LayerQ) else
+                                                      QL.conv_frames(self.conv, x, self.conv.weight, pad_to))
         if self.empty:
             return y
         if inject is not None:

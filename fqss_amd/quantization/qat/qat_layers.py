@@ -236,16 +236,18 @@ def is_depthwise3(m):
             and conv.groups == conv.in_channels == conv.out_channels and conv.padding[0] == conv.dilation[0])
 
 
-def run_conv1d(conv, x, weight, nl, aq):
-    """fq_act(nl(conv1d(x, weight) + bias)) through one fused autograd node"""
+def run_conv1d(conv, x, weight, nl, aq, pad_to=None):
+    """fq_act(nl(conv1d(x, weight) + bias)) through one fused autograd node; pad_to (conv_frames): x stands for itself zero-padded on the
+    right to that length (general geometry only -- the caller pads for the other kinds)"""
     if isinstance(nl, (nn.Tanh, nn.Sigmoid, nn.GELU, nn.GLU)):
         # gated output convs of the dual-path separators (dptnetq.py:286-287), GELU / GLU convs of the HTDemucs layers
         # (hdemucsq.py:126-127): conv, then the map, then the quantizer
-        z = run_conv1d(conv, x, weight, None, None)
+        z = run_conv1d(conv, x, weight, None, None, pad_to)
         return fq_node(aq, apply_map(nl, ops.real(z)))
     L = conv1d_geometry(conv)
     if L.kind == "gather":
-        return fq_node(aq, conv_frames(conv, x, weight), nl)
+        return fq_node(aq, conv_frames(conv, x, weight, pad_to), nl)
+    assert pad_to is None or pad_to == x.shape[-1], "pad_to: general-geometry convolutions only"
     act, slope = _act_of(nl)
     L.w_param, L.b_param, L.slope_param = conv.weight, conv.bias, slope
     q = aq.qctx() if aq is not None else ops.BYPASS
@@ -275,7 +277,7 @@ def _conv_geom(conv, one_d):
                       _pair(conv.dilation) if not one_d else (1, conv.dilation[0]))
 
 
-def conv_frames(conv, x, weight):
+def conv_frames(conv, x, weight, pad_to=None):
     """nn.Conv1d / nn.Conv2d (groups = 1, any kernel / stride / dilation / zero padding) of the HTDemucs layers (DConv's dilated k3
     convs, the k8 s4 encoders, Conv2d (8,1) along frequency, the 3x3 decoder rewrites; hdemucsq.py:72-162, 261-347,
     demucsq.py:110-182): frame gather (fqss_frames_gather) + the pointwise GEMM kernels over Ci*kh*kw channels; the data
@@ -286,9 +288,17 @@ def conv_frames(conv, x, weight):
     x4 = x.unsqueeze(2) if one_d else x
     B, C, H, W = x4.shape
     Ho, Wo = geom.out_hw(H, W)
+    grid = None
+    if pad_to is not None and pad_to > W:
+        # the input zero-padded on the right to `pad_to` columns (`F.pad(x, (0, stride - le % stride))` in front of the strided encoder
+        # convolutions, hdemucsq.py:131-135): the frame gather reads zeros past the signal, so only the frame GRID is the padded one's
+        Wo = geom.out_hw(H, pad_to)[1]
+        grid = (Ho, Wo)
     Co = conv.out_channels
     L = ops._Lin("pw", b_param=conv.bias, six=True)
-    if geom.args() == (1, 1, 1, 1, 0, 0, 1, 1):
+    if grid is not None:
+        cols = ops_dp.FramesGather.apply(x4, geom, grid)
+    elif geom.args() == (1, 1, 1, 1, 0, 0, 1, 1):
         cols = x4.reshape(B, C, H * W)
     elif one_d and geom.sw == 1 and K.conv1d_s1_ok(C, geom.kw) and geom.dw * (geom.kw - 1) - geom.pw >= 0 and Co <= K.CONV_IMPLICIT_MAX_CO:
         # stride-1 Conv1d with FEW output channels (DConv's dilated k3 convs, C -> C / 8): implicit GEMM, no frame image
@@ -429,8 +439,8 @@ class Conv1dNlQ(LayerQ):
         self.conv1d = conv1d
         self.nl = nl
 
-    def forward(self, x):
-        return run_conv1d(self.conv1d, x, self._wq(self.conv1d.weight), self.nl, self.activation_fake_quantize)
+    def forward(self, x, pad_to=None):
+        return run_conv1d(self.conv1d, x, self._wq(self.conv1d.weight), self.nl, self.activation_fake_quantize, pad_to)
 
 
 class GroupNormQ(LayerQ):
