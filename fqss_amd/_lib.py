@@ -35,6 +35,8 @@ _PROTOS = {
     "fqss_conv1d_s1_fwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_conv1d_s1_bwd_w": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, P],
     "fqss_halo_pack": [P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I64, I64, P],
+    "fqss_phase_pack": [P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I64, I64, P],
+    "fqss_phase_unpack": [P, P, I64, I64, I64, I64, I64, I64, I64, I32, I32, I32, I64, I64, I64, I32, P, P],
     "fqss_conv2_fwd_wq": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_conv2_fwd_x3s": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],
     "fqss_conv2_bwd_x_wq": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, P],

@@ -418,10 +418,16 @@ __global__ __launch_bounds__(256) void k_halo_pack(const float* __restrict__ x, 
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (h >= 0 && h < H) {
                 const float* xr = xb + (int64_t)h * sh_;
+                const int w0 = wp - pw;
+                if (w0 >= 0 && w0 + 3 < W) {          // (one possibly unaligned 16-B request)
+                    const G4U t = *reinterpret_cast<const G4U*>(xr + w0);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int w = wp + q - pw;
-                    if (w >= 0 && w < W) v[q] = xr[w];
+                    for (int q = 0; q < 4; ++q) {
+                        const int w = w0 + q;
+                        if (w >= 0 && w < W) v[q] = xr[w];
+                    }
                 }
             }
             *reinterpret_cast<float4*>(op + 4 * (int64_t)i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -439,6 +445,154 @@ extern "C" int fqss_halo_pack(const float* x, float* xp, int64_t B, int64_t C, i
     hipLaunchKernelGGL(k_halo_pack, plane_grid(plane, B * C), dim3(256), 0, (hipStream_t)stream, x, xp, B * C, (int)C, (int)H, (int)W, sb, sc, sh, ph, pw,
                        (int)Wp, plane);
     return launch_status("fqss_halo_pack");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Phase-packed signal of a STRIDED convolution along one axis (round 6; kernel k = T s taps, stride s, zero padding p, dilation 1 -- the
+// k8 s4 p2 encoder / decoder layers of HTDemucs, hdemucsq.py:72-162, 261-347).  With t - p = s q + r the convolution
+//   z[n] = sum_t W[t] x[s n + t - p]   is   sum_r sum_{q'} W[t0(r) + s q'] Y_r[n + q'],   Y_r[m] = x[s (m + q0(r)) + r],
+// t0(r) = (r + p) mod s the first tap of phase r and q0(r) = (t0(r) - p - r) / s its offset: a stride-1 convolution with T = k / s taps
+// over s C phase channels.  k_phase_pack writes the planes xp[b][c s + r] = Y_r (rows of Wp floats, zeros outside the signal) once --
+// the frame image is k / s times that -- and the implicit GEMMs of fqss_conv2_* run on them; k_phase_unpack is the inverse map (every
+// signal position lies in exactly one phase plane): the data gradient's way back, and the transposed convolution's way out.
+//   axis 0: along H ([B][C][H][W] with (k, 1) kernels: planes of Hy rows x Wp, Hy = Ho + T - 1);  axis 1: along W (H = 1: one row)
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int phase_q0(int r, int s, int p) { return ((r + p) % s - p - r) / s; }      // (exact: the numerator is a multiple of s)
+
+__global__ __launch_bounds__(256) void k_phase_pack(const float* __restrict__ x, float* __restrict__ xp, int64_t planes, int C, int H, int W,
+                                                     int64_t sb, int64_t sc, int64_t sh_, int axis, int s, int p, int Wp, int64_t plane) {
+    const int groups = (int)(plane >> 2);
+    const float inv_wp = 1.0f / (float)Wp;
+    for (int64_t pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+        const int r = (int)(pl % s);
+        const int64_t bc = pl / s, b = bc / C, c = bc - b * C;
+        const int q0 = phase_q0(r, s, p);
+        const float* xb = x + b * sb + c * sc;
+        float* op = xp + pl * plane;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < groups; i += gridDim.x * 256) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (axis == 0) {
+                int m, w;
+                div_small(4 * i, Wp, inv_wp, m, w);
+                const int h = s * (m + q0) + r;
+                if (h >= 0 && h < H) {
+                    const float* xr = xb + (int64_t)h * sh_ + w;
+                    if (w + 3 < W) {
+                        const G4U t = *reinterpret_cast<const G4U*>(xr);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (w + e < W) v[e] = xr[e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t col = (int64_t)s * (4 * i + e + q0) + r;
+                    if (col >= 0 && col < W) v[e] = xb[col];
+                }
+            }
+            *reinterpret_cast<float4*>(op + 4 * (int64_t)i) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// gx[b][c][h][w] (a window starting `off` positions into the strided axis of the full signal) = the phase planes' element of that position
+__global__ __launch_bounds__(256) void k_phase_unpack(const float* __restrict__ gy, float* __restrict__ gx, int64_t planes, int C, int H, int W,
+                                                       int64_t sb, int64_t sc, int64_t sh_, int axis, int s, int p, int Hy, int Wp, int64_t plane,
+                                                       int off, const float* __restrict__ bias) {
+    const int HW = H * W;
+    const float inv_w = 1.0f / (float)W;
+    for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
+        const int64_t b = bc / C, c = bc - b * C;
+        const float* yb = gy + bc * s * plane;
+        float* ob = gx + b * sb + c * sc;
+        const float bv = bias != nullptr ? bias[c] : 0.0f;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+            int h, w;
+            div_small(i, W, inv_w, h, w);
+            const int pos = (axis == 0 ? h : w) + off;
+            const int r = pos % s, m = pos / s - phase_q0(r, s, p);
+            float v = 0.0f;
+            if (axis == 0) {
+                if (m >= 0 && m < Hy) v = yb[(int64_t)r * plane + (int64_t)m * Wp + w];
+            } else {
+                if (m >= 0 && m < Hy) v = yb[(int64_t)r * plane + m];      // (axis 1: Hy = the phase rows' live length, Lo + T - 1)
+            }
+            ob[(int64_t)h * sh_ + w] = v + bv;
+        }
+    }
+}
+
+// ... four consecutive columns per thread.  axis 0: the four share their phase plane and row -- one 16-B load (rows of Wp % 4 == 0 floats,
+// w % 4 == 0), one (unaligned) 16-B store; axis 1 with s = 4: the four are the four phases of one group -- four loads, one 16-B store.
+__global__ __launch_bounds__(256) void k_phase_unpack4(const float* __restrict__ gy, float* __restrict__ gx, int64_t planes, int C, int H, int W,
+                                                        int64_t sb, int64_t sc, int64_t sh_, int axis, int s, int p, int Hy, int Wp, int64_t plane,
+                                                        int off, const float* __restrict__ bias) {
+    const int groups_w = (W + 3) >> 2, total = H * groups_w;
+    const float inv_gw = 1.0f / (float)groups_w;
+    for (int64_t bc = blockIdx.y; bc < planes; bc += gridDim.y) {
+        const int64_t b = bc / C, c = bc - b * C;
+        const float* yb = gy + bc * s * plane;
+        float* ob = gx + b * sb + c * sc;
+        const float bv = bias != nullptr ? bias[c] : 0.0f;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            int h, gw;
+            div_small(i, groups_w, inv_gw, h, gw);
+            const int w = 4 * gw;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (axis == 0) {
+                const int pos = h + off, r = pos % s, m = pos / s - phase_q0(r, s, p);
+                if (m >= 0 && m < Hy) {
+                    const float4 t = *reinterpret_cast<const float4*>(yb + (int64_t)r * plane + (int64_t)m * Wp + w);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pos = w + e + off, r = pos % s, m = pos / s - phase_q0(r, s, p);
+                    if (m >= 0 && m < Hy) v[e] = yb[(int64_t)r * plane + m];
+                }
+            }
+            float* o = ob + (int64_t)h * sh_ + w;
+            if (w + 3 < W) {
+                G4U t; t.x = v[0] + bv; t.y = v[1] + bv; t.z = v[2] + bv; t.w = v[3] + bv;
+                *reinterpret_cast<G4U*>(o) = t;
+            } else {
+                for (int e = 0; e < 4 && w + e < W; ++e) o[e] = v[e] + bv;
+            }
+        }
+    }
+}
+
+extern "C" int fqss_phase_pack(const float* x, float* xp, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh, int axis,
+                               int s, int p, int64_t Wp, int64_t plane, fqss_stream_t stream) {
+    FQSS_REQUIRE(x && xp, "null pointer");
+    FQSS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (axis == 0 || (axis == 1 && H == 1)) && s >= 1 && p >= 0, "bad shape");
+    FQSS_REQUIRE(Wp % 4 == 0 && plane % 4 == 0 && plane >= Wp && plane < (1ll << 24) && aligned16(xp) && (axis == 1 || Wp >= W), "packed planes");
+    FQSS_REQUIRE(sh >= W && sc >= sh * (H - 1) + W && (B == 1 || sb >= sc * (C - 1) + W) && W < (1ll << 30), "bad strides");
+    hipLaunchKernelGGL(k_phase_pack, plane_grid(plane, B * C * s), dim3(256), 0, (hipStream_t)stream, x, xp, B * C * s, (int)C, (int)H, (int)W, sb, sc, sh,
+                       axis, s, p, (int)Wp, plane);
+    return launch_status("fqss_phase_pack");
+}
+
+/* the inverse move: gx [B][C][H][W] (strides sb, sc, sh; a window that starts `off` positions into the strided axis) from the phase planes
+ * gy [B][C s][plane] (Hy rows of Wp floats); bias [C] (nullable) is added: the tail of a transposed convolution */
+extern "C" int fqss_phase_unpack(const float* gy, float* gx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh, int axis,
+                                 int s, int p, int64_t Hy, int64_t Wp, int64_t plane, int off, const float* bias, fqss_stream_t stream) {
+    FQSS_REQUIRE(gy && gx, "null pointer");
+    FQSS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (axis == 0 || (axis == 1 && H == 1)) && s >= 1 && p >= 0 && off >= 0, "bad shape");
+    FQSS_REQUIRE(Wp % 4 == 0 && (axis == 0 ? plane >= Hy * Wp : (Hy <= Wp && plane >= Wp)) && H * W < (1ll << 24), "packed planes");
+    FQSS_REQUIRE(sh >= W && sc >= sh * (H - 1) + W && (B == 1 || sb >= sc * (C - 1) + W), "bad strides");
+    static const bool one = getenv("FQSS_UNPACK_V1") != nullptr;       // (A/B knob: the one-element kernel)
+    if (!one && W >= 8)
+        hipLaunchKernelGGL(k_phase_unpack4, plane_grid(H * ((W + 3) / 4) * 4, B * C), dim3(256), 0, (hipStream_t)stream, gy, gx, B * C, (int)C, (int)H, (int)W,
+                           sb, sc, sh, axis, s, p, (int)Hy, (int)Wp, plane, off, bias);
+    else
+        hipLaunchKernelGGL(k_phase_unpack, plane_grid(H * W, B * C), dim3(256), 0, (hipStream_t)stream, gy, gx, B * C, (int)C, (int)H, (int)W, sb, sc, sh, axis,
+                           s, p, (int)Hy, (int)Wp, plane, off, bias);
+    return launch_status("fqss_phase_unpack");
 }
 
 extern "C" int fqss_chan_sum(const float* g, float* out, int64_t B, int64_t C, int64_t M, int64_t ld, fqss_stream_t stream) {

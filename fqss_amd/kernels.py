@@ -2214,6 +2214,7 @@ def _sig4(x):
 
 # ---- stride-1 convolutions on halo-packed planes (fqss_halo_pack / fqss_conv2_*): no frame image
 CONV_HALO = os.environ.get("FQSS_CONV_HALO", "1") != "0"      # (A/B knob: "0" = every general convolution gathers frames)
+CONV_PHASE = os.environ.get("FQSS_CONV_PHASE", "1") != "0"    # (A/B knob: "0" = the strided convolutions gather frames)
 
 
 class HaloPlan:
@@ -2270,8 +2271,9 @@ def conv2_fwd(xp, plan, Co, wc, w2, bias):
     return zb[..., :plan.Wo]
 
 
-def conv2_bwd_x(gzp, plan, Ci, wcT, dw, w2T):
-    """gx [B, Ci, H, W] (a view of a pitch-Wp buffer) from the packed gradient; wcT int8 [Ci][Co * taps] + dw [Co], or w2T float"""
+def conv2_bwd_x(gzp, plan, Ci, wcT, dw, w2T, raw=False):
+    """gx [B, Ci, H, W] (a view of a pitch-Wp buffer; raw: the [B, Ci, H, Wp] buffer itself) from the packed gradient; wcT int8
+    [Ci][Co * taps] + dw [Co], or w2T float"""
     g = plan.geom
     B, Co = gzp.shape[0], gzp.shape[1]
     gb = torch.empty(B, Ci, plan.H, plan.Wp, device=gzp.device, dtype=torch.float32)
@@ -2283,7 +2285,7 @@ def conv2_bwd_x(gzp, plan, Ci, wcT, dw, w2T):
     else:
         _lib.call("fqss_conv2_fwd_x3s", _p(gzp), _p(w2T), None, _p(gb), B, Co, Ci, plan.taps, g.kw, base, -g.dh * plan.Wp, -g.dw, N,
                   plan.plane_g, N, _stream())
-    return gb[..., :plan.W]
+    return gb if raw else gb[..., :plan.W]
 
 
 def conv2_bwd_w(gzp, xp, gw2, plan):
@@ -2294,6 +2296,87 @@ def conv2_bwd_w(gzp, xp, gw2, plan):
     assert gw2.is_contiguous() and gw2.numel() == Co * Ci * plan.taps
     _lib.call("fqss_conv2_bwd_w", _p(gzp), _p(xp), _p(gw2), B, Ci, Co, plan.taps, g.kw, g.dh * plan.Wp, g.dw, plan.phg * plan.Wp + plan.pwg,
               plan.plane_g, plan.plane_x, _stream())
+
+
+class PhasePlan:
+    """a convolution strided along ONE axis (kernel k = T s, stride s, padding p, dilation 1; (k, 1) kernels along H of [B, C, H, W] or
+    1-D along W) as a stride-1 convolution with T taps over the s C phase planes of its input (fqss_phase_pack, csrc/conv_frames.hip):
+    `inner` is that convolution's HaloPlan, `perm` regroups a weight's (ci, t) columns as (ci, r, q')"""
+    __slots__ = ("axis", "s", "k", "p", "T", "H", "W", "Ho", "Wo", "Hy", "inner", "perm", "inv")
+    _perms = {}
+
+    def __init__(self, H, W, geom, pad_to=None, no=None):
+        """no: the frame grid along the strided axis when it is not the geometry's own (a transposed convolution's input length: its
+        output may be a window, K.frames_ola)"""
+        self.axis = 0 if geom.sh > 1 else 1
+        self.s, self.k, self.p = (geom.sh, geom.kh, geom.ph) if self.axis == 0 else (geom.sw, geom.kw, geom.pw)
+        self.T, self.H, self.W = self.k // self.s, H, W
+        if no is None:
+            no = ((H if self.axis == 0 else (pad_to or W)) + 2 * self.p - self.k) // self.s + 1
+        self.Hy = no + self.T - 1
+        if self.axis == 0:
+            self.Ho, self.Wo = no, W
+            self.inner = HaloPlan(self.Hy, W, ConvGeom((self.T, 1)))
+        else:
+            self.Ho, self.Wo = 1, no
+            self.inner = HaloPlan(1, self.Hy, ConvGeom((1, self.T)))
+
+    @staticmethod
+    def serves(H, W, geom):
+        """strided along exactly one axis with a kernel that is a whole number of strides long, nothing along the other axis"""
+        if geom.dh != 1 or geom.dw != 1:
+            return False
+        if geom.sh > 1:
+            return geom.sw == 1 and geom.kw == 1 and geom.pw == 0 and geom.kh % geom.sh == 0 and geom.kh > geom.sh and geom.ph < geom.kh
+        return geom.sw > 1 and H == 1 and geom.kh == 1 and geom.ph == 0 and geom.kw % geom.sw == 0 and geom.kw > geom.sw and geom.pw < geom.kw
+
+    def ok(self, Ci, Co, coded):
+        return self.Hy >= self.T and self.inner.ok(Ci * self.s, Co, coded) and self.H * self.W < (1 << 24) and DetMode.owner is None
+
+    def taps(self, device):
+        """[s][T] tap indices: tap q' of phase r is tap t0(r) + s q' of the kernel"""
+        key = ("taps", self.k, self.s, self.p, str(device))      # (cached: a host -> device copy cannot be captured into a hipGraph)
+        if key not in PhasePlan._perms:
+            PhasePlan._perms[key] = torch.tensor([[(r + self.p) % self.s + self.s * q for q in range(self.T)] for r in range(self.s)],
+                                                 dtype=torch.int64, device=device)
+        return PhasePlan._perms[key]
+
+    def perms(self, Ci, device):
+        """(perm, inv): column j = (ci s + r) T + q' of the regrouped weight is column perm[j] = ci k + t0(r) + s q' of the conv's"""
+        key = (Ci, self.k, self.s, self.p, str(device))
+        if key not in PhasePlan._perms:
+            idx = []
+            for ci in range(Ci):
+                for r in range(self.s):
+                    t0 = (r + self.p) % self.s
+                    idx += [ci * self.k + t0 + self.s * q for q in range(self.T)]
+            perm = torch.tensor(idx, dtype=torch.int64, device=device)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), device=device)
+            PhasePlan._perms[key] = (perm, inv)
+        return PhasePlan._perms[key]
+
+
+def phase_pack(x4, pp):
+    """x4 [B, C, H, W] -> the phase planes [B, C s, plane] of a PhasePlan (zeros outside the signal: the padding, front and back)"""
+    _need_gpu(x4)
+    x4, sb, sc, sh = _sig4(x4)
+    B, C, H, W = x4.shape
+    xp = torch.empty(B, C * pp.s, pp.inner.plane_x, device=x4.device, dtype=torch.float32)
+    _lib.call("fqss_phase_pack", _p(x4), _p(xp), B, C, H, W, sb, sc, sh, pp.axis, pp.s, pp.p, pp.inner.Wp, pp.inner.plane_x, _stream())
+    return xp
+
+
+def phase_unpack(gy, pp, shape, off=0, bias=None):
+    """the inverse move: gy [B, C s, Hy, Wp] (phase planes on their pitch-Wp grid) -> [B, C, H, W] = `shape`, a window starting `off`
+    positions into the strided axis; bias [C] is added"""
+    B, C, H, W = shape
+    assert gy.is_contiguous() and gy.shape[0] == B and gy.shape[1] == C * pp.s
+    plane = gy.shape[2] * gy.shape[3]
+    out = empty_sig((B, C, H, W), gy.device)
+    _, sb, sc, sh = _sig4(out)
+    _lib.call("fqss_phase_unpack", _p(gy), _p(out), B, C, H, W, sb, sc, sh, pp.axis, pp.s, pp.p, pp.Hy, pp.inner.Wp, plane, off, _p(bias), _stream())
+    return out
 
 
 def frames_gather(x, geom, out_hw=None):

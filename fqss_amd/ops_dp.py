@@ -827,6 +827,116 @@ class ConvHalo(Function):
         return gx, gw, gb, None, None
 
 
+class ConvPhase(Function):
+    """nn.Conv1d / nn.Conv2d strided along one axis with a kernel of T strides (the k8 s4 p2 encoder layers of HTDemucs, hdemucsq.py:72-162)
+    as a stride-1 convolution with T taps over the s C PHASE planes of its input (K.PhasePlan / K.phase_pack): the implicit GEMMs of
+    ConvHalo on a signal that was moved once -- the frame image is T times that, written and read back; the data gradient comes out on
+    the phase planes and K.phase_unpack moves it back (the overlap-add's job), the weight gradient is regrouped with the plan's
+    permutation.  w [Co, Ci, kh, kw]; wc: int8 codes of a table-quantized weight or None."""
+
+    @staticmethod
+    def forward(ctx, x4, w, bias, pp, wc):
+        Co, Ci = w.shape[0], x4.shape[1]
+        perm, _ = pp.perms(Ci, x4.device)
+        xp = K.phase_pack(x4, pp)
+        wcp = w2 = None
+        if wc is not None:
+            wcp = K.WCodes()
+            wcp.idx, wcp.dw = wc.idx.index_select(1, perm), wc.dw
+        else:
+            w2 = w.reshape(Co, -1).index_select(1, perm)
+        z = K.conv2_fwd(xp, pp.inner, Co, wcp, w2, bias)
+        touch(w)
+        ctx.pp, ctx.wc, ctx.bias, ctx.xshape = pp, wc, bias, tuple(x4.shape)
+        ctx.save_for_backward(xp, w)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        xp, w = ctx.saved_tensors
+        pp, wc = ctx.pp, ctx.wc
+        B, Ci, H, W = ctx.xshape
+        Co, T, Cs = w.shape[0], pp.T, Ci * pp.s
+        perm, inv = pp.perms(Ci, gz.device)
+        inner = pp.inner
+        gzp = K.halo_pack(gz, inner.phg, inner.pwg, inner.Wp, inner.plane_g)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if wc is not None:
+                wcT = wc.idx.index_select(1, perm).view(Co, Cs, T).permute(1, 0, 2).reshape(Cs, Co * T).contiguous()
+                gy = K.conv2_bwd_x(gzp, inner, Cs, wcT, wc.dw, None, raw=True)
+            else:
+                w2T = w.reshape(Co, -1).index_select(1, perm).view(Co, Cs, T).permute(1, 0, 2).reshape(Cs, Co * T).contiguous()
+                gy = K.conv2_bwd_x(gzp, inner, Cs, None, None, w2T, raw=True)
+            gx = K.phase_unpack(gy, pp, (B, Ci, H, W))
+        gw = gb = None
+        gwq = getattr(w, "_fqss_gwq", None)
+        if ctx.needs_input_grad[1] or gwq is not None:
+            gwp = torch.zeros(Co, Ci * pp.k, device=gz.device, dtype=torch.float32)
+            K.conv2_bwd_w(gzp, xp, gwp, inner)
+            gw = gwq if gwq is not None else torch.zeros_like(w)
+            K.axpby_(gw.view(Co, -1), gwp.index_select(1, inv), 1.0)
+            if gwq is not None:
+                gw = None
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            buf, direct = _param_grad(ctx.bias, ctx.bias)
+            K.chan_sum(gzp, buf)
+            gb = None if direct else buf
+        return gx, gw, gb, None, None
+
+
+class ConvTrPhase(Function):
+    """nn.ConvTranspose1d / 2d strided along one axis with a kernel of T strides (the k8 s4 decoder layers of HTDemucs, hdemucsq.py:261-347),
+    the adjoint of ConvPhase: the output's s Co phase planes are a stride-1 T-tap convolution of the (halo-packed) input -- one implicit
+    GEMM (fqss_conv2_fwd_x3s with negated tap steps) that writes s Co rows where the frame GEMM wrote k Co -- and K.phase_unpack lays them
+    out as the signal, bias added, straight onto the window the caller keeps (`pp` carries the window's start as padding): no frame
+    image, no overlap-add.  Backward: the phase planes of the output gradient are the input of ConvPhase's forward (data gradient) and
+    of its weight gradient.  w [Ci, Co, kh, kw] float (six-product split: the transposed weights have no coded image)."""
+
+    @staticmethod
+    def forward(ctx, x4, w, bias, pp, out_shape):
+        B, Ci = x4.shape[0], x4.shape[1]
+        Co, T, s = w.shape[1], pp.T, pp.s
+        inner = pp.inner
+        tt = pp.taps(x4.device).reshape(-1)
+        wv = w.reshape(Ci, Co, -1).index_select(2, tt).view(Ci, Co, s, T)                 # [ci][co][r][q'] = W[ci][co][t0(r) + s q']
+        xp = K.halo_pack(x4, inner.phg, inner.pwg, inner.Wp, inner.plane_g)
+        gy = K.conv2_bwd_x(xp, inner, Co * s, None, None, wv.permute(1, 2, 0, 3).reshape(Co * s, Ci * T).contiguous(), raw=True)
+        y = K.phase_unpack(gy, pp, out_shape, 0, bias)
+        touch(w)
+        ctx.pp, ctx.bias, ctx.Ci, ctx.Co = pp, bias, Ci, Co
+        ctx.save_for_backward(xp, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, w = ctx.saved_tensors
+        pp, Ci, Co = ctx.pp, ctx.Ci, ctx.Co
+        T, s, inner = pp.T, pp.s, pp.inner
+        yp = K.phase_pack(g, pp)                       # [B, Co s, plane_x]: the phase planes of the output gradient
+        gx = None
+        if ctx.needs_input_grad[0]:
+            tt = pp.taps(g.device).reshape(-1)
+            w2 = w.reshape(Ci, Co, -1).index_select(2, tt).reshape(Ci, Co * s * T)     # [ci][(co, r, q')]
+            gx = K.conv2_fwd(yp, inner, Ci, None, w2, None)
+        gw = gb = None
+        gwq = getattr(w, "_fqss_gwq", None)
+        if ctx.needs_input_grad[1] or gwq is not None:
+            _, inv = pp.perms(Co, g.device)
+            gwp = torch.zeros(Ci, Co * pp.k, device=g.device, dtype=torch.float32)
+            K.conv2_bwd_w(xp, yp, gwp, inner)
+            gw = gwq if gwq is not None else torch.zeros_like(w)
+            K.axpby_(gw.view(Ci, -1), gwp.index_select(1, inv), 1.0)
+            if gwq is not None:
+                gw = None
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            buf, direct = _param_grad(ctx.bias, ctx.bias)
+            B, C2, H, W = g.shape
+            K.chan_sum(g.reshape(B, C2, H * W), buf)
+            gb = None if direct else buf
+        return gx, gw, gb, None, None
+
+
 class FramesOla(Function):
     """frames [B, C*kh*kw, Ho*Wo] (+ bias [C]) -> y [B, C, H, W]: the overlap-add half of nn.ConvTranspose1d / 2d"""
 

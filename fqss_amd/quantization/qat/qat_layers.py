@@ -296,6 +296,14 @@ def conv_frames(conv, x, weight, pad_to=None):
         grid = (Ho, Wo)
     Co = conv.out_channels
     L = ops._Lin("pw", b_param=conv.bias, six=True)
+    if K.CONV_HALO and K.CONV_PHASE and K.PhasePlan.serves(H, W, geom):
+        # strided along one axis with a kernel of T strides (the k8 s4 p2 encoder layers): a stride-1 T-tap convolution over the phase
+        # planes of the input (ops_dp.ConvPhase) -- the signal moves once, the frame image would be T times it
+        wc = getattr(weight, "_fqss_wcodes_dgrad", None) if (ops.FRAME_CODES_FWD and ops.FRAME_CODES_DGRAD) else None
+        pp = K.PhasePlan(H, W, geom, pad_to)
+        if pp.ok(C, Co, wc is not None) and (wc is None or (wc.idx.is_contiguous() and wc.Ci == C * pp.k)):
+            z = ops_dp.ConvPhase.apply(x4, ops.weight_view(weight, Co, C, geom.kh, geom.kw), conv.bias, pp, wc)
+            return z.squeeze(2) if one_d else z
     if grid is not None:
         cols = ops_dp.FramesGather.apply(x4, geom, grid)
     elif geom.args() == (1, 1, 1, 1, 0, 0, 1, 1):
@@ -354,6 +362,14 @@ def convtr_frames(convtr, x, weight, bias=_OWN, window=None):
         else:
             geom, W = K.ConvGeom((geom.kh, geom.kw), (geom.sh, geom.sw), (geom.ph, geom.pw + start), (geom.dh, geom.dw)), length
     Co = convtr.out_channels
+    if K.CONV_HALO and K.CONV_PHASE and K.PhasePlan.serves(H, W, geom) and op == (0, 0):
+        # strided along one axis with a kernel of T strides (the k8 s4 decoder layers): the output's phase planes from one implicit GEMM
+        # on the halo-packed input, laid out as the signal -- the kept window of it -- by fqss_phase_unpack (ops_dp.ConvTrPhase)
+        pp = K.PhasePlan(H, W, geom, no=(Hi if geom.sh > 1 else Wi))
+        if pp.ok(Co, Ci, False) and pp.inner.Ho == (Hi if pp.axis == 0 else 1) and pp.inner.Wo == (Wi if pp.axis == 1 else W):
+            b_ = convtr.bias if bias is _OWN else bias
+            y = ops_dp.ConvTrPhase.apply(x4, ops.weight_view(weight, Ci, Co, geom.kh, geom.kw), b_, pp, (B, Co, H, W))
+            return y.squeeze(2) if one_d else y
     ops_dp.touch(weight)
     wt = weight.reshape(Ci, -1).t().contiguous().unsqueeze(-1)           # [Co*kh*kw, Ci, 1]: a transposing copy of the (small) weight
     gwq = getattr(weight, "_fqss_gwq", None)

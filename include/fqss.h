@@ -194,6 +194,15 @@ int fqss_conv1d_s1_bwd_w(const float* gz, const float* x, float* gw, int B, int 
  *          off = the gradient's own halo offset, (ph_g Wp + pw_g); zero outside the plane) */
 int fqss_halo_pack(const float* x, float* xp, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh,
                    int ph, int pw, int64_t Wp, int64_t plane, fqss_stream_t stream);
+/* Strided convolutions along one axis (kernel k = T s taps, stride s, padding p: the k8 s4 p2 encoder / decoder layers) on the same
+ * kernels: the signal phase-packed -- xp[b][c s + r][m] = x[b][c][s (m + q0(r)) + r], rows of Wp floats, zeros outside -- is the input of
+ * a stride-1 convolution with T taps over s C channels whose weight is the conv's own, regrouped (ci, r, q') <- (ci, t = t0(r) + s q');
+ * fqss_phase_unpack is the inverse move (data gradient back to the signal's layout; a transposed convolution's output, + bias, onto a
+ * window that starts `off` positions in).  axis 0: along H of [B][C][H][W] with (k, 1) kernels; axis 1: along W (H = 1). */
+int fqss_phase_pack(const float* x, float* xp, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh, int axis,
+                    int s, int p, int64_t Wp, int64_t plane, fqss_stream_t stream);
+int fqss_phase_unpack(const float* gy, float* gx, int64_t B, int64_t C, int64_t H, int64_t W, int64_t sb, int64_t sc, int64_t sh, int axis,
+                      int s, int p, int64_t Hy, int64_t Wp, int64_t plane, int off, const float* bias, fqss_stream_t stream);
 int fqss_conv2_fwd_wq(const float* xp, const int8_t* wi, const float* dw, const float* bias, float* z, int B, int Ci, int Co, int taps,
                       int kw, int base, int row_step, int col_step, int64_t N, int64_t plane_in, int64_t plane_out, fqss_stream_t stream);
 int fqss_conv2_fwd_x3s(const float* xp, const float* w, const float* bias, float* z, int B, int Ci, int Co, int taps, int kw, int base,
