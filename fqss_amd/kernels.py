@@ -2331,7 +2331,7 @@ class PhasePlan:
         return geom.sw > 1 and H == 1 and geom.kh == 1 and geom.ph == 0 and geom.kw % geom.sw == 0 and geom.kw > geom.sw and geom.pw < geom.kw
 
     def ok(self, Ci, Co, coded):
-        return self.Hy >= self.T and self.inner.ok(Ci * self.s, Co, coded) and self.H * self.W < (1 << 24) and DetMode.owner is None
+        return self.Hy >= self.T and self.inner.ok(Ci * self.s, Co, coded) and self.H * self.W < (1 << 24)
 
     def taps(self, device):
         """[s][T] tap indices: tap q' of phase r is tap t0(r) + s q' of the kernel"""

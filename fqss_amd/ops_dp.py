@@ -872,8 +872,10 @@ class ConvPhase(Function):
         gw = gb = None
         gwq = getattr(w, "_fqss_gwq", None)
         if ctx.needs_input_grad[1] or gwq is not None:
-            gwp = torch.zeros(Co, Ci * pp.k, device=gz.device, dtype=torch.float32)
+            gwt = ops._wgrad_temp(w)           # (phase-ordered columns; under FQSS_DETERMINISTIC=1 cut from the integer-shadow pool)
+            gwp = gwt.view(Co, Ci * pp.k)
             K.conv2_bwd_w(gzp, xp, gwp, inner)
+            ops._wgrad_temp_done(gwt, None)
             gw = gwq if gwq is not None else torch.zeros_like(w)
             K.axpby_(gw.view(Co, -1), gwp.index_select(1, inv), 1.0)
             if gwq is not None:
@@ -923,8 +925,10 @@ class ConvTrPhase(Function):
         gwq = getattr(w, "_fqss_gwq", None)
         if ctx.needs_input_grad[1] or gwq is not None:
             _, inv = pp.perms(Co, g.device)
-            gwp = torch.zeros(Ci, Co * pp.k, device=g.device, dtype=torch.float32)
+            gwt = ops._wgrad_temp(w)
+            gwp = gwt.view(Ci, Co * pp.k)
             K.conv2_bwd_w(xp, yp, gwp, inner)
+            ops._wgrad_temp_done(gwt, None)
             gw = gwq if gwq is not None else torch.zeros_like(w)
             K.axpby_(gw.view(Ci, -1), gwp.index_select(1, inv), 1.0)
             if gwq is not None:

