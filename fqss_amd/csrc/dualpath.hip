@@ -383,9 +383,13 @@ __global__ __launch_bounds__(256) void k_unary_fwd(const float* __restrict__ x, 
 // 16-B aligned rows; grid (column chunks, rows)
 __global__ __launch_bounds__(256) void k_unary_rows_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int cols, int64_t ld_x,
                                                          int64_t ld_y, int kind, float p) {
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= cols) return;
-    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    // a thread per (row, 4-column group), rows and groups flattened: narrow blocks (64 columns of an attention head block: 16 groups)
+    // keep every lane busy (one workgroup per row left 16 of 256 lanes with work)
+    const int groups = cols >> 2;
+    const int64_t total = rows * groups;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / groups;
+        const int c = (int)(i - r * groups) * 4;
         const float4 v4 = *reinterpret_cast<const float4*>(x + r * ld_x + c);
         const float v[4] = {v4.x, v4.y, v4.z, v4.w};
         float o[4];
@@ -1185,8 +1189,7 @@ extern "C" int fqss_unary_rows_fwd(const float* x, float* y, int64_t rows, int c
     FQSS_REQUIRE(cols % 4 == 0 && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= cols && ld_y >= cols && aligned16(x) && aligned16(y),
                  "rows of 4-float groups, 16-B aligned");
     if (rows == 0 || cols == 0) return FQSS_OK;
-    const dim3 grid((unsigned)cdiv(cols, 1024), (unsigned)(rows < 65535 ? rows : 65535));
-    hipLaunchKernelGGL(k_unary_rows_fwd, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ld_x, ld_y, kind, (float)p);
+    hipLaunchKernelGGL(k_unary_rows_fwd, dim3(flat_grid(rows * (cols / 4))), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ld_x, ld_y, kind, (float)p);
     return launch_status("fqss_unary_rows_fwd");
 }
 
