@@ -1630,3 +1630,63 @@ def test_unary_maps_read_a_column_block_in_place():
     assert K.as_rowmat_view(odd) is None
     assert torch.equal(K.unary_fwd(odd, K.UNARY_DIVS, 3.0), K.unary_fwd(odd.contiguous(), K.UNARY_DIVS, 3.0))
     assert torch.equal(K.unary_fwd(X[..., :64], K.UNARY_DIVS, 8.0), X[..., :64] / 8.0)       # (a power of two: exact either way)
+
+
+@pytest.mark.parametrize("cols,ld,trail", [(431, 432, 0), (110250 % 1000 + 250, 512, 0), (510, 512, 2), (62, 128, 66), (7, 16, 0), (433, 448, 15)])
+def test_activation_quantizer_stores_nothing_past_the_last_column(cols, ld, trail):
+    """fqss_actq_fwd / fqss_actq_bwd (round 6): every 16-B aligned row takes the 16-B form -- rows padded to 64 B by more than three
+    floats ([B, C, 110250] -> 110256) used to fall to the one-element kernel -- and the last, partial group of a row is stored element by
+    element (store_group4): the output may be a COLUMN BLOCK of a wider matrix whose next columns hold data.  Against the dense
+    call: same values; the columns behind the block keep their contents (`trail` of them are real data in the cases that have any)."""
+    dev = "cuda"
+    g = torch.Generator().manual_seed(cols * 7 + ld)
+    rows = 37
+    z = torch.randn(rows, cols, generator=g).to(dev)
+    gy = torch.randn(rows, cols, generator=g).to(dev)
+    lo, hi = torch.tensor([-0.8], device=dev), torch.tensor([1.1], device=dev)
+    slope = torch.tensor([0.2], device=dev)
+    # reference: dense operands
+    gacc0 = torch.zeros(K.GACC_DOUBLES, dtype=torch.float64, device=dev)
+    out0, idx0 = K.actq_fwd(z.clone(), K.ACT_PRELU, slope, K.Q_QUANT, lo, hi, None, want_idx=True, dense_idx=True)
+    gz0 = K.actq_bwd(z.clone(), gy.clone(), K.ACT_PRELU, slope, K.Q_QUANT, lo, hi, gacc0)
+    # the same rows as the leading columns of wider buffers, sentinel values behind them
+    zb, gb = torch.full((rows, ld), 7.5, device=dev), torch.full((rows, ld), -3.25, device=dev)
+    zb[:, :cols], gb[:, :cols] = z, gy
+    ob = torch.full((rows, ld), 123.0, device=dev)
+    gacc1 = torch.zeros_like(gacc0)
+    gz1 = K.actq_bwd(zb[:, :cols], gb[:, :cols], K.ACT_PRELU, slope, K.Q_QUANT, lo, hi, gacc1, out=ob[:, :cols])
+    torch.cuda.synchronize()
+    assert torch.equal(gz1, gz0[:, :cols] if gz0.shape[1] != cols else gz0) or torch.equal(ob[:, :cols], gz0[..., :cols])
+    assert float((ob[:, cols:] - 123.0).abs().max()) == 0, "columns behind the block were written"
+    a, b = gacc1.view(-1, 3).sum(0), gacc0.view(-1, 3).sum(0)          # (per-thread fp32 partials: the dense rows take another thread -> element map)
+    assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    out1 = K.actq_fwd(zb[:, :cols], K.ACT_PRELU, slope, K.Q_QUANT, lo, hi, None)
+    assert torch.equal(out1[..., :cols], out0[..., :cols])
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 431), (1, 3, 4, 64), (3, 2, 9, 33)])
+def test_permute4_into_row_padded_output_and_unary_maps_on_padded_activations(shape):
+    """fqss_permute4_ld (round 6): the [B, P, Q, T] -> [B, Q, P, T] move into a row-padded activation (rows 16-B aligned, padding
+    zero-filled) equals the dense move; kernels.unary_fwd / unary_bwd map a row-padded activation where it lies (kernels.padded_dense)
+    and equal the maps of its dense copy."""
+    dev = "cuda"
+    B, P, Q, T = shape
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(T)).to(dev)
+    sB, sP, sQ, _ = x.stride()
+    dense = K.permute4(x, (B, Q, P), (sB, sQ, sP), T, dense=False)
+    padded = K.permute4(x, (B, Q, P), (sB, sQ, sP), T, dense=False, pad_out=True)
+    assert padded.shape == dense.shape == (B, Q, P, T) and torch.equal(padded, dense) and torch.equal(dense, x.transpose(1, 2))
+    if T % 4:
+        assert padded.stride(-2) % 4 == 0 and padded.stride(-2) > T
+        buf = padded.as_strided((B * Q * P, padded.stride(-2)), (padded.stride(-2), 1))
+        assert float(buf[:, T:].abs().max()) == 0                     # the padding columns hold zeros
+    a = K.empty_act((B, P * Q, T), dev).copy_(x.reshape(B, P * Q, T))
+    if K.padded_dense(a) is not None:
+        for kind in (K.UNARY_GELU, K.UNARY_TANH):
+            y0 = K.unary_fwd(a.contiguous(), kind)
+            y1 = K.unary_fwd(a, kind)
+            assert not y1.is_contiguous() and torch.equal(y1, y0)
+            g = torch.randn(a.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            ref_in = a.contiguous() if kind == K.UNARY_GELU else y0
+            arg_in = a if kind == K.UNARY_GELU else y1
+            assert torch.equal(K.unary_bwd(g, arg_in, kind), K.unary_bwd(g, ref_in, kind))
