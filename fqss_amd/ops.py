@@ -524,6 +524,7 @@ def _lin_bwd_w(L, gz, x, gw):
 
 
 FRAME_CODES_DGRAD = os.environ.get("FQSS_FRAME_CODES_DGRAD", "1") != "0"
+PLAIN_BIAS_SUM = os.environ.get("FQSS_PLAIN_BIAS_SUM", "1") != "0"       # (A/B knob: "0" = the bias gradient of a float conv from the epilogue pass)
 
 
 class LinearActQ(Function):
@@ -579,6 +580,13 @@ class LinearActQ(Function):
             _touch(L.slope_param if act == ACT_PRELU else None, q.owner.min_range, q.owner.max_range, L.b_param)
         elif ctx.plain and not ctx.has_bias:
             gz, g_slope, g_min, g_max, g_bias = g, None, None, None, None
+        elif ctx.plain and PLAIN_BIAS_SUM and g.dim() == 3 and g.is_cuda and L.kind in ("pw", "conv1") and K.rowmat(g) is not None \
+                and K.rowmat(g)[2] % 4 == 0 and g.data_ptr() % 16 == 0:
+            # a float (BYPASS) channel-first conv with a bias -- the DConv / frame-path convolutions of HTDemucs: the bias gradient is the
+            # channel sum of g (one read-only pass, fqss_chan_sum) and g itself is gz; the epilogue kernel wrote a COPY of g to get it
+            gb, gb_direct = _grad_buf(L.b_param, ctx.bias_like)
+            K.chan_sum(g, gb)
+            gz, g_slope, g_min, g_max, g_bias = g, None, None, None, (None if gb_direct else gb)
         else:
             gz, g_slope, g_min, g_max, g_bias = _epilogue_bwd(
                 g if ctx.plain else z, g, act, slope, L.slope_param, q, bias_param=L.b_param,
