@@ -75,7 +75,8 @@ def test_pwconv_exact_integers():
 
 
 @pytest.mark.parametrize("B,Ci,Co,M,taps,dil,pad", [(2, 48, 6, 1000, 3, 1, 1), (3, 16, 96, 431, 3, 2, 2), (1, 8, 40, 77, 3, 1, 0), (2, 4, 130, 300, 5, 3, 6),
-                                                     (4, 48, 96, 5000, 3, 2, 2), (1, 384, 48, 1723, 3, 1, 1), (2, 12, 7, 33, 3, 2, 4)])
+                                                     (4, 48, 96, 5000, 3, 2, 2), (1, 384, 48, 1723, 3, 1, 1), (2, 12, 7, 33, 3, 2, 4),
+                                                     (5, 96, 12, 431, 3, 2, 2), (3, 24, 24, 130, 3, 1, 1), (2, 16, 2, 4099, 3, 4, 4)])
 def test_conv1d_stride1_implicit_gemm(B, Ci, Co, M, taps, dil, pad):
     """stride-1 Conv1d without a frame image (fqss_conv1d_s1_fwd / _bwd_w, the data gradient as the same entry on the flipped,
     transposed weight) against F.conv1d and its autograd"""
