@@ -325,6 +325,27 @@ def cut(*tensors, late=False):
     return tuple(leaves)
 
 
+FLAT_CM = os.environ.get("FQSS_FLAT_CM", "1") != "0"        # (A/B knob: "0" = reshape(B, C, -1), copying what is not a view)
+
+
+def flat_cm(x):
+    """a channel-first tensor [B, C, ...] as [B, C', M] WITHOUT a copy, for maps that pair or walk channels (GLU, per-channel streams):
+    [B, C, H W] when the trailing dims are dense; [B, C H, W] when rows of W are `ld` apart with the planes dense in rows -- the
+    pitch-Wp outputs of the halo-packed convolutions (ops_dp.ConvHalo), row-padded activations -- where `reshape(B, C, -1)` would copy the
+    tensor.  Channel halves stay halves (C H = 2 (C / 2) H)."""
+    if x.dim() <= 3:
+        return x
+    B, C = x.shape[0], x.shape[1]
+    if x.dim() == 4 and FLAT_CM:
+        _, _, H, W = x.shape
+        st = x.stride()
+        if st[3] == 1 and st[2] == W and st[1] >= H * W:
+            return x.reshape(B, C, H * W)            # (a view)
+        if st[3] == 1 and st[1] == H * st[2] and (B == 1 or st[0] >= C * st[1]):
+            return x.as_strided((B, C * H, W), (st[0], st[2], 1))
+    return x.reshape(B, C, -1)
+
+
 def weight_view(w, *shape):
     """w.view(shape) of a (possibly fake-quantized) weight that keeps the dL/dW_q arena slot of a weight fake-quantized by
     runtime.QuantTables: such a tensor has no autograd history, its consumers accumulate its gradient into `_fqss_gwq`"""

@@ -509,7 +509,7 @@ def apply_map(nl, x):
         if nl.dim != 1 or x.dim() < 3:
             raise NotImplementedError("GLU: only dim=1 of a channel-first tensor has a HIP kernel")
         shp = x.shape
-        y = ops_dp.Glu.apply(x.reshape(shp[0], shp[1], -1))
+        y = ops_dp.Glu.apply(ops.flat_cm(x))            # (no copy of a pitch-Wp / row-padded 4-D input)
         return y.reshape(shp[0], shp[1] // 2, *shp[2:])
     raise NotImplementedError(type(nl).__name__)
 
@@ -780,7 +780,7 @@ def fq_node(aq, x, nl=None, codes=False, q=None, post_relu=False):
         if q is None:
             q = aq.qctx()
         xr = ops.real(x)
-        x3 = xr.reshape(xr.shape[0], xr.shape[1], -1)
+        x3 = ops.flat_cm(xr)
         if q.qmode != ops.Q_BYPASS and K.gluq_rows_ok(x3):
             q.no_codes = True
             y = ops_dp.GluActQ.apply(x3, q.qmin, q.qmax, q)

@@ -90,7 +90,8 @@ def main():
                 recs.append((f"aten.{name} {tuple(t.shape)}", where, e0, e1))
                 return r
             setattr(owner, name, f)
-        for nm in ("contiguous", "clone", "copy_", "zero_", "fill_", "add_", "add", "mul", "sub", "__add__", "__mul__", "__sub__", "__iadd__"):
+        for nm in ("contiguous", "clone", "copy_", "zero_", "fill_", "add_", "add", "mul", "sub", "__add__", "__mul__", "__sub__", "__iadd__",
+                   "reshape", "index_select", "narrow_copy"):      # (reshape: copies when the view does not exist)
             wrap(torch.Tensor, nm)
     step(mix, src)
     torch.cuda.synchronize()
