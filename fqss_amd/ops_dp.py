@@ -827,6 +827,23 @@ class ConvHalo(Function):
         return gx, gw, gb, None, None
 
 
+def _frozen_cache(w, key, make):
+    """the regrouped image of a weight that cannot change under the caller (no autograd in flight: the frozen float teacher,
+    mysystem.py:132-133 -- runtime.KDTrainStep sets requires_grad False on its parameters and nothing but load_state_dict, which bumps the
+    version, writes them): built once per (parameter, in-place version) and kept on the parameter -- the student's weights change every
+    step and are regrouped inside the step"""
+    base = w._base if (w._is_view() and w._base is not None) else w          # (the layer hands a view of its parameter)
+    if torch.is_grad_enabled() or base.requires_grad or not isinstance(base, torch.nn.Parameter):
+        return make()
+    cache = getattr(base, "_fqss_regroup", None)
+    if cache is None or cache[0] != base._version:
+        cache = (base._version, {})
+        base._fqss_regroup = cache
+    if key not in cache[1]:
+        cache[1][key] = make()
+    return cache[1][key]
+
+
 class ConvPhase(Function):
     """nn.Conv1d / nn.Conv2d strided along one axis with a kernel of T strides (the k8 s4 p2 encoder layers of HTDemucs, hdemucsq.py:72-162)
     as a stride-1 convolution with T taps over the s C PHASE planes of its input (K.PhasePlan / K.phase_pack): the implicit GEMMs of
@@ -844,7 +861,7 @@ class ConvPhase(Function):
             wcp = K.WCodes()
             wcp.idx, wcp.dw = wc.idx.index_select(1, perm), wc.dw
         else:
-            w2 = w.reshape(Co, -1).index_select(1, perm)
+            w2 = _frozen_cache(w, ("phase", pp.k, pp.s, pp.p), lambda: w.reshape(Co, -1).index_select(1, perm))
         z = K.conv2_fwd(xp, pp.inner, Co, wcp, w2, bias)
         touch(w)
         ctx.pp, ctx.wc, ctx.bias, ctx.xshape = pp, wc, bias, tuple(x4.shape)
@@ -901,9 +918,11 @@ class ConvTrPhase(Function):
         Co, T, s = w.shape[1], pp.T, pp.s
         inner = pp.inner
         tt = pp.taps(x4.device).reshape(-1)
-        wv = w.reshape(Ci, Co, -1).index_select(2, tt).view(Ci, Co, s, T)                 # [ci][co][r][q'] = W[ci][co][t0(r) + s q']
+        # [ci][co][r][q'] = W[ci][co][t0(r) + s q'], regrouped as rows (co, r) x columns (ci, q')
+        w2t = _frozen_cache(w, ("trphase", pp.k, s, pp.p), lambda: w.reshape(Ci, Co, -1).index_select(2, tt).view(Ci, Co, s, T)
+                            .permute(1, 2, 0, 3).reshape(Co * s, Ci * T).contiguous())
         xp = K.halo_pack(x4, inner.phg, inner.pwg, inner.Wp, inner.plane_g)
-        gy = K.conv2_bwd_x(xp, inner, Co * s, None, None, wv.permute(1, 2, 0, 3).reshape(Co * s, Ci * T).contiguous(), raw=True)
+        gy = K.conv2_bwd_x(xp, inner, Co * s, None, None, w2t, raw=True)
         y = K.phase_unpack(gy, pp, out_shape, 0, bias)
         touch(w)
         ctx.pp, ctx.bias, ctx.Ci, ctx.Co = pp, bias, Ci, Co
