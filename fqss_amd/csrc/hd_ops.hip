@@ -6,6 +6,7 @@
 //     mean and unbiased std over all other dims, (x - mean) / (1e-5 + std) and its inverse x * std + mean.
 // All HBM streams: one pass, 16-B accesses where rows are aligned, wave shuffles + one atomic per workgroup for the sums.
 #define FQSS_USES_GRAD_ADD   // the fp32 gradient atomics of this file go through grad_add (fqss_dev.h: FQSS_DETERMINISTIC=1)
+#include <cstdlib>
 #include "fqss_dev.h"
 
 namespace fqss {
@@ -172,7 +173,10 @@ extern "C" int fqss_col_scale_bwd(const float* g, const float* x, const float* s
                                   int64_t ld_x, int64_t ld_gx, fqss_stream_t stream) {
     FQSS_REQUIRE(g && x && s && gx && gs, "null pointer");
     FQSS_REQUIRE(R > 0 && C > 0 && ld_g >= C && ld_x >= C && ld_gx >= C, "bad shape");
-    const int64_t rpb = cdiv(R, 1024) < 8 ? 8 : cdiv(R, 1024);
+    // rows per workgroup: every workgroup ends in C float adds on the same C addresses, so taller bands win until the serial walk of a
+    // band shows (13792 x 512, 20 launches of a cfg-5 step: 14 rows 1.02 ms, 32 rows 0.87, 64 rows 1.24, 128 rows 2.20; FQSS_COLSCALE_RPB for A/B)
+    static const int64_t rpb_env = [] { const char* e = getenv("FQSS_COLSCALE_RPB"); return e ? (int64_t)atoi(e) : (int64_t)0; }();
+    const int64_t rpb = rpb_env > 0 ? rpb_env : (cdiv(R, 1024) < 32 ? (R >= 8192 ? 32 : 8) : cdiv(R, 1024));
     hipLaunchKernelGGL(k_col_scale_bwd, dim3((unsigned)cdiv(R, rpb)), dim3(256), 0, (hipStream_t)stream, g, x, s, gx, gs, R, C, ld_g, ld_x, ld_gx, rpb);
     return launch_status("fqss_col_scale_bwd");
 }
